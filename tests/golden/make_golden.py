@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE (read-only, from /root/reference).
+
+Run in the build container only:  python tests/golden/make_golden.py
+The GPU box never has /root/reference; it only sees the committed .npz files.
+
+What is executed from the reference, by file path (its package __init__ would import PyG datasets):
+  kernel/go_model.py      Gene_ontology_network  (forward + backward)
+  kernel/sgcn_img_snp.py  SGCN_GCN_IMGSNP        (forward both isExplain modes, loss_probability,
+                                                  consist_loss, OrthogonalConstraint, backward)
+Un-vendored third-party modules that are not installable here are substituted, and the substitution
+is stated in every fixture's ``meta``:
+  torch_scatter.scatter          -> out.index_add_(dim, index, src)       (pytorch-scatter 2.0.9)
+  torch_geometric.nn.GCNConv     -> oracle.pyg_ops.GCNConvModule          (pyg 2.0.2; parity UNPINNED
+  torch_geometric.utils.to_dense_batch -> oracle.pyg_ops.to_dense_batch    by the reference)
+  seaborn                        -> empty module (plotting only)
+Dropout cannot match across devices, so "train" captures run the modules in training mode (BatchNorm
+uses batch statistics) with every dropout probability forced to 0.
+
+The loss combination of train() (kernel/train_eval_sgcn_img_snps.py:521-543) is restated below on top
+of the reference model's own methods, because importing the trainer module pulls the absent data
+stack; Adam is torch.optim.Adam as at :108.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import igcn_amd  # noqa: E402,F401  (shim registers the package)
+from igcn_amd import synth  # noqa: E402
+from igcn_amd.data import Batch  # noqa: E402
+from oracle import go_network as OG  # noqa: E402
+from oracle import pyg_ops  # noqa: E402
+from oracle import sgcn_img_snp as OS  # noqa: E402
+from _weights import seeded_state, summarise  # noqa: E402
+
+BIG = 4096
+
+
+def _load_reference():
+    def scatter(src, index, dim=-1, out=None, dim_size=None, reduce="sum"):
+        assert reduce == "sum" and out is not None
+        return out.index_add_(dim, index, src)
+
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter = scatter
+    ts.scatter_add = scatter
+    sys.modules["torch_scatter"] = ts
+
+    tg = types.ModuleType("torch_geometric")
+    tgn = types.ModuleType("torch_geometric.nn")
+    tgu = types.ModuleType("torch_geometric.utils")
+    tgn.GCNConv = pyg_ops.GCNConvModule
+    for name in ("ChebConv", "GATConv", "global_add_pool", "global_mean_pool", "global_sort_pool",
+                 "global_max_pool"):
+        setattr(tgn, name, None)
+    tgu.to_dense_batch = pyg_ops.to_dense_batch
+    tg.nn, tg.utils = tgn, tgu
+    sys.modules.update({"torch_geometric": tg, "torch_geometric.nn": tgn, "torch_geometric.utils": tgu})
+    sys.modules["seaborn"] = types.ModuleType("seaborn")
+
+    sys.path.insert(0, REF)                      # for the reference's own ``util`` package
+    kpkg = types.ModuleType("kernel")
+    kpkg.__path__ = [os.path.join(REF, "kernel")]
+    sys.modules["kernel"] = kpkg
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    go = load("kernel.go_model", "kernel/go_model.py")
+    sg = load("kernel.sgcn_img_snp", "kernel/sgcn_img_snp.py")
+    return go, sg
+
+
+def _no_dropout(module):
+    for m in module.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            m.p = 0.0
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x  # noqa: E731  (functional calls in forward)
+
+
+def _pack(prefix, tensors, store):
+    for k, v in tensors.items():
+        if v is None:
+            continue
+        v = v.detach()
+        if v.numel() > BIG:
+            store[f"{prefix}/{k}#summary"] = summarise(v)
+        else:
+            store[f"{prefix}/{k}"] = v.cpu().numpy()
+
+
+def _probe_weights(outs, seed):
+    """Fixed pseudo-random cotangents so one scalar exercises every output."""
+    rng = np.random.default_rng(seed)
+    return [torch.from_numpy(rng.standard_normal(tuple(o.shape))).float() for o in outs]
+
+
+# ------------------------------------------------------------------------------------------------
+def capture_go(go_mod, name, go_snps, adj, pool_dim, l_dim, d_att, bsz, seed):
+    a_g, a = synth.go_sparse_inputs(go_snps, adj)
+    net = go_mod.Gene_ontology_network(a_g, a, 2, 2, [5, 5], pool_dim, l_dim, "cpu", dim_snps_atten=d_att)
+    ref_sd = net.state_dict()
+    sd = seeded_state({k: v.shape for k, v in ref_sd.items()}, seed, ref_sd)
+    store = {"meta": np.array(
+        "reference kernel/go_model.py executed on CPU; torch_scatter.scatter -> index_add_; "
+        f"torch {torch.__version__}; weights = seeded_state(shapes, seed={seed})"),
+        "go_snps": go_snps.astype(np.float32), "adj": adj.astype(np.float32),
+        "pool": np.array(pool_dim[0]), "l_dim": np.array(l_dim), "d_att": np.array(d_att),
+        "seed": np.array(seed)}
+    rng = np.random.default_rng(seed + 1)
+    snps = torch.from_numpy(rng.random((bsz, 54))).float()
+    store["snps"] = snps.numpy()
+    for mode in ("eval", "train"):
+        net.load_state_dict(sd)
+        net.train(mode == "train")
+        _no_dropout(net)
+        net.zero_grad()
+        inp = snps.clone().requires_grad_(True)
+        latent, x_d, _, att = net(inp, torch.tensor(0.1), "cpu")
+        outs = [latent, x_d, att]
+        cot = _probe_weights(outs, seed + 2)
+        sum((o * c).sum() for o, c in zip(outs, cot)).backward()
+        _pack(f"{mode}/out", {"latent": latent, "x_D": x_d, "atten_out": att}, store)
+        _pack(f"{mode}/grad", {"snps": inp.grad, **{k: p.grad for k, p in net.named_parameters()}}, store)
+        if mode == "train":
+            _pack("train/buffers_after", {k: v for k, v in net.state_dict().items() if "running" in k}, store)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **store)
+    print("wrote", name, {k: v.shape for k, v in store.items() if k.startswith("eval/out")})
+
+
+# ------------------------------------------------------------------------------------------------
+def _reference_losses(model, data, lam, hp, outs1, outs2):
+    """train() :521-543 on the reference model's own methods."""
+    out, snps_hat, out_feat, _, _, reg = outs1
+    out_p, snps_hat_p, out_feat_p, _, _, reg_p = outs2
+    y = data.y.view(-1)
+    t = {}
+    t["ce"] = lam[0] * F.nll_loss(out, y)
+    t["mi"] = lam[0] * F.nll_loss(out_p, y)
+    clin = data.clini_score.view(-1)
+    t["reg"] = lam[1] * (F.mse_loss(reg.view(-1), clin) + F.mse_loss(reg_p.view(-1), clin)) / 2
+    t["prob"] = lam[2] * model.loss_probability(data.x, data.edge_index, data.edge_attr, hp)
+    mse = torch.nn.MSELoss(reduction="none")
+    t["recon"] = lam[3] * (torch.sum(mse(snps_hat, data.snps_feat)) + torch.sum(mse(snps_hat_p, data.snps_feat))) / 2
+    t["cluster"] = lam[4] * (model.consist_loss(out_feat, data.tsne_fdim)
+                             + model.consist_loss(out_feat_p, data.tsne_fdim)) / 2
+    t["orth"] = lam[5] * model.OrthogonalConstraint(out_feat)
+    if lam[0] == 0:
+        t["ce"], t["mi"] = 0.0, 0.0
+    loss = hp.lamda_ce * t["ce"] + hp.lamda_mi * t["mi"] + t["reg"] + t["prob"] + t["recon"] + t["cluster"] + t["orth"]
+    return loss, t
+
+
+def capture_full(sg_mod, name, rois, hidden, layers, bsz, pool, seed, lam, top_k=3):
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=seed)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj)
+    model = sg_mod.SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cpu", rois=rois, H_0=3, num_classes=3,
+                                   isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
+                                   model4eachregr=False, isuseProb4Regr=True, isImageOnly=False,
+                                   isSNPsOnly=False, isMultiFusion=False)
+    ref_sd = model.state_dict()
+    sd = seeded_state({k: v.shape for k, v in ref_sd.items()}, seed, ref_sd)
+    graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=rois, top_k=top_k, tsne_dim=16)
+    store = {"meta": np.array(
+        "reference kernel/sgcn_img_snp.py + kernel/go_model.py executed on CPU; GCNConv/to_dense_batch = "
+        "oracle.pyg_ops (PyG 2.0.2 absent: unpinned), torch_scatter.scatter -> index_add_; dropout p=0; "
+        f"torch {torch.__version__}; weights = seeded_state(shapes, seed={seed}); "
+        f"graphs = synth.brain_graph_list({bsz}, seed={seed + 10}, rois={rois}, top_k={top_k}, tsne_dim=16); "
+        f"GO = synth.go_hierarchy({list(pool)}, seed={seed})"),
+        "cfg": np.array([rois, hidden, layers, bsz, seed, top_k]), "pool": np.array(pool),
+        "lam": np.array(lam), "state_keys": np.array(sorted(ref_sd.keys()))}
+    hp = OS.HP
+    for mode in ("eval", "train"):
+        for explain in (False, True):
+            model.load_state_dict(sd)
+            model.train(mode == "train")
+            _no_dropout(model)
+            model.zero_grad()
+            data = Batch.from_data_list(graphs)
+            outs = model(data, torch.tensor(0.1), "cpu", isExplain=explain)
+            cot = _probe_weights(outs, seed + 3)
+            sum((o * c).sum() for o, c in zip(outs, cot)).backward()
+            tag = f"{mode}/explain{int(explain)}"
+            _pack(tag + "/out", dict(zip(["logp", "x_hat", "out_z", "out_lin", "lin_f", "reg"], outs)), store)
+            _pack(tag + "/grad", {"data.x": data.x.grad, **{k: p.grad for k, p in model.named_parameters()}}, store)
+    # one optimisation step (training mode, dropout off)
+    model.load_state_dict(sd)
+    model.train(True)
+    _no_dropout(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0)
+    opt.zero_grad()
+    data = Batch.from_data_list(graphs)
+    o1 = model(data, torch.tensor(0.1), "cpu")
+    o2 = model(data, torch.tensor(0.1), "cpu", isExplain=True)
+    loss, terms = _reference_losses(model, data, lam, hp, o1, o2)
+    loss.backward()
+    _pack("step/grad", {"data.x": data.x.grad, **{k: p.grad for k, p in model.named_parameters()}}, store)
+    opt.step()
+    store["step/loss"] = np.array(float(loss))
+    for k, v in terms.items():
+        store[f"step/term/{k}"] = np.array(float(v))
+    _pack("step/param_after", dict(model.named_parameters()), store)
+    _pack("step/buffers_after", {k: v for k, v in model.state_dict().items() if "running" in k}, store)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **store)
+    print("wrote", name, "loss", float(loss), {k: float(v) for k, v in terms.items()})
+
+
+def main():
+    torch.manual_seed(0)
+    go_mod, sg_mod = _load_reference()
+    # go_tiny: the shape of the reference's own __main__ smoke block (go_model.py:290-303):
+    # 20 nodes, arbitrary 0/1 adjacency (self loops, empty rows, cross-level edges), pool [[3,6,11]]
+    rng = np.random.default_rng(5)
+    adj = rng.integers(0, 2, (20, 20)).astype(np.float32)
+    adj[:, 7] = 0          # a node with no incoming edges in A = adj.T (empty attention row)
+    go_snps = rng.integers(0, 2, (20, 54)).astype(np.float32)
+    capture_go(go_mod, "go_tiny", go_snps, adj, [[3, 6, 11]], 5, 5, 4, seed=11)
+    # go_small: 5-level hierarchy with the generator used by the benchmark
+    gs, ad, pd = synth.go_hierarchy((100, 50, 30, 19, 1), seed=3)
+    capture_go(go_mod, "go_small", gs, ad, pd, 32, 32, 8, seed=12)
+    # full model, small dims (every tensor stored in full)
+    capture_full(sg_mod, "full_tiny", rois=10, hidden=4, layers=2, bsz=4, pool=(20, 10, 6, 3, 1), seed=21,
+                 lam=[1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2])
+    # full model at the real brain-graph dims (big tensors stored as signatures)
+    capture_full(sg_mod, "full_r90", rois=90, hidden=16, layers=2, bsz=3, pool=(30, 15, 10, 4, 1), seed=22,
+                 lam=[0.0, 1.0, 0.5, 1.5e-6, 0.1, 0.0])
+    # 3-layer variant (sweep entry (3,16,3) main.py:152-158) at small dims
+    capture_full(sg_mod, "full_l3", rois=12, hidden=4, layers=3, bsz=3, pool=(16, 8, 5, 2, 1), seed=23,
+                 lam=[1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""Pin the oracle (CPU restatement) against vectors captured from the reference itself
+(tests/golden/make_golden.py ran kernel/go_model.py and kernel/sgcn_img_snp.py from /root/reference)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_matches, golden_group
+from _weights import seeded_state
+from igcn_amd import synth
+from igcn_amd.data import Batch
+from oracle import go_network as OG
+from oracle import sgcn_img_snp as OS
+
+# scale-relative tolerances; training-mode BatchNorm over 3-8 samples amplifies fp32 rounding (the fp64
+# oracle sits just as far from the reference's fp32 numbers), hence the looser training bound
+TOL = {"eval": 1e-5, "train": 3e-4}
+GTOL = {"eval": 5e-4, "train": 5e-3}
+
+
+def _go_setup(store):
+    a_g, a = synth.go_sparse_inputs(store["go_snps"], store["adj"])
+    idx = OG.go_index_sets(a_g, a, store["pool"].tolist(), 2)
+    shapes = OG.go_param_shapes(idx, l_dim=int(store["l_dim"]), d_att=int(store["d_att"]))
+    sd = seeded_state(shapes, int(store["seed"]))
+    return idx, sd
+
+
+def _probe(outs, seed):
+    rng = np.random.default_rng(seed)
+    return [torch.from_numpy(rng.standard_normal(tuple(o.shape))).float() for o in outs]
+
+
+@pytest.mark.parametrize("name", ["go_tiny", "go_small"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("faithful", [False, True])
+def test_go_network_matches_reference(golden, name, mode, faithful):
+    store = golden(name)
+    idx, sd0 = _go_setup(store)
+    sd = OS.make_leaf_state(sd0)
+    snps = torch.from_numpy(store["snps"]).clone().requires_grad_(True)
+    latent, x_d, att = OG.go_forward(sd, idx, snps, training=(mode == "train"), dropout=False, faithful=faithful)
+    want = golden_group(store, f"{mode}/out")
+    assert_matches(latent, want["latent"], TOL[mode], "latent")
+    assert_matches(x_d, want["x_D"], TOL[mode], "x_D")
+    assert_matches(att, want["atten_out"], TOL[mode], "atten_out")
+    cot = _probe([latent, x_d, att], int(store["seed"]) + 2)
+    sum((o * c).sum() for o, c in zip([latent, x_d, att], cot)).backward()
+    wg = golden_group(store, f"{mode}/grad")
+    assert_matches(snps.grad, wg.pop("snps"), GTOL[mode], "grad snps")
+    for k, w in wg.items():
+        assert sd[k].grad is not None, k
+        assert_matches(sd[k].grad, w, GTOL[mode], "grad " + k, floor=1e-4)
+    if mode == "train":
+        for k, w in golden_group(store, "train/buffers_after").items():
+            assert_matches(sd[k], w, TOL[mode], "buffer " + k)
+
+
+def _full_setup(store):
+    rois, hidden, layers, bsz, seed, top_k = [int(v) for v in store["cfg"]]
+    pool = store["pool"].tolist()
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=seed)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj)
+    idx = OG.go_index_sets(a_g, a, pool, 2)
+    shapes = dict(OS.sgcn_param_shapes(layers, hidden, rois=rois))
+    shapes.update({"go_network." + k: v for k, v in OG.go_param_shapes(idx, l_dim=32, d_att=layers * hidden).items()})
+    shapes["batch_norm_1d.weight"] = (rois * layers * hidden + 32,)
+    for nm, c in (("batch_norm_1d", rois * layers * hidden + 32), ("batch_norm", layers * hidden)):
+        shapes.update({f"{nm}.weight": (c,), f"{nm}.bias": (c,), f"{nm}.running_mean": (c,),
+                       f"{nm}.running_var": (c,), f"{nm}.num_batches_tracked": ()})
+    assert sorted(shapes) == sorted(store["state_keys"].tolist())
+    sd = seeded_state(shapes, seed)
+    graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=rois, top_k=top_k, tsne_dim=16)
+    cfg = SimpleNamespace(num_layers=layers, rois=rois, image_only=False, rbf_gamma=0.01)
+    return cfg, idx, sd, graphs, seed
+
+
+NAMES = ["logp", "x_hat", "out_z", "out_lin", "lin_f", "reg"]
+
+
+@pytest.mark.parametrize("name", ["full_tiny", "full_r90", "full_l3"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("explain", [False, True])
+def test_full_model_matches_reference(golden, name, mode, explain):
+    store = golden(name)
+    cfg, idx, sd0, graphs, seed = _full_setup(store)
+    sd = OS.make_leaf_state(sd0)
+    data = Batch.from_data_list(graphs)
+    data.x.requires_grad_(True)
+    outs = OS.model_forward(sd, cfg, idx, data, explain, training=(mode == "train"), dropout=False)
+    tag = f"{mode}/explain{int(explain)}"
+    want = golden_group(store, tag + "/out")
+    for n, o in zip(NAMES, outs):
+        assert_matches(o, want[n], TOL[mode], n)
+    cot = _probe(outs, seed + 3)
+    sum((o * c).sum() for o, c in zip(outs, cot)).backward()
+    wg = golden_group(store, tag + "/grad")
+    assert_matches(data.x.grad, wg.pop("data.x"), GTOL[mode], "grad data.x")
+    for k, w in wg.items():
+        assert sd[k].grad is not None, k
+        assert_matches(sd[k].grad, w, GTOL[mode], "grad " + k, floor=1e-4)
+
+
+@pytest.mark.parametrize("name", ["full_tiny", "full_r90", "full_l3"])
+@pytest.mark.parametrize("faithful", [False, True])
+def test_train_step_matches_reference(golden, name, faithful):
+    store = golden(name)
+    cfg, idx, sd0, graphs, seed = _full_setup(store)
+    sd = OS.make_leaf_state(sd0)
+    data = Batch.from_data_list(graphs)
+    lam = store["lam"].tolist()
+    loss, terms, _ = OS.train_step(sd, cfg, idx, data, lr=1e-3, lam=lam, dropout=False, faithful=faithful)
+    assert abs(float(loss) - float(store["step/loss"])) <= 1e-5 * max(1.0, abs(float(store["step/loss"])))
+    for k, v in terms.items():
+        assert abs(float(v) - float(store[f"step/term/{k}"])) <= 1e-5 * max(1.0, abs(float(store[f"step/term/{k}"]))), k
+    wg = golden_group(store, "step/grad")
+    assert_matches(data.x.grad, wg.pop("data.x"), 5e-3, "grad data.x")
+    grads = {}
+    for k, w in wg.items():
+        if sd[k].grad is None:      # parameters the reference never touches (edge_prob, unused BNs, classification.*)
+            assert isinstance(w, tuple) or not np.any(w), k
+            continue
+        assert_matches(sd[k].grad, w, 5e-3, "grad " + k, floor=1e-5)
+        grads[k] = w
+    lr = 1e-3
+    for k, w in golden_group(store, "step/param_after").items():
+        # Adam's first step is p - lr*g/(|g|+eps): ill-conditioned where g is rounding noise, so elements
+        # whose reference gradient is < 2% of the tensor's largest are only bounded by the step size
+        if isinstance(w, tuple) or k not in grads or isinstance(grads[k], tuple):
+            assert_matches(sd[k], w, 2.5 * lr, "param " + k, floor=1.0)
+            continue
+        g = torch.from_numpy(grads[k])
+        solid = g.abs() > 2e-2 * g.abs().max()
+        diff = (sd[k].detach() - torch.from_numpy(w)).abs()
+        assert float(diff[solid].max() if solid.any() else 0.0) <= 2e-5, "param " + k
+        assert float(diff.max()) <= 2.01 * lr, "param (noise-level grads) " + k
+    for k, w in golden_group(store, "step/buffers_after").items():
+        assert_matches(sd[k], w, 3e-4, "buffer " + k, floor=1e-2)
