@@ -1,0 +1,87 @@
+"""ctypes binding of libigcn.so (C ABI in include/igcn.h).  No torch types cross the boundary:
+only raw device pointers (tensor.data_ptr()), sizes and the hipStream_t of the current torch stream.
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
+
+P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes) ; mirrors include/igcn.h one to one
+SIGNATURES = {
+    "igcn_version": (I, []),
+    "igcn_last_error": (ctypes.c_char_p, []),
+    "igcn_graph_plan_workspace_bytes": (Z, [L, L]),
+    "igcn_graph_plan_build": (I, [L, L, P, P, P, P, P, P, P, P, P, Z, P]),
+    "igcn_edge_mask_fwd": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_edge_mask_bwd": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_gcn_norm_fwd": (I, [L, L, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_gcn_norm_bwd": (I, [L, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_gcn_propagate_fwd": (I, [L, L, I, P, L, P, P, P, P, P, P, P, L, I, P]),
+    "igcn_gcn_propagate_bwd_scratch_floats": (Z, [L, I]),
+    "igcn_gcn_propagate_bwd": (I, [L, L, I, P, L, P, L, I, P, L, P, P, P, P, P, P, P, L, P, I, P, P, P, P]),
+    "igcn_gemm_f32": (I, [L, L, L, P, L, L, P, L, L, P, P, L, I, I, P, P]),
+    "igcn_spmm_fwd": (I, [I, I, I, I, L, P, P, P, P, P, P]),
+    "igcn_spmm_bwd": (I, [I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_go_attn_fwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P]),
+    "igcn_go_attn_bwd_scratch_floats": (Z, [I, I, I, I]),
+    "igcn_go_attn_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_nodes_ln_fwd": (I, [I, I, I, I, F, P, P, P, P, P, P, P, P]),
+    "igcn_nodes_ln_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_go_decode_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P]),
+    "igcn_go_decode_bwd_scratch_floats": (Z, [I, I, I, I]),
+    "igcn_go_decode_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_adam_step": (I, [L, P, P, P, P, P, F, F, F, F, F, P]),
+}
+
+_lib = None
+
+
+class IgcnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libigcn.so once.  Raises IgcnError when it has not been built (python ig-gcn_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IgcnError(f"{LIB_PATH} is missing: build it with `python ig-gcn_amd/build.py` "
+                        "(there is no CPU or PyTorch fallback for the HIP path)")
+    lib = ctypes.CDLL(LIB_PATH)      # torch is imported above, so libamdhip64.so.7 resolves to torch's runtime
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA tensor (or None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise IgcnError("libigcn operates on device memory only; got a CPU tensor")
+    if not t.is_contiguous():
+        raise IgcnError("libigcn needs contiguous tensors")
+    return t.data_ptr()
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise with igcn_last_error() on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise IgcnError(f"{name} failed (rc={rc}): {lib.igcn_last_error().decode()}")

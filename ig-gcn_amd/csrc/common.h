@@ -1,0 +1,81 @@
+// Shared host/device helpers for libigcn.so (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/igcn.h"
+
+#define IGCN_WAVE 64
+
+void igcn_set_error(const char* fmt, ...);
+
+#define IGCN_REQUIRE(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      igcn_set_error(__VA_ARGS__);              \
+      return IGCN_ERR_BADARG;                   \
+    }                                           \
+  } while (0)
+
+#define IGCN_CHECK_LAUNCH(name)                                          \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      igcn_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return IGCN_ERR_LAUNCH;                                            \
+    }                                                                    \
+  } while (0)
+
+static inline int64_t igcn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- wave / block reductions (deterministic: fixed tree) ---------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024; `red` must hold >= 16 floats of LDS. Result valid in all threads.
+__device__ __forceinline__ float block_sum_all(float v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();  // protect `red` from a previous use
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// Reduce NV per-thread values over the block; thread j < NV of the block ends up holding total j in
+// out[j] (written to global partial row).  red: LDS float[(blockDim/64) * NV].
+template <int NV>
+__device__ __forceinline__ void block_reduce_vec(const float (&v)[NV], float* red, float* partial_row) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    float s = wave_sum(v[j]);
+    if (lane == 0) red[w * NV + j] = s;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < NV; j += blockDim.x) {
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i * NV + j];
+    partial_row[j] = t;
+  }
+}
+
+// out[j] = sum_{r<rows} partial[r*ld + j], j < n.  One thread per j, rows summed in order.
+__global__ void k_reduce_rows(const float* __restrict__ partial, int64_t rows, int64_t ld, int n,
+                              float* __restrict__ out, int accumulate);
+
+int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int n, float* out, int accumulate,
+                            hipStream_t st);

@@ -1,0 +1,127 @@
+// Dense feature transforms on the CDNA4 matrix cores: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).
+//   C[m,n] = act( sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + bias[n] )
+// One 256-thread workgroup = 4 waves; wave w owns rows [16w,16w+16) of a 64 x BN tile and keeps BN/16
+// 16x16 accumulators.  A/B tiles are staged through LDS in BK=16 slices (row pad +1 => conflict-free
+// operand reads: lane l reads [l&15][4kk + (l>>4)]).  The staging thread->element map follows whichever
+// operand axis is contiguous in memory, so NT (forward), NN (input gradient) and TN (weight gradient)
+// all read global memory coalesced.  Long-K / few-tile problems are split over gridDim.z into partial
+// slabs that a second kernel sums in slab order (deterministic).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define G_BM 64
+#define G_BK 16
+
+template <int BN>
+__global__ void __launch_bounds__(256)
+k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,
+           const float* __restrict__ B, int64_t sbn, int64_t sbk, const float* __restrict__ bias,
+           float* __restrict__ C, int64_t ldc, int act, int64_t k_per_split, int64_t slab_stride) {
+  __shared__ float As[G_BM][G_BK + 1];
+  __shared__ float Bs[BN][G_BK + 1];
+  constexpr int NT = BN / 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * G_BM, n0 = (int64_t)blockIdx.y * BN;
+  const int64_t k_begin = (int64_t)blockIdx.z * k_per_split;
+  const int64_t k_end = k_begin + k_per_split < K ? k_begin + k_per_split : K;
+  const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t kb = k_begin; kb < k_end; kb += G_BK) {
+    // stage A: 64 x 16
+#pragma unroll
+    for (int i = 0; i < (G_BM * G_BK) / 256; ++i) {
+      const int idx = tid + i * 256;
+      const int mm = a_kfast ? idx / G_BK : idx % G_BM;
+      const int kk = a_kfast ? idx % G_BK : idx / G_BM;
+      const int64_t gm = m0 + mm, gk = kb + kk;
+      As[mm][kk] = (gm < M && gk < k_end) ? A[gm * sam + gk * sak] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < (BN * G_BK + 255) / 256; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < BN * G_BK) {
+        const int nn = b_kfast ? idx / G_BK : idx % BN;
+        const int kk = b_kfast ? idx % G_BK : idx / BN;
+        const int64_t gn = n0 + nn, gk = kb + kk;
+        Bs[nn][kk] = (gn < N && gk < k_end) ? B[gn * sbn + gk * sbk] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < G_BK / 4; ++ks) {
+      const float a = As[w * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float b = Bs[t * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + r
+  float* Cz = C + (int64_t)blockIdx.z * slab_stride;
+  const bool final_out = (gridDim.z == 1);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int64_t gn = n0 + t * 16 + (lane & 15);
+    if (gn >= N) continue;
+    const float bv = (final_out && bias) ? bias[gn] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t gm = m0 + w * 16 + (lane >> 4) * 4 + r;
+      if (gm < M) {
+        float v = acc[t][r] + bv;
+        if (final_out && act == 1) v = fmaxf(v, 0.f);
+        Cz[gm * ldc + gn] = v;
+      }
+    }
+  }
+}
+
+__global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const float* __restrict__ slabs,
+                                     const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int act) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int64_t m = i / N, n = i - m * N;
+  float t = 0.f;
+  for (int z = 0; z < split_k; ++z) t += slabs[(int64_t)z * M * N + i];
+  if (bias) t += bias[n];
+  if (act == 1) t = fmaxf(t, 0.f);
+  C[m * ldc + n] = t;
+}
+
+extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t sam, int64_t sak,
+                             const float* B, int64_t sbn, int64_t sbk, const float* bias, float* C, int64_t ldc,
+                             int act, int split_k, float* scratch, void* stream) {
+  IGCN_REQUIRE(M > 0 && N > 0 && K >= 0 && split_k >= 1, "gemm_f32: bad sizes M=%lld N=%lld K=%lld split=%d",
+               (long long)M, (long long)N, (long long)K, split_k);
+  IGCN_REQUIRE(split_k == 1 || scratch != nullptr, "gemm_f32: split_k>1 needs scratch");
+  hipStream_t st = (hipStream_t)stream;
+  if (split_k > K / G_BK) split_k = (int)(K / G_BK > 0 ? K / G_BK : 1);
+  int64_t kps = igcn_cdiv(igcn_cdiv(K, split_k), G_BK) * G_BK;
+  if (kps == 0) kps = G_BK;
+  split_k = (int)igcn_cdiv(K > 0 ? K : 1, kps);
+  const bool split = split_k > 1;
+  float* out = split ? scratch : C;
+  const int64_t ld = split ? N : ldc;
+  const int64_t slab = split ? M * N : 0;
+  const int bn = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+  dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)split_k);
+#define LAUNCH_G(BNV)                                                                                          \
+  hipLaunchKernelGGL((k_gemm_f32<BNV>), grid, dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk, bias, out, ld, \
+                     act, kps, slab)
+  if (bn == 16) { LAUNCH_G(16); } else if (bn == 32) { LAUNCH_G(32); } else { LAUNCH_G(64); }
+#undef LAUNCH_G
+  IGCN_CHECK_LAUNCH("gemm_f32");
+  if (split) {
+    hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3((unsigned)igcn_cdiv(M * N, 256)), dim3(256), 0, st, M, N, split_k,
+                       scratch, bias, C, ldc, act);
+    IGCN_CHECK_LAUNCH("gemm_splitk_reduce");
+  }
+  return IGCN_OK;
+}

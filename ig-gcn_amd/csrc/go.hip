@@ -1,0 +1,614 @@
+// GO-hierarchical attention network kernels (include/igcn.h).  Activations are channel-major
+// [B, f, N]: lanes map to consecutive nodes, so every direct access is a coalesced dword stream and the
+// neighbour gathers stay inside one sample's f*N*4-byte slab (L2 resident).
+// One launch covers all samples: this replaces the reference's per-sample python loop
+// (kernel/go_model.py:236-244) and its dense N x N autograd temporaries.
+#include "common.h"
+
+#define GO_T 256
+
+// =================================================================================================
+// sparse maps with learnable non-zeros (gene encode / decode)
+// =================================================================================================
+__global__ void k_spmm_fwd(int C, int I, int J, int64_t nnz, const int32_t* __restrict__ row_ptr,
+                           const int32_t* __restrict__ col, const float* __restrict__ val,
+                           const float* __restrict__ x, float* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= I) return;
+  const float* xb = x + (int64_t)b * J;
+  const int32_t p0 = row_ptr[i], p1 = row_ptr[i + 1];
+  for (int c = 0; c < C; ++c) {
+    float acc = 0.f;
+    for (int32_t p = p0; p < p1; ++p) acc += val[(int64_t)c * nnz + p] * xb[col[p]];
+    y[((int64_t)b * C + c) * I + i] = acc;
+  }
+}
+
+extern "C" int igcn_spmm_fwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
+                             const float* val, const float* x, float* y, void* stream) {
+  IGCN_REQUIRE(B > 0 && C > 0 && I > 0 && J > 0, "spmm_fwd: bad sizes");
+  hipLaunchKernelGGL(k_spmm_fwd, dim3((unsigned)igcn_cdiv(I, GO_T), B), dim3(GO_T), 0, (hipStream_t)stream, C, I, J,
+                     nnz, row_ptr, col, val, x, y);
+  IGCN_CHECK_LAUNCH("spmm_fwd");
+  return IGCN_OK;
+}
+
+__global__ void k_spmm_bwd_dx(int C, int I, int J, int64_t nnz, const int32_t* __restrict__ t_ptr,
+                              const int32_t* __restrict__ t_row, const int32_t* __restrict__ t_k,
+                              const float* __restrict__ val, const float* __restrict__ dy, float* __restrict__ dx) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (j >= J) return;
+  float acc = 0.f;
+  for (int32_t q = t_ptr[j]; q < t_ptr[j + 1]; ++q) {
+    const int32_t r = t_row[q], k = t_k[q];
+    for (int c = 0; c < C; ++c) acc += val[(int64_t)c * nnz + k] * dy[((int64_t)b * C + c) * I + r];
+  }
+  dx[(int64_t)b * J + j] = acc;
+}
+
+__global__ void k_spmm_bwd_dval(int B, int C, int I, int J, int64_t nnz, const int32_t* __restrict__ col,
+                                const int32_t* __restrict__ row_of, const float* __restrict__ x,
+                                const float* __restrict__ dy, float* __restrict__ dval) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  if (k >= nnz) return;
+  const int32_t r = row_of[k], j = col[k];
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc += dy[((int64_t)b * C + c) * I + r] * x[(int64_t)b * J + j];
+  dval[(int64_t)c * nnz + k] = acc;
+}
+
+extern "C" int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
+                             const int32_t* row_of, const int32_t* t_ptr, const int32_t* t_row, const int32_t* t_k,
+                             const float* val, const float* x, const float* dy, float* dx, float* dval,
+                             void* stream) {
+  (void)row_ptr;
+  IGCN_REQUIRE(B > 0 && C > 0 && I > 0 && J > 0, "spmm_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) {
+    hipLaunchKernelGGL(k_spmm_bwd_dx, dim3((unsigned)igcn_cdiv(J, GO_T), B), dim3(GO_T), 0, st, C, I, J, nnz, t_ptr,
+                       t_row, t_k, val, dy, dx);
+  }
+  if (dval && nnz > 0) {
+    hipLaunchKernelGGL(k_spmm_bwd_dval, dim3((unsigned)igcn_cdiv(nnz, GO_T), C), dim3(GO_T), 0, st, B, C, I, J, nnz,
+                       col, row_of, x, dy, dval);
+  }
+  IGCN_CHECK_LAUNCH("spmm_bwd");
+  return IGCN_OK;
+}
+
+// =================================================================================================
+// attention-GCN encoder layer
+// =================================================================================================
+template <int FIN, int FOUT>
+struct AttnW {
+  float wi[FOUT][FIN], ws[FOUT][FIN], a1[FOUT], a2[FOUT], as[FOUT];
+  __device__ __forceinline__ void load(const float* w_inc, const float* w_s, const float* a_in, const float* a_s) {
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) {
+#pragma unroll
+      for (int d = 0; d < FIN; ++d) {
+        wi[c][d] = w_inc[c * FIN + d];
+        ws[c][d] = w_s[c * FIN + d];
+      }
+      a1[c] = a_in[c];
+      a2[c] = a_in[FOUT + c];
+      as[c] = a_s[c];
+    }
+  }
+};
+
+template <int FIN, int FOUT>
+__device__ __forceinline__ void transform(const float (&w)[FOUT][FIN], const float (&x)[FIN], float (&o)[FOUT]) {
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c) {
+    float t = 0.f;
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) t += w[c][d] * x[d];
+    o[c] = t;
+  }
+}
+
+template <int FIN>
+__device__ __forceinline__ void load_node(const float* __restrict__ xb, int N, int n, float (&v)[FIN]) {
+#pragma unroll
+  for (int d = 0; d < FIN; ++d) v[d] = xb[(int64_t)d * N + n];
+}
+
+template <int F>
+__device__ __forceinline__ float dot(const float (&a)[F], const float (&b)[F]) {
+  float t = 0.f;
+#pragma unroll
+  for (int c = 0; c < F; ++c) t += a[c] * b[c];
+  return t;
+}
+
+template <int FIN, int FOUT>
+__global__ void __launch_bounds__(GO_T)
+k_go_attn_fwd(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+              const float* __restrict__ x, const float* __restrict__ w_inc, const float* __restrict__ w_s,
+              const float* __restrict__ a_in, const float* __restrict__ a_s, float* __restrict__ y) {
+  AttnW<FIN, FOUT> W;
+  W.load(w_inc, w_s, a_in, a_s);
+  const int n = blockIdx.x * GO_T + threadIdx.x;
+  const int b = blockIdx.y;
+  if (n >= N) return;
+  const float* xb = x + (int64_t)b * FIN * N;
+  float xr[FIN], xin[FOUT], xs[FOUT];
+  load_node<FIN>(xb, N, n, xr);
+  transform<FIN, FOUT>(W.wi, xr, xin);
+  transform<FIN, FOUT>(W.ws, xr, xs);
+  const float p = dot<FOUT>(W.a1, xin);
+  float Z = 0.f, agg[FOUT];
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c) agg[c] = 0.f;
+  const int32_t p0 = row_ptr[n], p1 = row_ptr[n + 1];
+  for (int32_t e = p0; e < p1; ++e) {
+    const int m = col[e];
+    float xm[FIN], xim[FOUT];
+    load_node<FIN>(xb, N, m, xm);
+    transform<FIN, FOUT>(W.wi, xm, xim);
+    const float s = expf(tanhf(p + dot<FOUT>(W.a2, xim)));
+    Z += s;
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) agg[c] += s * xim[c];
+  }
+  const float zinv = p1 > p0 ? 1.f / Z : 0.f;
+  const float g = 1.f / (1.f + expf(-dot<FOUT>(W.as, xs)));
+  float* yb = y + (int64_t)b * FOUT * N;
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c) yb[(int64_t)c * N + n] = agg[c] * zinv + xs[c] * g;
+}
+
+#define GO_DISPATCH(fin, fout, CALL)                         \
+  if (fin == 2 && fout == 5) { CALL(2, 5); }                 \
+  else if (fin == 5 && fout == 5) { CALL(5, 5); }            \
+  else if (fin == 5 && fout == 2) { CALL(5, 2); }            \
+  else if (fin == 2 && fout == 2) { CALL(2, 2); }            \
+  else {                                                     \
+    igcn_set_error("unsupported GO feature dims fin=%d fout=%d (built: 2->5, 5->5, 5->2, 2->2)", fin, fout); \
+    return IGCN_ERR_UNSUPPORTED;                             \
+  }
+
+extern "C" int igcn_go_attn_fwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
+                                const float* x, const float* w_inc, const float* w_s, const float* a_in,
+                                const float* a_s, float* y, void* stream) {
+  IGCN_REQUIRE(B > 0 && N > 0, "go_attn_fwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)igcn_cdiv(N, GO_T), B);
+#define CALL(FI, FO) \
+  hipLaunchKernelGGL((k_go_attn_fwd<FI, FO>), grid, dim3(GO_T), 0, st, N, row_ptr, col, x, w_inc, w_s, a_in, a_s, y)
+  GO_DISPATCH(fin, fout, CALL)
+#undef CALL
+  IGCN_CHECK_LAUNCH("go_attn_fwd");
+  return IGCN_OK;
+}
+
+// ---- backward, kernel A: per-row softmax statistics -------------------------------------------
+// stats[0]=p (a1.x_in), [1]=q (a2.x_in), [2]=1/Z, [3]=tr = dy . (agg/Z), each [B,N]
+template <int FIN, int FOUT>
+__global__ void __launch_bounds__(GO_T)
+k_go_attn_bwd_stats(int B, int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                    const float* __restrict__ x, const float* __restrict__ w_inc, const float* __restrict__ a_in,
+                    const float* __restrict__ dy, float* __restrict__ stats) {
+  float wi[FOUT][FIN], a1[FOUT], a2[FOUT];
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c) {
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) wi[c][d] = w_inc[c * FIN + d];
+    a1[c] = a_in[c];
+    a2[c] = a_in[FOUT + c];
+  }
+  const int n = blockIdx.x * GO_T + threadIdx.x;
+  const int b = blockIdx.y;
+  if (n >= N) return;
+  const float* xb = x + (int64_t)b * FIN * N;
+  float xr[FIN], xin[FOUT];
+  load_node<FIN>(xb, N, n, xr);
+  transform<FIN, FOUT>(wi, xr, xin);
+  const float p = dot<FOUT>(a1, xin);
+  const float q = dot<FOUT>(a2, xin);
+  float Z = 0.f, agg[FOUT];
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c) agg[c] = 0.f;
+  const int32_t p0 = row_ptr[n], p1 = row_ptr[n + 1];
+  for (int32_t e = p0; e < p1; ++e) {
+    const int m = col[e];
+    float xm[FIN], xim[FOUT];
+    load_node<FIN>(xb, N, m, xm);
+    transform<FIN, FOUT>(wi, xm, xim);
+    const float s = expf(tanhf(p + dot<FOUT>(a2, xim)));
+    Z += s;
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) agg[c] += s * xim[c];
+  }
+  const float zinv = p1 > p0 ? 1.f / Z : 0.f;
+  float tr = 0.f;
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c) tr += dy[((int64_t)b * FOUT + c) * N + n] * agg[c];
+  const int64_t BN = (int64_t)B * N, o = (int64_t)b * N + n;
+  stats[o] = p;
+  stats[BN + o] = q;
+  stats[2 * BN + o] = zinv;
+  stats[3 * BN + o] = tr * zinv;
+}
+
+// ---- backward, kernel B: input gradient + block partials of the parameter gradients ------------
+#define GO_SB 8  // samples per thread (amortises the block reduction of the parameter gradients)
+template <int FIN, int FOUT>
+__global__ void __launch_bounds__(GO_T)
+k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                   const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ t_row,
+                   const float* __restrict__ x, const float* __restrict__ w_inc, const float* __restrict__ w_s,
+                   const float* __restrict__ a_in, const float* __restrict__ a_s, const float* __restrict__ dy,
+                   const float* __restrict__ stats, float* __restrict__ dx, float* __restrict__ partial) {
+  constexpr int NW = 2 * FOUT * FIN + 3 * FOUT;
+  __shared__ float red[(GO_T / 64) * NW];
+  AttnW<FIN, FOUT> W;
+  W.load(w_inc, w_s, a_in, a_s);
+  const int n = blockIdx.x * GO_T + threadIdx.x;
+  const int64_t BN = (int64_t)B * N;
+  float gw[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) gw[j] = 0.f;
+  if (n < N) {
+    const int32_t r0 = row_ptr[n], r1 = row_ptr[n + 1];
+    const int32_t c0 = t_ptr[n], c1 = t_ptr[n + 1];
+    const int b_end = min(B, (int)(blockIdx.y + 1) * GO_SB);
+    for (int b = blockIdx.y * GO_SB; b < b_end; ++b) {
+      const float* xb = x + (int64_t)b * FIN * N;
+      const float* dyb = dy + (int64_t)b * FOUT * N;
+      const float* sp = stats + (int64_t)b * N;  // p ; q at +BN ; zinv at +2BN ; tr at +3BN
+      float xr[FIN], xin[FOUT], xs[FOUT], dyn[FOUT];
+      load_node<FIN>(xb, N, n, xr);
+      load_node<FOUT>(dyb, N, n, dyn);
+      transform<FIN, FOUT>(W.wi, xr, xin);
+      transform<FIN, FOUT>(W.ws, xr, xs);
+      const float p_n = sp[n], q_n = sp[BN + n], zinv_n = sp[2 * BN + n], tr_n = sp[3 * BN + n];
+      // n as ROW: d(score) of its own edges
+      float dp = 0.f;
+      for (int32_t e = r0; e < r1; ++e) {
+        const int m = col[e];
+        float xm[FIN], xim[FOUT];
+        load_node<FIN>(xb, N, m, xm);
+        transform<FIN, FOUT>(W.wi, xm, xim);
+        const float th = tanhf(p_n + sp[BN + m]);
+        const float alpha = expf(th) * zinv_n;
+        dp += (dot<FOUT>(dyn, xim) - tr_n) * alpha * (1.f - th * th);
+      }
+      // n as COLUMN: what the rows reading n send back
+      float dq = 0.f, dxin[FOUT];
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) dxin[c] = 0.f;
+      for (int32_t e = c0; e < c1; ++e) {
+        const int r = t_row[e];
+        float dyr[FOUT];
+        load_node<FOUT>(dyb, N, r, dyr);
+        const float th = tanhf(sp[r] + q_n);
+        const float alpha = expf(th) * sp[2 * BN + r];
+        dq += (dot<FOUT>(dyr, xin) - sp[3 * BN + r]) * alpha * (1.f - th * th);
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) dxin[c] += alpha * dyr[c];
+      }
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) dxin[c] += dp * W.a1[c] + dq * W.a2[c];
+      // gated self term
+      const float g = 1.f / (1.f + expf(-dot<FOUT>(W.as, xs)));
+      const float dgate = dot<FOUT>(dyn, xs) * g * (1.f - g);
+      float dxs[FOUT];
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) dxs[c] = dyn[c] * g + dgate * W.as[c];
+      // input gradient
+      float* dxb = dx + (int64_t)b * FIN * N;
+#pragma unroll
+      for (int d = 0; d < FIN; ++d) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) t += W.wi[c][d] * dxin[c] + W.ws[c][d] * dxs[c];
+        dxb[(int64_t)d * N + n] = t;
+      }
+      // parameter gradients
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) {
+#pragma unroll
+        for (int d = 0; d < FIN; ++d) {
+          gw[c * FIN + d] += dxin[c] * xr[d];
+          gw[FOUT * FIN + c * FIN + d] += dxs[c] * xr[d];
+        }
+        gw[2 * FOUT * FIN + c] += dp * xin[c];
+        gw[2 * FOUT * FIN + FOUT + c] += dq * xin[c];
+        gw[2 * FOUT * FIN + 2 * FOUT + c] += dgate * xs[c];
+      }
+    }
+  }
+  block_reduce_vec<NW>(gw, red, partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NW);
+}
+
+extern "C" size_t igcn_go_attn_bwd_scratch_floats(int B, int N, int fin, int fout) {
+  const int64_t nw = 2 * fout * fin + 3 * fout;
+  return (size_t)(4 * (int64_t)B * N + igcn_cdiv(N, GO_T) * igcn_cdiv(B, GO_SB) * nw + 64);
+}
+
+extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
+                                const int32_t* t_ptr, const int32_t* t_row, const float* x, const float* w_inc,
+                                const float* w_s, const float* a_in, const float* a_s, const float* dy, float* dx,
+                                float* dparams, float* scratch, void* stream) {
+  IGCN_REQUIRE(B > 0 && N > 0, "go_attn_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  float* stats = scratch;
+  float* partial = scratch + 4 * (int64_t)B * N;
+  dim3 gridA((unsigned)igcn_cdiv(N, GO_T), B);
+  dim3 gridB((unsigned)igcn_cdiv(N, GO_T), (unsigned)igcn_cdiv(B, GO_SB));
+  const int nw = 2 * fout * fin + 3 * fout;
+#define CALL(FI, FO)                                                                                              \
+  hipLaunchKernelGGL((k_go_attn_bwd_stats<FI, FO>), gridA, dim3(GO_T), 0, st, B, N, row_ptr, col, x, w_inc, a_in, \
+                     dy, stats);                                                                                  \
+  hipLaunchKernelGGL((k_go_attn_bwd_main<FI, FO>), gridB, dim3(GO_T), 0, st, B, N, row_ptr, col, t_ptr, t_row, x, \
+                     w_inc, w_s, a_in, a_s, dy, stats, dx, partial)
+  GO_DISPATCH(fin, fout, CALL)
+#undef CALL
+  IGCN_CHECK_LAUNCH("go_attn_bwd");
+  return igcn_launch_reduce_rows(partial, (int64_t)gridB.x * gridB.y, nw, nw, dparams, 0, st);
+}
+
+// =================================================================================================
+// LayerNorm over nodes + ReLU + node dropout + pooling
+// =================================================================================================
+__global__ void __launch_bounds__(GO_T)
+k_nodes_ln_fwd(int f, int N, int pool, float eps, const float* __restrict__ y, const float* __restrict__ gamma,
+               const float* __restrict__ beta, const float* __restrict__ keep, float* __restrict__ z,
+               float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  __shared__ float red[16];
+  const int row = blockIdx.x;  // b*f + c
+  const int b = row / f;
+  const float* yr = y + (int64_t)row * N;
+  float s = 0.f;
+  for (int n = threadIdx.x; n < N; n += GO_T) s += yr[n];
+  const float mean = block_sum_all(s, red) / (float)N;
+  float v = 0.f;
+  for (int n = threadIdx.x; n < N; n += GO_T) {
+    const float d = yr[n] - mean;
+    v += d * d;
+  }
+  const float var = block_sum_all(v, red) / (float)N;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+  const int M = N - pool;
+  float* zr = z + (int64_t)row * M;
+  for (int n = pool + threadIdx.x; n < N; n += GO_T) {
+    float t = (yr[n] - mean) * rstd * gamma[n] + beta[n];
+    t = fmaxf(t, 0.f);
+    if (keep) t *= keep[(int64_t)b * N + n];
+    zr[n - pool] = t;
+  }
+}
+
+extern "C" int igcn_nodes_ln_fwd(int B, int f, int N, int pool, float eps, const float* y, const float* gamma,
+                                 const float* beta, const float* keep, float* z, float* mean, float* rstd,
+                                 void* stream) {
+  IGCN_REQUIRE(B > 0 && f > 0 && N > 0 && pool >= 0 && pool < N, "nodes_ln_fwd: bad sizes");
+  hipLaunchKernelGGL(k_nodes_ln_fwd, dim3(B * f), dim3(GO_T), 0, (hipStream_t)stream, f, N, pool, eps, y, gamma,
+                     beta, keep, z, mean, rstd);
+  IGCN_CHECK_LAUNCH("nodes_ln_fwd");
+  return IGCN_OK;
+}
+
+__global__ void __launch_bounds__(GO_T)
+k_nodes_ln_bwd_dy(int f, int N, int pool, const float* __restrict__ y, const float* __restrict__ gamma,
+                  const float* __restrict__ beta, const float* __restrict__ keep, const float* __restrict__ mean,
+                  const float* __restrict__ rstd, const float* __restrict__ dz, float* __restrict__ dy) {
+  __shared__ float red[16];
+  const int row = blockIdx.x;
+  const int b = row / f;
+  const float mu = mean[row], rs = rstd[row];
+  const float* yr = y + (int64_t)row * N;
+  const int M = N - pool;
+  const float* dzr = dz + (int64_t)row * M;
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = threadIdx.x; n < N; n += GO_T) {
+    const float xh = (yr[n] - mu) * rs;
+    float up = 0.f;
+    if (n >= pool && xh * gamma[n] + beta[n] > 0.f) {
+      up = dzr[n - pool];
+      if (keep) up *= keep[(int64_t)b * N + n];
+    }
+    const float dxh = up * gamma[n];
+    s1 += dxh;
+    s2 += dxh * xh;
+  }
+  s1 = block_sum_all(s1, red) / (float)N;
+  s2 = block_sum_all(s2, red) / (float)N;
+  float* dyr = dy + (int64_t)row * N;
+  for (int n = threadIdx.x; n < N; n += GO_T) {
+    const float xh = (yr[n] - mu) * rs;
+    float up = 0.f;
+    if (n >= pool && xh * gamma[n] + beta[n] > 0.f) {
+      up = dzr[n - pool];
+      if (keep) up *= keep[(int64_t)b * N + n];
+    }
+    dyr[n] = rs * (up * gamma[n] - s1 - xh * s2);
+  }
+}
+
+// dgamma[n] = sum_rows up*xhat ; dbeta[n] = sum_rows up   (thread per node, rows in order)
+__global__ void k_nodes_ln_bwd_affine(int rows, int f, int N, int pool, const float* __restrict__ y,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ keep, const float* __restrict__ mean,
+                                      const float* __restrict__ rstd, const float* __restrict__ dz,
+                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float dg = 0.f, db = 0.f;
+  if (n >= pool) {
+    const float ga = gamma[n], be = beta[n];
+    const int M = N - pool;
+    for (int row = 0; row < rows; ++row) {
+      const float xh = (y[(int64_t)row * N + n] - mean[row]) * rstd[row];
+      if (xh * ga + be > 0.f) {
+        float up = dz[(int64_t)row * M + (n - pool)];
+        if (keep) up *= keep[(int64_t)(row / f) * N + n];
+        dg += up * xh;
+        db += up;
+      }
+    }
+  }
+  dgamma[n] = dg;
+  dbeta[n] = db;
+}
+
+extern "C" int igcn_nodes_ln_bwd(int B, int f, int N, int pool, const float* y, const float* gamma,
+                                 const float* beta, const float* keep, const float* mean, const float* rstd,
+                                 const float* dz, float* dy, float* dgamma, float* dbeta, void* stream) {
+  IGCN_REQUIRE(B > 0 && f > 0 && N > 0 && pool >= 0 && pool < N, "nodes_ln_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_nodes_ln_bwd_dy, dim3(B * f), dim3(GO_T), 0, st, f, N, pool, y, gamma, beta, keep, mean, rstd,
+                     dz, dy);
+  hipLaunchKernelGGL(k_nodes_ln_bwd_affine, dim3((unsigned)igcn_cdiv(N, 64)), dim3(64), 0, st, B * f, f, N, pool, y,
+                     gamma, beta, keep, mean, rstd, dz, dgamma, dbeta);
+  IGCN_CHECK_LAUNCH("nodes_ln_bwd");
+  return IGCN_OK;
+}
+
+// =================================================================================================
+// decoder layer: mean aggregation + zero-padded self term
+// =================================================================================================
+template <int FIN, int FOUT>
+__global__ void __launch_bounds__(GO_T)
+k_go_decode_fwd(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                const float* __restrict__ x, const float* __restrict__ w_out, const float* __restrict__ w_sout,
+                float* __restrict__ y) {
+  float wo[FOUT][FIN], wso[FOUT][FIN];
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c)
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) {
+      wo[c][d] = w_out[c * FIN + d];
+      wso[c][d] = w_sout[c * FIN + d];
+    }
+  const int r = blockIdx.x * GO_T + threadIdx.x;
+  const int b = blockIdx.y;
+  if (r >= Nout) return;
+  const int off = Nout - Nin;
+  const float* xb = x + (int64_t)b * FIN * Nin;
+  float acc[FIN];
+#pragma unroll
+  for (int d = 0; d < FIN; ++d) acc[d] = 0.f;
+  const int32_t p0 = row_ptr[r], p1 = row_ptr[r + 1];
+  for (int32_t e = p0; e < p1; ++e) {
+    const int m = col[e];
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) acc[d] += xb[(int64_t)d * Nin + m];
+  }
+  const float inv = p1 > p0 ? 1.f / (float)(p1 - p0) : 0.f;
+  float out[FOUT];
+  transform<FIN, FOUT>(wo, acc, out);
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c) out[c] *= inv;
+  if (r >= off) {
+    float xs[FIN], o2[FOUT];
+    load_node<FIN>(xb, Nin, r - off, xs);
+    transform<FIN, FOUT>(wso, xs, o2);
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) out[c] += o2[c];
+  }
+  float* yb = y + (int64_t)b * FOUT * Nout;
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c) yb[(int64_t)c * Nout + r] = out[c];
+}
+
+extern "C" int igcn_go_decode_fwd(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr,
+                                  const int32_t* col, const float* x, const float* w_out, const float* w_sout,
+                                  float* y, void* stream) {
+  IGCN_REQUIRE(B > 0 && Nin > 0 && Nout >= Nin, "go_decode_fwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)igcn_cdiv(Nout, GO_T), B);
+#define CALL(FI, FO) \
+  hipLaunchKernelGGL((k_go_decode_fwd<FI, FO>), grid, dim3(GO_T), 0, st, Nin, Nout, row_ptr, col, x, w_out, w_sout, y)
+  GO_DISPATCH(fin, fout, CALL)
+#undef CALL
+  IGCN_CHECK_LAUNCH("go_decode_fwd");
+  return IGCN_OK;
+}
+
+template <int FIN, int FOUT>
+__global__ void __launch_bounds__(GO_T)
+k_go_decode_bwd(int B, int Nin, int Nout, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ t_ptr,
+                const int32_t* __restrict__ t_row, const float* __restrict__ x, const float* __restrict__ w_out,
+                const float* __restrict__ w_sout, const float* __restrict__ dy, float* __restrict__ dx,
+                float* __restrict__ partial) {
+  constexpr int NW = 2 * FOUT * FIN;
+  __shared__ float red[(GO_T / 64) * NW];
+  float wo[FOUT][FIN], wso[FOUT][FIN];
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c)
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) {
+      wo[c][d] = w_out[c * FIN + d];
+      wso[c][d] = w_sout[c * FIN + d];
+    }
+  const int m = blockIdx.x * GO_T + threadIdx.x;
+  const int off = Nout - Nin;
+  float gw[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) gw[j] = 0.f;
+  if (m < Nin) {
+    const int32_t c0 = t_ptr[m], c1 = t_ptr[m + 1];
+    const int b_end = min(B, (int)(blockIdx.y + 1) * GO_SB);
+    for (int b = blockIdx.y * GO_SB; b < b_end; ++b) {
+      const float* dyb = dy + (int64_t)b * FOUT * Nout;
+      float G[FOUT], Gs[FOUT], xr[FIN];
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) G[c] = 0.f;
+      for (int32_t e = c0; e < c1; ++e) {
+        const int r = t_row[e];
+        const float inv = 1.f / (float)(row_ptr[r + 1] - row_ptr[r]);
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) G[c] += dyb[(int64_t)c * Nout + r] * inv;
+      }
+      load_node<FOUT>(dyb, Nout, m + off, Gs);
+      load_node<FIN>(x + (int64_t)b * FIN * Nin, Nin, m, xr);
+      float* dxb = dx + (int64_t)b * FIN * Nin;
+#pragma unroll
+      for (int d = 0; d < FIN; ++d) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) t += wo[c][d] * G[c] + wso[c][d] * Gs[c];
+        dxb[(int64_t)d * Nin + m] = t;
+      }
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c)
+#pragma unroll
+        for (int d = 0; d < FIN; ++d) {
+          gw[c * FIN + d] += G[c] * xr[d];
+          gw[FOUT * FIN + c * FIN + d] += Gs[c] * xr[d];
+        }
+    }
+  }
+  block_reduce_vec<NW>(gw, red, partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NW);
+}
+
+extern "C" size_t igcn_go_decode_bwd_scratch_floats(int B, int Nin, int fin, int fout) {
+  return (size_t)(igcn_cdiv(Nin, GO_T) * igcn_cdiv(B, GO_SB) * 2 * fout * fin + 64);
+}
+
+extern "C" int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr,
+                                  const int32_t* t_ptr, const int32_t* t_row, const float* x, const float* w_out,
+                                  const float* w_sout, const float* dy, float* dx, float* dparams, float* scratch,
+                                  void* stream) {
+  IGCN_REQUIRE(B > 0 && Nin > 0 && Nout >= Nin, "go_decode_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)igcn_cdiv(Nin, GO_T), (unsigned)igcn_cdiv(B, GO_SB));
+  const int nw = 2 * fout * fin;
+#define CALL(FI, FO)                                                                                             \
+  hipLaunchKernelGGL((k_go_decode_bwd<FI, FO>), grid, dim3(GO_T), 0, st, B, Nin, Nout, row_ptr, t_ptr, t_row, x, \
+                     w_out, w_sout, dy, dx, scratch)
+  GO_DISPATCH(fin, fout, CALL)
+#undef CALL
+  IGCN_CHECK_LAUNCH("go_decode_bwd");
+  return igcn_launch_reduce_rows(scratch, (int64_t)grid.x * grid.y, nw, nw, dparams, 0, st);
+}

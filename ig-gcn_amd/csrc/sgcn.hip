@@ -1,0 +1,427 @@
+// SGCN branch kernels: importance masks, GCN normalisation, scatter-aggregate (include/igcn.h).
+// All per-node sums walk the plan's stable edge groups, so results are deterministic and the forward
+// sums run in the same order as the reference's sequential scatter_add.
+#include "common.h"
+
+#define MAX_H0 8
+
+// =================================================================================================
+// edge mask forward  (cal_probability, kernel/sgcn_img_snp.py:133-151)
+// =================================================================================================
+__global__ void k_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* __restrict__ x,
+                                const float* __restrict__ prob, const float* __restrict__ pb,
+                                const float* __restrict__ ew, const int32_t* __restrict__ src32,
+                                const int32_t* __restrict__ dst32, float* __restrict__ xm, float* __restrict__ e,
+                                float* __restrict__ ewm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_nodes * h0) {
+    const int64_t node = i / h0;
+    const int h = (int)(i - node * h0);
+    xm[i] = x[i] * prob[(node % rois) * h0 + h];
+  }
+  if (i < n_edges) {
+    const int64_t s = src32[i], d = dst32[i];
+    const int64_t rs = (s % rois) * h0, rd = (d % rois) * h0;
+    float z = 0.f;
+    for (int h = 0; h < h0; ++h) z += (x[s * h0 + h] * prob[rs + h]) * pb[h];
+    for (int h = 0; h < h0; ++h) z += (x[d * h0 + h] * prob[rd + h]) * pb[h0 + h];
+    const float p = 1.f / (1.f + expf(-z));
+    e[i] = p;
+    ewm[i] = ew[i] * p;
+  }
+}
+
+extern "C" int igcn_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x,
+                                  const float* prob, const float* prob_bias, const float* ew, const int32_t* src32,
+                                  const int32_t* dst32, float* xm, float* e, float* ewm, void* stream) {
+  IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0,
+               "edge_mask_fwd: need n_nodes %% rois == 0 and 0 < h0 <= %d (n_nodes=%lld rois=%d h0=%d)", MAX_H0,
+               (long long)n_nodes, rois, h0);
+  const int64_t n = n_nodes * h0 > n_edges ? n_nodes * h0 : n_edges;
+  if (n == 0) return IGCN_OK;
+  hipLaunchKernelGGL(k_edge_mask_fwd, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n_nodes,
+                     n_edges, rois, h0, x, prob, prob_bias, ew, src32, dst32, xm, e, ewm);
+  IGCN_CHECK_LAUNCH("edge_mask_fwd");
+  return IGCN_OK;
+}
+
+// =================================================================================================
+// edge mask backward
+//   dz_k = (d_ewm_k * ew_k + d_e_k) * e_k (1 - e_k)
+//   g_i  = d_xm_i + pb[:h0] * S_i + pb[h0:] * T_i,   S_i = sum_{k: src=i} dz_k, T_i = sum_{k: dst=i} dz_k
+//   dx_i = g_i * prob[roi(i)] ;  dprob[r] = sum_graphs g_i * x_i ;  dpb = (sum_i xm_i S_i , sum_i xm_i T_i)
+// =================================================================================================
+__global__ void k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict__ x,
+                                      const float* __restrict__ prob, const float* __restrict__ pb,
+                                      const float* __restrict__ ew, const float* __restrict__ e,
+                                      const float* __restrict__ d_xm, const float* __restrict__ d_ewm,
+                                      const float* __restrict__ d_e, const int32_t* __restrict__ tgt_ptr,
+                                      const int32_t* __restrict__ tgt_perm, const int32_t* __restrict__ src_ptr,
+                                      const int32_t* __restrict__ src_perm, float* __restrict__ dx,
+                                      float* __restrict__ gx /*[N,h0]*/, float* __restrict__ pb_partial /*[nblk,2h0]*/) {
+  __shared__ float red[4 * 2 * MAX_H0];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float acc[2 * MAX_H0];
+#pragma unroll
+  for (int j = 0; j < 2 * MAX_H0; ++j) acc[j] = 0.f;
+  if (i < n_nodes) {
+    float S = 0.f, T = 0.f;
+    for (int32_t p = src_ptr[i]; p < src_ptr[i + 1]; ++p) {
+      const int32_t k = src_perm[p];
+      const float ek = e[k];
+      const float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
+      S += up * ek * (1.f - ek);
+    }
+    for (int32_t p = tgt_ptr[i]; p < tgt_ptr[i + 1]; ++p) {
+      const int32_t k = tgt_perm[p];
+      const float ek = e[k];
+      const float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
+      T += up * ek * (1.f - ek);
+    }
+    const int64_t r = (i % rois) * h0;
+    for (int h = 0; h < h0; ++h) {
+      const float xv = x[i * h0 + h], pv = prob[r + h];
+      const float g = (d_xm ? d_xm[i * h0 + h] : 0.f) + pb[h] * S + pb[h0 + h] * T;
+      dx[i * h0 + h] = g * pv;
+      gx[i * h0 + h] = g * xv;
+      acc[h] = xv * pv * S;
+      acc[MAX_H0 + h] = xv * pv * T;
+    }
+  }
+  block_reduce_vec<2 * MAX_H0>(acc, red, pb_partial + (int64_t)blockIdx.x * 2 * MAX_H0);
+}
+
+// dprob[r,h] = sum_b gx[(b*rois + r), h]
+__global__ void k_edge_mask_bwd_prob(int64_t n_graphs, int rois, int h0, const float* __restrict__ gx,
+                                     float* __restrict__ dprob) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= rois * h0) return;
+  float t = 0.f;
+  for (int64_t b = 0; b < n_graphs; ++b) t += gx[b * rois * h0 + j];
+  dprob[j] = t;
+}
+
+__global__ void k_edge_mask_bwd_pb(int64_t nblk, int h0, const float* __restrict__ partial, float* __restrict__ dpb) {
+  const int j = threadIdx.x;
+  if (j >= 2 * h0) return;
+  const int col = j < h0 ? j : MAX_H0 + (j - h0);
+  float t = 0.f;
+  for (int64_t r = 0; r < nblk; ++r) t += partial[r * 2 * MAX_H0 + col];
+  dpb[j] = t;
+}
+
+extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x,
+                                  const float* prob, const float* prob_bias, const float* ew, const float* e,
+                                  const float* d_xm, const float* d_ewm, const float* d_e, const int32_t* tgt_ptr,
+                                  const int32_t* tgt_perm, const int32_t* src_ptr, const int32_t* src_perm,
+                                  float* dx, float* dprob, float* dprob_bias, float* scratch, void* stream) {
+  IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0, "edge_mask_bwd: bad rois/h0");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nblk = igcn_cdiv(n_nodes, 256);
+  float* gx = scratch;
+  float* part = scratch + n_nodes * h0;  // [nblk, 2*MAX_H0]
+  hipLaunchKernelGGL(k_edge_mask_bwd_nodes, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
+                     prob_bias, ew, e, d_xm, d_ewm, d_e, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
+  hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)igcn_cdiv(rois * h0, 256)), dim3(256), 0, st,
+                     n_nodes / rois, rois, h0, gx, dprob);
+  hipLaunchKernelGGL(k_edge_mask_bwd_pb, dim3(1), dim3(64), 0, st, nblk, h0, part, dprob_bias);
+  IGCN_CHECK_LAUNCH("edge_mask_bwd");
+  return IGCN_OK;
+}
+
+// =================================================================================================
+// gcn_norm forward: one thread per node
+// =================================================================================================
+__global__ void k_gcn_norm_fwd(int64_t n_nodes, const float* __restrict__ ew, const int32_t* __restrict__ src32,
+                               const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
+                               const int32_t* __restrict__ loop_edge, float* __restrict__ dis,
+                               float* __restrict__ wl) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  float deg = 0.f;
+  for (int32_t p = tgt_ptr[i]; p < tgt_ptr[i + 1]; ++p) {
+    const int32_t k = tgt_perm[p];
+    if (src32[k] != (int32_t)i) deg += ew[k];
+  }
+  const int32_t le = loop_edge[i];
+  const float lw = le >= 0 ? ew[le] : 1.f;
+  deg += lw;
+  float d = 1.0f / sqrtf(deg);      // deg^-1/2 ; deg==0 -> inf -> masked to 0 ; deg<0 -> NaN (as torch.pow)
+  if (deg == 0.f) d = 0.f;
+  dis[i] = d;
+  wl[i] = lw;
+}
+
+// what[k] = dis[src]*ew[k]*dis[dst] (0 for stored loops: they are replaced) ; what_loop[i] = dis[i]*wl[i]*dis[i]
+__global__ void k_gcn_norm_coef(int64_t n_nodes, int64_t n_edges, const float* __restrict__ ew,
+                                const float* __restrict__ dis, const float* __restrict__ wl,
+                                const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
+                                float* __restrict__ what, float* __restrict__ what_loop) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_edges) {
+    const int32_t s = src32[i], t = dst32[i];
+    what[i] = s != t ? dis[s] * ew[i] * dis[t] : 0.f;
+  }
+  if (i < n_nodes) {
+    const float d = dis[i];
+    what_loop[i] = d * wl[i] * d;
+  }
+}
+
+extern "C" int igcn_gcn_norm_fwd(int64_t n_nodes, int64_t n_edges, const float* ew, const int32_t* src32,
+                                 const int32_t* dst32, const int32_t* tgt_ptr, const int32_t* tgt_perm,
+                                 const int32_t* loop_edge, float* dis, float* wl, float* what, float* what_loop,
+                                 void* stream) {
+  if (n_nodes == 0) return IGCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gcn_norm_fwd, dim3((unsigned)igcn_cdiv(n_nodes, 256)), dim3(256), 0, st, n_nodes, ew, src32,
+                     tgt_ptr, tgt_perm, loop_edge, dis, wl);
+  const int64_t n = n_nodes > n_edges ? n_nodes : n_edges;
+  hipLaunchKernelGGL(k_gcn_norm_coef, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, st, n_nodes, n_edges, ew, dis,
+                     wl, src32, dst32, what, what_loop);
+  IGCN_CHECK_LAUNCH("gcn_norm_fwd");
+  return IGCN_OK;
+}
+
+// gcn_norm backward, phase 1 (per node): d(deg)
+//   d dis_i = sum_{k out of i, non-loop} dwhat_k ew_k dis[dst_k] + sum_{k into i, non-loop} dwhat_k ew_k dis[src_k]
+//             + 2 dwhat_loop_i wl_i dis_i ;   d deg_i = -1/2 dis_i^3 d dis_i
+__global__ void k_gcn_norm_bwd_deg(int64_t n_nodes, const float* __restrict__ ew, const float* __restrict__ dis,
+                                   const float* __restrict__ wl, const float* __restrict__ dwhat,
+                                   const float* __restrict__ dwhat_loop, const int32_t* __restrict__ src32,
+                                   const int32_t* __restrict__ dst32, const int32_t* __restrict__ tgt_ptr,
+                                   const int32_t* __restrict__ tgt_perm, const int32_t* __restrict__ src_ptr,
+                                   const int32_t* __restrict__ src_perm, float* __restrict__ ddeg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  float dd = 0.f;
+  for (int32_t p = src_ptr[i]; p < src_ptr[i + 1]; ++p) {
+    const int32_t k = src_perm[p];
+    const int32_t t = dst32[k];
+    if (t != (int32_t)i) dd += dwhat[k] * ew[k] * dis[t];
+  }
+  for (int32_t p = tgt_ptr[i]; p < tgt_ptr[i + 1]; ++p) {
+    const int32_t k = tgt_perm[p];
+    const int32_t s = src32[k];
+    if (s != (int32_t)i) dd += dwhat[k] * ew[k] * dis[s];
+  }
+  const float di = dis[i];
+  dd += 2.f * dwhat_loop[i] * wl[i] * di;
+  ddeg[i] = -0.5f * di * di * di * dd;
+}
+
+// phase 2 (per edge)
+__global__ void k_gcn_norm_bwd_edge(int64_t n_edges, const float* __restrict__ dis,
+                                    const float* __restrict__ dwhat, const float* __restrict__ dwhat_loop,
+                                    const float* __restrict__ ddeg, const int32_t* __restrict__ src32,
+                                    const int32_t* __restrict__ dst32, const int32_t* __restrict__ loop_edge,
+                                    float* __restrict__ dew) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_edges) return;
+  const int32_t s = src32[k], t = dst32[k];
+  float g;
+  if (s != t) {
+    g = dis[s] * dis[t] * dwhat[k] + ddeg[t];
+  } else {
+    g = (loop_edge[s] == (int32_t)k) ? ddeg[s] + dis[s] * dis[s] * dwhat_loop[s] : 0.f;
+  }
+  dew[k] = g;
+}
+
+extern "C" int igcn_gcn_norm_bwd(int64_t n_nodes, int64_t n_edges, const float* ew, const float* dis,
+                                 const float* wl, const float* dwhat, const float* dwhat_loop,
+                                 const int32_t* src32, const int32_t* dst32, const int32_t* tgt_ptr,
+                                 const int32_t* tgt_perm, const int32_t* src_ptr, const int32_t* src_perm,
+                                 const int32_t* loop_edge, float* dew, float* scratch, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_nodes == 0 || n_edges == 0) return IGCN_OK;
+  hipLaunchKernelGGL(k_gcn_norm_bwd_deg, dim3((unsigned)igcn_cdiv(n_nodes, 256)), dim3(256), 0, st, n_nodes, ew, dis,
+                     wl, dwhat, dwhat_loop, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, scratch);
+  hipLaunchKernelGGL(k_gcn_norm_bwd_edge, dim3((unsigned)igcn_cdiv(n_edges, 256)), dim3(256), 0, st, n_edges, dis,
+                     dwhat, dwhat_loop, scratch, src32, dst32, loop_edge, dew);
+  IGCN_CHECK_LAUNCH("gcn_norm_bwd");
+  return IGCN_OK;
+}
+
+// =================================================================================================
+// scatter-aggregate forward.  Thread (node, f): FP = F rounded up to a power of two <= 64 lanes share a
+// node, so the node's edge list is read once per FP-lane group (same-address loads broadcast) and the
+// gathered source row h[src, 0:F] is one contiguous segment per group.
+// =================================================================================================
+template <int FP>
+__global__ void __launch_bounds__(256)
+k_gcn_propagate_fwd(int64_t n_nodes, int F, const float* __restrict__ h, int64_t ld_h,
+                    const float* __restrict__ what, const float* __restrict__ what_loop,
+                    const float* __restrict__ bias, const int32_t* __restrict__ src32,
+                    const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
+                    float* __restrict__ out, int64_t ld_out, int relu) {
+  constexpr int NPB = 256 / FP;  // nodes per block
+  const int f = threadIdx.x % FP;
+  const int64_t t = (int64_t)blockIdx.x * NPB + threadIdx.x / FP;
+  if (t >= n_nodes || f >= F) return;
+  float acc = 0.f;
+  const int32_t p1 = tgt_ptr[t + 1];
+  for (int32_t p = tgt_ptr[t]; p < p1; ++p) {
+    const int32_t k = tgt_perm[p];
+    const int32_t s = src32[k];
+    if (s != (int32_t)t) acc += what[k] * h[(int64_t)s * ld_h + f];
+  }
+  acc += what_loop[t] * h[t * ld_h + f];
+  acc += bias ? bias[f] : 0.f;
+  if (relu) acc = fmaxf(acc, 0.f);
+  out[t * ld_out + f] = acc;
+}
+
+static int pow2_ge(int F) {
+  int p = 1;
+  while (p < F) p <<= 1;
+  return p;
+}
+
+extern "C" int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, const float* h, int64_t ld_h,
+                                      const float* what, const float* what_loop, const float* bias,
+                                      const int32_t* src32, const int32_t* tgt_ptr, const int32_t* tgt_perm,
+                                      float* out, int64_t ld_out, int relu, void* stream) {
+  (void)n_edges;
+  IGCN_REQUIRE(F >= 1 && F <= 256, "gcn_propagate_fwd: F=%d unsupported (1..256)", F);
+  if (n_nodes == 0) return IGCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int FP = pow2_ge(F);
+#define LAUNCH_FWD(FPV)                                                                                         \
+  hipLaunchKernelGGL((k_gcn_propagate_fwd<FPV>), dim3((unsigned)igcn_cdiv(n_nodes, 256 / FPV)), dim3(256), 0, st, \
+                     n_nodes, F, h, ld_h, what, what_loop, bias, src32, tgt_ptr, tgt_perm, out, ld_out, relu)
+  switch (FP) {
+    case 1: LAUNCH_FWD(1); break;
+    case 2: LAUNCH_FWD(2); break;
+    case 4: LAUNCH_FWD(4); break;
+    case 8: LAUNCH_FWD(8); break;
+    case 16: LAUNCH_FWD(16); break;
+    case 32: LAUNCH_FWD(32); break;
+    case 64: LAUNCH_FWD(64); break;
+    case 128: LAUNCH_FWD(128); break;
+    default: LAUNCH_FWD(256); break;
+  }
+#undef LAUNCH_FWD
+  IGCN_CHECK_LAUNCH("gcn_propagate_fwd");
+  return IGCN_OK;
+}
+
+// =================================================================================================
+// scatter-aggregate backward
+// =================================================================================================
+// dh[s,f] = sum_{k out of s, non-loop} what_k g[dst_k,f] + what_loop_s g[s,f] ; g = dout*(out>0)
+// also block partials of dbias[f] = sum_t g[t,f]
+template <int FP>
+__global__ void __launch_bounds__(256)
+k_gcn_propagate_bwd_dh(int64_t n_nodes, int F, const float* __restrict__ dout, int64_t ld_dout,
+                       const float* __restrict__ out, int64_t ld_out, int relu, const float* __restrict__ what,
+                       const float* __restrict__ what_loop,
+                       const int32_t* __restrict__ dst32, const int32_t* __restrict__ src_ptr,
+                       const int32_t* __restrict__ src_perm, float* __restrict__ dh, int64_t ld_dh,
+                       float* __restrict__ dbias_partial /*[nblk, FP]*/) {
+  constexpr int NPB = 256 / FP;
+  __shared__ float red[256];
+  const int f = threadIdx.x % FP;
+  const int nl = threadIdx.x / FP;
+  const int64_t s = (int64_t)blockIdx.x * NPB + nl;
+  float gself = 0.f;
+  if (s < n_nodes && f < F) {
+    float acc = 0.f;
+    const int32_t p1 = src_ptr[s + 1];
+    for (int32_t p = src_ptr[s]; p < p1; ++p) {
+      const int32_t k = src_perm[p];
+      const int32_t t = dst32[k];
+      if (t != (int32_t)s) {
+        float g = dout[(int64_t)t * ld_dout + f];
+        if (relu && !(out[(int64_t)t * ld_out + f] > 0.f)) g = 0.f;
+        acc += what[k] * g;
+      }
+    }
+    gself = dout[s * ld_dout + f];
+    if (relu && !(out[s * ld_out + f] > 0.f)) gself = 0.f;
+    acc += what_loop[s] * gself;
+    dh[s * ld_dh + f] = acc;
+  }
+  // dbias partial: sum over the block's nodes for each f
+  red[threadIdx.x] = gself;
+  __syncthreads();
+  if (threadIdx.x < FP) {
+    float t = 0.f;
+    for (int j = 0; j < NPB; ++j) t += red[j * FP + threadIdx.x];
+    dbias_partial[(int64_t)blockIdx.x * FP + threadIdx.x] = t;
+  }
+}
+
+// dwhat_k (+)= g[dst_k,:].h[src_k,:] for non-loop edges ; dwhat_loop_i (+)= g[i,:].h[i,:]
+__global__ void k_gcn_propagate_bwd_dw(int64_t n_nodes, int64_t n_edges, int F, const float* __restrict__ dout,
+                                       int64_t ld_dout, const float* __restrict__ out, int64_t ld_out, int relu,
+                                       const float* __restrict__ h, int64_t ld_h,
+                                       const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
+                                       float* __restrict__ dwhat, float* __restrict__ dwhat_loop) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_edges + n_nodes) return;
+  int64_t s, t;
+  float* dstp;
+  if (i < n_edges) {
+    s = src32[i];
+    t = dst32[i];
+    dstp = dwhat + i;
+    if (s == t) { *dstp = 0.f; return; }
+  } else {
+    s = t = i - n_edges;
+    dstp = dwhat_loop + s;
+  }
+  float acc = 0.f;
+  for (int f = 0; f < F; ++f) {
+    float g = dout[t * ld_dout + f];
+    if (relu && !(out[t * ld_out + f] > 0.f)) g = 0.f;
+    acc += g * h[s * ld_h + f];
+  }
+  *dstp = acc;
+}
+
+extern "C" size_t igcn_gcn_propagate_bwd_scratch_floats(int64_t n_nodes, int F) {
+  const int FP = pow2_ge(F > 0 ? F : 1);
+  const int npb = FP >= 256 ? 1 : 256 / FP;
+  return (size_t)(igcn_cdiv(n_nodes, npb) * FP + 64);
+}
+
+extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, const float* dout, int64_t ld_dout,
+                                      const float* out, int64_t ld_out, int relu, const float* h, int64_t ld_h,
+                                      const float* what, const float* what_loop, const int32_t* src32,
+                                      const int32_t* dst32, const int32_t* src_ptr, const int32_t* src_perm,
+                                      float* dh, int64_t ld_dh, float* dbias, int need_dw,
+                                      float* dwhat, float* dwhat_loop, float* scratch, void* stream) {
+  IGCN_REQUIRE(F >= 1 && F <= 256, "gcn_propagate_bwd: F=%d unsupported (1..256)", F);
+  if (n_nodes == 0) return IGCN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int FP = pow2_ge(F);
+  const int64_t nblk = igcn_cdiv(n_nodes, 256 / FP);
+#define LAUNCH_BWD(FPV)                                                                                          \
+  hipLaunchKernelGGL((k_gcn_propagate_bwd_dh<FPV>), dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, F, dout,    \
+                     ld_dout, out, ld_out, relu, what, what_loop, dst32, src_ptr, src_perm, dh, ld_dh, scratch)
+  switch (FP) {
+    case 1: LAUNCH_BWD(1); break;
+    case 2: LAUNCH_BWD(2); break;
+    case 4: LAUNCH_BWD(4); break;
+    case 8: LAUNCH_BWD(8); break;
+    case 16: LAUNCH_BWD(16); break;
+    case 32: LAUNCH_BWD(32); break;
+    case 64: LAUNCH_BWD(64); break;
+    case 128: LAUNCH_BWD(128); break;
+    default: LAUNCH_BWD(256); break;
+  }
+#undef LAUNCH_BWD
+  IGCN_CHECK_LAUNCH("gcn_propagate_bwd_dh");
+  if (dbias) {
+    int rc = igcn_launch_reduce_rows(scratch, nblk, FP, F, dbias, 0, st);
+    if (rc) return rc;
+  }
+  if (need_dw) {
+    hipLaunchKernelGGL(k_gcn_propagate_bwd_dw, dim3((unsigned)igcn_cdiv(n_edges + n_nodes, 256)), dim3(256), 0, st,
+                       n_nodes, n_edges, F, dout, ld_dout, out, ld_out, relu, h, ld_h, src32, dst32, dwhat,
+                       dwhat_loop);
+    IGCN_CHECK_LAUNCH("gcn_propagate_bwd_dw");
+  }
+  return IGCN_OK;
+}

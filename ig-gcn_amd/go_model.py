@@ -1,0 +1,131 @@
+"""Drop-in ``Gene_ontology_network`` on the HIP kernels.
+
+Mirrors the interface of the reference's kernel/go_model.py: constructor (:24), ``forward(data, T,
+device) -> (latent, x_D, [zeros(3)], atten_out)`` (:205,287) and an identical ``state_dict()`` key set,
+so checkpoints interchange.  The arithmetic is restructured for the GPU:
+
+* activations are channel-major [B, f, N]; one kernel launch covers every sample (the reference loops
+  over samples in python and builds two sparse matrices per sample and layer, :236-244);
+* the hierarchy's edge lists are built once on the host as CSR + transposed CSR (``ops.Csr``); the
+  reference keeps COO index tensors and re-derives row sums with torch.sparse.sum per sample;
+* LayerNorm-over-nodes, ReLU, Dropout2d and the level pooling of :246-251 are one fused kernel.
+
+Dense read-outs (BatchNorm over nodes, the latent MLP) are small torch ops on the same stream.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+N_SNPS = 54
+
+
+def _coo_rows_cols(sp):
+    sp = sp.coalesce()
+    idx = sp.indices().cpu()
+    keep = (sp.values() != 0).cpu()          # the reference's to_dense().to_sparse() drops stored zeros
+    return idx[0][keep], idx[1][keep]
+
+
+class Gene_ontology_network(nn.Module):
+    def __init__(self, A_g, A, in_f_dim, n_l, f_dim, pool_dim, l_dim, device, dim_snps_atten=5):
+        super().__init__()
+        self.device = device
+        pool = [int(p) for p in pool_dim[0]]
+        n = int(A.shape[0])
+        self.pool, self.n_l, self.n_nodes = pool, n_l, n
+        n_top = n - sum(pool[:n_l])
+        self.n_top = n_top
+        f_dim = [in_f_dim] + list(f_dim)
+        self.f_dim = f_dim
+
+        # ---- index structures (go_model.py:42-88), host-built once -------------------------------
+        r, c = _coo_rows_cols(A)
+        self.enc_csr = []
+        for i in range(n_l):
+            off = sum(pool[:i])
+            m = (r >= off) & (c >= off)
+            self.enc_csr.append(ops.Csr(r[m] - off, c[m] - off, n - off, n - off, device))
+        rt, ct = _coo_rows_cols(A.t())
+        self.dec_csr = []
+        for i in range(n_l):
+            ro, co = sum(pool[:n_l - i - 1]), sum(pool[:n_l - i])
+            m = (rt >= ro) & (ct >= co)
+            self.dec_csr.append(ops.Csr(rt[m] - ro, ct[m] - co, n - ro, n - co, device))
+        ag = A_g.coalesce()
+        gi = ag.indices().cpu()
+        self.gene_csr = ops.Csr(gi[0], gi[1], n, N_SNPS, device)                       # rows = GO nodes
+        agt = A_g.t().coalesce()
+        gti = agt.indices().cpu()
+        self.gene_t_csr = ops.Csr(gti[0], gti[1], N_SNPS, n, device)                   # rows = SNPs
+        nnz_g = int(gi.shape[1])
+
+        # ---- parameters: same names / shapes / init as the reference (:80-157) --------------------
+        self.t = nn.ParameterList([nn.Parameter(torch.empty(nnz_g).normal_(1.0, 0.1)) for _ in range(in_f_dim)])
+        self.t_D = nn.ParameterList([nn.Parameter(torch.empty(nnz_g).normal_(1.0, 0.1))])
+        lin = lambda i, o: nn.Linear(i, o, bias=False)       # noqa: E731
+        self.w_inc = nn.ModuleList([lin(f_dim[i], f_dim[i + 1]) for i in range(n_l)])
+        self.w_s_loop = nn.ModuleList([lin(f_dim[i], f_dim[i + 1]) for i in range(n_l)])
+        self.w_att_s = nn.ModuleList([lin(f_dim[i + 1], 1) for i in range(n_l)])
+        self.G_B = nn.ModuleList([nn.LayerNorm(sum(pool[i:])) for i in range(n_l)])
+        self.w_att_in = nn.ModuleList([lin(2 * f_dim[i + 1], 1) for i in range(n_l)])
+        self.w_out = nn.ModuleList([lin(f_dim[i], f_dim[i - 1]) for i in range(n_l, 0, -1)])
+        self.w_s_loop_out = nn.ModuleList([lin(f_dim[i], f_dim[i - 1]) for i in range(n_l, 0, -1)])
+        self.G_B_D = nn.ModuleList([nn.LayerNorm(sum(pool[i:])) for i in range(n_l - 1, -1, -1)])
+        self.conc_for_attention = nn.Sequential(lin(f_dim[-1], dim_snps_atten), nn.BatchNorm1d(n_top), nn.ReLU())
+        self.conc = lin(f_dim[-1], 1)
+        self.B = nn.Sequential(nn.BatchNorm1d(n_top), nn.ReLU(), nn.Dropout(0.5))
+        self.conc_D = lin(f_dim[0], 1)
+        self.B_D = nn.Sequential(nn.BatchNorm1d(n), nn.ReLU(), nn.Dropout(0.5))
+        self.latent = nn.Sequential(lin(n_top, 32), nn.BatchNorm1d(32), nn.ReLU(), nn.Dropout(0.5),
+                                    lin(32, l_dim), nn.BatchNorm1d(l_dim), nn.ReLU())
+        # present in the reference's state_dict, never used by forward (:148-157)
+        self.classification = nn.Sequential(nn.BatchNorm1d(l_dim + N_SNPS), nn.ReLU(), nn.Dropout(0.5),
+                                            lin(l_dim + N_SNPS, 16), nn.ReLU(), nn.Dropout(0.3),
+                                            nn.Linear(16, 1, bias=True), nn.Sigmoid())
+        self.node_dropout_p = 0.4           # nn.Dropout2d(0.4) at :104,113
+        self._dropout_enabled = True        # parity tests switch every dropout off
+
+    # ---------------------------------------------------------------------------------------------
+    def _node_keep(self, b, n, dev):
+        """Dropout2d on [B,N,f] zeroes whole nodes per sample: keep/(1-p) mask [B,N] or None."""
+        if not (self.training and self._dropout_enabled and self.node_dropout_p > 0):
+            return None
+        p = self.node_dropout_p
+        return torch.empty(b, n, dtype=torch.float32, device=dev).bernoulli_(1.0 - p).div_(1.0 - p)
+
+    def _drop(self, x, p):
+        return F.dropout(x, p, True) if (self.training and self._dropout_enabled) else x
+
+    def forward(self, data, T=None, device=None):
+        bsz, dev = data.shape[0], data.device
+        # gene encoding (:208-215)
+        x = ops.SparseMap.apply(data, torch.stack(list(self.t)), self.gene_csr)          # [B, in_f, N]
+        # encoder (:219-251)
+        for j in range(self.n_l):
+            csr = self.enc_csr[j]
+            y = ops.GoAttention.apply(x, self.w_inc[j].weight, self.w_s_loop[j].weight,
+                                      self.w_att_in[j].weight.view(-1), self.w_att_s[j].weight.view(-1), csr)
+            x = ops.NodesLayerNorm.apply(y, self.G_B[j].weight, self.G_B[j].bias,
+                                         self._node_keep(bsz, csr.n_rows, dev), self.pool[j], self.G_B[j].eps)
+        # read-outs (:254-255): BatchNorm1d(n_top) normalises per NODE over (batch, feature)
+        xt = x.transpose(1, 2)                                                            # [B, n_top, f]
+        atten_out = self.conc_for_attention[2](self.conc_for_attention[1](
+            F.linear(xt, self.conc_for_attention[0].weight)))
+        inp = F.linear(xt, self.conc.weight).squeeze(2)                                   # [B, n_top]
+        inp_out = self._drop(self.B[1](self.B[0](inp)), 0.5)
+        # decoder (:258-275)
+        for j in range(self.n_l):
+            csr = self.dec_csr[j]
+            y = ops.GoDecode.apply(x, self.w_out[j].weight, self.w_s_loop_out[j].weight, csr)
+            x = ops.NodesLayerNorm.apply(y, self.G_B_D[j].weight, self.G_B_D[j].bias,
+                                         self._node_keep(bsz, csr.n_rows, dev), 0, self.G_B_D[j].eps)
+        # gene decoding (:278-282)
+        out_d = (x * self.conc_D.weight.view(1, -1, 1)).sum(1)                            # [B, N]
+        out_d = self._drop(self.B_D[1](self.B_D[0](out_d)), 0.5)
+        x_d = ops.SparseMap.apply(out_d, self.t_D[0].unsqueeze(0), self.gene_t_csr).squeeze(1)   # [B, 54]
+        # latent projection (:138-146,285)
+        h = self._drop(self.latent[2](self.latent[1](self.latent[0](inp_out.view(bsz, -1)))), 0.5)
+        latent = self.latent[6](self.latent[5](self.latent[4](h)))
+        return latent, x_d, [torch.zeros(3, device=dev)], atten_out

@@ -1,0 +1,384 @@
+"""torch.autograd wrappers over the C ABI (include/igcn.h).  Every op here launches hand-written HIP
+kernels from libigcn.so on the current torch stream; nothing falls back to PyTorch arithmetic.
+
+Index structures (``GraphPlan`` for a batch of brain graphs, ``Csr``/``CsrPair`` for the GO hierarchy)
+are plain int32 device tensors owned by Python.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise _lib.IgcnError(f"libigcn computes in fp32; got {t.dtype}")
+    return t.contiguous()
+
+
+# =================================================================================================
+# Graph plan (once per batch)
+# =================================================================================================
+class GraphPlan:
+    """Stable by-target / by-source grouping of a batch's edges (igcn_graph_plan_build)."""
+
+    def __init__(self, edge_index, n_nodes):
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise _lib.IgcnError("edge_index must be int64 [2,E]")
+        ei = edge_index.contiguous()
+        dev = ei.device
+        self.n_nodes, self.n_edges = int(n_nodes), int(ei.shape[1])
+        n, e = self.n_nodes, self.n_edges
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.src32 = torch.empty(max(e, 1), **i32)
+        self.dst32 = torch.empty(max(e, 1), **i32)
+        self.tgt_ptr = torch.empty(n + 1, **i32)
+        self.tgt_perm = torch.empty(max(e, 1), **i32)
+        self.src_ptr = torch.empty(n + 1, **i32)
+        self.src_perm = torch.empty(max(e, 1), **i32)
+        self.loop_edge = torch.empty(n, **i32)
+        lib = _lib.load()
+        wbytes = int(lib.igcn_graph_plan_workspace_bytes(n, e))
+        ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        call("igcn_graph_plan_build", n, e, ptr(ei), ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr),
+             ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(ws), wbytes,
+             stream_ptr())
+        self._ws = ws            # keep alive until the stream has consumed it
+
+
+def plan_for(data):
+    """The GraphPlan of a batch object, built on first use and cached on it."""
+    plan = getattr(data, "_igcn_plan", None)
+    if plan is None or plan.n_edges != data.edge_index.shape[1] or plan.src32.device != data.edge_index.device:
+        plan = GraphPlan(data.edge_index, data.x.shape[0])
+        try:
+            data._igcn_plan = plan
+        except AttributeError:
+            pass
+    return plan
+
+
+# =================================================================================================
+# SGCN branch
+# =================================================================================================
+class EdgeMask(torch.autograd.Function):
+    """cal_probability (kernel/sgcn_img_snp.py:133-151) -> (xm, ewm, e)."""
+
+    @staticmethod
+    def forward(ctx, x, prob, prob_bias, ew, plan, rois):
+        x, prob, pb, ew = _f32(x), _f32(prob), _f32(prob_bias), _f32(ew)
+        n, h0 = x.shape
+        xm, e, ewm = torch.empty_like(x), torch.empty_like(ew), torch.empty_like(ew)
+        call("igcn_edge_mask_fwd", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew),
+             ptr(plan.src32), ptr(plan.dst32), ptr(xm), ptr(e), ptr(ewm), stream_ptr())
+        ctx.save_for_backward(x, prob, pb, ew, e)
+        ctx.plan, ctx.rois = plan, rois
+        return xm, ewm, e
+
+    @staticmethod
+    def backward(ctx, d_xm, d_ewm, d_e):
+        x, prob, pb, ew, e = ctx.saved_tensors
+        plan, rois = ctx.plan, ctx.rois
+        n, h0 = x.shape
+        d_xm = _f32(d_xm) if d_xm is not None else None
+        d_ewm = _f32(d_ewm) if d_ewm is not None else None
+        d_e = _f32(d_e) if d_e is not None else None
+        dx, dprob, dpb = torch.empty_like(x), torch.empty_like(prob), torch.empty_like(pb)
+        scratch = torch.empty(n * h0 + 16 * ((n + 255) // 256), dtype=torch.float32, device=x.device)
+        call("igcn_edge_mask_bwd", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew), ptr(e),
+             ptr(d_xm), ptr(d_ewm), ptr(d_e), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr),
+             ptr(plan.src_perm), ptr(dx), ptr(dprob), ptr(dpb), ptr(scratch), stream_ptr())
+        return dx, dprob, dpb, None, None, None
+
+
+class GcnNorm(torch.autograd.Function):
+    """PyG gcn_norm (add_remaining_self_loops + symmetric normalisation) -> (what [E], what_loop [N])."""
+
+    @staticmethod
+    def forward(ctx, ew, plan):
+        ew = _f32(ew)
+        n, e = plan.n_nodes, plan.n_edges
+        f = dict(dtype=torch.float32, device=ew.device)
+        dis, wl = torch.empty(n, **f), torch.empty(n, **f)
+        what, wloop = torch.empty(max(e, 1), **f), torch.empty(n, **f)
+        call("igcn_gcn_norm_fwd", n, e, ptr(ew), ptr(plan.src32), ptr(plan.dst32), ptr(plan.tgt_ptr),
+             ptr(plan.tgt_perm), ptr(plan.loop_edge), ptr(dis), ptr(wl), ptr(what), ptr(wloop), stream_ptr())
+        ctx.save_for_backward(ew, dis, wl)
+        ctx.plan = plan
+        return what, wloop
+
+    @staticmethod
+    def backward(ctx, dwhat, dwloop):
+        ew, dis, wl = ctx.saved_tensors
+        plan = ctx.plan
+        n, e = plan.n_nodes, plan.n_edges
+        dwhat = _f32(dwhat) if dwhat is not None else torch.zeros_like(ew)
+        dwloop = _f32(dwloop) if dwloop is not None else torch.zeros_like(dis)
+        dew = torch.empty_like(ew)
+        scratch = torch.empty(n, dtype=torch.float32, device=ew.device)
+        call("igcn_gcn_norm_bwd", n, e, ptr(ew), ptr(dis), ptr(wl), ptr(dwhat), ptr(dwloop), ptr(plan.src32),
+             ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm),
+             ptr(plan.loop_edge), ptr(dew), ptr(scratch), stream_ptr())
+        return dew, None
+
+
+class GcnPropagate(torch.autograd.Function):
+    """out = act(A_hat h + bias): the scatter-aggregate of GCNConv (+ F.relu of sgcn_img_snp.py:218,221)."""
+
+    @staticmethod
+    def forward(ctx, h, what, wloop, bias, plan, relu):
+        h, what, wloop = _f32(h), _f32(what), _f32(wloop)
+        bias = _f32(bias) if bias is not None else None
+        n, f = h.shape
+        out = torch.empty_like(h)
+        call("igcn_gcn_propagate_fwd", n, plan.n_edges, f, ptr(h), f, ptr(what), ptr(wloop), ptr(bias),
+             ptr(plan.src32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(out), f, int(relu), stream_ptr())
+        ctx.save_for_backward(h, what, wloop, out)
+        ctx.plan, ctx.relu, ctx.has_bias = plan, int(relu), bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, what, wloop, out = ctx.saved_tensors
+        plan = ctx.plan
+        dout = _f32(dout)
+        n, f = h.shape
+        need_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dh = torch.empty_like(h)
+        dbias = torch.empty(f, dtype=torch.float32, device=h.device) if ctx.has_bias else None
+        dwhat = torch.empty_like(what) if need_dw else None
+        dwloop = torch.empty_like(wloop) if need_dw else None
+        lib = _lib.load()
+        scratch = torch.empty(int(lib.igcn_gcn_propagate_bwd_scratch_floats(n, f)), dtype=torch.float32,
+                              device=h.device)
+        call("igcn_gcn_propagate_bwd", n, plan.n_edges, f, ptr(dout), f, ptr(out), f, ctx.relu, ptr(h), f,
+             ptr(what), ptr(wloop), ptr(plan.src32), ptr(plan.dst32), ptr(plan.src_ptr), ptr(plan.src_perm),
+             ptr(dh), f, ptr(dbias), int(need_dw), ptr(dwhat), ptr(dwloop), ptr(scratch), stream_ptr())
+        return dh, dwhat, dwloop, dbias, None, None
+
+
+# =================================================================================================
+# Dense transforms on MFMA
+# =================================================================================================
+def _split_k(m, n, k):
+    """Enough K-slices to put >= ~256 workgroups on the chip when the output has few tiles."""
+    tiles = ((m + 63) // 64) * ((n + 63) // 64)
+    if tiles >= 128 or k < 256:
+        return 1
+    return int(max(1, min(k // 64, (256 + tiles - 1) // tiles)))
+
+
+def gemm_nt(a, b, bias=None, act=0, out=None):
+    """out[M,N] = act(a[M,K] @ b[N,K]^T + bias) on igcn_gemm_f32."""
+    a, b = _f32(a), _f32(b)
+    m, k = a.shape
+    n = b.shape[0]
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    sk = _split_k(m, n, k)
+    scratch = torch.empty(sk * m * n, dtype=torch.float32, device=a.device) if sk > 1 else None
+    call("igcn_gemm_f32", m, n, k, ptr(a), k, 1, ptr(b), k, 1, ptr(bias), ptr(out), n, act, sk, ptr(scratch),
+         stream_ptr())
+    return out
+
+
+def gemm_nn(a, b):
+    """out[M,N] = a[M,K] @ b[K,N]."""
+    a, b = _f32(a), _f32(b)
+    m, k = a.shape
+    n = b.shape[1]
+    out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    sk = _split_k(m, n, k)
+    scratch = torch.empty(sk * m * n, dtype=torch.float32, device=a.device) if sk > 1 else None
+    call("igcn_gemm_f32", m, n, k, ptr(a), k, 1, ptr(b), 1, n, None, ptr(out), n, 0, sk, ptr(scratch), stream_ptr())
+    return out
+
+
+def gemm_tn(a, b):
+    """out[M,N] = a[K,M]^T @ b[K,N]  (weight gradient: reduction over the long row axis K)."""
+    a, b = _f32(a), _f32(b)
+    k, m = a.shape
+    n = b.shape[1]
+    out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    sk = _split_k(m, n, k)
+    scratch = torch.empty(sk * m * n, dtype=torch.float32, device=a.device) if sk > 1 else None
+    call("igcn_gemm_f32", m, n, k, ptr(a), 1, m, ptr(b), 1, n, None, ptr(out), n, 0, sk, ptr(scratch), stream_ptr())
+    return out
+
+
+class Linear(torch.autograd.Function):
+    """y = act(x W^T + b) with W [out,in] (GCNConv.lin, lin1, lin1_regr, ...)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        y = gemm_nt(x, weight, _f32(bias) if bias is not None else None, 1 if relu else 0)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = _f32(dy)
+        if ctx.relu:
+            dy = dy * (y > 0)
+        dx = gemm_nn(dy, weight) if ctx.needs_input_grad[0] else None
+        dw = gemm_tn(dy, x) if ctx.needs_input_grad[1] else None
+        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    lead = x.shape[:-1]
+    y = Linear.apply(x.reshape(-1, x.shape[-1]), weight, bias, relu)
+    return y.view(*lead, weight.shape[0])
+
+
+# =================================================================================================
+# GO hierarchy structures
+# =================================================================================================
+class Csr:
+    """Row-grouped sparse structure + its transpose, as int32 device tensors.
+
+    rows/cols: int64 CPU tensors of the non-zeros in ROW-MAJOR (coalesced) order.
+    """
+
+    def __init__(self, rows, cols, n_rows, n_cols, device):
+        rows, cols = rows.long().cpu(), cols.long().cpu()
+        self.n_rows, self.n_cols, self.nnz = int(n_rows), int(n_cols), int(rows.numel())
+        key = rows * n_cols + cols
+        assert self.nnz == 0 or bool((key[1:] > key[:-1]).all()), "non-zeros must be row-major and unique"
+        row_ptr = torch.zeros(n_rows + 1, dtype=torch.long)
+        row_ptr[1:] = torch.bincount(rows, minlength=n_rows).cumsum(0)
+        order = torch.argsort(cols * n_rows + rows)          # column-major order; unique keys => deterministic
+        t_ptr = torch.zeros(n_cols + 1, dtype=torch.long)
+        t_ptr[1:] = torch.bincount(cols, minlength=n_cols).cumsum(0)
+        i32 = lambda t: t.to(torch.int32).to(device).contiguous()     # noqa: E731
+        pad = lambda t: t if t.numel() else torch.zeros(1, dtype=torch.long)   # noqa: E731
+        self.row_ptr, self.col, self.row_of = i32(row_ptr), i32(pad(cols)), i32(pad(rows))
+        self.t_ptr, self.t_row, self.t_k = i32(t_ptr), i32(pad(rows[order])), i32(pad(order))
+
+
+class SparseMap(torch.autograd.Function):
+    """y[b,c,i] = sum_k val[c,k] x[b,col_k]  (gene encode go_model.py:208-215 / decode :281-282)."""
+
+    @staticmethod
+    def forward(ctx, x, val, csr):
+        x, val = _f32(x), _f32(val)
+        b, c = x.shape[0], val.shape[0]
+        y = torch.empty(b, c, csr.n_rows, dtype=torch.float32, device=x.device)
+        call("igcn_spmm_fwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col), ptr(val),
+             ptr(x), ptr(y), stream_ptr())
+        ctx.save_for_backward(x, val)
+        ctx.csr = csr
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, val = ctx.saved_tensors
+        csr = ctx.csr
+        dy = _f32(dy)
+        b, c = x.shape[0], val.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dval = torch.empty_like(val) if ctx.needs_input_grad[1] else None
+        call("igcn_spmm_bwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
+             ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(x), ptr(dy), ptr(dx),
+             ptr(dval), stream_ptr())
+        return dx, dval, None
+
+
+class GoAttention(torch.autograd.Function):
+    """One GO encoder layer for all samples (go_model.py:226-244).  x [B,fin,N] -> y [B,fout,N]."""
+
+    @staticmethod
+    def forward(ctx, x, w_inc, w_s, a_in, a_s, csr):
+        x, w_inc, w_s, a_in, a_s = _f32(x), _f32(w_inc), _f32(w_s), _f32(a_in), _f32(a_s)
+        b, fin, n = x.shape
+        fout = w_inc.shape[0]
+        y = torch.empty(b, fout, n, dtype=torch.float32, device=x.device)
+        call("igcn_go_attn_fwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(x), ptr(w_inc), ptr(w_s),
+             ptr(a_in), ptr(a_s), ptr(y), stream_ptr())
+        ctx.save_for_backward(x, w_inc, w_s, a_in, a_s)
+        ctx.csr = csr
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_inc, w_s, a_in, a_s = ctx.saved_tensors
+        csr = ctx.csr
+        dy = _f32(dy)
+        b, fin, n = x.shape
+        fout = w_inc.shape[0]
+        lib = _lib.load()
+        dx = torch.empty_like(x)
+        dpar = torch.empty(2 * fout * fin + 3 * fout, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(int(lib.igcn_go_attn_bwd_scratch_floats(b, n, fin, fout)), dtype=torch.float32,
+                              device=x.device)
+        call("igcn_go_attn_bwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(csr.t_ptr), ptr(csr.t_row),
+             ptr(x), ptr(w_inc), ptr(w_s), ptr(a_in), ptr(a_s), ptr(dy), ptr(dx), ptr(dpar), ptr(scratch),
+             stream_ptr())
+        k = fout * fin
+        return (dx, dpar[:k].view(fout, fin), dpar[k:2 * k].view(fout, fin),
+                dpar[2 * k:2 * k + 2 * fout].view_as(a_in), dpar[2 * k + 2 * fout:].view_as(a_s), None)
+
+
+class NodesLayerNorm(torch.autograd.Function):
+    """LayerNorm over nodes + ReLU + node dropout + level pooling (go_model.py:246-251, :273-275)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, keep, pool, eps):
+        y, gamma, beta = _f32(y), _f32(gamma), _f32(beta)
+        keep = _f32(keep) if keep is not None else None
+        b, f, n = y.shape
+        z = torch.empty(b, f, n - pool, dtype=torch.float32, device=y.device)
+        mean = torch.empty(b * f, dtype=torch.float32, device=y.device)
+        rstd = torch.empty_like(mean)
+        call("igcn_nodes_ln_fwd", b, f, n, pool, float(eps), ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(z),
+             ptr(mean), ptr(rstd), stream_ptr())
+        ctx.save_for_backward(y, gamma, beta, keep, mean, rstd)
+        ctx.pool = pool
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, gamma, beta, keep, mean, rstd = ctx.saved_tensors
+        dz = _f32(dz)
+        b, f, n = y.shape
+        dy, dg, db = torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta)
+        call("igcn_nodes_ln_bwd", b, f, n, ctx.pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean),
+             ptr(rstd), ptr(dz), ptr(dy), ptr(dg), ptr(db), stream_ptr())
+        return dy, dg, db, None, None, None
+
+
+class GoDecode(torch.autograd.Function):
+    """One GO decoder layer (go_model.py:262-272).  x [B,fin,Nin] -> y [B,fout,Nout]."""
+
+    @staticmethod
+    def forward(ctx, x, w_out, w_sout, csr):
+        x, w_out, w_sout = _f32(x), _f32(w_out), _f32(w_sout)
+        b, fin, nin = x.shape
+        fout, nout = w_out.shape[0], csr.n_rows
+        assert csr.n_cols == nin
+        y = torch.empty(b, fout, nout, dtype=torch.float32, device=x.device)
+        call("igcn_go_decode_fwd", b, nin, nout, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(x), ptr(w_out),
+             ptr(w_sout), ptr(y), stream_ptr())
+        ctx.save_for_backward(x, w_out, w_sout)
+        ctx.csr = csr
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_out, w_sout = ctx.saved_tensors
+        csr = ctx.csr
+        dy = _f32(dy)
+        b, fin, nin = x.shape
+        fout, nout = w_out.shape[0], csr.n_rows
+        lib = _lib.load()
+        dx = torch.empty_like(x)
+        dpar = torch.empty(2 * fout * fin, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(int(lib.igcn_go_decode_bwd_scratch_floats(b, nin, fin, fout)), dtype=torch.float32,
+                              device=x.device)
+        call("igcn_go_decode_bwd", b, nin, nout, fin, fout, ptr(csr.row_ptr), ptr(csr.t_ptr), ptr(csr.t_row),
+             ptr(x), ptr(w_out), ptr(w_sout), ptr(dy), ptr(dx), ptr(dpar), ptr(scratch), stream_ptr())
+        k = fout * fin
+        return dx, dpar[:k].view(fout, fin), dpar[k:].view(fout, fin), None

@@ -1,0 +1,224 @@
+"""Drop-in ``SGCN_GCN_IMGSNP`` on the HIP kernels.
+
+Mirrors the interface of the reference's kernel/sgcn_img_snp.py: constructor kwargs (:15-17),
+``forward(data, temperature, device, isExplain=False)`` and its 6-tuple (:207,307), ``cal_probability``
+(:133), ``loss_probability`` (:153), ``consist_loss`` (:183), ``OrthogonalConstraint`` (:198),
+``reset_parameters`` (:104), the attributes read by util/output.py:21-23 (``prob``, ``snps_prob``,
+``prob_bias``) and an identical ``state_dict()`` key set (PyG-2.0.2 GCNConv keys ``<conv>.lin.weight``,
+``<conv>.bias``).
+
+What changes underneath: one ``GraphPlan`` per batch shared by both passes and the mask loss; gcn_norm
+once per pass instead of once per layer; scatter-aggregate / masks / dense transforms are libigcn kernels;
+the two ``x.min().item()`` host syncs of :225,293 are gone (every graph has exactly ``rois`` nodes, so
+to_dense_batch is a view); OrthogonalConstraint uses the Gram identity (B x B instead of (R*D)^2).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch.nn import Linear, Parameter, init
+
+from . import ops
+from .go_model import Gene_ontology_network
+
+
+class GCNConv(torch.nn.Module):
+    """GCNConv(in, out) with PyG 2.0.2's parameter names; forward = MFMA transform + scatter-aggregate."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = Linear(in_channels, out_channels, bias=False)
+        self.bias = Parameter(torch.zeros(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        a = math.sqrt(6.0 / (self.in_channels + self.out_channels))        # PyG glorot
+        with torch.no_grad():
+            self.lin.weight.uniform_(-a, a)
+            self.bias.zero_()
+
+    def forward(self, x, plan, coef, relu=False):
+        what, wloop = coef
+        h = ops.linear(x, self.lin.weight)
+        return ops.GcnPropagate.apply(h, what, wloop, self.bias, plan, relu)
+
+
+def rbf_kernel_torch(X, Y, gamma=0.015):
+    """util/image_cluster.py:15-31."""
+    return torch.exp(-gamma * torch.cdist(X, Y, p=2) ** 2)
+
+
+class SGCN_GCN_IMGSNP(torch.nn.Module):
+    def __init__(self, num_layers, hidden, A_g, A, pool_dim, l_dim, device, *args, hidden_linear=64, rois=90,
+                 H_0=3, num_classes=2, isCrossAtten=False, isSoftSimilarity=False, rbf_gamma=0.005,
+                 graph_pool=False, isuseProb4Regr=False, num_regr=4, model4eachregr=False, isImageOnly=True,
+                 isSNPsOnly=False, isMultiFusion=False, **kwargs):
+        super().__init__()
+        if graph_pool:
+            raise NotImplementedError("graph_pool=True is a dead branch in the reference trainer "
+                                      "(train_eval_sgcn_img_snps.py:101-106) and is not built")
+        if model4eachregr:
+            raise NotImplementedError("model4eachregr=True is not built")
+        self.device = device
+        self.isCrossAtten, self.isSoftSimilarity, self.rbf_gamma = isCrossAtten, isSoftSimilarity, rbf_gamma
+        self.model4eachregr, self.isuseProb4Regr = model4eachregr, isuseProb4Regr
+        self.isImageOnly, self.isSNPsOnly, self.isMultiFusion = isImageOnly, isSNPsOnly, isMultiFusion
+        self.num_regr, self.rois, self.prob_dim, self.graph_pool = num_regr, rois, H_0, graph_pool
+        self.input = None
+        self.conv1 = GCNConv(H_0, hidden)
+        self.convs = torch.nn.ModuleList()
+        n_l = 2
+        dim_att = hidden
+        n_more = (num_layers - 1) if isCrossAtten else (num_layers - 1)
+        for _ in range(n_more):
+            self.convs.append(GCNConv(hidden, hidden))
+        if isCrossAtten:
+            dim_att = hidden * num_layers
+            self.pool = pool_dim[0]
+            self.multihead_attn = torch.nn.MultiheadAttention(dim_att, 2, batch_first=True)
+        d_img = rois * num_layers * hidden
+        if isImageOnly:
+            self.lin1 = Linear(d_img, hidden_linear)
+            d_reg = d_img + (rois * H_0 if isuseProb4Regr else 0)
+        elif isSNPsOnly:
+            self.lin1 = Linear(l_dim + 54, hidden_linear)
+            d_reg = l_dim + 54
+        else:
+            self.lin1 = Linear(d_img + l_dim, hidden_linear)
+            d_reg = d_img + l_dim + (rois * H_0 if isuseProb4Regr else 0)
+        self.lin1_regr = Linear(d_reg, hidden_linear)
+        self.lin2 = Linear(hidden_linear, num_classes)
+        self.lin2_regr = Linear(hidden_linear, num_regr)
+        self.batch_norm_1d = torch.nn.BatchNorm1d(d_img + l_dim)          # unused by forward (as in the reference)
+        self.prob = Parameter(torch.empty(rois, H_0))
+        self.prob_bias = Parameter(torch.empty(H_0 * 2, 1))
+        self.edge_prob = Parameter(torch.empty(rois, rois))               # unused by forward
+        self.snps_prob = Parameter(torch.empty(1, 54))
+        for p in (self.prob_bias, self.prob, self.edge_prob, self.snps_prob):
+            init.kaiming_uniform_(p, a=math.sqrt(5))
+        self.go_network = Gene_ontology_network(A_g, A, 2, n_l, [5, 5], pool_dim, l_dim, device,
+                                                dim_snps_atten=dim_att)
+        self.batch_norm = torch.nn.BatchNorm1d(num_layers * hidden)       # unused by forward
+        self._dropout_enabled = True
+
+    def reset_parameters(self):
+        self.conv1.reset_parameters()
+        for conv in self.convs:
+            conv.reset_parameters()
+        for m in (self.lin1, self.lin2, self.lin1_regr, self.lin2_regr):
+            m.reset_parameters()
+        with torch.no_grad():
+            for p in (self.prob_bias, self.prob, self.edge_prob, self.snps_prob):
+                init.kaiming_uniform_(p, a=math.sqrt(5))
+
+    # ---- masks / regularisers --------------------------------------------------------------------
+    def _plan(self, data_or_ei, n_nodes=None):
+        if torch.is_tensor(data_or_ei):
+            return ops.GraphPlan(data_or_ei, n_nodes)
+        return ops.plan_for(data_or_ei)
+
+    def cal_probability(self, x, edge_index, edge_weight, snps_feat=None, plan=None):
+        plan = plan if plan is not None else ops.GraphPlan(edge_index, x.shape[0])
+        xm, ewm, e = ops.EdgeMask.apply(x, self.prob, self.prob_bias, edge_weight, plan, self.rois)
+        if snps_feat is not None:
+            sp = torch.sigmoid(self.snps_prob)
+            return xm, ewm, self.prob, e, snps_feat * sp, sp
+        return xm, ewm, self.prob, e
+
+    @staticmethod
+    def _l1_entropy(p, eps):
+        n = p.numel()
+        l1 = p.norm(p=1) / n
+        ent = -torch.sum(p * torch.log(p + eps) + (1 - p) * torch.log((1 - p) + eps)) / n
+        return l1, ent
+
+    def loss_probability(self, x, edge_index, edge_weight, hp, eps=1e-6, plan=None, edge_prob=None):
+        """:153-181.  ``edge_prob`` lets the train step reuse the mask the explain pass already computed."""
+        if edge_prob is None:
+            _, _, _, edge_prob = self.cal_probability(x, edge_index, edge_weight, plan=plan)
+        f_l1, f_ent = self._l1_entropy(torch.sigmoid(self.prob), eps)
+        e_l1, e_ent = self._l1_entropy(edge_prob, eps)
+        s_l1, s_ent = self._l1_entropy(torch.sigmoid(self.snps_prob), eps)
+        loss_l1 = hp.lamda_x_l1 * f_l1 + hp.lamda_e_l1 * e_l1 + hp.lamda_x_l1 * s_l1
+        loss_ent = hp.lamda_x_ent * f_ent + hp.lamda_e_ent * e_ent + hp.lamda_x_ent * s_ent
+        return loss_l1 + loss_ent
+
+    def consist_loss(self, s, tsne_result=None):
+        """:183-196 — tr(s^T (D-W) s)/B^2 evaluated as (sum_i d_i |s_i|^2 - sum_ij W_ij s_i.s_j)/B^2."""
+        if len(s) == 0:
+            return 0
+        b = s.shape[0]
+        if self.isSoftSimilarity and tsne_result is not None:
+            w = rbf_kernel_torch(tsne_result, tsne_result, gamma=self.rbf_gamma)
+        else:
+            w = torch.ones(b, b, device=s.device, dtype=s.dtype)
+        gram = s @ s.t()
+        return ((w.sum(dim=1) * gram.diagonal()).sum() - (w * gram).sum()) / (b * b)
+
+    def OrthogonalConstraint(self, w):
+        """:198-205 via ||Wn^T Wn - I||_F^2 = ||Wn Wn^T||_F^2 - 2 tr(Wn Wn^T) + R*D, Wn rows unit norm."""
+        wn = w / w.norm(dim=1)[:, None]
+        gram = wn @ wn.t()
+        pen = (gram * gram).sum() - 2.0 * gram.diagonal().sum() + wn.shape[1]
+        return pen / (wn.shape[0] * wn.shape[0])
+
+    def _drop(self, x, p):
+        return F.dropout(x, p, True) if (self.training and self._dropout_enabled) else x
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def forward(self, data, temperature=None, device=None, isExplain=False):
+        x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
+        snps_feat = data.snps_feat
+        x.requires_grad = True                                        # :210 — populates data.x.grad
+        self.input = x
+        n = x.shape[0]
+        if n % self.rois:
+            raise ValueError(f"every graph must have exactly rois={self.rois} nodes (got {n} nodes)")
+        bsz = n // self.rois
+        plan = ops.plan_for(data)
+        self.last_edge_prob = None
+        if isExplain:
+            x_m, ew_m, _, e, snps_m, _ = self.cal_probability(x, edge_index, edge_weight, snps_feat, plan=plan)
+            self.last_edge_prob = e
+        else:
+            x_m, ew_m, snps_m = x, edge_weight, snps_feat
+        coef = ops.GcnNorm.apply(ew_m, plan)                          # once per pass (PyG: once per layer)
+        h = self.conv1(x_m, plan, coef, relu=True)
+        hs = [h]
+        for conv in self.convs:
+            h = conv(h, plan, coef, relu=True)
+            hs.append(h)
+        xcat = torch.cat(hs, dim=1)
+        batch_x = xcat.view(bsz, self.rois, -1)                       # to_dense_batch == view (:226)
+        img_out = batch_x.reshape(bsz, -1)
+
+        latent, x_hat, _, atten_out = self.go_network(snps_m, temperature, device)
+        if self.isCrossAtten:
+            attn, _ = self.multihead_attn(batch_x, atten_out, atten_out, need_weights=False)
+            out_cross = F.relu(attn).reshape(bsz, -1)
+        else:
+            out_cross = torch.cat((img_out, latent), -1)
+
+        if self.isImageOnly:
+            out_z = img_out
+            out_lin = out_z
+        elif self.isSNPsOnly:
+            out_z = latent
+            out_lin = torch.cat((snps_m, latent), -1)
+        else:
+            out_z = (img_out + out_cross) / 2
+            out_lin = torch.cat((out_z, latent), -1)
+        linear_outf = ops.linear(out_lin, self.lin1.weight, self.lin1.bias, relu=True)
+        logits = ops.linear(self._drop(linear_outf, 0.5), self.lin2.weight, self.lin2.bias)
+        if self.isuseProb4Regr and not self.isSNPsOnly:
+            img_feat = (data.x.view(bsz, self.rois, -1) * self.prob).reshape(bsz, -1)      # :293-297
+            feat = torch.cat((out_lin, img_feat), -1)
+        else:
+            feat = out_lin
+        reg = ops.linear(feat, self.lin1_regr.weight, self.lin1_regr.bias, relu=True)
+        our_reg = ops.linear(self._drop(reg, 0.3), self.lin2_regr.weight, self.lin2_regr.bias)
+        return F.log_softmax(logits, dim=-1), x_hat, out_z, out_lin, linear_outf, our_reg
+
+    def __repr__(self):
+        return self.__class__.__name__

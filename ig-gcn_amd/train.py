@@ -1,0 +1,120 @@
+"""One optimisation step of the IG-GCN hot path — mirror of ``train()`` in the reference's
+kernel/train_eval_sgcn_img_snps.py:511-548 (two forwards, seven loss terms, backward, Adam), plus the
+graph-batch data parallelism the reference does not have (one process per GPU, one RCCL all-reduce of a
+flat fp32 gradient buffer per step).
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
+# sgcn_hyperparameters.py:18-23
+HP = SimpleNamespace(lamda_x_l1=0.1, lamda_e_l1=0.1, lamda_x_ent=0.1, lamda_e_ent=0.1, lamda_mi=1, lamda_ce=1)
+# main.py:73-78,204 : [disease, regr, prob, reco, simi, orth]
+DEFAULT_LAMBDA = (0.0, 1.0, 0.5, 1.5e-6, 0.1, 0.0)
+
+
+class FlatAdam:
+    """Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) over ONE flat fp32 buffer (igcn_adam_step).
+
+    Parameters and their ``.grad`` become views into two contiguous buffers, so the data-parallel
+    gradient exchange is a single all-reduce and the update a single kernel.  Parameters that never
+    receive a gradient keep a zero gradient, for which the Adam update is exactly zero (torch's Adam
+    skips them: same result).
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no parameters")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + k].view_as(p)
+                p.grad = self.grad[off:off + k].view_as(p)
+                off += k
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def step(self, grad_scale=1.0):
+        call("igcn_adam_step", self.flat.numel(), ptr(self.flat), ptr(self.grad), ptr(self.exp_avg),
+             ptr(self.exp_avg_sq), ptr(self.step_count), float(self.lr), float(self.betas[0]),
+             float(self.betas[1]), float(self.eps), float(grad_scale), stream_ptr())
+
+
+def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None):
+    """train() :521-543.  Returns (loss, terms dict, (outs_plain, outs_explain))."""
+    lam = lambda_loss
+    dev = data.x.device
+    o1 = model(data, temperature, dev)
+    o2 = model(data, temperature, dev, isExplain=True)
+    out, snps_hat, out_feat, _, _, reg = o1
+    out_p, snps_hat_p, out_feat_p, _, _, reg_p = o2
+    y = data.y.view(-1)
+    clin = data.clini_score.view(-1)
+    t = {}
+    t["ce"] = lam[0] * F.nll_loss(out, y)
+    t["mi"] = lam[0] * F.nll_loss(out_p, y)
+    t["reg"] = lam[1] * (F.mse_loss(reg.view(-1), clin) + F.mse_loss(reg_p.view(-1), clin)) / 2
+    # the mask loss re-evaluates cal_probability on the same inputs in the reference (:528); the explain
+    # pass has just produced that very edge mask, so it is reused (same value, gradients add up)
+    t["prob"] = lam[2] * model.loss_probability(data.x, data.edge_index, data.edge_attr, hp,
+                                                edge_prob=model.last_edge_prob)
+    t["recon"] = lam[3] * (torch.sum((snps_hat - data.snps_feat) ** 2)
+                           + torch.sum((snps_hat_p - data.snps_feat) ** 2)) / 2
+    if model.isSoftSimilarity:
+        t["cluster"] = lam[4] * (model.consist_loss(out_feat, data.tsne_fdim)
+                                 + model.consist_loss(out_feat_p, data.tsne_fdim)) / 2
+    else:
+        t["cluster"] = 0.0
+        for c in range(2):
+            sel = data.clust_y.view(-1) == c
+            t["cluster"] = t["cluster"] + lam[4] * (model.consist_loss(out_feat[sel])
+                                                    + model.consist_loss(out_feat_p[sel])) / 2
+    t["orth"] = lam[5] * model.OrthogonalConstraint(out_feat)
+    if lam[0] == 0:
+        t["ce"], t["mi"] = 0.0, 0.0
+    loss = hp.lamda_ce * t["ce"] + hp.lamda_mi * t["mi"] + t["reg"] + t["prob"] + t["recon"] + t["cluster"] \
+        + t["orth"]
+    return loss, t, (o1, o2)
+
+
+def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None, world_size=1):
+    """One iteration of the loop body of train() :515-547.  Returns the (device) loss tensor.
+
+    With ``world_size > 1`` (torch.distributed initialised, backend nccl == RCCL) every rank has run
+    the step on its own shard of the graph batch; gradients are summed with ONE all-reduce over the flat
+    buffer and averaged inside the Adam kernel (grad_scale = 1/W).
+    """
+    optimizer.zero_grad()
+    if data.x.grad is not None:
+        data.x.grad = None
+    loss, _, _ = losses(model, data, lambda_loss, hp, temperature)
+    loss.backward()
+    if world_size > 1:
+        torch.distributed.all_reduce(optimizer.grad)
+    optimizer.step(grad_scale=1.0 / world_size)
+    return loss.detach()
+
+
+def shard_batch(graphs, rank, world_size):
+    """Contiguous graph-range shard of a list of graphs for rank r."""
+    n = len(graphs)
+    per = n // world_size
+    if per * world_size != n:
+        raise ValueError(f"{n} graphs do not split evenly over {world_size} ranks")
+    return graphs[rank * per:(rank + 1) * per]

@@ -1,0 +1,203 @@
+/* igcn.h — C ABI of libigcn.so: hand-written gfx950 (CDNA4) kernels for IG-GCN's hot path.
+ *
+ * The reference (Houliang-Zhou/IG-GCN) is pure Python with no FFI: the path is entered through
+ * kernel/sgcn_img_snp.py (SGCN_GCN_IMGSNP) and kernel/go_model.py (Gene_ontology_network), whose sparse
+ * arithmetic lives in PyG 2.0.2 / torch-scatter 2.0.9 / torch.sparse.  Each entry point below names the
+ * reference operator call site(s) it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *  - every pointer is a CALLER-OWNED DEVICE pointer (contiguous, from tensor.data_ptr()); the library
+ *    never allocates, frees, copies to host or synchronises; all work is enqueued on `stream`
+ *    (a hipStream_t passed as void*), so every call may be captured into a hipGraph.
+ *  - float = fp32.  edge_index stays int64 at the boundary (PyG surface, sgcn_data.py:268-269); the plan
+ *    holds int32 copies/permutations for the kernels.
+ *  - return 0 on success, a negative IGCN_ERR_* otherwise; igcn_last_error() gives a thread-local text.
+ *  - "CSR" = (ptr[n_rows+1], idx[nnz]) int32.  GO activations are CHANNEL-MAJOR: [B, f, N] (node index
+ *    fastest) so that every access with consecutive nodes on consecutive lanes is coalesced.
+ */
+#ifndef IGCN_H
+#define IGCN_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGCN_OK 0
+#define IGCN_ERR_BADARG (-1)
+#define IGCN_ERR_LAUNCH (-2)
+#define IGCN_ERR_UNSUPPORTED (-3)
+
+int igcn_version(void);
+const char* igcn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph plan: replaces the index work PyG's gcn_norm/propagate redo in every GCNConv call
+ * (mask src!=dst, cat, arange, scatter index math; call sites kernel/sgcn_img_snp.py:218,221).
+ * Built once per batch and shared by both forward passes, loss_probability and the backward.
+ *   src32/dst32 [E]   int32 copies of edge_index rows
+ *   tgt_ptr [N+1], tgt_perm [E] : edges grouped by TARGET node, original edge order kept inside a
+ *                                 group (stable) => per-target sums run in the reference's scatter order
+ *   src_ptr [N+1], src_perm [E] : same, grouped by SOURCE node (transposed structure for the backward)
+ *   loop_edge [N]               : id of the LAST stored self-loop of node i, or -1
+ * workspace: igcn_graph_plan_workspace_bytes(n_nodes, n_edges) bytes.
+ */
+size_t igcn_graph_plan_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int igcn_graph_plan_build(int64_t n_nodes, int64_t n_edges, const int64_t* edge_index /*[2,E]*/,
+                          int32_t* src32, int32_t* dst32, int32_t* tgt_ptr, int32_t* tgt_perm,
+                          int32_t* src_ptr, int32_t* src_perm, int32_t* loop_edge,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Learned regional / connective importance masks — cal_probability, kernel/sgcn_img_snp.py:133-151.
+ *   xm[i,:]  = x[i,:] * prob[i % rois,:]
+ *   e[k]     = sigmoid( [xm[src_k] || xm[dst_k]] . prob_bias )          ewm[k] = ew[k] * e[k]
+ */
+int igcn_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0,
+                       const float* x, const float* prob, const float* prob_bias, const float* ew,
+                       const int32_t* src32, const int32_t* dst32,
+                       float* xm, float* e, float* ewm, void* stream);
+/* d_xm [N,h0] may be NULL (=0); d_ewm, d_e [E] may be NULL.  Outputs: dx [N,h0], dprob [rois,h0],
+ * dprob_bias [2*h0].  scratch: float[ N*h0 + 16*ceil(N/256) ]. */
+int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, int h0,
+                       const float* x, const float* prob, const float* prob_bias, const float* ew,
+                       const float* e, const float* d_xm, const float* d_ewm, const float* d_e,
+                       const int32_t* tgt_ptr, const int32_t* tgt_perm,
+                       const int32_t* src_ptr, const int32_t* src_perm,
+                       float* dx, float* dprob, float* dprob_bias, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GCN normalisation — PyG gcn_norm inside GCNConv (kernel/sgcn_img_snp.py:218,221):
+ * stored self-loops are replaced by one loop per node (weight wl = last stored loop weight, else 1),
+ *   deg[i] = sum_{k: dst=i, src!=dst} ew[k] + wl[i] ;  dis = deg^-1/2 (inf -> 0)
+ *   what[k] = dis[src]*ew[k]*dis[dst]  (0 at stored loops) ;  what_loop[i] = dis[i]*wl[i]*dis[i]
+ * Computed ONCE per forward pass (the reference recomputes it in every layer); the L layers and the
+ * backward all read the same coefficient arrays.
+ */
+int igcn_gcn_norm_fwd(int64_t n_nodes, int64_t n_edges, const float* ew,
+                      const int32_t* src32, const int32_t* dst32, const int32_t* tgt_ptr, const int32_t* tgt_perm,
+                      const int32_t* loop_edge, float* dis, float* wl, float* what, float* what_loop, void* stream);
+/* dwhat [E] (entries of stored loops ignored) and dwhat_loop [N] are d(loss)/d(coefficient) summed over all
+ * layers.  Output dew [E].  scratch: float[N]. */
+int igcn_gcn_norm_bwd(int64_t n_nodes, int64_t n_edges, const float* ew, const float* dis, const float* wl,
+                      const float* dwhat, const float* dwhat_loop,
+                      const int32_t* src32, const int32_t* dst32,
+                      const int32_t* tgt_ptr, const int32_t* tgt_perm,
+                      const int32_t* src_ptr, const int32_t* src_perm, const int32_t* loop_edge,
+                      float* dew, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GCN scatter-aggregate (the north-star kernel) — GCNConv.propagate + bias (+ the F.relu of
+ * kernel/sgcn_img_snp.py:218,221):
+ *   out[t, :F] = act( sum_{k: dst=t, src!=dst} what[k] * h[src_k,:] + what_loop[t]*h[t,:] + bias )
+ * summed in the reference's scatter order (non-loop edges in stored order, then the loop).
+ * h [N,F] row stride ld_h; out row stride ld_out (so a layer can write its column slice of the JK-concat
+ * buffer of :223 directly).  relu != 0 applies max(.,0).
+ */
+int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, const float* h, int64_t ld_h,
+                           const float* what, const float* what_loop, const float* bias,
+                           const int32_t* src32, const int32_t* tgt_ptr, const int32_t* tgt_perm,
+                           float* out, int64_t ld_out, int relu, void* stream);
+/* Backward of the above.  g = dout * (out>0 if relu).  Outputs:
+ *   dh [N,F] (row stride ld_dh)  = A_hat^T g          dbias [F] (may be NULL)
+ *   dwhat [E] = g[dst_k].h[src_k] (0 at stored loops), dwhat_loop [N] = g[i].h[i]   (only when need_dw != 0)
+ * scratch: igcn_gcn_propagate_bwd_scratch_floats(n_nodes, F) floats (block partials of dbias). */
+size_t igcn_gcn_propagate_bwd_scratch_floats(int64_t n_nodes, int F);
+int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F,
+                           const float* dout, int64_t ld_dout, const float* out, int64_t ld_out, int relu,
+                           const float* h, int64_t ld_h, const float* what, const float* what_loop,
+                           const int32_t* src32, const int32_t* dst32,
+                           const int32_t* src_ptr, const int32_t* src_perm,
+                           float* dh, int64_t ld_dh, float* dbias,
+                           int need_dw, float* dwhat, float* dwhat_loop,
+                           float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense feature transform on the matrix cores (f32-input MFMA 16x16x4, exact fp32):
+ *   out[M,N] = act( A[M,K] . W[N,K]^T + bias )      — GCNConv.lin (kernel/sgcn_img_snp.py:34-49),
+ *   lin1 / lin1_regr / lin2 / lin2_regr (:62-84,289-301).  General strided form so the same kernel
+ *   serves forward (NT), input-gradient (NN) and weight-gradient (TN, split over the long M axis):
+ *   C[m,n] = sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk]  (+ bias[n]) ; C row stride ldc.
+ * split_k > 1 writes split_k partial slabs into `scratch` (float[split_k*M*N]) and reduces them in order
+ * (deterministic).  act: 0 none, 1 relu.
+ */
+int igcn_gemm_f32(int64_t M, int64_t N, int64_t K,
+                  const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
+                  const float* bias, float* C, int64_t ldc, int act, int split_k, float* scratch,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sparse SNP<->GO maps with learnable non-zeros — gene encoding go_model.py:208-215 (C=2 channels,
+ * rows = GO nodes, cols = SNPs) and gene decoding :281-282 (C=1, rows = SNPs, cols = GO nodes):
+ *   y[b,c,i] = sum_{k in row i} val[c,k] * x[b, col[k]]          x [B,J], y [B,C,I], val [C,nnz]
+ * Backward needs the transposed structure: t_ptr [J+1], t_row [nnz] (row of each entry in column order),
+ * t_k [nnz] (its position in the row-major value array).
+ */
+int igcn_spmm_fwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
+                  const float* val, const float* x, float* y, void* stream);
+int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
+                  const int32_t* row_of /*[nnz]*/, const int32_t* t_ptr, const int32_t* t_row, const int32_t* t_k,
+                  const float* val, const float* x, const float* dy,
+                  float* dx /*[B,J] or NULL*/, float* dval /*[C,nnz]*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GO attention-GCN encoder layer, all samples at once — replaces the dense transforms, the edge gathers
+ * and the PER-SAMPLE python loop of go_model.py:226-244 (helper :182-186, attention_adj :173-180, gcn :170):
+ *   x_in = W_inc x, x_s = W_s x                              (per node, fin -> fout)
+ *   s_e  = exp(tanh(a_in[:fout].x_in[row_e] + a_in[fout:].x_in[col_e]))
+ *   y[b,:,r] = sum_{e in row r} (s_e / sum_{e' in row r} s_e') x_in[col_e] + x_s[r] * sigmoid(a_s.x_s[r])
+ * x [B,fin,N] and y [B,fout,N] channel-major.  Supported (fin,fout): (2,5) (5,5).
+ */
+int igcn_go_attn_fwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
+                     const float* x, const float* w_inc, const float* w_s, const float* a_in, const float* a_s,
+                     float* y, void* stream);
+/* Backward in O(nnz*f) (the reference's autograd forms a dense N x N product per sample and layer).
+ * t_ptr/t_row: the transposed structure (for each column the rows that read it).
+ * Outputs: dx [B,fin,N]; dparams float[ 2*fout*fin + 2*fout + fout ] = (dW_inc, dW_s, da_in, da_s).
+ * scratch floats: igcn_go_attn_bwd_scratch_floats(B,N,fin,fout). */
+size_t igcn_go_attn_bwd_scratch_floats(int B, int N, int fin, int fout);
+int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
+                     const int32_t* t_ptr, const int32_t* t_row,
+                     const float* x, const float* w_inc, const float* w_s, const float* a_in, const float* a_s,
+                     const float* dy, float* dx, float* dparams, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the NODE axis + ReLU + node dropout + hierarchical pooling — go_model.py:246-251
+ * (encoder) and :273-275 (decoder): for every (sample, channel) row of y [B,f,N]
+ *   z = relu( (y-mean)/sqrt(var+eps) * gamma[n] + beta[n] ) * keep[b,n]      (keep may be NULL)
+ * and only nodes n >= pool are written: z [B,f,N-pool].  Saves mean, rstd [B*f].
+ */
+int igcn_nodes_ln_fwd(int B, int f, int N, int pool, float eps, const float* y, const float* gamma,
+                      const float* beta, const float* keep, float* z, float* mean, float* rstd, void* stream);
+/* Outputs dy [B,f,N], dgamma [N], dbeta [N]. */
+int igcn_nodes_ln_bwd(int B, int f, int N, int pool, const float* y, const float* gamma, const float* beta,
+                      const float* keep, const float* mean, const float* rstd, const float* dz,
+                      float* dy, float* dgamma, float* dbeta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GO decoder layer (mean aggregation down the hierarchy) — go_model.py:262-272, batch_mul :197-201:
+ *   y[b,:,r] = (1/deg_r) sum_{e in row r} W_out x[b,:,col_e]  +  (r >= off ? W_sout x[b,:,r-off] : 0)
+ * x [B,fin,Nin], y [B,fout,Nout], off = Nout-Nin.  Supported (fin,fout): (5,5) (5,2).
+ */
+int igcn_go_decode_fwd(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
+                       const float* x, const float* w_out, const float* w_sout, float* y, void* stream);
+/* Outputs dx [B,fin,Nin], dparams float[2*fout*fin] = (dW_out, dW_sout). */
+size_t igcn_go_decode_bwd_scratch_floats(int B, int Nin, int fin, int fout);
+int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr,
+                       const int32_t* t_ptr, const int32_t* t_row,
+                       const float* x, const float* w_out, const float* w_sout, const float* dy,
+                       float* dx, float* dparams, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Adam step over a flat fp32 parameter buffer — torch.optim.Adam(lr, weight_decay=0) at
+ * kernel/train_eval_sgcn_img_snps.py:108,547.  `step` is a device int32 that the kernel's caller
+ * increments (igcn_adam_step does it: one extra 1-thread kernel) so the call is graph-capturable.
+ */
+int igcn_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   int32_t* step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGCN_H */

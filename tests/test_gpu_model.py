@@ -1,0 +1,199 @@
+"""GPU parity of the drop-in model classes: the HIP-backed SGCN_GCN_IMGSNP / Gene_ontology_network against
+(a) the golden vectors captured from the reference itself and (b) the CPU oracle on larger seeded inputs.
+Everything goes through libigcn.so (the C ABI); tolerance is scale-relative 1e-4 in eval mode.  Training
+mode normalises with BatchNorm over 3-8 samples, which amplifies fp32 rounding (the fp64 oracle is just as
+far from the reference's own fp32 numbers, see test_oracle_golden.py), hence the looser bound there.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_matches, golden_group
+from _weights import seeded_state
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"eval": 1e-4, "train": 1e-3}
+GTOL = {"eval": 1e-3, "train": 3e-2}
+NAMES = ["logp", "x_hat", "out_z", "out_lin", "lin_f", "reg"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from igcn_amd import _lib
+    _lib.load()
+
+
+def _probe(outs, seed):
+    rng = np.random.default_rng(seed)
+    return [torch.from_numpy(rng.standard_normal(tuple(o.shape))).float() for o in outs]
+
+
+def _go_model(store):
+    from igcn_amd import synth
+    from igcn_amd.go_model import Gene_ontology_network
+    a_g, a = synth.go_sparse_inputs(store["go_snps"], store["adj"], "cuda")
+    net = Gene_ontology_network(a_g, a, 2, 2, [5, 5], [store["pool"].tolist()], int(store["l_dim"]), "cuda",
+                                dim_snps_atten=int(store["d_att"])).cuda()
+    sd = seeded_state({k: v.shape for k, v in net.state_dict().items()}, int(store["seed"]), net.state_dict())
+    net.load_state_dict(sd)
+    net._dropout_enabled = False
+    return net
+
+
+@pytest.mark.parametrize("name", ["go_tiny", "go_small"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_go_network_vs_reference_golden(golden, name, mode):
+    store = golden(name)
+    net = _go_model(store)
+    net.train(mode == "train")
+    snps = torch.from_numpy(store["snps"]).cuda().requires_grad_(True)
+    latent, x_d, _, att = net(snps, None, "cuda")
+    want = golden_group(store, f"{mode}/out")
+    assert_matches(latent, want["latent"], TOL[mode], "latent")
+    assert_matches(x_d, want["x_D"], TOL[mode], "x_D")
+    assert_matches(att, want["atten_out"], TOL[mode], "atten_out")
+    cot = _probe([latent, x_d, att], int(store["seed"]) + 2)
+    sum((o * c.cuda()).sum() for o, c in zip([latent, x_d, att], cot)).backward()
+    wg = golden_group(store, f"{mode}/grad")
+    assert_matches(snps.grad, wg.pop("snps"), GTOL[mode], "grad snps")
+    params = dict(net.named_parameters())
+    for k, w in wg.items():
+        assert params[k].grad is not None, k
+        assert_matches(params[k].grad, w, GTOL[mode], "grad " + k, floor=1e-4)
+    if mode == "train":
+        bufs = net.state_dict()
+        for k, w in golden_group(store, "train/buffers_after").items():
+            assert_matches(bufs[k], w, TOL[mode], "buffer " + k, floor=1e-2)
+
+
+def _full_model(store):
+    from igcn_amd import synth
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    rois, hidden, layers, bsz, seed, top_k = [int(v) for v in store["cfg"]]
+    pool = store["pool"].tolist()
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=seed)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+    model = SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=3, num_classes=3,
+                            isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
+                            isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False).cuda()
+    ref_keys = sorted(store["state_keys"].tolist())
+    assert sorted(model.state_dict().keys()) == ref_keys          # checkpoints interchange with the reference
+    sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, seed, model.state_dict())
+    model.load_state_dict(sd)
+    model._dropout_enabled = False
+    model.go_network._dropout_enabled = False
+    graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=rois, top_k=top_k, tsne_dim=16)
+    return model, graphs, seed
+
+
+@pytest.mark.parametrize("name", ["full_tiny", "full_r90", "full_l3"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("explain", [False, True])
+def test_full_model_vs_reference_golden(golden, name, mode, explain):
+    from igcn_amd.data import Batch
+    store = golden(name)
+    model, graphs, seed = _full_model(store)
+    model.train(mode == "train")
+    data = Batch.from_data_list(graphs).to("cuda")
+    outs = model(data, None, "cuda", isExplain=explain)
+    tag = f"{mode}/explain{int(explain)}"
+    want = golden_group(store, tag + "/out")
+    for n, o in zip(NAMES, outs):
+        assert_matches(o, want[n], TOL[mode], n)
+    cot = _probe(outs, seed + 3)
+    sum((o * c.cuda()).sum() for o, c in zip(outs, cot)).backward()
+    wg = golden_group(store, tag + "/grad")
+    assert_matches(data.x.grad, wg.pop("data.x"), GTOL[mode], "grad data.x")
+    params = dict(model.named_parameters())
+    for k, w in wg.items():
+        assert params[k].grad is not None, k
+        assert_matches(params[k].grad, w, GTOL[mode], "grad " + k, floor=1e-4)
+
+
+@pytest.mark.parametrize("name", ["full_tiny", "full_r90", "full_l3"])
+def test_train_step_vs_reference_golden(golden, name):
+    from igcn_amd.data import Batch
+    from igcn_amd.train import FlatAdam, losses
+    store = golden(name)
+    model, graphs, seed = _full_model(store)
+    model.train(True)
+    data = Batch.from_data_list(graphs).to("cuda")
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    opt.zero_grad()
+    lam = store["lam"].tolist()
+    loss, terms, _ = losses(model, data, lam)
+    ref_loss = float(store["step/loss"])
+    assert abs(float(loss) - ref_loss) <= 2e-4 * max(1.0, abs(ref_loss))
+    for k, v in terms.items():
+        ref = float(store[f"step/term/{k}"])
+        assert abs(float(v) - ref) <= 2e-4 * max(1.0, abs(ref)), (k, float(v), ref)
+    loss.backward()
+    params = dict(model.named_parameters())
+    wg = golden_group(store, "step/grad")
+    assert_matches(data.x.grad, wg.pop("data.x"), 1e-2, "grad data.x")
+    grads = {}
+    for k, w in wg.items():
+        if isinstance(w, tuple) or np.any(w):
+            assert_matches(params[k].grad, w, 1e-2, "grad " + k, floor=1e-5)
+        else:
+            assert not bool(params[k].grad.abs().max() > 0), k       # untouched parameters stay at zero grad
+        grads[k] = w
+    opt.step()
+    lr = 1e-3
+    for k, w in golden_group(store, "step/param_after").items():
+        p = params[k].detach().cpu()
+        if isinstance(w, tuple) or k not in grads or isinstance(grads[k], tuple):
+            assert_matches(p, w, 2.5 * lr, "param " + k, floor=1.0)
+            continue
+        g = torch.from_numpy(grads[k])
+        diff = (p - torch.from_numpy(w)).abs()
+        solid = g.abs() > 5e-2 * g.abs().max() if g.abs().max() > 0 else torch.zeros_like(g, dtype=torch.bool)
+        assert float(diff[solid].max() if solid.any() else 0.0) <= 5e-5, "param " + k
+        assert float(diff.max()) <= 2.01 * lr, "param (noise-level grads) " + k
+
+
+@pytest.mark.parametrize("bsz,pool,explain", [(32, (300, 120, 60, 19, 1), False), (32, (300, 120, 60, 19, 1), True),
+                                              (16, (1800, 800, 300, 99, 1), True)])
+def test_full_model_vs_oracle_larger(bsz, pool, explain):
+    """R=90, L=2, h=16 (the benchmark model) against the CPU oracle, eval mode, 1e-4."""
+    from igcn_amd import synth
+    from igcn_amd.data import Batch
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    from oracle import go_network as OG, sgcn_img_snp as OS
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=1)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+    model = SGCN_GCN_IMGSNP(2, 16, a_g, a, pool_dim, 32, "cuda", rois=90, H_0=3, num_classes=3,
+                            isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
+                            isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False).cuda().eval()
+    sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, 5)
+    model.load_state_dict(sd)
+    graphs = synth.brain_graph_list(bsz, seed=77, rois=90, tsne_dim=16)
+    data = Batch.from_data_list(graphs).to("cuda")
+    outs = model(data, None, "cuda", isExplain=explain)
+    cot = _probe(outs, 9)
+    sum((o * c.cuda()).sum() for o, c in zip(outs, cot)).backward()
+    # oracle, fp64
+    a_g_c, a_c = synth.go_sparse_inputs(go_snps, adj)
+    idx = OG.go_index_sets(a_g_c, a_c, list(pool), 2)
+    sdo = OS.make_leaf_state(sd, dtype=torch.float64)
+    dcpu = Batch.from_data_list(graphs)
+    dcpu.x = dcpu.x.double().requires_grad_(True)
+    dcpu.edge_attr, dcpu.snps_feat = dcpu.edge_attr.double(), dcpu.snps_feat.double()
+    cfg = SimpleNamespace(num_layers=2, rois=90, image_only=False, rbf_gamma=0.01)
+    ref = OS.model_forward(sdo, cfg, idx, dcpu, explain, training=False)
+    sum((o * c.double()).sum() for o, c in zip(ref, cot)).backward()
+    for n, o, r in zip(NAMES, outs, ref):
+        assert_matches(o, r.detach().numpy(), 1e-4, n)
+    # gradients: a ReLU whose pre-activation is ~1e-7 may switch between the fp32 kernels and the fp64
+    # oracle, which moves a parameter gradient by one summand => slightly looser bound than the outputs
+    assert_matches(data.x.grad, dcpu.x.grad.numpy(), 3e-3, "grad data.x")
+    params = dict(model.named_parameters())
+    for k in OS.trainable_keys(sdo):
+        if sdo[k].grad is None:
+            continue
+        assert_matches(params[k].grad, sdo[k].grad.numpy(), 3e-3, "grad " + k, floor=1e-6)

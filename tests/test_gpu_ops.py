@@ -1,0 +1,292 @@
+"""GPU parity, op by op: every libigcn entry point (called through the C ABI via igcn_amd.ops) against the
+CPU oracle / a plain PyTorch fp64 restatement of the same operator on identical seeded inputs.
+Tolerance: scale-relative 1e-4 (north_star: 1e-4 fp32); index work (graph plan) is bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_matches
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from igcn_amd import _lib, ops as o
+    _lib.load()          # raises if libigcn.so is missing: no fallback
+    return o
+
+
+def _rand_graph(rng, n, e, loops=True, multi_loops=False, isolated=True):
+    src = rng.integers(0, n, e)
+    dst = rng.integers(0, n, e)
+    if not loops:
+        dst = np.where(dst == src, (dst + 1) % n, dst)
+    if isolated and n > 3:
+        src = np.where(src == n - 1, 0, src)
+        dst = np.where(dst == n - 1, 1, dst)
+    # at most one stored loop per node unless asked for (several stored loops on a node make the
+    # reference's index_put gradient undefined)
+    seen, keep = set(), np.ones(src.size, dtype=bool)
+    for k in range(src.size):
+        if src[k] == dst[k]:
+            if int(src[k]) in seen or (multi_loops and src[k] == 2):
+                keep[k] = False
+            seen.add(int(src[k]))
+    src, dst = src[keep], dst[keep]
+    if multi_loops:
+        src = np.concatenate([src, [2, 2, 2]])
+        dst = np.concatenate([dst, [2, 2, 2]])
+    ei = torch.from_numpy(np.vstack([src, dst])).long()
+    w = torch.from_numpy(rng.random(ei.shape[1]) + 0.05).float()
+    return ei, w
+
+
+# ------------------------------------------------------------------------------------------------ plan
+@pytest.mark.parametrize("n,e,seed", [(7, 0, 0), (90, 270, 1), (1, 5, 2), (1000, 20000, 3), (23040, 69120, 4),
+                                       (4096, 300000, 5)])
+def test_graph_plan_bit_exact(ops, n, e, seed):
+    rng = np.random.default_rng(seed)
+    ei = torch.from_numpy(rng.integers(0, n, (2, e))).long()
+    plan = ops.GraphPlan(ei.cuda(), n)
+    torch.cuda.synchronize()
+    src, dst = ei[0].numpy(), ei[1].numpy()
+    for key, ptr_t, perm_t in ((dst, plan.tgt_ptr, plan.tgt_perm), (src, plan.src_ptr, plan.src_perm)):
+        perm = np.argsort(key, kind="stable").astype(np.int32)
+        ptr_ref = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=n))]).astype(np.int32)
+        assert np.array_equal(ptr_t.cpu().numpy(), ptr_ref)
+        if e:
+            assert np.array_equal(perm_t.cpu().numpy()[:e], perm)
+    if e:
+        assert np.array_equal(plan.src32.cpu().numpy()[:e], src.astype(np.int32))
+        assert np.array_equal(plan.dst32.cpu().numpy()[:e], dst.astype(np.int32))
+        # int64 round trip of the permutation: gathering edge_index through it is exactly sorted edge_index
+        back = ei[:, plan.tgt_perm.cpu().long()[:e]]
+        assert torch.equal(back[1], torch.sort(ei[1], stable=True)[0])
+    loop = np.full(n, -1, dtype=np.int32)
+    for k in range(e):
+        if src[k] == dst[k]:
+            loop[src[k]] = k
+    assert np.array_equal(plan.loop_edge.cpu().numpy(), loop)
+
+
+# ------------------------------------------------------------------------------------------------ masks
+@pytest.mark.parametrize("bsz,rois,h0,seed", [(3, 10, 3, 0), (8, 90, 3, 1), (2, 17, 5, 2)])
+def test_edge_mask_fwd_bwd(ops, bsz, rois, h0, seed):
+    from oracle import sgcn_img_snp as OS
+    rng = np.random.default_rng(seed)
+    n = bsz * rois
+    ei, ew = _rand_graph(rng, n, 6 * n)
+    x = torch.from_numpy(rng.random((n, h0))).float()
+    sd = {"prob": torch.from_numpy(rng.standard_normal((rois, h0))).float(),
+          "prob_bias": torch.from_numpy(rng.standard_normal((2 * h0, 1))).float()}
+    cots = [torch.from_numpy(rng.standard_normal(s)).float() for s in ((n, h0), (ei.shape[1],), (ei.shape[1],))]
+    # oracle (fp64 autograd)
+    ref_in = [t.double().requires_grad_(True) for t in (x, sd["prob"], sd["prob_bias"])]
+    xm, ewm, e = OS.edge_and_region_masks({"prob": ref_in[1], "prob_bias": ref_in[2]}, ref_in[0], ei, ew.double(),
+                                          rois)
+    g_ref = torch.autograd.grad(sum((o * c.double()).sum() for o, c in zip((xm, ewm, e), cots)), ref_in)
+    # HIP
+    dev_in = [t.cuda().requires_grad_(True) for t in (x, sd["prob"], sd["prob_bias"])]
+    plan = ops.GraphPlan(ei.cuda(), n)
+    xm_g, ewm_g, e_g = ops.EdgeMask.apply(dev_in[0], dev_in[1], dev_in[2], ew.cuda(), plan, rois)
+    g = torch.autograd.grad(sum((o * c.cuda()).sum() for o, c in zip((xm_g, ewm_g, e_g), cots)), dev_in)
+    for got, want, nm in zip((xm_g, ewm_g, e_g), (xm, ewm, e), ("xm", "ewm", "e")):
+        assert_matches(got, want.detach().numpy(), TOL, nm)
+    for got, want, nm in zip(g, g_ref, ("dx", "dprob", "dprob_bias")):
+        assert_matches(got, want.numpy(), TOL, nm)
+
+
+# ------------------------------------------------------------------------------------------------ GCN layer
+@pytest.mark.parametrize("n,e,fin,fout,loops,multi,seed", [
+    (12, 40, 3, 16, True, True, 0), (90, 270, 3, 16, False, False, 1), (200, 3000, 16, 16, True, False, 2),
+    (64, 500, 5, 7, True, True, 3), (33, 0, 4, 4, False, False, 4), (512, 20000, 16, 32, True, False, 5)])
+def test_gcn_layer_fwd_bwd(ops, n, e, fin, fout, loops, multi, seed):
+    from oracle import pyg_ops
+    rng = np.random.default_rng(seed)
+    ei, ew = _rand_graph(rng, n, e, loops=loops, multi_loops=multi) if e else (
+        torch.zeros(2, 0, dtype=torch.long), torch.zeros(0))
+    x = torch.from_numpy(rng.standard_normal((n, fin))).float()
+    w = torch.from_numpy(rng.standard_normal((fout, fin)) / np.sqrt(fin)).float()
+    b = torch.from_numpy(rng.standard_normal(fout)).float()
+    cot = torch.from_numpy(rng.standard_normal((n, fout))).float()
+    ref_in = [t.double().requires_grad_(True) for t in (x, ew, w, b)]
+    out_ref = torch.relu(pyg_ops.gcn_conv(ref_in[0], ei, ref_in[1], ref_in[2], ref_in[3]))
+    g_ref = torch.autograd.grad((out_ref * cot.double()).sum(), ref_in, allow_unused=True)
+    dev_in = [t.cuda().requires_grad_(True) for t in (x, ew, w, b)]
+    plan = ops.GraphPlan(ei.cuda(), n)
+    coef = ops.GcnNorm.apply(dev_in[1], plan)
+    h = ops.linear(dev_in[0], dev_in[2])
+    out = ops.GcnPropagate.apply(h, coef[0], coef[1], dev_in[3], plan, True)
+    g = torch.autograd.grad((out * cot.cuda()).sum(), dev_in, allow_unused=True)
+    assert_matches(out, out_ref.detach().numpy(), TOL, "out")
+    for got, want, nm in zip(g, g_ref, ("dx", "dew", "dW", "db")):
+        if want is None or (nm == "dew" and (e == 0 or multi)):
+            continue      # several stored loops on one node: index_put's duplicate-index gradient is undefined
+        assert_matches(got, want.numpy(), TOL, nm, floor=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("m,n,k", [(23040, 16, 3), (23040, 16, 16), (256, 64, 2912), (256, 64, 3182), (256, 3, 64),
+                                   (5, 7, 9), (1000, 33, 130), (64, 64, 4096)])
+def test_gemm_nt_nn_tn(ops, m, n, k):
+    rng = np.random.default_rng(m + n + k)
+    a = torch.from_numpy(rng.standard_normal((m, k))).float()
+    b = torch.from_numpy(rng.standard_normal((n, k))).float()
+    bias = torch.from_numpy(rng.standard_normal(n)).float()
+    want = a.double() @ b.double().t() + bias.double()
+    assert_matches(ops.gemm_nt(a.cuda(), b.cuda(), bias.cuda(), 0), want.numpy(), TOL, "NT")
+    assert_matches(ops.gemm_nt(a.cuda(), b.cuda(), bias.cuda(), 1), torch.relu(want).numpy(), TOL, "NT+relu")
+    dy = torch.from_numpy(rng.standard_normal((m, n))).float()
+    assert_matches(ops.gemm_nn(dy.cuda(), b.cuda()), (dy.double() @ b.double()).numpy(), TOL, "NN")
+    assert_matches(ops.gemm_tn(dy.cuda(), a.cuda()), (dy.double().t() @ a.double()).numpy(), TOL, "TN")
+
+
+def test_gemm_is_exact_fp32_fma_chain(ops):
+    """MFMA f32 = k-ordered fmaf chain: small-integer operands must be reproduced exactly."""
+    rng = np.random.default_rng(0)
+    a = torch.from_numpy(rng.integers(-8, 9, (130, 70)).astype(np.float32))
+    b = torch.from_numpy(rng.integers(-8, 9, (45, 70)).astype(np.float32))   # asymmetric B catches a swapped C map
+    got = ops.gemm_nt(a.cuda(), b.cuda())
+    assert torch.equal(got.cpu(), a @ b.t())
+
+
+# ------------------------------------------------------------------------------------------------ GO ops
+def _hier(pool, seed):
+    from igcn_amd import synth
+    from oracle import go_network as OG
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=seed)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj)
+    return a_g, a, pool_dim, OG.go_index_sets(a_g, a, pool, 2)
+
+
+@pytest.mark.parametrize("bsz,pool,fin,seed", [(4, (20, 10, 6, 3, 1), 2, 0), (16, (300, 120, 60, 19, 1), 2, 1),
+                                               (5, (40, 20, 9, 2, 1), 5, 2)])
+def test_go_attention_layer(ops, bsz, pool, fin, seed):
+    _, _, _, idx = _hier(pool, seed)
+    layer = 0 if fin == 2 else 1
+    row, col, nj = idx["enc"][layer]
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal((bsz, nj, fin))).float()
+    par = [torch.from_numpy(rng.standard_normal(s) * 0.5).float() for s in ((5, fin), (5, fin), (1, 10), (1, 5))]
+    cot = torch.from_numpy(rng.standard_normal((bsz, nj, 5))).float()
+
+    def ref(xd, w_inc, w_s, a_in, a_s):
+        x_in, x_s = xd @ w_inc.t(), xd @ w_s.t()
+        v = torch.exp(torch.tanh(torch.cat([x_in[:, row], x_in[:, col]], 2) @ a_in.t())).squeeze(2)
+        z = torch.zeros(bsz, nj, dtype=xd.dtype).index_add(1, row, v)
+        alpha = v / z[:, row]
+        return torch.zeros(bsz, nj, 5, dtype=xd.dtype).index_add(1, row, alpha.unsqueeze(2) * x_in[:, col]) \
+            + x_s * torch.sigmoid(x_s @ a_s.t())
+
+    ref_in = [t.double().requires_grad_(True) for t in [x] + par]
+    y_ref = ref(*ref_in)
+    g_ref = torch.autograd.grad((y_ref * cot.double()).sum(), ref_in)
+    csr = ops.Csr(row, col, nj, nj, "cuda")
+    dev = [x.transpose(1, 2).contiguous().cuda().requires_grad_(True)] + [p.cuda().requires_grad_(True) for p in par]
+    y = ops.GoAttention.apply(dev[0], dev[1], dev[2], dev[3].view(-1), dev[4].view(-1), csr)
+    g = torch.autograd.grad((y * cot.transpose(1, 2).contiguous().cuda()).sum(), dev)
+    assert_matches(y.transpose(1, 2), y_ref.detach().numpy(), TOL, "y")
+    assert_matches(g[0].transpose(1, 2), g_ref[0].numpy(), TOL, "dx")
+    for got, want, nm in zip(g[1:], g_ref[1:], ("dW_inc", "dW_s", "da_in", "da_s")):
+        assert_matches(got, want.numpy(), TOL, nm)
+
+
+@pytest.mark.parametrize("bsz,f,n,pool,with_keep", [(3, 5, 40, 20, False), (8, 5, 3000, 1800, True),
+                                                     (4, 2, 257, 0, True), (2, 5, 1200, 800, False)])
+def test_nodes_layernorm(ops, bsz, f, n, pool, with_keep):
+    rng = np.random.default_rng(n)
+    y = torch.from_numpy(rng.standard_normal((bsz, f, n)) * 2 + 0.3).float()
+    gamma = torch.from_numpy(1 + 0.2 * rng.standard_normal(n)).float()
+    beta = torch.from_numpy(0.1 * rng.standard_normal(n)).float()
+    keep = torch.from_numpy((rng.random((bsz, n)) > 0.4) / 0.6).float() if with_keep else None
+    cot = torch.from_numpy(rng.standard_normal((bsz, f, n - pool))).float()
+    ref_in = [t.double().requires_grad_(True) for t in (y, gamma, beta)]
+    z_ref = torch.relu(torch.nn.functional.layer_norm(ref_in[0], (n,), ref_in[1], ref_in[2], 1e-5))
+    if keep is not None:
+        z_ref = z_ref * keep.double().unsqueeze(1)
+    z_ref = z_ref[:, :, pool:]
+    g_ref = torch.autograd.grad((z_ref * cot.double()).sum(), ref_in)
+    dev = [t.cuda().requires_grad_(True) for t in (y, gamma, beta)]
+    z = ops.NodesLayerNorm.apply(dev[0], dev[1], dev[2], keep.cuda() if keep is not None else None, pool, 1e-5)
+    g = torch.autograd.grad((z * cot.cuda()).sum(), dev)
+    assert_matches(z, z_ref.detach().numpy(), TOL, "z")
+    for got, want, nm in zip(g, g_ref, ("dy", "dgamma", "dbeta")):
+        assert_matches(got, want.numpy(), TOL, nm)
+
+
+@pytest.mark.parametrize("bsz,pool,layer,seed", [(4, (20, 10, 6, 3, 1), 0, 0), (4, (20, 10, 6, 3, 1), 1, 1),
+                                                 (9, (300, 120, 60, 19, 1), 0, 2), (9, (300, 120, 60, 19, 1), 1, 3)])
+def test_go_decoder_layer(ops, bsz, pool, layer, seed):
+    _, _, _, idx = _hier(pool, seed)
+    row, col, n_rows, n_cols = idx["dec"][layer]
+    fin, fout = 5, (5 if layer == 0 else 2)
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal((bsz, n_cols, fin))).float()
+    par = [torch.from_numpy(rng.standard_normal((fout, fin)) * 0.5).float() for _ in range(2)]
+    cot = torch.from_numpy(rng.standard_normal((bsz, n_rows, fout))).float()
+
+    def ref(xd, w_out, w_sout):
+        deg = torch.zeros(n_rows, dtype=xd.dtype).index_add(0, row, torch.ones(row.numel(), dtype=xd.dtype))
+        agg = torch.zeros(bsz, n_rows, fout, dtype=xd.dtype).index_add(
+            1, row, (xd @ w_out.t())[:, col] / deg[row].view(1, -1, 1))
+        pad = torch.zeros_like(agg)
+        pad[:, n_rows - n_cols:] = xd @ w_sout.t()
+        return agg + pad
+
+    ref_in = [t.double().requires_grad_(True) for t in [x] + par]
+    y_ref = ref(*ref_in)
+    g_ref = torch.autograd.grad((y_ref * cot.double()).sum(), ref_in)
+    csr = ops.Csr(row, col, n_rows, n_cols, "cuda")
+    dev = [x.transpose(1, 2).contiguous().cuda().requires_grad_(True)] + [p.cuda().requires_grad_(True) for p in par]
+    y = ops.GoDecode.apply(dev[0], dev[1], dev[2], csr)
+    g = torch.autograd.grad((y * cot.transpose(1, 2).contiguous().cuda()).sum(), dev)
+    assert_matches(y.transpose(1, 2), y_ref.detach().numpy(), TOL, "y")
+    assert_matches(g[0].transpose(1, 2), g_ref[0].numpy(), TOL, "dx")
+    assert_matches(g[1], g_ref[1].numpy(), TOL, "dW_out")
+    assert_matches(g[2], g_ref[2].numpy(), TOL, "dW_sout")
+
+
+@pytest.mark.parametrize("bsz,pool,seed", [(4, (20, 10, 6, 3, 1), 0), (32, (300, 120, 60, 19, 1), 1)])
+def test_sparse_map_encode_decode(ops, bsz, pool, seed):
+    a_g, _, _, idx = _hier(pool, seed)
+    n = idx["n"]
+    gn, gs = idx["gene"]
+    rng = np.random.default_rng(seed)
+    snps = torch.from_numpy(rng.random((bsz, 54))).float()
+    val = torch.from_numpy(1 + 0.1 * rng.standard_normal((2, gn.numel()))).float()
+    cot = torch.from_numpy(rng.standard_normal((bsz, 2, n))).float()
+    ref_in = [snps.double().requires_grad_(True), val.double().requires_grad_(True)]
+    y_ref = torch.stack([torch.zeros(bsz, n, dtype=torch.float64).index_add(1, gn, ref_in[0][:, gs] * ref_in[1][c])
+                         for c in range(2)], dim=1)
+    g_ref = torch.autograd.grad((y_ref * cot.double()).sum(), ref_in)
+    csr = ops.Csr(gn, gs, n, 54, "cuda")
+    dev = [snps.cuda().requires_grad_(True), val.cuda().requires_grad_(True)]
+    y = ops.SparseMap.apply(dev[0], dev[1], csr)
+    g = torch.autograd.grad((y * cot.cuda()).sum(), dev)
+    assert_matches(y, y_ref.detach().numpy(), TOL, "y")
+    assert_matches(g[0], g_ref[0].numpy(), TOL, "dsnps")
+    assert_matches(g[1], g_ref[1].numpy(), TOL, "dval")
+
+
+def test_adam_matches_torch(ops):
+    from igcn_amd.train import FlatAdam
+    rng = np.random.default_rng(0)
+    ps = [torch.nn.Parameter(torch.from_numpy(rng.standard_normal(s)).float().cuda()) for s in ((7, 5), (33,), (2, 3, 4))]
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt, opt_ref = FlatAdam(ps, lr=1e-3), torch.optim.Adam(ref, lr=1e-3)
+    for it in range(5):
+        opt.zero_grad()
+        for p, r in zip(ps, ref):
+            g = torch.from_numpy(rng.standard_normal(tuple(p.shape))).float()
+            p.grad.add_(g.cuda())
+            r.grad = g.clone()
+        opt.step()
+        opt_ref.step()
+    for p, r in zip(ps, ref):
+        assert torch.allclose(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
