@@ -196,4 +196,4 @@ def test_full_model_vs_oracle_larger(bsz, pool, explain):
     for k in OS.trainable_keys(sdo):
         if sdo[k].grad is None:
             continue
-        assert_matches(params[k].grad, sdo[k].grad.numpy(), 3e-3, "grad " + k, floor=1e-6)
+        assert_matches(params[k].grad, sdo[k].grad.numpy(), 5e-3, "grad " + k, floor=1e-6)
