@@ -28,11 +28,12 @@ SIGNATURES = {
     "igcn_gcn_propagate_bwd": (I, [L, L, I, P, L, P, L, I, P, L, P, P, P, P, P, P, P, L, P, I, P, P, P, P]),
     "igcn_gemm_f32": (I, [L, L, L, P, L, L, P, L, L, P, P, L, I, I, P, P]),
     "igcn_spmm_fwd": (I, [I, I, I, I, L, P, P, P, P, P, P]),
-    "igcn_spmm_bwd": (I, [I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_spmm_bwd": (I, [I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_go_attn_fwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "igcn_go_attn_bwd_scratch_floats": (Z, [I, I, I, I]),
     "igcn_go_attn_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_nodes_ln_fwd": (I, [I, I, I, I, F, P, P, P, P, P, P, P, P]),
+    "igcn_nodes_ln_bwd_scratch_floats": (Z, [I, I, I]),
     "igcn_nodes_ln_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_go_decode_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P]),
     "igcn_go_decode_bwd_scratch_floats": (Z, [I, I, I, I]),

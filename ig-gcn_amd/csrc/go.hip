@@ -25,11 +25,35 @@ __global__ void k_spmm_fwd(int C, int I, int J, int64_t nnz, const int32_t* __re
   }
 }
 
+// long rows (gene decode: ~150 GO nodes per SNP): one wave per (sample, row), lanes stride the row
+__global__ void __launch_bounds__(GO_T)
+k_spmm_fwd_wave(int B, int C, int I, int J, int64_t nnz, const int32_t* __restrict__ row_ptr,
+                const int32_t* __restrict__ col, const float* __restrict__ val, const float* __restrict__ x,
+                float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * (GO_T / 64) + (threadIdx.x >> 6);
+  if (wid >= (int64_t)B * I) return;
+  const int b = (int)(wid / I), i = (int)(wid - (int64_t)b * I);
+  const float* xb = x + (int64_t)b * J;
+  const int32_t p0 = row_ptr[i], p1 = row_ptr[i + 1];
+  for (int c = 0; c < C; ++c) {
+    float acc = 0.f;
+    for (int32_t p = p0 + lane; p < p1; p += 64) acc += val[(int64_t)c * nnz + p] * xb[col[p]];
+    acc = wave_sum(acc);
+    if (lane == 0) y[((int64_t)b * C + c) * I + i] = acc;
+  }
+}
+
 extern "C" int igcn_spmm_fwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
                              const float* val, const float* x, float* y, void* stream) {
   IGCN_REQUIRE(B > 0 && C > 0 && I > 0 && J > 0, "spmm_fwd: bad sizes");
-  hipLaunchKernelGGL(k_spmm_fwd, dim3((unsigned)igcn_cdiv(I, GO_T), B), dim3(GO_T), 0, (hipStream_t)stream, C, I, J,
-                     nnz, row_ptr, col, val, x, y);
+  if (nnz > (int64_t)8 * I) {
+    hipLaunchKernelGGL(k_spmm_fwd_wave, dim3((unsigned)igcn_cdiv((int64_t)B * I, GO_T / 64)), dim3(GO_T), 0,
+                       (hipStream_t)stream, B, C, I, J, nnz, row_ptr, col, val, x, y);
+  } else {
+    hipLaunchKernelGGL(k_spmm_fwd, dim3((unsigned)igcn_cdiv(I, GO_T), B), dim3(GO_T), 0, (hipStream_t)stream, C, I, J,
+                       nnz, row_ptr, col, val, x, y);
+  }
   IGCN_CHECK_LAUNCH("spmm_fwd");
   return IGCN_OK;
 }
@@ -48,34 +72,64 @@ __global__ void k_spmm_bwd_dx(int C, int I, int J, int64_t nnz, const int32_t* _
   dx[(int64_t)b * J + j] = acc;
 }
 
+__global__ void __launch_bounds__(GO_T)
+k_spmm_bwd_dx_wave(int B, int C, int I, int J, int64_t nnz, const int32_t* __restrict__ t_ptr,
+                   const int32_t* __restrict__ t_row, const int32_t* __restrict__ t_k,
+                   const float* __restrict__ val, const float* __restrict__ dy, float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * (GO_T / 64) + (threadIdx.x >> 6);
+  if (wid >= (int64_t)B * J) return;
+  const int b = (int)(wid / J), j = (int)(wid - (int64_t)b * J);
+  float acc = 0.f;
+  for (int32_t q = t_ptr[j] + lane; q < t_ptr[j + 1]; q += 64) {
+    const int32_t r = t_row[q], k = t_k[q];
+    for (int c = 0; c < C; ++c) acc += val[(int64_t)c * nnz + k] * dy[((int64_t)b * C + c) * I + r];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) dx[(int64_t)b * J + j] = acc;
+}
+
+// dval[c,k] = sum_b dy[b,c,row_k] x[b,col_k]: samples split into gridDim.z chunks -> partial[z][c][k]
+#define SPMM_BCH 16
 __global__ void k_spmm_bwd_dval(int B, int C, int I, int J, int64_t nnz, const int32_t* __restrict__ col,
                                 const int32_t* __restrict__ row_of, const float* __restrict__ x,
-                                const float* __restrict__ dy, float* __restrict__ dval) {
+                                const float* __restrict__ dy, float* __restrict__ partial) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int c = blockIdx.y;
   if (k >= nnz) return;
+  const int per = (B + gridDim.z - 1) / gridDim.z;
+  const int b0 = blockIdx.z * per, b1 = min(B, b0 + per);
   const int32_t r = row_of[k], j = col[k];
   float acc = 0.f;
-  for (int b = 0; b < B; ++b) acc += dy[((int64_t)b * C + c) * I + r] * x[(int64_t)b * J + j];
-  dval[(int64_t)c * nnz + k] = acc;
+  for (int b = b0; b < b1; ++b) acc += dy[((int64_t)b * C + c) * I + r] * x[(int64_t)b * J + j];
+  partial[((int64_t)blockIdx.z * C + c) * nnz + k] = acc;
 }
 
 extern "C" int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
                              const int32_t* row_of, const int32_t* t_ptr, const int32_t* t_row, const int32_t* t_k,
                              const float* val, const float* x, const float* dy, float* dx, float* dval,
-                             void* stream) {
+                             float* scratch, void* stream) {
   (void)row_ptr;
   IGCN_REQUIRE(B > 0 && C > 0 && I > 0 && J > 0, "spmm_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
-    hipLaunchKernelGGL(k_spmm_bwd_dx, dim3((unsigned)igcn_cdiv(J, GO_T), B), dim3(GO_T), 0, st, C, I, J, nnz, t_ptr,
-                       t_row, t_k, val, dy, dx);
+    if (nnz > (int64_t)8 * J) {
+      hipLaunchKernelGGL(k_spmm_bwd_dx_wave, dim3((unsigned)igcn_cdiv((int64_t)B * J, GO_T / 64)), dim3(GO_T), 0, st,
+                         B, C, I, J, nnz, t_ptr, t_row, t_k, val, dy, dx);
+    } else {
+      hipLaunchKernelGGL(k_spmm_bwd_dx, dim3((unsigned)igcn_cdiv(J, GO_T), B), dim3(GO_T), 0, st, C, I, J, nnz, t_ptr,
+                         t_row, t_k, val, dy, dx);
+    }
   }
+  IGCN_CHECK_LAUNCH("spmm_bwd_dx");
   if (dval && nnz > 0) {
-    hipLaunchKernelGGL(k_spmm_bwd_dval, dim3((unsigned)igcn_cdiv(nnz, GO_T), C), dim3(GO_T), 0, st, B, C, I, J, nnz,
-                       col, row_of, x, dy, dval);
+    IGCN_REQUIRE(scratch != nullptr, "spmm_bwd: dval needs scratch float[%d*C*nnz]", SPMM_BCH);
+    const int bch = B < SPMM_BCH ? B : SPMM_BCH;
+    hipLaunchKernelGGL(k_spmm_bwd_dval, dim3((unsigned)igcn_cdiv(nnz, GO_T), C, bch), dim3(GO_T), 0, st, B, C, I, J,
+                       nnz, col, row_of, x, dy, scratch);
+    IGCN_CHECK_LAUNCH("spmm_bwd_dval");
+    return igcn_launch_reduce_rows(scratch, bch, (int64_t)C * nnz, (int)((int64_t)C * nnz), dval, 0, st);
   }
-  IGCN_CHECK_LAUNCH("spmm_bwd");
   return IGCN_OK;
 }
 
@@ -236,7 +290,7 @@ k_go_attn_bwd_stats(int B, int N, const int32_t* __restrict__ row_ptr, const int
 }
 
 // ---- backward, kernel B: input gradient + block partials of the parameter gradients ------------
-#define GO_SB 8  // samples per thread (amortises the block reduction of the parameter gradients)
+#define GO_SB 1  // samples per thread: 1 keeps the longest per-thread edge walk (the root's children) short
 template <int FIN, int FOUT>
 __global__ void __launch_bounds__(GO_T)
 k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
@@ -435,19 +489,24 @@ k_nodes_ln_bwd_dy(int f, int N, int pool, const float* __restrict__ y, const flo
   }
 }
 
-// dgamma[n] = sum_rows up*xhat ; dbeta[n] = sum_rows up   (thread per node, rows in order)
-__global__ void k_nodes_ln_bwd_affine(int rows, int f, int N, int pool, const float* __restrict__ y,
-                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                      const float* __restrict__ keep, const float* __restrict__ mean,
-                                      const float* __restrict__ rstd, const float* __restrict__ dz,
-                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// dgamma[n] = sum_rows up*xhat ; dbeta[n] = sum_rows up.  Block = 64 node lanes x 4 row groups over a
+// chunk of LN_RC rows; partial[chunk][2][N] is summed over chunks (in order) by k_reduce_rows.
+#define LN_RC 64
+__global__ void __launch_bounds__(256)
+k_nodes_ln_bwd_affine(int rows, int f, int N, int pool, const float* __restrict__ y,
+                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                      const float* __restrict__ keep, const float* __restrict__ mean,
+                      const float* __restrict__ rstd, const float* __restrict__ dz,
+                      float* __restrict__ partial) {
+  __shared__ float sg[4][64], sb[4][64];
+  const int nl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + nl;
+  const int r0 = blockIdx.y * LN_RC, r1 = min(rows, r0 + LN_RC);
   float dg = 0.f, db = 0.f;
-  if (n >= pool) {
+  if (n < N && n >= pool) {
     const float ga = gamma[n], be = beta[n];
     const int M = N - pool;
-    for (int row = 0; row < rows; ++row) {
+    for (int row = r0 + rg; row < r1; row += 4) {
       const float xh = (y[(int64_t)row * N + n] - mean[row]) * rstd[row];
       if (xh * ga + be > 0.f) {
         float up = dz[(int64_t)row * M + (n - pool)];
@@ -457,21 +516,33 @@ __global__ void k_nodes_ln_bwd_affine(int rows, int f, int N, int pool, const fl
       }
     }
   }
-  dgamma[n] = dg;
-  dbeta[n] = db;
+  sg[rg][nl] = dg;
+  sb[rg][nl] = db;
+  __syncthreads();
+  if (rg == 0 && n < N) {
+    float* prow = partial + (int64_t)blockIdx.y * 2 * N;
+    prow[n] = (sg[0][nl] + sg[1][nl]) + (sg[2][nl] + sg[3][nl]);
+    prow[N + n] = (sb[0][nl] + sb[1][nl]) + (sb[2][nl] + sb[3][nl]);
+  }
+}
+
+extern "C" size_t igcn_nodes_ln_bwd_scratch_floats(int B, int f, int N) {
+  return (size_t)(igcn_cdiv((int64_t)B * f, LN_RC) * 2 * N + 64);
 }
 
 extern "C" int igcn_nodes_ln_bwd(int B, int f, int N, int pool, const float* y, const float* gamma,
                                  const float* beta, const float* keep, const float* mean, const float* rstd,
-                                 const float* dz, float* dy, float* dgamma, float* dbeta, void* stream) {
+                                 const float* dz, float* dy, float* dgb /*[2,N]: dgamma then dbeta*/,
+                                 float* scratch, void* stream) {
   IGCN_REQUIRE(B > 0 && f > 0 && N > 0 && pool >= 0 && pool < N, "nodes_ln_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_nodes_ln_bwd_dy, dim3(B * f), dim3(GO_T), 0, st, f, N, pool, y, gamma, beta, keep, mean, rstd,
                      dz, dy);
-  hipLaunchKernelGGL(k_nodes_ln_bwd_affine, dim3((unsigned)igcn_cdiv(N, 64)), dim3(64), 0, st, B * f, f, N, pool, y,
-                     gamma, beta, keep, mean, rstd, dz, dgamma, dbeta);
+  const int64_t chunks = igcn_cdiv((int64_t)B * f, LN_RC);
+  hipLaunchKernelGGL(k_nodes_ln_bwd_affine, dim3((unsigned)igcn_cdiv(N, 64), (unsigned)chunks), dim3(256), 0, st,
+                     B * f, f, N, pool, y, gamma, beta, keep, mean, rstd, dz, scratch);
   IGCN_CHECK_LAUNCH("nodes_ln_bwd");
-  return IGCN_OK;
+  return igcn_launch_reduce_rows(scratch, chunks, 2 * (int64_t)N, 2 * N, dgb, 0, st);
 }
 
 // =================================================================================================

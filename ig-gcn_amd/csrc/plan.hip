@@ -28,9 +28,26 @@ __global__ void k_reduce_rows(const float* __restrict__ partial, int64_t rows, i
   out[j] = accumulate ? out[j] + t : t;
 }
 
+// many rows, few columns: one 256-thread block per column, fixed reduction tree (deterministic)
+__global__ void __launch_bounds__(256)
+k_reduce_rows_par(const float* __restrict__ partial, int64_t rows, int64_t ld, float* __restrict__ out,
+                  int accumulate) {
+  __shared__ float red[16];
+  const int j = blockIdx.x;
+  float t = 0.f;
+  for (int64_t r = threadIdx.x; r < rows; r += 256) t += partial[r * ld + j];
+  t = block_sum_all(t, red);
+  if (threadIdx.x == 0) out[j] = accumulate ? out[j] + t : t;
+}
+
 int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int n, float* out, int accumulate,
                             hipStream_t st) {
   if (n <= 0) return IGCN_OK;
+  if (rows > 32 && n <= 4096) {
+    hipLaunchKernelGGL(k_reduce_rows_par, dim3((unsigned)n), dim3(256), 0, st, partial, rows, ld, out, accumulate);
+    IGCN_CHECK_LAUNCH("reduce_rows_par");
+    return IGCN_OK;
+  }
   hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)igcn_cdiv(n, 64)), dim3(64), 0, st, partial, rows, ld, n, out,
                      accumulate);
   IGCN_CHECK_LAUNCH("reduce_rows");

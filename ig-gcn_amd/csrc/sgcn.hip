@@ -92,13 +92,15 @@ __global__ void k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const f
 }
 
 // dprob[r,h] = sum_b gx[(b*rois + r), h]
-__global__ void k_edge_mask_bwd_prob(int64_t n_graphs, int rois, int h0, const float* __restrict__ gx,
-                                     float* __restrict__ dprob) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= rois * h0) return;
+__global__ void __launch_bounds__(256)
+k_edge_mask_bwd_prob(int64_t n_graphs, int rois, int h0, const float* __restrict__ gx,
+                     float* __restrict__ dprob) {
+  __shared__ float red[16];
+  const int j = blockIdx.x;           // one block per (roi, feature)
   float t = 0.f;
-  for (int64_t b = 0; b < n_graphs; ++b) t += gx[b * rois * h0 + j];
-  dprob[j] = t;
+  for (int64_t b = threadIdx.x; b < n_graphs; b += 256) t += gx[b * rois * h0 + j];
+  t = block_sum_all(t, red);
+  if (threadIdx.x == 0) dprob[j] = t;
 }
 
 __global__ void k_edge_mask_bwd_pb(int64_t nblk, int h0, const float* __restrict__ partial, float* __restrict__ dpb) {
@@ -122,8 +124,8 @@ extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, in
   float* part = scratch + n_nodes * h0;  // [nblk, 2*MAX_H0]
   hipLaunchKernelGGL(k_edge_mask_bwd_nodes, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
                      prob_bias, ew, e, d_xm, d_ewm, d_e, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
-  hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)igcn_cdiv(rois * h0, 256)), dim3(256), 0, st,
-                     n_nodes / rois, rois, h0, gx, dprob);
+  hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)(rois * h0)), dim3(256), 0, st, n_nodes / rois, rois, h0,
+                     gx, dprob);
   hipLaunchKernelGGL(k_edge_mask_bwd_pb, dim3(1), dim3(64), 0, st, nblk, h0, part, dprob_bias);
   IGCN_CHECK_LAUNCH("edge_mask_bwd");
   return IGCN_OK;

@@ -281,9 +281,11 @@ class SparseMap(torch.autograd.Function):
         b, c = x.shape[0], val.shape[0]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dval = torch.empty_like(val) if ctx.needs_input_grad[1] else None
+        scratch = torch.empty(16 * c * max(csr.nnz, 1), dtype=torch.float32, device=x.device) \
+            if dval is not None else None
         call("igcn_spmm_bwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
              ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(x), ptr(dy), ptr(dx),
-             ptr(dval), stream_ptr())
+             ptr(dval), ptr(scratch), stream_ptr())
         return dx, dval, None
 
 
@@ -344,10 +346,14 @@ class NodesLayerNorm(torch.autograd.Function):
         y, gamma, beta, keep, mean, rstd = ctx.saved_tensors
         dz = _f32(dz)
         b, f, n = y.shape
-        dy, dg, db = torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta)
+        dy = torch.empty_like(y)
+        dgb = torch.empty(2, n, dtype=torch.float32, device=y.device)
+        lib = _lib.load()
+        scratch = torch.empty(int(lib.igcn_nodes_ln_bwd_scratch_floats(b, f, n)), dtype=torch.float32,
+                              device=y.device)
         call("igcn_nodes_ln_bwd", b, f, n, ctx.pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean),
-             ptr(rstd), ptr(dz), ptr(dy), ptr(dg), ptr(db), stream_ptr())
-        return dy, dg, db, None, None, None
+             ptr(rstd), ptr(dz), ptr(dy), ptr(dgb), ptr(scratch), stream_ptr())
+        return dy, dgb[0], dgb[1], None, None, None
 
 
 class GoDecode(torch.autograd.Function):

@@ -138,7 +138,8 @@ int igcn_spmm_fwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_pt
 int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
                   const int32_t* row_of /*[nnz]*/, const int32_t* t_ptr, const int32_t* t_row, const int32_t* t_k,
                   const float* val, const float* x, const float* dy,
-                  float* dx /*[B,J] or NULL*/, float* dval /*[C,nnz]*/, void* stream);
+                  float* dx /*[B,J] or NULL*/, float* dval /*[C,nnz] or NULL*/,
+                  float* scratch /* float[16*C*nnz], needed when dval != NULL */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GO attention-GCN encoder layer, all samples at once — replaces the dense transforms, the edge gathers
@@ -169,10 +170,12 @@ int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, co
  */
 int igcn_nodes_ln_fwd(int B, int f, int N, int pool, float eps, const float* y, const float* gamma,
                       const float* beta, const float* keep, float* z, float* mean, float* rstd, void* stream);
-/* Outputs dy [B,f,N], dgamma [N], dbeta [N]. */
+/* Outputs dy [B,f,N], dgb [2,N] (dgamma row then dbeta row).
+ * scratch: igcn_nodes_ln_bwd_scratch_floats(B,f,N) floats. */
+size_t igcn_nodes_ln_bwd_scratch_floats(int B, int f, int N);
 int igcn_nodes_ln_bwd(int B, int f, int N, int pool, const float* y, const float* gamma, const float* beta,
                       const float* keep, const float* mean, const float* rstd, const float* dz,
-                      float* dy, float* dgamma, float* dbeta, void* stream);
+                      float* dy, float* dgb, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GO decoder layer (mean aggregation down the hierarchy) — go_model.py:262-272, batch_mul :197-201:

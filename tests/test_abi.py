@@ -1,0 +1,68 @@
+"""CPU checks of the drop-in boundary: libigcn.so loads, exports every symbol include/igcn.h declares, and the
+ctypes signature table (igcn_amd/_lib.py) agrees with the header prototype by prototype.  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from igcn_amd import _lib
+
+HEADER = os.path.join(ROOT, "include", "igcn.h")
+
+CTYPE = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "float": ctypes.c_float}
+
+
+def _prototypes():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|size_t|const char\s*\*)\s+(igcn_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        types = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    types.append(ctypes.c_void_p)
+                else:
+                    types.append(CTYPE[a.replace("const ", "").split()[0]])
+        protos[name] = (ret.replace(" ", ""), types)
+    return protos
+
+
+def test_header_declares_what_python_binds():
+    protos = _prototypes()
+    assert set(protos) == set(_lib.SIGNATURES), set(protos) ^ set(_lib.SIGNATURES)
+    for name, (ret, types) in protos.items():
+        res, args = _lib.SIGNATURES[name]
+        assert list(args) == types, f"{name}: header {types} vs ctypes {args}"
+        want = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "constchar*": ctypes.c_char_p}[ret]
+        assert res is want, name
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()
+    for name in _prototypes():
+        assert hasattr(lib, name), name
+    assert lib.igcn_version() >= 100
+    # host-only helpers may be called without a GPU
+    assert lib.igcn_gcn_propagate_bwd_scratch_floats(23040, 16) >= 1440 * 16
+    assert lib.igcn_go_attn_bwd_scratch_floats(256, 3000, 5, 5) > 4 * 256 * 3000
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.IgcnError):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected():
+    import torch
+    with pytest.raises(_lib.IgcnError):
+        _lib.ptr(torch.zeros(3))
