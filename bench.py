@@ -145,7 +145,7 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=device)
 
     from igcn_amd import _lib
-    from igcn_amd.train import FlatAdam, train_step
+    from igcn_amd.train import FlatAdam, GraphedTrainStep, train_step
     _lib.load()                                   # fail loudly when the HIP library is missing
 
     model, go = build_model(device)
@@ -156,9 +156,12 @@ def main():
     data = Batch.from_data_list(graphs).to(device)
     data.x.requires_grad_(True)
 
-    def step():
-        data._igcn_plan = None                    # the plan is per batch: rebuild it inside every step
-        return train_step(model, opt, data, world_size=world)
+    if args.eager:
+        def step():
+            data._igcn_plan = None                # the plan is per batch: rebuild it inside every step
+            return train_step(model, opt, data, world_size=world)
+    else:
+        step = GraphedTrainStep(model, opt, data, world_size=world)     # whole step = one hipGraph replay
 
     for _ in range(args.warmup):
         step()
@@ -193,7 +196,7 @@ def main():
                                    "90-ROI k=3 brain graphs + 3000-node GO-SNP DAG",
                        "graphs_per_gpu": GRAPHS_PER_GPU, "global_batch": GRAPHS_PER_GPU * world,
                        "layers": LAYERS, "hidden": HIDDEN, "rois": ROIS, "go_nodes": sum(POOL),
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "launch": "eager" if args.eager else "hipGraph replay"},
             "loss": round(float(loss), 6),
         }
         res["roofline"] = scatter_roofline(data, device)

@@ -111,6 +111,69 @@ def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temper
     return loss.detach()
 
 
+class GraphedTrainStep:
+    """The whole optimisation step captured ONCE into a hipGraph and replayed per step.
+
+    CDNA4 idiom for a launch-bound step (hundreds of microsecond-sized kernels): no tracing compiler,
+    just stream capture of the eager step — graph-plan build, two forwards, losses, backward and Adam
+    become one graph launch.  Inputs live in static device tensors (``self.data``); ``load(batch)`` copies
+    a new batch of identical shape into them.  With ``world_size > 1`` the gradient all-reduce stays
+    outside the graphs: [zero_grad .. backward] graph -> RCCL all-reduce -> [Adam] graph.
+    """
+
+    def __init__(self, model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, world_size=1, warmup=3):
+        self.model, self.opt, self.data, self.world = model, optimizer, data, world_size
+        self.lam, self.hp = lambda_loss, hp
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                     # eager steps: allocator + library warm-up
+                self._fwd_bwd()
+                self._reduce()
+                self.opt.step(grad_scale=1.0 / world_size)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_main = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_main):
+            self.loss = self._fwd_bwd()
+            if world_size == 1:
+                self.opt.step()
+        self.g_opt = None
+        if world_size > 1:
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=self.g_main.pool()):
+                self.opt.step(grad_scale=1.0 / world_size)
+
+    def _fwd_bwd(self):
+        self.opt.zero_grad()
+        self.data._igcn_plan = None                     # the plan is per batch: rebuilt inside every step
+        self.data.x.grad = None
+        loss, _, _ = losses(self.model, self.data, self.lam, self.hp)
+        loss.backward()
+        return loss.detach()
+
+    def _reduce(self):
+        if self.world > 1:
+            torch.distributed.all_reduce(self.opt.grad)
+
+    def load(self, batch):
+        """Copy a new batch (same graph count / edge count) into the static input tensors."""
+        for k in ("x", "edge_index", "edge_attr", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y"):
+            dst, src = getattr(self.data, k, None), getattr(batch, k, None)
+            if dst is not None and src is not None:
+                if dst.shape != src.shape:
+                    raise ValueError(f"graphed step needs fixed shapes; {k}: {tuple(src.shape)} vs {tuple(dst.shape)}")
+                with torch.no_grad():
+                    dst.copy_(src, non_blocking=True)
+
+    def __call__(self):
+        self.g_main.replay()
+        if self.g_opt is not None:
+            self._reduce()
+            self.g_opt.replay()
+        return self.loss
+
+
 def shard_batch(graphs, rank, world_size):
     """Contiguous graph-range shard of a list of graphs for rank r."""
     n = len(graphs)
