@@ -174,6 +174,14 @@ class GraphedTrainStep:
         return self.loss
 
 
+def allreduce_mean_(flat_grad, world_size):
+    """Sum the flat gradient bucket over ranks (one collective) and divide by the world size, in place."""
+    if world_size > 1:
+        torch.distributed.all_reduce(flat_grad)
+        flat_grad.div_(world_size)
+    return flat_grad
+
+
 def shard_batch(graphs, rank, world_size):
     """Contiguous graph-range shard of a list of graphs for rank r."""
     n = len(graphs)
