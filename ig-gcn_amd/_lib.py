@@ -27,6 +27,16 @@ SIGNATURES = {
     "igcn_gcn_propagate_bwd_scratch_floats": (Z, [L, I]),
     "igcn_gcn_propagate_bwd": (I, [L, L, I, P, L, P, L, I, P, L, P, P, P, P, P, P, P, L, P, I, P, P, P, P]),
     "igcn_gemm_f32": (I, [L, L, L, P, L, L, P, L, L, P, P, L, I, I, P, P]),
+    "igcn_gemm_f32_batched_sum": (I, [L, L, L, I, P, L, L, L, P, L, L, L, P, L, P, P]),
+    "igcn_node_linear_bn_scratch_floats": (Z, [I, I]),
+    "igcn_node_linear_bn_fwd": (I, [I, I, I, I, P, P, P, P, P, P, I, F, F, P, P, P, P, P]),
+    "igcn_node_linear_bn_bwd_scratch_floats": (Z, [I, I, I, I]),
+    "igcn_node_linear_bn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_mask_reg_fwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P]),
+    "igcn_mask_reg_bwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P, P, P]),
+    "igcn_rbf_laplacian": (I, [I, I, F, P, P, P]),
+    "igcn_gram_loss_fwd": (I, [I, I, P, P, P, P, P]),
+    "igcn_gram_loss_bwd": (I, [I, P, P, P, P, P]),
     "igcn_spmm_fwd": (I, [I, I, I, I, L, P, P, P, P, P, P]),
     "igcn_spmm_bwd": (I, [I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_go_attn_fwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P]),

@@ -323,6 +323,7 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
       const float p_n = sp[n], q_n = sp[BN + n], zinv_n = sp[2 * BN + n], tr_n = sp[3 * BN + n];
       // n as ROW: d(score) of its own edges
       float dp = 0.f;
+#pragma unroll 2
       for (int32_t e = r0; e < r1; ++e) {
         const int m = col[e];
         float xm[FIN], xim[FOUT];
@@ -336,6 +337,7 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
       float dq = 0.f, dxin[FOUT];
 #pragma unroll
       for (int c = 0; c < FOUT; ++c) dxin[c] = 0.f;
+#pragma unroll 4
       for (int32_t e = c0; e < c1; ++e) {
         const int r = t_row[e];
         float dyr[FOUT];
@@ -635,6 +637,7 @@ k_go_decode_bwd(int B, int Nin, int Nout, const int32_t* __restrict__ row_ptr, c
       float G[FOUT], Gs[FOUT], xr[FIN];
 #pragma unroll
       for (int c = 0; c < FOUT; ++c) G[c] = 0.f;
+#pragma unroll 4
       for (int32_t e = c0; e < c1; ++e) {
         const int r = t_row[e];
         const float inv = 1.f / (float)(row_ptr[r + 1] - row_ptr[r]);

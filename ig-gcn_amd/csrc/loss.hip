@@ -1,0 +1,189 @@
+// Loss terms of the train step as first-class kernels:
+//  * mask regulariser  — loss_probability, kernel/sgcn_img_snp.py:153-181
+//  * Gram-form batch losses — consist_loss :183-196 and OrthogonalConstraint :198-205 from ONE B x B Gram
+//    matrix G = s s^T of the fused features (the reference forms an (R*D) x (R*D) product for the latter).
+#include "common.h"
+
+// -------------------------------------------------------------------------------------------------
+// mask regulariser.  For p in (0,1):  r(p) = l1*p + ent*( -(p log(p+eps) + (1-p) log(1-p+eps)) ), averaged.
+//   loss = mean r_x(sigmoid(prob)) + mean r_e(e) + mean r_x(sigmoid(snps_prob))
+// element ranges: [0,n_prob) prob logits, [n_prob, n_prob+n_edge) edge mask values, then snps logits.
+// -------------------------------------------------------------------------------------------------
+struct MaskRegArgs {
+  const float *prob, *e, *snps;
+  int64_t n_prob, n_edge, n_snps;
+  float l1_x, ent_x, l1_e, ent_e, eps;
+};
+
+__device__ __forceinline__ float reg_term(float p, float l1, float ent, float eps) {
+  return l1 * fabsf(p) - ent * (p * logf(p + eps) + (1.f - p) * logf((1.f - p) + eps));
+}
+
+__device__ __forceinline__ float reg_grad(float p, float l1, float ent, float eps) {
+  // d/dp of reg_term (p > 0)
+  return l1 - ent * (logf(p + eps) + p / (p + eps) - logf((1.f - p) + eps) - (1.f - p) / ((1.f - p) + eps));
+}
+
+__global__ void __launch_bounds__(256) k_mask_reg_fwd(MaskRegArgs a, float* __restrict__ partial) {
+  __shared__ float red[16];
+  const int64_t total = a.n_prob + a.n_edge + a.n_snps;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    if (i < a.n_prob) {
+      const float p = 1.f / (1.f + expf(-a.prob[i]));
+      acc += reg_term(p, a.l1_x, a.ent_x, a.eps) / (float)a.n_prob;
+    } else if (i < a.n_prob + a.n_edge) {
+      acc += reg_term(a.e[i - a.n_prob], a.l1_e, a.ent_e, a.eps) / (float)a.n_edge;
+    } else {
+      const float p = 1.f / (1.f + expf(-a.snps[i - a.n_prob - a.n_edge]));
+      acc += reg_term(p, a.l1_x, a.ent_x, a.eps) / (float)a.n_snps;
+    }
+  }
+  acc = block_sum_all(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__global__ void k_mask_reg_bwd(MaskRegArgs a, const float* __restrict__ gout, float* __restrict__ dprob,
+                               float* __restrict__ de, float* __restrict__ dsnps) {
+  const int64_t total = a.n_prob + a.n_edge + a.n_snps;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float g = gout[0];
+  if (i < a.n_prob) {
+    const float p = 1.f / (1.f + expf(-a.prob[i]));
+    dprob[i] = g * reg_grad(p, a.l1_x, a.ent_x, a.eps) * p * (1.f - p) / (float)a.n_prob;
+  } else if (i < a.n_prob + a.n_edge) {
+    const int64_t k = i - a.n_prob;
+    de[k] = g * reg_grad(a.e[k], a.l1_e, a.ent_e, a.eps) / (float)a.n_edge;
+  } else {
+    const int64_t k = i - a.n_prob - a.n_edge;
+    const float p = 1.f / (1.f + expf(-a.snps[k]));
+    dsnps[k] = g * reg_grad(p, a.l1_x, a.ent_x, a.eps) * p * (1.f - p) / (float)a.n_snps;
+  }
+}
+
+#define MR_BLOCKS 128
+
+extern "C" int igcn_mask_reg_fwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const float* prob, const float* e,
+                                 const float* snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,
+                                 float* loss /*[1]*/, float* scratch /*[128]*/, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  MaskRegArgs a{prob, e, snps, n_prob, n_edge, n_snps, l1_x, ent_x, l1_e, ent_e, eps};
+  hipLaunchKernelGGL(k_mask_reg_fwd, dim3(MR_BLOCKS), dim3(256), 0, st, a, scratch);
+  IGCN_CHECK_LAUNCH("mask_reg_fwd");
+  return igcn_launch_reduce_rows(scratch, MR_BLOCKS, 1, 1, loss, 0, st);
+}
+
+extern "C" int igcn_mask_reg_bwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const float* prob, const float* e,
+                                 const float* snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,
+                                 const float* gout /*[1] device*/, float* dprob, float* de, float* dsnps,
+                                 void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  MaskRegArgs a{prob, e, snps, n_prob, n_edge, n_snps, l1_x, ent_x, l1_e, ent_e, eps};
+  const int64_t total = n_prob + n_edge + n_snps;
+  if (total == 0) return IGCN_OK;
+  hipLaunchKernelGGL(k_mask_reg_bwd, dim3((unsigned)igcn_cdiv(total, 256)), dim3(256), 0, st, a, gout, dprob, de,
+                     dsnps);
+  IGCN_CHECK_LAUNCH("mask_reg_bwd");
+  return IGCN_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Gram-form batch losses on G = s s^T  (B x B, symmetric), Lap = diag(W 1) - W  (B x B):
+//   out[0] = consist = sum_ij Lap_ij G_ij / B^2                       ( = tr(s^T Lap s)/B^2 )
+//   out[1] = orth    = ( sum_ij G_ij^2/(G_ii G_jj) - 2 sum_i 1 + RD ) / B^2
+//            ( = ||Wn^T Wn - I||_F^2 / B^2 with Wn the row-normalised s, via ||Wn^T Wn||_F = ||Wn Wn^T||_F )
+// backward writes S = dG + dG^T so that ds = S s :
+//   dG_ij = gc*Lap_ij/B^2 + go*( 2 G_ij/(G_ii G_jj)  [i != j]  ;  -2 sum_{k != i} G_ik^2/(G_ii^2 G_kk)  [i == j] )/B^2
+// -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gram_loss_fwd(int B, int RD, const float* __restrict__ G, const float* __restrict__ Lap,
+                float* __restrict__ partial /*[B,2]*/) {
+  __shared__ float red[16];
+  const int i = blockIdx.x;
+  const float gii = G[(int64_t)i * B + i];
+  float c = 0.f, o = 0.f;
+  for (int j = threadIdx.x; j < B; j += 256) {
+    const float g = G[(int64_t)i * B + j];
+    c += Lap[(int64_t)i * B + j] * g;
+    o += g * g / (gii * G[(int64_t)j * B + j]);
+  }
+  c = block_sum_all(c, red);
+  o = block_sum_all(o, red);
+  if (threadIdx.x == 0) {
+    const float b2 = (float)B * (float)B;
+    partial[2 * i] = c / b2;
+    partial[2 * i + 1] = (o - 2.f + (float)RD / (float)B) / b2;     // the -2B + RD constants, spread over rows
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_gram_loss_bwd(int B, const float* __restrict__ G, const float* __restrict__ Lap, const float* __restrict__ gout,
+                float* __restrict__ S) {
+  __shared__ float red[16];
+  const int i = blockIdx.x;
+  const float gc = gout[0], go = gout[1];
+  const float b2 = (float)B * (float)B;
+  const float gii = G[(int64_t)i * B + i];
+  float dsum = 0.f;
+  for (int j = threadIdx.x; j < B; j += 256) {
+    if (j == i) continue;
+    const float g = G[(int64_t)i * B + j], gjj = G[(int64_t)j * B + j];
+    dsum += g * g / (gii * gii * gjj);
+    // off-diagonal: dG_ij + dG_ji (both symmetric expressions)
+    S[(int64_t)i * B + j] = (gc * (Lap[(int64_t)i * B + j] + Lap[(int64_t)j * B + i]) + go * 4.f * g / (gii * gjj)) / b2;
+  }
+  dsum = block_sum_all(dsum, red);
+  if (threadIdx.x == 0) S[(int64_t)i * B + i] = 2.f * (gc * Lap[(int64_t)i * B + i] - go * 2.f * dsum) / b2;
+}
+
+extern "C" int igcn_gram_loss_fwd(int B, int RD, const float* G, const float* Lap, float* out /*[2]*/,
+                                  float* scratch /*[2B]*/, void* stream) {
+  IGCN_REQUIRE(B > 0, "gram_loss_fwd: bad B");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gram_loss_fwd, dim3(B), dim3(256), 0, st, B, RD, G, Lap, scratch);
+  IGCN_CHECK_LAUNCH("gram_loss_fwd");
+  return igcn_launch_reduce_rows(scratch, B, 2, 2, out, 0, st);
+}
+
+extern "C" int igcn_gram_loss_bwd(int B, const float* G, const float* Lap, const float* gout /*[2] device*/,
+                                  float* S /*[B,B]*/, void* stream) {
+  IGCN_REQUIRE(B > 0, "gram_loss_bwd: bad B");
+  hipLaunchKernelGGL(k_gram_loss_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, B, G, Lap, gout, S);
+  IGCN_CHECK_LAUNCH("gram_loss_bwd");
+  return IGCN_OK;
+}
+
+// Lap = diag(W 1) - W,  W_ij = exp(-gamma * ||t_i - t_j||^2)   (rbf_kernel_torch, util/image_cluster.py:15-31);
+// t == NULL gives W = 1 (the non-soft branch of consist_loss).  One block per row i.
+__global__ void __launch_bounds__(256)
+k_rbf_laplacian(int B, int T, float gamma, const float* __restrict__ t, float* __restrict__ Lap) {
+  __shared__ float red[16];
+  const int i = blockIdx.x;
+  float rs = 0.f;
+  for (int j = threadIdx.x; j < B; j += 256) {
+    float w = 1.f;
+    if (t) {
+      float d2 = 0.f;
+      for (int k = 0; k < T; ++k) {
+        const float d = t[(int64_t)i * T + k] - t[(int64_t)j * T + k];
+        d2 += d * d;
+      }
+      w = expf(-gamma * d2);
+    }
+    rs += w;
+    if (j != i) Lap[(int64_t)i * B + j] = -w;
+  }
+  rs = block_sum_all(rs, red);
+  if (threadIdx.x == 0) {
+    float wii = 1.f;     // exp(0)
+    Lap[(int64_t)i * B + i] = rs - wii;
+  }
+}
+
+extern "C" int igcn_rbf_laplacian(int B, int T, float gamma, const float* t, float* Lap, void* stream) {
+  IGCN_REQUIRE(B > 0, "rbf_laplacian: bad B");
+  hipLaunchKernelGGL(k_rbf_laplacian, dim3(B), dim3(256), 0, (hipStream_t)stream, B, T, gamma, t, Lap);
+  IGCN_CHECK_LAUNCH("rbf_laplacian");
+  return IGCN_OK;
+}

@@ -1,0 +1,321 @@
+// Node-wise read-outs of the GO network: per-node linear transform + BatchNorm1d(#nodes) + ReLU, fused.
+//   pre[b,n,:] = W x[b,:,n]             x [B,F,N] channel-major, W [D,F]
+//   out[b,n,:] = relu( (pre - mean_n) * rstd_n * gamma[n] + beta[n] )         out [B,N,D]
+// BatchNorm1d(N) on a [B,N,D] tensor normalises every NODE over (batch, feature) — go_model.py:117-121
+// (conc_for_attention, D = dim_snps_atten), :123-128 (conc + B, D = 1), :130-136 (conc_D + B_D, D = 1).
+// Replaces per call: a permute copy, a K=5 rocBLAS GEMM, ~6 BatchNorm kernels, a clamp, and in the backward the
+// K = B*N weight-gradient GEMMs that rocBLAS runs at ~190 us each.
+#include "common.h"
+
+#define RO_T 256
+#define RO_NL 64      // node lanes per block
+#define RO_SG 4       // sample groups per block
+
+// W is read through wave-uniform addresses: the compiler keeps it on the scalar path (s_load + SGPR operands),
+// so no vector registers are spent on the D*F weights.
+template <int F, int D>
+__device__ __forceinline__ void ro_pre(const float* __restrict__ w, const float (&x)[F], float (&o)[D]) {
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < F; ++c) t += w[d * F + c] * x[c];
+    o[d] = t;
+  }
+}
+
+// ---- forward pass 1: shifted sums per (node, sample chunk) ---------------------------------------
+// partial[chunk][0][n] = sum (pre - pivot_n), partial[chunk][1][n] = sum (pre - pivot_n)^2 ; pivot from sample 0
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_stats(int B, int N, const float* __restrict__ x, const float* __restrict__ W, float* __restrict__ partial) {
+  __shared__ float s1[RO_SG][RO_NL], s2[RO_SG][RO_NL];
+  const float* __restrict__ w = W;
+  const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int n = blockIdx.x * RO_NL + nl;
+  const int per = (B + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  float a1 = 0.f, a2 = 0.f;
+  if (n < N) {
+    float xv[F], pre[D];
+#pragma unroll
+    for (int c = 0; c < F; ++c) xv[c] = x[(int64_t)c * N + n];          // sample 0
+    ro_pre<F, D>(w, xv, pre);
+    float piv = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) piv += pre[d];
+    piv *= (1.f / D);
+    for (int b = b0 + sg; b < b1; b += RO_SG) {
+#pragma unroll
+      for (int c = 0; c < F; ++c) xv[c] = x[((int64_t)b * F + c) * N + n];
+      ro_pre<F, D>(w, xv, pre);
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const float v = pre[d] - piv;
+        a1 += v;
+        a2 += v * v;
+      }
+    }
+  }
+  s1[sg][nl] = a1;
+  s2[sg][nl] = a2;
+  __syncthreads();
+  if (sg == 0 && n < N) {
+    float* p = partial + (int64_t)blockIdx.y * 2 * N;
+    p[n] = (s1[0][nl] + s1[1][nl]) + (s1[2][nl] + s1[3][nl]);
+    p[N + n] = (s2[0][nl] + s2[1][nl]) + (s2[2][nl] + s2[3][nl]);
+  }
+}
+
+// ---- forward pass 2: finalise statistics (training) or take the running ones (eval) ----------------
+template <int F, int D>
+__global__ void k_nlbn_finalize(int B, int N, int chunks, int training, float eps, float momentum,
+                                const float* __restrict__ x, const float* __restrict__ W,
+                                const float* __restrict__ partial, float* __restrict__ running_mean,
+                                float* __restrict__ running_var, float* __restrict__ mean_out,
+                                float* __restrict__ rstd_out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float mean, var;
+  if (training) {
+    const float* __restrict__ w = W;
+    float xv[F], pre[D];
+#pragma unroll
+    for (int c = 0; c < F; ++c) xv[c] = x[(int64_t)c * N + n];
+    ro_pre<F, D>(w, xv, pre);
+    float piv = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) piv += pre[d];
+    piv *= (1.f / D);
+    float a1 = 0.f, a2 = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+      a1 += partial[(int64_t)k * 2 * N + n];
+      a2 += partial[(int64_t)k * 2 * N + N + n];
+    }
+    const float cnt = (float)B * D;
+    const float m = a1 / cnt;
+    mean = piv + m;
+    var = fmaxf(a2 / cnt - m * m, 0.f);
+    running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * mean;
+    running_var[n] = (1.f - momentum) * running_var[n] + momentum * var * (cnt / (cnt - 1.f));
+  } else {
+    mean = running_mean[n];
+    var = running_var[n];
+  }
+  mean_out[n] = mean;
+  rstd_out[n] = 1.0f / sqrtf(var + eps);
+}
+
+// ---- forward pass 3: normalise + ReLU, write [B,N,D] ---------------------------------------------
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_apply(int B, int N, const float* __restrict__ x, const float* __restrict__ W,
+             const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+             const float* __restrict__ rstd, float* __restrict__ out) {
+  const float* __restrict__ w = W;
+  const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int n = blockIdx.x * RO_NL + nl;
+  if (n >= N) return;
+  const int per = (B + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const float sc = rstd[n] * gamma[n], sh = beta[n] - mean[n] * sc;
+  for (int b = b0 + sg; b < b1; b += RO_SG) {
+    float xv[F], pre[D];
+#pragma unroll
+    for (int c = 0; c < F; ++c) xv[c] = x[((int64_t)b * F + c) * N + n];
+    ro_pre<F, D>(w, xv, pre);
+    float* o = out + ((int64_t)b * N + n) * D;
+    if constexpr (D % 4 == 0) {
+#pragma unroll
+      for (int d = 0; d < D; d += 4) {
+        float4 v;
+        v.x = fmaxf(pre[d] * sc + sh, 0.f);
+        v.y = fmaxf(pre[d + 1] * sc + sh, 0.f);
+        v.z = fmaxf(pre[d + 2] * sc + sh, 0.f);
+        v.w = fmaxf(pre[d + 3] * sc + sh, 0.f);
+        *reinterpret_cast<float4*>(o + d) = v;
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < D; ++d) o[d] = fmaxf(pre[d] * sc + sh, 0.f);
+    }
+  }
+}
+
+// ---- backward pass 1: per node sum(dy), sum(dy*xhat) over (b,d), dy = dout * [out > 0] ---------------
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_bwd_stats(int B, int N, const float* __restrict__ x, const float* __restrict__ W,
+                 const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                 const float* __restrict__ rstd, const float* __restrict__ dout, float* __restrict__ partial) {
+  __shared__ float s1[RO_SG][RO_NL], s2[RO_SG][RO_NL];
+  const float* __restrict__ w = W;
+  const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int n = blockIdx.x * RO_NL + nl;
+  const int per = (B + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  float a1 = 0.f, a2 = 0.f;
+  if (n < N) {
+    const float mu = mean[n], rs = rstd[n], ga = gamma[n], be = beta[n];
+    for (int b = b0 + sg; b < b1; b += RO_SG) {
+      float xv[F], pre[D];
+#pragma unroll
+      for (int c = 0; c < F; ++c) xv[c] = x[((int64_t)b * F + c) * N + n];
+      ro_pre<F, D>(w, xv, pre);
+      const float* g = dout + ((int64_t)b * N + n) * D;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const float xh = (pre[d] - mu) * rs;
+        const float dy = (xh * ga + be > 0.f) ? g[d] : 0.f;
+        a1 += dy * xh;      // -> dgamma
+        a2 += dy;           // -> dbeta
+      }
+    }
+  }
+  s1[sg][nl] = a1;
+  s2[sg][nl] = a2;
+  __syncthreads();
+  if (sg == 0 && n < N) {
+    float* p = partial + (int64_t)blockIdx.y * 2 * N;
+    p[n] = (s1[0][nl] + s1[1][nl]) + (s1[2][nl] + s1[3][nl]);
+    p[N + n] = (s2[0][nl] + s2[1][nl]) + (s2[2][nl] + s2[3][nl]);
+  }
+}
+
+// ---- backward pass 2: dx [B,F,N] and the weight gradient -------------------------------------------
+//   training: dpre = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)) ;  eval: dpre = gamma*rstd*dy
+//   D*F <= 16 : dW accumulated in registers, block-reduced, one partial row per block (wpartial)
+//   otherwise : dpre [B,N,D] is written out and dW = sum_b dpre_b^T x_b runs on the MFMA batched-sum GEMM
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_bwd_apply(int B, int N, int training, const float* __restrict__ x, const float* __restrict__ W,
+                 const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                 const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ dgb,
+                 float* __restrict__ dpre_out, float* __restrict__ dx, float* __restrict__ wpartial) {
+  constexpr bool SMALL = (D * F <= 16);
+  constexpr int NW = SMALL ? D * F : 1;
+  __shared__ float red[(RO_T / 64) * NW];
+  const float* __restrict__ w = W;
+  const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int n = blockIdx.x * RO_NL + nl;
+  float gw[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) gw[j] = 0.f;
+  if (n < N) {
+    const int per = (B + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+    const float mu = mean[n], rs = rstd[n], ga = gamma[n], be = beta[n];
+    const float cnt = (float)B * D;
+    const float m1 = training ? dgb[N + n] / cnt : 0.f;     // mean(dy)
+    const float m2 = training ? dgb[n] / cnt : 0.f;         // mean(dy*xhat)
+    for (int b = b0 + sg; b < b1; b += RO_SG) {
+      float xv[F], pre[D], dxv[F];
+#pragma unroll
+      for (int c = 0; c < F; ++c) {
+        xv[c] = x[((int64_t)b * F + c) * N + n];
+        dxv[c] = 0.f;
+      }
+      ro_pre<F, D>(w, xv, pre);
+      const float* g = dout + ((int64_t)b * N + n) * D;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const float xh = (pre[d] - mu) * rs;
+        const float dy = (xh * ga + be > 0.f) ? g[d] : 0.f;
+        const float t = ga * rs * (dy - m1 - xh * m2);
+        if constexpr (SMALL) {
+#pragma unroll
+          for (int c = 0; c < F; ++c) gw[d * F + c] += t * xv[c];
+        } else {
+          dpre_out[((int64_t)b * N + n) * D + d] = t;
+        }
+#pragma unroll
+        for (int c = 0; c < F; ++c) dxv[c] += w[d * F + c] * t;
+      }
+#pragma unroll
+      for (int c = 0; c < F; ++c) dx[((int64_t)b * F + c) * N + n] = dxv[c];
+    }
+  }
+  if constexpr (SMALL)
+    block_reduce_vec<NW>(gw, red, wpartial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NW);
+}
+
+#define RO_DISPATCH(F, D, CALL)                                    \
+  if (F == 5 && D == 32) { CALL(5, 32); }                          \
+  else if (F == 5 && D == 48) { CALL(5, 48); }                     \
+  else if (F == 5 && D == 30) { CALL(5, 30); }                     \
+  else if (F == 5 && D == 20) { CALL(5, 20); }                     \
+  else if (F == 5 && D == 16) { CALL(5, 16); }                     \
+  else if (F == 5 && D == 12) { CALL(5, 12); }                     \
+  else if (F == 5 && D == 8) { CALL(5, 8); }                       \
+  else if (F == 5 && D == 5) { CALL(5, 5); }                       \
+  else if (F == 5 && D == 1) { CALL(5, 1); }                       \
+  else if (F == 2 && D == 1) { CALL(2, 1); }                       \
+  else {                                                           \
+    igcn_set_error("node_linear_bn: unsupported (F=%d, D=%d)", F, D); \
+    return IGCN_ERR_UNSUPPORTED;                                   \
+  }
+
+static int ro_chunks(int B) { return B >= 16 ? 16 : (B > 0 ? B : 1); }
+
+extern "C" size_t igcn_node_linear_bn_scratch_floats(int B, int N) { return (size_t)ro_chunks(B) * 2 * N + 64; }
+
+extern "C" int igcn_node_linear_bn_fwd(int B, int F, int N, int D, const float* x, const float* W,
+                                       const float* gamma, const float* beta, float* running_mean,
+                                       float* running_var, int training, float momentum, float eps, float* out,
+                                       float* save_mean, float* save_rstd, float* scratch, void* stream) {
+  IGCN_REQUIRE(B > 0 && N > 0, "node_linear_bn_fwd: bad sizes");
+  IGCN_REQUIRE(!training || (int64_t)B * D > 1, "node_linear_bn_fwd: need more than one value per node to train");
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = ro_chunks(B);
+  dim3 grid((unsigned)igcn_cdiv(N, RO_NL), chunks);
+#define CALL(FV, DV)                                                                                             \
+  if (training) hipLaunchKernelGGL((k_nlbn_stats<FV, DV>), grid, dim3(RO_T), 0, st, B, N, x, W, scratch);        \
+  hipLaunchKernelGGL((k_nlbn_finalize<FV, DV>), dim3((unsigned)igcn_cdiv(N, 64)), dim3(64), 0, st, B, N, chunks,  \
+                     training, eps, momentum, x, W, scratch, running_mean, running_var, save_mean, save_rstd);    \
+  hipLaunchKernelGGL((k_nlbn_apply<FV, DV>), grid, dim3(RO_T), 0, st, B, N, x, W, gamma, beta, save_mean,         \
+                     save_rstd, out)
+  RO_DISPATCH(F, D, CALL)
+#undef CALL
+  IGCN_CHECK_LAUNCH("node_linear_bn_fwd");
+  return IGCN_OK;
+}
+
+int igcn_gemm_f32_batched_sum_impl(int64_t M, int64_t N, int64_t K, int batch, const float* A, int64_t sam,
+                                   int64_t sak, int64_t a_batch, const float* B, int64_t sbn, int64_t sbk,
+                                   int64_t b_batch, float* C, int64_t ldc, float* scratch, hipStream_t st);
+
+extern "C" size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, int D) {
+  const size_t stats = (size_t)ro_chunks(B) * 2 * N;
+  const size_t blocks = (size_t)igcn_cdiv(N, RO_NL) * ro_chunks(B);
+  if (D * F <= 16) return stats + blocks * D * F + 64;
+  return stats + (size_t)B * N * D + (size_t)B * D * F + 64;
+}
+
+extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int training, const float* x, const float* W,
+                                       const float* gamma, const float* beta, const float* save_mean,
+                                       const float* save_rstd, const float* dout, float* dx, float* dW,
+                                       float* dgb /*[2,N]: dgamma, dbeta*/, float* scratch, void* stream) {
+  IGCN_REQUIRE(B > 0 && N > 0, "node_linear_bn_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = ro_chunks(B);
+  dim3 grid((unsigned)igcn_cdiv(N, RO_NL), chunks);
+  float* stats = scratch;
+  float* aux = scratch + (size_t)chunks * 2 * N;       // wpartial (small) or dpre then slabs (large)
+  const bool small = D * F <= 16;
+#define CALL(FV, DV)                                                                                              \
+  hipLaunchKernelGGL((k_nlbn_bwd_stats<FV, DV>), grid, dim3(RO_T), 0, st, B, N, x, W, gamma, beta, save_mean,      \
+                     save_rstd, dout, stats);                                                                      \
+  {                                                                                                                \
+    int rc = igcn_launch_reduce_rows(stats, chunks, 2 * (int64_t)N, 2 * N, dgb, 0, st);                            \
+    if (rc) return rc;                                                                                             \
+  }                                                                                                                \
+  hipLaunchKernelGGL((k_nlbn_bwd_apply<FV, DV>), grid, dim3(RO_T), 0, st, B, N, training, x, W, gamma, beta,       \
+                     save_mean, save_rstd, dout, dgb, aux, dx, aux)
+  RO_DISPATCH(F, D, CALL)
+#undef CALL
+  IGCN_CHECK_LAUNCH("node_linear_bn_bwd");
+  if (small) return igcn_launch_reduce_rows(aux, (int64_t)grid.x * grid.y, D * F, D * F, dW, 0, st);
+  // dW[d,c] = sum_b sum_n dpre[b,n,d] * x[b,c,n]
+  return igcn_gemm_f32_batched_sum_impl(D, F, N, B, aux, 1, D, (int64_t)N * D, x, N, 1, (int64_t)F * N, dW, F,
+                                        aux + (size_t)B * N * D, st);
+}

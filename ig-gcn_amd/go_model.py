@@ -98,6 +98,13 @@ class Gene_ontology_network(nn.Module):
     def _drop(self, x, p):
         return F.dropout(x, p, True) if (self.training and self._dropout_enabled) else x
 
+    def _node_linear_bn(self, x, weight, bn):
+        """relu(bn(linear(x))) with bn = BatchNorm1d(#nodes): one fused op (igcn_node_linear_bn_*)."""
+        if self.training and bn.track_running_stats:
+            bn.num_batches_tracked += 1
+        return ops.NodeLinearBN.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                      self.training, bn.momentum, bn.eps)
+
     def forward(self, data, T=None, device=None):
         bsz, dev = data.shape[0], data.device
         # gene encoding (:208-215)
@@ -109,12 +116,9 @@ class Gene_ontology_network(nn.Module):
                                       self.w_att_in[j].weight.view(-1), self.w_att_s[j].weight.view(-1), csr)
             x = ops.NodesLayerNorm.apply(y, self.G_B[j].weight, self.G_B[j].bias,
                                          self._node_keep(bsz, csr.n_rows, dev), self.pool[j], self.G_B[j].eps)
-        # read-outs (:254-255): BatchNorm1d(n_top) normalises per NODE over (batch, feature)
-        xt = x.transpose(1, 2)                                                            # [B, n_top, f]
-        atten_out = self.conc_for_attention[2](self.conc_for_attention[1](
-            F.linear(xt, self.conc_for_attention[0].weight)))
-        inp = F.linear(xt, self.conc.weight).squeeze(2)                                   # [B, n_top]
-        inp_out = self._drop(self.B[1](self.B[0](inp)), 0.5)
+        # read-outs (:254-255): BatchNorm1d(n_top) normalises per NODE over (batch, feature); fused kernels
+        atten_out = self._node_linear_bn(x, self.conc_for_attention[0].weight, self.conc_for_attention[1])
+        inp_out = self._drop(self._node_linear_bn(x, self.conc.weight, self.B[0]).squeeze(2), 0.5)
         # decoder (:258-275)
         for j in range(self.n_l):
             csr = self.dec_csr[j]
@@ -122,8 +126,7 @@ class Gene_ontology_network(nn.Module):
             x = ops.NodesLayerNorm.apply(y, self.G_B_D[j].weight, self.G_B_D[j].bias,
                                          self._node_keep(bsz, csr.n_rows, dev), 0, self.G_B_D[j].eps)
         # gene decoding (:278-282)
-        out_d = (x * self.conc_D.weight.view(1, -1, 1)).sum(1)                            # [B, N]
-        out_d = self._drop(self.B_D[1](self.B_D[0](out_d)), 0.5)
+        out_d = self._drop(self._node_linear_bn(x, self.conc_D.weight, self.B_D[0]).squeeze(2), 0.5)   # [B, N]
         x_d = ops.SparseMap.apply(out_d, self.t_D[0].unsqueeze(0), self.gene_t_csr).squeeze(1)   # [B, 54]
         # latent projection (:138-146,285)
         h = self._drop(self.latent[2](self.latent[1](self.latent[0](inp_out.view(bsz, -1)))), 0.5)

@@ -388,3 +388,104 @@ class GoDecode(torch.autograd.Function):
              ptr(x), ptr(w_out), ptr(w_sout), ptr(dy), ptr(dx), ptr(dpar), ptr(scratch), stream_ptr())
         k = fout * fin
         return dx, dpar[:k].view(fout, fin), dpar[k:].view(fout, fin), None
+
+
+# =================================================================================================
+# GO read-outs: node-wise linear + BatchNorm-over-nodes + ReLU
+# =================================================================================================
+class NodeLinearBN(torch.autograd.Function):
+    """relu(BatchNorm1d_N(W x)) for x [B,F,N] channel-major -> [B,N,D]  (go_model.py:117-136,254-255,278)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps):
+        x, weight, gamma, beta = _f32(x), _f32(weight), _f32(gamma), _f32(beta)
+        b, f, n = x.shape
+        d = weight.shape[0]
+        lib = _lib.load()
+        dev = x.device
+        out = torch.empty(b, n, d, dtype=torch.float32, device=dev)
+        mean, rstd = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(lib.igcn_node_linear_bn_scratch_floats(b, n)), dtype=torch.float32, device=dev)
+        call("igcn_node_linear_bn_fwd", b, f, n, d, ptr(x), ptr(weight), ptr(gamma), ptr(beta), ptr(running_mean),
+             ptr(running_var), int(training), float(momentum), float(eps), ptr(out), ptr(mean), ptr(rstd),
+             ptr(scratch), stream_ptr())
+        ctx.save_for_backward(x, weight, gamma, beta, mean, rstd)
+        ctx.training = int(training)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, gamma, beta, mean, rstd = ctx.saved_tensors
+        dout = _f32(dout)
+        b, f, n = x.shape
+        d = weight.shape[0]
+        lib = _lib.load()
+        dev = x.device
+        dx, dw = torch.empty_like(x), torch.empty_like(weight)
+        dgb = torch.empty(2, n, dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(lib.igcn_node_linear_bn_bwd_scratch_floats(b, f, n, d)), dtype=torch.float32,
+                              device=dev)
+        call("igcn_node_linear_bn_bwd", b, f, n, d, ctx.training, ptr(x), ptr(weight), ptr(gamma), ptr(beta),
+             ptr(mean), ptr(rstd), ptr(dout), ptr(dx), ptr(dw), ptr(dgb), ptr(scratch), stream_ptr())
+        return dx, dw, dgb[0], dgb[1], None, None, None, None, None
+
+
+# =================================================================================================
+# Loss terms
+# =================================================================================================
+class MaskRegulariser(torch.autograd.Function):
+    """loss_probability (kernel/sgcn_img_snp.py:153-181) as one reduction kernel + one elementwise backward."""
+
+    @staticmethod
+    def forward(ctx, prob, e, snps_prob, l1_x, ent_x, l1_e, ent_e, eps):
+        prob, e, snps_prob = _f32(prob), _f32(e), _f32(snps_prob)
+        dev = prob.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        scratch = torch.empty(128, dtype=torch.float32, device=dev)
+        ctx.hp = (float(l1_x), float(ent_x), float(l1_e), float(ent_e), float(eps))
+        call("igcn_mask_reg_fwd", prob.numel(), e.numel(), snps_prob.numel(), ptr(prob), ptr(e), ptr(snps_prob),
+             *ctx.hp, ptr(loss), ptr(scratch), stream_ptr())
+        ctx.save_for_backward(prob, e, snps_prob)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        prob, e, snps_prob = ctx.saved_tensors
+        gout = _f32(gout).reshape(1)
+        dprob, de, dsnps = torch.empty_like(prob), torch.empty_like(e), torch.empty_like(snps_prob)
+        call("igcn_mask_reg_bwd", prob.numel(), e.numel(), snps_prob.numel(), ptr(prob), ptr(e), ptr(snps_prob),
+             *ctx.hp, ptr(gout), ptr(dprob), ptr(de), ptr(dsnps), stream_ptr())
+        return dprob, de, dsnps, None, None, None, None, None
+
+
+def rbf_laplacian(tsne, n, gamma, device):
+    """Lap = diag(W1) - W with W = exp(-gamma*cdist(t,t)^2) (util/image_cluster.py:15-31); tsne None -> W = 1."""
+    lap = torch.empty(n, n, dtype=torch.float32, device=device)
+    t = _f32(tsne) if tsne is not None else None
+    call("igcn_rbf_laplacian", n, t.shape[1] if t is not None else 0, float(gamma), ptr(t), ptr(lap), stream_ptr())
+    return lap
+
+
+class GramLosses(torch.autograd.Function):
+    """(consist_loss, OrthogonalConstraint) of s [B,R*D] from one Gram matrix (sgcn_img_snp.py:183-205)."""
+
+    @staticmethod
+    def forward(ctx, s, lap):
+        s, lap = _f32(s), _f32(lap)
+        b, rd = s.shape
+        gram = gemm_nt(s, s)
+        out = torch.empty(2, dtype=torch.float32, device=s.device)
+        scratch = torch.empty(2 * b, dtype=torch.float32, device=s.device)
+        call("igcn_gram_loss_fwd", b, rd, ptr(gram), ptr(lap), ptr(out), ptr(scratch), stream_ptr())
+        ctx.save_for_backward(s, lap, gram)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_c, g_o):
+        s, lap, gram = ctx.saved_tensors
+        b = s.shape[0]
+        zero = torch.zeros((), dtype=torch.float32, device=s.device)
+        gout = torch.stack([g_c if g_c is not None else zero, g_o if g_o is not None else zero]).contiguous()
+        sym = torch.empty(b, b, dtype=torch.float32, device=s.device)
+        call("igcn_gram_loss_bwd", b, ptr(gram), ptr(lap), ptr(gout), ptr(sym), stream_ptr())
+        return gemm_nn(sym, s), None

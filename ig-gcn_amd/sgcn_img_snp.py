@@ -134,37 +134,49 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         return l1, ent
 
     def loss_probability(self, x, edge_index, edge_weight, hp, eps=1e-6, plan=None, edge_prob=None):
-        """:153-181.  ``edge_prob`` lets the train step reuse the mask the explain pass already computed."""
+        """:153-181 as one fused reduction (igcn_mask_reg_*).  ``edge_prob`` lets the train step reuse the mask
+        the explain pass already computed."""
         if edge_prob is None:
             _, _, _, edge_prob = self.cal_probability(x, edge_index, edge_weight, plan=plan)
-        f_l1, f_ent = self._l1_entropy(torch.sigmoid(self.prob), eps)
-        e_l1, e_ent = self._l1_entropy(edge_prob, eps)
-        s_l1, s_ent = self._l1_entropy(torch.sigmoid(self.snps_prob), eps)
-        loss_l1 = hp.lamda_x_l1 * f_l1 + hp.lamda_e_l1 * e_l1 + hp.lamda_x_l1 * s_l1
-        loss_ent = hp.lamda_x_ent * f_ent + hp.lamda_e_ent * e_ent + hp.lamda_x_ent * s_ent
-        return loss_l1 + loss_ent
+        return ops.MaskRegulariser.apply(self.prob, edge_prob, self.snps_prob, hp.lamda_x_l1, hp.lamda_x_ent,
+                                         hp.lamda_e_l1, hp.lamda_e_ent, eps)
+
+    def laplacian(self, n, tsne_result=None):
+        """D - W of consist_loss (:188-193): RBF similarity of the t-SNE embedding, or all-ones."""
+        soft = self.isSoftSimilarity and tsne_result is not None
+        return ops.rbf_laplacian(tsne_result if soft else None, n, self.rbf_gamma, self.prob.device)
+
+    def batch_losses(self, s, lap):
+        """(consist_loss(s), OrthogonalConstraint(s)) from ONE B x B Gram matrix s s^T (igcn_gram_loss_*):
+        tr(s^T Lap s) = sum_ij Lap_ij G_ij and ||Wn^T Wn - I||_F^2 = sum_ij G_ij^2/(G_ii G_jj) - 2B + R*D."""
+        return ops.GramLosses.apply(s, lap)
 
     def consist_loss(self, s, tsne_result=None):
-        """:183-196 — tr(s^T (D-W) s)/B^2 evaluated as (sum_i d_i |s_i|^2 - sum_ij W_ij s_i.s_j)/B^2."""
+        """:183-196."""
         if len(s) == 0:
             return 0
-        b = s.shape[0]
-        if self.isSoftSimilarity and tsne_result is not None:
-            w = rbf_kernel_torch(tsne_result, tsne_result, gamma=self.rbf_gamma)
-        else:
-            w = torch.ones(b, b, device=s.device, dtype=s.dtype)
-        gram = s @ s.t()
-        return ((w.sum(dim=1) * gram.diagonal()).sum() - (w * gram).sum()) / (b * b)
+        return self.batch_losses(s, self.laplacian(s.shape[0], tsne_result))[0]
 
     def OrthogonalConstraint(self, w):
-        """:198-205 via ||Wn^T Wn - I||_F^2 = ||Wn Wn^T||_F^2 - 2 tr(Wn Wn^T) + R*D, Wn rows unit norm."""
-        wn = w / w.norm(dim=1)[:, None]
-        gram = wn @ wn.t()
-        pen = (gram * gram).sum() - 2.0 * gram.diagonal().sum() + wn.shape[1]
-        return pen / (wn.shape[0] * wn.shape[0])
+        """:198-205 (the Laplacian factor is irrelevant for this term)."""
+        return self.batch_losses(w, torch.zeros(w.shape[0], w.shape[0], device=w.device))[1]
 
     def _drop(self, x, p):
         return F.dropout(x, p, True) if (self.training and self._dropout_enabled) else x
+
+    def _cross_attention(self, query, memory):
+        """nn.MultiheadAttention(D, 2, batch_first=True)(query, memory, memory)[0] (:240) with the parameters of
+        ``self.multihead_attn``: projections on the MFMA GEMM (their weight gradients reduce over B*L rows,
+        split-K), attention core = library scaled-dot-product kernel."""
+        mha = self.multihead_attn
+        d, h = mha.embed_dim, mha.num_heads
+        b, lq, lk = query.shape[0], query.shape[1], memory.shape[1]
+        w, bias = mha.in_proj_weight, mha.in_proj_bias
+        q = ops.linear(query, w[:d], bias[:d]).view(b, lq, h, d // h).transpose(1, 2)
+        kv = ops.linear(memory, w[d:], bias[d:]).view(b, lk, 2, h, d // h)
+        k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, lq, d)
+        return ops.linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, data, temperature=None, device=None, isExplain=False):
@@ -195,8 +207,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
 
         latent, x_hat, _, atten_out = self.go_network(snps_m, temperature, device)
         if self.isCrossAtten:
-            attn, _ = self.multihead_attn(batch_x, atten_out, atten_out, need_weights=False)
-            out_cross = F.relu(attn).reshape(bsz, -1)
+            out_cross = F.relu(self._cross_attention(batch_x, atten_out)).reshape(bsz, -1)
         else:
             out_cross = torch.cat((img_out, latent), -1)
 

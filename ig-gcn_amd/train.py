@@ -77,15 +77,20 @@ def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None):
     t["recon"] = lam[3] * (torch.sum((snps_hat - data.snps_feat) ** 2)
                            + torch.sum((snps_hat_p - data.snps_feat) ** 2)) / 2
     if model.isSoftSimilarity:
-        t["cluster"] = lam[4] * (model.consist_loss(out_feat, data.tsne_fdim)
-                                 + model.consist_loss(out_feat_p, data.tsne_fdim)) / 2
+        # the RBF Laplacian depends on the batch only: built once, shared by both passes; consist_loss and
+        # OrthogonalConstraint of the plain pass come from the same Gram matrix
+        lap = model.laplacian(out_feat.shape[0], data.tsne_fdim)
+        c1, orth = model.batch_losses(out_feat, lap)
+        c2, _ = model.batch_losses(out_feat_p, lap)
+        t["cluster"] = lam[4] * (c1 + c2) / 2
     else:
+        orth = None
         t["cluster"] = 0.0
         for c in range(2):
             sel = data.clust_y.view(-1) == c
             t["cluster"] = t["cluster"] + lam[4] * (model.consist_loss(out_feat[sel])
                                                     + model.consist_loss(out_feat_p[sel])) / 2
-    t["orth"] = lam[5] * model.OrthogonalConstraint(out_feat)
+    t["orth"] = lam[5] * (orth if orth is not None else model.OrthogonalConstraint(out_feat))
     if lam[0] == 0:
         t["ce"], t["mi"] = 0.0, 0.0
     loss = hp.lamda_ce * t["ce"] + hp.lamda_mi * t["mi"] + t["reg"] + t["prob"] + t["recon"] + t["cluster"] \

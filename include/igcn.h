@@ -126,6 +126,62 @@ int igcn_gemm_f32(int64_t M, int64_t N, int64_t K,
                   const float* bias, float* C, int64_t ldc, int act, int split_k, float* scratch,
                   void* stream);
 
+/* Batched-sum variant: C = sum_z A_z . B_z^T with A_z = A + z*a_batch, B_z = B + z*b_batch (element offsets),
+ * every z covering the whole K; slabs are summed in z order.  Used for weight gradients whose reduction index is
+ * (sample, node) over channel-major activations.  scratch: float[batch*M*N]. */
+int igcn_gemm_f32_batched_sum(int64_t M, int64_t N, int64_t K, int batch,
+                              const float* A, int64_t sam, int64_t sak, int64_t a_batch,
+                              const float* B, int64_t sbn, int64_t sbk, int64_t b_batch,
+                              float* C, int64_t ldc, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GO read-outs: per-node linear + BatchNorm1d(#nodes) + ReLU, fused — go_model.py:117-121,254
+ * (conc_for_attention, D = dim_snps_atten), :123-128,255 (conc + B, D = 1), :130-136,278 (conc_D + B_D, D = 1):
+ *   pre[b,n,:] = W x[b,:,n]   (x [B,F,N] channel-major, W [D,F])
+ *   out[b,n,:] = relu((pre - mean_n)*rstd_n*gamma[n] + beta[n])      out [B,N,D]
+ * BatchNorm1d(N) on [B,N,D] normalises every node over (batch, feature); training != 0 uses batch statistics
+ * (biased variance) and updates running_mean/var (momentum, unbiased variance), else the running ones.
+ * scratch: igcn_node_linear_bn_scratch_floats(B,N).
+ */
+size_t igcn_node_linear_bn_scratch_floats(int B, int N);
+int igcn_node_linear_bn_fwd(int B, int F, int N, int D, const float* x, const float* W,
+                            const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            int training, float momentum, float eps,
+                            float* out, float* save_mean, float* save_rstd, float* scratch, void* stream);
+/* Outputs dx [B,F,N], dW [D,F], dgb [2,N] = (dgamma, dbeta).  dW = sum_{b,n} dpre[b,n,:] (x) x[b,:,n] is formed in
+ * registers when D*F <= 16, else on the MFMA batched-sum GEMM.
+ * scratch: igcn_node_linear_bn_bwd_scratch_floats(B,F,N,D). */
+size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, int D);
+int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int training, const float* x, const float* W,
+                            const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
+                            const float* dout, float* dx, float* dW, float* dgb, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mask regulariser — loss_probability, kernel/sgcn_img_snp.py:153-181:
+ *   loss = mean r_x(sigmoid(prob)) + mean r_e(e) + mean r_x(sigmoid(snps_prob)),
+ *   r(p) = l1*|p| - ent*(p log(p+eps) + (1-p) log(1-p+eps))
+ * prob [n_prob] and snps [n_snps] are logits, e [n_edge] the edge mask of igcn_edge_mask_fwd.
+ * scratch: float[128].  gout: device scalar d(loss_total)/d(loss).
+ */
+int igcn_mask_reg_fwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const float* prob, const float* e,
+                      const float* snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,
+                      float* loss, float* scratch, void* stream);
+int igcn_mask_reg_bwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const float* prob, const float* e,
+                      const float* snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,
+                      const float* gout, float* dprob, float* de, float* dsnps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch-level losses from ONE Gram matrix G = s s^T [B,B] of the fused features s [B, R*D]:
+ *   out[0] = consist_loss (kernel/sgcn_img_snp.py:183-196) = sum_ij Lap_ij G_ij / B^2
+ *   out[1] = OrthogonalConstraint (:198-205) = (sum_ij G_ij^2/(G_ii G_jj) - 2B + RD)/B^2
+ * igcn_rbf_laplacian builds Lap = diag(W1) - W, W = exp(-gamma*||t_i-t_j||^2) (util/image_cluster.py:15-31;
+ * t == NULL: W = 1).  The backward writes S = dG + dG^T [B,B] (ds = S s); gout [2] is a device array.
+ * scratch (fwd): float[2B].
+ */
+int igcn_rbf_laplacian(int B, int T, float gamma, const float* t, float* Lap, void* stream);
+int igcn_gram_loss_fwd(int B, int RD, const float* G, const float* Lap, float* out, float* scratch, void* stream);
+int igcn_gram_loss_bwd(int B, const float* G, const float* Lap, const float* gout, float* S, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Sparse SNP<->GO maps with learnable non-zeros — gene encoding go_model.py:208-215 (C=2 channels,
  * rows = GO nodes, cols = SNPs) and gene decoding :281-282 (C=1, rows = SNPs, cols = GO nodes):

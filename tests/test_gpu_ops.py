@@ -290,3 +290,72 @@ def test_adam_matches_torch(ops):
         opt_ref.step()
     for p, r in zip(ps, ref):
         assert torch.allclose(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ read-outs / losses
+@pytest.mark.parametrize("bsz,f,n,d,training", [(6, 5, 11, 5, True), (32, 5, 400, 32, True), (32, 5, 400, 1, True),
+                                                 (16, 2, 3000, 1, True), (8, 5, 70, 8, False), (5, 5, 33, 12, True)])
+def test_node_linear_bn(ops, bsz, f, n, d, training):
+    rng = np.random.default_rng(n + d)
+    x = torch.from_numpy(rng.standard_normal((bsz, f, n)) + 0.5).float()
+    w = torch.from_numpy(rng.standard_normal((d, f)) * 0.6).float()
+    gamma = torch.from_numpy(1 + 0.2 * rng.standard_normal(n)).float()
+    beta = torch.from_numpy(0.2 * rng.standard_normal(n)).float()
+    rm0 = torch.from_numpy(0.1 * rng.standard_normal(n)).float()
+    rv0 = torch.from_numpy(1 + 0.3 * rng.random(n)).float()
+    cot = torch.from_numpy(rng.standard_normal((bsz, n, d))).float()
+    ref_in = [t.double().requires_grad_(True) for t in (x, w, gamma, beta)]
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    pre = ref_in[0].transpose(1, 2) @ ref_in[1].t()                       # [B,N,D]
+    out_ref = torch.relu(torch.nn.functional.batch_norm(pre, rm, rv, ref_in[2], ref_in[3], training, 0.1, 1e-5))
+    g_ref = torch.autograd.grad((out_ref * cot.double()).sum(), ref_in)
+    dev = [t.cuda().requires_grad_(True) for t in (x, w, gamma, beta)]
+    rmg, rvg = rm0.cuda(), rv0.cuda()
+    out = ops.NodeLinearBN.apply(dev[0], dev[1], dev[2], dev[3], rmg, rvg, training, 0.1, 1e-5)
+    g = torch.autograd.grad((out * cot.cuda()).sum(), dev)
+    assert_matches(out, out_ref.detach().numpy(), TOL, "out")
+    for got, want, nm in zip(g, g_ref, ("dx", "dW", "dgamma", "dbeta")):
+        assert_matches(got, want.numpy(), 3e-4, nm, floor=1e-6)
+    assert_matches(rmg, rm.numpy(), TOL, "running_mean")
+    assert_matches(rvg, rv.numpy(), TOL, "running_var")
+
+
+def test_mask_regulariser(ops):
+    from oracle import sgcn_img_snp as OS
+    rng = np.random.default_rng(3)
+    prob = torch.from_numpy(rng.standard_normal((90, 3))).float()
+    snps = torch.from_numpy(rng.standard_normal((1, 54))).float()
+    e = torch.from_numpy(rng.random(5000) * 0.98 + 0.01).float()
+    ref_in = [t.double().requires_grad_(True) for t in (prob, e, snps)]
+    hp = OS.HP
+    parts = [OS._bin_entropy_and_l1(torch.sigmoid(ref_in[0]), 1e-6), OS._bin_entropy_and_l1(ref_in[1], 1e-6),
+             OS._bin_entropy_and_l1(torch.sigmoid(ref_in[2]), 1e-6)]
+    ref = hp.lamda_x_l1 * parts[0][0] + hp.lamda_e_l1 * parts[1][0] + hp.lamda_x_l1 * parts[2][0] \
+        + hp.lamda_x_ent * parts[0][1] + hp.lamda_e_ent * parts[1][1] + hp.lamda_x_ent * parts[2][1]
+    g_ref = torch.autograd.grad(ref * 1.7, ref_in)
+    dev = [t.cuda().requires_grad_(True) for t in (prob, e, snps)]
+    got = ops.MaskRegulariser.apply(dev[0], dev[1], dev[2], hp.lamda_x_l1, hp.lamda_x_ent, hp.lamda_e_l1,
+                                    hp.lamda_e_ent, 1e-6)
+    g = torch.autograd.grad(got * 1.7, dev)
+    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref))
+    for a, b, nm in zip(g, g_ref, ("dprob", "de", "dsnps")):
+        assert_matches(a, b.numpy(), TOL, nm)
+
+
+@pytest.mark.parametrize("bsz,rd,soft", [(7, 40, True), (64, 2880, True), (32, 300, False)])
+def test_gram_losses(ops, bsz, rd, soft):
+    from oracle import sgcn_img_snp as OS
+    rng = np.random.default_rng(bsz)
+    s = torch.from_numpy(rng.standard_normal((bsz, rd)) + 0.3).float()
+    tsne = torch.from_numpy(rng.random((bsz, 16)) * 3).float()
+    sr = s.double().requires_grad_(True)
+    c_ref = OS.consist_loss(sr, tsne.double() if soft else None, 0.01, soft=soft)
+    o_ref = OS.orthogonal_constraint(sr)
+    g_ref = torch.autograd.grad(0.7 * c_ref + 0.3 * o_ref, sr)[0]
+    sg = s.cuda().requires_grad_(True)
+    lap = ops.rbf_laplacian(tsne.cuda() if soft else None, bsz, 0.01, "cuda")
+    c, o = ops.GramLosses.apply(sg, lap)
+    g = torch.autograd.grad(0.7 * c + 0.3 * o, sg)[0]
+    assert abs(float(c) - float(c_ref)) <= 1e-4 * max(abs(float(c_ref)), 1e-6)
+    assert abs(float(o) - float(o_ref)) <= 1e-4 * max(abs(float(o_ref)), 1e-6)
+    assert_matches(g, g_ref.numpy(), 2e-4, "ds")
