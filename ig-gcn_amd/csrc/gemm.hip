@@ -18,19 +18,19 @@ __global__ void __launch_bounds__(256)
 k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,
            const float* __restrict__ B, int64_t sbn, int64_t sbk, const float* __restrict__ bias,
            float* __restrict__ C, int64_t ldc, int act, int64_t k_per_split, int64_t slab_stride,
-           int64_t a_zs, int64_t b_zs) {
+           int64_t a_zs, int64_t b_zs, int zsplit) {
   __shared__ float As[G_BM][G_BK + 1];
   __shared__ float Bs[BN][G_BK + 1];
   constexpr int NT = BN / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * G_BM, n0 = (int64_t)blockIdx.y * BN;
-  // gridDim.z slices either the K axis (a_zs == b_zs == 0) or a batch of independent products whose
-  // slabs are summed afterwards (a_zs/b_zs = element offsets of operand z)
-  const bool batched = (a_zs != 0 || b_zs != 0);
-  const int64_t k_begin = batched ? 0 : (int64_t)blockIdx.z * k_per_split;
-  const int64_t k_end = batched ? K : (k_begin + k_per_split < K ? k_begin + k_per_split : K);
-  A += (int64_t)blockIdx.z * a_zs;
-  B += (int64_t)blockIdx.z * b_zs;
+  // blockIdx.z = (batch index) * zsplit + (K slice): K slices of one product (a_zs == b_zs == 0) and/or a batch
+  // of independent products (a_zs/b_zs = element offsets per batch) whose slabs are all summed afterwards
+  const int64_t bidx = blockIdx.z / zsplit, ks = blockIdx.z % zsplit;
+  const int64_t k_begin = ks * k_per_split;
+  const int64_t k_end = k_begin + k_per_split < K ? k_begin + k_per_split : K;
+  A += bidx * a_zs;
+  B += bidx * b_zs;
   const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
 
   f32x4 acc[NT];
@@ -120,7 +120,7 @@ extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, in
   dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)split_k);
 #define LAUNCH_G(BNV)                                                                                          \
   hipLaunchKernelGGL((k_gemm_f32<BNV>), grid, dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk, bias, out, ld, \
-                     act, kps, slab, (int64_t)0, (int64_t)0)
+                     act, kps, slab, (int64_t)0, (int64_t)0, split_k)
   if (bn == 16) { LAUNCH_G(16); } else if (bn == 32) { LAUNCH_G(32); } else { LAUNCH_G(64); }
 #undef LAUNCH_G
   IGCN_CHECK_LAUNCH("gemm_f32");
@@ -154,16 +154,22 @@ int igcn_gemm_f32_batched_sum_impl(int64_t M, int64_t N, int64_t K, int batch, c
   IGCN_REQUIRE(M > 0 && N > 0 && K > 0 && batch >= 1 && scratch != nullptr && (a_batch != 0 || b_batch != 0),
                "gemm_f32_batched_sum: bad arguments");
   const int bn = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
-  dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)batch);
+  // long K per product: also slice K so that ~2k workgroups are in flight (slabs = batch * ksplit)
+  int ksplit = 1;
+  while (ksplit < 16 && (int64_t)batch * ksplit * 2 <= 2048 && K / (ksplit * 2) >= 128) ksplit *= 2;
+  const int64_t kps = igcn_cdiv(igcn_cdiv(K, ksplit), G_BK) * G_BK;
+  ksplit = (int)igcn_cdiv(K, kps);
+  const int slabs = batch * ksplit;
+  dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)slabs);
 #define LAUNCH_B(BNV)                                                                                           \
   hipLaunchKernelGGL((k_gemm_f32<BNV>), grid, dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk,               \
-                     (const float*)nullptr, scratch, N, 0, K, M * N, a_batch, b_batch)
+                     (const float*)nullptr, scratch, N, 0, kps, M * N, a_batch, b_batch, ksplit)
   if (bn == 16) { LAUNCH_B(16); } else if (bn == 32) { LAUNCH_B(32); } else { LAUNCH_B(64); }
 #undef LAUNCH_B
   IGCN_CHECK_LAUNCH("gemm_f32_batched_sum");
-  if (ldc == N && M * N <= 4096 && batch > 32)     // few outputs, many slabs: block-per-output tree reduce
-    return igcn_launch_reduce_rows(scratch, batch, M * N, (int)(M * N), C, 0, st);
-  hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3((unsigned)igcn_cdiv(M * N, 256)), dim3(256), 0, st, M, N, batch,
+  if (ldc == N && M * N <= 4096 && slabs > 32)     // few outputs, many slabs: block-per-output tree reduce
+    return igcn_launch_reduce_rows(scratch, slabs, M * N, (int)(M * N), C, 0, st);
+  hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3((unsigned)igcn_cdiv(M * N, 256)), dim3(256), 0, st, M, N, slabs,
                      scratch, (const float*)nullptr, C, ldc, 0);
   IGCN_CHECK_LAUNCH("gemm_batched_reduce");
   return IGCN_OK;

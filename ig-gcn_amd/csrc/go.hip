@@ -290,101 +290,153 @@ k_go_attn_bwd_stats(int B, int N, const int32_t* __restrict__ row_ptr, const int
 }
 
 // ---- backward, kernel B: input gradient + block partials of the parameter gradients ------------
-#define GO_SB 1  // samples per thread: 1 keeps the longest per-thread edge walk (the root's children) short
+// One thread per (sample, node).  A node's row list (its parents) is short, but its COLUMN list (the rows that
+// read it = its children) can be long for hub nodes (the root feeds every level-1 term): columns longer than
+// GO_HEAVY are walked by the whole wave (lanes stride the list, wave reduction), so the kernel's duration is
+// not set by one thread's serial walk.
+#define GO_SB 1
+#define GO_HEAVY 12
 template <int FIN, int FOUT>
 __global__ void __launch_bounds__(GO_T)
 k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
                    const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ t_row,
                    const float* __restrict__ x, const float* __restrict__ w_inc, const float* __restrict__ w_s,
                    const float* __restrict__ a_in, const float* __restrict__ a_s, const float* __restrict__ dy,
-                   const float* __restrict__ stats, float* __restrict__ dx, float* __restrict__ partial) {
-  constexpr int NW = 2 * FOUT * FIN + 3 * FOUT;
-  __shared__ float red[(GO_T / 64) * NW];
+                   const float* __restrict__ stats, float* __restrict__ dx, float* __restrict__ u) {
   AttnW<FIN, FOUT> W;
   W.load(w_inc, w_s, a_in, a_s);
   const int n = blockIdx.x * GO_T + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
   const int64_t BN = (int64_t)B * N;
-  float gw[NW];
+  const bool live = n < N;
+  const int nn = live ? n : N - 1;                 // dead lanes shadow a valid node, results discarded
+  const float* xb = x + (int64_t)b * FIN * N;
+  const float* dyb = dy + (int64_t)b * FOUT * N;
+  const float* sp = stats + (int64_t)b * N;        // p ; q at +BN ; zinv at +2BN ; tr at +3BN
+  const int32_t r0 = row_ptr[nn], r1 = row_ptr[nn + 1];
+  const int32_t c0 = t_ptr[nn], c1 = t_ptr[nn + 1];
+  float xr[FIN], xin[FOUT], xs[FOUT], dyn[FOUT];
+  load_node<FIN>(xb, N, nn, xr);
+  load_node<FOUT>(dyb, N, nn, dyn);
+  transform<FIN, FOUT>(W.wi, xr, xin);
+  transform<FIN, FOUT>(W.ws, xr, xs);
+  const float p_n = sp[nn], q_n = sp[BN + nn], zinv_n = sp[2 * BN + nn], tr_n = sp[3 * BN + nn];
+  // n as ROW: d(score) of its own edges
+  float dp = 0.f;
+  for (int32_t e = r0; e < r1; ++e) {
+    const int m = col[e];
+    float xm[FIN], xim[FOUT];
+    load_node<FIN>(xb, N, m, xm);
+    transform<FIN, FOUT>(W.wi, xm, xim);
+    const float th = tanhf(p_n + sp[BN + m]);
+    const float alpha = expf(th) * zinv_n;
+    dp += (dot<FOUT>(dyn, xim) - tr_n) * alpha * (1.f - th * th);
+  }
+  // n as COLUMN: what the rows reading n send back
+  float dq = 0.f, dxin[FOUT];
 #pragma unroll
-  for (int j = 0; j < NW; ++j) gw[j] = 0.f;
-  if (n < N) {
-    const int32_t r0 = row_ptr[n], r1 = row_ptr[n + 1];
-    const int32_t c0 = t_ptr[n], c1 = t_ptr[n + 1];
-    const int b_end = min(B, (int)(blockIdx.y + 1) * GO_SB);
-    for (int b = blockIdx.y * GO_SB; b < b_end; ++b) {
-      const float* xb = x + (int64_t)b * FIN * N;
-      const float* dyb = dy + (int64_t)b * FOUT * N;
-      const float* sp = stats + (int64_t)b * N;  // p ; q at +BN ; zinv at +2BN ; tr at +3BN
-      float xr[FIN], xin[FOUT], xs[FOUT], dyn[FOUT];
-      load_node<FIN>(xb, N, n, xr);
-      load_node<FOUT>(dyb, N, n, dyn);
-      transform<FIN, FOUT>(W.wi, xr, xin);
-      transform<FIN, FOUT>(W.ws, xr, xs);
-      const float p_n = sp[n], q_n = sp[BN + n], zinv_n = sp[2 * BN + n], tr_n = sp[3 * BN + n];
-      // n as ROW: d(score) of its own edges
-      float dp = 0.f;
-#pragma unroll 2
-      for (int32_t e = r0; e < r1; ++e) {
-        const int m = col[e];
-        float xm[FIN], xim[FOUT];
-        load_node<FIN>(xb, N, m, xm);
-        transform<FIN, FOUT>(W.wi, xm, xim);
-        const float th = tanhf(p_n + sp[BN + m]);
-        const float alpha = expf(th) * zinv_n;
-        dp += (dot<FOUT>(dyn, xim) - tr_n) * alpha * (1.f - th * th);
-      }
-      // n as COLUMN: what the rows reading n send back
-      float dq = 0.f, dxin[FOUT];
+  for (int c = 0; c < FOUT; ++c) dxin[c] = 0.f;
+  const bool heavy = live && (c1 - c0 > GO_HEAVY);
+  if (!heavy) {
+    for (int32_t e = c0; e < c1; ++e) {
+      const int r = t_row[e];
+      float dyr[FOUT];
+      load_node<FOUT>(dyb, N, r, dyr);
+      const float th = tanhf(sp[r] + q_n);
+      const float alpha = expf(th) * sp[2 * BN + r];
+      dq += (dot<FOUT>(dyr, xin) - sp[3 * BN + r]) * alpha * (1.f - th * th);
 #pragma unroll
-      for (int c = 0; c < FOUT; ++c) dxin[c] = 0.f;
-#pragma unroll 4
-      for (int32_t e = c0; e < c1; ++e) {
-        const int r = t_row[e];
-        float dyr[FOUT];
-        load_node<FOUT>(dyb, N, r, dyr);
-        const float th = tanhf(sp[r] + q_n);
-        const float alpha = expf(th) * sp[2 * BN + r];
-        dq += (dot<FOUT>(dyr, xin) - sp[3 * BN + r]) * alpha * (1.f - th * th);
-#pragma unroll
-        for (int c = 0; c < FOUT; ++c) dxin[c] += alpha * dyr[c];
-      }
-#pragma unroll
-      for (int c = 0; c < FOUT; ++c) dxin[c] += dp * W.a1[c] + dq * W.a2[c];
-      // gated self term
-      const float g = 1.f / (1.f + expf(-dot<FOUT>(W.as, xs)));
-      const float dgate = dot<FOUT>(dyn, xs) * g * (1.f - g);
-      float dxs[FOUT];
-#pragma unroll
-      for (int c = 0; c < FOUT; ++c) dxs[c] = dyn[c] * g + dgate * W.as[c];
-      // input gradient
-      float* dxb = dx + (int64_t)b * FIN * N;
-#pragma unroll
-      for (int d = 0; d < FIN; ++d) {
-        float t = 0.f;
-#pragma unroll
-        for (int c = 0; c < FOUT; ++c) t += W.wi[c][d] * dxin[c] + W.ws[c][d] * dxs[c];
-        dxb[(int64_t)d * N + n] = t;
-      }
-      // parameter gradients
-#pragma unroll
-      for (int c = 0; c < FOUT; ++c) {
-#pragma unroll
-        for (int d = 0; d < FIN; ++d) {
-          gw[c * FIN + d] += dxin[c] * xr[d];
-          gw[FOUT * FIN + c * FIN + d] += dxs[c] * xr[d];
-        }
-        gw[2 * FOUT * FIN + c] += dp * xin[c];
-        gw[2 * FOUT * FIN + FOUT + c] += dq * xin[c];
-        gw[2 * FOUT * FIN + 2 * FOUT + c] += dgate * xs[c];
-      }
+      for (int c = 0; c < FOUT; ++c) dxin[c] += alpha * dyr[c];
     }
   }
-  block_reduce_vec<NW>(gw, red, partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NW);
+  unsigned long long hmask = __ballot(heavy);
+  while (hmask) {                                   // wave-uniform loop over this wave's hub nodes
+    const int src = __ffsll((long long)hmask) - 1;
+    hmask &= hmask - 1;
+    const int32_t hc0 = __shfl(c0, src, 64), hc1 = __shfl(c1, src, 64);
+    const float hq = __shfl(q_n, src, 64);
+    float hxin[FOUT];
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) hxin[c] = __shfl(xin[c], src, 64);
+    float pdq = 0.f, pdx[FOUT];
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) pdx[c] = 0.f;
+    for (int32_t e = hc0 + lane; e < hc1; e += 64) {
+      const int r = t_row[e];
+      float dyr[FOUT];
+      load_node<FOUT>(dyb, N, r, dyr);
+      const float th = tanhf(sp[r] + hq);
+      const float alpha = expf(th) * sp[2 * BN + r];
+      pdq += (dot<FOUT>(dyr, hxin) - sp[3 * BN + r]) * alpha * (1.f - th * th);
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) pdx[c] += alpha * dyr[c];
+    }
+    pdq = wave_sum_all(pdq);
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) pdx[c] = wave_sum_all(pdx[c]);
+    if (lane == src) {
+      dq = pdq;
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) dxin[c] = pdx[c];
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) dxin[c] += dp * W.a1[c] + dq * W.a2[c];
+    // gated self term
+    const float g = 1.f / (1.f + expf(-dot<FOUT>(W.as, xs)));
+    const float dgate = dot<FOUT>(dyn, xs) * g * (1.f - g);
+    float dxs[FOUT];
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) dxs[c] = dyn[c] * g + dgate * W.as[c];
+    // input gradient
+    float* dxb = dx + (int64_t)b * FIN * N;
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) {
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) t += W.wi[c][d] * dxin[c] + W.ws[c][d] * dxs[c];
+      dxb[(int64_t)d * N + n] = t;
+    }
+    // rows for the parameter-gradient product  G[13,FIN] = sum_{b,n} u[b,:,n] (x) x[b,:,n]  (MFMA batched-sum
+    // GEMM): u = (dxin[FOUT], dxs[FOUT], dp, dq, dgate), channel-major so the stores are coalesced
+    float* ub = u + (int64_t)b * (2 * FOUT + 3) * N;
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) {
+      ub[(int64_t)c * N + n] = dxin[c];
+      ub[(int64_t)(FOUT + c) * N + n] = dxs[c];
+    }
+    ub[(int64_t)(2 * FOUT) * N + n] = dp;
+    ub[(int64_t)(2 * FOUT + 1) * N + n] = dq;
+    ub[(int64_t)(2 * FOUT + 2) * N + n] = dgate;
+  }
 }
 
+// dparams = (dW_inc [FOUT,FIN], dW_s [FOUT,FIN], da_in [2 FOUT], da_s [FOUT]) from G [2 FOUT + 3, FIN]:
+//   da1 = W_inc (sum dp x), da2 = W_inc (sum dq x), da_s = W_s (sum dgate x)      (x_in = W_inc x, x_s = W_s x)
+__global__ void k_go_attn_bwd_finish(int fin, int fout, const float* __restrict__ G, const float* __restrict__ w_inc,
+                                     const float* __restrict__ w_s, float* __restrict__ dparams) {
+  const int j = threadIdx.x;
+  const int k = fout * fin;
+  if (j < 2 * k) {
+    dparams[j] = G[j];
+  } else if (j < 2 * k + 3 * fout) {
+    const int q = j - 2 * k, which = q / fout, c = q % fout;        // which: 0 -> a1, 1 -> a2, 2 -> a_s
+    const float* w = which == 2 ? w_s : w_inc;
+    float t = 0.f;
+    for (int d = 0; d < fin; ++d) t += w[c * fin + d] * G[(2 * fout + which) * fin + d];
+    dparams[j] = t;
+  }
+}
+
+int igcn_gemm_f32_batched_sum_impl(int64_t M, int64_t N, int64_t K, int batch, const float* A, int64_t sam,
+                                   int64_t sak, int64_t a_batch, const float* B, int64_t sbn, int64_t sbk,
+                                   int64_t b_batch, float* C, int64_t ldc, float* scratch, hipStream_t st);
+
 extern "C" size_t igcn_go_attn_bwd_scratch_floats(int B, int N, int fin, int fout) {
-  const int64_t nw = 2 * fout * fin + 3 * fout;
-  return (size_t)(4 * (int64_t)B * N + igcn_cdiv(N, GO_T) * igcn_cdiv(B, GO_SB) * nw + 64);
+  const int64_t rows = 2 * fout + 3;
+  return (size_t)(4 * (int64_t)B * N + rows * (int64_t)B * N + 16 * (int64_t)B * rows * fin + rows * fin + 64);
 }
 
 extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
@@ -393,20 +445,27 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
                                 float* dparams, float* scratch, void* stream) {
   IGCN_REQUIRE(B > 0 && N > 0, "go_attn_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = 2 * fout + 3;
   float* stats = scratch;
-  float* partial = scratch + 4 * (int64_t)B * N;
-  dim3 gridA((unsigned)igcn_cdiv(N, GO_T), B);
-  dim3 gridB((unsigned)igcn_cdiv(N, GO_T), (unsigned)igcn_cdiv(B, GO_SB));
-  const int nw = 2 * fout * fin + 3 * fout;
-#define CALL(FI, FO)                                                                                              \
-  hipLaunchKernelGGL((k_go_attn_bwd_stats<FI, FO>), gridA, dim3(GO_T), 0, st, B, N, row_ptr, col, x, w_inc, a_in, \
+  float* u = stats + 4 * (int64_t)B * N;
+  float* G = u + rows * (int64_t)B * N;
+  float* slabs = G + rows * fin;
+  dim3 grid((unsigned)igcn_cdiv(N, GO_T), B);
+#define CALL(FI, FO)                                                                                             \
+  hipLaunchKernelGGL((k_go_attn_bwd_stats<FI, FO>), grid, dim3(GO_T), 0, st, B, N, row_ptr, col, x, w_inc, a_in,  \
                      dy, stats);                                                                                  \
-  hipLaunchKernelGGL((k_go_attn_bwd_main<FI, FO>), gridB, dim3(GO_T), 0, st, B, N, row_ptr, col, t_ptr, t_row, x, \
-                     w_inc, w_s, a_in, a_s, dy, stats, dx, partial)
+  hipLaunchKernelGGL((k_go_attn_bwd_main<FI, FO>), grid, dim3(GO_T), 0, st, B, N, row_ptr, col, t_ptr, t_row, x,  \
+                     w_inc, w_s, a_in, a_s, dy, stats, dx, u)
   GO_DISPATCH(fin, fout, CALL)
 #undef CALL
   IGCN_CHECK_LAUNCH("go_attn_bwd");
-  return igcn_launch_reduce_rows(partial, (int64_t)gridB.x * gridB.y, nw, nw, dparams, 0, st);
+  // G[r,d] = sum_b sum_n u[b,r,n] * x[b,d,n]
+  int rc = igcn_gemm_f32_batched_sum_impl(rows, fin, N, B, u, N, 1, rows * (int64_t)N, x, N, 1, (int64_t)fin * N, G,
+                                          fin, slabs, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_go_attn_bwd_finish, dim3(1), dim3(128), 0, st, fin, fout, G, w_inc, w_s, dparams);
+  IGCN_CHECK_LAUNCH("go_attn_bwd_finish");
+  return IGCN_OK;
 }
 
 // =================================================================================================
@@ -564,19 +623,45 @@ k_go_decode_fwd(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const in
       wso[c][d] = w_sout[c * FIN + d];
     }
   const int r = blockIdx.x * GO_T + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int b = blockIdx.y;
-  if (r >= Nout) return;
+  const bool live = r < Nout;
+  const int rr = live ? r : Nout - 1;
   const int off = Nout - Nin;
   const float* xb = x + (int64_t)b * FIN * Nin;
   float acc[FIN];
 #pragma unroll
   for (int d = 0; d < FIN; ++d) acc[d] = 0.f;
-  const int32_t p0 = row_ptr[r], p1 = row_ptr[r + 1];
-  for (int32_t e = p0; e < p1; ++e) {
-    const int m = col[e];
+  const int32_t p0 = row_ptr[rr], p1 = row_ptr[rr + 1];
+  const bool heavy = live && (p1 - p0 > GO_HEAVY);   // hub rows (a parent with many children): whole wave
+  if (!heavy) {
+    for (int32_t e = p0; e < p1; ++e) {
+      const int m = col[e];
 #pragma unroll
-    for (int d = 0; d < FIN; ++d) acc[d] += xb[(int64_t)d * Nin + m];
+      for (int d = 0; d < FIN; ++d) acc[d] += xb[(int64_t)d * Nin + m];
+    }
   }
+  unsigned long long hmask = __ballot(heavy);
+  while (hmask) {
+    const int src = __ffsll((long long)hmask) - 1;
+    hmask &= hmask - 1;
+    const int32_t h0 = __shfl(p0, src, 64), h1 = __shfl(p1, src, 64);
+    float part[FIN];
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) part[d] = 0.f;
+    for (int32_t e = h0 + lane; e < h1; e += 64) {
+      const int m = col[e];
+#pragma unroll
+      for (int d = 0; d < FIN; ++d) part[d] += xb[(int64_t)d * Nin + m];
+    }
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) part[d] = wave_sum_all(part[d]);
+    if (lane == src) {
+#pragma unroll
+      for (int d = 0; d < FIN; ++d) acc[d] = part[d];
+    }
+  }
+  if (!live) return;
   const float inv = p1 > p0 ? 1.f / (float)(p1 - p0) : 0.f;
   float out[FOUT];
   transform<FIN, FOUT>(wo, acc, out);

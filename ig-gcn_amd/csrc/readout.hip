@@ -288,7 +288,7 @@ extern "C" size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, in
   const size_t stats = (size_t)ro_chunks(B) * 2 * N;
   const size_t blocks = (size_t)igcn_cdiv(N, RO_NL) * ro_chunks(B);
   if (D * F <= 16) return stats + blocks * D * F + 64;
-  return stats + (size_t)B * N * D + (size_t)B * D * F + 64;
+  return stats + (size_t)B * N * D + (size_t)16 * B * D * F + 64;
 }
 
 extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int training, const float* x, const float* W,

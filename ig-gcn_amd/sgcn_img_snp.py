@@ -13,6 +13,7 @@ the two ``x.min().item()`` host syncs of :225,293 are gone (every graph has exac
 to_dense_batch is a view); OrthogonalConstraint uses the Gram identity (B x B instead of (R*D)^2).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -101,6 +102,9 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                                                 dim_snps_atten=dim_att)
         self.batch_norm = torch.nn.BatchNorm1d(num_layers * hidden)       # unused by forward
         self._dropout_enabled = True
+        # igcn_xattn_* (one fused VALU kernel per direction) is exact but currently slower than MFMA-GEMM
+        # projections + the library attention core at B=256 (profiles/): opt-in until its MFMA version lands
+        self.fused_cross_attention = os.environ.get("IGCN_FUSED_XATTN", "0") == "1"
 
     def reset_parameters(self):
         self.conv1.reset_parameters()
@@ -165,18 +169,21 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         return F.dropout(x, p, True) if (self.training and self._dropout_enabled) else x
 
     def _cross_attention(self, query, memory):
-        """nn.MultiheadAttention(D, 2, batch_first=True)(query, memory, memory)[0] (:240) with the parameters of
-        ``self.multihead_attn``: projections on the MFMA GEMM (their weight gradients reduce over B*L rows,
-        split-K), attention core = library scaled-dot-product kernel."""
+        """relu(nn.MultiheadAttention(D, 2, batch_first=True)(query, memory, memory)[0]) (:240-241) with the
+        parameters of ``self.multihead_attn``: one fused kernel per direction (igcn_xattn_*: projections,
+        softmax and PV stay in LDS).  Shapes the fused kernel does not cover fall back to MFMA-GEMM projections
+        around the library scaled-dot-product kernel."""
         mha = self.multihead_attn
         d, h = mha.embed_dim, mha.num_heads
         b, lq, lk = query.shape[0], query.shape[1], memory.shape[1]
         w, bias = mha.in_proj_weight, mha.in_proj_bias
+        if self.fused_cross_attention and ops.xattn_supported(d, h, lq, lk):
+            return ops.CrossAttention.apply(query, memory, w, bias, mha.out_proj.weight, mha.out_proj.bias, h)
         q = ops.linear(query, w[:d], bias[:d]).view(b, lq, h, d // h).transpose(1, 2)
         kv = ops.linear(memory, w[d:], bias[d:]).view(b, lk, 2, h, d // h)
         k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, lq, d)
-        return ops.linear(o, mha.out_proj.weight, mha.out_proj.bias)
+        return F.relu(ops.linear(o, mha.out_proj.weight, mha.out_proj.bias))
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, data, temperature=None, device=None, isExplain=False):
@@ -207,7 +214,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
 
         latent, x_hat, _, atten_out = self.go_network(snps_m, temperature, device)
         if self.isCrossAtten:
-            out_cross = F.relu(self._cross_attention(batch_x, atten_out)).reshape(bsz, -1)
+            out_cross = self._cross_attention(batch_x, atten_out).reshape(bsz, -1)
         else:
             out_cross = torch.cat((img_out, latent), -1)
 

@@ -128,7 +128,8 @@ int igcn_gemm_f32(int64_t M, int64_t N, int64_t K,
 
 /* Batched-sum variant: C = sum_z A_z . B_z^T with A_z = A + z*a_batch, B_z = B + z*b_batch (element offsets),
  * every z covering the whole K; slabs are summed in z order.  Used for weight gradients whose reduction index is
- * (sample, node) over channel-major activations.  scratch: float[batch*M*N]. */
+ * (sample, node) over channel-major activations.  Long K is additionally sliced (<= 16 ways).
+ * scratch: float[16*batch*M*N]. */
 int igcn_gemm_f32_batched_sum(int64_t M, int64_t N, int64_t K, int batch,
                               const float* A, int64_t sam, int64_t sak, int64_t a_batch,
                               const float* B, int64_t sbn, int64_t sbk, int64_t b_batch,
@@ -181,6 +182,26 @@ int igcn_mask_reg_bwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const floa
 int igcn_rbf_laplacian(int B, int T, float gamma, const float* t, float* Lap, void* stream);
 int igcn_gram_loss_fwd(int B, int RD, const float* G, const float* Lap, float* out, float* scratch, void* stream);
 int igcn_gram_loss_bwd(int B, const float* G, const float* Lap, const float* gout, float* S, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused cross-attention fusion block — kernel/sgcn_img_snp.py:46,239-242:
+ *   out = relu( nn.MultiheadAttention(D, H, batch_first=True)(xq, mem, mem)[0] )
+ * xq [B,Lq,D] (dense-batched SGCN features), mem [B,Lk,D] (GO attention read-out); w_in [3D,D], b_in [3D] =
+ * in_proj_weight/bias (q,k,v rows), w_out [D,D], b_out [D] = out_proj.  One workgroup per sample; the K/V
+ * projections live only in LDS.  Saves o_save [B,Lq,D] (concatenated head outputs) and lse [B,H,Lq].
+ * igcn_xattn_lds_bytes returns the dynamic LDS the shape needs, or 0 when the fused kernel does not cover it
+ * (head_dim in {4,6,10,15,16,24}, H = 2, Lq <= 512, Lk <= 1024, LDS <= 160 KB).
+ * Backward: dxq, dmem, dparams = (dW_in, db_in, dW_out, db_out) flat; scratch: float[B * igcn_xattn_param_floats(D)].
+ */
+size_t igcn_xattn_lds_bytes(int D, int H, int Lq, int Lk, int backward);
+size_t igcn_xattn_param_floats(int D);
+int igcn_xattn_fwd(int B, int D, int H, int Lq, int Lk, const float* xq, const float* mem,
+                   const float* w_in, const float* b_in, const float* w_out, const float* b_out,
+                   float* out, float* o_save, float* lse, void* stream);
+int igcn_xattn_bwd(int B, int D, int H, int Lq, int Lk, const float* xq, const float* mem,
+                   const float* w_in, const float* b_in, const float* w_out,
+                   const float* out, const float* o_save, const float* lse, const float* dout,
+                   float* dxq, float* dmem, float* dparams, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sparse SNP<->GO maps with learnable non-zeros — gene encoding go_model.py:208-215 (C=2 channels,

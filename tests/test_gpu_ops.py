@@ -359,3 +359,26 @@ def test_gram_losses(ops, bsz, rd, soft):
     assert abs(float(c) - float(c_ref)) <= 1e-4 * max(abs(float(c_ref)), 1e-6)
     assert abs(float(o) - float(o_ref)) <= 1e-4 * max(abs(float(o_ref)), 1e-6)
     assert_matches(g, g_ref.numpy(), 2e-4, "ds")
+
+
+@pytest.mark.parametrize("bsz,lq,lk,d", [(3, 10, 9, 8), (4, 90, 400, 32), (2, 12, 23, 12), (5, 90, 45, 32)])
+def test_fused_cross_attention(ops, bsz, lq, lk, d):
+    rng = np.random.default_rng(lq + lk)
+    mha = torch.nn.MultiheadAttention(d, 2, batch_first=True).double()
+    with torch.no_grad():
+        for p in mha.parameters():
+            p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape)) * 0.4))
+    xq = torch.from_numpy(rng.standard_normal((bsz, lq, d))).float()
+    mem = torch.from_numpy(rng.standard_normal((bsz, lk, d))).float()
+    cot = torch.from_numpy(rng.standard_normal((bsz, lq, d))).float()
+    ref_in = [xq.double().requires_grad_(True), mem.double().requires_grad_(True)]
+    out_ref = torch.relu(mha(ref_in[0], ref_in[1], ref_in[1], need_weights=False)[0])
+    pars = [mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias]
+    g_ref = torch.autograd.grad((out_ref * cot.double()).sum(), ref_in + pars)
+    assert ops.xattn_supported(d, 2, lq, lk)
+    dev = [t.cuda().requires_grad_(True) for t in (xq, mem)] + [p.detach().float().cuda().requires_grad_(True) for p in pars]
+    out = ops.CrossAttention.apply(*dev, 2)
+    g = torch.autograd.grad((out * cot.cuda()).sum(), dev)
+    assert_matches(out, out_ref.detach().numpy(), TOL, "out")
+    for got, want, nm in zip(g, g_ref, ("dxq", "dmem", "dW_in", "db_in", "dW_out", "db_out")):
+        assert_matches(got, want.numpy(), 2e-4, nm, floor=1e-6)
