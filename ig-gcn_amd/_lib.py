@@ -19,6 +19,7 @@ SIGNATURES = {
     "igcn_last_error": (ctypes.c_char_p, []),
     "igcn_graph_plan_workspace_bytes": (Z, [L, L]),
     "igcn_graph_plan_build": (I, [L, L, P, P, P, P, P, P, P, P, P, Z, P]),
+    "igcn_graph_plan_replicate": (I, [L, L, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_edge_mask_fwd": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P]),
     "igcn_edge_mask_bwd": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_gcn_norm_fwd": (I, [L, L, P, P, P, P, P, P, P, P, P, P, P]),
@@ -28,10 +29,12 @@ SIGNATURES = {
     "igcn_gcn_propagate_bwd": (I, [L, L, I, P, L, P, L, I, P, L, P, P, P, P, P, P, P, L, P, I, P, P, P, P]),
     "igcn_gemm_f32": (I, [L, L, L, P, L, L, P, L, L, P, P, L, I, I, P, P]),
     "igcn_gemm_f32_batched_sum": (I, [L, L, L, I, P, L, L, L, P, L, L, L, P, L, P, P]),
-    "igcn_node_linear_bn_scratch_floats": (Z, [I, I]),
-    "igcn_node_linear_bn_fwd": (I, [I, I, I, I, P, P, P, P, P, P, I, F, F, P, P, P, P, P]),
-    "igcn_node_linear_bn_bwd_scratch_floats": (Z, [I, I, I, I]),
-    "igcn_node_linear_bn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_node_linear_bn_scratch_floats": (Z, [I, I, I]),
+    "igcn_node_linear_bn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, I, F, F, P, P, P, P, P]),
+    "igcn_node_linear_bn_bwd_scratch_floats": (Z, [I, I, I, I, I]),
+    "igcn_node_linear_bn_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_bn1d_fwd": (I, [I, I, I, P, P, P, P, P, I, F, F, I, P, P, P, P]),
+    "igcn_bn1d_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
     "igcn_mask_reg_fwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P]),
     "igcn_mask_reg_bwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P, P, P]),
     "igcn_rbf_laplacian": (I, [I, I, F, P, P, P]),
@@ -53,6 +56,8 @@ SIGNATURES = {
     "igcn_go_decode_bwd_scratch_floats": (Z, [I, I, I, I]),
     "igcn_go_decode_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_adam_step": (I, [L, P, P, P, P, P, F, F, F, F, F, P]),
+    "igcn_adam_step_multi": (I, [I, P, P, P, F, F, F, F, F, P]),
+    "igcn_pack_grads": (I, [I, P, P, P, P, P]),
 }
 
 _lib = None

@@ -149,3 +149,51 @@ extern "C" int igcn_graph_plan_build(int64_t n_nodes, int64_t n_edges, const int
   IGCN_CHECK_LAUNCH("graph_plan_build");
   return IGCN_OK;
 }
+
+// Plan of `copies` disjoint copies of the same batch (nodes g*N + i, edges g*E + k): used to run the plain and the
+// masked forward pass of a train step as ONE block-diagonal problem without sorting again.
+__global__ void k_plan_replicate(int64_t n, int64_t e, int copies, const int32_t* __restrict__ src32,
+                                 const int32_t* __restrict__ dst32, const int32_t* __restrict__ tgt_ptr,
+                                 const int32_t* __restrict__ tgt_perm, const int32_t* __restrict__ src_ptr,
+                                 const int32_t* __restrict__ src_perm, const int32_t* __restrict__ loop_edge,
+                                 int32_t* __restrict__ o_src32, int32_t* __restrict__ o_dst32,
+                                 int32_t* __restrict__ o_tgt_ptr, int32_t* __restrict__ o_tgt_perm,
+                                 int32_t* __restrict__ o_src_ptr, int32_t* __restrict__ o_src_perm,
+                                 int32_t* __restrict__ o_loop_edge) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tot_e = e * copies, tot_n = n * copies;
+  if (i < tot_e) {
+    const int64_t g = i / e, k = i - g * e;
+    o_src32[i] = src32[k] + (int32_t)(g * n);
+    o_dst32[i] = dst32[k] + (int32_t)(g * n);
+    o_tgt_perm[i] = tgt_perm[k] + (int32_t)(g * e);
+    o_src_perm[i] = src_perm[k] + (int32_t)(g * e);
+  }
+  if (i < tot_n) {
+    const int64_t g = i / n, v = i - g * n;
+    o_tgt_ptr[i] = tgt_ptr[v] + (int32_t)(g * e);
+    o_src_ptr[i] = src_ptr[v] + (int32_t)(g * e);
+    const int32_t le = loop_edge[v];
+    o_loop_edge[i] = le >= 0 ? le + (int32_t)(g * e) : -1;
+  }
+  if (i == tot_n) {
+    o_tgt_ptr[tot_n] = (int32_t)tot_e;
+    o_src_ptr[tot_n] = (int32_t)tot_e;
+  }
+}
+
+extern "C" int igcn_graph_plan_replicate(int64_t n_nodes, int64_t n_edges, int copies, const int32_t* src32,
+                                         const int32_t* dst32, const int32_t* tgt_ptr, const int32_t* tgt_perm,
+                                         const int32_t* src_ptr, const int32_t* src_perm, const int32_t* loop_edge,
+                                         int32_t* o_src32, int32_t* o_dst32, int32_t* o_tgt_ptr, int32_t* o_tgt_perm,
+                                         int32_t* o_src_ptr, int32_t* o_src_perm, int32_t* o_loop_edge,
+                                         void* stream) {
+  IGCN_REQUIRE(copies >= 1 && n_nodes > 0 && n_nodes * copies < ((int64_t)1 << 31) &&
+               n_edges * copies < ((int64_t)1 << 31), "graph_plan_replicate: sizes out of int32 range");
+  const int64_t work = (n_edges * copies > n_nodes * copies + 1) ? n_edges * copies : n_nodes * copies + 1;
+  hipLaunchKernelGGL(k_plan_replicate, dim3((unsigned)igcn_cdiv(work, 256)), dim3(256), 0, (hipStream_t)stream,
+                     n_nodes, n_edges, copies, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, loop_edge, o_src32,
+                     o_dst32, o_tgt_ptr, o_tgt_perm, o_src_ptr, o_src_perm, o_loop_edge);
+  IGCN_CHECK_LAUNCH("graph_plan_replicate");
+  return IGCN_OK;
+}

@@ -24,22 +24,41 @@ __device__ __forceinline__ void ro_pre(const float* __restrict__ w, const float 
   }
 }
 
+// Samples are split into `groups` equal groups that are normalised independently (the two forward passes of a
+// train step batched into one launch keep their own BatchNorm statistics).  gridDim.y = groups * cpg chunks;
+// chunk cy covers samples [b0,b1) of group g = cy / cpg.
+struct RoChunk {
+  int g, ck, b0, b1, first;
+};
+__device__ __forceinline__ RoChunk ro_chunk(int B, int groups) {
+  const int cpg = gridDim.y / groups, bg = B / groups;
+  RoChunk c;
+  c.g = blockIdx.y / cpg;
+  c.ck = blockIdx.y % cpg;
+  const int per = (bg + cpg - 1) / cpg;
+  c.first = c.g * bg;
+  c.b0 = c.first + c.ck * per;
+  c.b1 = min(c.first + bg, c.b0 + per);
+  return c;
+}
+
 // ---- forward pass 1: shifted sums per (node, sample chunk) ---------------------------------------
 // partial[chunk][0][n] = sum (pre - pivot_n), partial[chunk][1][n] = sum (pre - pivot_n)^2 ; pivot from sample 0
 template <int F, int D>
 __global__ void __launch_bounds__(RO_T)
-k_nlbn_stats(int B, int N, const float* __restrict__ x, const float* __restrict__ W, float* __restrict__ partial) {
+k_nlbn_stats(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+             float* __restrict__ partial) {
   __shared__ float s1[RO_SG][RO_NL], s2[RO_SG][RO_NL];
   const float* __restrict__ w = W;
   const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int n = blockIdx.x * RO_NL + nl;
-  const int per = (B + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const RoChunk ch = ro_chunk(B, groups);
+  const int b0 = ch.b0, b1 = ch.b1;
   float a1 = 0.f, a2 = 0.f;
   if (n < N) {
     float xv[F], pre[D];
 #pragma unroll
-    for (int c = 0; c < F; ++c) xv[c] = x[(int64_t)c * N + n];          // sample 0
+    for (int c = 0; c < F; ++c) xv[c] = x[((int64_t)ch.first * F + c) * N + n];   // pivot: the group's first sample
     ro_pre<F, D>(w, xv, pre);
     float piv = 0.f;
 #pragma unroll
@@ -68,57 +87,67 @@ k_nlbn_stats(int B, int N, const float* __restrict__ x, const float* __restrict_
 }
 
 // ---- forward pass 2: finalise statistics (training) or take the running ones (eval) ----------------
+// mean_out / rstd_out are [groups, N]; the running statistics are updated group after group, exactly as two
+// successive forward calls would.
 template <int F, int D>
-__global__ void k_nlbn_finalize(int B, int N, int chunks, int training, float eps, float momentum,
+__global__ void k_nlbn_finalize(int B, int N, int groups, int cpg, int training, float eps, float momentum,
                                 const float* __restrict__ x, const float* __restrict__ W,
                                 const float* __restrict__ partial, float* __restrict__ running_mean,
                                 float* __restrict__ running_var, float* __restrict__ mean_out,
                                 float* __restrict__ rstd_out) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  float mean, var;
-  if (training) {
-    const float* __restrict__ w = W;
-    float xv[F], pre[D];
+  const int bg = B / groups;
+  float rm = running_mean[n], rv = running_var[n];
+  for (int g = 0; g < groups; ++g) {
+    float mean, var;
+    if (training) {
+      const float* __restrict__ w = W;
+      float xv[F], pre[D];
 #pragma unroll
-    for (int c = 0; c < F; ++c) xv[c] = x[(int64_t)c * N + n];
-    ro_pre<F, D>(w, xv, pre);
-    float piv = 0.f;
+      for (int c = 0; c < F; ++c) xv[c] = x[((int64_t)g * bg * F + c) * N + n];
+      ro_pre<F, D>(w, xv, pre);
+      float piv = 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) piv += pre[d];
-    piv *= (1.f / D);
-    float a1 = 0.f, a2 = 0.f;
-    for (int k = 0; k < chunks; ++k) {
-      a1 += partial[(int64_t)k * 2 * N + n];
-      a2 += partial[(int64_t)k * 2 * N + N + n];
+      for (int d = 0; d < D; ++d) piv += pre[d];
+      piv *= (1.f / D);
+      float a1 = 0.f, a2 = 0.f;
+      for (int k = 0; k < cpg; ++k) {
+        a1 += partial[(int64_t)(g * cpg + k) * 2 * N + n];
+        a2 += partial[(int64_t)(g * cpg + k) * 2 * N + N + n];
+      }
+      const float cnt = (float)bg * D;
+      const float m = a1 / cnt;
+      mean = piv + m;
+      var = fmaxf(a2 / cnt - m * m, 0.f);
+      rm = (1.f - momentum) * rm + momentum * mean;
+      rv = (1.f - momentum) * rv + momentum * var * (cnt / (cnt - 1.f));
+    } else {
+      mean = rm;
+      var = rv;
     }
-    const float cnt = (float)B * D;
-    const float m = a1 / cnt;
-    mean = piv + m;
-    var = fmaxf(a2 / cnt - m * m, 0.f);
-    running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * mean;
-    running_var[n] = (1.f - momentum) * running_var[n] + momentum * var * (cnt / (cnt - 1.f));
-  } else {
-    mean = running_mean[n];
-    var = running_var[n];
+    mean_out[(int64_t)g * N + n] = mean;
+    rstd_out[(int64_t)g * N + n] = 1.0f / sqrtf(var + eps);
   }
-  mean_out[n] = mean;
-  rstd_out[n] = 1.0f / sqrtf(var + eps);
+  if (training) {
+    running_mean[n] = rm;
+    running_var[n] = rv;
+  }
 }
 
 // ---- forward pass 3: normalise + ReLU, write [B,N,D] ---------------------------------------------
 template <int F, int D>
 __global__ void __launch_bounds__(RO_T)
-k_nlbn_apply(int B, int N, const float* __restrict__ x, const float* __restrict__ W,
+k_nlbn_apply(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
              const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
              const float* __restrict__ rstd, float* __restrict__ out) {
   const float* __restrict__ w = W;
   const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int n = blockIdx.x * RO_NL + nl;
   if (n >= N) return;
-  const int per = (B + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
-  const float sc = rstd[n] * gamma[n], sh = beta[n] - mean[n] * sc;
+  const RoChunk ch = ro_chunk(B, groups);
+  const int b0 = ch.b0, b1 = ch.b1;
+  const float sc = rstd[(int64_t)ch.g * N + n] * gamma[n], sh = beta[n] - mean[(int64_t)ch.g * N + n] * sc;
   for (int b = b0 + sg; b < b1; b += RO_SG) {
     float xv[F], pre[D];
 #pragma unroll
@@ -145,18 +174,18 @@ k_nlbn_apply(int B, int N, const float* __restrict__ x, const float* __restrict_
 // ---- backward pass 1: per node sum(dy), sum(dy*xhat) over (b,d), dy = dout * [out > 0] ---------------
 template <int F, int D>
 __global__ void __launch_bounds__(RO_T)
-k_nlbn_bwd_stats(int B, int N, const float* __restrict__ x, const float* __restrict__ W,
+k_nlbn_bwd_stats(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
                  const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                  const float* __restrict__ rstd, const float* __restrict__ dout, float* __restrict__ partial) {
   __shared__ float s1[RO_SG][RO_NL], s2[RO_SG][RO_NL];
   const float* __restrict__ w = W;
   const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int n = blockIdx.x * RO_NL + nl;
-  const int per = (B + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const RoChunk ch = ro_chunk(B, groups);
+  const int b0 = ch.b0, b1 = ch.b1;
   float a1 = 0.f, a2 = 0.f;
   if (n < N) {
-    const float mu = mean[n], rs = rstd[n], ga = gamma[n], be = beta[n];
+    const float mu = mean[(int64_t)ch.g * N + n], rs = rstd[(int64_t)ch.g * N + n], ga = gamma[n], be = beta[n];
     for (int b = b0 + sg; b < b1; b += RO_SG) {
       float xv[F], pre[D];
 #pragma unroll
@@ -176,7 +205,7 @@ k_nlbn_bwd_stats(int B, int N, const float* __restrict__ x, const float* __restr
   s2[sg][nl] = a2;
   __syncthreads();
   if (sg == 0 && n < N) {
-    float* p = partial + (int64_t)blockIdx.y * 2 * N;
+    float* p = partial + (int64_t)(ch.ck * groups + ch.g) * 2 * N;      // [chunk][group][2][N]
     p[n] = (s1[0][nl] + s1[1][nl]) + (s1[2][nl] + s1[3][nl]);
     p[N + n] = (s2[0][nl] + s2[1][nl]) + (s2[2][nl] + s2[3][nl]);
   }
@@ -188,7 +217,7 @@ k_nlbn_bwd_stats(int B, int N, const float* __restrict__ x, const float* __restr
 //   otherwise : dpre [B,N,D] is written out and dW = sum_b dpre_b^T x_b runs on the MFMA batched-sum GEMM
 template <int F, int D>
 __global__ void __launch_bounds__(RO_T)
-k_nlbn_bwd_apply(int B, int N, int training, const float* __restrict__ x, const float* __restrict__ W,
+k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict__ x, const float* __restrict__ W,
                  const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                  const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ dgb,
                  float* __restrict__ dpre_out, float* __restrict__ dx, float* __restrict__ wpartial) {
@@ -202,12 +231,13 @@ k_nlbn_bwd_apply(int B, int N, int training, const float* __restrict__ x, const 
 #pragma unroll
   for (int j = 0; j < NW; ++j) gw[j] = 0.f;
   if (n < N) {
-    const int per = (B + gridDim.y - 1) / gridDim.y;
-    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
-    const float mu = mean[n], rs = rstd[n], ga = gamma[n], be = beta[n];
-    const float cnt = (float)B * D;
-    const float m1 = training ? dgb[N + n] / cnt : 0.f;     // mean(dy)
-    const float m2 = training ? dgb[n] / cnt : 0.f;         // mean(dy*xhat)
+    const RoChunk ch = ro_chunk(B, groups);
+    const int b0 = ch.b0, b1 = ch.b1;
+    const float mu = mean[(int64_t)ch.g * N + n], rs = rstd[(int64_t)ch.g * N + n], ga = gamma[n], be = beta[n];
+    const float cnt = (float)(B / groups) * D;
+    const float* dgg = dgb + (int64_t)ch.g * 2 * N;         // this group's (sum dy*xhat, sum dy)
+    const float m1 = training ? dgg[N + n] / cnt : 0.f;     // mean(dy)
+    const float m2 = training ? dgg[n] / cnt : 0.f;         // mean(dy*xhat)
     for (int b = b0 + sg; b < b1; b += RO_SG) {
       float xv[F], pre[D], dxv[F];
 #pragma unroll
@@ -255,25 +285,32 @@ k_nlbn_bwd_apply(int B, int N, int training, const float* __restrict__ x, const 
     return IGCN_ERR_UNSUPPORTED;                                   \
   }
 
-static int ro_chunks(int B) { return B >= 16 ? 16 : (B > 0 ? B : 1); }
+static int ro_cpg(int B, int groups) {
+  const int bg = B / groups;
+  return bg >= 8 ? 8 : (bg > 0 ? bg : 1);
+}
 
-extern "C" size_t igcn_node_linear_bn_scratch_floats(int B, int N) { return (size_t)ro_chunks(B) * 2 * N + 64; }
+extern "C" size_t igcn_node_linear_bn_scratch_floats(int B, int N, int groups) {
+  return (size_t)groups * ro_cpg(B, groups) * 2 * N + 64;
+}
 
-extern "C" int igcn_node_linear_bn_fwd(int B, int F, int N, int D, const float* x, const float* W,
+extern "C" int igcn_node_linear_bn_fwd(int B, int F, int N, int D, int groups, const float* x, const float* W,
                                        const float* gamma, const float* beta, float* running_mean,
                                        float* running_var, int training, float momentum, float eps, float* out,
                                        float* save_mean, float* save_rstd, float* scratch, void* stream) {
-  IGCN_REQUIRE(B > 0 && N > 0, "node_linear_bn_fwd: bad sizes");
-  IGCN_REQUIRE(!training || (int64_t)B * D > 1, "node_linear_bn_fwd: need more than one value per node to train");
+  IGCN_REQUIRE(B > 0 && N > 0 && groups >= 1 && B % groups == 0, "node_linear_bn_fwd: bad sizes");
+  IGCN_REQUIRE(!training || (int64_t)(B / groups) * D > 1,
+               "node_linear_bn_fwd: need more than one value per node and group to train");
   hipStream_t st = (hipStream_t)stream;
-  const int chunks = ro_chunks(B);
-  dim3 grid((unsigned)igcn_cdiv(N, RO_NL), chunks);
+  const int cpg = ro_cpg(B, groups);
+  dim3 grid((unsigned)igcn_cdiv(N, RO_NL), groups * cpg);
 #define CALL(FV, DV)                                                                                             \
-  if (training) hipLaunchKernelGGL((k_nlbn_stats<FV, DV>), grid, dim3(RO_T), 0, st, B, N, x, W, scratch);        \
-  hipLaunchKernelGGL((k_nlbn_finalize<FV, DV>), dim3((unsigned)igcn_cdiv(N, 64)), dim3(64), 0, st, B, N, chunks,  \
-                     training, eps, momentum, x, W, scratch, running_mean, running_var, save_mean, save_rstd);    \
-  hipLaunchKernelGGL((k_nlbn_apply<FV, DV>), grid, dim3(RO_T), 0, st, B, N, x, W, gamma, beta, save_mean,         \
-                     save_rstd, out)
+  if (training) hipLaunchKernelGGL((k_nlbn_stats<FV, DV>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, scratch); \
+  hipLaunchKernelGGL((k_nlbn_finalize<FV, DV>), dim3((unsigned)igcn_cdiv(N, 64)), dim3(64), 0, st, B, N, groups,  \
+                     cpg, training, eps, momentum, x, W, scratch, running_mean, running_var, save_mean,           \
+                     save_rstd);                                                                                  \
+  hipLaunchKernelGGL((k_nlbn_apply<FV, DV>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta,            \
+                     save_mean, save_rstd, out)
   RO_DISPATCH(F, D, CALL)
 #undef CALL
   IGCN_CHECK_LAUNCH("node_linear_bn_fwd");
@@ -284,38 +321,151 @@ int igcn_gemm_f32_batched_sum_impl(int64_t M, int64_t N, int64_t K, int batch, c
                                    int64_t sak, int64_t a_batch, const float* B, int64_t sbn, int64_t sbk,
                                    int64_t b_batch, float* C, int64_t ldc, float* scratch, hipStream_t st);
 
-extern "C" size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, int D) {
-  const size_t stats = (size_t)ro_chunks(B) * 2 * N;
-  const size_t blocks = (size_t)igcn_cdiv(N, RO_NL) * ro_chunks(B);
+extern "C" size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, int D, int groups) {
+  const size_t cpg = ro_cpg(B, groups);
+  const size_t stats = (size_t)groups * cpg * 2 * N + (size_t)groups * 2 * N;
+  const size_t blocks = (size_t)igcn_cdiv(N, RO_NL) * groups * cpg;
   if (D * F <= 16) return stats + blocks * D * F + 64;
   return stats + (size_t)B * N * D + (size_t)16 * B * D * F + 64;
 }
 
-extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int training, const float* x, const float* W,
-                                       const float* gamma, const float* beta, const float* save_mean,
-                                       const float* save_rstd, const float* dout, float* dx, float* dW,
-                                       float* dgb /*[2,N]: dgamma, dbeta*/, float* scratch, void* stream) {
-  IGCN_REQUIRE(B > 0 && N > 0, "node_linear_bn_bwd: bad sizes");
+extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, int training, const float* x,
+                                       const float* W, const float* gamma, const float* beta,
+                                       const float* save_mean, const float* save_rstd, const float* dout,
+                                       float* dx, float* dW, float* dgb /*[2,N]: dgamma, dbeta*/, float* scratch,
+                                       void* stream) {
+  IGCN_REQUIRE(B > 0 && N > 0 && groups >= 1 && B % groups == 0, "node_linear_bn_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  const int chunks = ro_chunks(B);
-  dim3 grid((unsigned)igcn_cdiv(N, RO_NL), chunks);
-  float* stats = scratch;
-  float* aux = scratch + (size_t)chunks * 2 * N;       // wpartial (small) or dpre then slabs (large)
+  const int cpg = ro_cpg(B, groups);
+  dim3 grid((unsigned)igcn_cdiv(N, RO_NL), groups * cpg);
+  float* stats = scratch;                                    // [cpg][groups][2][N]
+  float* dgg = stats + (size_t)groups * cpg * 2 * N;         // [groups][2][N]
+  float* aux = dgg + (size_t)groups * 2 * N;                 // wpartial (small) or dpre then slabs (large)
   const bool small = D * F <= 16;
 #define CALL(FV, DV)                                                                                              \
-  hipLaunchKernelGGL((k_nlbn_bwd_stats<FV, DV>), grid, dim3(RO_T), 0, st, B, N, x, W, gamma, beta, save_mean,      \
-                     save_rstd, dout, stats);                                                                      \
+  hipLaunchKernelGGL((k_nlbn_bwd_stats<FV, DV>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta,         \
+                     save_mean, save_rstd, dout, stats);                                                           \
   {                                                                                                                \
-    int rc = igcn_launch_reduce_rows(stats, chunks, 2 * (int64_t)N, 2 * N, dgb, 0, st);                            \
+    int rc = igcn_launch_reduce_rows(stats, cpg, (int64_t)groups * 2 * N, groups * 2 * N, dgg, 0, st);             \
     if (rc) return rc;                                                                                             \
   }                                                                                                                \
-  hipLaunchKernelGGL((k_nlbn_bwd_apply<FV, DV>), grid, dim3(RO_T), 0, st, B, N, training, x, W, gamma, beta,       \
-                     save_mean, save_rstd, dout, dgb, aux, dx, aux)
+  hipLaunchKernelGGL((k_nlbn_bwd_apply<FV, DV>), grid, dim3(RO_T), 0, st, B, N, groups, training, x, W, gamma,     \
+                     beta, save_mean, save_rstd, dout, dgg, aux, dx, aux)
   RO_DISPATCH(F, D, CALL)
 #undef CALL
   IGCN_CHECK_LAUNCH("node_linear_bn_bwd");
+  int rc = igcn_launch_reduce_rows(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, 0, st);     // dgamma/dbeta over groups
+  if (rc) return rc;
   if (small) return igcn_launch_reduce_rows(aux, (int64_t)grid.x * grid.y, D * F, D * F, dW, 0, st);
   // dW[d,c] = sum_b sum_n dpre[b,n,d] * x[b,c,n]
   return igcn_gemm_f32_batched_sum_impl(D, F, N, B, aux, 1, D, (int64_t)N * D, x, N, 1, (int64_t)F * N, dW, F,
                                         aux + (size_t)B * N * D, st);
+}
+
+// =================================================================================================
+// BatchNorm1d(C) (+ optional ReLU) on a 2-D input [B, C] with grouped statistics — the latent MLP of the GO
+// network (go_model.py:138-146).  Tiny tensors ([512,32]): one workgroup per channel, groups handled in turn.
+// =================================================================================================
+__global__ void __launch_bounds__(256)
+k_bn1d_fwd(int B, int C, int groups, int training, float momentum, float eps, int relu,
+           const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+           float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ y,
+           float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, bg = B / groups;
+  float rm = running_mean[c], rv = running_var[c];
+  const float ga = gamma[c], be = beta[c];
+  for (int g = 0; g < groups; ++g) {
+    const float* xg = x + (int64_t)g * bg * C + c;
+    float mean, var;
+    if (training) {
+      float s = 0.f;
+      for (int b = threadIdx.x; b < bg; b += 256) s += xg[(int64_t)b * C];
+      mean = block_sum_all(s, red) / (float)bg;
+      float v = 0.f;
+      for (int b = threadIdx.x; b < bg; b += 256) {
+        const float d = xg[(int64_t)b * C] - mean;
+        v += d * d;
+      }
+      var = block_sum_all(v, red) / (float)bg;
+      rm = (1.f - momentum) * rm + momentum * mean;
+      rv = (1.f - momentum) * rv + momentum * var * ((float)bg / (float)(bg - 1));
+    } else {
+      mean = rm;
+      var = rv;
+    }
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (threadIdx.x == 0) {
+      save_mean[g * C + c] = mean;
+      save_rstd[g * C + c] = rstd;
+    }
+    float* yg = y + (int64_t)g * bg * C + c;
+    for (int b = threadIdx.x; b < bg; b += 256) {
+      float t = (xg[(int64_t)b * C] - mean) * rstd * ga + be;
+      yg[(int64_t)b * C] = relu ? fmaxf(t, 0.f) : t;
+    }
+  }
+  if (training && threadIdx.x == 0) {
+    running_mean[c] = rm;
+    running_var[c] = rv;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_bn1d_bwd(int B, int C, int groups, int training, int relu, const float* __restrict__ x,
+           const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ save_mean,
+           const float* __restrict__ save_rstd, const float* __restrict__ dy, float* __restrict__ dx,
+           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, bg = B / groups;
+  const float ga = gamma[c], be = beta[c];
+  float dg_tot = 0.f, db_tot = 0.f;
+  for (int g = 0; g < groups; ++g) {
+    const float mean = save_mean[g * C + c], rstd = save_rstd[g * C + c];
+    const float* xg = x + (int64_t)g * bg * C + c;
+    const float* dyg = dy + (int64_t)g * bg * C + c;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = threadIdx.x; b < bg; b += 256) {
+      const float xh = (xg[(int64_t)b * C] - mean) * rstd;
+      const float d = (!relu || xh * ga + be > 0.f) ? dyg[(int64_t)b * C] : 0.f;
+      s1 += d;
+      s2 += d * xh;
+    }
+    s1 = block_sum_all(s1, red);
+    s2 = block_sum_all(s2, red);
+    dg_tot += s2;
+    db_tot += s1;
+    const float m1 = training ? s1 / (float)bg : 0.f, m2 = training ? s2 / (float)bg : 0.f;
+    float* dxg = dx + (int64_t)g * bg * C + c;
+    for (int b = threadIdx.x; b < bg; b += 256) {
+      const float xh = (xg[(int64_t)b * C] - mean) * rstd;
+      const float d = (!relu || xh * ga + be > 0.f) ? dyg[(int64_t)b * C] : 0.f;
+      dxg[(int64_t)b * C] = ga * rstd * (d - m1 - xh * m2);
+    }
+  }
+  if (threadIdx.x == 0) {
+    dgamma[c] = dg_tot;
+    dbeta[c] = db_tot;
+  }
+}
+
+extern "C" int igcn_bn1d_fwd(int B, int C, int groups, const float* x, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, int training, float momentum, float eps,
+                             int relu, float* y, float* save_mean, float* save_rstd, void* stream) {
+  IGCN_REQUIRE(B > 0 && C > 0 && groups >= 1 && B % groups == 0 && (!training || B / groups > 1),
+               "bn1d_fwd: bad sizes");
+  hipLaunchKernelGGL(k_bn1d_fwd, dim3(C), dim3(256), 0, (hipStream_t)stream, B, C, groups, training, momentum, eps,
+                     relu, x, gamma, beta, running_mean, running_var, y, save_mean, save_rstd);
+  IGCN_CHECK_LAUNCH("bn1d_fwd");
+  return IGCN_OK;
+}
+
+extern "C" int igcn_bn1d_bwd(int B, int C, int groups, int training, int relu, const float* x, const float* gamma,
+                             const float* beta, const float* save_mean, const float* save_rstd, const float* dy,
+                             float* dx, float* dgamma, float* dbeta, void* stream) {
+  IGCN_REQUIRE(B > 0 && C > 0 && groups >= 1 && B % groups == 0, "bn1d_bwd: bad sizes");
+  hipLaunchKernelGGL(k_bn1d_bwd, dim3(C), dim3(256), 0, (hipStream_t)stream, B, C, groups, training, relu, x, gamma,
+                     beta, save_mean, save_rstd, dy, dx, dgamma, dbeta);
+  IGCN_CHECK_LAUNCH("bn1d_bwd");
+  return IGCN_OK;
 }

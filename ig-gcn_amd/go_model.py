@@ -98,14 +98,23 @@ class Gene_ontology_network(nn.Module):
     def _drop(self, x, p):
         return F.dropout(x, p, True) if (self.training and self._dropout_enabled) else x
 
-    def _node_linear_bn(self, x, weight, bn):
+    def _node_linear_bn(self, x, weight, bn, groups=1):
         """relu(bn(linear(x))) with bn = BatchNorm1d(#nodes): one fused op (igcn_node_linear_bn_*)."""
         if self.training and bn.track_running_stats:
-            bn.num_batches_tracked += 1
+            bn.num_batches_tracked += groups
         return ops.NodeLinearBN.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                      self.training, bn.momentum, bn.eps)
+                                      self.training, bn.momentum, bn.eps, groups)
 
-    def forward(self, data, T=None, device=None):
+    def _bn_relu(self, x, bn, groups=1):
+        """relu(bn(x)) for the latent MLP's BatchNorm1d layers (igcn_bn1d_*)."""
+        if self.training and bn.track_running_stats:
+            bn.num_batches_tracked += groups
+        return ops.BatchNorm1dGrouped.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
+                                            bn.momentum, bn.eps, True, groups)
+
+    def forward(self, data, T=None, device=None, groups=1):
+        """``groups`` > 1: ``data`` holds that many equally sized batches stacked along dim 0 that are treated as
+        successive forward calls (own BatchNorm statistics, running statistics updated in order)."""
         bsz, dev = data.shape[0], data.device
         # gene encoding (:208-215)
         x = ops.SparseMap.apply(data, torch.stack(list(self.t)), self.gene_csr)          # [B, in_f, N]
@@ -117,8 +126,8 @@ class Gene_ontology_network(nn.Module):
             x = ops.NodesLayerNorm.apply(y, self.G_B[j].weight, self.G_B[j].bias,
                                          self._node_keep(bsz, csr.n_rows, dev), self.pool[j], self.G_B[j].eps)
         # read-outs (:254-255): BatchNorm1d(n_top) normalises per NODE over (batch, feature); fused kernels
-        atten_out = self._node_linear_bn(x, self.conc_for_attention[0].weight, self.conc_for_attention[1])
-        inp_out = self._drop(self._node_linear_bn(x, self.conc.weight, self.B[0]).squeeze(2), 0.5)
+        atten_out = self._node_linear_bn(x, self.conc_for_attention[0].weight, self.conc_for_attention[1], groups)
+        inp_out = self._drop(self._node_linear_bn(x, self.conc.weight, self.B[0], groups).squeeze(2), 0.5)
         # decoder (:258-275)
         for j in range(self.n_l):
             csr = self.dec_csr[j]
@@ -126,9 +135,10 @@ class Gene_ontology_network(nn.Module):
             x = ops.NodesLayerNorm.apply(y, self.G_B_D[j].weight, self.G_B_D[j].bias,
                                          self._node_keep(bsz, csr.n_rows, dev), 0, self.G_B_D[j].eps)
         # gene decoding (:278-282)
-        out_d = self._drop(self._node_linear_bn(x, self.conc_D.weight, self.B_D[0]).squeeze(2), 0.5)   # [B, N]
+        out_d = self._drop(self._node_linear_bn(x, self.conc_D.weight, self.B_D[0], groups).squeeze(2), 0.5)  # [B,N]
         x_d = ops.SparseMap.apply(out_d, self.t_D[0].unsqueeze(0), self.gene_t_csr).squeeze(1)   # [B, 54]
         # latent projection (:138-146,285)
-        h = self._drop(self.latent[2](self.latent[1](self.latent[0](inp_out.view(bsz, -1)))), 0.5)
-        latent = self.latent[6](self.latent[5](self.latent[4](h)))
+        h = self._drop(self._bn_relu(ops.linear(inp_out.view(bsz, -1), self.latent[0].weight), self.latent[1],
+                                     groups), 0.5)
+        latent = self._bn_relu(ops.linear(h, self.latent[4].weight), self.latent[5], groups)
         return latent, x_d, [torch.zeros(3, device=dev)], atten_out

@@ -44,6 +44,28 @@ class GraphPlan:
              ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(ws), wbytes,
              stream_ptr())
         self._ws = ws            # keep alive until the stream has consumed it
+        self._copies = {}
+
+    def replicate(self, copies):
+        """Plan of ``copies`` disjoint copies of this batch (igcn_graph_plan_replicate), cached."""
+        if copies == 1:
+            return self
+        if copies not in self._copies:
+            rep = object.__new__(GraphPlan)
+            n, e = self.n_nodes, self.n_edges
+            rep.n_nodes, rep.n_edges = n * copies, e * copies
+            i32 = dict(dtype=torch.int32, device=self.src32.device)
+            for name, size in (("src32", e * copies), ("dst32", e * copies), ("tgt_ptr", n * copies + 1),
+                               ("tgt_perm", e * copies), ("src_ptr", n * copies + 1), ("src_perm", e * copies),
+                               ("loop_edge", n * copies)):
+                setattr(rep, name, torch.empty(max(size, 1), **i32))
+            rep._copies = {}
+            call("igcn_graph_plan_replicate", n, e, copies, ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr),
+                 ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(rep.src32),
+                 ptr(rep.dst32), ptr(rep.tgt_ptr), ptr(rep.tgt_perm), ptr(rep.src_ptr), ptr(rep.src_perm),
+                 ptr(rep.loop_edge), stream_ptr())
+            self._copies[copies] = rep
+        return self._copies[copies]
 
 
 def plan_for(data):
@@ -394,23 +416,26 @@ class GoDecode(torch.autograd.Function):
 # GO read-outs: node-wise linear + BatchNorm-over-nodes + ReLU
 # =================================================================================================
 class NodeLinearBN(torch.autograd.Function):
-    """relu(BatchNorm1d_N(W x)) for x [B,F,N] channel-major -> [B,N,D]  (go_model.py:117-136,254-255,278)."""
+    """relu(BatchNorm1d_N(W x)) for x [B,F,N] channel-major -> [B,N,D]  (go_model.py:117-136,254-255,278).
+    ``groups``: consecutive sample groups with independent batch statistics (passes batched into one launch)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, groups=1):
         x, weight, gamma, beta = _f32(x), _f32(weight), _f32(gamma), _f32(beta)
         b, f, n = x.shape
         d = weight.shape[0]
         lib = _lib.load()
         dev = x.device
         out = torch.empty(b, n, d, dtype=torch.float32, device=dev)
-        mean, rstd = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
-        scratch = torch.empty(int(lib.igcn_node_linear_bn_scratch_floats(b, n)), dtype=torch.float32, device=dev)
-        call("igcn_node_linear_bn_fwd", b, f, n, d, ptr(x), ptr(weight), ptr(gamma), ptr(beta), ptr(running_mean),
-             ptr(running_var), int(training), float(momentum), float(eps), ptr(out), ptr(mean), ptr(rstd),
-             ptr(scratch), stream_ptr())
+        mean = torch.empty(groups, n, dtype=torch.float32, device=dev)
+        rstd = torch.empty(groups, n, dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(lib.igcn_node_linear_bn_scratch_floats(b, n, groups)), dtype=torch.float32,
+                              device=dev)
+        call("igcn_node_linear_bn_fwd", b, f, n, d, groups, ptr(x), ptr(weight), ptr(gamma), ptr(beta),
+             ptr(running_mean), ptr(running_var), int(training), float(momentum), float(eps), ptr(out), ptr(mean),
+             ptr(rstd), ptr(scratch), stream_ptr())
         ctx.save_for_backward(x, weight, gamma, beta, mean, rstd)
-        ctx.training = int(training)
+        ctx.training, ctx.groups = int(training), groups
         return out
 
     @staticmethod
@@ -423,11 +448,39 @@ class NodeLinearBN(torch.autograd.Function):
         dev = x.device
         dx, dw = torch.empty_like(x), torch.empty_like(weight)
         dgb = torch.empty(2, n, dtype=torch.float32, device=dev)
-        scratch = torch.empty(int(lib.igcn_node_linear_bn_bwd_scratch_floats(b, f, n, d)), dtype=torch.float32,
-                              device=dev)
-        call("igcn_node_linear_bn_bwd", b, f, n, d, ctx.training, ptr(x), ptr(weight), ptr(gamma), ptr(beta),
-             ptr(mean), ptr(rstd), ptr(dout), ptr(dx), ptr(dw), ptr(dgb), ptr(scratch), stream_ptr())
-        return dx, dw, dgb[0], dgb[1], None, None, None, None, None
+        scratch = torch.empty(int(lib.igcn_node_linear_bn_bwd_scratch_floats(b, f, n, d, ctx.groups)),
+                              dtype=torch.float32, device=dev)
+        call("igcn_node_linear_bn_bwd", b, f, n, d, ctx.groups, ctx.training, ptr(x), ptr(weight), ptr(gamma),
+             ptr(beta), ptr(mean), ptr(rstd), ptr(dout), ptr(dx), ptr(dw), ptr(dgb), ptr(scratch), stream_ptr())
+        return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None
+
+
+class BatchNorm1dGrouped(torch.autograd.Function):
+    """(ReLU of) BatchNorm1d(C) on [B,C] with grouped batch statistics (latent MLP, go_model.py:138-146)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, groups):
+        x, gamma, beta = _f32(x), _f32(gamma), _f32(beta)
+        b, c = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(groups, c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call("igcn_bn1d_fwd", b, c, groups, ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+             int(training), float(momentum), float(eps), int(relu), ptr(y), ptr(mean), ptr(rstd), stream_ptr())
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (int(training), int(relu), groups)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, relu, groups = ctx.cfg
+        dy = _f32(dy)
+        b, c = x.shape
+        dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(beta)
+        call("igcn_bn1d_bwd", b, c, groups, training, relu, ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+             ptr(dy), ptr(dx), ptr(dg), ptr(db), stream_ptr())
+        return dx, dg, db, None, None, None, None, None, None, None
 
 
 # =================================================================================================

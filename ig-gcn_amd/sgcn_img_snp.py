@@ -187,6 +187,18 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, data, temperature=None, device=None, isExplain=False):
+        """:207-307.  Returns (log_softmax, x_hat, out_z, out_lin, linear_outf, our_reg)."""
+        return self._forward_grouped(data, temperature, device, (bool(isExplain),))[0]
+
+    def forward_pair(self, data, temperature=None, device=None):
+        """The two forward passes of one train step (train() :521,523: plain, then isExplain=True) as ONE batched
+        sweep over 2B samples / a 2-copy block-diagonal graph.  Numerically the same two passes: every sample is
+        independent except through BatchNorm, whose batch statistics are taken per pass (``groups=2``) and whose
+        running statistics are updated plain-then-masked.  Halves the launch count of a step and lets autograd
+        produce every parameter gradient once instead of adding two per-pass contributions."""
+        return self._forward_grouped(data, temperature, device, (False, True))
+
+    def _forward_grouped(self, data, temperature, device, explain_flags):
         x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
         snps_feat = data.snps_feat
         x.requires_grad = True                                        # :210 — populates data.x.grad
@@ -194,27 +206,32 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         n = x.shape[0]
         if n % self.rois:
             raise ValueError(f"every graph must have exactly rois={self.rois} nodes (got {n} nodes)")
-        bsz = n // self.rois
+        bsz, g = n // self.rois, len(explain_flags)
         plan = ops.plan_for(data)
         self.last_edge_prob = None
-        if isExplain:
+        if any(explain_flags):
             x_m, ew_m, _, e, snps_m, _ = self.cal_probability(x, edge_index, edge_weight, snps_feat, plan=plan)
             self.last_edge_prob = e
-        else:
-            x_m, ew_m, snps_m = x, edge_weight, snps_feat
-        coef = ops.GcnNorm.apply(ew_m, plan)                          # once per pass (PyG: once per layer)
-        h = self.conv1(x_m, plan, coef, relu=True)
+        pick = lambda plain, masked: [masked if f else plain for f in explain_flags]      # noqa: E731
+        xs, ews, snps = pick(x, x_m if any(explain_flags) else None), pick(edge_weight, ew_m if any(
+            explain_flags) else None), pick(snps_feat, snps_m if any(explain_flags) else None)
+        stack = lambda ts: ts[0] if g == 1 else torch.cat(ts, dim=0)                       # noqa: E731
+        x_in, ew_in, snps_in = stack(xs), stack(ews), stack(snps)
+        plan_g = plan.replicate(g)
+        coef = ops.GcnNorm.apply(ew_in, plan_g)                       # once per pass (PyG: once per layer)
+        h = self.conv1(x_in, plan_g, coef, relu=True)
         hs = [h]
         for conv in self.convs:
-            h = conv(h, plan, coef, relu=True)
+            h = conv(h, plan_g, coef, relu=True)
             hs.append(h)
         xcat = torch.cat(hs, dim=1)
-        batch_x = xcat.view(bsz, self.rois, -1)                       # to_dense_batch == view (:226)
-        img_out = batch_x.reshape(bsz, -1)
+        gb = g * bsz
+        batch_x = xcat.view(gb, self.rois, -1)                        # to_dense_batch == view (:226)
+        img_out = batch_x.reshape(gb, -1)
 
-        latent, x_hat, _, atten_out = self.go_network(snps_m, temperature, device)
+        latent, x_hat, _, atten_out = self.go_network(snps_in, temperature, device, groups=g)
         if self.isCrossAtten:
-            out_cross = self._cross_attention(batch_x, atten_out).reshape(bsz, -1)
+            out_cross = self._cross_attention(batch_x, atten_out).reshape(gb, -1)
         else:
             out_cross = torch.cat((img_out, latent), -1)
 
@@ -223,7 +240,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             out_lin = out_z
         elif self.isSNPsOnly:
             out_z = latent
-            out_lin = torch.cat((snps_m, latent), -1)
+            out_lin = torch.cat((snps_in, latent), -1)
         else:
             out_z = (img_out + out_cross) / 2
             out_lin = torch.cat((out_z, latent), -1)
@@ -231,12 +248,15 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         logits = ops.linear(self._drop(linear_outf, 0.5), self.lin2.weight, self.lin2.bias)
         if self.isuseProb4Regr and not self.isSNPsOnly:
             img_feat = (data.x.view(bsz, self.rois, -1) * self.prob).reshape(bsz, -1)      # :293-297
-            feat = torch.cat((out_lin, img_feat), -1)
+            feat = torch.cat((out_lin, img_feat if g == 1 else img_feat.repeat(g, 1)), -1)
         else:
             feat = out_lin
         reg = ops.linear(feat, self.lin1_regr.weight, self.lin1_regr.bias, relu=True)
         our_reg = ops.linear(self._drop(reg, 0.3), self.lin2_regr.weight, self.lin2_regr.bias)
-        return F.log_softmax(logits, dim=-1), x_hat, out_z, out_lin, linear_outf, our_reg
+        outs = (F.log_softmax(logits, dim=-1), x_hat, out_z, out_lin, linear_outf, our_reg)
+        if g == 1:
+            return [outs]
+        return [tuple(t[k * bsz:(k + 1) * bsz] for t in outs) for k in range(g)]
 
     def __repr__(self):
         return self.__class__.__name__

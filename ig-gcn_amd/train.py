@@ -18,50 +18,101 @@ DEFAULT_LAMBDA = (0.0, 1.0, 0.5, 1.5e-6, 0.1, 0.0)
 
 
 class FlatAdam:
-    """Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) over ONE flat fp32 buffer (igcn_adam_step).
+    """Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) over ONE flat fp32 parameter buffer.
 
-    Parameters and their ``.grad`` become views into two contiguous buffers, so the data-parallel
-    gradient exchange is a single all-reduce and the update a single kernel.  Parameters that never
-    receive a gradient keep a zero gradient, for which the Adam update is exactly zero (torch's Adam
-    skips them: same result).
+    Parameters (and the Adam moments) are views into contiguous buffers.  Two gradient modes:
+
+    * table mode (default on the GPU): ``zero_grad`` just drops the ``.grad`` references, autograd hands over
+      freshly written gradient tensors, and ONE multi-tensor kernel (igcn_adam_step_multi) walks a device table
+      of {param, grad, exp_avg, exp_avg_sq} pointers — no per-parameter AccumulateGrad add, no memset.  Under
+      data parallelism igcn_pack_grads gathers the gradients into the flat bucket for the single all-reduce.
+    * flat mode (``flat_grads=True``): ``.grad`` are views of one flat buffer that autograd accumulates into.
+
+    Parameters without a gradient are left untouched, like torch.optim.Adam.
     """
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, flat_grads=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no parameters")
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
         self.lr, self.betas, self.eps = lr, betas, eps
+        self.flat_grads = (dev.type != "cuda") if flat_grads is None else bool(flat_grads)
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        off = 0
+        off, offs = 0, []
         with torch.no_grad():
             for p in self.params:
                 k = p.numel()
                 self.flat[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + k].view_as(p)
-                p.grad = self.grad[off:off + k].view_as(p)
+                p.grad = self.grad[off:off + k].view_as(p) if self.flat_grads else None
+                offs.append(off)
                 off += k
+        nt = len(self.params)
+        self._offs = offs
+        self._host = torch.zeros(nt, 4, dtype=torch.int64, pin_memory=(dev.type == "cuda"))
+        for t, (p, o) in enumerate(zip(self.params, offs)):
+            self._host[t, 0] = self.flat.data_ptr() + 4 * o
+            self._host[t, 2] = self.exp_avg.data_ptr() + 4 * o
+            self._host[t, 3] = self.exp_avg_sq.data_ptr() + 4 * o
+        self.table = torch.zeros(nt, 4, dtype=torch.int64, device=dev)
+        self.numel = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
+        self.offset = torch.tensor(offs, dtype=torch.int64, device=dev)
 
     def zero_grad(self):
-        self.grad.zero_()
+        if self.flat_grads:
+            self.grad.zero_()
+        else:
+            for p in self.params:
+                p.grad = None
 
-    def step(self, grad_scale=1.0):
-        call("igcn_adam_step", self.flat.numel(), ptr(self.flat), ptr(self.grad), ptr(self.exp_avg),
-             ptr(self.exp_avg_sq), ptr(self.step_count), float(self.lr), float(self.betas[0]),
-             float(self.betas[1]), float(self.eps), float(grad_scale), stream_ptr())
+    def refresh_table(self):
+        """Upload the current gradient pointers (host-side, not capturable: under a hipGraph the gradient
+        tensors keep their addresses, so this runs once after capture)."""
+        for t, p in enumerate(self.params):
+            g = p.grad
+            if g is not None and not g.is_contiguous():
+                g = p.grad = g.contiguous()
+            self._host[t, 1] = g.data_ptr() if g is not None else 0
+        self.table.copy_(self._host, non_blocking=True)
+
+    def pack_grads(self, refresh=True):
+        """Gather the per-tensor gradients into the flat bucket ``self.grad`` (data-parallel exchange)."""
+        if self.flat_grads:
+            return self.grad
+        if refresh:
+            self.refresh_table()
+        call("igcn_pack_grads", len(self.params), ptr(self.table), ptr(self.numel), ptr(self.offset),
+             ptr(self.grad), stream_ptr())
+        return self.grad
+
+    def step(self, grad_scale=1.0, refresh=True, from_flat=None):
+        """``from_flat``: read gradients from the flat bucket (after an all-reduce); default = flat mode only."""
+        hyper = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(grad_scale))
+        if self.flat_grads or from_flat:
+            call("igcn_adam_step", self.flat.numel(), ptr(self.flat), ptr(self.grad), ptr(self.exp_avg),
+                 ptr(self.exp_avg_sq), ptr(self.step_count), *hyper, stream_ptr())
+            return
+        if refresh:
+            self.refresh_table()
+        call("igcn_adam_step_multi", len(self.params), ptr(self.table), ptr(self.numel), ptr(self.step_count),
+             *hyper, stream_ptr())
 
 
 def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None):
     """train() :521-543.  Returns (loss, terms dict, (outs_plain, outs_explain))."""
     lam = lambda_loss
     dev = data.x.device
-    o1 = model(data, temperature, dev)
-    o2 = model(data, temperature, dev, isExplain=True)
+    if getattr(model, "batched_passes", True) and hasattr(model, "forward_pair"):
+        o1, o2 = model.forward_pair(data, temperature, dev)      # both passes of :521,523 in one batched sweep
+    else:
+        o1 = model(data, temperature, dev)
+        o2 = model(data, temperature, dev, isExplain=True)
     out, snps_hat, out_feat, _, _, reg = o1
     out_p, snps_hat_p, out_feat_p, _, _, reg_p = o2
     y = data.y.view(-1)
@@ -111,8 +162,10 @@ def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temper
     loss, _, _ = losses(model, data, lambda_loss, hp, temperature)
     loss.backward()
     if world_size > 1:
-        torch.distributed.all_reduce(optimizer.grad)
-    optimizer.step(grad_scale=1.0 / world_size)
+        torch.distributed.all_reduce(optimizer.pack_grads())
+        optimizer.step(grad_scale=1.0 / world_size, from_flat=True)
+    else:
+        optimizer.step()
     return loss.detach()
 
 
@@ -134,20 +187,28 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):
             for _ in range(warmup):                     # eager steps: allocator + library warm-up
                 self._fwd_bwd()
-                self._reduce()
-                self.opt.step(grad_scale=1.0 / world_size)
+                if world_size > 1:
+                    self.opt.pack_grads()
+                    self._reduce()
+                    self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
+                else:
+                    self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_main):
             self.loss = self._fwd_bwd()
             if world_size == 1:
-                self.opt.step()
+                self.opt.step(refresh=False)            # reads the pointer table at replay time
+            else:
+                self.opt.pack_grads(refresh=False)
+        self.opt.refresh_table()                        # the captured gradient tensors keep their addresses
         self.g_opt = None
         if world_size > 1:
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=self.g_main.pool()):
-                self.opt.step(grad_scale=1.0 / world_size)
+                self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
+        torch.cuda.synchronize()
 
     def _fwd_bwd(self):
         self.opt.zero_grad()

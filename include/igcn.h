@@ -48,6 +48,15 @@ int igcn_graph_plan_build(int64_t n_nodes, int64_t n_edges, const int64_t* edge_
                           int32_t* src_ptr, int32_t* src_perm, int32_t* loop_edge,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Plan of `copies` disjoint copies of the batch (node g*N+i, edge g*E+k) derived from an existing plan without
+ * sorting again; output arrays are sized for copies*N nodes / copies*E edges. */
+int igcn_graph_plan_replicate(int64_t n_nodes, int64_t n_edges, int copies,
+                              const int32_t* src32, const int32_t* dst32, const int32_t* tgt_ptr,
+                              const int32_t* tgt_perm, const int32_t* src_ptr, const int32_t* src_perm,
+                              const int32_t* loop_edge,
+                              int32_t* o_src32, int32_t* o_dst32, int32_t* o_tgt_ptr, int32_t* o_tgt_perm,
+                              int32_t* o_src_ptr, int32_t* o_src_perm, int32_t* o_loop_edge, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Learned regional / connective importance masks — cal_probability, kernel/sgcn_img_snp.py:133-151.
  *   xm[i,:]  = x[i,:] * prob[i % rois,:]
@@ -142,20 +151,33 @@ int igcn_gemm_f32_batched_sum(int64_t M, int64_t N, int64_t K, int batch,
  *   out[b,n,:] = relu((pre - mean_n)*rstd_n*gamma[n] + beta[n])      out [B,N,D]
  * BatchNorm1d(N) on [B,N,D] normalises every node over (batch, feature); training != 0 uses batch statistics
  * (biased variance) and updates running_mean/var (momentum, unbiased variance), else the running ones.
+ * `groups` > 1 splits the B samples into equal consecutive groups that are normalised independently and update
+ * the running statistics one after the other (= that many successive module calls; used to run the plain and the
+ * masked forward pass of a train step as one launch).
  * scratch: igcn_node_linear_bn_scratch_floats(B,N).
  */
-size_t igcn_node_linear_bn_scratch_floats(int B, int N);
-int igcn_node_linear_bn_fwd(int B, int F, int N, int D, const float* x, const float* W,
+size_t igcn_node_linear_bn_scratch_floats(int B, int N, int groups);
+int igcn_node_linear_bn_fwd(int B, int F, int N, int D, int groups, const float* x, const float* W,
                             const float* gamma, const float* beta, float* running_mean, float* running_var,
                             int training, float momentum, float eps,
-                            float* out, float* save_mean, float* save_rstd, float* scratch, void* stream);
+                            float* out, float* save_mean /*[groups,N]*/, float* save_rstd /*[groups,N]*/,
+                            float* scratch, void* stream);
 /* Outputs dx [B,F,N], dW [D,F], dgb [2,N] = (dgamma, dbeta).  dW = sum_{b,n} dpre[b,n,:] (x) x[b,:,n] is formed in
  * registers when D*F <= 16, else on the MFMA batched-sum GEMM.
- * scratch: igcn_node_linear_bn_bwd_scratch_floats(B,F,N,D). */
-size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, int D);
-int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int training, const float* x, const float* W,
+ * scratch: igcn_node_linear_bn_bwd_scratch_floats(B,F,N,D,groups). */
+size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, int D, int groups);
+int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, int training, const float* x, const float* W,
                             const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
                             const float* dout, float* dx, float* dW, float* dgb, float* scratch, void* stream);
+
+/* BatchNorm1d(C) (+ReLU when relu != 0) on a 2-D input [B,C] with the same grouped-statistics semantics —
+ * the latent MLP of go_model.py:138-146.  save_mean/save_rstd are [groups,C]. */
+int igcn_bn1d_fwd(int B, int C, int groups, const float* x, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, int training, float momentum, float eps, int relu,
+                  float* y, float* save_mean, float* save_rstd, void* stream);
+int igcn_bn1d_bwd(int B, int C, int groups, int training, int relu, const float* x, const float* gamma,
+                  const float* beta, const float* save_mean, const float* save_rstd, const float* dy,
+                  float* dx, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Mask regulariser — loss_probability, kernel/sgcn_img_snp.py:153-181:
@@ -276,6 +298,15 @@ int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, const int32_
 int igcn_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                    int32_t* step, float lr, float beta1, float beta2, float eps, float grad_scale,
                    void* stream);
+
+/* Multi-tensor forms: `table` is a device array int64[n_tensors][4] = {param, grad, exp_avg, exp_avg_sq}
+ * pointers, `numel` int64[n_tensors].  A zero grad pointer skips the tensor (torch's Adam skips parameters whose
+ * .grad is None).  igcn_pack_grads copies the gradients (zeros where missing) to flat[offset[t]...] — the bucket of
+ * the data-parallel all-reduce. */
+int igcn_adam_step_multi(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
+                         float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_t* numel, const int64_t* offset,
+                    float* flat, void* stream);
 
 #ifdef __cplusplus
 }

@@ -116,12 +116,14 @@ def test_full_model_vs_reference_golden(golden, name, mode, explain):
 
 
 @pytest.mark.parametrize("name", ["full_tiny", "full_r90", "full_l3"])
-def test_train_step_vs_reference_golden(golden, name):
+@pytest.mark.parametrize("batched", [True, False])
+def test_train_step_vs_reference_golden(golden, name, batched):
     from igcn_amd.data import Batch
     from igcn_amd.train import FlatAdam, losses
     store = golden(name)
     model, graphs, seed = _full_model(store)
     model.train(True)
+    model.batched_passes = batched      # True: both passes as one 2B-sample sweep; False: two forward() calls
     data = Batch.from_data_list(graphs).to("cuda")
     opt = FlatAdam(model.parameters(), lr=1e-3)
     opt.zero_grad()
@@ -141,10 +143,14 @@ def test_train_step_vs_reference_golden(golden, name):
         if isinstance(w, tuple) or np.any(w):
             assert_matches(params[k].grad, w, 1e-2, "grad " + k, floor=1e-5)
         else:
-            assert not bool(params[k].grad.abs().max() > 0), k       # untouched parameters stay at zero grad
+            g = params[k].grad                                        # untouched parameters: no (or zero) grad
+            assert g is None or not bool(g.abs().max() > 0), k
         grads[k] = w
     opt.step()
     lr = 1e-3
+    bufs = model.state_dict()
+    for k, w in golden_group(store, "step/buffers_after").items():      # running stats: plain pass, then masked
+        assert_matches(bufs[k], w, 1e-3, "buffer " + k, floor=1e-2)
     for k, w in golden_group(store, "step/param_after").items():
         p = params[k].detach().cpu()
         if isinstance(w, tuple) or k not in grads or isinstance(grads[k], tuple):

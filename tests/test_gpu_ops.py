@@ -284,7 +284,7 @@ def test_adam_matches_torch(ops):
         opt.zero_grad()
         for p, r in zip(ps, ref):
             g = torch.from_numpy(rng.standard_normal(tuple(p.shape))).float()
-            p.grad.add_(g.cuda())
+            p.grad = g.cuda()
             r.grad = g.clone()
         opt.step()
         opt_ref.step()
@@ -293,9 +293,11 @@ def test_adam_matches_torch(ops):
 
 
 # ------------------------------------------------------------------------------------------------ read-outs / losses
-@pytest.mark.parametrize("bsz,f,n,d,training", [(6, 5, 11, 5, True), (32, 5, 400, 32, True), (32, 5, 400, 1, True),
-                                                 (16, 2, 3000, 1, True), (8, 5, 70, 8, False), (5, 5, 33, 12, True)])
-def test_node_linear_bn(ops, bsz, f, n, d, training):
+@pytest.mark.parametrize("bsz,f,n,d,training,groups", [
+    (6, 5, 11, 5, True, 1), (32, 5, 400, 32, True, 1), (32, 5, 400, 1, True, 1), (16, 2, 3000, 1, True, 1),
+    (8, 5, 70, 8, False, 1), (5, 5, 33, 12, True, 1), (64, 5, 400, 32, True, 2), (12, 2, 130, 1, True, 2),
+    (10, 5, 50, 1, False, 2)])
+def test_node_linear_bn(ops, bsz, f, n, d, training, groups):
     rng = np.random.default_rng(n + d)
     x = torch.from_numpy(rng.standard_normal((bsz, f, n)) + 0.5).float()
     w = torch.from_numpy(rng.standard_normal((d, f)) * 0.6).float()
@@ -307,17 +309,57 @@ def test_node_linear_bn(ops, bsz, f, n, d, training):
     ref_in = [t.double().requires_grad_(True) for t in (x, w, gamma, beta)]
     rm, rv = rm0.double().clone(), rv0.double().clone()
     pre = ref_in[0].transpose(1, 2) @ ref_in[1].t()                       # [B,N,D]
-    out_ref = torch.relu(torch.nn.functional.batch_norm(pre, rm, rv, ref_in[2], ref_in[3], training, 0.1, 1e-5))
+    bg = bsz // groups                                                    # groups == successive module calls
+    out_ref = torch.cat([torch.relu(torch.nn.functional.batch_norm(
+        pre[g * bg:(g + 1) * bg], rm, rv, ref_in[2], ref_in[3], training, 0.1, 1e-5)) for g in range(groups)])
     g_ref = torch.autograd.grad((out_ref * cot.double()).sum(), ref_in)
     dev = [t.cuda().requires_grad_(True) for t in (x, w, gamma, beta)]
     rmg, rvg = rm0.cuda(), rv0.cuda()
-    out = ops.NodeLinearBN.apply(dev[0], dev[1], dev[2], dev[3], rmg, rvg, training, 0.1, 1e-5)
+    out = ops.NodeLinearBN.apply(dev[0], dev[1], dev[2], dev[3], rmg, rvg, training, 0.1, 1e-5, groups)
     g = torch.autograd.grad((out * cot.cuda()).sum(), dev)
     assert_matches(out, out_ref.detach().numpy(), TOL, "out")
     for got, want, nm in zip(g, g_ref, ("dx", "dW", "dgamma", "dbeta")):
         assert_matches(got, want.numpy(), 3e-4, nm, floor=1e-6)
     assert_matches(rmg, rm.numpy(), TOL, "running_mean")
     assert_matches(rvg, rv.numpy(), TOL, "running_var")
+
+
+@pytest.mark.parametrize("bsz,c,training,relu,groups", [(32, 32, True, True, 1), (512, 32, True, True, 2),
+                                                         (10, 7, True, False, 2), (9, 5, False, True, 1)])
+def test_batchnorm1d_grouped(ops, bsz, c, training, relu, groups):
+    rng = np.random.default_rng(bsz + c)
+    x = torch.from_numpy(rng.standard_normal((bsz, c)) * 1.5 + 0.2).float()
+    gamma = torch.from_numpy(1 + 0.2 * rng.standard_normal(c)).float()
+    beta = torch.from_numpy(0.2 * rng.standard_normal(c)).float()
+    rm0, rv0 = torch.from_numpy(0.1 * rng.standard_normal(c)).float(), torch.from_numpy(1 + rng.random(c)).float()
+    cot = torch.from_numpy(rng.standard_normal((bsz, c))).float()
+    ref_in = [t.double().requires_grad_(True) for t in (x, gamma, beta)]
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    bg = bsz // groups
+    parts = [torch.nn.functional.batch_norm(ref_in[0][g * bg:(g + 1) * bg], rm, rv, ref_in[1], ref_in[2], training,
+                                            0.1, 1e-5) for g in range(groups)]
+    y_ref = torch.cat(parts)
+    y_ref = torch.relu(y_ref) if relu else y_ref
+    g_ref = torch.autograd.grad((y_ref * cot.double()).sum(), ref_in)
+    dev = [t.cuda().requires_grad_(True) for t in (x, gamma, beta)]
+    rmg, rvg = rm0.cuda(), rv0.cuda()
+    y = ops.BatchNorm1dGrouped.apply(dev[0], dev[1], dev[2], rmg, rvg, training, 0.1, 1e-5, relu, groups)
+    g = torch.autograd.grad((y * cot.cuda()).sum(), dev)
+    assert_matches(y, y_ref.detach().numpy(), TOL, "y")
+    for got, want, nm in zip(g, g_ref, ("dx", "dgamma", "dbeta")):
+        assert_matches(got, want.numpy(), 3e-4, nm, floor=1e-6)
+    assert_matches(rmg, rm.numpy(), TOL, "running_mean")
+    assert_matches(rvg, rv.numpy(), TOL, "running_var")
+
+
+def test_plan_replicate_equals_plan_of_the_doubled_graph(ops):
+    rng = np.random.default_rng(0)
+    n, e = 90 * 4, 270 * 4
+    ei = torch.from_numpy(rng.integers(0, n, (2, e))).long().cuda()
+    rep = ops.GraphPlan(ei, n).replicate(2)
+    full = ops.GraphPlan(torch.cat([ei, ei + n], dim=1), 2 * n)
+    for name in ("src32", "dst32", "tgt_ptr", "tgt_perm", "src_ptr", "src_perm", "loop_edge"):
+        assert torch.equal(getattr(rep, name), getattr(full, name)), name
 
 
 def test_mask_regulariser(ops):
