@@ -187,7 +187,7 @@ def _split_k(m, n, k):
     tiles = ((m + 63) // 64) * ((n + 63) // 64)
     if tiles >= 128 or k < 256:
         return 1
-    return int(max(1, min(k // 64, (256 + tiles - 1) // tiles)))
+    return int(max(1, min(k // 64, (512 + tiles - 1) // tiles)))
 
 
 def gemm_nt(a, b, bias=None, act=0, out=None):
