@@ -204,12 +204,13 @@ def gemm_nt(a, b, bias=None, act=0, out=None):
     return out
 
 
-def gemm_nn(a, b):
+def gemm_nn(a, b, out=None):
     """out[M,N] = a[M,K] @ b[K,N]."""
     a, b = _f32(a), _f32(b)
     m, k = a.shape
     n = b.shape[1]
-    out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
     sk = _split_k(m, n, k)
     scratch = torch.empty(sk * m * n, dtype=torch.float32, device=a.device) if sk > 1 else None
     call("igcn_gemm_f32", m, n, k, ptr(a), k, 1, ptr(b), 1, n, None, ptr(out), n, 0, sk, ptr(scratch), stream_ptr())
@@ -520,28 +521,38 @@ def rbf_laplacian(tsne, n, gamma, device):
 
 
 class GramLosses(torch.autograd.Function):
-    """(consist_loss, OrthogonalConstraint) of s [B,R*D] from one Gram matrix (sgcn_img_snp.py:183-205)."""
+    """(consist_loss, OrthogonalConstraint) of s [G*B, R*D] per group of B rows, each from one B x B Gram matrix
+    (sgcn_img_snp.py:183-205).  Returns two tensors of shape [G]."""
 
     @staticmethod
-    def forward(ctx, s, lap):
+    def forward(ctx, s, lap, groups=1):
         s, lap = _f32(s), _f32(lap)
-        b, rd = s.shape
-        gram = gemm_nt(s, s)
-        out = torch.empty(2, dtype=torch.float32, device=s.device)
+        gb, rd = s.shape
+        b = gb // groups
+        gram = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
+        out = torch.empty(groups, 2, dtype=torch.float32, device=s.device)
         scratch = torch.empty(2 * b, dtype=torch.float32, device=s.device)
-        call("igcn_gram_loss_fwd", b, rd, ptr(gram), ptr(lap), ptr(out), ptr(scratch), stream_ptr())
+        for g in range(groups):
+            sg = s[g * b:(g + 1) * b]
+            gemm_nt(sg, sg, out=gram[g])
+            call("igcn_gram_loss_fwd", b, rd, ptr(gram[g]), ptr(lap), ptr(out[g]), ptr(scratch), stream_ptr())
         ctx.save_for_backward(s, lap, gram)
-        return out[0], out[1]
+        ctx.groups = groups
+        return out[:, 0], out[:, 1]
 
     @staticmethod
     def backward(ctx, g_c, g_o):
         s, lap, gram = ctx.saved_tensors
-        b = s.shape[0]
-        zero = torch.zeros((), dtype=torch.float32, device=s.device)
-        gout = torch.stack([g_c if g_c is not None else zero, g_o if g_o is not None else zero]).contiguous()
+        groups = ctx.groups
+        b = s.shape[0] // groups
+        zero = torch.zeros(groups, dtype=torch.float32, device=s.device)
+        gout = torch.stack([g_c if g_c is not None else zero, g_o if g_o is not None else zero], dim=1).contiguous()
         sym = torch.empty(b, b, dtype=torch.float32, device=s.device)
-        call("igcn_gram_loss_bwd", b, ptr(gram), ptr(lap), ptr(gout), ptr(sym), stream_ptr())
-        return gemm_nn(sym, s), None
+        ds = torch.empty_like(s)
+        for g in range(groups):
+            call("igcn_gram_loss_bwd", b, ptr(gram[g]), ptr(lap), ptr(gout[g]), ptr(sym), stream_ptr())
+            gemm_nn(sym, s[g * b:(g + 1) * b], out=ds[g * b:(g + 1) * b])
+        return ds, None, None
 
 
 # =================================================================================================

@@ -150,10 +150,11 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         soft = self.isSoftSimilarity and tsne_result is not None
         return ops.rbf_laplacian(tsne_result if soft else None, n, self.rbf_gamma, self.prob.device)
 
-    def batch_losses(self, s, lap):
+    def batch_losses(self, s, lap, groups=1):
         """(consist_loss(s), OrthogonalConstraint(s)) from ONE B x B Gram matrix s s^T (igcn_gram_loss_*):
         tr(s^T Lap s) = sum_ij Lap_ij G_ij and ||Wn^T Wn - I||_F^2 = sum_ij G_ij^2/(G_ii G_jj) - 2B + R*D."""
-        return ops.GramLosses.apply(s, lap)
+        c, o = ops.GramLosses.apply(s, lap, groups)
+        return (c[0], o[0]) if groups == 1 else (c, o)
 
     def consist_loss(self, s, tsne_result=None):
         """:183-196."""
@@ -198,7 +199,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         produce every parameter gradient once instead of adding two per-pass contributions."""
         return self._forward_grouped(data, temperature, device, (False, True))
 
-    def _forward_grouped(self, data, temperature, device, explain_flags):
+    def _forward_grouped(self, data, temperature, device, explain_flags, split=True):
         x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
         snps_feat = data.snps_feat
         x.requires_grad = True                                        # :210 — populates data.x.grad
@@ -254,6 +255,8 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         reg = ops.linear(feat, self.lin1_regr.weight, self.lin1_regr.bias, relu=True)
         our_reg = ops.linear(self._drop(reg, 0.3), self.lin2_regr.weight, self.lin2_regr.bias)
         outs = (F.log_softmax(logits, dim=-1), x_hat, out_z, out_lin, linear_outf, our_reg)
+        if not split:
+            return outs                                               # stacked [g*B, ...] (pass-major)
         if g == 1:
             return [outs]
         return [tuple(t[k * bsz:(k + 1) * bsz] for t in outs) for k in range(g)]

@@ -36,23 +36,24 @@ class FlatAdam:
         if not self.params:
             raise ValueError("no parameters")
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
+        align = 16                                   # floats: every parameter starts on a 64-byte boundary, so
+        offs, n = [], 0                              # the GEMM kernels can stage weights with 16-byte loads
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + align - 1) // align * align
         self.lr, self.betas, self.eps = lr, betas, eps
         self.flat_grads = (dev.type != "cuda") if flat_grads is None else bool(flat_grads)
-        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        off, offs = 0, []
         with torch.no_grad():
-            for p in self.params:
+            for p, off in zip(self.params, offs):
                 k = p.numel()
                 self.flat[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + k].view_as(p)
                 p.grad = self.grad[off:off + k].view_as(p) if self.flat_grads else None
-                offs.append(off)
-                off += k
         nt = len(self.params)
         self._offs = offs
         self._host = torch.zeros(nt, 4, dtype=torch.int64, pin_memory=(dev.type == "cuda"))
@@ -105,14 +106,13 @@ class FlatAdam:
 
 
 def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None):
-    """train() :521-543.  Returns (loss, terms dict, (outs_plain, outs_explain))."""
+    """train() :521-543.  Returns (loss, terms dict, outputs)."""
+    if getattr(model, "batched_passes", True) and hasattr(model, "_forward_grouped") and model.isSoftSimilarity:
+        return _losses_batched(model, data, lambda_loss, hp, temperature)
     lam = lambda_loss
     dev = data.x.device
-    if getattr(model, "batched_passes", True) and hasattr(model, "forward_pair"):
-        o1, o2 = model.forward_pair(data, temperature, dev)      # both passes of :521,523 in one batched sweep
-    else:
-        o1 = model(data, temperature, dev)
-        o2 = model(data, temperature, dev, isExplain=True)
+    o1 = model(data, temperature, dev)
+    o2 = model(data, temperature, dev, isExplain=True)
     out, snps_hat, out_feat, _, _, reg = o1
     out_p, snps_hat_p, out_feat_p, _, _, reg_p = o2
     y = data.y.view(-1)
@@ -147,6 +147,35 @@ def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None):
     loss = hp.lamda_ce * t["ce"] + hp.lamda_mi * t["mi"] + t["reg"] + t["prob"] + t["recon"] + t["cluster"] \
         + t["orth"]
     return loss, t, (o1, o2)
+
+
+def _losses_batched(model, data, lam, hp, temperature):
+    """Same seven terms on the outputs of ONE batched sweep over both passes (rows [0,B) = plain pass of :521,
+    rows [B,2B) = isExplain pass of :523).  The per-pass means of equal-sized halves are taken on the stacked
+    tensors, so no slicing (and no slice-gradient fill/copy) is needed:
+    (mse_1 + mse_2)/2 = mse over 2B rows, (sum_1 + sum_2)/2 = sum over 2B rows / 2."""
+    dev = data.x.device
+    logp, x_hat, out_z, out_lin, lin_f, reg = model._forward_grouped(data, temperature, dev, (False, True),
+                                                                     split=False)
+    bsz = logp.shape[0] // 2
+    y2 = data.y.view(-1).repeat(2)
+    clin2 = data.clini_score.view(-1).repeat(2)
+    t = {}
+    ce_mi = F.nll_loss(logp, y2, reduction="none").view(2, bsz).mean(dim=1)
+    t["ce"], t["mi"] = lam[0] * ce_mi[0], lam[0] * ce_mi[1]
+    t["reg"] = lam[1] * F.mse_loss(reg.view(-1), clin2)
+    t["prob"] = lam[2] * model.loss_probability(data.x, data.edge_index, data.edge_attr, hp,
+                                                edge_prob=model.last_edge_prob)
+    t["recon"] = lam[3] * torch.sum((x_hat - data.snps_feat.repeat(2, 1)) ** 2) / 2
+    lap = model.laplacian(bsz, data.tsne_fdim)
+    consist, orth = model.batch_losses(out_z, lap, groups=2)
+    t["cluster"] = lam[4] * consist.mean()
+    t["orth"] = lam[5] * orth[0]
+    if lam[0] == 0:
+        t["ce"], t["mi"] = 0.0, 0.0
+    loss = hp.lamda_ce * t["ce"] + hp.lamda_mi * t["mi"] + t["reg"] + t["prob"] + t["recon"] + t["cluster"] \
+        + t["orth"]
+    return loss, t, (logp, x_hat, out_z, out_lin, lin_f, reg)
 
 
 def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None, world_size=1):

@@ -396,7 +396,8 @@ def test_gram_losses(ops, bsz, rd, soft):
     g_ref = torch.autograd.grad(0.7 * c_ref + 0.3 * o_ref, sr)[0]
     sg = s.cuda().requires_grad_(True)
     lap = ops.rbf_laplacian(tsne.cuda() if soft else None, bsz, 0.01, "cuda")
-    c, o = ops.GramLosses.apply(sg, lap)
+    c, o = ops.GramLosses.apply(sg, lap, 1)
+    c, o = c[0], o[0]
     g = torch.autograd.grad(0.7 * c + 0.3 * o, sg)[0]
     assert abs(float(c) - float(c_ref)) <= 1e-4 * max(abs(float(c_ref)), 1e-6)
     assert abs(float(o) - float(o_ref)) <= 1e-4 * max(abs(float(o_ref)), 1e-6)
@@ -424,3 +425,21 @@ def test_fused_cross_attention(ops, bsz, lq, lk, d):
     assert_matches(out, out_ref.detach().numpy(), TOL, "out")
     for got, want, nm in zip(g, g_ref, ("dxq", "dmem", "dW_in", "db_in", "dW_out", "db_out")):
         assert_matches(got, want.numpy(), 2e-4, nm, floor=1e-6)
+
+
+def test_gram_losses_grouped(ops):
+    from oracle import sgcn_img_snp as OS
+    rng = np.random.default_rng(1)
+    bsz, rd = 16, 96
+    s = torch.from_numpy(rng.standard_normal((2 * bsz, rd)) + 0.3).float()
+    tsne = torch.from_numpy(rng.random((bsz, 8)) * 3).float()
+    sr = s.double().requires_grad_(True)
+    ref = [0.7 * OS.consist_loss(sr[k * bsz:(k + 1) * bsz], tsne.double(), 0.01) * (k + 1)
+           + 0.3 * OS.orthogonal_constraint(sr[k * bsz:(k + 1) * bsz]) for k in range(2)]
+    g_ref = torch.autograd.grad(ref[0] + ref[1], sr)[0]
+    sg = s.cuda().requires_grad_(True)
+    lap = ops.rbf_laplacian(tsne.cuda(), bsz, 0.01, "cuda")
+    c, o = ops.GramLosses.apply(sg, lap, 2)
+    w = torch.tensor([1.0, 2.0], device="cuda")
+    g = torch.autograd.grad((0.7 * c * w).sum() + 0.3 * o.sum(), sg)[0]
+    assert_matches(g, g_ref.numpy(), 2e-4, "ds")
