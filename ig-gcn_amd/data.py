@@ -113,6 +113,8 @@ class Batch(Data):
         out._num_graphs = len(data_list)
         out.ptr = torch.tensor(node_ptr, dtype=torch.long)
         out.edge_ptr = torch.tensor(edge_ptr, dtype=torch.long)
+        out._max_nodes = max(b - a for a, b in zip(node_ptr[:-1], node_ptr[1:]))
+        out._max_edges = max(b - a for a, b in zip(edge_ptr[:-1], edge_ptr[1:]))
         return out.contiguous()
 
     @property

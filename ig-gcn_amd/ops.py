@@ -22,7 +22,11 @@ def _f32(t):
 class GraphPlan:
     """Stable by-target / by-source grouping of a batch's edges (igcn_graph_plan_build)."""
 
-    def __init__(self, edge_index, n_nodes):
+    SEG_MAX_NODES, SEG_MAX_EDGES = 1024, 4096
+
+    def __init__(self, edge_index, n_nodes, node_ptr=None, edge_ptr=None, max_nodes=None, max_edges=None):
+        """``node_ptr``/``edge_ptr`` (int64 device tensors [G+1]) + the host-known per-graph maxima select the
+        segmented build (one workgroup per graph, no device-wide sort); otherwise the general radix-sort build."""
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise _lib.IgcnError("edge_index must be int64 [2,E]")
         ei = edge_index.contiguous()
@@ -37,6 +41,17 @@ class GraphPlan:
         self.src_ptr = torch.empty(n + 1, **i32)
         self.src_perm = torch.empty(max(e, 1), **i32)
         self.loop_edge = torch.empty(n, **i32)
+        self._copies = {}
+        self.status = None
+        if (node_ptr is not None and edge_ptr is not None and max_nodes is not None and max_edges is not None
+                and 0 < max_nodes <= self.SEG_MAX_NODES and max_edges <= self.SEG_MAX_EDGES and e > 0
+                and node_ptr.device == dev and edge_ptr.device == dev):
+            self.status = torch.zeros(1, **i32)
+            call("igcn_graph_plan_build_segmented", n, e, int(node_ptr.numel()) - 1, ptr(ei),
+                 ptr(node_ptr.contiguous()), ptr(edge_ptr.contiguous()), int(max_nodes), int(max_edges),
+                 ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr), ptr(self.tgt_perm), ptr(self.src_ptr),
+                 ptr(self.src_perm), ptr(self.loop_edge), ptr(self.status), stream_ptr())
+            return
         lib = _lib.load()
         wbytes = int(lib.igcn_graph_plan_workspace_bytes(n, e))
         ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
@@ -44,7 +59,11 @@ class GraphPlan:
              ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(ws), wbytes,
              stream_ptr())
         self._ws = ws            # keep alive until the stream has consumed it
-        self._copies = {}
+
+    def check(self):
+        """Host-synchronising validation of the segmented build (tests / debugging only)."""
+        if self.status is not None and int(self.status.item()) != 0:
+            raise _lib.IgcnError("graph plan: the batch is not block diagonal within the declared graph segments")
 
     def replicate(self, copies):
         """Plan of ``copies`` disjoint copies of this batch (igcn_graph_plan_replicate), cached."""
@@ -72,7 +91,9 @@ def plan_for(data):
     """The GraphPlan of a batch object, built on first use and cached on it."""
     plan = getattr(data, "_igcn_plan", None)
     if plan is None or plan.n_edges != data.edge_index.shape[1] or plan.src32.device != data.edge_index.device:
-        plan = GraphPlan(data.edge_index, data.x.shape[0])
+        plan = GraphPlan(data.edge_index, data.x.shape[0], getattr(data, "ptr", None),
+                         getattr(data, "edge_ptr", None), getattr(data, "_max_nodes", None),
+                         getattr(data, "_max_edges", None))
         try:
             data._igcn_plan = plan
         except AttributeError:

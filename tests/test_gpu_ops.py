@@ -443,3 +443,31 @@ def test_gram_losses_grouped(ops):
     w = torch.tensor([1.0, 2.0], device="cuda")
     g = torch.autograd.grad((0.7 * c * w).sum() + 0.3 * o.sum(), sg)[0]
     assert_matches(g, g_ref.numpy(), 2e-4, "ds")
+
+
+@pytest.mark.parametrize("n_graphs,seed", [(1, 0), (8, 1), (256, 2)])
+def test_segmented_plan_is_bit_identical_to_the_sorted_plan(ops, n_graphs, seed):
+    from igcn_amd import synth
+    batch = synth.brain_batch(n_graphs, seed=seed, rois=90).to("cuda")
+    seg = ops.plan_for(batch)
+    assert seg.status is not None          # the one-workgroup-per-graph path was taken
+    seg.check()
+    ref = ops.GraphPlan(batch.edge_index, batch.x.shape[0])          # device-wide stable radix sort
+    for name in ("src32", "dst32", "tgt_ptr", "tgt_perm", "src_ptr", "src_perm", "loop_edge"):
+        assert torch.equal(getattr(seg, name), getattr(ref, name)), name
+
+
+def test_segmented_plan_ragged_graphs_and_loops(ops):
+    from igcn_amd.data import Batch, Data
+    rng = np.random.default_rng(5)
+    graphs = []
+    for n in (1, 7, 90, 33, 2):
+        e = int(rng.integers(0, 6 * n + 1))
+        ei = torch.from_numpy(rng.integers(0, n, (2, e))).long()
+        graphs.append(Data(x=torch.zeros(n, 3), edge_index=ei, edge_attr=torch.ones(e)))
+    batch = Batch.from_data_list(graphs).to("cuda")
+    seg = ops.plan_for(batch)
+    seg.check()
+    ref = ops.GraphPlan(batch.edge_index, batch.x.shape[0])
+    for name in ("tgt_ptr", "tgt_perm", "src_ptr", "src_perm", "loop_edge"):
+        assert torch.equal(getattr(seg, name), getattr(ref, name)), name
