@@ -43,22 +43,19 @@ def build_model(device):
     return model, (go_snps, adj, pool_dim)
 
 
-def scatter_roofline(data, device, iters=200):
-    """Live roofline of the GCN scatter-aggregate kernel (igcn_gcn_propagate_fwd, F=16) on this batch:
-    algorithmic bytes = (20*E' + 8*R*F) per graph over the HIP-event time of the launch."""
+def _time_propagate(plan, ew, n, f, device, iters, nodes_per_graph=0):
+    """Average device time (us) of igcn_gcn_propagate_fwd: `iters` back-to-back launches captured in one hipGraph
+    and bracketed by two HIP events on the launch stream."""
     from igcn_amd import ops
-    plan = ops.plan_for(data)
-    n, f = data.x.shape[0], HIDDEN
-    coef = ops.GcnNorm.apply(data.edge_attr, plan)
+    from igcn_amd._lib import call, stream_ptr
+    coef = ops.GcnNorm.apply(ew, plan)
     h = torch.randn(n, f, device=device)
     bias = torch.zeros(f, device=device)
     out = torch.empty_like(h)
-    args = (n, plan.n_edges, f, h.data_ptr(), f, coef[0].data_ptr(), coef[1].data_ptr(), bias.data_ptr(),
-            plan.src32.data_ptr(), plan.tgt_ptr.data_ptr(), plan.tgt_perm.data_ptr(), out.data_ptr(), f, 1)
-    from igcn_amd._lib import call, stream_ptr
-    for _ in range(10):
+    args = (n, plan.n_edges, f, nodes_per_graph, h.data_ptr(), f, coef[2].data_ptr(), coef[1].data_ptr(),
+            bias.data_ptr(), plan.tgt_ptr.data_ptr(), out.data_ptr(), f, 1)
+    for _ in range(5):
         call("igcn_gcn_propagate_fwd", *args, stream_ptr())
-    # one hipGraph of `iters` back-to-back launches: the event pair brackets device time only
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(iters):
@@ -70,14 +67,47 @@ def scatter_roofline(data, device, iters=200):
     g.replay()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def scatter_roofline(data, device, iters=200):
+    """Live roofline of the GCN scatter-aggregate kernel (igcn_gcn_propagate_fwd, F=16) exactly as the train step
+    launches it: both passes batched = 2 copies of the batch's graphs.  Algorithmic bytes = (20*E' + 8*R*F) per
+    graph (int64 endpoints + fp32 coefficient per edge, each feature row read and written once)."""
+    from igcn_amd import ops
+    plan = ops.plan_for(data).replicate(2)
+    n, f = 2 * data.x.shape[0], HIDDEN
+    us = _time_propagate(plan, torch.cat([data.edge_attr, data.edge_attr]), n, f, device, iters)
     n_graphs = n // ROIS
     e_prime = plan.n_edges // n_graphs          # GDC graphs store their self-loops: E' = E
     alg_bytes = n_graphs * (20 * e_prime + 8 * ROIS * f)
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "k_gcn_propagate_fwd<16>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+    return {"bound": "hbm", "kernel": "k_gcn_propagate_fwd_q<4>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-            "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3)}
+            "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
+            "launch": f"{n_graphs} graphs x {e_prime} edges (both passes of a step), F={f}"}
+
+
+def scatter_roofline_stress(device, n_graphs=32, rois=512, f=16, iters=20):
+    """The same kernel at the stress shape of BASELINE.json configs[4] (512-ROI dense graphs, E' = R^2 per graph):
+    the launch moves ~170 MB, so it is bandwidth- rather than latency-limited."""
+    import numpy as np
+    from igcn_amd import ops
+    rng = np.random.default_rng(0)
+    r = torch.arange(rois).repeat_interleave(rois)
+    c = torch.arange(rois).repeat(rois)
+    ei = torch.cat([torch.stack([r, c]) + g * rois for g in range(n_graphs)], dim=1).to(device)
+    w = torch.from_numpy(rng.random(ei.shape[1]).astype(np.float32) / rois).to(device)
+    n = n_graphs * rois
+    plan = ops.GraphPlan(ei, n)
+    us = _time_propagate(plan, w, n, f, device, iters, nodes_per_graph=rois)
+    e_prime = rois * rois
+    alg_bytes = n_graphs * (20 * e_prime + 8 * rois * f)
+    gbs = alg_bytes / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "k_gcn_propagate_fwd_wide<4>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
+            "launch": f"{n_graphs} dense graphs x {rois} ROIs ({e_prime} edges each), F={f}"}
 
 
 def cpu_baseline(go, seconds=20.0):
@@ -130,6 +160,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay of the step")
+    ap.add_argument("--no-stress", action="store_true", help="skip the stress-shape roofline measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,6 +231,8 @@ def main():
             "loss": round(float(loss), 6),
         }
         res["roofline"] = scatter_roofline(data, device)
+        if world == 1 and not args.no_stress:
+            res["roofline_stress"] = scatter_roofline_stress(device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(go)
         print(json.dumps(res))

@@ -154,15 +154,31 @@ __global__ void k_gcn_norm_fwd(int64_t n_nodes, const float* __restrict__ ew, co
   wl[i] = lw;
 }
 
+struct EdgeRec {      // one 8-byte record per edge: neighbour index + normalised coefficient
+  int32_t idx;
+  float w;
+};
+
 // what[k] = dis[src]*ew[k]*dis[dst] (0 for stored loops: they are replaced) ; what_loop[i] = dis[i]*wl[i]*dis[i]
 __global__ void k_gcn_norm_coef(int64_t n_nodes, int64_t n_edges, const float* __restrict__ ew,
                                 const float* __restrict__ dis, const float* __restrict__ wl,
                                 const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
-                                float* __restrict__ what, float* __restrict__ what_loop) {
+                                const int32_t* __restrict__ tgt_perm, const int32_t* __restrict__ src_perm,
+                                float* __restrict__ what, float* __restrict__ what_loop,
+                                EdgeRec* __restrict__ tstream, EdgeRec* __restrict__ sstream) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_edges) {
     const int32_t s = src32[i], t = dst32[i];
     what[i] = s != t ? dis[s] * ew[i] * dis[t] : 0.f;
+    // the same coefficients as two streams in the order the aggregation kernels consume them: position p of the
+    // by-target grouping holds (source node, coefficient), position p of the by-source grouping (target node, coef.)
+    const int32_t kt = tgt_perm[i], ks = src_perm[i];
+    const int32_t ts = src32[kt], tt = dst32[kt];
+    tstream[i].idx = ts;
+    tstream[i].w = ts != tt ? dis[ts] * ew[kt] * dis[tt] : 0.f;
+    const int32_t ss = src32[ks], st = dst32[ks];
+    sstream[i].idx = st;
+    sstream[i].w = ss != st ? dis[ss] * ew[ks] * dis[st] : 0.f;
   }
   if (i < n_nodes) {
     const float d = dis[i];
@@ -172,15 +188,15 @@ __global__ void k_gcn_norm_coef(int64_t n_nodes, int64_t n_edges, const float* _
 
 extern "C" int igcn_gcn_norm_fwd(int64_t n_nodes, int64_t n_edges, const float* ew, const int32_t* src32,
                                  const int32_t* dst32, const int32_t* tgt_ptr, const int32_t* tgt_perm,
-                                 const int32_t* loop_edge, float* dis, float* wl, float* what, float* what_loop,
-                                 void* stream) {
+                                 const int32_t* src_perm, const int32_t* loop_edge, float* dis, float* wl,
+                                 float* what, float* what_loop, void* tstream, void* sstream, void* stream) {
   if (n_nodes == 0) return IGCN_OK;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_gcn_norm_fwd, dim3((unsigned)igcn_cdiv(n_nodes, 256)), dim3(256), 0, st, n_nodes, ew, src32,
                      tgt_ptr, tgt_perm, loop_edge, dis, wl);
   const int64_t n = n_nodes > n_edges ? n_nodes : n_edges;
   hipLaunchKernelGGL(k_gcn_norm_coef, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, st, n_nodes, n_edges, ew, dis,
-                     wl, src32, dst32, what, what_loop);
+                     wl, src32, dst32, tgt_perm, src_perm, what, what_loop, (EdgeRec*)tstream, (EdgeRec*)sstream);
   IGCN_CHECK_LAUNCH("gcn_norm_fwd");
   return IGCN_OK;
 }
@@ -253,9 +269,8 @@ extern "C" int igcn_gcn_norm_bwd(int64_t n_nodes, int64_t n_edges, const float* 
 template <int FP>
 __global__ void __launch_bounds__(256)
 k_gcn_propagate_fwd(int64_t n_nodes, int F, const float* __restrict__ h, int64_t ld_h,
-                    const float* __restrict__ what, const float* __restrict__ what_loop,
-                    const float* __restrict__ bias, const int32_t* __restrict__ src32,
-                    const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
+                    const EdgeRec* __restrict__ tstream, const float* __restrict__ what_loop,
+                    const float* __restrict__ bias, const int32_t* __restrict__ tgt_ptr,
                     float* __restrict__ out, int64_t ld_out, int relu) {
   constexpr int NPB = 256 / FP;  // nodes per block
   const int f = threadIdx.x % FP;
@@ -263,15 +278,85 @@ k_gcn_propagate_fwd(int64_t n_nodes, int F, const float* __restrict__ h, int64_t
   if (t >= n_nodes || f >= F) return;
   float acc = 0.f;
   const int32_t p1 = tgt_ptr[t + 1];
-  for (int32_t p = tgt_ptr[t]; p < p1; ++p) {
-    const int32_t k = tgt_perm[p];
-    const int32_t s = src32[k];
-    if (s != (int32_t)t) acc += what[k] * h[(int64_t)s * ld_h + f];
+#pragma unroll 4
+  for (int32_t p = tgt_ptr[t]; p < p1; ++p) {      // coalesced 8-byte records; stored loops carry w = 0
+    const EdgeRec e = tstream[p];
+    acc += e.w * h[(int64_t)e.idx * ld_h + f];
   }
   acc += what_loop[t] * h[t * ld_h + f];
   acc += bias ? bias[f] : 0.f;
   if (relu) acc = fmaxf(acc, 0.f);
   out[t * ld_out + f] = acc;
+}
+
+// Low in-degree shape with 16 bytes per lane: thread = (target, feature quad).  F/4 lanes share a target, so a wave
+// covers 64/(F/4) targets; per edge step it issues one 8-byte record load and one 16-byte row gather (a quarter of
+// the vector-memory instructions of the thread-per-feature shape) and needs no cross-lane reduction.
+template <int FQ>
+__global__ void __launch_bounds__(256)
+k_gcn_propagate_fwd_q(int64_t n_nodes, const float* __restrict__ h, int64_t ld_h,
+                      const EdgeRec* __restrict__ tstream, const float* __restrict__ what_loop,
+                      const float* __restrict__ bias, const int32_t* __restrict__ tgt_ptr,
+                      float* __restrict__ out, int64_t ld_out, int relu) {
+  constexpr int NPB = 256 / FQ;
+  const int fq = threadIdx.x % FQ;
+  const int64_t t = (int64_t)blockIdx.x * NPB + threadIdx.x / FQ;
+  if (t >= n_nodes) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int32_t p1 = tgt_ptr[t + 1];
+#pragma unroll 4
+  for (int32_t p = tgt_ptr[t]; p < p1; ++p) {
+    const EdgeRec e = tstream[p];
+    const float4 r = *reinterpret_cast<const float4*>(h + (int64_t)e.idx * ld_h + fq * 4);
+    acc.x += e.w * r.x; acc.y += e.w * r.y; acc.z += e.w * r.z; acc.w += e.w * r.w;
+  }
+  const float wl = what_loop[t];
+  const float4 hs = *reinterpret_cast<const float4*>(h + t * ld_h + fq * 4);
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) b4 = *reinterpret_cast<const float4*>(bias + fq * 4);
+  acc.x += wl * hs.x + b4.x; acc.y += wl * hs.y + b4.y; acc.z += wl * hs.z + b4.z; acc.w += wl * hs.w + b4.w;
+  if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+  *reinterpret_cast<float4*>(out + t * ld_out + fq * 4) = acc;
+}
+
+// High in-degree variant (dense graphs: hundreds of edges per target): one wave per target node, every lane moves
+// 16 bytes per memory instruction.  With FQ = F/4 lanes per feature row the wave covers 64/FQ edge slots: per step
+// it issues ONE 8-byte record load (64/FQ consecutive records = up to 128 contiguous bytes) and ONE 16-byte row
+// gather (64/FQ rows of F floats).  The vector-memory path retires one wave instruction per ~16 cycles whatever
+// the width, so the (target, feature)-per-thread shape (4 B per lane) would be instruction-bound here.
+template <int FQ>
+__global__ void __launch_bounds__(256)
+k_gcn_propagate_fwd_wide(int64_t n_nodes, const float* __restrict__ h, int64_t ld_h,
+                         const EdgeRec* __restrict__ tstream, const float* __restrict__ what_loop,
+                         const float* __restrict__ bias, const int32_t* __restrict__ tgt_ptr,
+                         float* __restrict__ out, int64_t ld_out, int relu) {
+  constexpr int SL = 64 / FQ;                     // edge slots per wave
+  const int lane = threadIdx.x & 63;
+  const int fq = lane % FQ, slot = lane / FQ;
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= n_nodes) return;                       // wave-uniform
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int32_t p1 = tgt_ptr[t + 1];
+#pragma unroll 4
+  for (int32_t p = tgt_ptr[t] + slot; p < p1; p += SL) {
+    const EdgeRec e = tstream[p];
+    const float4 r = *reinterpret_cast<const float4*>(h + (int64_t)e.idx * ld_h + fq * 4);
+    acc.x += e.w * r.x; acc.y += e.w * r.y; acc.z += e.w * r.z; acc.w += e.w * r.w;
+  }
+#pragma unroll
+  for (int o = FQ; o < 64; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  if (slot == 0) {
+    const float wl = what_loop[t];
+    const float4 hs = *reinterpret_cast<const float4*>(h + t * ld_h + fq * 4);
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b4 = *reinterpret_cast<const float4*>(bias + fq * 4);
+    acc.x += wl * hs.x + b4.x; acc.y += wl * hs.y + b4.y; acc.z += wl * hs.z + b4.z; acc.w += wl * hs.w + b4.w;
+    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    *reinterpret_cast<float4*>(out + t * ld_out + fq * 4) = acc;
+  }
 }
 
 static int pow2_ge(int F) {
@@ -280,18 +365,51 @@ static int pow2_ge(int F) {
   return p;
 }
 
-extern "C" int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, const float* h, int64_t ld_h,
-                                      const float* what, const float* what_loop, const float* bias,
-                                      const int32_t* src32, const int32_t* tgt_ptr, const int32_t* tgt_perm,
+extern "C" int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, int nodes_per_graph,
+                                      const float* h, int64_t ld_h,
+                                      const void* tstream, const float* what_loop, const float* bias,
+                                      const int32_t* tgt_ptr,
                                       float* out, int64_t ld_out, int relu, void* stream) {
-  (void)n_edges;
   IGCN_REQUIRE(F >= 1 && F <= 256, "gcn_propagate_fwd: F=%d unsupported (1..256)", F);
   if (n_nodes == 0) return IGCN_OK;
   hipStream_t st = (hipStream_t)stream;
   const int FP = pow2_ge(F);
+  (void)nodes_per_graph;
+  const bool al16 = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && ld_h % 4 == 0 && ld_out % 4 == 0 &&
+                    (bias == nullptr || (uintptr_t)bias % 16 == 0);
+  if (n_edges >= 16 * n_nodes && al16 && (F == 4 || F == 8 || F == 16 || F == 32 || F == 64)) {
+#define LAUNCH_WIDE(FQV)                                                                                          \
+  hipLaunchKernelGGL((k_gcn_propagate_fwd_wide<FQV>), dim3((unsigned)igcn_cdiv(n_nodes, 4)), dim3(256), 0, st,     \
+                     n_nodes, h, ld_h, (const EdgeRec*)tstream, what_loop, bias, tgt_ptr, out, ld_out, relu)
+    switch (F / 4) {
+      case 1: LAUNCH_WIDE(1); break;
+      case 2: LAUNCH_WIDE(2); break;
+      case 4: LAUNCH_WIDE(4); break;
+      case 8: LAUNCH_WIDE(8); break;
+      default: LAUNCH_WIDE(16); break;
+    }
+#undef LAUNCH_WIDE
+    IGCN_CHECK_LAUNCH("gcn_propagate_fwd_wide");
+    return IGCN_OK;
+  }
+  if (al16 && (F == 4 || F == 8 || F == 16 || F == 32 || F == 64)) {
+#define LAUNCH_Q(FQV)                                                                                            \
+  hipLaunchKernelGGL((k_gcn_propagate_fwd_q<FQV>), dim3((unsigned)igcn_cdiv(n_nodes, 256 / FQV)), dim3(256), 0,   \
+                     st, n_nodes, h, ld_h, (const EdgeRec*)tstream, what_loop, bias, tgt_ptr, out, ld_out, relu)
+    switch (F / 4) {
+      case 1: LAUNCH_Q(1); break;
+      case 2: LAUNCH_Q(2); break;
+      case 4: LAUNCH_Q(4); break;
+      case 8: LAUNCH_Q(8); break;
+      default: LAUNCH_Q(16); break;
+    }
+#undef LAUNCH_Q
+    IGCN_CHECK_LAUNCH("gcn_propagate_fwd_q");
+    return IGCN_OK;
+  }
 #define LAUNCH_FWD(FPV)                                                                                         \
   hipLaunchKernelGGL((k_gcn_propagate_fwd<FPV>), dim3((unsigned)igcn_cdiv(n_nodes, 256 / FPV)), dim3(256), 0, st, \
-                     n_nodes, F, h, ld_h, what, what_loop, bias, src32, tgt_ptr, tgt_perm, out, ld_out, relu)
+                     n_nodes, F, h, ld_h, (const EdgeRec*)tstream, what_loop, bias, tgt_ptr, out, ld_out, relu)
   switch (FP) {
     case 1: LAUNCH_FWD(1); break;
     case 2: LAUNCH_FWD(2); break;
@@ -316,10 +434,9 @@ extern "C" int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, c
 template <int FP>
 __global__ void __launch_bounds__(256)
 k_gcn_propagate_bwd_dh(int64_t n_nodes, int F, const float* __restrict__ dout, int64_t ld_dout,
-                       const float* __restrict__ out, int64_t ld_out, int relu, const float* __restrict__ what,
-                       const float* __restrict__ what_loop,
-                       const int32_t* __restrict__ dst32, const int32_t* __restrict__ src_ptr,
-                       const int32_t* __restrict__ src_perm, float* __restrict__ dh, int64_t ld_dh,
+                       const float* __restrict__ out, int64_t ld_out, int relu,
+                       const EdgeRec* __restrict__ sstream, const float* __restrict__ what_loop,
+                       const int32_t* __restrict__ src_ptr, float* __restrict__ dh, int64_t ld_dh,
                        float* __restrict__ dbias_partial /*[nblk, FP]*/) {
   constexpr int NPB = 256 / FP;
   __shared__ float red[256];
@@ -330,14 +447,12 @@ k_gcn_propagate_bwd_dh(int64_t n_nodes, int F, const float* __restrict__ dout, i
   if (s < n_nodes && f < F) {
     float acc = 0.f;
     const int32_t p1 = src_ptr[s + 1];
+#pragma unroll 4
     for (int32_t p = src_ptr[s]; p < p1; ++p) {
-      const int32_t k = src_perm[p];
-      const int32_t t = dst32[k];
-      if (t != (int32_t)s) {
-        float g = dout[(int64_t)t * ld_dout + f];
-        if (relu && !(out[(int64_t)t * ld_out + f] > 0.f)) g = 0.f;
-        acc += what[k] * g;
-      }
+      const EdgeRec e = sstream[p];
+      float g = dout[(int64_t)e.idx * ld_dout + f];
+      if (relu && !(out[(int64_t)e.idx * ld_out + f] > 0.f)) g = 0.f;
+      acc += e.w * g;
     }
     gself = dout[s * ld_dout + f];
     if (relu && !(out[s * ld_out + f] > 0.f)) gself = 0.f;
@@ -351,6 +466,55 @@ k_gcn_propagate_bwd_dh(int64_t n_nodes, int F, const float* __restrict__ dout, i
     float t = 0.f;
     for (int j = 0; j < NPB; ++j) t += red[j * FP + threadIdx.x];
     dbias_partial[(int64_t)blockIdx.x * FP + threadIdx.x] = t;
+  }
+}
+
+// 16-bytes-per-lane shape of the above: thread = (source node, feature quad)
+template <int FQ>
+__global__ void __launch_bounds__(256)
+k_gcn_propagate_bwd_dh_q(int64_t n_nodes, const float* __restrict__ dout, int64_t ld_dout,
+                         const float* __restrict__ out, int64_t ld_out, int relu,
+                         const EdgeRec* __restrict__ sstream, const float* __restrict__ what_loop,
+                         const int32_t* __restrict__ src_ptr, float* __restrict__ dh, int64_t ld_dh,
+                         float* __restrict__ dbias_partial /*[nblk, 4*FQ]*/) {
+  constexpr int NPB = 256 / FQ;
+  __shared__ float4 red[256];
+  const int fq = threadIdx.x % FQ, nl = threadIdx.x / FQ;
+  const int64_t s = (int64_t)blockIdx.x * NPB + nl;
+  float4 gself = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (s < n_nodes) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t p1 = src_ptr[s + 1];
+#pragma unroll 4
+    for (int32_t p = src_ptr[s]; p < p1; ++p) {
+      const EdgeRec e = sstream[p];
+      float4 g = *reinterpret_cast<const float4*>(dout + (int64_t)e.idx * ld_dout + fq * 4);
+      if (relu) {
+        const float4 o = *reinterpret_cast<const float4*>(out + (int64_t)e.idx * ld_out + fq * 4);
+        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      acc.x += e.w * g.x; acc.y += e.w * g.y; acc.z += e.w * g.z; acc.w += e.w * g.w;
+    }
+    gself = *reinterpret_cast<const float4*>(dout + s * ld_dout + fq * 4);
+    if (relu) {
+      const float4 o = *reinterpret_cast<const float4*>(out + s * ld_out + fq * 4);
+      gself.x = o.x > 0.f ? gself.x : 0.f; gself.y = o.y > 0.f ? gself.y : 0.f;
+      gself.z = o.z > 0.f ? gself.z : 0.f; gself.w = o.w > 0.f ? gself.w : 0.f;
+    }
+    const float wl = what_loop[s];
+    acc.x += wl * gself.x; acc.y += wl * gself.y; acc.z += wl * gself.z; acc.w += wl * gself.w;
+    *reinterpret_cast<float4*>(dh + s * ld_dh + fq * 4) = acc;
+  }
+  red[threadIdx.x] = gself;
+  __syncthreads();
+  if (threadIdx.x < FQ) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NPB; ++j) {
+      const float4 v = red[j * FQ + threadIdx.x];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    float* dst = dbias_partial + ((int64_t)blockIdx.x * FQ + threadIdx.x) * 4;
+    dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
   }
 }
 
@@ -390,18 +554,35 @@ extern "C" size_t igcn_gcn_propagate_bwd_scratch_floats(int64_t n_nodes, int F) 
 
 extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, const float* dout, int64_t ld_dout,
                                       const float* out, int64_t ld_out, int relu, const float* h, int64_t ld_h,
-                                      const float* what, const float* what_loop, const int32_t* src32,
-                                      const int32_t* dst32, const int32_t* src_ptr, const int32_t* src_perm,
+                                      const void* sstream, const float* what_loop, const int32_t* src32,
+                                      const int32_t* dst32, const int32_t* src_ptr,
                                       float* dh, int64_t ld_dh, float* dbias, int need_dw,
                                       float* dwhat, float* dwhat_loop, float* scratch, void* stream) {
   IGCN_REQUIRE(F >= 1 && F <= 256, "gcn_propagate_bwd: F=%d unsupported (1..256)", F);
   if (n_nodes == 0) return IGCN_OK;
   hipStream_t st = (hipStream_t)stream;
   const int FP = pow2_ge(F);
-  const int64_t nblk = igcn_cdiv(n_nodes, 256 / FP);
+  int64_t nblk = igcn_cdiv(n_nodes, 256 / FP);
+  const bool al16 = ((uintptr_t)dout % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)dh % 16 == 0) &&
+                    ld_dout % 4 == 0 && ld_out % 4 == 0 && ld_dh % 4 == 0;
+  const bool quad = al16 && (F == 4 || F == 8 || F == 16 || F == 32 || F == 64);
+  if (quad) {
+    nblk = igcn_cdiv(n_nodes, 256 / (F / 4));
+#define LAUNCH_BQ(FQV)                                                                                            \
+  hipLaunchKernelGGL((k_gcn_propagate_bwd_dh_q<FQV>), dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, dout,       \
+                     ld_dout, out, ld_out, relu, (const EdgeRec*)sstream, what_loop, src_ptr, dh, ld_dh, scratch)
+    switch (F / 4) {
+      case 1: LAUNCH_BQ(1); break;
+      case 2: LAUNCH_BQ(2); break;
+      case 4: LAUNCH_BQ(4); break;
+      case 8: LAUNCH_BQ(8); break;
+      default: LAUNCH_BQ(16); break;
+    }
+#undef LAUNCH_BQ
+  } else {
 #define LAUNCH_BWD(FPV)                                                                                          \
   hipLaunchKernelGGL((k_gcn_propagate_bwd_dh<FPV>), dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, F, dout,    \
-                     ld_dout, out, ld_out, relu, what, what_loop, dst32, src_ptr, src_perm, dh, ld_dh, scratch)
+                     ld_dout, out, ld_out, relu, (const EdgeRec*)sstream, what_loop, src_ptr, dh, ld_dh, scratch)
   switch (FP) {
     case 1: LAUNCH_BWD(1); break;
     case 2: LAUNCH_BWD(2); break;
@@ -414,9 +595,10 @@ extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, c
     default: LAUNCH_BWD(256); break;
   }
 #undef LAUNCH_BWD
+  }
   IGCN_CHECK_LAUNCH("gcn_propagate_bwd_dh");
   if (dbias) {
-    int rc = igcn_launch_reduce_rows(scratch, nblk, FP, F, dbias, 0, st);
+    int rc = igcn_launch_reduce_rows(scratch, nblk, quad ? F : FP, F, dbias, 0, st);
     if (rc) return rc;
   }
   if (need_dw) {

@@ -135,7 +135,10 @@ class EdgeMask(torch.autograd.Function):
 
 
 class GcnNorm(torch.autograd.Function):
-    """PyG gcn_norm (add_remaining_self_loops + symmetric normalisation) -> (what [E], what_loop [N])."""
+    """PyG gcn_norm (add_remaining_self_loops + symmetric normalisation) -> (what [E], what_loop [N], streams).
+
+    ``streams`` = (tstream, sstream): the same coefficients as 8-byte (neighbour, coefficient) records in by-target /
+    by-source order, consumed by the aggregation kernels; not differentiable (gradients flow through ``what``)."""
 
     @staticmethod
     def forward(ctx, ew, plan):
@@ -144,14 +147,17 @@ class GcnNorm(torch.autograd.Function):
         f = dict(dtype=torch.float32, device=ew.device)
         dis, wl = torch.empty(n, **f), torch.empty(n, **f)
         what, wloop = torch.empty(max(e, 1), **f), torch.empty(n, **f)
+        tstream, sstream = torch.empty(max(e, 1), 2, **f), torch.empty(max(e, 1), 2, **f)
         call("igcn_gcn_norm_fwd", n, e, ptr(ew), ptr(plan.src32), ptr(plan.dst32), ptr(plan.tgt_ptr),
-             ptr(plan.tgt_perm), ptr(plan.loop_edge), ptr(dis), ptr(wl), ptr(what), ptr(wloop), stream_ptr())
+             ptr(plan.tgt_perm), ptr(plan.src_perm), ptr(plan.loop_edge), ptr(dis), ptr(wl), ptr(what), ptr(wloop),
+             ptr(tstream), ptr(sstream), stream_ptr())
         ctx.save_for_backward(ew, dis, wl)
         ctx.plan = plan
-        return what, wloop
+        ctx.mark_non_differentiable(tstream, sstream)
+        return what, wloop, tstream, sstream
 
     @staticmethod
-    def backward(ctx, dwhat, dwloop):
+    def backward(ctx, dwhat, dwloop, _dt, _ds):
         ew, dis, wl = ctx.saved_tensors
         plan = ctx.plan
         n, e = plan.n_nodes, plan.n_edges
@@ -166,23 +172,24 @@ class GcnNorm(torch.autograd.Function):
 
 
 class GcnPropagate(torch.autograd.Function):
-    """out = act(A_hat h + bias): the scatter-aggregate of GCNConv (+ F.relu of sgcn_img_snp.py:218,221)."""
+    """out = act(A_hat h + bias): the scatter-aggregate of GCNConv (+ F.relu of sgcn_img_snp.py:218,221).
+    ``what`` carries the autograd dependency on the edge weights; the kernels read the sorted ``streams``."""
 
     @staticmethod
-    def forward(ctx, h, what, wloop, bias, plan, relu):
-        h, what, wloop = _f32(h), _f32(what), _f32(wloop)
+    def forward(ctx, h, what, wloop, bias, plan, relu, tstream, sstream):
+        h, wloop = _f32(h), _f32(wloop)
         bias = _f32(bias) if bias is not None else None
         n, f = h.shape
         out = torch.empty_like(h)
-        call("igcn_gcn_propagate_fwd", n, plan.n_edges, f, ptr(h), f, ptr(what), ptr(wloop), ptr(bias),
-             ptr(plan.src32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(out), f, int(relu), stream_ptr())
-        ctx.save_for_backward(h, what, wloop, out)
+        call("igcn_gcn_propagate_fwd", n, plan.n_edges, f, int(getattr(plan, "nodes_per_graph", 0) or 0), ptr(h), f,
+             ptr(tstream), ptr(wloop), ptr(bias), ptr(plan.tgt_ptr), ptr(out), f, int(relu), stream_ptr())
+        ctx.save_for_backward(h, what, wloop, out, sstream)
         ctx.plan, ctx.relu, ctx.has_bias = plan, int(relu), bias is not None
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        h, what, wloop, out = ctx.saved_tensors
+        h, what, wloop, out, sstream = ctx.saved_tensors
         plan = ctx.plan
         dout = _f32(dout)
         n, f = h.shape
@@ -195,9 +202,9 @@ class GcnPropagate(torch.autograd.Function):
         scratch = torch.empty(int(lib.igcn_gcn_propagate_bwd_scratch_floats(n, f)), dtype=torch.float32,
                               device=h.device)
         call("igcn_gcn_propagate_bwd", n, plan.n_edges, f, ptr(dout), f, ptr(out), f, ctx.relu, ptr(h), f,
-             ptr(what), ptr(wloop), ptr(plan.src32), ptr(plan.dst32), ptr(plan.src_ptr), ptr(plan.src_perm),
-             ptr(dh), f, ptr(dbias), int(need_dw), ptr(dwhat), ptr(dwloop), ptr(scratch), stream_ptr())
-        return dh, dwhat, dwloop, dbias, None, None
+             ptr(sstream), ptr(wloop), ptr(plan.src32), ptr(plan.dst32), ptr(plan.src_ptr), ptr(dh), f, ptr(dbias),
+             int(need_dw), ptr(dwhat), ptr(dwloop), ptr(scratch), stream_ptr())
+        return dh, dwhat, dwloop, dbias, None, None, None, None
 
 
 # =================================================================================================

@@ -40,9 +40,9 @@ class GCNConv(torch.nn.Module):
             self.bias.zero_()
 
     def forward(self, x, plan, coef, relu=False):
-        what, wloop = coef
+        what, wloop, tstream, sstream = coef
         h = ops.linear(x, self.lin.weight)
-        return ops.GcnPropagate.apply(h, what, wloop, self.bias, plan, relu)
+        return ops.GcnPropagate.apply(h, what, wloop, self.bias, plan, relu, tstream, sstream)
 
 
 def rbf_kernel_torch(X, Y, gamma=0.015):

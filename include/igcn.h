@@ -97,7 +97,12 @@ int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, int h0,
  */
 int igcn_gcn_norm_fwd(int64_t n_nodes, int64_t n_edges, const float* ew,
                       const int32_t* src32, const int32_t* dst32, const int32_t* tgt_ptr, const int32_t* tgt_perm,
-                      const int32_t* loop_edge, float* dis, float* wl, float* what, float* what_loop, void* stream);
+                      const int32_t* src_perm, const int32_t* loop_edge, float* dis, float* wl,
+                      float* what, float* what_loop, void* tstream /*[E] x 8 B*/, void* sstream /*[E] x 8 B*/,
+                      void* stream);
+/* tstream[p] = {int32 source node, float coefficient} of the p-th edge of the by-TARGET grouping, sstream[p] =
+ * {int32 target node, float coefficient} of the p-th edge of the by-SOURCE grouping: the aggregation kernels stream
+ * these 8-byte records coalesced instead of chasing permutation -> edge -> endpoint. */
 /* dwhat [E] (entries of stored loops ignored) and dwhat_loop [N] are d(loss)/d(coefficient) summed over all
  * layers.  Output dew [E].  scratch: float[N]. */
 int igcn_gcn_norm_bwd(int64_t n_nodes, int64_t n_edges, const float* ew, const float* dis, const float* wl,
@@ -110,15 +115,17 @@ int igcn_gcn_norm_bwd(int64_t n_nodes, int64_t n_edges, const float* ew, const f
 /* ------------------------------------------------------------------------------------------------
  * GCN scatter-aggregate (the north-star kernel) — GCNConv.propagate + bias (+ the F.relu of
  * kernel/sgcn_img_snp.py:218,221):
- *   out[t, :F] = act( sum_{k: dst=t, src!=dst} what[k] * h[src_k,:] + what_loop[t]*h[t,:] + bias )
+ *   out[t, :F] = act( sum_{p in group(t)} tstream[p].w * h[tstream[p].idx,:] + what_loop[t]*h[t,:] + bias )
  * summed in the reference's scatter order (non-loop edges in stored order, then the loop).
  * h [N,F] row stride ld_h; out row stride ld_out (so a layer can write its column slice of the JK-concat
- * buffer of :223 directly).  relu != 0 applies max(.,0).
+ * buffer of :223 directly).  relu != 0 applies max(.,0).  Two launch shapes, picked from the arguments:
+ * thread = (target, feature) for low in-degree (brain graphs, k = 3); for an average in-degree >= 16 one wave per
+ * target in which every lane moves 16 bytes per memory instruction (F/4 lanes per feature row, 64/(F/4) edge slots).
+ * `nodes_per_graph` (uniform graph size, 0 = unknown) is a hint reserved for LDS-staged variants.
  */
-int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, const float* h, int64_t ld_h,
-                           const float* what, const float* what_loop, const float* bias,
-                           const int32_t* src32, const int32_t* tgt_ptr, const int32_t* tgt_perm,
-                           float* out, int64_t ld_out, int relu, void* stream);
+int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, int nodes_per_graph /*0 = unknown*/,
+                           const float* h, int64_t ld_h, const void* tstream, const float* what_loop, const float* bias,
+                           const int32_t* tgt_ptr, float* out, int64_t ld_out, int relu, void* stream);
 /* Backward of the above.  g = dout * (out>0 if relu).  Outputs:
  *   dh [N,F] (row stride ld_dh)  = A_hat^T g          dbias [F] (may be NULL)
  *   dwhat [E] = g[dst_k].h[src_k] (0 at stored loops), dwhat_loop [N] = g[i].h[i]   (only when need_dw != 0)
@@ -126,9 +133,8 @@ int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, const float*
 size_t igcn_gcn_propagate_bwd_scratch_floats(int64_t n_nodes, int F);
 int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F,
                            const float* dout, int64_t ld_dout, const float* out, int64_t ld_out, int relu,
-                           const float* h, int64_t ld_h, const float* what, const float* what_loop,
-                           const int32_t* src32, const int32_t* dst32,
-                           const int32_t* src_ptr, const int32_t* src_perm,
+                           const float* h, int64_t ld_h, const void* sstream, const float* what_loop,
+                           const int32_t* src32, const int32_t* dst32, const int32_t* src_ptr,
                            float* dh, int64_t ld_dh, float* dbias,
                            int need_dw, float* dwhat, float* dwhat_loop,
                            float* scratch, void* stream);

@@ -122,7 +122,7 @@ def test_gcn_layer_fwd_bwd(ops, n, e, fin, fout, loops, multi, seed):
     plan = ops.GraphPlan(ei.cuda(), n)
     coef = ops.GcnNorm.apply(dev_in[1], plan)
     h = ops.linear(dev_in[0], dev_in[2])
-    out = ops.GcnPropagate.apply(h, coef[0], coef[1], dev_in[3], plan, True)
+    out = ops.GcnPropagate.apply(h, coef[0], coef[1], dev_in[3], plan, True, coef[2], coef[3])
     g = torch.autograd.grad((out * cot.cuda()).sum(), dev_in, allow_unused=True)
     assert_matches(out, out_ref.detach().numpy(), TOL, "out")
     for got, want, nm in zip(g, g_ref, ("dx", "dew", "dW", "db")):
@@ -471,3 +471,24 @@ def test_segmented_plan_ragged_graphs_and_loops(ops):
     ref = ops.GraphPlan(batch.edge_index, batch.x.shape[0])
     for name in ("tgt_ptr", "tgt_perm", "src_ptr", "src_perm", "loop_edge"):
         assert torch.equal(getattr(seg, name), getattr(ref, name)), name
+
+
+@pytest.mark.parametrize("hint", [0, 64])
+def test_propagate_dense_graph_variants(ops, hint):
+    """High in-degree launch shape of the scatter-aggregate (one wave per target, 16 B per lane)."""
+    from oracle import pyg_ops
+    rng = np.random.default_rng(hint)
+    g, r, f = 3, 64, 16
+    rr = torch.arange(r).repeat_interleave(r)
+    cc = torch.arange(r).repeat(r)
+    ei = torch.cat([torch.stack([rr, cc]) + k * r for k in range(g)], dim=1)
+    ew = torch.from_numpy(rng.random(ei.shape[1]) / r + 0.01).float()
+    x = torch.from_numpy(rng.standard_normal((g * r, f))).float()
+    w = torch.eye(f)
+    b = torch.from_numpy(rng.standard_normal(f)).float()
+    want = torch.relu(pyg_ops.gcn_conv(x.double(), ei, ew.double(), w.double(), b.double()))
+    plan = ops.GraphPlan(ei.cuda(), g * r)
+    plan.nodes_per_graph = hint
+    coef = ops.GcnNorm.apply(ew.cuda(), plan)
+    out = ops.GcnPropagate.apply(x.cuda(), coef[0], coef[1], b.cuda(), plan, True, coef[2], coef[3])
+    assert_matches(out, want.numpy(), TOL, "out")
