@@ -503,10 +503,128 @@ k_nodes_ln_fwd(int f, int N, int pool, float eps, const float* __restrict__ y, c
   }
 }
 
+// Register-resident form: the row (N <= 4096 floats, N and pool multiples of 4) is read ONCE with 16-byte loads and
+// kept in registers for the mean, the variance and the normalisation (the generic kernel makes three passes).
+#define LN_VPT 4
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__global__ void __launch_bounds__(GO_T)
+k_nodes_ln_fwd_v(int f, int N, int pool, float eps, const float* __restrict__ y, const float* __restrict__ gamma,
+                 const float* __restrict__ beta, const float* __restrict__ keep, float* __restrict__ z,
+                 float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  __shared__ float red[16];
+  const int row = blockIdx.x, b = row / f, nv = N / 4;
+  const float* yr = y + (int64_t)row * N;
+  float4 v[LN_VPT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_VPT; ++i) {
+    const int q = threadIdx.x + i * GO_T;
+    v[i] = q < nv ? ld4(yr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = block_sum_all(s, red) / (float)N;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_VPT; ++i) {
+    if (threadIdx.x + i * GO_T < nv) {
+      const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      var += (a * a + bb * bb) + (c * c + d * d);
+    }
+  }
+  var = block_sum_all(var, red) / (float)N;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+  float* zr = z + (int64_t)row * (N - pool);
+#pragma unroll
+  for (int i = 0; i < LN_VPT; ++i) {
+    const int q = threadIdx.x + i * GO_T, n = 4 * q;
+    if (q < nv && n >= pool) {
+      const float4 g = ld4(gamma + n), be = ld4(beta + n);
+      float4 o;
+      o.x = fmaxf((v[i].x - mean) * rstd * g.x + be.x, 0.f);
+      o.y = fmaxf((v[i].y - mean) * rstd * g.y + be.y, 0.f);
+      o.z = fmaxf((v[i].z - mean) * rstd * g.z + be.z, 0.f);
+      o.w = fmaxf((v[i].w - mean) * rstd * g.w + be.w, 0.f);
+      if (keep) {
+        const float4 k = ld4(keep + (int64_t)b * N + n);
+        o.x *= k.x; o.y *= k.y; o.z *= k.z; o.w *= k.w;
+      }
+      *reinterpret_cast<float4*>(zr + (n - pool)) = o;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(GO_T)
+k_nodes_ln_bwd_dy_v(int f, int N, int pool, const float* __restrict__ y, const float* __restrict__ gamma,
+                    const float* __restrict__ beta, const float* __restrict__ keep, const float* __restrict__ mean,
+                    const float* __restrict__ rstd, const float* __restrict__ dz, float* __restrict__ dy) {
+  __shared__ float red[16];
+  const int row = blockIdx.x, b = row / f, nv = N / 4;
+  const float mu = mean[row], rs = rstd[row];
+  const float* yr = y + (int64_t)row * N;
+  const float* dzr = dz + (int64_t)row * (N - pool);
+  float4 xh[LN_VPT], dx[LN_VPT];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_VPT; ++i) {
+    const int q = threadIdx.x + i * GO_T, n = 4 * q;
+    xh[i] = dx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < nv) {
+      const float4 yv = ld4(yr + n), g = ld4(gamma + n);
+      xh[i] = make_float4((yv.x - mu) * rs, (yv.y - mu) * rs, (yv.z - mu) * rs, (yv.w - mu) * rs);
+      if (n >= pool) {
+        const float4 be = ld4(beta + n);
+        float4 up = ld4(dzr + (n - pool));
+        if (keep) {
+          const float4 k = ld4(keep + (int64_t)b * N + n);
+          up.x *= k.x; up.y *= k.y; up.z *= k.z; up.w *= k.w;
+        }
+        dx[i].x = xh[i].x * g.x + be.x > 0.f ? up.x * g.x : 0.f;
+        dx[i].y = xh[i].y * g.y + be.y > 0.f ? up.y * g.y : 0.f;
+        dx[i].z = xh[i].z * g.z + be.z > 0.f ? up.z * g.z : 0.f;
+        dx[i].w = xh[i].w * g.w + be.w > 0.f ? up.w * g.w : 0.f;
+      }
+      s1 += (dx[i].x + dx[i].y) + (dx[i].z + dx[i].w);
+      s2 += (dx[i].x * xh[i].x + dx[i].y * xh[i].y) + (dx[i].z * xh[i].z + dx[i].w * xh[i].w);
+    }
+  }
+  s1 = block_sum_all(s1, red) / (float)N;
+  s2 = block_sum_all(s2, red) / (float)N;
+  float* dyr = dy + (int64_t)row * N;
+#pragma unroll
+  for (int i = 0; i < LN_VPT; ++i) {
+    const int q = threadIdx.x + i * GO_T;
+    if (q < nv) {
+      float4 o;
+      o.x = rs * (dx[i].x - s1 - xh[i].x * s2);
+      o.y = rs * (dx[i].y - s1 - xh[i].y * s2);
+      o.z = rs * (dx[i].z - s1 - xh[i].z * s2);
+      o.w = rs * (dx[i].w - s1 - xh[i].w * s2);
+      *reinterpret_cast<float4*>(dyr + 4 * q) = o;
+    }
+  }
+}
+
+static bool ln_vec_ok(int N, int pool, const void* a, const void* b, const void* c, const void* d, const void* e,
+                      const void* k) {
+  auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; };
+  return N % 4 == 0 && pool % 4 == 0 && N <= GO_T * 4 * LN_VPT && al(a) && al(b) && al(c) && al(d) && al(e) && al(k);
+}
+
 extern "C" int igcn_nodes_ln_fwd(int B, int f, int N, int pool, float eps, const float* y, const float* gamma,
                                  const float* beta, const float* keep, float* z, float* mean, float* rstd,
                                  void* stream) {
   IGCN_REQUIRE(B > 0 && f > 0 && N > 0 && pool >= 0 && pool < N, "nodes_ln_fwd: bad sizes");
+  if (ln_vec_ok(N, pool, y, gamma, beta, z, nullptr, keep)) {
+    hipLaunchKernelGGL(k_nodes_ln_fwd_v, dim3(B * f), dim3(GO_T), 0, (hipStream_t)stream, f, N, pool, eps, y, gamma,
+                       beta, keep, z, mean, rstd);
+    IGCN_CHECK_LAUNCH("nodes_ln_fwd_v");
+    return IGCN_OK;
+  }
   hipLaunchKernelGGL(k_nodes_ln_fwd, dim3(B * f), dim3(GO_T), 0, (hipStream_t)stream, f, N, pool, eps, y, gamma,
                      beta, keep, z, mean, rstd);
   IGCN_CHECK_LAUNCH("nodes_ln_fwd");
@@ -597,8 +715,13 @@ extern "C" int igcn_nodes_ln_bwd(int B, int f, int N, int pool, const float* y, 
                                  float* scratch, void* stream) {
   IGCN_REQUIRE(B > 0 && f > 0 && N > 0 && pool >= 0 && pool < N, "nodes_ln_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_nodes_ln_bwd_dy, dim3(B * f), dim3(GO_T), 0, st, f, N, pool, y, gamma, beta, keep, mean, rstd,
-                     dz, dy);
+  if (ln_vec_ok(N, pool, y, gamma, beta, dz, dy, keep)) {
+    hipLaunchKernelGGL(k_nodes_ln_bwd_dy_v, dim3(B * f), dim3(GO_T), 0, st, f, N, pool, y, gamma, beta, keep, mean,
+                       rstd, dz, dy);
+  } else {
+    hipLaunchKernelGGL(k_nodes_ln_bwd_dy, dim3(B * f), dim3(GO_T), 0, st, f, N, pool, y, gamma, beta, keep, mean, rstd,
+                       dz, dy);
+  }
   const int64_t chunks = igcn_cdiv((int64_t)B * f, LN_RC);
   hipLaunchKernelGGL(k_nodes_ln_bwd_affine, dim3((unsigned)igcn_cdiv(N, 64), (unsigned)chunks), dim3(256), 0, st,
                      B * f, f, N, pool, y, gamma, beta, keep, mean, rstd, dz, scratch);

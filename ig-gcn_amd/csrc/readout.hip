@@ -287,7 +287,7 @@ k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict
 
 static int ro_cpg(int B, int groups) {
   const int bg = B / groups;
-  return bg >= 8 ? 8 : (bg > 0 ? bg : 1);
+  return bg >= 32 ? 32 : (bg > 0 ? bg : 1);   // sample chunks per group: enough workgroups for small N
 }
 
 extern "C" size_t igcn_node_linear_bn_scratch_floats(int B, int N, int groups) {
