@@ -169,11 +169,19 @@ def main():
     if args.gpus > 1 and world == 1:
         print("launch multi-GPU runs with torch.distributed.run (one process per GPU)", file=sys.stderr)
         sys.exit(2)
+    # IGCN_BENCH_ONE_DEVICE=1 (rehearsal on a single-GPU box only): every rank shares cuda:0 and the gradient
+    # exchange runs over gloo, so the multi-process control flow can be exercised without several GPUs
+    rehearsal = os.environ.get("IGCN_BENCH_ONE_DEVICE", "0") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)     # backend nccl == RCCL over xGMI
 
     from igcn_amd import _lib
     from igcn_amd.train import FlatAdam, GraphedTrainStep, train_step
