@@ -29,6 +29,9 @@ GRAPHS_PER_GPU = 256
 POOL = (1800, 800, 300, 99, 1)
 LAYERS, HIDDEN, ROIS = 2, 16, 90
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# HBM bytes per launch from the rocprofv3 PMC passes of tools/roofline_kernel.py (FETCH_SIZE x2 gfx950 correction,
+# calibrated on a 256 MiB float4 copy; WRITE_SIZE x1): profiles/r01_pmc/scatter_aggregate_traffic.json
+PMC_TRAFFIC = {"bench": 10004117, "stress": 77630016}
 
 
 def build_model(device):
@@ -83,7 +86,8 @@ def scatter_roofline(data, device, iters=200):
     alg_bytes = n_graphs * (20 * e_prime + 8 * ROIS * f)
     gbs = alg_bytes / (us * 1e-6) / 1e9
     return {"bound": "hbm", "kernel": "k_gcn_propagate_fwd_q<4>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": PMC_TRAFFIC["bench"] if (n_graphs, e_prime, f) == (512, 270, 16) else None,
             "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
             "launch": f"{n_graphs} graphs x {e_prime} edges (both passes of a step), F={f}"}
 
@@ -105,7 +109,8 @@ def scatter_roofline_stress(device, n_graphs=32, rois=512, f=16, iters=20):
     alg_bytes = n_graphs * (20 * e_prime + 8 * rois * f)
     gbs = alg_bytes / (us * 1e-6) / 1e9
     return {"bound": "hbm", "kernel": "k_gcn_propagate_fwd_wide<4>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": PMC_TRAFFIC["stress"] if (n_graphs, rois, f) == (32, 512, 16) else None,
             "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
             "launch": f"{n_graphs} dense graphs x {rois} ROIs ({e_prime} edges each), F={f}"}
 
