@@ -10,18 +10,35 @@
 // =================================================================================================
 // sparse maps with learnable non-zeros (gene encode / decode)
 // =================================================================================================
+#define SPMM_HEAVY 12
+// thread = (sample, row); rows longer than SPMM_HEAVY (the GO root is linked to every SNP) are walked by the whole
+// wave so that one thread's serial walk does not set the kernel's duration
 __global__ void k_spmm_fwd(int C, int I, int J, int64_t nnz, const int32_t* __restrict__ row_ptr,
                            const int32_t* __restrict__ col, const float* __restrict__ val,
                            const float* __restrict__ x, float* __restrict__ y) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int b = blockIdx.y;
-  if (i >= I) return;
+  const bool live = i < I;
+  const int ii = live ? i : I - 1;
   const float* xb = x + (int64_t)b * J;
-  const int32_t p0 = row_ptr[i], p1 = row_ptr[i + 1];
+  const int32_t p0 = row_ptr[ii], p1 = row_ptr[ii + 1];
+  const bool heavy = live && (p1 - p0 > SPMM_HEAVY);
   for (int c = 0; c < C; ++c) {
     float acc = 0.f;
-    for (int32_t p = p0; p < p1; ++p) acc += val[(int64_t)c * nnz + p] * xb[col[p]];
-    y[((int64_t)b * C + c) * I + i] = acc;
+    if (!heavy)
+      for (int32_t p = p0; p < p1; ++p) acc += val[(int64_t)c * nnz + p] * xb[col[p]];
+    unsigned long long hm = __ballot(heavy);
+    while (hm) {
+      const int src = __ffsll((long long)hm) - 1;
+      hm &= hm - 1;
+      const int32_t h0 = __shfl(p0, src, 64), h1 = __shfl(p1, src, 64);
+      float part = 0.f;
+      for (int32_t p = h0 + lane; p < h1; p += 64) part += val[(int64_t)c * nnz + p] * xb[col[p]];
+      part = wave_sum_all(part);
+      if (lane == src) acc = part;
+    }
+    if (live) y[((int64_t)b * C + c) * I + i] = acc;
   }
 }
 
@@ -62,14 +79,33 @@ __global__ void k_spmm_bwd_dx(int C, int I, int J, int64_t nnz, const int32_t* _
                               const int32_t* __restrict__ t_row, const int32_t* __restrict__ t_k,
                               const float* __restrict__ val, const float* __restrict__ dy, float* __restrict__ dx) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int b = blockIdx.y;
-  if (j >= J) return;
+  const bool live = j < J;
+  const int jj = live ? j : J - 1;
+  const int32_t q0 = t_ptr[jj], q1 = t_ptr[jj + 1];
+  const bool heavy = live && (q1 - q0 > SPMM_HEAVY);
   float acc = 0.f;
-  for (int32_t q = t_ptr[j]; q < t_ptr[j + 1]; ++q) {
-    const int32_t r = t_row[q], k = t_k[q];
-    for (int c = 0; c < C; ++c) acc += val[(int64_t)c * nnz + k] * dy[((int64_t)b * C + c) * I + r];
+  if (!heavy) {
+    for (int32_t q = q0; q < q1; ++q) {
+      const int32_t r = t_row[q], k = t_k[q];
+      for (int c = 0; c < C; ++c) acc += val[(int64_t)c * nnz + k] * dy[((int64_t)b * C + c) * I + r];
+    }
   }
-  dx[(int64_t)b * J + j] = acc;
+  unsigned long long hm = __ballot(heavy);
+  while (hm) {
+    const int src = __ffsll((long long)hm) - 1;
+    hm &= hm - 1;
+    const int32_t h0 = __shfl(q0, src, 64), h1 = __shfl(q1, src, 64);
+    float part = 0.f;
+    for (int32_t q = h0 + lane; q < h1; q += 64) {
+      const int32_t r = t_row[q], k = t_k[q];
+      for (int c = 0; c < C; ++c) part += val[(int64_t)c * nnz + k] * dy[((int64_t)b * C + c) * I + r];
+    }
+    part = wave_sum_all(part);
+    if (lane == src) acc = part;
+  }
+  if (live) dx[(int64_t)b * J + j] = acc;
 }
 
 __global__ void __launch_bounds__(GO_T)

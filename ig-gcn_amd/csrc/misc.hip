@@ -65,7 +65,7 @@ extern "C" int igcn_adam_step_multi(int n_tensors, const int64_t* table, const i
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, step);
   if (n_tensors > 0)
-    hipLaunchKernelGGL(k_adam_multi, dim3(32, n_tensors), dim3(256), 0, st, table, numel, step, lr, beta1, beta2,
+    hipLaunchKernelGGL(k_adam_multi, dim3(96, n_tensors), dim3(256), 0, st, table, numel, step, lr, beta1, beta2,
                        eps, grad_scale);
   IGCN_CHECK_LAUNCH("adam_step_multi");
   return IGCN_OK;

@@ -246,11 +246,17 @@ k_plan_segmented(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* 
     tgt_ptr[nb + i] = (int32_t)(eb + ct[i]);
     src_ptr[nb + i] = (int32_t)(eb + cs[i]);
     loop_edge[nb + i] = lp[i] >= 0 ? (int32_t)(eb + lp[i]) : -1;
-    int pt = ct[i], ps = cs[i];
-    for (int k = 0; k < ne; ++k) {                                 // stored order => stable groups
-      if (ld[k] == i) tgt_perm[eb + pt++] = (int32_t)(eb + k);
-      if (ls[k] == i) src_perm[eb + ps++] = (int32_t)(eb + k);
-    }
+  }
+  // stable placement: the two halves of the workgroup build the by-target and the by-source grouping; each thread
+  // owns nodes and walks the graph's edges in stored order
+  const int role = tid >> 7;
+  const int16_t* key = role == 0 ? ld : ls;
+  const int32_t* base = role == 0 ? ct : cs;
+  int32_t* perm = role == 0 ? tgt_perm : src_perm;
+  for (int i = tid & 127; i < nn; i += 128) {
+    int pos = base[i];
+    for (int k = 0; k < ne; ++k)
+      if (key[k] == i) perm[eb + pos++] = (int32_t)(eb + k);
   }
   if (g == n_graphs - 1 && tid == 0) {
     tgt_ptr[n_nodes] = (int32_t)n_edges;
