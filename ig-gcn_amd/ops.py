@@ -622,3 +622,35 @@ class CrossAttention(torch.autograd.Function):
              ptr(o_save), ptr(lse), ptr(dout), ptr(dxq), ptr(dmem), ptr(dpar), ptr(scratch), stream_ptr())
         o0, o1, o2 = 3 * d * d, 3 * d * d + 3 * d, 3 * d * d + 3 * d + d * d
         return (dxq, dmem, dpar[:o0].view(3 * d, d), dpar[o0:o1], dpar[o1:o2].view(d, d), dpar[o2:], None)
+
+
+def attn_core_supported(d, h, lq, lk):
+    lib = _lib.load()
+    return bool(lib.igcn_attn_core_lds_bytes(d, h, lq, lk, 0)) and bool(lib.igcn_attn_core_lds_bytes(d, h, lq, lk, 1))
+
+
+class AttentionCore(torch.autograd.Function):
+    """softmax(q k^T/sqrt(hd)) v per head on the projection outputs in place: q [B,Lq,D], kv [B,Lk,2D] -> [B,Lq,D]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads):
+        q, kv = _f32(q), _f32(kv)
+        b, lq, d = q.shape
+        lk = kv.shape[1]
+        o = torch.empty_like(q)
+        lse = torch.empty(b, heads, lq, dtype=torch.float32, device=q.device)
+        call("igcn_attn_core_fwd", b, d, heads, lq, lk, ptr(q), ptr(kv), ptr(o), ptr(lse), stream_ptr())
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, o, lse = ctx.saved_tensors
+        dout = _f32(dout)
+        b, lq, d = q.shape
+        lk = kv.shape[1]
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        call("igcn_attn_core_bwd", b, d, ctx.heads, lq, lk, ptr(q), ptr(kv), ptr(o), ptr(lse), ptr(dout), ptr(dq),
+             ptr(dkv), stream_ptr())
+        return dq, dkv, None

@@ -173,17 +173,22 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         """relu(nn.MultiheadAttention(D, 2, batch_first=True)(query, memory, memory)[0]) (:240-241) with the
         parameters of ``self.multihead_attn``: one fused kernel per direction (igcn_xattn_*: projections,
         softmax and PV stay in LDS).  Shapes the fused kernel does not cover fall back to MFMA-GEMM projections
-        around the library scaled-dot-product kernel."""
+        around igcn_attn_core_* (attention core on the projection outputs in place; library SDPA for other shapes)."""
         mha = self.multihead_attn
         d, h = mha.embed_dim, mha.num_heads
         b, lq, lk = query.shape[0], query.shape[1], memory.shape[1]
         w, bias = mha.in_proj_weight, mha.in_proj_bias
         if self.fused_cross_attention and ops.xattn_supported(d, h, lq, lk):
             return ops.CrossAttention.apply(query, memory, w, bias, mha.out_proj.weight, mha.out_proj.bias, h)
-        q = ops.linear(query, w[:d], bias[:d]).view(b, lq, h, d // h).transpose(1, 2)
-        kv = ops.linear(memory, w[d:], bias[d:]).view(b, lk, 2, h, d // h)
-        k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, lq, d)
+        q = ops.linear(query, w[:d], bias[:d])                               # [B, Lq, D]
+        kv = ops.linear(memory, w[d:], bias[d:])                            # [B, Lk, 2D] = key | value
+        if ops.attn_core_supported(d, h, lq, lk):
+            o = ops.AttentionCore.apply(q, kv, h)                           # heads addressed in place
+        else:
+            qh = q.view(b, lq, h, d // h).transpose(1, 2)
+            kvh = kv.view(b, lk, 2, h, d // h)
+            o = F.scaled_dot_product_attention(qh, kvh[:, :, 0].transpose(1, 2), kvh[:, :, 1].transpose(1, 2))
+            o = o.transpose(1, 2).reshape(b, lq, d)
         return F.relu(ops.linear(o, mha.out_proj.weight, mha.out_proj.bias))
 
     # ---- forward ---------------------------------------------------------------------------------

@@ -224,6 +224,20 @@ int igcn_gram_loss_fwd(int B, int RD, const float* G, const float* Lap, float* o
 int igcn_gram_loss_bwd(int B, const float* G, const float* Lap, const float* gout, float* S, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Cross-attention core of nn.MultiheadAttention (kernel/sgcn_img_snp.py:240) on the projection outputs in place:
+ *   q [B,Lq,D] (query projection), kv [B,Lk,2,D] (key|value projection as ONE GEMM output), D = H*head_dim
+ *   o [B,Lq,D] = per head softmax(q k^T / sqrt(head_dim)) v, heads concatenated; lse [B,H,Lq] saved for the backward
+ * One workgroup per (sample, head); no head transposes or contiguous copies on either side.  The backward returns
+ * dq [B,Lq,D] and dkv [B,Lk,2,D] in the layouts the projection-gradient GEMMs read.
+ * igcn_attn_core_lds_bytes: dynamic LDS needed, 0 = shape not covered (head_dim in {4,8,12,16,20,24}, Lq <= 256).
+ */
+size_t igcn_attn_core_lds_bytes(int D, int H, int Lq, int Lk, int backward);
+int igcn_attn_core_fwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o, float* lse,
+                       void* stream);
+int igcn_attn_core_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
+                       const float* lse, const float* dout, float* dq, float* dkv, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused cross-attention fusion block — kernel/sgcn_img_snp.py:46,239-242:
  *   out = relu( nn.MultiheadAttention(D, H, batch_first=True)(xq, mem, mem)[0] )
  * xq [B,Lq,D] (dense-batched SGCN features), mem [B,Lk,D] (GO attention read-out); w_in [3D,D], b_in [3D] =

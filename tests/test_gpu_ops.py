@@ -492,3 +492,26 @@ def test_propagate_dense_graph_variants(ops, hint):
     coef = ops.GcnNorm.apply(ew.cuda(), plan)
     out = ops.GcnPropagate.apply(x.cuda(), coef[0], coef[1], b.cuda(), plan, True, coef[2], coef[3])
     assert_matches(out, want.numpy(), TOL, "out")
+
+
+@pytest.mark.parametrize("bsz,lq,lk,d", [(3, 10, 9, 8), (4, 90, 400, 32), (2, 130, 77, 16), (5, 90, 45, 32)])
+def test_attention_core(ops, bsz, lq, lk, d):
+    rng = np.random.default_rng(lq * lk)
+    h = 2
+    q = torch.from_numpy(rng.standard_normal((bsz, lq, d))).float()
+    kv = torch.from_numpy(rng.standard_normal((bsz, lk, 2 * d))).float()
+    cot = torch.from_numpy(rng.standard_normal((bsz, lq, d))).float()
+    rq, rkv = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    qh = rq.view(bsz, lq, h, d // h).transpose(1, 2)
+    kvh = rkv.view(bsz, lk, 2, h, d // h)
+    k_, v_ = kvh[:, :, 0].transpose(1, 2), kvh[:, :, 1].transpose(1, 2)
+    att = torch.softmax(qh @ k_.transpose(-1, -2) / (d // h) ** 0.5, dim=-1)
+    o_ref = (att @ v_).transpose(1, 2).reshape(bsz, lq, d)
+    g_ref = torch.autograd.grad((o_ref * cot.double()).sum(), [rq, rkv])
+    assert ops.attn_core_supported(d, h, lq, lk)
+    dq_, dkv_ = q.cuda().requires_grad_(True), kv.cuda().requires_grad_(True)
+    o = ops.AttentionCore.apply(dq_, dkv_, h)
+    g = torch.autograd.grad((o * cot.cuda()).sum(), [dq_, dkv_])
+    assert_matches(o, o_ref.detach().numpy(), TOL, "o")
+    assert_matches(g[0], g_ref[0].numpy(), 2e-4, "dq", floor=1e-6)
+    assert_matches(g[1], g_ref[1].numpy(), 2e-4, "dkv", floor=1e-6)
