@@ -6,7 +6,7 @@
 // keys (dK/dV), 48-64 FMAs per 8 LDS reads.  Backward recomputes the probabilities from the saved log-sum-exp.
 #include "common.h"
 
-#define AC_T 256
+#define AC_T 1024     // 16 waves = 4 per SIMD: one workgroup per CU (K,V of the head fill LDS) hides its own latencies
 
 template <int HD>
 __device__ __forceinline__ void ld_row(const float* __restrict__ p, float (&r)[HD]) {
@@ -55,7 +55,7 @@ k_attn_core_fwd(int H, int Lq, int Lk, const float* __restrict__ q, const float*
                 float* __restrict__ o, float* __restrict__ lse) {
   extern __shared__ float smem[];
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD;
-  const int rp = (Lq + 63) / 64 * 64, G = AC_T / rp;       // key groups per query row
+  const int rp = (Lq + 31) / 32 * 32, G = AC_T / rp;       // key groups per query row
   float* Ks = smem;
   float* Vs = Ks + (size_t)Lk * HD;
   float* Qs = Vs + (size_t)Lk * HD;
@@ -71,21 +71,37 @@ k_attn_core_fwd(int H, int Lq, int Lk, const float* __restrict__ q, const float*
     ld_row<HD>(Qs + i * HD, qi);
 #pragma unroll
     for (int c = 0; c < HD; ++c) { qi[c] *= scale; acc[c] = 0.f; }
-    float m = -INFINITY;
-    for (int j = j0; j < j1; ++j) {
-      float kj[HD];
-      ld_row<HD>(Ks + j * HD, kj);
-      m = fmaxf(m, dot_row<HD>(qi, kj));
-    }
-    float l = 0.f;
-    for (int j = j0; j < j1; ++j) {
-      float kj[HD], vj[HD];
-      ld_row<HD>(Ks + j * HD, kj);
-      ld_row<HD>(Vs + j * HD, vj);
-      const float p = __expf(dot_row<HD>(qi, kj) - m);
-      l += p;
+    // single pass, keys in chunks of 8: chunk scores -> chunk max -> one rescale of the running sums per chunk
+    float m = -INFINITY, l = 0.f;
+    for (int jb = j0; jb < j1; jb += 8) {
+      float sc[8];
+      float cm = m;
 #pragma unroll
-      for (int c = 0; c < HD; ++c) acc[c] += p * vj[c];
+      for (int u = 0; u < 8; ++u) {
+        sc[u] = -INFINITY;
+        if (jb + u < j1) {
+          float kj[HD];
+          ld_row<HD>(Ks + (jb + u) * HD, kj);
+          sc[u] = dot_row<HD>(qi, kj);
+        }
+        cm = fmaxf(cm, sc[u]);
+      }
+      const float f = __expf(m - cm);           // exp(-inf) = 0 on the first chunk
+      l *= f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) acc[c] *= f;
+      m = cm;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (jb + u < j1) {
+          float vj[HD];
+          ld_row<HD>(Vs + (jb + u) * HD, vj);
+          const float p = __expf(sc[u] - m);
+          l += p;
+#pragma unroll
+          for (int c = 0; c < HD; ++c) acc[c] += p * vj[c];
+        }
+      }
     }
     float* mg = Mg + ((size_t)g * Lq + i) * (HD + 2);
     mg[0] = m;
@@ -127,7 +143,7 @@ k_attn_core_bwd(int H, int Lq, int Lk, const float* __restrict__ q, const float*
                 float* __restrict__ dq, float* __restrict__ dkv) {
   extern __shared__ float smem[];
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * HD;
-  const int rp = (Lq + 63) / 64 * 64, G = AC_T / rp;
+  const int rp = (Lq + 31) / 32 * 32, G = AC_T / rp;
   float* Ks = smem;
   float* Vs = Ks + (size_t)Lk * HD;
   float* Qs = Vs + (size_t)Lk * HD;
@@ -177,14 +193,21 @@ k_attn_core_bwd(int H, int Lq, int Lk, const float* __restrict__ q, const float*
     for (int gg = 0; gg < G; ++gg) acc += Mg[(size_t)gg * Lq * HD + t];
     dq[(int64_t)(b * Lq + t / HD) * D + h * HD + (t % HD)] = acc;
   }
-  // ---- dK, dV: lanes = keys ----
-  for (int j = threadIdx.x; j < Lk; j += AC_T) {
+  // ---- dK, dV: lanes = (key, row part); the rs parts of a key sit on adjacent lanes and are summed by shuffles ----
+  int rs = 1;
+  while (rs < 16 && Lk * rs * 2 <= AC_T) rs *= 2;
+  const int rper = (Lq + rs - 1) / rs;
+  for (int t0 = 0; t0 < Lk * rs; t0 += AC_T) {
+    const int t = t0 + threadIdx.x;
+    const bool live = t < Lk * rs;
+    const int j = live ? t / rs : 0, part = t % rs;
     float kj[HD], vj[HD], dk[HD], dv[HD];
     ld_row<HD>(Ks + j * HD, kj);
     ld_row<HD>(Vs + j * HD, vj);
 #pragma unroll
     for (int c = 0; c < HD; ++c) dk[c] = dv[c] = 0.f;
-    for (int r = 0; r < Lq; ++r) {
+    const int r1 = live ? min(Lq, (part + 1) * rper) : 0;
+    for (int r = part * rper; r < r1; ++r) {
       float qr[HD], dor[HD];
       ld_row<HD>(Qs + r * HD, qr);
       ld_row<HD>(dOs + r * HD, dor);
@@ -196,17 +219,26 @@ k_attn_core_bwd(int H, int Lq, int Lk, const float* __restrict__ q, const float*
         dv[c] += p * dor[c];
       }
     }
-    float* base = dkv + ((int64_t)(b * Lk + j) * 2) * D + h * HD;
+    for (int o2 = 1; o2 < rs; o2 <<= 1) {
 #pragma unroll
-    for (int c = 0; c < HD; c += 4) {
-      *reinterpret_cast<float4*>(base + c) = make_float4(dk[c], dk[c + 1], dk[c + 2], dk[c + 3]);
-      *reinterpret_cast<float4*>(base + D + c) = make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+      for (int c = 0; c < HD; ++c) {
+        dk[c] += __shfl_xor(dk[c], o2, 64);
+        dv[c] += __shfl_xor(dv[c], o2, 64);
+      }
+    }
+    if (live && part == 0) {
+      float* base = dkv + ((int64_t)(b * Lk + j) * 2) * D + h * HD;
+#pragma unroll
+      for (int c = 0; c < HD; c += 4) {
+        *reinterpret_cast<float4*>(base + c) = make_float4(dk[c], dk[c + 1], dk[c + 2], dk[c + 3]);
+        *reinterpret_cast<float4*>(base + D + c) = make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+      }
     }
   }
 }
 
 static size_t ac_lds_floats(int HD, int Lq, int Lk, int backward) {
-  const int rp = (Lq + 63) / 64 * 64, G = AC_T / rp;
+  const int rp = (Lq + 31) / 32 * 32, G = AC_T / rp;
   if (backward) return (size_t)2 * Lk * HD + 2 * (size_t)Lq * HD + 2 * (size_t)Lq + (size_t)G * Lq * HD;
   return (size_t)2 * Lk * HD + (size_t)Lq * HD + (size_t)G * Lq * (HD + 2);
 }
@@ -222,7 +254,7 @@ static size_t ac_lds_floats(int HD, int Lq, int Lk, int backward) {
 
 // dynamic LDS bytes needed, or 0 when the shape is not covered (head_dim in {4,8,12,16,20,24}, Lq <= 256, <= 160 KB)
 extern "C" size_t igcn_attn_core_lds_bytes(int D, int H, int Lq, int Lk, int backward) {
-  if (H <= 0 || D % H || Lq <= 0 || Lq > AC_T || Lk <= 0) return 0;
+  if (H <= 0 || D % H || Lq <= 0 || Lq > 256 || Lk <= 0) return 0;
   const int hd = D / H;
   if (!(hd == 4 || hd == 8 || hd == 12 || hd == 16 || hd == 20 || hd == 24)) return 0;
   const size_t bytes = ac_lds_floats(hd, Lq, Lk, backward) * sizeof(float);
