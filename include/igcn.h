@@ -119,7 +119,7 @@ int igcn_gcn_norm_bwd(int64_t n_nodes, int64_t n_edges, const float* ew, const f
  * summed in the reference's scatter order (non-loop edges in stored order, then the loop).
  * h [N,F] row stride ld_h; out row stride ld_out (so a layer can write its column slice of the JK-concat
  * buffer of :223 directly).  relu != 0 applies max(.,0).  Two launch shapes, picked from the arguments:
- * thread = (target, feature) for low in-degree (brain graphs, k = 3); for an average in-degree >= 16 one wave per
+ * thread = (target, feature quad) for low in-degree (brain graphs, k = 3); for an average in-degree >= 16 one wave per
  * target in which every lane moves 16 bytes per memory instruction (F/4 lanes per feature row, 64/(F/4) edge slots).
  * `nodes_per_graph` (uniform graph size, 0 = unknown) is a hint reserved for LDS-staged variants.
  */

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Timeline statistics of one steady-state step from a rocprofv3 kernel trace CSV.
-usage: trace_gaps.py <dir> [marker kernel substring, default k_plan_split]"""
+usage: trace_gaps.py <dir> [marker kernel substring, default k_plan_segmented]"""
 import csv, glob, sys, re, collections
-d = sys.argv[1]; marker = sys.argv[2] if len(sys.argv) > 2 else "k_plan_split"
+d = sys.argv[1]; marker = sys.argv[2] if len(sys.argv) > 2 else "k_plan_segmented"
 rows = list(csv.DictReader(open(glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
