@@ -34,12 +34,30 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PMC_TRAFFIC = {"bench": 10004117, "stress": 77630016}
 
 
-def build_model(device):
-    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
-    go_snps, adj, pool_dim = synth.go_hierarchy(POOL, seed=0)
-    a_g, a = synth.go_sparse_inputs(go_snps, adj, device)
+# --workload: the default is the configuration the metric is quoted on; the other two are side measurements
+WORKLOADS = {
+    "full": dict(rois=ROIS, pool=POOL, graphs=GRAPHS_PER_GPU, dense=False,
+                 name="configs[2]: full sgcn_img_snp train step (2 fwd + 7 losses + bwd + Adam), "
+                      "90-ROI k=3 brain graphs + 3000-node GO-SNP DAG"),
+    "sgcn": dict(rois=ROIS, pool=None, graphs=GRAPHS_PER_GPU, dense=False,
+                 name="configs[1]: SGCN-only train step (kernel/train_eval_sgcn.py:296-314), 90-ROI k=3 brain graphs"),
+    "stress": dict(rois=512, pool=(6000, 2700, 1000, 299, 1), graphs=32, dense=True,
+                   name="configs[4] shape in fp32: full train step, 512-ROI dense brain graphs + 10k-node GO DAG"),
+}
+
+
+def build_model(device, wl=None):
+    wl = wl or WORKLOADS["full"]
     torch.manual_seed(1000)                                   # main.py:102 seed
-    model = SGCN_GCN_IMGSNP(LAYERS, HIDDEN, a_g, a, pool_dim, 32, device, rois=ROIS, H_0=3, num_classes=3,
+    if wl["pool"] is None:
+        from igcn_amd.sgcn import SGCN_GCN
+        model = SGCN_GCN(None, LAYERS, HIDDEN, rois=wl["rois"], H_0=3, num_features=3, num_classes=3).to(device)
+        model.train()
+        return model, None
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    go_snps, adj, pool_dim = synth.go_hierarchy(wl["pool"], seed=0)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj, device)
+    model = SGCN_GCN_IMGSNP(LAYERS, HIDDEN, a_g, a, pool_dim, 32, device, rois=wl["rois"], H_0=3, num_classes=3,
                             isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
                             isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False).to(device)
     model.train()
@@ -166,6 +184,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay of the step")
     ap.add_argument("--no-stress", action="store_true", help="skip the stress-shape roofline measurement")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="full",
+                    help="full = BASELINE configs[2] (the metric); sgcn / stress are side measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,11 +212,13 @@ def main():
     from igcn_amd.train import FlatAdam, GraphedTrainStep, train_step
     _lib.load()                                   # fail loudly when the HIP library is missing
 
-    model, go = build_model(device)
+    wl = WORKLOADS[args.workload]
+    per_gpu = wl["graphs"]
+    model, go = build_model(device, wl)
     opt = FlatAdam(model.parameters(), lr=1e-3)
     if world > 1:                                 # identical replicas
         torch.distributed.broadcast(opt.flat, 0)
-    graphs = synth.brain_graph_list(GRAPHS_PER_GPU, seed=1000 + rank, rois=ROIS, tsne_dim=90)
+    graphs = synth.brain_graph_list(per_gpu, seed=1000 + rank, rois=wl["rois"], tsne_dim=90, dense=wl["dense"])
     data = Batch.from_data_list(graphs).to(device)
     data.x.requires_grad_(True)
 
@@ -230,24 +252,25 @@ def main():
         sys.exit(3)
 
     if rank == 0:
-        total_graphs = GRAPHS_PER_GPU * world * args.steps
+        total_graphs = per_gpu * world * args.steps
         res = {
             "metric": "graphs/s train step (90-ROI brain + GO-SNP)", "value": round(total_graphs / dt, 1),
             "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: full sgcn_img_snp train step (2 fwd + 7 losses + bwd + Adam), "
-                                   "90-ROI k=3 brain graphs + 3000-node GO-SNP DAG",
-                       "graphs_per_gpu": GRAPHS_PER_GPU, "global_batch": GRAPHS_PER_GPU * world,
-                       "layers": LAYERS, "hidden": HIDDEN, "rois": ROIS, "go_nodes": sum(POOL),
+            "config": {"workload": wl["name"],
+                       "graphs_per_gpu": per_gpu, "global_batch": per_gpu * world,
+                       "layers": LAYERS, "hidden": HIDDEN, "rois": wl["rois"],
+                       "go_nodes": sum(wl["pool"]) if wl["pool"] else 0,
                        "parallelism": f"dp{world}", "launch": "eager" if args.eager else "hipGraph replay"},
             "loss": round(float(loss), 6),
         }
-        res["roofline"] = scatter_roofline(data, device)
-        if world == 1 and not args.no_stress:
-            res["roofline_stress"] = scatter_roofline_stress(device)
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(go)
+        if args.workload == "full":
+            res["roofline"] = scatter_roofline(data, device)
+            if world == 1 and not args.no_stress:
+                res["roofline_stress"] = scatter_roofline_stress(device)
+            if world == 1 and not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(go)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()

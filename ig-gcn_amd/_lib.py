@@ -5,6 +5,7 @@ There is NO fallback: if the library is missing or a call fails, an exception is
 """
 import ctypes
 import os
+import sys
 
 import torch
 
@@ -103,9 +104,20 @@ def ptr(t):
     return t.data_ptr()
 
 
+_DEBUG_SYNC = os.environ.get("IGCN_DEBUG_SYNC", "0") == "1"
+
+
 def call(name, *args):
-    """Invoke an int-returning entry point; raise with igcn_last_error() on failure."""
+    """Invoke an int-returning entry point; raise with igcn_last_error() on failure.
+
+    IGCN_DEBUG_SYNC=1 (debugging a kernel fault): announce every entry point on stderr and synchronise the device
+    after it, so that the last line printed names the faulting call."""
     lib = load()
+    if _DEBUG_SYNC:
+        print(f"[igcn] {name} {args}", file=sys.stderr, flush=True)
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise IgcnError(f"{name} failed (rc={rc}): {lib.igcn_last_error().decode()}")
+    if _DEBUG_SYNC:
+        import torch
+        torch.cuda.synchronize()

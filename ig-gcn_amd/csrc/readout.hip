@@ -276,7 +276,13 @@ k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict
   else if (F == 5 && D == 20) { CALL(5, 20); }                     \
   else if (F == 5 && D == 16) { CALL(5, 16); }                     \
   else if (F == 5 && D == 12) { CALL(5, 12); }                     \
+  else if (F == 5 && D == 24) { CALL(5, 24); }                     \
+  else if (F == 5 && D == 10) { CALL(5, 10); }                     \
   else if (F == 5 && D == 8) { CALL(5, 8); }                       \
+  else if (F == 5 && D == 6) { CALL(5, 6); }                       \
+  else if (F == 5 && D == 4) { CALL(5, 4); }                       \
+  else if (F == 5 && D == 3) { CALL(5, 3); }                       \
+  else if (F == 5 && D == 2) { CALL(5, 2); }                       \
   else if (F == 5 && D == 5) { CALL(5, 5); }                       \
   else if (F == 5 && D == 1) { CALL(5, 1); }                       \
   else if (F == 2 && D == 1) { CALL(2, 1); }                       \

@@ -43,22 +43,42 @@ class GraphPlan:
         self.loop_edge = torch.empty(n, **i32)
         self._copies = {}
         self.status = None
+        self._seg = None
         if (node_ptr is not None and edge_ptr is not None and max_nodes is not None and max_edges is not None
                 and 0 < max_nodes <= self.SEG_MAX_NODES and max_edges <= self.SEG_MAX_EDGES and e > 0
                 and node_ptr.device == dev and edge_ptr.device == dev):
             self.status = torch.zeros(1, **i32)
-            call("igcn_graph_plan_build_segmented", n, e, int(node_ptr.numel()) - 1, ptr(ei),
-                 ptr(node_ptr.contiguous()), ptr(edge_ptr.contiguous()), int(max_nodes), int(max_edges),
-                 ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr), ptr(self.tgt_perm), ptr(self.src_ptr),
-                 ptr(self.src_perm), ptr(self.loop_edge), ptr(self.status), stream_ptr())
+            self._seg = (node_ptr.contiguous(), edge_ptr.contiguous(), int(max_nodes), int(max_edges))
+        else:
+            self._ws = torch.empty(int(_lib.load().igcn_graph_plan_workspace_bytes(n, e)), dtype=torch.uint8,
+                                   device=dev)
+        self._build(ei)
+
+    @property
+    def segmented(self):
+        return self._seg is not None
+
+    def _build(self, ei):
+        n, e = self.n_nodes, self.n_edges
+        if self._seg is not None:
+            node_ptr, edge_ptr, max_nodes, max_edges = self._seg
+            call("igcn_graph_plan_build_segmented", n, e, int(node_ptr.numel()) - 1, ptr(ei), ptr(node_ptr),
+                 ptr(edge_ptr), max_nodes, max_edges, ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr),
+                 ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(self.status),
+                 stream_ptr())
             return
-        lib = _lib.load()
-        wbytes = int(lib.igcn_graph_plan_workspace_bytes(n, e))
-        ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
         call("igcn_graph_plan_build", n, e, ptr(ei), ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr),
-             ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(ws), wbytes,
-             stream_ptr())
-        self._ws = ws            # keep alive until the stream has consumed it
+             ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(self._ws),
+             self._ws.numel(), stream_ptr())
+
+    def rebuild(self, edge_index):
+        """Build again IN PLACE for a new ``edge_index`` of the same size (same graph segments): every plan tensor
+        keeps its address, so kernels captured in a hipGraph keep reading the right memory.  Derived replicas are
+        dropped (igcn_graph_plan_replicate is cheap and capturable)."""
+        if edge_index.shape != (2, self.n_edges) or edge_index.dtype != torch.int64:
+            raise _lib.IgcnError("rebuild needs an int64 edge_index of the shape the plan was built for")
+        self._copies = {}
+        self._build(edge_index.contiguous())
 
     def check(self):
         """Host-synchronising validation of the segmented build (tests / debugging only)."""
@@ -78,7 +98,7 @@ class GraphPlan:
                                ("tgt_perm", e * copies), ("src_ptr", n * copies + 1), ("src_perm", e * copies),
                                ("loop_edge", n * copies)):
                 setattr(rep, name, torch.empty(max(size, 1), **i32))
-            rep._copies = {}
+            rep._copies, rep._seg, rep.status = {}, None, None
             call("igcn_graph_plan_replicate", n, e, copies, ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr),
                  ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(rep.src32),
                  ptr(rep.dst32), ptr(rep.tgt_ptr), ptr(rep.tgt_perm), ptr(rep.src_ptr), ptr(rep.src_perm),

@@ -173,7 +173,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         """relu(nn.MultiheadAttention(D, 2, batch_first=True)(query, memory, memory)[0]) (:240-241) with the
         parameters of ``self.multihead_attn``: one fused kernel per direction (igcn_xattn_*: projections,
         softmax and PV stay in LDS).  Shapes the fused kernel does not cover fall back to MFMA-GEMM projections
-        around igcn_attn_core_* (attention core on the projection outputs in place; library SDPA for other shapes)."""
+        around igcn_attn_core_* (attention core on the projection outputs in place; batched GEMM + softmax otherwise)."""
         mha = self.multihead_attn
         d, h = mha.embed_dim, mha.num_heads
         b, lq, lk = query.shape[0], query.shape[1], memory.shape[1]
@@ -185,10 +185,14 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         if ops.attn_core_supported(d, h, lq, lk):
             o = ops.AttentionCore.apply(q, kv, h)                           # heads addressed in place
         else:
-            qh = q.view(b, lq, h, d // h).transpose(1, 2)
-            kvh = kv.view(b, lk, 2, h, d // h)
-            o = F.scaled_dot_product_attention(qh, kvh[:, :, 0].transpose(1, 2), kvh[:, :, 1].transpose(1, 2))
-            o = o.transpose(1, 2).reshape(b, lq, d)
+            # shapes outside the core's coverage (head_dim not a multiple of 4 up to 24, or more than 256 query
+            # rows): plain batched-GEMM + softmax composite.  Deliberately not the library's fused SDPA kernels:
+            # with several steps in flight on one stream they faulted on gfx950
+            hd = d // h
+            qh = q.view(b, lq, h, hd).transpose(1, 2)
+            kvh = kv.view(b, lk, 2, h, hd)
+            att = torch.softmax((qh @ kvh[:, :, 0].permute(0, 2, 3, 1)) * (1.0 / math.sqrt(hd)), dim=-1)
+            o = (att @ kvh[:, :, 1].transpose(1, 2)).transpose(1, 2).reshape(b, lq, d)
         return F.relu(ops.linear(o, mha.out_proj.weight, mha.out_proj.bias))
 
     # ---- forward ---------------------------------------------------------------------------------

@@ -56,11 +56,16 @@ class FlatAdam:
                 p.grad = self.grad[off:off + k].view_as(p) if self.flat_grads else None
         nt = len(self.params)
         self._offs = offs
-        self._host = torch.zeros(nt, 4, dtype=torch.int64, pin_memory=(dev.type == "cuda"))
-        for t, (p, o) in enumerate(zip(self.params, offs)):
-            self._host[t, 0] = self.flat.data_ptr() + 4 * o
-            self._host[t, 2] = self.exp_avg.data_ptr() + 4 * o
-            self._host[t, 3] = self.exp_avg_sq.data_ptr() + 4 * o
+        # pinned staging buffers for the pointer table, used round-robin: a buffer is rewritten only after the
+        # upload that read it has completed (the host may run several eager steps ahead of the device)
+        self._hosts = [torch.zeros(nt, 4, dtype=torch.int64, pin_memory=(dev.type == "cuda")) for _ in range(4)]
+        self._uploaded = [None] * len(self._hosts)
+        self._turn = 0
+        for host in self._hosts:
+            for t, (p, o) in enumerate(zip(self.params, offs)):
+                host[t, 0] = self.flat.data_ptr() + 4 * o
+                host[t, 2] = self.exp_avg.data_ptr() + 4 * o
+                host[t, 3] = self.exp_avg_sq.data_ptr() + 4 * o
         self.table = torch.zeros(nt, 4, dtype=torch.int64, device=dev)
         self.numel = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
         self.offset = torch.tensor(offs, dtype=torch.int64, device=dev)
@@ -75,12 +80,20 @@ class FlatAdam:
     def refresh_table(self):
         """Upload the current gradient pointers (host-side, not capturable: under a hipGraph the gradient
         tensors keep their addresses, so this runs once after capture)."""
+        k = self._turn
+        self._turn = (k + 1) % len(self._hosts)
+        if self._uploaded[k] is not None:
+            self._uploaded[k].synchronize()
+        host = self._hosts[k]
         for t, p in enumerate(self.params):
             g = p.grad
             if g is not None and not g.is_contiguous():
                 g = p.grad = g.contiguous()
-            self._host[t, 1] = g.data_ptr() if g is not None else 0
-        self.table.copy_(self._host, non_blocking=True)
+            host[t, 1] = g.data_ptr() if g is not None else 0
+        self.table.copy_(host, non_blocking=True)
+        if self.table.is_cuda:
+            self._uploaded[k] = torch.cuda.Event()
+            self._uploaded[k].record()
 
     def pack_grads(self, refresh=True):
         """Gather the per-tensor gradients into the flat bucket ``self.grad`` (data-parallel exchange)."""
@@ -105,8 +118,25 @@ class FlatAdam:
              *hyper, stream_ptr())
 
 
+def losses_sgcn(model, data, hp=HP):
+    """Loss of the image-only sibling: train() kernel/train_eval_sgcn.py:303-308
+    (``lamda_ce*ce + loss_probability + lamda_mi*mi``).  Returns (loss, terms dict, outputs)."""
+    if getattr(model, "batched_passes", True):
+        out, out_p = model.forward_pair(data)
+    else:
+        out, out_p = model(data), model(data, True)
+    y = data.y.view(-1)
+    t = {"ce": F.nll_loss(out, y), "mi": F.nll_loss(out_p, y),
+         "prob": model.loss_probability(data.x, data.edge_index, data.edge_attr, hp,
+                                        edge_prob=model.last_edge_prob)}
+    return hp.lamda_ce * t["ce"] + t["prob"] + hp.lamda_mi * t["mi"], t, (out, out_p)
+
+
 def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None):
-    """train() :521-543.  Returns (loss, terms dict, outputs)."""
+    """train() :521-543.  Returns (loss, terms dict, outputs).  A model without a GO branch (``SGCN_GCN``)
+    takes the three-term loss of kernel/train_eval_sgcn.py:303-308 (``lambda_loss`` is not used there)."""
+    if not hasattr(model, "go_network"):
+        return losses_sgcn(model, data, hp)
     if getattr(model, "batched_passes", True) and hasattr(model, "_forward_grouped") and model.isSoftSimilarity:
         return _losses_batched(model, data, lambda_loss, hp, temperature)
     lam = lambda_loss
@@ -206,11 +236,19 @@ class GraphedTrainStep:
     become one graph launch.  Inputs live in static device tensors (``self.data``); ``load(batch)`` copies
     a new batch of identical shape into them.  With ``world_size > 1`` the gradient all-reduce stays
     outside the graphs: [zero_grad .. backward] graph -> RCCL all-reduce -> [Adam] graph.
+
+    The graph plan of the batch is rebuilt every step.  The segmented build (one launch, batches of graphs with
+    <= 1024 nodes / 4096 edges each) is part of the graph; the general radix-sort build (rocPRIM) is launched
+    eagerly, in place, right before the replay — replaying rocPRIM's onesweep sort from inside the full-step graph
+    faulted on this ROCm stack (known issues), while the same launches issued on the stream are fine.
     """
 
     def __init__(self, model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, world_size=1, warmup=3):
         self.model, self.opt, self.data, self.world = model, optimizer, data, world_size
         self.lam, self.hp = lambda_loss, hp
+        from . import ops
+        self.plan = ops.plan_for(data)                  # static plan tensors: rebuilt in place every step
+        self.plan_in_graph = self.plan.segmented
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -225,8 +263,10 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
+        if not self.plan_in_graph:
+            self.plan.rebuild(self.data.edge_index)
         with torch.cuda.graph(self.g_main):
-            self.loss = self._fwd_bwd()
+            self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
             if world_size == 1:
                 self.opt.step(refresh=False)            # reads the pointer table at replay time
             else:
@@ -239,9 +279,13 @@ class GraphedTrainStep:
                 self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
         torch.cuda.synchronize()
 
-    def _fwd_bwd(self):
+    def _fwd_bwd(self, rebuild=True):
         self.opt.zero_grad()
-        self.data._igcn_plan = None                     # the plan is per batch: rebuilt inside every step
+        self.data._igcn_plan = self.plan
+        if rebuild:
+            self.plan.rebuild(self.data.edge_index)     # the plan is per batch: rebuilt (in place) every step
+        else:
+            self.plan._copies = {}                      # the replica of the batched sweep is derived in-graph
         self.data.x.grad = None
         loss, _, _ = losses(self.model, self.data, self.lam, self.hp)
         loss.backward()
@@ -262,11 +306,75 @@ class GraphedTrainStep:
                     dst.copy_(src, non_blocking=True)
 
     def __call__(self):
+        if not self.plan_in_graph:
+            self.plan.rebuild(self.data.edge_index)
         self.g_main.replay()
         if self.g_opt is not None:
             self._reduce()
             self.g_opt.replay()
         return self.loss
+
+
+def _batches(loader, device):
+    for data in loader:
+        yield data.to(device) if device is not None else data
+
+
+@torch.no_grad()
+def eval_loss(model, loader, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None, device=None):
+    """eval_loss() kernel/train_eval_sgcn_img_snps.py:564-600 (and kernel/train_eval_sgcn.py:328-347): the
+    training loss in eval mode, graph-weighted mean over the loader.  The per-batch ``.item()`` of the
+    reference becomes one device accumulation and a single read at the end."""
+    model.eval()
+    total, count = None, 0
+    for data in _batches(loader, device):
+        loss, _, _ = losses(model, data, lambda_loss, hp, temperature)
+        total = loss * data.num_graphs if total is None else total + loss * data.num_graphs
+        count += data.num_graphs
+    return float(total) / count
+
+
+@torch.no_grad()
+def eval_acc(model, loader, temperature=None, device=None):
+    """eval_acc() kernel/train_eval_sgcn_img_snps.py:551-561 / kernel/train_eval_sgcn.py:316-325."""
+    model.eval()
+    correct, count = None, 0
+    for data in _batches(loader, device):
+        out = model(data, temperature, data.x.device) if hasattr(model, "go_network") else model(data)
+        logp = out[0] if isinstance(out, tuple) else out
+        hit = logp.max(1)[1].eq(data.y.view(-1)).sum()
+        correct = hit if correct is None else correct + hit
+        count += data.num_graphs
+    return int(correct) / count
+
+
+@torch.no_grad()
+def eval_outputs(model, loader, temperature=None, device=None):
+    """The tensors eval_scores() (kernel/train_eval_sgcn_img_snps.py:602-631) collects before handing them to
+    sklearn: class scores, predictions, regression outputs, hidden features — concatenated over the loader on
+    the device; the metric arithmetic itself (roc/f1/pearson) is host-side sklearn code and out of scope."""
+    model.eval()
+    cols = {"logp": [], "pred": [], "reg": [], "out_lin": [], "linear_outf": []}
+    for data in _batches(loader, device):
+        if hasattr(model, "go_network"):
+            logp, _, _, out_lin, lin_f, reg = model(data, temperature, data.x.device)
+            cols["reg"].append(reg.reshape(-1, model.num_regr))
+            cols["out_lin"].append(out_lin)
+            cols["linear_outf"].append(lin_f)
+        else:
+            logp = model(data)
+        cols["logp"].append(logp)
+        cols["pred"].append(logp.max(1)[1])
+    return {k: torch.cat(v) for k, v in cols.items() if v}
+
+
+def output_importance(model):
+    """The arrays util/output.py:20-32 writes per fold: node / SNP importance and the edge-mask weights."""
+    out = {"node_importance": model.prob.detach().cpu().numpy(),
+           "prob_bias": model.prob_bias.detach().cpu().numpy()}
+    if hasattr(model, "snps_prob"):
+        out["snps_importance"] = model.snps_prob.detach().cpu().numpy()
+    return out
 
 
 def allreduce_mean_(flat_grad, world_size):

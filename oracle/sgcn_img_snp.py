@@ -7,7 +7,7 @@ Follows /root/reference:
   util/image_cluster.py:15-31      rbf_kernel_torch         -> (inside consist_loss)
   kernel/sgcn_img_snp.py:198-205   OrthogonalConstraint     -> orthogonal_constraint
   kernel/sgcn_img_snp.py:207-307   forward (default branch: isCrossAtten, both modalities,
-                                   isuseProb4Regr; and the isImageOnly head)   -> model_forward
+                                   isuseProb4Regr; the isImageOnly and isSNPsOnly heads) -> model_forward
   kernel/train_eval_sgcn_img_snps.py:511-548  train()       -> train_step
   sgcn_hyperparameters.py:18-23    lamda_*                  -> HP
 
@@ -99,7 +99,7 @@ def model_forward(sd, cfg, go_idx, data, is_explain=False, training=False, dropo
                   faithful=False):
     """SGCN_GCN_IMGSNP.forward :207-307.
 
-    cfg: SimpleNamespace(num_layers, rois, image_only) ; data: object with x, edge_index, edge_attr,
+    cfg: SimpleNamespace(num_layers, rois[, image_only, snps_only, use_prob4regr]) ; data: object with x, edge_index, edge_attr,
     batch, snps_feat.  Returns the reference 6-tuple.
     """
     x, ei, batch, ew, snps = data.x, data.edge_index, data.batch, data.edge_attr, data.snps_feat
@@ -121,9 +121,13 @@ def model_forward(sd, cfg, go_idx, data, is_explain=False, training=False, dropo
 
     latent, x_hat, atten_out = G.go_forward(sd, go_idx, snpsm, training, dropout, faithful,
                                             prefix="go_network.")
-    if cfg.image_only:                                                        # :257-276
+    image_only, snps_only = getattr(cfg, "image_only", False), getattr(cfg, "snps_only", False)
+    if image_only:                                                            # :257-276
         out_z = img_out
         out_lin = out_z
+    elif snps_only:                                                           # :277-285
+        out_z = latent
+        out_lin = torch.cat([snpsm, latent], dim=-1)
     else:                                                                     # :239-242,286-288
         out_cross = torch.relu(_mha(sd, dense, atten_out)).reshape(bsz, -1)
         out_z = (img_out + out_cross) / 2
@@ -131,9 +135,13 @@ def model_forward(sd, cfg, go_idx, data, is_explain=False, training=False, dropo
     lin_f = torch.relu(out_lin @ sd["lin1.weight"].t() + sd["lin1.bias"])
     h = F.dropout(lin_f, 0.5, True) if (training and dropout) else lin_f
     logits = h @ sd["lin2.weight"].t() + sd["lin2.bias"]
-    xd, _ = to_dense_batch(data.x, batch, float(data.x.min()) - 1)            # :293-297 (isuseProb4Regr)
-    img_feat = (xd * sd["prob"]).reshape(bsz, -1)
-    r = torch.relu(torch.cat([out_lin, img_feat], dim=-1) @ sd["lin1_regr.weight"].t() + sd["lin1_regr.bias"])
+    if getattr(cfg, "use_prob4regr", True) and not snps_only:
+        xd, _ = to_dense_batch(data.x, batch, float(data.x.min()) - 1)        # :293-297 (isuseProb4Regr)
+        img_feat = (xd * sd["prob"]).reshape(bsz, -1)
+        feat = torch.cat([out_lin, img_feat], dim=-1)
+    else:
+        feat = out_lin
+    r = torch.relu(feat @ sd["lin1_regr.weight"].t() + sd["lin1_regr.bias"])
     r = F.dropout(r, 0.3, True) if (training and dropout) else r
     reg = r @ sd["lin2_regr.weight"].t() + sd["lin2_regr.bias"]
     return F.log_softmax(logits, dim=-1), x_hat, out_z, out_lin, lin_f, reg
@@ -194,22 +202,24 @@ def train_step(sd, cfg, go_idx, data, lr=1e-3, lam=None, dropout=True, faithful=
 
 
 def sgcn_param_shapes(num_layers, hidden, rois=90, h0=3, l_dim=32, num_classes=3, num_regr=3,
-                      hidden_linear=64, image_only=False):
-    """Top-level parameter shapes of SGCN_GCN_IMGSNP with isCrossAtten + isuseProb4Regr (:34-101)."""
+                      hidden_linear=64, image_only=False, snps_only=False, cross_atten=True, use_prob4regr=True):
+    """Top-level parameter shapes of SGCN_GCN_IMGSNP (:34-101) for the head selected by the flags."""
     d = num_layers * hidden
     shp = {"prob": (rois, h0), "prob_bias": (2 * h0, 1), "edge_prob": (rois, rois), "snps_prob": (1, 54),
            "conv1.bias": (hidden,), "conv1.lin.weight": (hidden, h0)}
     for i in range(num_layers - 1):
         shp[f"convs.{i}.bias"] = (hidden,)
         shp[f"convs.{i}.lin.weight"] = (hidden, hidden)
-    shp["multihead_attn.in_proj_weight"] = (3 * d, d)
-    shp["multihead_attn.in_proj_bias"] = (3 * d,)
-    shp["multihead_attn.out_proj.weight"] = (d, d)
-    shp["multihead_attn.out_proj.bias"] = (d,)
-    lin_in = rois * d if image_only else rois * d + l_dim
+    if cross_atten:
+        shp["multihead_attn.in_proj_weight"] = (3 * d, d)
+        shp["multihead_attn.in_proj_bias"] = (3 * d,)
+        shp["multihead_attn.out_proj.weight"] = (d, d)
+        shp["multihead_attn.out_proj.bias"] = (d,)
+    lin_in = rois * d if image_only else (l_dim + 54 if snps_only else rois * d + l_dim)
+    reg_in = lin_in + (rois * h0 if (use_prob4regr and not snps_only) else 0)
     shp["lin1.weight"] = (hidden_linear, lin_in)
     shp["lin1.bias"] = (hidden_linear,)
-    shp["lin1_regr.weight"] = (hidden_linear, lin_in + rois * h0)
+    shp["lin1_regr.weight"] = (hidden_linear, reg_in)
     shp["lin1_regr.bias"] = (hidden_linear,)
     shp["lin2.weight"] = (num_classes, hidden_linear)
     shp["lin2.bias"] = (num_classes,)

@@ -166,13 +166,16 @@ def _reference_losses(model, data, lam, hp, outs1, outs2):
     return loss, t
 
 
-def capture_full(sg_mod, name, rois, hidden, layers, bsz, pool, seed, lam, top_k=3):
+def capture_full(sg_mod, name, rois, hidden, layers, bsz, pool, seed, lam, top_k=3, **variant):
+    """``variant`` overrides the constructor flags of the default (cross-attention, both modalities) branch:
+    isImageOnly / isSNPsOnly / isCrossAtten / isuseProb4Regr (kernel/sgcn_img_snp.py:257-285)."""
     go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=seed)
     a_g, a = synth.go_sparse_inputs(go_snps, adj)
+    flags = dict(isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3, model4eachregr=False,
+                 isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False, isMultiFusion=False)
+    flags.update(variant)
     model = sg_mod.SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cpu", rois=rois, H_0=3, num_classes=3,
-                                   isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
-                                   model4eachregr=False, isuseProb4Regr=True, isImageOnly=False,
-                                   isSNPsOnly=False, isMultiFusion=False)
+                                   **flags)
     ref_sd = model.state_dict()
     sd = seeded_state({k: v.shape for k, v in ref_sd.items()}, seed, ref_sd)
     graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=rois, top_k=top_k, tsne_dim=16)
@@ -183,7 +186,8 @@ def capture_full(sg_mod, name, rois, hidden, layers, bsz, pool, seed, lam, top_k
         f"graphs = synth.brain_graph_list({bsz}, seed={seed + 10}, rois={rois}, top_k={top_k}, tsne_dim=16); "
         f"GO = synth.go_hierarchy({list(pool)}, seed={seed})"),
         "cfg": np.array([rois, hidden, layers, bsz, seed, top_k]), "pool": np.array(pool),
-        "lam": np.array(lam), "state_keys": np.array(sorted(ref_sd.keys()))}
+        "lam": np.array(lam), "state_keys": np.array(sorted(ref_sd.keys())),
+        "variant": np.array(repr(sorted(variant.items())))}
     hp = OS.HP
     for mode in ("eval", "train"):
         for explain in (False, True):
@@ -220,9 +224,78 @@ def capture_full(sg_mod, name, rois, hidden, layers, bsz, pool, seed, lam, top_k
     print("wrote", name, "loss", float(loss), {k: float(v) for k, v in terms.items()})
 
 
+def capture_sgcn(sgcn_mod, name, hidden, layers, bsz, seed, top_k=3):
+    """kernel/sgcn.py SGCN_GCN (rois is hard-wired to 90 at :285) + the loss of kernel/train_eval_sgcn.py:303-308."""
+    model = sgcn_mod.SGCN_GCN(None, layers, hidden, rois=90, H_0=3, num_features=3, num_classes=2)
+    ref_sd = model.state_dict()
+    sd = seeded_state({k: v.shape for k, v in ref_sd.items()}, seed, ref_sd)
+    graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=90, top_k=top_k, tsne_dim=16, num_classes=2)
+    store = {"meta": np.array(
+        "reference kernel/sgcn.py SGCN_GCN executed on CPU; GCNConv/to_dense_batch = oracle.pyg_ops (PyG 2.0.2 "
+        f"absent: unpinned); dropout p=0; torch {torch.__version__}; weights = seeded_state(shapes, seed={seed}); "
+        f"graphs = synth.brain_graph_list({bsz}, seed={seed + 10}, rois=90, top_k={top_k}, tsne_dim=16, "
+        "num_classes=2)"),
+        "cfg": np.array([90, hidden, layers, bsz, seed, top_k]), "state_keys": np.array(sorted(ref_sd.keys()))}
+    hp = OS.HP
+    for mode in ("eval", "train"):
+        for explain in (False, True):
+            model.load_state_dict(sd)
+            model.train(mode == "train")
+            _no_dropout(model)
+            model.zero_grad()
+            data = Batch.from_data_list(graphs)
+            out = model(data, explain)
+            cot = _probe_weights([out], seed + 3)[0]
+            (out * cot).sum().backward()
+            tag = f"{mode}/explain{int(explain)}"
+            _pack(tag + "/out", {"logp": out}, store)
+            _pack(tag + "/grad", {"data.x": data.x.grad, **{k: p.grad for k, p in model.named_parameters()}}, store)
+    model.load_state_dict(sd)
+    model.train(True)
+    _no_dropout(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0)
+    opt.zero_grad()
+    data = Batch.from_data_list(graphs)
+    y = data.y.view(-1)
+    out, out_p = model(data), model(data, True)
+    terms = {"ce": F.nll_loss(out, y), "mi": F.nll_loss(out_p, y),
+             "prob": model.loss_probability(data.x, data.edge_index, data.edge_attr, hp)}
+    loss = hp.lamda_ce * terms["ce"] + terms["prob"] + hp.lamda_mi * terms["mi"]
+    loss.backward()
+    _pack("step/grad", {"data.x": data.x.grad, **{k: p.grad for k, p in model.named_parameters()}}, store)
+    opt.step()
+    store["step/loss"] = np.array(float(loss))
+    for k, v in terms.items():
+        store[f"step/term/{k}"] = np.array(float(v))
+    _pack("step/param_after", dict(model.named_parameters()), store)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **store)
+    print("wrote", name, "loss", float(loss), {k: float(v) for k, v in terms.items()})
+
+
 def main():
+    """``make_golden.py`` regenerates everything; ``make_golden.py NAME ...`` only the named fixtures."""
     torch.manual_seed(0)
     go_mod, sg_mod = _load_reference()
+    want = set(sys.argv[1:])
+    if want & {"sgcn_only"} or not want:
+        spec = importlib.util.spec_from_file_location("kernel.sgcn", os.path.join(REF, "kernel/sgcn.py"))
+        sgcn_mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(sgcn_mod)
+        # the image-only sibling at its real dims (BASELINE configs[0]/[1] shape, small batch)
+        capture_sgcn(sgcn_mod, "sgcn_only", hidden=16, layers=2, bsz=4, seed=31)
+    variants = {
+        # the other heads of forward(): kernel/sgcn_img_snp.py:257-285
+        "var_image_only": dict(isImageOnly=True, isCrossAtten=False, isuseProb4Regr=True),
+        "var_image_only_noprob": dict(isImageOnly=True, isCrossAtten=True, isuseProb4Regr=False),
+        "var_snps_only": dict(isImageOnly=False, isSNPsOnly=True, isCrossAtten=False),
+        "var_fusion_noprob": dict(isuseProb4Regr=False),
+    }
+    for k, (name, flags) in enumerate(variants.items()):
+        if name in want or not want:
+            capture_full(sg_mod, name, rois=10, hidden=4, layers=2, bsz=4, pool=(20, 10, 6, 3, 1), seed=41 + k,
+                         lam=[1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2], **flags)
+    if want and not (want & {"go_tiny", "go_small", "full_tiny", "full_r90", "full_l3"}):
+        return
     # go_tiny: the shape of the reference's own __main__ smoke block (go_model.py:290-303):
     # 20 nodes, arbitrary 0/1 adjacency (self loops, empty rows, cross-level edges), pool [[3,6,11]]
     rng = np.random.default_rng(5)

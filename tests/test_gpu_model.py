@@ -4,6 +4,7 @@ Everything goes through libigcn.so (the C ABI); tolerance is scale-relative 1e-4
 mode normalises with BatchNorm over 3-8 samples, which amplifies fp32 rounding (the fp64 oracle is just as
 far from the reference's own fp32 numbers, see test_oracle_golden.py), hence the looser bound there.
 """
+import ast
 from types import SimpleNamespace
 
 import numpy as np
@@ -18,6 +19,16 @@ pytestmark = pytest.mark.gpu
 TOL = {"eval": 1e-4, "train": 1e-3}
 GTOL = {"eval": 1e-3, "train": 3e-2}
 NAMES = ["logp", "x_hat", "out_z", "out_lin", "lin_f", "reg"]
+FULL = ["full_tiny", "full_r90", "full_l3", "var_image_only", "var_image_only_noprob", "var_snps_only",
+        "var_fusion_noprob"]
+
+
+def grad_floor(wg, k, floor):
+    """See tests/test_oracle_golden.py: a shift with a (nearly) zero exact gradient is judged on its layer's scale."""
+    sib = wg.get(k[:-5] + ".weight") if k.endswith(".bias") else None
+    if sib is not None and not isinstance(sib, tuple):
+        floor = max(floor, 0.5 * float(np.abs(sib).max()))
+    return floor
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -78,9 +89,12 @@ def _full_model(store):
     pool = store["pool"].tolist()
     go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=seed)
     a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+    flags = dict(isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3, isuseProb4Regr=True,
+                 isImageOnly=False, isSNPsOnly=False)
+    if "variant" in store:              # var_* fixtures: the other heads of forward() (sgcn_img_snp.py:257-285)
+        flags.update(dict(ast.literal_eval(str(store["variant"]))))
     model = SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=3, num_classes=3,
-                            isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
-                            isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False).cuda()
+                            **flags).cuda()
     ref_keys = sorted(store["state_keys"].tolist())
     assert sorted(model.state_dict().keys()) == ref_keys          # checkpoints interchange with the reference
     sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, seed, model.state_dict())
@@ -91,7 +105,7 @@ def _full_model(store):
     return model, graphs, seed
 
 
-@pytest.mark.parametrize("name", ["full_tiny", "full_r90", "full_l3"])
+@pytest.mark.parametrize("name", FULL)
 @pytest.mark.parametrize("mode", ["eval", "train"])
 @pytest.mark.parametrize("explain", [False, True])
 def test_full_model_vs_reference_golden(golden, name, mode, explain):
@@ -108,14 +122,20 @@ def test_full_model_vs_reference_golden(golden, name, mode, explain):
     cot = _probe(outs, seed + 3)
     sum((o * c.cuda()).sum() for o, c in zip(outs, cot)).backward()
     wg = golden_group(store, tag + "/grad")
-    assert_matches(data.x.grad, wg.pop("data.x"), GTOL[mode], "grad data.x")
+    if "data.x" in wg:
+        assert_matches(data.x.grad, wg.pop("data.x"), GTOL[mode], "grad data.x")
+    else:                                   # SNP-only head, plain pass: the image branch is not on the path
+        assert data.x.grad is None or not bool(data.x.grad.abs().max() > 0)
     params = dict(model.named_parameters())
     for k, w in wg.items():
         assert params[k].grad is not None, k
-        assert_matches(params[k].grad, w, GTOL[mode], "grad " + k, floor=1e-4)
+        assert_matches(params[k].grad, w, GTOL[mode], "grad " + k, floor=grad_floor(wg, k, 1e-4))
+    for k, p in params.items():             # nothing the reference leaves without a gradient gets one here
+        if k not in wg and p.grad is not None:
+            assert not bool(p.grad.abs().max() > 0), "unexpected grad " + k
 
 
-@pytest.mark.parametrize("name", ["full_tiny", "full_r90", "full_l3"])
+@pytest.mark.parametrize("name", FULL)
 @pytest.mark.parametrize("batched", [True, False])
 def test_train_step_vs_reference_golden(golden, name, batched):
     from igcn_amd.data import Batch
@@ -141,7 +161,7 @@ def test_train_step_vs_reference_golden(golden, name, batched):
     grads = {}
     for k, w in wg.items():
         if isinstance(w, tuple) or np.any(w):
-            assert_matches(params[k].grad, w, 1e-2, "grad " + k, floor=1e-5)
+            assert_matches(params[k].grad, w, 1e-2, "grad " + k, floor=grad_floor(wg, k, 1e-5))
         else:
             g = params[k].grad                                        # untouched parameters: no (or zero) grad
             assert g is None or not bool(g.abs().max() > 0), k
@@ -159,6 +179,9 @@ def test_train_step_vs_reference_golden(golden, name, batched):
         g = torch.from_numpy(grads[k])
         diff = (p - torch.from_numpy(w)).abs()
         solid = g.abs() > 5e-2 * g.abs().max() if g.abs().max() > 0 else torch.zeros_like(g, dtype=torch.bool)
+        sib = grads.get(k[:-5] + ".weight") if k.endswith(".bias") else None
+        if sib is not None and not isinstance(sib, tuple) and float(g.abs().max()) < 1e-2 * float(np.abs(sib).max()):
+            solid = torch.zeros_like(solid)                            # an all-noise gradient
         assert float(diff[solid].max() if solid.any() else 0.0) <= 5e-5, "param " + k
         assert float(diff.max()) <= 2.01 * lr, "param (noise-level grads) " + k
 
@@ -203,3 +226,237 @@ def test_full_model_vs_oracle_larger(bsz, pool, explain):
         if sdo[k].grad is None:
             continue
         assert_matches(params[k].grad, sdo[k].grad.numpy(), 5e-3, "grad " + k, floor=1e-6)
+
+
+# ---- the image-only sibling SGCN_GCN (kernel/sgcn.py:272-388; BASELINE configs[0]/[1]) -------------------------
+def _sgcn_model(store):
+    from igcn_amd import synth
+    from igcn_amd.sgcn import SGCN_GCN
+    rois, hidden, layers, bsz, seed, top_k = [int(v) for v in store["cfg"]]
+    model = SGCN_GCN(None, layers, hidden, rois=rois, H_0=3, num_features=3, num_classes=2).cuda()
+    assert sorted(model.state_dict().keys()) == sorted(store["state_keys"].tolist())
+    sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, seed, model.state_dict())
+    model.load_state_dict(sd)
+    model._dropout_enabled = False
+    graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=rois, top_k=top_k, tsne_dim=16, num_classes=2)
+    return model, graphs, seed
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("explain", [False, True])
+def test_sgcn_only_vs_reference_golden(golden, mode, explain):
+    from igcn_amd.data import Batch
+    store = golden("sgcn_only")
+    model, graphs, seed = _sgcn_model(store)
+    model.train(mode == "train")
+    data = Batch.from_data_list(graphs).to("cuda")
+    out = model(data, explain)
+    tag = f"{mode}/explain{int(explain)}"
+    assert_matches(out, golden_group(store, tag + "/out")["logp"], 1e-4, "logp")
+    (out * _probe([out], seed + 3)[0].cuda()).sum().backward()
+    wg = golden_group(store, tag + "/grad")
+    assert_matches(data.x.grad, wg.pop("data.x"), 1e-3, "grad data.x")
+    params = dict(model.named_parameters())
+    for k, w in wg.items():
+        assert_matches(params[k].grad, w, 1e-3, "grad " + k, floor=1e-4)
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_sgcn_only_train_step_vs_reference_golden(golden, batched):
+    """train() of kernel/train_eval_sgcn.py:296-314: loss terms, gradients and the post-Adam parameters."""
+    from igcn_amd.data import Batch
+    from igcn_amd.train import FlatAdam, losses
+    store = golden("sgcn_only")
+    model, graphs, seed = _sgcn_model(store)
+    model.train(True)
+    model.batched_passes = batched
+    data = Batch.from_data_list(graphs).to("cuda")
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    opt.zero_grad()
+    loss, terms, _ = losses(model, data)
+    assert abs(float(loss) - float(store["step/loss"])) <= 1e-4 * max(1.0, abs(float(store["step/loss"])))
+    for k, v in terms.items():
+        assert abs(float(v) - float(store[f"step/term/{k}"])) <= 1e-4, k
+    loss.backward()
+    params = dict(model.named_parameters())
+    wg = golden_group(store, "step/grad")
+    assert_matches(data.x.grad, wg.pop("data.x"), 1e-3, "grad data.x")
+    for k, w in wg.items():
+        assert_matches(params[k].grad, w, 1e-3, "grad " + k, floor=1e-5)
+    opt.step()
+    for k, w in golden_group(store, "step/param_after").items():
+        p = params[k].detach().cpu()
+        if isinstance(w, tuple):
+            assert_matches(p, w, 2.5e-3, "param " + k, floor=1.0)
+            continue
+        assert float((p - torch.from_numpy(w)).abs().max()) <= 2.01e-3, "param " + k
+        if k in wg and not isinstance(wg[k], tuple):
+            g = torch.from_numpy(wg[k])
+            solid = g.abs() > 5e-2 * g.abs().max()
+            if solid.any():
+                assert float((p - torch.from_numpy(w)).abs()[solid].max()) <= 5e-5, "param " + k
+
+
+@pytest.mark.parametrize("bsz", [32, 256])
+def test_sgcn_only_vs_oracle_config_sizes(bsz):
+    """BASELINE configs[0] (B=32) and configs[1] (B=256): SGCN-only forward/backward against the fp64 oracle."""
+    from igcn_amd import synth
+    from igcn_amd.data import Batch
+    from igcn_amd.sgcn import SGCN_GCN
+    from oracle import sgcn as OSG, sgcn_img_snp as OS
+    model = SGCN_GCN(None, 2, 16, rois=90, H_0=3, num_features=3, num_classes=3).cuda().eval()
+    sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, 6)
+    model.load_state_dict(sd)
+    graphs = synth.brain_graph_list(bsz, seed=1000, rois=90, tsne_dim=16)
+    for explain in (False, True):
+        data = Batch.from_data_list(graphs).to("cuda")
+        model.zero_grad()
+        out = model(data, explain)
+        cot = _probe([out], 4)[0]
+        (out * cot.cuda()).sum().backward()
+        sdo = OS.make_leaf_state(sd, dtype=torch.float64)
+        dcpu = Batch.from_data_list(graphs)
+        dcpu.x = dcpu.x.double().requires_grad_(True)
+        dcpu.edge_attr = dcpu.edge_attr.double()
+        ref = OSG.model_forward(sdo, 90, dcpu, explain)
+        (ref * cot.double()).sum().backward()
+        assert_matches(out, ref.detach().numpy(), 1e-4, "logp")
+        assert_matches(data.x.grad, dcpu.x.grad.numpy(), 3e-3, "grad data.x")
+        params = dict(model.named_parameters())
+        for k in OS.trainable_keys(sdo):
+            if sdo[k].grad is not None:
+                assert_matches(params[k].grad, sdo[k].grad.numpy(), 5e-3, "grad " + k, floor=1e-6)
+
+
+def test_eval_passes_vs_oracle():
+    """eval_loss / eval_acc / eval_outputs (kernel/train_eval_sgcn_img_snps.py:551-631) over a two-batch loader."""
+    from igcn_amd import synth
+    from igcn_amd.data import DataLoader
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    from igcn_amd.train import eval_acc, eval_loss, eval_outputs, output_importance
+    from igcn_amd.data import Batch
+    from oracle import go_network as OG, sgcn_img_snp as OS
+    pool = (60, 30, 20, 9, 1)
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=2)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+    model = SGCN_GCN_IMGSNP(2, 8, a_g, a, pool_dim, 32, "cuda", rois=90, H_0=3, num_classes=3,
+                            isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
+                            isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False).cuda()
+    sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, 8)
+    model.load_state_dict(sd)
+    graphs = synth.brain_graph_list(12, seed=5, rois=90, tsne_dim=16)
+    lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
+    got = eval_loss(model, DataLoader(graphs, batch_size=8), lam, device="cuda")
+    acc = eval_acc(model, DataLoader(graphs, batch_size=8), device="cuda")
+    outs = eval_outputs(model, DataLoader(graphs, batch_size=8), device="cuda")
+    a_g_c, a_c = synth.go_sparse_inputs(go_snps, adj)
+    idx = OG.go_index_sets(a_g_c, a_c, list(pool), 2)
+    cfg = SimpleNamespace(num_layers=2, rois=90, image_only=False, rbf_gamma=0.01)
+    want, hits, logps = 0.0, 0, []
+    sd = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}     # fp64 oracle
+    with torch.no_grad():
+        for lo, hi in ((0, 8), (8, 12)):
+            d = Batch.from_data_list(graphs[lo:hi])
+            for k in ("x", "edge_attr", "snps_feat", "clini_score", "tsne_fdim"):
+                setattr(d, k, getattr(d, k).double())
+            o1 = OS.model_forward(sd, cfg, idx, d, False, training=False)
+            o2 = OS.model_forward(sd, cfg, idx, d, True, training=False)
+            y, clin = d.y.view(-1), d.clini_score.view(-1)
+            import torch.nn.functional as F
+            loss = lam[0] * F.nll_loss(o1[0], y) + lam[0] * F.nll_loss(o2[0], y) \
+                + lam[1] * (F.mse_loss(o1[5].view(-1), clin) + F.mse_loss(o2[5].view(-1), clin)) / 2 \
+                + lam[2] * OS.loss_probability(sd, d.x, d.edge_index, d.edge_attr, 90) \
+                + lam[3] * (((o1[1] - d.snps_feat) ** 2).sum() + ((o2[1] - d.snps_feat) ** 2).sum()) / 2 \
+                + lam[4] * (OS.consist_loss(o1[2], d.tsne_fdim, 0.01) + OS.consist_loss(o2[2], d.tsne_fdim, 0.01)) / 2 \
+                + lam[5] * OS.orthogonal_constraint(o1[2])
+            want += float(loss) * (hi - lo)
+            hits += int(o1[0].max(1)[1].eq(y).sum())
+            logps.append(o1[0])
+    assert abs(got - want / 12) <= 1e-4 * max(1.0, abs(want / 12)), (got, want / 12)
+    assert acc == hits / 12
+    assert_matches(outs["logp"], torch.cat(logps).numpy(), 1e-4, "logp")
+    assert outs["reg"].shape == (12, 3) and outs["out_lin"].shape[0] == 12 and outs["linear_outf"].shape == (12, 64)
+    imp = output_importance(model)
+    assert imp["node_importance"].shape == (90, 3) and imp["snps_importance"].shape == (1, 54) \
+        and imp["prob_bias"].shape == (6, 1)
+
+
+@pytest.mark.parametrize("rois,bsz", [(96, 4), (300, 2)])
+def test_full_model_dense_graphs_vs_oracle(rois, bsz):
+    """The stress shape of BASELINE configs[4] in small: dense brain graphs (E = R^2 per graph -> radix-sort graph
+    plan, wave-per-target scatter-aggregate), more ROIs than the attention core's 256-query limit at R=300."""
+    from igcn_amd import synth
+    from igcn_amd.data import Batch
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    from oracle import go_network as OG, sgcn_img_snp as OS
+    pool = (300, 120, 60, 19, 1)
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=1)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+    model = SGCN_GCN_IMGSNP(2, 16, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=3, num_classes=3,
+                            isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
+                            isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False).cuda().eval()
+    sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, 5)
+    model.load_state_dict(sd)
+    graphs = synth.brain_graph_list(bsz, seed=78, rois=rois, tsne_dim=16, dense=True)
+    data = Batch.from_data_list(graphs).to("cuda")
+    outs = model(data, None, "cuda", isExplain=True)
+    cot = _probe(outs, 9)
+    sum((o * c.cuda()).sum() for o, c in zip(outs, cot)).backward()
+    a_g_c, a_c = synth.go_sparse_inputs(go_snps, adj)
+    idx = OG.go_index_sets(a_g_c, a_c, list(pool), 2)
+    sdo = OS.make_leaf_state(sd, dtype=torch.float64)
+    dcpu = Batch.from_data_list(graphs)
+    dcpu.x = dcpu.x.double().requires_grad_(True)
+    dcpu.edge_attr, dcpu.snps_feat = dcpu.edge_attr.double(), dcpu.snps_feat.double()
+    cfg = SimpleNamespace(num_layers=2, rois=rois, image_only=False, rbf_gamma=0.01)
+    ref = OS.model_forward(sdo, cfg, idx, dcpu, True, training=False)
+    sum((o * c.double()).sum() for o, c in zip(ref, cot)).backward()
+    for n, o, r in zip(NAMES, outs, ref):
+        assert_matches(o, r.detach().numpy(), 1e-4, n)
+    assert_matches(data.x.grad, dcpu.x.grad.numpy(), 3e-3, "grad data.x")
+    params = dict(model.named_parameters())
+    for k in OS.trainable_keys(sdo):
+        if sdo[k].grad is not None:
+            assert_matches(params[k].grad, sdo[k].grad.numpy(), 5e-3, "grad " + k, floor=1e-6)
+
+
+@pytest.mark.parametrize("rois,dense", [(90, False), (72, True)])
+def test_graphed_train_step_matches_eager(rois, dense):
+    """GraphedTrainStep (whole step replayed from one hipGraph) against the eager train_step on a twin model, three
+    steps on changing batches.  k=3 graphs take the in-graph segmented plan build; dense 72-ROI graphs (5184 edges
+    per graph) take the radix-sort build that is issued eagerly, in place, before each replay."""
+    import copy
+    from igcn_amd import synth
+    from igcn_amd.data import Batch
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    from igcn_amd.train import FlatAdam, GraphedTrainStep, train_step
+    pool = (60, 30, 20, 9, 1)
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=2)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+    torch.manual_seed(3)
+    m1 = SGCN_GCN_IMGSNP(2, 8, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=3, num_classes=3,
+                         isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
+                         isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False).cuda().train()
+    for m in (m1, m1.go_network):
+        m._dropout_enabled = False
+    m2 = copy.deepcopy(m1)
+    batches = [Batch.from_data_list(synth.brain_graph_list(6, seed=50 + i, rois=rois, tsne_dim=16, dense=dense)).to("cuda")
+               for i in range(3)]
+    lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
+    o1, o2 = FlatAdam(m1.parameters(), lr=1e-3), FlatAdam(m2.parameters(), lr=1e-3)
+    static = Batch.from_data_list(synth.brain_graph_list(6, seed=50, rois=rois, tsne_dim=16, dense=dense)).to("cuda")
+    static.x.requires_grad_(True)
+    snap = {k: v.detach().clone() for k, v in m1.state_dict().items()}
+    step = GraphedTrainStep(m1, o1, static, lam, warmup=2)
+    assert step.plan_in_graph == (not dense)
+    # the warm-up steps moved m1: restore parameters, buffers and the optimiser state
+    m1.load_state_dict(snap)
+    for t in (o1.exp_avg, o1.exp_avg_sq, o1.step_count):
+        t.zero_()
+    for b in batches:
+        step.load(b)
+        l1 = float(step())
+        l2 = float(train_step(m2, o2, b, lam))
+        assert abs(l1 - l2) <= 1e-4 * max(1.0, abs(l2)), (l1, l2)
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert float((p1 - p2).abs().max()) <= 2e-4, k
