@@ -340,6 +340,19 @@ int igcn_adam_step_multi(int n_tensors, const int64_t* table, const int64_t* num
 int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_t* numel, const int64_t* offset,
                     float* flat, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Graph-diffusion pre-transform + block-diagonal collation of B dense adjacencies A [B,R,R] (f32), on the device —
+ * replaces, per graph, preprocess_diffusion_imgs_snps (util_gdc.py:71-86: get_ppr_matrix :7-15 with `alpha`,
+ * get_top_k_matrix :25-31 with `k`, scipy coo_matrix) and the index offsetting of Batch.from_data_list
+ * (batch.py:98-104).  fp64 arithmetic in LDS, one workgroup per graph; R <= igcn_gdc_topk_max_rois().
+ *   edge_index int64 [2, B*R*k], edge_attr f32 [B*R*k]: graph g owns slots [g*R*k, (g+1)*R*k), its edges in
+ *   (row, col) order with both endpoints offset by g*R, then (-1,-1,0) padding if fewer than R*k entries are
+ *   non-zero; counts int32 [B] = edges of each graph.
+ */
+int igcn_gdc_topk_max_rois(void);
+int igcn_gdc_topk(int B, int R, int k, double alpha, const float* A, int64_t* edge_index, float* edge_attr,
+                  int32_t* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -272,11 +272,55 @@ def capture_sgcn(sgcn_mod, name, hidden, layers, bsz, seed, top_k=3):
     print("wrote", name, "loss", float(loss), {k: float(v) for k, v in terms.items()})
 
 
+def synthetic_adjacency(rng, rois, knn=5):
+    """Symmetric non-negative connectivity with a connected kNN support (what data.A holds, sgcn_data.py:262-282)."""
+    s = rng.random((rois, rois))
+    s = (s + s.T) / 2
+    np.fill_diagonal(s, 0.0)
+    nbr = np.argsort(-s, axis=1)[:, :knn]
+    a = np.zeros((rois, rois))
+    rows = np.repeat(np.arange(rois), knn)
+    a[rows, nbr.ravel()] = s[rows, nbr.ravel()]
+    return np.maximum(a, a.T)
+
+
+def capture_gdc(name):
+    """util_gdc.py get_ppr_matrix / get_top_k_matrix / scipy coo_matrix, exactly as preprocess_diffusion_imgs_snps
+    (:71-86) chains them, on seeded adjacencies (float32-representable, because data.A is a float tensor)."""
+    from scipy.sparse import coo_matrix
+    tgd = types.ModuleType("torch_geometric.data")
+    tgd.Data, tgd.InMemoryDataset = object, object
+    sys.modules["torch_geometric.data"] = tgd
+    sys.modules["torch_geometric"].data = tgd
+    spec = importlib.util.spec_from_file_location("util_gdc", os.path.join(REF, "util_gdc.py"))
+    gdc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gdc)
+    rng = np.random.default_rng(77)
+    store = {"meta": np.array("reference util_gdc.py get_ppr_matrix(alpha) -> get_top_k_matrix(k) -> scipy "
+                              "coo_matrix, executed on CPU (numpy float64); torch_geometric.data stubbed (import only)")}
+    cases = [(90, 3, 0.05, 5), (90, 5, 0.05, 8), (12, 3, 0.05, 3), (33, 2, 0.15, 6), (128, 4, 0.05, 9)]
+    for c, (rois, k, alpha, knn) in enumerate(cases):
+        a = synthetic_adjacency(rng, rois, knn).astype(np.float32)
+        if c == 3:
+            a = rng.random((rois, rois)).astype(np.float32)          # dense, NOT symmetric
+        res = gdc.get_top_k_matrix(gdc.get_ppr_matrix(a.astype(np.float64).copy(), alpha=alpha), k=k)
+        coo = coo_matrix(res)
+        store[f"case{c}/cfg"] = np.array([rois, k, knn])
+        store[f"case{c}/alpha"] = np.array(alpha)
+        store[f"case{c}/A"] = a
+        store[f"case{c}/edge_index"] = np.vstack([coo.row, coo.col]).astype(np.int64)
+        store[f"case{c}/edge_attr"] = torch.from_numpy(coo.data).float().numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **store)
+    print("wrote", name, [store[f"case{c}/edge_index"].shape for c in range(len(cases))])
+
+
 def main():
     """``make_golden.py`` regenerates everything; ``make_golden.py NAME ...`` only the named fixtures."""
     torch.manual_seed(0)
     go_mod, sg_mod = _load_reference()
     want = set(sys.argv[1:])
+    if "gdc" in want or not want:
+        capture_gdc("gdc")
     if want & {"sgcn_only"} or not want:
         spec = importlib.util.spec_from_file_location("kernel.sgcn", os.path.join(REF, "kernel/sgcn.py"))
         sgcn_mod = importlib.util.module_from_spec(spec)
