@@ -63,6 +63,8 @@ SIGNATURES = {
     "igcn_adam_step": (I, [L, P, P, P, P, P, F, F, F, F, F, P]),
     "igcn_adam_step_multi": (I, [I, P, P, P, F, F, F, F, F, P]),
     "igcn_pack_grads": (I, [I, P, P, P, P, P]),
+    "igcn_loss_head_fwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, F, F, P, P, P]),
+    "igcn_loss_head_bwd": (I, [I, I, I, I, P, P, P, P, P, P, F, F, P, P, P, P, P, P, P]),
     "igcn_gdc_topk_max_rois": (I, []),
     "igcn_gdc_topk": (I, [I, I, I, ctypes.c_double, P, P, P, P, P]),
 }

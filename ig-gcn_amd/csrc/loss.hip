@@ -187,3 +187,123 @@ extern "C" int igcn_rbf_laplacian(int B, int T, float gamma, const float* t, flo
   IGCN_CHECK_LAUNCH("rbf_laplacian");
   return IGCN_OK;
 }
+
+// -------------------------------------------------------------------------------------------------
+// Loss head of train() (kernel/train_eval_sgcn_img_snps.py:525-543) on the STACKED outputs of the batched sweep
+// (rows [0,B): plain pass, rows [B,2B): isExplain pass), one launch per direction instead of ~40 scalar-sized ones:
+//   ce = nll(logp[:B], y)   mi = nll(logp[B:], y)                      (:525-526; mean over the batch)
+//   reg = (mse(reg[:B], clin) + mse(reg[B:], clin)) / 2                (:527)  = mean over all 2B*NR elements
+//   recon = (sum (x_hat[:B]-snps)^2 + sum (x_hat[B:]-snps)^2) / 2      (:530)
+//   cluster = (consist[0] + consist[1]) / 2   orth = orth[0]           (:533-538; gram = igcn_gram_loss_fwd outputs)
+//   terms = {lam0*ce, lam0*mi, lam1*reg, lam2*prob, lam3*recon, lam4*cluster, lam5*orth}
+//   loss = hp_ce*terms[0] + hp_mi*terms[1] + terms[2..6]               (:543)
+// -------------------------------------------------------------------------------------------------
+struct LossHeadW { float lam[6]; float hp_ce, hp_mi; };
+
+__global__ void __launch_bounds__(1024)
+k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, const int64_t* __restrict__ y,
+                const float* __restrict__ reg, const float* __restrict__ clin, const float* __restrict__ x_hat,
+                const float* __restrict__ snps, const float* __restrict__ gram, const float* __restrict__ prob,
+                LossHeadW w, float* __restrict__ loss, float* __restrict__ terms) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x;
+  float ce = 0.f, mi = 0.f, mse = 0.f, rec = 0.f;
+  for (int b = tid; b < B; b += 1024) {
+    const int64_t c = y[b];
+    ce -= logp[(int64_t)b * C + c];
+    mi -= logp[(int64_t)(B + b) * C + c];
+  }
+  const int nreg = B * NR, nrec = B * S;
+  for (int i = tid; i < 2 * nreg; i += 1024) {
+    const float d = reg[i] - clin[i < nreg ? i : i - nreg];
+    mse += d * d;
+  }
+  for (int i = tid; i < 2 * nrec; i += 1024) {
+    const float d = x_hat[i] - snps[i < nrec ? i : i - nrec];
+    rec += d * d;
+  }
+  ce = block_sum_all(ce, red);
+  mi = block_sum_all(mi, red);
+  mse = block_sum_all(mse, red);
+  rec = block_sum_all(rec, red);
+  if (tid == 0) {
+    float t[7];
+    t[0] = w.lam[0] * (ce / (float)B);
+    t[1] = w.lam[0] * (mi / (float)B);
+    t[2] = w.lam[1] * (mse / (float)(2 * nreg));
+    t[3] = w.lam[2] * prob[0];
+    t[4] = w.lam[3] * (rec * 0.5f);
+    t[5] = w.lam[4] * ((gram[0] + gram[2]) * 0.5f);
+    t[6] = w.lam[5] * gram[1];
+    for (int k = 0; k < 7; ++k) terms[k] = t[k];
+    loss[0] = w.hp_ce * t[0] + w.hp_mi * t[1] + t[2] + t[3] + t[4] + t[5] + t[6];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_loss_head_bwd(int B, int C, int NR, int S, const int64_t* __restrict__ y, const float* __restrict__ reg,
+                const float* __restrict__ clin, const float* __restrict__ x_hat, const float* __restrict__ snps,
+                LossHeadW w, const float* __restrict__ gout, float* __restrict__ dlogp, float* __restrict__ dreg,
+                float* __restrict__ dxhat, float* __restrict__ dgram, float* __restrict__ dprob) {
+  const float g = gout[0];
+  const int n0 = 2 * B * C, n1 = 2 * B * NR, n2 = 2 * B * S;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n0) {
+    const int row = i / C, c = i % C, b = row < B ? row : row - B;
+    const float wt = (row < B ? w.hp_ce : w.hp_mi) * w.lam[0];
+    dlogp[i] = (y[b] == c) ? -g * wt / (float)B : 0.f;
+    return;
+  }
+  i -= n0;
+  if (i < n1) {
+    const int h = n1 / 2;
+    dreg[i] = g * w.lam[1] * 2.f * (reg[i] - clin[i < h ? i : i - h]) / (float)n1;
+    return;
+  }
+  i -= n1;
+  if (i < n2) {
+    const int h = n2 / 2;
+    dxhat[i] = g * w.lam[3] * (x_hat[i] - snps[i < h ? i : i - h]);
+    return;
+  }
+  i -= n2;
+  if (i == 0) {
+    dgram[0] = g * w.lam[4] * 0.5f;
+    dgram[1] = g * w.lam[5];
+    dgram[2] = g * w.lam[4] * 0.5f;
+    dgram[3] = 0.f;
+    dprob[0] = g * w.lam[2];
+  }
+}
+
+static LossHeadW loss_head_w(const float* lam6, float hp_ce, float hp_mi) {
+  LossHeadW w;
+  for (int k = 0; k < 6; ++k) w.lam[k] = lam6[k];
+  w.hp_ce = hp_ce;
+  w.hp_mi = hp_mi;
+  return w;
+}
+
+extern "C" int igcn_loss_head_fwd(int B, int C, int NR, int S, const float* logp, const int64_t* y, const float* reg,
+                                  const float* clin, const float* x_hat, const float* snps, const float* gram,
+                                  const float* prob, const float* lam6 /*HOST [6]*/, float hp_ce, float hp_mi,
+                                  float* loss /*[1]*/, float* terms /*[7]*/, void* stream) {
+  IGCN_REQUIRE(B > 0 && C > 0 && NR > 0 && S > 0, "loss_head_fwd: bad sizes");
+  hipLaunchKernelGGL(k_loss_head_fwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, C, NR, S, logp, y, reg, clin,
+                     x_hat, snps, gram, prob, loss_head_w(lam6, hp_ce, hp_mi), loss, terms);
+  IGCN_CHECK_LAUNCH("loss_head_fwd");
+  return IGCN_OK;
+}
+
+extern "C" int igcn_loss_head_bwd(int B, int C, int NR, int S, const int64_t* y, const float* reg, const float* clin,
+                                  const float* x_hat, const float* snps, const float* lam6 /*HOST [6]*/, float hp_ce,
+                                  float hp_mi, const float* gout /*[1] device*/, float* dlogp, float* dreg,
+                                  float* dxhat, float* dgram /*[4]*/, float* dprob /*[1]*/, void* stream) {
+  IGCN_REQUIRE(B > 0 && C > 0 && NR > 0 && S > 0, "loss_head_bwd: bad sizes");
+  const int64_t total = (int64_t)2 * B * (C + NR + S) + 1;
+  hipLaunchKernelGGL(k_loss_head_bwd, dim3((unsigned)igcn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, B, C,
+                     NR, S, y, reg, clin, x_hat, snps, loss_head_w(lam6, hp_ce, hp_mi), gout, dlogp, dreg, dxhat,
+                     dgram, dprob);
+  IGCN_CHECK_LAUNCH("loss_head_bwd");
+  return IGCN_OK;
+}

@@ -88,12 +88,18 @@ class Gene_ontology_network(nn.Module):
         self._dropout_enabled = True        # parity tests switch every dropout off
 
     # ---------------------------------------------------------------------------------------------
-    def _node_keep(self, b, n, dev):
-        """Dropout2d on [B,N,f] zeroes whole nodes per sample: keep/(1-p) mask [B,N] or None."""
+    def _node_keeps(self, b, sizes, dev):
+        """Dropout2d on [B,N,f] zeroes whole nodes per sample: keep/(1-p) masks [B,n] for every LayerNorm site of
+        the forward (drawn with one bernoulli launch for all sites), or Nones."""
         if not (self.training and self._dropout_enabled and self.node_dropout_p > 0):
-            return None
+            return [None] * len(sizes)
         p = self.node_dropout_p
-        return torch.empty(b, n, dtype=torch.float32, device=dev).bernoulli_(1.0 - p).div_(1.0 - p)
+        flat = torch.empty(b * sum(sizes), dtype=torch.float32, device=dev).bernoulli_(1.0 - p).div_(1.0 - p)
+        out, off = [], 0
+        for n in sizes:
+            out.append(flat[off:off + b * n].view(b, n))
+            off += b * n
+        return out
 
     def _drop(self, x, p):
         return F.dropout(x, p, True) if (self.training and self._dropout_enabled) else x
@@ -101,14 +107,14 @@ class Gene_ontology_network(nn.Module):
     def _node_linear_bn(self, x, weight, bn, groups=1):
         """relu(bn(linear(x))) with bn = BatchNorm1d(#nodes): one fused op (igcn_node_linear_bn_*)."""
         if self.training and bn.track_running_stats:
-            bn.num_batches_tracked += groups
+            self._tracked.append(bn.num_batches_tracked)
         return ops.NodeLinearBN.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                       self.training, bn.momentum, bn.eps, groups)
 
     def _bn_relu(self, x, bn, groups=1):
         """relu(bn(x)) for the latent MLP's BatchNorm1d layers (igcn_bn1d_*)."""
         if self.training and bn.track_running_stats:
-            bn.num_batches_tracked += groups
+            self._tracked.append(bn.num_batches_tracked)
         return ops.BatchNorm1dGrouped.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
                                             bn.momentum, bn.eps, True, groups)
 
@@ -116,6 +122,8 @@ class Gene_ontology_network(nn.Module):
         """``groups`` > 1: ``data`` holds that many equally sized batches stacked along dim 0 that are treated as
         successive forward calls (own BatchNorm statistics, running statistics updated in order)."""
         bsz, dev = data.shape[0], data.device
+        self._tracked = []
+        keeps = self._node_keeps(bsz, [c.n_rows for c in self.enc_csr] + [c.n_rows for c in self.dec_csr], dev)
         # gene encoding (:208-215)
         x = ops.SparseMap.apply(data, torch.stack(list(self.t)), self.gene_csr)          # [B, in_f, N]
         # encoder (:219-251)
@@ -123,8 +131,8 @@ class Gene_ontology_network(nn.Module):
             csr = self.enc_csr[j]
             y = ops.GoAttention.apply(x, self.w_inc[j].weight, self.w_s_loop[j].weight,
                                       self.w_att_in[j].weight.view(-1), self.w_att_s[j].weight.view(-1), csr)
-            x = ops.NodesLayerNorm.apply(y, self.G_B[j].weight, self.G_B[j].bias,
-                                         self._node_keep(bsz, csr.n_rows, dev), self.pool[j], self.G_B[j].eps)
+            x = ops.NodesLayerNorm.apply(y, self.G_B[j].weight, self.G_B[j].bias, keeps[j], self.pool[j],
+                                         self.G_B[j].eps)
         # read-outs (:254-255): BatchNorm1d(n_top) normalises per NODE over (batch, feature); fused kernels
         atten_out = self._node_linear_bn(x, self.conc_for_attention[0].weight, self.conc_for_attention[1], groups)
         inp_out = self._drop(self._node_linear_bn(x, self.conc.weight, self.B[0], groups).squeeze(2), 0.5)
@@ -132,8 +140,8 @@ class Gene_ontology_network(nn.Module):
         for j in range(self.n_l):
             csr = self.dec_csr[j]
             y = ops.GoDecode.apply(x, self.w_out[j].weight, self.w_s_loop_out[j].weight, csr)
-            x = ops.NodesLayerNorm.apply(y, self.G_B_D[j].weight, self.G_B_D[j].bias,
-                                         self._node_keep(bsz, csr.n_rows, dev), 0, self.G_B_D[j].eps)
+            x = ops.NodesLayerNorm.apply(y, self.G_B_D[j].weight, self.G_B_D[j].bias, keeps[self.n_l + j], 0,
+                                         self.G_B_D[j].eps)
         # gene decoding (:278-282)
         out_d = self._drop(self._node_linear_bn(x, self.conc_D.weight, self.B_D[0], groups).squeeze(2), 0.5)  # [B,N]
         x_d = ops.SparseMap.apply(out_d, self.t_D[0].unsqueeze(0), self.gene_t_csr).squeeze(1)   # [B, 54]
@@ -141,4 +149,7 @@ class Gene_ontology_network(nn.Module):
         h = self._drop(self._bn_relu(ops.linear(inp_out.view(bsz, -1), self.latent[0].weight), self.latent[1],
                                      groups), 0.5)
         latent = self._bn_relu(ops.linear(h, self.latent[4].weight), self.latent[5], groups)
+        if self._tracked:                              # num_batches_tracked of the five BatchNorms: one launch
+            torch._foreach_add_(self._tracked, groups)
+            self._tracked = []
         return latent, x_d, [torch.zeros(3, device=dev)], atten_out

@@ -4,6 +4,8 @@ kernels from libigcn.so on the current torch stream; nothing falls back to PyTor
 Index structures (``GraphPlan`` for a batch of brain graphs, ``Csr``/``CsrPair`` for the GO hierarchy)
 are plain int32 device tensors owned by Python.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -44,6 +46,9 @@ class GraphPlan:
         self._copies = {}
         self.status = None
         self._seg = None
+        # uniform graph size (every PyG batch of R-ROI brain graphs), passed to the aggregation as a hint
+        self.nodes_per_graph = int(max_nodes) if (max_nodes and node_ptr is not None and
+                                                  n == int(max_nodes) * (int(node_ptr.numel()) - 1)) else 0
         if (node_ptr is not None and edge_ptr is not None and max_nodes is not None and max_edges is not None
                 and 0 < max_nodes <= self.SEG_MAX_NODES and max_edges <= self.SEG_MAX_EDGES and e > 0
                 and node_ptr.device == dev and edge_ptr.device == dev):
@@ -99,6 +104,7 @@ class GraphPlan:
                                ("loop_edge", n * copies)):
                 setattr(rep, name, torch.empty(max(size, 1), **i32))
             rep._copies, rep._seg, rep.status = {}, None, None
+            rep.nodes_per_graph = self.nodes_per_graph
             call("igcn_graph_plan_replicate", n, e, copies, ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr),
                  ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(rep.src32),
                  ptr(rep.dst32), ptr(rep.tgt_ptr), ptr(rep.tgt_perm), ptr(rep.src_ptr), ptr(rep.src_perm),
@@ -573,7 +579,8 @@ class GramLosses(torch.autograd.Function):
     (sgcn_img_snp.py:183-205).  Returns two tensors of shape [G]."""
 
     @staticmethod
-    def forward(ctx, s, lap, groups=1):
+    def forward(ctx, s, lap, groups=1, packed=False):
+        """``packed``: return ONE tensor [G,2] = (consist, orth) per group (what igcn_loss_head_* consumes)."""
         s, lap = _f32(s), _f32(lap)
         gb, rd = s.shape
         b = gb // groups
@@ -585,22 +592,69 @@ class GramLosses(torch.autograd.Function):
             gemm_nt(sg, sg, out=gram[g])
             call("igcn_gram_loss_fwd", b, rd, ptr(gram[g]), ptr(lap), ptr(out[g]), ptr(scratch), stream_ptr())
         ctx.save_for_backward(s, lap, gram)
-        ctx.groups = groups
+        ctx.groups, ctx.packed = groups, packed
+        if packed:
+            return out
         return out[:, 0], out[:, 1]
 
     @staticmethod
-    def backward(ctx, g_c, g_o):
+    def backward(ctx, g_c, g_o=None):
         s, lap, gram = ctx.saved_tensors
         groups = ctx.groups
         b = s.shape[0] // groups
-        zero = torch.zeros(groups, dtype=torch.float32, device=s.device)
-        gout = torch.stack([g_c if g_c is not None else zero, g_o if g_o is not None else zero], dim=1).contiguous()
+        if ctx.packed:
+            gout = _f32(g_c)
+        else:
+            zero = torch.zeros(groups, dtype=torch.float32, device=s.device)
+            gout = torch.stack([g_c if g_c is not None else zero, g_o if g_o is not None else zero],
+                               dim=1).contiguous()
         sym = torch.empty(b, b, dtype=torch.float32, device=s.device)
         ds = torch.empty_like(s)
         for g in range(groups):
             call("igcn_gram_loss_bwd", b, ptr(gram[g]), ptr(lap), ptr(gout[g]), ptr(sym), stream_ptr())
             gemm_nn(sym, s[g * b:(g + 1) * b], out=ds[g * b:(g + 1) * b])
-        return ds, None, None
+        return ds, None, None, None
+
+
+class LossHead(torch.autograd.Function):
+    """The seven loss terms of train() (kernel/train_eval_sgcn_img_snps.py:525-543) and their weighted sum on the
+    stacked outputs of the batched sweep, one kernel per direction (igcn_loss_head_*).
+    Returns (loss scalar, terms [7] — not differentiable: {ce, mi, reg, prob, recon, cluster, orth} lam-weighted)."""
+
+    @staticmethod
+    def forward(ctx, logp, y, reg, clin, x_hat, snps, gram, prob, lam, hp_ce, hp_mi):
+        logp, reg, clin, x_hat, snps, gram, prob = (_f32(t) for t in (logp, reg, clin, x_hat, snps, gram, prob))
+        y = y.contiguous()
+        b, c = logp.shape[0] // 2, logp.shape[1]
+        nr, s = reg.numel() // (2 * b), snps.shape[1]
+        if y.dtype != torch.int64 or y.numel() != b or clin.numel() != b * nr or x_hat.shape != (2 * b, s) \
+                or gram.numel() != 4 or snps.shape[0] != b:
+            raise _lib.IgcnError("loss head: inconsistent shapes")
+        dev = logp.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        terms = torch.empty(7, dtype=torch.float32, device=dev)
+        lam6 = (ctypes.c_float * 6)(*[float(v) for v in lam])
+        ctx.cfg = (b, c, nr, s, [float(v) for v in lam], float(hp_ce), float(hp_mi))
+        call("igcn_loss_head_fwd", b, c, nr, s, ptr(logp), ptr(y), ptr(reg), ptr(clin), ptr(x_hat), ptr(snps),
+             ptr(gram), ptr(prob), lam6, float(hp_ce), float(hp_mi), ptr(loss), ptr(terms), stream_ptr())
+        ctx.save_for_backward(y, reg, clin, x_hat, snps)
+        ctx.mark_non_differentiable(terms)
+        return loss.view(()), terms
+
+    @staticmethod
+    def backward(ctx, gout, _gterms):
+        y, reg, clin, x_hat, snps = ctx.saved_tensors
+        b, c, nr, s, lam, hp_ce, hp_mi = ctx.cfg
+        gout = _f32(gout).reshape(1)
+        dev = reg.device
+        dlogp = torch.empty(2 * b, c, dtype=torch.float32, device=dev)
+        dreg, dxhat = torch.empty_like(reg), torch.empty_like(x_hat)
+        dgram = torch.empty(2, 2, dtype=torch.float32, device=dev)
+        dprob = torch.empty((), dtype=torch.float32, device=dev)
+        lam6 = (ctypes.c_float * 6)(*lam)
+        call("igcn_loss_head_bwd", b, c, nr, s, ptr(y), ptr(reg), ptr(clin), ptr(x_hat), ptr(snps), lam6, hp_ce,
+             hp_mi, ptr(gout), ptr(dlogp), ptr(dreg), ptr(dxhat), ptr(dgram), ptr(dprob), stream_ptr())
+        return dlogp, None, dreg, None, dxhat, None, dgram, dprob, None, None, None
 
 
 # =================================================================================================

@@ -181,30 +181,20 @@ def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None):
 
 def _losses_batched(model, data, lam, hp, temperature):
     """Same seven terms on the outputs of ONE batched sweep over both passes (rows [0,B) = plain pass of :521,
-    rows [B,2B) = isExplain pass of :523).  The per-pass means of equal-sized halves are taken on the stacked
-    tensors, so no slicing (and no slice-gradient fill/copy) is needed:
-    (mse_1 + mse_2)/2 = mse over 2B rows, (sum_1 + sum_2)/2 = sum over 2B rows / 2."""
+    rows [B,2B) = isExplain pass of :523): the mask regulariser, one Gram matrix per pass, and ONE loss-head kernel
+    per direction (igcn_loss_head_*) for the terms and their weighted sum — the per-pass means of equal-sized
+    halves are taken on the stacked tensors, so nothing is sliced."""
     dev = data.x.device
     logp, x_hat, out_z, out_lin, lin_f, reg = model._forward_grouped(data, temperature, dev, (False, True),
                                                                      split=False)
-    bsz = logp.shape[0] // 2
-    y2 = data.y.view(-1).repeat(2)
-    clin2 = data.clini_score.view(-1).repeat(2)
-    t = {}
-    ce_mi = F.nll_loss(logp, y2, reduction="none").view(2, bsz).mean(dim=1)
-    t["ce"], t["mi"] = lam[0] * ce_mi[0], lam[0] * ce_mi[1]
-    t["reg"] = lam[1] * F.mse_loss(reg.view(-1), clin2)
-    t["prob"] = lam[2] * model.loss_probability(data.x, data.edge_index, data.edge_attr, hp,
-                                                edge_prob=model.last_edge_prob)
-    t["recon"] = lam[3] * torch.sum((x_hat - data.snps_feat.repeat(2, 1)) ** 2) / 2
-    lap = model.laplacian(bsz, data.tsne_fdim)
-    consist, orth = model.batch_losses(out_z, lap, groups=2)
-    t["cluster"] = lam[4] * consist.mean()
-    t["orth"] = lam[5] * orth[0]
-    if lam[0] == 0:
-        t["ce"], t["mi"] = 0.0, 0.0
-    loss = hp.lamda_ce * t["ce"] + hp.lamda_mi * t["mi"] + t["reg"] + t["prob"] + t["recon"] + t["cluster"] \
-        + t["orth"]
+    from . import ops
+    lap = model.laplacian(logp.shape[0] // 2, data.tsne_fdim)
+    gram = ops.GramLosses.apply(out_z, lap, 2, True)                     # [2,2] = (consist, orth) per pass
+    prob = model.loss_probability(data.x, data.edge_index, data.edge_attr, hp, edge_prob=model.last_edge_prob)
+    lam6 = [float(v) for v in lam]
+    loss, terms = ops.LossHead.apply(logp, data.y.view(-1), reg, data.clini_score.view(-1), x_hat, data.snps_feat,
+                                     gram, prob, lam6, hp.lamda_ce, hp.lamda_mi)
+    t = dict(zip(("ce", "mi", "reg", "prob", "recon", "cluster", "orth"), terms.unbind(0)))
     return loss, t, (logp, x_hat, out_z, out_lin, lin_f, reg)
 
 

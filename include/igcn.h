@@ -341,6 +341,25 @@ int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_t* numel, c
                     float* flat, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Loss head of train() — kernel/train_eval_sgcn_img_snps.py:525-543 — on the STACKED outputs of the batched sweep
+ * (rows [0,B) = plain pass :521, rows [B,2B) = isExplain pass :523):
+ *   terms[7] = {lam0*nll(logp[:B],y), lam0*nll(logp[B:],y), lam1*(mse_1+mse_2)/2, lam2*prob,
+ *               lam3*(sse_1+sse_2)/2 (snps reconstruction), lam4*(consist_1+consist_2)/2, lam5*orth_1}
+ *   loss = hp_ce*terms[0] + hp_mi*terms[1] + terms[2] + ... + terms[6]
+ * logp [2B,C] log-probabilities, y int64 [B], reg [2B,NR], clin [B*NR], x_hat [2B,S], snps [B,S],
+ * gram [2][2] = igcn_gram_loss_fwd outputs of the two passes, prob [1] = igcn_mask_reg_fwd output.
+ * lam6 is a HOST array (read at call time).  Backward: gout [1] device scalar; dgram [4], dprob [1].
+ */
+int igcn_loss_head_fwd(int B, int C, int NR, int S, const float* logp, const int64_t* y, const float* reg,
+                       const float* clin, const float* x_hat, const float* snps, const float* gram,
+                       const float* prob, const float* lam6, float hp_ce, float hp_mi, float* loss, float* terms,
+                       void* stream);
+int igcn_loss_head_bwd(int B, int C, int NR, int S, const int64_t* y, const float* reg, const float* clin,
+                       const float* x_hat, const float* snps, const float* lam6, float hp_ce, float hp_mi,
+                       const float* gout, float* dlogp, float* dreg, float* dxhat, float* dgram, float* dprob,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Graph-diffusion pre-transform + block-diagonal collation of B dense adjacencies A [B,R,R] (f32), on the device —
  * replaces, per graph, preprocess_diffusion_imgs_snps (util_gdc.py:71-86: get_ppr_matrix :7-15 with `alpha`,
  * get_top_k_matrix :25-31 with `k`, scipy coo_matrix) and the index offsetting of Batch.from_data_list

@@ -515,3 +515,38 @@ def test_attention_core(ops, bsz, lq, lk, d):
     assert_matches(o, o_ref.detach().numpy(), TOL, "o")
     assert_matches(g[0], g_ref[0].numpy(), 2e-4, "dq", floor=1e-6)
     assert_matches(g[1], g_ref[1].numpy(), 2e-4, "dkv", floor=1e-6)
+
+
+def test_loss_head_matches_composite():
+    """igcn_loss_head_* against the term-by-term composition of train() :525-543 (fp64 torch), values and gradients."""
+    import torch.nn.functional as F
+    from igcn_amd import ops
+    torch.manual_seed(0)
+    b, c, nr, s = 37, 3, 3, 54
+    dev = "cuda"
+    logp = torch.log_softmax(torch.randn(2 * b, c, device=dev), -1).requires_grad_(True)
+    y = torch.randint(0, c, (b,), device=dev)
+    reg = torch.randn(2 * b, nr, device=dev, requires_grad=True)
+    clin = torch.rand(b * nr, device=dev)
+    x_hat = torch.randn(2 * b, s, device=dev, requires_grad=True)
+    snps = torch.rand(b, s, device=dev)
+    gram = torch.rand(2, 2, device=dev, requires_grad=True)
+    prob = torch.rand((), device=dev, requires_grad=True)
+    lam, hp_ce, hp_mi = [0.7, 1.0, 0.5, 1.5e-3, 0.1, 0.2], 1.3, 0.8
+    loss, terms = ops.LossHead.apply(logp, y, reg, clin, x_hat, snps, gram, prob, lam, hp_ce, hp_mi)
+    (loss * 1.7).backward()
+    got = [t.grad.clone() for t in (logp, reg, x_hat, gram, prob)]
+    d = lambda t: t.detach().double().requires_grad_(True)          # noqa: E731
+    logp2, reg2, x2, gram2, prob2 = d(logp), d(reg), d(x_hat), d(gram), d(prob)
+    t = [lam[0] * F.nll_loss(logp2[:b], y), lam[0] * F.nll_loss(logp2[b:], y),
+         lam[1] * (F.mse_loss(reg2[:b].reshape(-1), clin.double()) + F.mse_loss(reg2[b:].reshape(-1), clin.double())) / 2,
+         lam[2] * prob2,
+         lam[3] * (((x2[:b] - snps.double()) ** 2).sum() + ((x2[b:] - snps.double()) ** 2).sum()) / 2,
+         lam[4] * (gram2[0, 0] + gram2[1, 0]) / 2, lam[5] * gram2[0, 1]]
+    want = hp_ce * t[0] + hp_mi * t[1] + sum(t[2:])
+    (want * 1.7).backward()
+    assert abs(float(loss) - float(want)) <= 1e-5 * abs(float(want))
+    for k in range(7):
+        assert abs(float(terms[k]) - float(t[k])) <= 1e-5 * max(1e-3, abs(float(t[k]))), k
+    for g, w, name in zip(got, (logp2, reg2, x2, gram2, prob2), ("logp", "reg", "x_hat", "gram", "prob")):
+        assert_matches(g, w.grad.float().cpu().numpy(), 1e-5, "grad " + name)
