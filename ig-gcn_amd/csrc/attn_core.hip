@@ -4,6 +4,8 @@
 // kernel/sgcn_img_snp.py:240 (nn.MultiheadAttention core).  One workgroup per (sample, head); K and V of the head
 // live in LDS un-padded so every K/V row is read as four 16-byte LDS broadcasts; lanes = query rows (forward, dQ) or
 // keys (dK/dV), 48-64 FMAs per 8 LDS reads.  Backward recomputes the probabilities from the saved log-sum-exp.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define AC_T 1024     // 16 waves = 4 per SIMD: one workgroup per CU (K,V of the head fill LDS) hides its own latencies
@@ -252,8 +254,26 @@ static size_t ac_lds_floats(int HD, int Lq, int Lk, int backward) {
   else if (hd == 24) { CALL(24); }            \
   else { return 0; }
 
-// dynamic LDS bytes needed, or 0 when the shape is not covered (head_dim in {4,8,12,16,20,24}, Lq <= 256, <= 160 KB)
+// attn_mfma.hip: head_dim 16 on the matrix cores (any Lq; K, V (and Q, dO) of one head must fit LDS)
+size_t igcn_attn_mfma_lds_bytes(int D, int H, int Lq, int Lk, int backward);
+int igcn_attn_mfma_fwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o, float* lse,
+                       hipStream_t st);
+int igcn_attn_mfma_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
+                       const float* lse, const float* dout, float* dq, float* dkv, hipStream_t st);
+
+static bool use_mfma(int D, int H, int Lq, int Lk) {
+  static int valu_only = -1;                       // IGCN_ATTN_VALU=1: force the VALU kernels (A/B comparisons)
+  if (valu_only < 0) {
+    const char* e = getenv("IGCN_ATTN_VALU");
+    valu_only = (e && e[0] == '1') ? 1 : 0;
+  }
+  return !valu_only && igcn_attn_mfma_lds_bytes(D, H, Lq, Lk, 1) != 0;
+}
+
+// dynamic LDS bytes needed, or 0 when the shape is not covered (head_dim 16: MFMA path, any Lq; otherwise
+// head_dim in {4,8,12,20,24}, Lq <= 256; <= 160 KB either way)
 extern "C" size_t igcn_attn_core_lds_bytes(int D, int H, int Lq, int Lk, int backward) {
+  if (H > 0 && Lq > 0 && Lk > 0 && use_mfma(D, H, Lq, Lk)) return igcn_attn_mfma_lds_bytes(D, H, Lq, Lk, backward);
   if (H <= 0 || D % H || Lq <= 0 || Lq > 256 || Lk <= 0) return 0;
   const int hd = D / H;
   if (!(hd == 4 || hd == 8 || hd == 12 || hd == 16 || hd == 20 || hd == 24)) return 0;
@@ -263,6 +283,8 @@ extern "C" size_t igcn_attn_core_lds_bytes(int D, int H, int Lq, int Lk, int bac
 
 extern "C" int igcn_attn_core_fwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o,
                                   float* lse, void* stream) {
+  if (H > 0 && Lq > 0 && Lk > 0 && use_mfma(D, H, Lq, Lk))
+    return igcn_attn_mfma_fwd(B, D, H, Lq, Lk, q, kv, o, lse, (hipStream_t)stream);
   const size_t lds = igcn_attn_core_lds_bytes(D, H, Lq, Lk, 0);
   if (lds == 0) { igcn_set_error("attn_core_fwd: unsupported shape D=%d H=%d Lq=%d Lk=%d", D, H, Lq, Lk); return IGCN_ERR_UNSUPPORTED; }
   const int hd = D / H;
@@ -280,6 +302,8 @@ extern "C" int igcn_attn_core_fwd(int B, int D, int H, int Lq, int Lk, const flo
 
 extern "C" int igcn_attn_core_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
                                   const float* lse, const float* dout, float* dq, float* dkv, void* stream) {
+  if (H > 0 && Lq > 0 && Lk > 0 && use_mfma(D, H, Lq, Lk))
+    return igcn_attn_mfma_bwd(B, D, H, Lq, Lk, q, kv, o, lse, dout, dq, dkv, (hipStream_t)stream);
   const size_t lds = igcn_attn_core_lds_bytes(D, H, Lq, Lk, 1);
   if (lds == 0) { igcn_set_error("attn_core_bwd: unsupported shape D=%d H=%d Lq=%d Lk=%d", D, H, Lq, Lk); return IGCN_ERR_UNSUPPORTED; }
   const int hd = D / H;

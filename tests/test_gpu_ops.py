@@ -494,7 +494,8 @@ def test_propagate_dense_graph_variants(ops, hint):
     assert_matches(out, want.numpy(), TOL, "out")
 
 
-@pytest.mark.parametrize("bsz,lq,lk,d", [(3, 10, 9, 8), (4, 90, 400, 32), (2, 130, 77, 16), (5, 90, 45, 32)])
+@pytest.mark.parametrize("bsz,lq,lk,d", [(3, 10, 9, 8), (4, 90, 400, 32), (2, 130, 77, 16), (5, 90, 45, 32),
+                                          (2, 300, 130, 32), (3, 7, 5, 32), (2, 16, 16, 32)])
 def test_attention_core(ops, bsz, lq, lk, d):
     rng = np.random.default_rng(lq * lk)
     h = 2
