@@ -338,7 +338,12 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
                    const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ t_row,
                    const float* __restrict__ x, const float* __restrict__ w_inc, const float* __restrict__ w_s,
                    const float* __restrict__ a_in, const float* __restrict__ a_s, const float* __restrict__ dy,
-                   const float* __restrict__ stats, float* __restrict__ dx, float* __restrict__ u) {
+                   const float* __restrict__ stats, float* __restrict__ dx, float* __restrict__ gpart) {
+  // parameter-gradient products G[2 FOUT + 3, FIN] = sum_nodes u[:,node] (x) x[:,node] are reduced over the block's
+  // nodes on the matrix cores: u and x go through LDS once (node-major -> MFMA operand layout)
+  constexpr int ROWS = 2 * FOUT + 3, TP = GO_T + 4;
+  __shared__ float us[ROWS][TP];
+  __shared__ float xt[FIN][TP];
   AttnW<FIN, FOUT> W;
   W.load(w_inc, w_s, a_in, a_s);
   const int n = blockIdx.x * GO_T + threadIdx.x;
@@ -435,17 +440,43 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
       for (int c = 0; c < FOUT; ++c) t += W.wi[c][d] * dxin[c] + W.ws[c][d] * dxs[c];
       dxb[(int64_t)d * N + n] = t;
     }
-    // rows for the parameter-gradient product  G[13,FIN] = sum_{b,n} u[b,:,n] (x) x[b,:,n]  (MFMA batched-sum
-    // GEMM): u = (dxin[FOUT], dxs[FOUT], dp, dq, dgate), channel-major so the stores are coalesced
-    float* ub = u + (int64_t)b * (2 * FOUT + 3) * N;
+    // rows of the parameter-gradient product: u = (dxin[FOUT], dxs[FOUT], dp, dq, dgate)
 #pragma unroll
     for (int c = 0; c < FOUT; ++c) {
-      ub[(int64_t)c * N + n] = dxin[c];
-      ub[(int64_t)(FOUT + c) * N + n] = dxs[c];
+      us[c][threadIdx.x] = dxin[c];
+      us[FOUT + c][threadIdx.x] = dxs[c];
     }
-    ub[(int64_t)(2 * FOUT) * N + n] = dp;
-    ub[(int64_t)(2 * FOUT + 1) * N + n] = dq;
-    ub[(int64_t)(2 * FOUT + 2) * N + n] = dgate;
+    us[2 * FOUT][threadIdx.x] = dp;
+    us[2 * FOUT + 1][threadIdx.x] = dq;
+    us[2 * FOUT + 2][threadIdx.x] = dgate;
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) xt[d][threadIdx.x] = xr[d];
+  } else {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) us[r][threadIdx.x] = 0.f;
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) xt[d][threadIdx.x] = 0.f;
+  }
+  __syncthreads();
+  {
+    // wave w reduces nodes [64 w, 64 w + 64): 16 MFMAs (K = 4 nodes each); acc[r] = G[row 4g+r][feature m]
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int w = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* ua = &us[m < ROWS ? m : 0][64 * w + g];
+    const float* xb2 = &xt[m < FIN ? m : 0][64 * w + g];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float a = (m < ROWS) ? ua[4 * c] : 0.f;
+      const float bq = (m < FIN) ? xb2[4 * c] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
+    }
+    float* gp = gpart + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (GO_T / 64) + w) * (ROWS * FIN);
+    if (m < FIN) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * g + r < ROWS) gp[(4 * g + r) * FIN + m] = acc[r];
+    }
   }
 }
 
@@ -471,8 +502,8 @@ int igcn_gemm_f32_batched_sum_impl(int64_t M, int64_t N, int64_t K, int batch, c
                                    int64_t b_batch, float* C, int64_t ldc, float* scratch, hipStream_t st);
 
 extern "C" size_t igcn_go_attn_bwd_scratch_floats(int B, int N, int fin, int fout) {
-  const int64_t rows = 2 * fout + 3;
-  return (size_t)(4 * (int64_t)B * N + rows * (int64_t)B * N + 16 * (int64_t)B * rows * fin + rows * fin + 64);
+  const int64_t rows = 2 * fout + 3, parts = igcn_cdiv(N, GO_T) * (int64_t)B * (GO_T / 64);
+  return (size_t)(4 * (int64_t)B * N + parts * rows * fin + rows * fin + 64);
 }
 
 extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
@@ -483,21 +514,20 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = 2 * fout + 3;
   float* stats = scratch;
-  float* u = stats + 4 * (int64_t)B * N;
-  float* G = u + rows * (int64_t)B * N;
-  float* slabs = G + rows * fin;
+  float* gpart = stats + 4 * (int64_t)B * N;                       // [blocks * 4 waves][rows * fin] block partials
   dim3 grid((unsigned)igcn_cdiv(N, GO_T), B);
+  const int64_t parts = (int64_t)grid.x * grid.y * (GO_T / 64);
+  float* G = gpart + parts * rows * fin;
 #define CALL(FI, FO)                                                                                             \
   hipLaunchKernelGGL((k_go_attn_bwd_stats<FI, FO>), grid, dim3(GO_T), 0, st, B, N, row_ptr, col, x, w_inc, a_in,  \
                      dy, stats);                                                                                  \
   hipLaunchKernelGGL((k_go_attn_bwd_main<FI, FO>), grid, dim3(GO_T), 0, st, B, N, row_ptr, col, t_ptr, t_row, x,  \
-                     w_inc, w_s, a_in, a_s, dy, stats, dx, u)
+                     w_inc, w_s, a_in, a_s, dy, stats, dx, gpart)
   GO_DISPATCH(fin, fout, CALL)
 #undef CALL
   IGCN_CHECK_LAUNCH("go_attn_bwd");
-  // G[r,d] = sum_b sum_n u[b,r,n] * x[b,d,n]
-  int rc = igcn_gemm_f32_batched_sum_impl(rows, fin, N, B, u, N, 1, rows * (int64_t)N, x, N, 1, (int64_t)fin * N, G,
-                                          fin, slabs, st);
+  // G[r,d] = sum over the block partials
+  int rc = igcn_launch_reduce_rows(gpart, parts, rows * fin, (int)(rows * fin), G, 0, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_go_attn_bwd_finish, dim3(1), dim3(128), 0, st, fin, fout, G, w_inc, w_s, dparams);
   IGCN_CHECK_LAUNCH("go_attn_bwd_finish");
