@@ -77,5 +77,6 @@ __device__ __forceinline__ void block_reduce_vec(const float (&v)[NV], float* re
 __global__ void k_reduce_rows(const float* __restrict__ partial, int64_t rows, int64_t ld, int n,
                               float* __restrict__ out, int accumulate);
 
+int igcn_launch_reduce_contig(const float* partial, int64_t rows, int n, float* out, hipStream_t st);
 int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int n, float* out, int accumulate,
                             hipStream_t st);

@@ -323,11 +323,8 @@ k_go_attn_bwd_stats(int B, int N, const int32_t* __restrict__ row_ptr, const int
   float tr = 0.f;
 #pragma unroll
   for (int c = 0; c < FOUT; ++c) tr += dy[((int64_t)b * FOUT + c) * N + n] * agg[c];
-  const int64_t BN = (int64_t)B * N, o = (int64_t)b * N + n;
-  stats[o] = p;
-  stats[BN + o] = q;
-  stats[2 * BN + o] = zinv;
-  stats[3 * BN + o] = tr * zinv;
+  // one 16-byte record per node: the walks of kernel B fetch a neighbour's statistics with one load
+  reinterpret_cast<float4*>(stats)[(int64_t)b * N + n] = make_float4(p, q, zinv, tr * zinv);
 }
 
 // ---- backward, kernel B: input gradient + block partials of the parameter gradients ------------
@@ -354,12 +351,11 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
   const int n = blockIdx.x * GO_T + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.y;
-  const int64_t BN = (int64_t)B * N;
   const bool live = n < N;
   const int nn = live ? n : N - 1;                 // dead lanes shadow a valid node, results discarded
   const float* xb = x + (int64_t)b * FIN * N;
   const float* dyb = dy + (int64_t)b * FOUT * N;
-  const float* sp = stats + (int64_t)b * N;        // p ; q at +BN ; zinv at +2BN ; tr at +3BN
+  const float4* sp = reinterpret_cast<const float4*>(stats) + (int64_t)b * N;     // (p, q, zinv, tr) per node
   const int32_t r0 = row_ptr[nn], r1 = row_ptr[nn + 1];
   const int32_t c0 = t_ptr[nn], c1 = t_ptr[nn + 1];
   float xr[FIN], xin[FOUT], xs[FOUT], dyn[FOUT];
@@ -367,7 +363,8 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
   load_node<FOUT>(dyb, N, nn, dyn);
   transform<FIN, FOUT>(W.wi, xr, xin);
   transform<FIN, FOUT>(W.ws, xr, xs);
-  const float p_n = sp[nn], q_n = sp[BN + nn], zinv_n = sp[2 * BN + nn], tr_n = sp[3 * BN + nn];
+  const float4 st_n = sp[nn];
+  const float p_n = st_n.x, q_n = st_n.y, zinv_n = st_n.z, tr_n = st_n.w;
   // n as ROW: d(score) of its own edges
   float dp = 0.f;
   for (int32_t e = r0; e < r1; ++e) {
@@ -375,7 +372,7 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
     float xm[FIN], xim[FOUT];
     load_node<FIN>(xb, N, m, xm);
     transform<FIN, FOUT>(W.wi, xm, xim);
-    const float th = go_tanh(p_n + sp[BN + m]);
+    const float th = go_tanh(p_n + sp[m].y);
     const float alpha = go_exp(th) * zinv_n;
     dp += (dot<FOUT>(dyn, xim) - tr_n) * alpha * (1.f - th * th);
   }
@@ -389,9 +386,10 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
       const int r = t_row[e];
       float dyr[FOUT];
       load_node<FOUT>(dyb, N, r, dyr);
-      const float th = go_tanh(sp[r] + q_n);
-      const float alpha = go_exp(th) * sp[2 * BN + r];
-      dq += (dot<FOUT>(dyr, xin) - sp[3 * BN + r]) * alpha * (1.f - th * th);
+      const float4 sr = sp[r];
+      const float th = go_tanh(sr.x + q_n);
+      const float alpha = go_exp(th) * sr.z;
+      dq += (dot<FOUT>(dyr, xin) - sr.w) * alpha * (1.f - th * th);
 #pragma unroll
       for (int c = 0; c < FOUT; ++c) dxin[c] += alpha * dyr[c];
     }
@@ -412,9 +410,10 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
       const int r = t_row[e];
       float dyr[FOUT];
       load_node<FOUT>(dyb, N, r, dyr);
-      const float th = go_tanh(sp[r] + hq);
-      const float alpha = go_exp(th) * sp[2 * BN + r];
-      pdq += (dot<FOUT>(dyr, hxin) - sp[3 * BN + r]) * alpha * (1.f - th * th);
+      const float4 sr = sp[r];
+      const float th = go_tanh(sr.x + hq);
+      const float alpha = go_exp(th) * sr.z;
+      pdq += (dot<FOUT>(dyr, hxin) - sr.w) * alpha * (1.f - th * th);
 #pragma unroll
       for (int c = 0; c < FOUT; ++c) pdx[c] += alpha * dyr[c];
     }
@@ -476,11 +475,13 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
       const float bq = (m < FIN) ? xb2[4 * c] : 0.f;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
     }
-    float* gp = gpart + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (GO_T / 64) + w) * (ROWS * FIN);
+    // partial layout [ROWS * FIN][parts]: the second-stage sum of an entry reads contiguous memory
+    const int64_t parts = (int64_t)gridDim.x * gridDim.y * (GO_T / 64);
+    float* gp = gpart + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (GO_T / 64) + w;
     if (m < FIN) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (4 * g + r < ROWS) gp[(4 * g + r) * FIN + m] = acc[r];
+        if (4 * g + r < ROWS) gp[(int64_t)((4 * g + r) * FIN + m) * parts] = acc[r];
     }
   }
 }
@@ -532,7 +533,7 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
 #undef CALL
   IGCN_CHECK_LAUNCH("go_attn_bwd");
   // G[r,d] = sum over the block partials
-  int rc = igcn_launch_reduce_rows(gpart, parts, rows * fin, (int)(rows * fin), G, 0, st);
+  int rc = igcn_launch_reduce_contig(gpart, parts, (int)(rows * fin), G, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_go_attn_bwd_finish, dim3(1), dim3(128), 0, st, fin, fout, G, w_inc, w_s, dparams);
   IGCN_CHECK_LAUNCH("go_attn_bwd_finish");

@@ -40,6 +40,24 @@ k_reduce_rows_par(const float* __restrict__ partial, int64_t rows, int64_t ld, f
   if (threadIdx.x == 0) out[j] = accumulate ? out[j] + t : t;
 }
 
+// out[j] = sum_r partial[j * rows + r]: the summands of one output are CONTIGUOUS (coalesced), one block per output
+__global__ void __launch_bounds__(256)
+k_reduce_contig(const float* __restrict__ partial, int64_t rows, float* __restrict__ out) {
+  __shared__ float red[16];
+  const float* p = partial + (int64_t)blockIdx.x * rows;
+  float t = 0.f;
+  for (int64_t r = threadIdx.x; r < rows; r += 256) t += p[r];
+  t = block_sum_all(t, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+
+int igcn_launch_reduce_contig(const float* partial, int64_t rows, int n, float* out, hipStream_t st) {
+  if (n <= 0) return IGCN_OK;
+  hipLaunchKernelGGL(k_reduce_contig, dim3((unsigned)n), dim3(256), 0, st, partial, rows, out);
+  IGCN_CHECK_LAUNCH("reduce_contig");
+  return IGCN_OK;
+}
+
 int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int n, float* out, int accumulate,
                             hipStream_t st) {
   if (n <= 0) return IGCN_OK;
