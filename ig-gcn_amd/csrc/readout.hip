@@ -171,6 +171,33 @@ k_nlbn_apply(int B, int N, int groups, const float* __restrict__ x, const float*
   }
 }
 
+// a thread's D consecutive floats with 16-byte loads / stores when D allows it (rows of [.., D] tensors start on
+// 16-byte boundaries then): the scalar form issues D vector-memory instructions per row
+template <int D>
+__device__ __forceinline__ void ro_load_row(const float* __restrict__ p, float (&v)[D]) {
+  if constexpr (D % 4 == 0) {
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + d);
+      v[d] = t.x; v[d + 1] = t.y; v[d + 2] = t.z; v[d + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; ++d) v[d] = p[d];
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void ro_store_row(float* __restrict__ p, const float (&v)[D]) {
+  if constexpr (D % 4 == 0) {
+#pragma unroll
+    for (int d = 0; d < D; d += 4) *reinterpret_cast<float4*>(p + d) = make_float4(v[d], v[d + 1], v[d + 2], v[d + 3]);
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; ++d) p[d] = v[d];
+  }
+}
+
 // ---- backward pass 1: per node sum(dy), sum(dy*xhat) over (b,d), dy = dout * [out > 0] ---------------
 template <int F, int D>
 __global__ void __launch_bounds__(RO_T)
@@ -191,7 +218,8 @@ k_nlbn_bwd_stats(int B, int N, int groups, const float* __restrict__ x, const fl
 #pragma unroll
       for (int c = 0; c < F; ++c) xv[c] = x[((int64_t)b * F + c) * N + n];
       ro_pre<F, D>(w, xv, pre);
-      const float* g = dout + ((int64_t)b * N + n) * D;
+      float g[D];
+      ro_load_row<D>(dout + ((int64_t)b * N + n) * D, g);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const float xh = (pre[d] - mu) * rs;
@@ -246,7 +274,8 @@ k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict
         dxv[c] = 0.f;
       }
       ro_pre<F, D>(w, xv, pre);
-      const float* g = dout + ((int64_t)b * N + n) * D;
+      float g[D];
+      ro_load_row<D>(dout + ((int64_t)b * N + n) * D, g);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const float xh = (pre[d] - mu) * rs;
@@ -256,11 +285,12 @@ k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict
 #pragma unroll
           for (int c = 0; c < F; ++c) gw[d * F + c] += t * xv[c];
         } else {
-          dpre_out[((int64_t)b * N + n) * D + d] = t;
+          g[d] = t;                                             // dpre, stored as a row below
         }
 #pragma unroll
         for (int c = 0; c < F; ++c) dxv[c] += w[d * F + c] * t;
       }
+      if constexpr (!SMALL) ro_store_row<D>(dpre_out + ((int64_t)b * N + n) * D, g);
 #pragma unroll
       for (int c = 0; c < F; ++c) dx[((int64_t)b * F + c) * N + n] = dxv[c];
     }
@@ -331,8 +361,8 @@ extern "C" size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, in
   const size_t cpg = ro_cpg(B, groups);
   const size_t stats = (size_t)groups * cpg * 2 * N + (size_t)groups * 2 * N;
   const size_t blocks = (size_t)igcn_cdiv(N, RO_NL) * groups * cpg;
-  if (D * F <= 16) return stats + blocks * D * F + 64;
-  return stats + (size_t)B * N * D + (size_t)16 * B * D * F + 64;
+  if (D * F <= 16) return stats + blocks * D * F + 68;
+  return stats + (size_t)B * N * D + (size_t)16 * B * D * F + 68;
 }
 
 extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, int training, const float* x,
@@ -346,7 +376,8 @@ extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, i
   dim3 grid((unsigned)igcn_cdiv(N, RO_NL), groups * cpg);
   float* stats = scratch;                                    // [cpg][groups][2][N]
   float* dgg = stats + (size_t)groups * cpg * 2 * N;         // [groups][2][N]
-  float* aux = dgg + (size_t)groups * 2 * N;                 // wpartial (small) or dpre then slabs (large)
+  float* aux = scratch + (((size_t)(dgg - scratch) + (size_t)groups * 2 * N + 3) & ~(size_t)3);   // 16-B aligned:
+                                                             // wpartial (small) or dpre rows, then slabs (large)
   const bool small = D * F <= 16;
 #define CALL(FV, DV)                                                                                              \
   hipLaunchKernelGGL((k_nlbn_bwd_stats<FV, DV>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta,         \
