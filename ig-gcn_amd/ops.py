@@ -334,20 +334,45 @@ class Csr:
         pad = lambda t: t if t.numel() else torch.zeros(1, dtype=torch.long)   # noqa: E731
         self.row_ptr, self.col, self.row_of = i32(row_ptr), i32(pad(cols)), i32(pad(rows))
         self.t_ptr, self.t_row, self.t_k = i32(t_ptr), i32(pad(rows[order])), i32(pad(order))
+        self.flat_pos = key.to(device)            # row * n_cols + col of every non-zero (dense formulation)
+        self._dense = {}
+
+    def dense(self, channels):
+        """Persistent zero-initialised dense image [channels, n_rows * n_cols]; only the non-zero positions are ever
+        written (SparseMap scatters the current values into it), so the zeros stay zeros."""
+        t = self._dense.get(channels)
+        if t is None:
+            t = torch.zeros(channels, self.n_rows * self.n_cols, dtype=torch.float32, device=self.flat_pos.device)
+            self._dense[channels] = t
+        return t
 
 
 class SparseMap(torch.autograd.Function):
-    """y[b,c,i] = sum_k val[c,k] x[b,col_k]  (gene encode go_model.py:208-215 / decode :281-282)."""
+    """y[b,c,i] = sum_k val[c,k] x[b,col_k]  (gene encode go_model.py:208-215 / decode :281-282).
+
+    The maps are small (N_go x 54 with ~5 % non-zeros), the batch is not: the learnable values are scattered into
+    a dense image and all three products run on the matrix cores (igcn_gemm_f32) — y = x T^T, dx = dy T,
+    dT = dy^T x with the value gradients gathered back from dT.  Adding the structural zeros changes the fp32
+    summation order only.  Maps whose dense image would exceed DENSE_LIMIT floats use the CSR kernels (igcn_spmm_*)."""
+
+    DENSE_LIMIT = 1 << 24
 
     @staticmethod
     def forward(ctx, x, val, csr):
         x, val = _f32(x), _f32(val)
         b, c = x.shape[0], val.shape[0]
+        ctx.csr = csr
+        ctx.dense = c * csr.n_rows * csr.n_cols <= SparseMap.DENSE_LIMIT and csr.nnz > 0
+        if ctx.dense:
+            t = csr.dense(c)
+            t.index_copy_(1, csr.flat_pos, val)
+            y = gemm_nt(x, t.view(c * csr.n_rows, csr.n_cols)).view(b, c, csr.n_rows)
+            ctx.save_for_backward(x, val)
+            return y
         y = torch.empty(b, c, csr.n_rows, dtype=torch.float32, device=x.device)
         call("igcn_spmm_fwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col), ptr(val),
              ptr(x), ptr(y), stream_ptr())
         ctx.save_for_backward(x, val)
-        ctx.csr = csr
         return y
 
     @staticmethod
@@ -356,6 +381,14 @@ class SparseMap(torch.autograd.Function):
         csr = ctx.csr
         dy = _f32(dy)
         b, c = x.shape[0], val.shape[0]
+        if ctx.dense:
+            dy2 = dy.view(b, c * csr.n_rows)
+            t = csr.dense(c)                     # still holds the values of the forward (same parameters)
+            dx = gemm_nn(dy2, t.view(c * csr.n_rows, csr.n_cols)) if ctx.needs_input_grad[0] else None
+            dval = None
+            if ctx.needs_input_grad[1]:
+                dval = gemm_tn(dy2, x).view(c, csr.n_rows * csr.n_cols).index_select(1, csr.flat_pos)
+            return dx, dval, None
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dval = torch.empty_like(val) if ctx.needs_input_grad[1] else None
         scratch = torch.empty(16 * c * max(csr.nnz, 1), dtype=torch.float32, device=x.device) \

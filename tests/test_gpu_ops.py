@@ -252,8 +252,12 @@ def test_go_decoder_layer(ops, bsz, pool, layer, seed):
     assert_matches(g[2], g_ref[2].numpy(), TOL, "dW_sout")
 
 
+@pytest.mark.parametrize("dense", [True, False])
 @pytest.mark.parametrize("bsz,pool,seed", [(4, (20, 10, 6, 3, 1), 0), (32, (300, 120, 60, 19, 1), 1)])
-def test_sparse_map_encode_decode(ops, bsz, pool, seed):
+def test_sparse_map_encode_decode(ops, monkeypatch, bsz, pool, seed, dense):
+    """Both formulations of the learnable sparse maps: dense image + MFMA GEMMs (default) and the CSR kernels."""
+    if not dense:
+        monkeypatch.setattr(ops.SparseMap, "DENSE_LIMIT", 0)
     a_g, _, _, idx = _hier(pool, seed)
     n = idx["n"]
     gn, gs = idx["gene"]
