@@ -51,41 +51,53 @@ extern "C" int igcn_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, in
 //   g_i  = d_xm_i + pb[:h0] * S_i + pb[h0:] * T_i,   S_i = sum_{k: src=i} dz_k, T_i = sum_{k: dst=i} dz_k
 //   dx_i = g_i * prob[roi(i)] ;  dprob[r] = sum_graphs g_i * x_i ;  dpb = (sum_i xm_i S_i , sum_i xm_i T_i)
 // =================================================================================================
-__global__ void k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict__ x,
-                                      const float* __restrict__ prob, const float* __restrict__ pb,
-                                      const float* __restrict__ ew, const float* __restrict__ e,
-                                      const float* __restrict__ d_xm, const float* __restrict__ d_ewm,
-                                      const float* __restrict__ d_e, const int32_t* __restrict__ tgt_ptr,
-                                      const int32_t* __restrict__ tgt_perm, const int32_t* __restrict__ src_ptr,
-                                      const int32_t* __restrict__ src_perm, float* __restrict__ dx,
-                                      float* __restrict__ gx /*[N,h0]*/, float* __restrict__ pb_partial /*[nblk,2h0]*/) {
+// LPN lanes share a node (1: low degree; 64: dense graphs, the wave strides the node's edge lists).  A block always
+// covers 256 consecutive nodes, so the partial layout does not depend on LPN.
+template <int LPN>
+__global__ void __launch_bounds__(256)
+k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict__ x,
+                      const float* __restrict__ prob, const float* __restrict__ pb,
+                      const float* __restrict__ ew, const float* __restrict__ e,
+                      const float* __restrict__ d_xm, const float* __restrict__ d_ewm,
+                      const float* __restrict__ d_e, const int32_t* __restrict__ tgt_ptr,
+                      const int32_t* __restrict__ tgt_perm, const int32_t* __restrict__ src_ptr,
+                      const int32_t* __restrict__ src_perm, float* __restrict__ dx,
+                      float* __restrict__ gx /*[N,h0]*/, float* __restrict__ pb_partial /*[nblk,2h0]*/) {
   __shared__ float red[4 * 2 * MAX_H0];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float acc[2 * MAX_H0];
 #pragma unroll
   for (int j = 0; j < 2 * MAX_H0; ++j) acc[j] = 0.f;
-  if (i < n_nodes) {
+  const int sub = threadIdx.x % LPN;
+  for (int it = 0; it < LPN; ++it) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + it * (256 / LPN) + threadIdx.x / LPN;
+    if (i >= n_nodes) break;                       // uniform over the LPN lanes of a node (and the wave for LPN=64)
     float S = 0.f, T = 0.f;
-    for (int32_t p = src_ptr[i]; p < src_ptr[i + 1]; ++p) {
+    for (int32_t p = src_ptr[i] + sub; p < src_ptr[i + 1]; p += LPN) {
       const int32_t k = src_perm[p];
       const float ek = e[k];
       const float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
       S += up * ek * (1.f - ek);
     }
-    for (int32_t p = tgt_ptr[i]; p < tgt_ptr[i + 1]; ++p) {
+    for (int32_t p = tgt_ptr[i] + sub; p < tgt_ptr[i + 1]; p += LPN) {
       const int32_t k = tgt_perm[p];
       const float ek = e[k];
       const float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
       T += up * ek * (1.f - ek);
     }
-    const int64_t r = (i % rois) * h0;
-    for (int h = 0; h < h0; ++h) {
-      const float xv = x[i * h0 + h], pv = prob[r + h];
-      const float g = (d_xm ? d_xm[i * h0 + h] : 0.f) + pb[h] * S + pb[h0 + h] * T;
-      dx[i * h0 + h] = g * pv;
-      gx[i * h0 + h] = g * xv;
-      acc[h] = xv * pv * S;
-      acc[MAX_H0 + h] = xv * pv * T;
+    if (LPN > 1) {
+      S = wave_sum_all(S);
+      T = wave_sum_all(T);
+    }
+    if (sub == 0) {
+      const int64_t r = (i % rois) * h0;
+      for (int h = 0; h < h0; ++h) {
+        const float xv = x[i * h0 + h], pv = prob[r + h];
+        const float g = (d_xm ? d_xm[i * h0 + h] : 0.f) + pb[h] * S + pb[h0 + h] * T;
+        dx[i * h0 + h] = g * pv;
+        gx[i * h0 + h] = g * xv;
+        acc[h] += xv * pv * S;
+        acc[MAX_H0 + h] += xv * pv * T;
+      }
     }
   }
   block_reduce_vec<2 * MAX_H0>(acc, red, pb_partial + (int64_t)blockIdx.x * 2 * MAX_H0);
@@ -122,8 +134,12 @@ extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, in
   const int64_t nblk = igcn_cdiv(n_nodes, 256);
   float* gx = scratch;
   float* part = scratch + n_nodes * h0;  // [nblk, 2*MAX_H0]
-  hipLaunchKernelGGL(k_edge_mask_bwd_nodes, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
-                     prob_bias, ew, e, d_xm, d_ewm, d_e, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
+  if (n_edges >= 16 * n_nodes)                     // dense graphs: the wave strides a node's edge lists
+    hipLaunchKernelGGL(k_edge_mask_bwd_nodes<64>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
+                       prob_bias, ew, e, d_xm, d_ewm, d_e, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
+  else
+    hipLaunchKernelGGL(k_edge_mask_bwd_nodes<1>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
+                       prob_bias, ew, e, d_xm, d_ewm, d_e, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
   hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)(rois * h0)), dim3(256), 0, st, n_nodes / rois, rois, h0,
                      gx, dprob);
   hipLaunchKernelGGL(k_edge_mask_bwd_pb, dim3(1), dim3(64), 0, st, nblk, h0, part, dprob_bias);
@@ -134,17 +150,22 @@ extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, in
 // =================================================================================================
 // gcn_norm forward: one thread per node
 // =================================================================================================
-__global__ void k_gcn_norm_fwd(int64_t n_nodes, const float* __restrict__ ew, const int32_t* __restrict__ src32,
-                               const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
-                               const int32_t* __restrict__ loop_edge, float* __restrict__ dis,
-                               float* __restrict__ wl) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+template <int LPN>
+__global__ void __launch_bounds__(256)
+k_gcn_norm_fwd(int64_t n_nodes, const float* __restrict__ ew, const int32_t* __restrict__ src32,
+               const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
+               const int32_t* __restrict__ loop_edge, float* __restrict__ dis, float* __restrict__ wl) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = gid / LPN;
+  const int sub = (int)(gid % LPN);
   if (i >= n_nodes) return;
   float deg = 0.f;
-  for (int32_t p = tgt_ptr[i]; p < tgt_ptr[i + 1]; ++p) {
+  for (int32_t p = tgt_ptr[i] + sub; p < tgt_ptr[i + 1]; p += LPN) {
     const int32_t k = tgt_perm[p];
     if (src32[k] != (int32_t)i) deg += ew[k];
   }
+  if (LPN > 1) deg = wave_sum_all(deg);
+  if (sub != 0) return;
   const int32_t le = loop_edge[i];
   const float lw = le >= 0 ? ew[le] : 1.f;
   deg += lw;
@@ -192,8 +213,12 @@ extern "C" int igcn_gcn_norm_fwd(int64_t n_nodes, int64_t n_edges, const float* 
                                  float* what, float* what_loop, void* tstream, void* sstream, void* stream) {
   if (n_nodes == 0) return IGCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gcn_norm_fwd, dim3((unsigned)igcn_cdiv(n_nodes, 256)), dim3(256), 0, st, n_nodes, ew, src32,
-                     tgt_ptr, tgt_perm, loop_edge, dis, wl);
+  if (n_edges >= 16 * n_nodes)                     // dense graphs: one wave per node
+    hipLaunchKernelGGL(k_gcn_norm_fwd<64>, dim3((unsigned)igcn_cdiv(n_nodes * 64, 256)), dim3(256), 0, st, n_nodes, ew,
+                       src32, tgt_ptr, tgt_perm, loop_edge, dis, wl);
+  else
+    hipLaunchKernelGGL(k_gcn_norm_fwd<1>, dim3((unsigned)igcn_cdiv(n_nodes, 256)), dim3(256), 0, st, n_nodes, ew,
+                       src32, tgt_ptr, tgt_perm, loop_edge, dis, wl);
   const int64_t n = n_nodes > n_edges ? n_nodes : n_edges;
   hipLaunchKernelGGL(k_gcn_norm_coef, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, st, n_nodes, n_edges, ew, dis,
                      wl, src32, dst32, tgt_perm, src_perm, what, what_loop, (EdgeRec*)tstream, (EdgeRec*)sstream);
@@ -204,25 +229,31 @@ extern "C" int igcn_gcn_norm_fwd(int64_t n_nodes, int64_t n_edges, const float* 
 // gcn_norm backward, phase 1 (per node): d(deg)
 //   d dis_i = sum_{k out of i, non-loop} dwhat_k ew_k dis[dst_k] + sum_{k into i, non-loop} dwhat_k ew_k dis[src_k]
 //             + 2 dwhat_loop_i wl_i dis_i ;   d deg_i = -1/2 dis_i^3 d dis_i
-__global__ void k_gcn_norm_bwd_deg(int64_t n_nodes, const float* __restrict__ ew, const float* __restrict__ dis,
-                                   const float* __restrict__ wl, const float* __restrict__ dwhat,
-                                   const float* __restrict__ dwhat_loop, const int32_t* __restrict__ src32,
-                                   const int32_t* __restrict__ dst32, const int32_t* __restrict__ tgt_ptr,
-                                   const int32_t* __restrict__ tgt_perm, const int32_t* __restrict__ src_ptr,
-                                   const int32_t* __restrict__ src_perm, float* __restrict__ ddeg) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+template <int LPN>
+__global__ void __launch_bounds__(256)
+k_gcn_norm_bwd_deg(int64_t n_nodes, const float* __restrict__ ew, const float* __restrict__ dis,
+                   const float* __restrict__ wl, const float* __restrict__ dwhat,
+                   const float* __restrict__ dwhat_loop, const int32_t* __restrict__ src32,
+                   const int32_t* __restrict__ dst32, const int32_t* __restrict__ tgt_ptr,
+                   const int32_t* __restrict__ tgt_perm, const int32_t* __restrict__ src_ptr,
+                   const int32_t* __restrict__ src_perm, float* __restrict__ ddeg) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = gid / LPN;
+  const int sub = (int)(gid % LPN);
   if (i >= n_nodes) return;
   float dd = 0.f;
-  for (int32_t p = src_ptr[i]; p < src_ptr[i + 1]; ++p) {
+  for (int32_t p = src_ptr[i] + sub; p < src_ptr[i + 1]; p += LPN) {
     const int32_t k = src_perm[p];
     const int32_t t = dst32[k];
     if (t != (int32_t)i) dd += dwhat[k] * ew[k] * dis[t];
   }
-  for (int32_t p = tgt_ptr[i]; p < tgt_ptr[i + 1]; ++p) {
+  for (int32_t p = tgt_ptr[i] + sub; p < tgt_ptr[i + 1]; p += LPN) {
     const int32_t k = tgt_perm[p];
     const int32_t s = src32[k];
     if (s != (int32_t)i) dd += dwhat[k] * ew[k] * dis[s];
   }
+  if (LPN > 1) dd = wave_sum_all(dd);
+  if (sub != 0) return;
   const float di = dis[i];
   dd += 2.f * dwhat_loop[i] * wl[i] * di;
   ddeg[i] = -0.5f * di * di * di * dd;
@@ -253,8 +284,12 @@ extern "C" int igcn_gcn_norm_bwd(int64_t n_nodes, int64_t n_edges, const float* 
                                  const int32_t* loop_edge, float* dew, float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n_nodes == 0 || n_edges == 0) return IGCN_OK;
-  hipLaunchKernelGGL(k_gcn_norm_bwd_deg, dim3((unsigned)igcn_cdiv(n_nodes, 256)), dim3(256), 0, st, n_nodes, ew, dis,
-                     wl, dwhat, dwhat_loop, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, scratch);
+  if (n_edges >= 16 * n_nodes)
+    hipLaunchKernelGGL(k_gcn_norm_bwd_deg<64>, dim3((unsigned)igcn_cdiv(n_nodes * 64, 256)), dim3(256), 0, st, n_nodes,
+                       ew, dis, wl, dwhat, dwhat_loop, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, scratch);
+  else
+    hipLaunchKernelGGL(k_gcn_norm_bwd_deg<1>, dim3((unsigned)igcn_cdiv(n_nodes, 256)), dim3(256), 0, st, n_nodes, ew,
+                       dis, wl, dwhat, dwhat_loop, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, scratch);
   hipLaunchKernelGGL(k_gcn_norm_bwd_edge, dim3((unsigned)igcn_cdiv(n_edges, 256)), dim3(256), 0, st, n_edges, dis,
                      dwhat, dwhat_loop, scratch, src32, dst32, loop_edge, dew);
   IGCN_CHECK_LAUNCH("gcn_norm_bwd");
@@ -546,6 +581,103 @@ __global__ void k_gcn_propagate_bwd_dw(int64_t n_nodes, int64_t n_edges, int F, 
   *dstp = acc;
 }
 
+// 16-byte rows: the scalar form above issues 3 F four-byte loads per edge, each lane on its own cache line
+__global__ void __launch_bounds__(256)
+k_gcn_propagate_bwd_dw_q(int64_t n_nodes, int64_t n_edges, int FQ, const float* __restrict__ dout, int64_t ld_dout,
+                         const float* __restrict__ out, int64_t ld_out, int relu, const float* __restrict__ h,
+                         int64_t ld_h, const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
+                         float* __restrict__ dwhat, float* __restrict__ dwhat_loop) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_edges + n_nodes) return;
+  int64_t s, t;
+  float* dstp;
+  if (i < n_edges) {
+    s = src32[i];
+    t = dst32[i];
+    dstp = dwhat + i;
+    if (s == t) { *dstp = 0.f; return; }
+  } else {
+    s = t = i - n_edges;
+    dstp = dwhat_loop + s;
+  }
+  const float4* g4 = reinterpret_cast<const float4*>(dout + t * ld_dout);
+  const float4* o4 = reinterpret_cast<const float4*>(out + t * ld_out);
+  const float4* h4 = reinterpret_cast<const float4*>(h + s * ld_h);
+  float acc = 0.f;
+  for (int f = 0; f < FQ; ++f) {
+    float4 g = g4[f];
+    const float4 hv = h4[f];
+    if (relu) {
+      const float4 o = o4[f];
+      g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+    }
+    acc += g.x * hv.x;                      // same summation order as the scalar kernel
+    acc += g.y * hv.y;
+    acc += g.z * hv.z;
+    acc += g.w * hv.w;
+  }
+  *dstp = acc;
+}
+
+// dense graphs (hundreds of out-edges per source): one wave per source node, as k_gcn_propagate_fwd_wide; a block
+// still covers 256/FQ source nodes so that the dbias partial layout equals the quad kernel's
+template <int FQ>
+__global__ void __launch_bounds__(256)
+k_gcn_propagate_bwd_dh_wide(int64_t n_nodes, const float* __restrict__ dout, int64_t ld_dout,
+                            const float* __restrict__ out, int64_t ld_out, int relu,
+                            const EdgeRec* __restrict__ sstream, const float* __restrict__ what_loop,
+                            const int32_t* __restrict__ src_ptr, float* __restrict__ dh, int64_t ld_dh,
+                            float* __restrict__ dbias_partial /*[nblk, 4*FQ]*/) {
+  constexpr int NPB = 256 / FQ, SL = 64 / FQ;
+  __shared__ float4 red[4 * FQ];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fq = lane % FQ, slot = lane / FQ;
+  float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int it = 0; it < NPB / 4; ++it) {
+    const int64_t s = (int64_t)blockIdx.x * NPB + it * 4 + w;
+    if (s >= n_nodes) break;                        // wave-uniform
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t p1 = src_ptr[s + 1];
+#pragma unroll 4
+    for (int32_t p = src_ptr[s] + slot; p < p1; p += SL) {
+      const EdgeRec e = sstream[p];
+      float4 g = *reinterpret_cast<const float4*>(dout + (int64_t)e.idx * ld_dout + fq * 4);
+      if (relu) {
+        const float4 o = *reinterpret_cast<const float4*>(out + (int64_t)e.idx * ld_out + fq * 4);
+        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+      }
+      acc.x += e.w * g.x; acc.y += e.w * g.y; acc.z += e.w * g.z; acc.w += e.w * g.w;
+    }
+#pragma unroll
+    for (int o2 = FQ; o2 < 64; o2 <<= 1) {
+      acc.x += __shfl_xor(acc.x, o2, 64); acc.y += __shfl_xor(acc.y, o2, 64);
+      acc.z += __shfl_xor(acc.z, o2, 64); acc.w += __shfl_xor(acc.w, o2, 64);
+    }
+    if (slot == 0) {
+      float4 gself = *reinterpret_cast<const float4*>(dout + s * ld_dout + fq * 4);
+      if (relu) {
+        const float4 o = *reinterpret_cast<const float4*>(out + s * ld_out + fq * 4);
+        gself.x = o.x > 0.f ? gself.x : 0.f; gself.y = o.y > 0.f ? gself.y : 0.f;
+        gself.z = o.z > 0.f ? gself.z : 0.f; gself.w = o.w > 0.f ? gself.w : 0.f;
+      }
+      const float wl = what_loop[s];
+      acc.x += wl * gself.x; acc.y += wl * gself.y; acc.z += wl * gself.z; acc.w += wl * gself.w;
+      *reinterpret_cast<float4*>(dh + s * ld_dh + fq * 4) = acc;
+      gsum.x += gself.x; gsum.y += gself.y; gsum.z += gself.z; gsum.w += gself.w;
+    }
+  }
+  if (slot == 0) red[w * FQ + fq] = gsum;
+  __syncthreads();
+  if (threadIdx.x < FQ) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = red[j * FQ + threadIdx.x];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    float* dst = dbias_partial + ((int64_t)blockIdx.x * FQ + threadIdx.x) * 4;
+    dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+  }
+}
+
 extern "C" size_t igcn_gcn_propagate_bwd_scratch_floats(int64_t n_nodes, int F) {
   const int FP = pow2_ge(F > 0 ? F : 1);
   const int npb = FP >= 256 ? 1 : 256 / FP;
@@ -568,9 +700,15 @@ extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, c
   const bool quad = al16 && (F == 4 || F == 8 || F == 16 || F == 32 || F == 64);
   if (quad) {
     nblk = igcn_cdiv(n_nodes, 256 / (F / 4));
+    const bool wide = n_edges >= 16 * n_nodes;
 #define LAUNCH_BQ(FQV)                                                                                            \
-  hipLaunchKernelGGL((k_gcn_propagate_bwd_dh_q<FQV>), dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, dout,       \
-                     ld_dout, out, ld_out, relu, (const EdgeRec*)sstream, what_loop, src_ptr, dh, ld_dh, scratch)
+  if (wide)                                                                                                       \
+    hipLaunchKernelGGL((k_gcn_propagate_bwd_dh_wide<FQV>), dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, dout,  \
+                       ld_dout, out, ld_out, relu, (const EdgeRec*)sstream, what_loop, src_ptr, dh, ld_dh,         \
+                       scratch);                                                                                   \
+  else                                                                                                            \
+    hipLaunchKernelGGL((k_gcn_propagate_bwd_dh_q<FQV>), dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, dout,     \
+                       ld_dout, out, ld_out, relu, (const EdgeRec*)sstream, what_loop, src_ptr, dh, ld_dh, scratch)
     switch (F / 4) {
       case 1: LAUNCH_BQ(1); break;
       case 2: LAUNCH_BQ(2); break;
@@ -602,9 +740,14 @@ extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, c
     if (rc) return rc;
   }
   if (need_dw) {
-    hipLaunchKernelGGL(k_gcn_propagate_bwd_dw, dim3((unsigned)igcn_cdiv(n_edges + n_nodes, 256)), dim3(256), 0, st,
-                       n_nodes, n_edges, F, dout, ld_dout, out, ld_out, relu, h, ld_h, src32, dst32, dwhat,
-                       dwhat_loop);
+    if (quad && (uintptr_t)h % 16 == 0 && ld_h % 4 == 0)
+      hipLaunchKernelGGL(k_gcn_propagate_bwd_dw_q, dim3((unsigned)igcn_cdiv(n_edges + n_nodes, 256)), dim3(256), 0,
+                         st, n_nodes, n_edges, F / 4, dout, ld_dout, out, ld_out, relu, h, ld_h, src32, dst32, dwhat,
+                         dwhat_loop);
+    else
+      hipLaunchKernelGGL(k_gcn_propagate_bwd_dw, dim3((unsigned)igcn_cdiv(n_edges + n_nodes, 256)), dim3(256), 0, st,
+                         n_nodes, n_edges, F, dout, ld_dout, out, ld_out, relu, h, ld_h, src32, dst32, dwhat,
+                         dwhat_loop);
     IGCN_CHECK_LAUNCH("gcn_propagate_bwd_dw");
   }
   return IGCN_OK;

@@ -76,12 +76,13 @@ def test_graph_plan_bit_exact(ops, n, e, seed):
 
 
 # ------------------------------------------------------------------------------------------------ masks
-@pytest.mark.parametrize("bsz,rois,h0,seed", [(3, 10, 3, 0), (8, 90, 3, 1), (2, 17, 5, 2)])
-def test_edge_mask_fwd_bwd(ops, bsz, rois, h0, seed):
+@pytest.mark.parametrize("bsz,rois,h0,seed,deg", [(3, 10, 3, 0, 6), (8, 90, 3, 1, 6), (2, 17, 5, 2, 6),
+                                                  (3, 70, 3, 3, 40)])      # deg >= 16: wave-per-node backward
+def test_edge_mask_fwd_bwd(ops, bsz, rois, h0, seed, deg):
     from oracle import sgcn_img_snp as OS
     rng = np.random.default_rng(seed)
     n = bsz * rois
-    ei, ew = _rand_graph(rng, n, 6 * n)
+    ei, ew = _rand_graph(rng, n, deg * n)
     x = torch.from_numpy(rng.random((n, h0))).float()
     sd = {"prob": torch.from_numpy(rng.standard_normal((rois, h0))).float(),
           "prob_bias": torch.from_numpy(rng.standard_normal((2 * h0, 1))).float()}
