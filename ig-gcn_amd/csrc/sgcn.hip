@@ -51,8 +51,8 @@ extern "C" int igcn_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, in
 //   g_i  = d_xm_i + pb[:h0] * S_i + pb[h0:] * T_i,   S_i = sum_{k: src=i} dz_k, T_i = sum_{k: dst=i} dz_k
 //   dx_i = g_i * prob[roi(i)] ;  dprob[r] = sum_graphs g_i * x_i ;  dpb = (sum_i xm_i S_i , sum_i xm_i T_i)
 // =================================================================================================
-// LPN lanes share a node (1: low degree; 64: dense graphs, the wave strides the node's edge lists).  A block always
-// covers 256 consecutive nodes, so the partial layout does not depend on LPN.
+// LPN lanes share a node (1: low degree; 64: dense graphs, the wave strides the node's edge lists); a block covers
+// 256/LPN consecutive nodes and writes one partial row.
 template <int LPN>
 __global__ void __launch_bounds__(256)
 k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict__ x,
@@ -68,9 +68,8 @@ k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict
 #pragma unroll
   for (int j = 0; j < 2 * MAX_H0; ++j) acc[j] = 0.f;
   const int sub = threadIdx.x % LPN;
-  for (int it = 0; it < LPN; ++it) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + it * (256 / LPN) + threadIdx.x / LPN;
-    if (i >= n_nodes) break;                       // uniform over the LPN lanes of a node (and the wave for LPN=64)
+  const int64_t i = (int64_t)blockIdx.x * (256 / LPN) + threadIdx.x / LPN;
+  if (i < n_nodes) {                               // uniform over the LPN lanes of a node (the wave for LPN=64)
     float S = 0.f, T = 0.f;
     for (int32_t p = src_ptr[i] + sub; p < src_ptr[i + 1]; p += LPN) {
       const int32_t k = src_perm[p];
@@ -131,10 +130,11 @@ extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, in
                                   float* dx, float* dprob, float* dprob_bias, float* scratch, void* stream) {
   IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0, "edge_mask_bwd: bad rois/h0");
   hipStream_t st = (hipStream_t)stream;
-  const int64_t nblk = igcn_cdiv(n_nodes, 256);
+  const bool dense = n_edges >= 16 * n_nodes;
+  const int64_t nblk = igcn_cdiv(n_nodes, dense ? 4 : 256);
   float* gx = scratch;
   float* part = scratch + n_nodes * h0;  // [nblk, 2*MAX_H0]
-  if (n_edges >= 16 * n_nodes)                     // dense graphs: the wave strides a node's edge lists
+  if (dense)                                       // dense graphs: the wave strides a node's edge lists
     hipLaunchKernelGGL(k_edge_mask_bwd_nodes<64>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
                        prob_bias, ew, e, d_xm, d_ewm, d_e, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
   else
@@ -142,7 +142,14 @@ extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, in
                        prob_bias, ew, e, d_xm, d_ewm, d_e, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
   hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)(rois * h0)), dim3(256), 0, st, n_nodes / rois, rois, h0,
                      gx, dprob);
-  hipLaunchKernelGGL(k_edge_mask_bwd_pb, dim3(1), dim3(64), 0, st, nblk, h0, part, dprob_bias);
+  if (nblk > 256) {                                // many partial rows: parallel column sums first
+    float* tot = part + nblk * 2 * MAX_H0;
+    int rc = igcn_launch_reduce_rows(part, nblk, 2 * MAX_H0, 2 * MAX_H0, tot, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_edge_mask_bwd_pb, dim3(1), dim3(64), 0, st, (int64_t)1, h0, tot, dprob_bias);
+  } else {
+    hipLaunchKernelGGL(k_edge_mask_bwd_pb, dim3(1), dim3(64), 0, st, nblk, h0, part, dprob_bias);
+  }
   IGCN_CHECK_LAUNCH("edge_mask_bwd");
   return IGCN_OK;
 }

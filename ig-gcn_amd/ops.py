@@ -153,7 +153,7 @@ class EdgeMask(torch.autograd.Function):
         d_ewm = _f32(d_ewm) if d_ewm is not None else None
         d_e = _f32(d_e) if d_e is not None else None
         dx, dprob, dpb = torch.empty_like(x), torch.empty_like(prob), torch.empty_like(pb)
-        scratch = torch.empty(n * h0 + 16 * ((n + 255) // 256), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(n * h0 + 16 * ((n + 3) // 4) + 16, dtype=torch.float32, device=x.device)
         call("igcn_edge_mask_bwd", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew), ptr(e),
              ptr(d_xm), ptr(d_ewm), ptr(d_e), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr),
              ptr(plan.src_perm), ptr(dx), ptr(dprob), ptr(dpb), ptr(scratch), stream_ptr())

@@ -79,7 +79,7 @@ int igcn_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0,
                        const int32_t* src32, const int32_t* dst32,
                        float* xm, float* e, float* ewm, void* stream);
 /* d_xm [N,h0] may be NULL (=0); d_ewm, d_e [E] may be NULL.  Outputs: dx [N,h0], dprob [rois,h0],
- * dprob_bias [2*h0].  scratch: float[ N*h0 + 16*ceil(N/256) ]. */
+ * dprob_bias [2*h0].  scratch: float[ N*h0 + 16*ceil(N/4) + 16 ]. */
 int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, int h0,
                        const float* x, const float* prob, const float* prob_bias, const float* ew,
                        const float* e, const float* d_xm, const float* d_ewm, const float* d_e,
