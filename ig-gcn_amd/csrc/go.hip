@@ -475,13 +475,23 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
       const float bq = (m < FIN) ? xb2[4 * c] : 0.f;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
     }
-    // partial layout [ROWS * FIN][parts]: the second-stage sum of an entry reads contiguous memory
-    const int64_t parts = (int64_t)gridDim.x * gridDim.y * (GO_T / 64);
-    float* gp = gpart + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (GO_T / 64) + w;
-    if (m < FIN) {
+    // the four waves' accumulators are summed through LDS (us is free again after the barrier): one partial per
+    // block, layout [ROWS * FIN][blocks] so that the second-stage sum of an entry reads contiguous memory
+    __syncthreads();
+    float* wsum = &us[0][0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wsum[(w * 4 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (w == 0 && m < FIN) {
+      const int64_t parts = (int64_t)gridDim.x * gridDim.y;
+      float* gp = gpart + (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (4 * g + r < ROWS) gp[(int64_t)((4 * g + r) * FIN + m) * parts] = acc[r];
+        if (4 * g + r < ROWS) {
+          const float t = (wsum[r * 64 + lane] + wsum[(4 + r) * 64 + lane]) +
+                          (wsum[(8 + r) * 64 + lane] + wsum[(12 + r) * 64 + lane]);
+          gp[(int64_t)((4 * g + r) * FIN + m) * parts] = t;
+        }
     }
   }
 }
@@ -522,7 +532,7 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
   float* stats = scratch;
   float* gpart = stats + 4 * (int64_t)B * N;                       // [blocks * 4 waves][rows * fin] block partials
   dim3 grid((unsigned)igcn_cdiv(N, GO_T), B);
-  const int64_t parts = (int64_t)grid.x * grid.y * (GO_T / 64);
+  const int64_t parts = (int64_t)grid.x * grid.y;
   float* G = gpart + parts * rows * fin;
 #define CALL(FI, FO)                                                                                             \
   hipLaunchKernelGGL((k_go_attn_bwd_stats<FI, FO>), grid, dim3(GO_T), 0, st, B, N, row_ptr, col, x, w_inc, a_in,  \

@@ -165,6 +165,7 @@ k_rbf_laplacian(int B, int T, float gamma, const float* __restrict__ t, float* _
     float w = 1.f;
     if (t) {
       float d2 = 0.f;
+#pragma unroll 10
       for (int k = 0; k < T; ++k) {
         const float d = t[(int64_t)i * T + k] - t[(int64_t)j * T + k];
         d2 += d * d;
@@ -214,10 +215,12 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, con
     mi -= logp[(int64_t)(B + b) * C + c];
   }
   const int nreg = B * NR, nrec = B * S;
+#pragma unroll 4
   for (int i = tid; i < 2 * nreg; i += 1024) {
     const float d = reg[i] - clin[i < nreg ? i : i - nreg];
     mse += d * d;
   }
+#pragma unroll 8
   for (int i = tid; i < 2 * nrec; i += 1024) {
     const float d = x_hat[i] - snps[i < nrec ? i : i - nrec];
     rec += d * d;

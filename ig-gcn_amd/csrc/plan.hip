@@ -24,7 +24,8 @@ __global__ void k_reduce_rows(const float* __restrict__ partial, int64_t rows, i
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   float t = 0.f;
-  for (int64_t r = 0; r < rows; ++r) t += partial[r * ld + j];
+#pragma unroll 8
+  for (int64_t r = 0; r < rows; ++r) t += partial[r * ld + j];     // independent loads: several in flight
   out[j] = accumulate ? out[j] + t : t;
 }
 
@@ -35,25 +36,27 @@ k_reduce_rows_par(const float* __restrict__ partial, int64_t rows, int64_t ld, f
   __shared__ float red[16];
   const int j = blockIdx.x;
   float t = 0.f;
+#pragma unroll 4
   for (int64_t r = threadIdx.x; r < rows; r += 256) t += partial[r * ld + j];
   t = block_sum_all(t, red);
   if (threadIdx.x == 0) out[j] = accumulate ? out[j] + t : t;
 }
 
 // out[j] = sum_r partial[j * rows + r]: the summands of one output are CONTIGUOUS (coalesced), one block per output
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_reduce_contig(const float* __restrict__ partial, int64_t rows, float* __restrict__ out) {
   __shared__ float red[16];
   const float* p = partial + (int64_t)blockIdx.x * rows;
   float t = 0.f;
-  for (int64_t r = threadIdx.x; r < rows; r += 256) t += p[r];
+#pragma unroll 8
+  for (int64_t r = threadIdx.x; r < rows; r += 1024) t += p[r];
   t = block_sum_all(t, red);
   if (threadIdx.x == 0) out[blockIdx.x] = t;
 }
 
 int igcn_launch_reduce_contig(const float* partial, int64_t rows, int n, float* out, hipStream_t st) {
   if (n <= 0) return IGCN_OK;
-  hipLaunchKernelGGL(k_reduce_contig, dim3((unsigned)n), dim3(256), 0, st, partial, rows, out);
+  hipLaunchKernelGGL(k_reduce_contig, dim3((unsigned)n), dim3(1024), 0, st, partial, rows, out);
   IGCN_CHECK_LAUNCH("reduce_contig");
   return IGCN_OK;
 }

@@ -112,7 +112,8 @@ __global__ void k_nlbn_finalize(int B, int N, int groups, int cpg, int training,
       for (int d = 0; d < D; ++d) piv += pre[d];
       piv *= (1.f / D);
       float a1 = 0.f, a2 = 0.f;
-      for (int k = 0; k < cpg; ++k) {
+#pragma unroll 8
+      for (int k = 0; k < cpg; ++k) {                 // independent loads: keep several in flight
         a1 += partial[(int64_t)(g * cpg + k) * 2 * N + n];
         a2 += partial[(int64_t)(g * cpg + k) * 2 * N + N + n];
       }

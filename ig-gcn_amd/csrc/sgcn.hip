@@ -119,6 +119,7 @@ __global__ void k_edge_mask_bwd_pb(int64_t nblk, int h0, const float* __restrict
   if (j >= 2 * h0) return;
   const int col = j < h0 ? j : MAX_H0 + (j - h0);
   float t = 0.f;
+#pragma unroll 8
   for (int64_t r = 0; r < nblk; ++r) t += partial[r * 2 * MAX_H0 + col];
   dpb[j] = t;
 }
