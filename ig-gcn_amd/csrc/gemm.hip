@@ -175,7 +175,8 @@ __global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const fl
   if (i >= M * N) return;
   const int64_t m = i / N, n = i - m * N;
   float t = 0.f;
-  for (int z = 0; z < split_k; ++z) t += slabs[(int64_t)z * M * N + i];
+#pragma unroll 8
+  for (int z = 0; z < split_k; ++z) t += slabs[(int64_t)z * M * N + i];      // independent loads in flight
   if (bias) t += bias[n];
   if (act == 1) t = fmaxf(t, 0.f);
   C[m * ldc + n] = t;

@@ -240,15 +240,26 @@ k_go_attn_fwd(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restr
 #pragma unroll
   for (int c = 0; c < FOUT; ++c) agg[c] = 0.f;
   const int32_t p0 = row_ptr[n], p1 = row_ptr[n + 1];
-  for (int32_t e = p0; e < p1; ++e) {
-    const int m = col[e];
-    float xm[FIN], xim[FOUT];
-    load_node<FIN>(xb, N, m, xm);
-    transform<FIN, FOUT>(W.wi, xm, xim);
-    const float s = go_exp(go_tanh(p + dot<FOUT>(W.a2, xim)));
-    Z += s;
+  // two edges per step: both neighbour indices, then both neighbour rows, are in flight together (a GO term has
+  // 1-2 parents: most walks are one dependent index->row chain instead of two); summation order is unchanged
+  for (int32_t e = p0; e < p1; e += 2) {
+    const bool two = e + 1 < p1;
+    const int m0 = col[e], m1 = col[two ? e + 1 : e];
+    float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
+    load_node<FIN>(xb, N, m0, xm0);
+    load_node<FIN>(xb, N, m1, xm1);
+    transform<FIN, FOUT>(W.wi, xm0, xi0);
+    transform<FIN, FOUT>(W.wi, xm1, xi1);
+    const float s0 = go_exp(go_tanh(p + dot<FOUT>(W.a2, xi0)));
+    const float s1 = two ? go_exp(go_tanh(p + dot<FOUT>(W.a2, xi1))) : 0.f;
+    Z += s0;
 #pragma unroll
-    for (int c = 0; c < FOUT; ++c) agg[c] += s * xim[c];
+    for (int c = 0; c < FOUT; ++c) agg[c] += s0 * xi0[c];
+    if (two) {
+      Z += s1;
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) agg[c] += s1 * xi1[c];
+    }
   }
   const float zinv = p1 > p0 ? 1.f / Z : 0.f;
   const float g = 1.f / (1.f + go_exp(-dot<FOUT>(W.as, xs)));
@@ -309,15 +320,24 @@ k_go_attn_bwd_stats(int B, int N, const int32_t* __restrict__ row_ptr, const int
 #pragma unroll
   for (int c = 0; c < FOUT; ++c) agg[c] = 0.f;
   const int32_t p0 = row_ptr[n], p1 = row_ptr[n + 1];
-  for (int32_t e = p0; e < p1; ++e) {
-    const int m = col[e];
-    float xm[FIN], xim[FOUT];
-    load_node<FIN>(xb, N, m, xm);
-    transform<FIN, FOUT>(wi, xm, xim);
-    const float s = go_exp(go_tanh(p + dot<FOUT>(a2, xim)));
-    Z += s;
+  for (int32_t e = p0; e < p1; e += 2) {            // two edges per step, as in the forward kernel
+    const bool two = e + 1 < p1;
+    const int m0 = col[e], m1 = col[two ? e + 1 : e];
+    float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
+    load_node<FIN>(xb, N, m0, xm0);
+    load_node<FIN>(xb, N, m1, xm1);
+    transform<FIN, FOUT>(wi, xm0, xi0);
+    transform<FIN, FOUT>(wi, xm1, xi1);
+    const float s0 = go_exp(go_tanh(p + dot<FOUT>(a2, xi0)));
+    const float s1 = two ? go_exp(go_tanh(p + dot<FOUT>(a2, xi1))) : 0.f;
+    Z += s0;
 #pragma unroll
-    for (int c = 0; c < FOUT; ++c) agg[c] += s * xim[c];
+    for (int c = 0; c < FOUT; ++c) agg[c] += s0 * xi0[c];
+    if (two) {
+      Z += s1;
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) agg[c] += s1 * xi1[c];
+    }
   }
   const float zinv = p1 > p0 ? 1.f / Z : 0.f;
   float tr = 0.f;
@@ -367,14 +387,18 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
   const float p_n = st_n.x, q_n = st_n.y, zinv_n = st_n.z, tr_n = st_n.w;
   // n as ROW: d(score) of its own edges
   float dp = 0.f;
-  for (int32_t e = r0; e < r1; ++e) {
-    const int m = col[e];
-    float xm[FIN], xim[FOUT];
-    load_node<FIN>(xb, N, m, xm);
-    transform<FIN, FOUT>(W.wi, xm, xim);
-    const float th = go_tanh(p_n + sp[m].y);
-    const float alpha = go_exp(th) * zinv_n;
-    dp += (dot<FOUT>(dyn, xim) - tr_n) * alpha * (1.f - th * th);
+  for (int32_t e = r0; e < r1; e += 2) {            // two edges per step: indices, then rows, in flight together
+    const bool two = e + 1 < r1;
+    const int m0 = col[e], m1 = col[two ? e + 1 : e];
+    float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
+    load_node<FIN>(xb, N, m0, xm0);
+    load_node<FIN>(xb, N, m1, xm1);
+    const float q0 = sp[m0].y, q1 = sp[m1].y;
+    transform<FIN, FOUT>(W.wi, xm0, xi0);
+    transform<FIN, FOUT>(W.wi, xm1, xi1);
+    const float th0 = go_tanh(p_n + q0), th1 = go_tanh(p_n + q1);
+    dp += (dot<FOUT>(dyn, xi0) - tr_n) * (go_exp(th0) * zinv_n) * (1.f - th0 * th0);
+    if (two) dp += (dot<FOUT>(dyn, xi1) - tr_n) * (go_exp(th1) * zinv_n) * (1.f - th1 * th1);
   }
   // n as COLUMN: what the rows reading n send back
   float dq = 0.f, dxin[FOUT];
@@ -382,16 +406,23 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
   for (int c = 0; c < FOUT; ++c) dxin[c] = 0.f;
   const bool heavy = live && (c1 - c0 > GO_HEAVY);
   if (!heavy) {
-    for (int32_t e = c0; e < c1; ++e) {
-      const int r = t_row[e];
-      float dyr[FOUT];
-      load_node<FOUT>(dyb, N, r, dyr);
-      const float4 sr = sp[r];
-      const float th = go_tanh(sr.x + q_n);
-      const float alpha = go_exp(th) * sr.z;
-      dq += (dot<FOUT>(dyr, xin) - sr.w) * alpha * (1.f - th * th);
+    for (int32_t e = c0; e < c1; e += 2) {
+      const bool two = e + 1 < c1;
+      const int ra = t_row[e], rb = t_row[two ? e + 1 : e];
+      float dya[FOUT], dyb2[FOUT];
+      load_node<FOUT>(dyb, N, ra, dya);
+      load_node<FOUT>(dyb, N, rb, dyb2);
+      const float4 sa = sp[ra], sb = sp[rb];
+      const float tha = go_tanh(sa.x + q_n), thb = go_tanh(sb.x + q_n);
+      const float ala = go_exp(tha) * sa.z, alb = two ? go_exp(thb) * sb.z : 0.f;
+      dq += (dot<FOUT>(dya, xin) - sa.w) * ala * (1.f - tha * tha);
 #pragma unroll
-      for (int c = 0; c < FOUT; ++c) dxin[c] += alpha * dyr[c];
+      for (int c = 0; c < FOUT; ++c) dxin[c] += ala * dya[c];
+      if (two) {
+        dq += (dot<FOUT>(dyb2, xin) - sb.w) * alb * (1.f - thb * thb);
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) dxin[c] += alb * dyb2[c];
+      }
     }
   }
   unsigned long long hmask = __ballot(heavy);
@@ -767,14 +798,15 @@ k_nodes_ln_bwd_affine(int rows, int f, int N, int pool, const float* __restrict_
   if (n < N && n >= pool) {
     const float ga = gamma[n], be = beta[n];
     const int M = N - pool;
-    for (int row = r0 + rg; row < r1; row += 4) {
-      const float xh = (y[(int64_t)row * N + n] - mean[row]) * rstd[row];
-      if (xh * ga + be > 0.f) {
-        float up = dz[(int64_t)row * M + (n - pool)];
-        if (keep) up *= keep[(int64_t)(row / f) * N + n];
-        dg += up * xh;
-        db += up;
-      }
+#pragma unroll 4
+    for (int row = r0 + rg; row < r1; row += 4) {      // unconditional, independent loads: several rows in flight
+      const float yv = y[(int64_t)row * N + n];
+      float up = dz[(int64_t)row * M + (n - pool)];
+      if (keep) up *= keep[(int64_t)(row / f) * N + n];
+      const float xh = (yv - mean[row]) * rstd[row];
+      up = (xh * ga + be > 0.f) ? up : 0.f;
+      dg += up * xh;
+      db += up;
     }
   }
   sg[rg][nl] = dg;
