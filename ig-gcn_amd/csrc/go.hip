@@ -871,11 +871,23 @@ k_go_decode_fwd(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const in
   for (int d = 0; d < FIN; ++d) acc[d] = 0.f;
   const int32_t p0 = row_ptr[rr], p1 = row_ptr[rr + 1];
   const bool heavy = live && (p1 - p0 > GO_HEAVY);   // hub rows (a parent with many children): whole wave
-  if (!heavy) {
-    for (int32_t e = p0; e < p1; ++e) {
-      const int m = col[e];
+  // the self term does not depend on the walk: its loads go out first
+  float xs[FIN];
 #pragma unroll
-      for (int d = 0; d < FIN; ++d) acc[d] += xb[(int64_t)d * Nin + m];
+  for (int d = 0; d < FIN; ++d) xs[d] = 0.f;
+  if (live && r >= off) load_node<FIN>(xb, Nin, r - off, xs);
+  if (!heavy) {
+    for (int32_t e = p0; e < p1; e += 2) {           // two edges per step: indices, then rows, in flight together
+      const bool two = e + 1 < p1;
+      const int m0 = col[e], m1 = col[two ? e + 1 : e];
+      float x0[FIN], x1[FIN];
+      load_node<FIN>(xb, Nin, m0, x0);
+      load_node<FIN>(xb, Nin, m1, x1);
+#pragma unroll
+      for (int d = 0; d < FIN; ++d) {
+        acc[d] += x0[d];
+        if (two) acc[d] += x1[d];
+      }
     }
   }
   unsigned long long hmask = __ballot(heavy);
@@ -905,8 +917,7 @@ k_go_decode_fwd(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const in
 #pragma unroll
   for (int c = 0; c < FOUT; ++c) out[c] *= inv;
   if (r >= off) {
-    float xs[FIN], o2[FOUT];
-    load_node<FIN>(xb, Nin, r - off, xs);
+    float o2[FOUT];
     transform<FIN, FOUT>(wso, xs, o2);
 #pragma unroll
     for (int c = 0; c < FOUT; ++c) out[c] += o2[c];
@@ -959,15 +970,22 @@ k_go_decode_bwd(int B, int Nin, int Nout, const int32_t* __restrict__ row_ptr, c
       float G[FOUT], Gs[FOUT], xr[FIN];
 #pragma unroll
       for (int c = 0; c < FOUT; ++c) G[c] = 0.f;
-#pragma unroll 4
-      for (int32_t e = c0; e < c1; ++e) {
-        const int r = t_row[e];
-        const float inv = 1.f / (float)(row_ptr[r + 1] - row_ptr[r]);
-#pragma unroll
-        for (int c = 0; c < FOUT; ++c) G[c] += dyb[(int64_t)c * Nout + r] * inv;
-      }
-      load_node<FOUT>(dyb, Nout, m + off, Gs);
+      load_node<FOUT>(dyb, Nout, m + off, Gs);          // independent of the walk: issued first
       load_node<FIN>(x + (int64_t)b * FIN * Nin, Nin, m, xr);
+      for (int32_t e = c0; e < c1; e += 2) {              // two edges per step
+        const bool two = e + 1 < c1;
+        const int ra = t_row[e], rb = t_row[two ? e + 1 : e];
+        const int32_t da = row_ptr[ra + 1] - row_ptr[ra], db = row_ptr[rb + 1] - row_ptr[rb];
+        float ya[FOUT], yb2[FOUT];
+        load_node<FOUT>(dyb, Nout, ra, ya);
+        load_node<FOUT>(dyb, Nout, rb, yb2);
+        const float ia = 1.f / (float)da, ib = 1.f / (float)db;
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) {
+          G[c] += ya[c] * ia;
+          if (two) G[c] += yb2[c] * ib;
+        }
+      }
       float* dxb = dx + (int64_t)b * FIN * Nin;
 #pragma unroll
       for (int d = 0; d < FIN; ++d) {
