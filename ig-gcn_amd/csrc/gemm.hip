@@ -15,40 +15,37 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define G_LD (G_BK + 2)   // row stride 34: MFMA operand reads [m][4ks + (lane>>4)] hit 32 distinct banks per half-wave
 
 // One operand tile (ROWS x G_BK) global -> registers -> LDS.  `rfast` = the row (m or n) axis is the contiguous
-// one in memory, else the k axis is.  VEC: 16-byte loads along the contiguous axis (host guarantees alignment and
-// that no float4 straddles the matrix edge); otherwise scalar loads with per-element bounds checks.
-template <int ROWS, bool VEC>
+// one in memory, else the k axis is.  VW = floats per load along the contiguous axis: 4 (16-byte loads), 2 (8-byte
+// loads: row strides such as 54 or 3182 floats) — the host guarantees alignment and that no vector straddles the
+// matrix edge — or 1 (scalar loads with per-element bounds checks).
+template <int ROWS, int VW>
 struct TileLoader {
-  static constexpr int NV = (ROWS * G_BK / 4 + 255) / 256;   // float4 per thread
-  static constexpr int NS = (ROWS * G_BK + 255) / 256;       // scalars per thread
-  float4 v[VEC ? NV : 1];
-  float s[VEC ? 1 : NS];
+  static constexpr int NU = (ROWS * G_BK / VW + 255) / 256;   // vectors per thread
+  float v[NU][VW];
 
   __device__ __forceinline__ void load(const float* __restrict__ P, int64_t srow, int64_t sk, bool rfast, int64_t r0,
                                        int64_t rows, int64_t kb, int64_t k_end) {
     const int tid = threadIdx.x;
-    if constexpr (VEC) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int f = tid + i * 256;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < ROWS * G_BK / 4) {
-          const int r = rfast ? (f % (ROWS / 4)) * 4 : f / (G_BK / 4);
-          const int k = rfast ? f / (ROWS / 4) : (f % (G_BK / 4)) * 4;
-          const int64_t gr = r0 + r, gk = kb + k;
-          if (gr < rows && gk < k_end) v[i] = *reinterpret_cast<const float4*>(P + gr * srow + gk * sk);
-        }
-      }
-    } else {
+    for (int i = 0; i < NU; ++i) {
+      const int f = tid + i * 256;
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        const int idx = tid + i * 256;
-        s[i] = 0.f;
-        if (idx < ROWS * G_BK) {
-          const int r = rfast ? idx % ROWS : idx / G_BK;
-          const int k = rfast ? idx / ROWS : idx % G_BK;
-          const int64_t gr = r0 + r, gk = kb + k;
-          if (gr < rows && gk < k_end) s[i] = P[gr * srow + gk * sk];
+      for (int j = 0; j < VW; ++j) v[i][j] = 0.f;
+      if (f < ROWS * G_BK / VW) {
+        const int r = rfast ? (f % (ROWS / VW)) * VW : f / (G_BK / VW);
+        const int k = rfast ? f / (ROWS / VW) : (f % (G_BK / VW)) * VW;
+        const int64_t gr = r0 + r, gk = kb + k;
+        if (gr < rows && gk < k_end) {
+          const float* src = P + gr * srow + gk * sk;
+          if constexpr (VW == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(src);
+            v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+          } else if constexpr (VW == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(src);
+            v[i][0] = t.x; v[i][1] = t.y;
+          } else {
+            v[i][0] = *src;
+          }
         }
       }
     }
@@ -56,35 +53,25 @@ struct TileLoader {
 
   __device__ __forceinline__ void store(float (*T)[G_LD], bool rfast) const {
     const int tid = threadIdx.x;
-    if constexpr (VEC) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int f = tid + i * 256;
-        if (f < ROWS * G_BK / 4) {
-          if (rfast) {
-            const int r = (f % (ROWS / 4)) * 4, k = f / (ROWS / 4);
-            T[r][k] = v[i].x; T[r + 1][k] = v[i].y; T[r + 2][k] = v[i].z; T[r + 3][k] = v[i].w;
-          } else {
-            const int r = f / (G_BK / 4), k = (f % (G_BK / 4)) * 4;
-            T[r][k] = v[i].x; T[r][k + 1] = v[i].y; T[r][k + 2] = v[i].z; T[r][k + 3] = v[i].w;
-          }
-        }
-      }
-    } else {
+    for (int i = 0; i < NU; ++i) {
+      const int f = tid + i * 256;
+      if (f < ROWS * G_BK / VW) {
+        if (rfast) {
+          const int r = (f % (ROWS / VW)) * VW, k = f / (ROWS / VW);
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        const int idx = tid + i * 256;
-        if (idx < ROWS * G_BK) {
-          const int r = rfast ? idx % ROWS : idx / G_BK;
-          const int k = rfast ? idx / ROWS : idx % G_BK;
-          T[r][k] = s[i];
+          for (int j = 0; j < VW; ++j) T[r + j][k] = v[i][j];
+        } else {
+          const int r = f / (G_BK / VW), k = (f % (G_BK / VW)) * VW;
+#pragma unroll
+          for (int j = 0; j < VW; ++j) T[r][k + j] = v[i][j];
         }
       }
     }
   }
 };
 
-template <int BN, bool VEC>
+template <int BN, int VW>
 __global__ void __launch_bounds__(256)
 k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,
            const float* __restrict__ B, int64_t sbn, int64_t sbk, const float* __restrict__ bias,
@@ -109,8 +96,8 @@ k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // software pipeline: the global loads of K-tile i+1 are in flight while the matrix cores work on tile i
-  TileLoader<G_BM, VEC> la;
-  TileLoader<BN, VEC> lb;
+  TileLoader<G_BM, VW> la;
+  TileLoader<BN, VW> lb;
   if (k_begin < k_end) {
     la.load(A, sam, sak, a_rfast, m0, M, k_begin, k_end);
     lb.load(B, sbn, sbk, b_rfast, n0, N, k_begin, k_end);
@@ -161,13 +148,17 @@ k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t
   }
 }
 
-// can operand (ptr, row stride, k stride, rows, K) be read with aligned float4 along its contiguous axis?
-static bool vec_ok(const float* p, int64_t srow, int64_t sk, int64_t rows, int64_t K) {
-  if (((uintptr_t)p & 15) != 0) return false;
-  if (sk == 1) return (srow % 4 == 0) && (K % 4 == 0);                 // k contiguous
-  if (srow == 1) return (sk % 4 == 0) && (rows % 4 == 0);              // row contiguous
-  return false;
+// widest aligned vector (4, 2 or 1 floats) operand (ptr, row stride, k stride, rows, K) can be read with along its
+// contiguous axis
+static int vec_width(const float* p, int64_t srow, int64_t sk, int64_t rows, int64_t K) {
+  for (int w = 4; w >= 2; w >>= 1) {
+    if (((uintptr_t)p & (uintptr_t)(4 * w - 1)) != 0) continue;
+    if (sk == 1 && srow % w == 0 && K % w == 0) return w;               // k contiguous
+    if (srow == 1 && sk % w == 0 && rows % w == 0) return w;            // row contiguous
+  }
+  return 1;
 }
+static int min_int(int a, int b) { return a < b ? a : b; }
 
 __global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const float* __restrict__ slabs,
                                      const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int act) {
@@ -199,14 +190,16 @@ extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, in
   const int64_t slab = split ? M * N : 0;
   const int bn = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
   dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)split_k);
-  const bool vec = vec_ok(A, sam, sak, M, K) && vec_ok(B, sbn, sbk, N, K);
+  const int vw = min_int(vec_width(A, sam, sak, M, K), vec_width(B, sbn, sbk, N, K));
 #define LAUNCH_G(BNV, VECV)                                                                                    \
   hipLaunchKernelGGL((k_gemm_f32<BNV, VECV>), grid, dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk, bias, \
                      out, ld, act, kps, slab, (int64_t)0, (int64_t)0, split_k)
-  if (vec) {
-    if (bn == 16) { LAUNCH_G(16, true); } else if (bn == 32) { LAUNCH_G(32, true); } else { LAUNCH_G(64, true); }
+  if (vw == 4) {
+    if (bn == 16) { LAUNCH_G(16, 4); } else if (bn == 32) { LAUNCH_G(32, 4); } else { LAUNCH_G(64, 4); }
+  } else if (vw == 2) {
+    if (bn == 16) { LAUNCH_G(16, 2); } else if (bn == 32) { LAUNCH_G(32, 2); } else { LAUNCH_G(64, 2); }
   } else {
-    if (bn == 16) { LAUNCH_G(16, false); } else if (bn == 32) { LAUNCH_G(32, false); } else { LAUNCH_G(64, false); }
+    if (bn == 16) { LAUNCH_G(16, 1); } else if (bn == 32) { LAUNCH_G(32, 1); } else { LAUNCH_G(64, 1); }
   }
 #undef LAUNCH_G
   IGCN_CHECK_LAUNCH("gemm_f32");
@@ -247,14 +240,17 @@ int igcn_gemm_f32_batched_sum_impl(int64_t M, int64_t N, int64_t K, int batch, c
   ksplit = (int)igcn_cdiv(K, kps);
   const int slabs = batch * ksplit;
   dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)slabs);
-  const bool vec = vec_ok(A, sam, sak, M, K) && vec_ok(B, sbn, sbk, N, K) && a_batch % 4 == 0 && b_batch % 4 == 0;
+  int vw = min_int(vec_width(A, sam, sak, M, K), vec_width(B, sbn, sbk, N, K));
+  while (vw > 1 && (a_batch % vw != 0 || b_batch % vw != 0)) vw >>= 1;
 #define LAUNCH_B(BNV, VECV)                                                                                     \
   hipLaunchKernelGGL((k_gemm_f32<BNV, VECV>), grid, dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk,         \
                      (const float*)nullptr, scratch, N, 0, kps, M * N, a_batch, b_batch, ksplit)
-  if (vec) {
-    if (bn == 16) { LAUNCH_B(16, true); } else if (bn == 32) { LAUNCH_B(32, true); } else { LAUNCH_B(64, true); }
+  if (vw == 4) {
+    if (bn == 16) { LAUNCH_B(16, 4); } else if (bn == 32) { LAUNCH_B(32, 4); } else { LAUNCH_B(64, 4); }
+  } else if (vw == 2) {
+    if (bn == 16) { LAUNCH_B(16, 2); } else if (bn == 32) { LAUNCH_B(32, 2); } else { LAUNCH_B(64, 2); }
   } else {
-    if (bn == 16) { LAUNCH_B(16, false); } else if (bn == 32) { LAUNCH_B(32, false); } else { LAUNCH_B(64, false); }
+    if (bn == 16) { LAUNCH_B(16, 1); } else if (bn == 32) { LAUNCH_B(32, 1); } else { LAUNCH_B(64, 1); }
   }
 #undef LAUNCH_B
   IGCN_CHECK_LAUNCH("gemm_f32_batched_sum");
