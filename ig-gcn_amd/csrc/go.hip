@@ -209,7 +209,7 @@ __device__ __forceinline__ void transform(const float (&w)[FOUT][FIN], const flo
 template <int FIN>
 __device__ __forceinline__ void load_node(const float* __restrict__ xb, int N, int n, float (&v)[FIN]) {
 #pragma unroll
-  for (int d = 0; d < FIN; ++d) v[d] = xb[(int64_t)d * N + n];
+  for (int d = 0; d < FIN; ++d) v[d] = xb[d * N + n];       // 32-bit offset from the sample's base pointer
 }
 
 template <int F>
@@ -265,7 +265,7 @@ k_go_attn_fwd(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restr
   const float g = 1.f / (1.f + go_exp(-dot<FOUT>(W.as, xs)));
   float* yb = y + (int64_t)b * FOUT * N;
 #pragma unroll
-  for (int c = 0; c < FOUT; ++c) yb[(int64_t)c * N + n] = agg[c] * zinv + xs[c] * g;
+  for (int c = 0; c < FOUT; ++c) yb[c * N + n] = agg[c] * zinv + xs[c] * g;
 }
 
 #define GO_DISPATCH(fin, fout, CALL)                         \
@@ -473,7 +473,7 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
       float t = 0.f;
 #pragma unroll
       for (int c = 0; c < FOUT; ++c) t += W.wi[c][d] * dxin[c] + W.ws[c][d] * dxs[c];
-      dxb[(int64_t)d * N + n] = t;
+      dxb[d * N + n] = t;
     }
     // rows of the parameter-gradient product: u = (dxin[FOUT], dxs[FOUT], dp, dq, dgate)
 #pragma unroll
@@ -901,7 +901,7 @@ k_go_decode_fwd(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const in
     for (int32_t e = h0 + lane; e < h1; e += 64) {
       const int m = col[e];
 #pragma unroll
-      for (int d = 0; d < FIN; ++d) part[d] += xb[(int64_t)d * Nin + m];
+      for (int d = 0; d < FIN; ++d) part[d] += xb[d * Nin + m];
     }
 #pragma unroll
     for (int d = 0; d < FIN; ++d) part[d] = wave_sum_all(part[d]);
@@ -924,7 +924,7 @@ k_go_decode_fwd(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const in
   }
   float* yb = y + (int64_t)b * FOUT * Nout;
 #pragma unroll
-  for (int c = 0; c < FOUT; ++c) yb[(int64_t)c * Nout + r] = out[c];
+  for (int c = 0; c < FOUT; ++c) yb[c * Nout + r] = out[c];
 }
 
 extern "C" int igcn_go_decode_fwd(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr,
@@ -992,7 +992,7 @@ k_go_decode_bwd(int B, int Nin, int Nout, const int32_t* __restrict__ row_ptr, c
         float t = 0.f;
 #pragma unroll
         for (int c = 0; c < FOUT; ++c) t += wo[c][d] * G[c] + wso[c][d] * Gs[c];
-        dxb[(int64_t)d * Nin + m] = t;
+        dxb[d * Nin + m] = t;
       }
 #pragma unroll
       for (int c = 0; c < FOUT; ++c)
