@@ -118,7 +118,9 @@ k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const float b = Bs[buf][t * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+        // operands swapped: the accumulator holds the TRANSPOSED tile, i.e. lane (g = lane>>4, j = lane&15) owns
+        // C[m0 + 16 w + j][n0 + 16 t + 4 g + r], r = 0..3 — four consecutive columns of one row = one 16-byte store
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[t], 0, 0, 0);
       }
     }
     if (more) {
@@ -128,21 +130,29 @@ k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t
     __syncthreads();
     buf ^= 1;
   }
-  // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + r
+  // epilogue: 16 bytes per lane when the output rows allow it
   float* Cz = C + (int64_t)blockIdx.z * slab_stride;
   const bool final_out = (gridDim.z == 1);
+  const int64_t gm = m0 + w * 16 + (lane & 15);
+  const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)Cz & 15) == 0);
+  if (gm < M) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int64_t gn = n0 + t * 16 + (lane & 15);
-    if (gn >= N) continue;
-    const float bv = (final_out && bias) ? bias[gn] : 0.f;
+    for (int t = 0; t < NT; ++t) {
+      const int64_t gn = n0 + t * 16 + (lane >> 4) * 4;
+      if (gn >= N) continue;
+      float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t gm = m0 + w * 16 + (lane >> 4) * 4 + r;
-      if (gm < M) {
-        float v = acc[t][r] + bv;
-        if (final_out && act == 1) v = fmaxf(v, 0.f);
-        Cz[gm * ldc + gn] = v;
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[t][r] + ((final_out && bias && gn + r < N) ? bias[gn + r] : 0.f);
+        if (final_out && act == 1) v[r] = fmaxf(v[r], 0.f);
+      }
+      float* dst = Cz + gm * ldc + gn;
+      if (c_vec && gn + 3 < N) {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (gn + r < N) dst[r] = v[r];
       }
     }
   }
