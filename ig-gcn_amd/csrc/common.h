@@ -43,6 +43,14 @@ __device__ __forceinline__ float wave_sum_all(float v) {
   return v;
 }
 
+// Sum over groups of G consecutive lanes (G = 1, 2, 4, ..., 64), result in every lane of the group; fixed tree.
+template <int G>
+__device__ __forceinline__ float group_sum_all(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 // Block-wide sum for blockDim.x <= 1024; `red` must hold >= 16 floats of LDS. Result valid in all threads.
 __device__ __forceinline__ float block_sum_all(float v, float* red) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

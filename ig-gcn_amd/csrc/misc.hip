@@ -49,6 +49,7 @@ k_adam_multi(const int64_t* __restrict__ table, const int64_t* __restrict__ nume
   const int64_t n = numel[t];
   const float ts = (float)(*step);
   const float bc1 = 1.f - powf(b1, ts), bc2s = sqrtf(1.f - powf(b2, ts));
+#pragma unroll 4
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i] * gscale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;

@@ -83,10 +83,8 @@ k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict
       const float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
       T += up * ek * (1.f - ek);
     }
-    if (LPN > 1) {
-      S = wave_sum_all(S);
-      T = wave_sum_all(T);
-    }
+    S = group_sum_all<LPN>(S);
+    T = group_sum_all<LPN>(T);
     if (sub == 0) {
       const int64_t r = (i % rois) * h0;
       for (int h = 0; h < h0; ++h) {
@@ -132,14 +130,14 @@ extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, in
   IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0, "edge_mask_bwd: bad rois/h0");
   hipStream_t st = (hipStream_t)stream;
   const bool dense = n_edges >= 16 * n_nodes;
-  const int64_t nblk = igcn_cdiv(n_nodes, dense ? 4 : 256);
+  const int64_t nblk = igcn_cdiv(n_nodes, dense ? 4 : 64);        // 64 or 4 lanes per node
   float* gx = scratch;
   float* part = scratch + n_nodes * h0;  // [nblk, 2*MAX_H0]
   if (dense)                                       // dense graphs: the wave strides a node's edge lists
     hipLaunchKernelGGL(k_edge_mask_bwd_nodes<64>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
                        prob_bias, ew, e, d_xm, d_ewm, d_e, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
-  else
-    hipLaunchKernelGGL(k_edge_mask_bwd_nodes<1>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
+  else                                             // k = 3 graphs: four lanes share a node's six list entries
+    hipLaunchKernelGGL(k_edge_mask_bwd_nodes<4>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
                        prob_bias, ew, e, d_xm, d_ewm, d_e, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
   hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)(rois * h0)), dim3(256), 0, st, n_nodes / rois, rois, h0,
                      gx, dprob);
@@ -172,7 +170,7 @@ k_gcn_norm_fwd(int64_t n_nodes, const float* __restrict__ ew, const int32_t* __r
     const int32_t k = tgt_perm[p];
     if (src32[k] != (int32_t)i) deg += ew[k];
   }
-  if (LPN > 1) deg = wave_sum_all(deg);
+  deg = group_sum_all<LPN>(deg);
   if (sub != 0) return;
   const int32_t le = loop_edge[i];
   const float lw = le >= 0 ? ew[le] : 1.f;
@@ -225,7 +223,7 @@ extern "C" int igcn_gcn_norm_fwd(int64_t n_nodes, int64_t n_edges, const float* 
     hipLaunchKernelGGL(k_gcn_norm_fwd<64>, dim3((unsigned)igcn_cdiv(n_nodes * 64, 256)), dim3(256), 0, st, n_nodes, ew,
                        src32, tgt_ptr, tgt_perm, loop_edge, dis, wl);
   else
-    hipLaunchKernelGGL(k_gcn_norm_fwd<1>, dim3((unsigned)igcn_cdiv(n_nodes, 256)), dim3(256), 0, st, n_nodes, ew,
+    hipLaunchKernelGGL(k_gcn_norm_fwd<4>, dim3((unsigned)igcn_cdiv(n_nodes * 4, 256)), dim3(256), 0, st, n_nodes, ew,
                        src32, tgt_ptr, tgt_perm, loop_edge, dis, wl);
   const int64_t n = n_nodes > n_edges ? n_nodes : n_edges;
   hipLaunchKernelGGL(k_gcn_norm_coef, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, st, n_nodes, n_edges, ew, dis,
@@ -260,7 +258,7 @@ k_gcn_norm_bwd_deg(int64_t n_nodes, const float* __restrict__ ew, const float* _
     const int32_t s = src32[k];
     if (s != (int32_t)i) dd += dwhat[k] * ew[k] * dis[s];
   }
-  if (LPN > 1) dd = wave_sum_all(dd);
+  dd = group_sum_all<LPN>(dd);
   if (sub != 0) return;
   const float di = dis[i];
   dd += 2.f * dwhat_loop[i] * wl[i] * di;
@@ -296,8 +294,8 @@ extern "C" int igcn_gcn_norm_bwd(int64_t n_nodes, int64_t n_edges, const float* 
     hipLaunchKernelGGL(k_gcn_norm_bwd_deg<64>, dim3((unsigned)igcn_cdiv(n_nodes * 64, 256)), dim3(256), 0, st, n_nodes,
                        ew, dis, wl, dwhat, dwhat_loop, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, scratch);
   else
-    hipLaunchKernelGGL(k_gcn_norm_bwd_deg<1>, dim3((unsigned)igcn_cdiv(n_nodes, 256)), dim3(256), 0, st, n_nodes, ew,
-                       dis, wl, dwhat, dwhat_loop, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, scratch);
+    hipLaunchKernelGGL(k_gcn_norm_bwd_deg<4>, dim3((unsigned)igcn_cdiv(n_nodes * 4, 256)), dim3(256), 0, st, n_nodes,
+                       ew, dis, wl, dwhat, dwhat_loop, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, scratch);
   hipLaunchKernelGGL(k_gcn_norm_bwd_edge, dim3((unsigned)igcn_cdiv(n_edges, 256)), dim3(256), 0, st, n_edges, dis,
                      dwhat, dwhat_loop, scratch, src32, dst32, loop_edge, dew);
   IGCN_CHECK_LAUNCH("gcn_norm_bwd");
