@@ -259,8 +259,23 @@ k_plan_segmented(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* 
   }
   if (bad) atomicExch(status, 2);                                  // edge leaves its graph: not a PyG batch
   __syncthreads();
-  if (tid == 0) {                                                  // nn <= 1024: a serial scan is ~1 us
-    for (int i = 0; i < nn; ++i) { ct[i + 1] += ct[i]; cs[i + 1] += cs[i]; }
+  if (tid < 64) {
+    // exclusive -> inclusive scan of both histograms by one wave: every lane owns a run of consecutive entries
+    // (a serial scan by one thread is a chain of ~2 nn dependent LDS round trips)
+    const int per = (nn + 64) / 64, lo = tid * per, hi = min(nn + 1, lo + per);
+    int st = 0, ss = 0;
+    for (int i = lo; i < hi; ++i) { st += ct[i]; ss += cs[i]; }
+    int pt = st, ps = ss;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int a = __shfl_up(pt, o, 64), b = __shfl_up(ps, o, 64);
+      if (tid >= o) { pt += a; ps += b; }
+    }
+    int rt = pt - st, rs = ps - ss;                                 // sums of the lanes before this one
+    for (int i = lo; i < hi; ++i) {
+      rt += ct[i]; rs += cs[i];
+      ct[i] = rt; cs[i] = rs;
+    }
   }
   __syncthreads();
   for (int i = tid; i < nn; i += 256) {
@@ -268,16 +283,19 @@ k_plan_segmented(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* 
     src_ptr[nb + i] = (int32_t)(eb + cs[i]);
     loop_edge[nb + i] = lp[i] >= 0 ? (int32_t)(eb + lp[i]) : -1;
   }
-  // stable placement: the two halves of the workgroup build the by-target and the by-source grouping; each thread
-  // owns nodes and walks the graph's edges in stored order
-  const int role = tid >> 7;
-  const int16_t* key = role == 0 ? ld : ls;
-  const int32_t* base = role == 0 ? ct : cs;
-  int32_t* perm = role == 0 ? tgt_perm : src_perm;
-  for (int i = tid & 127; i < nn; i += 128) {
-    int pos = base[i];
-    for (int k = 0; k < ne; ++k)
-      if (key[k] == i) perm[eb + pos++] = (int32_t)(eb + k);
+  // stable placement, one thread per edge: its slot inside its group = the number of EARLIER edges with the same
+  // key.  All lanes read the same ld[j] / ls[j] (an LDS broadcast), so the scan is a divergence-free stream of
+  // compare-and-count steps for both groupings at once.
+  for (int k = tid; k < ne; k += 256) {
+    const int16_t kd = ld[k], ks = ls[k];
+    int rd = 0, rs = 0;
+#pragma unroll 8
+    for (int j = 0; j < k; ++j) {
+      rd += (ld[j] == kd);
+      rs += (ls[j] == ks);
+    }
+    tgt_perm[eb + ct[kd] + rd] = (int32_t)(eb + k);
+    src_perm[eb + cs[ks] + rs] = (int32_t)(eb + k);
   }
   if (g == n_graphs - 1 && tid == 0) {
     tgt_ptr[n_nodes] = (int32_t)n_edges;
