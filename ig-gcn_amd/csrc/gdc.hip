@@ -45,24 +45,28 @@ k_gdc_topk(int R, int k, double alpha, const float* __restrict__ A, int64_t* __r
   __syncthreads();
 
   // ---- in-place Gauss-Jordan inversion with partial pivoting --------------------------------------
+  int cw = 8;
+  while (cw < R && cw < GDC_T) cw <<= 1;               // columns per pass (power of two >= R, R <= 128 < GDC_T)
+  const int jc = tid & (cw - 1), i0 = tid / cw;
   for (int p = 0; p < R; ++p) {
-    double best = -1.0;
-    int bi = p;
-    for (int i = p + tid; i < R; i += GDC_T) {
-      const double v = fabs(M[i * ld + p]);
-      if (v > best) { best = v; bi = i; }
-    }
-    cand[tid] = best;
-    candi[tid] = bi;
-    __syncthreads();
-    for (int s = GDC_T / 2; s > 0; s >>= 1) {
-      if (tid < s) {
-        const double o = cand[tid + s];
-        const int oi = candi[tid + s];
-        if (o > cand[tid] || (o == cand[tid] && oi < candi[tid])) { cand[tid] = o; candi[tid] = oi; }
+    // partial-pivot search by ONE wave (shuffle arg-max, lowest row wins ties): one barrier instead of a
+    // log2(256)-step LDS tree per pivot
+    if (tid < 64) {
+      double best = -1.0;
+      int bi = p;
+      for (int i = p + tid; i < R; i += 64) {
+        const double v = fabs(M[i * ld + p]);
+        if (v > best) { best = v; bi = i; }
       }
-      __syncthreads();
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (tid == 0) candi[0] = bi;
     }
+    __syncthreads();
     const int r = candi[0];
     if (tid == 0) piv[p] = r;
     if (r != p)
@@ -77,12 +81,15 @@ k_gdc_topk(int R, int k, double alpha, const float* __restrict__ A, int64_t* __r
     __syncthreads();
     for (int j = tid; j < R; j += GDC_T) M[p * ld + j] = (j == p ? 1.0 : M[p * ld + j]) * inv;
     __syncthreads();
-    for (int t = tid; t < R * R; t += GDC_T) {
-      const int i = t / R, j = t % R;
-      if (i == p) continue;
-      const double f = colf[i];
-      const double base = (j == p) ? 0.0 : M[i * ld + j];
-      M[i * ld + j] = base - f * M[p * ld + j];
+    // rank-1 update of all other rows; thread = (row slice, column) with a power-of-two column count so that the
+    // index arithmetic is shifts and masks (an integer division per element costs more than the update itself)
+    if (jc < R) {
+      const double pj = M[p * ld + jc];
+      for (int i = i0; i < R; i += GDC_T / cw) {
+        if (i == p) continue;
+        const double base = (jc == p) ? 0.0 : M[i * ld + jc];
+        M[i * ld + jc] = base - colf[i] * pj;
+      }
     }
     __syncthreads();
   }
