@@ -102,8 +102,8 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                                                 dim_snps_atten=dim_att)
         self.batch_norm = torch.nn.BatchNorm1d(num_layers * hidden)       # unused by forward
         self._dropout_enabled = True
-        # igcn_xattn_* (one fused VALU kernel per direction) is exact but currently slower than MFMA-GEMM
-        # projections + the library attention core at B=256 (profiles/): opt-in until its MFMA version lands
+        # igcn_xattn_* (one fused all-in-LDS VALU kernel per direction) is exact but slower than MFMA-GEMM
+        # projections + the matrix-core attention core (igcn_attn_core_*) at B=256 (profiles/): opt-in
         self.fused_cross_attention = os.environ.get("IGCN_FUSED_XATTN", "0") == "1"
 
     def reset_parameters(self):
@@ -171,9 +171,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
 
     def _cross_attention(self, query, memory):
         """relu(nn.MultiheadAttention(D, 2, batch_first=True)(query, memory, memory)[0]) (:240-241) with the
-        parameters of ``self.multihead_attn``: one fused kernel per direction (igcn_xattn_*: projections,
-        softmax and PV stay in LDS).  Shapes the fused kernel does not cover fall back to MFMA-GEMM projections
-        around igcn_attn_core_* (attention core on the projection outputs in place; batched GEMM + softmax otherwise)."""
+        parameters of ``self.multihead_attn``: MFMA-GEMM projections (key and value as one GEMM) around the attention
+        core igcn_attn_core_*, which works on the projection outputs in place (head_dim 16: matrix cores); shapes the
+        core does not cover use a batched GEMM + softmax composite.  ``fused_cross_attention`` selects the
+        one-kernel-per-direction variant igcn_xattn_* instead."""
         mha = self.multihead_attn
         d, h = mha.embed_dim, mha.num_heads
         b, lq, lk = query.shape[0], query.shape[1], memory.shape[1]

@@ -229,7 +229,9 @@ int igcn_gram_loss_bwd(int B, const float* G, const float* Lap, const float* gou
  *   o [B,Lq,D] = per head softmax(q k^T / sqrt(head_dim)) v, heads concatenated; lse [B,H,Lq] saved for the backward
  * One workgroup per (sample, head); no head transposes or contiguous copies on either side.  The backward returns
  * dq [B,Lq,D] and dkv [B,Lk,2,D] in the layouts the projection-gradient GEMMs read.
- * igcn_attn_core_lds_bytes: dynamic LDS needed, 0 = shape not covered (head_dim in {4,8,12,16,20,24}, Lq <= 256).
+ * head_dim 16 runs on the matrix cores (exact-fp32 MFMA, any Lq; K, V — and Q, dO in the backward — of one head must
+ * fit LDS); head_dim in {4,8,12,20,24} on a VALU kernel (Lq <= 256).
+ * igcn_attn_core_lds_bytes: dynamic LDS needed, 0 = shape not covered.
  */
 size_t igcn_attn_core_lds_bytes(int D, int H, int Lq, int Lk, int backward);
 int igcn_attn_core_fwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o, float* lse,
