@@ -82,7 +82,7 @@ def _time_propagate(plan, ew, n, f, device, iters, nodes_per_graph=0):
     for _ in range(5):
         call("igcn_gcn_propagate_fwd", *args, stream_ptr())
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):      # a process group's threads may be alive
         for _ in range(iters):
             call("igcn_gcn_propagate_fwd", *args, stream_ptr())
     g.replay()

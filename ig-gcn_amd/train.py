@@ -255,7 +255,11 @@ class GraphedTrainStep:
         self.g_main = torch.cuda.CUDAGraph()
         if not self.plan_in_graph:
             self.plan.rebuild(self.data.edge_index)
-        with torch.cuda.graph(self.g_main):
+        # with a process group alive, its watchdog / progress threads may touch the runtime while this thread
+        # captures: flag only this thread's unsafe calls (the launches of the autograd thread still land in the
+        # capturing stream and are captured)
+        mode = "global" if world_size == 1 else "thread_local"
+        with torch.cuda.graph(self.g_main, capture_error_mode=mode):
             self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
             if world_size == 1:
                 self.opt.step(refresh=False)            # reads the pointer table at replay time
@@ -265,7 +269,7 @@ class GraphedTrainStep:
         self.g_opt = None
         if world_size > 1:
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt, pool=self.g_main.pool()):
+            with torch.cuda.graph(self.g_opt, pool=self.g_main.pool(), capture_error_mode=mode):
                 self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
         torch.cuda.synchronize()
 
