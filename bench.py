@@ -228,12 +228,20 @@ def main():
     data = Batch.from_data_list(graphs).to(device)
     data.x.requires_grad_(True)
 
-    if args.eager:
-        def step():
-            data._igcn_plan = None                # the plan is per batch: rebuild it inside every step
-            return train_step(model, opt, data, world_size=world)
-    else:
-        step = GraphedTrainStep(model, opt, data, world_size=world)     # whole step = one hipGraph replay
+    def eager_step():
+        data._igcn_plan = None                    # the plan is per batch: rebuild it inside every step
+        return train_step(model, opt, data, world_size=world)
+
+    launch = "eager"
+    step = eager_step
+    if not args.eager:
+        try:
+            step = GraphedTrainStep(model, opt, data, world_size=world)     # whole step = one hipGraph replay
+            launch = "hipGraph replay"
+        except Exception as exc:                  # noqa: BLE001 — a capture refused by the runtime must not sink the run
+            print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running the eager step",
+                  file=sys.stderr)
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -268,7 +276,7 @@ def main():
                        "graphs_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "layers": LAYERS, "hidden": HIDDEN, "rois": wl["rois"],
                        "go_nodes": sum(wl["pool"]) if wl["pool"] else 0,
-                       "parallelism": f"dp{world}", "launch": "eager" if args.eager else "hipGraph replay"},
+                       "parallelism": f"dp{world}", "launch": launch},
             "loss": round(float(loss), 6),
         }
         if args.workload == "full":

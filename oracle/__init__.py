@@ -16,6 +16,10 @@ Parity pinning status:
 * ``sgcn_img_snp`` glue (masks, fusion, MHA wiring, heads, losses, train step) — pinned against
   the reference's ``kernel/sgcn_img_snp.py`` executed with PyG's ``GCNConv``/``to_dense_batch``
   replaced by ``oracle.pyg_ops`` (PyG 2.0.2 is not installable here).
+* ``sgcn`` (the image-only sibling ``SGCN_GCN`` and its train loss) — pinned against the reference's
+  ``kernel/sgcn.py`` executed the same way (tests/golden/sgcn_only.npz).
+* ``gdc`` (PPR diffusion, top-k, column normalisation, COO emission) — pinned against the reference's own
+  ``util_gdc.py`` functions, numpy float64, bit-identical outputs (tests/golden/gdc.npz).
 * ``pyg_ops`` (``gcn_norm``/``GCNConv``/``to_dense_batch``/``scatter``) — third-party code that is
   absent from /root/reference (pyg=2.0.2, pytorch-scatter=2.0.9, environment.yml:183,211):
   **parity unpinned by the reference**; pinned here only by fp64 dense known-answer tests of the
