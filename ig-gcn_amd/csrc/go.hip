@@ -567,10 +567,30 @@ extern "C" size_t igcn_go_attn_bwd_scratch_floats(int B, int N, int fin, int fou
 // special-casing either).  x, dy, the statistics and dx are kept as [f][N][B]; the entry point transposes the
 // channel-major operands on the way in and dx on the way out (64x64 LDS tiles).
 // =================================================================================================
+// 64 (samples) x 64 (nodes) tiles; 16 bytes per lane on both global sides when the extents allow it
 __global__ void __launch_bounds__(256)
-k_cm_to_bm(int B, int F, int N, const float* __restrict__ in /*[B,F,N]*/, float* __restrict__ out /*[F,N,B]*/) {
-  __shared__ float tile[64][65];
+k_cm_to_bm(int B, int F, int N, int vec, const float* __restrict__ in /*[B,F,N]*/, float* __restrict__ out /*[F,N,B]*/) {
+  __shared__ float tile[64][65];                      // [sample][node]
   const int f = blockIdx.z, n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  if (vec) {                                          // N % 4 == 0, B % 4 == 0, 16-byte aligned bases
+    const int q = threadIdx.x & 15, r0 = threadIdx.x >> 4;          // 16 lanes x float4 = one 64-wide row
+#pragma unroll
+    for (int r = r0; r < 64; r += 16) {
+      const int b = b0 + r, n = n0 + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < B && n < N) v = *reinterpret_cast<const float4*>(in + ((int64_t)b * F + f) * N + n);
+      tile[r][q * 4] = v.x; tile[r][q * 4 + 1] = v.y; tile[r][q * 4 + 2] = v.z; tile[r][q * 4 + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = r0; r < 64; r += 16) {
+      const int n = n0 + r, b = b0 + q * 4;
+      if (n < N && b < B)
+        *reinterpret_cast<float4*>(out + ((int64_t)f * N + n) * B + b) =
+            make_float4(tile[q * 4][r], tile[q * 4 + 1][r], tile[q * 4 + 2][r], tile[q * 4 + 3][r]);
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll 4
   for (int r = ty; r < 64; r += 4) {
@@ -586,9 +606,28 @@ k_cm_to_bm(int B, int F, int N, const float* __restrict__ in /*[B,F,N]*/, float*
 }
 
 __global__ void __launch_bounds__(256)
-k_bm_to_cm(int B, int F, int N, const float* __restrict__ in /*[F,N,B]*/, float* __restrict__ out /*[B,F,N]*/) {
-  __shared__ float tile[64][65];
+k_bm_to_cm(int B, int F, int N, int vec, const float* __restrict__ in /*[F,N,B]*/, float* __restrict__ out /*[B,F,N]*/) {
+  __shared__ float tile[64][65];                      // [node][sample]
   const int f = blockIdx.z, n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  if (vec) {
+    const int q = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int r = r0; r < 64; r += 16) {
+      const int n = n0 + r, b = b0 + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N && b < B) v = *reinterpret_cast<const float4*>(in + ((int64_t)f * N + n) * B + b);
+      tile[r][q * 4] = v.x; tile[r][q * 4 + 1] = v.y; tile[r][q * 4 + 2] = v.z; tile[r][q * 4 + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = r0; r < 64; r += 16) {
+      const int b = b0 + r, n = n0 + q * 4;
+      if (b < B && n < N)
+        *reinterpret_cast<float4*>(out + ((int64_t)b * F + f) * N + n) =
+            make_float4(tile[q * 4][r], tile[q * 4 + 1][r], tile[q * 4 + 2][r], tile[q * 4 + 3][r]);
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll 4
   for (int r = ty; r < 64; r += 4) {
@@ -805,10 +844,12 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
     dim3 grid((unsigned)igcn_cdiv(N, 4 * npw), (unsigned)igcn_cdiv(B, 64));
     const int64_t parts = (int64_t)grid.x * grid.y;
     float* G = gpart + parts * rows * fin;
+    const int tvec = (N % 4 == 0 && B % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) &&
+                      ((uintptr_t)dx % 16 == 0) && ((uintptr_t)scratch % 16 == 0)) ? 1 : 0;
     tg.z = fin;
-    hipLaunchKernelGGL(k_cm_to_bm, tg, dim3(256), 0, st, B, fin, N, x, xb);
+    hipLaunchKernelGGL(k_cm_to_bm, tg, dim3(256), 0, st, B, fin, N, tvec, x, xb);
     tg.z = fout;
-    hipLaunchKernelGGL(k_cm_to_bm, tg, dim3(256), 0, st, B, fout, N, dy, dyb);
+    hipLaunchKernelGGL(k_cm_to_bm, tg, dim3(256), 0, st, B, fout, N, tvec, dy, dyb);
 #define CALLB(FI, FO)                                                                                            \
   hipLaunchKernelGGL((k_go_attn_bwd_stats_bm<FI, FO>), grid, dim3(256), 0, st, B, N, npw, row_ptr, col, xb, w_inc, \
                      a_in, dyb, (float4*)statsb);                                                                 \
@@ -817,7 +858,7 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
     GO_DISPATCH(fin, fout, CALLB)
 #undef CALLB
     tg.z = fin;
-    hipLaunchKernelGGL(k_bm_to_cm, tg, dim3(256), 0, st, B, fin, N, dxb, dx);
+    hipLaunchKernelGGL(k_bm_to_cm, tg, dim3(256), 0, st, B, fin, N, tvec, dxb, dx);
     IGCN_CHECK_LAUNCH("go_attn_bwd(bm)");
     int rc = igcn_launch_reduce_contig(gpart, parts, (int)(rows * fin), G, st);
     if (rc) return rc;
