@@ -254,7 +254,7 @@ static size_t ac_lds_floats(int HD, int Lq, int Lk, int backward) {
   else if (hd == 24) { CALL(24); }            \
   else { return 0; }
 
-// attn_mfma.hip: head_dim 16 on the matrix cores (any Lq; K, V (and Q, dO) of one head must fit LDS)
+// attn_mfma.hip: head_dim <= 32 on the matrix cores (any Lq; K, V (and Q, dO) of one head must fit LDS)
 size_t igcn_attn_mfma_lds_bytes(int D, int H, int Lq, int Lk, int backward);
 int igcn_attn_mfma_fwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o, float* lse,
                        hipStream_t st);
@@ -270,8 +270,9 @@ static bool use_mfma(int D, int H, int Lq, int Lk) {
   return !valu_only && igcn_attn_mfma_lds_bytes(D, H, Lq, Lk, 1) != 0;
 }
 
-// dynamic LDS bytes needed, or 0 when the shape is not covered (head_dim 16: MFMA path, any Lq; otherwise
-// head_dim in {4,8,12,20,24}, Lq <= 256; <= 160 KB either way)
+// dynamic LDS bytes needed, or 0 when the shape is not covered (matrix-core path: head_dim <= 32, any Lq; the VALU
+// kernels of this file — head_dim in {4,8,12,16,20,24}, Lq <= 256 — serve IGCN_ATTN_VALU=1 A/B runs and shapes whose
+// K/V do not fit the matrix-core kernel's LDS budget)
 extern "C" size_t igcn_attn_core_lds_bytes(int D, int H, int Lq, int Lk, int backward) {
   if (H > 0 && Lq > 0 && Lk > 0 && use_mfma(D, H, Lq, Lk)) return igcn_attn_mfma_lds_bytes(D, H, Lq, Lk, backward);
   if (H <= 0 || D % H || Lq <= 0 || Lq > 256 || Lk <= 0) return 0;

@@ -229,8 +229,9 @@ int igcn_gram_loss_bwd(int B, const float* G, const float* Lap, const float* gou
  *   o [B,Lq,D] = per head softmax(q k^T / sqrt(head_dim)) v, heads concatenated; lse [B,H,Lq] saved for the backward
  * One workgroup per (sample, head); no head transposes or contiguous copies on either side.  The backward returns
  * dq [B,Lq,D] and dkv [B,Lk,2,D] in the layouts the projection-gradient GEMMs read.
- * head_dim 16 runs on the matrix cores (exact-fp32 MFMA, any Lq; K, V — and Q, dO in the backward — of one head must
- * fit LDS); head_dim in {4,8,12,20,24} on a VALU kernel (Lq <= 256).
+ * head_dim <= 32 runs on the matrix cores (exact-fp32 MFMA, any Lq, head columns zero-padded to a multiple of 4 in
+ * LDS; K, V — and Q, dO in the backward — of one head must fit LDS); a VALU kernel (head_dim in {4,..,24} step 4,
+ * Lq <= 256) remains for A/B runs.
  * igcn_attn_core_lds_bytes: dynamic LDS needed, 0 = shape not covered.
  */
 size_t igcn_attn_core_lds_bytes(int D, int H, int Lq, int Lk, int backward);

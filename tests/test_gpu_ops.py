@@ -500,7 +500,10 @@ def test_propagate_dense_graph_variants(ops, hint):
 
 
 @pytest.mark.parametrize("bsz,lq,lk,d", [(3, 10, 9, 8), (4, 90, 400, 32), (2, 130, 77, 16), (5, 90, 45, 32),
-                                          (2, 300, 130, 32), (3, 7, 5, 32), (2, 16, 16, 32)])
+                                          (2, 300, 130, 32), (3, 7, 5, 32), (2, 16, 16, 32),
+                                          # head dims off the fast path of round 1: 10, 15, 24, 12, 32, 5 (padded in LDS)
+                                          (4, 90, 400, 20), (3, 90, 140, 30), (4, 90, 200, 48), (2, 33, 50, 24),
+                                          (2, 40, 70, 64), (3, 21, 19, 10)])
 def test_attention_core(ops, bsz, lq, lk, d):
     rng = np.random.default_rng(lq * lk)
     h = 2
