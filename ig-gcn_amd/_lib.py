@@ -44,7 +44,8 @@ SIGNATURES = {
     "igcn_gram_loss_bwd": (I, [I, P, P, P, P, P]),
     "igcn_attn_core_lds_bytes": (Z, [I, I, I, I, I]),
     "igcn_attn_core_fwd": (I, [I, I, I, I, I, P, P, P, P, P]),
-    "igcn_attn_core_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P]),
+    "igcn_attn_core_bwd_scratch_floats": (Z, [I, I, I]),
+    "igcn_attn_core_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "igcn_xattn_lds_bytes": (Z, [I, I, I, I, I]),
     "igcn_xattn_param_floats": (Z, [I]),
     "igcn_xattn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),

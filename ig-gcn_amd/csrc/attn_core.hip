@@ -260,6 +260,12 @@ int igcn_attn_mfma_fwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
                        hipStream_t st);
 int igcn_attn_mfma_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
                        const float* lse, const float* dout, float* dq, float* dkv, hipStream_t st);
+size_t igcn_attn_mfma_chunked_scratch_floats(int B, int H, int Lq);
+int igcn_attn_mfma_fwd_chunked(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o,
+                               float* lse, hipStream_t st);
+int igcn_attn_mfma_bwd_chunked(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
+                               const float* lse, const float* dout, float* dq, float* dkv, float* delta,
+                               hipStream_t st);
 
 static bool use_mfma(int D, int H, int Lq, int Lk) {
   static int valu_only = -1;                       // IGCN_ATTN_VALU=1: force the VALU kernels (A/B comparisons)
@@ -270,11 +276,22 @@ static bool use_mfma(int D, int H, int Lq, int Lk) {
   return !valu_only && igcn_attn_mfma_lds_bytes(D, H, Lq, Lk, 1) != 0;
 }
 
+// K, V (and Q, dO) of a head too large for LDS: the chunked matrix-core kernels stream them (head_dim <= 32)
+static bool use_mfma_chunked(int D, int H, int Lq, int Lk) {
+  return H > 0 && D > 0 && D % H == 0 && D / H <= 32 && Lq > 0 && Lk > 0 && !use_mfma(D, H, Lq, Lk) &&
+         igcn_attn_mfma_lds_bytes(D, H, 16, 16, 1) != 0 && getenv("IGCN_ATTN_VALU") == nullptr;
+}
+
 // dynamic LDS bytes needed, or 0 when the shape is not covered (matrix-core path: head_dim <= 32, any Lq; the VALU
 // kernels of this file — head_dim in {4,8,12,16,20,24}, Lq <= 256 — serve IGCN_ATTN_VALU=1 A/B runs and shapes whose
 // K/V do not fit the matrix-core kernel's LDS budget)
+extern "C" size_t igcn_attn_core_bwd_scratch_floats(int B, int H, int Lq) {
+  return igcn_attn_mfma_chunked_scratch_floats(B, H, Lq);
+}
+
 extern "C" size_t igcn_attn_core_lds_bytes(int D, int H, int Lq, int Lk, int backward) {
   if (H > 0 && Lq > 0 && Lk > 0 && use_mfma(D, H, Lq, Lk)) return igcn_attn_mfma_lds_bytes(D, H, Lq, Lk, backward);
+  if (use_mfma_chunked(D, H, Lq, Lk)) return 96 * 1024;            // streamed in ~96 KB chunks
   if (H <= 0 || D % H || Lq <= 0 || Lq > 256 || Lk <= 0) return 0;
   const int hd = D / H;
   if (!(hd == 4 || hd == 8 || hd == 12 || hd == 16 || hd == 20 || hd == 24)) return 0;
@@ -286,6 +303,8 @@ extern "C" int igcn_attn_core_fwd(int B, int D, int H, int Lq, int Lk, const flo
                                   float* lse, void* stream) {
   if (H > 0 && Lq > 0 && Lk > 0 && use_mfma(D, H, Lq, Lk))
     return igcn_attn_mfma_fwd(B, D, H, Lq, Lk, q, kv, o, lse, (hipStream_t)stream);
+  if (use_mfma_chunked(D, H, Lq, Lk))
+    return igcn_attn_mfma_fwd_chunked(B, D, H, Lq, Lk, q, kv, o, lse, (hipStream_t)stream);
   const size_t lds = igcn_attn_core_lds_bytes(D, H, Lq, Lk, 0);
   if (lds == 0) { igcn_set_error("attn_core_fwd: unsupported shape D=%d H=%d Lq=%d Lk=%d", D, H, Lq, Lk); return IGCN_ERR_UNSUPPORTED; }
   const int hd = D / H;
@@ -302,9 +321,14 @@ extern "C" int igcn_attn_core_fwd(int B, int D, int H, int Lq, int Lk, const flo
 }
 
 extern "C" int igcn_attn_core_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
-                                  const float* lse, const float* dout, float* dq, float* dkv, void* stream) {
+                                  const float* lse, const float* dout, float* dq, float* dkv, float* scratch,
+                                  void* stream) {
   if (H > 0 && Lq > 0 && Lk > 0 && use_mfma(D, H, Lq, Lk))
     return igcn_attn_mfma_bwd(B, D, H, Lq, Lk, q, kv, o, lse, dout, dq, dkv, (hipStream_t)stream);
+  if (use_mfma_chunked(D, H, Lq, Lk)) {
+    IGCN_REQUIRE(scratch != nullptr, "attn_core_bwd: this shape needs igcn_attn_core_bwd_scratch_floats() of scratch");
+    return igcn_attn_mfma_bwd_chunked(B, D, H, Lq, Lk, q, kv, o, lse, dout, dq, dkv, scratch, (hipStream_t)stream);
+  }
   const size_t lds = igcn_attn_core_lds_bytes(D, H, Lq, Lk, 1);
   if (lds == 0) { igcn_set_error("attn_core_bwd: unsupported shape D=%d H=%d Lq=%d Lk=%d", D, H, Lq, Lk); return IGCN_ERR_UNSUPPORTED; }
   const int hd = D / H;

@@ -352,3 +352,293 @@ int igcn_attn_mfma_bwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
   IGCN_CHECK_LAUNCH("attn_mfma_bwd");
   return IGCN_OK;
 }
+
+// =================================================================================================
+// Chunked variants for heads whose K, V (and Q, dO) do not fit LDS at once (e.g. 512 queries x 1300 keys): the
+// same tile arithmetic, with the other side of the attention streamed through LDS in chunks.
+//   forward / dQ : workgroup = (sample, head, block of 16*nw queries), wave = one 16-query tile, key chunks streamed
+//   dK, dV       : workgroup = (sample, head, block of 16*nw keys),    wave = one 16-key tile,  query chunks streamed
+// delta = rowsum(o * do) is written by the dQ kernel ([B,H,Lq] scratch) and read by the dK/dV kernel.
+// =================================================================================================
+template <int HDP>
+__global__ void __launch_bounds__(64 * AM_MAX_WAVES)
+k_attn_mfma_fwd_chunked(int H, int hd, int vec, int Lq, int Lk, int CH, const float* __restrict__ q,
+                        const float* __restrict__ kv, float* __restrict__ o, float* __restrict__ lse) {
+  constexpr int LD = HDP + 1, NC = HDP / 4, NO = (HDP + 15) / 16;
+  extern __shared__ float smem[];
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * hd;
+  float* Ks = smem;
+  float* Vs = Ks + (size_t)CH * LD;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
+  const float scale = rsqrtf((float)hd);
+  const int qi = (blockIdx.y * nw + w) * 16 + n;                 // this wave's query tile (may be past Lq)
+  float qb[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+    qb[c] = (qi < Lq && 4 * c + g < hd) ? q[(int64_t)(b * Lq + qi) * D + h * hd + 4 * c + g] * scale : 0.f;
+  float m = -INFINITY, l = 0.f;
+  f32x4 oacc[NO];
+#pragma unroll
+  for (int t = 0; t < NO; ++t) oacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < Lk; k0 += CH) {
+    const int kn = min(CH, Lk - k0), knp = (kn + 15) & ~15;
+    __syncthreads();                                            // previous chunk fully consumed
+    const float* kbase = kv + ((int64_t)b * Lk + k0) * 2 * D + h * hd;
+    am_stage<HDP>(kbase, 2 * D, hd, vec, kn, knp, Ks);
+    am_stage<HDP>(kbase + D, 2 * D, hd, vec, kn, knp, Vs);
+    __syncthreads();
+    for (int kt = 0; kt < (knp >> 4); ++kt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* kr = Ks + (kt * 16 + n) * LD + g;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc = mfma4(kr[4 * c], qb[c], acc);
+      float s[4], tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[r] = (kt * 16 + 4 * g + r < kn) ? acc[r] : -INFINITY;
+        tmax = fmaxf(tmax, s[r]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mn = fmaxf(m, tmax);
+      const float f = __expf(m - mn);
+      m = mn;
+      l *= f;
+#pragma unroll
+      for (int t = 0; t < NO; ++t) oacc[t] *= f;
+      const float* vr = Vs + (kt * 16 + 4 * g) * LD + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[r] - m);
+        l += p;
+#pragma unroll
+        for (int t = 0; t < NO; ++t) oacc[t] = mfma4((16 * t + n < HDP) ? vr[r * LD + 16 * t] : 0.f, p, oacc[t]);
+      }
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (qi < Lq) {
+    const float inv = 1.f / l;
+    float* op = o + (int64_t)(b * Lq + qi) * D + h * hd;
+#pragma unroll
+    for (int t = 0; t < NO; ++t)
+      am_store4(op, 16 * t + 4 * g, hd, vec, oacc[t][0] * inv, oacc[t][1] * inv, oacc[t][2] * inv, oacc[t][3] * inv);
+    if (g == 0) lse[((int64_t)b * H + h) * Lq + qi] = m + __logf(l);
+  }
+}
+
+template <int HDP>
+__global__ void __launch_bounds__(64 * AM_MAX_WAVES)
+k_attn_mfma_bwd_dq_chunked(int H, int hd, int vec, int Lq, int Lk, int CH, const float* __restrict__ q,
+                           const float* __restrict__ kv, const float* __restrict__ o, const float* __restrict__ lse,
+                           const float* __restrict__ dout, float* __restrict__ dq, float* __restrict__ delta) {
+  constexpr int LD = HDP + 1, NC = HDP / 4, NO = (HDP + 15) / 16;
+  extern __shared__ float smem[];
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * hd;
+  float* Ks = smem;
+  float* Vs = Ks + (size_t)CH * LD;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
+  const float scale = rsqrtf((float)hd);
+  const int qi = (blockIdx.y * nw + w) * 16 + n;
+  const bool qlive = qi < Lq;
+  const float* qrow = q + (int64_t)(b * Lq + (qlive ? qi : 0)) * D + h * hd;
+  const float* dorow = dout + (int64_t)(b * Lq + (qlive ? qi : 0)) * D + h * hd;
+  float qb[NC], dob[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const bool in = qlive && 4 * c + g < hd;
+    qb[c] = in ? qrow[4 * c + g] * scale : 0.f;
+    dob[c] = in ? dorow[4 * c + g] : 0.f;
+  }
+  // delta of this lane's query: the four lanes g = 0..3 of a column each sum a quarter of the head columns
+  float dpart = 0.f;
+  if (qlive) {
+    const float* orow = o + (int64_t)(b * Lq + qi) * D + h * hd;
+    for (int c = g; c < hd; c += 4) dpart += orow[c] * dorow[c];
+  }
+  dpart += __shfl_xor(dpart, 16, 64);
+  dpart += __shfl_xor(dpart, 32, 64);
+  const float dln = dpart;
+  const float lsn = qlive ? lse[((int64_t)b * H + h) * Lq + qi] : INFINITY;
+  if (qlive && g == 0) delta[((int64_t)b * H + h) * Lq + qi] = dln;
+  f32x4 acc[NO];
+#pragma unroll
+  for (int t = 0; t < NO; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < Lk; k0 += CH) {
+    const int kn = min(CH, Lk - k0), knp = (kn + 15) & ~15;
+    __syncthreads();
+    const float* kbase = kv + ((int64_t)b * Lk + k0) * 2 * D + h * hd;
+    am_stage<HDP>(kbase, 2 * D, hd, vec, kn, knp, Ks);
+    am_stage<HDP>(kbase + D, 2 * D, hd, vec, kn, knp, Vs);
+    __syncthreads();
+    for (int kt = 0; kt < (knp >> 4); ++kt) {
+      f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+      const float* kr = Ks + (kt * 16 + n) * LD + g;
+      const float* vr = Vs + (kt * 16 + n) * LD + g;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        st = mfma4(kr[4 * c], qb[c], st);
+        dpt = mfma4(vr[4 * c], dob[c], dpt);
+      }
+      const float* kc = Ks + (kt * 16 + 4 * g) * LD + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ds = __expf(st[r] - lsn) * (dpt[r] - dln) * scale;       // padded keys: zero K rows
+#pragma unroll
+        for (int t = 0; t < NO; ++t) acc[t] = mfma4((16 * t + n < HDP) ? kc[r * LD + 16 * t] : 0.f, ds, acc[t]);
+      }
+    }
+  }
+  if (qlive) {
+    float* dst = dq + (int64_t)(b * Lq + qi) * D + h * hd;
+#pragma unroll
+    for (int t = 0; t < NO; ++t) am_store4(dst, 16 * t + 4 * g, hd, vec, acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  }
+}
+
+template <int HDP>
+__global__ void __launch_bounds__(64 * AM_MAX_WAVES)
+k_attn_mfma_bwd_dkv_chunked(int H, int hd, int vec, int Lq, int Lk, int CH, const float* __restrict__ q,
+                            const float* __restrict__ kv, const float* __restrict__ lse,
+                            const float* __restrict__ dout, const float* __restrict__ delta,
+                            float* __restrict__ dkv) {
+  constexpr int LD = HDP + 1, NC = HDP / 4, NO = (HDP + 15) / 16;
+  extern __shared__ float smem[];
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * hd;
+  float* Qs = smem;
+  float* dOs = Qs + (size_t)CH * LD;
+  float* ls = dOs + (size_t)CH * LD;                            // [CH]
+  float* dl = ls + CH;                                          // [CH]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
+  const float scale = rsqrtf((float)hd);
+  const int ki = (blockIdx.y * nw + w) * 16 + n;
+  const bool klive = ki < Lk;
+  const float* krow = kv + ((int64_t)(b * Lk + (klive ? ki : 0)) * 2) * D + h * hd;
+  float kb[NC], vb[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const bool in = klive && 4 * c + g < hd;
+    kb[c] = in ? krow[4 * c + g] * scale : 0.f;
+    vb[c] = in ? krow[D + 4 * c + g] : 0.f;
+  }
+  f32x4 dka[NO], dva[NO];
+#pragma unroll
+  for (int t = 0; t < NO; ++t) dka[t] = dva[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int q0 = 0; q0 < Lq; q0 += CH) {
+    const int qn = min(CH, Lq - q0), qnp = (qn + 15) & ~15;
+    __syncthreads();
+    am_stage<HDP>(q + ((int64_t)b * Lq + q0) * D + h * hd, D, hd, vec, qn, qnp, Qs);
+    am_stage<HDP>(dout + ((int64_t)b * Lq + q0) * D + h * hd, D, hd, vec, qn, qnp, dOs);
+    for (int r = threadIdx.x; r < qnp; r += blockDim.x) {
+      const bool in = r < qn;
+      ls[r] = in ? lse[((int64_t)b * H + h) * Lq + q0 + r] : INFINITY;       // padding queries: p = 0
+      dl[r] = in ? delta[((int64_t)b * H + h) * Lq + q0 + r] : 0.f;
+    }
+    __syncthreads();
+    for (int qt = 0; qt < (qnp >> 4); ++qt) {
+      f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+      const float* qr = Qs + (qt * 16 + n) * LD + g;
+      const float* dr = dOs + (qt * 16 + n) * LD + g;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        st = mfma4(qr[4 * c], kb[c], st);
+        dpt = mfma4(dr[4 * c], vb[c], dpt);
+      }
+      const float* qc = Qs + (qt * 16 + 4 * g) * LD + n;
+      const float* dc = dOs + (qt * 16 + 4 * g) * LD + n;
+      const float* lsr = ls + qt * 16 + 4 * g;
+      const float* dlr = dl + qt * 16 + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(st[r] - lsr[r]);
+        const float ds = p * (dpt[r] - dlr[r]) * scale;
+#pragma unroll
+        for (int t = 0; t < NO; ++t) {
+          const bool in = 16 * t + n < HDP;
+          dva[t] = mfma4(in ? dc[r * LD + 16 * t] : 0.f, p, dva[t]);
+          dka[t] = mfma4(in ? qc[r * LD + 16 * t] : 0.f, ds, dka[t]);
+        }
+      }
+    }
+  }
+  if (klive) {
+    float* base = dkv + ((int64_t)(b * Lk + ki) * 2) * D + h * hd;
+#pragma unroll
+    for (int t = 0; t < NO; ++t) {
+      am_store4(base, 16 * t + 4 * g, hd, vec, dka[t][0], dka[t][1], dka[t][2], dka[t][3]);
+      am_store4(base + D, 16 * t + 4 * g, hd, vec, dva[t][0], dva[t][1], dva[t][2], dva[t][3]);
+    }
+  }
+}
+
+// rows of the other side streamed per chunk: as many as ~96 KB of LDS hold (two matrices of HDP+1 columns)
+static int am_chunk_rows(int hd) {
+  const int ld = am_hdp(hd) + 1;
+  int ch = (96 * 1024) / (2 * ld * 4 + 8);
+  ch &= ~15;
+  return ch < 16 ? 16 : ch;
+}
+
+size_t igcn_attn_mfma_chunked_scratch_floats(int B, int H, int Lq) { return (size_t)B * H * Lq + 16; }
+
+int igcn_attn_mfma_fwd_chunked(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o,
+                               float* lse, hipStream_t st) {
+  const int hd = D / H, vec = am_vec(D, hd, q, kv, o, o);
+  int ch = am_chunk_rows(hd);
+  if (ch > ((Lk + 15) & ~15)) ch = (Lk + 15) & ~15;
+  const size_t lds = (size_t)2 * ch * (am_hdp(hd) + 1) * sizeof(float);
+  const int nqt = (Lq + 15) / 16, nw = nqt < 8 ? (nqt < 4 ? 4 : nqt) : 8;
+  dim3 grid(B * H, (nqt + nw - 1) / nw);
+#define CALL(HDPV)                                                                                               \
+  {                                                                                                              \
+    static bool once = false;                                                                                    \
+    if (!once) {                                                                                                 \
+      hipFuncSetAttribute((const void*)k_attn_mfma_fwd_chunked<HDPV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          160 * 1024);                                                                           \
+      once = true;                                                                                               \
+    }                                                                                                            \
+    hipLaunchKernelGGL((k_attn_mfma_fwd_chunked<HDPV>), grid, dim3(64 * nw), lds, st, H, hd, vec, Lq, Lk, ch, q,  \
+                       kv, o, lse);                                                                              \
+  }
+  AM_DISPATCH(am_hdp(hd), CALL)
+#undef CALL
+  IGCN_CHECK_LAUNCH("attn_mfma_fwd_chunked");
+  return IGCN_OK;
+}
+
+int igcn_attn_mfma_bwd_chunked(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
+                               const float* lse, const float* dout, float* dq, float* dkv, float* delta,
+                               hipStream_t st) {
+  const int hd = D / H;
+  const int vec = am_vec(D, hd, q, kv, dout, dq) && (uintptr_t)dkv % 16 == 0;
+  const int chmax = am_chunk_rows(hd);
+  int chk = chmax, chq = chmax;
+  if (chk > ((Lk + 15) & ~15)) chk = (Lk + 15) & ~15;
+  if (chq > ((Lq + 15) & ~15)) chq = (Lq + 15) & ~15;
+  const size_t ld = (size_t)am_hdp(hd) + 1;
+  const size_t lds_q = (size_t)2 * chk * ld * sizeof(float);
+  const size_t lds_k = ((size_t)2 * chq * ld + 2 * chq) * sizeof(float);
+  const int nqt = (Lq + 15) / 16, nkt = (Lk + 15) / 16;
+  const int nwq = nqt < 8 ? (nqt < 4 ? 4 : nqt) : 8, nwk = nkt < 8 ? (nkt < 4 ? 4 : nkt) : 8;
+  dim3 gq(B * H, (nqt + nwq - 1) / nwq), gk(B * H, (nkt + nwk - 1) / nwk);
+#define CALL(HDPV)                                                                                               \
+  {                                                                                                              \
+    static bool once = false;                                                                                    \
+    if (!once) {                                                                                                 \
+      hipFuncSetAttribute((const void*)k_attn_mfma_bwd_dq_chunked<HDPV>,                                         \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
+      hipFuncSetAttribute((const void*)k_attn_mfma_bwd_dkv_chunked<HDPV>,                                        \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
+      once = true;                                                                                               \
+    }                                                                                                            \
+    hipLaunchKernelGGL((k_attn_mfma_bwd_dq_chunked<HDPV>), gq, dim3(64 * nwq), lds_q, st, H, hd, vec, Lq, Lk, chk, \
+                       q, kv, o, lse, dout, dq, delta);                                                          \
+    hipLaunchKernelGGL((k_attn_mfma_bwd_dkv_chunked<HDPV>), gk, dim3(64 * nwk), lds_k, st, H, hd, vec, Lq, Lk,    \
+                       chq, q, kv, lse, dout, delta, dkv);                                                       \
+  }
+  AM_DISPATCH(am_hdp(hd), CALL)
+#undef CALL
+  IGCN_CHECK_LAUNCH("attn_mfma_bwd_chunked");
+  return IGCN_OK;
+}

@@ -758,6 +758,8 @@ class AttentionCore(torch.autograd.Function):
         b, lq, d = q.shape
         lk = kv.shape[1]
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        nscr = int(_lib.load().igcn_attn_core_bwd_scratch_floats(b, ctx.heads, lq))
+        scratch = torch.empty(nscr, dtype=torch.float32, device=q.device)
         call("igcn_attn_core_bwd", b, d, ctx.heads, lq, lk, ptr(q), ptr(kv), ptr(o), ptr(lse), ptr(dout), ptr(dq),
-             ptr(dkv), stream_ptr())
+             ptr(dkv), ptr(scratch), stream_ptr())
         return dq, dkv, None

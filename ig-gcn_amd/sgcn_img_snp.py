@@ -186,9 +186,8 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         if ops.attn_core_supported(d, h, lq, lk):
             o = ops.AttentionCore.apply(q, kv, h)                           # heads addressed in place
         else:
-            # shapes outside the core's coverage (head_dim not a multiple of 4 up to 24, or more than 256 query
-            # rows): plain batched-GEMM + softmax composite.  Deliberately not the library's fused SDPA kernels:
-            # with several steps in flight on one stream they faulted on gfx950
+            # head_dim > 32 (outside the core's coverage): plain batched-GEMM + softmax composite.  Deliberately not
+            # the library's fused SDPA kernels (known issues)
             hd = d // h
             qh = q.view(b, lq, h, hd).transpose(1, 2)
             kvh = kv.view(b, lk, 2, h, hd)

@@ -230,15 +230,19 @@ int igcn_gram_loss_bwd(int B, const float* G, const float* Lap, const float* gou
  * One workgroup per (sample, head); no head transposes or contiguous copies on either side.  The backward returns
  * dq [B,Lq,D] and dkv [B,Lk,2,D] in the layouts the projection-gradient GEMMs read.
  * head_dim <= 32 runs on the matrix cores (exact-fp32 MFMA, any Lq, head columns zero-padded to a multiple of 4 in
- * LDS; K, V — and Q, dO in the backward — of one head must fit LDS); a VALU kernel (head_dim in {4,..,24} step 4,
- * Lq <= 256) remains for A/B runs.
+ * LDS); when K, V — and Q, dO in the backward — of one head fit LDS one workgroup per (sample, head) keeps them
+ * resident, otherwise the other side of the attention is streamed through LDS in chunks (512 queries x 1300 keys of
+ * the 512-ROI configuration).  A VALU kernel (head_dim in {4,..,24} step 4, Lq <= 256) remains for A/B runs.
  * igcn_attn_core_lds_bytes: dynamic LDS needed, 0 = shape not covered.
  */
 size_t igcn_attn_core_lds_bytes(int D, int H, int Lq, int Lk, int backward);
+size_t igcn_attn_core_bwd_scratch_floats(int B, int H, int Lq);
 int igcn_attn_core_fwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o, float* lse,
                        void* stream);
 int igcn_attn_core_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
-                       const float* lse, const float* dout, float* dq, float* dkv, void* stream);
+                       const float* lse, const float* dout, float* dq, float* dkv,
+                       float* scratch /* igcn_attn_core_bwd_scratch_floats(): rowsum(o*do) of the chunked path */,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused cross-attention fusion block — kernel/sgcn_img_snp.py:46,239-242:

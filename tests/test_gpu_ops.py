@@ -503,7 +503,9 @@ def test_propagate_dense_graph_variants(ops, hint):
                                           (2, 300, 130, 32), (3, 7, 5, 32), (2, 16, 16, 32),
                                           # head dims off the fast path of round 1: 10, 15, 24, 12, 32, 5 (padded in LDS)
                                           (4, 90, 400, 20), (3, 90, 140, 30), (4, 90, 200, 48), (2, 33, 50, 24),
-                                          (2, 40, 70, 64), (3, 21, 19, 10)])
+                                          (2, 40, 70, 64), (3, 21, 19, 10),
+                                          # K, V too large for LDS: the chunked (streamed) kernels
+                                          (2, 512, 1300, 32), (1, 300, 2500, 20), (2, 1100, 90, 32)])
 def test_attention_core(ops, bsz, lq, lk, d):
     rng = np.random.default_rng(lq * lk)
     h = 2

@@ -23,6 +23,7 @@ o = torch.empty_like(q)
 lse = torch.empty(b, h, lq, device=dev)
 do = torch.randn_like(q)
 dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+scr = torch.empty(b * h * lq + 16, device=dev)
 
 
 def fwd():
@@ -31,7 +32,7 @@ def fwd():
 
 def bwd():
     call("igcn_attn_core_bwd", b, d, h, lq, lk, q.data_ptr(), kv.data_ptr(), o.data_ptr(), lse.data_ptr(),
-         do.data_ptr(), dq.data_ptr(), dkv.data_ptr(), stream_ptr())
+         do.data_ptr(), dq.data_ptr(), dkv.data_ptr(), scr.data_ptr(), stream_ptr())
 
 
 for name, fn in (("fwd", fwd), ("bwd", bwd)):
