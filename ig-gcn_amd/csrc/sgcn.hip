@@ -684,10 +684,25 @@ k_gcn_propagate_bwd_dh_wide(int64_t n_nodes, const float* __restrict__ dout, int
   }
 }
 
-extern "C" size_t igcn_gcn_propagate_bwd_scratch_floats(int64_t n_nodes, int F) {
+// g = dout * [out > 0], once per call: the per-edge kernels then gather ONE row per edge end instead of two
+__global__ void __launch_bounds__(256)
+k_relu_mask_rows(int64_t n_nodes, int F, const float* __restrict__ dout, int64_t ld_dout,
+                 const float* __restrict__ out, int64_t ld_out, float* __restrict__ g /*[N,F] dense*/) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_nodes * F) return;
+  const int64_t r = i / F;
+  const int c = (int)(i - r * F);
+  g[i] = out[r * ld_out + c] > 0.f ? dout[r * ld_dout + c] : 0.f;
+}
+
+static size_t propagate_bwd_partial_floats(int64_t n_nodes, int F) {
   const int FP = pow2_ge(F > 0 ? F : 1);
   const int npb = FP >= 256 ? 1 : 256 / FP;
-  return (size_t)(igcn_cdiv(n_nodes, npb) * FP + 64);
+  return ((size_t)(igcn_cdiv(n_nodes, npb) * FP + 64) + 3) & ~(size_t)3;
+}
+
+extern "C" size_t igcn_gcn_propagate_bwd_scratch_floats(int64_t n_nodes, int F) {
+  return propagate_bwd_partial_floats(n_nodes, F) + (size_t)n_nodes * (F > 0 ? F : 1);   // partials + masked dout
 }
 
 extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, const float* dout, int64_t ld_dout,
@@ -699,6 +714,14 @@ extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, c
   IGCN_REQUIRE(F >= 1 && F <= 256, "gcn_propagate_bwd: F=%d unsupported (1..256)", F);
   if (n_nodes == 0) return IGCN_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (relu) {                                      // fold the ReLU mask into a dense copy of dout once
+    float* gm = scratch + propagate_bwd_partial_floats(n_nodes, F);
+    hipLaunchKernelGGL(k_relu_mask_rows, dim3((unsigned)igcn_cdiv(n_nodes * F, 256)), dim3(256), 0, st, n_nodes, F,
+                       dout, ld_dout, out, ld_out, gm);
+    dout = gm;
+    ld_dout = F;
+    relu = 0;
+  }
   const int FP = pow2_ge(F);
   int64_t nblk = igcn_cdiv(n_nodes, 256 / FP);
   const bool al16 = ((uintptr_t)dout % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)dh % 16 == 0) &&

@@ -129,7 +129,8 @@ int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, int nodes_pe
 /* Backward of the above.  g = dout * (out>0 if relu).  Outputs:
  *   dh [N,F] (row stride ld_dh)  = A_hat^T g          dbias [F] (may be NULL)
  *   dwhat [E] = g[dst_k].h[src_k] (0 at stored loops), dwhat_loop [N] = g[i].h[i]   (only when need_dw != 0)
- * scratch: igcn_gcn_propagate_bwd_scratch_floats(n_nodes, F) floats (block partials of dbias). */
+ * scratch: igcn_gcn_propagate_bwd_scratch_floats(n_nodes, F) floats (block partials of dbias + the ReLU-masked
+ * copy of dout that the per-edge kernels gather). */
 size_t igcn_gcn_propagate_bwd_scratch_floats(int64_t n_nodes, int F);
 int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F,
                            const float* dout, int64_t ld_dout, const float* out, int64_t ld_out, int relu,
