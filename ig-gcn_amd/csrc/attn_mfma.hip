@@ -60,11 +60,13 @@ __device__ __forceinline__ void am_store4(float* __restrict__ p, int c0, int hd,
   }
 }
 
-template <int HDP>
+// EXACT: head_dim == HDP and 16-byte aligned rows — the clipping guards fold away at compile time
+template <int HDP, bool EXACT>
 __global__ void __launch_bounds__(64 * AM_MAX_WAVES)
-k_attn_mfma_fwd(int H, int hd, int vec, int Lq, int Lk, const float* __restrict__ q, const float* __restrict__ kv,
-                float* __restrict__ o, float* __restrict__ lse) {
+k_attn_mfma_fwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __restrict__ q,
+                const float* __restrict__ kv, float* __restrict__ o, float* __restrict__ lse) {
   constexpr int LD = HDP + 1, NC = HDP / 4, NO = (HDP + 15) / 16;
+  const int hd = EXACT ? HDP : hd_rt, vec = EXACT ? 1 : vec_rt;
   extern __shared__ float smem[];
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * hd;
   const int Lkp = (Lk + 15) & ~15, nkt = Lkp >> 4, nqt = (Lq + 15) >> 4;
@@ -144,12 +146,13 @@ k_attn_mfma_fwd(int H, int hd, int vec, int Lq, int Lk, const float* __restrict_
 }
 
 // backward: dq [B,Lq,D], dkv [B,Lk,2,D]
-template <int HDP>
+template <int HDP, bool EXACT>
 __global__ void __launch_bounds__(64 * AM_MAX_WAVES)
-k_attn_mfma_bwd(int H, int hd, int vec, int Lq, int Lk, const float* __restrict__ q, const float* __restrict__ kv,
-                const float* __restrict__ o, const float* __restrict__ lse, const float* __restrict__ dout,
-                float* __restrict__ dq, float* __restrict__ dkv) {
+k_attn_mfma_bwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __restrict__ q,
+                const float* __restrict__ kv, const float* __restrict__ o, const float* __restrict__ lse,
+                const float* __restrict__ dout, float* __restrict__ dq, float* __restrict__ dkv) {
   constexpr int LD = HDP + 1, NC = HDP / 4, NO = (HDP + 15) / 16;
+  const int hd = EXACT ? HDP : hd_rt, vec = EXACT ? 1 : vec_rt;
   extern __shared__ float smem[];
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * hd;
   const int Lkp = (Lk + 15) & ~15, Lqp = (Lq + 15) & ~15, nkt = Lkp >> 4, nqt = Lqp >> 4;
@@ -316,12 +319,18 @@ int igcn_attn_mfma_fwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
   {                                                                                                              \
     static bool once = false;                                                                                    \
     if (!once) {                                                                                                 \
-      hipFuncSetAttribute((const void*)k_attn_mfma_fwd<HDPV>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+      hipFuncSetAttribute((const void*)k_attn_mfma_fwd<HDPV, true>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                          160 * 1024);                                                                           \
+      hipFuncSetAttribute((const void*)k_attn_mfma_fwd<HDPV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                           160 * 1024);                                                                           \
       once = true;                                                                                               \
     }                                                                                                            \
-    hipLaunchKernelGGL((k_attn_mfma_fwd<HDPV>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq, Lk, q, kv, \
-                       o, lse);                                                                                  \
+    if (vec && hd == HDPV)                                                                                       \
+      hipLaunchKernelGGL((k_attn_mfma_fwd<HDPV, true>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq,  \
+                         Lk, q, kv, o, lse);                                                                     \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_attn_mfma_fwd<HDPV, false>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq, \
+                         Lk, q, kv, o, lse);                                                                     \
   }
   AM_DISPATCH(am_hdp(hd), CALL)
 #undef CALL
@@ -340,12 +349,18 @@ int igcn_attn_mfma_bwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
   {                                                                                                              \
     static bool once = false;                                                                                    \
     if (!once) {                                                                                                 \
-      hipFuncSetAttribute((const void*)k_attn_mfma_bwd<HDPV>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+      hipFuncSetAttribute((const void*)k_attn_mfma_bwd<HDPV, true>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                          160 * 1024);                                                                           \
+      hipFuncSetAttribute((const void*)k_attn_mfma_bwd<HDPV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                           160 * 1024);                                                                           \
       once = true;                                                                                               \
     }                                                                                                            \
-    hipLaunchKernelGGL((k_attn_mfma_bwd<HDPV>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq, Lk, q, kv, \
-                       o, lse, dout, dq, dkv);                                                                   \
+    if (vec && hd == HDPV)                                                                                       \
+      hipLaunchKernelGGL((k_attn_mfma_bwd<HDPV, true>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq,  \
+                         Lk, q, kv, o, lse, dout, dq, dkv);                                                      \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_attn_mfma_bwd<HDPV, false>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq, \
+                         Lk, q, kv, o, lse, dout, dq, dkv);                                                      \
   }
   AM_DISPATCH(am_hdp(hd), CALL)
 #undef CALL
