@@ -561,3 +561,53 @@ def test_loss_head_matches_composite():
         assert abs(float(terms[k]) - float(t[k])) <= 1e-5 * max(1e-3, abs(float(t[k]))), k
     for g, w, name in zip(got, (logp2, reg2, x2, gram2, prob2), ("logp", "reg", "x_hat", "gram", "prob")):
         assert_matches(g, w.grad.float().cpu().numpy(), 1e-5, "grad " + name)
+
+
+_AB_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import igcn_amd
+from igcn_amd import ops, synth
+rng = np.random.default_rng(3)
+# GO attention layer (2 -> 5 features) on a small hierarchy
+go_snps, adj, pool_dim = synth.go_hierarchy((60, 30, 20, 9, 1), seed=4)
+a = torch.from_numpy(adj.T.copy()).to_sparse().coalesce()
+idx = a.indices()
+csr = ops.Csr(idx[0], idx[1], adj.shape[0], adj.shape[0], "cuda")
+n = adj.shape[0]
+x = torch.from_numpy(rng.standard_normal((5, 2, n))).float().cuda().requires_grad_(True)
+par = [torch.from_numpy(rng.standard_normal(s)).float().cuda().requires_grad_(True) for s in ((5, 2), (5, 2), (10,), (5,))]
+y = ops.GoAttention.apply(x, par[0], par[1], par[2], par[3], csr)
+cot = torch.from_numpy(rng.standard_normal(tuple(y.shape))).float().cuda()
+g = torch.autograd.grad((y * cot).sum(), [x] + par)
+# attention core, head_dim 16
+q = torch.from_numpy(rng.standard_normal((3, 40, 32))).float().cuda().requires_grad_(True)
+kv = torch.from_numpy(rng.standard_normal((3, 70, 64))).float().cuda().requires_grad_(True)
+o = ops.AttentionCore.apply(q, kv, 2)
+co = torch.from_numpy(rng.standard_normal((3, 40, 32))).float().cuda()
+ga = torch.autograd.grad((o * co).sum(), [q, kv])
+np.savez(sys.argv[2], y=y.detach().cpu().numpy(), o=o.detach().cpu().numpy(),
+         **{f"g{i}": t.cpu().numpy() for i, t in enumerate(g)}, **{f"a{i}": t.cpu().numpy() for i, t in enumerate(ga)})
+"""
+
+
+def test_alternative_kernel_variants_agree(tmp_path):
+    """The A/B switches stay honest: the channel-major GO attention backward (IGCN_GO_ATTN_CM=1) and the VALU attention
+    core (IGCN_ATTN_VALU=1) give the numbers of the default batch-minor / matrix-core kernels.  The switches are read
+    once per process, so each variant runs in a short child process (one at a time)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "ab.py"
+    script.write_text(_AB_SCRIPT)
+    outs = {}
+    for tag, env in (("default", {}), ("alt", {"IGCN_GO_ATTN_CM": "1", "IGCN_ATTN_VALU": "1"})):
+        out = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env={**os.environ, **env},
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(out)
+    for k in outs["default"].files:
+        a, b = outs["default"][k], outs["alt"][k]
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), k
