@@ -22,6 +22,7 @@ of the reference model's own methods, because importing the trainer module pulls
 stack; Adam is torch.optim.Adam as at :108.
 """
 import importlib.util
+import json
 import os
 import sys
 import types
@@ -314,6 +315,78 @@ def capture_gdc(name):
     print("wrote", name, [store[f"case{c}/edge_index"].shape for c in range(len(cases))])
 
 
+def synthetic_go_files(seed=5):
+    """PANTHER over-representation JSON, root-connection paths and a SNP->gene table in the formats the reference
+    reads (snps_graph.py:12-174, snps_get_root_go_by_html.py:63-92, snps_graph.py:224-238) — synthetic content."""
+    rng = np.random.default_rng(seed)
+    gid = lambda k: "GO:%07d" % k                                   # noqa: E731
+    genes = ["GENE%d" % k for k in range(40)]
+    snp_genes = [";".join(rng.choice(genes, size=int(rng.integers(1, 3)), replace=False)) for _ in range(54)]
+    groups, tops = [], []
+    next_id = 100
+    for w in range(9):
+        terms, n_chain = [], int(rng.integers(1, 4))
+        for c in range(n_chain):                                    # chains: specific term (level 0) then its ancestors
+            depth = int(rng.integers(1, 4))
+            for lv in range(depth):
+                if lv == depth - 1 and tops and rng.random() < 0.3:
+                    tid = tops[int(rng.integers(len(tops)))]        # re-use an ancestor seen in another group
+                else:
+                    tid = gid(next_id)
+                    next_id += 1
+                g = list(rng.choice(genes, size=int(rng.integers(1, 5)), replace=False))
+                terms.append({"term": {"id": tid, "level": lv},
+                              "input_list": {"fdr": float(rng.random()), "mapped_id_list": {"mapped_id": g}}})
+                if lv == depth - 1 and tid not in tops:
+                    tops.append(tid)
+        groups.append({"result": terms if len(terms) > 1 or w % 2 else terms[0]})
+    mids = [gid(k) for k in range(10, 16)]
+    lines = []
+    for t in tops + [gid(next_id + 1)]:                             # one path per group top (+ a term only known here)
+        a, b = mids[int(rng.integers(3))], mids[3 + int(rng.integers(3))]
+        extra = [gid(k) for k in rng.integers(20, 30, size=int(rng.integers(0, 3)))]
+        path = ["GO:0008150", a, b] + extra + [t]
+        lines.append(".".join(p.replace("GO:", "") for p in path))
+    return json.dumps({"overrepresentation": {"group": groups}}), "\n".join(lines) + "\n", "\n".join(snp_genes) + "\n"
+
+
+def capture_go_builder(name):
+    """snps_graph.parse_go_json (the whole builder: :12-174, :251-293, :224-249 + the root-connection loader) run
+    from a scratch directory that holds the three synthetic input files under the reference's hard-wired paths."""
+    import tempfile
+    js, conn, s2g = synthetic_go_files()
+    for mod in ("requests", "bs4"):                                 # imported by the HTML scraper only
+        if mod not in sys.modules:
+            sys.modules[mod] = types.ModuleType(mod)
+    sys.modules["bs4"].BeautifulSoup = object
+    spec = importlib.util.spec_from_file_location("snps_get_root_go_by_html",
+                                                  os.path.join(REF, "snps_get_root_go_by_html.py"))
+    html_mod = importlib.util.module_from_spec(spec)
+    sys.modules["snps_get_root_go_by_html"] = html_mod
+    spec.loader.exec_module(html_mod)
+    spec = importlib.util.spec_from_file_location("snps_graph", os.path.join(REF, "snps_graph.py"))
+    sg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sg)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "data", "snps"))
+        open(os.path.join(tmp, "data", "snps", "analysis.json"), "w").write(js)
+        open(os.path.join(tmp, "data", "go_root_connection.txt"), "w").write(conn)
+        open(os.path.join(tmp, "data", "snps_to_gene.txt"), "w").write(s2g)
+        os.chdir(tmp)
+        try:
+            go_snps, adj, pool_dim, n_l, go_level, ids, genes = sg.parse_go_json("./data/snps/analysis.json")
+        finally:
+            os.chdir(cwd)
+    store = {"meta": np.array("reference snps_graph.parse_go_json executed on synthetic PANTHER-format inputs "
+                              "(requests / bs4 stubbed: imported by the HTML scraper only)"),
+             "json": np.array(js), "connection": np.array(conn), "snps_to_gene": np.array(s2g),
+             "go_snps": go_snps, "adj": adj, "pool_dim": np.asarray(pool_dim), "n_l": np.array(n_l),
+             "go_level": go_level, "ids": np.array(ids), "genes": np.array(json.dumps(genes))}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **store)
+    print("wrote", name, "nodes", len(ids), "pool", pool_dim, "edges", int(adj.sum()))
+
+
 def main():
     """``make_golden.py`` regenerates everything; ``make_golden.py NAME ...`` only the named fixtures."""
     torch.manual_seed(0)
@@ -321,6 +394,8 @@ def main():
     want = set(sys.argv[1:])
     if "gdc" in want or not want:
         capture_gdc("gdc")
+    if "go_builder" in want or not want:
+        capture_go_builder("go_builder")
     if want & {"sgcn_only"} or not want:
         spec = importlib.util.spec_from_file_location("kernel.sgcn", os.path.join(REF, "kernel/sgcn.py"))
         sgcn_mod = importlib.util.module_from_spec(spec)

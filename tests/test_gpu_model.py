@@ -460,3 +460,42 @@ def test_graphed_train_step_matches_eager(rois, dense):
         assert abs(l1 - l2) <= 1e-4 * max(1.0, abs(l2)), (l1, l2)
     for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert float((p1 - p2).abs().max()) <= 2e-4, k
+
+
+def test_model_on_builder_output_vs_oracle(golden, tmp_path):
+    """The GO-DAG builder's output (PANTHER-format JSON -> go_snps, adj, pool_dim) drives the HIP model; eval forward
+    and input gradient against the fp64 oracle on the same structure."""
+    from igcn_amd import go_builder, synth
+    from igcn_amd.data import Batch
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    from oracle import go_network as OG, sgcn_img_snp as OS
+    store = golden("go_builder")
+    (tmp_path / "a.json").write_text(str(store["json"]))
+    (tmp_path / "c.txt").write_text(str(store["connection"]))
+    (tmp_path / "s.txt").write_text(str(store["snps_to_gene"]))
+    go_snps, adj, pool_dim, _, _, _, _ = go_builder.parse_go_json(str(tmp_path / "a.json"), str(tmp_path / "c.txt"),
+                                                                   str(tmp_path / "s.txt"))
+    pool = [[int(v) for v in pool_dim[0]]]
+    a_g, a = go_builder.model_inputs(go_snps, adj, "cuda")
+    model = SGCN_GCN_IMGSNP(2, 8, a_g, a, pool, 32, "cuda", rois=90, H_0=3, num_classes=3, isSoftSimilarity=True,
+                            rbf_gamma=0.01, isCrossAtten=True, num_regr=3, isuseProb4Regr=True, isImageOnly=False,
+                            isSNPsOnly=False).cuda().eval()
+    sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, 13)
+    model.load_state_dict(sd)
+    graphs = synth.brain_graph_list(6, seed=9, rois=90, tsne_dim=16)
+    data = Batch.from_data_list(graphs).to("cuda")
+    outs = model(data, None, "cuda", isExplain=True)
+    cot = _probe(outs, 2)
+    sum((o * c.cuda()).sum() for o, c in zip(outs, cot)).backward()
+    a_g_c, a_c = go_builder.model_inputs(go_snps, adj)
+    idx = OG.go_index_sets(a_g_c, a_c, pool[0], 2)
+    sdo = OS.make_leaf_state(sd, dtype=torch.float64)
+    dcpu = Batch.from_data_list(graphs)
+    dcpu.x = dcpu.x.double().requires_grad_(True)
+    dcpu.edge_attr, dcpu.snps_feat = dcpu.edge_attr.double(), dcpu.snps_feat.double()
+    cfg = SimpleNamespace(num_layers=2, rois=90, image_only=False, rbf_gamma=0.01)
+    ref = OS.model_forward(sdo, cfg, idx, dcpu, True, training=False)
+    sum((o * c.double()).sum() for o, c in zip(ref, cot)).backward()
+    for n, o, r in zip(NAMES, outs, ref):
+        assert_matches(o, r.detach().numpy(), 1e-4, n)
+    assert_matches(data.x.grad, dcpu.x.grad.numpy(), 3e-3, "grad data.x")
