@@ -8,7 +8,6 @@ from types import SimpleNamespace
 import torch
 import torch.nn.functional as F
 
-from . import _lib
 from ._lib import call, ptr, stream_ptr
 
 # sgcn_hyperparameters.py:18-23
