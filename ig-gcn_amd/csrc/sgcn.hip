@@ -343,18 +343,37 @@ k_gcn_propagate_fwd_q(int64_t n_nodes, const float* __restrict__ h, int64_t ld_h
   const int fq = threadIdx.x % FQ;
   const int64_t t = (int64_t)blockIdx.x * NPB + threadIdx.x / FQ;
   if (t >= n_nodes) return;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int32_t p1 = tgt_ptr[t + 1];
-#pragma unroll 4
-  for (int32_t p = tgt_ptr[t]; p < p1; ++p) {
-    const EdgeRec e = tstream[p];
-    const float4 r = *reinterpret_cast<const float4*>(h + (int64_t)e.idx * ld_h + fq * 4);
-    acc.x += e.w * r.x; acc.y += e.w * r.y; acc.z += e.w * r.z; acc.w += e.w * r.w;
-  }
+  const int32_t p0 = tgt_ptr[t], p1 = tgt_ptr[t + 1];
+  // the self-loop operands do not depend on the edge walk: issue their loads first so that they are in flight
+  // together with the pointer / record / row chain instead of adding a fourth dependent round trip after it
   const float wl = what_loop[t];
   const float4 hs = *reinterpret_cast<const float4*>(h + t * ld_h + fq * 4);
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) b4 = *reinterpret_cast<const float4*>(bias + fq * 4);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // four edges per step, the tail predicated instead of peeled: a compiler-unrolled loop runs its remainder (ALL
+  // of a 3-edge walk) one load-wait-gather-wait at a time, this one has up to four record loads and then up to
+  // four row gathers in flight.  Same summation order as the plain loop.  (Clamping the tail to the last record
+  // instead of masking it costs 8%: the launch is close enough to the L2 request rate that a wasted gather shows.)
+  for (int32_t p = p0; p < p1; p += 4) {
+    EdgeRec e[4];
+    float4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      e[i].idx = 0; e[i].w = 0.f;
+      if (p + i < p1) e[i] = tstream[p + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p + i < p1) r[i] = *reinterpret_cast<const float4*>(h + (int64_t)e[i].idx * ld_h + fq * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (p + i < p1) {
+        acc.x += e[i].w * r[i].x; acc.y += e[i].w * r[i].y; acc.z += e[i].w * r[i].z; acc.w += e[i].w * r[i].w;
+      }
+  }
   acc.x += wl * hs.x + b4.x; acc.y += wl * hs.y + b4.y; acc.z += wl * hs.z + b4.z; acc.w += wl * hs.w + b4.w;
   if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
   *reinterpret_cast<float4*>(out + t * ld_out + fq * 4) = acc;
@@ -524,25 +543,44 @@ k_gcn_propagate_bwd_dh_q(int64_t n_nodes, const float* __restrict__ dout, int64_
   const int64_t s = (int64_t)blockIdx.x * NPB + nl;
   float4 gself = make_float4(0.f, 0.f, 0.f, 0.f);
   if (s < n_nodes) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int32_t p1 = src_ptr[s + 1];
-#pragma unroll 4
-    for (int32_t p = src_ptr[s]; p < p1; ++p) {
-      const EdgeRec e = sstream[p];
-      float4 g = *reinterpret_cast<const float4*>(dout + (int64_t)e.idx * ld_dout + fq * 4);
-      if (relu) {
-        const float4 o = *reinterpret_cast<const float4*>(out + (int64_t)e.idx * ld_out + fq * 4);
-        g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
-      }
-      acc.x += e.w * g.x; acc.y += e.w * g.y; acc.z += e.w * g.z; acc.w += e.w * g.w;
-    }
+    const int32_t p0 = src_ptr[s], p1 = src_ptr[s + 1];
+    // self-loop operands first: in flight together with the pointer / record / row chain
+    const float wl = what_loop[s];
     gself = *reinterpret_cast<const float4*>(dout + s * ld_dout + fq * 4);
     if (relu) {
       const float4 o = *reinterpret_cast<const float4*>(out + s * ld_out + fq * 4);
       gself.x = o.x > 0.f ? gself.x : 0.f; gself.y = o.y > 0.f ? gself.y : 0.f;
       gself.z = o.z > 0.f ? gself.z : 0.f; gself.w = o.w > 0.f ? gself.w : 0.f;
     }
-    const float wl = what_loop[s];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // four edges per step with a predicated tail (see k_gcn_propagate_fwd_q)
+    for (int32_t p = p0; p < p1; p += 4) {
+      EdgeRec e[4];
+      float4 g[4], o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i].idx = 0; e[i].w = 0.f;
+        if (p + i < p1) e[i] = sstream[p + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        o[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p + i < p1) {
+          g[i] = *reinterpret_cast<const float4*>(dout + (int64_t)e[i].idx * ld_dout + fq * 4);
+          if (relu) o[i] = *reinterpret_cast<const float4*>(out + (int64_t)e[i].idx * ld_out + fq * 4);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (p + i < p1) {
+          if (relu) {
+            g[i].x = o[i].x > 0.f ? g[i].x : 0.f; g[i].y = o[i].y > 0.f ? g[i].y : 0.f;
+            g[i].z = o[i].z > 0.f ? g[i].z : 0.f; g[i].w = o[i].w > 0.f ? g[i].w : 0.f;
+          }
+          acc.x += e[i].w * g[i].x; acc.y += e[i].w * g[i].y; acc.z += e[i].w * g[i].z; acc.w += e[i].w * g[i].w;
+        }
+    }
     acc.x += wl * gself.x; acc.y += wl * gself.y; acc.z += wl * gself.z; acc.w += wl * gself.w;
     *reinterpret_cast<float4*>(dh + s * ld_dh + fq * 4) = acc;
   }
