@@ -207,6 +207,14 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    # IGCN_BENCH_FORCE_DIST=1 with one rank: an RCCL process group of size 1 and the N>1 control flow (two graphs
+    # around the all-reduce) on a one-GPU box
+    force_dist = world == 1 and os.environ.get("IGCN_BENCH_FORCE_DIST", "0") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
@@ -236,8 +244,8 @@ def main():
     step = eager_step
     if not args.eager:
         try:
-            step = GraphedTrainStep(model, opt, data, world_size=world)     # whole step = one hipGraph replay
-            launch = "hipGraph replay"
+            step = GraphedTrainStep(model, opt, data, world_size=world, distributed=world > 1 or force_dist)
+            launch = "hipGraph replay"                  # the whole step (N>1: two graphs around the all-reduce)
         except Exception as exc:                  # noqa: BLE001 — a capture refused by the runtime must not sink the run
             print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running the eager step",
                   file=sys.stderr)
@@ -288,6 +296,7 @@ def main():
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()
+    if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -232,8 +232,12 @@ class GraphedTrainStep:
     faulted on this ROCm stack (known issues), while the same launches issued on the stream are fine.
     """
 
-    def __init__(self, model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, world_size=1, warmup=3):
+    def __init__(self, model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, world_size=1, warmup=3,
+                 distributed=None):
         self.model, self.opt, self.data, self.world = model, optimizer, data, world_size
+        # distributed=True with world_size 1 takes the multi-rank control flow (two graphs around a collective) on
+        # a single-rank process group: the rehearsal of the N>1 path that a one-GPU box allows
+        self.dist = dist = world_size > 1 if distributed is None else bool(distributed)
         self.lam, self.hp = lambda_loss, hp
         from . import ops
         self.plan = ops.plan_for(data)                  # static plan tensors: rebuilt in place every step
@@ -243,7 +247,7 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):
             for _ in range(warmup):                     # eager steps: allocator + library warm-up
                 self._fwd_bwd()
-                if world_size > 1:
+                if dist:
                     self.opt.pack_grads()
                     self._reduce()
                     self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
@@ -257,16 +261,16 @@ class GraphedTrainStep:
         # with a process group alive, its watchdog / progress threads may touch the runtime while this thread
         # captures: flag only this thread's unsafe calls (the launches of the autograd thread still land in the
         # capturing stream and are captured)
-        mode = "global" if world_size == 1 else "thread_local"
+        mode = "thread_local" if dist else "global"
         with torch.cuda.graph(self.g_main, capture_error_mode=mode):
             self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
-            if world_size == 1:
+            if not dist:
                 self.opt.step(refresh=False)            # reads the pointer table at replay time
             else:
                 self.opt.pack_grads(refresh=False)
         self.opt.refresh_table()                        # the captured gradient tensors keep their addresses
         self.g_opt = None
-        if world_size > 1:
+        if dist:
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=self.g_main.pool(), capture_error_mode=mode):
                 self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
@@ -285,7 +289,7 @@ class GraphedTrainStep:
         return loss.detach()
 
     def _reduce(self):
-        if self.world > 1:
+        if self.dist:
             torch.distributed.all_reduce(self.opt.grad)
 
     def load(self, batch):

@@ -462,6 +462,66 @@ def test_graphed_train_step_matches_eager(rois, dense):
         assert float((p1 - p2).abs().max()) <= 2e-4, k
 
 
+_DIST_SCRIPT = r"""
+import copy, os, sys, torch
+sys.path.insert(0, os.environ["IGCN_ROOT"])
+import igcn_amd  # noqa: F401
+from igcn_amd import synth
+from igcn_amd.data import Batch
+from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+from igcn_amd.train import FlatAdam, GraphedTrainStep, train_step
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29577")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+pool = (60, 30, 20, 9, 1)
+go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=2)
+a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+torch.manual_seed(3)
+m1 = SGCN_GCN_IMGSNP(2, 8, a_g, a, pool_dim, 32, "cuda", rois=90, H_0=3, num_classes=3, isSoftSimilarity=True,
+                     rbf_gamma=0.01, isCrossAtten=True, num_regr=3, isuseProb4Regr=True, isImageOnly=False,
+                     isSNPsOnly=False).cuda().train()
+for m in (m1, m1.go_network):
+    m._dropout_enabled = False
+m2 = copy.deepcopy(m1)
+batches = [Batch.from_data_list(synth.brain_graph_list(6, seed=50 + i, rois=90, tsne_dim=16)).to("cuda")
+           for i in range(3)]
+lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
+o1, o2 = FlatAdam(m1.parameters(), lr=1e-3), FlatAdam(m2.parameters(), lr=1e-3)
+static = Batch.from_data_list(synth.brain_graph_list(6, seed=50, rois=90, tsne_dim=16)).to("cuda")
+static.x.requires_grad_(True)
+snap = {k: v.detach().clone() for k, v in m1.state_dict().items()}
+step = GraphedTrainStep(m1, o1, static, lam, warmup=2, distributed=True)
+assert step.g_opt is not None
+m1.load_state_dict(snap)
+for t in (o1.exp_avg, o1.exp_avg_sq, o1.step_count):
+    t.zero_()
+for b in batches:
+    step.load(b)
+    l1 = float(step())
+    l2 = float(train_step(m2, o2, b, lam))
+    assert abs(l1 - l2) <= 1e-4 * max(1.0, abs(l2)), (l1, l2)
+for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+    assert float((p1 - p2).abs().max()) <= 2e-4, k
+torch.distributed.destroy_process_group()
+print("DIST-OK")
+"""
+
+
+def test_graphed_step_with_live_rccl_group():
+    """The N>1 control flow of GraphedTrainStep ([forward..backward, pack] graph -> all-reduce on the flat gradient ->
+    [Adam] graph, captured in thread-local mode while the process group's threads are alive) on a single-rank RCCL
+    group — the part of the multi-GPU path a one-GPU box can run — against the eager step of a twin model.  In a
+    child process, so that the process group does not outlive the test."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, IGCN_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", _DIST_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIST-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_model_on_builder_output_vs_oracle(golden, tmp_path):
     """The GO-DAG builder's output (PANTHER-format JSON -> go_snps, adj, pool_dim) drives the HIP model; eval forward
     and input gradient against the fp64 oracle on the same structure."""
