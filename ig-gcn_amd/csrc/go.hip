@@ -22,10 +22,10 @@ __global__ void k_spmm_fwd(int C, int I, int J, int64_t nnz, const int32_t* __re
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.y;
   const bool live = i < I;
-  const int ii = live ? i : I - 1;
   const float* xb = x + (int64_t)b * J;
-  const int32_t p0 = row_ptr[ii], p1 = row_ptr[ii + 1];
-  const bool heavy = live && (p1 - p0 > SPMM_HEAVY);
+  // lanes past the end get an EMPTY range: shadowing the last row would make them walk the hub serially
+  const int32_t p0 = live ? row_ptr[i] : 0, p1 = live ? row_ptr[i + 1] : 0;
+  const bool heavy = p1 - p0 > SPMM_HEAVY;
   for (int c = 0; c < C; ++c) {
     float acc = 0.f;
     if (!heavy)
@@ -84,9 +84,8 @@ __global__ void k_spmm_bwd_dx(int C, int I, int J, int64_t nnz, const int32_t* _
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.y;
   const bool live = j < J;
-  const int jj = live ? j : J - 1;
-  const int32_t q0 = t_ptr[jj], q1 = t_ptr[jj + 1];
-  const bool heavy = live && (q1 - q0 > SPMM_HEAVY);
+  const int32_t q0 = live ? t_ptr[j] : 0, q1 = live ? t_ptr[j + 1] : 0;     // empty range past the end
+  const bool heavy = q1 - q0 > SPMM_HEAVY;
   float acc = 0.f;
   if (!heavy) {
     for (int32_t q = q0; q < q1; ++q) {
@@ -378,8 +377,10 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
   const float* xb = x + (int64_t)b * FIN * N;
   const float* dyb = dy + (int64_t)b * FOUT * N;
   const float4* sp = reinterpret_cast<const float4*>(stats) + (int64_t)b * N;     // (p, q, zinv, tr) per node
-  const int32_t r0 = row_ptr[nn], r1 = row_ptr[nn + 1];
-  const int32_t c0 = t_ptr[nn], c1 = t_ptr[nn + 1];
+  // ... but with EMPTY edge ranges: N-1 is the root, and a dead lane walking its column list serially (it is not
+  // "heavy", being dead) used to set the duration of the whole kernel
+  const int32_t r0 = live ? row_ptr[n] : 0, r1 = live ? row_ptr[n + 1] : 0;
+  const int32_t c0 = live ? t_ptr[n] : 0, c1 = live ? t_ptr[n + 1] : 0;
   float xr[FIN], xin[FOUT], xs[FOUT], dyn[FOUT];
   load_node<FIN>(xb, N, nn, xr);
   load_node<FOUT>(dyb, N, nn, dyn);
@@ -406,7 +407,7 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
   float dq = 0.f, dxin[FOUT];
 #pragma unroll
   for (int c = 0; c < FOUT; ++c) dxin[c] = 0.f;
-  const bool heavy = live && (c1 - c0 > GO_HEAVY);
+  const bool heavy = c1 - c0 > GO_HEAVY;
   if (!heavy) {
     for (int32_t e = c0; e < c1; e += 2) {
       const bool two = e + 1 < c1;
@@ -1175,8 +1176,8 @@ k_go_decode_fwd(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const in
   float acc[FIN];
 #pragma unroll
   for (int d = 0; d < FIN; ++d) acc[d] = 0.f;
-  const int32_t p0 = row_ptr[rr], p1 = row_ptr[rr + 1];
-  const bool heavy = live && (p1 - p0 > GO_HEAVY);   // hub rows (a parent with many children): whole wave
+  const int32_t p0 = live ? row_ptr[rr] : 0, p1 = live ? row_ptr[rr + 1] : 0;     // empty range past the end
+  const bool heavy = p1 - p0 > GO_HEAVY;             // hub rows (a parent with many children): whole wave
   // the self term does not depend on the walk: its loads go out first
   float xs[FIN];
 #pragma unroll
@@ -1233,11 +1234,133 @@ k_go_decode_fwd(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const in
   for (int c = 0; c < FOUT; ++c) yb[c * Nout + r] = out[c];
 }
 
+// LDS-staged form.  The GO graph is very sparse (most rows of a decoder layer have no edge at all, a few have up to
+// a dozen, one hub has ~100) and identical for every sample, and a sample's [FIN][Nin] slab is 24 KB at most in the
+// shapes of the model.  In the global-memory kernel above a wave pays one dependent L2 round trip per edge step of
+// its LONGEST row (index, then FIN scalar gathers).  Here a 1024-thread workgroup copies the slab, its rows'
+// pointers and their column indices into LDS once (coalesced), and the walk never leaves LDS.
+#define GO_DEC_T 1024
+#define GO_DEC_ITERS 3
+#define GO_DEC_COLCAP 4096
+template <int FIN, int FOUT>
+__global__ void __launch_bounds__(GO_DEC_T)
+k_go_decode_fwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                    const float* __restrict__ x, const float* __restrict__ w_out, const float* __restrict__ w_sout,
+                    float* __restrict__ y) {
+  extern __shared__ float go_slab[];                   // [FIN][Nin] | rows+1 pointers | GO_DEC_COLCAP indices
+  constexpr int ROWS = GO_DEC_T * GO_DEC_ITERS;
+  const int total = FIN * Nin;
+  int32_t* rp = reinterpret_cast<int32_t*>(go_slab + ((total + 3) & ~3));
+  int32_t* cl = rp + ROWS + 4;
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int r_base = blockIdx.x * ROWS, nrows = min(Nout - r_base, ROWS);
+  const int32_t e_base = row_ptr[r_base], e_cnt = row_ptr[r_base + nrows] - e_base;
+  const bool col_lds = e_cnt <= GO_DEC_COLCAP;         // block-uniform; larger ranges are read from global memory
+  const float* xb = x + (int64_t)b * FIN * Nin;
+  if ((total & 3) == 0) {                              // slab base = b * total floats: 16-byte aligned with x
+    for (int i = threadIdx.x * 4; i < total; i += GO_DEC_T * 4)
+      *reinterpret_cast<float4*>(go_slab + i) = *reinterpret_cast<const float4*>(xb + i);
+  } else {
+    for (int i = threadIdx.x; i < total; i += GO_DEC_T) go_slab[i] = xb[i];
+  }
+  for (int i = threadIdx.x; i <= nrows; i += GO_DEC_T) rp[i] = row_ptr[r_base + i] - e_base;
+  if (col_lds)
+    for (int i = threadIdx.x; i < e_cnt; i += GO_DEC_T) cl[i] = col[e_base + i];
+  float wo[FOUT][FIN], wso[FOUT][FIN];
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c)
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) {
+      wo[c][d] = w_out[c * FIN + d];
+      wso[c][d] = w_sout[c * FIN + d];
+    }
+  __syncthreads();
+  const int32_t* cg = col + e_base;
+  const int off = Nout - Nin;
+  float* yb = y + (int64_t)b * FOUT * Nout;
+#pragma unroll 1
+  for (int it = 0; it < GO_DEC_ITERS; ++it) {
+    if (it * GO_DEC_T >= nrows) break;                 // block-uniform
+    const int rl = it * GO_DEC_T + threadIdx.x, r = r_base + rl;
+    const bool live = rl < nrows;
+    float acc[FIN];
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) acc[d] = 0.f;
+    const int32_t p0 = live ? rp[rl] : 0, p1 = live ? rp[rl + 1] : 0;     // lanes past the end walk nothing
+    const bool heavy = p1 - p0 > GO_HEAVY;
+    if (!heavy) {
+      for (int32_t e = p0; e < p1; e += 4) {           // four indices, then their gathers: two LDS round trips
+        int m[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = (e + i < p1) ? (col_lds ? cl[e + i] : cg[e + i]) : -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (m[i] >= 0) {
+#pragma unroll
+            for (int d = 0; d < FIN; ++d) acc[d] += go_slab[d * Nin + m[i]];
+          }
+      }
+    }
+    unsigned long long hmask = __ballot(heavy);
+    while (hmask) {                                    // hub rows: the whole wave walks the row
+      const int src = __ffsll((long long)hmask) - 1;
+      hmask &= hmask - 1;
+      const int32_t h0 = __shfl(p0, src, 64), h1 = __shfl(p1, src, 64);
+      float part[FIN];
+#pragma unroll
+      for (int d = 0; d < FIN; ++d) part[d] = 0.f;
+      for (int32_t e = h0 + lane; e < h1; e += 64) {
+        const int mm = col_lds ? cl[e] : cg[e];
+#pragma unroll
+        for (int d = 0; d < FIN; ++d) part[d] += go_slab[d * Nin + mm];
+      }
+#pragma unroll
+      for (int d = 0; d < FIN; ++d) part[d] = wave_sum_all(part[d]);
+      if (lane == src) {
+#pragma unroll
+        for (int d = 0; d < FIN; ++d) acc[d] = part[d];
+      }
+    }
+    if (live) {
+      const float inv = p1 > p0 ? 1.f / (float)(p1 - p0) : 0.f;
+      float out[FOUT];
+      transform<FIN, FOUT>(wo, acc, out);
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) out[c] *= inv;
+      if (r >= off) {
+        float xs[FIN], o2[FOUT];
+#pragma unroll
+        for (int d = 0; d < FIN; ++d) xs[d] = go_slab[d * Nin + (r - off)];
+        transform<FIN, FOUT>(wso, xs, o2);
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) out[c] += o2[c];
+      }
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) yb[c * Nout + r] = out[c];
+    }
+  }
+}
+
+static size_t go_dec_lds_bytes(int fin, int Nin) {
+  return ((((size_t)fin * Nin + 3) & ~(size_t)3) + GO_DEC_T * GO_DEC_ITERS + 4 + GO_DEC_COLCAP) * sizeof(float);
+}
+
 extern "C" int igcn_go_decode_fwd(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr,
                                   const int32_t* col, const float* x, const float* w_out, const float* w_sout,
                                   float* y, void* stream) {
   IGCN_REQUIRE(B > 0 && Nin > 0 && Nout >= Nin, "go_decode_fwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
+  const size_t lds = go_dec_lds_bytes(fin, Nin);
+  if (lds <= 64 * 1024 && ((uintptr_t)x % 16) == 0) {
+    dim3 lgrid((unsigned)igcn_cdiv(Nout, GO_DEC_T * GO_DEC_ITERS), B);
+#define CALL(FI, FO)                                                                                                \
+  hipLaunchKernelGGL((k_go_decode_fwd_lds<FI, FO>), lgrid, dim3(GO_DEC_T), lds, st, Nin, Nout, row_ptr, col, x, w_out, \
+                     w_sout, y)
+    GO_DISPATCH(fin, fout, CALL)
+#undef CALL
+    IGCN_CHECK_LAUNCH("go_decode_fwd_lds");
+    return IGCN_OK;
+  }
   dim3 grid((unsigned)igcn_cdiv(Nout, GO_T), B);
 #define CALL(FI, FO) \
   hipLaunchKernelGGL((k_go_decode_fwd<FI, FO>), grid, dim3(GO_T), 0, st, Nin, Nout, row_ptr, col, x, w_out, w_sout, y)

@@ -22,6 +22,14 @@ def has_gpu():
     return torch.cuda.is_available()
 
 
+def pytest_sessionstart(session):
+    """On a GPU box make sure libigcn.so matches the sources (a digest check; compiles only when the library is
+    missing or stale).  Test infrastructure only: the package itself never builds or falls back — it raises."""
+    if has_gpu():
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
