@@ -809,6 +809,257 @@ k_go_attn_bwd_main_bm(int B, int N, int npw, const int32_t* __restrict__ row_ptr
   }
 }
 
+// =================================================================================================
+// LDS-resident formulation of the backward: ONE 1024-thread workgroup per sample.  A sample's operands — x [FIN][N],
+// dy [FOUT][N] and the per-node softmax statistics — are 132 KB at most in the shapes of the model (N = 3000,
+// 2 -> 5), i.e. they fit the 160 KB of a CU.  The workgroup copies x and dy in once (coalesced), computes the
+// statistics of all nodes into LDS (what k_go_attn_bwd_stats writes to HBM), and then runs the walks of
+// k_go_attn_bwd_main with every gather — neighbour features, neighbour gradients, neighbour statistics — served
+// from LDS; only the CSR indices (identical for all samples, L2-resident) and the coalesced dx rows touch global
+// memory.  The parameter-gradient rows u (x) x of a thread's nodes wait in registers until the walks are done, then
+// go through the (now free) LDS to the matrix cores exactly as in the channel-major kernel.
+// =================================================================================================
+#define GO_ABL_T 1024
+#define GO_ABL_MAXIT 4
+template <int FIN, int FOUT>
+__global__ void __launch_bounds__(GO_ABL_T)
+k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                  const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ t_row, const float* __restrict__ x,
+                  const float* __restrict__ w_inc, const float* __restrict__ w_s, const float* __restrict__ a_in,
+                  const float* __restrict__ a_s, const float* __restrict__ dy, float* __restrict__ dx,
+                  float* __restrict__ gpart) {
+  extern __shared__ float go_abl[];
+  constexpr int ROWS = 2 * FOUT + 3, TP = GO_ABL_T + 4;
+  const int NP = (N + 3) & ~3;
+  float* xs = go_abl;                                   // [FIN][NP]
+  float* dys = xs + FIN * NP;                           // [FOUT][NP]
+  float4* st = reinterpret_cast<float4*>(dys + FOUT * NP);      // [N]: (p, q, 1/Z, tr/Z)
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const float* xb = x + (int64_t)b * FIN * N;
+  const float* dyb = dy + (int64_t)b * FOUT * N;
+  if (NP == N && (((uintptr_t)xb | (uintptr_t)dyb) & 15) == 0) {
+    for (int i = tid * 4; i < FIN * N; i += GO_ABL_T * 4)
+      *reinterpret_cast<float4*>(xs + i) = *reinterpret_cast<const float4*>(xb + i);
+    for (int i = tid * 4; i < FOUT * N; i += GO_ABL_T * 4)
+      *reinterpret_cast<float4*>(dys + i) = *reinterpret_cast<const float4*>(dyb + i);
+  } else {
+    for (int d = 0; d < FIN; ++d)
+      for (int n = tid; n < N; n += GO_ABL_T) xs[d * NP + n] = xb[d * N + n];
+    for (int c = 0; c < FOUT; ++c)
+      for (int n = tid; n < N; n += GO_ABL_T) dys[c * NP + n] = dyb[c * N + n];
+  }
+  AttnW<FIN, FOUT> W;
+  W.load(w_inc, w_s, a_in, a_s);
+  __syncthreads();
+
+  // ---- statistics of every node of the sample ----------------------------------------------------
+  for (int n = tid; n < N; n += GO_ABL_T) {
+    float xr[FIN], xin[FOUT];
+    load_node<FIN>(xs, NP, n, xr);
+    transform<FIN, FOUT>(W.wi, xr, xin);
+    const float p = dot<FOUT>(W.a1, xin), q = dot<FOUT>(W.a2, xin);
+    float Z = 0.f, agg[FOUT];
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) agg[c] = 0.f;
+    const int32_t p0 = row_ptr[n], p1 = row_ptr[n + 1];
+    for (int32_t e = p0; e < p1; e += 2) {              // two indices in flight
+      const bool two = e + 1 < p1;
+      const int m0 = col[e], m1 = col[two ? e + 1 : e];
+      float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
+      load_node<FIN>(xs, NP, m0, xm0);
+      load_node<FIN>(xs, NP, m1, xm1);
+      transform<FIN, FOUT>(W.wi, xm0, xi0);
+      transform<FIN, FOUT>(W.wi, xm1, xi1);
+      const float s0 = go_exp(go_tanh(p + dot<FOUT>(W.a2, xi0)));
+      Z += s0;
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) agg[c] += s0 * xi0[c];
+      if (two) {
+        const float s1 = go_exp(go_tanh(p + dot<FOUT>(W.a2, xi1)));
+        Z += s1;
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) agg[c] += s1 * xi1[c];
+      }
+    }
+    const float zinv = p1 > p0 ? 1.f / Z : 0.f;
+    float tr = 0.f;
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) tr += dys[c * NP + n] * agg[c];
+    st[n] = make_float4(p, q, zinv, tr * zinv);
+  }
+  __syncthreads();
+
+  // ---- walks: input gradient, parameter-gradient rows kept in registers ---------------------------
+  float uu[GO_ABL_MAXIT][ROWS], xx[GO_ABL_MAXIT][FIN];
+  float* dxb = dx + (int64_t)b * FIN * N;
+#pragma unroll
+  for (int it = 0; it < GO_ABL_MAXIT; ++it) {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) uu[it][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) xx[it][d] = 0.f;
+    if (it * GO_ABL_T < N) {                            // block-uniform
+      const int n = it * GO_ABL_T + tid;
+      const bool live = n < N;
+      const int nn = live ? n : N - 1;                  // dead lanes shadow a valid node with EMPTY edge ranges
+      const int32_t r0 = live ? row_ptr[n] : 0, r1 = live ? row_ptr[n + 1] : 0;
+      const int32_t c0 = live ? t_ptr[n] : 0, c1 = live ? t_ptr[n + 1] : 0;
+      float xr[FIN], xin[FOUT], xsl[FOUT], dyn[FOUT];
+      load_node<FIN>(xs, NP, nn, xr);
+      load_node<FOUT>(dys, NP, nn, dyn);
+      transform<FIN, FOUT>(W.wi, xr, xin);
+      transform<FIN, FOUT>(W.ws, xr, xsl);
+      const float4 st_n = st[nn];
+      const float p_n = st_n.x, q_n = st_n.y, zinv_n = st_n.z, tr_n = st_n.w;
+      float dp = 0.f;
+      for (int32_t e = r0; e < r1; e += 2) {            // n as ROW: d(score) of its own edges
+        const bool two = e + 1 < r1;
+        const int m0 = col[e], m1 = col[two ? e + 1 : e];
+        float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
+        load_node<FIN>(xs, NP, m0, xm0);
+        load_node<FIN>(xs, NP, m1, xm1);
+        const float q0 = st[m0].y, q1 = st[m1].y;
+        transform<FIN, FOUT>(W.wi, xm0, xi0);
+        transform<FIN, FOUT>(W.wi, xm1, xi1);
+        const float th0 = go_tanh(p_n + q0), th1 = go_tanh(p_n + q1);
+        dp += (dot<FOUT>(dyn, xi0) - tr_n) * (go_exp(th0) * zinv_n) * (1.f - th0 * th0);
+        if (two) dp += (dot<FOUT>(dyn, xi1) - tr_n) * (go_exp(th1) * zinv_n) * (1.f - th1 * th1);
+      }
+      float dq = 0.f, dxin[FOUT];                       // n as COLUMN: what the rows reading n send back
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c) dxin[c] = 0.f;
+      const bool heavy = c1 - c0 > GO_HEAVY;
+      if (!heavy) {
+        for (int32_t e = c0; e < c1; e += 2) {
+          const bool two = e + 1 < c1;
+          const int ra = t_row[e], rb = t_row[two ? e + 1 : e];
+          float dya[FOUT], dyb2[FOUT];
+          load_node<FOUT>(dys, NP, ra, dya);
+          load_node<FOUT>(dys, NP, rb, dyb2);
+          const float4 sa = st[ra], sb = st[rb];
+          const float tha = go_tanh(sa.x + q_n), thb = go_tanh(sb.x + q_n);
+          const float ala = go_exp(tha) * sa.z, alb = two ? go_exp(thb) * sb.z : 0.f;
+          dq += (dot<FOUT>(dya, xin) - sa.w) * ala * (1.f - tha * tha);
+#pragma unroll
+          for (int c = 0; c < FOUT; ++c) dxin[c] += ala * dya[c];
+          if (two) {
+            dq += (dot<FOUT>(dyb2, xin) - sb.w) * alb * (1.f - thb * thb);
+#pragma unroll
+            for (int c = 0; c < FOUT; ++c) dxin[c] += alb * dyb2[c];
+          }
+        }
+      }
+      unsigned long long hmask = __ballot(heavy);
+      while (hmask) {                                   // hub columns: the whole wave strides the list
+        const int src = __ffsll((long long)hmask) - 1;
+        hmask &= hmask - 1;
+        const int32_t hc0 = __shfl(c0, src, 64), hc1 = __shfl(c1, src, 64);
+        const float hq = __shfl(q_n, src, 64);
+        float hxin[FOUT];
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) hxin[c] = __shfl(xin[c], src, 64);
+        float pdq = 0.f, pdx[FOUT];
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) pdx[c] = 0.f;
+        for (int32_t e = hc0 + lane; e < hc1; e += 64) {
+          const int r = t_row[e];
+          float dyr[FOUT];
+          load_node<FOUT>(dys, NP, r, dyr);
+          const float4 sr = st[r];
+          const float th = go_tanh(sr.x + hq);
+          const float alpha = go_exp(th) * sr.z;
+          pdq += (dot<FOUT>(dyr, hxin) - sr.w) * alpha * (1.f - th * th);
+#pragma unroll
+          for (int c = 0; c < FOUT; ++c) pdx[c] += alpha * dyr[c];
+        }
+        pdq = wave_sum_all(pdq);
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) pdx[c] = wave_sum_all(pdx[c]);
+        if (lane == src) {
+          dq = pdq;
+#pragma unroll
+          for (int c = 0; c < FOUT; ++c) dxin[c] = pdx[c];
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) dxin[c] += dp * W.a1[c] + dq * W.a2[c];
+        const float g = 1.f / (1.f + go_exp(-dot<FOUT>(W.as, xsl)));       // gated self term
+        const float dgate = dot<FOUT>(dyn, xsl) * g * (1.f - g);
+        float dxs[FOUT];
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) dxs[c] = dyn[c] * g + dgate * W.as[c];
+#pragma unroll
+        for (int d = 0; d < FIN; ++d) {
+          float t = 0.f;
+#pragma unroll
+          for (int c = 0; c < FOUT; ++c) t += W.wi[c][d] * dxin[c] + W.ws[c][d] * dxs[c];
+          dxb[d * N + n] = t;
+        }
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) {
+          uu[it][c] = dxin[c];
+          uu[it][FOUT + c] = dxs[c];
+        }
+        uu[it][2 * FOUT] = dp;
+        uu[it][2 * FOUT + 1] = dq;
+        uu[it][2 * FOUT + 2] = dgate;
+#pragma unroll
+        for (int d = 0; d < FIN; ++d) xx[it][d] = xr[d];
+      }
+    }
+  }
+  __syncthreads();                                      // the slabs are dead: LDS becomes the MFMA staging area
+
+  // ---- G[ROWS, FIN] += u (x) x over the sample's nodes on the matrix cores ----------------------
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  float* us = go_abl;                                   // [ROWS][TP]
+  float* xt = us + ROWS * TP;                           // [FIN][TP]
+  const int w = tid >> 6, m = lane & 15, g4 = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < GO_ABL_MAXIT; ++it) {
+    if (it * GO_ABL_T < N) {                            // block-uniform
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) us[r * TP + tid] = uu[it][r];
+#pragma unroll
+      for (int d = 0; d < FIN; ++d) xt[d * TP + tid] = xx[it][d];
+      __syncthreads();
+      const float* ua = us + (m < ROWS ? m : 0) * TP + 64 * w + g4;
+      const float* xa = xt + (m < FIN ? m : 0) * TP + 64 * w + g4;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float a = (m < ROWS) ? ua[4 * c] : 0.f;
+        const float bq = (m < FIN) ? xa[4 * c] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  float* wsum = go_abl;                                 // [16 waves * 4][64]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wsum[(w * 4 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (w == 0 && m < FIN) {
+    const int64_t parts = gridDim.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * g4 + r < ROWS) {
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < GO_ABL_T / 64; ++ww) t += wsum[(ww * 4 + r) * 64 + lane];
+        gpart[(int64_t)((4 * g4 + r) * FIN + m) * parts + b] = t;
+      }
+  }
+}
+
+static size_t go_abl_lds_bytes(int N, int fin, int fout) {
+  const size_t np = ((size_t)N + 3) & ~(size_t)3;
+  const size_t slabs = (size_t)(fin + fout + 4) * np * sizeof(float);
+  const size_t stage = (size_t)(2 * fout + 3 + fin) * (GO_ABL_T + 4) * sizeof(float);
+  return slabs > stage ? slabs : stage;
+}
+
 static int go_bm_npw(int B, int N) {
   const int64_t pairs = (int64_t)N * igcn_cdiv(B, 64);     // (node, sample tile) units of wave work
   int64_t npw = pairs / 8192;                               // >= ~8 k waves: latency hidden by occupancy
@@ -817,14 +1068,18 @@ static int go_bm_npw(int B, int N) {
   return (int)npw;
 }
 
-static bool go_use_bm(void) {
-  static int cm_only = -1;                                  // IGCN_GO_ATTN_CM=1: channel-major kernels (A/B runs)
-  if (cm_only < 0) {
-    const char* e = getenv("IGCN_GO_ATTN_CM");
-    cm_only = (e && e[0] == '1') ? 1 : 0;
+// Variant of the backward (A/B runs): default = LDS-resident kernel when the sample fits, else channel-major;
+// IGCN_GO_ATTN_CM=1 forces the channel-major global-memory kernels, IGCN_GO_ATTN_BM=1 the batch-minor formulation.
+static int go_attn_variant(void) {
+  static int v = -1;
+  if (v < 0) {
+    const char* cm = getenv("IGCN_GO_ATTN_CM");
+    const char* bm = getenv("IGCN_GO_ATTN_BM");
+    v = (cm && cm[0] == '1') ? 1 : ((bm && bm[0] == '1') ? 2 : 0);
   }
-  return !cm_only;
+  return v;
 }
+static bool go_use_bm(void) { return go_attn_variant() == 2; }
 
 extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
                                 const int32_t* t_ptr, const int32_t* t_row, const float* x, const float* w_inc,
@@ -833,6 +1088,30 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
   IGCN_REQUIRE(B > 0 && N > 0, "go_attn_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = 2 * fout + 3;
+  const size_t abl_lds = go_abl_lds_bytes(N, fin, fout);
+  if (go_attn_variant() == 0 && abl_lds <= 160 * 1024 && N <= GO_ABL_T * GO_ABL_MAXIT) {
+    float* gpart = scratch;                                         // [rows * fin][B] block partials
+    float* G = gpart + (int64_t)B * rows * fin;
+#define CALLL(FI, FO)                                                                                             \
+  {                                                                                                               \
+    static bool attr = false;                                                                                     \
+    if (!attr) {                                                                                                  \
+      hipFuncSetAttribute((const void*)k_go_attn_bwd_lds<FI, FO>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                          160 * 1024);                                                                            \
+      attr = true;                                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL((k_go_attn_bwd_lds<FI, FO>), dim3(B), dim3(GO_ABL_T), abl_lds, st, N, row_ptr, col, t_ptr, \
+                       t_row, x, w_inc, w_s, a_in, a_s, dy, dx, gpart);                                           \
+  }
+    GO_DISPATCH(fin, fout, CALLL)
+#undef CALLL
+    IGCN_CHECK_LAUNCH("go_attn_bwd(lds)");
+    int rc = igcn_launch_reduce_contig(gpart, B, (int)(rows * fin), G, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_go_attn_bwd_finish, dim3(1), dim3(128), 0, st, fin, fout, G, w_inc, w_s, dparams);
+    IGCN_CHECK_LAUNCH("go_attn_bwd_finish");
+    return IGCN_OK;
+  }
   if (go_use_bm() && (int64_t)(fin > fout ? fin : fout) * N * B < ((int64_t)1 << 31)) {
     const int64_t nb = ((int64_t)N * B + 3) & ~(int64_t)3;          // sections start on 16-byte boundaries
     float* xb = scratch;
