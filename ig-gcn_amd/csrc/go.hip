@@ -821,7 +821,7 @@ k_go_attn_bwd_main_bm(int B, int N, int npw, const int32_t* __restrict__ row_ptr
 // =================================================================================================
 #define GO_ABL_T 1024
 #define GO_ABL_MAXIT 4
-template <int FIN, int FOUT>
+template <int FIN, int FOUT, int MAXIT>
 __global__ void __launch_bounds__(GO_ABL_T)
 k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
                   const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ t_row, const float* __restrict__ x,
@@ -837,6 +837,15 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const float* xb = x + (int64_t)b * FIN * N;
   const float* dyb = dy + (int64_t)b * FOUT * N;
+  // CSR pointers of this thread's nodes: issued before the slab copy so that their latency hides behind it
+  int32_t pr0[MAXIT], pr1[MAXIT], pc0[MAXIT], pc1[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int n = it * GO_ABL_T + tid;
+    const bool live = n < N;                            // lanes past the end: EMPTY edge ranges
+    pr0[it] = live ? row_ptr[n] : 0; pr1[it] = live ? row_ptr[n + 1] : 0;
+    pc0[it] = live ? t_ptr[n] : 0; pc1[it] = live ? t_ptr[n + 1] : 0;
+  }
   if (NP == N && (((uintptr_t)xb | (uintptr_t)dyb) & 15) == 0) {
     for (int i = tid * 4; i < FIN * N; i += GO_ABL_T * 4)
       *reinterpret_cast<float4*>(xs + i) = *reinterpret_cast<const float4*>(xb + i);
@@ -848,12 +857,25 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
     for (int c = 0; c < FOUT; ++c)
       for (int n = tid; n < N; n += GO_ABL_T) dys[c * NP + n] = dyb[c * N + n];
   }
+  // ... and the first two neighbours of each list (the GO DAG rarely has more: the walks then never wait on L2)
+  int pm0[MAXIT], pm1[MAXIT], pra[MAXIT], prb[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int dr = pr1[it] - pr0[it], dc = pc1[it] - pc0[it];
+    pm0[it] = dr > 0 ? col[pr0[it]] : 0;
+    pm1[it] = dr > 1 ? col[pr0[it] + 1] : 0;
+    pra[it] = dc > 0 ? t_row[pc0[it]] : 0;
+    prb[it] = dc > 1 ? t_row[pc0[it] + 1] : 0;
+  }
   AttnW<FIN, FOUT> W;
   W.load(w_inc, w_s, a_in, a_s);
   __syncthreads();
 
   // ---- statistics of every node of the sample ----------------------------------------------------
-  for (int n = tid; n < N; n += GO_ABL_T) {
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int n = it * GO_ABL_T + tid;
+    if (n >= N) continue;
     float xr[FIN], xin[FOUT];
     load_node<FIN>(xs, NP, n, xr);
     transform<FIN, FOUT>(W.wi, xr, xin);
@@ -861,10 +883,10 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
     float Z = 0.f, agg[FOUT];
 #pragma unroll
     for (int c = 0; c < FOUT; ++c) agg[c] = 0.f;
-    const int32_t p0 = row_ptr[n], p1 = row_ptr[n + 1];
-    for (int32_t e = p0; e < p1; e += 2) {              // two indices in flight
+    const int32_t p0 = pr0[it], p1 = pr1[it];
+    for (int32_t e = p0; e < p1; e += 2) {              // two edges per step, the first pair already in registers
       const bool two = e + 1 < p1;
-      const int m0 = col[e], m1 = col[two ? e + 1 : e];
+      const int m0 = e == p0 ? pm0[it] : col[e], m1 = two ? (e == p0 ? pm1[it] : col[e + 1]) : m0;
       float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
       load_node<FIN>(xs, NP, m0, xm0);
       load_node<FIN>(xs, NP, m1, xm1);
@@ -890,10 +912,10 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
   __syncthreads();
 
   // ---- walks: input gradient, parameter-gradient rows kept in registers ---------------------------
-  float uu[GO_ABL_MAXIT][ROWS], xx[GO_ABL_MAXIT][FIN];
+  float uu[MAXIT][ROWS], xx[MAXIT][FIN];
   float* dxb = dx + (int64_t)b * FIN * N;
 #pragma unroll
-  for (int it = 0; it < GO_ABL_MAXIT; ++it) {
+  for (int it = 0; it < MAXIT; ++it) {
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) uu[it][r] = 0.f;
 #pragma unroll
@@ -902,8 +924,7 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
       const int n = it * GO_ABL_T + tid;
       const bool live = n < N;
       const int nn = live ? n : N - 1;                  // dead lanes shadow a valid node with EMPTY edge ranges
-      const int32_t r0 = live ? row_ptr[n] : 0, r1 = live ? row_ptr[n + 1] : 0;
-      const int32_t c0 = live ? t_ptr[n] : 0, c1 = live ? t_ptr[n + 1] : 0;
+      const int32_t r0 = pr0[it], r1 = pr1[it], c0 = pc0[it], c1 = pc1[it];
       float xr[FIN], xin[FOUT], xsl[FOUT], dyn[FOUT];
       load_node<FIN>(xs, NP, nn, xr);
       load_node<FOUT>(dys, NP, nn, dyn);
@@ -914,7 +935,7 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
       float dp = 0.f;
       for (int32_t e = r0; e < r1; e += 2) {            // n as ROW: d(score) of its own edges
         const bool two = e + 1 < r1;
-        const int m0 = col[e], m1 = col[two ? e + 1 : e];
+        const int m0 = e == r0 ? pm0[it] : col[e], m1 = two ? (e == r0 ? pm1[it] : col[e + 1]) : m0;
         float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
         load_node<FIN>(xs, NP, m0, xm0);
         load_node<FIN>(xs, NP, m1, xm1);
@@ -932,7 +953,7 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
       if (!heavy) {
         for (int32_t e = c0; e < c1; e += 2) {
           const bool two = e + 1 < c1;
-          const int ra = t_row[e], rb = t_row[two ? e + 1 : e];
+          const int ra = e == c0 ? pra[it] : t_row[e], rb = two ? (e == c0 ? prb[it] : t_row[e + 1]) : ra;
           float dya[FOUT], dyb2[FOUT];
           load_node<FOUT>(dys, NP, ra, dya);
           load_node<FOUT>(dys, NP, rb, dyb2);
@@ -1018,7 +1039,7 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
   const int w = tid >> 6, m = lane & 15, g4 = lane >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int it = 0; it < GO_ABL_MAXIT; ++it) {
+  for (int it = 0; it < MAXIT; ++it) {
     if (it * GO_ABL_T < N) {                            // block-uniform
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) us[r * TP + tid] = uu[it][r];
@@ -1092,19 +1113,24 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
   if (go_attn_variant() == 0 && abl_lds <= 160 * 1024 && N <= GO_ABL_T * GO_ABL_MAXIT) {
     float* gpart = scratch;                                         // [rows * fin][B] block partials
     float* G = gpart + (int64_t)B * rows * fin;
-#define CALLL(FI, FO)                                                                                             \
+    const int iters = (int)igcn_cdiv(N, GO_ABL_T);
+#define CALLLI(FI, FO, MI)                                                                                        \
   {                                                                                                               \
     static bool attr = false;                                                                                     \
     if (!attr) {                                                                                                  \
-      hipFuncSetAttribute((const void*)k_go_attn_bwd_lds<FI, FO>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+      hipFuncSetAttribute((const void*)k_go_attn_bwd_lds<FI, FO, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                           160 * 1024);                                                                            \
       attr = true;                                                                                                \
     }                                                                                                             \
-    hipLaunchKernelGGL((k_go_attn_bwd_lds<FI, FO>), dim3(B), dim3(GO_ABL_T), abl_lds, st, N, row_ptr, col, t_ptr, \
-                       t_row, x, w_inc, w_s, a_in, a_s, dy, dx, gpart);                                           \
+    hipLaunchKernelGGL((k_go_attn_bwd_lds<FI, FO, MI>), dim3(B), dim3(GO_ABL_T), abl_lds, st, N, row_ptr, col,    \
+                       t_ptr, t_row, x, w_inc, w_s, a_in, a_s, dy, dx, gpart);                                    \
   }
+#define CALLL(FI, FO)                                                                                             \
+  if (iters <= 1) CALLLI(FI, FO, 1) else if (iters == 2) CALLLI(FI, FO, 2) else if (iters == 3) CALLLI(FI, FO, 3) \
+  else CALLLI(FI, FO, 4)
     GO_DISPATCH(fin, fout, CALLL)
 #undef CALLL
+#undef CALLLI
     IGCN_CHECK_LAUNCH("go_attn_bwd(lds)");
     int rc = igcn_launch_reduce_contig(gpart, B, (int)(rows * fin), G, st);
     if (rc) return rc;
@@ -1714,6 +1740,124 @@ k_go_decode_bwd(int B, int Nin, int Nout, const int32_t* __restrict__ row_ptr, c
   block_reduce_vec<NW>(gw, red, partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NW);
 }
 
+// LDS-resident form, one 1024-thread workgroup per sample: the sample's dy slab [FOUT][Nout] and the rows' inverse
+// degrees live in LDS, so the walk over a node's readers gathers from there; the parameter-gradient products
+// (G | G_self) (x) x go through LDS to the matrix cores once per 1024 nodes and leave the workgroup as ONE partial per
+// sample (the thread-per-node kernel above reduces 2*FOUT*FIN values per 256 nodes and writes 5x as many partials).
+#define GO_DBL_T 1024
+template <int FIN, int FOUT>
+__global__ void __launch_bounds__(GO_DBL_T)
+k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ t_ptr,
+                    const int32_t* __restrict__ t_row, const float* __restrict__ x, const float* __restrict__ w_out,
+                    const float* __restrict__ w_sout, const float* __restrict__ dy, float* __restrict__ dx,
+                    float* __restrict__ partial) {
+  extern __shared__ float go_dbl[];
+  constexpr int ROWS = 2 * FOUT, TP = GO_DBL_T + 4, NW = 2 * FOUT * FIN;
+  const int NPo = (Nout + 3) & ~3;
+  float* dys = go_dbl;                                  // [FOUT][NPo]
+  float* inv = dys + FOUT * NPo;                        // [NPo]  1 / (row degree)
+  float* us = inv + NPo;                                // [ROWS][TP]
+  float* xt = us + ROWS * TP;                           // [FIN][TP]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const float* dyb = dy + (int64_t)b * FOUT * Nout;
+  if (NPo == Nout && ((uintptr_t)dyb & 15) == 0) {
+    for (int i = tid * 4; i < FOUT * Nout; i += GO_DBL_T * 4)
+      *reinterpret_cast<float4*>(dys + i) = *reinterpret_cast<const float4*>(dyb + i);
+  } else {
+    for (int c = 0; c < FOUT; ++c)
+      for (int r = tid; r < Nout; r += GO_DBL_T) dys[c * NPo + r] = dyb[c * Nout + r];
+  }
+  for (int r = tid; r < Nout; r += GO_DBL_T) {
+    const int32_t d = row_ptr[r + 1] - row_ptr[r];
+    inv[r] = d > 0 ? 1.f / (float)d : 0.f;
+  }
+  float wo[FOUT][FIN], wso[FOUT][FIN];
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c)
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) {
+      wo[c][d] = w_out[c * FIN + d];
+      wso[c][d] = w_sout[c * FIN + d];
+    }
+  __syncthreads();
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int w = tid >> 6, mm = lane & 15, g4 = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int off = Nout - Nin;
+  const float* xb = x + (int64_t)b * FIN * Nin;
+  float* dxb = dx + (int64_t)b * FIN * Nin;
+#pragma unroll 1
+  for (int base = 0; base < Nin; base += GO_DBL_T) {    // block-uniform
+    const int m = base + tid;
+    float G[FOUT], Gs[FOUT], xr[FIN];
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) G[c] = Gs[c] = 0.f;
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) xr[d] = 0.f;
+    if (m < Nin) {
+      const int32_t c0 = t_ptr[m], c1 = t_ptr[m + 1];
+      load_node<FIN>(xb, Nin, m, xr);
+      load_node<FOUT>(dys, NPo, m + off, Gs);
+      for (int32_t e = c0; e < c1; e += 2) {            // two reader indices in flight, then LDS gathers
+        const bool two = e + 1 < c1;
+        const int ra = t_row[e], rb = t_row[two ? e + 1 : e];
+        float ya[FOUT], yb2[FOUT];
+        load_node<FOUT>(dys, NPo, ra, ya);
+        load_node<FOUT>(dys, NPo, rb, yb2);
+        const float ia = inv[ra], ib = inv[rb];
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) {
+          G[c] += ya[c] * ia;
+          if (two) G[c] += yb2[c] * ib;
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < FIN; ++d) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < FOUT; ++c) t += wo[c][d] * G[c] + wso[c][d] * Gs[c];
+        dxb[d * Nin + m] = t;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) {
+      us[c * TP + tid] = G[c];
+      us[(FOUT + c) * TP + tid] = Gs[c];
+    }
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) xt[d * TP + tid] = xr[d];
+    __syncthreads();
+    const float* ua = us + (mm < ROWS ? mm : 0) * TP + 64 * w + g4;
+    const float* xa = xt + (mm < FIN ? mm : 0) * TP + 64 * w + g4;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float a = (mm < ROWS) ? ua[4 * c] : 0.f;
+      const float bq = (mm < FIN) ? xa[4 * c] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* wsum = us;                                     // [16 waves * 4][64] <= ROWS * TP floats (ROWS >= 4)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wsum[(w * 4 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (w == 0 && mm < FIN) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * g4 + r < ROWS) {
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < GO_DBL_T / 64; ++ww) t += wsum[(ww * 4 + r) * 64 + lane];
+        partial[(int64_t)b * NW + (4 * g4 + r) * FIN + mm] = t;
+      }
+  }
+}
+
+static size_t go_dbl_lds_bytes(int Nout, int fin, int fout) {
+  const size_t npo = ((size_t)Nout + 3) & ~(size_t)3;
+  return ((size_t)(fout + 1) * npo + (size_t)(2 * fout + fin) * (GO_DBL_T + 4)) * sizeof(float);
+}
+
 extern "C" size_t igcn_go_decode_bwd_scratch_floats(int B, int Nin, int fin, int fout) {
   return (size_t)(igcn_cdiv(Nin, GO_T) * igcn_cdiv(B, GO_SB) * 2 * fout * fin + 64);
 }
@@ -1724,8 +1868,26 @@ extern "C" int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, c
                                   void* stream) {
   IGCN_REQUIRE(B > 0 && Nin > 0 && Nout >= Nin, "go_decode_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((unsigned)igcn_cdiv(Nin, GO_T), (unsigned)igcn_cdiv(B, GO_SB));
   const int nw = 2 * fout * fin;
+  const size_t lds = go_dbl_lds_bytes(Nout, fin, fout);
+  if (lds <= 160 * 1024 && 2 * fout >= 4) {
+#define CALL(FI, FO)                                                                                             \
+  {                                                                                                               \
+    static bool attr = false;                                                                                     \
+    if (!attr) {                                                                                                  \
+      hipFuncSetAttribute((const void*)k_go_decode_bwd_lds<FI, FO>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                          160 * 1024);                                                                            \
+      attr = true;                                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL((k_go_decode_bwd_lds<FI, FO>), dim3(B), dim3(GO_DBL_T), lds, st, Nin, Nout, row_ptr, t_ptr, \
+                       t_row, x, w_out, w_sout, dy, dx, scratch);                                                 \
+  }
+    GO_DISPATCH(fin, fout, CALL)
+#undef CALL
+    IGCN_CHECK_LAUNCH("go_decode_bwd(lds)");
+    return igcn_launch_reduce_rows(scratch, B, nw, nw, dparams, 0, st);
+  }
+  dim3 grid((unsigned)igcn_cdiv(Nin, GO_T), (unsigned)igcn_cdiv(B, GO_SB));
 #define CALL(FI, FO)                                                                                             \
   hipLaunchKernelGGL((k_go_decode_bwd<FI, FO>), grid, dim3(GO_T), 0, st, B, Nin, Nout, row_ptr, t_ptr, t_row, x, \
                      w_out, w_sout, dy, dx, scratch)
