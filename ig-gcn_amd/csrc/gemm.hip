@@ -183,6 +183,26 @@ __global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const fl
   C[m * ldc + n] = t;
 }
 
+// Launch shape, fitted to a sweep over the products of the train step (tools/gemm_sweep.py): the tile is 64 x BN.
+// A wide tile only pays when there are tens of thousands of rows to stream; otherwise narrower tiles put more
+// workgroups (one per CU is the common case here) on the chip.  K is split so that ~384 workgroups exist, each
+// keeping at least one 32-deep K step.
+static int gemm_tile_n(int64_t M, int64_t N) {
+  if (N <= 16) return 16;
+  if (N <= 32) return 32;
+  if (M >= 32768) return 64;
+  return igcn_cdiv(M, G_BM) * igcn_cdiv(N, 32) < 128 ? 16 : 32;
+}
+
+extern "C" int igcn_gemm_f32_split_k(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K < 128) return 1;
+  const int64_t tiles = igcn_cdiv(M, G_BM) * igcn_cdiv(N, gemm_tile_n(M, N));
+  if (tiles >= 192) return 1;
+  int64_t sk = (384 + tiles / 2) / tiles;
+  if (sk > K / G_BK) sk = K / G_BK;
+  return (int)(sk < 1 ? 1 : sk);
+}
+
 extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t sam, int64_t sak,
                              const float* B, int64_t sbn, int64_t sbk, const float* bias, float* C, int64_t ldc,
                              int act, int split_k, float* scratch, void* stream) {
@@ -198,7 +218,8 @@ extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, in
   float* out = split ? scratch : C;
   const int64_t ld = split ? N : ldc;
   const int64_t slab = split ? M * N : 0;
-  const int bn = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+  int bn = gemm_tile_n(M, N);
+  if (const char* cap = getenv("IGCN_GEMM_BN")) bn = atoi(cap) < bn ? atoi(cap) : bn;      // sweeps only
   dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)split_k);
   const int vw = min_int(vec_width(A, sam, sak, M, K), vec_width(B, sbn, sbk, N, K));
 #define LAUNCH_G(BNV, VECV)                                                                                    \

@@ -237,11 +237,8 @@ class GcnPropagate(torch.autograd.Function):
 # Dense transforms on MFMA
 # =================================================================================================
 def _split_k(m, n, k):
-    """Enough K-slices to put >= ~256 workgroups on the chip when the output has few tiles."""
-    tiles = ((m + 63) // 64) * ((n + 63) // 64)
-    if tiles >= 128 or k < 256:
-        return 1
-    return int(max(1, min(k // 64, (512 + tiles - 1) // tiles)))
+    """K-slices for a product with few output tiles: the library's own launch heuristic (gemm.hip)."""
+    return int(_lib.load().igcn_gemm_f32_split_k(m, n, k))
 
 
 def gemm_nt(a, b, bias=None, act=0, out=None):

@@ -149,6 +149,9 @@ int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F,
  * split_k > 1 writes split_k partial slabs into `scratch` (float[split_k*M*N]) and reduces them in order
  * (deterministic).  act: 0 none, 1 relu.
  */
+/* The split the library's launch heuristic prefers for (M, N, K): callers size `scratch` with it and pass it as
+ * `split_k` (any other value >= 1 is honoured too). */
+int igcn_gemm_f32_split_k(int64_t M, int64_t N, int64_t K);
 int igcn_gemm_f32(int64_t M, int64_t N, int64_t K,
                   const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
                   const float* bias, float* C, int64_t ldc, int act, int split_k, float* scratch,
