@@ -167,7 +167,11 @@ def _hier(pool, seed):
 
 
 @pytest.mark.parametrize("bsz,pool,fin,seed", [(4, (20, 10, 6, 3, 1), 2, 0), (16, (300, 120, 60, 19, 1), 2, 1),
-                                               (5, (40, 20, 9, 2, 1), 5, 2)])
+                                               (5, (40, 20, 9, 2, 1), 5, 2),
+                                               # the bench hierarchy: 3000 / 1200 nodes = 3 / 2 passes of the
+                                               # LDS-resident backward's 1024 threads, and the 99-reader hub
+                                               (3, (1800, 800, 300, 99, 1), 2, 3), (3, (1800, 800, 300, 99, 1), 5, 4),
+                                               (2, (1801, 800, 300, 99, 1), 2, 5)])
 def test_go_attention_layer(ops, bsz, pool, fin, seed):
     _, _, _, idx = _hier(pool, seed)
     layer = 0 if fin == 2 else 1
@@ -222,7 +226,9 @@ def test_nodes_layernorm(ops, bsz, f, n, pool, with_keep):
 
 
 @pytest.mark.parametrize("bsz,pool,layer,seed", [(4, (20, 10, 6, 3, 1), 0, 0), (4, (20, 10, 6, 3, 1), 1, 1),
-                                                 (9, (300, 120, 60, 19, 1), 0, 2), (9, (300, 120, 60, 19, 1), 1, 3)])
+                                                 (9, (300, 120, 60, 19, 1), 0, 2), (9, (300, 120, 60, 19, 1), 1, 3),
+                                                 (3, (1800, 800, 300, 99, 1), 0, 4), (3, (1800, 800, 300, 99, 1), 1, 5),
+                                                 (2, (1801, 800, 300, 99, 1), 1, 6)])
 def test_go_decoder_layer(ops, bsz, pool, layer, seed):
     _, _, _, idx = _hier(pool, seed)
     row, col, n_rows, n_cols = idx["dec"][layer]
@@ -592,9 +598,10 @@ np.savez(sys.argv[2], y=y.detach().cpu().numpy(), o=o.detach().cpu().numpy(),
 
 
 def test_alternative_kernel_variants_agree(tmp_path):
-    """The A/B switches stay honest: the channel-major GO attention backward (IGCN_GO_ATTN_CM=1) and the VALU attention
-    core (IGCN_ATTN_VALU=1) give the numbers of the default batch-minor / matrix-core kernels.  The switches are read
-    once per process, so each variant runs in a short child process (one at a time)."""
+    """The A/B switches stay honest: the channel-major (IGCN_GO_ATTN_CM=1) and batch-minor (IGCN_GO_ATTN_BM=1) GO
+    attention backward and the VALU attention core (IGCN_ATTN_VALU=1) give the numbers of the default LDS-resident /
+    matrix-core kernels.  The switches are read once per process, so each variant runs in a short child process (one
+    at a time)."""
     import os
     import subprocess
     import sys
@@ -602,12 +609,14 @@ def test_alternative_kernel_variants_agree(tmp_path):
     script = tmp_path / "ab.py"
     script.write_text(_AB_SCRIPT)
     outs = {}
-    for tag, env in (("default", {}), ("alt", {"IGCN_GO_ATTN_CM": "1", "IGCN_ATTN_VALU": "1"})):
+    for tag, env in (("default", {}), ("alt", {"IGCN_GO_ATTN_CM": "1", "IGCN_ATTN_VALU": "1"}),
+                     ("alt2", {"IGCN_GO_ATTN_BM": "1"})):
         out = tmp_path / f"{tag}.npz"
         r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env={**os.environ, **env},
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = np.load(out)
-    for k in outs["default"].files:
-        a, b = outs["default"][k], outs["alt"][k]
-        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), k
+    for other in ("alt", "alt2"):
+        for k in outs["default"].files:
+            a, b = outs["default"][k], outs[other][k]
+            assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), (other, k)
