@@ -31,11 +31,11 @@ LAYERS, HIDDEN, ROIS = 2, 16, 90
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes per launch from the rocprofv3 PMC passes of tools/roofline_kernel.py (FETCH_SIZE x2 gfx950 correction,
 # calibrated on a 256 MiB float4 copy; WRITE_SIZE x1): profiles/r01_pmc/scatter_aggregate_traffic.json
-PMC_TRAFFIC = {"bench": 10004117, "stress": 77630016}
+PMC_TRAFFIC = {"bench": 10010260, "stress": 77631040}
 # average duration of the same kernels in the committed rocprofv3 --kernel-trace --stats summary of this command
 # (profiles/r01_final_default_bench/kernel_stats.csv).  The profiler adds ~1-2 us to every dispatch and sees the
 # in-step launches with cold caches, which matters for the 3-us kernel and not for the 36-us one.
-ROCPROF_AVG_US = {"bench": 4.92, "stress": 35.8}
+ROCPROF_AVG_US = {"bench": 4.95, "stress": 36.3}
 
 
 # --workload: the default is the configuration the metric is quoted on; the other two are side measurements
