@@ -297,6 +297,8 @@ int igcn_go_attn_fwd(int B, int N, int fin, int fout, const int32_t* row_ptr, co
 /* Backward in O(nnz*f) (the reference's autograd forms a dense N x N product per sample and layer).
  * t_ptr/t_row: the transposed structure (for each column the rows that read it).
  * Outputs: dx [B,fin,N]; dparams float[ 2*fout*fin + 2*fout + fout ] = (dW_inc, dW_s, da_in, da_s).
+ * Samples whose operands fit a CU's LDS ((fin+fout+4)*N*4 <= 160 KB, N <= 4096) run in an LDS-resident kernel, one
+ * workgroup per sample; larger ones in global-memory kernels (hub columns walked by the whole wave).
  * scratch floats: igcn_go_attn_bwd_scratch_floats(B,N,fin,fout). */
 size_t igcn_go_attn_bwd_scratch_floats(int B, int N, int fin, int fout);
 int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
