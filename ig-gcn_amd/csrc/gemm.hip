@@ -77,8 +77,12 @@ k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t
            const float* __restrict__ B, int64_t sbn, int64_t sbk, const float* __restrict__ bias,
            float* __restrict__ C, int64_t ldc, int act, int64_t k_per_split, int64_t slab_stride,
            int64_t a_zs, int64_t b_zs, int zsplit) {
-  __shared__ float As[2][G_BM][G_LD];
-  __shared__ float Bs[2][BN][G_LD];
+  // dynamic LDS: one buffer per operand when the workgroup has a single K step (short-K streaming products: more
+  // workgroups per CU hide each other's load latency), two otherwise
+  extern __shared__ float g_lds[];
+  const int nbuf = k_per_split <= G_BK ? 1 : 2;
+  float (*As)[G_BM][G_LD] = reinterpret_cast<float (*)[G_BM][G_LD]>(g_lds);
+  float (*Bs)[BN][G_LD] = reinterpret_cast<float (*)[BN][G_LD]>(g_lds + (size_t)nbuf * G_BM * G_LD);
   constexpr int NT = BN / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * G_BM, n0 = (int64_t)blockIdx.y * BN;
@@ -169,6 +173,9 @@ static int vec_width(const float* p, int64_t srow, int64_t sk, int64_t rows, int
   return 1;
 }
 static int min_int(int a, int b) { return a < b ? a : b; }
+static size_t gemm_lds_bytes(int bn, int64_t k_per_split) {
+  return (size_t)(k_per_split <= G_BK ? 1 : 2) * (G_BM + bn) * G_LD * sizeof(float);
+}
 
 __global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const float* __restrict__ slabs,
                                      const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int act) {
@@ -223,8 +230,8 @@ extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, in
   dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)split_k);
   const int vw = min_int(vec_width(A, sam, sak, M, K), vec_width(B, sbn, sbk, N, K));
 #define LAUNCH_G(BNV, VECV)                                                                                    \
-  hipLaunchKernelGGL((k_gemm_f32<BNV, VECV>), grid, dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk, bias, \
-                     out, ld, act, kps, slab, (int64_t)0, (int64_t)0, split_k)
+  hipLaunchKernelGGL((k_gemm_f32<BNV, VECV>), grid, dim3(256), gemm_lds_bytes(BNV, kps), st, M, N, K, A, sam, sak, \
+                     B, sbn, sbk, bias, out, ld, act, kps, slab, (int64_t)0, (int64_t)0, split_k)
   if (vw == 4) {
     if (bn == 16) { LAUNCH_G(16, 4); } else if (bn == 32) { LAUNCH_G(32, 4); } else { LAUNCH_G(64, 4); }
   } else if (vw == 2) {
@@ -274,8 +281,8 @@ int igcn_gemm_f32_batched_sum_impl(int64_t M, int64_t N, int64_t K, int batch, c
   int vw = min_int(vec_width(A, sam, sak, M, K), vec_width(B, sbn, sbk, N, K));
   while (vw > 1 && (a_batch % vw != 0 || b_batch % vw != 0)) vw >>= 1;
 #define LAUNCH_B(BNV, VECV)                                                                                     \
-  hipLaunchKernelGGL((k_gemm_f32<BNV, VECV>), grid, dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk,         \
-                     (const float*)nullptr, scratch, N, 0, kps, M * N, a_batch, b_batch, ksplit)
+  hipLaunchKernelGGL((k_gemm_f32<BNV, VECV>), grid, dim3(256), gemm_lds_bytes(BNV, kps), st, M, N, K, A, sam,    \
+                     sak, B, sbn, sbk, (const float*)nullptr, scratch, N, 0, kps, M * N, a_batch, b_batch, ksplit)
   if (vw == 4) {
     if (bn == 16) { LAUNCH_B(16, 4); } else if (bn == 32) { LAUNCH_B(32, 4); } else { LAUNCH_B(64, 4); }
   } else if (vw == 2) {
