@@ -310,8 +310,7 @@ extern "C" int igcn_attn_core_fwd(int B, int D, int H, int Lq, int Lk, const flo
   const int hd = D / H;
 #define CALL(HDV)                                                                                                  \
   {                                                                                                                \
-    static bool once = false;                                                                                      \
-    if (!once) { hipFuncSetAttribute((const void*)k_attn_core_fwd<HDV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; } \
+    IGCN_ALLOW_BIG_LDS((k_attn_core_fwd<HDV>));                                                            \
     hipLaunchKernelGGL((k_attn_core_fwd<HDV>), dim3(B * H), dim3(AC_T), lds, (hipStream_t)stream, H, Lq, Lk, q, kv, o, lse); \
   }
   AC_DISPATCH(hd, CALL)
@@ -334,8 +333,7 @@ extern "C" int igcn_attn_core_bwd(int B, int D, int H, int Lq, int Lk, const flo
   const int hd = D / H;
 #define CALL(HDV)                                                                                                  \
   {                                                                                                                \
-    static bool once = false;                                                                                      \
-    if (!once) { hipFuncSetAttribute((const void*)k_attn_core_bwd<HDV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; } \
+    IGCN_ALLOW_BIG_LDS((k_attn_core_bwd<HDV>));                                                            \
     hipLaunchKernelGGL((k_attn_core_bwd<HDV>), dim3(B * H), dim3(AC_T), lds, (hipStream_t)stream, H, Lq, Lk, q, kv, o, lse, dout, dq, dkv); \
   }
   AC_DISPATCH(hd, CALL)

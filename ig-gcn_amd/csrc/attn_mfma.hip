@@ -317,14 +317,8 @@ int igcn_attn_mfma_fwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
   if (waves < 4) waves = 4;                       // enough threads to stage K/V quickly
 #define CALL(HDPV)                                                                                               \
   {                                                                                                              \
-    static bool once = false;                                                                                    \
-    if (!once) {                                                                                                 \
-      hipFuncSetAttribute((const void*)k_attn_mfma_fwd<HDPV, true>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                          160 * 1024);                                                                           \
-      hipFuncSetAttribute((const void*)k_attn_mfma_fwd<HDPV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          160 * 1024);                                                                           \
-      once = true;                                                                                               \
-    }                                                                                                            \
+    IGCN_ALLOW_BIG_LDS((k_attn_mfma_fwd<HDPV, true>));                                        \
+    IGCN_ALLOW_BIG_LDS((k_attn_mfma_fwd<HDPV, false>));                                        \
     if (vec && hd == HDPV)                                                                                       \
       hipLaunchKernelGGL((k_attn_mfma_fwd<HDPV, true>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq,  \
                          Lk, q, kv, o, lse);                                                                     \
@@ -347,14 +341,8 @@ int igcn_attn_mfma_bwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
   const int waves = tasks < 8 ? (tasks < 4 ? 4 : tasks) : 8;
 #define CALL(HDPV)                                                                                               \
   {                                                                                                              \
-    static bool once = false;                                                                                    \
-    if (!once) {                                                                                                 \
-      hipFuncSetAttribute((const void*)k_attn_mfma_bwd<HDPV, true>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                          160 * 1024);                                                                           \
-      hipFuncSetAttribute((const void*)k_attn_mfma_bwd<HDPV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          160 * 1024);                                                                           \
-      once = true;                                                                                               \
-    }                                                                                                            \
+    IGCN_ALLOW_BIG_LDS((k_attn_mfma_bwd<HDPV, true>));                                        \
+    IGCN_ALLOW_BIG_LDS((k_attn_mfma_bwd<HDPV, false>));                                        \
     if (vec && hd == HDPV)                                                                                       \
       hipLaunchKernelGGL((k_attn_mfma_bwd<HDPV, true>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq,  \
                          Lk, q, kv, o, lse, dout, dq, dkv);                                                      \
@@ -607,12 +595,7 @@ int igcn_attn_mfma_fwd_chunked(int B, int D, int H, int Lq, int Lk, const float*
   dim3 grid(B * H, (nqt + nw - 1) / nw);
 #define CALL(HDPV)                                                                                               \
   {                                                                                                              \
-    static bool once = false;                                                                                    \
-    if (!once) {                                                                                                 \
-      hipFuncSetAttribute((const void*)k_attn_mfma_fwd_chunked<HDPV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          160 * 1024);                                                                           \
-      once = true;                                                                                               \
-    }                                                                                                            \
+    IGCN_ALLOW_BIG_LDS((k_attn_mfma_fwd_chunked<HDPV>));                                        \
     hipLaunchKernelGGL((k_attn_mfma_fwd_chunked<HDPV>), grid, dim3(64 * nw), lds, st, H, hd, vec, Lq, Lk, ch, q,  \
                        kv, o, lse);                                                                              \
   }
@@ -639,14 +622,8 @@ int igcn_attn_mfma_bwd_chunked(int B, int D, int H, int Lq, int Lk, const float*
   dim3 gq(B * H, (nqt + nwq - 1) / nwq), gk(B * H, (nkt + nwk - 1) / nwk);
 #define CALL(HDPV)                                                                                               \
   {                                                                                                              \
-    static bool once = false;                                                                                    \
-    if (!once) {                                                                                                 \
-      hipFuncSetAttribute((const void*)k_attn_mfma_bwd_dq_chunked<HDPV>,                                         \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
-      hipFuncSetAttribute((const void*)k_attn_mfma_bwd_dkv_chunked<HDPV>,                                        \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
-      once = true;                                                                                               \
-    }                                                                                                            \
+    IGCN_ALLOW_BIG_LDS((k_attn_mfma_bwd_dq_chunked<HDPV>));                                        \
+    IGCN_ALLOW_BIG_LDS((k_attn_mfma_bwd_dkv_chunked<HDPV>));                                        \
     hipLaunchKernelGGL((k_attn_mfma_bwd_dq_chunked<HDPV>), gq, dim3(64 * nwq), lds_q, st, H, hd, vec, Lq, Lk, chk, \
                        q, kv, o, lse, dout, dq, delta);                                                          \
     hipLaunchKernelGGL((k_attn_mfma_bwd_dkv_chunked<HDPV>), gk, dim3(64 * nwk), lds_k, st, H, hd, vec, Lq, Lk,    \

@@ -19,6 +19,24 @@ void igcn_set_error(const char* fmt, ...);
     }                                           \
   } while (0)
 
+// Kernels that ask for more than 64 KB of dynamic LDS need the attribute raised once PER DEVICE (one process may
+// drive several GPUs); legal during stream capture.
+struct IgcnPerDevice { bool done[64]; };
+static inline bool igcn_first_on_device(IgcnPerDevice& f) {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  d &= 63;
+  if (f.done[d]) return false;
+  f.done[d] = true;
+  return true;
+}
+#define IGCN_ALLOW_BIG_LDS(kernel)                                                                              \
+  do {                                                                                                          \
+    static IgcnPerDevice f_ = {};                                                                               \
+    if (igcn_first_on_device(f_))                                                                               \
+      (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  } while (0)
+
 #define IGCN_CHECK_LAUNCH(name)                                          \
   do {                                                                   \
     hipError_t e_ = hipGetLastError();                                   \

@@ -180,11 +180,7 @@ extern "C" int igcn_gdc_topk(int B, int R, int k, double alpha, const float* A, 
     return IGCN_ERR_UNSUPPORTED;
   }
   if (B == 0) return IGCN_OK;
-  static bool once = false;
-  if (!once) {
-    hipFuncSetAttribute((const void*)k_gdc_topk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    once = true;
-  }
+  IGCN_ALLOW_BIG_LDS(k_gdc_topk);
   const int64_t slots = (int64_t)B * R * k;
   hipLaunchKernelGGL(k_gdc_topk, dim3(B), dim3(GDC_T), lds, (hipStream_t)stream, R, k, alpha, A, edge_index,
                      edge_index + slots, edge_attr, counts);

@@ -1116,12 +1116,7 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
     const int iters = (int)igcn_cdiv(N, GO_ABL_T);
 #define CALLLI(FI, FO, MI)                                                                                        \
   {                                                                                                               \
-    static bool attr = false;                                                                                     \
-    if (!attr) {                                                                                                  \
-      hipFuncSetAttribute((const void*)k_go_attn_bwd_lds<FI, FO, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          160 * 1024);                                                                            \
-      attr = true;                                                                                                \
-    }                                                                                                             \
+    IGCN_ALLOW_BIG_LDS((k_go_attn_bwd_lds<FI, FO, MI>));                                        \
     hipLaunchKernelGGL((k_go_attn_bwd_lds<FI, FO, MI>), dim3(B), dim3(GO_ABL_T), abl_lds, st, N, row_ptr, col,    \
                        t_ptr, t_row, x, w_inc, w_s, a_in, a_s, dy, dx, gpart);                                    \
   }
@@ -1873,12 +1868,7 @@ extern "C" int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, c
   if (lds <= 160 * 1024 && 2 * fout >= 4) {
 #define CALL(FI, FO)                                                                                             \
   {                                                                                                               \
-    static bool attr = false;                                                                                     \
-    if (!attr) {                                                                                                  \
-      hipFuncSetAttribute((const void*)k_go_decode_bwd_lds<FI, FO>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                          160 * 1024);                                                                            \
-      attr = true;                                                                                                \
-    }                                                                                                             \
+    IGCN_ALLOW_BIG_LDS((k_go_decode_bwd_lds<FI, FO>));                                        \
     hipLaunchKernelGGL((k_go_decode_bwd_lds<FI, FO>), dim3(B), dim3(GO_DBL_T), lds, st, Nin, Nout, row_ptr, t_ptr, \
                        t_row, x, w_out, w_sout, dy, dx, scratch);                                                 \
   }

@@ -41,12 +41,13 @@ __global__ void __launch_bounds__(256)
 k_adam_multi(const int64_t* __restrict__ table, const int64_t* __restrict__ numel,
              const int32_t* __restrict__ step, float lr, float b1, float b2, float eps, float gscale) {
   const int t = blockIdx.y;
+  const int64_t n = numel[t];
+  if ((int64_t)blockIdx.x * 256 >= n) return;       // most tensors are tiny: their surplus workgroups leave at once
   const float* g = reinterpret_cast<const float*>(table[4 * t + 1]);
   if (g == nullptr) return;
   float* p = reinterpret_cast<float*>(table[4 * t]);
   float* m = reinterpret_cast<float*>(table[4 * t + 2]);
   float* v = reinterpret_cast<float*>(table[4 * t + 3]);
-  const int64_t n = numel[t];
   const float ts = (float)(*step);
   const float bc1 = 1.f - powf(b1, ts), bc2s = sqrtf(1.f - powf(b2, ts));
 #pragma unroll 4

@@ -408,12 +408,7 @@ extern "C" int igcn_xattn_fwd(int B, int D, int H, int Lq, int Lk, const float* 
   const int hd = D / H;
 #define CALL(HDV, HV)                                                                                           \
   {                                                                                                             \
-    static bool once = false;                                                                                   \
-    if (!once) {                                                                                                \
-      hipFuncSetAttribute((const void*)k_xattn_fwd<HDV, HV>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                          160 * 1024);                                                                          \
-      once = true;                                                                                              \
-    }                                                                                                           \
+    IGCN_ALLOW_BIG_LDS((k_xattn_fwd<HDV, HV>));                                        \
     hipLaunchKernelGGL((k_xattn_fwd<HDV, HV>), dim3(B), dim3(XA_T), lds, st, Lq, Lk, xq, mem, w_in, b_in, w_out,  \
                        b_out, out, o_save, lse);                                                                \
   }
@@ -438,12 +433,7 @@ extern "C" int igcn_xattn_bwd(int B, int D, int H, int Lq, int Lk, const float* 
   const int hd = D / H;
 #define CALL(HDV, HV)                                                                                           \
   {                                                                                                             \
-    static bool once = false;                                                                                   \
-    if (!once) {                                                                                                \
-      hipFuncSetAttribute((const void*)k_xattn_bwd<HDV, HV>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                          160 * 1024);                                                                          \
-      once = true;                                                                                              \
-    }                                                                                                           \
+    IGCN_ALLOW_BIG_LDS((k_xattn_bwd<HDV, HV>));                                        \
     hipLaunchKernelGGL((k_xattn_bwd<HDV, HV>), dim3(B), dim3(XA_T), lds, st, Lq, Lk, xq, mem, w_in, b_in, w_out,  \
                        out, o_save, lse, dout, dxq, dmem, scratch);                                             \
   }
