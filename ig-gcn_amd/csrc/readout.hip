@@ -89,15 +89,35 @@ k_nlbn_stats(int B, int N, int groups, const float* __restrict__ x, const float*
 // ---- forward pass 2: finalise statistics (training) or take the running ones (eval) ----------------
 // mean_out / rstd_out are [groups, N]; the running statistics are updated group after group, exactly as two
 // successive forward calls would.
+// 64 nodes x 4 chunk slices per workgroup: the cpg partials of a node are summed by four lanes (one batch of
+// independent loads each) and combined through LDS — with a thread per node and ceil(N/64) waves on the whole chip
+// the serial walk over the chunks was a 10-us latency chain for a few KB of data.
+#define RO_FIN_MAXG 8
 template <int F, int D>
-__global__ void k_nlbn_finalize(int B, int N, int groups, int cpg, int training, float eps, float momentum,
-                                const float* __restrict__ x, const float* __restrict__ W,
-                                const float* __restrict__ partial, float* __restrict__ running_mean,
-                                float* __restrict__ running_var, float* __restrict__ mean_out,
-                                float* __restrict__ rstd_out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+__global__ void __launch_bounds__(256)
+k_nlbn_finalize(int B, int N, int groups, int cpg, int training, float eps, float momentum,
+                const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ partial,
+                float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean_out,
+                float* __restrict__ rstd_out) {
+  __shared__ float r1[RO_FIN_MAXG][4][64], r2[RO_FIN_MAXG][4][64];
+  const int nl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + nl;
+  const bool live = n < N;
   const int bg = B / groups;
+  if (training && live) {
+    for (int g = 0; g < groups; ++g) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
+      for (int k = sl; k < cpg; k += 4) {               // independent loads: one batch per slice
+        a1 += partial[(int64_t)(g * cpg + k) * 2 * N + n];
+        a2 += partial[(int64_t)(g * cpg + k) * 2 * N + N + n];
+      }
+      r1[g][sl][nl] = a1;
+      r2[g][sl][nl] = a2;
+    }
+  }
+  __syncthreads();
+  if (sl != 0 || !live) return;
   float rm = running_mean[n], rv = running_var[n];
   for (int g = 0; g < groups; ++g) {
     float mean, var;
@@ -111,12 +131,8 @@ __global__ void k_nlbn_finalize(int B, int N, int groups, int cpg, int training,
 #pragma unroll
       for (int d = 0; d < D; ++d) piv += pre[d];
       piv *= (1.f / D);
-      float a1 = 0.f, a2 = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < cpg; ++k) {                 // independent loads: keep several in flight
-        a1 += partial[(int64_t)(g * cpg + k) * 2 * N + n];
-        a2 += partial[(int64_t)(g * cpg + k) * 2 * N + N + n];
-      }
+      const float a1 = (r1[g][0][nl] + r1[g][1][nl]) + (r1[g][2][nl] + r1[g][3][nl]);
+      const float a2 = (r2[g][0][nl] + r2[g][1][nl]) + (r2[g][2][nl] + r2[g][3][nl]);
       const float cnt = (float)bg * D;
       const float m = a1 / cnt;
       mean = piv + m;
@@ -169,6 +185,59 @@ k_nlbn_apply(int B, int N, int groups, const float* __restrict__ x, const float*
 #pragma unroll
       for (int d = 0; d < D; ++d) o[d] = fmaxf(pre[d] * sc + sh, 0.f);
     }
+  }
+}
+
+// Row-coalesced form of the pass above for D % 4 == 0, D <= 64: lane = (node, output quad), so a wave's store
+// instruction covers 64/(D/4) whole rows of `out` = contiguous memory (the thread-per-node form writes D/4 float4
+// per lane at a stride of D floats: every store instruction touches 64 different 128-byte lines).  The F inputs of
+// a node are loaded by its first F lanes and passed around with shuffles.
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_apply_q(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+               const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+               const float* __restrict__ rstd, float* __restrict__ out) {
+  constexpr int DQ = D / 4, NPW = 64 / DQ;             // quads per row, nodes per wave
+  static_assert(D % 4 == 0 && 64 % DQ == 0 && F <= DQ, "k_nlbn_apply_q: unsupported shape");
+  const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int q = lane % DQ, nw = lane / DQ;
+  const int n = blockIdx.x * NPW + nw;
+  const bool live = n < N;
+  const int nc = live ? n : N - 1;
+  const RoChunk ch = ro_chunk(B, groups);
+  float w[4][F];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < F; ++c) w[r][c] = W[(q * 4 + r) * F + c];
+  const float sc = rstd[(int64_t)ch.g * N + nc] * gamma[nc], sh = beta[nc] - mean[(int64_t)ch.g * N + nc] * sc;
+  const int base = lane - q;                            // first lane of this node
+  for (int b = ch.b0 + sg; b < ch.b1; b += RO_SG) {
+    const float mine = q < F ? x[((int64_t)b * F + q) * N + nc] : 0.f;
+    float4 v;
+    float* vv = reinterpret_cast<float*>(&v);
+    float xv[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) xv[c] = __shfl(mine, base + c, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < F; ++c) t += w[r][c] * xv[c];
+      vv[r] = fmaxf(t * sc + sh, 0.f);
+    }
+    if (live) *reinterpret_cast<float4*>(out + ((int64_t)b * N + n) * D + q * 4) = v;
+  }
+}
+
+template <int F, int D>
+static void ro_launch_apply(dim3 grid, hipStream_t st, int B, int N, int groups, const float* x, const float* W,
+                            const float* gamma, const float* beta, const float* mean, const float* rstd, float* out) {
+  if constexpr (D % 4 == 0 && D <= 64 && D >= 16 && 64 % (D / 4) == 0 && F <= D / 4) {
+    dim3 gq((unsigned)igcn_cdiv(N, 64 / (D / 4)), grid.y);
+    hipLaunchKernelGGL((k_nlbn_apply_q<F, D>), gq, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, mean, rstd, out);
+  } else {
+    hipLaunchKernelGGL((k_nlbn_apply<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, mean, rstd, out);
   }
 }
 
@@ -335,7 +404,8 @@ extern "C" int igcn_node_linear_bn_fwd(int B, int F, int N, int D, int groups, c
                                        const float* gamma, const float* beta, float* running_mean,
                                        float* running_var, int training, float momentum, float eps, float* out,
                                        float* save_mean, float* save_rstd, float* scratch, void* stream) {
-  IGCN_REQUIRE(B > 0 && N > 0 && groups >= 1 && B % groups == 0, "node_linear_bn_fwd: bad sizes");
+  IGCN_REQUIRE(B > 0 && N > 0 && groups >= 1 && groups <= RO_FIN_MAXG && B % groups == 0,
+               "node_linear_bn_fwd: bad sizes (1 <= groups <= 8, B divisible by groups)");
   IGCN_REQUIRE(!training || (int64_t)(B / groups) * D > 1,
                "node_linear_bn_fwd: need more than one value per node and group to train");
   hipStream_t st = (hipStream_t)stream;
@@ -343,11 +413,10 @@ extern "C" int igcn_node_linear_bn_fwd(int B, int F, int N, int D, int groups, c
   dim3 grid((unsigned)igcn_cdiv(N, RO_NL), groups * cpg);
 #define CALL(FV, DV)                                                                                             \
   if (training) hipLaunchKernelGGL((k_nlbn_stats<FV, DV>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, scratch); \
-  hipLaunchKernelGGL((k_nlbn_finalize<FV, DV>), dim3((unsigned)igcn_cdiv(N, 64)), dim3(64), 0, st, B, N, groups,  \
+  hipLaunchKernelGGL((k_nlbn_finalize<FV, DV>), dim3((unsigned)igcn_cdiv(N, 64)), dim3(256), 0, st, B, N, groups, \
                      cpg, training, eps, momentum, x, W, scratch, running_mean, running_var, save_mean,           \
                      save_rstd);                                                                                  \
-  hipLaunchKernelGGL((k_nlbn_apply<FV, DV>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta,            \
-                     save_mean, save_rstd, out)
+  ro_launch_apply<FV, DV>(grid, st, B, N, groups, x, W, gamma, beta, save_mean, save_rstd, out)
   RO_DISPATCH(F, D, CALL)
 #undef CALL
   IGCN_CHECK_LAUNCH("node_linear_bn_fwd");
