@@ -6,6 +6,7 @@
 // Replaces per call: a permute copy, a K=5 rocBLAS GEMM, ~6 BatchNorm kernels, a clamp, and in the backward the
 // K = B*N weight-gradient GEMMs that rocBLAS runs at ~190 us each.
 #include "common.h"
+#include <type_traits>
 
 #define RO_T 256
 #define RO_NL 64      // node lanes per block
@@ -230,11 +231,17 @@ k_nlbn_apply_q(int B, int N, int groups, const float* __restrict__ x, const floa
   }
 }
 
+static int ro_quad_chunks(unsigned grid_y, int groups) {
+  const int cpg = (int)grid_y / groups;
+  return cpg > 8 ? 8 : cpg;
+}
+
 template <int F, int D>
 static void ro_launch_apply(dim3 grid, hipStream_t st, int B, int N, int groups, const float* x, const float* W,
                             const float* gamma, const float* beta, const float* mean, const float* rstd, float* out) {
   if constexpr (D % 4 == 0 && D <= 64 && D >= 16 && 64 % (D / 4) == 0 && F <= D / 4) {
-    dim3 gq((unsigned)igcn_cdiv(N, 64 / (D / 4)), grid.y);
+    // 64/(D/4) nodes per wave give 8x the workgroups of the thread-per-node grid: fewer, longer sample chunks
+    dim3 gq((unsigned)igcn_cdiv(N, 64 / (D / 4)), ro_quad_chunks(grid.y, groups) * groups);
     hipLaunchKernelGGL((k_nlbn_apply_q<F, D>), gq, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, mean, rstd, out);
   } else {
     hipLaunchKernelGGL((k_nlbn_apply<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, mean, rstd, out);
@@ -369,6 +376,158 @@ k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict
     block_reduce_vec<NW>(gw, red, wpartial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NW);
 }
 
+// Sum over the G (= 2, 4, 8, 16) consecutive lanes of a group with DPP cross-lane moves (VALU; __shfl_xor is an LDS-pipe
+// ds_bpermute): xor 1 and xor 2 as quad permutations, then the 8- and 16-lane mirrors (a mirror pairs every lane with
+// one of the other half, which is all a sum needs).  Result in every lane of the group.
+template <int G>
+__device__ __forceinline__ float ro_group_sum_dpp(float v) {
+  static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "ro_group_sum_dpp: group size");
+  auto dpp = [](float a, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  if constexpr (G >= 2) v += dpp(v, std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+  if constexpr (G >= 4) v += dpp(v, std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+  if constexpr (G >= 8) v += dpp(v, std::integral_constant<int, 0x141>{});    // row_half_mirror
+  if constexpr (G >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  return v;
+}
+
+// ---- row-coalesced backward (D % 4 == 0, 16 <= D <= 64): lane = (node, quad of outputs) -------------------------
+// dout rows are read (and nothing but dx / block partials written) with one 16-byte access per lane over contiguous
+// memory; a node's F inputs are loaded by its first F lanes and shuffled around; sums over a node's outputs are
+// xor-shuffles inside its D/4 lanes.  The weight gradient is accumulated in registers (4 x F per lane) and leaves the
+// workgroup as one [D, F] partial: no dpre [B, N, D] round trip through HBM and no batched GEMM behind it.
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_bwd_stats_q(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+                   const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                   const float* __restrict__ rstd, const float* __restrict__ dout, float* __restrict__ partial) {
+  constexpr int DQ = D / 4, NPW = 64 / DQ;
+  __shared__ float s1[RO_SG][NPW], s2[RO_SG][NPW];
+  const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int q = lane % DQ, nw = lane / DQ, base = lane - q;
+  const int n = blockIdx.x * NPW + nw;
+  const bool live = n < N;
+  const int nc = live ? n : N - 1;
+  const RoChunk ch = ro_chunk(B, groups);
+  float w[4][F];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < F; ++c) w[r][c] = W[(q * 4 + r) * F + c];
+  const float mu = mean[(int64_t)ch.g * N + nc], rs = rstd[(int64_t)ch.g * N + nc], ga = gamma[nc], be = beta[nc];
+  float a1 = 0.f, a2 = 0.f;
+  for (int b = ch.b0 + sg; b < ch.b1; b += RO_SG) {
+    const float mine = q < F ? x[((int64_t)b * F + q) * N + nc] : 0.f;
+    const float4 g4 = *reinterpret_cast<const float4*>(dout + ((int64_t)b * N + nc) * D + q * 4);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    float xv[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) xv[c] = __shfl(mine, base + c, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float pre = 0.f;
+#pragma unroll
+      for (int c = 0; c < F; ++c) pre += w[r][c] * xv[c];
+      const float xh = (pre - mu) * rs;
+      const float dy = (xh * ga + be > 0.f) ? g[r] : 0.f;
+      a1 += dy * xh;
+      a2 += dy;
+    }
+  }
+  a1 = ro_group_sum_dpp<DQ>(a1);
+  a2 = ro_group_sum_dpp<DQ>(a2);
+  if (q == 0) {
+    s1[sg][nw] = a1;
+    s2[sg][nw] = a2;
+  }
+  __syncthreads();
+  if (sg == 0 && q == 0 && live) {
+    float* p = partial + (int64_t)(ch.ck * groups + ch.g) * 2 * N;      // [chunk][group][2][N]
+    p[n] = (s1[0][nw] + s1[1][nw]) + (s1[2][nw] + s1[3][nw]);
+    p[N + n] = (s2[0][nw] + s2[1][nw]) + (s2[2][nw] + s2[3][nw]);
+  }
+}
+
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_bwd_apply_q(int B, int N, int groups, int training, const float* __restrict__ x, const float* __restrict__ W,
+                   const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                   const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ dgb,
+                   float* __restrict__ dx, float* __restrict__ wpartial) {
+  constexpr int DQ = D / 4, NPW = 64 / DQ;
+  __shared__ float red[RO_T / 64][D * F];
+  const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int q = lane % DQ, nw = lane / DQ, base = lane - q;
+  const int n = blockIdx.x * NPW + nw;
+  const bool live = n < N;
+  const int nc = live ? n : N - 1;
+  const RoChunk ch = ro_chunk(B, groups);
+  float w[4][F], gw[4][F];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+      w[r][c] = W[(q * 4 + r) * F + c];
+      gw[r][c] = 0.f;
+    }
+  const float mu = mean[(int64_t)ch.g * N + nc], rs = rstd[(int64_t)ch.g * N + nc], ga = gamma[nc], be = beta[nc];
+  const float cnt = (float)(B / groups) * D;
+  const float* dgg = dgb + (int64_t)ch.g * 2 * N;           // this group's (sum dy*xhat, sum dy)
+  const float m1 = training ? dgg[N + nc] / cnt : 0.f;      // mean(dy)
+  const float m2 = training ? dgg[nc] / cnt : 0.f;          // mean(dy*xhat)
+  for (int b = ch.b0 + sg; b < ch.b1; b += RO_SG) {
+    const float mine = q < F ? x[((int64_t)b * F + q) * N + nc] : 0.f;
+    const float4 g4 = *reinterpret_cast<const float4*>(dout + ((int64_t)b * N + nc) * D + q * 4);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    float xv[F], dxv[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+      xv[c] = __shfl(mine, base + c, 64);
+      dxv[c] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float pre = 0.f;
+#pragma unroll
+      for (int c = 0; c < F; ++c) pre += w[r][c] * xv[c];
+      const float xh = (pre - mu) * rs;
+      const float dy = (xh * ga + be > 0.f) ? g[r] : 0.f;
+      const float t = live ? ga * rs * (dy - m1 - xh * m2) : 0.f;       // shadow lanes add nothing to dW
+#pragma unroll
+      for (int c = 0; c < F; ++c) {
+        gw[r][c] += t * xv[c];
+        dxv[c] += w[r][c] * t;
+      }
+    }
+    float mydx = 0.f;                                       // lane q < F ends up with channel q of dx
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+      const float t = ro_group_sum_dpp<DQ>(dxv[c]);
+      if (q == c) mydx = t;
+    }
+    if (live && q < F) dx[((int64_t)b * F + q) * N + n] = mydx;
+  }
+  // dW partial of the workgroup: sum over the wave's nodes (lanes with equal q), then over the four waves
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+      float t = gw[r][c];
+#pragma unroll
+      for (int o = DQ; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+      if (nw == 0) red[sg][(q * 4 + r) * F + c] = t;
+    }
+  __syncthreads();
+  float* prow = wpartial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (D * F);
+  for (int j = threadIdx.x; j < D * F; j += RO_T) prow[j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+}
+
+template <int F, int D>
+static constexpr bool ro_quad_ok() {
+  return D % 4 == 0 && D >= 16 && D <= 64 && 64 % (D / 4) == 0 && F <= D / 4;
+}
+
 #define RO_DISPATCH(F, D, CALL)                                    \
   if (F == 5 && D == 32) { CALL(5, 32); }                          \
   else if (F == 5 && D == 48) { CALL(5, 48); }                     \
@@ -432,7 +591,42 @@ extern "C" size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, in
   const size_t stats = (size_t)groups * cpg * 2 * N + (size_t)groups * 2 * N;
   const size_t blocks = (size_t)igcn_cdiv(N, RO_NL) * groups * cpg;
   if (D * F <= 16) return stats + blocks * D * F + 68;
-  return stats + (size_t)B * N * D + (size_t)16 * B * D * F + 68;
+  // dpre rows + batched-GEMM slabs, or (row-coalesced path) one [D, F] partial per workgroup of 64/(D/4) nodes
+  const size_t gemm_path = (size_t)B * N * D + (size_t)16 * B * D * F;
+  const size_t quad_path = D % 4 == 0 ? (size_t)igcn_cdiv(N, 64 / (D / 4 > 64 ? 64 : D / 4)) * groups * cpg * D * F : 0;
+  return stats + (gemm_path > quad_path ? gemm_path : quad_path) + 68;
+}
+
+template <int F, int D>
+static int ro_bwd(dim3 grid, int cpg, hipStream_t st, int B, int N, int groups, int training, const float* x,
+                  const float* W, const float* gamma, const float* beta, const float* save_mean,
+                  const float* save_rstd, const float* dout, float* stats, float* dgg, float* aux, float* dx,
+                  float* dW, float* dgb) {
+  int rc;
+  if constexpr (ro_quad_ok<F, D>()) {
+    const int cq = ro_quad_chunks(grid.y, groups);           // chunks per group of the row-coalesced kernels
+    dim3 gq((unsigned)igcn_cdiv(N, 64 / (D / 4)), cq * groups);
+    hipLaunchKernelGGL((k_nlbn_bwd_stats_q<F, D>), gq, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, save_mean,
+                       save_rstd, dout, stats);
+    if ((rc = igcn_launch_reduce_rows(stats, cq, (int64_t)groups * 2 * N, groups * 2 * N, dgg, 0, st))) return rc;
+    hipLaunchKernelGGL((k_nlbn_bwd_apply_q<F, D>), gq, dim3(RO_T), 0, st, B, N, groups, training, x, W, gamma, beta,
+                       save_mean, save_rstd, dout, dgg, dx, aux);
+    IGCN_CHECK_LAUNCH("node_linear_bn_bwd(q)");
+    if ((rc = igcn_launch_reduce_rows(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, 0, st))) return rc;
+    return igcn_launch_reduce_rows(aux, (int64_t)gq.x * gq.y, D * F, D * F, dW, 0, st);
+  } else {
+    hipLaunchKernelGGL((k_nlbn_bwd_stats<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, save_mean,
+                       save_rstd, dout, stats);
+    if ((rc = igcn_launch_reduce_rows(stats, cpg, (int64_t)groups * 2 * N, groups * 2 * N, dgg, 0, st))) return rc;
+    hipLaunchKernelGGL((k_nlbn_bwd_apply<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, training, x, W, gamma, beta,
+                       save_mean, save_rstd, dout, dgg, aux, dx, aux);
+    IGCN_CHECK_LAUNCH("node_linear_bn_bwd");
+    if ((rc = igcn_launch_reduce_rows(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, 0, st))) return rc;
+    if (D * F <= 16) return igcn_launch_reduce_rows(aux, (int64_t)grid.x * grid.y, D * F, D * F, dW, 0, st);
+    // dW[d,c] = sum_b sum_n dpre[b,n,d] * x[b,c,n]
+    return igcn_gemm_f32_batched_sum_impl(D, F, N, B, aux, 1, D, (int64_t)N * D, x, N, 1, (int64_t)F * N, dW, F,
+                                          aux + (size_t)B * N * D, st);
+  }
 }
 
 extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, int training, const float* x,
@@ -448,25 +642,11 @@ extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, i
   float* dgg = stats + (size_t)groups * cpg * 2 * N;         // [groups][2][N]
   float* aux = scratch + (((size_t)(dgg - scratch) + (size_t)groups * 2 * N + 3) & ~(size_t)3);   // 16-B aligned:
                                                              // wpartial (small) or dpre rows, then slabs (large)
-  const bool small = D * F <= 16;
-#define CALL(FV, DV)                                                                                              \
-  hipLaunchKernelGGL((k_nlbn_bwd_stats<FV, DV>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta,         \
-                     save_mean, save_rstd, dout, stats);                                                           \
-  {                                                                                                                \
-    int rc = igcn_launch_reduce_rows(stats, cpg, (int64_t)groups * 2 * N, groups * 2 * N, dgg, 0, st);             \
-    if (rc) return rc;                                                                                             \
-  }                                                                                                                \
-  hipLaunchKernelGGL((k_nlbn_bwd_apply<FV, DV>), grid, dim3(RO_T), 0, st, B, N, groups, training, x, W, gamma,     \
-                     beta, save_mean, save_rstd, dout, dgg, aux, dx, aux)
+#define CALL(FV, DV)                                                                                           \
+  return ro_bwd<FV, DV>(grid, cpg, st, B, N, groups, training, x, W, gamma, beta, save_mean, save_rstd, dout,   \
+                        stats, dgg, aux, dx, dW, dgb)
   RO_DISPATCH(F, D, CALL)
 #undef CALL
-  IGCN_CHECK_LAUNCH("node_linear_bn_bwd");
-  int rc = igcn_launch_reduce_rows(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, 0, st);     // dgamma/dbeta over groups
-  if (rc) return rc;
-  if (small) return igcn_launch_reduce_rows(aux, (int64_t)grid.x * grid.y, D * F, D * F, dW, 0, st);
-  // dW[d,c] = sum_b sum_n dpre[b,n,d] * x[b,c,n]
-  return igcn_gemm_f32_batched_sum_impl(D, F, N, B, aux, 1, D, (int64_t)N * D, x, N, 1, (int64_t)F * N, dW, F,
-                                        aux + (size_t)B * N * D, st);
 }
 
 // =================================================================================================
