@@ -50,14 +50,35 @@ k_adam_multi(const int64_t* __restrict__ table, const int64_t* __restrict__ nume
   float* v = reinterpret_cast<float*>(table[4 * t + 3]);
   const float ts = (float)(*step);
   const float bc1 = 1.f - powf(b1, ts), bc2s = sqrtf(1.f - powf(b2, ts));
+  auto upd = [&](float gi, float& mi, float& vi, float& pi) {
+    gi *= gscale;
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2s + eps));
+  };
+  // 16 bytes per lane on all four streams when the tensors allow it (the big matrices: two passes instead of eight)
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  const int64_t nv = vec ? n / 4 : 0;
+#pragma unroll 2
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+    float4 p4 = reinterpret_cast<float4*>(p)[i];
+    upd(g4.x, m4.x, v4.x, p4.x);
+    upd(g4.y, m4.y, v4.y, p4.y);
+    upd(g4.z, m4.z, v4.z, p4.z);
+    upd(g4.w, m4.w, v4.w, p4.w);
+    reinterpret_cast<float4*>(m)[i] = m4;
+    reinterpret_cast<float4*>(v)[i] = v4;
+    reinterpret_cast<float4*>(p)[i] = p4;
+  }
 #pragma unroll 4
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = g[i] * gscale;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  for (int64_t i = nv * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float mi = m[i], vi = v[i], pi = p[i];
+    upd(g[i], mi, vi, pi);
     m[i] = mi;
     v[i] = vi;
-    p[i] -= (lr / bc1) * (mi / (sqrtf(vi) / bc2s + eps));
+    p[i] = pi;
   }
 }
 
@@ -93,4 +114,77 @@ extern "C" int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_
                        flat);
   IGCN_CHECK_LAUNCH("pack_grads");
   return IGCN_OK;
+}
+
+// =================================================================================================
+// Backward glue of y = act(x W^T + b) (ops.Linear): g = dy * [y > 0] (when y is given) and db[c] = sum_r g[r,c] in
+// ONE pass over dy — instead of compare + multiply + (memset + two-stage sum) as four library launches.
+// Rows are split over workgroups; each writes one [cols] partial, summed in order by the common row reduction.
+// =================================================================================================
+#define BG_T 256
+template <int VW>
+__global__ void __launch_bounds__(BG_T)
+k_bias_grad(int64_t rows, int cols, int64_t rows_per_block, const float* __restrict__ dy, const float* __restrict__ y,
+            float* __restrict__ g, float* __restrict__ partial) {
+  // thread = (row lane, column group of VW): cpr column groups per row, BG_T / cpr row lanes
+  __shared__ float red[BG_T * VW];
+  const int cpr = cols / VW, rl = threadIdx.x / cpr, cg = threadIdx.x % cpr, lanes = BG_T / cpr;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float acc[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) acc[j] = 0.f;
+  if (rl < lanes) {
+#pragma unroll 4
+    for (int64_t r = r0 + rl; r < r1; r += lanes) {
+      const int64_t o = r * cols + cg * VW;
+      float v[VW];
+      if constexpr (VW == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(dy + o);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        if (y) {
+          const float4 u = *reinterpret_cast<const float4*>(y + o);
+          v[0] = u.x > 0.f ? v[0] : 0.f; v[1] = u.y > 0.f ? v[1] : 0.f;
+          v[2] = u.z > 0.f ? v[2] : 0.f; v[3] = u.w > 0.f ? v[3] : 0.f;
+          *reinterpret_cast<float4*>(g + o) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+        v[0] = dy[o];
+        if (y) {
+          v[0] = y[o] > 0.f ? v[0] : 0.f;
+          g[o] = v[0];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VW; ++j) acc[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VW; ++j) red[threadIdx.x * VW + j] = (rl < lanes) ? acc[j] : 0.f;
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += BG_T) {      // column c = group c / VW, slot c % VW; row lanes in order
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += red[(l * cpr + c / VW) * VW + c % VW];
+    partial[(int64_t)blockIdx.x * cols + c] = t;
+  }
+}
+
+extern "C" size_t igcn_bias_grad_scratch_floats(int64_t rows, int cols) {
+  const int64_t blocks = rows < 512 * 64 ? igcn_cdiv(rows, 64) : 512;
+  return (size_t)(blocks * cols + 64);
+}
+
+extern "C" int igcn_bias_grad(int64_t rows, int cols, const float* dy, const float* y, float* g, float* db,
+                              float* scratch, void* stream) {
+  IGCN_REQUIRE(rows > 0 && cols > 0 && cols <= BG_T && (y == nullptr || g != nullptr), "bias_grad: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t blocks = rows < 512 * 64 ? igcn_cdiv(rows, 64) : 512;       // >= 64 rows per workgroup, <= 512 of them
+  const int64_t rpb = igcn_cdiv(rows, blocks);
+  const int64_t nb = igcn_cdiv(rows, rpb);
+  const bool vec = cols % 4 == 0 && BG_T % (cols / 4) == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)g) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL((k_bias_grad<4>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, rpb, dy, y, g, scratch);
+  else
+    hipLaunchKernelGGL((k_bias_grad<1>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, rpb, dy, y, g, scratch);
+  IGCN_CHECK_LAUNCH("bias_grad");
+  return igcn_launch_reduce_rows(scratch, nb, cols, cols, db, 0, st);
 }

@@ -294,11 +294,28 @@ class Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
         dy = _f32(dy)
-        if ctx.relu:
-            dy = dy * (y > 0)
+        db = None
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        rows, cols = dy.shape
+        if (ctx.relu or need_db) and cols <= 256:
+            # ReLU mask and bias gradient in one pass over dy (igcn_bias_grad)
+            lib = _lib.load()
+            g = torch.empty_like(dy) if ctx.relu else None
+            db = torch.empty(cols, dtype=torch.float32, device=dy.device)
+            scratch = torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, cols)), dtype=torch.float32,
+                                  device=dy.device)
+            call("igcn_bias_grad", rows, cols, ptr(dy), ptr(y) if ctx.relu else None, ptr(g), ptr(db), ptr(scratch),
+                 stream_ptr())
+            if ctx.relu:
+                dy = g
+            if not need_db:
+                db = None
+        else:
+            if ctx.relu:
+                dy = dy * (y > 0)
+            db = dy.sum(0) if need_db else None
         dx = gemm_nn(dy, weight) if ctx.needs_input_grad[0] else None
         dw = gemm_tn(dy, x) if ctx.needs_input_grad[1] else None
-        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 
 

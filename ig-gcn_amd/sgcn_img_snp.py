@@ -181,8 +181,12 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         w, bias = mha.in_proj_weight, mha.in_proj_bias
         if self.fused_cross_attention and ops.xattn_supported(d, h, lq, lk):
             return ops.CrossAttention.apply(query, memory, w, bias, mha.out_proj.weight, mha.out_proj.bias, h)
-        q = ops.linear(query, w[:d], bias[:d])                               # [B, Lq, D]
-        kv = ops.linear(memory, w[d:], bias[d:])                            # [B, Lk, 2D] = key | value
+        # split, not two slices: the backward of a split is ONE concatenation of the two gradients, that of two
+        # slices is zeros + copy for each and an add (ten launches per step for these two parameters)
+        w_q, w_kv = w.split([d, 2 * d])
+        b_q, b_kv = bias.split([d, 2 * d])
+        q = ops.linear(query, w_q, b_q)                                      # [B, Lq, D]
+        kv = ops.linear(memory, w_kv, b_kv)                                  # [B, Lk, 2D] = key | value
         if ops.attn_core_supported(d, h, lq, lk):
             o = ops.AttentionCore.apply(q, kv, h)                           # heads addressed in place
         else:

@@ -197,6 +197,23 @@ def _losses_batched(model, data, lam, hp, temperature):
     return loss, t, (logp, x_hat, out_z, out_lin, lin_f, reg)
 
 
+def backward_to_grads(loss, optimizer, data=None):
+    """``loss.backward()`` for the table-mode FlatAdam: the gradients are taken with ``torch.autograd.grad`` and
+    assigned to ``.grad`` as they come.  ``backward()`` routes every leaf through AccumulateGrad, which CLONES a
+    gradient it cannot steal — and the kernels here hand back several parameter gradients as slices of one flat
+    buffer (dW_inc | dW_s | da_in | da_s ...), i.e. views: a dozen device copies per step that nothing needs, since
+    the Adam kernel reads the gradients through a pointer table.  Other optimisers keep ``backward()``."""
+    params = getattr(optimizer, "params", None)
+    if params is None or getattr(optimizer, "flat_grads", True):
+        loss.backward()
+        return
+    leaves = list(params)
+    if data is not None and getattr(data, "x", None) is not None and data.x.requires_grad:
+        leaves.append(data.x)
+    for t, g in zip(leaves, torch.autograd.grad(loss, leaves, allow_unused=True)):
+        t.grad = g
+
+
 def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None, world_size=1):
     """One iteration of the loop body of train() :515-547.  Returns the (device) loss tensor.
 
@@ -208,7 +225,7 @@ def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temper
     if data.x.grad is not None:
         data.x.grad = None
     loss, _, _ = losses(model, data, lambda_loss, hp, temperature)
-    loss.backward()
+    backward_to_grads(loss, optimizer, data)
     if world_size > 1:
         torch.distributed.all_reduce(optimizer.pack_grads())
         optimizer.step(grad_scale=1.0 / world_size, from_flat=True)
@@ -285,7 +302,7 @@ class GraphedTrainStep:
             self.plan._copies = {}                      # the replica of the batched sweep is derived in-graph
         self.data.x.grad = None
         loss, _, _ = losses(self.model, self.data, self.lam, self.hp)
-        loss.backward()
+        backward_to_grads(loss, self.opt, self.data)
         return loss.detach()
 
     def _reduce(self):

@@ -149,6 +149,14 @@ int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F,
  * split_k > 1 writes split_k partial slabs into `scratch` (float[split_k*M*N]) and reduces them in order
  * (deterministic).  act: 0 none, 1 relu.
  */
+/* Backward glue of out = act(A W^T + bias) (ops.Linear; lin1 / lin2 / GCNConv.lin of kernel/sgcn_img_snp.py:34-84):
+ * g = dy * [y > 0] when `y` (the ReLU output) is given — then `g` receives the masked gradient the two GEMMs of
+ * the backward read — and db[c] = sum_r g[r,c] (y == NULL: g unused, db = column sums of dy).  dy, y, g [rows, cols]
+ * row-major, cols <= 256.  scratch: igcn_bias_grad_scratch_floats(rows, cols) floats. */
+size_t igcn_bias_grad_scratch_floats(int64_t rows, int cols);
+int igcn_bias_grad(int64_t rows, int cols, const float* dy, const float* y, float* g, float* db, float* scratch,
+                   void* stream);
+
 /* The split the library's launch heuristic prefers for (M, N, K): callers size `scratch` with it and pass it as
  * `split_k` (any other value >= 1 is honoured too). */
 int igcn_gemm_f32_split_k(int64_t M, int64_t N, int64_t K);

@@ -148,6 +148,30 @@ def test_gemm_nt_nn_tn(ops, m, n, k):
     assert_matches(ops.gemm_tn(dy.cuda(), a.cuda()), (dy.double().t() @ a.double()).numpy(), TOL, "TN")
 
 
+@pytest.mark.parametrize("rows,fin,fout,relu,bias", [(512, 64, 3, False, True), (512, 2912, 64, True, True),
+                                                     (46080, 16, 32, False, True), (1000, 7, 12, True, True),
+                                                     (300, 5, 64, True, False), (70000, 32, 64, False, True)])
+def test_linear_fwd_bwd(ops, rows, fin, fout, relu, bias):
+    """ops.linear = GEMM with fused bias/ReLU epilogue; backward = igcn_bias_grad (ReLU mask + bias gradient in one
+    pass) + two GEMMs, against torch in fp64."""
+    rng = np.random.default_rng(rows + fout)
+    x = torch.from_numpy(rng.standard_normal((rows, fin))).float()
+    w = torch.from_numpy(rng.standard_normal((fout, fin)) / np.sqrt(fin)).float()
+    b = torch.from_numpy(rng.standard_normal(fout)).float() if bias else None
+    cot = torch.from_numpy(rng.standard_normal((rows, fout))).float()
+    ref_in = [t.double().requires_grad_(True) for t in (x, w)] + ([b.double().requires_grad_(True)] if bias else [])
+    y_ref = torch.nn.functional.linear(ref_in[0], ref_in[1], ref_in[2] if bias else None)
+    if relu:
+        y_ref = torch.relu(y_ref)
+    g_ref = torch.autograd.grad((y_ref * cot.double()).sum(), ref_in)
+    dev = [t.cuda().requires_grad_(True) for t in (x, w)] + ([b.cuda().requires_grad_(True)] if bias else [])
+    y = ops.linear(dev[0], dev[1], dev[2] if bias else None, relu=relu)
+    g = torch.autograd.grad((y * cot.cuda()).sum(), dev)
+    assert_matches(y, y_ref.detach().numpy(), TOL, "y")
+    for got, want, nm in zip(g, g_ref, ("dx", "dW", "db")):
+        assert_matches(got, want.numpy(), TOL, nm)
+
+
 def test_gemm_is_exact_fp32_fma_chain(ops):
     """MFMA f32 = k-ordered fmaf chain: small-integer operands must be reproduced exactly."""
     rng = np.random.default_rng(0)
