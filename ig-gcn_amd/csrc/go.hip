@@ -552,261 +552,10 @@ int igcn_gemm_f32_batched_sum_impl(int64_t M, int64_t N, int64_t K, int batch, c
                                    int64_t b_batch, float* C, int64_t ldc, float* scratch, hipStream_t st);
 
 extern "C" size_t igcn_go_attn_bwd_scratch_floats(int B, int N, int fin, int fout) {
+  // channel-major kernels: statistics [B,N] float4 + one partial per wave; the LDS-resident kernel needs only one
+  // partial per sample, which is less
   const int64_t rows = 2 * fout + 3, parts = igcn_cdiv(N, GO_T) * (int64_t)B * (GO_T / 64);
-  const int64_t cm = 4 * (int64_t)B * N + parts * rows * fin + rows * fin + 64;
-  // batch-minor path: x, dy, statistics, dx as [f][N][B] + block partials
-  const int64_t bm_parts = igcn_cdiv(N, 4) * igcn_cdiv(B, 64);
-  const int64_t bm = (int64_t)(2 * fin + fout + 4) * (((int64_t)N * B + 3) & ~(int64_t)3) + bm_parts * rows * fin +
-                     rows * fin + 64;
-  return (size_t)(cm > bm ? cm : bm);
-}
-
-// =================================================================================================
-// Batch-minor formulation of the backward.  The GO graph is the same for every sample, so with the 64 lanes of a
-// wave on 64 SAMPLES of one node every access — direct or through the CSR — is one coalesced 256-byte row,
-// neighbour indices are wave-uniform scalar loads, and there is no degree divergence inside a wave (no hub
-// special-casing either).  x, dy, the statistics and dx are kept as [f][N][B]; the entry point transposes the
-// channel-major operands on the way in and dx on the way out (64x64 LDS tiles).
-// =================================================================================================
-// 64 (samples) x 64 (nodes) tiles; 16 bytes per lane on both global sides when the extents allow it
-__global__ void __launch_bounds__(256)
-k_cm_to_bm(int B, int F, int N, int vec, const float* __restrict__ in /*[B,F,N]*/, float* __restrict__ out /*[F,N,B]*/) {
-  __shared__ float tile[64][65];                      // [sample][node]
-  const int f = blockIdx.z, n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
-  if (vec) {                                          // N % 4 == 0, B % 4 == 0, 16-byte aligned bases
-    const int q = threadIdx.x & 15, r0 = threadIdx.x >> 4;          // 16 lanes x float4 = one 64-wide row
-#pragma unroll
-    for (int r = r0; r < 64; r += 16) {
-      const int b = b0 + r, n = n0 + q * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b < B && n < N) v = *reinterpret_cast<const float4*>(in + ((int64_t)b * F + f) * N + n);
-      tile[r][q * 4] = v.x; tile[r][q * 4 + 1] = v.y; tile[r][q * 4 + 2] = v.z; tile[r][q * 4 + 3] = v.w;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = r0; r < 64; r += 16) {
-      const int n = n0 + r, b = b0 + q * 4;
-      if (n < N && b < B)
-        *reinterpret_cast<float4*>(out + ((int64_t)f * N + n) * B + b) =
-            make_float4(tile[q * 4][r], tile[q * 4 + 1][r], tile[q * 4 + 2][r], tile[q * 4 + 3][r]);
-    }
-    return;
-  }
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll 4
-  for (int r = ty; r < 64; r += 4) {
-    const int b = b0 + r, n = n0 + tx;
-    tile[r][tx] = (b < B && n < N) ? in[((int64_t)b * F + f) * N + n] : 0.f;
-  }
-  __syncthreads();
-#pragma unroll 4
-  for (int r = ty; r < 64; r += 4) {
-    const int n = n0 + r, b = b0 + tx;
-    if (n < N && b < B) out[((int64_t)f * N + n) * B + b] = tile[tx][r];
-  }
-}
-
-__global__ void __launch_bounds__(256)
-k_bm_to_cm(int B, int F, int N, int vec, const float* __restrict__ in /*[F,N,B]*/, float* __restrict__ out /*[B,F,N]*/) {
-  __shared__ float tile[64][65];                      // [node][sample]
-  const int f = blockIdx.z, n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
-  if (vec) {
-    const int q = threadIdx.x & 15, r0 = threadIdx.x >> 4;
-#pragma unroll
-    for (int r = r0; r < 64; r += 16) {
-      const int n = n0 + r, b = b0 + q * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N && b < B) v = *reinterpret_cast<const float4*>(in + ((int64_t)f * N + n) * B + b);
-      tile[r][q * 4] = v.x; tile[r][q * 4 + 1] = v.y; tile[r][q * 4 + 2] = v.z; tile[r][q * 4 + 3] = v.w;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = r0; r < 64; r += 16) {
-      const int b = b0 + r, n = n0 + q * 4;
-      if (b < B && n < N)
-        *reinterpret_cast<float4*>(out + ((int64_t)b * F + f) * N + n) =
-            make_float4(tile[q * 4][r], tile[q * 4 + 1][r], tile[q * 4 + 2][r], tile[q * 4 + 3][r]);
-    }
-    return;
-  }
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll 4
-  for (int r = ty; r < 64; r += 4) {
-    const int n = n0 + r, b = b0 + tx;
-    tile[r][tx] = (n < N && b < B) ? in[((int64_t)f * N + n) * B + b] : 0.f;
-  }
-  __syncthreads();
-#pragma unroll 4
-  for (int r = ty; r < 64; r += 4) {
-    const int b = b0 + r, n = n0 + tx;
-    if (b < B && n < N) out[((int64_t)b * F + f) * N + n] = tile[tx][r];
-  }
-}
-
-template <int F>
-__device__ __forceinline__ void load_bm(const float* __restrict__ p, int N, int B, int n, int b, float (&v)[F]) {
-#pragma unroll
-  for (int d = 0; d < F; ++d) v[d] = p[(d * N + n) * B + b];
-}
-
-// statistics (p, q, 1/Z, dy.agg/Z) of every (node, sample), one 16-byte record, [N][B]
-template <int FIN, int FOUT>
-__global__ void __launch_bounds__(256)
-k_go_attn_bwd_stats_bm(int B, int N, int npw, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-                       const float* __restrict__ xb, const float* __restrict__ w_inc, const float* __restrict__ a_in,
-                       const float* __restrict__ dyb, float4* __restrict__ statsb) {
-  float wi[FOUT][FIN], a1[FOUT], a2[FOUT];
-#pragma unroll
-  for (int c = 0; c < FOUT; ++c) {
-#pragma unroll
-    for (int d = 0; d < FIN; ++d) wi[c][d] = w_inc[c * FIN + d];
-    a1[c] = a_in[c];
-    a2[c] = a_in[FOUT + c];
-  }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int b = blockIdx.y * 64 + lane;
-  const bool live = b < B;
-  const int bb = live ? b : B - 1;
-  for (int it = 0; it < npw; ++it) {
-    const int n = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + w) * npw + it);
-    if (n >= N) break;
-    float xr[FIN], xin[FOUT], dyn[FOUT];
-    load_bm<FIN>(xb, N, B, n, bb, xr);
-    load_bm<FOUT>(dyb, N, B, n, bb, dyn);
-    transform<FIN, FOUT>(wi, xr, xin);
-    const float p = dot<FOUT>(a1, xin), q = dot<FOUT>(a2, xin);
-    float Z = 0.f, agg[FOUT];
-#pragma unroll
-    for (int c = 0; c < FOUT; ++c) agg[c] = 0.f;
-    const int32_t p0 = row_ptr[n], p1 = row_ptr[n + 1];
-#pragma unroll 2
-    for (int32_t e = p0; e < p1; ++e) {
-      const int m = col[e];
-      float xm[FIN], xim[FOUT];
-      load_bm<FIN>(xb, N, B, m, bb, xm);
-      transform<FIN, FOUT>(wi, xm, xim);
-      const float sc = go_exp(go_tanh(p + dot<FOUT>(a2, xim)));
-      Z += sc;
-#pragma unroll
-      for (int c = 0; c < FOUT; ++c) agg[c] += sc * xim[c];
-    }
-    const float zinv = p1 > p0 ? 1.f / Z : 0.f;
-    if (live) statsb[n * B + b] = make_float4(p, q, zinv, dot<FOUT>(dyn, agg) * zinv);
-  }
-}
-
-template <int FIN, int FOUT>
-__global__ void __launch_bounds__(256)
-k_go_attn_bwd_main_bm(int B, int N, int npw, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-                      const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ t_row,
-                      const float* __restrict__ xb, const float* __restrict__ w_inc, const float* __restrict__ w_s,
-                      const float* __restrict__ a_in, const float* __restrict__ a_s, const float* __restrict__ dyb,
-                      const float4* __restrict__ statsb, float* __restrict__ dxb, float* __restrict__ gpart) {
-  constexpr int ROWS = 2 * FOUT + 3, NG = ROWS * FIN;
-  __shared__ float gl[256][17];
-  __shared__ float gw[4][16];
-  AttnW<FIN, FOUT> W;
-  W.load(w_inc, w_s, a_in, a_s);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int b = blockIdx.y * 64 + lane;
-  const bool live = b < B;
-  const int bb = live ? b : B - 1;
-  float G[NG];                                        // this lane's share of sum_nodes u (x) x
-#pragma unroll
-  for (int j = 0; j < NG; ++j) G[j] = 0.f;
-  for (int it = 0; it < npw; ++it) {
-    const int n = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + w) * npw + it);
-    if (n >= N) break;
-    float xr[FIN], xin[FOUT], xs[FOUT], dyn[FOUT];
-    load_bm<FIN>(xb, N, B, n, bb, xr);
-    load_bm<FOUT>(dyb, N, B, n, bb, dyn);
-    const float4 st_n = statsb[n * B + bb];
-    transform<FIN, FOUT>(W.wi, xr, xin);
-    transform<FIN, FOUT>(W.ws, xr, xs);
-    const float p_n = st_n.x, q_n = st_n.y, zinv_n = st_n.z, tr_n = st_n.w;
-    // n as ROW: d(score) of its own edges
-    float dp = 0.f;
-    const int32_t r0 = row_ptr[n], r1 = row_ptr[n + 1];
-#pragma unroll 2
-    for (int32_t e = r0; e < r1; ++e) {
-      const int m = col[e];
-      float xm[FIN], xim[FOUT];
-      load_bm<FIN>(xb, N, B, m, bb, xm);
-      const float qm = statsb[m * B + bb].y;
-      transform<FIN, FOUT>(W.wi, xm, xim);
-      const float th = go_tanh(p_n + qm);
-      dp += (dot<FOUT>(dyn, xim) - tr_n) * (go_exp(th) * zinv_n) * (1.f - th * th);
-    }
-    // n as COLUMN: what the rows reading n send back (uniform trip count: no divergence, no hub handling)
-    float dq = 0.f, dxin[FOUT];
-#pragma unroll
-    for (int c = 0; c < FOUT; ++c) dxin[c] = 0.f;
-    const int32_t c0 = t_ptr[n], c1 = t_ptr[n + 1];
-#pragma unroll 4
-    for (int32_t e = c0; e < c1; ++e) {
-      const int r = t_row[e];
-      float dyr[FOUT];
-      load_bm<FOUT>(dyb, N, B, r, bb, dyr);
-      const float4 sr = statsb[r * B + bb];
-      const float th = go_tanh(sr.x + q_n);
-      const float alpha = go_exp(th) * sr.z;
-      dq += (dot<FOUT>(dyr, xin) - sr.w) * alpha * (1.f - th * th);
-#pragma unroll
-      for (int c = 0; c < FOUT; ++c) dxin[c] += alpha * dyr[c];
-    }
-#pragma unroll
-    for (int c = 0; c < FOUT; ++c) dxin[c] += dp * W.a1[c] + dq * W.a2[c];
-    const float g = 1.f / (1.f + go_exp(-dot<FOUT>(W.as, xs)));
-    const float dgate = dot<FOUT>(dyn, xs) * g * (1.f - g);
-    float dxs[FOUT];
-#pragma unroll
-    for (int c = 0; c < FOUT; ++c) dxs[c] = dyn[c] * g + dgate * W.as[c];
-    if (live) {
-#pragma unroll
-      for (int d = 0; d < FIN; ++d) {
-        float t = 0.f;
-#pragma unroll
-        for (int c = 0; c < FOUT; ++c) t += W.wi[c][d] * dxin[c] + W.ws[c][d] * dxs[c];
-        dxb[(d * N + n) * B + b] = t;
-      }
-      // u = (dxin[FOUT], dxs[FOUT], dp, dq, dgate): rows of the parameter-gradient product G = sum u (x) x
-#pragma unroll
-      for (int d = 0; d < FIN; ++d) {
-#pragma unroll
-        for (int c = 0; c < FOUT; ++c) {
-          G[c * FIN + d] += dxin[c] * xr[d];
-          G[(FOUT + c) * FIN + d] += dxs[c] * xr[d];
-        }
-        G[(2 * FOUT) * FIN + d] += dp * xr[d];
-        G[(2 * FOUT + 1) * FIN + d] += dq * xr[d];
-        G[(2 * FOUT + 2) * FIN + d] += dgate * xr[d];
-      }
-    }
-  }
-  // lanes -> block through LDS, 16 accumulators at a time (a wave-shuffle reduction of all NG values would cost
-  // 6 NG cross-lane operations per wave and dominate the kernel): every lane writes its 16 values as a row, thread
-  // (j, part) sums 16 rows of column j, two shuffles and a 4-way add finish it.  Fixed order: deterministic.
-  // One partial row per block, layout [NG][blocks] (contiguous second-stage sums).
-  const int64_t parts = (int64_t)gridDim.x * gridDim.y;
-  const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-  const int tj = threadIdx.x & 15, tpart = threadIdx.x >> 4;
-#pragma unroll
-  for (int c0 = 0; c0 < NG; c0 += 16) {
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) gl[threadIdx.x][k] = (c0 + k < NG) ? G[c0 + k < NG ? c0 + k : 0] : 0.f;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t += gl[tpart * 16 + r][tj];
-    t += __shfl_xor(t, 16, 64);
-    t += __shfl_xor(t, 32, 64);
-    if (lane < 16) gw[w][lane] = t;
-    __syncthreads();
-    if (threadIdx.x < 16 && c0 + threadIdx.x < NG)
-      gpart[(int64_t)(c0 + threadIdx.x) * parts + blk] =
-          (gw[0][threadIdx.x] + gw[1][threadIdx.x]) + (gw[2][threadIdx.x] + gw[3][threadIdx.x]);
-  }
+  return (size_t)(4 * (int64_t)B * N + parts * rows * fin + rows * fin + 64);
 }
 
 // =================================================================================================
@@ -1081,26 +830,15 @@ static size_t go_abl_lds_bytes(int N, int fin, int fout) {
   return slabs > stage ? slabs : stage;
 }
 
-static int go_bm_npw(int B, int N) {
-  const int64_t pairs = (int64_t)N * igcn_cdiv(B, 64);     // (node, sample tile) units of wave work
-  int64_t npw = pairs / 8192;                               // >= ~8 k waves: latency hidden by occupancy
-  if (npw < 1) npw = 1;
-  if (npw > 16) npw = 16;
-  return (int)npw;
-}
-
-// Variant of the backward (A/B runs): default = LDS-resident kernel when the sample fits, else channel-major;
-// IGCN_GO_ATTN_CM=1 forces the channel-major global-memory kernels, IGCN_GO_ATTN_BM=1 the batch-minor formulation.
-static int go_attn_variant(void) {
+// IGCN_GO_ATTN_CM=1 (A/B runs): the channel-major global-memory kernels even when a sample fits LDS
+static bool go_attn_force_cm(void) {
   static int v = -1;
   if (v < 0) {
-    const char* cm = getenv("IGCN_GO_ATTN_CM");
-    const char* bm = getenv("IGCN_GO_ATTN_BM");
-    v = (cm && cm[0] == '1') ? 1 : ((bm && bm[0] == '1') ? 2 : 0);
+    const char* e = getenv("IGCN_GO_ATTN_CM");
+    v = (e && e[0] == '1') ? 1 : 0;
   }
-  return v;
+  return v == 1;
 }
-static bool go_use_bm(void) { return go_attn_variant() == 2; }
 
 extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
                                 const int32_t* t_ptr, const int32_t* t_row, const float* x, const float* w_inc,
@@ -1110,7 +848,7 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = 2 * fout + 3;
   const size_t abl_lds = go_abl_lds_bytes(N, fin, fout);
-  if (go_attn_variant() == 0 && abl_lds <= 160 * 1024 && N <= GO_ABL_T * GO_ABL_MAXIT) {
+  if (!go_attn_force_cm() && abl_lds <= 160 * 1024 && N <= GO_ABL_T * GO_ABL_MAXIT) {
     float* gpart = scratch;                                         // [rows * fin][B] block partials
     float* G = gpart + (int64_t)B * rows * fin;
     const int iters = (int)igcn_cdiv(N, GO_ABL_T);
@@ -1128,40 +866,6 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
 #undef CALLLI
     IGCN_CHECK_LAUNCH("go_attn_bwd(lds)");
     int rc = igcn_launch_reduce_contig(gpart, B, (int)(rows * fin), G, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_go_attn_bwd_finish, dim3(1), dim3(128), 0, st, fin, fout, G, w_inc, w_s, dparams);
-    IGCN_CHECK_LAUNCH("go_attn_bwd_finish");
-    return IGCN_OK;
-  }
-  if (go_use_bm() && (int64_t)(fin > fout ? fin : fout) * N * B < ((int64_t)1 << 31)) {
-    const int64_t nb = ((int64_t)N * B + 3) & ~(int64_t)3;          // sections start on 16-byte boundaries
-    float* xb = scratch;
-    float* dyb = xb + fin * nb;
-    float* statsb = dyb + fout * nb;                                // float4 [N][B]
-    float* dxb = statsb + 4 * nb;
-    float* gpart = dxb + fin * nb;
-    const int npw = go_bm_npw(B, N);
-    dim3 tg((unsigned)igcn_cdiv(N, 64), (unsigned)igcn_cdiv(B, 64), 1);
-    dim3 grid((unsigned)igcn_cdiv(N, 4 * npw), (unsigned)igcn_cdiv(B, 64));
-    const int64_t parts = (int64_t)grid.x * grid.y;
-    float* G = gpart + parts * rows * fin;
-    const int tvec = (N % 4 == 0 && B % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) &&
-                      ((uintptr_t)dx % 16 == 0) && ((uintptr_t)scratch % 16 == 0)) ? 1 : 0;
-    tg.z = fin;
-    hipLaunchKernelGGL(k_cm_to_bm, tg, dim3(256), 0, st, B, fin, N, tvec, x, xb);
-    tg.z = fout;
-    hipLaunchKernelGGL(k_cm_to_bm, tg, dim3(256), 0, st, B, fout, N, tvec, dy, dyb);
-#define CALLB(FI, FO)                                                                                            \
-  hipLaunchKernelGGL((k_go_attn_bwd_stats_bm<FI, FO>), grid, dim3(256), 0, st, B, N, npw, row_ptr, col, xb, w_inc, \
-                     a_in, dyb, (float4*)statsb);                                                                 \
-  hipLaunchKernelGGL((k_go_attn_bwd_main_bm<FI, FO>), grid, dim3(256), 0, st, B, N, npw, row_ptr, col, t_ptr,     \
-                     t_row, xb, w_inc, w_s, a_in, a_s, dyb, (const float4*)statsb, dxb, gpart)
-    GO_DISPATCH(fin, fout, CALLB)
-#undef CALLB
-    tg.z = fin;
-    hipLaunchKernelGGL(k_bm_to_cm, tg, dim3(256), 0, st, B, fin, N, tvec, dxb, dx);
-    IGCN_CHECK_LAUNCH("go_attn_bwd(bm)");
-    int rc = igcn_launch_reduce_contig(gpart, parts, (int)(rows * fin), G, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_go_attn_bwd_finish, dim3(1), dim3(128), 0, st, fin, fout, G, w_inc, w_s, dparams);
     IGCN_CHECK_LAUNCH("go_attn_bwd_finish");
