@@ -331,7 +331,9 @@ def test_adam_matches_torch(ops):
 @pytest.mark.parametrize("bsz,f,n,d,training,groups", [
     (6, 5, 11, 5, True, 1), (32, 5, 400, 32, True, 1), (32, 5, 400, 1, True, 1), (16, 2, 3000, 1, True, 1),
     (8, 5, 70, 8, False, 1), (5, 5, 33, 12, True, 1), (64, 5, 400, 32, True, 2), (12, 2, 130, 1, True, 2),
-    (10, 5, 50, 1, False, 2)])
+    (10, 5, 50, 1, False, 2),
+    # row-coalesced kernels (D = 16 / 32): node counts that leave shadow lanes, eval mode, the bench shape
+    (9, 5, 77, 32, True, 1), (6, 5, 77, 32, False, 1), (8, 5, 70, 16, True, 2), (512, 5, 400, 32, True, 2)])
 def test_node_linear_bn(ops, bsz, f, n, d, training, groups):
     rng = np.random.default_rng(n + d)
     x = torch.from_numpy(rng.standard_normal((bsz, f, n)) + 0.5).float()
