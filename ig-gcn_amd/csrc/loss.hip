@@ -206,7 +206,7 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, con
                 const float* __restrict__ reg, const float* __restrict__ clin, const float* __restrict__ x_hat,
                 const float* __restrict__ snps, const float* __restrict__ gram, const float* __restrict__ prob,
                 LossHeadW w, float* __restrict__ loss, float* __restrict__ terms) {
-  __shared__ float red[16];
+  __shared__ float red[4][16];
   const int tid = threadIdx.x;
   float ce = 0.f, mi = 0.f, mse = 0.f, rec = 0.f;
   for (int b = tid; b < B; b += 1024) {
@@ -220,15 +220,35 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, con
     const float d = reg[i] - clin[i < nreg ? i : i - nreg];
     mse += d * d;
   }
+  // one workgroup walks everything: 16 bytes per lane and the whole walk unrolled, so that it is one batch of loads
+  // instead of a chain of dependent trips (the kernel is pure latency)
+  if ((nrec & 3) == 0 && (((uintptr_t)x_hat | (uintptr_t)snps) & 15) == 0) {
+    const int nq = nrec / 4;
 #pragma unroll 8
-  for (int i = tid; i < 2 * nrec; i += 1024) {
-    const float d = x_hat[i] - snps[i < nrec ? i : i - nrec];
-    rec += d * d;
+    for (int i = tid; i < 2 * nq; i += 1024) {
+      const float4 a = reinterpret_cast<const float4*>(x_hat)[i];
+      const float4 s4 = reinterpret_cast<const float4*>(snps)[i < nq ? i : i - nq];
+      const float d0 = a.x - s4.x, d1 = a.y - s4.y, d2 = a.z - s4.z, d3 = a.w - s4.w;
+      rec += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  } else {
+#pragma unroll 8
+    for (int i = tid; i < 2 * nrec; i += 1024) {
+      const float d = x_hat[i] - snps[i < nrec ? i : i - nrec];
+      rec += d * d;
+    }
   }
-  ce = block_sum_all(ce, red);
-  mi = block_sum_all(mi, red);
-  mse = block_sum_all(mse, red);
-  rec = block_sum_all(rec, red);
+  // the four sums through LDS together: two barriers instead of eight
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+    ce = wave_sum(ce); mi = wave_sum(mi); mse = wave_sum(mse); rec = wave_sum(rec);
+    if (lane == 0) { red[0][wv] = ce; red[1][wv] = mi; red[2][wv] = mse; red[3][wv] = rec; }
+    __syncthreads();
+    if (tid == 0) {
+      ce = mi = mse = rec = 0.f;
+      for (int i = 0; i < 16; ++i) { ce += red[0][i]; mi += red[1][i]; mse += red[2][i]; rec += red[3][i]; }
+    }
+  }
   if (tid == 0) {
     float t[7];
     t[0] = w.lam[0] * (ce / (float)B);
