@@ -319,6 +319,35 @@ class Linear(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class ConcatCols(torch.autograd.Function):
+    """torch.cat(parts, dim=1) for up to four [N, F] tensors of equal width (F % 4 == 0): the jumping-knowledge
+    concatenation of the GCN layer outputs, moved 16 bytes per lane (igcn_concat_cols)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        import ctypes
+        parts = [_f32(p) for p in parts]
+        n, f = parts[0].shape
+        out = torch.empty(n, len(parts) * f, dtype=torch.float32, device=parts[0].device)
+        arr = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+        call("igcn_concat_cols", n, f, len(parts), arr, ptr(out), stream_ptr())
+        ctx.f, ctx.k = f, len(parts)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return tuple(d[:, i * ctx.f:(i + 1) * ctx.f] for i in range(ctx.k))
+
+
+def concat_cols(parts):
+    parts = list(parts)
+    ok = 1 <= len(parts) <= 4 and all(p.dim() == 2 and p.shape == parts[0].shape and p.is_cuda and
+                                      p.dtype == torch.float32 for p in parts) and parts[0].shape[1] % 4 == 0
+    if len(parts) == 1:
+        return parts[0]
+    return ConcatCols.apply(*parts) if ok else torch.cat(parts, dim=1)
+
+
 def linear(x, weight, bias=None, relu=False):
     lead = x.shape[:-1]
     y = Linear.apply(x.reshape(-1, x.shape[-1]), weight, bias, relu)

@@ -99,7 +99,7 @@ class SGCN_GCN(torch.nn.Module):
         for conv in self.convs:
             h = conv(h, plan_g, coef, relu=True)
             hs.append(h)
-        z = torch.cat(hs, dim=1).view(g * bsz, -1)                     # to_dense_batch == view (:378-381)
+        z = ops.concat_cols(hs).view(g * bsz, -1)                     # to_dense_batch == view (:378-381)
         f1 = ops.linear(z, self.lin1.weight, self.lin1.bias, relu=True)
         if self.training and self._dropout_enabled:
             f1 = F.dropout(f1, 0.5, True)

@@ -238,7 +238,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         for conv in self.convs:
             h = conv(h, plan_g, coef, relu=True)
             hs.append(h)
-        xcat = torch.cat(hs, dim=1)
+        xcat = ops.concat_cols(hs)
         gb = g * bsz
         batch_x = xcat.view(gb, self.rois, -1)                        # to_dense_batch == view (:226)
         img_out = batch_x.reshape(gb, -1)

@@ -149,6 +149,11 @@ int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F,
  * split_k > 1 writes split_k partial slabs into `scratch` (float[split_k*M*N]) and reduces them in order
  * (deterministic).  act: 0 none, 1 relu.
  */
+/* out[r, p*F + c] = parts[p][r, c], p < nparts <= 4: concatenation of the GCN layer outputs along the feature axis
+ * (kernel/sgcn_img_snp.py:223-224, kernel/sgcn.py:376-377 `torch.cat(xs, dim=1)`).  F % 4 == 0, 16-byte aligned
+ * tensors; `parts` is a HOST array of device pointers. */
+int igcn_concat_cols(int64_t rows, int F, int nparts, const float* const* parts, float* out, void* stream);
+
 /* Backward glue of out = act(A W^T + bias) (ops.Linear; lin1 / lin2 / GCNConv.lin of kernel/sgcn_img_snp.py:34-84):
  * g = dy * [y > 0] when `y` (the ReLU output) is given — then `g` receives the masked gradient the two GEMMs of
  * the backward read — and db[c] = sum_r g[r,c] (y == NULL: g unused, db = column sums of dy).  dy, y, g [rows, cols]
