@@ -222,3 +222,120 @@ extern "C" int igcn_concat_cols(int64_t rows, int F, int nparts, const float* co
   IGCN_CHECK_LAUNCH("concat_cols");
   return IGCN_OK;
 }
+
+// =================================================================================================
+// Inputs of the two MLP heads (kernel/sgcn_img_snp.py:284-297) in one pass:
+//   out_z   [R, W]         = (img + cross) / 2
+//   out_lin [R, W + L]     = out_z | latent
+//   feat    [R, W + L + P] = out_lin | (x * prob) of the row's sample          (P = 0: no regression features)
+// R = passes * bsz rows (pass-major), x [bsz, P], prob [P].  All widths are even: 8 bytes per lane (W + L + P = 3182
+// floats per row leaves odd rows only 8-byte aligned).  The composite is seven library launches forward and a dozen
+// backward (add, scale, two concatenations, broadcast multiply, repeat, their gradients and reductions).
+// =================================================================================================
+__global__ void __launch_bounds__(256)
+k_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, const float* __restrict__ img,
+                  const float* __restrict__ cross, const float* __restrict__ latent, const float* __restrict__ x,
+                  const float* __restrict__ prob, float* __restrict__ out_z, float* __restrict__ out_lin,
+                  float* __restrict__ feat) {
+  const int wf = (W + L + P) / 2;                               // float2 per row of the widest output
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * wf) return;
+  const int64_t r = i / wf;
+  const int c = (int)(i - r * wf) * 2;
+  float2 v;
+  if (c < W) {
+    const float2 a = *reinterpret_cast<const float2*>(img + r * W + c);
+    const float2 b = *reinterpret_cast<const float2*>(cross + r * W + c);
+    v = make_float2((a.x + b.x) * 0.5f, (a.y + b.y) * 0.5f);
+    *reinterpret_cast<float2*>(out_z + r * W + c) = v;
+  } else if (c < W + L) {
+    v = *reinterpret_cast<const float2*>(latent + r * L + (c - W));
+  } else {
+    const int j = c - W - L;
+    const int64_t b = r % bsz;
+    const float2 xv = *reinterpret_cast<const float2*>(x + b * P + j);
+    const float2 pv = *reinterpret_cast<const float2*>(prob + j);
+    v = make_float2(xv.x * pv.x, xv.y * pv.y);
+  }
+  if (c < W + L) *reinterpret_cast<float2*>(out_lin + r * (W + L) + c) = v;
+  if (feat) *reinterpret_cast<float2*>(feat + r * (W + L + P) + c) = v;
+}
+
+// d_mid [R, W] = (d_out_z + d_out_lin[:, :W] + d_feat[:, :W]) / 2  (the gradient of img AND of cross);
+// d_latent [R, L] = d_out_lin[:, W:] + d_feat[:, W:W+L].  Any of the three incoming gradients may be NULL.
+__global__ void __launch_bounds__(256)
+k_head_inputs_bwd_main(int64_t R, int W, int L, int P, const float* __restrict__ d_out_z,
+                       const float* __restrict__ d_out_lin, const float* __restrict__ d_feat,
+                       float* __restrict__ d_mid, float* __restrict__ d_latent) {
+  const int wf = (W + L) / 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * wf) return;
+  const int64_t r = i / wf;
+  const int c = (int)(i - r * wf) * 2;
+  float2 t = make_float2(0.f, 0.f);
+  if (d_out_lin) {
+    const float2 a = *reinterpret_cast<const float2*>(d_out_lin + r * (W + L) + c);
+    t.x += a.x; t.y += a.y;
+  }
+  if (d_feat) {
+    const float2 a = *reinterpret_cast<const float2*>(d_feat + r * (W + L + P) + c);
+    t.x += a.x; t.y += a.y;
+  }
+  if (c < W) {
+    if (d_out_z) {
+      const float2 a = *reinterpret_cast<const float2*>(d_out_z + r * W + c);
+      t.x += a.x; t.y += a.y;
+    }
+    *reinterpret_cast<float2*>(d_mid + r * W + c) = make_float2(t.x * 0.5f, t.y * 0.5f);
+  } else {
+    *reinterpret_cast<float2*>(d_latent + r * L + (c - W)) = t;
+  }
+}
+
+// regression features: g[b, j] = sum_passes d_feat[pass*bsz + b, W+L+j];  dx[b, j] = g * prob[j];
+// dprob[j] = sum_b g[b, j] * x[b, j].  One workgroup per column j, threads stride the samples.
+__global__ void __launch_bounds__(256)
+k_head_inputs_bwd_prob(int64_t R, int bsz, int W, int L, int P, const float* __restrict__ d_feat,
+                       const float* __restrict__ x, const float* __restrict__ prob, float* __restrict__ dx,
+                       float* __restrict__ dprob) {
+  __shared__ float red[16];
+  const int j = blockIdx.x, passes = (int)(R / bsz);
+  const float pj = prob[j];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < bsz; b += 256) {
+    float g = 0.f;
+    if (d_feat)
+      for (int k = 0; k < passes; ++k) g += d_feat[((int64_t)k * bsz + b) * (W + L + P) + W + L + j];
+    dx[(int64_t)b * P + j] = g * pj;
+    acc += g * x[(int64_t)b * P + j];
+  }
+  acc = block_sum_all(acc, red);
+  if (threadIdx.x == 0) dprob[j] = acc;
+}
+
+extern "C" int igcn_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, const float* img, const float* cross,
+                                    const float* latent, const float* x, const float* prob, float* out_z,
+                                    float* out_lin, float* feat, void* stream) {
+  IGCN_REQUIRE(R > 0 && bsz > 0 && R % bsz == 0 && W > 0 && L > 0 && P >= 0 && W % 2 == 0 && L % 2 == 0 && P % 2 == 0,
+               "head_inputs_fwd: even widths, R divisible by bsz");
+  IGCN_REQUIRE((P == 0) == (feat == nullptr), "head_inputs_fwd: feat goes with P > 0");
+  const int64_t total = R * ((W + L + P) / 2);
+  hipLaunchKernelGGL(k_head_inputs_fwd, dim3((unsigned)igcn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, R,
+                     bsz, W, L, P, img, cross, latent, x, prob, out_z, out_lin, feat);
+  IGCN_CHECK_LAUNCH("head_inputs_fwd");
+  return IGCN_OK;
+}
+
+extern "C" int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, const float* d_out_z,
+                                    const float* d_out_lin, const float* d_feat, const float* x, const float* prob,
+                                    float* d_mid, float* d_latent, float* dx, float* dprob, void* stream) {
+  IGCN_REQUIRE(R > 0 && bsz > 0 && R % bsz == 0 && W % 2 == 0 && L % 2 == 0 && P % 2 == 0, "head_inputs_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = R * ((W + L) / 2);
+  hipLaunchKernelGGL(k_head_inputs_bwd_main, dim3((unsigned)igcn_cdiv(total, 256)), dim3(256), 0, st, R, W, L, P,
+                     d_out_z, d_out_lin, d_feat, d_mid, d_latent);
+  if (P > 0 && dx && dprob)
+    hipLaunchKernelGGL(k_head_inputs_bwd_prob, dim3(P), dim3(256), 0, st, R, bsz, W, L, P, d_feat, x, prob, dx, dprob);
+  IGCN_CHECK_LAUNCH("head_inputs_bwd");
+  return IGCN_OK;
+}

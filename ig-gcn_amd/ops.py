@@ -348,6 +348,62 @@ def concat_cols(parts):
     return ConcatCols.apply(*parts) if ok else torch.cat(parts, dim=1)
 
 
+class HeadInputs(torch.autograd.Function):
+    """(out_z, out_lin, feat) of kernel/sgcn_img_snp.py:284-297 from (img_out, out_cross, latent, x, prob) in one
+    launch (igcn_head_inputs_*): out_z = (img + cross)/2, out_lin = out_z | latent, feat = out_lin | x * prob of the
+    row's sample.  ``prob`` None: no regression features, ``feat`` is ``out_lin``."""
+
+    @staticmethod
+    def forward(ctx, img, cross, latent, x, prob, bsz):
+        img, cross, latent = _f32(img), _f32(cross), _f32(latent)
+        r, w = img.shape
+        l = latent.shape[1]
+        p = 0
+        if prob is not None:
+            x, prob = _f32(x), _f32(prob)
+            p = prob.numel()
+        dev = img.device
+        out_z = torch.empty(r, w, dtype=torch.float32, device=dev)
+        out_lin = torch.empty(r, w + l, dtype=torch.float32, device=dev)
+        feat = torch.empty(r, w + l + p, dtype=torch.float32, device=dev) if p else None
+        call("igcn_head_inputs_fwd", r, bsz, w, l, p, ptr(img), ptr(cross), ptr(latent), ptr(x) if p else None,
+             ptr(prob) if p else None, ptr(out_z), ptr(out_lin), ptr(feat), stream_ptr())
+        ctx.save_for_backward(x if p else None, prob if p else None)
+        ctx.dims = (r, bsz, w, l, p)
+        ctx.x_shape = x.shape if p else None
+        ctx.set_materialize_grads(False)
+        if p:
+            return out_z, out_lin, feat
+        none = out_lin.new_empty(0)
+        ctx.mark_non_differentiable(none)
+        return out_z, out_lin, none
+
+    @staticmethod
+    def backward(ctx, d_out_z, d_out_lin, d_feat):
+        x, prob = ctx.saved_tensors
+        r, bsz, w, l, p = ctx.dims
+        dev = d_out_z.device if d_out_z is not None else (d_out_lin.device if d_out_lin is not None else d_feat.device)
+        gz = _f32(d_out_z) if d_out_z is not None else None
+        gl = _f32(d_out_lin) if d_out_lin is not None else None
+        gf = _f32(d_feat) if (d_feat is not None and p) else None
+        d_mid = torch.empty(r, w, dtype=torch.float32, device=dev)
+        d_latent = torch.empty(r, l, dtype=torch.float32, device=dev)
+        dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if p else None
+        dprob = torch.empty(prob.shape, dtype=torch.float32, device=dev) if p else None
+        call("igcn_head_inputs_bwd", r, bsz, w, l, p, ptr(gz), ptr(gl), ptr(gf), ptr(x), ptr(prob), ptr(d_mid),
+             ptr(d_latent), ptr(dx), ptr(dprob), stream_ptr())
+        return d_mid, d_mid, d_latent, dx, dprob, None
+
+
+def head_inputs_supported(img, cross, latent, x, prob):
+    ts = [img, cross, latent] + ([x, prob] if prob is not None else [])
+    if not all(t.is_cuda and t.dtype == torch.float32 for t in ts):
+        return False
+    w, l = img.shape[1], latent.shape[1]
+    p = prob.numel() if prob is not None else 0
+    return img.shape == cross.shape and w % 2 == 0 and l % 2 == 0 and p % 2 == 0
+
+
 def linear(x, weight, bias=None, relu=False):
     lead = x.shape[:-1]
     y = Linear.apply(x.reshape(-1, x.shape[-1]), weight, bias, relu)

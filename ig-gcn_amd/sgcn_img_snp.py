@@ -249,6 +249,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         else:
             out_cross = torch.cat((img_out, latent), -1)
 
+        fused_head = False
         if self.isImageOnly:
             out_z = img_out
             out_lin = out_z
@@ -256,11 +257,21 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             out_z = latent
             out_lin = torch.cat((snps_in, latent), -1)
         else:
-            out_z = (img_out + out_cross) / 2
-            out_lin = torch.cat((out_z, latent), -1)
+            use_prob = self.isuseProb4Regr
+            x_flat, prob_flat = (data.x.view(bsz, -1), self.prob.view(-1)) if use_prob else (None, None)
+            if ops.head_inputs_supported(img_out, out_cross, latent, x_flat, prob_flat):
+                fused_head = True                                         # :284-297 in one launch
+                out_z, out_lin, feat = ops.HeadInputs.apply(img_out, out_cross, latent, x_flat, prob_flat, bsz)
+                if not use_prob:
+                    feat = out_lin
+            else:
+                out_z = (img_out + out_cross) / 2
+                out_lin = torch.cat((out_z, latent), -1)
         linear_outf = ops.linear(out_lin, self.lin1.weight, self.lin1.bias, relu=True)
         logits = ops.linear(self._drop(linear_outf, 0.5), self.lin2.weight, self.lin2.bias)
-        if self.isuseProb4Regr and not self.isSNPsOnly:
+        if fused_head:
+            pass
+        elif self.isuseProb4Regr and not self.isSNPsOnly:
             img_feat = (data.x.view(bsz, self.rois, -1) * self.prob).reshape(bsz, -1)      # :293-297
             feat = torch.cat((out_lin, img_feat if g == 1 else img_feat.repeat(g, 1)), -1)
         else:

@@ -149,6 +149,18 @@ int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F,
  * split_k > 1 writes split_k partial slabs into `scratch` (float[split_k*M*N]) and reduces them in order
  * (deterministic).  act: 0 none, 1 relu.
  */
+/* Inputs of the two MLP heads (kernel/sgcn_img_snp.py:284-297) in one pass, R = passes * bsz rows (pass-major):
+ *   out_z [R,W] = (img + cross) / 2;  out_lin [R,W+L] = out_z | latent;
+ *   feat [R,W+L+P] = out_lin | (x * prob)[row % bsz]   (x [bsz,P] = data.x per sample, prob [P]; P = 0: feat NULL).
+ * Backward: any of d_out_z / d_out_lin / d_feat may be NULL; d_mid [R,W] is the gradient of img and of cross,
+ * d_latent [R,L], dx [bsz,P], dprob [P] (the last two only when P > 0).  W, L, P even. */
+int igcn_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, const float* img, const float* cross,
+                         const float* latent, const float* x, const float* prob, float* out_z, float* out_lin,
+                         float* feat, void* stream);
+int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, const float* d_out_z, const float* d_out_lin,
+                         const float* d_feat, const float* x, const float* prob, float* d_mid, float* d_latent,
+                         float* dx, float* dprob, void* stream);
+
 /* out[r, p*F + c] = parts[p][r, c], p < nparts <= 4: concatenation of the GCN layer outputs along the feature axis
  * (kernel/sgcn_img_snp.py:223-224, kernel/sgcn.py:376-377 `torch.cat(xs, dim=1)`).  F % 4 == 0, 16-byte aligned
  * tensors; `parts` is a HOST array of device pointers. */

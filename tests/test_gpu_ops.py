@@ -172,6 +172,47 @@ def test_linear_fwd_bwd(ops, rows, fin, fout, relu, bias):
         assert_matches(got, want.numpy(), TOL, nm)
 
 
+@pytest.mark.parametrize("bsz,g,w,l,rois,use_prob,used", [(6, 2, 96, 32, 8, True, (1, 1, 1)), (5, 1, 40, 6, 4, True, (0, 1, 1)),
+                                                          (4, 2, 64, 32, 8, False, (1, 1, 0)), (256, 2, 2880, 32, 90, True, (1, 0, 1))])
+def test_head_inputs(ops, bsz, g, w, l, rois, use_prob, used):
+    """igcn_head_inputs_* (out_z, out_lin, feat in one launch) against the composite of kernel/sgcn_img_snp.py:284-297;
+    ``used`` selects which outputs feed the loss (unused ones reach the backward as None)."""
+    rng = np.random.default_rng(bsz + w)
+    mk = lambda *shape: torch.from_numpy(rng.standard_normal(shape)).float()      # noqa: E731
+    img, cross, latent, x, prob = mk(g * bsz, w), mk(g * bsz, w), mk(g * bsz, l), mk(bsz * rois, 3), mk(rois, 3)
+    cots = [mk(g * bsz, w), mk(g * bsz, w + l), mk(g * bsz, w + l + (3 * rois if use_prob else 0))]
+
+    def composite(img, cross, latent, x, prob):
+        out_z = (img + cross) / 2
+        out_lin = torch.cat((out_z, latent), -1)
+        feat = out_lin
+        if use_prob:
+            img_feat = (x.view(bsz, rois, -1) * prob).reshape(bsz, -1)
+            feat = torch.cat((out_lin, img_feat.repeat(g, 1)), -1)
+        return out_z, out_lin, feat
+
+    def total(outs, cots):
+        return sum((o * c).sum() for o, c, u in zip(outs, cots, used) if u)
+
+    ref_in = [t.double().requires_grad_(True) for t in (img, cross, latent, x, prob)]
+    ref_out = composite(*ref_in)
+    g_ref = torch.autograd.grad(total(ref_out, [c.double() for c in cots]), ref_in, allow_unused=True)
+    dev = [t.cuda().requires_grad_(True) for t in (img, cross, latent, x, prob)]
+    if use_prob:
+        outs = ops.HeadInputs.apply(dev[0], dev[1], dev[2], dev[3].view(bsz, -1), dev[4].view(-1), bsz)
+    else:
+        oz, ol, _ = ops.HeadInputs.apply(dev[0], dev[1], dev[2], None, None, bsz)
+        outs = (oz, ol, ol)
+    for got, want, nm in zip(outs, ref_out, ("out_z", "out_lin", "feat")):
+        assert_matches(got, want.detach().numpy(), TOL, nm)
+    gd = torch.autograd.grad(total(outs, [c.cuda() for c in cots]), dev, allow_unused=True)
+    for got, want, nm in zip(gd, g_ref, ("d_img", "d_cross", "d_latent", "dx", "dprob")):
+        if want is None:
+            assert got is None or float(got.abs().max()) == 0.0, nm
+        else:
+            assert_matches(got, want.numpy(), TOL, nm)
+
+
 def test_gemm_is_exact_fp32_fma_chain(ops):
     """MFMA f32 = k-ordered fmaf chain: small-integer operands must be reproduced exactly."""
     rng = np.random.default_rng(0)
