@@ -339,3 +339,50 @@ extern "C" int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, con
   IGCN_CHECK_LAUNCH("head_inputs_bwd");
   return IGCN_OK;
 }
+
+// =================================================================================================
+// SNP importance mask (kernel/sgcn_img_snp.py:147-151): out[b, j] = snps[b, j] * sigmoid(p[j]), sp[j] = sigmoid(p[j]);
+// backward dp[j] = (sum_b dout[b, j] snps[b, j] + dsp[j]) * sp (1 - sp).  One workgroup per SNP column.
+// =================================================================================================
+__global__ void __launch_bounds__(256)
+k_snps_mask_fwd(int B, int S, const float* __restrict__ snps, const float* __restrict__ p, float* __restrict__ out,
+                float* __restrict__ sp) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * S) return;
+  const int j = (int)(i % S);
+  const float sg = 1.f / (1.f + __expf(-p[j]));
+  out[i] = snps[i] * sg;
+  if (i < S) sp[j] = sg;
+}
+
+__global__ void __launch_bounds__(256)
+k_snps_mask_bwd(int B, int S, const float* __restrict__ snps, const float* __restrict__ p,
+                const float* __restrict__ dout, const float* __restrict__ dsp, float* __restrict__ dp) {
+  __shared__ float red[16];
+  const int j = blockIdx.x;
+  float acc = 0.f;
+  if (dout)
+    for (int b = threadIdx.x; b < B; b += 256) acc += dout[(int64_t)b * S + j] * snps[(int64_t)b * S + j];
+  acc = block_sum_all(acc, red);
+  if (threadIdx.x == 0) {
+    const float sg = 1.f / (1.f + __expf(-p[j]));
+    dp[j] = (acc + (dsp ? dsp[j] : 0.f)) * sg * (1.f - sg);
+  }
+}
+
+extern "C" int igcn_snps_mask_fwd(int B, int S, const float* snps, const float* p, float* out, float* sp,
+                                  void* stream) {
+  IGCN_REQUIRE(B > 0 && S > 0, "snps_mask_fwd: bad sizes");
+  hipLaunchKernelGGL(k_snps_mask_fwd, dim3((unsigned)igcn_cdiv((int64_t)B * S, 256)), dim3(256), 0, (hipStream_t)stream,
+                     B, S, snps, p, out, sp);
+  IGCN_CHECK_LAUNCH("snps_mask_fwd");
+  return IGCN_OK;
+}
+
+extern "C" int igcn_snps_mask_bwd(int B, int S, const float* snps, const float* p, const float* dout, const float* dsp,
+                                  float* dp, void* stream) {
+  IGCN_REQUIRE(B > 0 && S > 0, "snps_mask_bwd: bad sizes");
+  hipLaunchKernelGGL(k_snps_mask_bwd, dim3(S), dim3(256), 0, (hipStream_t)stream, B, S, snps, p, dout, dsp, dp);
+  IGCN_CHECK_LAUNCH("snps_mask_bwd");
+  return IGCN_OK;
+}

@@ -348,6 +348,31 @@ def concat_cols(parts):
     return ConcatCols.apply(*parts) if ok else torch.cat(parts, dim=1)
 
 
+class SnpsMask(torch.autograd.Function):
+    """(snps * sigmoid(p), sigmoid(p)) of cal_probability (kernel/sgcn_img_snp.py:147-151); p [1,S] or [S]."""
+
+    @staticmethod
+    def forward(ctx, snps, p):
+        snps, p = _f32(snps), _f32(p)
+        b, s = snps.shape
+        out, sp = torch.empty_like(snps), torch.empty_like(p)
+        call("igcn_snps_mask_fwd", b, s, ptr(snps), ptr(p), ptr(out), ptr(sp), stream_ptr())
+        ctx.save_for_backward(snps, p)
+        ctx.set_materialize_grads(False)
+        return out, sp
+
+    @staticmethod
+    def backward(ctx, dout, dsp):
+        snps, p = ctx.saved_tensors
+        if dout is None and dsp is None:
+            return None, None
+        b, s = snps.shape
+        dp = torch.empty_like(p)
+        call("igcn_snps_mask_bwd", b, s, ptr(snps), ptr(p), ptr(_f32(dout)) if dout is not None else None,
+             ptr(_f32(dsp)) if dsp is not None else None, ptr(dp), stream_ptr())
+        return None, dp
+
+
 class HeadInputs(torch.autograd.Function):
     """(out_z, out_lin, feat) of kernel/sgcn_img_snp.py:284-297 from (img_out, out_cross, latent, x, prob) in one
     launch (igcn_head_inputs_*): out_z = (img + cross)/2, out_lin = out_z | latent, feat = out_lin | x * prob of the

@@ -126,6 +126,9 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         plan = plan if plan is not None else ops.GraphPlan(edge_index, x.shape[0])
         xm, ewm, e = ops.EdgeMask.apply(x, self.prob, self.prob_bias, edge_weight, plan, self.rois)
         if snps_feat is not None:
+            if snps_feat.is_cuda and snps_feat.dim() == 2 and snps_feat.shape[1] == self.snps_prob.numel():
+                snps_m, sp = ops.SnpsMask.apply(snps_feat, self.snps_prob)     # sigmoid + multiply in one launch
+                return xm, ewm, self.prob, e, snps_m, sp
             sp = torch.sigmoid(self.snps_prob)
             return xm, ewm, self.prob, e, snps_feat * sp, sp
         return xm, ewm, self.prob, e

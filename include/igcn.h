@@ -149,6 +149,12 @@ int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F,
  * split_k > 1 writes split_k partial slabs into `scratch` (float[split_k*M*N]) and reduces them in order
  * (deterministic).  act: 0 none, 1 relu.
  */
+/* SNP importance mask of cal_probability (kernel/sgcn_img_snp.py:147-151): out [B,S] = snps * sigmoid(p),
+ * sp [S] = sigmoid(p).  Backward: dp [S] from dout [B,S] and/or dsp [S] (either may be NULL); snps gets no gradient. */
+int igcn_snps_mask_fwd(int B, int S, const float* snps, const float* p, float* out, float* sp, void* stream);
+int igcn_snps_mask_bwd(int B, int S, const float* snps, const float* p, const float* dout, const float* dsp,
+                       float* dp, void* stream);
+
 /* Inputs of the two MLP heads (kernel/sgcn_img_snp.py:284-297) in one pass, R = passes * bsz rows (pass-major):
  *   out_z [R,W] = (img + cross) / 2;  out_lin [R,W+L] = out_z | latent;
  *   feat [R,W+L+P] = out_lin | (x * prob)[row % bsz]   (x [bsz,P] = data.x per sample, prob [P]; P = 0: feat NULL).
