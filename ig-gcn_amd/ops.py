@@ -180,6 +180,7 @@ class GcnNorm(torch.autograd.Function):
         ctx.save_for_backward(ew, dis, wl)
         ctx.plan = plan
         ctx.mark_non_differentiable(tstream, sstream)
+        ctx.set_materialize_grads(False)          # no zero tensors for the two record streams in the backward
         return what, wloop, tstream, sstream
 
     @staticmethod
@@ -796,6 +797,7 @@ class LossHead(torch.autograd.Function):
              ptr(gram), ptr(prob), lam6, float(hp_ce), float(hp_mi), ptr(loss), ptr(terms), stream_ptr())
         ctx.save_for_backward(y, reg, clin, x_hat, snps)
         ctx.mark_non_differentiable(terms)
+        ctx.set_materialize_grads(False)          # no zero tensor for `terms` in the backward
         return loss.view(()), terms
 
     @staticmethod
