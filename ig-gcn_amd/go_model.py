@@ -152,4 +152,7 @@ class Gene_ontology_network(nn.Module):
         if self._tracked:                              # num_batches_tracked of the five BatchNorms: one launch
             torch._foreach_add_(self._tracked, groups)
             self._tracked = []
-        return latent, x_d, [torch.zeros(3, device=dev)], atten_out
+        zeros3 = getattr(self, "_zeros3", None)          # placeholder of the reference's unused third output
+        if zeros3 is None or zeros3.device != dev:
+            zeros3 = self._zeros3 = torch.zeros(3, device=dev)
+        return latent, x_d, [zeros3], atten_out

@@ -200,7 +200,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             kvh = kv.view(b, lk, 2, h, hd)
             att = torch.softmax((qh @ kvh[:, :, 0].permute(0, 2, 3, 1)) * (1.0 / math.sqrt(hd)), dim=-1)
             o = (att @ kvh[:, :, 1].transpose(1, 2)).transpose(1, 2).reshape(b, lq, d)
-        return F.relu(ops.linear(o, mha.out_proj.weight, mha.out_proj.bias))
+        return ops.linear(o, mha.out_proj.weight, mha.out_proj.bias, relu=True)      # F.relu(...) of :242, fused
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, data, temperature=None, device=None, isExplain=False):
