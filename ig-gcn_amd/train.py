@@ -8,6 +8,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn.functional as F
 
+from . import _lib
 from ._lib import call, ptr, stream_ptr
 
 # sgcn_hyperparameters.py:18-23
@@ -285,7 +286,13 @@ class GraphedTrainStep:
                 self.opt.step(refresh=False)            # reads the pointer table at replay time
             else:
                 self.opt.pack_grads(refresh=False)
-        self.opt.refresh_table()                        # the captured gradient tensors keep their addresses
+        # the captured gradient tensors keep their addresses — which only helps if the table can point AT them: a
+        # non-contiguous gradient would be copied by refresh_table, and the replays would never update the copy
+        for p in self.opt.params:
+            if p.grad is not None and not p.grad.is_contiguous():
+                raise _lib.IgcnError("graphed step: a parameter gradient is not contiguous "
+                                     f"(shape {tuple(p.shape)}, strides {p.grad.stride()})")
+        self.opt.refresh_table()
         self.g_opt = None
         if dist:
             self.g_opt = torch.cuda.CUDAGraph()
