@@ -22,14 +22,14 @@ SIGNATURES = {
     "igcn_graph_plan_build": (I, [L, L, P, P, P, P, P, P, P, P, P, Z, P]),
     "igcn_graph_plan_build_segmented": (I, [L, L, I, P, P, P, L, L, P, P, P, P, P, P, P, P, P]),
     "igcn_graph_plan_replicate": (I, [L, L, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "igcn_edge_mask_fwd": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P]),
-    "igcn_edge_mask_bwd": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_edge_mask_fwd": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_edge_mask_bwd": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_gcn_norm_fwd": (I, [L, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_gcn_norm_bwd": (I, [L, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_gcn_propagate_fwd": (I, [L, L, I, I, P, L, P, P, P, P, P, L, I, P]),
     "igcn_gcn_propagate_bwd_scratch_floats": (Z, [L, I]),
     "igcn_gcn_propagate_bwd": (I, [L, L, I, P, L, P, L, I, P, L, P, P, P, P, P, P, L, P, I, P, P, P, P]),
-    "igcn_snps_mask_fwd": (I, [I, I, P, P, P, P, P]),
+    "igcn_snps_mask_fwd": (I, [I, I, P, P, P, P, P, P]),
     "igcn_snps_mask_bwd": (I, [I, I, P, P, P, P, P, P]),
     "igcn_head_inputs_fwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "igcn_head_inputs_bwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),

@@ -346,12 +346,14 @@ extern "C" int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, con
 // =================================================================================================
 __global__ void __launch_bounds__(256)
 k_snps_mask_fwd(int B, int S, const float* __restrict__ snps, const float* __restrict__ p, float* __restrict__ out,
-                float* __restrict__ sp) {
+                float* __restrict__ sp, float* __restrict__ plain) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)B * S) return;
   const int j = (int)(i % S);
   const float sg = 1.f / (1.f + __expf(-p[j]));
-  out[i] = snps[i] * sg;
+  const float v = snps[i];
+  out[i] = v * sg;
+  if (plain) plain[i] = v;                              // first half of the stacked (plain | masked) batch
   if (i < S) sp[j] = sg;
 }
 
@@ -371,10 +373,10 @@ k_snps_mask_bwd(int B, int S, const float* __restrict__ snps, const float* __res
 }
 
 extern "C" int igcn_snps_mask_fwd(int B, int S, const float* snps, const float* p, float* out, float* sp,
-                                  void* stream) {
+                                  float* plain, void* stream) {
   IGCN_REQUIRE(B > 0 && S > 0, "snps_mask_fwd: bad sizes");
   hipLaunchKernelGGL(k_snps_mask_fwd, dim3((unsigned)igcn_cdiv((int64_t)B * S, 256)), dim3(256), 0, (hipStream_t)stream,
-                     B, S, snps, p, out, sp);
+                     B, S, snps, p, out, sp, plain);
   IGCN_CHECK_LAUNCH("snps_mask_fwd");
   return IGCN_OK;
 }

@@ -12,12 +12,14 @@ __global__ void k_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int 
                                 const float* __restrict__ prob, const float* __restrict__ pb,
                                 const float* __restrict__ ew, const int32_t* __restrict__ src32,
                                 const int32_t* __restrict__ dst32, float* __restrict__ xm, float* __restrict__ e,
-                                float* __restrict__ ewm) {
+                                float* __restrict__ ewm, float* __restrict__ x_plain, float* __restrict__ ew_plain) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_nodes * h0) {
     const int64_t node = i / h0;
     const int h = (int)(i - node * h0);
-    xm[i] = x[i] * prob[(node % rois) * h0 + h];
+    const float xv = x[i];
+    xm[i] = xv * prob[(node % rois) * h0 + h];
+    if (x_plain) x_plain[i] = xv;                     // first half of the stacked (plain | masked) batch
   }
   if (i < n_edges) {
     const int64_t s = src32[i], d = dst32[i];
@@ -27,20 +29,23 @@ __global__ void k_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int 
     for (int h = 0; h < h0; ++h) z += (x[d * h0 + h] * prob[rd + h]) * pb[h0 + h];
     const float p = 1.f / (1.f + expf(-z));
     e[i] = p;
-    ewm[i] = ew[i] * p;
+    const float wv = ew[i];
+    ewm[i] = wv * p;
+    if (ew_plain) ew_plain[i] = wv;
   }
 }
 
 extern "C" int igcn_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x,
                                   const float* prob, const float* prob_bias, const float* ew, const int32_t* src32,
-                                  const int32_t* dst32, float* xm, float* e, float* ewm, void* stream) {
+                                  const int32_t* dst32, float* xm, float* e, float* ewm, float* x_plain,
+                                  float* ew_plain, void* stream) {
   IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0,
                "edge_mask_fwd: need n_nodes %% rois == 0 and 0 < h0 <= %d (n_nodes=%lld rois=%d h0=%d)", MAX_H0,
                (long long)n_nodes, rois, h0);
   const int64_t n = n_nodes * h0 > n_edges ? n_nodes * h0 : n_edges;
   if (n == 0) return IGCN_OK;
   hipLaunchKernelGGL(k_edge_mask_fwd, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n_nodes,
-                     n_edges, rois, h0, x, prob, prob_bias, ew, src32, dst32, xm, e, ewm);
+                     n_edges, rois, h0, x, prob, prob_bias, ew, src32, dst32, xm, e, ewm, x_plain, ew_plain);
   IGCN_CHECK_LAUNCH("edge_mask_fwd");
   return IGCN_OK;
 }
@@ -59,7 +64,8 @@ k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict
                       const float* __restrict__ prob, const float* __restrict__ pb,
                       const float* __restrict__ ew, const float* __restrict__ e,
                       const float* __restrict__ d_xm, const float* __restrict__ d_ewm,
-                      const float* __restrict__ d_e, const int32_t* __restrict__ tgt_ptr,
+                      const float* __restrict__ d_e, const float* __restrict__ d_x_plain,
+                      const int32_t* __restrict__ tgt_ptr,
                       const int32_t* __restrict__ tgt_perm, const int32_t* __restrict__ src_ptr,
                       const int32_t* __restrict__ src_perm, float* __restrict__ dx,
                       float* __restrict__ gx /*[N,h0]*/, float* __restrict__ pb_partial /*[nblk,2h0]*/) {
@@ -90,7 +96,7 @@ k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict
       for (int h = 0; h < h0; ++h) {
         const float xv = x[i * h0 + h], pv = prob[r + h];
         const float g = (d_xm ? d_xm[i * h0 + h] : 0.f) + pb[h] * S + pb[h0 + h] * T;
-        dx[i * h0 + h] = g * pv;
+        dx[i * h0 + h] = g * pv + (d_x_plain ? d_x_plain[i * h0 + h] : 0.f);   // + the plain half of a stacked batch
         gx[i * h0 + h] = g * xv;
         acc[h] += xv * pv * S;
         acc[MAX_H0 + h] += xv * pv * T;
@@ -124,9 +130,10 @@ __global__ void k_edge_mask_bwd_pb(int64_t nblk, int h0, const float* __restrict
 
 extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x,
                                   const float* prob, const float* prob_bias, const float* ew, const float* e,
-                                  const float* d_xm, const float* d_ewm, const float* d_e, const int32_t* tgt_ptr,
-                                  const int32_t* tgt_perm, const int32_t* src_ptr, const int32_t* src_perm,
-                                  float* dx, float* dprob, float* dprob_bias, float* scratch, void* stream) {
+                                  const float* d_xm, const float* d_ewm, const float* d_e, const float* d_x_plain,
+                                  const int32_t* tgt_ptr, const int32_t* tgt_perm, const int32_t* src_ptr,
+                                  const int32_t* src_perm, float* dx, float* dprob, float* dprob_bias, float* scratch,
+                                  void* stream) {
   IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0, "edge_mask_bwd: bad rois/h0");
   hipStream_t st = (hipStream_t)stream;
   const bool dense = n_edges >= 16 * n_nodes;
@@ -135,10 +142,10 @@ extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, in
   float* part = scratch + n_nodes * h0;  // [nblk, 2*MAX_H0]
   if (dense)                                       // dense graphs: the wave strides a node's edge lists
     hipLaunchKernelGGL(k_edge_mask_bwd_nodes<64>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
-                       prob_bias, ew, e, d_xm, d_ewm, d_e, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
+                       prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
   else                                             // k = 3 graphs: four lanes share a node's six list entries
     hipLaunchKernelGGL(k_edge_mask_bwd_nodes<4>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
-                       prob_bias, ew, e, d_xm, d_ewm, d_e, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
+                       prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
   hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)(rois * h0)), dim3(256), 0, st, n_nodes / rois, rois, h0,
                      gx, dprob);
   if (nblk > 256) {                                // many partial rows: parallel column sums first

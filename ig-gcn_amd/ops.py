@@ -139,25 +139,57 @@ class EdgeMask(torch.autograd.Function):
         n, h0 = x.shape
         xm, e, ewm = torch.empty_like(x), torch.empty_like(ew), torch.empty_like(ew)
         call("igcn_edge_mask_fwd", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew),
-             ptr(plan.src32), ptr(plan.dst32), ptr(xm), ptr(e), ptr(ewm), stream_ptr())
+             ptr(plan.src32), ptr(plan.dst32), ptr(xm), ptr(e), ptr(ewm), None, None, stream_ptr())
         ctx.save_for_backward(x, prob, pb, ew, e)
         ctx.plan, ctx.rois = plan, rois
         return xm, ewm, e
 
     @staticmethod
     def backward(ctx, d_xm, d_ewm, d_e):
-        x, prob, pb, ew, e = ctx.saved_tensors
-        plan, rois = ctx.plan, ctx.rois
+        return _edge_mask_backward(ctx, d_xm, d_ewm, d_e, None)
+
+
+def _edge_mask_backward(ctx, d_xm, d_ewm, d_e, d_x_plain):
+    x, prob, pb, ew, e = ctx.saved_tensors
+    plan, rois = ctx.plan, ctx.rois
+    n, h0 = x.shape
+    d_xm, d_ewm, d_e, d_x_plain = (_f32(t) if t is not None else None for t in (d_xm, d_ewm, d_e, d_x_plain))
+    dx, dprob, dpb = torch.empty_like(x), torch.empty_like(prob), torch.empty_like(pb)
+    scratch = torch.empty(n * h0 + 16 * ((n + 3) // 4) + 16, dtype=torch.float32, device=x.device)
+    call("igcn_edge_mask_bwd", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew), ptr(e),
+         ptr(d_xm), ptr(d_ewm), ptr(d_e), ptr(d_x_plain), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr),
+         ptr(plan.src_perm), ptr(dx), ptr(dprob), ptr(dpb), ptr(scratch), stream_ptr())
+    return dx, dprob, dpb, None, None, None
+
+
+class EdgeMaskStacked(torch.autograd.Function):
+    """The (plain | masked) batch of the two passes of a train step in one launch: x_in = cat(x, xm) [2N,h0],
+    ew_in = cat(ew, ewm) [2E], and the edge mask e — cal_probability (kernel/sgcn_img_snp.py:133-151) writing both
+    halves itself instead of two concatenations behind it."""
+
+    @staticmethod
+    def forward(ctx, x, prob, prob_bias, ew, plan, rois):
+        x, prob, pb, ew = _f32(x), _f32(prob), _f32(prob_bias), _f32(ew)
         n, h0 = x.shape
-        d_xm = _f32(d_xm) if d_xm is not None else None
-        d_ewm = _f32(d_ewm) if d_ewm is not None else None
-        d_e = _f32(d_e) if d_e is not None else None
-        dx, dprob, dpb = torch.empty_like(x), torch.empty_like(prob), torch.empty_like(pb)
-        scratch = torch.empty(n * h0 + 16 * ((n + 3) // 4) + 16, dtype=torch.float32, device=x.device)
-        call("igcn_edge_mask_bwd", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew), ptr(e),
-             ptr(d_xm), ptr(d_ewm), ptr(d_e), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr),
-             ptr(plan.src_perm), ptr(dx), ptr(dprob), ptr(dpb), ptr(scratch), stream_ptr())
-        return dx, dprob, dpb, None, None, None
+        ne = ew.shape[0]
+        x_in = torch.empty(2 * n, h0, dtype=torch.float32, device=x.device)
+        ew_in = torch.empty(2 * ne, dtype=torch.float32, device=x.device)
+        e = torch.empty_like(ew)
+        call("igcn_edge_mask_fwd", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew),
+             ptr(plan.src32), ptr(plan.dst32), ptr(x_in[n:]), ptr(e), ptr(ew_in[ne:]), ptr(x_in[:n]), ptr(ew_in[:ne]),
+             stream_ptr())
+        ctx.save_for_backward(x, prob, pb, ew, e)
+        ctx.plan, ctx.rois = plan, rois
+        ctx.set_materialize_grads(False)
+        return x_in, ew_in, e
+
+    @staticmethod
+    def backward(ctx, d_x_in, d_ew_in, d_e):
+        n, ne = ctx.saved_tensors[0].shape[0], ctx.saved_tensors[3].shape[0]
+        d_xm = d_x_in[n:] if d_x_in is not None else None
+        d_xp = d_x_in[:n] if d_x_in is not None else None
+        d_ewm = d_ew_in[ne:] if d_ew_in is not None else None
+        return _edge_mask_backward(ctx, d_xm, d_ewm, d_e, d_xp)
 
 
 class GcnNorm(torch.autograd.Function):
@@ -353,25 +385,35 @@ class SnpsMask(torch.autograd.Function):
     """(snps * sigmoid(p), sigmoid(p)) of cal_probability (kernel/sgcn_img_snp.py:147-151); p [1,S] or [S]."""
 
     @staticmethod
-    def forward(ctx, snps, p):
+    def forward(ctx, snps, p, stacked=False):
+        """``stacked``: the first output is cat(snps, snps * sigmoid(p)) [2B,S] (plain | masked pass)."""
         snps, p = _f32(snps), _f32(p)
         b, s = snps.shape
-        out, sp = torch.empty_like(snps), torch.empty_like(p)
-        call("igcn_snps_mask_fwd", b, s, ptr(snps), ptr(p), ptr(out), ptr(sp), stream_ptr())
+        sp = torch.empty_like(p)
+        if stacked:
+            full = torch.empty(2 * b, s, dtype=torch.float32, device=snps.device)
+            out = full[b:]
+        else:
+            full = out = torch.empty_like(snps)
+        call("igcn_snps_mask_fwd", b, s, ptr(snps), ptr(p), ptr(out), ptr(sp), ptr(full[:b]) if stacked else None,
+             stream_ptr())
         ctx.save_for_backward(snps, p)
+        ctx.stacked = stacked
         ctx.set_materialize_grads(False)
-        return out, sp
+        return full, sp
 
     @staticmethod
     def backward(ctx, dout, dsp):
         snps, p = ctx.saved_tensors
         if dout is None and dsp is None:
-            return None, None
+            return None, None, None
         b, s = snps.shape
+        if dout is not None and ctx.stacked:
+            dout = dout[b:]
         dp = torch.empty_like(p)
         call("igcn_snps_mask_bwd", b, s, ptr(snps), ptr(p), ptr(_f32(dout)) if dout is not None else None,
              ptr(_f32(dsp)) if dsp is not None else None, ptr(dp), stream_ptr())
-        return None, dp
+        return None, dp, None
 
 
 class HeadInputs(torch.autograd.Function):

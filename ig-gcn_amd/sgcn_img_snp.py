@@ -127,7 +127,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         xm, ewm, e = ops.EdgeMask.apply(x, self.prob, self.prob_bias, edge_weight, plan, self.rois)
         if snps_feat is not None:
             if snps_feat.is_cuda and snps_feat.dim() == 2 and snps_feat.shape[1] == self.snps_prob.numel():
-                snps_m, sp = ops.SnpsMask.apply(snps_feat, self.snps_prob)     # sigmoid + multiply in one launch
+                snps_m, sp = ops.SnpsMask.apply(snps_feat, self.snps_prob, False)   # sigmoid + multiply, one launch
                 return xm, ewm, self.prob, e, snps_m, sp
             sp = torch.sigmoid(self.snps_prob)
             return xm, ewm, self.prob, e, snps_feat * sp, sp
@@ -226,14 +226,21 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         bsz, g = n // self.rois, len(explain_flags)
         plan = ops.plan_for(data)
         self.last_edge_prob = None
-        if any(explain_flags):
-            x_m, ew_m, _, e, snps_m, _ = self.cal_probability(x, edge_index, edge_weight, snps_feat, plan=plan)
+        if (tuple(explain_flags) == (False, True) and x.is_cuda and snps_feat is not None and snps_feat.dim() == 2
+                and snps_feat.shape[1] == self.snps_prob.numel()):
+            # the train step's (plain | masked) pair: cal_probability writes both halves of the stacked batch itself
+            x_in, ew_in, e = ops.EdgeMaskStacked.apply(x, self.prob, self.prob_bias, edge_weight, plan, self.rois)
+            snps_in, _ = ops.SnpsMask.apply(snps_feat, self.snps_prob, True)
             self.last_edge_prob = e
-        pick = lambda plain, masked: [masked if f else plain for f in explain_flags]      # noqa: E731
-        xs, ews, snps = pick(x, x_m if any(explain_flags) else None), pick(edge_weight, ew_m if any(
-            explain_flags) else None), pick(snps_feat, snps_m if any(explain_flags) else None)
-        stack = lambda ts: ts[0] if g == 1 else torch.cat(ts, dim=0)                       # noqa: E731
-        x_in, ew_in, snps_in = stack(xs), stack(ews), stack(snps)
+        else:
+            if any(explain_flags):
+                x_m, ew_m, _, e, snps_m, _ = self.cal_probability(x, edge_index, edge_weight, snps_feat, plan=plan)
+                self.last_edge_prob = e
+            pick = lambda plain, masked: [masked if f else plain for f in explain_flags]      # noqa: E731
+            xs, ews, snps = pick(x, x_m if any(explain_flags) else None), pick(edge_weight, ew_m if any(
+                explain_flags) else None), pick(snps_feat, snps_m if any(explain_flags) else None)
+            stack = lambda ts: ts[0] if g == 1 else torch.cat(ts, dim=0)                       # noqa: E731
+            x_in, ew_in, snps_in = stack(xs), stack(ews), stack(snps)
         plan_g = plan.replicate(g)
         coef = ops.GcnNorm.apply(ew_in, plan_g)                       # once per pass (PyG: once per layer)
         h = self.conv1(x_in, plan_g, coef, relu=True)

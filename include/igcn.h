@@ -73,17 +73,21 @@ int igcn_graph_plan_replicate(int64_t n_nodes, int64_t n_edges, int copies,
  * Learned regional / connective importance masks — cal_probability, kernel/sgcn_img_snp.py:133-151.
  *   xm[i,:]  = x[i,:] * prob[i % rois,:]
  *   e[k]     = sigmoid( [xm[src_k] || xm[dst_k]] . prob_bias )          ewm[k] = ew[k] * e[k]
+ * x_plain [N,h0] / ew_plain [E] (may be NULL): plain copies of x / ew written alongside — the train step stacks the
+ * plain and the masked pass (train() :521,523) into one batch, and xm / x_plain (ewm / ew_plain) are then the two
+ * halves of the stacked tensors.
  */
 int igcn_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0,
                        const float* x, const float* prob, const float* prob_bias, const float* ew,
                        const int32_t* src32, const int32_t* dst32,
-                       float* xm, float* e, float* ewm, void* stream);
-/* d_xm [N,h0] may be NULL (=0); d_ewm, d_e [E] may be NULL.  Outputs: dx [N,h0], dprob [rois,h0],
- * dprob_bias [2*h0].  scratch: float[ N*h0 + 16*ceil(N/4) + 16 ]. */
+                       float* xm, float* e, float* ewm, float* x_plain, float* ew_plain, void* stream);
+/* d_xm [N,h0] may be NULL (=0); d_ewm, d_e [E] may be NULL; d_x_plain [N,h0] (may be NULL) is the gradient of the
+ * plain copy, added into dx.  Outputs: dx [N,h0], dprob [rois,h0], dprob_bias [2*h0].
+ * scratch: float[ N*h0 + 16*ceil(N/4) + 16 ]. */
 int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, int h0,
                        const float* x, const float* prob, const float* prob_bias, const float* ew,
                        const float* e, const float* d_xm, const float* d_ewm, const float* d_e,
-                       const int32_t* tgt_ptr, const int32_t* tgt_perm,
+                       const float* d_x_plain, const int32_t* tgt_ptr, const int32_t* tgt_perm,
                        const int32_t* src_ptr, const int32_t* src_perm,
                        float* dx, float* dprob, float* dprob_bias, float* scratch, void* stream);
 
@@ -151,7 +155,8 @@ int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F,
  */
 /* SNP importance mask of cal_probability (kernel/sgcn_img_snp.py:147-151): out [B,S] = snps * sigmoid(p),
  * sp [S] = sigmoid(p).  Backward: dp [S] from dout [B,S] and/or dsp [S] (either may be NULL); snps gets no gradient. */
-int igcn_snps_mask_fwd(int B, int S, const float* snps, const float* p, float* out, float* sp, void* stream);
+int igcn_snps_mask_fwd(int B, int S, const float* snps, const float* p, float* out, float* sp,
+                       float* plain /* [B,S] copy of snps for the stacked batch, or NULL */, void* stream);
 int igcn_snps_mask_bwd(int B, int S, const float* snps, const float* p, const float* dout, const float* dsp,
                        float* dp, void* stream);
 
