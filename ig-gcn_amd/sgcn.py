@@ -84,14 +84,19 @@ class SGCN_GCN(torch.nn.Module):
         bsz, g = n // self.rois, len(explain_flags)
         plan = ops.plan_for(data)
         self.last_edge_prob = None
-        x_m = ew_m = None
-        if any(explain_flags):
-            x_m, ew_m, _, e = self.cal_probability(x, edge_index, edge_weight, plan=plan)
+        if tuple(explain_flags) == (False, True) and x.is_cuda:
+            # the train step's (plain | masked) pair: cal_probability writes both halves of the stacked batch itself
+            x_in, ew_in, e = ops.EdgeMaskStacked.apply(x, self.prob, self.prob_bias, edge_weight, plan, self.rois)
             self.last_edge_prob = e
-        xs = [x_m if f else x for f in explain_flags]
-        ews = [ew_m if f else edge_weight for f in explain_flags]
-        x_in = xs[0] if g == 1 else torch.cat(xs, dim=0)
-        ew_in = ews[0] if g == 1 else torch.cat(ews, dim=0)
+        else:
+            x_m = ew_m = None
+            if any(explain_flags):
+                x_m, ew_m, _, e = self.cal_probability(x, edge_index, edge_weight, plan=plan)
+                self.last_edge_prob = e
+            xs = [x_m if f else x for f in explain_flags]
+            ews = [ew_m if f else edge_weight for f in explain_flags]
+            x_in = xs[0] if g == 1 else torch.cat(xs, dim=0)
+            ew_in = ews[0] if g == 1 else torch.cat(ews, dim=0)
         plan_g = plan.replicate(g)
         coef = ops.GcnNorm.apply(ew_in, plan_g)
         h = self.conv1(x_in, plan_g, coef, relu=True)
