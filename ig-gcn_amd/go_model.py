@@ -90,11 +90,15 @@ class Gene_ontology_network(nn.Module):
     # ---------------------------------------------------------------------------------------------
     def _node_keeps(self, b, sizes, dev):
         """Dropout2d on [B,N,f] zeroes whole nodes per sample: keep/(1-p) masks [B,n] for every LayerNorm site of
-        the forward (drawn with one bernoulli launch for all sites), or Nones."""
+        the forward (drawn with one launch for all sites), or Nones."""
         if not (self.training and self._dropout_enabled and self.node_dropout_p > 0):
             return [None] * len(sizes)
         p = self.node_dropout_p
-        flat = torch.empty(b * sum(sizes), dtype=torch.float32, device=dev).bernoulli_(1.0 - p).div_(1.0 - p)
+        total = b * sum(sizes)
+        ones = getattr(self, "_keep_ones", None)       # dropout of a constant: the {0, 1/(1-p)} masks in ONE launch
+        if ones is None or ones.numel() != total or ones.device != dev:
+            ones = self._keep_ones = torch.ones(total, dtype=torch.float32, device=dev)
+        flat = F.dropout(ones, p, True)
         out, off = [], 0
         for n in sizes:
             out.append(flat[off:off + b * n].view(b, n))
