@@ -29,6 +29,9 @@ SIGNATURES = {
     "igcn_gcn_propagate_fwd": (I, [L, L, I, I, P, L, P, P, P, P, P, L, I, P]),
     "igcn_gcn_propagate_bwd_scratch_floats": (Z, [L, I]),
     "igcn_gcn_propagate_bwd": (I, [L, L, I, P, L, P, L, I, P, L, P, P, P, P, P, P, L, P, I, P, P, P, P]),
+    "igcn_small_linear_bwd_scratch_floats": (Z, [L, I, I]),
+    "igcn_small_linear_fwd": (I, [L, I, I, P, P, P, P, P]),
+    "igcn_small_linear_bwd": (I, [L, I, I, P, P, P, P, P, P, P]),
     "igcn_snps_mask_fwd": (I, [I, I, P, P, P, P, P, P]),
     "igcn_snps_mask_bwd": (I, [I, I, P, P, P, P, P, P]),
     "igcn_head_inputs_fwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P]),

@@ -388,3 +388,129 @@ extern "C" int igcn_snps_mask_bwd(int B, int S, const float* snps, const float* 
   IGCN_CHECK_LAUNCH("snps_mask_bwd");
   return IGCN_OK;
 }
+
+// =================================================================================================
+// Narrow output layers: y[r, c] = sum_k x[r, k] W[c, k] + b[c] with C <= 4 outputs (lin2 / lin2_regr of
+// kernel/sgcn_img_snp.py:289-301: 64 -> 3).  On the GEMM path such a layer costs a launch forward and five
+// backward (bias-gradient pass + its reduction, dX, split-K dW + its reduction) for a few hundred KB of data; here
+// it is one VALU kernel forward and one (+ a short reduction of block partials) backward.
+// Thread = (row, quad of K): KQ = K/4 lanes per row, 256/KQ rows per workgroup pass.
+// =================================================================================================
+#define SL_MAXC 4
+__global__ void __launch_bounds__(256)
+k_small_linear_fwd(int64_t R, int K, int C, const float* __restrict__ x, const float* __restrict__ W,
+                   const float* __restrict__ b, float* __restrict__ y) {
+  const int kq = K / 4, q = threadIdx.x % kq, rl = threadIdx.x / kq, rpb = 256 / kq;
+  const int64_t r = (int64_t)blockIdx.x * rpb + rl;
+  float acc[SL_MAXC];
+#pragma unroll
+  for (int c = 0; c < SL_MAXC; ++c) acc[c] = 0.f;
+  if (rl < rpb && r < R) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * K + 4 * q);
+#pragma unroll
+    for (int c = 0; c < SL_MAXC; ++c)
+      if (c < C) {
+        const float4 w = *reinterpret_cast<const float4*>(W + c * K + 4 * q);
+        acc[c] = (xv.x * w.x + xv.y * w.y) + (xv.z * w.z + xv.w * w.w);
+      }
+  }
+  // sum over the kq lanes of a row (kq is a power of two <= 64, rows do not straddle waves)
+#pragma unroll
+  for (int c = 0; c < SL_MAXC; ++c)
+    for (int o = 1; o < kq; o <<= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+  if (q == 0 && rl < rpb && r < R) {
+#pragma unroll
+    for (int c = 0; c < SL_MAXC; ++c)
+      if (c < C) y[r * C + c] = acc[c] + (b ? b[c] : 0.f);
+  }
+}
+
+// dx[r, k] = sum_c dy[r, c] W[c, k];  partial[blk][c*K + k] = sum_{r in blk} dy[r, c] x[r, k];
+// partial[blk][C*K + c] = sum_{r in blk} dy[r, c].  Rows of a workgroup: rows_per_block, walked 256/KQ at a time.
+__global__ void __launch_bounds__(256)
+k_small_linear_bwd(int64_t R, int K, int C, int rows_per_block, const float* __restrict__ x,
+                   const float* __restrict__ W, const float* __restrict__ dy, float* __restrict__ dx,
+                   float* __restrict__ partial) {
+  __shared__ float red[256 * 4];
+  const int kq = K / 4, q = threadIdx.x % kq, rl = threadIdx.x / kq, rpb = 256 / kq;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  float4 w[SL_MAXC], gw[SL_MAXC];
+  float gb[SL_MAXC];
+#pragma unroll
+  for (int c = 0; c < SL_MAXC; ++c) {
+    w[c] = (c < C) ? *reinterpret_cast<const float4*>(W + c * K + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    gw[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gb[c] = 0.f;
+  }
+  if (rl < rpb) {
+#pragma unroll 4
+    for (int64_t r = r0 + rl; r < r1; r += rpb) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + r * K + 4 * q);
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < SL_MAXC; ++c)
+        if (c < C) {
+          const float g = dy[r * C + c];
+          d.x += g * w[c].x; d.y += g * w[c].y; d.z += g * w[c].z; d.w += g * w[c].w;
+          gw[c].x += g * xv.x; gw[c].y += g * xv.y; gw[c].z += g * xv.z; gw[c].w += g * xv.w;
+          gb[c] += g;
+        }
+      if (dx) *reinterpret_cast<float4*>(dx + r * K + 4 * q) = d;
+    }
+  }
+  float* prow = partial + (int64_t)blockIdx.x * (C * K + C);
+  for (int c = 0; c < C; ++c) {                         // row lanes summed in order through LDS, one channel at a time
+    __syncthreads();
+    red[threadIdx.x * 4 + 0] = gw[c].x; red[threadIdx.x * 4 + 1] = gw[c].y;
+    red[threadIdx.x * 4 + 2] = gw[c].z; red[threadIdx.x * 4 + 3] = gw[c].w;
+    __syncthreads();
+    if (threadIdx.x < K) {
+      const int qq = threadIdx.x / 4, j = threadIdx.x % 4;
+      float t = 0.f;
+      for (int l = 0; l < rpb; ++l) t += red[(l * kq + qq) * 4 + j];
+      prow[c * K + threadIdx.x] = t;
+    }
+    __syncthreads();
+    red[threadIdx.x] = (q == 0 && rl < rpb) ? gb[c] : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int l = 0; l < rpb; ++l) t += red[l * kq];
+      prow[C * K + c] = t;
+    }
+  }
+}
+
+static bool small_linear_ok(int K, int C) {
+  const int kq = K / 4;
+  return K % 4 == 0 && kq >= 1 && kq <= 64 && (kq & (kq - 1)) == 0 && C >= 1 && C <= SL_MAXC;
+}
+
+extern "C" size_t igcn_small_linear_bwd_scratch_floats(int64_t R, int K, int C) {
+  return (size_t)(igcn_cdiv(R, 64) * (C * K + C) + 64);
+}
+
+extern "C" int igcn_small_linear_fwd(int64_t R, int K, int C, const float* x, const float* W, const float* b, float* y,
+                                     void* stream) {
+  IGCN_REQUIRE(R > 0 && small_linear_ok(K, C), "small_linear: K/4 a power of two <= 64, 1 <= C <= 4 (K=%d C=%d)", K, C);
+  IGCN_REQUIRE((((uintptr_t)x | (uintptr_t)W) & 15) == 0, "small_linear: x and W must be 16-byte aligned");
+  const int rpb = 256 / (K / 4);
+  hipLaunchKernelGGL(k_small_linear_fwd, dim3((unsigned)igcn_cdiv(R, rpb)), dim3(256), 0, (hipStream_t)stream, R, K, C,
+                     x, W, b, y);
+  IGCN_CHECK_LAUNCH("small_linear_fwd");
+  return IGCN_OK;
+}
+
+extern "C" int igcn_small_linear_bwd(int64_t R, int K, int C, const float* x, const float* W, const float* dy,
+                                     float* dx /* or NULL */, float* dwb /* [C*K + C]: dW, then db */, float* scratch,
+                                     void* stream) {
+  IGCN_REQUIRE(R > 0 && small_linear_ok(K, C), "small_linear: K/4 a power of two <= 64, 1 <= C <= 4 (K=%d C=%d)", K, C);
+  IGCN_REQUIRE((((uintptr_t)x | (uintptr_t)W | (uintptr_t)dx) & 15) == 0, "small_linear: 16-byte aligned tensors");
+  hipStream_t st = (hipStream_t)stream;
+  const int rows_per_block = 64;
+  const int64_t nb = igcn_cdiv(R, rows_per_block);
+  hipLaunchKernelGGL(k_small_linear_bwd, dim3((unsigned)nb), dim3(256), 0, st, R, K, C, rows_per_block, x, W, dy, dx,
+                     scratch);
+  IGCN_CHECK_LAUNCH("small_linear_bwd");
+  return igcn_launch_reduce_rows(scratch, nb, C * K + C, C * K + C, dwb, 0, st);     // dW | db in one pass
+}

@@ -472,9 +472,51 @@ def head_inputs_supported(img, cross, latent, x, prob):
     return img.shape == cross.shape and w % 2 == 0 and l % 2 == 0 and p % 2 == 0
 
 
+class SmallLinear(torch.autograd.Function):
+    """y = x W^T + b for C <= 4 outputs (lin2 / lin2_regr: 64 -> 3) as one VALU kernel per direction
+    (igcn_small_linear_*) instead of a GEMM forward and five launches backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight = _f32(x), _f32(weight)
+        bias = _f32(bias) if bias is not None else None
+        r, k = x.shape
+        c = weight.shape[0]
+        y = torch.empty(r, c, dtype=torch.float32, device=x.device)
+        call("igcn_small_linear_fwd", r, k, c, ptr(x), ptr(weight), ptr(bias), ptr(y), stream_ptr())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _f32(dy)
+        r, k = x.shape
+        c = weight.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dwb = torch.empty(c * k + c, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(int(_lib.load().igcn_small_linear_bwd_scratch_floats(r, k, c)), dtype=torch.float32,
+                              device=x.device)
+        call("igcn_small_linear_bwd", r, k, c, ptr(x), ptr(weight), ptr(dy), ptr(dx), ptr(dwb), ptr(scratch),
+             stream_ptr())
+        return dx, dwb[:c * k].view(c, k), (dwb[c * k:] if ctx.has_bias else None)
+
+
+def _small_linear_ok(x2, weight, relu):
+    k, c = x2.shape[1], weight.shape[0]
+    kq = k // 4
+    return (not relu and x2.is_cuda and c <= 4 and k % 4 == 0 and 1 <= kq <= 64 and (kq & (kq - 1)) == 0
+            and x2.shape[0] > 0)
+
+
 def linear(x, weight, bias=None, relu=False):
     lead = x.shape[:-1]
-    y = Linear.apply(x.reshape(-1, x.shape[-1]), weight, bias, relu)
+    x2 = x.reshape(-1, x.shape[-1])
+    if _small_linear_ok(x2, weight, relu):
+        y = SmallLinear.apply(x2, weight, bias)
+    else:
+        y = Linear.apply(x2, weight, bias, relu)
     return y.view(*lead, weight.shape[0])
 
 

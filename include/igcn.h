@@ -153,6 +153,16 @@ int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F,
  * split_k > 1 writes split_k partial slabs into `scratch` (float[split_k*M*N]) and reduces them in order
  * (deterministic).  act: 0 none, 1 relu.
  */
+/* Narrow output layer y[R,C] = x[R,K] W[C,K]^T + b[C] with C <= 4 (lin2 / lin2_regr, kernel/sgcn_img_snp.py:289-301)
+ * as one VALU kernel per direction.  K/4 must be a power of two <= 64; x, W, dx 16-byte aligned.
+ * Backward: dx [R,K] (may be NULL) and dwb [C*K + C] = dW (row-major [C,K]) followed by db.
+ * scratch: igcn_small_linear_bwd_scratch_floats(R, K, C). */
+size_t igcn_small_linear_bwd_scratch_floats(int64_t R, int K, int C);
+int igcn_small_linear_fwd(int64_t R, int K, int C, const float* x, const float* W, const float* b, float* y,
+                          void* stream);
+int igcn_small_linear_bwd(int64_t R, int K, int C, const float* x, const float* W, const float* dy, float* dx,
+                          float* dwb, float* scratch, void* stream);
+
 /* SNP importance mask of cal_probability (kernel/sgcn_img_snp.py:147-151): out [B,S] = snps * sigmoid(p),
  * sp [S] = sigmoid(p).  Backward: dp [S] from dout [B,S] and/or dsp [S] (either may be NULL); snps gets no gradient. */
 int igcn_snps_mask_fwd(int B, int S, const float* snps, const float* p, float* out, float* sp,

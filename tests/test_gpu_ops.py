@@ -150,7 +150,10 @@ def test_gemm_nt_nn_tn(ops, m, n, k):
 
 @pytest.mark.parametrize("rows,fin,fout,relu,bias", [(512, 64, 3, False, True), (512, 2912, 64, True, True),
                                                      (46080, 16, 32, False, True), (1000, 7, 12, True, True),
-                                                     (300, 5, 64, True, False), (70000, 32, 64, False, True)])
+                                                     (300, 5, 64, True, False), (70000, 32, 64, False, True),
+                                                     # narrow outputs (<= 4): the VALU kernels igcn_small_linear_*
+                                                     (46080, 16, 3, False, True), (517, 64, 1, False, True),
+                                                     (130, 256, 4, False, False), (9, 4, 2, False, True)])
 def test_linear_fwd_bwd(ops, rows, fin, fout, relu, bias):
     """ops.linear = GEMM with fused bias/ReLU epilogue; backward = igcn_bias_grad (ReLU mask + bias gradient in one
     pass) + two GEMMs, against torch in fp64."""
