@@ -35,7 +35,7 @@ PMC_TRAFFIC = {"bench": 10010260, "stress": 77631040}
 # average duration of the same kernels in the committed rocprofv3 --kernel-trace --stats summary of this command
 # (profiles/r01_final_default_bench/kernel_stats.csv).  The profiler adds ~1-2 us to every dispatch and sees the
 # in-step launches with cold caches, which matters for the 3-us kernel and not for the 36-us one.
-ROCPROF_AVG_US = {"bench": 4.82, "stress": 36.0}
+ROCPROF_AVG_US = {"bench": 4.47, "stress": 35.8}
 
 
 # --workload: the default is the configuration the metric is quoted on; the other two are side measurements
