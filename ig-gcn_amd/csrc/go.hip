@@ -830,7 +830,8 @@ static size_t go_abl_lds_bytes(int N, int fin, int fout) {
   return slabs > stage ? slabs : stage;
 }
 
-// IGCN_GO_ATTN_CM=1 (A/B runs): the channel-major global-memory kernels even when a sample fits LDS
+// IGCN_GO_ATTN_CM=1 (A/B runs): the global-memory kernels (attention backward, decoder forward / backward) even when a
+// sample fits LDS — these are also the fallbacks for hierarchies too large for LDS
 static bool go_attn_force_cm(void) {
   static int v = -1;
   if (v < 0) {
@@ -1411,7 +1412,7 @@ extern "C" int igcn_go_decode_fwd(int B, int Nin, int Nout, int fin, int fout, c
   IGCN_REQUIRE(B > 0 && Nin > 0 && Nout >= Nin, "go_decode_fwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = go_dec_lds_bytes(fin, Nin);
-  if (lds <= 64 * 1024 && ((uintptr_t)x % 16) == 0) {
+  if (!go_attn_force_cm() && lds <= 64 * 1024 && ((uintptr_t)x % 16) == 0) {
     dim3 lgrid((unsigned)igcn_cdiv(Nout, GO_DEC_T * GO_DEC_ITERS), B);
 #define CALL(FI, FO)                                                                                                \
   hipLaunchKernelGGL((k_go_decode_fwd_lds<FI, FO>), lgrid, dim3(GO_DEC_T), lds, st, Nin, Nout, row_ptr, col, x, w_out, \
@@ -1625,7 +1626,7 @@ extern "C" int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, c
   hipStream_t st = (hipStream_t)stream;
   const int nw = 2 * fout * fin;
   const size_t lds = go_dbl_lds_bytes(Nout, fin, fout);
-  if (lds <= 160 * 1024 && 2 * fout >= 4) {
+  if (!go_attn_force_cm() && lds <= 160 * 1024 && 2 * fout >= 4) {
 #define CALL(FI, FO)                                                                                             \
   {                                                                                                               \
     IGCN_ALLOW_BIG_LDS((k_go_decode_bwd_lds<FI, FO>));                                        \

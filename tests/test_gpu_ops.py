@@ -656,21 +656,33 @@ par = [torch.from_numpy(rng.standard_normal(s)).float().cuda().requires_grad_(Tr
 y = ops.GoAttention.apply(x, par[0], par[1], par[2], par[3], csr)
 cot = torch.from_numpy(rng.standard_normal(tuple(y.shape))).float().cuda()
 g = torch.autograd.grad((y * cot).sum(), [x] + par)
+# GO decoder layer (5 -> 2) on the same hierarchy: rows = the 120 nodes, cols = the top 60 (LDS-resident by default,
+# global-memory kernels under IGCN_GO_ATTN_CM=1)
+ad = torch.from_numpy(adj[:, 60:].copy()).to_sparse().coalesce()
+di = ad.indices()
+dcsr = ops.Csr(di[0], di[1], n, n - 60, "cuda")
+xd = torch.from_numpy(rng.standard_normal((5, 5, n - 60))).float().cuda().requires_grad_(True)
+pd = [torch.from_numpy(rng.standard_normal((2, 5))).float().cuda().requires_grad_(True) for _ in range(2)]
+yd = ops.GoDecode.apply(xd, pd[0], pd[1], dcsr)
+cd = torch.from_numpy(rng.standard_normal(tuple(yd.shape))).float().cuda()
+gd = torch.autograd.grad((yd * cd).sum(), [xd] + pd)
 # attention core, head_dim 16
 q = torch.from_numpy(rng.standard_normal((3, 40, 32))).float().cuda().requires_grad_(True)
 kv = torch.from_numpy(rng.standard_normal((3, 70, 64))).float().cuda().requires_grad_(True)
 o = ops.AttentionCore.apply(q, kv, 2)
 co = torch.from_numpy(rng.standard_normal((3, 40, 32))).float().cuda()
 ga = torch.autograd.grad((o * co).sum(), [q, kv])
-np.savez(sys.argv[2], y=y.detach().cpu().numpy(), o=o.detach().cpu().numpy(),
-         **{f"g{i}": t.cpu().numpy() for i, t in enumerate(g)}, **{f"a{i}": t.cpu().numpy() for i, t in enumerate(ga)})
+np.savez(sys.argv[2], y=y.detach().cpu().numpy(), o=o.detach().cpu().numpy(), yd=yd.detach().cpu().numpy(),
+         **{f"g{i}": t.cpu().numpy() for i, t in enumerate(g)}, **{f"a{i}": t.cpu().numpy() for i, t in enumerate(ga)},
+         **{f"d{i}": t.cpu().numpy() for i, t in enumerate(gd)})
 """
 
 
 def test_alternative_kernel_variants_agree(tmp_path):
-    """The A/B switches stay honest: the channel-major global-memory GO attention backward (IGCN_GO_ATTN_CM=1) and the
-    VALU attention core (IGCN_ATTN_VALU=1) give the numbers of the default LDS-resident / matrix-core kernels.  The
-    switches are read once per process, so each variant runs in a short child process (one at a time)."""
+    """The A/B switches stay honest: the global-memory GO kernels (attention backward, decoder forward / backward:
+    IGCN_GO_ATTN_CM=1 — also the fallbacks for hierarchies too large for LDS) and the VALU attention core
+    (IGCN_ATTN_VALU=1) give the numbers of the default LDS-resident / matrix-core kernels.  The switches are read
+    once per process, so each variant runs in a short child process (one at a time)."""
     import os
     import subprocess
     import sys
