@@ -37,6 +37,8 @@ SIGNATURES = {
     "igcn_head_inputs_fwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "igcn_head_inputs_bwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
     "igcn_concat_cols": (I, [L, I, I, P, P, P]),
+    "igcn_graph_pool_fwd": (I, [L, I, I, P, P, P, P]),
+    "igcn_graph_pool_bwd": (I, [L, I, I, P, P, P, P]),
     "igcn_bias_grad_scratch_floats": (Z, [L, I]),
     "igcn_bias_grad": (I, [L, I, P, P, P, P, P, P]),
     "igcn_gemm_f32_split_k": (I, [L, L, L]),
@@ -75,6 +77,11 @@ SIGNATURES = {
     "igcn_adam_step": (I, [L, P, P, P, P, P, F, F, F, F, F, P]),
     "igcn_adam_step_multi": (I, [I, P, P, P, F, F, F, F, F, P]),
     "igcn_pack_grads": (I, [I, P, P, P, P, P]),
+    "igcn_comm_unique_id_bytes": (I, []),
+    "igcn_comm_get_unique_id": (I, [P]),
+    "igcn_comm_init": (I, [I, I, P, P]),
+    "igcn_comm_allreduce": (I, [P, P, L, P]),
+    "igcn_comm_destroy": (I, [P]),
     "igcn_loss_head_fwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, F, F, P, P, P]),
     "igcn_loss_head_bwd": (I, [I, I, I, I, P, P, P, P, P, P, F, F, P, P, P, P, P, P, P]),
     "igcn_gdc_topk_max_rois": (I, []),

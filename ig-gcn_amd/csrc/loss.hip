@@ -209,10 +209,18 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, con
   __shared__ float red[4][16];
   const int tid = threadIdx.x;
   float ce = 0.f, mi = 0.f, mse = 0.f, rec = 0.f;
-  for (int b = tid; b < B; b += 1024) {
-    const int64_t c = y[b];
-    ce -= logp[(int64_t)b * C + c];
-    mi -= logp[(int64_t)(B + b) * C + c];
+  // lam[0] == 0 (main.py's default): the reference sets loss_ce = loss_mi = 0.0 outright (:540-542) — the class
+  // scores are not read at all, so a non-finite log-probability cannot poison the loss through 0 * inf
+  if (w.lam[0] != 0.f) {
+    for (int b = tid; b < B; b += 1024) {
+      const int64_t c = y[b];
+      if (c < 0 || c >= C) {             // F.nll_loss raises on the host; a kernel cannot: poison the loss instead of
+        ce = __builtin_nanf("");         // reading out of bounds (the NaN is what the caller sees)
+        continue;
+      }
+      ce -= logp[(int64_t)b * C + c];
+      mi -= logp[(int64_t)(B + b) * C + c];
+    }
   }
   const int nreg = B * NR, nrec = B * S;
 #pragma unroll 4
@@ -251,8 +259,8 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, con
   }
   if (tid == 0) {
     float t[7];
-    t[0] = w.lam[0] * (ce / (float)B);
-    t[1] = w.lam[0] * (mi / (float)B);
+    t[0] = w.lam[0] != 0.f ? w.lam[0] * (ce / (float)B) : 0.f;
+    t[1] = w.lam[0] != 0.f ? w.lam[0] * (mi / (float)B) : 0.f;
     t[2] = w.lam[1] * (mse / (float)(2 * nreg));
     t[3] = w.lam[2] * prob[0];
     t[4] = w.lam[3] * (rec * 0.5f);

@@ -514,3 +514,68 @@ extern "C" int igcn_small_linear_bwd(int64_t R, int K, int C, const float* x, co
   IGCN_CHECK_LAUNCH("small_linear_bwd");
   return igcn_launch_reduce_rows(scratch, nb, C * K + C, C * K + C, dwb, 0, st);     // dW | db in one pass
 }
+
+// =================================================================================================
+// global_mean_pool | global_max_pool | global_add_pool over the nodes of each graph, concatenated
+// (kernel/sgcn_img_snp.py:230-235,246-252; PyG 2.0.2 global_*_pool = scatter(x, batch, reduce)).
+// Uniform graphs of R nodes (the model's contract): x [G*R, D] -> out [G, 3D] = mean | max | add.
+// One thread per (graph, column): the R rows are read with consecutive lanes on consecutive columns (coalesced),
+// summed in node order (the reference's sequential scatter order); the max keeps the FIRST arg-max
+// (torch-scatter's CPU scatter_max updates on strictly-greater only), saved for the backward.
+// =================================================================================================
+__global__ void __launch_bounds__(256)
+k_graph_pool_fwd(int64_t G, int R, int D, const float* __restrict__ x, float* __restrict__ out,
+                 int32_t* __restrict__ arg) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= G * D) return;
+  const int64_t g = i / D;
+  const int d = (int)(i - g * D);
+  const float* p = x + g * R * D + d;
+  float s = 0.f, m = p[0];
+  int am = 0;
+#pragma unroll 4
+  for (int r = 0; r < R; ++r) {
+    const float v = p[(int64_t)r * D];
+    s += v;
+    if (v > m || (v != v && !(m != m))) { m = v; am = r; }      // NaN propagates like torch's max
+  }
+  float* o = out + g * 3 * D;
+  o[d] = s / (float)R;
+  o[D + d] = m;
+  o[2 * D + d] = s;
+  arg[i] = am;
+}
+
+// dx[g*R + r, d] = dmean[g,d]/R + dadd[g,d] + (r == arg[g,d]) * dmax[g,d]
+__global__ void __launch_bounds__(256)
+k_graph_pool_bwd(int64_t G, int R, int D, const float* __restrict__ dout, const int32_t* __restrict__ arg,
+                 float* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= G * R * D) return;
+  const int64_t row = i / D;
+  const int d = (int)(i - row * D);
+  const int64_t g = row / R;
+  const int r = (int)(row - g * R);
+  const float* o = dout + g * 3 * D;
+  float v = o[d] / (float)R + o[2 * D + d];
+  if (arg[g * D + d] == r) v += o[D + d];
+  dx[i] = v;
+}
+
+extern "C" int igcn_graph_pool_fwd(int64_t n_graphs, int nodes_per_graph, int D, const float* x, float* out,
+                                   int32_t* argmax, void* stream) {
+  IGCN_REQUIRE(n_graphs > 0 && nodes_per_graph > 0 && D > 0, "graph_pool_fwd: bad sizes");
+  hipLaunchKernelGGL(k_graph_pool_fwd, dim3((unsigned)igcn_cdiv(n_graphs * D, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n_graphs, nodes_per_graph, D, x, out, argmax);
+  IGCN_CHECK_LAUNCH("graph_pool_fwd");
+  return IGCN_OK;
+}
+
+extern "C" int igcn_graph_pool_bwd(int64_t n_graphs, int nodes_per_graph, int D, const float* dout,
+                                   const int32_t* argmax, float* dx, void* stream) {
+  IGCN_REQUIRE(n_graphs > 0 && nodes_per_graph > 0 && D > 0, "graph_pool_bwd: bad sizes");
+  hipLaunchKernelGGL(k_graph_pool_bwd, dim3((unsigned)igcn_cdiv(n_graphs * nodes_per_graph * D, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n_graphs, nodes_per_graph, D, dout, argmax, dx);
+  IGCN_CHECK_LAUNCH("graph_pool_bwd");
+  return IGCN_OK;
+}

@@ -54,6 +54,8 @@ class Data:
         return -1 if bool(re.search("(index|face)", key)) else 0
 
     def __inc__(self, key, value):
+        if "batch" in key:                              # PyG 2.0.2: per-graph assignment vectors count graphs
+            return int(value.max()) + 1
         return self.num_nodes if bool(re.search("(index|face)", key)) else 0
 
     def to(self, device, non_blocking=False):
@@ -87,15 +89,15 @@ class Batch(Data):
         assert "batch" not in keys
         out = Batch()
         cols = {k: [] for k in keys}
+        cumsum = {k: 0 for k in keys}                   # batch.py:41,89: running increment per key
         node_off, node_ptr, edge_ptr, bvec = 0, [0], [0], []
         for i, d in enumerate(data_list):
             n = d.num_nodes
             for k in d.keys:
                 item = d[k]
-                if torch.is_tensor(item) and item.dtype != torch.bool:
-                    inc = node_off if d.__inc__(k, item) else 0
-                    if inc:
-                        item = item + inc
+                if torch.is_tensor(item) and item.dtype != torch.bool and cumsum[k]:
+                    item = item + cumsum[k]
+                cumsum[k] = cumsum[k] + d.__inc__(k, item)
                 cols[k].append(item)
             bvec.append(torch.full((n,), i, dtype=torch.long))
             node_off += n

@@ -381,6 +381,35 @@ def concat_cols(parts):
     return ConcatCols.apply(*parts) if ok else torch.cat(parts, dim=1)
 
 
+class GraphPool(torch.autograd.Function):
+    """global_mean_pool | global_max_pool | global_add_pool concatenated (kernel/sgcn_img_snp.py:230-235,246-252)
+    for a batch of uniform graphs: x [G*R, D] -> [G, 3D] (igcn_graph_pool_*)."""
+
+    @staticmethod
+    def forward(ctx, x, nodes_per_graph):
+        x = _f32(x)
+        n, d = x.shape
+        r = int(nodes_per_graph)
+        if r <= 0 or n % r:
+            raise _lib.IgcnError(f"graph pool: {n} nodes do not split into graphs of {r}")
+        g = n // r
+        out = torch.empty(g, 3 * d, dtype=torch.float32, device=x.device)
+        arg = torch.empty(g, d, dtype=torch.int32, device=x.device)
+        call("igcn_graph_pool_fwd", g, r, d, ptr(x), ptr(out), ptr(arg), stream_ptr())
+        ctx.save_for_backward(arg)
+        ctx.dims = (g, r, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        arg, = ctx.saved_tensors
+        g, r, d = ctx.dims
+        dout = _f32(dout)
+        dx = torch.empty(g * r, d, dtype=torch.float32, device=dout.device)
+        call("igcn_graph_pool_bwd", g, r, d, ptr(dout), ptr(arg), ptr(dx), stream_ptr())
+        return dx, None
+
+
 class SnpsMask(torch.autograd.Function):
     """(snps * sigmoid(p), sigmoid(p)) of cal_probability (kernel/sgcn_img_snp.py:147-151); p [1,S] or [S]."""
 

@@ -56,9 +56,12 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                  graph_pool=False, isuseProb4Regr=False, num_regr=4, model4eachregr=False, isImageOnly=True,
                  isSNPsOnly=False, isMultiFusion=False, **kwargs):
         super().__init__()
-        if graph_pool:
-            raise NotImplementedError("graph_pool=True is a dead branch in the reference trainer "
-                                      "(train_eval_sgcn_img_snps.py:101-106) and is not built")
+        if graph_pool and not (isCrossAtten and not isImageOnly and not isSNPsOnly and not isuseProb4Regr):
+            # the reference's graph_pool branch (:230-235,246-252) only runs for this flag combination: without
+            # cross-attention :247 indexes shape[2] of a 2-D tensor, and the other heads feed lin1 / lin1_regr
+            # (3*L*h + l_dim inputs, :51-54) tensors of a different width
+            raise ValueError("graph_pool=True needs isCrossAtten=True, isImageOnly=False, isSNPsOnly=False, "
+                             "isuseProb4Regr=False (the only combination the reference's forward() runs)")
         if model4eachregr:
             raise NotImplementedError("model4eachregr=True is not built")
         self.device = device
@@ -79,7 +82,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             self.pool = pool_dim[0]
             self.multihead_attn = torch.nn.MultiheadAttention(dim_att, 2, batch_first=True)
         d_img = rois * num_layers * hidden
-        if isImageOnly:
+        if graph_pool:                                                    # :51-54
+            self.lin1 = Linear(3 * num_layers * hidden + l_dim, hidden_linear)
+            d_reg = 3 * num_layers * hidden + l_dim
+        elif isImageOnly:
             self.lin1 = Linear(d_img, hidden_linear)
             d_reg = d_img + (rois * H_0 if isuseProb4Regr else 0)
         elif isSNPsOnly:
@@ -252,10 +258,16 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         gb = g * bsz
         batch_x = xcat.view(gb, self.rois, -1)                        # to_dense_batch == view (:226)
         img_out = batch_x.reshape(gb, -1)
+        if self.graph_pool:                                           # :230-235 mean | max | add over a graph's nodes
+            img_out = ops.GraphPool.apply(xcat, self.rois)
 
         latent, x_hat, _, atten_out = self.go_network(snps_in, temperature, device, groups=g)
         if self.isCrossAtten:
-            out_cross = self._cross_attention(batch_x, atten_out).reshape(gb, -1)
+            out_cross = self._cross_attention(batch_x, atten_out)
+            if self.graph_pool:                                       # :246-252
+                out_cross = ops.GraphPool.apply(out_cross.reshape(gb * self.rois, -1), self.rois)
+            else:
+                out_cross = out_cross.reshape(gb, -1)
         else:
             out_cross = torch.cat((img_out, latent), -1)
 

@@ -215,20 +215,28 @@ def backward_to_grads(loss, optimizer, data=None):
         t.grad = g
 
 
-def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None, world_size=1):
+def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None, world_size=1,
+               comm=None):
     """One iteration of the loop body of train() :515-547.  Returns the (device) loss tensor.
 
-    With ``world_size > 1`` (torch.distributed initialised, backend nccl == RCCL) every rank has run
-    the step on its own shard of the graph batch; gradients are summed with ONE all-reduce over the flat
-    buffer and averaged inside the Adam kernel (grad_scale = 1/W).
+    With ``world_size > 1`` every rank has run the step on its own shard of the graph batch; gradients are summed
+    with ONE all-reduce over the flat buffer and averaged inside the Adam kernel (grad_scale = 1/W).  ``comm``
+    (``igcn_amd.comm.Comm``): the all-reduce is libigcn's igcn_comm_allreduce (RCCL) on the launch stream;
+    otherwise ``torch.distributed.all_reduce`` of the initialised process group (backend nccl == RCCL).
+    BatchNorm running statistics stay LOCAL to each rank (DDP convention): call
+    ``broadcast_buffers(model)`` before checkpointing if one rank's ``state_dict()`` should stand for all.
     """
     optimizer.zero_grad()
     if data.x.grad is not None:
         data.x.grad = None
     loss, _, _ = losses(model, data, lambda_loss, hp, temperature)
     backward_to_grads(loss, optimizer, data)
-    if world_size > 1:
-        torch.distributed.all_reduce(optimizer.pack_grads())
+    if world_size > 1 or comm is not None:
+        flat = optimizer.pack_grads()
+        if comm is not None:
+            comm.all_reduce_(flat)
+        else:
+            torch.distributed.all_reduce(flat)
         optimizer.step(grad_scale=1.0 / world_size, from_flat=True)
     else:
         optimizer.step()
@@ -248,18 +256,30 @@ class GraphedTrainStep:
     <= 1024 nodes / 4096 edges each) is part of the graph; the general radix-sort build (rocPRIM) is launched
     eagerly, in place, right before the replay — replaying rocPRIM's onesweep sort from inside the full-step graph
     faulted on this ROCm stack (known issues), while the same launches issued on the stream are fine.
+
+    Construction runs ``warmup`` eager steps (allocator / library warm-up) on the construction batch; the optimiser
+    state (parameters, Adam moments, step count) and every module buffer (BatchNorm running statistics,
+    ``num_batches_tracked``) are snapshotted before and restored after them, so N replays equal N reference steps.
     """
 
     def __init__(self, model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, world_size=1, warmup=3,
-                 distributed=None):
+                 distributed=None, comm=None, comm_in_graph=None):
+        """``comm`` (``igcn_amd.comm.Comm``): the gradient all-reduce is igcn_comm_allreduce on the launch stream.
+        ``comm_in_graph``: capture it INTO the step graph (one graph: ... pack -> all-reduce -> Adam); None = try,
+        and fall back to [graph] -> all-reduce -> [Adam graph] if the runtime refuses the capture."""
         self.model, self.opt, self.data, self.world = model, optimizer, data, world_size
         # distributed=True with world_size 1 takes the multi-rank control flow (two graphs around a collective) on
         # a single-rank process group: the rehearsal of the N>1 path that a one-GPU box allows
-        self.dist = dist = world_size > 1 if distributed is None else bool(distributed)
+        self.dist = dist = (world_size > 1 or comm is not None) if distributed is None else bool(distributed)
+        self.comm = comm
+        self.comm_in_graph = False
         self.lam, self.hp = lambda_loss, hp
         from . import ops
         self.plan = ops.plan_for(data)                  # static plan tensors: rebuilt in place every step
         self.plan_in_graph = self.plan.segmented
+        opt = self.opt
+        saved = [t.clone() for t in (opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_count)]
+        saved_buf = [(b, b.clone()) for b in model.buffers()]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -272,6 +292,11 @@ class GraphedTrainStep:
                 else:
                     self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():                           # undo the warm-up steps (capture itself executes nothing)
+            for dst, src in zip((opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_count), saved):
+                dst.copy_(src)
+            for b, v in saved_buf:
+                b.copy_(v)
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
         if not self.plan_in_graph:
@@ -280,12 +305,27 @@ class GraphedTrainStep:
         # captures: flag only this thread's unsafe calls (the launches of the autograd thread still land in the
         # capturing stream and are captured)
         mode = "thread_local" if dist else "global"
-        with torch.cuda.graph(self.g_main, capture_error_mode=mode):
-            self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
-            if not dist:
-                self.opt.step(refresh=False)            # reads the pointer table at replay time
-            else:
-                self.opt.pack_grads(refresh=False)
+        if dist and comm is not None and comm_in_graph is not False:
+            # one graph for the whole distributed step: RCCL's all-reduce is captured between pack and Adam
+            try:
+                with torch.cuda.graph(self.g_main, capture_error_mode=mode):
+                    self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
+                    self.opt.pack_grads(refresh=False)
+                    comm.all_reduce_(self.opt.grad)
+                    self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
+                self.comm_in_graph = True
+            except Exception:                            # noqa: BLE001 — capture refused: two graphs instead
+                if comm_in_graph:
+                    raise
+                torch.cuda.synchronize()
+                self.g_main = torch.cuda.CUDAGraph()
+        if not self.comm_in_graph:
+            with torch.cuda.graph(self.g_main, capture_error_mode=mode):
+                self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
+                if not dist:
+                    self.opt.step(refresh=False)        # reads the pointer table at replay time
+                else:
+                    self.opt.pack_grads(refresh=False)
         # the captured gradient tensors keep their addresses — which only helps if the table can point AT them: a
         # non-contiguous gradient would be copied by refresh_table, and the replays would never update the copy
         for p in self.opt.params:
@@ -294,7 +334,7 @@ class GraphedTrainStep:
                                      f"(shape {tuple(p.shape)}, strides {p.grad.stride()})")
         self.opt.refresh_table()
         self.g_opt = None
-        if dist:
+        if dist and not self.comm_in_graph:
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=self.g_main.pool(), capture_error_mode=mode):
                 self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
@@ -313,11 +353,31 @@ class GraphedTrainStep:
         return loss.detach()
 
     def _reduce(self):
-        if self.dist:
+        if self.comm is not None:
+            self.comm.all_reduce_(self.opt.grad)
+        elif self.dist:
             torch.distributed.all_reduce(self.opt.grad)
 
     def load(self, batch):
-        """Copy a new batch (same graph count / edge count) into the static input tensors."""
+        """Copy a new batch (same graph count / node count / edge count) into the static input tensors — including
+        the per-graph node and edge offsets the segmented plan build reads (a batch with the same total edge count
+        but different per-graph counts would otherwise be grouped on the wrong segments)."""
+        if self.plan.segmented:
+            node_ptr, edge_ptr, _, _ = self.plan._seg
+            bp, be = getattr(batch, "ptr", None), getattr(batch, "edge_ptr", None)
+            if bp is None or be is None or bp.shape != node_ptr.shape or be.shape != edge_ptr.shape:
+                raise ValueError("graphed step (segmented plan): the new batch must carry ptr / edge_ptr of the "
+                                 "same graph count")
+            mn, me = getattr(batch, "_max_nodes", None), getattr(batch, "_max_edges", None)
+            if mn is None or me is None or mn > self.plan.SEG_MAX_NODES or me > self.plan.SEG_MAX_EDGES:
+                raise ValueError("graphed step (segmented plan): the new batch exceeds the per-graph limits of the "
+                                 f"LDS build ({self.plan.SEG_MAX_NODES} nodes / {self.plan.SEG_MAX_EDGES} edges)")
+            if self.plan.nodes_per_graph and int(mn) * (int(bp.numel()) - 1) != self.plan.n_nodes:
+                raise ValueError("graphed step: the captured kernels assume uniform graphs of "
+                                 f"{self.plan.nodes_per_graph} nodes")
+            with torch.no_grad():
+                node_ptr.copy_(bp, non_blocking=True)
+                edge_ptr.copy_(be, non_blocking=True)
         for k in ("x", "edge_index", "edge_attr", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y"):
             dst, src = getattr(self.data, k, None), getattr(batch, k, None)
             if dst is not None and src is not None:
@@ -333,6 +393,8 @@ class GraphedTrainStep:
         if self.g_opt is not None:
             self._reduce()
             self.g_opt.replay()
+        if _lib._DEBUG_SYNC:                            # checked mode: surface the segmented build's status flag
+            self.plan.check()
         return self.loss
 
 
@@ -396,6 +458,16 @@ def output_importance(model):
     if hasattr(model, "snps_prob"):
         out["snps_importance"] = model.snps_prob.detach().cpu().numpy()
     return out
+
+
+def broadcast_buffers(model, src=0):
+    """Copy rank ``src``'s module buffers (BatchNorm running statistics, ``num_batches_tracked``) to every rank.
+    The data-parallel step keeps them local (every rank normalises with its own shard's statistics, like DDP without
+    SyncBatchNorm), so replicas' buffers drift apart; call this before a checkpoint or an evaluation that should not
+    depend on the rank."""
+    if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        for b in model.buffers():
+            torch.distributed.broadcast(b, src)
 
 
 def allreduce_mean_(flat_grad, world_size):

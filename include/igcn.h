@@ -187,6 +187,16 @@ int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, const float* d
  * tensors; `parts` is a HOST array of device pointers. */
 int igcn_concat_cols(int64_t rows, int F, int nparts, const float* const* parts, float* out, void* stream);
 
+/* Graph read-out of the `graph_pool=True` branch (kernel/sgcn_img_snp.py:230-235,246-252): PyG 2.0.2
+ * global_mean_pool | global_max_pool | global_add_pool over the nodes of each graph, concatenated.  Uniform graphs of
+ * `nodes_per_graph` nodes (the model's contract): x [n_graphs*nodes_per_graph, D] -> out [n_graphs, 3*D].
+ * argmax [n_graphs, D] int32 (node index inside the graph, first maximum) is saved for the backward:
+ * dx[g*R+r, d] = dout[g,d]/R + dout[g,2D+d] + (r == argmax[g,d]) * dout[g,D+d]. */
+int igcn_graph_pool_fwd(int64_t n_graphs, int nodes_per_graph, int D, const float* x, float* out, int32_t* argmax,
+                        void* stream);
+int igcn_graph_pool_bwd(int64_t n_graphs, int nodes_per_graph, int D, const float* dout, const int32_t* argmax,
+                        float* dx, void* stream);
+
 /* Backward glue of out = act(A W^T + bias) (ops.Linear; lin1 / lin2 / GCNConv.lin of kernel/sgcn_img_snp.py:34-84):
  * g = dy * [y > 0] when `y` (the ReLU output) is given — then `g` receives the masked gradient the two GEMMs of
  * the backward read — and db[c] = sum_r g[r,c] (y == NULL: g unused, db = column sums of dy).  dy, y, g [rows, cols]
@@ -398,6 +408,21 @@ int igcn_adam_step_multi(int n_tensors, const int64_t* table, const int64_t* num
                          float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_t* numel, const int64_t* offset,
                     float* flat, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Gradient exchange of the data-parallel step (the reference has no multi-GPU code): one RCCL
+ * communicator per process (one process per GPU), ONE all-reduce(sum) of the flat fp32 gradient bucket that
+ * igcn_pack_grads fills, in place, enqueued on `stream` — i.e. on the launch stream between the pack kernel and
+ * igcn_adam_step(grad_scale = 1/world_size), capturable into the step's hipGraph.  RCCL is resolved at run time
+ * (the librccl already loaded in the process — PyTorch-ROCm's — else dlopen): IGCN_ERR_UNSUPPORTED when absent.
+ *   rank 0: igcn_comm_get_unique_id(buf[igcn_comm_unique_id_bytes()]) -> host-side broadcast of the bytes (any
+ *   channel: torch.distributed store, MPI, a file) -> every rank: igcn_comm_init(W, rank, bytes, &comm) with its
+ *   GPU current.  These three calls are host-blocking set-up, not stream work; igcn_comm_allreduce never blocks. */
+int igcn_comm_unique_id_bytes(void);
+int igcn_comm_get_unique_id(void* out_bytes);
+int igcn_comm_init(int world_size, int rank, const void* unique_id, void** comm_out);
+int igcn_comm_allreduce(void* comm, float* buf, int64_t n, void* stream);
+int igcn_comm_destroy(void* comm);
 
 /* ------------------------------------------------------------------------------------------------
  * Loss head of train() — kernel/train_eval_sgcn_img_snps.py:525-543 — on the STACKED outputs of the batched sweep

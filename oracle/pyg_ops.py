@@ -8,6 +8,7 @@ pinned only by the fp64 dense known-answer tests in tests/test_oracle_pyg_ops.py
 Call sites in the reference that these stand for:
   GCNConv            kernel/sgcn_img_snp.py:34,40,42,49 (ctor)  :218,221 (forward)
   to_dense_batch     kernel/sgcn_img_snp.py:226,265,294
+  global_*_pool      kernel/sgcn_img_snp.py:231-233,248-250 (graph_pool=True)
   scatter(sum)       kernel/go_model.py:200
 """
 import math
@@ -87,6 +88,37 @@ def to_dense_batch(x, batch, fill_value=0.0):
     mask = torch.zeros(b * n_max, dtype=torch.bool, device=x.device)
     mask[pos] = True
     return out.view(b, n_max, x.shape[1]), mask.view(b, n_max)
+
+
+def global_pools(x, batch):
+    """cat(global_mean_pool, global_max_pool, global_add_pool)(x, batch) of PyG 2.0.2
+    (call sites kernel/sgcn_img_snp.py:231-235,248-252): per-graph reductions over the node rows.  The max routes
+    its gradient to the FIRST maximal row (torch-scatter's CPU scatter_max updates on strictly-greater only)."""
+    b = int(batch.max()) + 1 if batch.numel() else 0
+    means, maxs, adds = [], [], []
+    for g in range(b):
+        rows = x[batch == g]
+        adds.append(rows.sum(0))
+        means.append(rows.mean(0))
+        mx, am = rows.max(dim=0)
+        first = (rows == mx.unsqueeze(0)).float().argmax(dim=0)      # first occurrence of the maximum
+        maxs.append(rows.gather(0, first.unsqueeze(0)).squeeze(0))
+    return torch.cat([torch.stack(means), torch.stack(maxs), torch.stack(adds)], dim=1)
+
+
+def global_mean_pool(x, batch):
+    d = x.shape[1]
+    return global_pools(x, batch)[:, :d]
+
+
+def global_max_pool(x, batch):
+    d = x.shape[1]
+    return global_pools(x, batch)[:, d:2 * d]
+
+
+def global_add_pool(x, batch):
+    d = x.shape[1]
+    return global_pools(x, batch)[:, 2 * d:]
 
 
 def scatter_sum_dim1(src, index, dim_size):

@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from . import go_network as G
-from .pyg_ops import gcn_conv, to_dense_batch
+from .pyg_ops import gcn_conv, global_pools, to_dense_batch
 
 HP = SimpleNamespace(lamda_x_l1=0.1, lamda_e_l1=0.1, lamda_x_ent=0.1, lamda_e_ent=0.1,
                      lamda_mi=1, lamda_ce=1)                      # sgcn_hyperparameters.py:18-23
@@ -118,6 +118,9 @@ def model_forward(sd, cfg, go_idx, data, is_explain=False, training=False, dropo
     dense, _ = to_dense_batch(xcat, batch, float(xcat.min()) - 1)            # :225-226
     bsz = dense.shape[0]
     img_out = dense.reshape(bsz, -1)
+    graph_pool = getattr(cfg, "graph_pool", False)
+    if graph_pool:                                                            # :230-235
+        img_out = global_pools(xcat, batch)
 
     latent, x_hat, atten_out = G.go_forward(sd, go_idx, snpsm, training, dropout, faithful,
                                             prefix="go_network.")
@@ -129,7 +132,11 @@ def model_forward(sd, cfg, go_idx, data, is_explain=False, training=False, dropo
         out_z = latent
         out_lin = torch.cat([snpsm, latent], dim=-1)
     else:                                                                     # :239-242,286-288
-        out_cross = torch.relu(_mha(sd, dense, atten_out)).reshape(bsz, -1)
+        out_cross = torch.relu(_mha(sd, dense, atten_out))
+        if graph_pool:                                                        # :246-252
+            out_cross = global_pools(out_cross.reshape(-1, out_cross.shape[2]), batch)
+        else:
+            out_cross = out_cross.reshape(bsz, -1)
         out_z = (img_out + out_cross) / 2
         out_lin = torch.cat([out_z, latent], dim=-1)
     lin_f = torch.relu(out_lin @ sd["lin1.weight"].t() + sd["lin1.bias"])
@@ -202,7 +209,8 @@ def train_step(sd, cfg, go_idx, data, lr=1e-3, lam=None, dropout=True, faithful=
 
 
 def sgcn_param_shapes(num_layers, hidden, rois=90, h0=3, l_dim=32, num_classes=3, num_regr=3,
-                      hidden_linear=64, image_only=False, snps_only=False, cross_atten=True, use_prob4regr=True):
+                      hidden_linear=64, image_only=False, snps_only=False, cross_atten=True, use_prob4regr=True,
+                      graph_pool=False):
     """Top-level parameter shapes of SGCN_GCN_IMGSNP (:34-101) for the head selected by the flags."""
     d = num_layers * hidden
     shp = {"prob": (rois, h0), "prob_bias": (2 * h0, 1), "edge_prob": (rois, rois), "snps_prob": (1, 54),
@@ -217,6 +225,8 @@ def sgcn_param_shapes(num_layers, hidden, rois=90, h0=3, l_dim=32, num_classes=3
         shp["multihead_attn.out_proj.bias"] = (d,)
     lin_in = rois * d if image_only else (l_dim + 54 if snps_only else rois * d + l_dim)
     reg_in = lin_in + (rois * h0 if (use_prob4regr and not snps_only) else 0)
+    if graph_pool:                                                            # :51-54
+        lin_in = reg_in = 3 * d + l_dim
     shp["lin1.weight"] = (hidden_linear, lin_in)
     shp["lin1.bias"] = (hidden_linear,)
     shp["lin1_regr.weight"] = (hidden_linear, reg_in)

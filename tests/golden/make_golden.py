@@ -13,6 +13,9 @@ is stated in every fixture's ``meta``:
   torch_scatter.scatter          -> out.index_add_(dim, index, src)       (pytorch-scatter 2.0.9)
   torch_geometric.nn.GCNConv     -> oracle.pyg_ops.GCNConvModule          (pyg 2.0.2; parity UNPINNED
   torch_geometric.utils.to_dense_batch -> oracle.pyg_ops.to_dense_batch    by the reference)
+  torch_geometric.nn.global_{mean,max,add}_pool -> oracle.pyg_ops.global_*_pool (graph_pool=True only)
+  torch_geometric.data.Data      -> PygDataStub below (batch.py's base class; public contract of SURVEY
+                                    Appendix A.5: keys / __getitem__ / __cat_dim__ / __inc__ / num_nodes)
   seaborn                        -> empty module (plotting only)
 Dropout cannot match across devices, so "train" captures run the modules in training mode (BatchNorm
 uses batch statistics) with every dropout probability forced to 0.
@@ -62,9 +65,10 @@ def _load_reference():
     tgn = types.ModuleType("torch_geometric.nn")
     tgu = types.ModuleType("torch_geometric.utils")
     tgn.GCNConv = pyg_ops.GCNConvModule
-    for name in ("ChebConv", "GATConv", "global_add_pool", "global_mean_pool", "global_sort_pool",
-                 "global_max_pool"):
+    for name in ("ChebConv", "GATConv", "global_sort_pool"):
         setattr(tgn, name, None)
+    tgn.global_add_pool, tgn.global_mean_pool, tgn.global_max_pool = (
+        pyg_ops.global_add_pool, pyg_ops.global_mean_pool, pyg_ops.global_max_pool)
     tgu.to_dense_batch = pyg_ops.to_dense_batch
     tg.nn, tg.utils = tgn, tgu
     sys.modules.update({"torch_geometric": tg, "torch_geometric.nn": tgn, "torch_geometric.utils": tgu})
@@ -273,6 +277,110 @@ def capture_sgcn(sgcn_mod, name, hidden, layers, bsz, seed, top_k=3):
     print("wrote", name, "loss", float(loss), {k: float(v) for k, v in terms.items()})
 
 
+class PygDataStub:
+    """The slice of torch_geometric.data.Data (pyg 2.0.2) that the reference's batch.py:9-123,188-191 uses — the
+    un-vendored base class of its Batch.  Restated from PyG's public contract."""
+
+    def __init__(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def keys(self):
+        return [k for k, v in self.__dict__.items() if v is not None and k[:2] != "__" and k[-2:] != "__"]
+
+    def __getitem__(self, key):
+        return getattr(self, key, None)
+
+    def __setitem__(self, key, value):
+        setattr(self, key, value)
+
+    def __contains__(self, key):
+        return key in self.keys
+
+    @property
+    def num_nodes(self):
+        x = getattr(self, "x", None)
+        if x is not None:
+            return x.size(0)
+        ei = getattr(self, "edge_index", None)
+        return int(ei.max()) + 1 if ei is not None and ei.numel() else None
+
+    def __cat_dim__(self, key, value, *args, **kwargs):
+        return -1 if ("index" in key or "face" in key) else 0
+
+    def __inc__(self, key, value, *args, **kwargs):
+        if "batch" in key:
+            return int(value.max()) + 1
+        return self.num_nodes if ("index" in key or "face" in key) else 0
+
+    def contiguous(self):
+        for k in self.keys:
+            v = self[k]
+            if torch.is_tensor(v):
+                self[k] = v.contiguous()
+        return self
+
+
+def capture_collate(name):
+    """Batch.from_data_list of the reference's batch.py:24-123 (+ num_graphs :188-191) executed on seeded graph
+    lists: the brain-graph attribute set of sgcn_data.py:262-282 (uniform 90-ROI graphs) and a ragged list with an
+    extra ``*_index`` key, a bool tensor and python scalars (the __cat_dim__ / __inc__ contract of :57,89)."""
+    tg = sys.modules["torch_geometric"]
+    tgd = types.ModuleType("torch_geometric.data")
+    tgd.Data, tgd.InMemoryDataset = PygDataStub, object
+    tg.data = tgd
+    tg.is_debug_enabled = lambda: False
+    sys.modules["torch_geometric.data"] = tgd
+    spec = importlib.util.spec_from_file_location("ref_batch", os.path.join(REF, "batch.py"))
+    rb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rb)
+    store = {"meta": np.array("reference batch.py Batch.from_data_list / num_graphs executed on CPU; "
+                              "torch_geometric.data.Data -> PygDataStub (PyG 2.0.2 absent)")}
+
+    def as_ref(d):
+        return PygDataStub(**{k: d[k] for k in d.keys})
+
+    def put(tag, b):
+        keys = sorted(b.keys)
+        store[f"{tag}/keys"] = np.array(keys)
+        for k in keys:
+            v = b[k]
+            store[f"{tag}/{k}"] = v.numpy() if torch.is_tensor(v) else np.array(v)
+        store[f"{tag}/num_graphs"] = np.array(b.num_graphs)
+
+    # (a) uniform brain graphs: cfg = (n_graphs, seed, rois, top_k, tsne_dim)
+    cfg = (6, 91, 90, 3, 16)
+    graphs = synth.brain_graph_list(cfg[0], seed=cfg[1], rois=cfg[2], top_k=cfg[3], tsne_dim=cfg[4])
+    store["brain/cfg"] = np.array(cfg)
+    put("brain", rb.Batch.from_data_list([as_ref(g) for g in graphs]))
+    # (b) ragged graphs, generated from a seed the test re-uses
+    store["ragged/seed"] = np.array(92)
+    put("ragged", rb.Batch.from_data_list([as_ref(g) for g in ragged_graph_list(92)]))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **store)
+    print("wrote", name, [k for k in store if k.endswith("/keys")])
+
+
+def ragged_graph_list(seed):
+    """Graphs of different sizes with every kind of attribute the collation distinguishes.  Imported by the tests."""
+    from igcn_amd.data import Data
+    rng = np.random.default_rng(seed)
+    out = []
+    for i, n in enumerate((5, 9, 1, 7)):
+        e = int(rng.integers(0, 3 * n + 1)) if n > 1 else 2
+        out.append(Data(
+            x=torch.from_numpy(rng.random((n, 3))).float(),
+            edge_index=torch.from_numpy(rng.integers(0, n, (2, e))).long(),
+            edge_attr=torch.from_numpy(rng.random(e)).float(),
+            pair_index=torch.from_numpy(rng.integers(0, n, (2, 2))).long(),       # '*index*': cat dim -1, += num_nodes
+            flag=torch.from_numpy(rng.integers(0, 2, n)).bool(),                  # bool: never incremented
+            snps_feat=torch.from_numpy(rng.random((1, 54))).float(),
+            y=torch.tensor([int(rng.integers(3))]),
+            clini_score=torch.from_numpy(rng.random(3)).float(),
+            age=float(rng.random()), visit=int(i)))                               # python scalars -> torch.tensor(list)
+    return out
+
+
 def synthetic_adjacency(rng, rois, knn=5):
     """Symmetric non-negative connectivity with a connected kNN support (what data.A holds, sgcn_data.py:262-282)."""
     s = rng.random((rois, rois))
@@ -402,17 +510,29 @@ def main():
         spec.loader.exec_module(sgcn_mod)
         # the image-only sibling at its real dims (BASELINE configs[0]/[1] shape, small batch)
         capture_sgcn(sgcn_mod, "sgcn_only", hidden=16, layers=2, bsz=4, seed=31)
+    if "batch_collate" in want or not want:
+        capture_collate("batch_collate")
     variants = {
         # the other heads of forward(): kernel/sgcn_img_snp.py:257-285
         "var_image_only": dict(isImageOnly=True, isCrossAtten=False, isuseProb4Regr=True),
         "var_image_only_noprob": dict(isImageOnly=True, isCrossAtten=True, isuseProb4Regr=False),
         "var_snps_only": dict(isImageOnly=False, isSNPsOnly=True, isCrossAtten=False),
         "var_fusion_noprob": dict(isuseProb4Regr=False),
+        # the graph read-out branch (:230-235,246-252): the one flag combination its forward() runs with
+        "var_graph_pool": dict(graph_pool=True, isuseProb4Regr=False),
     }
     for k, (name, flags) in enumerate(variants.items()):
         if name in want or not want:
             capture_full(sg_mod, name, rois=10, hidden=4, layers=2, bsz=4, pool=(20, 10, 6, 3, 1), seed=41 + k,
                          lam=[1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2], **flags)
+    # training-mode parity at a batch size where BatchNorm does not amplify fp32 rounding (B=32, real brain-graph
+    # dims, 500-node GO DAG; big tensors stored as signatures)
+    if "go_b32" in want or not want:
+        gs, ad, pd = synth.go_hierarchy((300, 120, 60, 19, 1), seed=7)
+        capture_go(go_mod, "go_b32", gs, ad, pd, 32, 32, 32, seed=13)
+    if "full_b32" in want or not want:
+        capture_full(sg_mod, "full_b32", rois=90, hidden=16, layers=2, bsz=32, pool=(300, 120, 60, 19, 1), seed=24,
+                     lam=[1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2])
     if want and not (want & {"go_tiny", "go_small", "full_tiny", "full_r90", "full_l3"}):
         return
     # go_tiny: the shape of the reference's own __main__ smoke block (go_model.py:290-303):

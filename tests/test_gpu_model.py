@@ -19,8 +19,19 @@ pytestmark = pytest.mark.gpu
 TOL = {"eval": 1e-4, "train": 1e-3}
 GTOL = {"eval": 1e-3, "train": 3e-2}
 NAMES = ["logp", "x_hat", "out_z", "out_lin", "lin_f", "reg"]
-FULL = ["full_tiny", "full_r90", "full_l3", "var_image_only", "var_image_only_noprob", "var_snps_only",
-        "var_fusion_noprob"]
+FULL = ["full_tiny", "full_r90", "full_l3", "full_b32", "var_image_only", "var_image_only_noprob", "var_snps_only",
+        "var_fusion_noprob", "var_graph_pool"]
+# the *_b32 fixtures were captured from the reference at B=32, where training-mode BatchNorm no longer amplifies fp32
+# rounding: there the north-star bounds hold in TRAINING mode too — 1e-4 on outputs, 1e-3 on gradients
+B32 = ("go_b32", "full_b32")
+
+
+def tol(name, mode):
+    return 1e-4 if name in B32 else TOL[mode]
+
+
+def gtol(name, mode):
+    return 1e-3 if name in B32 else GTOL[mode]
 
 
 def grad_floor(wg, k, floor):
@@ -56,7 +67,7 @@ def _go_model(store):
     return net
 
 
-@pytest.mark.parametrize("name", ["go_tiny", "go_small"])
+@pytest.mark.parametrize("name", ["go_tiny", "go_small", "go_b32"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_go_network_vs_reference_golden(golden, name, mode):
     store = golden(name)
@@ -65,21 +76,21 @@ def test_go_network_vs_reference_golden(golden, name, mode):
     snps = torch.from_numpy(store["snps"]).cuda().requires_grad_(True)
     latent, x_d, _, att = net(snps, None, "cuda")
     want = golden_group(store, f"{mode}/out")
-    assert_matches(latent, want["latent"], TOL[mode], "latent")
-    assert_matches(x_d, want["x_D"], TOL[mode], "x_D")
-    assert_matches(att, want["atten_out"], TOL[mode], "atten_out")
+    assert_matches(latent, want["latent"], tol(name, mode), "latent")
+    assert_matches(x_d, want["x_D"], tol(name, mode), "x_D")
+    assert_matches(att, want["atten_out"], tol(name, mode), "atten_out")
     cot = _probe([latent, x_d, att], int(store["seed"]) + 2)
     sum((o * c.cuda()).sum() for o, c in zip([latent, x_d, att], cot)).backward()
     wg = golden_group(store, f"{mode}/grad")
-    assert_matches(snps.grad, wg.pop("snps"), GTOL[mode], "grad snps")
+    assert_matches(snps.grad, wg.pop("snps"), gtol(name, mode), "grad snps")
     params = dict(net.named_parameters())
     for k, w in wg.items():
         assert params[k].grad is not None, k
-        assert_matches(params[k].grad, w, GTOL[mode], "grad " + k, floor=1e-4)
+        assert_matches(params[k].grad, w, gtol(name, mode), "grad " + k, floor=1e-4)
     if mode == "train":
         bufs = net.state_dict()
         for k, w in golden_group(store, "train/buffers_after").items():
-            assert_matches(bufs[k], w, TOL[mode], "buffer " + k, floor=1e-2)
+            assert_matches(bufs[k], w, tol(name, mode), "buffer " + k, floor=1e-2)
 
 
 def _full_model(store):
@@ -118,18 +129,18 @@ def test_full_model_vs_reference_golden(golden, name, mode, explain):
     tag = f"{mode}/explain{int(explain)}"
     want = golden_group(store, tag + "/out")
     for n, o in zip(NAMES, outs):
-        assert_matches(o, want[n], TOL[mode], n)
+        assert_matches(o, want[n], tol(name, mode), n)
     cot = _probe(outs, seed + 3)
     sum((o * c.cuda()).sum() for o, c in zip(outs, cot)).backward()
     wg = golden_group(store, tag + "/grad")
     if "data.x" in wg:
-        assert_matches(data.x.grad, wg.pop("data.x"), GTOL[mode], "grad data.x")
+        assert_matches(data.x.grad, wg.pop("data.x"), gtol(name, mode), "grad data.x")
     else:                                   # SNP-only head, plain pass: the image branch is not on the path
         assert data.x.grad is None or not bool(data.x.grad.abs().max() > 0)
     params = dict(model.named_parameters())
     for k, w in wg.items():
         assert params[k].grad is not None, k
-        assert_matches(params[k].grad, w, GTOL[mode], "grad " + k, floor=grad_floor(wg, k, 1e-4))
+        assert_matches(params[k].grad, w, gtol(name, mode), "grad " + k, floor=grad_floor(wg, k, 1e-4))
     for k, p in params.items():             # nothing the reference leaves without a gradient gets one here
         if k not in wg and p.grad is not None:
             assert not bool(p.grad.abs().max() > 0), "unexpected grad " + k
@@ -148,20 +159,32 @@ def test_train_step_vs_reference_golden(golden, name, batched):
     opt = FlatAdam(model.parameters(), lr=1e-3)
     opt.zero_grad()
     lam = store["lam"].tolist()
-    loss, terms, _ = losses(model, data, lam)
+    loss, terms, outs = losses(model, data, lam)
     ref_loss = float(store["step/loss"])
-    assert abs(float(loss) - ref_loss) <= 2e-4 * max(1.0, abs(ref_loss))
+    # OrthogonalConstraint: the reference sums the squares of an (R*D) x (R*D) fp32 matrix (:198-205), which at
+    # R*D = 2880 is itself ~1e-3 away from the exact value; the Gram form here is exact to 1e-7 (checked against an
+    # fp64 evaluation of the reference's own formula below), so this one term gets the reference's rounding as slack
+    ref_orth = float(store["step/term/orth"])
+    slack = 2e-3 * abs(ref_orth)
+    assert abs(float(loss) - ref_loss) <= 2e-4 * max(1.0, abs(ref_loss)) + slack
     for k, v in terms.items():
         ref = float(store[f"step/term/{k}"])
-        assert abs(float(v) - ref) <= 2e-4 * max(1.0, abs(ref)), (k, float(v), ref)
+        assert abs(float(v) - ref) <= 2e-4 * max(1.0, abs(ref)) + (slack if k == "orth" else 0.0), (k, float(v), ref)
+    if lam[5] != 0:
+        out_z = (outs[2] if len(outs) == 6 else outs[0][2]).detach().double().cpu()
+        w = out_z[:len(graphs)]
+        wn = w / w.norm(dim=1)[:, None]
+        exact = float(torch.norm(wn.T @ wn - torch.eye(wn.shape[1], dtype=torch.float64)) ** 2 / w.shape[0] ** 2)
+        assert abs(float(terms["orth"]) - lam[5] * exact) <= 1e-5 * max(1.0, abs(lam[5] * exact))
     loss.backward()
     params = dict(model.named_parameters())
     wg = golden_group(store, "step/grad")
-    assert_matches(data.x.grad, wg.pop("data.x"), 1e-2, "grad data.x")
+    gt = 1e-3 if name in B32 else 1e-2
+    assert_matches(data.x.grad, wg.pop("data.x"), gt, "grad data.x")
     grads = {}
     for k, w in wg.items():
         if isinstance(w, tuple) or np.any(w):
-            assert_matches(params[k].grad, w, 1e-2, "grad " + k, floor=grad_floor(wg, k, 1e-5))
+            assert_matches(params[k].grad, w, gt, "grad " + k, floor=grad_floor(wg, k, 1e-5))
         else:
             g = params[k].grad                                        # untouched parameters: no (or zero) grad
             assert g is None or not bool(g.abs().max() > 0), k

@@ -699,3 +699,26 @@ def test_alternative_kernel_variants_agree(tmp_path):
     for k in outs["default"].files:
         a, b = outs["default"][k], outs["alt"][k]
         assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), k
+
+
+# ------------------------------------------------------------------------------------------------ graph pool
+@pytest.mark.parametrize("g,r,d,seed", [(3, 10, 8, 0), (32, 90, 32, 1), (5, 1, 4, 2), (7, 13, 5, 3)])
+def test_graph_pool_mean_max_add(ops, g, r, d, seed):
+    """igcn_graph_pool_* against torch on the [G,R,D] view (kernel/sgcn_img_snp.py:230-235): ties in the max (ReLU
+    zeros) send the gradient to the first maximal node, as torch-scatter's CPU scatter_max does."""
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal((g * r, d))).float()
+    x = torch.relu(x)                                   # exact zeros => ties
+    x[:r, 0] = 0.0                                      # an all-tied column
+    xg = x.cuda().requires_grad_(True)
+    out = ops.GraphPool.apply(xg, r)
+    xr = x.double().requires_grad_(True)
+    v = xr.view(g, r, d)
+    mx = v.max(dim=1).values
+    first = (v == mx.unsqueeze(1)).double().argmax(dim=1)
+    ref = torch.cat([v.mean(1), v.gather(1, first.unsqueeze(1)).squeeze(1), v.sum(1)], dim=1)
+    assert_matches(out, ref.detach().float().numpy(), 1e-6, "pool")
+    cot = torch.from_numpy(rng.standard_normal((g, 3 * d))).float()
+    (out * cot.cuda()).sum().backward()
+    (ref * cot.double()).sum().backward()
+    assert_matches(xg.grad, xr.grad.float().numpy(), 1e-6, "pool grad")

@@ -18,6 +18,17 @@ from oracle import sgcn_img_snp as OS
 # oracle sits just as far from the reference's fp32 numbers), hence the looser training bound
 TOL = {"eval": 1e-5, "train": 3e-4}
 GTOL = {"eval": 5e-4, "train": 5e-3}
+# the *_b32 fixtures (B=32): BatchNorm over 32 samples no longer amplifies rounding, so training mode holds the
+# north-star bounds (1e-4 outputs / 1e-3 gradients)
+B32 = ("go_b32", "full_b32")
+
+
+def tol(name, mode):
+    return 1e-4 if (name in B32 and mode == "train") else TOL[mode]
+
+
+def gtol(name, mode):
+    return 1e-3 if (name in B32 and mode == "train") else GTOL[mode]
 
 
 def _go_setup(store):
@@ -33,7 +44,7 @@ def _probe(outs, seed):
     return [torch.from_numpy(rng.standard_normal(tuple(o.shape))).float() for o in outs]
 
 
-@pytest.mark.parametrize("name", ["go_tiny", "go_small"])
+@pytest.mark.parametrize("name", ["go_tiny", "go_small", "go_b32"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 @pytest.mark.parametrize("faithful", [False, True])
 def test_go_network_matches_reference(golden, name, mode, faithful):
@@ -43,26 +54,27 @@ def test_go_network_matches_reference(golden, name, mode, faithful):
     snps = torch.from_numpy(store["snps"]).clone().requires_grad_(True)
     latent, x_d, att = OG.go_forward(sd, idx, snps, training=(mode == "train"), dropout=False, faithful=faithful)
     want = golden_group(store, f"{mode}/out")
-    assert_matches(latent, want["latent"], TOL[mode], "latent")
-    assert_matches(x_d, want["x_D"], TOL[mode], "x_D")
-    assert_matches(att, want["atten_out"], TOL[mode], "atten_out")
+    assert_matches(latent, want["latent"], tol(name, mode), "latent")
+    assert_matches(x_d, want["x_D"], tol(name, mode), "x_D")
+    assert_matches(att, want["atten_out"], tol(name, mode), "atten_out")
     cot = _probe([latent, x_d, att], int(store["seed"]) + 2)
     sum((o * c).sum() for o, c in zip([latent, x_d, att], cot)).backward()
     wg = golden_group(store, f"{mode}/grad")
-    assert_matches(snps.grad, wg.pop("snps"), GTOL[mode], "grad snps")
+    assert_matches(snps.grad, wg.pop("snps"), gtol(name, mode), "grad snps")
     for k, w in wg.items():
         assert sd[k].grad is not None, k
-        assert_matches(sd[k].grad, w, GTOL[mode], "grad " + k, floor=1e-4)
+        assert_matches(sd[k].grad, w, gtol(name, mode), "grad " + k, floor=1e-4)
     if mode == "train":
         for k, w in golden_group(store, "train/buffers_after").items():
-            assert_matches(sd[k], w, TOL[mode], "buffer " + k)
+            assert_matches(sd[k], w, tol(name, mode), "buffer " + k)
 
 
 def variant_flags(store):
     """Constructor flags of a var_* fixture as the oracle's cfg fields."""
     v = dict(ast.literal_eval(str(store["variant"]))) if "variant" in store else {}
     return dict(image_only=v.get("isImageOnly", False), snps_only=v.get("isSNPsOnly", False),
-                cross_atten=v.get("isCrossAtten", True), use_prob4regr=v.get("isuseProb4Regr", True))
+                cross_atten=v.get("isCrossAtten", True), use_prob4regr=v.get("isuseProb4Regr", True),
+                graph_pool=v.get("graph_pool", False))
 
 
 def grad_floor(wg, k, floor):
@@ -96,8 +108,8 @@ def _full_setup(store):
 
 
 NAMES = ["logp", "x_hat", "out_z", "out_lin", "lin_f", "reg"]
-FULL = ["full_tiny", "full_r90", "full_l3", "var_image_only", "var_image_only_noprob", "var_snps_only",
-        "var_fusion_noprob"]
+FULL = ["full_tiny", "full_r90", "full_l3", "full_b32", "var_image_only", "var_image_only_noprob", "var_snps_only",
+        "var_fusion_noprob", "var_graph_pool"]
 
 
 @pytest.mark.parametrize("name", FULL)
@@ -113,18 +125,18 @@ def test_full_model_matches_reference(golden, name, mode, explain):
     tag = f"{mode}/explain{int(explain)}"
     want = golden_group(store, tag + "/out")
     for n, o in zip(NAMES, outs):
-        assert_matches(o, want[n], TOL[mode], n)
+        assert_matches(o, want[n], tol(name, mode), n)
     cot = _probe(outs, seed + 3)
     sum((o * c).sum() for o, c in zip(outs, cot)).backward()
     wg = golden_group(store, tag + "/grad")
     if "data.x" in wg:
-        assert_matches(data.x.grad, wg.pop("data.x"), GTOL[mode], "grad data.x")
+        assert_matches(data.x.grad, wg.pop("data.x"), gtol(name, mode), "grad data.x")
     else:                              # SNP-only head, plain pass: the image branch is not on the path
         assert data.x.grad is None or not bool(data.x.grad.abs().max() > 0)
     for k, w in wg.items():
         assert sd[k].grad is not None, k
         floor = grad_floor(wg, k, 1e-4)
-        assert_matches(sd[k].grad, w, GTOL[mode], "grad " + k, floor=floor)
+        assert_matches(sd[k].grad, w, gtol(name, mode), "grad " + k, floor=floor)
     for k, v in sd.items():            # and nothing the reference leaves without a gradient gets one here
         if v.requires_grad and v.grad is not None and k not in wg:
             assert not bool(v.grad.abs().max() > 0), "unexpected grad " + k
