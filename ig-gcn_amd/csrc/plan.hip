@@ -1,9 +1,8 @@
 // Graph plan: stable grouping of the batch's edges by target and by source node (include/igcn.h).
-// The sort is rocPRIM's LSD radix sort (stable), restricted to the bits a node id needs; everything
-// else is hand-written.  Runs once per batch; every later kernel reuses its output.
+// Three builders with bit-identical output, all hand-written and hipGraph-capturable: one workgroup per graph in LDS
+// (small graphs), a tiled one-pass counting sort per graph (<= 1024 nodes per graph, any number of edges) and a
+// general LSD radix sort (arbitrary edge_index).  Runs once per batch; every later kernel reuses its output.
 #include <stdarg.h>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
 
@@ -75,19 +74,255 @@ int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int 
   return IGCN_OK;
 }
 
-// ---- kernels -----------------------------------------------------------------------------------
-// Coalesced read of the int64 edge_index rows; int32 copies + identity values for the sorts;
-// loop_edge via atomicMax (max edge id == "last stored loop wins", order independent => deterministic).
-__global__ void k_plan_split(int64_t n_nodes, int64_t n_edges, const int64_t* __restrict__ ei, int32_t* __restrict__ src32,
-                             int32_t* __restrict__ dst32, int32_t* __restrict__ iota,
-                             int32_t* __restrict__ loop_edge) {
-  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_edges) return;
-  int32_t s = (int32_t)ei[k], d = (int32_t)ei[n_edges + k];
-  src32[k] = s;
-  dst32[k] = d;
-  iota[k] = (int32_t)k;
-  if (s == d && s >= 0 && s < n_nodes) atomicMax(&loop_edge[s], (int32_t)k);
+// ---- stable grouping by a hand-written counting / radix sort ------------------------------------------------
+// No library sort: three kernels per pass, no scratch beyond the caller's workspace, nothing that cannot be captured
+// into a hipGraph (round 1 used rocPRIM's onesweep radix sort, which faulted when replayed from inside the step graph).
+//
+// A pass orders the elements of every SEGMENT by a digit < ND (ND <= 1024), stably:
+//   k_sort_hist    tile (<= ST_TILE consecutive elements of one segment) -> digit histogram hist[seg][tile][ND]
+//   k_sort_scan    per segment: hist -> exclusive offsets over (digit, tile)  (+ the row pointers in one-pass mode)
+//   k_sort_scatter tile re-read in order; every element's slot = offset of (digit, tile, wave) + its rank among the
+//                  EARLIER elements of the wave's chunk with the same digit (wave ballots: no atomics, no sort)
+// Both groupings (A: by target = dst, B: by source = src) run through the same launches.
+//  * segmented one-pass mode (a PyG batch: graph g owns nodes [node_ptr[g], node_ptr[g+1]) and edges
+//    [edge_ptr[g], edge_ptr[g+1]), at most 1024 nodes per graph, any number of edges): digit = node id inside the
+//    graph, so ONE pass finishes the grouping and the digit totals ARE the row pointers;
+//  * general mode (one segment = all edges): LSD passes of 10 bits over the node id, ping-pong through the workspace.
+#define ST_TILE 4096
+#define ST_WAVES 4
+#define ST_MAXD 1024
+
+struct SortArgs {
+  int64_t n_nodes, n_edges;
+  const int64_t* ei;            // first pass: int64 edge_index [2,E]; keys = its rows, values = edge ids
+  const int64_t* node_ptr;      // segmented mode (else NULL: one segment)
+  const int64_t* edge_ptr;
+  const int32_t *keyA_in, *valA_in, *keyB_in, *valB_in;   // later passes: permuted keys / edge ids of the last pass
+  int32_t *keyA_out, *valA_out, *keyB_out, *valB_out;     // key*_out may be NULL (one-pass mode)
+  int32_t *src32, *dst32, *loop_edge, *status;            // first pass side outputs
+  int32_t *histA, *histB;       // [segments][tiles][nd]
+  int32_t *dbaseA, *dbaseB;     // [segments][nd]
+  int32_t *ptrA, *ptrB;         // one-pass mode: tgt_ptr / src_ptr
+  int tiles, nd, shift, first, onepass;
+};
+
+// the wave's chunk of the tile: elements [lo, hi) (absolute edge positions), segment offsets nb / eb
+__device__ __forceinline__ void sort_tile_range(const SortArgs& a, int seg, int tile, int64_t& nb, int64_t& nn,
+                                                int64_t& lo, int64_t& hi) {
+  int64_t eb = 0, ee = a.n_edges;
+  nb = 0;
+  nn = a.n_nodes;
+  if (a.node_ptr) {
+    nb = a.node_ptr[seg];
+    nn = a.node_ptr[seg + 1] - nb;
+    eb = a.edge_ptr[seg];
+    ee = a.edge_ptr[seg + 1];
+  }
+  lo = eb + (int64_t)tile * ST_TILE;
+  hi = lo + ST_TILE < ee ? lo + ST_TILE : ee;
+  if (lo > hi) lo = hi;
+}
+
+// digits (A, B) of element i; first pass also emits src32 / dst32 / loop_edge
+__device__ __forceinline__ void sort_load(const SortArgs& a, int64_t i, int64_t nb, int64_t nn, int32_t& kA, int32_t& kB,
+                                          int32_t& vA, int32_t& vB, int& dA, int& dB) {
+  if (a.first) {
+    const int64_t s = a.ei[i], d = a.ei[a.n_edges + i];
+    kA = (int32_t)d;
+    kB = (int32_t)s;
+    vA = vB = (int32_t)i;
+  } else {
+    kA = a.keyA_in[i]; vA = a.valA_in[i];
+    kB = a.keyB_in[i]; vB = a.valB_in[i];
+  }
+  if (a.onepass) {
+    int64_t la = (int64_t)kA - nb, lb = (int64_t)kB - nb;
+    if (la < 0 || la >= nn || lb < 0 || lb >= nn) {      // edge leaves its graph: not a PyG batch
+      atomicExch(a.status, 2);
+      la = la < 0 || la >= nn ? 0 : la;
+      lb = lb < 0 || lb >= nn ? 0 : lb;
+    }
+    dA = (int)la;
+    dB = (int)lb;
+  } else {
+    dA = (kA >> a.shift) & (a.nd - 1);
+    dB = (kB >> a.shift) & (a.nd - 1);
+  }
+}
+
+// lanes of the wave whose digit equals this lane's (restricted to `active`)
+__device__ __forceinline__ unsigned long long sort_peers(int d, int nbits, unsigned long long active) {
+  unsigned long long peers = active;
+  for (int b = 0; b < nbits; ++b) {
+    const bool bit = (d >> b) & 1;
+    const unsigned long long m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+__device__ __forceinline__ int sort_nbits(int nd) {
+  int b = 0;
+  while ((1 << b) < nd) ++b;
+  return b;
+}
+
+// per-wave digit counts of the tile into cnt[2][ST_WAVES][nd] (LDS, zeroed here)
+__device__ __forceinline__ void sort_wave_hist(const SortArgs& a, int32_t* cnt, int64_t nb, int64_t nn, int64_t lo,
+                                               int64_t hi, bool side_outputs) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nd = a.nd, nbits = sort_nbits(nd);
+  for (int i = tid; i < 2 * ST_WAVES * nd; i += 256) cnt[i] = 0;
+  __syncthreads();
+  int32_t* cA = cnt + w * nd;
+  int32_t* cB = cnt + (ST_WAVES + w) * nd;
+  const int64_t wlo = lo + (int64_t)w * (ST_TILE / ST_WAVES);
+  for (int64_t base = wlo; base < wlo + ST_TILE / ST_WAVES && base < hi; base += 64) {     // wave-uniform bounds
+    const int64_t i = base + lane;
+    const bool valid = i < hi;
+    int32_t kA = 0, kB = 0, vA = 0, vB = 0;
+    int dA = 0, dB = 0;
+    if (valid) {
+      sort_load(a, i, nb, nn, kA, kB, vA, vB, dA, dB);
+      if (side_outputs) {
+        a.src32[i] = kB;
+        a.dst32[i] = kA;
+        if (kA == kB && kA >= 0 && kA < a.n_nodes) atomicMax(&a.loop_edge[kA], (int32_t)i);   // last stored loop wins
+      }
+    }
+    const unsigned long long active = __ballot(valid);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long pA = sort_peers(dA, nbits, active), pB = sort_peers(dB, nbits, active);
+    if (valid && (pA & lt) == 0) cA[dA] += __popcll(pA);      // one leader per digit: no two lanes share an address
+    if (valid && (pB & lt) == 0) cB[dB] += __popcll(pB);
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_sort_hist(SortArgs a) {
+  extern __shared__ int32_t st_cnt[];
+  const int seg = blockIdx.y, tile = blockIdx.x, nd = a.nd;
+  int64_t nb, nn, lo, hi;
+  sort_tile_range(a, seg, tile, nb, nn, lo, hi);
+  if (a.onepass && nn > nd) {                       // the host checked the maximum; refuse, do not corrupt
+    if (threadIdx.x == 0) atomicExch(a.status, 1);
+    nn = nd;
+  }
+  sort_wave_hist(a, st_cnt, nb, nn, lo, hi, a.first != 0);
+  int32_t* hA = a.histA + ((int64_t)seg * a.tiles + tile) * nd;
+  int32_t* hB = a.histB + ((int64_t)seg * a.tiles + tile) * nd;
+  for (int d = threadIdx.x; d < nd; d += 256) {
+    int tA = 0, tB = 0;
+#pragma unroll
+    for (int w = 0; w < ST_WAVES; ++w) {
+      tA += st_cnt[w * nd + d];
+      tB += st_cnt[(ST_WAVES + w) * nd + d];
+    }
+    hA[d] = tA;
+    hB[d] = tB;
+  }
+}
+
+// one 1024-thread block per segment: thread d owns digit d.  hist[seg][t][d] becomes the number of elements of digit
+// d in the EARLIER tiles of the segment; dbase[seg][d] = segment start + elements of smaller digits.
+__global__ void __launch_bounds__(1024) k_sort_scan(SortArgs a, int n_segments) {
+  __shared__ int32_t part[2][16];
+  const int seg = blockIdx.x, d = threadIdx.x, nd = a.nd, lane = d & 63, w = d >> 6;
+  int64_t eb = 0, nb = 0, nn = a.n_nodes;
+  if (a.node_ptr) {
+    eb = a.edge_ptr[seg];
+    nb = a.node_ptr[seg];
+    nn = a.node_ptr[seg + 1] - nb;
+  }
+  int totA = 0, totB = 0;
+  if (d < nd) {
+    int32_t* hA = a.histA + (int64_t)seg * a.tiles * nd + d;
+    int32_t* hB = a.histB + (int64_t)seg * a.tiles * nd + d;
+#pragma unroll 4
+    for (int t = 0; t < a.tiles; ++t) {
+      const int cA = hA[(int64_t)t * nd], cB = hB[(int64_t)t * nd];
+      hA[(int64_t)t * nd] = totA;
+      hB[(int64_t)t * nd] = totB;
+      totA += cA;
+      totB += cB;
+    }
+  }
+  // exclusive scan of the digit totals over the block (wave scans + one pass over the 16 wave sums)
+  int sA = totA, sB = totB;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int uA = __shfl_up(sA, o, 64), uB = __shfl_up(sB, o, 64);
+    if (lane >= o) { sA += uA; sB += uB; }
+  }
+  if (lane == 63) { part[0][w] = sA; part[1][w] = sB; }
+  __syncthreads();
+  int offA = 0, offB = 0;
+  for (int i = 0; i < w; ++i) { offA += part[0][i]; offB += part[1][i]; }
+  const int exA = offA + sA - totA, exB = offB + sB - totB;
+  if (d < nd) {
+    a.dbaseA[(int64_t)seg * nd + d] = (int32_t)eb + exA;
+    a.dbaseB[(int64_t)seg * nd + d] = (int32_t)eb + exB;
+    if (a.onepass && d < nn) {
+      a.ptrA[nb + d] = (int32_t)eb + exA;
+      a.ptrB[nb + d] = (int32_t)eb + exB;
+    }
+  }
+  if (a.onepass && seg == n_segments - 1 && d == 0) {
+    a.ptrA[a.n_nodes] = (int32_t)a.n_edges;
+    a.ptrB[a.n_nodes] = (int32_t)a.n_edges;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_sort_scatter(SortArgs a) {
+  extern __shared__ int32_t st_cnt[];
+  const int seg = blockIdx.y, tile = blockIdx.x, nd = a.nd, nbits = sort_nbits(nd);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int64_t nb, nn, lo, hi;
+  sort_tile_range(a, seg, tile, nb, nn, lo, hi);
+  if (a.onepass && nn > nd) nn = nd;
+  sort_wave_hist(a, st_cnt, nb, nn, lo, hi, false);
+  // per-wave counts -> first slot of (digit, wave): digit base + earlier tiles + earlier waves of this tile
+  const int32_t* hA = a.histA + ((int64_t)seg * a.tiles + tile) * nd;
+  const int32_t* hB = a.histB + ((int64_t)seg * a.tiles + tile) * nd;
+  for (int d = tid; d < nd; d += 256) {
+    int rA = a.dbaseA[(int64_t)seg * nd + d] + hA[d], rB = a.dbaseB[(int64_t)seg * nd + d] + hB[d];
+#pragma unroll
+    for (int k = 0; k < ST_WAVES; ++k) {
+      const int cA = st_cnt[k * nd + d], cB = st_cnt[(ST_WAVES + k) * nd + d];
+      st_cnt[k * nd + d] = rA;
+      st_cnt[(ST_WAVES + k) * nd + d] = rB;
+      rA += cA;
+      rB += cB;
+    }
+  }
+  __syncthreads();
+  int32_t* cA = st_cnt + w * nd;
+  int32_t* cB = st_cnt + (ST_WAVES + w) * nd;
+  const int64_t wlo = lo + (int64_t)w * (ST_TILE / ST_WAVES);
+  for (int64_t base = wlo; base < wlo + ST_TILE / ST_WAVES && base < hi; base += 64) {
+    const int64_t i = base + lane;
+    const bool valid = i < hi;
+    int32_t kA = 0, kB = 0, vA = 0, vB = 0;
+    int dA = 0, dB = 0;
+    if (valid) sort_load(a, i, nb, nn, kA, kB, vA, vB, dA, dB);
+    const unsigned long long active = __ballot(valid);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long pA = sort_peers(dA, nbits, active), pB = sort_peers(dB, nbits, active);
+    int posA = 0, posB = 0;
+    if (valid) {
+      posA = cA[dA] + __popcll(pA & lt);
+      posB = cB[dB] + __popcll(pB & lt);
+    }
+    // all lanes have read their running offsets (LDS operations of a wave execute in order) before the leaders
+    // advance them
+    if (valid && (pA & lt) == 0) cA[dA] += __popcll(pA);
+    if (valid && (pB & lt) == 0) cB[dB] += __popcll(pB);
+    if (valid) {
+      a.valA_out[posA] = vA;
+      a.valB_out[posB] = vB;
+      if (a.keyA_out) { a.keyA_out[posA] = kA; a.keyB_out[posB] = kB; }
+    }
+  }
 }
 
 __global__ void k_fill_i32(int64_t n, int32_t* p, int32_t v) {
@@ -108,26 +343,38 @@ __global__ void k_plan_ptr(int64_t n_nodes, int64_t n_edges, const int32_t* __re
   ptr[i] = (int32_t)lo;
 }
 
-static int key_bits(int64_t n_nodes) {
-  int b = 1;
-  while (((int64_t)1 << b) < n_nodes) ++b;
-  return b;
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static int pow2_digits(int64_t n) {        // smallest power of two >= n, at least 2
+  int d = 2;
+  while (d < n) d <<= 1;
+  return d;
 }
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static int sort_launch_pass(const SortArgs& a, int n_segments, hipStream_t st) {
+  const size_t lds = (size_t)2 * ST_WAVES * a.nd * sizeof(int32_t);
+  dim3 grid((unsigned)a.tiles, (unsigned)n_segments);
+  hipLaunchKernelGGL(k_sort_hist, grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k_sort_scan, dim3((unsigned)n_segments), dim3(1024), 0, st, a, n_segments);
+  hipLaunchKernelGGL(k_sort_scatter, grid, dim3(256), lds, st, a);
+  IGCN_CHECK_LAUNCH("graph_plan sort pass");
+  return IGCN_OK;
+}
 
-static size_t sort_temp_bytes(int64_t n_nodes, int64_t n_edges) {
-  size_t bytes = 0;
-  int32_t* nul = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, nul, nul, nul, nul, (size_t)n_edges, 0u,
-                                  (unsigned)key_bits(n_nodes), (hipStream_t)0);
-  return bytes;
+// ---- general build: arbitrary edge_index, LSD passes of 10 bits over the node id ------------------------------
+static int general_passes(int64_t n_nodes) {
+  int bits = 1;
+  while (((int64_t)1 << bits) < n_nodes) ++bits;
+  return (bits + 9) / 10;
 }
 
 extern "C" size_t igcn_graph_plan_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
   if (n_edges <= 0) return 256;
-  // iota [E] + sorted keys [E] + rocPRIM temp
-  return 2 * align256((size_t)n_edges * 4) + align256(sort_temp_bytes(n_nodes, n_edges)) + 256;
+  const int64_t tiles = igcn_cdiv(n_edges, ST_TILE);
+  const int passes = general_passes(n_nodes);
+  // two histograms + two digit-base rows, then (multi-pass only) two ping-pong (key, value) buffer pairs per grouping
+  size_t bytes = 2 * align256((size_t)tiles * ST_MAXD * 4) + 2 * align256((size_t)ST_MAXD * 4) + 256;
+  bytes += (size_t)(passes > 1 ? 8 : 2) * align256((size_t)n_edges * 4);
+  return bytes;
 }
 
 extern "C" int igcn_graph_plan_build(int64_t n_nodes, int64_t n_edges, const int64_t* edge_index, int32_t* src32,
@@ -148,27 +395,113 @@ extern "C" int igcn_graph_plan_build(int64_t n_nodes, int64_t n_edges, const int
     IGCN_CHECK_LAUNCH("graph_plan_build(empty)");
     return IGCN_OK;
   }
+  const int64_t tiles = igcn_cdiv(n_edges, ST_TILE);
+  const int passes = general_passes(n_nodes);
   char* ws = (char*)workspace;
-  int32_t* iota = (int32_t*)ws;
-  int32_t* skeys = (int32_t*)(ws + align256((size_t)n_edges * 4));
-  void* temp = ws + 2 * align256((size_t)n_edges * 4);
-  size_t temp_bytes = sort_temp_bytes(n_nodes, n_edges);
-  const unsigned bits = (unsigned)key_bits(n_nodes);
-
-  hipLaunchKernelGGL(k_plan_split, dim3((unsigned)igcn_cdiv(n_edges, T)), dim3(T), 0, st, n_nodes, n_edges,
-                     edge_index, src32, dst32, iota, loop_edge);
-  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const int32_t*)dst32, skeys, (const int32_t*)iota,
-                                           tgt_perm, (size_t)n_edges, 0u, bits, st);
-  if (e != hipSuccess) { igcn_set_error("graph_plan_build: sort(dst): %s", hipGetErrorString(e)); return IGCN_ERR_LAUNCH; }
-  hipLaunchKernelGGL(k_plan_ptr, dim3((unsigned)igcn_cdiv(n_nodes + 1, T)), dim3(T), 0, st, n_nodes, n_edges, skeys,
+  const size_t hsz = align256((size_t)tiles * ST_MAXD * 4), dsz = align256((size_t)ST_MAXD * 4);
+  const size_t esz = align256((size_t)n_edges * 4);
+  SortArgs a = {};
+  a.n_nodes = n_nodes;
+  a.n_edges = n_edges;
+  a.ei = edge_index;
+  a.src32 = src32;
+  a.dst32 = dst32;
+  a.loop_edge = loop_edge;
+  a.histA = (int32_t*)ws;
+  a.histB = (int32_t*)(ws + hsz);
+  a.dbaseA = (int32_t*)(ws + 2 * hsz);
+  a.dbaseB = (int32_t*)(ws + 2 * hsz + dsz);
+  char* eb = ws + 2 * hsz + 2 * dsz;
+  int32_t* buf[8];
+  for (int i = 0; i < 8; ++i) buf[i] = (int32_t*)(eb + (size_t)(passes > 1 ? i : (i & 1)) * esz);
+  a.tiles = (int)tiles;
+  a.ptrA = tgt_ptr;
+  a.ptrB = src_ptr;
+  a.status = nullptr;
+  a.onepass = 0;
+  // keys of the final order go to buf[.] for the row-pointer search; values of the final pass are the permutations
+  const int32_t *kA = nullptr, *vA = nullptr, *kB = nullptr, *vB = nullptr;
+  int bits_left = 1;
+  while (((int64_t)1 << bits_left) < n_nodes) ++bits_left;
+  for (int p = 0; p < passes; ++p) {
+    const bool last = p == passes - 1;
+    const int pb = bits_left < 10 ? bits_left : 10;
+    a.nd = 1 << pb;
+    a.shift = 10 * p;
+    a.first = p == 0;
+    a.keyA_in = kA; a.valA_in = vA; a.keyB_in = kB; a.valB_in = vB;
+    const int o = (p & 1) * 4;
+    a.keyA_out = buf[o + 0];
+    a.keyB_out = buf[o + 1];
+    a.valA_out = last ? tgt_perm : buf[o + 2];
+    a.valB_out = last ? src_perm : buf[o + 3];
+    const int rc = sort_launch_pass(a, 1, st);
+    if (rc) return rc;
+    kA = a.keyA_out; vA = a.valA_out; kB = a.keyB_out; vB = a.valB_out;
+    bits_left -= pb;
+  }
+  hipLaunchKernelGGL(k_plan_ptr, dim3((unsigned)igcn_cdiv(n_nodes + 1, T)), dim3(T), 0, st, n_nodes, n_edges, kA,
                      tgt_ptr);
-  e = rocprim::radix_sort_pairs(temp, temp_bytes, (const int32_t*)src32, skeys, (const int32_t*)iota, src_perm,
-                                (size_t)n_edges, 0u, bits, st);
-  if (e != hipSuccess) { igcn_set_error("graph_plan_build: sort(src): %s", hipGetErrorString(e)); return IGCN_ERR_LAUNCH; }
-  hipLaunchKernelGGL(k_plan_ptr, dim3((unsigned)igcn_cdiv(n_nodes + 1, T)), dim3(T), 0, st, n_nodes, n_edges, skeys,
+  hipLaunchKernelGGL(k_plan_ptr, dim3((unsigned)igcn_cdiv(n_nodes + 1, T)), dim3(T), 0, st, n_nodes, n_edges, kB,
                      src_ptr);
   IGCN_CHECK_LAUNCH("graph_plan_build");
   return IGCN_OK;
+}
+
+// ---- tiled segmented build: a PyG batch of graphs with <= 1024 nodes and ANY number of edges each --------------
+extern "C" size_t igcn_graph_plan_tiled_workspace_bytes(int n_graphs, int64_t max_nodes_per_graph,
+                                                        int64_t max_edges_per_graph) {
+  const int64_t tiles = igcn_cdiv(max_edges_per_graph > 0 ? max_edges_per_graph : 1, ST_TILE);
+  const int nd = pow2_digits(max_nodes_per_graph);
+  return 2 * align256((size_t)n_graphs * tiles * nd * 4) + 2 * align256((size_t)n_graphs * nd * 4) + 256;
+}
+
+extern "C" int igcn_graph_plan_build_tiled(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* edge_index,
+                                           const int64_t* node_ptr, const int64_t* edge_ptr,
+                                           int64_t max_nodes_per_graph, int64_t max_edges_per_graph, int32_t* src32,
+                                           int32_t* dst32, int32_t* tgt_ptr, int32_t* tgt_perm, int32_t* src_ptr,
+                                           int32_t* src_perm, int32_t* loop_edge, int32_t* status, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  IGCN_REQUIRE(n_graphs > 0 && n_nodes > 0 && n_nodes < ((int64_t)1 << 31) && n_edges > 0 &&
+               n_edges < ((int64_t)1 << 31) && max_nodes_per_graph > 0 && max_edges_per_graph > 0,
+               "graph_plan_build_tiled: bad sizes");
+  if (max_nodes_per_graph > ST_MAXD) {
+    igcn_set_error("graph_plan_build_tiled: more than %d nodes per graph (use igcn_graph_plan_build)", ST_MAXD);
+    return IGCN_ERR_UNSUPPORTED;
+  }
+  IGCN_REQUIRE(workspace_bytes >= igcn_graph_plan_tiled_workspace_bytes(n_graphs, max_nodes_per_graph,
+                                                                         max_edges_per_graph),
+               "graph_plan_build_tiled: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)igcn_cdiv(n_nodes, 256)), dim3(256), 0, st, n_nodes, loop_edge, -1);
+  const int64_t tiles = igcn_cdiv(max_edges_per_graph, ST_TILE);
+  const int nd = pow2_digits(max_nodes_per_graph);
+  char* ws = (char*)workspace;
+  const size_t hsz = align256((size_t)n_graphs * tiles * nd * 4), dsz = align256((size_t)n_graphs * nd * 4);
+  SortArgs a = {};
+  a.n_nodes = n_nodes;
+  a.n_edges = n_edges;
+  a.ei = edge_index;
+  a.node_ptr = node_ptr;
+  a.edge_ptr = edge_ptr;
+  a.valA_out = tgt_perm;
+  a.valB_out = src_perm;
+  a.src32 = src32;
+  a.dst32 = dst32;
+  a.loop_edge = loop_edge;
+  a.status = status;
+  a.histA = (int32_t*)ws;
+  a.histB = (int32_t*)(ws + hsz);
+  a.dbaseA = (int32_t*)(ws + 2 * hsz);
+  a.dbaseB = (int32_t*)(ws + 2 * hsz + dsz);
+  a.ptrA = tgt_ptr;
+  a.ptrB = src_ptr;
+  a.tiles = (int)tiles;
+  a.nd = nd;
+  a.shift = 0;
+  a.first = 1;
+  a.onepass = 1;
+  return sort_launch_pass(a, n_graphs, st);
 }
 
 // Plan of `copies` disjoint copies of the same batch (nodes g*N + i, edges g*E + k): used to run the plain and the

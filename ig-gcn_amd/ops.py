@@ -27,8 +27,9 @@ class GraphPlan:
     SEG_MAX_NODES, SEG_MAX_EDGES = 1024, 4096
 
     def __init__(self, edge_index, n_nodes, node_ptr=None, edge_ptr=None, max_nodes=None, max_edges=None):
-        """``node_ptr``/``edge_ptr`` (int64 device tensors [G+1]) + the host-known per-graph maxima select the
-        segmented build (one workgroup per graph, no device-wide sort); otherwise the general radix-sort build."""
+        """``node_ptr``/``edge_ptr`` (int64 device tensors [G+1]) + the host-known per-graph maxima select a per-graph
+        build (graphs of at most 1024 nodes: in LDS up to 4096 edges per graph, tiled counting sort beyond);
+        otherwise the general radix-sort build.  All three are hand-written and hipGraph-capturable."""
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise _lib.IgcnError("edge_index must be int64 [2,E]")
         ei = edge_index.contiguous()
@@ -46,14 +47,23 @@ class GraphPlan:
         self._copies = {}
         self.status = None
         self._seg = None
+        self._tiled = False
         # uniform graph size (every PyG batch of R-ROI brain graphs), passed to the aggregation as a hint
         self.nodes_per_graph = int(max_nodes) if (max_nodes and node_ptr is not None and
                                                   n == int(max_nodes) * (int(node_ptr.numel()) - 1)) else 0
-        if (node_ptr is not None and edge_ptr is not None and max_nodes is not None and max_edges is not None
-                and 0 < max_nodes <= self.SEG_MAX_NODES and max_edges <= self.SEG_MAX_EDGES and e > 0
-                and node_ptr.device == dev and edge_ptr.device == dev):
+        have_seg = (node_ptr is not None and edge_ptr is not None and max_nodes is not None and max_edges is not None
+                    and 0 < max_nodes <= self.SEG_MAX_NODES and e > 0 and node_ptr.device == dev
+                    and edge_ptr.device == dev)
+        if have_seg:
+            # per-graph builds (hand-written, hipGraph-capturable): all in LDS for small graphs, tiled counting sort
+            # for graphs with more than SEG_MAX_EDGES edges (dense 512-ROI graphs)
             self.status = torch.zeros(1, **i32)
             self._seg = (node_ptr.contiguous(), edge_ptr.contiguous(), int(max_nodes), int(max_edges))
+            self._tiled = max_edges > self.SEG_MAX_EDGES
+            if self._tiled:
+                nb = int(_lib.load().igcn_graph_plan_tiled_workspace_bytes(int(node_ptr.numel()) - 1, int(max_nodes),
+                                                                           int(max_edges)))
+                self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         else:
             self._ws = torch.empty(int(_lib.load().igcn_graph_plan_workspace_bytes(n, e)), dtype=torch.uint8,
                                    device=dev)
@@ -67,10 +77,13 @@ class GraphPlan:
         n, e = self.n_nodes, self.n_edges
         if self._seg is not None:
             node_ptr, edge_ptr, max_nodes, max_edges = self._seg
-            call("igcn_graph_plan_build_segmented", n, e, int(node_ptr.numel()) - 1, ptr(ei), ptr(node_ptr),
-                 ptr(edge_ptr), max_nodes, max_edges, ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr),
-                 ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(self.status),
-                 stream_ptr())
+            head = (n, e, int(node_ptr.numel()) - 1, ptr(ei), ptr(node_ptr), ptr(edge_ptr), max_nodes, max_edges,
+                    ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr), ptr(self.tgt_perm), ptr(self.src_ptr),
+                    ptr(self.src_perm), ptr(self.loop_edge), ptr(self.status))
+            if self._tiled:
+                call("igcn_graph_plan_build_tiled", *head, ptr(self._ws), self._ws.numel(), stream_ptr())
+            else:
+                call("igcn_graph_plan_build_segmented", *head, stream_ptr())
             return
         call("igcn_graph_plan_build", n, e, ptr(ei), ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr),
              ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(self._ws),

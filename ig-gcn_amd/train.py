@@ -3,6 +3,7 @@ kernel/train_eval_sgcn_img_snps.py:511-548 (two forwards, seven loss terms, back
 graph-batch data parallelism the reference does not have (one process per GPU, one RCCL all-reduce of a
 flat fp32 gradient buffer per step).
 """
+import os
 from types import SimpleNamespace
 
 import torch
@@ -252,10 +253,8 @@ class GraphedTrainStep:
     a new batch of identical shape into them.  With ``world_size > 1`` the gradient all-reduce stays
     outside the graphs: [zero_grad .. backward] graph -> RCCL all-reduce -> [Adam] graph.
 
-    The graph plan of the batch is rebuilt every step.  The segmented build (one launch, batches of graphs with
-    <= 1024 nodes / 4096 edges each) is part of the graph; the general radix-sort build (rocPRIM) is launched
-    eagerly, in place, right before the replay — replaying rocPRIM's onesweep sort from inside the full-step graph
-    faulted on this ROCm stack (known issues), while the same launches issued on the stream are fine.
+    The graph plan of the batch is rebuilt every step, inside the graph: all three builders (LDS per graph, tiled
+    counting sort per graph, general LSD radix sort) are hand-written kernels with caller-owned workspace.
 
     Construction runs ``warmup`` eager steps (allocator / library warm-up) on the construction batch; the optimiser
     state (parameters, Adam moments, step count) and every module buffer (BatchNorm running statistics,
@@ -276,7 +275,9 @@ class GraphedTrainStep:
         self.lam, self.hp = lambda_loss, hp
         from . import ops
         self.plan = ops.plan_for(data)                  # static plan tensors: rebuilt in place every step
-        self.plan_in_graph = self.plan.segmented
+        # every plan builder is hand-written and capturable; IGCN_PLAN_EAGER=1 keeps the build outside the graph
+        # (launched eagerly before each replay) for A/B runs
+        self.plan_in_graph = os.environ.get("IGCN_PLAN_EAGER", "0") != "1"
         opt = self.opt
         saved = [t.clone() for t in (opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_count)]
         saved_buf = [(b, b.clone()) for b in model.buffers()]
@@ -369,9 +370,12 @@ class GraphedTrainStep:
                 raise ValueError("graphed step (segmented plan): the new batch must carry ptr / edge_ptr of the "
                                  "same graph count")
             mn, me = getattr(batch, "_max_nodes", None), getattr(batch, "_max_edges", None)
-            if mn is None or me is None or mn > self.plan.SEG_MAX_NODES or me > self.plan.SEG_MAX_EDGES:
-                raise ValueError("graphed step (segmented plan): the new batch exceeds the per-graph limits of the "
-                                 f"LDS build ({self.plan.SEG_MAX_NODES} nodes / {self.plan.SEG_MAX_EDGES} edges)")
+            # LDS build: the kernel's own limits; tiled build: the tile count the workspace was sized for
+            e_lim = self.plan._seg[3] if self.plan._tiled else self.plan.SEG_MAX_EDGES
+            n_lim = self.plan._seg[2] if self.plan._tiled else self.plan.SEG_MAX_NODES
+            if mn is None or me is None or mn > n_lim or me > e_lim:
+                raise ValueError("graphed step (per-graph plan): the new batch exceeds the per-graph sizes the "
+                                 f"captured build was sized for ({n_lim} nodes / {e_lim} edges)")
             if self.plan.nodes_per_graph and int(mn) * (int(bp.numel()) - 1) != self.plan.n_nodes:
                 raise ValueError("graphed step: the captured kernels assume uniform graphs of "
                                  f"{self.plan.nodes_per_graph} nodes")

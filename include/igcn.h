@@ -51,14 +51,28 @@ int igcn_graph_plan_build(int64_t n_nodes, int64_t n_edges, const int64_t* edge_
 /* Same plan for a block-diagonal PyG batch of SMALL graphs, one workgroup per graph, everything in LDS (no
  * device-wide sort): graph g owns nodes [node_ptr[g],node_ptr[g+1]) and edges [edge_ptr[g],edge_ptr[g+1]) (int64
  * device arrays of n_graphs+1 entries, as Batch.from_data_list records them; batch.py:24-123).  Limits: 1024 nodes
- * and 4096 edges per graph (IGCN_ERR_UNSUPPORTED otherwise: use igcn_graph_plan_build).  `status` (device int32,
- * zeroed by the caller) is set non-zero if a graph exceeds the limits or an edge leaves its graph. */
+ * and 4096 edges per graph (IGCN_ERR_UNSUPPORTED otherwise: use igcn_graph_plan_build_tiled / igcn_graph_plan_build).
+ * `status` (device int32, zeroed by the caller) is set non-zero if a graph exceeds the limits or an edge leaves its
+ * graph. */
 int igcn_graph_plan_build_segmented(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* edge_index,
                                     const int64_t* node_ptr, const int64_t* edge_ptr,
                                     int64_t max_nodes_per_graph, int64_t max_edges_per_graph,
                                     int32_t* src32, int32_t* dst32, int32_t* tgt_ptr, int32_t* tgt_perm,
                                     int32_t* src_ptr, int32_t* src_perm, int32_t* loop_edge, int32_t* status,
                                     void* stream);
+
+/* Same plan for a PyG batch whose graphs have at most 1024 nodes and ANY number of edges (the dense 512-ROI graphs of
+ * the stress configuration: 262 144 edges each): a hand-written one-pass stable counting sort per graph over tiles of
+ * 4096 edges (histogram / scan / ranked scatter, three launches for both groupings), the node id inside its graph
+ * being the digit.  Same outputs and `status` convention as the segmented build; workspace:
+ * igcn_graph_plan_tiled_workspace_bytes(n_graphs, max_nodes_per_graph, max_edges_per_graph) bytes. */
+size_t igcn_graph_plan_tiled_workspace_bytes(int n_graphs, int64_t max_nodes_per_graph, int64_t max_edges_per_graph);
+int igcn_graph_plan_build_tiled(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* edge_index,
+                                const int64_t* node_ptr, const int64_t* edge_ptr,
+                                int64_t max_nodes_per_graph, int64_t max_edges_per_graph,
+                                int32_t* src32, int32_t* dst32, int32_t* tgt_ptr, int32_t* tgt_perm,
+                                int32_t* src_ptr, int32_t* src_perm, int32_t* loop_edge, int32_t* status,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* Plan of `copies` disjoint copies of the batch (node g*N+i, edge g*E+k) derived from an existing plan without
  * sorting again; output arrays are sized for copies*N nodes / copies*E edges. */

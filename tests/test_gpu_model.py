@@ -446,8 +446,9 @@ def test_full_model_dense_graphs_vs_oracle(rois, bsz):
 @pytest.mark.parametrize("rois,dense", [(90, False), (72, True)])
 def test_graphed_train_step_matches_eager(rois, dense):
     """GraphedTrainStep (whole step replayed from one hipGraph) against the eager train_step on a twin model, three
-    steps on changing batches.  k=3 graphs take the in-graph segmented plan build; dense 72-ROI graphs (5184 edges
-    per graph) take the radix-sort build that is issued eagerly, in place, before each replay."""
+    steps on changing batches.  k=3 graphs take the LDS plan build, dense 72-ROI graphs (5184 edges per graph) the
+    tiled counting-sort build — both hand-written and captured inside the step graph.  The warm-up steps of the
+    constructor are rolled back, so no state is restored by hand here."""
     import copy
     from igcn_amd import synth
     from igcn_amd.data import Batch
@@ -471,11 +472,10 @@ def test_graphed_train_step_matches_eager(rois, dense):
     static.x.requires_grad_(True)
     snap = {k: v.detach().clone() for k, v in m1.state_dict().items()}
     step = GraphedTrainStep(m1, o1, static, lam, warmup=2)
-    assert step.plan_in_graph == (not dense)
-    # the warm-up steps moved m1: restore parameters, buffers and the optimiser state
-    m1.load_state_dict(snap)
-    for t in (o1.exp_avg, o1.exp_avg_sq, o1.step_count):
-        t.zero_()
+    assert step.plan_in_graph and step.plan._tiled == dense
+    for k, v in m1.state_dict().items():                 # the constructor's warm-up steps left no trace
+        assert torch.equal(v, snap[k]), k
+    assert int(o1.step_count.item()) == 0 and not bool(o1.exp_avg.any())
     for b in batches:
         step.load(b)
         l1 = float(step())
@@ -511,40 +511,51 @@ m1 = SGCN_GCN_IMGSNP(2, 8, a_g, a, pool_dim, 32, "cuda", rois=90, H_0=3, num_cla
                      isSNPsOnly=False).cuda().train()
 for m in (m1, m1.go_network):
     m._dropout_enabled = False
-m2 = copy.deepcopy(m1)
+m2, m3 = copy.deepcopy(m1), copy.deepcopy(m1)
 batches = [Batch.from_data_list(synth.brain_graph_list(6, seed=50 + i, rois=90, tsne_dim=16)).to("cuda")
            for i in range(3)]
 lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
-o1, o2 = FlatAdam(m1.parameters(), lr=1e-3), FlatAdam(m2.parameters(), lr=1e-3)
-static = Batch.from_data_list(synth.brain_graph_list(6, seed=50, rois=90, tsne_dim=16)).to("cuda")
-static.x.requires_grad_(True)
-snap = {k: v.detach().clone() for k, v in m1.state_dict().items()}
-step = GraphedTrainStep(m1, o1, static, lam, warmup=2, distributed=True)
+o1, o2, o3 = (FlatAdam(m.parameters(), lr=1e-3) for m in (m1, m2, m3))
+def static_batch():
+    b = Batch.from_data_list(synth.brain_graph_list(6, seed=50, rois=90, tsne_dim=16)).to("cuda")
+    b.x.requires_grad_(True)
+    return b
+# (1) torch.distributed's RCCL group between two graphs
+step = GraphedTrainStep(m1, o1, static_batch(), lam, warmup=2, distributed=True)
 assert step.g_opt is not None
-m1.load_state_dict(snap)
-for t in (o1.exp_avg, o1.exp_avg_sq, o1.step_count):
-    t.zero_()
+# (2) libigcn's own communicator (igcn_comm_*): the all-reduce captured INSIDE the one step graph
+from igcn_amd.comm import Comm
+comm = Comm()
+step3 = GraphedTrainStep(m3, o3, static_batch(), lam, warmup=2, comm=comm)
+print("comm_in_graph", step3.comm_in_graph)
+assert step3.comm_in_graph and step3.g_opt is None
 for b in batches:
     step.load(b)
+    step3.load(b)
     l1 = float(step())
+    l3 = float(step3())
     l2 = float(train_step(m2, o2, b, lam))
     assert abs(l1 - l2) <= 1e-4 * max(1.0, abs(l2)), (l1, l2)
-for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
-    # Adam normalises: an ELEMENT whose gradient is rounding noise (< 1e-6) moves by up to lr per step in a
-    # direction the noise picks, and the noise depends on buffer alignment (vector vs scalar code paths)
-    d = (p1.detach() - p2.detach()).abs()
-    tol = torch.full_like(d, 2e-4) if p2.grad is None else torch.where(p2.grad.abs() > 1e-6, 2e-4, 3.5e-3)
-    assert bool((d <= tol).all()), (k, float(d.max()))
+    assert abs(l3 - l2) <= 1e-4 * max(1.0, abs(l2)), (l3, l2)
+for ma in (m1, m3):
+    for (k, p1), (_, p2) in zip(ma.named_parameters(), m2.named_parameters()):
+        # Adam normalises: an ELEMENT whose gradient is rounding noise (< 1e-6) moves by up to lr per step in a
+        # direction the noise picks, and the noise depends on buffer alignment (vector vs scalar code paths)
+        d = (p1.detach() - p2.detach()).abs()
+        tol = torch.full_like(d, 2e-4) if p2.grad is None else torch.where(p2.grad.abs() > 1e-6, 2e-4, 3.5e-3)
+        assert bool((d <= tol).all()), (k, float(d.max()))
+comm.close()
 torch.distributed.destroy_process_group()
 print("DIST-OK")
 """
 
 
 def test_graphed_step_with_live_rccl_group():
-    """The N>1 control flow of GraphedTrainStep ([forward..backward, pack] graph -> all-reduce on the flat gradient ->
-    [Adam] graph, captured in thread-local mode while the process group's threads are alive) on a single-rank RCCL
-    group — the part of the multi-GPU path a one-GPU box can run — against the eager step of a twin model.  In a
-    child process, so that the process group does not outlive the test."""
+    """The N>1 control flow of GraphedTrainStep on a single-rank RCCL group — the part of the multi-GPU path a one-GPU
+    box can run — against the eager step of a twin model: (1) [forward..backward, pack] graph -> torch.distributed
+    all-reduce on the flat gradient -> [Adam] graph, captured in thread-local mode while the process group's threads
+    are alive; (2) libigcn's own communicator (igcn_comm_*), its all-reduce captured inside ONE step graph.  In a child
+    process, so that the process group does not outlive the test."""
     import os
     import subprocess
     import sys

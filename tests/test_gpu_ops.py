@@ -49,7 +49,8 @@ def _rand_graph(rng, n, e, loops=True, multi_loops=False, isolated=True):
 
 # ------------------------------------------------------------------------------------------------ plan
 @pytest.mark.parametrize("n,e,seed", [(7, 0, 0), (90, 270, 1), (1, 5, 2), (1000, 20000, 3), (23040, 69120, 4),
-                                       (4096, 300000, 5)])
+                                       (4096, 300000, 5), (2, 9000, 6), (1025, 4097, 7), (1 << 21, 50000, 8),
+                                       (1500000, 700000, 9)])     # 1, 2 and 3 LSD passes of the hand-written sort
 def test_graph_plan_bit_exact(ops, n, e, seed):
     rng = np.random.default_rng(seed)
     ei = torch.from_numpy(rng.integers(0, n, (2, e))).long()
@@ -552,6 +553,53 @@ def test_segmented_plan_ragged_graphs_and_loops(ops):
     ref = ops.GraphPlan(batch.edge_index, batch.x.shape[0])
     for name in ("tgt_ptr", "tgt_perm", "src_ptr", "src_perm", "loop_edge"):
         assert torch.equal(getattr(seg, name), getattr(ref, name)), name
+
+
+@pytest.mark.parametrize("sizes,edges", [((512, 512, 512), (262144, 262144, 262144)),     # dense stress-shape graphs
+                                         ((300, 1024, 5, 77), (9000, 40000, 0, 4097)),     # ragged, an empty graph
+                                         ((90, 90), (270, 4097))])
+def test_tiled_plan_is_bit_identical_to_a_stable_sort(ops, sizes, edges):
+    """igcn_graph_plan_build_tiled (graphs with more than 4096 edges: one-pass counting sort per graph) against
+    numpy's stable argsort and the general multi-pass build."""
+    from igcn_amd.data import Batch, Data
+    rng = np.random.default_rng(11)
+    graphs = []
+    for n, e in zip(sizes, edges):
+        if e == n * n:                                              # all pairs in row-major order, like dense_graph()
+            ei = torch.stack([torch.arange(n).repeat_interleave(n), torch.arange(n).repeat(n)])
+        else:
+            ei = torch.from_numpy(rng.integers(0, n, (2, e))).long()
+        graphs.append(Data(x=torch.zeros(n, 3), edge_index=ei, edge_attr=torch.ones(ei.shape[1])))
+    batch = Batch.from_data_list(graphs).to("cuda")
+    plan = ops.plan_for(batch)
+    assert plan._tiled
+    plan.check()
+    ei = batch.edge_index.cpu().numpy()
+    n = int(batch.x.shape[0])
+    for key, ptr_t, perm_t in ((ei[1], plan.tgt_ptr, plan.tgt_perm), (ei[0], plan.src_ptr, plan.src_perm)):
+        perm = np.argsort(key, kind="stable").astype(np.int32)
+        assert np.array_equal(perm_t.cpu().numpy(), perm)
+        assert np.array_equal(ptr_t.cpu().numpy(), np.searchsorted(key[perm], np.arange(n + 1)).astype(np.int32))
+    ref = ops.GraphPlan(batch.edge_index, n)                        # general LSD build
+    for name in ("src32", "dst32", "tgt_ptr", "tgt_perm", "src_ptr", "src_perm", "loop_edge"):
+        assert torch.equal(getattr(plan, name), getattr(ref, name)), name
+    # rebuilt in place inside a hipGraph: same result after a replay on a permuted batch of the same sizes
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.rebuild(batch.edge_index)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(g):
+        plan.rebuild(batch.edge_index)
+        ref.rebuild(batch.edge_index)
+    flipped = batch.edge_index.flip(0).contiguous()                 # still block diagonal, same per-graph counts
+    batch.edge_index.copy_(flipped)
+    g.replay()
+    torch.cuda.synchronize()
+    key = flipped[1].cpu().numpy()
+    assert np.array_equal(plan.tgt_perm.cpu().numpy(), np.argsort(key, kind="stable").astype(np.int32))
+    assert torch.equal(plan.tgt_perm, ref.tgt_perm) and torch.equal(plan.src_ptr, ref.src_ptr)
 
 
 @pytest.mark.parametrize("hint", [0, 64])
