@@ -1,19 +1,38 @@
 #!/usr/bin/env python3
 """bench.py — graphs/s of the full IG-GCN train step (SGCN over 90-ROI brain graphs + GO-SNP network).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full|sgcn|stress]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2]): full SGCN_GCN_IMGSNP (L=2, hidden=16, R=90, H0=3,
+Default workload (BASELINE.json configs[2]): full SGCN_GCN_IMGSNP (L=2, hidden=16, R=90, H0=3,
 cross-attention fusion, 3 classes, 3 regression targets), synthetic GO DAG N=3000 pool [1800,800,300,99,1],
 256 graphs per GPU (weak scaling), fp32.  One step = kernel/train_eval_sgcn_img_snps.py:515-547: graph-plan
 build, forward, masked forward, 7 loss terms, backward, (all-reduce), Adam — on inputs already resident
 in HBM.  Prints ONE JSON line on rank 0.
+
+``--workload stress`` = BASELINE configs[4]: 512-ROI dense graphs + 10k-node GO DAG, 32 graphs per GPU, dense
+feature transforms with bf16 operands on the matrix cores (fp32 accumulation); same JSON contract.
+
+Roofline fields (rank 0, N=1):
+  roofline        the GCN scatter-aggregate kernel AS THE STEP LAUNCHES IT.  ``us_per_launch`` is the kernel's average
+                  duration inside the train step, read from a ``rocprofv3 --kernel-trace --stats`` run of this very
+                  command made by this invocation (a child process; the CSV is the one committed under profiles/).
+                  ``achieved`` = SURVEY §8d algorithmic bytes / that duration; ``frac`` = achieved / 8 TB/s.
+                  Beside it: the bytes the kernel itself moves (8-byte edge records instead of int64 pairs),
+                  a hot back-to-back replay and a COLD replay rotating through > 256 MiB of distinct buffers (both
+                  timed with HIP events on the launch stream), and the launch floor of the same grid.
+  roofline_mfma   dense feature transforms (lin1, K|V projection) against the MFMA peak of their operand type.
+  cpu_baseline    the oracle (CPU restatement of the reference) on this box's host cores, bounded sample.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -29,29 +48,25 @@ GRAPHS_PER_GPU = 256
 POOL = (1800, 800, 300, 99, 1)
 LAYERS, HIDDEN, ROIS = 2, 16, 90
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# HBM bytes per launch from the rocprofv3 PMC passes of tools/roofline_kernel.py (FETCH_SIZE x2 gfx950 correction,
-# calibrated on a 256 MiB float4 copy; WRITE_SIZE x1): profiles/r01_pmc/scatter_aggregate_traffic.json
-PMC_TRAFFIC = {"bench": 10010260, "stress": 77631040}
-# average duration of the same kernels in the committed rocprofv3 --kernel-trace --stats summary of this command
-# (profiles/r01_final_default_bench/kernel_stats.csv).  The profiler adds ~1-2 us to every dispatch and sees the
-# in-step launches with cold caches, which matters for the 3-us kernel and not for the 36-us one.
-ROCPROF_AVG_US = {"bench": 4.47, "stress": 35.8}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}     # dense peaks, MI355X_MICROARCH.md § Matrix cores
+INFINITY_CACHE_BYTES = 256 << 20
 
-
-# --workload: the default is the configuration the metric is quoted on; the other two are side measurements
+# --workload: the default is the configuration the metric is quoted on
 WORKLOADS = {
-    "full": dict(rois=ROIS, pool=POOL, graphs=GRAPHS_PER_GPU, dense=False,
+    "full": dict(rois=ROIS, pool=POOL, graphs=GRAPHS_PER_GPU, dense=False, bf16=False,
                  name="configs[2]: full sgcn_img_snp train step (2 fwd + 7 losses + bwd + Adam), "
                       "90-ROI k=3 brain graphs + 3000-node GO-SNP DAG"),
-    "sgcn": dict(rois=ROIS, pool=None, graphs=GRAPHS_PER_GPU, dense=False,
+    "sgcn": dict(rois=ROIS, pool=None, graphs=GRAPHS_PER_GPU, dense=False, bf16=False,
                  name="configs[1]: SGCN-only train step (kernel/train_eval_sgcn.py:296-314), 90-ROI k=3 brain graphs"),
-    "stress": dict(rois=512, pool=(6000, 2700, 1000, 299, 1), graphs=32, dense=True,
-                   name="configs[4] shape in fp32: full train step, 512-ROI dense brain graphs + 10k-node GO DAG"),
+    "stress": dict(rois=512, pool=(6000, 2700, 1000, 299, 1), graphs=32, dense=True, bf16=True,
+                   name="configs[4]: full train step, 512-ROI dense brain graphs + 10k-node GO DAG, bf16 feature "
+                        "transforms on MFMA (fp32 accumulate)"),
 }
 
 
-def build_model(device, wl=None):
+def build_model(device, wl=None, bf16=None):
     wl = wl or WORKLOADS["full"]
+    bf16 = wl["bf16"] if bf16 is None else bf16
     torch.manual_seed(1000)                                   # main.py:102 seed
     if wl["pool"] is None:
         from igcn_amd.sgcn import SGCN_GCN
@@ -63,91 +78,226 @@ def build_model(device, wl=None):
     a_g, a = synth.go_sparse_inputs(go_snps, adj, device)
     model = SGCN_GCN_IMGSNP(LAYERS, HIDDEN, a_g, a, pool_dim, 32, device, rois=wl["rois"], H_0=3, num_classes=3,
                             isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
-                            isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False).to(device)
+                            isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False,
+                            bf16_transforms=bf16).to(device)
     model.train()
     return model, (go_snps, adj, pool_dim)
 
 
-def _time_propagate(plan, ew, n, f, device, iters, nodes_per_graph=0):
-    """Average device time (us) of igcn_gcn_propagate_fwd: `iters` back-to-back launches captured in one hipGraph
-    and bracketed by two HIP events on the launch stream."""
+# ---------------------------------------------------------------------------------------------------------------
+# in-step kernel durations: rocprofv3 --kernel-trace --stats of this command, made by this invocation
+# ---------------------------------------------------------------------------------------------------------------
+def instep_profile(workload, bf16, steps=12, timeout=420):
+    """Run ``bench.py --inner-profile`` (the same train step, nothing else) under rocprofv3 in a CHILD process and
+    return ({kernel name: (calls, average us, total us)}, steps, path of the stats CSV) — or None when the profiler
+    is not available.  The profiler goes around the python program itself (no env/bash hop behind ``--``)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    keep = os.environ.get("IGCN_BENCH_PROFILE_DIR")
+    out = keep or tempfile.mkdtemp(prefix="igcn_prof_")
+    os.makedirs(out, exist_ok=True)
+    cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--inner-profile", "--workload", workload, "--steps", str(steps),
+           "--warmup", "3", "--bf16", "1" if bf16 else "0"]
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+        files = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            print(f"[bench] rocprofv3 child failed (rc={r.returncode}): {r.stderr[-400:]}", file=sys.stderr)
+            return None
+        inner = None
+        for line in r.stdout.splitlines():
+            if line.startswith("{") and "inner_steps" in line:
+                inner = json.loads(line)
+        stats = {}
+        with open(files[0]) as fh:
+            for row in csv.DictReader(fh):
+                stats[row["Name"]] = (int(row["Calls"]), float(row["AverageNs"]) / 1e3, float(row["TotalDurationNs"]) / 1e3)
+        if keep:
+            shutil.copy(files[0], os.path.join(out, f"{workload}_kernel_stats.csv"))
+        return stats, (inner or {}).get("inner_steps", steps + 3), files[0]
+    except Exception as exc:                       # noqa: BLE001 — the profile is evidence, not the metric
+        print(f"[bench] rocprofv3 child failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+        return None
+    finally:
+        if not keep:
+            shutil.rmtree(out, ignore_errors=True)
+
+
+def _pick(stats, prefix):
+    """(name, calls, avg us, total us) of the kernels whose demangled name starts with ``prefix`` (largest total)."""
+    best = None
+    for name, (calls, avg, tot) in (stats or {}).items():
+        n = name[5:] if name.startswith("void ") else name
+        if n.startswith(prefix) and (best is None or tot > best[3]):
+            best = (n.split("(")[0], calls, avg, tot)
+    return best
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the scatter-aggregate kernel: replay timings with HIP events on the launch stream
+# ---------------------------------------------------------------------------------------------------------------
+def _propagate_args(plan, coef, h, bias, out, f, npg):
+    n = h.shape[0]
+    return (n, plan.n_edges, f, npg, h.data_ptr(), f, coef[2].data_ptr(), coef[1].data_ptr(), bias.data_ptr(),
+            plan.tgt_ptr.data_ptr(), out.data_ptr(), f, 1)
+
+
+def _time_graph(launch_all, reps=3):
+    """Average device time (us) per replay of a hipGraph made of ``launch_all()``, between two HIP events on the
+    launch stream (the current torch stream: igcn kernels are launched on it)."""
+    launch_all()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):      # a process group's threads may be alive
+        launch_all()
+    g.replay()
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e3
+        best = t if best is None else min(best, t)
+    return best
+
+
+def _propagate_timings(plan, ew, n, f, device, npg, hot_iters):
+    """(hot us per launch, cold us per launch, sets used for the cold rotation)."""
     from igcn_amd import ops
     from igcn_amd._lib import call, stream_ptr
     coef = ops.GcnNorm.apply(ew, plan)
-    h = torch.randn(n, f, device=device)
     bias = torch.zeros(f, device=device)
+    h = torch.randn(n, f, device=device)
     out = torch.empty_like(h)
-    args = (n, plan.n_edges, f, nodes_per_graph, h.data_ptr(), f, coef[2].data_ptr(), coef[1].data_ptr(),
-            bias.data_ptr(), plan.tgt_ptr.data_ptr(), out.data_ptr(), f, 1)
-    for _ in range(5):
-        call("igcn_gcn_propagate_fwd", *args, stream_ptr())
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):      # a process group's threads may be alive
-        for _ in range(iters):
-            call("igcn_gcn_propagate_fwd", *args, stream_ptr())
-    g.replay()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    g.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / iters
+    args = _propagate_args(plan, coef, h, bias, out, f, npg)
+    hot = _time_graph(lambda: [call("igcn_gcn_propagate_fwd", *args, stream_ptr()) for _ in range(hot_iters)]) / hot_iters
+    # cold: every launch reads its own copy of the record stream and of h and writes its own out; the copies add up
+    # to more than the 256 MiB Infinity Cache, so a buffer is evicted before its turn comes again
+    per_set = coef[2].numel() * 4 + 2 * h.numel() * 4
+    sets = max(3, int(1.5 * INFINITY_CACHE_BYTES / per_set) + 1)
+    rec = [coef[2].clone() for _ in range(sets)]
+    hs = [torch.randn(n, f, device=device) for _ in range(sets)]
+    outs = [torch.empty(n, f, device=device) for _ in range(sets)]
+    argl = []
+    for k in range(sets):
+        c = (coef[0], coef[1], rec[k], coef[3])
+        argl.append(_propagate_args(plan, c, hs[k], bias, outs[k], f, npg))
+    cold = _time_graph(lambda: [call("igcn_gcn_propagate_fwd", *a, stream_ptr()) for a in argl]) / sets
+    return hot, cold, sets
 
 
-def scatter_roofline(data, device, iters=200):
-    """Live roofline of the GCN scatter-aggregate kernel (igcn_gcn_propagate_fwd, F=16) exactly as the train step
-    launches it: both passes batched = 2 copies of the batch's graphs.  Algorithmic bytes = (20*E' + 8*R*F) per
-    graph (int64 endpoints + fp32 coefficient per edge, each feature row read and written once)."""
+def _floor_timings(n, f, device, iters, dense=False):
+    """Launch floor of the scatter-aggregate grid: an EMPTY kernel of the same grid and one that only WRITES the
+    output rows (igcn_launch_floor), per launch, hot replay."""
+    from igcn_amd._lib import call, stream_ptr
+    out = torch.empty(n, f, device=device)
+    res = {}
+    for mode, key in ((0, "empty_grid_us"), (1, "write_only_us")):
+        t = _time_graph(lambda: [call("igcn_launch_floor", n, f, int(dense), mode, out.data_ptr(), stream_ptr())
+                                 for _ in range(iters)]) / iters
+        res[key] = round(t, 3)
+    return res
+
+
+def scatter_roofline(data, device, wl, stats, hot_iters=200):
+    """Roofline of igcn_gcn_propagate_fwd (F=16) exactly as the train step launches it: both passes batched = 2
+    copies of the batch's graphs.  SURVEY §8d algorithmic bytes = (20*E' + 8*R*F) per graph (int64 endpoints + fp32
+    coefficient per edge, each feature row read and written once)."""
     from igcn_amd import ops
+    rois = wl["rois"]
     plan = ops.plan_for(data).replicate(2)
     n, f = 2 * data.x.shape[0], HIDDEN
-    us = _time_propagate(plan, torch.cat([data.edge_attr, data.edge_attr]), n, f, device, iters)
-    n_graphs = n // ROIS
-    e_prime = plan.n_edges // n_graphs          # GDC graphs store their self-loops: E' = E
-    alg_bytes = n_graphs * (20 * e_prime + 8 * ROIS * f)
-    gbs = alg_bytes / (us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "k_gcn_propagate_fwd_q<4>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": PMC_TRAFFIC["bench"] if (n_graphs, e_prime, f) == (512, 270, 16) else None,
-            "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
-            "rocprof_avg_us": ROCPROF_AVG_US["bench"] if (n_graphs, e_prime, f) == (512, 270, 16) else None,
-            "launch": f"{n_graphs} graphs x {e_prime} edges (both passes of a step), F={f}"}
-
-
-def scatter_roofline_stress(device, n_graphs=32, rois=512, f=16, iters=20):
-    """The same kernel at the stress shape of BASELINE.json configs[4] (512-ROI dense graphs, E' = R^2 per graph):
-    the launch moves ~170 MB, so it is bandwidth- rather than latency-limited."""
-    import numpy as np
-    from igcn_amd import ops
-    rng = np.random.default_rng(0)
-    r = torch.arange(rois).repeat_interleave(rois)
-    c = torch.arange(rois).repeat(rois)
-    ei = torch.cat([torch.stack([r, c]) + g * rois for g in range(n_graphs)], dim=1).to(device)
-    w = torch.from_numpy(rng.random(ei.shape[1]).astype(np.float32) / rois).to(device)
-    n = n_graphs * rois
-    plan = ops.GraphPlan(ei, n)
-    us = _time_propagate(plan, w, n, f, device, iters, nodes_per_graph=rois)
-    e_prime = rois * rois
+    n_graphs = n // rois
+    e_prime = plan.n_edges // n_graphs                       # GDC / dense graphs store their self-loops: E' = E
     alg_bytes = n_graphs * (20 * e_prime + 8 * rois * f)
+    # what the kernel itself moves: one 8-byte (neighbour, coefficient) record per edge, the row pointers and the
+    # self-loop coefficient per node, each feature row in and out once
+    kern_bytes = n_graphs * (8 * e_prime + 4 * (rois + 1) + 4 * rois + 8 * rois * f)
+    dense = plan.n_edges >= 16 * n
+    hot, cold, sets = _propagate_timings(plan, torch.cat([data.edge_attr, data.edge_attr]), n, f, device,
+                                         rois if dense else 0, hot_iters if not dense else 20)
+    prefix = "k_gcn_propagate_fwd"
+    picked = _pick(stats[0], prefix) if stats else None
+    us = picked[2] if picked else cold
+    src = ("rocprofv3 --kernel-trace --stats of this command (child process): average over the in-step launches"
+           if picked else "HIP events, cold replay (rocprofv3 unavailable)")
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "k_gcn_propagate_fwd_wide<4>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": PMC_TRAFFIC["stress"] if (n_graphs, rois, f) == (32, 512, 16) else None,
-            "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
-            "rocprof_avg_us": ROCPROF_AVG_US["stress"] if (n_graphs, rois, f) == (32, 512, 16) else None,
-            "launch": f"{n_graphs} dense graphs x {rois} ROIs ({e_prime} edges each), F={f}"}
+    res = {"bound": "hbm", "kernel": picked[0] if picked else prefix, "achieved": round(gbs, 1),
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+           "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3), "timing": src,
+           "launches_profiled": picked[1] if picked else 0,
+           "kernel_bytes_per_launch": kern_bytes,
+           "frac_kernel_bytes": round(kern_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+           "replay_hot_us": round(hot, 3), "frac_replay_hot": round(alg_bytes / (hot * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+           "replay_cold_us": round(cold, 3),
+           "frac_replay_cold": round(alg_bytes / (cold * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+           "cold_rotation": f"{sets} buffer sets = {sets * (kern_bytes) / 2**20:.0f} MiB > 256 MiB Infinity Cache",
+           "launch": f"{n_graphs} graphs x {e_prime} edges (both passes of a step), F={f}"}
+    try:
+        res["floor"] = _floor_timings(n, f, device, hot_iters if not dense else 50, dense)
+        res["floor"]["note"] = ("same grid, hot replay: an empty kernel and one that only writes the output rows; "
+                                "frac_ceiling = alg bytes / write-only time / peak")
+        res["floor"]["frac_ceiling"] = round(alg_bytes / (res["floor"]["write_only_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    except Exception as exc:                       # noqa: BLE001
+        res["floor"] = {"error": f"{type(exc).__name__}: {exc}"}
+    traffic = os.environ.get("IGCN_BENCH_PMC_JSON")        # written by tools/pmc_traffic.py from separate --pmc passes
+    if traffic and os.path.exists(traffic):
+        with open(traffic) as fh:
+            t = json.load(fh).get(res["kernel"].split("<")[0])
+        res["traffic"] = t
+    return res
 
 
-def cpu_baseline(go, seconds=20.0):
+def mfma_roofline(model, wl, device, stats, bf16):
+    """Dense feature transforms against the matrix-core peak of their operand type: lin1 (the widest product of the
+    heads) and the key|value projection of the cross-attention — hot replay, HIP events on the launch stream — plus the
+    in-step total of the GEMM kernels from the rocprofv3 child."""
+    from igcn_amd import ops
+    kind = "bf16" if bf16 else "f32"
+    peak = MFMA_PEAK_TFLOPS[kind]
+    out = {"bound": "mfma", "operands": kind, "peak": peak, "unit": "TFLOP/s", "products": []}
+    g = 2 * wl["graphs"]
+    d = LAYERS * HIDDEN
+    n_top = sum(wl["pool"][2:])
+    shapes = [("lin1", g, 64, wl["rois"] * d + 32), ("kv_proj", g * n_top, 2 * d, d)]
+    for name, m, n, k in shapes:
+        a = torch.randn(m, k, device=device)
+        b = torch.randn(n, k, device=device)
+        bias = torch.zeros(n, device=device)
+        iters = 50
+        us = _time_graph(lambda: [ops.gemm_nt(a, b, bias, 1, bf16=bf16) for _ in range(iters)]) / iters
+        tf = 2.0 * m * n * k / (us * 1e-6) / 1e12
+        byt = 4.0 * (m * k + n * k + m * n)
+        out["products"].append({"name": name, "M": m, "N": n, "K": k, "us": round(us, 2), "achieved": round(tf, 2),
+                                "frac": round(tf / peak, 4),
+                                "frac_hbm": round(byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
+    best = max(out["products"], key=lambda p: p["frac"])
+    out["achieved"], out["frac"], out["kernel"] = best["achieved"], best["frac"], \
+        ("k_gemm_bf16" if bf16 else "k_gemm_f32") + f" ({best['name']})"
+    if stats:
+        tot = sum(t for nme, (c, a_, t) in stats[0].items() if "k_gemm_" in nme and "reduce" not in nme)
+        red = sum(t for nme, (c, a_, t) in stats[0].items() if "reduce" in nme)
+        out["instep_gemm_us_per_step"] = round(tot / stats[1], 1)
+        out["instep_reduction_kernels_us_per_step"] = round(red / stats[1], 1)
+    return out
+
+
+def cpu_baseline(go, wl, seconds=20.0):
     """The oracle (CPU restatement, faithful mode: per-sample sparse loop) timed on this box's host cores on
-    a bounded sample of the same workload: B=32 graphs per step."""
+    a bounded sample of the same workload."""
     from types import SimpleNamespace
     from oracle import go_network as OG, sgcn_img_snp as OS
     go_snps, adj, pool_dim = go
+    pool, rois = wl["pool"], wl["rois"]
     a_g, a = synth.go_sparse_inputs(go_snps, adj)
-    idx = OG.go_index_sets(a_g, a, list(POOL), 2)
-    shapes = dict(OS.sgcn_param_shapes(LAYERS, HIDDEN, rois=ROIS))
+    idx = OG.go_index_sets(a_g, a, list(pool), 2)
+    shapes = dict(OS.sgcn_param_shapes(LAYERS, HIDDEN, rois=rois))
     shapes.update({"go_network." + k: v for k, v in OG.go_param_shapes(idx, l_dim=32, d_att=LAYERS * HIDDEN).items()})
     gen = torch.Generator().manual_seed(0)
     sd = {}
@@ -163,9 +313,9 @@ def cpu_baseline(go, seconds=20.0):
         else:
             sd[k] = (torch.rand(s, generator=gen) * 2 - 1) / max(1.0, float(s[-1] if len(s) > 1 else s[0])) ** 0.5
     sd = OS.make_leaf_state(sd)
-    cfg = SimpleNamespace(num_layers=LAYERS, rois=ROIS, image_only=False, rbf_gamma=0.01)
-    b = 32
-    data = Batch.from_data_list(synth.brain_graph_list(b, seed=1000, rois=ROIS, tsne_dim=90))
+    cfg = SimpleNamespace(num_layers=LAYERS, rois=rois, image_only=False, rbf_gamma=0.01)
+    b = 32 if not wl["dense"] else 4
+    data = Batch.from_data_list(synth.brain_graph_list(b, seed=1000, rois=rois, tsne_dim=90, dense=wl["dense"]))
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     opt = None
     times = []
@@ -179,7 +329,7 @@ def cpu_baseline(go, seconds=20.0):
     times = sorted(times[1:]) if len(times) > 1 else times
     med = times[len(times) // 2]
     return {"value": round(b / med, 2), "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} train steps of B={b} graphs (same model/GO DAG), median; oracle faithful mode"}
+            "sample": f"{len(times)} train steps of B={b} graphs (same model/GO DAG, fp32), median; oracle faithful mode"}
 
 
 def main():
@@ -188,10 +338,15 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the roofline measurements (and the profiler child)")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay of the step")
-    ap.add_argument("--no-stress", action="store_true", help="skip the stress-shape roofline measurement")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="full",
-                    help="full = BASELINE configs[2] (the metric); sgcn / stress are side measurements")
+                    help="full = BASELINE configs[2] (the metric); stress = configs[4]; sgcn = configs[1]")
+    ap.add_argument("--bf16", choices=["auto", "0", "1"], default="auto",
+                    help="dense feature transforms with bf16 operands (auto: the workload's own setting)")
+    ap.add_argument("--rotate", type=int, default=0,
+                    help="time GraphedTrainStep.load + replay over this many distinct device-resident batches")
+    ap.add_argument("--inner-profile", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,8 +362,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    # IGCN_BENCH_FORCE_DIST=1 with one rank: an RCCL process group of size 1 and the N>1 control flow (two graphs
-    # around the all-reduce) on a one-GPU box
+    # IGCN_BENCH_FORCE_DIST=1 with one rank: an RCCL process group of size 1 and the N>1 control flow on a one-GPU box
     force_dist = world == 1 and os.environ.get("IGCN_BENCH_FORCE_DIST", "0") == "1"
     if force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -227,8 +381,9 @@ def main():
     _lib.load()                                   # fail loudly when the HIP library is missing
 
     wl = WORKLOADS[args.workload]
+    bf16 = wl["bf16"] if args.bf16 == "auto" else args.bf16 == "1"
     per_gpu = wl["graphs"]
-    model, go = build_model(device, wl)
+    model, go = build_model(device, wl, bf16)
     opt = FlatAdam(model.parameters(), lr=1e-3)
     if world > 1:                                 # identical replicas
         torch.distributed.broadcast(opt.flat, 0)
@@ -236,16 +391,42 @@ def main():
     data = Batch.from_data_list(graphs).to(device)
     data.x.requires_grad_(True)
 
+    # gradient exchange: libigcn's own RCCL communicator (igcn_comm_*: all-reduce on the launch stream, captured into
+    # the step graph), verified against torch.distributed once; any failure falls back to torch.distributed's group
+    comm, exchange = None, "none"
+    dist_on = world > 1 or force_dist
+    if dist_on and not rehearsal and os.environ.get("IGCN_BENCH_TORCH_ALLREDUCE", "0") != "1":
+        try:
+            from igcn_amd.comm import Comm
+            comm = Comm()
+            probe = torch.arange(1024, dtype=torch.float32, device=device) * (rank + 1)
+            want = probe.clone()
+            torch.distributed.all_reduce(want)
+            comm.all_reduce_(probe)
+            torch.cuda.synchronize()
+            if not torch.equal(probe, want):
+                raise RuntimeError("igcn_comm all-reduce disagrees with torch.distributed")
+            exchange = "igcn_comm (RCCL via the C ABI)"
+        except Exception as exc:                  # noqa: BLE001
+            print(f"[bench] igcn_comm unavailable ({type(exc).__name__}: {exc}); using torch.distributed",
+                  file=sys.stderr)
+            comm = None
+    if dist_on and comm is None:
+        exchange = "torch.distributed all_reduce (%s)" % torch.distributed.get_backend()
+
     def eager_step():
         data._igcn_plan = None                    # the plan is per batch: rebuild it inside every step
-        return train_step(model, opt, data, world_size=world)
+        return train_step(model, opt, data, world_size=world, comm=comm)
 
     launch = "eager"
     step = eager_step
+    gstep = None
     if not args.eager:
         try:
-            step = GraphedTrainStep(model, opt, data, world_size=world, distributed=world > 1 or force_dist)
-            launch = "hipGraph replay"                  # the whole step (N>1: two graphs around the all-reduce)
+            gstep = step = GraphedTrainStep(model, opt, data, world_size=world, distributed=dist_on, comm=comm)
+            launch = "hipGraph replay"
+            if dist_on:
+                launch += " (all-reduce inside the graph)" if gstep.comm_in_graph else " (two graphs around the all-reduce)"
         except Exception as exc:                  # noqa: BLE001 — a capture refused by the runtime must not sink the run
             print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running the eager step",
                   file=sys.stderr)
@@ -273,29 +454,54 @@ def main():
         print("non-finite loss", file=sys.stderr)
         sys.exit(3)
 
+    if args.inner_profile:                        # the child under rocprofv3: the train step and nothing else
+        print(json.dumps({"inner_steps": args.steps + args.warmup + (3 if gstep is not None else 0),
+                          "ms_per_step": round(dt / args.steps * 1e3, 3)}))
+        return
+
     if rank == 0:
         total_graphs = per_gpu * world * args.steps
         res = {
             "metric": "graphs/s train step (90-ROI brain + GO-SNP)", "value": round(total_graphs / dt, 1),
             "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if (bf16 and wl["pool"] is not None) else "f32", "data": "synthetic",
             "config": {"workload": wl["name"],
                        "graphs_per_gpu": per_gpu, "global_batch": per_gpu * world,
                        "layers": LAYERS, "hidden": HIDDEN, "rois": wl["rois"],
                        "go_nodes": sum(wl["pool"]) if wl["pool"] else 0,
-                       "parallelism": f"dp{world}", "launch": launch},
+                       "parallelism": f"dp{world}", "launch": launch, "gradient_exchange": exchange,
+                       "rccl_world_size": torch.distributed.get_world_size() if dist_on else 1},
             "loss": round(float(loss), 6),
         }
-        if args.workload == "full":
-            res["roofline"] = scatter_roofline(data, device)
-            if world == 1 and not args.no_stress:
-                res["roofline_stress"] = scatter_roofline_stress(device)
-            if world == 1 and not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(go)
+        if args.rotate > 1 and gstep is not None:
+            # hand-over of NEW batches: GraphedTrainStep.load (device-to-device copies into the static inputs) + replay
+            pool_b = [Batch.from_data_list(synth.brain_graph_list(per_gpu, seed=2000 + i, rois=wl["rois"], tsne_dim=90,
+                                                                  dense=wl["dense"])).to(device)
+                      for i in range(args.rotate)]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                gstep.load(pool_b[i % args.rotate])
+                gstep()
+            torch.cuda.synchronize()
+            res["rotating_batches"] = {"batches": args.rotate,
+                                       "ms_per_step_load_plus_replay": round((time.perf_counter() - t1) / args.steps * 1e3, 3)}
+        if wl["pool"] is not None and world == 1 and not args.no_roofline:
+            stats = instep_profile(args.workload, bf16)
+            res["roofline"] = scatter_roofline(data, device, wl, stats)
+            res["roofline_mfma"] = mfma_roofline(model, wl, device, stats, bf16)
+            if stats:
+                res["profile"] = {"steps_profiled": stats[1],
+                                  "kernel_us_per_step": round(sum(t for _, _, t in stats[0].values()) / stats[1], 1),
+                                  "launches_per_step": round(sum(c for c, _, _ in stats[0].values()) / stats[1], 1)}
+        if wl["pool"] is not None and world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(go, wl)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()
+    if comm is not None:
+        comm.close()
     if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
 

@@ -30,7 +30,7 @@ SIGNATURES = {
     "igcn_gcn_norm_bwd": (I, [L, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_gcn_propagate_fwd": (I, [L, L, I, I, P, L, P, P, P, P, P, L, I, P]),
     "igcn_gcn_propagate_bwd_scratch_floats": (Z, [L, I]),
-    "igcn_gcn_propagate_bwd": (I, [L, L, I, P, L, P, L, I, P, L, P, P, P, P, P, P, L, P, I, P, P, P, P]),
+    "igcn_gcn_propagate_bwd": (I, [L, L, I, I, P, L, P, L, I, P, L, P, P, P, P, P, P, L, P, I, P, P, P, P]),
     "igcn_small_linear_bwd_scratch_floats": (Z, [L, I, I]),
     "igcn_small_linear_fwd": (I, [L, I, I, P, P, P, P, P]),
     "igcn_small_linear_bwd": (I, [L, I, I, P, P, P, P, P, P, P]),
@@ -39,12 +39,14 @@ SIGNATURES = {
     "igcn_head_inputs_fwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "igcn_head_inputs_bwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
     "igcn_concat_cols": (I, [L, I, I, P, P, P]),
+    "igcn_launch_floor": (I, [L, I, I, I, P, P]),
     "igcn_graph_pool_fwd": (I, [L, I, I, P, P, P, P]),
     "igcn_graph_pool_bwd": (I, [L, I, I, P, P, P, P]),
     "igcn_bias_grad_scratch_floats": (Z, [L, I]),
     "igcn_bias_grad": (I, [L, I, P, P, P, P, P, P]),
     "igcn_gemm_f32_split_k": (I, [L, L, L]),
     "igcn_gemm_f32": (I, [L, L, L, P, L, L, P, L, L, P, P, L, I, I, P, P]),
+    "igcn_gemm_bf16": (I, [L, L, L, P, L, L, P, L, L, P, P, L, I, I, P, P]),
     "igcn_gemm_f32_batched_sum": (I, [L, L, L, I, P, L, L, L, P, L, L, L, P, L, P, P]),
     "igcn_node_linear_bn_scratch_floats": (Z, [I, I, I]),
     "igcn_node_linear_bn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, I, F, F, P, P, P, P, P]),
@@ -79,6 +81,9 @@ SIGNATURES = {
     "igcn_adam_step": (I, [L, P, P, P, P, P, F, F, F, F, F, P]),
     "igcn_adam_step_multi": (I, [I, P, P, P, F, F, F, F, F, P]),
     "igcn_pack_grads": (I, [I, P, P, P, P, P]),
+    "igcn_reduce_defer": (I, [I]),
+    "igcn_reduce_pending": (I, []),
+    "igcn_reduce_flush": (I, [P]),
     "igcn_comm_unique_id_bytes": (I, []),
     "igcn_comm_get_unique_id": (I, [P]),
     "igcn_comm_init": (I, [I, I, P, P]),

@@ -162,6 +162,124 @@ k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t
   }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// bf16 feature transforms (BASELINE configs[4]: "bf16 feature transforms on CDNA4 MFMA"): the same tiling with the
+// operands rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) while they are staged into LDS, products on
+// v_mfma_f32_16x16x32_bf16 (16x the rate of the fp32 matrix instruction), accumulation and output in fp32.
+// Activations and weights stay fp32 in HBM, so the entry point has the signature of igcn_gemm_f32 and a model
+// switches between the two with a flag.  LDS rows hold 32 bf16 + 8 pad (80 B): an operand fragment
+// (row = lane & 15, k = 8 (lane >> 4) .. +7) is ONE 16-byte LDS read.
+// -------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define G_LDB (G_BK + 8)
+
+template <int ROWS, int VW>
+__device__ __forceinline__ void store_tile_bf16(const TileLoader<ROWS, VW>& l, __bf16 (*T)[G_LDB], bool rfast) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < TileLoader<ROWS, VW>::NU; ++i) {
+    const int f = tid + i * 256;
+    if (f < ROWS * G_BK / VW) {
+      if (rfast) {
+        const int r = (f % (ROWS / VW)) * VW, k = f / (ROWS / VW);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) T[r + j][k] = (__bf16)l.v[i][j];
+      } else {
+        const int r = f / (G_BK / VW), k = (f % (G_BK / VW)) * VW;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) T[r][k + j] = (__bf16)l.v[i][j];
+      }
+    }
+  }
+}
+
+template <int BN, int VW>
+__global__ void __launch_bounds__(256)
+k_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,
+            const float* __restrict__ B, int64_t sbn, int64_t sbk, const float* __restrict__ bias,
+            float* __restrict__ C, int64_t ldc, int act, int64_t k_per_split, int64_t slab_stride,
+            int64_t a_zs, int64_t b_zs, int zsplit) {
+  extern __shared__ float g_lds[];
+  const int nbuf = k_per_split <= G_BK ? 1 : 2;
+  __bf16 (*As)[G_BM][G_LDB] = reinterpret_cast<__bf16 (*)[G_BM][G_LDB]>(g_lds);
+  __bf16 (*Bs)[BN][G_LDB] = reinterpret_cast<__bf16 (*)[BN][G_LDB]>(reinterpret_cast<__bf16*>(g_lds) +
+                                                                      (size_t)nbuf * G_BM * G_LDB);
+  constexpr int NT = BN / 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * G_BM, n0 = (int64_t)blockIdx.y * BN;
+  const int64_t bidx = blockIdx.z / zsplit, ks_id = blockIdx.z % zsplit;
+  const int64_t k_begin = ks_id * k_per_split;
+  const int64_t k_end = k_begin + k_per_split < K ? k_begin + k_per_split : K;
+  A += bidx * a_zs;
+  B += bidx * b_zs;
+  const bool a_rfast = (sam == 1 && sak != 1), b_rfast = (sbn == 1 && sbk != 1);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  TileLoader<G_BM, VW> la;
+  TileLoader<BN, VW> lb;
+  if (k_begin < k_end) {
+    la.load(A, sam, sak, a_rfast, m0, M, k_begin, k_end);
+    lb.load(B, sbn, sbk, b_rfast, n0, N, k_begin, k_end);
+    store_tile_bf16<G_BM, VW>(la, As[0], a_rfast);
+    store_tile_bf16<BN, VW>(lb, Bs[0], b_rfast);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int64_t kb = k_begin; kb < k_end; kb += G_BK) {
+    const bool more = kb + G_BK < k_end;
+    if (more) {
+      la.load(A, sam, sak, a_rfast, m0, M, kb + G_BK, k_end);
+      lb.load(B, sbn, sbk, b_rfast, n0, N, kb + G_BK, k_end);
+    }
+    // one 32-deep matrix instruction per accumulator tile; operands swapped as in k_gemm_f32 (transposed accumulator:
+    // lane (g, j) owns C[m0 + 16 w + j][n0 + 16 t + 4 g + r], four consecutive columns of one row)
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[buf][w * 16 + (lane & 15)][(lane >> 4) * 8]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[buf][t * 16 + (lane & 15)][(lane >> 4) * 8]);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc[t], 0, 0, 0);
+    }
+    if (more) {
+      store_tile_bf16<G_BM, VW>(la, As[buf ^ 1], a_rfast);
+      store_tile_bf16<BN, VW>(lb, Bs[buf ^ 1], b_rfast);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* Cz = C + (int64_t)blockIdx.z * slab_stride;
+  const bool final_out = (gridDim.z == 1);
+  const int64_t gm = m0 + w * 16 + (lane & 15);
+  const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)Cz & 15) == 0);
+  if (gm < M) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int64_t gn = n0 + t * 16 + (lane >> 4) * 4;
+      if (gn >= N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[t][r] + ((final_out && bias && gn + r < N) ? bias[gn + r] : 0.f);
+        if (final_out && act == 1) v[r] = fmaxf(v[r], 0.f);
+      }
+      float* dst = Cz + gm * ldc + gn;
+      if (c_vec && gn + 3 < N) {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (gn + r < N) dst[r] = v[r];
+      }
+    }
+  }
+}
+
+static size_t gemm_bf16_lds_bytes(int bn, int64_t k_per_split) {
+  return (size_t)(k_per_split <= G_BK ? 1 : 2) * (G_BM + bn) * G_LDB * sizeof(__bf16);
+}
+
 // widest aligned vector (4, 2 or 1 floats) operand (ptr, row stride, k stride, rows, K) can be read with along its
 // contiguous axis
 static int vec_width(const float* p, int64_t srow, int64_t sk, int64_t rows, int64_t K) {
@@ -210,12 +328,15 @@ extern "C" int igcn_gemm_f32_split_k(int64_t M, int64_t N, int64_t K) {
   return (int)(sk < 1 ? 1 : sk);
 }
 
-extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t sam, int64_t sak,
-                             const float* B, int64_t sbn, int64_t sbk, const float* bias, float* C, int64_t ldc,
-                             int act, int split_k, float* scratch, void* stream) {
-  IGCN_REQUIRE(M > 0 && N > 0 && K >= 0 && split_k >= 1, "gemm_f32: bad sizes M=%lld N=%lld K=%lld split=%d",
+static int gemm_launch(bool bf16, int64_t M, int64_t N, int64_t K, const float* A, int64_t sam, int64_t sak,
+                       const float* B, int64_t sbn, int64_t sbk, const float* bias, float* C, int64_t ldc, int act,
+                       int split_k, float* scratch, void* stream) {
+  const char* nm = bf16 ? "gemm_bf16" : "gemm_f32";
+  const bool final_grad = (act & 0x100) != 0;     // the output is a parameter gradient: its split-K sum may be deferred
+  act &= 0xff;
+  IGCN_REQUIRE(M > 0 && N > 0 && K >= 0 && split_k >= 1, "%s: bad sizes M=%lld N=%lld K=%lld split=%d", nm,
                (long long)M, (long long)N, (long long)K, split_k);
-  IGCN_REQUIRE(split_k == 1 || scratch != nullptr, "gemm_f32: split_k>1 needs scratch");
+  IGCN_REQUIRE(split_k == 1 || scratch != nullptr, "%s: split_k>1 needs scratch", nm);
   hipStream_t st = (hipStream_t)stream;
   if (split_k > K / G_BK) split_k = (int)(K / G_BK > 0 ? K / G_BK : 1);
   int64_t kps = igcn_cdiv(igcn_cdiv(K, split_k), G_BK) * G_BK;
@@ -229,9 +350,15 @@ extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, in
   if (const char* cap = getenv("IGCN_GEMM_BN")) bn = atoi(cap) < bn ? atoi(cap) : bn;      // sweeps only
   dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)split_k);
   const int vw = min_int(vec_width(A, sam, sak, M, K), vec_width(B, sbn, sbk, N, K));
-#define LAUNCH_G(BNV, VECV)                                                                                    \
-  hipLaunchKernelGGL((k_gemm_f32<BNV, VECV>), grid, dim3(256), gemm_lds_bytes(BNV, kps), st, M, N, K, A, sam, sak, \
-                     B, sbn, sbk, bias, out, ld, act, kps, slab, (int64_t)0, (int64_t)0, split_k)
+#define LAUNCH_G(BNV, VECV)                                                                                        \
+  do {                                                                                                             \
+    if (bf16)                                                                                                      \
+      hipLaunchKernelGGL((k_gemm_bf16<BNV, VECV>), grid, dim3(256), gemm_bf16_lds_bytes(BNV, kps), st, M, N, K, A,  \
+                         sam, sak, B, sbn, sbk, bias, out, ld, act, kps, slab, (int64_t)0, (int64_t)0, split_k);    \
+    else                                                                                                           \
+      hipLaunchKernelGGL((k_gemm_f32<BNV, VECV>), grid, dim3(256), gemm_lds_bytes(BNV, kps), st, M, N, K, A, sam,   \
+                         sak, B, sbn, sbk, bias, out, ld, act, kps, slab, (int64_t)0, (int64_t)0, split_k);         \
+  } while (0)
   if (vw == 4) {
     if (bn == 16) { LAUNCH_G(16, 4); } else if (bn == 32) { LAUNCH_G(32, 4); } else { LAUNCH_G(64, 4); }
   } else if (vw == 2) {
@@ -240,7 +367,9 @@ extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, in
     if (bn == 16) { LAUNCH_G(16, 1); } else if (bn == 32) { LAUNCH_G(32, 1); } else { LAUNCH_G(64, 1); }
   }
 #undef LAUNCH_G
-  IGCN_CHECK_LAUNCH("gemm_f32");
+  IGCN_CHECK_LAUNCH(nm);
+  if (split && final_grad && ldc == N && bias == nullptr && act == 0 && M * N < ((int64_t)1 << 31))
+    return igcn_launch_reduce_rows_final(scratch, split_k, M * N, (int)(M * N), C, st);
   if (split && ldc == N && M * N <= 4096 && split_k > 32 && bias == nullptr && act == 0)
     return igcn_launch_reduce_rows(scratch, split_k, M * N, (int)(M * N), C, 0, st);   // block-per-output tree
   if (split) {
@@ -249,6 +378,18 @@ extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, in
     IGCN_CHECK_LAUNCH("gemm_splitk_reduce");
   }
   return IGCN_OK;
+}
+
+extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t sam, int64_t sak,
+                             const float* B, int64_t sbn, int64_t sbk, const float* bias, float* C, int64_t ldc,
+                             int act, int split_k, float* scratch, void* stream) {
+  return gemm_launch(false, M, N, K, A, sam, sak, B, sbn, sbk, bias, C, ldc, act, split_k, scratch, stream);
+}
+
+extern "C" int igcn_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* A, int64_t sam, int64_t sak,
+                              const float* B, int64_t sbn, int64_t sbk, const float* bias, float* C, int64_t ldc,
+                              int act, int split_k, float* scratch, void* stream) {
+  return gemm_launch(true, M, N, K, A, sam, sak, B, sbn, sbk, bias, C, ldc, act, split_k, scratch, stream);
 }
 
 

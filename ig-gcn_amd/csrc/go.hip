@@ -1208,7 +1208,7 @@ extern "C" int igcn_nodes_ln_bwd(int B, int f, int N, int pool, const float* y, 
                        B * f, f, N, pool, y, gamma, beta, keep, mean, rstd, dz, scratch);
   }
   IGCN_CHECK_LAUNCH("nodes_ln_bwd");
-  return igcn_launch_reduce_rows(scratch, chunks, 2 * (int64_t)N, 2 * N, dgb, 0, st);
+  return igcn_launch_reduce_rows_final(scratch, chunks, 2 * (int64_t)N, 2 * N, dgb, st);
 }
 
 // =================================================================================================
@@ -1636,7 +1636,7 @@ extern "C" int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, c
     GO_DISPATCH(fin, fout, CALL)
 #undef CALL
     IGCN_CHECK_LAUNCH("go_decode_bwd(lds)");
-    return igcn_launch_reduce_rows(scratch, B, nw, nw, dparams, 0, st);
+    return igcn_launch_reduce_rows_final(scratch, B, nw, nw, dparams, st);
   }
   dim3 grid((unsigned)igcn_cdiv(Nin, GO_T), (unsigned)igcn_cdiv(B, GO_SB));
 #define CALL(FI, FO)                                                                                             \
@@ -1645,5 +1645,5 @@ extern "C" int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, c
   GO_DISPATCH(fin, fout, CALL)
 #undef CALL
   IGCN_CHECK_LAUNCH("go_decode_bwd");
-  return igcn_launch_reduce_rows(scratch, (int64_t)grid.x * grid.y, nw, nw, dparams, 0, st);
+  return igcn_launch_reduce_rows_final(scratch, (int64_t)grid.x * grid.y, nw, nw, dparams, st);
 }

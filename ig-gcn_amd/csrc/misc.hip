@@ -186,7 +186,7 @@ extern "C" int igcn_bias_grad(int64_t rows, int cols, const float* dy, const flo
   else
     hipLaunchKernelGGL((k_bias_grad<1>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, rpb, dy, y, g, scratch);
   IGCN_CHECK_LAUNCH("bias_grad");
-  return igcn_launch_reduce_rows(scratch, nb, cols, cols, db, 0, st);
+  return igcn_launch_reduce_rows_final(scratch, nb, cols, cols, db, st);
 }
 
 // =================================================================================================
@@ -512,7 +512,7 @@ extern "C" int igcn_small_linear_bwd(int64_t R, int K, int C, const float* x, co
   hipLaunchKernelGGL(k_small_linear_bwd, dim3((unsigned)nb), dim3(256), 0, st, R, K, C, rows_per_block, x, W, dy, dx,
                      scratch);
   IGCN_CHECK_LAUNCH("small_linear_bwd");
-  return igcn_launch_reduce_rows(scratch, nb, C * K + C, C * K + C, dwb, 0, st);     // dW | db in one pass
+  return igcn_launch_reduce_rows_final(scratch, nb, C * K + C, C * K + C, dwb, st);     // dW | db in one pass
 }
 
 // =================================================================================================

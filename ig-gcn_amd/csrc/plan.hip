@@ -74,6 +74,98 @@ int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int 
   return IGCN_OK;
 }
 
+// ---- deferred reductions -------------------------------------------------------------------------------------
+// A backward pass ends ~30 of its kernels with a small "sum the block partials" launch whose output is a parameter
+// gradient that nothing reads before the optimiser.  With igcn_reduce_defer(1) those launches are queued (the
+// partial buffers stay alive on the caller's side) and igcn_reduce_flush performs all of them in ONE launch whose
+// table travels by value in the kernel arguments — same arithmetic and summation order as the stand-alone kernels.
+#define MRQ_MAX 40
+struct ReduceEntry {
+  const float* partial;
+  float* out;
+  int64_t rows, ld;
+  int n;
+};
+struct ReduceTable {
+  ReduceEntry e[MRQ_MAX];
+};
+
+__global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t) {
+  __shared__ float red[16];
+  const ReduceEntry e = t.e[blockIdx.y];
+  if (e.rows > 32 && e.n <= 4096) {                  // tall: one block per column, fixed tree (k_reduce_rows_par)
+    const int j = blockIdx.x;
+    if (j >= e.n) return;
+    float s = 0.f;
+#pragma unroll 4
+    for (int64_t r = threadIdx.x; r < e.rows; r += 256) s += e.partial[r * e.ld + j];
+    s = block_sum_all(s, red);
+    if (threadIdx.x == 0) e.out[j] = s;
+  } else {                                           // wide: one thread per column, rows in order (k_reduce_rows)
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= e.n) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int64_t r = 0; r < e.rows; ++r) s += e.partial[r * e.ld + j];
+    e.out[j] = s;
+  }
+}
+
+#include <mutex>
+#include <vector>
+static std::mutex g_rq_mutex;
+static std::vector<ReduceEntry> g_rq;
+static int g_rq_defer = 0;
+
+extern "C" int igcn_reduce_defer(int on) {
+  std::lock_guard<std::mutex> lk(g_rq_mutex);
+  g_rq_defer = on != 0;
+  return IGCN_OK;
+}
+
+extern "C" int igcn_reduce_pending(void) {
+  std::lock_guard<std::mutex> lk(g_rq_mutex);
+  return (int)g_rq.size();
+}
+
+static int reduce_flush_locked(hipStream_t st) {
+  size_t done = 0;
+  while (done < g_rq.size()) {
+    ReduceTable t = {};
+    const int cnt = (int)(g_rq.size() - done < MRQ_MAX ? g_rq.size() - done : MRQ_MAX);
+    int64_t gx = 1;
+    for (int i = 0; i < cnt; ++i) {
+      const ReduceEntry& e = g_rq[done + i];
+      t.e[i] = e;
+      const int64_t need = (e.rows > 32 && e.n <= 4096) ? e.n : igcn_cdiv(e.n, 256);
+      gx = need > gx ? need : gx;
+    }
+    hipLaunchKernelGGL(k_multi_reduce, dim3((unsigned)gx, (unsigned)cnt), dim3(256), 0, st, t);
+    done += cnt;
+  }
+  g_rq.clear();
+  IGCN_CHECK_LAUNCH("reduce_flush");
+  return IGCN_OK;
+}
+
+extern "C" int igcn_reduce_flush(void* stream) {
+  std::lock_guard<std::mutex> lk(g_rq_mutex);
+  return reduce_flush_locked((hipStream_t)stream);
+}
+
+int igcn_launch_reduce_rows_final(const float* partial, int64_t rows, int64_t ld, int n, float* out,
+                                  hipStream_t st) {
+  if (n <= 0) return IGCN_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_rq_mutex);
+    if (g_rq_defer) {
+      g_rq.push_back(ReduceEntry{partial, out, rows, ld, n});
+      return IGCN_OK;
+    }
+  }
+  return igcn_launch_reduce_rows(partial, rows, ld, n, out, 0, st);
+}
+
 // ---- stable grouping by a hand-written counting / radix sort ------------------------------------------------
 // No library sort: three kernels per pass, no scratch beyond the caller's workspace, nothing that cannot be captured
 // into a hipGraph (round 1 used rocPRIM's onesweep radix sort, which faulted when replayed from inside the step graph).

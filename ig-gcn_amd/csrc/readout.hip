@@ -612,8 +612,8 @@ static int ro_bwd(dim3 grid, int cpg, hipStream_t st, int B, int N, int groups, 
     hipLaunchKernelGGL((k_nlbn_bwd_apply_q<F, D>), gq, dim3(RO_T), 0, st, B, N, groups, training, x, W, gamma, beta,
                        save_mean, save_rstd, dout, dgg, dx, aux);
     IGCN_CHECK_LAUNCH("node_linear_bn_bwd(q)");
-    if ((rc = igcn_launch_reduce_rows(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, 0, st))) return rc;
-    return igcn_launch_reduce_rows(aux, (int64_t)gq.x * gq.y, D * F, D * F, dW, 0, st);
+    if ((rc = igcn_launch_reduce_rows_final(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, st))) return rc;
+    return igcn_launch_reduce_rows_final(aux, (int64_t)gq.x * gq.y, D * F, D * F, dW, st);
   } else {
     hipLaunchKernelGGL((k_nlbn_bwd_stats<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, save_mean,
                        save_rstd, dout, stats);
@@ -621,8 +621,8 @@ static int ro_bwd(dim3 grid, int cpg, hipStream_t st, int B, int N, int groups, 
     hipLaunchKernelGGL((k_nlbn_bwd_apply<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, training, x, W, gamma, beta,
                        save_mean, save_rstd, dout, dgg, aux, dx, aux);
     IGCN_CHECK_LAUNCH("node_linear_bn_bwd");
-    if ((rc = igcn_launch_reduce_rows(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, 0, st))) return rc;
-    if (D * F <= 16) return igcn_launch_reduce_rows(aux, (int64_t)grid.x * grid.y, D * F, D * F, dW, 0, st);
+    if ((rc = igcn_launch_reduce_rows_final(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, st))) return rc;
+    if (D * F <= 16) return igcn_launch_reduce_rows_final(aux, (int64_t)grid.x * grid.y, D * F, D * F, dW, st);
     // dW[d,c] = sum_b sum_n dpre[b,n,d] * x[b,c,n]
     return igcn_gemm_f32_batched_sum_impl(D, F, N, B, aux, 1, D, (int64_t)N * D, x, N, 1, (int64_t)F * N, dW, F,
                                           aux + (size_t)B * N * D, st);

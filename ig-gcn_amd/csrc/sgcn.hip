@@ -426,6 +426,149 @@ k_gcn_propagate_fwd_wide(int64_t n_nodes, const float* __restrict__ h, int64_t l
   }
 }
 
+// High in-degree variant for batches of UNIFORM graphs whose feature rows fit LDS (the dense 512-ROI graphs of the
+// stress configuration: 512 x 16 floats = 32 KB per graph): the L2 gather of one 64-byte row per edge (8.4 M rows per
+// launch, each row of a graph gathered 512 times) is what bounds the wave-per-target kernel above.  Here a workgroup
+// (512 threads) owns LP_TG = 32 targets of ONE graph, stages that graph's rows in LDS once (coalesced 16-byte loads, row stride F + 4
+// floats => conflict-free 16-byte row reads), and HBM only streams the 8-byte records: a lane loads TWO records per
+// 16-byte load, reads their rows from LDS and keeps a whole F-wide accumulator; the 64 partial rows of a wave are
+// summed with a halving butterfly (log2 F exchange steps, then the plain xor steps).  A record whose neighbour is
+// not a node of this graph (not a block-diagonal batch) falls back to the global row: correct for any input.
+#define LP_TG 32
+#define LP_THREADS 512
+// sum of `acc` over the 64 lanes: while a lane still holds more than one value, lanes m apart exchange the half the
+// partner keeps (HALF shuffles instead of 2*HALF), then plain xor steps.  All indices are compile-time constants.
+template <int F, int HALF, int M>
+__device__ __forceinline__ void lp_butterfly(float (&acc)[F], int lane) {
+  if constexpr (M >= 1) {
+    if constexpr (HALF >= 1) {
+      const bool up = (lane & M) != 0;
+#pragma unroll
+      for (int j = 0; j < HALF; ++j) {
+        const float send = up ? acc[j] : acc[j + HALF];
+        const float recv = __shfl_xor(send, M, 64);
+        acc[j] = (up ? acc[j + HALF] : acc[j]) + recv;
+      }
+      lp_butterfly<F, HALF / 2, M / 2>(acc, lane);
+    } else {
+      acc[0] += __shfl_xor(acc[0], M, 64);
+      lp_butterfly<F, 0, M / 2>(acc, lane);
+    }
+  }
+}
+
+__device__ __forceinline__ int lp_slot(int r, int R) { return (r >> 1) + (r & 1) * ((R + 1) >> 1); }
+
+template <int FQ>
+__global__ void __launch_bounds__(LP_THREADS)
+k_gcn_propagate_fwd_lds(int64_t n_nodes, int R, const float* __restrict__ h, int64_t ld_h,
+                        const EdgeRec* __restrict__ tstream, const float* __restrict__ what_loop,
+                        const float* __restrict__ bias, const int32_t* __restrict__ tgt_ptr,
+                        float* __restrict__ out, int64_t ld_out, int relu) {
+  constexpr int F = 4 * FQ, LD = F + 4;
+  extern __shared__ float lp_rows[];                 // [R][LD]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t g0 = (int64_t)blockIdx.y * R;        // first node of the graph
+  for (int i = tid; i < R * FQ; i += LP_THREADS) {
+    const int r = i / FQ, q = i - r * FQ;
+    *reinterpret_cast<float4*>(lp_rows + lp_slot(r, R) * LD + q * 4) =
+        *reinterpret_cast<const float4*>(h + (g0 + r) * ld_h + q * 4);
+  }
+  __syncthreads();
+  constexpr int TPW = LP_TG / (LP_THREADS / 64);      // targets per wave
+  const int t_lo = blockIdx.x * LP_TG + w * TPW;
+  // (requesting the records of target i+1 before target i is summed — a software pipeline over the wave's targets —
+  // measured SLOWER: 57 us against 40 us at the stress shape; the extra live registers cost more occupancy than the
+  // overlap returns, the 32 resident waves of a CU already cover each other's chains)
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int tl = t_lo + ti;
+    if (tl >= R) break;                              // wave-uniform
+    const int64_t t = g0 + tl;
+    const int32_t p0 = tgt_ptr[t], p1 = tgt_ptr[t + 1];
+    float acc[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) acc[j] = 0.f;
+    // records two at a time from an even (16-byte aligned) position, FOUR 16-byte loads (512 records per wave) per
+    // group; entries outside [p0, p1) carry weight 0 and point at the graph's row 0.
+    // A lane holds records (2l, 2l+1): in a dense list those are rows (2l, 2l+1), so the lanes of one LDS row read
+    // sit on every second row — the rows are therefore stored EVEN ROWS FIRST (slot(r) = r/2 + (r&1) ceil(R/2)), which
+    // makes that access a run of consecutive slots (conflict-free) instead of a 2-way bank conflict.
+    for (int32_t qb = (p0 & ~1); qb < p1; qb += 512) {
+      int4 v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int32_t q = qb + c * 128 + 2 * lane;
+        v[c] = make_int4((int)g0, 0, (int)g0, 0);
+        if (q + 1 < p1) {
+          v[c] = *reinterpret_cast<const int4*>(tstream + q);
+        } else if (q < p1) {
+          const EdgeRec e = tstream[q];
+          v[c].x = e.idx;
+          v[c].y = __float_as_int(e.w);
+        }
+        if (q < p0) { v[c].x = (int)g0; v[c].y = 0; }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int idx = k == 0 ? v[c].x : v[c].z;
+          const float wgt = __int_as_float(k == 0 ? v[c].y : v[c].w);
+          const int64_t loc = (int64_t)idx - g0;
+          if (loc >= 0 && loc < R) {                 // two code paths: an LDS/global pointer select would turn the
+            const float* row = lp_rows + lp_slot((int)loc, R) * LD;     // row reads into FLAT loads
+#pragma unroll
+            for (int cq = 0; cq < FQ; ++cq) {
+              const float4 r4 = *reinterpret_cast<const float4*>(row + cq * 4);
+              acc[4 * cq] += wgt * r4.x; acc[4 * cq + 1] += wgt * r4.y;
+              acc[4 * cq + 2] += wgt * r4.z; acc[4 * cq + 3] += wgt * r4.w;
+            }
+          } else {
+            const float* row = h + (int64_t)idx * ld_h;
+#pragma unroll
+            for (int cq = 0; cq < FQ; ++cq) {
+              const float4 r4 = *reinterpret_cast<const float4*>(row + cq * 4);
+              acc[4 * cq] += wgt * r4.x; acc[4 * cq + 1] += wgt * r4.y;
+              acc[4 * cq + 2] += wgt * r4.z; acc[4 * cq + 3] += wgt * r4.w;
+            }
+          }
+        }
+      }
+    }
+    lp_butterfly<F, F / 2, 32>(acc, lane);
+    // lane holds the sum of feature f = the log2(F) top bits of its id, read MSB = F/2 ... ; lanes with the low
+    // (6 - log2 F) bits zero write
+    constexpr int LOGF = FQ == 1 ? 2 : (FQ == 2 ? 3 : (FQ == 4 ? 4 : (FQ == 8 ? 5 : 6)));
+    constexpr int LOW = 6 - LOGF;
+    if ((lane & ((1 << LOW) - 1)) == 0) {
+      int f = 0;
+#pragma unroll
+      for (int b2 = 0; b2 < LOGF; ++b2)                // step b2 used mask 32 >> b2 and kept half F >> (b2 + 1)
+        if (lane & (32 >> b2)) f += F >> (b2 + 1);
+      float v = acc[0] + what_loop[t] * lp_rows[lp_slot(tl, R) * LD + f] + (bias ? bias[f] : 0.f);
+      if (relu) v = fmaxf(v, 0.f);
+      out[t * ld_out + f] = v;
+    }
+  }
+}
+
+static bool propagate_lds_ok(int64_t n_nodes, int64_t n_edges, int F, int nodes_per_graph) {
+  if (nodes_per_graph <= 0 || n_nodes % nodes_per_graph != 0) return false;
+  if (!(F == 4 || F == 8 || F == 16 || F == 32 || F == 64)) return false;
+  if ((size_t)nodes_per_graph * (F + 4) * sizeof(float) > 64 * 1024) return false;
+  return n_edges >= 64 * n_nodes;                    // long lists: the staging pays for itself
+}
+
+template <int FQ>
+static void launch_propagate_lds(int64_t n_nodes, int R, const float* h, int64_t ld_h, const EdgeRec* stream_,
+                                 const float* what_loop, const float* bias, const int32_t* ptr, float* out,
+                                 int64_t ld_out, int relu, hipStream_t st) {
+  const size_t lds = (size_t)R * (4 * FQ + 4) * sizeof(float);
+  dim3 grid((unsigned)igcn_cdiv(R, LP_TG), (unsigned)(n_nodes / R));
+  hipLaunchKernelGGL((k_gcn_propagate_fwd_lds<FQ>), grid, dim3(LP_THREADS), lds, st, n_nodes, R, h, ld_h, stream_, what_loop,
+                     bias, ptr, out, ld_out, relu);
+}
+
 static int pow2_ge(int F) {
   int p = 1;
   while (p < F) p <<= 1;
@@ -441,9 +584,20 @@ extern "C" int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, i
   if (n_nodes == 0) return IGCN_OK;
   hipStream_t st = (hipStream_t)stream;
   const int FP = pow2_ge(F);
-  (void)nodes_per_graph;
   const bool al16 = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && ld_h % 4 == 0 && ld_out % 4 == 0 &&
                     (bias == nullptr || (uintptr_t)bias % 16 == 0);
+  if (al16 && ((uintptr_t)tstream % 16 == 0) && propagate_lds_ok(n_nodes, n_edges, F, nodes_per_graph) &&
+      getenv("IGCN_PROPAGATE_NO_LDS") == nullptr) {
+    switch (F / 4) {
+      case 1: launch_propagate_lds<1>(n_nodes, nodes_per_graph, h, ld_h, (const EdgeRec*)tstream, what_loop, bias, tgt_ptr, out, ld_out, relu, st); break;
+      case 2: launch_propagate_lds<2>(n_nodes, nodes_per_graph, h, ld_h, (const EdgeRec*)tstream, what_loop, bias, tgt_ptr, out, ld_out, relu, st); break;
+      case 4: launch_propagate_lds<4>(n_nodes, nodes_per_graph, h, ld_h, (const EdgeRec*)tstream, what_loop, bias, tgt_ptr, out, ld_out, relu, st); break;
+      case 8: launch_propagate_lds<8>(n_nodes, nodes_per_graph, h, ld_h, (const EdgeRec*)tstream, what_loop, bias, tgt_ptr, out, ld_out, relu, st); break;
+      default: launch_propagate_lds<16>(n_nodes, nodes_per_graph, h, ld_h, (const EdgeRec*)tstream, what_loop, bias, tgt_ptr, out, ld_out, relu, st); break;
+    }
+    IGCN_CHECK_LAUNCH("gcn_propagate_fwd_lds");
+    return IGCN_OK;
+  }
   if (n_edges >= 16 * n_nodes && al16 && (F == 4 || F == 8 || F == 16 || F == 32 || F == 64)) {
 #define LAUNCH_WIDE(FQV)                                                                                          \
   hipLaunchKernelGGL((k_gcn_propagate_fwd_wide<FQV>), dim3((unsigned)igcn_cdiv(n_nodes, 4)), dim3(256), 0, st,     \
@@ -490,6 +644,37 @@ extern "C" int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, i
   }
 #undef LAUNCH_FWD
   IGCN_CHECK_LAUNCH("gcn_propagate_fwd");
+  return IGCN_OK;
+}
+
+// Launch floor of the scatter-aggregate (measurement aid of bench.py's roofline): the grid
+// igcn_gcn_propagate_fwd uses for (n_nodes, F) — thread = (target, feature quad), or one wave per target when
+// `dense` — with the body removed (mode 0: nothing; mode 1: the 16-byte output store only).
+__global__ void __launch_bounds__(256)
+k_launch_floor(int64_t n_nodes, int fq_lanes, int dense, int mode, float* __restrict__ out, int64_t ld_out) {
+  int64_t t;
+  int fq;
+  if (dense) {
+    const int lane = threadIdx.x & 63;
+    fq = lane % fq_lanes;
+    t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lane / fq_lanes != 0) return;
+  } else {
+    fq = threadIdx.x % fq_lanes;
+    t = (int64_t)blockIdx.x * (256 / fq_lanes) + threadIdx.x / fq_lanes;
+  }
+  if (t >= n_nodes || mode == 0) return;
+  *reinterpret_cast<float4*>(out + t * ld_out + fq * 4) = make_float4(0.f, 1.f, 2.f, 3.f);
+}
+
+extern "C" int igcn_launch_floor(int64_t n_nodes, int F, int dense, int mode, float* out, void* stream) {
+  IGCN_REQUIRE(n_nodes > 0 && (F == 4 || F == 8 || F == 16 || F == 32 || F == 64) && ((uintptr_t)out % 16 == 0),
+               "launch_floor: F in {4,8,16,32,64}, 16-byte aligned out");
+  const int fq = F / 4;
+  const int64_t blocks = dense ? igcn_cdiv(n_nodes, 4) : igcn_cdiv(n_nodes, 256 / fq);
+  hipLaunchKernelGGL(k_launch_floor, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_nodes, fq, dense,
+                     mode, out, (int64_t)F);
+  IGCN_CHECK_LAUNCH("launch_floor");
   return IGCN_OK;
 }
 
@@ -729,6 +914,110 @@ k_gcn_propagate_bwd_dh_wide(int64_t n_nodes, const float* __restrict__ dout, int
   }
 }
 
+// Per-edge coefficient gradients for the same dense uniform batches: a workgroup takes a run of DW_CHUNK consecutive
+// edges; when they all belong to ONE graph (block-diagonal batch in stored order) it stages that graph's g and h rows
+// in LDS and every edge costs one coalesced (src, dst) read and two LDS row reads instead of two L2 row gathers.
+// Edges outside the staged graph (a chunk across a graph boundary, or a batch that is not block diagonal) read the
+// rows from global memory.
+#define DW_CHUNK 32768
+#define DW_THREADS 1024
+template <int FQ>
+__global__ void __launch_bounds__(DW_THREADS)
+k_gcn_propagate_bwd_dw_lds(int64_t n_nodes, int64_t n_edges, int R, const float* __restrict__ g, int64_t ld_g,
+                           const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ src32,
+                           const int32_t* __restrict__ dst32, float* __restrict__ dwhat,
+                           float* __restrict__ dwhat_loop) {
+  constexpr int F = 4 * FQ, LD = F + 4;
+  extern __shared__ float dw_rows[];                 // g rows [R][LD] then h rows [R][LD]
+  float* gs = dw_rows;
+  float* hs = dw_rows + (size_t)R * LD;
+  const int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * DW_CHUNK;
+  const int64_t i1 = i0 + DW_CHUNK < n_edges ? i0 + DW_CHUNK : n_edges;
+  const int64_t graph = (int64_t)src32[i0] / R;      // the graph most of the chunk belongs to
+  const int64_t g0 = graph * R;
+  for (int i = tid; i < R * FQ; i += DW_THREADS) {
+    const int r = i / FQ, q = i - r * FQ;
+    *reinterpret_cast<float4*>(gs + r * LD + q * 4) = *reinterpret_cast<const float4*>(g + (g0 + r) * ld_g + q * 4);
+    *reinterpret_cast<float4*>(hs + r * LD + q * 4) = *reinterpret_cast<const float4*>(h + (g0 + r) * ld_h + q * 4);
+  }
+  __syncthreads();
+  for (int64_t i = i0 + tid; i < i1; i += DW_THREADS) {
+    const int64_t sg = src32[i], tg = dst32[i];
+    if (sg == tg) { dwhat[i] = 0.f; continue; }
+    const int64_t sl = sg - g0, tl = tg - g0;
+    const bool in = sl >= 0 && sl < R && tl >= 0 && tl < R;
+    float acc = 0.f;
+    if (in) {                                        // separate LDS / global code paths (no pointer select: FLAT loads)
+      const float* hr = hs + (int)sl * LD;
+      const float* gr = gs + (int)tl * LD;
+#pragma unroll
+      for (int c = 0; c < FQ; ++c) {
+        const float4 gv = *reinterpret_cast<const float4*>(gr + c * 4);
+        const float4 hv = *reinterpret_cast<const float4*>(hr + c * 4);
+        acc += gv.x * hv.x;                          // same summation order as the global-memory kernels
+        acc += gv.y * hv.y;
+        acc += gv.z * hv.z;
+        acc += gv.w * hv.w;
+      }
+    } else {
+      const float* hr = h + sg * ld_h;
+      const float* gr = g + tg * ld_g;
+#pragma unroll
+      for (int c = 0; c < FQ; ++c) {
+        const float4 gv = *reinterpret_cast<const float4*>(gr + c * 4);
+        const float4 hv = *reinterpret_cast<const float4*>(hr + c * 4);
+        acc += gv.x * hv.x;
+        acc += gv.y * hv.y;
+        acc += gv.z * hv.z;
+        acc += gv.w * hv.w;
+      }
+    }
+    dwhat[i] = acc;
+  }
+  // self-loop coefficients of the staged graph's nodes: one chunk per graph does it (the one holding its first edge
+  // ... which this workgroup cannot know cheaply), so node t is taken by the workgroup whose chunk index == t's
+  // position modulo the grid: a plain grid-stride over nodes, rows from global memory
+  for (int64_t t = (int64_t)blockIdx.x * DW_THREADS + tid; t < n_nodes; t += (int64_t)gridDim.x * DW_THREADS) {
+    const float* gr = g + t * ld_g;
+    const float* hr = h + t * ld_h;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < FQ; ++c) {
+      const float4 gv = *reinterpret_cast<const float4*>(gr + c * 4);
+      const float4 hv = *reinterpret_cast<const float4*>(hr + c * 4);
+      acc += gv.x * hv.x;
+      acc += gv.y * hv.y;
+      acc += gv.z * hv.z;
+      acc += gv.w * hv.w;
+    }
+    dwhat_loop[t] = acc;
+  }
+}
+
+// block partials of the column sums of g [N, F] (bias gradient), layout [nblk, F] like the quad dh kernels
+template <int FQ>
+__global__ void __launch_bounds__(256)
+k_colsum_partial_q(int64_t n_nodes, const float* __restrict__ g, int64_t ld_g, float* __restrict__ partial) {
+  constexpr int NPB = 256 / FQ;
+  __shared__ float4 red[256];
+  const int fq = threadIdx.x % FQ, nl = threadIdx.x / FQ;
+  const int64_t s = (int64_t)blockIdx.x * NPB + nl;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (s < n_nodes) v = *reinterpret_cast<const float4*>(g + s * ld_g + fq * 4);
+  red[threadIdx.x] = v;
+  __syncthreads();
+  if (threadIdx.x < FQ) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NPB; ++j) {
+      const float4 u = red[j * FQ + threadIdx.x];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    float* dst = partial + ((int64_t)blockIdx.x * FQ + threadIdx.x) * 4;
+    dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+  }
+}
+
 // g = dout * [out > 0], once per call: the per-edge kernels then gather ONE row per edge end instead of two
 __global__ void __launch_bounds__(256)
 k_relu_mask_rows(int64_t n_nodes, int F, const float* __restrict__ dout, int64_t ld_dout,
@@ -750,7 +1039,8 @@ extern "C" size_t igcn_gcn_propagate_bwd_scratch_floats(int64_t n_nodes, int F) 
   return propagate_bwd_partial_floats(n_nodes, F) + (size_t)n_nodes * (F > 0 ? F : 1);   // partials + masked dout
 }
 
-extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, const float* dout, int64_t ld_dout,
+extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, int nodes_per_graph,
+                                      const float* dout, int64_t ld_dout,
                                       const float* out, int64_t ld_out, int relu, const float* h, int64_t ld_h,
                                       const void* sstream, const float* what_loop, const int32_t* src32,
                                       const int32_t* dst32, const int32_t* src_ptr,
@@ -772,7 +1062,37 @@ extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, c
   const bool al16 = ((uintptr_t)dout % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)dh % 16 == 0) &&
                     ld_dout % 4 == 0 && ld_out % 4 == 0 && ld_dh % 4 == 0;
   const bool quad = al16 && (F == 4 || F == 8 || F == 16 || F == 32 || F == 64);
-  if (quad) {
+  if (quad && relu == 0 && ((uintptr_t)sstream % 16 == 0) && (uintptr_t)h % 16 == 0 && ld_h % 4 == 0 &&
+      propagate_lds_ok(n_nodes, n_edges, F, nodes_per_graph) && getenv("IGCN_PROPAGATE_NO_LDS") == nullptr) {
+    // dense uniform batch (stress shape): the graph's rows staged in LDS — dh is the forward kernel on the
+    // by-source stream, the bias gradient a column-sum pass, the coefficient gradients an LDS-staged edge walk
+    const int R = nodes_per_graph;
+    nblk = igcn_cdiv(n_nodes, 256 / (F / 4));
+#define LAUNCH_LDS_BWD(FQV)                                                                                       \
+  do {                                                                                                            \
+    launch_propagate_lds<FQV>(n_nodes, R, dout, ld_dout, (const EdgeRec*)sstream, what_loop, nullptr, src_ptr, dh, \
+                              ld_dh, 0, st);                                                                       \
+    if (dbias)                                                                                                    \
+      hipLaunchKernelGGL((k_colsum_partial_q<FQV>), dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, dout, ld_dout, \
+                         scratch);                                                                                 \
+    if (need_dw && 2 * (size_t)R * (4 * FQV + 4) * sizeof(float) <= 150 * 1024) {                                 \
+      IGCN_ALLOW_BIG_LDS((k_gcn_propagate_bwd_dw_lds<FQV>));                                                      \
+      hipLaunchKernelGGL((k_gcn_propagate_bwd_dw_lds<FQV>), dim3((unsigned)igcn_cdiv(n_edges, DW_CHUNK)),          \
+                         dim3(DW_THREADS), 2 * (size_t)R * (4 * FQV + 4) * sizeof(float), st, n_nodes, n_edges, R, \
+                         dout,                                                                                     \
+                         ld_dout, h, ld_h, src32, dst32, dwhat, dwhat_loop);                                       \
+      need_dw = 0;                                                                                                \
+    }                                                                                                             \
+  } while (0)
+    switch (F / 4) {
+      case 1: LAUNCH_LDS_BWD(1); break;
+      case 2: LAUNCH_LDS_BWD(2); break;
+      case 4: LAUNCH_LDS_BWD(4); break;
+      case 8: LAUNCH_LDS_BWD(8); break;
+      default: LAUNCH_LDS_BWD(16); break;
+    }
+#undef LAUNCH_LDS_BWD
+  } else if (quad) {
     nblk = igcn_cdiv(n_nodes, 256 / (F / 4));
     const bool wide = n_edges >= 16 * n_nodes;
 #define LAUNCH_BQ(FQV)                                                                                            \
@@ -810,7 +1130,7 @@ extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, c
   }
   IGCN_CHECK_LAUNCH("gcn_propagate_bwd_dh");
   if (dbias) {
-    int rc = igcn_launch_reduce_rows(scratch, nblk, quad ? F : FP, F, dbias, 0, st);
+    int rc = igcn_launch_reduce_rows_final(scratch, nblk, quad ? F : FP, F, dbias, st);
     if (rc) return rc;
   }
   if (need_dw) {

@@ -19,6 +19,65 @@ def _f32(t):
 
 
 # =================================================================================================
+# Deferred reductions of a backward pass (igcn_reduce_defer / igcn_reduce_flush)
+# =================================================================================================
+_DEFER = {"on": False, "keep": []}
+
+
+class deferred_reductions:
+    """``with ops.deferred_reductions(): backward`` — the ~30 "sum the block partials" launches whose output is a
+    parameter gradient are queued by the library and performed by ONE launch at exit.  Gradients are therefore only
+    valid after the block; the partial buffers are kept alive here until then.  Used by train.py around the backward
+    of a step (the optimiser runs after the flush); plain ``loss.backward()`` elsewhere reduces immediately."""
+
+    def __enter__(self):
+        if _DEFER["on"]:
+            raise _lib.IgcnError("deferred_reductions does not nest")
+        _DEFER["on"] = True
+        call("igcn_reduce_defer", 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            call("igcn_reduce_defer", 0)
+            call("igcn_reduce_flush", stream_ptr())
+        finally:
+            _DEFER["on"] = False
+            _DEFER["keep"].clear()
+        return False
+
+
+def _keep(t):
+    """Scratch whose block partials a queued reduction still has to read."""
+    if _DEFER["on"] and t is not None:
+        _DEFER["keep"].append(t)
+    return t
+
+
+def _leaves(*ts):
+    """True when every given tensor is an autograd LEAF (a parameter): only then is its gradient final — a view of a
+    parameter (``in_proj_weight.split``), or any tensor with a grad_fn, hands its gradient to another backward node,
+    which would read it before the flush."""
+    return all(t is None or t.is_leaf for t in ts)
+
+
+class _immediate:
+    """Reduce now, not at the flush, for one library call (the op's parameter-like inputs are not leaves)."""
+
+    def __init__(self, final):
+        self.off = _DEFER["on"] and not final
+
+    def __enter__(self):
+        if self.off:
+            call("igcn_reduce_defer", 0)
+
+    def __exit__(self, *exc):
+        if self.off:
+            call("igcn_reduce_defer", 1)
+        return False
+
+
+# =================================================================================================
 # Graph plan (once per batch)
 # =================================================================================================
 class GraphPlan:
@@ -257,6 +316,7 @@ class GcnPropagate(torch.autograd.Function):
              ptr(tstream), ptr(wloop), ptr(bias), ptr(plan.tgt_ptr), ptr(out), f, int(relu), stream_ptr())
         ctx.save_for_backward(h, what, wloop, out, sstream)
         ctx.plan, ctx.relu, ctx.has_bias = plan, int(relu), bias is not None
+        ctx.final = _leaves(bias)
         return out
 
     @staticmethod
@@ -271,11 +331,13 @@ class GcnPropagate(torch.autograd.Function):
         dwhat = torch.empty_like(what) if need_dw else None
         dwloop = torch.empty_like(wloop) if need_dw else None
         lib = _lib.load()
-        scratch = torch.empty(int(lib.igcn_gcn_propagate_bwd_scratch_floats(n, f)), dtype=torch.float32,
-                              device=h.device)
-        call("igcn_gcn_propagate_bwd", n, plan.n_edges, f, ptr(dout), f, ptr(out), f, ctx.relu, ptr(h), f,
-             ptr(sstream), ptr(wloop), ptr(plan.src32), ptr(plan.dst32), ptr(plan.src_ptr), ptr(dh), f, ptr(dbias),
-             int(need_dw), ptr(dwhat), ptr(dwloop), ptr(scratch), stream_ptr())
+        scratch = _keep(torch.empty(int(lib.igcn_gcn_propagate_bwd_scratch_floats(n, f)), dtype=torch.float32,
+                                    device=h.device))
+        with _immediate(ctx.final):
+            call("igcn_gcn_propagate_bwd", n, plan.n_edges, f, int(getattr(plan, "nodes_per_graph", 0) or 0), ptr(dout),
+                 f, ptr(out), f, ctx.relu, ptr(h), f,
+                 ptr(sstream), ptr(wloop), ptr(plan.src32), ptr(plan.dst32), ptr(plan.src_ptr), ptr(dh), f, ptr(dbias),
+                 int(need_dw), ptr(dwhat), ptr(dwloop), ptr(scratch), stream_ptr())
         return dh, dwhat, dwloop, dbias, None, None, None, None
 
 
@@ -287,8 +349,12 @@ def _split_k(m, n, k):
     return int(_lib.load().igcn_gemm_f32_split_k(m, n, k))
 
 
-def gemm_nt(a, b, bias=None, act=0, out=None):
-    """out[M,N] = act(a[M,K] @ b[N,K]^T + bias) on igcn_gemm_f32."""
+def _gemm(bf16):
+    return "igcn_gemm_bf16" if bf16 else "igcn_gemm_f32"
+
+
+def gemm_nt(a, b, bias=None, act=0, out=None, bf16=False):
+    """out[M,N] = act(a[M,K] @ b[N,K]^T + bias) on igcn_gemm_f32 (``bf16``: operands rounded to bf16, igcn_gemm_bf16)."""
     a, b = _f32(a), _f32(b)
     m, k = a.shape
     n = b.shape[0]
@@ -296,12 +362,12 @@ def gemm_nt(a, b, bias=None, act=0, out=None):
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
     sk = _split_k(m, n, k)
     scratch = torch.empty(sk * m * n, dtype=torch.float32, device=a.device) if sk > 1 else None
-    call("igcn_gemm_f32", m, n, k, ptr(a), k, 1, ptr(b), k, 1, ptr(bias), ptr(out), n, act, sk, ptr(scratch),
+    call(_gemm(bf16), m, n, k, ptr(a), k, 1, ptr(b), k, 1, ptr(bias), ptr(out), n, act, sk, ptr(scratch),
          stream_ptr())
     return out
 
 
-def gemm_nn(a, b, out=None):
+def gemm_nn(a, b, out=None, bf16=False):
     """out[M,N] = a[M,K] @ b[K,N]."""
     a, b = _f32(a), _f32(b)
     m, k = a.shape
@@ -310,30 +376,36 @@ def gemm_nn(a, b, out=None):
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
     sk = _split_k(m, n, k)
     scratch = torch.empty(sk * m * n, dtype=torch.float32, device=a.device) if sk > 1 else None
-    call("igcn_gemm_f32", m, n, k, ptr(a), k, 1, ptr(b), 1, n, None, ptr(out), n, 0, sk, ptr(scratch), stream_ptr())
+    call(_gemm(bf16), m, n, k, ptr(a), k, 1, ptr(b), 1, n, None, ptr(out), n, 0, sk, ptr(scratch), stream_ptr())
     return out
 
 
-def gemm_tn(a, b):
-    """out[M,N] = a[K,M]^T @ b[K,N]  (weight gradient: reduction over the long row axis K)."""
+def gemm_tn(a, b, bf16=False, final_grad=False):
+    """out[M,N] = a[K,M]^T @ b[K,N]  (weight gradient: reduction over the long row axis K).  ``final_grad``: the
+    output is a parameter gradient — its split-K sum may be deferred (``deferred_reductions``)."""
     a, b = _f32(a), _f32(b)
     k, m = a.shape
     n = b.shape[1]
     out = torch.empty(m, n, dtype=torch.float32, device=a.device)
     sk = _split_k(m, n, k)
     scratch = torch.empty(sk * m * n, dtype=torch.float32, device=a.device) if sk > 1 else None
-    call("igcn_gemm_f32", m, n, k, ptr(a), 1, m, ptr(b), 1, n, None, ptr(out), n, 0, sk, ptr(scratch), stream_ptr())
+    if final_grad:
+        _keep(scratch)
+    call(_gemm(bf16), m, n, k, ptr(a), 1, m, ptr(b), 1, n, None, ptr(out), n, 0x100 if final_grad else 0, sk,
+         ptr(scratch), stream_ptr())
     return out
 
 
 class Linear(torch.autograd.Function):
-    """y = act(x W^T + b) with W [out,in] (GCNConv.lin, lin1, lin1_regr, ...)."""
+    """y = act(x W^T + b) with W [out,in] (GCNConv.lin, lin1, lin1_regr, ...).  ``bf16``: the three products of the
+    layer (forward, input gradient, weight gradient) take bf16 operands on the matrix cores, fp32 accumulation."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
-        y = gemm_nt(x, weight, _f32(bias) if bias is not None else None, 1 if relu else 0)
+    def forward(ctx, x, weight, bias, relu, bf16=False):
+        y = gemm_nt(x, weight, _f32(bias) if bias is not None else None, 1 if relu else 0, bf16=bf16)
         ctx.save_for_backward(x, weight, y if relu else None)
-        ctx.relu, ctx.has_bias = relu, bias is not None
+        ctx.relu, ctx.has_bias, ctx.bf16 = relu, bias is not None, bf16
+        ctx.w_final, ctx.b_final = _leaves(weight), _leaves(bias)
         return y
 
     @staticmethod
@@ -348,10 +420,11 @@ class Linear(torch.autograd.Function):
             lib = _lib.load()
             g = torch.empty_like(dy) if ctx.relu else None
             db = torch.empty(cols, dtype=torch.float32, device=dy.device)
-            scratch = torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, cols)), dtype=torch.float32,
-                                  device=dy.device)
-            call("igcn_bias_grad", rows, cols, ptr(dy), ptr(y) if ctx.relu else None, ptr(g), ptr(db), ptr(scratch),
-                 stream_ptr())
+            scratch = _keep(torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, cols)), dtype=torch.float32,
+                                        device=dy.device))
+            with _immediate(ctx.b_final):
+                call("igcn_bias_grad", rows, cols, ptr(dy), ptr(y) if ctx.relu else None, ptr(g), ptr(db),
+                     ptr(scratch), stream_ptr())
             if ctx.relu:
                 dy = g
             if not need_db:
@@ -360,9 +433,9 @@ class Linear(torch.autograd.Function):
             if ctx.relu:
                 dy = dy * (y > 0)
             db = dy.sum(0) if need_db else None
-        dx = gemm_nn(dy, weight) if ctx.needs_input_grad[0] else None
-        dw = gemm_tn(dy, x) if ctx.needs_input_grad[1] else None
-        return dx, dw, db, None
+        dx = gemm_nn(dy, weight, bf16=ctx.bf16) if ctx.needs_input_grad[0] else None
+        dw = gemm_tn(dy, x, bf16=ctx.bf16, final_grad=ctx.w_final) if ctx.needs_input_grad[1] else None
+        return dx, dw, db, None, None
 
 
 class ConcatCols(torch.autograd.Function):
@@ -528,6 +601,7 @@ class SmallLinear(torch.autograd.Function):
         call("igcn_small_linear_fwd", r, k, c, ptr(x), ptr(weight), ptr(bias), ptr(y), stream_ptr())
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.final = _leaves(weight, bias)
         return y
 
     @staticmethod
@@ -538,10 +612,11 @@ class SmallLinear(torch.autograd.Function):
         c = weight.shape[0]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dwb = torch.empty(c * k + c, dtype=torch.float32, device=x.device)
-        scratch = torch.empty(int(_lib.load().igcn_small_linear_bwd_scratch_floats(r, k, c)), dtype=torch.float32,
-                              device=x.device)
-        call("igcn_small_linear_bwd", r, k, c, ptr(x), ptr(weight), ptr(dy), ptr(dx), ptr(dwb), ptr(scratch),
-             stream_ptr())
+        scratch = _keep(torch.empty(int(_lib.load().igcn_small_linear_bwd_scratch_floats(r, k, c)),
+                                    dtype=torch.float32, device=x.device))
+        with _immediate(ctx.final):
+            call("igcn_small_linear_bwd", r, k, c, ptr(x), ptr(weight), ptr(dy), ptr(dx), ptr(dwb), ptr(scratch),
+                 stream_ptr())
         return dx, dwb[:c * k].view(c, k), (dwb[c * k:] if ctx.has_bias else None)
 
 
@@ -552,13 +627,13 @@ def _small_linear_ok(x2, weight, relu):
             and x2.shape[0] > 0)
 
 
-def linear(x, weight, bias=None, relu=False):
+def linear(x, weight, bias=None, relu=False, bf16=False):
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
-    if _small_linear_ok(x2, weight, relu):
+    if _small_linear_ok(x2, weight, relu) and not bf16:
         y = SmallLinear.apply(x2, weight, bias)
     else:
-        y = Linear.apply(x2, weight, bias, relu)
+        y = Linear.apply(x2, weight, bias, relu, bf16)
     return y.view(*lead, weight.shape[0])
 
 
@@ -700,6 +775,7 @@ class NodesLayerNorm(torch.autograd.Function):
              ptr(mean), ptr(rstd), stream_ptr())
         ctx.save_for_backward(y, gamma, beta, keep, mean, rstd)
         ctx.pool = pool
+        ctx.final = _leaves(gamma, beta)
         return z
 
     @staticmethod
@@ -710,10 +786,11 @@ class NodesLayerNorm(torch.autograd.Function):
         dy = torch.empty_like(y)
         dgb = torch.empty(2, n, dtype=torch.float32, device=y.device)
         lib = _lib.load()
-        scratch = torch.empty(int(lib.igcn_nodes_ln_bwd_scratch_floats(b, f, n)), dtype=torch.float32,
-                              device=y.device)
-        call("igcn_nodes_ln_bwd", b, f, n, ctx.pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean),
-             ptr(rstd), ptr(dz), ptr(dy), ptr(dgb), ptr(scratch), stream_ptr())
+        scratch = _keep(torch.empty(int(lib.igcn_nodes_ln_bwd_scratch_floats(b, f, n)), dtype=torch.float32,
+                                    device=y.device))
+        with _immediate(ctx.final):
+            call("igcn_nodes_ln_bwd", b, f, n, ctx.pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean),
+                 ptr(rstd), ptr(dz), ptr(dy), ptr(dgb), ptr(scratch), stream_ptr())
         return dy, dgb[0], dgb[1], None, None, None
 
 
@@ -731,6 +808,7 @@ class GoDecode(torch.autograd.Function):
              ptr(w_sout), ptr(y), stream_ptr())
         ctx.save_for_backward(x, w_out, w_sout)
         ctx.csr = csr
+        ctx.final = _leaves(w_out, w_sout)
         return y
 
     @staticmethod
@@ -743,10 +821,11 @@ class GoDecode(torch.autograd.Function):
         lib = _lib.load()
         dx = torch.empty_like(x)
         dpar = torch.empty(2 * fout * fin, dtype=torch.float32, device=x.device)
-        scratch = torch.empty(int(lib.igcn_go_decode_bwd_scratch_floats(b, nin, fin, fout)), dtype=torch.float32,
-                              device=x.device)
-        call("igcn_go_decode_bwd", b, nin, nout, fin, fout, ptr(csr.row_ptr), ptr(csr.t_ptr), ptr(csr.t_row),
-             ptr(x), ptr(w_out), ptr(w_sout), ptr(dy), ptr(dx), ptr(dpar), ptr(scratch), stream_ptr())
+        scratch = _keep(torch.empty(int(lib.igcn_go_decode_bwd_scratch_floats(b, nin, fin, fout)),
+                                    dtype=torch.float32, device=x.device))
+        with _immediate(ctx.final):
+            call("igcn_go_decode_bwd", b, nin, nout, fin, fout, ptr(csr.row_ptr), ptr(csr.t_ptr), ptr(csr.t_row),
+                 ptr(x), ptr(w_out), ptr(w_sout), ptr(dy), ptr(dx), ptr(dpar), ptr(scratch), stream_ptr())
         k = fout * fin
         return dx, dpar[:k].view(fout, fin), dpar[k:].view(fout, fin), None
 
@@ -775,6 +854,7 @@ class NodeLinearBN(torch.autograd.Function):
              ptr(rstd), ptr(scratch), stream_ptr())
         ctx.save_for_backward(x, weight, gamma, beta, mean, rstd)
         ctx.training, ctx.groups = int(training), groups
+        ctx.final = _leaves(weight, gamma, beta)
         return out
 
     @staticmethod
@@ -787,10 +867,11 @@ class NodeLinearBN(torch.autograd.Function):
         dev = x.device
         dx, dw = torch.empty_like(x), torch.empty_like(weight)
         dgb = torch.empty(2, n, dtype=torch.float32, device=dev)
-        scratch = torch.empty(int(lib.igcn_node_linear_bn_bwd_scratch_floats(b, f, n, d, ctx.groups)),
-                              dtype=torch.float32, device=dev)
-        call("igcn_node_linear_bn_bwd", b, f, n, d, ctx.groups, ctx.training, ptr(x), ptr(weight), ptr(gamma),
-             ptr(beta), ptr(mean), ptr(rstd), ptr(dout), ptr(dx), ptr(dw), ptr(dgb), ptr(scratch), stream_ptr())
+        scratch = _keep(torch.empty(int(lib.igcn_node_linear_bn_bwd_scratch_floats(b, f, n, d, ctx.groups)),
+                                    dtype=torch.float32, device=dev))
+        with _immediate(ctx.final):
+            call("igcn_node_linear_bn_bwd", b, f, n, d, ctx.groups, ctx.training, ptr(x), ptr(weight), ptr(gamma),
+                 ptr(beta), ptr(mean), ptr(rstd), ptr(dout), ptr(dx), ptr(dw), ptr(dgb), ptr(scratch), stream_ptr())
         return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None
 
 

@@ -39,9 +39,9 @@ class GCNConv(torch.nn.Module):
             self.lin.weight.uniform_(-a, a)
             self.bias.zero_()
 
-    def forward(self, x, plan, coef, relu=False):
+    def forward(self, x, plan, coef, relu=False, bf16=False):
         what, wloop, tstream, sstream = coef
-        h = ops.linear(x, self.lin.weight)
+        h = ops.linear(x, self.lin.weight, bf16=bf16)
         return ops.GcnPropagate.apply(h, what, wloop, self.bias, plan, relu, tstream, sstream)
 
 
@@ -108,6 +108,9 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                                                 dim_snps_atten=dim_att)
         self.batch_norm = torch.nn.BatchNorm1d(num_layers * hidden)       # unused by forward
         self._dropout_enabled = True
+        # BASELINE configs[4]: the dense feature transforms (GCNConv.lin, the attention projections, lin1 /
+        # lin1_regr) with bf16 operands on the matrix cores, fp32 accumulation (igcn_gemm_bf16); default fp32
+        self.bf16_transforms = bool(kwargs.get("bf16_transforms", False))
         # igcn_xattn_* (one fused all-in-LDS VALU kernel per direction) is exact but slower than MFMA-GEMM
         # projections + the matrix-core attention core (igcn_attn_core_*) at B=256 (profiles/): opt-in
         self.fused_cross_attention = os.environ.get("IGCN_FUSED_XATTN", "0") == "1"
@@ -194,8 +197,9 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         # slices is zeros + copy for each and an add (ten launches per step for these two parameters)
         w_q, w_kv = w.split([d, 2 * d])
         b_q, b_kv = bias.split([d, 2 * d])
-        q = ops.linear(query, w_q, b_q)                                      # [B, Lq, D]
-        kv = ops.linear(memory, w_kv, b_kv)                                  # [B, Lk, 2D] = key | value
+        bf = self.bf16_transforms
+        q = ops.linear(query, w_q, b_q, bf16=bf)                             # [B, Lq, D]
+        kv = ops.linear(memory, w_kv, b_kv, bf16=bf)                         # [B, Lk, 2D] = key | value
         if ops.attn_core_supported(d, h, lq, lk):
             o = ops.AttentionCore.apply(q, kv, h)                           # heads addressed in place
         else:
@@ -206,7 +210,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             kvh = kv.view(b, lk, 2, h, hd)
             att = torch.softmax((qh @ kvh[:, :, 0].permute(0, 2, 3, 1)) * (1.0 / math.sqrt(hd)), dim=-1)
             o = (att @ kvh[:, :, 1].transpose(1, 2)).transpose(1, 2).reshape(b, lq, d)
-        return ops.linear(o, mha.out_proj.weight, mha.out_proj.bias, relu=True)      # F.relu(...) of :242, fused
+        return ops.linear(o, mha.out_proj.weight, mha.out_proj.bias, relu=True, bf16=bf)   # F.relu(...) of :242, fused
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, data, temperature=None, device=None, isExplain=False):
@@ -249,10 +253,11 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             x_in, ew_in, snps_in = stack(xs), stack(ews), stack(snps)
         plan_g = plan.replicate(g)
         coef = ops.GcnNorm.apply(ew_in, plan_g)                       # once per pass (PyG: once per layer)
-        h = self.conv1(x_in, plan_g, coef, relu=True)
+        bf = self.bf16_transforms
+        h = self.conv1(x_in, plan_g, coef, relu=True, bf16=bf)
         hs = [h]
         for conv in self.convs:
-            h = conv(h, plan_g, coef, relu=True)
+            h = conv(h, plan_g, coef, relu=True, bf16=bf)
             hs.append(h)
         xcat = ops.concat_cols(hs)
         gb = g * bsz
@@ -289,7 +294,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             else:
                 out_z = (img_out + out_cross) / 2
                 out_lin = torch.cat((out_z, latent), -1)
-        linear_outf = ops.linear(out_lin, self.lin1.weight, self.lin1.bias, relu=True)
+        linear_outf = ops.linear(out_lin, self.lin1.weight, self.lin1.bias, relu=True, bf16=bf)
         logits = ops.linear(self._drop(linear_outf, 0.5), self.lin2.weight, self.lin2.bias)
         if fused_head:
             pass
@@ -298,7 +303,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             feat = torch.cat((out_lin, img_feat if g == 1 else img_feat.repeat(g, 1)), -1)
         else:
             feat = out_lin
-        reg = ops.linear(feat, self.lin1_regr.weight, self.lin1_regr.bias, relu=True)
+        reg = ops.linear(feat, self.lin1_regr.weight, self.lin1_regr.bias, relu=True, bf16=bf)
         our_reg = ops.linear(self._drop(reg, 0.3), self.lin2_regr.weight, self.lin2_regr.bias)
         outs = (F.log_softmax(logits, dim=-1), x_hat, out_z, out_lin, linear_outf, our_reg)
         if not split:

@@ -199,7 +199,7 @@ def _losses_batched(model, data, lam, hp, temperature):
     return loss, t, (logp, x_hat, out_z, out_lin, lin_f, reg)
 
 
-def backward_to_grads(loss, optimizer, data=None):
+def backward_to_grads(loss, optimizer, data=None, defer=False):
     """``loss.backward()`` for the table-mode FlatAdam: the gradients are taken with ``torch.autograd.grad`` and
     assigned to ``.grad`` as they come.  ``backward()`` routes every leaf through AccumulateGrad, which CLONES a
     gradient it cannot steal — and the kernels here hand back several parameter gradients as slices of one flat
@@ -212,8 +212,29 @@ def backward_to_grads(loss, optimizer, data=None):
     leaves = list(params)
     if data is not None and getattr(data, "x", None) is not None and data.x.requires_grad:
         leaves.append(data.x)
-    for t, g in zip(leaves, torch.autograd.grad(loss, leaves, allow_unused=True)):
+    if defer:
+        from . import ops
+        # the small "sum the block partials" launches that end ~30 backward kernels are queued and run as ONE launch
+        # when the block exits: the gradients below are complete only after it.  Only for the batched sweep, where
+        # every parameter enters the graph ONCE — a parameter used twice has its two gradients added by autograd
+        # during the backward, i.e. before the flush.
+        with ops.deferred_reductions():
+            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+    else:
+        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+    for t, g in zip(leaves, grads):
         t.grad = g
+
+
+def _single_use_parameters(model):
+    """True when the step runs both passes as ONE batched sweep (``losses`` picks ``_losses_batched`` /
+    ``forward_pair``): every parameter then enters the autograd graph once, which is what deferring the final
+    gradient reductions needs (``backward_to_grads``).  IGCN_NO_DEFER=1 switches the deferral off (A/B runs)."""
+    if os.environ.get("IGCN_NO_DEFER", "0") == "1" or not getattr(model, "batched_passes", True):
+        return False
+    if hasattr(model, "go_network"):
+        return hasattr(model, "_forward_grouped") and bool(model.isSoftSimilarity)
+    return hasattr(model, "forward_pair")
 
 
 def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None, world_size=1,
@@ -231,7 +252,7 @@ def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temper
     if data.x.grad is not None:
         data.x.grad = None
     loss, _, _ = losses(model, data, lambda_loss, hp, temperature)
-    backward_to_grads(loss, optimizer, data)
+    backward_to_grads(loss, optimizer, data, defer=_single_use_parameters(model))
     if world_size > 1 or comm is not None:
         flat = optimizer.pack_grads()
         if comm is not None:
@@ -350,7 +371,7 @@ class GraphedTrainStep:
             self.plan._copies = {}                      # the replica of the batched sweep is derived in-graph
         self.data.x.grad = None
         loss, _, _ = losses(self.model, self.data, self.lam, self.hp)
-        backward_to_grads(loss, self.opt, self.data)
+        backward_to_grads(loss, self.opt, self.data, defer=_single_use_parameters(self.model))
         return loss.detach()
 
     def _reduce(self):

@@ -136,10 +136,13 @@ int igcn_gcn_norm_bwd(int64_t n_nodes, int64_t n_edges, const float* ew, const f
  *   out[t, :F] = act( sum_{p in group(t)} tstream[p].w * h[tstream[p].idx,:] + what_loop[t]*h[t,:] + bias )
  * summed in the reference's scatter order (non-loop edges in stored order, then the loop).
  * h [N,F] row stride ld_h; out row stride ld_out (so a layer can write its column slice of the JK-concat
- * buffer of :223 directly).  relu != 0 applies max(.,0).  Two launch shapes, picked from the arguments:
+ * buffer of :223 directly).  relu != 0 applies max(.,0).  Three launch shapes, picked from the arguments:
  * thread = (target, feature quad) for low in-degree (brain graphs, k = 3); for an average in-degree >= 16 one wave per
- * target in which every lane moves 16 bytes per memory instruction (F/4 lanes per feature row, 64/(F/4) edge slots).
- * `nodes_per_graph` (uniform graph size, 0 = unknown) is a hint reserved for LDS-staged variants.
+ * target in which every lane moves 16 bytes per memory instruction (F/4 lanes per feature row, 64/(F/4) edge slots);
+ * and, when `nodes_per_graph` (uniform graph size of a block-diagonal batch, 0 = unknown) is given, the average
+ * in-degree is >= 64 and a graph's rows fit 64 KB of LDS (the dense 512-ROI graphs of the stress configuration), a
+ * workgroup per 64 targets of one graph that stages the graph's rows in LDS and streams the 8-byte records from HBM
+ * (two per 16-byte load) — per-target sums then run lane-parallel, not in the sequential scatter order.
  */
 int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, int nodes_per_graph /*0 = unknown*/,
                            const float* h, int64_t ld_h, const void* tstream, const float* what_loop, const float* bias,
@@ -150,7 +153,7 @@ int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, int nodes_pe
  * scratch: igcn_gcn_propagate_bwd_scratch_floats(n_nodes, F) floats (block partials of dbias + the ReLU-masked
  * copy of dout that the per-edge kernels gather). */
 size_t igcn_gcn_propagate_bwd_scratch_floats(int64_t n_nodes, int F);
-int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F,
+int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, int nodes_per_graph /*0 = unknown*/,
                            const float* dout, int64_t ld_dout, const float* out, int64_t ld_out, int relu,
                            const float* h, int64_t ld_h, const void* sstream, const float* what_loop,
                            const int32_t* src32, const int32_t* dst32, const int32_t* src_ptr,
@@ -201,6 +204,11 @@ int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, const float* d
  * tensors; `parts` is a HOST array of device pointers. */
 int igcn_concat_cols(int64_t rows, int F, int nparts, const float* const* parts, float* out, void* stream);
 
+/* Measurement aid (bench.py roofline): the launch of igcn_gcn_propagate_fwd for (n_nodes, F) — thread =
+ * (target, feature quad), or one wave per target when `dense` — with the body removed: mode 0 = empty kernel,
+ * mode 1 = only the 16-byte store of each output row.  What the dispatch of that grid costs when no byte is read. */
+int igcn_launch_floor(int64_t n_nodes, int F, int dense, int mode, float* out, void* stream);
+
 /* Graph read-out of the `graph_pool=True` branch (kernel/sgcn_img_snp.py:230-235,246-252): PyG 2.0.2
  * global_mean_pool | global_max_pool | global_add_pool over the nodes of each graph, concatenated.  Uniform graphs of
  * `nodes_per_graph` nodes (the model's contract): x [n_graphs*nodes_per_graph, D] -> out [n_graphs, 3*D].
@@ -219,13 +227,25 @@ size_t igcn_bias_grad_scratch_floats(int64_t rows, int cols);
 int igcn_bias_grad(int64_t rows, int cols, const float* dy, const float* y, float* g, float* db, float* scratch,
                    void* stream);
 
-/* The split the library's launch heuristic prefers for (M, N, K): callers size `scratch` with it and pass it as
+/* `act`: 0 = none, 1 = ReLU; bit 0x100 = the output is a final parameter gradient (deferred reductions, below).
+ * The split the library's launch heuristic prefers for (M, N, K): callers size `scratch` with it and pass it as
  * `split_k` (any other value >= 1 is honoured too). */
 int igcn_gemm_f32_split_k(int64_t M, int64_t N, int64_t K);
 int igcn_gemm_f32(int64_t M, int64_t N, int64_t K,
                   const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
                   const float* bias, float* C, int64_t ldc, int act, int split_k, float* scratch,
                   void* stream);
+
+/* The same product with bf16 operands (BASELINE configs[4]: "bf16 feature transforms on CDNA4 MFMA"): A and B are
+ * rounded to bf16 (round-to-nearest-even) while they are staged into LDS, multiplied on v_mfma_f32_16x16x32_bf16,
+ * accumulated and written in fp32.  Tensors stay fp32 in memory: same arguments, launch shapes and split-K
+ * convention as igcn_gemm_f32, so a model flag swaps the two (GCNConv.lin, the attention projections, lin1 /
+ * lin1_regr of kernel/sgcn_img_snp.py:34-84,239-241).  Exact w.r.t. an fp64 product of the bf16-rounded operands up
+ * to fp32 accumulation order. */
+int igcn_gemm_bf16(int64_t M, int64_t N, int64_t K,
+                   const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
+                   const float* bias, float* C, int64_t ldc, int act, int split_k, float* scratch,
+                   void* stream);
 
 /* Batched-sum variant: C = sum_z A_z . B_z^T with A_z = A + z*a_batch, B_z = B + z*b_batch (element offsets),
  * every z covering the whole K; slabs are summed in z order.  Used for weight gradients whose reduction index is
@@ -422,6 +442,18 @@ int igcn_adam_step_multi(int n_tensors, const int64_t* table, const int64_t* num
                          float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_t* numel, const int64_t* offset,
                     float* flat, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Deferred reductions of a backward pass.  About thirty kernels of the train step's backward end in a small "sum the
+ * block partials" launch whose output is a parameter gradient that nothing reads before the optimiser (bias and
+ * LayerNorm / BatchNorm affine gradients, split-K weight-gradient slabs, ...).  After igcn_reduce_defer(1) those
+ * launches are QUEUED instead (process-wide; the partial buffers — the `scratch` arguments of the calls — must then
+ * stay alive until the flush), and igcn_reduce_flush(stream) performs every queued reduction in ONE launch, with the
+ * arithmetic and summation order of the stand-alone kernels.  igcn_gemm_f32 / igcn_gemm_bf16 take part when bit 0x100
+ * of `act` marks their output as such a gradient.  Host-side state only: capturable like any other launch. */
+int igcn_reduce_defer(int on);
+int igcn_reduce_pending(void);
+int igcn_reduce_flush(void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Gradient exchange of the data-parallel step (the reference has no multi-GPU code): one RCCL

@@ -601,3 +601,33 @@ def test_model_on_builder_output_vs_oracle(golden, tmp_path):
     for n, o, r in zip(NAMES, outs, ref):
         assert_matches(o, r.detach().numpy(), 1e-4, n)
     assert_matches(data.x.grad, dcpu.x.grad.numpy(), 3e-3, "grad data.x")
+
+
+def test_deferred_reductions_give_the_same_gradients(golden):
+    """backward_to_grads(defer=True) queues the ~30 final "sum the block partials" launches of the backward and runs
+    them as ONE launch (igcn_reduce_flush): same arithmetic, same summation order => bit-identical gradients."""
+    from igcn_amd import _lib
+    from igcn_amd.data import Batch
+    from igcn_amd.train import FlatAdam, backward_to_grads, losses, _single_use_parameters
+    store = golden("full_b32")
+    model, graphs, seed = _full_model(store)
+    model.train(True)
+    assert _single_use_parameters(model)
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    got = []
+    for defer in (False, True):
+        data = Batch.from_data_list(graphs).to("cuda")
+        opt.zero_grad()
+        loss, _, _ = losses(model, data, store["lam"].tolist())
+        backward_to_grads(loss, opt, data, defer=defer)
+        assert _lib.load().igcn_reduce_pending() == 0
+        got.append({k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()})
+        got[-1]["data.x"] = data.x.grad.clone()
+    n_grads = 0
+    for k, g in got[0].items():
+        if g is None:
+            assert got[1][k] is None, k
+            continue
+        n_grads += 1
+        assert torch.equal(g, got[1][k]), k
+    assert n_grads > 40

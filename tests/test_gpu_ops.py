@@ -149,6 +149,27 @@ def test_gemm_nt_nn_tn(ops, m, n, k):
     assert_matches(ops.gemm_tn(dy.cuda(), a.cuda()), (dy.double().t() @ a.double()).numpy(), TOL, "TN")
 
 
+@pytest.mark.parametrize("m,n,k", [(23040, 16, 3), (32768, 16, 16), (256, 64, 2912), (64, 64, 16416), (83200, 64, 32),
+                                   (100, 37, 50), (1000, 32, 64)])
+def test_gemm_bf16_operands_fp32_accumulate(ops, m, n, k):
+    """igcn_gemm_bf16 (BASELINE configs[4]): exact w.r.t. the fp64 product of the bf16-ROUNDED operands up to fp32
+    accumulation order — and within the bf16 rounding bound of the unrounded product."""
+    rng = np.random.default_rng(m + n + k)
+    a = torch.from_numpy(rng.standard_normal((m, k))).float()
+    b = torch.from_numpy(rng.standard_normal((n, k))).float()
+    bias = torch.from_numpy(rng.standard_normal(n)).float()
+    r = lambda t: t.bfloat16().double()                                       # noqa: E731  (round-to-nearest-even)
+    want = r(a) @ r(b).t() + bias.double()
+    got = ops.gemm_nt(a.cuda(), b.cuda(), bias.cuda(), 0, bf16=True)
+    assert_matches(got, want.numpy(), 2e-5, "NT bf16")
+    exact = a.double() @ b.double().t() + bias.double()
+    assert_matches(got, exact.numpy(), 2.0 ** -7, "NT vs unrounded")
+    assert_matches(ops.gemm_nt(a.cuda(), b.cuda(), bias.cuda(), 1, bf16=True), torch.relu(want).numpy(), 2e-5, "relu")
+    dy = torch.from_numpy(rng.standard_normal((m, n))).float()
+    assert_matches(ops.gemm_nn(dy.cuda(), b.cuda(), bf16=True), (r(dy) @ r(b)).numpy(), 2e-5, "NN bf16")
+    assert_matches(ops.gemm_tn(dy.cuda(), a.cuda(), bf16=True), (r(dy).t() @ r(a)).numpy(), 2e-5, "TN bf16")
+
+
 @pytest.mark.parametrize("rows,fin,fout,relu,bias", [(512, 64, 3, False, True), (512, 2912, 64, True, True),
                                                      (46080, 16, 32, False, True), (1000, 7, 12, True, True),
                                                      (300, 5, 64, True, False), (70000, 32, 64, False, True),
@@ -621,6 +642,52 @@ def test_propagate_dense_graph_variants(ops, hint):
     coef = ops.GcnNorm.apply(ew.cuda(), plan)
     out = ops.GcnPropagate.apply(x.cuda(), coef[0], coef[1], b.cuda(), plan, True, coef[2], coef[3])
     assert_matches(out, want.numpy(), TOL, "out")
+
+
+@pytest.mark.parametrize("g,r,f,density,cross", [(3, 64, 16, 1.0, False), (2, 200, 16, 0.9, False),
+                                                 (2, 130, 8, 1.0, False), (2, 70, 64, 1.0, False),
+                                                 (3, 96, 4, 0.8, False), (2, 128, 32, 1.0, True)])
+def test_propagate_lds_staged_dense_fwd_bwd(ops, monkeypatch, g, r, f, density, cross):
+    """The LDS-staged scatter-aggregate for dense uniform batches (igcn_gcn_propagate_{fwd,bwd} with the
+    nodes_per_graph hint, average in-degree >= 64): forward, dh, dbias and the coefficient gradients against the fp64
+    oracle and against the wave-per-target kernels (IGCN_PROPAGATE_NO_LDS=1).  `density` < 1 gives ragged lists (odd
+    record offsets: the 16-byte record loads start on an even position and mask the neighbour's record); `cross`
+    adds edges BETWEEN graphs, which the staged rows do not cover (global-row fallback)."""
+    from oracle import pyg_ops
+    rng = np.random.default_rng(g * 1000 + r + f)
+    src, dst = [], []
+    for k in range(g):
+        m = rng.random((r, r)) < density
+        rr, cc = np.nonzero(m)
+        src.append(rr + k * r)
+        dst.append(cc + k * r)
+    if cross:
+        src.append(rng.integers(0, r, 300)), dst.append(rng.integers(r, 2 * r, 300))
+    ei = torch.from_numpy(np.vstack([np.concatenate(src), np.concatenate(dst)])).long()
+    ew = torch.from_numpy(rng.random(ei.shape[1]) / r + 0.01).float()
+    x = torch.from_numpy(rng.standard_normal((g * r, f))).float()
+    b = torch.from_numpy(rng.standard_normal(f)).float()
+    cot = torch.from_numpy(rng.standard_normal((g * r, f))).float()
+    xd, ewd, bd = x.double().requires_grad_(True), ew.double().requires_grad_(True), b.double().requires_grad_(True)
+    want = torch.relu(pyg_ops.gcn_conv(xd, ei, ewd, torch.eye(f, dtype=torch.float64), bd))
+    (want * cot.double()).sum().backward()
+
+    def run():
+        plan = ops.GraphPlan(ei.cuda(), g * r)
+        plan.nodes_per_graph = r
+        xg, ewg, bg = x.cuda().requires_grad_(True), ew.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        coef = ops.GcnNorm.apply(ewg, plan)
+        out = ops.GcnPropagate.apply(xg, coef[0], coef[1], bg, plan, True, coef[2], coef[3])
+        (out * cot.cuda()).sum().backward()
+        return out.detach(), xg.grad, ewg.grad, bg.grad
+
+    assert ei.shape[1] >= 64 * g * r                     # the shape that selects the LDS-staged kernels
+    got = run()
+    monkeypatch.setenv("IGCN_PROPAGATE_NO_LDS", "1")
+    ref = run()
+    for name, a, c, w in zip(("out", "dh", "dew", "dbias"), got, ref, (want.detach(), xd.grad, ewd.grad, bd.grad)):
+        assert_matches(a, w.numpy(), TOL, name + " vs oracle")
+        assert_matches(a, c.cpu().numpy(), 2e-5, name + " vs wave-per-target kernels")
 
 
 @pytest.mark.parametrize("bsz,lq,lk,d", [(3, 10, 9, 8), (4, 90, 400, 32), (2, 130, 77, 16), (5, 90, 45, 32),
