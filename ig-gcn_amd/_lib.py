@@ -31,6 +31,10 @@ SIGNATURES = {
     "igcn_gcn_propagate_fwd": (I, [L, L, I, I, P, L, P, P, P, P, P, L, I, P]),
     "igcn_gcn_propagate_bwd_scratch_floats": (Z, [L, I]),
     "igcn_gcn_propagate_bwd": (I, [L, L, I, I, P, L, P, L, I, P, L, P, P, P, P, P, P, L, P, I, P, P, P, P]),
+    "igcn_sgcn_stack_lds_bytes": (Z, [I, I, I, I, I, I]),
+    "igcn_sgcn_stack_param_floats": (I, [I, I, I]),
+    "igcn_sgcn_stack_fwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_sgcn_stack_bwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_small_linear_bwd_scratch_floats": (Z, [L, I, I]),
     "igcn_small_linear_fwd": (I, [L, I, I, P, P, P, P, P]),
     "igcn_small_linear_bwd": (I, [L, I, I, P, P, P, P, P, P, P]),

@@ -1,0 +1,453 @@
+// The SGCN stack of one brain graph, LDS-resident: gcn_norm + L x (X W^T, scatter-aggregate, + bias, ReLU) + the
+// jumping-knowledge concatenation of kernel/sgcn_img_snp.py:218-224 (PyG GCNConv x L) as ONE
+// kernel per direction, one 512-thread workgroup per graph.
+//
+// A 90-ROI graph is tiny (90 x 3 inputs, 270 edges, 90 x 16 activations per layer): as separate launches (norm x 2,
+// GEMM + aggregate per layer, concat; a dozen more backward) every kernel sits on the dispatch floor and the
+// activations make an HBM / L2 round trip between each pair.  Here the graph's node features, edge lists and
+// coefficients are staged in LDS once, every layer runs out of LDS, and HBM sees the compulsory traffic only:
+// x, the edge list and its weights in; the concatenated layer outputs out (SURVEY §8d "fused SGCN forward lower bound").
+// The backward kernel recomputes the forward in LDS (cheaper than saving it) and writes dx, d(edge weight) and one
+// row of parameter-gradient partials per graph.
+//
+// Preconditions (checked by the host wrappers / guaranteed by the per-graph plan builders): a block-diagonal batch of
+// uniform graphs (R nodes each, graph g = nodes [gR, (g+1)R), its edges contiguous in stored order), edge lists
+// from the graph plan.  Sums run in the plan's stable (reference scatter) order; no atomics: deterministic.
+#include "common.h"
+
+// threads per workgroup (= per graph).  The kernels are chains of ~20 barrier-separated phases over ~1.5 k work items;
+// measured at the bench shape (512 graphs, hot): forward 16.7 / 12.6 / 12.3 us and backward 52 / 40 / 53 us with
+// 256 / 512 / 1024 threads.
+#define SF_T 512           // forward
+#define SF_TB 512          // backward
+#define SF_MAXL 4
+#define SF_MAXH0 8
+
+struct SfParams {
+  const float* W[SF_MAXL];     // W_l [F, Fin_l] row-major (Fin_0 = H0, then F)
+  const float* b[SF_MAXL];     // b_l [F]
+};
+
+// LDS carve-out shared by both kernels (all offsets in 4-byte words)
+struct SfLayout {
+  int x, dis, wl, wloop, ew, what, src, dst, tptr, tperm, w, bias, act, wall, loop;   // forward part
+  int ycat;                                                                             // [R][L*F] layer outputs
+  int sptr, sperm, g, dh, dx, dwhat, dwloop, ddeg, red, dycat, prow;     // backward part
+  int total;
+};
+
+__host__ __device__ inline SfLayout sf_layout(int R, int Emax, int H0, int F, int L, int backward) {
+  SfLayout o;
+  int p = 0;
+  auto take = [&](int n) { int q = p; p += (n + 3) & ~3; return q; };
+  const int fin_max = F > H0 ? F : H0;
+  o.x = take(R * H0);
+  o.dis = take(R);
+  o.wl = take(R);
+  o.wloop = take(R);
+  o.ew = take(Emax);
+  o.what = take(Emax);
+  o.src = take(Emax);
+  o.dst = take(Emax);
+  o.tptr = take(R + 1);
+  o.tperm = take(Emax);
+  o.w = take(F * fin_max);
+  o.bias = take(F);
+  o.wall = take(L * (F * fin_max + F));            // every layer's W_l | b_l, fetched with the graph (one round trip)
+  o.loop = take(R);
+  // activations: the transforms H_l (the forward keeps the current one only, the backward all of them) and the
+  // concatenated layer outputs Y [R][L*F], which leave for HBM in ONE coalesced pass at the end — a store in front of
+  // a barrier makes the whole workgroup wait for its acknowledgement, so nothing is stored before the last barrier
+  o.act = take((backward ? L : 1) * R * F);
+  o.ycat = take(R * L * F);
+  o.sptr = o.sperm = o.g = o.dh = o.dx = o.dwhat = o.dwloop = o.ddeg = o.red = o.dycat = o.prow = 0;
+  if (backward) {
+    o.sptr = take(R + 1);
+    o.sperm = take(Emax);
+    o.g = take(R * F);
+    o.dh = take(R * F);
+    o.dx = take(R * fin_max);
+    o.dwhat = take(Emax);
+    o.dwloop = take(R);
+    o.ddeg = take(R);
+    o.red = take(SF_TB + (SF_TB > F * fin_max ? SF_TB : F * fin_max));
+    o.dycat = take(R * L * F);
+    o.prow = take(L * (F * fin_max + F));
+  }
+  o.total = p;
+  return o;
+}
+
+extern "C" size_t igcn_sgcn_stack_lds_bytes(int R, int max_edges, int H0, int F, int L, int backward) {
+  return (size_t)sf_layout(R, max_edges, H0, F, L, backward).total * 4;
+}
+
+// stage the graph: node features, edges (local endpoints, weights), lists, and the gcn_norm coefficients
+template <bool BWD>
+__device__ __forceinline__ void sf_stage(float* lds, const SfLayout& o, int R, int H0, int64_t nb, int32_t eb, int ne,
+                                         const float* __restrict__ x_in, const float* __restrict__ ew_in,
+                                         const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
+                                         const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
+                                         const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_perm,
+                                         const int32_t* __restrict__ loop_edge, const SfParams& prm, int F, int L) {
+  const int tid = threadIdx.x;
+  const int wstride = F * (F > H0 ? F : H0) + F;
+  for (int l = 0; l < L; ++l) {
+    const int fin = l == 0 ? H0 : F;
+    for (int i = tid; i < F * fin; i += (int)blockDim.x) lds[o.wall + l * wstride + i] = prm.W[l][i];
+    for (int i = tid; i < F; i += (int)blockDim.x) lds[o.wall + l * wstride + F * fin + i] = prm.b[l][i];
+  }
+  for (int i = tid; i < R; i += (int)blockDim.x) reinterpret_cast<int32_t*>(lds + o.loop)[i] = loop_edge[nb + i];
+  int32_t* ssrc = reinterpret_cast<int32_t*>(lds + o.src);
+  int32_t* sdst = reinterpret_cast<int32_t*>(lds + o.dst);
+  int32_t* stptr = reinterpret_cast<int32_t*>(lds + o.tptr);
+  int32_t* stperm = reinterpret_cast<int32_t*>(lds + o.tperm);
+  for (int i = tid; i < R * H0; i += (int)blockDim.x) lds[o.x + i] = x_in[nb * H0 + i];
+  for (int k = tid; k < ne; k += (int)blockDim.x) {
+    ssrc[k] = src32[eb + k] - (int32_t)nb;
+    sdst[k] = dst32[eb + k] - (int32_t)nb;
+    lds[o.ew + k] = ew_in[eb + k];
+    stperm[k] = tgt_perm[eb + k] - eb;             // by-target position eb + k holds edge tgt_perm[.] of this graph
+    if (BWD) reinterpret_cast<int32_t*>(lds + o.sperm)[k] = src_perm[eb + k] - eb;
+  }
+  for (int i = tid; i <= R; i += (int)blockDim.x) {
+    stptr[i] = tgt_ptr[nb + i] - eb;
+    if (BWD) reinterpret_cast<int32_t*>(lds + o.sptr)[i] = src_ptr[nb + i] - eb;
+  }
+  __syncthreads();
+  // gcn_norm (PyG: drop stored loops, add one loop per node whose weight is the LAST stored loop's or 1)
+  for (int i = tid; i < R; i += (int)blockDim.x) {
+    float deg = 0.f;
+    for (int p = stptr[i]; p < stptr[i + 1]; ++p) {
+      const int k = stperm[p];
+      if (ssrc[k] != i) deg += lds[o.ew + k];
+    }
+    const int32_t le = reinterpret_cast<const int32_t*>(lds + o.loop)[i];
+    const float lw = le >= 0 ? lds[o.ew + (le - eb)] : 1.f;
+    deg += lw;
+    float d = 1.0f / sqrtf(deg);
+    if (deg == 0.f) d = 0.f;
+    lds[o.dis + i] = d;
+    lds[o.wl + i] = lw;
+    lds[o.wloop + i] = d * lw * d;
+  }
+  __syncthreads();
+  for (int k = tid; k < ne; k += (int)blockDim.x) {
+    const int s = ssrc[k], t = sdst[k];
+    lds[o.what + k] = s != t ? lds[o.dis + s] * lds[o.ew + k] * lds[o.dis + t] : 0.f;
+  }
+  // (the caller's next __syncthreads() orders `what` before its first use)
+}
+
+// H = X W^T (X [R, fin], row stride ldx, at `xin`), then Y = relu(A_hat H + b) (row stride ldy): one layer, out of LDS
+// into LDS
+template <int F>
+__device__ __forceinline__ void sf_layer(float* lds, const SfLayout& o, int R, int fin, const float* xin, int ldx,
+                                         float* H, float* Y, int ldy, const float* Wg, const float* bg) {
+  const int tid = threadIdx.x;
+  const int32_t* ssrc = reinterpret_cast<const int32_t*>(lds + o.src);
+  const int32_t* stptr = reinterpret_cast<const int32_t*>(lds + o.tptr);
+  const int32_t* stperm = reinterpret_cast<const int32_t*>(lds + o.tperm);
+  // weights TRANSPOSED in LDS (Wt[fi][fo]): the F lanes of a node read consecutive words, not a stride-fin column
+  for (int i = tid; i < F * fin; i += (int)blockDim.x) lds[o.w + (i % fin) * F + i / fin] = Wg[i];
+  for (int i = tid; i < F; i += (int)blockDim.x) lds[o.bias + i] = bg[i];
+  __syncthreads();
+  for (int e = tid; e < R * F; e += (int)blockDim.x) {
+    const int i = e / F, fo = e - i * F;
+    float acc = 0.f;
+    for (int fi = 0; fi < fin; ++fi) acc += xin[i * ldx + fi] * lds[o.w + fi * F + fo];
+    H[e] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < R * F; e += (int)blockDim.x) {
+    const int i = e / F, fo = e - i * F;
+    float acc = 0.f;
+    for (int p = stptr[i]; p < stptr[i + 1]; ++p) {          // stored order of the target's edges (reference order)
+      const int k = stperm[p];
+      acc += lds[o.what + k] * H[ssrc[k] * F + fo];
+    }
+    acc += lds[o.wloop + i] * H[e];
+    acc += lds[o.bias + fo];
+    Y[i * ldy + fo] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+}
+
+template <int F>
+__global__ void __launch_bounds__(SF_T)
+k_sgcn_stack_fwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in, const float* __restrict__ ew_in,
+                 const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
+                 const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
+                 const int32_t* __restrict__ loop_edge, SfParams prm, float* __restrict__ xcat) {
+  extern __shared__ float sf_lds[];
+  const SfLayout o = sf_layout(R, Emax, H0, F, L, 0);
+  const int64_t nb = (int64_t)blockIdx.x * R;
+  const int32_t eb = tgt_ptr[nb];
+  const int ne = tgt_ptr[nb + R] - eb;
+  if (ne > Emax) return;                               // host-checked; never corrupt LDS
+  sf_stage<false>(sf_lds, o, R, H0, nb, eb, ne, x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, nullptr, nullptr,
+                  loop_edge, prm, F, L);
+  float* H = sf_lds + o.act;
+  float* Y = sf_lds + o.ycat;
+  const int D = L * F;
+  for (int l = 0; l < L; ++l) {
+    // layer l owns columns [l F, (l+1) F) of the concatenated output rows and reads the columns of layer l-1
+    const float* wl = sf_lds + o.wall + l * (F * (F > H0 ? F : H0) + F);
+    sf_layer<F>(sf_lds, o, R, l == 0 ? H0 : F, l == 0 ? sf_lds + o.x : Y + (l - 1) * F, l == 0 ? H0 : D, H, Y + l * F, D,
+                wl, wl + F * (l == 0 ? H0 : F));
+  }
+  // jumping-knowledge concatenation: the rows are already laid out [R][L F] — one coalesced 16-byte pass
+  for (int e = threadIdx.x; e < R * D / 4; e += SF_T)
+    reinterpret_cast<float4*>(xcat + nb * D)[e] = reinterpret_cast<const float4*>(Y)[e];
+}
+
+// parameter-gradient partial row of one graph: [ dW_0 (F x H0) | db_0 (F) | dW_1 (F x F) | db_1 | ... ]
+__host__ __device__ inline int sf_param_offset(int l, int H0, int F) {
+  return l == 0 ? 0 : (F * H0 + F) + (l - 1) * (F * F + F);
+}
+
+extern "C" int igcn_sgcn_stack_param_floats(int H0, int F, int L) { return sf_param_offset(L, H0, F); }
+
+template <int F>
+__global__ void __launch_bounds__(SF_TB)
+k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in, const float* __restrict__ ew_in,
+                 const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
+                 const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
+                 const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_perm,
+                 const int32_t* __restrict__ loop_edge, SfParams prm, const float* __restrict__ dxcat,
+                 float* __restrict__ dx_in, float* __restrict__ dew_in, float* __restrict__ dpar_partial, int P) {
+  extern __shared__ float sf_lds[];
+  const SfLayout o = sf_layout(R, Emax, H0, F, L, 1);
+  const int tid = threadIdx.x;
+  const int64_t nb = (int64_t)blockIdx.x * R;
+  const int32_t eb = tgt_ptr[nb];
+  const int ne = tgt_ptr[nb + R] - eb;
+  if (ne > Emax) return;
+  sf_stage<true>(sf_lds, o, R, H0, nb, eb, ne, x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm,
+                 loop_edge, prm, F, L);
+  const int32_t* ssrc = reinterpret_cast<const int32_t*>(sf_lds + o.src);
+  const int32_t* sdst = reinterpret_cast<const int32_t*>(sf_lds + o.dst);
+  const int32_t* ssptr = reinterpret_cast<const int32_t*>(sf_lds + o.sptr);
+  const int32_t* ssperm = reinterpret_cast<const int32_t*>(sf_lds + o.sperm);
+  const int D = L * F;
+  // the incoming gradient rows travel with the staging loads (one round trip), not one layer at a time
+  for (int e = tid; e < R * D / 4; e += SF_TB)
+    reinterpret_cast<float4*>(sf_lds + o.dycat)[e] = reinterpret_cast<const float4*>(dxcat + nb * D)[e];
+  // ---- forward, every transform kept: H_l at act + l R F; outputs in the concatenated layout
+  float* Ycat = sf_lds + o.ycat;
+  for (int l = 0; l < L; ++l) {
+    const float* wl = sf_lds + o.wall + l * (F * (F > H0 ? F : H0) + F);
+    sf_layer<F>(sf_lds, o, R, l == 0 ? H0 : F, l == 0 ? sf_lds + o.x : Ycat + (l - 1) * F, l == 0 ? H0 : D,
+                sf_lds + o.act + l * R * F, Ycat + l * F, D, wl, wl + F * (l == 0 ? H0 : F));
+  }
+  for (int k = tid; k < ne; k += SF_TB) sf_lds[o.dwhat + k] = 0.f;
+  for (int i = tid; i < R; i += SF_TB) sf_lds[o.dwloop + i] = 0.f;
+  float* G = sf_lds + o.g;
+  float* dH = sf_lds + o.dh;
+  float* dX = sf_lds + o.dx;
+  float* prow = sf_lds + o.prow;                       // this graph's parameter-gradient row, stored at the very end
+  // ---- backward, last layer first.  Sums over the graph's nodes (db, dW) are split over thread groups whose
+  // partials meet in `red` (db) / `red + SF_TB` (dW) behind the next barrier; the dW partials of a layer are summed
+  // at the top of the next iteration (or after the loop).
+  float* red_db = sf_lds + o.red;
+  float* red_dw = sf_lds + o.red + SF_TB;
+  int pend_off = -1, pend_n = 0, pend_parts = 0;       // dW partials waiting in red_dw
+  for (int l = L - 1; l >= 0; --l) {
+    const int fin = l == 0 ? H0 : F;
+    const float* H = sf_lds + o.act + l * R * F;
+    const float* Y = Ycat + l * F;                     // row stride D
+    const float* xin = l == 0 ? sf_lds + o.x : Ycat + (l - 1) * F;
+    const int ldx = l == 0 ? H0 : D;
+    if (pend_off >= 0)                                 // dW of the layer above
+      for (int e = tid; e < pend_n; e += SF_TB) {
+        float acc = 0.f;
+        for (int p2 = 0; p2 < pend_parts; ++p2) acc += red_dw[p2 * pend_n + e];
+        prow[pend_off + e] = acc;
+      }
+    // G = (d xcat[:, l] + d X_l from the layer above) * [Y_l > 0]
+    for (int e = tid; e < R * F; e += SF_TB) {
+      const int i = e / F, fo = e - i * F;
+      float g = sf_lds[o.dycat + i * D + l * F + fo];
+      if (l < L - 1) g += dX[e];
+      G[e] = Y[i * D + fo] > 0.f ? g : 0.f;
+    }
+    for (int i = tid; i < F * fin; i += SF_TB)                                      // W_l [fo][fi] for dX = dH W
+      sf_lds[o.w + i] = sf_lds[o.wall + l * (F * (F > H0 ? F : H0) + F) + i];
+    __syncthreads();
+    // dH = A_hat^T G (by-source lists); coefficient gradients accumulate over the layers
+    for (int e = tid; e < R * F; e += SF_TB) {
+      const int s = e / F, fo = e - s * F;
+      float acc = 0.f;
+      for (int p = ssptr[s]; p < ssptr[s + 1]; ++p) {
+        const int k = ssperm[p];
+        acc += sf_lds[o.what + k] * G[sdst[k] * F + fo];
+      }
+      acc += sf_lds[o.wloop + s] * G[e];
+      dH[e] = acc;
+    }
+    for (int k = tid; k < ne; k += SF_TB) {
+      const int s = ssrc[k], t = sdst[k];
+      if (s == t) continue;
+      float acc = 0.f;
+#pragma unroll
+      for (int fo = 0; fo < F; ++fo) acc += G[t * F + fo] * H[s * F + fo];
+      sf_lds[o.dwhat + k] += acc;
+    }
+    for (int i = tid; i < R; i += SF_TB) {
+      float acc = 0.f;
+#pragma unroll
+      for (int fo = 0; fo < F; ++fo) acc += G[i * F + fo] * H[i * F + fo];
+      sf_lds[o.dwloop + i] += acc;
+    }
+    constexpr int DB_PARTS = SF_TB / F < 16 ? SF_TB / F : 16;
+    if (tid < DB_PARTS * F) {                          // bias gradient: 16 thread groups share the node range
+      const int fo = tid % F, part = tid / F;
+      float acc = 0.f;
+      for (int i = part; i < R; i += DB_PARTS) acc += G[i * F + fo];
+      red_db[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < F) {
+      float acc = 0.f;
+#pragma unroll
+      for (int p2 = 0; p2 < DB_PARTS; ++p2) acc += red_db[p2 * F + tid];
+      prow[sf_param_offset(l, H0, F) + F * fin + tid] = acc;
+    }
+    // dW_l = dH^T X_{l-1} (partials)   and   dX_{l-1} = dH W_l
+    {
+      const int n_out = F * fin;
+      int parts = SF_TB / n_out;
+      parts = parts > 16 ? 16 : (parts < 1 ? 1 : parts);
+      for (int idx = tid; idx < parts * n_out; idx += SF_TB) {
+        const int e = idx % n_out, part = idx / n_out;
+        const int fo = e / fin, fi = e - fo * fin;
+        float acc = 0.f;
+        for (int i = part; i < R; i += parts) acc += dH[i * F + fo] * xin[i * ldx + fi];
+        red_dw[idx] = acc;
+      }
+      pend_off = sf_param_offset(l, H0, F);
+      pend_n = n_out;
+      pend_parts = parts;
+    }
+    for (int e = tid; e < R * fin; e += SF_TB) {
+      const int i = e / fin, fi = e - i * fin;
+      float acc = 0.f;
+#pragma unroll
+      for (int fo = 0; fo < F; ++fo) acc += dH[i * F + fo] * sf_lds[o.w + fo * fin + fi];
+      dX[e] = acc;                                    // layer 0: d x_in, stored after the last barrier
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < pend_n; e += SF_TB) {          // dW of layer 0
+    float acc = 0.f;
+    for (int p2 = 0; p2 < pend_parts; ++p2) acc += red_dw[p2 * pend_n + e];
+    prow[pend_off + e] = acc;
+  }
+  // ---- gcn_norm backward (k_gcn_norm_bwd_deg / _edge of sgcn.hip, per graph)
+  const int32_t* stptr = reinterpret_cast<const int32_t*>(sf_lds + o.tptr);
+  const int32_t* stperm = reinterpret_cast<const int32_t*>(sf_lds + o.tperm);
+  for (int i = tid; i < R; i += SF_TB) {
+    float dd = 0.f;
+    for (int p = ssptr[i]; p < ssptr[i + 1]; ++p) {
+      const int k = ssperm[p];
+      const int t = sdst[k];
+      if (t != i) dd += sf_lds[o.dwhat + k] * sf_lds[o.ew + k] * sf_lds[o.dis + t];
+    }
+    for (int p = stptr[i]; p < stptr[i + 1]; ++p) {
+      const int k = stperm[p];
+      const int s = ssrc[k];
+      if (s != i) dd += sf_lds[o.dwhat + k] * sf_lds[o.ew + k] * sf_lds[o.dis + s];
+    }
+    const float di = sf_lds[o.dis + i];
+    dd += 2.f * sf_lds[o.dwloop + i] * sf_lds[o.wl + i] * di;
+    sf_lds[o.ddeg + i] = -0.5f * di * di * di * dd;
+  }
+  __syncthreads();
+  for (int k = tid; k < ne; k += SF_TB) {
+    const int s = ssrc[k], t = sdst[k];
+    float g;
+    if (s != t) {
+      g = sf_lds[o.dis + s] * sf_lds[o.dis + t] * sf_lds[o.dwhat + k] + sf_lds[o.ddeg + t];
+    } else {
+      g = (reinterpret_cast<const int32_t*>(sf_lds + o.loop)[s] == eb + k) ? sf_lds[o.ddeg + s] + sf_lds[o.dis + s] * sf_lds[o.dis + s] * sf_lds[o.dwloop + s]
+                                        : 0.f;
+    }
+    dew_in[eb + k] = g;
+  }
+  for (int e = tid; e < R * H0; e += SF_TB) dx_in[nb * H0 + e] = dX[e];
+  for (int e = tid; e < P; e += SF_TB) dpar_partial[(int64_t)blockIdx.x * P + e] = prow[e];
+}
+
+static int sf_check(const char* nm, int64_t n_graphs, int R, int max_edges, int H0, int F, int L, int backward) {
+  IGCN_REQUIRE(n_graphs > 0 && R > 0 && max_edges >= 0 && H0 >= 1 && H0 <= SF_MAXH0 && L >= 1 && L <= SF_MAXL,
+               "%s: bad sizes (1 <= H0 <= %d, 1 <= L <= %d)", nm, SF_MAXH0, SF_MAXL);
+  if (!(F == 4 || F == 8 || F == 16 || F == 32) ||
+      igcn_sgcn_stack_lds_bytes(R, max_edges, H0, F, L, backward) > 150 * 1024) {
+    igcn_set_error("%s: needs F in {4, 8, 16, 32} and a graph that fits 150 KB of LDS (R=%d, E<=%d, F=%d, L=%d)", nm,
+                   R, max_edges, F, L);
+    return IGCN_ERR_UNSUPPORTED;
+  }
+  return IGCN_OK;
+}
+
+extern "C" int igcn_sgcn_stack_fwd(int64_t n_graphs, int R, int max_edges, int H0, int F, int L, const float* x_in,
+                                   const float* ew_in, const int32_t* src32, const int32_t* dst32,
+                                   const int32_t* tgt_ptr, const int32_t* tgt_perm, const int32_t* loop_edge,
+                                   const float* const* W /*HOST [L]*/, const float* const* b /*HOST [L]*/, float* xcat,
+                                   void* stream) {
+  int rc = sf_check("sgcn_stack_fwd", n_graphs, R, max_edges, H0, F, L, 0);
+  if (rc) return rc;
+  IGCN_REQUIRE(((uintptr_t)xcat & 15) == 0, "sgcn_stack_fwd: xcat must be 16-byte aligned");
+  SfParams prm = {};
+  for (int l = 0; l < L; ++l) { prm.W[l] = W[l]; prm.b[l] = b[l]; }
+  const size_t lds = igcn_sgcn_stack_lds_bytes(R, max_edges, H0, F, L, 0);
+  hipStream_t st = (hipStream_t)stream;
+#define SF_FWD(FV)                                                                                                \
+  {                                                                                                               \
+    if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS((k_sgcn_stack_fwd<FV>));                                              \
+    hipLaunchKernelGGL((k_sgcn_stack_fwd<FV>), dim3((unsigned)n_graphs), dim3(SF_T), lds, st, R, max_edges, H0, L, \
+                       x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, loop_edge, prm, xcat);                        \
+  }
+  switch (F) {
+    case 4: SF_FWD(4) break;
+    case 8: SF_FWD(8) break;
+    case 16: SF_FWD(16) break;
+    default: SF_FWD(32) break;
+  }
+#undef SF_FWD
+  IGCN_CHECK_LAUNCH("sgcn_stack_fwd");
+  return IGCN_OK;
+}
+
+extern "C" int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H0, int F, int L, const float* x_in,
+                                   const float* ew_in, const int32_t* src32, const int32_t* dst32,
+                                   const int32_t* tgt_ptr, const int32_t* tgt_perm, const int32_t* src_ptr,
+                                   const int32_t* src_perm, const int32_t* loop_edge, const float* const* W,
+                                   const float* const* b, const float* dxcat, float* dx_in, float* dew_in,
+                                   float* dparams /*[param_floats]*/, float* scratch /*[n_graphs * param_floats]*/,
+                                   void* stream) {
+  int rc = sf_check("sgcn_stack_bwd", n_graphs, R, max_edges, H0, F, L, 1);
+  if (rc) return rc;
+  IGCN_REQUIRE(((uintptr_t)dxcat & 15) == 0, "sgcn_stack_bwd: dxcat must be 16-byte aligned");
+  SfParams prm = {};
+  for (int l = 0; l < L; ++l) { prm.W[l] = W[l]; prm.b[l] = b[l]; }
+  const size_t lds = igcn_sgcn_stack_lds_bytes(R, max_edges, H0, F, L, 1);
+  const int P = igcn_sgcn_stack_param_floats(H0, F, L);
+  hipStream_t st = (hipStream_t)stream;
+#define SF_BWD(FV)                                                                                                \
+  {                                                                                                               \
+    if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS((k_sgcn_stack_bwd<FV>));                                              \
+    hipLaunchKernelGGL((k_sgcn_stack_bwd<FV>), dim3((unsigned)n_graphs), dim3(SF_TB), lds, st, R, max_edges, H0, L, \
+                       x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, loop_edge, prm, dxcat,     \
+                       dx_in, dew_in, scratch, P);                                                                 \
+  }
+  switch (F) {
+    case 4: SF_BWD(4) break;
+    case 8: SF_BWD(8) break;
+    case 16: SF_BWD(16) break;
+    default: SF_BWD(32) break;
+  }
+#undef SF_BWD
+  IGCN_CHECK_LAUNCH("sgcn_stack_bwd");
+  return igcn_launch_reduce_rows_final(scratch, n_graphs, P, P, dparams, st);
+}

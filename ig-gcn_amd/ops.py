@@ -107,6 +107,7 @@ class GraphPlan:
         self.status = None
         self._seg = None
         self._tiled = False
+        self._stack_dims = None
         # uniform graph size (every PyG batch of R-ROI brain graphs), passed to the aggregation as a hint
         self.nodes_per_graph = int(max_nodes) if (max_nodes and node_ptr is not None and
                                                   n == int(max_nodes) * (int(node_ptr.numel()) - 1)) else 0
@@ -119,6 +120,8 @@ class GraphPlan:
             self.status = torch.zeros(1, **i32)
             self._seg = (node_ptr.contiguous(), edge_ptr.contiguous(), int(max_nodes), int(max_edges))
             self._tiled = max_edges > self.SEG_MAX_EDGES
+            if self.nodes_per_graph:                    # uniform graphs: (nodes, max edges) per graph
+                self._stack_dims = (self.nodes_per_graph, int(max_edges))
             if self._tiled:
                 nb = int(_lib.load().igcn_graph_plan_tiled_workspace_bytes(int(node_ptr.numel()) - 1, int(max_nodes),
                                                                            int(max_edges)))
@@ -177,6 +180,7 @@ class GraphPlan:
                 setattr(rep, name, torch.empty(max(size, 1), **i32))
             rep._copies, rep._seg, rep.status = {}, None, None
             rep.nodes_per_graph = self.nodes_per_graph
+            rep._tiled, rep._stack_dims = False, self._stack_dims
             call("igcn_graph_plan_replicate", n, e, copies, ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr),
                  ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(rep.src32),
                  ptr(rep.dst32), ptr(rep.tgt_ptr), ptr(rep.tgt_perm), ptr(rep.src_ptr), ptr(rep.src_perm),
@@ -339,6 +343,70 @@ class GcnPropagate(torch.autograd.Function):
                  ptr(sstream), ptr(wloop), ptr(plan.src32), ptr(plan.dst32), ptr(plan.src_ptr), ptr(dh), f, ptr(dbias),
                  int(need_dw), ptr(dwhat), ptr(dwloop), ptr(scratch), stream_ptr())
         return dh, dwhat, dwloop, dbias, None, None, None, None
+
+
+def sgcn_stack_supported(plan, rois, h0, f, layers):
+    """The LDS-resident SGCN stack (igcn_sgcn_stack_*) covers this batch: per-graph plan of uniform graphs (block
+    diagonal, verified by the builder), supported widths, and the graph fits LDS."""
+    seg = getattr(plan, "_stack_dims", None)
+    if seg is None or seg[0] != rois or f not in (4, 8, 16, 32) or not (1 <= layers <= 4) or not (1 <= h0 <= 8):
+        return False
+    lib = _lib.load()
+    return int(lib.igcn_sgcn_stack_lds_bytes(rois, seg[1], h0, f, layers, 1)) <= 150 * 1024
+
+
+class SgcnStack(torch.autograd.Function):
+    """xcat = cat_l relu(GCNConv_l(...)) of kernel/sgcn_img_snp.py:218-224 for a batch of small uniform graphs: one
+    LDS-resident kernel per direction (igcn_sgcn_stack_*) instead of gcn_norm + (GEMM, scatter-aggregate) per layer
+    + concatenation.  ``wb`` = W_0, b_0, W_1, b_1, ..."""
+
+    @staticmethod
+    def forward(ctx, x_in, ew_in, plan, rois, *wb):
+        x_in, ew_in = _f32(x_in), _f32(ew_in)
+        wb = [_f32(t) for t in wb]
+        ws, bs = wb[0::2], wb[1::2]
+        n, h0 = x_in.shape
+        f, layers = ws[0].shape[0], len(ws)
+        emax = plan._stack_dims[1]
+        xcat = torch.empty(n, layers * f, dtype=torch.float32, device=x_in.device)
+        wp = (ctypes.c_void_p * layers)(*[w.data_ptr() for w in ws])
+        bp = (ctypes.c_void_p * layers)(*[b.data_ptr() for b in bs])
+        call("igcn_sgcn_stack_fwd", n // rois, rois, emax, h0, f, layers, ptr(x_in), ptr(ew_in), ptr(plan.src32),
+             ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.loop_edge), wp, bp, ptr(xcat),
+             stream_ptr())
+        ctx.save_for_backward(x_in, ew_in, *wb)
+        ctx.plan, ctx.rois = plan, rois
+        ctx.final = _leaves(*wb)
+        return xcat
+
+    @staticmethod
+    def backward(ctx, dxcat):
+        x_in, ew_in, *wb = ctx.saved_tensors
+        ws, bs = wb[0::2], wb[1::2]
+        plan, rois = ctx.plan, ctx.rois
+        dxcat = _f32(dxcat)
+        n, h0 = x_in.shape
+        f, layers = ws[0].shape[0], len(ws)
+        emax = plan._stack_dims[1]
+        g = n // rois
+        lib = _lib.load()
+        npar = int(lib.igcn_sgcn_stack_param_floats(h0, f, layers))
+        dx, dew = torch.empty_like(x_in), torch.empty_like(ew_in)
+        dpar = torch.empty(npar, dtype=torch.float32, device=x_in.device)
+        scratch = _keep(torch.empty(g * npar, dtype=torch.float32, device=x_in.device))
+        wp = (ctypes.c_void_p * layers)(*[w.data_ptr() for w in ws])
+        bp = (ctypes.c_void_p * layers)(*[b.data_ptr() for b in bs])
+        with _immediate(ctx.final):
+            call("igcn_sgcn_stack_bwd", g, rois, emax, h0, f, layers, ptr(x_in), ptr(ew_in), ptr(plan.src32),
+                 ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm),
+                 ptr(plan.loop_edge), wp, bp, ptr(dxcat), ptr(dx), ptr(dew), ptr(dpar), ptr(scratch), stream_ptr())
+        grads, off = [], 0
+        for l in range(layers):
+            fin = h0 if l == 0 else f
+            grads.append(dpar[off:off + f * fin].view(f, fin))
+            grads.append(dpar[off + f * fin:off + f * fin + f])
+            off += f * fin + f
+        return (dx, dew, None, None, *grads)
 
 
 # =================================================================================================

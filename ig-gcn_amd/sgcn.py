@@ -14,6 +14,8 @@ interact at all.
 """
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.nn import Linear, Parameter, init
@@ -98,13 +100,20 @@ class SGCN_GCN(torch.nn.Module):
             x_in = xs[0] if g == 1 else torch.cat(xs, dim=0)
             ew_in = ews[0] if g == 1 else torch.cat(ews, dim=0)
         plan_g = plan.replicate(g)
-        coef = ops.GcnNorm.apply(ew_in, plan_g)
-        h = self.conv1(x_in, plan_g, coef, relu=True)
-        hs = [h]
-        for conv in self.convs:
-            h = conv(h, plan_g, coef, relu=True)
-            hs.append(h)
-        z = ops.concat_cols(hs).view(g * bsz, -1)                     # to_dense_batch == view (:378-381)
+        convs = [self.conv1, *self.convs]
+        if (os.environ.get("IGCN_NO_FUSED_SGCN", "0") != "1" and x_in.is_cuda
+                and ops.sgcn_stack_supported(plan_g, self.rois, x_in.shape[1], self.conv1.out_channels, len(convs))):
+            wb = [t for c in convs for t in (c.lin.weight, c.bias)]
+            xcat = ops.SgcnStack.apply(x_in, ew_in, plan_g, self.rois, *wb)          # one LDS-resident kernel
+        else:
+            coef = ops.GcnNorm.apply(ew_in, plan_g)
+            h = self.conv1(x_in, plan_g, coef, relu=True)
+            hs = [h]
+            for conv in self.convs:
+                h = conv(h, plan_g, coef, relu=True)
+                hs.append(h)
+            xcat = ops.concat_cols(hs)
+        z = xcat.view(g * bsz, -1)                                    # to_dense_batch == view (:378-381)
         f1 = ops.linear(z, self.lin1.weight, self.lin1.bias, relu=True)
         if self.training and self._dropout_enabled:
             f1 = F.dropout(f1, 0.5, True)

@@ -111,6 +111,9 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         # BASELINE configs[4]: the dense feature transforms (GCNConv.lin, the attention projections, lin1 /
         # lin1_regr) with bf16 operands on the matrix cores, fp32 accumulation (igcn_gemm_bf16); default fp32
         self.bf16_transforms = bool(kwargs.get("bf16_transforms", False))
+        # one LDS-resident kernel per direction for the whole SGCN stack when the batch allows it (small uniform
+        # graphs); IGCN_NO_FUSED_SGCN=1 keeps the per-layer kernels (A/B runs, tests of the unfused path)
+        self.fused_sgcn_stack = os.environ.get("IGCN_NO_FUSED_SGCN", "0") != "1"
         # igcn_xattn_* (one fused all-in-LDS VALU kernel per direction) is exact but slower than MFMA-GEMM
         # projections + the matrix-core attention core (igcn_attn_core_*) at B=256 (profiles/): opt-in
         self.fused_cross_attention = os.environ.get("IGCN_FUSED_XATTN", "0") == "1"
@@ -252,14 +255,22 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             stack = lambda ts: ts[0] if g == 1 else torch.cat(ts, dim=0)                       # noqa: E731
             x_in, ew_in, snps_in = stack(xs), stack(ews), stack(snps)
         plan_g = plan.replicate(g)
-        coef = ops.GcnNorm.apply(ew_in, plan_g)                       # once per pass (PyG: once per layer)
         bf = self.bf16_transforms
-        h = self.conv1(x_in, plan_g, coef, relu=True, bf16=bf)
-        hs = [h]
-        for conv in self.convs:
-            h = conv(h, plan_g, coef, relu=True, bf16=bf)
-            hs.append(h)
-        xcat = ops.concat_cols(hs)
+        convs = [self.conv1, *self.convs]
+        hidden = self.conv1.out_channels
+        if (not bf and self.fused_sgcn_stack and x_in.is_cuda
+                and ops.sgcn_stack_supported(plan_g, self.rois, x_in.shape[1], hidden, len(convs))):
+            # small uniform graphs: gcn_norm + every GCNConv + ReLU + the concatenation in ONE LDS-resident kernel
+            wb = [t for c in convs for t in (c.lin.weight, c.bias)]
+            xcat = ops.SgcnStack.apply(x_in, ew_in, plan_g, self.rois, *wb)
+        else:
+            coef = ops.GcnNorm.apply(ew_in, plan_g)                   # once per pass (PyG: once per layer)
+            h = self.conv1(x_in, plan_g, coef, relu=True, bf16=bf)
+            hs = [h]
+            for conv in self.convs:
+                h = conv(h, plan_g, coef, relu=True, bf16=bf)
+                hs.append(h)
+            xcat = ops.concat_cols(hs)
         gb = g * bsz
         batch_x = xcat.view(gb, self.rois, -1)                        # to_dense_batch == view (:226)
         img_out = batch_x.reshape(gb, -1)

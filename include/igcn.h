@@ -162,6 +162,31 @@ int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, int nodes_pe
                            float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The whole SGCN stack of kernel/sgcn_img_snp.py:218-224 for batches of SMALL UNIFORM graphs, LDS-resident: PyG
+ * gcn_norm + L x (X W_l^T, scatter-aggregate, + b_l, ReLU) + the jumping-knowledge concatenation as ONE kernel per
+ * direction, one workgroup per graph (north_star: "LDS staging of per-block node features").  HBM carries only the
+ * compulsory traffic of SURVEY §8d's "fused SGCN forward lower bound": x_in [n_graphs*R, H0], the graph's edges and
+ * ew_in in, xcat [n_graphs*R, L*F] out.  Needs a block-diagonal batch (graph g = nodes [gR, (g+1)R), its edges
+ * contiguous in stored order — what the per-graph plan builders verify), at most `max_edges` edges per graph,
+ * F in {4,8,16,32}, L <= 4, H0 <= 8 and igcn_sgcn_stack_lds_bytes(...) <= 150 KB (IGCN_ERR_UNSUPPORTED otherwise: use
+ * igcn_gcn_norm_* / igcn_gemm_f32 / igcn_gcn_propagate_*).  W / b: HOST arrays of L device pointers, W_l [F, Fin_l]
+ * row-major (Fin_0 = H0, then F), b_l [F].
+ * Backward recomputes the forward in LDS; outputs dx_in [N, H0], dew_in [E] and dparams
+ * [igcn_sgcn_stack_param_floats] = dW_0 | db_0 | dW_1 | db_1 | ... (scratch: n_graphs * that many floats; the sum over
+ * graphs is a final reduction in the sense of igcn_reduce_defer). */
+size_t igcn_sgcn_stack_lds_bytes(int R, int max_edges, int H0, int F, int L, int backward);
+int igcn_sgcn_stack_param_floats(int H0, int F, int L);
+int igcn_sgcn_stack_fwd(int64_t n_graphs, int R, int max_edges, int H0, int F, int L, const float* x_in,
+                        const float* ew_in, const int32_t* src32, const int32_t* dst32, const int32_t* tgt_ptr,
+                        const int32_t* tgt_perm, const int32_t* loop_edge, const float* const* W,
+                        const float* const* b, float* xcat, void* stream);
+int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H0, int F, int L, const float* x_in,
+                        const float* ew_in, const int32_t* src32, const int32_t* dst32, const int32_t* tgt_ptr,
+                        const int32_t* tgt_perm, const int32_t* src_ptr, const int32_t* src_perm,
+                        const int32_t* loop_edge, const float* const* W, const float* const* b, const float* dxcat,
+                        float* dx_in, float* dew_in, float* dparams, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Dense feature transform on the matrix cores (f32-input MFMA 16x16x4, exact fp32):
  *   out[M,N] = act( A[M,K] . W[N,K]^T + bias )      — GCNConv.lin (kernel/sgcn_img_snp.py:34-49),
  *   lin1 / lin1_regr / lin2 / lin2_regr (:62-84,289-301).  General strided form so the same kernel

@@ -837,3 +837,66 @@ def test_graph_pool_mean_max_add(ops, g, r, d, seed):
     (out * cot.cuda()).sum().backward()
     (ref * cot.double()).sum().backward()
     assert_matches(xg.grad, xr.grad.float().numpy(), 1e-6, "pool grad")
+
+
+# ------------------------------------------------------------------------------------------------ fused SGCN stack
+@pytest.mark.parametrize("g,r,h0,f,layers,deg,loops", [(4, 90, 3, 16, 2, 3, "all"), (3, 10, 3, 4, 2, 3, "some"),
+                                                       (2, 33, 5, 8, 3, 6, "none"), (5, 17, 2, 32, 1, 4, "multi"),
+                                                       (2, 90, 3, 16, 4, 5, "some")])
+def test_fused_sgcn_stack_fwd_bwd(ops, g, r, h0, f, layers, deg, loops):
+    """igcn_sgcn_stack_* (gcn_norm + L x GCNConv + ReLU + concatenation, LDS-resident, one workgroup per graph) against
+    the fp64 PyG restatement: outputs, dx, d(edge weight), every dW / db.  Stored self-loops (kept weight), nodes
+    without a stored loop (added with weight 1), several stored loops on one node (last wins), isolated nodes."""
+    from igcn_amd.data import Batch, Data
+    from oracle import pyg_ops
+    rng = np.random.default_rng(g * 100 + r + f)
+    graphs = []
+    for _ in range(g):
+        src = rng.integers(0, r, deg * r)
+        dst = rng.integers(0, r, deg * r)
+        keep = src != dst
+        src, dst = src[keep], dst[keep]
+        src, dst = src[dst != r - 1], dst[dst != r - 1]            # node r-1 has no incoming edge
+        if loops in ("all", "some", "multi"):
+            nodes = np.arange(r) if loops == "all" else rng.choice(r, r // 2, replace=False)
+            src, dst = np.concatenate([src, nodes]), np.concatenate([dst, nodes])
+        if loops == "multi":
+            src, dst = np.concatenate([src, [2, 2]]), np.concatenate([dst, [2, 2]])
+        order = rng.permutation(src.size)
+        ei = torch.from_numpy(np.vstack([src[order], dst[order]])).long()
+        graphs.append(Data(x=torch.from_numpy(rng.random((r, h0))).float(), edge_index=ei,
+                           edge_attr=torch.from_numpy(rng.random(ei.shape[1]) + 0.05).float()))
+    batch = Batch.from_data_list(graphs).to("cuda")
+    plan = ops.plan_for(batch)
+    plan.check()
+    assert ops.sgcn_stack_supported(plan, r, h0, f, layers)
+    ws = [torch.from_numpy(rng.standard_normal((f, h0 if l == 0 else f)) / np.sqrt(h0 if l == 0 else f)).float()
+          for l in range(layers)]
+    bs = [torch.from_numpy(0.3 * rng.standard_normal(f)).float() for _ in range(layers)]
+    cot = torch.from_numpy(rng.standard_normal((g * r, layers * f))).float()
+    # oracle, fp64
+    xd = batch.x.cpu().double().requires_grad_(True)
+    ewd = batch.edge_attr.cpu().double().requires_grad_(True)
+    wd = [w.double().requires_grad_(True) for w in ws]
+    bd = [b.double().requires_grad_(True) for b in bs]
+    ei_c = batch.edge_index.cpu()
+    hs, hcur = [], xd
+    for l in range(layers):
+        hcur = torch.relu(pyg_ops.gcn_conv(hcur, ei_c, ewd, wd[l], bd[l]))
+        hs.append(hcur)
+    want = torch.cat(hs, dim=1)
+    (want * cot.double()).sum().backward()
+    # HIP
+    xg = batch.x.clone().requires_grad_(True)
+    ewg = batch.edge_attr.clone().requires_grad_(True)
+    wg = [w.cuda().requires_grad_(True) for w in ws]
+    bg = [b.cuda().requires_grad_(True) for b in bs]
+    out = ops.SgcnStack.apply(xg, ewg, plan, r, *[t for pair in zip(wg, bg) for t in pair])
+    (out * cot.cuda()).sum().backward()
+    assert_matches(out, want.detach().numpy(), TOL, "xcat")
+    assert_matches(xg.grad, xd.grad.numpy(), TOL, "dx")
+    if loops != "multi":          # several stored loops on one node: index_put's duplicate-index gradient is undefined
+        assert_matches(ewg.grad, ewd.grad.numpy(), TOL, "dew")
+    for l in range(layers):
+        assert_matches(wg[l].grad, wd[l].grad.numpy(), TOL, f"dW{l}", floor=1e-6)
+        assert_matches(bg[l].grad, bd[l].grad.numpy(), TOL, f"db{l}", floor=1e-6)
