@@ -30,9 +30,9 @@ struct SfParams {
 
 // LDS carve-out shared by both kernels (all offsets in 4-byte words)
 struct SfLayout {
-  int x, dis, wl, wloop, ew, what, src, dst, tptr, tperm, w, bias, act, wall, loop;   // forward part
+  int x, dis, wl, wloop, ew, what, src, dst, tptr, tperm, w, bias, act, wall, loop, tsrc, twhat;   // forward part
   int ycat;                                                                             // [R][L*F] layer outputs
-  int sptr, sperm, g, dh, dx, dwhat, dwloop, ddeg, red, dycat, prow;     // backward part
+  int sptr, sperm, g, dh, dx, dwhat, dwloop, ddeg, red, dycat, prow, bdst, bwhat;   // backward part
   int total;
 };
 
@@ -51,6 +51,8 @@ __host__ __device__ inline SfLayout sf_layout(int R, int Emax, int H0, int F, in
   o.dst = take(Emax);
   o.tptr = take(R + 1);
   o.tperm = take(Emax);
+  o.tsrc = take(Emax + 4);                         // by-TARGET order: source node and coefficient of every list entry
+  o.twhat = take(Emax + 4);                        // (+4: the 4-wide list walk may read past the end; never used)
   o.w = take(F * fin_max);
   o.bias = take(F);
   o.wall = take(L * (F * fin_max + F));            // every layer's W_l | b_l, fetched with the graph (one round trip)
@@ -60,7 +62,7 @@ __host__ __device__ inline SfLayout sf_layout(int R, int Emax, int H0, int F, in
   // a barrier makes the whole workgroup wait for its acknowledgement, so nothing is stored before the last barrier
   o.act = take((backward ? L : 1) * R * F);
   o.ycat = take(R * L * F);
-  o.sptr = o.sperm = o.g = o.dh = o.dx = o.dwhat = o.dwloop = o.ddeg = o.red = o.dycat = o.prow = 0;
+  o.sptr = o.sperm = o.g = o.dh = o.dx = o.dwhat = o.dwloop = o.ddeg = o.red = o.dycat = o.prow = o.bdst = o.bwhat = 0;
   if (backward) {
     o.sptr = take(R + 1);
     o.sperm = take(Emax);
@@ -73,6 +75,8 @@ __host__ __device__ inline SfLayout sf_layout(int R, int Emax, int H0, int F, in
     o.red = take(SF_TB + (SF_TB > F * fin_max ? SF_TB : F * fin_max));
     o.dycat = take(R * L * F);
     o.prow = take(L * (F * fin_max + F));
+    o.bdst = take(Emax + 4);                       // by-SOURCE order: target node and coefficient of every list entry
+    o.bwhat = take(Emax + 4);
   }
   o.total = p;
   return o;
@@ -115,12 +119,19 @@ __device__ __forceinline__ void sf_stage(float* lds, const SfLayout& o, int R, i
     if (BWD) reinterpret_cast<int32_t*>(lds + o.sptr)[i] = src_ptr[nb + i] - eb;
   }
   __syncthreads();
-  // gcn_norm (PyG: drop stored loops, add one loop per node whose weight is the LAST stored loop's or 1)
+  // gcn_norm (PyG: drop stored loops, add one loop per node whose weight is the LAST stored loop's or 1).  The walk
+  // also lays the list entries out in BY-TARGET order (tsrc, twhat): every later walk of a target's list then reads
+  // two consecutive arrays instead of chasing permutation -> edge -> endpoint
+  int32_t* stsrc = reinterpret_cast<int32_t*>(lds + o.tsrc);
   for (int i = tid; i < R; i += (int)blockDim.x) {
     float deg = 0.f;
     for (int p = stptr[i]; p < stptr[i + 1]; ++p) {
       const int k = stperm[p];
-      if (ssrc[k] != i) deg += lds[o.ew + k];
+      const int sk = ssrc[k];
+      const float wk = lds[o.ew + k];
+      stsrc[p] = sk;
+      lds[o.twhat + p] = sk != i ? wk : 0.f;           // stored loops are replaced by the added loop
+      if (sk != i) deg += wk;
     }
     const int32_t le = reinterpret_cast<const int32_t*>(lds + o.loop)[i];
     const float lw = le >= 0 ? lds[o.ew + (le - eb)] : 1.f;
@@ -132,9 +143,28 @@ __device__ __forceinline__ void sf_stage(float* lds, const SfLayout& o, int R, i
     lds[o.wloop + i] = d * lw * d;
   }
   __syncthreads();
-  for (int k = tid; k < ne; k += (int)blockDim.x) {
-    const int s = ssrc[k], t = sdst[k];
-    lds[o.what + k] = s != t ? lds[o.dis + s] * lds[o.ew + k] * lds[o.dis + t] : 0.f;
+  for (int i = tid; i < R; i += (int)blockDim.x) {
+    const float di = lds[o.dis + i];
+    for (int p = stptr[i]; p < stptr[i + 1]; ++p) lds[o.twhat + p] = lds[o.dis + stsrc[p]] * lds[o.twhat + p] * di;
+  }
+  if (BWD) {
+    for (int k = tid; k < ne; k += (int)blockDim.x) {
+      const int s = ssrc[k], t = sdst[k];
+      lds[o.what + k] = s != t ? lds[o.dis + s] * lds[o.ew + k] * lds[o.dis + t] : 0.f;
+    }
+    // the transposed lists (edges out of a source) in BY-SOURCE order, for dH = A_hat^T G
+    const int32_t* ssptr = reinterpret_cast<const int32_t*>(lds + o.sptr);
+    const int32_t* ssperm = reinterpret_cast<const int32_t*>(lds + o.sperm);
+    int32_t* sbdst = reinterpret_cast<int32_t*>(lds + o.bdst);
+    for (int i = tid; i < R; i += (int)blockDim.x) {
+      const float di = lds[o.dis + i];
+      for (int p = ssptr[i]; p < ssptr[i + 1]; ++p) {
+        const int k = ssperm[p];
+        const int t = sdst[k];
+        sbdst[p] = t;
+        lds[o.bwhat + p] = t != i ? di * lds[o.ew + k] * lds[o.dis + t] : 0.f;
+      }
+    }
   }
   // (the caller's next __syncthreads() orders `what` before its first use)
 }
@@ -145,30 +175,74 @@ template <int F>
 __device__ __forceinline__ void sf_layer(float* lds, const SfLayout& o, int R, int fin, const float* xin, int ldx,
                                          float* H, float* Y, int ldy, const float* Wg, const float* bg) {
   const int tid = threadIdx.x;
-  const int32_t* ssrc = reinterpret_cast<const int32_t*>(lds + o.src);
   const int32_t* stptr = reinterpret_cast<const int32_t*>(lds + o.tptr);
-  const int32_t* stperm = reinterpret_cast<const int32_t*>(lds + o.tperm);
+  const int32_t* stsrc = reinterpret_cast<const int32_t*>(lds + o.tsrc);
   // weights TRANSPOSED in LDS (Wt[fi][fo]): the F lanes of a node read consecutive words, not a stride-fin column
   for (int i = tid; i < F * fin; i += (int)blockDim.x) lds[o.w + (i % fin) * F + i / fin] = Wg[i];
   for (int i = tid; i < F; i += (int)blockDim.x) lds[o.bias + i] = bg[i];
   __syncthreads();
-  for (int e = tid; e < R * F; e += (int)blockDim.x) {
-    const int i = e / F, fo = e - i * F;
-    float acc = 0.f;
-    for (int fi = 0; fi < fin; ++fi) acc += xin[i * ldx + fi] * lds[o.w + fi * F + fo];
-    H[e] = acc;
+  // work item = (node, output quad): every LDS access moves 16 bytes (one weight-row quad serves four FMAs, one
+  // gathered activation quad four more) — with one item per output word the phase is bound by the LDS instruction
+  // rate, two 4-byte reads per FMA.  Dot products fully unrolled: the reads of an item are issued together.
+  constexpr int FQ = F / 4;
+  if (fin == F) {
+    for (int e = tid; e < R * FQ; e += (int)blockDim.x) {
+      const int i = e / FQ, q = e - i * FQ;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int f4 = 0; f4 < FQ; ++f4) {
+        const float4 xv = *reinterpret_cast<const float4*>(xin + i * ldx + f4 * 4);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 w4 = *reinterpret_cast<const float4*>(lds + o.w + (f4 * 4 + j) * F + q * 4);
+          acc.x += xs[j] * w4.x; acc.y += xs[j] * w4.y; acc.z += xs[j] * w4.z; acc.w += xs[j] * w4.w;
+        }
+      }
+      *reinterpret_cast<float4*>(H + i * F + q * 4) = acc;
+    }
+  } else {
+    for (int e = tid; e < R * FQ; e += (int)blockDim.x) {
+      const int i = e / FQ, q = e - i * FQ;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int fi = 0; fi < SF_MAXH0; ++fi)
+        if (fi < fin) {
+          const float xv = xin[i * ldx + fi];
+          const float4 w4 = *reinterpret_cast<const float4*>(lds + o.w + fi * F + q * 4);
+          acc.x += xv * w4.x; acc.y += xv * w4.y; acc.z += xv * w4.z; acc.w += xv * w4.w;
+        }
+      *reinterpret_cast<float4*>(H + i * F + q * 4) = acc;
+    }
   }
   __syncthreads();
-  for (int e = tid; e < R * F; e += (int)blockDim.x) {
-    const int i = e / F, fo = e - i * F;
-    float acc = 0.f;
-    for (int p = stptr[i]; p < stptr[i + 1]; ++p) {          // stored order of the target's edges (reference order)
-      const int k = stperm[p];
-      acc += lds[o.what + k] * H[ssrc[k] * F + fo];
+  for (int e = tid; e < R * FQ; e += (int)blockDim.x) {
+    const int i = e / FQ, q = e - i * FQ;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int p1 = stptr[i + 1];
+    for (int p = stptr[i]; p < p1; p += 4) {                 // stored order of the target's edges (reference order),
+      int sj[4];                                             // four entries per step: their reads overlap
+      float wj[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sj[j] = stsrc[p + j];
+        wj[j] = lds[o.twhat + p + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (p + j < p1) {
+          const float4 h4 = *reinterpret_cast<const float4*>(H + sj[j] * F + q * 4);
+          acc.x += wj[j] * h4.x; acc.y += wj[j] * h4.y; acc.z += wj[j] * h4.z; acc.w += wj[j] * h4.w;
+        }
     }
-    acc += lds[o.wloop + i] * H[e];
-    acc += lds[o.bias + fo];
-    Y[i * ldy + fo] = fmaxf(acc, 0.f);
+    const float wl = lds[o.wloop + i];
+    const float4 hs = *reinterpret_cast<const float4*>(H + i * F + q * 4);
+    const float4 b4 = *reinterpret_cast<const float4*>(lds + o.bias + q * 4);
+    acc.x = fmaxf(acc.x + wl * hs.x + b4.x, 0.f);            // + self loop, + bias in the reference's order, ReLU
+    acc.y = fmaxf(acc.y + wl * hs.y + b4.y, 0.f);
+    acc.z = fmaxf(acc.z + wl * hs.z + b4.z, 0.f);
+    acc.w = fmaxf(acc.w + wl * hs.w + b4.w, 0.f);
+    *reinterpret_cast<float4*>(Y + i * ldy + q * 4) = acc;
   }
   __syncthreads();
 }
@@ -264,40 +338,75 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
         for (int p2 = 0; p2 < pend_parts; ++p2) acc += red_dw[p2 * pend_n + e];
         prow[pend_off + e] = acc;
       }
+    // work items are (node, feature quad) / edges with 16-byte LDS accesses throughout (see sf_layer)
+    constexpr int FQ = F / 4;
     // G = (d xcat[:, l] + d X_l from the layer above) * [Y_l > 0]
-    for (int e = tid; e < R * F; e += SF_TB) {
-      const int i = e / F, fo = e - i * F;
-      float g = sf_lds[o.dycat + i * D + l * F + fo];
-      if (l < L - 1) g += dX[e];
-      G[e] = Y[i * D + fo] > 0.f ? g : 0.f;
+    for (int e = tid; e < R * FQ; e += SF_TB) {
+      const int i = e / FQ, q = e - i * FQ;
+      float4 g = *reinterpret_cast<const float4*>(sf_lds + o.dycat + i * D + l * F + q * 4);
+      if (l < L - 1) {
+        const float4 d4 = *reinterpret_cast<const float4*>(dX + i * F + q * 4);
+        g.x += d4.x; g.y += d4.y; g.z += d4.z; g.w += d4.w;
+      }
+      const float4 y4 = *reinterpret_cast<const float4*>(Y + i * D + q * 4);
+      g.x = y4.x > 0.f ? g.x : 0.f; g.y = y4.y > 0.f ? g.y : 0.f;
+      g.z = y4.z > 0.f ? g.z : 0.f; g.w = y4.w > 0.f ? g.w : 0.f;
+      *reinterpret_cast<float4*>(G + i * F + q * 4) = g;
     }
     for (int i = tid; i < F * fin; i += SF_TB)                                      // W_l [fo][fi] for dX = dH W
       sf_lds[o.w + i] = sf_lds[o.wall + l * (F * (F > H0 ? F : H0) + F) + i];
     __syncthreads();
-    // dH = A_hat^T G (by-source lists); coefficient gradients accumulate over the layers
-    for (int e = tid; e < R * F; e += SF_TB) {
-      const int s = e / F, fo = e - s * F;
-      float acc = 0.f;
-      for (int p = ssptr[s]; p < ssptr[s + 1]; ++p) {
-        const int k = ssperm[p];
-        acc += sf_lds[o.what + k] * G[sdst[k] * F + fo];
+    // dH = A_hat^T G (by-source lists, four entries per step); coefficient gradients accumulate over the layers
+    {
+      const int32_t* sbdst = reinterpret_cast<const int32_t*>(sf_lds + o.bdst);
+      for (int e = tid; e < R * FQ; e += SF_TB) {
+        const int sn = e / FQ, q = e - sn * FQ;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int p1 = ssptr[sn + 1];
+        for (int p = ssptr[sn]; p < p1; p += 4) {
+          int tj[4];
+          float wj[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            tj[j] = sbdst[p + j];
+            wj[j] = sf_lds[o.bwhat + p + j];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (p + j < p1) {
+              const float4 g4 = *reinterpret_cast<const float4*>(G + tj[j] * F + q * 4);
+              acc.x += wj[j] * g4.x; acc.y += wj[j] * g4.y; acc.z += wj[j] * g4.z; acc.w += wj[j] * g4.w;
+            }
+        }
+        const float wl = sf_lds[o.wloop + sn];
+        const float4 gs = *reinterpret_cast<const float4*>(G + sn * F + q * 4);
+        acc.x += wl * gs.x; acc.y += wl * gs.y; acc.z += wl * gs.z; acc.w += wl * gs.w;
+        *reinterpret_cast<float4*>(dH + sn * F + q * 4) = acc;
       }
-      acc += sf_lds[o.wloop + s] * G[e];
-      dH[e] = acc;
     }
-    for (int k = tid; k < ne; k += SF_TB) {
-      const int s = ssrc[k], t = sdst[k];
-      if (s == t) continue;
+    for (int k = tid; k < ne + R; k += SF_TB) {          // per edge: G[dst] . H[src]; then per node: G[i] . H[i]
+      int sn, tn;
+      float* dstp;
+      if (k < ne) {
+        sn = ssrc[k];
+        tn = sdst[k];
+        if (sn == tn) continue;
+        dstp = sf_lds + o.dwhat + k;
+      } else {
+        sn = tn = k - ne;
+        dstp = sf_lds + o.dwloop + sn;
+      }
       float acc = 0.f;
 #pragma unroll
-      for (int fo = 0; fo < F; ++fo) acc += G[t * F + fo] * H[s * F + fo];
-      sf_lds[o.dwhat + k] += acc;
-    }
-    for (int i = tid; i < R; i += SF_TB) {
-      float acc = 0.f;
-#pragma unroll
-      for (int fo = 0; fo < F; ++fo) acc += G[i * F + fo] * H[i * F + fo];
-      sf_lds[o.dwloop + i] += acc;
+      for (int c = 0; c < FQ; ++c) {
+        const float4 g4 = *reinterpret_cast<const float4*>(G + tn * F + c * 4);
+        const float4 h4 = *reinterpret_cast<const float4*>(H + sn * F + c * 4);
+        acc += g4.x * h4.x;
+        acc += g4.y * h4.y;
+        acc += g4.z * h4.z;
+        acc += g4.w * h4.w;
+      }
+      *dstp += acc;
     }
     constexpr int DB_PARTS = SF_TB / F < 16 ? SF_TB / F : 16;
     if (tid < DB_PARTS * F) {                          // bias gradient: 16 thread groups share the node range
@@ -329,12 +438,30 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
       pend_n = n_out;
       pend_parts = parts;
     }
-    for (int e = tid; e < R * fin; e += SF_TB) {
-      const int i = e / fin, fi = e - i * fin;
-      float acc = 0.f;
+    if (fin == F) {
+      for (int e = tid; e < R * FQ; e += SF_TB) {      // d X_{l-1}[i, quad] = sum_fo dH[i, fo] W[fo, quad]
+        const int i = e / FQ, q = e - i * FQ;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int fo = 0; fo < F; ++fo) acc += dH[i * F + fo] * sf_lds[o.w + fo * fin + fi];
-      dX[e] = acc;                                    // layer 0: d x_in, stored after the last barrier
+        for (int c = 0; c < FQ; ++c) {
+          const float4 d4 = *reinterpret_cast<const float4*>(dH + i * F + c * 4);
+          const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 w4 = *reinterpret_cast<const float4*>(sf_lds + o.w + (c * 4 + j) * F + q * 4);
+            acc.x += ds[j] * w4.x; acc.y += ds[j] * w4.y; acc.z += ds[j] * w4.z; acc.w += ds[j] * w4.w;
+          }
+        }
+        *reinterpret_cast<float4*>(dX + i * F + q * 4) = acc;
+      }
+    } else {
+      for (int e = tid; e < R * fin; e += SF_TB) {
+        const int i = e / fin, fi = e - i * fin;
+        float acc = 0.f;
+#pragma unroll
+        for (int fo = 0; fo < F; ++fo) acc += dH[i * F + fo] * sf_lds[o.w + fo * fin + fi];
+        dX[e] = acc;                                  // layer 0: d x_in, stored after the last barrier
+      }
     }
     __syncthreads();
   }
