@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch.nn import Linear, Parameter, init
 
 from . import ops
-from .sgcn_img_snp import GCNConv
+from .sgcn_img_snp import GCNConv, sgcn_stack
 
 
 class SGCN_GCN(torch.nn.Module):
@@ -100,19 +100,8 @@ class SGCN_GCN(torch.nn.Module):
             x_in = xs[0] if g == 1 else torch.cat(xs, dim=0)
             ew_in = ews[0] if g == 1 else torch.cat(ews, dim=0)
         plan_g = plan.replicate(g)
-        convs = [self.conv1, *self.convs]
-        if (os.environ.get("IGCN_NO_FUSED_SGCN", "0") != "1" and x_in.is_cuda
-                and ops.sgcn_stack_supported(plan_g, self.rois, x_in.shape[1], self.conv1.out_channels, len(convs))):
-            wb = [t for c in convs for t in (c.lin.weight, c.bias)]
-            xcat = ops.SgcnStack.apply(x_in, ew_in, plan_g, self.rois, *wb)          # one LDS-resident kernel
-        else:
-            coef = ops.GcnNorm.apply(ew_in, plan_g)
-            h = self.conv1(x_in, plan_g, coef, relu=True)
-            hs = [h]
-            for conv in self.convs:
-                h = conv(h, plan_g, coef, relu=True)
-                hs.append(h)
-            xcat = ops.concat_cols(hs)
+        xcat = sgcn_stack([self.conv1, *self.convs], x_in, ew_in, plan_g, self.rois,
+                          os.environ.get("IGCN_NO_FUSED_SGCN", "0") != "1")
         z = xcat.view(g * bsz, -1)                                    # to_dense_batch == view (:378-381)
         f1 = ops.linear(z, self.lin1.weight, self.lin1.bias, relu=True)
         if self.training and self._dropout_enabled:

@@ -631,3 +631,48 @@ def test_deferred_reductions_give_the_same_gradients(golden):
         n_grads += 1
         assert torch.equal(g, got[1][k]), k
     assert n_grads > 40
+
+
+@pytest.mark.parametrize("layers,hidden", [(2, 10), (3, 10), (4, 5)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_sweep_widths_off_the_kernel_grid_vs_oracle(layers, hidden, fused):
+    """The (layers, hidden) entries of the reference's sweep (main.py:152-158) whose width is not a multiple of 4 —
+    (2,10), (3,10), (4,5) — run zero-PADDED to 16 / 8 columns through the 16-byte kernels (the LDS-resident stack when
+    ``fused``, gcn_norm + MFMA transform + scatter-aggregate otherwise): eval forward (isExplain=True) and every
+    gradient against the fp64 oracle at R=90."""
+    from igcn_amd import synth
+    from igcn_amd.data import Batch
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    from oracle import go_network as OG, sgcn_img_snp as OS
+    pool = (60, 30, 20, 9, 1)
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=1)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+    model = SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cuda", rois=90, H_0=3, num_classes=3,
+                            isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
+                            isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False).cuda().eval()
+    model.fused_sgcn_stack = fused
+    sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, 6)
+    model.load_state_dict(sd)
+    graphs = synth.brain_graph_list(8, seed=78, rois=90, tsne_dim=16)
+    data = Batch.from_data_list(graphs).to("cuda")
+    outs = model(data, None, "cuda", isExplain=True)
+    assert outs[2].shape == (8, 90 * layers * hidden)
+    cot = _probe(outs, 9)
+    sum((o * c.cuda()).sum() for o, c in zip(outs, cot)).backward()
+    a_g_c, a_c = synth.go_sparse_inputs(go_snps, adj)
+    idx = OG.go_index_sets(a_g_c, a_c, list(pool), 2)
+    sdo = OS.make_leaf_state(sd, dtype=torch.float64)
+    dcpu = Batch.from_data_list(graphs)
+    dcpu.x = dcpu.x.double().requires_grad_(True)
+    dcpu.edge_attr, dcpu.snps_feat = dcpu.edge_attr.double(), dcpu.snps_feat.double()
+    cfg = SimpleNamespace(num_layers=layers, rois=90, image_only=False, rbf_gamma=0.01)
+    ref = OS.model_forward(sdo, cfg, idx, dcpu, True, training=False)
+    sum((o * c.double()).sum() for o, c in zip(ref, cot)).backward()
+    for n, o, r in zip(NAMES, outs, ref):
+        assert_matches(o, r.detach().numpy(), 1e-4, n)
+    assert_matches(data.x.grad, dcpu.x.grad.numpy(), 3e-3, "grad data.x")
+    params = dict(model.named_parameters())
+    for k in OS.trainable_keys(sdo):
+        if sdo[k].grad is None:
+            continue
+        assert_matches(params[k].grad, sdo[k].grad.numpy(), 5e-3, "grad " + k, floor=1e-6)

@@ -21,6 +21,14 @@ SHAPES = [  # (what, M, N, K, form)
     ("lin1 dW", 64, 2912, 512, "tn"),
     ("Gram matrix s s^T (one pass)", 256, 256, 2880, "nt"),
     ("gene map  x T^T", 512, 6000, 54, "nt"),
+    ("gene map dx = dy T", 512, 54, 6000, "nn"),
+    ("lin1_regr [2B,3182] -> 64", 512, 64, 3182, "nt"),
+    ("lin1 dX", 512, 2912, 64, "nn"),
+    ("Gram backward  S s", 256, 2880, 256, "nn"),
+    ("latent 0  [2B,400] -> 32", 512, 32, 400, "nt"),
+    ("latent 0 dW", 32, 400, 512, "tn"),
+    ("q projection", 46080, 32, 32, "nt"),
+    ("q projection dW", 32, 32, 46080, "tn"),
     ("square 4096 (reference point)", 4096, 4096, 4096, "nt"),
 ]
 dev = "cuda"
