@@ -484,7 +484,11 @@ def main():
     gstep = None
     if not args.eager:
         try:
-            gstep = step = GraphedTrainStep(model, opt, data, world_size=world, distributed=dist_on, comm=comm)
+            # N > 1: the all-reduce sits BETWEEN two graph replays on the launch stream by default; capturing the RCCL
+            # call into the one step graph is verified on a single-rank communicator only (IGCN_COMM_IN_GRAPH=1)
+            in_graph = None if os.environ.get("IGCN_COMM_IN_GRAPH", "0") == "1" else False
+            gstep = step = GraphedTrainStep(model, opt, data, world_size=world, distributed=dist_on, comm=comm,
+                                            comm_in_graph=in_graph)
             launch = "hipGraph replay"
             if dist_on:
                 launch += " (all-reduce inside the graph)" if gstep.comm_in_graph else " (two graphs around the all-reduce)"
