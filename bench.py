@@ -126,6 +126,28 @@ def instep_profile(workload, bf16, steps=12, timeout=420):
             shutil.rmtree(out, ignore_errors=True)
 
 
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc", "traffic.json")
+
+
+def _attach_traffic(res):
+    """``traffic``: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction, calibrated
+    on a 256 MiB float4 copy; WRITE_SIZE x1).  PMC collection needs its own profiler passes, so the figure comes from
+    the COMMITTED passes of tools/roofline_kernel.py (profiles/r02_pmc/, or $IGCN_BENCH_PMC_JSON) — a separate run of
+    the same kernel on the same launch shape, not this invocation — and says so."""
+    path = os.environ.get("IGCN_BENCH_PMC_JSON", PMC_JSON)
+    try:
+        with open(path) as fh:
+            table = json.load(fh)
+    except OSError:
+        return
+    for key, row in table.items():
+        if key != "calibration" and res["kernel"].startswith(key) and row.get("alg_bytes") == res["alg_bytes_per_launch"]:
+            res["traffic"] = row["traffic_bytes"]
+            res["traffic_source"] = (f"{os.path.relpath(path, ROOT)}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                     f"of tools/roofline_kernel.py on this launch shape ({row['us_median']} us median there)")
+            res["frac_traffic"] = round(row["traffic_bytes"] / (res["us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+
+
 def _pick(stats, prefix):
     """(name, calls, avg us, total us) of the kernels whose demangled name starts with ``prefix`` (largest total)."""
     best = None
@@ -250,7 +272,7 @@ def fused_stack_roofline(model, data, device, wl, stats):
     src = ("rocprofv3 --kernel-trace --stats of this command (child process): average over the in-step launches"
            if picked else "HIP events, cold replay (rocprofv3 unavailable)")
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": picked[0] if picked else "k_sgcn_stack_fwd", "achieved": round(gbs, 1),
+    res = {"bound": "hbm", "kernel": picked[0] if picked else "k_sgcn_stack_fwd", "achieved": round(gbs, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
             "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3), "timing": src,
             "launches_profiled": picked[1] if picked else 0, "kernel_bytes_per_launch": kern_bytes,
@@ -264,6 +286,8 @@ def fused_stack_roofline(model, data, device, wl, stats):
             "note": "latency-bound by construction: 512 workgroups (2 per CU) each run ~12 barrier-separated LDS phases; "
                     "the kernel replaces 7 launches (norm x2, GEMM + scatter-aggregate per layer, concat), whose "
                     "own scatter-aggregate launch is roofline_scatter_standalone"}
+    _attach_traffic(res)
+    return res
 
 
 def scatter_roofline(data, device, wl, stats, hot_iters=200):
@@ -289,7 +313,8 @@ def scatter_roofline(data, device, wl, stats, hot_iters=200):
     src = ("rocprofv3 --kernel-trace --stats of this command (child process): average over the in-step launches"
            if picked else "HIP events, cold replay (rocprofv3 unavailable)")
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    res = {"bound": "hbm", "kernel": picked[0] if picked else prefix, "achieved": round(gbs, 1),
+    fallback_name = "k_gcn_propagate_fwd_lds<4>" if dense else "k_gcn_propagate_fwd_q<4>"
+    res = {"bound": "hbm", "kernel": picked[0] if picked else fallback_name, "achieved": round(gbs, 1),
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
            "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3), "timing": src,
            "launches_profiled": picked[1] if picked else 0,
@@ -300,6 +325,10 @@ def scatter_roofline(data, device, wl, stats, hot_iters=200):
            "frac_replay_cold": round(alg_bytes / (cold * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
            "cold_rotation": f"{sets} buffer sets = {sets * (kern_bytes) / 2**20:.0f} MiB > 256 MiB Infinity Cache",
            "launch": f"{n_graphs} graphs x {e_prime} edges (both passes of a step), F={f}"}
+    if dense:
+        res["note"] = ("SURVEY 8d counts int64 endpoint pairs (20 B per edge); this kernel streams the plan's 8-byte "
+                       "(neighbour, coefficient) records, so `frac` over-states it — frac_kernel_bytes / frac_traffic "
+                       "(what the kernel really moves) are the figures to read at this shape")
     try:
         res["floor"] = _floor_timings(n, f, device, hot_iters if not dense else 50, dense)
         res["floor"]["note"] = ("same grid, hot replay: an empty kernel and one that only writes the output rows; "
@@ -307,11 +336,7 @@ def scatter_roofline(data, device, wl, stats, hot_iters=200):
         res["floor"]["frac_ceiling"] = round(alg_bytes / (res["floor"]["write_only_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     except Exception as exc:                       # noqa: BLE001
         res["floor"] = {"error": f"{type(exc).__name__}: {exc}"}
-    traffic = os.environ.get("IGCN_BENCH_PMC_JSON")        # written by tools/pmc_traffic.py from separate --pmc passes
-    if traffic and os.path.exists(traffic):
-        with open(traffic) as fh:
-            t = json.load(fh).get(res["kernel"].split("<")[0])
-        res["traffic"] = t
+    _attach_traffic(res)
     return res
 
 

@@ -62,16 +62,20 @@ __global__ void k_mask_reg_bwd(MaskRegArgs a, const float* __restrict__ gout, fl
   }
 }
 
-#define MR_BLOCKS 128
+#define MR_BLOCKS 1024        // upper bound; scratch holds this many partials
 
 extern "C" int igcn_mask_reg_fwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const float* prob, const float* e,
                                  const float* snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,
-                                 float* loss /*[1]*/, float* scratch /*[128]*/, void* stream) {
+                                 float* loss /*[1]*/, float* scratch /*[1024]*/, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   MaskRegArgs a{prob, e, snps, n_prob, n_edge, n_snps, l1_x, ent_x, l1_e, ent_e, eps};
-  hipLaunchKernelGGL(k_mask_reg_fwd, dim3(MR_BLOCKS), dim3(256), 0, st, a, scratch);
+  // ~2k elements per workgroup, at most MR_BLOCKS of them (the dense stress shape has 8.4 M edge-mask values: 128
+  // workgroups left half the chip idle)
+  int64_t blocks = igcn_cdiv(n_prob + n_edge + n_snps, 2048);
+  blocks = blocks < 1 ? 1 : (blocks > MR_BLOCKS ? MR_BLOCKS : blocks);
+  hipLaunchKernelGGL(k_mask_reg_fwd, dim3((unsigned)blocks), dim3(256), 0, st, a, scratch);
   IGCN_CHECK_LAUNCH("mask_reg_fwd");
-  return igcn_launch_reduce_rows(scratch, MR_BLOCKS, 1, 1, loss, 0, st);
+  return igcn_launch_reduce_rows(scratch, blocks, 1, 1, loss, 0, st);
 }
 
 extern "C" int igcn_mask_reg_bwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const float* prob, const float* e,

@@ -982,7 +982,7 @@ class MaskRegulariser(torch.autograd.Function):
         prob, e, snps_prob = _f32(prob), _f32(e), _f32(snps_prob)
         dev = prob.device
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        scratch = torch.empty(128, dtype=torch.float32, device=dev)
+        scratch = torch.empty(1024, dtype=torch.float32, device=dev)
         ctx.hp = (float(l1_x), float(ent_x), float(l1_e), float(ent_e), float(eps))
         call("igcn_mask_reg_fwd", prob.numel(), e.numel(), snps_prob.numel(), ptr(prob), ptr(e), ptr(snps_prob),
              *ctx.hp, ptr(loss), ptr(scratch), stream_ptr())

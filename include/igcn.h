@@ -321,7 +321,7 @@ int igcn_bn1d_bwd(int B, int C, int groups, int training, int relu, const float*
  *   loss = mean r_x(sigmoid(prob)) + mean r_e(e) + mean r_x(sigmoid(snps_prob)),
  *   r(p) = l1*|p| - ent*(p log(p+eps) + (1-p) log(1-p+eps))
  * prob [n_prob] and snps [n_snps] are logits, e [n_edge] the edge mask of igcn_edge_mask_fwd.
- * scratch: float[128].  gout: device scalar d(loss_total)/d(loss).
+ * scratch: float[1024].  gout: device scalar d(loss_total)/d(loss).
  */
 int igcn_mask_reg_fwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const float* prob, const float* e,
                       const float* snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,

@@ -30,7 +30,10 @@ known = 256 * 1024 * 1024
 cf = known / (med(fetch[cal_name]) * 1024)
 cw = known / (med(write[cal_name]) * 1024)
 out = {"calibration": {"kernel": cal_name[:60], "fetch_factor": round(cf, 3), "write_factor": round(cw, 3)}}
-alg = {"k_gcn_propagate_fwd_q": 8663040, "k_gcn_propagate_fwd_wide": 169869312}
+# SURVEY 8d algorithmic bytes per launch: stand-alone scatter-aggregate (20 E' + 8 R F per graph), fused stack lower
+# bound (4 R H0 + 20 E + 4 R D per graph), 512 graphs; dense stress shape, 64 graphs
+alg = {"k_gcn_propagate_fwd_q": 512 * 16920, "k_sgcn_stack_fwd": 512 * 18000,
+       "k_gcn_propagate_fwd_lds": 64 * (20 * 262144 + 8 * 512 * 16)}
 for k in fetch:
     for tag, ab in alg.items():
         if tag in k:

@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""Launch the GCN scatter-aggregate kernel (and a calibration copy) a fixed number of times, for rocprofv3:
+"""Launch the scatter-aggregate kernels (and a calibration copy) a fixed number of times, for rocprofv3:
 
-  rocprofv3 --kernel-trace --stats --output-format csv -d out/trace -- python3 tools/roofline_kernel.py
+  rocprofv3 --kernel-trace --output-format csv -d out/trace -- python3 tools/roofline_kernel.py
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/fetch -- python3 tools/roofline_kernel.py
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/write -- python3 tools/roofline_kernel.py
+  python3 tools/pmc_report.py out > profiles/rNN_pmc/traffic.json
 
-Shapes: `bench` = the launch of the train step (512 x 90-ROI k=3 graphs, F=16); `stress` = 32 dense 512-ROI graphs.
+Kernels: `k_sgcn_stack_fwd` = the LDS-resident SGCN stack at the bench shape (512 x 90-ROI k=3 graphs, F=16, L=2: the
+kernel the default train step launches); `k_gcn_propagate_fwd_q` = the stand-alone scatter-aggregate at the same shape;
+`k_gcn_propagate_fwd_lds` = the LDS-staged dense scatter-aggregate at the stress shape (64 dense 512-ROI graphs).
 The calibration kernel is a float4 device copy of a known byte count (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads
 1/2 of the bytes of a wide coalesced stream; every other access width must be calibrated on a known pattern).
 """
+import ctypes
 import os
 import sys
 
@@ -18,20 +22,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import igcn_amd  # noqa: E402,F401
 from igcn_amd import ops, synth  # noqa: E402
-from igcn_amd._lib import call, stream_ptr  # noqa: E402
+from igcn_amd._lib import call, ptr, stream_ptr  # noqa: E402
+from igcn_amd.data import Batch  # noqa: E402
 
 LAUNCHES = 20
 dev = torch.device("cuda", 0)
 
 
-def run(plan, ew, n, f):
+def run_propagate(plan, ew, n, f, npg):
     coef = ops.GcnNorm.apply(ew, plan)
     h = torch.randn(n, f, device=dev)
     bias = torch.zeros(f, device=dev)
     out = torch.empty_like(h)
     torch.cuda.synchronize()
     for _ in range(LAUNCHES):
-        call("igcn_gcn_propagate_fwd", n, plan.n_edges, f, 0, h.data_ptr(), f, coef[2].data_ptr(), coef[1].data_ptr(),
+        call("igcn_gcn_propagate_fwd", n, plan.n_edges, f, npg, h.data_ptr(), f, coef[2].data_ptr(), coef[1].data_ptr(),
              bias.data_ptr(), plan.tgt_ptr.data_ptr(), out.data_ptr(), f, 1, stream_ptr())
     torch.cuda.synchronize()
 
@@ -44,16 +49,27 @@ for _ in range(LAUNCHES):
     dst.copy_(src)
 torch.cuda.synchronize()
 
-# bench shape
+# bench shape: stand-alone kernel, then the LDS-resident stack
 batch = synth.brain_batch(256, seed=1000, rois=90, tsne_dim=90).to(dev)
 plan = ops.plan_for(batch).replicate(2)
-run(plan, torch.cat([batch.edge_attr, batch.edge_attr]), 2 * batch.x.shape[0], 16)
+ew2 = torch.cat([batch.edge_attr, batch.edge_attr])
+n2 = 2 * batch.x.shape[0]
+run_propagate(plan, ew2, n2, 16, 0)
+h0, f, layers, rois = 3, 16, 2, 90
+x2 = torch.cat([batch.x, batch.x])
+ws = [torch.randn(f, h0 if l == 0 else f, device=dev) * 0.3 for l in range(layers)]
+bs = [torch.randn(f, device=dev) * 0.1 for _ in range(layers)]
+wp = (ctypes.c_void_p * layers)(*[w.data_ptr() for w in ws])
+bp = (ctypes.c_void_p * layers)(*[b.data_ptr() for b in bs])
+xcat = torch.empty(n2, layers * f, device=dev)
+torch.cuda.synchronize()
+for _ in range(LAUNCHES):
+    call("igcn_sgcn_stack_fwd", n2 // rois, rois, plan._stack_dims[1], h0, f, layers, ptr(x2), ptr(ew2), ptr(plan.src32),
+         ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.loop_edge), wp, bp, ptr(xcat), stream_ptr())
+torch.cuda.synchronize()
 
-# stress shape
-rois, g = 512, 32
-r = torch.arange(rois).repeat_interleave(rois)
-c = torch.arange(rois).repeat(rois)
-ei = torch.cat([torch.stack([r, c]) + k * rois for k in range(g)], dim=1).to(dev)
-w = (torch.rand(ei.shape[1], device=dev) / rois)
-run(ops.GraphPlan(ei, g * rois), w, g * rois, 16)
+# stress shape: 64 dense 512-ROI graphs (both passes of a configs[4] step)
+sb = Batch.from_data_list(synth.brain_graph_list(32, seed=1, rois=512, tsne_dim=8, dense=True)).to(dev)
+splan = ops.plan_for(sb).replicate(2)
+run_propagate(splan, torch.cat([sb.edge_attr, sb.edge_attr]), 2 * sb.x.shape[0], 16, 512)
 print("done")
