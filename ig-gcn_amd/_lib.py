@@ -36,8 +36,8 @@ SIGNATURES = {
     "igcn_sgcn_stack_fwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_sgcn_stack_bwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_small_linear_bwd_scratch_floats": (Z, [L, I, I]),
-    "igcn_small_linear_fwd": (I, [L, I, I, P, P, P, P, P]),
-    "igcn_small_linear_bwd": (I, [L, I, I, P, P, P, P, P, P, P]),
+    "igcn_small_linear_fwd": (I, [L, I, I, P, P, P, P, P, P]),
+    "igcn_small_linear_bwd": (I, [L, I, I, P, P, P, P, P, P, P, P]),
     "igcn_snps_mask_fwd": (I, [I, I, P, P, P, P, P, P]),
     "igcn_snps_mask_bwd": (I, [I, I, P, P, P, P, P, P]),
     "igcn_head_inputs_fwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P]),
@@ -53,11 +53,12 @@ SIGNATURES = {
     "igcn_gemm_bf16": (I, [L, L, L, P, L, L, P, L, L, P, P, L, I, I, P, P]),
     "igcn_gemm_f32_batched_sum": (I, [L, L, L, I, P, L, L, L, P, L, L, L, P, L, P, P]),
     "igcn_node_linear_bn_scratch_floats": (Z, [I, I, I]),
-    "igcn_node_linear_bn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, I, F, F, P, P, P, P, P]),
+    "igcn_node_linear_bn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, I, F, F, P, P, P, P, P, P]),
     "igcn_node_linear_bn_bwd_scratch_floats": (Z, [I, I, I, I, I]),
-    "igcn_node_linear_bn_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "igcn_bn1d_fwd": (I, [I, I, I, P, P, P, P, P, I, F, F, I, P, P, P, P]),
-    "igcn_bn1d_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_node_linear_bn_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_bn1d_fwd": (I, [I, I, I, P, P, P, P, P, I, F, F, I, P, P, P, P, P]),
+    "igcn_bn1d_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_dropout_masks": (I, [L, I, P, P, P, P, P]),
     "igcn_mask_reg_fwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P]),
     "igcn_mask_reg_bwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P, P, P]),
     "igcn_rbf_laplacian": (I, [I, I, F, P, P, P]),

@@ -398,15 +398,19 @@ extern "C" int igcn_snps_mask_bwd(int B, int S, const float* snps, const float* 
 // =================================================================================================
 #define SL_MAXC 4
 __global__ void __launch_bounds__(256)
-k_small_linear_fwd(int64_t R, int K, int C, const float* __restrict__ x, const float* __restrict__ W,
-                   const float* __restrict__ b, float* __restrict__ y) {
+k_small_linear_fwd(int64_t R, int K, int C, const float* __restrict__ x, const float* __restrict__ keep,
+                   const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ y) {
   const int kq = K / 4, q = threadIdx.x % kq, rl = threadIdx.x / kq, rpb = 256 / kq;
   const int64_t r = (int64_t)blockIdx.x * rpb + rl;
   float acc[SL_MAXC];
 #pragma unroll
   for (int c = 0; c < SL_MAXC; ++c) acc[c] = 0.f;
   if (rl < rpb && r < R) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + r * K + 4 * q);
+    float4 xv = *reinterpret_cast<const float4*>(x + r * K + 4 * q);
+    if (keep) {                                          // dropout of the input, fused: x * keep
+      const float4 kv = *reinterpret_cast<const float4*>(keep + r * K + 4 * q);
+      xv.x *= kv.x; xv.y *= kv.y; xv.z *= kv.z; xv.w *= kv.w;
+    }
 #pragma unroll
     for (int c = 0; c < SL_MAXC; ++c)
       if (c < C) {
@@ -429,8 +433,8 @@ k_small_linear_fwd(int64_t R, int K, int C, const float* __restrict__ x, const f
 // partial[blk][C*K + c] = sum_{r in blk} dy[r, c].  Rows of a workgroup: rows_per_block, walked 256/KQ at a time.
 __global__ void __launch_bounds__(256)
 k_small_linear_bwd(int64_t R, int K, int C, int rows_per_block, const float* __restrict__ x,
-                   const float* __restrict__ W, const float* __restrict__ dy, float* __restrict__ dx,
-                   float* __restrict__ partial) {
+                   const float* __restrict__ keep, const float* __restrict__ W, const float* __restrict__ dy,
+                   float* __restrict__ dx, float* __restrict__ partial) {
   __shared__ float red[256 * 4];
   const int kq = K / 4, q = threadIdx.x % kq, rl = threadIdx.x / kq, rpb = 256 / kq;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
@@ -445,7 +449,12 @@ k_small_linear_bwd(int64_t R, int K, int C, int rows_per_block, const float* __r
   if (rl < rpb) {
 #pragma unroll 4
     for (int64_t r = r0 + rl; r < r1; r += rpb) {
-      const float4 xv = *reinterpret_cast<const float4*>(x + r * K + 4 * q);
+      float4 xv = *reinterpret_cast<const float4*>(x + r * K + 4 * q);
+      float4 kv = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (keep) {
+        kv = *reinterpret_cast<const float4*>(keep + r * K + 4 * q);
+        xv.x *= kv.x; xv.y *= kv.y; xv.z *= kv.z; xv.w *= kv.w;
+      }
       float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int c = 0; c < SL_MAXC; ++c)
@@ -455,7 +464,7 @@ k_small_linear_bwd(int64_t R, int K, int C, int rows_per_block, const float* __r
           gw[c].x += g * xv.x; gw[c].y += g * xv.y; gw[c].z += g * xv.z; gw[c].w += g * xv.w;
           gb[c] += g;
         }
-      if (dx) *reinterpret_cast<float4*>(dx + r * K + 4 * q) = d;
+      if (dx) *reinterpret_cast<float4*>(dx + r * K + 4 * q) = make_float4(d.x * kv.x, d.y * kv.y, d.z * kv.z, d.w * kv.w);
     }
   }
   float* prow = partial + (int64_t)blockIdx.x * (C * K + C);
@@ -490,27 +499,29 @@ extern "C" size_t igcn_small_linear_bwd_scratch_floats(int64_t R, int K, int C) 
   return (size_t)(igcn_cdiv(R, 64) * (C * K + C) + 64);
 }
 
-extern "C" int igcn_small_linear_fwd(int64_t R, int K, int C, const float* x, const float* W, const float* b, float* y,
-                                     void* stream) {
+extern "C" int igcn_small_linear_fwd(int64_t R, int K, int C, const float* x, const float* keep, const float* W,
+                                     const float* b, float* y, void* stream) {
   IGCN_REQUIRE(R > 0 && small_linear_ok(K, C), "small_linear: K/4 a power of two <= 64, 1 <= C <= 4 (K=%d C=%d)", K, C);
-  IGCN_REQUIRE((((uintptr_t)x | (uintptr_t)W) & 15) == 0, "small_linear: x and W must be 16-byte aligned");
+  IGCN_REQUIRE((((uintptr_t)x | (uintptr_t)W | (uintptr_t)keep) & 15) == 0,
+               "small_linear: x, keep and W must be 16-byte aligned");
   const int rpb = 256 / (K / 4);
   hipLaunchKernelGGL(k_small_linear_fwd, dim3((unsigned)igcn_cdiv(R, rpb)), dim3(256), 0, (hipStream_t)stream, R, K, C,
-                     x, W, b, y);
+                     x, keep, W, b, y);
   IGCN_CHECK_LAUNCH("small_linear_fwd");
   return IGCN_OK;
 }
 
-extern "C" int igcn_small_linear_bwd(int64_t R, int K, int C, const float* x, const float* W, const float* dy,
-                                     float* dx /* or NULL */, float* dwb /* [C*K + C]: dW, then db */, float* scratch,
-                                     void* stream) {
+extern "C" int igcn_small_linear_bwd(int64_t R, int K, int C, const float* x, const float* keep, const float* W,
+                                     const float* dy, float* dx /* or NULL */,
+                                     float* dwb /* [C*K + C]: dW, then db */, float* scratch, void* stream) {
   IGCN_REQUIRE(R > 0 && small_linear_ok(K, C), "small_linear: K/4 a power of two <= 64, 1 <= C <= 4 (K=%d C=%d)", K, C);
-  IGCN_REQUIRE((((uintptr_t)x | (uintptr_t)W | (uintptr_t)dx) & 15) == 0, "small_linear: 16-byte aligned tensors");
+  IGCN_REQUIRE((((uintptr_t)x | (uintptr_t)W | (uintptr_t)dx | (uintptr_t)keep) & 15) == 0,
+               "small_linear: 16-byte aligned tensors");
   hipStream_t st = (hipStream_t)stream;
   const int rows_per_block = 64;
   const int64_t nb = igcn_cdiv(R, rows_per_block);
-  hipLaunchKernelGGL(k_small_linear_bwd, dim3((unsigned)nb), dim3(256), 0, st, R, K, C, rows_per_block, x, W, dy, dx,
-                     scratch);
+  hipLaunchKernelGGL(k_small_linear_bwd, dim3((unsigned)nb), dim3(256), 0, st, R, K, C, rows_per_block, x, keep, W, dy,
+                     dx, scratch);
   IGCN_CHECK_LAUNCH("small_linear_bwd");
   return igcn_launch_reduce_rows_final(scratch, nb, C * K + C, C * K + C, dwb, st);     // dW | db in one pass
 }
@@ -577,5 +588,87 @@ extern "C" int igcn_graph_pool_bwd(int64_t n_graphs, int nodes_per_graph, int D,
   hipLaunchKernelGGL(k_graph_pool_bwd, dim3((unsigned)igcn_cdiv(n_graphs * nodes_per_graph * D, 256)), dim3(256), 0,
                      (hipStream_t)stream, n_graphs, nodes_per_graph, D, dout, argmax, dx);
   IGCN_CHECK_LAUNCH("graph_pool_bwd");
+  return IGCN_OK;
+}
+
+
+// =================================================================================================
+// Dropout masks of every site of a forward pass in ONE launch (the reference draws them site by site: nn.Dropout
+// / nn.Dropout2d / F.dropout at kernel/go_model.py:104,113,128,136,143 and kernel/sgcn_img_snp.py:289,299 — a dozen
+// library launches per step forward and backward).  out[i] = 0 with probability p(segment of i), else 1/(1-p): the
+// {0, 1/(1-p)} factors the consumers multiply by (igcn_nodes_ln_*, igcn_node_linear_bn_*, igcn_bn1d_*,
+// igcn_small_linear_* take them as `keep`).  Counter-based generator: a 32-bit integer hash of (index, stream counter);
+// `state` = {counter, workgroups done} on the device — the LAST workgroup to finish advances the counter, so every
+// replay of a captured launch draws fresh masks without a host round trip.
+// =================================================================================================
+#define DM_MAXSEG 16
+struct DropSegs {
+  int64_t end[DM_MAXSEG];
+  float p[DM_MAXSEG];
+  int n;
+};
+
+__device__ __forceinline__ uint32_t dm_hash(uint32_t x) {       // lowbias32
+  x ^= x >> 16; x *= 0x7feb352dU;
+  x ^= x >> 15; x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+
+__global__ void __launch_bounds__(256)
+k_dropout_masks(int64_t total, DropSegs segs, unsigned long long* __restrict__ state, float* __restrict__ out) {
+  const unsigned long long c = state[0];
+  const uint32_t k0 = dm_hash((uint32_t)c ^ 0x9E3779B9u), k1 = dm_hash((uint32_t)(c >> 32) + 0x85EBCA6Bu + k0);
+  // grid-stride over quads: a few hundred workgroups whatever the size — every workgroup ends with one atomic on the
+  // `done` word, and a single word takes ~90 atomics per microsecond (6000 one-shot workgroups spent 68 us there)
+  for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < total; i0 += (int64_t)gridDim.x * 1024) {
+    float v[4];
+    float p = 0.f;                                     // a quad never straddles sites (sites start on multiples of 4)
+    for (int sgm = 0; sgm < segs.n; ++sgm)
+      if (i0 < segs.end[sgm]) { p = segs.p[sgm]; break; }
+    const float scale = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = i0 + j;
+      const uint32_t h = dm_hash(((uint32_t)i * 0x9E3779B1u) ^ k0) + (uint32_t)(i >> 32) * 0x85EBCA77u;
+      const float u = (float)(dm_hash(h ^ k1) >> 8) * (1.0f / 16777216.0f);             // [0, 1)
+      v[j] = u < p ? 0.f : scale;
+    }
+    if (i0 + 3 < total) {
+      *reinterpret_cast<float4*>(out + i0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int j = 0; j < 4 && i0 + j < total; ++j) out[i0 + j] = v[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long done = atomicAdd(&state[1], 1ull);
+    if (done == (unsigned long long)gridDim.x - 1) {             // every workgroup has read the counter by now
+      state[0] = c + 1;
+      state[1] = 0;
+    }
+  }
+}
+
+extern "C" int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end /*HOST*/,
+                                  const float* seg_p /*HOST*/, void* state /*device uint64[2]*/, float* out,
+                                  void* stream) {
+  IGCN_REQUIRE(total > 0 && n_segments >= 1 && n_segments <= DM_MAXSEG && state != nullptr &&
+               ((uintptr_t)out & 15) == 0, "dropout_masks: 1..%d segments, 16-byte aligned output", DM_MAXSEG);
+  DropSegs sg = {};
+  sg.n = n_segments;
+  for (int k = 0; k < n_segments; ++k) {
+    IGCN_REQUIRE(seg_p[k] >= 0.f && seg_p[k] < 1.f && seg_end[k] <= total, "dropout_masks: bad segment %d", k);
+    sg.end[k] = seg_end[k];
+    sg.p[k] = seg_p[k];
+  }
+  IGCN_REQUIRE(sg.end[n_segments - 1] == total, "dropout_masks: the segments must cover [0, total)");
+  for (int k = 0; k + 1 < n_segments; ++k)
+    IGCN_REQUIRE(sg.end[k] % 4 == 0, "dropout_masks: interior segment ends must be multiples of 4");
+  int64_t blocks = igcn_cdiv(total, 1024);
+  blocks = blocks > 512 ? 512 : blocks;
+  hipLaunchKernelGGL(k_dropout_masks, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, total, sg,
+                     (unsigned long long*)state, out);
+  IGCN_CHECK_LAUNCH("dropout_masks");
   return IGCN_OK;
 }

@@ -158,7 +158,8 @@ template <int F, int D>
 __global__ void __launch_bounds__(RO_T)
 k_nlbn_apply(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
              const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-             const float* __restrict__ rstd, float* __restrict__ out) {
+             const float* __restrict__ rstd, const float* __restrict__ keep /*[B,N] or NULL (D == 1)*/,
+             float* __restrict__ out) {
   const float* __restrict__ w = W;
   const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int n = blockIdx.x * RO_NL + nl;
@@ -183,8 +184,9 @@ k_nlbn_apply(int B, int N, int groups, const float* __restrict__ x, const float*
         *reinterpret_cast<float4*>(o + d) = v;
       }
     } else {
+      const float kp = keep ? keep[(int64_t)b * N + n] : 1.f;          // fused dropout of the read-out (D == 1)
 #pragma unroll
-      for (int d = 0; d < D; ++d) o[d] = fmaxf(pre[d] * sc + sh, 0.f);
+      for (int d = 0; d < D; ++d) o[d] = fmaxf(pre[d] * sc + sh, 0.f) * kp;
     }
   }
 }
@@ -238,13 +240,15 @@ static int ro_quad_chunks(unsigned grid_y, int groups) {
 
 template <int F, int D>
 static void ro_launch_apply(dim3 grid, hipStream_t st, int B, int N, int groups, const float* x, const float* W,
-                            const float* gamma, const float* beta, const float* mean, const float* rstd, float* out) {
+                            const float* gamma, const float* beta, const float* mean, const float* rstd,
+                            const float* keep, float* out) {
   if constexpr (D % 4 == 0 && D <= 64 && D >= 16 && 64 % (D / 4) == 0 && F <= D / 4) {
     // 64/(D/4) nodes per wave give 8x the workgroups of the thread-per-node grid: fewer, longer sample chunks
     dim3 gq((unsigned)igcn_cdiv(N, 64 / (D / 4)), ro_quad_chunks(grid.y, groups) * groups);
     hipLaunchKernelGGL((k_nlbn_apply_q<F, D>), gq, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, mean, rstd, out);
   } else {
-    hipLaunchKernelGGL((k_nlbn_apply<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, mean, rstd, out);
+    hipLaunchKernelGGL((k_nlbn_apply<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, mean, rstd, keep,
+                       out);
   }
 }
 
@@ -280,7 +284,8 @@ template <int F, int D>
 __global__ void __launch_bounds__(RO_T)
 k_nlbn_bwd_stats(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
                  const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-                 const float* __restrict__ rstd, const float* __restrict__ dout, float* __restrict__ partial) {
+                 const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ keep,
+                 float* __restrict__ partial) {
   __shared__ float s1[RO_SG][RO_NL], s2[RO_SG][RO_NL];
   const float* __restrict__ w = W;
   const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
@@ -297,10 +302,11 @@ k_nlbn_bwd_stats(int B, int N, int groups, const float* __restrict__ x, const fl
       ro_pre<F, D>(w, xv, pre);
       float g[D];
       ro_load_row<D>(dout + ((int64_t)b * N + n) * D, g);
+      const float kp = keep ? keep[(int64_t)b * N + n] : 1.f;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const float xh = (pre[d] - mu) * rs;
-        const float dy = (xh * ga + be > 0.f) ? g[d] : 0.f;
+        const float dy = (xh * ga + be > 0.f) ? g[d] * kp : 0.f;
         a1 += dy * xh;      // -> dgamma
         a2 += dy;           // -> dbeta
       }
@@ -324,8 +330,9 @@ template <int F, int D>
 __global__ void __launch_bounds__(RO_T)
 k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict__ x, const float* __restrict__ W,
                  const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-                 const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ dgb,
-                 float* __restrict__ dpre_out, float* __restrict__ dx, float* __restrict__ wpartial) {
+                 const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ keep,
+                 const float* __restrict__ dgb, float* __restrict__ dpre_out, float* __restrict__ dx,
+                 float* __restrict__ wpartial) {
   constexpr bool SMALL = (D * F <= 16);
   constexpr int NW = SMALL ? D * F : 1;
   __shared__ float red[(RO_T / 64) * NW];
@@ -353,10 +360,11 @@ k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict
       ro_pre<F, D>(w, xv, pre);
       float g[D];
       ro_load_row<D>(dout + ((int64_t)b * N + n) * D, g);
+      const float kp = keep ? keep[(int64_t)b * N + n] : 1.f;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const float xh = (pre[d] - mu) * rs;
-        const float dy = (xh * ga + be > 0.f) ? g[d] : 0.f;
+        const float dy = (xh * ga + be > 0.f) ? g[d] * kp : 0.f;
         const float t = ga * rs * (dy - m1 - xh * m2);
         if constexpr (SMALL) {
 #pragma unroll
@@ -561,10 +569,12 @@ extern "C" size_t igcn_node_linear_bn_scratch_floats(int B, int N, int groups) {
 
 extern "C" int igcn_node_linear_bn_fwd(int B, int F, int N, int D, int groups, const float* x, const float* W,
                                        const float* gamma, const float* beta, float* running_mean,
-                                       float* running_var, int training, float momentum, float eps, float* out,
+                                       float* running_var, int training, float momentum, float eps,
+                                       const float* keep /*[B,N] dropout factors, D == 1 only, or NULL*/, float* out,
                                        float* save_mean, float* save_rstd, float* scratch, void* stream) {
   IGCN_REQUIRE(B > 0 && N > 0 && groups >= 1 && groups <= RO_FIN_MAXG && B % groups == 0,
                "node_linear_bn_fwd: bad sizes (1 <= groups <= 8, B divisible by groups)");
+  IGCN_REQUIRE(keep == nullptr || D == 1, "node_linear_bn_fwd: fused dropout (keep) needs D == 1");
   IGCN_REQUIRE(!training || (int64_t)(B / groups) * D > 1,
                "node_linear_bn_fwd: need more than one value per node and group to train");
   hipStream_t st = (hipStream_t)stream;
@@ -575,7 +585,7 @@ extern "C" int igcn_node_linear_bn_fwd(int B, int F, int N, int D, int groups, c
   hipLaunchKernelGGL((k_nlbn_finalize<FV, DV>), dim3((unsigned)igcn_cdiv(N, 64)), dim3(256), 0, st, B, N, groups, \
                      cpg, training, eps, momentum, x, W, scratch, running_mean, running_var, save_mean,           \
                      save_rstd);                                                                                  \
-  ro_launch_apply<FV, DV>(grid, st, B, N, groups, x, W, gamma, beta, save_mean, save_rstd, out)
+  ro_launch_apply<FV, DV>(grid, st, B, N, groups, x, W, gamma, beta, save_mean, save_rstd, keep, out)
   RO_DISPATCH(F, D, CALL)
 #undef CALL
   IGCN_CHECK_LAUNCH("node_linear_bn_fwd");
@@ -600,8 +610,8 @@ extern "C" size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, in
 template <int F, int D>
 static int ro_bwd(dim3 grid, int cpg, hipStream_t st, int B, int N, int groups, int training, const float* x,
                   const float* W, const float* gamma, const float* beta, const float* save_mean,
-                  const float* save_rstd, const float* dout, float* stats, float* dgg, float* aux, float* dx,
-                  float* dW, float* dgb) {
+                  const float* save_rstd, const float* dout, const float* keep, float* stats, float* dgg, float* aux,
+                  float* dx, float* dW, float* dgb) {
   int rc;
   if constexpr (ro_quad_ok<F, D>()) {
     const int cq = ro_quad_chunks(grid.y, groups);           // chunks per group of the row-coalesced kernels
@@ -616,10 +626,10 @@ static int ro_bwd(dim3 grid, int cpg, hipStream_t st, int B, int N, int groups, 
     return igcn_launch_reduce_rows_final(aux, (int64_t)gq.x * gq.y, D * F, D * F, dW, st);
   } else {
     hipLaunchKernelGGL((k_nlbn_bwd_stats<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, save_mean,
-                       save_rstd, dout, stats);
+                       save_rstd, dout, keep, stats);
     if ((rc = igcn_launch_reduce_rows(stats, cpg, (int64_t)groups * 2 * N, groups * 2 * N, dgg, 0, st))) return rc;
     hipLaunchKernelGGL((k_nlbn_bwd_apply<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, training, x, W, gamma, beta,
-                       save_mean, save_rstd, dout, dgg, aux, dx, aux);
+                       save_mean, save_rstd, dout, keep, dgg, aux, dx, aux);
     IGCN_CHECK_LAUNCH("node_linear_bn_bwd");
     if ((rc = igcn_launch_reduce_rows_final(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, st))) return rc;
     if (D * F <= 16) return igcn_launch_reduce_rows_final(aux, (int64_t)grid.x * grid.y, D * F, D * F, dW, st);
@@ -632,9 +642,10 @@ static int ro_bwd(dim3 grid, int cpg, hipStream_t st, int B, int N, int groups, 
 extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, int training, const float* x,
                                        const float* W, const float* gamma, const float* beta,
                                        const float* save_mean, const float* save_rstd, const float* dout,
-                                       float* dx, float* dW, float* dgb /*[2,N]: dgamma, dbeta*/, float* scratch,
-                                       void* stream) {
+                                       const float* keep, float* dx, float* dW,
+                                       float* dgb /*[2,N]: dgamma, dbeta*/, float* scratch, void* stream) {
   IGCN_REQUIRE(B > 0 && N > 0 && groups >= 1 && B % groups == 0, "node_linear_bn_bwd: bad sizes");
+  IGCN_REQUIRE(keep == nullptr || D == 1, "node_linear_bn_bwd: fused dropout (keep) needs D == 1");
   hipStream_t st = (hipStream_t)stream;
   const int cpg = ro_cpg(B, groups);
   dim3 grid((unsigned)igcn_cdiv(N, RO_NL), groups * cpg);
@@ -644,7 +655,7 @@ extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, i
                                                              // wpartial (small) or dpre rows, then slabs (large)
 #define CALL(FV, DV)                                                                                           \
   return ro_bwd<FV, DV>(grid, cpg, st, B, N, groups, training, x, W, gamma, beta, save_mean, save_rstd, dout,   \
-                        stats, dgg, aux, dx, dW, dgb)
+                        keep, stats, dgg, aux, dx, dW, dgb)
   RO_DISPATCH(F, D, CALL)
 #undef CALL
 }
@@ -656,7 +667,8 @@ extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, i
 __global__ void __launch_bounds__(256)
 k_bn1d_fwd(int B, int C, int groups, int training, float momentum, float eps, int relu,
            const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-           float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ y,
+           const float* __restrict__ keep, float* __restrict__ running_mean, float* __restrict__ running_var,
+           float* __restrict__ y,
            float* __restrict__ save_mean, float* __restrict__ save_rstd) {
   __shared__ float red[16];
   const int c = blockIdx.x, bg = B / groups;
@@ -687,9 +699,11 @@ k_bn1d_fwd(int B, int C, int groups, int training, float momentum, float eps, in
       save_rstd[g * C + c] = rstd;
     }
     float* yg = y + (int64_t)g * bg * C + c;
+    const float* kg = keep ? keep + (int64_t)g * bg * C + c : nullptr;
     for (int b = threadIdx.x; b < bg; b += 256) {
       float t = (xg[(int64_t)b * C] - mean) * rstd * ga + be;
-      yg[(int64_t)b * C] = relu ? fmaxf(t, 0.f) : t;
+      t = relu ? fmaxf(t, 0.f) : t;
+      yg[(int64_t)b * C] = kg ? t * kg[(int64_t)b * C] : t;          // fused dropout of the activation
     }
   }
   if (training && threadIdx.x == 0) {
@@ -701,8 +715,8 @@ k_bn1d_fwd(int B, int C, int groups, int training, float momentum, float eps, in
 __global__ void __launch_bounds__(256)
 k_bn1d_bwd(int B, int C, int groups, int training, int relu, const float* __restrict__ x,
            const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ save_mean,
-           const float* __restrict__ save_rstd, const float* __restrict__ dy, float* __restrict__ dx,
-           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+           const float* __restrict__ save_rstd, const float* __restrict__ dy, const float* __restrict__ keep,
+           float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float red[16];
   const int c = blockIdx.x, bg = B / groups;
   const float ga = gamma[c], be = beta[c];
@@ -711,10 +725,12 @@ k_bn1d_bwd(int B, int C, int groups, int training, int relu, const float* __rest
     const float mean = save_mean[g * C + c], rstd = save_rstd[g * C + c];
     const float* xg = x + (int64_t)g * bg * C + c;
     const float* dyg = dy + (int64_t)g * bg * C + c;
+    const float* kg = keep ? keep + (int64_t)g * bg * C + c : nullptr;
     float s1 = 0.f, s2 = 0.f;
     for (int b = threadIdx.x; b < bg; b += 256) {
       const float xh = (xg[(int64_t)b * C] - mean) * rstd;
-      const float d = (!relu || xh * ga + be > 0.f) ? dyg[(int64_t)b * C] : 0.f;
+      const float up = kg ? dyg[(int64_t)b * C] * kg[(int64_t)b * C] : dyg[(int64_t)b * C];
+      const float d = (!relu || xh * ga + be > 0.f) ? up : 0.f;
       s1 += d;
       s2 += d * xh;
     }
@@ -726,7 +742,8 @@ k_bn1d_bwd(int B, int C, int groups, int training, int relu, const float* __rest
     float* dxg = dx + (int64_t)g * bg * C + c;
     for (int b = threadIdx.x; b < bg; b += 256) {
       const float xh = (xg[(int64_t)b * C] - mean) * rstd;
-      const float d = (!relu || xh * ga + be > 0.f) ? dyg[(int64_t)b * C] : 0.f;
+      const float up = kg ? dyg[(int64_t)b * C] * kg[(int64_t)b * C] : dyg[(int64_t)b * C];
+      const float d = (!relu || xh * ga + be > 0.f) ? up : 0.f;
       dxg[(int64_t)b * C] = ga * rstd * (d - m1 - xh * m2);
     }
   }
@@ -738,21 +755,22 @@ k_bn1d_bwd(int B, int C, int groups, int training, int relu, const float* __rest
 
 extern "C" int igcn_bn1d_fwd(int B, int C, int groups, const float* x, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, int training, float momentum, float eps,
-                             int relu, float* y, float* save_mean, float* save_rstd, void* stream) {
+                             int relu, const float* keep /*[B,C] dropout factors or NULL*/, float* y,
+                             float* save_mean, float* save_rstd, void* stream) {
   IGCN_REQUIRE(B > 0 && C > 0 && groups >= 1 && B % groups == 0 && (!training || B / groups > 1),
                "bn1d_fwd: bad sizes");
   hipLaunchKernelGGL(k_bn1d_fwd, dim3(C), dim3(256), 0, (hipStream_t)stream, B, C, groups, training, momentum, eps,
-                     relu, x, gamma, beta, running_mean, running_var, y, save_mean, save_rstd);
+                     relu, x, gamma, beta, keep, running_mean, running_var, y, save_mean, save_rstd);
   IGCN_CHECK_LAUNCH("bn1d_fwd");
   return IGCN_OK;
 }
 
 extern "C" int igcn_bn1d_bwd(int B, int C, int groups, int training, int relu, const float* x, const float* gamma,
                              const float* beta, const float* save_mean, const float* save_rstd, const float* dy,
-                             float* dx, float* dgamma, float* dbeta, void* stream) {
+                             const float* keep, float* dx, float* dgamma, float* dbeta, void* stream) {
   IGCN_REQUIRE(B > 0 && C > 0 && groups >= 1 && B % groups == 0, "bn1d_bwd: bad sizes");
   hipLaunchKernelGGL(k_bn1d_bwd, dim3(C), dim3(256), 0, (hipStream_t)stream, B, C, groups, training, relu, x, gamma,
-                     beta, save_mean, save_rstd, dy, dx, dgamma, dbeta);
+                     beta, save_mean, save_rstd, dy, keep, dx, dgamma, dbeta);
   IGCN_CHECK_LAUNCH("bn1d_bwd");
   return IGCN_OK;
 }

@@ -88,46 +88,53 @@ class Gene_ontology_network(nn.Module):
         self._dropout_enabled = True        # parity tests switch every dropout off
 
     # ---------------------------------------------------------------------------------------------
-    def _node_keeps(self, b, sizes, dev):
-        """Dropout2d on [B,N,f] zeroes whole nodes per sample: keep/(1-p) masks [B,n] for every LayerNorm site of
-        the forward (drawn with one launch for all sites), or Nones."""
-        if not (self.training and self._dropout_enabled and self.node_dropout_p > 0):
-            return [None] * len(sizes)
-        p = self.node_dropout_p
-        total = b * sum(sizes)
-        ones = getattr(self, "_keep_ones", None)       # dropout of a constant: the {0, 1/(1-p)} masks in ONE launch
-        if ones is None or ones.numel() != total or ones.device != dev:
-            ones = self._keep_ones = torch.ones(total, dtype=torch.float32, device=dev)
-        flat = F.dropout(ones, p, True)
-        out, off = [], 0
-        for n in sizes:
-            out.append(flat[off:off + b * n].view(b, n))
-            off += b * n
-        return out
+    def _dropout_masks(self, b, dev, extra=()):
+        """Every dropout of this forward pass from ONE kernel launch (igcn_dropout_masks), as {0, 1/(1-p)} factors
+        that the consumers multiply by inside their own kernels:
+          * nn.Dropout2d(0.4) on [B,N,f] (:104,113) zeroes whole nodes per sample -> ``ln`` [B,n] per LayerNorm site;
+          * nn.Dropout(0.5) on the read-outs inp_out [B,n_top] (:128), out_D [B,N] (:136) and the latent MLP's hidden
+            layer [B,32] (:143);
+          * ``extra`` [(shape, p), ...]: sites of the enclosing model (the two F.dropout of the heads).
+        Returns (dict of GO masks, list of extra masks) — Nones when dropout is off."""
+        ln_sizes = [c.n_rows for c in self.enc_csr] + [c.n_rows for c in self.dec_csr]
+        if not (self.training and self._dropout_enabled):
+            return {"ln": [None] * len(ln_sizes), "inp": None, "out_d": None, "h": None}, [None] * len(extra)
+        state = getattr(self, "_drop_state", None)
+        if state is None or state.state.device != dev:
+            state = self._drop_state = ops.DropoutState(dev)
+        sites = [((b, n), self.node_dropout_p) for n in ln_sizes]
+        sites += [((b, self.n_top), 0.5), ((b, self.n_nodes), 0.5), ((b, self.latent[0].weight.shape[0]), 0.5)]
+        sites += list(extra)
+        m = ops.dropout_masks(sites, state)
+        k = len(ln_sizes)
+        return {"ln": m[:k], "inp": m[k], "out_d": m[k + 1], "h": m[k + 2]}, m[k + 3:]
 
     def _drop(self, x, p):
         return F.dropout(x, p, True) if (self.training and self._dropout_enabled) else x
 
-    def _node_linear_bn(self, x, weight, bn, groups=1):
-        """relu(bn(linear(x))) with bn = BatchNorm1d(#nodes): one fused op (igcn_node_linear_bn_*)."""
+    def _node_linear_bn(self, x, weight, bn, groups=1, keep=None):
+        """dropout(relu(bn(linear(x)))) with bn = BatchNorm1d(#nodes): one fused op (igcn_node_linear_bn_*)."""
         if self.training and bn.track_running_stats:
             self._tracked.append(bn.num_batches_tracked)
         return ops.NodeLinearBN.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                      self.training, bn.momentum, bn.eps, groups)
+                                      self.training, bn.momentum, bn.eps, groups, keep)
 
-    def _bn_relu(self, x, bn, groups=1):
-        """relu(bn(x)) for the latent MLP's BatchNorm1d layers (igcn_bn1d_*)."""
+    def _bn_relu(self, x, bn, groups=1, keep=None):
+        """dropout(relu(bn(x))) for the latent MLP's BatchNorm1d layers (igcn_bn1d_*)."""
         if self.training and bn.track_running_stats:
             self._tracked.append(bn.num_batches_tracked)
         return ops.BatchNorm1dGrouped.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
-                                            bn.momentum, bn.eps, True, groups)
+                                            bn.momentum, bn.eps, True, groups, keep)
 
-    def forward(self, data, T=None, device=None, groups=1):
+    def forward(self, data, T=None, device=None, groups=1, extra_dropout=()):
         """``groups`` > 1: ``data`` holds that many equally sized batches stacked along dim 0 that are treated as
-        successive forward calls (own BatchNorm statistics, running statistics updated in order)."""
+        successive forward calls (own BatchNorm statistics, running statistics updated in order).
+        ``extra_dropout`` [(shape, p), ...]: dropout sites of the caller drawn by the same launch; their factors are
+        left in ``self.extra_masks``."""
         bsz, dev = data.shape[0], data.device
         self._tracked = []
-        keeps = self._node_keeps(bsz, [c.n_rows for c in self.enc_csr] + [c.n_rows for c in self.dec_csr], dev)
+        masks, self.extra_masks = self._dropout_masks(bsz, dev, extra_dropout)
+        keeps = masks["ln"]
         # gene encoding (:208-215)
         x = ops.SparseMap.apply(data, torch.stack(list(self.t)), self.gene_csr)          # [B, in_f, N]
         # encoder (:219-251)
@@ -139,7 +146,7 @@ class Gene_ontology_network(nn.Module):
                                          self.G_B[j].eps)
         # read-outs (:254-255): BatchNorm1d(n_top) normalises per NODE over (batch, feature); fused kernels
         atten_out = self._node_linear_bn(x, self.conc_for_attention[0].weight, self.conc_for_attention[1], groups)
-        inp_out = self._drop(self._node_linear_bn(x, self.conc.weight, self.B[0], groups).squeeze(2), 0.5)
+        inp_out = self._node_linear_bn(x, self.conc.weight, self.B[0], groups, masks["inp"]).squeeze(2)
         # decoder (:258-275)
         for j in range(self.n_l):
             csr = self.dec_csr[j]
@@ -147,11 +154,10 @@ class Gene_ontology_network(nn.Module):
             x = ops.NodesLayerNorm.apply(y, self.G_B_D[j].weight, self.G_B_D[j].bias, keeps[self.n_l + j], 0,
                                          self.G_B_D[j].eps)
         # gene decoding (:278-282)
-        out_d = self._drop(self._node_linear_bn(x, self.conc_D.weight, self.B_D[0], groups).squeeze(2), 0.5)  # [B,N]
+        out_d = self._node_linear_bn(x, self.conc_D.weight, self.B_D[0], groups, masks["out_d"]).squeeze(2)   # [B,N]
         x_d = ops.SparseMap.apply(out_d, self.t_D[0].unsqueeze(0), self.gene_t_csr).squeeze(1)   # [B, 54]
         # latent projection (:138-146,285)
-        h = self._drop(self._bn_relu(ops.linear(inp_out.view(bsz, -1), self.latent[0].weight), self.latent[1],
-                                     groups), 0.5)
+        h = self._bn_relu(ops.linear(inp_out.view(bsz, -1), self.latent[0].weight), self.latent[1], groups, masks["h"])
         latent = self._bn_relu(ops.linear(h, self.latent[4].weight), self.latent[5], groups)
         if self._tracked:                              # num_batches_tracked of the five BatchNorms: one launch
             torch._foreach_add_(self._tracked, groups)

@@ -656,25 +656,27 @@ def head_inputs_supported(img, cross, latent, x, prob):
 
 
 class SmallLinear(torch.autograd.Function):
-    """y = x W^T + b for C <= 4 outputs (lin2 / lin2_regr: 64 -> 3) as one VALU kernel per direction
-    (igcn_small_linear_*) instead of a GEMM forward and five launches backward."""
+    """y = (x * keep) W^T + b for C <= 4 outputs (lin2 / lin2_regr: 64 -> 3) as one VALU kernel per direction
+    (igcn_small_linear_*) instead of a GEMM forward and five launches backward.  ``keep`` (same shape as x, or None):
+    dropout factors of the input, applied inside the kernels (F.dropout of kernel/sgcn_img_snp.py:289,299)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, keep=None):
         x, weight = _f32(x), _f32(weight)
         bias = _f32(bias) if bias is not None else None
+        keep = _f32(keep) if keep is not None else None
         r, k = x.shape
         c = weight.shape[0]
         y = torch.empty(r, c, dtype=torch.float32, device=x.device)
-        call("igcn_small_linear_fwd", r, k, c, ptr(x), ptr(weight), ptr(bias), ptr(y), stream_ptr())
-        ctx.save_for_backward(x, weight)
+        call("igcn_small_linear_fwd", r, k, c, ptr(x), ptr(keep), ptr(weight), ptr(bias), ptr(y), stream_ptr())
+        ctx.save_for_backward(x, weight, keep)
         ctx.has_bias = bias is not None
         ctx.final = _leaves(weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, keep = ctx.saved_tensors
         dy = _f32(dy)
         r, k = x.shape
         c = weight.shape[0]
@@ -683,9 +685,9 @@ class SmallLinear(torch.autograd.Function):
         scratch = _keep(torch.empty(int(_lib.load().igcn_small_linear_bwd_scratch_floats(r, k, c)),
                                     dtype=torch.float32, device=x.device))
         with _immediate(ctx.final):
-            call("igcn_small_linear_bwd", r, k, c, ptr(x), ptr(weight), ptr(dy), ptr(dx), ptr(dwb), ptr(scratch),
-                 stream_ptr())
-        return dx, dwb[:c * k].view(c, k), (dwb[c * k:] if ctx.has_bias else None)
+            call("igcn_small_linear_bwd", r, k, c, ptr(x), ptr(keep), ptr(weight), ptr(dy), ptr(dx), ptr(dwb),
+                 ptr(scratch), stream_ptr())
+        return dx, dwb[:c * k].view(c, k), (dwb[c * k:] if ctx.has_bias else None), None
 
 
 def _small_linear_ok(x2, weight, relu):
@@ -695,14 +697,47 @@ def _small_linear_ok(x2, weight, relu):
             and x2.shape[0] > 0)
 
 
-def linear(x, weight, bias=None, relu=False, bf16=False):
+def linear(x, weight, bias=None, relu=False, bf16=False, keep=None):
+    """``keep``: dropout factors of the INPUT (same shape as x) — fused into the narrow-output kernel, a plain
+    multiply in front of the GEMM otherwise."""
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     if _small_linear_ok(x2, weight, relu) and not bf16:
-        y = SmallLinear.apply(x2, weight, bias)
+        y = SmallLinear.apply(x2, weight, bias, keep.reshape(x2.shape) if keep is not None else None)
     else:
+        if keep is not None:
+            x2 = x2 * keep.reshape(x2.shape)
         y = Linear.apply(x2, weight, bias, relu, bf16)
     return y.view(*lead, weight.shape[0])
+
+
+# =================================================================================================
+# Dropout masks of a forward pass (one launch)
+# =================================================================================================
+class DropoutState:
+    """Device-resident counter of the mask generator (igcn_dropout_masks): seeded from torch's generator, advanced by
+    the kernel itself, so the launch is capturable and every replay draws fresh masks."""
+
+    def __init__(self, device):
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+
+
+def dropout_masks(sites, state):
+    """``sites``: [(shape, p), ...] -> list of float tensors of {0, 1/(1-p)} factors, drawn by ONE kernel launch."""
+    import math
+    sizes = [int(math.prod(shape)) for shape, _ in sites]
+    # every site starts on a 16-byte boundary (its consumers read it with 16-byte loads)
+    starts, total = [], 0
+    for n in sizes:
+        starts.append(total)
+        total += (n + 3) // 4 * 4
+    ends = [(starts[k + 1] if k + 1 < len(sites) else total) for k in range(len(sites))]
+    out = torch.empty(total, dtype=torch.float32, device=state.state.device)
+    seg_end = (ctypes.c_int64 * len(sites))(*ends)
+    seg_p = (ctypes.c_float * len(sites))(*[float(p) for _, p in sites])
+    call("igcn_dropout_masks", total, len(sites), seg_end, seg_p, ptr(state.state), ptr(out), stream_ptr())
+    return [out[s0:s0 + n].view(*shape) for (shape, _), s0, n in zip(sites, starts, sizes)]
 
 
 # =================================================================================================
@@ -906,8 +941,10 @@ class NodeLinearBN(torch.autograd.Function):
     ``groups``: consecutive sample groups with independent batch statistics (passes batched into one launch)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, groups=1):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, groups=1, keep=None):
+        """``keep`` [B,N] (D == 1 only): dropout factors of the output, applied inside the kernels."""
         x, weight, gamma, beta = _f32(x), _f32(weight), _f32(gamma), _f32(beta)
+        keep = _f32(keep) if keep is not None else None
         b, f, n = x.shape
         d = weight.shape[0]
         lib = _lib.load()
@@ -918,16 +955,16 @@ class NodeLinearBN(torch.autograd.Function):
         scratch = torch.empty(int(lib.igcn_node_linear_bn_scratch_floats(b, n, groups)), dtype=torch.float32,
                               device=dev)
         call("igcn_node_linear_bn_fwd", b, f, n, d, groups, ptr(x), ptr(weight), ptr(gamma), ptr(beta),
-             ptr(running_mean), ptr(running_var), int(training), float(momentum), float(eps), ptr(out), ptr(mean),
-             ptr(rstd), ptr(scratch), stream_ptr())
-        ctx.save_for_backward(x, weight, gamma, beta, mean, rstd)
+             ptr(running_mean), ptr(running_var), int(training), float(momentum), float(eps), ptr(keep), ptr(out),
+             ptr(mean), ptr(rstd), ptr(scratch), stream_ptr())
+        ctx.save_for_backward(x, weight, gamma, beta, mean, rstd, keep)
         ctx.training, ctx.groups = int(training), groups
         ctx.final = _leaves(weight, gamma, beta)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, weight, gamma, beta, mean, rstd = ctx.saved_tensors
+        x, weight, gamma, beta, mean, rstd, keep = ctx.saved_tensors
         dout = _f32(dout)
         b, f, n = x.shape
         d = weight.shape[0]
@@ -939,36 +976,40 @@ class NodeLinearBN(torch.autograd.Function):
                                     dtype=torch.float32, device=dev))
         with _immediate(ctx.final):
             call("igcn_node_linear_bn_bwd", b, f, n, d, ctx.groups, ctx.training, ptr(x), ptr(weight), ptr(gamma),
-                 ptr(beta), ptr(mean), ptr(rstd), ptr(dout), ptr(dx), ptr(dw), ptr(dgb), ptr(scratch), stream_ptr())
-        return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None
+                 ptr(beta), ptr(mean), ptr(rstd), ptr(dout), ptr(keep), ptr(dx), ptr(dw), ptr(dgb), ptr(scratch),
+                 stream_ptr())
+        return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, None
 
 
 class BatchNorm1dGrouped(torch.autograd.Function):
     """(ReLU of) BatchNorm1d(C) on [B,C] with grouped batch statistics (latent MLP, go_model.py:138-146)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, groups):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, groups, keep=None):
+        """``keep`` [B,C]: dropout factors of the output, applied inside the kernels."""
         x, gamma, beta = _f32(x), _f32(gamma), _f32(beta)
+        keep = _f32(keep) if keep is not None else None
         b, c = x.shape
         y = torch.empty_like(x)
         mean = torch.empty(groups, c, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         call("igcn_bn1d_fwd", b, c, groups, ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-             int(training), float(momentum), float(eps), int(relu), ptr(y), ptr(mean), ptr(rstd), stream_ptr())
-        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+             int(training), float(momentum), float(eps), int(relu), ptr(keep), ptr(y), ptr(mean), ptr(rstd),
+             stream_ptr())
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, keep)
         ctx.cfg = (int(training), int(relu), groups)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        x, gamma, beta, mean, rstd, keep = ctx.saved_tensors
         training, relu, groups = ctx.cfg
         dy = _f32(dy)
         b, c = x.shape
         dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(beta)
         call("igcn_bn1d_bwd", b, c, groups, training, relu, ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
-             ptr(dy), ptr(dx), ptr(dg), ptr(db), stream_ptr())
-        return dx, dg, db, None, None, None, None, None, None, None
+             ptr(dy), ptr(keep), ptr(dx), ptr(dg), ptr(db), stream_ptr())
+        return dx, dg, db, None, None, None, None, None, None, None, None
 
 
 # =================================================================================================

@@ -300,7 +300,11 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         if self.graph_pool:                                           # :230-235 mean | max | add over a graph's nodes
             img_out = ops.GraphPool.apply(xcat, self.rois)
 
-        latent, x_hat, _, atten_out = self.go_network(snps_in, temperature, device, groups=g)
+        hl = self.lin1.weight.shape[0]
+        head_drop = [((gb, hl), 0.5), ((gb, hl), 0.3)] if (self.training and self._dropout_enabled) else []
+        latent, x_hat, _, atten_out = self.go_network(snps_in, temperature, device, groups=g, extra_dropout=head_drop)
+        keep1, keep2 = self.go_network.extra_masks if head_drop and self.go_network.extra_masks[0] is not None \
+            else (None, None)
         if self.isCrossAtten:
             out_cross = self._cross_attention(batch_x, atten_out)
             if self.graph_pool:                                       # :246-252
@@ -329,7 +333,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                 out_z = (img_out + out_cross) / 2
                 out_lin = torch.cat((out_z, latent), -1)
         linear_outf = ops.linear(out_lin, self.lin1.weight, self.lin1.bias, relu=True, bf16=bf)
-        logits = ops.linear(self._drop(linear_outf, 0.5), self.lin2.weight, self.lin2.bias)
+        if head_drop and keep1 is None:               # the GO network's own dropout is switched off: library masks
+            logits = ops.linear(self._drop(linear_outf, 0.5), self.lin2.weight, self.lin2.bias)
+        else:
+            logits = ops.linear(linear_outf, self.lin2.weight, self.lin2.bias, keep=keep1)
         if fused_head:
             pass
         elif self.isuseProb4Regr and not self.isSNPsOnly:
@@ -338,7 +345,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         else:
             feat = out_lin
         reg = ops.linear(feat, self.lin1_regr.weight, self.lin1_regr.bias, relu=True, bf16=bf)
-        our_reg = ops.linear(self._drop(reg, 0.3), self.lin2_regr.weight, self.lin2_regr.bias)
+        if head_drop and keep2 is None:
+            our_reg = ops.linear(self._drop(reg, 0.3), self.lin2_regr.weight, self.lin2_regr.bias)
+        else:
+            our_reg = ops.linear(reg, self.lin2_regr.weight, self.lin2_regr.bias, keep=keep2)
         outs = (F.log_softmax(logits, dim=-1), x_hat, out_z, out_lin, linear_outf, our_reg)
         if not split:
             return outs                                               # stacked [g*B, ...] (pass-major)

@@ -200,10 +200,12 @@ int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H0, int F, i
  * Backward: dx [R,K] (may be NULL) and dwb [C*K + C] = dW (row-major [C,K]) followed by db.
  * scratch: igcn_small_linear_bwd_scratch_floats(R, K, C). */
 size_t igcn_small_linear_bwd_scratch_floats(int64_t R, int K, int C);
-int igcn_small_linear_fwd(int64_t R, int K, int C, const float* x, const float* W, const float* b, float* y,
-                          void* stream);
-int igcn_small_linear_bwd(int64_t R, int K, int C, const float* x, const float* W, const float* dy, float* dx,
-                          float* dwb, float* scratch, void* stream);
+/* `keep` [R,K] (may be NULL): dropout factors {0, 1/(1-p)} of the INPUT (F.dropout in front of lin2 / lin2_regr,
+ * kernel/sgcn_img_snp.py:289,299), applied inside the kernels: y = (x * keep) W^T + b. */
+int igcn_small_linear_fwd(int64_t R, int K, int C, const float* x, const float* keep, const float* W, const float* b,
+                          float* y, void* stream);
+int igcn_small_linear_bwd(int64_t R, int K, int C, const float* x, const float* keep, const float* W,
+                          const float* dy, float* dx, float* dwb, float* scratch, void* stream);
 
 /* SNP importance mask of cal_probability (kernel/sgcn_img_snp.py:147-151): out [B,S] = snps * sigmoid(p),
  * sp [S] = sigmoid(p).  Backward: dp [S] from dout [B,S] and/or dsp [S] (either may be NULL); snps gets no gradient. */
@@ -297,6 +299,7 @@ size_t igcn_node_linear_bn_scratch_floats(int B, int N, int groups);
 int igcn_node_linear_bn_fwd(int B, int F, int N, int D, int groups, const float* x, const float* W,
                             const float* gamma, const float* beta, float* running_mean, float* running_var,
                             int training, float momentum, float eps,
+                            const float* keep /*[B,N] dropout factors of the output, D == 1 only; NULL = none*/,
                             float* out, float* save_mean /*[groups,N]*/, float* save_rstd /*[groups,N]*/,
                             float* scratch, void* stream);
 /* Outputs dx [B,F,N], dW [D,F], dgb [2,N] = (dgamma, dbeta).  dW = sum_{b,n} dpre[b,n,:] (x) x[b,:,n] is formed in
@@ -305,16 +308,27 @@ int igcn_node_linear_bn_fwd(int B, int F, int N, int D, int groups, const float*
 size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, int D, int groups);
 int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, int training, const float* x, const float* W,
                             const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
-                            const float* dout, float* dx, float* dW, float* dgb, float* scratch, void* stream);
+                            const float* dout, const float* keep, float* dx, float* dW, float* dgb, float* scratch,
+                            void* stream);
 
 /* BatchNorm1d(C) (+ReLU when relu != 0) on a 2-D input [B,C] with the same grouped-statistics semantics —
  * the latent MLP of go_model.py:138-146.  save_mean/save_rstd are [groups,C]. */
 int igcn_bn1d_fwd(int B, int C, int groups, const float* x, const float* gamma, const float* beta,
                   float* running_mean, float* running_var, int training, float momentum, float eps, int relu,
+                  const float* keep /*[B,C] dropout factors of the output or NULL*/,
                   float* y, float* save_mean, float* save_rstd, void* stream);
 int igcn_bn1d_bwd(int B, int C, int groups, int training, int relu, const float* x, const float* gamma,
                   const float* beta, const float* save_mean, const float* save_rstd, const float* dy,
-                  float* dx, float* dgamma, float* dbeta, void* stream);
+                  const float* keep, float* dx, float* dgamma, float* dbeta, void* stream);
+
+/* Dropout factors of every site of a forward pass in ONE launch (the reference draws them site by site: nn.Dropout /
+ * nn.Dropout2d / F.dropout, kernel/go_model.py:104,113,128,136,143, kernel/sgcn_img_snp.py:289,299).  out [total]:
+ * element i of segment k (segments given by their END offsets, HOST arrays, <= 16) is 0 with probability seg_p[k],
+ * else 1/(1-seg_p[k]); consumed as `keep` by igcn_nodes_ln_*, igcn_node_linear_bn_*, igcn_bn1d_*, igcn_small_linear_*.
+ * Counter-based integer-hash generator; `state` = device uint64[2] {stream counter (seed), workgroups done (0)}: the
+ * last workgroup of a launch advances the counter, so every replay of a captured launch draws fresh masks. */
+int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end, const float* seg_p, void* state,
+                       float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Mask regulariser — loss_probability, kernel/sgcn_img_snp.py:153-181:

@@ -900,3 +900,78 @@ def test_fused_sgcn_stack_fwd_bwd(ops, g, r, h0, f, layers, deg, loops):
     for l in range(layers):
         assert_matches(wg[l].grad, wd[l].grad.numpy(), TOL, f"dW{l}", floor=1e-6)
         assert_matches(bg[l].grad, bd[l].grad.numpy(), TOL, f"db{l}", floor=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ fused dropout
+def test_dropout_masks_one_launch(ops):
+    """igcn_dropout_masks: factors in {0, 1/(1-p)} per site, keep rate ~ 1-p, fresh masks on every launch AND on every
+    replay of a captured launch (the kernel advances its own device-side counter)."""
+    torch.manual_seed(123)
+    state = ops.DropoutState(torch.device("cuda"))
+    sites = [((64, 3000), 0.4), ((64, 401), 0.5), ((7,), 0.3), ((128, 64), 0.3)]
+    m1 = ops.dropout_masks(sites, state)
+    m2 = ops.dropout_masks(sites, state)
+    for (shape, p), a, b in zip(sites, m1, m2):
+        assert tuple(a.shape) == tuple(shape)
+        vals = torch.unique(a)
+        assert all(abs(float(v)) < 1e-12 or abs(float(v) - 1.0 / (1.0 - p)) < 1e-6 for v in vals), (p, vals)
+        if a.numel() > 1000:
+            rate = float((a > 0).float().mean())
+            assert abs(rate - (1.0 - p)) < 4.0 * (p * (1 - p) / a.numel()) ** 0.5 + 1e-3, (p, rate)
+            assert float((a != b).float().mean()) > 0.2          # a second launch draws different masks
+            # no visible structure along rows / columns
+            assert float(((a > 0).float().mean(0) - (1 - p)).abs().max()) < 0.35
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        mg = ops.dropout_masks(sites, state)
+    g.replay()
+    first = mg[0].clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float((first != mg[0]).float().mean()) > 0.2          # replays advance the counter
+    assert int(state.state[1].item()) == 0
+
+
+def test_consumers_apply_the_dropout_factors(ops):
+    """`keep` inside igcn_small_linear_*, igcn_bn1d_* and igcn_node_linear_bn_* (D = 1) equals a multiply in front of /
+    behind the unfused op, forward and backward."""
+    rng = np.random.default_rng(5)
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s)).float().cuda()          # noqa: E731
+    keepf = lambda *s: (torch.from_numpy((rng.random(s) > 0.5) * 2.0).float().cuda())   # noqa: E731
+    # --- narrow linear: y = (x * keep) W^T + b
+    x, w, b, k = t(512, 64).requires_grad_(True), t(3, 64).requires_grad_(True), t(3).requires_grad_(True), keepf(512, 64)
+    y = ops.linear(x, w, b, keep=k)
+    cot = t(512, 3)
+    g = torch.autograd.grad((y * cot).sum(), (x, w, b))
+    xr, wr, br = (v.detach().double().requires_grad_(True) for v in (x, w, b))
+    yr = (xr * k.double()) @ wr.t() + br
+    gr = torch.autograd.grad((yr * cot.double()).sum(), (xr, wr, br))
+    assert_matches(y, yr.detach().cpu().numpy(), TOL, "small_linear keep")
+    for a, c, nm in zip(g, gr, ("dx", "dW", "db")):
+        assert_matches(a, c.cpu().numpy(), TOL, "small_linear keep " + nm)
+    # --- BatchNorm1d + ReLU + dropout
+    x, ga, be = t(256, 32).requires_grad_(True), (1 + 0.2 * t(32)).requires_grad_(True), t(32).requires_grad_(True)
+    k = keepf(256, 32)
+    rm, rv = torch.zeros(32, device="cuda"), torch.ones(32, device="cuda")
+    y = ops.BatchNorm1dGrouped.apply(x, ga, be, rm, rv, True, 0.1, 1e-5, True, 2, k)
+    y0 = ops.BatchNorm1dGrouped.apply(x, ga, be, rm.clone(), rv.clone(), True, 0.1, 1e-5, True, 2, None)
+    cot = t(256, 32)
+    g = torch.autograd.grad((y * cot).sum(), (x, ga, be))
+    g0 = torch.autograd.grad((y0 * (cot * k)).sum(), (x, ga, be))
+    assert_matches(y, (y0 * k).detach().cpu().numpy(), 1e-6, "bn1d keep")
+    for a, c, nm in zip(g, g0, ("dx", "dgamma", "dbeta")):
+        assert_matches(a, c.cpu().numpy(), 1e-5, "bn1d keep " + nm)
+    # --- node-wise linear + BatchNorm(#nodes) + ReLU + dropout, D = 1
+    bsz, f, n = 64, 5, 400
+    x, w = t(bsz, f, n).requires_grad_(True), t(1, f).requires_grad_(True)
+    ga, be = (1 + 0.2 * t(n)).requires_grad_(True), (0.1 * t(n)).requires_grad_(True)
+    k = keepf(bsz, n)
+    rm, rv = torch.zeros(n, device="cuda"), torch.ones(n, device="cuda")
+    y = ops.NodeLinearBN.apply(x, w, ga, be, rm, rv, True, 0.1, 1e-5, 2, k)
+    y0 = ops.NodeLinearBN.apply(x, w, ga, be, rm.clone(), rv.clone(), True, 0.1, 1e-5, 2, None)
+    cot = t(bsz, n, 1)
+    g = torch.autograd.grad((y * cot).sum(), (x, w, ga, be))
+    g0 = torch.autograd.grad((y0 * (cot * k.unsqueeze(2))).sum(), (x, w, ga, be))
+    assert_matches(y, (y0 * k.unsqueeze(2)).detach().cpu().numpy(), 1e-6, "nlbn keep")
+    for a, c, nm in zip(g, g0, ("dx", "dW", "dgamma", "dbeta")):
+        assert_matches(a, c.cpu().numpy(), 1e-5, "nlbn keep " + nm, floor=1e-6)
