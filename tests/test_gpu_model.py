@@ -676,3 +676,75 @@ def test_sweep_widths_off_the_kernel_grid_vs_oracle(layers, hidden, fused):
         if sdo[k].grad is None:
             continue
         assert_matches(params[k].grad, sdo[k].grad.numpy(), 5e-3, "grad " + k, floor=1e-6)
+
+
+def test_graphed_step_load_takes_the_new_batch_s_graph_offsets():
+    """GraphedTrainStep.load copies ptr / edge_ptr too: a batch with the same totals but other per-graph edge counts
+    must be grouped on ITS segments (the per-graph plan builders read them), not on the construction batch's."""
+    import copy
+    from igcn_amd import synth
+    from igcn_amd.data import Batch, Data
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    from igcn_amd.train import FlatAdam, GraphedTrainStep, train_step
+    rois, pool = 12, (16, 8, 5, 2, 1)
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=2)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+    torch.manual_seed(4)
+    m1 = SGCN_GCN_IMGSNP(2, 8, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=3, num_classes=3, isSoftSimilarity=True,
+                         rbf_gamma=0.01, isCrossAtten=True, num_regr=3, isuseProb4Regr=True, isImageOnly=False,
+                         isSNPsOnly=False).cuda().train()
+    for m in (m1, m1.go_network):
+        m._dropout_enabled = False
+    m2 = copy.deepcopy(m1)
+    rng = np.random.default_rng(9)
+
+    def graph(e):
+        src, dst = rng.integers(0, rois, e), rng.integers(0, rois, e)
+        return Data(x=torch.from_numpy(rng.random((rois, 3))).float(),
+                    edge_index=torch.from_numpy(np.vstack([src, dst])).long(),
+                    edge_attr=torch.from_numpy(rng.random(e) + 0.05).float(),
+                    y=torch.tensor([int(rng.integers(3))]), clust_y=torch.tensor([0]),
+                    snps_feat=torch.from_numpy(rng.random((1, 54))).float(),
+                    tsne_fdim=torch.from_numpy(rng.random((1, 6))).float(),
+                    clini_score=torch.from_numpy(rng.random(3)).float())
+    counts_a, counts_b = (30, 10, 25, 15), (10, 30, 15, 25)           # same total, other segments
+    batch_a = Batch.from_data_list([graph(e) for e in counts_a]).to("cuda")
+    batch_b = Batch.from_data_list([graph(e) for e in counts_b]).to("cuda")
+    assert batch_a.edge_index.shape == batch_b.edge_index.shape and not torch.equal(batch_a.edge_ptr, batch_b.edge_ptr)
+    lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
+    o1, o2 = FlatAdam(m1.parameters(), lr=1e-3), FlatAdam(m2.parameters(), lr=1e-3)
+    batch_a.x.requires_grad_(True)
+    step = GraphedTrainStep(m1, o1, batch_a, lam, warmup=1)
+    step.load(batch_b)
+    l1 = float(step())
+    step.plan.check()
+    l2 = float(train_step(m2, o2, batch_b, lam))
+    assert abs(l1 - l2) <= 1e-5 * max(1.0, abs(l2)), (l1, l2)
+    with pytest.raises(ValueError):                                   # a batch without the offsets is refused
+        step.load(SimpleNamespace(x=batch_b.x, edge_index=batch_b.edge_index))
+
+
+def test_loss_head_bad_labels_and_disabled_class_terms():
+    """igcn_loss_head_fwd: a label outside [0, C) poisons the loss (NaN) instead of reading out of bounds, and with
+    lam[0] == 0 (main.py's default) the class scores are not read at all — a non-finite log-probability cannot reach
+    the loss through 0 * inf (the reference sets loss_ce = loss_mi = 0.0 outright, :540-542)."""
+    from igcn_amd import ops
+    b, c, nr, s = 8, 3, 3, 54
+    dev = "cuda"
+    logp = torch.log_softmax(torch.randn(2 * b, c, device=dev), dim=1)
+    y = torch.randint(0, c, (b,), device=dev)
+    reg, clin = torch.randn(2 * b, nr, device=dev), torch.randn(b * nr, device=dev)
+    x_hat, snps = torch.randn(2 * b, s, device=dev), torch.randn(b, s, device=dev)
+    gram, prob = torch.rand(2, 2, device=dev), torch.rand((), device=dev)
+    lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
+    good, _ = ops.LossHead.apply(logp, y, reg, clin, x_hat, snps, gram, prob, lam, 1.0, 1.0)
+    assert bool(torch.isfinite(good))
+    bad = y.clone()
+    bad[3] = c                                                         # out of range
+    loss, _ = ops.LossHead.apply(logp, bad, reg, clin, x_hat, snps, gram, prob, lam, 1.0, 1.0)
+    assert bool(torch.isnan(loss))
+    logp_inf = logp.clone()
+    logp_inf[0, int(y[0])] = float("-inf")
+    lam0 = [0.0] + lam[1:]
+    loss0, terms0 = ops.LossHead.apply(logp_inf, y, reg, clin, x_hat, snps, gram, prob, lam0, 1.0, 1.0)
+    assert bool(torch.isfinite(loss0)) and float(terms0[0]) == 0.0 and float(terms0[1]) == 0.0
