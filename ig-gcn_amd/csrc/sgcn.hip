@@ -6,6 +6,188 @@
 #define MAX_H0 8
 
 // =================================================================================================
+// Long edge lists (dense graphs: hundreds of edges per node): per-node sums over a list reached through a permutation
+// (tgt_perm / src_perm) gather 4-byte values at the list's stride — one 64-byte sector per value.  In a dense or
+// otherwise "transposed" structure the SAME list position of NEIGHBOURING nodes is adjacent in memory, so the walks
+// below put the 64 lanes of a wave on 64 consecutive nodes and advance all of them one list position at a time: the
+// permutation entries of a (64 nodes x TL_POS positions) tile are staged in LDS with coalesced reads, then every
+// gather of a step is one contiguous run.  A lane owns its node's running sum (stored order: no cross-lane
+// reduction); the waves of a workgroup take the tiles of a node group in turn and their partial sums meet in LDS in
+// tile order — deterministic, no atomics.  For unstructured sparse graphs the gathers are no better than before, and
+// no worse.  By-source lists of source-sorted edge lists are contiguous instead and keep the wave-per-list walk.
+// =================================================================================================
+#define TL_NODES 64
+#define TL_POS 16
+#define TL_WAVES 8
+#define TL_T (64 * TL_WAVES)
+
+// `fn(k)` is called by the lane that owns node n0 + lane for every edge id k of its list, in list order, for the
+// tiles c = wave, wave + TL_WAVES, ...  tile: this wave's LDS scratch [TL_NODES][TL_POS + 1].
+template <typename Fn>
+__device__ __forceinline__ void tl_walk(int32_t (*tile)[TL_POS + 1], const int32_t* __restrict__ ptr,
+                                        const int32_t* __restrict__ perm, int64_t n0, int64_t n_nodes, int wave,
+                                        int lane, Fn fn) {
+  const int64_t node = n0 + lane;
+  const int32_t p0 = node < n_nodes ? ptr[node] : 0, p1 = node < n_nodes ? ptr[node + 1] : 0;
+  int maxdeg = p1 - p0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o, 64));
+  const int sub = lane >> 4, q = lane & 15;            // staging: 4 nodes x 16 positions per wave instruction
+  for (int c = wave; c * TL_POS < maxdeg; c += TL_WAVES) {
+#pragma unroll 4
+    for (int r = 0; r < TL_NODES; r += 4) {
+      const int tt = r + sub;
+      const int32_t a0 = __shfl(p0, tt, 64), a1 = __shfl(p1, tt, 64);
+      const int32_t pos = a0 + c * TL_POS + q;
+      tile[tt][q] = pos < a1 ? perm[pos] : -1;
+    }
+    // (same wave wrote and reads the tile: LDS operations of a wave execute in order)
+#pragma unroll 4
+    for (int j = 0; j < TL_POS; ++j) {
+      const int32_t k = tile[lane][j];
+      if (k >= 0) fn(k);
+    }
+  }
+}
+
+// The other structure: lists that are CONTIGUOUS in the gathered arrays (the by-source lists of an edge list sorted by
+// source — what coo_matrix / nonzero / dense_to_sparse produce — have src_perm = identity): there the lanes of a wave
+// stride ONE node's list.  The waves of the workgroup take the 64 nodes in turn; out[node - n0] = sum_k fn(k, node).
+template <typename Fn>
+__device__ __forceinline__ void tl_rowwalk(float* out /*LDS [TL_NODES]*/, const int32_t* __restrict__ ptr,
+                                           const int32_t* __restrict__ perm, int64_t n0, int64_t n_nodes, int wave,
+                                           int lane, Fn fn) {
+  for (int nn = wave; nn < TL_NODES; nn += TL_WAVES) {
+    const int64_t node = n0 + nn;
+    float acc = 0.f;
+    if (node < n_nodes) {                               // wave-uniform
+      const int32_t p1 = ptr[node + 1];
+#pragma unroll 4
+      for (int32_t pp = ptr[node] + lane; pp < p1; pp += 64) acc += fn(perm[pp], node);
+      acc = wave_sum_all(acc);
+    }
+    if (lane == 0) out[nn] = acc;
+  }
+}
+
+// sum of the waves' per-node partials in wave order; red: [TL_WAVES][TL_NODES]; result valid for tid < TL_NODES
+__device__ __forceinline__ float tl_combine(float v, float (*red)[TL_NODES], int wave, int lane) {
+  __syncthreads();
+  red[wave][lane] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < TL_WAVES; ++w) t += red[w][lane];
+  }
+  return t;
+}
+
+// gcn_norm forward, dense graphs: deg, dis, wl for 64 nodes per workgroup
+__global__ void __launch_bounds__(TL_T)
+k_gcn_norm_fwd_tiled(int64_t n_nodes, const float* __restrict__ ew, const int32_t* __restrict__ src32,
+                     const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
+                     const int32_t* __restrict__ loop_edge, float* __restrict__ dis, float* __restrict__ wl) {
+  __shared__ int32_t tiles[TL_WAVES][TL_NODES][TL_POS + 1];
+  __shared__ float red[TL_WAVES][TL_NODES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n0 = (int64_t)blockIdx.x * TL_NODES, node = n0 + lane;
+  float deg = 0.f;
+  tl_walk(tiles[wave], tgt_ptr, tgt_perm, n0, n_nodes, wave, lane, [&](int32_t k) {
+    if (src32[k] != (int32_t)node) deg += ew[k];
+  });
+  deg = tl_combine(deg, red, wave, lane);
+  if (wave == 0 && node < n_nodes) {
+    const int32_t le = loop_edge[node];
+    const float lw = le >= 0 ? ew[le] : 1.f;
+    deg += lw;
+    float d = 1.0f / sqrtf(deg);
+    if (deg == 0.f) d = 0.f;
+    dis[node] = d;
+    wl[node] = lw;
+  }
+}
+
+// gcn_norm backward phase 1, dense graphs (formula: k_gcn_norm_bwd_deg)
+__global__ void __launch_bounds__(TL_T)
+k_gcn_norm_bwd_deg_tiled(int64_t n_nodes, const float* __restrict__ ew, const float* __restrict__ dis,
+                         const float* __restrict__ wl, const float* __restrict__ dwhat,
+                         const float* __restrict__ dwhat_loop, const int32_t* __restrict__ src32,
+                         const int32_t* __restrict__ dst32, const int32_t* __restrict__ tgt_ptr,
+                         const int32_t* __restrict__ tgt_perm, const int32_t* __restrict__ src_ptr,
+                         const int32_t* __restrict__ src_perm, float* __restrict__ ddeg) {
+  __shared__ int32_t tiles[TL_WAVES][TL_NODES][TL_POS + 1];
+  __shared__ float red[TL_WAVES][TL_NODES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n0 = (int64_t)blockIdx.x * TL_NODES, node = n0 + lane;
+  __shared__ float bysrc[TL_NODES];
+  tl_rowwalk(bysrc, src_ptr, src_perm, n0, n_nodes, wave, lane, [&](int32_t k, int64_t nd) {
+    const int32_t t = dst32[k];
+    return t != (int32_t)nd ? dwhat[k] * ew[k] * dis[t] : 0.f;
+  });
+  float dd = 0.f;
+  tl_walk(tiles[wave], tgt_ptr, tgt_perm, n0, n_nodes, wave, lane, [&](int32_t k) {
+    const int32_t sn = src32[k];
+    if (sn != (int32_t)node) dd += dwhat[k] * ew[k] * dis[sn];
+  });
+  dd = tl_combine(dd, red, wave, lane);                 // (its barriers also publish bysrc)
+  if (wave == 0 && node < n_nodes) {
+    const float di = dis[node];
+    dd += bysrc[lane];
+    dd += 2.f * dwhat_loop[node] * wl[node] * di;
+    ddeg[node] = -0.5f * di * di * di * dd;
+  }
+}
+
+// edge-mask backward node pass, dense graphs (formula: k_edge_mask_bwd_nodes); partial row layout identical
+__global__ void __launch_bounds__(TL_T)
+k_edge_mask_bwd_nodes_tiled(int64_t n_nodes, int rois, int h0, const float* __restrict__ x,
+                            const float* __restrict__ prob, const float* __restrict__ pb,
+                            const float* __restrict__ ew, const float* __restrict__ e,
+                            const float* __restrict__ d_xm, const float* __restrict__ d_ewm,
+                            const float* __restrict__ d_e, const float* __restrict__ d_x_plain,
+                            const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
+                            const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_perm,
+                            float* __restrict__ dx, float* __restrict__ gx, float* __restrict__ pb_partial) {
+  __shared__ int32_t tiles[TL_WAVES][TL_NODES][TL_POS + 1];
+  __shared__ float red[TL_WAVES][TL_NODES];
+  __shared__ float pbred[TL_NODES][2 * MAX_H0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n0 = (int64_t)blockIdx.x * TL_NODES, node = n0 + lane;
+  auto dz = [&](int32_t k) {
+    const float ek = e[k];
+    const float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
+    return up * ek * (1.f - ek);
+  };
+  __shared__ float bysrc[TL_NODES];
+  tl_rowwalk(bysrc, src_ptr, src_perm, n0, n_nodes, wave, lane, [&](int32_t k, int64_t) { return dz(k); });
+  float T = 0.f;
+  tl_walk(tiles[wave], tgt_ptr, tgt_perm, n0, n_nodes, wave, lane, [&](int32_t k) { T += dz(k); });
+  T = tl_combine(T, red, wave, lane);                   // (its barriers also publish bysrc)
+  const float S = bysrc[lane];
+  if (wave == 0) {
+    for (int j = 0; j < 2 * MAX_H0; ++j) pbred[lane][j] = 0.f;
+    if (node < n_nodes) {
+      const int64_t r = (node % rois) * h0;
+      for (int h = 0; h < h0; ++h) {
+        const float xv = x[node * h0 + h], pv = prob[r + h];
+        const float g = (d_xm ? d_xm[node * h0 + h] : 0.f) + pb[h] * S + pb[h0 + h] * T;
+        dx[node * h0 + h] = g * pv + (d_x_plain ? d_x_plain[node * h0 + h] : 0.f);
+        gx[node * h0 + h] = g * xv;
+        pbred[lane][h] = xv * pv * S;
+        pbred[lane][MAX_H0 + h] = xv * pv * T;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * MAX_H0) {
+    float t = 0.f;
+    for (int l = 0; l < TL_NODES; ++l) t += pbred[l][threadIdx.x];
+    pb_partial[(int64_t)blockIdx.x * 2 * MAX_H0 + threadIdx.x] = t;
+  }
+}
+
+// =================================================================================================
 // edge mask forward  (cal_probability, kernel/sgcn_img_snp.py:133-151)
 // =================================================================================================
 __global__ void k_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* __restrict__ x,
@@ -137,10 +319,14 @@ extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, in
   IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0, "edge_mask_bwd: bad rois/h0");
   hipStream_t st = (hipStream_t)stream;
   const bool dense = n_edges >= 16 * n_nodes;
-  const int64_t nblk = igcn_cdiv(n_nodes, dense ? 4 : 64);        // 64 or 4 lanes per node
+  const bool tiled = dense && getenv("IGCN_NO_TILED_LISTS") == nullptr;
+  const int64_t nblk = tiled ? igcn_cdiv(n_nodes, TL_NODES) : igcn_cdiv(n_nodes, dense ? 4 : 64);
   float* gx = scratch;
   float* part = scratch + n_nodes * h0;  // [nblk, 2*MAX_H0]
-  if (dense)                                       // dense graphs: the wave strides a node's edge lists
+  if (tiled)                                       // dense graphs: lanes own nodes, permutation tiles through LDS
+    hipLaunchKernelGGL(k_edge_mask_bwd_nodes_tiled, dim3((unsigned)nblk), dim3(TL_T), 0, st, n_nodes, rois, h0, x, prob,
+                       prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
+  else if (dense)                                  // (A/B: the wave strides a node's edge lists)
     hipLaunchKernelGGL(k_edge_mask_bwd_nodes<64>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
                        prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
   else                                             // k = 3 graphs: four lanes share a node's six list entries
@@ -220,21 +406,104 @@ __global__ void k_gcn_norm_coef(int64_t n_nodes, int64_t n_edges, const float* _
   }
 }
 
+// Dense graphs: the same outputs as k_gcn_norm_coef in three coalesced passes instead of one pass of ~12 strided
+// 4-byte gathers per edge: (1) what / what_loop in edge order; (2) the by-target record stream through the tiled
+// lane-per-node walk (gathers of a step contiguous), its records transposed back through LDS so that a node's 16
+// records leave as one 128-byte run; (3) the by-source stream position by position (contiguous lists).
+__global__ void k_gcn_norm_what(int64_t n_nodes, int64_t n_edges, const float* __restrict__ ew,
+                                const float* __restrict__ dis, const float* __restrict__ wl,
+                                const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
+                                float* __restrict__ what, float* __restrict__ what_loop) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_edges) {
+    const int32_t sn = src32[i], tn = dst32[i];
+    what[i] = sn != tn ? dis[sn] * ew[i] * dis[tn] : 0.f;
+  }
+  if (i < n_nodes) {
+    const float d = dis[i];
+    what_loop[i] = d * wl[i] * d;
+  }
+}
+
+__global__ void __launch_bounds__(TL_T)
+k_stream_by_target_tiled(int64_t n_nodes, const float* __restrict__ what, const int32_t* __restrict__ src32,
+                         const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
+                         EdgeRec* __restrict__ tstream) {
+  __shared__ int32_t tiles[TL_WAVES][TL_NODES][TL_POS + 1];
+  __shared__ EdgeRec recs[TL_WAVES][TL_NODES][TL_POS + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n0 = (int64_t)blockIdx.x * TL_NODES, node = n0 + lane;
+  const int32_t p0 = node < n_nodes ? tgt_ptr[node] : 0, p1 = node < n_nodes ? tgt_ptr[node + 1] : 0;
+  int maxdeg = p1 - p0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o, 64));
+  const int sub = lane >> 4, q = lane & 15;
+  int32_t (*tile)[TL_POS + 1] = tiles[wave];
+  EdgeRec (*rec)[TL_POS + 1] = recs[wave];
+  for (int c = wave; c * TL_POS < maxdeg; c += TL_WAVES) {
+#pragma unroll 4
+    for (int r = 0; r < TL_NODES; r += 4) {
+      const int tt = r + sub;
+      const int32_t a0 = __shfl(p0, tt, 64), a1 = __shfl(p1, tt, 64);
+      const int32_t pos = a0 + c * TL_POS + q;
+      tile[tt][q] = pos < a1 ? tgt_perm[pos] : -1;
+    }
+#pragma unroll 4
+    for (int j = 0; j < TL_POS; ++j) {                   // lanes = nodes: the gathers of a step are one run
+      const int32_t k = tile[lane][j];
+      EdgeRec e;
+      e.idx = 0; e.w = 0.f;
+      if (k >= 0) { e.idx = src32[k]; e.w = what[k]; }
+      rec[lane][j] = e;
+    }
+#pragma unroll 4
+    for (int r = 0; r < TL_NODES; r += 4) {              // lanes = (node, position): 128-byte runs out
+      const int tt = r + sub;
+      const int32_t a0 = __shfl(p0, tt, 64), a1 = __shfl(p1, tt, 64);
+      const int32_t pos = a0 + c * TL_POS + q;
+      if (pos < a1) tstream[pos] = rec[tt][q];
+    }
+  }
+}
+
+__global__ void k_stream_by_source(int64_t n_edges, const float* __restrict__ what, const int32_t* __restrict__ dst32,
+                                   const int32_t* __restrict__ src_perm, EdgeRec* __restrict__ sstream) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_edges) return;
+  const int32_t k = src_perm[i];
+  EdgeRec e;
+  e.idx = dst32[k];
+  e.w = what[k];
+  sstream[i] = e;
+}
+
 extern "C" int igcn_gcn_norm_fwd(int64_t n_nodes, int64_t n_edges, const float* ew, const int32_t* src32,
                                  const int32_t* dst32, const int32_t* tgt_ptr, const int32_t* tgt_perm,
                                  const int32_t* src_perm, const int32_t* loop_edge, float* dis, float* wl,
                                  float* what, float* what_loop, void* tstream, void* sstream, void* stream) {
   if (n_nodes == 0) return IGCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (n_edges >= 16 * n_nodes)                     // dense graphs: one wave per node
+  if (n_edges >= 16 * n_nodes && getenv("IGCN_NO_TILED_LISTS") == nullptr)      // dense graphs: lanes own nodes
+    hipLaunchKernelGGL(k_gcn_norm_fwd_tiled, dim3((unsigned)igcn_cdiv(n_nodes, TL_NODES)), dim3(TL_T), 0, st, n_nodes,
+                       ew, src32, tgt_ptr, tgt_perm, loop_edge, dis, wl);
+  else if (n_edges >= 16 * n_nodes)                // (A/B: one wave per node)
     hipLaunchKernelGGL(k_gcn_norm_fwd<64>, dim3((unsigned)igcn_cdiv(n_nodes * 64, 256)), dim3(256), 0, st, n_nodes, ew,
                        src32, tgt_ptr, tgt_perm, loop_edge, dis, wl);
   else
     hipLaunchKernelGGL(k_gcn_norm_fwd<4>, dim3((unsigned)igcn_cdiv(n_nodes * 4, 256)), dim3(256), 0, st, n_nodes, ew,
                        src32, tgt_ptr, tgt_perm, loop_edge, dis, wl);
   const int64_t n = n_nodes > n_edges ? n_nodes : n_edges;
-  hipLaunchKernelGGL(k_gcn_norm_coef, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, st, n_nodes, n_edges, ew, dis,
-                     wl, src32, dst32, tgt_perm, src_perm, what, what_loop, (EdgeRec*)tstream, (EdgeRec*)sstream);
+  if (n_edges >= 16 * n_nodes && getenv("IGCN_NO_TILED_LISTS") == nullptr) {
+    hipLaunchKernelGGL(k_gcn_norm_what, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, st, n_nodes, n_edges, ew, dis,
+                       wl, src32, dst32, what, what_loop);
+    hipLaunchKernelGGL(k_stream_by_target_tiled, dim3((unsigned)igcn_cdiv(n_nodes, TL_NODES)), dim3(TL_T), 0, st,
+                       n_nodes, what, src32, tgt_ptr, tgt_perm, (EdgeRec*)tstream);
+    hipLaunchKernelGGL(k_stream_by_source, dim3((unsigned)igcn_cdiv(n_edges, 256)), dim3(256), 0, st, n_edges, what,
+                       dst32, src_perm, (EdgeRec*)sstream);
+  } else {
+    hipLaunchKernelGGL(k_gcn_norm_coef, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, st, n_nodes, n_edges, ew, dis,
+                       wl, src32, dst32, tgt_perm, src_perm, what, what_loop, (EdgeRec*)tstream, (EdgeRec*)sstream);
+  }
   IGCN_CHECK_LAUNCH("gcn_norm_fwd");
   return IGCN_OK;
 }
@@ -297,7 +566,11 @@ extern "C" int igcn_gcn_norm_bwd(int64_t n_nodes, int64_t n_edges, const float* 
                                  const int32_t* loop_edge, float* dew, float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n_nodes == 0 || n_edges == 0) return IGCN_OK;
-  if (n_edges >= 16 * n_nodes)
+  if (n_edges >= 16 * n_nodes && getenv("IGCN_NO_TILED_LISTS") == nullptr)
+    hipLaunchKernelGGL(k_gcn_norm_bwd_deg_tiled, dim3((unsigned)igcn_cdiv(n_nodes, TL_NODES)), dim3(TL_T), 0, st,
+                       n_nodes, ew, dis, wl, dwhat, dwhat_loop, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm,
+                       scratch);
+  else if (n_edges >= 16 * n_nodes)
     hipLaunchKernelGGL(k_gcn_norm_bwd_deg<64>, dim3((unsigned)igcn_cdiv(n_nodes * 64, 256)), dim3(256), 0, st, n_nodes,
                        ew, dis, wl, dwhat, dwhat_loop, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, scratch);
   else
