@@ -62,8 +62,8 @@ SIGNATURES = {
     "igcn_mask_reg_fwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P]),
     "igcn_mask_reg_bwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P, P, P]),
     "igcn_rbf_laplacian": (I, [I, I, F, P, P, P]),
-    "igcn_gram_loss_fwd": (I, [I, I, P, P, P, P, P]),
-    "igcn_gram_loss_bwd": (I, [I, P, P, P, P, P]),
+    "igcn_gram_loss_fwd": (I, [I, I, I, P, P, P, P, P]),
+    "igcn_gram_loss_bwd": (I, [I, I, P, P, P, P, P]),
     "igcn_attn_core_lds_bytes": (Z, [I, I, I, I, I]),
     "igcn_attn_core_fwd": (I, [I, I, I, I, I, P, P, P, P, P]),
     "igcn_attn_core_bwd_scratch_floats": (Z, [I, I, I]),

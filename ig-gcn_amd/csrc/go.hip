@@ -207,6 +207,20 @@ __device__ __forceinline__ void transform(const float (&w)[FOUT][FIN], const flo
   }
 }
 
+// y[d] = sum_c w[c][d] * v[c]: a FOUT-vector pulled back to the input features.  Scores and row sums only ever
+// need x_in = W_inc x of a NEIGHBOUR inside a dot product, a . (W x) = (W^T a) . x: FIN multiply-adds per edge instead
+// of a FIN x FOUT transform plus a FOUT dot
+template <int FIN, int FOUT>
+__device__ __forceinline__ void pull_back(const float (&w)[FOUT][FIN], const float (&v)[FOUT], float (&y)[FIN]) {
+#pragma unroll
+  for (int d = 0; d < FIN; ++d) {
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) t += w[c][d] * v[c];
+    y[d] = t;
+  }
+}
+
 template <int FIN>
 __device__ __forceinline__ void load_node(const float* __restrict__ xb, int N, int n, float (&v)[FIN]) {
 #pragma unroll
@@ -237,31 +251,33 @@ k_go_attn_fwd(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restr
   transform<FIN, FOUT>(W.wi, xr, xin);
   transform<FIN, FOUT>(W.ws, xr, xs);
   const float p = dot<FOUT>(W.a1, xin);
-  float Z = 0.f, agg[FOUT];
+  float v2[FIN];
+  pull_back<FIN, FOUT>(W.wi, W.a2, v2);
+  float Z = 0.f, ax[FIN];                            // sum_e s_e x_m: transformed ONCE after the walk
 #pragma unroll
-  for (int c = 0; c < FOUT; ++c) agg[c] = 0.f;
+  for (int d = 0; d < FIN; ++d) ax[d] = 0.f;
   const int32_t p0 = row_ptr[n], p1 = row_ptr[n + 1];
   // two edges per step: both neighbour indices, then both neighbour rows, are in flight together (a GO term has
   // 1-2 parents: most walks are one dependent index->row chain instead of two); summation order is unchanged
   for (int32_t e = p0; e < p1; e += 2) {
     const bool two = e + 1 < p1;
     const int m0 = col[e], m1 = col[two ? e + 1 : e];
-    float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
+    float xm0[FIN], xm1[FIN];
     load_node<FIN>(xb, N, m0, xm0);
     load_node<FIN>(xb, N, m1, xm1);
-    transform<FIN, FOUT>(W.wi, xm0, xi0);
-    transform<FIN, FOUT>(W.wi, xm1, xi1);
-    const float s0 = go_exp(go_tanh(p + dot<FOUT>(W.a2, xi0)));
-    const float s1 = two ? go_exp(go_tanh(p + dot<FOUT>(W.a2, xi1))) : 0.f;
+    const float s0 = go_exp(go_tanh(p + dot<FIN>(v2, xm0)));
+    const float s1 = two ? go_exp(go_tanh(p + dot<FIN>(v2, xm1))) : 0.f;
     Z += s0;
 #pragma unroll
-    for (int c = 0; c < FOUT; ++c) agg[c] += s0 * xi0[c];
+    for (int d = 0; d < FIN; ++d) ax[d] += s0 * xm0[d];
     if (two) {
       Z += s1;
 #pragma unroll
-      for (int c = 0; c < FOUT; ++c) agg[c] += s1 * xi1[c];
+      for (int d = 0; d < FIN; ++d) ax[d] += s1 * xm1[d];
     }
   }
+  float agg[FOUT];
+  transform<FIN, FOUT>(W.wi, ax, agg);
   const float zinv = p1 > p0 ? 1.f / Z : 0.f;
   const float g = 1.f / (1.f + go_exp(-dot<FOUT>(W.as, xs)));
   float* yb = y + (int64_t)b * FOUT * N;
@@ -293,8 +309,35 @@ extern "C" int igcn_go_attn_fwd(int B, int N, int fin, int fout, const int32_t* 
   return IGCN_OK;
 }
 
-// ---- backward, kernel A: per-row softmax statistics -------------------------------------------
-// stats[0]=p (a1.x_in), [1]=q (a2.x_in), [2]=1/Z, [3]=tr = dy . (agg/Z), each [B,N]
+// ---- backward, kernel A: per-row softmax statistics + the row-side score gradient --------------
+// stats = (p (a1.x_in), q (a2.x_in), 1/Z, tr = dy . (agg/Z)) per node as one float4, then dp [B,N].
+// With s_e = exp(tanh(p + q_m)), w_e = s_e (1 - tanh^2), D_e = dy_n . x_in,m = (W_inc^T dy_n) . x_m, one walk over a
+// node's own edges yields everything the row side needs:
+//   Z = sum s_e,  tr = (sum s_e D_e) / Z,  dp = sum_e (D_e - tr) (s_e / Z) (1 - tanh^2) = (sum w_e D_e - tr sum w_e) / Z
+// — the second walk of the same edges the first version made (recomputing the transforms, tanh and exp) is gone, and
+// a neighbour costs 2 FIN multiply-adds instead of a FIN x FOUT transform and two FOUT dots.
+template <int FIN, int FOUT>
+struct RowPass {
+  float v2[FIN], g[FIN], p, Z, A, Bw, Cw;
+  __device__ __forceinline__ void begin(const float (&wi)[FOUT][FIN], const float (&a2)[FOUT], const float (&dyn)[FOUT],
+                                        float p_) {
+    pull_back<FIN, FOUT>(wi, a2, v2);
+    pull_back<FIN, FOUT>(wi, dyn, g);
+    p = p_; Z = 0.f; A = 0.f; Bw = 0.f; Cw = 0.f;
+  }
+  __device__ __forceinline__ void edge(const float (&xm)[FIN]) {
+    const float th = go_tanh(p + dot<FIN>(v2, xm));
+    const float s = go_exp(th), w = s * (1.f - th * th), D = dot<FIN>(g, xm);
+    Z += s; A += s * D; Bw += w * D; Cw += w;
+  }
+  // (1/Z, tr, dp)
+  __device__ __forceinline__ void end(bool any, float& zinv, float& tr, float& dp) const {
+    zinv = any ? 1.f / Z : 0.f;
+    tr = A * zinv;
+    dp = (Bw - tr * Cw) * zinv;
+  }
+};
+
 template <int FIN, int FOUT>
 __global__ void __launch_bounds__(GO_T)
 k_go_attn_bwd_stats(int B, int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
@@ -312,40 +355,65 @@ k_go_attn_bwd_stats(int B, int N, const int32_t* __restrict__ row_ptr, const int
   const int b = blockIdx.y;
   if (n >= N) return;
   const float* xb = x + (int64_t)b * FIN * N;
-  float xr[FIN], xin[FOUT];
+  float xr[FIN], xin[FOUT], dyn[FOUT];
   load_node<FIN>(xb, N, n, xr);
+  load_node<FOUT>(dy + (int64_t)b * FOUT * N, N, n, dyn);
   transform<FIN, FOUT>(wi, xr, xin);
-  const float p = dot<FOUT>(a1, xin);
-  const float q = dot<FOUT>(a2, xin);
-  float Z = 0.f, agg[FOUT];
-#pragma unroll
-  for (int c = 0; c < FOUT; ++c) agg[c] = 0.f;
+  RowPass<FIN, FOUT> rp;
+  rp.begin(wi, a2, dyn, dot<FOUT>(a1, xin));
   const int32_t p0 = row_ptr[n], p1 = row_ptr[n + 1];
   for (int32_t e = p0; e < p1; e += 2) {            // two edges per step, as in the forward kernel
     const bool two = e + 1 < p1;
     const int m0 = col[e], m1 = col[two ? e + 1 : e];
-    float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
+    float xm0[FIN], xm1[FIN];
     load_node<FIN>(xb, N, m0, xm0);
     load_node<FIN>(xb, N, m1, xm1);
-    transform<FIN, FOUT>(wi, xm0, xi0);
-    transform<FIN, FOUT>(wi, xm1, xi1);
-    const float s0 = go_exp(go_tanh(p + dot<FOUT>(a2, xi0)));
-    const float s1 = two ? go_exp(go_tanh(p + dot<FOUT>(a2, xi1))) : 0.f;
-    Z += s0;
-#pragma unroll
-    for (int c = 0; c < FOUT; ++c) agg[c] += s0 * xi0[c];
-    if (two) {
-      Z += s1;
-#pragma unroll
-      for (int c = 0; c < FOUT; ++c) agg[c] += s1 * xi1[c];
-    }
+    rp.edge(xm0);
+    if (two) rp.edge(xm1);
   }
-  const float zinv = p1 > p0 ? 1.f / Z : 0.f;
-  float tr = 0.f;
-#pragma unroll
-  for (int c = 0; c < FOUT; ++c) tr += dy[((int64_t)b * FOUT + c) * N + n] * agg[c];
+  float zinv, tr, dp;
+  rp.end(p1 > p0, zinv, tr, dp);
   // one 16-byte record per node: the walks of kernel B fetch a neighbour's statistics with one load
-  reinterpret_cast<float4*>(stats)[(int64_t)b * N + n] = make_float4(p, q, zinv, tr * zinv);
+  reinterpret_cast<float4*>(stats)[(int64_t)b * N + n] = make_float4(rp.p, dot<FOUT>(a2, xin), zinv, tr);
+  stats[4 * (int64_t)B * N + (int64_t)b * N + n] = dp;
+}
+
+// dparams = (dW_inc [FOUT,FIN], dW_s [FOUT,FIN], da_in [2 FOUT], da_s [FOUT]) from G [2 FOUT + 3, FIN]:
+//   da1 = W_inc (sum dp x), da2 = W_inc (sum dq x), da_s = W_s (sum dgate x)      (x_in = W_inc x, x_s = W_s x)
+// ONE workgroup: sums the workgroups' partials gpart [ROWS * FIN][parts] itself — a wave per entry, lanes striding the
+// partials, fixed tree — and writes the parameter gradients (the separate "sum the partials" launch of the first
+// version is gone).  [Tried: the LAST workgroup of the main kernel doing this behind a device-scope ticket.  On this
+// 8-XCD part 512 arrivals at one ticket serialise at about a microsecond each — 35 -> 600 us — whether the cost is
+// the release fence (an L2 write-back per arrival) or the compare-and-swap retries; per-tile tickets in the split-K
+// GEMMs cost more per product (+8 us) than the reduction launch they replaced.  Not kept.]
+#define GO_FIN_T 1024
+template <int FIN, int FOUT>
+__global__ void __launch_bounds__(GO_FIN_T)
+k_go_attn_bwd_finish(const float* __restrict__ gpart, int64_t parts, const float* __restrict__ w_inc,
+                     const float* __restrict__ w_s, float* __restrict__ dparams) {
+  constexpr int ROWS = 2 * FOUT + 3, NE = ROWS * FIN, KW = FOUT * FIN;
+  __shared__ float G[NE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int e = w; e < NE; e += GO_FIN_T / 64) {
+    const float* src = gpart + (int64_t)e * parts;
+    float t = 0.f;
+#pragma unroll 4
+    for (int64_t i = lane; i < parts; i += 64) t += src[i];
+    t = wave_sum_all(t);
+    if (lane == 0) G[e] = t;
+  }
+  __syncthreads();
+  const int j = threadIdx.x;
+  if (j < 2 * KW) {
+    dparams[j] = G[j];
+  } else if (j < 2 * KW + 3 * FOUT) {
+    const int q = j - 2 * KW, which = q / FOUT, c = q % FOUT;       // which: 0 -> a1, 1 -> a2, 2 -> a_s
+    const float* wm = which == 2 ? w_s : w_inc;
+    float t = 0.f;
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) t += wm[c * FIN + d] * G[(2 * FOUT + which) * FIN + d];
+    dparams[j] = t;
+  }
 }
 
 // ---- backward, kernel B: input gradient + block partials of the parameter gradients ------------
@@ -379,7 +447,6 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
   const float4* sp = reinterpret_cast<const float4*>(stats) + (int64_t)b * N;     // (p, q, zinv, tr) per node
   // ... but with EMPTY edge ranges: N-1 is the root, and a dead lane walking its column list serially (it is not
   // "heavy", being dead) used to set the duration of the whole kernel
-  const int32_t r0 = live ? row_ptr[n] : 0, r1 = live ? row_ptr[n + 1] : 0;
   const int32_t c0 = live ? t_ptr[n] : 0, c1 = live ? t_ptr[n + 1] : 0;
   float xr[FIN], xin[FOUT], xs[FOUT], dyn[FOUT];
   load_node<FIN>(xb, N, nn, xr);
@@ -387,22 +454,8 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
   transform<FIN, FOUT>(W.wi, xr, xin);
   transform<FIN, FOUT>(W.ws, xr, xs);
   const float4 st_n = sp[nn];
-  const float p_n = st_n.x, q_n = st_n.y, zinv_n = st_n.z, tr_n = st_n.w;
-  // n as ROW: d(score) of its own edges
-  float dp = 0.f;
-  for (int32_t e = r0; e < r1; e += 2) {            // two edges per step: indices, then rows, in flight together
-    const bool two = e + 1 < r1;
-    const int m0 = col[e], m1 = col[two ? e + 1 : e];
-    float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
-    load_node<FIN>(xb, N, m0, xm0);
-    load_node<FIN>(xb, N, m1, xm1);
-    const float q0 = sp[m0].y, q1 = sp[m1].y;
-    transform<FIN, FOUT>(W.wi, xm0, xi0);
-    transform<FIN, FOUT>(W.wi, xm1, xi1);
-    const float th0 = go_tanh(p_n + q0), th1 = go_tanh(p_n + q1);
-    dp += (dot<FOUT>(dyn, xi0) - tr_n) * (go_exp(th0) * zinv_n) * (1.f - th0 * th0);
-    if (two) dp += (dot<FOUT>(dyn, xi1) - tr_n) * (go_exp(th1) * zinv_n) * (1.f - th1 * th1);
-  }
+  const float q_n = st_n.y;
+  const float dp = live ? stats[4 * (int64_t)B * N + (int64_t)b * N + n] : 0.f;     // n as ROW: from kernel A
   // n as COLUMN: what the rows reading n send back
   float dq = 0.f, dxin[FOUT];
 #pragma unroll
@@ -530,23 +583,6 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
   }
 }
 
-// dparams = (dW_inc [FOUT,FIN], dW_s [FOUT,FIN], da_in [2 FOUT], da_s [FOUT]) from G [2 FOUT + 3, FIN]:
-//   da1 = W_inc (sum dp x), da2 = W_inc (sum dq x), da_s = W_s (sum dgate x)      (x_in = W_inc x, x_s = W_s x)
-__global__ void k_go_attn_bwd_finish(int fin, int fout, const float* __restrict__ G, const float* __restrict__ w_inc,
-                                     const float* __restrict__ w_s, float* __restrict__ dparams) {
-  const int j = threadIdx.x;
-  const int k = fout * fin;
-  if (j < 2 * k) {
-    dparams[j] = G[j];
-  } else if (j < 2 * k + 3 * fout) {
-    const int q = j - 2 * k, which = q / fout, c = q % fout;        // which: 0 -> a1, 1 -> a2, 2 -> a_s
-    const float* w = which == 2 ? w_s : w_inc;
-    float t = 0.f;
-    for (int d = 0; d < fin; ++d) t += w[c * fin + d] * G[(2 * fout + which) * fin + d];
-    dparams[j] = t;
-  }
-}
-
 int igcn_gemm_f32_batched_sum_impl(int64_t M, int64_t N, int64_t K, int batch, const float* A, int64_t sam,
                                    int64_t sak, int64_t a_batch, const float* B, int64_t sbn, int64_t sbk,
                                    int64_t b_batch, float* C, int64_t ldc, float* scratch, hipStream_t st);
@@ -555,7 +591,7 @@ extern "C" size_t igcn_go_attn_bwd_scratch_floats(int B, int N, int fin, int fou
   // channel-major kernels: statistics [B,N] float4 + one partial per wave; the LDS-resident kernel needs only one
   // partial per sample, which is less
   const int64_t rows = 2 * fout + 3, parts = igcn_cdiv(N, GO_T) * (int64_t)B * (GO_T / 64);
-  return (size_t)(4 * (int64_t)B * N + parts * rows * fin + rows * fin + 64);
+  return (size_t)(5 * (int64_t)B * N + parts * rows * fin + rows * fin + 64);
 }
 
 // =================================================================================================
@@ -568,6 +604,15 @@ extern "C" size_t igcn_go_attn_bwd_scratch_floats(int B, int N, int fin, int fou
 // memory.  The parameter-gradient rows u (x) x of a thread's nodes wait in registers until the walks are done, then
 // go through the (now free) LDS to the matrix cores exactly as in the channel-major kernel.
 // =================================================================================================
+#ifdef GO_ABL_PROBE
+__device__ long long go_probe_buf[8 * 16];
+#define GO_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8) go_probe_buf[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+extern "C" int igcn_debug_go_probe(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(go_probe_buf), sizeof(long long) * 8 * 16);
+}
+#else
+#define GO_PROBE(i)
+#endif
 #define GO_ABL_T 1024
 #define GO_ABL_MAXIT 4
 template <int FIN, int FOUT, int MAXIT>
@@ -584,6 +629,7 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
   float* dys = xs + FIN * NP;                           // [FOUT][NP]
   float4* st = reinterpret_cast<float4*>(dys + FOUT * NP);      // [N]: (p, q, 1/Z, tr/Z)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  GO_PROBE(0);
   const float* xb = x + (int64_t)b * FIN * N;
   const float* dyb = dy + (int64_t)b * FOUT * N;
   // CSR pointers of this thread's nodes: issued before the slab copy so that their latency hides behind it
@@ -619,82 +665,63 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
   AttnW<FIN, FOUT> W;
   W.load(w_inc, w_s, a_in, a_s);
   __syncthreads();
+  GO_PROBE(1);
 
-  // ---- statistics of every node of the sample ----------------------------------------------------
+  // ---- statistics of every node of the sample + the row-side score gradient (RowPass) ---------------
+  float dpv[MAXIT], xx[MAXIT][FIN];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
+    dpv[it] = 0.f;
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) xx[it][d] = 0.f;
     const int n = it * GO_ABL_T + tid;
     if (n >= N) continue;
-    float xr[FIN], xin[FOUT];
+    float xr[FIN], xin[FOUT], dyn[FOUT];
     load_node<FIN>(xs, NP, n, xr);
+    load_node<FOUT>(dys, NP, n, dyn);
     transform<FIN, FOUT>(W.wi, xr, xin);
-    const float p = dot<FOUT>(W.a1, xin), q = dot<FOUT>(W.a2, xin);
-    float Z = 0.f, agg[FOUT];
-#pragma unroll
-    for (int c = 0; c < FOUT; ++c) agg[c] = 0.f;
+    RowPass<FIN, FOUT> rp;
+    rp.begin(W.wi, W.a2, dyn, dot<FOUT>(W.a1, xin));
     const int32_t p0 = pr0[it], p1 = pr1[it];
     for (int32_t e = p0; e < p1; e += 2) {              // two edges per step, the first pair already in registers
       const bool two = e + 1 < p1;
       const int m0 = e == p0 ? pm0[it] : col[e], m1 = two ? (e == p0 ? pm1[it] : col[e + 1]) : m0;
-      float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
+      float xm0[FIN], xm1[FIN];
       load_node<FIN>(xs, NP, m0, xm0);
       load_node<FIN>(xs, NP, m1, xm1);
-      transform<FIN, FOUT>(W.wi, xm0, xi0);
-      transform<FIN, FOUT>(W.wi, xm1, xi1);
-      const float s0 = go_exp(go_tanh(p + dot<FOUT>(W.a2, xi0)));
-      Z += s0;
-#pragma unroll
-      for (int c = 0; c < FOUT; ++c) agg[c] += s0 * xi0[c];
-      if (two) {
-        const float s1 = go_exp(go_tanh(p + dot<FOUT>(W.a2, xi1)));
-        Z += s1;
-#pragma unroll
-        for (int c = 0; c < FOUT; ++c) agg[c] += s1 * xi1[c];
-      }
+      rp.edge(xm0);
+      if (two) rp.edge(xm1);
     }
-    const float zinv = p1 > p0 ? 1.f / Z : 0.f;
-    float tr = 0.f;
+    float zinv, tr, dp;
+    rp.end(p1 > p0, zinv, tr, dp);
+    st[n] = make_float4(rp.p, dot<FOUT>(W.a2, xin), zinv, tr);
+    dpv[it] = dp;
 #pragma unroll
-    for (int c = 0; c < FOUT; ++c) tr += dys[c * NP + n] * agg[c];
-    st[n] = make_float4(p, q, zinv, tr * zinv);
+    for (int d = 0; d < FIN; ++d) xx[it][d] = xr[d];
   }
   __syncthreads();
+  GO_PROBE(2);
 
-  // ---- walks: input gradient, parameter-gradient rows kept in registers ---------------------------
-  float uu[MAXIT][ROWS], xx[MAXIT][FIN];
+  // ---- column walks: input gradient, parameter-gradient rows kept in registers ---------------------
+  float uu[MAXIT][ROWS];
   float* dxb = dx + (int64_t)b * FIN * N;
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) uu[it][r] = 0.f;
-#pragma unroll
-    for (int d = 0; d < FIN; ++d) xx[it][d] = 0.f;
     if (it * GO_ABL_T < N) {                            // block-uniform
       const int n = it * GO_ABL_T + tid;
       const bool live = n < N;
       const int nn = live ? n : N - 1;                  // dead lanes shadow a valid node with EMPTY edge ranges
-      const int32_t r0 = pr0[it], r1 = pr1[it], c0 = pc0[it], c1 = pc1[it];
+      const int32_t c0 = pc0[it], c1 = pc1[it];
       float xr[FIN], xin[FOUT], xsl[FOUT], dyn[FOUT];
-      load_node<FIN>(xs, NP, nn, xr);
+#pragma unroll
+      for (int d = 0; d < FIN; ++d) xr[d] = xx[it][d];
       load_node<FOUT>(dys, NP, nn, dyn);
       transform<FIN, FOUT>(W.wi, xr, xin);
       transform<FIN, FOUT>(W.ws, xr, xsl);
-      const float4 st_n = st[nn];
-      const float p_n = st_n.x, q_n = st_n.y, zinv_n = st_n.z, tr_n = st_n.w;
-      float dp = 0.f;
-      for (int32_t e = r0; e < r1; e += 2) {            // n as ROW: d(score) of its own edges
-        const bool two = e + 1 < r1;
-        const int m0 = e == r0 ? pm0[it] : col[e], m1 = two ? (e == r0 ? pm1[it] : col[e + 1]) : m0;
-        float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
-        load_node<FIN>(xs, NP, m0, xm0);
-        load_node<FIN>(xs, NP, m1, xm1);
-        const float q0 = st[m0].y, q1 = st[m1].y;
-        transform<FIN, FOUT>(W.wi, xm0, xi0);
-        transform<FIN, FOUT>(W.wi, xm1, xi1);
-        const float th0 = go_tanh(p_n + q0), th1 = go_tanh(p_n + q1);
-        dp += (dot<FOUT>(dyn, xi0) - tr_n) * (go_exp(th0) * zinv_n) * (1.f - th0 * th0);
-        if (two) dp += (dot<FOUT>(dyn, xi1) - tr_n) * (go_exp(th1) * zinv_n) * (1.f - th1 * th1);
-      }
+      const float q_n = st[nn].y;
+      const float dp = dpv[it];
       float dq = 0.f, dxin[FOUT];                       // n as COLUMN: what the rows reading n send back
 #pragma unroll
       for (int c = 0; c < FOUT; ++c) dxin[c] = 0.f;
@@ -774,14 +801,16 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
         uu[it][2 * FOUT] = dp;
         uu[it][2 * FOUT + 1] = dq;
         uu[it][2 * FOUT + 2] = dgate;
-#pragma unroll
-        for (int d = 0; d < FIN; ++d) xx[it][d] = xr[d];
       }
     }
   }
+  GO_PROBE(3);
   __syncthreads();                                      // the slabs are dead: LDS becomes the MFMA staging area
+  GO_PROBE(4);
 
   // ---- G[ROWS, FIN] += u (x) x over the sample's nodes on the matrix cores ----------------------
+  // wave w stages and reduces the nodes of its own 64 threads: the staging columns [64 w, 64 w + 64) are private to
+  // the wave, so the iterations need no workgroup barrier (LDS serves a wave's accesses in order)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   float* us = go_abl;                                   // [ROWS][TP]
   float* xt = us + ROWS * TP;                           // [FIN][TP]
@@ -794,7 +823,8 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
       for (int r = 0; r < ROWS; ++r) us[r * TP + tid] = uu[it][r];
 #pragma unroll
       for (int d = 0; d < FIN; ++d) xt[d * TP + tid] = xx[it][d];
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       const float* ua = us + (m < ROWS ? m : 0) * TP + 64 * w + g4;
       const float* xa = xt + (m < FIN ? m : 0) * TP + 64 * w + g4;
 #pragma unroll
@@ -803,10 +833,12 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
         const float bq = (m < FIN) ? xa[4 * c] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
-  float* wsum = go_abl;                                 // [16 waves * 4][64]
+  GO_PROBE(5);
+  float* wsum = xt + FIN * TP;                          // [16 waves * 4][64], behind the staging area
 #pragma unroll
   for (int r = 0; r < 4; ++r) wsum[(w * 4 + r) * 64 + lane] = acc[r];
   __syncthreads();
@@ -821,12 +853,13 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
         gpart[(int64_t)((4 * g4 + r) * FIN + m) * parts + b] = t;
       }
   }
+  GO_PROBE(6);
 }
 
 static size_t go_abl_lds_bytes(int N, int fin, int fout) {
   const size_t np = ((size_t)N + 3) & ~(size_t)3;
   const size_t slabs = (size_t)(fin + fout + 4) * np * sizeof(float);
-  const size_t stage = (size_t)(2 * fout + 3 + fin) * (GO_ABL_T + 4) * sizeof(float);
+  const size_t stage = ((size_t)(2 * fout + 3 + fin) * (GO_ABL_T + 4) + (GO_ABL_T / 64) * 4 * 64) * sizeof(float);
   return slabs > stage ? slabs : stage;
 }
 
@@ -851,7 +884,6 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
   const size_t abl_lds = go_abl_lds_bytes(N, fin, fout);
   if (!go_attn_force_cm() && abl_lds <= 160 * 1024 && N <= GO_ABL_T * GO_ABL_MAXIT) {
     float* gpart = scratch;                                         // [rows * fin][B] block partials
-    float* G = gpart + (int64_t)B * rows * fin;
     const int iters = (int)igcn_cdiv(N, GO_ABL_T);
 #define CALLLI(FI, FO, MI)                                                                                        \
   {                                                                                                               \
@@ -866,17 +898,17 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
 #undef CALLL
 #undef CALLLI
     IGCN_CHECK_LAUNCH("go_attn_bwd(lds)");
-    int rc = igcn_launch_reduce_contig(gpart, B, (int)(rows * fin), G, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_go_attn_bwd_finish, dim3(1), dim3(128), 0, st, fin, fout, G, w_inc, w_s, dparams);
+#define CALLF(FI, FO) \
+  hipLaunchKernelGGL((k_go_attn_bwd_finish<FI, FO>), dim3(1), dim3(GO_FIN_T), 0, st, gpart, (int64_t)B, w_inc, w_s, dparams)
+    GO_DISPATCH(fin, fout, CALLF)
+#undef CALLF
     IGCN_CHECK_LAUNCH("go_attn_bwd_finish");
     return IGCN_OK;
   }
-  float* stats = scratch;
-  float* gpart = stats + 4 * (int64_t)B * N;                       // [blocks * 4 waves][rows * fin] block partials
+  float* stats = scratch;                                         // float4 [B,N] + dp [B,N]
+  float* gpart = stats + 5 * (int64_t)B * N;                       // [blocks * 4 waves][rows * fin] block partials
   dim3 grid((unsigned)igcn_cdiv(N, GO_T), B);
   const int64_t parts = (int64_t)grid.x * grid.y;
-  float* G = gpart + parts * rows * fin;
 #define CALL(FI, FO)                                                                                             \
   hipLaunchKernelGGL((k_go_attn_bwd_stats<FI, FO>), grid, dim3(GO_T), 0, st, B, N, row_ptr, col, x, w_inc, a_in,  \
                      dy, stats);                                                                                  \
@@ -885,10 +917,10 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
   GO_DISPATCH(fin, fout, CALL)
 #undef CALL
   IGCN_CHECK_LAUNCH("go_attn_bwd");
-  // G[r,d] = sum over the block partials
-  int rc = igcn_launch_reduce_contig(gpart, parts, (int)(rows * fin), G, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_go_attn_bwd_finish, dim3(1), dim3(128), 0, st, fin, fout, G, w_inc, w_s, dparams);
+#define CALLF(FI, FO) \
+  hipLaunchKernelGGL((k_go_attn_bwd_finish<FI, FO>), dim3(1), dim3(GO_FIN_T), 0, st, gpart, parts, w_inc, w_s, dparams)
+  GO_DISPATCH(fin, fout, CALLF)
+#undef CALLF
   IGCN_CHECK_LAUNCH("go_attn_bwd_finish");
   return IGCN_OK;
 }

@@ -100,11 +100,13 @@ extern "C" int igcn_mask_reg_bwd(int64_t n_prob, int64_t n_edge, int64_t n_snps,
 // backward writes S = dG + dG^T so that ds = S s :
 //   dG_ij = gc*Lap_ij/B^2 + go*( 2 G_ij/(G_ii G_jj)  [i != j]  ;  -2 sum_{k != i} G_ik^2/(G_ii^2 G_kk)  [i == j] )/B^2
 // -------------------------------------------------------------------------------------------------
+// `groups` Gram matrices (the passes of a batched sweep) per launch: blockIdx.y = group, one Laplacian for all
 __global__ void __launch_bounds__(256)
-k_gram_loss_fwd(int B, int RD, const float* __restrict__ G, const float* __restrict__ Lap,
-                float* __restrict__ partial /*[B,2]*/) {
+k_gram_loss_fwd(int B, int RD, const float* __restrict__ Gall, const float* __restrict__ Lap,
+                float* __restrict__ partial /*[B, 2 groups]*/) {
   __shared__ float red[16];
-  const int i = blockIdx.x;
+  const int i = blockIdx.x, grp = blockIdx.y, groups = gridDim.y;
+  const float* G = Gall + (int64_t)grp * B * B;
   const float gii = G[(int64_t)i * B + i];
   float c = 0.f, o = 0.f;
   for (int j = threadIdx.x; j < B; j += 256) {
@@ -116,17 +118,19 @@ k_gram_loss_fwd(int B, int RD, const float* __restrict__ G, const float* __restr
   o = block_sum_all(o, red);
   if (threadIdx.x == 0) {
     const float b2 = (float)B * (float)B;
-    partial[2 * i] = c / b2;
-    partial[2 * i + 1] = (o - 2.f + (float)RD / (float)B) / b2;     // the -2B + RD constants, spread over rows
+    partial[(int64_t)i * 2 * groups + 2 * grp] = c / b2;
+    partial[(int64_t)i * 2 * groups + 2 * grp + 1] = (o - 2.f + (float)RD / (float)B) / b2;   // -2B + RD, spread over rows
   }
 }
 
 __global__ void __launch_bounds__(256)
-k_gram_loss_bwd(int B, const float* __restrict__ G, const float* __restrict__ Lap, const float* __restrict__ gout,
-                float* __restrict__ S) {
+k_gram_loss_bwd(int B, const float* __restrict__ Gall, const float* __restrict__ Lap, const float* __restrict__ gout,
+                float* __restrict__ Sall) {
   __shared__ float red[16];
-  const int i = blockIdx.x;
-  const float gc = gout[0], go = gout[1];
+  const int i = blockIdx.x, grp = blockIdx.y;
+  const float* G = Gall + (int64_t)grp * B * B;
+  float* S = Sall + (int64_t)grp * B * B;
+  const float gc = gout[2 * grp], go = gout[2 * grp + 1];
   const float b2 = (float)B * (float)B;
   const float gii = G[(int64_t)i * B + i];
   float dsum = 0.f;
@@ -141,19 +145,19 @@ k_gram_loss_bwd(int B, const float* __restrict__ G, const float* __restrict__ La
   if (threadIdx.x == 0) S[(int64_t)i * B + i] = 2.f * (gc * Lap[(int64_t)i * B + i] - go * 2.f * dsum) / b2;
 }
 
-extern "C" int igcn_gram_loss_fwd(int B, int RD, const float* G, const float* Lap, float* out /*[2]*/,
-                                  float* scratch /*[2B]*/, void* stream) {
-  IGCN_REQUIRE(B > 0, "gram_loss_fwd: bad B");
+extern "C" int igcn_gram_loss_fwd(int B, int RD, int groups, const float* G /*[groups,B,B]*/, const float* Lap,
+                                  float* out /*[groups,2]*/, float* scratch /*[2 B groups]*/, void* stream) {
+  IGCN_REQUIRE(B > 0 && groups >= 1 && groups <= 64, "gram_loss_fwd: bad B / groups");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gram_loss_fwd, dim3(B), dim3(256), 0, st, B, RD, G, Lap, scratch);
+  hipLaunchKernelGGL(k_gram_loss_fwd, dim3(B, groups), dim3(256), 0, st, B, RD, G, Lap, scratch);
   IGCN_CHECK_LAUNCH("gram_loss_fwd");
-  return igcn_launch_reduce_rows(scratch, B, 2, 2, out, 0, st);
+  return igcn_launch_reduce_rows(scratch, B, 2 * groups, 2 * groups, out, 0, st);
 }
 
-extern "C" int igcn_gram_loss_bwd(int B, const float* G, const float* Lap, const float* gout /*[2] device*/,
-                                  float* S /*[B,B]*/, void* stream) {
-  IGCN_REQUIRE(B > 0, "gram_loss_bwd: bad B");
-  hipLaunchKernelGGL(k_gram_loss_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, B, G, Lap, gout, S);
+extern "C" int igcn_gram_loss_bwd(int B, int groups, const float* G, const float* Lap,
+                                  const float* gout /*[groups,2] device*/, float* S /*[groups,B,B]*/, void* stream) {
+  IGCN_REQUIRE(B > 0 && groups >= 1 && groups <= 64, "gram_loss_bwd: bad B / groups");
+  hipLaunchKernelGGL(k_gram_loss_bwd, dim3(B, groups), dim3(256), 0, (hipStream_t)stream, B, G, Lap, gout, S);
   IGCN_CHECK_LAUNCH("gram_loss_bwd");
   return IGCN_OK;
 }

@@ -331,8 +331,8 @@ __global__ void __launch_bounds__(RO_T)
 k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict__ x, const float* __restrict__ W,
                  const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                  const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ keep,
-                 const float* __restrict__ dgb, float* __restrict__ dpre_out, float* __restrict__ dx,
-                 float* __restrict__ wpartial) {
+                 const float* __restrict__ partial, int nchunks, float* __restrict__ dpre_out,
+                 float* __restrict__ dx, float* __restrict__ wpartial) {
   constexpr bool SMALL = (D * F <= 16);
   constexpr int NW = SMALL ? D * F : 1;
   __shared__ float red[(RO_T / 64) * NW];
@@ -347,9 +347,17 @@ k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict
     const int b0 = ch.b0, b1 = ch.b1;
     const float mu = mean[(int64_t)ch.g * N + n], rs = rstd[(int64_t)ch.g * N + n], ga = gamma[n], be = beta[n];
     const float cnt = (float)(B / groups) * D;
-    const float* dgg = dgb + (int64_t)ch.g * 2 * N;         // this group's (sum dy*xhat, sum dy)
-    const float m1 = training ? dgg[N + n] / cnt : 0.f;     // mean(dy)
-    const float m2 = training ? dgg[n] / cnt : 0.f;         // mean(dy*xhat)
+    // this group's (sum dy*xhat, sum dy): the chunk partials of pass 1 [chunk][group][2][N], summed here in chunk
+    // order — the launch that used to do it between the two passes is gone
+    float t1 = 0.f, t2 = 0.f;
+    if (training)
+      for (int c = 0; c < nchunks; ++c) {
+        const float* p = partial + (int64_t)(c * groups + ch.g) * 2 * N;
+        t2 += p[n];
+        t1 += p[N + n];
+      }
+    const float m1 = t1 / cnt;                              // mean(dy)
+    const float m2 = t2 / cnt;                              // mean(dy*xhat)
     for (int b = b0 + sg; b < b1; b += RO_SG) {
       float xv[F], pre[D], dxv[F];
 #pragma unroll
@@ -461,8 +469,9 @@ template <int F, int D>
 __global__ void __launch_bounds__(RO_T)
 k_nlbn_bwd_apply_q(int B, int N, int groups, int training, const float* __restrict__ x, const float* __restrict__ W,
                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-                   const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ dgb,
-                   float* __restrict__ dx, float* __restrict__ wpartial) {
+                   const float* __restrict__ rstd, const float* __restrict__ dout,
+                   const float* __restrict__ partial, int nchunks, float* __restrict__ dx,
+                   float* __restrict__ wpartial) {
   constexpr int DQ = D / 4, NPW = 64 / DQ;
   __shared__ float red[RO_T / 64][D * F];
   const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
@@ -481,9 +490,15 @@ k_nlbn_bwd_apply_q(int B, int N, int groups, int training, const float* __restri
     }
   const float mu = mean[(int64_t)ch.g * N + nc], rs = rstd[(int64_t)ch.g * N + nc], ga = gamma[nc], be = beta[nc];
   const float cnt = (float)(B / groups) * D;
-  const float* dgg = dgb + (int64_t)ch.g * 2 * N;           // this group's (sum dy*xhat, sum dy)
-  const float m1 = training ? dgg[N + nc] / cnt : 0.f;      // mean(dy)
-  const float m2 = training ? dgg[nc] / cnt : 0.f;          // mean(dy*xhat)
+  float t1 = 0.f, t2 = 0.f;                                  // this group's (sum dy*xhat, sum dy): chunk partials of
+  if (training)                                              // pass 1, summed here in chunk order
+    for (int c = 0; c < nchunks; ++c) {
+      const float* p = partial + (int64_t)(c * groups + ch.g) * 2 * N;
+      t2 += p[nc];
+      t1 += p[N + nc];
+    }
+  const float m1 = t1 / cnt;                                 // mean(dy)
+  const float m2 = t2 / cnt;                                 // mean(dy*xhat)
   for (int b = ch.b0 + sg; b < ch.b1; b += RO_SG) {
     const float mine = q < F ? x[((int64_t)b * F + q) * N + nc] : 0.f;
     const float4 g4 = *reinterpret_cast<const float4*>(dout + ((int64_t)b * N + nc) * D + q * 4);
@@ -610,7 +625,7 @@ extern "C" size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, in
 template <int F, int D>
 static int ro_bwd(dim3 grid, int cpg, hipStream_t st, int B, int N, int groups, int training, const float* x,
                   const float* W, const float* gamma, const float* beta, const float* save_mean,
-                  const float* save_rstd, const float* dout, const float* keep, float* stats, float* dgg, float* aux,
+                  const float* save_rstd, const float* dout, const float* keep, float* stats, float* aux,
                   float* dx, float* dW, float* dgb) {
   int rc;
   if constexpr (ro_quad_ok<F, D>()) {
@@ -618,20 +633,19 @@ static int ro_bwd(dim3 grid, int cpg, hipStream_t st, int B, int N, int groups, 
     dim3 gq((unsigned)igcn_cdiv(N, 64 / (D / 4)), cq * groups);
     hipLaunchKernelGGL((k_nlbn_bwd_stats_q<F, D>), gq, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, save_mean,
                        save_rstd, dout, stats);
-    if ((rc = igcn_launch_reduce_rows(stats, cq, (int64_t)groups * 2 * N, groups * 2 * N, dgg, 0, st))) return rc;
     hipLaunchKernelGGL((k_nlbn_bwd_apply_q<F, D>), gq, dim3(RO_T), 0, st, B, N, groups, training, x, W, gamma, beta,
-                       save_mean, save_rstd, dout, dgg, dx, aux);
+                       save_mean, save_rstd, dout, stats, cq, dx, aux);
     IGCN_CHECK_LAUNCH("node_linear_bn_bwd(q)");
-    if ((rc = igcn_launch_reduce_rows_final(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, st))) return rc;
+    // dgamma | dbeta = the chunk partials [chunk][group][2N] summed over chunks AND groups: rows of 2N
+    if ((rc = igcn_launch_reduce_rows_final(stats, (int64_t)cq * groups, 2 * (int64_t)N, 2 * N, dgb, st))) return rc;
     return igcn_launch_reduce_rows_final(aux, (int64_t)gq.x * gq.y, D * F, D * F, dW, st);
   } else {
     hipLaunchKernelGGL((k_nlbn_bwd_stats<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, save_mean,
                        save_rstd, dout, keep, stats);
-    if ((rc = igcn_launch_reduce_rows(stats, cpg, (int64_t)groups * 2 * N, groups * 2 * N, dgg, 0, st))) return rc;
     hipLaunchKernelGGL((k_nlbn_bwd_apply<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, training, x, W, gamma, beta,
-                       save_mean, save_rstd, dout, keep, dgg, aux, dx, aux);
+                       save_mean, save_rstd, dout, keep, stats, cpg, aux, dx, aux);
     IGCN_CHECK_LAUNCH("node_linear_bn_bwd");
-    if ((rc = igcn_launch_reduce_rows_final(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, st))) return rc;
+    if ((rc = igcn_launch_reduce_rows_final(stats, (int64_t)cpg * groups, 2 * (int64_t)N, 2 * N, dgb, st))) return rc;
     if (D * F <= 16) return igcn_launch_reduce_rows_final(aux, (int64_t)grid.x * grid.y, D * F, D * F, dW, st);
     // dW[d,c] = sum_b sum_n dpre[b,n,d] * x[b,c,n]
     return igcn_gemm_f32_batched_sum_impl(D, F, N, B, aux, 1, D, (int64_t)N * D, x, N, 1, (int64_t)F * N, dW, F,
@@ -655,7 +669,7 @@ extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, i
                                                              // wpartial (small) or dpre rows, then slabs (large)
 #define CALL(FV, DV)                                                                                           \
   return ro_bwd<FV, DV>(grid, cpg, st, B, N, groups, training, x, W, gamma, beta, save_mean, save_rstd, dout,   \
-                        keep, stats, dgg, aux, dx, dW, dgb)
+                        keep, stats, aux, dx, dW, dgb)
   RO_DISPATCH(F, D, CALL)
 #undef CALL
 }

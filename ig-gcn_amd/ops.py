@@ -448,13 +448,14 @@ def gemm_nn(a, b, out=None, bf16=False):
     return out
 
 
-def gemm_tn(a, b, bf16=False, final_grad=False):
+def gemm_tn(a, b, bf16=False, final_grad=False, out=None):
     """out[M,N] = a[K,M]^T @ b[K,N]  (weight gradient: reduction over the long row axis K).  ``final_grad``: the
     output is a parameter gradient — its split-K sum may be deferred (``deferred_reductions``)."""
     a, b = _f32(a), _f32(b)
     k, m = a.shape
     n = b.shape[1]
-    out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
     sk = _split_k(m, n, k)
     scratch = torch.empty(sk * m * n, dtype=torch.float32, device=a.device) if sk > 1 else None
     if final_grad:
@@ -504,6 +505,53 @@ class Linear(torch.autograd.Function):
         dx = gemm_nn(dy, weight, bf16=ctx.bf16) if ctx.needs_input_grad[0] else None
         dw = gemm_tn(dy, x, bf16=ctx.bf16, final_grad=ctx.w_final) if ctx.needs_input_grad[1] else None
         return dx, dw, db, None, None
+
+
+def _bias_grad_into(dy, db, final):
+    """db[cols] = column sums of dy (igcn_bias_grad without a ReLU mask), written into ``db`` (may be a slice)."""
+    lib = _lib.load()
+    rows, cols = dy.shape
+    scratch = _keep(torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, cols)), dtype=torch.float32,
+                                device=dy.device))
+    with _immediate(final):
+        call("igcn_bias_grad", rows, cols, ptr(dy), None, None, ptr(db), ptr(scratch), stream_ptr())
+
+
+class InProj(torch.autograd.Function):
+    """The packed input projection of nn.MultiheadAttention for cross-attention (kernel/sgcn_img_snp.py:240-241:
+    ``multihead_attn(query, memory, memory)``): q = query W_q^T + b_q, kv = memory [W_k; W_v]^T + [b_k; b_v] with
+    W = in_proj_weight [3D, D] and bias = in_proj_bias [3D] taken WHOLE.  Two GEMMs forward; the backward writes the
+    two weight-gradient blocks and the two bias-gradient blocks straight into ONE [3D, D] / [3D] gradient, so the
+    parameters stay autograd leaves of this op: no concatenation of per-slice gradients (what ``in_proj_weight.split``
+    costs in its backward), and their split-K / block-partial sums are final and can wait for the deferred flush."""
+
+    @staticmethod
+    def forward(ctx, query, memory, w, bias, bf16=False):
+        d = w.shape[1]
+        q2, m2 = _f32(query).reshape(-1, d), _f32(memory).reshape(-1, d)
+        w, bias = _f32(w), _f32(bias)
+        q = gemm_nt(q2, w[:d], bias[:d], 0, bf16=bf16)
+        kv = gemm_nt(m2, w[d:], bias[d:], 0, bf16=bf16)
+        ctx.save_for_backward(q2, m2, w)
+        ctx.bf16, ctx.final = bf16, _leaves(w, bias)
+        ctx.shapes = (query.shape, memory.shape)
+        return q.view(*query.shape[:-1], d), kv.view(*memory.shape[:-1], 2 * d)
+
+    @staticmethod
+    def backward(ctx, dq, dkv):
+        q2, m2, w = ctx.saved_tensors
+        d = w.shape[1]
+        dq, dkv = _f32(dq).reshape(-1, d), _f32(dkv).reshape(-1, 2 * d)
+        dw = torch.empty_like(w)
+        db = torch.empty(3 * d, dtype=torch.float32, device=w.device)
+        _bias_grad_into(dq, db[:d], ctx.final)
+        _bias_grad_into(dkv, db[d:], ctx.final)
+        dquery = gemm_nn(dq, w[:d], bf16=ctx.bf16).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None
+        dmem = gemm_nn(dkv, w[d:], bf16=ctx.bf16).view(ctx.shapes[1]) if ctx.needs_input_grad[1] else None
+        with _immediate(ctx.final):
+            gemm_tn(dq, q2, bf16=ctx.bf16, final_grad=True, out=dw[:d])
+            gemm_tn(dkv, m2, bf16=ctx.bf16, final_grad=True, out=dw[d:])
+        return dquery, dmem, dw, db, None
 
 
 class ConcatCols(torch.autograd.Function):
@@ -1060,11 +1108,11 @@ class GramLosses(torch.autograd.Function):
         b = gb // groups
         gram = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
         out = torch.empty(groups, 2, dtype=torch.float32, device=s.device)
-        scratch = torch.empty(2 * b, dtype=torch.float32, device=s.device)
+        scratch = torch.empty(2 * b * groups, dtype=torch.float32, device=s.device)
         for g in range(groups):
             sg = s[g * b:(g + 1) * b]
             gemm_nt(sg, sg, out=gram[g])
-            call("igcn_gram_loss_fwd", b, rd, ptr(gram[g]), ptr(lap), ptr(out[g]), ptr(scratch), stream_ptr())
+        call("igcn_gram_loss_fwd", b, rd, groups, ptr(gram), ptr(lap), ptr(out), ptr(scratch), stream_ptr())
         ctx.save_for_backward(s, lap, gram)
         ctx.groups, ctx.packed = groups, packed
         if packed:
@@ -1082,11 +1130,11 @@ class GramLosses(torch.autograd.Function):
             zero = torch.zeros(groups, dtype=torch.float32, device=s.device)
             gout = torch.stack([g_c if g_c is not None else zero, g_o if g_o is not None else zero],
                                dim=1).contiguous()
-        sym = torch.empty(b, b, dtype=torch.float32, device=s.device)
+        sym = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
         ds = torch.empty_like(s)
+        call("igcn_gram_loss_bwd", b, groups, ptr(gram), ptr(lap), ptr(gout), ptr(sym), stream_ptr())
         for g in range(groups):
-            call("igcn_gram_loss_bwd", b, ptr(gram[g]), ptr(lap), ptr(gout[g]), ptr(sym), stream_ptr())
-            gemm_nn(sym, s[g * b:(g + 1) * b], out=ds[g * b:(g + 1) * b])
+            gemm_nn(sym[g], s[g * b:(g + 1) * b], out=ds[g * b:(g + 1) * b])
         return ds, None, None, None
 
 

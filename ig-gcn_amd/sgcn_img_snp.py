@@ -233,13 +233,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         w, bias = mha.in_proj_weight, mha.in_proj_bias
         if self.fused_cross_attention and ops.xattn_supported(d, h, lq, lk):
             return ops.CrossAttention.apply(query, memory, w, bias, mha.out_proj.weight, mha.out_proj.bias, h)
-        # split, not two slices: the backward of a split is ONE concatenation of the two gradients, that of two
-        # slices is zeros + copy for each and an add (ten launches per step for these two parameters)
-        w_q, w_kv = w.split([d, 2 * d])
-        b_q, b_kv = bias.split([d, 2 * d])
+        # the packed projection taken whole (ops.InProj): its backward fills ONE [3D, D] / [3D] gradient, so the two
+        # parameters stay leaves (no concatenation of slice gradients, deferrable partial sums)
         bf = self.bf16_transforms
-        q = ops.linear(query, w_q, b_q, bf16=bf)                             # [B, Lq, D]
-        kv = ops.linear(memory, w_kv, b_kv, bf16=bf)                         # [B, Lk, 2D] = key | value
+        q, kv = ops.InProj.apply(query, memory, w, bias, bf)                 # [B, Lq, D], [B, Lk, 2D] = key | value
         if ops.attn_core_supported(d, h, lq, lk):
             o = ops.AttentionCore.apply(q, kv, h)                           # heads addressed in place
         else:

@@ -350,11 +350,14 @@ int igcn_mask_reg_bwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const floa
  *   out[1] = OrthogonalConstraint (:198-205) = (sum_ij G_ij^2/(G_ii G_jj) - 2B + RD)/B^2
  * igcn_rbf_laplacian builds Lap = diag(W1) - W, W = exp(-gamma*||t_i-t_j||^2) (util/image_cluster.py:15-31;
  * t == NULL: W = 1).  The backward writes S = dG + dG^T [B,B] (ds = S s); gout [2] is a device array.
- * scratch (fwd): float[2B].
+ * `groups` Gram matrices that share the Laplacian (the passes of a batched sweep: G [groups,B,B], out / gout
+ * [groups,2], S [groups,B,B]) take one launch.  scratch (fwd): float[2 B groups].
  */
 int igcn_rbf_laplacian(int B, int T, float gamma, const float* t, float* Lap, void* stream);
-int igcn_gram_loss_fwd(int B, int RD, const float* G, const float* Lap, float* out, float* scratch, void* stream);
-int igcn_gram_loss_bwd(int B, const float* G, const float* Lap, const float* gout, float* S, void* stream);
+int igcn_gram_loss_fwd(int B, int RD, int groups, const float* G, const float* Lap, float* out, float* scratch,
+                       void* stream);
+int igcn_gram_loss_bwd(int B, int groups, const float* G, const float* Lap, const float* gout, float* S,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Cross-attention core of nn.MultiheadAttention (kernel/sgcn_img_snp.py:240) on the projection outputs in place:

@@ -238,6 +238,38 @@ def test_head_inputs(ops, bsz, g, w, l, rois, use_prob, used):
             assert_matches(got, want.numpy(), TOL, nm)
 
 
+@pytest.mark.parametrize("b,lq,lk,d", [(6, 90, 40, 32), (3, 7, 5, 16)])
+def test_in_proj_packed_projection(ops, b, lq, lk, d):
+    """ops.InProj = the packed q / key|value projection of nn.MultiheadAttention (cross-attention) with the parameters
+    taken whole: outputs and all four gradients against F.linear on the slices in fp64; under deferred reductions the
+    parameters are leaves of the op and the gradients are bit-identical to the immediate ones."""
+    rng = np.random.default_rng(b * 100 + d)
+    mk = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32))     # noqa: E731
+    query, memory, w, bias = mk(b, lq, d), mk(b, lk, d), mk(3 * d, d), mk(3 * d)
+    gq, gkv = mk(b, lq, d), mk(b, lk, 2 * d)
+    ref = [t.double().requires_grad_(True) for t in (query, memory, w, bias)]
+    rq = torch.nn.functional.linear(ref[0], ref[2][:d], ref[3][:d])
+    rkv = torch.nn.functional.linear(ref[1], ref[2][d:], ref[3][d:])
+    rg = torch.autograd.grad([rq, rkv], ref, [gq.double(), gkv.double()])
+    grads = []
+    for defer in (False, True):
+        dev = [t.cuda().requires_grad_(True) for t in (query, memory, w, bias)]
+        q, kv = ops.InProj.apply(*dev)
+        if defer:
+            with ops.deferred_reductions():
+                g = torch.autograd.grad([q, kv], dev, [gq.cuda(), gkv.cuda()])
+        else:
+            g = torch.autograd.grad([q, kv], dev, [gq.cuda(), gkv.cuda()])
+        torch.cuda.synchronize()
+        assert_matches(q, rq.detach().numpy(), TOL, "q")
+        assert_matches(kv, rkv.detach().numpy(), TOL, "kv")
+        for got, want, nm in zip(g, rg, ("dquery", "dmemory", "dW", "dbias")):
+            assert_matches(got, want.numpy(), TOL, nm)
+        grads.append([t.cpu() for t in g])
+    for a, c in zip(*grads):
+        assert torch.equal(a, c)
+
+
 def test_gemm_is_exact_fp32_fma_chain(ops):
     """MFMA f32 = k-ordered fmaf chain: small-integer operands must be reproduced exactly."""
     rng = np.random.default_rng(0)
