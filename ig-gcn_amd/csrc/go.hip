@@ -6,6 +6,8 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 #define GO_T 256
 
@@ -251,33 +253,31 @@ k_go_attn_fwd(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restr
   transform<FIN, FOUT>(W.wi, xr, xin);
   transform<FIN, FOUT>(W.ws, xr, xs);
   const float p = dot<FOUT>(W.a1, xin);
-  float v2[FIN];
-  pull_back<FIN, FOUT>(W.wi, W.a2, v2);
-  float Z = 0.f, ax[FIN];                            // sum_e s_e x_m: transformed ONCE after the walk
+  float Z = 0.f, agg[FOUT];
 #pragma unroll
-  for (int d = 0; d < FIN; ++d) ax[d] = 0.f;
+  for (int c = 0; c < FOUT; ++c) agg[c] = 0.f;
   const int32_t p0 = row_ptr[n], p1 = row_ptr[n + 1];
   // two edges per step: both neighbour indices, then both neighbour rows, are in flight together (a GO term has
   // 1-2 parents: most walks are one dependent index->row chain instead of two); summation order is unchanged
   for (int32_t e = p0; e < p1; e += 2) {
     const bool two = e + 1 < p1;
     const int m0 = col[e], m1 = col[two ? e + 1 : e];
-    float xm0[FIN], xm1[FIN];
+    float xm0[FIN], xm1[FIN], xi0[FOUT], xi1[FOUT];
     load_node<FIN>(xb, N, m0, xm0);
     load_node<FIN>(xb, N, m1, xm1);
-    const float s0 = go_exp(go_tanh(p + dot<FIN>(v2, xm0)));
-    const float s1 = two ? go_exp(go_tanh(p + dot<FIN>(v2, xm1))) : 0.f;
+    transform<FIN, FOUT>(W.wi, xm0, xi0);
+    transform<FIN, FOUT>(W.wi, xm1, xi1);
+    const float s0 = go_exp(go_tanh(p + dot<FOUT>(W.a2, xi0)));
+    const float s1 = two ? go_exp(go_tanh(p + dot<FOUT>(W.a2, xi1))) : 0.f;
     Z += s0;
 #pragma unroll
-    for (int d = 0; d < FIN; ++d) ax[d] += s0 * xm0[d];
+    for (int c = 0; c < FOUT; ++c) agg[c] += s0 * xi0[c];
     if (two) {
       Z += s1;
 #pragma unroll
-      for (int d = 0; d < FIN; ++d) ax[d] += s1 * xm1[d];
+      for (int c = 0; c < FOUT; ++c) agg[c] += s1 * xi1[c];
     }
   }
-  float agg[FOUT];
-  transform<FIN, FOUT>(W.wi, ax, agg);
   const float zinv = p1 > p0 ? 1.f / Z : 0.f;
   const float g = 1.f / (1.f + go_exp(-dot<FOUT>(W.as, xs)));
   float* yb = y + (int64_t)b * FOUT * N;
@@ -620,26 +620,38 @@ __global__ void __launch_bounds__(GO_ABL_T)
 k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
                   const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ t_row, const float* __restrict__ x,
                   const float* __restrict__ w_inc, const float* __restrict__ w_s, const float* __restrict__ a_in,
-                  const float* __restrict__ a_s, const float* __restrict__ dy, float* __restrict__ dx,
-                  float* __restrict__ gpart) {
+                  const float* __restrict__ a_s, const float* __restrict__ dy, const int32_t* __restrict__ order,
+                  float* __restrict__ dx, float* __restrict__ gpart) {
   extern __shared__ float go_abl[];
   constexpr int ROWS = 2 * FOUT + 3, TP = GO_ABL_T + 4;
   const int NP = (N + 3) & ~3;
   float* xs = go_abl;                                   // [FIN][NP]
   float* dys = xs + FIN * NP;                           // [FOUT][NP]
-  float4* st = reinterpret_cast<float4*>(dys + FOUT * NP);      // [N]: (p, q, 1/Z, tr/Z)
+  float4* st = reinterpret_cast<float4*>(dys + FOUT * NP);      // [N]: (p, dp, 1/Z, tr/Z)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   GO_PROBE(0);
   const float* xb = x + (int64_t)b * FIN * N;
   const float* dyb = dy + (int64_t)b * FOUT * N;
-  // CSR pointers of this thread's nodes: issued before the slab copy so that their latency hides behind it
-  int32_t pr0[MAXIT], pr1[MAXIT], pc0[MAXIT], pc1[MAXIT];
+  // Two thread -> node maps.  The row side (statistics walk: 1-2 parents per GO term, no imbalance) takes nodes in
+  // order, slot it * 1024 + tid.  The COLUMN side (children lists: 0 for the leaves, ~4 +- 3 for inner terms, 99 for
+  // the root) takes them through `order` (igcn_go_attn_walk_order): nodes sorted by column degree, dealt to the
+  // (wave, pass) slots in groups of 64 so that the lanes of a wave walk lists of (nearly) equal length and the 16
+  // waves carry (nearly) equal totals — in node order the waves holding the upper levels walked 5-10 steps per
+  // pass while the leaf waves idled at the barrier (9.7 us of a 23.5 us workgroup; 3 us of it was work).
+  // CSR pointers: issued before the slab copy so that their latency hides behind it
+  int32_t pr0[MAXIT], pr1[MAXIT], pc0[MAXIT], pc1[MAXIT], ncol[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int slot = it * GO_ABL_T + tid;
+    ncol[it] = order ? order[slot] : (slot < N ? slot : -1);
+  }
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int n = it * GO_ABL_T + tid;
     const bool live = n < N;                            // lanes past the end: EMPTY edge ranges
     pr0[it] = live ? row_ptr[n] : 0; pr1[it] = live ? row_ptr[n + 1] : 0;
-    pc0[it] = live ? t_ptr[n] : 0; pc1[it] = live ? t_ptr[n + 1] : 0;
+    const int nc = ncol[it];
+    pc0[it] = nc >= 0 ? t_ptr[nc] : 0; pc1[it] = nc >= 0 ? t_ptr[nc + 1] : 0;
   }
   if (NP == N && (((uintptr_t)xb | (uintptr_t)dyb) & 15) == 0) {
     for (int i = tid * 4; i < FIN * N; i += GO_ABL_T * 4)
@@ -668,12 +680,8 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
   GO_PROBE(1);
 
   // ---- statistics of every node of the sample + the row-side score gradient (RowPass) ---------------
-  float dpv[MAXIT], xx[MAXIT][FIN];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
-    dpv[it] = 0.f;
-#pragma unroll
-    for (int d = 0; d < FIN; ++d) xx[it][d] = 0.f;
     const int n = it * GO_ABL_T + tid;
     if (n >= N) continue;
     float xr[FIN], xin[FOUT], dyn[FOUT];
@@ -694,34 +702,31 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
     }
     float zinv, tr, dp;
     rp.end(p1 > p0, zinv, tr, dp);
-    st[n] = make_float4(rp.p, dot<FOUT>(W.a2, xin), zinv, tr);
-    dpv[it] = dp;
-#pragma unroll
-    for (int d = 0; d < FIN; ++d) xx[it][d] = xr[d];
+    st[n] = make_float4(rp.p, dp, zinv, tr);
   }
   __syncthreads();
   GO_PROBE(2);
 
   // ---- column walks: input gradient, parameter-gradient rows kept in registers ---------------------
-  float uu[MAXIT][ROWS];
-  float* dxb = dx + (int64_t)b * FIN * N;
+  float uu[MAXIT][ROWS], xx[MAXIT][FIN];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) uu[it][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < FIN; ++d) xx[it][d] = 0.f;
     if (it * GO_ABL_T < N) {                            // block-uniform
-      const int n = it * GO_ABL_T + tid;
-      const bool live = n < N;
+      const int n = ncol[it];
+      const bool live = n >= 0;
       const int nn = live ? n : N - 1;                  // dead lanes shadow a valid node with EMPTY edge ranges
       const int32_t c0 = pc0[it], c1 = pc1[it];
       float xr[FIN], xin[FOUT], xsl[FOUT], dyn[FOUT];
-#pragma unroll
-      for (int d = 0; d < FIN; ++d) xr[d] = xx[it][d];
+      load_node<FIN>(xs, NP, nn, xr);
       load_node<FOUT>(dys, NP, nn, dyn);
       transform<FIN, FOUT>(W.wi, xr, xin);
       transform<FIN, FOUT>(W.ws, xr, xsl);
-      const float q_n = st[nn].y;
-      const float dp = dpv[it];
+      const float q_n = dot<FOUT>(W.a2, xin);
+      const float dp = st[nn].y;                        // row side, from the statistics walk
       float dq = 0.f, dxin[FOUT];                       // n as COLUMN: what the rows reading n send back
 #pragma unroll
       for (int c = 0; c < FOUT; ++c) dxin[c] = 0.f;
@@ -791,8 +796,8 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
           float t = 0.f;
 #pragma unroll
           for (int c = 0; c < FOUT; ++c) t += W.wi[c][d] * dxin[c] + W.ws[c][d] * dxs[c];
-          dxb[d * N + n] = t;
-        }
+          xs[d * NP + n] = t;                             // dx over x in place (nobody else reads x[., n] any more):
+        }                                                 // leaves LDS in one coalesced pass below
 #pragma unroll
         for (int c = 0; c < FOUT; ++c) {
           uu[it][c] = dxin[c];
@@ -801,18 +806,30 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
         uu[it][2 * FOUT] = dp;
         uu[it][2 * FOUT + 1] = dq;
         uu[it][2 * FOUT + 2] = dgate;
+#pragma unroll
+        for (int d = 0; d < FIN; ++d) xx[it][d] = xr[d];
       }
     }
   }
   GO_PROBE(3);
-  __syncthreads();                                      // the slabs are dead: LDS becomes the MFMA staging area
+  __syncthreads();                                      // dy and the statistics are dead: MFMA staging area
   GO_PROBE(4);
 
   // ---- G[ROWS, FIN] += u (x) x over the sample's nodes on the matrix cores ----------------------
   // wave w stages and reduces the nodes of its own 64 threads: the staging columns [64 w, 64 w + 64) are private to
   // the wave, so the iterations need no workgroup barrier (LDS serves a wave's accesses in order)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  float* us = go_abl;                                   // [ROWS][TP]
+  {                                                     // dx [FIN][N] out of LDS, 16 bytes per lane
+    float* dxb = dx + (int64_t)b * FIN * N;
+    if (NP == N && ((uintptr_t)dxb & 15) == 0) {
+      for (int i = tid * 4; i < FIN * N; i += GO_ABL_T * 4)
+        *reinterpret_cast<float4*>(dxb + i) = *reinterpret_cast<const float4*>(xs + i);
+    } else {
+      for (int d = 0; d < FIN; ++d)
+        for (int n = tid; n < N; n += GO_ABL_T) dxb[d * N + n] = xs[d * NP + n];
+    }
+  }
+  float* us = dys;                                      // [ROWS][TP], behind the dx slab
   float* xt = us + ROWS * TP;                           // [FIN][TP]
   const int w = tid >> 6, m = lane & 15, g4 = lane >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -858,9 +875,56 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
 
 static size_t go_abl_lds_bytes(int N, int fin, int fout) {
   const size_t np = ((size_t)N + 3) & ~(size_t)3;
-  const size_t slabs = (size_t)(fin + fout + 4) * np * sizeof(float);
+  const size_t walk = (size_t)(fout + 4) * np * sizeof(float);          // dy + statistics, then (same bytes) ...
   const size_t stage = ((size_t)(2 * fout + 3 + fin) * (GO_ABL_T + 4) + (GO_ABL_T / 64) * 4 * 64) * sizeof(float);
-  return slabs > stage ? slabs : stage;
+  return (size_t)fin * np * sizeof(float) + (walk > stage ? walk : stage);      // x / dx slab in front
+}
+
+// Thread -> node map of the LDS-resident backward's column walks (HOST code; structure-only, computed once per
+// hierarchy).  Slots: pass it, thread tid -> order[it * 1024 + tid] (-1 = idle); wave w owns slots [64 w, 64 w + 64) of
+// every pass.  Nodes are sorted by column degree (descending, ties by id) and cut into groups of 64 = one wave-pass
+// each (hub nodes last), so a wave's lanes walk lists of nearly equal length; a group's cost ~ fixed per-node work + list steps of its
+// longest ordinary list + the wave-cooperative hub lists; groups go to the wave with the smallest load so far (longest
+// first).  Any permutation gives the same numbers per node; the order only moves work between waves.
+extern "C" int igcn_go_attn_walk_slots(int N) { return (int)(igcn_cdiv(N > 0 ? N : 1, GO_ABL_T) * GO_ABL_T); }
+
+extern "C" int igcn_go_attn_walk_order(int N, const int32_t* t_ptr_host, int32_t* order_host) {
+  IGCN_REQUIRE(N > 0 && t_ptr_host && order_host, "go_attn_walk_order: bad arguments");
+  const int passes = (int)igcn_cdiv(N, GO_ABL_T), waves = GO_ABL_T / 64;
+  std::vector<int> nodes(N);
+  for (int i = 0; i < N; ++i) nodes[i] = i;
+  auto deg = [&](int n) { return t_ptr_host[n + 1] - t_ptr_host[n]; };
+  // hubs (walked by the whole wave, whatever their lane) sort BEHIND the leaves: they join wave-passes that have no
+  // list work of their own instead of the pass with the longest ordinary lists
+  auto key = [&](int n) { const int d = deg(n); return d > GO_HEAVY ? -1 : d; };
+  std::stable_sort(nodes.begin(), nodes.end(), [&](int a, int b) { return key(a) > key(b); });
+  const int ngroups = (int)igcn_cdiv(N, 64);
+  std::vector<double> cost(ngroups);
+  for (int g = 0; g < ngroups; ++g) {
+    int longest = 0, hubs = 0;
+    for (int k = g * 64; k < N && k < g * 64 + 64; ++k) {
+      const int d = deg(nodes[k]);
+      if (d > GO_HEAVY) hubs += 1 + d / 64; else if (d > longest) longest = d;
+    }
+    cost[g] = 1.5 + (longest + 1) / 2 + 3.0 * hubs;     // in units of one two-edge list step
+  }
+  std::vector<int> gorder(ngroups);
+  for (int g = 0; g < ngroups; ++g) gorder[g] = g;
+  std::stable_sort(gorder.begin(), gorder.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  std::vector<double> load(waves, 0.0);
+  std::vector<int> used(waves, 0);
+  for (int i = 0; i < passes * GO_ABL_T; ++i) order_host[i] = -1;
+  for (int g : gorder) {
+    int best = -1;
+    for (int w = 0; w < waves; ++w)
+      if (used[w] < passes && (best < 0 || load[w] < load[best])) best = w;
+    IGCN_REQUIRE(best >= 0, "go_attn_walk_order: no free slot");
+    const int base = used[best] * GO_ABL_T + best * 64;
+    for (int k = g * 64, j = 0; k < N && j < 64; ++k, ++j) order_host[base + j] = nodes[k];
+    used[best] += 1;
+    load[best] += cost[g];
+  }
+  return IGCN_OK;
 }
 
 // IGCN_GO_ATTN_CM=1 (A/B runs): the global-memory kernels (attention backward, decoder forward / backward) even when a
@@ -875,7 +939,8 @@ static bool go_attn_force_cm(void) {
 }
 
 extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
-                                const int32_t* t_ptr, const int32_t* t_row, const float* x, const float* w_inc,
+                                const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order,
+                                const float* x, const float* w_inc,
                                 const float* w_s, const float* a_in, const float* a_s, const float* dy, float* dx,
                                 float* dparams, float* scratch, void* stream) {
   IGCN_REQUIRE(B > 0 && N > 0, "go_attn_bwd: bad sizes");
@@ -889,7 +954,7 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
   {                                                                                                               \
     IGCN_ALLOW_BIG_LDS((k_go_attn_bwd_lds<FI, FO, MI>));                                        \
     hipLaunchKernelGGL((k_go_attn_bwd_lds<FI, FO, MI>), dim3(B), dim3(GO_ABL_T), abl_lds, st, N, row_ptr, col,    \
-                       t_ptr, t_row, x, w_inc, w_s, a_in, a_s, dy, dx, gpart);                                    \
+                       t_ptr, t_row, x, w_inc, w_s, a_in, a_s, dy, walk_order, dx, gpart);                        \
   }
 #define CALLL(FI, FO)                                                                                             \
   if (iters <= 1) CALLLI(FI, FO, 1) else if (iters == 2) CALLLI(FI, FO, 2) else if (iters == 3) CALLLI(FI, FO, 3) \

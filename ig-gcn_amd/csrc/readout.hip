@@ -625,7 +625,7 @@ extern "C" size_t igcn_node_linear_bn_bwd_scratch_floats(int B, int F, int N, in
 template <int F, int D>
 static int ro_bwd(dim3 grid, int cpg, hipStream_t st, int B, int N, int groups, int training, const float* x,
                   const float* W, const float* gamma, const float* beta, const float* save_mean,
-                  const float* save_rstd, const float* dout, const float* keep, float* stats, float* aux,
+                  const float* save_rstd, const float* dout, const float* keep, float* stats, float* dgg, float* aux,
                   float* dx, float* dW, float* dgb) {
   int rc;
   if constexpr (ro_quad_ok<F, D>()) {
@@ -642,10 +642,13 @@ static int ro_bwd(dim3 grid, int cpg, hipStream_t st, int B, int N, int groups, 
   } else {
     hipLaunchKernelGGL((k_nlbn_bwd_stats<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, x, W, gamma, beta, save_mean,
                        save_rstd, dout, keep, stats);
+    // thin rows (D = 1): a thread's own work is a handful of loads, so summing `cpg` chunk partials per thread costs
+    // more than the launch it saves (measured: +17 us against -4.5) — the chunk sums keep their own launch here
+    if ((rc = igcn_launch_reduce_rows(stats, cpg, (int64_t)groups * 2 * N, groups * 2 * N, dgg, 0, st))) return rc;
     hipLaunchKernelGGL((k_nlbn_bwd_apply<F, D>), grid, dim3(RO_T), 0, st, B, N, groups, training, x, W, gamma, beta,
-                       save_mean, save_rstd, dout, keep, stats, cpg, aux, dx, aux);
+                       save_mean, save_rstd, dout, keep, dgg, 1, aux, dx, aux);
     IGCN_CHECK_LAUNCH("node_linear_bn_bwd");
-    if ((rc = igcn_launch_reduce_rows_final(stats, (int64_t)cpg * groups, 2 * (int64_t)N, 2 * N, dgb, st))) return rc;
+    if ((rc = igcn_launch_reduce_rows_final(dgg, groups, 2 * (int64_t)N, 2 * N, dgb, st))) return rc;
     if (D * F <= 16) return igcn_launch_reduce_rows_final(aux, (int64_t)grid.x * grid.y, D * F, D * F, dW, st);
     // dW[d,c] = sum_b sum_n dpre[b,n,d] * x[b,c,n]
     return igcn_gemm_f32_batched_sum_impl(D, F, N, B, aux, 1, D, (int64_t)N * D, x, N, 1, (int64_t)F * N, dW, F,
@@ -669,7 +672,7 @@ extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, i
                                                              // wpartial (small) or dpre rows, then slabs (large)
 #define CALL(FV, DV)                                                                                           \
   return ro_bwd<FV, DV>(grid, cpg, st, B, N, groups, training, x, W, gamma, beta, save_mean, save_rstd, dout,   \
-                        keep, stats, aux, dx, dW, dgb)
+                        keep, stats, dgg, aux, dx, dW, dgb)
   RO_DISPATCH(F, D, CALL)
 #undef CALL
 }

@@ -30,7 +30,7 @@ struct SfParams {
 
 // LDS carve-out shared by both kernels (all offsets in 4-byte words)
 struct SfLayout {
-  int x, dis, wl, wloop, ew, what, src, dst, tptr, tperm, w, bias, act, wall, loop, tsrc, twhat;   // forward part
+  int x, dis, wl, wloop, ew, what, src, dst, tptr, tperm, wallT, act, wall, loop, tsrc, twhat;   // forward part
   int ycat;                                                                             // [R][L*F] layer outputs
   int sptr, sperm, g, dh, dx, dwhat, dwloop, ddeg, red, dycat, prow, bdst, bwhat;   // backward part
   int total;
@@ -53,9 +53,10 @@ __host__ __device__ inline SfLayout sf_layout(int R, int Emax, int H0, int F, in
   o.tperm = take(Emax);
   o.tsrc = take(Emax + 4);                         // by-TARGET order: source node and coefficient of every list entry
   o.twhat = take(Emax + 4);                        // (+4: the 4-wide list walk may read past the end; never used)
-  o.w = take(F * fin_max);
-  o.bias = take(F);
-  o.wall = take(L * (F * fin_max + F));            // every layer's W_l | b_l, fetched with the graph (one round trip)
+  // every layer's weights, fetched with the graph (one round trip): wallT = W_l TRANSPOSED (Wt[fi][fo]: the F lanes of
+  // a node read consecutive words in the transforms) | b_l; wall = W_l [fo][fi] as stored (backward: dX = dH W)
+  o.wallT = take(L * (F * fin_max + F));
+  o.wall = take(backward ? L * (F * fin_max + F) : 0);
   o.loop = take(R);
   // activations: the transforms H_l (the forward keeps the current one only, the backward all of them) and the
   // concatenated layer outputs Y [R][L*F], which leave for HBM in ONE coalesced pass at the end — a store in front of
@@ -87,52 +88,148 @@ extern "C" size_t igcn_sgcn_stack_lds_bytes(int R, int max_edges, int H0, int F,
 }
 
 // stage the graph: node features, edges (local endpoints, weights), lists, and the gcn_norm coefficients
+#ifdef SF_PROBE_ON
+__device__ long long sf_probe_buf[8 * 16];
+#define SF_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8) sf_probe_buf[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+extern "C" int igcn_debug_sf_probe(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sf_probe_buf), sizeof(long long) * 8 * 16);
+}
+#else
+#define SF_PROBE(i)
+#endif
+
+// Returns the graph's edge count, or -1 (nothing staged beyond the fixed-size arrays) when it exceeds Emax.  The loads
+// whose size is fixed by R go out FIRST, together with the two pointer words that give the graph's edge range: the
+// edge arrays then follow one round trip later instead of two (the range used to be fetched, and waited for, in front
+// of everything).
 template <bool BWD>
-__device__ __forceinline__ void sf_stage(float* lds, const SfLayout& o, int R, int H0, int64_t nb, int32_t eb, int ne,
-                                         const float* __restrict__ x_in, const float* __restrict__ ew_in,
-                                         const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
-                                         const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
-                                         const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_perm,
-                                         const int32_t* __restrict__ loop_edge, const SfParams& prm, int F, int L) {
+__device__ __forceinline__ int sf_stage(float* lds, const SfLayout& o, int R, int Emax, int H0, int64_t nb,
+                                        const float* __restrict__ x_in, const float* __restrict__ ew_in,
+                                        const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
+                                        const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
+                                        const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_perm,
+                                        const int32_t* __restrict__ loop_edge, const SfParams& prm, int F, int L) {
   const int tid = threadIdx.x;
+  const int32_t eb = tgt_ptr[nb];                      // workgroup-uniform: scalar loads, waited for where first used
+  const int ne = tgt_ptr[nb + R] - eb;
   const int wstride = F * (F > H0 ? F : H0) + F;
-  for (int l = 0; l < L; ++l) {
-    const int fin = l == 0 ? H0 : F;
-    for (int i = tid; i < F * fin; i += (int)blockDim.x) lds[o.wall + l * wstride + i] = prm.W[l][i];
-    for (int i = tid; i < F; i += (int)blockDim.x) lds[o.wall + l * wstride + F * fin + i] = prm.b[l][i];
+  // weights and biases of all layers as one flat list [W_0 | b_0 | W_1 | b_1 | ...]: entry j of layer l lands at
+  // wall + l * wstride + j.  The first two entries per thread ride in the register batch below.
+  auto wsrc = [&](int j, int& dst, int& dstT) -> const float* {
+    int off = 0;
+    for (int l = 0; l < L; ++l) {
+      const int fin = l == 0 ? H0 : F, nw = F * fin, n = nw + F;
+      if (j < off + n) {
+        const int r = j - off;
+        dst = o.wall + l * wstride + r;
+        dstT = o.wallT + l * wstride + (r < nw ? (r % fin) * F + r / fin : r);
+        return r < nw ? prm.W[l] + r : prm.b[l] + (r - nw);
+      }
+      off += n;
+    }
+    dst = dstT = -1;
+    return nullptr;
+  };
+  const int wtotal = F * H0 + F + (L - 1) * (F * F + F);
+  float wv[2];
+  int wd[2], wdT[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float* src = wsrc(tid + j * (int)blockDim.x, wd[j], wdT[j]);
+    wv[j] = src ? *src : 0.f;
   }
-  for (int i = tid; i < R; i += (int)blockDim.x) reinterpret_cast<int32_t*>(lds + o.loop)[i] = loop_edge[nb + i];
   int32_t* ssrc = reinterpret_cast<int32_t*>(lds + o.src);
   int32_t* sdst = reinterpret_cast<int32_t*>(lds + o.dst);
   int32_t* stptr = reinterpret_cast<int32_t*>(lds + o.tptr);
   int32_t* stperm = reinterpret_cast<int32_t*>(lds + o.tperm);
-  for (int i = tid; i < R * H0; i += (int)blockDim.x) lds[o.x + i] = x_in[nb * H0 + i];
-  for (int k = tid; k < ne; k += (int)blockDim.x) {
-    ssrc[k] = src32[eb + k] - (int32_t)nb;
-    sdst[k] = dst32[eb + k] - (int32_t)nb;
-    lds[o.ew + k] = ew_in[eb + k];
-    stperm[k] = tgt_perm[eb + k] - eb;             // by-target position eb + k holds edge tgt_perm[.] of this graph
-    if (BWD) reinterpret_cast<int32_t*>(lds + o.sperm)[k] = src_perm[eb + k] - eb;
+  // ONE batch of loads per thread, parked in registers: x, the loop edges, the list pointers — and, as soon as the
+  // (scalar) edge range has arrived, this thread's edge of every edge array; only then the LDS stores.  The vector
+  // loads of the first group are still in flight when the second group goes out: one round trip, not two.
+  float xv[4];
+  int32_t lp = 0, tp[2] = {0, 0}, sp[2] = {0, 0};
+  const int nx = R * H0, bd = (int)blockDim.x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xv[j] = tid + j * bd < nx ? x_in[nb * H0 + tid + j * bd] : 0.f;
+  if (tid < R) lp = loop_edge[nb + tid];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + j * bd;
+    if (i <= R) {
+      tp[j] = tgt_ptr[nb + i];
+      if (BWD) sp[j] = src_ptr[nb + i];
+    }
   }
-  for (int i = tid; i <= R; i += (int)blockDim.x) {
+  if (ne > Emax) return -1;                            // host-checked; never corrupt LDS
+  int32_t es = 0, ed = 0, et = 0, ep = 0;
+  float ev = 0.f;
+  if (tid < ne) {
+    es = src32[eb + tid];
+    ed = dst32[eb + tid];
+    ev = ew_in[eb + tid];
+    et = tgt_perm[eb + tid];
+    if (BWD) ep = src_perm[eb + tid];
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (wd[j] >= 0) {
+      lds[wdT[j]] = wv[j];
+      if (BWD) lds[wd[j]] = wv[j];
+    }
+  for (int j = tid + 2 * bd; j < wtotal; j += bd) {
+    int dst, dstT;
+    const float v = *wsrc(j, dst, dstT);
+    lds[dstT] = v;
+    if (BWD) lds[dst] = v;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (tid + j * bd < nx) lds[o.x + tid + j * bd] = xv[j];
+  for (int i = tid + 4 * bd; i < nx; i += bd) lds[o.x + i] = x_in[nb * H0 + i];
+  for (int i = tid; i < R; i += bd) reinterpret_cast<int32_t*>(lds + o.loop)[i] = i == tid ? lp : loop_edge[nb + i];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + j * bd;
+    if (i <= R) {
+      stptr[i] = tp[j] - eb;
+      if (BWD) reinterpret_cast<int32_t*>(lds + o.sptr)[i] = sp[j] - eb;
+    }
+  }
+  for (int i = tid + 2 * bd; i <= R; i += bd) {
     stptr[i] = tgt_ptr[nb + i] - eb;
     if (BWD) reinterpret_cast<int32_t*>(lds + o.sptr)[i] = src_ptr[nb + i] - eb;
   }
+  if (tid < ne) {
+    ssrc[tid] = es - (int32_t)nb;
+    sdst[tid] = ed - (int32_t)nb;
+    lds[o.ew + tid] = ev;
+    stperm[tid] = et - eb;                         // by-target position eb + k holds edge tgt_perm[.] of this graph
+    if (BWD) reinterpret_cast<int32_t*>(lds + o.sperm)[tid] = ep - eb;
+  }
+  for (int k = tid + bd; k < ne; k += bd) {
+    ssrc[k] = src32[eb + k] - (int32_t)nb;
+    sdst[k] = dst32[eb + k] - (int32_t)nb;
+    lds[o.ew + k] = ew_in[eb + k];
+    stperm[k] = tgt_perm[eb + k] - eb;
+    if (BWD) reinterpret_cast<int32_t*>(lds + o.sperm)[k] = src_perm[eb + k] - eb;
+  }
   __syncthreads();
-  // gcn_norm (PyG: drop stored loops, add one loop per node whose weight is the LAST stored loop's or 1).  The walk
-  // also lays the list entries out in BY-TARGET order (tsrc, twhat): every later walk of a target's list then reads
-  // two consecutive arrays instead of chasing permutation -> edge -> endpoint
+  SF_PROBE(1);
+  // gcn_norm (PyG: drop stored loops, add one loop per node whose weight is the LAST stored loop's or 1), with the
+  // list entries laid out in BY-TARGET order (tsrc, twhat): every later walk of a target's list reads two consecutive
+  // arrays instead of chasing permutation -> edge -> endpoint.  Three short phases with a thread per list POSITION
+  // (360 of them) or per node — a thread per node walking its list through the permutation was a serial chain of
+  // dependent LDS reads on 90 of the 512 threads.
   int32_t* stsrc = reinterpret_cast<int32_t*>(lds + o.tsrc);
+  for (int p = tid; p < ne; p += (int)blockDim.x) {
+    const int k = stperm[p];
+    const int sk = ssrc[k];
+    stsrc[p] = sk;
+    lds[o.twhat + p] = sk != sdst[k] ? lds[o.ew + k] : 0.f;      // stored loops are replaced by the added loop
+  }
+  __syncthreads();
   for (int i = tid; i < R; i += (int)blockDim.x) {
     float deg = 0.f;
-    for (int p = stptr[i]; p < stptr[i + 1]; ++p) {
-      const int k = stperm[p];
-      const int sk = ssrc[k];
-      const float wk = lds[o.ew + k];
-      stsrc[p] = sk;
-      lds[o.twhat + p] = sk != i ? wk : 0.f;           // stored loops are replaced by the added loop
-      if (sk != i) deg += wk;
-    }
+    for (int p = stptr[i]; p < stptr[i + 1]; ++p) deg += lds[o.twhat + p];     // list order (loops add an exact 0)
     const int32_t le = reinterpret_cast<const int32_t*>(lds + o.loop)[i];
     const float lw = le >= 0 ? lds[o.ew + (le - eb)] : 1.f;
     deg += lw;
@@ -143,10 +240,9 @@ __device__ __forceinline__ void sf_stage(float* lds, const SfLayout& o, int R, i
     lds[o.wloop + i] = d * lw * d;
   }
   __syncthreads();
-  for (int i = tid; i < R; i += (int)blockDim.x) {
-    const float di = lds[o.dis + i];
-    for (int p = stptr[i]; p < stptr[i + 1]; ++p) lds[o.twhat + p] = lds[o.dis + stsrc[p]] * lds[o.twhat + p] * di;
-  }
+  SF_PROBE(2);
+  for (int p = tid; p < ne; p += (int)blockDim.x)
+    lds[o.twhat + p] = lds[o.dis + stsrc[p]] * lds[o.twhat + p] * lds[o.dis + sdst[stperm[p]]];
   if (BWD) {
     for (int k = tid; k < ne; k += (int)blockDim.x) {
       const int s = ssrc[k], t = sdst[k];
@@ -167,20 +263,19 @@ __device__ __forceinline__ void sf_stage(float* lds, const SfLayout& o, int R, i
     }
   }
   // (the caller's next __syncthreads() orders `what` before its first use)
+  return ne;
 }
 
 // H = X W^T (X [R, fin], row stride ldx, at `xin`), then Y = relu(A_hat H + b) (row stride ldy): one layer, out of LDS
 // into LDS
 template <int F>
 __device__ __forceinline__ void sf_layer(float* lds, const SfLayout& o, int R, int fin, const float* xin, int ldx,
-                                         float* H, float* Y, int ldy, const float* Wg, const float* bg) {
+                                         float* H, float* Y, int ldy, const float* Wt, const float* bt) {
+  // Wt = the layer's weights TRANSPOSED in LDS (Wt[fi][fo], staged that way with the graph: the F lanes of a node
+  // read consecutive words, not a stride-fin column), bt = its bias
   const int tid = threadIdx.x;
   const int32_t* stptr = reinterpret_cast<const int32_t*>(lds + o.tptr);
   const int32_t* stsrc = reinterpret_cast<const int32_t*>(lds + o.tsrc);
-  // weights TRANSPOSED in LDS (Wt[fi][fo]): the F lanes of a node read consecutive words, not a stride-fin column
-  for (int i = tid; i < F * fin; i += (int)blockDim.x) lds[o.w + (i % fin) * F + i / fin] = Wg[i];
-  for (int i = tid; i < F; i += (int)blockDim.x) lds[o.bias + i] = bg[i];
-  __syncthreads();
   // work item = (node, output quad): every LDS access moves 16 bytes (one weight-row quad serves four FMAs, one
   // gathered activation quad four more) — with one item per output word the phase is bound by the LDS instruction
   // rate, two 4-byte reads per FMA.  Dot products fully unrolled: the reads of an item are issued together.
@@ -195,7 +290,7 @@ __device__ __forceinline__ void sf_layer(float* lds, const SfLayout& o, int R, i
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float4 w4 = *reinterpret_cast<const float4*>(lds + o.w + (f4 * 4 + j) * F + q * 4);
+          const float4 w4 = *reinterpret_cast<const float4*>(Wt + (f4 * 4 + j) * F + q * 4);
           acc.x += xs[j] * w4.x; acc.y += xs[j] * w4.y; acc.z += xs[j] * w4.z; acc.w += xs[j] * w4.w;
         }
       }
@@ -209,7 +304,7 @@ __device__ __forceinline__ void sf_layer(float* lds, const SfLayout& o, int R, i
       for (int fi = 0; fi < SF_MAXH0; ++fi)
         if (fi < fin) {
           const float xv = xin[i * ldx + fi];
-          const float4 w4 = *reinterpret_cast<const float4*>(lds + o.w + fi * F + q * 4);
+          const float4 w4 = *reinterpret_cast<const float4*>(Wt + fi * F + q * 4);
           acc.x += xv * w4.x; acc.y += xv * w4.y; acc.z += xv * w4.z; acc.w += xv * w4.w;
         }
       *reinterpret_cast<float4*>(H + i * F + q * 4) = acc;
@@ -237,7 +332,7 @@ __device__ __forceinline__ void sf_layer(float* lds, const SfLayout& o, int R, i
     }
     const float wl = lds[o.wloop + i];
     const float4 hs = *reinterpret_cast<const float4*>(H + i * F + q * 4);
-    const float4 b4 = *reinterpret_cast<const float4*>(lds + o.bias + q * 4);
+    const float4 b4 = *reinterpret_cast<const float4*>(bt + q * 4);
     acc.x = fmaxf(acc.x + wl * hs.x + b4.x, 0.f);            // + self loop, + bias in the reference's order, ReLU
     acc.y = fmaxf(acc.y + wl * hs.y + b4.y, 0.f);
     acc.z = fmaxf(acc.z + wl * hs.z + b4.z, 0.f);
@@ -256,23 +351,25 @@ k_sgcn_stack_fwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
   extern __shared__ float sf_lds[];
   const SfLayout o = sf_layout(R, Emax, H0, F, L, 0);
   const int64_t nb = (int64_t)blockIdx.x * R;
-  const int32_t eb = tgt_ptr[nb];
-  const int ne = tgt_ptr[nb + R] - eb;
-  if (ne > Emax) return;                               // host-checked; never corrupt LDS
-  sf_stage<false>(sf_lds, o, R, H0, nb, eb, ne, x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, nullptr, nullptr,
-                  loop_edge, prm, F, L);
+  SF_PROBE(0);
+  if (sf_stage<false>(sf_lds, o, R, Emax, H0, nb, x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, nullptr, nullptr,
+                      loop_edge, prm, F, L) < 0)
+    return;
   float* H = sf_lds + o.act;
   float* Y = sf_lds + o.ycat;
   const int D = L * F;
+  SF_PROBE(3);
   for (int l = 0; l < L; ++l) {
     // layer l owns columns [l F, (l+1) F) of the concatenated output rows and reads the columns of layer l-1
-    const float* wl = sf_lds + o.wall + l * (F * (F > H0 ? F : H0) + F);
+    const float* wl = sf_lds + o.wallT + l * (F * (F > H0 ? F : H0) + F);
     sf_layer<F>(sf_lds, o, R, l == 0 ? H0 : F, l == 0 ? sf_lds + o.x : Y + (l - 1) * F, l == 0 ? H0 : D, H, Y + l * F, D,
                 wl, wl + F * (l == 0 ? H0 : F));
+    SF_PROBE(4 + l);
   }
   // jumping-knowledge concatenation: the rows are already laid out [R][L F] — one coalesced 16-byte pass
   for (int e = threadIdx.x; e < R * D / 4; e += SF_T)
     reinterpret_cast<float4*>(xcat + nb * D)[e] = reinterpret_cast<const float4*>(Y)[e];
+  SF_PROBE(8);
 }
 
 // parameter-gradient partial row of one graph: [ dW_0 (F x H0) | db_0 (F) | dW_1 (F x F) | db_1 | ... ]
@@ -295,22 +392,29 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
   const int tid = threadIdx.x;
   const int64_t nb = (int64_t)blockIdx.x * R;
   const int32_t eb = tgt_ptr[nb];
-  const int ne = tgt_ptr[nb + R] - eb;
-  if (ne > Emax) return;
-  sf_stage<true>(sf_lds, o, R, H0, nb, eb, ne, x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm,
-                 loop_edge, prm, F, L);
+  const int D = L * F;
+  // the incoming gradient rows travel with the staging loads: issued first, parked in registers, stored behind them
+  float4 dyv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    dyv[j] = tid + j * SF_TB < R * D / 4 ? reinterpret_cast<const float4*>(dxcat + nb * D)[tid + j * SF_TB]
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ne = sf_stage<true>(sf_lds, o, R, Emax, H0, nb, x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, src_ptr,
+                                src_perm, loop_edge, prm, F, L);
+  if (ne < 0) return;
   const int32_t* ssrc = reinterpret_cast<const int32_t*>(sf_lds + o.src);
   const int32_t* sdst = reinterpret_cast<const int32_t*>(sf_lds + o.dst);
   const int32_t* ssptr = reinterpret_cast<const int32_t*>(sf_lds + o.sptr);
   const int32_t* ssperm = reinterpret_cast<const int32_t*>(sf_lds + o.sperm);
-  const int D = L * F;
-  // the incoming gradient rows travel with the staging loads (one round trip), not one layer at a time
-  for (int e = tid; e < R * D / 4; e += SF_TB)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (tid + j * SF_TB < R * D / 4) reinterpret_cast<float4*>(sf_lds + o.dycat)[tid + j * SF_TB] = dyv[j];
+  for (int e = tid + 2 * SF_TB; e < R * D / 4; e += SF_TB)
     reinterpret_cast<float4*>(sf_lds + o.dycat)[e] = reinterpret_cast<const float4*>(dxcat + nb * D)[e];
   // ---- forward, every transform kept: H_l at act + l R F; outputs in the concatenated layout
   float* Ycat = sf_lds + o.ycat;
   for (int l = 0; l < L; ++l) {
-    const float* wl = sf_lds + o.wall + l * (F * (F > H0 ? F : H0) + F);
+    const float* wl = sf_lds + o.wallT + l * (F * (F > H0 ? F : H0) + F);
     sf_layer<F>(sf_lds, o, R, l == 0 ? H0 : F, l == 0 ? sf_lds + o.x : Ycat + (l - 1) * F, l == 0 ? H0 : D,
                 sf_lds + o.act + l * R * F, Ycat + l * F, D, wl, wl + F * (l == 0 ? H0 : F));
   }
@@ -353,8 +457,7 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
       g.z = y4.z > 0.f ? g.z : 0.f; g.w = y4.w > 0.f ? g.w : 0.f;
       *reinterpret_cast<float4*>(G + i * F + q * 4) = g;
     }
-    for (int i = tid; i < F * fin; i += SF_TB)                                      // W_l [fo][fi] for dX = dH W
-      sf_lds[o.w + i] = sf_lds[o.wall + l * (F * (F > H0 ? F : H0) + F) + i];
+    const float* Wl = sf_lds + o.wall + l * (F * (F > H0 ? F : H0) + F);            // W_l [fo][fi] for dX = dH W
     __syncthreads();
     // dH = A_hat^T G (by-source lists, four entries per step); coefficient gradients accumulate over the layers
     {
@@ -448,7 +551,7 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
           const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float4 w4 = *reinterpret_cast<const float4*>(sf_lds + o.w + (c * 4 + j) * F + q * 4);
+            const float4 w4 = *reinterpret_cast<const float4*>(Wl + (c * 4 + j) * F + q * 4);
             acc.x += ds[j] * w4.x; acc.y += ds[j] * w4.y; acc.z += ds[j] * w4.z; acc.w += ds[j] * w4.w;
           }
         }
@@ -459,7 +562,7 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
         const int i = e / fin, fi = e - i * fin;
         float acc = 0.f;
 #pragma unroll
-        for (int fo = 0; fo < F; ++fo) acc += dH[i * F + fo] * sf_lds[o.w + fo * fin + fi];
+        for (int fo = 0; fo < F; ++fo) acc += dH[i * F + fo] * Wl[fo * fin + fi];
         dX[e] = acc;                                  // layer 0: d x_in, stored after the last barrier
       }
     }

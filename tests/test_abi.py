@@ -56,6 +56,42 @@ def test_library_exports_every_declared_symbol():
     assert lib.igcn_go_attn_bwd_scratch_floats(256, 3000, 5, 5) > 4 * 256 * 3000
 
 
+def test_go_attn_walk_order_is_a_balanced_permutation():
+    """igcn_go_attn_walk_order (host code): every node exactly once, idle slots -1, the lanes of a wave-pass get
+    nodes of (nearly) equal column degree, and no wave is left with much more list work than the average."""
+    import numpy as np
+    import torch
+    import igcn_amd  # noqa: F401
+    from igcn_amd import synth
+    lib = _lib.load()
+    _, adj, _ = synth.go_hierarchy()
+    deg = (np.asarray(adj) != 0).sum(1).astype(np.int64)      # readers of each node = its children (adj[parent, child])
+    n = deg.size
+    t_ptr = torch.zeros(n + 1, dtype=torch.int32)
+    t_ptr[1:] = torch.from_numpy(np.cumsum(deg)).to(torch.int32)
+    slots = lib.igcn_go_attn_walk_slots(n)
+    assert slots == 3072
+    order = torch.full((slots,), -7, dtype=torch.int32)
+    assert lib.igcn_go_attn_walk_order(n, t_ptr.data_ptr(), order.data_ptr()) == 0
+    o = order.numpy()
+    assert sorted(o[o >= 0].tolist()) == list(range(n)) and set(o[o < 0].tolist()) <= {-1}
+    steps = np.zeros(16)
+    spread = []
+    for it in range(3):
+        for w in range(16):
+            grp = o[it * 1024 + w * 64: it * 1024 + w * 64 + 64]
+            d = deg[grp[grp >= 0]]
+            d = d[d <= 12]                                    # hubs are walked by the whole wave
+            if d.size:
+                steps[w] += (d.max() + 1) // 2
+                spread.append(d.max() - d.min())
+    spread.sort()                                             # sorted by degree: no lane waits on a long neighbour
+    assert spread[-2] <= 2 and spread[-1] <= 6                # (the group holding the tail of the distribution aside)
+    # in node order the slowest wave walked 10 steps against a mean of 4; now one wave holds the indivisible group with
+    # the longest ordinary lists (6 steps) and everybody else is within 2 of the mean
+    assert steps.max() <= 6 and np.sort(steps)[-2] <= steps.mean() + 2, steps
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))

@@ -317,11 +317,20 @@ def test_go_attention_layer(ops, bsz, pool, fin, seed):
     csr = ops.Csr(row, col, nj, nj, "cuda")
     dev = [x.transpose(1, 2).contiguous().cuda().requires_grad_(True)] + [p.cuda().requires_grad_(True) for p in par]
     y = ops.GoAttention.apply(dev[0], dev[1], dev[2], dev[3].view(-1), dev[4].view(-1), csr)
-    g = torch.autograd.grad((y * cot.transpose(1, 2).contiguous().cuda()).sum(), dev)
+    g = torch.autograd.grad((y * cot.transpose(1, 2).contiguous().cuda()).sum(), dev, retain_graph=True)
     assert_matches(y.transpose(1, 2), y_ref.detach().numpy(), TOL, "y")
     assert_matches(g[0].transpose(1, 2), g_ref[0].numpy(), TOL, "dx")
     for got, want, nm in zip(g[1:], g_ref[1:], ("dW_inc", "dW_s", "da_in", "da_s")):
         assert_matches(got, want.numpy(), TOL, nm)
+    # the balanced thread -> node map of the column walks (igcn_go_attn_walk_order) only moves work between waves: in
+    # plain node order the per-node results are the same bits, the parameter sums the same up to summation order
+    assert csr.walk_order is not None and int((csr.walk_order >= 0).sum()) == nj
+    csr._walk_order = torch.arange(csr.walk_order.numel(), dtype=torch.int32, device="cuda")
+    csr._walk_order[nj:] = -1
+    g2 = torch.autograd.grad((y * cot.transpose(1, 2).contiguous().cuda()).sum(), dev)
+    assert torch.equal(g2[0], g[0])
+    for a, c2, nm in zip(g2[1:], g[1:], ("dW_inc", "dW_s", "da_in", "da_s")):
+        assert_matches(a, c2.cpu().numpy(), 1e-5, nm)
 
 
 @pytest.mark.parametrize("bsz,f,n,pool,with_keep", [(3, 5, 40, 20, False), (8, 5, 3000, 1800, True),
