@@ -1028,9 +1028,11 @@ k_nodes_ln_fwd(int f, int N, int pool, float eps, const float* __restrict__ y, c
 // Register-resident form: the row (N <= 4096 floats, N and pool multiples of 4) is read ONCE with 16-byte loads and
 // kept in registers for the mean, the variance and the normalisation (the generic kernel makes three passes).
 #define LN_VPT 4
+#define LN_TMAX 1024
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-__global__ void __launch_bounds__(GO_T)
+// (256 threads for rows up to 4096 nodes, 1024 threads up to 16384: the 10 000-node hierarchy of configs[4])
+__global__ void __launch_bounds__(LN_TMAX)
 k_nodes_ln_fwd_v(int f, int N, int pool, float eps, const float* __restrict__ y, const float* __restrict__ gamma,
                  const float* __restrict__ beta, const float* __restrict__ keep, float* __restrict__ z,
                  float* __restrict__ mean_out, float* __restrict__ rstd_out) {
@@ -1041,7 +1043,7 @@ k_nodes_ln_fwd_v(int f, int N, int pool, float eps, const float* __restrict__ y,
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_VPT; ++i) {
-    const int q = threadIdx.x + i * GO_T;
+    const int q = threadIdx.x + i * (int)blockDim.x;
     v[i] = q < nv ? ld4(yr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
@@ -1049,7 +1051,7 @@ k_nodes_ln_fwd_v(int f, int N, int pool, float eps, const float* __restrict__ y,
   float var = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_VPT; ++i) {
-    if (threadIdx.x + i * GO_T < nv) {
+    if (threadIdx.x + i * (int)blockDim.x < nv) {
       const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
       var += (a * a + bb * bb) + (c * c + d * d);
     }
@@ -1063,7 +1065,7 @@ k_nodes_ln_fwd_v(int f, int N, int pool, float eps, const float* __restrict__ y,
   float* zr = z + (int64_t)row * (N - pool);
 #pragma unroll
   for (int i = 0; i < LN_VPT; ++i) {
-    const int q = threadIdx.x + i * GO_T, n = 4 * q;
+    const int q = threadIdx.x + i * (int)blockDim.x, n = 4 * q;
     if (q < nv && n >= pool) {
       const float4 g = ld4(gamma + n), be = ld4(beta + n);
       float4 o;
@@ -1080,7 +1082,7 @@ k_nodes_ln_fwd_v(int f, int N, int pool, float eps, const float* __restrict__ y,
   }
 }
 
-__global__ void __launch_bounds__(GO_T)
+__global__ void __launch_bounds__(LN_TMAX)
 k_nodes_ln_bwd_dy_v(int f, int N, int pool, const float* __restrict__ y, const float* __restrict__ gamma,
                     const float* __restrict__ beta, const float* __restrict__ keep, const float* __restrict__ mean,
                     const float* __restrict__ rstd, const float* __restrict__ dz, float* __restrict__ dy) {
@@ -1093,7 +1095,7 @@ k_nodes_ln_bwd_dy_v(int f, int N, int pool, const float* __restrict__ y, const f
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_VPT; ++i) {
-    const int q = threadIdx.x + i * GO_T, n = 4 * q;
+    const int q = threadIdx.x + i * (int)blockDim.x, n = 4 * q;
     xh[i] = dx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < nv) {
       const float4 yv = ld4(yr + n), g = ld4(gamma + n);
@@ -1119,7 +1121,7 @@ k_nodes_ln_bwd_dy_v(int f, int N, int pool, const float* __restrict__ y, const f
   float* dyr = dy + (int64_t)row * N;
 #pragma unroll
   for (int i = 0; i < LN_VPT; ++i) {
-    const int q = threadIdx.x + i * GO_T;
+    const int q = threadIdx.x + i * (int)blockDim.x;
     if (q < nv) {
       float4 o;
       o.x = rs * (dx[i].x - s1 - xh[i].x * s2);
@@ -1131,10 +1133,11 @@ k_nodes_ln_bwd_dy_v(int f, int N, int pool, const float* __restrict__ y, const f
   }
 }
 
+static int ln_threads(int N) { return N <= GO_T * 4 * LN_VPT ? GO_T : LN_TMAX; }
 static bool ln_vec_ok(int N, int pool, const void* a, const void* b, const void* c, const void* d, const void* e,
                       const void* k) {
   auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; };
-  return N % 4 == 0 && pool % 4 == 0 && N <= GO_T * 4 * LN_VPT && al(a) && al(b) && al(c) && al(d) && al(e) && al(k);
+  return N % 4 == 0 && pool % 4 == 0 && N <= LN_TMAX * 4 * LN_VPT && al(a) && al(b) && al(c) && al(d) && al(e) && al(k);
 }
 
 extern "C" int igcn_nodes_ln_fwd(int B, int f, int N, int pool, float eps, const float* y, const float* gamma,
@@ -1142,7 +1145,7 @@ extern "C" int igcn_nodes_ln_fwd(int B, int f, int N, int pool, float eps, const
                                  void* stream) {
   IGCN_REQUIRE(B > 0 && f > 0 && N > 0 && pool >= 0 && pool < N, "nodes_ln_fwd: bad sizes");
   if (ln_vec_ok(N, pool, y, gamma, beta, z, nullptr, keep)) {
-    hipLaunchKernelGGL(k_nodes_ln_fwd_v, dim3(B * f), dim3(GO_T), 0, (hipStream_t)stream, f, N, pool, eps, y, gamma,
+    hipLaunchKernelGGL(k_nodes_ln_fwd_v, dim3(B * f), dim3(ln_threads(N)), 0, (hipStream_t)stream, f, N, pool, eps, y, gamma,
                        beta, keep, z, mean, rstd);
     IGCN_CHECK_LAUNCH("nodes_ln_fwd_v");
     return IGCN_OK;
@@ -1290,7 +1293,7 @@ extern "C" int igcn_nodes_ln_bwd(int B, int f, int N, int pool, const float* y, 
   IGCN_REQUIRE(B > 0 && f > 0 && N > 0 && pool >= 0 && pool < N, "nodes_ln_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   if (ln_vec_ok(N, pool, y, gamma, beta, dz, dy, keep)) {
-    hipLaunchKernelGGL(k_nodes_ln_bwd_dy_v, dim3(B * f), dim3(GO_T), 0, st, f, N, pool, y, gamma, beta, keep, mean,
+    hipLaunchKernelGGL(k_nodes_ln_bwd_dy_v, dim3(B * f), dim3(ln_threads(N)), 0, st, f, N, pool, y, gamma, beta, keep, mean,
                        rstd, dz, dy);
   } else {
     hipLaunchKernelGGL(k_nodes_ln_bwd_dy, dim3(B * f), dim3(GO_T), 0, st, f, N, pool, y, gamma, beta, keep, mean, rstd,

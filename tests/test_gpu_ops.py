@@ -334,7 +334,11 @@ def test_go_attention_layer(ops, bsz, pool, fin, seed):
 
 
 @pytest.mark.parametrize("bsz,f,n,pool,with_keep", [(3, 5, 40, 20, False), (8, 5, 3000, 1800, True),
-                                                     (4, 2, 257, 0, True), (2, 5, 1200, 800, False)])
+                                                     (4, 2, 257, 0, True), (2, 5, 1200, 800, False),
+                                                     # rows beyond 4096 nodes: the 1024-thread form of the 16-byte
+                                                     # kernels (configs[4]: 10 000 GO nodes), and beyond 16384: scalar
+                                                     (2, 5, 10000, 6000, True), (2, 2, 4100, 0, False),
+                                                     (1, 2, 16400, 400, False)])
 def test_nodes_layernorm(ops, bsz, f, n, pool, with_keep):
     rng = np.random.default_rng(n)
     y = torch.from_numpy(rng.standard_normal((bsz, f, n)) * 2 + 0.3).float()
