@@ -65,15 +65,238 @@ k_spmm_fwd_wave(int B, int C, int I, int J, int64_t nnz, const int32_t* __restri
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The structure of a map is the SAME for every sample, and small (8 k non-zeros): the kernels below read it once per
+// workgroup and reuse it across a tile of samples whose operand rows sit in LDS.  The first versions (above / below:
+// kept as the fallback for structures that do not fit) re-read pointers, indices and values for every (sample, row)
+// — 130 us per step for the two maps of the model, which is why the model used to scatter the values into a dense
+// image and run six dense GEMMs (114 us) instead.  Three shapes cover the six products of the two maps:
+//   rows_tiled : SHORT lists (a GO node's SNPs; a node's readers), operand rows of <= 1024 floats: thread = output
+//                row, SPMM_SB samples per workgroup, their operand rows in LDS
+//   long_lds   : LONG lists (a SNP's ~150 GO nodes): workgroup = sample, its operand vector (C x L floats) in LDS,
+//                wave per output, lanes stride the list
+//   dval_lds   : value gradients: workgroup = SPMM_DB samples, their long vectors and short rows in LDS, thread per
+//                non-zero; one partial row per workgroup, summed by the (deferrable) final reduction
+// Summation order per output is that of the first versions (list order / lanes stride + fixed tree).
+// -------------------------------------------------------------------------------------------------
+#define SPMM_SB 8
+// sum_c == 0: out[b, c, i] = sum_{p in list i} val[c, vk?] * x[b, idx[p]]                      (x rows [J])
+// sum_c == 1: out[b, i]    = sum_{p in list i} sum_c val[c, vk?] * x[b, c, idx[p]]              (x rows [C][J])
+// (vk?: val index vk[p] when a transposed list is walked, p otherwise); row length (sum_c ? C : 1) * J <= 1024 floats
+__global__ void __launch_bounds__(GO_T)
+k_spmm_rows_tiled(int B, int C, int I, int J, int64_t nnz, int sum_c, const int32_t* __restrict__ ptr_,
+                  const int32_t* __restrict__ idx, const int32_t* __restrict__ vk, const float* __restrict__ val,
+                  const float* __restrict__ x, float* __restrict__ y) {
+  extern __shared__ float sp_lds[];                    // [SPMM_SB][RL]
+  const int RL = sum_c ? C * J : J;
+  const int b0 = blockIdx.y * SPMM_SB, nb = min(SPMM_SB, B - b0);
+  for (int t = threadIdx.x; t < nb * RL; t += GO_T) sp_lds[t] = x[(int64_t)b0 * RL + t];
+  for (int t = nb * RL + threadIdx.x; t < SPMM_SB * RL; t += GO_T) sp_lds[t] = 0.f;
+  __syncthreads();
+  const int i = blockIdx.x * GO_T + threadIdx.x, lane = threadIdx.x & 63;
+  const bool live = i < I;
+  const int32_t p0 = live ? ptr_[i] : 0, p1 = live ? ptr_[i + 1] : 0;      // empty range past the end
+  const bool heavy = p1 - p0 > SPMM_HEAVY;
+  const int nc_out = sum_c ? 1 : C, nc_in = sum_c ? C : 1;
+  for (int co = 0; co < nc_out; ++co) {
+    float acc[SPMM_SB];
+#pragma unroll
+    for (int s = 0; s < SPMM_SB; ++s) acc[s] = 0.f;
+    if (!heavy)
+      for (int32_t p = p0; p < p1; ++p) {
+        const int32_t k = vk ? vk[p] : p, r = idx[p];
+        for (int ci = 0; ci < nc_in; ++ci) {
+          const float v = val[(int64_t)(co + ci) * nnz + k];
+          const float* xr = sp_lds + ci * J + r;
+#pragma unroll
+          for (int s = 0; s < SPMM_SB; ++s) acc[s] += v * xr[s * RL];
+        }
+      }
+    unsigned long long hm = __ballot(heavy);
+    while (hm) {                                       // hub lists (the GO root): the whole wave strides the list
+      const int src = __ffsll((long long)hm) - 1;
+      hm &= hm - 1;
+      const int32_t h0 = __shfl(p0, src, 64), h1 = __shfl(p1, src, 64);
+      float part[SPMM_SB];
+#pragma unroll
+      for (int s = 0; s < SPMM_SB; ++s) part[s] = 0.f;
+      for (int32_t p = h0 + lane; p < h1; p += 64) {
+        const int32_t k = vk ? vk[p] : p, r = idx[p];
+        for (int ci = 0; ci < nc_in; ++ci) {
+          const float v = val[(int64_t)(co + ci) * nnz + k];
+          const float* xr = sp_lds + ci * J + r;
+#pragma unroll
+          for (int s = 0; s < SPMM_SB; ++s) part[s] += v * xr[s * RL];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < SPMM_SB; ++s) {
+        part[s] = wave_sum_all(part[s]);
+        if (lane == src) acc[s] = part[s];
+      }
+    }
+    if (live)
+#pragma unroll
+      for (int s = 0; s < SPMM_SB; ++s)
+        if (s < nb) y[((int64_t)(b0 + s) * nc_out + co) * I + i] = acc[s];
+  }
+}
+
+// sum_c == 0: out[b, c, j] = sum_{q in list j} val[c, vk?] * vec[b, idx[q]]                  (vec [B][L])
+// sum_c == 1: out[b, j]    = sum_{q in list j} sum_c val[c, vk?] * vec[b, c, idx[q]]          (vec [B][C][L])
+// A wave owns every 8th list and walks SPMM_RM of them AT ONCE: pointers of all, then the first SPMM_LU stride-64
+// entries of all (indices, then values, then the LDS gathers), then the wave sums.  [A list costs ~2-3.5 us of
+// dependent latency — pointer, index, value, gather, six-step tree — whatever is in flight inside it (phase probe:
+// tools/spmm_probe.py); one after the other, a wave's seven lists were the whole 12 / 24 us of the kernel.
+// Entry-parallel products parked in LDS + a second phase of list sums: 88 KB of LDS, one workgroup per CU, 31 us.]
+#ifdef SPMM_PROBE_ON
+__device__ long long spmm_probe_buf[2 * 8 * 8];
+#define SPMM_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x < 8) spmm_probe_buf[(sum_c * 8 + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+extern "C" int igcn_debug_spmm_probe(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(spmm_probe_buf), sizeof(long long) * 128);
+}
+#else
+#define SPMM_PROBE(i)
+#endif
+#define SPMM_LT 512
+#define SPMM_LU 3
+#define SPMM_RM 7
+__global__ void __launch_bounds__(SPMM_LT, 4)
+k_spmm_long_lds(int C, int L, int n_out, int64_t nnz, int sum_c, const int32_t* __restrict__ ptr_,
+                const int32_t* __restrict__ idx, const int32_t* __restrict__ vk, const float* __restrict__ val,
+                const float* __restrict__ vec, float* __restrict__ out) {
+  extern __shared__ float sp_lds[];                    // [sum_c ? C : 1][L]
+  const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nv = sum_c ? C * L : L;
+  const float* vb = vec + (int64_t)b * nv;
+  SPMM_PROBE(0);
+  if (nv % 4 == 0 && ((uintptr_t)vb & 15) == 0) {
+    for (int t = threadIdx.x * 4; t < nv; t += SPMM_LT * 4)
+      *reinterpret_cast<float4*>(sp_lds + t) = *reinterpret_cast<const float4*>(vb + t);
+  } else {
+    for (int t = threadIdx.x; t < nv; t += SPMM_LT) sp_lds[t] = vb[t];
+  }
+  __syncthreads();
+  SPMM_PROBE(1);
+  const int nc_out = sum_c ? 1 : C, nc_in = sum_c ? C : 1;
+  constexpr int NWV = SPMM_LT / 64;
+  for (int jb = w; jb < n_out; jb += NWV * SPMM_RM) {
+    // SPMM_RM lists per wave AT ONCE: their pointers, then the first SPMM_LU stride-64 entries of every list, then the
+    // values, then the LDS gathers — the dependent round trips of a list overlap with those of its siblings
+    int32_t q0[SPMM_RM], q1[SPMM_RM];
+#pragma unroll
+    for (int m = 0; m < SPMM_RM; ++m) {
+      const int j = jb + m * NWV;
+      q0[m] = j < n_out ? ptr_[j] : 0;
+      q1[m] = j < n_out ? ptr_[j + 1] : 0;
+    }
+    for (int co = 0; co < nc_out; ++co) {
+      float acc[SPMM_RM];
+      int32_t r[SPMM_RM][SPMM_LU], k[SPMM_RM][SPMM_LU];
+#pragma unroll
+      for (int m = 0; m < SPMM_RM; ++m) {
+        acc[m] = 0.f;
+#pragma unroll
+        for (int u = 0; u < SPMM_LU; ++u) {
+          const int32_t qq = q0[m] + lane + 64 * u;
+          const bool ok = qq < q1[m];
+          r[m][u] = ok ? idx[qq] : -1;
+          k[m][u] = ok ? (vk ? vk[qq] : qq) : 0;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < SPMM_RM; ++m) {
+#pragma unroll
+        for (int u = 0; u < SPMM_LU; ++u)
+          for (int ci = 0; ci < nc_in; ++ci) {
+            const float v = r[m][u] >= 0 ? val[(int64_t)(co + ci) * nnz + k[m][u]] : 0.f;
+            acc[m] += v * sp_lds[ci * L + (r[m][u] >= 0 ? r[m][u] : 0)];
+          }
+        for (int32_t q = q0[m] + lane + 64 * SPMM_LU; q < q1[m]; q += 64)       // lists beyond 64 SPMM_LU entries
+          for (int ci = 0; ci < nc_in; ++ci)
+            acc[m] += val[(int64_t)(co + ci) * nnz + (vk ? vk[q] : q)] * sp_lds[ci * L + idx[q]];
+      }
+#pragma unroll
+      for (int m = 0; m < SPMM_RM; ++m) {
+        const int j = jb + m * NWV;
+        const float t = wave_sum(acc[m]);
+        if (lane == 0 && j < n_out) out[((int64_t)b * nc_out + co) * n_out + j] = t;
+      }
+    }
+    if (jb == w) SPMM_PROBE(2);
+  }
+  SPMM_PROBE(3);
+}
+static size_t spmm_long_lds_bytes(int C, int L, int64_t nnz, int sum_c) {
+  (void)nnz;
+  return (size_t)(sum_c ? C * L : L) * sizeof(float);
+}
+
+// partial[wg][c][k] = sum_{b in tile} big[b, c, bidx[k]] * small[b, sidx[k]]     (big [B][C][L], small [B][S])
+#define SPMM_DT 1024
+__global__ void __launch_bounds__(SPMM_DT)
+k_spmm_dval_lds(int B, int C, int L, int S, int64_t nnz, int tile, const int32_t* __restrict__ bidx,
+                const int32_t* __restrict__ sidx, const float* __restrict__ big, const float* __restrict__ small_,
+                float* __restrict__ partial) {
+  extern __shared__ float sp_lds[];                    // [tile][C*L] then [tile][S]
+  const int b0 = blockIdx.x * tile, nb = min(tile, B - b0), CL = C * L;
+  float* bs = sp_lds;
+  float* ss = sp_lds + (size_t)tile * CL;
+  const float* bsrc = big + (int64_t)b0 * CL;
+  if (CL % 4 == 0 && ((uintptr_t)bsrc & 15) == 0) {
+    for (int t = threadIdx.x * 4; t < nb * CL; t += SPMM_DT * 4)
+      *reinterpret_cast<float4*>(bs + t) = *reinterpret_cast<const float4*>(bsrc + t);
+  } else {
+    for (int t = threadIdx.x; t < nb * CL; t += SPMM_DT) bs[t] = bsrc[t];
+  }
+  for (int t = threadIdx.x; t < nb * S; t += SPMM_DT) ss[t] = small_[(int64_t)b0 * S + t];
+  __syncthreads();
+  float* prow = partial + (int64_t)blockIdx.x * C * nnz;
+  for (int64_t k = threadIdx.x; k < nnz; k += SPMM_DT) {
+    const int32_t r = bidx[k], j = sidx[k];
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.f;
+      for (int s = 0; s < nb; ++s) acc += bs[s * CL + c * L + r] * ss[s * S + j];
+      prow[(int64_t)c * nnz + k] = acc;
+    }
+  }
+}
+
+// samples per workgroup of k_spmm_dval_lds: what ~120 KB of LDS hold, at most 4 (0: the vectors do not fit)
+static int spmm_dval_tile(int C, int L, int S) {
+  const size_t per = ((size_t)C * L + S) * sizeof(float);
+  const int t = (int)((size_t)120 * 1024 / per);
+  return t > 4 ? 4 : t;
+}
+static bool spmm_no_lds(void) {                        // IGCN_SPMM_NO_LDS=1: the first versions (A/B runs)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("IGCN_SPMM_NO_LDS");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 extern "C" int igcn_spmm_fwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
                              const float* val, const float* x, float* y, void* stream) {
   IGCN_REQUIRE(B > 0 && C > 0 && I > 0 && J > 0, "spmm_fwd: bad sizes");
-  if (nnz > (int64_t)8 * I) {
-    hipLaunchKernelGGL(k_spmm_fwd_wave, dim3((unsigned)igcn_cdiv((int64_t)B * I, GO_T / 64)), dim3(GO_T), 0,
-                       (hipStream_t)stream, B, C, I, J, nnz, row_ptr, col, val, x, y);
+  hipStream_t st = (hipStream_t)stream;
+  const bool longrows = nnz > (int64_t)8 * I;
+  if (!spmm_no_lds() && longrows && spmm_long_lds_bytes(C, J, nnz, 0) <= 150 * 1024) {
+    const size_t lds = spmm_long_lds_bytes(C, J, nnz, 0);
+    if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS(k_spmm_long_lds);
+    hipLaunchKernelGGL(k_spmm_long_lds, dim3(B), dim3(SPMM_LT), lds, st, C, J, I, nnz, 0, row_ptr, col,
+                       (const int32_t*)nullptr, val, x, y);
+  } else if (!spmm_no_lds() && !longrows && J <= 1024) {
+    hipLaunchKernelGGL(k_spmm_rows_tiled, dim3((unsigned)igcn_cdiv(I, GO_T), (unsigned)igcn_cdiv(B, SPMM_SB)),
+                       dim3(GO_T), (size_t)SPMM_SB * J * sizeof(float), st, B, C, I, J, nnz, 0, row_ptr, col,
+                       (const int32_t*)nullptr, val, x, y);
+  } else if (longrows) {
+    hipLaunchKernelGGL(k_spmm_fwd_wave, dim3((unsigned)igcn_cdiv((int64_t)B * I, GO_T / 64)), dim3(GO_T), 0, st, B, C,
+                       I, J, nnz, row_ptr, col, val, x, y);
   } else {
-    hipLaunchKernelGGL(k_spmm_fwd, dim3((unsigned)igcn_cdiv(I, GO_T), B), dim3(GO_T), 0, (hipStream_t)stream, C, I, J,
-                       nnz, row_ptr, col, val, x, y);
+    hipLaunchKernelGGL(k_spmm_fwd, dim3((unsigned)igcn_cdiv(I, GO_T), B), dim3(GO_T), 0, st, C, I, J, nnz, row_ptr, col,
+                       val, x, y);
   }
   IGCN_CHECK_LAUNCH("spmm_fwd");
   return IGCN_OK;
@@ -144,6 +367,15 @@ __global__ void k_spmm_bwd_dval(int B, int C, int I, int J, int64_t nnz, const i
   partial[((int64_t)blockIdx.z * C + c) * nnz + k] = acc;
 }
 
+// scratch of igcn_spmm_bwd (value gradients): one partial row [C][nnz] per workgroup of the tiled kernel, or the
+// SPMM_BCH sample chunks of the fallback
+extern "C" size_t igcn_spmm_bwd_scratch_floats(int B, int C, int I, int J, int64_t nnz) {
+  const int L = I > J ? I : J, S = I > J ? J : I;
+  const int tile = spmm_dval_tile(C, L, S);
+  const int64_t rows = (tile >= 1 && !spmm_no_lds()) ? igcn_cdiv(B, tile) : SPMM_BCH;
+  return (size_t)((rows > SPMM_BCH ? rows : SPMM_BCH) * C * (nnz > 0 ? nnz : 1));
+}
+
 extern "C" int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
                              const int32_t* row_of, const int32_t* t_ptr, const int32_t* t_row, const int32_t* t_k,
                              const float* val, const float* x, const float* dy, float* dx, float* dval,
@@ -152,7 +384,18 @@ extern "C" int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int3
   IGCN_REQUIRE(B > 0 && C > 0 && I > 0 && J > 0, "spmm_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
-    if (nnz > (int64_t)8 * J) {
+    // dx[b, j] = sum over column j's entries q, over channels c: val[c, t_k[q]] * dy[b, c, t_row[q]]
+    const bool longcols = nnz > (int64_t)8 * J;
+    const size_t vec_bytes = spmm_long_lds_bytes(C, I, nnz, 1);
+    if (!spmm_no_lds() && longcols && vec_bytes <= 150 * 1024) {
+      if (vec_bytes > 64 * 1024) IGCN_ALLOW_BIG_LDS(k_spmm_long_lds);
+      hipLaunchKernelGGL(k_spmm_long_lds, dim3(B), dim3(SPMM_LT), vec_bytes, st, C, I, J, nnz, 1, t_ptr, t_row, t_k,
+                         val, dy, dx);
+    } else if (!spmm_no_lds() && !longcols && (int64_t)C * I <= 1024) {
+      hipLaunchKernelGGL(k_spmm_rows_tiled, dim3((unsigned)igcn_cdiv(J, GO_T), (unsigned)igcn_cdiv(B, SPMM_SB)),
+                         dim3(GO_T), (size_t)SPMM_SB * C * I * sizeof(float), st, B, C, J, I, nnz, 1, t_ptr, t_row, t_k,
+                         val, dy, dx);
+    } else if (longcols) {
       hipLaunchKernelGGL(k_spmm_bwd_dx_wave, dim3((unsigned)igcn_cdiv((int64_t)B * J, GO_T / 64)), dim3(GO_T), 0, st,
                          B, C, I, J, nnz, t_ptr, t_row, t_k, val, dy, dx);
     } else {
@@ -162,12 +405,27 @@ extern "C" int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int3
   }
   IGCN_CHECK_LAUNCH("spmm_bwd_dx");
   if (dval && nnz > 0) {
-    IGCN_REQUIRE(scratch != nullptr, "spmm_bwd: dval needs scratch float[%d*C*nnz]", SPMM_BCH);
+    IGCN_REQUIRE(scratch != nullptr, "spmm_bwd: dval needs scratch (igcn_spmm_bwd_scratch_floats)");
+    // dval[c, k] = sum_b dy[b, c, row_of[k]] * x[b, col[k]]: the LONG side of the map (per-sample vector with a channel
+    // axis only if it is dy) goes to LDS per sample, the short side rides along
+    const bool rows_long = I >= J;
+    const int L = rows_long ? I : J, S = rows_long ? J : I;
+    const int tile = (rows_long || C == 1) ? spmm_dval_tile(C, L, S) : 0;     // x has no channel axis
+    if (!spmm_no_lds() && tile >= 1) {
+      const int64_t wgs = igcn_cdiv(B, tile);
+      const size_t lds = (size_t)tile * ((size_t)C * L + S) * sizeof(float);
+      if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS(k_spmm_dval_lds);
+      hipLaunchKernelGGL(k_spmm_dval_lds, dim3((unsigned)wgs), dim3(SPMM_DT), lds, st, B, C, L, S, nnz, tile,
+                         rows_long ? row_of : col, rows_long ? col : row_of, rows_long ? dy : x, rows_long ? x : dy,
+                         scratch);
+      IGCN_CHECK_LAUNCH("spmm_bwd_dval(lds)");
+      return igcn_launch_reduce_rows_final(scratch, wgs, (int64_t)C * nnz, (int)((int64_t)C * nnz), dval, st);
+    }
     const int bch = B < SPMM_BCH ? B : SPMM_BCH;
     hipLaunchKernelGGL(k_spmm_bwd_dval, dim3((unsigned)igcn_cdiv(nnz, GO_T), C, bch), dim3(GO_T), 0, st, B, C, I, J,
                        nnz, col, row_of, x, dy, scratch);
     IGCN_CHECK_LAUNCH("spmm_bwd_dval");
-    return igcn_launch_reduce_rows(scratch, bch, (int64_t)C * nnz, (int)((int64_t)C * nnz), dval, 0, st);
+    return igcn_launch_reduce_rows_final(scratch, bch, (int64_t)C * nnz, (int)((int64_t)C * nnz), dval, st);
   }
   return IGCN_OK;
 }

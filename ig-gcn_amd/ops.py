@@ -5,6 +5,7 @@ Index structures (``GraphPlan`` for a batch of brain graphs, ``Csr``/``CsrPair``
 are plain int32 device tensors owned by Python.
 """
 import ctypes
+import os
 
 import torch
 
@@ -840,19 +841,34 @@ class Csr:
 class SparseMap(torch.autograd.Function):
     """y[b,c,i] = sum_k val[c,k] x[b,col_k]  (gene encode go_model.py:208-215 / decode :281-282).
 
-    The maps are small (N_go x 54 with ~5 % non-zeros), the batch is not: the learnable values are scattered into
-    a dense image and all three products run on the matrix cores (igcn_gemm_f32) — y = x T^T, dx = dy T,
-    dT = dy^T x with the value gradients gathered back from dT.  Adding the structural zeros changes the fp32
-    summation order only.  Maps whose dense image would exceed DENSE_LIMIT floats use the CSR kernels (igcn_spmm_*)."""
+    Two formulations.  (a) The CSR kernels igcn_spmm_*: the structure is shared by all samples, so a workgroup reads it
+    once and reuses it across a tile of samples whose operand rows sit in LDS — the default from SPARSE_MIN_BATCH samples
+    (both passes of a 256-graph step: 512) up, where every launch fills the chip.  (b) For small batches (configs[4]:
+    2 x 32 samples, 10 000 nodes) the values are scattered into a dense image and all three products run on the matrix
+    cores (igcn_gemm_f32) — y = x T^T, dx = dy T, dT = dy^T x with the value gradients gathered back from dT; adding the
+    structural zeros changes the fp32 summation order only.  IGCN_DENSE_MAPS=1 / IGCN_SPARSE_MAPS=1 force one of them;
+    maps whose dense image would exceed DENSE_LIMIT floats always use (a)."""
 
     DENSE_LIMIT = 1 << 24
+    SPARSE_MIN_BATCH = 256
+
+    @staticmethod
+    def _use_dense(b, c, csr):
+        if c * csr.n_rows * csr.n_cols > SparseMap.DENSE_LIMIT or csr.nnz == 0:
+            return False
+        if os.environ.get("IGCN_DENSE_MAPS") == "1":
+            return True
+        if os.environ.get("IGCN_SPARSE_MAPS") == "1":
+            return False
+        return b < SparseMap.SPARSE_MIN_BATCH
 
     @staticmethod
     def forward(ctx, x, val, csr):
         x, val = _f32(x), _f32(val)
         b, c = x.shape[0], val.shape[0]
         ctx.csr = csr
-        ctx.dense = c * csr.n_rows * csr.n_cols <= SparseMap.DENSE_LIMIT and csr.nnz > 0
+        ctx.final = _leaves(val)
+        ctx.dense = SparseMap._use_dense(b, c, csr)
         if ctx.dense:
             t = csr.dense(c)
             t.index_copy_(1, csr.flat_pos, val)
@@ -881,11 +897,12 @@ class SparseMap(torch.autograd.Function):
             return dx, dval, None
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dval = torch.empty_like(val) if ctx.needs_input_grad[1] else None
-        scratch = torch.empty(16 * c * max(csr.nnz, 1), dtype=torch.float32, device=x.device) \
-            if dval is not None else None
-        call("igcn_spmm_bwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
-             ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(x), ptr(dy), ptr(dx),
-             ptr(dval), ptr(scratch), stream_ptr())
+        scratch = _keep(torch.empty(int(_lib.load().igcn_spmm_bwd_scratch_floats(b, c, csr.n_rows, csr.n_cols, csr.nnz)),
+                                    dtype=torch.float32, device=x.device)) if dval is not None else None
+        with _immediate(ctx.final):
+            call("igcn_spmm_bwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
+                 ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(x), ptr(dy), ptr(dx),
+                 ptr(dval), ptr(scratch), stream_ptr())
         return dx, dval, None
 
 

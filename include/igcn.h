@@ -406,14 +406,20 @@ int igcn_xattn_bwd(int B, int D, int H, int Lq, int Lk, const float* xq, const f
  *   y[b,c,i] = sum_{k in row i} val[c,k] * x[b, col[k]]          x [B,J], y [B,C,I], val [C,nnz]
  * Backward needs the transposed structure: t_ptr [J+1], t_row [nnz] (row of each entry in column order),
  * t_k [nnz] (its position in the row-major value array).
+ * The structure is shared by all samples and small: the kernels read it once per workgroup and reuse it across a tile
+ * of samples whose operand rows sit in LDS (short lists: thread per output row; ~150-entry lists: workgroup per sample
+ * with its vector in LDS, wave per output; value gradients: a few samples' vectors in LDS, thread per non-zero).
+ * dval is a parameter gradient: its final sum over the workgroups' partial rows takes part in the deferred
+ * reductions (igcn_reduce_defer).  scratch: igcn_spmm_bwd_scratch_floats(...) floats.
  */
 int igcn_spmm_fwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
                   const float* val, const float* x, float* y, void* stream);
+size_t igcn_spmm_bwd_scratch_floats(int B, int C, int I, int J, int64_t nnz);
 int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
                   const int32_t* row_of /*[nnz]*/, const int32_t* t_ptr, const int32_t* t_row, const int32_t* t_k,
                   const float* val, const float* x, const float* dy,
                   float* dx /*[B,J] or NULL*/, float* dval /*[C,nnz] or NULL*/,
-                  float* scratch /* float[16*C*nnz], needed when dval != NULL */, void* stream);
+                  float* scratch /* needed when dval != NULL */, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GO attention-GCN encoder layer, all samples at once — replaces the dense transforms, the edge gathers

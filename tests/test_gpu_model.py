@@ -67,9 +67,14 @@ def _go_model(store):
     return net
 
 
+@pytest.mark.parametrize("maps", ["default", "csr"])
 @pytest.mark.parametrize("name", ["go_tiny", "go_small", "go_b32"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_go_network_vs_reference_golden(golden, name, mode):
+def test_go_network_vs_reference_golden(golden, monkeypatch, name, mode, maps):
+    """``maps``: the SNP <-> GO maps as the batch size selects them (these fixtures: dense image + GEMMs) and forced
+    onto the LDS-tiled CSR kernels a 256-graph step runs on (IGCN_SPARSE_MAPS=1)."""
+    if maps == "csr":
+        monkeypatch.setenv("IGCN_SPARSE_MAPS", "1")
     store = golden(name)
     net = _go_model(store)
     net.train(mode == "train")

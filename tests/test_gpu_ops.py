@@ -394,16 +394,20 @@ def test_go_decoder_layer(ops, bsz, pool, layer, seed):
     assert_matches(g[2], g_ref[2].numpy(), TOL, "dW_sout")
 
 
-@pytest.mark.parametrize("dense", [True, False])
-@pytest.mark.parametrize("bsz,pool,seed", [(4, (20, 10, 6, 3, 1), 0), (32, (300, 120, 60, 19, 1), 1)])
+@pytest.mark.parametrize("dense", [False, True])
+@pytest.mark.parametrize("bsz,pool,seed", [(4, (20, 10, 6, 3, 1), 0), (32, (300, 120, 60, 19, 1), 1),
+                                           (37, (1800, 800, 300, 99, 1), 2)])
 def test_sparse_map_encode_decode(ops, monkeypatch, bsz, pool, seed, dense):
-    """Both formulations of the learnable sparse maps: dense image + MFMA GEMMs (default) and the CSR kernels."""
-    if not dense:
-        monkeypatch.setattr(ops.SparseMap, "DENSE_LIMIT", 0)
+    """The learnable sparse SNP <-> GO maps in both orientations — encode (C = 2, rows = GO nodes with a few SNPs each,
+    plus the root's 54) and decode (C = 1, rows = SNPs with ~5 % of the nodes each) — on the LDS-tiled CSR kernels
+    (default) and as dense image + MFMA GEMMs (IGCN_DENSE_MAPS): outputs and both gradients against fp64.  Batch
+    sizes off the sample-tile sizes (8 / 4) exercise the partial tiles."""
+    monkeypatch.setattr(ops.SparseMap, "DENSE_LIMIT", (1 << 24) if dense else 0)
     a_g, _, _, idx = _hier(pool, seed)
     n = idx["n"]
     gn, gs = idx["gene"]
     rng = np.random.default_rng(seed)
+    # ---- encode: y[b, c, node] = sum over the node's SNPs
     snps = torch.from_numpy(rng.random((bsz, 54))).float()
     val = torch.from_numpy(1 + 0.1 * rng.standard_normal((2, gn.numel()))).float()
     cot = torch.from_numpy(rng.standard_normal((bsz, 2, n))).float()
@@ -418,6 +422,22 @@ def test_sparse_map_encode_decode(ops, monkeypatch, bsz, pool, seed, dense):
     assert_matches(y, y_ref.detach().numpy(), TOL, "y")
     assert_matches(g[0], g_ref[0].numpy(), TOL, "dsnps")
     assert_matches(g[1], g_ref[1].numpy(), TOL, "dval")
+    # ---- decode: y[b, 0, snp] = sum over the SNP's GO nodes (the transposed structure, row-major again)
+    order = torch.argsort(gs * n + gn)
+    rs, cn = gs[order], gn[order]
+    xg = torch.from_numpy(rng.standard_normal((bsz, n))).float()
+    vald = torch.from_numpy(1 + 0.1 * rng.standard_normal((1, rs.numel()))).float()
+    cotd = torch.from_numpy(rng.standard_normal((bsz, 1, 54))).float()
+    ref_in = [xg.double().requires_grad_(True), vald.double().requires_grad_(True)]
+    yd_ref = torch.zeros(bsz, 54, dtype=torch.float64).index_add(1, rs, ref_in[0][:, cn] * ref_in[1][0]).unsqueeze(1)
+    gd_ref = torch.autograd.grad((yd_ref * cotd.double()).sum(), ref_in)
+    csrd = ops.Csr(rs, cn, 54, n, "cuda")
+    dev = [xg.cuda().requires_grad_(True), vald.cuda().requires_grad_(True)]
+    yd = ops.SparseMap.apply(dev[0], dev[1], csrd)
+    gd = torch.autograd.grad((yd * cotd.cuda()).sum(), dev)
+    assert_matches(yd, yd_ref.detach().numpy(), TOL, "decode y")
+    assert_matches(gd[0], gd_ref[0].numpy(), TOL, "decode dx")
+    assert_matches(gd[1], gd_ref[1].numpy(), TOL, "decode dval")
 
 
 def test_adam_matches_torch(ops):
