@@ -136,7 +136,7 @@ class Gene_ontology_network(nn.Module):
         masks, self.extra_masks = self._dropout_masks(bsz, dev, extra_dropout)
         keeps = masks["ln"]
         # gene encoding (:208-215)
-        x = ops.SparseMap.apply(data, torch.stack(list(self.t)), self.gene_csr)          # [B, in_f, N]
+        x = ops.SparseMap.apply(data, self.gene_csr, *self.t)                            # [B, in_f, N]
         # encoder (:219-251)
         for j in range(self.n_l):
             csr = self.enc_csr[j]
@@ -155,7 +155,7 @@ class Gene_ontology_network(nn.Module):
                                          self.G_B_D[j].eps)
         # gene decoding (:278-282)
         out_d = self._node_linear_bn(x, self.conc_D.weight, self.B_D[0], groups, masks["out_d"]).squeeze(2)   # [B,N]
-        x_d = ops.SparseMap.apply(out_d, self.t_D[0].unsqueeze(0), self.gene_t_csr).squeeze(1)   # [B, 54]
+        x_d = ops.SparseMap.apply(out_d, self.gene_t_csr, self.t_D[0]).squeeze(1)               # [B, 54]
         # latent projection (:138-146,285)
         h = self._bn_relu(ops.linear(inp_out.view(bsz, -1), self.latent[0].weight), self.latent[1], groups, masks["h"])
         latent = self._bn_relu(ops.linear(h, self.latent[4].weight), self.latent[5], groups)

@@ -863,11 +863,20 @@ class SparseMap(torch.autograd.Function):
         return b < SparseMap.SPARSE_MIN_BATCH
 
     @staticmethod
-    def forward(ctx, x, val, csr):
-        x, val = _f32(x), _f32(val)
+    def forward(ctx, x, csr, *vals):
+        """``vals``: the C per-channel value vectors [nnz] (the model's ParameterList entries, taken as they are: they
+        stay autograd leaves of this op, so the value-gradient sums are final and deferrable) or ONE tensor [C, nnz]."""
+        x = _f32(x)
+        stacked = len(vals) == 1 and vals[0].dim() == 2
+        if stacked:
+            val = _f32(vals[0])
+        elif len(vals) == 1:
+            val = _f32(vals[0]).reshape(1, -1)                   # one channel: a view, no launch
+        else:
+            val = torch.stack([_f32(v).reshape(-1) for v in vals])
         b, c = x.shape[0], val.shape[0]
-        ctx.csr = csr
-        ctx.final = _leaves(val)
+        ctx.csr, ctx.stacked, ctx.nvals = csr, stacked, len(vals)
+        ctx.final = _leaves(*vals)
         ctx.dense = SparseMap._use_dense(b, c, csr)
         if ctx.dense:
             t = csr.dense(c)
@@ -887,23 +896,31 @@ class SparseMap(torch.autograd.Function):
         csr = ctx.csr
         dy = _f32(dy)
         b, c = x.shape[0], val.shape[0]
+        need_val = any(ctx.needs_input_grad[2:])
         if ctx.dense:
             dy2 = dy.view(b, c * csr.n_rows)
             t = csr.dense(c)                     # still holds the values of the forward (same parameters)
             dx = gemm_nn(dy2, t.view(c * csr.n_rows, csr.n_cols)) if ctx.needs_input_grad[0] else None
             dval = None
-            if ctx.needs_input_grad[1]:
+            if need_val:
                 dval = gemm_tn(dy2, x).view(c, csr.n_rows * csr.n_cols).index_select(1, csr.flat_pos)
-            return dx, dval, None
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dval = torch.empty_like(val) if ctx.needs_input_grad[1] else None
-        scratch = _keep(torch.empty(int(_lib.load().igcn_spmm_bwd_scratch_floats(b, c, csr.n_rows, csr.n_cols, csr.nnz)),
-                                    dtype=torch.float32, device=x.device)) if dval is not None else None
-        with _immediate(ctx.final):
-            call("igcn_spmm_bwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
-                 ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(x), ptr(dy), ptr(dx),
-                 ptr(dval), ptr(scratch), stream_ptr())
-        return dx, dval, None
+        else:
+            dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            dval = torch.empty_like(val) if need_val else None
+            scratch = _keep(torch.empty(int(_lib.load().igcn_spmm_bwd_scratch_floats(b, c, csr.n_rows, csr.n_cols,
+                                                                                      csr.nnz)),
+                                        dtype=torch.float32, device=x.device)) if dval is not None else None
+            with _immediate(ctx.final):
+                call("igcn_spmm_bwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
+                     ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(x), ptr(dy), ptr(dx),
+                     ptr(dval), ptr(scratch), stream_ptr())
+        if dval is None:
+            grads = (None,) * ctx.nvals
+        elif ctx.stacked:
+            grads = (dval,)
+        else:
+            grads = tuple(dval[i] for i in range(ctx.nvals))         # rows of one buffer: no copies
+        return (dx, None) + grads
 
 
 class GoAttention(torch.autograd.Function):

@@ -417,7 +417,7 @@ def test_sparse_map_encode_decode(ops, monkeypatch, bsz, pool, seed, dense):
     g_ref = torch.autograd.grad((y_ref * cot.double()).sum(), ref_in)
     csr = ops.Csr(gn, gs, n, 54, "cuda")
     dev = [snps.cuda().requires_grad_(True), val.cuda().requires_grad_(True)]
-    y = ops.SparseMap.apply(dev[0], dev[1], csr)
+    y = ops.SparseMap.apply(dev[0], csr, dev[1])
     g = torch.autograd.grad((y * cot.cuda()).sum(), dev)
     assert_matches(y, y_ref.detach().numpy(), TOL, "y")
     assert_matches(g[0], g_ref[0].numpy(), TOL, "dsnps")
@@ -433,7 +433,7 @@ def test_sparse_map_encode_decode(ops, monkeypatch, bsz, pool, seed, dense):
     gd_ref = torch.autograd.grad((yd_ref * cotd.double()).sum(), ref_in)
     csrd = ops.Csr(rs, cn, 54, n, "cuda")
     dev = [xg.cuda().requires_grad_(True), vald.cuda().requires_grad_(True)]
-    yd = ops.SparseMap.apply(dev[0], dev[1], csrd)
+    yd = ops.SparseMap.apply(dev[0], csrd, dev[1])
     gd = torch.autograd.grad((yd * cotd.cuda()).sum(), dev)
     assert_matches(yd, yd_ref.detach().numpy(), TOL, "decode y")
     assert_matches(gd[0], gd_ref[0].numpy(), TOL, "decode dx")

@@ -21,9 +21,9 @@ val = torch.rand(2, go.gene_csr.nnz, device=dev, requires_grad=True)
 xd = torch.rand(B, go.gene_t_csr.n_cols, device=dev, requires_grad=True)
 vd = torch.rand(1, go.gene_t_csr.nnz, device=dev, requires_grad=True)
 for _ in range(3):
-    y = ops.SparseMap.apply(x, val, go.gene_csr)
+    y = ops.SparseMap.apply(x, go.gene_csr, val)
     torch.autograd.grad(y.sum(), (x, val))
-    yd = ops.SparseMap.apply(xd, vd, go.gene_t_csr)
+    yd = ops.SparseMap.apply(xd, go.gene_t_csr, vd)
     torch.autograd.grad(yd.sum(), (xd, vd))
 torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
