@@ -58,6 +58,7 @@ SIGNATURES = {
     "igcn_node_linear_bn_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_bn1d_fwd": (I, [I, I, I, P, P, P, P, P, I, F, F, I, P, P, P, P, P]),
     "igcn_bn1d_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_dropout_state_words": (I, []),
     "igcn_dropout_masks": (I, [L, I, P, P, P, P, P]),
     "igcn_mask_reg_fwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P]),
     "igcn_mask_reg_bwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P, P, P]),

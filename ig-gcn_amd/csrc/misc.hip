@@ -598,8 +598,8 @@ extern "C" int igcn_graph_pool_bwd(int64_t n_graphs, int nodes_per_graph, int D,
 // library launches per step forward and backward).  out[i] = 0 with probability p(segment of i), else 1/(1-p): the
 // {0, 1/(1-p)} factors the consumers multiply by (igcn_nodes_ln_*, igcn_node_linear_bn_*, igcn_bn1d_*,
 // igcn_small_linear_* take them as `keep`).  Counter-based generator: a 32-bit integer hash of (index, stream counter);
-// `state` = {counter, workgroups done} on the device — the LAST workgroup to finish advances the counter, so every
-// replay of a captured launch draws fresh masks without a host round trip.
+// `state` on the device holds the counter and arrival words — the LAST workgroup to finish advances the counter, so
+// every replay of a captured launch draws fresh masks without a host round trip.
 // =================================================================================================
 #define DM_MAXSEG 16
 struct DropSegs {
@@ -615,12 +615,16 @@ __device__ __forceinline__ uint32_t dm_hash(uint32_t x) {       // lowbias32
   return x;
 }
 
+// `state` (device uint64[IGCN_DROPOUT_STATE_WORDS]): [0] stream counter, [1] groups done, [2 + 32 g] workgroups done of
+// group g (DM_GROUPS groups, their words 256 bytes apart).  "Last one out advances the counter" in two levels: a
+// single word takes ~90 atomics per microsecond, so 6000 one-shot workgroups spent 68 us there and the first remedy —
+// at most 512 grid-striding workgroups — left two waves per SIMD to do the hashing (19 us for 18 MB of factors).
+#define DM_GROUPS 16
+#define DM_WORDS (2 + 32 * DM_GROUPS)
 __global__ void __launch_bounds__(256)
 k_dropout_masks(int64_t total, DropSegs segs, unsigned long long* __restrict__ state, float* __restrict__ out) {
   const unsigned long long c = state[0];
   const uint32_t k0 = dm_hash((uint32_t)c ^ 0x9E3779B9u), k1 = dm_hash((uint32_t)(c >> 32) + 0x85EBCA6Bu + k0);
-  // grid-stride over quads: a few hundred workgroups whatever the size — every workgroup ends with one atomic on the
-  // `done` word, and a single word takes ~90 atomics per microsecond (6000 one-shot workgroups spent 68 us there)
   for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < total; i0 += (int64_t)gridDim.x * 1024) {
     float v[4];
     float p = 0.f;                                     // a quad never straddles sites (sites start on multiples of 4)
@@ -642,13 +646,22 @@ k_dropout_masks(int64_t total, DropSegs segs, unsigned long long* __restrict__ s
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned long long done = atomicAdd(&state[1], 1ull);
-    if (done == (unsigned long long)gridDim.x - 1) {             // every workgroup has read the counter by now
-      state[0] = c + 1;
-      state[1] = 0;
+    // every workgroup has read the counter before it arrives here; group g = blockIdx % DM_GROUPS has
+    // ceil((gridDim - g) / DM_GROUPS) members
+    const unsigned g = blockIdx.x % DM_GROUPS, ng = gridDim.x < DM_GROUPS ? gridDim.x : DM_GROUPS;
+    const unsigned members = (gridDim.x - g + DM_GROUPS - 1) / DM_GROUPS;
+    unsigned long long* gw = state + 2 + 32 * g;
+    if (atomicAdd(gw, 1ull) == (unsigned long long)members - 1) {
+      *gw = 0;
+      if (atomicAdd(&state[1], 1ull) == (unsigned long long)ng - 1) {
+        state[0] = c + 1;
+        state[1] = 0;
+      }
     }
   }
 }
+
+extern "C" int igcn_dropout_state_words(void) { return DM_WORDS; }
 
 extern "C" int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end /*HOST*/,
                                   const float* seg_p /*HOST*/, void* state /*device uint64[2]*/, float* out,
@@ -666,7 +679,7 @@ extern "C" int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* 
   for (int k = 0; k + 1 < n_segments; ++k)
     IGCN_REQUIRE(sg.end[k] % 4 == 0, "dropout_masks: interior segment ends must be multiples of 4");
   int64_t blocks = igcn_cdiv(total, 1024);
-  blocks = blocks > 512 ? 512 : blocks;
+  blocks = blocks > 2048 ? 2048 : blocks;
   hipLaunchKernelGGL(k_dropout_masks, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, total, sg,
                      (unsigned long long*)state, out);
   IGCN_CHECK_LAUNCH("dropout_masks");

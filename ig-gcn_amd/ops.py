@@ -769,7 +769,9 @@ class DropoutState:
 
     def __init__(self, device):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        words = int(_lib.load().igcn_dropout_state_words())
+        self.state = torch.zeros(words, dtype=torch.int64, device=device)
+        self.state[0] = seed
 
 
 def dropout_masks(sites, state):

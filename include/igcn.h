@@ -325,8 +325,10 @@ int igcn_bn1d_bwd(int B, int C, int groups, int training, int relu, const float*
  * nn.Dropout2d / F.dropout, kernel/go_model.py:104,113,128,136,143, kernel/sgcn_img_snp.py:289,299).  out [total]:
  * element i of segment k (segments given by their END offsets, HOST arrays, <= 16) is 0 with probability seg_p[k],
  * else 1/(1-seg_p[k]); consumed as `keep` by igcn_nodes_ln_*, igcn_node_linear_bn_*, igcn_bn1d_*, igcn_small_linear_*.
- * Counter-based integer-hash generator; `state` = device uint64[2] {stream counter (seed), workgroups done (0)}: the
- * last workgroup of a launch advances the counter, so every replay of a captured launch draws fresh masks. */
+ * Counter-based integer-hash generator; `state` = device uint64[igcn_dropout_state_words()], word 0 = the stream
+ * counter (seed), every other word 0 (arrival counts, left at 0 by every launch): the last workgroup of a launch
+ * advances the counter, so every replay of a captured launch draws fresh masks. */
+int igcn_dropout_state_words(void);
 int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end, const float* seg_p, void* state,
                        float* out, void* stream);
 

@@ -994,7 +994,9 @@ def test_dropout_masks_one_launch(ops):
     g.replay()
     torch.cuda.synchronize()
     assert float((first != mg[0]).float().mean()) > 0.2          # replays advance the counter
-    assert int(state.state[1].item()) == 0
+    assert int(state.state[1:].abs().sum().item()) == 0          # every arrival word is back at 0
+    big = ops.dropout_masks([((2048, 3000), 0.4)], state)[0]     # more workgroups than the launch cap: grid-stride
+    assert abs(float((big > 0).float().mean()) - 0.6) < 2e-3 and int(state.state[1:].abs().sum().item()) == 0
 
 
 def test_consumers_apply_the_dropout_factors(ops):
