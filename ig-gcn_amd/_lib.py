@@ -78,8 +78,9 @@ SIGNATURES = {
     "igcn_spmm_bwd": (I, [I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_go_attn_fwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "igcn_go_attn_bwd_scratch_floats": (Z, [I, I, I, I]),
-    "igcn_go_attn_walk_slots": (I, [I]),
-    "igcn_go_attn_walk_order": (I, [I, P, P]),
+    "igcn_go_attn_bwd_threads": (I, [I, I, I]),
+    "igcn_go_attn_walk_slots": (I, [I, I, I]),
+    "igcn_go_attn_walk_order": (I, [I, I, I, P, P]),
     "igcn_go_attn_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_nodes_ln_fwd": (I, [I, I, I, I, F, P, P, P, P, P, P, P, P]),
     "igcn_nodes_ln_bwd_scratch_floats": (Z, [I, I, I]),

@@ -871,17 +871,17 @@ extern "C" int igcn_debug_go_probe(long long* out) {
 #else
 #define GO_PROBE(i)
 #endif
-#define GO_ABL_T 1024
+#define GO_ABL_T 1024                                   // default workgroup; 512 when two workgroups then share a CU
 #define GO_ABL_MAXIT 4
-template <int FIN, int FOUT, int MAXIT>
-__global__ void __launch_bounds__(GO_ABL_T)
+template <int FIN, int FOUT, int MAXIT, int T>
+__global__ void __launch_bounds__(T, 4)
 k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
                   const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ t_row, const float* __restrict__ x,
                   const float* __restrict__ w_inc, const float* __restrict__ w_s, const float* __restrict__ a_in,
                   const float* __restrict__ a_s, const float* __restrict__ dy, const int32_t* __restrict__ order,
                   float* __restrict__ dx, float* __restrict__ gpart) {
   extern __shared__ float go_abl[];
-  constexpr int ROWS = 2 * FOUT + 3, TP = GO_ABL_T + 4;
+  constexpr int ROWS = 2 * FOUT + 3, TP = T + 4;
   const int NP = (N + 3) & ~3;
   float* xs = go_abl;                                   // [FIN][NP]
   float* dys = xs + FIN * NP;                           // [FOUT][NP]
@@ -900,27 +900,27 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
   int32_t pr0[MAXIT], pr1[MAXIT], pc0[MAXIT], pc1[MAXIT], ncol[MAXIT];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
-    const int slot = it * GO_ABL_T + tid;
+    const int slot = it * T + tid;
     ncol[it] = order ? order[slot] : (slot < N ? slot : -1);
   }
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
-    const int n = it * GO_ABL_T + tid;
+    const int n = it * T + tid;
     const bool live = n < N;                            // lanes past the end: EMPTY edge ranges
     pr0[it] = live ? row_ptr[n] : 0; pr1[it] = live ? row_ptr[n + 1] : 0;
     const int nc = ncol[it];
     pc0[it] = nc >= 0 ? t_ptr[nc] : 0; pc1[it] = nc >= 0 ? t_ptr[nc + 1] : 0;
   }
   if (NP == N && (((uintptr_t)xb | (uintptr_t)dyb) & 15) == 0) {
-    for (int i = tid * 4; i < FIN * N; i += GO_ABL_T * 4)
+    for (int i = tid * 4; i < FIN * N; i += T * 4)
       *reinterpret_cast<float4*>(xs + i) = *reinterpret_cast<const float4*>(xb + i);
-    for (int i = tid * 4; i < FOUT * N; i += GO_ABL_T * 4)
+    for (int i = tid * 4; i < FOUT * N; i += T * 4)
       *reinterpret_cast<float4*>(dys + i) = *reinterpret_cast<const float4*>(dyb + i);
   } else {
     for (int d = 0; d < FIN; ++d)
-      for (int n = tid; n < N; n += GO_ABL_T) xs[d * NP + n] = xb[d * N + n];
+      for (int n = tid; n < N; n += T) xs[d * NP + n] = xb[d * N + n];
     for (int c = 0; c < FOUT; ++c)
-      for (int n = tid; n < N; n += GO_ABL_T) dys[c * NP + n] = dyb[c * N + n];
+      for (int n = tid; n < N; n += T) dys[c * NP + n] = dyb[c * N + n];
   }
   // ... and the first two neighbours of each list (the GO DAG rarely has more: the walks then never wait on L2)
   int pm0[MAXIT], pm1[MAXIT], pra[MAXIT], prb[MAXIT];
@@ -940,7 +940,7 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
   // ---- statistics of every node of the sample + the row-side score gradient (RowPass) ---------------
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
-    const int n = it * GO_ABL_T + tid;
+    const int n = it * T + tid;
     if (n >= N) continue;
     float xr[FIN], xin[FOUT], dyn[FOUT];
     load_node<FIN>(xs, NP, n, xr);
@@ -973,7 +973,7 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
     for (int r = 0; r < ROWS; ++r) uu[it][r] = 0.f;
 #pragma unroll
     for (int d = 0; d < FIN; ++d) xx[it][d] = 0.f;
-    if (it * GO_ABL_T < N) {                            // block-uniform
+    if (it * T < N) {                            // block-uniform
       const int n = ncol[it];
       const bool live = n >= 0;
       const int nn = live ? n : N - 1;                  // dead lanes shadow a valid node with EMPTY edge ranges
@@ -1080,11 +1080,11 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
   {                                                     // dx [FIN][N] out of LDS, 16 bytes per lane
     float* dxb = dx + (int64_t)b * FIN * N;
     if (NP == N && ((uintptr_t)dxb & 15) == 0) {
-      for (int i = tid * 4; i < FIN * N; i += GO_ABL_T * 4)
+      for (int i = tid * 4; i < FIN * N; i += T * 4)
         *reinterpret_cast<float4*>(dxb + i) = *reinterpret_cast<const float4*>(xs + i);
     } else {
       for (int d = 0; d < FIN; ++d)
-        for (int n = tid; n < N; n += GO_ABL_T) dxb[d * N + n] = xs[d * NP + n];
+        for (int n = tid; n < N; n += T) dxb[d * N + n] = xs[d * NP + n];
     }
   }
   float* us = dys;                                      // [ROWS][TP], behind the dx slab
@@ -1093,7 +1093,7 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
-    if (it * GO_ABL_T < N) {                            // block-uniform
+    if (it * T < N) {                            // block-uniform
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) us[r * TP + tid] = uu[it][r];
 #pragma unroll
@@ -1124,31 +1124,43 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
       if (4 * g4 + r < ROWS) {
         float t = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < GO_ABL_T / 64; ++ww) t += wsum[(ww * 4 + r) * 64 + lane];
+        for (int ww = 0; ww < T / 64; ++ww) t += wsum[(ww * 4 + r) * 64 + lane];
         gpart[(int64_t)((4 * g4 + r) * FIN + m) * parts + b] = t;
       }
   }
   GO_PROBE(6);
 }
 
-static size_t go_abl_lds_bytes(int N, int fin, int fout) {
+static size_t go_abl_lds_bytes(int N, int fin, int fout, int T) {
   const size_t np = ((size_t)N + 3) & ~(size_t)3;
   const size_t walk = (size_t)(fout + 4) * np * sizeof(float);          // dy + statistics, then (same bytes) ...
-  const size_t stage = ((size_t)(2 * fout + 3 + fin) * (GO_ABL_T + 4) + (GO_ABL_T / 64) * 4 * 64) * sizeof(float);
+  const size_t stage = ((size_t)(2 * fout + 3 + fin) * (T + 4) + (T / 64) * 4 * 64) * sizeof(float);
   return (size_t)fin * np * sizeof(float) + (walk > stage ? walk : stage);      // x / dx slab in front
 }
+// Workgroup size: 512 threads when that lets TWO workgroups share a CU (<= 80 KB of LDS each, <= 128 registers at
+// 4 waves per SIMD) — one stages its sample while the other computes, and all samples of a 256-graph step are
+// resident at once; 1024 threads otherwise (N = 3000: 132 KB, one workgroup per CU whatever its size).
+static int go_abl_threads(int N, int fin, int fout) {
+  if (N <= 512 * GO_ABL_MAXIT && go_abl_lds_bytes(N, fin, fout, 512) <= 80 * 1024) return 512;
+  return GO_ABL_T;
+}
+extern "C" int igcn_go_attn_bwd_threads(int N, int fin, int fout) { return go_abl_threads(N, fin, fout); }
 
 // Thread -> node map of the LDS-resident backward's column walks (HOST code; structure-only, computed once per
-// hierarchy).  Slots: pass it, thread tid -> order[it * 1024 + tid] (-1 = idle); wave w owns slots [64 w, 64 w + 64) of
+// hierarchy).  T = igcn_go_attn_bwd_threads(N, fin, fout).  Slots: pass it, thread tid -> order[it * T + tid] (-1 = idle); wave w owns slots [64 w, 64 w + 64) of
 // every pass.  Nodes are sorted by column degree (descending, ties by id) and cut into groups of 64 = one wave-pass
 // each (hub nodes last), so a wave's lanes walk lists of nearly equal length; a group's cost ~ fixed per-node work + list steps of its
 // longest ordinary list + the wave-cooperative hub lists; groups go to the wave with the smallest load so far (longest
 // first).  Any permutation gives the same numbers per node; the order only moves work between waves.
-extern "C" int igcn_go_attn_walk_slots(int N) { return (int)(igcn_cdiv(N > 0 ? N : 1, GO_ABL_T) * GO_ABL_T); }
+extern "C" int igcn_go_attn_walk_slots(int N, int fin, int fout) {
+  const int T = go_abl_threads(N, fin, fout);
+  return (int)(igcn_cdiv(N > 0 ? N : 1, T) * T);
+}
 
-extern "C" int igcn_go_attn_walk_order(int N, const int32_t* t_ptr_host, int32_t* order_host) {
+extern "C" int igcn_go_attn_walk_order(int N, int fin, int fout, const int32_t* t_ptr_host, int32_t* order_host) {
   IGCN_REQUIRE(N > 0 && t_ptr_host && order_host, "go_attn_walk_order: bad arguments");
-  const int passes = (int)igcn_cdiv(N, GO_ABL_T), waves = GO_ABL_T / 64;
+  const int T = go_abl_threads(N, fin, fout);
+  const int passes = (int)igcn_cdiv(N, T), waves = T / 64;
   std::vector<int> nodes(N);
   for (int i = 0; i < N; ++i) nodes[i] = i;
   auto deg = [&](int n) { return t_ptr_host[n + 1] - t_ptr_host[n]; };
@@ -1171,13 +1183,13 @@ extern "C" int igcn_go_attn_walk_order(int N, const int32_t* t_ptr_host, int32_t
   std::stable_sort(gorder.begin(), gorder.end(), [&](int a, int b) { return cost[a] > cost[b]; });
   std::vector<double> load(waves, 0.0);
   std::vector<int> used(waves, 0);
-  for (int i = 0; i < passes * GO_ABL_T; ++i) order_host[i] = -1;
+  for (int i = 0; i < passes * T; ++i) order_host[i] = -1;
   for (int g : gorder) {
     int best = -1;
     for (int w = 0; w < waves; ++w)
       if (used[w] < passes && (best < 0 || load[w] < load[best])) best = w;
     IGCN_REQUIRE(best >= 0, "go_attn_walk_order: no free slot");
-    const int base = used[best] * GO_ABL_T + best * 64;
+    const int base = used[best] * T + best * 64;
     for (int k = g * 64, j = 0; k < N && j < 64; ++k, ++j) order_host[base + j] = nodes[k];
     used[best] += 1;
     load[best] += cost[g];
@@ -1204,21 +1216,25 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
   IGCN_REQUIRE(B > 0 && N > 0, "go_attn_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = 2 * fout + 3;
-  const size_t abl_lds = go_abl_lds_bytes(N, fin, fout);
-  if (!go_attn_force_cm() && abl_lds <= 160 * 1024 && N <= GO_ABL_T * GO_ABL_MAXIT) {
+  const int TT = go_abl_threads(N, fin, fout);
+  const size_t abl_lds = go_abl_lds_bytes(N, fin, fout, TT);
+  if (!go_attn_force_cm() && abl_lds <= 160 * 1024 && N <= TT * GO_ABL_MAXIT) {
     float* gpart = scratch;                                         // [rows * fin][B] block partials
-    const int iters = (int)igcn_cdiv(N, GO_ABL_T);
-#define CALLLI(FI, FO, MI)                                                                                        \
+    const int iters = (int)igcn_cdiv(N, TT);
+#define CALLLI(FI, FO, MI, TV)                                                                                    \
   {                                                                                                               \
-    IGCN_ALLOW_BIG_LDS((k_go_attn_bwd_lds<FI, FO, MI>));                                        \
-    hipLaunchKernelGGL((k_go_attn_bwd_lds<FI, FO, MI>), dim3(B), dim3(GO_ABL_T), abl_lds, st, N, row_ptr, col,    \
+    IGCN_ALLOW_BIG_LDS((k_go_attn_bwd_lds<FI, FO, MI, TV>));                                                      \
+    hipLaunchKernelGGL((k_go_attn_bwd_lds<FI, FO, MI, TV>), dim3(B), dim3(TV), abl_lds, st, N, row_ptr, col,      \
                        t_ptr, t_row, x, w_inc, w_s, a_in, a_s, dy, walk_order, dx, gpart);                        \
   }
+#define CALLLT(FI, FO, TV)                                                                                        \
+  if (iters <= 1) CALLLI(FI, FO, 1, TV) else if (iters == 2) CALLLI(FI, FO, 2, TV)                                \
+  else if (iters == 3) CALLLI(FI, FO, 3, TV) else CALLLI(FI, FO, 4, TV)
 #define CALLL(FI, FO)                                                                                             \
-  if (iters <= 1) CALLLI(FI, FO, 1) else if (iters == 2) CALLLI(FI, FO, 2) else if (iters == 3) CALLLI(FI, FO, 3) \
-  else CALLLI(FI, FO, 4)
+  if (TT == 512) { CALLLT(FI, FO, 512) } else { CALLLT(FI, FO, 1024) }
     GO_DISPATCH(fin, fout, CALLL)
 #undef CALLL
+#undef CALLLT
 #undef CALLLI
     IGCN_CHECK_LAUNCH("go_attn_bwd(lds)");
 #define CALLF(FI, FO) \

@@ -817,18 +817,20 @@ class Csr:
         self.flat_pos = key.to(device)            # row * n_cols + col of every non-zero (dense formulation)
         self._dense = {}
         self._t_ptr_host = t_ptr.to(torch.int32).contiguous()
-        self._walk_order = None
+        self._walk_order = {}
 
-    @property
-    def walk_order(self):
-        """Thread -> node map of the GO attention backward's column walks (igcn_go_attn_walk_order; square
-        structures only), built on first use."""
-        if self._walk_order is None and self.n_rows == self.n_cols:
+    def walk_order(self, fin, fout):
+        """Thread -> node map of the GO attention backward's column walks for a layer of this shape
+        (igcn_go_attn_walk_order; square structures only), built on first use."""
+        if self.n_rows != self.n_cols:
+            return None
+        key = (int(fin), int(fout))
+        if key not in self._walk_order:
             lib = _lib.load()
-            host = torch.empty(int(lib.igcn_go_attn_walk_slots(self.n_cols)), dtype=torch.int32)
-            call("igcn_go_attn_walk_order", self.n_cols, self._t_ptr_host.data_ptr(), host.data_ptr())
-            self._walk_order = host.to(self.flat_pos.device)
-        return self._walk_order
+            host = torch.empty(int(lib.igcn_go_attn_walk_slots(self.n_cols, *key)), dtype=torch.int32)
+            call("igcn_go_attn_walk_order", self.n_cols, key[0], key[1], self._t_ptr_host.data_ptr(), host.data_ptr())
+            self._walk_order[key] = host.to(self.flat_pos.device)
+        return self._walk_order[key]
 
     def dense(self, channels):
         """Persistent zero-initialised dense image [channels, n_rows * n_cols]; only the non-zero positions are ever
@@ -953,7 +955,7 @@ class GoAttention(torch.autograd.Function):
         scratch = torch.empty(int(lib.igcn_go_attn_bwd_scratch_floats(b, n, fin, fout)), dtype=torch.float32,
                               device=x.device)
         call("igcn_go_attn_bwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(csr.t_ptr), ptr(csr.t_row),
-             ptr(csr.walk_order), ptr(x), ptr(w_inc), ptr(w_s), ptr(a_in), ptr(a_s), ptr(dy), ptr(dx), ptr(dpar), ptr(scratch),
+             ptr(csr.walk_order(fin, fout)), ptr(x), ptr(w_inc), ptr(w_s), ptr(a_in), ptr(a_s), ptr(dy), ptr(dx), ptr(dpar), ptr(scratch),
              stream_ptr())
         k = fout * fin
         return (dx, dpar[:k].view(fout, fin), dpar[k:2 * k].view(fout, fin),

@@ -441,12 +441,15 @@ int igcn_go_attn_fwd(int B, int N, int fin, int fout, const int32_t* row_ptr, co
  * workgroup per sample; larger ones in global-memory kernels (hub columns walked by the whole wave).
  * scratch floats: igcn_go_attn_bwd_scratch_floats(B,N,fin,fout). */
 size_t igcn_go_attn_bwd_scratch_floats(int B, int N, int fin, int fout);
-/* `walk_order` (device int32[igcn_go_attn_walk_slots(N)], or NULL = node order): the thread -> node map of the
- * LDS-resident kernel's column walks, from igcn_go_attn_walk_order(N, t_ptr on the HOST, order out on the HOST) —
- * structure-only, computed once per hierarchy: nodes sorted by their number of readers and dealt to the waves so that
- * lanes walk lists of equal length and waves carry equal totals.  Results do not depend on it. */
-int igcn_go_attn_walk_slots(int N);
-int igcn_go_attn_walk_order(int N, const int32_t* t_ptr_host, int32_t* order_host);
+/* `walk_order` (device int32[igcn_go_attn_walk_slots(N, fin, fout)], or NULL = node order): the thread -> node map of
+ * the LDS-resident kernel's column walks, from igcn_go_attn_walk_order(N, fin, fout, t_ptr on the HOST, order out on
+ * the HOST) — structure-only, computed once per hierarchy and layer shape: nodes sorted by their number of readers and
+ * dealt to the waves so that lanes walk lists of equal length and waves carry equal totals.  Results do not depend on
+ * it.  igcn_go_attn_bwd_threads: the workgroup size the LDS-resident kernel runs with for that shape (512 when two
+ * workgroups then fit a CU, else 1024) — the slot count is its multiple. */
+int igcn_go_attn_bwd_threads(int N, int fin, int fout);
+int igcn_go_attn_walk_slots(int N, int fin, int fout);
+int igcn_go_attn_walk_order(int N, int fin, int fout, const int32_t* t_ptr_host, int32_t* order_host);
 int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
                      const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order,
                      const float* x, const float* w_inc, const float* w_s, const float* a_in, const float* a_s,

@@ -69,10 +69,11 @@ def test_go_attn_walk_order_is_a_balanced_permutation():
     n = deg.size
     t_ptr = torch.zeros(n + 1, dtype=torch.int32)
     t_ptr[1:] = torch.from_numpy(np.cumsum(deg)).to(torch.int32)
-    slots = lib.igcn_go_attn_walk_slots(n)
-    assert slots == 3072
+    assert lib.igcn_go_attn_bwd_threads(n, 2, 5) == 1024 and lib.igcn_go_attn_bwd_threads(1200, 5, 5) == 512
+    slots = lib.igcn_go_attn_walk_slots(n, 2, 5)
+    assert slots == 3072 and lib.igcn_go_attn_walk_slots(1200, 5, 5) == 1536
     order = torch.full((slots,), -7, dtype=torch.int32)
-    assert lib.igcn_go_attn_walk_order(n, t_ptr.data_ptr(), order.data_ptr()) == 0
+    assert lib.igcn_go_attn_walk_order(n, 2, 5, t_ptr.data_ptr(), order.data_ptr()) == 0
     o = order.numpy()
     assert sorted(o[o >= 0].tolist()) == list(range(n)) and set(o[o < 0].tolist()) <= {-1}
     steps = np.zeros(16)

@@ -324,9 +324,11 @@ def test_go_attention_layer(ops, bsz, pool, fin, seed):
         assert_matches(got, want.numpy(), TOL, nm)
     # the balanced thread -> node map of the column walks (igcn_go_attn_walk_order) only moves work between waves: in
     # plain node order the per-node results are the same bits, the parameter sums the same up to summation order
-    assert csr.walk_order is not None and int((csr.walk_order >= 0).sum()) == nj
-    csr._walk_order = torch.arange(csr.walk_order.numel(), dtype=torch.int32, device="cuda")
-    csr._walk_order[nj:] = -1
+    wo = csr.walk_order(fin, 5)
+    assert wo is not None and int((wo >= 0).sum()) == nj
+    ident = torch.arange(wo.numel(), dtype=torch.int32, device="cuda")
+    ident[nj:] = -1
+    csr._walk_order[(fin, 5)] = ident
     g2 = torch.autograd.grad((y * cot.transpose(1, 2).contiguous().cuda()).sum(), dev)
     assert torch.equal(g2[0], g[0])
     for a, c2, nm in zip(g2[1:], g[1:], ("dW_inc", "dW_s", "da_in", "da_s")):
