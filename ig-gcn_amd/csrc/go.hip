@@ -1956,7 +1956,10 @@ k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
     }
 #pragma unroll
     for (int d = 0; d < FIN; ++d) xt[d * TP + tid] = xr[d];
-    __syncthreads();
+    // the staging columns [64 w, 64 w + 64) belong to wave w alone (written and read by it, LDS serves a wave's
+    // accesses in order): no workgroup barrier inside the loop
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const float* ua = us + (mm < ROWS ? mm : 0) * TP + 64 * w + g4;
     const float* xa = xt + (mm < FIN ? mm : 0) * TP + 64 * w + g4;
 #pragma unroll
@@ -1965,8 +1968,10 @@ k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
       const float bq = (mm < FIN) ? xa[4 * c] : 0.f;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+  __syncthreads();                                      // every wave is done with the staging area
   float* wsum = us;                                     // [16 waves * 4][64] <= ROWS * TP floats (ROWS >= 4)
 #pragma unroll
   for (int r = 0; r < 4; ++r) wsum[(w * 4 + r) * 64 + lane] = acc[r];
