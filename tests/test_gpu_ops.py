@@ -135,7 +135,9 @@ def test_gcn_layer_fwd_bwd(ops, n, e, fin, fout, loops, multi, seed):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("m,n,k", [(23040, 16, 3), (23040, 16, 16), (256, 64, 2912), (256, 64, 3182), (256, 3, 64),
-                                   (5, 7, 9), (1000, 33, 130), (64, 64, 4096)])
+                                   (5, 7, 9), (1000, 33, 130), (64, 64, 4096),
+                                   # short-K streaming kernel (M >= 4096, N, K multiples of 16 up to 64), ragged M
+                                   (8197, 64, 32), (5003, 32, 64), (4100, 48, 48), (20480, 64, 64)])
 def test_gemm_nt_nn_tn(ops, m, n, k):
     rng = np.random.default_rng(m + n + k)
     a = torch.from_numpy(rng.standard_normal((m, k))).float()
