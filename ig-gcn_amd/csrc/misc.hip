@@ -124,8 +124,8 @@ extern "C" int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_
 #define BG_T 256
 template <int VW>
 __global__ void __launch_bounds__(BG_T)
-k_bias_grad(int64_t rows, int cols, int64_t rows_per_block, const float* __restrict__ dy, const float* __restrict__ y,
-            float* __restrict__ g, float* __restrict__ partial) {
+k_bias_grad(int64_t rows, int cols, int zero_cols, int64_t rows_per_block, const float* __restrict__ dy,
+            const float* __restrict__ y, float* __restrict__ g, float* __restrict__ partial) {
   // thread = (row lane, column group of VW): cpr column groups per row, BG_T / cpr row lanes
   __shared__ float red[BG_T * VW];
   const int cpr = cols / VW, rl = threadIdx.x / cpr, cg = threadIdx.x % cpr, lanes = BG_T / cpr;
@@ -164,8 +164,10 @@ k_bias_grad(int64_t rows, int cols, int64_t rows_per_block, const float* __restr
   for (int c = threadIdx.x; c < cols; c += BG_T) {      // column c = group c / VW, slot c % VW; row lanes in order
     float t = 0.f;
     for (int l = 0; l < lanes; ++l) t += red[(l * cpr + c / VW) * VW + c % VW];
-    partial[(int64_t)blockIdx.x * cols + c] = t;
+    partial[(int64_t)blockIdx.x * (cols + zero_cols) + c] = t;
   }
+  // `zero_cols` structurally zero outputs behind the sums (igcn_col_sums): they ride through the same reduction
+  for (int c = threadIdx.x; c < zero_cols; c += BG_T) partial[(int64_t)blockIdx.x * (cols + zero_cols) + cols + c] = 0.f;
 }
 
 extern "C" size_t igcn_bias_grad_scratch_floats(int64_t rows, int cols) {
@@ -182,11 +184,32 @@ extern "C" int igcn_bias_grad(int64_t rows, int cols, const float* dy, const flo
   const int64_t nb = igcn_cdiv(rows, rpb);
   const bool vec = cols % 4 == 0 && BG_T % (cols / 4) == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)g) & 15) == 0;
   if (vec)
-    hipLaunchKernelGGL((k_bias_grad<4>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, rpb, dy, y, g, scratch);
+    hipLaunchKernelGGL((k_bias_grad<4>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, 0, rpb, dy, y, g, scratch);
   else
-    hipLaunchKernelGGL((k_bias_grad<1>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, rpb, dy, y, g, scratch);
+    hipLaunchKernelGGL((k_bias_grad<1>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, 0, rpb, dy, y, g, scratch);
   IGCN_CHECK_LAUNCH("bias_grad");
   return igcn_launch_reduce_rows_final(scratch, nb, cols, cols, db, st);
+}
+
+// out[0:cols] = column sums of x [rows, cols]; out[cols : cols + zero_cols] = 0 — a gradient block that is known to
+// vanish (the key bias of a softmax over keys, ops.ProjectedAttention) written by the launch that sums its neighbour.
+// scratch: igcn_bias_grad_scratch_floats(rows, cols + zero_cols).  Final-gradient semantics (deferrable).
+extern "C" int igcn_col_sums(int64_t rows, int cols, int zero_cols, const float* x, float* out, float* scratch,
+                             void* stream) {
+  IGCN_REQUIRE(rows > 0 && cols > 0 && cols <= BG_T && zero_cols >= 0 && zero_cols <= 4096, "col_sums: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t blocks = rows < 512 * 64 ? igcn_cdiv(rows, 64) : 512;
+  const int64_t rpb = igcn_cdiv(rows, blocks);
+  const int64_t nb = igcn_cdiv(rows, rpb);
+  const bool vec = cols % 4 == 0 && BG_T % (cols / 4) == 0 && ((uintptr_t)x & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL((k_bias_grad<4>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, zero_cols, rpb, x,
+                       (const float*)nullptr, (float*)nullptr, scratch);
+  else
+    hipLaunchKernelGGL((k_bias_grad<1>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, zero_cols, rpb, x,
+                       (const float*)nullptr, (float*)nullptr, scratch);
+  IGCN_CHECK_LAUNCH("col_sums");
+  return igcn_launch_reduce_rows_final(scratch, nb, cols + zero_cols, cols + zero_cols, out, st);
 }
 
 // =================================================================================================

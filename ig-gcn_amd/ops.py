@@ -1189,6 +1189,60 @@ class GramLosses(torch.autograd.Function):
         return ds, None, None, None
 
 
+class ProjectedAttention(torch.autograd.Function):
+    """ops.InProj + ops.AttentionCore as ONE autograd node (the cross-attention of kernel/sgcn_img_snp.py:240-241 up to
+    the output projection): q = query W_q^T + b_q, k | v = memory [W_k; W_v]^T + [b_k; b_v], o = softmax(q k^T/sqrt(hd)) v.
+    Seeing the core's incoming gradient and the projections together lets the backward take the key / value bias
+    gradients in closed form instead of summing the 52 MB gradient of k | v over its rows:
+      d b_k = 0 exactly        (a key bias adds q . b_k to every score of a query: the softmax over keys cannot see it)
+      d b_v = sum_{b,q} d o    (every query's attention weights sum to 1)
+    — the reference's autograd evaluates the first as rounding noise around 0 and the second as the same sum, reached
+    through the 400-key value gradient."""
+
+    @staticmethod
+    def forward(ctx, query, memory, w, bias, heads, bf16=False):
+        d = w.shape[1]
+        q2, m2 = _f32(query).reshape(-1, d), _f32(memory).reshape(-1, d)
+        w, bias = _f32(w), _f32(bias)
+        b, lq, lk = query.shape[0], query.shape[1], memory.shape[1]
+        q = gemm_nt(q2, w[:d], bias[:d], 0, bf16=bf16).view(b, lq, d)
+        kv = gemm_nt(m2, w[d:], bias[d:], 0, bf16=bf16).view(b, lk, 2 * d)
+        o = torch.empty_like(q)
+        lse = torch.empty(b, heads, lq, dtype=torch.float32, device=q.device)
+        call("igcn_attn_core_fwd", b, d, heads, lq, lk, ptr(q), ptr(kv), ptr(o), ptr(lse), stream_ptr())
+        ctx.save_for_backward(q2, m2, w, q, kv, o, lse)
+        ctx.heads, ctx.bf16, ctx.final = heads, bf16, _leaves(w, bias)
+        ctx.shapes = (query.shape, memory.shape)
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        q2, m2, w, q, kv, o, lse = ctx.saved_tensors
+        dout = _f32(dout)
+        b, lq, d = q.shape
+        lk = kv.shape[1]
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        nscr = int(_lib.load().igcn_attn_core_bwd_scratch_floats(b, ctx.heads, lq))
+        scratch = torch.empty(nscr, dtype=torch.float32, device=q.device)
+        call("igcn_attn_core_bwd", b, d, ctx.heads, lq, lk, ptr(q), ptr(kv), ptr(o), ptr(lse), ptr(dout), ptr(dq),
+             ptr(dkv), ptr(scratch), stream_ptr())
+        dq2, dkv2 = dq.view(-1, d), dkv.view(-1, 2 * d)
+        dw = torch.empty_like(w)
+        db = torch.empty(3 * d, dtype=torch.float32, device=w.device)
+        lib = _lib.load()
+        rows = dq2.shape[0]
+        scr = _keep(torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, 2 * d)), dtype=torch.float32, device=w.device))
+        with _immediate(ctx.final):
+            call("igcn_col_sums", rows, d, d, ptr(dq2), ptr(db), ptr(scr), stream_ptr())          # d b_q, then d b_k = 0
+        _bias_grad_into(dout.reshape(-1, d), db[2 * d:], ctx.final)                                  # d b_v
+        dquery = gemm_nn(dq2, w[:d], bf16=ctx.bf16).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None
+        dmem = gemm_nn(dkv2, w[d:], bf16=ctx.bf16).view(ctx.shapes[1]) if ctx.needs_input_grad[1] else None
+        with _immediate(ctx.final):
+            gemm_tn(dq2, q2, bf16=ctx.bf16, final_grad=True, out=dw[:d])
+            gemm_tn(dkv2, m2, bf16=ctx.bf16, final_grad=True, out=dw[d:])
+        return dquery, dmem, dw, db, None, None
+
+
 class LossHead(torch.autograd.Function):
     """The seven loss terms of train() (kernel/train_eval_sgcn_img_snps.py:525-543) and their weighted sum on the
     stacked outputs of the batched sweep, one kernel per direction (igcn_loss_head_*).

@@ -233,15 +233,15 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         w, bias = mha.in_proj_weight, mha.in_proj_bias
         if self.fused_cross_attention and ops.xattn_supported(d, h, lq, lk):
             return ops.CrossAttention.apply(query, memory, w, bias, mha.out_proj.weight, mha.out_proj.bias, h)
-        # the packed projection taken whole (ops.InProj): its backward fills ONE [3D, D] / [3D] gradient, so the two
-        # parameters stay leaves (no concatenation of slice gradients, deferrable partial sums)
         bf = self.bf16_transforms
-        q, kv = ops.InProj.apply(query, memory, w, bias, bf)                 # [B, Lq, D], [B, Lk, 2D] = key | value
         if ops.attn_core_supported(d, h, lq, lk):
-            o = ops.AttentionCore.apply(q, kv, h)                           # heads addressed in place
+            # projections + core as one autograd node: parameters taken whole (leaves: ONE [3D, D] / [3D] gradient,
+            # deferrable partial sums), key / value bias gradients in closed form
+            o = ops.ProjectedAttention.apply(query, memory, w, bias, h, bf)
         else:
             # head_dim > 32 (outside the core's coverage): plain batched-GEMM + softmax composite.  Deliberately not
             # the library's fused SDPA kernels (known issues)
+            q, kv = ops.InProj.apply(query, memory, w, bias, bf)             # [B, Lq, D], [B, Lk, 2D] = key | value
             hd = d // h
             qh = q.view(b, lq, h, hd).transpose(1, 2)
             kvh = kv.view(b, lk, 2, h, hd)

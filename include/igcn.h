@@ -253,6 +253,10 @@ int igcn_graph_pool_bwd(int64_t n_graphs, int nodes_per_graph, int D, const floa
 size_t igcn_bias_grad_scratch_floats(int64_t rows, int cols);
 int igcn_bias_grad(int64_t rows, int cols, const float* dy, const float* y, float* g, float* db, float* scratch,
                    void* stream);
+/* out[0:cols] = column sums of x [rows, cols]; out[cols : cols + zero_cols] = 0 (a gradient block known to vanish,
+ * written by the launch that sums its neighbour: the key bias of nn.MultiheadAttention, kernel/sgcn_img_snp.py:240 —
+ * a softmax over keys cannot see a key bias).  scratch: igcn_bias_grad_scratch_floats(rows, cols + zero_cols). */
+int igcn_col_sums(int64_t rows, int cols, int zero_cols, const float* x, float* out, float* scratch, void* stream);
 
 /* `act`: 0 = none, 1 = ReLU; bit 0x100 = the output is a final parameter gradient (deferred reductions, below).
  * The split the library's launch heuristic prefers for (M, N, K): callers size `scratch` with it and pass it as

@@ -272,6 +272,31 @@ def test_in_proj_packed_projection(ops, b, lq, lk, d):
         assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("b,lq,lk,d,h", [(5, 90, 40, 32, 2), (3, 17, 70, 32, 4)])
+def test_projected_attention_matches_multihead_attention(ops, b, lq, lk, d, h):
+    """ops.ProjectedAttention (packed in-projection + attention core as one autograd node) against
+    nn.MultiheadAttention's in-projection + scaled-dot-product attention in fp64: output and all four gradients —
+    including the closed forms d b_k = 0 and d b_v = sum d o, which the reference reaches through autograd."""
+    rng = np.random.default_rng(b + lq + lk)
+    mk = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32))     # noqa: E731
+    query, memory, w, bias, cot = mk(b, lq, d), mk(b, lk, d), mk(3 * d, d) * 0.3, mk(3 * d), mk(b, lq, d)
+    ref = [t.double().requires_grad_(True) for t in (query, memory, w, bias)]
+    q = torch.nn.functional.linear(ref[0], ref[2][:d], ref[3][:d]).view(b, lq, h, d // h).transpose(1, 2)
+    k = torch.nn.functional.linear(ref[1], ref[2][d:2 * d], ref[3][d:2 * d]).view(b, lk, h, d // h).transpose(1, 2)
+    v = torch.nn.functional.linear(ref[1], ref[2][2 * d:], ref[3][2 * d:]).view(b, lk, h, d // h).transpose(1, 2)
+    att = torch.softmax(q @ k.transpose(2, 3) / (d // h) ** 0.5, dim=-1)
+    o_ref = (att @ v).transpose(1, 2).reshape(b, lq, d)
+    g_ref = torch.autograd.grad((o_ref * cot.double()).sum(), ref)
+    assert float(g_ref[3][d:2 * d].abs().max()) < 1e-12 * max(1.0, float(g_ref[3].abs().max()))   # d b_k: noise around 0
+    dev = [t.cuda().requires_grad_(True) for t in (query, memory, w, bias)]
+    o = ops.ProjectedAttention.apply(*dev, h)
+    g = torch.autograd.grad((o * cot.cuda()).sum(), dev)
+    assert_matches(o, o_ref.detach().numpy(), TOL, "o")
+    for got, want, nm in zip(g, g_ref, ("dquery", "dmemory", "dW", "dbias")):
+        assert_matches(got, want.numpy(), TOL, nm)
+    assert float(g[3][d:2 * d].abs().max()) == 0.0
+
+
 def test_gemm_is_exact_fp32_fma_chain(ops):
     """MFMA f32 = k-ordered fmaf chain: small-integer operands must be reproduced exactly."""
     rng = np.random.default_rng(0)
