@@ -28,17 +28,53 @@ __global__ void k_reduce_rows(const float* __restrict__ partial, int64_t rows, i
   out[j] = accumulate ? out[j] + t : t;
 }
 
-// many rows, few columns: one 256-thread block per column, fixed reduction tree (deterministic)
+// many rows AND many columns (split-K / per-workgroup partial rows of wide gradients): a thread per column walking all
+// rows is a chain of `rows` dependent-latency loads (128 rows: 16 batches of 8 = the whole 16 us of the launch).  Four
+// row groups per column (rows r = g mod 4), combined in the fixed order ((s0 + s1) + s2) + s3: 64 columns x 4 groups per
+// 256-thread workgroup.  Shared by the stand-alone and the deferred reduction so that both give the same bits.
+#define RR_WIDE_ROWS 32
+__device__ __forceinline__ void reduce_cols_grouped(const float* __restrict__ partial, int64_t rows, int64_t ld, int n,
+                                                    float* __restrict__ out, int accumulate, int64_t block,
+                                                    float (*lds)[64]) {
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t j = block * 64 + c;
+  float t = 0.f;
+  if (j < n) {
+#pragma unroll 8
+    for (int64_t r = g; r < rows; r += 4) t += partial[r * ld + j];
+  }
+  lds[g][c] = t;
+  __syncthreads();
+  if (g == 0 && j < n) {
+    const float v = ((lds[0][c] + lds[1][c]) + lds[2][c]) + lds[3][c];
+    out[j] = accumulate ? out[j] + v : v;
+  }
+}
 __global__ void __launch_bounds__(256)
-k_reduce_rows_par(const float* __restrict__ partial, int64_t rows, int64_t ld, float* __restrict__ out,
-                  int accumulate) {
-  __shared__ float red[16];
-  const int j = blockIdx.x;
+k_reduce_rows_grouped(const float* __restrict__ partial, int64_t rows, int64_t ld, int n, float* __restrict__ out,
+                      int accumulate) {
+  __shared__ float lds[4][64];
+  reduce_cols_grouped(partial, rows, ld, n, out, accumulate, blockIdx.x, lds);
+}
+
+// many rows, few columns: one WAVE per column (four columns per 256-thread workgroup): lanes stride the rows, fixed
+// xor tree — no LDS, no barrier.  [A workgroup per column with a block-wide tree: 5 000 one-load workgroups in the
+// deferred launch of a train step, whose cost was their dispatch.]  Shared by the stand-alone and the deferred form.
+__device__ __forceinline__ void reduce_col_wave(const float* __restrict__ partial, int64_t rows, int64_t ld, int n,
+                                                float* __restrict__ out, int accumulate, int64_t block) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = block * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;                                 // wave-uniform
   float t = 0.f;
 #pragma unroll 4
-  for (int64_t r = threadIdx.x; r < rows; r += 256) t += partial[r * ld + j];
-  t = block_sum_all(t, red);
-  if (threadIdx.x == 0) out[j] = accumulate ? out[j] + t : t;
+  for (int64_t r = lane; r < rows; r += 64) t += partial[r * ld + j];
+  t = wave_sum(t);
+  if (lane == 0) out[j] = accumulate ? out[j] + t : t;
+}
+__global__ void __launch_bounds__(256)
+k_reduce_rows_par(const float* __restrict__ partial, int64_t rows, int64_t ld, int n, float* __restrict__ out,
+                  int accumulate) {
+  reduce_col_wave(partial, rows, ld, n, out, accumulate, blockIdx.x);
 }
 
 // out[j] = sum_r partial[j * rows + r]: the summands of one output are CONTIGUOUS (coalesced), one block per output
@@ -64,8 +100,15 @@ int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int 
                             hipStream_t st) {
   if (n <= 0) return IGCN_OK;
   if (rows > 32 && n <= 4096) {
-    hipLaunchKernelGGL(k_reduce_rows_par, dim3((unsigned)n), dim3(256), 0, st, partial, rows, ld, out, accumulate);
+    hipLaunchKernelGGL(k_reduce_rows_par, dim3((unsigned)igcn_cdiv(n, 4)), dim3(256), 0, st, partial, rows, ld, n, out,
+                       accumulate);
     IGCN_CHECK_LAUNCH("reduce_rows_par");
+    return IGCN_OK;
+  }
+  if (rows > RR_WIDE_ROWS) {
+    hipLaunchKernelGGL(k_reduce_rows_grouped, dim3((unsigned)igcn_cdiv(n, 64)), dim3(256), 0, st, partial, rows, ld, n,
+                       out, accumulate);
+    IGCN_CHECK_LAUNCH("reduce_rows_grouped");
     return IGCN_OK;
   }
   hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)igcn_cdiv(n, 64)), dim3(64), 0, st, partial, rows, ld, n, out,
@@ -88,21 +131,26 @@ struct ReduceEntry {
 };
 struct ReduceTable {
   ReduceEntry e[MRQ_MAX];
+  int start[MRQ_MAX + 1];                            // first workgroup of every entry (flat grid: no idle workgroups)
+  int count;
 };
 
 __global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t) {
-  __shared__ float red[16];
-  const ReduceEntry e = t.e[blockIdx.y];
-  if (e.rows > 32 && e.n <= 4096) {                  // tall: one block per column, fixed tree (k_reduce_rows_par)
-    const int j = blockIdx.x;
-    if (j >= e.n) return;
-    float s = 0.f;
-#pragma unroll 4
-    for (int64_t r = threadIdx.x; r < e.rows; r += 256) s += e.partial[r * e.ld + j];
-    s = block_sum_all(s, red);
-    if (threadIdx.x == 0) e.out[j] = s;
+  __shared__ float lds[4][64];
+  // flat grid: workgroup -> (entry, block inside the entry).  [A (max blocks) x (entries) grid launched 57 000
+  // workgroups for 11 000 with work.]
+  int ei = 0;
+  while (ei + 1 < t.count && (int)blockIdx.x >= t.start[ei + 1]) ++ei;
+  const ReduceEntry e = t.e[ei];
+  const int64_t blk = (int64_t)blockIdx.x - t.start[ei];
+  if (e.rows > RR_WIDE_ROWS && e.n > 4096) {         // tall and wide: grouped rows (k_reduce_rows_grouped)
+    reduce_cols_grouped(e.partial, e.rows, e.ld, e.n, e.out, 0, blk, lds);
+    return;
+  }
+  if (e.rows > 32 && e.n <= 4096) {                  // tall: a wave per column, fixed tree (k_reduce_rows_par)
+    reduce_col_wave(e.partial, e.rows, e.ld, e.n, e.out, 0, blk);
   } else {                                           // wide: one thread per column, rows in order (k_reduce_rows)
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t j = blk * 256 + threadIdx.x;
     if (j >= e.n) return;
     float s = 0.f;
 #pragma unroll 8
@@ -129,18 +177,26 @@ extern "C" int igcn_reduce_pending(void) {
 }
 
 static int reduce_flush_locked(hipStream_t st) {
+  if (getenv("IGCN_DEBUG_REDUCE"))
+    for (const ReduceEntry& e : g_rq)
+      fprintf(stderr, "[igcn] deferred reduction: rows %lld x n %d (ld %lld)%s\n", (long long)e.rows, e.n,
+              (long long)e.ld, (e.rows > 32 && e.n <= 4096) ? "  tree" : "  in-order");
   size_t done = 0;
   while (done < g_rq.size()) {
     ReduceTable t = {};
     const int cnt = (int)(g_rq.size() - done < MRQ_MAX ? g_rq.size() - done : MRQ_MAX);
-    int64_t gx = 1;
+    int64_t total = 0;
     for (int i = 0; i < cnt; ++i) {
       const ReduceEntry& e = g_rq[done + i];
       t.e[i] = e;
-      const int64_t need = (e.rows > 32 && e.n <= 4096) ? e.n : igcn_cdiv(e.n, 256);
-      gx = need > gx ? need : gx;
+      const int64_t need = (e.rows > 32 && e.n <= 4096) ? igcn_cdiv(e.n, 4)
+                                                        : (e.rows > RR_WIDE_ROWS ? igcn_cdiv(e.n, 64) : igcn_cdiv(e.n, 256));
+      t.start[i] = (int)total;
+      total += need;
     }
-    hipLaunchKernelGGL(k_multi_reduce, dim3((unsigned)gx, (unsigned)cnt), dim3(256), 0, st, t);
+    t.start[cnt] = (int)total;
+    t.count = cnt;
+    hipLaunchKernelGGL(k_multi_reduce, dim3((unsigned)total), dim3(256), 0, st, t);
     done += cnt;
   }
   g_rq.clear();
