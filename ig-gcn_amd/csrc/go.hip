@@ -871,6 +871,28 @@ extern "C" int igcn_debug_go_probe(long long* out) {
 #else
 #define GO_PROBE(i)
 #endif
+// sum of `acc[0..F)` over the 64 lanes of a wave: while a lane still holds more than one value, lanes M apart exchange
+// the half the partner keeps (HALF shuffles instead of 2 HALF), then plain xor steps; the total of value f ends up in
+// acc[0] of lane 2 f (F = 32).  All indices are compile-time constants; fixed order.
+template <int F, int HALF, int M>
+__device__ __forceinline__ void go_butterfly(float (&acc)[F], int lane) {
+  if constexpr (M >= 1) {
+    if constexpr (HALF >= 1) {
+      const bool up = (lane & M) != 0;
+#pragma unroll
+      for (int j = 0; j < HALF; ++j) {
+        const float send = up ? acc[j] : acc[j + HALF];
+        const float recv = __shfl_xor(send, M, 64);
+        acc[j] = (up ? acc[j + HALF] : acc[j]) + recv;
+      }
+      go_butterfly<F, HALF / 2, M / 2>(acc, lane);
+    } else {
+      acc[0] += __shfl_xor(acc[0], M, 64);
+      go_butterfly<F, 0, M / 2>(acc, lane);
+    }
+  }
+}
+
 #define GO_ABL_T 1024                                   // default workgroup; 512 when two workgroups then share a CU
 #define GO_ABL_MAXIT 4
 template <int FIN, int FOUT, int MAXIT, int T>
@@ -1087,9 +1109,34 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
         for (int n = tid; n < N; n += T) dxb[d * N + n] = xs[d * NP + n];
     }
   }
+  const int w = tid >> 6;
+  if constexpr (ROWS * FIN <= 32) {
+    // few products (f_in = 2: 13 x 2): per-thread sums over its nodes, a halving butterfly over the wave (32 shuffles
+    // for 32 values), the 16 wave totals through LDS.  [On the matrix cores the same products cost 768 16x16x4
+    // instructions per workgroup for 26 useful outputs each — 4.6 us of a 20 us workgroup (phase probe).]
+    float gv[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) gv[e] = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int d = 0; d < FIN; ++d) gv[r * FIN + d] += uu[it][r] * xx[it][d];
+    go_butterfly<32, 16, 32>(gv, lane);
+    float* wpart = dys;                                 // [T / 64][32]
+    if ((lane & 1) == 0) wpart[w * 32 + (lane >> 1)] = gv[0];
+    __syncthreads();
+    if (tid < ROWS * FIN) {
+      float t = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < T / 64; ++ww) t += wpart[ww * 32 + tid];
+      gpart[(int64_t)tid * gridDim.x + b] = t;
+    }
+  } else {
   float* us = dys;                                      // [ROWS][TP], behind the dx slab
   float* xt = us + ROWS * TP;                           // [FIN][TP]
-  const int w = tid >> 6, m = lane & 15, g4 = lane >> 4;
+  const int m = lane & 15, g4 = lane >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
@@ -1127,6 +1174,7 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
         for (int ww = 0; ww < T / 64; ++ww) t += wsum[(ww * 4 + r) * 64 + lane];
         gpart[(int64_t)((4 * g4 + r) * FIN + m) * parts + b] = t;
       }
+  }
   }
   GO_PROBE(6);
 }
