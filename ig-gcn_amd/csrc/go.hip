@@ -1961,6 +1961,9 @@ k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int w = tid >> 6, mm = lane & 15, g4 = lane >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float gv[32];
+#pragma unroll
+  for (int e = 0; e < 32; ++e) gv[e] = 0.f;
   const int off = Nout - Nin;
   const float* xb = x + (int64_t)b * FIN * Nin;
   float* dxb = dx + (int64_t)b * FIN * Nin;
@@ -1997,6 +2000,16 @@ k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
         dxb[d * Nin + m] = t;
       }
     }
+    if constexpr (NW <= 32) {                           // few products: per-thread sums, one butterfly at the end
+#pragma unroll
+      for (int c = 0; c < FOUT; ++c)
+#pragma unroll
+        for (int d = 0; d < FIN; ++d) {
+          gv[c * FIN + d] += G[c] * xr[d];
+          gv[(FOUT + c) * FIN + d] += Gs[c] * xr[d];
+        }
+      continue;
+    }
 #pragma unroll
     for (int c = 0; c < FOUT; ++c) {
       us[c * TP + tid] = G[c];
@@ -2018,6 +2031,19 @@ k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  }
+  if constexpr (NW <= 32) {
+    go_butterfly<32, 16, 32>(gv, lane);                 // total of value f in lane 2 f
+    float* wpart = us;                                  // [16 waves][32]
+    if ((lane & 1) == 0) wpart[w * 32 + (lane >> 1)] = gv[0];
+    __syncthreads();
+    if (tid < NW) {
+      float t = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < GO_DBL_T / 64; ++ww) t += wpart[ww * 32 + tid];
+      partial[(int64_t)b * NW + tid] = t;
+    }
+    return;
   }
   __syncthreads();                                      // every wave is done with the staging area
   float* wsum = us;                                     // [16 waves * 4][64] <= ROWS * TP floats (ROWS >= 4)
