@@ -2064,7 +2064,9 @@ k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
 
 static size_t go_dbl_lds_bytes(int Nout, int fin, int fout) {
   const size_t npo = ((size_t)Nout + 3) & ~(size_t)3;
-  return ((size_t)(fout + 1) * npo + (size_t)(2 * fout + fin) * (GO_DBL_T + 4)) * sizeof(float);
+  // few parameter-gradient products (VALU + butterfly path): 16 waves x 32 totals instead of the MFMA staging area
+  const size_t stage = 2 * fout * fin <= 32 ? (size_t)(GO_DBL_T / 64) * 32 : (size_t)(2 * fout + fin) * (GO_DBL_T + 4);
+  return ((size_t)(fout + 1) * npo + stage) * sizeof(float);
 }
 
 extern "C" size_t igcn_go_decode_bwd_scratch_floats(int B, int Nin, int fin, int fout) {
