@@ -32,7 +32,7 @@ struct SfParams {
 struct SfLayout {
   int x, dis, wl, wloop, ew, what, src, dst, tptr, tperm, wallT, act, wall, loop, tsrc, twhat;   // forward part
   int ycat;                                                                             // [R][L*F] layer outputs
-  int sptr, sperm, g, dh, dx, dwhat, dwloop, ddeg, red, dycat, prow, bdst, bwhat;   // backward part
+  int sptr, sperm, g, dh, dx, dwhat, dwloop, ddeg, red, dycat, prow, bdst, bwhat, v1, v2;   // backward part
   int total;
 };
 
@@ -64,11 +64,15 @@ __host__ __device__ inline SfLayout sf_layout(int R, int Emax, int H0, int F, in
   o.act = take((backward ? L : 1) * R * F);
   o.ycat = take(R * L * F);
   o.sptr = o.sperm = o.g = o.dh = o.dx = o.dwhat = o.dwloop = o.ddeg = o.red = o.dycat = o.prow = o.bdst = o.bwhat = 0;
+  o.v1 = o.v2 = 0;
   if (backward) {
     o.sptr = take(R + 1);
     o.sperm = take(Emax);
     o.g = take(R * F);
     o.dh = take(R * F);
+    // gcn_norm backward: per-position products (by-source / by-target order) — in G / dH, dead by then, when they fit
+    o.v1 = Emax <= R * F ? o.g : take(Emax);
+    o.v2 = Emax <= R * F ? o.dh : take(Emax);
     o.dx = take(R * fin_max);
     o.dwhat = take(Emax);
     o.dwloop = take(R);
@@ -252,14 +256,12 @@ __device__ __forceinline__ int sf_stage(float* lds, const SfLayout& o, int R, in
     const int32_t* ssptr = reinterpret_cast<const int32_t*>(lds + o.sptr);
     const int32_t* ssperm = reinterpret_cast<const int32_t*>(lds + o.sperm);
     int32_t* sbdst = reinterpret_cast<int32_t*>(lds + o.bdst);
-    for (int i = tid; i < R; i += (int)blockDim.x) {
-      const float di = lds[o.dis + i];
-      for (int p = ssptr[i]; p < ssptr[i + 1]; ++p) {
-        const int k = ssperm[p];
-        const int t = sdst[k];
-        sbdst[p] = t;
-        lds[o.bwhat + p] = t != i ? di * lds[o.ew + k] * lds[o.dis + t] : 0.f;
-      }
+    (void)ssptr;
+    for (int p = tid; p < ne; p += (int)blockDim.x) {  // a thread per list POSITION (the source of position p is the
+      const int k = ssperm[p];                          // source of the edge stored there)
+      const int i = ssrc[k], t = sdst[k];
+      sbdst[p] = t;
+      lds[o.bwhat + p] = t != i ? lds[o.dis + i] * lds[o.ew + k] * lds[o.dis + t] : 0.f;
     }
   }
   // (the caller's next __syncthreads() orders `what` before its first use)
@@ -391,6 +393,7 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
   const SfLayout o = sf_layout(R, Emax, H0, F, L, 1);
   const int tid = threadIdx.x;
   const int64_t nb = (int64_t)blockIdx.x * R;
+  SF_PROBE(8);
   const int32_t eb = tgt_ptr[nb];
   const int D = L * F;
   // the incoming gradient rows travel with the staging loads: issued first, parked in registers, stored behind them
@@ -402,6 +405,7 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
   const int ne = sf_stage<true>(sf_lds, o, R, Emax, H0, nb, x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, src_ptr,
                                 src_perm, loop_edge, prm, F, L);
   if (ne < 0) return;
+  SF_PROBE(9);
   const int32_t* ssrc = reinterpret_cast<const int32_t*>(sf_lds + o.src);
   const int32_t* sdst = reinterpret_cast<const int32_t*>(sf_lds + o.dst);
   const int32_t* ssptr = reinterpret_cast<const int32_t*>(sf_lds + o.sptr);
@@ -418,6 +422,7 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
     sf_layer<F>(sf_lds, o, R, l == 0 ? H0 : F, l == 0 ? sf_lds + o.x : Ycat + (l - 1) * F, l == 0 ? H0 : D,
                 sf_lds + o.act + l * R * F, Ycat + l * F, D, wl, wl + F * (l == 0 ? H0 : F));
   }
+  SF_PROBE(10);
   for (int k = tid; k < ne; k += SF_TB) sf_lds[o.dwhat + k] = 0.f;
   for (int i = tid; i < R; i += SF_TB) sf_lds[o.dwloop + i] = 0.f;
   float* G = sf_lds + o.g;
@@ -429,8 +434,10 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
   // at the top of the next iteration (or after the loop).
   float* red_db = sf_lds + o.red;
   float* red_dw = sf_lds + o.red + SF_TB;
-  int pend_off = -1, pend_n = 0, pend_parts = 0;       // dW partials waiting in red_dw
+  int pend_off = -1, pend_n = 0, pend_parts = 0;       // dW partials waiting (in red_dw or in a dead H_l)
+  const float* pend_src = red_dw;
   for (int l = L - 1; l >= 0; --l) {
+    SF_PROBE(11 + (L - 1 - l));
     const int fin = l == 0 ? H0 : F;
     const float* H = sf_lds + o.act + l * R * F;
     const float* Y = Ycat + l * F;                     // row stride D
@@ -439,7 +446,7 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
     if (pend_off >= 0)                                 // dW of the layer above
       for (int e = tid; e < pend_n; e += SF_TB) {
         float acc = 0.f;
-        for (int p2 = 0; p2 < pend_parts; ++p2) acc += red_dw[p2 * pend_n + e];
+        for (int p2 = 0; p2 < pend_parts; ++p2) acc += pend_src[p2 * pend_n + e];
         prow[pend_off + e] = acc;
       }
     // work items are (node, feature quad) / edges with 16-byte LDS accesses throughout (see sf_layer)
@@ -526,7 +533,32 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
       prow[sf_param_offset(l, H0, F) + F * fin + tid] = acc;
     }
     // dW_l = dH^T X_{l-1} (partials)   and   dX_{l-1} = dH W_l
-    {
+    if (fin == F) {
+      // work item = (fo, input quad, node part): one dH word and one 16-byte X read feed four FMAs (with one item per
+      // output word the 90-node sums were 180 4-byte LDS reads per thread)
+      // partials in H_l (R F floats): the transform of this layer has served its last reader (the coefficient gradients
+      // above) and no lower layer touches it
+      const int n_out = F * F, nq = F * FQ;
+      int parts = SF_TB / nq, cap = (R * F) / n_out;
+      parts = parts > cap ? cap : parts;
+      parts = parts > 16 ? 16 : (parts < 1 ? 1 : parts);
+      float* pdst = sf_lds + o.act + l * R * F;
+      for (int idx = tid; idx < parts * nq; idx += SF_TB) {
+        const int e = idx % nq, part = idx / nq;
+        const int fo = e / FQ, q = e - fo * FQ;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = part; i < R; i += parts) {
+          const float d = dH[i * F + fo];
+          const float4 x4 = *reinterpret_cast<const float4*>(xin + i * ldx + q * 4);
+          acc.x += d * x4.x; acc.y += d * x4.y; acc.z += d * x4.z; acc.w += d * x4.w;
+        }
+        *reinterpret_cast<float4*>(pdst + part * n_out + fo * F + q * 4) = acc;
+      }
+      pend_off = sf_param_offset(l, H0, F);
+      pend_n = n_out;
+      pend_parts = parts;
+      pend_src = pdst;
+    } else {
       const int n_out = F * fin;
       int parts = SF_TB / n_out;
       parts = parts > 16 ? 16 : (parts < 1 ? 1 : parts);
@@ -540,6 +572,7 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
       pend_off = sf_param_offset(l, H0, F);
       pend_n = n_out;
       pend_parts = parts;
+      pend_src = red_dw;
     }
     if (fin == F) {
       for (int e = tid; e < R * FQ; e += SF_TB) {      // d X_{l-1}[i, quad] = sum_fo dH[i, fo] W[fo, quad]
@@ -570,24 +603,31 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
   }
   for (int e = tid; e < pend_n; e += SF_TB) {          // dW of layer 0
     float acc = 0.f;
-    for (int p2 = 0; p2 < pend_parts; ++p2) acc += red_dw[p2 * pend_n + e];
+    for (int p2 = 0; p2 < pend_parts; ++p2) acc += pend_src[p2 * pend_n + e];
     prow[pend_off + e] = acc;
   }
+  SF_PROBE(13);
   // ---- gcn_norm backward (k_gcn_norm_bwd_deg / _edge of sgcn.hip, per graph)
   const int32_t* stptr = reinterpret_cast<const int32_t*>(sf_lds + o.tptr);
   const int32_t* stperm = reinterpret_cast<const int32_t*>(sf_lds + o.tperm);
+  // the two sums of a node — over the edges it sends (by-source list) and over those it receives (by-target list) —
+  // as products per list POSITION first (360 + 360 independent threads), then short sums of consecutive words per
+  // node: the node-per-thread form chased permutation -> edge -> endpoint through ~8 dependent LDS reads on 90 threads
+  float* v1 = sf_lds + o.v1;                            // [ne] by-source order
+  float* v2 = sf_lds + o.v2;                            // [ne] by-target order
+  const int32_t* sbdst2 = reinterpret_cast<const int32_t*>(sf_lds + o.bdst);
+  const int32_t* stsrc2 = reinterpret_cast<const int32_t*>(sf_lds + o.tsrc);
+  for (int p = tid; p < ne; p += SF_TB) {
+    const int k1 = ssperm[p], t = sbdst2[p];
+    v1[p] = t != ssrc[k1] ? sf_lds[o.dwhat + k1] * sf_lds[o.ew + k1] * sf_lds[o.dis + t] : 0.f;
+    const int k2 = stperm[p], sn = stsrc2[p];
+    v2[p] = sn != sdst[k2] ? sf_lds[o.dwhat + k2] * sf_lds[o.ew + k2] * sf_lds[o.dis + sn] : 0.f;
+  }
+  __syncthreads();
   for (int i = tid; i < R; i += SF_TB) {
     float dd = 0.f;
-    for (int p = ssptr[i]; p < ssptr[i + 1]; ++p) {
-      const int k = ssperm[p];
-      const int t = sdst[k];
-      if (t != i) dd += sf_lds[o.dwhat + k] * sf_lds[o.ew + k] * sf_lds[o.dis + t];
-    }
-    for (int p = stptr[i]; p < stptr[i + 1]; ++p) {
-      const int k = stperm[p];
-      const int s = ssrc[k];
-      if (s != i) dd += sf_lds[o.dwhat + k] * sf_lds[o.ew + k] * sf_lds[o.dis + s];
-    }
+    for (int p = ssptr[i]; p < ssptr[i + 1]; ++p) dd += v1[p];       // list order; stored loops add an exact 0
+    for (int p = stptr[i]; p < stptr[i + 1]; ++p) dd += v2[p];
     const float di = sf_lds[o.dis + i];
     dd += 2.f * sf_lds[o.dwloop + i] * sf_lds[o.wl + i] * di;
     sf_lds[o.ddeg + i] = -0.5f * di * di * di * dd;
@@ -606,6 +646,7 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
   }
   for (int e = tid; e < R * H0; e += SF_TB) dx_in[nb * H0 + e] = dX[e];
   for (int e = tid; e < P; e += SF_TB) dpar_partial[(int64_t)blockIdx.x * P + e] = prow[e];
+  SF_PROBE(14);
 }
 
 static int sf_check(const char* nm, int64_t n_graphs, int R, int max_edges, int H0, int F, int L, int backward) {

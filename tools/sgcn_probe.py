@@ -39,3 +39,23 @@ for wg in range(8):
     t = [buf[wg * 16 + i] for i in idx]
     print(f"  wg {wg}: start {(t[0] - buf[0]) * 10:6d} ns  " +
           "  ".join(f"{nm} {(t[i + 1] - t[i]) * 10:5d}" for i, nm in enumerate(names)) + f"  total {(t[-1] - t[0]) * 10} ns")
+
+# ---- backward
+dxcat = torch.randn(n, layers * f, device=dev)
+dx, dew = torch.empty_like(x), torch.empty_like(ew)
+npar = int(_lib.load().igcn_sgcn_stack_param_floats(h0, f, layers))
+dpar = torch.empty(npar, device=dev)
+scratch = torch.empty((n // rois) * npar, device=dev)
+for _ in range(5):
+    call("igcn_sgcn_stack_bwd", n // rois, rois, emax, h0, f, layers, ptr(x), ptr(ew), ptr(plan.src32), ptr(plan.dst32),
+         ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm), ptr(plan.loop_edge), wp, bp,
+         ptr(dxcat), ptr(dx), ptr(dew), ptr(dpar), ptr(scratch), stream_ptr())
+torch.cuda.synchronize()
+raw.igcn_debug_sf_probe(buf)
+names = ["staging+norm", "forward", "bwd layer 1", "bwd layer 0", "norm bwd + stores"]
+idx = [8, 9, 10, 11, 12, 13, 14]
+print("backward: stamps 8 start, 9 staged, 10 forward done, 11/12 backward layers begin, 13 norm backward begins, 14 end")
+for wg in range(8):
+    t = [buf[wg * 16 + i] for i in idx]
+    print(f"  wg {wg}: " + "  ".join(f"{i}->{j} {(t[b2 + 1] - t[b2]) * 10:5d}" for b2, (i, j) in enumerate(zip(idx[:-1], idx[1:]))) +
+          f"  total {(t[-1] - t[0]) * 10} ns")
