@@ -1923,14 +1923,14 @@ k_go_decode_bwd(int B, int Nin, int Nout, const int32_t* __restrict__ row_ptr, c
 // (G | G_self) (x) x go through LDS to the matrix cores once per 1024 nodes and leave the workgroup as ONE partial per
 // sample (the thread-per-node kernel above reduces 2*FOUT*FIN values per 256 nodes and writes 5x as many partials).
 #define GO_DBL_T 1024
-template <int FIN, int FOUT>
-__global__ void __launch_bounds__(GO_DBL_T)
+template <int FIN, int FOUT, int T>
+__global__ void __launch_bounds__(T)
 k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ t_ptr,
                     const int32_t* __restrict__ t_row, const float* __restrict__ x, const float* __restrict__ w_out,
                     const float* __restrict__ w_sout, const float* __restrict__ dy, float* __restrict__ dx,
                     float* __restrict__ partial) {
   extern __shared__ float go_dbl[];
-  constexpr int ROWS = 2 * FOUT, TP = GO_DBL_T + 4, NW = 2 * FOUT * FIN;
+  constexpr int ROWS = 2 * FOUT, TP = T + 4, NW = 2 * FOUT * FIN;
   const int NPo = (Nout + 3) & ~3;
   float* dys = go_dbl;                                  // [FOUT][NPo]
   float* inv = dys + FOUT * NPo;                        // [NPo]  1 / (row degree)
@@ -1939,13 +1939,13 @@ k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const float* dyb = dy + (int64_t)b * FOUT * Nout;
   if (NPo == Nout && ((uintptr_t)dyb & 15) == 0) {
-    for (int i = tid * 4; i < FOUT * Nout; i += GO_DBL_T * 4)
+    for (int i = tid * 4; i < FOUT * Nout; i += T * 4)
       *reinterpret_cast<float4*>(dys + i) = *reinterpret_cast<const float4*>(dyb + i);
   } else {
     for (int c = 0; c < FOUT; ++c)
-      for (int r = tid; r < Nout; r += GO_DBL_T) dys[c * NPo + r] = dyb[c * Nout + r];
+      for (int r = tid; r < Nout; r += T) dys[c * NPo + r] = dyb[c * Nout + r];
   }
-  for (int r = tid; r < Nout; r += GO_DBL_T) {
+  for (int r = tid; r < Nout; r += T) {
     const int32_t d = row_ptr[r + 1] - row_ptr[r];
     inv[r] = d > 0 ? 1.f / (float)d : 0.f;
   }
@@ -1968,7 +1968,7 @@ k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
   const float* xb = x + (int64_t)b * FIN * Nin;
   float* dxb = dx + (int64_t)b * FIN * Nin;
 #pragma unroll 1
-  for (int base = 0; base < Nin; base += GO_DBL_T) {    // block-uniform
+  for (int base = 0; base < Nin; base += T) {    // block-uniform
     const int m = base + tid;
     float G[FOUT], Gs[FOUT], xr[FIN];
 #pragma unroll
@@ -2040,7 +2040,7 @@ k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
     if (tid < NW) {
       float t = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < GO_DBL_T / 64; ++ww) t += wpart[ww * 32 + tid];
+      for (int ww = 0; ww < T / 64; ++ww) t += wpart[ww * 32 + tid];
       partial[(int64_t)b * NW + tid] = t;
     }
     return;
@@ -2056,17 +2056,22 @@ k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
       if (4 * g4 + r < ROWS) {
         float t = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < GO_DBL_T / 64; ++ww) t += wsum[(ww * 4 + r) * 64 + lane];
+        for (int ww = 0; ww < T / 64; ++ww) t += wsum[(ww * 4 + r) * 64 + lane];
         partial[(int64_t)b * NW + (4 * g4 + r) * FIN + mm] = t;
       }
   }
 }
 
-static size_t go_dbl_lds_bytes(int Nout, int fin, int fout) {
+static size_t go_dbl_lds_bytes(int Nout, int fin, int fout, int T) {
   const size_t npo = ((size_t)Nout + 3) & ~(size_t)3;
-  // few parameter-gradient products (VALU + butterfly path): 16 waves x 32 totals instead of the MFMA staging area
-  const size_t stage = 2 * fout * fin <= 32 ? (size_t)(GO_DBL_T / 64) * 32 : (size_t)(2 * fout + fin) * (GO_DBL_T + 4);
+  // few parameter-gradient products (VALU + butterfly path): one row of 32 totals per wave instead of the MFMA staging
+  const size_t stage = 2 * fout * fin <= 32 ? (size_t)(T / 64) * 32 : (size_t)(2 * fout + fin) * (T + 4);
   return ((size_t)(fout + 1) * npo + stage) * sizeof(float);
+}
+// 512 threads when the layer's INPUT nodes fit one pass of them and two workgroups then share a CU (the 400 -> 1200
+// layer: 60 KB instead of 90 KB, and no 624 idle threads), 1024 otherwise
+static int go_dbl_threads(int Nin, int Nout, int fin, int fout) {
+  return (Nin <= 512 && go_dbl_lds_bytes(Nout, fin, fout, 512) <= 80 * 1024) ? 512 : GO_DBL_T;
 }
 
 extern "C" size_t igcn_go_decode_bwd_scratch_floats(int B, int Nin, int fin, int fout) {
@@ -2080,16 +2085,20 @@ extern "C" int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, c
   IGCN_REQUIRE(B > 0 && Nin > 0 && Nout >= Nin, "go_decode_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   const int nw = 2 * fout * fin;
-  const size_t lds = go_dbl_lds_bytes(Nout, fin, fout);
+  const int TT = go_dbl_threads(Nin, Nout, fin, fout);
+  const size_t lds = go_dbl_lds_bytes(Nout, fin, fout, TT);
   if (!go_attn_force_cm() && lds <= 160 * 1024 && 2 * fout >= 4) {
-#define CALL(FI, FO)                                                                                             \
+#define CALLT(FI, FO, TV)                                                                                        \
   {                                                                                                               \
-    IGCN_ALLOW_BIG_LDS((k_go_decode_bwd_lds<FI, FO>));                                        \
-    hipLaunchKernelGGL((k_go_decode_bwd_lds<FI, FO>), dim3(B), dim3(GO_DBL_T), lds, st, Nin, Nout, row_ptr, t_ptr, \
+    IGCN_ALLOW_BIG_LDS((k_go_decode_bwd_lds<FI, FO, TV>));                                                        \
+    hipLaunchKernelGGL((k_go_decode_bwd_lds<FI, FO, TV>), dim3(B), dim3(TV), lds, st, Nin, Nout, row_ptr, t_ptr,  \
                        t_row, x, w_out, w_sout, dy, dx, scratch);                                                 \
   }
+#define CALL(FI, FO) \
+  if (TT == 512) CALLT(FI, FO, 512) else CALLT(FI, FO, 1024)
     GO_DISPATCH(fin, fout, CALL)
 #undef CALL
+#undef CALLT
     IGCN_CHECK_LAUNCH("go_decode_bwd(lds)");
     return igcn_launch_reduce_rows_final(scratch, B, nw, nw, dparams, st);
   }
