@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256)
 k_small_linear_bwd(int64_t R, int K, int C, int rows_per_block, const float* __restrict__ x,
                    const float* __restrict__ keep, const float* __restrict__ W, const float* __restrict__ dy,
                    float* __restrict__ dx, float* __restrict__ partial) {
-  __shared__ float red[256 * 4];
+  __shared__ float red[256 * 4 * SL_MAXC + 256 * SL_MAXC];
   const int kq = K / 4, q = threadIdx.x % kq, rl = threadIdx.x / kq, rpb = 256 / kq;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
   float4 w[SL_MAXC], gw[SL_MAXC];
@@ -490,26 +490,29 @@ k_small_linear_bwd(int64_t R, int K, int C, int rows_per_block, const float* __r
       if (dx) *reinterpret_cast<float4*>(dx + r * K + 4 * q) = make_float4(d.x * kv.x, d.y * kv.y, d.z * kv.z, d.w * kv.w);
     }
   }
+  // row lanes summed in order through LDS: every channel's partials staged at once (one barrier pair instead of four
+  // per channel), one thread per (channel, column) / per channel
   float* prow = partial + (int64_t)blockIdx.x * (C * K + C);
-  for (int c = 0; c < C; ++c) {                         // row lanes summed in order through LDS, one channel at a time
-    __syncthreads();
-    red[threadIdx.x * 4 + 0] = gw[c].x; red[threadIdx.x * 4 + 1] = gw[c].y;
-    red[threadIdx.x * 4 + 2] = gw[c].z; red[threadIdx.x * 4 + 3] = gw[c].w;
-    __syncthreads();
-    if (threadIdx.x < K) {
-      const int qq = threadIdx.x / 4, j = threadIdx.x % 4;
-      float t = 0.f;
-      for (int l = 0; l < rpb; ++l) t += red[(l * kq + qq) * 4 + j];
-      prow[c * K + threadIdx.x] = t;
+  float* redb = red + 256 * 4 * SL_MAXC;               // [SL_MAXC][256] bias partials
+#pragma unroll
+  for (int c = 0; c < SL_MAXC; ++c)
+    if (c < C) {
+      float* rc = red + c * 1024;
+      rc[threadIdx.x * 4 + 0] = gw[c].x; rc[threadIdx.x * 4 + 1] = gw[c].y;
+      rc[threadIdx.x * 4 + 2] = gw[c].z; rc[threadIdx.x * 4 + 3] = gw[c].w;
+      redb[c * 256 + threadIdx.x] = (q == 0 && rl < rpb) ? gb[c] : 0.f;
     }
-    __syncthreads();
-    red[threadIdx.x] = (q == 0 && rl < rpb) ? gb[c] : 0.f;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0.f;
-      for (int l = 0; l < rpb; ++l) t += red[l * kq];
-      prow[C * K + c] = t;
-    }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < C * K; idx += 256) {
+    const int c = idx / K, k = idx - c * K, qq = k / 4, j = k % 4;
+    float t = 0.f;
+    for (int l = 0; l < rpb; ++l) t += red[c * 1024 + (l * kq + qq) * 4 + j];
+    prow[c * K + k] = t;
+  }
+  if (threadIdx.x < C) {
+    float t = 0.f;
+    for (int l = 0; l < rpb; ++l) t += redb[threadIdx.x * 256 + l * kq];
+    prow[C * K + threadIdx.x] = t;
   }
 }
 
@@ -518,8 +521,11 @@ static bool small_linear_ok(int K, int C) {
   return K % 4 == 0 && kq >= 1 && kq <= 64 && (kq & (kq - 1)) == 0 && C >= 1 && C <= SL_MAXC;
 }
 
+// rows per workgroup: 64, or 16 while that leaves fewer than a few hundred workgroups (512 rows: 8 workgroups were the
+// whole launch, 10 us of latency for 130 KB)
+static int small_linear_rpb(int64_t R) { return R < 16384 ? 16 : 64; }
 extern "C" size_t igcn_small_linear_bwd_scratch_floats(int64_t R, int K, int C) {
-  return (size_t)(igcn_cdiv(R, 64) * (C * K + C) + 64);
+  return (size_t)(igcn_cdiv(R, small_linear_rpb(R)) * (C * K + C) + 64);
 }
 
 extern "C" int igcn_small_linear_fwd(int64_t R, int K, int C, const float* x, const float* keep, const float* W,
@@ -541,7 +547,7 @@ extern "C" int igcn_small_linear_bwd(int64_t R, int K, int C, const float* x, co
   IGCN_REQUIRE((((uintptr_t)x | (uintptr_t)W | (uintptr_t)dx | (uintptr_t)keep) & 15) == 0,
                "small_linear: 16-byte aligned tensors");
   hipStream_t st = (hipStream_t)stream;
-  const int rows_per_block = 64;
+  const int rows_per_block = small_linear_rpb(R);
   const int64_t nb = igcn_cdiv(R, rows_per_block);
   hipLaunchKernelGGL(k_small_linear_bwd, dim3((unsigned)nb), dim3(256), 0, st, R, K, C, rows_per_block, x, keep, W, dy,
                      dx, scratch);
