@@ -81,6 +81,26 @@ __device__ __forceinline__ float block_sum_all(float v, float* red) {
   return t;
 }
 
+// Two block-wide sums behind ONE barrier pair (same arithmetic as two block_sum_all calls); `red` >= 32 floats.
+__device__ __forceinline__ void block_sum_all2(float& a, float& b, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  __syncthreads();  // protect `red` from a previous use
+  if (lane == 0) {
+    red[w] = a;
+    red[16 + w] = b;
+  }
+  __syncthreads();
+  float ta = 0.f, tb = 0.f;
+  for (int i = 0; i < nw; ++i) {
+    ta += red[i];
+    tb += red[16 + i];
+  }
+  a = ta;
+  b = tb;
+}
+
 // Reduce NV per-thread values over the block; thread j < NV of the block ends up holding total j in
 // out[j] (written to global partial row).  red: LDS float[(blockDim/64) * NV].
 template <int NV>

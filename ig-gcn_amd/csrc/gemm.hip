@@ -322,7 +322,7 @@ static int gemm_tile_n(int64_t M, int64_t N) {
 extern "C" int igcn_gemm_f32_split_k(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K < 128) return 1;
   const int64_t tiles = igcn_cdiv(M, G_BM) * igcn_cdiv(N, gemm_tile_n(M, N));
-  if (tiles >= 192) return 1;
+  if (tiles >= 256) return 1;                      // (192..255 tiles: 2 slices — 199 one-slice workgroups left a fifth of the CUs idle)
   int64_t sk = (384 + tiles / 2) / tiles;
   if (sk > K / G_BK) sk = K / G_BK;
   return (int)(sk < 1 ? 1 : sk);

@@ -522,7 +522,9 @@ def test_node_linear_bn(ops, bsz, f, n, d, training, groups):
 
 
 @pytest.mark.parametrize("bsz,c,training,relu,groups", [(32, 32, True, True, 1), (512, 32, True, True, 2),
-                                                         (10, 7, True, False, 2), (9, 5, False, True, 1)])
+                                                         (10, 7, True, False, 2), (9, 5, False, True, 1),
+                                                      # general kernels: three groups / 1100 samples per group
+                                                      (96, 8, True, True, 3), (2200, 4, True, False, 2)])
 def test_batchnorm1d_grouped(ops, bsz, c, training, relu, groups):
     rng = np.random.default_rng(bsz + c)
     x = torch.from_numpy(rng.standard_normal((bsz, c)) * 1.5 + 0.2).float()
