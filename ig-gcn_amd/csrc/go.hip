@@ -644,33 +644,44 @@ k_go_attn_bwd_stats(int B, int N, const int32_t* __restrict__ row_ptr, const int
 // 8-XCD part 512 arrivals at one ticket serialise at about a microsecond each — 35 -> 600 us — whether the cost is
 // the release fence (an L2 write-back per arrival) or the compare-and-swap retries; per-tile tickets in the split-K
 // GEMMs cost more per product (+8 us) than the reduction launch they replaced.  Not kept.]
+// One workgroup of FIN waves per OUTPUT (grid = 2 FOUT FIN + 3 FOUT): a weight-gradient output is one entry of G, an
+// attention-vector output the dot product of a weight row with FIN entries — wave d sums entry d's partials (lanes
+// stride them, fixed tree).  [One 1024-thread workgroup walking all 65 entries, 4-5 per wave: 6.4 us of latency.]
 #define GO_FIN_T 1024
 template <int FIN, int FOUT>
-__global__ void __launch_bounds__(GO_FIN_T)
+__global__ void __launch_bounds__(64 * FIN)
 k_go_attn_bwd_finish(const float* __restrict__ gpart, int64_t parts, const float* __restrict__ w_inc,
                      const float* __restrict__ w_s, float* __restrict__ dparams) {
-  constexpr int ROWS = 2 * FOUT + 3, NE = ROWS * FIN, KW = FOUT * FIN;
-  __shared__ float G[NE];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int e = w; e < NE; e += GO_FIN_T / 64) {
+  constexpr int KW = FOUT * FIN;
+  __shared__ float G[FIN];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = blockIdx.x;
+  int e = -1;                                           // entry this wave sums
+  if (j < 2 * KW) {
+    if (w == 0) e = j;
+  } else {
+    const int which = (j - 2 * KW) / FOUT;              // 0 -> a1, 1 -> a2, 2 -> a_s
+    e = (2 * FOUT + which) * FIN + w;
+  }
+  if (e >= 0) {
     const float* src = gpart + (int64_t)e * parts;
     float t = 0.f;
 #pragma unroll 4
     for (int64_t i = lane; i < parts; i += 64) t += src[i];
     t = wave_sum_all(t);
-    if (lane == 0) G[e] = t;
+    if (lane == 0) G[w] = t;
   }
   __syncthreads();
-  const int j = threadIdx.x;
-  if (j < 2 * KW) {
-    dparams[j] = G[j];
-  } else if (j < 2 * KW + 3 * FOUT) {
-    const int q = j - 2 * KW, which = q / FOUT, c = q % FOUT;       // which: 0 -> a1, 1 -> a2, 2 -> a_s
-    const float* wm = which == 2 ? w_s : w_inc;
-    float t = 0.f;
+  if (threadIdx.x == 0) {
+    if (j < 2 * KW) {
+      dparams[j] = G[0];
+    } else {
+      const int q = j - 2 * KW, which = q / FOUT, c = q % FOUT;
+      const float* wm = which == 2 ? w_s : w_inc;
+      float t = 0.f;
 #pragma unroll
-    for (int d = 0; d < FIN; ++d) t += wm[c * FIN + d] * G[(2 * FOUT + which) * FIN + d];
-    dparams[j] = t;
+      for (int d = 0; d < FIN; ++d) t += wm[c * FIN + d] * G[d];
+      dparams[j] = t;
+    }
   }
 }
 
@@ -1286,7 +1297,7 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
 #undef CALLLI
     IGCN_CHECK_LAUNCH("go_attn_bwd(lds)");
 #define CALLF(FI, FO) \
-  hipLaunchKernelGGL((k_go_attn_bwd_finish<FI, FO>), dim3(1), dim3(GO_FIN_T), 0, st, gpart, (int64_t)B, w_inc, w_s, dparams)
+  hipLaunchKernelGGL((k_go_attn_bwd_finish<FI, FO>), dim3(2 * FO * FI + 3 * FO), dim3(64 * FI), 0, st, gpart, (int64_t)B, w_inc, w_s, dparams)
     GO_DISPATCH(fin, fout, CALLF)
 #undef CALLF
     IGCN_CHECK_LAUNCH("go_attn_bwd_finish");
@@ -1305,7 +1316,7 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
 #undef CALL
   IGCN_CHECK_LAUNCH("go_attn_bwd");
 #define CALLF(FI, FO) \
-  hipLaunchKernelGGL((k_go_attn_bwd_finish<FI, FO>), dim3(1), dim3(GO_FIN_T), 0, st, gpart, parts, w_inc, w_s, dparams)
+  hipLaunchKernelGGL((k_go_attn_bwd_finish<FI, FO>), dim3(2 * FO * FI + 3 * FO), dim3(64 * FI), 0, st, gpart, parts, w_inc, w_s, dparams)
   GO_DISPATCH(fin, fout, CALLF)
 #undef CALLF
   IGCN_CHECK_LAUNCH("go_attn_bwd_finish");
