@@ -419,6 +419,10 @@ def cpu_baseline(go, wl, seconds=20.0):
 
 
 def main():
+    # the image exports NCCL_DEBUG=VERSION: RCCL then prints a five-line banner on STDOUT at communicator creation —
+    # in front of the one JSON line this script owes its caller
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        del os.environ["NCCL_DEBUG"]
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
