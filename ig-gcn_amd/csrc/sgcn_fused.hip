@@ -539,10 +539,16 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
       // partials in H_l (R F floats): the transform of this layer has served its last reader (the coefficient gradients
       // above) and no lower layer touches it
       const int n_out = F * F, nq = F * FQ;
-      int parts = SF_TB / nq, cap = (R * F) / n_out;
-      parts = parts > cap ? cap : parts;
-      parts = parts > 16 ? 16 : (parts < 1 ? 1 : parts);
+      int parts = SF_TB / nq;
+      const int cap = (R * F) / n_out;                  // whole [F, F] partials that fit H_l
       float* pdst = sf_lds + o.act + l * R * F;
+      if (cap < 1) {                                    // fewer nodes than features: one partial, in `red` (>= F F floats)
+        pdst = red_dw;
+        parts = 1;
+      } else {
+        parts = parts > cap ? cap : parts;
+      }
+      parts = parts > 16 ? 16 : (parts < 1 ? 1 : parts);
       for (int idx = tid; idx < parts * nq; idx += SF_TB) {
         const int e = idx % nq, part = idx / nq;
         const int fo = e / FQ, q = e - fo * FQ;

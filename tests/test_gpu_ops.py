@@ -938,7 +938,10 @@ def test_graph_pool_mean_max_add(ops, g, r, d, seed):
 # ------------------------------------------------------------------------------------------------ fused SGCN stack
 @pytest.mark.parametrize("g,r,h0,f,layers,deg,loops", [(4, 90, 3, 16, 2, 3, "all"), (3, 10, 3, 4, 2, 3, "some"),
                                                        (2, 33, 5, 8, 3, 6, "none"), (5, 17, 2, 32, 1, 4, "multi"),
-                                                       (2, 90, 3, 16, 4, 5, "some")])
+                                                       (2, 90, 3, 16, 4, 5, "some"),
+                                                       # fewer nodes than features: the weight-gradient partials of a
+                                                       # layer do not fit its (dead) transform buffer
+                                                       (3, 9, 3, 16, 2, 3, "some"), (2, 20, 3, 32, 3, 4, "all")])
 def test_fused_sgcn_stack_fwd_bwd(ops, g, r, h0, f, layers, deg, loops):
     """igcn_sgcn_stack_* (gcn_norm + L x GCNConv + ReLU + concatenation, LDS-resident, one workgroup per graph) against
     the fp64 PyG restatement: outputs, dx, d(edge weight), every dW / db.  Stored self-loops (kept weight), nodes
