@@ -70,10 +70,6 @@ SIGNATURES = {
     "igcn_attn_core_fwd": (I, [I, I, I, I, I, P, P, P, P, P]),
     "igcn_attn_core_bwd_scratch_floats": (Z, [I, I, I]),
     "igcn_attn_core_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
-    "igcn_xattn_lds_bytes": (Z, [I, I, I, I, I]),
-    "igcn_xattn_param_floats": (Z, [I]),
-    "igcn_xattn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
-    "igcn_xattn_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_spmm_fwd": (I, [I, I, I, I, L, P, P, P, P, P, P]),
     "igcn_spmm_bwd_scratch_floats": (Z, [I, I, I, I, L]),
     "igcn_spmm_bwd": (I, [I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P]),

@@ -1286,46 +1286,8 @@ class LossHead(torch.autograd.Function):
 
 
 # =================================================================================================
-# Fused cross-attention
+# Cross-attention: projections + attention core
 # =================================================================================================
-def xattn_supported(d, h, lq, lk):
-    lib = _lib.load()
-    return bool(lib.igcn_xattn_lds_bytes(d, h, lq, lk, 0)) and bool(lib.igcn_xattn_lds_bytes(d, h, lq, lk, 1))
-
-
-class CrossAttention(torch.autograd.Function):
-    """relu(MultiheadAttention(D,H)(xq, mem, mem)) in one kernel per direction (sgcn_img_snp.py:239-242)."""
-
-    @staticmethod
-    def forward(ctx, xq, mem, w_in, b_in, w_out, b_out, heads):
-        xq, mem, w_in, b_in, w_out, b_out = (_f32(t) for t in (xq, mem, w_in, b_in, w_out, b_out))
-        b, lq, d = xq.shape
-        lk = mem.shape[1]
-        out, o_save = torch.empty_like(xq), torch.empty_like(xq)
-        lse = torch.empty(b, heads, lq, dtype=torch.float32, device=xq.device)
-        call("igcn_xattn_fwd", b, d, heads, lq, lk, ptr(xq), ptr(mem), ptr(w_in), ptr(b_in), ptr(w_out), ptr(b_out),
-             ptr(out), ptr(o_save), ptr(lse), stream_ptr())
-        ctx.save_for_backward(xq, mem, w_in, b_in, w_out, out, o_save, lse)
-        ctx.heads = heads
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        xq, mem, w_in, b_in, w_out, out, o_save, lse = ctx.saved_tensors
-        dout = _f32(dout)
-        b, lq, d = xq.shape
-        lk = mem.shape[1]
-        lib = _lib.load()
-        pw = int(lib.igcn_xattn_param_floats(d))
-        dxq, dmem = torch.empty_like(xq), torch.empty_like(mem)
-        dpar = torch.empty(pw, dtype=torch.float32, device=xq.device)
-        scratch = torch.empty(b * pw, dtype=torch.float32, device=xq.device)
-        call("igcn_xattn_bwd", b, d, ctx.heads, lq, lk, ptr(xq), ptr(mem), ptr(w_in), ptr(b_in), ptr(w_out), ptr(out),
-             ptr(o_save), ptr(lse), ptr(dout), ptr(dxq), ptr(dmem), ptr(dpar), ptr(scratch), stream_ptr())
-        o0, o1, o2 = 3 * d * d, 3 * d * d + 3 * d, 3 * d * d + 3 * d + d * d
-        return (dxq, dmem, dpar[:o0].view(3 * d, d), dpar[o0:o1], dpar[o1:o2].view(d, d), dpar[o2:], None)
-
-
 def attn_core_supported(d, h, lq, lk):
     lib = _lib.load()
     return bool(lib.igcn_attn_core_lds_bytes(d, h, lq, lk, 0)) and bool(lib.igcn_attn_core_lds_bytes(d, h, lq, lk, 1))

@@ -151,9 +151,6 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         # one LDS-resident kernel per direction for the whole SGCN stack when the batch allows it (small uniform
         # graphs); IGCN_NO_FUSED_SGCN=1 keeps the per-layer kernels (A/B runs, tests of the unfused path)
         self.fused_sgcn_stack = os.environ.get("IGCN_NO_FUSED_SGCN", "0") != "1"
-        # igcn_xattn_* (one fused all-in-LDS VALU kernel per direction) is exact but slower than MFMA-GEMM
-        # projections + the matrix-core attention core (igcn_attn_core_*) at B=256 (profiles/): opt-in
-        self.fused_cross_attention = os.environ.get("IGCN_FUSED_XATTN", "0") == "1"
 
     def reset_parameters(self):
         self.conv1.reset_parameters()
@@ -225,14 +222,11 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         """relu(nn.MultiheadAttention(D, 2, batch_first=True)(query, memory, memory)[0]) (:240-241) with the
         parameters of ``self.multihead_attn``: MFMA-GEMM projections (key and value as one GEMM) around the attention
         core igcn_attn_core_*, which works on the projection outputs in place (head_dim 16: matrix cores); shapes the
-        core does not cover use a batched GEMM + softmax composite.  ``fused_cross_attention`` selects the
-        one-kernel-per-direction variant igcn_xattn_* instead."""
+        core does not cover use a batched GEMM + softmax composite."""
         mha = self.multihead_attn
         d, h = mha.embed_dim, mha.num_heads
         b, lq, lk = query.shape[0], query.shape[1], memory.shape[1]
         w, bias = mha.in_proj_weight, mha.in_proj_bias
-        if self.fused_cross_attention and ops.xattn_supported(d, h, lq, lk):
-            return ops.CrossAttention.apply(query, memory, w, bias, mha.out_proj.weight, mha.out_proj.bias, h)
         bf = self.bf16_transforms
         if ops.attn_core_supported(d, h, lq, lk):
             # projections + core as one autograd node: parameters taken whole (leaves: ONE [3D, D] / [3D] gradient,

@@ -387,26 +387,6 @@ int igcn_attn_core_bwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Fused cross-attention fusion block — kernel/sgcn_img_snp.py:46,239-242:
- *   out = relu( nn.MultiheadAttention(D, H, batch_first=True)(xq, mem, mem)[0] )
- * xq [B,Lq,D] (dense-batched SGCN features), mem [B,Lk,D] (GO attention read-out); w_in [3D,D], b_in [3D] =
- * in_proj_weight/bias (q,k,v rows), w_out [D,D], b_out [D] = out_proj.  One workgroup per sample; the K/V
- * projections live only in LDS.  Saves o_save [B,Lq,D] (concatenated head outputs) and lse [B,H,Lq].
- * igcn_xattn_lds_bytes returns the dynamic LDS the shape needs, or 0 when the fused kernel does not cover it
- * (head_dim in {4,6,10,15,16,24}, H = 2, Lq <= 512, Lk <= 1024, LDS <= 160 KB).
- * Backward: dxq, dmem, dparams = (dW_in, db_in, dW_out, db_out) flat; scratch: float[B * igcn_xattn_param_floats(D)].
- */
-size_t igcn_xattn_lds_bytes(int D, int H, int Lq, int Lk, int backward);
-size_t igcn_xattn_param_floats(int D);
-int igcn_xattn_fwd(int B, int D, int H, int Lq, int Lk, const float* xq, const float* mem,
-                   const float* w_in, const float* b_in, const float* w_out, const float* b_out,
-                   float* out, float* o_save, float* lse, void* stream);
-int igcn_xattn_bwd(int B, int D, int H, int Lq, int Lk, const float* xq, const float* mem,
-                   const float* w_in, const float* b_in, const float* w_out,
-                   const float* out, const float* o_save, const float* lse, const float* dout,
-                   float* dxq, float* dmem, float* dparams, float* scratch, void* stream);
-
-/* ------------------------------------------------------------------------------------------------
  * Sparse SNP<->GO maps with learnable non-zeros — gene encoding go_model.py:208-215 (C=2 channels,
  * rows = GO nodes, cols = SNPs) and gene decoding :281-282 (C=1, rows = SNPs, cols = GO nodes):
  *   y[b,c,i] = sum_{k in row i} val[c,k] * x[b, col[k]]          x [B,J], y [B,C,I], val [C,nnz]

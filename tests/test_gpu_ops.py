@@ -603,29 +603,6 @@ def test_gram_losses(ops, bsz, rd, soft):
     assert_matches(g, g_ref.numpy(), 2e-4, "ds")
 
 
-@pytest.mark.parametrize("bsz,lq,lk,d", [(3, 10, 9, 8), (4, 90, 400, 32), (2, 12, 23, 12), (5, 90, 45, 32)])
-def test_fused_cross_attention(ops, bsz, lq, lk, d):
-    rng = np.random.default_rng(lq + lk)
-    mha = torch.nn.MultiheadAttention(d, 2, batch_first=True).double()
-    with torch.no_grad():
-        for p in mha.parameters():
-            p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape)) * 0.4))
-    xq = torch.from_numpy(rng.standard_normal((bsz, lq, d))).float()
-    mem = torch.from_numpy(rng.standard_normal((bsz, lk, d))).float()
-    cot = torch.from_numpy(rng.standard_normal((bsz, lq, d))).float()
-    ref_in = [xq.double().requires_grad_(True), mem.double().requires_grad_(True)]
-    out_ref = torch.relu(mha(ref_in[0], ref_in[1], ref_in[1], need_weights=False)[0])
-    pars = [mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias]
-    g_ref = torch.autograd.grad((out_ref * cot.double()).sum(), ref_in + pars)
-    assert ops.xattn_supported(d, 2, lq, lk)
-    dev = [t.cuda().requires_grad_(True) for t in (xq, mem)] + [p.detach().float().cuda().requires_grad_(True) for p in pars]
-    out = ops.CrossAttention.apply(*dev, 2)
-    g = torch.autograd.grad((out * cot.cuda()).sum(), dev)
-    assert_matches(out, out_ref.detach().numpy(), TOL, "out")
-    for got, want, nm in zip(g, g_ref, ("dxq", "dmem", "dW_in", "db_in", "dW_out", "db_out")):
-        assert_matches(got, want.numpy(), 2e-4, nm, floor=1e-6)
-
-
 def test_gram_losses_grouped(ops):
     from oracle import sgcn_img_snp as OS
     rng = np.random.default_rng(1)
@@ -877,6 +854,15 @@ pd = [torch.from_numpy(rng.standard_normal((2, 5))).float().cuda().requires_grad
 yd = ops.GoDecode.apply(xd, pd[0], pd[1], dcsr)
 cd = torch.from_numpy(rng.standard_normal(tuple(yd.shape))).float().cuda()
 gd = torch.autograd.grad((yd * cd).sum(), [xd] + pd)
+# SNP -> GO map (C = 2) on the CSR kernels (LDS-tiled by default, the first kernels under IGCN_SPMM_NO_LDS=1)
+ops.SparseMap.DENSE_LIMIT = 0
+gidx = torch.from_numpy((rng.random((n, 54)) < 0.06).astype(np.float32)).to_sparse().coalesce().indices()
+gcsr = ops.Csr(gidx[0], gidx[1], n, 54, "cuda")
+xs = torch.from_numpy(rng.random((5, 54))).float().cuda().requires_grad_(True)
+vs = torch.from_numpy(rng.standard_normal((2, gidx.shape[1]))).float().cuda().requires_grad_(True)
+ys = ops.SparseMap.apply(xs, gcsr, vs)
+cs = torch.from_numpy(rng.standard_normal(tuple(ys.shape))).float().cuda()
+gs = torch.autograd.grad((ys * cs).sum(), [xs, vs])
 # attention core, head_dim 16
 q = torch.from_numpy(rng.standard_normal((3, 40, 32))).float().cuda().requires_grad_(True)
 kv = torch.from_numpy(rng.standard_normal((3, 70, 64))).float().cuda().requires_grad_(True)
@@ -885,15 +871,17 @@ co = torch.from_numpy(rng.standard_normal((3, 40, 32))).float().cuda()
 ga = torch.autograd.grad((o * co).sum(), [q, kv])
 np.savez(sys.argv[2], y=y.detach().cpu().numpy(), o=o.detach().cpu().numpy(), yd=yd.detach().cpu().numpy(),
          **{f"g{i}": t.cpu().numpy() for i, t in enumerate(g)}, **{f"a{i}": t.cpu().numpy() for i, t in enumerate(ga)},
-         **{f"d{i}": t.cpu().numpy() for i, t in enumerate(gd)})
+         **{f"d{i}": t.cpu().numpy() for i, t in enumerate(gd)}, ys=ys.detach().cpu().numpy(),
+         **{f"s{i}": t.cpu().numpy() for i, t in enumerate(gs)})
 """
 
 
 def test_alternative_kernel_variants_agree(tmp_path):
     """The A/B switches stay honest: the global-memory GO kernels (attention backward, decoder forward / backward:
-    IGCN_GO_ATTN_CM=1 — also the fallbacks for hierarchies too large for LDS) and the VALU attention core
-    (IGCN_ATTN_VALU=1) give the numbers of the default LDS-resident / matrix-core kernels.  The switches are read
-    once per process, so each variant runs in a short child process (one at a time)."""
+    IGCN_GO_ATTN_CM=1 — also the fallbacks for hierarchies too large for LDS), the first CSR map kernels
+    (IGCN_SPMM_NO_LDS=1 — the fallback for structures whose operand rows do not fit LDS) give the numbers of the default
+    LDS-resident kernels.  The switches are read once per process, so each variant runs in a short child process (one
+    at a time)."""
     import os
     import subprocess
     import sys
@@ -901,7 +889,7 @@ def test_alternative_kernel_variants_agree(tmp_path):
     script = tmp_path / "ab.py"
     script.write_text(_AB_SCRIPT)
     outs = {}
-    for tag, env in (("default", {}), ("alt", {"IGCN_GO_ATTN_CM": "1", "IGCN_ATTN_VALU": "1"})):
+    for tag, env in (("default", {}), ("alt", {"IGCN_GO_ATTN_CM": "1", "IGCN_SPMM_NO_LDS": "1"})):
         out = tmp_path / f"{tag}.npz"
         r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env={**os.environ, **env},
                            capture_output=True, text=True, timeout=300)
