@@ -1,10 +1,10 @@
 // Dense feature transforms on the CDNA4 matrix cores: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).
 //   C[m,n] = act( sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] + bias[n] )
 // One 256-thread workgroup = 4 waves; wave w owns rows [16w,16w+16) of a 64 x BN tile and keeps BN/16
-// 16x16 accumulators.  A/B tiles are staged through LDS in BK=16 slices (row pad +1 => conflict-free
-// operand reads).  The staging thread->element map follows whichever
-// operand axis is contiguous in memory, so NT (forward), NN (input gradient) and TN (weight gradient)
-// all read global memory coalesced.  Long-K / few-tile problems are split over gridDim.z into partial
+// 16x16 accumulators.  A/B tiles are staged through LDS in 32-deep K slices (padded rows => conflict-free
+// operand reads), one or two slices ahead in registers.  The staging thread->element map follows whichever
+// operand axis is contiguous in memory (a compile-time property of the instantiation), so NT (forward), NN (input
+// gradient) and TN (weight gradient) all read global memory coalesced.  Long-K / few-tile problems are split over gridDim.z into partial
 // slabs that a second kernel sums in slab order (deterministic).
 #include "common.h"
 
@@ -12,9 +12,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define G_BM 64
 #define G_BK 32
-#define G_LD (G_BK + 2)   // row stride 34: MFMA operand reads [m][4ks + (lane>>4)] hit 32 distinct banks per half-wave
 
-// One operand tile (ROWS x G_BK) global -> registers -> LDS.  `rfast` = the row (m or n) axis is the contiguous
+// One operand tile (ROWS x G_BK) of k_gemm_bf16, global -> registers (-> bf16 -> LDS).  `rfast` = the row (m or n) axis is the contiguous
 // one in memory, else the k axis is.  VW = floats per load along the contiguous axis: 4 (16-byte loads), 2 (8-byte
 // loads: row strides such as 54 or 3182 floats) — the host guarantees alignment and that no vector straddles the
 // matrix edge — or 1 (scalar loads with per-element bounds checks).
@@ -22,56 +21,114 @@ template <int ROWS, int VW>
 struct TileLoader {
   static constexpr int NU = (ROWS * G_BK / VW + 255) / 256;   // vectors per thread
   float v[NU][VW];
+  unsigned ok;                                                // bit i: vector i lies inside the matrix and the K slice
 
+  // Branch-free on purpose: every thread issues every load (out-of-range vectors read the matrix origin, a broadcast
+  // hit) and the zeroing happens at store time.  With the loads under divergent or uniform branches the compiler can no
+  // longer count how many are outstanding and waits for ALL of them before the first LDS store — which serialises a
+  // multi-stage pipeline back into one round trip per K step.
   __device__ __forceinline__ void load(const float* __restrict__ P, int64_t srow, int64_t sk, bool rfast, int64_t r0,
                                        int64_t rows, int64_t kb, int64_t k_end) {
+    const int tid = threadIdx.x;
+    ok = 0;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int f = tid + i * 256;
+      const int r = rfast ? (f % (ROWS / VW)) * VW : f / (G_BK / VW);
+      const int k = rfast ? f / (ROWS / VW) : (f % (G_BK / VW)) * VW;
+      const int64_t gr = r0 + r, gk = kb + k;
+      const bool in = f < ROWS * G_BK / VW && gr < rows && gk < k_end;
+      ok |= in ? 1u << i : 0u;
+      const float* src = in ? P + gr * srow + gk * sk : P;
+      if constexpr (VW == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src);
+        v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+      } else if constexpr (VW == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(src);
+        v[i][0] = t.x; v[i][1] = t.y;
+      } else {
+        v[i][0] = *src;
+      }
+    }
+  }
+};
+
+#ifdef G_PROBE_ON
+__device__ long long g_probe_buf[8 * 8];
+#define G_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z < 8 ) { g_probe_buf[blockIdx.z * 8 + (i)] = wall_clock64(); g_probe_buf[blockIdx.z * 8 + 4 + (i)] = clock64(); } } while (0)
+extern "C" int igcn_debug_gemm_probe(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe_buf), sizeof(long long) * 64);
+}
+#define G_ACC(j) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); __builtin_amdgcn_sched_barrier(0); g_acc[j] += t_ - g_t; g_t = t_; } while (0)
+#else
+#define G_PROBE(i)
+#define G_ACC(j)
+#endif
+
+// 16 zero bytes: the source of every out-of-range vector (beyond the matrix edge or the K slice).  Loading zeros
+// instead of masking afterwards keeps the loads unconditional AND the LDS stores free of selects.
+__device__ float4 g_zero_src = {0.f, 0.f, 0.f, 0.f};
+
+// One operand tile (ROWS x G_BK) of k_gemm_f32, global -> registers -> LDS, layout known at compile time.
+// RF = the row (m or n) axis is the contiguous one in memory, else the k axis is.  LDS row stride: 36 floats for a
+// k-fast operand (16-byte aligned rows: one ds_write_b128 per vector; the operand reads [row][4 ks + (lane >> 4)] stay
+// conflict-free: 36 r mod 64 visits every multiple of 4 once over 16 rows), 34 for a row-fast one (scalar stores).
+template <int ROWS, int VW, bool RF>
+struct Stage {
+  static constexpr int NU = (ROWS * G_BK / VW + 255) / 256;   // vectors per thread
+  static constexpr int LD = RF ? G_BK + 2 : G_BK + 4;
+  float v[NU][VW];
+
+  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t srow, int64_t sk, int64_t r0, int64_t rows,
+                                       int64_t kb, int64_t k_end) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       const int f = tid + i * 256;
-#pragma unroll
-      for (int j = 0; j < VW; ++j) v[i][j] = 0.f;
-      if (f < ROWS * G_BK / VW) {
-        const int r = rfast ? (f % (ROWS / VW)) * VW : f / (G_BK / VW);
-        const int k = rfast ? f / (ROWS / VW) : (f % (G_BK / VW)) * VW;
-        const int64_t gr = r0 + r, gk = kb + k;
-        if (gr < rows && gk < k_end) {
-          const float* src = P + gr * srow + gk * sk;
-          if constexpr (VW == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(src);
-            v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
-          } else if constexpr (VW == 2) {
-            const float2 t = *reinterpret_cast<const float2*>(src);
-            v[i][0] = t.x; v[i][1] = t.y;
-          } else {
-            v[i][0] = *src;
-          }
-        }
+      const int r = RF ? (f % (ROWS / VW)) * VW : f / (G_BK / VW);
+      const int k = RF ? f / (ROWS / VW) : (f % (G_BK / VW)) * VW;
+      const int64_t gr = r0 + r, gk = kb + k;
+      const bool in = f < ROWS * G_BK / VW && gr < rows && gk < k_end;
+      const float* src = in ? P + gr * srow + gk * sk : reinterpret_cast<const float*>(&g_zero_src);
+      if constexpr (VW == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src);
+        v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+      } else if constexpr (VW == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(src);
+        v[i][0] = t.x; v[i][1] = t.y;
+      } else {
+        v[i][0] = *src;
       }
     }
   }
 
-  __device__ __forceinline__ void store(float (*T)[G_LD], bool rfast) const {
+  __device__ __forceinline__ void store(float (*T)[LD]) const {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       const int f = tid + i * 256;
       if (f < ROWS * G_BK / VW) {
-        if (rfast) {
+        if constexpr (RF) {
           const int r = (f % (ROWS / VW)) * VW, k = f / (ROWS / VW);
 #pragma unroll
           for (int j = 0; j < VW; ++j) T[r + j][k] = v[i][j];
         } else {
           const int r = f / (G_BK / VW), k = (f % (G_BK / VW)) * VW;
+          if constexpr (VW == 4) {
+            *reinterpret_cast<float4*>(&T[r][k]) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+          } else {
 #pragma unroll
-          for (int j = 0; j < VW; ++j) T[r][k + j] = v[i][j];
+            for (int j = 0; j < VW; ++j) T[r][k + j] = v[i][j];
+          }
         }
       }
     }
   }
 };
 
-template <int BN, int VW>
+// PF = K-tiles in flight in registers ahead of the one in LDS (1 for products of one or two K steps — the short-K
+// streaming products, where registers are better spent on more workgroups per CU — 2 otherwise).
+template <int BN, int VW, int PF, bool ARF, bool BRF>
 __global__ void __launch_bounds__(256)
 k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,
            const float* __restrict__ B, int64_t sbn, int64_t sbk, const float* __restrict__ bias,
@@ -79,63 +136,117 @@ k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t
            int64_t a_zs, int64_t b_zs, int zsplit) {
   // dynamic LDS: one buffer per operand when the workgroup has a single K step (short-K streaming products: more
   // workgroups per CU hide each other's load latency), two otherwise
-  extern __shared__ float g_lds[];
+  extern __shared__ __attribute__((aligned(16))) float g_lds[];
+  typedef Stage<G_BM, VW, ARF> StA;
+  typedef Stage<BN, VW, BRF> StB;
   const int nbuf = k_per_split <= G_BK ? 1 : 2;
-  float (*As)[G_BM][G_LD] = reinterpret_cast<float (*)[G_BM][G_LD]>(g_lds);
-  float (*Bs)[BN][G_LD] = reinterpret_cast<float (*)[BN][G_LD]>(g_lds + (size_t)nbuf * G_BM * G_LD);
+  float (*As)[G_BM][StA::LD] = reinterpret_cast<float (*)[G_BM][StA::LD]>(g_lds);
+  float (*Bs)[BN][StB::LD] = reinterpret_cast<float (*)[BN][StB::LD]>(g_lds + (size_t)nbuf * G_BM * StA::LD);
   constexpr int NT = BN / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * G_BM, n0 = (int64_t)blockIdx.y * BN;
-  // blockIdx.z = (batch index) * zsplit + (K slice): K slices of one product (a_zs == b_zs == 0) and/or a batch
+  // (an XCD-aware remap of the launch order — each L2 serving one K slice / one run of N tiles — measured 0.5 % slower
+  // in the step: these operands are a few MB and the Infinity Cache already absorbs the re-reads)
+  const dim3 tile = blockIdx;
+  const int64_t m0 = (int64_t)tile.x * G_BM, n0 = (int64_t)tile.y * BN;
+  // tile.z = (batch index) * zsplit + (K slice): K slices of one product (a_zs == b_zs == 0) and/or a batch
   // of independent products (a_zs/b_zs = element offsets per batch) whose slabs are all summed afterwards
-  const int64_t bidx = blockIdx.z / zsplit, ks_id = blockIdx.z % zsplit;
+  const int64_t bidx = tile.z / zsplit, ks_id = tile.z % zsplit;
   const int64_t k_begin = ks_id * k_per_split;
   const int64_t k_end = k_begin + k_per_split < K ? k_begin + k_per_split : K;
   A += bidx * a_zs;
   B += bidx * b_zs;
-  const bool a_rfast = (sam == 1 && sak != 1), b_rfast = (sbn == 1 && sbk != 1);
 
+  G_PROBE(0);
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // software pipeline: the global loads of K-tile i+1 are in flight while the matrix cores work on tile i
-  TileLoader<G_BM, VW> la;
-  TileLoader<BN, VW> lb;
-  if (k_begin < k_end) {
-    la.load(A, sam, sak, a_rfast, m0, M, k_begin, k_end);
-    lb.load(B, sbn, sbk, b_rfast, n0, N, k_begin, k_end);
-    la.store(As[0], a_rfast);
-    lb.store(Bs[0], b_rfast);
+  // software pipeline, PF tiles deep: while the matrix cores work on K-tile i (in LDS), the global loads of tiles
+  // i+1 .. i+PF are in flight in registers.  Every load is unconditional (see g_zero_src): with loads under divergent
+  // or uniform branches the compiler can no longer count how many are outstanding and waits for ALL of them before
+  // the first LDS store, which turns a multi-stage pipeline back into one round trip per K step.
+  StA la[PF];
+  StB lb[PF];
+  la[0].load(A, sam, sak, m0, M, k_begin, k_end);
+  lb[0].load(B, sbn, sbk, n0, N, k_begin, k_end);
+  la[0].store(As[0]);
+  lb[0].store(Bs[0]);
+  const int nsteps = (int)((k_end - k_begin + G_BK - 1) / G_BK);
+  if (nsteps > 1) {                                    // block-uniform; ahead of the loop, so no path skips loads in it
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const int64_t kk = k_begin + (int64_t)(s + 1) * G_BK;
+      la[s].load(A, sam, sak, m0, M, kk, k_end);
+      lb[s].load(B, sbn, sbk, n0, N, kk, k_end);
+    }
   }
   __syncthreads();
+  G_PROBE(1);
   int buf = 0;
-  for (int64_t kb = k_begin; kb < k_end; kb += G_BK) {
-    const bool more = kb + G_BK < k_end;
-    if (more) {
-      la.load(A, sam, sak, a_rfast, m0, M, kb + G_BK, k_end);
-      lb.load(B, sbn, sbk, b_rfast, n0, N, kb + G_BK, k_end);
-    }
+  // one K step of the tile product.  All LDS reads of the step are issued first and the matrix instructions follow
+  // back to back: with one wave per SIMD there is nobody else to cover a read -> multiply -> read -> multiply chain.
+  auto mma_tile = [&](int bsel) {
+    float af[G_BK / 4], bf[NT][G_BK / 4];
 #pragma unroll
     for (int ks = 0; ks < G_BK / 4; ++ks) {
-      const float a = As[buf][w * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+      af[ks] = As[bsel][w * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bf[t][ks] = Bs[bsel][t * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // the scheduler would otherwise re-interleave reads and multiplies
+#pragma unroll
+    for (int ks = 0; ks < G_BK / 4; ++ks) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const float b = Bs[buf][t * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
         // operands swapped: the accumulator holds the TRANSPOSED tile, i.e. lane (g = lane>>4, j = lane&15) owns
         // C[m0 + 16 w + j][n0 + 16 t + 4 g + r], r = 0..3 — four consecutive columns of one row = one 16-byte store
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t][ks], af[ks], acc[t], 0, 0, 0);
       }
     }
-    if (more) {
-      la.store(As[buf ^ 1], a_rfast);
-      lb.store(Bs[buf ^ 1], b_rfast);
+  };
+  // The K loop runs PF steps per trip so that every register stage has a compile-time index (moving an in-flight
+  // stage into another register would wait for its loads), and it has ONE exit, at the top: with an exit per step the
+  // compiler routes them all through the loop latch, sees a path from step s straight back to step s, and again
+  // waits for every outstanding load.  The < PF left-over steps run after the loop as straight-line code.
+  int i = 0;
+#ifdef G_PROBE_ON
+  long long g_acc[4] = {0, 0, 0, 0}, g_t = clock64();
+#endif
+  for (; i + PF <= nsteps && nsteps > 1; i += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      mma_tile(buf);
+      G_ACC(0);
+      la[s].store(As[buf ^ 1]);                        // stage s holds tile i+s+1, requested PF steps ago (all zero
+      lb[s].store(Bs[buf ^ 1]);                        // past the end of the slice) ...
+      G_ACC(1);
+      const int64_t kk = k_begin + (int64_t)(i + s + 1 + PF) * G_BK;        // ... and is free for tile i+s+1+PF
+      la[s].load(A, sam, sak, m0, M, kk, k_end);
+      lb[s].load(B, sbn, sbk, n0, N, kk, k_end);
+      G_ACC(2);
+      __syncthreads();
+      G_ACC(3);
+      buf ^= 1;
     }
-    __syncthreads();
-    buf ^= 1;
   }
+#ifdef G_PROBE_ON
+  if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int j = 0; j < 4; ++j) g_probe_buf[16 + j] = g_acc[j];
+#endif
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {                       // (s < PF - 1 steps when the loop ran; one when nsteps == 1)
+    if (i + s >= nsteps) break;                        // block-uniform
+    mma_tile(buf);
+    if (i + s + 1 < nsteps) {                          // the tile this step stages is already in flight
+      la[s].store(As[buf ^ 1]);
+      lb[s].store(Bs[buf ^ 1]);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  G_PROBE(2);
   // epilogue: 16 bytes per lane when the output rows allow it
-  float* Cz = C + (int64_t)blockIdx.z * slab_stride;
+  float* Cz = C + (int64_t)tile.z * slab_stride;
   const bool final_out = (gridDim.z == 1);
   const int64_t gm = m0 + w * 16 + (lane & 15);
   const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)Cz & 15) == 0);
@@ -180,14 +291,15 @@ __device__ __forceinline__ void store_tile_bf16(const TileLoader<ROWS, VW>& l, _
   for (int i = 0; i < TileLoader<ROWS, VW>::NU; ++i) {
     const int f = tid + i * 256;
     if (f < ROWS * G_BK / VW) {
+      const bool in = (l.ok >> i) & 1u;
       if (rfast) {
         const int r = (f % (ROWS / VW)) * VW, k = f / (ROWS / VW);
 #pragma unroll
-        for (int j = 0; j < VW; ++j) T[r + j][k] = (__bf16)l.v[i][j];
+        for (int j = 0; j < VW; ++j) T[r + j][k] = (__bf16)(in ? l.v[i][j] : 0.f);
       } else {
         const int r = f / (G_BK / VW), k = (f % (G_BK / VW)) * VW;
 #pragma unroll
-        for (int j = 0; j < VW; ++j) T[r][k + j] = (__bf16)l.v[i][j];
+        for (int j = 0; j < VW; ++j) T[r][k + j] = (__bf16)(in ? l.v[i][j] : 0.f);
       }
     }
   }
@@ -206,8 +318,9 @@ k_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_
                                                                       (size_t)nbuf * G_BM * G_LDB);
   constexpr int NT = BN / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * G_BM, n0 = (int64_t)blockIdx.y * BN;
-  const int64_t bidx = blockIdx.z / zsplit, ks_id = blockIdx.z % zsplit;
+  const dim3 tile = blockIdx;
+  const int64_t m0 = (int64_t)tile.x * G_BM, n0 = (int64_t)tile.y * BN;
+  const int64_t bidx = tile.z / zsplit, ks_id = tile.z % zsplit;
   const int64_t k_begin = ks_id * k_per_split;
   const int64_t k_end = k_begin + k_per_split < K ? k_begin + k_per_split : K;
   A += bidx * a_zs;
@@ -249,7 +362,7 @@ k_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_
     __syncthreads();
     buf ^= 1;
   }
-  float* Cz = C + (int64_t)blockIdx.z * slab_stride;
+  float* Cz = C + (int64_t)tile.z * slab_stride;
   const bool final_out = (gridDim.z == 1);
   const int64_t gm = m0 + w * 16 + (lane & 15);
   const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)Cz & 15) == 0);
@@ -291,8 +404,42 @@ static int vec_width(const float* p, int64_t srow, int64_t sk, int64_t rows, int
   return 1;
 }
 static int min_int(int a, int b) { return a < b ? a : b; }
-static size_t gemm_lds_bytes(int bn, int64_t k_per_split) {
-  return (size_t)(k_per_split <= G_BK ? 1 : 2) * (G_BM + bn) * G_LD * sizeof(float);
+static size_t gemm_lds_bytes(int bn, int64_t k_per_split, bool a_rfast, bool b_rfast) {
+  return (size_t)(k_per_split <= G_BK ? 1 : 2) * sizeof(float) *
+         ((size_t)G_BM * (a_rfast ? G_BK + 2 : G_BK + 4) + (size_t)bn * (b_rfast ? G_BK + 2 : G_BK + 4));
+}
+
+// k_gemm_f32 instantiation table: tile width x vector width x pipeline depth x operand layouts.
+struct GemmArgs {
+  int64_t M, N, K;
+  const float* A; int64_t sam, sak;
+  const float* B; int64_t sbn, sbk;
+  const float* bias; float* C; int64_t ldc; int act;
+  int64_t kps, slab, a_zs, b_zs; int zsplit;
+};
+template <int BN, int VW, int PF, bool ARF, bool BRF>
+static void launch_f32_t(dim3 grid, hipStream_t st, const GemmArgs& g) {
+  hipLaunchKernelGGL((k_gemm_f32<BN, VW, PF, ARF, BRF>), grid, dim3(256), gemm_lds_bytes(BN, g.kps, ARF, BRF), st, g.M,
+                     g.N, g.K, g.A, g.sam, g.sak, g.B, g.sbn, g.sbk, g.bias, g.C, g.ldc, g.act, g.kps, g.slab, g.a_zs,
+                     g.b_zs, g.zsplit);
+}
+template <int BN, int VW, int PF>
+static void launch_f32_l(dim3 grid, hipStream_t st, const GemmArgs& g) {
+  const bool arf = (g.sam == 1 && g.sak != 1), brf = (g.sbn == 1 && g.sbk != 1);
+  if (arf) { if (brf) launch_f32_t<BN, VW, PF, true, true>(grid, st, g); else launch_f32_t<BN, VW, PF, true, false>(grid, st, g); }
+  else     { if (brf) launch_f32_t<BN, VW, PF, false, true>(grid, st, g); else launch_f32_t<BN, VW, PF, false, false>(grid, st, g); }
+}
+template <int BN, int VW>
+static void launch_f32_p(dim3 grid, hipStream_t st, const GemmArgs& g) {
+  const int64_t span = g.kps < g.K ? g.kps : g.K;
+  if (igcn_cdiv(span, G_BK) <= 2) launch_f32_l<BN, VW, 1>(grid, st, g); else launch_f32_l<BN, VW, 2>(grid, st, g);
+}
+template <int BN>
+static void launch_f32_v(int vw, dim3 grid, hipStream_t st, const GemmArgs& g) {
+  if (vw == 4) launch_f32_p<BN, 4>(grid, st, g); else if (vw == 2) launch_f32_p<BN, 2>(grid, st, g); else launch_f32_p<BN, 1>(grid, st, g);
+}
+static void launch_f32(int bn, int vw, dim3 grid, hipStream_t st, const GemmArgs& g) {
+  if (bn == 16) launch_f32_v<16>(vw, grid, st, g); else if (bn == 32) launch_f32_v<32>(vw, grid, st, g); else launch_f32_v<64>(vw, grid, st, g);
 }
 
 __global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const float* __restrict__ slabs,
@@ -310,8 +457,7 @@ __global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const fl
 
 // Launch shape, fitted to a sweep over the products of the train step (tools/gemm_sweep.py): the tile is 64 x BN.
 // A wide tile only pays when there are tens of thousands of rows to stream; otherwise narrower tiles put more
-// workgroups (one per CU is the common case here) on the chip.  K is split so that ~384 workgroups exist, each
-// keeping at least one 32-deep K step.
+// workgroups on the chip.  K is split so that ~512 workgroups exist, each keeping at least one 32-deep K step.
 static int gemm_tile_n(int64_t M, int64_t N) {
   if (N <= 16) return 16;
   if (N <= 32) return 32;
@@ -322,8 +468,12 @@ static int gemm_tile_n(int64_t M, int64_t N) {
 extern "C" int igcn_gemm_f32_split_k(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K < 128) return 1;
   const int64_t tiles = igcn_cdiv(M, G_BM) * igcn_cdiv(N, gemm_tile_n(M, N));
-  if (tiles >= 256) return 1;                      // (192..255 tiles: 2 slices — 199 one-slice workgroups left a fifth of the CUs idle)
-  int64_t sk = (384 + tiles / 2) / tiles;
+  // a split costs a second pass over the slabs: it pays up to ~128 tiles (r02 sweep: 182-199 tiles ran 10-15 % faster
+  // whole than in two slices), and ~512 workgroups — two per CU, covering each other's stalls — is where it stops
+  // paying; beyond 256 slices the slab sum outweighs the shorter K loops.
+  if (tiles > 128) return 1;
+  int64_t sk = (512 + tiles / 2) / tiles;
+  if (sk > 256) sk = 256;
   if (sk > K / G_BK) sk = K / G_BK;
   return (int)(sk < 1 ? 1 : sk);
 }
@@ -350,23 +500,22 @@ static int gemm_launch(bool bf16, int64_t M, int64_t N, int64_t K, const float* 
   if (const char* cap = getenv("IGCN_GEMM_BN")) bn = atoi(cap) < bn ? atoi(cap) : bn;      // sweeps only
   dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)split_k);
   const int vw = min_int(vec_width(A, sam, sak, M, K), vec_width(B, sbn, sbk, N, K));
+  if (bf16) {
 #define LAUNCH_G(BNV, VECV)                                                                                        \
-  do {                                                                                                             \
-    if (bf16)                                                                                                      \
-      hipLaunchKernelGGL((k_gemm_bf16<BNV, VECV>), grid, dim3(256), gemm_bf16_lds_bytes(BNV, kps), st, M, N, K, A,  \
-                         sam, sak, B, sbn, sbk, bias, out, ld, act, kps, slab, (int64_t)0, (int64_t)0, split_k);    \
-    else                                                                                                           \
-      hipLaunchKernelGGL((k_gemm_f32<BNV, VECV>), grid, dim3(256), gemm_lds_bytes(BNV, kps), st, M, N, K, A, sam,   \
-                         sak, B, sbn, sbk, bias, out, ld, act, kps, slab, (int64_t)0, (int64_t)0, split_k);         \
-  } while (0)
-  if (vw == 4) {
-    if (bn == 16) { LAUNCH_G(16, 4); } else if (bn == 32) { LAUNCH_G(32, 4); } else { LAUNCH_G(64, 4); }
-  } else if (vw == 2) {
-    if (bn == 16) { LAUNCH_G(16, 2); } else if (bn == 32) { LAUNCH_G(32, 2); } else { LAUNCH_G(64, 2); }
-  } else {
-    if (bn == 16) { LAUNCH_G(16, 1); } else if (bn == 32) { LAUNCH_G(32, 1); } else { LAUNCH_G(64, 1); }
-  }
+  hipLaunchKernelGGL((k_gemm_bf16<BNV, VECV>), grid, dim3(256), gemm_bf16_lds_bytes(BNV, kps), st, M, N, K, A, sam,  \
+                     sak, B, sbn, sbk, bias, out, ld, act, kps, slab, (int64_t)0, (int64_t)0, split_k)
+    if (vw == 4) {
+      if (bn == 16) { LAUNCH_G(16, 4); } else if (bn == 32) { LAUNCH_G(32, 4); } else { LAUNCH_G(64, 4); }
+    } else if (vw == 2) {
+      if (bn == 16) { LAUNCH_G(16, 2); } else if (bn == 32) { LAUNCH_G(32, 2); } else { LAUNCH_G(64, 2); }
+    } else {
+      if (bn == 16) { LAUNCH_G(16, 1); } else if (bn == 32) { LAUNCH_G(32, 1); } else { LAUNCH_G(64, 1); }
+    }
 #undef LAUNCH_G
+  } else {
+    const GemmArgs g = {M, N, K, A, sam, sak, B, sbn, sbk, bias, out, ld, act, kps, slab, 0, 0, split_k};
+    launch_f32(bn, vw, grid, st, g);
+  }
   IGCN_CHECK_LAUNCH(nm);
   if (split && final_grad && ldc == N && bias == nullptr && act == 0 && M * N < ((int64_t)1 << 31))
     return igcn_launch_reduce_rows_final(scratch, split_k, M * N, (int)(M * N), C, st);
@@ -421,17 +570,10 @@ int igcn_gemm_f32_batched_sum_impl(int64_t M, int64_t N, int64_t K, int batch, c
   dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)slabs);
   int vw = min_int(vec_width(A, sam, sak, M, K), vec_width(B, sbn, sbk, N, K));
   while (vw > 1 && (a_batch % vw != 0 || b_batch % vw != 0)) vw >>= 1;
-#define LAUNCH_B(BNV, VECV)                                                                                     \
-  hipLaunchKernelGGL((k_gemm_f32<BNV, VECV>), grid, dim3(256), gemm_lds_bytes(BNV, kps), st, M, N, K, A, sam,    \
-                     sak, B, sbn, sbk, (const float*)nullptr, scratch, N, 0, kps, M * N, a_batch, b_batch, ksplit)
-  if (vw == 4) {
-    if (bn == 16) { LAUNCH_B(16, 4); } else if (bn == 32) { LAUNCH_B(32, 4); } else { LAUNCH_B(64, 4); }
-  } else if (vw == 2) {
-    if (bn == 16) { LAUNCH_B(16, 2); } else if (bn == 32) { LAUNCH_B(32, 2); } else { LAUNCH_B(64, 2); }
-  } else {
-    if (bn == 16) { LAUNCH_B(16, 1); } else if (bn == 32) { LAUNCH_B(32, 1); } else { LAUNCH_B(64, 1); }
+  {
+    const GemmArgs g = {M, N, K, A, sam, sak, B, sbn, sbk, nullptr, scratch, N, 0, kps, M * N, a_batch, b_batch, ksplit};
+    launch_f32(bn, vw, grid, st, g);
   }
-#undef LAUNCH_B
   IGCN_CHECK_LAUNCH("gemm_f32_batched_sum");
   if (ldc == N && M * N <= 4096 && slabs > 32)     // few outputs, many slabs: block-per-output tree reduce
     return igcn_launch_reduce_rows(scratch, slabs, M * N, (int)(M * N), C, 0, st);
