@@ -47,6 +47,58 @@ __device__ __forceinline__ void am_stage(const float* __restrict__ src, int64_t 
   }
 }
 
+// Two matrices of the same geometry (K and V of a head; Q and dO) in ONE pass: every thread first issues all the loads
+// of a batch of AM_SU slots of both sources, then stores — a workgroup's staging is then one or two memory round trips
+// instead of one per 16-byte slot per matrix (eight serial trips for 400 keys on 384 threads, ~12 us per workgroup,
+// which was most of what kept the matrix cores under 30 % busy).
+#define AM_SU 5
+// LD = LDS row stride (HDP + 1, or HDP for the unpadded 16-column layout of the forward kernel, where SWZ_A also XORs
+// matrix A's 4-column group with bits 2-3 of the row: see k_attn_mfma_fwd).
+template <int HDP, int LD = HDP + 1, bool SWZ_A = false>
+__device__ __forceinline__ void am_stage_pair(const float* __restrict__ src_a, const float* __restrict__ src_b,
+                                              int64_t row_stride, int hd, int vec, int rows_valid, int rows_pad,
+                                              float* __restrict__ dst_a, float* __restrict__ dst_b) {
+  constexpr int NQ = HDP / 4;
+  const int total = rows_pad * NQ, step = (int)blockDim.x;
+  for (int t0 = threadIdx.x; t0 < total; t0 += step * AM_SU) {
+    float va[AM_SU][4], vb[AM_SU][4];
+#pragma unroll
+    for (int u = 0; u < AM_SU; ++u) {
+      const int t = t0 + u * step, j = t / NQ, c = (t % NQ) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) va[u][e] = vb[u][e] = 0.f;
+      if (t < total && j < rows_valid) {
+        const float* pa = src_a + (int64_t)j * row_stride + c;
+        const float* pb = src_b + (int64_t)j * row_stride + c;
+        if (vec) {
+          const float4 a4 = *reinterpret_cast<const float4*>(pa), b4 = *reinterpret_cast<const float4*>(pb);
+          va[u][0] = a4.x; va[u][1] = a4.y; va[u][2] = a4.z; va[u][3] = a4.w;
+          vb[u][0] = b4.x; vb[u][1] = b4.y; vb[u][2] = b4.z; vb[u][3] = b4.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < hd) { va[u][e] = pa[e]; vb[u][e] = pb[e]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < AM_SU; ++u) {
+      const int t = t0 + u * step, j = t / NQ, c = (t % NQ) * 4;
+      if (t < total) {
+        float* da = dst_a + j * LD + (SWZ_A ? (c ^ (((j >> 2) & 3) << 2)) : c);
+        float* db = dst_b + j * LD + c;
+        if constexpr (LD % 4 == 0) {                              // 16-byte aligned rows: one LDS store per slot
+          *reinterpret_cast<float4*>(da) = make_float4(va[u][0], va[u][1], va[u][2], va[u][3]);
+          *reinterpret_cast<float4*>(db) = make_float4(vb[u][0], vb[u][1], vb[u][2], vb[u][3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { da[e] = va[u][e]; db[e] = vb[u][e]; }
+        }
+      }
+    }
+  }
+}
+
 // four consecutive head columns [c0, c0+4) of one row of a [*, D] tensor, clipped to hd
 __device__ __forceinline__ void am_store4(float* __restrict__ p, int c0, int hd, int vec, float a, float b, float c,
                                           float d) {
@@ -60,30 +112,60 @@ __device__ __forceinline__ void am_store4(float* __restrict__ p, int c0, int hd,
   }
 }
 
+#ifdef AM_PROBE_ON
+__device__ long long am_probe_buf[16 * 8];
+#define AM_PROBE(i) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x % 128) == 0 && (threadIdx.x >> 6) < 2) { am_probe_buf[((blockIdx.x / 128) * 2 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } } while (0)
+extern "C" int igcn_debug_attn_probe(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(am_probe_buf), sizeof(long long) * 128);
+}
+#else
+#define AM_PROBE(i)
+#endif
+
 // EXACT: head_dim == HDP and 16-byte aligned rows — the clipping guards fold away at compile time
 template <int HDP, bool EXACT>
 __global__ void __launch_bounds__(64 * AM_MAX_WAVES)
 k_attn_mfma_fwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __restrict__ q,
                 const float* __restrict__ kv, float* __restrict__ o, float* __restrict__ lse) {
-  constexpr int LD = HDP + 1, NC = HDP / 4, NO = (HDP + 15) / 16;
+  // HDP == 16 (the bench model: two heads of 16): UNPADDED 16-float rows, 51 KB per workgroup at 400 keys instead of
+  // 54 KB — three workgroups per CU instead of two, i.e. one can stage while two compute.  Conflict-free without the
+  // pad column because (a) K's 4-column groups are XOR-swizzled with bits 2-3 of the row, and (b) the rows of a key
+  // tile enter the score product in the order pi(m) = (m >> 2) + 4 (m & 3): register r of lane group g then holds key
+  // g + 4r, so the four lane groups of a P.V step read V rows g (mod 4) = four different 16-bank windows.
+  constexpr bool FLAT = (HDP == 16);
+  constexpr int LD = FLAT ? HDP : HDP + 1, NC = HDP / 4, NO = (HDP + 15) / 16;
   const int hd = EXACT ? HDP : hd_rt, vec = EXACT ? 1 : vec_rt;
-  extern __shared__ float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * hd;
   const int Lkp = (Lk + 15) & ~15, nkt = Lkp >> 4, nqt = (Lq + 15) >> 4;
   float* Ks = smem;
   float* Vs = Ks + (size_t)Lkp * LD;
   const float* kbase = kv + (int64_t)b * Lk * 2 * D + h * hd;
-  am_stage<HDP>(kbase, 2 * D, hd, vec, Lk, Lkp, Ks);
-  am_stage<HDP>(kbase + D, 2 * D, hd, vec, Lk, Lkp, Vs);
-  __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
   const float scale = rsqrtf((float)hd);
+  const int krow = FLAT ? (n >> 2) + 4 * (n & 3) : n;            // K row (within a tile) behind score row n
+  const int ksw = FLAT ? (krow >> 2) & 3 : 0;
+  AM_PROBE(0);
+  // the wave's first query tile is requested before the K/V staging, so that its round trip runs under the staging's
+  float qn[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+    qn[c] = (w * 16 + n < Lq && 4 * c + g < hd) ? q[(int64_t)(b * Lq + w * 16 + n) * D + h * hd + 4 * c + g] * scale : 0.f;
+  am_stage_pair<HDP, LD, FLAT>(kbase, kbase + D, 2 * D, hd, vec, Lk, Lkp, Ks, Vs);
+  AM_PROBE(1);
+  __syncthreads();
+  AM_PROBE(2);
   for (int qt = w; qt < nqt; qt += nw) {
     const int qi = qt * 16 + n;
     float qb[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
-      qb[c] = (qi < Lq && 4 * c + g < hd) ? q[(int64_t)(b * Lq + qi) * D + h * hd + 4 * c + g] * scale : 0.f;
+    for (int c = 0; c < NC; ++c) qb[c] = qn[c];
+    if (qt + nw < nqt) {                                        // wave-uniform: the next tile's queries, one tile ahead
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        qn[c] = (qi + nw * 16 < Lq && 4 * c + g < hd)
+                    ? q[(int64_t)(b * Lq + qi + nw * 16) * D + h * hd + 4 * c + g] * scale : 0.f;
+    }
     float m = -INFINITY, l = 0.f;
     f32x4 oacc[NO];
 #pragma unroll
@@ -96,13 +178,13 @@ k_attn_mfma_fwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __res
         s[u] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         if (kt0 + u < nkt) {                                    // wave-uniform
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          const float* kr = Ks + ((kt0 + u) * 16 + n) * LD + g;
+          const float* kr = Ks + ((kt0 + u) * 16 + krow) * LD + g;
 #pragma unroll
-          for (int c = 0; c < NC; ++c) acc = mfma4(kr[4 * c], qb[c], acc);
-          const int key0 = (kt0 + u) * 16 + 4 * g;
+          for (int c = 0; c < NC; ++c) acc = mfma4(kr[4 * (c ^ ksw)], qb[c], acc);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            s[u][r] = (key0 + r < Lk) ? acc[r] : -INFINITY;
+            const int key = (kt0 + u) * 16 + (FLAT ? g + 4 * r : 4 * g + r);
+            s[u][r] = (key < Lk) ? acc[r] : -INFINITY;
             tmax = fmaxf(tmax, s[u][r]);
           }
         }
@@ -118,14 +200,14 @@ k_attn_mfma_fwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __res
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (kt0 + u < nkt) {
-          const float* vr = Vs + ((kt0 + u) * 16 + 4 * g) * LD + n;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            const float* vr = Vs + ((kt0 + u) * 16 + (FLAT ? g + 4 * r : 4 * g + r)) * LD + n;
             const float p = __expf(s[u][r] - m);
             l += p;
 #pragma unroll
             for (int t = 0; t < NO; ++t) {
-              const float a = (16 * t + n < HDP) ? vr[r * LD + 16 * t] : 0.f;      // A = V[key 4g+r][hd 16t+n]
+              const float a = (16 * t + n < HDP) ? vr[16 * t] : 0.f;          // A = V[key of (g, r)][hd 16t+n]
               oacc[t] = mfma4(a, p, oacc[t]);
             }
           }
@@ -134,6 +216,7 @@ k_attn_mfma_fwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __res
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
+    AM_PROBE(3);
     if (qi < Lq) {
       const float inv = 1.f / l;
       float* op = o + (int64_t)(b * Lq + qi) * D + h * hd;
@@ -166,20 +249,52 @@ k_attn_mfma_bwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __res
   const float* kbase = kv + (int64_t)b * Lk * 2 * D + h * hd;
   const float* qbase = q + (int64_t)b * Lq * D + h * hd;
   const float* dobase = dout + (int64_t)b * Lq * D + h * hd;
-  am_stage<HDP>(kbase, 2 * D, hd, vec, Lk, Lkp, Ks);
-  am_stage<HDP>(kbase + D, 2 * D, hd, vec, Lk, Lkp, Vs);
-  am_stage<HDP>(qbase, D, hd, vec, Lq, Lqp, Qs);
-  am_stage<HDP>(dobase, D, hd, vec, Lq, Lqp, dOs);
-  for (int r = threadIdx.x; r < Lqp; r += blockDim.x) {
-    float d = 0.f, lv = INFINITY;
-    if (r < Lq) {
+  // delta = rowsum(o * do) and lse: thread r's row, requested ahead of the staging passes (same reason as there)
+  {
+    const int r = threadIdx.x;
+    float orow[HDP], drow[HDP], lv = INFINITY;
+    const bool mine = r < Lqp, live = r < Lq;
+    if (live) {
       const float* op = o + (int64_t)(b * Lq + r) * D + h * hd;
       const float* dp = dobase + (int64_t)r * D;
-      for (int c = 0; c < hd; ++c) d += op[c] * dp[c];
+      if (vec) {
+#pragma unroll
+        for (int c = 0; c < HDP; c += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(op + c), d4 = *reinterpret_cast<const float4*>(dp + c);
+          orow[c] = a.x; orow[c + 1] = a.y; orow[c + 2] = a.z; orow[c + 3] = a.w;
+          drow[c] = d4.x; drow[c + 1] = d4.y; drow[c + 2] = d4.z; drow[c + 3] = d4.w;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < HDP; ++c) {
+          orow[c] = c < hd ? op[c] : 0.f;
+          drow[c] = c < hd ? dp[c] : 0.f;
+        }
+      }
       lv = lse[((int64_t)b * H + h) * Lq + r];
     }
-    dl[r] = d;
-    ls[r] = lv;
+    am_stage_pair<HDP>(kbase, kbase + D, 2 * D, hd, vec, Lk, Lkp, Ks, Vs);
+    am_stage_pair<HDP>(qbase, dobase, D, hd, vec, Lq, Lqp, Qs, dOs);
+    if (mine) {
+      float d = 0.f;
+      if (live) {
+#pragma unroll
+        for (int c = 0; c < HDP; ++c) d += orow[c] * drow[c];
+      }
+      dl[r] = d;
+      ls[r] = lv;
+    }
+    for (int r2 = r + blockDim.x; r2 < Lqp; r2 += blockDim.x) {      // more query rows than threads
+      float d = 0.f, l2 = INFINITY;
+      if (r2 < Lq) {
+        const float* op = o + (int64_t)(b * Lq + r2) * D + h * hd;
+        const float* dp = dobase + (int64_t)r2 * D;
+        for (int c = 0; c < hd; ++c) d += op[c] * dp[c];
+        l2 = lse[((int64_t)b * H + h) * Lq + r2];
+      }
+      dl[r2] = d;
+      ls[r2] = l2;
+    }
   }
   if (threadIdx.x == 0) *next_task = 0;
   __syncthreads();
@@ -281,7 +396,8 @@ k_attn_mfma_bwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __res
 static int am_hdp(int hd) { return (hd + 3) & ~3; }
 
 static size_t am_lds_bytes(int hd, int Lq, int Lk, int backward) {
-  const size_t Lkp = (size_t)((Lk + 15) & ~15), Lqp = (size_t)((Lq + 15) & ~15), ld = (size_t)am_hdp(hd) + 1;
+  const size_t Lkp = (size_t)((Lk + 15) & ~15), Lqp = (size_t)((Lq + 15) & ~15);
+  const size_t ld = (size_t)am_hdp(hd) + ((!backward && am_hdp(hd) == 16) ? 0 : 1);   // forward, 16 columns: unpadded
   size_t fl = 2 * Lkp * ld;
   if (backward) fl += 2 * Lqp * ld + 2 * Lqp + 4;
   return fl * sizeof(float);
@@ -387,8 +503,7 @@ k_attn_mfma_fwd_chunked(int H, int hd, int vec, int Lq, int Lk, int CH, const fl
     const int kn = min(CH, Lk - k0), knp = (kn + 15) & ~15;
     __syncthreads();                                            // previous chunk fully consumed
     const float* kbase = kv + ((int64_t)b * Lk + k0) * 2 * D + h * hd;
-    am_stage<HDP>(kbase, 2 * D, hd, vec, kn, knp, Ks);
-    am_stage<HDP>(kbase + D, 2 * D, hd, vec, kn, knp, Vs);
+    am_stage_pair<HDP>(kbase, kbase + D, 2 * D, hd, vec, kn, knp, Ks, Vs);
     __syncthreads();
     for (int kt = 0; kt < (knp >> 4); ++kt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -472,8 +587,7 @@ k_attn_mfma_bwd_dq_chunked(int H, int hd, int vec, int Lq, int Lk, int CH, const
     const int kn = min(CH, Lk - k0), knp = (kn + 15) & ~15;
     __syncthreads();
     const float* kbase = kv + ((int64_t)b * Lk + k0) * 2 * D + h * hd;
-    am_stage<HDP>(kbase, 2 * D, hd, vec, kn, knp, Ks);
-    am_stage<HDP>(kbase + D, 2 * D, hd, vec, kn, knp, Vs);
+    am_stage_pair<HDP>(kbase, kbase + D, 2 * D, hd, vec, kn, knp, Ks, Vs);
     __syncthreads();
     for (int kt = 0; kt < (knp >> 4); ++kt) {
       f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
@@ -531,8 +645,8 @@ k_attn_mfma_bwd_dkv_chunked(int H, int hd, int vec, int Lq, int Lk, int CH, cons
   for (int q0 = 0; q0 < Lq; q0 += CH) {
     const int qn = min(CH, Lq - q0), qnp = (qn + 15) & ~15;
     __syncthreads();
-    am_stage<HDP>(q + ((int64_t)b * Lq + q0) * D + h * hd, D, hd, vec, qn, qnp, Qs);
-    am_stage<HDP>(dout + ((int64_t)b * Lq + q0) * D + h * hd, D, hd, vec, qn, qnp, dOs);
+    am_stage_pair<HDP>(q + ((int64_t)b * Lq + q0) * D + h * hd, dout + ((int64_t)b * Lq + q0) * D + h * hd, D, hd, vec,
+                       qn, qnp, Qs, dOs);
     for (int r = threadIdx.x; r < qnp; r += blockDim.x) {
       const bool in = r < qn;
       ls[r] = in ? lse[((int64_t)b * H + h) * Lq + q0 + r] : INFINITY;       // padding queries: p = 0

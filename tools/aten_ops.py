@@ -41,3 +41,13 @@ for ev in prof.events():
 for (name, where, shp), c in sorted(cnt.items(), key=lambda kv: (kv[0][1], kv[0][0])):
     print(f"{c:3d} {name:28s} {where}")
 print("total aten launches:", sum(cnt.values()))
+
+# device-to-device copies are memcpy activities, not kernels: list every aten::copy_ with the frames that issued it
+cp = Counter()
+for ev in prof.events():
+    if ev.device_type == torch.autograd.DeviceType.CPU and ev.name == "aten::copy_":
+        frames = [fr.split("/")[-1][:70] for fr in ev.stack if "ig-gcn_amd" in fr or "igcn_amd" in fr][:2]
+        cp[" <- ".join(frames) if frames else ("autograd:" + (ev.stack[0].split("/")[-1][:60] if ev.stack else "?"))] += 1
+print("aten::copy_ calls (kernel or memcpy):")
+for k, c in sorted(cp.items(), key=lambda kv: -kv[1]):
+    print(f"{c:3d} {k}")
