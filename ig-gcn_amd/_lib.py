@@ -61,6 +61,7 @@ SIGNATURES = {
     "igcn_bn1d_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_dropout_state_words": (I, []),
     "igcn_dropout_masks": (I, [L, I, P, P, P, P, P]),
+    "igcn_mask_reg_blocks": (I, [L]),
     "igcn_mask_reg_fwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P]),
     "igcn_mask_reg_bwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P, P, P]),
     "igcn_rbf_laplacian": (I, [I, I, F, P, P, P]),
@@ -96,8 +97,8 @@ SIGNATURES = {
     "igcn_comm_init": (I, [I, I, P, P]),
     "igcn_comm_allreduce": (I, [P, P, L, P]),
     "igcn_comm_destroy": (I, [P]),
-    "igcn_loss_head_fwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, F, F, P, P, P]),
-    "igcn_loss_head_bwd": (I, [I, I, I, I, P, P, P, P, P, P, F, F, P, P, P, P, P, P, P]),
+    "igcn_loss_head_fwd": (I, [I, I, I, I, P, I, P, P, P, P, P, P, P, I, P, I, P, F, F, P, P, P]),
+    "igcn_loss_head_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, F, F, P, P, P, P, P, P, P]),
     "igcn_gdc_topk_max_rois": (I, []),
     "igcn_gdc_topk": (I, [I, I, I, ctypes.c_double, P, P, P, P, P]),
 }

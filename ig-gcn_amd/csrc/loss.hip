@@ -64,17 +64,24 @@ __global__ void k_mask_reg_bwd(MaskRegArgs a, const float* __restrict__ gout, fl
 
 #define MR_BLOCKS 1024        // upper bound; scratch holds this many partials
 
+// workgroups of igcn_mask_reg_fwd = block partials it leaves in scratch[0 .. blocks): ~2k elements per workgroup, at
+// most MR_BLOCKS of them (the dense stress shape has 8.4 M edge-mask values: 128 workgroups left half the chip idle)
+extern "C" int igcn_mask_reg_blocks(int64_t n_total) {
+  int64_t blocks = igcn_cdiv(n_total, 2048);
+  return (int)(blocks < 1 ? 1 : (blocks > MR_BLOCKS ? MR_BLOCKS : blocks));
+}
+
+// loss == NULL: the block partials stay in scratch and their consumer sums them (igcn_loss_head_fwd, prob_rows):
+// one launch less on the step's critical path.
 extern "C" int igcn_mask_reg_fwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const float* prob, const float* e,
                                  const float* snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,
-                                 float* loss /*[1]*/, float* scratch /*[1024]*/, void* stream) {
+                                 float* loss /*[1] or NULL*/, float* scratch /*[1024]*/, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   MaskRegArgs a{prob, e, snps, n_prob, n_edge, n_snps, l1_x, ent_x, l1_e, ent_e, eps};
-  // ~2k elements per workgroup, at most MR_BLOCKS of them (the dense stress shape has 8.4 M edge-mask values: 128
-  // workgroups left half the chip idle)
-  int64_t blocks = igcn_cdiv(n_prob + n_edge + n_snps, 2048);
-  blocks = blocks < 1 ? 1 : (blocks > MR_BLOCKS ? MR_BLOCKS : blocks);
+  const int blocks = igcn_mask_reg_blocks(n_prob + n_edge + n_snps);
   hipLaunchKernelGGL(k_mask_reg_fwd, dim3((unsigned)blocks), dim3(256), 0, st, a, scratch);
   IGCN_CHECK_LAUNCH("mask_reg_fwd");
+  if (loss == nullptr) return IGCN_OK;
   return igcn_launch_reduce_rows(scratch, blocks, 1, 1, loss, 0, st);
 }
 
@@ -145,12 +152,14 @@ k_gram_loss_bwd(int B, const float* __restrict__ Gall, const float* __restrict__
   if (threadIdx.x == 0) S[(int64_t)i * B + i] = 2.f * (gc * Lap[(int64_t)i * B + i] - go * 2.f * dsum) / b2;
 }
 
+// out == NULL: the row partials [B][groups*2] stay in scratch for the consumer to sum (igcn_loss_head_fwd, gram_rows).
 extern "C" int igcn_gram_loss_fwd(int B, int RD, int groups, const float* G /*[groups,B,B]*/, const float* Lap,
-                                  float* out /*[groups,2]*/, float* scratch /*[2 B groups]*/, void* stream) {
+                                  float* out /*[groups,2] or NULL*/, float* scratch /*[2 B groups]*/, void* stream) {
   IGCN_REQUIRE(B > 0 && groups >= 1 && groups <= 64, "gram_loss_fwd: bad B / groups");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_gram_loss_fwd, dim3(B, groups), dim3(256), 0, st, B, RD, G, Lap, scratch);
   IGCN_CHECK_LAUNCH("gram_loss_fwd");
+  if (out == nullptr) return IGCN_OK;
   return igcn_launch_reduce_rows(scratch, B, 2 * groups, 2 * groups, out, 0, st);
 }
 
@@ -209,17 +218,49 @@ extern "C" int igcn_rbf_laplacian(int B, int T, float gamma, const float* t, flo
 // -------------------------------------------------------------------------------------------------
 struct LossHeadW { float lam[6]; float hp_ce, hp_mi; };
 
+//   from_logits: `logp` holds the raw class scores; log_softmax (sgcn_img_snp.py:305) is taken here, row by row, and
+//   written to logp_out [2B, C] (the model output, and what the backward reads).  gram [gram_rows][4] and prob
+//   [prob_rows] may be the un-reduced partials of igcn_gram_loss_fwd / igcn_mask_reg_fwd: their rows are summed here.
 __global__ void __launch_bounds__(1024)
-k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, const int64_t* __restrict__ y,
+k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, int from_logits,
+                float* __restrict__ logp_out, const int64_t* __restrict__ y,
                 const float* __restrict__ reg, const float* __restrict__ clin, const float* __restrict__ x_hat,
-                const float* __restrict__ snps, const float* __restrict__ gram, const float* __restrict__ prob,
+                const float* __restrict__ snps, const float* __restrict__ gram, int gram_rows,
+                const float* __restrict__ prob, int prob_rows,
                 LossHeadW w, float* __restrict__ loss, float* __restrict__ terms) {
-  __shared__ float red[4][16];
+  __shared__ float red[9][16];
   const int tid = threadIdx.x;
   float ce = 0.f, mi = 0.f, mse = 0.f, rec = 0.f;
+  float gs[4] = {0.f, 0.f, 0.f, 0.f}, ps = 0.f;
+  for (int r = tid; r < gram_rows; r += 1024) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gs[j] += gram[(int64_t)r * 4 + j];
+  }
+  for (int r = tid; r < prob_rows; r += 1024) ps += prob[r];
+  if (from_logits) {
+    for (int row = tid; row < 2 * B; row += 1024) {
+      const float* xr = logp + (int64_t)row * C;
+      float m = -INFINITY;
+      for (int c = 0; c < C; ++c) m = fmaxf(m, xr[c]);
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += expf(xr[c] - m);
+      const float lse = logf(se);
+      for (int c = 0; c < C; ++c) logp_out[(int64_t)row * C + c] = (xr[c] - m) - lse;
+      if (w.lam[0] != 0.f) {
+        const int b = row < B ? row : row - B;
+        const int64_t c = y[b];
+        if (c < 0 || c >= C) {
+          ce = __builtin_nanf("");
+        } else {
+          const float v = (xr[c] - m) - lse;
+          if (row < B) ce -= v; else mi -= v;
+        }
+      }
+    }
+  }
   // lam[0] == 0 (main.py's default): the reference sets loss_ce = loss_mi = 0.0 outright (:540-542) — the class
   // scores are not read at all, so a non-finite log-probability cannot poison the loss through 0 * inf
-  if (w.lam[0] != 0.f) {
+  if (w.lam[0] != 0.f && !from_logits) {
     for (int b = tid; b < B; b += 1024) {
       const int64_t c = y[b];
       if (c < 0 || c >= C) {             // F.nll_loss raises on the host; a kernel cannot: poison the loss instead of
@@ -258,11 +299,23 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, con
   {
     const int lane = tid & 63, wv = tid >> 6;
     ce = wave_sum(ce); mi = wave_sum(mi); mse = wave_sum(mse); rec = wave_sum(rec);
-    if (lane == 0) { red[0][wv] = ce; red[1][wv] = mi; red[2][wv] = mse; red[3][wv] = rec; }
+    ps = wave_sum(ps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gs[j] = wave_sum(gs[j]);
+    if (lane == 0) {
+      red[0][wv] = ce; red[1][wv] = mi; red[2][wv] = mse; red[3][wv] = rec; red[4][wv] = ps;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[5 + j][wv] = gs[j];
+    }
     __syncthreads();
     if (tid == 0) {
-      ce = mi = mse = rec = 0.f;
-      for (int i = 0; i < 16; ++i) { ce += red[0][i]; mi += red[1][i]; mse += red[2][i]; rec += red[3][i]; }
+      ce = mi = mse = rec = ps = 0.f;
+      gs[0] = gs[1] = gs[2] = gs[3] = 0.f;
+      for (int i = 0; i < 16; ++i) {
+        ce += red[0][i]; mi += red[1][i]; mse += red[2][i]; rec += red[3][i]; ps += red[4][i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gs[j] += red[5 + j][i];
+      }
     }
   }
   if (tid == 0) {
@@ -270,10 +323,10 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, con
     t[0] = w.lam[0] != 0.f ? w.lam[0] * (ce / (float)B) : 0.f;
     t[1] = w.lam[0] != 0.f ? w.lam[0] * (mi / (float)B) : 0.f;
     t[2] = w.lam[1] * (mse / (float)(2 * nreg));
-    t[3] = w.lam[2] * prob[0];
+    t[3] = w.lam[2] * ps;
     t[4] = w.lam[3] * (rec * 0.5f);
-    t[5] = w.lam[4] * ((gram[0] + gram[2]) * 0.5f);
-    t[6] = w.lam[5] * gram[1];
+    t[5] = w.lam[4] * ((gs[0] + gs[2]) * 0.5f);
+    t[6] = w.lam[5] * gs[1];
     for (int k = 0; k < 7; ++k) terms[k] = t[k];
     loss[0] = w.hp_ce * t[0] + w.hp_mi * t[1] + t[2] + t[3] + t[4] + t[5] + t[6];
   }
@@ -282,6 +335,7 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, con
 __global__ void __launch_bounds__(256)
 k_loss_head_bwd(int B, int C, int NR, int S, const int64_t* __restrict__ y, const float* __restrict__ reg,
                 const float* __restrict__ clin, const float* __restrict__ x_hat, const float* __restrict__ snps,
+                const float* __restrict__ logp /* forward took raw scores: dlogp is the gradient of THOSE; or NULL */,
                 LossHeadW w, const float* __restrict__ gout, float* __restrict__ dlogp, float* __restrict__ dreg,
                 float* __restrict__ dxhat, float* __restrict__ dgram, float* __restrict__ dprob) {
   const float g = gout[0];
@@ -290,7 +344,9 @@ k_loss_head_bwd(int B, int C, int NR, int S, const int64_t* __restrict__ y, cons
   if (i < n0) {
     const int row = i / C, c = i % C, b = row < B ? row : row - B;
     const float wt = (row < B ? w.hp_ce : w.hp_mi) * w.lam[0];
-    dlogp[i] = (y[b] == c) ? -g * wt / (float)B : 0.f;
+    const float hit = (y[b] == c) ? 1.f : 0.f;
+    if (logp == nullptr) dlogp[i] = -g * wt / (float)B * hit;
+    else dlogp[i] = wt != 0.f ? g * wt / (float)B * (expf(logp[i]) - hit) : 0.f;      // nll o log_softmax
     return;
   }
   i -= n0;
@@ -323,25 +379,29 @@ static LossHeadW loss_head_w(const float* lam6, float hp_ce, float hp_mi) {
   return w;
 }
 
-extern "C" int igcn_loss_head_fwd(int B, int C, int NR, int S, const float* logp, const int64_t* y, const float* reg,
-                                  const float* clin, const float* x_hat, const float* snps, const float* gram,
-                                  const float* prob, const float* lam6 /*HOST [6]*/, float hp_ce, float hp_mi,
+extern "C" int igcn_loss_head_fwd(int B, int C, int NR, int S, const float* logp, int from_logits, float* logp_out,
+                                  const int64_t* y, const float* reg, const float* clin, const float* x_hat,
+                                  const float* snps, const float* gram, int gram_rows, const float* prob,
+                                  int prob_rows, const float* lam6 /*HOST [6]*/, float hp_ce, float hp_mi,
                                   float* loss /*[1]*/, float* terms /*[7]*/, void* stream) {
-  IGCN_REQUIRE(B > 0 && C > 0 && NR > 0 && S > 0, "loss_head_fwd: bad sizes");
-  hipLaunchKernelGGL(k_loss_head_fwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, C, NR, S, logp, y, reg, clin,
-                     x_hat, snps, gram, prob, loss_head_w(lam6, hp_ce, hp_mi), loss, terms);
+  IGCN_REQUIRE(B > 0 && C > 0 && NR > 0 && S > 0 && gram_rows >= 1 && prob_rows >= 1, "loss_head_fwd: bad sizes");
+  IGCN_REQUIRE(!from_logits || logp_out != nullptr, "loss_head_fwd: from_logits needs logp_out");
+  hipLaunchKernelGGL(k_loss_head_fwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, C, NR, S, logp, from_logits,
+                     logp_out, y, reg, clin, x_hat, snps, gram, gram_rows, prob, prob_rows,
+                     loss_head_w(lam6, hp_ce, hp_mi), loss, terms);
   IGCN_CHECK_LAUNCH("loss_head_fwd");
   return IGCN_OK;
 }
 
 extern "C" int igcn_loss_head_bwd(int B, int C, int NR, int S, const int64_t* y, const float* reg, const float* clin,
-                                  const float* x_hat, const float* snps, const float* lam6 /*HOST [6]*/, float hp_ce,
+                                  const float* x_hat, const float* snps, const float* logp /*[2B,C] or NULL*/,
+                                  const float* lam6 /*HOST [6]*/, float hp_ce,
                                   float hp_mi, const float* gout /*[1] device*/, float* dlogp, float* dreg,
                                   float* dxhat, float* dgram /*[4]*/, float* dprob /*[1]*/, void* stream) {
   IGCN_REQUIRE(B > 0 && C > 0 && NR > 0 && S > 0, "loss_head_bwd: bad sizes");
   const int64_t total = (int64_t)2 * B * (C + NR + S) + 1;
   hipLaunchKernelGGL(k_loss_head_bwd, dim3((unsigned)igcn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, B, C,
-                     NR, S, y, reg, clin, x_hat, snps, loss_head_w(lam6, hp_ce, hp_mi), gout, dlogp, dreg, dxhat,
+                     NR, S, y, reg, clin, x_hat, snps, logp, loss_head_w(lam6, hp_ce, hp_mi), gout, dlogp, dreg, dxhat,
                      dgram, dprob);
   IGCN_CHECK_LAUNCH("loss_head_bwd");
   return IGCN_OK;

@@ -1118,25 +1118,30 @@ class MaskRegulariser(torch.autograd.Function):
     """loss_probability (kernel/sgcn_img_snp.py:153-181) as one reduction kernel + one elementwise backward."""
 
     @staticmethod
-    def forward(ctx, prob, e, snps_prob, l1_x, ent_x, l1_e, ent_e, eps):
+    def forward(ctx, prob, e, snps_prob, l1_x, ent_x, l1_e, ent_e, eps, partials=False):
+        """``partials``: return the [blocks] workgroup partials whose SUM is the loss (LossHead adds them up inside its
+        own kernel: one launch less); their gradient is the same scalar in every element."""
         prob, e, snps_prob = _f32(prob), _f32(e), _f32(snps_prob)
         dev = prob.device
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
         scratch = torch.empty(1024, dtype=torch.float32, device=dev)
         ctx.hp = (float(l1_x), float(ent_x), float(l1_e), float(ent_e), float(eps))
+        loss = None if partials else torch.empty(1, dtype=torch.float32, device=dev)
         call("igcn_mask_reg_fwd", prob.numel(), e.numel(), snps_prob.numel(), ptr(prob), ptr(e), ptr(snps_prob),
              *ctx.hp, ptr(loss), ptr(scratch), stream_ptr())
         ctx.save_for_backward(prob, e, snps_prob)
+        ctx.partials = partials
+        if partials:
+            return scratch[:int(_lib.load().igcn_mask_reg_blocks(prob.numel() + e.numel() + snps_prob.numel()))]
         return loss.view(())
 
     @staticmethod
     def backward(ctx, gout):
         prob, e, snps_prob = ctx.saved_tensors
-        gout = _f32(gout).reshape(1)
+        gout = _f32(gout[:1] if ctx.partials else gout).reshape(1)     # partials: the same scalar in every element
         dprob, de, dsnps = torch.empty_like(prob), torch.empty_like(e), torch.empty_like(snps_prob)
         call("igcn_mask_reg_bwd", prob.numel(), e.numel(), snps_prob.numel(), ptr(prob), ptr(e), ptr(snps_prob),
              *ctx.hp, ptr(gout), ptr(dprob), ptr(de), ptr(dsnps), stream_ptr())
-        return dprob, de, dsnps, None, None, None, None, None
+        return dprob, de, dsnps, None, None, None, None, None, None
 
 
 def rbf_laplacian(tsne, n, gamma, device):
@@ -1153,12 +1158,15 @@ class GramLosses(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, s, lap, groups=1, packed=False):
-        """``packed``: return ONE tensor [G,2] = (consist, orth) per group (what igcn_loss_head_* consumes)."""
+        """``packed``: return ONE tensor [G,2] = (consist, orth) per group (what igcn_loss_head_* consumes);
+        ``packed == "partials"``: the un-reduced row partials [B, G*2] whose column sums are that tensor (LossHead adds
+        them up inside its own kernel: one launch less); every row then receives the gradient of the sum."""
         s, lap = _f32(s), _f32(lap)
         gb, rd = s.shape
         b = gb // groups
+        partials = packed == "partials"
         gram = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
-        out = torch.empty(groups, 2, dtype=torch.float32, device=s.device)
+        out = None if partials else torch.empty(groups, 2, dtype=torch.float32, device=s.device)
         scratch = torch.empty(2 * b * groups, dtype=torch.float32, device=s.device)
         for g in range(groups):
             sg = s[g * b:(g + 1) * b]
@@ -1166,6 +1174,8 @@ class GramLosses(torch.autograd.Function):
         call("igcn_gram_loss_fwd", b, rd, groups, ptr(gram), ptr(lap), ptr(out), ptr(scratch), stream_ptr())
         ctx.save_for_backward(s, lap, gram)
         ctx.groups, ctx.packed = groups, packed
+        if partials:
+            return scratch.view(b, 2 * groups)
         if packed:
             return out
         return out[:, 0], out[:, 1]
@@ -1175,7 +1185,9 @@ class GramLosses(torch.autograd.Function):
         s, lap, gram = ctx.saved_tensors
         groups = ctx.groups
         b = s.shape[0] // groups
-        if ctx.packed:
+        if ctx.packed == "partials":
+            gout = _f32(g_c[0])                                   # the same [G*2] row in every partial row
+        elif ctx.packed:
             gout = _f32(g_c)
         else:
             zero = torch.zeros(groups, dtype=torch.float32, device=s.device)
@@ -1249,40 +1261,53 @@ class LossHead(torch.autograd.Function):
     Returns (loss scalar, terms [7] — not differentiable: {ce, mi, reg, prob, recon, cluster, orth} lam-weighted)."""
 
     @staticmethod
-    def forward(ctx, logp, y, reg, clin, x_hat, snps, gram, prob, lam, hp_ce, hp_mi):
+    def forward(ctx, logp, y, reg, clin, x_hat, snps, gram, prob, lam, hp_ce, hp_mi, from_logits=False):
+        """``from_logits``: ``logp`` holds the raw class scores; log_softmax is taken inside the kernel and returned as
+        a third (non-differentiable) output.  ``gram`` [rows, 4] / ``prob`` [rows] may be un-reduced partials
+        (GramLosses ``packed="partials"``, MaskRegulariser ``partials=True``): their rows are summed by the kernel."""
         logp, reg, clin, x_hat, snps, gram, prob = (_f32(t) for t in (logp, reg, clin, x_hat, snps, gram, prob))
         y = y.contiguous()
         b, c = logp.shape[0] // 2, logp.shape[1]
         nr, s = reg.numel() // (2 * b), snps.shape[1]
         if y.dtype != torch.int64 or y.numel() != b or clin.numel() != b * nr or x_hat.shape != (2 * b, s) \
-                or gram.numel() != 4 or snps.shape[0] != b:
+                or gram.numel() % 4 != 0 or gram.numel() == 0 or prob.numel() == 0 or snps.shape[0] != b:
             raise _lib.IgcnError("loss head: inconsistent shapes")
         dev = logp.device
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         terms = torch.empty(7, dtype=torch.float32, device=dev)
+        logp_out = torch.empty_like(logp) if from_logits else None
         lam6 = (ctypes.c_float * 6)(*[float(v) for v in lam])
         ctx.cfg = (b, c, nr, s, [float(v) for v in lam], float(hp_ce), float(hp_mi))
-        call("igcn_loss_head_fwd", b, c, nr, s, ptr(logp), ptr(y), ptr(reg), ptr(clin), ptr(x_hat), ptr(snps),
-             ptr(gram), ptr(prob), lam6, float(hp_ce), float(hp_mi), ptr(loss), ptr(terms), stream_ptr())
-        ctx.save_for_backward(y, reg, clin, x_hat, snps)
+        ctx.gram_shape, ctx.prob_shape = tuple(gram.shape), tuple(prob.shape)
+        call("igcn_loss_head_fwd", b, c, nr, s, ptr(logp), 1 if from_logits else 0, ptr(logp_out), ptr(y), ptr(reg),
+             ptr(clin), ptr(x_hat), ptr(snps), ptr(gram), gram.numel() // 4, ptr(prob), prob.numel(), lam6,
+             float(hp_ce), float(hp_mi), ptr(loss), ptr(terms), stream_ptr())
+        ctx.save_for_backward(y, reg, clin, x_hat, snps, logp_out)
         ctx.mark_non_differentiable(terms)
         ctx.set_materialize_grads(False)          # no zero tensor for `terms` in the backward
+        if from_logits:
+            ctx.mark_non_differentiable(logp_out)
+            return loss.view(()), terms, logp_out
         return loss.view(()), terms
 
     @staticmethod
-    def backward(ctx, gout, _gterms):
-        y, reg, clin, x_hat, snps = ctx.saved_tensors
+    def backward(ctx, gout, _gterms, _glogp=None):
+        y, reg, clin, x_hat, snps, logp = ctx.saved_tensors
         b, c, nr, s, lam, hp_ce, hp_mi = ctx.cfg
         gout = _f32(gout).reshape(1)
         dev = reg.device
         dlogp = torch.empty(2 * b, c, dtype=torch.float32, device=dev)
         dreg, dxhat = torch.empty_like(reg), torch.empty_like(x_hat)
-        dgram = torch.empty(2, 2, dtype=torch.float32, device=dev)
-        dprob = torch.empty((), dtype=torch.float32, device=dev)
+        dgram = torch.empty(4, dtype=torch.float32, device=dev)
+        dprob = torch.empty(1, dtype=torch.float32, device=dev)
         lam6 = (ctypes.c_float * 6)(*lam)
-        call("igcn_loss_head_bwd", b, c, nr, s, ptr(y), ptr(reg), ptr(clin), ptr(x_hat), ptr(snps), lam6, hp_ce,
-             hp_mi, ptr(gout), ptr(dlogp), ptr(dreg), ptr(dxhat), ptr(dgram), ptr(dprob), stream_ptr())
-        return dlogp, None, dreg, None, dxhat, None, dgram, dprob, None, None, None
+        call("igcn_loss_head_bwd", b, c, nr, s, ptr(y), ptr(reg), ptr(clin), ptr(x_hat), ptr(snps), ptr(logp), lam6,
+             hp_ce, hp_mi, ptr(gout), ptr(dlogp), ptr(dreg), ptr(dxhat), ptr(dgram), ptr(dprob), stream_ptr())
+        # un-reduced partial inputs: every row gets the gradient of the sum (stride-0 views: no launch)
+        gs, ps = ctx.gram_shape, ctx.prob_shape
+        dgram = dgram.view(2, 2) if gs == (2, 2) else dgram.view(1, 4).expand(gs[0], 4)
+        dprob = dprob.view(()) if ps == () else dprob.expand(ps)
+        return dlogp, None, dreg, None, dxhat, None, dgram, dprob, None, None, None, None
 
 
 # =================================================================================================

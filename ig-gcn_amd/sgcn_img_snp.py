@@ -186,13 +186,13 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         ent = -torch.sum(p * torch.log(p + eps) + (1 - p) * torch.log((1 - p) + eps)) / n
         return l1, ent
 
-    def loss_probability(self, x, edge_index, edge_weight, hp, eps=1e-6, plan=None, edge_prob=None):
+    def loss_probability(self, x, edge_index, edge_weight, hp, eps=1e-6, plan=None, edge_prob=None, partials=False):
         """:153-181 as one fused reduction (igcn_mask_reg_*).  ``edge_prob`` lets the train step reuse the mask
-        the explain pass already computed."""
+        the explain pass already computed; ``partials``: the un-reduced workgroup sums (ops.LossHead adds them up)."""
         if edge_prob is None:
             _, _, _, edge_prob = self.cal_probability(x, edge_index, edge_weight, plan=plan)
         return ops.MaskRegulariser.apply(self.prob, edge_prob, self.snps_prob, hp.lamda_x_l1, hp.lamda_x_ent,
-                                         hp.lamda_e_l1, hp.lamda_e_ent, eps)
+                                         hp.lamda_e_l1, hp.lamda_e_ent, eps, partials)
 
     def laplacian(self, n, tsne_result=None):
         """D - W of consist_loss (:188-193): RBF similarity of the t-SNE embedding, or all-ones."""
@@ -256,7 +256,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         produce every parameter gradient once instead of adding two per-pass contributions."""
         return self._forward_grouped(data, temperature, device, (False, True))
 
-    def _forward_grouped(self, data, temperature, device, explain_flags, split=True):
+    def _forward_grouped(self, data, temperature, device, explain_flags, split=True, raw_scores=False):
         x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
         snps_feat = data.snps_feat
         x.requires_grad = True                                        # :210 — populates data.x.grad
@@ -340,7 +340,8 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             our_reg = ops.linear(self._drop(reg, 0.3), self.lin2_regr.weight, self.lin2_regr.bias)
         else:
             our_reg = ops.linear(reg, self.lin2_regr.weight, self.lin2_regr.bias, keep=keep2)
-        outs = (F.log_softmax(logits, dim=-1), x_hat, out_z, out_lin, linear_outf, our_reg)
+        # raw_scores: the caller takes log_softmax itself (ops.LossHead does it inside the loss kernel)
+        outs = (logits if raw_scores else F.log_softmax(logits, dim=-1), x_hat, out_z, out_lin, linear_outf, our_reg)
         if not split:
             return outs                                               # stacked [g*B, ...] (pass-major)
         if g == 1:

@@ -186,17 +186,31 @@ def _losses_batched(model, data, lam, hp, temperature):
     per direction (igcn_loss_head_*) for the terms and their weighted sum — the per-pass means of equal-sized
     halves are taken on the stacked tensors, so nothing is sliced."""
     dev = data.x.device
-    logp, x_hat, out_z, out_lin, lin_f, reg = model._forward_grouped(data, temperature, dev, (False, True),
-                                                                     split=False)
+    scores, x_hat, out_z, out_lin, lin_f, reg = model._forward_grouped(data, temperature, dev, (False, True),
+                                                                       split=False, raw_scores=True)
     from . import ops
-    lap = model.laplacian(logp.shape[0] // 2, data.tsne_fdim)
-    gram = ops.GramLosses.apply(out_z, lap, 2, True)                     # [2,2] = (consist, orth) per pass
-    prob = model.loss_probability(data.x, data.edge_index, data.edge_attr, hp, edge_prob=model.last_edge_prob)
+    lap = model.laplacian(scores.shape[0] // 2, data.tsne_fdim)
+    # the Gram terms and the mask regulariser arrive as un-reduced partial sums and the class scores raw: the loss
+    # kernel adds the partials up and takes log_softmax itself (two reductions and two torch launches less)
+    gram = ops.GramLosses.apply(out_z, lap, 2, "partials")               # rows sum to [2,2] = (consist, orth) per pass
+    prob = model.loss_probability(data.x, data.edge_index, data.edge_attr, hp, edge_prob=model.last_edge_prob,
+                                  partials=True)
     lam6 = [float(v) for v in lam]
-    loss, terms = ops.LossHead.apply(logp, data.y.view(-1), reg, data.clini_score.view(-1), x_hat, data.snps_feat,
-                                     gram, prob, lam6, hp.lamda_ce, hp.lamda_mi)
+    loss, terms, logp = ops.LossHead.apply(scores, data.y.view(-1), reg, data.clini_score.view(-1), x_hat,
+                                           data.snps_feat, gram, prob, lam6, hp.lamda_ce, hp.lamda_mi, True)
     t = dict(zip(("ce", "mi", "reg", "prob", "recon", "cluster", "orth"), terms.unbind(0)))
     return loss, t, (logp, x_hat, out_z, out_lin, lin_f, reg)
+
+
+_UNIT = {}
+
+
+def _unit_grad(loss):
+    """d loss / d loss = 1 as a cached device scalar (autograd would otherwise launch a fill for it every step)."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    if key not in _UNIT:
+        _UNIT[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+    return _UNIT[key]
 
 
 def backward_to_grads(loss, optimizer, data=None, defer=False):
@@ -219,9 +233,9 @@ def backward_to_grads(loss, optimizer, data=None, defer=False):
         # every parameter enters the graph ONCE — a parameter used twice has its two gradients added by autograd
         # during the backward, i.e. before the flush.
         with ops.deferred_reductions():
-            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+            grads = torch.autograd.grad(loss, leaves, grad_outputs=_unit_grad(loss), allow_unused=True)
     else:
-        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        grads = torch.autograd.grad(loss, leaves, grad_outputs=_unit_grad(loss), allow_unused=True)
     for t, g in zip(leaves, grads):
         t.grad = g
 

@@ -343,6 +343,9 @@ int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end, co
  * prob [n_prob] and snps [n_snps] are logits, e [n_edge] the edge mask of igcn_edge_mask_fwd.
  * scratch: float[1024].  gout: device scalar d(loss_total)/d(loss).
  */
+/* loss == NULL: no final sum — the igcn_mask_reg_blocks(n_prob + n_edge + n_snps) block partials stay in scratch for
+ * the consumer to add up (igcn_loss_head_fwd, prob_rows). */
+int igcn_mask_reg_blocks(int64_t n_total);
 int igcn_mask_reg_fwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const float* prob, const float* e,
                       const float* snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,
                       float* loss, float* scratch, void* stream);
@@ -360,6 +363,7 @@ int igcn_mask_reg_bwd(int64_t n_prob, int64_t n_edge, int64_t n_snps, const floa
  * [groups,2], S [groups,B,B]) take one launch.  scratch (fwd): float[2 B groups].
  */
 int igcn_rbf_laplacian(int B, int T, float gamma, const float* t, float* Lap, void* stream);
+/* out == NULL: no final sum — the row partials [B][groups*2] stay in scratch (igcn_loss_head_fwd, gram_rows). */
 int igcn_gram_loss_fwd(int B, int RD, int groups, const float* G, const float* Lap, float* out, float* scratch,
                        void* stream);
 int igcn_gram_loss_bwd(int B, int groups, const float* G, const float* Lap, const float* gout, float* S,
@@ -522,15 +526,20 @@ int igcn_comm_destroy(void* comm);
  * logp [2B,C] log-probabilities, y int64 [B], reg [2B,NR], clin [B*NR], x_hat [2B,S], snps [B,S],
  * gram [2][2] = igcn_gram_loss_fwd outputs of the two passes, prob [1] = igcn_mask_reg_fwd output.
  * lam6 is a HOST array (read at call time).  Backward: gout [1] device scalar; dgram [4], dprob [1].
+ * from_logits != 0: `logp` holds the raw class scores [2B,C]; F.log_softmax (kernel/sgcn_img_snp.py:305) is taken
+ * inside and written to logp_out [2B,C]; the backward, given that logp, returns the gradient of the raw scores.
+ * gram_rows / prob_rows > 1: gram [gram_rows][4] / prob [prob_rows] are the un-reduced partials of
+ * igcn_gram_loss_fwd (out == NULL) / igcn_mask_reg_fwd (loss == NULL); their rows are summed here (the gradient of
+ * every row is dgram / dprob).
  */
-int igcn_loss_head_fwd(int B, int C, int NR, int S, const float* logp, const int64_t* y, const float* reg,
-                       const float* clin, const float* x_hat, const float* snps, const float* gram,
-                       const float* prob, const float* lam6, float hp_ce, float hp_mi, float* loss, float* terms,
-                       void* stream);
+int igcn_loss_head_fwd(int B, int C, int NR, int S, const float* logp, int from_logits, float* logp_out,
+                       const int64_t* y, const float* reg, const float* clin, const float* x_hat, const float* snps,
+                       const float* gram, int gram_rows, const float* prob, int prob_rows, const float* lam6,
+                       float hp_ce, float hp_mi, float* loss, float* terms, void* stream);
 int igcn_loss_head_bwd(int B, int C, int NR, int S, const int64_t* y, const float* reg, const float* clin,
-                       const float* x_hat, const float* snps, const float* lam6, float hp_ce, float hp_mi,
-                       const float* gout, float* dlogp, float* dreg, float* dxhat, float* dgram, float* dprob,
-                       void* stream);
+                       const float* x_hat, const float* snps, const float* logp, const float* lam6, float hp_ce,
+                       float hp_mi, const float* gout, float* dlogp, float* dreg, float* dxhat, float* dgram,
+                       float* dprob, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Graph-diffusion pre-transform + block-diagonal collation of B dense adjacencies A [B,R,R] (f32), on the device —

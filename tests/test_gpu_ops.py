@@ -827,6 +827,55 @@ def test_loss_head_matches_composite():
         assert_matches(g, w.grad.float().cpu().numpy(), 1e-5, "grad " + name)
 
 
+@pytest.mark.gpu
+def test_loss_head_from_scores_and_partials():
+    """The step's form of the loss head: raw class scores (log_softmax inside the kernel, returned as an output),
+    un-reduced Gram / regulariser partials as inputs — against F.log_softmax + the term-by-term composite in fp64."""
+    import torch.nn.functional as F
+    from igcn_amd import ops
+    torch.manual_seed(1)
+    b, c, nr, s = 37, 3, 3, 54
+    dev = "cuda"
+    scores = (3 * torch.randn(2 * b, c, device=dev)).requires_grad_(True)
+    y = torch.randint(0, c, (b,), device=dev)
+    reg = torch.randn(2 * b, nr, device=dev, requires_grad=True)
+    clin = torch.rand(b * nr, device=dev)
+    x_hat = torch.randn(2 * b, s, device=dev, requires_grad=True)
+    snps = torch.rand(b, s, device=dev)
+    gram_p = torch.rand(b, 4, device=dev, requires_grad=True)           # rows sum to (consist0, orth0, consist1, orth1)
+    prob_p = torch.rand(19, device=dev, requires_grad=True)
+    lam, hp_ce, hp_mi = [0.7, 1.0, 0.5, 1.5e-3, 0.1, 0.2], 1.3, 0.8
+    loss, terms, logp = ops.LossHead.apply(scores, y, reg, clin, x_hat, snps, gram_p, prob_p, lam, hp_ce, hp_mi, True)
+    (loss * 1.7).backward()
+    got = [t.grad.clone() for t in (scores, reg, x_hat, gram_p, prob_p)]
+    d = lambda t: t.detach().double().requires_grad_(True)          # noqa: E731
+    sc2, reg2, x2, gram2, prob2 = d(scores), d(reg), d(x_hat), d(gram_p), d(prob_p)
+    logp2 = F.log_softmax(sc2, dim=-1)
+    gsum = gram2.sum(0)
+    t = [lam[0] * F.nll_loss(logp2[:b], y), lam[0] * F.nll_loss(logp2[b:], y),
+         lam[1] * (F.mse_loss(reg2[:b].reshape(-1), clin.double()) + F.mse_loss(reg2[b:].reshape(-1), clin.double())) / 2,
+         lam[2] * prob2.sum(),
+         lam[3] * (((x2[:b] - snps.double()) ** 2).sum() + ((x2[b:] - snps.double()) ** 2).sum()) / 2,
+         lam[4] * (gsum[0] + gsum[2]) / 2, lam[5] * gsum[1]]
+    want = hp_ce * t[0] + hp_mi * t[1] + sum(t[2:])
+    (want * 1.7).backward()
+    assert_matches(logp, logp2.detach().float().cpu().numpy(), 1e-5, "log_softmax")
+    assert abs(float(loss) - float(want)) <= 1e-5 * abs(float(want))
+    for k in range(7):
+        assert abs(float(terms[k]) - float(t[k])) <= 1e-5 * max(1e-3, abs(float(t[k]))), k
+    for g, w, name in zip(got, (sc2, reg2, x2, gram2, prob2), ("scores", "reg", "x_hat", "gram", "prob")):
+        assert_matches(g, w.grad.float().cpu().numpy(), 1e-5, "grad " + name, floor=1e-7)
+    # lam[0] == 0: the class scores are not read for the loss and their gradient is exactly zero, even when non-finite
+    bad = scores.detach().clone()
+    bad[0, 0] = float("inf")
+    bad.requires_grad_(True)
+    lam0 = [0.0] + lam[1:]
+    loss0, _, _ = ops.LossHead.apply(bad, y, reg.detach(), clin, x_hat.detach(), snps, gram_p.detach(), prob_p.detach(),
+                                     lam0, hp_ce, hp_mi, True)
+    loss0.backward()
+    assert bool(torch.isfinite(loss0)) and float(bad.grad.abs().max()) == 0.0
+
+
 _AB_SCRIPT = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])

@@ -30,7 +30,13 @@ cnt = Counter()
 class Log(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func.overloadpacket.__name__
-        if name in ("copy_", "clone", "_to_copy", "contiguous", "fill_", "zero_", "zeros_like", "add", "add_", "cat"):
+        views = ("view", "_unsafe_view", "reshape", "expand", "t", "transpose", "permute", "slice", "select", "detach",
+                 "alias", "as_strided", "unsqueeze", "squeeze", "split", "split_with_sizes", "unbind", "empty",
+                 "empty_like", "empty_strided", "new_empty", "narrow", "chunk", "is_same_size", "sym_size", "stride",
+                 "size", "numel", "dim", "_local_scalar_dense", "item", "lift_fresh", "unfold", "flatten", "view_as",
+                 "record_stream", "is_pinned", "storage_offset", "sym_numel", "sym_stride", "sym_storage_offset",
+                 "is_contiguous", "result_type", "movedim")
+        if name not in views:
             t = next((a for a in args if isinstance(a, torch.Tensor)), None)
             if t is not None and t.is_cuda:
                 fr = [f"{os.path.basename(f.filename)}:{f.lineno}" for f in traceback.extract_stack()
