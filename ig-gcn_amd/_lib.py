@@ -53,6 +53,8 @@ SIGNATURES = {
     "igcn_gemm_f32": (I, [L, L, L, P, L, L, P, L, L, P, P, L, I, I, P, P]),
     "igcn_gemm_bf16": (I, [L, L, L, P, L, L, P, L, L, P, P, L, I, I, P, P]),
     "igcn_gemm_f32_batched_sum": (I, [L, L, L, I, P, L, L, L, P, L, L, L, P, L, P, P]),
+    "igcn_gemm_f32_batched": (I, [L, L, L, I, P, L, L, L, P, L, L, L, P, L, L, I, P, P]),
+    "igcn_gemm_f32_grouped": (I, [I, P, P]),
     "igcn_node_linear_bn_scratch_floats": (Z, [I, I, I]),
     "igcn_node_linear_bn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, I, F, F, P, P, P, P, P, P]),
     "igcn_node_linear_bn_bwd_scratch_floats": (Z, [I, I, I, I, I]),

@@ -129,11 +129,11 @@ struct Stage {
 // PF = K-tiles in flight in registers ahead of the one in LDS (1 for products of one or two K steps — the short-K
 // streaming products, where registers are better spent on more workgroups per CU — 2 otherwise).
 template <int BN, int VW, int PF, bool ARF, bool BRF>
-__global__ void __launch_bounds__(256)
-k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,
-           const float* __restrict__ B, int64_t sbn, int64_t sbk, const float* __restrict__ bias,
-           float* __restrict__ C, int64_t ldc, int act, int64_t k_per_split, int64_t slab_stride,
-           int64_t a_zs, int64_t b_zs, int zsplit) {
+__device__ __forceinline__ void
+gemm_f32_tile(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,
+              const float* __restrict__ B, int64_t sbn, int64_t sbk, const float* __restrict__ bias,
+              float* __restrict__ C, int64_t ldc, int act, int64_t k_per_split, int64_t slab_stride,
+              int64_t a_zs, int64_t b_zs, int zsplit, const dim3 tile, const bool final_out) {
   // dynamic LDS: one buffer per operand when the workgroup has a single K step (short-K streaming products: more
   // workgroups per CU hide each other's load latency), two otherwise
   extern __shared__ __attribute__((aligned(16))) float g_lds[];
@@ -146,7 +146,6 @@ k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // (an XCD-aware remap of the launch order — each L2 serving one K slice / one run of N tiles — measured 0.5 % slower
   // in the step: these operands are a few MB and the Infinity Cache already absorbs the re-reads)
-  const dim3 tile = blockIdx;
   const int64_t m0 = (int64_t)tile.x * G_BM, n0 = (int64_t)tile.y * BN;
   // tile.z = (batch index) * zsplit + (K slice): K slices of one product (a_zs == b_zs == 0) and/or a batch
   // of independent products (a_zs/b_zs = element offsets per batch) whose slabs are all summed afterwards
@@ -247,7 +246,6 @@ k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t
   G_PROBE(2);
   // epilogue: 16 bytes per lane when the output rows allow it
   float* Cz = C + (int64_t)tile.z * slab_stride;
-  const bool final_out = (gridDim.z == 1);
   const int64_t gm = m0 + w * 16 + (lane & 15);
   const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)Cz & 15) == 0);
   if (gm < M) {
@@ -271,6 +269,50 @@ k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t
       }
     }
   }
+}
+
+template <int BN, int VW, int PF, bool ARF, bool BRF>
+__global__ void __launch_bounds__(256)
+k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,
+           const float* __restrict__ B, int64_t sbn, int64_t sbk, const float* __restrict__ bias,
+           float* __restrict__ C, int64_t ldc, int act, int64_t k_per_split, int64_t slab_stride,
+           int64_t a_zs, int64_t b_zs, int zsplit) {
+  gemm_f32_tile<BN, VW, PF, ARF, BRF>(M, N, K, A, sam, sak, B, sbn, sbk, bias, C, ldc, act, k_per_split, slab_stride,
+                                      a_zs, b_zs, zsplit, blockIdx, gridDim.z == 1);
+}
+
+// Several products of DIFFERENT shapes in one launch (the dX and dW products of a linear layer's backward, which share
+// the upstream gradient and nothing else): the workgroups of all problems form one flat grid, so the small grids of a
+// backward pass fill the chip together instead of one after the other.  Tile width, vector width and pipeline depth are
+// common to the group (host: the narrowest / safest of the members); the operand layouts are per problem.
+#define GG_MAX 4
+struct GemmProb {
+  int64_t M, N, K;
+  const float* A; int64_t sam, sak;
+  const float* B; int64_t sbn, sbk;
+  const float* bias; float* C; int64_t ldc; int act;
+  int64_t kps, slab; int zsplit;
+  int gx, gy, gz, wg0;                                  // tiles per axis; first workgroup of the problem in the flat grid
+  int arf, brf;
+};
+struct GemmGroup { int n; GemmProb p[GG_MAX]; };
+
+template <int BN, int VW, int PF>
+__global__ void __launch_bounds__(256) k_gemm_f32_grouped(const GemmGroup G) {
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GG_MAX; ++i)
+    if (i < G.n && (int)blockIdx.x >= G.p[i].wg0) pi = i;
+  const GemmProb& p = G.p[pi];
+  const int l = (int)blockIdx.x - p.wg0;
+  const dim3 tile((unsigned)(l % p.gx), (unsigned)((l / p.gx) % p.gy), (unsigned)(l / (p.gx * p.gy)));
+  const bool fin = p.gz == 1;
+#define GG_BODY(ARFV, BRFV)                                                                                          \
+  gemm_f32_tile<BN, VW, PF, ARFV, BRFV>(p.M, p.N, p.K, p.A, p.sam, p.sak, p.B, p.sbn, p.sbk, p.bias, p.C, p.ldc, p.act,  \
+                                        p.kps, p.slab, 0, 0, p.zsplit, tile, fin)
+  if (p.arf) { if (p.brf) GG_BODY(true, true); else GG_BODY(true, false); }
+  else       { if (p.brf) GG_BODY(false, true); else GG_BODY(false, false); }
+#undef GG_BODY
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -442,10 +484,14 @@ static void launch_f32(int bn, int vw, dim3 grid, hipStream_t st, const GemmArgs
   if (bn == 16) launch_f32_v<16>(vw, grid, st, g); else if (bn == 32) launch_f32_v<32>(vw, grid, st, g); else launch_f32_v<64>(vw, grid, st, g);
 }
 
+// (gridDim.y = independent products of a batch: slabs [batch][split_k][M*N], C + blockIdx.y * c_batch)
 __global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const float* __restrict__ slabs,
-                                     const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int act) {
+                                     const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int act,
+                                     int64_t c_batch) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * N) return;
+  slabs += (int64_t)blockIdx.y * split_k * M * N;
+  C += (int64_t)blockIdx.y * c_batch;
   const int64_t m = i / N, n = i - m * N;
   float t = 0.f;
 #pragma unroll 8
@@ -476,6 +522,21 @@ extern "C" int igcn_gemm_f32_split_k(int64_t M, int64_t N, int64_t K) {
   if (sk > 256) sk = 256;
   if (sk > K / G_BK) sk = K / G_BK;
   return (int)(sk < 1 ? 1 : sk);
+}
+
+// the slab sum behind a split product: deferred to the backward's flush (parameter gradients), a block-per-output tree
+// (few outputs, many slabs), or the plain column walk with bias / activation
+static int gemm_sum_slabs(int split_k, bool final_grad, int64_t M, int64_t N, float* scratch, const float* bias,
+                          float* C, int64_t ldc, int act, hipStream_t st) {
+  if (split_k <= 1) return IGCN_OK;
+  if (final_grad && ldc == N && bias == nullptr && act == 0 && M * N < ((int64_t)1 << 31))
+    return igcn_launch_reduce_rows_final(scratch, split_k, M * N, (int)(M * N), C, st);
+  if (ldc == N && M * N <= 4096 && split_k > 32 && bias == nullptr && act == 0)
+    return igcn_launch_reduce_rows(scratch, split_k, M * N, (int)(M * N), C, 0, st);   // block-per-output tree
+  hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3((unsigned)igcn_cdiv(M * N, 256)), dim3(256), 0, st, M, N, split_k,
+                     scratch, bias, C, ldc, act, (int64_t)0);
+  IGCN_CHECK_LAUNCH("gemm_splitk_reduce");
+  return IGCN_OK;
 }
 
 static int gemm_launch(bool bf16, int64_t M, int64_t N, int64_t K, const float* A, int64_t sam, int64_t sak,
@@ -517,16 +578,7 @@ static int gemm_launch(bool bf16, int64_t M, int64_t N, int64_t K, const float* 
     launch_f32(bn, vw, grid, st, g);
   }
   IGCN_CHECK_LAUNCH(nm);
-  if (split && final_grad && ldc == N && bias == nullptr && act == 0 && M * N < ((int64_t)1 << 31))
-    return igcn_launch_reduce_rows_final(scratch, split_k, M * N, (int)(M * N), C, st);
-  if (split && ldc == N && M * N <= 4096 && split_k > 32 && bias == nullptr && act == 0)
-    return igcn_launch_reduce_rows(scratch, split_k, M * N, (int)(M * N), C, 0, st);   // block-per-output tree
-  if (split) {
-    hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3((unsigned)igcn_cdiv(M * N, 256)), dim3(256), 0, st, M, N, split_k,
-                       scratch, bias, C, ldc, act);
-    IGCN_CHECK_LAUNCH("gemm_splitk_reduce");
-  }
-  return IGCN_OK;
+  return gemm_sum_slabs(split_k, final_grad, M, N, scratch, bias, C, ldc, act, st);
 }
 
 extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t sam, int64_t sak,
@@ -578,7 +630,126 @@ int igcn_gemm_f32_batched_sum_impl(int64_t M, int64_t N, int64_t K, int batch, c
   if (ldc == N && M * N <= 4096 && slabs > 32)     // few outputs, many slabs: block-per-output tree reduce
     return igcn_launch_reduce_rows(scratch, slabs, M * N, (int)(M * N), C, 0, st);
   hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3((unsigned)igcn_cdiv(M * N, 256)), dim3(256), 0, st, M, N, slabs,
-                     scratch, (const float*)nullptr, C, ldc, 0);
+                     scratch, (const float*)nullptr, C, ldc, 0, (int64_t)0);
   IGCN_CHECK_LAUNCH("gemm_batched_reduce");
+  return IGCN_OK;
+}
+
+
+// `batch` independent products of one shape in ONE launch (+ one slab sum when K is split):
+//   C_z [M,N] = A_z B_z^T,  A_z = A + z a_batch, B_z = B + z b_batch, C_z = C + z c_batch   (element offsets)
+// — the per-pass Gram matrices of the batched train step and their backward products: two half-empty grids and two
+// slab sums become one launch each.  scratch: batch * split_k * M * N floats when split_k > 1.
+extern "C" int igcn_gemm_f32_batched(int64_t M, int64_t N, int64_t K, int batch, const float* A, int64_t sam,
+                                     int64_t sak, int64_t a_batch, const float* B, int64_t sbn, int64_t sbk,
+                                     int64_t b_batch, float* C, int64_t c_batch, int64_t ldc, int split_k,
+                                     float* scratch, void* stream) {
+  IGCN_REQUIRE(M > 0 && N > 0 && K > 0 && batch >= 1 && split_k >= 1, "gemm_f32_batched: bad sizes");
+  IGCN_REQUIRE(split_k == 1 || scratch != nullptr, "gemm_f32_batched: split_k > 1 needs scratch");
+  hipStream_t st = (hipStream_t)stream;
+  if (split_k > K / G_BK) split_k = (int)(K / G_BK > 0 ? K / G_BK : 1);
+  int64_t kps = igcn_cdiv(igcn_cdiv(K, split_k), G_BK) * G_BK;
+  split_k = (int)igcn_cdiv(K, kps);
+  const bool split = split_k > 1;
+  const int bn = gemm_tile_n(M, N);
+  dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)(batch * split_k));
+  int vw = min_int(vec_width(A, sam, sak, M, K), vec_width(B, sbn, sbk, N, K));
+  while (vw > 1 && (a_batch % vw != 0 || b_batch % vw != 0)) vw >>= 1;
+  // split: slab (z, k) of the scratch, row stride N; unsplit: straight into C_z (the kernel's slab stride = c_batch)
+  const GemmArgs g = {M, N, K, A, sam, sak, B, sbn, sbk, nullptr, split ? scratch : C, split ? N : ldc, 0, kps,
+                      split ? M * N : c_batch, a_batch, b_batch, split_k};
+  launch_f32(bn, vw, grid, st, g);
+  IGCN_CHECK_LAUNCH("gemm_f32_batched");
+  if (split) {
+    hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3((unsigned)igcn_cdiv(M * N, 256), (unsigned)batch), dim3(256), 0, st, M,
+                       N, split_k, scratch, (const float*)nullptr, C, ldc, 0, c_batch);
+    IGCN_CHECK_LAUNCH("gemm_f32_batched reduce");
+  }
+  return IGCN_OK;
+}
+
+
+// n (<= 4) products of different shapes in ONE launch: table [n][16] int64 =
+//   {M, N, K, A, sam, sak, B, sbn, sbk, bias, C, ldc, act (| 0x100: parameter gradient), split_k, scratch, 0}
+// with the meaning of igcn_gemm_f32's arguments.  Slab sums follow per problem as there.  Falls back to one launch per
+// problem when the operands do not all allow at least 8-byte loads.
+static size_t gemm_lds_bytes(int bn, int64_t k_per_split, bool a_rfast, bool b_rfast);
+extern "C" int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream) {
+  IGCN_REQUIRE(n >= 1 && n <= GG_MAX && table != nullptr, "gemm_f32_grouped: 1..%d problems", GG_MAX);
+  hipStream_t st = (hipStream_t)stream;
+  GemmGroup G;
+  G.n = n;
+  int bn = 64, vw = 4, pf = 1, wgs = 0, split_of[GG_MAX];
+  bool fgrad[GG_MAX];
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    const int64_t* t = table + 16 * i;
+    GemmProb& p = G.p[i];
+    p.M = t[0]; p.N = t[1]; p.K = t[2];
+    p.A = (const float*)t[3]; p.sam = t[4]; p.sak = t[5];
+    p.B = (const float*)t[6]; p.sbn = t[7]; p.sbk = t[8];
+    p.bias = (const float*)t[9];
+    float* C = (float*)t[10];
+    const int64_t ldc = t[11];
+    int act = (int)t[12], split_k = (int)t[13];
+    float* scratch = (float*)t[14];
+    fgrad[i] = (act & 0x100) != 0;
+    act &= 0xff;
+    IGCN_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && split_k >= 1 && (split_k == 1 || scratch != nullptr),
+                 "gemm_f32_grouped: bad problem %d", i);
+    if (split_k > p.K / G_BK) split_k = (int)(p.K / G_BK > 0 ? p.K / G_BK : 1);
+    const int64_t kps = igcn_cdiv(igcn_cdiv(p.K, split_k), G_BK) * G_BK;
+    split_k = (int)igcn_cdiv(p.K, kps);
+    split_of[i] = split_k;
+    const bool split = split_k > 1;
+    p.C = split ? scratch : C;
+    p.ldc = split ? p.N : ldc;
+    p.act = act;
+    p.kps = kps;
+    p.slab = split ? p.M * p.N : 0;
+    p.zsplit = split_k;
+    p.arf = (p.sam == 1 && p.sak != 1);
+    p.brf = (p.sbn == 1 && p.sbk != 1);
+    const int b = gemm_tile_n(p.M, p.N);
+    bn = b < bn ? b : bn;
+    const int v = min_int(vec_width(p.A, p.sam, p.sak, p.M, p.K), vec_width(p.B, p.sbn, p.sbk, p.N, p.K));
+    vw = v < vw ? v : vw;
+    if (igcn_cdiv(kps < p.K ? kps : p.K, G_BK) > 2) pf = 2;
+  }
+  if (vw < 2 || n == 1) {                              // not groupable: the ordinary launches, one after the other
+    for (int i = 0; i < n; ++i) {
+      const int64_t* t = table + 16 * i;
+      const int rc = gemm_launch(false, t[0], t[1], t[2], (const float*)t[3], t[4], t[5], (const float*)t[6], t[7], t[8],
+                                 (const float*)t[9], (float*)t[10], t[11], (int)t[12], (int)t[13], (float*)t[14], stream);
+      if (rc) return rc;
+    }
+    return IGCN_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    GemmProb& p = G.p[i];
+    p.gx = (int)igcn_cdiv(p.M, G_BM);
+    p.gy = (int)igcn_cdiv(p.N, bn);
+    p.gz = p.zsplit;
+    p.wg0 = wgs;
+    wgs += p.gx * p.gy * p.gz;
+    const size_t l = gemm_lds_bytes(bn, p.kps, p.arf, p.brf);
+    lds = l > lds ? l : lds;
+  }
+  for (int i = n; i < GG_MAX; ++i) G.p[i] = G.p[0];
+#define LAUNCH_GG(BNV, PFV)                                                                                          \
+  do {                                                                                                               \
+    if (vw == 4) hipLaunchKernelGGL((k_gemm_f32_grouped<BNV, 4, PFV>), dim3((unsigned)wgs), dim3(256), lds, st, G);   \
+    else hipLaunchKernelGGL((k_gemm_f32_grouped<BNV, 2, PFV>), dim3((unsigned)wgs), dim3(256), lds, st, G);           \
+  } while (0)
+  if (pf == 1) { if (bn == 16) LAUNCH_GG(16, 1); else if (bn == 32) LAUNCH_GG(32, 1); else LAUNCH_GG(64, 1); }
+  else         { if (bn == 16) LAUNCH_GG(16, 2); else if (bn == 32) LAUNCH_GG(32, 2); else LAUNCH_GG(64, 2); }
+#undef LAUNCH_GG
+  IGCN_CHECK_LAUNCH("gemm_f32_grouped");
+  for (int i = 0; i < n; ++i) {
+    const int64_t* t = table + 16 * i;
+    const int rc = gemm_sum_slabs(split_of[i], fgrad[i], t[0], t[1], (float*)t[14], (const float*)t[9], (float*)t[10], t[11],
+                                  (int)t[12] & 0xff, st);
+    if (rc) return rc;
+  }
   return IGCN_OK;
 }

@@ -466,6 +466,48 @@ def gemm_tn(a, b, bf16=False, final_grad=False, out=None):
     return out
 
 
+def gemm_group(specs, bf16=False):
+    """Several independent products in ONE launch (igcn_gemm_f32_grouped; at most four).  ``specs``: tuples
+    (form, a, b, out, bias, final_grad) with form "nt" (a [M,K], b [N,K]), "nn" (a [M,K], b [K,N]) or "tn" (a [K,M],
+    b [K,N]); ``out`` None allocates.  Returns the outputs.  bf16 operands: one launch per product, as before."""
+    outs = []
+    if bf16 or len(specs) > 4 or os.environ.get("IGCN_NO_GEMM_GROUPS", "0") == "1":
+        for form, a, b, out, bias, final in specs:
+            if form == "nt":
+                outs.append(gemm_nt(a, b, bias, 0, out=out, bf16=bf16))
+            elif form == "nn":
+                outs.append(gemm_nn(a, b, out=out, bf16=bf16))
+            else:
+                outs.append(gemm_tn(a, b, bf16=bf16, final_grad=final, out=out))
+        return outs
+    table = (ctypes.c_int64 * (16 * len(specs)))()
+    hold = []
+    for i, (form, a, b, out, bias, final) in enumerate(specs):
+        a, b = _f32(a), _f32(b)
+        if form == "nt":
+            (m, k), n = a.shape, b.shape[0]
+            st = (k, 1, k, 1)
+        elif form == "nn":
+            (m, k), n = a.shape, b.shape[1]
+            st = (k, 1, 1, n)
+        else:
+            (k, m), n = a.shape, b.shape[1]
+            st = (1, m, 1, n)
+        if out is None:
+            out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+        sk = _split_k(m, n, k)
+        scratch = torch.empty(sk * m * n, dtype=torch.float32, device=a.device) if sk > 1 else None
+        if final:
+            _keep(scratch)
+        bias = _f32(bias) if bias is not None else None
+        hold += [a, b, out, scratch, bias]
+        table[16 * i:16 * i + 15] = [m, n, k, ptr(a) or 0, st[0], st[1], ptr(b) or 0, st[2], st[3], ptr(bias) or 0,
+                                     ptr(out) or 0, n, 0x100 if final else 0, sk, ptr(scratch) or 0]
+        outs.append(out)
+    call("igcn_gemm_f32_grouped", len(specs), ctypes.addressof(table), stream_ptr())
+    return outs
+
+
 class Linear(torch.autograd.Function):
     """y = act(x W^T + b) with W [out,in] (GCNConv.lin, lin1, lin1_regr, ...).  ``bf16``: the three products of the
     layer (forward, input gradient, weight gradient) take bf16 operands on the matrix cores, fp32 accumulation."""
@@ -503,8 +545,13 @@ class Linear(torch.autograd.Function):
             if ctx.relu:
                 dy = dy * (y > 0)
             db = dy.sum(0) if need_db else None
-        dx = gemm_nn(dy, weight, bf16=ctx.bf16) if ctx.needs_input_grad[0] else None
-        dw = gemm_tn(dy, x, bf16=ctx.bf16, final_grad=ctx.w_final) if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # dX = dy W and dW = dy^T x share dy and nothing else: one launch, their small grids side by side
+            dx, dw = gemm_group([("nn", dy, weight, None, None, False), ("tn", dy, x, None, None, ctx.w_final)],
+                                bf16=ctx.bf16)
+        else:
+            dx = gemm_nn(dy, weight, bf16=ctx.bf16) if ctx.needs_input_grad[0] else None
+            dw = gemm_tn(dy, x, bf16=ctx.bf16, final_grad=ctx.w_final) if ctx.needs_input_grad[1] else None
         return dx, dw, db, None, None
 
 
@@ -516,6 +563,23 @@ def _bias_grad_into(dy, db, final):
                                 device=dy.device))
     with _immediate(final):
         call("igcn_bias_grad", rows, cols, ptr(dy), None, None, ptr(db), ptr(scratch), stream_ptr())
+
+
+def _proj_backward(ctx, dq, dkv, q2, m2, w, dw, d):
+    """The four products behind the packed input projection's backward — input gradients of query and memory, weight
+    gradients of the two blocks (written into ``dw``) — in one launch when all four are wanted."""
+    if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+        with _immediate(ctx.final):
+            dquery, dmem, _, _ = gemm_group([("nn", dq, w[:d], None, None, False), ("nn", dkv, w[d:], None, None, False),
+                                             ("tn", dq, q2, dw[:d], None, True), ("tn", dkv, m2, dw[d:], None, True)],
+                                            bf16=ctx.bf16)
+        return dquery.view(ctx.shapes[0]), dmem.view(ctx.shapes[1])
+    dquery = gemm_nn(dq, w[:d], bf16=ctx.bf16).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None
+    dmem = gemm_nn(dkv, w[d:], bf16=ctx.bf16).view(ctx.shapes[1]) if ctx.needs_input_grad[1] else None
+    with _immediate(ctx.final):
+        gemm_tn(dq, q2, bf16=ctx.bf16, final_grad=True, out=dw[:d])
+        gemm_tn(dkv, m2, bf16=ctx.bf16, final_grad=True, out=dw[d:])
+    return dquery, dmem
 
 
 class InProj(torch.autograd.Function):
@@ -531,8 +595,8 @@ class InProj(torch.autograd.Function):
         d = w.shape[1]
         q2, m2 = _f32(query).reshape(-1, d), _f32(memory).reshape(-1, d)
         w, bias = _f32(w), _f32(bias)
-        q = gemm_nt(q2, w[:d], bias[:d], 0, bf16=bf16)
-        kv = gemm_nt(m2, w[d:], bias[d:], 0, bf16=bf16)
+        q, kv = gemm_group([("nt", q2, w[:d], None, bias[:d], False), ("nt", m2, w[d:], None, bias[d:], False)],
+                           bf16=bf16)
         ctx.save_for_backward(q2, m2, w)
         ctx.bf16, ctx.final = bf16, _leaves(w, bias)
         ctx.shapes = (query.shape, memory.shape)
@@ -547,11 +611,7 @@ class InProj(torch.autograd.Function):
         db = torch.empty(3 * d, dtype=torch.float32, device=w.device)
         _bias_grad_into(dq, db[:d], ctx.final)
         _bias_grad_into(dkv, db[d:], ctx.final)
-        dquery = gemm_nn(dq, w[:d], bf16=ctx.bf16).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None
-        dmem = gemm_nn(dkv, w[d:], bf16=ctx.bf16).view(ctx.shapes[1]) if ctx.needs_input_grad[1] else None
-        with _immediate(ctx.final):
-            gemm_tn(dq, q2, bf16=ctx.bf16, final_grad=True, out=dw[:d])
-            gemm_tn(dkv, m2, bf16=ctx.bf16, final_grad=True, out=dw[d:])
+        dquery, dmem = _proj_backward(ctx, dq, dkv, q2, m2, w, dw, d)
         return dquery, dmem, dw, db, None
 
 
@@ -1168,9 +1228,11 @@ class GramLosses(torch.autograd.Function):
         gram = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
         out = None if partials else torch.empty(groups, 2, dtype=torch.float32, device=s.device)
         scratch = torch.empty(2 * b * groups, dtype=torch.float32, device=s.device)
-        for g in range(groups):
-            sg = s[g * b:(g + 1) * b]
-            gemm_nt(sg, sg, out=gram[g])
+        # the per-group Gram matrices s_g s_g^T in ONE launch (+ one slab sum)
+        sk = _split_k(b * groups, b, rd)
+        gscr = torch.empty(groups * sk * b * b, dtype=torch.float32, device=s.device) if sk > 1 else None
+        call("igcn_gemm_f32_batched", b, b, rd, groups, ptr(s), rd, 1, b * rd, ptr(s), rd, 1, b * rd, ptr(gram), b * b, b,
+             sk, ptr(gscr), stream_ptr())
         call("igcn_gram_loss_fwd", b, rd, groups, ptr(gram), ptr(lap), ptr(out), ptr(scratch), stream_ptr())
         ctx.save_for_backward(s, lap, gram)
         ctx.groups, ctx.packed = groups, packed
@@ -1196,8 +1258,9 @@ class GramLosses(torch.autograd.Function):
         sym = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
         ds = torch.empty_like(s)
         call("igcn_gram_loss_bwd", b, groups, ptr(gram), ptr(lap), ptr(gout), ptr(sym), stream_ptr())
-        for g in range(groups):
-            gemm_nn(sym[g], s[g * b:(g + 1) * b], out=ds[g * b:(g + 1) * b])
+        rd = s.shape[1]
+        call("igcn_gemm_f32_batched", b, rd, b, groups, ptr(sym), b, 1, b * b, ptr(s), 1, rd, b * rd, ptr(ds), b * rd, rd,
+             1, None, stream_ptr())                                # ds_g = S_g s_g, every group in one launch
         return ds, None, None, None
 
 
@@ -1217,8 +1280,9 @@ class ProjectedAttention(torch.autograd.Function):
         q2, m2 = _f32(query).reshape(-1, d), _f32(memory).reshape(-1, d)
         w, bias = _f32(w), _f32(bias)
         b, lq, lk = query.shape[0], query.shape[1], memory.shape[1]
-        q = gemm_nt(q2, w[:d], bias[:d], 0, bf16=bf16).view(b, lq, d)
-        kv = gemm_nt(m2, w[d:], bias[d:], 0, bf16=bf16).view(b, lk, 2 * d)
+        q, kv = gemm_group([("nt", q2, w[:d], None, bias[:d], False), ("nt", m2, w[d:], None, bias[d:], False)],
+                           bf16=bf16)
+        q, kv = q.view(b, lq, d), kv.view(b, lk, 2 * d)
         o = torch.empty_like(q)
         lse = torch.empty(b, heads, lq, dtype=torch.float32, device=q.device)
         call("igcn_attn_core_fwd", b, d, heads, lq, lk, ptr(q), ptr(kv), ptr(o), ptr(lse), stream_ptr())
@@ -1247,11 +1311,7 @@ class ProjectedAttention(torch.autograd.Function):
         with _immediate(ctx.final):
             call("igcn_col_sums", rows, d, d, ptr(dq2), ptr(db), ptr(scr), stream_ptr())          # d b_q, then d b_k = 0
         _bias_grad_into(dout.reshape(-1, d), db[2 * d:], ctx.final)                                  # d b_v
-        dquery = gemm_nn(dq2, w[:d], bf16=ctx.bf16).view(ctx.shapes[0]) if ctx.needs_input_grad[0] else None
-        dmem = gemm_nn(dkv2, w[d:], bf16=ctx.bf16).view(ctx.shapes[1]) if ctx.needs_input_grad[1] else None
-        with _immediate(ctx.final):
-            gemm_tn(dq2, q2, bf16=ctx.bf16, final_grad=True, out=dw[:d])
-            gemm_tn(dkv2, m2, bf16=ctx.bf16, final_grad=True, out=dw[d:])
+        dquery, dmem = _proj_backward(ctx, dq2, dkv2, q2, m2, w, dw, d)
         return dquery, dmem, dw, db, None, None
 
 

@@ -209,6 +209,8 @@ def _unit_grad(loss):
     """d loss / d loss = 1 as a cached device scalar (autograd would otherwise launch a fill for it every step)."""
     key = (loss.device, loss.dtype, tuple(loss.shape))
     if key not in _UNIT:
+        if loss.is_cuda and torch.cuda.is_current_stream_capturing():
+            return None                  # never allocate the cached scalar from a capture's private pool
         _UNIT[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
     return _UNIT[key]
 

@@ -286,6 +286,16 @@ int igcn_gemm_f32_batched_sum(int64_t M, int64_t N, int64_t K, int batch,
                               const float* A, int64_t sam, int64_t sak, int64_t a_batch,
                               const float* B, int64_t sbn, int64_t sbk, int64_t b_batch,
                               float* C, int64_t ldc, float* scratch, void* stream);
+/* `batch` independent products of one shape in one launch: C_z [M,N] = A_z B_z^T with A_z = A + z*a_batch,
+ * B_z = B + z*b_batch, C_z = C + z*c_batch (element offsets).  split_k > 1 (see igcn_gemm_f32_split_k) needs
+ * scratch of batch*split_k*M*N floats; the slabs of every product are summed by one more launch. */
+int igcn_gemm_f32_batched(int64_t M, int64_t N, int64_t K, int batch, const float* A, int64_t sam, int64_t sak,
+                          int64_t a_batch, const float* B, int64_t sbn, int64_t sbk, int64_t b_batch, float* C,
+                          int64_t c_batch, int64_t ldc, int split_k, float* scratch, void* stream);
+/* n (1..4) products of DIFFERENT shapes in one launch (the dX and dW products of a linear layer's backward): table
+ * [n][16] int64 = {M, N, K, A, sam, sak, B, sbn, sbk, bias, C, ldc, act, split_k, scratch, 0} per problem, each field
+ * as the igcn_gemm_f32 argument of that name (pointers as integers).  Same results as n igcn_gemm_f32 calls. */
+int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GO read-outs: per-node linear + BatchNorm1d(#nodes) + ReLU, fused — go_model.py:117-121,254

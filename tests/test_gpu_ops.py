@@ -827,6 +827,48 @@ def test_loss_head_matches_composite():
         assert_matches(g, w.grad.float().cpu().numpy(), 1e-5, "grad " + name)
 
 
+@pytest.mark.parametrize("m,n,k,batch,sk,form", [(256, 256, 2880, 2, 4, "nt"), (256, 2880, 256, 2, 1, "nn"),
+                                                 (70, 33, 131, 3, 2, "nt"), (5, 7, 32, 4, 1, "nn")])
+def test_gemm_f32_batched(m, n, k, batch, sk, form):
+    """igcn_gemm_f32_batched: `batch` independent products in one launch (the Gram matrices of the two passes and their
+    backward products) against fp64 matmul, split and unsplit, both operand layouts, ragged sizes."""
+    from igcn_amd._lib import call, ptr, stream_ptr
+    torch.manual_seed(m + n + k)
+    a = torch.randn(batch, m, k, device="cuda")
+    b = torch.randn(batch, n, k, device="cuda") if form == "nt" else torch.randn(batch, k, n, device="cuda")
+    c = torch.full((batch, m, n), float("nan"), device="cuda")
+    scr = torch.empty(batch * sk * m * n, device="cuda") if sk > 1 else None
+    if form == "nt":
+        call("igcn_gemm_f32_batched", m, n, k, batch, ptr(a), k, 1, m * k, ptr(b), k, 1, n * k, ptr(c), m * n, n, sk,
+             ptr(scr), stream_ptr())
+        want = a.double() @ b.double().transpose(1, 2)
+    else:
+        call("igcn_gemm_f32_batched", m, n, k, batch, ptr(a), k, 1, m * k, ptr(b), 1, n, k * n, ptr(c), m * n, n, sk,
+             ptr(scr), stream_ptr())
+        want = a.double() @ b.double()
+    assert_matches(c, want.float().cpu().numpy(), 2e-6, "batched product")
+
+
+@pytest.mark.parametrize("rows,fin,fout", [(512, 64, 32), (4608, 32, 32), (300, 54, 7), (70, 33, 5)])
+def test_gemm_group_matches_single_products(rows, fin, fout):
+    """ops.gemm_group (igcn_gemm_f32_grouped): the dX / dW pair of a linear layer and a forward pair with bias in one
+    launch each — the same bits as the one-product launches (same tiling and K split per problem), also on shapes
+    whose rows allow only 8-byte loads, or none (there the entry point falls back to one launch per product)."""
+    from igcn_amd import ops
+    torch.manual_seed(rows + fin)
+    dy = torch.randn(rows, fout, device="cuda")
+    x = torch.randn(rows, fin, device="cuda")
+    w = torch.randn(fout, fin, device="cuda")
+    bias = torch.randn(fout, device="cuda")
+    dx, dw = ops.gemm_group([("nn", dy, w, None, None, False), ("tn", dy, x, None, None, False)])
+    assert torch.equal(dx, ops.gemm_nn(dy, w)) and torch.equal(dw, ops.gemm_tn(dy, x))
+    assert_matches(dx, (dy.double() @ w.double()).float().cpu().numpy(), 2e-6, "dx")
+    assert_matches(dw, (dy.double().t() @ x.double()).float().cpu().numpy(), 2e-6, "dw")
+    y1, y2 = ops.gemm_group([("nt", x, w, None, bias, False), ("nt", x[: rows // 2], w[: max(1, fout // 2)], None, None, False)])
+    assert torch.equal(y1, ops.gemm_nt(x, w, bias, 0))
+    assert torch.equal(y2, ops.gemm_nt(x[: rows // 2], w[: max(1, fout // 2)], None, 0))
+
+
 @pytest.mark.gpu
 def test_loss_head_from_scores_and_partials():
     """The step's form of the loss head: raw class scores (log_softmax inside the kernel, returned as an output),
