@@ -468,13 +468,15 @@ def gemm_tn(a, b, bf16=False, final_grad=False, out=None):
 
 def gemm_group(specs, bf16=False):
     """Several independent products in ONE launch (igcn_gemm_f32_grouped; at most four).  ``specs``: tuples
-    (form, a, b, out, bias, final_grad) with form "nt" (a [M,K], b [N,K]), "nn" (a [M,K], b [K,N]) or "tn" (a [K,M],
-    b [K,N]); ``out`` None allocates.  Returns the outputs.  bf16 operands: one launch per product, as before."""
+    (form, a, b, out, bias, final_grad[, act]) with form "nt" (a [M,K], b [N,K]), "nn" (a [M,K], b [K,N]) or "tn"
+    (a [K,M], b [K,N]); ``out`` None allocates; act 1 = ReLU ("nt" only).  Returns the outputs.  bf16 operands: one
+    launch per product, as before."""
     outs = []
+    specs = [tuple(sp) + (0,) * (7 - len(sp)) for sp in specs]
     if bf16 or len(specs) > 4 or os.environ.get("IGCN_NO_GEMM_GROUPS", "0") == "1":
-        for form, a, b, out, bias, final in specs:
+        for form, a, b, out, bias, final, act in specs:
             if form == "nt":
-                outs.append(gemm_nt(a, b, bias, 0, out=out, bf16=bf16))
+                outs.append(gemm_nt(a, b, bias, act, out=out, bf16=bf16))
             elif form == "nn":
                 outs.append(gemm_nn(a, b, out=out, bf16=bf16))
             else:
@@ -482,7 +484,7 @@ def gemm_group(specs, bf16=False):
         return outs
     table = (ctypes.c_int64 * (16 * len(specs)))()
     hold = []
-    for i, (form, a, b, out, bias, final) in enumerate(specs):
+    for i, (form, a, b, out, bias, final, act) in enumerate(specs):
         a, b = _f32(a), _f32(b)
         if form == "nt":
             (m, k), n = a.shape, b.shape[0]
@@ -502,7 +504,7 @@ def gemm_group(specs, bf16=False):
         bias = _f32(bias) if bias is not None else None
         hold += [a, b, out, scratch, bias]
         table[16 * i:16 * i + 15] = [m, n, k, ptr(a) or 0, st[0], st[1], ptr(b) or 0, st[2], st[3], ptr(bias) or 0,
-                                     ptr(out) or 0, n, 0x100 if final else 0, sk, ptr(scratch) or 0]
+                                     ptr(out) or 0, n, act | (0x100 if final else 0), sk, ptr(scratch) or 0]
         outs.append(out)
     call("igcn_gemm_f32_grouped", len(specs), ctypes.addressof(table), stream_ptr())
     return outs
@@ -563,6 +565,53 @@ def _bias_grad_into(dy, db, final):
                                 device=dy.device))
     with _immediate(final):
         call("igcn_bias_grad", rows, cols, ptr(dy), None, None, ptr(db), ptr(scratch), stream_ptr())
+
+
+class LinearPair(torch.autograd.Function):
+    """Two independent linear layers y_i = act(x_i W_i^T + b_i) as one op — the two heads' first layers (lin1 on
+    [out_z | latent], lin1_regr on the regression features; kernel/sgcn_img_snp.py:299-304): their forward products
+    share one grouped launch and their backward's four products (dX_1, dW_1, dX_2, dW_2) another, instead of running
+    as six half-empty grids one after the other."""
+
+    @staticmethod
+    def forward(ctx, x1, w1, b1, x2, w2, b2, relu):
+        x1, x2 = _f32(x1), _f32(x2)
+        y1, y2 = gemm_group([("nt", x1, w1, None, b1, False, 1 if relu else 0),
+                             ("nt", x2, w2, None, b2, False, 1 if relu else 0)])
+        ctx.save_for_backward(x1, w1, x2, w2, y1 if relu else None, y2 if relu else None)
+        ctx.relu = relu
+        ctx.final = (_leaves(w1), _leaves(b1), _leaves(w2), _leaves(b2))
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x1, w1, x2, w2, y1, y2 = ctx.saved_tensors
+        lib = _lib.load()
+        gs, dbs = [], []
+        for dy, y, b_final in ((dy1, y1, ctx.final[1]), (dy2, y2, ctx.final[3])):
+            dy = _f32(dy)
+            rows, cols = dy.shape
+            g = torch.empty_like(dy) if ctx.relu else None
+            db = torch.empty(cols, dtype=torch.float32, device=dy.device)
+            scratch = _keep(torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, cols)), dtype=torch.float32,
+                                        device=dy.device))
+            with _immediate(b_final):                                   # ReLU mask + bias gradient in one pass
+                call("igcn_bias_grad", rows, cols, ptr(dy), ptr(y) if ctx.relu else None, ptr(g), ptr(db),
+                     ptr(scratch), stream_ptr())
+            gs.append(g if ctx.relu else dy)
+            dbs.append(db)
+        with _immediate(ctx.final[0] and ctx.final[2]):
+            dx1, dw1, dx2, dw2 = gemm_group([("nn", gs[0], w1, None, None, False), ("tn", gs[0], x1, None, None, True),
+                                             ("nn", gs[1], w2, None, None, False), ("tn", gs[1], x2, None, None, True)])
+        return dx1, dw1, dbs[0], dx2, dw2, dbs[1], None
+
+
+def linear_pair(x1, w1, b1, x2, w2, b2, relu=True, bf16=False):
+    """(act(x1 W1^T + b1), act(x2 W2^T + b2)) with grouped launches; separate ops.linear calls when the shapes fall
+    outside the grouped kernel (bf16 operands, bias-less layers, wide outputs)."""
+    if bf16 or b1 is None or b2 is None or w1.shape[0] > 256 or w2.shape[0] > 256 or x1.dim() != 2 or x2.dim() != 2:
+        return linear(x1, w1, b1, relu=relu, bf16=bf16), linear(x2, w2, b2, relu=relu, bf16=bf16)
+    return LinearPair.apply(x1, w1, b1, x2, w2, b2, relu)
 
 
 def _proj_backward(ctx, dq, dkv, q2, m2, w, dw, d):

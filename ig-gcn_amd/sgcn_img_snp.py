@@ -323,11 +323,6 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             else:
                 out_z = (img_out + out_cross) / 2
                 out_lin = torch.cat((out_z, latent), -1)
-        linear_outf = ops.linear(out_lin, self.lin1.weight, self.lin1.bias, relu=True, bf16=bf)
-        if head_drop and keep1 is None:               # the GO network's own dropout is switched off: library masks
-            logits = ops.linear(self._drop(linear_outf, 0.5), self.lin2.weight, self.lin2.bias)
-        else:
-            logits = ops.linear(linear_outf, self.lin2.weight, self.lin2.bias, keep=keep1)
         if fused_head:
             pass
         elif self.isuseProb4Regr and not self.isSNPsOnly:
@@ -335,7 +330,13 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             feat = torch.cat((out_lin, img_feat if g == 1 else img_feat.repeat(g, 1)), -1)
         else:
             feat = out_lin
-        reg = ops.linear(feat, self.lin1_regr.weight, self.lin1_regr.bias, relu=True, bf16=bf)
+        # the first layers of the two heads (:299 lin1, :302 lin1_regr) are independent: one grouped launch each way
+        linear_outf, reg = ops.linear_pair(out_lin, self.lin1.weight, self.lin1.bias, feat, self.lin1_regr.weight,
+                                           self.lin1_regr.bias, relu=True, bf16=bf)
+        if head_drop and keep1 is None:               # the GO network's own dropout is switched off: library masks
+            logits = ops.linear(self._drop(linear_outf, 0.5), self.lin2.weight, self.lin2.bias)
+        else:
+            logits = ops.linear(linear_outf, self.lin2.weight, self.lin2.bias, keep=keep1)
         if head_drop and keep2 is None:
             our_reg = ops.linear(self._drop(reg, 0.3), self.lin2_regr.weight, self.lin2_regr.bias)
         else:
