@@ -49,6 +49,7 @@ SIGNATURES = {
     "igcn_bias_grad_scratch_floats": (Z, [L, I]),
     "igcn_bias_grad": (I, [L, I, P, P, P, P, P, P]),
     "igcn_col_sums": (I, [L, I, I, P, P, P, P]),
+    "igcn_bias_grad_pair": (I, [L, I, P, P, P, P, I, P, P, P, P, P, I, P, P]),
     "igcn_gemm_f32_split_k": (I, [L, L, L]),
     "igcn_gemm_f32": (I, [L, L, L, P, L, L, P, L, L, P, P, L, I, I, P, P]),
     "igcn_gemm_bf16": (I, [L, L, L, P, L, L, P, L, L, P, P, L, I, I, P, P]),

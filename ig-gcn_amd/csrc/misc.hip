@@ -122,10 +122,16 @@ extern "C" int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_
 // Rows are split over workgroups; each writes one [cols] partial, summed in order by the common row reduction.
 // =================================================================================================
 #define BG_T 256
+// (blockIdx.y selects one of up to two problems of the same shape: igcn_bias_grad_pair)
+struct BiasGradPtrs { const float* dy[2]; const float* y[2]; float* g[2]; float* partial[2]; int zero_cols[2]; };
 template <int VW>
 __global__ void __launch_bounds__(BG_T)
-k_bias_grad(int64_t rows, int cols, int zero_cols, int64_t rows_per_block, const float* __restrict__ dy,
-            const float* __restrict__ y, float* __restrict__ g, float* __restrict__ partial) {
+k_bias_grad(int64_t rows, int cols, int64_t rows_per_block, BiasGradPtrs pp) {
+  const float* __restrict__ dy = pp.dy[blockIdx.y];
+  const float* __restrict__ y = pp.y[blockIdx.y];
+  float* __restrict__ g = pp.g[blockIdx.y];
+  float* __restrict__ partial = pp.partial[blockIdx.y];
+  const int zero_cols = pp.zero_cols[blockIdx.y];
   // thread = (row lane, column group of VW): cpr column groups per row, BG_T / cpr row lanes
   __shared__ float red[BG_T * VW];
   const int cpr = cols / VW, rl = threadIdx.x / cpr, cg = threadIdx.x % cpr, lanes = BG_T / cpr;
@@ -175,20 +181,56 @@ extern "C" size_t igcn_bias_grad_scratch_floats(int64_t rows, int cols) {
   return (size_t)(blocks * cols + 64);
 }
 
-extern "C" int igcn_bias_grad(int64_t rows, int cols, const float* dy, const float* y, float* g, float* db,
-                              float* scratch, void* stream) {
-  IGCN_REQUIRE(rows > 0 && cols > 0 && cols <= BG_T && (y == nullptr || g != nullptr), "bias_grad: bad arguments");
-  hipStream_t st = (hipStream_t)stream;
+// one or two column-sum problems of the same [rows, cols] shape in one launch
+static int bias_grad_launch(int64_t rows, int cols, int n, const float* const* dy, const float* const* y, float* const* g,
+                            float* const* out, float* const* scratch, const int* zero_cols, hipStream_t st,
+                            const char* nm) {
   const int64_t blocks = rows < 512 * 64 ? igcn_cdiv(rows, 64) : 512;       // >= 64 rows per workgroup, <= 512 of them
   const int64_t rpb = igcn_cdiv(rows, blocks);
   const int64_t nb = igcn_cdiv(rows, rpb);
-  const bool vec = cols % 4 == 0 && BG_T % (cols / 4) == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)g) & 15) == 0;
+  bool vec = cols % 4 == 0 && BG_T % (cols / 4) == 0;
+  BiasGradPtrs pp = {};
+  for (int i = 0; i < 2; ++i) {
+    const int k = i < n ? i : 0;
+    pp.dy[i] = dy[k]; pp.y[i] = y[k]; pp.g[i] = g[k]; pp.partial[i] = scratch[k]; pp.zero_cols[i] = zero_cols[k];
+    vec = vec && (((uintptr_t)dy[k] | (uintptr_t)y[k] | (uintptr_t)g[k]) & 15) == 0;
+  }
   if (vec)
-    hipLaunchKernelGGL((k_bias_grad<4>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, 0, rpb, dy, y, g, scratch);
+    hipLaunchKernelGGL((k_bias_grad<4>), dim3((unsigned)nb, (unsigned)n), dim3(BG_T), 0, st, rows, cols, rpb, pp);
   else
-    hipLaunchKernelGGL((k_bias_grad<1>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, 0, rpb, dy, y, g, scratch);
-  IGCN_CHECK_LAUNCH("bias_grad");
-  return igcn_launch_reduce_rows_final(scratch, nb, cols, cols, db, st);
+    hipLaunchKernelGGL((k_bias_grad<1>), dim3((unsigned)nb, (unsigned)n), dim3(BG_T), 0, st, rows, cols, rpb, pp);
+  IGCN_CHECK_LAUNCH(nm);
+  for (int i = 0; i < n; ++i) {
+    const int w = cols + zero_cols[i];
+    const int rc = igcn_launch_reduce_rows_final(scratch[i], nb, w, w, out[i], st);
+    if (rc) return rc;
+  }
+  return IGCN_OK;
+}
+
+extern "C" int igcn_bias_grad(int64_t rows, int cols, const float* dy, const float* y, float* g, float* db,
+                              float* scratch, void* stream) {
+  IGCN_REQUIRE(rows > 0 && cols > 0 && cols <= BG_T && (y == nullptr || g != nullptr), "bias_grad: bad arguments");
+  const int z = 0;
+  return bias_grad_launch(rows, cols, 1, &dy, &y, &g, &db, &scratch, &z, (hipStream_t)stream, "bias_grad");
+}
+
+// Two igcn_bias_grad / igcn_col_sums problems of the SAME [rows, cols] shape in one launch (the two heads' first
+// layers; d b_q and d b_v of the attention projection): per problem dy, optional ReLU reference y with masked copy g,
+// output db [cols + zero_cols] (zero_cols structurally zero entries behind the sums), scratch as for one problem.
+extern "C" int igcn_bias_grad_pair(int64_t rows, int cols, const float* dy0, const float* y0, float* g0, float* db0,
+                                   int zero_cols0, float* scratch0, const float* dy1, const float* y1, float* g1,
+                                   float* db1, int zero_cols1, float* scratch1, void* stream) {
+  IGCN_REQUIRE(rows > 0 && cols > 0 && cols <= BG_T && (y0 == nullptr || g0 != nullptr) &&
+                   (y1 == nullptr || g1 != nullptr) && zero_cols0 >= 0 && zero_cols1 >= 0 && zero_cols0 <= 4096 &&
+                   zero_cols1 <= 4096, "bias_grad_pair: bad arguments");
+  const float* dy[2] = {dy0, dy1};
+  const float* y[2] = {y0, y1};
+  float* g[2] = {g0, g1};
+  float* out[2] = {db0, db1};
+  float* scr[2] = {scratch0, scratch1};
+  const int z[2] = {zero_cols0, zero_cols1};
+  return bias_grad_launch(rows, cols, 2, dy, y, g, out, scr, z, (hipStream_t)stream, "bias_grad_pair");
 }
 
 // out[0:cols] = column sums of x [rows, cols]; out[cols : cols + zero_cols] = 0 — a gradient block that is known to
@@ -197,19 +239,9 @@ extern "C" int igcn_bias_grad(int64_t rows, int cols, const float* dy, const flo
 extern "C" int igcn_col_sums(int64_t rows, int cols, int zero_cols, const float* x, float* out, float* scratch,
                              void* stream) {
   IGCN_REQUIRE(rows > 0 && cols > 0 && cols <= BG_T && zero_cols >= 0 && zero_cols <= 4096, "col_sums: bad arguments");
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t blocks = rows < 512 * 64 ? igcn_cdiv(rows, 64) : 512;
-  const int64_t rpb = igcn_cdiv(rows, blocks);
-  const int64_t nb = igcn_cdiv(rows, rpb);
-  const bool vec = cols % 4 == 0 && BG_T % (cols / 4) == 0 && ((uintptr_t)x & 15) == 0;
-  if (vec)
-    hipLaunchKernelGGL((k_bias_grad<4>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, zero_cols, rpb, x,
-                       (const float*)nullptr, (float*)nullptr, scratch);
-  else
-    hipLaunchKernelGGL((k_bias_grad<1>), dim3((unsigned)nb), dim3(BG_T), 0, st, rows, cols, zero_cols, rpb, x,
-                       (const float*)nullptr, (float*)nullptr, scratch);
-  IGCN_CHECK_LAUNCH("col_sums");
-  return igcn_launch_reduce_rows_final(scratch, nb, cols + zero_cols, cols + zero_cols, out, st);
+  const float* y = nullptr;
+  float* g = nullptr;
+  return bias_grad_launch(rows, cols, 1, &x, &y, &g, &out, &scratch, &zero_cols, (hipStream_t)stream, "col_sums");
 }
 
 // =================================================================================================

@@ -587,19 +587,31 @@ class LinearPair(torch.autograd.Function):
     def backward(ctx, dy1, dy2):
         x1, w1, x2, w2, y1, y2 = ctx.saved_tensors
         lib = _lib.load()
-        gs, dbs = [], []
-        for dy, y, b_final in ((dy1, y1, ctx.final[1]), (dy2, y2, ctx.final[3])):
-            dy = _f32(dy)
-            rows, cols = dy.shape
-            g = torch.empty_like(dy) if ctx.relu else None
-            db = torch.empty(cols, dtype=torch.float32, device=dy.device)
-            scratch = _keep(torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, cols)), dtype=torch.float32,
-                                        device=dy.device))
-            with _immediate(b_final):                                   # ReLU mask + bias gradient in one pass
-                call("igcn_bias_grad", rows, cols, ptr(dy), ptr(y) if ctx.relu else None, ptr(g), ptr(db),
-                     ptr(scratch), stream_ptr())
-            gs.append(g if ctx.relu else dy)
-            dbs.append(db)
+        dy1, dy2 = _f32(dy1), _f32(dy2)
+        rows, cols = dy1.shape
+        if dy2.shape == dy1.shape:                                          # both heads: ONE mask + bias-gradient launch
+            gs = [torch.empty_like(dy1), torch.empty_like(dy2)] if ctx.relu else [dy1, dy2]
+            dbs = [torch.empty(cols, dtype=torch.float32, device=dy1.device) for _ in range(2)]
+            nscr = int(lib.igcn_bias_grad_scratch_floats(rows, cols))
+            scr = [_keep(torch.empty(nscr, dtype=torch.float32, device=dy1.device)) for _ in range(2)]
+            with _immediate(ctx.final[1] and ctx.final[3]):
+                call("igcn_bias_grad_pair", rows, cols,
+                     ptr(dy1), ptr(y1) if ctx.relu else None, ptr(gs[0]) if ctx.relu else None, ptr(dbs[0]), 0, ptr(scr[0]),
+                     ptr(dy2), ptr(y2) if ctx.relu else None, ptr(gs[1]) if ctx.relu else None, ptr(dbs[1]), 0, ptr(scr[1]),
+                     stream_ptr())
+        else:
+            gs, dbs = [], []
+            for dy, y, b_final in ((dy1, y1, ctx.final[1]), (dy2, y2, ctx.final[3])):
+                rows, cols = dy.shape
+                g = torch.empty_like(dy) if ctx.relu else None
+                db = torch.empty(cols, dtype=torch.float32, device=dy.device)
+                scratch = _keep(torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, cols)), dtype=torch.float32,
+                                            device=dy.device))
+                with _immediate(b_final):                                   # ReLU mask + bias gradient in one pass
+                    call("igcn_bias_grad", rows, cols, ptr(dy), ptr(y) if ctx.relu else None, ptr(g), ptr(db),
+                         ptr(scratch), stream_ptr())
+                gs.append(g if ctx.relu else dy)
+                dbs.append(db)
         with _immediate(ctx.final[0] and ctx.final[2]):
             dx1, dw1, dx2, dw2 = gemm_group([("nn", gs[0], w1, None, None, False), ("tn", gs[0], x1, None, None, True),
                                              ("nn", gs[1], w2, None, None, False), ("tn", gs[1], x2, None, None, True)])
@@ -1357,9 +1369,10 @@ class ProjectedAttention(torch.autograd.Function):
         lib = _lib.load()
         rows = dq2.shape[0]
         scr = _keep(torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, 2 * d)), dtype=torch.float32, device=w.device))
-        with _immediate(ctx.final):
-            call("igcn_col_sums", rows, d, d, ptr(dq2), ptr(db), ptr(scr), stream_ptr())          # d b_q, then d b_k = 0
-        _bias_grad_into(dout.reshape(-1, d), db[2 * d:], ctx.final)                                  # d b_v
+        scr2 = _keep(torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, d)), dtype=torch.float32, device=w.device))
+        with _immediate(ctx.final):                                 # d b_q (then d b_k = 0) and d b_v in one launch
+            call("igcn_bias_grad_pair", rows, d, ptr(dq2), None, None, ptr(db), d, ptr(scr),
+                 ptr(dout.reshape(-1, d)), None, None, ptr(db[2 * d:]), 0, ptr(scr2), stream_ptr())
         dquery, dmem = _proj_backward(ctx, dq2, dkv2, q2, m2, w, dw, d)
         return dquery, dmem, dw, db, None, None
 

@@ -257,6 +257,12 @@ int igcn_bias_grad(int64_t rows, int cols, const float* dy, const float* y, floa
  * written by the launch that sums its neighbour: the key bias of nn.MultiheadAttention, kernel/sgcn_img_snp.py:240 —
  * a softmax over keys cannot see a key bias).  scratch: igcn_bias_grad_scratch_floats(rows, cols + zero_cols). */
 int igcn_col_sums(int64_t rows, int cols, int zero_cols, const float* x, float* out, float* scratch, void* stream);
+/* Two igcn_bias_grad / igcn_col_sums problems of the same [rows, cols] shape in one launch: per problem dy, optional
+ * ReLU reference y (then g = dy * [y > 0] is written), db [cols + zero_cols] with zero_cols structurally zero
+ * entries behind the sums, scratch of igcn_bias_grad_scratch_floats(rows, cols + zero_cols) floats. */
+int igcn_bias_grad_pair(int64_t rows, int cols, const float* dy0, const float* y0, float* g0, float* db0,
+                        int zero_cols0, float* scratch0, const float* dy1, const float* y1, float* g1, float* db1,
+                        int zero_cols1, float* scratch1, void* stream);
 
 /* `act`: 0 = none, 1 = ReLU; bit 0x100 = the output is a final parameter gradient (deferred reductions, below).
  * The split the library's launch heuristic prefers for (M, N, K): callers size `scratch` with it and pass it as
