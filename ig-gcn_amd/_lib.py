@@ -38,6 +38,8 @@ SIGNATURES = {
     "igcn_small_linear_bwd_scratch_floats": (Z, [L, I, I]),
     "igcn_small_linear_fwd": (I, [L, I, I, P, P, P, P, P, P]),
     "igcn_small_linear_bwd": (I, [L, I, I, P, P, P, P, P, P, P, P]),
+    "igcn_small_linear_pair_fwd": (I, [L, I, I, P, P, P, P, P, I, P, P, P, P, P, P]),
+    "igcn_small_linear_pair_bwd": (I, [L, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P]),
     "igcn_snps_mask_fwd": (I, [I, I, P, P, P, P, P, P]),
     "igcn_snps_mask_bwd": (I, [I, I, P, P, P, P, P, P]),
     "igcn_head_inputs_fwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P]),

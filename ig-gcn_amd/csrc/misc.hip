@@ -452,9 +452,19 @@ extern "C" int igcn_snps_mask_bwd(int B, int S, const float* snps, const float* 
 // Thread = (row, quad of K): KQ = K/4 lanes per row, 256/KQ rows per workgroup pass.
 // =================================================================================================
 #define SL_MAXC 4
+// (blockIdx.y selects one of up to two layers over the same [R, K] input shape: igcn_small_linear_pair_*)
+struct SmallLinPtrs {
+  const float* x[2]; const float* keep[2]; const float* W[2]; const float* b[2]; float* y[2];
+  const float* dy[2]; float* dx[2]; float* partial[2]; int C[2];
+};
 __global__ void __launch_bounds__(256)
-k_small_linear_fwd(int64_t R, int K, int C, const float* __restrict__ x, const float* __restrict__ keep,
-                   const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ y) {
+k_small_linear_fwd(int64_t R, int K, SmallLinPtrs pp) {
+  const float* __restrict__ x = pp.x[blockIdx.y];
+  const float* __restrict__ keep = pp.keep[blockIdx.y];
+  const float* __restrict__ W = pp.W[blockIdx.y];
+  const float* __restrict__ b = pp.b[blockIdx.y];
+  float* __restrict__ y = pp.y[blockIdx.y];
+  const int C = pp.C[blockIdx.y];
   const int kq = K / 4, q = threadIdx.x % kq, rl = threadIdx.x / kq, rpb = 256 / kq;
   const int64_t r = (int64_t)blockIdx.x * rpb + rl;
   float acc[SL_MAXC];
@@ -487,9 +497,14 @@ k_small_linear_fwd(int64_t R, int K, int C, const float* __restrict__ x, const f
 // dx[r, k] = sum_c dy[r, c] W[c, k];  partial[blk][c*K + k] = sum_{r in blk} dy[r, c] x[r, k];
 // partial[blk][C*K + c] = sum_{r in blk} dy[r, c].  Rows of a workgroup: rows_per_block, walked 256/KQ at a time.
 __global__ void __launch_bounds__(256)
-k_small_linear_bwd(int64_t R, int K, int C, int rows_per_block, const float* __restrict__ x,
-                   const float* __restrict__ keep, const float* __restrict__ W, const float* __restrict__ dy,
-                   float* __restrict__ dx, float* __restrict__ partial) {
+k_small_linear_bwd(int64_t R, int K, int rows_per_block, SmallLinPtrs pp) {
+  const float* __restrict__ x = pp.x[blockIdx.y];
+  const float* __restrict__ keep = pp.keep[blockIdx.y];
+  const float* __restrict__ W = pp.W[blockIdx.y];
+  const float* __restrict__ dy = pp.dy[blockIdx.y];
+  float* __restrict__ dx = pp.dx[blockIdx.y];
+  float* __restrict__ partial = pp.partial[blockIdx.y];
+  const int C = pp.C[blockIdx.y];
   __shared__ float red[256 * 4 * SL_MAXC + 256 * SL_MAXC];
   const int kq = K / 4, q = threadIdx.x % kq, rl = threadIdx.x / kq, rpb = 256 / kq;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
@@ -560,31 +575,75 @@ extern "C" size_t igcn_small_linear_bwd_scratch_floats(int64_t R, int K, int C) 
   return (size_t)(igcn_cdiv(R, small_linear_rpb(R)) * (C * K + C) + 64);
 }
 
+static int small_linear_fwd_launch(int64_t R, int K, int n, const SmallLinPtrs& pp, hipStream_t st) {
+  for (int i = 0; i < n; ++i) {
+    IGCN_REQUIRE(R > 0 && small_linear_ok(K, pp.C[i]), "small_linear: K/4 a power of two <= 64, 1 <= C <= 4 (K=%d C=%d)",
+                 K, pp.C[i]);
+    IGCN_REQUIRE((((uintptr_t)pp.x[i] | (uintptr_t)pp.W[i] | (uintptr_t)pp.keep[i]) & 15) == 0,
+                 "small_linear: x, keep and W must be 16-byte aligned");
+  }
+  const int rpb = 256 / (K / 4);
+  hipLaunchKernelGGL(k_small_linear_fwd, dim3((unsigned)igcn_cdiv(R, rpb), (unsigned)n), dim3(256), 0, st, R, K, pp);
+  IGCN_CHECK_LAUNCH("small_linear_fwd");
+  return IGCN_OK;
+}
+
 extern "C" int igcn_small_linear_fwd(int64_t R, int K, int C, const float* x, const float* keep, const float* W,
                                      const float* b, float* y, void* stream) {
-  IGCN_REQUIRE(R > 0 && small_linear_ok(K, C), "small_linear: K/4 a power of two <= 64, 1 <= C <= 4 (K=%d C=%d)", K, C);
-  IGCN_REQUIRE((((uintptr_t)x | (uintptr_t)W | (uintptr_t)keep) & 15) == 0,
-               "small_linear: x, keep and W must be 16-byte aligned");
-  const int rpb = 256 / (K / 4);
-  hipLaunchKernelGGL(k_small_linear_fwd, dim3((unsigned)igcn_cdiv(R, rpb)), dim3(256), 0, (hipStream_t)stream, R, K, C,
-                     x, keep, W, b, y);
-  IGCN_CHECK_LAUNCH("small_linear_fwd");
+  SmallLinPtrs pp = {};
+  pp.x[0] = pp.x[1] = x; pp.keep[0] = pp.keep[1] = keep; pp.W[0] = pp.W[1] = W; pp.b[0] = pp.b[1] = b;
+  pp.y[0] = pp.y[1] = y; pp.C[0] = pp.C[1] = C;
+  return small_linear_fwd_launch(R, K, 1, pp, (hipStream_t)stream);
+}
+
+// Two narrow layers over inputs of the same [R, K] shape in one launch (lin2 and lin2_regr of the two heads).
+extern "C" int igcn_small_linear_pair_fwd(int64_t R, int K, int C0, const float* x0, const float* keep0,
+                                          const float* W0, const float* b0, float* y0, int C1, const float* x1,
+                                          const float* keep1, const float* W1, const float* b1, float* y1,
+                                          void* stream) {
+  SmallLinPtrs pp = {};
+  pp.x[0] = x0; pp.keep[0] = keep0; pp.W[0] = W0; pp.b[0] = b0; pp.y[0] = y0; pp.C[0] = C0;
+  pp.x[1] = x1; pp.keep[1] = keep1; pp.W[1] = W1; pp.b[1] = b1; pp.y[1] = y1; pp.C[1] = C1;
+  return small_linear_fwd_launch(R, K, 2, pp, (hipStream_t)stream);
+}
+
+static int small_linear_bwd_launch(int64_t R, int K, int n, const SmallLinPtrs& pp, float* const* dwb, hipStream_t st) {
+  for (int i = 0; i < n; ++i) {
+    IGCN_REQUIRE(R > 0 && small_linear_ok(K, pp.C[i]), "small_linear: K/4 a power of two <= 64, 1 <= C <= 4 (K=%d C=%d)",
+                 K, pp.C[i]);
+    IGCN_REQUIRE((((uintptr_t)pp.x[i] | (uintptr_t)pp.W[i] | (uintptr_t)pp.dx[i] | (uintptr_t)pp.keep[i]) & 15) == 0,
+                 "small_linear: 16-byte aligned tensors");
+  }
+  const int rows_per_block = small_linear_rpb(R);
+  const int64_t nb = igcn_cdiv(R, rows_per_block);
+  hipLaunchKernelGGL(k_small_linear_bwd, dim3((unsigned)nb, (unsigned)n), dim3(256), 0, st, R, K, rows_per_block, pp);
+  IGCN_CHECK_LAUNCH("small_linear_bwd");
+  for (int i = 0; i < n; ++i) {
+    const int w = pp.C[i] * K + pp.C[i];
+    const int rc = igcn_launch_reduce_rows_final(pp.partial[i], nb, w, w, dwb[i], st);     // dW | db in one pass
+    if (rc) return rc;
+  }
   return IGCN_OK;
 }
 
 extern "C" int igcn_small_linear_bwd(int64_t R, int K, int C, const float* x, const float* keep, const float* W,
                                      const float* dy, float* dx /* or NULL */,
                                      float* dwb /* [C*K + C]: dW, then db */, float* scratch, void* stream) {
-  IGCN_REQUIRE(R > 0 && small_linear_ok(K, C), "small_linear: K/4 a power of two <= 64, 1 <= C <= 4 (K=%d C=%d)", K, C);
-  IGCN_REQUIRE((((uintptr_t)x | (uintptr_t)W | (uintptr_t)dx | (uintptr_t)keep) & 15) == 0,
-               "small_linear: 16-byte aligned tensors");
-  hipStream_t st = (hipStream_t)stream;
-  const int rows_per_block = small_linear_rpb(R);
-  const int64_t nb = igcn_cdiv(R, rows_per_block);
-  hipLaunchKernelGGL(k_small_linear_bwd, dim3((unsigned)nb), dim3(256), 0, st, R, K, C, rows_per_block, x, keep, W, dy,
-                     dx, scratch);
-  IGCN_CHECK_LAUNCH("small_linear_bwd");
-  return igcn_launch_reduce_rows_final(scratch, nb, C * K + C, C * K + C, dwb, st);     // dW | db in one pass
+  SmallLinPtrs pp = {};
+  pp.x[0] = pp.x[1] = x; pp.keep[0] = pp.keep[1] = keep; pp.W[0] = pp.W[1] = W; pp.dy[0] = pp.dy[1] = dy;
+  pp.dx[0] = pp.dx[1] = dx; pp.partial[0] = pp.partial[1] = scratch; pp.C[0] = pp.C[1] = C;
+  return small_linear_bwd_launch(R, K, 1, pp, &dwb, (hipStream_t)stream);
+}
+
+extern "C" int igcn_small_linear_pair_bwd(int64_t R, int K, int C0, const float* x0, const float* keep0,
+                                          const float* W0, const float* dy0, float* dx0, float* dwb0, float* scratch0,
+                                          int C1, const float* x1, const float* keep1, const float* W1,
+                                          const float* dy1, float* dx1, float* dwb1, float* scratch1, void* stream) {
+  SmallLinPtrs pp = {};
+  pp.x[0] = x0; pp.keep[0] = keep0; pp.W[0] = W0; pp.dy[0] = dy0; pp.dx[0] = dx0; pp.partial[0] = scratch0; pp.C[0] = C0;
+  pp.x[1] = x1; pp.keep[1] = keep1; pp.W[1] = W1; pp.dy[1] = dy1; pp.dx[1] = dx1; pp.partial[1] = scratch1; pp.C[1] = C1;
+  float* dwb[2] = {dwb0, dwb1};
+  return small_linear_bwd_launch(R, K, 2, pp, dwb, (hipStream_t)stream);
 }
 
 // =================================================================================================

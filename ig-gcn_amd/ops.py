@@ -860,6 +860,53 @@ class SmallLinear(torch.autograd.Function):
         return dx, dwb[:c * k].view(c, k), (dwb[c * k:] if ctx.has_bias else None), None
 
 
+class SmallLinearPair(torch.autograd.Function):
+    """Two SmallLinear layers over inputs of the same shape — lin2 on the classifier features and lin2_regr on the
+    regression features — as one launch per direction (igcn_small_linear_pair_*): the two are independent and each is a
+    few workgroups' worth of work."""
+
+    @staticmethod
+    def forward(ctx, x1, w1, b1, keep1, x2, w2, b2, keep2):
+        f = lambda t: _f32(t) if t is not None else None               # noqa: E731
+        x1, w1, b1, keep1, x2, w2, b2, keep2 = (f(t) for t in (x1, w1, b1, keep1, x2, w2, b2, keep2))
+        r, k = x1.shape
+        c1, c2 = w1.shape[0], w2.shape[0]
+        y1 = torch.empty(r, c1, dtype=torch.float32, device=x1.device)
+        y2 = torch.empty(r, c2, dtype=torch.float32, device=x1.device)
+        call("igcn_small_linear_pair_fwd", r, k, c1, ptr(x1), ptr(keep1), ptr(w1), ptr(b1), ptr(y1),
+             c2, ptr(x2), ptr(keep2), ptr(w2), ptr(b2), ptr(y2), stream_ptr())
+        ctx.save_for_backward(x1, w1, keep1, x2, w2, keep2)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.final = _leaves(w1, b1, w2, b2)
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x1, w1, keep1, x2, w2, keep2 = ctx.saved_tensors
+        dy1, dy2 = _f32(dy1), _f32(dy2)
+        r, k = x1.shape
+        c1, c2 = w1.shape[0], w2.shape[0]
+        lib = _lib.load()
+        dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+        dwb1 = torch.empty(c1 * k + c1, dtype=torch.float32, device=x1.device)
+        dwb2 = torch.empty(c2 * k + c2, dtype=torch.float32, device=x1.device)
+        s1 = _keep(torch.empty(int(lib.igcn_small_linear_bwd_scratch_floats(r, k, c1)), dtype=torch.float32, device=x1.device))
+        s2 = _keep(torch.empty(int(lib.igcn_small_linear_bwd_scratch_floats(r, k, c2)), dtype=torch.float32, device=x1.device))
+        with _immediate(ctx.final):
+            call("igcn_small_linear_pair_bwd", r, k, c1, ptr(x1), ptr(keep1), ptr(w1), ptr(dy1), ptr(dx1), ptr(dwb1),
+                 ptr(s1), c2, ptr(x2), ptr(keep2), ptr(w2), ptr(dy2), ptr(dx2), ptr(dwb2), ptr(s2), stream_ptr())
+        return (dx1, dwb1[:c1 * k].view(c1, k), dwb1[c1 * k:] if ctx.has_bias[0] else None, None,
+                dx2, dwb2[:c2 * k].view(c2, k), dwb2[c2 * k:] if ctx.has_bias[1] else None, None)
+
+
+def small_linear_pair(x1, w1, b1, keep1, x2, w2, b2, keep2):
+    """(linear(x1, w1, b1, keep=keep1), linear(x2, w2, b2, keep=keep2)) for two narrow layers over inputs of the same
+    2-D shape in one launch each way; two ops.linear calls otherwise."""
+    if (x1.dim() == 2 and x1.shape == x2.shape and _small_linear_ok(x1, w1, False) and _small_linear_ok(x2, w2, False)):
+        return SmallLinearPair.apply(x1, w1, b1, keep1, x2, w2, b2, keep2)
+    return linear(x1, w1, b1, keep=keep1), linear(x2, w2, b2, keep=keep2)
+
+
 def _small_linear_ok(x2, weight, relu):
     k, c = x2.shape[1], weight.shape[0]
     kq = k // 4

@@ -335,12 +335,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                                            self.lin1_regr.bias, relu=True, bf16=bf)
         if head_drop and keep1 is None:               # the GO network's own dropout is switched off: library masks
             logits = ops.linear(self._drop(linear_outf, 0.5), self.lin2.weight, self.lin2.bias)
-        else:
-            logits = ops.linear(linear_outf, self.lin2.weight, self.lin2.bias, keep=keep1)
-        if head_drop and keep2 is None:
             our_reg = ops.linear(self._drop(reg, 0.3), self.lin2_regr.weight, self.lin2_regr.bias)
-        else:
-            our_reg = ops.linear(reg, self.lin2_regr.weight, self.lin2_regr.bias, keep=keep2)
+        else:                                         # (:289-290 lin2, :300-301 lin2_regr: one launch for both)
+            logits, our_reg = ops.small_linear_pair(linear_outf, self.lin2.weight, self.lin2.bias, keep1,
+                                                    reg, self.lin2_regr.weight, self.lin2_regr.bias, keep2)
         # raw_scores: the caller takes log_softmax itself (ops.LossHead does it inside the loss kernel)
         outs = (logits if raw_scores else F.log_softmax(logits, dim=-1), x_hat, out_z, out_lin, linear_outf, our_reg)
         if not split:

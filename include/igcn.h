@@ -206,6 +206,15 @@ int igcn_small_linear_fwd(int64_t R, int K, int C, const float* x, const float* 
                           float* y, void* stream);
 int igcn_small_linear_bwd(int64_t R, int K, int C, const float* x, const float* keep, const float* W,
                           const float* dy, float* dx, float* dwb, float* scratch, void* stream);
+/* Two such layers over inputs of the same [R, K] shape in one launch each way (lin2 and lin2_regr of the two heads):
+ * per layer the arguments of igcn_small_linear_{fwd,bwd}. */
+int igcn_small_linear_pair_fwd(int64_t R, int K, int C0, const float* x0, const float* keep0, const float* W0,
+                               const float* b0, float* y0, int C1, const float* x1, const float* keep1,
+                               const float* W1, const float* b1, float* y1, void* stream);
+int igcn_small_linear_pair_bwd(int64_t R, int K, int C0, const float* x0, const float* keep0, const float* W0,
+                               const float* dy0, float* dx0, float* dwb0, float* scratch0, int C1, const float* x1,
+                               const float* keep1, const float* W1, const float* dy1, float* dx1, float* dwb1,
+                               float* scratch1, void* stream);
 
 /* SNP importance mask of cal_probability (kernel/sgcn_img_snp.py:147-151): out [B,S] = snps * sigmoid(p),
  * sp [S] = sigmoid(p).  Backward: dp [S] from dout [B,S] and/or dsp [S] (either may be NULL); snps gets no gradient. */

@@ -869,6 +869,31 @@ def test_gemm_group_matches_single_products(rows, fin, fout):
     assert torch.equal(y2, ops.gemm_nt(x[: rows // 2], w[: max(1, fout // 2)], None, 0))
 
 
+def test_small_linear_pair_matches_two_layers():
+    """ops.small_linear_pair (lin2 + lin2_regr in one launch each way) against two ops.linear calls: same bits."""
+    from igcn_amd import ops
+    torch.manual_seed(9)
+    r, k = 512, 64
+    x1 = torch.randn(r, k, device="cuda", requires_grad=True)
+    x2 = torch.randn(r, k, device="cuda", requires_grad=True)
+    w1 = torch.randn(3, k, device="cuda", requires_grad=True)
+    w2 = torch.randn(1, k, device="cuda", requires_grad=True)
+    b1 = torch.randn(3, device="cuda", requires_grad=True)
+    b2 = torch.randn(1, device="cuda", requires_grad=True)
+    keep1 = (torch.rand(r, k, device="cuda") > 0.5).float() * 2
+    c1, c2 = torch.randn(r, 3, device="cuda"), torch.randn(r, 1, device="cuda")
+    leaves = [x1, w1, b1, x2, w2, b2]
+    y1, y2 = ops.small_linear_pair(x1, w1, b1, keep1, x2, w2, b2, None)
+    got = torch.autograd.grad((y1 * c1).sum() + (y2 * c2).sum(), leaves)
+    z1, z2 = ops.linear(x1, w1, b1, keep=keep1), ops.linear(x2, w2, b2)
+    want = torch.autograd.grad((z1 * c1).sum() + (z2 * c2).sum(), leaves)
+    assert torch.equal(y1, z1) and torch.equal(y2, z2)
+    for g, w_, nm in zip(got, want, ("dx1", "dw1", "db1", "dx2", "dw2", "db2")):
+        assert torch.equal(g, w_), nm
+    ref = (x1 * keep1).double() @ w1.double().t() + b1.double()
+    assert_matches(y1, ref.detach().float().cpu().numpy(), 2e-6, "y1 vs fp64")
+
+
 def test_linear_pair_matches_two_linears():
     """ops.linear_pair (the heads' first layers as one op, grouped launches both ways) against two ops.linear calls:
     the same bits forward and backward (same kernels, same tiling per product), also with 8-byte-only rows."""
