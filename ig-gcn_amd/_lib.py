@@ -62,6 +62,13 @@ SIGNATURES = {
     "igcn_node_linear_bn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, I, F, F, P, P, P, P, P, P]),
     "igcn_node_linear_bn_bwd_scratch_floats": (Z, [I, I, I, I, I]),
     "igcn_node_linear_bn_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_node_linear_bn_pair_supported": (I, [I, I, I]),
+    "igcn_node_linear_bn_pair_fwd": (I, [I, I, I, I, P, I,
+                                         I, P, P, P, P, P, F, F, P, P, P, P,
+                                         I, P, P, P, P, P, F, F, P, P, P, P, P, P]),
+    "igcn_node_linear_bn_pair_bwd": (I, [I, I, I, I, I, P,
+                                         I, P, P, P, P, P, P, P, P, P, P,
+                                         I, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_bn1d_fwd": (I, [I, I, I, P, P, P, P, P, I, F, F, I, P, P, P, P, P]),
     "igcn_bn1d_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_dropout_state_words": (I, []),

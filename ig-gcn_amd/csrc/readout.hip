@@ -31,11 +31,15 @@ __device__ __forceinline__ void ro_pre(const float* __restrict__ w, const float 
 struct RoChunk {
   int g, ck, b0, b1, first;
 };
-__device__ __forceinline__ RoChunk ro_chunk(int B, int groups) {
-  const int cpg = gridDim.y / groups, bg = B / groups;
+// A kernel body sees its block through RoBlk: its own launch (blockIdx / gridDim), or its half of a PAIRED launch in
+// which two read-outs of the same input share one grid (k_nlbn_pair_*).
+struct RoBlk { int bx, by, gx, gy; };
+#define RO_BLK_OF_LAUNCH RoBlk{(int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y}
+__device__ __forceinline__ RoChunk ro_chunk(int B, int groups, const RoBlk rb) {
+  const int cpg = rb.gy / groups, bg = B / groups;
   RoChunk c;
-  c.g = blockIdx.y / cpg;
-  c.ck = blockIdx.y % cpg;
+  c.g = rb.by / cpg;
+  c.ck = rb.by % cpg;
   const int per = (bg + cpg - 1) / cpg;
   c.first = c.g * bg;
   c.b0 = c.first + c.ck * per;
@@ -46,14 +50,14 @@ __device__ __forceinline__ RoChunk ro_chunk(int B, int groups) {
 // ---- forward pass 1: shifted sums per (node, sample chunk) ---------------------------------------
 // partial[chunk][0][n] = sum (pre - pivot_n), partial[chunk][1][n] = sum (pre - pivot_n)^2 ; pivot from sample 0
 template <int F, int D>
-__global__ void __launch_bounds__(RO_T)
-k_nlbn_stats(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+__device__ __forceinline__ void
+nlbn_stats_body(const RoBlk rb, int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
              float* __restrict__ partial) {
   __shared__ float s1[RO_SG][RO_NL], s2[RO_SG][RO_NL];
   const float* __restrict__ w = W;
   const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int n = blockIdx.x * RO_NL + nl;
-  const RoChunk ch = ro_chunk(B, groups);
+  const int n = rb.bx * RO_NL + nl;
+  const RoChunk ch = ro_chunk(B, groups, rb);
   const int b0 = ch.b0, b1 = ch.b1;
   float a1 = 0.f, a2 = 0.f;
   if (n < N) {
@@ -81,10 +85,16 @@ k_nlbn_stats(int B, int N, int groups, const float* __restrict__ x, const float*
   s2[sg][nl] = a2;
   __syncthreads();
   if (sg == 0 && n < N) {
-    float* p = partial + (int64_t)blockIdx.y * 2 * N;
+    float* p = partial + (int64_t)rb.by * 2 * N;
     p[n] = (s1[0][nl] + s1[1][nl]) + (s1[2][nl] + s1[3][nl]);
     p[N + n] = (s2[0][nl] + s2[1][nl]) + (s2[2][nl] + s2[3][nl]);
   }
+}
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_stats(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+             float* __restrict__ partial) {
+  nlbn_stats_body<F, D>(RO_BLK_OF_LAUNCH, B, N, groups, x, W, partial);
 }
 
 // ---- forward pass 2: finalise statistics (training) or take the running ones (eval) ----------------
@@ -95,14 +105,14 @@ k_nlbn_stats(int B, int N, int groups, const float* __restrict__ x, const float*
 // the serial walk over the chunks was a 10-us latency chain for a few KB of data.
 #define RO_FIN_MAXG 8
 template <int F, int D>
-__global__ void __launch_bounds__(256)
-k_nlbn_finalize(int B, int N, int groups, int cpg, int training, float eps, float momentum,
+__device__ __forceinline__ void
+nlbn_finalize_body(const RoBlk rb, int B, int N, int groups, int cpg, int training, float eps, float momentum,
                 const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ partial,
                 float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean_out,
                 float* __restrict__ rstd_out) {
   __shared__ float r1[RO_FIN_MAXG][4][64], r2[RO_FIN_MAXG][4][64];
   const int nl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + nl;
+  const int n = rb.bx * 64 + nl;
   const bool live = n < N;
   const int bg = B / groups;
   if (training && live) {
@@ -152,19 +162,27 @@ k_nlbn_finalize(int B, int N, int groups, int cpg, int training, float eps, floa
     running_var[n] = rv;
   }
 }
+template <int F, int D>
+__global__ void __launch_bounds__(256)
+k_nlbn_finalize(int B, int N, int groups, int cpg, int training, float eps, float momentum,
+                const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ partial,
+                float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean_out,
+                float* __restrict__ rstd_out) {
+  nlbn_finalize_body<F, D>(RO_BLK_OF_LAUNCH, B, N, groups, cpg, training, eps, momentum, x, W, partial, running_mean, running_var, mean_out, rstd_out);
+}
 
 // ---- forward pass 3: normalise + ReLU, write [B,N,D] ---------------------------------------------
 template <int F, int D>
-__global__ void __launch_bounds__(RO_T)
-k_nlbn_apply(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+__device__ __forceinline__ void
+nlbn_apply_body(const RoBlk rb, int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
              const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
              const float* __restrict__ rstd, const float* __restrict__ keep /*[B,N] or NULL (D == 1)*/,
              float* __restrict__ out) {
   const float* __restrict__ w = W;
   const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int n = blockIdx.x * RO_NL + nl;
+  const int n = rb.bx * RO_NL + nl;
   if (n >= N) return;
-  const RoChunk ch = ro_chunk(B, groups);
+  const RoChunk ch = ro_chunk(B, groups, rb);
   const int b0 = ch.b0, b1 = ch.b1;
   const float sc = rstd[(int64_t)ch.g * N + n] * gamma[n], sh = beta[n] - mean[(int64_t)ch.g * N + n] * sc;
   for (int b = b0 + sg; b < b1; b += RO_SG) {
@@ -190,24 +208,32 @@ k_nlbn_apply(int B, int N, int groups, const float* __restrict__ x, const float*
     }
   }
 }
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_apply(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+             const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+             const float* __restrict__ rstd, const float* __restrict__ keep /*[B,N] or NULL (D == 1)*/,
+             float* __restrict__ out) {
+  nlbn_apply_body<F, D>(RO_BLK_OF_LAUNCH, B, N, groups, x, W, gamma, beta, mean, rstd, keep, out);
+}
 
 // Row-coalesced form of the pass above for D % 4 == 0, D <= 64: lane = (node, output quad), so a wave's store
 // instruction covers 64/(D/4) whole rows of `out` = contiguous memory (the thread-per-node form writes D/4 float4
 // per lane at a stride of D floats: every store instruction touches 64 different 128-byte lines).  The F inputs of
 // a node are loaded by its first F lanes and passed around with shuffles.
 template <int F, int D>
-__global__ void __launch_bounds__(RO_T)
-k_nlbn_apply_q(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+__device__ __forceinline__ void
+nlbn_apply_q_body(const RoBlk rb, int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                const float* __restrict__ rstd, float* __restrict__ out) {
   constexpr int DQ = D / 4, NPW = 64 / DQ;             // quads per row, nodes per wave
   static_assert(D % 4 == 0 && 64 % DQ == 0 && F <= DQ, "k_nlbn_apply_q: unsupported shape");
   const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int q = lane % DQ, nw = lane / DQ;
-  const int n = blockIdx.x * NPW + nw;
+  const int n = rb.bx * NPW + nw;
   const bool live = n < N;
   const int nc = live ? n : N - 1;
-  const RoChunk ch = ro_chunk(B, groups);
+  const RoChunk ch = ro_chunk(B, groups, rb);
   float w[4][F];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -231,6 +257,13 @@ k_nlbn_apply_q(int B, int N, int groups, const float* __restrict__ x, const floa
     }
     if (live) *reinterpret_cast<float4*>(out + ((int64_t)b * N + n) * D + q * 4) = v;
   }
+}
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_apply_q(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+               const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+               const float* __restrict__ rstd, float* __restrict__ out) {
+  nlbn_apply_q_body<F, D>(RO_BLK_OF_LAUNCH, B, N, groups, x, W, gamma, beta, mean, rstd, out);
 }
 
 static int ro_quad_chunks(unsigned grid_y, int groups) {
@@ -281,16 +314,16 @@ __device__ __forceinline__ void ro_store_row(float* __restrict__ p, const float 
 
 // ---- backward pass 1: per node sum(dy), sum(dy*xhat) over (b,d), dy = dout * [out > 0] ---------------
 template <int F, int D>
-__global__ void __launch_bounds__(RO_T)
-k_nlbn_bwd_stats(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+__device__ __forceinline__ void
+nlbn_bwd_stats_body(const RoBlk rb, int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
                  const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                  const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ keep,
                  float* __restrict__ partial) {
   __shared__ float s1[RO_SG][RO_NL], s2[RO_SG][RO_NL];
   const float* __restrict__ w = W;
   const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int n = blockIdx.x * RO_NL + nl;
-  const RoChunk ch = ro_chunk(B, groups);
+  const int n = rb.bx * RO_NL + nl;
+  const RoChunk ch = ro_chunk(B, groups, rb);
   const int b0 = ch.b0, b1 = ch.b1;
   float a1 = 0.f, a2 = 0.f;
   if (n < N) {
@@ -321,14 +354,22 @@ k_nlbn_bwd_stats(int B, int N, int groups, const float* __restrict__ x, const fl
     p[N + n] = (s2[0][nl] + s2[1][nl]) + (s2[2][nl] + s2[3][nl]);
   }
 }
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_bwd_stats(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+                 const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                 const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ keep,
+                 float* __restrict__ partial) {
+  nlbn_bwd_stats_body<F, D>(RO_BLK_OF_LAUNCH, B, N, groups, x, W, gamma, beta, mean, rstd, dout, keep, partial);
+}
 
 // ---- backward pass 2: dx [B,F,N] and the weight gradient -------------------------------------------
 //   training: dpre = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)) ;  eval: dpre = gamma*rstd*dy
 //   D*F <= 16 : dW accumulated in registers, block-reduced, one partial row per block (wpartial)
 //   otherwise : dpre [B,N,D] is written out and dW = sum_b dpre_b^T x_b runs on the MFMA batched-sum GEMM
 template <int F, int D>
-__global__ void __launch_bounds__(RO_T)
-k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict__ x, const float* __restrict__ W,
+__device__ __forceinline__ void
+nlbn_bwd_apply_body(const RoBlk rb, int B, int N, int groups, int training, const float* __restrict__ x, const float* __restrict__ W,
                  const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                  const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ keep,
                  const float* __restrict__ partial, int nchunks, float* __restrict__ dpre_out,
@@ -338,12 +379,12 @@ k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict
   __shared__ float red[(RO_T / 64) * NW];
   const float* __restrict__ w = W;
   const int nl = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int n = blockIdx.x * RO_NL + nl;
+  const int n = rb.bx * RO_NL + nl;
   float gw[NW];
 #pragma unroll
   for (int j = 0; j < NW; ++j) gw[j] = 0.f;
   if (n < N) {
-    const RoChunk ch = ro_chunk(B, groups);
+    const RoChunk ch = ro_chunk(B, groups, rb);
     const int b0 = ch.b0, b1 = ch.b1;
     const float mu = mean[(int64_t)ch.g * N + n], rs = rstd[(int64_t)ch.g * N + n], ga = gamma[n], be = beta[n];
     const float cnt = (float)(B / groups) * D;
@@ -389,7 +430,16 @@ k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict
     }
   }
   if constexpr (SMALL)
-    block_reduce_vec<NW>(gw, red, wpartial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NW);
+    block_reduce_vec<NW>(gw, red, wpartial + ((int64_t)rb.by * rb.gx + rb.bx) * NW);
+}
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict__ x, const float* __restrict__ W,
+                 const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                 const float* __restrict__ rstd, const float* __restrict__ dout, const float* __restrict__ keep,
+                 const float* __restrict__ partial, int nchunks, float* __restrict__ dpre_out,
+                 float* __restrict__ dx, float* __restrict__ wpartial) {
+  nlbn_bwd_apply_body<F, D>(RO_BLK_OF_LAUNCH, B, N, groups, training, x, W, gamma, beta, mean, rstd, dout, keep, partial, nchunks, dpre_out, dx, wpartial);
 }
 
 // Sum over the G (= 2, 4, 8, 16) consecutive lanes of a group with DPP cross-lane moves (VALU; __shfl_xor is an LDS-pipe
@@ -414,18 +464,18 @@ __device__ __forceinline__ float ro_group_sum_dpp(float v) {
 // xor-shuffles inside its D/4 lanes.  The weight gradient is accumulated in registers (4 x F per lane) and leaves the
 // workgroup as one [D, F] partial: no dpre [B, N, D] round trip through HBM and no batched GEMM behind it.
 template <int F, int D>
-__global__ void __launch_bounds__(RO_T)
-k_nlbn_bwd_stats_q(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+__device__ __forceinline__ void
+nlbn_bwd_stats_q_body(const RoBlk rb, int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                    const float* __restrict__ rstd, const float* __restrict__ dout, float* __restrict__ partial) {
   constexpr int DQ = D / 4, NPW = 64 / DQ;
   __shared__ float s1[RO_SG][NPW], s2[RO_SG][NPW];
   const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int q = lane % DQ, nw = lane / DQ, base = lane - q;
-  const int n = blockIdx.x * NPW + nw;
+  const int n = rb.bx * NPW + nw;
   const bool live = n < N;
   const int nc = live ? n : N - 1;
-  const RoChunk ch = ro_chunk(B, groups);
+  const RoChunk ch = ro_chunk(B, groups, rb);
   float w[4][F];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -464,10 +514,17 @@ k_nlbn_bwd_stats_q(int B, int N, int groups, const float* __restrict__ x, const 
     p[N + n] = (s2[0][nw] + s2[1][nw]) + (s2[2][nw] + s2[3][nw]);
   }
 }
-
 template <int F, int D>
 __global__ void __launch_bounds__(RO_T)
-k_nlbn_bwd_apply_q(int B, int N, int groups, int training, const float* __restrict__ x, const float* __restrict__ W,
+k_nlbn_bwd_stats_q(int B, int N, int groups, const float* __restrict__ x, const float* __restrict__ W,
+                   const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                   const float* __restrict__ rstd, const float* __restrict__ dout, float* __restrict__ partial) {
+  nlbn_bwd_stats_q_body<F, D>(RO_BLK_OF_LAUNCH, B, N, groups, x, W, gamma, beta, mean, rstd, dout, partial);
+}
+
+template <int F, int D>
+__device__ __forceinline__ void
+nlbn_bwd_apply_q_body(const RoBlk rb, int B, int N, int groups, int training, const float* __restrict__ x, const float* __restrict__ W,
                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                    const float* __restrict__ rstd, const float* __restrict__ dout,
                    const float* __restrict__ partial, int nchunks, float* __restrict__ dx,
@@ -476,10 +533,10 @@ k_nlbn_bwd_apply_q(int B, int N, int groups, int training, const float* __restri
   __shared__ float red[RO_T / 64][D * F];
   const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int q = lane % DQ, nw = lane / DQ, base = lane - q;
-  const int n = blockIdx.x * NPW + nw;
+  const int n = rb.bx * NPW + nw;
   const bool live = n < N;
   const int nc = live ? n : N - 1;
-  const RoChunk ch = ro_chunk(B, groups);
+  const RoChunk ch = ro_chunk(B, groups, rb);
   float w[4][F], gw[4][F];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -542,8 +599,17 @@ k_nlbn_bwd_apply_q(int B, int N, int groups, int training, const float* __restri
       if (nw == 0) red[sg][(q * 4 + r) * F + c] = t;
     }
   __syncthreads();
-  float* prow = wpartial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (D * F);
+  float* prow = wpartial + ((int64_t)rb.by * rb.gx + rb.bx) * (D * F);
   for (int j = threadIdx.x; j < D * F; j += RO_T) prow[j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+}
+template <int F, int D>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_bwd_apply_q(int B, int N, int groups, int training, const float* __restrict__ x, const float* __restrict__ W,
+                   const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                   const float* __restrict__ rstd, const float* __restrict__ dout,
+                   const float* __restrict__ partial, int nchunks, float* __restrict__ dx,
+                   float* __restrict__ wpartial) {
+  nlbn_bwd_apply_q_body<F, D>(RO_BLK_OF_LAUNCH, B, N, groups, training, x, W, gamma, beta, mean, rstd, dout, partial, nchunks, dx, wpartial);
 }
 
 template <int F, int D>
@@ -674,6 +740,186 @@ extern "C" int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, i
   return ro_bwd<FV, DV>(grid, cpg, st, B, N, groups, training, x, W, gamma, beta, save_mean, save_rstd, dout,   \
                         keep, stats, dgg, aux, dx, dW, dgb)
   RO_DISPATCH(F, D, CALL)
+#undef CALL
+}
+
+// =================================================================================================
+// Two read-outs of the SAME input in paired launches (go_model.py:254-255: conc_for_attention [D1 = dim_snps_atten,
+// row-coalesced kernels] and conc [D2 = 1, thread-per-node kernels, fused dropout] both read the encoder output): the
+// kernel bodies above, selected by blockIdx.z, in one grid per pass — three launches forward and three backward instead
+// of six and five, and the two small grids share the chip.
+// =================================================================================================
+struct RoSide {
+  const float *W, *gamma, *beta, *keep, *mean_c, *rstd_c, *dout;
+  float *running_mean, *running_var, *mean, *rstd, *partial, *out, *dgg, *aux, *dx;
+  float eps, momentum;
+};
+__device__ __forceinline__ bool ro_in(const RoBlk& rb) { return rb.bx < rb.gx && rb.by < rb.gy; }
+#define RO_SIDE_BLK(gxv, gyv) RoBlk{(int)blockIdx.x, (int)blockIdx.y, (int)(gxv), (int)(gyv)}
+
+template <int F, int D1, int D2>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_pair_stats(int B, int N, int groups, const float* __restrict__ x, RoSide a, RoSide b) {
+  const RoBlk rb = RO_BLK_OF_LAUNCH;                            // both sides use the same (node block, chunk) grid
+  if (blockIdx.z == 0) nlbn_stats_body<F, D1>(rb, B, N, groups, x, a.W, a.partial);
+  else nlbn_stats_body<F, D2>(rb, B, N, groups, x, b.W, b.partial);
+}
+
+template <int F, int D1, int D2>
+__global__ void __launch_bounds__(256)
+k_nlbn_pair_finalize(int B, int N, int groups, int cpg, int training, const float* __restrict__ x, RoSide a, RoSide b) {
+  const RoBlk rb = RO_BLK_OF_LAUNCH;
+  if (blockIdx.z == 0)
+    nlbn_finalize_body<F, D1>(rb, B, N, groups, cpg, training, a.eps, a.momentum, x, a.W, a.partial, a.running_mean,
+                              a.running_var, a.mean, a.rstd);
+  else
+    nlbn_finalize_body<F, D2>(rb, B, N, groups, cpg, training, b.eps, b.momentum, x, b.W, b.partial, b.running_mean,
+                              b.running_var, b.mean, b.rstd);
+}
+
+// side a: row-coalesced kernels on grid (ax, ay); side b: thread-per-node kernels on grid (bx, by)
+template <int F, int D1, int D2>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_pair_apply(int B, int N, int groups, int ax, int ay, int bx, int by, const float* __restrict__ x, RoSide a,
+                  RoSide b) {
+  if (blockIdx.z == 0) {
+    const RoBlk rb = RO_SIDE_BLK(ax, ay);
+    if (ro_in(rb)) nlbn_apply_q_body<F, D1>(rb, B, N, groups, x, a.W, a.gamma, a.beta, a.mean_c, a.rstd_c, a.out);
+  } else {
+    const RoBlk rb = RO_SIDE_BLK(bx, by);
+    if (ro_in(rb)) nlbn_apply_body<F, D2>(rb, B, N, groups, x, b.W, b.gamma, b.beta, b.mean_c, b.rstd_c, b.keep, b.out);
+  }
+}
+
+template <int F, int D1, int D2>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_pair_bwd_stats(int B, int N, int groups, int ax, int ay, int bx, int by, const float* __restrict__ x, RoSide a,
+                      RoSide b) {
+  if (blockIdx.z == 0) {
+    const RoBlk rb = RO_SIDE_BLK(ax, ay);
+    if (ro_in(rb))
+      nlbn_bwd_stats_q_body<F, D1>(rb, B, N, groups, x, a.W, a.gamma, a.beta, a.mean_c, a.rstd_c, a.dout, a.partial);
+  } else {
+    const RoBlk rb = RO_SIDE_BLK(bx, by);
+    if (ro_in(rb))
+      nlbn_bwd_stats_body<F, D2>(rb, B, N, groups, x, b.W, b.gamma, b.beta, b.mean_c, b.rstd_c, b.dout, b.keep, b.partial);
+  }
+}
+
+template <int F, int D1, int D2>
+__global__ void __launch_bounds__(RO_T)
+k_nlbn_pair_bwd_apply(int B, int N, int groups, int training, int ax, int ay, int a_chunks, int bx, int by,
+                      const float* __restrict__ x, RoSide a, RoSide b) {
+  if (blockIdx.z == 0) {
+    const RoBlk rb = RO_SIDE_BLK(ax, ay);
+    if (ro_in(rb))
+      nlbn_bwd_apply_q_body<F, D1>(rb, B, N, groups, training, x, a.W, a.gamma, a.beta, a.mean_c, a.rstd_c, a.dout,
+                                   a.partial, a_chunks, a.dx, a.aux);
+  } else {
+    const RoBlk rb = RO_SIDE_BLK(bx, by);
+    if (ro_in(rb))
+      nlbn_bwd_apply_body<F, D2>(rb, B, N, groups, training, x, b.W, b.gamma, b.beta, b.mean_c, b.rstd_c, b.dout, b.keep,
+                                 b.dgg, 1, b.aux, b.dx, b.aux);
+  }
+}
+
+// the (F, D1, D2) combinations of the paired launches: D1 on the row-coalesced kernels, D2 = 1
+// (of the D values of the reference's sweep only 32 = 2 layers x 16 hidden meets the row-coalesced kernels' shape rule)
+#define RO_PAIR_DISPATCH(F, D1, D2, CALL)                                  \
+  if (F == 5 && D2 == 1 && D1 == 32) { CALL(5, 32, 1); }                   \
+  else {                                                                   \
+    igcn_set_error("node_linear_bn_pair: unsupported (F=%d, D1=%d, D2=%d)", F, D1, D2); \
+    return IGCN_ERR_UNSUPPORTED;                                           \
+  }
+
+extern "C" int igcn_node_linear_bn_pair_supported(int F, int D1, int D2) {
+  return F == 5 && D2 == 1 && D1 == 32;
+}
+
+// Arguments per side as igcn_node_linear_bn_fwd (scratch: igcn_node_linear_bn_scratch_floats each); keep2 [B,N] or NULL.
+extern "C" int igcn_node_linear_bn_pair_fwd(int B, int F, int N, int groups, const float* x, int training,
+                                            int D1, const float* W1, const float* gamma1, const float* beta1,
+                                            float* running_mean1, float* running_var1, float momentum1, float eps1,
+                                            float* out1, float* save_mean1, float* save_rstd1, float* scratch1,
+                                            int D2, const float* W2, const float* gamma2, const float* beta2,
+                                            float* running_mean2, float* running_var2, float momentum2, float eps2,
+                                            const float* keep2, float* out2, float* save_mean2, float* save_rstd2,
+                                            float* scratch2, void* stream) {
+  IGCN_REQUIRE(B > 0 && N > 0 && groups >= 1 && groups <= RO_FIN_MAXG && B % groups == 0,
+               "node_linear_bn_pair_fwd: bad sizes (1 <= groups <= 8, B divisible by groups)");
+  IGCN_REQUIRE(!training || (int64_t)(B / groups) > 1, "node_linear_bn_pair_fwd: need more than one sample per group to train");
+  hipStream_t st = (hipStream_t)stream;
+  const int cpg = ro_cpg(B, groups);
+  dim3 grid((unsigned)igcn_cdiv(N, RO_NL), groups * cpg);
+  RoSide a = {}, b = {};
+  a.W = W1; a.gamma = gamma1; a.beta = beta1; a.running_mean = running_mean1; a.running_var = running_var1;
+  a.mean = save_mean1; a.rstd = save_rstd1; a.mean_c = save_mean1; a.rstd_c = save_rstd1; a.partial = scratch1;
+  a.out = out1; a.eps = eps1; a.momentum = momentum1;
+  b.W = W2; b.gamma = gamma2; b.beta = beta2; b.running_mean = running_mean2; b.running_var = running_var2;
+  b.mean = save_mean2; b.rstd = save_rstd2; b.mean_c = save_mean2; b.rstd_c = save_rstd2; b.partial = scratch2;
+  b.out = out2; b.keep = keep2; b.eps = eps2; b.momentum = momentum2;
+#define CALL(FV, D1V, D2V)                                                                                        \
+  {                                                                                                               \
+    if (training)                                                                                                 \
+      hipLaunchKernelGGL((k_nlbn_pair_stats<FV, D1V, D2V>), dim3(grid.x, grid.y, 2), dim3(RO_T), 0, st, B, N, groups, \
+                         x, a, b);                                                                                \
+    hipLaunchKernelGGL((k_nlbn_pair_finalize<FV, D1V, D2V>), dim3((unsigned)igcn_cdiv(N, 64), 1, 2), dim3(256), 0, st, \
+                       B, N, groups, cpg, training, x, a, b);                                                     \
+    const int ax = (int)igcn_cdiv(N, 64 / (D1V / 4)), ay = ro_quad_chunks(grid.y, groups) * groups;               \
+    const unsigned mx = (unsigned)(ax > (int)grid.x ? ax : (int)grid.x), my = (unsigned)(ay > (int)grid.y ? ay : (int)grid.y); \
+    hipLaunchKernelGGL((k_nlbn_pair_apply<FV, D1V, D2V>), dim3(mx, my, 2), dim3(RO_T), 0, st, B, N, groups, ax, ay,  \
+                       (int)grid.x, (int)grid.y, x, a, b);                                                        \
+  }
+  RO_PAIR_DISPATCH(F, D1, D2, CALL)
+#undef CALL
+  IGCN_CHECK_LAUNCH("node_linear_bn_pair_fwd");
+  return IGCN_OK;
+}
+
+// Arguments per side as igcn_node_linear_bn_bwd (scratch: igcn_node_linear_bn_bwd_scratch_floats each).
+extern "C" int igcn_node_linear_bn_pair_bwd(int B, int F, int N, int groups, int training, const float* x,
+                                            int D1, const float* W1, const float* gamma1, const float* beta1,
+                                            const float* save_mean1, const float* save_rstd1, const float* dout1,
+                                            float* dx1, float* dW1, float* dgb1, float* scratch1,
+                                            int D2, const float* W2, const float* gamma2, const float* beta2,
+                                            const float* save_mean2, const float* save_rstd2, const float* dout2,
+                                            const float* keep2, float* dx2, float* dW2, float* dgb2, float* scratch2,
+                                            void* stream) {
+  IGCN_REQUIRE(B > 0 && N > 0 && groups >= 1 && B % groups == 0, "node_linear_bn_pair_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const int cpg = ro_cpg(B, groups);
+  dim3 grid((unsigned)igcn_cdiv(N, RO_NL), groups * cpg);
+  auto split = [&](float* scratch, float*& stats, float*& dgg, float*& aux) {
+    stats = scratch;
+    dgg = stats + (size_t)groups * cpg * 2 * N;
+    aux = scratch + (((size_t)(dgg - scratch) + (size_t)groups * 2 * N + 3) & ~(size_t)3);
+  };
+  RoSide a = {}, b = {};
+  float *st1, *dg1, *ax1, *st2, *dg2, *ax2;
+  split(scratch1, st1, dg1, ax1);
+  split(scratch2, st2, dg2, ax2);
+  a.W = W1; a.gamma = gamma1; a.beta = beta1; a.mean_c = save_mean1; a.rstd_c = save_rstd1; a.dout = dout1;
+  a.partial = st1; a.dgg = dg1; a.aux = ax1; a.dx = dx1;
+  b.W = W2; b.gamma = gamma2; b.beta = beta2; b.mean_c = save_mean2; b.rstd_c = save_rstd2; b.dout = dout2;
+  b.keep = keep2; b.partial = st2; b.dgg = dg2; b.aux = ax2; b.dx = dx2;
+  int rc;
+#define CALL(FV, D1V, D2V)                                                                                        \
+  {                                                                                                               \
+    const int cq = ro_quad_chunks(grid.y, groups);                                                                \
+    const int ax = (int)igcn_cdiv(N, 64 / (D1V / 4)), ay = cq * groups;                                           \
+    const unsigned mx = (unsigned)(ax > (int)grid.x ? ax : (int)grid.x), my = (unsigned)(ay > (int)grid.y ? ay : (int)grid.y); \
+    hipLaunchKernelGGL((k_nlbn_pair_bwd_stats<FV, D1V, D2V>), dim3(mx, my, 2), dim3(RO_T), 0, st, B, N, groups, ax, ay, \
+                       (int)grid.x, (int)grid.y, x, a, b);                                                        \
+    if ((rc = igcn_launch_reduce_rows(st2, cpg, (int64_t)groups * 2 * N, groups * 2 * N, dg2, 0, st))) return rc;  \
+    hipLaunchKernelGGL((k_nlbn_pair_bwd_apply<FV, D1V, D2V>), dim3(mx, my, 2), dim3(RO_T), 0, st, B, N, groups,    \
+                       training, ax, ay, cq, (int)grid.x, (int)grid.y, x, a, b);                                  \
+    IGCN_CHECK_LAUNCH("node_linear_bn_pair_bwd");                                                                 \
+    if ((rc = igcn_launch_reduce_rows_final(st1, (int64_t)cq * groups, 2 * (int64_t)N, 2 * N, dgb1, st))) return rc; \
+    if ((rc = igcn_launch_reduce_rows_final(ax1, (int64_t)ax * ay, D1V * FV, D1V * FV, dW1, st))) return rc;       \
+    if ((rc = igcn_launch_reduce_rows_final(dg2, groups, 2 * (int64_t)N, 2 * N, dgb2, st))) return rc;             \
+    return igcn_launch_reduce_rows_final(ax2, (int64_t)grid.x * grid.y, D2V * FV, D2V * FV, dW2, st);              \
+  }
+  RO_PAIR_DISPATCH(F, D1, D2, CALL)
 #undef CALL
 }
 

@@ -12,6 +12,8 @@ so checkpoints interchange.  The arithmetic is restructured for the GPU:
 
 Dense read-outs (BatchNorm over nodes, the latent MLP) are small torch ops on the same stream.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -145,8 +147,20 @@ class Gene_ontology_network(nn.Module):
             x = ops.NodesLayerNorm.apply(y, self.G_B[j].weight, self.G_B[j].bias, keeps[j], self.pool[j],
                                          self.G_B[j].eps)
         # read-outs (:254-255): BatchNorm1d(n_top) normalises per NODE over (batch, feature); fused kernels
-        atten_out = self._node_linear_bn(x, self.conc_for_attention[0].weight, self.conc_for_attention[1], groups)
-        inp_out = self._node_linear_bn(x, self.conc.weight, self.B[0], groups, masks["inp"]).squeeze(2)
+        bn_a, bn_i = self.conc_for_attention[1], self.B[0]
+        if ops.node_linear_bn_pair_supported(x, self.conc_for_attention[0].weight, self.conc.weight, None) \
+                and os.environ.get("IGCN_NO_READOUT_PAIR", "0") != "1":
+            # both read-outs of the encoder output in paired launches (and one input gradient back)
+            if self.training:
+                self._tracked += [bn.num_batches_tracked for bn in (bn_a, bn_i) if bn.track_running_stats]
+            atten_out, inp_out = ops.NodeLinearBNPair.apply(
+                x, self.conc_for_attention[0].weight, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var,
+                bn_a.momentum, bn_a.eps, self.conc.weight, bn_i.weight, bn_i.bias, bn_i.running_mean, bn_i.running_var,
+                bn_i.momentum, bn_i.eps, masks["inp"], self.training, groups)
+            inp_out = inp_out.squeeze(2)
+        else:
+            atten_out = self._node_linear_bn(x, self.conc_for_attention[0].weight, bn_a, groups)
+            inp_out = self._node_linear_bn(x, self.conc.weight, bn_i, groups, masks["inp"]).squeeze(2)
         # decoder (:258-275)
         for j in range(self.n_l):
             csr = self.dec_csr[j]

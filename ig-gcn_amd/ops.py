@@ -1248,6 +1248,65 @@ class NodeLinearBN(torch.autograd.Function):
         return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, None
 
 
+class NodeLinearBNPair(torch.autograd.Function):
+    """Two NodeLinearBN read-outs of the SAME input (go_model.py:254-255: conc_for_attention -> [B,N,D1] and conc ->
+    [B,N,1] with its dropout) as one op: paired launches (igcn_node_linear_bn_pair_*), three forward and three
+    backward for both, and ONE input gradient (the sum of the two) handed back to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, mom1, eps1, w2, g2, b2, rm2, rv2, mom2, eps2, keep2, training, groups):
+        x, w1, g1, b1, w2, g2, b2 = (_f32(t) for t in (x, w1, g1, b1, w2, g2, b2))
+        keep2 = _f32(keep2) if keep2 is not None else None
+        b, f, n = x.shape
+        d1, d2 = w1.shape[0], w2.shape[0]
+        lib = _lib.load()
+        dev = x.device
+        e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)          # noqa: E731
+        out1, out2 = e(b, n, d1), e(b, n, d2)
+        mean1, rstd1, mean2, rstd2 = e(groups, n), e(groups, n), e(groups, n), e(groups, n)
+        nscr = int(lib.igcn_node_linear_bn_scratch_floats(b, n, groups))
+        s1, s2 = e(nscr), e(nscr)
+        call("igcn_node_linear_bn_pair_fwd", b, f, n, groups, ptr(x), int(training),
+             d1, ptr(w1), ptr(g1), ptr(b1), ptr(rm1), ptr(rv1), float(mom1), float(eps1), ptr(out1), ptr(mean1),
+             ptr(rstd1), ptr(s1),
+             d2, ptr(w2), ptr(g2), ptr(b2), ptr(rm2), ptr(rv2), float(mom2), float(eps2), ptr(keep2), ptr(out2),
+             ptr(mean2), ptr(rstd2), ptr(s2), stream_ptr())
+        ctx.save_for_backward(x, w1, g1, b1, mean1, rstd1, w2, g2, b2, mean2, rstd2, keep2)
+        ctx.training, ctx.groups = int(training), groups
+        ctx.final = _leaves(w1, g1, b1, w2, g2, b2)
+        return out1, out2
+
+    @staticmethod
+    def backward(ctx, dout1, dout2):
+        x, w1, g1, b1, mean1, rstd1, w2, g2, b2, mean2, rstd2, keep2 = ctx.saved_tensors
+        dout1, dout2 = _f32(dout1), _f32(dout2)
+        b, f, n = x.shape
+        d1, d2 = w1.shape[0], w2.shape[0]
+        lib = _lib.load()
+        dev = x.device
+        dx1, dx2 = torch.empty_like(x), torch.empty_like(x)
+        dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+        dgb1 = torch.empty(2, n, dtype=torch.float32, device=dev)
+        dgb2 = torch.empty(2, n, dtype=torch.float32, device=dev)
+        s1 = _keep(torch.empty(int(lib.igcn_node_linear_bn_bwd_scratch_floats(b, f, n, d1, ctx.groups)),
+                               dtype=torch.float32, device=dev))
+        s2 = _keep(torch.empty(int(lib.igcn_node_linear_bn_bwd_scratch_floats(b, f, n, d2, ctx.groups)),
+                               dtype=torch.float32, device=dev))
+        with _immediate(ctx.final):
+            call("igcn_node_linear_bn_pair_bwd", b, f, n, ctx.groups, ctx.training, ptr(x),
+                 d1, ptr(w1), ptr(g1), ptr(b1), ptr(mean1), ptr(rstd1), ptr(dout1), ptr(dx1), ptr(dw1), ptr(dgb1), ptr(s1),
+                 d2, ptr(w2), ptr(g2), ptr(b2), ptr(mean2), ptr(rstd2), ptr(dout2), ptr(keep2), ptr(dx2), ptr(dw2),
+                 ptr(dgb2), ptr(s2), stream_ptr())
+        dx = dx1.add_(dx2)
+        return (dx, dw1, dgb1[0], dgb1[1], None, None, None, None, dw2, dgb2[0], dgb2[1], None, None, None, None, None,
+                None, None)
+
+
+def node_linear_bn_pair_supported(x, w1, w2, keep1):
+    return (keep1 is None and x.is_cuda and x.dim() == 3
+            and bool(_lib.load().igcn_node_linear_bn_pair_supported(x.shape[1], w1.shape[0], w2.shape[0])))
+
+
 class BatchNorm1dGrouped(torch.autograd.Function):
     """(ReLU of) BatchNorm1d(C) on [B,C] with grouped batch statistics (latent MLP, go_model.py:138-146)."""
 

@@ -339,6 +339,26 @@ int igcn_node_linear_bn_bwd(int B, int F, int N, int D, int groups, int training
                             const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
                             const float* dout, const float* keep, float* dx, float* dW, float* dgb, float* scratch,
                             void* stream);
+/* Two read-outs of the SAME input x [B,F,N] in paired launches (go_model.py:254-255: conc_for_attention, D1 outputs per
+ * node, and conc, D2 = 1 with fused dropout keep2): three launches forward and three backward for both, their grids
+ * sharing the chip.  Per side the arguments of igcn_node_linear_bn_{fwd,bwd} (scratch sizes as there).
+ * igcn_node_linear_bn_pair_supported(F, D1, D2) != 0 for the shapes the paired kernels cover (F = 5, D1 = 32, D2 = 1). */
+int igcn_node_linear_bn_pair_supported(int F, int D1, int D2);
+int igcn_node_linear_bn_pair_fwd(int B, int F, int N, int groups, const float* x, int training,
+                                 int D1, const float* W1, const float* gamma1, const float* beta1,
+                                 float* running_mean1, float* running_var1, float momentum1, float eps1, float* out1,
+                                 float* save_mean1, float* save_rstd1, float* scratch1,
+                                 int D2, const float* W2, const float* gamma2, const float* beta2,
+                                 float* running_mean2, float* running_var2, float momentum2, float eps2,
+                                 const float* keep2, float* out2, float* save_mean2, float* save_rstd2, float* scratch2,
+                                 void* stream);
+int igcn_node_linear_bn_pair_bwd(int B, int F, int N, int groups, int training, const float* x,
+                                 int D1, const float* W1, const float* gamma1, const float* beta1,
+                                 const float* save_mean1, const float* save_rstd1, const float* dout1, float* dx1,
+                                 float* dW1, float* dgb1, float* scratch1,
+                                 int D2, const float* W2, const float* gamma2, const float* beta2,
+                                 const float* save_mean2, const float* save_rstd2, const float* dout2,
+                                 const float* keep2, float* dx2, float* dW2, float* dgb2, float* scratch2, void* stream);
 
 /* BatchNorm1d(C) (+ReLU when relu != 0) on a 2-D input [B,C] with the same grouped-statistics semantics —
  * the latent MLP of go_model.py:138-146.  save_mean/save_rstd are [groups,C]. */

@@ -869,6 +869,38 @@ def test_gemm_group_matches_single_products(rows, fin, fout):
     assert torch.equal(y2, ops.gemm_nt(x[: rows // 2], w[: max(1, fout // 2)], None, 0))
 
 
+@pytest.mark.parametrize("groups,training", [(2, True), (1, True), (2, False)])
+def test_node_linear_bn_pair_matches_two_readouts(groups, training):
+    """ops.NodeLinearBNPair (conc_for_attention + conc read-outs of one input in paired launches) against two
+    ops.NodeLinearBN calls: outputs, running statistics and every gradient bit for bit (same kernel bodies)."""
+    from igcn_amd import ops
+    torch.manual_seed(11)
+    b, f, n, d1 = 64, 5, 403, 32
+    x = torch.randn(b, f, n, device="cuda", requires_grad=True)
+    keep = (torch.rand(b, n, device="cuda") > 0.5).float() * 2
+    par = lambda *s_: torch.randn(*s_, device="cuda", requires_grad=True)          # noqa: E731
+    w1, g1, b1, w2, g2, b2 = par(d1, f), par(n), par(n), par(1, f), par(n), par(n)
+    assert ops.node_linear_bn_pair_supported(x, w1, w2, None)
+    stats = lambda: [torch.zeros(n, device="cuda"), torch.ones(n, device="cuda")]   # noqa: E731
+    (rm1, rv1), (rm2, rv2), (qm1, qv1), (qm2, qv2) = stats(), stats(), stats(), stats()
+    c1, c2 = torch.randn(b, n, d1, device="cuda"), torch.randn(b, n, 1, device="cuda")
+    leaves = [x, w1, g1, b1, w2, g2, b2]
+    o1, o2 = ops.NodeLinearBNPair.apply(x, w1, g1, b1, rm1, rv1, 0.1, 1e-5, w2, g2, b2, rm2, rv2, 0.1, 1e-5, keep,
+                                        training, groups)
+    got = torch.autograd.grad((o1 * c1).sum() + (o2 * c2).sum(), leaves)
+    z1 = ops.NodeLinearBN.apply(x, w1, g1, b1, qm1, qv1, training, 0.1, 1e-5, groups, None)
+    z2 = ops.NodeLinearBN.apply(x, w2, g2, b2, qm2, qv2, training, 0.1, 1e-5, groups, keep)
+    want = torch.autograd.grad((z1 * c1).sum() + (z2 * c2).sum(), leaves)
+    assert torch.equal(o1, z1) and torch.equal(o2, z2)
+    for a_, b_ in ((rm1, qm1), (rv1, qv1), (rm2, qm2), (rv2, qv2)):
+        assert torch.equal(a_, b_)
+    for g, w_, nm in zip(got, want, ("dx", "dw1", "dg1", "db1", "dw2", "dg2", "db2")):
+        if nm == "dx":
+            assert_matches(g, w_.cpu().numpy(), 1e-6, nm)       # one sum of the two branches either way
+        else:
+            assert torch.equal(g, w_), nm
+
+
 def test_small_linear_pair_matches_two_layers():
     """ops.small_linear_pair (lin2 + lin2_regr in one launch each way) against two ops.linear calls: same bits."""
     from igcn_amd import ops
