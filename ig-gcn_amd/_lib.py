@@ -95,6 +95,8 @@ SIGNATURES = {
     "igcn_nodes_ln_fwd": (I, [I, I, I, I, F, P, P, P, P, P, P, P, P]),
     "igcn_nodes_ln_bwd_scratch_floats": (Z, [I, I, I]),
     "igcn_nodes_ln_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_nodes_ln_bwd_dy": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P]),
+    "igcn_nodes_ln_bwd_affine_multi": (I, [I, P, P]),
     "igcn_go_decode_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P]),
     "igcn_go_decode_bwd_scratch_floats": (Z, [I, I, I, I]),
     "igcn_go_decode_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),

@@ -1566,16 +1566,16 @@ k_nodes_ln_bwd_affine(int rows, int f, int N, int pool, const float* __restrict_
 
 // 16-bytes-per-lane form (N, pool multiples of 4, aligned rows): thread = (quad of nodes, row lane); one float4 of y,
 // dz and keep per row instead of four scalar loads each.  Same chunk layout of the partials.
-__global__ void __launch_bounds__(256)
-k_nodes_ln_bwd_affine_v(int rows, int f, int N, int pool, const float* __restrict__ y,
-                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                        const float* __restrict__ keep, const float* __restrict__ mean,
-                        const float* __restrict__ rstd, const float* __restrict__ dz,
-                        float* __restrict__ partial) {
+__device__ __forceinline__ void
+ln_bwd_affine_v_body(const int bx, const int by, int rows, int f, int N, int pool, const float* __restrict__ y,
+                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                     const float* __restrict__ keep, const float* __restrict__ mean,
+                     const float* __restrict__ rstd, const float* __restrict__ dz,
+                     float* __restrict__ partial) {
   __shared__ float4 sg[16][16], sb[16][16];
   const int nq = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const int n = (blockIdx.x * 16 + nq) * 4;
-  const int r0 = blockIdx.y * LN_RC, r1 = min(rows, r0 + LN_RC);
+  const int n = (bx * 16 + nq) * 4;
+  const int r0 = by * LN_RC, r1 = min(rows, r0 + LN_RC);
   float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
   if (n < N && n >= pool) {
     const float4 ga = ld4(gamma + n), be = ld4(beta + n);
@@ -1609,10 +1609,40 @@ k_nodes_ln_bwd_affine_v(int rows, int f, int N, int pool, const float* __restric
       tg.x += a.x; tg.y += a.y; tg.z += a.z; tg.w += a.w;
       tb.x += c.x; tb.y += c.y; tb.z += c.z; tb.w += c.w;
     }
-    float* prow = partial + (int64_t)blockIdx.y * 2 * N;
+    float* prow = partial + (int64_t)by * 2 * N;
     *reinterpret_cast<float4*>(prow + n) = tg;
     *reinterpret_cast<float4*>(prow + N + n) = tb;
   }
+}
+
+__global__ void __launch_bounds__(256)
+k_nodes_ln_bwd_affine_v(int rows, int f, int N, int pool, const float* __restrict__ y,
+                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                        const float* __restrict__ keep, const float* __restrict__ mean,
+                        const float* __restrict__ rstd, const float* __restrict__ dz,
+                        float* __restrict__ partial) {
+  ln_bwd_affine_v_body((int)blockIdx.x, (int)blockIdx.y, rows, f, N, pool, y, gamma, beta, keep, mean, rstd, dz, partial);
+}
+
+// The affine-gradient passes of SEVERAL LayerNorm layers in one flat grid: d gamma / d beta are parameter gradients —
+// nothing in the backward reads them — so the passes of a whole backward can wait for its end and share one launch
+// (four grids of 150-750 workgroups each, which otherwise run one after the other between the layers' dX kernels).
+#define LN_AFF_MAX 4
+struct LnAffProb {
+  int rows, f, N, pool, gx, wg0;
+  const float *y, *gamma, *beta, *keep, *mean, *rstd, *dz;
+  float* partial;
+};
+struct LnAffGroup { int n; LnAffProb p[LN_AFF_MAX]; };
+__global__ void __launch_bounds__(256) k_nodes_ln_bwd_affine_multi(const LnAffGroup G) {
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < LN_AFF_MAX; ++i)
+    if (i < G.n && (int)blockIdx.x >= G.p[i].wg0) pi = i;
+  const LnAffProb& p = G.p[pi];
+  const int l = (int)blockIdx.x - p.wg0;
+  ln_bwd_affine_v_body(l % p.gx, l / p.gx, p.rows, p.f, p.N, p.pool, p.y, p.gamma, p.beta, p.keep, p.mean, p.rstd, p.dz,
+                       p.partial);
 }
 
 extern "C" size_t igcn_nodes_ln_bwd_scratch_floats(int B, int f, int N) {
@@ -1642,6 +1672,71 @@ extern "C" int igcn_nodes_ln_bwd(int B, int f, int N, int pool, const float* y, 
   }
   IGCN_CHECK_LAUNCH("nodes_ln_bwd");
   return igcn_launch_reduce_rows_final(scratch, chunks, 2 * (int64_t)N, 2 * N, dgb, st);
+}
+
+// The backward in two calls: igcn_nodes_ln_bwd_dy now, and the affine gradients of up to LN_AFF_MAX layers later in one
+// launch (igcn_nodes_ln_bwd_affine_multi) — see k_nodes_ln_bwd_affine_multi.
+extern "C" int igcn_nodes_ln_bwd_dy(int B, int f, int N, int pool, const float* y, const float* gamma,
+                                    const float* beta, const float* keep, const float* mean, const float* rstd,
+                                    const float* dz, float* dy, void* stream) {
+  IGCN_REQUIRE(B > 0 && f > 0 && N > 0 && pool >= 0 && pool < N, "nodes_ln_bwd_dy: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (ln_vec_ok(N, pool, y, gamma, beta, dz, dy, keep)) {
+    hipLaunchKernelGGL(k_nodes_ln_bwd_dy_v, dim3(B * f), dim3(ln_threads(N)), 0, st, f, N, pool, y, gamma, beta, keep, mean,
+                       rstd, dz, dy);
+  } else {
+    hipLaunchKernelGGL(k_nodes_ln_bwd_dy, dim3(B * f), dim3(GO_T), 0, st, f, N, pool, y, gamma, beta, keep, mean, rstd,
+                       dz, dy);
+  }
+  IGCN_CHECK_LAUNCH("nodes_ln_bwd_dy");
+  return IGCN_OK;
+}
+
+// table [n][13] int64 = {B, f, N, pool, y, gamma, beta, keep, mean, rstd, dz, scratch, dgb} per layer (pointers as
+// integers; scratch of igcn_nodes_ln_bwd_scratch_floats, dgb [2,N]).  Layers whose tensors do not allow 16-byte
+// accesses get their own launch of the scalar kernel.
+extern "C" int igcn_nodes_ln_bwd_affine_multi(int n, const int64_t* table, void* stream) {
+  IGCN_REQUIRE(n >= 1 && n <= LN_AFF_MAX && table != nullptr, "nodes_ln_bwd_affine_multi: 1..%d layers", LN_AFF_MAX);
+  hipStream_t st = (hipStream_t)stream;
+  LnAffGroup G = {};
+  int wgs = 0;
+  int64_t chunks_of[LN_AFF_MAX];
+  bool grouped[LN_AFF_MAX];
+  for (int i = 0; i < n; ++i) {
+    const int64_t* t = table + 13 * i;
+    const int B = (int)t[0], f = (int)t[1], N = (int)t[2], pool = (int)t[3];
+    const float *y = (const float*)t[4], *gamma = (const float*)t[5], *beta = (const float*)t[6], *keep = (const float*)t[7];
+    const float *mean = (const float*)t[8], *rstd = (const float*)t[9], *dz = (const float*)t[10];
+    float* scratch = (float*)t[11];
+    IGCN_REQUIRE(B > 0 && f > 0 && N > 0 && pool >= 0 && pool < N && scratch != nullptr,
+                 "nodes_ln_bwd_affine_multi: bad layer %d", i);
+    const int64_t chunks = igcn_cdiv((int64_t)B * f, LN_RC);
+    chunks_of[i] = chunks;
+    grouped[i] = ln_vec_ok(N, pool, y, gamma, beta, dz, scratch, keep);
+    if (!grouped[i]) {
+      hipLaunchKernelGGL(k_nodes_ln_bwd_affine, dim3((unsigned)igcn_cdiv(N, 64), (unsigned)chunks), dim3(256), 0, st,
+                         B * f, f, N, pool, y, gamma, beta, keep, mean, rstd, dz, scratch);
+      continue;
+    }
+    LnAffProb& p = G.p[G.n++];
+    p.rows = B * f; p.f = f; p.N = N; p.pool = pool;
+    p.y = y; p.gamma = gamma; p.beta = beta; p.keep = keep; p.mean = mean; p.rstd = rstd; p.dz = dz; p.partial = scratch;
+    p.gx = (int)igcn_cdiv(N, 64);
+    p.wg0 = wgs;
+    wgs += p.gx * (int)chunks;
+  }
+  if (G.n > 0) {
+    for (int i = G.n; i < LN_AFF_MAX; ++i) G.p[i] = G.p[0];
+    hipLaunchKernelGGL(k_nodes_ln_bwd_affine_multi, dim3((unsigned)wgs), dim3(256), 0, st, G);
+  }
+  IGCN_CHECK_LAUNCH("nodes_ln_bwd_affine_multi");
+  for (int i = 0; i < n; ++i) {
+    const int64_t* t = table + 13 * i;
+    const int N = (int)t[2];
+    const int rc = igcn_launch_reduce_rows_final((float*)t[11], chunks_of[i], 2 * (int64_t)N, 2 * N, (float*)t[12], st);
+    if (rc) return rc;
+  }
+  return IGCN_OK;
 }
 
 // =================================================================================================

@@ -22,7 +22,7 @@ def _f32(t):
 # =================================================================================================
 # Deferred reductions of a backward pass (igcn_reduce_defer / igcn_reduce_flush)
 # =================================================================================================
-_DEFER = {"on": False, "keep": []}
+_DEFER = {"on": False, "keep": [], "ln_affine": []}
 
 
 class deferred_reductions:
@@ -40,12 +40,27 @@ class deferred_reductions:
 
     def __exit__(self, *exc):
         try:
+            if exc[0] is None:
+                _flush_ln_affine()           # queued parameter-gradient passes: one launch for all of them (still deferred)
             call("igcn_reduce_defer", 0)
             call("igcn_reduce_flush", stream_ptr())
         finally:
             _DEFER["on"] = False
             _DEFER["keep"].clear()
+            _DEFER["ln_affine"].clear()
         return False
+
+
+def _flush_ln_affine():
+    """The affine-gradient passes queued by NodesLayerNorm.backward, four layers per launch."""
+    q = _DEFER["ln_affine"]
+    for i in range(0, len(q), 4):
+        part = q[i:i + 4]
+        table = (ctypes.c_int64 * (13 * len(part)))()
+        for j, (dims, tens) in enumerate(part):
+            table[13 * j:13 * j + 13] = list(dims) + [ptr(t) or 0 for t in tens]
+        call("igcn_nodes_ln_bwd_affine_multi", len(part), ctypes.addressof(table), stream_ptr())
+    q.clear()
 
 
 def _keep(t):
@@ -1158,9 +1173,16 @@ class NodesLayerNorm(torch.autograd.Function):
         lib = _lib.load()
         scratch = _keep(torch.empty(int(lib.igcn_nodes_ln_bwd_scratch_floats(b, f, n)), dtype=torch.float32,
                                     device=y.device))
-        with _immediate(ctx.final):
-            call("igcn_nodes_ln_bwd", b, f, n, ctx.pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean),
-                 ptr(rstd), ptr(dz), ptr(dy), ptr(dgb), ptr(scratch), stream_ptr())
+        if _DEFER["on"] and ctx.final and os.environ.get("IGCN_LN_AFFINE_NOW", "0") != "1":
+            # d gamma / d beta are parameter gradients: their pass joins those of the other layers in ONE launch when
+            # the backward ends (operands kept alive until then)
+            call("igcn_nodes_ln_bwd_dy", b, f, n, ctx.pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean),
+                 ptr(rstd), ptr(dz), ptr(dy), stream_ptr())
+            _DEFER["ln_affine"].append(((b, f, n, ctx.pool), (y, gamma, beta, keep, mean, rstd, dz, scratch, dgb)))
+        else:
+            with _immediate(ctx.final):
+                call("igcn_nodes_ln_bwd", b, f, n, ctx.pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean),
+                     ptr(rstd), ptr(dz), ptr(dy), ptr(dgb), ptr(scratch), stream_ptr())
         return dy, dgb[0], dgb[1], None, None, None
 
 

@@ -502,6 +502,13 @@ size_t igcn_nodes_ln_bwd_scratch_floats(int B, int f, int N);
 int igcn_nodes_ln_bwd(int B, int f, int N, int pool, const float* y, const float* gamma, const float* beta,
                       const float* keep, const float* mean, const float* rstd, const float* dz,
                       float* dy, float* dgb, float* scratch, void* stream);
+/* The same backward in two calls: the input gradient now, the affine gradients (d gamma | d beta: parameter gradients,
+ * read by nobody before the optimiser) of up to four layers later, in ONE launch.  table [n][13] int64 =
+ * {B, f, N, pool, y, gamma, beta, keep, mean, rstd, dz, scratch, dgb} per layer (pointers as integers). */
+int igcn_nodes_ln_bwd_dy(int B, int f, int N, int pool, const float* y, const float* gamma, const float* beta,
+                         const float* keep, const float* mean, const float* rstd, const float* dz, float* dy,
+                         void* stream);
+int igcn_nodes_ln_bwd_affine_multi(int n, const int64_t* table, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GO decoder layer (mean aggregation down the hierarchy) — go_model.py:262-272, batch_mul :197-201:
