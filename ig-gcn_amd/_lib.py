@@ -86,6 +86,7 @@ SIGNATURES = {
     "igcn_spmm_fwd": (I, [I, I, I, I, L, P, P, P, P, P, P]),
     "igcn_spmm_bwd_scratch_floats": (Z, [I, I, I, I, L]),
     "igcn_spmm_bwd": (I, [I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_spmm_bwd_dval_multi": (I, [I, P, P]),
     "igcn_go_attn_fwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "igcn_go_attn_bwd_scratch_floats": (Z, [I, I, I, I]),
     "igcn_go_attn_bwd_threads": (I, [I, I, I]),

@@ -234,12 +234,12 @@ static size_t spmm_long_lds_bytes(int C, int L, int64_t nnz, int sum_c) {
 
 // partial[wg][c][k] = sum_{b in tile} big[b, c, bidx[k]] * small[b, sidx[k]]     (big [B][C][L], small [B][S])
 #define SPMM_DT 1024
-__global__ void __launch_bounds__(SPMM_DT)
-k_spmm_dval_lds(int B, int C, int L, int S, int64_t nnz, int tile, const int32_t* __restrict__ bidx,
-                const int32_t* __restrict__ sidx, const float* __restrict__ big, const float* __restrict__ small_,
-                float* __restrict__ partial) {
+__device__ __forceinline__ void
+spmm_dval_lds_body(const int bx, int B, int C, int L, int S, int64_t nnz, int tile, const int32_t* __restrict__ bidx,
+                   const int32_t* __restrict__ sidx, const float* __restrict__ big, const float* __restrict__ small_,
+                   float* __restrict__ partial) {
   extern __shared__ float sp_lds[];                    // [tile][C*L] then [tile][S]
-  const int b0 = blockIdx.x * tile, nb = min(tile, B - b0), CL = C * L;
+  const int b0 = bx * tile, nb = min(tile, B - b0), CL = C * L;
   float* bs = sp_lds;
   float* ss = sp_lds + (size_t)tile * CL;
   const float* bsrc = big + (int64_t)b0 * CL;
@@ -251,7 +251,7 @@ k_spmm_dval_lds(int B, int C, int L, int S, int64_t nnz, int tile, const int32_t
   }
   for (int t = threadIdx.x; t < nb * S; t += SPMM_DT) ss[t] = small_[(int64_t)b0 * S + t];
   __syncthreads();
-  float* prow = partial + (int64_t)blockIdx.x * C * nnz;
+  float* prow = partial + (int64_t)bx * C * nnz;
   for (int64_t k = threadIdx.x; k < nnz; k += SPMM_DT) {
     const int32_t r = bidx[k], j = sidx[k];
     for (int c = 0; c < C; ++c) {
@@ -260,6 +260,30 @@ k_spmm_dval_lds(int B, int C, int L, int S, int64_t nnz, int tile, const int32_t
       prow[(int64_t)c * nnz + k] = acc;
     }
   }
+}
+
+__global__ void __launch_bounds__(SPMM_DT)
+k_spmm_dval_lds(int B, int C, int L, int S, int64_t nnz, int tile, const int32_t* __restrict__ bidx,
+                const int32_t* __restrict__ sidx, const float* __restrict__ big, const float* __restrict__ small_,
+                float* __restrict__ partial) {
+  spmm_dval_lds_body((int)blockIdx.x, B, C, L, S, nnz, tile, bidx, sidx, big, small_, partial);
+}
+
+// The value-gradient passes of TWO maps (the SNP -> GO encoding and the GO -> SNP decoding of one backward) as one flat
+// grid: each alone is B / 4 = 128 workgroups of 1024 threads with ~100 KB of LDS — half the CUs — and both are
+// parameter gradients that nothing reads before the optimiser, so the first can wait for the second.
+struct SpmmDvalProb {
+  int B, C, L, S, tile, wg0;
+  int64_t nnz;
+  const int32_t *bidx, *sidx;
+  const float *big, *small_;
+  float* partial;
+};
+struct SpmmDvalGroup { int n; SpmmDvalProb p[2]; };
+__global__ void __launch_bounds__(SPMM_DT) k_spmm_dval_lds_multi(const SpmmDvalGroup G) {
+  const int pi = (G.n > 1 && (int)blockIdx.x >= G.p[1].wg0) ? 1 : 0;
+  const SpmmDvalProb& p = G.p[pi];
+  spmm_dval_lds_body((int)blockIdx.x - p.wg0, p.B, p.C, p.L, p.S, p.nnz, p.tile, p.bidx, p.sidx, p.big, p.small_, p.partial);
 }
 
 // samples per workgroup of k_spmm_dval_lds: what ~120 KB of LDS hold, at most 4 (0: the vectors do not fit)
@@ -426,6 +450,65 @@ extern "C" int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int3
                        nnz, col, row_of, x, dy, scratch);
     IGCN_CHECK_LAUNCH("spmm_bwd_dval");
     return igcn_launch_reduce_rows_final(scratch, bch, (int64_t)C * nnz, (int)((int64_t)C * nnz), dval, st);
+  }
+  return IGCN_OK;
+}
+
+// table [n <= 2][12] int64 = {B, C, I, J, nnz, col, row_of, x, dy, dval, scratch, 0} per map: the dval half of
+// igcn_spmm_bwd (same arguments, same scratch) for up to two maps in one launch.  A map whose vectors do not fit LDS
+// gets its own launch of the global-memory kernel.
+extern "C" int igcn_spmm_bwd_dval_multi(int n, const int64_t* table, void* stream) {
+  IGCN_REQUIRE(n >= 1 && n <= 2 && table != nullptr, "spmm_bwd_dval_multi: one or two maps");
+  hipStream_t st = (hipStream_t)stream;
+  SpmmDvalGroup G = {};
+  int wgs = 0;
+  size_t lds = 0;
+  int64_t rows_of[2] = {0, 0};
+  for (int i = 0; i < n; ++i) {
+    const int64_t* t = table + 12 * i;
+    const int B = (int)t[0], C = (int)t[1], I = (int)t[2], J = (int)t[3];
+    const int64_t nnz = t[4];
+    const int32_t *col = (const int32_t*)t[5], *row_of = (const int32_t*)t[6];
+    const float *x = (const float*)t[7], *dy = (const float*)t[8];
+    float* scratch = (float*)t[10];
+    IGCN_REQUIRE(B > 0 && C > 0 && I > 0 && J > 0 && scratch != nullptr, "spmm_bwd_dval_multi: bad map %d", i);
+    if (nnz <= 0) continue;
+    const bool rows_long = I >= J;
+    const int L = rows_long ? I : J, S = rows_long ? J : I;
+    const int tile = (rows_long || C == 1) ? spmm_dval_tile(C, L, S) : 0;
+    if (spmm_no_lds() || tile < 1) {
+      const int bch = B < SPMM_BCH ? B : SPMM_BCH;
+      hipLaunchKernelGGL(k_spmm_bwd_dval, dim3((unsigned)igcn_cdiv(nnz, GO_T), C, bch), dim3(GO_T), 0, st, B, C, I, J,
+                         nnz, col, row_of, x, dy, scratch);
+      rows_of[i] = bch;
+      continue;
+    }
+    SpmmDvalProb& p = G.p[G.n++];
+    p.B = B; p.C = C; p.L = L; p.S = S; p.tile = tile; p.nnz = nnz;
+    p.bidx = rows_long ? row_of : col;
+    p.sidx = rows_long ? col : row_of;
+    p.big = rows_long ? dy : x;
+    p.small_ = rows_long ? x : dy;
+    p.partial = scratch;
+    p.wg0 = wgs;
+    const int w = (int)igcn_cdiv(B, tile);
+    wgs += w;
+    rows_of[i] = w;
+    const size_t l = (size_t)tile * ((size_t)C * L + S) * sizeof(float);
+    lds = l > lds ? l : lds;
+  }
+  if (G.n > 0) {
+    if (G.n == 1) G.p[1] = G.p[0];
+    if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS(k_spmm_dval_lds_multi);
+    hipLaunchKernelGGL(k_spmm_dval_lds_multi, dim3((unsigned)wgs), dim3(SPMM_DT), lds, st, G);
+  }
+  IGCN_CHECK_LAUNCH("spmm_bwd_dval_multi");
+  for (int i = 0; i < n; ++i) {
+    const int64_t* t = table + 12 * i;
+    if (t[4] <= 0) continue;
+    const int64_t cn = t[1] * t[4];
+    const int rc = igcn_launch_reduce_rows_final((float*)t[10], rows_of[i], cn, (int)cn, (float*)t[9], st);
+    if (rc) return rc;
   }
   return IGCN_OK;
 }

@@ -22,7 +22,7 @@ def _f32(t):
 # =================================================================================================
 # Deferred reductions of a backward pass (igcn_reduce_defer / igcn_reduce_flush)
 # =================================================================================================
-_DEFER = {"on": False, "keep": [], "ln_affine": []}
+_DEFER = {"on": False, "keep": [], "ln_affine": [], "spmm_dval": []}
 
 
 class deferred_reductions:
@@ -40,14 +40,16 @@ class deferred_reductions:
 
     def __exit__(self, *exc):
         try:
-            if exc[0] is None:
-                _flush_ln_affine()           # queued parameter-gradient passes: one launch for all of them (still deferred)
+            if exc[0] is None:           # queued parameter-gradient passes: one launch per kind (their sums still deferred)
+                _flush_ln_affine()
+                _flush_spmm_dval()
             call("igcn_reduce_defer", 0)
             call("igcn_reduce_flush", stream_ptr())
         finally:
             _DEFER["on"] = False
             _DEFER["keep"].clear()
             _DEFER["ln_affine"].clear()
+            _DEFER["spmm_dval"].clear()
         return False
 
 
@@ -60,6 +62,18 @@ def _flush_ln_affine():
         for j, (dims, tens) in enumerate(part):
             table[13 * j:13 * j + 13] = list(dims) + [ptr(t) or 0 for t in tens]
         call("igcn_nodes_ln_bwd_affine_multi", len(part), ctypes.addressof(table), stream_ptr())
+    q.clear()
+
+
+def _flush_spmm_dval():
+    """The value-gradient passes queued by SparseMap.backward, two maps per launch."""
+    q = _DEFER["spmm_dval"]
+    for i in range(0, len(q), 2):
+        part = q[i:i + 2]
+        table = (ctypes.c_int64 * (12 * len(part)))()
+        for j, (dims, tens) in enumerate(part):
+            table[12 * j:12 * j + 11] = list(dims) + [ptr(t) or 0 for t in tens]
+        call("igcn_spmm_bwd_dval_multi", len(part), ctypes.addressof(table), stream_ptr())
     q.clear()
 
 
@@ -1097,10 +1111,21 @@ class SparseMap(torch.autograd.Function):
             scratch = _keep(torch.empty(int(_lib.load().igcn_spmm_bwd_scratch_floats(b, c, csr.n_rows, csr.n_cols,
                                                                                       csr.nnz)),
                                         dtype=torch.float32, device=x.device)) if dval is not None else None
-            with _immediate(ctx.final):
-                call("igcn_spmm_bwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
-                     ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(x), ptr(dy), ptr(dx),
-                     ptr(dval), ptr(scratch), stream_ptr())
+            def bwd(dx_, dval_):
+                with _immediate(ctx.final):
+                    call("igcn_spmm_bwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
+                         ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(x), ptr(dy),
+                         ptr(dx_), ptr(dval_), ptr(scratch), stream_ptr())
+            if (dval is not None and _DEFER["on"] and ctx.final and csr.nnz > 0
+                    and os.environ.get("IGCN_SPMM_DVAL_NOW", "0") != "1"):
+                # the value gradients are parameter gradients: queued, and launched together with the other map's at
+                # the end of the backward (each pass alone fills half the chip)
+                if dx is not None:
+                    bwd(dx, None)
+                _DEFER["spmm_dval"].append(((b, c, csr.n_rows, csr.n_cols, csr.nnz),
+                                            (csr.col, csr.row_of, x, dy, dval, scratch)))
+            else:
+                bwd(dx, dval)
         if dval is None:
             grads = (None,) * ctx.nvals
         elif ctx.stacked:

@@ -455,6 +455,9 @@ int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_pt
                   const float* val, const float* x, const float* dy,
                   float* dx /*[B,J] or NULL*/, float* dval /*[C,nnz] or NULL*/,
                   float* scratch /* needed when dval != NULL */, void* stream);
+/* The value-gradient half of igcn_spmm_bwd for one or two maps in ONE launch (call igcn_spmm_bwd with dval = NULL for
+ * the input gradients): table [n][12] int64 = {B, C, I, J, nnz, col, row_of, x, dy, dval, scratch, 0} per map. */
+int igcn_spmm_bwd_dval_multi(int n, const int64_t* table, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GO attention-GCN encoder layer, all samples at once — replaces the dense transforms, the edge gathers
