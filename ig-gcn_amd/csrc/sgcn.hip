@@ -288,26 +288,35 @@ k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict
   block_reduce_vec<2 * MAX_H0>(acc, red, pb_partial + (int64_t)blockIdx.x * 2 * MAX_H0);
 }
 
-// dprob[r,h] = sum_b gx[(b*rois + r), h]
+// dprob[r,h] = sum_b gx[(b*rois + r), h]: one block per (roi, feature).  One MORE block sums the node kernel's block
+// partials into the bias gradient dpb [2 h0] (16 row lanes x 16 column slots, lanes combined in order) — that sum used
+// to be two further launches (column sums of the partial rows, then the pick-and-store).
 __global__ void __launch_bounds__(256)
-k_edge_mask_bwd_prob(int64_t n_graphs, int rois, int h0, const float* __restrict__ gx,
-                     float* __restrict__ dprob) {
-  __shared__ float red[16];
-  const int j = blockIdx.x;           // one block per (roi, feature)
+k_edge_mask_bwd_prob(int64_t n_graphs, int rois, int h0, const float* __restrict__ gx, float* __restrict__ dprob,
+                     int64_t nblk, const float* __restrict__ partial, float* __restrict__ dpb) {
+  __shared__ float red[16 * 16];
+  const int j = blockIdx.x;
+  if (j == rois * h0) {
+    const int rl = threadIdx.x >> 4, cs = threadIdx.x & 15;
+    float t = 0.f;
+    if (cs < 2 * h0) {
+      const int col = cs < h0 ? cs : MAX_H0 + (cs - h0);
+#pragma unroll 4
+      for (int64_t r = rl; r < nblk; r += 16) t += partial[r * 2 * MAX_H0 + col];
+    }
+    red[rl * 16 + cs] = t;
+    __syncthreads();
+    if (rl == 0 && cs < 2 * h0) {
+      float a = 0.f;
+      for (int l = 0; l < 16; ++l) a += red[l * 16 + cs];
+      dpb[cs] = a;
+    }
+    return;
+  }
   float t = 0.f;
   for (int64_t b = threadIdx.x; b < n_graphs; b += 256) t += gx[b * rois * h0 + j];
   t = block_sum_all(t, red);
   if (threadIdx.x == 0) dprob[j] = t;
-}
-
-__global__ void k_edge_mask_bwd_pb(int64_t nblk, int h0, const float* __restrict__ partial, float* __restrict__ dpb) {
-  const int j = threadIdx.x;
-  if (j >= 2 * h0) return;
-  const int col = j < h0 ? j : MAX_H0 + (j - h0);
-  float t = 0.f;
-#pragma unroll 8
-  for (int64_t r = 0; r < nblk; ++r) t += partial[r * 2 * MAX_H0 + col];
-  dpb[j] = t;
 }
 
 extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x,
@@ -332,16 +341,9 @@ extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, in
   else                                             // k = 3 graphs: four lanes share a node's six list entries
     hipLaunchKernelGGL(k_edge_mask_bwd_nodes<4>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
                        prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
-  hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)(rois * h0)), dim3(256), 0, st, n_nodes / rois, rois, h0,
-                     gx, dprob);
-  if (nblk > 256) {                                // many partial rows: parallel column sums first
-    float* tot = part + nblk * 2 * MAX_H0;
-    int rc = igcn_launch_reduce_rows(part, nblk, 2 * MAX_H0, 2 * MAX_H0, tot, 0, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_edge_mask_bwd_pb, dim3(1), dim3(64), 0, st, (int64_t)1, h0, tot, dprob_bias);
-  } else {
-    hipLaunchKernelGGL(k_edge_mask_bwd_pb, dim3(1), dim3(64), 0, st, nblk, h0, part, dprob_bias);
-  }
+  static_assert(2 * MAX_H0 <= 16, "k_edge_mask_bwd_prob: the bias-gradient block has 16 column slots");
+  hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)(rois * h0 + 1)), dim3(256), 0, st, n_nodes / rois, rois, h0,
+                     gx, dprob, nblk, part, dprob_bias);
   IGCN_CHECK_LAUNCH("edge_mask_bwd");
   return IGCN_OK;
 }
