@@ -501,6 +501,24 @@ __global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const fl
   C[m * ldc + n] = t;
 }
 
+// the slab sums of up to four split products of the SAME output shape in one launch (blockIdx.y = product)
+struct SlabSums { const float* slabs[4]; const float* bias[4]; float* C[4]; int split[4]; };
+__global__ void k_gemm_splitk_reduce_multi(int64_t M, int64_t N, SlabSums q, int64_t ldc, int act) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const float* __restrict__ slabs = q.slabs[blockIdx.y];
+  const float* __restrict__ bias = q.bias[blockIdx.y];
+  float* __restrict__ C = q.C[blockIdx.y];
+  const int split_k = q.split[blockIdx.y];
+  const int64_t m = i / N, n = i - m * N;
+  float t = 0.f;
+#pragma unroll 8
+  for (int z = 0; z < split_k; ++z) t += slabs[(int64_t)z * M * N + i];
+  if (bias) t += bias[n];
+  if (act == 1) t = fmaxf(t, 0.f);
+  C[m * ldc + n] = t;
+}
+
 // Launch shape, fitted to a sweep over the products of the train step (tools/gemm_sweep.py): the tile is 64 x BN.
 // A wide tile only pays when there are tens of thousands of rows to stream; otherwise narrower tiles put more
 // workgroups on the chip.  K is split so that ~512 workgroups exist, each keeping at least one 32-deep K step.
@@ -745,7 +763,34 @@ extern "C" int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream) 
   else         { if (bn == 16) LAUNCH_GG(16, 2); else if (bn == 32) LAUNCH_GG(32, 2); else LAUNCH_GG(64, 2); }
 #undef LAUNCH_GG
   IGCN_CHECK_LAUNCH("gemm_f32_grouped");
+  // slab sums: the plain column-walk ones of equal output shape share a launch (lin1 / lin1_regr: two [512, 64] sums)
+  bool done[GG_MAX] = {false, false, false, false};
   for (int i = 0; i < n; ++i) {
+    const int64_t* t = table + 16 * i;
+    const int act = (int)t[12] & 0xff;
+    auto plain = [&](int k) {
+      const int64_t* u = table + 16 * k;
+      const bool tree = u[11] == u[1] && u[0] * u[1] <= 4096 && split_of[k] > 32 && u[9] == 0 && ((int)u[12] & 0xff) == 0;
+      return split_of[k] > 1 && !fgrad[k] && !tree;
+    };
+    if (done[i] || !plain(i)) continue;
+    SlabSums q = {};
+    int cnt = 0;
+    for (int k = i; k < n; ++k) {
+      const int64_t* u = table + 16 * k;
+      if (!done[k] && plain(k) && u[0] == t[0] && u[1] == t[1] && u[11] == t[11] && ((int)u[12] & 0xff) == act) {
+        q.slabs[cnt] = (const float*)u[14]; q.bias[cnt] = (const float*)u[9]; q.C[cnt] = (float*)u[10];
+        q.split[cnt] = split_of[k];
+        done[k] = true;
+        ++cnt;
+      }
+    }
+    hipLaunchKernelGGL(k_gemm_splitk_reduce_multi, dim3((unsigned)igcn_cdiv(t[0] * t[1], 256), (unsigned)cnt), dim3(256), 0,
+                       st, t[0], t[1], q, t[11], act);
+    IGCN_CHECK_LAUNCH("gemm_splitk_reduce_multi");
+  }
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
     const int64_t* t = table + 16 * i;
     const int rc = gemm_sum_slabs(split_of[i], fgrad[i], t[0], t[1], (float*)t[14], (const float*)t[9], (float*)t[10], t[11],
                                   (int)t[12] & 0xff, st);
