@@ -348,11 +348,11 @@ __device__ __forceinline__ void store_tile_bf16(const TileLoader<ROWS, VW>& l, _
 }
 
 template <int BN, int VW>
-__global__ void __launch_bounds__(256)
-k_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,
+__device__ __forceinline__ void
+gemm_bf16_tile(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,
             const float* __restrict__ B, int64_t sbn, int64_t sbk, const float* __restrict__ bias,
             float* __restrict__ C, int64_t ldc, int act, int64_t k_per_split, int64_t slab_stride,
-            int64_t a_zs, int64_t b_zs, int zsplit) {
+            int64_t a_zs, int64_t b_zs, int zsplit, const dim3 tile, const bool final_out) {
   extern __shared__ float g_lds[];
   const int nbuf = k_per_split <= G_BK ? 1 : 2;
   __bf16 (*As)[G_BM][G_LDB] = reinterpret_cast<__bf16 (*)[G_BM][G_LDB]>(g_lds);
@@ -360,7 +360,6 @@ k_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_
                                                                       (size_t)nbuf * G_BM * G_LDB);
   constexpr int NT = BN / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const dim3 tile = blockIdx;
   const int64_t m0 = (int64_t)tile.x * G_BM, n0 = (int64_t)tile.y * BN;
   const int64_t bidx = tile.z / zsplit, ks_id = tile.z % zsplit;
   const int64_t k_begin = ks_id * k_per_split;
@@ -405,7 +404,6 @@ k_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_
     buf ^= 1;
   }
   float* Cz = C + (int64_t)tile.z * slab_stride;
-  const bool final_out = (gridDim.z == 1);
   const int64_t gm = m0 + w * 16 + (lane & 15);
   const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)Cz & 15) == 0);
   if (gm < M) {
@@ -429,6 +427,30 @@ k_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_
       }
     }
   }
+}
+
+template <int BN, int VW>
+__global__ void __launch_bounds__(256)
+k_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,
+            const float* __restrict__ B, int64_t sbn, int64_t sbk, const float* __restrict__ bias,
+            float* __restrict__ C, int64_t ldc, int act, int64_t k_per_split, int64_t slab_stride,
+            int64_t a_zs, int64_t b_zs, int zsplit) {
+  gemm_bf16_tile<BN, VW>(M, N, K, A, sam, sak, B, sbn, sbk, bias, C, ldc, act, k_per_split, slab_stride, a_zs, b_zs, zsplit,
+                         blockIdx, gridDim.z == 1);
+}
+
+// bf16-operand form of k_gemm_f32_grouped (the operand layouts are runtime properties of this kernel anyway)
+template <int BN, int VW>
+__global__ void __launch_bounds__(256) k_gemm_bf16_grouped(const GemmGroup G) {
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GG_MAX; ++i)
+    if (i < G.n && (int)blockIdx.x >= G.p[i].wg0) pi = i;
+  const GemmProb& p = G.p[pi];
+  const int l = (int)blockIdx.x - p.wg0;
+  const dim3 tile((unsigned)(l % p.gx), (unsigned)((l / p.gx) % p.gy), (unsigned)(l / (p.gx * p.gy)));
+  gemm_bf16_tile<BN, VW>(p.M, p.N, p.K, p.A, p.sam, p.sak, p.B, p.sbn, p.sbk, p.bias, p.C, p.ldc, p.act, p.kps, p.slab, 0, 0,
+                         p.zsplit, tile, p.gz == 1);
 }
 
 static size_t gemm_bf16_lds_bytes(int bn, int64_t k_per_split) {
@@ -688,8 +710,9 @@ extern "C" int igcn_gemm_f32_batched(int64_t M, int64_t N, int64_t K, int batch,
 
 
 // n (<= 4) products of different shapes in ONE launch: table [n][16] int64 =
-//   {M, N, K, A, sam, sak, B, sbn, sbk, bias, C, ldc, act (| 0x100: parameter gradient), split_k, scratch, 0}
-// with the meaning of igcn_gemm_f32's arguments.  Slab sums follow per problem as there.  Falls back to one launch per
+//   {M, N, K, A, sam, sak, B, sbn, sbk, bias, C, ldc, act (| 0x100: parameter gradient), split_k, scratch, bf16}
+// with the meaning of igcn_gemm_f32's arguments; bf16 != 0 (first problem's entry decides): operands rounded to bf16
+// as in igcn_gemm_bf16.  Slab sums follow per problem as there.  Falls back to one launch per
 // problem when the operands do not all allow at least 8-byte loads.
 static size_t gemm_lds_bytes(int bn, int64_t k_per_split, bool a_rfast, bool b_rfast);
 extern "C" int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream) {
@@ -734,10 +757,11 @@ extern "C" int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream) 
     vw = v < vw ? v : vw;
     if (igcn_cdiv(kps < p.K ? kps : p.K, G_BK) > 2) pf = 2;
   }
+  const bool bf16 = table[15] != 0;
   if (vw < 2 || n == 1) {                              // not groupable: the ordinary launches, one after the other
     for (int i = 0; i < n; ++i) {
       const int64_t* t = table + 16 * i;
-      const int rc = gemm_launch(false, t[0], t[1], t[2], (const float*)t[3], t[4], t[5], (const float*)t[6], t[7], t[8],
+      const int rc = gemm_launch(bf16, t[0], t[1], t[2], (const float*)t[3], t[4], t[5], (const float*)t[6], t[7], t[8],
                                  (const float*)t[9], (float*)t[10], t[11], (int)t[12], (int)t[13], (float*)t[14], stream);
       if (rc) return rc;
     }
@@ -750,7 +774,7 @@ extern "C" int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream) 
     p.gz = p.zsplit;
     p.wg0 = wgs;
     wgs += p.gx * p.gy * p.gz;
-    const size_t l = gemm_lds_bytes(bn, p.kps, p.arf, p.brf);
+    const size_t l = bf16 ? gemm_bf16_lds_bytes(bn, p.kps) : gemm_lds_bytes(bn, p.kps, p.arf, p.brf);
     lds = l > lds ? l : lds;
   }
   for (int i = n; i < GG_MAX; ++i) G.p[i] = G.p[0];
@@ -759,8 +783,15 @@ extern "C" int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream) 
     if (vw == 4) hipLaunchKernelGGL((k_gemm_f32_grouped<BNV, 4, PFV>), dim3((unsigned)wgs), dim3(256), lds, st, G);   \
     else hipLaunchKernelGGL((k_gemm_f32_grouped<BNV, 2, PFV>), dim3((unsigned)wgs), dim3(256), lds, st, G);           \
   } while (0)
-  if (pf == 1) { if (bn == 16) LAUNCH_GG(16, 1); else if (bn == 32) LAUNCH_GG(32, 1); else LAUNCH_GG(64, 1); }
-  else         { if (bn == 16) LAUNCH_GG(16, 2); else if (bn == 32) LAUNCH_GG(32, 2); else LAUNCH_GG(64, 2); }
+#define LAUNCH_GB(BNV)                                                                                             \
+  do {                                                                                                             \
+    if (vw == 4) hipLaunchKernelGGL((k_gemm_bf16_grouped<BNV, 4>), dim3((unsigned)wgs), dim3(256), lds, st, G);      \
+    else hipLaunchKernelGGL((k_gemm_bf16_grouped<BNV, 2>), dim3((unsigned)wgs), dim3(256), lds, st, G);              \
+  } while (0)
+  if (bf16) { if (bn == 16) LAUNCH_GB(16); else if (bn == 32) LAUNCH_GB(32); else LAUNCH_GB(64); }
+  else if (pf == 1) { if (bn == 16) LAUNCH_GG(16, 1); else if (bn == 32) LAUNCH_GG(32, 1); else LAUNCH_GG(64, 1); }
+  else              { if (bn == 16) LAUNCH_GG(16, 2); else if (bn == 32) LAUNCH_GG(32, 2); else LAUNCH_GG(64, 2); }
+#undef LAUNCH_GB
 #undef LAUNCH_GG
   IGCN_CHECK_LAUNCH("gemm_f32_grouped");
   // slab sums: the plain column-walk ones of equal output shape share a launch (lin1 / lin1_regr: two [512, 64] sums)

@@ -498,11 +498,11 @@ def gemm_tn(a, b, bf16=False, final_grad=False, out=None):
 def gemm_group(specs, bf16=False):
     """Several independent products in ONE launch (igcn_gemm_f32_grouped; at most four).  ``specs``: tuples
     (form, a, b, out, bias, final_grad[, act]) with form "nt" (a [M,K], b [N,K]), "nn" (a [M,K], b [K,N]) or "tn"
-    (a [K,M], b [K,N]); ``out`` None allocates; act 1 = ReLU ("nt" only).  Returns the outputs.  bf16 operands: one
-    launch per product, as before."""
+    (a [K,M], b [K,N]); ``out`` None allocates; act 1 = ReLU ("nt" only).  Returns the outputs.  ``bf16``: operands
+    rounded to bf16 on the way into LDS (igcn_gemm_bf16 semantics) for every member."""
     outs = []
     specs = [tuple(sp) + (0,) * (7 - len(sp)) for sp in specs]
-    if bf16 or len(specs) > 4 or os.environ.get("IGCN_NO_GEMM_GROUPS", "0") == "1":
+    if len(specs) > 4 or os.environ.get("IGCN_NO_GEMM_GROUPS", "0") == "1":
         for form, a, b, out, bias, final, act in specs:
             if form == "nt":
                 outs.append(gemm_nt(a, b, bias, act, out=out, bf16=bf16))
@@ -534,6 +534,7 @@ def gemm_group(specs, bf16=False):
         hold += [a, b, out, scratch, bias]
         table[16 * i:16 * i + 15] = [m, n, k, ptr(a) or 0, st[0], st[1], ptr(b) or 0, st[2], st[3], ptr(bias) or 0,
                                      ptr(out) or 0, n, act | (0x100 if final else 0), sk, ptr(scratch) or 0]
+        table[16 * i + 15] = 1 if bf16 else 0
         outs.append(out)
     call("igcn_gemm_f32_grouped", len(specs), ctypes.addressof(table), stream_ptr())
     return outs
@@ -603,12 +604,12 @@ class LinearPair(torch.autograd.Function):
     as six half-empty grids one after the other."""
 
     @staticmethod
-    def forward(ctx, x1, w1, b1, x2, w2, b2, relu):
+    def forward(ctx, x1, w1, b1, x2, w2, b2, relu, bf16=False):
         x1, x2 = _f32(x1), _f32(x2)
         y1, y2 = gemm_group([("nt", x1, w1, None, b1, False, 1 if relu else 0),
-                             ("nt", x2, w2, None, b2, False, 1 if relu else 0)])
+                             ("nt", x2, w2, None, b2, False, 1 if relu else 0)], bf16=bf16)
         ctx.save_for_backward(x1, w1, x2, w2, y1 if relu else None, y2 if relu else None)
-        ctx.relu = relu
+        ctx.relu, ctx.bf16 = relu, bf16
         ctx.final = (_leaves(w1), _leaves(b1), _leaves(w2), _leaves(b2))
         return y1, y2
 
@@ -643,16 +644,17 @@ class LinearPair(torch.autograd.Function):
                 dbs.append(db)
         with _immediate(ctx.final[0] and ctx.final[2]):
             dx1, dw1, dx2, dw2 = gemm_group([("nn", gs[0], w1, None, None, False), ("tn", gs[0], x1, None, None, True),
-                                             ("nn", gs[1], w2, None, None, False), ("tn", gs[1], x2, None, None, True)])
-        return dx1, dw1, dbs[0], dx2, dw2, dbs[1], None
+                                             ("nn", gs[1], w2, None, None, False), ("tn", gs[1], x2, None, None, True)],
+                                            bf16=ctx.bf16)
+        return dx1, dw1, dbs[0], dx2, dw2, dbs[1], None, None
 
 
 def linear_pair(x1, w1, b1, x2, w2, b2, relu=True, bf16=False):
     """(act(x1 W1^T + b1), act(x2 W2^T + b2)) with grouped launches; separate ops.linear calls when the shapes fall
-    outside the grouped kernel (bf16 operands, bias-less layers, wide outputs)."""
-    if bf16 or b1 is None or b2 is None or w1.shape[0] > 256 or w2.shape[0] > 256 or x1.dim() != 2 or x2.dim() != 2:
+    outside the grouped kernel (bias-less layers, wide outputs)."""
+    if b1 is None or b2 is None or w1.shape[0] > 256 or w2.shape[0] > 256 or x1.dim() != 2 or x2.dim() != 2:
         return linear(x1, w1, b1, relu=relu, bf16=bf16), linear(x2, w2, b2, relu=relu, bf16=bf16)
-    return LinearPair.apply(x1, w1, b1, x2, w2, b2, relu)
+    return LinearPair.apply(x1, w1, b1, x2, w2, b2, relu, bf16)
 
 
 def _proj_backward(ctx, dq, dkv, q2, m2, w, dw, d):

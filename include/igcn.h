@@ -308,8 +308,9 @@ int igcn_gemm_f32_batched(int64_t M, int64_t N, int64_t K, int batch, const floa
                           int64_t a_batch, const float* B, int64_t sbn, int64_t sbk, int64_t b_batch, float* C,
                           int64_t c_batch, int64_t ldc, int split_k, float* scratch, void* stream);
 /* n (1..4) products of DIFFERENT shapes in one launch (the dX and dW products of a linear layer's backward): table
- * [n][16] int64 = {M, N, K, A, sam, sak, B, sbn, sbk, bias, C, ldc, act, split_k, scratch, 0} per problem, each field
- * as the igcn_gemm_f32 argument of that name (pointers as integers).  Same results as n igcn_gemm_f32 calls. */
+ * [n][16] int64 = {M, N, K, A, sam, sak, B, sbn, sbk, bias, C, ldc, act, split_k, scratch, bf16} per problem, each
+ * field as the igcn_gemm_f32 argument of that name (pointers as integers); bf16 != 0 in the first problem: operands
+ * rounded to bf16 as in igcn_gemm_bf16.  Same results as n igcn_gemm_f32 / igcn_gemm_bf16 calls. */
 int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -867,6 +867,11 @@ def test_gemm_group_matches_single_products(rows, fin, fout):
     y1, y2 = ops.gemm_group([("nt", x, w, None, bias, False), ("nt", x[: rows // 2], w[: max(1, fout // 2)], None, None, False)])
     assert torch.equal(y1, ops.gemm_nt(x, w, bias, 0))
     assert torch.equal(y2, ops.gemm_nt(x[: rows // 2], w[: max(1, fout // 2)], None, 0))
+    # bf16-operand members (configs[4]): the same bits as igcn_gemm_bf16 product by product
+    dxb, dwb = ops.gemm_group([("nn", dy, w, None, None, False), ("tn", dy, x, None, None, False)], bf16=True)
+    assert torch.equal(dxb, ops.gemm_nn(dy, w, bf16=True)) and torch.equal(dwb, ops.gemm_tn(dy, x, bf16=True))
+    yb, = ops.gemm_group([("nt", x, w, None, bias, False, 1)], bf16=True)
+    assert torch.equal(yb, ops.gemm_nt(x, w, bias, 1, bf16=True))
 
 
 @pytest.mark.parametrize("groups,training", [(2, True), (1, True), (2, False)])
