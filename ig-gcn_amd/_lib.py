@@ -21,6 +21,7 @@ SIGNATURES = {
     "igcn_graph_plan_workspace_bytes": (Z, [L, L]),
     "igcn_graph_plan_build": (I, [L, L, P, P, P, P, P, P, P, P, P, Z, P]),
     "igcn_graph_plan_build_segmented": (I, [L, L, I, P, P, P, L, L, P, P, P, P, P, P, P, P, P]),
+    "igcn_graph_plan_build_segmented_rep": (I, [L, L, I, P, P, P, L, L, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P]),
     "igcn_graph_plan_tiled_workspace_bytes": (Z, [I, L, L]),
     "igcn_graph_plan_build_tiled": (I, [L, L, I, P, P, P, L, L, P, P, P, P, P, P, P, P, P, Z, P]),
     "igcn_graph_plan_replicate": (I, [L, L, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),

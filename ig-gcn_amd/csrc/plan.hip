@@ -708,12 +708,16 @@ extern "C" int igcn_graph_plan_replicate(int64_t n_nodes, int64_t n_edges, int c
 // sort), for targets and for sources.  One launch replaces two device-wide radix sorts (~14 launches).
 #define SEG_MAXE 4096
 #define SEG_MAXN 1024
+// `rep`: the plan of `copies` disjoint copies of the batch (what igcn_graph_plan_replicate derives from the plan: the
+// two passes of a train step as one block-diagonal problem), written by the same workgroups — one launch less per step.
+struct PlanRep { int copies; int32_t *src32, *dst32, *tgt_ptr, *tgt_perm, *src_ptr, *src_perm, *loop_edge; };
 __global__ void __launch_bounds__(256)
 k_plan_segmented(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* __restrict__ ei,
                  const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ edge_ptr,
                  int32_t* __restrict__ src32, int32_t* __restrict__ dst32, int32_t* __restrict__ tgt_ptr,
                  int32_t* __restrict__ tgt_perm, int32_t* __restrict__ src_ptr, int32_t* __restrict__ src_perm,
-                 int32_t* __restrict__ loop_edge, int32_t* __restrict__ status) {
+                 int32_t* __restrict__ loop_edge, int32_t* __restrict__ status, const PlanRep rep) {
+  const int32_t N32 = (int32_t)n_nodes, E32 = (int32_t)n_edges;
   __shared__ int16_t ls[SEG_MAXE], ld[SEG_MAXE];        // local (graph-relative) endpoints
   __shared__ int32_t ct[SEG_MAXN + 1], cs[SEG_MAXN + 1], lp[SEG_MAXN];
   const int g = blockIdx.x, tid = threadIdx.x;
@@ -731,6 +735,10 @@ k_plan_segmented(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* 
     const int64_t s = ei[eb + k] - nb, d = ei[n_edges + eb + k] - nb;
     src32[eb + k] = (int32_t)(s + nb);
     dst32[eb + k] = (int32_t)(d + nb);
+    for (int c = 0; c < rep.copies; ++c) {
+      rep.src32[(int64_t)c * n_edges + eb + k] = (int32_t)(s + nb) + c * N32;
+      rep.dst32[(int64_t)c * n_edges + eb + k] = (int32_t)(d + nb) + c * N32;
+    }
     if (s < 0 || s >= nn || d < 0 || d >= nn) { bad = true; ls[k] = 0; ld[k] = 0; continue; }
     ls[k] = (int16_t)s;
     ld[k] = (int16_t)d;
@@ -760,9 +768,16 @@ k_plan_segmented(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* 
   }
   __syncthreads();
   for (int i = tid; i < nn; i += 256) {
-    tgt_ptr[nb + i] = (int32_t)(eb + ct[i]);
-    src_ptr[nb + i] = (int32_t)(eb + cs[i]);
-    loop_edge[nb + i] = lp[i] >= 0 ? (int32_t)(eb + lp[i]) : -1;
+    const int32_t tp = (int32_t)(eb + ct[i]), sp = (int32_t)(eb + cs[i]);
+    const int32_t le = lp[i] >= 0 ? (int32_t)(eb + lp[i]) : -1;
+    tgt_ptr[nb + i] = tp;
+    src_ptr[nb + i] = sp;
+    loop_edge[nb + i] = le;
+    for (int c = 0; c < rep.copies; ++c) {
+      rep.tgt_ptr[(int64_t)c * n_nodes + nb + i] = tp + c * E32;
+      rep.src_ptr[(int64_t)c * n_nodes + nb + i] = sp + c * E32;
+      rep.loop_edge[(int64_t)c * n_nodes + nb + i] = le >= 0 ? le + c * E32 : -1;
+    }
   }
   // stable placement, one thread per edge: its slot inside its group = the number of EARLIER edges with the same
   // key.  All lanes read the same ld[j] / ls[j] (an LDS broadcast), so the scan is a divergence-free stream of
@@ -777,11 +792,41 @@ k_plan_segmented(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* 
     }
     tgt_perm[eb + ct[kd] + rd] = (int32_t)(eb + k);
     src_perm[eb + cs[ks] + rs] = (int32_t)(eb + k);
+    for (int c = 0; c < rep.copies; ++c) {
+      rep.tgt_perm[(int64_t)c * n_edges + eb + ct[kd] + rd] = (int32_t)(eb + k) + c * E32;
+      rep.src_perm[(int64_t)c * n_edges + eb + cs[ks] + rs] = (int32_t)(eb + k) + c * E32;
+    }
   }
   if (g == n_graphs - 1 && tid == 0) {
     tgt_ptr[n_nodes] = (int32_t)n_edges;
     src_ptr[n_nodes] = (int32_t)n_edges;
+    if (rep.copies > 0) {
+      rep.tgt_ptr[(int64_t)rep.copies * n_nodes] = rep.copies * E32;
+      rep.src_ptr[(int64_t)rep.copies * n_nodes] = rep.copies * E32;
+    }
   }
+}
+
+static int plan_build_segmented(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* edge_index,
+                                const int64_t* node_ptr, const int64_t* edge_ptr, int64_t max_nodes_per_graph,
+                                int64_t max_edges_per_graph, int32_t* src32, int32_t* dst32, int32_t* tgt_ptr,
+                                int32_t* tgt_perm, int32_t* src_ptr, int32_t* src_perm, int32_t* loop_edge,
+                                int32_t* status, const PlanRep& rep, void* stream) {
+  IGCN_REQUIRE(n_graphs > 0 && n_nodes > 0 && n_nodes < ((int64_t)1 << 31) && n_edges < ((int64_t)1 << 31),
+               "graph_plan_build_segmented: bad sizes");
+  IGCN_REQUIRE(rep.copies >= 0 && n_nodes * (rep.copies > 0 ? rep.copies : 1) < ((int64_t)1 << 31) &&
+                   n_edges * (rep.copies > 0 ? rep.copies : 1) < ((int64_t)1 << 31),
+               "graph_plan_build_segmented: replica sizes out of int32 range");
+  if (max_nodes_per_graph > SEG_MAXN || max_edges_per_graph > SEG_MAXE) {
+    igcn_set_error("graph_plan_build_segmented: graphs too large for the LDS path (max %d nodes / %d edges per graph)",
+                   SEG_MAXN, SEG_MAXE);
+    return IGCN_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(k_plan_segmented, dim3(n_graphs), dim3(256), 0, (hipStream_t)stream, n_nodes, n_edges, n_graphs,
+                     edge_index, node_ptr, edge_ptr, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, loop_edge,
+                     status, rep);
+  IGCN_CHECK_LAUNCH("graph_plan_build_segmented");
+  return IGCN_OK;
 }
 
 extern "C" int igcn_graph_plan_build_segmented(int64_t n_nodes, int64_t n_edges, int n_graphs,
@@ -791,16 +836,27 @@ extern "C" int igcn_graph_plan_build_segmented(int64_t n_nodes, int64_t n_edges,
                                                int32_t* tgt_ptr, int32_t* tgt_perm, int32_t* src_ptr,
                                                int32_t* src_perm, int32_t* loop_edge, int32_t* status,
                                                void* stream) {
-  IGCN_REQUIRE(n_graphs > 0 && n_nodes > 0 && n_nodes < ((int64_t)1 << 31) && n_edges < ((int64_t)1 << 31),
-               "graph_plan_build_segmented: bad sizes");
-  if (max_nodes_per_graph > SEG_MAXN || max_edges_per_graph > SEG_MAXE) {
-    igcn_set_error("graph_plan_build_segmented: graphs too large for the LDS path (max %d nodes / %d edges per graph)",
-                   SEG_MAXN, SEG_MAXE);
-    return IGCN_ERR_UNSUPPORTED;
-  }
-  hipLaunchKernelGGL(k_plan_segmented, dim3(n_graphs), dim3(256), 0, (hipStream_t)stream, n_nodes, n_edges, n_graphs,
-                     edge_index, node_ptr, edge_ptr, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, loop_edge,
-                     status);
-  IGCN_CHECK_LAUNCH("graph_plan_build_segmented");
-  return IGCN_OK;
+  const PlanRep none = {};
+  return plan_build_segmented(n_nodes, n_edges, n_graphs, edge_index, node_ptr, edge_ptr, max_nodes_per_graph,
+                              max_edges_per_graph, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, loop_edge, status,
+                              none, stream);
+}
+
+// The same build that also fills the plan of `copies` disjoint copies of the batch (the arrays
+// igcn_graph_plan_replicate would derive: sizes copies * E, copies * N + 1, copies * N).
+extern "C" int igcn_graph_plan_build_segmented_rep(int64_t n_nodes, int64_t n_edges, int n_graphs,
+                                                   const int64_t* edge_index, const int64_t* node_ptr,
+                                                   const int64_t* edge_ptr, int64_t max_nodes_per_graph,
+                                                   int64_t max_edges_per_graph, int32_t* src32, int32_t* dst32,
+                                                   int32_t* tgt_ptr, int32_t* tgt_perm, int32_t* src_ptr,
+                                                   int32_t* src_perm, int32_t* loop_edge, int32_t* status, int copies,
+                                                   int32_t* o_src32, int32_t* o_dst32, int32_t* o_tgt_ptr,
+                                                   int32_t* o_tgt_perm, int32_t* o_src_ptr, int32_t* o_src_perm,
+                                                   int32_t* o_loop_edge, void* stream) {
+  IGCN_REQUIRE(copies >= 1 && o_src32 && o_dst32 && o_tgt_ptr && o_tgt_perm && o_src_ptr && o_src_perm && o_loop_edge,
+               "graph_plan_build_segmented_rep: copies >= 1 and all seven replica arrays");
+  const PlanRep rep = {copies, o_src32, o_dst32, o_tgt_ptr, o_tgt_perm, o_src_ptr, o_src_perm, o_loop_edge};
+  return plan_build_segmented(n_nodes, n_edges, n_graphs, edge_index, node_ptr, edge_ptr, max_nodes_per_graph,
+                              max_edges_per_graph, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, loop_edge, status,
+                              rep, stream);
 }

@@ -174,6 +174,13 @@ class GraphPlan:
                     ptr(self.src_perm), ptr(self.loop_edge), ptr(self.status))
             if self._tiled:
                 call("igcn_graph_plan_build_tiled", *head, ptr(self._ws), self._ws.numel(), stream_ptr())
+            elif self._copies:
+                # a replica plan exists (the two passes of a train step as one block-diagonal problem): the build
+                # fills it too, instead of a replicate launch behind it
+                (copies, rep), = self._copies.items()
+                call("igcn_graph_plan_build_segmented_rep", *head, copies, ptr(rep.src32), ptr(rep.dst32),
+                     ptr(rep.tgt_ptr), ptr(rep.tgt_perm), ptr(rep.src_ptr), ptr(rep.src_perm), ptr(rep.loop_edge),
+                     stream_ptr())
             else:
                 call("igcn_graph_plan_build_segmented", *head, stream_ptr())
             return
@@ -183,11 +190,15 @@ class GraphPlan:
 
     def rebuild(self, edge_index):
         """Build again IN PLACE for a new ``edge_index`` of the same size (same graph segments): every plan tensor
-        keeps its address, so kernels captured in a hipGraph keep reading the right memory.  Derived replicas are
-        dropped (igcn_graph_plan_replicate is cheap and capturable)."""
+        keeps its address, so kernels captured in a hipGraph keep reading the right memory."""
         if edge_index.shape != (2, self.n_edges) or edge_index.dtype != torch.int64:
             raise _lib.IgcnError("rebuild needs an int64 edge_index of the shape the plan was built for")
-        self._copies = {}
+        # the LDS per-graph build refills ONE cached replica in place (same addresses: capturable); any other build
+        # drops the replicas, to be derived again on demand
+        keep = (self._seg is not None and not self._tiled and len(self._copies) == 1
+                and os.environ.get("IGCN_PLAN_REPLICATE_LAUNCH", "0") != "1")
+        if not keep:
+            self._copies = {}
         self._build(edge_index.contiguous())
 
     def check(self):

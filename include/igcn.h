@@ -60,6 +60,15 @@ int igcn_graph_plan_build_segmented(int64_t n_nodes, int64_t n_edges, int n_grap
                                     int32_t* src32, int32_t* dst32, int32_t* tgt_ptr, int32_t* tgt_perm,
                                     int32_t* src_ptr, int32_t* src_perm, int32_t* loop_edge, int32_t* status,
                                     void* stream);
+/* The same build, also filling the plan of `copies` disjoint copies of the batch (the seven arrays
+ * igcn_graph_plan_replicate derives: copies*E, copies*E, copies*N+1, copies*E, copies*N+1, copies*E, copies*N). */
+int igcn_graph_plan_build_segmented_rep(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* edge_index,
+                                        const int64_t* node_ptr, const int64_t* edge_ptr, int64_t max_nodes_per_graph,
+                                        int64_t max_edges_per_graph, int32_t* src32, int32_t* dst32, int32_t* tgt_ptr,
+                                        int32_t* tgt_perm, int32_t* src_ptr, int32_t* src_perm, int32_t* loop_edge,
+                                        int32_t* status, int copies, int32_t* o_src32, int32_t* o_dst32,
+                                        int32_t* o_tgt_ptr, int32_t* o_tgt_perm, int32_t* o_src_ptr, int32_t* o_src_perm,
+                                        int32_t* o_loop_edge, void* stream);
 
 /* Same plan for a PyG batch whose graphs have at most 1024 nodes and ANY number of edges (the dense 512-ROI graphs of
  * the stress configuration: 262 144 edges each): a hand-written one-pass stable counting sort per graph over tiles of

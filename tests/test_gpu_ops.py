@@ -561,6 +561,27 @@ def test_plan_replicate_equals_plan_of_the_doubled_graph(ops):
         assert torch.equal(getattr(rep, name), getattr(full, name)), name
 
 
+def test_segmented_rebuild_refills_the_replica_plan(ops):
+    """A per-graph (LDS) plan that has a 2-copy replica refills it inside rebuild() — no igcn_graph_plan_replicate launch
+    behind the build: after a rebuild on a permuted batch the replica equals the replica derived from a fresh plan."""
+    from igcn_amd import synth
+    from igcn_amd.data import Batch
+    batch = Batch.from_data_list(synth.brain_graph_list(8, seed=3, rois=90, tsne_dim=90)).to("cuda")
+    plan = ops.plan_for(batch)
+    assert plan.segmented and not plan._tiled
+    rep = plan.replicate(2)
+    addr = rep.tgt_perm.data_ptr()
+    flipped = batch.edge_index.flip(0).contiguous()                 # still block diagonal, same per-graph counts
+    plan.rebuild(flipped)
+    assert plan.replicate(2) is rep and rep.tgt_perm.data_ptr() == addr
+    n = int(batch.x.shape[0])
+    fresh = ops.GraphPlan(flipped, n, batch.ptr, batch.edge_ptr, batch._max_nodes, batch._max_edges)
+    want = ops.GraphPlan(torch.cat([flipped, flipped + n], dim=1), 2 * n)
+    for name in ("src32", "dst32", "tgt_ptr", "tgt_perm", "src_ptr", "src_perm", "loop_edge"):
+        assert torch.equal(getattr(plan, name), getattr(fresh, name)), name
+        assert torch.equal(getattr(rep, name), getattr(want, name)), "replica " + name
+
+
 def test_mask_regulariser(ops):
     from oracle import sgcn_img_snp as OS
     rng = np.random.default_rng(3)
