@@ -257,7 +257,7 @@ def fused_stack_roofline(model, data, device, wl, stats):
 
     def launcher(xb, ewb, arrs, out):
         return lambda: call("igcn_sgcn_stack_fwd", g, rois, emax, h0, f, layers, ptr(xb), ptr(ewb), ptr(arrs[0]),
-                            ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3]), ptr(arrs[4]), wp, bp, ptr(out), stream_ptr())
+                            ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3]), ptr(arrs[4]), wp, bp, ptr(out), None, stream_ptr())
     base = (plan.src32, plan.dst32, plan.tgt_ptr, plan.tgt_perm, plan.loop_edge)
     out = torch.empty(n, d, device=device)
     one = launcher(x, ew, base, out)
@@ -402,7 +402,7 @@ def cpu_baseline(go, wl, seconds=20.0):
     cfg = SimpleNamespace(num_layers=LAYERS, rois=rois, image_only=False, rbf_gamma=0.01)
     b = 32 if not wl["dense"] else 4
     data = Batch.from_data_list(synth.brain_graph_list(b, seed=1000, rois=rois, tsne_dim=90, dense=wl["dense"]))
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(os.cpu_count() or 1)               # every host core, stated
     opt = None
     times = []
     t_end = time.perf_counter() + seconds
@@ -415,7 +415,75 @@ def cpu_baseline(go, wl, seconds=20.0):
     times = sorted(times[1:]) if len(times) > 1 else times
     med = times[len(times) // 2]
     return {"value": round(b / med, 2), "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "physical_cores": _physical_cores(), "torch": torch.__version__,
             "sample": f"{len(times)} train steps of B={b} graphs (same model/GO DAG, fp32), median; oracle faithful mode"}
+
+
+def _physical_cores():
+    try:
+        import psutil
+        return psutil.cpu_count(logical=False)
+    except Exception:                              # noqa: BLE001
+        return None
+
+
+def stress_child(timeout=300):
+    """BASELINE configs[4] beside the headline: a short ``--workload stress`` run of this script in a CHILD process
+    (its own model, graph capture, in-step rocprofv3 profile and bounded CPU-oracle sample) whose result line is folded
+    into the default line as ``stress``.  None (with the reason on stderr) when the child fails: the headline stands."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "stress", "--steps", "10", "--warmup", "3",
+           "--cpu-baseline-seconds", "8", "--no-stress"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if r.returncode != 0 or not lines:
+            print(f"[bench] stress child failed (rc={r.returncode}): {r.stderr[-600:]}", file=sys.stderr)
+            return None
+        full = json.loads(lines[-1])
+    except Exception as exc:                       # noqa: BLE001
+        print(f"[bench] stress child failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+        return None
+    keep = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "loss", "roofline", "roofline_mfma",
+            "cpu_baseline", "profile", "edge_pipeline")
+    out = {k: full[k] for k in keep if k in full}
+    out["workload"] = full["config"]["workload"]
+    out["graphs_per_gpu"] = full["config"]["graphs_per_gpu"]
+    return out
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher around it: start the N ranks as CHILD processes
+    (``python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>``, rendezvous on 127.0.0.1), forward
+    rank 0's JSON line and return the launcher's exit code.  Runs before this process has made any GPU call — never
+    an exec of a GPU-initialised process; ``torch.cuda.device_count()`` does not initialise the runtime."""
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("IGCN_BENCH_ONE_DEVICE", "0") != "1":
+        print(f"bench.py --gpus {n}: this box has {have} GPU(s).  One process per GPU needs {n}; for a control-flow "
+              "rehearsal on one device set IGCN_BENCH_ONE_DEVICE=1 (ranks share cuda:0, gradients over gloo).",
+              file=sys.stderr)
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in r.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)                       # anything else the ranks wrote to stdout
+    if lines:
+        print(lines[-1])
+    elif r.returncode == 0:
+        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
+        return 4
+    return r.returncode
 
 
 def main():
@@ -436,14 +504,19 @@ def main():
                     help="dense feature transforms with bf16 operands (auto: the workload's own setting)")
     ap.add_argument("--rotate", type=int, default=0,
                     help="time GraphedTrainStep.load + replay over this many distinct device-resident batches")
+    ap.add_argument("--no-stress", action="store_true",
+                    help="default workload only: skip the short configs[4] child run reported as `stress`")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="bound of the CPU-oracle sample")
     ap.add_argument("--inner-profile", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("launch multi-GPU runs with torch.distributed.run (one process per GPU)", file=sys.stderr)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))                  # no launcher around us: become one (no GPU call made yet)
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     # IGCN_BENCH_ONE_DEVICE=1 (rehearsal on a single-GPU box only): every rank shares cuda:0 and the gradient
     # exchange runs over gloo, so the multi-process control flow can be exercised without several GPUs
@@ -501,6 +574,13 @@ def main():
             print(f"[bench] igcn_comm unavailable ({type(exc).__name__}: {exc}); using torch.distributed",
                   file=sys.stderr)
             comm = None
+        if world > 1:
+            # every rank takes the SAME exchange: one rank on igcn_comm and another on torch.distributed would deadlock
+            flag = torch.tensor([1 if comm is not None else 0], device=device, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if int(flag.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
     if dist_on and comm is None:
         exchange = "torch.distributed all_reduce (%s)" % torch.distributed.get_backend()
 
@@ -548,6 +628,26 @@ def main():
         print("non-finite loss", file=sys.stderr)
         sys.exit(3)
 
+    # the gradient exchange on its own: HIP events on the launch stream around the all-reduce of a few extra steps
+    # (two-graph form only; an all-reduce captured into the step graph cannot be bracketed)
+    allreduce_us = None
+    if dist_on and gstep is not None and gstep.g_opt is not None and not args.inner_profile:
+        pairs = []
+        for _ in range(10):
+            gstep.g_main.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gstep._reduce()
+            e1.record()
+            gstep.g_opt.replay()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)
+        t = torch.tensor([ts[len(ts) // 2]], device=device, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        allreduce_us = round(float(t.item()), 1)
+
     if args.inner_profile:                        # the child under rocprofv3: the train step and nothing else
         print(json.dumps({"inner_steps": args.steps + args.warmup + (3 if gstep is not None else 0),
                           "ms_per_step": round(dt / args.steps * 1e3, 3)}))
@@ -568,6 +668,12 @@ def main():
                        "rccl_world_size": torch.distributed.get_world_size() if dist_on else 1},
             "loss": round(float(loss), 6),
         }
+        if dist_on:
+            res["config"]["allreduce_us_per_step"] = allreduce_us      # median over 10 steps, max over ranks
+            res["config"]["allreduce_bytes"] = int(opt.grad.numel()) * 4
+            n1 = os.environ.get("IGCN_BENCH_N1_VALUE")                  # graphs/s of the N = 1 run, when the caller has it
+            if n1:
+                res["weak_scaling_efficiency_vs_n1"] = round(res["value"] / (world * float(n1)), 4)
         if args.rotate > 1 and gstep is not None:
             # hand-over of NEW batches: GraphedTrainStep.load (device-to-device copies into the static inputs) + replay
             pool_b = [Batch.from_data_list(synth.brain_graph_list(per_gpu, seed=2000 + i, rois=wl["rois"], tsne_dim=90,
@@ -601,7 +707,13 @@ def main():
                                   "kernel_us_per_step": round(sum(t for _, _, t in stats[0].values()) / stats[1], 1),
                                   "launches_per_step": round(sum(c for c, _, _ in stats[0].values()) / stats[1], 1)}
         if wl["pool"] is not None and world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(go, wl)
+            res["cpu_baseline"] = cpu_baseline(go, wl, seconds=args.cpu_baseline_seconds)
+        if args.workload == "full" and world == 1 and not args.no_roofline and not args.no_stress:
+            # the device is idle from here on: this process has finished its own measurements
+            torch.cuda.synchronize()
+            st = stress_child()
+            if st is not None:
+                res["stress"] = st
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()

@@ -12,6 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
+ABI_VERSION = 300        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
 # name -> (restype, argtypes) ; mirrors include/igcn.h one to one
@@ -34,8 +36,8 @@ SIGNATURES = {
     "igcn_gcn_propagate_bwd": (I, [L, L, I, I, P, L, P, L, I, P, L, P, P, P, P, P, P, L, P, I, P, P, P, P]),
     "igcn_sgcn_stack_lds_bytes": (Z, [I, I, I, I, I, I]),
     "igcn_sgcn_stack_param_floats": (I, [I, I, I]),
-    "igcn_sgcn_stack_fwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
-    "igcn_sgcn_stack_bwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_sgcn_stack_fwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_sgcn_stack_bwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_small_linear_bwd_scratch_floats": (Z, [L, I, I]),
     "igcn_small_linear_fwd": (I, [L, I, I, P, P, P, P, P, P]),
     "igcn_small_linear_bwd": (I, [L, I, I, P, P, P, P, P, P, P, P]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "igcn_bn1d_fwd": (I, [I, I, I, P, P, P, P, P, I, F, F, I, P, P, P, P, P]),
     "igcn_bn1d_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_dropout_state_words": (I, []),
+    "igcn_dropout_max_segments": (I, []),
     "igcn_dropout_masks": (I, [L, I, P, P, P, P, P]),
     "igcn_mask_reg_blocks": (I, [L]),
     "igcn_mask_reg_fwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P]),
@@ -139,6 +142,10 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
+    got = int(lib.igcn_version())
+    if got != ABI_VERSION:           # a stale libigcn.so would take shifted arguments without a word
+        raise IgcnError(f"{LIB_PATH} has ABI revision {got}, this binding is written for {ABI_VERSION}: "
+                        "rebuild it with `python ig-gcn_amd/build.py --force`")
     _lib = lib
     return lib
 

@@ -721,7 +721,7 @@ extern "C" int igcn_graph_pool_bwd(int64_t n_graphs, int nodes_per_graph, int D,
 // `state` on the device holds the counter and arrival words — the LAST workgroup to finish advances the counter, so
 // every replay of a captured launch draws fresh masks without a host round trip.
 // =================================================================================================
-#define DM_MAXSEG 16
+#define DM_MAXSEG 32
 struct DropSegs {
   int64_t end[DM_MAXSEG];
   float p[DM_MAXSEG];
@@ -782,6 +782,7 @@ k_dropout_masks(int64_t total, DropSegs segs, unsigned long long* __restrict__ s
 }
 
 extern "C" int igcn_dropout_state_words(void) { return DM_WORDS; }
+extern "C" int igcn_dropout_max_segments(void) { return DM_MAXSEG; }
 
 extern "C" int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end /*HOST*/,
                                   const float* seg_p /*HOST*/, void* state /*device uint64[2]*/, float* out,

@@ -16,7 +16,7 @@ void igcn_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* igcn_last_error(void) { return g_err; }
-extern "C" int igcn_version(void) { return 100; }
+extern "C" int igcn_version(void) { return IGCN_ABI_VERSION; }
 
 __global__ void k_reduce_rows(const float* __restrict__ partial, int64_t rows, int64_t ld, int n,
                               float* __restrict__ out, int accumulate) {
@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t) {
 #include <vector>
 static std::mutex g_rq_mutex;
 static std::vector<ReduceEntry> g_rq;
+static std::vector<hipStream_t> g_rq_stream;          // the stream every entry's producer kernel was launched on
 static int g_rq_defer = 0;
 
 extern "C" int igcn_reduce_defer(int on) {
@@ -177,6 +178,18 @@ extern "C" int igcn_reduce_pending(void) {
 }
 
 static int reduce_flush_locked(hipStream_t st) {
+  // the queue is process-wide (one training thread per process: DESIGN §8).  A flush must only ever see entries whose
+  // partials were produced on ITS stream — anything else means two backward passes interleaved, and summing another
+  // stream's partials here would race with their producers: refuse loudly instead.
+  for (size_t i = 0; i < g_rq.size(); ++i)
+    if (g_rq_stream[i] != st) {
+      const size_t n = g_rq.size();
+      g_rq.clear();
+      g_rq_stream.clear();
+      igcn_set_error("reduce_flush: %zu queued reductions, entry %zu was queued on another stream — deferred "
+                     "reductions support one backward pass at a time per process", n, i);
+      return IGCN_ERR_BADARG;
+    }
   if (getenv("IGCN_DEBUG_REDUCE"))
     for (const ReduceEntry& e : g_rq)
       fprintf(stderr, "[igcn] deferred reduction: rows %lld x n %d (ld %lld)%s\n", (long long)e.rows, e.n,
@@ -200,6 +213,7 @@ static int reduce_flush_locked(hipStream_t st) {
     done += cnt;
   }
   g_rq.clear();
+  g_rq_stream.clear();
   IGCN_CHECK_LAUNCH("reduce_flush");
   return IGCN_OK;
 }
@@ -216,6 +230,7 @@ int igcn_launch_reduce_rows_final(const float* partial, int64_t rows, int64_t ld
     std::lock_guard<std::mutex> lk(g_rq_mutex);
     if (g_rq_defer) {
       g_rq.push_back(ReduceEntry{partial, out, rows, ld, n});
+      g_rq_stream.push_back(st);
       return IGCN_OK;
     }
   }

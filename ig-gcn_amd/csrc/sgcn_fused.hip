@@ -112,7 +112,8 @@ __device__ __forceinline__ int sf_stage(float* lds, const SfLayout& o, int R, in
                                         const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
                                         const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
                                         const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_perm,
-                                        const int32_t* __restrict__ loop_edge, const SfParams& prm, int F, int L) {
+                                        const int32_t* __restrict__ loop_edge, const SfParams& prm, int F, int L,
+                                        int32_t* __restrict__ status) {
   const int tid = threadIdx.x;
   const int32_t eb = tgt_ptr[nb];                      // workgroup-uniform: scalar loads, waited for where first used
   const int ne = tgt_ptr[nb + R] - eb;
@@ -163,7 +164,10 @@ __device__ __forceinline__ int sf_stage(float* lds, const SfLayout& o, int R, in
       if (BWD) sp[j] = src_ptr[nb + i];
     }
   }
-  if (ne > Emax) return -1;                            // host-checked; never corrupt LDS
+  if (ne > Emax) {                                     // host-checked; never corrupt LDS — and never go unnoticed:
+    if (tid == 0 && status) atomicOr(status, 2);       // bit 1 of the plan's status word (GraphPlan.check)
+    return -1;
+  }
   int32_t es = 0, ed = 0, et = 0, ep = 0;
   float ev = 0.f;
   if (tid < ne) {
@@ -349,13 +353,14 @@ __global__ void __launch_bounds__(SF_T)
 k_sgcn_stack_fwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in, const float* __restrict__ ew_in,
                  const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32,
                  const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
-                 const int32_t* __restrict__ loop_edge, SfParams prm, float* __restrict__ xcat) {
+                 const int32_t* __restrict__ loop_edge, SfParams prm, float* __restrict__ xcat,
+                 int32_t* __restrict__ status) {
   extern __shared__ float sf_lds[];
   const SfLayout o = sf_layout(R, Emax, H0, F, L, 0);
   const int64_t nb = (int64_t)blockIdx.x * R;
   SF_PROBE(0);
   if (sf_stage<false>(sf_lds, o, R, Emax, H0, nb, x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, nullptr, nullptr,
-                      loop_edge, prm, F, L) < 0)
+                      loop_edge, prm, F, L, status) < 0)
     return;
   float* H = sf_lds + o.act;
   float* Y = sf_lds + o.ycat;
@@ -388,7 +393,8 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
                  const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
                  const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_perm,
                  const int32_t* __restrict__ loop_edge, SfParams prm, const float* __restrict__ dxcat,
-                 float* __restrict__ dx_in, float* __restrict__ dew_in, float* __restrict__ dpar_partial, int P) {
+                 float* __restrict__ dx_in, float* __restrict__ dew_in, float* __restrict__ dpar_partial, int P,
+                 int32_t* __restrict__ status) {
   extern __shared__ float sf_lds[];
   const SfLayout o = sf_layout(R, Emax, H0, F, L, 1);
   const int tid = threadIdx.x;
@@ -403,8 +409,12 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
     dyv[j] = tid + j * SF_TB < R * D / 4 ? reinterpret_cast<const float4*>(dxcat + nb * D)[tid + j * SF_TB]
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
   const int ne = sf_stage<true>(sf_lds, o, R, Emax, H0, nb, x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, src_ptr,
-                                src_perm, loop_edge, prm, F, L);
-  if (ne < 0) return;
+                                src_perm, loop_edge, prm, F, L, status);
+  if (ne < 0) {                                        // refused graph: defined (zero) outputs, flagged in `status`
+    for (int e = tid; e < R * H0; e += SF_TB) dx_in[nb * H0 + e] = 0.f;
+    for (int e = tid; e < P; e += SF_TB) dpar_partial[(int64_t)blockIdx.x * P + e] = 0.f;
+    return;
+  }
   SF_PROBE(9);
   const int32_t* ssrc = reinterpret_cast<const int32_t*>(sf_lds + o.src);
   const int32_t* sdst = reinterpret_cast<const int32_t*>(sf_lds + o.dst);
@@ -671,7 +681,7 @@ extern "C" int igcn_sgcn_stack_fwd(int64_t n_graphs, int R, int max_edges, int H
                                    const float* ew_in, const int32_t* src32, const int32_t* dst32,
                                    const int32_t* tgt_ptr, const int32_t* tgt_perm, const int32_t* loop_edge,
                                    const float* const* W /*HOST [L]*/, const float* const* b /*HOST [L]*/, float* xcat,
-                                   void* stream) {
+                                   int32_t* status /*device word or NULL*/, void* stream) {
   int rc = sf_check("sgcn_stack_fwd", n_graphs, R, max_edges, H0, F, L, 0);
   if (rc) return rc;
   IGCN_REQUIRE(((uintptr_t)xcat & 15) == 0, "sgcn_stack_fwd: xcat must be 16-byte aligned");
@@ -683,7 +693,7 @@ extern "C" int igcn_sgcn_stack_fwd(int64_t n_graphs, int R, int max_edges, int H
   {                                                                                                               \
     if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS((k_sgcn_stack_fwd<FV>));                                              \
     hipLaunchKernelGGL((k_sgcn_stack_fwd<FV>), dim3((unsigned)n_graphs), dim3(SF_T), lds, st, R, max_edges, H0, L, \
-                       x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, loop_edge, prm, xcat);                        \
+                       x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, loop_edge, prm, xcat, status);                \
   }
   switch (F) {
     case 4: SF_FWD(4) break;
@@ -702,7 +712,7 @@ extern "C" int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H
                                    const int32_t* src_perm, const int32_t* loop_edge, const float* const* W,
                                    const float* const* b, const float* dxcat, float* dx_in, float* dew_in,
                                    float* dparams /*[param_floats]*/, float* scratch /*[n_graphs * param_floats]*/,
-                                   void* stream) {
+                                   int32_t* status /*device word or NULL*/, void* stream) {
   int rc = sf_check("sgcn_stack_bwd", n_graphs, R, max_edges, H0, F, L, 1);
   if (rc) return rc;
   IGCN_REQUIRE(((uintptr_t)dxcat & 15) == 0, "sgcn_stack_bwd: dxcat must be 16-byte aligned");
@@ -716,7 +726,7 @@ extern "C" int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H
     if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS((k_sgcn_stack_bwd<FV>));                                              \
     hipLaunchKernelGGL((k_sgcn_stack_bwd<FV>), dim3((unsigned)n_graphs), dim3(SF_TB), lds, st, R, max_edges, H0, L, \
                        x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, loop_edge, prm, dxcat,     \
-                       dx_in, dew_in, scratch, P);                                                                 \
+                       dx_in, dew_in, scratch, P, status);                                                         \
   }
   switch (F) {
     case 4: SF_BWD(4) break;

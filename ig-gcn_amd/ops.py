@@ -203,7 +203,12 @@ class GraphPlan:
 
     def check(self):
         """Host-synchronising validation of the segmented build (tests / debugging only)."""
-        if self.status is not None and int(self.status.item()) != 0:
+        code = int(self.status.item()) if self.status is not None else 0
+        if code & 2:
+            raise _lib.IgcnError("fused SGCN stack: a graph has more edges than the launch was sized for "
+                                 f"(max_edges = {self._stack_dims[1] if self._stack_dims else '?'}); its outputs "
+                                 "were not computed")
+        if code:
             raise _lib.IgcnError("graph plan: the batch is not block diagonal within the declared graph segments")
 
     def replicate(self, copies):
@@ -219,7 +224,7 @@ class GraphPlan:
                                ("tgt_perm", e * copies), ("src_ptr", n * copies + 1), ("src_perm", e * copies),
                                ("loop_edge", n * copies)):
                 setattr(rep, name, torch.empty(max(size, 1), **i32))
-            rep._copies, rep._seg, rep.status = {}, None, None
+            rep._copies, rep._seg, rep.status = {}, None, self.status     # one status word for the plan and its replicas
             rep.nodes_per_graph = self.nodes_per_graph
             rep._tiled, rep._stack_dims = False, self._stack_dims
             call("igcn_graph_plan_replicate", n, e, copies, ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr),
@@ -414,7 +419,7 @@ class SgcnStack(torch.autograd.Function):
         bp = (ctypes.c_void_p * layers)(*[b.data_ptr() for b in bs])
         call("igcn_sgcn_stack_fwd", n // rois, rois, emax, h0, f, layers, ptr(x_in), ptr(ew_in), ptr(plan.src32),
              ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.loop_edge), wp, bp, ptr(xcat),
-             stream_ptr())
+             ptr(plan.status), stream_ptr())
         ctx.save_for_backward(x_in, ew_in, *wb)
         ctx.plan, ctx.rois = plan, rois
         ctx.final = _leaves(*wb)
@@ -440,7 +445,8 @@ class SgcnStack(torch.autograd.Function):
         with _immediate(ctx.final):
             call("igcn_sgcn_stack_bwd", g, rois, emax, h0, f, layers, ptr(x_in), ptr(ew_in), ptr(plan.src32),
                  ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm),
-                 ptr(plan.loop_edge), wp, bp, ptr(dxcat), ptr(dx), ptr(dew), ptr(dpar), ptr(scratch), stream_ptr())
+                 ptr(plan.loop_edge), wp, bp, ptr(dxcat), ptr(dx), ptr(dew), ptr(dpar), ptr(scratch), ptr(plan.status),
+                 stream_ptr())
         grads, off = [], 0
         for l in range(layers):
             fin = h0 if l == 0 else f
@@ -979,6 +985,10 @@ class DropoutState:
 
     def __init__(self, device):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # data-parallel ranks usually share torch.manual_seed: mix the rank in, so that replicas draw different masks
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) \
+            else int(os.environ.get("RANK", "0"))
+        seed = (seed ^ (rank * 0x9E3779B97F4A7C15)) & (2 ** 62 - 1)
         words = int(_lib.load().igcn_dropout_state_words())
         self.state = torch.zeros(words, dtype=torch.int64, device=device)
         self.state[0] = seed
@@ -995,9 +1005,14 @@ def dropout_masks(sites, state):
         total += (n + 3) // 4 * 4
     ends = [(starts[k + 1] if k + 1 < len(sites) else total) for k in range(len(sites))]
     out = torch.empty(total, dtype=torch.float32, device=state.state.device)
-    seg_end = (ctypes.c_int64 * len(sites))(*ends)
-    seg_p = (ctypes.c_float * len(sites))(*[float(p) for _, p in sites])
-    call("igcn_dropout_masks", total, len(sites), seg_end, seg_p, ptr(state.state), ptr(out), stream_ptr())
+    per = int(_lib.load().igcn_dropout_max_segments())
+    for k0 in range(0, len(sites), per):                     # a deep GO hierarchy has more sites than one launch takes
+        k1 = min(k0 + per, len(sites))
+        base = starts[k0]
+        seg_end = (ctypes.c_int64 * (k1 - k0))(*[e - base for e in ends[k0:k1]])
+        seg_p = (ctypes.c_float * (k1 - k0))(*[float(p) for _, p in sites[k0:k1]])
+        call("igcn_dropout_masks", ends[k1 - 1] - base, k1 - k0, seg_end, seg_p, ptr(state.state), ptr(out[base:]),
+             stream_ptr())
     return [out[s0:s0 + n].view(*shape) for (shape, _), s0, n in zip(sites, starts, sizes)]
 
 

@@ -299,10 +299,15 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, world_size=1, warmup=3,
-                 distributed=None, comm=None, comm_in_graph=None):
+                 distributed=None, comm=None, comm_in_graph=False, max_edges=None):
         """``comm`` (``igcn_amd.comm.Comm``): the gradient all-reduce is igcn_comm_allreduce on the launch stream.
-        ``comm_in_graph``: capture it INTO the step graph (one graph: ... pack -> all-reduce -> Adam); None = try,
-        and fall back to [graph] -> all-reduce -> [Adam graph] if the runtime refuses the capture."""
+        ``comm_in_graph`` (opt-in): capture it INTO the step graph (one graph: ... pack -> all-reduce -> Adam).  True =
+        required (a refused capture raises); None = try — the choice is agreed across ranks (an all-reduce of a flag)
+        and the cause of a refusal is printed — and fall back to [graph] -> all-reduce -> [Adam graph]; False
+        (default) = the two-graph form: in-graph capture of a multi-rank collective is verified on single-rank
+        communicators only.
+        ``max_edges``: size the captured per-graph kernels for graphs of up to this many edges (default: the largest
+        graph of the construction batch); ``load`` refuses batches beyond it."""
         self.model, self.opt, self.data, self.world = model, optimizer, data, world_size
         # distributed=True with world_size 1 takes the multi-rank control flow (two graphs around a collective) on
         # a single-rank process group: the rehearsal of the N>1 path that a one-GPU box allows
@@ -312,6 +317,11 @@ class GraphedTrainStep:
         self.lam, self.hp = lambda_loss, hp
         from . import ops
         self.plan = ops.plan_for(data)                  # static plan tensors: rebuilt in place every step
+        if max_edges is not None and self.plan._stack_dims is not None:
+            if int(max_edges) < self.plan._stack_dims[1]:
+                raise ValueError("max_edges is smaller than the construction batch's largest graph")
+            self.plan._stack_dims = (self.plan._stack_dims[0], int(max_edges))
+            self.plan._copies = {}
         # every plan builder is hand-written and capturable; IGCN_PLAN_EAGER=1 keeps the build outside the graph
         # (launched eagerly before each replay) for A/B runs
         self.plan_in_graph = os.environ.get("IGCN_PLAN_EAGER", "0") != "1"
@@ -352,11 +362,22 @@ class GraphedTrainStep:
                     comm.all_reduce_(self.opt.grad)
                     self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
                 self.comm_in_graph = True
-            except Exception:                            # noqa: BLE001 — capture refused: two graphs instead
+            except Exception as exc:                     # noqa: BLE001 — capture refused: two graphs instead
                 if comm_in_graph:
                     raise
+                import sys
+                print(f"[igcn] all-reduce capture refused ({type(exc).__name__}: {exc}); using two graphs around it",
+                      file=sys.stderr)
                 torch.cuda.synchronize()
                 self.g_main = torch.cuda.CUDAGraph()
+            if comm_in_graph is None and world_size > 1 and torch.distributed.is_initialized():
+                # every rank must replay the same form: one rank inside a captured collective and another outside
+                # would hang.  A rank that captured but must step down re-captures below.
+                flag = torch.tensor([1 if self.comm_in_graph else 0], device=self.opt.flat.device, dtype=torch.int32)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                if self.comm_in_graph and int(flag.item()) == 0:
+                    self.comm_in_graph = False
+                    self.g_main = torch.cuda.CUDAGraph()
         if not self.comm_in_graph:
             with torch.cuda.graph(self.g_main, capture_error_mode=mode):
                 self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
@@ -413,6 +434,12 @@ class GraphedTrainStep:
             if mn is None or me is None or mn > n_lim or me > e_lim:
                 raise ValueError("graphed step (per-graph plan): the new batch exceeds the per-graph sizes the "
                                  f"captured build was sized for ({n_lim} nodes / {e_lim} edges)")
+            if self.plan._stack_dims is not None and me > self.plan._stack_dims[1]:
+                # the captured LDS-resident SGCN stack was launched (and its LDS sized) for the construction batch's
+                # largest graph; a graph beyond that would be skipped by its workgroup (and flagged in plan.status)
+                raise ValueError("graphed step: a graph of the new batch has more edges "
+                                 f"({me}) than the captured SGCN stack was sized for ({self.plan._stack_dims[1]}); "
+                                 "build the step on a batch that contains the largest graph, or pass max_edges")
             if self.plan.nodes_per_graph and int(mn) * (int(bp.numel()) - 1) != self.plan.n_nodes:
                 raise ValueError("graphed step: the captured kernels assume uniform graphs of "
                                  f"{self.plan.nodes_per_graph} nodes")

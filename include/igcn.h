@@ -28,6 +28,10 @@ extern "C" {
 #define IGCN_ERR_LAUNCH (-2)
 #define IGCN_ERR_UNSUPPORTED (-3)
 
+/* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
+ * returns the revision the library was built from; a binding written against a different one must refuse to call
+ * (igcn_amd/_lib.py does). */
+#define IGCN_ABI_VERSION 300
 int igcn_version(void);
 const char* igcn_last_error(void);
 
@@ -188,12 +192,12 @@ int igcn_sgcn_stack_param_floats(int H0, int F, int L);
 int igcn_sgcn_stack_fwd(int64_t n_graphs, int R, int max_edges, int H0, int F, int L, const float* x_in,
                         const float* ew_in, const int32_t* src32, const int32_t* dst32, const int32_t* tgt_ptr,
                         const int32_t* tgt_perm, const int32_t* loop_edge, const float* const* W,
-                        const float* const* b, float* xcat, void* stream);
+                        const float* const* b, float* xcat, int32_t* status, void* stream);
 int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H0, int F, int L, const float* x_in,
                         const float* ew_in, const int32_t* src32, const int32_t* dst32, const int32_t* tgt_ptr,
                         const int32_t* tgt_perm, const int32_t* src_ptr, const int32_t* src_perm,
                         const int32_t* loop_edge, const float* const* W, const float* const* b, const float* dxcat,
-                        float* dx_in, float* dew_in, float* dparams, float* scratch, void* stream);
+                        float* dx_in, float* dew_in, float* dparams, float* scratch, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense feature transform on the matrix cores (f32-input MFMA 16x16x4, exact fp32):
@@ -387,6 +391,7 @@ int igcn_bn1d_bwd(int B, int C, int groups, int training, int relu, const float*
  * Counter-based integer-hash generator; `state` = device uint64[igcn_dropout_state_words()], word 0 = the stream
  * counter (seed), every other word 0 (arrival counts, left at 0 by every launch): the last workgroup of a launch
  * advances the counter, so every replay of a captured launch draws fresh masks. */
+int igcn_dropout_max_segments(void);   /* sites one igcn_dropout_masks launch takes; callers split longer lists */
 int igcn_dropout_state_words(void);
 int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end, const float* seg_p, void* state,
                        float* out, void* stream);

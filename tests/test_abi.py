@@ -50,7 +50,8 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _prototypes():
         assert hasattr(lib, name), name
-    assert lib.igcn_version() >= 100
+    declared = int(re.search(r"#define\s+IGCN_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert lib.igcn_version() == declared == _lib.ABI_VERSION
     # host-only helpers may be called without a GPU
     assert lib.igcn_gcn_propagate_bwd_scratch_floats(23040, 16) >= 1440 * 16
     assert lib.igcn_go_attn_bwd_scratch_floats(256, 3000, 5, 5) > 4 * 256 * 3000

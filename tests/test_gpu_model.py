@@ -727,6 +727,31 @@ def test_graphed_step_load_takes_the_new_batch_s_graph_offsets():
     assert abs(l1 - l2) <= 1e-5 * max(1.0, abs(l2)), (l1, l2)
     with pytest.raises(ValueError):                                   # a batch without the offsets is refused
         step.load(SimpleNamespace(x=batch_b.x, edge_index=batch_b.edge_index))
+    # same total edge count, but a graph LARGER than any of the construction batch (35 > 30): the captured fused stack
+    # was sized for 30 edges per graph — refused by load(); a step built with max_edges=40 takes it and agrees with
+    # the eager step; and the kernel itself flags (never silently skips) a graph beyond its launch size
+    batch_c = Batch.from_data_list([graph(e) for e in (35, 5, 20, 20)]).to("cuda")
+    with pytest.raises(ValueError, match="more edges"):
+        step.load(batch_c)
+    m3, m4 = copy.deepcopy(m2), copy.deepcopy(m2)
+    o3, o4 = FlatAdam(m3.parameters(), lr=1e-3), FlatAdam(m4.parameters(), lr=1e-3)
+    batch_a2 = Batch.from_data_list([graph(e) for e in counts_a]).to("cuda")
+    batch_a2.x.requires_grad_(True)
+    step3 = GraphedTrainStep(m3, o3, batch_a2, lam, warmup=1, max_edges=40)
+    step3.load(batch_c)
+    l3 = float(step3())
+    step3.plan.check()
+    l4 = float(train_step(m4, o4, batch_c, lam))
+    assert abs(l3 - l4) <= 1e-5 * max(1.0, abs(l4)), (l3, l4)
+    from igcn_amd import _lib, ops
+    plan_c = ops.plan_for(batch_c)
+    assert plan_c._stack_dims == (rois, 35)
+    plan_c._stack_dims = (rois, 30)                                   # lie about the launch size
+    convs = [m4.conv1, *m4.convs]
+    wb = [t for c in convs for t in (c.lin.weight.detach(), c.bias.detach())]
+    ops.SgcnStack.apply(batch_c.x.detach(), batch_c.edge_attr, plan_c, rois, *wb)
+    with pytest.raises(_lib.IgcnError, match="more edges"):
+        plan_c.check()
 
 
 def test_loss_head_bad_labels_and_disabled_class_terms():

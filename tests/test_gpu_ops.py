@@ -1218,6 +1218,14 @@ def test_dropout_masks_one_launch(ops):
     assert int(state.state[1:].abs().sum().item()) == 0          # every arrival word is back at 0
     big = ops.dropout_masks([((2048, 3000), 0.4)], state)[0]     # more workgroups than the launch cap: grid-stride
     assert abs(float((big > 0).float().mean()) - 0.6) < 2e-3 and int(state.state[1:].abs().sum().item()) == 0
+    # more sites than one launch takes (a GO hierarchy with many levels): split over launches, same contract per site
+    many = [((33, 40 + k), 0.1 + 0.02 * k) for k in range(40)]
+    mm = ops.dropout_masks(many, state)
+    assert len(mm) == 40
+    for (shape, p), a in zip(many, mm):
+        assert tuple(a.shape) == tuple(shape)
+        assert all(abs(float(v)) < 1e-12 or abs(float(v) - 1.0 / (1.0 - p)) < 1e-5 for v in torch.unique(a)), p
+        assert abs(float((a > 0).float().mean()) - (1 - p)) < 0.12
 
 
 def test_consumers_apply_the_dropout_factors(ops):

@@ -65,7 +65,7 @@ xcat = torch.empty(n2, layers * f, device=dev)
 torch.cuda.synchronize()
 for _ in range(LAUNCHES):
     call("igcn_sgcn_stack_fwd", n2 // rois, rois, plan._stack_dims[1], h0, f, layers, ptr(x2), ptr(ew2), ptr(plan.src32),
-         ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.loop_edge), wp, bp, ptr(xcat), stream_ptr())
+         ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.loop_edge), wp, bp, ptr(xcat), None, stream_ptr())
 torch.cuda.synchronize()
 
 # stress shape: 64 dense 512-ROI graphs (both passes of a configs[4] step)
