@@ -427,6 +427,92 @@ def _physical_cores():
         return None
 
 
+def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
+    """Loader-fed throughput (the reference's step starts at ``for data in loader: data.to(device)``,
+    kernel/train_eval_sgcn_img_snps.py:515-517): NEW graphs every step, three ways, each ending in
+    GraphedTrainStep.load (device-to-device copies into the captured step's static inputs) + one replay.
+      host        dataset on the host: a producer thread collates (vectorised, bit-identical to Batch.from_data_list)
+                  into pinned memory and uploads on a copy stream (igcn_amd.loader.HostFeeder)
+      device      dataset resident in HBM: the collation is a few device gathers (DeviceFeeder)
+      device_gdc  dense connectivity matrices resident in HBM: GDC pre-transform (PPR inverse, top-k, normalise) +
+                  collation of the batch on the device every step (igcn_gdc_topk), then load + replay
+    The reference's own collation loop (igcn_amd.data.Batch.from_data_list restates it) is timed beside them."""
+    from igcn_amd.data import Data
+    from igcn_amd.gdc import batch_from_dense
+    from igcn_amd.loader import DeviceFeeder, HostFeeder, UniformGraphStore
+    b = wl["graphs"]
+    subjects = 4 * b
+    graphs = synth.brain_graph_list(subjects, seed=3000, rois=wl["rois"], tsne_dim=90, dense=wl["dense"])
+    adj_all = torch.stack([g.A for g in graphs])
+    keep = ("x", "edge_index", "edge_attr", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y")
+    slim = [Data(**{k: getattr(g, k) for k in keep}) for g in graphs]
+    out = {"subjects": subjects, "graphs_per_step": b, "steps": steps, "host_cores": os.cpu_count(),
+           "resident_ms_per_step": resident_ms}
+    t0 = time.perf_counter()
+    for i in range(3):
+        Batch.from_data_list(slim[i * b:(i + 1) * b])
+    out["reference_collate_ms_per_batch"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
+    cur = torch.cuda.current_stream()
+
+    def run(feed, consume):
+        it = iter(feed)
+        for _ in range(warmup):
+            consume(next(it))
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            consume(next(it))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / steps * 1e3
+        for _ in it:                                     # drain (the producer thread ends)
+            pass
+        return {"ms_per_step": round(ms, 3), "graphs_per_s": round(b / ms * 1e3, 1),
+                "vs_resident": round(resident_ms / ms, 3)}
+
+    # host-fed
+    host_store = UniformGraphStore(slim, "cpu", pin=True)
+    t0 = time.perf_counter()
+    slot = host_store.batch(torch.arange(b))
+    for _ in range(5):
+        host_store.batch(torch.randint(0, subjects, (b,)), out=slot)
+    out["vectorised_collate_ms_per_batch"] = round((time.perf_counter() - t0) / 6 * 1e3, 3)
+
+    def consume_host(batch):
+        cur.wait_event(batch.ready)
+        gstep.load(batch)
+        batch.release()
+        gstep()
+    out["host"] = run(HostFeeder(host_store, b, device, steps + warmup + 1), consume_host)
+    # device-resident dataset
+    dev_store = UniformGraphStore(slim, device)
+
+    def consume_dev(batch):
+        gstep.load(batch)
+        gstep()
+    out["device"] = run(DeviceFeeder(dev_store, b, steps + warmup + 1), consume_dev)
+    # dense connectivity on the device -> GDC + collation every step
+    if not wl["dense"]:
+        adj_dev = adj_all.to(device)
+        gen = torch.Generator(device=device).manual_seed(1)
+        cols = {k: dev_store.cols[k] for k in ("x", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y")}
+
+        def gdc_feed():
+            for _ in range(steps + warmup + 1):
+                idx = torch.randint(0, subjects, (b,), generator=gen, device=device)
+                sel = {k: torch.index_select(v, 0, idx) for k, v in cols.items()}
+                yield batch_from_dense(torch.index_select(adj_dev, 0, idx), sel.pop("x"), top_k=3, alpha=0.05,
+                                       check=False, snps_feat=sel["snps_feat"].reshape(b, -1), y=sel["y"].reshape(-1),
+                                       clini_score=sel["clini_score"], tsne_fdim=sel["tsne_fdim"].reshape(b, -1),
+                                       clust_y=sel["clust_y"].reshape(-1))
+        first = batch_from_dense(adj_dev[:b], cols["x"][:b], top_k=3, alpha=0.05, check=True)
+        if first.edge_index.shape == gstep.data.edge_index.shape:
+            out["device_gdc"] = run(gdc_feed(), consume_dev)
+            gstep.plan.check()
+        else:
+            out["device_gdc"] = {"skipped": "the GDC of these matrices does not keep top_k entries in every column"}
+    return out
+
+
 def stress_child(timeout=300):
     """BASELINE configs[4] beside the headline: a short ``--workload stress`` run of this script in a CHILD process
     (its own model, graph capture, in-step rocprofv3 profile and bounded CPU-oracle sample) whose result line is folded
@@ -504,6 +590,8 @@ def main():
                     help="dense feature transforms with bf16 operands (auto: the workload's own setting)")
     ap.add_argument("--rotate", type=int, default=0,
                     help="time GraphedTrainStep.load + replay over this many distinct device-resident batches")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="also time the loader-fed step: host DataLoader thread / device-resident dataset / device GDC")
     ap.add_argument("--no-stress", action="store_true",
                     help="default workload only: skip the short configs[4] child run reported as `stress`")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="bound of the CPU-oracle sample")
@@ -687,6 +775,8 @@ def main():
             torch.cuda.synchronize()
             res["rotating_batches"] = {"batches": args.rotate,
                                        "ms_per_step_load_plus_replay": round((time.perf_counter() - t1) / args.steps * 1e3, 3)}
+        if args.pipeline and gstep is not None and world == 1:
+            res["pipeline"] = pipeline_bench(gstep, wl, device, args.steps, args.warmup, res["ms_per_step"])
         if wl["pool"] is not None and world == 1 and not args.no_roofline:
             stats = instep_profile(args.workload, bf16)
             standalone = scatter_roofline(data, device, wl, stats)

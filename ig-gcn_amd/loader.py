@@ -1,0 +1,237 @@
+"""Feeding the train step: the reference's loop starts at ``for data in loader: data = data.to(device)``
+(kernel/train_eval_sgcn_img_snps.py:515-517) over ``Batch.from_data_list`` (batch.py:24-123) — a Python loop per graph
+per key, 13 ms per 256 graphs on an 8-core host, i.e. 13x the 1 ms step it feeds.
+
+Brain-graph datasets are UNIFORM (every subject: R ROIs, the same attribute set, and after the GDC pre-transform R*k
+edges), so the collation is a gather plus one offset add:
+
+* ``UniformGraphStore``  the whole dataset as stacked tensors (host — pinned — or device).  ``batch(idx)`` yields the same
+  bytes as ``Batch.from_data_list([dataset[i] for i in idx])`` (bit for bit: tests/test_loader.py) with a handful of
+  ``index_select`` calls and ``edge_index += arange(B) * R``.
+* ``collate_uniform``    the same for an ad-hoc list of ``Data`` (drop-in collate function; falls back to
+  ``Batch.from_data_list`` when the list is not uniform).
+* ``HostFeeder``         a producer thread: store on the host -> pinned staging -> non-blocking H2D on a copy stream
+  into a ring of device staging batches; the consumer waits on the batch's event, copies it into the graphed step's
+  static inputs (``GraphedTrainStep.load``) and replays.
+* ``DeviceFeeder``       store on the device: collation is a few device gathers on the launch stream.
+"""
+import queue
+import threading
+
+import torch
+
+from .data import Batch, Data
+
+# keys whose per-graph value is a 1-D vector that the reference's collation concatenates (batch.py:110): [n] -> [n*B]
+_INDEX_KEY = ("index", "face")
+
+
+def _is_index_key(key):
+    return any(t in key for t in _INDEX_KEY)
+
+
+def _uniform(data_list):
+    d0 = data_list[0]
+    keys = sorted(d0.keys)
+    n, e = d0.num_nodes, d0.num_edges
+    for d in data_list[1:]:
+        if sorted(d.keys) != keys or d.num_nodes != n or d.num_edges != e:
+            return None
+        for k in keys:
+            a, b = d0[k], d[k]
+            if torch.is_tensor(a) != torch.is_tensor(b) or (torch.is_tensor(a) and (a.shape != b.shape or
+                                                                                    a.dtype != b.dtype)):
+                return None
+    return keys, n, e
+
+
+def collate_uniform(data_list):
+    """``Batch.from_data_list`` for a list of graphs with identical shapes: one ``torch.stack`` per key and one offset
+    add for the ``*index*`` keys instead of a Python loop per graph per key.  Identical output (bit for bit)."""
+    info = _uniform(data_list) if len(data_list) else None
+    if info is None or any(not torch.is_tensor(data_list[0][k]) for k in info[0]):
+        return Batch.from_data_list(data_list)
+    keys, n, e = info
+    b = len(data_list)
+    out = Batch()
+    for k in keys:
+        st = torch.stack([d[k] for d in data_list])                       # [B, ...]
+        first = data_list[0][k]
+        if _is_index_key(k):                                              # cat along the LAST dim, offset by nodes
+            if st.dtype != torch.bool:
+                st = st + (torch.arange(b, dtype=st.dtype) * n).view(b, *([1] * (st.dim() - 1)))
+            st = st.movedim(0, -2).reshape(*first.shape[:-1], b * first.shape[-1])
+        else:                                                             # cat along dim 0
+            st = st.reshape(b * first.shape[0], *first.shape[1:]) if first.dim() else st
+        out[k] = st.contiguous()
+    out.batch = torch.arange(b, dtype=torch.long).repeat_interleave(n)
+    _finish(out, b, n, e, "cpu")
+    return out
+
+
+def _finish(out, b, n, e, device):
+    out._num_graphs = b
+    out.ptr = torch.arange(b + 1, dtype=torch.long, device=device) * n
+    out.edge_ptr = torch.arange(b + 1, dtype=torch.long, device=device) * e
+    out._max_nodes, out._max_edges = n, e
+
+
+class UniformGraphStore:
+    """A dataset of uniform graphs as stacked tensors: ``cols[key]`` = [S, ...per-graph shape...]."""
+
+    def __init__(self, data_list, device="cpu", pin=False):
+        info = _uniform(data_list)
+        if info is None:
+            raise ValueError("UniformGraphStore needs graphs of identical shapes and keys")
+        self.keys, self.nodes, self.edges = info
+        self.size = len(data_list)
+        self.device = torch.device(device)
+        self.cols, self.shapes = {}, {}
+        for k in self.keys:
+            first = data_list[0][k]
+            if not torch.is_tensor(first):
+                raise ValueError(f"non-tensor attribute {k!r}")
+            st = torch.stack([d[k] for d in data_list]).contiguous()
+            self.shapes[k] = tuple(first.shape)
+            st = st.to(self.device)
+            if pin and self.device.type == "cpu":
+                st = st.pin_memory()
+            self.cols[k] = st
+
+    def batch(self, idx, out=None):
+        """Collate the graphs ``idx`` (int64 tensor on the store's device).  ``out``: a Batch made by an earlier call
+        (same batch size) whose tensors are overwritten in place — stable addresses for pinned staging."""
+        b = int(idx.numel())
+        dev = self.device
+        n, e = self.nodes, self.edges
+        res = out if out is not None else Batch()
+        for k in self.keys:
+            shp = self.shapes[k]
+            if out is not None and not _is_index_key(k):                  # gather straight into the destination
+                torch.index_select(self.cols[k], 0, idx, out=getattr(res, k).view(b, *shp))
+                continue
+            sel = torch.index_select(self.cols[k], 0, idx)                # [B, *shp]
+            if _is_index_key(k):
+                if sel.dtype != torch.bool:
+                    sel += (torch.arange(b, dtype=sel.dtype, device=dev) * n).view(b, *([1] * len(shp)))
+                val = sel.movedim(0, -2).reshape(*shp[:-1], b * shp[-1])
+            else:
+                val = sel.reshape(b * shp[0], *shp[1:]) if len(shp) else sel
+            if out is not None:
+                getattr(res, k).copy_(val)
+            else:
+                res[k] = val.contiguous()
+        if out is None:
+            res.batch = torch.arange(b, dtype=torch.long, device=dev).repeat_interleave(n)
+            _finish(res, b, n, e, dev)
+        return res
+
+
+def _like(batch, device, pin=False):
+    """An empty Batch with the tensors of ``batch`` re-allocated on ``device`` (staging slot)."""
+    out = Batch()
+    for k, v in batch.__dict__.items():
+        if torch.is_tensor(v):
+            t = torch.empty(v.shape, dtype=v.dtype, device=device)
+            if pin and torch.device(device).type == "cpu":
+                t = t.pin_memory()
+            setattr(out, k, t)
+        else:
+            setattr(out, k, v)
+    return out
+
+
+def _copy_into(dst, src, non_blocking=True):
+    for k, v in src.__dict__.items():
+        if torch.is_tensor(v):
+            getattr(dst, k).copy_(v, non_blocking=non_blocking)
+
+
+class HostFeeder:
+    """Iterator over device-resident batches produced by a host thread: collate (vectorised) into pinned memory,
+    upload on a copy stream, hand over with an event.  ``depth`` staging slots in flight.
+
+        for batch in feeder:                       # batch.ready: the upload's event
+            torch.cuda.current_stream().wait_event(batch.ready)
+            step.load(batch); batch.release(); step()
+    """
+
+    def __init__(self, store, batch_size, device, steps, depth=3, seed=0, shuffle=True):
+        if store.device.type != "cpu":
+            raise ValueError("HostFeeder reads a host-resident store")
+        self.store, self.bsz, self.device, self.steps = store, int(batch_size), torch.device(device), int(steps)
+        self.gen = torch.Generator().manual_seed(seed)
+        self.shuffle = shuffle
+        proto = store.batch(torch.arange(self.bsz))
+        self.host = [_like(proto, "cpu", pin=True) for _ in range(depth)]
+        self.dev = [_like(proto, self.device) for _ in range(depth)]
+        self.uploaded = [torch.cuda.Event() for _ in range(depth)]
+        self.consumed = [None] * depth
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.q = queue.Queue(maxsize=depth - 1)
+        self.thread = threading.Thread(target=self._produce, daemon=True)
+        self.error = None
+
+    def _indices(self):
+        if self.shuffle:
+            return torch.randint(0, self.store.size, (self.bsz,), generator=self.gen)
+        return torch.arange(self.bsz)
+
+    def _produce(self):
+        try:
+            torch.cuda.set_device(self.device)
+            for i in range(self.steps):
+                k = i % len(self.host)
+                if self.consumed[k] is not None:
+                    self.consumed[k].synchronize()              # the consumer has copied slot k out (device side)
+                self.uploaded[k].synchronize() if i >= len(self.host) else None     # pinned buffer k is free again
+                self.store.batch(self._indices(), out=self.host[k])
+                with torch.cuda.stream(self.copy_stream):
+                    _copy_into(self.dev[k], self.host[k], non_blocking=True)
+                    self.uploaded[k].record(self.copy_stream)
+                self.q.put(k)
+        except Exception as exc:                                # noqa: BLE001 — surface it in the consumer
+            self.error = exc
+            self.q.put(None)
+
+    def __iter__(self):
+        self.thread.start()
+        for _ in range(self.steps):
+            k = self.q.get()
+            if k is None:
+                raise self.error
+            b = self.dev[k]
+            b.ready = self.uploaded[k]
+            b.release = lambda k=k: self._release(k)
+            yield b
+        self.thread.join()
+
+    def _release(self, k):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.consumed[k] = ev
+
+
+class DeviceFeeder:
+    """Store resident in HBM: every batch is a few device gathers on the launch stream (no host data path)."""
+
+    def __init__(self, store, batch_size, steps, seed=0, shuffle=True):
+        if store.device.type != "cuda":
+            raise ValueError("DeviceFeeder reads a device-resident store")
+        self.store, self.bsz, self.steps = store, int(batch_size), int(steps)
+        self.gen = torch.Generator(device=store.device).manual_seed(seed)
+        self.shuffle = shuffle
+        self.slot = store.batch(torch.arange(self.bsz, device=store.device))
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            idx = torch.randint(0, self.store.size, (self.bsz,), generator=self.gen, device=self.store.device) \
+                if self.shuffle else torch.arange(self.bsz, device=self.store.device)
+            yield self.store.batch(idx, out=self.slot)
+
+
+def as_data_list(batch_size, **kw):
+    """Convenience for tests: ``synth.brain_graph_list`` without the dense [R,R] adjacency (not on the hot path)."""
+    from . import synth
+    graphs = synth.brain_graph_list(batch_size, **kw)
+    return [Data(**{k: v for k, v in g.__dict__.items() if k != "A"}) for g in graphs]
