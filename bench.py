@@ -402,7 +402,8 @@ def cpu_baseline(go, wl, seconds=20.0):
     cfg = SimpleNamespace(num_layers=LAYERS, rois=rois, image_only=False, rbf_gamma=0.01)
     b = 32 if not wl["dense"] else 4
     data = Batch.from_data_list(synth.brain_graph_list(b, seed=1000, rois=rois, tsne_dim=90, dense=wl["dense"]))
-    torch.set_num_threads(os.cpu_count() or 1)               # every host core, stated
+    usable = _usable_cores()
+    torch.set_num_threads(usable)                            # every host core this process may use, stated
     opt = None
     times = []
     t_end = time.perf_counter() + seconds
@@ -415,8 +416,36 @@ def cpu_baseline(go, wl, seconds=20.0):
     times = sorted(times[1:]) if len(times) > 1 else times
     med = times[len(times) // 2]
     return {"value": round(b / med, 2), "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "physical_cores": _physical_cores(), "torch": torch.__version__,
+            "host_logical_cpus": os.cpu_count(), "physical_cores": _physical_cores(), "usable_cores": usable,
+            "torch": torch.__version__,
             "sample": f"{len(times)} train steps of B={b} graphs (same model/GO DAG, fp32), median; oracle faithful mode"}
+
+
+def _usable_cores():
+    """Host cores this process may actually run on: the smaller of the affinity mask and the cgroup CPU quota (a GPU
+    box shows every CPU of the host but grants a share of them: 256 OpenMP threads on a 16-core share thrash)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    per = int(fh.read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def _physical_cores():
@@ -446,7 +475,8 @@ def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
     adj_all = torch.stack([g.A for g in graphs])
     keep = ("x", "edge_index", "edge_attr", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y")
     slim = [Data(**{k: getattr(g, k) for k in keep}) for g in graphs]
-    out = {"subjects": subjects, "graphs_per_step": b, "steps": steps, "host_cores": os.cpu_count(),
+    out = {"subjects": subjects, "graphs_per_step": b, "steps": steps, "host_logical_cpus": os.cpu_count(),
+           "usable_cores": _usable_cores(), "feeder_threads": 1,
            "resident_ms_per_step": resident_ms}
     t0 = time.perf_counter()
     for i in range(3):

@@ -738,7 +738,10 @@ k_plan_segmented(int64_t n_nodes, int64_t n_edges, int n_graphs, const int64_t* 
   const int g = blockIdx.x, tid = threadIdx.x;
   const int64_t nb = node_ptr[g], eb = edge_ptr[g];
   const int nn = (int)(node_ptr[g + 1] - nb), ne = (int)(edge_ptr[g + 1] - eb);
-  if (nn > SEG_MAXN || ne > SEG_MAXE || nn < 0 || ne < 0) {       // host checked the maxima; refuse, don't corrupt
+  // host checked the maxima; the offsets themselves come from device memory (a loader may have handed over garbage):
+  // refuse anything that does not lie inside the batch, don't read or write out of bounds
+  if (nn > SEG_MAXN || ne > SEG_MAXE || nn < 0 || ne < 0 || nb < 0 || eb < 0 || nb + nn > n_nodes ||
+      eb + ne > n_edges) {
     if (tid == 0) atomicExch(status, 1);
     return;
   }

@@ -128,13 +128,16 @@ class UniformGraphStore:
 
 
 def _like(batch, device, pin=False):
-    """An empty Batch with the tensors of ``batch`` re-allocated on ``device`` (staging slot)."""
+    """A copy of ``batch`` with every tensor re-allocated on ``device`` (a staging slot).  The contents are COPIED, not
+    left empty: ``UniformGraphStore.batch(out=slot)`` rewrites the per-graph keys only, and the constant tensors of a
+    uniform batch (``ptr``, ``edge_ptr``, ``batch``) must be valid in every slot — the plan build reads them."""
     out = Batch()
     for k, v in batch.__dict__.items():
         if torch.is_tensor(v):
             t = torch.empty(v.shape, dtype=v.dtype, device=device)
             if pin and torch.device(device).type == "cpu":
                 t = t.pin_memory()
+            t.copy_(v)
             setattr(out, k, t)
         else:
             setattr(out, k, v)
@@ -166,9 +169,11 @@ class HostFeeder:
         self.host = [_like(proto, "cpu", pin=True) for _ in range(depth)]
         self.dev = [_like(proto, self.device) for _ in range(depth)]
         self.uploaded = [torch.cuda.Event() for _ in range(depth)]
-        self.consumed = [None] * depth
         self.copy_stream = torch.cuda.Stream(device=self.device)
-        self.q = queue.Queue(maxsize=depth - 1)
+        self.q = queue.Queue()                                   # filled slots, in order
+        self.free = queue.Queue()                                # (slot, event after the consumer's copy-out | None)
+        for k in range(depth):
+            self.free.put((k, None))
         self.thread = threading.Thread(target=self._produce, daemon=True)
         self.error = None
 
@@ -180,11 +185,14 @@ class HostFeeder:
     def _produce(self):
         try:
             torch.cuda.set_device(self.device)
-            for i in range(self.steps):
-                k = i % len(self.host)
-                if self.consumed[k] is not None:
-                    self.consumed[k].synchronize()              # the consumer has copied slot k out (device side)
-                self.uploaded[k].synchronize() if i >= len(self.host) else None     # pinned buffer k is free again
+            # gathers of a few hundred KB: one thread.  (A fresh thread would otherwise spin up its own OpenMP team of
+            # os.cpu_count() workers beside the main thread's — on a box whose CPU share is smaller than its CPU count
+            # the two teams' spinning workers cost 10 ms per batch.)
+            torch.set_num_threads(1)
+            for _ in range(self.steps):
+                k, done = self.free.get()                       # a slot the consumer has released ...
+                if done is not None:
+                    done.synchronize()                          # ... and whose copy-out has finished on the device
                 self.store.batch(self._indices(), out=self.host[k])
                 with torch.cuda.stream(self.copy_stream):
                     _copy_into(self.dev[k], self.host[k], non_blocking=True)
@@ -208,8 +216,8 @@ class HostFeeder:
 
     def _release(self, k):
         ev = torch.cuda.Event()
-        ev.record()
-        self.consumed[k] = ev
+        ev.record()                                             # behind the consumer's copies out of slot k
+        self.free.put((k, ev))
 
 
 class DeviceFeeder:

@@ -19,8 +19,10 @@ import igcn_amd  # noqa: E402,F401
 from igcn_amd import synth  # noqa: E402
 from igcn_amd.data import Batch  # noqa: E402
 
-POOL = (12, 6, 4, 2, 1)
-ROIS, HIDDEN, LAYERS, N_GRAPHS, SEED = 10, 4, 2, 32, 3
+# real brain-graph dims (R = 90, hidden 16: the LDS-resident fused SGCN stack at F = 16, the MFMA attention core) and a
+# 320-node GO DAG (LDS-resident GO attention backward and decoder) — the kernels of the default step, on two ranks
+POOL = (200, 80, 30, 9, 1)
+ROIS, HIDDEN, LAYERS, N_GRAPHS, SEED = 90, 16, 2, 32, 3
 LAM = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
 
 

@@ -246,14 +246,73 @@ def test_full_model_vs_oracle_larger(bsz, pool, explain):
     sum((o * c.double()).sum() for o, c in zip(ref, cot)).backward()
     for n, o, r in zip(NAMES, outs, ref):
         assert_matches(o, r.detach().numpy(), 1e-4, n)
-    # gradients: a ReLU whose pre-activation is ~1e-7 may switch between the fp32 kernels and the fp64
-    # oracle, which moves a parameter gradient by one summand => slightly looser bound than the outputs
-    assert_matches(data.x.grad, dcpu.x.grad.numpy(), 3e-3, "grad data.x")
+    # gradients at the stated 1e-3.  (Round 2 allowed 3e-3 / 5e-3 here "for ReLU flips"; measured with
+    # tools/relu_margin.py at these very shapes: 9 of ~0.5 M pre-activations lie within 1e-6 of zero, and the worst
+    # parameter gradient is 2e-5 away from the fp64 oracle — the slack was never used.)
+    assert_matches(data.x.grad, dcpu.x.grad.numpy(), 1e-3, "grad data.x")
     params = dict(model.named_parameters())
     for k in OS.trainable_keys(sdo):
         if sdo[k].grad is None:
             continue
-        assert_matches(params[k].grad, sdo[k].grad.numpy(), 5e-3, "grad " + k, floor=1e-6)
+        assert_matches(params[k].grad, sdo[k].grad.numpy(), 1e-3, "grad " + k, floor=1e-6)
+
+
+@pytest.mark.parametrize("maps", ["sparse", "default"])
+def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch, maps):
+    """TRAINING mode (batch statistics in every BatchNorm, dropout off) at the benchmark's own dimensions — R = 90,
+    L = 2, h = 16, the 3000-node GO DAG (LDS-resident GO attention backward, LDS decoder), B = 32 — with the CSR
+    SNP <-> GO maps the 256-graph step uses (``sparse``; the default at B = 32 is the dense-image form): the seven loss
+    terms of train() at 1e-4 and every gradient at 1e-3 against the fp64 oracle, both step formulations."""
+    from igcn_amd import synth
+    from igcn_amd.data import Batch
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    from igcn_amd.train import losses
+    from oracle import go_network as OG, sgcn_img_snp as OS
+    if maps == "sparse":
+        monkeypatch.setenv("IGCN_SPARSE_MAPS", "1")
+    pool, bsz = (1800, 800, 300, 99, 1), 32
+    lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=1)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+    model = SGCN_GCN_IMGSNP(2, 16, a_g, a, pool_dim, 32, "cuda", rois=90, H_0=3, num_classes=3,
+                            isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
+                            isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False).cuda().train()
+    sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, 5)
+    model.load_state_dict(sd)
+    for m in (model, model.go_network):
+        m._dropout_enabled = False
+    graphs = synth.brain_graph_list(bsz, seed=78, rois=90, tsne_dim=16)
+    # oracle, fp64, training mode
+    a_g_c, a_c = synth.go_sparse_inputs(go_snps, adj)
+    idx = OG.go_index_sets(a_g_c, a_c, list(pool), 2)
+    sdo = OS.make_leaf_state(sd, dtype=torch.float64)
+    dcpu = Batch.from_data_list(graphs)
+    dcpu.x = dcpu.x.double().requires_grad_(True)
+    dcpu.edge_attr, dcpu.snps_feat = dcpu.edge_attr.double(), dcpu.snps_feat.double()
+    dcpu.tsne_fdim, dcpu.clini_score = dcpu.tsne_fdim.double(), dcpu.clini_score.double()
+    cfg = SimpleNamespace(num_layers=2, rois=90, image_only=False, rbf_gamma=0.01)
+    ref_loss, ref_terms, _ = OS.train_losses(sdo, cfg, idx, dcpu, lam, dropout=False)
+    ref_loss.backward()
+    for batched in (True, False):
+        model.load_state_dict(sd)                                     # running statistics back to the start
+        model.zero_grad()
+        model.batched_passes = batched
+        data = Batch.from_data_list(graphs).to("cuda")
+        loss, terms, _ = losses(model, data, lam)
+        assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss))), (batched, float(loss))
+        for k, v in terms.items():
+            r = float(ref_terms[k])
+            assert abs(float(v) - r) <= 1e-4 * max(1.0, abs(r)), (batched, k, float(v), r)
+        loss.backward()
+        assert_matches(data.x.grad, dcpu.x.grad.numpy(), 1e-3, "grad data.x")
+        params = dict(model.named_parameters())
+        for k in OS.trainable_keys(sdo):
+            if sdo[k].grad is None:
+                continue
+            g = sdo[k].grad
+            sib = sdo[k[:-5] + ".weight"].grad if (k.endswith(".bias") and k[:-5] + ".weight" in sdo) else None
+            floor = max(1e-6, 0.5 * float(sib.abs().max())) if sib is not None else 1e-6
+            assert_matches(params[k].grad, g.numpy(), 1e-3, f"grad {k} (batched={batched})", floor=floor)
 
 
 # ---- the image-only sibling SGCN_GCN (kernel/sgcn.py:272-388; BASELINE configs[0]/[1]) -------------------------
@@ -700,7 +759,7 @@ def test_graphed_step_load_takes_the_new_batch_s_graph_offsets():
                          isSNPsOnly=False).cuda().train()
     for m in (m1, m1.go_network):
         m._dropout_enabled = False
-    m2 = copy.deepcopy(m1)
+    m2, m3, m4 = copy.deepcopy(m1), copy.deepcopy(m1), copy.deepcopy(m1)
     rng = np.random.default_rng(9)
 
     def graph(e):
@@ -733,7 +792,6 @@ def test_graphed_step_load_takes_the_new_batch_s_graph_offsets():
     batch_c = Batch.from_data_list([graph(e) for e in (35, 5, 20, 20)]).to("cuda")
     with pytest.raises(ValueError, match="more edges"):
         step.load(batch_c)
-    m3, m4 = copy.deepcopy(m2), copy.deepcopy(m2)
     o3, o4 = FlatAdam(m3.parameters(), lr=1e-3), FlatAdam(m4.parameters(), lr=1e-3)
     batch_a2 = Batch.from_data_list([graph(e) for e in counts_a]).to("cuda")
     batch_a2.x.requires_grad_(True)

@@ -670,6 +670,26 @@ def test_segmented_plan_ragged_graphs_and_loops(ops):
         assert torch.equal(getattr(seg, name), getattr(ref, name)), name
 
 
+def test_segmented_plan_refuses_offsets_outside_the_batch(ops):
+    """The per-graph build reads ptr / edge_ptr from DEVICE memory (GraphedTrainStep.load copies a loader's tensors
+    there): offsets that leave the batch set the status word; nothing is read or written out of bounds."""
+    from igcn_amd import _lib, synth
+    batch = synth.brain_batch(6, seed=3, rois=30).to("cuda")
+    plan = ops.plan_for(batch)
+    plan.check()
+    good = plan._seg[1].clone()
+    bad = good.clone()
+    bad[2] = 1 << 40                                                  # graph 1 "ends" (and graph 2 starts) far away
+    plan._seg[1].copy_(bad)
+    plan.rebuild(batch.edge_index)
+    with pytest.raises(_lib.IgcnError):
+        plan.check()
+    plan.status.zero_()
+    plan._seg[1].copy_(good)
+    plan.rebuild(batch.edge_index)
+    plan.check()
+
+
 @pytest.mark.parametrize("sizes,edges", [((512, 512, 512), (262144, 262144, 262144)),     # dense stress-shape graphs
                                          ((300, 1024, 5, 77), (9000, 40000, 0, 4097)),     # ragged, an empty graph
                                          ((90, 90), (270, 4097))])
