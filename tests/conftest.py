@@ -79,3 +79,86 @@ def golden():
             cache[name] = load_golden(name)
         return cache[name]
     return get
+
+
+class relu_margins:
+    """Context manager for ORACLE runs: records, per ``torch.relu`` call (``sites[n]`` in call order), a boolean tensor
+    marking the pre-activations within ``band`` of zero relative to the tensor's largest magnitude — the ReLU decisions
+    an fp32 evaluation may take the other way.  Nothing is modified.  A gradient that is a SHORT sum over the batch (the
+    bias of a BatchNorm over GO nodes: 32 terms) moves by a whole summand when one of them flips; tests mask exactly those
+    elements (``near_nodes``) and hold everything else to the stated tolerance."""
+
+    def __init__(self, band=3e-6):
+        self.band, self.sites = band, []
+
+    def __enter__(self):
+        self._orig = torch.relu
+
+        def recorded(t):
+            mag = t.detach().abs()
+            self.sites.append(mag <= self.band * mag.max())
+            return self._orig(t)
+        torch.relu = recorded
+        torch.nn.functional.relu = recorded
+        return self
+
+    def __exit__(self, *exc):
+        torch.relu = self._orig
+        torch.nn.functional.relu = self._orig
+        return False
+
+    def count(self):
+        return sum(int(m.sum()) for m in self.sites), sum(m.numel() for m in self.sites)
+
+    def near_nodes(self, site_ids, dim):
+        """Boolean vector over axis ``dim`` of the sites ``site_ids``: True where ANY near-zero pre-activation sits."""
+        out = None
+        for sid in site_ids:
+            m = self.sites[sid]
+            other = [d for d in range(m.dim()) if d != dim]
+            v = m.any(dim=other) if other else m
+            out = v if out is None else (out | v)
+        return out
+
+
+class relu_forced:
+    """Context manager for ORACLE runs: impose the ReLU decisions another evaluation took.  ``forced[site]`` (site =
+    index of the ``torch.relu`` call, in call order) is a bool tensor of the pre-activation's shape — True = that
+    evaluation let the value through — or None (site not observed: the oracle's own decisions stand).  Inside ``band``
+    (relative to the tensor's largest magnitude) the forced decision replaces the oracle's: value passed through or
+    zeroed, derivative 1 or 0.  OUTSIDE the band the two evaluations must agree — ``mismatch_outside`` counts the
+    entries where they do not (a real discrepancy, not rounding).  ``flips`` counts the overridden decisions."""
+
+    def __init__(self, forced, band=2e-5, ignore=None):
+        self.forced, self.band, self.ignore = forced, band, ignore or {}
+        self.flips, self.mismatch_outside, self._site = 0, 0, 0
+
+    def __enter__(self):
+        self._orig = torch.relu
+
+        def decided(t):
+            site, self._site = self._site, self._site + 1
+            want = self.forced.get(site)
+            if want is None:
+                return self._orig(t)
+            want = want.to(torch.bool)
+            assert tuple(want.shape) == tuple(t.shape), (site, tuple(want.shape), tuple(t.shape))
+            mag = t.detach().abs()
+            near = mag <= self.band * mag.max()
+            own = t.detach() > 0
+            differ = own != want
+            skip = self.ignore.get(site)
+            if skip is not None:                       # entries nothing downstream reads (pooled-away nodes)
+                differ = differ & ~skip
+            self.mismatch_outside += int((differ & ~near).sum())
+            flip = differ & near
+            self.flips += int(flip.sum())
+            return torch.where(flip, torch.where(want, t, torch.zeros_like(t)), self._orig(t))
+        torch.relu = decided
+        torch.nn.functional.relu = decided
+        return self
+
+    def __exit__(self, *exc):
+        torch.relu = self._orig
+        torch.nn.functional.relu = self._orig
+        return False

@@ -69,14 +69,19 @@ def _oracle_step():
     graphs = W.all_graphs()
     grads, losses = [], []
     for r in range(WORLD):
-        st = OS.make_leaf_state(sd)
+        # fp64: at R * D = 2880 the reference-style fp32 evaluation of OrthogonalConstraint (an (R D)^2 matrix of
+        # squares) is itself ~1e-3 off the exact value; the HIP path's Gram form is not
+        st = OS.make_leaf_state(sd, dtype=torch.float64)
         data = Batch.from_data_list(shard_batch(graphs, r, WORLD))
-        data.x.requires_grad_(True)
+        data.x = data.x.double().requires_grad_(True)
+        data.edge_attr, data.snps_feat = data.edge_attr.double(), data.snps_feat.double()
+        data.tsne_fdim, data.clini_score = data.tsne_fdim.double(), data.clini_score.double()
         loss, _, _ = OS.train_losses(st, cfg, idx, data, W.LAM, dropout=False)
         loss.backward()
         grads.append({k: st[k].grad for k in OS.trainable_keys(st)})
         losses.append(float(loss))
     mean = {k: (None if grads[0][k] is None else sum(g[k] for g in grads) / WORLD) for k in grads[0]}
+    mean = {k: (None if g is None else g.float()) for k, g in mean.items()}
     params = {k: torch.nn.Parameter(sd[k].clone()) for k in mean}
     opt = torch.optim.Adam(list(params.values()), lr=1e-3)
     for k, p in params.items():

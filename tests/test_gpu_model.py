@@ -257,8 +257,7 @@ def test_full_model_vs_oracle_larger(bsz, pool, explain):
         assert_matches(params[k].grad, sdo[k].grad.numpy(), 1e-3, "grad " + k, floor=1e-6)
 
 
-@pytest.mark.parametrize("maps", ["sparse", "default"])
-def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch, maps):
+def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch):
     """TRAINING mode (batch statistics in every BatchNorm, dropout off) at the benchmark's own dimensions — R = 90,
     L = 2, h = 16, the 3000-node GO DAG (LDS-resident GO attention backward, LDS decoder), B = 32 — with the CSR
     SNP <-> GO maps the 256-graph step uses (``sparse``; the default at B = 32 is the dense-image form): the seven loss
@@ -268,8 +267,6 @@ def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch, 
     from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
     from igcn_amd.train import losses
     from oracle import go_network as OG, sgcn_img_snp as OS
-    if maps == "sparse":
-        monkeypatch.setenv("IGCN_SPARSE_MAPS", "1")
     pool, bsz = (1800, 800, 300, 99, 1), 32
     lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
     go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=1)
@@ -285,34 +282,109 @@ def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch, 
     # oracle, fp64, training mode
     a_g_c, a_c = synth.go_sparse_inputs(go_snps, adj)
     idx = OG.go_index_sets(a_g_c, a_c, list(pool), 2)
-    sdo = OS.make_leaf_state(sd, dtype=torch.float64)
-    dcpu = Batch.from_data_list(graphs)
-    dcpu.x = dcpu.x.double().requires_grad_(True)
-    dcpu.edge_attr, dcpu.snps_feat = dcpu.edge_attr.double(), dcpu.snps_feat.double()
-    dcpu.tsne_fdim, dcpu.clini_score = dcpu.tsne_fdim.double(), dcpu.clini_score.double()
     cfg = SimpleNamespace(num_layers=2, rois=90, image_only=False, rbf_gamma=0.01)
-    ref_loss, ref_terms, _ = OS.train_losses(sdo, cfg, idx, dcpu, lam, dropout=False)
-    ref_loss.backward()
-    for batched in (True, False):
+    # ReLU decisions.  tools/relu_margin.py at these shapes: B.0's smallest pre-activation is 1.5e-6 of its layer's
+    # scale; fp32 puts it on the other side of zero, and d B.0.bias[node] — a 32-term sum of scale 7e-4 — moves by one
+    # 3e-5 summand (5 % of that tensor's scale; d conc.weight, a cancelling sum behind a training-mode BatchNorm, by
+    # 2 %), while everything else stays below 4e-4.  Instead of a blanket allowance the test OBSERVES the HIP path's
+    # decisions (the post-ReLU activations its fused kernels return), imposes them on the fp64 oracle where the
+    # pre-activation is within 2e-5 of zero, requires agreement everywhere else, and holds every gradient to 1e-3.
+    from conftest import relu_forced
+    from igcn_amd import ops
+    n0, n1, n_top = sum(pool), sum(pool[1:]), sum(pool[2:])
+
+    def hip_run(batched):
+        """(loss, terms, grads, forced decisions per oracle ReLU site, ignore masks) of one HIP evaluation."""
+        seen = {}
+        classes = (ops.SgcnStack, ops.NodesLayerNorm, ops.NodeLinearBNPair, ops.NodeLinearBN, ops.BatchNorm1dGrouped,
+                   ops.Linear, ops.LinearPair)
         model.load_state_dict(sd)                                     # running statistics back to the start
         model.zero_grad()
         model.batched_passes = batched
         data = Batch.from_data_list(graphs).to("cuda")
-        loss, terms, _ = losses(model, data, lam)
-        assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss))), (batched, float(loss))
-        for k, v in terms.items():
-            r = float(ref_terms[k])
-            assert abs(float(v) - r) <= 1e-4 * max(1.0, abs(r)), (batched, k, float(v), r)
+        with monkeypatch.context() as mp:
+            for cls in classes:
+                def wrapped(*a, _cls=cls, _apply=cls.apply):
+                    out = _apply(*a)
+                    seen.setdefault(_cls.__name__, []).append(out)
+                    return out
+                mp.setattr(cls, "apply", wrapped)
+            loss, terms, _ = losses(model, data, lam)
         loss.backward()
-        assert_matches(data.x.grad, dcpu.x.grad.numpy(), 1e-3, "grad data.x")
         params = dict(model.named_parameters())
-        for k in OS.trainable_keys(sdo):
-            if sdo[k].grad is None:
-                continue
-            g = sdo[k].grad
-            sib = sdo[k[:-5] + ".weight"].grad if (k.endswith(".bias") and k[:-5] + ".weight" in sdo) else None
-            floor = max(1e-6, 0.5 * float(sib.abs().max())) if sib is not None else 1e-6
-            assert_matches(params[k].grad, g.numpy(), 1e-3, f"grad {k} (batched={batched})", floor=floor)
+        grads = {k: params[k].grad for k in params if params[k].grad is not None}
+        grads["data.x"] = data.x.grad
+        forced, ignore = {}, {}
+
+        def halves(t):                      # stacked sweep: rows [0,B) plain pass, [B,2B) masked pass; else one pass each
+            t = t.detach().cpu()
+            return [t[:t.shape[0] // 2], t[t.shape[0] // 2:]] if batched else None
+        def per_pass(name, k_th, pick=lambda o: o):
+            """The k-th call's output per pass: batched -> the two halves of call k; else calls k (plain), k + n (masked)."""
+            calls = seen[name]
+            if batched:
+                return halves(pick(calls[k_th]))
+            n = len(calls) // 2
+            return [pick(calls[k_th]).detach().cpu(), pick(calls[n + k_th]).detach().cpu()]
+        xc = per_pass("SgcnStack", 0)
+        ln = [per_pass("NodesLayerNorm", k) for k in range(4)]
+        att = per_pass("NodeLinearBNPair", 0, lambda o: o[0])
+        inp = per_pass("NodeLinearBNPair", 0, lambda o: o[1])
+        outd = per_pass("NodeLinearBN", 0)
+        hb = [per_pass("BatchNorm1dGrouped", k) for k in range(2)]
+        lp = [per_pass("LinearPair", 0, lambda o, i=i: o[i]) for i in range(2)]
+        for p_ in range(2):
+            base = 14 * p_
+            forced[base + 0] = xc[p_][:, :16] > 0
+            forced[base + 1] = xc[p_][:, 16:] > 0
+            # encoder LayerNorm sites: the HIP kernel returns the POOLED activations (nodes >= pool[j]); the nodes it
+            # drops feed nothing (go_model.py:251), so their decisions are ignored
+            for j, (n_in, drop) in enumerate(((n0, pool[0]), (n1, pool[1]))):
+                z = ln[j][p_].permute(0, 2, 1) > 0                    # [B, N - drop, f]
+                full = torch.zeros(z.shape[0], n_in, z.shape[2], dtype=torch.bool)
+                full[:, drop:, :] = z
+                ig = torch.zeros_like(full)
+                ig[:, :drop, :] = True
+                forced[base + 2 + j], ignore[base + 2 + j] = full, ig
+            forced[base + 4] = att[p_] > 0
+            forced[base + 5] = inp[p_].reshape(inp[p_].shape[0], -1) > 0
+            forced[base + 6] = ln[2][p_].permute(0, 2, 1) > 0
+            forced[base + 7] = ln[3][p_].permute(0, 2, 1) > 0
+            forced[base + 8] = outd[p_].reshape(outd[p_].shape[0], -1) > 0
+            forced[base + 9], forced[base + 10] = hb[0][p_] > 0, hb[1][p_] > 0
+            forced[base + 11] = None                                  # out_proj + ReLU: fused in the GEMM epilogue
+            forced[base + 12], forced[base + 13] = lp[0][p_] > 0, lp[1][p_] > 0
+        return loss, terms, grads, forced, ignore
+
+    flips_seen = 0
+    for maps in ("sparse", "default"):
+        if maps == "sparse":
+            monkeypatch.setenv("IGCN_SPARSE_MAPS", "1")
+        else:
+            monkeypatch.delenv("IGCN_SPARSE_MAPS", raising=False)
+        for batched in (True, False):
+            loss, terms, got, forced, ignore = hip_run(batched)
+            st = OS.make_leaf_state(sd, dtype=torch.float64)
+            dd = Batch.from_data_list(graphs)
+            dd.x = dd.x.double().requires_grad_(True)
+            dd.edge_attr, dd.snps_feat = dd.edge_attr.double(), dd.snps_feat.double()
+            dd.tsne_fdim, dd.clini_score = dd.tsne_fdim.double(), dd.clini_score.double()
+            with relu_forced(forced, ignore=ignore) as rf:
+                ref_loss, ref_terms, _ = OS.train_losses(st, cfg, idx, dd, lam, dropout=False)
+            ref_loss.backward()
+            assert rf.mismatch_outside == 0, (maps, batched, rf.mismatch_outside)   # decisions agree outside the band
+            assert rf.flips <= 40, rf.flips                                           # of ~3.3 M
+            flips_seen += rf.flips
+            assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss))), (batched, float(loss))
+            for k, v in terms.items():
+                r = float(ref_terms[k])
+                assert abs(float(v) - r) <= 1e-4 * max(1.0, abs(r)), (batched, k, float(v), r)
+            want = {k: st[k].grad for k in OS.trainable_keys(st) if st[k].grad is not None}
+            want["data.x"] = dd.x.grad
+            for k, w in want.items():
+                assert_matches(got[k], w.numpy(), 1e-3, f"grad {k} (maps={maps}, batched={batched}, "
+                                                        f"{rf.flips} imposed decisions)", floor=1e-6)
+    assert flips_seen > 0                     # the mechanism is exercised: B.0 has a node that close to zero
 
 
 # ---- the image-only sibling SGCN_GCN (kernel/sgcn.py:272-388; BASELINE configs[0]/[1]) -------------------------
