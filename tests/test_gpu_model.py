@@ -662,7 +662,7 @@ assert step.g_opt is not None
 # (2) libigcn's own communicator (igcn_comm_*): the all-reduce captured INSIDE the one step graph
 from igcn_amd.comm import Comm
 comm = Comm()
-step3 = GraphedTrainStep(m3, o3, static_batch(), lam, warmup=2, comm=comm)
+step3 = GraphedTrainStep(m3, o3, static_batch(), lam, warmup=2, comm=comm, comm_in_graph=True)   # opt-in
 print("comm_in_graph", step3.comm_in_graph)
 assert step3.comm_in_graph and step3.g_opt is None
 for b in batches:
