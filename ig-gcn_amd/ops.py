@@ -160,6 +160,22 @@ class GraphPlan:
             self._ws = torch.empty(int(_lib.load().igcn_graph_plan_workspace_bytes(n, e)), dtype=torch.uint8,
                                    device=dev)
         self._build(ei)
+        self.dense_blocks = self._detect_dense_blocks(ei)
+
+    def _detect_dense_blocks(self, ei):
+        """True when every graph of the batch is COMPLETE and stored in row-major order (a dense adjacency as COO:
+        edge k of graph g = (g R + k / R, g R + k % R)): the SGCN kernels of csrc/sgcn_dense.hip then work on
+        ``edge_attr`` as the dense matrix it is.  Decided once, at construction (one host read); ``rebuild`` re-verifies
+        every new batch on the device (status bit 2).  IGCN_NO_DENSE_BLOCKS=1 keeps the general kernels."""
+        r = self.nodes_per_graph
+        if (not r or self._seg is None or os.environ.get("IGCN_NO_DENSE_BLOCKS", "0") == "1"
+                or self._seg[3] != r * r or self.n_edges != (self.n_nodes // r) * r * r
+                or not _lib.load().igcn_dense_sgcn_supported(r, 1, 16, 1) or ei.data_ptr() % 16
+                or torch.cuda.is_current_stream_capturing()):
+            return False
+        flag = torch.zeros(1, dtype=torch.int32, device=ei.device)
+        call("igcn_dense_blocks_check", self.n_nodes // r, r, ptr(ei), ptr(flag), stream_ptr())
+        return int(flag.item()) == 0
 
     @property
     def segmented(self):
@@ -193,6 +209,13 @@ class GraphPlan:
         keeps its address, so kernels captured in a hipGraph keep reading the right memory."""
         if edge_index.shape != (2, self.n_edges) or edge_index.dtype != torch.int64:
             raise _lib.IgcnError("rebuild needs an int64 edge_index of the shape the plan was built for")
+        if getattr(self, "dense_blocks", False):
+            # complete row-major graphs: the new batch has the SAME structure or none the dense kernels can use — one
+            # pass over edge_index verifies it (status bit 2); the sorted arrays of the first build stay valid
+            ei = edge_index.contiguous()
+            call("igcn_dense_blocks_check", self.n_nodes // self.nodes_per_graph, self.nodes_per_graph, ptr(ei),
+                 ptr(self.status), stream_ptr())
+            return
         # the LDS per-graph build refills ONE cached replica in place (same addresses: capturable); any other build
         # drops the replicas, to be derived again on demand
         keep = (self._seg is not None and not self._tiled and len(self._copies) == 1
@@ -204,6 +227,9 @@ class GraphPlan:
     def check(self):
         """Host-synchronising validation of the segmented build (tests / debugging only)."""
         code = int(self.status.item()) if self.status is not None else 0
+        if code & 4:
+            raise _lib.IgcnError("dense-block plan: the batch is not made of complete graphs in row-major order any "
+                                 "more (build a new plan for it)")
         if code & 2:
             raise _lib.IgcnError("fused SGCN stack: a graph has more edges than the launch was sized for "
                                  f"(max_edges = {self._stack_dims[1] if self._stack_dims else '?'}); its outputs "
@@ -226,7 +252,7 @@ class GraphPlan:
                 setattr(rep, name, torch.empty(max(size, 1), **i32))
             rep._copies, rep._seg, rep.status = {}, None, self.status     # one status word for the plan and its replicas
             rep.nodes_per_graph = self.nodes_per_graph
-            rep._tiled, rep._stack_dims = False, self._stack_dims
+            rep._tiled, rep._stack_dims, rep.dense_blocks = False, self._stack_dims, False
             call("igcn_graph_plan_replicate", n, e, copies, ptr(self.src32), ptr(self.dst32), ptr(self.tgt_ptr),
                  ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(rep.src32),
                  ptr(rep.dst32), ptr(rep.tgt_ptr), ptr(rep.tgt_perm), ptr(rep.src_ptr), ptr(rep.src_perm),
@@ -454,6 +480,83 @@ class SgcnStack(torch.autograd.Function):
             grads.append(dpar[off + f * fin:off + f * fin + f])
             off += f * fin + f
         return (dx, dew, None, None, *grads)
+
+
+def dense_sgcn_supported(plan, rois, h0, f, layers):
+    """The dense-block SGCN kernels (igcn_dense_sgcn_*) cover this batch: complete row-major graphs (verified by the
+    plan) of a supported size / width."""
+    return bool(getattr(plan, "dense_blocks", False) and plan.nodes_per_graph == rois
+                and _lib.load().igcn_dense_sgcn_supported(rois, h0, f, layers))
+
+
+class DenseSgcn(torch.autograd.Function):
+    """cal_probability + gcn_norm + cat_l relu(GCNConv_l(.)) + the edge / node / SNP terms of loss_probability
+    (kernel/sgcn_img_snp.py:133-181,218-224) for a batch of COMPLETE graphs (dense adjacency as COO), one or both
+    passes of a train step: ``mode`` "plain" (isExplain=False), "masked" (isExplain=True) or "both" (rows [0, N) of
+    ``xcat`` the plain pass, [N, 2N) the masked pass).  ``ew`` is read as the dense matrix [G, R, R] it is; no plan
+    arrays, no per-edge intermediates (csrc/sgcn_dense.hip).  Returns (xcat, partials of loss_probability — their
+    SUM is the loss; empty for "plain").  ``reg`` = (l1_x, ent_x, l1_e, ent_e, eps)."""
+
+    @staticmethod
+    def forward(ctx, x, ew, prob, prob_bias, snps_prob, mode, rois, reg, *wb):
+        x, ew, prob, pb = _f32(x), _f32(ew), _f32(prob), _f32(prob_bias)
+        sp = _f32(snps_prob) if snps_prob is not None else None
+        wb = [_f32(t) for t in wb]
+        ws_, bs_ = wb[0::2], wb[1::2]
+        n, h0 = x.shape
+        f, layers = ws_[0].shape[0], len(ws_)
+        g = n // rois
+        copies, first_masked = (2, 0) if mode == "both" else (1, int(mode == "masked"))
+        lib = _lib.load()
+        dev = x.device
+        xcat = torch.empty(copies * n, layers * f, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.igcn_dense_sgcn_ws_floats(g, rois, layers, copies)), dtype=torch.float32, device=dev)
+        anym = mode != "plain"
+        regp = torch.empty(int(lib.igcn_dense_sgcn_reg_blocks(g, rois)) if anym else 0, dtype=torch.float32, device=dev)
+        wp = (ctypes.c_void_p * layers)(*[w.data_ptr() for w in ws_])
+        bp = (ctypes.c_void_p * layers)(*[b.data_ptr() for b in bs_])
+        ctx.reg = tuple(float(v) for v in reg)
+        call("igcn_dense_sgcn_fwd", g, rois, h0, f, layers, copies, first_masked, ptr(x), ptr(prob), ptr(pb), ptr(ew),
+             wp, bp, ptr(sp), sp.numel() if sp is not None else 0, *ctx.reg, ptr(xcat), ptr(regp) if anym else None,
+             ptr(ws), stream_ptr())
+        ctx.save_for_backward(x, ew, prob, pb, sp, xcat, ws, *wb)
+        ctx.cfg = (g, rois, h0, f, layers, copies, first_masked, anym)
+        ctx.final = _leaves(pb, *wb)
+        ctx.set_materialize_grads(False)
+        if not anym:
+            ctx.mark_non_differentiable(regp)
+        return xcat, regp
+
+    @staticmethod
+    def backward(ctx, dxcat, dregp):
+        x, ew, prob, pb, sp, xcat, ws, *wb = ctx.saved_tensors
+        ws_ = wb[0::2]
+        g, rois, h0, f, layers, copies, first_masked, anym = ctx.cfg
+        lib = _lib.load()
+        dev = x.device
+        dxcat = _f32(dxcat) if dxcat is not None else torch.zeros_like(xcat)
+        d_reg = dregp[:1] if (dregp is not None and anym) else None        # the same scalar in every partial
+        if d_reg is not None and not d_reg.is_contiguous():
+            d_reg = d_reg.contiguous()
+        e32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)        # noqa: E731
+        dx = e32(x.shape)
+        dprob, dpb = (e32(prob.shape), e32(pb.shape)) if anym else (None, None)
+        dsp = e32(sp.shape) if (anym and sp is not None) else None
+        npar = int(lib.igcn_sgcn_stack_param_floats(h0, f, layers))
+        dpar = e32(npar)
+        bws = _keep(e32(int(lib.igcn_dense_sgcn_bwd_ws_floats(g, rois, h0, layers, copies))))
+        wp = (ctypes.c_void_p * layers)(*[w.data_ptr() for w in ws_])
+        with _immediate(ctx.final):
+            call("igcn_dense_sgcn_bwd", g, rois, h0, f, layers, copies, first_masked, ptr(x), ptr(prob), ptr(pb), ptr(ew),
+                 wp, ptr(sp), sp.numel() if sp is not None else 0, *ctx.reg, ptr(xcat), ptr(dxcat), ptr(d_reg), ptr(ws),
+                 ptr(bws), ptr(dx), ptr(dprob), ptr(dpb), ptr(dsp), ptr(dpar), stream_ptr())
+        grads, off = [], 0
+        for l in range(layers):
+            fin = h0 if l == 0 else f
+            grads.append(dpar[off:off + f * fin].view(f, fin))
+            grads.append(dpar[off + f * fin:off + f * fin + f])
+            off += f * fin + f
+        return (dx, None, dprob, dpb, dsp, None, None, None, *grads)
 
 
 # =================================================================================================

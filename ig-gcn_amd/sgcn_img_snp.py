@@ -151,6 +151,11 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         # one LDS-resident kernel per direction for the whole SGCN stack when the batch allows it (small uniform
         # graphs); IGCN_NO_FUSED_SGCN=1 keeps the per-layer kernels (A/B runs, tests of the unfused path)
         self.fused_sgcn_stack = os.environ.get("IGCN_NO_FUSED_SGCN", "0") != "1"
+        # loss_probability's constants as the dense-block path needs them at FORWARD time (it reduces the mask
+        # regulariser inside its first edge pass): (l1_x, ent_x, l1_e, ent_e, eps) — sgcn_hyperparameters.py:18-21;
+        # train.losses sets them from the ``hp`` it is given
+        self._reg_hp = (0.1, 0.1, 0.1, 0.1, 1e-6)
+        self._dense_reg = None
 
     def reset_parameters(self):
         self.conv1.reset_parameters()
@@ -189,6 +194,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
     def loss_probability(self, x, edge_index, edge_weight, hp, eps=1e-6, plan=None, edge_prob=None, partials=False):
         """:153-181 as one fused reduction (igcn_mask_reg_*).  ``edge_prob`` lets the train step reuse the mask
         the explain pass already computed; ``partials``: the un-reduced workgroup sums (ops.LossHead adds them up)."""
+        if edge_prob is None and self._dense_reg is not None and self._dense_reg[1] == (
+                float(hp.lamda_x_l1), float(hp.lamda_x_ent), float(hp.lamda_e_l1), float(hp.lamda_e_ent), float(eps)):
+            # the dense-block forward of the masked pass has already reduced every term (edge mask never materialised)
+            return self._dense_reg[0] if partials else self._dense_reg[0].sum()
         if edge_prob is None:
             _, _, _, edge_prob = self.cal_probability(x, edge_index, edge_weight, plan=plan)
         return ops.MaskRegulariser.apply(self.prob, edge_prob, self.snps_prob, hp.lamda_x_l1, hp.lamda_x_ent,
@@ -267,7 +276,26 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         bsz, g = n // self.rois, len(explain_flags)
         plan = ops.plan_for(data)
         self.last_edge_prob = None
-        if (tuple(explain_flags) == (False, True) and x.is_cuda and snps_feat is not None and snps_feat.dim() == 2
+        self._dense_reg = None
+        convs = [self.conv1, *self.convs]
+        mode = {(False,): "plain", (True,): "masked", (False, True): "both"}.get(tuple(explain_flags))
+        snps_ok = snps_feat is not None and snps_feat.is_cuda and snps_feat.dim() == 2 \
+            and snps_feat.shape[1] == self.snps_prob.numel()
+        xcat = None
+        if (mode is not None and x.is_cuda and (snps_ok or mode == "plain") and os.environ.get("IGCN_NO_DENSE_BLOCKS") != "1"
+                and ops.dense_sgcn_supported(plan, self.rois, x.shape[1], convs[0].out_channels, len(convs))):
+            # complete graphs (a dense adjacency as COO): masks, gcn_norm, every GCNConv and the mask regulariser of the
+            # pass(es) on the dense blocks — no plan arrays, no per-edge intermediates (ops.DenseSgcn)
+            wb = [t for c in convs for t in (c.lin.weight, c.bias)]
+            xcat, regp = ops.DenseSgcn.apply(x, edge_weight, self.prob, self.prob_bias, self.snps_prob, mode, self.rois,
+                                             self._reg_hp, *wb)
+            if mode != "plain":
+                self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp))
+            if mode == "plain":
+                snps_in = snps_feat
+            else:
+                snps_in, _ = ops.SnpsMask.apply(snps_feat, self.snps_prob, mode == "both")
+        elif (tuple(explain_flags) == (False, True) and x.is_cuda and snps_feat is not None and snps_feat.dim() == 2
                 and snps_feat.shape[1] == self.snps_prob.numel()):
             # the train step's (plain | masked) pair: cal_probability writes both halves of the stacked batch itself
             x_in, ew_in, e = ops.EdgeMaskStacked.apply(x, self.prob, self.prob_bias, edge_weight, plan, self.rois)
@@ -282,9 +310,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                 explain_flags) else None), pick(snps_feat, snps_m if any(explain_flags) else None)
             stack = lambda ts: ts[0] if g == 1 else torch.cat(ts, dim=0)                       # noqa: E731
             x_in, ew_in, snps_in = stack(xs), stack(ews), stack(snps)
-        plan_g = plan.replicate(g)
         bf = self.bf16_transforms
-        xcat = sgcn_stack([self.conv1, *self.convs], x_in, ew_in, plan_g, self.rois, self.fused_sgcn_stack, bf)
+        if xcat is None:
+            plan_g = plan.replicate(g)
+            xcat = sgcn_stack(convs, x_in, ew_in, plan_g, self.rois, self.fused_sgcn_stack, bf)
         gb = g * bsz
         batch_x = xcat.view(gb, self.rois, -1)                        # to_dense_batch == view (:226)
         img_out = batch_x.reshape(gb, -1)

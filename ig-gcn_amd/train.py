@@ -138,6 +138,8 @@ def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None):
     takes the three-term loss of kernel/train_eval_sgcn.py:303-308 (``lambda_loss`` is not used there)."""
     if not hasattr(model, "go_network"):
         return losses_sgcn(model, data, hp)
+    if hasattr(model, "_reg_hp"):                    # the dense-block SGCN path reduces loss_probability in its forward
+        model._reg_hp = (float(hp.lamda_x_l1), float(hp.lamda_x_ent), float(hp.lamda_e_l1), float(hp.lamda_e_ent), 1e-6)
     if getattr(model, "batched_passes", True) and hasattr(model, "_forward_grouped") and model.isSoftSimilarity:
         return _losses_batched(model, data, lambda_loss, hp, temperature)
     lam = lambda_loss

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 300
+#define IGCN_ABI_VERSION 301
 int igcn_version(void);
 const char* igcn_last_error(void);
 
@@ -198,6 +198,39 @@ int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H0, int F, i
                         const int32_t* tgt_perm, const int32_t* src_ptr, const int32_t* src_perm,
                         const int32_t* loop_edge, const float* const* W, const float* const* b, const float* dxcat,
                         float* dx_in, float* dew_in, float* dparams, float* scratch, int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SGCN over DENSE brain graphs (BASELINE configs[4]): batches whose graphs are COMPLETE — all R x R (source, target)
+ * pairs stored in row-major order, i.e. a dense adjacency turned into COO — so that edge_attr IS the matrix
+ * ew[g][src][dst] and edge_index carries no information.  Replaces, for such batches, cal_probability
+ * (kernel/sgcn_img_snp.py:133-151), PyG gcn_norm + GCNConv x L + ReLU + concatenation (:218-224) and the edge part of
+ * loss_probability (:153-181) of BOTH passes of a train step: every edge pass reads the 4-byte weight once and
+ * recomputes mask / coefficient on the fly; the aggregations run on the matrix cores (csrc/sgcn_dense.hip).
+ *   igcn_dense_blocks_check : verifies edge k of graph g == (g R + k / R, g R + k % R); sets bit 2 (value 4) of *status
+ *                             otherwise (device word, never read by the library).
+ *   igcn_dense_sgcn_supported: 64 <= R <= 1024, R % 64 == 0, F == 16, L <= 4, H0 <= 8.
+ *   copies = 1: one pass (first_masked = isExplain); copies = 2: rows [0, G R) of xcat = plain pass, [G R, 2 G R) = masked.
+ *   W / b: HOST arrays of L device pointers (W_l [F, Fin_l] row-major, Fin_0 = H0).  ws: igcn_dense_sgcn_ws_floats
+ *   floats, written by fwd and read by bwd.  reg_partials [igcn_dense_sgcn_reg_blocks]: un-reduced partials of
+ *   loss_probability (their SUM is the loss; NULL or copies == 1 plain: not written); snps_prob may be NULL.
+ *   bwd: d_reg = d loss / d (every partial), one device float (NULL: 0); outputs dx [G R, H0] (both passes' sum),
+ *   dprob [R, H0], dprob_bias [2 H0], dsnps_prob [n_snps] (regulariser part only; may be NULL) and dparams
+ *   [igcn_sgcn_stack_param_floats] = dW_0 | db_0 | dW_1 | ... (final reductions in the sense of igcn_reduce_defer);
+ *   bws: igcn_dense_sgcn_bwd_ws_floats floats of scratch. */
+int igcn_dense_blocks_check(int64_t n_graphs, int R, const int64_t* edge_index, int32_t* status, void* stream);
+int igcn_dense_sgcn_supported(int R, int H0, int F, int L);
+size_t igcn_dense_sgcn_ws_floats(int64_t n_graphs, int R, int L, int copies);
+size_t igcn_dense_sgcn_bwd_ws_floats(int64_t n_graphs, int R, int H0, int L, int copies);
+int igcn_dense_sgcn_reg_blocks(int64_t n_graphs, int R);
+int igcn_dense_sgcn_fwd(int64_t n_graphs, int R, int H0, int F, int L, int copies, int first_masked, const float* x,
+                        const float* prob, const float* prob_bias, const float* ew, const float* const* W,
+                        const float* const* b, const float* snps_prob, int n_snps, float l1_x, float ent_x, float l1_e,
+                        float ent_e, float eps, float* xcat, float* reg_partials, float* ws, void* stream);
+int igcn_dense_sgcn_bwd(int64_t n_graphs, int R, int H0, int F, int L, int copies, int first_masked, const float* x,
+                        const float* prob, const float* prob_bias, const float* ew, const float* const* W,
+                        const float* snps_prob, int n_snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,
+                        const float* xcat, const float* dxcat, const float* d_reg, const float* ws, float* bws,
+                        float* dx, float* dprob, float* dprob_bias, float* dsnps_prob, float* dparams, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense feature transform on the matrix cores (f32-input MFMA 16x16x4, exact fp32):
