@@ -44,16 +44,92 @@ struct DsReg {                                   // loss_probability's constants
   float l1_x, ent_x, l1_e, ent_e, eps;
 };
 
-__device__ __forceinline__ float ds_sigmoid(float z) { return 1.f / (1.f + expf(-z)); }
+// The mask is evaluated once per edge in EVERY edge pass (six times per train step) instead of being stored: hardware
+// exp / reciprocal / log (v_exp_f32, v_rcp_f32, v_log_f32: ~1e-6 relative) keep that at a handful of instructions.
+// Every pass uses the same function, so forward and backward see the same mask.
+__device__ __forceinline__ float ds_sigmoid(float z) { return __frcp_rn(1.f + __expf(-z)); }
+// edge mask from the per-node factors a[s] = exp(-u[s]), b[d] = exp(-v[d]): sigmoid(u + v) = 1 / (1 + a b) — one
+// multiply-add and one reciprocal per edge, no exponential (a b = inf -> 0, a b = 0 -> 1: the right limits)
+__device__ __forceinline__ float ds_mask(float a, float b) { return __frcp_rn(fmaf(a, b, 1.f)); }
 __device__ __forceinline__ float ds_reg_term(float p, float l1, float ent, float eps) {
-  return l1 * fabsf(p) - ent * (p * logf(p + eps) + (1.f - p) * logf((1.f - p) + eps));
+  return l1 * p - ent * (p * __logf(p + eps) + (1.f - p) * __logf((1.f - p) + eps));          // p in (0, 1)
 }
 __device__ __forceinline__ float ds_reg_grad(float p, float l1, float ent, float eps) {
-  return l1 - ent * (logf(p + eps) + p / (p + eps) - logf((1.f - p) + eps) - (1.f - p) / ((1.f - p) + eps));
+  const float a = p + eps, b = (1.f - p) + eps;
+  return l1 - ent * (__logf(a) + p * __frcp_rn(a) - __logf(b) - (1.f - p) * __frcp_rn(b));
 }
 
 template <int NC, bool M0>
 __device__ __forceinline__ constexpr bool ds_masked(int c) { return NC == 2 ? c == 1 : M0; }
+
+// The edge passes walk their rows in STEPS of one 16-byte load per lane.  Two forms of every edge kernel:
+//  * FAST (template flag PIPE; R = 256 or 512): the per-NODE operands of the graph (h' / g' rows, mask factors) are
+//    staged in LDS once per workgroup, so the only global loads of the walk are the streamed ew values — and a wave
+//    issues ALL of them (8 or 16 x 16 bytes per lane: 16 KB per wave, the whole 33.5 MB matrix in flight chip-wide)
+//    before its first multiply, then consumes them in order.  What it took (aggregation, both passes: 19 us -> DESIGN
+//    §4): (i) NO branch or predicate between a load and its use — with one, the compiler waits for every outstanding
+//    load (s_waitcnt vmcnt(0)), i.e. "load everything, wait, compute"; (ii) enough bytes in flight: a two-buffer
+//    pipeline of 4-step chunks kept 4 KB per wave = 8 MB chip-wide in flight, less than bandwidth x latency, and was
+//    LATENCY-bound at 4 TB/s however well it overlapped; (iii) node operands out of LDS, so that a step costs 4
+//    registers, not 7-16, and the whole walk fits the register file.
+//  * generic (any supported R): one step at a time out of global memory.
+// Workgroup -> (graph, 64-node block) of the edge kernels, XCD-aware: the hardware deals consecutive workgroup ids
+// round-robin over the 8 XCDs (each with its own L2).  With the plain (block, graph) grid the 8 blocks of a graph sit
+// on 8 different XCDs: every XCD fetches every graph's node operands, and its ew reads are 256-byte pieces 2 KB apart.
+// Here XCD c takes the work items [c T/8, (c+1) T/8) in order, so the blocks of a graph run on ONE XCD, back to back:
+// the graph's h' / g' rows cross the fabric once, and the XCD's L2 sees whole 2 KB rows of ew.
+__device__ __forceinline__ void ds_block(int nblk, int& g, int& xb) {
+  const int total = gridDim.x, id = blockIdx.x;
+  int j = id;
+  if ((total & 7) == 0) j = (id & 7) * (total >> 3) + (id >> 3);
+  g = j / nblk;
+  xb = j - g * nblk;
+}
+
+#ifdef DS_PROBE_ON
+// phase stamps of the first workgroups of k_ds_agg (tools/dense_probe.py, IGCN_HIPCC_EXTRA=-DDS_PROBE_ON)
+__device__ long long ds_probe_buf[8 * 8 * 8];                     // [workgroup][wave][stamp]
+#define DS_PROBE(i)                                                                                     \
+  do {                                                                                                  \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64 && (blockIdx.x & 7) == 0)                            \
+      ds_probe_buf[((blockIdx.x >> 3) * 8 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64();            \
+  } while (0)
+extern "C" int igcn_debug_ds_probe(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ds_probe_buf), sizeof(long long) * 8 * 8 * 8);
+}
+#else
+#define DS_PROBE(i)
+#endif
+#define DS_PCH 4
+template <int V>
+struct DsInt {
+  static constexpr int value = V;
+};
+template <bool PIPE, int STEP, typename BufP, typename Buf1, typename LoadP, typename CompP, typename Load1, typename Comp1>
+__device__ __forceinline__ void ds_walk(int begin, int end, LoadP loadp, CompP compp, Load1 load1, Comp1 comp1) {
+  if constexpr (PIPE) {
+    constexpr int CW = DS_PCH * STEP;                       // rows (or columns) per chunk
+    BufP b0, b1;
+    loadp(b0, begin);
+    int p = begin;
+    for (; p + 2 * CW < end; p += 2 * CW) {
+      loadp(b1, p + CW);
+      compp(b0, p);
+      loadp(b0, p + 2 * CW);
+      compp(b1, p + CW);
+    }
+    loadp(b1, p + CW);
+    compp(b0, p);
+    compp(b1, p + CW);
+  } else {
+#pragma unroll 2
+    for (int p = begin; p < end; p += STEP) {
+      Buf1 b;
+      load1(b, p);
+      comp1(b, p);
+    }
+  }
+}
 
 // ---- forward workspace (kept for the backward): u, v [GR] | dis [NC][GR] | hp [L][NC][GR][F] | agg [L][NC][GR][F]
 struct DsWs {
@@ -114,8 +190,8 @@ extern "C" int igcn_dense_blocks_check(int64_t n_graphs, int R, const int64_t* e
 // =================================================================================================
 // forward
 // =================================================================================================
-// u[i] = xm[i] . a[:H0], v[i] = xm[i] . a[H0:] with xm = x * prob (cal_probability :137-143: the pair logit of edge
-// (s, d) is u[s] + v[d]); workgroup 0 also leaves the node / SNP parts of loss_probability in reg_out[0]
+// u[i] = exp(-xm[i] . a[:H0]), v[i] = exp(-xm[i] . a[H0:]) with xm = x * prob (cal_probability :137-143: the pair logit
+// of edge (s, d) is the sum of the two dot products, its sigmoid 1 / (1 + u[s] v[d])); workgroup 0 also leaves the node / SNP parts of loss_probability in reg_out[0]
 __global__ void __launch_bounds__(256)
 k_ds_prep(int64_t GR, int R, int H0, const float* __restrict__ x, const float* __restrict__ prob,
           const float* __restrict__ pb, float* __restrict__ u, float* __restrict__ v,
@@ -130,8 +206,8 @@ k_ds_prep(int64_t GR, int R, int H0, const float* __restrict__ x, const float* _
       uu += xm * pb[h];
       vv += xm * pb[H0 + h];
     }
-    u[node] = uu;
-    v[node] = vv;
+    u[node] = __expf(-uu);                              // the edge passes want exp(-u), exp(-v): ds_mask
+    v[node] = __expf(-vv);
   }
   if (blockIdx.x == 0 && reg_out) {
     float acc = 0.f;
@@ -147,14 +223,22 @@ k_ds_prep(int64_t GR, int R, int H0, const float* __restrict__ x, const float* _
 // deg[c][d] = sum_s w_c[s,d] -> dis = deg^-1/2 ; the edge part of loss_probability as one partial per workgroup.
 // grid (R / 64, G), 512 threads: wave w walks source rows [w R/8, (w+1) R/8), lane (q, sub) loads 16 bytes of row
 // s + sub at targets d0 + 4 q .. + 3.
-template <int NC, bool M0>
+template <int N>
+struct DsDegBuf {
+  float4 w4[N];
+  float us[N];
+};
+
+template <int NC, bool M0, bool PIPE>
 __global__ void __launch_bounds__(512)
 k_ds_deg(int R, int64_t GR, const float* __restrict__ ew, const float* __restrict__ u, const float* __restrict__ v,
          float* __restrict__ dis, DsReg rg, float inv_ne, float* __restrict__ reg_partial) {
   constexpr bool ANYM = NC == 2 || M0;
   __shared__ float red[8][NC][64];
   __shared__ float rsum[16];
-  const int g = blockIdx.y, d0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int g, xb;
+  ds_block(R / 64, g, xb);
+  const int d0 = xb * 64, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int q = lane & 15, sub = lane >> 4;
   const int rows = R / 8, sb = w * rows;
   float vd[4] = {0.f, 0.f, 0.f, 0.f};
@@ -168,26 +252,37 @@ k_ds_deg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[c][t] = 0.f;
   float racc = 0.f;
-  const float* base = ew + (int64_t)g * R * R + d0 + 4 * q;
-#pragma unroll 4
-  for (int j = 0; j < rows; j += 4) {
-    const int s = sb + j + sub;
-    const float4 w4 = *reinterpret_cast<const float4*>(base + (int64_t)s * R);
-    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-    float ev[4] = {1.f, 1.f, 1.f, 1.f};
-    if (ANYM) {
-      const float us = u[(int64_t)g * R + s];
+  const int64_t nb = (int64_t)g * R;
+  const float* base = ew + nb * R + d0 + 4 * q;
+  auto load = [&](auto& bf, int row) {
+    constexpr int N = sizeof(bf.us) / sizeof(float);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        ev[t] = ds_sigmoid(us + vd[t]);
-        racc += ds_reg_term(ev[t], rg.l1_e, rg.ent_e, rg.eps);
-      }
+    for (int jj = 0; jj < N; ++jj) {
+      const int s = row + 4 * jj + sub;
+      bf.w4[jj] = *reinterpret_cast<const float4*>(base + (int64_t)s * R);
+      bf.us[jj] = ANYM ? u[nb + s] : 0.f;
     }
+  };
+  auto compute = [&](const auto& bf, int) {
+    constexpr int N = sizeof(bf.us) / sizeof(float);
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
+    for (int jj = 0; jj < N; ++jj) {
+      const float wv[4] = {bf.w4[jj].x, bf.w4[jj].y, bf.w4[jj].z, bf.w4[jj].w};
+      float ev[4] = {1.f, 1.f, 1.f, 1.f};
+      if (ANYM) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[c][t] += ds_masked<NC, M0>(c) ? wv[t] * ev[t] : wv[t];
-  }
+        for (int t = 0; t < 4; ++t) {
+          ev[t] = ds_mask(bf.us[jj], vd[t]);
+          racc += ds_reg_term(ev[t], rg.l1_e, rg.ent_e, rg.eps);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[c][t] += ds_masked<NC, M0>(c) ? wv[t] * ev[t] : wv[t];
+    }
+  };
+  ds_walk<PIPE, 4, DsDegBuf<DS_PCH>, DsDegBuf<1>>(sb, sb + rows, load, compute, load, compute);
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -205,13 +300,13 @@ k_ds_deg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
     float deg = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 8; ++ww) deg += red[ww][c][dl];
-    dis[(int64_t)c * GR + (int64_t)g * R + d0 + dl] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;
+    dis[(int64_t)c * GR + nb + d0 + dl] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;
   }
   if (ANYM && reg_partial && tid == 0) {
     float t = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 8; ++ww) t += rsum[ww];
-    reg_partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t * inv_ne;
+    reg_partial[(int64_t)g * (R / 64) + xb] = t * inv_ne;
   }
 }
 
@@ -237,7 +332,13 @@ k_ds_h0(int64_t GR, int R, int H0, const float* __restrict__ x, const float* __r
 // One GCNConv aggregation for every copy: AGG[c][d] = sum_s w_c[s,d] hp[c][s] on the matrix cores, then
 // Y = relu(dis[d] AGG + b) into its columns of xcat and — when another layer follows — hp_next = dis * (Y W_next^T).
 // grid (R / 64, G), 512 threads; dynamic LDS: 8 waves' partial tiles [8][NC][64][16] + the Y rows [NC][64][16].
-template <int NC, bool M0>
+template <int N, int NC>
+struct DsAggBuf {
+  float4 w4[N];
+  float bop[N][NC], us[N];
+};
+
+template <int NC, bool M0, bool PIPE>
 __global__ void __launch_bounds__(512)
 k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restrict__ u, const float* __restrict__ v,
          const float* __restrict__ dis, const float* __restrict__ hp, const float* __restrict__ bias,
@@ -246,7 +347,9 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
   extern __shared__ float ds_lds[];
   float* part = ds_lds;                                   // [8][NC][64][16]
   float* ys = ds_lds + 8 * NC * 64 * DS_F;                // [NC][64][16]
-  const int g = blockIdx.y, d0 = blockIdx.x * 64, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int g, xb;
+  ds_block(R / 64, g, xb);
+  const int d0 = xb * 64, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int q = lane & 15, sub = lane >> 4;
   const int rows = R / 8, sb = w * rows;
   constexpr bool ANYM = NC == 2 || M0;
@@ -260,30 +363,44 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
   for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* base = ew + (int64_t)g * R * R + d0 + 4 * q;
   const int64_t nb = (int64_t)g * R;
-#pragma unroll 4
-  for (int j = 0; j < rows; j += 4) {
-    const int s = sb + j + sub;
-    const float4 w4 = *reinterpret_cast<const float4*>(base + (int64_t)s * R);
-    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-    float bop[NC];
+  const float* base = ew + nb * R + d0 + 4 * q;
+  auto load = [&](auto& bf, int row) {
+    constexpr int N = sizeof(bf.us) / sizeof(float);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) bop[c] = hp[((int64_t)c * GR + nb + s) * DS_F + q];     // B[k = sub][f = q]
-    float ev[4] = {1.f, 1.f, 1.f, 1.f};
-    if (ANYM) {
-      const float us = u[nb + s];
+    for (int jj = 0; jj < N; ++jj) {
+      const int s = row + 4 * jj + sub;
+      bf.w4[jj] = *reinterpret_cast<const float4*>(base + (int64_t)s * R);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) ev[t] = ds_sigmoid(us + vd[t]);
+      for (int c = 0; c < NC; ++c) bf.bop[jj][c] = hp[((int64_t)c * GR + nb + s) * DS_F + q];   // B[k = sub][f = q]
+      bf.us[jj] = ANYM ? u[nb + s] : 0.f;
     }
+  };
+  auto compute = [&](const auto& bf, int) {
+    constexpr int N = sizeof(bf.us) / sizeof(float);
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
+    for (int jj = 0; jj < N; ++jj) {
+      const float wv[4] = {bf.w4[jj].x, bf.w4[jj].y, bf.w4[jj].z, bf.w4[jj].w};
+      float ev[4] = {1.f, 1.f, 1.f, 1.f};
+      if (ANYM) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float a = ds_masked<NC, M0>(c) ? wv[t] * ev[t] : wv[t];                    // A[target 4 q + t][k = sub]
-        acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bop[c], acc[c][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) ev[t] = ds_mask(bf.us[jj], vd[t]);
       }
-  }
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float a = ds_masked<NC, M0>(c) ? wv[t] * ev[t] : wv[t];                  // A[target 4 q + t][k = sub]
+          acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf.bop[jj][c], acc[c][t], 0, 0, 0);
+        }
+    }
+  };
+  DS_PROBE(0);
+  // measured at 512-node graphs, both passes (us per launch): node operands staged in LDS + every ew load of the walk
+  // issued up front 17.3 (the operand staging and the barrier behind it cost more than the per-step loads they
+  // replace); the same with the staging loads issued first 21.4; two-buffer pipeline out of global memory 14.6 <- kept
+  ds_walk<PIPE, 4, DsAggBuf<DS_PCH, NC>, DsAggBuf<1, NC>>(sb, sb + rows, load, compute, load, compute);
+  DS_PROBE(3);
   // accumulator lane (q, sub), tile t, register r = (target d0 + 16 sub + 4 r + t, feature q)
 #pragma unroll
   for (int c = 0; c < NC; ++c)
@@ -304,6 +421,7 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
     xcat[node * ldx + col0 + f] = y;
     ys[(c * 64 + dl) * DS_F + f] = y;
   }
+  DS_PROBE(5);
   if (Wnext == nullptr) return;
   __syncthreads();
   for (int o = tid; o < NC * 64 * DS_F; o += 512) {
@@ -314,12 +432,14 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
     const int64_t node = (int64_t)c * GR + nb + d0 + dl;
     hp_next[node * DS_F + fo] = dis[node] * a;
   }
+  DS_PROBE(6);
 }
 
 // =================================================================================================
 // backward
 // =================================================================================================
-// backward workspace: gp [L][NC][GR][F] | dhp [NC][GR][F] | T [GR] | ddeg [GR] | dup [R/16][GR] | dv [GR] |
+// backward workspace: gp [L][NC][F][GR] (feature-major: the matrix-core operands of the edge passes are 16-byte loads
+//                     along the node axis) | dhp [NC][GR][F] | T [GR] | ddeg [GR] | dup [R/16][GR] | dv [GR] |
 //                     dxin [NC][GR][H0] | dxm [GR][H0] | db partials [L][nblk][F] | dW partials [L][nblk][F*F] |
 //                     da partials [nblk2][2 H0]
 struct DsBws {
@@ -329,7 +449,7 @@ struct DsBws {
 __host__ __device__ inline DsBws ds_bws(int64_t GR, int R, int H0, int L, int NC) {
   DsBws o;
   o.nblk = (int64_t)NC * GR / 16;
-  o.nblk2 = (GR + 255) / 256;
+  o.nblk2 = (GR + 63) / 64;
   int64_t p = 0;
   o.gp = p; p += (int64_t)L * NC * GR * DS_F;
   o.dhp = p; p += (int64_t)NC * GR * DS_F;
@@ -360,7 +480,7 @@ k_ds_node_top(int64_t GR, int L, const float* __restrict__ xcat, const float* __
   const int64_t cn = (int64_t)blockIdx.x * 16 + nl;                   // copy * GR + node
   const int64_t off = cn * ldx + (int64_t)(L - 1) * DS_F + f;
   const float g = xcat[off] > 0.f ? dxcat[off] : 0.f;
-  gp_last[cn * DS_F + f] = dis[cn] * g;
+  gp_last[((cn / GR) * DS_F + f) * GR + cn % GR] = dis[cn] * g;       // feature-major: [copy][f][node]
   gs[nl][f] = g;
   __syncthreads();
   if (tid < DS_F) {
@@ -373,14 +493,24 @@ k_ds_node_top(int64_t GR, int L, const float* __restrict__ xcat, const float* __
 
 // dH'[c][s] = sum_d w_c[s,d] g'[c][d] (the transposed aggregation) on the matrix cores.  grid (R / 64, G), 512 threads:
 // wave w owns source tile (w & 3) of the block's 64 sources and one half (w >> 2) of the targets.
-template <int NC, bool M0>
+template <int N, int NC>
+struct DsAggTBuf {
+  float4 w4[N], v4[N], b4[N][NC];
+};
+
+template <int NC, bool M0, bool PIPE>
 __global__ void __launch_bounds__(512)
 k_ds_aggT(int R, int64_t GR, const float* __restrict__ ew, const float* __restrict__ u, const float* __restrict__ v,
           const float* __restrict__ gp, float* __restrict__ dhp) {
-  __shared__ float part[2][4][NC][16][DS_F];
-  const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // dynamic LDS only (a kernel with static LDS cannot raise its dynamic limit to the full 160 KB):
+  //   part [2][4][NC][16][16] | FAST: lgp [NC][16][R + 4] | lv [R]
+  extern __shared__ float dt_lds[];
+  float (*part)[4][NC][16][DS_F] = reinterpret_cast<float (*)[4][NC][16][DS_F]>(dt_lds);
+  int g, xb;
+  ds_block(R / 64, g, xb);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int q = lane & 15, sub = lane >> 4, st = w & 3, dh = w >> 2;
-  const int s0 = blockIdx.x * 64 + 16 * st;
+  const int s0 = xb * 64 + 16 * st;
   const int64_t nb = (int64_t)g * R;
   constexpr bool ANYM = NC == 2 || M0;
   const float us = ANYM ? u[nb + s0 + q] : 0.f;
@@ -389,24 +519,70 @@ k_ds_aggT(int R, int64_t GR, const float* __restrict__ ew, const float* __restri
   for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* row = ew + (nb + s0 + q) * (int64_t)R + 4 * sub;
   const int dbeg = dh * (R / 2), dend = dbeg + R / 2;
-#pragma unroll 2
-  for (int ds = dbeg; ds < dend; ds += 16) {
-    const float4 w4 = *reinterpret_cast<const float4*>(row + ds);
-    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-    float ev[4] = {1.f, 1.f, 1.f, 1.f};
-    if (ANYM) {
-      const float4 v4 = *reinterpret_cast<const float4*>(v + nb + ds + 4 * sub);
-      ev[0] = ds_sigmoid(us + v4.x); ev[1] = ds_sigmoid(us + v4.y);
-      ev[2] = ds_sigmoid(us + v4.z); ev[3] = ds_sigmoid(us + v4.w);
-    }
+  auto load = [&](auto& bf, int col) {
+    constexpr int N = sizeof(bf.w4) / sizeof(float4);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int jj = 0; jj < N; ++jj) {
+      const int ds = col + 16 * jj;
+      bf.w4[jj] = *reinterpret_cast<const float4*>(row + ds);
+      if (ANYM) bf.v4[jj] = *reinterpret_cast<const float4*>(v + nb + ds + 4 * sub);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)            // B[k = sub][f = q] of the four products: targets ds + 4 sub + (0..3)
+        bf.b4[jj][c] = *reinterpret_cast<const float4*>(gp + ((int64_t)c * DS_F + q) * GR + nb + ds + 4 * sub);
+    }
+  };
+  auto compute = [&](const auto& bf, int) {
+    constexpr int N = sizeof(bf.w4) / sizeof(float4);
+#pragma unroll
+    for (int jj = 0; jj < N; ++jj) {
+      const float wv[4] = {bf.w4[jj].x, bf.w4[jj].y, bf.w4[jj].z, bf.w4[jj].w};
+      float ev[4] = {1.f, 1.f, 1.f, 1.f};
+      if (ANYM) {
+        ev[0] = ds_mask(us, bf.v4[jj].x); ev[1] = ds_mask(us, bf.v4[jj].y);
+        ev[2] = ds_mask(us, bf.v4[jj].z); ev[3] = ds_mask(us, bf.v4[jj].w);
+      }
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const float b = gp[((int64_t)c * GR + nb + ds + 4 * sub + t) * DS_F + q];          // B[k = sub][f = q]
-        const float a = ds_masked<NC, M0>(c) ? wv[t] * ev[t] : wv[t];                       // A[source q][k = sub]
-        acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+        const float bv[4] = {bf.b4[jj][c].x, bf.b4[jj][c].y, bf.b4[jj][c].z, bf.b4[jj][c].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float a = ds_masked<NC, M0>(c) ? wv[t] * ev[t] : wv[t];                     // A[source q][k = sub]
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[t], acc[c], 0, 0, 0);
+        }
       }
+    }
+  };
+  if constexpr (PIPE) {
+    const int ldg = R + 4;                                // padded row: the 16 features of a lane group hit other banks
+    float* lgp = dt_lds + 2 * 4 * NC * 16 * DS_F;         // [NC][16][R + 4], feature-major like gp
+    float* lv = lgp + NC * DS_F * ldg;                    // [R]
+    for (int i = tid; i < NC * DS_F * (R / 4); i += 512) {
+      const int rowi = i / (R / 4), c4 = i - rowi * (R / 4);          // rowi = c * 16 + f
+      *reinterpret_cast<float4*>(lgp + rowi * ldg + 4 * c4) =
+          *reinterpret_cast<const float4*>(gp + (int64_t)rowi * GR + nb + 4 * c4);
+    }
+    if (ANYM)
+      for (int i = tid; i < R; i += 512) lv[i] = v[nb + i];
+    __syncthreads();
+    auto run = [&](auto nsc) {
+      constexpr int NS = decltype(nsc)::value;
+      float4 w4[NS];
+#pragma unroll
+      for (int jj = 0; jj < NS; ++jj) w4[jj] = *reinterpret_cast<const float4*>(row + dbeg + 16 * jj);
+#pragma unroll
+      for (int jj = 0; jj < NS; ++jj) {
+        const int ds = dbeg + 16 * jj;
+        DsAggTBuf<1, NC> bf;
+        bf.w4[0] = w4[jj];
+        if (ANYM) bf.v4[0] = *reinterpret_cast<const float4*>(lv + ds + 4 * sub);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) bf.b4[0][c] = *reinterpret_cast<const float4*>(lgp + (c * DS_F + q) * ldg + ds + 4 * sub);
+        compute(bf, 0);
+      }
+    };
+    if (R == 512) run(DsInt<16>{}); else run(DsInt<8>{});
+  } else {
+    ds_walk<false, 16, DsAggTBuf<DS_PCH, NC>, DsAggTBuf<1, NC>>(dbeg, dend, load, compute, load, compute);
   }
 #pragma unroll
   for (int c = 0; c < NC; ++c)
@@ -416,7 +592,7 @@ k_ds_aggT(int R, int64_t GR, const float* __restrict__ ew, const float* __restri
   for (int o = tid; o < 4 * NC * 16 * DS_F; o += 512) {
     const int f = o & 15, i = (o >> 4) & 15, c = (o >> 8) % NC, t4 = o / (256 * NC);
     const float a = part[0][t4][c][i][f] + part[1][t4][c][i][f];
-    dhp[((int64_t)c * GR + nb + blockIdx.x * 64 + 16 * t4 + i) * DS_F + f] = a;
+    dhp[((int64_t)c * GR + nb + xb * 64 + 16 * t4 + i) * DS_F + f] = a;
   }
 }
 
@@ -453,7 +629,7 @@ k_ds_node_mid(int64_t GR, int R, int H0, int L, int l, const float* __restrict__
     Ws[nl][f] = Wl[nl * fin + f];                              // W_l [F][fin]: row nl (an output feature), column f
   }
   if (masked) {
-    float t = gp_l[cn * DS_F + f] * agg_l[cn * DS_F + f] + hp_l[cn * DS_F + f] * dh;
+    float t = gp_l[((int64_t)c * DS_F + f) * GR + node] * agg_l[cn * DS_F + f] + hp_l[cn * DS_F + f] * dh;
     t = group_sum_all<16>(t);
     if (f == 0) {
       const float tot = (l == L - 1 ? 0.f : T[node]) + t;
@@ -481,7 +657,7 @@ k_ds_node_mid(int64_t GR, int R, int H0, int L, int l, const float* __restrict__
   }
   const int64_t off = cn * ldx + (int64_t)(l - 1) * DS_F + f;
   const float gval = xcat[off] > 0.f ? dxcat[off] + dxv : 0.f;
-  gp_prev[cn * DS_F + f] = di * gval;
+  gp_prev[((int64_t)c * DS_F + f) * GR + node] = di * gval;
   gs[nl][f] = gval;
   __syncthreads();
   if (tid < DS_F) {
@@ -494,23 +670,34 @@ k_ds_node_mid(int64_t GR, int R, int H0, int L, int l, const float* __restrict__
 
 // The mask gradient's edge pass (masked copy): q[s,d] = sum_l g'_l[d] . h'_l[s] on the matrix cores (K = L F),
 //   dz = ((q + ddeg[d]) ew + greg reg'(e) / nE) e (1 - e);  du[s] = sum_d dz (partials per 16-target tile), dv[d] = sum_s dz.
-// grid (R / 64, G), 256 threads: wave w owns targets [d0 + 16 w, + 16) and walks every source tile.
-template <int L>
-__global__ void __launch_bounds__(256)
+// grid (R / 64, G), 512 threads: wave w owns targets [d0 + 16 (w & 3), + 16) and one half (w >> 2) of the source tiles.
+// Operand pairing: k index (kk, sub) <-> feature 4 sub + kk, so that a lane's four k-steps of a layer are ONE 16-byte
+// load of h'_l[source][4 sub .. 4 sub + 3] (g' is feature-major: its operands are loaded once per wave).
+template <int N, int L>
+struct DsMbBuf {
+  float4 w4[N], h4[N][L];
+  float us[N];
+};
+
+template <int L, bool PIPE>
+__global__ void __launch_bounds__(512)
 k_ds_mask_bwd(int R, int64_t GR, const float* __restrict__ ew, const float* __restrict__ u, const float* __restrict__ v,
-              const float* __restrict__ gpm /*layer stride = lstride*/, const float* __restrict__ hpm, int64_t lstride,
-              const float* __restrict__ ddeg, const float* __restrict__ greg, DsReg rg, float inv_ne,
+              const float* __restrict__ gpm /*[L][..][F][GR] at the masked copy*/, const float* __restrict__ hpm,
+              int64_t lstride, const float* __restrict__ ddeg, const float* __restrict__ greg, DsReg rg, float inv_ne,
               float* __restrict__ dup, float* __restrict__ dv) {
-  const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int q = lane & 15, sub = lane >> 4;
-  const int d0 = blockIdx.x * 64 + 16 * w;
+  __shared__ float dvs[2][4][16];
+  int g, xb;
+  ds_block(R / 64, g, xb);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int q = lane & 15, sub = lane >> 4, dt = w & 3, sh = w >> 2;
+  const int d0 = xb * 64 + 16 * dt;
   const int64_t nb = (int64_t)g * R;
   const float gr = greg ? greg[0] * inv_ne : 0.f;
   float aop[L][4];
 #pragma unroll
   for (int l = 0; l < L; ++l)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) aop[l][kk] = gpm[l * lstride + (nb + d0 + q) * DS_F + 4 * kk + sub];   // A[target q][k = sub]
+    for (int kk = 0; kk < 4; ++kk) aop[l][kk] = gpm[l * lstride + (int64_t)(4 * sub + kk) * GR + nb + d0 + q];   // A[target q][k]
   float vd[4], dd[4], dvacc[4] = {0.f, 0.f, 0.f, 0.f};
   {
     const float4 v4 = *reinterpret_cast<const float4*>(v + nb + d0 + 4 * sub);
@@ -518,34 +705,49 @@ k_ds_mask_bwd(int R, int64_t GR, const float* __restrict__ ew, const float* __re
     vd[0] = v4.x; vd[1] = v4.y; vd[2] = v4.z; vd[3] = v4.w;
     dd[0] = d4.x; dd[1] = d4.y; dd[2] = d4.z; dd[3] = d4.w;
   }
-  const int tile = blockIdx.x * 4 + w;                                     // 16-target tile of this graph
-#pragma unroll 2
-  for (int s0 = 0; s0 < R; s0 += 16) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float4 w4 = *reinterpret_cast<const float4*>(ew + (nb + s0 + q) * (int64_t)R + d0 + 4 * sub);
-    const float us = u[nb + s0 + q];
+  const int tile = xb * 4 + dt;                                            // 16-target tile of this graph
+  const int sbeg = sh * (R / 2), send = sbeg + R / 2;
+  auto load = [&](auto& bf, int srow) {
+    constexpr int N = sizeof(bf.us) / sizeof(float);
 #pragma unroll
-    for (int l = 0; l < L; ++l)
+    for (int jj = 0; jj < N; ++jj) {
+      const int s0 = srow + 16 * jj;
+      bf.w4[jj] = *reinterpret_cast<const float4*>(ew + (nb + s0 + q) * (int64_t)R + d0 + 4 * sub);
+      bf.us[jj] = u[nb + s0 + q];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const float b = hpm[l * lstride + (nb + s0 + q) * DS_F + 4 * kk + sub];            // B[k = sub][source q]
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[l][kk], b, acc, 0, 0, 0);
-      }
-    // accumulator register r = (target d0 + 4 sub + r, source s0 + q): the four targets of this lane's 16-byte load
-    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-    float rs = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float e = ds_sigmoid(us + vd[r]);
-      const float de = (acc[r] + dd[r]) * wv[r] + gr * ds_reg_grad(e, rg.l1_e, rg.ent_e, rg.eps);
-      const float dz = de * e * (1.f - e);
-      dvacc[r] += dz;
-      rs += dz;
+      for (int l = 0; l < L; ++l)
+        bf.h4[jj][l] = *reinterpret_cast<const float4*>(hpm + l * lstride + (nb + s0 + q) * DS_F + 4 * sub);   // B[k][source q]
     }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
-    if (sub == 0) dup[(int64_t)tile * GR + nb + s0 + q] = rs;
-  }
+  };
+  auto compute = [&](const auto& bf, int srow) {
+    constexpr int N = sizeof(bf.us) / sizeof(float);
+#pragma unroll
+    for (int jj = 0; jj < N; ++jj) {
+      const int s0 = srow + 16 * jj;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const float hv[4] = {bf.h4[jj][l].x, bf.h4[jj][l].y, bf.h4[jj][l].z, bf.h4[jj][l].w};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[l][kk], hv[kk], acc, 0, 0, 0);
+      }
+      // accumulator register r = (target d0 + 4 sub + r, source s0 + q): the four targets of this lane's 16-byte load
+      const float wv[4] = {bf.w4[jj].x, bf.w4[jj].y, bf.w4[jj].z, bf.w4[jj].w};
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = ds_mask(bf.us[jj], vd[r]);
+        const float de = (acc[r] + dd[r]) * wv[r] + gr * ds_reg_grad(e, rg.l1_e, rg.ent_e, rg.eps);
+        const float dz = de * e * (1.f - e);
+        dvacc[r] += dz;
+        rs += dz;
+      }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      if (sub == 0) dup[(int64_t)tile * GR + nb + s0 + q] = rs;
+    }
+  };
+  ds_walk<PIPE, 16, DsMbBuf<DS_PCH, L>, DsMbBuf<1, L>>(sbeg, send, load, compute, load, compute);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float a = dvacc[r];
@@ -553,22 +755,24 @@ k_ds_mask_bwd(int R, int64_t GR, const float* __restrict__ ew, const float* __re
     a += __shfl_xor(a, 2, 64);
     a += __shfl_xor(a, 4, 64);
     a += __shfl_xor(a, 8, 64);
-    if (q == 0) dv[nb + d0 + 4 * sub + r] = a;
+    if (q == 0) dvs[sh][dt][4 * sub + r] = a;
   }
+  __syncthreads();
+  if (tid < 64) dv[nb + xb * 64 + tid] = dvs[0][tid >> 4][tid & 15] + dvs[1][tid >> 4][tid & 15];
 }
 
 // node-level end of the mask backward: du = sum of the tile partials, dxm = du a[:H0] + dv a[H0:] + dX_0(masked copy),
 // dx = dX_0(plain copy) + dxm * prob, d prob_bias partials (sum_i du xm, sum_i dv xm)
 template <int NC, bool M0>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 k_ds_mask_nodes(int64_t GR, int R, int H0, const float* __restrict__ x, const float* __restrict__ prob,
                 const float* __restrict__ pb, const float* __restrict__ dup, const float* __restrict__ dv,
                 const float* __restrict__ dxin, float* __restrict__ dxm, float* __restrict__ dx,
                 float* __restrict__ da_partial) {
-  __shared__ float red[4 * 2 * DS_MAXH0];
+  // one wave per workgroup (GR / 64 of them: 16 K nodes are 256 workgroups, not 64)
   constexpr bool ANYM = NC == 2 || M0;
   constexpr int CM = NC - 1;                                     // index of the masked copy when there is one
-  const int64_t node = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t node = (int64_t)blockIdx.x * 64 + threadIdx.x;
   float da[2 * DS_MAXH0];
 #pragma unroll
   for (int h = 0; h < 2 * DS_MAXH0; ++h) da[h] = 0.f;
@@ -576,7 +780,13 @@ k_ds_mask_nodes(int64_t GR, int R, int H0, const float* __restrict__ x, const fl
     const int r = (int)(node % R);
     float du = 0.f, dvv = 0.f;
     if (ANYM) {
-      for (int p = 0; p < R / 16; ++p) du += dup[(int64_t)p * GR + node];
+      // R / 16 partials (a multiple of 4): four independent loads per trip, not a chain of waits
+      float d4[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int p = 0; p < R / 16; p += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d4[k] += dup[(int64_t)(p + k) * GR + node];
+      }
+      du = (d4[0] + d4[1]) + (d4[2] + d4[3]);
       dvv = dv[node];
     }
 #pragma unroll
@@ -596,35 +806,34 @@ k_ds_mask_nodes(int64_t GR, int R, int H0, const float* __restrict__ x, const fl
       }
   }
   if (!ANYM) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int h = 0; h < 2 * DS_MAXH0; ++h) {
-    const float s = wave_sum(da[h]);
-    if (lane == 0) red[w * 2 * DS_MAXH0 + h] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < 2 * H0) {
-    const int h = threadIdx.x < H0 ? threadIdx.x : DS_MAXH0 + (threadIdx.x - H0);
-    float s = 0.f;
-    for (int ww = 0; ww < 4; ++ww) s += red[ww * 2 * DS_MAXH0 + h];
-    da_partial[(int64_t)blockIdx.x * 2 * H0 + threadIdx.x] = s;
+    const float s = wave_sum(da[h]);                             // valid in lane 0
+    if (threadIdx.x == 0 && (h < H0 || (h >= DS_MAXH0 && h - DS_MAXH0 < H0)))
+      da_partial[(int64_t)blockIdx.x * 2 * H0 + (h < DS_MAXH0 ? h : H0 + h - DS_MAXH0)] = s;
   }
 }
 
-// d prob[r,h] = sum_g dxm[g,r,h] x[g,r,h] + the regulariser's gradient ; d snps_prob = the regulariser's gradient
+// d prob[r,h] = sum_g dxm[g,r,h] x[g,r,h] + the regulariser's gradient ; d snps_prob = the regulariser's gradient.
+// 8 lanes share an item and split the graphs (a thread per item walked 32 graphs serially on 7 workgroups: 10 us).
 __global__ void __launch_bounds__(256)
 k_ds_dprob(int64_t G, int R, int H0, const float* __restrict__ x, const float* __restrict__ prob,
            const float* __restrict__ dxm, const float* __restrict__ snps_prob, int n_snps,
            const float* __restrict__ greg, DsReg rg, float* __restrict__ dprob, float* __restrict__ dsnps) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3), gs = threadIdx.x & 7;
   const int np = R * H0;
   const float gr = greg ? greg[0] : 0.f;
   if (i < np) {
     float s = 0.f;
-    for (int64_t g = 0; g < G; ++g) s += dxm[g * np + i] * x[g * np + i];
-    const float p = ds_sigmoid(prob[i]);
-    dprob[i] = s + gr * ds_reg_grad(p, rg.l1_x, rg.ent_x, rg.eps) * p * (1.f - p) / (float)np;
-  } else if (i < np + n_snps && dsnps) {
+    for (int64_t g = gs; g < G; g += 8) s += dxm[g * np + i] * x[g * np + i];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (gs == 0) {
+      const float p = ds_sigmoid(prob[i]);
+      dprob[i] = s + gr * ds_reg_grad(p, rg.l1_x, rg.ent_x, rg.eps) * p * (1.f - p) / (float)np;
+    }
+  } else if (i < np + n_snps && dsnps && gs == 0) {
     const int k = i - np;
     const float p = ds_sigmoid(snps_prob[k]);
     dsnps[k] = gr * ds_reg_grad(p, rg.l1_x, rg.ent_x, rg.eps) * p * (1.f - p) / (float)n_snps;
@@ -668,10 +877,13 @@ extern "C" int igcn_dense_sgcn_fwd(int64_t n_graphs, int R, int H0, int F, int L
     hipLaunchKernelGGL(k_ds_prep, dim3((unsigned)igcn_cdiv(GR, 256)), dim3(256), 0, st, GR, R, H0, x, prob, prob_bias,
                        ws + o.u, ws + o.v, snps_prob, snps_prob ? n_snps : 0, rg, regp ? regp + (nreg - 1) : nullptr);
   }
-  const dim3 eg((unsigned)(R / 64), (unsigned)n_graphs);
+  const dim3 eg((unsigned)(n_graphs * (R / 64)));            // 1-D: ds_block maps ids to (graph, block), XCD-aware
   const float inv_ne = 1.0f / (float)((double)n_graphs * R * R);
-  DS_DISPATCH(hipLaunchKernelGGL((k_ds_deg<NC, M0>), eg, dim3(512), 0, st, R, GR, ew, ws + o.u, ws + o.v, ws + o.dis, rg,
-                                 inv_ne, regp));
+  const bool pipe = R == 256 || R == 512;              // pipelined walks need whole chunk pairs (R % 256 == 0); the LDS-
+                                                       // staged transposed aggregation additionally R <= 512
+#define DS_PIPE(...) if (pipe) { constexpr bool PIPE = true; __VA_ARGS__; } else { constexpr bool PIPE = false; __VA_ARGS__; }
+  DS_DISPATCH(DS_PIPE(hipLaunchKernelGGL((k_ds_deg<NC, M0, PIPE>), eg, dim3(512), 0, st, R, GR, ew, ws + o.u, ws + o.v,
+                                         ws + o.dis, rg, inv_ne, regp)));
   DS_DISPATCH(hipLaunchKernelGGL((k_ds_h0<NC, M0>), dim3((unsigned)igcn_cdiv((int64_t)copies * GR * DS_F, 256)),
                                  dim3(256), 0, st, GR, R, H0, x, prob, W[0], ws + o.dis, ws + o.hp));
   const size_t lds = (size_t)(8 * copies * 64 * DS_F + copies * 64 * DS_F) * sizeof(float);
@@ -679,9 +891,10 @@ extern "C" int igcn_dense_sgcn_fwd(int64_t n_graphs, int R, int H0, int F, int L
     const float* hp = ws + o.hp + (int64_t)l * copies * GR * DS_F;
     float* hpn = l + 1 < L ? ws + o.hp + (int64_t)(l + 1) * copies * GR * DS_F : nullptr;
     float* ag = ws + o.agg + (int64_t)l * copies * GR * DS_F;
-    DS_DISPATCH(if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS((k_ds_agg<NC, M0>));
-                hipLaunchKernelGGL((k_ds_agg<NC, M0>), eg, dim3(512), lds, st, R, GR, ew, ws + o.u, ws + o.v, ws + o.dis,
-                                   hp, b[l], l + 1 < L ? W[l + 1] : nullptr, ag, xcat, L * DS_F, l * DS_F, hpn));
+    DS_DISPATCH(DS_PIPE(if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS((k_ds_agg<NC, M0, PIPE>));
+                        hipLaunchKernelGGL((k_ds_agg<NC, M0, PIPE>), eg, dim3(512), lds, st, R, GR, ew, ws + o.u, ws + o.v,
+                                           ws + o.dis, hp, b[l], l + 1 < L ? W[l + 1] : nullptr, ag, xcat, L * DS_F,
+                                           l * DS_F, hpn)));
   }
   IGCN_CHECK_LAUNCH("dense_sgcn_fwd");
   return IGCN_OK;
@@ -702,14 +915,17 @@ extern "C" int igcn_dense_sgcn_bwd(int64_t n_graphs, int R, int H0, int F, int L
   const DsBws q = ds_bws(GR, R, H0, L, copies);
   const DsReg rg = {l1_x, ent_x, l1_e, ent_e, eps};
   const int ldx = L * DS_F;
-  const dim3 eg((unsigned)(R / 64), (unsigned)n_graphs);
+  const bool pipe = R == 256 || R == 512;
+  const dim3 eg((unsigned)(n_graphs * (R / 64)));            // 1-D: ds_block maps ids to (graph, block), XCD-aware
   const int64_t lsz = (int64_t)copies * GR * DS_F;                    // one layer of hp / agg / gp
   const float* dis = ws + o.dis;
   hipLaunchKernelGGL(k_ds_node_top, dim3((unsigned)q.nblk), dim3(256), 0, st, GR, L, xcat, dxcat, ldx, dis,
                      bws + q.gp + (int64_t)(L - 1) * lsz, bws + q.pdb + (int64_t)(L - 1) * q.nblk * DS_F);
   for (int l = L - 1; l >= 0; --l) {
-    DS_DISPATCH(hipLaunchKernelGGL((k_ds_aggT<NC, M0>), eg, dim3(512), 0, st, R, GR, ew, ws + o.u, ws + o.v,
-                                   bws + q.gp + (int64_t)l * lsz, bws + q.dhp));
+    const size_t ldt = (size_t)(2 * 4 * copies * 16 * DS_F + (pipe ? copies * DS_F * (R + 4) + R : 0)) * sizeof(float);
+    DS_DISPATCH(DS_PIPE(if (ldt > 64 * 1024) IGCN_ALLOW_BIG_LDS((k_ds_aggT<NC, M0, PIPE>));
+                        hipLaunchKernelGGL((k_ds_aggT<NC, M0, PIPE>), eg, dim3(512), ldt, st, R, GR, ew, ws + o.u, ws + o.v,
+                                           bws + q.gp + (int64_t)l * lsz, bws + q.dhp)));
     DS_DISPATCH(hipLaunchKernelGGL(
         (k_ds_node_mid<NC, M0>), dim3((unsigned)q.nblk), dim3(256), 0, st, GR, R, H0, L, l, x, prob, xcat, dxcat, ldx, dis,
         W[l], ws + o.hp + (int64_t)l * lsz, ws + o.agg + (int64_t)l * lsz, bws + q.gp + (int64_t)l * lsz, bws + q.dhp,
@@ -722,8 +938,8 @@ extern "C" int igcn_dense_sgcn_bwd(int64_t n_graphs, int R, int H0, int F, int L
     const float* gpm = bws + q.gp + (int64_t)cm * GR * DS_F;
     const float* hpm = ws + o.hp + (int64_t)cm * GR * DS_F;
 #define DS_MB(LV)                                                                                                       \
-  hipLaunchKernelGGL((k_ds_mask_bwd<LV>), eg, dim3(256), 0, st, R, GR, ew, ws + o.u, ws + o.v, gpm, hpm, lsz,            \
-                     bws + q.ddeg, d_reg, rg, inv_ne, bws + q.dup, bws + q.dv)
+  DS_PIPE(hipLaunchKernelGGL((k_ds_mask_bwd<LV, PIPE>), eg, dim3(512), 0, st, R, GR, ew, ws + o.u, ws + o.v, gpm, hpm, lsz, \
+                             bws + q.ddeg, d_reg, rg, inv_ne, bws + q.dup, bws + q.dv))
     switch (L) {
       case 1: DS_MB(1); break;
       case 2: DS_MB(2); break;
@@ -732,11 +948,11 @@ extern "C" int igcn_dense_sgcn_bwd(int64_t n_graphs, int R, int H0, int F, int L
     }
 #undef DS_MB
   }
-  DS_DISPATCH(hipLaunchKernelGGL((k_ds_mask_nodes<NC, M0>), dim3((unsigned)q.nblk2), dim3(256), 0, st, GR, R, H0, x,
+  DS_DISPATCH(hipLaunchKernelGGL((k_ds_mask_nodes<NC, M0>), dim3((unsigned)q.nblk2), dim3(64), 0, st, GR, R, H0, x,
                                  prob, prob_bias, bws + q.dup, bws + q.dv, bws + q.dxin, bws + q.dxm, dx, bws + q.pda));
   if (anym) {
     const int np = R * H0 + (dsnps_prob ? n_snps : 0);
-    hipLaunchKernelGGL(k_ds_dprob, dim3((unsigned)igcn_cdiv(np, 256)), dim3(256), 0, st, n_graphs, R, H0, x, prob,
+    hipLaunchKernelGGL(k_ds_dprob, dim3((unsigned)igcn_cdiv(np, 32)), dim3(256), 0, st, n_graphs, R, H0, x, prob,
                        bws + q.dxm, snps_prob, dsnps_prob ? n_snps : 0, d_reg, rg, dprob, dsnps_prob);
   }
   IGCN_CHECK_LAUNCH("dense_sgcn_bwd");

@@ -32,7 +32,7 @@ def test_complete_graphs_are_detected_and_anything_else_is_not():
     from igcn_amd import _lib, ops
     b = _batch(3, 64, 1).to("cuda")
     plan = ops.plan_for(b)
-    assert plan.dense_blocks and plan._tiled
+    assert plan.dense_blocks
     plan.check()
     # the same edges in another order: not row-major -> general kernels
     ei = b.edge_index.clone()
