@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 301        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 302        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -37,7 +37,7 @@ SIGNATURES = {
     "igcn_sgcn_stack_lds_bytes": (Z, [I, I, I, I, I, I]),
     "igcn_sgcn_stack_param_floats": (I, [I, I, I]),
     "igcn_sgcn_stack_fwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "igcn_sgcn_stack_bwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_sgcn_stack_bwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_dense_blocks_check": (I, [L, I, P, P, P]),
     "igcn_dense_sgcn_supported": (I, [I, I, I, I]),
     "igcn_dense_sgcn_ws_floats": (Z, [L, I, I, I]),
@@ -83,7 +83,8 @@ SIGNATURES = {
     "igcn_bn1d_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_dropout_state_words": (I, []),
     "igcn_dropout_max_segments": (I, []),
-    "igcn_dropout_masks": (I, [L, I, P, P, P, P, P]),
+    "igcn_dropout_masks": (I, [L, I, P, P, P, P, I, P, L, P]),
+    "igcn_sum_n": (I, [L, I, P, P, P]),
     "igcn_mask_reg_blocks": (I, [L]),
     "igcn_mask_reg_fwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P]),
     "igcn_mask_reg_bwd": (I, [L, L, L, P, P, P, F, F, F, F, F, P, P, P, P, P]),

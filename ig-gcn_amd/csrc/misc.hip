@@ -261,6 +261,44 @@ k_concat_cols(int64_t rows, int F, int nparts, CatParts parts, float* __restrict
   reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(src)[r * fq + q];
 }
 
+// out = sum of n <= 4 tensors of `numel` floats (16 bytes per lane, scalar tail).  The gradient of a tensor with several
+// consumers: autograd would add the incoming gradients pairwise, one launch per add (ops.GradFan).
+struct SumParts {
+  const float* p[4];
+};
+__global__ void __launch_bounds__(256) k_sum_n(int64_t numel, int n, SumParts sp, float* __restrict__ out) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 + 3 < numel && n >= 1) {
+    float4 a = *reinterpret_cast<const float4*>(sp.p[0] + i4);
+    for (int k = 1; k < n; ++k) {
+      const float4 b = *reinterpret_cast<const float4*>(sp.p[k] + i4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    *reinterpret_cast<float4*>(out + i4) = a;
+  } else {
+    for (int64_t i = i4; i < numel && i < i4 + 4; ++i) {
+      float a = sp.p[0][i];
+      for (int k = 1; k < n; ++k) a += sp.p[k][i];
+      out[i] = a;
+    }
+  }
+}
+
+extern "C" int igcn_sum_n(int64_t numel, int n, const float* const* parts /*HOST array*/, float* out, void* stream) {
+  IGCN_REQUIRE(numel >= 0 && n >= 1 && n <= 4 && parts && out, "sum_n: 1..4 parts");
+  SumParts sp = {};
+  for (int k = 0; k < n; ++k) {
+    IGCN_REQUIRE(parts[k] != nullptr && ((uintptr_t)parts[k] & 15) == 0, "sum_n: parts must be 16-byte aligned");
+    sp.p[k] = parts[k];
+  }
+  IGCN_REQUIRE(((uintptr_t)out & 15) == 0, "sum_n: out must be 16-byte aligned");
+  if (numel == 0) return IGCN_OK;
+  hipLaunchKernelGGL(k_sum_n, dim3((unsigned)igcn_cdiv(numel, 1024)), dim3(256), 0, (hipStream_t)stream, numel, n, sp,
+                     out);
+  IGCN_CHECK_LAUNCH("sum_n");
+  return IGCN_OK;
+}
+
 extern "C" int igcn_concat_cols(int64_t rows, int F, int nparts, const float* const* parts /*HOST array*/, float* out,
                                 void* stream) {
   IGCN_REQUIRE(rows >= 0 && F > 0 && F % 4 == 0 && nparts >= 1 && nparts <= 4, "concat_cols: F %% 4 == 0, <= 4 parts");
@@ -727,6 +765,15 @@ struct DropSegs {
   float p[DM_MAXSEG];
   int n;
 };
+// int64 device counters the launch bumps by `inc` (BatchNorm's num_batches_tracked of the model's five BatchNorms: the
+// masks are drawn once per training forward, which is exactly when those counters advance — a torch._foreach_add_
+// launch less per step)
+#define DM_MAXCNT 8
+struct DropCounters {
+  long long* c[DM_MAXCNT];
+  int n;
+  long long inc;
+};
 
 __device__ __forceinline__ uint32_t dm_hash(uint32_t x) {       // lowbias32
   x ^= x >> 16; x *= 0x7feb352dU;
@@ -742,7 +789,9 @@ __device__ __forceinline__ uint32_t dm_hash(uint32_t x) {       // lowbias32
 #define DM_GROUPS 16
 #define DM_WORDS (2 + 32 * DM_GROUPS)
 __global__ void __launch_bounds__(256)
-k_dropout_masks(int64_t total, DropSegs segs, unsigned long long* __restrict__ state, float* __restrict__ out) {
+k_dropout_masks(int64_t total, DropSegs segs, unsigned long long* __restrict__ state, float* __restrict__ out,
+                DropCounters cnt) {
+  if (blockIdx.x == 0 && threadIdx.x < cnt.n) *cnt.c[threadIdx.x] += cnt.inc;
   const unsigned long long c = state[0];
   const uint32_t k0 = dm_hash((uint32_t)c ^ 0x9E3779B9u), k1 = dm_hash((uint32_t)(c >> 32) + 0x85EBCA6Bu + k0);
   for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < total; i0 += (int64_t)gridDim.x * 1024) {
@@ -786,7 +835,14 @@ extern "C" int igcn_dropout_max_segments(void) { return DM_MAXSEG; }
 
 extern "C" int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end /*HOST*/,
                                   const float* seg_p /*HOST*/, void* state /*device uint64[2]*/, float* out,
-                                  void* stream) {
+                                  int n_counters, int64_t* const* counters /*HOST array of device pointers*/,
+                                  int64_t counter_inc, void* stream) {
+  IGCN_REQUIRE(n_counters >= 0 && n_counters <= DM_MAXCNT && (n_counters == 0 || counters != nullptr),
+               "dropout_masks: at most %d counters", DM_MAXCNT);
+  DropCounters cnt = {};
+  cnt.n = n_counters;
+  cnt.inc = counter_inc;
+  for (int k = 0; k < n_counters; ++k) cnt.c[k] = (long long*)counters[k];
   IGCN_REQUIRE(total > 0 && n_segments >= 1 && n_segments <= DM_MAXSEG && state != nullptr &&
                ((uintptr_t)out & 15) == 0, "dropout_masks: 1..%d segments, 16-byte aligned output", DM_MAXSEG);
   DropSegs sg = {};
@@ -802,7 +858,7 @@ extern "C" int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* 
   int64_t blocks = igcn_cdiv(total, 1024);
   blocks = blocks > 2048 ? 2048 : blocks;
   hipLaunchKernelGGL(k_dropout_masks, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, total, sg,
-                     (unsigned long long*)state, out);
+                     (unsigned long long*)state, out, cnt);
   IGCN_CHECK_LAUNCH("dropout_masks");
   return IGCN_OK;
 }

@@ -393,6 +393,7 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
                  const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
                  const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_perm,
                  const int32_t* __restrict__ loop_edge, SfParams prm, const float* __restrict__ dxcat,
+                 const float* __restrict__ dxcat2 /*a second consumer's gradient, added on load; or NULL*/,
                  float* __restrict__ dx_in, float* __restrict__ dew_in, float* __restrict__ dpar_partial, int P,
                  int32_t* __restrict__ status) {
   extern __shared__ float sf_lds[];
@@ -408,6 +409,14 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
   for (int j = 0; j < 2; ++j)
     dyv[j] = tid + j * SF_TB < R * D / 4 ? reinterpret_cast<const float4*>(dxcat + nb * D)[tid + j * SF_TB]
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (dxcat2) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (tid + j * SF_TB < R * D / 4) {
+        const float4 b = reinterpret_cast<const float4*>(dxcat2 + nb * D)[tid + j * SF_TB];
+        dyv[j].x += b.x; dyv[j].y += b.y; dyv[j].z += b.z; dyv[j].w += b.w;
+      }
+  }
   const int ne = sf_stage<true>(sf_lds, o, R, Emax, H0, nb, x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, src_ptr,
                                 src_perm, loop_edge, prm, F, L, status);
   if (ne < 0) {                                        // refused graph: defined (zero) outputs, flagged in `status`
@@ -424,7 +433,14 @@ k_sgcn_stack_bwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
   for (int j = 0; j < 2; ++j)
     if (tid + j * SF_TB < R * D / 4) reinterpret_cast<float4*>(sf_lds + o.dycat)[tid + j * SF_TB] = dyv[j];
   for (int e = tid + 2 * SF_TB; e < R * D / 4; e += SF_TB)
-    reinterpret_cast<float4*>(sf_lds + o.dycat)[e] = reinterpret_cast<const float4*>(dxcat + nb * D)[e];
+  {
+    float4 a = reinterpret_cast<const float4*>(dxcat + nb * D)[e];
+    if (dxcat2) {
+      const float4 b = reinterpret_cast<const float4*>(dxcat2 + nb * D)[e];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(sf_lds + o.dycat)[e] = a;
+  }
   // ---- forward, every transform kept: H_l at act + l R F; outputs in the concatenated layout
   float* Ycat = sf_lds + o.ycat;
   for (int l = 0; l < L; ++l) {
@@ -710,12 +726,14 @@ extern "C" int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H
                                    const float* ew_in, const int32_t* src32, const int32_t* dst32,
                                    const int32_t* tgt_ptr, const int32_t* tgt_perm, const int32_t* src_ptr,
                                    const int32_t* src_perm, const int32_t* loop_edge, const float* const* W,
-                                   const float* const* b, const float* dxcat, float* dx_in, float* dew_in,
+                                   const float* const* b, const float* dxcat, const float* dxcat2, float* dx_in,
+                                   float* dew_in,
                                    float* dparams /*[param_floats]*/, float* scratch /*[n_graphs * param_floats]*/,
                                    int32_t* status /*device word or NULL*/, void* stream) {
   int rc = sf_check("sgcn_stack_bwd", n_graphs, R, max_edges, H0, F, L, 1);
   if (rc) return rc;
-  IGCN_REQUIRE(((uintptr_t)dxcat & 15) == 0, "sgcn_stack_bwd: dxcat must be 16-byte aligned");
+  IGCN_REQUIRE(((uintptr_t)dxcat & 15) == 0 && ((uintptr_t)dxcat2 & 15) == 0,
+               "sgcn_stack_bwd: dxcat / dxcat2 must be 16-byte aligned");
   SfParams prm = {};
   for (int l = 0; l < L; ++l) { prm.W[l] = W[l]; prm.b[l] = b[l]; }
   const size_t lds = igcn_sgcn_stack_lds_bytes(R, max_edges, H0, F, L, 1);
@@ -726,7 +744,7 @@ extern "C" int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H
     if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS((k_sgcn_stack_bwd<FV>));                                              \
     hipLaunchKernelGGL((k_sgcn_stack_bwd<FV>), dim3((unsigned)n_graphs), dim3(SF_TB), lds, st, R, max_edges, H0, L, \
                        x_in, ew_in, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm, loop_edge, prm, dxcat,     \
-                       dx_in, dew_in, scratch, P, status);                                                         \
+                       dxcat2, dx_in, dew_in, scratch, P, status);                                                 \
   }
   switch (F) {
     case 4: SF_BWD(4) break;

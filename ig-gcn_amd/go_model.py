@@ -90,7 +90,12 @@ class Gene_ontology_network(nn.Module):
         self._dropout_enabled = True        # parity tests switch every dropout off
 
     # ---------------------------------------------------------------------------------------------
-    def _dropout_masks(self, b, dev, extra=()):
+    def _batch_counters(self):
+        """num_batches_tracked of the BatchNorms this forward runs in training mode (go_model.py:119-146)."""
+        bns = (self.conc_for_attention[1], self.B[0], self.B_D[0], self.latent[1], self.latent[5])
+        return [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
+
+    def _dropout_masks(self, b, dev, extra=(), groups=1):
         """Every dropout of this forward pass from ONE kernel launch (igcn_dropout_masks), as {0, 1/(1-p)} factors
         that the consumers multiply by inside their own kernels:
           * nn.Dropout2d(0.4) on [B,N,f] (:104,113) zeroes whole nodes per sample -> ``ln`` [B,n] per LayerNorm site;
@@ -107,7 +112,10 @@ class Gene_ontology_network(nn.Module):
         sites = [((b, n), self.node_dropout_p) for n in ln_sizes]
         sites += [((b, self.n_top), 0.5), ((b, self.n_nodes), 0.5), ((b, self.latent[0].weight.shape[0]), 0.5)]
         sites += list(extra)
-        m = ops.dropout_masks(sites, state)
+        # the launch that draws the masks also advances the BatchNorm batch counters (one torch launch less per step)
+        cnt = self._batch_counters()
+        m = ops.dropout_masks(sites, state, cnt, groups)
+        self._counters_done = bool(cnt)
         k = len(ln_sizes)
         return {"ln": m[:k], "inp": m[k], "out_d": m[k + 1], "h": m[k + 2]}, m[k + 3:]
 
@@ -135,7 +143,8 @@ class Gene_ontology_network(nn.Module):
         left in ``self.extra_masks``."""
         bsz, dev = data.shape[0], data.device
         self._tracked = []
-        masks, self.extra_masks = self._dropout_masks(bsz, dev, extra_dropout)
+        self._counters_done = False
+        masks, self.extra_masks = self._dropout_masks(bsz, dev, extra_dropout, groups)
         keeps = masks["ln"]
         # gene encoding (:208-215)
         x = ops.SparseMap.apply(data, self.gene_csr, *self.t)                            # [B, in_f, N]
@@ -150,11 +159,17 @@ class Gene_ontology_network(nn.Module):
         bn_a, bn_i = self.conc_for_attention[1], self.B[0]
         if ops.node_linear_bn_pair_supported(x, self.conc_for_attention[0].weight, self.conc.weight, None) \
                 and os.environ.get("IGCN_NO_READOUT_PAIR", "0") != "1":
-            # both read-outs of the encoder output in paired launches (and one input gradient back)
+            # both read-outs of the encoder output in paired launches.  The encoder output has three consumers (two
+            # read-outs, the decoder): their gradients are summed in one launch (ops.GradFan), not by two adds
+            x_alias = None
+            if x.requires_grad and x.is_cuda and os.environ.get("IGCN_NO_GRAD_FAN", "0") != "1":
+                x_pair, x_alias, x = ops.GradFan.apply(x, 3)
+            else:
+                x_pair = x
             if self.training:
                 self._tracked += [bn.num_batches_tracked for bn in (bn_a, bn_i) if bn.track_running_stats]
             atten_out, inp_out = ops.NodeLinearBNPair.apply(
-                x, self.conc_for_attention[0].weight, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var,
+                x_pair, x_alias, self.conc_for_attention[0].weight, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var,
                 bn_a.momentum, bn_a.eps, self.conc.weight, bn_i.weight, bn_i.bias, bn_i.running_mean, bn_i.running_var,
                 bn_i.momentum, bn_i.eps, masks["inp"], self.training, groups)
             inp_out = inp_out.squeeze(2)
@@ -173,9 +188,9 @@ class Gene_ontology_network(nn.Module):
         # latent projection (:138-146,285)
         h = self._bn_relu(ops.linear(inp_out.view(bsz, -1), self.latent[0].weight), self.latent[1], groups, masks["h"])
         latent = self._bn_relu(ops.linear(h, self.latent[4].weight), self.latent[5], groups)
-        if self._tracked:                              # num_batches_tracked of the five BatchNorms: one launch
-            torch._foreach_add_(self._tracked, groups)
-            self._tracked = []
+        if self._tracked and not self._counters_done:  # num_batches_tracked of the five BatchNorms: one launch (with
+            torch._foreach_add_(self._tracked, groups)  # dropout on, the mask launch has advanced them already)
+        self._tracked = []
         zeros3 = getattr(self, "_zeros3", None)          # placeholder of the reference's unused third output
         if zeros3 is None or zeros3.device != dev:
             zeros3 = self._zeros3 = torch.zeros(3, device=dev)

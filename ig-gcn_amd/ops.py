@@ -417,6 +417,35 @@ class GcnPropagate(torch.autograd.Function):
         return dh, dwhat, dwloop, dbias, None, None, None, None
 
 
+class GradFan(torch.autograd.Function):
+    """``a, b[, c, d] = GradFan.apply(t, k)``: k aliases of ``t`` for k consumers.  The backward sums the k incoming
+    gradients in ONE launch (igcn_sum_n) — autograd left to itself adds them pairwise, a library launch per add (seven
+    per train step: the encoder output's three consumers, ``prob``'s three, ``data.x``, ``snps_prob``)."""
+
+    @staticmethod
+    def forward(ctx, t, k):
+        ctx.set_materialize_grads(False)
+        return tuple(t.view_as(t) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        ok = all(g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() % 16 == 0 for g in gs)
+        if not ok or len(gs) > 4:
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None
+        out = torch.empty_like(gs[0])
+        arr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+        call("igcn_sum_n", out.numel(), len(gs), arr, ptr(out), stream_ptr())
+        return out, None
+
+
 def sgcn_stack_supported(plan, rois, h0, f, layers):
     """The LDS-resident SGCN stack (igcn_sgcn_stack_*) covers this batch: per-graph plan of uniform graphs (block
     diagonal, verified by the builder), supported widths, and the graph fits LDS."""
@@ -434,6 +463,10 @@ class SgcnStack(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_in, ew_in, plan, rois, *wb):
+        """``rois`` negative: DUAL output — returns (xcat, xcat) as two autograd outputs sharing one buffer, for the two
+        consumers of the model (attention query, head inputs); their gradients are added by the backward kernel while it
+        stages the rows, instead of by an autograd add in front of it."""
+        dual, rois = rois < 0, abs(rois)
         x_in, ew_in = _f32(x_in), _f32(ew_in)
         wb = [_f32(t) for t in wb]
         ws, bs = wb[0::2], wb[1::2]
@@ -449,14 +482,22 @@ class SgcnStack(torch.autograd.Function):
         ctx.save_for_backward(x_in, ew_in, *wb)
         ctx.plan, ctx.rois = plan, rois
         ctx.final = _leaves(*wb)
+        if dual:
+            ctx.set_materialize_grads(False)
+            return xcat, xcat.view(n, layers * f)
         return xcat
 
     @staticmethod
-    def backward(ctx, dxcat):
+    def backward(ctx, dxcat, dxcat2=None):
         x_in, ew_in, *wb = ctx.saved_tensors
         ws, bs = wb[0::2], wb[1::2]
         plan, rois = ctx.plan, ctx.rois
+        if dxcat is None:
+            dxcat, dxcat2 = dxcat2, None
+        if dxcat is None:
+            dxcat = torch.zeros(x_in.shape[0], len(ws) * ws[0].shape[0], dtype=torch.float32, device=x_in.device)
         dxcat = _f32(dxcat)
+        dxcat2 = _f32(dxcat2) if dxcat2 is not None else None
         n, h0 = x_in.shape
         f, layers = ws[0].shape[0], len(ws)
         emax = plan._stack_dims[1]
@@ -471,8 +512,8 @@ class SgcnStack(torch.autograd.Function):
         with _immediate(ctx.final):
             call("igcn_sgcn_stack_bwd", g, rois, emax, h0, f, layers, ptr(x_in), ptr(ew_in), ptr(plan.src32),
                  ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm),
-                 ptr(plan.loop_edge), wp, bp, ptr(dxcat), ptr(dx), ptr(dew), ptr(dpar), ptr(scratch), ptr(plan.status),
-                 stream_ptr())
+                 ptr(plan.loop_edge), wp, bp, ptr(dxcat), ptr(dxcat2), ptr(dx), ptr(dew), ptr(dpar), ptr(scratch),
+                 ptr(plan.status), stream_ptr())
         grads, off = [], 0
         for l in range(layers):
             fin = h0 if l == 0 else f
@@ -1097,8 +1138,9 @@ class DropoutState:
         self.state[0] = seed
 
 
-def dropout_masks(sites, state):
-    """``sites``: [(shape, p), ...] -> list of float tensors of {0, 1/(1-p)} factors, drawn by ONE kernel launch."""
+def dropout_masks(sites, state, counters=(), inc=0):
+    """``sites``: [(shape, p), ...] -> list of float tensors of {0, 1/(1-p)} factors, drawn by ONE kernel launch.
+    ``counters`` (<= 8 int64 device scalars): bumped by ``inc`` by the same launch (BatchNorm's num_batches_tracked)."""
     import math
     sizes = [int(math.prod(shape)) for shape, _ in sites]
     # every site starts on a 16-byte boundary (its consumers read it with 16-byte loads)
@@ -1114,8 +1156,10 @@ def dropout_masks(sites, state):
         base = starts[k0]
         seg_end = (ctypes.c_int64 * (k1 - k0))(*[e - base for e in ends[k0:k1]])
         seg_p = (ctypes.c_float * (k1 - k0))(*[float(p) for _, p in sites[k0:k1]])
+        cnt = list(counters) if k0 == 0 else []
+        carr = (ctypes.c_void_p * max(len(cnt), 1))(*[c.data_ptr() for c in cnt])
         call("igcn_dropout_masks", ends[k1 - 1] - base, k1 - k0, seg_end, seg_p, ptr(state.state), ptr(out[base:]),
-             stream_ptr())
+             len(cnt), carr, int(inc), stream_ptr())
     return [out[s0:s0 + n].view(*shape) for (shape, _), s0, n in zip(sites, starts, sizes)]
 
 
@@ -1432,7 +1476,12 @@ class NodeLinearBNPair(torch.autograd.Function):
     backward for both, and ONE input gradient (the sum of the two) handed back to autograd."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, rm1, rv1, mom1, eps1, w2, g2, b2, rm2, rv2, mom2, eps2, keep2, training, groups):
+    def forward(ctx, x, x_alias, w1, g1, b1, rm1, rv1, mom1, eps1, w2, g2, b2, rm2, rv2, mom2, eps2, keep2, training,
+                groups):
+        """``x_alias``: a second autograd handle of the same tensor (ops.GradFan) or None.  With it the two read-outs'
+        input gradients go back separately — the caller's GradFan sums them together with the decoder's in one launch
+        — instead of being added here."""
+        ctx.split = x_alias is not None
         x, w1, g1, b1, w2, g2, b2 = (_f32(t) for t in (x, w1, g1, b1, w2, g2, b2))
         keep2 = _f32(keep2) if keep2 is not None else None
         b, f, n = x.shape
@@ -1475,9 +1524,12 @@ class NodeLinearBNPair(torch.autograd.Function):
                  d1, ptr(w1), ptr(g1), ptr(b1), ptr(mean1), ptr(rstd1), ptr(dout1), ptr(dx1), ptr(dw1), ptr(dgb1), ptr(s1),
                  d2, ptr(w2), ptr(g2), ptr(b2), ptr(mean2), ptr(rstd2), ptr(dout2), ptr(keep2), ptr(dx2), ptr(dw2),
                  ptr(dgb2), ptr(s2), stream_ptr())
-        dx = dx1.add_(dx2)
-        return (dx, dw1, dgb1[0], dgb1[1], None, None, None, None, dw2, dgb2[0], dgb2[1], None, None, None, None, None,
-                None, None)
+        if ctx.split:
+            dxa, dxb = dx1, dx2
+        else:
+            dxa, dxb = dx1.add_(dx2), None
+        return (dxa, dxb, dw1, dgb1[0], dgb1[1], None, None, None, None, dw2, dgb2[0], dgb2[1], None, None, None, None,
+                None, None, None)
 
 
 def node_linear_bn_pair_supported(x, w1, w2, keep1):

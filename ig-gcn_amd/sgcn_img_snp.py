@@ -48,7 +48,7 @@ class GCNConv(torch.nn.Module):
 _WIDE = (4, 8, 16, 32, 64)          # widths the 16-byte-per-lane kernels (and the LDS-resident stack, <= 32) cover
 
 
-def sgcn_stack(convs, x_in, ew_in, plan_g, rois, fused=True, bf16=False):
+def sgcn_stack(convs, x_in, ew_in, plan_g, rois, fused=True, bf16=False, dual=False):
     """xcat = cat_l relu(GCNConv_l(.)) (kernel/sgcn_img_snp.py:218-224, kernel/sgcn.py:370-377) for the GCNConv list
     ``convs`` on the batched plan ``plan_g``.
 
@@ -68,6 +68,10 @@ def sgcn_stack(convs, x_in, ew_in, plan_g, rois, fused=True, bf16=False):
     n = x_in.shape[0]
     if (fused and not bf16 and x_in.is_cuda
             and ops.sgcn_stack_supported(plan_g, rois, x_in.shape[1], fp, len(convs))):
+        if dual and fp == f:
+            # two autograd handles of one buffer for the model's two consumers: their gradients meet inside the backward
+            # kernel (ops.SgcnStack), not in an autograd add in front of it
+            return ops.SgcnStack.apply(x_in, ew_in, plan_g, -rois, *[t for pair in zip(ws, bs) for t in pair])
         xcat = ops.SgcnStack.apply(x_in, ew_in, plan_g, rois, *[t for pair in zip(ws, bs) for t in pair])
     else:
         coef = ops.GcnNorm.apply(ew_in, plan_g)                       # once per pass (PyG: once per layer)
@@ -79,7 +83,7 @@ def sgcn_stack(convs, x_in, ew_in, plan_g, rois, fused=True, bf16=False):
         xcat = ops.concat_cols(hs)
     if fp != f:
         xcat = xcat.view(n, len(convs), fp)[:, :, :f].reshape(n, len(convs) * f)
-    return xcat
+    return (xcat, xcat) if dual else xcat
 
 
 def rbf_kernel_torch(X, Y, gamma=0.015):
@@ -200,7 +204,11 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             return self._dense_reg[0] if partials else self._dense_reg[0].sum()
         if edge_prob is None:
             _, _, _, edge_prob = self.cal_probability(x, edge_index, edge_weight, plan=plan)
-        return ops.MaskRegulariser.apply(self.prob, edge_prob, self.snps_prob, hp.lamda_x_l1, hp.lamda_x_ent,
+        # inside a train step the forward has handed out gradient aliases of prob / snps_prob (ops.GradFan)
+        prob = self._fan_prob if getattr(self, "_fan_prob", None) is not None else self.prob
+        sprob = self._fan_snps if getattr(self, "_fan_snps", None) is not None else self.snps_prob
+        self._fan_prob = self._fan_snps = None
+        return ops.MaskRegulariser.apply(prob, edge_prob, sprob, hp.lamda_x_l1, hp.lamda_x_ent,
                                          hp.lamda_e_l1, hp.lamda_e_ent, eps, partials)
 
     def laplacian(self, n, tsne_result=None):
@@ -277,6 +285,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         plan = ops.plan_for(data)
         self.last_edge_prob = None
         self._dense_reg = None
+        self._fan_prob = self._fan_snps = None
+        fan = x.is_cuda and torch.is_grad_enabled() and os.environ.get("IGCN_NO_GRAD_FAN", "0") != "1"
+        prob_m = prob_h = self.prob
+        x_m = x_h = x
         convs = [self.conv1, *self.convs]
         mode = {(False,): "plain", (True,): "masked", (False, True): "both"}.get(tuple(explain_flags))
         snps_ok = snps_feat is not None and snps_feat.is_cuda and snps_feat.dim() == 2 \
@@ -297,9 +309,17 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                 snps_in, _ = ops.SnpsMask.apply(snps_feat, self.snps_prob, mode == "both")
         elif (tuple(explain_flags) == (False, True) and x.is_cuda and snps_feat is not None and snps_feat.dim() == 2
                 and snps_feat.shape[1] == self.snps_prob.numel()):
-            # the train step's (plain | masked) pair: cal_probability writes both halves of the stacked batch itself
-            x_in, ew_in, e = ops.EdgeMaskStacked.apply(x, self.prob, self.prob_bias, edge_weight, plan, self.rois)
-            snps_in, _ = ops.SnpsMask.apply(snps_feat, self.snps_prob, True)
+            # the train step's (plain | masked) pair: cal_probability writes both halves of the stacked batch itself.
+            # prob (mask, head inputs, regulariser), data.x (mask, head inputs) and snps_prob (mask, regulariser) each
+            # feed several ops: ops.GradFan hands out aliases and sums their gradients in one launch per tensor
+            if fan:
+                prob_m, prob_h, self._fan_prob = ops.GradFan.apply(self.prob, 3)
+                x_m, x_h = ops.GradFan.apply(x, 2)
+                sp_m, self._fan_snps = ops.GradFan.apply(self.snps_prob, 2)
+            else:
+                sp_m = self.snps_prob
+            x_in, ew_in, e = ops.EdgeMaskStacked.apply(x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois)
+            snps_in, _ = ops.SnpsMask.apply(snps_feat, sp_m, True)
             self.last_edge_prob = e
         else:
             if any(explain_flags):
@@ -311,12 +331,16 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             stack = lambda ts: ts[0] if g == 1 else torch.cat(ts, dim=0)                       # noqa: E731
             x_in, ew_in, snps_in = stack(xs), stack(ews), stack(snps)
         bf = self.bf16_transforms
+        xcat_img = None
         if xcat is None:
             plan_g = plan.replicate(g)
-            xcat = sgcn_stack(convs, x_in, ew_in, plan_g, self.rois, self.fused_sgcn_stack, bf)
+            if fan and self.isCrossAtten and not self.graph_pool and not self.isImageOnly and not self.isSNPsOnly:
+                xcat, xcat_img = sgcn_stack(convs, x_in, ew_in, plan_g, self.rois, self.fused_sgcn_stack, bf, dual=True)
+            else:
+                xcat = sgcn_stack(convs, x_in, ew_in, plan_g, self.rois, self.fused_sgcn_stack, bf)
         gb = g * bsz
         batch_x = xcat.view(gb, self.rois, -1)                        # to_dense_batch == view (:226)
-        img_out = batch_x.reshape(gb, -1)
+        img_out = (xcat_img if xcat_img is not None else xcat).view(gb, -1)
         if self.graph_pool:                                           # :230-235 mean | max | add over a graph's nodes
             img_out = ops.GraphPool.apply(xcat, self.rois)
 
@@ -343,7 +367,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             out_lin = torch.cat((snps_in, latent), -1)
         else:
             use_prob = self.isuseProb4Regr
-            x_flat, prob_flat = (data.x.view(bsz, -1), self.prob.view(-1)) if use_prob else (None, None)
+            x_flat, prob_flat = (x_h.view(bsz, -1), prob_h.view(-1)) if use_prob else (None, None)
             if ops.head_inputs_supported(img_out, out_cross, latent, x_flat, prob_flat):
                 fused_head = True                                         # :284-297 in one launch
                 out_z, out_lin, feat = ops.HeadInputs.apply(img_out, out_cross, latent, x_flat, prob_flat, bsz)

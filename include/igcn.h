@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 301
+#define IGCN_ABI_VERSION 302
 int igcn_version(void);
 const char* igcn_last_error(void);
 
@@ -186,7 +186,8 @@ int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, int nodes_pe
  * row-major (Fin_0 = H0, then F), b_l [F].
  * Backward recomputes the forward in LDS; outputs dx_in [N, H0], dew_in [E] and dparams
  * [igcn_sgcn_stack_param_floats] = dW_0 | db_0 | dW_1 | db_1 | ... (scratch: n_graphs * that many floats; the sum over
- * graphs is a final reduction in the sense of igcn_reduce_defer). */
+ * graphs is a final reduction in the sense of igcn_reduce_defer).  dxcat2 (or NULL): the gradient of a second consumer
+ * of xcat, added to dxcat while the rows are staged (the attention query and the head inputs both read xcat). */
 size_t igcn_sgcn_stack_lds_bytes(int R, int max_edges, int H0, int F, int L, int backward);
 int igcn_sgcn_stack_param_floats(int H0, int F, int L);
 int igcn_sgcn_stack_fwd(int64_t n_graphs, int R, int max_edges, int H0, int F, int L, const float* x_in,
@@ -197,7 +198,8 @@ int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H0, int F, i
                         const float* ew_in, const int32_t* src32, const int32_t* dst32, const int32_t* tgt_ptr,
                         const int32_t* tgt_perm, const int32_t* src_ptr, const int32_t* src_perm,
                         const int32_t* loop_edge, const float* const* W, const float* const* b, const float* dxcat,
-                        float* dx_in, float* dew_in, float* dparams, float* scratch, int32_t* status, void* stream);
+                        const float* dxcat2, float* dx_in, float* dew_in, float* dparams, float* scratch,
+                        int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SGCN over DENSE brain graphs (BASELINE configs[4]): batches whose graphs are COMPLETE — all R x R (source, target)
@@ -419,7 +421,7 @@ int igcn_bn1d_bwd(int B, int C, int groups, int training, int relu, const float*
 
 /* Dropout factors of every site of a forward pass in ONE launch (the reference draws them site by site: nn.Dropout /
  * nn.Dropout2d / F.dropout, kernel/go_model.py:104,113,128,136,143, kernel/sgcn_img_snp.py:289,299).  out [total]:
- * element i of segment k (segments given by their END offsets, HOST arrays, <= 16) is 0 with probability seg_p[k],
+ * element i of segment k (segments given by their END offsets, HOST arrays, <= igcn_dropout_max_segments()) is 0 with probability seg_p[k],
  * else 1/(1-seg_p[k]); consumed as `keep` by igcn_nodes_ln_*, igcn_node_linear_bn_*, igcn_bn1d_*, igcn_small_linear_*.
  * Counter-based integer-hash generator; `state` = device uint64[igcn_dropout_state_words()], word 0 = the stream
  * counter (seed), every other word 0 (arrival counts, left at 0 by every launch): the last workgroup of a launch
@@ -427,7 +429,13 @@ int igcn_bn1d_bwd(int B, int C, int groups, int training, int relu, const float*
 int igcn_dropout_max_segments(void);   /* sites one igcn_dropout_masks launch takes; callers split longer lists */
 int igcn_dropout_state_words(void);
 int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end, const float* seg_p, void* state,
-                       float* out, void* stream);
+                       float* out, int n_counters, int64_t* const* counters, int64_t counter_inc, void* stream);
+/* counters (HOST array of <= 8 device int64 pointers, or n_counters = 0): each is bumped by counter_inc by the launch —
+ * BatchNorm's num_batches_tracked (kernel/go_model.py:119-146), which advance exactly when the masks are drawn.
+ *
+ * out[i] = sum_k parts[k][i], k < n <= 4 (HOST array of device pointers, 16-byte aligned): the gradient of a tensor
+ * with several consumers in one launch instead of autograd's pairwise adds (ops.GradFan). */
+int igcn_sum_n(int64_t numel, int n, const float* const* parts, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Mask regulariser — loss_probability, kernel/sgcn_img_snp.py:153-181:

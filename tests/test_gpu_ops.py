@@ -931,7 +931,7 @@ def test_node_linear_bn_pair_matches_two_readouts(groups, training):
     (rm1, rv1), (rm2, rv2), (qm1, qv1), (qm2, qv2) = stats(), stats(), stats(), stats()
     c1, c2 = torch.randn(b, n, d1, device="cuda"), torch.randn(b, n, 1, device="cuda")
     leaves = [x, w1, g1, b1, w2, g2, b2]
-    o1, o2 = ops.NodeLinearBNPair.apply(x, w1, g1, b1, rm1, rv1, 0.1, 1e-5, w2, g2, b2, rm2, rv2, 0.1, 1e-5, keep,
+    o1, o2 = ops.NodeLinearBNPair.apply(x, None, w1, g1, b1, rm1, rv1, 0.1, 1e-5, w2, g2, b2, rm2, rv2, 0.1, 1e-5, keep,
                                         training, groups)
     got = torch.autograd.grad((o1 * c1).sum() + (o2 * c2).sum(), leaves)
     z1 = ops.NodeLinearBN.apply(x, w1, g1, b1, qm1, qv1, training, 0.1, 1e-5, groups, None)

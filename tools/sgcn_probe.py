@@ -49,7 +49,7 @@ scratch = torch.empty((n // rois) * npar, device=dev)
 for _ in range(5):
     call("igcn_sgcn_stack_bwd", n // rois, rois, emax, h0, f, layers, ptr(x), ptr(ew), ptr(plan.src32), ptr(plan.dst32),
          ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm), ptr(plan.loop_edge), wp, bp,
-         ptr(dxcat), ptr(dx), ptr(dew), ptr(dpar), ptr(scratch), None, stream_ptr())
+         ptr(dxcat), None, ptr(dx), ptr(dew), ptr(dpar), ptr(scratch), None, stream_ptr())
 torch.cuda.synchronize()
 raw.igcn_debug_sf_probe(buf)
 names = ["staging+norm", "forward", "bwd layer 1", "bwd layer 0", "norm bwd + stores"]

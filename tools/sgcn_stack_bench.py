@@ -45,7 +45,7 @@ def bwd():
     for _ in range(iters):
         call("igcn_sgcn_stack_bwd", n // rois, rois, emax, h0, f, layers, ptr(x), ptr(ew), ptr(plan.src32), ptr(plan.dst32),
              ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm), ptr(plan.loop_edge), wp, bp,
-             ptr(dxcat), ptr(dx), ptr(dew), ptr(dpar), ptr(scratch), None, stream_ptr())
+             ptr(dxcat), None, ptr(dx), ptr(dew), ptr(dpar), ptr(scratch), None, stream_ptr())
 
 
 alg = (n // rois) * (4 * rois * h0 + 20 * (e // (n // rois)) + 4 * rois * layers * f)
