@@ -48,4 +48,4 @@ def test_gpus_2_self_launch_rehearsal_on_one_device():
     assert cfg["parallelism"] == "dp2" and "all_reduce" in cfg["gradient_exchange"]
     assert cfg["allreduce_us_per_step"] is not None and cfg["allreduce_us_per_step"] > 0
     assert math.isfinite(res["loss"]) and res["value"] > 0
-    assert res["weak_scaling_efficiency_vs_n1"] == pytest.approx(res["value"] / 500000.0, rel=1e-3)
+    assert res["weak_scaling_efficiency_vs_n1"] == pytest.approx(res["value"] / 500000.0, abs=1e-4)

@@ -326,7 +326,7 @@ def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch):
                 return halves(pick(calls[k_th]))
             n = len(calls) // 2
             return [pick(calls[k_th]).detach().cpu(), pick(calls[n + k_th]).detach().cpu()]
-        xc = per_pass("SgcnStack", 0)
+        xc = per_pass("SgcnStack", 0, lambda o: o[0] if isinstance(o, tuple) else o)
         ln = [per_pass("NodesLayerNorm", k) for k in range(4)]
         att = per_pass("NodeLinearBNPair", 0, lambda o: o[0])
         inp = per_pass("NodeLinearBNPair", 0, lambda o: o[1])

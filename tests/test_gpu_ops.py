@@ -693,10 +693,13 @@ def test_segmented_plan_refuses_offsets_outside_the_batch(ops):
 @pytest.mark.parametrize("sizes,edges", [((512, 512, 512), (262144, 262144, 262144)),     # dense stress-shape graphs
                                          ((300, 1024, 5, 77), (9000, 40000, 0, 4097)),     # ragged, an empty graph
                                          ((90, 90), (270, 4097))])
-def test_tiled_plan_is_bit_identical_to_a_stable_sort(ops, sizes, edges):
+def test_tiled_plan_is_bit_identical_to_a_stable_sort(ops, sizes, edges, monkeypatch):
     """igcn_graph_plan_build_tiled (graphs with more than 4096 edges: one-pass counting sort per graph) against
     numpy's stable argsort and the general multi-pass build."""
     from igcn_amd.data import Batch, Data
+    # complete row-major graphs would make this a dense-block plan, whose rebuild only re-verifies the structure
+    # (tests/test_gpu_dense.py); this test is about the sorting builders
+    monkeypatch.setenv("IGCN_NO_DENSE_BLOCKS", "1")
     rng = np.random.default_rng(11)
     graphs = []
     for n, e in zip(sizes, edges):
