@@ -126,13 +126,13 @@ def instep_profile(workload, bf16, steps=12, timeout=420):
             shutil.rmtree(out, ignore_errors=True)
 
 
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc", "traffic.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc", "traffic.json")
 
 
 def _attach_traffic(res):
     """``traffic``: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction, calibrated
     on a 256 MiB float4 copy; WRITE_SIZE x1).  PMC collection needs its own profiler passes, so the figure comes from
-    the COMMITTED passes of tools/roofline_kernel.py (profiles/r02_pmc/, or $IGCN_BENCH_PMC_JSON) — a separate run of
+    the COMMITTED passes of tools/roofline_kernel.py (profiles/r03_pmc/, or $IGCN_BENCH_PMC_JSON) — a separate run of
     the same kernel on the same launch shape, not this invocation — and says so."""
     path = os.environ.get("IGCN_BENCH_PMC_JSON", PMC_JSON)
     try:
@@ -336,6 +336,47 @@ def scatter_roofline(data, device, wl, stats, hot_iters=200):
         res["floor"]["frac_ceiling"] = round(alg_bytes / (res["floor"]["write_only_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     except Exception as exc:                       # noqa: BLE001
         res["floor"] = {"error": f"{type(exc).__name__}: {exc}"}
+    _attach_traffic(res)
+    return res
+
+
+def dense_roofline(data, wl, stats):
+    """configs[4] on the dense-block path: the scatter-aggregate of a GCNConv layer is k_ds_agg (csrc/sgcn_dense.hip) —
+    ONE launch per layer for BOTH passes of the step, reading edge_attr as the dense matrix it is (4 bytes per edge, once)
+    and recomputing mask and coefficient on the fly.  ``frac`` follows the contract (SURVEY §8d algorithmic bytes: int64
+    endpoint pair + fp32 coefficient per edge and pass, 20 E' + 8 R F per graph and pass — none of which this kernel reads,
+    so the figure exceeds 1); the figures to read are ``frac_kernel_bytes`` (what the kernel moves) and ``frac_traffic``
+    (PMC).  Duration: average over the in-step launches of the rocprofv3 child of this command."""
+    picked = _pick(stats[0], "k_ds_agg") if stats else None
+    if picked is None:
+        return None
+    rois, f = wl["rois"], HIDDEN
+    g = data.x.shape[0] // rois
+    e = rois * rois
+    copies = 2
+    alg_bytes = copies * g * (20 * e + 8 * rois * f)
+    # ew once (both passes), h' rows in, AGG + activations + the next layer's h' out, per-node factors
+    kern_bytes = 4 * g * e + copies * g * rois * f * 4 * 4 + 4 * g * rois * 4
+    us = picked[2]
+    res = {"bound": "hbm", "kernel": picked[0], "achieved": round(alg_bytes / (us * 1e-6) / 1e9, 1),
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+           "traffic": None, "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
+           "timing": "rocprofv3 --kernel-trace --stats of this command (child process): average over the in-step launches",
+           "launches_profiled": picked[1], "kernel_bytes_per_launch": kern_bytes,
+           "frac_kernel_bytes": round(kern_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+           "launch": f"{g} complete graphs x {e} edges, BOTH passes of the step in one launch, F={f}",
+           "note": "dense-block path: no index arrays are read (edge_index is verified once per step by k_ds_check), so "
+                   "the contract's `frac` (int64 pairs + coefficient per edge and pass) exceeds 1; frac_kernel_bytes / "
+                   "frac_traffic are the honest figures.  The launch also carries 0.54 GFLOP of fp32 MFMA (3.4 us at "
+                   "the 157 TFLOP/s peak)."}
+    others = {}
+    for name in ("k_ds_aggT", "k_ds_mask_bwd", "k_ds_deg", "k_ds_check"):
+        pk = _pick(stats[0], name)
+        if pk:
+            byt = 16 * g * e if name == "k_ds_check" else 4 * g * e
+            others[name] = {"us": round(pk[2], 2), "launches_profiled": pk[1], "edge_bytes_per_launch": byt,
+                            "frac_edge_bytes": round(byt / (pk[2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    res["other_edge_passes"] = others
     _attach_traffic(res)
     return res
 
@@ -809,11 +850,14 @@ def main():
             res["pipeline"] = pipeline_bench(gstep, wl, device, args.steps, args.warmup, res["ms_per_step"])
         if wl["pool"] is not None and world == 1 and not args.no_roofline:
             stats = instep_profile(args.workload, bf16)
-            standalone = scatter_roofline(data, device, wl, stats)
+            dense_rf = dense_roofline(data, wl, stats) if wl["dense"] else None
+            standalone = scatter_roofline(data, device, wl, stats) if dense_rf is None else None
             fused = None
-            if stats is None or _pick(stats[0], "k_gcn_propagate_fwd") is None:
+            if dense_rf is None and (stats is None or _pick(stats[0], "k_gcn_propagate_fwd") is None):
                 fused = fused_stack_roofline(model, data, device, wl, stats)
-            if fused is not None:
+            if dense_rf is not None:
+                res["roofline"] = dense_rf
+            elif fused is not None:
                 # the default step runs the scatter-aggregate inside the LDS-resident stack kernel; the stand-alone
                 # kernel (other widths / graph shapes) keeps its own replay measurements beside it
                 res["roofline"] = fused

@@ -63,15 +63,13 @@ template <int NC, bool M0>
 __device__ __forceinline__ constexpr bool ds_masked(int c) { return NC == 2 ? c == 1 : M0; }
 
 // The edge passes walk their rows in STEPS of one 16-byte load per lane.  Two forms of every edge kernel:
-//  * FAST (template flag PIPE; R = 256 or 512): the per-NODE operands of the graph (h' / g' rows, mask factors) are
-//    staged in LDS once per workgroup, so the only global loads of the walk are the streamed ew values — and a wave
-//    issues ALL of them (8 or 16 x 16 bytes per lane: 16 KB per wave, the whole 33.5 MB matrix in flight chip-wide)
-//    before its first multiply, then consumes them in order.  What it took (aggregation, both passes: 19 us -> DESIGN
-//    §4): (i) NO branch or predicate between a load and its use — with one, the compiler waits for every outstanding
-//    load (s_waitcnt vmcnt(0)), i.e. "load everything, wait, compute"; (ii) enough bytes in flight: a two-buffer
-//    pipeline of 4-step chunks kept 4 KB per wave = 8 MB chip-wide in flight, less than bandwidth x latency, and was
-//    LATENCY-bound at 4 TB/s however well it overlapped; (iii) node operands out of LDS, so that a step costs 4
-//    registers, not 7-16, and the whole walk fits the register file.
+//  * pipelined (template flag PIPE; R = 256 or 512): the walk is software-pipelined over two register buffers of
+//    chunk-many steps — the loads of chunk k + 1 are in flight while chunk k feeds the arithmetic — with NO branch or
+//    predicate between a load and its use: with one, the compiler waits for every outstanding load (s_waitcnt vmcnt(0))
+//    before the first multiply, i.e. "load everything, wait, compute" (measured on the aggregation: 19.1 against 14.6 us).
+//    Hence a single-exit loop plus a peeled tail, and walks that are whole numbers of chunk pairs.  The transposed
+//    aggregation additionally stages its node operands in LDS (it would otherwise issue eight 4-byte operand loads per
+//    step); for the forward aggregation that did not pay (measurements at the call site).
 //  * generic (any supported R): one step at a time out of global memory.
 // Workgroup -> (graph, 64-node block) of the edge kernels, XCD-aware: the hardware deals consecutive workgroup ids
 // round-robin over the 8 XCDs (each with its own L2).  With the plain (block, graph) grid the 8 blocks of a graph sit
@@ -105,10 +103,11 @@ template <int V>
 struct DsInt {
   static constexpr int value = V;
 };
-template <bool PIPE, int STEP, typename BufP, typename Buf1, typename LoadP, typename CompP, typename Load1, typename Comp1>
+template <bool PIPE, int STEP, typename BufP, typename Buf1, typename LoadP, typename CompP, typename Load1, typename Comp1,
+          int PCH = DS_PCH>
 __device__ __forceinline__ void ds_walk(int begin, int end, LoadP loadp, CompP compp, Load1 load1, Comp1 comp1) {
   if constexpr (PIPE) {
-    constexpr int CW = DS_PCH * STEP;                       // rows (or columns) per chunk
+    constexpr int CW = PCH * STEP;                          // rows (or columns) per chunk
     BufP b0, b1;
     loadp(b0, begin);
     int p = begin;
@@ -396,10 +395,20 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
     }
   };
   DS_PROBE(0);
-  // measured at 512-node graphs, both passes (us per launch): node operands staged in LDS + every ew load of the walk
-  // issued up front 17.3 (the operand staging and the barrier behind it cost more than the per-step loads they
-  // replace); the same with the staging loads issued first 21.4; two-buffer pipeline out of global memory 14.6 <- kept
-  ds_walk<PIPE, 4, DsAggBuf<DS_PCH, NC>, DsAggBuf<1, NC>>(sb, sb + rows, load, compute, load, compute);
+  // Measured at 512-node graphs, both passes (us per launch; 42.4 MB of HBM traffic by the PMC counters = the bytes the
+  // kernel has to move; 0.54 GFLOP of exact-fp32 MFMA = 3.4 us at peak, ~5 us of walk time by the phase probe):
+  //   one step at a time                                                             19.7
+  //   all 16 steps' loads up front, predicated (=> s_waitcnt vmcnt(0) before the first multiply) 19.1
+  //   two-buffer pipeline, chunks of 4 steps, branch-free                             14.6
+  //   the same, chunks of 8 (= every load of the wave in flight, second half arriving under the first half's products)  13.6  <- kept
+  //   node operands staged in LDS per workgroup (64 KB + barrier) + all loads up front            17.3 / 21.4
+  //   node operands staged in LDS per WAVE (8 KB, no barrier) + all loads up front                17.0
+  // The single-pass instance (NC = 1: 4 instead of 8 matrix instructions per step) runs in 9.1 us.
+  if (R == 512)
+    ds_walk<PIPE, 4, DsAggBuf<8, NC>, DsAggBuf<1, NC>, decltype(load), decltype(compute), decltype(load),
+            decltype(compute), 8>(sb, sb + rows, load, compute, load, compute);
+  else
+    ds_walk<PIPE, 4, DsAggBuf<DS_PCH, NC>, DsAggBuf<1, NC>>(sb, sb + rows, load, compute, load, compute);
   DS_PROBE(3);
   // accumulator lane (q, sub), tile t, register r = (target d0 + 16 sub + 4 r + t, feature q)
 #pragma unroll

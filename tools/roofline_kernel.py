@@ -8,7 +8,8 @@
 
 Kernels: `k_sgcn_stack_fwd` = the LDS-resident SGCN stack at the bench shape (512 x 90-ROI k=3 graphs, F=16, L=2: the
 kernel the default train step launches); `k_gcn_propagate_fwd_q` = the stand-alone scatter-aggregate at the same shape;
-`k_gcn_propagate_fwd_lds` = the LDS-staged dense scatter-aggregate at the stress shape (64 dense 512-ROI graphs).
+`k_gcn_propagate_fwd_lds` = the LDS-staged dense scatter-aggregate at the stress shape (64 dense 512-ROI graphs);
+`k_ds_agg` = the dense-block aggregation of the same 32 graphs (both passes per launch: what configs[4] runs).
 The calibration kernel is a float4 device copy of a known byte count (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads
 1/2 of the bytes of a wide coalesced stream; every other access width must be calibrated on a known pattern).
 """
@@ -72,4 +73,17 @@ torch.cuda.synchronize()
 sb = Batch.from_data_list(synth.brain_graph_list(32, seed=1, rois=512, tsne_dim=8, dense=True)).to(dev)
 splan = ops.plan_for(sb).replicate(2)
 run_propagate(splan, torch.cat([sb.edge_attr, sb.edge_attr]), 2 * sb.x.shape[0], 16, 512)
+
+# the same batch as COMPLETE graphs on the dense-block path (what the configs[4] step launches now): k_ds_agg — one
+# launch aggregates BOTH passes of a layer, reading every 4-byte weight once
+assert ops.plan_for(sb).dense_blocks
+prob = torch.randn(512, 3, device=dev)
+pb = torch.randn(6, 1, device=dev)
+spr = torch.randn(1, 54, device=dev)
+dw = [torch.randn(16, 3, device=dev) * 0.5, torch.zeros(16, device=dev), torch.randn(16, 16, device=dev) * 0.3,
+      torch.zeros(16, device=dev)]
+torch.cuda.synchronize()
+for _ in range(LAUNCHES // 2):                      # two k_ds_agg launches (two layers) per forward
+    ops.DenseSgcn.apply(sb.x, sb.edge_attr, prob, pb, spr, "both", 512, (0.1, 0.1, 0.1, 0.1, 1e-6), *dw)
+torch.cuda.synchronize()
 print("done")
