@@ -11,6 +11,18 @@
 
 void igcn_set_error(const char* fmt, ...);
 
+// A/B switches of the library (IGCN_* environment variables of earlier rounds).  They are read ONCE, by the binding when it
+// loads the library (igcn_configure, include/igcn.h) — no getenv in any launch path, so a variable flipped in the
+// middle of a process cannot silently change which kernel a captured graph's next eager twin runs.
+#define IGCN_OPT_NO_TILED_LISTS 1u        /* dense graphs: wave-per-list walks instead of the tiled node-lane kernels */
+#define IGCN_OPT_PROPAGATE_NO_LDS 2u      /* dense graphs: the wave-per-target aggregation instead of the LDS-staged one */
+#define IGCN_OPT_SPMM_NO_LDS 4u           /* SNP <-> GO maps: the first (untiled) CSR kernels */
+#define IGCN_OPT_GO_ATTN_CM 8u            /* GO attention backward: the global-memory kernels even when a sample fits LDS */
+#define IGCN_OPT_DEBUG_REDUCE 16u         /* print every deferred reduction at the flush */
+extern unsigned g_igcn_options;
+extern int g_igcn_gemm_bn_cap;            /* > 0: cap of the GEMM tile width (sweeps only) */
+static inline bool igcn_opt(unsigned bit) { return (g_igcn_options & bit) != 0; }
+
 #define IGCN_REQUIRE(cond, ...)                 \
   do {                                          \
     if (!(cond)) {                              \

@@ -598,7 +598,7 @@ static int gemm_launch(bool bf16, int64_t M, int64_t N, int64_t K, const float* 
   const int64_t ld = split ? N : ldc;
   const int64_t slab = split ? M * N : 0;
   int bn = gemm_tile_n(M, N);
-  if (const char* cap = getenv("IGCN_GEMM_BN")) bn = atoi(cap) < bn ? atoi(cap) : bn;      // sweeps only
+  if (g_igcn_gemm_bn_cap > 0 && g_igcn_gemm_bn_cap < bn) bn = g_igcn_gemm_bn_cap;         // sweeps only (igcn_configure)
   dim3 grid((unsigned)igcn_cdiv(M, G_BM), (unsigned)igcn_cdiv(N, bn), (unsigned)split_k);
   const int vw = min_int(vec_width(A, sam, sak, M, K), vec_width(B, sbn, sbk, N, K));
   if (bf16) {

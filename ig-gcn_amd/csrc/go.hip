@@ -292,14 +292,7 @@ static int spmm_dval_tile(int C, int L, int S) {
   const int t = (int)((size_t)120 * 1024 / per);
   return t > 4 ? 4 : t;
 }
-static bool spmm_no_lds(void) {                        // IGCN_SPMM_NO_LDS=1: the first versions (A/B runs)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("IGCN_SPMM_NO_LDS");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
-}
+static bool spmm_no_lds(void) { return igcn_opt(IGCN_OPT_SPMM_NO_LDS); }     // the first versions (A/B runs)
 
 extern "C" int igcn_spmm_fwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
                              const float* val, const float* x, float* y, void* stream) {
@@ -1341,14 +1334,7 @@ extern "C" int igcn_go_attn_walk_order(int N, int fin, int fout, const int32_t* 
 
 // IGCN_GO_ATTN_CM=1 (A/B runs): the global-memory kernels (attention backward, decoder forward / backward) even when a
 // sample fits LDS — these are also the fallbacks for hierarchies too large for LDS
-static bool go_attn_force_cm(void) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("IGCN_GO_ATTN_CM");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
-}
+static bool go_attn_force_cm(void) { return igcn_opt(IGCN_OPT_GO_ATTN_CM); }
 
 extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
                                 const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order,

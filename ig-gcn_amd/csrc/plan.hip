@@ -18,6 +18,14 @@ void igcn_set_error(const char* fmt, ...) {
 extern "C" const char* igcn_last_error(void) { return g_err; }
 extern "C" int igcn_version(void) { return IGCN_ABI_VERSION; }
 
+unsigned g_igcn_options = 0;
+int g_igcn_gemm_bn_cap = 0;
+extern "C" int igcn_configure(unsigned options, int gemm_bn_cap) {
+  g_igcn_options = options;
+  g_igcn_gemm_bn_cap = gemm_bn_cap;
+  return IGCN_OK;
+}
+
 __global__ void k_reduce_rows(const float* __restrict__ partial, int64_t rows, int64_t ld, int n,
                               float* __restrict__ out, int accumulate) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,7 +198,7 @@ static int reduce_flush_locked(hipStream_t st) {
                      "reductions support one backward pass at a time per process", n, i);
       return IGCN_ERR_BADARG;
     }
-  if (getenv("IGCN_DEBUG_REDUCE"))
+  if (igcn_opt(IGCN_OPT_DEBUG_REDUCE))
     for (const ReduceEntry& e : g_rq)
       fprintf(stderr, "[igcn] deferred reduction: rows %lld x n %d (ld %lld)%s\n", (long long)e.rows, e.n,
               (long long)e.ld, (e.rows > 32 && e.n <= 4096) ? "  tree" : "  in-order");

@@ -328,7 +328,7 @@ extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, in
   IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0, "edge_mask_bwd: bad rois/h0");
   hipStream_t st = (hipStream_t)stream;
   const bool dense = n_edges >= 16 * n_nodes;
-  const bool tiled = dense && getenv("IGCN_NO_TILED_LISTS") == nullptr;
+  const bool tiled = dense && !igcn_opt(IGCN_OPT_NO_TILED_LISTS);
   const int64_t nblk = tiled ? igcn_cdiv(n_nodes, TL_NODES) : igcn_cdiv(n_nodes, dense ? 4 : 64);
   float* gx = scratch;
   float* part = scratch + n_nodes * h0;  // [nblk, 2*MAX_H0]
@@ -485,7 +485,7 @@ extern "C" int igcn_gcn_norm_fwd(int64_t n_nodes, int64_t n_edges, const float* 
                                  float* what, float* what_loop, void* tstream, void* sstream, void* stream) {
   if (n_nodes == 0) return IGCN_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (n_edges >= 16 * n_nodes && getenv("IGCN_NO_TILED_LISTS") == nullptr)      // dense graphs: lanes own nodes
+  if (n_edges >= 16 * n_nodes && !igcn_opt(IGCN_OPT_NO_TILED_LISTS))      // dense graphs: lanes own nodes
     hipLaunchKernelGGL(k_gcn_norm_fwd_tiled, dim3((unsigned)igcn_cdiv(n_nodes, TL_NODES)), dim3(TL_T), 0, st, n_nodes,
                        ew, src32, tgt_ptr, tgt_perm, loop_edge, dis, wl);
   else if (n_edges >= 16 * n_nodes)                // (A/B: one wave per node)
@@ -495,7 +495,7 @@ extern "C" int igcn_gcn_norm_fwd(int64_t n_nodes, int64_t n_edges, const float* 
     hipLaunchKernelGGL(k_gcn_norm_fwd<4>, dim3((unsigned)igcn_cdiv(n_nodes * 4, 256)), dim3(256), 0, st, n_nodes, ew,
                        src32, tgt_ptr, tgt_perm, loop_edge, dis, wl);
   const int64_t n = n_nodes > n_edges ? n_nodes : n_edges;
-  if (n_edges >= 16 * n_nodes && getenv("IGCN_NO_TILED_LISTS") == nullptr) {
+  if (n_edges >= 16 * n_nodes && !igcn_opt(IGCN_OPT_NO_TILED_LISTS)) {
     hipLaunchKernelGGL(k_gcn_norm_what, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, st, n_nodes, n_edges, ew, dis,
                        wl, src32, dst32, what, what_loop);
     hipLaunchKernelGGL(k_stream_by_target_tiled, dim3((unsigned)igcn_cdiv(n_nodes, TL_NODES)), dim3(TL_T), 0, st,
@@ -568,7 +568,7 @@ extern "C" int igcn_gcn_norm_bwd(int64_t n_nodes, int64_t n_edges, const float* 
                                  const int32_t* loop_edge, float* dew, float* scratch, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (n_nodes == 0 || n_edges == 0) return IGCN_OK;
-  if (n_edges >= 16 * n_nodes && getenv("IGCN_NO_TILED_LISTS") == nullptr)
+  if (n_edges >= 16 * n_nodes && !igcn_opt(IGCN_OPT_NO_TILED_LISTS))
     hipLaunchKernelGGL(k_gcn_norm_bwd_deg_tiled, dim3((unsigned)igcn_cdiv(n_nodes, TL_NODES)), dim3(TL_T), 0, st,
                        n_nodes, ew, dis, wl, dwhat, dwhat_loop, src32, dst32, tgt_ptr, tgt_perm, src_ptr, src_perm,
                        scratch);
@@ -862,7 +862,7 @@ extern "C" int igcn_gcn_propagate_fwd(int64_t n_nodes, int64_t n_edges, int F, i
   const bool al16 = ((uintptr_t)h % 16 == 0) && ((uintptr_t)out % 16 == 0) && ld_h % 4 == 0 && ld_out % 4 == 0 &&
                     (bias == nullptr || (uintptr_t)bias % 16 == 0);
   if (al16 && ((uintptr_t)tstream % 16 == 0) && propagate_lds_ok(n_nodes, n_edges, F, nodes_per_graph) &&
-      getenv("IGCN_PROPAGATE_NO_LDS") == nullptr) {
+      !igcn_opt(IGCN_OPT_PROPAGATE_NO_LDS)) {
     switch (F / 4) {
       case 1: launch_propagate_lds<1>(n_nodes, nodes_per_graph, h, ld_h, (const EdgeRec*)tstream, what_loop, bias, tgt_ptr, out, ld_out, relu, st); break;
       case 2: launch_propagate_lds<2>(n_nodes, nodes_per_graph, h, ld_h, (const EdgeRec*)tstream, what_loop, bias, tgt_ptr, out, ld_out, relu, st); break;
@@ -1338,7 +1338,7 @@ extern "C" int igcn_gcn_propagate_bwd(int64_t n_nodes, int64_t n_edges, int F, i
                     ld_dout % 4 == 0 && ld_out % 4 == 0 && ld_dh % 4 == 0;
   const bool quad = al16 && (F == 4 || F == 8 || F == 16 || F == 32 || F == 64);
   if (quad && relu == 0 && ((uintptr_t)sstream % 16 == 0) && (uintptr_t)h % 16 == 0 && ld_h % 4 == 0 &&
-      propagate_lds_ok(n_nodes, n_edges, F, nodes_per_graph) && getenv("IGCN_PROPAGATE_NO_LDS") == nullptr) {
+      propagate_lds_ok(n_nodes, n_edges, F, nodes_per_graph) && !igcn_opt(IGCN_OPT_PROPAGATE_NO_LDS)) {
     // dense uniform batch (stress shape): the graph's rows staged in LDS — dh is the forward kernel on the
     // by-source stream, the bias gradient a column-sum pass, the coefficient gradients an LDS-staged edge walk
     const int R = nodes_per_graph;

@@ -12,7 +12,7 @@ from igcn_amd import _lib
 HEADER = os.path.join(ROOT, "include", "igcn.h")
 
 CTYPE = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
-         "double": ctypes.c_double}
+         "double": ctypes.c_double, "unsigned": ctypes.c_uint}
 
 
 def _prototypes():
