@@ -141,7 +141,7 @@ def _attach_traffic(res):
     except OSError:
         return
     for key, row in table.items():
-        if key != "calibration" and res["kernel"].startswith(key) and row.get("alg_bytes") == res["alg_bytes_per_launch"]:
+        if key != "calibration" and res["kernel"].split("<")[0] == key and row.get("alg_bytes") == res["alg_bytes_per_launch"]:
             res["traffic"] = row["traffic_bytes"]
             res["traffic_source"] = (f"{os.path.relpath(path, ROOT)}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                      f"of tools/roofline_kernel.py on this launch shape ({row['us_median']} us median there)")
@@ -347,7 +347,7 @@ def dense_roofline(data, wl, stats):
     endpoint pair + fp32 coefficient per edge and pass, 20 E' + 8 R F per graph and pass — none of which this kernel reads,
     so the figure exceeds 1); the figures to read are ``frac_kernel_bytes`` (what the kernel moves) and ``frac_traffic``
     (PMC).  Duration: average over the in-step launches of the rocprofv3 child of this command."""
-    picked = _pick(stats[0], "k_ds_agg") if stats else None
+    picked = _pick(stats[0], "k_ds_agg<") if stats else None      # not k_ds_aggT (the transposed pass)
     if picked is None:
         return None
     rois, f = wl["rois"], HIDDEN
@@ -371,7 +371,7 @@ def dense_roofline(data, wl, stats):
                    "the 157 TFLOP/s peak)."}
     others = {}
     for name in ("k_ds_aggT", "k_ds_mask_bwd", "k_ds_deg", "k_ds_check"):
-        pk = _pick(stats[0], name)
+        pk = _pick(stats[0], name + ("<" if name != "k_ds_check" else ""))
         if pk:
             byt = 16 * g * e if name == "k_ds_check" else 4 * g * e
             others[name] = {"us": round(pk[2], 2), "launches_profiled": pk[1], "edge_bytes_per_launch": byt,
