@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 303        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 304        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -20,7 +20,7 @@ P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, c
 SIGNATURES = {
     "igcn_version": (I, []),
     "igcn_last_error": (ctypes.c_char_p, []),
-    "igcn_configure": (I, [ctypes.c_uint, I]),
+    "igcn_configure": (I, [ctypes.c_uint, I, I]),
     "igcn_graph_plan_workspace_bytes": (Z, [L, L]),
     "igcn_graph_plan_build": (I, [L, L, P, P, P, P, P, P, P, P, P, Z, P]),
     "igcn_graph_plan_build_segmented": (I, [L, L, I, P, P, P, L, L, P, P, P, P, P, P, P, P, P]),
@@ -162,7 +162,8 @@ def load():
         v = os.environ.get(name)
         if v is not None and (v == "1" or name in ("IGCN_NO_TILED_LISTS", "IGCN_PROPAGATE_NO_LDS", "IGCN_DEBUG_REDUCE")):
             bits |= 1 << bit
-    lib.igcn_configure(bits, int(os.environ.get("IGCN_GEMM_BN", "0") or 0))
+    lib.igcn_configure(bits, int(os.environ.get("IGCN_GEMM_BN", "0") or 0),
+                       int(os.environ.get("IGCN_ATTN_CHUNK", "0") or 0))
     _lib = lib
     return lib
 

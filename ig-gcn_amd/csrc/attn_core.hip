@@ -25,6 +25,7 @@ int igcn_attn_mfma_bwd_chunked(int B, int D, int H, int Lq, int Lk, const float*
 
 // K, V (and Q, dO) of one head fit LDS
 static bool use_resident(int D, int H, int Lq, int Lk) {
+  if (g_igcn_attn_chunk_rows > 0 && g_igcn_attn_chunk_rows < Lk) return false;      // sweeps: force the streamed kernels
   return H > 0 && Lq > 0 && Lk > 0 && igcn_attn_mfma_lds_bytes(D, H, Lq, Lk, 1) != 0;
 }
 

@@ -690,9 +690,15 @@ k_attn_mfma_bwd_dkv_chunked(int H, int hd, int vec, int Lq, int Lk, int CH, cons
 }
 
 // rows of the other side streamed per chunk: as many as ~96 KB of LDS hold (two matrices of HDP+1 columns)
-static int am_chunk_rows(int hd) {
+// `keys`: the chunk streams KEYS past resident query tiles (forward, dQ).  There a third of the LDS-filling chunk is
+// better: 336 rows = 46 KB per workgroup, three workgroups per CU instead of one, so that one stages while the others
+// multiply (configs[4], 512 x 1300: forward 99 -> 85 us, dQ 109 -> 97 us; 448 / 224 / 160 rows: 85 / 87 / 88 and
+// 97 / 99 / 100).  The dK | dV kernel streams QUERIES (at most Lq rows: unchanged by the cap).
+static int am_chunk_rows(int hd, bool keys = false) {
   const int ld = am_hdp(hd) + 1;
   int ch = (96 * 1024) / (2 * ld * 4 + 8);
+  if (keys && ch > 336) ch = 336;
+  if (g_igcn_attn_chunk_rows > 0 && g_igcn_attn_chunk_rows < ch) ch = g_igcn_attn_chunk_rows;   // sweeps (igcn_configure)
   ch &= ~15;
   return ch < 16 ? 16 : ch;
 }
@@ -702,7 +708,7 @@ size_t igcn_attn_mfma_chunked_scratch_floats(int B, int H, int Lq) { return (siz
 int igcn_attn_mfma_fwd_chunked(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o,
                                float* lse, hipStream_t st) {
   const int hd = D / H, vec = am_vec(D, hd, q, kv, o, o);
-  int ch = am_chunk_rows(hd);
+  int ch = am_chunk_rows(hd, true);
   if (ch > ((Lk + 15) & ~15)) ch = (Lk + 15) & ~15;
   const size_t lds = (size_t)2 * ch * (am_hdp(hd) + 1) * sizeof(float);
   const int nqt = (Lq + 15) / 16, nw = nqt < 8 ? (nqt < 4 ? 4 : nqt) : 8;
@@ -724,8 +730,7 @@ int igcn_attn_mfma_bwd_chunked(int B, int D, int H, int Lq, int Lk, const float*
                                hipStream_t st) {
   const int hd = D / H;
   const int vec = am_vec(D, hd, q, kv, dout, dq) && (uintptr_t)dkv % 16 == 0;
-  const int chmax = am_chunk_rows(hd);
-  int chk = chmax, chq = chmax;
+  int chk = am_chunk_rows(hd, true), chq = am_chunk_rows(hd);
   if (chk > ((Lk + 15) & ~15)) chk = (Lk + 15) & ~15;
   if (chq > ((Lq + 15) & ~15)) chq = (Lq + 15) & ~15;
   const size_t ld = (size_t)am_hdp(hd) + 1;

@@ -21,6 +21,7 @@ void igcn_set_error(const char* fmt, ...);
 #define IGCN_OPT_DEBUG_REDUCE 16u         /* print every deferred reduction at the flush */
 extern unsigned g_igcn_options;
 extern int g_igcn_gemm_bn_cap;            /* > 0: cap of the GEMM tile width (sweeps only) */
+extern int g_igcn_attn_chunk_rows;        /* > 0: rows per LDS chunk of the streamed attention kernels (sweeps only) */
 static inline bool igcn_opt(unsigned bit) { return (g_igcn_options & bit) != 0; }
 
 #define IGCN_REQUIRE(cond, ...)                 \

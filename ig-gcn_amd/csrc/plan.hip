@@ -20,9 +20,11 @@ extern "C" int igcn_version(void) { return IGCN_ABI_VERSION; }
 
 unsigned g_igcn_options = 0;
 int g_igcn_gemm_bn_cap = 0;
-extern "C" int igcn_configure(unsigned options, int gemm_bn_cap) {
+int g_igcn_attn_chunk_rows = 0;
+extern "C" int igcn_configure(unsigned options, int gemm_bn_cap, int attn_chunk_rows) {
   g_igcn_options = options;
   g_igcn_gemm_bn_cap = gemm_bn_cap;
+  g_igcn_attn_chunk_rows = attn_chunk_rows;
   return IGCN_OK;
 }
 

@@ -31,13 +31,14 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 303
+#define IGCN_ABI_VERSION 304
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
  * list walks, 1 no LDS-staged dense aggregation, 2 untiled CSR map kernels, 3 global-memory GO attention backward, 4 print
- * deferred reductions; gemm_bn_cap > 0 caps the GEMM tile width (sweeps).  No launch path reads the environment. */
-int igcn_configure(unsigned options, int gemm_bn_cap);
+ * deferred reductions; gemm_bn_cap > 0 caps the GEMM tile width, attn_chunk_rows > 0 the rows per LDS chunk of the streamed
+ * attention kernels (sweeps).  No launch path reads the environment. */
+int igcn_configure(unsigned options, int gemm_bn_cap, int attn_chunk_rows);
 
 /* ------------------------------------------------------------------------------------------------
  * Graph plan: replaces the index work PyG's gcn_norm/propagate redo in every GCNConv call
