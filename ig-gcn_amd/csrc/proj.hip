@@ -1,0 +1,169 @@
+// Backward of a bias-free projection y = x W^T (x [M, K], W [N, K], y [M, N]) in ONE pass over the gradient:
+//   dX [M, K] = G W          dW [N, K] = G^T X            (G = dL/dy [M, N])
+// for the packed input projection of the cross-attention (kernel/sgcn_img_snp.py:240-241: nn.MultiheadAttention's
+// in_proj; K = embed dim = 32, N = 32 for the queries, 64 for key | value).  As two GEMMs (igcn_gemm_f32_grouped) G is
+// read twice — and for key | value G is the 52 MB gradient of a [512 x 400, 64] tensor: 180 MB of traffic for 48 us, all
+// of it bandwidth.  Here a workgroup walks 64-row blocks: G and X tiles staged in LDS once, dX tile out of the matrix
+// cores straight to HBM, dW accumulated in registers over the workgroup's blocks and left as ONE partial per workgroup
+// (summed by a final, deferrable reduction).  122 MB instead of 180 MB.
+// Exact fp32 (v_mfma_f32_16x16x4_f32).  K must be 32, N 32 or 64; everything else takes the grouped GEMM.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PJ_K 32
+#define PJ_ROWS 64
+
+extern "C" int igcn_proj_bwd_supported(int64_t M, int N, int K) { return K == PJ_K && (N == 32 || N == 64) && M > 0; }
+
+// workgroups: enough to fill the chip a few times, never more than row blocks
+extern "C" int igcn_proj_bwd_blocks(int64_t M) {
+  const int64_t nb = igcn_cdiv(M, PJ_ROWS);
+  return (int)(nb < 1024 ? nb : 1024);
+}
+
+struct PjArgs {
+  int64_t M;
+  const float *G, *X, *W;
+  float *dX, *dWp;
+  int blocks;
+};
+
+#define PJ_LDS_FLOATS (PJ_ROWS * (64 + 4) + PJ_ROWS * (PJ_K + 4) + 64 * (PJ_K + 4))
+
+template <int N>
+__device__ __forceinline__ void proj_bwd_body(float* lds, const PjArgs& a, int bid) {
+  constexpr int LG = N + 4, LX = PJ_K + 4;            // padded rows: operand reads of 16 lanes spread over the banks
+  float (*Gs)[LG] = reinterpret_cast<float (*)[LG]>(lds);
+  float (*Xs)[LX] = reinterpret_cast<float (*)[LX]>(lds + PJ_ROWS * LG);
+  float (*Ws)[LX] = reinterpret_cast<float (*)[LX]>(lds + PJ_ROWS * LG + PJ_ROWS * LX);
+  const int64_t M = a.M;
+  const float* __restrict__ G = a.G;
+  const float* __restrict__ X = a.X;
+  const float* __restrict__ W = a.W;
+  float* __restrict__ dX = a.dX;
+  float* __restrict__ dW_partial = a.dWp;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
+  for (int i = tid; i < N * PJ_K / 4; i += 256) {
+    const int r = i / (PJ_K / 4), c4 = i - r * (PJ_K / 4);
+    *reinterpret_cast<float4*>(&Ws[r][4 * c4]) = *reinterpret_cast<const float4*>(W + r * PJ_K + 4 * c4);
+  }
+  // dW tiles of this wave: N = 64 -> rows [16 w, 16 w + 16) x both 16-column tiles; N = 32 -> row tile w & 1, column
+  // tile w >> 1
+  constexpr int NT = N == 64 ? 2 : 1;
+  const int wr = N == 64 ? 16 * w : 16 * (w & 1), wc0 = N == 64 ? 0 : 16 * (w >> 1);
+  f32x4 dw[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) dw[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t nblk = (M + PJ_ROWS - 1) / PJ_ROWS;
+  for (int64_t blk = bid; blk < nblk; blk += a.blocks) {
+    const int64_t r0 = blk * PJ_ROWS;
+    __syncthreads();                                    // the previous block's tiles are fully consumed (and Ws is in)
+    // stage: G tile [64, N] and X tile [64, 32], 16 bytes per lane, rows past M zero-filled
+    float4 gq[N / 16], xq[2];
+#pragma unroll
+    for (int k = 0; k < N / 16; ++k) {
+      const int i = tid + 256 * k, r = i / (N / 4), c4 = i - r * (N / 4);
+      gq[k] = r0 + r < M ? *reinterpret_cast<const float4*>(G + (r0 + r) * N + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + 256 * k, r = i >> 3, c4 = i & 7;
+      xq[k] = r0 + r < M ? *reinterpret_cast<const float4*>(X + (r0 + r) * PJ_K + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < N / 16; ++k) {
+      const int i = tid + 256 * k, r = i / (N / 4), c4 = i - r * (N / 4);
+      *reinterpret_cast<float4*>(&Gs[r][4 * c4]) = gq[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + 256 * k, r = i >> 3, c4 = i & 7;
+      *reinterpret_cast<float4*>(&Xs[r][4 * c4]) = xq[k];
+    }
+    __syncthreads();
+    // dX tile, TRANSPOSED accumulator: dX^T[k][row] = sum_n W^T[k][n] G^T[n][row] — lane (g, n) then owns four
+    // consecutive columns 4 g .. 4 g + 3 (+ 16 t) of row 16 w + n: one 16-byte store per tile
+    f32x4 dx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < N / 4; ++kk) {
+      const float b = Gs[16 * w + n][4 * kk + g];       // B[k = g][col = row n] = G[row][n-index 4 kk + g]
+#pragma unroll
+      for (int t = 0; t < 2; ++t) dx[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[4 * kk + g][16 * t + n], b, dx[t], 0, 0, 0);
+    }
+    // A above: lane (g, n) supplies A[i = n][k = g] = W^T[column 16 t + n][n-index 4 kk + g] = Ws[4 kk + g][16 t + n]
+    if (r0 + 16 * w + n < M) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        *reinterpret_cast<float4*>(dX + (r0 + 16 * w + n) * PJ_K + 16 * t + 4 * g) =
+            make_float4(dx[t][0], dx[t][1], dx[t][2], dx[t][3]);
+    }
+    // dW += G_tile^T X_tile over the 64 rows: A[i = n-index wr + n][k = row 4 kk + g], B[k][col wc0 + 16 t + n]
+#pragma unroll
+    for (int kk = 0; kk < PJ_ROWS / 4; ++kk) {
+      const float a = Gs[4 * kk + g][wr + n];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Xs[4 * kk + g][wc0 + 16 * t + n], dw[t], 0, 0, 0);
+    }
+  }
+  // the workgroup's partial of dW [N, 32]: accumulator lane (g, n), register r = (row wr + 4 g + r, column wc0 + 16 t + n)
+  float* out = dW_partial + (int64_t)bid * N * PJ_K;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(wr + 4 * g + r) * PJ_K + wc0 + 16 * t + n] = dw[t][r];
+}
+
+// One launch for up to two projections (the query block and the key | value block of the packed in-projection): the
+// first `a.blocks` workgroups take `a`, the rest `b` (b.blocks == 0: single).
+__global__ void __launch_bounds__(256) k_proj_bwd(PjArgs a, int na, PjArgs b, int nbn) {
+  __shared__ __attribute__((aligned(16))) float lds[PJ_LDS_FLOATS];
+  const bool first = (int)blockIdx.x < a.blocks;
+  const PjArgs& p = first ? a : b;
+  const int bid = first ? blockIdx.x : blockIdx.x - a.blocks;
+  if ((first ? na : nbn) == 64)
+    proj_bwd_body<64>(lds, p, bid);
+  else
+    proj_bwd_body<32>(lds, p, bid);
+}
+
+static int pj_check(int64_t M, int N, int K, const float* G, const float* X, const float* W, float* dX, float* dW,
+                    float* scratch) {
+  if (!igcn_proj_bwd_supported(M, N, K)) {
+    igcn_set_error("proj_bwd: needs K == 32 and N in {32, 64} (M=%lld N=%d K=%d)", (long long)M, N, K);
+    return IGCN_ERR_UNSUPPORTED;
+  }
+  IGCN_REQUIRE((((uintptr_t)G | (uintptr_t)X | (uintptr_t)W | (uintptr_t)dX) & 15) == 0 && dW && scratch,
+               "proj_bwd: operands must be 16-byte aligned");
+  return IGCN_OK;
+}
+
+// scratch: igcn_proj_bwd_blocks(M) * N * K floats.  dW is a FINAL reduction (igcn_reduce_defer).
+extern "C" int igcn_proj_bwd(int64_t M, int N, int K, const float* G, const float* X, const float* W, float* dX,
+                             float* dW, float* scratch, void* stream) {
+  int rc = pj_check(M, N, K, G, X, W, dX, dW, scratch);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PjArgs a = {M, G, X, W, dX, scratch, igcn_proj_bwd_blocks(M)}, none = {};
+  hipLaunchKernelGGL(k_proj_bwd, dim3(a.blocks), dim3(256), 0, st, a, N, none, 0);
+  IGCN_CHECK_LAUNCH("proj_bwd");
+  return igcn_launch_reduce_rows_final(scratch, a.blocks, (int64_t)N * K, N * K, dW, st);
+}
+
+// two projections (different M / N, same K) in one launch
+extern "C" int igcn_proj_bwd_pair(int64_t M1, int N1, const float* G1, const float* X1, const float* W1, float* dX1,
+                                  float* dW1, float* scratch1, int64_t M2, int N2, const float* G2, const float* X2,
+                                  const float* W2, float* dX2, float* dW2, float* scratch2, int K, void* stream) {
+  int rc = pj_check(M1, N1, K, G1, X1, W1, dX1, dW1, scratch1);
+  if (rc) return rc;
+  rc = pj_check(M2, N2, K, G2, X2, W2, dX2, dW2, scratch2);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const PjArgs a = {M1, G1, X1, W1, dX1, scratch1, igcn_proj_bwd_blocks(M1)};
+  const PjArgs b = {M2, G2, X2, W2, dX2, scratch2, igcn_proj_bwd_blocks(M2)};
+  hipLaunchKernelGGL(k_proj_bwd, dim3(a.blocks + b.blocks), dim3(256), 0, st, a, N1, b, N2);
+  IGCN_CHECK_LAUNCH("proj_bwd_pair");
+  rc = igcn_launch_reduce_rows_final(scratch1, a.blocks, (int64_t)N1 * K, N1 * K, dW1, st);
+  if (rc) return rc;
+  return igcn_launch_reduce_rows_final(scratch2, b.blocks, (int64_t)N2 * K, N2 * K, dW2, st);
+}

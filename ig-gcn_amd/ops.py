@@ -821,6 +821,20 @@ def linear_pair(x1, w1, b1, x2, w2, b2, relu=True, bf16=False):
 def _proj_backward(ctx, dq, dkv, q2, m2, w, dw, d):
     """The four products behind the packed input projection's backward — input gradients of query and memory, weight
     gradients of the two blocks (written into ``dw``) — in one launch when all four are wanted."""
+    lib = _lib.load()
+    if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not ctx.bf16 and dq.is_cuda
+            and os.environ.get("IGCN_NO_PROJ_FUSED", "0") != "1"
+            and lib.igcn_proj_bwd_supported(dq.shape[0], d, d) and lib.igcn_proj_bwd_supported(dkv.shape[0], 2 * d, d)):
+        # input gradient AND weight gradient of a block from ONE pass over its incoming gradient (igcn_proj_bwd): the
+        # key | value gradient (52 MB at the bench shape) is read once, not twice
+        dquery, dmem = torch.empty_like(q2), torch.empty_like(m2)
+        f32 = dict(dtype=torch.float32, device=dq.device)
+        s1 = _keep(torch.empty(int(lib.igcn_proj_bwd_blocks(dq.shape[0])) * d * d, **f32))
+        s2 = _keep(torch.empty(int(lib.igcn_proj_bwd_blocks(dkv.shape[0])) * 2 * d * d, **f32))
+        with _immediate(ctx.final):                 # both blocks in one launch: the small one rides along
+            call("igcn_proj_bwd_pair", dq.shape[0], d, ptr(dq), ptr(q2), ptr(w[:d]), ptr(dquery), ptr(dw[:d]), ptr(s1),
+                 dkv.shape[0], 2 * d, ptr(dkv), ptr(m2), ptr(w[d:]), ptr(dmem), ptr(dw[d:]), ptr(s2), d, stream_ptr())
+        return dquery.view(ctx.shapes[0]), dmem.view(ctx.shapes[1])
     if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
         with _immediate(ctx.final):
             dquery, dmem, _, _ = gemm_group([("nn", dq, w[:d], None, None, False), ("nn", dkv, w[d:], None, None, False),

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 304
+#define IGCN_ABI_VERSION 306
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -205,6 +205,21 @@ int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H0, int F, i
                         const int32_t* loop_edge, const float* const* W, const float* const* b, const float* dxcat,
                         const float* dxcat2, float* dx_in, float* dew_in, float* dparams, float* scratch,
                         int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward of a bias-free projection y = x W^T (x [M, K], W [N, K]) in ONE pass over the gradient G = dL/dy [M, N]:
+ * dX [M, K] = G W and dW [N, K] = G^T X — the packed input projection of nn.MultiheadAttention
+ * (kernel/sgcn_img_snp.py:240-241), whose key | value gradient is a 52 MB tensor that two separate GEMMs read twice.
+ * K == 32, N in {32, 64} (igcn_proj_bwd_supported); scratch: igcn_proj_bwd_blocks(M) * N * K floats; dW is a final
+ * reduction in the sense of igcn_reduce_defer. */
+int igcn_proj_bwd_supported(int64_t M, int N, int K);
+int igcn_proj_bwd_blocks(int64_t M);
+int igcn_proj_bwd(int64_t M, int N, int K, const float* G, const float* X, const float* W, float* dX, float* dW,
+                  float* scratch, void* stream);
+/* two projections with the same K in ONE launch (the query block and the key | value block of the packed in-projection) */
+int igcn_proj_bwd_pair(int64_t M1, int N1, const float* G1, const float* X1, const float* W1, float* dX1, float* dW1,
+                       float* scratch1, int64_t M2, int N2, const float* G2, const float* X2, const float* W2,
+                       float* dX2, float* dW2, float* scratch2, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SGCN over DENSE brain graphs (BASELINE configs[4]): batches whose graphs are COMPLETE — all R x R (source, target)

@@ -297,6 +297,25 @@ def test_projected_attention_matches_multihead_attention(ops, b, lq, lk, d, h):
     assert float(g[3][d:2 * d].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("m,n", [(64, 32), (1000, 64), (70001, 64), (4613, 32)])
+def test_proj_bwd_one_pass(ops, m, n):
+    """igcn_proj_bwd: dX = G W and dW = G^T X of a bias-free projection from ONE pass over G (K = 32; ragged last row
+    block, more row blocks than workgroups) against fp64."""
+    from igcn_amd._lib import call, load, ptr, stream_ptr
+    rng = np.random.default_rng(m + n)
+    mk = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32))     # noqa: E731
+    g, x, w = mk(m, n), mk(m, 32), mk(n, 32)
+    lib = load()
+    assert lib.igcn_proj_bwd_supported(m, n, 32) and not lib.igcn_proj_bwd_supported(m, n, 16)
+    gd, xd, wd = g.cuda(), x.cuda(), w.cuda()
+    dx = torch.empty(m, 32, device="cuda")
+    dw = torch.empty(n, 32, device="cuda")
+    scr = torch.empty(int(lib.igcn_proj_bwd_blocks(m)) * n * 32, device="cuda")
+    call("igcn_proj_bwd", m, n, 32, ptr(gd), ptr(xd), ptr(wd), ptr(dx), ptr(dw), ptr(scr), stream_ptr())
+    assert_matches(dx, (g.double() @ w.double()).numpy(), TOL, "dX")
+    assert_matches(dw, (g.double().t() @ x.double()).numpy(), TOL, "dW")
+
+
 def test_gemm_is_exact_fp32_fma_chain(ops):
     """MFMA f32 = k-ordered fmaf chain: small-integer operands must be reproduced exactly."""
     rng = np.random.default_rng(0)
