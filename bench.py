@@ -590,8 +590,13 @@ def stress_child(timeout=300):
     into the default line as ``stress``.  None (with the reason on stderr) when the child fails: the headline stands."""
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "stress", "--steps", "10", "--warmup", "3",
            "--cpu-baseline-seconds", "8", "--no-stress"]
+    # the child profiles into its own directory (a kept parent directory would hand it the parent's kernel summary)
+    env = dict(os.environ)
+    keep = env.pop("IGCN_BENCH_PROFILE_DIR", None)
+    if keep:
+        env["IGCN_BENCH_PROFILE_DIR"] = os.path.join(keep, "stress_child")
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
         if r.returncode != 0 or not lines:
             print(f"[bench] stress child failed (rc={r.returncode}): {r.stderr[-600:]}", file=sys.stderr)
