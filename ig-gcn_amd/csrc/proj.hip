@@ -19,7 +19,7 @@ extern "C" int igcn_proj_bwd_supported(int64_t M, int N, int K) { return K == PJ
 // workgroups: enough to fill the chip a few times, never more than row blocks
 extern "C" int igcn_proj_bwd_blocks(int64_t M) {
   const int64_t nb = igcn_cdiv(M, PJ_ROWS);
-  return (int)(nb < 1024 ? nb : 1024);
+  return (int)(nb < 512 ? nb : 512);          // every workgroup leaves an N x K partial for the final reduction (1024 / 512 / 320 workgroups: kernel 27.6 / 29.1 / 38.3 us, reduction 28.4 / 20.8 / 17.1)
 }
 
 struct PjArgs {
