@@ -1270,6 +1270,72 @@ def test_dropout_masks_one_launch(ops):
         assert abs(float((a > 0).float().mean()) - (1 - p)) < 0.12
 
 
+def test_dropout_launch_advances_the_batch_counters(ops):
+    """igcn_dropout_masks with counters: BatchNorm's num_batches_tracked words advance by `inc` per launch — eagerly and
+    on every replay of a captured launch — and nothing else of the contract changes."""
+    state = ops.DropoutState(torch.device("cuda"))
+    cnt = [torch.tensor(v, dtype=torch.int64, device="cuda") for v in (0, 7, 100)]
+    sites = [((16, 50), 0.5), ((33,), 0.25)]
+    m = ops.dropout_masks(sites, state, cnt, 2)
+    assert [int(c) for c in cnt] == [2, 9, 102] and tuple(m[0].shape) == (16, 50)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ops.dropout_masks(sites, state, cnt, 2)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert [int(c) for c in cnt] == [8, 15, 108]
+
+
+def test_grad_fan_sums_the_consumers_gradients_in_one_launch(ops):
+    """ops.GradFan: k aliases of a tensor, the k incoming gradients summed by igcn_sum_n (16-byte path and scalar tail),
+    a missing consumer gradient skipped, unaligned gradients summed by the fallback — all equal to autograd's own adds."""
+    rng = np.random.default_rng(3)
+    for shape in ((90, 3), (512, 5, 400), (1, 54), (7,)):
+        t = torch.from_numpy(rng.standard_normal(shape)).float().cuda().requires_grad_(True)
+        w = [torch.from_numpy(rng.standard_normal(shape)).float().cuda() for _ in range(3)]
+        a, b, c = ops.GradFan.apply(t, 3)
+        ((a * w[0]).sum() + (b * w[1]).sum() + (c * w[2]).sum()).backward()
+        assert_matches(t.grad, (w[0].double() + w[1].double() + w[2].double()).cpu().numpy(), 1e-6, "three consumers")
+        t.grad = None
+        a, b, c = ops.GradFan.apply(t, 3)
+        ((a * w[0]).sum() + (c * w[2]).sum()).backward()                  # the second alias is never used
+        assert_matches(t.grad, (w[0].double() + w[2].double()).cpu().numpy(), 1e-6, "two of three")
+        t.grad = None
+    # a gradient that is a misaligned view: the fallback adds
+    t = torch.zeros(8, device="cuda", requires_grad=True)
+    a, b = ops.GradFan.apply(t, 2)
+    base = torch.arange(9, dtype=torch.float32, device="cuda")
+    torch.autograd.backward([a, b], [base[1:], torch.ones(8, device="cuda")])
+    assert torch.equal(t.grad, base[1:] + 1)
+
+
+def test_fused_stack_adds_a_second_consumers_gradient_on_load(ops):
+    """ops.SgcnStack with the dual output (negative rois): two autograd handles of one buffer, whose gradients the
+    backward kernel adds while staging — equal to the single-output op fed the sum."""
+    from igcn_amd import synth
+    rng = np.random.default_rng(8)
+    b = synth.brain_batch(5, seed=2, rois=90).to("cuda")
+    plan = ops.plan_for(b)
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s)).float().cuda()             # noqa: E731
+    ws = [t(16, 3) * 0.5, t(16) * 0.1, t(16, 16) * 0.3, t(16) * 0.1]
+    g1, g2 = t(450, 32), t(450, 32)
+    res = []
+    for dual in (True, False):
+        x = b.x.clone().requires_grad_(True)
+        par = [w.clone().requires_grad_(True) for w in ws]
+        if dual:
+            y1, y2 = ops.SgcnStack.apply(x, b.edge_attr, plan, -90, *par)
+            assert y1.data_ptr() == y2.data_ptr()
+            torch.autograd.backward([y1, y2], [g1, g2])
+        else:
+            y = ops.SgcnStack.apply(x, b.edge_attr, plan, 90, *par)
+            y.backward(g1 + g2)
+        res.append([x.grad] + [p.grad for p in par])
+    for a, c in zip(*res):
+        assert_matches(a, c.cpu().numpy(), 2e-6, "dual vs summed")
+
+
 def test_consumers_apply_the_dropout_factors(ops):
     """`keep` inside igcn_small_linear_*, igcn_bn1d_* and igcn_node_linear_bn_* (D = 1) equals a multiply in front of /
     behind the unfused op, forward and backward."""
