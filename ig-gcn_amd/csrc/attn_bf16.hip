@@ -1,0 +1,361 @@
+// Cross-attention core with bf16 operands on v_mfma_f32_16x16x32_bf16 (kernel/sgcn_img_snp.py:240, nn.MultiheadAttention
+// core; BASELINE configs[4] "bf16 feature transforms on CDNA4 MFMA"): the five products of the attention — q k^T, p v,
+// do v^T, ds k, ds^T q | p^T do — take operands rounded to bf16 (round to nearest even) and accumulate in fp32; the
+// softmax (row maximum, exponentials, denominator, log-sum-exp) and delta = rowsum(o * do) stay fp32, and q, k | v, o
+// and every gradient stay fp32 in HBM.  head_dim must be 16 (the model's 32-wide embedding over 2 heads).
+//
+// Same decomposition as the streamed fp32 kernels (attn_mfma.hip):
+//   forward / dQ : workgroup = (sample, head, block of 16 nw queries), wave = one 16-query tile, KEY chunks through LDS
+//   dK | dV      : workgroup = (sample, head, block of 16 nw keys),    wave = one 16-key tile,  QUERY chunks through LDS
+// but one step covers 32 rows of the streamed side, not 16:
+//   * score tiles  S^T[key][query] (two per step): A = 16 staged rows x head_dim (a 16-byte LDS read per lane; the
+//     instruction's reduction depth is 32, lanes 32..63 pair with the resident side's zero half), B = the wave's own
+//     tile from registers.
+//   * the accumulator layout of the two score tiles (lane (g, n): rows 4 g + r of tile 0 and of tile 1, column n) IS a
+//     B operand of the 32-deep instruction once packed to bf16 — slot j < 4 = row 4 g + j of tile 0, slot j >= 4 =
+//     row 16 + 4 g + (j - 4) — so probabilities / score gradients feed the second product without leaving registers;
+//     the A operand (values, keys, queries or do TRANSPOSED: [head_dim][rows]) is read from LDS in the same slot
+//     order: two 8-byte reads per lane.
+// The streamed side is therefore staged twice where both orientations are needed (row-major [rows][16] and
+// transposed [16][rows + pad]), 2 bytes per element.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define AB_HD 16
+#define AB_MAX_WAVES 8
+#define AB_KEY_CHUNK 448          // keys per chunk of the forward / dQ kernels (31 / 46 KB of LDS: several workgroups per CU)
+#define AB_QUERY_CHUNK 256        // queries per chunk of the dK | dV kernel (35 KB)
+
+__device__ __forceinline__ f32x4 mfma32(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// row length of a transposed tile: >= rows, and = 16 (mod 128) elements, i.e. 32 bytes (mod 256): the sixteen
+// head-dim rows an operand read touches then start 8 banks apart
+__host__ __device__ inline int ab_ldt(int rows) { return ((rows + 111) / 128) * 128 + 16; }
+
+__device__ __forceinline__ bf16x4 ab_cvt4(const float4 v) {
+  return bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+}
+
+__device__ __forceinline__ bf16x8 ab_pack(const float a[4], const float b[4]) {
+  return bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+}
+
+// eight consecutive floats of a row -> the resident side's operand half (lanes g < 2); lanes g >= 2 hold zeros
+__device__ __forceinline__ bf16x8 ab_row8(const float* __restrict__ row, bool live, float scale) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)0.f;
+  if (live) {
+    const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 4);
+    r = bf16x8{(__bf16)(a.x * scale), (__bf16)(a.y * scale), (__bf16)(a.z * scale), (__bf16)(a.w * scale),
+               (__bf16)(b.x * scale), (__bf16)(b.y * scale), (__bf16)(b.z * scale), (__bf16)(b.w * scale)};
+  }
+  return r;
+}
+
+// the transposed operand of a 32-row step: slots 0..3 = rows 4 g .. 4 g + 3, slots 4..7 = rows 16 + 4 g .. of the step
+__device__ __forceinline__ bf16x8 ab_tfrag(const __bf16* __restrict__ t, int ldt, int n, int g, int step) {
+  const __bf16* p = t + n * ldt + step * 32 + 4 * g;
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(p), b = *reinterpret_cast<const bf16x4*>(p + 16);
+  return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+// row-major operand of tile `tile` (16 rows): lane (g, n) reads columns 8 (g & 1) .. + 7 of row n; lanes g >= 2 read
+// the same bytes again — their products meet the resident side's zeros
+__device__ __forceinline__ bf16x8 ab_rfrag(const __bf16* __restrict__ r, int tile, int n, int g) {
+  return *reinterpret_cast<const bf16x8*>(r + (tile * 16 + n) * AB_HD + 8 * (g & 1));
+}
+
+// Rows [0, rows_valid) of two row_stride-strided fp32 sources (16 floats per row) -> bf16 in LDS, each in the layouts
+// asked for: R* row-major [rows_pad][16], T* transposed [16][ldt].  Rows up to rows_pad (a multiple of 32) are zeros.
+// One item = two rows x four columns of both sources: four 16-byte loads, then 8-byte row-major stores and 4-byte
+// (row pair) transposed stores.
+template <bool RA, bool TA, bool RB, bool TB>
+__device__ __forceinline__ void ab_stage(const float* __restrict__ a, const float* __restrict__ b, int64_t row_stride,
+                                         int rows_valid, int rows_pad, int ldt, __bf16* __restrict__ ra,
+                                         __bf16* __restrict__ ta, __bf16* __restrict__ rb, __bf16* __restrict__ tb) {
+  const int items = rows_pad * 2;
+  for (int t = threadIdx.x; t < items; t += blockDim.x) {
+    const int c = (t & 3) * 4, r0 = (t >> 2) * 2;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a0 = z, a1 = z, b0 = z, b1 = z;
+    if (r0 < rows_valid) {
+      a0 = *reinterpret_cast<const float4*>(a + (int64_t)r0 * row_stride + c);
+      b0 = *reinterpret_cast<const float4*>(b + (int64_t)r0 * row_stride + c);
+    }
+    if (r0 + 1 < rows_valid) {
+      a1 = *reinterpret_cast<const float4*>(a + (int64_t)(r0 + 1) * row_stride + c);
+      b1 = *reinterpret_cast<const float4*>(b + (int64_t)(r0 + 1) * row_stride + c);
+    }
+    if constexpr (RA) {
+      *reinterpret_cast<bf16x4*>(ra + r0 * AB_HD + c) = ab_cvt4(a0);
+      *reinterpret_cast<bf16x4*>(ra + (r0 + 1) * AB_HD + c) = ab_cvt4(a1);
+    }
+    if constexpr (RB) {
+      *reinterpret_cast<bf16x4*>(rb + r0 * AB_HD + c) = ab_cvt4(b0);
+      *reinterpret_cast<bf16x4*>(rb + (r0 + 1) * AB_HD + c) = ab_cvt4(b1);
+    }
+    if constexpr (TA) {
+      const float x0[4] = {a0.x, a0.y, a0.z, a0.w}, x1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<bf16x2*>(ta + (c + e) * ldt + r0) = bf16x2{(__bf16)x0[e], (__bf16)x1[e]};
+    }
+    if constexpr (TB) {
+      const float x0[4] = {b0.x, b0.y, b0.z, b0.w}, x1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<bf16x2*>(tb + (c + e) * ldt + r0) = bf16x2{(__bf16)x0[e], (__bf16)x1[e]};
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// forward: o = softmax(q k^T / 4) v, lse = log sum exp of the scaled scores (fp32, for the backward)
+// -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64 * AB_MAX_WAVES)
+k_attn_bf16_fwd(int H, int Lq, int Lk, int CH, const float* __restrict__ q, const float* __restrict__ kv,
+                float* __restrict__ o, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ab_smem[];
+  const int ldt = ab_ldt(CH);
+  __bf16* Kb = reinterpret_cast<__bf16*>(ab_smem);                // [CH][16]
+  __bf16* Vt = Kb + (size_t)CH * AB_HD;                           // [16][ldt]
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * AB_HD;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
+  const int qi = (blockIdx.y * nw + w) * 16 + n;                  // this wave's query tile (may be past Lq)
+  const bool qlive = qi < Lq;
+  const bf16x8 qf = ab_row8(q + (int64_t)(b * Lq + (qlive ? qi : 0)) * D + h * AB_HD + 8 * (g & 1), qlive && g < 2, 0.25f);
+  float m = -INFINITY, l = 0.f;
+  f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < Lk; k0 += CH) {
+    const int kn = min(CH, Lk - k0), knp = (kn + 31) & ~31;
+    __syncthreads();                                              // previous chunk fully consumed
+    const float* kbase = kv + ((int64_t)b * Lk + k0) * 2 * D + h * AB_HD;
+    ab_stage<true, false, false, true>(kbase, kbase + D, 2 * D, kn, knp, ldt, Kb, nullptr, nullptr, Vt);
+    __syncthreads();
+    for (int st = 0; st < (knp >> 5); ++st) {
+      const f32x4 s0 = mfma32(ab_rfrag(Kb, 2 * st, n, g), qf, zero);
+      const f32x4 s1 = mfma32(ab_rfrag(Kb, 2 * st + 1, n, g), qf, zero);
+      float a[4], c[4], tmax = -INFINITY;
+      const int kr = st * 32 + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a[r] = kr + r < kn ? s0[r] : -INFINITY;
+        c[r] = kr + 16 + r < kn ? s1[r] : -INFINITY;
+        tmax = fmaxf(tmax, fmaxf(a[r], c[r]));
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mn = fmaxf(m, tmax);                            // finite: a step holds at least one live key
+      const float f = __expf(m - mn);
+      m = mn;
+      l *= f;
+      oacc *= f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a[r] = __expf(a[r] - m);
+        c[r] = __expf(c[r] - m);
+        l += a[r] + c[r];
+      }
+      oacc = mfma32(ab_tfrag(Vt, ldt, n, g, st), ab_pack(a, c), oacc);
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (qlive) {
+    const float inv = 1.f / l;
+    *reinterpret_cast<float4*>(o + (int64_t)(b * Lq + qi) * D + h * AB_HD + 4 * g) =
+        make_float4(oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv);
+    if (g == 0) lse[((int64_t)b * H + h) * Lq + qi] = m + __logf(l);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// dQ (and delta = rowsum(o * do) for the dK | dV kernel)
+// -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64 * AB_MAX_WAVES)
+k_attn_bf16_bwd_dq(int H, int Lq, int Lk, int CH, const float* __restrict__ q, const float* __restrict__ kv,
+                   const float* __restrict__ o, const float* __restrict__ lse, const float* __restrict__ dout,
+                   float* __restrict__ dq, float* __restrict__ delta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ab_smem[];
+  const int ldt = ab_ldt(CH);
+  __bf16* Kb = reinterpret_cast<__bf16*>(ab_smem);                // [CH][16]
+  __bf16* Vb = Kb + (size_t)CH * AB_HD;                           // [CH][16]
+  __bf16* Kt = Vb + (size_t)CH * AB_HD;                           // [16][ldt]
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * AB_HD;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
+  const int qi = (blockIdx.y * nw + w) * 16 + n;
+  const bool qlive = qi < Lq;
+  const int64_t rowoff = (int64_t)(b * Lq + (qlive ? qi : 0)) * D + h * AB_HD;
+  const bf16x8 qf = ab_row8(q + rowoff + 8 * (g & 1), qlive && g < 2, 0.25f);
+  const bf16x8 dof = ab_row8(dout + rowoff + 8 * (g & 1), qlive && g < 2, 1.f);
+  // delta of this lane's query: lanes g = 0..3 of a column each take four head columns
+  float dpart = 0.f;
+  if (qlive) {
+    const float4 ov = *reinterpret_cast<const float4*>(o + rowoff + 4 * g);
+    const float4 dv = *reinterpret_cast<const float4*>(dout + rowoff + 4 * g);
+    dpart = ov.x * dv.x + ov.y * dv.y + ov.z * dv.z + ov.w * dv.w;
+  }
+  dpart += __shfl_xor(dpart, 16, 64);
+  dpart += __shfl_xor(dpart, 32, 64);
+  const float dln = dpart;
+  const float lsn = qlive ? lse[((int64_t)b * H + h) * Lq + qi] : INFINITY;
+  if (qlive && g == 0) delta[((int64_t)b * H + h) * Lq + qi] = dln;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < Lk; k0 += CH) {
+    const int kn = min(CH, Lk - k0), knp = (kn + 31) & ~31;
+    __syncthreads();
+    const float* kbase = kv + ((int64_t)b * Lk + k0) * 2 * D + h * AB_HD;
+    ab_stage<true, true, true, false>(kbase, kbase + D, 2 * D, kn, knp, ldt, Kb, Kt, Vb, nullptr);
+    __syncthreads();
+    for (int st = 0; st < (knp >> 5); ++st) {
+      const f32x4 s0 = mfma32(ab_rfrag(Kb, 2 * st, n, g), qf, zero);
+      const f32x4 s1 = mfma32(ab_rfrag(Kb, 2 * st + 1, n, g), qf, zero);
+      const f32x4 d0 = mfma32(ab_rfrag(Vb, 2 * st, n, g), dof, zero);
+      const f32x4 d1 = mfma32(ab_rfrag(Vb, 2 * st + 1, n, g), dof, zero);
+      float a[4], c[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                               // padded keys: their K^T columns are zeros
+        a[r] = __expf(s0[r] - lsn) * (d0[r] - dln) * 0.25f;
+        c[r] = __expf(s1[r] - lsn) * (d1[r] - dln) * 0.25f;
+      }
+      acc = mfma32(ab_tfrag(Kt, ldt, n, g, st), ab_pack(a, c), acc);
+    }
+  }
+  if (qlive)
+    *reinterpret_cast<float4*>(dq + rowoff + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// dK | dV
+// -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64 * AB_MAX_WAVES)
+k_attn_bf16_bwd_dkv(int H, int Lq, int Lk, int CH, const float* __restrict__ q, const float* __restrict__ kv,
+                    const float* __restrict__ lse, const float* __restrict__ dout, const float* __restrict__ delta,
+                    float* __restrict__ dkv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ab_smem[];
+  const int ldt = ab_ldt(CH);
+  __bf16* Qb = reinterpret_cast<__bf16*>(ab_smem);                // [CH][16]
+  __bf16* Ob = Qb + (size_t)CH * AB_HD;                           // [CH][16]    do, row-major
+  __bf16* Qt = Ob + (size_t)CH * AB_HD;                           // [16][ldt]
+  __bf16* Ot = Qt + (size_t)AB_HD * ldt;                          // [16][ldt]
+  float* ls = reinterpret_cast<float*>(Ot + (size_t)AB_HD * ldt); // [CH]
+  float* dl = ls + CH;                                            // [CH]
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * AB_HD;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
+  const int ki = (blockIdx.y * nw + w) * 16 + n;
+  const bool klive = ki < Lk;
+  const int64_t rowoff = ((int64_t)(b * Lk + (klive ? ki : 0)) * 2) * D + h * AB_HD;
+  const bf16x8 kf = ab_row8(kv + rowoff + 8 * (g & 1), klive && g < 2, 0.25f);
+  const bf16x8 vf = ab_row8(kv + rowoff + D + 8 * (g & 1), klive && g < 2, 1.f);
+  f32x4 dka = {0.f, 0.f, 0.f, 0.f}, dva = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int q0 = 0; q0 < Lq; q0 += CH) {
+    const int qn = min(CH, Lq - q0), qnp = (qn + 31) & ~31;
+    __syncthreads();
+    const int64_t qoff = ((int64_t)b * Lq + q0) * D + h * AB_HD;
+    ab_stage<true, true, true, true>(q + qoff, dout + qoff, D, qn, qnp, ldt, Qb, Qt, Ob, Ot);
+    for (int r = threadIdx.x; r < qnp; r += blockDim.x) {
+      const bool in = r < qn;
+      ls[r] = in ? lse[((int64_t)b * H + h) * Lq + q0 + r] : INFINITY;       // padding queries: p = 0
+      dl[r] = in ? delta[((int64_t)b * H + h) * Lq + q0 + r] : 0.f;
+    }
+    __syncthreads();
+    for (int st = 0; st < (qnp >> 5); ++st) {
+      // S orientation: rows = queries 4 g + r of the tile, column = this lane's key n
+      const f32x4 s0 = mfma32(ab_rfrag(Qb, 2 * st, n, g), kf, zero);
+      const f32x4 s1 = mfma32(ab_rfrag(Qb, 2 * st + 1, n, g), kf, zero);
+      const f32x4 d0 = mfma32(ab_rfrag(Ob, 2 * st, n, g), vf, zero);
+      const f32x4 d1 = mfma32(ab_rfrag(Ob, 2 * st + 1, n, g), vf, zero);
+      const float4 l0 = *reinterpret_cast<const float4*>(ls + st * 32 + 4 * g);
+      const float4 l1 = *reinterpret_cast<const float4*>(ls + st * 32 + 16 + 4 * g);
+      const float4 e0 = *reinterpret_cast<const float4*>(dl + st * 32 + 4 * g);
+      const float4 e1 = *reinterpret_cast<const float4*>(dl + st * 32 + 16 + 4 * g);
+      const float la[4] = {l0.x, l0.y, l0.z, l0.w}, lc[4] = {l1.x, l1.y, l1.z, l1.w};
+      const float ea[4] = {e0.x, e0.y, e0.z, e0.w}, ec[4] = {e1.x, e1.y, e1.z, e1.w};
+      float pa[4], pc[4], da[4], dc[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pa[r] = __expf(s0[r] - la[r]);
+        pc[r] = __expf(s1[r] - lc[r]);
+        da[r] = pa[r] * (d0[r] - ea[r]) * 0.25f;
+        dc[r] = pc[r] * (d1[r] - ec[r]) * 0.25f;
+      }
+      dva = mfma32(ab_tfrag(Ot, ldt, n, g, st), ab_pack(pa, pc), dva);
+      dka = mfma32(ab_tfrag(Qt, ldt, n, g, st), ab_pack(da, dc), dka);
+    }
+  }
+  if (klive) {
+    *reinterpret_cast<float4*>(dkv + rowoff + 4 * g) = make_float4(dka[0], dka[1], dka[2], dka[3]);
+    *reinterpret_cast<float4*>(dkv + rowoff + D + 4 * g) = make_float4(dva[0], dva[1], dva[2], dva[3]);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------------------
+static int ab_waves(int tiles) { return tiles < AB_MAX_WAVES ? (tiles < 4 ? 4 : tiles) : AB_MAX_WAVES; }
+static int ab_chunk(int rows, int cap) {
+  const int padded = (rows + 31) & ~31;
+  return padded < cap ? padded : cap;
+}
+
+static bool ab_shape_ok(int D, int H, int Lq, int Lk) { return H > 0 && D == H * AB_HD && Lq > 0 && Lk > 0; }
+
+// what a model asks before routing here (the A/B switch IGCN_OPT_ATTN_FP32_CORE answers 0; the entry points below
+// still run when called directly)
+extern "C" int igcn_attn_core_bf16_supported(int D, int H, int Lq, int Lk) {
+  return ab_shape_ok(D, H, Lq, Lk) && !igcn_opt(IGCN_OPT_ATTN_FP32_CORE);
+}
+
+static int ab_check(const char* what, int B, int D, int H, int Lq, int Lk, const void* a, const void* b, const void* c,
+                    const void* d) {
+  if (!ab_shape_ok(D, H, Lq, Lk) || B <= 0) {
+    igcn_set_error("%s: head_dim must be 16 (B=%d D=%d H=%d Lq=%d Lk=%d)", what, B, D, H, Lq, Lk);
+    return IGCN_ERR_UNSUPPORTED;
+  }
+  IGCN_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0, "attn_core_bf16: operands must be 16-byte aligned");
+  IGCN_REQUIRE((int64_t)B * H <= 0x7fffffff && (int64_t)B * (Lq > Lk ? Lq : Lk) <= 0x7fffffff, "attn_core_bf16: batch too large");
+  return IGCN_OK;
+}
+
+extern "C" int igcn_attn_core_bf16_fwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o,
+                                       float* lse, void* stream) {
+  int rc = ab_check("attn_core_bf16_fwd", B, D, H, Lq, Lk, q, kv, o, o);
+  if (rc) return rc;
+  const int ch = ab_chunk(Lk, AB_KEY_CHUNK), ldt = ab_ldt(ch);
+  const size_t lds = ((size_t)ch * AB_HD + (size_t)AB_HD * ldt) * 2;
+  const int nqt = (Lq + 15) / 16, nw = ab_waves(nqt);
+  hipLaunchKernelGGL(k_attn_bf16_fwd, dim3(B * H, (nqt + nw - 1) / nw), dim3(64 * nw), lds, (hipStream_t)stream, H, Lq,
+                     Lk, ch, q, kv, o, lse);
+  IGCN_CHECK_LAUNCH("attn_core_bf16_fwd");
+  return IGCN_OK;
+}
+
+// scratch: igcn_attn_core_bwd_scratch_floats(B, H, Lq) floats (delta)
+extern "C" int igcn_attn_core_bf16_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv,
+                                       const float* o, const float* lse, const float* dout, float* dq, float* dkv,
+                                       float* scratch, void* stream) {
+  int rc = ab_check("attn_core_bf16_bwd", B, D, H, Lq, Lk, q, kv, o, dout);
+  if (rc) return rc;
+  IGCN_REQUIRE(scratch != nullptr && (((uintptr_t)dq | (uintptr_t)dkv) & 15) == 0, "attn_core_bf16_bwd: scratch / aligned gradients needed");
+  hipStream_t st = (hipStream_t)stream;
+  const int chk = ab_chunk(Lk, AB_KEY_CHUNK), chq = ab_chunk(Lq, AB_QUERY_CHUNK);
+  const size_t lds_q = ((size_t)2 * chk * AB_HD + (size_t)AB_HD * ab_ldt(chk)) * 2;
+  const size_t lds_k = ((size_t)2 * chq * AB_HD + (size_t)2 * AB_HD * ab_ldt(chq)) * 2 + (size_t)2 * chq * sizeof(float);
+  const int nqt = (Lq + 15) / 16, nkt = (Lk + 15) / 16, nwq = ab_waves(nqt), nwk = ab_waves(nkt);
+  hipLaunchKernelGGL(k_attn_bf16_bwd_dq, dim3(B * H, (nqt + nwq - 1) / nwq), dim3(64 * nwq), lds_q, st, H, Lq, Lk, chk,
+                     q, kv, o, lse, dout, dq, scratch);
+  hipLaunchKernelGGL(k_attn_bf16_bwd_dkv, dim3(B * H, (nkt + nwk - 1) / nwk), dim3(64 * nwk), lds_k, st, H, Lq, Lk,
+                     chq, q, kv, lse, dout, scratch, dkv);
+  IGCN_CHECK_LAUNCH("attn_core_bf16_bwd");
+  return IGCN_OK;
+}

@@ -1696,9 +1696,11 @@ class ProjectedAttention(torch.autograd.Function):
         q, kv = q.view(b, lq, d), kv.view(b, lk, 2 * d)
         o = torch.empty_like(q)
         lse = torch.empty(b, heads, lq, dtype=torch.float32, device=q.device)
-        call("igcn_attn_core_fwd", b, d, heads, lq, lk, ptr(q), ptr(kv), ptr(o), ptr(lse), stream_ptr())
+        core16 = bool(bf16) and attn_core_bf16(d, heads, lq, lk)
+        call("igcn_attn_core_bf16_fwd" if core16 else "igcn_attn_core_fwd", b, d, heads, lq, lk, ptr(q), ptr(kv), ptr(o),
+             ptr(lse), stream_ptr())
         ctx.save_for_backward(q2, m2, w, q, kv, o, lse)
-        ctx.heads, ctx.bf16, ctx.final = heads, bf16, _leaves(w, bias)
+        ctx.heads, ctx.bf16, ctx.core16, ctx.final = heads, bf16, core16, _leaves(w, bias)
         ctx.shapes = (query.shape, memory.shape)
         return o
 
@@ -1711,8 +1713,8 @@ class ProjectedAttention(torch.autograd.Function):
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         nscr = int(_lib.load().igcn_attn_core_bwd_scratch_floats(b, ctx.heads, lq))
         scratch = torch.empty(nscr, dtype=torch.float32, device=q.device)
-        call("igcn_attn_core_bwd", b, d, ctx.heads, lq, lk, ptr(q), ptr(kv), ptr(o), ptr(lse), ptr(dout), ptr(dq),
-             ptr(dkv), ptr(scratch), stream_ptr())
+        call("igcn_attn_core_bf16_bwd" if ctx.core16 else "igcn_attn_core_bwd", b, d, ctx.heads, lq, lk, ptr(q), ptr(kv),
+             ptr(o), ptr(lse), ptr(dout), ptr(dq), ptr(dkv), ptr(scratch), stream_ptr())
         dq2, dkv2 = dq.view(-1, d), dkv.view(-1, 2 * d)
         dw = torch.empty_like(w)
         db = torch.empty(3 * d, dtype=torch.float32, device=w.device)
@@ -1790,19 +1792,27 @@ def attn_core_supported(d, h, lq, lk):
     return bool(lib.igcn_attn_core_lds_bytes(d, h, lq, lk, 0)) and bool(lib.igcn_attn_core_lds_bytes(d, h, lq, lk, 1))
 
 
+def attn_core_bf16(d, h, lq, lk):
+    """The bf16-operand core (v_mfma_f32_16x16x32_bf16) covers this shape (head_dim 16); IGCN_ATTN_FP32_CORE=1 (read
+    once at load) keeps the fp32 core under bf16 feature transforms (A/B runs)."""
+    return bool(_lib.load().igcn_attn_core_bf16_supported(d, h, lq, lk))
+
+
 class AttentionCore(torch.autograd.Function):
     """softmax(q k^T/sqrt(hd)) v per head on the projection outputs in place: q [B,Lq,D], kv [B,Lk,2D] -> [B,Lq,D]."""
 
     @staticmethod
-    def forward(ctx, q, kv, heads):
+    def forward(ctx, q, kv, heads, bf16=False):
         q, kv = _f32(q), _f32(kv)
         b, lq, d = q.shape
         lk = kv.shape[1]
         o = torch.empty_like(q)
         lse = torch.empty(b, heads, lq, dtype=torch.float32, device=q.device)
-        call("igcn_attn_core_fwd", b, d, heads, lq, lk, ptr(q), ptr(kv), ptr(o), ptr(lse), stream_ptr())
+        core16 = bool(bf16) and attn_core_bf16(d, heads, lq, lk)
+        call("igcn_attn_core_bf16_fwd" if core16 else "igcn_attn_core_fwd", b, d, heads, lq, lk, ptr(q), ptr(kv), ptr(o),
+             ptr(lse), stream_ptr())
         ctx.save_for_backward(q, kv, o, lse)
-        ctx.heads = heads
+        ctx.heads, ctx.core16 = heads, core16
         return o
 
     @staticmethod
@@ -1814,6 +1824,6 @@ class AttentionCore(torch.autograd.Function):
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         nscr = int(_lib.load().igcn_attn_core_bwd_scratch_floats(b, ctx.heads, lq))
         scratch = torch.empty(nscr, dtype=torch.float32, device=q.device)
-        call("igcn_attn_core_bwd", b, d, ctx.heads, lq, lk, ptr(q), ptr(kv), ptr(o), ptr(lse), ptr(dout), ptr(dq),
-             ptr(dkv), ptr(scratch), stream_ptr())
-        return dq, dkv, None
+        call("igcn_attn_core_bf16_bwd" if ctx.core16 else "igcn_attn_core_bwd", b, d, ctx.heads, lq, lk, ptr(q), ptr(kv),
+             ptr(o), ptr(lse), ptr(dout), ptr(dq), ptr(dkv), ptr(scratch), stream_ptr())
+        return dq, dkv, None, None

@@ -31,12 +31,12 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 306
+#define IGCN_ABI_VERSION 307
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
  * list walks, 1 no LDS-staged dense aggregation, 2 untiled CSR map kernels, 3 global-memory GO attention backward, 4 print
- * deferred reductions; gemm_bn_cap > 0 caps the GEMM tile width, attn_chunk_rows > 0 the rows per LDS chunk of the streamed
+ * deferred reductions, 5 fp32 attention core under bf16 transforms; gemm_bn_cap > 0 caps the GEMM tile width, attn_chunk_rows > 0 the rows per LDS chunk of the streamed
  * attention kernels (sweeps).  No launch path reads the environment. */
 int igcn_configure(unsigned options, int gemm_bn_cap, int attn_chunk_rows);
 
@@ -510,6 +510,16 @@ int igcn_attn_core_bwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
                        const float* lse, const float* dout, float* dq, float* dkv,
                        float* scratch /* igcn_attn_core_bwd_scratch_floats(): rowsum(o*do) of the chunked path */,
                        void* stream);
+/* The same core with bf16 OPERANDS on v_mfma_f32_16x16x32_bf16 (BASELINE configs[4] "bf16 feature transforms on
+ * CDNA4 MFMA"): q k^T, p v and the three gradient products take operands rounded to bf16 and accumulate in fp32; the
+ * softmax, lse and delta stay fp32, and every tensor stays fp32 in HBM (same layouts and signatures as above; scratch
+ * is always needed).  head_dim must be 16 (igcn_attn_core_bf16_supported); any Lq, Lk (both sides streamed through
+ * LDS in chunks).  Tolerance vs the fp32 core: ~4e-3 relative on o, ~1e-2 on the gradients (tests/test_gpu_ops.py). */
+int igcn_attn_core_bf16_supported(int D, int H, int Lq, int Lk);
+int igcn_attn_core_bf16_fwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o, float* lse,
+                            void* stream);
+int igcn_attn_core_bf16_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
+                            const float* lse, const float* dout, float* dq, float* dkv, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sparse SNP<->GO maps with learnable non-zeros — gene encoding go_model.py:208-215 (C=2 channels,

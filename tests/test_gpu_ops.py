@@ -855,6 +855,39 @@ def test_attention_core(ops, bsz, lq, lk, d):
     assert_matches(g[1], g_ref[1].numpy(), 2e-4, "dkv", floor=1e-6)
 
 
+@pytest.mark.parametrize("bsz,lq,lk", [(4, 90, 400), (2, 512, 1300), (3, 50, 37), (2, 16, 32), (1, 7, 5),
+                                        (1, 300, 2500), (2, 1100, 90)])
+def test_attention_core_bf16_operands(ops, bsz, lq, lk):
+    """igcn_attn_core_bf16_*: the same attention with bf16 OPERANDS on the matrix cores (fp32 accumulation, fp32 softmax).
+    Against fp64 torch: o within 1e-2, the gradients within 3e-2 of their scale (bf16 has 8 mantissa bits: 4e-3 per
+    operand, averaged down over the reductions); and NOT identical to the fp32 core, so the test sees the kernels it
+    names.  Ragged tile edges (50, 37, 7, 5), one chunk and several chunks on either side."""
+    rng = np.random.default_rng(lq * lk + 1)
+    h, d = 2, 32
+    q = torch.from_numpy(rng.standard_normal((bsz, lq, d))).float()
+    kv = torch.from_numpy(rng.standard_normal((bsz, lk, 2 * d))).float()
+    cot = torch.from_numpy(rng.standard_normal((bsz, lq, d))).float()
+    rq, rkv = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    qh = rq.view(bsz, lq, h, d // h).transpose(1, 2)
+    kvh = rkv.view(bsz, lk, 2, h, d // h)
+    k_, v_ = kvh[:, :, 0].transpose(1, 2), kvh[:, :, 1].transpose(1, 2)
+    att = torch.softmax(qh @ k_.transpose(-1, -2) / (d // h) ** 0.5, dim=-1)
+    o_ref = (att @ v_).transpose(1, 2).reshape(bsz, lq, d)
+    g_ref = torch.autograd.grad((o_ref * cot.double()).sum(), [rq, rkv])
+    assert ops.attn_core_bf16(d, h, lq, lk)
+    dq_, dkv_ = q.cuda().requires_grad_(True), kv.cuda().requires_grad_(True)
+    o = ops.AttentionCore.apply(dq_, dkv_, h, True)
+    g = torch.autograd.grad((o * cot.cuda()).sum(), [dq_, dkv_])
+    o32 = ops.AttentionCore.apply(dq_, dkv_, h)
+    assert not torch.equal(o, o32)
+    assert_matches(o, o_ref.detach().numpy(), 1e-2, "o")
+    assert_matches(g[0], g_ref[0].numpy(), 3e-2, "dq")
+    assert_matches(g[1], g_ref[1].numpy(), 3e-2, "dkv")
+    # rms error well under the bound (a systematic layout slip shows up here long before it reaches the max)
+    rel = lambda a, w: float((a.detach().cpu().double() - w).pow(2).mean().sqrt() / w.pow(2).mean().sqrt())   # noqa: E731
+    assert rel(o, o_ref.detach()) < 5e-3 and rel(g[0], g_ref[0]) < 1e-2 and rel(g[1], g_ref[1]) < 1e-2
+
+
 def test_loss_head_matches_composite():
     """igcn_loss_head_* against the term-by-term composition of train() :525-543 (fp64 torch), values and gradients."""
     import torch.nn.functional as F

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Attention core (igcn_attn_core_*) alone at the bench shape: event-timed forward / backward, for A/B runs and
-rocprofv3 --pmc passes.  usage: attn_bench.py [B=512] [Lq=90] [Lk=400] [iters=20]"""
+rocprofv3 --pmc passes.  usage: attn_bench.py [B=512] [Lq=90] [Lk=400] [iters=20] [core=fp32|bf16]"""
 import os
 import sys
 
@@ -15,6 +15,8 @@ b = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 lq = int(sys.argv[2]) if len(sys.argv) > 2 else 90
 lk = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+core = sys.argv[5] if len(sys.argv) > 5 else "fp32"
+FWD, BWD = ("igcn_attn_core_bf16_fwd", "igcn_attn_core_bf16_bwd") if core == "bf16" else ("igcn_attn_core_fwd", "igcn_attn_core_bwd")
 h, d = 2, 32
 dev = "cuda"
 q = torch.randn(b, lq, d, device=dev)
@@ -27,11 +29,11 @@ scr = torch.empty(b * h * lq + 16, device=dev)
 
 
 def fwd():
-    call("igcn_attn_core_fwd", b, d, h, lq, lk, q.data_ptr(), kv.data_ptr(), o.data_ptr(), lse.data_ptr(), stream_ptr())
+    call(FWD, b, d, h, lq, lk, q.data_ptr(), kv.data_ptr(), o.data_ptr(), lse.data_ptr(), stream_ptr())
 
 
 def bwd():
-    call("igcn_attn_core_bwd", b, d, h, lq, lk, q.data_ptr(), kv.data_ptr(), o.data_ptr(), lse.data_ptr(),
+    call(BWD, b, d, h, lq, lk, q.data_ptr(), kv.data_ptr(), o.data_ptr(), lse.data_ptr(),
          do.data_ptr(), dq.data_ptr(), dkv.data_ptr(), scr.data_ptr(), stream_ptr())
 
 
@@ -47,4 +49,4 @@ for name, fn in (("fwd", fwd), ("bwd", bwd)):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     flops = b * h * lq * lk * 16 * 2 * (2 if name == "fwd" else 5)
-    print(f"{name}: {us:8.1f} us   {flops / us / 1e6:6.1f} TFLOP/s (useful)", flush=True)
+    print(f"{core} {name}: {us:8.1f} us   {flops / us / 1e6:6.1f} TFLOP/s (useful)", flush=True)
