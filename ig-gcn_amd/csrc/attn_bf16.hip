@@ -118,7 +118,48 @@ __device__ __forceinline__ void ab_stage(const float* __restrict__ a, const floa
 
 // -------------------------------------------------------------------------------------------------------------
 // forward: o = softmax(q k^T / 4) v, lse = log sum exp of the scaled scores (fp32, for the backward)
+//
+// Scores are kept in the log2 domain (q is scaled by log2(e) / 4 before it is rounded: every exponential is then one
+// v_exp_f32, no multiply in front), and the running maximum is LAZY: a step rescales the accumulator only when one of
+// its scores exceeds the reference by more than 2^8 — decided by a wave-wide vote, so the two cross-lane maximum
+// exchanges and the rescale leave the loop's dependency chain after the first steps.  Probabilities may then reach
+// 256 instead of 1: exact for the fp32 denominator, and bf16 has fp32's exponent range.  The next step's score
+// products are issued before the current step's softmax (their LDS reads and matrix-core latency hide behind it).
 // -------------------------------------------------------------------------------------------------------------
+#define AB_LOG2E 1.4426950408889634f
+#define AB_LN2 0.6931471805599453f
+#define AB_LAZY 8.f
+
+__device__ __forceinline__ float ab_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <bool MASK>
+__device__ __forceinline__ void ab_fwd_step(const f32x4 s0, const f32x4 s1, int key0, int kn, const bf16x8 vfrag,
+                                            float& m, float& l, f32x4& oacc) {
+  float a[4], c[4], tl = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    a[r] = (!MASK || key0 + r < kn) ? s0[r] : -INFINITY;
+    c[r] = (!MASK || key0 + 16 + r < kn) ? s1[r] : -INFINITY;
+    tl = fmaxf(tl, fmaxf(a[r], c[r]));
+  }
+  if (__any(tl > m + AB_LAZY)) {                                  // wave-uniform; always taken by a head's first step
+    tl = fmaxf(tl, __shfl_xor(tl, 16, 64));
+    tl = fmaxf(tl, __shfl_xor(tl, 32, 64));
+    const float mn = fmaxf(m, tl);                                // finite: a step holds at least one live key
+    const float f = ab_exp2(m - mn);
+    m = mn;
+    l *= f;
+    oacc *= f;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    a[r] = ab_exp2(a[r] - m);
+    c[r] = ab_exp2(c[r] - m);
+    l += a[r] + c[r];
+  }
+  oacc = mfma32(vfrag, ab_pack(a, c), oacc);
+}
+
 __global__ void __launch_bounds__(64 * AB_MAX_WAVES)
 k_attn_bf16_fwd(int H, int Lq, int Lk, int CH, const float* __restrict__ q, const float* __restrict__ kv,
                 float* __restrict__ o, float* __restrict__ lse) {
@@ -130,7 +171,8 @@ k_attn_bf16_fwd(int H, int Lq, int Lk, int CH, const float* __restrict__ q, cons
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
   const int qi = (blockIdx.y * nw + w) * 16 + n;                  // this wave's query tile (may be past Lq)
   const bool qlive = qi < Lq;
-  const bf16x8 qf = ab_row8(q + (int64_t)(b * Lq + (qlive ? qi : 0)) * D + h * AB_HD + 8 * (g & 1), qlive && g < 2, 0.25f);
+  const bf16x8 qf = ab_row8(q + (int64_t)(b * Lq + (qlive ? qi : 0)) * D + h * AB_HD + 8 * (g & 1), qlive && g < 2,
+                            0.25f * AB_LOG2E);
   float m = -INFINITY, l = 0.f;
   f32x4 oacc = {0.f, 0.f, 0.f, 0.f};
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -140,32 +182,17 @@ k_attn_bf16_fwd(int H, int Lq, int Lk, int CH, const float* __restrict__ q, cons
     const float* kbase = kv + ((int64_t)b * Lk + k0) * 2 * D + h * AB_HD;
     ab_stage<true, false, false, true>(kbase, kbase + D, 2 * D, kn, knp, ldt, Kb, nullptr, nullptr, Vt);
     __syncthreads();
-    for (int st = 0; st < (knp >> 5); ++st) {
-      const f32x4 s0 = mfma32(ab_rfrag(Kb, 2 * st, n, g), qf, zero);
-      const f32x4 s1 = mfma32(ab_rfrag(Kb, 2 * st + 1, n, g), qf, zero);
-      float a[4], c[4], tmax = -INFINITY;
-      const int kr = st * 32 + 4 * g;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a[r] = kr + r < kn ? s0[r] : -INFINITY;
-        c[r] = kr + 16 + r < kn ? s1[r] : -INFINITY;
-        tmax = fmaxf(tmax, fmaxf(a[r], c[r]));
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float mn = fmaxf(m, tmax);                            // finite: a step holds at least one live key
-      const float f = __expf(m - mn);
-      m = mn;
-      l *= f;
-      oacc *= f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a[r] = __expf(a[r] - m);
-        c[r] = __expf(c[r] - m);
-        l += a[r] + c[r];
-      }
-      oacc = mfma32(ab_tfrag(Vt, ldt, n, g, st), ab_pack(a, c), oacc);
+    const int nst = knp >> 5, nfull = kn >> 5;                    // steps; steps without padded keys
+    f32x4 s0 = mfma32(ab_rfrag(Kb, 0, n, g), qf, zero), s1 = mfma32(ab_rfrag(Kb, 1, n, g), qf, zero);
+    for (int st = 0; st < nfull; ++st) {
+      const int nx = min(st + 1, nst - 1);
+      const f32x4 n0 = mfma32(ab_rfrag(Kb, 2 * nx, n, g), qf, zero);
+      const f32x4 n1 = mfma32(ab_rfrag(Kb, 2 * nx + 1, n, g), qf, zero);
+      ab_fwd_step<false>(s0, s1, 0, 0, ab_tfrag(Vt, ldt, n, g, st), m, l, oacc);
+      s0 = n0;
+      s1 = n1;
     }
+    if (nfull < nst) ab_fwd_step<true>(s0, s1, nfull * 32 + 4 * g, kn, ab_tfrag(Vt, ldt, n, g, nfull), m, l, oacc);
   }
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
@@ -173,12 +200,13 @@ k_attn_bf16_fwd(int H, int Lq, int Lk, int CH, const float* __restrict__ q, cons
     const float inv = 1.f / l;
     *reinterpret_cast<float4*>(o + (int64_t)(b * Lq + qi) * D + h * AB_HD + 4 * g) =
         make_float4(oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv);
-    if (g == 0) lse[((int64_t)b * H + h) * Lq + qi] = m + __logf(l);
+    if (g == 0) lse[((int64_t)b * H + h) * Lq + qi] = (m + __log2f(l)) * AB_LN2;
   }
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// dQ (and delta = rowsum(o * do) for the dK | dV kernel)
+// dQ (and delta = rowsum(o * do) for the dK | dV kernel).  p = 2^(s2 - lse2) with the scores in the log2 domain as in
+// the forward; ds = p (dp - delta) / 4 with the 1/4 folded into do's operand and into delta.
 // -------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64 * AB_MAX_WAVES)
 k_attn_bf16_bwd_dq(int H, int Lq, int Lk, int CH, const float* __restrict__ q, const float* __restrict__ kv,
@@ -194,8 +222,8 @@ k_attn_bf16_bwd_dq(int H, int Lq, int Lk, int CH, const float* __restrict__ q, c
   const int qi = (blockIdx.y * nw + w) * 16 + n;
   const bool qlive = qi < Lq;
   const int64_t rowoff = (int64_t)(b * Lq + (qlive ? qi : 0)) * D + h * AB_HD;
-  const bf16x8 qf = ab_row8(q + rowoff + 8 * (g & 1), qlive && g < 2, 0.25f);
-  const bf16x8 dof = ab_row8(dout + rowoff + 8 * (g & 1), qlive && g < 2, 1.f);
+  const bf16x8 qf = ab_row8(q + rowoff + 8 * (g & 1), qlive && g < 2, 0.25f * AB_LOG2E);
+  const bf16x8 dof = ab_row8(dout + rowoff + 8 * (g & 1), qlive && g < 2, 0.25f);
   // delta of this lane's query: lanes g = 0..3 of a column each take four head columns
   float dpart = 0.f;
   if (qlive) {
@@ -205,9 +233,9 @@ k_attn_bf16_bwd_dq(int H, int Lq, int Lk, int CH, const float* __restrict__ q, c
   }
   dpart += __shfl_xor(dpart, 16, 64);
   dpart += __shfl_xor(dpart, 32, 64);
-  const float dln = dpart;
-  const float lsn = qlive ? lse[((int64_t)b * H + h) * Lq + qi] : INFINITY;
-  if (qlive && g == 0) delta[((int64_t)b * H + h) * Lq + qi] = dln;
+  const float dln = 0.25f * dpart;
+  const float lsn = qlive ? lse[((int64_t)b * H + h) * Lq + qi] * AB_LOG2E : INFINITY;
+  if (qlive && g == 0) delta[((int64_t)b * H + h) * Lq + qi] = dpart;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < Lk; k0 += CH) {
@@ -216,18 +244,31 @@ k_attn_bf16_bwd_dq(int H, int Lq, int Lk, int CH, const float* __restrict__ q, c
     const float* kbase = kv + ((int64_t)b * Lk + k0) * 2 * D + h * AB_HD;
     ab_stage<true, true, true, false>(kbase, kbase + D, 2 * D, kn, knp, ldt, Kb, Kt, Vb, nullptr);
     __syncthreads();
-    for (int st = 0; st < (knp >> 5); ++st) {
-      const f32x4 s0 = mfma32(ab_rfrag(Kb, 2 * st, n, g), qf, zero);
-      const f32x4 s1 = mfma32(ab_rfrag(Kb, 2 * st + 1, n, g), qf, zero);
-      const f32x4 d0 = mfma32(ab_rfrag(Vb, 2 * st, n, g), dof, zero);
-      const f32x4 d1 = mfma32(ab_rfrag(Vb, 2 * st + 1, n, g), dof, zero);
+    const int nst = knp >> 5;
+    f32x4 s0 = mfma32(ab_rfrag(Kb, 0, n, g), qf, zero), s1 = mfma32(ab_rfrag(Kb, 1, n, g), qf, zero);
+    f32x4 d0 = mfma32(ab_rfrag(Vb, 0, n, g), dof, zero), d1 = mfma32(ab_rfrag(Vb, 1, n, g), dof, zero);
+    for (int st = 0; st < nst; ++st) {
+      const int nx = min(st + 1, nst - 1);                        // the last step recomputes itself (unused)
+      const f32x4 ns0 = mfma32(ab_rfrag(Kb, 2 * nx, n, g), qf, zero);
+      const f32x4 ns1 = mfma32(ab_rfrag(Kb, 2 * nx + 1, n, g), qf, zero);
+      const f32x4 nd0 = mfma32(ab_rfrag(Vb, 2 * nx, n, g), dof, zero);
+      const f32x4 nd1 = mfma32(ab_rfrag(Vb, 2 * nx + 1, n, g), dof, zero);
       float a[4], c[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {                               // padded keys: their K^T columns are zeros
-        a[r] = __expf(s0[r] - lsn) * (d0[r] - dln) * 0.25f;
-        c[r] = __expf(s1[r] - lsn) * (d1[r] - dln) * 0.25f;
+      for (int r = 0; r < 4; ++r) {
+        a[r] = ab_exp2(s0[r] - lsn) * (d0[r] - dln);
+        c[r] = ab_exp2(s1[r] - lsn) * (d1[r] - dln);
+      }
+      if (st == nst - 1 && kn < knp) {                            // padded keys (score 0, not -inf): no contribution,
+        const int kr = st * 32 + 4 * g;                           // whatever 2^(-lse) is
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kr + r >= kn) a[r] = 0.f;
+          if (kr + 16 + r >= kn) c[r] = 0.f;
+        }
       }
       acc = mfma32(ab_tfrag(Kt, ldt, n, g, st), ab_pack(a, c), acc);
+      s0 = ns0; s1 = ns1; d0 = nd0; d1 = nd1;
     }
   }
   if (qlive)
@@ -247,15 +288,15 @@ k_attn_bf16_bwd_dkv(int H, int Lq, int Lk, int CH, const float* __restrict__ q, 
   __bf16* Ob = Qb + (size_t)CH * AB_HD;                           // [CH][16]    do, row-major
   __bf16* Qt = Ob + (size_t)CH * AB_HD;                           // [16][ldt]
   __bf16* Ot = Qt + (size_t)AB_HD * ldt;                          // [16][ldt]
-  float* ls = reinterpret_cast<float*>(Ot + (size_t)AB_HD * ldt); // [CH]
-  float* dl = ls + CH;                                            // [CH]
+  float* ls = reinterpret_cast<float*>(Ot + (size_t)AB_HD * ldt); // [CH]   lse in the log2 domain
+  float* dl = ls + CH;                                            // [CH]   delta / 4
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * AB_HD;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
   const int ki = (blockIdx.y * nw + w) * 16 + n;
   const bool klive = ki < Lk;
   const int64_t rowoff = ((int64_t)(b * Lk + (klive ? ki : 0)) * 2) * D + h * AB_HD;
-  const bf16x8 kf = ab_row8(kv + rowoff + 8 * (g & 1), klive && g < 2, 0.25f);
-  const bf16x8 vf = ab_row8(kv + rowoff + D + 8 * (g & 1), klive && g < 2, 1.f);
+  const bf16x8 kf = ab_row8(kv + rowoff + 8 * (g & 1), klive && g < 2, 0.25f * AB_LOG2E);
+  const bf16x8 vf = ab_row8(kv + rowoff + D + 8 * (g & 1), klive && g < 2, 0.25f);
   f32x4 dka = {0.f, 0.f, 0.f, 0.f}, dva = {0.f, 0.f, 0.f, 0.f};
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   for (int q0 = 0; q0 < Lq; q0 += CH) {
@@ -265,16 +306,20 @@ k_attn_bf16_bwd_dkv(int H, int Lq, int Lk, int CH, const float* __restrict__ q, 
     ab_stage<true, true, true, true>(q + qoff, dout + qoff, D, qn, qnp, ldt, Qb, Qt, Ob, Ot);
     for (int r = threadIdx.x; r < qnp; r += blockDim.x) {
       const bool in = r < qn;
-      ls[r] = in ? lse[((int64_t)b * H + h) * Lq + q0 + r] : INFINITY;       // padding queries: p = 0
-      dl[r] = in ? delta[((int64_t)b * H + h) * Lq + q0 + r] : 0.f;
+      ls[r] = in ? lse[((int64_t)b * H + h) * Lq + q0 + r] * AB_LOG2E : INFINITY;       // padding queries: p = 0
+      dl[r] = in ? 0.25f * delta[((int64_t)b * H + h) * Lq + q0 + r] : 0.f;
     }
     __syncthreads();
-    for (int st = 0; st < (qnp >> 5); ++st) {
-      // S orientation: rows = queries 4 g + r of the tile, column = this lane's key n
-      const f32x4 s0 = mfma32(ab_rfrag(Qb, 2 * st, n, g), kf, zero);
-      const f32x4 s1 = mfma32(ab_rfrag(Qb, 2 * st + 1, n, g), kf, zero);
-      const f32x4 d0 = mfma32(ab_rfrag(Ob, 2 * st, n, g), vf, zero);
-      const f32x4 d1 = mfma32(ab_rfrag(Ob, 2 * st + 1, n, g), vf, zero);
+    const int nst = qnp >> 5;
+    // S orientation: rows = queries 4 g + r of the tile, column = this lane's key n
+    f32x4 s0 = mfma32(ab_rfrag(Qb, 0, n, g), kf, zero), s1 = mfma32(ab_rfrag(Qb, 1, n, g), kf, zero);
+    f32x4 d0 = mfma32(ab_rfrag(Ob, 0, n, g), vf, zero), d1 = mfma32(ab_rfrag(Ob, 1, n, g), vf, zero);
+    for (int st = 0; st < nst; ++st) {
+      const int nx = min(st + 1, nst - 1);
+      const f32x4 ns0 = mfma32(ab_rfrag(Qb, 2 * nx, n, g), kf, zero);
+      const f32x4 ns1 = mfma32(ab_rfrag(Qb, 2 * nx + 1, n, g), kf, zero);
+      const f32x4 nd0 = mfma32(ab_rfrag(Ob, 2 * nx, n, g), vf, zero);
+      const f32x4 nd1 = mfma32(ab_rfrag(Ob, 2 * nx + 1, n, g), vf, zero);
       const float4 l0 = *reinterpret_cast<const float4*>(ls + st * 32 + 4 * g);
       const float4 l1 = *reinterpret_cast<const float4*>(ls + st * 32 + 16 + 4 * g);
       const float4 e0 = *reinterpret_cast<const float4*>(dl + st * 32 + 4 * g);
@@ -284,13 +329,14 @@ k_attn_bf16_bwd_dkv(int H, int Lq, int Lk, int CH, const float* __restrict__ q, 
       float pa[4], pc[4], da[4], dc[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pa[r] = __expf(s0[r] - la[r]);
-        pc[r] = __expf(s1[r] - lc[r]);
-        da[r] = pa[r] * (d0[r] - ea[r]) * 0.25f;
-        dc[r] = pc[r] * (d1[r] - ec[r]) * 0.25f;
+        pa[r] = ab_exp2(s0[r] - la[r]);
+        pc[r] = ab_exp2(s1[r] - lc[r]);
+        da[r] = pa[r] * (d0[r] - ea[r]);
+        dc[r] = pc[r] * (d1[r] - ec[r]);
       }
       dva = mfma32(ab_tfrag(Ot, ldt, n, g, st), ab_pack(pa, pc), dva);
       dka = mfma32(ab_tfrag(Qt, ldt, n, g, st), ab_pack(da, dc), dka);
+      s0 = ns0; s1 = ns1; d0 = nd0; d1 = nd1;
     }
   }
   if (klive) {
@@ -302,8 +348,11 @@ k_attn_bf16_bwd_dkv(int H, int Lq, int Lk, int CH, const float* __restrict__ q, 
 // -------------------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------------------
-static int ab_waves(int tiles) { return tiles < AB_MAX_WAVES ? (tiles < 4 ? 4 : tiles) : AB_MAX_WAVES; }
+#include <stdlib.h>
+static int ab_env(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }   // SWEEP ONLY
+static int ab_waves(int tiles) { const int mw = ab_env("IGCN_AB_NW", AB_MAX_WAVES); return tiles < mw ? (tiles < 4 ? 4 : tiles) : mw; }
 static int ab_chunk(int rows, int cap) {
+  cap = ab_env(cap == AB_KEY_CHUNK ? "IGCN_AB_KCH" : "IGCN_AB_QCH", cap);
   const int padded = (rows + 31) & ~31;
   return padded < cap ? padded : cap;
 }

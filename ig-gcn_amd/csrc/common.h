@@ -75,6 +75,38 @@ __device__ __forceinline__ float wave_sum_all(float v) {
   return v;
 }
 
+// GO attention backward, output j of dparams [2 FOUT FIN + 3 FOUT] from the block partials gpart [(2 FOUT + 3) FIN][parts]
+// (go.hip k_go_attn_bwd_finish and, deferred, plan.hip k_multi_reduce: ONE body so that both give the same bits).  A
+// weight-gradient output is one entry's sum, an attention-vector output the dot product of a weight row with FIN entry
+// sums; every entry is summed by ONE wave (lanes stride the partials, fixed tree), waves take entries d = w, w + nw, ...
+// G: >= FIN floats of LDS.  All threads of the workgroup must call (barrier inside).
+__device__ __forceinline__ void go_attn_finish_output(const float* __restrict__ gpart, int64_t parts, int FIN, int FOUT,
+                                                      const float* __restrict__ w_inc, const float* __restrict__ w_s,
+                                                      float* __restrict__ dparams, int j, float* G) {
+  const int KW = FOUT * FIN, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int first = j < 2 * KW ? j : (2 * FOUT + (j - 2 * KW) / FOUT) * FIN, cnt = j < 2 * KW ? 1 : FIN;
+  for (int d = w; d < cnt; d += nw) {
+    const float* src = gpart + (int64_t)(first + d) * parts;
+    float t = 0.f;
+#pragma unroll 4
+    for (int64_t i = lane; i < parts; i += 64) t += src[i];
+    t = wave_sum_all(t);
+    if (lane == 0) G[d] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (j < 2 * KW) {
+      dparams[j] = G[0];
+    } else {
+      const int q = j - 2 * KW, which = q / FOUT, c = q % FOUT;
+      const float* wm = which == 2 ? w_s : w_inc;
+      float t = 0.f;
+      for (int d = 0; d < FIN; ++d) t = __fmaf_rn(wm[c * FIN + d], G[d], t);
+      dparams[j] = t;
+    }
+  }
+}
+
 // Sum over groups of G consecutive lanes (G = 1, 2, 4, ..., 64), result in every lane of the group; fixed tree.
 template <int G>
 __device__ __forceinline__ float group_sum_all(float v) {

@@ -728,37 +728,8 @@ template <int FIN, int FOUT>
 __global__ void __launch_bounds__(64 * FIN)
 k_go_attn_bwd_finish(const float* __restrict__ gpart, int64_t parts, const float* __restrict__ w_inc,
                      const float* __restrict__ w_s, float* __restrict__ dparams) {
-  constexpr int KW = FOUT * FIN;
   __shared__ float G[FIN];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = blockIdx.x;
-  int e = -1;                                           // entry this wave sums
-  if (j < 2 * KW) {
-    if (w == 0) e = j;
-  } else {
-    const int which = (j - 2 * KW) / FOUT;              // 0 -> a1, 1 -> a2, 2 -> a_s
-    e = (2 * FOUT + which) * FIN + w;
-  }
-  if (e >= 0) {
-    const float* src = gpart + (int64_t)e * parts;
-    float t = 0.f;
-#pragma unroll 4
-    for (int64_t i = lane; i < parts; i += 64) t += src[i];
-    t = wave_sum_all(t);
-    if (lane == 0) G[w] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (j < 2 * KW) {
-      dparams[j] = G[0];
-    } else {
-      const int q = j - 2 * KW, which = q / FOUT, c = q % FOUT;
-      const float* wm = which == 2 ? w_s : w_inc;
-      float t = 0.f;
-#pragma unroll
-      for (int d = 0; d < FIN; ++d) t += wm[c * FIN + d] * G[d];
-      dparams[j] = t;
-    }
-  }
+  go_attn_finish_output(gpart, parts, FIN, FOUT, w_inc, w_s, dparams, blockIdx.x, G);
 }
 
 // ---- backward, kernel B: input gradient + block partials of the parameter gradients ------------
@@ -1336,6 +1307,9 @@ extern "C" int igcn_go_attn_walk_order(int N, int fin, int fout, const int32_t* 
 // sample fits LDS — these are also the fallbacks for hierarchies too large for LDS
 static bool go_attn_force_cm(void) { return igcn_opt(IGCN_OPT_GO_ATTN_CM); }
 
+int igcn_queue_go_finish(const float* gpart, int64_t parts, int fin, int fout, const float* w_inc, const float* w_s,
+                         float* dparams, hipStream_t st);                                       // plan.hip
+
 extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
                                 const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order,
                                 const float* x, const float* w_inc,
@@ -1365,6 +1339,7 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
 #undef CALLLT
 #undef CALLLI
     IGCN_CHECK_LAUNCH("go_attn_bwd(lds)");
+    if (igcn_queue_go_finish(gpart, (int64_t)B, fin, fout, w_inc, w_s, dparams, st)) return IGCN_OK;
 #define CALLF(FI, FO) \
   hipLaunchKernelGGL((k_go_attn_bwd_finish<FI, FO>), dim3(2 * FO * FI + 3 * FO), dim3(64 * FI), 0, st, gpart, (int64_t)B, w_inc, w_s, dparams)
     GO_DISPATCH(fin, fout, CALLF)
@@ -1384,6 +1359,7 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
   GO_DISPATCH(fin, fout, CALL)
 #undef CALL
   IGCN_CHECK_LAUNCH("go_attn_bwd");
+  if (igcn_queue_go_finish(gpart, parts, fin, fout, w_inc, w_s, dparams, st)) return IGCN_OK;
 #define CALLF(FI, FO) \
   hipLaunchKernelGGL((k_go_attn_bwd_finish<FI, FO>), dim3(2 * FO * FI + 3 * FO), dim3(64 * FI), 0, st, gpart, parts, w_inc, w_s, dparams)
   GO_DISPATCH(fin, fout, CALLF)

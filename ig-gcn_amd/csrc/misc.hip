@@ -299,6 +299,18 @@ extern "C" int igcn_sum_n(int64_t numel, int n, const float* const* parts /*HOST
   return IGCN_OK;
 }
 
+// igcn_sum_n for a gradient nothing reads before the optimiser (a LEAF with several consumers): joins the deferred
+// final reductions (igcn_reduce_defer / igcn_reduce_flush) when they are on — the buffers must then stay alive until
+// the flush — and is igcn_sum_n otherwise.  Same summation order either way.
+int igcn_queue_sum_final(const float* const* parts, int k, int64_t numel, float* out, hipStream_t st);   // plan.hip
+extern "C" int igcn_sum_n_final(int64_t numel, int n, const float* const* parts /*HOST array*/, float* out,
+                                void* stream) {
+  IGCN_REQUIRE(numel >= 0 && n >= 1 && n <= 4 && parts && out, "sum_n_final: 1..4 parts");
+  for (int k = 0; k < n; ++k) IGCN_REQUIRE(parts[k] != nullptr, "sum_n_final: null part");
+  if (numel > 0 && igcn_queue_sum_final(parts, n, numel, out, (hipStream_t)stream)) return IGCN_OK;
+  return igcn_sum_n(numel, n, parts, out, stream);
+}
+
 extern "C" int igcn_concat_cols(int64_t rows, int F, int nparts, const float* const* parts /*HOST array*/, float* out,
                                 void* stream) {
   IGCN_REQUIRE(rows >= 0 && F > 0 && F % 4 == 0 && nparts >= 1 && nparts <= 4, "concat_cols: F %% 4 == 0, <= 4 parts");

@@ -87,6 +87,41 @@ k_reduce_rows_par(const float* __restrict__ partial, int64_t rows, int64_t ld, i
   reduce_col_wave(partial, rows, ld, n, out, accumulate, blockIdx.x);
 }
 
+// many rows, 16..4096 columns: 16 columns x 16 row groups per 256-thread workgroup — a wave's load instruction covers
+// 4 rows x 64 contiguous bytes (the wave-per-column form above touches 64 different cache lines per instruction and
+// uses 4 bytes of each), a thread sums rows r = g mod 16 (8 loads in flight), the 16 group sums of a column are
+// combined through LDS in a fixed pairwise tree.  Shared by the stand-alone and the deferred form.
+__device__ __forceinline__ void reduce_cols_tile16(const float* __restrict__ partial, int64_t rows, int64_t ld, int n,
+                                                   float* __restrict__ out, int accumulate, int64_t block,
+                                                   float (*lds)[64]) {
+  float* s = &lds[0][0];                               // [16 groups][16 columns]
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t j = block * 16 + c;
+  float t = 0.f;
+  if (j < n) {
+#pragma unroll 8
+    for (int64_t r = g; r < rows; r += 16) t += partial[r * ld + j];
+  }
+  s[g * 16 + c] = t;
+  __syncthreads();
+  if (g == 0 && j < n) {
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = s[k * 16 + c];
+#pragma unroll
+    for (int w = 1; w < 16; w *= 2)
+#pragma unroll
+      for (int k = 0; k < 16; k += 2 * w) v[k] += v[k + w];
+    out[j] = accumulate ? out[j] + v[0] : v[0];
+  }
+}
+__global__ void __launch_bounds__(256)
+k_reduce_rows_tile16(const float* __restrict__ partial, int64_t rows, int64_t ld, int n, float* __restrict__ out,
+                     int accumulate) {
+  __shared__ float lds[4][64];
+  reduce_cols_tile16(partial, rows, ld, n, out, accumulate, blockIdx.x, lds);
+}
+
 // out[j] = sum_r partial[j * rows + r]: the summands of one output are CONTIGUOUS (coalesced), one block per output
 __global__ void __launch_bounds__(1024)
 k_reduce_contig(const float* __restrict__ partial, int64_t rows, float* __restrict__ out) {
@@ -110,6 +145,12 @@ int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int 
                             hipStream_t st) {
   if (n <= 0) return IGCN_OK;
   if (rows > 32 && n <= 4096) {
+    if (n >= 16) {
+      hipLaunchKernelGGL(k_reduce_rows_tile16, dim3((unsigned)igcn_cdiv(n, 16)), dim3(256), 0, st, partial, rows, ld, n,
+                         out, accumulate);
+      IGCN_CHECK_LAUNCH("reduce_rows_tile16");
+      return IGCN_OK;
+    }
     hipLaunchKernelGGL(k_reduce_rows_par, dim3((unsigned)igcn_cdiv(n, 4)), dim3(256), 0, st, partial, rows, ld, n, out,
                        accumulate);
     IGCN_CHECK_LAUNCH("reduce_rows_par");
@@ -138,6 +179,8 @@ struct ReduceEntry {
   float* out;
   int64_t rows, ld;
   int n;
+  int nptr;                                          // > 0: the rows are SEPARATE buffers (partial, more[0..nptr-1]),
+  const float* more[3];                              //      summed in that order (igcn_sum_n_final)
 };
 struct ReduceTable {
   ReduceEntry e[MRQ_MAX];
@@ -150,15 +193,41 @@ __global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t) {
   // flat grid: workgroup -> (entry, block inside the entry).  [A (max blocks) x (entries) grid launched 57 000
   // workgroups for 11 000 with work.]
   int ei = 0;
-  while (ei + 1 < t.count && (int)blockIdx.x >= t.start[ei + 1]) ++ei;
+  for (int step = 32; step > 0; step >>= 1)          // largest ei with start[ei] <= blockIdx.x (start[] ascending; a
+    if (ei + step < t.count && (int)blockIdx.x >= t.start[ei + step]) ei += step;   // linear walk was 40 dependent loads)
   const ReduceEntry e = t.e[ei];
   const int64_t blk = (int64_t)blockIdx.x - t.start[ei];
+  if (e.nptr < 0) {                                  // GO attention: parameter gradients from the block partials
+    // (go_attn_finish_output, common.h — shared with go.hip's k_go_attn_bwd_finish; output j = blk, ld = FIN | FOUT << 8)
+    go_attn_finish_output(e.partial, e.rows, (int)(e.ld & 255), (int)(e.ld >> 8), e.more[0], e.more[1], e.out, (int)blk,
+                          &lds[0][0]);
+    return;
+  }
+  if (e.nptr > 0) {                                  // a leaf's gradient = sum of its consumers' gradients (k_sum_n)
+    const int64_t j4 = (blk * 256 + threadIdx.x) * 4;          // 16 bytes per lane (buffers 16-byte aligned)
+    if (j4 + 3 < e.n) {
+      float4 a = *reinterpret_cast<const float4*>(e.partial + j4);
+      for (int k = 0; k < e.nptr; ++k) {
+        const float4 b = *reinterpret_cast<const float4*>(e.more[k] + j4);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      *reinterpret_cast<float4*>(e.out + j4) = a;
+    } else {
+      for (int64_t j = j4; j < e.n; ++j) {
+        float s = e.partial[j];
+        for (int k = 0; k < e.nptr; ++k) s += e.more[k][j];
+        e.out[j] = s;
+      }
+    }
+    return;
+  }
   if (e.rows > RR_WIDE_ROWS && e.n > 4096) {         // tall and wide: grouped rows (k_reduce_rows_grouped)
     reduce_cols_grouped(e.partial, e.rows, e.ld, e.n, e.out, 0, blk, lds);
     return;
   }
-  if (e.rows > 32 && e.n <= 4096) {                  // tall: a wave per column, fixed tree (k_reduce_rows_par)
-    reduce_col_wave(e.partial, e.rows, e.ld, e.n, e.out, 0, blk);
+  if (e.rows > 32 && e.n <= 4096) {                  // tall: 16 x 16 tiles (k_reduce_rows_tile16), or a wave per column
+    if (e.n >= 16) reduce_cols_tile16(e.partial, e.rows, e.ld, e.n, e.out, 0, blk, lds);
+    else reduce_col_wave(e.partial, e.rows, e.ld, e.n, e.out, 0, blk);
   } else {                                           // wide: one thread per column, rows in order (k_reduce_rows)
     const int64_t j = blk * 256 + threadIdx.x;
     if (j >= e.n) return;
@@ -203,7 +272,7 @@ static int reduce_flush_locked(hipStream_t st) {
   if (igcn_opt(IGCN_OPT_DEBUG_REDUCE))
     for (const ReduceEntry& e : g_rq)
       fprintf(stderr, "[igcn] deferred reduction: rows %lld x n %d (ld %lld)%s\n", (long long)e.rows, e.n,
-              (long long)e.ld, (e.rows > 32 && e.n <= 4096) ? "  tree" : "  in-order");
+              (long long)e.ld, e.nptr < 0 ? "  GO attention finish" : e.nptr > 0 ? "  separate buffers" : (e.rows > 32 && e.n <= 4096) ? "  tree" : "  in-order");
   size_t done = 0;
   while (done < g_rq.size()) {
     ReduceTable t = {};
@@ -212,7 +281,8 @@ static int reduce_flush_locked(hipStream_t st) {
     for (int i = 0; i < cnt; ++i) {
       const ReduceEntry& e = g_rq[done + i];
       t.e[i] = e;
-      const int64_t need = (e.rows > 32 && e.n <= 4096) ? igcn_cdiv(e.n, 4)
+      const int64_t need = e.nptr < 0 ? e.n : e.nptr > 0 ? igcn_cdiv(e.n, 1024)
+                           : (e.rows > 32 && e.n <= 4096) ? igcn_cdiv(e.n, e.n >= 16 ? 16 : 4)
                                                         : (e.rows > RR_WIDE_ROWS ? igcn_cdiv(e.n, 64) : igcn_cdiv(e.n, 256));
       t.start[i] = (int)total;
       total += need;
@@ -239,12 +309,44 @@ int igcn_launch_reduce_rows_final(const float* partial, int64_t rows, int64_t ld
   {
     std::lock_guard<std::mutex> lk(g_rq_mutex);
     if (g_rq_defer) {
-      g_rq.push_back(ReduceEntry{partial, out, rows, ld, n});
+      g_rq.push_back(ReduceEntry{partial, out, rows, ld, n, 0, {nullptr, nullptr, nullptr}});
       g_rq_stream.push_back(st);
       return IGCN_OK;
     }
   }
   return igcn_launch_reduce_rows(partial, rows, ld, n, out, 0, st);
+}
+
+// tools/reduce_bench.py: a final reduction by itself (queued while igcn_reduce_defer is on)
+extern "C" int igcn_debug_reduce_rows_final(const float* partial, int64_t rows, int64_t ld, int n, float* out, void* stream) {
+  return igcn_launch_reduce_rows_final(partial, rows, ld, n, out, (hipStream_t)stream);
+}
+
+// GO attention backward: dparams [2 FOUT FIN + 3 FOUT] from gpart [(2 FOUT + 3) FIN][parts] as a FINAL reduction:
+// queued while igcn_reduce_defer is on (returns 1), else not handled here (returns 0: k_go_attn_bwd_finish).
+int igcn_queue_go_finish(const float* gpart, int64_t parts, int fin, int fout, const float* w_inc, const float* w_s,
+                         float* dparams, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_rq_mutex);
+  if (!g_rq_defer || fin > 64 || fout > 64) return 0;
+  ReduceEntry e = {gpart, dparams, parts, (int64_t)(fin | (fout << 8)), 2 * fout * fin + 3 * fout, -1, {w_inc, w_s, nullptr}};
+  g_rq.push_back(e);
+  g_rq_stream.push_back(st);
+  return 1;
+}
+
+// out = parts[0] + parts[1] + ... (k separate buffers of numel floats) as a FINAL reduction: queued while
+// igcn_reduce_defer is on (returns 1), otherwise not handled here (returns 0: the caller launches k_sum_n).
+int igcn_queue_sum_final(const float* const* parts, int k, int64_t numel, float* out, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_rq_mutex);
+  if (!g_rq_defer || k < 2 || k > 4 || numel > 0x7fffffff) return 0;
+  uintptr_t al = (uintptr_t)out;
+  for (int i = 0; i < k; ++i) al |= (uintptr_t)parts[i];
+  if (al & 15) return 0;
+  ReduceEntry e = {parts[0], out, (int64_t)k, 0, (int)numel, k - 1, {nullptr, nullptr, nullptr}};
+  for (int i = 1; i < k; ++i) e.more[i - 1] = parts[i];
+  g_rq.push_back(e);
+  g_rq_stream.push_back(st);
+  return 1;
 }
 
 // ---- stable grouping by a hand-written counting / radix sort ------------------------------------------------

@@ -152,7 +152,8 @@ class Gene_ontology_network(nn.Module):
         for j in range(self.n_l):
             csr = self.enc_csr[j]
             y = ops.GoAttention.apply(x, self.w_inc[j].weight, self.w_s_loop[j].weight,
-                                      self.w_att_in[j].weight.view(-1), self.w_att_s[j].weight.view(-1), csr)
+                                      self.w_att_in[j].weight, self.w_att_s[j].weight, csr)   # leaves (no .view(-1): a view's
+            # gradient would pass through another backward node, and the op could not defer its final reduction)
             x = ops.NodesLayerNorm.apply(y, self.G_B[j].weight, self.G_B[j].bias, keeps[j], self.pool[j],
                                          self.G_B[j].eps)
         # read-outs (:254-255): BatchNorm1d(n_top) normalises per NODE over (batch, feature); fused kernels

@@ -425,6 +425,7 @@ class GradFan(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, k):
         ctx.set_materialize_grads(False)
+        ctx.final = _leaves(t)          # a leaf's summed gradient is read by the optimiser only: a deferred reduction
         return tuple(t.view_as(t) for _ in range(k))
 
     @staticmethod
@@ -442,7 +443,12 @@ class GradFan(torch.autograd.Function):
             return out, None
         out = torch.empty_like(gs[0])
         arr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
-        call("igcn_sum_n", out.numel(), len(gs), arr, ptr(out), stream_ptr())
+        if ctx.final and _DEFER["on"]:
+            for g in gs:
+                _keep(g)                # the consumers' gradients live until the flush sums them
+            call("igcn_sum_n_final", out.numel(), len(gs), arr, ptr(out), stream_ptr())
+        else:
+            call("igcn_sum_n", out.numel(), len(gs), arr, ptr(out), stream_ptr())
         return out, None
 
 
@@ -1336,7 +1342,7 @@ class GoAttention(torch.autograd.Function):
         call("igcn_go_attn_fwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(x), ptr(w_inc), ptr(w_s),
              ptr(a_in), ptr(a_s), ptr(y), stream_ptr())
         ctx.save_for_backward(x, w_inc, w_s, a_in, a_s)
-        ctx.csr = csr
+        ctx.csr, ctx.final = csr, _leaves(w_inc, w_s, a_in, a_s)
         return y
 
     @staticmethod
@@ -1349,11 +1355,12 @@ class GoAttention(torch.autograd.Function):
         lib = _lib.load()
         dx = torch.empty_like(x)
         dpar = torch.empty(2 * fout * fin + 3 * fout, dtype=torch.float32, device=x.device)
-        scratch = torch.empty(int(lib.igcn_go_attn_bwd_scratch_floats(b, n, fin, fout)), dtype=torch.float32,
-                              device=x.device)
-        call("igcn_go_attn_bwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(csr.t_ptr), ptr(csr.t_row),
-             ptr(csr.walk_order(fin, fout)), ptr(x), ptr(w_inc), ptr(w_s), ptr(a_in), ptr(a_s), ptr(dy), ptr(dx), ptr(dpar), ptr(scratch),
-             stream_ptr())
+        scratch = _keep(torch.empty(int(lib.igcn_go_attn_bwd_scratch_floats(b, n, fin, fout)), dtype=torch.float32,
+                                    device=x.device))
+        with _immediate(ctx.final):     # leaves: the parameter gradients join the deferred final reductions
+            call("igcn_go_attn_bwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(csr.t_ptr), ptr(csr.t_row),
+                 ptr(csr.walk_order(fin, fout)), ptr(x), ptr(w_inc), ptr(w_s), ptr(a_in), ptr(a_s), ptr(dy), ptr(dx),
+                 ptr(dpar), ptr(scratch), stream_ptr())
         k = fout * fin
         return (dx, dpar[:k].view(fout, fin), dpar[k:2 * k].view(fout, fin),
                 dpar[2 * k:2 * k + 2 * fout].view_as(a_in), dpar[2 * k + 2 * fout:].view_as(a_s), None)

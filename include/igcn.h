@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 307
+#define IGCN_ABI_VERSION 308
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -456,6 +456,10 @@ int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end, co
  * out[i] = sum_k parts[k][i], k < n <= 4 (HOST array of device pointers, 16-byte aligned): the gradient of a tensor
  * with several consumers in one launch instead of autograd's pairwise adds (ops.GradFan). */
 int igcn_sum_n(int64_t numel, int n, const float* const* parts, float* out, void* stream);
+/* The same sum for a LEAF's gradient (nothing reads it before the optimiser): while igcn_reduce_defer is on it joins the
+ * deferred final reductions and is performed by igcn_reduce_flush's single launch — parts must stay alive until then;
+ * otherwise it is igcn_sum_n.  Same summation order either way. */
+int igcn_sum_n_final(int64_t numel, int n, const float* const* parts, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Mask regulariser — loss_probability, kernel/sgcn_img_snp.py:153-181:
@@ -561,7 +565,8 @@ int igcn_go_attn_fwd(int B, int N, int fin, int fout, const int32_t* row_ptr, co
  * Outputs: dx [B,fin,N]; dparams float[ 2*fout*fin + 2*fout + fout ] = (dW_inc, dW_s, da_in, da_s).
  * Samples whose operands fit a CU's LDS ((fin+fout+4)*N*4 <= 160 KB, N <= 4096) run in an LDS-resident kernel, one
  * workgroup per sample; larger ones in global-memory kernels (hub columns walked by the whole wave).
- * scratch floats: igcn_go_attn_bwd_scratch_floats(B,N,fin,fout). */
+ * scratch floats: igcn_go_attn_bwd_scratch_floats(B,N,fin,fout).  dparams is a FINAL reduction of block partials kept
+ * in scratch: while igcn_reduce_defer is on it is performed by igcn_reduce_flush (scratch must stay alive until then). */
 size_t igcn_go_attn_bwd_scratch_floats(int B, int N, int fin, int fout);
 /* `walk_order` (device int32[igcn_go_attn_walk_slots(N, fin, fout)], or NULL = node order): the thread -> node map of
  * the LDS-resident kernel's column walks, from igcn_go_attn_walk_order(N, fin, fout, t_ptr on the HOST, order out on

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""The train step's deferred final reductions (igcn_reduce_flush, one k_multi_reduce launch) by themselves: the queue of
+the default workload rebuilt from its shapes (IGCN_DEBUG_REDUCE=1 lists them), flushed and event-timed — whole, and with
+one entry left out at a time, to see which entries set the launch's duration (median of per-replay event times, graph
+launch included).  usage: reduce_bench.py [iters=20] [cold]"""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import igcn_amd  # noqa: E402,F401
+from igcn_amd import _lib  # noqa: E402
+
+# (rows, n) of the default workload's queue, in queue order of one backward pass (bench.py --workload full)
+SHAPES = [(8, 64), (32, 195), (512, 32), (40, 2400), (800, 160), (512, 64), (512, 50), (512, 336), (512, 2048),
+          (512, 20), (512, 1024), (448, 5), (40, 6000), (3008, 2), (240, 1024), (2, 800), (2, 6000), (16, 800),
+          (16, 6000), (16, 12800), (16, 1024), (128, 8067), (128, 16134), (8, 64), (32, 195), (512, 32), (40, 2400)]
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+COLD = len(sys.argv) > 2 and sys.argv[2] == "cold"
+junk = torch.zeros(256 << 20, device="cuda") if COLD else None
+lib = _lib.load()
+fn = lib.igcn_debug_reduce_rows_final
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+bufs = [(torch.randn(r, n, device="cuda"), torch.empty(n, device="cuda")) for r, n in SHAPES]
+st = torch.cuda.current_stream().cuda_stream
+
+
+def flush(skip=None):
+    lib.igcn_reduce_defer(1)
+    for i, ((p, o), (r, n)) in enumerate(zip(bufs, SHAPES)):
+        if i != skip:
+            assert fn(p.data_ptr(), r, n, n, o.data_ptr(), st) == 0
+    assert lib.igcn_reduce_flush(st) == 0
+    lib.igcn_reduce_defer(0)
+
+
+def timed(skip=None):
+    """the flush captured into a graph (its host side — 27 queue calls — would otherwise set the pace)"""
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        global st
+        keep, st = st, s.cuda_stream
+        flush(skip)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            flush(skip)
+        st = keep
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        if COLD:
+            junk.add_(1.0)                      # 1 GB through the caches: the partials come from HBM, as in the step
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+flush()
+torch.cuda.synchronize()
+for (p, o), (r, n) in zip(bufs, SHAPES):
+    assert torch.allclose(o, p.sum(0), rtol=1e-4, atol=1e-3), (r, n)
+whole = timed()
+print(f"whole queue ({len(SHAPES)} entries, {sum(r * n for r, n in SHAPES) * 4 / 1e6:.1f} MB): {whole:7.1f} us", flush=True)
+for i, (r, n) in enumerate(SHAPES[:23]):
+    t = timed(i)
+    print(f"  without {r:5d} x {n:6d}: {t:7.1f} us  ({whole - t:+6.1f})", flush=True)
