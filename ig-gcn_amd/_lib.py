@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 308        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 310        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -43,6 +43,11 @@ SIGNATURES = {
     "igcn_proj_bwd_blocks": (I, [L]),
     "igcn_proj_bwd": (I, [L, I, I, P, P, P, P, P, P, P]),
     "igcn_proj_bwd_pair": (I, [L, I, P, P, P, P, P, P, L, I, P, P, P, P, P, P, I, P]),
+    "igcn_proj_fwd_blocks": (I, [L]),
+    "igcn_proj_fwd_pair": (I, [L, I, P, P, P, P, L, I, P, P, P, P, I, P]),
+    "igcn_head_bwd_supported": (I, [I, I, I]),
+    "igcn_head_bwd_scratch_floats": (Z, [I, I]),
+    "igcn_head_bwd_pair": (I, [I, I, I, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, P]),
     "igcn_dense_blocks_check": (I, [L, I, P, P, P]),
     "igcn_dense_sgcn_supported": (I, [I, I, I, I]),
     "igcn_dense_sgcn_ws_floats": (Z, [L, I, I, I]),

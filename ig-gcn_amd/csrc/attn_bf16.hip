@@ -348,11 +348,12 @@ k_attn_bf16_bwd_dkv(int H, int Lq, int Lk, int CH, const float* __restrict__ q, 
 // -------------------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------------------
-#include <stdlib.h>
-static int ab_env(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }   // SWEEP ONLY
-static int ab_waves(int tiles) { const int mw = ab_env("IGCN_AB_NW", AB_MAX_WAVES); return tiles < mw ? (tiles < 4 ? 4 : tiles) : mw; }
+static int ab_waves(int tiles) { return tiles < AB_MAX_WAVES ? (tiles < 4 ? 4 : tiles) : AB_MAX_WAVES; }
+// rows of the streamed side per LDS chunk.  In-step sweeps at 512 queries x 1300 keys (configs[4]): keys 224 / 448 / 672 /
+// 1312 -> forward 31.1 / 31.3 / 30.5 / 39.4 us, dQ 33.0 / 32.9 / 32.0 / 41.1; queries 128 / 256 / 512 -> dK|dV 53.9 / 49.9 /
+// 53.1; 4 instead of 8 waves per workgroup: 33.7 / 46.5 / 54.9.  Flat: the kernels are bound by their per-step issue
+// (exponentials, packing), not by staging.
 static int ab_chunk(int rows, int cap) {
-  cap = ab_env(cap == AB_KEY_CHUNK ? "IGCN_AB_KCH" : "IGCN_AB_QCH", cap);
   const int padded = (rows + 31) & ~31;
   return padded < cap ? padded : cap;
 }

@@ -188,6 +188,12 @@ struct ReduceTable {
   int count;
 };
 
+// the wide in-order form may take four columns per thread (same sums, column by column)
+__host__ __device__ inline bool rq_wide_vec(const ReduceEntry& e) {
+  return e.nptr == 0 && !(e.rows > 32) && e.n >= 1024 && (e.n & 3) == 0 && (e.ld & 3) == 0 &&
+         (((uintptr_t)e.partial | (uintptr_t)e.out) & 15) == 0;
+}
+
 __global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t) {
   __shared__ float lds[4][64];
   // flat grid: workgroup -> (entry, block inside the entry).  [A (max blocks) x (entries) grid launched 57 000
@@ -228,6 +234,16 @@ __global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t) {
   if (e.rows > 32 && e.n <= 4096) {                  // tall: 16 x 16 tiles (k_reduce_rows_tile16), or a wave per column
     if (e.n >= 16) reduce_cols_tile16(e.partial, e.rows, e.ld, e.n, e.out, 0, blk, lds);
     else reduce_col_wave(e.partial, e.rows, e.ld, e.n, e.out, 0, blk);
+  } else if (rq_wide_vec(e)) {                       // wide, 16-byte rows: four columns per thread, rows in order
+    const int64_t j = (blk * 256 + threadIdx.x) * 4;
+    if (j >= e.n) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int64_t r = 0; r < e.rows; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(e.partial + r * e.ld + j);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(e.out + j) = s;
   } else {                                           // wide: one thread per column, rows in order (k_reduce_rows)
     const int64_t j = blk * 256 + threadIdx.x;
     if (j >= e.n) return;
@@ -283,7 +299,8 @@ static int reduce_flush_locked(hipStream_t st) {
       t.e[i] = e;
       const int64_t need = e.nptr < 0 ? e.n : e.nptr > 0 ? igcn_cdiv(e.n, 1024)
                            : (e.rows > 32 && e.n <= 4096) ? igcn_cdiv(e.n, e.n >= 16 ? 16 : 4)
-                                                        : (e.rows > RR_WIDE_ROWS ? igcn_cdiv(e.n, 64) : igcn_cdiv(e.n, 256));
+                                                        : (e.rows > RR_WIDE_ROWS ? igcn_cdiv(e.n, 64)
+                                                                                   : igcn_cdiv(e.n, rq_wide_vec(e) ? 1024 : 256));
       t.start[i] = (int)total;
       total += need;
     }

@@ -786,6 +786,20 @@ class LinearPair(torch.autograd.Function):
         lib = _lib.load()
         dy1, dy2 = _f32(dy1), _f32(dy2)
         rows, cols = dy1.shape
+        if (not ctx.bf16 and dy1.is_cuda and dy2.shape == dy1.shape and os.environ.get("IGCN_NO_HEAD_FUSED", "0") != "1"
+                and lib.igcn_head_bwd_supported(rows, cols, x1.shape[1]) and lib.igcn_head_bwd_supported(rows, cols, x2.shape[1])
+                and all(t.is_contiguous() for t in (dy1, dy2, x1, x2, w1, w2))):
+            # ReLU mask, bias gradients and the four products in ONE launch, the wide operands read once (igcn_head_bwd_pair)
+            f32 = dict(dtype=torch.float32, device=dy1.device)
+            dx1, dx2, dw1, dw2 = torch.empty_like(x1), torch.empty_like(x2), torch.empty_like(w1), torch.empty_like(w2)
+            db1, db2 = torch.empty(cols, **f32), torch.empty(cols, **f32)
+            s1 = _keep(torch.empty(int(lib.igcn_head_bwd_scratch_floats(rows, x1.shape[1])), **f32))
+            s2 = _keep(torch.empty(int(lib.igcn_head_bwd_scratch_floats(rows, x2.shape[1])), **f32))
+            with _immediate(all(ctx.final)):
+                call("igcn_head_bwd_pair", rows, cols, x1.shape[1], ptr(dy1), ptr(y1) if ctx.relu else None, ptr(w1), ptr(x1),
+                     ptr(dx1), ptr(dw1), ptr(db1), ptr(s1), x2.shape[1], ptr(dy2), ptr(y2) if ctx.relu else None, ptr(w2),
+                     ptr(x2), ptr(dx2), ptr(dw2), ptr(db2), ptr(s2), stream_ptr())
+            return dx1, dw1, db1, dx2, dw2, db2, None, None
         if dy2.shape == dy1.shape:                                          # both heads: ONE mask + bias-gradient launch
             gs = [torch.empty_like(dy1), torch.empty_like(dy2)] if ctx.relu else [dy1, dy2]
             dbs = [torch.empty(cols, dtype=torch.float32, device=dy1.device) for _ in range(2)]
@@ -822,6 +836,21 @@ def linear_pair(x1, w1, b1, x2, w2, b2, relu=True, bf16=False):
     if b1 is None or b2 is None or w1.shape[0] > 256 or w2.shape[0] > 256 or x1.dim() != 2 or x2.dim() != 2:
         return linear(x1, w1, b1, relu=relu, bf16=bf16), linear(x2, w2, b2, relu=relu, bf16=bf16)
     return LinearPair.apply(x1, w1, b1, x2, w2, b2, relu, bf16)
+
+
+def _proj_forward(q2, m2, w, bias, d, bf16):
+    """q = q2 W_q^T + b_q, k | v = m2 [W_k; W_v]^T + [b_k; b_v] of the packed input projection: one streaming launch
+    (igcn_proj_fwd_pair: reduction depth 32, W resident in LDS) when the shape allows it, the grouped GEMM otherwise."""
+    lib = _lib.load()
+    if (not bf16 and q2.is_cuda and os.environ.get("IGCN_NO_PROJ_FUSED", "0") != "1" and q2.is_contiguous()
+            and m2.is_contiguous() and w.is_contiguous() and bias.is_contiguous() and q2.shape[0] > 0 and m2.shape[0] > 0
+            and lib.igcn_proj_bwd_supported(q2.shape[0], d, d) and lib.igcn_proj_bwd_supported(m2.shape[0], 2 * d, d)):
+        q = torch.empty(q2.shape[0], d, dtype=torch.float32, device=q2.device)
+        kv = torch.empty(m2.shape[0], 2 * d, dtype=torch.float32, device=q2.device)
+        call("igcn_proj_fwd_pair", q2.shape[0], d, ptr(q2), ptr(w[:d]), ptr(bias[:d]), ptr(q), m2.shape[0], 2 * d, ptr(m2),
+             ptr(w[d:]), ptr(bias[d:]), ptr(kv), d, stream_ptr())
+        return q, kv
+    return gemm_group([("nt", q2, w[:d], None, bias[:d], False), ("nt", m2, w[d:], None, bias[d:], False)], bf16=bf16)
 
 
 def _proj_backward(ctx, dq, dkv, q2, m2, w, dw, d):
@@ -868,8 +897,7 @@ class InProj(torch.autograd.Function):
         d = w.shape[1]
         q2, m2 = _f32(query).reshape(-1, d), _f32(memory).reshape(-1, d)
         w, bias = _f32(w), _f32(bias)
-        q, kv = gemm_group([("nt", q2, w[:d], None, bias[:d], False), ("nt", m2, w[d:], None, bias[d:], False)],
-                           bf16=bf16)
+        q, kv = _proj_forward(q2, m2, w, bias, d, bf16)
         ctx.save_for_backward(q2, m2, w)
         ctx.bf16, ctx.final = bf16, _leaves(w, bias)
         ctx.shapes = (query.shape, memory.shape)
@@ -1698,8 +1726,7 @@ class ProjectedAttention(torch.autograd.Function):
         q2, m2 = _f32(query).reshape(-1, d), _f32(memory).reshape(-1, d)
         w, bias = _f32(w), _f32(bias)
         b, lq, lk = query.shape[0], query.shape[1], memory.shape[1]
-        q, kv = gemm_group([("nt", q2, w[:d], None, bias[:d], False), ("nt", m2, w[d:], None, bias[d:], False)],
-                           bf16=bf16)
+        q, kv = _proj_forward(q2, m2, w, bias, d, bf16)
         q, kv = q.view(b, lq, d), kv.view(b, lk, 2 * d)
         o = torch.empty_like(q)
         lse = torch.empty(b, heads, lq, dtype=torch.float32, device=q.device)

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 308
+#define IGCN_ABI_VERSION 310
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -220,6 +220,27 @@ int igcn_proj_bwd(int64_t M, int N, int K, const float* G, const float* X, const
 int igcn_proj_bwd_pair(int64_t M1, int N1, const float* G1, const float* X1, const float* W1, float* dX1, float* dW1,
                        float* scratch1, int64_t M2, int N2, const float* G2, const float* X2, const float* W2,
                        float* dX2, float* dW2, float* scratch2, int K, void* stream);
+/* Forward of the same projections, y = x W^T + b (bias [N] or NULL), as ONE streaming launch for up to two of them
+ * (M2 = 0: the first alone): W and b resident in LDS, x read once, y written in contiguous runs — the in-projection's
+ * reduction depth is 32, so the general tiled GEMM's K loop and per-column-tile re-reads of x only cost.  Same shape
+ * limits as igcn_proj_bwd_supported; exact fp32. */
+int igcn_proj_fwd_blocks(int64_t M);
+int igcn_proj_fwd_pair(int64_t M1, int N1, const float* X1, const float* W1, const float* b1, float* Y1, int64_t M2, int N2,
+                       const float* X2, const float* W2, const float* b2, float* Y2, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the two heads' first layers y = relu(x W^T + b) (kernel/sgcn_img_snp.py:299 lin1, :302 lin1_regr; x [R, C]
+ * the head inputs, W [64, C]) in one pass over the wide operands: g = dy * (y > 0), db = column sums of g, dx = g W,
+ * dW = g^T x — x and W read once, dx written once, no masked copy of dy, no separate bias-gradient launch.
+ * Hidden width H == 64, C even (igcn_head_bwd_supported); y_i NULL = no ReLU; C2 = 0 = the first layer alone.  With
+ * R > 128 the rows are split: dW_i / db_i are then final reductions in the sense of igcn_reduce_defer over partials in
+ * scratch_i (igcn_head_bwd_scratch_floats(R, C_i) floats; must stay alive until the flush).  Exact fp32. */
+int igcn_head_bwd_supported(int R, int H, int C);
+size_t igcn_head_bwd_scratch_floats(int R, int C);
+int igcn_head_bwd_pair(int R, int H, int C1, const float* dy1, const float* y1, const float* W1, const float* X1,
+                       float* dX1, float* dW1, float* db1, float* scratch1, int C2, const float* dy2, const float* y2,
+                       const float* W2, const float* X2, float* dX2, float* dW2, float* db2, float* scratch2,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SGCN over DENSE brain graphs (BASELINE configs[4]): batches whose graphs are COMPLETE — all R x R (source, target)

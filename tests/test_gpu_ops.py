@@ -316,6 +316,37 @@ def test_proj_bwd_one_pass(ops, m, n):
     assert_matches(dw, (g.double().t() @ x.double()).numpy(), TOL, "dW")
 
 
+@pytest.mark.parametrize("m1,m2", [(23040, 102400), (90, 400), (1, 1), (64 * 2100 + 7, 130)])
+def test_proj_fwd_streaming_pair(ops, m1, m2):
+    """igcn_proj_fwd_pair: y1 = x1 W1^T + b1 (32 columns) and y2 = x2 W2^T + b2 (64 columns) in one streaming launch
+    (K = 32): the bench shape, single tiles, ragged last tiles, more tiles than workgroups; small-integer operands are
+    reproduced EXACTLY (fp32 products, k-ordered accumulation), random ones match fp64; and the second projection may be
+    absent."""
+    from igcn_amd._lib import call, load, ptr, stream_ptr
+    rng = np.random.default_rng(m1 + m2)
+    lib = load()
+    assert int(lib.igcn_proj_fwd_blocks(64 * 5000)) < 5000        # a workgroup then walks several tiles
+    for exact in (True, False):
+        mk = (lambda *sh: torch.from_numpy(rng.integers(-8, 9, sh).astype(np.float32))) if exact else \
+            (lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32)))
+        x1, w1, b1, x2, w2, b2 = mk(m1, 32), mk(32, 32), mk(32), mk(m2, 32), mk(64, 32), mk(64)
+        dev = [t.cuda() for t in (x1, w1, b1, x2, w2, b2)]
+        y1 = torch.full((m1, 32), float("nan"), device="cuda")
+        y2 = torch.full((m2, 64), float("nan"), device="cuda")
+        call("igcn_proj_fwd_pair", m1, 32, ptr(dev[0]), ptr(dev[1]), ptr(dev[2]), ptr(y1), m2, 64, ptr(dev[3]), ptr(dev[4]),
+             ptr(dev[5]), ptr(y2), 32, stream_ptr())
+        r1 = x1.double() @ w1.double().t() + b1.double()
+        r2 = x2.double() @ w2.double().t() + b2.double()
+        if exact:
+            assert torch.equal(y1.cpu().double(), r1) and torch.equal(y2.cpu().double(), r2)
+        else:
+            assert_matches(y1, r1.numpy(), TOL, "y1")
+            assert_matches(y2, r2.numpy(), TOL, "y2")
+    y1.fill_(float("nan"))
+    call("igcn_proj_fwd_pair", m1, 32, ptr(dev[0]), ptr(dev[1]), None, ptr(y1), 0, 0, None, None, None, None, 32, stream_ptr())
+    assert_matches(y1, (x1.double() @ w1.double().t()).numpy(), TOL, "y1 alone, no bias")
+
+
 def test_gemm_is_exact_fp32_fma_chain(ops):
     """MFMA f32 = k-ordered fmaf chain: small-integer operands must be reproduced exactly."""
     rng = np.random.default_rng(0)
@@ -1027,10 +1058,45 @@ def test_small_linear_pair_matches_two_layers():
     assert_matches(y1, ref.detach().float().cpu().numpy(), 2e-6, "y1 vs fp64")
 
 
-def test_linear_pair_matches_two_linears():
+@pytest.mark.parametrize("rows,k1,k2,relu", [(512, 2912, 3182, True), (37, 34, 70, True), (300, 96, 54, False),
+                                             (256, 32, 2, True), (700, 130, 66, True)])
+def test_head_bwd_one_pass(ops, rows, k1, k2, relu):
+    """igcn_head_bwd_pair behind ops.linear_pair's backward: ReLU mask, bias gradients, input gradients and weight
+    gradients of both first layers from one launch, against fp64 — the bench shape, one / two / three row splits with
+    ragged ends, column blocks cut by the matrix edge (34, 70, 54, 130, 66, 2 columns), no ReLU; and the same bits when the
+    row-split sums are deferred."""
+    lib = __import__("igcn_amd")._lib.load()
+    assert lib.igcn_head_bwd_supported(rows, 64, k1) and not lib.igcn_head_bwd_supported(rows, 64, 33) \
+        and not lib.igcn_head_bwd_supported(rows, 32, k1)
+    rng = np.random.default_rng(rows + k1)
+    mk = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32))     # noqa: E731
+    host = [mk(rows, k1), mk(64, k1) / 8, mk(64), mk(rows, k2), mk(64, k2) / 8, mk(64)]
+    c1, c2 = mk(rows, 64), mk(rows, 64)
+
+    def run(defer):
+        leaves = [t.cuda().requires_grad_(True) for t in host]
+        y1, y2 = ops.linear_pair(*leaves, relu=relu)
+        if defer:
+            with ops.deferred_reductions():
+                return torch.autograd.grad((y1 * c1.cuda()).sum() + (y2 * c2.cuda()).sum(), leaves)
+        return torch.autograd.grad((y1 * c1.cuda()).sum() + (y2 * c2.cuda()).sum(), leaves)
+
+    got, got_deferred = run(False), run(True)
+    ref = [t.double().requires_grad_(True) for t in host]
+    act = torch.relu if relu else (lambda t: t)
+    z1, z2 = act(ref[0] @ ref[1].t() + ref[2]), act(ref[3] @ ref[4].t() + ref[5])
+    want = torch.autograd.grad((z1 * c1.double()).sum() + (z2 * c2.double()).sum(), ref)
+    for g, gd, w_, nm in zip(got, got_deferred, want, ("dx1", "dw1", "db1", "dx2", "dw2", "db2")):
+        assert_matches(g, w_.numpy(), 5e-6, nm)
+        assert torch.equal(g, gd), nm + " deferred"
+
+
+def test_linear_pair_matches_two_linears(monkeypatch):
     """ops.linear_pair (the heads' first layers as one op, grouped launches both ways) against two ops.linear calls:
-    the same bits forward and backward (same kernels, same tiling per product), also with 8-byte-only rows."""
+    the same bits forward and backward (same kernels, same tiling per product), also with 8-byte-only rows.  [The
+    grouped-GEMM backward: the one-pass kernel of test_head_bwd_one_pass is switched off.]"""
     from igcn_amd import ops
+    monkeypatch.setenv("IGCN_NO_HEAD_FUSED", "1")
     torch.manual_seed(5)
     for k1, k2 in ((2912, 3182), (96, 54)):
         x1 = torch.randn(512, k1, device="cuda", requires_grad=True)
