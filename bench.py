@@ -392,23 +392,30 @@ def mfma_roofline(model, wl, device, stats, bf16):
     g = 2 * wl["graphs"]
     d = LAYERS * HIDDEN
     n_top = sum(wl["pool"][2:])
-    shapes = [("lin1", g, 64, wl["rois"] * d + 32), ("kv_proj", g * n_top, 2 * d, d)]
-    for name, m, n, k in shapes:
-        a = torch.randn(m, k, device=device)
-        b = torch.randn(n, k, device=device)
-        bias = torch.zeros(n, device=device)
-        iters = 50
-        us = _time_graph(lambda: [ops.gemm_nt(a, b, bias, 1, bf16=bf16) for _ in range(iters)]) / iters
-        tf = 2.0 * m * n * k / (us * 1e-6) / 1e12
-        byt = 4.0 * (m * k + n * k + m * n)
-        out["products"].append({"name": name, "M": m, "N": n, "K": k, "us": round(us, 2), "achieved": round(tf, 2),
-                                "frac": round(tf / peak, 4),
-                                "frac_hbm": round(byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
+    iters = 50
+
+    def add(name, us, flops, byt, dims, kernel):
+        tf = flops / (us * 1e-6) / 1e12
+        out["products"].append(dict(name=name, **dims, us=round(us, 2), achieved=round(tf, 2), frac=round(tf / peak, 4),
+                                    frac_hbm=round(byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), kernel=kernel))
+
+    m, n, k = g, 64, wl["rois"] * d + 32                     # lin1 (:299): the widest product of the heads
+    a, b, bias = torch.randn(m, k, device=device), torch.randn(n, k, device=device), torch.zeros(n, device=device)
+    us = _time_graph(lambda: [ops.gemm_nt(a, b, bias, 1, bf16=bf16) for _ in range(iters)]) / iters
+    add("lin1", us, 2.0 * m * n * k, 4.0 * (m * k + n * k + m * n), dict(M=m, N=n, K=k), "k_gemm_bf16" if bf16 else "k_gemm_f32")
+    # the packed in-projection of the cross-attention (:240) as the model runs it: queries [g * rois, d] -> d and
+    # key | value [g * n_top, d] -> 2 d in one launch (fp32: the streaming kernel igcn_proj_fwd_pair; bf16: grouped GEMM)
+    mq, mk = g * wl["rois"], g * n_top
+    q2, m2 = torch.randn(mq, d, device=device), torch.randn(mk, d, device=device)
+    w, pb = torch.randn(3 * d, d, device=device), torch.zeros(3 * d, device=device)
+    us = _time_graph(lambda: [ops._proj_forward(q2, m2, w, pb, d, bf16) for _ in range(iters)]) / iters
+    add("in_proj", us, 2.0 * d * d * (mq + 2 * mk), 4.0 * (2 * mq * d + 3 * mk * d + 3 * d * d),
+        dict(M=mq + mk, N=2 * d, K=d), "k_gemm_bf16_grouped" if bf16 else "k_proj_fwd")
     best = max(out["products"], key=lambda p: p["frac"])
-    out["achieved"], out["frac"], out["kernel"] = best["achieved"], best["frac"], \
-        ("k_gemm_bf16" if bf16 else "k_gemm_f32") + f" ({best['name']})"
+    out["achieved"], out["frac"], out["kernel"] = best["achieved"], best["frac"], f"{best['kernel']} ({best['name']})"
     if stats:
-        tot = sum(t for nme, (c, a_, t) in stats[0].items() if "k_gemm_" in nme and "reduce" not in nme)
+        tot = sum(t for nme, (c, a_, t) in stats[0].items()
+                  if ("k_gemm_" in nme or "k_proj_" in nme or "k_head_bwd" in nme) and "reduce" not in nme)
         red = sum(t for nme, (c, a_, t) in stats[0].items() if "reduce" in nme)
         out["instep_gemm_us_per_step"] = round(tot / stats[1], 1)
         out["instep_reduction_kernels_us_per_step"] = round(red / stats[1], 1)

@@ -299,14 +299,22 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             # complete graphs (a dense adjacency as COO): masks, gcn_norm, every GCNConv and the mask regulariser of the
             # pass(es) on the dense blocks — no plan arrays, no per-edge intermediates (ops.DenseSgcn)
             wb = [t for c in convs for t in (c.lin.weight, c.bias)]
-            xcat, regp = ops.DenseSgcn.apply(x, edge_weight, self.prob, self.prob_bias, self.snps_prob, mode, self.rois,
+            prob_d, sp_d, sp_m, x_d = self.prob, self.snps_prob, self.snps_prob, x
+            if fan and mode != "plain":
+                # prob (dense path: mask + regulariser; head inputs), snps_prob (regulariser; SNP mask) and data.x (dense
+                # path; head inputs) have two consumers each: their gradients meet in ONE sum per tensor (ops.GradFan —
+                # a deferred final reduction for these leaves) instead of a library add each
+                prob_d, prob_h = ops.GradFan.apply(self.prob, 2)
+                sp_d, sp_m = ops.GradFan.apply(self.snps_prob, 2)
+                x_d, x_h = ops.GradFan.apply(x, 2)
+            xcat, regp = ops.DenseSgcn.apply(x_d, edge_weight, prob_d, self.prob_bias, sp_d, mode, self.rois,
                                              self._reg_hp, *wb)
             if mode != "plain":
                 self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp))
             if mode == "plain":
                 snps_in = snps_feat
             else:
-                snps_in, _ = ops.SnpsMask.apply(snps_feat, self.snps_prob, mode == "both")
+                snps_in, _ = ops.SnpsMask.apply(snps_feat, sp_m, mode == "both")
         elif (tuple(explain_flags) == (False, True) and x.is_cuda and snps_feat is not None and snps_feat.dim() == 2
                 and snps_feat.shape[1] == self.snps_prob.numel()):
             # the train step's (plain | masked) pair: cal_probability writes both halves of the stacked batch itself.
