@@ -171,9 +171,9 @@ def load():
     # the library's A/B switches: read from the environment HERE, once, and handed over (no getenv in a launch path)
     bits = 0
     for bit, name in enumerate(("IGCN_NO_TILED_LISTS", "IGCN_PROPAGATE_NO_LDS", "IGCN_SPMM_NO_LDS", "IGCN_GO_ATTN_CM",
-                                "IGCN_DEBUG_REDUCE", "IGCN_ATTN_FP32_CORE")):
+                                "IGCN_DEBUG_REDUCE", "IGCN_ATTN_FP32_CORE", "IGCN_ATTN_BWD_TWICE")):
         v = os.environ.get(name)
-        if v is not None and (v == "1" or name in ("IGCN_NO_TILED_LISTS", "IGCN_PROPAGATE_NO_LDS", "IGCN_DEBUG_REDUCE", "IGCN_ATTN_FP32_CORE")):
+        if v is not None and (v == "1" or name in ("IGCN_NO_TILED_LISTS", "IGCN_PROPAGATE_NO_LDS", "IGCN_DEBUG_REDUCE", "IGCN_ATTN_FP32_CORE", "IGCN_ATTN_BWD_TWICE")):
             bits |= 1 << bit
     lib.igcn_configure(bits, int(os.environ.get("IGCN_GEMM_BN", "0") or 0),
                        int(os.environ.get("IGCN_ATTN_CHUNK", "0") or 0))

@@ -393,6 +393,163 @@ k_attn_mfma_bwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __res
   }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// Backward with SHARED score tiles (head_dim 16, <= 8 query tiles, at least as many key tiles as waves: the model's
+// 90 queries x 400 keys).  k_attn_mfma_bwd computes every (key tile, query tile) pair TWICE — S^T, dP^T in the
+// query-tile tasks (dQ reduces over keys), S, dP in the key-tile tasks (dK, dV reduce over queries): 28 matrix
+// instructions and 8 exponentials per pair.  Here a pair is computed once, in the S orientation, and its score-gradient
+// tile dS is TRANSPOSED through a wave-private 16 x 16 LDS tile (four 4-byte writes, one 16-byte read per lane) to feed
+// the dQ product as well: 20 matrix instructions, 4 exponentials per pair.
+//   * The pairs (key-tile major) are cut into one contiguous, equally long chunk per wave — a static split, so every
+//     sum has a fixed order (the task queue of the kernel above hands out tiles by arrival).
+//   * dQ: a wave keeps one accumulator per query tile (NQT x 4 registers) over its whole chunk; at the end the waves'
+//     partials meet in LDS (over K | V, which are no longer needed) and are summed in wave order.
+//   * dK | dV of a key tile whose pairs straddle two chunks: the first wave stores its part to the output rows, the
+//     second adds that part (read back after the barrier) to its own and overwrites them.
+// -------------------------------------------------------------------------------------------------------------
+#define AM_TLD 20                                               // transpose tile row stride (16-byte aligned rows)
+template <int NQT>
+__global__ void __launch_bounds__(64 * 8)
+k_attn_mfma_bwd_shared(int H, int Lq, int Lk, const float* __restrict__ q, const float* __restrict__ kv,
+                       const float* __restrict__ o, const float* __restrict__ lse, const float* __restrict__ dout,
+                       float* __restrict__ dq, float* __restrict__ dkv) {
+  constexpr int HDP = 16, LD = HDP + 1, NC = HDP / 4, hd = HDP;
+  extern __shared__ float smem[];
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * hd;
+  const int Lkp = (Lk + 15) & ~15, Lqp = NQT * 16, nkt = Lkp >> 4;
+  float* Ks = smem;
+  float* Vs = Ks + (size_t)Lkp * LD;
+  float* Qs = Vs + (size_t)Lkp * LD;
+  float* dOs = Qs + (size_t)Lqp * LD;
+  float* ls = dOs + (size_t)Lqp * LD;                           // lse [Lqp]   (+inf on padding rows: p = 0)
+  float* dl = ls + Lqp;                                         // delta [Lqp]
+  float* Tw = dl + Lqp;                                         // [waves][16][AM_TLD] transpose tiles
+  const float* kbase = kv + (int64_t)b * Lk * 2 * D + h * hd;
+  const float* qbase = q + (int64_t)b * Lq * D + h * hd;
+  const float* dobase = dout + (int64_t)b * Lq * D + h * hd;
+  {
+    const int r = threadIdx.x;                                  // delta = rowsum(o * do), lse: thread r's query row
+    float orow[HDP], drow[HDP], lv = INFINITY;
+    const bool mine = r < Lqp, live = r < Lq;
+    if (live) {
+      const float* op = o + (int64_t)(b * Lq + r) * D + h * hd;
+      const float* dp = dobase + (int64_t)r * D;
+#pragma unroll
+      for (int c = 0; c < HDP; c += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(op + c), d4 = *reinterpret_cast<const float4*>(dp + c);
+        orow[c] = a.x; orow[c + 1] = a.y; orow[c + 2] = a.z; orow[c + 3] = a.w;
+        drow[c] = d4.x; drow[c + 1] = d4.y; drow[c + 2] = d4.z; drow[c + 3] = d4.w;
+      }
+      lv = lse[((int64_t)b * H + h) * Lq + r];
+    }
+    am_stage_pair<HDP>(kbase, kbase + D, 2 * D, hd, 1, Lk, Lkp, Ks, Vs);
+    am_stage_pair<HDP>(qbase, dobase, D, hd, 1, Lq, Lqp, Qs, dOs);
+    if (mine) {
+      float d = 0.f;
+      if (live) {
+#pragma unroll
+        for (int c = 0; c < HDP; ++c) d += orow[c] * drow[c];
+      }
+      dl[r] = d;
+      ls[r] = lv;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in a scalar register: the chunk bounds below are uniform
+  const float scale = 0.25f;
+  float* T = Tw + w * 16 * AM_TLD;
+  const int P = nkt * NQT, lo = (w * P) / nw, hi = ((w + 1) * P) / nw;           // this wave's pairs [lo, hi)
+  f32x4 dqa[NQT];                                               // dQ^T[hd 4g+r][query n] per query tile
+#pragma unroll
+  for (int t = 0; t < NQT; ++t) dqa[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 pend_k = {0.f, 0.f, 0.f, 0.f}, pend_v = {0.f, 0.f, 0.f, 0.f};            // first tile's part, if its head is elsewhere
+  int pend_row = -1;
+  const int kt_first = lo / NQT, kt_last = (hi - 1) / NQT;
+  for (int kt = kt_first; kt <= kt_last; ++kt) {
+    const int q_lo = kt == kt_first ? lo - kt * NQT : 0, q_hi = kt == kt_last ? hi - kt * NQT : NQT;
+    const int krow = kt * 16 + n;
+    float kb[NC], vb[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      kb[c] = Ks[krow * LD + 4 * c + g] * scale;
+      vb[c] = Vs[krow * LD + 4 * c + g];
+    }
+    f32x4 dka = {0.f, 0.f, 0.f, 0.f}, dva = {0.f, 0.f, 0.f, 0.f};                // dK^T / dV^T [hd 4g+r][key n]
+    const float* kc = Ks + (kt * 16 + 4 * g) * LD + n;           // K[key 4g + r][hd n]: the dQ product's A operand
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+      if (qt >= q_lo && qt < q_hi) {                            // wave-uniform
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+        const float* qr = Qs + (qt * 16 + n) * LD + g;
+        const float* dr = dOs + (qt * 16 + n) * LD + g;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          st = mfma4(qr[4 * c], kb[c], st);                     // S = Q K^T (scaled): rows = queries 4g+r, column = key n
+          dpt = mfma4(dr[4 * c], vb[c], dpt);                   // dP = dO V^T
+        }
+        const float* qc = Qs + (qt * 16 + 4 * g) * LD + n;
+        const float* dc = dOs + (qt * 16 + 4 * g) * LD + n;
+        const float* lsr = ls + qt * 16 + 4 * g;
+        const float* dlr = dl + qt * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(st[r] - lsr[r]);               // padding queries: lse = +inf -> p = 0
+          const float ds = p * (dpt[r] - dlr[r]) * scale;
+          T[(4 * g + r) * AM_TLD + n] = ds;
+          dva = mfma4(dc[r * LD], p, dva);                      // dV^T += dO^T P
+          dka = mfma4(qc[r * LD], ds, dka);                     // dK^T += Q^T dS
+        }
+        asm volatile("" ::: "memory");   // compiler-level order only: a wave's LDS operations execute in issue order, so
+        const float4 dst = *reinterpret_cast<const float4*>(T + n * AM_TLD + 4 * g);   // the read sees the writes: dS^T, query n, keys 4g .. 4g+3
+        asm volatile("" ::: "memory");   // (and the next pair's writes stay behind this read)
+        dqa[qt] = mfma4(kc[0], dst.x, dqa[qt]);                 // dQ^T += K^T dS^T
+        dqa[qt] = mfma4(kc[LD], dst.y, dqa[qt]);
+        dqa[qt] = mfma4(kc[2 * LD], dst.z, dqa[qt]);
+        dqa[qt] = mfma4(kc[3 * LD], dst.w, dqa[qt]);
+      }
+    }
+    if (q_lo > 0) {                                             // the tile's first queries belong to the previous wave
+      pend_k = dka;
+      pend_v = dva;
+      pend_row = krow;
+    } else if (krow < Lk) {                                     // whole tile, or its first part (completed after the barrier)
+      float* base = dkv + ((int64_t)(b * Lk + krow) * 2) * D + h * hd + 4 * g;
+      *reinterpret_cast<float4*>(base) = make_float4(dka[0], dka[1], dka[2], dka[3]);
+      *reinterpret_cast<float4*>(base + D) = make_float4(dva[0], dva[1], dva[2], dva[3]);
+    }
+  }
+  // the first parts must be visible to the waves of THIS workgroup that complete them: the barrier's workgroup-scope
+  // release / acquire is enough (one CU; a device-scope fence is an L2 write-back on this part: 107 -> 344 us)
+  __syncthreads();                                              // ... and K | V are free
+  if (pend_row >= 0 && pend_row < Lk) {
+    float* base = dkv + ((int64_t)(b * Lk + pend_row) * 2) * D + h * hd + 4 * g;
+    // (plain loads: these rows were never read before, so no stale line can sit in this CU's L1; the stores above went
+    // through to L2 before the barrier)
+    const float4 hk = *reinterpret_cast<const float4*>(base), hv = *reinterpret_cast<const float4*>(base + D);
+    *reinterpret_cast<float4*>(base) = make_float4(hk.x + pend_k[0], hk.y + pend_k[1], hk.z + pend_k[2], hk.w + pend_k[3]);
+    *reinterpret_cast<float4*>(base + D) = make_float4(hv.x + pend_v[0], hv.y + pend_v[1], hv.z + pend_v[2], hv.w + pend_v[3]);
+  }
+  // dQ: the waves' partials [wave][query][16 hd] over the K | V area, then summed in wave order
+  float* R = smem;
+#pragma unroll
+  for (int t = 0; t < NQT; ++t)
+    *reinterpret_cast<float4*>(R + ((size_t)(w * Lqp + t * 16 + n)) * HDP + 4 * g) =
+        make_float4(dqa[t][0], dqa[t][1], dqa[t][2], dqa[t][3]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < Lqp * 4; i += blockDim.x) {
+    const int qrow = i >> 2, c4 = i & 3;
+    if (qrow < Lq) {
+      float4 a = *reinterpret_cast<const float4*>(R + (size_t)qrow * HDP + 4 * c4);
+      for (int ww = 1; ww < nw; ++ww) {
+        const float4 t4 = *reinterpret_cast<const float4*>(R + ((size_t)(ww * Lqp + qrow)) * HDP + 4 * c4);
+        a.x += t4.x; a.y += t4.y; a.z += t4.z; a.w += t4.w;
+      }
+      *reinterpret_cast<float4*>(dq + (int64_t)(b * Lq + qrow) * D + h * hd + 4 * c4) = a;
+    }
+  }
+}
+
 static int am_hdp(int hd) { return (hd + 3) & ~3; }
 
 static size_t am_lds_bytes(int hd, int Lq, int Lk, int backward) {
@@ -455,6 +612,24 @@ int igcn_attn_mfma_bwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
   const int vec = am_vec(D, hd, q, kv, dout, dq) && (uintptr_t)dkv % 16 == 0;
   const int tasks = (Lq + 15) / 16 + (Lk + 15) / 16;
   const int waves = tasks < 8 ? (tasks < 4 ? 4 : tasks) : 8;
+  {
+    // shared score tiles: head_dim 16 with 16-byte rows, <= 8 query tiles, >= 8 key tiles, partials fit over K | V
+    const int nqt = (Lq + 15) / 16, nkt = (Lk + 15) / 16;
+    const size_t lds2 = lds + (size_t)8 * 16 * AM_TLD * sizeof(float);
+    if (vec && hd == 16 && nqt <= 8 && nkt >= 8 && (size_t)8 * nqt * 16 * 16 <= (size_t)2 * nkt * 16 * 17 &&
+        lds2 <= 150 * 1024 && !igcn_opt(IGCN_OPT_ATTN_BWD_TWICE)) {
+#define CALLS(NQTV)                                                                                              \
+  case NQTV:                                                                                                     \
+    IGCN_ALLOW_BIG_LDS((k_attn_mfma_bwd_shared<NQTV>));                                                          \
+    hipLaunchKernelGGL((k_attn_mfma_bwd_shared<NQTV>), dim3(B * H), dim3(64 * 8), lds2, st, H, Lq, Lk, q, kv, o,  \
+                       lse, dout, dq, dkv);                                                                      \
+    break;
+      switch (nqt) { CALLS(1) CALLS(2) CALLS(3) CALLS(4) CALLS(5) CALLS(6) CALLS(7) CALLS(8) }
+#undef CALLS
+      IGCN_CHECK_LAUNCH("attn_mfma_bwd_shared");
+      return IGCN_OK;
+    }
+  }
 #define CALL(HDPV)                                                                                               \
   {                                                                                                              \
     IGCN_ALLOW_BIG_LDS((k_attn_mfma_bwd<HDPV, true>));                                        \

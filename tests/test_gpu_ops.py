@@ -859,6 +859,10 @@ def test_propagate_lds_staged_dense_fwd_bwd(ops, monkeypatch, g, r, f, density, 
 
 @pytest.mark.parametrize("bsz,lq,lk,d", [(3, 10, 9, 8), (4, 90, 400, 32), (2, 130, 77, 16), (5, 90, 45, 32),
                                           (2, 300, 130, 32), (3, 7, 5, 32), (2, 16, 16, 32),
+                                          # head_dim 16 with <= 8 query tiles and >= 8 key tiles: the shared-score-tile
+                                          # backward (ragged tiles, chunks that split key tiles between waves)
+                                          (3, 128, 400, 32), (2, 17, 130, 32), (2, 90, 136, 32), (2, 48, 300, 32),
+                                          (1, 1, 128, 32), (2, 113, 777, 32),
                                           # head dims off the fast path of round 1: 10, 15, 24, 12, 32, 5 (padded in LDS)
                                           (4, 90, 400, 20), (3, 90, 140, 30), (4, 90, 200, 48), (2, 33, 50, 24),
                                           (2, 40, 70, 64), (3, 21, 19, 10),
