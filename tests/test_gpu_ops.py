@@ -2,6 +2,8 @@
 CPU oracle / a plain PyTorch fp64 restatement of the same operator on identical seeded inputs.
 Tolerance: scale-relative 1e-4 (north_star: 1e-4 fp32); index work (graph plan) is bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -921,6 +923,48 @@ def test_attention_core_bf16_operands(ops, bsz, lq, lk):
     # rms error well under the bound (a systematic layout slip shows up here long before it reaches the max)
     rel = lambda a, w: float((a.detach().cpu().double() - w).pow(2).mean().sqrt() / w.pow(2).mean().sqrt())   # noqa: E731
     assert rel(o, o_ref.detach()) < 5e-3 and rel(g[0], g_ref[0]) < 1e-2 and rel(g[1], g_ref[1]) < 1e-2
+
+
+def test_attention_backward_shared_tiles_is_deterministic_and_matches_the_two_pass_kernel(ops):
+    """The default step's attention backward (k_attn_mfma_bwd_shared: every score tile computed once, static split of
+    the tile pairs over the waves) gives the same bits on every run, and agrees with the two-orientation kernel
+    (IGCN_ATTN_BWD_TWICE=1 keeps it reachable) to fp32 rounding — run in a child process, because the
+    switch is read once when the library loads."""
+    import subprocess
+    import sys
+    code = """
+import os, sys, torch
+sys.path.insert(0, %r)
+import igcn_amd
+from igcn_amd import ops
+torch.manual_seed(3)
+q = torch.randn(6, 90, 32, device="cuda", requires_grad=True)
+kv = torch.randn(6, 400, 64, device="cuda", requires_grad=True)
+cot = torch.randn(6, 90, 32, device="cuda")
+gs = []
+for _ in range(3):
+    o = ops.AttentionCore.apply(q, kv, 2)
+    gs.append(torch.autograd.grad((o * cot).sum(), [q, kv]))
+assert all(torch.equal(a, b) for g in gs[1:] for a, b in zip(gs[0], g)), "run-to-run bits differ"
+torch.save([t.cpu() for t in gs[0]], sys.argv[1])
+"""
+    import tempfile
+    from conftest import ROOT
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for twice in ("0", "1"):
+            env = dict(os.environ)
+            env.pop("IGCN_ATTN_BWD_TWICE", None)
+            if twice == "1":
+                env["IGCN_ATTN_BWD_TWICE"] = "1"
+            path = os.path.join(d, f"g{twice}.pt")
+            r = subprocess.run([sys.executable, "-c", code % ROOT, path], env=env, capture_output=True, text=True,
+                               timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(torch.load(path))
+    for a, b, nm in zip(outs[0], outs[1], ("dq", "dkv")):
+        assert not torch.equal(a, b), nm + ": the switch did not change the kernel"
+        assert_matches(a, b.numpy(), 2e-5, nm + " shared vs two-pass", floor=1e-6)
 
 
 def test_loss_head_matches_composite():
