@@ -59,6 +59,22 @@ __device__ __forceinline__ float ds_reg_grad(float p, float l1, float ent, float
   return l1 - ent * (__logf(a) + p * __frcp_rn(a) - __logf(b) - (1.f - p) * __frcp_rn(b));
 }
 
+// loss_probability's term of an EDGE mask p = sigmoid(z), from p and its logit z = u[s] + v[d]:
+//   l1 p - ent (p log p + (1 - p) log(1 - p)) = l1 p + ent (L + (1 - p) z),  L = -log p = log(1 + e^-z)
+// — one logarithm per edge instead of two.  The reference's eps (1e-6, kernel/sgcn_img_snp.py:153) inside its logarithms
+// adds p log(1 + eps / p) + (1 - p) log(1 + eps / (1 - p)) = 2 eps to first order wherever p and 1 - p are >> eps: kept
+// as the constant -2 ent eps; what is left is O(eps^2 / p), and at most eps on a saturated edge (tests: 1e-5 on the
+// loss, 1e-3 on its gradients against the fp64 oracle WITH eps).
+// Saturation: p = 0 (the factors' product overflowed) gives L clamped at 87 and z clamped to >= -L: p L = 0, as the
+// reference's 0 * log(eps); p = 1 gives L = 0 and (1 - p) = 0.
+__device__ __forceinline__ float ds_reg_term_logit(float p, float z, float l1, float ent, float eps) {
+  const float L = -__logf(fmaxf(p, 1e-38f));
+  return fmaf(l1, p, ent * (fmaf(1.f - p, fmaxf(z, -L), L) - 2.f * eps));
+}
+// u (or v) back from its stored factor exp(-u): the logit of an edge is u[s] + v[d].  Clamped so that a saturated
+// factor (0 or inf) gives a finite logit: the mask's e (1 - e) is then 0 and kills the term.
+__device__ __forceinline__ float ds_logit_part(float a) { return -__logf(fminf(fmaxf(a, 1e-37f), 1e37f)); }
+
 template <int NC, bool M0>
 __device__ __forceinline__ constexpr bool ds_masked(int c) { return NC == 2 ? c == 1 : M0; }
 
@@ -245,6 +261,9 @@ k_ds_deg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
     const float4 t = *reinterpret_cast<const float4*>(v + (int64_t)g * R + d0 + 4 * q);
     vd[0] = t.x; vd[1] = t.y; vd[2] = t.z; vd[3] = t.w;
   }
+  float lvd[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) lvd[t] = ds_logit_part(vd[t]);
   float acc[NC][4];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
@@ -269,10 +288,11 @@ k_ds_deg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
       const float wv[4] = {bf.w4[jj].x, bf.w4[jj].y, bf.w4[jj].z, bf.w4[jj].w};
       float ev[4] = {1.f, 1.f, 1.f, 1.f};
       if (ANYM) {
+        const float lus = ds_logit_part(bf.us[jj]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           ev[t] = ds_mask(bf.us[jj], vd[t]);
-          racc += ds_reg_term(ev[t], rg.l1_e, rg.ent_e, rg.eps);
+          racc += ds_reg_term_logit(ev[t], lus + lvd[t], rg.l1_e, rg.ent_e, rg.eps);
         }
       }
 #pragma unroll
@@ -448,7 +468,7 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
 // backward
 // =================================================================================================
 // backward workspace: gp [L][NC][F][GR] (feature-major: the matrix-core operands of the edge passes are 16-byte loads
-//                     along the node axis) | dhp [NC][GR][F] | T [GR] | ddeg [GR] | dup [R/16][GR] | dv [GR] |
+//                     along the node axis) | dhp [NC][GR][F] | T [GR] | ddeg [GR] | dup [R/64 .. R/16][GR] | dv [GR] |
 //                     dxin [NC][GR][H0] | dxm [GR][H0] | db partials [L][nblk][F] | dW partials [L][nblk][F*F] |
 //                     da partials [nblk2][2 H0]
 struct DsBws {
@@ -678,15 +698,30 @@ k_ds_node_mid(int64_t GR, int R, int H0, int L, int l, const float* __restrict__
 }
 
 // The mask gradient's edge pass (masked copy): q[s,d] = sum_l g'_l[d] . h'_l[s] on the matrix cores (K = L F),
-//   dz = ((q + ddeg[d]) ew + greg reg'(e) / nE) e (1 - e);  du[s] = sum_d dz (partials per 16-target tile), dv[d] = sum_s dz.
-// grid (R / 64, G), 512 threads: wave w owns targets [d0 + 16 (w & 3), + 16) and one half (w >> 2) of the source tiles.
-// Operand pairing: k index (kk, sub) <-> feature 4 sub + kk, so that a lane's four k-steps of a layer are ONE 16-byte
-// load of h'_l[source][4 sub .. 4 sub + 3] (g' is feature-major: its operands are loaded once per wave).
+//   dz = ((q + ddeg[d]) ew + greg reg'(e) / nE) e (1 - e);  du[s] = sum_d dz (one partial per 64-target block), dv[d] = sum_s dz.
+// grid (R / 64, G), 512 threads: the workgroup owns 64 targets, wave w the sources [w R / 8, (w + 1) R / 8).
+// Lane (q = lane & 15, sub = lane >> 4) loads 16 bytes ew[s0 + 4 sub + r][d0 + 4 q ..] for r = 0..3 — a wave's load
+// instruction covers four rows x 256 contiguous bytes, as in k_ds_agg (the first form of this kernel gave a wave 16
+// targets: 16 rows x 64 bytes per instruction, 29 us for the 33.5 MB) — and these are exactly the elements of four
+// accumulator tiles t: D_t[i = source 4 sub + r][j = q] <-> (source s0 + 4 sub + r, target d0 + 4 q + t), with
+// A = h'_l[s0 + q][features] (one 16-byte load per layer: k index (kk, sub) <-> feature 4 sub + kk) and
+// B_t = g'_l[d0 + 4 q + t][features] (feature-major g': 16-byte loads over t, once per wave).
 template <int N, int L>
 struct DsMbBuf {
-  float4 w4[N], h4[N][L];
-  float us[N];
+  float4 w4[N][4], h4[N][L];
+  float us[N][4];
 };
+
+__device__ __forceinline__ float ds_row16_sum(float v) {        // sum over the 16 lanes of a DPP row, in every lane
+  auto dpp = [](float a, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});             // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});             // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});            // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});            // row_mirror
+  return v;
+}
 
 template <int L, bool PIPE>
 __global__ void __launch_bounds__(512)
@@ -694,80 +729,108 @@ k_ds_mask_bwd(int R, int64_t GR, const float* __restrict__ ew, const float* __re
               const float* __restrict__ gpm /*[L][..][F][GR] at the masked copy*/, const float* __restrict__ hpm,
               int64_t lstride, const float* __restrict__ ddeg, const float* __restrict__ greg, DsReg rg, float inv_ne,
               float* __restrict__ dup, float* __restrict__ dv) {
-  __shared__ float dvs[2][4][16];
+  __shared__ float dvs[8][64];
   int g, xb;
   ds_block(R / 64, g, xb);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int q = lane & 15, sub = lane >> 4, dt = w & 3, sh = w >> 2;
-  const int d0 = xb * 64 + 16 * dt;
+  const int q = lane & 15, sub = lane >> 4;
+  const int d0 = xb * 64;
   const int64_t nb = (int64_t)g * R;
   const float gr = greg ? greg[0] * inv_ne : 0.f;
-  float aop[L][4];
+  float bop[L][4][4];                                                       // [layer][kk][tile t]
 #pragma unroll
   for (int l = 0; l < L; ++l)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) aop[l][kk] = gpm[l * lstride + (int64_t)(4 * sub + kk) * GR + nb + d0 + q];   // A[target q][k]
+    for (int kk = 0; kk < 4; ++kk) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gpm + l * lstride + (int64_t)(4 * sub + kk) * GR + nb + d0 + 4 * q);
+      bop[l][kk][0] = g4.x; bop[l][kk][1] = g4.y; bop[l][kk][2] = g4.z; bop[l][kk][3] = g4.w;
+    }
   float vd[4], dd[4], dvacc[4] = {0.f, 0.f, 0.f, 0.f};
   {
-    const float4 v4 = *reinterpret_cast<const float4*>(v + nb + d0 + 4 * sub);
-    const float4 d4 = *reinterpret_cast<const float4*>(ddeg + nb + d0 + 4 * sub);
+    const float4 v4 = *reinterpret_cast<const float4*>(v + nb + d0 + 4 * q);
+    const float4 d4 = *reinterpret_cast<const float4*>(ddeg + nb + d0 + 4 * q);
     vd[0] = v4.x; vd[1] = v4.y; vd[2] = v4.z; vd[3] = v4.w;
     dd[0] = d4.x; dd[1] = d4.y; dd[2] = d4.z; dd[3] = d4.w;
   }
-  const int tile = xb * 4 + dt;                                            // 16-target tile of this graph
-  const int sbeg = sh * (R / 2), send = sbeg + R / 2;
+  float lvd[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) lvd[t] = ds_logit_part(vd[t]);
+  const float c0 = gr * rg.l1_e, c1 = -gr * rg.ent_e;
+  const int nblk = R / 16, sbeg = 16 * ((w * nblk) / 8), send = 16 * (((w + 1) * nblk) / 8);   // whole 16-source blocks
   auto load = [&](auto& bf, int srow) {
-    constexpr int N = sizeof(bf.us) / sizeof(float);
+    constexpr int N = sizeof(bf.h4) / sizeof(bf.h4[0]);
 #pragma unroll
     for (int jj = 0; jj < N; ++jj) {
       const int s0 = srow + 16 * jj;
-      bf.w4[jj] = *reinterpret_cast<const float4*>(ew + (nb + s0 + q) * (int64_t)R + d0 + 4 * sub);
-      bf.us[jj] = u[nb + s0 + q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bf.w4[jj][r] = *reinterpret_cast<const float4*>(ew + (nb + s0 + 4 * sub + r) * (int64_t)R + d0 + 4 * q);
+        bf.us[jj][r] = u[nb + s0 + 4 * sub + r];
+      }
 #pragma unroll
       for (int l = 0; l < L; ++l)
-        bf.h4[jj][l] = *reinterpret_cast<const float4*>(hpm + l * lstride + (nb + s0 + q) * DS_F + 4 * sub);   // B[k][source q]
+        bf.h4[jj][l] = *reinterpret_cast<const float4*>(hpm + l * lstride + (nb + s0 + q) * DS_F + 4 * sub);   // A[source q][k]
     }
   };
   auto compute = [&](const auto& bf, int srow) {
-    constexpr int N = sizeof(bf.us) / sizeof(float);
+    constexpr int N = sizeof(bf.h4) / sizeof(bf.h4[0]);
 #pragma unroll
     for (int jj = 0; jj < N; ++jj) {
       const int s0 = srow + 16 * jj;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      f32x4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         const float hv[4] = {bf.h4[jj][l].x, bf.h4[jj][l].y, bf.h4[jj][l].z, bf.h4[jj][l].w};
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[l][kk], hv[kk], acc, 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[kk], bop[l][kk][t], acc[t], 0, 0, 0);
       }
-      // accumulator register r = (target d0 + 4 sub + r, source s0 + q): the four targets of this lane's 16-byte load
-      const float wv[4] = {bf.w4[jj].x, bf.w4[jj].y, bf.w4[jj].z, bf.w4[jj].w};
-      float rs = 0.f;
+      float rs[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = ds_mask(bf.us[jj], vd[r]);
-        const float de = (acc[r] + dd[r]) * wv[r] + gr * ds_reg_grad(e, rg.l1_e, rg.ent_e, rg.eps);
-        const float dz = de * e * (1.f - e);
-        dvacc[r] += dz;
-        rs += dz;
+        const float wv[4] = {bf.w4[jj][r].x, bf.w4[jj][r].y, bf.w4[jj][r].z, bf.w4[jj][r].w};
+        const float lus = ds_logit_part(bf.us[jj][r]);
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          // reg'(e) e (1 - e) with e = sigmoid(z): log(e / (1 - e)) IS the logit z = u[s] + v[d], so the entropy term's
+          // gradient l1 - ent (log e - log(1 - e)) costs one add per edge instead of two logarithms and two reciprocals
+          // (the reference's eps = 1e-6 inside the logarithms changes the product by O(eps): see ds_reg_term_logit)
+          const float e = ds_mask(bf.us[jj][r], vd[t]);
+          const float de = fmaf(acc[t][r] + dd[t], wv[t], fmaf(c1, lus + lvd[t], c0));
+          const float dz = de * fmaf(-e, e, e);
+          dvacc[t] += dz;
+          a += dz;
+        }
+        rs[r] = ds_row16_sum(a);                                              // over the block's 64 targets
       }
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
-      if (sub == 0) dup[(int64_t)tile * GR + nb + s0 + q] = rs;
+      if (q < 4) {
+        const float out = q == 0 ? rs[0] : q == 1 ? rs[1] : q == 2 ? rs[2] : rs[3];
+        dup[(int64_t)xb * GR + nb + s0 + 4 * sub + q] = out;
+      }
     }
   };
-  ds_walk<PIPE, 16, DsMbBuf<DS_PCH, L>, DsMbBuf<1, L>>(sbeg, send, load, compute, load, compute);
+  // two-buffer pipeline of single 16-source blocks (two blocks' 20 loads per lane in flight; chunks of two blocks: 256
+  // registers and spills)
+  ds_walk<PIPE, 16, DsMbBuf<1, L>, DsMbBuf<1, L>, decltype(load), decltype(compute), decltype(load), decltype(compute), 1>(
+      sbeg, send, load, compute, load, compute);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float a = dvacc[r];
-    a += __shfl_xor(a, 1, 64);
-    a += __shfl_xor(a, 2, 64);
-    a += __shfl_xor(a, 4, 64);
-    a += __shfl_xor(a, 8, 64);
-    if (q == 0) dvs[sh][dt][4 * sub + r] = a;
+  for (int t = 0; t < 4; ++t) {
+    float a = dvacc[t];
+    a += __shfl_xor(a, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    if (sub == 0) dvs[w][4 * q + t] = a;
   }
   __syncthreads();
-  if (tid < 64) dv[nb + xb * 64 + tid] = dvs[0][tid >> 4][tid & 15] + dvs[1][tid >> 4][tid & 15];
+  if (tid < 64) {
+    float a = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) a += dvs[ww][tid];
+    dv[nb + d0 + tid] = a;
+  }
 }
 
 // node-level end of the mask backward: du = sum of the tile partials, dxm = du a[:H0] + dv a[H0:] + dX_0(masked copy),
@@ -789,13 +852,9 @@ k_ds_mask_nodes(int64_t GR, int R, int H0, const float* __restrict__ x, const fl
     const int r = (int)(node % R);
     float du = 0.f, dvv = 0.f;
     if (ANYM) {
-      // R / 16 partials (a multiple of 4): four independent loads per trip, not a chain of waits
-      float d4[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int p = 0; p < R / 16; p += 4) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) d4[k] += dup[(int64_t)(p + k) * GR + node];
-      }
-      du = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+      // R / 64 partials (one per 64-target block of k_ds_mask_bwd), independent loads
+#pragma unroll 8
+      for (int p = 0; p < R / 64; ++p) du += dup[(int64_t)p * GR + node];
       dvv = dv[node];
     }
 #pragma unroll
@@ -946,9 +1005,12 @@ extern "C" int igcn_dense_sgcn_bwd(int64_t n_graphs, int R, int H0, int F, int L
     const float inv_ne = 1.0f / (float)((double)n_graphs * R * R);
     const float* gpm = bws + q.gp + (int64_t)cm * GR * DS_F;
     const float* hpm = ws + o.hp + (int64_t)cm * GR * DS_F;
+    // (pipelined walk: every wave needs at least two 16-source blocks, i.e. R >= 256)
 #define DS_MB(LV)                                                                                                       \
-  DS_PIPE(hipLaunchKernelGGL((k_ds_mask_bwd<LV, PIPE>), eg, dim3(512), 0, st, R, GR, ew, ws + o.u, ws + o.v, gpm, hpm, lsz, \
-                             bws + q.ddeg, d_reg, rg, inv_ne, bws + q.dup, bws + q.dv))
+  if (R % 256 == 0) hipLaunchKernelGGL((k_ds_mask_bwd<LV, true>), eg, dim3(512), 0, st, R, GR, ew, ws + o.u, ws + o.v, gpm, \
+                                       hpm, lsz, bws + q.ddeg, d_reg, rg, inv_ne, bws + q.dup, bws + q.dv);                \
+  else hipLaunchKernelGGL((k_ds_mask_bwd<LV, false>), eg, dim3(512), 0, st, R, GR, ew, ws + o.u, ws + o.v, gpm, hpm, lsz,    \
+                          bws + q.ddeg, d_reg, rg, inv_ne, bws + q.dup, bws + q.dv)
     switch (L) {
       case 1: DS_MB(1); break;
       case 2: DS_MB(2); break;
