@@ -445,6 +445,7 @@ k_nlbn_bwd_apply(int B, int N, int groups, int training, const float* __restrict
 // Sum over the G (= 2, 4, 8, 16) consecutive lanes of a group with DPP cross-lane moves (VALU; __shfl_xor is an LDS-pipe
 // ds_bpermute): xor 1 and xor 2 as quad permutations, then the 8- and 16-lane mirrors (a mirror pairs every lane with
 // one of the other half, which is all a sum needs).  Result in every lane of the group.
+#define RO_QU 4        // samples per trip of the statistics pass (loads only)
 template <int G>
 __device__ __forceinline__ float ro_group_sum_dpp(float v) {
   static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "ro_group_sum_dpp: group size");
@@ -483,22 +484,34 @@ nlbn_bwd_stats_q_body(const RoBlk rb, int B, int N, int groups, const float* __r
     for (int c = 0; c < F; ++c) w[r][c] = W[(q * 4 + r) * F + c];
   const float mu = mean[(int64_t)ch.g * N + nc], rs = rstd[(int64_t)ch.g * N + nc], ga = gamma[nc], be = beta[nc];
   float a1 = 0.f, a2 = 0.f;
-  for (int b = ch.b0 + sg; b < ch.b1; b += RO_SG) {
-    const float mine = q < F ? x[((int64_t)b * F + q) * N + nc] : 0.f;
-    const float4 g4 = *reinterpret_cast<const float4*>(dout + ((int64_t)b * N + nc) * D + q * 4);
-    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
-    float xv[F];
+  // RO_QU samples per trip, their loads issued together (clamped, branch-free): one sample per trip was a chain of
+  // eight dependent round trips per thread (14.4 us for 30 MB)
+  for (int b0 = ch.b0 + sg; b0 < ch.b1; b0 += RO_QU * RO_SG) {
+    float mine[RO_QU];
+    float4 g4[RO_QU];
 #pragma unroll
-    for (int c = 0; c < F; ++c) xv[c] = __shfl(mine, base + c, 64);
+    for (int u = 0; u < RO_QU; ++u) {
+      const int b = min(b0 + u * RO_SG, ch.b1 - 1);
+      mine[u] = q < F ? x[((int64_t)b * F + q) * N + nc] : 0.f;
+      g4[u] = *reinterpret_cast<const float4*>(dout + ((int64_t)b * N + nc) * D + q * 4);
+    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float pre = 0.f;
+    for (int u = 0; u < RO_QU; ++u) {
+      if (b0 + u * RO_SG >= ch.b1) break;                       // (uniform over the wave)
+      const float g[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+      float xv[F];
 #pragma unroll
-      for (int c = 0; c < F; ++c) pre += w[r][c] * xv[c];
-      const float xh = (pre - mu) * rs;
-      const float dy = (xh * ga + be > 0.f) ? g[r] : 0.f;
-      a1 += dy * xh;
-      a2 += dy;
+      for (int c = 0; c < F; ++c) xv[c] = __shfl(mine[u], base + c, 64);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pre = 0.f;
+#pragma unroll
+        for (int c = 0; c < F; ++c) pre += w[r][c] * xv[c];
+        const float xh = (pre - mu) * rs;
+        const float dy = (xh * ga + be > 0.f) ? g[r] : 0.f;
+        a1 += dy * xh;
+        a2 += dy;
+      }
     }
   }
   a1 = ro_group_sum_dpp<DQ>(a1);
@@ -556,6 +569,8 @@ nlbn_bwd_apply_q_body(const RoBlk rb, int B, int N, int groups, int training, co
     }
   const float m1 = t1 / cnt;                                 // mean(dy)
   const float m2 = t2 / cnt;                                 // mean(dy*xhat)
+  // (one sample per trip: batching the loads as in pass 1 did not pay here — 17.4 us against 18.7 with two samples per
+  // trip and 23.3 with four: the pass is bound by its per-sample arithmetic and register footprint, not its load chain)
   for (int b = ch.b0 + sg; b < ch.b1; b += RO_SG) {
     const float mine = q < F ? x[((int64_t)b * F + q) * N + nc] : 0.f;
     const float4 g4 = *reinterpret_cast<const float4*>(dout + ((int64_t)b * N + nc) * D + q * 4);
