@@ -376,6 +376,17 @@ def dense_roofline(data, wl, stats):
             byt = 16 * g * e if name == "k_ds_check" else 4 * g * e
             others[name] = {"us": round(pk[2], 2), "launches_profiled": pk[1], "edge_bytes_per_launch": byt,
                             "frac_edge_bytes": round(byt / (pk[2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    # PMC traffic of the other passes, where the committed passes cover them at this launch shape (32 graphs x R = 512)
+    try:
+        with open(os.environ.get("IGCN_BENCH_PMC_JSON", PMC_JSON)) as fh:
+            table = json.load(fh)
+    except OSError:
+        table = {}
+    for name, row in others.items():
+        t = table.get(name)
+        if t and g == 32 and e == 512 * 512:
+            row["traffic"] = t["traffic_bytes"]
+            row["frac_traffic"] = round(t["traffic_bytes"] / (row["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     res["other_edge_passes"] = others
     _attach_traffic(res)
     return res
