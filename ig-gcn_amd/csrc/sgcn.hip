@@ -139,6 +139,23 @@ k_gcn_norm_bwd_deg_tiled(int64_t n_nodes, const float* __restrict__ ew, const fl
   }
 }
 
+// loss_probability (kernel/sgcn_img_snp.py:153-181) riding in the mask kernels (igcn_edge_mask_{fwd,bwd}_reg): the
+// same term / derivative as csrc/loss.hip's stand-alone regulariser.  For p in (0,1):
+//   r(p) = l1 p - ent (p log(p + eps) + (1 - p) log(1 - p + eps))
+__device__ __forceinline__ float em_reg_term(float p, float l1, float ent, float eps) {
+  return l1 * fabsf(p) - ent * (p * logf(p + eps) + (1.f - p) * logf((1.f - p) + eps));
+}
+__device__ __forceinline__ float em_reg_grad(float p, float l1, float ent, float eps) {
+  return l1 - ent * (logf(p + eps) + p / (p + eps) - logf((1.f - p) + eps) - (1.f - p) / ((1.f - p) + eps));
+}
+struct EmReg {                    // greg == NULL: no regulariser in this launch
+  const float* greg;              // backward: d loss / d (regulariser), device scalar
+  const float* snps;              // SNP mask logits [n_snps] (may be NULL)
+  float* dsnps;                   // backward: their gradient (regulariser part)
+  int n_snps;
+  float l1_x, ent_x, l1_e, ent_e, eps;
+};
+
 // edge-mask backward node pass, dense graphs (formula: k_edge_mask_bwd_nodes); partial row layout identical
 __global__ void __launch_bounds__(TL_T)
 k_edge_mask_bwd_nodes_tiled(int64_t n_nodes, int rois, int h0, const float* __restrict__ x,
@@ -148,15 +165,18 @@ k_edge_mask_bwd_nodes_tiled(int64_t n_nodes, int rois, int h0, const float* __re
                             const float* __restrict__ d_e, const float* __restrict__ d_x_plain,
                             const int32_t* __restrict__ tgt_ptr, const int32_t* __restrict__ tgt_perm,
                             const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_perm,
-                            float* __restrict__ dx, float* __restrict__ gx, float* __restrict__ pb_partial) {
+                            float* __restrict__ dx, float* __restrict__ gx, float* __restrict__ pb_partial, EmReg rg,
+                            float inv_ne) {
   __shared__ int32_t tiles[TL_WAVES][TL_NODES][TL_POS + 1];
   __shared__ float red[TL_WAVES][TL_NODES];
   __shared__ float pbred[TL_NODES][2 * MAX_H0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n0 = (int64_t)blockIdx.x * TL_NODES, node = n0 + lane;
+  const float gre = rg.greg ? rg.greg[0] * inv_ne : 0.f;
   auto dz = [&](int32_t k) {
     const float ek = e[k];
-    const float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
+    float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
+    if (rg.greg) up += gre * em_reg_grad(ek, rg.l1_e, rg.ent_e, rg.eps);
     return up * ek * (1.f - ek);
   };
   __shared__ float bysrc[TL_NODES];
@@ -190,12 +210,17 @@ k_edge_mask_bwd_nodes_tiled(int64_t n_nodes, int rois, int h0, const float* __re
 // =================================================================================================
 // edge mask forward  (cal_probability, kernel/sgcn_img_snp.py:133-151)
 // =================================================================================================
-__global__ void k_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* __restrict__ x,
-                                const float* __restrict__ prob, const float* __restrict__ pb,
-                                const float* __restrict__ ew, const int32_t* __restrict__ src32,
-                                const int32_t* __restrict__ dst32, float* __restrict__ xm, float* __restrict__ e,
-                                float* __restrict__ ewm, float* __restrict__ x_plain, float* __restrict__ ew_plain) {
+template <bool REG>
+__global__ void __launch_bounds__(256)
+k_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* __restrict__ x,
+                const float* __restrict__ prob, const float* __restrict__ pb,
+                const float* __restrict__ ew, const int32_t* __restrict__ src32,
+                const int32_t* __restrict__ dst32, float* __restrict__ xm, float* __restrict__ e,
+                float* __restrict__ ewm, float* __restrict__ x_plain, float* __restrict__ ew_plain, EmReg rg,
+                float* __restrict__ reg_partial) {
+  __shared__ float red[16];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float acc = 0.f;
   if (i < n_nodes * h0) {
     const int64_t node = i / h0;
     const int h = (int)(i - node * h0);
@@ -214,7 +239,21 @@ __global__ void k_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int 
     const float wv = ew[i];
     ewm[i] = wv * p;
     if (ew_plain) ew_plain[i] = wv;
+    if (REG) acc += em_reg_term(p, rg.l1_e, rg.ent_e, rg.eps) / (float)n_edges;
   }
+  if (REG) {                                          // loss_probability's three means, one partial per workgroup
+    const int64_t np = (int64_t)rois * h0;
+    if (i < np) acc += em_reg_term(1.f / (1.f + expf(-prob[i])), rg.l1_x, rg.ent_x, rg.eps) / (float)np;
+    if (rg.snps && i < rg.n_snps)
+      acc += em_reg_term(1.f / (1.f + expf(-rg.snps[i])), rg.l1_x, rg.ent_x, rg.eps) / (float)rg.n_snps;
+    acc = block_sum_all(acc, red);
+    if (threadIdx.x == 0) reg_partial[blockIdx.x] = acc;
+  }
+}
+
+static int64_t em_fwd_items(int64_t n_nodes, int64_t n_edges, int h0, int n_snps) {
+  int64_t n = n_nodes * h0 > n_edges ? n_nodes * h0 : n_edges;
+  return n > n_snps ? n : n_snps;
 }
 
 extern "C" int igcn_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x,
@@ -224,11 +263,34 @@ extern "C" int igcn_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, in
   IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0,
                "edge_mask_fwd: need n_nodes %% rois == 0 and 0 < h0 <= %d (n_nodes=%lld rois=%d h0=%d)", MAX_H0,
                (long long)n_nodes, rois, h0);
-  const int64_t n = n_nodes * h0 > n_edges ? n_nodes * h0 : n_edges;
+  const int64_t n = em_fwd_items(n_nodes, n_edges, h0, 0);
   if (n == 0) return IGCN_OK;
-  hipLaunchKernelGGL(k_edge_mask_fwd, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n_nodes,
-                     n_edges, rois, h0, x, prob, prob_bias, ew, src32, dst32, xm, e, ewm, x_plain, ew_plain);
+  hipLaunchKernelGGL(k_edge_mask_fwd<false>, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     n_nodes, n_edges, rois, h0, x, prob, prob_bias, ew, src32, dst32, xm, e, ewm, x_plain, ew_plain,
+                     EmReg{}, nullptr);
   IGCN_CHECK_LAUNCH("edge_mask_fwd");
+  return IGCN_OK;
+}
+
+// The same launch also leaves loss_probability (kernel/sgcn_img_snp.py:153-181) as igcn_edge_mask_reg_blocks()
+// workgroup partials whose SUM is the loss — mean r_x(sigmoid(prob)) + mean r_e(e) + mean r_x(sigmoid(snps_logits)),
+// snps_logits NULL: without the last — so that a train step needs no regulariser launch of its own.
+extern "C" int igcn_edge_mask_reg_blocks(int64_t n_nodes, int64_t n_edges, int h0, int n_snps) {
+  return (int)igcn_cdiv(em_fwd_items(n_nodes, n_edges, h0, n_snps), 256);
+}
+extern "C" int igcn_edge_mask_fwd_reg(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x,
+                                      const float* prob, const float* prob_bias, const float* ew, const int32_t* src32,
+                                      const int32_t* dst32, float* xm, float* e, float* ewm, float* x_plain,
+                                      float* ew_plain, const float* snps_logits, int n_snps, float l1_x, float ent_x,
+                                      float l1_e, float ent_e, float eps, float* reg_partial, void* stream) {
+  IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0 && n_nodes > 0 && n_edges > 0 && reg_partial &&
+                   n_snps >= 0, "edge_mask_fwd_reg: bad arguments");
+  const int64_t n = em_fwd_items(n_nodes, n_edges, h0, snps_logits ? n_snps : 0);
+  const EmReg rg = {nullptr, snps_logits, nullptr, snps_logits ? n_snps : 0, l1_x, ent_x, l1_e, ent_e, eps};
+  hipLaunchKernelGGL(k_edge_mask_fwd<true>, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     n_nodes, n_edges, rois, h0, x, prob, prob_bias, ew, src32, dst32, xm, e, ewm, x_plain, ew_plain, rg,
+                     reg_partial);
+  IGCN_CHECK_LAUNCH("edge_mask_fwd_reg");
   return IGCN_OK;
 }
 
@@ -250,8 +312,10 @@ k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict
                       const int32_t* __restrict__ tgt_ptr,
                       const int32_t* __restrict__ tgt_perm, const int32_t* __restrict__ src_ptr,
                       const int32_t* __restrict__ src_perm, float* __restrict__ dx,
-                      float* __restrict__ gx /*[N,h0]*/, float* __restrict__ pb_partial /*[nblk,2h0]*/) {
+                      float* __restrict__ gx /*[N,h0]*/, float* __restrict__ pb_partial /*[nblk,2h0]*/, EmReg rg,
+                      float inv_ne) {
   __shared__ float red[4 * 2 * MAX_H0];
+  const float gre = rg.greg ? rg.greg[0] * inv_ne : 0.f;
   float acc[2 * MAX_H0];
 #pragma unroll
   for (int j = 0; j < 2 * MAX_H0; ++j) acc[j] = 0.f;
@@ -262,13 +326,15 @@ k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict
     for (int32_t p = src_ptr[i] + sub; p < src_ptr[i + 1]; p += LPN) {
       const int32_t k = src_perm[p];
       const float ek = e[k];
-      const float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
+      float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
+      if (rg.greg) up += gre * em_reg_grad(ek, rg.l1_e, rg.ent_e, rg.eps);
       S += up * ek * (1.f - ek);
     }
     for (int32_t p = tgt_ptr[i] + sub; p < tgt_ptr[i + 1]; p += LPN) {
       const int32_t k = tgt_perm[p];
       const float ek = e[k];
-      const float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
+      float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
+      if (rg.greg) up += gre * em_reg_grad(ek, rg.l1_e, rg.ent_e, rg.eps);
       T += up * ek * (1.f - ek);
     }
     S = group_sum_all<LPN>(S);
@@ -293,9 +359,18 @@ k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict
 // to be two further launches (column sums of the partial rows, then the pick-and-store).
 __global__ void __launch_bounds__(256)
 k_edge_mask_bwd_prob(int64_t n_graphs, int rois, int h0, const float* __restrict__ gx, float* __restrict__ dprob,
-                     int64_t nblk, const float* __restrict__ partial, float* __restrict__ dpb) {
+                     int64_t nblk, const float* __restrict__ partial, float* __restrict__ dpb,
+                     const float* __restrict__ prob, EmReg rg) {
   __shared__ float red[16 * 16];
   const int j = blockIdx.x;
+  if (j == rois * h0 + 1) {                          // regulariser: the SNP mask logits' gradient (extra workgroup)
+    const float g = rg.greg[0] / (float)rg.n_snps;
+    for (int k = threadIdx.x; k < rg.n_snps; k += 256) {
+      const float p = 1.f / (1.f + expf(-rg.snps[k]));
+      rg.dsnps[k] = g * em_reg_grad(p, rg.l1_x, rg.ent_x, rg.eps) * p * (1.f - p);
+    }
+    return;
+  }
   if (j == rois * h0) {
     const int rl = threadIdx.x >> 4, cs = threadIdx.x & 15;
     float t = 0.f;
@@ -316,7 +391,44 @@ k_edge_mask_bwd_prob(int64_t n_graphs, int rois, int h0, const float* __restrict
   float t = 0.f;
   for (int64_t b = threadIdx.x; b < n_graphs; b += 256) t += gx[b * rois * h0 + j];
   t = block_sum_all(t, red);
-  if (threadIdx.x == 0) dprob[j] = t;
+  if (threadIdx.x == 0) {
+    if (rg.greg) {                                   // + the regulariser's own term on sigmoid(prob)
+      const float p = 1.f / (1.f + expf(-prob[j]));
+      t += rg.greg[0] / (float)(rois * h0) * em_reg_grad(p, rg.l1_x, rg.ent_x, rg.eps) * p * (1.f - p);
+    }
+    dprob[j] = t;
+  }
+}
+
+static int em_bwd_impl(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x, const float* prob,
+                       const float* prob_bias, const float* ew, const float* e, const float* d_xm, const float* d_ewm,
+                       const float* d_e, const float* d_x_plain, const int32_t* tgt_ptr, const int32_t* tgt_perm,
+                       const int32_t* src_ptr, const int32_t* src_perm, float* dx, float* dprob, float* dprob_bias,
+                       float* scratch, EmReg rg, hipStream_t st) {
+  const bool dense = n_edges >= 16 * n_nodes;
+  const bool tiled = dense && !igcn_opt(IGCN_OPT_NO_TILED_LISTS);
+  const int64_t nblk = tiled ? igcn_cdiv(n_nodes, TL_NODES) : igcn_cdiv(n_nodes, dense ? 4 : 64);
+  const float inv_ne = n_edges > 0 ? 1.0f / (float)n_edges : 0.f;
+  float* gx = scratch;
+  float* part = scratch + n_nodes * h0;  // [nblk, 2*MAX_H0]
+  if (tiled)                                       // dense graphs: lanes own nodes, permutation tiles through LDS
+    hipLaunchKernelGGL(k_edge_mask_bwd_nodes_tiled, dim3((unsigned)nblk), dim3(TL_T), 0, st, n_nodes, rois, h0, x, prob,
+                       prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part, rg,
+                       inv_ne);
+  else if (dense)                                  // a wave per node strides its edge lists
+    hipLaunchKernelGGL(k_edge_mask_bwd_nodes<64>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
+                       prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part, rg,
+                       inv_ne);
+  else                                             // k = 3 graphs: four lanes share a node's six list entries
+    hipLaunchKernelGGL(k_edge_mask_bwd_nodes<4>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
+                       prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part, rg,
+                       inv_ne);
+  static_assert(2 * MAX_H0 <= 16, "k_edge_mask_bwd_prob: the bias-gradient block has 16 column slots");
+  const bool snps_block = rg.greg && rg.snps && rg.dsnps && rg.n_snps > 0;
+  hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)(rois * h0 + 1 + (snps_block ? 1 : 0))), dim3(256), 0, st,
+                     n_nodes / rois, rois, h0, gx, dprob, nblk, part, dprob_bias, prob, rg);
+  IGCN_CHECK_LAUNCH("edge_mask_bwd");
+  return IGCN_OK;
 }
 
 extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x,
@@ -326,26 +438,24 @@ extern "C" int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, in
                                   const int32_t* src_perm, float* dx, float* dprob, float* dprob_bias, float* scratch,
                                   void* stream) {
   IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0, "edge_mask_bwd: bad rois/h0");
-  hipStream_t st = (hipStream_t)stream;
-  const bool dense = n_edges >= 16 * n_nodes;
-  const bool tiled = dense && !igcn_opt(IGCN_OPT_NO_TILED_LISTS);
-  const int64_t nblk = tiled ? igcn_cdiv(n_nodes, TL_NODES) : igcn_cdiv(n_nodes, dense ? 4 : 64);
-  float* gx = scratch;
-  float* part = scratch + n_nodes * h0;  // [nblk, 2*MAX_H0]
-  if (tiled)                                       // dense graphs: lanes own nodes, permutation tiles through LDS
-    hipLaunchKernelGGL(k_edge_mask_bwd_nodes_tiled, dim3((unsigned)nblk), dim3(TL_T), 0, st, n_nodes, rois, h0, x, prob,
-                       prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
-  else if (dense)                                  // (A/B: the wave strides a node's edge lists)
-    hipLaunchKernelGGL(k_edge_mask_bwd_nodes<64>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
-                       prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
-  else                                             // k = 3 graphs: four lanes share a node's six list entries
-    hipLaunchKernelGGL(k_edge_mask_bwd_nodes<4>, dim3((unsigned)nblk), dim3(256), 0, st, n_nodes, rois, h0, x, prob,
-                       prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm, src_ptr, src_perm, dx, gx, part);
-  static_assert(2 * MAX_H0 <= 16, "k_edge_mask_bwd_prob: the bias-gradient block has 16 column slots");
-  hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)(rois * h0 + 1)), dim3(256), 0, st, n_nodes / rois, rois, h0,
-                     gx, dprob, nblk, part, dprob_bias);
-  IGCN_CHECK_LAUNCH("edge_mask_bwd");
-  return IGCN_OK;
+  return em_bwd_impl(n_nodes, n_edges, rois, h0, x, prob, prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm,
+                     src_ptr, src_perm, dx, dprob, dprob_bias, scratch, EmReg{}, (hipStream_t)stream);
+}
+
+// ... with the gradient of the regulariser of igcn_edge_mask_fwd_reg inside: d_reg [1] (device) = d loss / d (sum of
+// the partials); its edge part joins d_e per edge, its sigmoid(prob) part dprob, and dsnps [n_snps] (may be NULL with
+// snps_logits) receives the SNP mask logits' part.
+extern "C" int igcn_edge_mask_bwd_reg(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x,
+                                      const float* prob, const float* prob_bias, const float* ew, const float* e,
+                                      const float* d_xm, const float* d_ewm, const float* d_e, const float* d_x_plain,
+                                      const int32_t* tgt_ptr, const int32_t* tgt_perm, const int32_t* src_ptr,
+                                      const int32_t* src_perm, const float* d_reg, const float* snps_logits, int n_snps,
+                                      float l1_x, float ent_x, float l1_e, float ent_e, float eps, float* dx, float* dprob,
+                                      float* dprob_bias, float* dsnps, float* scratch, void* stream) {
+  IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0 && d_reg, "edge_mask_bwd_reg: bad arguments");
+  const EmReg rg = {d_reg, snps_logits, dsnps, snps_logits ? n_snps : 0, l1_x, ent_x, l1_e, ent_e, eps};
+  return em_bwd_impl(n_nodes, n_edges, rois, h0, x, prob, prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm,
+                     src_ptr, src_perm, dx, dprob, dprob_bias, scratch, rg, (hipStream_t)stream);
 }
 
 // =================================================================================================

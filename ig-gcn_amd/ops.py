@@ -298,7 +298,7 @@ class EdgeMask(torch.autograd.Function):
 
 
 def _edge_mask_backward(ctx, d_xm, d_ewm, d_e, d_x_plain):
-    x, prob, pb, ew, e = ctx.saved_tensors
+    x, prob, pb, ew, e = ctx.saved_tensors[:5]
     plan, rois = ctx.plan, ctx.rois
     n, h0 = x.shape
     d_xm, d_ewm, d_e, d_x_plain = (_f32(t) if t is not None else None for t in (d_xm, d_ewm, d_e, d_x_plain))
@@ -313,31 +313,64 @@ def _edge_mask_backward(ctx, d_xm, d_ewm, d_e, d_x_plain):
 class EdgeMaskStacked(torch.autograd.Function):
     """The (plain | masked) batch of the two passes of a train step in one launch: x_in = cat(x, xm) [2N,h0],
     ew_in = cat(ew, ewm) [2E], and the edge mask e — cal_probability (kernel/sgcn_img_snp.py:133-151) writing both
-    halves itself instead of two concatenations behind it."""
+    halves itself instead of two concatenations behind it.
+
+    With ``reg_hp`` = (l1_x, ent_x, l1_e, ent_e, eps) the launch also leaves loss_probability (:153-181) as a fourth
+    output — workgroup partials whose SUM is the regulariser (ops.LossHead adds them up), over sigmoid(prob), e and
+    sigmoid(``snps_logits``) — and the backward takes its gradient along: no regulariser launches in the step."""
 
     @staticmethod
-    def forward(ctx, x, prob, prob_bias, ew, plan, rois):
+    def forward(ctx, x, prob, prob_bias, ew, plan, rois, snps_logits=None, reg_hp=None):
         x, prob, pb, ew = _f32(x), _f32(prob), _f32(prob_bias), _f32(ew)
         n, h0 = x.shape
         ne = ew.shape[0]
         x_in = torch.empty(2 * n, h0, dtype=torch.float32, device=x.device)
         ew_in = torch.empty(2 * ne, dtype=torch.float32, device=x.device)
         e = torch.empty_like(ew)
-        call("igcn_edge_mask_fwd", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew),
-             ptr(plan.src32), ptr(plan.dst32), ptr(x_in[n:]), ptr(e), ptr(ew_in[ne:]), ptr(x_in[:n]), ptr(ew_in[:ne]),
-             stream_ptr())
-        ctx.save_for_backward(x, prob, pb, ew, e)
+        ctx.reg = None
+        snps = None
+        if reg_hp is not None:
+            snps = _f32(snps_logits).reshape(-1) if snps_logits is not None else None
+            ns = snps.numel() if snps is not None else 0
+            hp = tuple(float(v) for v in reg_hp)
+            regp = torch.empty(int(_lib.load().igcn_edge_mask_reg_blocks(n, plan.n_edges, h0, ns)), dtype=torch.float32,
+                               device=x.device)
+            call("igcn_edge_mask_fwd_reg", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew), ptr(plan.src32),
+                 ptr(plan.dst32), ptr(x_in[n:]), ptr(e), ptr(ew_in[ne:]), ptr(x_in[:n]), ptr(ew_in[:ne]), ptr(snps), ns, *hp,
+                 ptr(regp), stream_ptr())
+            ctx.reg = (hp, ns, snps_logits.shape if snps_logits is not None else None)
+        else:
+            call("igcn_edge_mask_fwd", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew),
+                 ptr(plan.src32), ptr(plan.dst32), ptr(x_in[n:]), ptr(e), ptr(ew_in[ne:]), ptr(x_in[:n]), ptr(ew_in[:ne]),
+                 stream_ptr())
+        ctx.save_for_backward(x, prob, pb, ew, e, snps)
         ctx.plan, ctx.rois = plan, rois
         ctx.set_materialize_grads(False)
+        if reg_hp is not None:
+            return x_in, ew_in, e, regp
         return x_in, ew_in, e
 
     @staticmethod
-    def backward(ctx, d_x_in, d_ew_in, d_e):
+    def backward(ctx, d_x_in, d_ew_in, d_e, d_regp=None):
         n, ne = ctx.saved_tensors[0].shape[0], ctx.saved_tensors[3].shape[0]
         d_xm = d_x_in[n:] if d_x_in is not None else None
         d_xp = d_x_in[:n] if d_x_in is not None else None
         d_ewm = d_ew_in[ne:] if d_ew_in is not None else None
-        return _edge_mask_backward(ctx, d_xm, d_ewm, d_e, d_xp)
+        if ctx.reg is None or d_regp is None:
+            return _edge_mask_backward(ctx, d_xm, d_ewm, d_e, d_xp) + (None, None)
+        x, prob, pb, ew, e, snps = ctx.saved_tensors
+        hp, ns, snps_shape = ctx.reg
+        plan, rois = ctx.plan, ctx.rois
+        h0 = x.shape[1]
+        d_xm, d_ewm, d_e, d_xp = (_f32(t) if t is not None else None for t in (d_xm, d_ewm, d_e, d_xp))
+        greg = _f32(d_regp[:1]).reshape(1)                 # the partials' gradient is one scalar, repeated
+        dx, dprob, dpb = torch.empty_like(x), torch.empty_like(prob), torch.empty_like(pb)
+        dsnps = torch.empty(snps_shape, dtype=torch.float32, device=x.device) if snps is not None else None
+        scratch = torch.empty(n * h0 + 16 * ((n + 3) // 4) + 16, dtype=torch.float32, device=x.device)
+        call("igcn_edge_mask_bwd_reg", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew), ptr(e), ptr(d_xm),
+             ptr(d_ewm), ptr(d_e), ptr(d_xp), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm),
+             ptr(greg), ptr(snps), ns, *hp, ptr(dx), ptr(dprob), ptr(dpb), ptr(dsnps), ptr(scratch), stream_ptr())
+        return dx, dprob, dpb, None, None, None, dsnps, None
 
 
 class GcnNorm(torch.autograd.Function):

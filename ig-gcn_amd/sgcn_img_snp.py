@@ -198,9 +198,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
     def loss_probability(self, x, edge_index, edge_weight, hp, eps=1e-6, plan=None, edge_prob=None, partials=False):
         """:153-181 as one fused reduction (igcn_mask_reg_*).  ``edge_prob`` lets the train step reuse the mask
         the explain pass already computed; ``partials``: the un-reduced workgroup sums (ops.LossHead adds them up)."""
-        if edge_prob is None and self._dense_reg is not None and self._dense_reg[1] == (
+        if (edge_prob is None or edge_prob is self.last_edge_prob) and self._dense_reg is not None and self._dense_reg[1] == (
                 float(hp.lamda_x_l1), float(hp.lamda_x_ent), float(hp.lamda_e_l1), float(hp.lamda_e_ent), float(eps)):
-            # the dense-block forward of the masked pass has already reduced every term (edge mask never materialised)
+            # the forward of the masked pass has already reduced every term: the dense-block path (edge mask never
+            # materialised) or the stacked sweep's mask launch (ops.EdgeMaskStacked with reg_hp)
             return self._dense_reg[0] if partials else self._dense_reg[0].sum()
         if edge_prob is None:
             _, _, _, edge_prob = self.cal_probability(x, edge_index, edge_weight, plan=plan)
@@ -320,13 +321,25 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             # the train step's (plain | masked) pair: cal_probability writes both halves of the stacked batch itself.
             # prob (mask, head inputs, regulariser), data.x (mask, head inputs) and snps_prob (mask, regulariser) each
             # feed several ops: ops.GradFan hands out aliases and sums their gradients in one launch per tensor
-            if fan:
+            reg_in_mask = fan and self._reg_hp is not None and os.environ.get("IGCN_NO_MASK_REG_FUSED", "0") != "1"
+            if fan and reg_in_mask:
+                # loss_probability rides in the mask launch (ops.EdgeMaskStacked with reg_hp): prob then has two
+                # consumers (mask + regulariser in one op; head inputs), snps_prob two (that op; the SNP mask)
+                prob_m, prob_h = ops.GradFan.apply(self.prob, 2)
+                x_m, x_h = ops.GradFan.apply(x, 2)
+                sp_m, sp_r = ops.GradFan.apply(self.snps_prob, 2)
+            elif fan:
                 prob_m, prob_h, self._fan_prob = ops.GradFan.apply(self.prob, 3)
                 x_m, x_h = ops.GradFan.apply(x, 2)
                 sp_m, self._fan_snps = ops.GradFan.apply(self.snps_prob, 2)
             else:
                 sp_m = self.snps_prob
-            x_in, ew_in, e = ops.EdgeMaskStacked.apply(x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois)
+            if reg_in_mask:
+                x_in, ew_in, e, regp = ops.EdgeMaskStacked.apply(x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois,
+                                                                 sp_r, self._reg_hp)
+                self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp))
+            else:
+                x_in, ew_in, e = ops.EdgeMaskStacked.apply(x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois)
             snps_in, _ = ops.SnpsMask.apply(snps_feat, sp_m, True)
             self.last_edge_prob = e
         else:

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 310
+#define IGCN_ABI_VERSION 311
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -122,6 +122,25 @@ int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, int h0,
                        const float* d_x_plain, const int32_t* tgt_ptr, const int32_t* tgt_perm,
                        const int32_t* src_ptr, const int32_t* src_perm,
                        float* dx, float* dprob, float* dprob_bias, float* scratch, void* stream);
+
+/* The same two entry points with loss_probability (kernel/sgcn_img_snp.py:153-181) riding along — in a train step the
+ * regulariser reads exactly what the mask launch has in registers (e per edge, prob, the SNP mask logits):
+ *   forward: reg_partial [igcn_edge_mask_reg_blocks(...)] workgroup partials whose SUM is
+ *            mean r_x(sigmoid(prob)) + mean r_e(e) + mean r_x(sigmoid(snps_logits))     (snps_logits NULL: without it)
+ *   backward: d_reg [1] (device) = d loss / d (that sum); its edge part joins d_e inside the node pass, its prob part
+ *            dprob, and dsnps [n_snps] receives the SNP logits' part.
+ * Same arithmetic as igcn_mask_reg_{fwd,bwd}; two launches less per step. */
+int igcn_edge_mask_reg_blocks(int64_t n_nodes, int64_t n_edges, int h0, int n_snps);
+int igcn_edge_mask_fwd_reg(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x, const float* prob,
+                           const float* prob_bias, const float* ew, const int32_t* src32, const int32_t* dst32, float* xm,
+                           float* e, float* ewm, float* x_plain, float* ew_plain, const float* snps_logits, int n_snps,
+                           float l1_x, float ent_x, float l1_e, float ent_e, float eps, float* reg_partial, void* stream);
+int igcn_edge_mask_bwd_reg(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x, const float* prob,
+                           const float* prob_bias, const float* ew, const float* e, const float* d_xm, const float* d_ewm,
+                           const float* d_e, const float* d_x_plain, const int32_t* tgt_ptr, const int32_t* tgt_perm,
+                           const int32_t* src_ptr, const int32_t* src_perm, const float* d_reg, const float* snps_logits,
+                           int n_snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps, float* dx, float* dprob,
+                           float* dprob_bias, float* dsnps, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GCN normalisation — PyG gcn_norm inside GCNConv (kernel/sgcn_img_snp.py:218,221):

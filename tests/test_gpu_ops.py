@@ -656,6 +656,50 @@ def test_mask_regulariser(ops):
         assert_matches(a, b.numpy(), TOL, nm)
 
 
+@pytest.mark.parametrize("bsz,rois,h0,deg,with_snps", [(8, 90, 3, 3, True), (3, 10, 3, 6, False), (3, 70, 3, 40, True),
+                                                       (2, 17, 5, 6, True)])
+def test_stacked_masks_carry_the_regulariser(ops, bsz, rois, h0, deg, with_snps):
+    """ops.EdgeMaskStacked with reg_hp: loss_probability (kernel/sgcn_img_snp.py:153-181) rides in the mask launch of
+    the stacked (plain | masked) sweep and its gradient in the mask's backward.  Against the fp64 oracle: both halves of
+    the stacked tensors, the regulariser (sum of the partials), and the gradients of a loss that uses all of them — low
+    and high degree graphs (4 lanes per node / a wave per node / the tiled walks), with and without SNP logits."""
+    from oracle import sgcn_img_snp as OS
+    rng = np.random.default_rng(bsz + rois)
+    n = bsz * rois
+    ei, ew = _rand_graph(rng, n, deg * n)
+    ne = ei.shape[1]
+    mk = lambda *sh: torch.from_numpy(rng.standard_normal(sh)).float()                 # noqa: E731
+    x = torch.from_numpy(rng.random((n, h0))).float()
+    prob, pb, snps = mk(rois, h0), mk(2 * h0, 1), mk(1, 54)
+    cx, cw, reg_w = mk(2 * n, h0), mk(2 * ne), 1.7
+    hp = OS.HP
+    ref_in = [t.double().requires_grad_(True) for t in (x, prob, pb, snps)]
+    xm, ewm, e = OS.edge_and_region_masks({"prob": ref_in[1], "prob_bias": ref_in[2]}, ref_in[0], ei, ew.double(), rois)
+    parts = [OS._bin_entropy_and_l1(torch.sigmoid(ref_in[1]), 1e-6), OS._bin_entropy_and_l1(e, 1e-6)]
+    if with_snps:
+        parts.append(OS._bin_entropy_and_l1(torch.sigmoid(ref_in[3]), 1e-6))
+    l1w, entw = (hp.lamda_x_l1, hp.lamda_e_l1, hp.lamda_x_l1), (hp.lamda_x_ent, hp.lamda_e_ent, hp.lamda_x_ent)
+    reg = sum(l1w[i] * pt[0] + entw[i] * pt[1] for i, pt in enumerate(parts))
+    total = (torch.cat([ref_in[0], xm]) * cx.double()).sum() + (torch.cat([ew.double(), ewm]) * cw.double()).sum() + reg_w * reg
+    g_ref = torch.autograd.grad(total, ref_in, allow_unused=True)
+    dev = [t.cuda().requires_grad_(True) for t in (x, prob, pb, snps)]
+    plan = ops.GraphPlan(ei.cuda(), n)
+    reg_hp = (hp.lamda_x_l1, hp.lamda_x_ent, hp.lamda_e_l1, hp.lamda_e_ent, 1e-6)
+    x_in, ew_in, e_g, regp = ops.EdgeMaskStacked.apply(dev[0], dev[1], dev[2], ew.cuda(), plan, rois,
+                                                       dev[3] if with_snps else None, reg_hp)
+    assert_matches(x_in, torch.cat([x.double(), xm.detach()]).numpy(), TOL, "x_in")
+    assert_matches(ew_in, torch.cat([ew.double(), ewm.detach()]).numpy(), TOL, "ew_in")
+    assert_matches(e_g, e.detach().numpy(), TOL, "e")
+    assert abs(float(regp.sum()) - float(reg)) <= 1e-5 * abs(float(reg))
+    got = torch.autograd.grad((x_in * cx.cuda()).sum() + (ew_in * cw.cuda()).sum() + reg_w * regp.sum(), dev,
+                              allow_unused=True)
+    for a, b, nm in zip(got, g_ref, ("dx", "dprob", "dprob_bias", "dsnps")):
+        if b is None:
+            assert a is None, nm
+            continue
+        assert_matches(a, b.numpy(), TOL, nm)
+
+
 @pytest.mark.parametrize("bsz,rd,soft", [(7, 40, True), (64, 2880, True), (32, 300, False)])
 def test_gram_losses(ops, bsz, rd, soft):
     from oracle import sgcn_img_snp as OS
