@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 311        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 312        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -30,9 +30,10 @@ SIGNATURES = {
     "igcn_graph_plan_replicate": (I, [L, L, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_edge_mask_fwd": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_edge_mask_bwd": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "igcn_edge_mask_reg_blocks": (I, [L, L, I, I]),
-    "igcn_edge_mask_fwd_reg": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, F, F, F, F, F, P, P]),
-    "igcn_edge_mask_bwd_reg": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, F, F, F, F, F, P, P, P, P, P, P]),
+    "igcn_edge_mask_reg_blocks": (I, [L, L, I, I, I]),
+    "igcn_edge_mask_fwd_reg": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, F, F, F, F, F, P, P, I, P, P]),
+    "igcn_edge_mask_bwd_reg": (I, [L, L, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, F, F, F, F, F, P, P, P, P, P,
+                                   P, I, P, P]),
     "igcn_gcn_norm_fwd": (I, [L, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_gcn_norm_bwd": (I, [L, L, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_gcn_propagate_fwd": (I, [L, L, I, I, P, L, P, P, P, P, P, L, I, P]),

@@ -151,9 +151,15 @@ __device__ __forceinline__ float em_reg_grad(float p, float l1, float ent, float
 struct EmReg {                    // greg == NULL: no regulariser in this launch
   const float* greg;              // backward: d loss / d (regulariser), device scalar
   const float* snps;              // SNP mask logits [n_snps] (may be NULL)
-  float* dsnps;                   // backward: their gradient (regulariser part)
+  float* dsnps;                   // backward: their gradient (regulariser part + mask part)
   int n_snps;
   float l1_x, ent_x, l1_e, ent_e, eps;
+  // the SNP mask itself (cal_probability :147-151) for the stacked sweep: feat [B, n_snps] -> full [2B, n_snps] =
+  // (feat | feat * sigmoid(logits)); backward: d_full [2B, n_snps] (its masked half is read)
+  const float* feat;
+  float* full;
+  const float* d_full;
+  int B;
 };
 
 // edge-mask backward node pass, dense graphs (formula: k_edge_mask_bwd_nodes); partial row layout identical
@@ -241,6 +247,11 @@ k_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float*
     if (ew_plain) ew_plain[i] = wv;
     if (REG) acc += em_reg_term(p, rg.l1_e, rg.ent_e, rg.eps) / (float)n_edges;
   }
+  if (REG && rg.feat && i < (int64_t)rg.B * rg.n_snps) {   // SNP mask of the stacked sweep: plain | masked halves
+    const float v = rg.feat[i];
+    rg.full[i] = v;
+    rg.full[(int64_t)rg.B * rg.n_snps + i] = v / (1.f + expf(-rg.snps[i % rg.n_snps]));
+  }
   if (REG) {                                          // loss_probability's three means, one partial per workgroup
     const int64_t np = (int64_t)rois * h0;
     if (i < np) acc += em_reg_term(1.f / (1.f + expf(-prob[i])), rg.l1_x, rg.ent_x, rg.eps) / (float)np;
@@ -251,7 +262,7 @@ k_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float*
   }
 }
 
-static int64_t em_fwd_items(int64_t n_nodes, int64_t n_edges, int h0, int n_snps) {
+static int64_t em_fwd_items(int64_t n_nodes, int64_t n_edges, int h0, int64_t n_snps) {   // n_snps: logits, or B * logits
   int64_t n = n_nodes * h0 > n_edges ? n_nodes * h0 : n_edges;
   return n > n_snps ? n : n_snps;
 }
@@ -275,18 +286,24 @@ extern "C" int igcn_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, in
 // The same launch also leaves loss_probability (kernel/sgcn_img_snp.py:153-181) as igcn_edge_mask_reg_blocks()
 // workgroup partials whose SUM is the loss — mean r_x(sigmoid(prob)) + mean r_e(e) + mean r_x(sigmoid(snps_logits)),
 // snps_logits NULL: without the last — so that a train step needs no regulariser launch of its own.
-extern "C" int igcn_edge_mask_reg_blocks(int64_t n_nodes, int64_t n_edges, int h0, int n_snps) {
-  return (int)igcn_cdiv(em_fwd_items(n_nodes, n_edges, h0, n_snps), 256);
+extern "C" int igcn_edge_mask_reg_blocks(int64_t n_nodes, int64_t n_edges, int h0, int n_snps, int snps_rows) {
+  return (int)igcn_cdiv(em_fwd_items(n_nodes, n_edges, h0, (int64_t)(snps_rows > 0 ? snps_rows : 1) * n_snps), 256);
 }
+// snps_feat [snps_rows, n_snps] (or NULL): the launch also writes the SNP mask of the stacked sweep,
+// snps_full [2 snps_rows, n_snps] = (snps_feat | snps_feat * sigmoid(snps_logits)).
 extern "C" int igcn_edge_mask_fwd_reg(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x,
                                       const float* prob, const float* prob_bias, const float* ew, const int32_t* src32,
                                       const int32_t* dst32, float* xm, float* e, float* ewm, float* x_plain,
                                       float* ew_plain, const float* snps_logits, int n_snps, float l1_x, float ent_x,
-                                      float l1_e, float ent_e, float eps, float* reg_partial, void* stream) {
+                                      float l1_e, float ent_e, float eps, float* reg_partial, const float* snps_feat,
+                                      int snps_rows, float* snps_full, void* stream) {
   IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0 && n_nodes > 0 && n_edges > 0 && reg_partial &&
-                   n_snps >= 0, "edge_mask_fwd_reg: bad arguments");
-  const int64_t n = em_fwd_items(n_nodes, n_edges, h0, snps_logits ? n_snps : 0);
-  const EmReg rg = {nullptr, snps_logits, nullptr, snps_logits ? n_snps : 0, l1_x, ent_x, l1_e, ent_e, eps};
+                   n_snps >= 0 && (snps_feat == nullptr || (snps_logits && snps_full && snps_rows > 0)),
+               "edge_mask_fwd_reg: bad arguments");
+  const int ns = snps_logits ? n_snps : 0;
+  const int64_t n = em_fwd_items(n_nodes, n_edges, h0, (int64_t)(snps_feat ? snps_rows : 1) * ns);
+  const EmReg rg = {nullptr, snps_logits, nullptr, ns, l1_x, ent_x, l1_e, ent_e, eps, snps_feat, snps_full, nullptr,
+                    snps_feat ? snps_rows : 0};
   hipLaunchKernelGGL(k_edge_mask_fwd<true>, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      n_nodes, n_edges, rois, h0, x, prob, prob_bias, ew, src32, dst32, xm, e, ewm, x_plain, ew_plain, rg,
                      reg_partial);
@@ -363,11 +380,17 @@ k_edge_mask_bwd_prob(int64_t n_graphs, int rois, int h0, const float* __restrict
                      const float* __restrict__ prob, EmReg rg) {
   __shared__ float red[16 * 16];
   const int j = blockIdx.x;
-  if (j == rois * h0 + 1) {                          // regulariser: the SNP mask logits' gradient (extra workgroup)
-    const float g = rg.greg[0] / (float)rg.n_snps;
-    for (int k = threadIdx.x; k < rg.n_snps; k += 256) {
+  if (j > rois * h0) {                               // one extra workgroup per SNP: the mask logit's gradient —
+    const int k = j - (rois * h0 + 1);               // regulariser part + (stacked sweep) sum_b d_masked[b,k] feat[b,k]
+    float acc = 0.f;
+    if (rg.d_full && rg.feat) {
+      const float* dm = rg.d_full + (int64_t)rg.B * rg.n_snps;
+      for (int b = threadIdx.x; b < rg.B; b += 256) acc += dm[(int64_t)b * rg.n_snps + k] * rg.feat[(int64_t)b * rg.n_snps + k];
+    }
+    acc = block_sum_all(acc, red);
+    if (threadIdx.x == 0) {
       const float p = 1.f / (1.f + expf(-rg.snps[k]));
-      rg.dsnps[k] = g * em_reg_grad(p, rg.l1_x, rg.ent_x, rg.eps) * p * (1.f - p);
+      rg.dsnps[k] = (acc + rg.greg[0] / (float)rg.n_snps * em_reg_grad(p, rg.l1_x, rg.ent_x, rg.eps)) * p * (1.f - p);
     }
     return;
   }
@@ -425,7 +448,7 @@ static int em_bwd_impl(int64_t n_nodes, int64_t n_edges, int rois, int h0, const
                        inv_ne);
   static_assert(2 * MAX_H0 <= 16, "k_edge_mask_bwd_prob: the bias-gradient block has 16 column slots");
   const bool snps_block = rg.greg && rg.snps && rg.dsnps && rg.n_snps > 0;
-  hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)(rois * h0 + 1 + (snps_block ? 1 : 0))), dim3(256), 0, st,
+  hipLaunchKernelGGL(k_edge_mask_bwd_prob, dim3((unsigned)(rois * h0 + 1 + (snps_block ? rg.n_snps : 0))), dim3(256), 0, st,
                      n_nodes / rois, rois, h0, gx, dprob, nblk, part, dprob_bias, prob, rg);
   IGCN_CHECK_LAUNCH("edge_mask_bwd");
   return IGCN_OK;
@@ -451,9 +474,11 @@ extern "C" int igcn_edge_mask_bwd_reg(int64_t n_nodes, int64_t n_edges, int rois
                                       const int32_t* tgt_ptr, const int32_t* tgt_perm, const int32_t* src_ptr,
                                       const int32_t* src_perm, const float* d_reg, const float* snps_logits, int n_snps,
                                       float l1_x, float ent_x, float l1_e, float ent_e, float eps, float* dx, float* dprob,
-                                      float* dprob_bias, float* dsnps, float* scratch, void* stream) {
+                                      float* dprob_bias, float* dsnps, float* scratch, const float* snps_feat,
+                                      int snps_rows, const float* d_snps_full, void* stream) {
   IGCN_REQUIRE(rois > 0 && h0 > 0 && h0 <= MAX_H0 && n_nodes % rois == 0 && d_reg, "edge_mask_bwd_reg: bad arguments");
-  const EmReg rg = {d_reg, snps_logits, dsnps, snps_logits ? n_snps : 0, l1_x, ent_x, l1_e, ent_e, eps};
+  const EmReg rg = {d_reg, snps_logits, dsnps, snps_logits ? n_snps : 0, l1_x, ent_x, l1_e, ent_e, eps, snps_feat, nullptr,
+                    d_snps_full, snps_feat ? snps_rows : 0};
   return em_bwd_impl(n_nodes, n_edges, rois, h0, x, prob, prob_bias, ew, e, d_xm, d_ewm, d_e, d_x_plain, tgt_ptr, tgt_perm,
                      src_ptr, src_perm, dx, dprob, dprob_bias, scratch, rg, (hipStream_t)stream);
 }

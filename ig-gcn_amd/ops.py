@@ -320,7 +320,9 @@ class EdgeMaskStacked(torch.autograd.Function):
     sigmoid(``snps_logits``) — and the backward takes its gradient along: no regulariser launches in the step."""
 
     @staticmethod
-    def forward(ctx, x, prob, prob_bias, ew, plan, rois, snps_logits=None, reg_hp=None):
+    def forward(ctx, x, prob, prob_bias, ew, plan, rois, snps_logits=None, reg_hp=None, snps_feat=None):
+        """``snps_feat`` [B, S] (with ``snps_logits`` and ``reg_hp``): a fifth output, the SNP mask of the stacked sweep
+        cat(snps_feat, snps_feat * sigmoid(snps_logits)) [2B, S] (cal_probability :147-151), from the same launch."""
         x, prob, pb, ew = _f32(x), _f32(prob), _f32(prob_bias), _f32(ew)
         n, h0 = x.shape
         ne = ew.shape[0]
@@ -328,49 +330,61 @@ class EdgeMaskStacked(torch.autograd.Function):
         ew_in = torch.empty(2 * ne, dtype=torch.float32, device=x.device)
         e = torch.empty_like(ew)
         ctx.reg = None
-        snps = None
+        snps = feat = full = None
         if reg_hp is not None:
             snps = _f32(snps_logits).reshape(-1) if snps_logits is not None else None
             ns = snps.numel() if snps is not None else 0
+            rows = 0
+            if snps_feat is not None:
+                feat = _f32(snps_feat)
+                rows = feat.shape[0]
+                if snps is None or feat.dim() != 2 or feat.shape[1] != ns:
+                    raise _lib.IgcnError("EdgeMaskStacked: snps_feat must be [B, S] with S = snps_logits.numel()")
+                full = torch.empty(2 * rows, ns, dtype=torch.float32, device=x.device)
             hp = tuple(float(v) for v in reg_hp)
-            regp = torch.empty(int(_lib.load().igcn_edge_mask_reg_blocks(n, plan.n_edges, h0, ns)), dtype=torch.float32,
-                               device=x.device)
+            regp = torch.empty(int(_lib.load().igcn_edge_mask_reg_blocks(n, plan.n_edges, h0, ns, rows)),
+                               dtype=torch.float32, device=x.device)
             call("igcn_edge_mask_fwd_reg", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew), ptr(plan.src32),
                  ptr(plan.dst32), ptr(x_in[n:]), ptr(e), ptr(ew_in[ne:]), ptr(x_in[:n]), ptr(ew_in[:ne]), ptr(snps), ns, *hp,
-                 ptr(regp), stream_ptr())
-            ctx.reg = (hp, ns, snps_logits.shape if snps_logits is not None else None)
+                 ptr(regp), ptr(feat), rows, ptr(full), stream_ptr())
+            ctx.reg = (hp, ns, snps_logits.shape if snps_logits is not None else None, rows)
         else:
             call("igcn_edge_mask_fwd", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew),
                  ptr(plan.src32), ptr(plan.dst32), ptr(x_in[n:]), ptr(e), ptr(ew_in[ne:]), ptr(x_in[:n]), ptr(ew_in[:ne]),
                  stream_ptr())
-        ctx.save_for_backward(x, prob, pb, ew, e, snps)
+        ctx.save_for_backward(x, prob, pb, ew, e, snps, feat)
         ctx.plan, ctx.rois = plan, rois
         ctx.set_materialize_grads(False)
+        if full is not None:
+            return x_in, ew_in, e, regp, full
         if reg_hp is not None:
             return x_in, ew_in, e, regp
         return x_in, ew_in, e
 
     @staticmethod
-    def backward(ctx, d_x_in, d_ew_in, d_e, d_regp=None):
+    def backward(ctx, d_x_in, d_ew_in, d_e, d_regp=None, d_full=None):
         n, ne = ctx.saved_tensors[0].shape[0], ctx.saved_tensors[3].shape[0]
         d_xm = d_x_in[n:] if d_x_in is not None else None
         d_xp = d_x_in[:n] if d_x_in is not None else None
         d_ewm = d_ew_in[ne:] if d_ew_in is not None else None
-        if ctx.reg is None or d_regp is None:
-            return _edge_mask_backward(ctx, d_xm, d_ewm, d_e, d_xp) + (None, None)
-        x, prob, pb, ew, e, snps = ctx.saved_tensors
-        hp, ns, snps_shape = ctx.reg
+        if ctx.reg is None:
+            return _edge_mask_backward(ctx, d_xm, d_ewm, d_e, d_xp) + (None, None, None)
+        x, prob, pb, ew, e, snps, feat = ctx.saved_tensors
+        hp, ns, snps_shape, rows = ctx.reg
         plan, rois = ctx.plan, ctx.rois
         h0 = x.shape[1]
-        d_xm, d_ewm, d_e, d_xp = (_f32(t) if t is not None else None for t in (d_xm, d_ewm, d_e, d_xp))
-        greg = _f32(d_regp[:1]).reshape(1)                 # the partials' gradient is one scalar, repeated
+        d_xm, d_ewm, d_e, d_xp, d_full = (_f32(t) if t is not None else None for t in (d_xm, d_ewm, d_e, d_xp, d_full))
+        # the partials' gradient is one scalar, repeated (ops.LossHead); none: the regulariser was not used
+        greg = _f32(d_regp[:1]).reshape(1) if d_regp is not None else torch.zeros(1, dtype=torch.float32, device=x.device)
         dx, dprob, dpb = torch.empty_like(x), torch.empty_like(prob), torch.empty_like(pb)
         dsnps = torch.empty(snps_shape, dtype=torch.float32, device=x.device) if snps is not None else None
         scratch = torch.empty(n * h0 + 16 * ((n + 3) // 4) + 16, dtype=torch.float32, device=x.device)
+        use_feat = feat is not None and d_full is not None
         call("igcn_edge_mask_bwd_reg", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew), ptr(e), ptr(d_xm),
              ptr(d_ewm), ptr(d_e), ptr(d_xp), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm),
-             ptr(greg), ptr(snps), ns, *hp, ptr(dx), ptr(dprob), ptr(dpb), ptr(dsnps), ptr(scratch), stream_ptr())
-        return dx, dprob, dpb, None, None, None, dsnps, None
+             ptr(greg), ptr(snps), ns, *hp, ptr(dx), ptr(dprob), ptr(dpb), ptr(dsnps), ptr(scratch),
+             ptr(feat) if use_feat else None, rows if use_feat else 0, ptr(d_full) if use_feat else None, stream_ptr())
+        return dx, dprob, dpb, None, None, None, dsnps, None, None
 
 
 class GcnNorm(torch.autograd.Function):

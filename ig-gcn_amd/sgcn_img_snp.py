@@ -323,11 +323,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             # feed several ops: ops.GradFan hands out aliases and sums their gradients in one launch per tensor
             reg_in_mask = fan and self._reg_hp is not None and os.environ.get("IGCN_NO_MASK_REG_FUSED", "0") != "1"
             if fan and reg_in_mask:
-                # loss_probability rides in the mask launch (ops.EdgeMaskStacked with reg_hp): prob then has two
-                # consumers (mask + regulariser in one op; head inputs), snps_prob two (that op; the SNP mask)
+                # loss_probability AND the SNP mask ride in the mask launch (ops.EdgeMaskStacked with reg_hp /
+                # snps_feat): prob then has two consumers (that op; the head inputs), snps_prob one
                 prob_m, prob_h = ops.GradFan.apply(self.prob, 2)
                 x_m, x_h = ops.GradFan.apply(x, 2)
-                sp_m, sp_r = ops.GradFan.apply(self.snps_prob, 2)
             elif fan:
                 prob_m, prob_h, self._fan_prob = ops.GradFan.apply(self.prob, 3)
                 x_m, x_h = ops.GradFan.apply(x, 2)
@@ -335,12 +334,12 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             else:
                 sp_m = self.snps_prob
             if reg_in_mask:
-                x_in, ew_in, e, regp = ops.EdgeMaskStacked.apply(x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois,
-                                                                 sp_r, self._reg_hp)
+                x_in, ew_in, e, regp, snps_in = ops.EdgeMaskStacked.apply(
+                    x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois, self.snps_prob, self._reg_hp, snps_feat)
                 self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp))
             else:
                 x_in, ew_in, e = ops.EdgeMaskStacked.apply(x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois)
-            snps_in, _ = ops.SnpsMask.apply(snps_feat, sp_m, True)
+                snps_in, _ = ops.SnpsMask.apply(snps_feat, sp_m, True)
             self.last_edge_prob = e
         else:
             if any(explain_flags):

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 311
+#define IGCN_ABI_VERSION 312
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -130,17 +130,23 @@ int igcn_edge_mask_bwd(int64_t n_nodes, int64_t n_edges, int rois, int h0,
  *   backward: d_reg [1] (device) = d loss / d (that sum); its edge part joins d_e inside the node pass, its prob part
  *            dprob, and dsnps [n_snps] receives the SNP logits' part.
  * Same arithmetic as igcn_mask_reg_{fwd,bwd}; two launches less per step. */
-int igcn_edge_mask_reg_blocks(int64_t n_nodes, int64_t n_edges, int h0, int n_snps);
+int igcn_edge_mask_reg_blocks(int64_t n_nodes, int64_t n_edges, int h0, int n_snps, int snps_rows);
+/* snps_feat [snps_rows, n_snps] (or NULL): the launch also writes the SNP mask of the stacked sweep (cal_probability
+ * :147-151), snps_full [2 snps_rows, n_snps] = (snps_feat | snps_feat * sigmoid(snps_logits)); the backward then takes
+ * d_snps_full and adds sum_b d_masked[b,k] snps_feat[b,k] sigmoid'(logit_k) to dsnps — four launches of a train step
+ * (mask, SNP mask, regulariser, and their backward pair) become the mask's two. */
 int igcn_edge_mask_fwd_reg(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x, const float* prob,
                            const float* prob_bias, const float* ew, const int32_t* src32, const int32_t* dst32, float* xm,
                            float* e, float* ewm, float* x_plain, float* ew_plain, const float* snps_logits, int n_snps,
-                           float l1_x, float ent_x, float l1_e, float ent_e, float eps, float* reg_partial, void* stream);
+                           float l1_x, float ent_x, float l1_e, float ent_e, float eps, float* reg_partial,
+                           const float* snps_feat, int snps_rows, float* snps_full, void* stream);
 int igcn_edge_mask_bwd_reg(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float* x, const float* prob,
                            const float* prob_bias, const float* ew, const float* e, const float* d_xm, const float* d_ewm,
                            const float* d_e, const float* d_x_plain, const int32_t* tgt_ptr, const int32_t* tgt_perm,
                            const int32_t* src_ptr, const int32_t* src_perm, const float* d_reg, const float* snps_logits,
                            int n_snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps, float* dx, float* dprob,
-                           float* dprob_bias, float* dsnps, float* scratch, void* stream);
+                           float* dprob_bias, float* dsnps, float* scratch, const float* snps_feat, int snps_rows,
+                           const float* d_snps_full, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GCN normalisation — PyG gcn_norm inside GCNConv (kernel/sgcn_img_snp.py:218,221):

@@ -681,17 +681,27 @@ def test_stacked_masks_carry_the_regulariser(ops, bsz, rois, h0, deg, with_snps)
     l1w, entw = (hp.lamda_x_l1, hp.lamda_e_l1, hp.lamda_x_l1), (hp.lamda_x_ent, hp.lamda_e_ent, hp.lamda_x_ent)
     reg = sum(l1w[i] * pt[0] + entw[i] * pt[1] for i, pt in enumerate(parts))
     total = (torch.cat([ref_in[0], xm]) * cx.double()).sum() + (torch.cat([ew.double(), ewm]) * cw.double()).sum() + reg_w * reg
+    feat, cs = torch.from_numpy(rng.random((bsz, 54))).float(), mk(2 * bsz, 54)
+    masked = feat.double() * torch.sigmoid(ref_in[3])
+    if with_snps:
+        total = total + (torch.cat([feat.double(), masked]) * cs.double()).sum()
     g_ref = torch.autograd.grad(total, ref_in, allow_unused=True)
     dev = [t.cuda().requires_grad_(True) for t in (x, prob, pb, snps)]
     plan = ops.GraphPlan(ei.cuda(), n)
     reg_hp = (hp.lamda_x_l1, hp.lamda_x_ent, hp.lamda_e_l1, hp.lamda_e_ent, 1e-6)
-    x_in, ew_in, e_g, regp = ops.EdgeMaskStacked.apply(dev[0], dev[1], dev[2], ew.cuda(), plan, rois,
-                                                       dev[3] if with_snps else None, reg_hp)
+    extra = 0.0
+    if with_snps:                                            # ... and the SNP mask of the stacked sweep (:147-151)
+        outs = ops.EdgeMaskStacked.apply(dev[0], dev[1], dev[2], ew.cuda(), plan, rois, dev[3], reg_hp, feat.cuda())
+        x_in, ew_in, e_g, regp, full = outs
+        assert_matches(full, torch.cat([feat.double(), masked.detach()]).numpy(), TOL, "snps (plain | masked)")
+        extra = (full * cs.cuda()).sum()
+    else:
+        x_in, ew_in, e_g, regp = ops.EdgeMaskStacked.apply(dev[0], dev[1], dev[2], ew.cuda(), plan, rois, None, reg_hp)
     assert_matches(x_in, torch.cat([x.double(), xm.detach()]).numpy(), TOL, "x_in")
     assert_matches(ew_in, torch.cat([ew.double(), ewm.detach()]).numpy(), TOL, "ew_in")
     assert_matches(e_g, e.detach().numpy(), TOL, "e")
     assert abs(float(regp.sum()) - float(reg)) <= 1e-5 * abs(float(reg))
-    got = torch.autograd.grad((x_in * cx.cuda()).sum() + (ew_in * cw.cuda()).sum() + reg_w * regp.sum(), dev,
+    got = torch.autograd.grad((x_in * cx.cuda()).sum() + (ew_in * cw.cuda()).sum() + reg_w * regp.sum() + extra, dev,
                               allow_unused=True)
     for a, b, nm in zip(got, g_ref, ("dx", "dprob", "dprob_bias", "dsnps")):
         if b is None:
