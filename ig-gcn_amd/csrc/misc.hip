@@ -21,16 +21,26 @@ __global__ void k_adam(int64_t n, float* __restrict__ p, const float* __restrict
   p[i] -= (lr / bc1) * (mi / denom);
 }
 
-extern "C" int igcn_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                              int32_t* step, float lr, float beta1, float beta2, float eps, float grad_scale,
-                              void* stream) {
+static int adam_step_impl(bool tick, int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                          int32_t* step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, step);
+  if (tick) hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, step);
   if (n > 0)
     hipLaunchKernelGGL(k_adam, dim3((unsigned)igcn_cdiv(n, 256)), dim3(256), 0, st, n, param, grad, exp_avg,
                        exp_avg_sq, step, lr, beta1, beta2, eps, grad_scale);
   IGCN_CHECK_LAUNCH("adam_step");
   return IGCN_OK;
+}
+extern "C" int igcn_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                              int32_t* step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                              void* stream) {
+  return adam_step_impl(true, n, param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_scale, stream);
+}
+// *step has been advanced already (igcn_reduce_flush_tick): no counter launch in front
+extern "C" int igcn_adam_step_ticked(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                     int32_t* step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                                     void* stream) {
+  return adam_step_impl(false, n, param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_scale, stream);
 }
 
 // ---- multi-tensor variants: one launch walks a device table of tensors --------------------------------
@@ -82,16 +92,25 @@ k_adam_multi(const int64_t* __restrict__ table, const int64_t* __restrict__ nume
   }
 }
 
-extern "C" int igcn_adam_step_multi(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
-                                    float lr, float beta1, float beta2, float eps, float grad_scale,
-                                    void* stream) {
+static int adam_step_multi_impl(bool tick, int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
+                                float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, step);
+  if (tick) hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, step);
   if (n_tensors > 0)
     hipLaunchKernelGGL(k_adam_multi, dim3(96, n_tensors), dim3(256), 0, st, table, numel, step, lr, beta1, beta2,
                        eps, grad_scale);
   IGCN_CHECK_LAUNCH("adam_step_multi");
   return IGCN_OK;
+}
+extern "C" int igcn_adam_step_multi(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
+                                    float lr, float beta1, float beta2, float eps, float grad_scale,
+                                    void* stream) {
+  return adam_step_multi_impl(true, n_tensors, table, numel, step, lr, beta1, beta2, eps, grad_scale, stream);
+}
+extern "C" int igcn_adam_step_multi_ticked(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
+                                           float lr, float beta1, float beta2, float eps, float grad_scale,
+                                           void* stream) {
+  return adam_step_multi_impl(false, n_tensors, table, numel, step, lr, beta1, beta2, eps, grad_scale, stream);
 }
 
 // dst_flat[off[t] .. off[t]+numel[t]) = grad tensor t (zeros when it has no gradient): packs the gradients

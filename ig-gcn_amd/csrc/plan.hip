@@ -194,8 +194,9 @@ __host__ __device__ inline bool rq_wide_vec(const ReduceEntry& e) {
          (((uintptr_t)e.partial | (uintptr_t)e.out) & 15) == 0;
 }
 
-__global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t) {
+__global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t, int32_t* tick) {
   __shared__ float lds[4][64];
+  if (tick && blockIdx.x == 0 && threadIdx.x == 0) *tick += 1;      // the optimiser's step counter (igcn_reduce_flush_tick)
   // flat grid: workgroup -> (entry, block inside the entry).  [A (max blocks) x (entries) grid launched 57 000
   // workgroups for 11 000 with work.]
   int ei = 0;
@@ -272,7 +273,9 @@ extern "C" int igcn_reduce_pending(void) {
   return (int)g_rq.size();
 }
 
-static int reduce_flush_locked(hipStream_t st) {
+__global__ void k_tick(int32_t* tick) { *tick += 1; }
+
+static int reduce_flush_locked(hipStream_t st, int32_t* tick = nullptr) {
   // the queue is process-wide (one training thread per process: DESIGN §8).  A flush must only ever see entries whose
   // partials were produced on ITS stream — anything else means two backward passes interleaved, and summing another
   // stream's partials here would race with their producers: refuse loudly instead.
@@ -306,9 +309,11 @@ static int reduce_flush_locked(hipStream_t st) {
     }
     t.start[cnt] = (int)total;
     t.count = cnt;
-    hipLaunchKernelGGL(k_multi_reduce, dim3((unsigned)total), dim3(256), 0, st, t);
     done += cnt;
+    hipLaunchKernelGGL(k_multi_reduce, dim3((unsigned)total), dim3(256), 0, st, t, done == g_rq.size() ? tick : nullptr);
+    if (done == g_rq.size()) tick = nullptr;
   }
+  if (tick) hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, st, tick);          // nothing was queued: the tick alone
   g_rq.clear();
   g_rq_stream.clear();
   IGCN_CHECK_LAUNCH("reduce_flush");
@@ -318,6 +323,13 @@ static int reduce_flush_locked(hipStream_t st) {
 extern "C" int igcn_reduce_flush(void* stream) {
   std::lock_guard<std::mutex> lk(g_rq_mutex);
   return reduce_flush_locked((hipStream_t)stream);
+}
+
+// The flush that ends a train step's backward also advances the optimiser's step counter (int32, device) — the one-thread
+// launch in front of igcn_adam_step_multi otherwise; pair with igcn_adam_step*_ticked.
+extern "C" int igcn_reduce_flush_tick(void* stream, int32_t* step_counter) {
+  std::lock_guard<std::mutex> lk(g_rq_mutex);
+  return reduce_flush_locked((hipStream_t)stream, step_counter);
 }
 
 int igcn_launch_reduce_rows_final(const float* partial, int64_t rows, int64_t ld, int n, float* out,

@@ -250,7 +250,7 @@ k_edge_mask_fwd(int64_t n_nodes, int64_t n_edges, int rois, int h0, const float*
   if (REG && rg.feat && i < (int64_t)rg.B * rg.n_snps) {   // SNP mask of the stacked sweep: plain | masked halves
     const float v = rg.feat[i];
     rg.full[i] = v;
-    rg.full[(int64_t)rg.B * rg.n_snps + i] = v / (1.f + expf(-rg.snps[i % rg.n_snps]));
+    rg.full[(int64_t)rg.B * rg.n_snps + i] = v * (1.f / (1.f + __expf(-rg.snps[i % rg.n_snps])));   // = k_snps_mask_fwd, bit for bit
   }
   if (REG) {                                          // loss_probability's three means, one partial per workgroup
     const int64_t np = (int64_t)rois * h0;
@@ -389,8 +389,8 @@ k_edge_mask_bwd_prob(int64_t n_graphs, int rois, int h0, const float* __restrict
     }
     acc = block_sum_all(acc, red);
     if (threadIdx.x == 0) {
-      const float p = 1.f / (1.f + expf(-rg.snps[k]));
-      rg.dsnps[k] = (acc + rg.greg[0] / (float)rg.n_snps * em_reg_grad(p, rg.l1_x, rg.ent_x, rg.eps)) * p * (1.f - p);
+      const float p = 1.f / (1.f + expf(-rg.snps[k])), pm = 1.f / (1.f + __expf(-rg.snps[k]));   // (regulariser's | mask's sigmoid)
+      rg.dsnps[k] = acc * pm * (1.f - pm) + rg.greg[0] / (float)rg.n_snps * em_reg_grad(p, rg.l1_x, rg.ent_x, rg.eps) * p * (1.f - p);
     }
     return;
   }

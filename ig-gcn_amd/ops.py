@@ -31,6 +31,11 @@ class deferred_reductions:
     valid after the block; the partial buffers are kept alive here until then.  Used by train.py around the backward
     of a step (the optimiser runs after the flush); plain ``loss.backward()`` elsewhere reduces immediately."""
 
+    def __init__(self, tick=None):
+        """``tick``: a device int32 counter (the optimiser's step) that the flush launch advances by one on its way —
+        the optimiser then skips its own one-thread counter launch (train.FlatAdam.step(ticked=True))."""
+        self.tick = tick
+
     def __enter__(self):
         if _DEFER["on"]:
             raise _lib.IgcnError("deferred_reductions does not nest")
@@ -44,7 +49,10 @@ class deferred_reductions:
                 _flush_ln_affine()
                 _flush_spmm_dval()
             call("igcn_reduce_defer", 0)
-            call("igcn_reduce_flush", stream_ptr())
+            if self.tick is not None and exc[0] is None:
+                call("igcn_reduce_flush_tick", stream_ptr(), ptr(self.tick))
+            else:
+                call("igcn_reduce_flush", stream_ptr())
         finally:
             _DEFER["on"] = False
             _DEFER["keep"].clear()

@@ -107,15 +107,19 @@ class FlatAdam:
         return self.grad
 
     def step(self, grad_scale=1.0, refresh=True, from_flat=None):
-        """``from_flat``: read gradients from the flat bucket (after an all-reduce); default = flat mode only."""
+        """``from_flat``: read gradients from the flat bucket (after an all-reduce); default = flat mode only.
+        When the backward's flush has advanced ``step_count`` already (``backward_to_grads`` with deferred reductions
+        sets ``_ticked``), the one-thread counter launch in front is skipped."""
         hyper = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(grad_scale))
+        sfx = "_ticked" if getattr(self, "_ticked", False) else ""
+        self._ticked = False
         if self.flat_grads or from_flat:
-            call("igcn_adam_step", self.flat.numel(), ptr(self.flat), ptr(self.grad), ptr(self.exp_avg),
+            call("igcn_adam_step" + sfx, self.flat.numel(), ptr(self.flat), ptr(self.grad), ptr(self.exp_avg),
                  ptr(self.exp_avg_sq), ptr(self.step_count), *hyper, stream_ptr())
             return
         if refresh:
             self.refresh_table()
-        call("igcn_adam_step_multi", len(self.params), ptr(self.table), ptr(self.numel), ptr(self.step_count),
+        call("igcn_adam_step_multi" + sfx, len(self.params), ptr(self.table), ptr(self.numel), ptr(self.step_count),
              *hyper, stream_ptr())
 
 
@@ -236,8 +240,12 @@ def backward_to_grads(loss, optimizer, data=None, defer=False):
         # when the block exits: the gradients below are complete only after it.  Only for the batched sweep, where
         # every parameter enters the graph ONCE — a parameter used twice has its two gradients added by autograd
         # during the backward, i.e. before the flush.
-        with ops.deferred_reductions():
+        # ... and the flush launch advances the optimiser's step counter on its way (one launch less in front of Adam)
+        tick = getattr(optimizer, "step_count", None) if os.environ.get("IGCN_NO_FLUSH_TICK", "0") != "1" else None
+        with ops.deferred_reductions(tick=tick):
             grads = torch.autograd.grad(loss, leaves, grad_outputs=_unit_grad(loss), allow_unused=True)
+        if tick is not None:
+            optimizer._ticked = True
     else:
         grads = torch.autograd.grad(loss, leaves, grad_outputs=_unit_grad(loss), allow_unused=True)
     for t, g in zip(leaves, grads):

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 312
+#define IGCN_ABI_VERSION 313
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -679,6 +679,12 @@ int igcn_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, f
  * the data-parallel all-reduce. */
 int igcn_adam_step_multi(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
                          float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* ..._ticked: `step` has been advanced already — by igcn_reduce_flush_tick, the launch that ends the backward — so
+ * no one-thread counter launch goes in front. */
+int igcn_adam_step_ticked(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t* step,
+                          float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int igcn_adam_step_multi_ticked(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step, float lr,
+                                float beta1, float beta2, float eps, float grad_scale, void* stream);
 int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_t* numel, const int64_t* offset,
                     float* flat, void* stream);
 
@@ -693,6 +699,9 @@ int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_t* numel, c
 int igcn_reduce_defer(int on);
 int igcn_reduce_pending(void);
 int igcn_reduce_flush(void* stream);
+/* the flush + `*step_counter += 1` (device int32: the optimiser's step) by the same launch (a one-thread launch of its
+ * own when nothing is queued) */
+int igcn_reduce_flush_tick(void* stream, int32_t* step_counter);
 
 /* ------------------------------------------------------------------------------------------------
  * Gradient exchange of the data-parallel step (the reference has no multi-GPU code): one RCCL
