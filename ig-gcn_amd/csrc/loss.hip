@@ -108,22 +108,51 @@ extern "C" int igcn_mask_reg_bwd(int64_t n_prob, int64_t n_edge, int64_t n_snps,
 //   dG_ij = gc*Lap_ij/B^2 + go*( 2 G_ij/(G_ii G_jj)  [i != j]  ;  -2 sum_{k != i} G_ik^2/(G_ii^2 G_kk)  [i == j] )/B^2
 // -------------------------------------------------------------------------------------------------
 // `groups` Gram matrices (the passes of a batched sweep) per launch: blockIdx.y = group, one Laplacian for all
+// RBF: the Laplacian is not read but MADE here — W_ij = exp(-gamma ||t_i - t_j||^2) (t NULL: W = 1) evaluated inside
+// the row walk, Lap = diag(W 1) - W written by group 0's workgroups for the backward: the stand-alone k_rbf_laplacian
+// launch in front disappears from the train step.
+template <bool RBF>
 __global__ void __launch_bounds__(256)
 k_gram_loss_fwd(int B, int RD, const float* __restrict__ Gall, const float* __restrict__ Lap,
-                float* __restrict__ partial /*[B, 2 groups]*/) {
+                float* __restrict__ partial /*[B, 2 groups]*/, const float* __restrict__ t, int T, float gamma,
+                float* __restrict__ lap_out) {
   __shared__ float red[16];
   const int i = blockIdx.x, grp = blockIdx.y, groups = gridDim.y;
   const float* G = Gall + (int64_t)grp * B * B;
   const float gii = G[(int64_t)i * B + i];
-  float c = 0.f, o = 0.f;
+  float c = 0.f, o = 0.f, rs = 0.f;
   for (int j = threadIdx.x; j < B; j += 256) {
     const float g = G[(int64_t)i * B + j];
-    c += Lap[(int64_t)i * B + j] * g;
+    if (RBF) {
+      float w = 1.f;
+      if (t) {
+        float d2 = 0.f;
+#pragma unroll 10
+        for (int k = 0; k < T; ++k) {
+          const float d = t[(int64_t)i * T + k] - t[(int64_t)j * T + k];
+          d2 += d * d;
+        }
+        w = expf(-gamma * d2);
+      }
+      rs += w;
+      if (j != i) {
+        c -= w * g;
+        if (grp == 0) lap_out[(int64_t)i * B + j] = -w;
+      }
+    } else {
+      c += Lap[(int64_t)i * B + j] * g;
+    }
     o += g * g / (gii * G[(int64_t)j * B + j]);
   }
   c = block_sum_all(c, red);
   o = block_sum_all(o, red);
+  if (RBF) rs = block_sum_all(rs, red);
   if (threadIdx.x == 0) {
+    if (RBF) {
+      const float dii = rs - 1.f;                               // diag(W 1) - W_ii, W_ii = exp(0)
+      c += dii * gii;
+      if (grp == 0) lap_out[(int64_t)i * B + i] = dii;
+    }
     const float b2 = (float)B * (float)B;
     partial[(int64_t)i * 2 * groups + 2 * grp] = c / b2;
     partial[(int64_t)i * 2 * groups + 2 * grp + 1] = (o - 2.f + (float)RD / (float)B) / b2;   // -2B + RD, spread over rows
@@ -157,8 +186,23 @@ extern "C" int igcn_gram_loss_fwd(int B, int RD, int groups, const float* G /*[g
                                   float* out /*[groups,2] or NULL*/, float* scratch /*[2 B groups]*/, void* stream) {
   IGCN_REQUIRE(B > 0 && groups >= 1 && groups <= 64, "gram_loss_fwd: bad B / groups");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gram_loss_fwd, dim3(B, groups), dim3(256), 0, st, B, RD, G, Lap, scratch);
+  hipLaunchKernelGGL(k_gram_loss_fwd<false>, dim3(B, groups), dim3(256), 0, st, B, RD, G, Lap, scratch, nullptr, 0, 0.f,
+                     nullptr);
   IGCN_CHECK_LAUNCH("gram_loss_fwd");
+  if (out == nullptr) return IGCN_OK;
+  return igcn_launch_reduce_rows(scratch, B, 2 * groups, 2 * groups, out, 0, st);
+}
+
+// The same with the RBF Laplacian of consist_loss (util/image_cluster.py:15-31; tsne [B, T] or NULL: W = 1) built inside:
+// lap_out [B, B] is an OUTPUT (what igcn_gram_loss_bwd reads).
+extern "C" int igcn_gram_loss_fwd_rbf(int B, int RD, int groups, const float* G /*[groups,B,B]*/, const float* tsne, int T,
+                                      float gamma, float* lap_out, float* out /*[groups,2] or NULL*/,
+                                      float* scratch /*[2 B groups]*/, void* stream) {
+  IGCN_REQUIRE(B > 0 && groups >= 1 && groups <= 64 && lap_out && (tsne == nullptr || T > 0), "gram_loss_fwd_rbf: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gram_loss_fwd<true>, dim3(B, groups), dim3(256), 0, st, B, RD, G, nullptr, scratch, tsne, T, gamma,
+                     lap_out);
+  IGCN_CHECK_LAUNCH("gram_loss_fwd_rbf");
   if (out == nullptr) return IGCN_OK;
   return igcn_launch_reduce_rows(scratch, B, 2 * groups, 2 * groups, out, 0, st);
 }

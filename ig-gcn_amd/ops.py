@@ -1718,13 +1718,21 @@ class GramLosses(torch.autograd.Function):
     (sgcn_img_snp.py:183-205).  Returns two tensors of shape [G]."""
 
     @staticmethod
-    def forward(ctx, s, lap, groups=1, packed=False):
+    def forward(ctx, s, lap, groups=1, packed=False, rbf=None):
         """``packed``: return ONE tensor [G,2] = (consist, orth) per group (what igcn_loss_head_* consumes);
         ``packed == "partials"``: the un-reduced row partials [B, G*2] whose column sums are that tensor (LossHead adds
-        them up inside its own kernel: one launch less); every row then receives the gradient of the sum."""
-        s, lap = _f32(s), _f32(lap)
+        them up inside its own kernel: one launch less); every row then receives the gradient of the sum.
+        ``rbf`` = (tsne [B, T] or None, gamma) with ``lap`` None: the Laplacian D - W of consist_loss is built inside the
+        loss kernel (igcn_gram_loss_fwd_rbf) instead of by its own launch in front."""
+        s = _f32(s)
         gb, rd = s.shape
         b = gb // groups
+        tsne = None
+        if lap is None:
+            tsne = _f32(rbf[0]) if rbf[0] is not None else None
+            lap = torch.empty(b, b, dtype=torch.float32, device=s.device)
+        else:
+            lap, rbf = _f32(lap), None
         partials = packed == "partials"
         gram = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
         out = None if partials else torch.empty(groups, 2, dtype=torch.float32, device=s.device)
@@ -1734,7 +1742,11 @@ class GramLosses(torch.autograd.Function):
         gscr = torch.empty(groups * sk * b * b, dtype=torch.float32, device=s.device) if sk > 1 else None
         call("igcn_gemm_f32_batched", b, b, rd, groups, ptr(s), rd, 1, b * rd, ptr(s), rd, 1, b * rd, ptr(gram), b * b, b,
              sk, ptr(gscr), stream_ptr())
-        call("igcn_gram_loss_fwd", b, rd, groups, ptr(gram), ptr(lap), ptr(out), ptr(scratch), stream_ptr())
+        if rbf is not None:
+            call("igcn_gram_loss_fwd_rbf", b, rd, groups, ptr(gram), ptr(tsne), tsne.shape[1] if tsne is not None else 0,
+                 float(rbf[1]), ptr(lap), ptr(out), ptr(scratch), stream_ptr())
+        else:
+            call("igcn_gram_loss_fwd", b, rd, groups, ptr(gram), ptr(lap), ptr(out), ptr(scratch), stream_ptr())
         ctx.save_for_backward(s, lap, gram)
         ctx.groups, ctx.packed = groups, packed
         if partials:
@@ -1762,7 +1774,7 @@ class GramLosses(torch.autograd.Function):
         rd = s.shape[1]
         call("igcn_gemm_f32_batched", b, rd, b, groups, ptr(sym), b, 1, b * b, ptr(s), 1, rd, b * rd, ptr(ds), b * rd, rd,
              1, None, stream_ptr())                                # ds_g = S_g s_g, every group in one launch
-        return ds, None, None, None
+        return ds, None, None, None, None
 
 
 class ProjectedAttention(torch.autograd.Function):

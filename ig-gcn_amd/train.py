@@ -195,10 +195,12 @@ def _losses_batched(model, data, lam, hp, temperature):
     scores, x_hat, out_z, out_lin, lin_f, reg = model._forward_grouped(data, temperature, dev, (False, True),
                                                                        split=False, raw_scores=True)
     from . import ops
-    lap = model.laplacian(scores.shape[0] // 2, data.tsne_fdim)
     # the Gram terms and the mask regulariser arrive as un-reduced partial sums and the class scores raw: the loss
-    # kernel adds the partials up and takes log_softmax itself (two reductions and two torch launches less)
-    gram = ops.GramLosses.apply(out_z, lap, 2, "partials")               # rows sum to [2,2] = (consist, orth) per pass
+    # kernel adds the partials up and takes log_softmax itself (two reductions and two torch launches less); the RBF
+    # Laplacian of consist_loss is built inside the Gram loss kernel (model.laplacian() is a launch of its own)
+    soft = model.isSoftSimilarity and data.tsne_fdim is not None
+    gram = ops.GramLosses.apply(out_z, None, 2, "partials", (data.tsne_fdim if soft else None, model.rbf_gamma))
+    # (rows sum to [2,2] = (consist, orth) per pass)
     prob = model.loss_probability(data.x, data.edge_index, data.edge_attr, hp, edge_prob=model.last_edge_prob,
                                   partials=True)
     lam6 = [float(v) for v in lam]

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 313
+#define IGCN_ABI_VERSION 314
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -539,6 +539,11 @@ int igcn_gram_loss_fwd(int B, int RD, int groups, const float* G, const float* L
                        void* stream);
 int igcn_gram_loss_bwd(int B, int groups, const float* G, const float* Lap, const float* gout, float* S,
                        void* stream);
+/* igcn_gram_loss_fwd with the RBF Laplacian of consist_loss (util/image_cluster.py:15-31; tsne [B, T], or NULL: W = 1)
+ * evaluated inside the row walk instead of read: lap_out [B, B] is an OUTPUT (igcn_gram_loss_bwd reads it) — no
+ * igcn_rbf_laplacian launch in the train step. */
+int igcn_gram_loss_fwd_rbf(int B, int RD, int groups, const float* G, const float* tsne, int T, float gamma, float* lap_out,
+                           float* out, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Cross-attention core of nn.MultiheadAttention (kernel/sgcn_img_snp.py:240) on the projection outputs in place:

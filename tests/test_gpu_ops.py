@@ -728,6 +728,13 @@ def test_gram_losses(ops, bsz, rd, soft):
     assert abs(float(c) - float(c_ref)) <= 1e-4 * max(abs(float(c_ref)), 1e-6)
     assert abs(float(o) - float(o_ref)) <= 1e-4 * max(abs(float(o_ref)), 1e-6)
     assert_matches(g, g_ref.numpy(), 2e-4, "ds")
+    # the train step's form: the Laplacian built INSIDE the loss kernel (igcn_gram_loss_fwd_rbf), no launch in front
+    sg2 = s.cuda().requires_grad_(True)
+    c2, o2 = ops.GramLosses.apply(sg2, None, 1, False, (tsne.cuda() if soft else None, 0.01))
+    g2 = torch.autograd.grad(0.7 * c2[0] + 0.3 * o2[0], sg2)[0]
+    assert abs(float(c2[0]) - float(c_ref)) <= 1e-4 * max(abs(float(c_ref)), 1e-6)
+    assert torch.equal(o2, torch.stack([o]))
+    assert_matches(g2, g_ref.numpy(), 2e-4, "ds (Laplacian built in the kernel)")
 
 
 def test_gram_losses_grouped(ops):
