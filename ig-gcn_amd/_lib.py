@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 314        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 315        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -148,6 +148,7 @@ SIGNATURES = {
     "igcn_comm_destroy": (I, [P]),
     "igcn_loss_head_fwd": (I, [I, I, I, I, P, I, P, P, P, P, P, P, P, I, P, I, P, F, F, P, P, P]),
     "igcn_loss_head_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, F, F, P, P, P, P, P, P, P]),
+    "igcn_loss_head_fwd_grads": (I, [I, I, I, I, P, I, P, P, P, P, P, P, P, I, P, I, P, F, F, P, P, P, P, P, P, P, P]),
     "igcn_gdc_topk_max_rois": (I, []),
     "igcn_gdc_topk": (I, [I, I, I, ctypes.c_double, P, P, P, P, P]),
 }

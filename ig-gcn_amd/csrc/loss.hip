@@ -261,6 +261,10 @@ extern "C" int igcn_rbf_laplacian(int B, int T, float gamma, const float* t, flo
 //   loss = hp_ce*terms[0] + hp_mi*terms[1] + terms[2..6]               (:543)
 // -------------------------------------------------------------------------------------------------
 struct LossHeadW { float lam[6]; float hp_ce, hp_mi; };
+// d loss / d input for an upstream gradient of ONE, written by the forward itself (igcn_loss_head_fwd_grads): every
+// element's gradient is known where its forward term is computed, so a train step (whose d loss / d loss IS one) needs
+// no backward launch for the loss head.  All NULL: plain forward.
+struct LossHeadGrads { float *dlogp, *dreg, *dxhat, *dgram, *dprob; };
 
 //   from_logits: `logp` holds the raw class scores; log_softmax (sgcn_img_snp.py:305) is taken here, row by row, and
 //   written to logp_out [2B, C] (the model output, and what the backward reads).  gram [gram_rows][4] and prob
@@ -271,7 +275,7 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, int
                 const float* __restrict__ reg, const float* __restrict__ clin, const float* __restrict__ x_hat,
                 const float* __restrict__ snps, const float* __restrict__ gram, int gram_rows,
                 const float* __restrict__ prob, int prob_rows,
-                LossHeadW w, float* __restrict__ loss, float* __restrict__ terms) {
+                LossHeadW w, float* __restrict__ loss, float* __restrict__ terms, LossHeadGrads gr) {
   __shared__ float red[9][16];
   const int tid = threadIdx.x;
   float ce = 0.f, mi = 0.f, mse = 0.f, rec = 0.f;
@@ -290,6 +294,12 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, int
       for (int c = 0; c < C; ++c) se += expf(xr[c] - m);
       const float lse = logf(se);
       for (int c = 0; c < C; ++c) logp_out[(int64_t)row * C + c] = (xr[c] - m) - lse;
+      if (gr.dlogp) {                                    // nll o log_softmax: wt / B (softmax - onehot)
+        const float wt = (row < B ? w.hp_ce : w.hp_mi) * w.lam[0];
+        const int64_t yc = y[row < B ? row : row - B];
+        for (int c = 0; c < C; ++c)
+          gr.dlogp[(int64_t)row * C + c] = wt != 0.f ? wt / (float)B * (expf((xr[c] - m) - lse) - (yc == c ? 1.f : 0.f)) : 0.f;
+      }
       if (w.lam[0] != 0.f) {
         const int b = row < B ? row : row - B;
         const int64_t c = y[b];
@@ -315,11 +325,19 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, int
       mi -= logp[(int64_t)(B + b) * C + c];
     }
   }
+  if (gr.dlogp && !from_logits) {                        // log-probabilities given: d nll = -wt / B at the label
+    for (int i = tid; i < 2 * B * C; i += 1024) {
+      const int row = i / C, c = i % C;
+      const float wt = (row < B ? w.hp_ce : w.hp_mi) * w.lam[0];
+      gr.dlogp[i] = (y[row < B ? row : row - B] == c) ? -wt / (float)B : 0.f;
+    }
+  }
   const int nreg = B * NR, nrec = B * S;
 #pragma unroll 4
   for (int i = tid; i < 2 * nreg; i += 1024) {
     const float d = reg[i] - clin[i < nreg ? i : i - nreg];
     mse += d * d;
+    if (gr.dreg) gr.dreg[i] = w.lam[1] * 2.f * d / (float)(2 * nreg);
   }
   // one workgroup walks everything: 16 bytes per lane and the whole walk unrolled, so that it is one batch of loads
   // instead of a chain of dependent trips (the kernel is pure latency)
@@ -331,12 +349,17 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, int
       const float4 s4 = reinterpret_cast<const float4*>(snps)[i < nq ? i : i - nq];
       const float d0 = a.x - s4.x, d1 = a.y - s4.y, d2 = a.z - s4.z, d3 = a.w - s4.w;
       rec += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      if (gr.dxhat) {
+        gr.dxhat[4 * i] = w.lam[3] * d0; gr.dxhat[4 * i + 1] = w.lam[3] * d1;
+        gr.dxhat[4 * i + 2] = w.lam[3] * d2; gr.dxhat[4 * i + 3] = w.lam[3] * d3;
+      }
     }
   } else {
 #pragma unroll 8
     for (int i = tid; i < 2 * nrec; i += 1024) {
       const float d = x_hat[i] - snps[i < nrec ? i : i - nrec];
       rec += d * d;
+      if (gr.dxhat) gr.dxhat[i] = w.lam[3] * d;
     }
   }
   // the four sums through LDS together: two barriers instead of eight
@@ -373,6 +396,10 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, int
     t[6] = w.lam[5] * gs[1];
     for (int k = 0; k < 7; ++k) terms[k] = t[k];
     loss[0] = w.hp_ce * t[0] + w.hp_mi * t[1] + t[2] + t[3] + t[4] + t[5] + t[6];
+    if (gr.dgram) {
+      gr.dgram[0] = w.lam[4] * 0.5f; gr.dgram[1] = w.lam[5]; gr.dgram[2] = w.lam[4] * 0.5f; gr.dgram[3] = 0.f;
+      gr.dprob[0] = w.lam[2];
+    }
   }
 }
 
@@ -432,8 +459,27 @@ extern "C" int igcn_loss_head_fwd(int B, int C, int NR, int S, const float* logp
   IGCN_REQUIRE(!from_logits || logp_out != nullptr, "loss_head_fwd: from_logits needs logp_out");
   hipLaunchKernelGGL(k_loss_head_fwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, C, NR, S, logp, from_logits,
                      logp_out, y, reg, clin, x_hat, snps, gram, gram_rows, prob, prob_rows,
-                     loss_head_w(lam6, hp_ce, hp_mi), loss, terms);
+                     loss_head_w(lam6, hp_ce, hp_mi), loss, terms, LossHeadGrads{});
   IGCN_CHECK_LAUNCH("loss_head_fwd");
+  return IGCN_OK;
+}
+
+// The forward that also writes what igcn_loss_head_bwd would for gout = 1: dlogp [2B,C] (the gradient of the raw scores
+// when from_logits), dreg [2B,NR], dxhat [2B,S], dgram [4], dprob [1].  In a train step d loss / d loss IS one: no
+// backward launch for the loss head.
+extern "C" int igcn_loss_head_fwd_grads(int B, int C, int NR, int S, const float* logp, int from_logits, float* logp_out,
+                                        const int64_t* y, const float* reg, const float* clin, const float* x_hat,
+                                        const float* snps, const float* gram, int gram_rows, const float* prob,
+                                        int prob_rows, const float* lam6 /*HOST [6]*/, float hp_ce, float hp_mi,
+                                        float* loss, float* terms, float* dlogp, float* dreg, float* dxhat, float* dgram,
+                                        float* dprob, void* stream) {
+  IGCN_REQUIRE(B > 0 && C > 0 && NR > 0 && S > 0 && gram_rows >= 1 && prob_rows >= 1, "loss_head_fwd_grads: bad sizes");
+  IGCN_REQUIRE(!from_logits || logp_out != nullptr, "loss_head_fwd_grads: from_logits needs logp_out");
+  IGCN_REQUIRE(dlogp && dreg && dxhat && dgram && dprob, "loss_head_fwd_grads: null gradient output");
+  hipLaunchKernelGGL(k_loss_head_fwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, C, NR, S, logp, from_logits,
+                     logp_out, y, reg, clin, x_hat, snps, gram, gram_rows, prob, prob_rows,
+                     loss_head_w(lam6, hp_ce, hp_mi), loss, terms, LossHeadGrads{dlogp, dreg, dxhat, dgram, dprob});
+  IGCN_CHECK_LAUNCH("loss_head_fwd_grads");
   return IGCN_OK;
 }
 

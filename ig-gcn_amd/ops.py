@@ -23,6 +23,9 @@ def _f32(t):
 # Deferred reductions of a backward pass (igcn_reduce_defer / igcn_reduce_flush)
 # =================================================================================================
 _DEFER = {"on": False, "keep": [], "ln_affine": [], "spmm_dval": []}
+# addresses of the cached "d loss / d loss = 1" scalars of train._unit_grad: ops.LossHead returns the gradients its
+# forward wrote for that upstream instead of launching its backward kernel
+UNIT_GRAD_PTRS = set()
 
 
 class deferred_reductions:
@@ -1854,9 +1857,21 @@ class LossHead(torch.autograd.Function):
         lam6 = (ctypes.c_float * 6)(*[float(v) for v in lam])
         ctx.cfg = (b, c, nr, s, [float(v) for v in lam], float(hp_ce), float(hp_mi))
         ctx.gram_shape, ctx.prob_shape = tuple(gram.shape), tuple(prob.shape)
-        call("igcn_loss_head_fwd", b, c, nr, s, ptr(logp), 1 if from_logits else 0, ptr(logp_out), ptr(y), ptr(reg),
-             ptr(clin), ptr(x_hat), ptr(snps), ptr(gram), gram.numel() // 4, ptr(prob), prob.numel(), lam6,
-             float(hp_ce), float(hp_mi), ptr(loss), ptr(terms), stream_ptr())
+        # when a backward will follow, the forward writes the gradients for an upstream gradient of ONE as it goes — a
+        # train step's d loss / d loss (train._unit_grad, recognised by its address): no backward launch for the loss head
+        ctx.unit = None
+        if any(ctx.needs_input_grad) and UNIT_GRAD_PTRS and os.environ.get("IGCN_NO_LOSS_HEAD_FUSED", "0") != "1":
+            f32 = dict(dtype=torch.float32, device=dev)
+            unit = (torch.empty(2 * b, c, **f32), torch.empty_like(reg), torch.empty_like(x_hat), torch.empty(4, **f32),
+                    torch.empty(1, **f32))
+            call("igcn_loss_head_fwd_grads", b, c, nr, s, ptr(logp), 1 if from_logits else 0, ptr(logp_out), ptr(y),
+                 ptr(reg), ptr(clin), ptr(x_hat), ptr(snps), ptr(gram), gram.numel() // 4, ptr(prob), prob.numel(), lam6,
+                 float(hp_ce), float(hp_mi), ptr(loss), ptr(terms), *[ptr(t) for t in unit], stream_ptr())
+            ctx.unit = unit
+        else:
+            call("igcn_loss_head_fwd", b, c, nr, s, ptr(logp), 1 if from_logits else 0, ptr(logp_out), ptr(y), ptr(reg),
+                 ptr(clin), ptr(x_hat), ptr(snps), ptr(gram), gram.numel() // 4, ptr(prob), prob.numel(), lam6,
+                 float(hp_ce), float(hp_mi), ptr(loss), ptr(terms), stream_ptr())
         ctx.save_for_backward(y, reg, clin, x_hat, snps, logp_out)
         ctx.mark_non_differentiable(terms)
         ctx.set_materialize_grads(False)          # no zero tensor for `terms` in the backward
@@ -1871,13 +1886,16 @@ class LossHead(torch.autograd.Function):
         b, c, nr, s, lam, hp_ce, hp_mi = ctx.cfg
         gout = _f32(gout).reshape(1)
         dev = reg.device
-        dlogp = torch.empty(2 * b, c, dtype=torch.float32, device=dev)
-        dreg, dxhat = torch.empty_like(reg), torch.empty_like(x_hat)
-        dgram = torch.empty(4, dtype=torch.float32, device=dev)
-        dprob = torch.empty(1, dtype=torch.float32, device=dev)
-        lam6 = (ctypes.c_float * 6)(*lam)
-        call("igcn_loss_head_bwd", b, c, nr, s, ptr(y), ptr(reg), ptr(clin), ptr(x_hat), ptr(snps), ptr(logp), lam6,
-             hp_ce, hp_mi, ptr(gout), ptr(dlogp), ptr(dreg), ptr(dxhat), ptr(dgram), ptr(dprob), stream_ptr())
+        if ctx.unit is not None and gout.data_ptr() in UNIT_GRAD_PTRS:
+            dlogp, dreg, dxhat, dgram, dprob = ctx.unit              # written by the forward for exactly this upstream
+        else:
+            dlogp = torch.empty(2 * b, c, dtype=torch.float32, device=dev)
+            dreg, dxhat = torch.empty_like(reg), torch.empty_like(x_hat)
+            dgram = torch.empty(4, dtype=torch.float32, device=dev)
+            dprob = torch.empty(1, dtype=torch.float32, device=dev)
+            lam6 = (ctypes.c_float * 6)(*lam)
+            call("igcn_loss_head_bwd", b, c, nr, s, ptr(y), ptr(reg), ptr(clin), ptr(x_hat), ptr(snps), ptr(logp), lam6,
+                 hp_ce, hp_mi, ptr(gout), ptr(dlogp), ptr(dreg), ptr(dxhat), ptr(dgram), ptr(dprob), stream_ptr())
         # un-reduced partial inputs: every row gets the gradient of the sum (stride-0 views: no launch)
         gs, ps = ctx.gram_shape, ctx.prob_shape
         dgram = dgram.view(2, 2) if gs == (2, 2) else dgram.view(1, 4).expand(gs[0], 4)

@@ -220,6 +220,9 @@ def _unit_grad(loss):
         if loss.is_cuda and torch.cuda.is_current_stream_capturing():
             return None                  # never allocate the cached scalar from a capture's private pool
         _UNIT[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+        if loss.is_cuda and loss.dtype == torch.float32:
+            from . import ops
+            ops.UNIT_GRAD_PTRS.add(_UNIT[key].data_ptr())   # (the tensor lives as long as the process: its address is its identity)
     return _UNIT[key]
 
 

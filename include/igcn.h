@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 314
+#define IGCN_ABI_VERSION 315
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -746,6 +746,14 @@ int igcn_loss_head_bwd(int B, int C, int NR, int S, const int64_t* y, const floa
                        const float* x_hat, const float* snps, const float* logp, const float* lam6, float hp_ce,
                        float hp_mi, const float* gout, float* dlogp, float* dreg, float* dxhat, float* dgram,
                        float* dprob, void* stream);
+/* igcn_loss_head_fwd that also writes the gradients igcn_loss_head_bwd would return for gout = 1 (each element's gradient
+ * is known where its forward term is computed): a train step, whose d loss / d loss is one, then has no backward launch
+ * for the loss head.  dlogp [2B,C] (of the raw scores when from_logits), dreg [2B,NR], dxhat [2B,S], dgram [4], dprob [1]. */
+int igcn_loss_head_fwd_grads(int B, int C, int NR, int S, const float* logp, int from_logits, float* logp_out,
+                             const int64_t* y, const float* reg, const float* clin, const float* x_hat, const float* snps,
+                             const float* gram, int gram_rows, const float* prob, int prob_rows, const float* lam6,
+                             float hp_ce, float hp_mi, float* loss, float* terms, float* dlogp, float* dreg, float* dxhat,
+                             float* dgram, float* dprob, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Graph-diffusion pre-transform + block-diagonal collation of B dense adjacencies A [B,R,R] (f32), on the device —

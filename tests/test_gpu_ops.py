@@ -1276,6 +1276,56 @@ def test_loss_head_from_scores_and_partials():
     assert bool(torch.isfinite(loss0)) and float(bad.grad.abs().max()) == 0.0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("from_logits", [True, False])
+def test_loss_head_forward_writes_the_unit_upstream_gradients(monkeypatch, from_logits):
+    """With the train step's cached d loss / d loss = 1 as the upstream gradient, ops.LossHead returns the gradients its
+    FORWARD wrote (igcn_loss_head_fwd_grads) and launches no backward kernel: the same bits as igcn_loss_head_bwd, and
+    any other upstream (here 1.7, or a fresh ones tensor) still takes the backward kernel."""
+    from igcn_amd import _lib, ops
+    from igcn_amd.train import _unit_grad
+    torch.manual_seed(2)
+    b, c, nr, s = 37, 3, 3, 54
+    dev = "cuda"
+    scores = 3 * torch.randn(2 * b, c, device=dev)
+    if not from_logits:
+        scores = torch.log_softmax(scores, -1)
+    y = torch.randint(0, c, (b,), device=dev)
+    ins = [scores, torch.randn(2 * b, nr, device=dev), torch.randn(2 * b, s, device=dev), torch.rand(b, 4, device=dev),
+           torch.rand(19, device=dev)]
+    clin, snps = torch.rand(b * nr, device=dev), torch.rand(b, s, device=dev)
+    lam, hp_ce, hp_mi = [0.7, 1.0, 0.5, 1.5e-3, 0.1, 0.2], 1.3, 0.8
+
+    def grads(upstream):
+        leaves = [t.clone().requires_grad_(True) for t in ins]
+        out = ops.LossHead.apply(leaves[0], y, leaves[1], clin, leaves[2], snps, leaves[3], leaves[4], lam, hp_ce, hp_mi,
+                                 from_logits)
+        return torch.autograd.grad(out[0], leaves, grad_outputs=upstream)
+
+    unit = _unit_grad(torch.zeros((), device=dev))
+    assert unit.data_ptr() in ops.UNIT_GRAD_PTRS
+    calls = []
+    real = ops.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return real(name, *a)
+    monkeypatch.setattr(ops, "call", spy)
+    fused = grads(unit)
+    assert "igcn_loss_head_fwd_grads" in calls and "igcn_loss_head_bwd" not in calls
+    calls.clear()
+    fresh = grads(torch.ones((), device=dev))                      # same value, another tensor: the backward kernel
+    assert "igcn_loss_head_bwd" in calls
+    scaled = grads(1.7 * torch.ones((), device=dev))
+    monkeypatch.setenv("IGCN_NO_LOSS_HEAD_FUSED", "1")
+    calls.clear()
+    plain = grads(unit)
+    assert "igcn_loss_head_fwd_grads" not in calls and "igcn_loss_head_bwd" in calls
+    for a, f, p_, sc, nm in zip(fused, fresh, plain, scaled, ("dscores", "dreg", "dxhat", "dgram", "dprob")):
+        assert torch.equal(a, f) and torch.equal(a, p_), nm
+        assert_matches(sc, (1.7 * a.double()).cpu().numpy(), 1e-6, nm + " x 1.7")
+
+
 _AB_SCRIPT = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
