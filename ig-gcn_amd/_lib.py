@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 315        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 316        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -118,6 +118,8 @@ SIGNATURES = {
     "igcn_spmm_bwd_scratch_floats": (Z, [I, I, I, I, L]),
     "igcn_spmm_bwd": (I, [I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_spmm_bwd_dval_multi": (I, [I, P, P]),
+    "igcn_spmm_fwd_strided": (I, [I, I, I, I, L, P, P, P, L, P, P, P]),
+    "igcn_spmm_bwd_strided": (I, [I, I, I, I, L, P, P, P, P, P, P, P, L, P, P, P, P, P, P]),
     "igcn_go_attn_fwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "igcn_go_attn_bwd_scratch_floats": (Z, [I, I, I, I]),
     "igcn_go_attn_bwd_threads": (I, [I, I, I]),

@@ -294,29 +294,43 @@ static int spmm_dval_tile(int C, int L, int S) {
 }
 static bool spmm_no_lds(void) { return igcn_opt(IGCN_OPT_SPMM_NO_LDS); }     // the first versions (A/B runs)
 
-extern "C" int igcn_spmm_fwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
-                             const float* val, const float* x, float* y, void* stream) {
-  IGCN_REQUIRE(B > 0 && C > 0 && I > 0 && J > 0, "spmm_fwd: bad sizes");
+// vs = floats between the value rows of consecutive channels (nnz when val is one [C, nnz] tensor; the kernels below
+// take it in the place of `nnz`, which they use for nothing else)
+static int spmm_fwd_impl(int B, int C, int I, int J, int64_t nnz, int64_t vs, const int32_t* row_ptr, const int32_t* col,
+                         const float* val, const float* x, float* y, void* stream) {
+  IGCN_REQUIRE(B > 0 && C > 0 && I > 0 && J > 0 && vs >= nnz, "spmm_fwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   const bool longrows = nnz > (int64_t)8 * I;
   if (!spmm_no_lds() && longrows && spmm_long_lds_bytes(C, J, nnz, 0) <= 150 * 1024) {
     const size_t lds = spmm_long_lds_bytes(C, J, nnz, 0);
     if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS(k_spmm_long_lds);
-    hipLaunchKernelGGL(k_spmm_long_lds, dim3(B), dim3(SPMM_LT), lds, st, C, J, I, nnz, 0, row_ptr, col,
+    hipLaunchKernelGGL(k_spmm_long_lds, dim3(B), dim3(SPMM_LT), lds, st, C, J, I, vs, 0, row_ptr, col,
                        (const int32_t*)nullptr, val, x, y);
   } else if (!spmm_no_lds() && !longrows && J <= 1024) {
     hipLaunchKernelGGL(k_spmm_rows_tiled, dim3((unsigned)igcn_cdiv(I, GO_T), (unsigned)igcn_cdiv(B, SPMM_SB)),
-                       dim3(GO_T), (size_t)SPMM_SB * J * sizeof(float), st, B, C, I, J, nnz, 0, row_ptr, col,
+                       dim3(GO_T), (size_t)SPMM_SB * J * sizeof(float), st, B, C, I, J, vs, 0, row_ptr, col,
                        (const int32_t*)nullptr, val, x, y);
   } else if (longrows) {
     hipLaunchKernelGGL(k_spmm_fwd_wave, dim3((unsigned)igcn_cdiv((int64_t)B * I, GO_T / 64)), dim3(GO_T), 0, st, B, C,
-                       I, J, nnz, row_ptr, col, val, x, y);
+                       I, J, vs, row_ptr, col, val, x, y);
   } else {
-    hipLaunchKernelGGL(k_spmm_fwd, dim3((unsigned)igcn_cdiv(I, GO_T), B), dim3(GO_T), 0, st, C, I, J, nnz, row_ptr, col,
+    hipLaunchKernelGGL(k_spmm_fwd, dim3((unsigned)igcn_cdiv(I, GO_T), B), dim3(GO_T), 0, st, C, I, J, vs, row_ptr, col,
                        val, x, y);
   }
   IGCN_CHECK_LAUNCH("spmm_fwd");
   return IGCN_OK;
+}
+
+extern "C" int igcn_spmm_fwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
+                             const float* val, const float* x, float* y, void* stream) {
+  return spmm_fwd_impl(B, C, I, J, nnz, nnz, row_ptr, col, val, x, y, stream);
+}
+// the C value rows val + c * val_stride need not be one contiguous tensor (per-channel parameters laid out at a
+// constant stride in the optimiser's flat buffer: no torch.stack in front of every step)
+extern "C" int igcn_spmm_fwd_strided(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr,
+                                     const int32_t* col, const float* val, int64_t val_stride, const float* x, float* y,
+                                     void* stream) {
+  return spmm_fwd_impl(B, C, I, J, nnz, val_stride, row_ptr, col, val, x, y, stream);
 }
 
 __global__ void k_spmm_bwd_dx(int C, int I, int J, int64_t nnz, const int32_t* __restrict__ t_ptr,
@@ -393,7 +407,7 @@ extern "C" size_t igcn_spmm_bwd_scratch_floats(int B, int C, int I, int J, int64
   return (size_t)((rows > SPMM_BCH ? rows : SPMM_BCH) * C * (nnz > 0 ? nnz : 1));
 }
 
-extern "C" int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
+static int spmm_bwd_impl(int B, int C, int I, int J, int64_t nnz, int64_t vs, const int32_t* row_ptr, const int32_t* col,
                              const int32_t* row_of, const int32_t* t_ptr, const int32_t* t_row, const int32_t* t_k,
                              const float* val, const float* x, const float* dy, float* dx, float* dval,
                              float* scratch, void* stream) {
@@ -406,17 +420,17 @@ extern "C" int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int3
     const size_t vec_bytes = spmm_long_lds_bytes(C, I, nnz, 1);
     if (!spmm_no_lds() && longcols && vec_bytes <= 150 * 1024) {
       if (vec_bytes > 64 * 1024) IGCN_ALLOW_BIG_LDS(k_spmm_long_lds);
-      hipLaunchKernelGGL(k_spmm_long_lds, dim3(B), dim3(SPMM_LT), vec_bytes, st, C, I, J, nnz, 1, t_ptr, t_row, t_k,
+      hipLaunchKernelGGL(k_spmm_long_lds, dim3(B), dim3(SPMM_LT), vec_bytes, st, C, I, J, vs, 1, t_ptr, t_row, t_k,
                          val, dy, dx);
     } else if (!spmm_no_lds() && !longcols && (int64_t)C * I <= 1024) {
       hipLaunchKernelGGL(k_spmm_rows_tiled, dim3((unsigned)igcn_cdiv(J, GO_T), (unsigned)igcn_cdiv(B, SPMM_SB)),
-                         dim3(GO_T), (size_t)SPMM_SB * C * I * sizeof(float), st, B, C, J, I, nnz, 1, t_ptr, t_row, t_k,
+                         dim3(GO_T), (size_t)SPMM_SB * C * I * sizeof(float), st, B, C, J, I, vs, 1, t_ptr, t_row, t_k,
                          val, dy, dx);
     } else if (longcols) {
       hipLaunchKernelGGL(k_spmm_bwd_dx_wave, dim3((unsigned)igcn_cdiv((int64_t)B * J, GO_T / 64)), dim3(GO_T), 0, st,
-                         B, C, I, J, nnz, t_ptr, t_row, t_k, val, dy, dx);
+                         B, C, I, J, vs, t_ptr, t_row, t_k, val, dy, dx);
     } else {
-      hipLaunchKernelGGL(k_spmm_bwd_dx, dim3((unsigned)igcn_cdiv(J, GO_T), B), dim3(GO_T), 0, st, C, I, J, nnz, t_ptr,
+      hipLaunchKernelGGL(k_spmm_bwd_dx, dim3((unsigned)igcn_cdiv(J, GO_T), B), dim3(GO_T), 0, st, C, I, J, vs, t_ptr,
                          t_row, t_k, val, dy, dx);
     }
   }
@@ -445,6 +459,22 @@ extern "C" int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int3
     return igcn_launch_reduce_rows_final(scratch, bch, (int64_t)C * nnz, (int)((int64_t)C * nnz), dval, st);
   }
   return IGCN_OK;
+}
+
+extern "C" int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
+                             const int32_t* row_of, const int32_t* t_ptr, const int32_t* t_row, const int32_t* t_k,
+                             const float* val, const float* x, const float* dy, float* dx, float* dval,
+                             float* scratch, void* stream) {
+  return spmm_bwd_impl(B, C, I, J, nnz, nnz, row_ptr, col, row_of, t_ptr, t_row, t_k, val, x, dy, dx, dval, scratch, stream);
+}
+// value rows at a constant stride (see igcn_spmm_fwd_strided); dval stays one contiguous [C, nnz] output
+extern "C" int igcn_spmm_bwd_strided(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr,
+                                     const int32_t* col, const int32_t* row_of, const int32_t* t_ptr, const int32_t* t_row,
+                                     const int32_t* t_k, const float* val, int64_t val_stride, const float* x,
+                                     const float* dy, float* dx, float* dval, float* scratch, void* stream) {
+  IGCN_REQUIRE(val_stride >= nnz, "spmm_bwd_strided: val_stride < nnz");
+  return spmm_bwd_impl(B, C, I, J, nnz, val_stride, row_ptr, col, row_of, t_ptr, t_row, t_k, val, x, dy, dx, dval, scratch,
+                       stream);
 }
 
 // table [n <= 2][12] int64 = {B, C, I, J, nnz, col, row_of, x, dy, dval, scratch, 0} per map: the dval half of

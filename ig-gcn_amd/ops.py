@@ -1350,16 +1350,23 @@ class SparseMap(torch.autograd.Function):
         stay autograd leaves of this op, so the value-gradient sums are final and deferrable) or ONE tensor [C, nnz]."""
         x = _f32(x)
         stacked = len(vals) == 1 and vals[0].dim() == 2
+        ctx.vstride = None
         if stacked:
             val = _f32(vals[0])
         elif len(vals) == 1:
             val = _f32(vals[0]).reshape(1, -1)                   # one channel: a view, no launch
         else:
-            val = torch.stack([_f32(v).reshape(-1) for v in vals])
-        b, c = x.shape[0], val.shape[0]
+            vs = SparseMap._row_stride(vals, csr.nnz)
+            if vs is not None and not SparseMap._use_dense(x.shape[0], len(vals), csr):
+                # the channels' vectors sit at a constant stride in one buffer (train.FlatAdam's flat parameters): the
+                # kernels read them where they are — no torch.stack launch in front of every step
+                ctx.vstride, val = vs, vals[0]
+            else:
+                val = torch.stack([_f32(v).reshape(-1) for v in vals])
+        b, c = x.shape[0], (len(vals) if ctx.vstride is not None else val.shape[0])
         ctx.csr, ctx.stacked, ctx.nvals = csr, stacked, len(vals)
         ctx.final = _leaves(*vals)
-        ctx.dense = SparseMap._use_dense(b, c, csr)
+        ctx.dense = ctx.vstride is None and SparseMap._use_dense(b, c, csr)
         if ctx.dense:
             t = csr.dense(c)
             t.index_copy_(1, csr.flat_pos, val)
@@ -1367,17 +1374,35 @@ class SparseMap(torch.autograd.Function):
             ctx.save_for_backward(x, val)
             return y
         y = torch.empty(b, c, csr.n_rows, dtype=torch.float32, device=x.device)
+        if ctx.vstride is not None:
+            call("igcn_spmm_fwd_strided", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col), ptr(val),
+                 ctx.vstride, ptr(x), ptr(y), stream_ptr())
+            ctx.save_for_backward(x, *vals)                        # (every channel's vector stays alive)
+            return y
         call("igcn_spmm_fwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col), ptr(val),
              ptr(x), ptr(y), stream_ptr())
         ctx.save_for_backward(x, val)
         return y
 
     @staticmethod
+    def _row_stride(vals, nnz):
+        """Floats between consecutive channel vectors when they are fp32, contiguous, on one device and equally spaced
+        in memory (stride >= nnz); None otherwise."""
+        v0 = vals[0]
+        if not all(v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and v.numel() == nnz
+                   and v.device == v0.device for v in vals) or os.environ.get("IGCN_SPMM_STACK", "0") == "1":
+            return None
+        d = vals[1].data_ptr() - v0.data_ptr()
+        if d <= 0 or d % 4 or d // 4 < nnz or any(vals[i].data_ptr() - v0.data_ptr() != i * d for i in range(2, len(vals))):
+            return None
+        return d // 4
+
+    @staticmethod
     def backward(ctx, dy):
-        x, val = ctx.saved_tensors
+        x, val = ctx.saved_tensors[0], ctx.saved_tensors[1]
         csr = ctx.csr
         dy = _f32(dy)
-        b, c = x.shape[0], val.shape[0]
+        b, c = x.shape[0], (ctx.nvals if ctx.vstride is not None else val.shape[0])
         need_val = any(ctx.needs_input_grad[2:])
         if ctx.dense:
             dy2 = dy.view(b, c * csr.n_rows)
@@ -1388,15 +1413,20 @@ class SparseMap(torch.autograd.Function):
                 dval = gemm_tn(dy2, x).view(c, csr.n_rows * csr.n_cols).index_select(1, csr.flat_pos)
         else:
             dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-            dval = torch.empty_like(val) if need_val else None
+            dval = torch.empty(c, csr.nnz, dtype=torch.float32, device=x.device) if need_val else None
             scratch = _keep(torch.empty(int(_lib.load().igcn_spmm_bwd_scratch_floats(b, c, csr.n_rows, csr.n_cols,
                                                                                       csr.nnz)),
                                         dtype=torch.float32, device=x.device)) if dval is not None else None
             def bwd(dx_, dval_):
                 with _immediate(ctx.final):
-                    call("igcn_spmm_bwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
-                         ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(x), ptr(dy),
-                         ptr(dx_), ptr(dval_), ptr(scratch), stream_ptr())
+                    if ctx.vstride is not None:
+                        call("igcn_spmm_bwd_strided", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
+                             ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ctx.vstride, ptr(x),
+                             ptr(dy), ptr(dx_), ptr(dval_), ptr(scratch), stream_ptr())
+                    else:
+                        call("igcn_spmm_bwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
+                             ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(x), ptr(dy),
+                             ptr(dx_), ptr(dval_), ptr(scratch), stream_ptr())
             if (dval is not None and _DEFER["on"] and ctx.final and csr.nnz > 0
                     and os.environ.get("IGCN_SPMM_DVAL_NOW", "0") != "1"):
                 # the value gradients are parameter gradients: queued, and launched together with the other map's at

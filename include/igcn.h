@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 315
+#define IGCN_ABI_VERSION 316
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -596,6 +596,15 @@ int igcn_spmm_bwd(int B, int C, int I, int J, int64_t nnz, const int32_t* row_pt
                   const float* val, const float* x, const float* dy,
                   float* dx /*[B,J] or NULL*/, float* dval /*[C,nnz] or NULL*/,
                   float* scratch /* needed when dval != NULL */, void* stream);
+/* The value rows of the C channels at a constant stride instead of one [C, nnz] tensor: val + c * val_stride (floats,
+ * >= nnz) — the per-channel parameter vectors of go_model.py:67 as the optimiser lays them out in its flat buffer, so
+ * that no concatenation runs in front of every step.  dval stays one contiguous [C, nnz] output. */
+int igcn_spmm_fwd_strided(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
+                          const float* val, int64_t val_stride, const float* x, float* y, void* stream);
+int igcn_spmm_bwd_strided(int B, int C, int I, int J, int64_t nnz, const int32_t* row_ptr, const int32_t* col,
+                          const int32_t* row_of, const int32_t* t_ptr, const int32_t* t_row, const int32_t* t_k,
+                          const float* val, int64_t val_stride, const float* x, const float* dy, float* dx, float* dval,
+                          float* scratch, void* stream);
 /* The value-gradient half of igcn_spmm_bwd for one or two maps in ONE launch (call igcn_spmm_bwd with dval = NULL for
  * the input gradients): table [n][12] int64 = {B, C, I, J, nnz, col, row_of, x, dy, dval, scratch, 0} per map. */
 int igcn_spmm_bwd_dval_multi(int n, const int64_t* table, void* stream);

@@ -349,6 +349,45 @@ def test_proj_fwd_streaming_pair(ops, m1, m2):
     assert_matches(y1, (x1.double() @ w1.double().t()).numpy(), TOL, "y1 alone, no bias")
 
 
+def test_sparse_map_reads_channel_vectors_at_a_stride(ops, monkeypatch):
+    """ops.SparseMap with per-channel value vectors that are views at a constant stride of one buffer (how FlatAdam lays
+    the ParameterList of go_model.py:67 out): the kernels read them in place (igcn_spmm_{fwd,bwd}_strided) — same bits
+    as the stacked [C, nnz] tensor, forward and every gradient, and no torch.stack."""
+    monkeypatch.setenv("IGCN_SPARSE_MAPS", "1")
+    a_g, a, pool_dim, idx = _hier((300, 120, 60, 19, 1), 1)
+    agc = a_g.coalesce()
+    gi = agc.indices()
+    csr = ops.Csr(gi[0], gi[1], a.shape[0], 54, "cuda")
+    nnz = csr.nnz
+    stride = (nnz + 15) // 16 * 16
+    rng = np.random.default_rng(0)
+    flat = torch.from_numpy(rng.standard_normal(2 * stride + 7).astype(np.float32)).cuda()
+    x = torch.from_numpy(rng.standard_normal((24, 54)).astype(np.float32)).cuda()
+    cot = torch.from_numpy(rng.standard_normal((24, 2, a.shape[0])).astype(np.float32)).cuda()
+
+    def run(strided):
+        xs = x.clone().requires_grad_(True)
+        if strided:
+            vals = [flat[c * stride:c * stride + nnz].detach().requires_grad_(True) for c in range(2)]
+            # leaves that ALIAS the flat buffer at the stride: what FlatAdam's `p.data = flat[...]` produces
+            assert ops.SparseMap._row_stride(vals, nnz) == stride
+        else:                                                # the stacked form (any two vectors with ascending
+            monkeypatch.setenv("IGCN_SPMM_STACK", "1")       # addresses would otherwise be read in place too)
+            vals = [flat[c * stride:c * stride + nnz].clone().requires_grad_(True) for c in range(2)]
+        y = ops.SparseMap.apply(xs, csr, *vals)
+        return (y,) + torch.autograd.grad((y * cot).sum(), [xs] + vals)
+
+    calls = []
+    real = torch.stack
+    monkeypatch.setattr(torch, "stack", lambda *a_, **k: (calls.append(1), real(*a_, **k))[1])
+    got = run(True)
+    assert not calls
+    want = run(False)
+    assert calls
+    for g, w_, nm in zip(got, want, ("y", "dx", "dval0", "dval1")):
+        assert torch.equal(g, w_), nm
+
+
 def test_gemm_is_exact_fp32_fma_chain(ops):
     """MFMA f32 = k-ordered fmaf chain: small-integer operands must be reproduced exactly."""
     rng = np.random.default_rng(0)
