@@ -27,6 +27,8 @@ struct PjArgs {
   const float *G, *X, *W;
   float *dX, *dWp;
   int blocks;
+  float* dbp;                 // [blocks][N] partials of the bias gradient = column sums of G (or NULL)
+  int db_zero;                // leading columns whose bias gradient is structurally zero (written as exact zeros)
 };
 
 #define PJ_LDS_FLOATS (PJ_ROWS * (64 + 4) + PJ_ROWS * (PJ_K + 4) + 64 * (PJ_K + 4))
@@ -55,6 +57,7 @@ __device__ __forceinline__ void proj_bwd_body(float* lds, const PjArgs& a, int b
   f32x4 dw[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) dw[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbacc = 0.f;                                    // (column tid % N, row slice tid / N) of G over this workgroup's tiles
   const int64_t nblk = (M + PJ_ROWS - 1) / PJ_ROWS;
   for (int64_t blk = bid; blk < nblk; blk += a.blocks) {
     const int64_t r0 = blk * PJ_ROWS;
@@ -82,6 +85,14 @@ __device__ __forceinline__ void proj_bwd_body(float* lds, const PjArgs& a, int b
       *reinterpret_cast<float4*>(&Xs[r][4 * c4]) = xq[k];
     }
     __syncthreads();
+    if (a.dbp) {                                        // bias gradient: thread = (column, 256 / N row slices), its slice
+      constexpr int NP = 256 / N, RP = PJ_ROWS / NP;    // of every tile summed in registers; slices meet after the loop
+      const int col = tid % N, r0 = (tid / N) * RP;
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < RP; ++r) t += Gs[r0 + r][col];
+      dbacc += t;
+    }
     // dX tile, TRANSPOSED accumulator: dX^T[k][row] = sum_n W^T[k][n] G^T[n][row] — lane (g, n) then owns four
     // consecutive columns 4 g .. 4 g + 3 (+ 16 t) of row 16 w + n: one 16-byte store per tile
     f32x4 dx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -112,6 +123,18 @@ __device__ __forceinline__ void proj_bwd_body(float* lds, const PjArgs& a, int b
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[(wr + 4 * g + r) * PJ_K + wc0 + 16 * t + n] = dw[t][r];
+  if (a.dbp) {
+    constexpr int NP = 256 / N;
+    __syncthreads();                                    // the tiles are consumed: LDS is free
+    lds[tid] = dbacc;                                   // [slice][column]
+    __syncthreads();
+    if (tid < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) t += lds[p * N + tid];
+      a.dbp[(int64_t)bid * N + tid] = tid < a.db_zero ? 0.f : t;
+    }
+  }
 }
 
 // One launch for up to two projections (the query block and the key | value block of the packed in-projection): the
@@ -144,11 +167,16 @@ extern "C" int igcn_proj_bwd(int64_t M, int N, int K, const float* G, const floa
   int rc = pj_check(M, N, K, G, X, W, dX, dW, scratch);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const PjArgs a = {M, G, X, W, dX, scratch, igcn_proj_bwd_blocks(M)}, none = {};
+  const PjArgs a = {M, G, X, W, dX, scratch, igcn_proj_bwd_blocks(M), nullptr, 0}, none = {};
   hipLaunchKernelGGL(k_proj_bwd, dim3(a.blocks), dim3(256), 0, st, a, N, none, 0);
   IGCN_CHECK_LAUNCH("proj_bwd");
   return igcn_launch_reduce_rows_final(scratch, a.blocks, (int64_t)N * K, N * K, dW, st);
 }
+
+extern "C" int igcn_proj_bwd_pair_bias(int64_t M1, int N1, const float* G1, const float* X1, const float* W1, float* dX1,
+                                       float* dW1, float* scratch1, float* db1, int db_zero1, int64_t M2, int N2,
+                                       const float* G2, const float* X2, const float* W2, float* dX2, float* dW2,
+                                       float* scratch2, float* db2, int db_zero2, int K, void* stream);
 
 // two projections (different M / N, same K) in one launch
 extern "C" int igcn_proj_bwd_pair(int64_t M1, int N1, const float* G1, const float* X1, const float* W1, float* dX1,
@@ -158,14 +186,32 @@ extern "C" int igcn_proj_bwd_pair(int64_t M1, int N1, const float* G1, const flo
   if (rc) return rc;
   rc = pj_check(M2, N2, K, G2, X2, W2, dX2, dW2, scratch2);
   if (rc) return rc;
+  return igcn_proj_bwd_pair_bias(M1, N1, G1, X1, W1, dX1, dW1, scratch1, nullptr, 0, M2, N2, G2, X2, W2, dX2, dW2, scratch2,
+                                 nullptr, 0, K, stream);
+}
+
+// ... with the BIAS gradients db_i [N_i] = column sums of G_i from the same pass (NULL: not wanted); the first
+// db_zero_i entries are written as exact zeros (the key bias of the attention's key | value projection: a softmax over
+// keys cannot see it).  scratch_i then holds igcn_proj_bwd_blocks(M_i) * N_i * (K + 1) floats; db_i are final reductions.
+extern "C" int igcn_proj_bwd_pair_bias(int64_t M1, int N1, const float* G1, const float* X1, const float* W1, float* dX1,
+                                       float* dW1, float* scratch1, float* db1, int db_zero1, int64_t M2, int N2,
+                                       const float* G2, const float* X2, const float* W2, float* dX2, float* dW2,
+                                       float* scratch2, float* db2, int db_zero2, int K, void* stream) {
+  int rc = pj_check(M1, N1, K, G1, X1, W1, dX1, dW1, scratch1);
+  if (rc) return rc;
+  rc = pj_check(M2, N2, K, G2, X2, W2, dX2, dW2, scratch2);
+  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const PjArgs a = {M1, G1, X1, W1, dX1, scratch1, igcn_proj_bwd_blocks(M1)};
-  const PjArgs b = {M2, G2, X2, W2, dX2, scratch2, igcn_proj_bwd_blocks(M2)};
+  const int nb1 = igcn_proj_bwd_blocks(M1), nb2 = igcn_proj_bwd_blocks(M2);
+  const PjArgs a = {M1, G1, X1, W1, dX1, scratch1, nb1, db1 ? scratch1 + (size_t)nb1 * N1 * K : nullptr, db_zero1};
+  const PjArgs b = {M2, G2, X2, W2, dX2, scratch2, nb2, db2 ? scratch2 + (size_t)nb2 * N2 * K : nullptr, db_zero2};
   hipLaunchKernelGGL(k_proj_bwd, dim3(a.blocks + b.blocks), dim3(256), 0, st, a, N1, b, N2);
   IGCN_CHECK_LAUNCH("proj_bwd_pair");
-  rc = igcn_launch_reduce_rows_final(scratch1, a.blocks, (int64_t)N1 * K, N1 * K, dW1, st);
-  if (rc) return rc;
-  return igcn_launch_reduce_rows_final(scratch2, b.blocks, (int64_t)N2 * K, N2 * K, dW2, st);
+  if ((rc = igcn_launch_reduce_rows_final(scratch1, a.blocks, (int64_t)N1 * K, N1 * K, dW1, st))) return rc;
+  if ((rc = igcn_launch_reduce_rows_final(scratch2, b.blocks, (int64_t)N2 * K, N2 * K, dW2, st))) return rc;
+  if (db1 && (rc = igcn_launch_reduce_rows_final(a.dbp, a.blocks, N1, N1, db1, st))) return rc;
+  if (db2 && (rc = igcn_launch_reduce_rows_final(b.dbp, b.blocks, N2, N2, db2, st))) return rc;
+  return IGCN_OK;
 }
 
 // -------------------------------------------------------------------------------------------------------------

@@ -911,10 +911,31 @@ def _proj_forward(q2, m2, w, bias, d, bf16):
     return gemm_group([("nt", q2, w[:d], None, bias[:d], False), ("nt", m2, w[d:], None, bias[d:], False)], bf16=bf16)
 
 
-def _proj_backward(ctx, dq, dkv, q2, m2, w, dw, d):
-    """The four products behind the packed input projection's backward — input gradients of query and memory, weight
-    gradients of the two blocks (written into ``dw``) — in one launch when all four are wanted."""
+def _proj_fused(ctx, dq, dkv, d):
+    """The one-pass kernels (igcn_proj_bwd_pair*) cover this backward."""
     lib = _lib.load()
+    return bool(ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not ctx.bf16 and dq.is_cuda
+                and os.environ.get("IGCN_NO_PROJ_FUSED", "0") != "1"
+                and lib.igcn_proj_bwd_supported(dq.shape[0], d, d) and lib.igcn_proj_bwd_supported(dkv.shape[0], 2 * d, d))
+
+
+def _proj_backward(ctx, dq, dkv, q2, m2, w, dw, d, db=None):
+    """The four products behind the packed input projection's backward — input gradients of query and memory, weight
+    gradients of the two blocks (written into ``dw``) — in one launch when all four are wanted.  ``db`` [3d] (only with
+    ``_proj_fused``): the bias gradients from the same pass — column sums of dq, exact zeros for the key bias (a
+    softmax over keys cannot see it), column sums of the value gradient (= sum of the attention's incoming gradient:
+    every query's weights sum to one; the reference's autograd takes this very sum)."""
+    lib = _lib.load()
+    if db is not None:
+        dquery, dmem = torch.empty_like(q2), torch.empty_like(m2)
+        f32 = dict(dtype=torch.float32, device=dq.device)
+        s1 = _keep(torch.empty(int(lib.igcn_proj_bwd_blocks(dq.shape[0])) * d * (d + 1), **f32))
+        s2 = _keep(torch.empty(int(lib.igcn_proj_bwd_blocks(dkv.shape[0])) * 2 * d * (d + 1), **f32))
+        with _immediate(ctx.final):
+            call("igcn_proj_bwd_pair_bias", dq.shape[0], d, ptr(dq), ptr(q2), ptr(w[:d]), ptr(dquery), ptr(dw[:d]), ptr(s1),
+                 ptr(db[:d]), 0, dkv.shape[0], 2 * d, ptr(dkv), ptr(m2), ptr(w[d:]), ptr(dmem), ptr(dw[d:]), ptr(s2),
+                 ptr(db[d:]), d, d, stream_ptr())
+        return dquery.view(ctx.shapes[0]), dmem.view(ctx.shapes[1])
     if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not ctx.bf16 and dq.is_cuda
             and os.environ.get("IGCN_NO_PROJ_FUSED", "0") != "1"
             and lib.igcn_proj_bwd_supported(dq.shape[0], d, d) and lib.igcn_proj_bwd_supported(dkv.shape[0], 2 * d, d)):
@@ -1856,6 +1877,9 @@ class ProjectedAttention(torch.autograd.Function):
         rows = dq2.shape[0]
         scr = _keep(torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, 2 * d)), dtype=torch.float32, device=w.device))
         scr2 = _keep(torch.empty(int(lib.igcn_bias_grad_scratch_floats(rows, d)), dtype=torch.float32, device=w.device))
+        if _proj_fused(ctx, dq2, dkv2, d) and os.environ.get("IGCN_NO_PROJ_BIAS_FUSED", "0") != "1":
+            dquery, dmem = _proj_backward(ctx, dq2, dkv2, q2, m2, w, dw, d, db)      # bias gradients ride in the pass
+            return dquery, dmem, dw, db, None, None
         with _immediate(ctx.final):                                 # d b_q (then d b_k = 0) and d b_v in one launch
             call("igcn_bias_grad_pair", rows, d, ptr(dq2), None, None, ptr(db), d, ptr(scr),
                  ptr(dout.reshape(-1, d)), None, None, ptr(db[2 * d:]), 0, ptr(scr2), stream_ptr())

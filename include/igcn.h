@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 316
+#define IGCN_ABI_VERSION 317
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -245,6 +245,13 @@ int igcn_proj_bwd(int64_t M, int N, int K, const float* G, const float* X, const
 int igcn_proj_bwd_pair(int64_t M1, int N1, const float* G1, const float* X1, const float* W1, float* dX1, float* dW1,
                        float* scratch1, int64_t M2, int N2, const float* G2, const float* X2, const float* W2,
                        float* dX2, float* dW2, float* scratch2, int K, void* stream);
+/* ... with the bias gradients db_i [N_i] = column sums of G_i from the same pass (NULL: not wanted); the first db_zero_i
+ * entries are written as exact zeros (the attention's key bias).  scratch_i: igcn_proj_bwd_blocks(M_i) * N_i * (K + 1)
+ * floats; db_i are final reductions like dW_i. */
+int igcn_proj_bwd_pair_bias(int64_t M1, int N1, const float* G1, const float* X1, const float* W1, float* dX1, float* dW1,
+                            float* scratch1, float* db1, int db_zero1, int64_t M2, int N2, const float* G2,
+                            const float* X2, const float* W2, float* dX2, float* dW2, float* scratch2, float* db2,
+                            int db_zero2, int K, void* stream);
 /* Forward of the same projections, y = x W^T + b (bias [N] or NULL), as ONE streaming launch for up to two of them
  * (M2 = 0: the first alone): W and b resident in LDS, x read once, y written in contiguous runs — the in-projection's
  * reduction depth is 32, so the general tiled GEMM's K loop and per-column-tile re-reads of x only cost.  Same shape
