@@ -22,6 +22,15 @@ extern "C" int igcn_proj_bwd_blocks(int64_t M) {
   return (int)(nb < 512 ? nb : 512);          // every workgroup leaves an N x K partial for the final reduction (1024 / 512 / 320 workgroups: kernel 27.6 / 29.1 / 38.3 us, reduction 28.4 / 20.8 / 17.1)
 }
 
+// Row stride of a workgroup's dW partial.  [Padding the 4 / 8 KB rows by 192 bytes, against a suspected channel-conflict
+// pattern in the final reduction's 16-column strips, changed nothing: k_multi_reduce 36.7 us either way.]
+#define PJ_PAD 0
+__host__ __device__ static inline int64_t pj_ps(int N) { return (int64_t)N * PJ_K + PJ_PAD; }
+// scratch floats of one projection: igcn_proj_bwd_blocks(M) partial rows of dW (padded) and, behind them, of db
+extern "C" size_t igcn_proj_bwd_scratch_floats(int64_t M, int N) {
+  return (size_t)igcn_proj_bwd_blocks(M) * (size_t)(pj_ps(N) + N) + 16;
+}
+
 struct PjArgs {
   int64_t M;
   const float *G, *X, *W;
@@ -118,7 +127,7 @@ __device__ __forceinline__ void proj_bwd_body(float* lds, const PjArgs& a, int b
     }
   }
   // the workgroup's partial of dW [N, 32]: accumulator lane (g, n), register r = (row wr + 4 g + r, column wc0 + 16 t + n)
-  float* out = dW_partial + (int64_t)bid * N * PJ_K;
+  float* out = dW_partial + (int64_t)bid * pj_ps(N);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -161,7 +170,7 @@ static int pj_check(int64_t M, int N, int K, const float* G, const float* X, con
   return IGCN_OK;
 }
 
-// scratch: igcn_proj_bwd_blocks(M) * N * K floats.  dW is a FINAL reduction (igcn_reduce_defer).
+// scratch: igcn_proj_bwd_scratch_floats(M, N) floats.  dW is a FINAL reduction (igcn_reduce_defer).
 extern "C" int igcn_proj_bwd(int64_t M, int N, int K, const float* G, const float* X, const float* W, float* dX,
                              float* dW, float* scratch, void* stream) {
   int rc = pj_check(M, N, K, G, X, W, dX, dW, scratch);
@@ -170,7 +179,7 @@ extern "C" int igcn_proj_bwd(int64_t M, int N, int K, const float* G, const floa
   const PjArgs a = {M, G, X, W, dX, scratch, igcn_proj_bwd_blocks(M), nullptr, 0}, none = {};
   hipLaunchKernelGGL(k_proj_bwd, dim3(a.blocks), dim3(256), 0, st, a, N, none, 0);
   IGCN_CHECK_LAUNCH("proj_bwd");
-  return igcn_launch_reduce_rows_final(scratch, a.blocks, (int64_t)N * K, N * K, dW, st);
+  return igcn_launch_reduce_rows_final(scratch, a.blocks, pj_ps(N), N * K, dW, st);
 }
 
 extern "C" int igcn_proj_bwd_pair_bias(int64_t M1, int N1, const float* G1, const float* X1, const float* W1, float* dX1,
@@ -192,7 +201,7 @@ extern "C" int igcn_proj_bwd_pair(int64_t M1, int N1, const float* G1, const flo
 
 // ... with the BIAS gradients db_i [N_i] = column sums of G_i from the same pass (NULL: not wanted); the first
 // db_zero_i entries are written as exact zeros (the key bias of the attention's key | value projection: a softmax over
-// keys cannot see it).  scratch_i then holds igcn_proj_bwd_blocks(M_i) * N_i * (K + 1) floats; db_i are final reductions.
+// keys cannot see it).  scratch_i: igcn_proj_bwd_scratch_floats(M_i, N_i) floats; db_i are final reductions.
 extern "C" int igcn_proj_bwd_pair_bias(int64_t M1, int N1, const float* G1, const float* X1, const float* W1, float* dX1,
                                        float* dW1, float* scratch1, float* db1, int db_zero1, int64_t M2, int N2,
                                        const float* G2, const float* X2, const float* W2, float* dX2, float* dW2,
@@ -203,12 +212,12 @@ extern "C" int igcn_proj_bwd_pair_bias(int64_t M1, int N1, const float* G1, cons
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int nb1 = igcn_proj_bwd_blocks(M1), nb2 = igcn_proj_bwd_blocks(M2);
-  const PjArgs a = {M1, G1, X1, W1, dX1, scratch1, nb1, db1 ? scratch1 + (size_t)nb1 * N1 * K : nullptr, db_zero1};
-  const PjArgs b = {M2, G2, X2, W2, dX2, scratch2, nb2, db2 ? scratch2 + (size_t)nb2 * N2 * K : nullptr, db_zero2};
+  const PjArgs a = {M1, G1, X1, W1, dX1, scratch1, nb1, db1 ? scratch1 + (size_t)nb1 * pj_ps(N1) : nullptr, db_zero1};
+  const PjArgs b = {M2, G2, X2, W2, dX2, scratch2, nb2, db2 ? scratch2 + (size_t)nb2 * pj_ps(N2) : nullptr, db_zero2};
   hipLaunchKernelGGL(k_proj_bwd, dim3(a.blocks + b.blocks), dim3(256), 0, st, a, N1, b, N2);
   IGCN_CHECK_LAUNCH("proj_bwd_pair");
-  if ((rc = igcn_launch_reduce_rows_final(scratch1, a.blocks, (int64_t)N1 * K, N1 * K, dW1, st))) return rc;
-  if ((rc = igcn_launch_reduce_rows_final(scratch2, b.blocks, (int64_t)N2 * K, N2 * K, dW2, st))) return rc;
+  if ((rc = igcn_launch_reduce_rows_final(scratch1, a.blocks, pj_ps(N1), N1 * K, dW1, st))) return rc;
+  if ((rc = igcn_launch_reduce_rows_final(scratch2, b.blocks, pj_ps(N2), N2 * K, dW2, st))) return rc;
   if (db1 && (rc = igcn_launch_reduce_rows_final(a.dbp, a.blocks, N1, N1, db1, st))) return rc;
   if (db2 && (rc = igcn_launch_reduce_rows_final(b.dbp, b.blocks, N2, N2, db2, st))) return rc;
   return IGCN_OK;

@@ -929,8 +929,8 @@ def _proj_backward(ctx, dq, dkv, q2, m2, w, dw, d, db=None):
     if db is not None:
         dquery, dmem = torch.empty_like(q2), torch.empty_like(m2)
         f32 = dict(dtype=torch.float32, device=dq.device)
-        s1 = _keep(torch.empty(int(lib.igcn_proj_bwd_blocks(dq.shape[0])) * d * (d + 1), **f32))
-        s2 = _keep(torch.empty(int(lib.igcn_proj_bwd_blocks(dkv.shape[0])) * 2 * d * (d + 1), **f32))
+        s1 = _keep(torch.empty(int(lib.igcn_proj_bwd_scratch_floats(dq.shape[0], d)), **f32))
+        s2 = _keep(torch.empty(int(lib.igcn_proj_bwd_scratch_floats(dkv.shape[0], 2 * d)), **f32))
         with _immediate(ctx.final):
             call("igcn_proj_bwd_pair_bias", dq.shape[0], d, ptr(dq), ptr(q2), ptr(w[:d]), ptr(dquery), ptr(dw[:d]), ptr(s1),
                  ptr(db[:d]), 0, dkv.shape[0], 2 * d, ptr(dkv), ptr(m2), ptr(w[d:]), ptr(dmem), ptr(dw[d:]), ptr(s2),
@@ -943,8 +943,8 @@ def _proj_backward(ctx, dq, dkv, q2, m2, w, dw, d, db=None):
         # key | value gradient (52 MB at the bench shape) is read once, not twice
         dquery, dmem = torch.empty_like(q2), torch.empty_like(m2)
         f32 = dict(dtype=torch.float32, device=dq.device)
-        s1 = _keep(torch.empty(int(lib.igcn_proj_bwd_blocks(dq.shape[0])) * d * d, **f32))
-        s2 = _keep(torch.empty(int(lib.igcn_proj_bwd_blocks(dkv.shape[0])) * 2 * d * d, **f32))
+        s1 = _keep(torch.empty(int(lib.igcn_proj_bwd_scratch_floats(dq.shape[0], d)), **f32))
+        s2 = _keep(torch.empty(int(lib.igcn_proj_bwd_scratch_floats(dkv.shape[0], 2 * d)), **f32))
         with _immediate(ctx.final):                 # both blocks in one launch: the small one rides along
             call("igcn_proj_bwd_pair", dq.shape[0], d, ptr(dq), ptr(q2), ptr(w[:d]), ptr(dquery), ptr(dw[:d]), ptr(s1),
                  dkv.shape[0], 2 * d, ptr(dkv), ptr(m2), ptr(w[d:]), ptr(dmem), ptr(dw[d:]), ptr(s2), d, stream_ptr())

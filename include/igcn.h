@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 317
+#define IGCN_ABI_VERSION 318
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -235,10 +235,11 @@ int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H0, int F, i
  * Backward of a bias-free projection y = x W^T (x [M, K], W [N, K]) in ONE pass over the gradient G = dL/dy [M, N]:
  * dX [M, K] = G W and dW [N, K] = G^T X — the packed input projection of nn.MultiheadAttention
  * (kernel/sgcn_img_snp.py:240-241), whose key | value gradient is a 52 MB tensor that two separate GEMMs read twice.
- * K == 32, N in {32, 64} (igcn_proj_bwd_supported); scratch: igcn_proj_bwd_blocks(M) * N * K floats; dW is a final
+ * K == 32, N in {32, 64} (igcn_proj_bwd_supported); scratch: igcn_proj_bwd_scratch_floats(M, N) floats; dW is a final
  * reduction in the sense of igcn_reduce_defer. */
 int igcn_proj_bwd_supported(int64_t M, int N, int K);
 int igcn_proj_bwd_blocks(int64_t M);
+size_t igcn_proj_bwd_scratch_floats(int64_t M, int N);   /* per projection, for every igcn_proj_bwd* entry point */
 int igcn_proj_bwd(int64_t M, int N, int K, const float* G, const float* X, const float* W, float* dX, float* dW,
                   float* scratch, void* stream);
 /* two projections with the same K in ONE launch (the query block and the key | value block of the packed in-projection) */
@@ -246,7 +247,7 @@ int igcn_proj_bwd_pair(int64_t M1, int N1, const float* G1, const float* X1, con
                        float* scratch1, int64_t M2, int N2, const float* G2, const float* X2, const float* W2,
                        float* dX2, float* dW2, float* scratch2, int K, void* stream);
 /* ... with the bias gradients db_i [N_i] = column sums of G_i from the same pass (NULL: not wanted); the first db_zero_i
- * entries are written as exact zeros (the attention's key bias).  scratch_i: igcn_proj_bwd_blocks(M_i) * N_i * (K + 1)
+ * entries are written as exact zeros (the attention's key bias).  scratch_i: igcn_proj_bwd_scratch_floats(M_i, N_i)
  * floats; db_i are final reductions like dW_i. */
 int igcn_proj_bwd_pair_bias(int64_t M1, int N1, const float* G1, const float* X1, const float* W1, float* dX1, float* dW1,
                             float* scratch1, float* db1, int db_zero1, int64_t M2, int N2, const float* G2,

@@ -312,7 +312,7 @@ def test_proj_bwd_one_pass(ops, m, n):
     gd, xd, wd = g.cuda(), x.cuda(), w.cuda()
     dx = torch.empty(m, 32, device="cuda")
     dw = torch.empty(n, 32, device="cuda")
-    scr = torch.empty(int(lib.igcn_proj_bwd_blocks(m)) * n * 32, device="cuda")
+    scr = torch.empty(int(lib.igcn_proj_bwd_scratch_floats(m, n)), device="cuda")
     call("igcn_proj_bwd", m, n, 32, ptr(gd), ptr(xd), ptr(wd), ptr(dx), ptr(dw), ptr(scr), stream_ptr())
     assert_matches(dx, (g.double() @ w.double()).numpy(), TOL, "dX")
     assert_matches(dw, (g.double().t() @ x.double()).numpy(), TOL, "dW")
