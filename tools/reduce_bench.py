@@ -17,10 +17,13 @@ from igcn_amd import _lib  # noqa: E402
 # (rows, n) of the default workload's queue, in queue order of one backward pass (bench.py --workload full)
 SHAPES = [(8, 64), (32, 195), (512, 32), (40, 2400), (800, 160), (512, 64), (512, 50), (512, 336), (512, 2048),
           (512, 20), (512, 1024), (448, 5), (40, 6000), (3008, 2), (240, 1024), (2, 800), (2, 6000), (16, 800),
-          (16, 6000), (16, 12800), (16, 1024), (128, 8067), (128, 16134), (8, 64), (32, 195), (512, 32), (40, 2400)]
+          (16, 6000), (16, 12800), (16, 1024), (128, 8067), (128, 16134), (4, 203648), (4, 186368), (4, 64), (4, 64),
+          (512, 32), (512, 64), (8, 64), (32, 195), (512, 32), (40, 2400)]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 COLD = len(sys.argv) > 2 and sys.argv[2] == "cold"
 junk = torch.zeros(256 << 20, device="cuda") if COLD else None
+if os.environ.get("REDUCE_BENCH_LIB"):              # A/B of two builds inside ONE gpurun call (boxes differ by 40 %)
+    _lib.LIB_PATH = os.environ["REDUCE_BENCH_LIB"]
 lib = _lib.load()
 fn = lib.igcn_debug_reduce_rows_final
 fn.restype = ctypes.c_int
@@ -32,7 +35,7 @@ st = torch.cuda.current_stream().cuda_stream
 def flush(skip=None):
     lib.igcn_reduce_defer(1)
     for i, ((p, o), (r, n)) in enumerate(zip(bufs, SHAPES)):
-        if i != skip:
+        if i != skip and (skip is None or not isinstance(skip, set) or i not in skip):
             assert fn(p.data_ptr(), r, n, n, o.data_ptr(), st) == 0
     assert lib.igcn_reduce_flush(st) == 0
     lib.igcn_reduce_defer(0)
@@ -53,18 +56,15 @@ def timed(skip=None):
     for _ in range(3):
         g.replay()
     torch.cuda.synchronize()
-    ts = []
-    for _ in range(iters):
-        if COLD:
-            junk.add_(1.0)                      # 1 GB through the caches: the partials come from HBM, as in the step
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if COLD:
+        junk.add_(1.0)
+    e0.record()
+    for _ in range(iters):                      # back to back: launch latency overlaps the previous replay
         g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) * 1e3)
-    ts.sort()
-    return ts[len(ts) // 2]
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
 
 
 flush()
@@ -73,6 +73,9 @@ for (p, o), (r, n) in zip(bufs, SHAPES):
     assert torch.allclose(o, p.sum(0), rtol=1e-4, atol=1e-3), (r, n)
 whole = timed()
 print(f"whole queue ({len(SHAPES)} entries, {sum(r * n for r, n in SHAPES) * 4 / 1e6:.1f} MB): {whole:7.1f} us", flush=True)
-for i, (r, n) in enumerate(SHAPES[:23]):
+for keep in (1, 5, 10, 15, 20, 25, 30):
+    t = timed(set(range(keep, len(SHAPES))))
+    print(f"  first {keep:2d} entries only: {t:7.1f} us", flush=True)
+for i, (r, n) in enumerate(SHAPES[:29]):
     t = timed(i)
     print(f"  without {r:5d} x {n:6d}: {t:7.1f} us  ({whole - t:+6.1f})", flush=True)
