@@ -981,6 +981,101 @@ __device__ __forceinline__ void go_butterfly(float (&acc)[F], int lane) {
   }
 }
 
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ---- LayerNorm-over-nodes backward folded into its consumer's copy-in -------------------------------------------
+// The gradient a GO layer's backward receives is the LayerNorm's input gradient (go_model.py:246-251: y = layer(x),
+// x' = dropout(relu(LN(y)))).  The LDS-resident backward kernels hold ONE sample — all FOUT rows of its N nodes — so
+// they can form that gradient themselves from (y, dz, gamma, beta, keep, mean, rstd) while they copy it into LDS: the
+// LayerNorm's own dX launch (one workgroup per (sample, channel) row: 12.8 us x 4 in the default step), the 15 MB it
+// writes and the 15 MB read back disappear, and since a workgroup sees all channels of a sample it also leaves the
+// affine gradients summed over them — part [B][2][N] (d gamma | d beta rows), reduced over samples by the deferred
+// final reduction instead of k_nodes_ln_bwd_affine_multi's second pass over y and dz.  Arithmetic per element as
+// k_nodes_ln_bwd_dy_v / ln_bwd_affine_v_body.  Preconditions (igcn_go_ln_fused_ok): N, pool multiples of 4, N / 4 <= T,
+// 16-byte aligned tensors.
+struct LnFuse {
+  const float *y, *dz, *gamma, *beta, *keep, *mean, *rstd;
+  float* part;
+  int pool;
+};
+
+// dys [FOUT][N] (LDS) = d loss / d y of sample b; red: >= (T / 64) * 2 * FOUT floats of LDS nobody else uses yet.
+// Every thread of the workgroup must call (barrier inside); the caller's next barrier publishes dys.
+template <int FOUT, int T>
+__device__ __forceinline__ void ln_bwd_into_lds(const LnFuse& L, int b, int N, float* __restrict__ dys,
+                                                float* __restrict__ red) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = 4 * tid, M = N - L.pool;
+  const bool live = n < N, act = live && n >= L.pool;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 yv[FOUT], up[FOUT];
+  float mu[FOUT], rs[FOUT];
+  float4 g = zero4, be = zero4, kp = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c) {                      // every load of the phase in flight at once
+    const int64_t row = (int64_t)b * FOUT + c;
+    mu[c] = L.mean[row];
+    rs[c] = L.rstd[row];
+    yv[c] = live ? ld4(L.y + row * N + n) : zero4;
+    up[c] = act ? ld4(L.dz + row * M + (n - L.pool)) : zero4;
+  }
+  if (live) g = ld4(L.gamma + n);
+  if (act) {
+    be = ld4(L.beta + n);
+    if (L.keep) kp = ld4(L.keep + (int64_t)b * N + n);
+  }
+  float s[2 * FOUT];
+  float4 dg = zero4, db = zero4;
+#pragma unroll
+  for (int c = 0; c < FOUT; ++c) {
+    float4 xh = zero4, dx = zero4;
+    if (live) xh = make_float4((yv[c].x - mu[c]) * rs[c], (yv[c].y - mu[c]) * rs[c], (yv[c].z - mu[c]) * rs[c],
+                               (yv[c].w - mu[c]) * rs[c]);
+    if (act) {
+      float4 u = up[c];
+      u.x *= kp.x; u.y *= kp.y; u.z *= kp.z; u.w *= kp.w;
+      u.x = xh.x * g.x + be.x > 0.f ? u.x : 0.f;
+      u.y = xh.y * g.y + be.y > 0.f ? u.y : 0.f;
+      u.z = xh.z * g.z + be.z > 0.f ? u.z : 0.f;
+      u.w = xh.w * g.w + be.w > 0.f ? u.w : 0.f;
+      dx = make_float4(u.x * g.x, u.y * g.y, u.z * g.z, u.w * g.w);
+      dg.x += u.x * xh.x; dg.y += u.y * xh.y; dg.z += u.z * xh.z; dg.w += u.w * xh.w;
+      db.x += u.x; db.y += u.y; db.z += u.z; db.w += u.w;
+    }
+    s[c] = (dx.x + dx.y) + (dx.z + dx.w);
+    s[FOUT + c] = (dx.x * xh.x + dx.y * xh.y) + (dx.z * xh.z + dx.w * xh.w);
+    yv[c] = xh;                                         // the registers now hold xhat and the masked, scaled upstream
+    up[c] = dx;
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * FOUT; ++i) {
+    const float t = wave_sum(s[i]);
+    if (lane == 0) red[w * 2 * FOUT + i] = t;
+  }
+  if (live) {                                           // per-sample affine partials (zero rows for the pooled nodes)
+    float* pr = L.part + (int64_t)b * 2 * N + n;
+    *reinterpret_cast<float4*>(pr) = dg;
+    *reinterpret_cast<float4*>(pr + N) = db;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2 * FOUT; ++i) s[i] = 0.f;
+  for (int ww = 0; ww < T / 64; ++ww)                   // wave totals in wave order (broadcast reads)
+#pragma unroll
+    for (int i = 0; i < 2 * FOUT; ++i) s[i] += red[ww * 2 * FOUT + i];
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) {
+      const float s1 = s[c] / (float)N, s2 = s[FOUT + c] / (float)N;
+      float4 o;
+      o.x = rs[c] * (up[c].x - s1 - yv[c].x * s2);
+      o.y = rs[c] * (up[c].y - s1 - yv[c].y * s2);
+      o.z = rs[c] * (up[c].z - s1 - yv[c].z * s2);
+      o.w = rs[c] * (up[c].w - s1 - yv[c].w * s2);
+      *reinterpret_cast<float4*>(dys + c * N + n) = o;
+    }
+  }
+}
+
 #define GO_ABL_T 1024                                   // default workgroup; 512 when two workgroups then share a CU
 #define GO_ABL_MAXIT 4
 template <int FIN, int FOUT, int MAXIT, int T>
@@ -989,7 +1084,7 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
                   const int32_t* __restrict__ t_ptr, const int32_t* __restrict__ t_row, const float* __restrict__ x,
                   const float* __restrict__ w_inc, const float* __restrict__ w_s, const float* __restrict__ a_in,
                   const float* __restrict__ a_s, const float* __restrict__ dy, const int32_t* __restrict__ order,
-                  float* __restrict__ dx, float* __restrict__ gpart) {
+                  float* __restrict__ dx, float* __restrict__ gpart, const LnFuse L) {
   extern __shared__ float go_abl[];
   constexpr int ROWS = 2 * FOUT + 3, TP = T + 4;
   const int NP = (N + 3) & ~3;
@@ -1021,7 +1116,11 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
     const int nc = ncol[it];
     pc0[it] = nc >= 0 ? t_ptr[nc] : 0; pc1[it] = nc >= 0 ? t_ptr[nc + 1] : 0;
   }
-  if (NP == N && (((uintptr_t)xb | (uintptr_t)dyb) & 15) == 0) {
+  if (L.y) {                                            // block-uniform: dy formed here (ln_bwd_into_lds; NP == N)
+    for (int i = tid * 4; i < FIN * N; i += T * 4)
+      *reinterpret_cast<float4*>(xs + i) = *reinterpret_cast<const float4*>(xb + i);
+    ln_bwd_into_lds<FOUT, T>(L, b, N, dys, reinterpret_cast<float*>(st));
+  } else if (NP == N && (((uintptr_t)xb | (uintptr_t)dyb) & 15) == 0) {
     for (int i = tid * 4; i < FIN * N; i += T * 4)
       *reinterpret_cast<float4*>(xs + i) = *reinterpret_cast<const float4*>(xb + i);
     for (int i = tid * 4; i < FOUT * N; i += T * 4)
@@ -1340,24 +1439,34 @@ static bool go_attn_force_cm(void) { return igcn_opt(IGCN_OPT_GO_ATTN_CM); }
 int igcn_queue_go_finish(const float* gpart, int64_t parts, int fin, int fout, const float* w_inc, const float* w_s,
                          float* dparams, hipStream_t st);                                       // plan.hip
 
-extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
-                                const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order,
-                                const float* x, const float* w_inc,
-                                const float* w_s, const float* a_in, const float* a_s, const float* dy, float* dx,
-                                float* dparams, float* scratch, void* stream) {
-  IGCN_REQUIRE(B > 0 && N > 0, "go_attn_bwd: bad sizes");
-  hipStream_t st = (hipStream_t)stream;
+static bool go_ln_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static bool go_attn_bwd_in_lds(int N, int fin, int fout) {
+  const int TT = go_abl_threads(N, fin, fout);
+  return !go_attn_force_cm() && go_abl_lds_bytes(N, fin, fout, TT) <= 160 * 1024 && N <= TT * GO_ABL_MAXIT;
+}
+// 1 when igcn_go_attn_ln_bwd runs for these sizes (the LDS-resident kernel takes the layer and LnFuse's shape
+// preconditions hold); otherwise call igcn_nodes_ln_bwd* and igcn_go_attn_bwd
+extern "C" int igcn_go_attn_ln_fused_ok(int N, int fin, int fout, int pool) {
+  if (N <= 0 || pool < 0 || pool >= N || N % 4 || pool % 4) return 0;
+  return go_attn_bwd_in_lds(N, fin, fout) && N / 4 <= go_abl_threads(N, fin, fout) ? 1 : 0;
+}
+extern "C" size_t igcn_go_ln_part_floats(int B, int N) { return (size_t)B * 2 * (size_t)N + 64; }
+
+static int go_attn_bwd_impl(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
+                            const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order, const float* x,
+                            const float* w_inc, const float* w_s, const float* a_in, const float* a_s, const float* dy,
+                            float* dx, float* dparams, float* scratch, const LnFuse& L, hipStream_t st) {
   const int64_t rows = 2 * fout + 3;
   const int TT = go_abl_threads(N, fin, fout);
   const size_t abl_lds = go_abl_lds_bytes(N, fin, fout, TT);
-  if (!go_attn_force_cm() && abl_lds <= 160 * 1024 && N <= TT * GO_ABL_MAXIT) {
+  if (go_attn_bwd_in_lds(N, fin, fout)) {
     float* gpart = scratch;                                         // [rows * fin][B] block partials
     const int iters = (int)igcn_cdiv(N, TT);
 #define CALLLI(FI, FO, MI, TV)                                                                                    \
   {                                                                                                               \
     IGCN_ALLOW_BIG_LDS((k_go_attn_bwd_lds<FI, FO, MI, TV>));                                                      \
     hipLaunchKernelGGL((k_go_attn_bwd_lds<FI, FO, MI, TV>), dim3(B), dim3(TV), abl_lds, st, N, row_ptr, col,      \
-                       t_ptr, t_row, x, w_inc, w_s, a_in, a_s, dy, walk_order, dx, gpart);                        \
+                       t_ptr, t_row, x, w_inc, w_s, a_in, a_s, dy, walk_order, dx, gpart, L);                     \
   }
 #define CALLLT(FI, FO, TV)                                                                                        \
   if (iters <= 1) CALLLI(FI, FO, 1, TV) else if (iters == 2) CALLLI(FI, FO, 2, TV)                                \
@@ -1377,6 +1486,7 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
     IGCN_CHECK_LAUNCH("go_attn_bwd_finish");
     return IGCN_OK;
   }
+  IGCN_REQUIRE(L.y == nullptr, "go_attn_ln_bwd: this layer does not run LDS-resident (igcn_go_attn_ln_fused_ok)");
   float* stats = scratch;                                         // float4 [B,N] + dp [B,N]
   float* gpart = stats + 5 * (int64_t)B * N;                       // [blocks * 4 waves][rows * fin] block partials
   dim3 grid((unsigned)igcn_cdiv(N, GO_T), B);
@@ -1396,6 +1506,38 @@ extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* 
 #undef CALLF
   IGCN_CHECK_LAUNCH("go_attn_bwd_finish");
   return IGCN_OK;
+}
+
+extern "C" int igcn_go_attn_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
+                                const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order,
+                                const float* x, const float* w_inc,
+                                const float* w_s, const float* a_in, const float* a_s, const float* dy, float* dx,
+                                float* dparams, float* scratch, void* stream) {
+  IGCN_REQUIRE(B > 0 && N > 0, "go_attn_bwd: bad sizes");
+  const LnFuse none = {};
+  return go_attn_bwd_impl(B, N, fin, fout, row_ptr, col, t_ptr, t_row, walk_order, x, w_inc, w_s, a_in, a_s, dy, dx,
+                          dparams, scratch, none, (hipStream_t)stream);
+}
+
+// GO attention layer backward WITH the backward of the LayerNorm block that follows it (go_model.py:219-251): dz is the
+// gradient of z = dropout(relu(LN(y)))[.., pool:], y the layer's own output; dx and dparams as igcn_go_attn_bwd,
+// dgb [2, N] = d gamma | d beta, part: igcn_go_ln_part_floats(B, N) floats (alive until the deferred reductions ran).
+extern "C" int igcn_go_attn_ln_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
+                                   const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order,
+                                   const float* x, const float* w_inc, const float* w_s, const float* a_in,
+                                   const float* a_s, int pool, const float* y, const float* gamma, const float* beta,
+                                   const float* keep, const float* mean, const float* rstd, const float* dz, float* dx,
+                                   float* dparams, float* dgb, float* scratch, float* part, void* stream) {
+  IGCN_REQUIRE(B > 0 && N > 0, "go_attn_ln_bwd: bad sizes");
+  IGCN_REQUIRE(igcn_go_attn_ln_fused_ok(N, fin, fout, pool), "go_attn_ln_bwd: sizes not supported (igcn_go_attn_ln_fused_ok)");
+  IGCN_REQUIRE(y && gamma && beta && mean && rstd && dz && dgb && part, "go_attn_ln_bwd: null operand");
+  IGCN_REQUIRE(go_ln_al16(x) && go_ln_al16(y) && go_ln_al16(dz) && go_ln_al16(gamma) && go_ln_al16(beta) &&
+               go_ln_al16(keep) && go_ln_al16(part) && go_ln_al16(dx), "go_attn_ln_bwd: operands must be 16-byte aligned");
+  const LnFuse L = {y, dz, gamma, beta, keep, mean, rstd, part, pool};
+  const int rc = go_attn_bwd_impl(B, N, fin, fout, row_ptr, col, t_ptr, t_row, walk_order, x, w_inc, w_s, a_in, a_s,
+                                  nullptr, dx, dparams, scratch, L, (hipStream_t)stream);
+  if (rc) return rc;
+  return igcn_launch_reduce_rows_final(part, B, 2 * (int64_t)N, 2 * N, dgb, (hipStream_t)stream);
 }
 
 // =================================================================================================
@@ -1437,7 +1579,6 @@ k_nodes_ln_fwd(int f, int N, int pool, float eps, const float* __restrict__ y, c
 // kept in registers for the mean, the variance and the normalisation (the generic kernel makes three passes).
 #define LN_VPT 4
 #define LN_TMAX 1024
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // (256 threads for rows up to 4096 nodes, 1024 threads up to 16384: the 10 000-node hierarchy of configs[4])
 __global__ void __launch_bounds__(LN_TMAX)
@@ -2109,7 +2250,7 @@ __global__ void __launch_bounds__(T)
 k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ t_ptr,
                     const int32_t* __restrict__ t_row, const float* __restrict__ x, const float* __restrict__ w_out,
                     const float* __restrict__ w_sout, const float* __restrict__ dy, float* __restrict__ dx,
-                    float* __restrict__ partial) {
+                    float* __restrict__ partial, const LnFuse L) {
   extern __shared__ float go_dbl[];
   constexpr int ROWS = 2 * FOUT, TP = T + 4, NW = 2 * FOUT * FIN;
   const int NPo = (Nout + 3) & ~3;
@@ -2119,7 +2260,9 @@ k_go_decode_bwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
   float* xt = us + ROWS * TP;                           // [FIN][TP]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const float* dyb = dy + (int64_t)b * FOUT * Nout;
-  if (NPo == Nout && ((uintptr_t)dyb & 15) == 0) {
+  if (L.y) {                                            // block-uniform: dy formed here (ln_bwd_into_lds; NPo == Nout)
+    ln_bwd_into_lds<FOUT, T>(L, b, Nout, dys, us);
+  } else if (NPo == Nout && ((uintptr_t)dyb & 15) == 0) {
     for (int i = tid * 4; i < FOUT * Nout; i += T * 4)
       *reinterpret_cast<float4*>(dys + i) = *reinterpret_cast<const float4*>(dyb + i);
   } else {
@@ -2259,21 +2402,29 @@ extern "C" size_t igcn_go_decode_bwd_scratch_floats(int B, int Nin, int fin, int
   return (size_t)(igcn_cdiv(Nin, GO_T) * igcn_cdiv(B, GO_SB) * 2 * fout * fin + 64);
 }
 
-extern "C" int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr,
-                                  const int32_t* t_ptr, const int32_t* t_row, const float* x, const float* w_out,
-                                  const float* w_sout, const float* dy, float* dx, float* dparams, float* scratch,
-                                  void* stream) {
-  IGCN_REQUIRE(B > 0 && Nin > 0 && Nout >= Nin, "go_decode_bwd: bad sizes");
-  hipStream_t st = (hipStream_t)stream;
+static bool go_decode_bwd_in_lds(int Nin, int Nout, int fin, int fout) {
+  const int TT = go_dbl_threads(Nin, Nout, fin, fout);
+  return !go_attn_force_cm() && go_dbl_lds_bytes(Nout, fin, fout, TT) <= 160 * 1024 && 2 * fout >= 4;
+}
+// 1 when igcn_go_decode_ln_bwd runs for these sizes (see igcn_go_attn_ln_fused_ok; the decoder's LayerNorm has no pooling)
+extern "C" int igcn_go_decode_ln_fused_ok(int Nin, int Nout, int fin, int fout) {
+  if (Nin <= 0 || Nout < Nin || Nout % 4) return 0;
+  return go_decode_bwd_in_lds(Nin, Nout, fin, fout) && Nout / 4 <= go_dbl_threads(Nin, Nout, fin, fout) ? 1 : 0;
+}
+
+static int go_decode_bwd_impl(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr, const int32_t* t_ptr,
+                              const int32_t* t_row, const float* x, const float* w_out, const float* w_sout,
+                              const float* dy, float* dx, float* dparams, float* scratch, const LnFuse& L,
+                              hipStream_t st) {
   const int nw = 2 * fout * fin;
   const int TT = go_dbl_threads(Nin, Nout, fin, fout);
   const size_t lds = go_dbl_lds_bytes(Nout, fin, fout, TT);
-  if (!go_attn_force_cm() && lds <= 160 * 1024 && 2 * fout >= 4) {
+  if (go_decode_bwd_in_lds(Nin, Nout, fin, fout)) {
 #define CALLT(FI, FO, TV)                                                                                        \
   {                                                                                                               \
     IGCN_ALLOW_BIG_LDS((k_go_decode_bwd_lds<FI, FO, TV>));                                                        \
     hipLaunchKernelGGL((k_go_decode_bwd_lds<FI, FO, TV>), dim3(B), dim3(TV), lds, st, Nin, Nout, row_ptr, t_ptr,  \
-                       t_row, x, w_out, w_sout, dy, dx, scratch);                                                 \
+                       t_row, x, w_out, w_sout, dy, dx, scratch, L);                                              \
   }
 #define CALL(FI, FO) \
   if (TT == 512) CALLT(FI, FO, 512) else CALLT(FI, FO, 1024)
@@ -2283,6 +2434,7 @@ extern "C" int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, c
     IGCN_CHECK_LAUNCH("go_decode_bwd(lds)");
     return igcn_launch_reduce_rows_final(scratch, B, nw, nw, dparams, st);
   }
+  IGCN_REQUIRE(L.y == nullptr, "go_decode_ln_bwd: this layer does not run LDS-resident (igcn_go_decode_ln_fused_ok)");
   dim3 grid((unsigned)igcn_cdiv(Nin, GO_T), (unsigned)igcn_cdiv(B, GO_SB));
 #define CALL(FI, FO)                                                                                             \
   hipLaunchKernelGGL((k_go_decode_bwd<FI, FO>), grid, dim3(GO_T), 0, st, B, Nin, Nout, row_ptr, t_ptr, t_row, x, \
@@ -2291,4 +2443,34 @@ extern "C" int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, c
 #undef CALL
   IGCN_CHECK_LAUNCH("go_decode_bwd");
   return igcn_launch_reduce_rows_final(scratch, (int64_t)grid.x * grid.y, nw, nw, dparams, st);
+}
+
+extern "C" int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr,
+                                  const int32_t* t_ptr, const int32_t* t_row, const float* x, const float* w_out,
+                                  const float* w_sout, const float* dy, float* dx, float* dparams, float* scratch,
+                                  void* stream) {
+  IGCN_REQUIRE(B > 0 && Nin > 0 && Nout >= Nin, "go_decode_bwd: bad sizes");
+  const LnFuse none = {};
+  return go_decode_bwd_impl(B, Nin, Nout, fin, fout, row_ptr, t_ptr, t_row, x, w_out, w_sout, dy, dx, dparams, scratch,
+                            none, (hipStream_t)stream);
+}
+
+// GO decoder layer backward WITH the backward of the LayerNorm block behind it (go_model.py:262-275; pool = 0): dz is
+// the gradient of z = dropout(relu(LN(y))), y [B, fout, Nout] the layer's own output; dgb [2, Nout], part:
+// igcn_go_ln_part_floats(B, Nout) floats (alive until the deferred reductions ran).
+extern "C" int igcn_go_decode_ln_bwd(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr,
+                                     const int32_t* t_ptr, const int32_t* t_row, const float* x, const float* w_out,
+                                     const float* w_sout, const float* y, const float* gamma, const float* beta,
+                                     const float* keep, const float* mean, const float* rstd, const float* dz,
+                                     float* dx, float* dparams, float* dgb, float* scratch, float* part, void* stream) {
+  IGCN_REQUIRE(B > 0 && Nin > 0 && Nout >= Nin, "go_decode_ln_bwd: bad sizes");
+  IGCN_REQUIRE(igcn_go_decode_ln_fused_ok(Nin, Nout, fin, fout), "go_decode_ln_bwd: sizes not supported (igcn_go_decode_ln_fused_ok)");
+  IGCN_REQUIRE(y && gamma && beta && mean && rstd && dz && dgb && part, "go_decode_ln_bwd: null operand");
+  IGCN_REQUIRE(go_ln_al16(y) && go_ln_al16(dz) && go_ln_al16(gamma) && go_ln_al16(beta) && go_ln_al16(keep) &&
+               go_ln_al16(part), "go_decode_ln_bwd: operands must be 16-byte aligned");
+  const LnFuse L = {y, dz, gamma, beta, keep, mean, rstd, part, 0};
+  const int rc = go_decode_bwd_impl(B, Nin, Nout, fin, fout, row_ptr, t_ptr, t_row, x, w_out, w_sout, nullptr, dx,
+                                    dparams, scratch, L, (hipStream_t)stream);
+  if (rc) return rc;
+  return igcn_launch_reduce_rows_final(part, B, 2 * (int64_t)Nout, 2 * Nout, dgb, (hipStream_t)stream);
 }

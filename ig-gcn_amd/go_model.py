@@ -151,11 +151,12 @@ class Gene_ontology_network(nn.Module):
         # encoder (:219-251)
         for j in range(self.n_l):
             csr = self.enc_csr[j]
-            y = ops.GoAttention.apply(x, self.w_inc[j].weight, self.w_s_loop[j].weight,
-                                      self.w_att_in[j].weight, self.w_att_s[j].weight, csr)   # leaves (no .view(-1): a view's
-            # gradient would pass through another backward node, and the op could not defer its final reduction)
-            x = ops.NodesLayerNorm.apply(y, self.G_B[j].weight, self.G_B[j].bias, keeps[j], self.pool[j],
-                                         self.G_B[j].eps)
+            # layer + LayerNorm block as ONE autograd node: its backward is one launch when the layer runs LDS-resident
+            # (ops.GoAttentionLN).  Leaves (no .view(-1): a view's gradient would pass through another backward node, and
+            # the op could not defer its final reductions)
+            x = ops.GoAttentionLN.apply(x, self.w_inc[j].weight, self.w_s_loop[j].weight, self.w_att_in[j].weight,
+                                        self.w_att_s[j].weight, csr, self.G_B[j].weight, self.G_B[j].bias, keeps[j],
+                                        self.pool[j], self.G_B[j].eps)
         # read-outs (:254-255): BatchNorm1d(n_top) normalises per NODE over (batch, feature); fused kernels
         bn_a, bn_i = self.conc_for_attention[1], self.B[0]
         if ops.node_linear_bn_pair_supported(x, self.conc_for_attention[0].weight, self.conc.weight, None) \
@@ -180,9 +181,8 @@ class Gene_ontology_network(nn.Module):
         # decoder (:258-275)
         for j in range(self.n_l):
             csr = self.dec_csr[j]
-            y = ops.GoDecode.apply(x, self.w_out[j].weight, self.w_s_loop_out[j].weight, csr)
-            x = ops.NodesLayerNorm.apply(y, self.G_B_D[j].weight, self.G_B_D[j].bias, keeps[self.n_l + j], 0,
-                                         self.G_B_D[j].eps)
+            x = ops.GoDecodeLN.apply(x, self.w_out[j].weight, self.w_s_loop_out[j].weight, csr, self.G_B_D[j].weight,
+                                     self.G_B_D[j].bias, keeps[self.n_l + j], self.G_B_D[j].eps)
         # gene decoding (:278-282)
         out_d = self._node_linear_bn(x, self.conc_D.weight, self.B_D[0], groups, masks["out_d"]).squeeze(2)   # [B,N]
         x_d = ops.SparseMap.apply(out_d, self.gene_t_csr, self.t_D[0]).squeeze(1)               # [B, 54]

@@ -1467,6 +1467,58 @@ class SparseMap(torch.autograd.Function):
         return (dx, None) + grads
 
 
+def _go_attn_backward(x, w_inc, w_s, a_in, a_s, csr, final, dy):
+    """igcn_go_attn_bwd: (dx, dparams) of one encoder layer (GoAttention, GoAttentionLN's unfused path)."""
+    b, fin, n = x.shape
+    fout = w_inc.shape[0]
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    dpar = torch.empty(2 * fout * fin + 3 * fout, dtype=torch.float32, device=x.device)
+    scratch = _keep(torch.empty(int(lib.igcn_go_attn_bwd_scratch_floats(b, n, fin, fout)), dtype=torch.float32,
+                                device=x.device))
+    with _immediate(final):     # leaves: the parameter gradients join the deferred final reductions
+        call("igcn_go_attn_bwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(csr.t_ptr), ptr(csr.t_row),
+             ptr(csr.walk_order(fin, fout)), ptr(x), ptr(w_inc), ptr(w_s), ptr(a_in), ptr(a_s), ptr(dy), ptr(dx),
+             ptr(dpar), ptr(scratch), stream_ptr())
+    return dx, dpar
+
+
+def _nodes_ln_backward(y, gamma, beta, keep, mean, rstd, pool, final, dz):
+    """(dy, dgb [2, N]) of NodesLayerNorm: the dX pass now, the affine pass with the other layers' when deferred."""
+    b, f, n = y.shape
+    dy = torch.empty_like(y)
+    dgb = torch.empty(2, n, dtype=torch.float32, device=y.device)
+    lib = _lib.load()
+    scratch = _keep(torch.empty(int(lib.igcn_nodes_ln_bwd_scratch_floats(b, f, n)), dtype=torch.float32,
+                                device=y.device))
+    if _DEFER["on"] and final and os.environ.get("IGCN_LN_AFFINE_NOW", "0") != "1":
+        # d gamma / d beta are parameter gradients: their pass joins those of the other layers in ONE launch when
+        # the backward ends (operands kept alive until then)
+        call("igcn_nodes_ln_bwd_dy", b, f, n, pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean),
+             ptr(rstd), ptr(dz), ptr(dy), stream_ptr())
+        _DEFER["ln_affine"].append(((b, f, n, pool), (y, gamma, beta, keep, mean, rstd, dz, scratch, dgb)))
+    else:
+        with _immediate(final):
+            call("igcn_nodes_ln_bwd", b, f, n, pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean),
+                 ptr(rstd), ptr(dz), ptr(dy), ptr(dgb), ptr(scratch), stream_ptr())
+    return dy, dgb
+
+
+def _go_decode_backward(x, w_out, w_sout, csr, final, dy):
+    """igcn_go_decode_bwd: (dx, dparams) of one decoder layer."""
+    b, fin, nin = x.shape
+    fout, nout = w_out.shape[0], csr.n_rows
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    dpar = torch.empty(2 * fout * fin, dtype=torch.float32, device=x.device)
+    scratch = _keep(torch.empty(int(lib.igcn_go_decode_bwd_scratch_floats(b, nin, fin, fout)),
+                                dtype=torch.float32, device=x.device))
+    with _immediate(final):
+        call("igcn_go_decode_bwd", b, nin, nout, fin, fout, ptr(csr.row_ptr), ptr(csr.t_ptr), ptr(csr.t_row),
+             ptr(x), ptr(w_out), ptr(w_sout), ptr(dy), ptr(dx), ptr(dpar), ptr(scratch), stream_ptr())
+    return dx, dpar
+
+
 class GoAttention(torch.autograd.Function):
     """One GO encoder layer for all samples (go_model.py:226-244).  x [B,fin,N] -> y [B,fout,N]."""
 
@@ -1485,19 +1537,8 @@ class GoAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w_inc, w_s, a_in, a_s = ctx.saved_tensors
-        csr = ctx.csr
-        dy = _f32(dy)
-        b, fin, n = x.shape
-        fout = w_inc.shape[0]
-        lib = _lib.load()
-        dx = torch.empty_like(x)
-        dpar = torch.empty(2 * fout * fin + 3 * fout, dtype=torch.float32, device=x.device)
-        scratch = _keep(torch.empty(int(lib.igcn_go_attn_bwd_scratch_floats(b, n, fin, fout)), dtype=torch.float32,
-                                    device=x.device))
-        with _immediate(ctx.final):     # leaves: the parameter gradients join the deferred final reductions
-            call("igcn_go_attn_bwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(csr.t_ptr), ptr(csr.t_row),
-                 ptr(csr.walk_order(fin, fout)), ptr(x), ptr(w_inc), ptr(w_s), ptr(a_in), ptr(a_s), ptr(dy), ptr(dx),
-                 ptr(dpar), ptr(scratch), stream_ptr())
+        fout, fin = w_inc.shape[0], x.shape[1]
+        dx, dpar = _go_attn_backward(x, w_inc, w_s, a_in, a_s, ctx.csr, ctx.final, _f32(dy))
         k = fout * fin
         return (dx, dpar[:k].view(fout, fin), dpar[k:2 * k].view(fout, fin),
                 dpar[2 * k:2 * k + 2 * fout].view_as(a_in), dpar[2 * k + 2 * fout:].view_as(a_s), None)
@@ -1524,24 +1565,120 @@ class NodesLayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         y, gamma, beta, keep, mean, rstd = ctx.saved_tensors
-        dz = _f32(dz)
-        b, f, n = y.shape
-        dy = torch.empty_like(y)
-        dgb = torch.empty(2, n, dtype=torch.float32, device=y.device)
-        lib = _lib.load()
-        scratch = _keep(torch.empty(int(lib.igcn_nodes_ln_bwd_scratch_floats(b, f, n)), dtype=torch.float32,
-                                    device=y.device))
-        if _DEFER["on"] and ctx.final and os.environ.get("IGCN_LN_AFFINE_NOW", "0") != "1":
-            # d gamma / d beta are parameter gradients: their pass joins those of the other layers in ONE launch when
-            # the backward ends (operands kept alive until then)
-            call("igcn_nodes_ln_bwd_dy", b, f, n, ctx.pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean),
-                 ptr(rstd), ptr(dz), ptr(dy), stream_ptr())
-            _DEFER["ln_affine"].append(((b, f, n, ctx.pool), (y, gamma, beta, keep, mean, rstd, dz, scratch, dgb)))
-        else:
-            with _immediate(ctx.final):
-                call("igcn_nodes_ln_bwd", b, f, n, ctx.pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean),
-                     ptr(rstd), ptr(dz), ptr(dy), ptr(dgb), ptr(scratch), stream_ptr())
+        dy, dgb = _nodes_ln_backward(y, gamma, beta, keep, mean, rstd, ctx.pool, ctx.final, _f32(dz))
         return dy, dgb[0], dgb[1], None, None, None
+
+
+def _al16(*ts):
+    return all(t is None or t.data_ptr() % 16 == 0 for t in ts)
+
+
+class GoAttentionLN(torch.autograd.Function):
+    """One GO encoder layer AND the LayerNorm block behind it (go_model.py:226-251): z = dropout(relu(LN(attn(x))))[.., pool:].
+    Forward: the two launches of GoAttention and NodesLayerNorm.  Backward: when the layer runs LDS-resident
+    (igcn_go_attn_ln_fused_ok) ONE launch — the attention backward forms the LayerNorm's input gradient while it
+    copies it in (igcn_go_attn_ln_bwd) and leaves per-sample d gamma | d beta rows to the final reductions; otherwise
+    the backward passes of the two ops in sequence (same arithmetic per element)."""
+
+    @staticmethod
+    def forward(ctx, x, w_inc, w_s, a_in, a_s, csr, gamma, beta, keep, pool, eps):
+        x, w_inc, w_s, a_in, a_s = _f32(x), _f32(w_inc), _f32(w_s), _f32(a_in), _f32(a_s)
+        gamma, beta = _f32(gamma), _f32(beta)
+        keep = _f32(keep) if keep is not None else None
+        b, fin, n = x.shape
+        fout = w_inc.shape[0]
+        y = torch.empty(b, fout, n, dtype=torch.float32, device=x.device)
+        call("igcn_go_attn_fwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(x), ptr(w_inc), ptr(w_s),
+             ptr(a_in), ptr(a_s), ptr(y), stream_ptr())
+        z = torch.empty(b, fout, n - pool, dtype=torch.float32, device=x.device)
+        mean = torch.empty(b * fout, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call("igcn_nodes_ln_fwd", b, fout, n, pool, float(eps), ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(z),
+             ptr(mean), ptr(rstd), stream_ptr())
+        ctx.save_for_backward(x, w_inc, w_s, a_in, a_s, y, gamma, beta, keep, mean, rstd)
+        ctx.csr, ctx.pool = csr, pool
+        ctx.final_attn, ctx.final_ln = _leaves(w_inc, w_s, a_in, a_s), _leaves(gamma, beta)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w_inc, w_s, a_in, a_s, y, gamma, beta, keep, mean, rstd = ctx.saved_tensors
+        csr, pool = ctx.csr, ctx.pool
+        dz = _f32(dz)
+        b, fin, n = x.shape
+        fout = w_inc.shape[0]
+        lib = _lib.load()
+        k = fout * fin
+        if lib.igcn_go_attn_ln_fused_ok(n, fin, fout, pool) and _al16(x, y, dz, gamma, beta, keep) \
+                and os.environ.get("IGCN_NO_LN_FUSED", "0") != "1":
+            dx = torch.empty_like(x)
+            dpar = torch.empty(2 * k + 3 * fout, dtype=torch.float32, device=x.device)
+            dgb = torch.empty(2, n, dtype=torch.float32, device=x.device)
+            scratch = _keep(torch.empty(int(lib.igcn_go_attn_bwd_scratch_floats(b, n, fin, fout)),
+                                        dtype=torch.float32, device=x.device))
+            part = _keep(torch.empty(int(lib.igcn_go_ln_part_floats(b, n)), dtype=torch.float32, device=x.device))
+            with _immediate(ctx.final_attn and ctx.final_ln):
+                call("igcn_go_attn_ln_bwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(csr.t_ptr),
+                     ptr(csr.t_row), ptr(csr.walk_order(fin, fout)), ptr(x), ptr(w_inc), ptr(w_s), ptr(a_in), ptr(a_s),
+                     pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean), ptr(rstd), ptr(dz), ptr(dx), ptr(dpar),
+                     ptr(dgb), ptr(scratch), ptr(part), stream_ptr())
+        else:
+            dy, dgb = _nodes_ln_backward(y, gamma, beta, keep, mean, rstd, pool, ctx.final_ln, dz)
+            dx, dpar = _go_attn_backward(x, w_inc, w_s, a_in, a_s, csr, ctx.final_attn, dy)
+        return (dx, dpar[:k].view(fout, fin), dpar[k:2 * k].view(fout, fin),
+                dpar[2 * k:2 * k + 2 * fout].view_as(a_in), dpar[2 * k + 2 * fout:].view_as(a_s), None,
+                dgb[0], dgb[1], None, None, None)
+
+
+class GoDecodeLN(torch.autograd.Function):
+    """One GO decoder layer AND the LayerNorm block behind it (go_model.py:262-275): z = dropout(relu(LN(decode(x)))).
+    Backward in one launch when the layer runs LDS-resident (igcn_go_decode_ln_bwd), see GoAttentionLN."""
+
+    @staticmethod
+    def forward(ctx, x, w_out, w_sout, csr, gamma, beta, keep, eps):
+        x, w_out, w_sout, gamma, beta = _f32(x), _f32(w_out), _f32(w_sout), _f32(gamma), _f32(beta)
+        keep = _f32(keep) if keep is not None else None
+        b, fin, nin = x.shape
+        fout, nout = w_out.shape[0], csr.n_rows
+        assert csr.n_cols == nin
+        y = torch.empty(b, fout, nout, dtype=torch.float32, device=x.device)
+        call("igcn_go_decode_fwd", b, nin, nout, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(x), ptr(w_out),
+             ptr(w_sout), ptr(y), stream_ptr())
+        z = torch.empty_like(y)
+        mean = torch.empty(b * fout, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call("igcn_nodes_ln_fwd", b, fout, nout, 0, float(eps), ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(z),
+             ptr(mean), ptr(rstd), stream_ptr())
+        ctx.save_for_backward(x, w_out, w_sout, y, gamma, beta, keep, mean, rstd)
+        ctx.csr = csr
+        ctx.final_dec, ctx.final_ln = _leaves(w_out, w_sout), _leaves(gamma, beta)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w_out, w_sout, y, gamma, beta, keep, mean, rstd = ctx.saved_tensors
+        csr = ctx.csr
+        dz = _f32(dz)
+        b, fin, nin = x.shape
+        fout, nout = w_out.shape[0], csr.n_rows
+        lib = _lib.load()
+        k = fout * fin
+        if lib.igcn_go_decode_ln_fused_ok(nin, nout, fin, fout) and _al16(y, dz, gamma, beta, keep) \
+                and os.environ.get("IGCN_NO_LN_FUSED", "0") != "1":
+            dx = torch.empty_like(x)
+            dpar = torch.empty(2 * k, dtype=torch.float32, device=x.device)
+            dgb = torch.empty(2, nout, dtype=torch.float32, device=x.device)
+            scratch = _keep(torch.empty(int(lib.igcn_go_decode_bwd_scratch_floats(b, nin, fin, fout)),
+                                        dtype=torch.float32, device=x.device))
+            part = _keep(torch.empty(int(lib.igcn_go_ln_part_floats(b, nout)), dtype=torch.float32, device=x.device))
+            with _immediate(ctx.final_dec and ctx.final_ln):
+                call("igcn_go_decode_ln_bwd", b, nin, nout, fin, fout, ptr(csr.row_ptr), ptr(csr.t_ptr), ptr(csr.t_row),
+                     ptr(x), ptr(w_out), ptr(w_sout), ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean), ptr(rstd),
+                     ptr(dz), ptr(dx), ptr(dpar), ptr(dgb), ptr(scratch), ptr(part), stream_ptr())
+        else:
+            dy, dgb = _nodes_ln_backward(y, gamma, beta, keep, mean, rstd, 0, ctx.final_ln, dz)
+            dx, dpar = _go_decode_backward(x, w_out, w_sout, csr, ctx.final_dec, dy)
+        return dx, dpar[:k].view(fout, fin), dpar[k:].view(fout, fin), None, dgb[0], dgb[1], None, None
 
 
 class GoDecode(torch.autograd.Function):
@@ -1564,18 +1701,8 @@ class GoDecode(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w_out, w_sout = ctx.saved_tensors
-        csr = ctx.csr
-        dy = _f32(dy)
-        b, fin, nin = x.shape
-        fout, nout = w_out.shape[0], csr.n_rows
-        lib = _lib.load()
-        dx = torch.empty_like(x)
-        dpar = torch.empty(2 * fout * fin, dtype=torch.float32, device=x.device)
-        scratch = _keep(torch.empty(int(lib.igcn_go_decode_bwd_scratch_floats(b, nin, fin, fout)),
-                                    dtype=torch.float32, device=x.device))
-        with _immediate(ctx.final):
-            call("igcn_go_decode_bwd", b, nin, nout, fin, fout, ptr(csr.row_ptr), ptr(csr.t_ptr), ptr(csr.t_row),
-                 ptr(x), ptr(w_out), ptr(w_sout), ptr(dy), ptr(dx), ptr(dpar), ptr(scratch), stream_ptr())
+        fout, fin = w_out.shape[0], x.shape[1]
+        dx, dpar = _go_decode_backward(x, w_out, w_sout, ctx.csr, ctx.final, _f32(dy))
         k = fout * fin
         return dx, dpar[:k].view(fout, fin), dpar[k:].view(fout, fin), None
 

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 318
+#define IGCN_ABI_VERSION 319
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -671,6 +671,29 @@ int igcn_nodes_ln_bwd_dy(int B, int f, int N, int pool, const float* y, const fl
                          const float* keep, const float* mean, const float* rstd, const float* dz, float* dy,
                          void* stream);
 int igcn_nodes_ln_bwd_affine_multi(int n, const int64_t* table, void* stream);
+
+/* A GO layer's backward WITH the backward of the LayerNorm block behind it (go_model.py:219-251 encoder,
+ * :262-275 decoder: y = layer(x); z = dropout(relu(LN(y)))[.., pool:]).  The layer's LDS-resident backward holds one
+ * sample per workgroup, so it forms d loss / d y from (y, dz, gamma, beta, keep, mean, rstd) while copying it in — the
+ * LayerNorm's own dX launch and the d y tensor disappear — and leaves d gamma | d beta summed over the sample's channels
+ * in part [B][2][N], reduced over samples by the (deferred) final reduction into dgb [2, N].  igcn_go_*_ln_fused_ok:
+ * 1 when the sizes qualify (LDS-resident layer, N and pool multiples of 4, N / 4 <= workgroup size); otherwise use
+ * igcn_nodes_ln_bwd* followed by igcn_go_attn_bwd / igcn_go_decode_bwd.  Every tensor 16-byte aligned.  dx, dparams and
+ * scratch as the plain entry points; part: igcn_go_ln_part_floats(B, N) floats, alive until the reductions ran. */
+int igcn_go_attn_ln_fused_ok(int N, int fin, int fout, int pool);
+int igcn_go_decode_ln_fused_ok(int Nin, int Nout, int fin, int fout);
+size_t igcn_go_ln_part_floats(int B, int N);
+int igcn_go_attn_ln_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
+                        const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order,
+                        const float* x, const float* w_inc, const float* w_s, const float* a_in, const float* a_s,
+                        int pool, const float* y, const float* gamma, const float* beta, const float* keep,
+                        const float* mean, const float* rstd, const float* dz, float* dx, float* dparams, float* dgb,
+                        float* scratch, float* part, void* stream);
+int igcn_go_decode_ln_bwd(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr,
+                          const int32_t* t_ptr, const int32_t* t_row, const float* x, const float* w_out,
+                          const float* w_sout, const float* y, const float* gamma, const float* beta,
+                          const float* keep, const float* mean, const float* rstd, const float* dz, float* dx,
+                          float* dparams, float* dgb, float* scratch, float* part, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GO decoder layer (mean aggregation down the hierarchy) — go_model.py:262-272, batch_mul :197-201:

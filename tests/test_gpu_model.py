@@ -296,7 +296,7 @@ def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch):
     def hip_run(batched):
         """(loss, terms, grads, forced decisions per oracle ReLU site, ignore masks) of one HIP evaluation."""
         seen = {}
-        classes = (ops.SgcnStack, ops.NodesLayerNorm, ops.NodeLinearBNPair, ops.NodeLinearBN, ops.BatchNorm1dGrouped,
+        classes = (ops.SgcnStack, ops.GoAttentionLN, ops.GoDecodeLN, ops.NodeLinearBNPair, ops.NodeLinearBN, ops.BatchNorm1dGrouped,
                    ops.Linear, ops.LinearPair)
         model.load_state_dict(sd)                                     # running statistics back to the start
         model.zero_grad()
@@ -327,7 +327,7 @@ def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch):
             n = len(calls) // 2
             return [pick(calls[k_th]).detach().cpu(), pick(calls[n + k_th]).detach().cpu()]
         xc = per_pass("SgcnStack", 0, lambda o: o[0] if isinstance(o, tuple) else o)
-        ln = [per_pass("NodesLayerNorm", k) for k in range(4)]
+        ln = [per_pass("GoAttentionLN", k) for k in range(2)] + [per_pass("GoDecodeLN", k) for k in range(2)]
         att = per_pass("NodeLinearBNPair", 0, lambda o: o[0])
         inp = per_pass("NodeLinearBNPair", 0, lambda o: o[1])
         outd = per_pass("NodeLinearBN", 0)

@@ -514,6 +514,116 @@ def test_go_decoder_layer(ops, bsz, pool, layer, seed):
     assert_matches(g[2], g_ref[2].numpy(), TOL, "dW_sout")
 
 
+def _ln_block_ref(y, gamma, beta, keep, pool):
+    """fp64 dropout(relu(LayerNorm_over_nodes(y)))[:, pool:] for y [B, N, f] (go_model.py:246-251)."""
+    z = torch.relu(torch.nn.functional.layer_norm(y.transpose(1, 2), (y.shape[1],), gamma, beta, 1e-5))
+    if keep is not None:
+        z = z * keep.double().unsqueeze(1)
+    return z[:, :, pool:]
+
+
+@pytest.mark.parametrize("bsz,pool,layer,with_keep,seed", [
+    (4, (20, 10, 6, 3, 1), 0, True, 0), (5, (40, 20, 8, 3, 1), 1, False, 1), (16, (300, 120, 60, 19, 1), 0, True, 2),
+    # the bench hierarchy: 3000 nodes on 1024 threads (layer 0), 1200 on 512 (layer 1)
+    (3, (1800, 800, 300, 99, 1), 0, True, 3), (3, (1800, 800, 300, 99, 1), 1, True, 4),
+    # 3001 nodes: no 16-byte rows, the op falls back to the two backward passes
+    (2, (1801, 800, 300, 99, 1), 0, True, 5)])
+def test_go_attention_with_layernorm_backward_in_one_launch(ops, monkeypatch, bsz, pool, layer, with_keep, seed):
+    """ops.GoAttentionLN: encoder layer + LayerNorm block.  Its backward forms the LayerNorm's input gradient inside the
+    LDS-resident attention backward (igcn_go_attn_ln_bwd) — against fp64 autograd of the composed reference, and
+    against the op's own two-pass path (IGCN_NO_LN_FUSED)."""
+    from igcn_amd import _lib
+    _, _, _, idx = _hier(pool, seed)
+    fin = 2 if layer == 0 else 5
+    row, col, nj = idx["enc"][layer]
+    drop = pool[layer]
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal((bsz, nj, fin))).float()
+    par = [torch.from_numpy(rng.standard_normal(s) * 0.5).float() for s in ((5, fin), (5, fin), (1, 10), (1, 5))]
+    gamma = torch.from_numpy(1 + 0.2 * rng.standard_normal(nj)).float()
+    beta = torch.from_numpy(0.1 * rng.standard_normal(nj)).float()
+    keep = torch.from_numpy((rng.random((bsz, nj)) > 0.3) / 0.7).float() if with_keep else None
+    cot = torch.from_numpy(rng.standard_normal((bsz, 5, nj - drop))).float()
+
+    def ref(xd, w_inc, w_s, a_in, a_s, g_, b_):
+        x_in, x_s = xd @ w_inc.t(), xd @ w_s.t()
+        v = torch.exp(torch.tanh(torch.cat([x_in[:, row], x_in[:, col]], 2) @ a_in.t())).squeeze(2)
+        z = torch.zeros(bsz, nj, dtype=xd.dtype).index_add(1, row, v)
+        alpha = v / z[:, row]
+        y = torch.zeros(bsz, nj, 5, dtype=xd.dtype).index_add(1, row, alpha.unsqueeze(2) * x_in[:, col]) \
+            + x_s * torch.sigmoid(x_s @ a_s.t())
+        return _ln_block_ref(y, g_, b_, keep, drop)
+
+    ref_in = [t.double().requires_grad_(True) for t in [x] + par + [gamma, beta]]
+    z_ref = ref(*ref_in)
+    g_ref = torch.autograd.grad((z_ref * cot.double()).sum(), ref_in)
+    csr = ops.Csr(row, col, nj, nj, "cuda")
+    dev = [x.transpose(1, 2).contiguous().cuda().requires_grad_(True)] + \
+          [p.cuda().requires_grad_(True) for p in par + [gamma, beta]]
+    kd = keep.cuda() if keep is not None else None
+    fused = bool(_lib.load().igcn_go_attn_ln_fused_ok(nj, fin, 5, drop))
+    assert fused == (nj % 4 == 0 and drop % 4 == 0)
+    z = ops.GoAttentionLN.apply(dev[0], dev[1], dev[2], dev[3], dev[4], csr, dev[5], dev[6], kd, drop, 1e-5)
+    g = torch.autograd.grad((z * cot.cuda()).sum(), dev, retain_graph=True)
+    names = ("dx", "dW_inc", "dW_s", "da_in", "da_s", "dgamma", "dbeta")
+    assert_matches(z, z_ref.detach().numpy(), TOL, "z")
+    assert_matches(g[0].transpose(1, 2), g_ref[0].numpy(), TOL, "dx")
+    for got, want, nm in zip(g[1:], g_ref[1:], names[1:]):
+        assert_matches(got, want.numpy(), TOL, nm)
+    monkeypatch.setenv("IGCN_NO_LN_FUSED", "1")
+    g2 = torch.autograd.grad((z * cot.cuda()).sum(), dev)
+    for a, c2, nm in zip(g2, g, names):
+        assert_matches(a, c2.cpu().numpy(), 2e-5, nm + " (two passes)")
+
+
+@pytest.mark.parametrize("bsz,pool,layer,with_keep,seed", [
+    (4, (20, 10, 6, 3, 1), 0, True, 0), (4, (20, 12, 8, 3, 1), 1, False, 1), (9, (300, 120, 60, 19, 1), 0, True, 2),
+    (9, (300, 120, 60, 19, 1), 1, False, 3), (3, (1800, 800, 300, 99, 1), 0, True, 4),
+    (3, (1800, 800, 300, 99, 1), 1, True, 5), (2, (1801, 800, 300, 99, 1), 1, True, 6)])
+def test_go_decoder_with_layernorm_backward_in_one_launch(ops, monkeypatch, bsz, pool, layer, with_keep, seed):
+    """ops.GoDecodeLN: decoder layer + LayerNorm block (no pooling), see the encoder test above."""
+    from igcn_amd import _lib
+    _, _, _, idx = _hier(pool, seed)
+    row, col, n_rows, n_cols = idx["dec"][layer]
+    fin, fout = 5, (5 if layer == 0 else 2)
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal((bsz, n_cols, fin))).float()
+    par = [torch.from_numpy(rng.standard_normal((fout, fin)) * 0.5).float() for _ in range(2)]
+    gamma = torch.from_numpy(1 + 0.2 * rng.standard_normal(n_rows)).float()
+    beta = torch.from_numpy(0.1 * rng.standard_normal(n_rows)).float()
+    keep = torch.from_numpy((rng.random((bsz, n_rows)) > 0.3) / 0.7).float() if with_keep else None
+    cot = torch.from_numpy(rng.standard_normal((bsz, fout, n_rows))).float()
+
+    def ref(xd, w_out, w_sout, g_, b_):
+        deg = torch.zeros(n_rows, dtype=xd.dtype).index_add(0, row, torch.ones(row.numel(), dtype=xd.dtype))
+        agg = torch.zeros(bsz, n_rows, fout, dtype=xd.dtype).index_add(
+            1, row, (xd @ w_out.t())[:, col] / deg[row].view(1, -1, 1))
+        pad = torch.zeros_like(agg)
+        pad[:, n_rows - n_cols:] = xd @ w_sout.t()
+        return _ln_block_ref(agg + pad, g_, b_, keep, 0)
+
+    ref_in = [t.double().requires_grad_(True) for t in [x] + par + [gamma, beta]]
+    z_ref = ref(*ref_in)
+    g_ref = torch.autograd.grad((z_ref * cot.double()).sum(), ref_in)
+    csr = ops.Csr(row, col, n_rows, n_cols, "cuda")
+    dev = [x.transpose(1, 2).contiguous().cuda().requires_grad_(True)] + \
+          [p.cuda().requires_grad_(True) for p in par + [gamma, beta]]
+    kd = keep.cuda() if keep is not None else None
+    fused = bool(_lib.load().igcn_go_decode_ln_fused_ok(n_cols, n_rows, fin, fout))
+    assert fused == (n_rows % 4 == 0)
+    z = ops.GoDecodeLN.apply(dev[0], dev[1], dev[2], csr, dev[3], dev[4], kd, 1e-5)
+    g = torch.autograd.grad((z * cot.cuda()).sum(), dev, retain_graph=True)
+    names = ("dx", "dW_out", "dW_sout", "dgamma", "dbeta")
+    assert_matches(z, z_ref.detach().numpy(), TOL, "z")
+    assert_matches(g[0].transpose(1, 2), g_ref[0].numpy(), TOL, "dx")
+    for got, want, nm in zip(g[1:], g_ref[1:], names[1:]):
+        assert_matches(got, want.numpy(), TOL, nm)
+    monkeypatch.setenv("IGCN_NO_LN_FUSED", "1")
+    g2 = torch.autograd.grad((z * cot.cuda()).sum(), dev)
+    for a, c2, nm in zip(g2, g, names):
+        assert_matches(a, c2.cpu().numpy(), 2e-5, nm + " (two passes)")
+
+
 @pytest.mark.parametrize("dense", [False, True])
 @pytest.mark.parametrize("bsz,pool,seed", [(4, (20, 10, 6, 3, 1), 0), (32, (300, 120, 60, 19, 1), 1),
                                            (37, (1800, 800, 300, 99, 1), 2)])
