@@ -43,6 +43,16 @@ __global__ void k_reduce_rows(const float* __restrict__ partial, int64_t rows, i
 // row groups per column (rows r = g mod 4), combined in the fixed order ((s0 + s1) + s2) + s3: 64 columns x 4 groups per
 // 256-thread workgroup.  Shared by the stand-alone and the deferred reduction so that both give the same bits.
 #define RR_WIDE_ROWS 32
+// Which form sums `rows` partial rows of n columns — ONE rule for the stand-alone launches, the deferred launch and its
+// workgroup count.  0: a thread per column, rows in order (few rows).  Tall (> 32 rows): 1 = a wave per column
+// (n < 16), 2 = 16 x 16 tiles (n <= 4096, or >= 256 rows whatever the width: with four row groups a thread would walk
+// rows / 4 dependent-latency loads — 512 per-sample rows of a LayerNorm's affine partials = 16 batches of 8), 3 = four
+// row groups per column (32 < rows < 256 and wide: fewer, fatter workgroups).
+__host__ __device__ inline int rr_form(int64_t rows, int n) {
+  if (!(rows > RR_WIDE_ROWS)) return 0;
+  if (n < 16) return 1;
+  return (n <= 4096 || rows >= 256) ? 2 : 3;
+}
 __device__ __forceinline__ void reduce_cols_grouped(const float* __restrict__ partial, int64_t rows, int64_t ld, int n,
                                                     float* __restrict__ out, int accumulate, int64_t block,
                                                     float (*lds)[64]) {
@@ -144,8 +154,9 @@ int igcn_launch_reduce_contig(const float* partial, int64_t rows, int n, float* 
 int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int n, float* out, int accumulate,
                             hipStream_t st) {
   if (n <= 0) return IGCN_OK;
-  if (rows > 32 && n <= 4096) {
-    if (n >= 16) {
+  const int form = rr_form(rows, n);
+  if (form == 1 || form == 2) {
+    if (form == 2) {
       hipLaunchKernelGGL(k_reduce_rows_tile16, dim3((unsigned)igcn_cdiv(n, 16)), dim3(256), 0, st, partial, rows, ld, n,
                          out, accumulate);
       IGCN_CHECK_LAUNCH("reduce_rows_tile16");
@@ -156,7 +167,7 @@ int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int 
     IGCN_CHECK_LAUNCH("reduce_rows_par");
     return IGCN_OK;
   }
-  if (rows > RR_WIDE_ROWS) {
+  if (form == 3) {
     hipLaunchKernelGGL(k_reduce_rows_grouped, dim3((unsigned)igcn_cdiv(n, 64)), dim3(256), 0, st, partial, rows, ld, n,
                        out, accumulate);
     IGCN_CHECK_LAUNCH("reduce_rows_grouped");
@@ -199,9 +210,12 @@ __global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t, int32_t* ti
   if (tick && blockIdx.x == 0 && threadIdx.x == 0) *tick += 1;      // the optimiser's step counter (igcn_reduce_flush_tick)
   // flat grid: workgroup -> (entry, block inside the entry).  [A (max blocks) x (entries) grid launched 57 000
   // workgroups for 11 000 with work.]
+  // entry = number of starts at or below blockIdx.x (start[] ascending, unused slots INT_MAX): the whole prefix table is
+  // fetched from the kernel arguments in ONE batch of scalar loads and compared in registers.  [A binary search is six
+  // DEPENDENT scalar loads before the entry itself can be fetched, a linear walk up to 40.]
   int ei = 0;
-  for (int step = 32; step > 0; step >>= 1)          // largest ei with start[ei] <= blockIdx.x (start[] ascending; a
-    if (ei + step < t.count && (int)blockIdx.x >= t.start[ei + step]) ei += step;   // linear walk was 40 dependent loads)
+#pragma unroll
+  for (int i = 1; i < MRQ_MAX; ++i) ei += (int)blockIdx.x >= t.start[i] ? 1 : 0;
   const ReduceEntry e = t.e[ei];
   const int64_t blk = (int64_t)blockIdx.x - t.start[ei];
   if (e.nptr < 0) {                                  // GO attention: parameter gradients from the block partials
@@ -228,12 +242,13 @@ __global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t, int32_t* ti
     }
     return;
   }
-  if (e.rows > RR_WIDE_ROWS && e.n > 4096) {         // tall and wide: grouped rows (k_reduce_rows_grouped)
+  const int form = rr_form(e.rows, e.n);
+  if (form == 3) {                                   // tall and wide: grouped rows (k_reduce_rows_grouped)
     reduce_cols_grouped(e.partial, e.rows, e.ld, e.n, e.out, 0, blk, lds);
     return;
   }
-  if (e.rows > 32 && e.n <= 4096) {                  // tall: 16 x 16 tiles (k_reduce_rows_tile16), or a wave per column
-    if (e.n >= 16) reduce_cols_tile16(e.partial, e.rows, e.ld, e.n, e.out, 0, blk, lds);
+  if (form != 0) {                                   // tall: 16 x 16 tiles (k_reduce_rows_tile16), or a wave per column
+    if (form == 2) reduce_cols_tile16(e.partial, e.rows, e.ld, e.n, e.out, 0, blk, lds);
     else reduce_col_wave(e.partial, e.rows, e.ld, e.n, e.out, 0, blk);
   } else if (rq_wide_vec(e)) {                       // wide, 16-byte rows: four columns per thread, rows in order
     const int64_t j = (blk * 256 + threadIdx.x) * 4;
@@ -291,7 +306,7 @@ static int reduce_flush_locked(hipStream_t st, int32_t* tick = nullptr) {
   if (igcn_opt(IGCN_OPT_DEBUG_REDUCE))
     for (const ReduceEntry& e : g_rq)
       fprintf(stderr, "[igcn] deferred reduction: rows %lld x n %d (ld %lld)%s\n", (long long)e.rows, e.n,
-              (long long)e.ld, e.nptr < 0 ? "  GO attention finish" : e.nptr > 0 ? "  separate buffers" : (e.rows > 32 && e.n <= 4096) ? "  tree" : "  in-order");
+              (long long)e.ld, e.nptr < 0 ? "  GO attention finish" : e.nptr > 0 ? "  separate buffers" : rr_form(e.rows, e.n) ? "  tree" : "  in-order");
   size_t done = 0;
   while (done < g_rq.size()) {
     ReduceTable t = {};
@@ -301,13 +316,14 @@ static int reduce_flush_locked(hipStream_t st, int32_t* tick = nullptr) {
       const ReduceEntry& e = g_rq[done + i];
       t.e[i] = e;
       const int64_t need = e.nptr < 0 ? e.n : e.nptr > 0 ? igcn_cdiv(e.n, 1024)
-                           : (e.rows > 32 && e.n <= 4096) ? igcn_cdiv(e.n, e.n >= 16 ? 16 : 4)
-                                                        : (e.rows > RR_WIDE_ROWS ? igcn_cdiv(e.n, 64)
-                                                                                   : igcn_cdiv(e.n, rq_wide_vec(e) ? 1024 : 256));
+                           : rr_form(e.rows, e.n) == 1 ? igcn_cdiv(e.n, 4)
+                           : rr_form(e.rows, e.n) == 2 ? igcn_cdiv(e.n, 16)
+                           : rr_form(e.rows, e.n) == 3 ? igcn_cdiv(e.n, 64)
+                                                       : igcn_cdiv(e.n, rq_wide_vec(e) ? 1024 : 256);
       t.start[i] = (int)total;
       total += need;
     }
-    t.start[cnt] = (int)total;
+    for (int i = cnt; i <= MRQ_MAX; ++i) t.start[i] = 0x7fffffff;
     t.count = cnt;
     done += cnt;
     hipLaunchKernelGGL(k_multi_reduce, dim3((unsigned)total), dim3(256), 0, st, t, done == g_rq.size() ? tick : nullptr);

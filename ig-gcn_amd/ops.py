@@ -1642,11 +1642,11 @@ class GoDecodeLN(torch.autograd.Function):
         fout, nout = w_out.shape[0], csr.n_rows
         assert csr.n_cols == nin
         y = torch.empty(b, fout, nout, dtype=torch.float32, device=x.device)
-        call("igcn_go_decode_fwd", b, nin, nout, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(x), ptr(w_out),
-             ptr(w_sout), ptr(y), stream_ptr())
         z = torch.empty_like(y)
         mean = torch.empty(b * fout, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
+        call("igcn_go_decode_fwd", b, nin, nout, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(x), ptr(w_out),
+             ptr(w_sout), ptr(y), stream_ptr())
         call("igcn_nodes_ln_fwd", b, fout, nout, 0, float(eps), ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(z),
              ptr(mean), ptr(rstd), stream_ptr())
         ctx.save_for_backward(x, w_out, w_sout, y, gamma, beta, keep, mean, rstd)

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 319
+#define IGCN_ABI_VERSION 320
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
