@@ -541,8 +541,10 @@ extern "C" int igcn_spmm_bwd_dval_multi(int n, const int64_t* table, void* strea
 // =================================================================================================
 // hardware exp2-based exp / tanh (v_exp_f32): ~1e-6 relative / ~1e-7 absolute error, a fraction of the instructions
 // of the libm versions; the attention kernels evaluate one tanh + one exp per edge per sample
+// (reciprocals on v_rcp_f32, 1 ulp: a plain `/` is the IEEE sequence — ten VALU instructions per edge per sample)
 __device__ __forceinline__ float go_exp(float z) { return __expf(z); }
-__device__ __forceinline__ float go_tanh(float z) { return 1.f - 2.f / (1.f + __expf(2.f * z)); }
+__device__ __forceinline__ float go_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float go_tanh(float z) { return 1.f - 2.f * go_rcp(1.f + __expf(2.f * z)); }
 
 template <int FIN, int FOUT>
 struct AttnW {
@@ -642,8 +644,8 @@ k_go_attn_fwd(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restr
       for (int c = 0; c < FOUT; ++c) agg[c] += s1 * xi1[c];
     }
   }
-  const float zinv = p1 > p0 ? 1.f / Z : 0.f;
-  const float g = 1.f / (1.f + go_exp(-dot<FOUT>(W.as, xs)));
+  const float zinv = p1 > p0 ? go_rcp(Z) : 0.f;
+  const float g = go_rcp(1.f + go_exp(-dot<FOUT>(W.as, xs)));
   float* yb = y + (int64_t)b * FOUT * N;
 #pragma unroll
   for (int c = 0; c < FOUT; ++c) yb[c * N + n] = agg[c] * zinv + xs[c] * g;
@@ -696,7 +698,7 @@ struct RowPass {
   }
   // (1/Z, tr, dp)
   __device__ __forceinline__ void end(bool any, float& zinv, float& tr, float& dp) const {
-    zinv = any ? 1.f / Z : 0.f;
+    zinv = any ? go_rcp(Z) : 0.f;
     tr = A * zinv;
     dp = (Bw - tr * Cw) * zinv;
   }
@@ -863,7 +865,7 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
 #pragma unroll
     for (int c = 0; c < FOUT; ++c) dxin[c] += dp * W.a1[c] + dq * W.a2[c];
     // gated self term
-    const float g = 1.f / (1.f + go_exp(-dot<FOUT>(W.as, xs)));
+    const float g = go_rcp(1.f + go_exp(-dot<FOUT>(W.as, xs)));
     const float dgate = dot<FOUT>(dyn, xs) * g * (1.f - g);
     float dxs[FOUT];
 #pragma unroll
@@ -1314,7 +1316,7 @@ k_go_attn_bwd_lds(int N, const int32_t* __restrict__ row_ptr, const int32_t* __r
       if (live) {
 #pragma unroll
         for (int c = 0; c < FOUT; ++c) dxin[c] += dp * W.a1[c] + dq * W.a2[c];
-        const float g = 1.f / (1.f + go_exp(-dot<FOUT>(W.as, xsl)));       // gated self term
+        const float g = go_rcp(1.f + go_exp(-dot<FOUT>(W.as, xsl)));       // gated self term
         const float dgate = dot<FOUT>(dyn, xsl) * g * (1.f - g);
         float dxs[FOUT];
 #pragma unroll

@@ -47,16 +47,20 @@ struct DsReg {                                   // loss_probability's constants
 // The mask is evaluated once per edge in EVERY edge pass (six times per train step) instead of being stored: hardware
 // exp / reciprocal / log (v_exp_f32, v_rcp_f32, v_log_f32: ~1e-6 relative) keep that at a handful of instructions.
 // Every pass uses the same function, so forward and backward see the same mask.
-__device__ __forceinline__ float ds_sigmoid(float z) { return __frcp_rn(1.f + __expf(-z)); }
+// [ds_rcp: v_rcp_f32, 1 ulp.  __frcp_rn — what these functions used first — is the correctly rounded reciprocal: ten
+// VALU instructions (v_div_scale x 2, v_rcp, four v_fma, v_div_fmas, v_div_fixup); four masks per aggregation step made
+// k_ds_agg issue-bound at 3.1 us of VALU + MFMA per wave, two waves per SIMD: 9.1 us whether ew came from HBM or L2.]
+__device__ __forceinline__ float ds_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float ds_sigmoid(float z) { return ds_rcp(1.f + __expf(-z)); }
 // edge mask from the per-node factors a[s] = exp(-u[s]), b[d] = exp(-v[d]): sigmoid(u + v) = 1 / (1 + a b) — one
 // multiply-add and one reciprocal per edge, no exponential (a b = inf -> 0, a b = 0 -> 1: the right limits)
-__device__ __forceinline__ float ds_mask(float a, float b) { return __frcp_rn(fmaf(a, b, 1.f)); }
+__device__ __forceinline__ float ds_mask(float a, float b) { return ds_rcp(fmaf(a, b, 1.f)); }
 __device__ __forceinline__ float ds_reg_term(float p, float l1, float ent, float eps) {
   return l1 * p - ent * (p * __logf(p + eps) + (1.f - p) * __logf((1.f - p) + eps));          // p in (0, 1)
 }
 __device__ __forceinline__ float ds_reg_grad(float p, float l1, float ent, float eps) {
   const float a = p + eps, b = (1.f - p) + eps;
-  return l1 - ent * (__logf(a) + p * __frcp_rn(a) - __logf(b) - (1.f - p) * __frcp_rn(b));
+  return l1 - ent * (__logf(a) + p * ds_rcp(a) - __logf(b) - (1.f - p) * ds_rcp(b));
 }
 
 // loss_probability's term of an EDGE mask p = sigmoid(z), from p and its logit z = u[s] + v[d]:
@@ -439,6 +443,7 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
       for (int r = 0; r < 4; ++r)
         part[((w * NC + c) * 64 + 16 * sub + 4 * r + t) * DS_F + q] = acc[c][t][r];
   __syncthreads();
+  DS_PROBE(4);
   for (int o = tid; o < NC * 64 * DS_F; o += 512) {
     const int f = o & 15, dl = (o >> 4) & 63, c = o >> 10;
     float a = 0.f;

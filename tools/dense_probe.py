@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase times inside k_ds_agg (dense-block aggregation, configs[4] shape): build with IGCN_HIPCC_EXTRA=-DDS_PROBE_ON.
-Stamps per wave of the 8 workgroups of graph 0: 0 start, 1 operands staged, 2 loads issued, 3 walk done, 4 barrier passed,
-5 reduced + stored, 6 next layer's operands written (layer 1 launch only: the last launch overwrites the buffer)."""
+Stamps per wave of the 8 workgroups of graph 0 (ns after the wave's start): 3 walk done, 4 barrier passed, 5 reduced +
+stored, 6 next layer's operands written (only when a layer follows)."""
 import ctypes
 import os
 import sys
@@ -31,10 +31,9 @@ raw = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_longlong * 512)()
 print("rc", raw.igcn_debug_ds_probe(buf))
 t0 = min(buf[(wg * 8 + w) * 8] for wg in range(8) for w in range(8))
-names = ["stage", "issue", "walk", "barrier", "reduce+store", "next"]
-for wg in (0, 3, 7):
-    for w in (0, 3, 7):
-        t = [buf[(wg * 8 + w) * 8 + i] for i in range(6)]
+names = {3: "walk done", 4: "barrier passed", 5: "reduced + stored", 6: "next layer's operands"}
+for wg in (0, 5):
+    for w in range(8):
+        t = [buf[(wg * 8 + w) * 8 + i] for i in range(7)]
         print(f"wg {wg} wave {w}: start +{(t[0] - t0) * 10:5d} ns  " +
-              "  ".join(f"{nm} {(t[i + 1] - t[i]) * 10:5d}" for i, nm in enumerate(names[:5])) +
-              f"  total {(t[5] - t[0]) * 10} ns")
+              "  ".join(f"{nm} +{(t[i] - t[0]) * 10:5d}" for i, nm in names.items() if t[i] >= t[0]))
