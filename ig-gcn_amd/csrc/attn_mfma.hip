@@ -112,6 +112,19 @@ __device__ __forceinline__ void am_store4(float* __restrict__ p, int c0, int hd,
   }
 }
 
+// workgroup -> (sample, head) item of a B * H launch.  The hardware deals workgroup i to XCD i mod 8, and the H heads
+// of a sample read the two halves of the SAME 128-byte lines of q / kv / dO (a [.., H * head_dim] row per token): with
+// item = blockIdx the two heads of a sample sat on different XCDs, i.e. different L2s, and every line came from HBM
+// twice — the K | V staging of the forward (768 workgroups at once) took 8-16 us for 39 MB.  Here XCD x takes the
+// items [x per, (x + 1) per) in order: a sample's heads are neighbours in ONE L2.  Grid = 8 per (am_grid); -1 = no item.
+__host__ __device__ inline int am_per_xcd(int items) { return (items + 7) >> 3; }
+static inline unsigned am_grid(int items) { return 8u * (unsigned)am_per_xcd(items); }
+__device__ __forceinline__ int am_item(int items) {
+  const int per = am_per_xcd(items), slot = (int)(blockIdx.x >> 3);
+  const int id = (int)(blockIdx.x & 7) * per + slot;
+  return id < items ? id : -1;
+}
+
 #ifdef AM_PROBE_ON
 __device__ long long am_probe_buf[16 * 8];
 #define AM_PROBE(i) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x % 128) == 0 && (threadIdx.x >> 6) < 2) { am_probe_buf[((blockIdx.x / 128) * 2 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64(); } } while (0)
@@ -126,7 +139,7 @@ extern "C" int igcn_debug_attn_probe(long long* out) {
 template <int HDP, bool EXACT>
 __global__ void __launch_bounds__(64 * AM_MAX_WAVES)
 k_attn_mfma_fwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __restrict__ q,
-                const float* __restrict__ kv, float* __restrict__ o, float* __restrict__ lse) {
+                const float* __restrict__ kv, float* __restrict__ o, float* __restrict__ lse, int items) {
   // HDP == 16 (the bench model: two heads of 16): UNPADDED 16-float rows, 51 KB per workgroup at 400 keys instead of
   // 54 KB — three workgroups per CU instead of two, i.e. one can stage while two compute.  Conflict-free without the
   // pad column because (a) K's 4-column groups are XOR-swizzled with bits 2-3 of the row, and (b) the rows of a key
@@ -136,7 +149,9 @@ k_attn_mfma_fwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __res
   constexpr int LD = FLAT ? HDP : HDP + 1, NC = HDP / 4, NO = (HDP + 15) / 16;
   const int hd = EXACT ? HDP : hd_rt, vec = EXACT ? 1 : vec_rt;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * hd;
+  const int item = am_item(items);
+  if (item < 0) return;                                          // workgroup-uniform, before any barrier
+  const int b = item / H, h = item % H, D = H * hd;
   const int Lkp = (Lk + 15) & ~15, nkt = Lkp >> 4, nqt = (Lq + 15) >> 4;
   float* Ks = smem;
   float* Vs = Ks + (size_t)Lkp * LD;
@@ -233,11 +248,13 @@ template <int HDP, bool EXACT>
 __global__ void __launch_bounds__(64 * AM_MAX_WAVES)
 k_attn_mfma_bwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __restrict__ q,
                 const float* __restrict__ kv, const float* __restrict__ o, const float* __restrict__ lse,
-                const float* __restrict__ dout, float* __restrict__ dq, float* __restrict__ dkv) {
+                const float* __restrict__ dout, float* __restrict__ dq, float* __restrict__ dkv, int items) {
   constexpr int LD = HDP + 1, NC = HDP / 4, NO = (HDP + 15) / 16;
   const int hd = EXACT ? HDP : hd_rt, vec = EXACT ? 1 : vec_rt;
   extern __shared__ float smem[];
-  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * hd;
+  const int item = am_item(items);
+  if (item < 0) return;                                          // workgroup-uniform, before any barrier
+  const int b = item / H, h = item % H, D = H * hd;
   const int Lkp = (Lk + 15) & ~15, Lqp = (Lq + 15) & ~15, nkt = Lkp >> 4, nqt = Lqp >> 4;
   float* Ks = smem;
   float* Vs = Ks + (size_t)Lkp * LD;
@@ -412,10 +429,12 @@ template <int NQT>
 __global__ void __launch_bounds__(64 * 8)
 k_attn_mfma_bwd_shared(int H, int Lq, int Lk, const float* __restrict__ q, const float* __restrict__ kv,
                        const float* __restrict__ o, const float* __restrict__ lse, const float* __restrict__ dout,
-                       float* __restrict__ dq, float* __restrict__ dkv) {
+                       float* __restrict__ dq, float* __restrict__ dkv, int items) {
   constexpr int HDP = 16, LD = HDP + 1, NC = HDP / 4, hd = HDP;
   extern __shared__ float smem[];
-  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * hd;
+  const int item = am_item(items);
+  if (item < 0) return;                                          // workgroup-uniform, before any barrier
+  const int b = item / H, h = item % H, D = H * hd;
   const int Lkp = (Lk + 15) & ~15, Lqp = NQT * 16, nkt = Lkp >> 4;
   float* Ks = smem;
   float* Vs = Ks + (size_t)Lkp * LD;
@@ -593,11 +612,11 @@ int igcn_attn_mfma_fwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
     IGCN_ALLOW_BIG_LDS((k_attn_mfma_fwd<HDPV, true>));                                        \
     IGCN_ALLOW_BIG_LDS((k_attn_mfma_fwd<HDPV, false>));                                        \
     if (vec && hd == HDPV)                                                                                       \
-      hipLaunchKernelGGL((k_attn_mfma_fwd<HDPV, true>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq,  \
-                         Lk, q, kv, o, lse);                                                                     \
+      hipLaunchKernelGGL((k_attn_mfma_fwd<HDPV, true>), dim3(am_grid(B * H)), dim3(64 * waves), lds, st, H, hd, vec, \
+                         Lq, Lk, q, kv, o, lse, B * H);                                                                     \
     else                                                                                                         \
-      hipLaunchKernelGGL((k_attn_mfma_fwd<HDPV, false>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq, \
-                         Lk, q, kv, o, lse);                                                                     \
+      hipLaunchKernelGGL((k_attn_mfma_fwd<HDPV, false>), dim3(am_grid(B * H)), dim3(64 * waves), lds, st, H, hd, vec, \
+                         Lq, Lk, q, kv, o, lse, B * H);                                                                     \
   }
   AM_DISPATCH(am_hdp(hd), CALL)
 #undef CALL
@@ -621,8 +640,8 @@ int igcn_attn_mfma_bwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
 #define CALLS(NQTV)                                                                                              \
   case NQTV:                                                                                                     \
     IGCN_ALLOW_BIG_LDS((k_attn_mfma_bwd_shared<NQTV>));                                                          \
-    hipLaunchKernelGGL((k_attn_mfma_bwd_shared<NQTV>), dim3(B * H), dim3(64 * 8), lds2, st, H, Lq, Lk, q, kv, o,  \
-                       lse, dout, dq, dkv);                                                                      \
+    hipLaunchKernelGGL((k_attn_mfma_bwd_shared<NQTV>), dim3(am_grid(B * H)), dim3(64 * 8), lds2, st, H, Lq, Lk, q, \
+                       kv, o, lse, dout, dq, dkv, B * H);                                                        \
     break;
       switch (nqt) { CALLS(1) CALLS(2) CALLS(3) CALLS(4) CALLS(5) CALLS(6) CALLS(7) CALLS(8) }
 #undef CALLS
@@ -635,11 +654,11 @@ int igcn_attn_mfma_bwd(int B, int D, int H, int Lq, int Lk, const float* q, cons
     IGCN_ALLOW_BIG_LDS((k_attn_mfma_bwd<HDPV, true>));                                        \
     IGCN_ALLOW_BIG_LDS((k_attn_mfma_bwd<HDPV, false>));                                        \
     if (vec && hd == HDPV)                                                                                       \
-      hipLaunchKernelGGL((k_attn_mfma_bwd<HDPV, true>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq,  \
-                         Lk, q, kv, o, lse, dout, dq, dkv);                                                      \
+      hipLaunchKernelGGL((k_attn_mfma_bwd<HDPV, true>), dim3(am_grid(B * H)), dim3(64 * waves), lds, st, H, hd, vec, \
+                         Lq, Lk, q, kv, o, lse, dout, dq, dkv, B * H);                                           \
     else                                                                                                         \
-      hipLaunchKernelGGL((k_attn_mfma_bwd<HDPV, false>), dim3(B * H), dim3(64 * waves), lds, st, H, hd, vec, Lq, \
-                         Lk, q, kv, o, lse, dout, dq, dkv);                                                      \
+      hipLaunchKernelGGL((k_attn_mfma_bwd<HDPV, false>), dim3(am_grid(B * H)), dim3(64 * waves), lds, st, H, hd, vec, \
+                         Lq, Lk, q, kv, o, lse, dout, dq, dkv, B * H);                                           \
   }
   AM_DISPATCH(am_hdp(hd), CALL)
 #undef CALL

@@ -418,6 +418,17 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
         }
     }
   };
+  // epilogue operands of this thread (its (copy, target, feature) slots o = tid + 512 k and its row of W_next): requested
+  // before the walk — behind the barrier each was a global round trip in front of the stores
+  constexpr int EPI = NC * 64 * DS_F / 512;
+  float e_dis[EPI], e_bias = bias[tid & 15], e_w[DS_F];
+#pragma unroll
+  for (int k = 0; k < EPI; ++k) {
+    const int o = tid + 512 * k, dl = (o >> 4) & 63, c = o >> 10;
+    e_dis[k] = dis[(int64_t)c * GR + nb + d0 + dl];
+  }
+#pragma unroll
+  for (int f = 0; f < DS_F; ++f) e_w[f] = Wnext ? Wnext[(tid & 15) * DS_F + f] : 0.f;
   DS_PROBE(0);
   // Measured at 512-node graphs, both passes (us per launch; 42.4 MB of HBM traffic by the PMC counters = the bytes the
   // kernel has to move; 0.54 GFLOP of exact-fp32 MFMA = 3.4 us at peak, ~5 us of walk time by the phase probe):
@@ -444,27 +455,29 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
         part[((w * NC + c) * 64 + 16 * sub + 4 * r + t) * DS_F + q] = acc[c][t][r];
   __syncthreads();
   DS_PROBE(4);
-  for (int o = tid; o < NC * 64 * DS_F; o += 512) {
-    const int f = o & 15, dl = (o >> 4) & 63, c = o >> 10;
+#pragma unroll
+  for (int k = 0; k < EPI; ++k) {
+    const int o = tid + 512 * k, f = o & 15, dl = (o >> 4) & 63, c = o >> 10;
     float a = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 8; ++ww) a += part[((ww * NC + c) * 64 + dl) * DS_F + f];
     const int64_t node = (int64_t)c * GR + nb + d0 + dl;
     agg[node * DS_F + f] = a;
-    const float y = fmaxf(dis[node] * a + bias[f], 0.f);
+    const float y = fmaxf(e_dis[k] * a + e_bias, 0.f);
     xcat[node * ldx + col0 + f] = y;
     ys[(c * 64 + dl) * DS_F + f] = y;
   }
   DS_PROBE(5);
   if (Wnext == nullptr) return;
   __syncthreads();
-  for (int o = tid; o < NC * 64 * DS_F; o += 512) {
-    const int fo = o & 15, dl = (o >> 4) & 63, c = o >> 10;
+#pragma unroll
+  for (int k = 0; k < EPI; ++k) {
+    const int o = tid + 512 * k, dl = (o >> 4) & 63, c = o >> 10;     // output feature = tid & 15
     float a = 0.f;
 #pragma unroll
-    for (int f = 0; f < DS_F; ++f) a += ys[(c * 64 + dl) * DS_F + f] * Wnext[fo * DS_F + f];
+    for (int f = 0; f < DS_F; ++f) a += ys[(c * 64 + dl) * DS_F + f] * e_w[f];
     const int64_t node = (int64_t)c * GR + nb + d0 + dl;
-    hp_next[node * DS_F + fo] = dis[node] * a;
+    hp_next[node * DS_F + (tid & 15)] = e_dis[k] * a;
   }
   DS_PROBE(6);
 }
