@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 320        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 321        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -137,7 +137,7 @@ SIGNATURES = {
     "igcn_go_attn_ln_fused_ok": (I, [I, I, I, I]),
     "igcn_go_decode_ln_fused_ok": (I, [I, I, I, I]),
     "igcn_go_ln_part_floats": (Z, [I, I]),
-    "igcn_go_attn_ln_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, P, I] + [P] * 13),
+    "igcn_go_attn_ln_bwd": (I, [I, I, I, I, P, P, P, P, P, P, P, P, P, P, I] + [P] * 15),
     "igcn_go_decode_ln_bwd": (I, [I, I, I, I, I] + [P] * 19),
     "igcn_go_decode_bwd_scratch_floats": (Z, [I, I, I, I]),
     "igcn_go_decode_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),

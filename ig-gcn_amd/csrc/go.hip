@@ -999,6 +999,7 @@ struct LnFuse {
   const float *y, *dz, *gamma, *beta, *keep, *mean, *rstd;
   float* part;
   int pool;
+  const float *dz2, *dz3;          // further consumers' gradients of z (same layout as dz), added on load in this order; or NULL
 };
 
 // sum over the 16 lanes of a DPP row, in every lane of the row (quad permutes, then the half-row and row mirrors)
@@ -1058,6 +1059,20 @@ __device__ __forceinline__ void ln_bwd_into_lds(const LnFuse& L, int b, int N, f
     rs[c] = L.rstd[row];
     yv[c] = live ? ld4(L.y + row * N + n) : zero4;
     up[c] = act ? ld4(L.dz + row * M + (n - L.pool)) : zero4;
+  }
+  if (L.dz2) {                                          // workgroup-uniform: z had several consumers (igcn_sum_n's order)
+#pragma unroll
+    for (int c = 0; c < FOUT; ++c) {
+      const int64_t off = ((int64_t)b * FOUT + c) * M + (n - L.pool);
+      if (act) {
+        const float4 t = ld4(L.dz2 + off);
+        up[c].x += t.x; up[c].y += t.y; up[c].z += t.z; up[c].w += t.w;
+        if (L.dz3) {
+          const float4 t3 = ld4(L.dz3 + off);
+          up[c].x += t3.x; up[c].y += t3.y; up[c].z += t3.z; up[c].w += t3.w;
+        }
+      }
+    }
   }
   if (live) g = ld4(L.gamma + n);
   if (act) {
@@ -1589,14 +1604,17 @@ extern "C" int igcn_go_attn_ln_bwd(int B, int N, int fin, int fout, const int32_
                                    const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order,
                                    const float* x, const float* w_inc, const float* w_s, const float* a_in,
                                    const float* a_s, int pool, const float* y, const float* gamma, const float* beta,
-                                   const float* keep, const float* mean, const float* rstd, const float* dz, float* dx,
-                                   float* dparams, float* dgb, float* scratch, float* part, void* stream) {
+                                   const float* keep, const float* mean, const float* rstd, const float* dz,
+                                   const float* dz2, const float* dz3, float* dx, float* dparams, float* dgb,
+                                   float* scratch, float* part, void* stream) {
   IGCN_REQUIRE(B > 0 && N > 0, "go_attn_ln_bwd: bad sizes");
   IGCN_REQUIRE(igcn_go_attn_ln_fused_ok(N, fin, fout, pool), "go_attn_ln_bwd: sizes not supported (igcn_go_attn_ln_fused_ok)");
   IGCN_REQUIRE(y && gamma && beta && mean && rstd && dz && dgb && part, "go_attn_ln_bwd: null operand");
   IGCN_REQUIRE(go_ln_al16(x) && go_ln_al16(y) && go_ln_al16(dz) && go_ln_al16(gamma) && go_ln_al16(beta) &&
-               go_ln_al16(keep) && go_ln_al16(part) && go_ln_al16(dx), "go_attn_ln_bwd: operands must be 16-byte aligned");
-  const LnFuse L = {y, dz, gamma, beta, keep, mean, rstd, part, pool};
+               go_ln_al16(keep) && go_ln_al16(part) && go_ln_al16(dx) && go_ln_al16(dz2) && go_ln_al16(dz3),
+               "go_attn_ln_bwd: operands must be 16-byte aligned");
+  IGCN_REQUIRE(dz2 != nullptr || dz3 == nullptr, "go_attn_ln_bwd: dz3 without dz2");
+  const LnFuse L = {y, dz, gamma, beta, keep, mean, rstd, part, pool, dz2, dz3};
   const int rc = go_attn_bwd_impl(B, N, fin, fout, row_ptr, col, t_ptr, t_row, walk_order, x, w_inc, w_s, a_in, a_s,
                                   nullptr, dx, dparams, scratch, L, (hipStream_t)stream);
   if (rc) return rc;
@@ -2531,7 +2549,7 @@ extern "C" int igcn_go_decode_ln_bwd(int B, int Nin, int Nout, int fin, int fout
   IGCN_REQUIRE(y && gamma && beta && mean && rstd && dz && dgb && part, "go_decode_ln_bwd: null operand");
   IGCN_REQUIRE(go_ln_al16(y) && go_ln_al16(dz) && go_ln_al16(gamma) && go_ln_al16(beta) && go_ln_al16(keep) &&
                go_ln_al16(part), "go_decode_ln_bwd: operands must be 16-byte aligned");
-  const LnFuse L = {y, dz, gamma, beta, keep, mean, rstd, part, 0};
+  const LnFuse L = {y, dz, gamma, beta, keep, mean, rstd, part, 0, nullptr, nullptr};
   const int rc = go_decode_bwd_impl(B, Nin, Nout, fin, fout, row_ptr, t_ptr, t_row, x, w_out, w_sout, nullptr, dx,
                                     dparams, scratch, L, (hipStream_t)stream);
   if (rc) return rc;

@@ -154,9 +154,16 @@ class Gene_ontology_network(nn.Module):
             # layer + LayerNorm block as ONE autograd node: its backward is one launch when the layer runs LDS-resident
             # (ops.GoAttentionLN).  Leaves (no .view(-1): a view's gradient would pass through another backward node, and
             # the op could not defer its final reductions)
+            # the encoder OUTPUT has three consumers (two read-outs, the decoder): the last layer hands out three
+            # aliases and its backward adds their gradients while it loads them — no sum launch, no autograd adds
+            fan = 3 if (j == self.n_l - 1 and x.is_cuda and torch.is_grad_enabled()
+                        and os.environ.get("IGCN_NO_GRAD_FAN", "0") != "1") else 1
             x = ops.GoAttentionLN.apply(x, self.w_inc[j].weight, self.w_s_loop[j].weight, self.w_att_in[j].weight,
                                         self.w_att_s[j].weight, csr, self.G_B[j].weight, self.G_B[j].bias, keeps[j],
-                                        self.pool[j], self.G_B[j].eps)
+                                        self.pool[j], self.G_B[j].eps, fan)
+        x_fan = None
+        if isinstance(x, tuple):
+            x_fan, x = x[:2], x[2]
         # read-outs (:254-255): BatchNorm1d(n_top) normalises per NODE over (batch, feature); fused kernels
         bn_a, bn_i = self.conc_for_attention[1], self.B[0]
         if ops.node_linear_bn_pair_supported(x, self.conc_for_attention[0].weight, self.conc.weight, None) \
@@ -164,7 +171,9 @@ class Gene_ontology_network(nn.Module):
             # both read-outs of the encoder output in paired launches.  The encoder output has three consumers (two
             # read-outs, the decoder): their gradients are summed in one launch (ops.GradFan), not by two adds
             x_alias = None
-            if x.requires_grad and x.is_cuda and os.environ.get("IGCN_NO_GRAD_FAN", "0") != "1":
+            if x_fan is not None:
+                x_pair, x_alias = x_fan
+            elif x.requires_grad and x.is_cuda and os.environ.get("IGCN_NO_GRAD_FAN", "0") != "1":
                 x_pair, x_alias, x = ops.GradFan.apply(x, 3)
             else:
                 x_pair = x
@@ -176,8 +185,9 @@ class Gene_ontology_network(nn.Module):
                 bn_i.momentum, bn_i.eps, masks["inp"], self.training, groups)
             inp_out = inp_out.squeeze(2)
         else:
-            atten_out = self._node_linear_bn(x, self.conc_for_attention[0].weight, bn_a, groups)
-            inp_out = self._node_linear_bn(x, self.conc.weight, bn_i, groups, masks["inp"]).squeeze(2)
+            xa, xi = x_fan if x_fan is not None else (x, x)
+            atten_out = self._node_linear_bn(xa, self.conc_for_attention[0].weight, bn_a, groups)
+            inp_out = self._node_linear_bn(xi, self.conc.weight, bn_i, groups, masks["inp"]).squeeze(2)
         # decoder (:258-275)
         for j in range(self.n_l):
             csr = self.dec_csr[j]

@@ -1581,7 +1581,10 @@ class GoAttentionLN(torch.autograd.Function):
     the backward passes of the two ops in sequence (same arithmetic per element)."""
 
     @staticmethod
-    def forward(ctx, x, w_inc, w_s, a_in, a_s, csr, gamma, beta, keep, pool, eps):
+    def forward(ctx, x, w_inc, w_s, a_in, a_s, csr, gamma, beta, keep, pool, eps, fan=1):
+        """``fan`` > 1: returns that many aliases of z, one per consumer (the encoder output feeds two read-outs and the
+        decoder); the backward adds their gradients while it loads them (``dz2`` / ``dz3`` of igcn_go_attn_ln_bwd)
+        instead of a sum launch in front of it (ops.GradFan)."""
         x, w_inc, w_s, a_in, a_s = _f32(x), _f32(w_inc), _f32(w_s), _f32(a_in), _f32(a_s)
         gamma, beta = _f32(gamma), _f32(beta)
         keep = _f32(keep) if keep is not None else None
@@ -1596,21 +1599,42 @@ class GoAttentionLN(torch.autograd.Function):
         call("igcn_nodes_ln_fwd", b, fout, n, pool, float(eps), ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(z),
              ptr(mean), ptr(rstd), stream_ptr())
         ctx.save_for_backward(x, w_inc, w_s, a_in, a_s, y, gamma, beta, keep, mean, rstd)
-        ctx.csr, ctx.pool = csr, pool
+        ctx.csr, ctx.pool, ctx.fan = csr, pool, fan
         ctx.final_attn, ctx.final_ln = _leaves(w_inc, w_s, a_in, a_s), _leaves(gamma, beta)
+        if fan > 1:
+            ctx.set_materialize_grads(False)
+            return tuple(z.view_as(z) for _ in range(fan))
         return z
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, *dzs):
         x, w_inc, w_s, a_in, a_s, y, gamma, beta, keep, mean, rstd = ctx.saved_tensors
         csr, pool = ctx.csr, ctx.pool
-        dz = _f32(dz)
         b, fin, n = x.shape
         fout = w_inc.shape[0]
         lib = _lib.load()
         k = fout * fin
-        if lib.igcn_go_attn_ln_fused_ok(n, fin, fout, pool) and _al16(x, y, dz, gamma, beta, keep) \
-                and os.environ.get("IGCN_NO_LN_FUSED", "0") != "1":
+        gs = [_f32(g) for g in dzs if g is not None]
+        none = (None,) * 12
+        if not gs:
+            return none
+        fused = bool(lib.igcn_go_attn_ln_fused_ok(n, fin, fout, pool)) and _al16(x, y, gamma, beta, keep, *gs) \
+            and os.environ.get("IGCN_NO_LN_FUSED", "0") != "1"
+        if len(gs) > 1 and not (fused and len(gs) <= 3):
+            # several consumers, no fused path to add them on load: one sum launch (what ops.GradFan does)
+            total = torch.empty_like(gs[0])
+            if len(gs) <= 4 and _al16(*gs):
+                arr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+                call("igcn_sum_n", total.numel(), len(gs), arr, ptr(total), stream_ptr())
+            else:
+                total = gs[0]
+                for g in gs[1:]:
+                    total = total + g
+            gs = [total]
+        dz = gs[0]
+        dz2 = gs[1] if len(gs) > 1 else None
+        dz3 = gs[2] if len(gs) > 2 else None
+        if fused:
             dx = torch.empty_like(x)
             dpar = torch.empty(2 * k + 3 * fout, dtype=torch.float32, device=x.device)
             dgb = torch.empty(2, n, dtype=torch.float32, device=x.device)
@@ -1620,14 +1644,14 @@ class GoAttentionLN(torch.autograd.Function):
             with _immediate(ctx.final_attn and ctx.final_ln):
                 call("igcn_go_attn_ln_bwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(csr.t_ptr),
                      ptr(csr.t_row), ptr(csr.walk_order(fin, fout)), ptr(x), ptr(w_inc), ptr(w_s), ptr(a_in), ptr(a_s),
-                     pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean), ptr(rstd), ptr(dz), ptr(dx), ptr(dpar),
-                     ptr(dgb), ptr(scratch), ptr(part), stream_ptr())
+                     pool, ptr(y), ptr(gamma), ptr(beta), ptr(keep), ptr(mean), ptr(rstd), ptr(dz), ptr(dz2), ptr(dz3),
+                     ptr(dx), ptr(dpar), ptr(dgb), ptr(scratch), ptr(part), stream_ptr())
         else:
             dy, dgb = _nodes_ln_backward(y, gamma, beta, keep, mean, rstd, pool, ctx.final_ln, dz)
             dx, dpar = _go_attn_backward(x, w_inc, w_s, a_in, a_s, csr, ctx.final_attn, dy)
         return (dx, dpar[:k].view(fout, fin), dpar[k:2 * k].view(fout, fin),
                 dpar[2 * k:2 * k + 2 * fout].view_as(a_in), dpar[2 * k + 2 * fout:].view_as(a_s), None,
-                dgb[0], dgb[1], None, None, None)
+                dgb[0], dgb[1], None, None, None, None)
 
 
 class GoDecodeLN(torch.autograd.Function):

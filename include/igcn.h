@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 320
+#define IGCN_ABI_VERSION 321
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -679,7 +679,9 @@ int igcn_nodes_ln_bwd_affine_multi(int n, const int64_t* table, void* stream);
  * in part [B][2][N], reduced over samples by the (deferred) final reduction into dgb [2, N].  igcn_go_*_ln_fused_ok:
  * 1 when the sizes qualify (LDS-resident layer, N and pool multiples of 4, N / 4 <= workgroup size); otherwise use
  * igcn_nodes_ln_bwd* followed by igcn_go_attn_bwd / igcn_go_decode_bwd.  Every tensor 16-byte aligned.  dx, dparams and
- * scratch as the plain entry points; part: igcn_go_ln_part_floats(B, N) floats, alive until the reductions ran. */
+ * scratch as the plain entry points; part: igcn_go_ln_part_floats(B, N) floats, alive until the reductions ran.
+ * igcn_go_attn_ln_bwd's dz2 / dz3: when z feeds several consumers (the encoder output: two read-outs and the decoder) their
+ * gradients are added while they are loaded, in that order — the sum igcn_sum_n would have written. */
 int igcn_go_attn_ln_fused_ok(int N, int fin, int fout, int pool);
 int igcn_go_decode_ln_fused_ok(int Nin, int Nout, int fin, int fout);
 size_t igcn_go_ln_part_floats(int B, int N);
@@ -687,8 +689,9 @@ int igcn_go_attn_ln_bwd(int B, int N, int fin, int fout, const int32_t* row_ptr,
                         const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order,
                         const float* x, const float* w_inc, const float* w_s, const float* a_in, const float* a_s,
                         int pool, const float* y, const float* gamma, const float* beta, const float* keep,
-                        const float* mean, const float* rstd, const float* dz, float* dx, float* dparams, float* dgb,
-                        float* scratch, float* part, void* stream);
+                        const float* mean, const float* rstd, const float* dz, const float* dz2 /*or NULL*/,
+                        const float* dz3 /*or NULL*/, float* dx, float* dparams, float* dgb, float* scratch, float* part,
+                        void* stream);
 int igcn_go_decode_ln_bwd(int B, int Nin, int Nout, int fin, int fout, const int32_t* row_ptr,
                           const int32_t* t_ptr, const int32_t* t_row, const float* x, const float* w_out,
                           const float* w_sout, const float* y, const float* gamma, const float* beta,

@@ -571,9 +571,23 @@ def test_go_attention_with_layernorm_backward_in_one_launch(ops, monkeypatch, bs
     for got, want, nm in zip(g[1:], g_ref[1:], names[1:]):
         assert_matches(got, want.numpy(), TOL, nm)
     monkeypatch.setenv("IGCN_NO_LN_FUSED", "1")
-    g2 = torch.autograd.grad((z * cot.cuda()).sum(), dev)
+    g2 = torch.autograd.grad((z * cot.cuda()).sum(), dev, retain_graph=True)
     for a, c2, nm in zip(g2, g, names):
         assert_matches(a, c2.cpu().numpy(), 2e-5, nm + " (two passes)")
+    monkeypatch.delenv("IGCN_NO_LN_FUSED")
+    # three consumers of z (fan = 3): their gradients are added while the backward loads them — the same bits as one
+    # consumer holding their (in-order) sum
+    z3 = ops.GoAttentionLN.apply(dev[0], dev[1], dev[2], dev[3], dev[4], csr, dev[5], dev[6], kd, drop, 1e-5, 3)
+    assert isinstance(z3, tuple) and len(z3) == 3 and all(t.data_ptr() == z3[0].data_ptr() for t in z3)
+    cots = [torch.from_numpy(rng.standard_normal(tuple(cot.shape))).float().cuda() for _ in range(3)]
+    g3 = torch.autograd.grad(sum((t * c).sum() for t, c in zip(z3, cots)), dev, retain_graph=True)
+    g1 = torch.autograd.grad((z * ((cots[0] + cots[1]) + cots[2])).sum(), dev, retain_graph=True)
+    for a, c2, nm in zip(g3, g1, names):
+        assert torch.equal(a, c2), nm + " (three consumers)"
+    g2c = torch.autograd.grad((z3[0] * cots[0]).sum() + (z3[2] * cots[2]).sum(), dev)      # one consumer unused
+    g1c = torch.autograd.grad((z * (cots[0] + cots[2])).sum(), dev)
+    for a, c2, nm in zip(g2c, g1c, names):
+        assert torch.equal(a, c2), nm + " (two of three consumers)"
 
 
 @pytest.mark.parametrize("bsz,pool,layer,with_keep,seed", [
