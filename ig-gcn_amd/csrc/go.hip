@@ -991,7 +991,7 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 // they can form that gradient themselves from (y, dz, gamma, beta, keep, mean, rstd) while they copy it into LDS: the
 // LayerNorm's own dX launch (one workgroup per (sample, channel) row: 12.8 us x 4 in the default step), the 15 MB it
 // writes and the 15 MB read back disappear, and since a workgroup sees all channels of a sample it also leaves the
-// affine gradients summed over them — part [B][2][N] (d gamma | d beta rows), reduced over samples by the deferred
+// affine gradients summed over them — part [B][2][N - pool] (d gamma | d beta rows of the kept nodes), reduced over samples by the deferred
 // final reduction instead of k_nodes_ln_bwd_affine_multi's second pass over y and dz.  Arithmetic per element as
 // k_nodes_ln_bwd_dy_v / ln_bwd_affine_v_body.  Preconditions (igcn_go_ln_fused_ok): N, pool multiples of 4, N / 4 <= T,
 // 16-byte aligned tensors.
@@ -1000,6 +1000,7 @@ struct LnFuse {
   float* part;
   int pool;
   const float *dz2, *dz3;          // further consumers' gradients of z (same layout as dz), added on load in this order; or NULL
+  float* dgb;                      // [2][N] d gamma | d beta: the kernel writes the zeros of the pooled nodes' columns
 };
 
 // sum over the 16 lanes of a DPP row, in every lane of the row (quad permutes, then the half-row and row mirrors)
@@ -1102,10 +1103,13 @@ __device__ __forceinline__ void ln_bwd_into_lds(const LnFuse& L, int b, int N, f
     yv[c] = xh;                                         // the registers now hold xhat and the masked, scaled upstream
     up[c] = dx;
   }
-  if (live) {                                           // per-sample affine partials (zero rows for the pooled nodes)
-    float* pr = L.part + (int64_t)b * 2 * N + n;
+  if (act) {                                            // per-sample affine partials [B][2][N - pool] of the KEPT nodes
+    float* pr = L.part + (int64_t)b * 2 * M + (n - L.pool);
     *reinterpret_cast<float4*>(pr) = dg;
-    *reinterpret_cast<float4*>(pr + N) = db;
+    *reinterpret_cast<float4*>(pr + M) = db;
+  } else if (live && b == 0) {                          // pooled nodes feed nothing: exact zeros, written once
+    *reinterpret_cast<float4*>(L.dgb + n) = zero4;
+    *reinterpret_cast<float4*>(L.dgb + N + n) = zero4;
   }
   // [first version: wave_sum per value and every thread adding up all T / 64 rows itself — 60 permutes and 160 LDS reads
   // per thread, 6.8 us of a 10.4 us copy-in; with go_block_sums 3.8 of 7.3]
@@ -1528,7 +1532,7 @@ extern "C" int igcn_go_attn_ln_fused_ok(int N, int fin, int fout, int pool) {
   if (N <= 0 || pool < 0 || pool >= N || N % 4 || pool % 4) return 0;
   return go_attn_bwd_in_lds(N, fin, fout) && N / 4 <= go_abl_threads(N, fin, fout) ? 1 : 0;
 }
-extern "C" size_t igcn_go_ln_part_floats(int B, int N) { return (size_t)B * 2 * (size_t)N + 64; }
+extern "C" size_t igcn_go_ln_part_floats(int B, int N) { return (size_t)B * 2 * (size_t)N + 64; }   // (N - pool columns used)
 
 static int go_attn_bwd_impl(int B, int N, int fin, int fout, const int32_t* row_ptr, const int32_t* col,
                             const int32_t* t_ptr, const int32_t* t_row, const int32_t* walk_order, const float* x,
@@ -1614,11 +1618,14 @@ extern "C" int igcn_go_attn_ln_bwd(int B, int N, int fin, int fout, const int32_
                go_ln_al16(keep) && go_ln_al16(part) && go_ln_al16(dx) && go_ln_al16(dz2) && go_ln_al16(dz3),
                "go_attn_ln_bwd: operands must be 16-byte aligned");
   IGCN_REQUIRE(dz2 != nullptr || dz3 == nullptr, "go_attn_ln_bwd: dz3 without dz2");
-  const LnFuse L = {y, dz, gamma, beta, keep, mean, rstd, part, pool, dz2, dz3};
-  const int rc = go_attn_bwd_impl(B, N, fin, fout, row_ptr, col, t_ptr, t_row, walk_order, x, w_inc, w_s, a_in, a_s,
-                                  nullptr, dx, dparams, scratch, L, (hipStream_t)stream);
+  const LnFuse L = {y, dz, gamma, beta, keep, mean, rstd, part, pool, dz2, dz3, dgb};
+  int rc = go_attn_bwd_impl(B, N, fin, fout, row_ptr, col, t_ptr, t_row, walk_order, x, w_inc, w_s, a_in, a_s,
+                            nullptr, dx, dparams, scratch, L, (hipStream_t)stream);
   if (rc) return rc;
-  return igcn_launch_reduce_rows_final(part, B, 2 * (int64_t)N, 2 * N, dgb, (hipStream_t)stream);
+  const int M = N - pool;                               // part rows: [d gamma (M) | d beta (M)] of the kept nodes
+  if (pool == 0) return igcn_launch_reduce_rows_final(part, B, 2 * (int64_t)M, 2 * M, dgb, (hipStream_t)stream);
+  if ((rc = igcn_launch_reduce_rows_final(part, B, 2 * (int64_t)M, M, dgb + pool, (hipStream_t)stream))) return rc;
+  return igcn_launch_reduce_rows_final(part + M, B, 2 * (int64_t)M, M, dgb + N + pool, (hipStream_t)stream);
 }
 
 // =================================================================================================
@@ -2549,7 +2556,7 @@ extern "C" int igcn_go_decode_ln_bwd(int B, int Nin, int Nout, int fin, int fout
   IGCN_REQUIRE(y && gamma && beta && mean && rstd && dz && dgb && part, "go_decode_ln_bwd: null operand");
   IGCN_REQUIRE(go_ln_al16(y) && go_ln_al16(dz) && go_ln_al16(gamma) && go_ln_al16(beta) && go_ln_al16(keep) &&
                go_ln_al16(part), "go_decode_ln_bwd: operands must be 16-byte aligned");
-  const LnFuse L = {y, dz, gamma, beta, keep, mean, rstd, part, 0, nullptr, nullptr};
+  const LnFuse L = {y, dz, gamma, beta, keep, mean, rstd, part, 0, nullptr, nullptr, dgb};
   const int rc = go_decode_bwd_impl(B, Nin, Nout, fin, fout, row_ptr, t_ptr, t_row, x, w_out, w_sout, nullptr, dx,
                                     dparams, scratch, L, (hipStream_t)stream);
   if (rc) return rc;

@@ -184,7 +184,7 @@ int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int 
 // gradient that nothing reads before the optimiser.  With igcn_reduce_defer(1) those launches are queued (the
 // partial buffers stay alive on the caller's side) and igcn_reduce_flush performs all of them in ONE launch whose
 // table travels by value in the kernel arguments — same arithmetic and summation order as the stand-alone kernels.
-#define MRQ_MAX 40
+#define MRQ_MAX 48
 struct ReduceEntry {
   const float* partial;
   float* out;
