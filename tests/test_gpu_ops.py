@@ -458,7 +458,9 @@ def test_go_attention_layer(ops, bsz, pool, fin, seed):
                                                      # rows beyond 4096 nodes: the 1024-thread form of the 16-byte
                                                      # kernels (configs[4]: 10 000 GO nodes), and beyond 16384: scalar
                                                      (2, 5, 10000, 6000, True), (2, 2, 4100, 0, False),
-                                                     (1, 2, 16400, 400, False)])
+                                                     (1, 2, 16400, 400, False),
+                                                     # many rows (the train step's launches have 1024-2560)
+                                                     (205, 5, 400, 200, True), (512, 2, 1200, 0, False)])
 def test_nodes_layernorm(ops, bsz, f, n, pool, with_keep):
     rng = np.random.default_rng(n)
     y = torch.from_numpy(rng.standard_normal((bsz, f, n)) * 2 + 0.3).float()
