@@ -397,6 +397,41 @@ def test_gemm_is_exact_fp32_fma_chain(ops):
     assert torch.equal(got.cpu(), a @ b.t())
 
 
+def test_final_reductions_deferred_and_immediate_give_the_same_bits(ops):
+    """Every form of the partial-row sums (plan.hip rr_form: in-order thread per column, 16-byte wide, wave per column,
+    16 x 16 tiles, four row groups) — launched on its own and as one entry of the deferred launch (k_multi_reduce) —
+    against an fp64 sum, and bit-identical between the two ways."""
+    import ctypes
+    from igcn_amd import _lib
+    lib = _lib.load()
+    fn = lib.igcn_debug_reduce_rows_final
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    # (rows, n, ld): few rows narrow / wide (16-byte) / wide unaligned; tall with < 16 columns; tall tiles; tall and wide
+    # below and above 256 rows; rows = 0 (writes zeros); a padded leading dimension
+    shapes = [(8, 64, 64), (16, 4096, 4096), (4, 1030, 1031), (448, 5, 5), (3008, 2, 2), (800, 160, 160),
+              (40, 2400, 2400), (128, 8067, 8067), (300, 5000, 5000), (512, 1208, 2416), (0, 100, 100), (33, 17, 20)]
+    torch.manual_seed(3)
+    st = torch.cuda.current_stream().cuda_stream
+    bufs = [(torch.randn(max(r, 1), ld, device="cuda"), torch.full((n,), 7.0, device="cuda"),
+             torch.full((n,), 9.0, device="cuda")) for r, n, ld in shapes]
+    for (p, o1, _), (r, n, ld) in zip(bufs, shapes):                    # immediate
+        assert fn(p.data_ptr(), r, ld, n, o1.data_ptr(), st) == 0
+    lib.igcn_reduce_defer(1)
+    try:
+        for (p, _, o2), (r, n, ld) in zip(bufs, shapes):                # queued, then ONE launch
+            assert fn(p.data_ptr(), r, ld, n, o2.data_ptr(), st) == 0
+        assert lib.igcn_reduce_pending() == len(shapes)
+        assert lib.igcn_reduce_flush(st) == 0
+    finally:
+        lib.igcn_reduce_defer(0)
+    torch.cuda.synchronize()
+    for (p, o1, o2), (r, n, ld) in zip(bufs, shapes):
+        want = p[:r, :n].double().sum(0).cpu().numpy() if r else np.zeros(n)
+        assert_matches(o1, want, 2e-6, f"immediate {r} x {n}", floor=float(max(r, 1)) ** 0.5)
+        assert torch.equal(o1, o2), f"deferred != immediate at {r} x {n} (ld {ld})"
+
+
 # ------------------------------------------------------------------------------------------------ GO ops
 def _hier(pool, seed):
     from igcn_amd import synth
