@@ -226,17 +226,34 @@ __global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t, int32_t* ti
   }
   if (e.nptr > 0) {                                  // a leaf's gradient = sum of its consumers' gradients (k_sum_n)
     const int64_t j4 = (blk * 256 + threadIdx.x) * 4;          // 16 bytes per lane (buffers 16-byte aligned)
+    // more[] with CONSTANT indices only.  [A `for (k < nptr) ... e.more[k]` loop indexes the entry dynamically: the
+    // compiler then keeps the whole entry addressable, and EVERY path of the kernel — the tiles, the row groups —
+    // re-reads its fields around each load instead of holding them in registers: a 512 x 2400 tile sum took 13 us in
+    // this launch and 4.7 us with this branch compiled out (tools/reduce_trace.py); same instructions otherwise.]
+    const float* m0 = e.more[0];
+    const float* m1 = e.more[1];
+    const float* m2 = e.more[2];
+    const int np = e.nptr;
     if (j4 + 3 < e.n) {
       float4 a = *reinterpret_cast<const float4*>(e.partial + j4);
-      for (int k = 0; k < e.nptr; ++k) {
-        const float4 b = *reinterpret_cast<const float4*>(e.more[k] + j4);
+      {
+        const float4 b = *reinterpret_cast<const float4*>(m0 + j4);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      if (np > 1) {
+        const float4 b = *reinterpret_cast<const float4*>(m1 + j4);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      if (np > 2) {
+        const float4 b = *reinterpret_cast<const float4*>(m2 + j4);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
       }
       *reinterpret_cast<float4*>(e.out + j4) = a;
     } else {
       for (int64_t j = j4; j < e.n; ++j) {
-        float s = e.partial[j];
-        for (int k = 0; k < e.nptr; ++k) s += e.more[k][j];
+        float s = e.partial[j] + m0[j];
+        if (np > 1) s += m1[j];
+        if (np > 2) s += m2[j];
         e.out[j] = s;
       }
     }

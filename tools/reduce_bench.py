@@ -76,6 +76,37 @@ print(f"whole queue ({len(SHAPES)} entries, {sum(r * n for r, n in SHAPES) * 4 /
 for keep in (1, 5, 10, 15, 20, 25, 30):
     t = timed(set(range(keep, len(SHAPES))))
     print(f"  first {keep:2d} entries only: {t:7.1f} us", flush=True)
+def timed_immediate(i):
+    """entry i through its stand-alone kernel (igcn_reduce_defer off), same graph-replay timing"""
+    (p, o), (r, n) = bufs[i], SHAPES[i]
+    g = torch.cuda.CUDAGraph()
+    s_ = torch.cuda.Stream()
+    with torch.cuda.stream(s_):
+        assert fn(p.data_ptr(), r, n, n, o.data_ptr(), s_.cuda_stream) == 0
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s_):
+            assert fn(p.data_ptr(), r, n, n, o.data_ptr(), s_.cuda_stream) == 0
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+
+seen = set()
+for i, (r, n) in enumerate(SHAPES):                  # every distinct entry ALONE: its own latency chain above the floor
+    if (r, n) in seen:
+        continue
+    seen.add((r, n))
+    t = timed(set(range(len(SHAPES))) - {i})
+    print(f"  alone {r:5d} x {n:6d} ({r * n * 4 / 1e6:5.1f} MB): {t:7.1f} us", flush=True)
 for i, (r, n) in enumerate(SHAPES[:0]):
     t = timed(i)
     print(f"  without {r:5d} x {n:6d}: {t:7.1f} us  ({whole - t:+6.1f})", flush=True)
