@@ -333,25 +333,48 @@ k_loss_head_fwd(int B, int C, int NR, int S, const float* __restrict__ logp, int
     }
   }
   const int nreg = B * NR, nrec = B * S;
-#pragma unroll 4
-  for (int i = tid; i < 2 * nreg; i += 1024) {
-    const float d = reg[i] - clin[i < nreg ? i : i - nreg];
-    mse += d * d;
-    if (gr.dreg) gr.dreg[i] = w.lam[1] * 2.f * d / (float)(2 * nreg);
+  for (int i0 = tid; i0 < 2 * nreg; i0 += 4 * 1024) {     // (batches of four slots, as the reconstruction walk below)
+    float rv[4], cv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 1024, ic = i < 2 * nreg ? i : tid;
+      rv[u] = reg[ic];
+      cv[u] = clin[ic < nreg ? ic : ic - nreg];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 1024;
+      if (i < 2 * nreg) {
+        const float d = rv[u] - cv[u];
+        mse += d * d;
+        if (gr.dreg) gr.dreg[i] = w.lam[1] * 2.f * d / (float)(2 * nreg);
+      }
+    }
   }
   // one workgroup walks everything: 16 bytes per lane and the whole walk unrolled, so that it is one batch of loads
   // instead of a chain of dependent trips (the kernel is pure latency)
-  if ((nrec & 3) == 0 && (((uintptr_t)x_hat | (uintptr_t)snps) & 15) == 0) {
+  if ((nrec & 3) == 0 && (((uintptr_t)x_hat | (uintptr_t)snps | (uintptr_t)gr.dxhat) & 15) == 0) {
     const int nq = nrec / 4;
-#pragma unroll 8
-    for (int i = tid; i < 2 * nq; i += 1024) {
-      const float4 a = reinterpret_cast<const float4*>(x_hat)[i];
-      const float4 s4 = reinterpret_cast<const float4*>(snps)[i < nq ? i : i - nq];
-      const float d0 = a.x - s4.x, d1 = a.y - s4.y, d2 = a.z - s4.z, d3 = a.w - s4.w;
-      rec += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      if (gr.dxhat) {
-        gr.dxhat[4 * i] = w.lam[3] * d0; gr.dxhat[4 * i + 1] = w.lam[3] * d1;
-        gr.dxhat[4 * i + 2] = w.lam[3] * d2; gr.dxhat[4 * i + 3] = w.lam[3] * d3;
+    // batches of eight slots, every load of a batch issued before the first use: out-of-range slots re-read slot `tid`
+    // and count as zero.  [`#pragma unroll 8` on the plain loop: 6.75 trips per thread at B = 256 = no full batch, and
+    // the remainder loop the compiler adds runs one load per trip, each waiting out its own round trip.]
+    for (int i0 = tid; i0 < 2 * nq; i0 += 8 * 1024) {
+      float4 a[8], s4[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 1024, ic = i < 2 * nq ? i : tid;
+        a[u] = reinterpret_cast<const float4*>(x_hat)[ic];
+        s4[u] = reinterpret_cast<const float4*>(snps)[ic < nq ? ic : ic - nq];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 1024;
+        if (i < 2 * nq) {
+          const float d0 = a[u].x - s4[u].x, d1 = a[u].y - s4[u].y, d2 = a[u].z - s4[u].z, d3 = a[u].w - s4[u].w;
+          rec += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          if (gr.dxhat)
+            reinterpret_cast<float4*>(gr.dxhat)[i] = make_float4(w.lam[3] * d0, w.lam[3] * d1, w.lam[3] * d2, w.lam[3] * d3);
+        }
       }
     }
   } else {
