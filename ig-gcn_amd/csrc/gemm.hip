@@ -506,6 +506,24 @@ static void launch_f32(int bn, int vw, dim3 grid, hipStream_t st, const GemmArgs
   if (bn == 16) launch_f32_v<16>(vw, grid, st, g); else if (bn == 32) launch_f32_v<32>(vw, grid, st, g); else launch_f32_v<64>(vw, grid, st, g);
 }
 
+// sum over the split_k slabs of one output element, in slab order, eight loads in flight per batch.  [`#pragma unroll 8`
+// on the plain loop: a 2- or 4-way split runs entirely in the remainder loop the compiler adds — one load per trip, each
+// waiting out its own round trip.]  Slots past split_k re-read slab 0 and count as +0.
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, int split_k, int64_t stride) {
+  float t = 0.f;
+  for (int z0 = 0; z0 < split_k; z0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float x = p[(int64_t)(z0 + u < split_k ? z0 + u : 0) * stride];
+      v[u] = z0 + u < split_k ? x : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
+  return t;
+}
+
 // (gridDim.y = independent products of a batch: slabs [batch][split_k][M*N], C + blockIdx.y * c_batch)
 __global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const float* __restrict__ slabs,
                                      const float* __restrict__ bias, float* __restrict__ C, int64_t ldc, int act,
@@ -515,9 +533,8 @@ __global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const fl
   slabs += (int64_t)blockIdx.y * split_k * M * N;
   C += (int64_t)blockIdx.y * c_batch;
   const int64_t m = i / N, n = i - m * N;
-  float t = 0.f;
-#pragma unroll 8
-  for (int z = 0; z < split_k; ++z) t += slabs[(int64_t)z * M * N + i];      // independent loads in flight
+  const float t0 = slab_sum(slabs + i, split_k, M * N);
+  float t = t0;
   if (bias) t += bias[n];
   if (act == 1) t = fmaxf(t, 0.f);
   C[m * ldc + n] = t;
@@ -533,9 +550,7 @@ __global__ void k_gemm_splitk_reduce_multi(int64_t M, int64_t N, SlabSums q, int
   float* __restrict__ C = q.C[blockIdx.y];
   const int split_k = q.split[blockIdx.y];
   const int64_t m = i / N, n = i - m * N;
-  float t = 0.f;
-#pragma unroll 8
-  for (int z = 0; z < split_k; ++z) t += slabs[(int64_t)z * M * N + i];
+  float t = slab_sum(slabs + i, split_k, M * N);
   if (bias) t += bias[n];
   if (act == 1) t = fmaxf(t, 0.f);
   C[m * ldc + n] = t;

@@ -118,10 +118,20 @@ nlbn_finalize_body(const RoBlk rb, int B, int N, int groups, int cpg, int traini
   if (training && live) {
     for (int g = 0; g < groups; ++g) {
       float a1 = 0.f, a2 = 0.f;
-#pragma unroll 8
-      for (int k = sl; k < cpg; k += 4) {               // independent loads: one batch per slice
-        a1 += partial[(int64_t)(g * cpg + k) * 2 * N + n];
-        a2 += partial[(int64_t)(g * cpg + k) * 2 * N + N + n];
+      for (int k0 = sl; k0 < cpg; k0 += 32) {           // eight chunk partials per batch, all loads before the first add
+        float v1[8], v2[8];                             // (a `#pragma unroll 8` loop leaves 2-7 trips to a serial remainder)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + 4 * u, kc = k < cpg ? k : sl;
+          v1[u] = partial[(int64_t)(g * cpg + kc) * 2 * N + n];
+          v2[u] = partial[(int64_t)(g * cpg + kc) * 2 * N + N + n];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + 4 * u < cpg) {
+            a1 += v1[u];
+            a2 += v2[u];
+          }
       }
       r1[g][sl][nl] = a1;
       r2[g][sl][nl] = a2;
