@@ -627,6 +627,45 @@ def test_go_attention_with_layernorm_backward_in_one_launch(ops, monkeypatch, bs
         assert torch.equal(a, c2), nm + " (two of three consumers)"
 
 
+def test_go_layer_with_layernorm_entry_points_refuse_what_they_do_not_cover(ops):
+    """igcn_go_attn_ln_bwd / igcn_go_decode_ln_bwd run only where igcn_go_*_ln_fused_ok says so: other sizes, a missing
+    operand or an unaligned one come back as an error (IgcnError), never as a silent different path."""
+    from igcn_amd import _lib
+    from igcn_amd._lib import call, ptr, stream_ptr
+    lib = _lib.load()
+    _, _, _, idx = _hier((20, 10, 6, 3, 1), 0)
+    row, col, nj = idx["enc"][0]
+    csr = ops.Csr(row, col, nj, nj, "cuda")
+    b, fin, fout, pool = 2, 2, 5, 20
+    f32 = dict(dtype=torch.float32, device="cuda")
+    x, y = torch.randn(b, fin, nj, **f32), torch.randn(b, fout, nj, **f32)
+    w = [torch.randn(fout, fin, **f32), torch.randn(fout, fin, **f32), torch.randn(2 * fout, **f32), torch.randn(fout, **f32)]
+    gamma, beta = torch.ones(nj, **f32), torch.zeros(nj, **f32)
+    mean, rstd = torch.zeros(b * fout, **f32), torch.ones(b * fout, **f32)
+    dz = torch.randn(b, fout, nj - pool, **f32)
+    dx, dpar, dgb = torch.empty_like(x), torch.empty(2 * fout * fin + 3 * fout, **f32), torch.empty(2, nj, **f32)
+    scratch = torch.empty(int(lib.igcn_go_attn_bwd_scratch_floats(b, nj, fin, fout)), **f32)
+    part = torch.empty(int(lib.igcn_go_ln_part_floats(b, nj)), **f32)
+
+    def run(n=nj, pool_=pool, y_=y, dz_=dz, dz3=None):
+        call("igcn_go_attn_ln_bwd", b, n, fin, fout, ptr(csr.row_ptr), ptr(csr.col), ptr(csr.t_ptr), ptr(csr.t_row),
+             ptr(csr.walk_order(fin, fout)), ptr(x), ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[3]), pool_, ptr(y_), ptr(gamma),
+             ptr(beta), None, ptr(mean), ptr(rstd), ptr(dz_), None, ptr(dz3), ptr(dx), ptr(dpar), ptr(dgb), ptr(scratch),
+             ptr(part), stream_ptr())
+
+    assert lib.igcn_go_attn_ln_fused_ok(nj, fin, fout, pool) == 1
+    run()                                                               # the covered case goes through
+    torch.cuda.synchronize()
+    assert lib.igcn_go_attn_ln_fused_ok(nj, fin, fout, pool + 2) == 0   # pooled prefix not a multiple of four nodes
+    with pytest.raises(_lib.IgcnError):
+        run(pool_=pool + 2)
+    with pytest.raises(_lib.IgcnError):
+        run(dz3=dz)                                                     # a third consumer without a second
+    with pytest.raises(_lib.IgcnError):
+        run(dz_=dz.view(-1)[1:])                                        # 4-byte aligned only
+    assert lib.igcn_go_decode_ln_fused_ok(10, 21, 5, 5) == 0            # 21 output nodes: no 16-byte rows
+
+
 @pytest.mark.parametrize("bsz,pool,layer,with_keep,seed", [
     (4, (20, 10, 6, 3, 1), 0, True, 0), (4, (20, 12, 8, 3, 1), 1, False, 1), (9, (300, 120, 60, 19, 1), 0, True, 2),
     (9, (300, 120, 60, 19, 1), 1, False, 3), (3, (1800, 800, 300, 99, 1), 0, True, 4),
