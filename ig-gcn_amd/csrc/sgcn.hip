@@ -339,33 +339,53 @@ k_edge_mask_bwd_nodes(int64_t n_nodes, int rois, int h0, const float* __restrict
   const int sub = threadIdx.x % LPN;
   const int64_t i = (int64_t)blockIdx.x * (256 / LPN) + threadIdx.x / LPN;
   if (i < n_nodes) {                               // uniform over the LPN lanes of a node (the wave for LPN=64)
+    // the first entry of BOTH lists per lane as one chain of three round trips (pointers; permutation entries; the
+    // edge operands) — list after list it was six, in a kernel that is nothing but that chain (k = 3 graphs with four
+    // lanes per node rarely have a second entry per lane; the loops behind take those)
+    const int32_t s0 = src_ptr[i], s1 = src_ptr[i + 1], t0 = tgt_ptr[i], t1 = tgt_ptr[i + 1];
+    // the node's own operands ride with the pointer loads (they are not needed before the list sums are done)
+    const int64_t r = (i % rois) * h0;
+    float nx[MAX_H0], npv[MAX_H0], ndxm[MAX_H0], ndxp[MAX_H0];
+#pragma unroll
+    for (int h = 0; h < MAX_H0; ++h) {
+      const bool on = sub == 0 && h < h0;
+      nx[h] = on ? x[i * h0 + h] : 0.f;
+      npv[h] = on ? prob[r + h] : 0.f;
+      ndxm[h] = on && d_xm ? d_xm[i * h0 + h] : 0.f;
+      ndxp[h] = on && d_x_plain ? d_x_plain[i * h0 + h] : 0.f;
+    }
+    int32_t ps = s0 + sub, pt = t0 + sub;
+    const bool hs = ps < s1, ht = pt < t1;
+    int32_t ks = hs ? src_perm[ps] : -1, kt = ht ? tgt_perm[pt] : -1;
+    if (ks < 0) ks = kt;                             // a lane with one entry reads it twice, a lane with none reads nothing
+    if (kt < 0) kt = ks;
+    auto term = [&](int32_t k) {
+      const float ek = e[k];
+      float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
+      if (rg.greg) up += gre * em_reg_grad(ek, rg.l1_e, rg.ent_e, rg.eps);
+      return up * ek * (1.f - ek);
+    };
     float S = 0.f, T = 0.f;
-    for (int32_t p = src_ptr[i] + sub; p < src_ptr[i + 1]; p += LPN) {
-      const int32_t k = src_perm[p];
-      const float ek = e[k];
-      float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
-      if (rg.greg) up += gre * em_reg_grad(ek, rg.l1_e, rg.ent_e, rg.eps);
-      S += up * ek * (1.f - ek);
+    if (ks >= 0) {                                   // ONE region: both entries' operands are requested together
+      const float fs = term(ks), ft = term(kt);
+      S = hs ? fs : 0.f;
+      T = ht ? ft : 0.f;
     }
-    for (int32_t p = tgt_ptr[i] + sub; p < tgt_ptr[i + 1]; p += LPN) {
-      const int32_t k = tgt_perm[p];
-      const float ek = e[k];
-      float up = (d_ewm ? d_ewm[k] * ew[k] : 0.f) + (d_e ? d_e[k] : 0.f);
-      if (rg.greg) up += gre * em_reg_grad(ek, rg.l1_e, rg.ent_e, rg.eps);
-      T += up * ek * (1.f - ek);
-    }
+    for (ps += LPN; ps < s1; ps += LPN) S += term(src_perm[ps]);
+    for (pt += LPN; pt < t1; pt += LPN) T += term(tgt_perm[pt]);
     S = group_sum_all<LPN>(S);
     T = group_sum_all<LPN>(T);
     if (sub == 0) {
-      const int64_t r = (i % rois) * h0;
-      for (int h = 0; h < h0; ++h) {
-        const float xv = x[i * h0 + h], pv = prob[r + h];
-        const float g = (d_xm ? d_xm[i * h0 + h] : 0.f) + pb[h] * S + pb[h0 + h] * T;
-        dx[i * h0 + h] = g * pv + (d_x_plain ? d_x_plain[i * h0 + h] : 0.f);   // + the plain half of a stacked batch
-        gx[i * h0 + h] = g * xv;
-        acc[h] += xv * pv * S;
-        acc[MAX_H0 + h] += xv * pv * T;
-      }
+#pragma unroll
+      for (int h = 0; h < MAX_H0; ++h)
+        if (h < h0) {
+          const float xv = nx[h], pv = npv[h];
+          const float g = ndxm[h] + pb[h] * S + pb[h0 + h] * T;
+          dx[i * h0 + h] = g * pv + ndxp[h];                                       // + the plain half of a stacked batch
+          gx[i * h0 + h] = g * xv;
+          acc[h] += xv * pv * S;
+          acc[MAX_H0 + h] += xv * pv * T;
+        }
     }
   }
   block_reduce_vec<2 * MAX_H0>(acc, red, pb_partial + (int64_t)blockIdx.x * 2 * MAX_H0);
