@@ -158,6 +158,15 @@ extern "C" int igcn_debug_spmm_probe(long long* out) {
 #else
 #define SPMM_PROBE(i)
 #endif
+__device__ __forceinline__ float spmm_wave_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+  const int ri = __float_as_int(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(ri, 0)) + __int_as_float(__builtin_amdgcn_readlane(ri, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(ri, 32)) + __int_as_float(__builtin_amdgcn_readlane(ri, 48)));
+}
 #define SPMM_LT 512
 #define SPMM_LU 3
 #define SPMM_RM 7
@@ -217,9 +226,9 @@ k_spmm_long_lds(int C, int L, int n_out, int64_t nnz, int sum_c, const int32_t* 
             acc[m] += val[(int64_t)(co + ci) * nnz + (vk ? vk[q] : q)] * sp_lds[ci * L + idx[q]];
       }
 #pragma unroll
-      for (int m = 0; m < SPMM_RM; ++m) {
-        const int j = jb + m * NWV;
-        const float t = wave_sum(acc[m]);
+      for (int m = 0; m < SPMM_RM; ++m) {                // seven wave sums on the VALU (DPP rows + v_readlane), not as seven
+        const int j = jb + m * NWV;                      // six-step chains of LDS-pipe permutes
+        const float t = spmm_wave_sum(acc[m]);
         if (lane == 0 && j < n_out) out[((int64_t)b * nc_out + co) * n_out + j] = t;
       }
     }
