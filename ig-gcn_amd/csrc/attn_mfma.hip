@@ -157,7 +157,9 @@ k_attn_mfma_fwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __res
   float* Vs = Ks + (size_t)Lkp * LD;
   const float* kbase = kv + (int64_t)b * Lk * 2 * D + h * hd;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
-  const float scale = rsqrtf((float)hd);
+  // scores in the LOG2 domain: q is scaled by log2(e) / sqrt(head_dim) once, every exponential of the tile loop is one
+  // v_exp_f32 without the multiply __expf puts in front of it; lse is converted back where it is stored
+  const float scale = rsqrtf((float)hd) * 1.44269504088896341f;
   const int krow = FLAT ? (n >> 2) + 4 * (n & 3) : n;            // K row (within a tile) behind score row n
   const int ksw = FLAT ? (krow >> 2) & 3 : 0;
   AM_PROBE(0);
@@ -196,29 +198,42 @@ k_attn_mfma_fwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __res
           const float* kr = Ks + ((kt0 + u) * 16 + krow) * LD + g;
 #pragma unroll
           for (int c = 0; c < NC; ++c) acc = mfma4(kr[4 * (c ^ ksw)], qb[c], acc);
+          if ((kt0 + u + 1) * 16 <= Lk) {                       // wave-uniform: a full key tile needs no masking (the
+#pragma unroll                                                    // compare + select per score were a quarter of the loop's
+            for (int r = 0; r < 4; ++r) {                        // vector instructions; only the last tile can be ragged)
+              s[u][r] = acc[r];
+              tmax = fmaxf(tmax, acc[r]);
+            }
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = (kt0 + u) * 16 + (FLAT ? g + 4 * r : 4 * g + r);
-            s[u][r] = (key < Lk) ? acc[r] : -INFINITY;
-            tmax = fmaxf(tmax, s[u][r]);
+            for (int r = 0; r < 4; ++r) {
+              const int key = (kt0 + u) * 16 + (FLAT ? g + 4 * r : 4 * g + r);
+              s[u][r] = (key < Lk) ? acc[r] : -INFINITY;
+              tmax = fmaxf(tmax, s[u][r]);
+            }
           }
         }
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float mn = fmaxf(m, tmax);
-      const float f = __expf(m - mn);                           // exp(-inf) = 0 on the first group
-      m = mn;
-      l *= f;
+      // LAZY running maximum: the reference m moves only when some lane of the wave sees a score more than 2^8 above it
+      // (a wave-wide vote: one compare), so the two cross-lane exchanges, the rescaling exponential and its five
+      // multiplies leave the loop's chain after the first groups; probabilities stay <= 2^8, sums far inside fp32
+      if (__any(tmax > m + 8.f)) {                              // wave-uniform (true on the first group: m = -inf)
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        const float f = __builtin_amdgcn_exp2f(m - mn);         // 2^(-inf) = 0 on the first group
+        m = mn;
+        l *= f;
 #pragma unroll
-      for (int t = 0; t < NO; ++t) oacc[t] *= f;
+        for (int t = 0; t < NO; ++t) oacc[t] *= f;
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (kt0 + u < nkt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float* vr = Vs + ((kt0 + u) * 16 + (FLAT ? g + 4 * r : 4 * g + r)) * LD + n;
-            const float p = __expf(s[u][r] - m);
+            const float p = __builtin_amdgcn_exp2f(s[u][r] - m);
             l += p;
 #pragma unroll
             for (int t = 0; t < NO; ++t) {
@@ -238,7 +253,7 @@ k_attn_mfma_fwd(int H, int hd_rt, int vec_rt, int Lq, int Lk, const float* __res
 #pragma unroll
       for (int t = 0; t < NO; ++t)
         am_store4(op, 16 * t + 4 * g, hd, vec, oacc[t][0] * inv, oacc[t][1] * inv, oacc[t][2] * inv, oacc[t][3] * inv);
-      if (g == 0) lse[((int64_t)b * H + h) * Lq + qi] = m + __logf(l);
+      if (g == 0) lse[((int64_t)b * H + h) * Lq + qi] = m * 0.693147180559945309f + __logf(l);   // natural log
     }
   }
 }
