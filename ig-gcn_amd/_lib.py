@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 321        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 400        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -141,10 +141,10 @@ SIGNATURES = {
     "igcn_go_decode_ln_bwd": (I, [I, I, I, I, I] + [P] * 19),
     "igcn_go_decode_bwd_scratch_floats": (Z, [I, I, I, I]),
     "igcn_go_decode_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
-    "igcn_adam_step": (I, [L, P, P, P, P, P, F, F, F, F, F, P]),
-    "igcn_adam_step_multi": (I, [I, P, P, P, F, F, F, F, F, P]),
-    "igcn_adam_step_ticked": (I, [L, P, P, P, P, P, F, F, F, F, F, P]),
-    "igcn_adam_step_multi_ticked": (I, [I, P, P, P, F, F, F, F, F, P]),
+    "igcn_adam_step": (I, [L, P, P, P, P, P, P, F, F, F, F, P]),
+    "igcn_adam_step_multi": (I, [I, P, P, P, P, F, F, F, F, P]),
+    "igcn_adam_step_ticked": (I, [L, P, P, P, P, P, P, F, F, F, F, P]),
+    "igcn_adam_step_multi_ticked": (I, [I, P, P, P, P, F, F, F, F, P]),
     "igcn_pack_grads": (I, [I, P, P, P, P, P]),
     "igcn_reduce_defer": (I, [I]),
     "igcn_reduce_pending": (I, []),

@@ -6,11 +6,12 @@ __global__ void k_adam_tick(int32_t* step) { *step += 1; }
 // torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False), single-tensor formulation:
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ void k_adam(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                       float* __restrict__ v, const int32_t* __restrict__ step, float lr, float b1, float b2,
-                       float eps, float gscale) {
+                       float* __restrict__ v, const int32_t* __restrict__ step, const float* __restrict__ lr_dev,
+                       float b1, float b2, float eps, float gscale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float t = (float)(*step);
+  const float lr = *lr_dev;                         // device scalar: a schedule reaches the captured launch
   const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
   const float gi = g[i] * gscale;
   const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -22,7 +23,7 @@ __global__ void k_adam(int64_t n, float* __restrict__ p, const float* __restrict
 }
 
 static int adam_step_impl(bool tick, int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                          int32_t* step, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+                          int32_t* step, const float* lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (tick) hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, step);
   if (n > 0)
@@ -32,14 +33,14 @@ static int adam_step_impl(bool tick, int64_t n, float* param, const float* grad,
   return IGCN_OK;
 }
 extern "C" int igcn_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                              int32_t* step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                              int32_t* step, const float* lr, float beta1, float beta2, float eps, float grad_scale,
                               void* stream) {
   return adam_step_impl(true, n, param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_scale, stream);
 }
 // *step has been advanced already (igcn_reduce_flush_tick): no counter launch in front
 extern "C" int igcn_adam_step_ticked(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                                     int32_t* step, float lr, float beta1, float beta2, float eps, float grad_scale,
-                                     void* stream) {
+                                     int32_t* step, const float* lr, float beta1, float beta2, float eps,
+                                     float grad_scale, void* stream) {
   return adam_step_impl(false, n, param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_scale, stream);
 }
 
@@ -49,7 +50,8 @@ extern "C" int igcn_adam_step_ticked(int64_t n, float* param, const float* grad,
 // written gradient tensors (no AccumulateGrad add into a pre-zeroed flat buffer, no zero_grad memset).
 __global__ void __launch_bounds__(256)
 k_adam_multi(const int64_t* __restrict__ table, const int64_t* __restrict__ numel,
-             const int32_t* __restrict__ step, float lr, float b1, float b2, float eps, float gscale) {
+             const int32_t* __restrict__ step, const float* __restrict__ lr_dev, float b1, float b2, float eps,
+             float gscale) {
   const int t = blockIdx.y;
   const int64_t n = numel[t];
   if ((int64_t)blockIdx.x * 256 >= n) return;       // most tensors are tiny: their surplus workgroups leave at once
@@ -59,6 +61,7 @@ k_adam_multi(const int64_t* __restrict__ table, const int64_t* __restrict__ nume
   float* m = reinterpret_cast<float*>(table[4 * t + 2]);
   float* v = reinterpret_cast<float*>(table[4 * t + 3]);
   const float ts = (float)(*step);
+  const float lr = *lr_dev;
   const float bc1 = 1.f - powf(b1, ts), bc2s = sqrtf(1.f - powf(b2, ts));
   auto upd = [&](float gi, float& mi, float& vi, float& pi) {
     gi *= gscale;
@@ -93,7 +96,7 @@ k_adam_multi(const int64_t* __restrict__ table, const int64_t* __restrict__ nume
 }
 
 static int adam_step_multi_impl(bool tick, int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
-                                float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+                                const float* lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (tick) hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, step);
   if (n_tensors > 0)
@@ -103,12 +106,12 @@ static int adam_step_multi_impl(bool tick, int n_tensors, const int64_t* table, 
   return IGCN_OK;
 }
 extern "C" int igcn_adam_step_multi(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
-                                    float lr, float beta1, float beta2, float eps, float grad_scale,
+                                    const float* lr, float beta1, float beta2, float eps, float grad_scale,
                                     void* stream) {
   return adam_step_multi_impl(true, n_tensors, table, numel, step, lr, beta1, beta2, eps, grad_scale, stream);
 }
 extern "C" int igcn_adam_step_multi_ticked(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
-                                           float lr, float beta1, float beta2, float eps, float grad_scale,
+                                           const float* lr, float beta1, float beta2, float eps, float grad_scale,
                                            void* stream) {
   return adam_step_multi_impl(false, n_tensors, table, numel, step, lr, beta1, beta2, eps, grad_scale, stream);
 }

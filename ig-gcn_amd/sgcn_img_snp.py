@@ -198,11 +198,19 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
     def loss_probability(self, x, edge_index, edge_weight, hp, eps=1e-6, plan=None, edge_prob=None, partials=False):
         """:153-181 as one fused reduction (igcn_mask_reg_*).  ``edge_prob`` lets the train step reuse the mask
         the explain pass already computed; ``partials``: the un-reduced workgroup sums (ops.LossHead adds them up)."""
-        if (edge_prob is None or edge_prob is self.last_edge_prob) and self._dense_reg is not None and self._dense_reg[1] == (
-                float(hp.lamda_x_l1), float(hp.lamda_x_ent), float(hp.lamda_e_l1), float(hp.lamda_e_ent), float(eps)):
-            # the forward of the masked pass has already reduced every term: the dense-block path (edge mask never
-            # materialised) or the stacked sweep's mask launch (ops.EdgeMaskStacked with reg_hp)
-            return self._dense_reg[0] if partials else self._dense_reg[0].sum()
+        cached, self._dense_reg = self._dense_reg, None              # handed out at most once per forward
+        if (cached is not None and (edge_prob is None or edge_prob is self.last_edge_prob)
+                and cached[1] == (float(hp.lamda_x_l1), float(hp.lamda_x_ent), float(hp.lamda_e_l1),
+                                  float(hp.lamda_e_ent), float(eps))
+                and cached[2] == self._reg_key(x, edge_weight)):
+            # the forward of the masked pass has already reduced every term ON THESE INPUTS: the dense-block path (edge
+            # mask never materialised) or the stacked sweep's mask launch (ops.EdgeMaskStacked with reg_hp).  Anything
+            # else — another batch, a second call, parameters that moved since — is recomputed from the arguments, as
+            # the reference does (:153-181)
+            return cached[0] if partials else cached[0].sum()
+        if edge_prob is not None and edge_prob is self.last_edge_prob and self._reg_key(x, edge_weight)[:4] != \
+                getattr(self, "_last_mask_key", (None,) * 4)[:4]:
+            edge_prob = None                                          # the mask of another batch: do not reuse it
         if edge_prob is None:
             _, _, _, edge_prob = self.cal_probability(x, edge_index, edge_weight, plan=plan)
         # inside a train step the forward has handed out gradient aliases of prob / snps_prob (ops.GradFan)
@@ -211,6 +219,13 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         self._fan_prob = self._fan_snps = None
         return ops.MaskRegulariser.apply(prob, edge_prob, sprob, hp.lamda_x_l1, hp.lamda_x_ent,
                                          hp.lamda_e_l1, hp.lamda_e_ent, eps, partials)
+
+    def _reg_key(self, x, edge_weight):
+        """Identity of what a cached mask / regulariser was computed from: the batch tensors and the parameter
+        versions (torch.optim bumps ``_version``; FlatAdam's kernels do not, which is why the cache is also
+        single-use)."""
+        return (x.data_ptr(), tuple(x.shape), edge_weight.data_ptr(), tuple(edge_weight.shape),
+                self.prob._version, self.prob_bias._version, self.snps_prob._version)
 
     def laplacian(self, n, tsne_result=None):
         """D - W of consist_loss (:188-193): RBF similarity of the t-SNE embedding, or all-ones."""
@@ -286,6 +301,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         plan = ops.plan_for(data)
         self.last_edge_prob = None
         self._dense_reg = None
+        self._last_mask_key = self._reg_key(x, edge_weight)
         self._fan_prob = self._fan_snps = None
         fan = x.is_cuda and torch.is_grad_enabled() and os.environ.get("IGCN_NO_GRAD_FAN", "0") != "1"
         prob_m = prob_h = self.prob
@@ -311,7 +327,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             xcat, regp = ops.DenseSgcn.apply(x_d, edge_weight, prob_d, self.prob_bias, sp_d, mode, self.rois,
                                              self._reg_hp, *wb)
             if mode != "plain":
-                self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp))
+                self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp), self._reg_key(x, edge_weight))
             if mode == "plain":
                 snps_in = snps_feat
             else:
@@ -336,7 +352,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             if reg_in_mask:
                 x_in, ew_in, e, regp, snps_in = ops.EdgeMaskStacked.apply(
                     x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois, self.snps_prob, self._reg_hp, snps_feat)
-                self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp))
+                self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp), self._reg_key(x, edge_weight))
             else:
                 x_in, ew_in, e = ops.EdgeMaskStacked.apply(x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois)
                 snps_in, _ = ops.SnpsMask.apply(snps_feat, sp_m, True)

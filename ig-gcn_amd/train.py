@@ -18,8 +18,42 @@ HP = SimpleNamespace(lamda_x_l1=0.1, lamda_e_l1=0.1, lamda_x_ent=0.1, lamda_e_en
 DEFAULT_LAMBDA = (0.0, 1.0, 0.5, 1.5e-6, 0.1, 0.0)
 
 
+class _ParamGroup(dict):
+    """The one ``param_groups`` entry of FlatAdam: a dict like torch.optim's, whose ``'lr'`` item is mirrored into the
+    device scalar the Adam kernel reads — so the reference's schedule
+    (``param_group['lr'] = lr_decay_factor * param_group['lr']``, kernel/train_eval_sgcn_img_snps.py:169-171) reaches
+    a step that was captured into a hipGraph.  ``betas`` / ``eps`` are by-value launch arguments: changing them
+    invalidates captured steps (GraphedTrainStep refuses to replay)."""
+
+    def __init__(self, owner, **items):
+        super().__init__(**items)
+        self._owner = owner
+
+    def __setitem__(self, key, value):
+        if key == "lr":
+            value = float(value)
+            self._owner._write_lr(value)
+        elif key in ("betas", "eps") and (key not in self or self[key] != value):
+            self._owner._hyper_version += 1
+        elif key in ("weight_decay", "amsgrad", "maximize") and value:
+            raise ValueError(f"FlatAdam is Adam({key}={value!r}) of the reference only with weight_decay=0, "
+                             "amsgrad=False, maximize=False (kernel/train_eval_sgcn_img_snps.py:108, main.py:92)")
+        super().__setitem__(key, value)
+
+    def update(self, *a, **kw):
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            self[key] = default
+        return self[key]
+
+
 class FlatAdam:
-    """Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) over ONE flat fp32 parameter buffer.
+    """Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) over ONE flat fp32 parameter buffer — the drop-in for
+    ``Adam(model.parameters(), lr=lr, weight_decay=weight_decay)`` at kernel/train_eval_sgcn_img_snps.py:108
+    (``weight_decay`` must be 0, the default of main.py).
 
     Parameters (and the Adam moments) are views into contiguous buffers.  Two gradient modes:
 
@@ -29,10 +63,18 @@ class FlatAdam:
       data parallelism igcn_pack_grads gathers the gradients into the flat bucket for the single all-reduce.
     * flat mode (``flat_grads=True``): ``.grad`` are views of one flat buffer that autograd accumulates into.
 
-    Parameters without a gradient are left untouched, like torch.optim.Adam.
+    Parameters without a gradient are left untouched, like torch.optim.Adam.  The step counter is ONE device int32
+    for all parameters (torch keeps one per parameter: the two agree whenever the set of parameters that receive a
+    gradient does not change from step to step, which holds for this model).
+
+    The torch.optim surface the reference's epoch loop touches is here: ``param_groups`` (one group; assigning
+    ``['lr']`` writes the device scalar the kernel reads — also inside a captured hipGraph), ``zero_grad``, ``step``,
+    ``state_dict`` / ``load_state_dict`` in torch.optim.Adam's own format (checkpoints interchange both ways).
     """
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, flat_grads=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, flat_grads=None):
+        if weight_decay:
+            raise ValueError("FlatAdam: weight_decay must be 0 (the reference trains with main.py's default 0)")
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no parameters")
@@ -42,13 +84,17 @@ class FlatAdam:
         for p in self.params:
             offs.append(n)
             n += (p.numel() + align - 1) // align * align
-        self.lr, self.betas, self.eps = lr, betas, eps
         self.flat_grads = (dev.type != "cuda") if flat_grads is None else bool(flat_grads)
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)    # read by k_adam / k_adam_multi at run time
+        self._hyper_version = 0
+        self.param_groups = [_ParamGroup(self, params=self.params, betas=tuple(betas), eps=float(eps),
+                                         weight_decay=0, amsgrad=False, maximize=False)]
+        self.param_groups[0]["lr"] = lr
         with torch.no_grad():
             for p, off in zip(self.params, offs):
                 k = p.numel()
@@ -57,6 +103,9 @@ class FlatAdam:
                 p.grad = self.grad[off:off + k].view_as(p) if self.flat_grads else None
         nt = len(self.params)
         self._offs = offs
+        # parameters that have been through a step with a gradient (torch.optim.Adam creates their state then):
+        # the entries state_dict() writes
+        self._has_state = [False] * nt
         # pinned staging buffers for the pointer table, used round-robin: a buffer is rewritten only after the
         # upload that read it has completed (the host may run several eager steps ahead of the device)
         self._hosts = [torch.zeros(nt, 4, dtype=torch.int64, pin_memory=(dev.type == "cuda")) for _ in range(4)]
@@ -68,17 +117,41 @@ class FlatAdam:
                 host[t, 2] = self.exp_avg.data_ptr() + 4 * o
                 host[t, 3] = self.exp_avg_sq.data_ptr() + 4 * o
         self.table = torch.zeros(nt, 4, dtype=torch.int64, device=dev)
+        self._table_owner = None                     # who wrote ``table`` last (a GraphedTrainStep restores its own)
+        self._table_live = [False] * nt              # which parameters the current table holds a gradient for
         self.numel = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
         self.offset = torch.tensor(offs, dtype=torch.int64, device=dev)
 
-    def zero_grad(self):
+    # ---- hyper-parameters -------------------------------------------------------------------------
+    def _write_lr(self, value):
+        if self.lr_dev.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FlatAdam: the learning rate is written between steps, not inside a stream capture")
+        self.lr_dev.fill_(value)                     # stream-ordered: the next step (eager or replayed) reads it
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]["lr"] = value
+
+    @property
+    def betas(self):
+        return self.param_groups[0]["betas"]
+
+    @property
+    def eps(self):
+        return self.param_groups[0]["eps"]
+
+    def zero_grad(self, set_to_none=True):
         if self.flat_grads:
             self.grad.zero_()
         else:
             for p in self.params:
                 p.grad = None
 
-    def refresh_table(self):
+    def refresh_table(self, owner=None):
         """Upload the current gradient pointers (host-side, not capturable: under a hipGraph the gradient
         tensors keep their addresses, so this runs once after capture)."""
         k = self._turn
@@ -91,7 +164,9 @@ class FlatAdam:
             if g is not None and not g.is_contiguous():
                 g = p.grad = g.contiguous()
             host[t, 1] = g.data_ptr() if g is not None else 0
+            self._table_live[t] = g is not None
         self.table.copy_(host, non_blocking=True)
+        self._table_owner = owner
         if self.table.is_cuda:
             self._uploaded[k] = torch.cuda.Event()
             self._uploaded[k].record()
@@ -108,19 +183,80 @@ class FlatAdam:
 
     def step(self, grad_scale=1.0, refresh=True, from_flat=None):
         """``from_flat``: read gradients from the flat bucket (after an all-reduce); default = flat mode only.
-        When the backward's flush has advanced ``step_count`` already (``backward_to_grads`` with deferred reductions
-        sets ``_ticked``), the one-thread counter launch in front is skipped."""
-        hyper = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(grad_scale))
+        When the backward's flush has advanced ``step_count`` already (``backward_to_grads(tick=True)`` with deferred
+        reductions sets ``_ticked``), the one-thread counter launch in front is skipped."""
+        hyper = (ptr(self.lr_dev), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(grad_scale))
         sfx = "_ticked" if getattr(self, "_ticked", False) else ""
         self._ticked = False
         if self.flat_grads or from_flat:
             call("igcn_adam_step" + sfx, self.flat.numel(), ptr(self.flat), ptr(self.grad), ptr(self.exp_avg),
                  ptr(self.exp_avg_sq), ptr(self.step_count), *hyper, stream_ptr())
+            self._has_state = [True] * len(self.params)
             return
         if refresh:
             self.refresh_table()
         call("igcn_adam_step_multi" + sfx, len(self.params), ptr(self.table), ptr(self.numel), ptr(self.step_count),
              *hyper, stream_ptr())
+        self.mark_stepped()
+
+    def mark_stepped(self):
+        """Book-keeping of a table-mode step (also called per replay of a captured one): the parameters the table holds
+        a gradient for now have Adam state."""
+        live = self._table_live
+        if live != self._has_state:
+            self._has_state = [a or b for a, b in zip(self._has_state, live)]
+
+    # ---- checkpointing: torch.optim.Adam's own layout ----------------------------------------------
+    def state_dict(self):
+        """``torch.optim.Adam(params).state_dict()`` of the same parameter list: ``state[i] = {step, exp_avg,
+        exp_avg_sq}`` for every parameter that has been stepped, one param group.  Host-synchronising (a checkpoint)."""
+        step = float(int(self.step_count.item()))
+        state = {}
+        for t, (p, o) in enumerate(zip(self.params, self._offs)):
+            if not self._has_state[t] or step == 0:
+                continue
+            k = p.numel()
+            state[t] = {"step": torch.tensor(step, dtype=torch.float32),
+                        "exp_avg": self.exp_avg[o:o + k].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + k].view_as(p).clone()}
+        g = self.param_groups[0]
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Accepts FlatAdam's and torch.optim.Adam's state_dict of the same parameter list."""
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("FlatAdam.load_state_dict: expected one param group over "
+                             f"{len(self.params)} parameters")
+        g = groups[0]
+        if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+            raise ValueError("FlatAdam.load_state_dict: weight_decay / amsgrad / maximize are not supported")
+        index = {pid: t for t, pid in enumerate(g["params"])}
+        steps = set()
+        with torch.no_grad():
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            self._has_state = [False] * len(self.params)
+            for pid, st in sd["state"].items():
+                t = index[pid]
+                p, o = self.params[t], self._offs[t]
+                k = p.numel()
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"FlatAdam.load_state_dict: state {pid} has shape {tuple(st['exp_avg'].shape)}, "
+                                     f"parameter {tuple(p.shape)}")
+                self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+                self._has_state[t] = True
+            if len(steps) > 1:
+                raise ValueError(f"FlatAdam keeps one step counter; the state holds {sorted(steps)}")
+            self.step_count.fill_(steps.pop() if steps else 0)
+        self.param_groups[0]["betas"] = tuple(g["betas"])
+        self.param_groups[0]["eps"] = float(g["eps"])
+        self.param_groups[0]["lr"] = g["lr"]
 
 
 def losses_sgcn(model, data, hp=HP):
@@ -226,12 +362,16 @@ def _unit_grad(loss):
     return _UNIT[key]
 
 
-def backward_to_grads(loss, optimizer, data=None, defer=False):
+def backward_to_grads(loss, optimizer, data=None, defer=False, tick=False):
     """``loss.backward()`` for the table-mode FlatAdam: the gradients are taken with ``torch.autograd.grad`` and
     assigned to ``.grad`` as they come.  ``backward()`` routes every leaf through AccumulateGrad, which CLONES a
     gradient it cannot steal — and the kernels here hand back several parameter gradients as slices of one flat
     buffer (dW_inc | dW_s | da_in | da_s ...), i.e. views: a dozen device copies per step that nothing needs, since
-    the Adam kernel reads the gradients through a pointer table.  Other optimisers keep ``backward()``."""
+    the Adam kernel reads the gradients through a pointer table.  Other optimisers keep ``backward()``.
+
+    ``tick`` (with ``defer``): the launch that ends the backward also advances ``optimizer.step_count`` — for callers
+    that ALWAYS follow this backward with exactly one ``optimizer.step()`` (``train_step``, ``GraphedTrainStep``).  A
+    loop that may skip the step (gradient accumulation, a non-finite-loss guard) leaves it off."""
     params = getattr(optimizer, "params", None)
     if params is None or getattr(optimizer, "flat_grads", True):
         loss.backward()
@@ -246,10 +386,13 @@ def backward_to_grads(loss, optimizer, data=None, defer=False):
         # every parameter enters the graph ONCE — a parameter used twice has its two gradients added by autograd
         # during the backward, i.e. before the flush.
         # ... and the flush launch advances the optimiser's step counter on its way (one launch less in front of Adam)
-        tick = getattr(optimizer, "step_count", None) if os.environ.get("IGCN_NO_FLUSH_TICK", "0") != "1" else None
-        with ops.deferred_reductions(tick=tick):
+        counter = getattr(optimizer, "step_count", None) if tick else None
+        if getattr(optimizer, "_ticked", False):
+            raise RuntimeError("backward_to_grads(tick=True): the previous backward advanced the step counter and no "
+                               "optimizer.step() followed it")
+        with ops.deferred_reductions(tick=counter):
             grads = torch.autograd.grad(loss, leaves, grad_outputs=_unit_grad(loss), allow_unused=True)
-        if tick is not None:
+        if counter is not None:
             optimizer._ticked = True
     else:
         grads = torch.autograd.grad(loss, leaves, grad_outputs=_unit_grad(loss), allow_unused=True)
@@ -283,7 +426,7 @@ def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temper
     if data.x.grad is not None:
         data.x.grad = None
     loss, _, _ = losses(model, data, lambda_loss, hp, temperature)
-    backward_to_grads(loss, optimizer, data, defer=_single_use_parameters(model))
+    backward_to_grads(loss, optimizer, data, defer=_single_use_parameters(model), tick=True)
     if world_size > 1 or comm is not None:
         flat = optimizer.pack_grads()
         if comm is not None:
@@ -343,6 +486,7 @@ class GraphedTrainStep:
         opt = self.opt
         saved = [t.clone() for t in (opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_count)]
         saved_buf = [(b, b.clone()) for b in model.buffers()]
+        saved_has = list(opt._has_state)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -360,6 +504,7 @@ class GraphedTrainStep:
                 dst.copy_(src)
             for b, v in saved_buf:
                 b.copy_(v)
+        opt._has_state = saved_has
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
         if not self.plan_in_graph:
@@ -406,7 +551,15 @@ class GraphedTrainStep:
             if p.grad is not None and not p.grad.is_contiguous():
                 raise _lib.IgcnError("graphed step: a parameter gradient is not contiguous "
                                      f"(shape {tuple(p.shape)}, strides {p.grad.stride()})")
-        self.opt.refresh_table()
+        self.opt.refresh_table(owner=self)
+        # the optimiser's pointer table and the parameters' ``.grad`` belong to whoever stepped last: an eager
+        # ``train_step`` (the ragged last batch of an epoch) or another captured step re-points them, and __call__ puts
+        # this graph's own back before it replays
+        self._table = self.opt.table.clone()
+        self._table_live = list(self.opt._table_live)
+        self._grads = [p.grad for p in self.opt.params]
+        self._x_grad = self.data.x.grad
+        self._hyper_version = self.opt._hyper_version
         self.g_opt = None
         if dist and not self.comm_in_graph:
             self.g_opt = torch.cuda.CUDAGraph()
@@ -423,7 +576,7 @@ class GraphedTrainStep:
             self.plan._copies = {}                      # the replica of the batched sweep is derived in-graph
         self.data.x.grad = None
         loss, _, _ = losses(self.model, self.data, self.lam, self.hp)
-        backward_to_grads(loss, self.opt, self.data, defer=_single_use_parameters(self.model))
+        backward_to_grads(loss, self.opt, self.data, defer=_single_use_parameters(self.model), tick=True)
         return loss.detach()
 
     def _reduce(self):
@@ -469,16 +622,132 @@ class GraphedTrainStep:
                 with torch.no_grad():
                     dst.copy_(src, non_blocking=True)
 
+    def _own_the_table(self):
+        opt = self.opt
+        if opt._hyper_version != self._hyper_version:
+            raise RuntimeError("graphed step: betas / eps of the optimiser changed after the capture (they are by-value "
+                               "launch arguments; only the learning rate is read from device memory) — rebuild the step")
+        if getattr(opt, "_ticked", False):
+            raise RuntimeError("graphed step: an eager backward advanced the step counter and no optimizer.step() "
+                               "followed it")
+        if opt._table_owner is not self:
+            with torch.no_grad():
+                opt.table.copy_(self._table)
+            opt._table_owner = self
+            opt._table_live = list(self._table_live)
+            for p, g in zip(opt.params, self._grads):
+                p.grad = g
+            self.data.x.grad = self._x_grad
+
     def __call__(self):
+        self._own_the_table()
         if not self.plan_in_graph:
             self.plan.rebuild(self.data.edge_index)
         self.g_main.replay()
         if self.g_opt is not None:
             self._reduce()
             self.g_opt.replay()
+            self.opt._has_state = [True] * len(self.opt.params)
+        elif self.dist:
+            self.opt._has_state = [True] * len(self.opt.params)
+        else:
+            self.opt.mark_stepped()
         if _lib._DEBUG_SYNC:                            # checked mode: surface the segmented build's status flag
             self.plan.check()
         return self.loss
+
+
+def _batch_signature(data):
+    """What a captured step is specialised on: graph count and the shapes of every tensor ``load`` copies."""
+    sig = [int(data.num_graphs)]
+    for k in ("x", "edge_index", "edge_attr", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y"):
+        v = getattr(data, k, None)
+        sig.append(tuple(v.shape) if torch.is_tensor(v) else None)
+    return tuple(sig)
+
+
+def _clone_batch(data):
+    """A private copy of a batch: the static input tensors of a captured step (``GraphedTrainStep.data``)."""
+    import copy
+    out = copy.copy(data)
+    for k, v in list(vars(data).items()):
+        if torch.is_tensor(v):
+            setattr(out, k, v.detach().clone())
+        elif k == "_igcn_plan":
+            setattr(out, k, None)
+    return out
+
+
+class EpochTrainer:
+    """``train()`` of kernel/train_eval_sgcn_img_snps.py:511-548 over a whole loader, on the fast path.
+
+    The reference's loader is ``DataLoader(train_dataset, batch_size, shuffle=True)`` (:96-97: no ``drop_last``), so an
+    epoch is a run of full batches plus one ragged tail.  Every batch SHAPE (graph count + tensor shapes) gets its own
+    captured step once it has been seen ``capture_after`` times (default: the second time — one-off shapes never pay for
+    a capture); until then, and beyond ``max_graphs`` captured shapes, the batch runs through the eager ``train_step``.
+    Both routes are the same kernels on the same optimiser state, so an epoch is the same sequence of Adam steps either
+    way.  All captured steps share the optimiser: each restores its own gradient-pointer table before it replays.
+
+    The learning-rate schedule of the epoch loop (:169-171) is ``optimizer.param_groups[0]['lr'] *= factor`` exactly as
+    with torch.optim.Adam: the rate lives in device memory and captured steps read it there.
+    """
+
+    def __init__(self, model, optimizer, lambda_loss=DEFAULT_LAMBDA, hp=HP, world_size=1, comm=None, capture_after=1,
+                 max_graphs=4, warmup=2):
+        self.model, self.opt, self.lam, self.hp = model, optimizer, lambda_loss, hp
+        self.world, self.comm = world_size, comm
+        self.capture_after, self.max_graphs, self.warmup = int(capture_after), int(max_graphs), int(warmup)
+        self.steps = {}                              # signature -> GraphedTrainStep
+        self.seen = {}                               # signature -> times met
+        self.counts = {"replayed": 0, "eager": 0, "captured": 0}
+
+    def step(self, data):
+        """One optimisation step on ``data`` (a device batch).  Returns the loss as a device scalar that stays valid
+        until the next step of the same shape."""
+        sig = _batch_signature(data)
+        g = self.steps.get(sig)
+        if g is None:
+            n = self.seen.get(sig, 0)
+            self.seen[sig] = n + 1
+            graphable = data.x.is_cuda and isinstance(self.opt, FlatAdam) and not self.opt.flat_grads
+            if graphable and n >= self.capture_after and len(self.steps) < self.max_graphs:
+                g = self.steps[sig] = GraphedTrainStep(self.model, self.opt, _clone_batch(data), self.lam, self.hp,
+                                                       world_size=self.world, comm=self.comm, warmup=self.warmup)
+                self.counts["captured"] += 1
+        if g is None:
+            self.counts["eager"] += 1
+            return train_step(self.model, self.opt, data, self.lam, self.hp, world_size=self.world, comm=self.comm)
+        g.load(data)
+        self.counts["replayed"] += 1
+        return g()
+
+    def fit_epoch(self, loader, device=None):
+        """The body of ``train()``: one pass over ``loader``; returns ``sum_b loss_b * num_graphs_b / len(dataset)``
+        (:546,548).  The per-batch ``loss.item()`` of the reference is one device accumulation, read once at the end."""
+        self.model.train()
+        total, count = None, 0
+        for data in _batches(loader, device):
+            loss = self.step(data)
+            part = loss.reshape(()) * float(data.num_graphs)          # (a new tensor: the replayed loss is overwritten)
+            total = part if total is None else total + part
+            count += int(data.num_graphs)
+        if total is None:
+            return 0.0
+        size = len(loader.dataset) if hasattr(loader, "dataset") else count
+        return float(total) / size
+
+
+def fit_epoch(model, optimizer, loader, temperature=None, lambda_loss=DEFAULT_LAMBDA, hp=HP, device=None,
+              world_size=1, comm=None):
+    """``train(model, optimizer, loader, temperature, lambda_loss, ..., device)`` of the reference (:511-548) as a
+    function: the EpochTrainer is kept on the optimiser, so calling this once per epoch — as the reference's epoch
+    loop calls ``train`` — re-uses the captured steps."""
+    key = (id(model), tuple(float(v) for v in lambda_loss), world_size, id(comm))
+    cache = optimizer.__dict__.setdefault("_igcn_epoch_trainers", {})
+    tr = cache.get(key)
+    if tr is None:
+        tr = cache[key] = EpochTrainer(model, optimizer, lambda_loss, hp, world_size=world_size, comm=comm)
+    return tr.fit_epoch(loader, device)
 
 
 def _batches(loader, device):

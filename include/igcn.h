@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 321
+#define IGCN_ABI_VERSION 400
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -716,9 +716,12 @@ int igcn_go_decode_bwd(int B, int Nin, int Nout, int fin, int fout, const int32_
  * Adam step over a flat fp32 parameter buffer — torch.optim.Adam(lr, weight_decay=0) at
  * kernel/train_eval_sgcn_img_snps.py:108,547.  `step` is a device int32 that the kernel's caller
  * increments (igcn_adam_step does it: one extra 1-thread kernel) so the call is graph-capturable.
+ * `lr` is a DEVICE float[1] read by the kernel at run time: the reference's schedule
+ * (`param_group['lr'] = lr_decay_factor * param_group['lr']`, kernel/train_eval_sgcn_img_snps.py:169-171) writes that
+ * scalar, and a launch captured into a hipGraph sees the new rate at its next replay.
  */
 int igcn_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                   int32_t* step, float lr, float beta1, float beta2, float eps, float grad_scale,
+                   int32_t* step, const float* lr, float beta1, float beta2, float eps, float grad_scale,
                    void* stream);
 
 /* Multi-tensor forms: `table` is a device array int64[n_tensors][4] = {param, grad, exp_avg, exp_avg_sq}
@@ -726,13 +729,13 @@ int igcn_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, f
  * .grad is None).  igcn_pack_grads copies the gradients (zeros where missing) to flat[offset[t]...] — the bucket of
  * the data-parallel all-reduce. */
 int igcn_adam_step_multi(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
-                         float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+                         const float* lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 /* ..._ticked: `step` has been advanced already — by igcn_reduce_flush_tick, the launch that ends the backward — so
  * no one-thread counter launch goes in front. */
 int igcn_adam_step_ticked(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t* step,
-                          float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
-int igcn_adam_step_multi_ticked(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step, float lr,
-                                float beta1, float beta2, float eps, float grad_scale, void* stream);
+                          const float* lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int igcn_adam_step_multi_ticked(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
+                                const float* lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_t* numel, const int64_t* offset,
                     float* flat, void* stream);
 

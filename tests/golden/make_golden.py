@@ -229,6 +229,98 @@ def capture_full(sg_mod, name, rois, hidden, layers, bsz, pool, seed, lam, top_k
     print("wrote", name, "loss", float(loss), {k: float(v) for k, v in terms.items()})
 
 
+def _sampled(v, cap=BIG):
+    """A tensor in full up to ``cap`` elements, else every stride-th element of its flattening (stride from numel)."""
+    flat = v.detach().reshape(-1)
+    stride = -(-flat.numel() // cap)
+    return flat[::stride].clone() if stride > 1 else v.detach().clone()
+
+
+def capture_traj(sg_mod, name, rois, hidden, layers, bsz, pool, seed, lam, n_steps=4, decay_after=2, factor=0.5,
+                 lr0=1e-3):
+    """A multi-step optimisation trajectory of the reference: the loop body of train()
+    (kernel/train_eval_sgcn_img_snps.py:515-547) with torch.optim.Adam (:108) over ``n_steps`` DIFFERENT batches, and
+    the learning-rate decay of the epoch loop (:169-171: ``param_group['lr'] = lr_decay_factor * param_group['lr']``)
+    applied after step ``decay_after``.  Stored: the loss and its seven terms per step, the parameters after the last
+    step (big tensors as every stride-th element), the BatchNorm running statistics, and per parameter element a
+    ``solid`` flag: True where the final value is determined beyond fp32 rounding — every step's gradient element is
+    above 5 % of that tensor's largest AND a second run of the same trajectory on one thread (another summation order
+    in the reference's own kernels) lands within 1e-5.  Adam divides by sqrt(v): an element whose gradient is rounding
+    noise moves by +-lr per step whatever the implementation, and no implementation can be held to it."""
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=seed)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj)
+    flags = dict(isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3, model4eachregr=False,
+                 isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False, isMultiFusion=False)
+    model = sg_mod.SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cpu", rois=rois, H_0=3, num_classes=3,
+                                   **flags)
+    ref_sd = model.state_dict()
+    sd = seeded_state({k: v.shape for k, v in ref_sd.items()}, seed, ref_sd)
+    batches = [synth.brain_graph_list(bsz, seed=seed + 10 + k, rois=rois, top_k=3, tsne_dim=16)
+               for k in range(n_steps)]
+    hp = OS.HP
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        model.load_state_dict(sd)
+        model.train(True)
+        _no_dropout(model)
+        opt = torch.optim.Adam(model.parameters(), lr=lr0, weight_decay=0)
+        rec = {"loss": [], "terms": [], "lr": [], "grads": []}
+        for k, graphs in enumerate(batches):
+            opt.zero_grad()
+            data = Batch.from_data_list(graphs)
+            o1 = model(data, torch.tensor(0.1), "cpu")
+            o2 = model(data, torch.tensor(0.1), "cpu", isExplain=True)
+            loss, terms = _reference_losses(model, data, lam, hp, o1, o2)
+            loss.backward()
+            rec["grads"].append({n: (p.grad.detach().clone() if p.grad is not None else None)
+                                 for n, p in model.named_parameters()})
+            rec["lr"].append(opt.param_groups[0]["lr"])
+            opt.step()
+            rec["loss"].append(float(loss))
+            rec["terms"].append([float(terms[t]) for t in ("ce", "mi", "reg", "prob", "recon", "cluster", "orth")])
+            if k + 1 == decay_after:
+                for group in opt.param_groups:                       # :169-171
+                    group["lr"] = factor * group["lr"]
+        rec["params"] = {n: p.detach().clone() for n, p in model.named_parameters()}
+        rec["buffers"] = {n: v.detach().clone() for n, v in model.state_dict().items() if "running" in n}
+        return rec
+
+    threads = torch.get_num_threads()
+    main, alt = run(threads), run(1)
+    torch.set_num_threads(threads)
+    store = {"meta": np.array(
+        "reference kernel/sgcn_img_snp.py + kernel/go_model.py executed on CPU, loop body of train() "
+        "(kernel/train_eval_sgcn_img_snps.py:515-547) + torch.optim.Adam + the lr decay of :169-171; GCNConv/"
+        "to_dense_batch = oracle.pyg_ops (PyG 2.0.2 absent: unpinned), torch_scatter.scatter -> index_add_; dropout "
+        f"p=0; torch {torch.__version__}; weights = seeded_state(shapes, seed={seed}); batch k = "
+        f"synth.brain_graph_list({bsz}, seed={seed + 10}+k, rois={rois}, top_k=3, tsne_dim=16); "
+        f"GO = synth.go_hierarchy({list(pool)}, seed={seed}); lr {lr0} x{factor} after step {decay_after}"),
+        "cfg": np.array([rois, hidden, layers, bsz, seed, 3]), "pool": np.array(pool), "lam": np.array(lam),
+        "state_keys": np.array(sorted(ref_sd.keys())), "n_steps": np.array(n_steps),
+        "traj/loss": np.array(main["loss"]), "traj/terms": np.array(main["terms"]), "traj/lr": np.array(main["lr"])}
+    n_solid = n_all = 0
+    for n, p in main["params"].items():
+        gs = [g[n] for g in main["grads"]]
+        if any(g is None for g in gs):
+            solid = torch.zeros_like(p, dtype=torch.bool)              # never stepped: value must be unchanged
+            store[f"traj/untouched/{n}"] = np.array(True)
+        else:
+            solid = torch.ones_like(p, dtype=torch.bool)
+            for g in gs:
+                solid &= g.abs() > 5e-2 * g.abs().max()
+            solid &= (p - alt["params"][n]).abs() <= 1e-5
+        store[f"traj/param_after/{n}"] = _sampled(p).cpu().numpy()
+        store[f"traj/solid/{n}"] = np.packbits(_sampled(solid).reshape(-1).cpu().numpy())
+        n_solid += int(_sampled(solid).sum())
+        n_all += int(_sampled(solid).numel())
+    for n, v in main["buffers"].items():
+        store[f"traj/buffers_after/{n}"] = _sampled(v).cpu().numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **store)
+    print("wrote", name, "losses", main["loss"], "lr", main["lr"], f"solid {n_solid}/{n_all} stored elements",
+          "max |loss(threads) - loss(1 thread)|", max(abs(a - b) for a, b in zip(main["loss"], alt["loss"])))
+
+
 def capture_sgcn(sgcn_mod, name, hidden, layers, bsz, seed, top_k=3):
     """kernel/sgcn.py SGCN_GCN (rois is hard-wired to 90 at :285) + the loss of kernel/train_eval_sgcn.py:303-308."""
     model = sgcn_mod.SGCN_GCN(None, layers, hidden, rois=90, H_0=3, num_features=3, num_classes=2)
@@ -532,6 +624,9 @@ def main():
         capture_go(go_mod, "go_b32", gs, ad, pd, 32, 32, 32, seed=13)
     if "full_b32" in want or not want:
         capture_full(sg_mod, "full_b32", rois=90, hidden=16, layers=2, bsz=32, pool=(300, 120, 60, 19, 1), seed=24,
+                     lam=[1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2])
+    if "train_traj" in want or not want:
+        capture_traj(sg_mod, "train_traj", rois=90, hidden=16, layers=2, bsz=32, pool=(300, 120, 60, 19, 1), seed=26,
                      lam=[1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2])
     if want and not (want & {"go_tiny", "go_small", "full_tiny", "full_r90", "full_l3"}):
         return
