@@ -87,10 +87,33 @@ def build_model(device, wl=None, bf16=None):
 # ---------------------------------------------------------------------------------------------------------------
 # in-step kernel durations: rocprofv3 --kernel-trace --stats of this command, made by this invocation
 # ---------------------------------------------------------------------------------------------------------------
+MARK = "k_launch_floor"        # a kernel no train step contains: the child brackets its timed replays with it
+
+
+def _replay_stats(trace_csv):
+    """{kernel name: (calls, average us, total us)} of the dispatches BETWEEN the child's two marker launches — the
+    timed replays only: the eager warm-up steps, the capture and the model set-up lie outside the bracket."""
+    with open(trace_csv) as fh:
+        rows = list(csv.DictReader(fh))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if MARK in r["Kernel_Name"]]
+    if len(marks) < 2:
+        return None, None
+    body = rows[marks[-2] + 1:marks[-1]]
+    agg = {}
+    for r in body:
+        a = agg.setdefault(r["Kernel_Name"], [0, 0.0])
+        a[0] += 1
+        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    span_us = (int(body[-1]["End_Timestamp"]) - int(body[0]["Start_Timestamp"])) / 1e3 if body else 0.0
+    return {n: (c, t / c, t) for n, (c, t) in agg.items()}, span_us
+
+
 def instep_profile(workload, bf16, steps=12, timeout=420):
-    """Run ``bench.py --inner-profile`` (the same train step, nothing else) under rocprofv3 in a CHILD process and
-    return ({kernel name: (calls, average us, total us)}, steps, path of the stats CSV) — or None when the profiler
-    is not available.  The profiler goes around the python program itself (no env/bash hop behind ``--``)."""
+    """Run ``bench.py --inner-profile`` (the same train step, nothing else) under ``rocprofv3 --kernel-trace --stats`` in
+    a CHILD process and return ({kernel name: (calls, average us, total us)} over the child's timed REPLAYS only, number
+    of replays, path of the profiler's stats CSV, span of the replays in us) — or None when the profiler is not
+    available.  The profiler goes around the python program itself (no env/bash hop behind ``--``)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
@@ -104,20 +127,23 @@ def instep_profile(workload, bf16, steps=12, timeout=420):
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
         files = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)
-        if r.returncode != 0 or not files:
+        traces = glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not files or not traces:
             print(f"[bench] rocprofv3 child failed (rc={r.returncode}): {r.stderr[-400:]}", file=sys.stderr)
             return None
-        inner = None
-        for line in r.stdout.splitlines():
-            if line.startswith("{") and "inner_steps" in line:
-                inner = json.loads(line)
-        stats = {}
-        with open(files[0]) as fh:
-            for row in csv.DictReader(fh):
-                stats[row["Name"]] = (int(row["Calls"]), float(row["AverageNs"]) / 1e3, float(row["TotalDurationNs"]) / 1e3)
+        stats, span = _replay_stats(traces[0])
+        if stats is None:
+            print("[bench] rocprofv3 child: marker launches not found in the kernel trace", file=sys.stderr)
+            return None
         if keep:
-            shutil.copy(files[0], os.path.join(out, f"{workload}_kernel_stats.csv"))
-        return stats, (inner or {}).get("inner_steps", steps + 3), files[0]
+            shutil.copy(files[0], os.path.join(out, f"{workload}_kernel_stats.csv"))      # the profiler's own summary
+            with open(os.path.join(out, f"{workload}_replay_kernel_stats.csv"), "w", newline="") as fh:
+                w = csv.writer(fh)                        # the same columns over the timed replays only
+                w.writerow(("Name", "Calls", "TotalDurationNs", "AverageNs", "CallsPerReplay", "UsPerReplay"))
+                for n, (c, avg, tot) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
+                    w.writerow((n, c, int(tot * 1e3), int(avg * 1e3), round(c / steps, 2), round(tot / steps, 2)))
+                w.writerow(("SPAN first start -> last end per replay", "", int(span * 1e3), "", "", round(span / steps, 2)))
+        return stats, steps, files[0], span
     except Exception as exc:                       # noqa: BLE001 — the profile is evidence, not the metric
         print(f"[bench] rocprofv3 child failed: {type(exc).__name__}: {exc}", file=sys.stderr)
         return None
@@ -269,8 +295,9 @@ def fused_stack_roofline(model, data, device, wl, stats):
     cold = _time_graph(lambda: [fn() for fn in fns]) / sets
     picked = _pick(stats[0], "k_sgcn_stack_fwd") if stats else None
     us = picked[2] if picked else cold
-    src = ("rocprofv3 --kernel-trace --stats of this command (child process): average over the in-step launches"
-           if picked else "HIP events, cold replay (rocprofv3 unavailable)")
+    src = ("rocprofv3 --kernel-trace of this command (child process): average over the launches of its timed replays"
+           if picked else ("HIP events, cold replay (the rocprofv3 child of this run failed)" if stats is None else
+                           "HIP events, cold replay (the step does not launch this kernel)"))
     gbs = alg_bytes / (us * 1e-6) / 1e9
     res = {"bound": "hbm", "kernel": picked[0] if picked else "k_sgcn_stack_fwd", "achieved": round(gbs, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
@@ -310,8 +337,9 @@ def scatter_roofline(data, device, wl, stats, hot_iters=200):
     prefix = "k_gcn_propagate_fwd"
     picked = _pick(stats[0], prefix) if stats else None
     us = picked[2] if picked else cold
-    src = ("rocprofv3 --kernel-trace --stats of this command (child process): average over the in-step launches"
-           if picked else "HIP events, cold replay (rocprofv3 unavailable)")
+    src = ("rocprofv3 --kernel-trace of this command (child process): average over the launches of its timed replays"
+           if picked else ("HIP events, cold replay (the rocprofv3 child of this run failed)" if stats is None else
+                           "HIP events, cold replay (the step does not launch this kernel)"))
     gbs = alg_bytes / (us * 1e-6) / 1e9
     fallback_name = "k_gcn_propagate_fwd_lds<4>" if dense else "k_gcn_propagate_fwd_q<4>"
     res = {"bound": "hbm", "kernel": picked[0] if picked else fallback_name, "achieved": round(gbs, 1),
@@ -361,7 +389,7 @@ def dense_roofline(data, wl, stats):
     res = {"bound": "hbm", "kernel": picked[0], "achieved": round(alg_bytes / (us * 1e-6) / 1e9, 1),
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
            "traffic": None, "alg_bytes_per_launch": alg_bytes, "us_per_launch": round(us, 3),
-           "timing": "rocprofv3 --kernel-trace --stats of this command (child process): average over the in-step launches",
+           "timing": "rocprofv3 --kernel-trace of this command (child process): average over the launches of its timed replays",
            "launches_profiled": picked[1], "kernel_bytes_per_launch": kern_bytes,
            "frac_kernel_bytes": round(kern_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
            "launch": f"{g} complete graphs x {e} edges, BOTH passes of the step in one launch, F={f}",
@@ -459,25 +487,36 @@ def cpu_baseline(go, wl, seconds=20.0):
             sd[k] = (torch.rand(s, generator=gen) * 2 - 1) / max(1.0, float(s[-1] if len(s) > 1 else s[0])) ** 0.5
     sd = OS.make_leaf_state(sd)
     cfg = SimpleNamespace(num_layers=LAYERS, rois=rois, image_only=False, rbf_gamma=0.01)
-    b = 32 if not wl["dense"] else 4
-    data = Batch.from_data_list(synth.brain_graph_list(b, seed=1000, rois=rois, tsne_dim=90, dense=wl["dense"]))
     usable = _usable_cores()
     torch.set_num_threads(usable)                            # every host core this process may use, stated
-    opt = None
-    times = []
-    t_end = time.perf_counter() + seconds
-    it = 0
-    while it < 2 or (time.perf_counter() < t_end and it < 12):
-        t0 = time.perf_counter()
-        _, _, opt = OS.train_step(sd, cfg, idx, data, lr=1e-3, dropout=True, faithful=True, opt=opt)
-        times.append(time.perf_counter() - t0)
-        it += 1
-    times = sorted(times[1:]) if len(times) > 1 else times
-    med = times[len(times) // 2]
+
+    def sample(b, budget, max_steps):
+        data = Batch.from_data_list(synth.brain_graph_list(b, seed=1000, rois=rois, tsne_dim=90, dense=wl["dense"]))
+        opt, times, it = None, [], 0
+        t_end = time.perf_counter() + budget
+        while it < 2 or (time.perf_counter() < t_end and it < max_steps):
+            t0 = time.perf_counter()
+            _, _, opt = OS.train_step(sd, cfg, idx, data, lr=1e-3, dropout=True, faithful=True, opt=opt)
+            times.append(time.perf_counter() - t0)
+            it += 1
+        times = sorted(times[1:]) if len(times) > 1 else times
+        return times[len(times) // 2], len(times)
+
+    # the headline's own batch size when three of its steps fit the time bound (probed on a small batch first),
+    # otherwise the small batch
+    b_small, b_full = (32 if not wl["dense"] else 4), wl["graphs"]
+    t_start = time.perf_counter()
+    med, n = sample(b_small, min(seconds, 6.0), 4)
+    b = b_small
+    left = seconds - (time.perf_counter() - t_start)
+    if b_full > b_small and med * (b_full / b_small) * 3.2 <= left:
+        med, n = sample(b_full, left, 8)
+        b = b_full
     return {"value": round(b / med, 2), "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
             "host_logical_cpus": os.cpu_count(), "physical_cores": _physical_cores(), "usable_cores": usable,
             "torch": torch.__version__,
-            "sample": f"{len(times)} train steps of B={b} graphs (same model/GO DAG, fp32), median; oracle faithful mode"}
+            "sample": f"{n} train steps of B={b} graphs (the headline runs B={b_full}; same model/GO DAG, fp32), median; "
+                      "oracle faithful mode"}
 
 
 def _usable_cores():
@@ -575,28 +614,39 @@ def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
     # device-resident dataset
     dev_store = UniformGraphStore(slim, device)
 
-    def consume_dev(batch):
+    def consume_dev(batch):                                  # hand-over by events: the batch was built on a side stream
+        cur.wait_event(batch.ready)
         gstep.load(batch)
+        batch.release()
         gstep()
     out["device"] = run(DeviceFeeder(dev_store, b, steps + warmup + 1), consume_dev)
-    # dense connectivity on the device -> GDC + collation every step
+    # dense connectivity on the device -> GDC + collation of batch k + 1 on a second stream while step k replays
     if not wl["dense"]:
+        from igcn_amd.loader import DeviceGdcFeeder
         adj_dev = adj_all.to(device)
-        gen = torch.Generator(device=device).manual_seed(1)
         cols = {k: dev_store.cols[k] for k in ("x", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y")}
-
-        def gdc_feed():
-            for _ in range(steps + warmup + 1):
-                idx = torch.randint(0, subjects, (b,), generator=gen, device=device)
-                sel = {k: torch.index_select(v, 0, idx) for k, v in cols.items()}
-                yield batch_from_dense(torch.index_select(adj_dev, 0, idx), sel.pop("x"), top_k=3, alpha=0.05,
-                                       check=False, snps_feat=sel["snps_feat"].reshape(b, -1), y=sel["y"].reshape(-1),
-                                       clini_score=sel["clini_score"], tsne_fdim=sel["tsne_fdim"].reshape(b, -1),
-                                       clust_y=sel["clust_y"].reshape(-1))
         first = batch_from_dense(adj_dev[:b], cols["x"][:b], top_k=3, alpha=0.05, check=True)
         if first.edge_index.shape == gstep.data.edge_index.shape:
-            out["device_gdc"] = run(gdc_feed(), consume_dev)
+            out["device_gdc"] = run(DeviceGdcFeeder(adj_dev, cols, b, steps + warmup + 1, top_k=3, alpha=0.05, seed=1),
+                                    consume_dev)
+            out["device_gdc"]["overlap"] = "GDC + collate of batch k+1 on a side stream during the replay of step k"
             gstep.plan.check()
+            if os.environ.get("IGCN_BENCH_GDC_SERIAL", "0") == "1":      # A/B: the transform on the launch stream
+                gen = torch.Generator(device=device).manual_seed(1)
+
+                def gdc_feed():
+                    for _ in range(steps + warmup + 1):
+                        idx = torch.randint(0, subjects, (b,), generator=gen, device=device)
+                        sel = {k: torch.index_select(v, 0, idx) for k, v in cols.items()}
+                        yield batch_from_dense(torch.index_select(adj_dev, 0, idx), sel.pop("x"), top_k=3, alpha=0.05,
+                                               check=False, snps_feat=sel["snps_feat"].reshape(b, -1),
+                                               y=sel["y"].reshape(-1), clini_score=sel["clini_score"],
+                                               tsne_fdim=sel["tsne_fdim"].reshape(b, -1),
+                                               clust_y=sel["clust_y"].reshape(-1))
+                def consume_serial(batch):
+                    gstep.load(batch)
+                    gstep()
+                out["device_gdc_serial"] = run(gdc_feed(), consume_serial)
         else:
             out["device_gdc"] = {"skipped": "the GDC of these matrices does not keep top_k entries in every column"}
     return out
@@ -607,7 +657,7 @@ def stress_child(timeout=300):
     (its own model, graph capture, in-step rocprofv3 profile and bounded CPU-oracle sample) whose result line is folded
     into the default line as ``stress``.  None (with the reason on stderr) when the child fails: the headline stands."""
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "stress", "--steps", "10", "--warmup", "3",
-           "--cpu-baseline-seconds", "8", "--no-stress"]
+           "--cpu-baseline-seconds", "8", "--no-stress", "--no-pipeline", "--blocks", "3"]
     # the child profiles into its own directory (a kept parent directory would hand it the parent's kernel summary)
     env = dict(os.environ)
     keep = env.pop("IGCN_BENCH_PROFILE_DIR", None)
@@ -623,7 +673,7 @@ def stress_child(timeout=300):
     except Exception as exc:                       # noqa: BLE001
         print(f"[bench] stress child failed: {type(exc).__name__}: {exc}", file=sys.stderr)
         return None
-    keep = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "loss", "roofline", "roofline_mfma",
+    keep = ("value", "unit", "ms_per_step", "timing", "steps", "warmup", "dtype", "loss", "roofline", "roofline_mfma",
             "cpu_baseline", "profile", "edge_pipeline")
     out = {k: full[k] for k in keep if k in full}
     out["workload"] = full["config"]["workload"]
@@ -666,6 +716,39 @@ def self_launch(n):
     return r.returncode
 
 
+def sweep(ns):
+    """IGCN_BENCH_SWEEP="1,2,4,8": one invocation, one result line per N.  Every N is a fresh CHILD process of this
+    script started before this process has made any GPU call (the child self-launches its ranks); the N = 1 value is
+    handed to the larger runs, whose lines then carry ``weak_scaling_efficiency_vs_n1`` = value_N / (N * value_1)."""
+    env = dict(os.environ)
+    env.pop("IGCN_BENCH_SWEEP")
+    n1, rc = None, 0
+    for n in ns:
+        argv = [a for a in sys.argv[1:]]
+        if "--gpus" in argv:
+            k = argv.index("--gpus")
+            del argv[k:k + 2]
+        argv = [a for a in argv if not a.startswith("--gpus=")]
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), *argv]
+        if n > 1:
+            cmd += [f for f in ("--no-roofline", "--no-cpu-baseline", "--no-pipeline") if f not in argv]
+        if n1 is not None:
+            env["IGCN_BENCH_N1_VALUE"] = str(n1)
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if r.returncode != 0 or not lines:
+            print(f"[bench] sweep: N={n} failed (rc={r.returncode})", file=sys.stderr)
+            rc = rc or r.returncode or 4
+            continue
+        line = json.loads(lines[-1])
+        if n == 1:
+            n1 = line["value"]
+        elif n1 is not None and "weak_scaling_efficiency_vs_n1" not in line:
+            line["weak_scaling_efficiency_vs_n1"] = round(line["value"] / (n * n1), 4)
+        print(json.dumps(line), flush=True)
+    return rc
+
+
 def main():
     # the image exports NCCL_DEBUG=VERSION: RCCL then prints a five-line banner on STDOUT at communicator creation —
     # in front of the one JSON line this script owes its caller
@@ -684,14 +767,19 @@ def main():
                     help="dense feature transforms with bf16 operands (auto: the workload's own setting)")
     ap.add_argument("--rotate", type=int, default=0,
                     help="time GraphedTrainStep.load + replay over this many distinct device-resident batches")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="also time the loader-fed step: host DataLoader thread / device-resident dataset / device GDC")
+    ap.add_argument("--pipeline", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="skip the loader-fed runs (host feeder thread / device-resident dataset / device GDC)")
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="the timed region (--steps steps) is repeated this many times; the median block is reported")
     ap.add_argument("--no-stress", action="store_true",
                     help="default workload only: skip the short configs[4] child run reported as `stress`")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="bound of the CPU-oracle sample")
     ap.add_argument("--inner-profile", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if os.environ.get("IGCN_BENCH_SWEEP") and "WORLD_SIZE" not in os.environ:
+        sys.exit(sweep([int(v) for v in os.environ["IGCN_BENCH_SWEEP"].replace(" ", "").split(",") if v]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -791,49 +879,101 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    if args.inner_profile:
+        # the child under rocprofv3: exactly --steps replays between two marker launches (a kernel no step contains), so
+        # the parent reads per-kernel launches and durations of REPLAYS only off the kernel trace
+        from igcn_amd._lib import call, stream_ptr
+        mark = torch.empty(64, 16, device=device)
+        call("igcn_launch_floor", 64, 16, 0, 0, mark.data_ptr(), stream_ptr())
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        call("igcn_launch_floor", 64, 16, 0, 0, mark.data_ptr(), stream_ptr())
+        torch.cuda.synchronize()
+        print(json.dumps({"inner_steps": args.steps, "ms_per_step": round((time.perf_counter() - t0) / args.steps * 1e3, 3)}))
+        return
+
+    def timed_block():
+        """EXACTLY --steps steps between barrier + synchronize on both sides; the max over ranks."""
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    # the timed region is repeated: --blocks blocks of --steps steps each; the line reports the MEDIAN block (and the
+    # spread), so one disturbed block does not decide the headline
+    block_s = []
+    for _ in range(max(1, args.blocks)):
+        dt, loss = timed_block()
+        block_s.append(dt)
+    dt = sorted(block_s)[len(block_s) // 2]
     if not bool(torch.isfinite(loss)):
         print("non-finite loss", file=sys.stderr)
         sys.exit(3)
 
-    # the gradient exchange on its own: HIP events on the launch stream around the all-reduce of a few extra steps
-    # (two-graph form only; an all-reduce captured into the step graph cannot be bracketed)
-    allreduce_us = None
-    if dist_on and gstep is not None and gstep.g_opt is not None and not args.inner_profile:
-        pairs = []
-        for _ in range(10):
+    # the distributed step taken apart (two-graph form; an all-reduce captured into the step graph cannot be bracketed):
+    # HIP events on the launch stream around [forward..backward + pack] graph | all-reduce | [Adam] graph of extra steps,
+    # the host's enqueue time per step, and the all-reduce alone back to back (no step around it) — per RANK
+    allreduce_us, dist_parts = None, None
+    if dist_on and gstep is not None and gstep.g_opt is not None:
+        def ev():
+            return torch.cuda.Event(enable_timing=True)
+        recs, host_us = [], []
+        for _ in range(20):
+            gstep._own_the_table()
+            e = [ev() for _ in range(4)]
+            h0 = time.perf_counter()
+            e[0].record()
             gstep.g_main.replay()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e[1].record()
             gstep._reduce()
-            e1.record()
+            e[2].record()
             gstep.g_opt.replay()
-            pairs.append((e0, e1))
+            e[3].record()
+            host_us.append((time.perf_counter() - h0) * 1e6)
+            recs.append(e)
         torch.cuda.synchronize()
-        ts = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)
-        t = torch.tensor([ts[len(ts) // 2]], device=device, dtype=torch.float64)
+        alone = []
+        for _ in range(20):
+            a, b = ev(), ev()
+            a.record()
+            gstep._reduce()
+            b.record()
+            alone.append((a, b))
+        torch.cuda.synchronize()
+        med = lambda v: sorted(v)[len(v) // 2]                    # noqa: E731
+        mine = [med([e[0].elapsed_time(e[1]) * 1e3 for e in recs]), med([e[1].elapsed_time(e[2]) * 1e3 for e in recs]),
+                med([e[2].elapsed_time(e[3]) * 1e3 for e in recs]), med([a.elapsed_time(b) * 1e3 for a, b in alone]),
+                med(host_us)]
+        t = torch.tensor(mine, device=device, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)] if world > 1 else [t]
         if world > 1:
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        allreduce_us = round(float(t.item()), 1)
-
-    if args.inner_profile:                        # the child under rocprofv3: the train step and nothing else
-        print(json.dumps({"inner_steps": args.steps + args.warmup + (3 if gstep is not None else 0),
-                          "ms_per_step": round(dt / args.steps * 1e3, 3)}))
-        return
+            torch.distributed.all_gather(every, t)
+        rows = [[round(float(v), 1) for v in r.tolist()] for r in every]
+        totals = [r[0] + r[1] + r[2] for r in rows]
+        allreduce_us = max(r[1] for r in rows)
+        dist_parts = {
+            "per_rank_median_us": {"g_main_replay": [r[0] for r in rows],
+                                   "allreduce_in_step (incl. any wait for the host to enqueue it)": [r[1] for r in rows],
+                                   "allreduce_alone_back_to_back": [r[3] for r in rows],
+                                   "gap_before_allreduce = in_step - alone": [round(r[1] - r[3], 1) for r in rows],
+                                   "g_opt_replay": [r[2] for r in rows],
+                                   "host_enqueue_per_step": [r[4] for r in rows]},
+            "slowest_rank": int(max(range(len(rows)), key=lambda i: totals[i])),
+            "device_us_per_step_by_rank": [round(v, 1) for v in totals], "steps_sampled": 20}
 
     if rank == 0:
         total_graphs = per_gpu * world * args.steps
@@ -841,6 +981,10 @@ def main():
             "metric": "graphs/s train step (90-ROI brain + GO-SNP)", "value": round(total_graphs / dt, 1),
             "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "timing": {"blocks": len(block_s), "steps_per_block": args.steps, "reported": "median block",
+                       "ms_per_step_min": round(min(block_s) / args.steps * 1e3, 3),
+                       "ms_per_step_max": round(max(block_s) / args.steps * 1e3, 3),
+                       "ms_per_step_blocks": [round(b / args.steps * 1e3, 3) for b in block_s]},
             "vs_baseline": None, "dtype": "bf16" if (bf16 and wl["pool"] is not None) else "f32", "data": "synthetic",
             "config": {"workload": wl["name"],
                        "graphs_per_gpu": per_gpu, "global_batch": per_gpu * world,
@@ -851,8 +995,10 @@ def main():
             "loss": round(float(loss), 6),
         }
         if dist_on:
-            res["config"]["allreduce_us_per_step"] = allreduce_us      # median over 10 steps, max over ranks
+            res["config"]["allreduce_us_per_step"] = allreduce_us      # median over 20 steps, max over ranks
             res["config"]["allreduce_bytes"] = int(opt.grad.numel()) * 4
+            if dist_parts is not None:
+                res["distributed_step"] = dist_parts
             n1 = os.environ.get("IGCN_BENCH_N1_VALUE")                  # graphs/s of the N = 1 run, when the caller has it
             if n1:
                 res["weak_scaling_efficiency_vs_n1"] = round(res["value"] / (world * float(n1)), 4)
@@ -869,8 +1015,9 @@ def main():
             torch.cuda.synchronize()
             res["rotating_batches"] = {"batches": args.rotate,
                                        "ms_per_step_load_plus_replay": round((time.perf_counter() - t1) / args.steps * 1e3, 3)}
-        if args.pipeline and gstep is not None and world == 1:
-            res["pipeline"] = pipeline_bench(gstep, wl, device, args.steps, args.warmup, res["ms_per_step"])
+        if not args.no_pipeline and gstep is not None and world == 1 and wl["pool"] is not None:
+            # the loader-fed step (the reference's step starts at `for data in loader: data = data.to(device)`, :515-517)
+            res["pipeline"] = pipeline_bench(gstep, wl, device, max(args.steps, 60), args.warmup, res["ms_per_step"])
         if wl["pool"] is not None and world == 1 and not args.no_roofline:
             stats = instep_profile(args.workload, bf16)
             dense_rf = dense_roofline(data, wl, stats) if wl["dense"] else None
@@ -890,9 +1037,13 @@ def main():
                 res["roofline"] = standalone
             res["roofline_mfma"] = mfma_roofline(model, wl, device, stats, bf16)
             if stats:
-                res["profile"] = {"steps_profiled": stats[1],
+                lib = [(c, t) for n, (c, _, t) in stats[0].items() if (n[5:] if n.startswith("void ") else n).startswith("k_")]
+                res["profile"] = {"replays_profiled": stats[1], "scope": "the child's timed hipGraph replays only "
+                                  "(bracketed by marker launches in the kernel trace)",
                                   "kernel_us_per_step": round(sum(t for _, _, t in stats[0].values()) / stats[1], 1),
-                                  "launches_per_step": round(sum(c for c, _, _ in stats[0].values()) / stats[1], 1)}
+                                  "launches_per_step": round(sum(c for c, _, _ in stats[0].values()) / stats[1], 1),
+                                  "libigcn_launches_per_step": round(sum(c for c, _ in lib) / stats[1], 1),
+                                  "span_us_per_step": round(stats[3] / stats[1], 1)}
         if wl["pool"] is not None and world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(go, wl, seconds=args.cpu_baseline_seconds)
         if args.workload == "full" and world == 1 and not args.no_roofline and not args.no_stress:

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 400        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 401        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -71,6 +71,7 @@ SIGNATURES = {
     "igcn_head_inputs_fwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "igcn_head_inputs_bwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
     "igcn_concat_cols": (I, [L, I, I, P, P, P]),
+    "igcn_copy_multi": (I, [I, P, P, P, P]),
     "igcn_launch_floor": (I, [L, I, I, I, P, P]),
     "igcn_graph_pool_fwd": (I, [L, I, I, P, P, P, P]),
     "igcn_graph_pool_bwd": (I, [L, I, I, P, P, P, P]),
@@ -231,3 +232,24 @@ def call(name, *args):
     if _DEBUG_SYNC:
         import torch
         torch.cuda.synchronize()
+
+
+def copy_multi(pairs):
+    """``dst.copy_(src)`` for every (dst, src) pair of same-shape, same-dtype contiguous DEVICE tensors as one launch
+    per 16 pairs (igcn_copy_multi) on the current stream.  Anything else (a host tensor, a dtype change, a strided
+    view) goes through ``Tensor.copy_``."""
+    fast = []
+    for dst, src in pairs:
+        if (dst.is_cuda and src.is_cuda and dst.device == src.device and dst.dtype == src.dtype
+                and dst.shape == src.shape and dst.is_contiguous() and src.is_contiguous()):
+            if dst.numel() and dst.data_ptr() != src.data_ptr():
+                fast.append((dst, src))
+        else:
+            dst.copy_(src, non_blocking=True)
+    for k in range(0, len(fast), 16):
+        chunk = fast[k:k + 16]
+        n = len(chunk)
+        d = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in chunk])
+        s = (ctypes.c_void_p * n)(*[t.data_ptr() for _, t in chunk])
+        nb = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t, _ in chunk])
+        call("igcn_copy_multi", n, d, s, nb, stream_ptr())

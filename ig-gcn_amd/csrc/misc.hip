@@ -139,6 +139,52 @@ extern "C" int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_
 }
 
 // =================================================================================================
+// igcn_copy_multi: n independent device-to-device copies in one launch (the hand-over of a batch to a captured step).
+// blockIdx.y = copy, blockIdx.x strides over it; the descriptors travel as kernel arguments (no table upload).
+// =================================================================================================
+struct CopyMulti {
+  void* dst[IGCN_COPY_MULTI_MAX];
+  const void* src[IGCN_COPY_MULTI_MAX];
+  int64_t nbytes[IGCN_COPY_MULTI_MAX];
+};
+__global__ void __launch_bounds__(256) k_copy_multi(CopyMulti cm) {
+  const int c = blockIdx.y;
+  const int64_t nb = cm.nbytes[c];
+  char* d = reinterpret_cast<char*>(cm.dst[c]);
+  const char* s = reinterpret_cast<const char*>(cm.src[c]);
+  const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  if ((((uintptr_t)d | (uintptr_t)s) & 15) == 0) {
+    const int64_t nv = nb >> 4;
+    for (int64_t i = first; i < nv; i += stride)
+      reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    for (int64_t i = (nv << 4) + first; i < nb; i += stride) d[i] = s[i];
+  } else {
+    for (int64_t i = first; i < nb; i += stride) d[i] = s[i];
+  }
+}
+
+extern "C" int igcn_copy_multi(int n, void* const* dst, const void* const* src, const int64_t* nbytes, void* stream) {
+  IGCN_REQUIRE(n >= 0 && n <= IGCN_COPY_MULTI_MAX, "copy_multi: n=%d outside [0, %d]", n, IGCN_COPY_MULTI_MAX);
+  if (n == 0) return IGCN_OK;
+  CopyMulti cm;
+  int64_t big = 0;
+  for (int c = 0; c < n; ++c) {
+    IGCN_REQUIRE(nbytes[c] >= 0 && (nbytes[c] == 0 || (dst[c] && src[c])), "copy_multi: bad descriptor %d", c);
+    cm.dst[c] = dst[c];
+    cm.src[c] = src[c];
+    cm.nbytes[c] = nbytes[c];
+    big = nbytes[c] > big ? nbytes[c] : big;
+  }
+  for (int c = n; c < IGCN_COPY_MULTI_MAX; ++c) { cm.dst[c] = nullptr; cm.src[c] = nullptr; cm.nbytes[c] = 0; }
+  // enough workgroups for the largest copy at 16 bytes per lane and ~4 vectors per thread, at most 64 per copy
+  int64_t gx = igcn_cdiv(igcn_cdiv(big, 16), 256 * 4);
+  gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+  hipLaunchKernelGGL(k_copy_multi, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, cm);
+  IGCN_CHECK_LAUNCH("copy_multi");
+  return IGCN_OK;
+}
+
+// =================================================================================================
 // Backward glue of y = act(x W^T + b) (ops.Linear): g = dy * [y > 0] (when y is given) and db[c] = sum_r g[r,c] in
 // ONE pass over dy — instead of compare + multiply + (memset + two-stage sum) as four library launches.
 // Rows are split over workgroups; each writes one [cols] partial, summed in order by the common row reduction.

@@ -14,6 +14,10 @@ edges), so the collation is a gather plus one offset add:
   into a ring of device staging batches; the consumer waits on the batch's event, copies it into the graphed step's
   static inputs (``GraphedTrainStep.load``) and replays.
 * ``DeviceFeeder``       store on the device: collation is a few device gathers on the launch stream.
+* ``DeviceGdcFeeder``    dense connectivity on the device: GDC pre-transform + collation of batch k + 1 on a second
+  stream while step k replays.
+* ``EpochIndex``         the index order all feeders draw from: ``randperm`` per epoch, every subject once (the
+  semantics of ``DataLoader(shuffle=True)``), ragged tail dropped or handed out as a shorter slice.
 """
 import queue
 import threading
@@ -145,9 +149,43 @@ def _like(batch, device, pin=False):
 
 
 def _copy_into(dst, src, non_blocking=True):
-    for k, v in src.__dict__.items():
-        if torch.is_tensor(v):
-            getattr(dst, k).copy_(v, non_blocking=non_blocking)
+    pairs = [(getattr(dst, k), v) for k, v in src.__dict__.items() if torch.is_tensor(v)]
+    if pairs and all(d.is_cuda and v.is_cuda for d, v in pairs):
+        from ._lib import copy_multi
+        copy_multi(pairs)                               # device to device: one launch (igcn_copy_multi)
+        return
+    for d, v in pairs:
+        d.copy_(v, non_blocking=non_blocking)
+
+
+class EpochIndex:
+    """The index stream of ``DataLoader(dataset, batch_size, shuffle=...)`` (kernel/train_eval_sgcn_img_snps.py:96-97)
+    for fixed-shape consumers: per epoch one ``torch.randperm(size)`` (``shuffle=True``; drawn from the seeded generator,
+    so the order of every epoch is reproducible) or ``arange(size)``, cut into consecutive slices of ``batch_size`` —
+    every subject exactly once per epoch.  ``drop_last=True`` (default: the captured step needs one shape) drops the
+    ``size % batch_size`` subjects of the ragged tail of each epoch, like ``DataLoader(drop_last=True)``;
+    ``drop_last=False`` yields the tail as a shorter index tensor (route it through ``train.EpochTrainer``)."""
+
+    def __init__(self, size, batch_size, seed=0, shuffle=True, drop_last=True, device="cpu"):
+        if batch_size > size and drop_last:
+            raise ValueError(f"batch_size {batch_size} exceeds the dataset ({size} subjects)")
+        self.size, self.bsz, self.shuffle, self.drop_last = int(size), int(batch_size), shuffle, drop_last
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device).manual_seed(seed)
+        self.epoch, self._order, self._pos = 0, None, 0
+
+    def per_epoch(self):
+        return self.size // self.bsz if self.drop_last else -(-self.size // self.bsz)
+
+    def next(self):
+        if self._order is None or self._pos >= (self.size - self.bsz + 1 if self.drop_last else self.size):
+            self._order = torch.randperm(self.size, generator=self.gen, device=self.device) if self.shuffle \
+                else torch.arange(self.size, device=self.device)
+            self._pos = 0
+            self.epoch += 1
+        idx = self._order[self._pos:self._pos + self.bsz]
+        self._pos += self.bsz
+        return idx
 
 
 class HostFeeder:
@@ -163,8 +201,7 @@ class HostFeeder:
         if store.device.type != "cpu":
             raise ValueError("HostFeeder reads a host-resident store")
         self.store, self.bsz, self.device, self.steps = store, int(batch_size), torch.device(device), int(steps)
-        self.gen = torch.Generator().manual_seed(seed)
-        self.shuffle = shuffle
+        self.index = EpochIndex(store.size, batch_size, seed, shuffle)       # every subject once per epoch
         proto = store.batch(torch.arange(self.bsz))
         self.host = [_like(proto, "cpu", pin=True) for _ in range(depth)]
         self.dev = [_like(proto, self.device) for _ in range(depth)]
@@ -178,9 +215,7 @@ class HostFeeder:
         self.error = None
 
     def _indices(self):
-        if self.shuffle:
-            return torch.randint(0, self.store.size, (self.bsz,), generator=self.gen)
-        return torch.arange(self.bsz)
+        return self.index.next()
 
     def _produce(self):
         try:
@@ -220,22 +255,95 @@ class HostFeeder:
         self.free.put((k, ev))
 
 
-class DeviceFeeder:
-    """Store resident in HBM: every batch is a few device gathers on the launch stream (no host data path)."""
+class _AheadOnSideStream:
+    """Batches built on the device ONE AHEAD of the train step and on a stream of their own: batch k + 1 has no
+    dependency on step k, so its gathers (and, for ``DeviceGdcFeeder``, the graph-diffusion transform) run beside the
+    replay of step k instead of in front of step k + 1 on the launch stream.  Hand-over by events:
 
-    def __init__(self, store, batch_size, steps, seed=0, shuffle=True):
-        if store.device.type != "cuda":
-            raise ValueError("DeviceFeeder reads a device-resident store")
-        self.store, self.bsz, self.steps = store, int(batch_size), int(steps)
-        self.gen = torch.Generator(device=store.device).manual_seed(seed)
-        self.shuffle = shuffle
-        self.slot = store.batch(torch.arange(self.bsz, device=store.device))
+        for batch in feeder:
+            torch.cuda.current_stream().wait_event(batch.ready)      # the side stream has finished this slot
+            step.load(batch); batch.release(); step()                # release: the slot may be refilled
+
+    ``depth`` output slots (>= 2) are allocated once; temporaries live on the side stream.  Subclasses provide
+    ``_build(idx) -> Batch`` and ``self.index`` (an ``EpochIndex`` on the device)."""
+
+    def _init_slots(self, device, steps, depth):
+        self.steps, self.depth = int(steps), max(2, int(depth))
+        self.side = torch.cuda.Stream(device=device)
+        proto = self._build(torch.arange(self.bsz, device=device), check=True)
+        self.slots = [_like(proto, device) for _ in range(self.depth)]
+        self.ready = [torch.cuda.Event() for _ in range(self.depth)]
+        self.consumed = [None] * self.depth
+        torch.cuda.synchronize(device)
+
+    def _produce(self, k):
+        slot = k % self.depth
+        if self.consumed[slot] is not None:
+            self.side.wait_event(self.consumed[slot])   # the consumer has copied the slot's previous batch out
+        with torch.cuda.stream(self.side):              # everything below is side-stream work: no wait on the step
+            _copy_into(self.slots[slot], self._build(self.index.next()), non_blocking=True)
+            self.ready[slot].record(self.side)
 
     def __iter__(self):
-        for _ in range(self.steps):
-            idx = torch.randint(0, self.store.size, (self.bsz,), generator=self.gen, device=self.store.device) \
-                if self.shuffle else torch.arange(self.bsz, device=self.store.device)
-            yield self.store.batch(idx, out=self.slot)
+        self._produce(0)
+        for k in range(self.steps):
+            if k + 1 < self.steps:
+                self._produce(k + 1)                    # enqueued before step k is: overlaps its replay
+            slot = k % self.depth
+            b = self.slots[slot]
+            b.ready = self.ready[slot]
+            b.release = lambda slot=slot: self._release(slot)
+            yield b
+
+    def _release(self, slot):
+        ev = torch.cuda.Event()
+        ev.record()                                     # behind the consumer's copies out of the slot
+        self.consumed[slot] = ev
+
+
+class DeviceFeeder(_AheadOnSideStream):
+    """Store resident in HBM: every batch is a few device gathers — no host data path — made one batch ahead on a side
+    stream (see ``_AheadOnSideStream`` for the hand-over protocol)."""
+
+    def __init__(self, store, batch_size, steps, seed=0, shuffle=True, depth=2):
+        if store.device.type != "cuda":
+            raise ValueError("DeviceFeeder reads a device-resident store")
+        self.store, self.bsz = store, int(batch_size)
+        self.index = EpochIndex(store.size, batch_size, seed, shuffle, device=store.device)
+        self._init_slots(store.device, steps, depth)
+
+    def _build(self, idx, check=False):
+        return self.store.batch(idx)
+
+
+class DeviceGdcFeeder(_AheadOnSideStream):
+    """Dense connectivity matrices resident in HBM -> graph-diffusion pre-transform (util_gdc.py:7-31,71-86) + collation
+    (batch.py:24-123) of every batch ON THE DEVICE, one batch ahead of the train step on a side stream: the fp64
+    Gauss-Jordan of batch k + 1 (igcn_gdc_topk, one workgroup per graph) runs beside the replay of step k.
+
+    ``cols``: per-subject tensors [S, ...] on the device (x [S, R, H0], snps_feat, y, clini_score, tsne_fdim, clust_y)."""
+
+    def __init__(self, adj, cols, batch_size, steps, top_k=3, alpha=0.05, seed=0, shuffle=True, depth=2):
+        from .gdc import batch_from_dense
+        if adj.device.type != "cuda":
+            raise ValueError("DeviceGdcFeeder reads device-resident matrices")
+        self.adj, self.cols, self.bsz = adj, cols, int(batch_size)
+        self.top_k, self.alpha = int(top_k), float(alpha)
+        self.index = EpochIndex(adj.shape[0], batch_size, seed, shuffle, device=adj.device)
+        self._make = batch_from_dense
+        self._init_slots(adj.device, steps, depth)
+
+    def _build(self, idx, check=False):
+        b = int(idx.numel())
+        sel = {k: torch.index_select(v, 0, idx) for k, v in self.cols.items()}
+        x = sel.pop("x")
+        per = {}
+        for k, v in sel.items():
+            per[k] = v.reshape(b, -1) if k in ("snps_feat", "tsne_fdim", "clini_score") else v.reshape(-1)
+        out = self._make(torch.index_select(self.adj, 0, idx), x, top_k=self.top_k, alpha=self.alpha, check=check,
+                         **per)
+        out.A = None                                    # the dense matrices are not an input of the step
+        return out
 
 
 def as_data_list(batch_size, **kw):

@@ -611,16 +611,17 @@ class GraphedTrainStep:
             if self.plan.nodes_per_graph and int(mn) * (int(bp.numel()) - 1) != self.plan.n_nodes:
                 raise ValueError("graphed step: the captured kernels assume uniform graphs of "
                                  f"{self.plan.nodes_per_graph} nodes")
-            with torch.no_grad():
-                node_ptr.copy_(bp, non_blocking=True)
-                edge_ptr.copy_(be, non_blocking=True)
+            pairs = [(node_ptr, bp), (edge_ptr, be)]
+        else:
+            pairs = []
         for k in ("x", "edge_index", "edge_attr", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y"):
             dst, src = getattr(self.data, k, None), getattr(batch, k, None)
             if dst is not None and src is not None:
                 if dst.shape != src.shape:
                     raise ValueError(f"graphed step needs fixed shapes; {k}: {tuple(src.shape)} vs {tuple(dst.shape)}")
-                with torch.no_grad():
-                    dst.copy_(src, non_blocking=True)
+                pairs.append((dst, src))
+        with torch.no_grad():
+            _lib.copy_multi(pairs)                      # one launch for the whole hand-over (igcn_copy_multi)
 
     def _own_the_table(self):
         opt = self.opt

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 400
+#define IGCN_ABI_VERSION 401
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -361,6 +361,14 @@ int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, const float* d
  * (kernel/sgcn_img_snp.py:223-224, kernel/sgcn.py:376-377 `torch.cat(xs, dim=1)`).  F % 4 == 0, 16-byte aligned
  * tensors; `parts` is a HOST array of device pointers. */
 int igcn_concat_cols(int64_t rows, int F, int nparts, const float* const* parts, float* out, void* stream);
+
+/* Hand-over of a new batch to a captured train step (train.GraphedTrainStep.load; the reference's
+ * `data = data.to(device)`, kernel/train_eval_sgcn_img_snps.py:517): up to IGCN_COPY_MULTI_MAX device-to-device copies
+ * of arbitrary byte counts as ONE launch — x, edge_index, edge_attr, snps_feat, y, clini_score, tsne_fdim, clust_y, ptr,
+ * edge_ptr of a batch are ten tensors of 1 KB - 1 MB, i.e. ten ~4 us copy launches in front of a 0.8 ms step otherwise.
+ * dst / src / nbytes are HOST arrays [n]; ranges must not overlap.  16-byte lanes where both ends are aligned. */
+#define IGCN_COPY_MULTI_MAX 16
+int igcn_copy_multi(int n, void* const* dst, const void* const* src, const int64_t* nbytes, void* stream);
 
 /* Measurement aid (bench.py roofline): the launch of igcn_gcn_propagate_fwd for (n_nodes, F) — thread =
  * (target, feature quad), or one wave per target when `dense` — with the body removed: mode 0 = empty kernel,

@@ -49,3 +49,26 @@ def test_gpus_2_self_launch_rehearsal_on_one_device():
     assert cfg["allreduce_us_per_step"] is not None and cfg["allreduce_us_per_step"] > 0
     assert math.isfinite(res["loss"]) and res["value"] > 0
     assert res["weak_scaling_efficiency_vs_n1"] == pytest.approx(res["value"] / 500000.0, abs=1e-4)
+    parts = res["distributed_step"]                              # the N > 1 step taken apart, per rank
+    assert parts["slowest_rank"] in (0, 1) and len(parts["device_us_per_step_by_rank"]) == 2
+    for key, vals in parts["per_rank_median_us"].items():
+        assert len(vals) == 2 and all(math.isfinite(v) for v in vals), key
+    assert res["timing"]["blocks"] == 5 and len(res["timing"]["ms_per_step_blocks"]) == 5
+    assert res["timing"]["ms_per_step_min"] <= res["ms_per_step"] <= res["timing"]["ms_per_step_max"]
+
+
+@pytest.mark.gpu
+def test_sweep_prints_one_line_per_n_with_efficiency():
+    """IGCN_BENCH_SWEEP="1,2": one invocation, a fresh child per N, the N = 2 line scaled by the sweep's own N = 1 run."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IGCN_BENCH_N1_VALUE")}
+    env.update(IGCN_BENCH_ONE_DEVICE="1", IGCN_BENCH_SWEEP="1,2")
+    r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--blocks", "2", "--no-roofline",
+                        "--no-cpu-baseline", "--no-pipeline", "--no-stress"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip()]
+    assert [ln["n_gpus"] for ln in lines] == [1, 2]
+    assert "weak_scaling_efficiency_vs_n1" not in lines[0]
+    assert lines[1]["weak_scaling_efficiency_vs_n1"] == pytest.approx(lines[1]["value"] / (2 * lines[0]["value"]), abs=1e-3)

@@ -330,3 +330,41 @@ def test_flat_adam_state_dict_interchanges_with_torch_adam():
     assert float(opt.lr_dev.item()) == pytest.approx(1e-3) and opt.lr == pytest.approx(1e-3)
     with pytest.raises(ValueError):
         opt.param_groups[0]["weight_decay"] = 1e-4
+
+
+def test_copy_multi_moves_the_same_bytes_as_copy():
+    """igcn_copy_multi (the one-launch hand-over of GraphedTrainStep.load): mixed dtypes and sizes, unaligned views
+    (byte path), empty tensors, more pairs than one launch takes — bit-identical to Tensor.copy_."""
+    from igcn_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(5)
+    shapes = [((23040, 3), torch.float32), ((2, 69120), torch.int64), ((69120,), torch.float32), ((256, 54), torch.float32),
+              ((256,), torch.int64), ((768,), torch.float32), ((257,), torch.int64), ((0,), torch.float32),
+              ((13,), torch.uint8), ((1000003,), torch.uint8)]
+    shapes = shapes + shapes                                   # 20 pairs: two launches
+    pairs = []
+    for shp, dt in shapes:
+        n = int(np.prod(shp))
+        raw = torch.randint(0, 255, (n * torch.empty(0, dtype=dt).element_size() + 32,), dtype=torch.uint8, device="cuda",
+                            generator=g)
+        src = raw[16:16 + n * torch.empty(0, dtype=dt).element_size()].view(dt).view(shp)
+        dst = torch.zeros(shp, dtype=dt, device="cuda")
+        pairs.append((dst, src))
+    # an unaligned source / destination (byte path): 1-byte offset views
+    a = torch.randint(0, 255, (4099,), dtype=torch.uint8, device="cuda", generator=g)
+    b = torch.zeros(4099, dtype=torch.uint8, device="cuda")
+    pairs.append((b[1:4098], a[2:4099]))
+    # a host source and a dtype change fall back to copy_
+    host = torch.arange(77, dtype=torch.float32)
+    dev = torch.zeros(77, device="cuda")
+    as_int = torch.zeros(5, dtype=torch.int32, device="cuda")
+    pairs += [(dev, host), (as_int, torch.arange(5, device="cuda", dtype=torch.int64))]
+    _lib.copy_multi(pairs)
+    torch.cuda.synchronize()
+    def raw(t):                                            # bytes, not values: random bytes make NaNs, and NaN != NaN
+        return t.cpu().contiguous().reshape(-1).view(torch.uint8)
+    for dst, src in pairs:
+        if dst.dtype == src.dtype:
+            assert torch.equal(raw(dst), raw(src)), (dst.shape, dst.dtype)
+        else:
+            assert torch.equal(dst.cpu(), src.cpu().to(dst.dtype)), (dst.shape, dst.dtype)
+    assert int(b[0]) == 0 and int(b[4098]) == 0            # nothing written outside the ranges

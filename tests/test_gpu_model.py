@@ -257,47 +257,47 @@ def test_full_model_vs_oracle_larger(bsz, pool, explain):
         assert_matches(params[k].grad, sdo[k].grad.numpy(), 1e-3, "grad " + k, floor=1e-6)
 
 
-def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch):
-    """TRAINING mode (batch statistics in every BatchNorm, dropout off) at the benchmark's own dimensions — R = 90,
-    L = 2, h = 16, the 3000-node GO DAG (LDS-resident GO attention backward, LDS decoder), B = 32 — with the CSR
-    SNP <-> GO maps the 256-graph step uses (``sparse``; the default at B = 32 is the dense-image form): the seven loss
-    terms of train() at 1e-4 and every gradient at 1e-3 against the fp64 oracle, both step formulations."""
-    from igcn_amd import synth
+def train_mode_vs_oracle(monkeypatch, rois, pool, bsz, dense=False, bf16=False, maps=("sparse", "default"),
+                         graph_seed=78, go_seed=1, tol=1e-4, gtol=1e-3, max_flips=40, band=2e-5, formulations=(True, False)):
+    """TRAINING mode (batch statistics in every BatchNorm, dropout off) of the HIP model against the fp64 oracle: the
+    seven loss terms of train() at ``tol`` and every gradient at ``gtol``, for the step formulations ``formulations``
+    (True: both passes as one 2B-sample sweep; False: two forward() calls).  Returns the number of imposed ReLU
+    decisions.
+
+    ReLU decisions.  tools/relu_margin.py at the default shapes: B.0's smallest pre-activation is 1.5e-6 of its layer's
+    scale; fp32 puts it on the other side of zero, and d B.0.bias[node] — a 32-term sum of scale 7e-4 — moves by one
+    3e-5 summand (5 % of that tensor's scale; d conc.weight, a cancelling sum behind a training-mode BatchNorm, by
+    2 %), while everything else stays below 4e-4.  Instead of a blanket allowance the test OBSERVES the HIP path's
+    decisions (the post-ReLU activations its fused kernels return), imposes them on the fp64 oracle where the
+    pre-activation is within ``band`` of zero, requires agreement everywhere else, and holds every gradient to ``gtol``."""
+    from conftest import relu_forced
+    from igcn_amd import ops, synth
     from igcn_amd.data import Batch
     from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
     from igcn_amd.train import losses
     from oracle import go_network as OG, sgcn_img_snp as OS
-    pool, bsz = (1800, 800, 300, 99, 1), 32
     lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
-    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=1)
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=go_seed)
     a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
-    model = SGCN_GCN_IMGSNP(2, 16, a_g, a, pool_dim, 32, "cuda", rois=90, H_0=3, num_classes=3,
+    model = SGCN_GCN_IMGSNP(2, 16, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=3, num_classes=3,
                             isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
-                            isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False).cuda().train()
+                            isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False, bf16_transforms=bf16).cuda().train()
     sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, 5)
     model.load_state_dict(sd)
     for m in (model, model.go_network):
         m._dropout_enabled = False
-    graphs = synth.brain_graph_list(bsz, seed=78, rois=90, tsne_dim=16)
+    graphs = synth.brain_graph_list(bsz, seed=graph_seed, rois=rois, tsne_dim=16, dense=dense)
     # oracle, fp64, training mode
     a_g_c, a_c = synth.go_sparse_inputs(go_snps, adj)
     idx = OG.go_index_sets(a_g_c, a_c, list(pool), 2)
-    cfg = SimpleNamespace(num_layers=2, rois=90, image_only=False, rbf_gamma=0.01)
-    # ReLU decisions.  tools/relu_margin.py at these shapes: B.0's smallest pre-activation is 1.5e-6 of its layer's
-    # scale; fp32 puts it on the other side of zero, and d B.0.bias[node] — a 32-term sum of scale 7e-4 — moves by one
-    # 3e-5 summand (5 % of that tensor's scale; d conc.weight, a cancelling sum behind a training-mode BatchNorm, by
-    # 2 %), while everything else stays below 4e-4.  Instead of a blanket allowance the test OBSERVES the HIP path's
-    # decisions (the post-ReLU activations its fused kernels return), imposes them on the fp64 oracle where the
-    # pre-activation is within 2e-5 of zero, requires agreement everywhere else, and holds every gradient to 1e-3.
-    from conftest import relu_forced
-    from igcn_amd import ops
-    n0, n1, n_top = sum(pool), sum(pool[1:]), sum(pool[2:])
+    cfg = SimpleNamespace(num_layers=2, rois=rois, image_only=False, rbf_gamma=0.01)
+    n0, n1 = sum(pool), sum(pool[1:])
 
     def hip_run(batched):
         """(loss, terms, grads, forced decisions per oracle ReLU site, ignore masks) of one HIP evaluation."""
         seen = {}
-        classes = (ops.SgcnStack, ops.GoAttentionLN, ops.GoDecodeLN, ops.NodeLinearBNPair, ops.NodeLinearBN, ops.BatchNorm1dGrouped,
-                   ops.Linear, ops.LinearPair)
+        classes = (ops.SgcnStack, ops.DenseSgcn, ops.GoAttentionLN, ops.GoDecodeLN, ops.NodeLinearBNPair, ops.NodeLinearBN,
+                   ops.BatchNorm1dGrouped, ops.Linear, ops.LinearPair)
         model.load_state_dict(sd)                                     # running statistics back to the start
         model.zero_grad()
         model.batched_passes = batched
@@ -319,6 +319,7 @@ def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch):
         def halves(t):                      # stacked sweep: rows [0,B) plain pass, [B,2B) masked pass; else one pass each
             t = t.detach().cpu()
             return [t[:t.shape[0] // 2], t[t.shape[0] // 2:]] if batched else None
+
         def per_pass(name, k_th, pick=lambda o: o):
             """The k-th call's output per pass: batched -> the two halves of call k; else calls k (plain), k + n (masked)."""
             calls = seen[name]
@@ -326,12 +327,16 @@ def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch):
                 return halves(pick(calls[k_th]))
             n = len(calls) // 2
             return [pick(calls[k_th]).detach().cpu(), pick(calls[n + k_th]).detach().cpu()]
-        xc = per_pass("SgcnStack", 0, lambda o: o[0] if isinstance(o, tuple) else o)
-        first = lambda o: o[0] if isinstance(o, tuple) else o        # the last encoder layer returns three aliases
+        stack = "DenseSgcn" if "DenseSgcn" in seen else "SgcnStack"    # complete graphs run on the dense blocks
+        xc = per_pass(stack, 0, lambda o: o[0] if isinstance(o, tuple) else o)
+        first = lambda o: o[0] if isinstance(o, tuple) else o        # noqa: E731 — the last encoder layer returns three aliases
         ln = [per_pass("GoAttentionLN", k, first) for k in range(2)] + [per_pass("GoDecodeLN", k) for k in range(2)]
-        att = per_pass("NodeLinearBNPair", 0, lambda o: o[0])
-        inp = per_pass("NodeLinearBNPair", 0, lambda o: o[1])
-        outd = per_pass("NodeLinearBN", 0)
+        if "NodeLinearBNPair" in seen:
+            att = per_pass("NodeLinearBNPair", 0, lambda o: o[0])
+            inp = per_pass("NodeLinearBNPair", 0, lambda o: o[1])
+            outd = per_pass("NodeLinearBN", 0)
+        else:                                # read-outs as three single launches: attention, input, gene decoding
+            att, inp, outd = (per_pass("NodeLinearBN", k) for k in range(3))
         hb = [per_pass("BatchNorm1dGrouped", k) for k in range(2)]
         lp = [per_pass("LinearPair", 0, lambda o, i=i: o[i]) for i in range(2)]
         for p_ in range(2):
@@ -358,34 +363,43 @@ def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch):
         return loss, terms, grads, forced, ignore
 
     flips_seen = 0
-    for maps in ("sparse", "default"):
-        if maps == "sparse":
+    for mp_ in maps:
+        if mp_ == "sparse":
             monkeypatch.setenv("IGCN_SPARSE_MAPS", "1")
         else:
             monkeypatch.delenv("IGCN_SPARSE_MAPS", raising=False)
-        for batched in (True, False):
+        for batched in formulations:
             loss, terms, got, forced, ignore = hip_run(batched)
             st = OS.make_leaf_state(sd, dtype=torch.float64)
             dd = Batch.from_data_list(graphs)
             dd.x = dd.x.double().requires_grad_(True)
             dd.edge_attr, dd.snps_feat = dd.edge_attr.double(), dd.snps_feat.double()
             dd.tsne_fdim, dd.clini_score = dd.tsne_fdim.double(), dd.clini_score.double()
-            with relu_forced(forced, ignore=ignore) as rf:
+            with relu_forced(forced, band=band, ignore=ignore) as rf:
                 ref_loss, ref_terms, _ = OS.train_losses(st, cfg, idx, dd, lam, dropout=False)
             ref_loss.backward()
-            assert rf.mismatch_outside == 0, (maps, batched, rf.mismatch_outside)   # decisions agree outside the band
-            assert rf.flips <= 40, rf.flips                                           # of ~3.3 M
+            assert rf.mismatch_outside == 0, (mp_, batched, rf.mismatch_outside)     # decisions agree outside the band
+            assert rf.flips <= max_flips, rf.flips
             flips_seen += rf.flips
-            assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss))), (batched, float(loss))
+            assert abs(float(loss) - float(ref_loss)) <= tol * max(1.0, abs(float(ref_loss))), (batched, float(loss))
             for k, v in terms.items():
                 r = float(ref_terms[k])
-                assert abs(float(v) - r) <= 1e-4 * max(1.0, abs(r)), (batched, k, float(v), r)
+                assert abs(float(v) - r) <= tol * max(1.0, abs(r)), (batched, k, float(v), r)
             want = {k: st[k].grad for k in OS.trainable_keys(st) if st[k].grad is not None}
             want["data.x"] = dd.x.grad
             for k, w in want.items():
-                assert_matches(got[k], w.numpy(), 1e-3, f"grad {k} (maps={maps}, batched={batched}, "
+                assert_matches(got[k], w.numpy(), gtol, f"grad {k} (maps={mp_}, batched={batched}, "
                                                         f"{rf.flips} imposed decisions)", floor=1e-6)
-    assert flips_seen > 0                     # the mechanism is exercised: B.0 has a node that close to zero
+    return flips_seen
+
+
+def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch):
+    """TRAINING mode at the benchmark's own dimensions — R = 90, L = 2, h = 16, the 3000-node GO DAG (LDS-resident GO
+    attention backward, LDS decoder), B = 32 — with the CSR SNP <-> GO maps the 256-graph step uses (``sparse``; the
+    default at B = 32 is the dense-image form): the seven loss terms of train() at 1e-4 and every gradient at 1e-3
+    against the fp64 oracle, both step formulations."""
+    flips = train_mode_vs_oracle(monkeypatch, 90, (1800, 800, 300, 99, 1), 32)
+    assert flips > 0                          # the mechanism is exercised: B.0 has a node that close to zero (of ~3.3 M)
 
 
 # ---- the image-only sibling SGCN_GCN (kernel/sgcn.py:272-388; BASELINE configs[0]/[1]) -------------------------

@@ -154,3 +154,17 @@ def test_stress_shape_graphed_train_step_equals_eager_at_b32(go):
         d = (p1.detach() - p2.detach()).abs()
         tol = torch.full_like(d, 2e-4) if p2.grad is None else torch.where(p2.grad.abs() > 1e-6, 2e-4, 3.5e-3)
         assert bool((d <= tol).all()), (k, float(d.max()))
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_stress_shape_train_mode_losses_and_gradients_vs_fp64_oracle(monkeypatch, bf16):
+    """TRAINING mode at the configs[4] dims — R = 512 complete graphs (dense-block SGCN path), N = 10 000 GO nodes (the
+    GLOBAL-memory GO kernels: k_go_attn_bwd_main, k_go_decode_fwd, k_nodes_ln_bwd_dy_v — N does not fit LDS), batch
+    statistics in every BatchNorm, dropout off, B = 4, both step formulations — against the fp64 oracle: the seven
+    loss terms of train() at 1e-4 and every gradient at 1e-3 on the fp32 path, the stated bf16 bounds otherwise
+    (kernel/go_model.py:236-275, kernel/train_eval_sgcn_img_snps.py:521-543)."""
+    from test_gpu_model import train_mode_vs_oracle
+    tol, gtol = (BF16_TOL, BF16_GTOL) if bf16 else (1e-4, 1e-3)
+    # a 4-sample BatchNorm over 10 000 nodes puts more pre-activations next to zero than the 32-sample default case
+    train_mode_vs_oracle(monkeypatch, ROIS, POOL, 4, dense=True, bf16=bf16, maps=("default",), graph_seed=79,
+                         tol=tol, gtol=gtol, max_flips=400, band=2e-5 if not bf16 else 2e-2)

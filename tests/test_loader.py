@@ -57,3 +57,25 @@ def test_store_batches_equal_from_data_list_and_reuse_their_slot():
     _same(first, Batch.from_data_list([graphs[i] for i in idx2.tolist()]))
     with pytest.raises(ValueError):
         UniformGraphStore(ragged_graph_list(3))
+
+
+def test_epoch_index_visits_every_subject_once_per_epoch():
+    """The feeders' index order is DataLoader(shuffle=True)'s (kernel/train_eval_sgcn_img_snps.py:96-97): a permutation per
+    epoch cut into batches, reproducible from the seed; the ragged tail is dropped or handed out as a short slice."""
+    from igcn_amd.loader import EpochIndex
+    ix = EpochIndex(10, 4, seed=3, shuffle=True, drop_last=True)
+    assert ix.per_epoch() == 2
+    e1 = torch.cat([ix.next(), ix.next()])
+    e2 = torch.cat([ix.next(), ix.next()])
+    assert ix.epoch == 2 and len(set(e1.tolist())) == 8 and len(set(e2.tolist())) == 8
+    assert e1.tolist() != e2.tolist()
+    again = EpochIndex(10, 4, seed=3, shuffle=True, drop_last=True)
+    assert torch.equal(torch.cat([again.next(), again.next()]), e1)
+    full = EpochIndex(10, 4, seed=3, shuffle=True, drop_last=False)
+    parts = [full.next() for _ in range(3)]
+    assert [p.numel() for p in parts] == [4, 4, 2] and sorted(torch.cat(parts).tolist()) == list(range(10))
+    assert full.next().numel() == 4 and full.epoch == 2
+    seq = EpochIndex(6, 3, shuffle=False)
+    assert [seq.next().tolist() for _ in range(3)] == [[0, 1, 2], [3, 4, 5], [0, 1, 2]]
+    with pytest.raises(ValueError):
+        EpochIndex(3, 4)
