@@ -180,28 +180,50 @@ extern "C" int igcn_dense_sgcn_reg_blocks(int64_t n_graphs, int R) { return (int
 // =================================================================================================
 // structure check: edge k of graph g must be (g R + k / R, g R + k % R)
 // =================================================================================================
+// A pure read stream of 16 bytes per edge: one matrix ROW (R edges of one source) per trip of a workgroup, four rows'
+// loads in flight per thread, the row's (graph, source) from ONE 32-bit division per row (round 3 divided 64-bit
+// integers twice per edge pair: the check ran at 0.62 of the HBM rate on integer arithmetic).
+// status[0] |= 4 (sticky: GraphPlan.check() reports it); status[1] |= 1 (consumed — and cleared — by the next
+// igcn_dense_sgcn_fwd, which turns it into NaN degrees: a batch that is not what the dense-block kernels assume cannot
+// train silently).
+#define DS_CHK_ROWS 4
 __global__ void __launch_bounds__(256)
-k_ds_check(int64_t n_edges, int R, const int64_t* __restrict__ ei, int32_t* __restrict__ status) {
-  const int64_t rr = (int64_t)R * R;
+k_ds_check(int64_t n_rows, int R, const int64_t* __restrict__ ei, int64_t n_edges, int32_t* __restrict__ status) {
   bool bad = false;
-  for (int64_t k = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; k < n_edges; k += (int64_t)gridDim.x * 512) {
-    const longlong2 s2 = *reinterpret_cast<const longlong2*>(ei + k);               // n_edges = G R^2: even, 16-B aligned
-    const longlong2 d2 = *reinterpret_cast<const longlong2*>(ei + n_edges + k);
-    const int64_t g = k / rr, rem = k - g * rr;                                      // k, k + 1 lie in the same row (R even)
-    const int64_t s = rem / R, d = rem - s * R;
-    bad |= s2.x != g * R + s || s2.y != g * R + s || d2.x != g * R + d || d2.y != g * R + d + 1;
+  for (int64_t r0 = (int64_t)blockIdx.x * DS_CHK_ROWS; r0 < n_rows; r0 += (int64_t)gridDim.x * DS_CHK_ROWS) {
+    for (int d = threadIdx.x * 2; d < R; d += 512) {
+      longlong2 s2[DS_CHK_ROWS], d2[DS_CHK_ROWS];
+#pragma unroll
+      for (int i = 0; i < DS_CHK_ROWS; ++i) {
+        const int64_t row = r0 + i < n_rows ? r0 + i : r0, k = row * R + d;       // (n_rows = G R; R even: 16-B aligned)
+        s2[i] = *reinterpret_cast<const longlong2*>(ei + k);
+        d2[i] = *reinterpret_cast<const longlong2*>(ei + n_edges + k);
+      }
+#pragma unroll
+      for (int i = 0; i < DS_CHK_ROWS; ++i) {
+        const int64_t row = r0 + i < n_rows ? r0 + i : r0;
+        const unsigned g = (unsigned)row / (unsigned)R;                            // (row < 2^31: checked by the caller)
+        const int64_t src = row, dst = (int64_t)g * R + d;                        // source id == row index
+        bad |= s2[i].x != src || s2[i].y != src || d2[i].x != dst || d2[i].y != dst + 1;
+      }
+    }
   }
-  if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(status, 4);
+  if (__syncthreads_or(bad) && threadIdx.x == 0) {
+    atomicOr(status, 4);
+    atomicOr(status + 1, 1);
+  }
 }
 
 extern "C" int igcn_dense_blocks_check(int64_t n_graphs, int R, const int64_t* edge_index, int32_t* status,
                                        void* stream) {
   IGCN_REQUIRE(n_graphs > 0 && R > 0 && R % 2 == 0 && edge_index && status && ((uintptr_t)edge_index & 15) == 0,
                "dense_blocks_check: bad arguments (R even, 16-byte aligned edge_index)");
-  const int64_t ne = n_graphs * R * R;
-  int64_t blocks = igcn_cdiv(ne, 512 * 8);
+  const int64_t rows = n_graphs * R, ne = rows * R;
+  IGCN_REQUIRE(rows < ((int64_t)1 << 31), "dense_blocks_check: more than 2^31 nodes");
+  int64_t blocks = igcn_cdiv(rows, DS_CHK_ROWS);
   blocks = blocks > 8192 ? 8192 : blocks;
-  hipLaunchKernelGGL(k_ds_check, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ne, R, edge_index, status);
+  hipLaunchKernelGGL(k_ds_check, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, R, edge_index, ne,
+                     status);
   IGCN_CHECK_LAUNCH("dense_blocks_check");
   return IGCN_OK;
 }
@@ -251,8 +273,11 @@ struct DsDegBuf {
 template <int NC, bool M0, bool PIPE>
 __global__ void __launch_bounds__(512)
 k_ds_deg(int R, int64_t GR, const float* __restrict__ ew, const float* __restrict__ u, const float* __restrict__ v,
-         float* __restrict__ dis, DsReg rg, float inv_ne, float* __restrict__ reg_partial) {
+         float* __restrict__ dis, DsReg rg, float inv_ne, float* __restrict__ reg_partial, int32_t* __restrict__ status) {
   constexpr bool ANYM = NC == 2 || M0;
+  // the structure check of this batch (igcn_dense_blocks_check, earlier on this stream) found edges that are not the
+  // row-major complete graph these kernels assume: the degrees — and through them every output and the loss — become NaN
+  const bool poisoned = status != nullptr && *reinterpret_cast<volatile int32_t*>(status + 1) != 0;
   __shared__ float red[8][NC][64];
   __shared__ float rsum[16];
   int g, xb;
@@ -323,13 +348,14 @@ k_ds_deg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
     float deg = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 8; ++ww) deg += red[ww][c][dl];
-    dis[(int64_t)c * GR + nb + d0 + dl] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;
+    dis[(int64_t)c * GR + nb + d0 + dl] = poisoned ? __int_as_float(0x7fc00000) : (deg > 0.f ? 1.0f / sqrtf(deg) : 0.f);
   }
+  if (poisoned && blockIdx.x == 0 && tid == 0) status[1] = 0;       // consumed: the next batch is judged on its own check
   if (ANYM && reg_partial && tid == 0) {
     float t = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 8; ++ww) t += rsum[ww];
-    reg_partial[(int64_t)g * (R / 64) + xb] = t * inv_ne;
+    reg_partial[(int64_t)g * (R / 64) + xb] = poisoned ? __int_as_float(0x7fc00000) : t * inv_ne;
   }
 }
 
@@ -463,7 +489,8 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
     for (int ww = 0; ww < 8; ++ww) a += part[((ww * NC + c) * 64 + dl) * DS_F + f];
     const int64_t node = (int64_t)c * GR + nb + d0 + dl;
     agg[node * DS_F + f] = a;
-    const float y = fmaxf(e_dis[k] * a + e_bias, 0.f);
+    const float t_ = e_dis[k] * a + e_bias;
+    const float y = t_ < 0.f ? 0.f : t_;                 // ReLU that lets NaN through (fmaxf would swallow the poisoned degrees)
     xcat[node * ldx + col0 + f] = y;
     ys[(c * 64 + dl) * DS_F + f] = y;
   }
@@ -948,7 +975,8 @@ extern "C" int igcn_dense_sgcn_fwd(int64_t n_graphs, int R, int H0, int F, int L
                                    const float* x, const float* prob, const float* prob_bias, const float* ew,
                                    const float* const* W /*HOST [L]*/, const float* const* b /*HOST [L]*/,
                                    const float* snps_prob, int n_snps, float l1_x, float ent_x, float l1_e, float ent_e,
-                                   float eps, float* xcat, float* reg_partials, float* ws, void* stream) {
+                                   float eps, float* xcat, float* reg_partials, float* ws, int32_t* status,
+                                   void* stream) {
   int rc = ds_check_args("dense_sgcn_fwd", n_graphs, R, H0, F, L, copies);
   if (rc) return rc;
   IGCN_REQUIRE(((uintptr_t)ew & 15) == 0 && ((uintptr_t)ws & 15) == 0, "dense_sgcn_fwd: ew / ws must be 16-byte aligned");
@@ -969,7 +997,7 @@ extern "C" int igcn_dense_sgcn_fwd(int64_t n_graphs, int R, int H0, int F, int L
                                                        // staged transposed aggregation additionally R <= 512
 #define DS_PIPE(...) if (pipe) { constexpr bool PIPE = true; __VA_ARGS__; } else { constexpr bool PIPE = false; __VA_ARGS__; }
   DS_DISPATCH(DS_PIPE(hipLaunchKernelGGL((k_ds_deg<NC, M0, PIPE>), eg, dim3(512), 0, st, R, GR, ew, ws + o.u, ws + o.v,
-                                         ws + o.dis, rg, inv_ne, regp)));
+                                         ws + o.dis, rg, inv_ne, regp, status)));
   DS_DISPATCH(hipLaunchKernelGGL((k_ds_h0<NC, M0>), dim3((unsigned)igcn_cdiv((int64_t)copies * GR * DS_F, 256)),
                                  dim3(256), 0, st, GR, R, H0, x, prob, W[0], ws + o.dis, ws + o.hp));
   const size_t lds = (size_t)(8 * copies * 64 * DS_F + copies * 64 * DS_F) * sizeof(float);

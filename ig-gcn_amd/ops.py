@@ -158,7 +158,7 @@ class GraphPlan:
         if have_seg:
             # per-graph builds (hand-written, hipGraph-capturable): all in LDS for small graphs, tiled counting sort
             # for graphs with more than SEG_MAX_EDGES edges (dense 512-ROI graphs)
-            self.status = torch.zeros(1, **i32)
+            self.status = torch.zeros(2, **i32)          # [0] sticky flags (check()), [1] consumed by the dense kernels
             self._seg = (node_ptr.contiguous(), edge_ptr.contiguous(), int(max_nodes), int(max_edges))
             self._tiled = max_edges > self.SEG_MAX_EDGES
             if self.nodes_per_graph:                    # uniform graphs: (nodes, max edges) per graph
@@ -237,7 +237,7 @@ class GraphPlan:
 
     def check(self):
         """Host-synchronising validation of the segmented build (tests / debugging only)."""
-        code = int(self.status.item()) if self.status is not None else 0
+        code = int(self.status[0].item()) if self.status is not None else 0
         if code & 4:
             raise _lib.IgcnError("dense-block plan: the batch is not made of complete graphs in row-major order any "
                                  "more (build a new plan for it)")
@@ -600,10 +600,12 @@ class DenseSgcn(torch.autograd.Function):
     passes of a train step: ``mode`` "plain" (isExplain=False), "masked" (isExplain=True) or "both" (rows [0, N) of
     ``xcat`` the plain pass, [N, 2N) the masked pass).  ``ew`` is read as the dense matrix [G, R, R] it is; no plan
     arrays, no per-edge intermediates (csrc/sgcn_dense.hip).  Returns (xcat, partials of loss_probability — their
-    SUM is the loss; empty for "plain").  ``reg`` = (l1_x, ent_x, l1_e, ent_e, eps)."""
+    SUM is the loss; empty for "plain").  ``reg`` = (l1_x, ent_x, l1_e, ent_e, eps).  ``status``: the plan's device
+    status words (``GraphPlan.status``, int32[2]) or None — when the structure check of the batch (``plan.rebuild``)
+    has flagged it, the kernels turn the degrees into NaN, so loss and gradients are NaN instead of silently wrong."""
 
     @staticmethod
-    def forward(ctx, x, ew, prob, prob_bias, snps_prob, mode, rois, reg, *wb):
+    def forward(ctx, x, ew, prob, prob_bias, snps_prob, mode, rois, reg, status, *wb):
         x, ew, prob, pb = _f32(x), _f32(ew), _f32(prob), _f32(prob_bias)
         sp = _f32(snps_prob) if snps_prob is not None else None
         wb = [_f32(t) for t in wb]
@@ -623,7 +625,7 @@ class DenseSgcn(torch.autograd.Function):
         ctx.reg = tuple(float(v) for v in reg)
         call("igcn_dense_sgcn_fwd", g, rois, h0, f, layers, copies, first_masked, ptr(x), ptr(prob), ptr(pb), ptr(ew),
              wp, bp, ptr(sp), sp.numel() if sp is not None else 0, *ctx.reg, ptr(xcat), ptr(regp) if anym else None,
-             ptr(ws), stream_ptr())
+             ptr(ws), ptr(status) if status is not None and status.numel() >= 2 else None, stream_ptr())
         ctx.save_for_backward(x, ew, prob, pb, sp, xcat, ws, *wb)
         ctx.cfg = (g, rois, h0, f, layers, copies, first_masked, anym)
         ctx.final = _leaves(pb, *wb)
@@ -661,7 +663,7 @@ class DenseSgcn(torch.autograd.Function):
             grads.append(dpar[off:off + f * fin].view(f, fin))
             grads.append(dpar[off + f * fin:off + f * fin + f])
             off += f * fin + f
-        return (dx, None, dprob, dpb, dsp, None, None, None, *grads)
+        return (dx, None, dprob, dpb, dsp, None, None, None, None, *grads)
 
 
 # =================================================================================================

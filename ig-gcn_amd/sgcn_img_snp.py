@@ -325,7 +325,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                 sp_d, sp_m = ops.GradFan.apply(self.snps_prob, 2)
                 x_d, x_h = ops.GradFan.apply(x, 2)
             xcat, regp = ops.DenseSgcn.apply(x_d, edge_weight, prob_d, self.prob_bias, sp_d, mode, self.rois,
-                                             self._reg_hp, *wb)
+                                             self._reg_hp, plan.status, *wb)
             if mode != "plain":
                 self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp), self._reg_key(x, edge_weight))
             if mode == "plain":

@@ -111,7 +111,7 @@ def test_dense_sgcn_vs_fp64_oracle(mode, rois, n_graphs, layers):
         wb += [dev["conv1.lin.weight"], dev["conv1.bias"]] if l == 0 else [dev[f"convs.{l - 1}.lin.weight"],
                                                                             dev[f"convs.{l - 1}.bias"]]
     reg_hp = (HP.lamda_x_l1, HP.lamda_x_ent, HP.lamda_e_l1, HP.lamda_e_ent, 1e-6)
-    xcat, regp = ops.DenseSgcn.apply(xg, bd.edge_attr, dev["prob"], dev["prob_bias"], dev["snps_prob"], mode, rois, reg_hp,
+    xcat, regp = ops.DenseSgcn.apply(xg, bd.edge_attr, dev["prob"], dev["prob_bias"], dev["snps_prob"], mode, rois, reg_hp, None,
                                      *wb)
     assert_matches(xcat, want_xcat.numpy(), 1e-4, "xcat")
     total = (xcat * cot.cuda()).sum()
@@ -173,3 +173,77 @@ def test_model_takes_the_dense_path_and_matches_the_general_kernels(monkeypatch)
         assert set(gd) == set(gg)
         for k in gg:
             assert_matches(gd[k], gg[k].cpu().numpy(), 2e-4, "grad " + k, floor=1e-6)
+
+
+def _poison_fixture(rois, bsz):
+    import copy
+    from igcn_amd import synth
+    from igcn_amd.data import Batch
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    go_snps, adj, pool_dim = synth.go_hierarchy((40, 20, 10, 4, 1), seed=3)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+    torch.manual_seed(0)
+    model = SGCN_GCN_IMGSNP(2, 16, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=3, num_classes=3, isSoftSimilarity=True,
+                            rbf_gamma=0.01, isCrossAtten=True, num_regr=3, isuseProb4Regr=True, isImageOnly=False,
+                            isSNPsOnly=False).cuda().train()
+    for m in (model, model.go_network):
+        m._dropout_enabled = False
+    make = lambda: Batch.from_data_list(synth.brain_graph_list(bsz, seed=5, rois=rois, tsne_dim=16, dense=True)).to("cuda")  # noqa: E731
+    good = make()
+    # the same shapes, but two edges of graph 1 swapped: not the row-major complete graph any more
+    bad = copy.copy(good)
+    bad.edge_index = good.edge_index.clone()
+    k = rois * rois + 7
+    bad.edge_index[:, [k, k + 1]] = bad.edge_index[:, [k + 1, k]]
+    bad._igcn_plan = None
+    return model, good, bad, make
+
+
+def test_a_batch_that_is_not_row_major_complete_poisons_the_loss():
+    """the dense-block kernels never read ``edge_index``; ``plan.rebuild`` verifies it on the device
+    (igcn_dense_blocks_check) and a failed check must not train silently — the next forward turns the degrees, hence
+    the outputs and the loss, into NaN, for that batch only (the flag is consumed)."""
+    from igcn_amd import ops
+    from igcn_amd.train import losses
+    model, good, bad, _ = _poison_fixture(64, 4)
+    plan = ops.plan_for(good)
+    assert plan.dense_blocks
+    loss, _, _ = losses(model, good)
+    assert bool(torch.isfinite(loss))
+    plan.rebuild(bad.edge_index)                                   # what every step does: the device-side check
+    bad._igcn_plan = plan
+    loss_bad, _, _ = losses(model, bad)
+    assert bool(torch.isnan(loss_bad))
+    with torch.no_grad():                                          # the plain (eval-style) pass shows it in its outputs
+        plan.rebuild(bad.edge_index)
+        out = model(bad, None, "cuda")
+    assert bool(torch.isnan(out[2]).any())
+    with pytest.raises(Exception):
+        plan.check()                                               # (the sticky word for host-side checks)
+    plan.status.zero_()
+    plan.rebuild(good.edge_index)
+    good._igcn_plan = plan
+    loss2, _, _ = losses(model, good)
+    assert bool(torch.isfinite(loss2)) and abs(float(loss2) - float(loss)) <= 1e-5 * abs(float(loss))
+
+
+def test_a_corrupted_batch_poisons_the_captured_step_too():
+    """The same guard inside the hipGraph: ``load()`` of a corrupted batch -> NaN loss from the replay (the check and
+    the kernels that consume its flag are both captured); a good batch afterwards trains normally."""
+    from igcn_amd.train import FlatAdam, GraphedTrainStep
+    model, good, bad, make = _poison_fixture(128, 4)
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    static = make()
+    static.x.requires_grad_(True)
+    step = GraphedTrainStep(model, opt, static, warmup=1)
+    assert step.plan.dense_blocks and bool(torch.isfinite(step()))
+    snap = opt.flat.clone()
+    step.load(bad)
+    assert bool(torch.isnan(step()))
+    with torch.no_grad():                                          # (the NaN step has poisoned the parameters: restore)
+        opt.flat.copy_(snap)
+        opt.exp_avg.zero_()
+        opt.exp_avg_sq.zero_()
+    step.plan.status.zero_()
+    step.load(good)
+    assert bool(torch.isfinite(step()))

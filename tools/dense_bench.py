@@ -33,7 +33,7 @@ for it in range(iters + 3):
     if it == 3:
         torch.cuda.synchronize()
         e0.record()
-    xcat, regp = ops.DenseSgcn.apply(x, b.edge_attr, prob, pb, sp, mode, rois, hp, w0, b0, w1, b1)
+    xcat, regp = ops.DenseSgcn.apply(x, b.edge_attr, prob, pb, sp, mode, rois, hp, None, w0, b0, w1, b1)
     loss = xcat.sum() + (regp.sum() if regp.numel() else 0.0)
     loss.backward()
 e1.record()

@@ -25,7 +25,7 @@ sp = torch.randn(1, 54, device=dev)
 w0, b0 = torch.randn(16, 3, device=dev) * 0.5, torch.zeros(16, device=dev)
 hp = (0.1, 0.1, 0.1, 0.1, 1e-6)
 for _ in range(5):
-    ops.DenseSgcn.apply(b.x, b.edge_attr, prob, pb, sp, mode, rois, hp, w0, b0)        # ONE layer: one k_ds_agg launch
+    ops.DenseSgcn.apply(b.x, b.edge_attr, prob, pb, sp, mode, rois, hp, None, w0, b0)        # ONE layer: one k_ds_agg launch
 torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_longlong * 512)()

@@ -84,13 +84,13 @@ dw = [torch.randn(16, 3, device=dev) * 0.5, torch.zeros(16, device=dev), torch.r
       torch.zeros(16, device=dev)]
 torch.cuda.synchronize()
 for _ in range(LAUNCHES // 2):                      # two k_ds_agg launches (two layers) per forward
-    ops.DenseSgcn.apply(sb.x, sb.edge_attr, prob, pb, spr, "both", 512, (0.1, 0.1, 0.1, 0.1, 1e-6), *dw)
+    ops.DenseSgcn.apply(sb.x, sb.edge_attr, prob, pb, spr, "both", 512, (0.1, 0.1, 0.1, 0.1, 1e-6), None, *dw)
 torch.cuda.synchronize()
 # ... and its backward: the transposed aggregation (two launches) and the mask-gradient edge pass
 leaves = [t.requires_grad_(True) for t in (prob, pb, spr)]
 cot = torch.randn(2 * sb.x.shape[0], 32, device=dev)
 for _ in range(max(2, LAUNCHES // 4)):
-    xcat, regp = ops.DenseSgcn.apply(sb.x, sb.edge_attr, prob, pb, spr, "both", 512, (0.1, 0.1, 0.1, 0.1, 1e-6), *dw)
+    xcat, regp = ops.DenseSgcn.apply(sb.x, sb.edge_attr, prob, pb, spr, "both", 512, (0.1, 0.1, 0.1, 0.1, 1e-6), None, *dw)
     torch.autograd.grad((xcat * cot).sum() + regp.sum(), leaves)
 torch.cuda.synchronize()
 print("done")
