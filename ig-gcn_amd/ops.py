@@ -47,20 +47,30 @@ class deferred_reductions:
         return self
 
     def __exit__(self, *exc):
+        ok = exc[0] is None
         try:
-            if exc[0] is None:           # queued parameter-gradient passes: one launch per kind (their sums still deferred)
+            if ok:                       # queued parameter-gradient passes: one launch per kind (their sums still deferred)
                 _flush_ln_affine()
                 _flush_spmm_dval()
-            call("igcn_reduce_defer", 0)
-            if self.tick is not None and exc[0] is None:
-                call("igcn_reduce_flush_tick", stream_ptr(), ptr(self.tick))
-            else:
-                call("igcn_reduce_flush", stream_ptr())
+        except BaseException:
+            ok = False
+            raise
         finally:
-            _DEFER["on"] = False
-            _DEFER["keep"].clear()
-            _DEFER["ln_affine"].clear()
-            _DEFER["spmm_dval"].clear()
+            # Whatever happened above, the library leaves defer mode and its queue is emptied HERE, while the partial
+            # buffers the queued entries point at are still alive (``keep`` is cleared last): a failed block must not
+            # leave entries behind that a later flush would run on freed memory.  On the error path the queued sums are
+            # still launched — they only read buffers that exist and write gradients nobody will use.
+            try:
+                call("igcn_reduce_defer", 0)
+                if self.tick is not None and ok:
+                    call("igcn_reduce_flush_tick", stream_ptr(), ptr(self.tick))
+                else:
+                    call("igcn_reduce_flush", stream_ptr())
+            finally:
+                _DEFER["on"] = False
+                _DEFER["ln_affine"].clear()
+                _DEFER["spmm_dval"].clear()
+                _DEFER["keep"].clear()
         return False
 
 
@@ -1413,7 +1423,7 @@ class SparseMap(torch.autograd.Function):
         in memory (stride >= nnz); None otherwise."""
         v0 = vals[0]
         if not all(v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and v.numel() == nnz
-                   and v.device == v0.device for v in vals) or os.environ.get("IGCN_SPMM_STACK", "0") == "1":
+                   and v.device == v0.device for v in vals):
             return None
         d = vals[1].data_ptr() - v0.data_ptr()
         if d <= 0 or d % 4 or d // 4 < nnz or any(vals[i].data_ptr() - v0.data_ptr() != i * d for i in range(2, len(vals))):

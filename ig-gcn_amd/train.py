@@ -480,9 +480,8 @@ class GraphedTrainStep:
                 raise ValueError("max_edges is smaller than the construction batch's largest graph")
             self.plan._stack_dims = (self.plan._stack_dims[0], int(max_edges))
             self.plan._copies = {}
-        # every plan builder is hand-written and capturable; IGCN_PLAN_EAGER=1 keeps the build outside the graph
-        # (launched eagerly before each replay) for A/B runs
-        self.plan_in_graph = os.environ.get("IGCN_PLAN_EAGER", "0") != "1"
+        # every plan builder is hand-written and capturable: the build is part of the captured step
+        self.plan_in_graph = True
         opt = self.opt
         saved = [t.clone() for t in (opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_count)]
         saved_buf = [(b, b.clone()) for b in model.buffers()]

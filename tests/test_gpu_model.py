@@ -784,6 +784,78 @@ def test_deferred_reductions_give_the_same_gradients(golden):
     assert n_grads > 40
 
 
+@pytest.mark.parametrize("switch", ["IGCN_NO_FUSED_SGCN", "IGCN_NO_DEFER", "IGCN_NO_GEMM_GROUPS", "IGCN_NO_READOUT_PAIR",
+                                    "IGCN_LN_AFFINE_NOW", "IGCN_SPMM_DVAL_NOW", "IGCN_NO_PROJ_FUSED", "IGCN_NO_HEAD_FUSED",
+                                    "IGCN_NO_MASK_REG_FUSED", "IGCN_NO_GRAD_FAN", "IGCN_NO_LN_FUSED",
+                                    "IGCN_NO_LOSS_HEAD_FUSED", "IGCN_SPARSE_MAPS"])
+def test_every_host_side_switch_gives_the_default_train_step(golden, monkeypatch, switch):
+    """every A/B switch that the Python layer reads selects a second code path — each of them must give
+    the default path's train step (loss, every gradient) on the ``full_b32`` model, so a losing variant cannot rot
+    unnoticed.  (The switches the library reads at load time are covered by test_alternative_kernel_variants_agree.)"""
+    from igcn_amd.data import Batch
+    from igcn_amd.train import FlatAdam, backward_to_grads, losses, _single_use_parameters
+    store = golden("full_b32")
+    lam = store["lam"].tolist()
+
+    def run():
+        model, graphs, _ = _full_model(store)
+        model.train(True)
+        opt = FlatAdam(model.parameters(), lr=1e-3)
+        data = Batch.from_data_list(graphs).to("cuda")
+        opt.zero_grad()
+        loss, terms, _ = losses(model, data, lam)
+        backward_to_grads(loss, opt, data, defer=_single_use_parameters(model))
+        g = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        g["data.x"] = data.x.grad.clone()
+        return float(loss), g
+
+    want_loss, want = run()
+    monkeypatch.setenv(switch, "1")
+    got_loss, got = run()
+    assert abs(got_loss - want_loss) <= 2e-5 * max(1.0, abs(want_loss)), (switch, got_loss, want_loss)
+    assert set(got) == set(want)
+    for k, w in want.items():
+        assert_matches(got[k], w.cpu().numpy(), 2e-4, f"{switch}: grad {k}", floor=1e-6)
+
+
+def test_a_failed_deferred_block_leaves_no_queue_behind(golden, monkeypatch):
+    """an exception while the block exits (here: the queued LayerNorm-affine pass fails) must not leave the
+    library in defer mode with entries that point at freed partial buffers — the queue is emptied while the buffers are
+    alive, and the next backward (plain or deferred) gives the usual gradients."""
+    from igcn_amd import _lib, ops
+    from igcn_amd.data import Batch
+    from igcn_amd.train import FlatAdam, backward_to_grads, losses
+    store = golden("full_b32")
+    model, graphs, _ = _full_model(store)
+    model.train(True)
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    lam = store["lam"].tolist()
+
+    def grads(defer):
+        data = Batch.from_data_list(graphs).to("cuda")
+        opt.zero_grad()
+        loss, _, _ = losses(model, data, lam)
+        backward_to_grads(loss, opt, data, defer=defer)
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    want = grads(True)
+
+    def boom():
+        raise RuntimeError("injected")
+    with monkeypatch.context() as mp:
+        mp.setattr(ops, "_flush_spmm_dval", boom)
+        with pytest.raises(RuntimeError, match="injected"):
+            grads(True)
+    lib = _lib.load()
+    assert lib.igcn_reduce_pending() == 0 and not ops._DEFER["on"] and not ops._DEFER["keep"]
+    torch.cuda.synchronize()
+    for defer in (False, True):
+        got = grads(defer)
+        assert set(got) == set(want)
+        for k in want:
+            assert torch.equal(got[k], want[k]), (defer, k)
+
+
 @pytest.mark.parametrize("layers,hidden", [(2, 10), (3, 10), (4, 5)])
 @pytest.mark.parametrize("fused", [True, False])
 def test_sweep_widths_off_the_kernel_grid_vs_oracle(layers, hidden, fused):

@@ -372,7 +372,7 @@ def test_sparse_map_reads_channel_vectors_at_a_stride(ops, monkeypatch):
             # leaves that ALIAS the flat buffer at the stride: what FlatAdam's `p.data = flat[...]` produces
             assert ops.SparseMap._row_stride(vals, nnz) == stride
         else:                                                # the stacked form (any two vectors with ascending
-            monkeypatch.setenv("IGCN_SPMM_STACK", "1")       # addresses would otherwise be read in place too)
+            monkeypatch.setattr(ops.SparseMap, "_row_stride", staticmethod(lambda vals, nnz: None))   # addresses would otherwise be read in place too)
             vals = [flat[c * stride:c * stride + nnz].clone().requires_grad_(True) for c in range(2)]
         y = ops.SparseMap.apply(xs, csr, *vals)
         return (y,) + torch.autograd.grad((y * cot).sum(), [xs] + vals)
@@ -1607,7 +1607,31 @@ kv = torch.from_numpy(rng.standard_normal((3, 70, 64))).float().cuda().requires_
 o = ops.AttentionCore.apply(q, kv, 2)
 co = torch.from_numpy(rng.standard_normal((3, 40, 32))).float().cuda()
 ga = torch.autograd.grad((o * co).sum(), [q, kv])
+# dense but NOT complete graphs (2 x 70 nodes, ~90 % of the pairs): edge mask + gcn_norm + scatter-aggregate on the tiled
+# record-stream kernels of csrc/sgcn.hip (lanes-over-nodes tiled walks, LDS-staged aggregation by default; the wave-per-list
+# / wave-per-target kernels under IGCN_NO_TILED_LISTS=1 / IGCN_PROPAGATE_NO_LDS=1)
+gq, rq = 2, 70
+src, dst = [], []
+for k in range(gq):
+    rr, cc = np.nonzero(rng.random((rq, rq)) < 0.9)
+    src.append(rr + k * rq), dst.append(cc + k * rq)
+ei = torch.from_numpy(np.vstack([np.concatenate(src), np.concatenate(dst)])).long().cuda()
+plan = ops.GraphPlan(ei, gq * rq)
+plan.nodes_per_graph = rq
+xq = torch.from_numpy(rng.random((gq * rq, 3))).float().cuda().requires_grad_(True)
+pq = torch.from_numpy(rng.standard_normal((rq, 3))).float().cuda().requires_grad_(True)
+pbq = torch.from_numpy(rng.standard_normal((6, 1))).float().cuda().requires_grad_(True)
+ewq = torch.from_numpy(rng.random(ei.shape[1]) + 0.05).float().cuda().requires_grad_(True)
+hq = torch.from_numpy(rng.standard_normal((gq * rq, 16))).float().cuda().requires_grad_(True)
+bq = torch.from_numpy(rng.standard_normal(16)).float().cuda().requires_grad_(True)
+xm, ewm, e = ops.EdgeMask.apply(xq, pq, pbq, ewq, plan, rq)
+coef = ops.GcnNorm.apply(ewm, plan)
+oq = ops.GcnPropagate.apply(hq, coef[0], coef[1], bq, plan, True, coef[2], coef[3])
+cq = torch.from_numpy(rng.standard_normal(tuple(oq.shape))).float().cuda()
+gq_ = torch.autograd.grad((oq * cq).sum() + (xm * xm).sum(), [xq, pq, pbq, ewq, hq, bq], allow_unused=True)
+gq_ = [t if t is not None else torch.zeros(1, device="cuda") for t in gq_]
 np.savez(sys.argv[2], y=y.detach().cpu().numpy(), o=o.detach().cpu().numpy(), yd=yd.detach().cpu().numpy(),
+         oq=oq.detach().cpu().numpy(), **{f"q{i}": t.cpu().numpy() for i, t in enumerate(gq_)},
          **{f"g{i}": t.cpu().numpy() for i, t in enumerate(g)}, **{f"a{i}": t.cpu().numpy() for i, t in enumerate(ga)},
          **{f"d{i}": t.cpu().numpy() for i, t in enumerate(gd)}, ys=ys.detach().cpu().numpy(),
          **{f"s{i}": t.cpu().numpy() for i, t in enumerate(gs)})
@@ -1617,8 +1641,9 @@ np.savez(sys.argv[2], y=y.detach().cpu().numpy(), o=o.detach().cpu().numpy(), yd
 def test_alternative_kernel_variants_agree(tmp_path):
     """The A/B switches stay honest: the global-memory GO kernels (attention backward, decoder forward / backward:
     IGCN_GO_ATTN_CM=1 — also the fallbacks for hierarchies too large for LDS), the first CSR map kernels
-    (IGCN_SPMM_NO_LDS=1 — the fallback for structures whose operand rows do not fit LDS) give the numbers of the default
-    LDS-resident kernels.  The switches are read once per process, so each variant runs in a short child process (one
+    (IGCN_SPMM_NO_LDS=1 — the fallback for structures whose operand rows do not fit LDS) and, on a dense-but-not-complete
+    batch, the wave-per-list / wave-per-target forms of the record-stream kernels (IGCN_NO_TILED_LISTS=1,
+    IGCN_PROPAGATE_NO_LDS=1) give the numbers of the default kernels.  The switches are read once per process, so each variant runs in a short child process (one
     at a time)."""
     import os
     import subprocess
@@ -1627,7 +1652,8 @@ def test_alternative_kernel_variants_agree(tmp_path):
     script = tmp_path / "ab.py"
     script.write_text(_AB_SCRIPT)
     outs = {}
-    for tag, env in (("default", {}), ("alt", {"IGCN_GO_ATTN_CM": "1", "IGCN_SPMM_NO_LDS": "1"})):
+    for tag, env in (("default", {}), ("alt", {"IGCN_GO_ATTN_CM": "1", "IGCN_SPMM_NO_LDS": "1", "IGCN_NO_TILED_LISTS": "1",
+                                               "IGCN_PROPAGATE_NO_LDS": "1"})):
         out = tmp_path / f"{tag}.npz"
         r = subprocess.run([sys.executable, str(script), ROOT, str(out)], env={**os.environ, **env},
                            capture_output=True, text=True, timeout=300)
