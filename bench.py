@@ -152,13 +152,14 @@ def instep_profile(workload, bf16, steps=12, timeout=420):
             shutil.rmtree(out, ignore_errors=True)
 
 
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc", "traffic.json")
+PMC_JSON = next((p for p in (os.path.join(ROOT, "profiles", r + "_pmc", "traffic.json") for r in ("r04", "r03"))
+                 if os.path.exists(p)), os.path.join(ROOT, "profiles", "r04_pmc", "traffic.json"))
 
 
 def _attach_traffic(res):
     """``traffic``: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction, calibrated
     on a 256 MiB float4 copy; WRITE_SIZE x1).  PMC collection needs its own profiler passes, so the figure comes from
-    the COMMITTED passes of tools/roofline_kernel.py (profiles/r03_pmc/, or $IGCN_BENCH_PMC_JSON) — a separate run of
+    the COMMITTED passes of tools/roofline_kernel.py (profiles/r04_pmc/, or $IGCN_BENCH_PMC_JSON) — a separate run of
     the same kernel on the same launch shape, not this invocation — and says so."""
     path = os.environ.get("IGCN_BENCH_PMC_JSON", PMC_JSON)
     try:
@@ -767,7 +768,8 @@ def main():
                     help="dense feature transforms with bf16 operands (auto: the workload's own setting)")
     ap.add_argument("--rotate", type=int, default=0,
                     help="time GraphedTrainStep.load + replay over this many distinct device-resident batches")
-    ap.add_argument("--pipeline", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="loader-fed runs: default for the sparse workloads since round 4; forces them for --workload stress")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="skip the loader-fed runs (host feeder thread / device-resident dataset / device GDC)")
     ap.add_argument("--blocks", type=int, default=5,
@@ -1015,7 +1017,9 @@ def main():
             torch.cuda.synchronize()
             res["rotating_batches"] = {"batches": args.rotate,
                                        "ms_per_step_load_plus_replay": round((time.perf_counter() - t1) / args.steps * 1e3, 3)}
-        if not args.no_pipeline and gstep is not None and world == 1 and wl["pool"] is not None:
+        # (dense 512-ROI subjects are 1.3 MB of edge list each: that dataset is not host-fed per step; --pipeline forces it)
+        if not args.no_pipeline and gstep is not None and world == 1 and wl["pool"] is not None \
+                and (not wl["dense"] or args.pipeline):
             # the loader-fed step (the reference's step starts at `for data in loader: data = data.to(device)`, :515-517)
             res["pipeline"] = pipeline_bench(gstep, wl, device, max(args.steps, 60), args.warmup, res["ms_per_step"])
         if wl["pool"] is not None and world == 1 and not args.no_roofline:

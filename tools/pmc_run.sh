@@ -1,7 +1,8 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r03_pmc
+TAG=${1:-r04}
+O=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc
 mkdir -p $O
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $GRAFT_REPO_ROOT/tools/roofline_kernel.py > $O/trace.log 2>&1
