@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """bench.py — graphs/s of the full IG-GCN train step (SGCN over 90-ROI brain graphs + GO-SNP network).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full|sgcn|stress]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks 5] [--workload full|sgcn|stress]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    IGCN_BENCH_SWEEP="1,2,4,8" python bench.py ...        one line per N, weak-scaling efficiency vs its own N = 1 run
+
+The timed region (--steps replays between barriers + synchronize) is repeated --blocks times; the line reports the
+MEDIAN block and the spread (`timing`).  The default line also carries the loader-fed step (`pipeline`: host feeder
+thread / device-resident dataset / device GDC one batch ahead on a side stream) and, at N > 1, the distributed step
+taken apart per rank (`distributed_step`).
 
 Default workload (BASELINE.json configs[2]): full SGCN_GCN_IMGSNP (L=2, hidden=16, R=90, H0=3,
 cross-attention fusion, 3 classes, 3 regression targets), synthetic GO DAG N=3000 pool [1800,800,300,99,1],
