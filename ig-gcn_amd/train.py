@@ -151,9 +151,10 @@ class FlatAdam:
             for p in self.params:
                 p.grad = None
 
-    def refresh_table(self, owner=None):
+    def refresh_table(self, owner=None, table=None):
         """Upload the current gradient pointers (host-side, not capturable: under a hipGraph the gradient
-        tensors keep their addresses, so this runs once after capture)."""
+        tensors keep their addresses, so this runs once after capture).  ``table``: a captured step's OWN pointer table
+        (``GraphedTrainStep`` keeps one per graph, so captured steps can alternate without re-uploading anything)."""
         k = self._turn
         self._turn = (k + 1) % len(self._hosts)
         if self._uploaded[k] is not None:
@@ -165,23 +166,24 @@ class FlatAdam:
                 g = p.grad = g.contiguous()
             host[t, 1] = g.data_ptr() if g is not None else 0
             self._table_live[t] = g is not None
-        self.table.copy_(host, non_blocking=True)
-        self._table_owner = owner
+        (self.table if table is None else table).copy_(host, non_blocking=True)
+        if table is None:
+            self._table_owner = owner
         if self.table.is_cuda:
             self._uploaded[k] = torch.cuda.Event()
             self._uploaded[k].record()
 
-    def pack_grads(self, refresh=True):
+    def pack_grads(self, refresh=True, table=None):
         """Gather the per-tensor gradients into the flat bucket ``self.grad`` (data-parallel exchange)."""
         if self.flat_grads:
             return self.grad
         if refresh:
-            self.refresh_table()
-        call("igcn_pack_grads", len(self.params), ptr(self.table), ptr(self.numel), ptr(self.offset),
-             ptr(self.grad), stream_ptr())
+            self.refresh_table(table=table)
+        call("igcn_pack_grads", len(self.params), ptr(self.table if table is None else table), ptr(self.numel),
+             ptr(self.offset), ptr(self.grad), stream_ptr())
         return self.grad
 
-    def step(self, grad_scale=1.0, refresh=True, from_flat=None):
+    def step(self, grad_scale=1.0, refresh=True, from_flat=None, table=None):
         """``from_flat``: read gradients from the flat bucket (after an all-reduce); default = flat mode only.
         When the backward's flush has advanced ``step_count`` already (``backward_to_grads(tick=True)`` with deferred
         reductions sets ``_ticked``), the one-thread counter launch in front is skipped."""
@@ -194,9 +196,9 @@ class FlatAdam:
             self._has_state = [True] * len(self.params)
             return
         if refresh:
-            self.refresh_table()
-        call("igcn_adam_step_multi" + sfx, len(self.params), ptr(self.table), ptr(self.numel), ptr(self.step_count),
-             *hyper, stream_ptr())
+            self.refresh_table(table=table)
+        call("igcn_adam_step_multi" + sfx, len(self.params), ptr(self.table if table is None else table), ptr(self.numel),
+             ptr(self.step_count), *hyper, stream_ptr())
         self.mark_stepped()
 
     def mark_stepped(self):
@@ -506,6 +508,9 @@ class GraphedTrainStep:
         opt._has_state = saved_has
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
+        # this graph's OWN gradient-pointer table: the captured Adam / pack kernels read it, so captured steps of one
+        # optimiser (the shapes of an epoch, two alternating input sets) never re-upload anything when they take turns
+        self._table = torch.zeros_like(opt.table)
         if not self.plan_in_graph:
             self.plan.rebuild(self.data.edge_index)
         # with a process group alive, its watchdog / progress threads may touch the runtime while this thread
@@ -517,7 +522,7 @@ class GraphedTrainStep:
             try:
                 with torch.cuda.graph(self.g_main, capture_error_mode=mode):
                     self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
-                    self.opt.pack_grads(refresh=False)
+                    self.opt.pack_grads(refresh=False, table=self._table)
                     comm.all_reduce_(self.opt.grad)
                     self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
                 self.comm_in_graph = True
@@ -541,20 +546,18 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.g_main, capture_error_mode=mode):
                 self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
                 if not dist:
-                    self.opt.step(refresh=False)        # reads the pointer table at replay time
+                    self.opt.step(refresh=False, table=self._table)   # reads the pointer table at replay time
                 else:
-                    self.opt.pack_grads(refresh=False)
+                    self.opt.pack_grads(refresh=False, table=self._table)
         # the captured gradient tensors keep their addresses — which only helps if the table can point AT them: a
         # non-contiguous gradient would be copied by refresh_table, and the replays would never update the copy
         for p in self.opt.params:
             if p.grad is not None and not p.grad.is_contiguous():
                 raise _lib.IgcnError("graphed step: a parameter gradient is not contiguous "
                                      f"(shape {tuple(p.shape)}, strides {p.grad.stride()})")
-        self.opt.refresh_table(owner=self)
-        # the optimiser's pointer table and the parameters' ``.grad`` belong to whoever stepped last: an eager
-        # ``train_step`` (the ragged last batch of an epoch) or another captured step re-points them, and __call__ puts
-        # this graph's own back before it replays
-        self._table = self.opt.table.clone()
+        self.opt.refresh_table(table=self._table)
+        # the parameters' ``.grad`` belong to whoever stepped last: an eager ``train_step`` (the ragged last batch of an
+        # epoch) or another captured step re-points them, and __call__ puts this graph's own back before it replays
         self._table_live = list(self.opt._table_live)
         self._grads = [p.grad for p in self.opt.params]
         self._x_grad = self.data.x.grad
@@ -630,9 +633,7 @@ class GraphedTrainStep:
         if getattr(opt, "_ticked", False):
             raise RuntimeError("graphed step: an eager backward advanced the step counter and no optimizer.step() "
                                "followed it")
-        if opt._table_owner is not self:
-            with torch.no_grad():
-                opt.table.copy_(self._table)
+        if opt._table_owner is not self:                # (host book-keeping only: the device table is this graph's own)
             opt._table_owner = self
             opt._table_live = list(self._table_live)
             for p, g in zip(opt.params, self._grads):
