@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 402        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 404        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "igcn_head_inputs_bwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
     "igcn_concat_cols": (I, [L, I, I, P, P, P]),
     "igcn_copy_multi": (I, [I, P, P, P, P]),
+    "igcn_gather_batch": (I, [I, I, L, P, P, P, P, P, P]),
     "igcn_launch_floor": (I, [L, I, I, I, P, P]),
     "igcn_graph_pool_fwd": (I, [L, I, I, P, P, P, P]),
     "igcn_graph_pool_bwd": (I, [L, I, I, P, P, P, P]),
@@ -146,6 +147,8 @@ SIGNATURES = {
     "igcn_adam_step_multi": (I, [I, P, P, P, P, F, F, F, F, P]),
     "igcn_adam_step_ticked": (I, [L, P, P, P, P, P, P, F, F, F, F, P]),
     "igcn_adam_step_multi_ticked": (I, [I, P, P, P, P, F, F, F, F, P]),
+    "igcn_adam_chunk": (I, []),
+    "igcn_adam_step_blocks": (I, [I, P, P, P, P, P, P, F, F, F, F, I, P]),
     "igcn_pack_grads": (I, [I, P, P, P, P, P]),
     "igcn_reduce_defer": (I, [I]),
     "igcn_reduce_pending": (I, []),
@@ -161,6 +164,7 @@ SIGNATURES = {
     "igcn_loss_head_fwd_grads": (I, [I, I, I, I, P, I, P, P, P, P, P, P, P, I, P, I, P, F, F, P, P, P, P, P, P, P, P]),
     "igcn_gdc_topk_max_rois": (I, []),
     "igcn_gdc_topk": (I, [I, I, I, ctypes.c_double, P, P, P, P, P]),
+    "igcn_gdc_topk_of": (I, [I, I, I, ctypes.c_double, P, P, P, P, P, P]),
 }
 
 _lib = None

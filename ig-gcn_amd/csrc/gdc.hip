@@ -72,7 +72,8 @@ extern "C" int igcn_debug_gdc_probe(long long* out) {
 template <int NR>                                       // rows of its column a thread keeps: NR * (GDC_T / cw) >= R
 __global__ void __launch_bounds__(GDC_T)
 k_gdc_topk(int R, int k, double alpha, const float* __restrict__ A, int64_t* __restrict__ ei_row,
-           int64_t* __restrict__ ei_col, float* __restrict__ ew, int32_t* __restrict__ counts) {
+           int64_t* __restrict__ ei_col, float* __restrict__ ew, int32_t* __restrict__ counts,
+           const int64_t* __restrict__ subject) {
   extern __shared__ double smem_d[];
   const int ld = gdc_ld(R), g = blockIdx.x, tid = threadIdx.x;
   const int cw = R <= 64 ? 64 : 128, nsl = GDC_T / cw;  // a wave lies inside one row slice
@@ -85,7 +86,7 @@ k_gdc_topk(int R, int k, double alpha, const float* __restrict__ A, int64_t* __r
   int* piv = (int*)(M + (size_t)R * ld);                // [R]  row chosen as the pivot of column p
   int* rinv = piv + R;                                  // [R]  step at which row w was the pivot
   int* rowcnt = rinv + R;                               // [R+2]
-  const float* a = A + (int64_t)g * R * R;
+  const float* a = A + (subject ? subject[g] : (int64_t)g) * R * R;   // graph g of the batch = matrix subject[g]
 
   GDC_PROBE(0);
   // ---- H = D^-1/2 A D^-1/2, M = I - (1 - alpha) H -------------------------------------------------
@@ -315,8 +316,8 @@ extern "C" int igcn_gdc_topk_max_rois(void) {
   return r;
 }
 
-extern "C" int igcn_gdc_topk(int B, int R, int k, double alpha, const float* A, int64_t* edge_index, float* edge_attr,
-                             int32_t* counts, void* stream) {
+static int gdc_topk(int B, int R, int k, double alpha, const float* A, const int64_t* subject, int64_t* edge_index,
+                    float* edge_attr, int32_t* counts, void* stream) {
   IGCN_REQUIRE(B >= 0 && R > 0 && k > 0 && k <= R, "gdc_topk: bad sizes B=%d R=%d k=%d", B, R, k);
   IGCN_REQUIRE(alpha > 0.0 && alpha <= 1.0, "gdc_topk: alpha=%g outside (0,1]", alpha);
   if (R > igcn_gdc_topk_max_rois()) {
@@ -330,7 +331,7 @@ extern "C" int igcn_gdc_topk(int B, int R, int k, double alpha, const float* A, 
   case NR:                                                                                                          \
     IGCN_ALLOW_BIG_LDS(k_gdc_topk<NR>);                                                                             \
     hipLaunchKernelGGL(k_gdc_topk<NR>, dim3(B), dim3(GDC_T), lds, (hipStream_t)stream, R, k, alpha, A, edge_index,   \
-                       edge_index + slots, edge_attr, counts);                                                      \
+                       edge_index + slots, edge_attr, counts, subject);                                             \
     break
   switch (gdc_rows(R)) {
     GDC_LAUNCH(8);
@@ -343,4 +344,15 @@ extern "C" int igcn_gdc_topk(int B, int R, int k, double alpha, const float* A, 
 #undef GDC_LAUNCH
   IGCN_CHECK_LAUNCH("gdc_topk");
   return IGCN_OK;
+}
+
+extern "C" int igcn_gdc_topk(int B, int R, int k, double alpha, const float* A, int64_t* edge_index, float* edge_attr,
+                             int32_t* counts, void* stream) {
+  return gdc_topk(B, R, k, alpha, A, nullptr, edge_index, edge_attr, counts, stream);
+}
+
+extern "C" int igcn_gdc_topk_of(int B, int R, int k, double alpha, const float* A, const int64_t* subject,
+                                int64_t* edge_index, float* edge_attr, int32_t* counts, void* stream) {
+  IGCN_REQUIRE(subject != nullptr, "gdc_topk_of: the subject list is missing");
+  return gdc_topk(B, R, k, alpha, A, subject, edge_index, edge_attr, counts, stream);
 }

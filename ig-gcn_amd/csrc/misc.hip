@@ -95,6 +95,75 @@ k_adam_multi(const int64_t* __restrict__ table, const int64_t* __restrict__ nume
   }
 }
 
+// The same update over a precomputed block list: block b covers elements [blk_off[b], blk_off[b] + ADAM_CHUNK) of tensor
+// blk_tensor[b].  The (96, n_tensors) grid above launches 7 680 workgroups for the ~80 tensors of the model, of which
+// ~7 400 find nothing to do (most tensors are a few hundred floats): their dispatch was most of the kernel's 10 us.
+#define ADAM_CHUNK 2048
+__global__ void __launch_bounds__(256)
+k_adam_blocks(const int64_t* __restrict__ table, const int64_t* __restrict__ numel, const int32_t* __restrict__ blk_tensor,
+              const int32_t* __restrict__ blk_off, const int32_t* __restrict__ step, const float* __restrict__ lr_dev,
+              float b1, float b2, float eps, float gscale) {
+  const int t = blk_tensor[blockIdx.x];
+  const float* g = reinterpret_cast<const float*>(table[4 * t + 1]);
+  if (g == nullptr) return;                           // (no gradient: torch's Adam skips the parameter)
+  float* p = reinterpret_cast<float*>(table[4 * t]);
+  float* m = reinterpret_cast<float*>(table[4 * t + 2]);
+  float* v = reinterpret_cast<float*>(table[4 * t + 3]);
+  const int64_t n = numel[t], lo = blk_off[blockIdx.x], hi = lo + ADAM_CHUNK < n ? lo + ADAM_CHUNK : n;
+  const float ts = (float)(*step);
+  const float lr = *lr_dev;
+  const float bc1 = 1.f - powf(b1, ts), bc2s = sqrtf(1.f - powf(b2, ts));
+  auto upd = [&](float gi, float& mi, float& vi, float& pi) {
+    gi *= gscale;
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2s + eps));
+  };
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);   // (lo is a multiple of 4)
+  int64_t i = lo + 4 * (int64_t)threadIdx.x;
+  if (vec) {
+    for (; i + 4 <= hi; i += 1024) {
+      const float4 g4 = *reinterpret_cast<const float4*>(g + i);
+      float4 m4 = *reinterpret_cast<float4*>(m + i), v4 = *reinterpret_cast<float4*>(v + i);
+      float4 p4 = *reinterpret_cast<float4*>(p + i);
+      upd(g4.x, m4.x, v4.x, p4.x);
+      upd(g4.y, m4.y, v4.y, p4.y);
+      upd(g4.z, m4.z, v4.z, p4.z);
+      upd(g4.w, m4.w, v4.w, p4.w);
+      *reinterpret_cast<float4*>(m + i) = m4;
+      *reinterpret_cast<float4*>(v + i) = v4;
+      *reinterpret_cast<float4*>(p + i) = p4;
+    }
+    if (i < hi && i + 4 > hi) {                       // the ragged last quad of the tensor
+      for (int64_t j = i; j < hi; ++j) {
+        float mi = m[j], vi = v[j], pi = p[j];
+        upd(g[j], mi, vi, pi);
+        m[j] = mi; v[j] = vi; p[j] = pi;
+      }
+    }
+  } else {
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) {
+      float mi = m[j], vi = v[j], pi = p[j];
+      upd(g[j], mi, vi, pi);
+      m[j] = mi; v[j] = vi; p[j] = pi;
+    }
+  }
+}
+
+extern "C" int igcn_adam_chunk(void) { return ADAM_CHUNK; }
+
+extern "C" int igcn_adam_step_blocks(int n_blocks, const int64_t* table, const int64_t* numel, const int32_t* blk_tensor,
+                                     const int32_t* blk_off, int32_t* step, const float* lr, float beta1, float beta2,
+                                     float eps, float grad_scale, int ticked, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!ticked) hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, step);
+  if (n_blocks > 0)
+    hipLaunchKernelGGL(k_adam_blocks, dim3((unsigned)n_blocks), dim3(256), 0, st, table, numel, blk_tensor, blk_off, step, lr,
+                       beta1, beta2, eps, grad_scale);
+  IGCN_CHECK_LAUNCH("adam_step_blocks");
+  return IGCN_OK;
+}
+
 static int adam_step_multi_impl(bool tick, int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
                                 const float* lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -181,6 +250,70 @@ extern "C" int igcn_copy_multi(int n, void* const* dst, const void* const* src, 
   gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
   hipLaunchKernelGGL(k_copy_multi, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, cm);
   IGCN_CHECK_LAUNCH("copy_multi");
+  return IGCN_OK;
+}
+
+// =================================================================================================
+// igcn_gather_batch: the block-diagonal collation of Batch.from_data_list (batch.py:24-123) for a dataset of UNIFORM
+// graphs held as stacked device tensors — every key of the batch in ONE launch (blockIdx.y = key):
+//   kind 0  rows:   dst[b, :] = src[idx[b], :]                       (x, edge_attr, snps_feat, y, ... : `row_bytes` each)
+//   kind 1  index:  dst[r, b E + e] = src[idx[b], r, e] + b * nodes   (edge_index [2, E] int64 per graph -> [2, B E]:
+//                   concatenated along the last dim, offset by the cumulative node count, batch.py:98-104)
+// A feeder on a side stream then costs the train step one launch instead of a dozen gathers.
+// =================================================================================================
+struct GatherBatch {
+  void* dst[IGCN_COPY_MULTI_MAX];
+  const void* src[IGCN_COPY_MULTI_MAX];
+  int64_t row_bytes[IGCN_COPY_MULTI_MAX];             // bytes per graph (kind 1: 2 * E * 8)
+  int kind[IGCN_COPY_MULTI_MAX];
+};
+__global__ void __launch_bounds__(256)
+k_gather_batch(int B, int64_t nodes, const int64_t* __restrict__ idx, GatherBatch gb) {
+  const int k = blockIdx.y;
+  const int64_t rb = gb.row_bytes[k];
+  const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  if (gb.kind[k] == 0) {
+    const int64_t w = rb >> 2, total = (int64_t)B * w;                        // 4-byte words
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(gb.src[k]);
+    uint32_t* d = reinterpret_cast<uint32_t*>(gb.dst[k]);
+    for (int64_t i = first; i < total; i += stride) {
+      const int64_t b = i / w, o = i - b * w;
+      d[i] = s[idx[b] * w + o];
+    }
+  } else {
+    const int64_t e2 = rb >> 3, E = e2 >> 1, total = (int64_t)B * e2;         // int64 entries: [2, E] per graph
+    const int64_t* s = reinterpret_cast<const int64_t*>(gb.src[k]);
+    int64_t* d = reinterpret_cast<int64_t*>(gb.dst[k]);
+    for (int64_t i = first; i < total; i += stride) {
+      const int64_t r = i / ((int64_t)B * E), rem = i - r * (int64_t)B * E, b = rem / E, e = rem - b * E;
+      d[i] = s[idx[b] * e2 + r * E + e] + b * nodes;
+    }
+  }
+}
+
+extern "C" int igcn_gather_batch(int n, int B, int64_t nodes_per_graph, const int64_t* idx, void* const* dst,
+                                 const void* const* src, const int64_t* row_bytes, const int* kind, void* stream) {
+  IGCN_REQUIRE(n >= 0 && n <= IGCN_COPY_MULTI_MAX && B > 0 && idx != nullptr, "gather_batch: n=%d outside [0, %d] or bad B", n,
+               IGCN_COPY_MULTI_MAX);
+  if (n == 0) return IGCN_OK;
+  GatherBatch gb;
+  int64_t big = 0;
+  for (int c = 0; c < IGCN_COPY_MULTI_MAX; ++c) {
+    gb.dst[c] = c < n ? dst[c] : nullptr;
+    gb.src[c] = c < n ? src[c] : nullptr;
+    gb.row_bytes[c] = c < n ? row_bytes[c] : 0;
+    gb.kind[c] = c < n ? kind[c] : 0;
+    if (c < n) {
+      IGCN_REQUIRE(dst[c] && src[c] && row_bytes[c] > 0 && row_bytes[c] % (kind[c] ? 16 : 4) == 0,
+                   "gather_batch: key %d: rows must be whole 4-byte words (index keys: [2, E] int64)", c);
+      big = row_bytes[c] > big ? row_bytes[c] : big;
+    }
+  }
+  int64_t gx = igcn_cdiv(igcn_cdiv(big * B, 4), 256 * 4);
+  gx = gx < 1 ? 1 : (gx > 128 ? 128 : gx);
+  hipLaunchKernelGGL(k_gather_batch, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, B, nodes_per_graph,
+                     idx, gb);
+  IGCN_CHECK_LAUNCH("gather_batch");
   return IGCN_OK;
 }
 

@@ -130,6 +130,44 @@ class UniformGraphStore:
             _finish(res, b, n, e, dev)
         return res
 
+    def one_launch(self):
+        """Whether ``gather_into`` applies: a device store whose rows are whole 4-byte words and whose ``*index*`` keys
+        are [2, E] int64 (every brain-graph dataset; a bool or int8 attribute takes ``batch(out=...)``)."""
+        for k in self.keys:
+            c = self.cols[k]
+            if _is_index_key(k):
+                if c.dtype != torch.int64 or len(self.shapes[k]) != 2 or self.shapes[k][0] != 2:
+                    return False
+            elif (c[0].numel() * c.element_size()) % 4:
+                return False
+        return self.device.type == "cuda"
+
+    def gather_into(self, idx, out):
+        """``batch(idx, out=out)`` as ONE kernel launch (igcn_gather_batch) — same bytes (tests/test_gpu_epoch.py)."""
+        gather_rows(idx, self.nodes, [(getattr(out, k), self.cols[k], _is_index_key(k)) for k in self.keys])
+        return out
+
+
+def gather_rows(idx, nodes, items):
+    """Every key of a batch in ONE launch (igcn_gather_batch) on the current stream.  ``items``: (dst, src, is_index)
+    with src [S, ...per-graph...] and dst the collated tensor — rows ``src[idx[b]]`` back to back, or for an ``*index*``
+    key ([S, 2, E] int64) the [2, B E] concatenation with graph b offset by ``b * nodes``."""
+    import ctypes
+    from ._lib import call, ptr, stream_ptr
+    b = int(idx.numel())
+    for k in range(0, len(items), 16):
+        chunk = items[k:k + 16]
+        n = len(chunk)
+        for dst, src, _ in chunk:
+            if not (dst.is_cuda and src.is_cuda and dst.is_contiguous() and src.is_contiguous()
+                    and dst.dtype == src.dtype and dst.numel() == b * src[0].numel()):
+                raise ValueError("gather_rows: destination does not match B rows of the source")
+        d = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _, _ in chunk])
+        sp = (ctypes.c_void_p * n)(*[t.data_ptr() for _, t, _ in chunk])
+        rb = (ctypes.c_int64 * n)(*[t[0].numel() * t.element_size() for _, t, _ in chunk])
+        kind = (ctypes.c_int * n)(*[1 if ix else 0 for _, _, ix in chunk])
+        call("igcn_gather_batch", n, b, int(nodes), ptr(idx), d, sp, rb, kind, stream_ptr())
+
 
 def _like(batch, device, pin=False):
     """A copy of ``batch`` with every tensor re-allocated on ``device`` (a staging slot).  The contents are COPIED, not
@@ -265,7 +303,8 @@ class _AheadOnSideStream:
             step.load(batch); batch.release(); step()                # release: the slot may be refilled
 
     ``depth`` output slots (>= 2) are allocated once; temporaries live on the side stream.  Subclasses provide
-    ``_build(idx) -> Batch`` and ``self.index`` (an ``EpochIndex`` on the device)."""
+    ``self.index`` (an ``EpochIndex`` on the device), ``_build(idx) -> Batch`` (the prototype of the slots) and may
+    override ``_fill(slot, idx)`` to write a slot in place."""
 
     def _init_slots(self, device, steps, depth):
         self.steps, self.depth = int(steps), max(2, int(depth))
@@ -281,8 +320,11 @@ class _AheadOnSideStream:
         if self.consumed[slot] is not None:
             self.side.wait_event(self.consumed[slot])   # the consumer has copied the slot's previous batch out
         with torch.cuda.stream(self.side):              # everything below is side-stream work: no wait on the step
-            _copy_into(self.slots[slot], self._build(self.index.next()), non_blocking=True)
+            self._fill(self.slots[slot], self.index.next())
             self.ready[slot].record(self.side)
+
+    def _fill(self, slot, idx):
+        _copy_into(slot, self._build(idx), non_blocking=True)
 
     def __iter__(self):
         self._produce(0)
@@ -302,8 +344,9 @@ class _AheadOnSideStream:
 
 
 class DeviceFeeder(_AheadOnSideStream):
-    """Store resident in HBM: every batch is a few device gathers — no host data path — made one batch ahead on a side
-    stream (see ``_AheadOnSideStream`` for the hand-over protocol)."""
+    """Store resident in HBM: every batch is ONE gather launch (igcn_gather_batch: all keys, index offsets included)
+    straight into its slot — no host data path — made one batch ahead on a side stream (see ``_AheadOnSideStream`` for
+    the hand-over protocol)."""
 
     def __init__(self, store, batch_size, steps, seed=0, shuffle=True, depth=2):
         if store.device.type != "cuda":
@@ -314,6 +357,12 @@ class DeviceFeeder(_AheadOnSideStream):
 
     def _build(self, idx, check=False):
         return self.store.batch(idx)
+
+    def _fill(self, slot, idx):
+        if self.store.one_launch():
+            self.store.gather_into(idx, slot)
+        else:
+            self.store.batch(idx, out=slot)
 
 
 class DeviceGdcFeeder(_AheadOnSideStream):
@@ -331,6 +380,9 @@ class DeviceGdcFeeder(_AheadOnSideStream):
         self.top_k, self.alpha = int(top_k), float(alpha)
         self.index = EpochIndex(adj.shape[0], batch_size, seed, shuffle, device=adj.device)
         self._make = batch_from_dense
+        self._counts = torch.empty(self.bsz, dtype=torch.int32, device=adj.device)
+        if adj.dtype != torch.float32 or not adj.is_contiguous():
+            raise ValueError("DeviceGdcFeeder: adj must be a contiguous float32 [S, R, R]")
         self._init_slots(adj.device, steps, depth)
 
     def _build(self, idx, check=False):
@@ -344,6 +396,16 @@ class DeviceGdcFeeder(_AheadOnSideStream):
                          **per)
         out.A = None                                    # the dense matrices are not an input of the step
         return out
+
+    def _fill(self, slot, idx):
+        """Three launches on the side stream: the per-subject attributes (igcn_gather_batch), the diffusion of the
+        drawn matrices read in place (igcn_gdc_topk_of) straight into the slot's edge list, the edge offsets."""
+        from ._lib import call, ptr, stream_ptr
+        b, r = int(idx.numel()), int(self.adj.shape[1])
+        gather_rows(idx, r, [(getattr(slot, k), v, False) for k, v in self.cols.items()])
+        call("igcn_gdc_topk_of", b, r, self.top_k, self.alpha, ptr(self.adj), ptr(idx), ptr(slot.edge_index),
+             ptr(slot.edge_attr), ptr(self._counts), stream_ptr())
+        torch.cumsum(self._counts, 0, out=slot.edge_ptr[1:])
 
 
 def as_data_list(batch_size, **kw):

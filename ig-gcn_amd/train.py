@@ -121,6 +121,16 @@ class FlatAdam:
         self._table_live = [False] * nt              # which parameters the current table holds a gradient for
         self.numel = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
         self.offset = torch.tensor(offs, dtype=torch.int64, device=dev)
+        # block list of the multi-tensor step: one workgroup per chunk of a tensor (igcn_adam_step_blocks)
+        self._blocks = None
+        if dev.type == "cuda":
+            chunk = int(_lib.load().igcn_adam_chunk())
+            bt, bo = [], []
+            for t, p in enumerate(self.params):
+                for lo in range(0, p.numel(), chunk):
+                    bt.append(t)
+                    bo.append(lo)
+            self._blocks = (torch.tensor(bt, dtype=torch.int32, device=dev), torch.tensor(bo, dtype=torch.int32, device=dev))
 
     # ---- hyper-parameters -------------------------------------------------------------------------
     def _write_lr(self, value):
@@ -197,8 +207,13 @@ class FlatAdam:
             return
         if refresh:
             self.refresh_table(table=table)
-        call("igcn_adam_step_multi" + sfx, len(self.params), ptr(self.table if table is None else table), ptr(self.numel),
-             ptr(self.step_count), *hyper, stream_ptr())
+        tab = self.table if table is None else table
+        if self._blocks is not None:
+            call("igcn_adam_step_blocks", int(self._blocks[0].numel()), ptr(tab), ptr(self.numel), ptr(self._blocks[0]),
+                 ptr(self._blocks[1]), ptr(self.step_count), *hyper, 1 if sfx else 0, stream_ptr())
+        else:
+            call("igcn_adam_step_multi" + sfx, len(self.params), ptr(tab), ptr(self.numel), ptr(self.step_count), *hyper,
+                 stream_ptr())
         self.mark_stepped()
 
     def mark_stepped(self):

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 402
+#define IGCN_ABI_VERSION 404
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -374,6 +374,14 @@ int igcn_concat_cols(int64_t rows, int F, int nparts, const float* const* parts,
  * dst / src / nbytes are HOST arrays [n]; ranges must not overlap.  16-byte lanes where both ends are aligned. */
 #define IGCN_COPY_MULTI_MAX 16
 int igcn_copy_multi(int n, void* const* dst, const void* const* src, const int64_t* nbytes, void* stream);
+
+/* Block-diagonal collation (Batch.from_data_list, batch.py:24-123) of B graphs drawn from a dataset of UNIFORM graphs held
+ * as stacked device tensors, every key in ONE launch: idx int64 [B] (device) = the subjects; per key c < n (HOST arrays):
+ * kind[c] == 0: dst_c [B, row] = src_c [idx[b], row] with row_bytes[c] bytes per graph (a multiple of 4);
+ * kind[c] == 1: an `*index*` key — src_c [S, 2, E] int64, dst_c [2, B E] = concatenation along the last dim with graph b's
+ * entries offset by b * nodes_per_graph (batch.py:98-104); row_bytes[c] = 2 * E * 8. */
+int igcn_gather_batch(int n, int B, int64_t nodes_per_graph, const int64_t* idx, void* const* dst, const void* const* src,
+                      const int64_t* row_bytes, const int* kind, void* stream);
 
 /* Measurement aid (bench.py roofline): the launch of igcn_gcn_propagate_fwd for (n_nodes, F) — thread =
  * (target, feature quad), or one wave per target when `dense` — with the body removed: mode 0 = empty kernel,
@@ -749,6 +757,13 @@ int igcn_adam_step_ticked(int64_t n, float* param, const float* grad, float* exp
                           const float* lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 int igcn_adam_step_multi_ticked(int n_tensors, const int64_t* table, const int64_t* numel, int32_t* step,
                                 const float* lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* igcn_adam_step_multi over a precomputed block list (the shapes of a model do not change between steps): block b covers
+ * elements [blk_off[b], blk_off[b] + igcn_adam_chunk()) of tensor blk_tensor[b] — one workgroup per block instead of a
+ * (96, n_tensors) grid whose workgroups mostly find nothing to do.  ticked != 0: `step` has been advanced already. */
+int igcn_adam_chunk(void);
+int igcn_adam_step_blocks(int n_blocks, const int64_t* table, const int64_t* numel, const int32_t* blk_tensor,
+                          const int32_t* blk_off, int32_t* step, const float* lr, float beta1, float beta2, float eps,
+                          float grad_scale, int ticked, void* stream);
 int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_t* numel, const int64_t* offset,
                     float* flat, void* stream);
 
@@ -826,6 +841,10 @@ int igcn_loss_head_fwd_grads(int B, int C, int NR, int S, const float* logp, int
 int igcn_gdc_topk_max_rois(void);
 int igcn_gdc_topk(int B, int R, int k, double alpha, const float* A, int64_t* edge_index, float* edge_attr,
                   int32_t* counts, void* stream);
+/* The same for a batch DRAWN from a resident dataset A [S,R,R]: graph g of the batch is matrix subject[g] (int64 [B],
+ * device) — a per-step producer needs no gathered copy of the B matrices. */
+int igcn_gdc_topk_of(int B, int R, int k, double alpha, const float* A, const int64_t* subject, int64_t* edge_index,
+                     float* edge_attr, int32_t* counts, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,107 @@
+"""The feeders in front of the train step on the GPU: every batch they hand over is, bit for bit, what the
+reference's loop would have built — ``Batch.from_data_list([dataset[i] for i in idx])`` (batch.py:24-123) for the subjects
+``idx`` of the epoch order (``DataLoader(shuffle=True)`` semantics: every subject once per epoch), and for the dense
+feeder the per-subject ``preprocess_diffusion_imgs_snps`` (util_gdc.py:71-101) in front of it."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("x", "edge_index", "edge_attr", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y", "batch", "ptr", "edge_ptr")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from igcn_amd import _lib
+    _lib.load()
+
+
+@pytest.fixture(scope="module")
+def subjects():
+    from igcn_amd import synth
+    from igcn_amd.data import Data
+    graphs = synth.brain_graph_list(40, seed=5, rois=90, tsne_dim=16)
+    slim = [Data(**{k: v for k, v in g.__dict__.items() if k != "A"}) for g in graphs]
+    return graphs, slim
+
+
+def _same(got, want, keys=KEYS):
+    for k in keys:
+        a, b = getattr(got, k), getattr(want, k)
+        assert a.dtype == b.dtype and a.shape == b.shape, k
+        assert torch.equal(a.cpu().view(torch.uint8), b.cpu().view(torch.uint8)), k
+
+
+def test_one_launch_gather_equals_from_data_list(subjects):
+    from igcn_amd.data import Batch
+    from igcn_amd.loader import UniformGraphStore, _like
+    _, slim = subjects
+    store = UniformGraphStore(slim, "cuda")
+    assert store.one_launch()
+    idx = torch.tensor([7, 0, 39, 7, 21, 3, 3, 12], device="cuda")
+    slot = _like(store.batch(torch.arange(8, device="cuda")), "cuda")
+    store.gather_into(idx, slot)
+    torch.cuda.synchronize()
+    want = Batch.from_data_list([slim[int(i)] for i in idx])
+    _same(slot, want, KEYS + ("sbjID", "demographics"))
+    assert slot.num_graphs == 8
+
+
+@pytest.mark.parametrize("kind", ["device", "host"])
+def test_feeder_hands_over_every_subject_once_per_epoch(subjects, kind):
+    """Two epochs of 3 batches of 12 out of 40 subjects (ragged tail of 4 dropped, DataLoader(drop_last=True)): the
+    batches are the collation of the seeded epoch order, slot reuse and side-stream hand-over included."""
+    from igcn_amd.data import Batch
+    from igcn_amd.loader import DeviceFeeder, EpochIndex, HostFeeder, UniformGraphStore
+    _, slim = subjects
+    if kind == "device":
+        feeder = DeviceFeeder(UniformGraphStore(slim, "cuda"), 12, steps=6, seed=11)
+        order = EpochIndex(40, 12, seed=11, device="cuda")
+    else:
+        feeder = HostFeeder(UniformGraphStore(slim, "cpu", pin=True), 12, torch.device("cuda", 0), steps=6, seed=11)
+        order = EpochIndex(40, 12, seed=11)
+    seen = []
+    for batch in feeder:
+        torch.cuda.current_stream().wait_event(batch.ready)
+        idx = order.next().cpu()
+        _same(batch, Batch.from_data_list([slim[int(i)] for i in idx]))
+        seen.append(batch.sbjID.cpu().clone())
+        batch.release()
+    for ep in (seen[:3], seen[3:]):
+        ids = torch.cat(ep)
+        assert ids.numel() == 36 and ids.unique().numel() == 36
+    assert not torch.equal(torch.cat(seen[:3]), torch.cat(seen[3:]))          # reshuffled
+
+
+def test_dense_feeder_equals_the_pre_transform_of_the_drawn_subjects(subjects):
+    """DeviceGdcFeeder (matrices read in place by igcn_gdc_topk_of, attributes by igcn_gather_batch) against
+    ``batch_from_dense`` of the gathered matrices — itself pinned to util_gdc.py by tests/test_gpu_gdc.py."""
+    from igcn_amd.gdc import batch_from_dense
+    from igcn_amd.loader import DeviceGdcFeeder, EpochIndex, UniformGraphStore
+    graphs, slim = subjects
+    adj = torch.stack([g.A for g in graphs]).cuda()
+    store = UniformGraphStore(slim, "cuda")
+    cols = {k: store.cols[k] for k in ("x", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y")}
+    feeder = DeviceGdcFeeder(adj, cols, 12, steps=5, top_k=3, alpha=0.05, seed=3)
+    order = EpochIndex(40, 12, seed=3, device="cuda")
+    for batch in feeder:
+        torch.cuda.current_stream().wait_event(batch.ready)
+        idx = order.next()
+        sel = {k: torch.index_select(v, 0, idx) for k, v in cols.items()}
+        x = sel.pop("x")
+        per = {k: (v.reshape(12, -1) if k in ("snps_feat", "tsne_fdim", "clini_score") else v.reshape(-1))
+               for k, v in sel.items()}
+        want = batch_from_dense(torch.index_select(adj, 0, idx), x, top_k=3, alpha=0.05, check=True, **per)
+        _same(batch, want)
+        batch.release()
+
+
+def test_gather_rejects_a_destination_of_the_wrong_size(subjects):
+    from igcn_amd.loader import UniformGraphStore, _like
+    _, slim = subjects
+    store = UniformGraphStore(slim, "cuda")
+    slot = _like(store.batch(torch.arange(8, device="cuda")), "cuda")
+    with pytest.raises(ValueError):
+        store.gather_into(torch.arange(6, device="cuda"), slot)
