@@ -626,7 +626,11 @@ def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
         gstep.load(batch)
         batch.release()
         gstep()
-    out["device"] = run(DeviceFeeder(dev_store, b, steps + warmup + 1), consume_dev)
+    # the gather as ONE launch on the launch stream straight into the step's static inputs (no slot, no second queue) ...
+    out["device"] = run(DeviceFeeder(dev_store, b, steps + warmup + 1, into=gstep.data), consume_dev)
+    out["device"]["how"] = "igcn_gather_batch into the step's inputs, on the launch stream"
+    # ... and one batch ahead on a side stream into a staging slot + hand-over copy (what device_gdc has to do)
+    out["device_side_stream"] = run(DeviceFeeder(dev_store, b, steps + warmup + 1), consume_dev)
     # dense connectivity on the device -> GDC + collation of batch k + 1 on a second stream while step k replays
     if not wl["dense"]:
         from igcn_amd.loader import DeviceGdcFeeder

@@ -344,16 +344,29 @@ class _AheadOnSideStream:
 
 
 class DeviceFeeder(_AheadOnSideStream):
-    """Store resident in HBM: every batch is ONE gather launch (igcn_gather_batch: all keys, index offsets included)
-    straight into its slot — no host data path — made one batch ahead on a side stream (see ``_AheadOnSideStream`` for
-    the hand-over protocol)."""
+    """Store resident in HBM: every batch is ONE gather launch (igcn_gather_batch: all keys, index offsets included) —
+    no host data path.
 
-    def __init__(self, store, batch_size, steps, seed=0, shuffle=True, depth=2):
+    ``into=step.data`` (the static inputs of a ``GraphedTrainStep``): the gather runs on the CURRENT stream straight into
+    the step's inputs, in front of the replay — no staging slot, no copy, no second queue (a 5 us kernel on a side
+    stream costs the replay more than it hides: DESIGN §6).  Without ``into`` batches are made one ahead on a side
+    stream into ``depth`` slots (see ``_AheadOnSideStream`` for the hand-over protocol).  Either way the consumer is
+
+        for batch in feeder:
+            torch.cuda.current_stream().wait_event(batch.ready); step.load(batch); batch.release(); step()
+    """
+
+    def __init__(self, store, batch_size, steps, seed=0, shuffle=True, depth=2, into=None):
         if store.device.type != "cuda":
             raise ValueError("DeviceFeeder reads a device-resident store")
-        self.store, self.bsz = store, int(batch_size)
+        self.store, self.bsz, self.into = store, int(batch_size), into
         self.index = EpochIndex(store.size, batch_size, seed, shuffle, device=store.device)
-        self._init_slots(store.device, steps, depth)
+        if into is None:
+            self._init_slots(store.device, steps, depth)
+        else:
+            self.steps = int(steps)
+            if int(into.num_graphs) != self.bsz:
+                raise ValueError(f"DeviceFeeder: the target holds {into.num_graphs} graphs, batch_size is {self.bsz}")
 
     def _build(self, idx, check=False):
         return self.store.batch(idx)
@@ -363,6 +376,22 @@ class DeviceFeeder(_AheadOnSideStream):
             self.store.gather_into(idx, slot)
         else:
             self.store.batch(idx, out=slot)
+
+    def __iter__(self):
+        if self.into is None:
+            yield from super().__iter__()
+            return
+        done = torch.cuda.Event()
+        for _ in range(self.steps):
+            with torch.no_grad():
+                self._fill(self.into, self.index.next())
+            done.record()                               # same stream as the consumer: the wait is free
+            self.into.ready, self.into.release = done, _nothing
+            yield self.into
+
+
+def _nothing():
+    return None
 
 
 class DeviceGdcFeeder(_AheadOnSideStream):

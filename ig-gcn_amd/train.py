@@ -605,7 +605,10 @@ class GraphedTrainStep:
     def load(self, batch):
         """Copy a new batch (same graph count / node count / edge count) into the static input tensors — including
         the per-graph node and edge offsets the segmented plan build reads (a batch with the same total edge count
-        but different per-graph counts would otherwise be grouped on the wrong segments)."""
+        but different per-graph counts would otherwise be grouped on the wrong segments).  ``batch is self.data``: a
+        producer wrote the static inputs in place (loader.DeviceFeeder(into=step.data)) — nothing to copy."""
+        if batch is self.data:
+            return
         if self.plan.segmented:
             node_ptr, edge_ptr, _, _ = self.plan._seg
             bp, be = getattr(batch, "ptr", None), getattr(batch, "edge_ptr", None)

@@ -75,6 +75,35 @@ def test_feeder_hands_over_every_subject_once_per_epoch(subjects, kind):
     assert not torch.equal(torch.cat(seen[:3]), torch.cat(seen[3:]))          # reshuffled
 
 
+def test_device_feeder_writes_a_captured_steps_inputs_in_place(subjects):
+    """``DeviceFeeder(into=step.data)``: the gather lands in the static inputs of a captured step (no slot, no copy;
+    ``load`` of the step's own batch is a no-op) and the fed step equals the eager step on the same subjects."""
+    import copy
+    from test_gpu_epoch import _small_model as small_model, LAM
+    from igcn_amd.data import Batch
+    from igcn_amd.loader import DeviceFeeder, EpochIndex, UniformGraphStore
+    from igcn_amd.train import FlatAdam, GraphedTrainStep, train_step
+    _, slim = subjects
+    m1 = small_model()
+    m2 = copy.deepcopy(m1)
+    o1, o2 = FlatAdam(m1.parameters(), lr=1e-3), FlatAdam(m2.parameters(), lr=1e-3)
+    static = Batch.from_data_list(slim[:12]).to("cuda")
+    static.x.requires_grad_(True)
+    step = GraphedTrainStep(m1, o1, static, LAM, warmup=1)
+    order = EpochIndex(40, 12, seed=2, device="cuda")
+    for batch in DeviceFeeder(UniformGraphStore(slim, "cuda"), 12, steps=4, seed=2, into=step.data):
+        assert batch is step.data
+        torch.cuda.current_stream().wait_event(batch.ready)
+        step.load(batch)
+        batch.release()
+        idx = order.next().cpu()
+        want = Batch.from_data_list([slim[int(i)] for i in idx])
+        _same(batch, want)
+        l1 = float(step())
+        l2 = float(train_step(m2, o2, want.to("cuda"), LAM))
+        assert abs(l1 - l2) <= 1e-5 * max(1.0, abs(l2)), (l1, l2)
+
+
 def test_dense_feeder_equals_the_pre_transform_of_the_drawn_subjects(subjects):
     """DeviceGdcFeeder (matrices read in place by igcn_gdc_topk_of, attributes by igcn_gather_batch) against
     ``batch_from_dense`` of the gathered matrices — itself pinned to util_gdc.py by tests/test_gpu_gdc.py."""
