@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 404        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 407        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -60,7 +60,7 @@ SIGNATURES = {
     "igcn_dense_sgcn_bwd_ws_floats": (Z, [L, I, I, I, I]),
     "igcn_dense_sgcn_reg_blocks": (I, [L, I]),
     "igcn_dense_sgcn_fwd": (I, [L, I, I, I, I, I, I, P, P, P, P, P, P, P, I, F, F, F, F, F, P, P, P, P, P]),
-    "igcn_dense_sgcn_bwd": (I, [L, I, I, I, I, I, I, P, P, P, P, P, P, I, F, F, F, F, F, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_dense_sgcn_bwd": (I, [L, I, I, I, I, I, I, P, P, P, P, P, P, I, F, F, F, F, F, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_small_linear_bwd_scratch_floats": (Z, [L, I, I]),
     "igcn_small_linear_fwd": (I, [L, I, I, P, P, P, P, P, P]),
     "igcn_small_linear_bwd": (I, [L, I, I, P, P, P, P, P, P, P, P]),
@@ -72,6 +72,8 @@ SIGNATURES = {
     "igcn_head_inputs_bwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
     "igcn_concat_cols": (I, [L, I, I, P, P, P]),
     "igcn_copy_multi": (I, [I, P, P, P, P]),
+    "igcn_image_put": (I, [I, L, P, P, L, P, L, P]),
+    "igcn_image_take": (I, [I, L, P, P, L, P, P]),
     "igcn_gather_batch": (I, [I, I, L, P, P, P, P, P, P]),
     "igcn_launch_floor": (I, [L, I, I, I, P, P]),
     "igcn_graph_pool_fwd": (I, [L, I, I, P, P, P, P]),

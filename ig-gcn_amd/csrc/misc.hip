@@ -254,6 +254,51 @@ extern "C" int igcn_copy_multi(int n, void* const* dst, const void* const* src, 
 }
 
 // =================================================================================================
+// Dense image of a sparse map (ops.SparseMap, small batches: the SNP <-> GO maps of configs[4] run as dense products on
+// the matrix cores): image[c][pos[k]] = val_c[k] before the products, dval[c][k] = dimage[c][pos[k]] after them.  The
+// channels' value vectors are read where they are (`val_stride` floats apart: the ParameterList entries inside
+// train.FlatAdam's flat buffer) — no stack, no index_copy / index_select launches of the tensor library.
+// =================================================================================================
+__global__ void __launch_bounds__(256)
+k_image_put(int64_t nnz, const int64_t* __restrict__ pos, const float* __restrict__ val, int64_t val_stride,
+            float* __restrict__ image, int64_t image_stride) {
+  const int c = blockIdx.y;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * 256)
+    image[c * image_stride + pos[k]] = val[c * val_stride + k];
+}
+__global__ void __launch_bounds__(256)
+k_image_take(int64_t nnz, const int64_t* __restrict__ pos, const float* __restrict__ image, int64_t image_stride,
+             float* __restrict__ out) {
+  const int c = blockIdx.y;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * 256)
+    out[c * nnz + k] = image[c * image_stride + pos[k]];
+}
+
+extern "C" int igcn_image_put(int channels, int64_t nnz, const int64_t* pos, const float* val, int64_t val_stride,
+                              float* image, int64_t image_stride, void* stream) {
+  IGCN_REQUIRE(channels > 0 && channels <= 65535 && nnz >= 0 && val_stride >= nnz, "image_put: bad sizes");
+  if (nnz == 0) return IGCN_OK;
+  int64_t gx = igcn_cdiv(nnz, 256 * 4);
+  gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+  hipLaunchKernelGGL(k_image_put, dim3((unsigned)gx, (unsigned)channels), dim3(256), 0, (hipStream_t)stream, nnz, pos, val,
+                     val_stride, image, image_stride);
+  IGCN_CHECK_LAUNCH("image_put");
+  return IGCN_OK;
+}
+
+extern "C" int igcn_image_take(int channels, int64_t nnz, const int64_t* pos, const float* image, int64_t image_stride,
+                               float* out, void* stream) {
+  IGCN_REQUIRE(channels > 0 && channels <= 65535 && nnz >= 0, "image_take: bad sizes");
+  if (nnz == 0) return IGCN_OK;
+  int64_t gx = igcn_cdiv(nnz, 256 * 4);
+  gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+  hipLaunchKernelGGL(k_image_take, dim3((unsigned)gx, (unsigned)channels), dim3(256), 0, (hipStream_t)stream, nnz, pos,
+                     image, image_stride, out);
+  IGCN_CHECK_LAUNCH("image_take");
+  return IGCN_OK;
+}
+
+// =================================================================================================
 // igcn_gather_batch: the block-diagonal collation of Batch.from_data_list (batch.py:24-123) for a dataset of UNIFORM
 // graphs held as stacked device tensors — every key of the batch in ONE launch (blockIdx.y = key):
 //   kind 0  rows:   dst[b, :] = src[idx[b], :]                       (x, edge_attr, snps_feat, y, ... : `row_bytes` each)

@@ -547,13 +547,14 @@ extern "C" size_t igcn_dense_sgcn_bwd_ws_floats(int64_t n_graphs, int R, int H0,
 // g'_{L-1} = dis * dY * (Y > 0) for the last layer + its bias-gradient partials.  256 threads = 16 nodes x 16 features
 // of ONE copy; grid NC GR / 16.
 __global__ void __launch_bounds__(256)
-k_ds_node_top(int64_t GR, int L, const float* __restrict__ xcat, const float* __restrict__ dxcat, int ldx,
+k_ds_node_top(int64_t GR, int L, const float* __restrict__ xcat, const float* __restrict__ dxcat,
+              const float* __restrict__ dxcat2 /* a second consumer's gradient of xcat, or NULL */, int ldx,
               const float* __restrict__ dis, float* __restrict__ gp_last, float* __restrict__ db_partial) {
   __shared__ float gs[16][DS_F];
   const int tid = threadIdx.x, f = tid & 15, nl = tid >> 4;
   const int64_t cn = (int64_t)blockIdx.x * 16 + nl;                   // copy * GR + node
   const int64_t off = cn * ldx + (int64_t)(L - 1) * DS_F + f;
-  const float g = xcat[off] > 0.f ? dxcat[off] : 0.f;
+  const float g = xcat[off] > 0.f ? dxcat[off] + (dxcat2 ? dxcat2[off] : 0.f) : 0.f;
   gp_last[((cn / GR) * DS_F + f) * GR + cn % GR] = dis[cn] * g;       // feature-major: [copy][f][node]
   gs[nl][f] = g;
   __syncthreads();
@@ -677,7 +678,7 @@ k_ds_aggT(int R, int64_t GR, const float* __restrict__ ew, const float* __restri
 template <int NC, bool M0>
 __global__ void __launch_bounds__(256)
 k_ds_node_mid(int64_t GR, int R, int H0, int L, int l, const float* __restrict__ x, const float* __restrict__ prob,
-              const float* __restrict__ xcat, const float* __restrict__ dxcat, int ldx,
+              const float* __restrict__ xcat, const float* __restrict__ dxcat, const float* __restrict__ dxcat2, int ldx,
               const float* __restrict__ dis, const float* __restrict__ Wl, const float* __restrict__ hp_l,
               const float* __restrict__ agg_l, const float* __restrict__ gp_l, const float* __restrict__ dhp,
               float* __restrict__ gp_prev, float* __restrict__ dxin, float* __restrict__ T,
@@ -730,7 +731,7 @@ k_ds_node_mid(int64_t GR, int R, int H0, int L, int l, const float* __restrict__
     return;
   }
   const int64_t off = cn * ldx + (int64_t)(l - 1) * DS_F + f;
-  const float gval = xcat[off] > 0.f ? dxcat[off] + dxv : 0.f;
+  const float gval = xcat[off] > 0.f ? dxcat[off] + (dxcat2 ? dxcat2[off] : 0.f) + dxv : 0.f;
   gp_prev[((int64_t)c * DS_F + f) * GR + node] = di * gval;
   gs[nl][f] = gval;
   __syncthreads();
@@ -1018,6 +1019,7 @@ extern "C" int igcn_dense_sgcn_bwd(int64_t n_graphs, int R, int H0, int F, int L
                                    const float* x, const float* prob, const float* prob_bias, const float* ew,
                                    const float* const* W, const float* snps_prob, int n_snps, float l1_x, float ent_x,
                                    float l1_e, float ent_e, float eps, const float* xcat, const float* dxcat,
+                                   const float* dxcat2 /* NULL: xcat had one consumer */,
                                    const float* d_reg /*device [1] or NULL*/, const float* ws, float* bws, float* dx,
                                    float* dprob, float* dprob_bias, float* dsnps_prob, float* dparams, void* stream) {
   int rc = ds_check_args("dense_sgcn_bwd", n_graphs, R, H0, F, L, copies);
@@ -1033,7 +1035,7 @@ extern "C" int igcn_dense_sgcn_bwd(int64_t n_graphs, int R, int H0, int F, int L
   const dim3 eg((unsigned)(n_graphs * (R / 64)));            // 1-D: ds_block maps ids to (graph, block), XCD-aware
   const int64_t lsz = (int64_t)copies * GR * DS_F;                    // one layer of hp / agg / gp
   const float* dis = ws + o.dis;
-  hipLaunchKernelGGL(k_ds_node_top, dim3((unsigned)q.nblk), dim3(256), 0, st, GR, L, xcat, dxcat, ldx, dis,
+  hipLaunchKernelGGL(k_ds_node_top, dim3((unsigned)q.nblk), dim3(256), 0, st, GR, L, xcat, dxcat, dxcat2, ldx, dis,
                      bws + q.gp + (int64_t)(L - 1) * lsz, bws + q.pdb + (int64_t)(L - 1) * q.nblk * DS_F);
   for (int l = L - 1; l >= 0; --l) {
     const size_t ldt = (size_t)(2 * 4 * copies * 16 * DS_F + (pipe ? copies * DS_F * (R + 4) + R : 0)) * sizeof(float);
@@ -1041,7 +1043,7 @@ extern "C" int igcn_dense_sgcn_bwd(int64_t n_graphs, int R, int H0, int F, int L
                         hipLaunchKernelGGL((k_ds_aggT<NC, M0, PIPE>), eg, dim3(512), ldt, st, R, GR, ew, ws + o.u, ws + o.v,
                                            bws + q.gp + (int64_t)l * lsz, bws + q.dhp)));
     DS_DISPATCH(hipLaunchKernelGGL(
-        (k_ds_node_mid<NC, M0>), dim3((unsigned)q.nblk), dim3(256), 0, st, GR, R, H0, L, l, x, prob, xcat, dxcat, ldx, dis,
+        (k_ds_node_mid<NC, M0>), dim3((unsigned)q.nblk), dim3(256), 0, st, GR, R, H0, L, l, x, prob, xcat, dxcat, dxcat2, ldx, dis,
         W[l], ws + o.hp + (int64_t)l * lsz, ws + o.agg + (int64_t)l * lsz, bws + q.gp + (int64_t)l * lsz, bws + q.dhp,
         l > 0 ? bws + q.gp + (int64_t)(l - 1) * lsz : nullptr, bws + q.dxin, bws + q.T, bws + q.ddeg,
         bws + q.pdw + (int64_t)l * q.nblk * DS_F * DS_F, l > 0 ? bws + q.pdb + (int64_t)(l - 1) * q.nblk * DS_F : nullptr));

@@ -194,9 +194,9 @@ class GraphPlan:
                 or not _lib.load().igcn_dense_sgcn_supported(r, 1, 16, 1) or ei.data_ptr() % 16
                 or torch.cuda.is_current_stream_capturing()):
             return False
-        flag = torch.zeros(1, dtype=torch.int32, device=ei.device)
+        flag = torch.zeros(2, dtype=torch.int32, device=ei.device)
         call("igcn_dense_blocks_check", self.n_nodes // r, r, ptr(ei), ptr(flag), stream_ptr())
-        return int(flag.item()) == 0
+        return int(flag[0].item()) == 0
 
     @property
     def segmented(self):
@@ -232,7 +232,9 @@ class GraphPlan:
             raise _lib.IgcnError("rebuild needs an int64 edge_index of the shape the plan was built for")
         if getattr(self, "dense_blocks", False):
             # complete row-major graphs: the new batch has the SAME structure or none the dense kernels can use — one
-            # pass over edge_index verifies it (status bit 2); the sorted arrays of the first build stay valid
+            # pass over edge_index verifies it (status bit 2); the sorted arrays of the first build stay valid.
+            # [Forked onto a side branch of the captured step, joined at the loss head: +74 us per replay — a second
+            # queue costs the replay far more than the 27 us it hides.]
             ei = edge_index.contiguous()
             call("igcn_dense_blocks_check", self.n_nodes // self.nodes_per_graph, self.nodes_per_graph, ptr(ei),
                  ptr(self.status), stream_ptr())
@@ -612,10 +614,13 @@ class DenseSgcn(torch.autograd.Function):
     arrays, no per-edge intermediates (csrc/sgcn_dense.hip).  Returns (xcat, partials of loss_probability — their
     SUM is the loss; empty for "plain").  ``reg`` = (l1_x, ent_x, l1_e, ent_e, eps).  ``status``: the plan's device
     status words (``GraphPlan.status``, int32[2]) or None — when the structure check of the batch (``plan.rebuild``)
-    has flagged it, the kernels turn the degrees into NaN, so loss and gradients are NaN instead of silently wrong."""
+    has flagged it, the kernels turn the degrees into NaN, so loss and gradients are NaN instead of silently wrong.
+    ``rois`` negative: DUAL output (xcat, regp, xcat again — two autograd handles of one buffer for the model's two
+    consumers, attention query and head inputs; their gradients meet where the backward kernels read them)."""
 
     @staticmethod
     def forward(ctx, x, ew, prob, prob_bias, snps_prob, mode, rois, reg, status, *wb):
+        dual, rois = rois < 0, abs(rois)
         x, ew, prob, pb = _f32(x), _f32(ew), _f32(prob), _f32(prob_bias)
         sp = _f32(snps_prob) if snps_prob is not None else None
         wb = [_f32(t) for t in wb]
@@ -642,16 +647,21 @@ class DenseSgcn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         if not anym:
             ctx.mark_non_differentiable(regp)
+        if dual:
+            return xcat, regp, xcat.view(copies * n, layers * f)
         return xcat, regp
 
     @staticmethod
-    def backward(ctx, dxcat, dregp):
+    def backward(ctx, dxcat, dregp, dxcat2=None):
         x, ew, prob, pb, sp, xcat, ws, *wb = ctx.saved_tensors
         ws_ = wb[0::2]
         g, rois, h0, f, layers, copies, first_masked, anym = ctx.cfg
         lib = _lib.load()
         dev = x.device
+        if dxcat is None:
+            dxcat, dxcat2 = dxcat2, None
         dxcat = _f32(dxcat) if dxcat is not None else torch.zeros_like(xcat)
+        dxcat2 = _f32(dxcat2) if dxcat2 is not None else None
         d_reg = dregp[:1] if (dregp is not None and anym) else None        # the same scalar in every partial
         if d_reg is not None and not d_reg.is_contiguous():
             d_reg = d_reg.contiguous()
@@ -665,8 +675,8 @@ class DenseSgcn(torch.autograd.Function):
         wp = (ctypes.c_void_p * layers)(*[w.data_ptr() for w in ws_])
         with _immediate(ctx.final):
             call("igcn_dense_sgcn_bwd", g, rois, h0, f, layers, copies, first_masked, ptr(x), ptr(prob), ptr(pb), ptr(ew),
-                 wp, ptr(sp), sp.numel() if sp is not None else 0, *ctx.reg, ptr(xcat), ptr(dxcat), ptr(d_reg), ptr(ws),
-                 ptr(bws), ptr(dx), ptr(dprob), ptr(dpb), ptr(dsp), ptr(dpar), stream_ptr())
+                 wp, ptr(sp), sp.numel() if sp is not None else 0, *ctx.reg, ptr(xcat), ptr(dxcat), ptr(dxcat2), ptr(d_reg),
+                 ptr(ws), ptr(bws), ptr(dx), ptr(dprob), ptr(dpb), ptr(dsp), ptr(dpar), stream_ptr())
         grads, off = [], 0
         for l in range(layers):
             fin = h0 if l == 0 else f
@@ -1384,13 +1394,14 @@ class SparseMap(torch.autograd.Function):
         x = _f32(x)
         stacked = len(vals) == 1 and vals[0].dim() == 2
         ctx.vstride = None
+        dense = SparseMap._use_dense(x.shape[0], vals[0].shape[0] if stacked else len(vals), csr)
         if stacked:
             val = _f32(vals[0])
         elif len(vals) == 1:
             val = _f32(vals[0]).reshape(1, -1)                   # one channel: a view, no launch
         else:
             vs = SparseMap._row_stride(vals, csr.nnz)
-            if vs is not None and not SparseMap._use_dense(x.shape[0], len(vals), csr):
+            if vs is not None:
                 # the channels' vectors sit at a constant stride in one buffer (train.FlatAdam's flat parameters): the
                 # kernels read them where they are — no torch.stack launch in front of every step
                 ctx.vstride, val = vs, vals[0]
@@ -1399,10 +1410,11 @@ class SparseMap(torch.autograd.Function):
         b, c = x.shape[0], (len(vals) if ctx.vstride is not None else val.shape[0])
         ctx.csr, ctx.stacked, ctx.nvals = csr, stacked, len(vals)
         ctx.final = _leaves(*vals)
-        ctx.dense = ctx.vstride is None and SparseMap._use_dense(b, c, csr)
+        ctx.dense, ctx.channels = dense, c
         if ctx.dense:
             t = csr.dense(c)
-            t.index_copy_(1, csr.flat_pos, val)
+            call("igcn_image_put", c, csr.nnz, ptr(csr.flat_pos), ptr(val),
+                 ctx.vstride if ctx.vstride is not None else csr.nnz, ptr(t), csr.n_rows * csr.n_cols, stream_ptr())
             y = gemm_nt(x, t.view(c * csr.n_rows, csr.n_cols)).view(b, c, csr.n_rows)
             ctx.save_for_backward(x, val)
             return y
@@ -1435,7 +1447,7 @@ class SparseMap(torch.autograd.Function):
         x, val = ctx.saved_tensors[0], ctx.saved_tensors[1]
         csr = ctx.csr
         dy = _f32(dy)
-        b, c = x.shape[0], (ctx.nvals if ctx.vstride is not None else val.shape[0])
+        b, c = x.shape[0], ctx.channels
         need_val = any(ctx.needs_input_grad[2:])
         if ctx.dense:
             dy2 = dy.view(b, c * csr.n_rows)
@@ -1443,7 +1455,10 @@ class SparseMap(torch.autograd.Function):
             dx = gemm_nn(dy2, t.view(c * csr.n_rows, csr.n_cols)) if ctx.needs_input_grad[0] else None
             dval = None
             if need_val:
-                dval = gemm_tn(dy2, x).view(c, csr.n_rows * csr.n_cols).index_select(1, csr.flat_pos)
+                dt = gemm_tn(dy2, x)                                  # [c * n_rows, n_cols]: the dense image of dT
+                dval = torch.empty(c, csr.nnz, dtype=torch.float32, device=x.device)
+                call("igcn_image_take", c, csr.nnz, ptr(csr.flat_pos), ptr(dt), csr.n_rows * csr.n_cols, ptr(dval),
+                     stream_ptr())
         else:
             dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
             dval = torch.empty(c, csr.nnz, dtype=torch.float32, device=x.device) if need_val else None

@@ -310,7 +310,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         mode = {(False,): "plain", (True,): "masked", (False, True): "both"}.get(tuple(explain_flags))
         snps_ok = snps_feat is not None and snps_feat.is_cuda and snps_feat.dim() == 2 \
             and snps_feat.shape[1] == self.snps_prob.numel()
-        xcat = None
+        xcat = xcat_dense_img = None
         if (mode is not None and x.is_cuda and (snps_ok or mode == "plain") and os.environ.get("IGCN_NO_DENSE_BLOCKS") != "1"
                 and ops.dense_sgcn_supported(plan, self.rois, x.shape[1], convs[0].out_channels, len(convs))):
             # complete graphs (a dense adjacency as COO): masks, gcn_norm, every GCNConv and the mask regulariser of the
@@ -324,8 +324,13 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                 prob_d, prob_h = ops.GradFan.apply(self.prob, 2)
                 sp_d, sp_m = ops.GradFan.apply(self.snps_prob, 2)
                 x_d, x_h = ops.GradFan.apply(x, 2)
-            xcat, regp = ops.DenseSgcn.apply(x_d, edge_weight, prob_d, self.prob_bias, sp_d, mode, self.rois,
-                                             self._reg_hp, plan.status, *wb)
+            if fan and self.isCrossAtten and not self.graph_pool and not self.isImageOnly and not self.isSNPsOnly:
+                # (xcat feeds the attention query and the head inputs: two handles, one sum inside the backward kernels)
+                xcat, regp, xcat_dense_img = ops.DenseSgcn.apply(x_d, edge_weight, prob_d, self.prob_bias, sp_d, mode,
+                                                                 -self.rois, self._reg_hp, plan.status, *wb)
+            else:
+                xcat, regp = ops.DenseSgcn.apply(x_d, edge_weight, prob_d, self.prob_bias, sp_d, mode, self.rois,
+                                                 self._reg_hp, plan.status, *wb)
             if mode != "plain":
                 self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp), self._reg_key(x, edge_weight))
             if mode == "plain":
@@ -367,7 +372,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             stack = lambda ts: ts[0] if g == 1 else torch.cat(ts, dim=0)                       # noqa: E731
             x_in, ew_in, snps_in = stack(xs), stack(ews), stack(snps)
         bf = self.bf16_transforms
-        xcat_img = None
+        xcat_img = xcat_dense_img
         if xcat is None:
             plan_g = plan.replicate(g)
             if fan and self.isCrossAtten and not self.graph_pool and not self.isImageOnly and not self.isSNPsOnly:

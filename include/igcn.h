@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 404
+#define IGCN_ABI_VERSION 407
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -293,7 +293,8 @@ int igcn_head_bwd_pair(int R, int H, int C1, const float* dy1, const float* y1, 
  *   W / b: HOST arrays of L device pointers (W_l [F, Fin_l] row-major, Fin_0 = H0).  ws: igcn_dense_sgcn_ws_floats
  *   floats, written by fwd and read by bwd.  reg_partials [igcn_dense_sgcn_reg_blocks]: un-reduced partials of
  *   loss_probability (their SUM is the loss; NULL or copies == 1 plain: not written); snps_prob may be NULL.
- *   bwd: d_reg = d loss / d (every partial), one device float (NULL: 0); outputs dx [G R, H0] (both passes' sum),
+ *   bwd: dxcat2 = the gradient of a second consumer of xcat (attention query | head inputs), added to dxcat where it is
+ *   read, or NULL; d_reg = d loss / d (every partial), one device float (NULL: 0); outputs dx [G R, H0] (both passes' sum),
  *   dprob [R, H0], dprob_bias [2 H0], dsnps_prob [n_snps] (regulariser part only; may be NULL) and dparams
  *   [igcn_sgcn_stack_param_floats] = dW_0 | db_0 | dW_1 | ... (final reductions in the sense of igcn_reduce_defer);
  *   bws: igcn_dense_sgcn_bwd_ws_floats floats of scratch. */
@@ -310,8 +311,9 @@ int igcn_dense_sgcn_fwd(int64_t n_graphs, int R, int H0, int F, int L, int copie
 int igcn_dense_sgcn_bwd(int64_t n_graphs, int R, int H0, int F, int L, int copies, int first_masked, const float* x,
                         const float* prob, const float* prob_bias, const float* ew, const float* const* W,
                         const float* snps_prob, int n_snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,
-                        const float* xcat, const float* dxcat, const float* d_reg, const float* ws, float* bws,
-                        float* dx, float* dprob, float* dprob_bias, float* dsnps_prob, float* dparams, void* stream);
+                        const float* xcat, const float* dxcat, const float* dxcat2, const float* d_reg, const float* ws,
+                        float* bws, float* dx, float* dprob, float* dprob_bias, float* dsnps_prob, float* dparams,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense feature transform on the matrix cores (f32-input MFMA 16x16x4, exact fp32):
@@ -374,6 +376,15 @@ int igcn_concat_cols(int64_t rows, int F, int nparts, const float* const* parts,
  * dst / src / nbytes are HOST arrays [n]; ranges must not overlap.  16-byte lanes where both ends are aligned. */
 #define IGCN_COPY_MULTI_MAX 16
 int igcn_copy_multi(int n, void* const* dst, const void* const* src, const int64_t* nbytes, void* stream);
+
+/* Dense image of a sparse map (the SNP <-> GO maps of kernel/go_model.py:208-215,281-282 as dense products, small
+ * batches): image[c * image_stride + pos[k]] = val[c * val_stride + k] for c < channels, k < nnz (pos int64 [nnz]: row *
+ * n_cols + col of every non-zero; the other entries of `image` are not touched), and the way back for the value
+ * gradients: out [channels, nnz], out[c][k] = image[c * image_stride + pos[k]]. */
+int igcn_image_put(int channels, int64_t nnz, const int64_t* pos, const float* val, int64_t val_stride, float* image,
+                   int64_t image_stride, void* stream);
+int igcn_image_take(int channels, int64_t nnz, const int64_t* pos, const float* image, int64_t image_stride, float* out,
+                    void* stream);
 
 /* Block-diagonal collation (Batch.from_data_list, batch.py:24-123) of B graphs drawn from a dataset of UNIFORM graphs held
  * as stacked device tensors, every key in ONE launch: idx int64 [B] (device) = the subjects; per key c < n (HOST arrays):
