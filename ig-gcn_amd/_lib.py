@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 407        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 408        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -113,6 +113,7 @@ SIGNATURES = {
     "igcn_gram_loss_fwd": (I, [I, I, I, P, P, P, P, P]),
     "igcn_gram_loss_bwd": (I, [I, I, P, P, P, P, P]),
     "igcn_gram_loss_fwd_rbf": (I, [I, I, I, P, P, I, F, P, P, P, P]),
+    "igcn_gram_loss_fwd_rbf_unit": (I, [I, I, I, P, P, I, F, P, P, P, P, P, P]),
     "igcn_attn_core_lds_bytes": (Z, [I, I, I, I, I]),
     "igcn_attn_core_fwd": (I, [I, I, I, I, I, P, P, P, P, P]),
     "igcn_attn_core_bwd_scratch_floats": (Z, [I, I, I]),

@@ -111,16 +111,23 @@ extern "C" int igcn_mask_reg_bwd(int64_t n_prob, int64_t n_edge, int64_t n_snps,
 // RBF: the Laplacian is not read but MADE here — W_ij = exp(-gamma ||t_i - t_j||^2) (t NULL: W = 1) evaluated inside
 // the row walk, Lap = diag(W 1) - W written by group 0's workgroups for the backward: the stand-alone k_rbf_laplacian
 // launch in front disappears from the train step.
+// UNIT (RBF only): the launch also writes what k_gram_loss_bwd would for the upstream gradient `unit` (gc, go per group,
+// known on the host: a train step's d loss / d (consist, orth) are the loss weights) — S = dG + dG^T per group, from the
+// same expressions in the same order, so a step whose upstream IS that has no Gram-loss backward launch.
+struct GramUnit { float gc[4], go[4]; };
 template <bool RBF>
 __global__ void __launch_bounds__(256)
 k_gram_loss_fwd(int B, int RD, const float* __restrict__ Gall, const float* __restrict__ Lap,
                 float* __restrict__ partial /*[B, 2 groups]*/, const float* __restrict__ t, int T, float gamma,
-                float* __restrict__ lap_out) {
+                float* __restrict__ lap_out, GramUnit unit, float* __restrict__ Sall) {
   __shared__ float red[16];
   const int i = blockIdx.x, grp = blockIdx.y, groups = gridDim.y;
   const float* G = Gall + (int64_t)grp * B * B;
   const float gii = G[(int64_t)i * B + i];
-  float c = 0.f, o = 0.f, rs = 0.f;
+  const bool UNIT = RBF && Sall != nullptr;
+  float* S = UNIT ? Sall + (int64_t)grp * B * B : nullptr;
+  const float gc = UNIT ? unit.gc[grp] : 0.f, go = UNIT ? unit.go[grp] : 0.f, b2u = (float)B * (float)B;
+  float c = 0.f, o = 0.f, rs = 0.f, dsum = 0.f;
   for (int j = threadIdx.x; j < B; j += 256) {
     const float g = G[(int64_t)i * B + j];
     if (RBF) {
@@ -138,6 +145,11 @@ k_gram_loss_fwd(int B, int RD, const float* __restrict__ Gall, const float* __re
       if (j != i) {
         c -= w * g;
         if (grp == 0) lap_out[(int64_t)i * B + j] = -w;
+        if (UNIT) {                                               // k_gram_loss_bwd's row walk (Lap_ij = Lap_ji = -w)
+          const float gjj = G[(int64_t)j * B + j];
+          dsum += g * g / (gii * gii * gjj);
+          S[(int64_t)i * B + j] = (gc * ((-w) + (-w)) + go * 4.f * g / (gii * gjj)) / b2u;
+        }
       }
     } else {
       c += Lap[(int64_t)i * B + j] * g;
@@ -147,11 +159,13 @@ k_gram_loss_fwd(int B, int RD, const float* __restrict__ Gall, const float* __re
   c = block_sum_all(c, red);
   o = block_sum_all(o, red);
   if (RBF) rs = block_sum_all(rs, red);
+  if (UNIT) dsum = block_sum_all(dsum, red);
   if (threadIdx.x == 0) {
     if (RBF) {
       const float dii = rs - 1.f;                               // diag(W 1) - W_ii, W_ii = exp(0)
       c += dii * gii;
       if (grp == 0) lap_out[(int64_t)i * B + i] = dii;
+      if (UNIT) S[(int64_t)i * B + i] = 2.f * (gc * dii - go * 2.f * dsum) / b2u;
     }
     const float b2 = (float)B * (float)B;
     partial[(int64_t)i * 2 * groups + 2 * grp] = c / b2;
@@ -187,7 +201,7 @@ extern "C" int igcn_gram_loss_fwd(int B, int RD, int groups, const float* G /*[g
   IGCN_REQUIRE(B > 0 && groups >= 1 && groups <= 64, "gram_loss_fwd: bad B / groups");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_gram_loss_fwd<false>, dim3(B, groups), dim3(256), 0, st, B, RD, G, Lap, scratch, nullptr, 0, 0.f,
-                     nullptr);
+                     nullptr, GramUnit{}, nullptr);
   IGCN_CHECK_LAUNCH("gram_loss_fwd");
   if (out == nullptr) return IGCN_OK;
   return igcn_launch_reduce_rows(scratch, B, 2 * groups, 2 * groups, out, 0, st);
@@ -201,8 +215,28 @@ extern "C" int igcn_gram_loss_fwd_rbf(int B, int RD, int groups, const float* G 
   IGCN_REQUIRE(B > 0 && groups >= 1 && groups <= 64 && lap_out && (tsne == nullptr || T > 0), "gram_loss_fwd_rbf: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_gram_loss_fwd<true>, dim3(B, groups), dim3(256), 0, st, B, RD, G, nullptr, scratch, tsne, T, gamma,
-                     lap_out);
+                     lap_out, GramUnit{}, nullptr);
   IGCN_CHECK_LAUNCH("gram_loss_fwd_rbf");
+  if (out == nullptr) return IGCN_OK;
+  return igcn_launch_reduce_rows(scratch, B, 2 * groups, 2 * groups, out, 0, st);
+}
+
+// igcn_gram_loss_fwd_rbf that also writes S [groups, B, B] = what igcn_gram_loss_bwd returns for the upstream gradient
+// gout [groups, 2] given HERE, on the host (bit for bit: the same expressions in the same order).
+extern "C" int igcn_gram_loss_fwd_rbf_unit(int B, int RD, int groups, const float* G, const float* tsne, int T, float gamma,
+                                           float* lap_out, float* out, float* scratch, const float* gout /*HOST*/,
+                                           float* S, void* stream) {
+  IGCN_REQUIRE(B > 0 && groups >= 1 && groups <= 4 && lap_out && gout && S && (tsne == nullptr || T > 0),
+               "gram_loss_fwd_rbf_unit: bad arguments (groups <= 4)");
+  hipStream_t st = (hipStream_t)stream;
+  GramUnit u{};
+  for (int g = 0; g < groups; ++g) {
+    u.gc[g] = gout[2 * g];
+    u.go[g] = gout[2 * g + 1];
+  }
+  hipLaunchKernelGGL(k_gram_loss_fwd<true>, dim3(B, groups), dim3(256), 0, st, B, RD, G, nullptr, scratch, tsne, T, gamma,
+                     lap_out, u, S);
+  IGCN_CHECK_LAUNCH("gram_loss_fwd_rbf_unit");
   if (out == nullptr) return IGCN_OK;
   return igcn_launch_reduce_rows(scratch, B, 2 * groups, 2 * groups, out, 0, st);
 }

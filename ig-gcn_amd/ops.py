@@ -26,6 +26,15 @@ _DEFER = {"on": False, "keep": [], "ln_affine": [], "spmm_dval": []}
 # addresses of the cached "d loss / d loss = 1" scalars of train._unit_grad: ops.LossHead returns the gradients its
 # forward wrote for that upstream instead of launching its backward kernel
 UNIT_GRAD_PTRS = set()
+# address -> values of the loss head's d loss / d (consist_1, orth_1, consist_2, orth_2) while a backward that took the
+# unit path is running (set by LossHead.backward, taken by GramLosses.backward in the same pass)
+UNIT_DGRAM = {}
+
+
+def unit_dgram(lam):
+    """d loss / d (consist, orth per pass) of train()'s weighted sum (:533-543) for d loss / d loss = 1 — what
+    igcn_loss_head_fwd_grads writes into dgram: cluster = lam4 (c1 + c2) / 2, orth = lam5 o1."""
+    return (float(lam[4]) * 0.5, float(lam[5]), float(lam[4]) * 0.5, 0.0)
 
 
 class deferred_reductions:
@@ -1950,8 +1959,12 @@ class GramLosses(torch.autograd.Function):
     (sgcn_img_snp.py:183-205).  Returns two tensors of shape [G]."""
 
     @staticmethod
-    def forward(ctx, s, lap, groups=1, packed=False, rbf=None):
-        """``packed``: return ONE tensor [G,2] = (consist, orth) per group (what igcn_loss_head_* consumes);
+    def forward(ctx, s, lap, groups=1, packed=False, rbf=None, expect=None):
+        """``expect`` (with ``rbf``): the upstream gradient [G*2] the caller expects in the backward, as host floats (a
+        train step's d loss / d (consist, orth) are its loss weights): the forward kernel then writes the backward's S
+        as it goes, and a backward whose upstream IS that (announced by LossHead through UNIT_DGRAM, recognised by
+        address like the unit scalar itself) launches no igcn_gram_loss_bwd.
+        ``packed``: return ONE tensor [G,2] = (consist, orth) per group (what igcn_loss_head_* consumes);
         ``packed == "partials"``: the un-reduced row partials [B, G*2] whose column sums are that tensor (LossHead adds
         them up inside its own kernel: one launch less); every row then receives the gradient of the sum.
         ``rbf`` = (tsne [B, T] or None, gamma) with ``lap`` None: the Laplacian D - W of consist_loss is built inside the
@@ -1974,7 +1987,15 @@ class GramLosses(torch.autograd.Function):
         gscr = torch.empty(groups * sk * b * b, dtype=torch.float32, device=s.device) if sk > 1 else None
         call("igcn_gemm_f32_batched", b, b, rd, groups, ptr(s), rd, 1, b * rd, ptr(s), rd, 1, b * rd, ptr(gram), b * b, b,
              sk, ptr(gscr), stream_ptr())
-        if rbf is not None:
+        ctx.sym = ctx.expect = None
+        if (rbf is not None and expect is not None and groups <= 4 and len(expect) == 2 * groups
+                and ctx.needs_input_grad[0]):
+            ctx.expect = tuple(float(v) for v in expect)
+            ctx.sym = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
+            call("igcn_gram_loss_fwd_rbf_unit", b, rd, groups, ptr(gram), ptr(tsne),
+                 tsne.shape[1] if tsne is not None else 0, float(rbf[1]), ptr(lap), ptr(out), ptr(scratch),
+                 (ctypes.c_float * (2 * groups))(*ctx.expect), ptr(ctx.sym), stream_ptr())
+        elif rbf is not None:
             call("igcn_gram_loss_fwd_rbf", b, rd, groups, ptr(gram), ptr(tsne), tsne.shape[1] if tsne is not None else 0,
                  float(rbf[1]), ptr(lap), ptr(out), ptr(scratch), stream_ptr())
         else:
@@ -2000,13 +2021,16 @@ class GramLosses(torch.autograd.Function):
             zero = torch.zeros(groups, dtype=torch.float32, device=s.device)
             gout = torch.stack([g_c if g_c is not None else zero, g_o if g_o is not None else zero],
                                dim=1).contiguous()
-        sym = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
         ds = torch.empty_like(s)
-        call("igcn_gram_loss_bwd", b, groups, ptr(gram), ptr(lap), ptr(gout), ptr(sym), stream_ptr())
+        if ctx.sym is not None and UNIT_DGRAM.pop(gout.data_ptr(), None) == ctx.expect:
+            sym = ctx.sym                                         # written by the forward for exactly this upstream
+        else:
+            sym = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
+            call("igcn_gram_loss_bwd", b, groups, ptr(gram), ptr(lap), ptr(gout), ptr(sym), stream_ptr())
         rd = s.shape[1]
         call("igcn_gemm_f32_batched", b, rd, b, groups, ptr(sym), b, 1, b * b, ptr(s), 1, rd, b * rd, ptr(ds), b * rd, rd,
              1, None, stream_ptr())                                # ds_g = S_g s_g, every group in one launch
-        return ds, None, None, None, None
+        return ds, None, None, None, None, None
 
 
 class ProjectedAttention(torch.autograd.Function):
@@ -2118,8 +2142,11 @@ class LossHead(torch.autograd.Function):
         b, c, nr, s, lam, hp_ce, hp_mi = ctx.cfg
         gout = _f32(gout).reshape(1)
         dev = reg.device
+        UNIT_DGRAM.clear()
         if ctx.unit is not None and gout.data_ptr() in UNIT_GRAD_PTRS:
             dlogp, dreg, dxhat, dgram, dprob = ctx.unit              # written by the forward for exactly this upstream
+            # the values behind dgram's address, for GramLosses (whose forward may have prepared its backward for them)
+            UNIT_DGRAM[dgram.data_ptr()] = unit_dgram(lam)
         else:
             dlogp = torch.empty(2 * b, c, dtype=torch.float32, device=dev)
             dreg, dxhat = torch.empty_like(reg), torch.empty_like(x_hat)

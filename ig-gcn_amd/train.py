@@ -352,7 +352,10 @@ def _losses_batched(model, data, lam, hp, temperature):
     # kernel adds the partials up and takes log_softmax itself (two reductions and two torch launches less); the RBF
     # Laplacian of consist_loss is built inside the Gram loss kernel (model.laplacian() is a launch of its own)
     soft = model.isSoftSimilarity and data.tsne_fdim is not None
-    gram = ops.GramLosses.apply(out_z, None, 2, "partials", (data.tsne_fdim if soft else None, model.rbf_gamma))
+    # (the loss head's gradient of these partials for a unit upstream is known here: the Gram loss forward prepares its
+    # own backward for it — ops.GramLosses ``expect``)
+    unit = ops.unit_dgram(lam) if (ops.UNIT_GRAD_PTRS and os.environ.get("IGCN_NO_LOSS_HEAD_FUSED", "0") != "1") else None
+    gram = ops.GramLosses.apply(out_z, None, 2, "partials", (data.tsne_fdim if soft else None, model.rbf_gamma), unit)
     # (rows sum to [2,2] = (consist, orth) per pass)
     prob = model.loss_probability(data.x, data.edge_index, data.edge_attr, hp, edge_prob=model.last_edge_prob,
                                   partials=True)

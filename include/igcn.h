@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 407
+#define IGCN_ABI_VERSION 408
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -584,6 +584,11 @@ int igcn_gram_loss_bwd(int B, int groups, const float* G, const float* Lap, cons
  * igcn_rbf_laplacian launch in the train step. */
 int igcn_gram_loss_fwd_rbf(int B, int RD, int groups, const float* G, const float* tsne, int T, float gamma, float* lap_out,
                            float* out, float* scratch, void* stream);
+/* ... that also writes S [groups, B, B] = the output of igcn_gram_loss_bwd for the upstream gradient gout [groups, 2]
+ * given here as a HOST array (groups <= 4), bit for bit: a train step knows its d loss / d (consist, orth) — the loss
+ * weights — when it launches the forward, and then has no Gram-loss backward launch. */
+int igcn_gram_loss_fwd_rbf_unit(int B, int RD, int groups, const float* G, const float* tsne, int T, float gamma,
+                                float* lap_out, float* out, float* scratch, const float* gout, float* S, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Cross-attention core of nn.MultiheadAttention (kernel/sgcn_img_snp.py:240) on the projection outputs in place:

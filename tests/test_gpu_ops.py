@@ -994,6 +994,52 @@ def test_gram_losses_grouped(ops):
     assert_matches(g, g_ref.numpy(), 2e-4, "ds")
 
 
+def test_gram_loss_forward_prepares_the_backward_for_the_announced_upstream(ops):
+    """``GramLosses(expect=...)`` (the train step: d loss / d (consist, orth) = the loss weights, known at the forward):
+    the forward kernel writes the backward's S itself; a backward whose upstream was announced through UNIT_DGRAM takes
+    it (no igcn_gram_loss_bwd launch) and returns the SAME bytes as the regular backward; any other upstream — other
+    values, or none announced — runs the regular backward."""
+    rng = np.random.default_rng(3)
+    bsz, rd = 48, 160
+    s = torch.from_numpy(rng.standard_normal((2 * bsz, rd)) + 0.3).float().cuda()
+    tsne = torch.from_numpy(rng.random((bsz, 16)) * 3).float().cuda()
+    lam = [0.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
+    unit = ops.unit_dgram(lam)
+    up = torch.tensor(unit, device="cuda")
+
+    def run(expect, announce):
+        sg = s.clone().requires_grad_(True)
+        part = ops.GramLosses.apply(sg, None, 2, "partials", (tsne, 0.01), expect)
+        g = up.view(1, 4).expand(part.shape[0], 4)
+        ops.UNIT_DGRAM.clear()
+        if announce is not None:
+            ops.UNIT_DGRAM[up.data_ptr()] = announce
+        before = _gram_bwd_calls[0]
+        ds = torch.autograd.grad(part, sg, g)[0]
+        return part.detach().clone(), ds, _gram_bwd_calls[0] - before
+
+    from igcn_amd import _lib
+    _gram_bwd_calls = [0]
+    real = _lib.call
+
+    def counting(name, *a):
+        if name == "igcn_gram_loss_bwd":
+            _gram_bwd_calls[0] += 1
+        return real(name, *a)
+    ops.call = counting
+    try:
+        p0, d0, n0 = run(None, None)                     # regular
+        p1, d1, n1 = run(unit, unit)                     # prepared and announced: no backward launch
+        p2, d2, n2 = run(unit, None)                     # prepared, nobody announced the upstream: regular backward
+        p3, d3, n3 = run(unit, (9.0, 9.0, 9.0, 9.0))     # announced with other values: regular backward
+    finally:
+        ops.call = real
+    assert (n0, n1, n2, n3) == (1, 0, 1, 1)
+    for p, d in ((p1, d1), (p2, d2), (p3, d3)):
+        assert torch.equal(p, p0) and torch.equal(d, d0)
+    assert not ops.UNIT_DGRAM or n3 == 1
+
+
 @pytest.mark.parametrize("n_graphs,seed", [(1, 0), (8, 1), (256, 2)])
 def test_segmented_plan_is_bit_identical_to_the_sorted_plan(ops, n_graphs, seed):
     from igcn_amd import synth
