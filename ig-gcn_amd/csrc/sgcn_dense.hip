@@ -381,45 +381,57 @@ k_ds_h0(int64_t GR, int R, int H0, const float* __restrict__ x, const float* __r
 // One GCNConv aggregation for every copy: AGG[c][d] = sum_s w_c[s,d] hp[c][s] on the matrix cores, then
 // Y = relu(dis[d] AGG + b) into its columns of xcat and — when another layer follows — hp_next = dis * (Y W_next^T).
 // grid (R / 64, G), 512 threads; dynamic LDS: 8 waves' partial tiles [8][NC][64][16] + the Y rows [NC][64][16].
-template <int N, int NC>
+template <int N, int NC, int VW = 4>
 struct DsAggBuf {
-  float4 w4[N];
+  float w[N][VW];
   float bop[N][NC], us[N];
 };
 
-template <int NC, bool M0, bool PIPE>
+// TB = targets per workgroup; a lane carries VW = TB / 16 consecutive targets of a source row.  Only TB = 64 is
+// instantiated: 32-target blocks (512 workgroups of 123 registers, two per CU, so that one workgroup's products and
+// epilogue run under the other's stream — VERDICT r3's first route to 0.5 of HBM) were built and measured at 32 graphs x
+// 512 nodes, both passes: 14.2 us against 12.7 us for the 64-target blocks in the same step (8-byte loads and 128-byte
+// row segments per wave instruction, twice the fixed cost per workgroup).  The other way to two workgroups per CU — one
+// workgroup per (block, COPY), plain and masked neighbours on one XCD so that the second reads ew from L2 — measured
+// 15.9 us: each of them pays the whole stream's latency chain for half the products.
+template <int NC, bool M0, bool PIPE, int TB = 64>
 __global__ void __launch_bounds__(512)
 k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restrict__ u, const float* __restrict__ v,
          const float* __restrict__ dis, const float* __restrict__ hp, const float* __restrict__ bias,
          const float* __restrict__ Wnext, float* __restrict__ agg, float* __restrict__ xcat, int ldx, int col0,
          float* __restrict__ hp_next) {
+  constexpr int VW = TB / 16;
   extern __shared__ float ds_lds[];
-  float* part = ds_lds;                                   // [8][NC][64][16]
-  float* ys = ds_lds + 8 * NC * 64 * DS_F;                // [NC][64][16]
+  float* part = ds_lds;                                   // [8][NC][TB][16]
+  float* ys = ds_lds + 8 * NC * TB * DS_F;                // [NC][TB][16]
   int g, xb;
-  ds_block(R / 64, g, xb);
-  const int d0 = xb * 64, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  ds_block(R / TB, g, xb);
+  const int d0 = xb * TB, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int q = lane & 15, sub = lane >> 4;
   const int rows = R / 8, sb = w * rows;
   constexpr bool ANYM = NC == 2 || M0;
-  float vd[4] = {0.f, 0.f, 0.f, 0.f};
-  if (ANYM) {
-    const float4 t = *reinterpret_cast<const float4*>(v + (int64_t)g * R + d0 + 4 * q);
-    vd[0] = t.x; vd[1] = t.y; vd[2] = t.z; vd[3] = t.w;
-  }
-  f32x4 acc[NC][4];
+  float vd[VW];
+#pragma unroll
+  for (int t = 0; t < VW; ++t) vd[t] = ANYM ? v[(int64_t)g * R + d0 + VW * q + t] : 0.f;
+  f32x4 acc[NC][VW];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < VW; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int64_t nb = (int64_t)g * R;
-  const float* base = ew + nb * R + d0 + 4 * q;
+  const float* base = ew + nb * R + d0 + VW * q;
   auto load = [&](auto& bf, int row) {
     constexpr int N = sizeof(bf.us) / sizeof(float);
 #pragma unroll
     for (int jj = 0; jj < N; ++jj) {
       const int s = row + 4 * jj + sub;
-      bf.w4[jj] = *reinterpret_cast<const float4*>(base + (int64_t)s * R);
+      if constexpr (VW == 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(base + (int64_t)s * R);
+        bf.w[jj][0] = t4.x; bf.w[jj][1] = t4.y; bf.w[jj][2] = t4.z; bf.w[jj][3] = t4.w;
+      } else {
+        const float2 t2 = *reinterpret_cast<const float2*>(base + (int64_t)s * R);
+        bf.w[jj][0] = t2.x; bf.w[jj][1] = t2.y;
+      }
 #pragma unroll
       for (int c = 0; c < NC; ++c) bf.bop[jj][c] = hp[((int64_t)c * GR + nb + s) * DS_F + q];   // B[k = sub][f = q]
       bf.us[jj] = ANYM ? u[nb + s] : 0.f;
@@ -429,28 +441,25 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
     constexpr int N = sizeof(bf.us) / sizeof(float);
 #pragma unroll
     for (int jj = 0; jj < N; ++jj) {
-      const float wv[4] = {bf.w4[jj].x, bf.w4[jj].y, bf.w4[jj].z, bf.w4[jj].w};
-      float ev[4] = {1.f, 1.f, 1.f, 1.f};
-      if (ANYM) {
+      float ev[VW];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) ev[t] = ds_mask(bf.us[jj], vd[t]);
-      }
+      for (int t = 0; t < VW; ++t) ev[t] = ANYM ? ds_mask(bf.us[jj], vd[t]) : 1.f;
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float a = ds_masked<NC, M0>(c) ? wv[t] * ev[t] : wv[t];                  // A[target 4 q + t][k = sub]
+        for (int t = 0; t < VW; ++t) {
+          const float a = ds_masked<NC, M0>(c) ? bf.w[jj][t] * ev[t] : bf.w[jj][t];      // A[target VW q + t][k = sub]
           acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf.bop[jj][c], acc[c][t], 0, 0, 0);
         }
     }
   };
   // epilogue operands of this thread (its (copy, target, feature) slots o = tid + 512 k and its row of W_next): requested
   // before the walk — behind the barrier each was a global round trip in front of the stores
-  constexpr int EPI = NC * 64 * DS_F / 512;
+  constexpr int EPI = NC * TB * DS_F / 512;
   float e_dis[EPI], e_bias = bias[tid & 15], e_w[DS_F];
 #pragma unroll
   for (int k = 0; k < EPI; ++k) {
-    const int o = tid + 512 * k, dl = (o >> 4) & 63, c = o >> 10;
+    const int o = tid + 512 * k, dl = (o >> 4) % TB, c = o / (DS_F * TB);
     e_dis[k] = dis[(int64_t)c * GR + nb + d0 + dl];
   }
 #pragma unroll
@@ -466,43 +475,43 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
   //   node operands staged in LDS per WAVE (8 KB, no barrier) + all loads up front                17.0
   // The single-pass instance (NC = 1: 4 instead of 8 matrix instructions per step) runs in 9.1 us.
   if (R == 512)
-    ds_walk<PIPE, 4, DsAggBuf<8, NC>, DsAggBuf<1, NC>, decltype(load), decltype(compute), decltype(load),
+    ds_walk<PIPE, 4, DsAggBuf<8, NC, VW>, DsAggBuf<1, NC, VW>, decltype(load), decltype(compute), decltype(load),
             decltype(compute), 8>(sb, sb + rows, load, compute, load, compute);
   else
-    ds_walk<PIPE, 4, DsAggBuf<DS_PCH, NC>, DsAggBuf<1, NC>>(sb, sb + rows, load, compute, load, compute);
+    ds_walk<PIPE, 4, DsAggBuf<DS_PCH, NC, VW>, DsAggBuf<1, NC, VW>>(sb, sb + rows, load, compute, load, compute);
   DS_PROBE(3);
-  // accumulator lane (q, sub), tile t, register r = (target d0 + 16 sub + 4 r + t, feature q)
+  // accumulator lane (q, sub), tile t, register r = (target d0 + VW (4 sub + r) + t, feature q)
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < VW; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        part[((w * NC + c) * 64 + 16 * sub + 4 * r + t) * DS_F + q] = acc[c][t][r];
+        part[((w * NC + c) * TB + VW * (4 * sub + r) + t) * DS_F + q] = acc[c][t][r];
   __syncthreads();
   DS_PROBE(4);
 #pragma unroll
   for (int k = 0; k < EPI; ++k) {
-    const int o = tid + 512 * k, f = o & 15, dl = (o >> 4) & 63, c = o >> 10;
+    const int o = tid + 512 * k, f = o & 15, dl = (o >> 4) % TB, c = o / (DS_F * TB);
     float a = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < 8; ++ww) a += part[((ww * NC + c) * 64 + dl) * DS_F + f];
+    for (int ww = 0; ww < 8; ++ww) a += part[((ww * NC + c) * TB + dl) * DS_F + f];
     const int64_t node = (int64_t)c * GR + nb + d0 + dl;
     agg[node * DS_F + f] = a;
     const float t_ = e_dis[k] * a + e_bias;
     const float y = t_ < 0.f ? 0.f : t_;                 // ReLU that lets NaN through (fmaxf would swallow the poisoned degrees)
     xcat[node * ldx + col0 + f] = y;
-    ys[(c * 64 + dl) * DS_F + f] = y;
+    ys[(c * TB + dl) * DS_F + f] = y;
   }
   DS_PROBE(5);
   if (Wnext == nullptr) return;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < EPI; ++k) {
-    const int o = tid + 512 * k, dl = (o >> 4) & 63, c = o >> 10;     // output feature = tid & 15
+    const int o = tid + 512 * k, dl = (o >> 4) % TB, c = o / (DS_F * TB);     // output feature = tid & 15
     float a = 0.f;
 #pragma unroll
-    for (int f = 0; f < DS_F; ++f) a += ys[(c * 64 + dl) * DS_F + f] * e_w[f];
+    for (int f = 0; f < DS_F; ++f) a += ys[(c * TB + dl) * DS_F + f] * e_w[f];
     const int64_t node = (int64_t)c * GR + nb + d0 + dl;
     hp_next[node * DS_F + (tid & 15)] = e_dis[k] * a;
   }
