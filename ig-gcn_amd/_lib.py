@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 408        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 409        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -74,7 +74,7 @@ SIGNATURES = {
     "igcn_copy_multi": (I, [I, P, P, P, P]),
     "igcn_image_put": (I, [I, L, P, P, L, P, L, P]),
     "igcn_image_take": (I, [I, L, P, P, L, P, P]),
-    "igcn_gather_batch": (I, [I, I, L, P, P, P, P, P, P]),
+    "igcn_gather_batch": (I, [I, I, L, L, P, P, P, P, P, P]),
     "igcn_launch_floor": (I, [L, I, I, I, P, P]),
     "igcn_graph_pool_fwd": (I, [L, I, I, P, P, P, P]),
     "igcn_graph_pool_bwd": (I, [L, I, I, P, P, P, P]),
@@ -167,7 +167,7 @@ SIGNATURES = {
     "igcn_loss_head_fwd_grads": (I, [I, I, I, I, P, I, P, P, P, P, P, P, P, I, P, I, P, F, F, P, P, P, P, P, P, P, P]),
     "igcn_gdc_topk_max_rois": (I, []),
     "igcn_gdc_topk": (I, [I, I, I, ctypes.c_double, P, P, P, P, P]),
-    "igcn_gdc_topk_of": (I, [I, I, I, ctypes.c_double, P, P, P, P, P, P]),
+    "igcn_gdc_topk_of": (I, [I, I, I, ctypes.c_double, P, L, P, P, P, P, P]),
 }
 
 _lib = None

@@ -73,7 +73,7 @@ template <int NR>                                       // rows of its column a 
 __global__ void __launch_bounds__(GDC_T)
 k_gdc_topk(int R, int k, double alpha, const float* __restrict__ A, int64_t* __restrict__ ei_row,
            int64_t* __restrict__ ei_col, float* __restrict__ ew, int32_t* __restrict__ counts,
-           const int64_t* __restrict__ subject) {
+           const int64_t* __restrict__ subject, int64_t n_subjects) {
   extern __shared__ double smem_d[];
   const int ld = gdc_ld(R), g = blockIdx.x, tid = threadIdx.x;
   const int cw = R <= 64 ? 64 : 128, nsl = GDC_T / cw;  // a wave lies inside one row slice
@@ -86,7 +86,20 @@ k_gdc_topk(int R, int k, double alpha, const float* __restrict__ A, int64_t* __r
   int* piv = (int*)(M + (size_t)R * ld);                // [R]  row chosen as the pivot of column p
   int* rinv = piv + R;                                  // [R]  step at which row w was the pivot
   int* rowcnt = rinv + R;                               // [R+2]
-  const float* a = A + (subject ? subject[g] : (int64_t)g) * R * R;   // graph g of the batch = matrix subject[g]
+  const int64_t sj = subject ? subject[g] : (int64_t)g;               // graph g of the batch = matrix subject[g]
+  if (subject && (sj < 0 || sj >= n_subjects)) {
+    // an index outside the dataset: no read — the graph is handed over EMPTY (all slots padding, count 0), which the
+    // consumer's plan build reports in its status word (uniform over the workgroup: no barrier has been reached yet)
+    const int64_t s0 = (int64_t)g * R * k;
+    for (int64_t t = s0 + tid; t < s0 + (int64_t)R * k; t += GDC_T) {
+      ei_row[t] = -1;
+      ei_col[t] = -1;
+      ew[t] = 0.f;
+    }
+    if (tid == 0) counts[g] = 0;
+    return;
+  }
+  const float* a = A + sj * R * R;
 
   GDC_PROBE(0);
   // ---- H = D^-1/2 A D^-1/2, M = I - (1 - alpha) H -------------------------------------------------
@@ -316,8 +329,8 @@ extern "C" int igcn_gdc_topk_max_rois(void) {
   return r;
 }
 
-static int gdc_topk(int B, int R, int k, double alpha, const float* A, const int64_t* subject, int64_t* edge_index,
-                    float* edge_attr, int32_t* counts, void* stream) {
+static int gdc_topk(int B, int R, int k, double alpha, const float* A, const int64_t* subject, int64_t n_subjects,
+                    int64_t* edge_index, float* edge_attr, int32_t* counts, void* stream) {
   IGCN_REQUIRE(B >= 0 && R > 0 && k > 0 && k <= R, "gdc_topk: bad sizes B=%d R=%d k=%d", B, R, k);
   IGCN_REQUIRE(alpha > 0.0 && alpha <= 1.0, "gdc_topk: alpha=%g outside (0,1]", alpha);
   if (R > igcn_gdc_topk_max_rois()) {
@@ -331,7 +344,7 @@ static int gdc_topk(int B, int R, int k, double alpha, const float* A, const int
   case NR:                                                                                                          \
     IGCN_ALLOW_BIG_LDS(k_gdc_topk<NR>);                                                                             \
     hipLaunchKernelGGL(k_gdc_topk<NR>, dim3(B), dim3(GDC_T), lds, (hipStream_t)stream, R, k, alpha, A, edge_index,   \
-                       edge_index + slots, edge_attr, counts, subject);                                             \
+                       edge_index + slots, edge_attr, counts, subject, n_subjects);                                             \
     break
   switch (gdc_rows(R)) {
     GDC_LAUNCH(8);
@@ -348,11 +361,12 @@ static int gdc_topk(int B, int R, int k, double alpha, const float* A, const int
 
 extern "C" int igcn_gdc_topk(int B, int R, int k, double alpha, const float* A, int64_t* edge_index, float* edge_attr,
                              int32_t* counts, void* stream) {
-  return gdc_topk(B, R, k, alpha, A, nullptr, edge_index, edge_attr, counts, stream);
+  return gdc_topk(B, R, k, alpha, A, nullptr, B, edge_index, edge_attr, counts, stream);
 }
 
-extern "C" int igcn_gdc_topk_of(int B, int R, int k, double alpha, const float* A, const int64_t* subject,
-                                int64_t* edge_index, float* edge_attr, int32_t* counts, void* stream) {
-  IGCN_REQUIRE(subject != nullptr, "gdc_topk_of: the subject list is missing");
-  return gdc_topk(B, R, k, alpha, A, subject, edge_index, edge_attr, counts, stream);
+extern "C" int igcn_gdc_topk_of(int B, int R, int k, double alpha, const float* A, int64_t n_subjects,
+                                const int64_t* subject, int64_t* edge_index, float* edge_attr, int32_t* counts,
+                                void* stream) {
+  IGCN_REQUIRE(subject != nullptr && n_subjects > 0, "gdc_topk_of: the subject list is missing");
+  return gdc_topk(B, R, k, alpha, A, subject, n_subjects, edge_index, edge_attr, counts, stream);
 }

@@ -313,7 +313,7 @@ struct GatherBatch {
   int kind[IGCN_COPY_MULTI_MAX];
 };
 __global__ void __launch_bounds__(256)
-k_gather_batch(int B, int64_t nodes, const int64_t* __restrict__ idx, GatherBatch gb) {
+k_gather_batch(int B, int64_t nodes, int64_t n_src, const int64_t* __restrict__ idx, GatherBatch gb) {
   const int k = blockIdx.y;
   const int64_t rb = gb.row_bytes[k];
   const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
@@ -322,24 +322,25 @@ k_gather_batch(int B, int64_t nodes, const int64_t* __restrict__ idx, GatherBatc
     const uint32_t* s = reinterpret_cast<const uint32_t*>(gb.src[k]);
     uint32_t* d = reinterpret_cast<uint32_t*>(gb.dst[k]);
     for (int64_t i = first; i < total; i += stride) {
-      const int64_t b = i / w, o = i - b * w;
-      d[i] = s[idx[b] * w + o];
+      const int64_t b = i / w, o = i - b * w, sj = idx[b];
+      d[i] = (sj >= 0 && sj < n_src) ? s[sj * w + o] : 0u;                   // (an index outside the dataset: zeros, no read)
     }
   } else {
     const int64_t e2 = rb >> 3, E = e2 >> 1, total = (int64_t)B * e2;         // int64 entries: [2, E] per graph
     const int64_t* s = reinterpret_cast<const int64_t*>(gb.src[k]);
     int64_t* d = reinterpret_cast<int64_t*>(gb.dst[k]);
     for (int64_t i = first; i < total; i += stride) {
-      const int64_t r = i / ((int64_t)B * E), rem = i - r * (int64_t)B * E, b = rem / E, e = rem - b * E;
-      d[i] = s[idx[b] * e2 + r * E + e] + b * nodes;
+      const int64_t r = i / ((int64_t)B * E), rem = i - r * (int64_t)B * E, b = rem / E, e = rem - b * E, sj = idx[b];
+      d[i] = (sj >= 0 && sj < n_src) ? s[sj * e2 + r * E + e] + b * nodes : -1;      // (-1: the plan build reports it)
     }
   }
 }
 
-extern "C" int igcn_gather_batch(int n, int B, int64_t nodes_per_graph, const int64_t* idx, void* const* dst,
-                                 const void* const* src, const int64_t* row_bytes, const int* kind, void* stream) {
-  IGCN_REQUIRE(n >= 0 && n <= IGCN_COPY_MULTI_MAX && B > 0 && idx != nullptr, "gather_batch: n=%d outside [0, %d] or bad B", n,
-               IGCN_COPY_MULTI_MAX);
+extern "C" int igcn_gather_batch(int n, int B, int64_t nodes_per_graph, int64_t n_subjects, const int64_t* idx,
+                                 void* const* dst, const void* const* src, const int64_t* row_bytes, const int* kind,
+                                 void* stream) {
+  IGCN_REQUIRE(n >= 0 && n <= IGCN_COPY_MULTI_MAX && B > 0 && idx != nullptr && n_subjects > 0,
+               "gather_batch: n=%d outside [0, %d] or bad B / dataset size", n, IGCN_COPY_MULTI_MAX);
   if (n == 0) return IGCN_OK;
   GatherBatch gb;
   int64_t big = 0;
@@ -357,7 +358,7 @@ extern "C" int igcn_gather_batch(int n, int B, int64_t nodes_per_graph, const in
   int64_t gx = igcn_cdiv(igcn_cdiv(big * B, 4), 256 * 4);
   gx = gx < 1 ? 1 : (gx > 128 ? 128 : gx);
   hipLaunchKernelGGL(k_gather_batch, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, B, nodes_per_graph,
-                     idx, gb);
+                     n_subjects, idx, gb);
   IGCN_CHECK_LAUNCH("gather_batch");
   return IGCN_OK;
 }

@@ -155,18 +155,20 @@ def gather_rows(idx, nodes, items):
     import ctypes
     from ._lib import call, ptr, stream_ptr
     b = int(idx.numel())
+    if not (idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous() and idx.dim() == 1):
+        raise ValueError("gather_rows: the subjects must be a contiguous int64 vector on the device")
     for k in range(0, len(items), 16):
         chunk = items[k:k + 16]
         n = len(chunk)
         for dst, src, _ in chunk:
             if not (dst.is_cuda and src.is_cuda and dst.is_contiguous() and src.is_contiguous()
-                    and dst.dtype == src.dtype and dst.numel() == b * src[0].numel()):
+                    and dst.dtype == src.dtype and dst.numel() == b * src[0].numel() and src.shape[0] == items[0][1].shape[0]):
                 raise ValueError("gather_rows: destination does not match B rows of the source")
         d = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _, _ in chunk])
         sp = (ctypes.c_void_p * n)(*[t.data_ptr() for _, t, _ in chunk])
         rb = (ctypes.c_int64 * n)(*[t[0].numel() * t.element_size() for _, t, _ in chunk])
         kind = (ctypes.c_int * n)(*[1 if ix else 0 for _, _, ix in chunk])
-        call("igcn_gather_batch", n, b, int(nodes), ptr(idx), d, sp, rb, kind, stream_ptr())
+        call("igcn_gather_batch", n, b, int(nodes), int(items[0][1].shape[0]), ptr(idx), d, sp, rb, kind, stream_ptr())
 
 
 def _like(batch, device, pin=False):
@@ -432,7 +434,7 @@ class DeviceGdcFeeder(_AheadOnSideStream):
         from ._lib import call, ptr, stream_ptr
         b, r = int(idx.numel()), int(self.adj.shape[1])
         gather_rows(idx, r, [(getattr(slot, k), v, False) for k, v in self.cols.items()])
-        call("igcn_gdc_topk_of", b, r, self.top_k, self.alpha, ptr(self.adj), ptr(idx), ptr(slot.edge_index),
+        call("igcn_gdc_topk_of", b, r, self.top_k, self.alpha, ptr(self.adj), int(self.adj.shape[0]), ptr(idx), ptr(slot.edge_index),
              ptr(slot.edge_attr), ptr(self._counts), stream_ptr())
         torch.cumsum(self._counts, 0, out=slot.edge_ptr[1:])
 

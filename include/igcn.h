@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 408
+#define IGCN_ABI_VERSION 409
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -390,9 +390,10 @@ int igcn_image_take(int channels, int64_t nnz, const int64_t* pos, const float* 
  * as stacked device tensors, every key in ONE launch: idx int64 [B] (device) = the subjects; per key c < n (HOST arrays):
  * kind[c] == 0: dst_c [B, row] = src_c [idx[b], row] with row_bytes[c] bytes per graph (a multiple of 4);
  * kind[c] == 1: an `*index*` key — src_c [S, 2, E] int64, dst_c [2, B E] = concatenation along the last dim with graph b's
- * entries offset by b * nodes_per_graph (batch.py:98-104); row_bytes[c] = 2 * E * 8. */
-int igcn_gather_batch(int n, int B, int64_t nodes_per_graph, const int64_t* idx, void* const* dst, const void* const* src,
-                      const int64_t* row_bytes, const int* kind, void* stream);
+ * entries offset by b * nodes_per_graph (batch.py:98-104); row_bytes[c] = 2 * E * 8.  An idx[b] outside [0, n_subjects)
+ * is not read: its rows are zeros, its index entries -1 (a consumer's plan build reports those in its status word). */
+int igcn_gather_batch(int n, int B, int64_t nodes_per_graph, int64_t n_subjects, const int64_t* idx, void* const* dst,
+                      const void* const* src, const int64_t* row_bytes, const int* kind, void* stream);
 
 /* Measurement aid (bench.py roofline): the launch of igcn_gcn_propagate_fwd for (n_nodes, F) — thread =
  * (target, feature quad), or one wave per target when `dense` — with the body removed: mode 0 = empty kernel,
@@ -858,9 +859,10 @@ int igcn_gdc_topk_max_rois(void);
 int igcn_gdc_topk(int B, int R, int k, double alpha, const float* A, int64_t* edge_index, float* edge_attr,
                   int32_t* counts, void* stream);
 /* The same for a batch DRAWN from a resident dataset A [S,R,R]: graph g of the batch is matrix subject[g] (int64 [B],
- * device) — a per-step producer needs no gathered copy of the B matrices. */
-int igcn_gdc_topk_of(int B, int R, int k, double alpha, const float* A, const int64_t* subject, int64_t* edge_index,
-                     float* edge_attr, int32_t* counts, void* stream);
+ * device) — a per-step producer needs no gathered copy of the B matrices.  A subject[g] outside [0, n_subjects) is
+ * not read: graph g comes out empty (counts[g] = 0, all its slots padding). */
+int igcn_gdc_topk_of(int B, int R, int k, double alpha, const float* A, int64_t n_subjects, const int64_t* subject,
+                     int64_t* edge_index, float* edge_attr, int32_t* counts, void* stream);
 
 #ifdef __cplusplus
 }

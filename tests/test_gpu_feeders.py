@@ -134,3 +134,29 @@ def test_gather_rejects_a_destination_of_the_wrong_size(subjects):
     slot = _like(store.batch(torch.arange(8, device="cuda")), "cuda")
     with pytest.raises(ValueError):
         store.gather_into(torch.arange(6, device="cuda"), slot)
+
+
+def test_an_index_outside_the_dataset_is_not_read(subjects):
+    """A subject index >= the dataset size (or negative) must not turn into an out-of-bounds read on the device: the
+    gather hands over zero rows and -1 index entries, the dense transform an empty graph (count 0, padding slots)."""
+    from igcn_amd._lib import call, ptr, stream_ptr
+    from igcn_amd.loader import UniformGraphStore, _like
+    graphs, slim = subjects
+    store = UniformGraphStore(slim, "cuda")
+    idx = torch.tensor([3, 40, 5, -1], device="cuda")              # 40 subjects: 40 and -1 are outside
+    slot = _like(store.batch(torch.arange(4, device="cuda")), "cuda")
+    store.gather_into(idx, slot)
+    good = store.batch(torch.tensor([3, 5], device="cuda"))
+    x = slot.x.view(4, 90, -1)
+    assert torch.equal(x[0], good.x.view(2, 90, -1)[0]) and torch.equal(x[2], good.x.view(2, 90, -1)[1])
+    assert float(x[1].abs().max()) == 0.0 and float(x[3].abs().max()) == 0.0
+    e = store.edges
+    ei = slot.edge_index.view(2, 4, e)
+    assert bool((ei[:, 1] == -1).all()) and bool((ei[:, 3] == -1).all()) and bool((ei[:, 0] >= 0).all())
+    adj = torch.stack([g.A for g in graphs]).cuda()
+    out_ei = torch.full((2, 4 * 90 * 3), 7, dtype=torch.int64, device="cuda")
+    out_ew = torch.full((4 * 90 * 3,), 7.0, device="cuda")
+    counts = torch.full((4,), 7, dtype=torch.int32, device="cuda")
+    call("igcn_gdc_topk_of", 4, 90, 3, 0.05, ptr(adj), 40, ptr(idx), ptr(out_ei), ptr(out_ew), ptr(counts), stream_ptr())
+    assert counts.tolist()[1] == 0 and counts.tolist()[3] == 0 and counts.tolist()[0] == 270
+    assert bool((out_ei.view(2, 4, 270)[:, 1] == -1).all()) and float(out_ew.view(4, 270)[3].abs().max()) == 0.0
