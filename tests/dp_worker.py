@@ -81,6 +81,31 @@ def main():
         res["graphed_loss"] = float(loss2)
         res["graphed_param_after"] = {k: p.detach().cpu().clone() for k, p in zip(names, opt2.params)}
         res["graphed_step_count"] = int(opt2.step_count.item())
+        # (C) the reference's epoch loop on every rank's shard (fit_epoch: captured steps for the full batches, the eager
+        # step for the ragged tail, the rate halved between the epochs) against the same steps through train_step
+        import copy
+        from igcn_amd.data import DataLoader
+        from igcn_amd.train import fit_epoch
+        model3, _ = build_model(dev)
+        model4 = copy.deepcopy(model3)
+        opt3, opt4 = FlatAdam(model3.parameters(), lr=1e-3), FlatAdam(model4.parameters(), lr=1e-3)
+        loader = DataLoader(graphs, 6, shuffle=False)                      # 16 graphs per rank: 6 + 6 + 4
+        ep = []
+        for epoch in range(3):
+            ep.append(fit_epoch(model3, opt3, loader, None, LAM, device=dev, world_size=world))
+            for data in loader:
+                train_step(model4, opt4, data.to(dev), LAM, world_size=world)
+            if epoch == 0:
+                for o in (opt3, opt4):
+                    for group in o.param_groups:
+                        group['lr'] = 0.5 * group['lr']
+        torch.cuda.synchronize()
+        tr = next(iter(opt3._igcn_epoch_trainers.values()))
+        res["epoch_counts"] = dict(tr.counts)
+        res["epoch_losses"] = [float(v) for v in ep]
+        res["epoch_param_after"] = {k: p.detach().cpu().clone() for k, p in zip(names, opt3.params)}
+        res["epoch_ref_param_after"] = {k: p.detach().cpu().clone() for k, p in zip(names, opt4.params)}
+        res["epoch_step_count"] = (int(opt3.step_count.item()), int(opt4.step_count.item()))
         torch.save(res, f"{out}.rank{rank}.pt")
         torch.distributed.barrier()
     finally:

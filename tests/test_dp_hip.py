@@ -134,6 +134,21 @@ def test_graphed_distributed_step_equals_the_eager_one(ranks):
         assert torch.equal(ranks[0]["graphed_param_after"][k], ranks[1]["graphed_param_after"][k]), k
 
 
+def test_epoch_loop_in_data_parallel_keeps_the_ranks_identical(ranks):
+    """``fit_epoch(world_size=2)`` on every rank's shard (batches of 6 + 6 + 4 graphs, three epochs, the rate halved after
+    the first): the ranks take the same route per batch (eager -> capture -> replay), end bit-identical, and land where
+    the same nine steps through the eager data-parallel ``train_step`` land (kernel/train_eval_sgcn_img_snps.py:96-97,
+    169-171,511-548 under SURVEY §8e's partitioning)."""
+    r0, r1 = ranks
+    assert r0["epoch_counts"] == r1["epoch_counts"] == {"eager": 2, "captured": 2, "replayed": 7}, r0["epoch_counts"]
+    assert r0["epoch_step_count"] == r1["epoch_step_count"] == (9, 9)
+    for k, p in r0["epoch_param_after"].items():
+        assert torch.equal(p, r1["epoch_param_after"][k]), "replicas diverged in the epoch loop: " + k
+        ref = r0["epoch_ref_param_after"][k]
+        assert float((p - ref).abs().max()) <= 2e-4 if p.numel() else True, k
+    assert all(np.isfinite(v) for v in r0["epoch_losses"] + r1["epoch_losses"])
+
+
 def test_comm_abi_single_rank_allreduce_and_graph_capture():
     """igcn_comm_* (RCCL through the C ABI) on the one GPU this box has: a 1-rank communicator, the all-reduce on
     the launch stream, eagerly and captured into a hipGraph between two kernels."""
