@@ -612,6 +612,19 @@ __device__ __forceinline__ float dot(const float (&a)[F], const float (&b)[F]) {
   return t;
 }
 
+// workgroup -> (node block, sample) of a (node blocks, B) grid.  The hardware deals workgroup i (x fastest) to XCD i mod 8,
+// so with (blockIdx.x, blockIdx.y) taken as they come the node blocks of ONE sample sit on all eight XCDs and every
+// neighbour gather pulls the sample's rows into eight L2s: k_go_attn_bwd_main<2,5> at 64 samples x 10 000 nodes read
+// 294 MB for 30 MB of operands (PMC, profiles/r04_step_traffic_stress.csv) and ran at the HBM rate.  Here XCD c takes
+// the items [c T/8, (c+1) T/8) in order: a sample's blocks run back to back on one XCD, its rows cross the fabric once.
+__device__ __forceinline__ void go_block(int& bx, int& b) {
+  const int nx = gridDim.x, total = nx * gridDim.y, id = blockIdx.y * nx + blockIdx.x;
+  int j = id;
+  if ((total & 7) == 0) j = (id & 7) * (total >> 3) + (id >> 3);
+  b = j / nx;
+  bx = j - b * nx;
+}
+
 template <int FIN, int FOUT>
 __global__ void __launch_bounds__(GO_T)
 k_go_attn_fwd(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
@@ -619,8 +632,9 @@ k_go_attn_fwd(int N, const int32_t* __restrict__ row_ptr, const int32_t* __restr
               const float* __restrict__ a_in, const float* __restrict__ a_s, float* __restrict__ y) {
   AttnW<FIN, FOUT> W;
   W.load(w_inc, w_s, a_in, a_s);
-  const int n = blockIdx.x * GO_T + threadIdx.x;
-  const int b = blockIdx.y;
+  int bx, b;
+  go_block(bx, b);
+  const int n = bx * GO_T + threadIdx.x;
   if (n >= N) return;
   const float* xb = x + (int64_t)b * FIN * N;
   float xr[FIN], xin[FOUT], xs[FOUT];
@@ -726,8 +740,9 @@ k_go_attn_bwd_stats(int B, int N, const int32_t* __restrict__ row_ptr, const int
     a1[c] = a_in[c];
     a2[c] = a_in[FOUT + c];
   }
-  const int n = blockIdx.x * GO_T + threadIdx.x;
-  const int b = blockIdx.y;
+  int bx, b;
+  go_block(bx, b);
+  const int n = bx * GO_T + threadIdx.x;
   if (n >= N) return;
   const float* xb = x + (int64_t)b * FIN * N;
   float xr[FIN], xin[FOUT], dyn[FOUT];
@@ -794,9 +809,10 @@ k_go_attn_bwd_main(int B, int N, const int32_t* __restrict__ row_ptr, const int3
   __shared__ float xt[FIN][TP];
   AttnW<FIN, FOUT> W;
   W.load(w_inc, w_s, a_in, a_s);
-  const int n = blockIdx.x * GO_T + threadIdx.x;
+  int bx, b;
+  go_block(bx, b);
+  const int n = bx * GO_T + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.y;
   const bool live = n < N;
   const int nn = live ? n : N - 1;                 // dead lanes shadow a valid node, results discarded
   const float* xb = x + (int64_t)b * FIN * N;
@@ -2068,9 +2084,10 @@ k_go_decode_fwd(int Nin, int Nout, const int32_t* __restrict__ row_ptr, const in
       wo[c][d] = w_out[c * FIN + d];
       wso[c][d] = w_sout[c * FIN + d];
     }
-  const int r = blockIdx.x * GO_T + threadIdx.x;
+  int bx, b;
+  go_block(bx, b);
+  const int r = bx * GO_T + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.y;
   const bool live = r < Nout;
   const int rr = live ? r : Nout - 1;
   const int off = Nout - Nin;
@@ -2154,8 +2171,10 @@ k_go_decode_fwd_lds(int Nin, int Nout, const int32_t* __restrict__ row_ptr, cons
   const int total = FIN * Nin;
   int32_t* rp = reinterpret_cast<int32_t*>(go_slab + ((total + 3) & ~3));
   int32_t* cl = rp + ROWS + 4;
-  const int b = blockIdx.y, lane = threadIdx.x & 63;
-  const int r_base = blockIdx.x * ROWS, nrows = min(Nout - r_base, ROWS);
+  int bx, b;
+  go_block(bx, b);
+  const int lane = threadIdx.x & 63;
+  const int r_base = bx * ROWS, nrows = min(Nout - r_base, ROWS);
   const int32_t e_base = row_ptr[r_base], e_cnt = row_ptr[r_base + nrows] - e_base;
   const bool col_lds = e_cnt <= GO_DEC_COLCAP;         // block-uniform; larger ranges are read from global memory
   const float* xb = x + (int64_t)b * FIN * Nin;
