@@ -271,6 +271,10 @@ gemm_f32_tile(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int6
   }
 }
 
+// [Tried: XCD-aware tile order — XCD c taking the tiles [c T/8, (c+1) T/8) of a product in order, so that the tiles
+// sharing an operand block meet in one L2 (the two 256 x 256 x 2880 Gram products read 29.6 MB for 5.9 MB of operands by
+// the PMC counters).  Every product of the two benchmarked steps got SLOWER by 0.3-1 us (Gram 15.3 -> 16.3 us): these
+// launches are latency chains of a dozen K steps, not traffic-bound, and the re-reads come out of the Infinity Cache.]
 template <int BN, int VW, int PF, bool ARF, bool BRF>
 __global__ void __launch_bounds__(256)
 k_gemm_f32(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sam, int64_t sak,

@@ -101,12 +101,23 @@ k_reduce_rows_par(const float* __restrict__ partial, int64_t rows, int64_t ld, i
 // 4 rows x 64 contiguous bytes (the wave-per-column form above touches 64 different cache lines per instruction and
 // uses 4 bytes of each), a thread sums rows r = g mod 16 (8 loads in flight), the 16 group sums of a column are
 // combined through LDS in a fixed pairwise tree.  Shared by the stand-alone and the deferred form.
+// Which 16-column tile a workgroup takes.  A tile's rows are 64-byte segments, i.e. HALF of the 128-byte lines the L2
+// fetches, and the hardware deals consecutive workgroups to the eight XCDs in turn: with tile = workgroup every line was
+// fetched by two XCDs — k_multi_reduce read 92 MB for 53 MB of queued partials (PMC, profiles/r04_step_traffic_full.csv)
+// at the HBM rate.  Within every 64 workgroups, the eight that land on XCD x (x, x + 8, ...) take eight CONSECUTIVE
+// tiles: 7 of 8 shared lines now meet in one L2.  (Which workgroup sums a column does not change the sum.)
+__device__ __forceinline__ int64_t tile16_of(int64_t block, int n) {
+  const int64_t base = block & ~(int64_t)63, tiles = ((int64_t)n + 15) >> 4;
+  if (base + 64 > tiles) return block;                  // the incomplete last group: as dealt
+  const int o = (int)(block & 63);
+  return base + ((o & 7) << 3) + (o >> 3);
+}
 __device__ __forceinline__ void reduce_cols_tile16(const float* __restrict__ partial, int64_t rows, int64_t ld, int n,
                                                    float* __restrict__ out, int accumulate, int64_t block,
                                                    float (*lds)[64]) {
   float* s = &lds[0][0];                               // [16 groups][16 columns]
   const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int64_t j = block * 16 + c;
+  const int64_t j = tile16_of(block, n) * 16 + c;
   float t = 0.f;
   if (j < n) {
 #pragma unroll 8
