@@ -176,5 +176,7 @@ int igcn_launch_reduce_rows(const float* partial, int64_t rows, int64_t ld, int 
 // The same column sums for an output that is a FINAL parameter gradient (read by nothing before the optimiser):
 // while igcn_reduce_defer(1) is in force the reduction is queued instead of launched, and igcn_reduce_flush runs
 // every queued reduction of the backward pass in ONE launch (include/igcn.h).
+int igcn_launch_reduce_rows_batched(const float* partial, int64_t rows, int64_t ld, int n, float* out, int batch,
+                                    int64_t p_batch, int64_t o_batch, hipStream_t st);
 int igcn_launch_reduce_rows_final(const float* partial, int64_t rows, int64_t ld, int n, float* out,
                                   hipStream_t st);

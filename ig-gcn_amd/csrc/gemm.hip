@@ -720,6 +720,11 @@ extern "C" int igcn_gemm_f32_batched(int64_t M, int64_t N, int64_t K, int batch,
   launch_f32(bn, vw, grid, st, g);
   IGCN_CHECK_LAUNCH("gemm_f32_batched");
   if (split) {
+    // few outputs, many slabs (the 32 x 32 Gram matrices of configs[4]: 256 slabs each): a thread walking its output's
+    // slabs is a chain of 32 dependent batches of loads (15.8 us for 2 MB); 16 x 16 tiles with 16 row groups instead
+    if (ldc == N && M * N <= 4096 && split_k > 32)
+      return igcn_launch_reduce_rows_batched(scratch, split_k, M * N, (int)(M * N), C, batch, (int64_t)split_k * M * N,
+                                             c_batch, st);
     hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3((unsigned)igcn_cdiv(M * N, 256), (unsigned)batch), dim3(256), 0, st, M,
                        N, split_k, scratch, (const float*)nullptr, C, ldc, 0, c_batch);
     IGCN_CHECK_LAUNCH("gemm_f32_batched reduce");

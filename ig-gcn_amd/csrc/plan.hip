@@ -143,6 +143,24 @@ k_reduce_rows_tile16(const float* __restrict__ partial, int64_t rows, int64_t ld
   reduce_cols_tile16(partial, rows, ld, n, out, accumulate, blockIdx.x, lds);
 }
 
+// gridDim.y independent sums of the same shape (the slab sums of a batched split-K product)
+__global__ void __launch_bounds__(256)
+k_reduce_rows_tile16_batched(const float* __restrict__ partial, int64_t rows, int64_t ld, int n, float* __restrict__ out,
+                             int64_t p_batch, int64_t o_batch) {
+  __shared__ float lds[4][64];
+  reduce_cols_tile16(partial + (int64_t)blockIdx.y * p_batch, rows, ld, n, out + (int64_t)blockIdx.y * o_batch, 0,
+                     blockIdx.x, lds);
+}
+
+int igcn_launch_reduce_rows_batched(const float* partial, int64_t rows, int64_t ld, int n, float* out, int batch,
+                                    int64_t p_batch, int64_t o_batch, hipStream_t st) {
+  if (n <= 0 || batch <= 0) return IGCN_OK;
+  hipLaunchKernelGGL(k_reduce_rows_tile16_batched, dim3((unsigned)igcn_cdiv(n, 16), (unsigned)batch), dim3(256), 0, st,
+                     partial, rows, ld, n, out, p_batch, o_batch);
+  IGCN_CHECK_LAUNCH("reduce_rows_batched");
+  return IGCN_OK;
+}
+
 // out[j] = sum_r partial[j * rows + r]: the summands of one output are CONTIGUOUS (coalesced), one block per output
 __global__ void __launch_bounds__(1024)
 k_reduce_contig(const float* __restrict__ partial, int64_t rows, float* __restrict__ out) {

@@ -665,8 +665,11 @@ static constexpr bool ro_quad_ok() {
   }
 
 static int ro_cpg(int B, int groups) {
-  const int bg = B / groups;
-  return bg >= 32 ? 32 : (bg > 0 ? bg : 1);   // sample chunks per group: enough workgroups for small N
+  // sample chunks per group: up to 32 (enough workgroups for small N), but never fewer than RO_SG samples per chunk — a
+  // workgroup's four waves take a chunk's samples in turn, so one-sample chunks (configs[4]: 32 samples per group) ran
+  // three of four waves idle in 4x the workgroups (k_nlbn_pair_bwd_apply: 27 us for 28 MB)
+  const int bg = B / groups, c = bg / RO_SG;
+  return c >= 32 ? 32 : (c > 0 ? c : 1);
 }
 
 extern "C" size_t igcn_node_linear_bn_scratch_floats(int B, int N, int groups) {
