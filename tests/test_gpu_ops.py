@@ -520,7 +520,10 @@ def test_nodes_layernorm(ops, bsz, f, n, pool, with_keep):
 @pytest.mark.parametrize("bsz,pool,layer,seed", [(4, (20, 10, 6, 3, 1), 0, 0), (4, (20, 10, 6, 3, 1), 1, 1),
                                                  (9, (300, 120, 60, 19, 1), 0, 2), (9, (300, 120, 60, 19, 1), 1, 3),
                                                  (3, (1800, 800, 300, 99, 1), 0, 4), (3, (1800, 800, 300, 99, 1), 1, 5),
-                                                 (2, (1801, 800, 300, 99, 1), 1, 6)])
+                                                 (2, (1801, 800, 300, 99, 1), 1, 6),
+                                                 # >= 128 samples: the one-workgroup-per-sample backward (below that the
+                                                 # thread-per-node kernel runs, unless the LayerNorm backward rides along)
+                                                 (130, (300, 120, 60, 19, 1), 0, 7), (130, (300, 120, 60, 19, 1), 1, 8)])
 def test_go_decoder_layer(ops, bsz, pool, layer, seed):
     _, _, _, idx = _hier(pool, seed)
     row, col, n_rows, n_cols = idx["dec"][layer]
