@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 409        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 410        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -153,7 +153,7 @@ SIGNATURES = {
     "igcn_adam_chunk": (I, []),
     "igcn_adam_step_blocks": (I, [I, P, P, P, P, P, P, F, F, F, F, I, P]),
     "igcn_pack_grads": (I, [I, P, P, P, P, P]),
-    "igcn_reduce_defer": (I, [I]),
+    "igcn_reduce_defer": (I, [P, I]),
     "igcn_reduce_pending": (I, []),
     "igcn_reduce_flush": (I, [P]),
     "igcn_reduce_flush_tick": (I, [P, P]),

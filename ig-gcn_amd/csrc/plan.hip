@@ -316,50 +316,57 @@ __global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t, int32_t* ti
   }
 }
 
+#include <map>
 #include <mutex>
 #include <vector>
+// One queue per STREAM: a backward pass defers on the stream it runs on (the autograd engine replays the forward's
+// stream on its own thread, so the key is the stream, not the thread) and flushes that stream's entries only — several
+// trainers in one process, each on a stream of its own, do not see each other's partials.
+struct DeferQueue {
+  bool on = false;
+  std::vector<ReduceEntry> q;
+};
 static std::mutex g_rq_mutex;
-static std::vector<ReduceEntry> g_rq;
-static std::vector<hipStream_t> g_rq_stream;          // the stream every entry's producer kernel was launched on
-static int g_rq_defer = 0;
+static std::map<hipStream_t, DeferQueue> g_rq;
 
-extern "C" int igcn_reduce_defer(int on) {
+extern "C" int igcn_reduce_defer(void* stream, int on) {
   std::lock_guard<std::mutex> lk(g_rq_mutex);
-  g_rq_defer = on != 0;
+  DeferQueue& d = g_rq[(hipStream_t)stream];
+  d.on = on != 0;
+  if (!d.on && d.q.empty()) g_rq.erase((hipStream_t)stream);
   return IGCN_OK;
 }
 
 extern "C" int igcn_reduce_pending(void) {
   std::lock_guard<std::mutex> lk(g_rq_mutex);
-  return (int)g_rq.size();
+  size_t n = 0;
+  for (const auto& kv : g_rq) n += kv.second.q.size();
+  return (int)n;
 }
 
 __global__ void k_tick(int32_t* tick) { *tick += 1; }
 
+// the queue of `st` when that stream is in defer mode, else NULL (caller holds the mutex)
+static std::vector<ReduceEntry>* rq_of(hipStream_t st) {
+  auto it = g_rq.find(st);
+  return it != g_rq.end() && it->second.on ? &it->second.q : nullptr;
+}
+
 static int reduce_flush_locked(hipStream_t st, int32_t* tick = nullptr) {
-  // the queue is process-wide (one training thread per process: DESIGN §8).  A flush must only ever see entries whose
-  // partials were produced on ITS stream — anything else means two backward passes interleaved, and summing another
-  // stream's partials here would race with their producers: refuse loudly instead.
-  for (size_t i = 0; i < g_rq.size(); ++i)
-    if (g_rq_stream[i] != st) {
-      const size_t n = g_rq.size();
-      g_rq.clear();
-      g_rq_stream.clear();
-      igcn_set_error("reduce_flush: %zu queued reductions, entry %zu was queued on another stream — deferred "
-                     "reductions support one backward pass at a time per process", n, i);
-      return IGCN_ERR_BADARG;
-    }
+  auto it = g_rq.find(st);
+  std::vector<ReduceEntry> none;
+  std::vector<ReduceEntry>& q = it != g_rq.end() ? it->second.q : none;
   if (igcn_opt(IGCN_OPT_DEBUG_REDUCE))
-    for (const ReduceEntry& e : g_rq)
+    for (const ReduceEntry& e : q)
       fprintf(stderr, "[igcn] deferred reduction: rows %lld x n %d (ld %lld)%s\n", (long long)e.rows, e.n,
               (long long)e.ld, e.nptr < 0 ? "  GO attention finish" : e.nptr > 0 ? "  separate buffers" : rr_form(e.rows, e.n) ? "  tree" : "  in-order");
   size_t done = 0;
-  while (done < g_rq.size()) {
+  while (done < q.size()) {
     ReduceTable t = {};
-    const int cnt = (int)(g_rq.size() - done < MRQ_MAX ? g_rq.size() - done : MRQ_MAX);
+    const int cnt = (int)(q.size() - done < MRQ_MAX ? q.size() - done : MRQ_MAX);
     int64_t total = 0;
     for (int i = 0; i < cnt; ++i) {
-      const ReduceEntry& e = g_rq[done + i];
+      const ReduceEntry& e = q[done + i];
       t.e[i] = e;
       const int64_t need = e.nptr < 0 ? e.n : e.nptr > 0 ? igcn_cdiv(e.n, 1024)
                            : rr_form(e.rows, e.n) == 1 ? igcn_cdiv(e.n, 4)
@@ -372,12 +379,12 @@ static int reduce_flush_locked(hipStream_t st, int32_t* tick = nullptr) {
     for (int i = cnt; i <= MRQ_MAX; ++i) t.start[i] = 0x7fffffff;
     t.count = cnt;
     done += cnt;
-    hipLaunchKernelGGL(k_multi_reduce, dim3((unsigned)total), dim3(256), 0, st, t, done == g_rq.size() ? tick : nullptr);
-    if (done == g_rq.size()) tick = nullptr;
+    hipLaunchKernelGGL(k_multi_reduce, dim3((unsigned)total), dim3(256), 0, st, t, done == q.size() ? tick : nullptr);
+    if (done == q.size()) tick = nullptr;
   }
   if (tick) hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, st, tick);          // nothing was queued: the tick alone
-  g_rq.clear();
-  g_rq_stream.clear();
+  q.clear();
+  if (it != g_rq.end() && !it->second.on) g_rq.erase(it);
   IGCN_CHECK_LAUNCH("reduce_flush");
   return IGCN_OK;
 }
@@ -399,9 +406,8 @@ int igcn_launch_reduce_rows_final(const float* partial, int64_t rows, int64_t ld
   if (n <= 0) return IGCN_OK;
   {
     std::lock_guard<std::mutex> lk(g_rq_mutex);
-    if (g_rq_defer) {
-      g_rq.push_back(ReduceEntry{partial, out, rows, ld, n, 0, {nullptr, nullptr, nullptr}});
-      g_rq_stream.push_back(st);
+    if (std::vector<ReduceEntry>* q = rq_of(st)) {
+      q->push_back(ReduceEntry{partial, out, rows, ld, n, 0, {nullptr, nullptr, nullptr}});
       return IGCN_OK;
     }
   }
@@ -414,29 +420,29 @@ extern "C" int igcn_debug_reduce_rows_final(const float* partial, int64_t rows, 
 }
 
 // GO attention backward: dparams [2 FOUT FIN + 3 FOUT] from gpart [(2 FOUT + 3) FIN][parts] as a FINAL reduction:
-// queued while igcn_reduce_defer is on (returns 1), else not handled here (returns 0: k_go_attn_bwd_finish).
+// queued while the stream defers (returns 1), else not handled here (returns 0: k_go_attn_bwd_finish).
 int igcn_queue_go_finish(const float* gpart, int64_t parts, int fin, int fout, const float* w_inc, const float* w_s,
                          float* dparams, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_rq_mutex);
-  if (!g_rq_defer || fin > 64 || fout > 64) return 0;
+  std::vector<ReduceEntry>* q = rq_of(st);
+  if (!q || fin > 64 || fout > 64) return 0;
   ReduceEntry e = {gpart, dparams, parts, (int64_t)(fin | (fout << 8)), 2 * fout * fin + 3 * fout, -1, {w_inc, w_s, nullptr}};
-  g_rq.push_back(e);
-  g_rq_stream.push_back(st);
+  q->push_back(e);
   return 1;
 }
 
-// out = parts[0] + parts[1] + ... (k separate buffers of numel floats) as a FINAL reduction: queued while
-// igcn_reduce_defer is on (returns 1), otherwise not handled here (returns 0: the caller launches k_sum_n).
+// out = parts[0] + parts[1] + ... (k separate buffers of numel floats) as a FINAL reduction: queued while the stream
+// defers (returns 1), otherwise not handled here (returns 0: the caller launches k_sum_n).
 int igcn_queue_sum_final(const float* const* parts, int k, int64_t numel, float* out, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_rq_mutex);
-  if (!g_rq_defer || k < 2 || k > 4 || numel > 0x7fffffff) return 0;
+  std::vector<ReduceEntry>* q = rq_of(st);
+  if (!q || k < 2 || k > 4 || numel > 0x7fffffff) return 0;
   uintptr_t al = (uintptr_t)out;
   for (int i = 0; i < k; ++i) al |= (uintptr_t)parts[i];
   if (al & 15) return 0;
   ReduceEntry e = {parts[0], out, (int64_t)k, 0, (int)numel, k - 1, {nullptr, nullptr, nullptr}};
   for (int i = 1; i < k; ++i) e.more[i - 1] = parts[i];
-  g_rq.push_back(e);
-  g_rq_stream.push_back(st);
+  q->push_back(e);
   return 1;
 }
 

@@ -22,7 +22,28 @@ def _f32(t):
 # =================================================================================================
 # Deferred reductions of a backward pass (igcn_reduce_defer / igcn_reduce_flush)
 # =================================================================================================
-_DEFER = {"on": False, "keep": [], "ln_affine": [], "spmm_dval": []}
+class _PerStream:
+    """The deferral state of the CURRENT stream (a backward pass runs on the stream of its forward, whichever thread the
+    autograd engine uses): trainers on different streams of one process keep their queues apart, like the library's."""
+
+    def __init__(self):
+        self.by_stream = {}
+
+    def _state(self):
+        key = stream_ptr() or 0
+        st = self.by_stream.get(key)
+        if st is None:
+            st = self.by_stream[key] = {"on": False, "keep": [], "ln_affine": [], "spmm_dval": []}
+        return st
+
+    def __getitem__(self, k):
+        return self._state()[k]
+
+    def __setitem__(self, k, v):
+        self._state()[k] = v
+
+
+_DEFER = _PerStream()
 # addresses of the cached "d loss / d loss = 1" scalars of train._unit_grad: ops.LossHead returns the gradients its
 # forward wrote for that upstream instead of launching its backward kernel
 UNIT_GRAD_PTRS = set()
@@ -52,7 +73,7 @@ class deferred_reductions:
         if _DEFER["on"]:
             raise _lib.IgcnError("deferred_reductions does not nest")
         _DEFER["on"] = True
-        call("igcn_reduce_defer", 1)
+        call("igcn_reduce_defer", stream_ptr(), 1)
         return self
 
     def __exit__(self, *exc):
@@ -70,7 +91,7 @@ class deferred_reductions:
             # leave entries behind that a later flush would run on freed memory.  On the error path the queued sums are
             # still launched — they only read buffers that exist and write gradients nobody will use.
             try:
-                call("igcn_reduce_defer", 0)
+                call("igcn_reduce_defer", stream_ptr(), 0)
                 if self.tick is not None and ok:
                     call("igcn_reduce_flush_tick", stream_ptr(), ptr(self.tick))
                 else:
@@ -129,11 +150,11 @@ class _immediate:
 
     def __enter__(self):
         if self.off:
-            call("igcn_reduce_defer", 0)
+            call("igcn_reduce_defer", stream_ptr(), 0)
 
     def __exit__(self, *exc):
         if self.off:
-            call("igcn_reduce_defer", 1)
+            call("igcn_reduce_defer", stream_ptr(), 1)
         return False
 
 

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 409
+#define IGCN_ABI_VERSION 410
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -787,12 +787,14 @@ int igcn_pack_grads(int n_tensors, const int64_t* table, const int64_t* numel, c
 /* ------------------------------------------------------------------------------------------------
  * Deferred reductions of a backward pass.  About thirty kernels of the train step's backward end in a small "sum the
  * block partials" launch whose output is a parameter gradient that nothing reads before the optimiser (bias and
- * LayerNorm / BatchNorm affine gradients, split-K weight-gradient slabs, ...).  After igcn_reduce_defer(1) those
- * launches are QUEUED instead (process-wide; the partial buffers — the `scratch` arguments of the calls — must then
- * stay alive until the flush), and igcn_reduce_flush(stream) performs every queued reduction in ONE launch, with the
- * arithmetic and summation order of the stand-alone kernels.  igcn_gemm_f32 / igcn_gemm_bf16 take part when bit 0x100
- * of `act` marks their output as such a gradient.  Host-side state only: capturable like any other launch. */
-int igcn_reduce_defer(int on);
+ * LayerNorm / BatchNorm affine gradients, split-K weight-gradient slabs, ...).  After igcn_reduce_defer(stream, 1)
+ * those launches ON THAT STREAM are QUEUED instead (one queue per stream: trainers on different streams do not see each
+ * other's partials; the partial buffers — the `scratch` arguments of the calls — must then stay alive until the
+ * flush), and igcn_reduce_flush(stream) performs the stream's queued reductions in ONE launch, with the arithmetic
+ * and summation order of the stand-alone kernels.  igcn_gemm_f32 / igcn_gemm_bf16 take part when bit 0x100 of `act`
+ * marks their output as such a gradient.  Host-side state only: capturable like any other launch.
+ * igcn_reduce_pending: queued entries over all streams. */
+int igcn_reduce_defer(void* stream, int on);
 int igcn_reduce_pending(void);
 int igcn_reduce_flush(void* stream);
 /* the flush + `*step_counter += 1` (device int32: the optimiser's step) by the same launch (a one-thread launch of its

@@ -417,19 +417,61 @@ def test_final_reductions_deferred_and_immediate_give_the_same_bits(ops):
              torch.full((n,), 9.0, device="cuda")) for r, n, ld in shapes]
     for (p, o1, _), (r, n, ld) in zip(bufs, shapes):                    # immediate
         assert fn(p.data_ptr(), r, ld, n, o1.data_ptr(), st) == 0
-    lib.igcn_reduce_defer(1)
+    lib.igcn_reduce_defer(st, 1)
     try:
         for (p, _, o2), (r, n, ld) in zip(bufs, shapes):                # queued, then ONE launch
             assert fn(p.data_ptr(), r, ld, n, o2.data_ptr(), st) == 0
         assert lib.igcn_reduce_pending() == len(shapes)
         assert lib.igcn_reduce_flush(st) == 0
     finally:
-        lib.igcn_reduce_defer(0)
+        lib.igcn_reduce_defer(st, 0)
     torch.cuda.synchronize()
     for (p, o1, o2), (r, n, ld) in zip(bufs, shapes):
         want = p[:r, :n].double().sum(0).cpu().numpy() if r else np.zeros(n)
         assert_matches(o1, want, 2e-6, f"immediate {r} x {n}", floor=float(max(r, 1)) ** 0.5)
         assert torch.equal(o1, o2), f"deferred != immediate at {r} x {n} (ld {ld})"
+
+
+def test_deferred_reductions_are_kept_per_stream(ops):
+    """Two streams in defer mode at once (two trainers of one process): each flush performs its OWN stream's entries
+    only, a stream that does not defer reduces at once, and the Python-side state (kept buffers, queued passes) is per
+    stream as well."""
+    import ctypes
+    from igcn_amd import _lib
+    lib = _lib.load()
+    fn = lib.igcn_debug_reduce_rows_final
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    s1, s2, s3 = (torch.cuda.Stream() for _ in range(3))
+    torch.manual_seed(5)
+    p = [torch.randn(40, 300, device="cuda") for _ in range(3)]
+    o = [torch.full((300,), 7.0, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    for st in (s1, s2):
+        assert lib.igcn_reduce_defer(st.cuda_stream, 1) == 0
+    try:
+        for k, st in enumerate((s1, s2, s3)):
+            assert fn(p[k].data_ptr(), 40, 300, 300, o[k].data_ptr(), st.cuda_stream) == 0
+        assert lib.igcn_reduce_pending() == 2                           # s3 does not defer: reduced at once
+        s3.synchronize()
+        assert torch.allclose(o[2], p[2].sum(0), atol=1e-4)
+        assert lib.igcn_reduce_flush(s1.cuda_stream) == 0               # s1's entry only
+        torch.cuda.synchronize()
+        assert torch.allclose(o[0], p[0].sum(0), atol=1e-4) and float(o[1][0]) == 7.0
+        assert lib.igcn_reduce_pending() == 1
+        assert lib.igcn_reduce_flush(s2.cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert torch.allclose(o[1], p[1].sum(0), atol=1e-4) and lib.igcn_reduce_pending() == 0
+    finally:
+        for st in (s1, s2):
+            lib.igcn_reduce_defer(st.cuda_stream, 0)
+            lib.igcn_reduce_flush(st.cuda_stream)
+    with torch.cuda.stream(s1):
+        with ops.deferred_reductions():
+            assert ops._DEFER["on"]
+            with torch.cuda.stream(s2):
+                assert not ops._DEFER["on"]                             # another stream: its own state
+        assert not ops._DEFER["on"]
 
 
 # ------------------------------------------------------------------------------------------------ GO ops

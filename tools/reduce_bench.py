@@ -33,12 +33,12 @@ st = torch.cuda.current_stream().cuda_stream
 
 
 def flush(skip=None):
-    lib.igcn_reduce_defer(1)
+    lib.igcn_reduce_defer(st, 1)
     for i, ((p, o), (r, n)) in enumerate(zip(bufs, SHAPES)):
         if i != skip and (skip is None or not isinstance(skip, set) or i not in skip):
             assert fn(p.data_ptr(), r, n, n, o.data_ptr(), st) == 0
     assert lib.igcn_reduce_flush(st) == 0
-    lib.igcn_reduce_defer(0)
+    lib.igcn_reduce_defer(st, 0)
 
 
 def timed(skip=None):
