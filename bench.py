@@ -580,7 +580,8 @@ def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
     adj_all = torch.stack([g.A for g in graphs])
     keep = ("x", "edge_index", "edge_attr", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y")
     slim = [Data(**{k: getattr(g, k) for k in keep}) for g in graphs]
-    out = {"subjects": subjects, "graphs_per_step": b, "steps": steps, "host_logical_cpus": os.cpu_count(),
+    out = {"subjects": subjects, "graphs_per_step": b, "steps": steps, "blocks": 3, "reported": "median block",
+           "host_logical_cpus": os.cpu_count(),
            "usable_cores": _usable_cores(), "feeder_threads": 1,
            "resident_ms_per_step": resident_ms}
     t0 = time.perf_counter()
@@ -589,20 +590,28 @@ def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
     out["reference_collate_ms_per_batch"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)
     cur = torch.cuda.current_stream()
 
+    blocks = 3
+    feed_steps = warmup + blocks * steps + 1             # what every feeder below is asked for
+
     def run(feed, consume):
+        """THREE timed blocks of `steps` fed steps, the median reported (a host feeder shares the box's CPUs with
+        whatever else runs there: one descheduled producer thread used to decide a single 60-step figure)."""
         it = iter(feed)
         for _ in range(warmup):
             consume(next(it))
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(steps):
-            consume(next(it))
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t) / steps * 1e3
+        per = []
+        for _ in range(blocks):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(steps):
+                consume(next(it))
+            torch.cuda.synchronize()
+            per.append((time.perf_counter() - t) / steps * 1e3)
         for _ in it:                                     # drain (the producer thread ends)
             pass
+        ms = sorted(per)[len(per) // 2]
         return {"ms_per_step": round(ms, 3), "graphs_per_s": round(b / ms * 1e3, 1),
-                "vs_resident": round(resident_ms / ms, 3)}
+                "vs_resident": round(resident_ms / ms, 3), "ms_per_step_blocks": [round(v, 3) for v in per]}
 
     # host-fed
     host_store = UniformGraphStore(slim, "cpu", pin=True)
@@ -617,7 +626,7 @@ def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
         gstep.load(batch)
         batch.release()
         gstep()
-    out["host"] = run(HostFeeder(host_store, b, device, steps + warmup + 1), consume_host)
+    out["host"] = run(HostFeeder(host_store, b, device, feed_steps), consume_host)
     # device-resident dataset
     dev_store = UniformGraphStore(slim, device)
 
@@ -627,10 +636,10 @@ def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
         batch.release()
         gstep()
     # the gather as ONE launch on the launch stream straight into the step's static inputs (no slot, no second queue) ...
-    out["device"] = run(DeviceFeeder(dev_store, b, steps + warmup + 1, into=gstep.data), consume_dev)
+    out["device"] = run(DeviceFeeder(dev_store, b, feed_steps, into=gstep.data), consume_dev)
     out["device"]["how"] = "igcn_gather_batch into the step's inputs, on the launch stream"
     # ... and one batch ahead on a side stream into a staging slot + hand-over copy (what device_gdc has to do)
-    out["device_side_stream"] = run(DeviceFeeder(dev_store, b, steps + warmup + 1), consume_dev)
+    out["device_side_stream"] = run(DeviceFeeder(dev_store, b, feed_steps), consume_dev)
     # dense connectivity on the device -> GDC + collation of batch k + 1 on a second stream while step k replays
     if not wl["dense"]:
         from igcn_amd.loader import DeviceGdcFeeder
@@ -638,7 +647,7 @@ def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
         cols = {k: dev_store.cols[k] for k in ("x", "snps_feat", "y", "clini_score", "tsne_fdim", "clust_y")}
         first = batch_from_dense(adj_dev[:b], cols["x"][:b], top_k=3, alpha=0.05, check=True)
         if first.edge_index.shape == gstep.data.edge_index.shape:
-            out["device_gdc"] = run(DeviceGdcFeeder(adj_dev, cols, b, steps + warmup + 1, top_k=3, alpha=0.05, seed=1),
+            out["device_gdc"] = run(DeviceGdcFeeder(adj_dev, cols, b, feed_steps, top_k=3, alpha=0.05, seed=1),
                                     consume_dev)
             out["device_gdc"]["overlap"] = "GDC + collate of batch k+1 on a side stream during the replay of step k"
             gstep.plan.check()
@@ -646,7 +655,7 @@ def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
                 gen = torch.Generator(device=device).manual_seed(1)
 
                 def gdc_feed():
-                    for _ in range(steps + warmup + 1):
+                    for _ in range(feed_steps):
                         idx = torch.randint(0, subjects, (b,), generator=gen, device=device)
                         sel = {k: torch.index_select(v, 0, idx) for k, v in cols.items()}
                         yield batch_from_dense(torch.index_select(adj_dev, 0, idx), sel.pop("x"), top_k=3, alpha=0.05,
