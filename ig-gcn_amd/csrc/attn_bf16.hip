@@ -30,6 +30,17 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define AB_KEY_CHUNK 448          // keys per chunk of the forward / dQ kernels (31 / 46 KB of LDS: several workgroups per CU)
 #define AB_QUERY_CHUNK 256        // queries per chunk of the dK | dV kernel (35 KB)
 
+// (sample, head) item of a workgroup.  Grid x = B * H items, y = row blocks; the hardware deals workgroup i (x fastest) to
+// XCD i mod 8, and the H heads of a sample read the two halves of the SAME 128-byte lines of q / k | v / do (a [..,
+// H * head_dim] row per token): with item = blockIdx.x the heads of a sample sat on different XCDs and every line came from
+// HBM once per head (k_attn_bf16_fwd read 51.8 MB for 25.5 MB of operands, PMC).  Here XCD c takes the items
+// [c n/8, (c+1) n/8): a sample's heads — and, the grid's x extent being a multiple of 8, all row blocks of an item —
+// share one L2.  (csrc/attn_mfma.hip does the same through am_per_xcd.)
+__device__ __forceinline__ int ab_item() {
+  const int n = (int)gridDim.x, x = (int)blockIdx.x;
+  return (n & 7) ? x : (x & 7) * (n >> 3) + (x >> 3);
+}
+
 __device__ __forceinline__ f32x4 mfma32(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -167,7 +178,7 @@ k_attn_bf16_fwd(int H, int Lq, int Lk, int CH, const float* __restrict__ q, cons
   const int ldt = ab_ldt(CH);
   __bf16* Kb = reinterpret_cast<__bf16*>(ab_smem);                // [CH][16]
   __bf16* Vt = Kb + (size_t)CH * AB_HD;                           // [16][ldt]
-  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * AB_HD;
+  const int item = ab_item(), b = item / H, h = item % H, D = H * AB_HD;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
   const int qi = (blockIdx.y * nw + w) * 16 + n;                  // this wave's query tile (may be past Lq)
   const bool qlive = qi < Lq;
@@ -217,7 +228,7 @@ k_attn_bf16_bwd_dq(int H, int Lq, int Lk, int CH, const float* __restrict__ q, c
   __bf16* Kb = reinterpret_cast<__bf16*>(ab_smem);                // [CH][16]
   __bf16* Vb = Kb + (size_t)CH * AB_HD;                           // [CH][16]
   __bf16* Kt = Vb + (size_t)CH * AB_HD;                           // [16][ldt]
-  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * AB_HD;
+  const int item = ab_item(), b = item / H, h = item % H, D = H * AB_HD;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
   const int qi = (blockIdx.y * nw + w) * 16 + n;
   const bool qlive = qi < Lq;
@@ -290,7 +301,7 @@ k_attn_bf16_bwd_dkv(int H, int Lq, int Lk, int CH, const float* __restrict__ q, 
   __bf16* Ot = Qt + (size_t)AB_HD * ldt;                          // [16][ldt]
   float* ls = reinterpret_cast<float*>(Ot + (size_t)AB_HD * ldt); // [CH]   lse in the log2 domain
   float* dl = ls + CH;                                            // [CH]   delta / 4
-  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * AB_HD;
+  const int item = ab_item(), b = item / H, h = item % H, D = H * AB_HD;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6, n = lane & 15, g = lane >> 4;
   const int ki = (blockIdx.y * nw + w) * 16 + n;
   const bool klive = ki < Lk;
