@@ -1693,13 +1693,21 @@ k_nodes_ln_fwd(int f, int N, int pool, float eps, const float* __restrict__ y, c
 #define LN_VPT 4
 #define LN_TMAX 1024
 
+// Which (sample, channel) row a workgroup takes: XCD c the rows [c R/8, (c+1) R/8) in order, so that the f channel rows
+// of a sample — which all read the sample's dropout factors keep[b, :] — meet in one L2 (blockIdx.x taken as it comes
+// puts them on f different XCDs).
+__device__ __forceinline__ int ln_row() {
+  const int n = (int)gridDim.x, x = (int)blockIdx.x;
+  return (n & 7) ? x : (x & 7) * (n >> 3) + (x >> 3);
+}
+
 // (256 threads for rows up to 4096 nodes, 1024 threads up to 16384: the 10 000-node hierarchy of configs[4])
 __global__ void __launch_bounds__(LN_TMAX)
 k_nodes_ln_fwd_v(int f, int N, int pool, float eps, const float* __restrict__ y, const float* __restrict__ gamma,
                  const float* __restrict__ beta, const float* __restrict__ keep, float* __restrict__ z,
                  float* __restrict__ mean_out, float* __restrict__ rstd_out) {
   __shared__ float red[16];
-  const int row = blockIdx.x, b = row / f, nv = N / 4;
+  const int row = ln_row(), b = row / f, nv = N / 4;
   const float* yr = y + (int64_t)row * N;
   float4 v[LN_VPT];
   float s = 0.f;
@@ -1749,7 +1757,7 @@ k_nodes_ln_bwd_dy_v(int f, int N, int pool, const float* __restrict__ y, const f
                     const float* __restrict__ beta, const float* __restrict__ keep, const float* __restrict__ mean,
                     const float* __restrict__ rstd, const float* __restrict__ dz, float* __restrict__ dy) {
   __shared__ float red[16];
-  const int row = blockIdx.x, b = row / f, nv = N / 4;
+  const int row = ln_row(), b = row / f, nv = N / 4;
   const float mu = mean[row], rs = rstd[row];
   const float* yr = y + (int64_t)row * N;
   const float* dzr = dz + (int64_t)row * (N - pool);
