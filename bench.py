@@ -28,6 +28,8 @@ Roofline fields (rank 0, N=1):
                   a hot back-to-back replay and a COLD replay rotating through > 256 MiB of distinct buffers (both
                   timed with HIP events on the launch stream), and the launch floor of the same grid.
   roofline_mfma   dense feature transforms (lin1, K|V projection) against the MFMA peak of their operand type.
+  roofline_step   the WHOLE step against the HBM roof: PMC bytes of every kernel of a replay (committed table of
+                  tools/step_traffic.sh) / this run's kernel time per replay.
   cpu_baseline    the oracle (CPU restatement of the reference) on this box's host cores, bounded sample.
 """
 import argparse
@@ -672,6 +674,27 @@ def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
     return out
 
 
+def step_traffic(workload, kernel_us_per_step):
+    """The WHOLE step against the HBM roof: bytes per replay summed over every kernel of the step — the COMMITTED PMC
+    passes of tools/step_traffic.sh (profiles/r04_step_traffic_<workload>.csv: --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+    runs of their own over marker-bracketed replays) — divided by THIS run's kernel time per replay."""
+    path = os.path.join(ROOT, "profiles", f"r04_step_traffic_{workload}.csv")
+    try:
+        import csv
+        with open(path, newline="") as fh:
+            tot = [r for r in csv.DictReader(fh) if r["kernel"] == "TOTAL"][0]
+        nbytes = (float(tot["MB_read_per_replay"]) + float(tot["MB_written_per_replay"])) * 1e6
+        rate = nbytes / kernel_us_per_step / 1e3                       # GB/s
+        return {"bound": "hbm", "traffic": int(nbytes), "read_bytes": int(float(tot["MB_read_per_replay"]) * 1e6),
+                "written_bytes": int(float(tot["MB_written_per_replay"]) * 1e6), "kernel_us_per_step": kernel_us_per_step,
+                "achieved": round(rate, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(rate / 8000.0, 4),
+                "launches_in_table": float(tot["launches_per_replay"]),
+                "traffic_source": os.path.relpath(path, ROOT) + ": PMC bytes of every kernel of the replay (committed passes); "
+                                  "time = this run's kernel time per replay"}
+    except Exception:                                                  # noqa: BLE001 — a missing table is not an error
+        return None
+
+
 def stress_child(timeout=300):
     """BASELINE configs[4] beside the headline: a short ``--workload stress`` run of this script in a CHILD process
     (its own model, graph capture, in-step rocprofv3 profile and bounded CPU-oracle sample) whose result line is folded
@@ -694,7 +717,7 @@ def stress_child(timeout=300):
         print(f"[bench] stress child failed: {type(exc).__name__}: {exc}", file=sys.stderr)
         return None
     keep = ("value", "unit", "ms_per_step", "timing", "steps", "warmup", "dtype", "loss", "roofline", "roofline_mfma",
-            "cpu_baseline", "profile", "edge_pipeline")
+            "roofline_step", "cpu_baseline", "profile", "edge_pipeline")
     out = {k: full[k] for k in keep if k in full}
     out["workload"] = full["config"]["workload"]
     out["graphs_per_gpu"] = full["config"]["graphs_per_gpu"]
@@ -1067,6 +1090,9 @@ def main():
                                   "launches_per_step": round(sum(c for c, _, _ in stats[0].values()) / stats[1], 1),
                                   "libigcn_launches_per_step": round(sum(c for c, _ in lib) / stats[1], 1),
                                   "span_us_per_step": round(stats[3] / stats[1], 1)}
+                whole = step_traffic(args.workload, res["profile"]["kernel_us_per_step"])
+                if whole is not None:
+                    res["roofline_step"] = whole
         if wl["pool"] is not None and world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(go, wl, seconds=args.cpu_baseline_seconds)
         if args.workload == "full" and world == 1 and not args.no_roofline and not args.no_stress:
