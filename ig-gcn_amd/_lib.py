@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 410        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 411        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -59,7 +59,7 @@ SIGNATURES = {
     "igcn_dense_sgcn_ws_floats": (Z, [L, I, I, I]),
     "igcn_dense_sgcn_bwd_ws_floats": (Z, [L, I, I, I, I]),
     "igcn_dense_sgcn_reg_blocks": (I, [L, I]),
-    "igcn_dense_sgcn_fwd": (I, [L, I, I, I, I, I, I, P, P, P, P, P, P, P, I, F, F, F, F, F, P, P, P, P, P]),
+    "igcn_dense_sgcn_fwd": (I, [L, I, I, I, I, I, I, P, P, P, P, P, P, P, I, F, F, F, F, F, P, P, P, P, P, P]),
     "igcn_dense_sgcn_bwd": (I, [L, I, I, I, I, I, I, P, P, P, P, P, P, I, F, F, F, F, F, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_small_linear_bwd_scratch_floats": (Z, [L, I, I]),
     "igcn_small_linear_fwd": (I, [L, I, I, P, P, P, P, P, P]),

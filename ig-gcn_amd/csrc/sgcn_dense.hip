@@ -96,6 +96,12 @@ __device__ __forceinline__ constexpr bool ds_masked(int c) { return NC == 2 ? c 
 // on 8 different XCDs: every XCD fetches every graph's node operands, and its ew reads are 256-byte pieces 2 KB apart.
 // Here XCD c takes the work items [c T/8, (c+1) T/8) in order, so the blocks of a graph run on ONE XCD, back to back:
 // the graph's h' / g' rows cross the fabric once, and the XCD's L2 sees whole 2 KB rows of ew.
+__device__ __forceinline__ void ds_block_of(int nblk, int total, int id, int& g, int& xb) {
+  int j = id;
+  if ((total & 7) == 0) j = (id & 7) * (total >> 3) + (id >> 3);
+  g = j / nblk;
+  xb = j - g * nblk;
+}
 __device__ __forceinline__ void ds_block(int nblk, int& g, int& xb) {
   const int total = gridDim.x, id = blockIdx.x;
   int j = id;
@@ -183,15 +189,21 @@ extern "C" int igcn_dense_sgcn_reg_blocks(int64_t n_graphs, int R) { return (int
 // A pure read stream of 16 bytes per edge: one matrix ROW (R edges of one source) per trip of a workgroup, four rows'
 // loads in flight per thread, the row's (graph, source) from ONE 32-bit division per row (round 3 divided 64-bit
 // integers twice per edge pair: the check ran at 0.62 of the HBM rate on integer arithmetic).
-// status[0] |= 4 (sticky: GraphPlan.check() reports it); status[1] |= 1 (consumed — and cleared — by the next
-// igcn_dense_sgcn_fwd, which turns it into NaN degrees: a batch that is not what the dense-block kernels assume cannot
-// train silently).
+// status[0] |= 4 (sticky: GraphPlan.check() reports it); status[1] = the LATEST check's verdict (cleared in front of
+// every check, set to 1 on a mismatch; igcn_dense_sgcn_fwd turns a set verdict into NaN features — hence NaN outputs and
+// loss: a batch that is not what the dense-block kernels assume cannot train silently).
+// The check runs stand-alone (igcn_dense_blocks_check) or RIDES in igcn_dense_sgcn_fwd's first edge pass: extra
+// workgroups of k_ds_deg's launch stream the index pairs beside its 4-byte weights (27.6 + 12.5 us as two launches).
 #define DS_CHK_ROWS 4
-__global__ void __launch_bounds__(256)
-k_ds_check(int64_t n_rows, int R, const int64_t* __restrict__ ei, int64_t n_edges, int32_t* __restrict__ status) {
+// `halves` = blockDim.x / 256 groups of 256 threads, each on DS_CHK_ROWS rows of its own per trip; workgroup `blk` of `nblk`
+__device__ __forceinline__ void ds_check_rows(int64_t blk, int64_t nblk, int64_t n_rows, int R,
+                                              const int64_t* __restrict__ ei, int64_t n_edges,
+                                              int32_t* __restrict__ status) {
   bool bad = false;
-  for (int64_t r0 = (int64_t)blockIdx.x * DS_CHK_ROWS; r0 < n_rows; r0 += (int64_t)gridDim.x * DS_CHK_ROWS) {
-    for (int d = threadIdx.x * 2; d < R; d += 512) {
+  const int halves = (int)blockDim.x >> 8, half = (int)threadIdx.x >> 8, t = (int)threadIdx.x & 255;
+  const int64_t per = (int64_t)halves * DS_CHK_ROWS;
+  for (int64_t r0 = blk * per + (int64_t)half * DS_CHK_ROWS; r0 < n_rows; r0 += nblk * per) {
+    for (int d = t * 2; d < R; d += 512) {
       longlong2 s2[DS_CHK_ROWS], d2[DS_CHK_ROWS];
 #pragma unroll
       for (int i = 0; i < DS_CHK_ROWS; ++i) {
@@ -213,6 +225,10 @@ k_ds_check(int64_t n_rows, int R, const int64_t* __restrict__ ei, int64_t n_edge
     atomicOr(status + 1, 1);
   }
 }
+__global__ void __launch_bounds__(256)
+k_ds_check(int64_t n_rows, int R, const int64_t* __restrict__ ei, int64_t n_edges, int32_t* __restrict__ status) {
+  ds_check_rows(blockIdx.x, gridDim.x, n_rows, R, ei, n_edges, status);
+}
 
 extern "C" int igcn_dense_blocks_check(int64_t n_graphs, int R, const int64_t* edge_index, int32_t* status,
                                        void* stream) {
@@ -222,6 +238,10 @@ extern "C" int igcn_dense_blocks_check(int64_t n_graphs, int R, const int64_t* e
   IGCN_REQUIRE(rows < ((int64_t)1 << 31), "dense_blocks_check: more than 2^31 nodes");
   int64_t blocks = igcn_cdiv(rows, DS_CHK_ROWS);
   blocks = blocks > 8192 ? 8192 : blocks;
+  if (hipMemsetAsync(status + 1, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {     // this check's own verdict
+    igcn_set_error("dense_blocks_check: clearing the verdict failed");
+    return IGCN_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(k_ds_check, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, R, edge_index, ne,
                      status);
   IGCN_CHECK_LAUNCH("dense_blocks_check");
@@ -236,8 +256,10 @@ extern "C" int igcn_dense_blocks_check(int64_t n_graphs, int R, const int64_t* e
 __global__ void __launch_bounds__(256)
 k_ds_prep(int64_t GR, int R, int H0, const float* __restrict__ x, const float* __restrict__ prob,
           const float* __restrict__ pb, float* __restrict__ u, float* __restrict__ v,
-          const float* __restrict__ snps_prob, int n_snps, DsReg rg, float* __restrict__ reg_out) {
+          const float* __restrict__ snps_prob, int n_snps, DsReg rg, float* __restrict__ reg_out,
+          int32_t* __restrict__ clear_verdict /* status words: [1] = 0 in front of a check that rides in k_ds_deg */) {
   __shared__ float red[16];
+  if (clear_verdict && blockIdx.x == 0 && threadIdx.x == 0) clear_verdict[1] = 0;
   const int64_t node = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (node < GR) {
     const int r = (int)(node % R);
@@ -273,15 +295,20 @@ struct DsDegBuf {
 template <int NC, bool M0, bool PIPE>
 __global__ void __launch_bounds__(512)
 k_ds_deg(int R, int64_t GR, const float* __restrict__ ew, const float* __restrict__ u, const float* __restrict__ v,
-         float* __restrict__ dis, DsReg rg, float inv_ne, float* __restrict__ reg_partial, int32_t* __restrict__ status) {
+         float* __restrict__ dis, DsReg rg, float inv_ne, float* __restrict__ reg_partial, int n_deg_blocks,
+         const int64_t* __restrict__ chk_ei, int64_t chk_rows, int64_t chk_edges, int32_t* __restrict__ status) {
   constexpr bool ANYM = NC == 2 || M0;
-  // the structure check of this batch (igcn_dense_blocks_check, earlier on this stream) found edges that are not the
-  // row-major complete graph these kernels assume: the degrees — and through them every output and the loss — become NaN
-  const bool poisoned = status != nullptr && *reinterpret_cast<volatile int32_t*>(status + 1) != 0;
+  if ((int)blockIdx.x >= n_deg_blocks) {
+    // the batch's structure check rides in this launch: these workgroups stream the index pairs (16 bytes per edge)
+    // while the others stream the weights (4 bytes per edge); the verdict is read by the NEXT launch (k_ds_h0)
+    ds_check_rows((int64_t)blockIdx.x - n_deg_blocks, (int64_t)gridDim.x - n_deg_blocks, chk_rows, R, chk_ei, chk_edges,
+                  status);
+    return;
+  }
   __shared__ float red[8][NC][64];
   __shared__ float rsum[16];
   int g, xb;
-  ds_block(R / 64, g, xb);
+  ds_block_of(R / 64, n_deg_blocks, (int)blockIdx.x, g, xb);
   const int d0 = xb * 64, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int q = lane & 15, sub = lane >> 4;
   const int rows = R / 8, sb = w * rows;
@@ -348,14 +375,13 @@ k_ds_deg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
     float deg = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 8; ++ww) deg += red[ww][c][dl];
-    dis[(int64_t)c * GR + nb + d0 + dl] = poisoned ? __int_as_float(0x7fc00000) : (deg > 0.f ? 1.0f / sqrtf(deg) : 0.f);
+    dis[(int64_t)c * GR + nb + d0 + dl] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;
   }
-  if (poisoned && blockIdx.x == 0 && tid == 0) status[1] = 0;       // consumed: the next batch is judged on its own check
   if (ANYM && reg_partial && tid == 0) {
     float t = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 8; ++ww) t += rsum[ww];
-    reg_partial[(int64_t)g * (R / 64) + xb] = poisoned ? __int_as_float(0x7fc00000) : t * inv_ne;
+    reg_partial[(int64_t)g * (R / 64) + xb] = t * inv_ne;
   }
 }
 
@@ -363,9 +389,17 @@ k_ds_deg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
 template <int NC, bool M0>
 __global__ void __launch_bounds__(256)
 k_ds_h0(int64_t GR, int R, int H0, const float* __restrict__ x, const float* __restrict__ prob,
-        const float* __restrict__ W0, const float* __restrict__ dis, float* __restrict__ hp0) {
+        const float* __restrict__ W0, const float* __restrict__ dis, float* __restrict__ hp0,
+        const int32_t* __restrict__ status) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)NC * GR * DS_F) return;
+  // the structure check of this batch (stand-alone earlier on the stream, or riding in k_ds_deg's launch) found edges that
+  // are not the row-major complete graph these kernels assume: the first layer's features — and through them every output
+  // and the loss — become NaN
+  if (status != nullptr && status[1] != 0) {
+    hp0[i] = __int_as_float(0x7fc00000);
+    return;
+  }
   const int f = (int)(i & (DS_F - 1));
   const int64_t cn = i >> 4, node = cn % GR;
   const int c = (int)(cn / GR), r = (int)(node % R);
@@ -986,7 +1020,7 @@ extern "C" int igcn_dense_sgcn_fwd(int64_t n_graphs, int R, int H0, int F, int L
                                    const float* const* W /*HOST [L]*/, const float* const* b /*HOST [L]*/,
                                    const float* snps_prob, int n_snps, float l1_x, float ent_x, float l1_e, float ent_e,
                                    float eps, float* xcat, float* reg_partials, float* ws, int32_t* status,
-                                   void* stream) {
+                                   const int64_t* check_edge_index, void* stream) {
   int rc = ds_check_args("dense_sgcn_fwd", n_graphs, R, H0, F, L, copies);
   if (rc) return rc;
   IGCN_REQUIRE(((uintptr_t)ew & 15) == 0 && ((uintptr_t)ws & 15) == 0, "dense_sgcn_fwd: ew / ws must be 16-byte aligned");
@@ -997,19 +1031,30 @@ extern "C" int igcn_dense_sgcn_fwd(int64_t n_graphs, int R, int H0, int F, int L
   const DsReg rg = {l1_x, ent_x, l1_e, ent_e, eps};
   const int nreg = igcn_dense_sgcn_reg_blocks(n_graphs, R);
   float* regp = anym ? reg_partials : nullptr;
+  const bool ride = check_edge_index != nullptr;           // the batch's structure check rides in k_ds_deg's launch
+  IGCN_REQUIRE(!ride || (status != nullptr && ((uintptr_t)check_edge_index & 15) == 0 && GR < ((int64_t)1 << 31)),
+               "dense_sgcn_fwd: a riding check needs the status words and a 16-byte aligned edge_index");
   if (anym) {
     hipLaunchKernelGGL(k_ds_prep, dim3((unsigned)igcn_cdiv(GR, 256)), dim3(256), 0, st, GR, R, H0, x, prob, prob_bias,
-                       ws + o.u, ws + o.v, snps_prob, snps_prob ? n_snps : 0, rg, regp ? regp + (nreg - 1) : nullptr);
+                       ws + o.u, ws + o.v, snps_prob, snps_prob ? n_snps : 0, rg, regp ? regp + (nreg - 1) : nullptr,
+                       ride ? status : nullptr);
+  } else if (ride && hipMemsetAsync(status + 1, 0, sizeof(int32_t), st) != hipSuccess) {
+    igcn_set_error("dense_sgcn_fwd: clearing the verdict failed");
+    return IGCN_ERR_LAUNCH;
   }
   const dim3 eg((unsigned)(n_graphs * (R / 64)));            // 1-D: ds_block maps ids to (graph, block), XCD-aware
   const float inv_ne = 1.0f / (float)((double)n_graphs * R * R);
   const bool pipe = R == 256 || R == 512;              // pipelined walks need whole chunk pairs (R % 256 == 0); the LDS-
                                                        // staged transposed aggregation additionally R <= 512
 #define DS_PIPE(...) if (pipe) { constexpr bool PIPE = true; __VA_ARGS__; } else { constexpr bool PIPE = false; __VA_ARGS__; }
-  DS_DISPATCH(DS_PIPE(hipLaunchKernelGGL((k_ds_deg<NC, M0, PIPE>), eg, dim3(512), 0, st, R, GR, ew, ws + o.u, ws + o.v,
-                                         ws + o.dis, rg, inv_ne, regp, status)));
+  int64_t chk = ride ? igcn_cdiv(GR, 2 * DS_CHK_ROWS) : 0;         // one trip of 8 rows per 512-thread workgroup
+  chk = chk > 4096 ? 4096 : chk;
+  const dim3 dg((unsigned)(eg.x + chk));
+  DS_DISPATCH(DS_PIPE(hipLaunchKernelGGL((k_ds_deg<NC, M0, PIPE>), dg, dim3(512), 0, st, R, GR, ew, ws + o.u, ws + o.v,
+                                         ws + o.dis, rg, inv_ne, regp, (int)eg.x, check_edge_index, GR, GR * R, status)));
   DS_DISPATCH(hipLaunchKernelGGL((k_ds_h0<NC, M0>), dim3((unsigned)igcn_cdiv((int64_t)copies * GR * DS_F, 256)),
-                                 dim3(256), 0, st, GR, R, H0, x, prob, W[0], ws + o.dis, ws + o.hp));
+                                 dim3(256), 0, st, GR, R, H0, x, prob, W[0], ws + o.dis, ws + o.hp,
+                                 (const int32_t*)status));
   const size_t lds = (size_t)(8 * copies * 64 * DS_F + copies * 64 * DS_F) * sizeof(float);
   for (int l = 0; l < L; ++l) {
     const float* hp = ws + o.hp + (int64_t)l * copies * GR * DS_F;

@@ -262,12 +262,12 @@ class GraphPlan:
             raise _lib.IgcnError("rebuild needs an int64 edge_index of the shape the plan was built for")
         if getattr(self, "dense_blocks", False):
             # complete row-major graphs: the new batch has the SAME structure or none the dense kernels can use — one
-            # pass over edge_index verifies it (status bit 2); the sorted arrays of the first build stay valid.
+            # pass over edge_index verifies it (status bit 2); the sorted arrays of the first build stay valid.  The
+            # pass is not launched here: it rides in the first edge pass of the dense SGCN forward that consumes this
+            # plan (DenseSgcn takes it with ``take_pending_check``); any other consumer launches it (``flush_pending_check``).
             # [Forked onto a side branch of the captured step, joined at the loss head: +74 us per replay — a second
             # queue costs the replay far more than the 27 us it hides.]
-            ei = edge_index.contiguous()
-            call("igcn_dense_blocks_check", self.n_nodes // self.nodes_per_graph, self.nodes_per_graph, ptr(ei),
-                 ptr(self.status), stream_ptr())
+            self._pending_check = edge_index.contiguous()
             return
         # the LDS per-graph build refills ONE cached replica in place (same addresses: capturable); any other build
         # drops the replicas, to be derived again on demand
@@ -277,8 +277,23 @@ class GraphPlan:
             self._copies = {}
         self._build(edge_index.contiguous())
 
+    def take_pending_check(self):
+        """The edge_index whose structure check is still to run (``rebuild`` of a dense-block plan), handed to the
+        consumer that lets it ride in its own launch (igcn_dense_sgcn_fwd); None when nothing is pending."""
+        ei = getattr(self, "_pending_check", None)
+        self._pending_check = None
+        return ei
+
+    def flush_pending_check(self):
+        """Launch a pending structure check now, as a launch of its own (a consumer other than the dense SGCN forward)."""
+        ei = self.take_pending_check()
+        if ei is not None:
+            call("igcn_dense_blocks_check", self.n_nodes // self.nodes_per_graph, self.nodes_per_graph, ptr(ei),
+                 ptr(self.status), stream_ptr())
+
     def check(self):
         """Host-synchronising validation of the segmented build (tests / debugging only)."""
+        self.flush_pending_check()
         code = int(self.status[0].item()) if self.status is not None else 0
         if code & 4:
             raise _lib.IgcnError("dense-block plan: the batch is not made of complete graphs in row-major order any "
@@ -650,6 +665,11 @@ class DenseSgcn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ew, prob, prob_bias, snps_prob, mode, rois, reg, status, *wb):
+        """``status``: the plan's status words, a ``GraphPlan`` (its words + a pending structure check, which then rides
+        in the first edge pass of this forward) or None."""
+        check_ei = None
+        if isinstance(status, GraphPlan):
+            check_ei, status = status.take_pending_check(), status.status
         dual, rois = rois < 0, abs(rois)
         x, ew, prob, pb = _f32(x), _f32(ew), _f32(prob), _f32(prob_bias)
         sp = _f32(snps_prob) if snps_prob is not None else None
@@ -670,7 +690,7 @@ class DenseSgcn(torch.autograd.Function):
         ctx.reg = tuple(float(v) for v in reg)
         call("igcn_dense_sgcn_fwd", g, rois, h0, f, layers, copies, first_masked, ptr(x), ptr(prob), ptr(pb), ptr(ew),
              wp, bp, ptr(sp), sp.numel() if sp is not None else 0, *ctx.reg, ptr(xcat), ptr(regp) if anym else None,
-             ptr(ws), ptr(status) if status is not None and status.numel() >= 2 else None, stream_ptr())
+             ptr(ws), ptr(status) if status is not None and status.numel() >= 2 else None, ptr(check_ei), stream_ptr())
         ctx.save_for_backward(x, ew, prob, pb, sp, xcat, ws, *wb)
         ctx.cfg = (g, rois, h0, f, layers, copies, first_masked, anym)
         ctx.final = _leaves(pb, *wb)

@@ -85,6 +85,7 @@ class SGCN_GCN(torch.nn.Module):
             raise ValueError(f"every graph must have exactly rois={self.rois} nodes (got {n} nodes)")
         bsz, g = n // self.rois, len(explain_flags)
         plan = ops.plan_for(data)
+        plan.flush_pending_check()
         self.last_edge_prob = None
         if tuple(explain_flags) == (False, True) and x.is_cuda:
             # the train step's (plain | masked) pair: cal_probability writes both halves of the stacked batch itself

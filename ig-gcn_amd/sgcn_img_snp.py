@@ -311,8 +311,12 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         snps_ok = snps_feat is not None and snps_feat.is_cuda and snps_feat.dim() == 2 \
             and snps_feat.shape[1] == self.snps_prob.numel()
         xcat = xcat_dense_img = None
-        if (mode is not None and x.is_cuda and (snps_ok or mode == "plain") and os.environ.get("IGCN_NO_DENSE_BLOCKS") != "1"
-                and ops.dense_sgcn_supported(plan, self.rois, x.shape[1], convs[0].out_channels, len(convs))):
+        use_dense = (mode is not None and x.is_cuda and (snps_ok or mode == "plain")
+                     and os.environ.get("IGCN_NO_DENSE_BLOCKS") != "1"
+                     and ops.dense_sgcn_supported(plan, self.rois, x.shape[1], convs[0].out_channels, len(convs)))
+        if not use_dense:
+            plan.flush_pending_check()     # (a dense-block plan's structure check rides in ops.DenseSgcn otherwise)
+        if use_dense:
             # complete graphs (a dense adjacency as COO): masks, gcn_norm, every GCNConv and the mask regulariser of the
             # pass(es) on the dense blocks — no plan arrays, no per-edge intermediates (ops.DenseSgcn)
             wb = [t for c in convs for t in (c.lin.weight, c.bias)]
@@ -327,10 +331,10 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             if fan and self.isCrossAtten and not self.graph_pool and not self.isImageOnly and not self.isSNPsOnly:
                 # (xcat feeds the attention query and the head inputs: two handles, one sum inside the backward kernels)
                 xcat, regp, xcat_dense_img = ops.DenseSgcn.apply(x_d, edge_weight, prob_d, self.prob_bias, sp_d, mode,
-                                                                 -self.rois, self._reg_hp, plan.status, *wb)
+                                                                 -self.rois, self._reg_hp, plan, *wb)
             else:
                 xcat, regp = ops.DenseSgcn.apply(x_d, edge_weight, prob_d, self.prob_bias, sp_d, mode, self.rois,
-                                                 self._reg_hp, plan.status, *wb)
+                                                 self._reg_hp, plan, *wb)
             if mode != "plain":
                 self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp), self._reg_key(x, edge_weight))
             if mode == "plain":

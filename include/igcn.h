@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 410
+#define IGCN_ABI_VERSION 411
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -282,12 +282,15 @@ int igcn_head_bwd_pair(int R, int H, int C1, const float* dy1, const float* y1, 
  * (kernel/sgcn_img_snp.py:133-151), PyG gcn_norm + GCNConv x L + ReLU + concatenation (:218-224) and the edge part of
  * loss_probability (:153-181) of BOTH passes of a train step: every edge pass reads the 4-byte weight once and
  * recomputes mask / coefficient on the fly; the aggregations run on the matrix cores (csrc/sgcn_dense.hip).
- *   igcn_dense_blocks_check : verifies edge k of graph g == (g R + k / R, g R + k % R) — a 16-byte-per-edge read stream;
- *                             otherwise sets bit 2 (value 4) of status[0] (sticky; a host-side check reads it) and
- *                             status[1] = 1.  status: device int32[2].
- *   igcn_dense_sgcn_fwd(status): int32[2] of the check that ran earlier on the stream, or NULL.  A non-zero status[1]
- *                             turns the degrees — hence every output and the loss — into NaN (a batch that is not
- *                             row-major complete must not train silently) and is cleared for the next batch.
+ *   igcn_dense_blocks_check : verifies edge k of graph g == (g R + k / R, g R + k % R) — a 16-byte-per-edge read stream.
+ *                             status: device int32[2]; status[1] = the LATEST check's verdict (cleared in front of every
+ *                             check, 1 on a mismatch), status[0] |= 4 on a mismatch (sticky; a host-side check reads it).
+ *   igcn_dense_sgcn_fwd(status, check_edge_index): status = those words, or NULL.  A set verdict turns the first layer's
+ *                             features — hence every output and the loss — into NaN (a batch that is not row-major
+ *                             complete must not train silently).  check_edge_index != NULL: the check of THIS batch
+ *                             rides in the forward's first edge pass (extra workgroups of that launch stream the
+ *                             index pairs) instead of a launch of its own in front; NULL: the verdict of an earlier
+ *                             igcn_dense_blocks_check on the stream is consumed.
  *   igcn_dense_sgcn_supported: 64 <= R <= 1024, R % 64 == 0, F == 16, L <= 4, H0 <= 8.
  *   copies = 1: one pass (first_masked = isExplain); copies = 2: rows [0, G R) of xcat = plain pass, [G R, 2 G R) = masked.
  *   W / b: HOST arrays of L device pointers (W_l [F, Fin_l] row-major, Fin_0 = H0).  ws: igcn_dense_sgcn_ws_floats
@@ -307,7 +310,7 @@ int igcn_dense_sgcn_fwd(int64_t n_graphs, int R, int H0, int F, int L, int copie
                         const float* prob, const float* prob_bias, const float* ew, const float* const* W,
                         const float* const* b, const float* snps_prob, int n_snps, float l1_x, float ent_x, float l1_e,
                         float ent_e, float eps, float* xcat, float* reg_partials, float* ws, int32_t* status,
-                        void* stream);
+                        const int64_t* check_edge_index, void* stream);
 int igcn_dense_sgcn_bwd(int64_t n_graphs, int R, int H0, int F, int L, int copies, int first_masked, const float* x,
                         const float* prob, const float* prob_bias, const float* ew, const float* const* W,
                         const float* snps_prob, int n_snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,
