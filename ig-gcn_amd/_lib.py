@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 411        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 412        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -104,6 +104,8 @@ SIGNATURES = {
     "igcn_dropout_state_words": (I, []),
     "igcn_dropout_max_segments": (I, []),
     "igcn_dropout_masks": (I, [L, I, P, P, P, P, I, P, L, P]),
+    "igcn_rider_dropout": (I, [P, L, I, P, P, P, P, I, P, L]),
+    "igcn_rider_flush": (I, [P]),
     "igcn_sum_n": (I, [L, I, P, P, P]),
     "igcn_sum_n_final": (I, [L, I, P, P, P]),
     "igcn_mask_reg_blocks": (I, [L]),

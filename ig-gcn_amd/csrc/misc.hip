@@ -1018,106 +1018,56 @@ extern "C" int igcn_graph_pool_bwd(int64_t n_graphs, int nodes_per_graph, int D,
 // `state` on the device holds the counter and arrival words — the LAST workgroup to finish advances the counter, so
 // every replay of a captured launch draws fresh masks without a host round trip.
 // =================================================================================================
-#define DM_MAXSEG 32
-struct DropSegs {
-  int64_t end[DM_MAXSEG];
-  float p[DM_MAXSEG];
-  int n;
-};
-// int64 device counters the launch bumps by `inc` (BatchNorm's num_batches_tracked of the model's five BatchNorms: the
-// masks are drawn once per training forward, which is exactly when those counters advance — a torch._foreach_add_
-// launch less per step)
-#define DM_MAXCNT 8
-struct DropCounters {
-  long long* c[DM_MAXCNT];
-  int n;
-  long long inc;
-};
-
-__device__ __forceinline__ uint32_t dm_hash(uint32_t x) {       // lowbias32
-  x ^= x >> 16; x *= 0x7feb352dU;
-  x ^= x >> 15; x *= 0x846ca68bU;
-  x ^= x >> 16;
-  return x;
-}
-
-// `state` (device uint64[IGCN_DROPOUT_STATE_WORDS]): [0] stream counter, [1] groups done, [2 + 32 g] workgroups done of
-// group g (DM_GROUPS groups, their words 256 bytes apart).  "Last one out advances the counter" in two levels: a
-// single word takes ~90 atomics per microsecond, so 6000 one-shot workgroups spent 68 us there and the first remedy —
-// at most 512 grid-striding workgroups — left two waves per SIMD to do the hashing (19 us for 18 MB of factors).
-#define DM_GROUPS 16
-#define DM_WORDS (2 + 32 * DM_GROUPS)
+#include "dropout.h"
 __global__ void __launch_bounds__(256)
 k_dropout_masks(int64_t total, DropSegs segs, unsigned long long* __restrict__ state, float* __restrict__ out,
                 DropCounters cnt) {
-  if (blockIdx.x == 0 && threadIdx.x < cnt.n) *cnt.c[threadIdx.x] += cnt.inc;
-  const unsigned long long c = state[0];
-  const uint32_t k0 = dm_hash((uint32_t)c ^ 0x9E3779B9u), k1 = dm_hash((uint32_t)(c >> 32) + 0x85EBCA6Bu + k0);
-  for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < total; i0 += (int64_t)gridDim.x * 1024) {
-    float v[4];
-    float p = 0.f;                                     // a quad never straddles sites (sites start on multiples of 4)
-    for (int sgm = 0; sgm < segs.n; ++sgm)
-      if (i0 < segs.end[sgm]) { p = segs.p[sgm]; break; }
-    const float scale = 1.0f / (1.0f - p);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t i = i0 + j;
-      const uint32_t h = dm_hash(((uint32_t)i * 0x9E3779B1u) ^ k0) + (uint32_t)(i >> 32) * 0x85EBCA77u;
-      const float u = (float)(dm_hash(h ^ k1) >> 8) * (1.0f / 16777216.0f);             // [0, 1)
-      v[j] = u < p ? 0.f : scale;
-    }
-    if (i0 + 3 < total) {
-      *reinterpret_cast<float4*>(out + i0) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-      for (int j = 0; j < 4 && i0 + j < total; ++j) out[i0 + j] = v[j];
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    // every workgroup has read the counter before it arrives here; group g = blockIdx % DM_GROUPS has
-    // ceil((gridDim - g) / DM_GROUPS) members
-    const unsigned g = blockIdx.x % DM_GROUPS, ng = gridDim.x < DM_GROUPS ? gridDim.x : DM_GROUPS;
-    const unsigned members = (gridDim.x - g + DM_GROUPS - 1) / DM_GROUPS;
-    unsigned long long* gw = state + 2 + 32 * g;
-    if (atomicAdd(gw, 1ull) == (unsigned long long)members - 1) {
-      *gw = 0;
-      if (atomicAdd(&state[1], 1ull) == (unsigned long long)ng - 1) {
-        state[0] = c + 1;
-        state[1] = 0;
-      }
-    }
-  }
+  dropout_masks_body(blockIdx.x, gridDim.x, total, segs, state, out, cnt);
 }
 
 extern "C" int igcn_dropout_state_words(void) { return DM_WORDS; }
 extern "C" int igcn_dropout_max_segments(void) { return DM_MAXSEG; }
 
+int igcn_dropout_job(DropJob& job, const char* who, int64_t total, int n_segments, const int64_t* seg_end, const float* seg_p,
+                     void* state, float* out, int n_counters, int64_t* const* counters, int64_t counter_inc) {
+  IGCN_REQUIRE(n_counters >= 0 && n_counters <= DM_MAXCNT && (n_counters == 0 || counters != nullptr),
+               "%s: at most %d counters", who, DM_MAXCNT);
+  job = DropJob{};
+  job.cnt.n = n_counters;
+  job.cnt.inc = counter_inc;
+  for (int k = 0; k < n_counters; ++k) job.cnt.c[k] = (long long*)counters[k];
+  IGCN_REQUIRE(total > 0 && n_segments >= 1 && n_segments <= DM_MAXSEG && state != nullptr &&
+               ((uintptr_t)out & 15) == 0, "%s: 1..%d segments, 16-byte aligned output", who, DM_MAXSEG);
+  job.sg.n = n_segments;
+  for (int k = 0; k < n_segments; ++k) {
+    IGCN_REQUIRE(seg_p[k] >= 0.f && seg_p[k] < 1.f && seg_end[k] <= total, "%s: bad segment %d", who, k);
+    job.sg.end[k] = seg_end[k];
+    job.sg.p[k] = seg_p[k];
+  }
+  IGCN_REQUIRE(job.sg.end[n_segments - 1] == total, "%s: the segments must cover [0, total)", who);
+  for (int k = 0; k + 1 < n_segments; ++k)
+    IGCN_REQUIRE(job.sg.end[k] % 4 == 0, "%s: interior segment ends must be multiples of 4", who);
+  int64_t blocks = igcn_cdiv(total, 1024);
+  job.blocks = (unsigned)(blocks > 2048 ? 2048 : blocks);
+  job.total = total;
+  job.state = (unsigned long long*)state;
+  job.out = out;
+  return IGCN_OK;
+}
+
+int igcn_dropout_launch(const DropJob& job, hipStream_t st) {
+  hipLaunchKernelGGL(k_dropout_masks, dim3(job.blocks), dim3(256), 0, st, job.total, job.sg, job.state, job.out, job.cnt);
+  IGCN_CHECK_LAUNCH("dropout_masks");
+  return IGCN_OK;
+}
+
 extern "C" int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end /*HOST*/,
                                   const float* seg_p /*HOST*/, void* state /*device uint64[2]*/, float* out,
                                   int n_counters, int64_t* const* counters /*HOST array of device pointers*/,
                                   int64_t counter_inc, void* stream) {
-  IGCN_REQUIRE(n_counters >= 0 && n_counters <= DM_MAXCNT && (n_counters == 0 || counters != nullptr),
-               "dropout_masks: at most %d counters", DM_MAXCNT);
-  DropCounters cnt = {};
-  cnt.n = n_counters;
-  cnt.inc = counter_inc;
-  for (int k = 0; k < n_counters; ++k) cnt.c[k] = (long long*)counters[k];
-  IGCN_REQUIRE(total > 0 && n_segments >= 1 && n_segments <= DM_MAXSEG && state != nullptr &&
-               ((uintptr_t)out & 15) == 0, "dropout_masks: 1..%d segments, 16-byte aligned output", DM_MAXSEG);
-  DropSegs sg = {};
-  sg.n = n_segments;
-  for (int k = 0; k < n_segments; ++k) {
-    IGCN_REQUIRE(seg_p[k] >= 0.f && seg_p[k] < 1.f && seg_end[k] <= total, "dropout_masks: bad segment %d", k);
-    sg.end[k] = seg_end[k];
-    sg.p[k] = seg_p[k];
-  }
-  IGCN_REQUIRE(sg.end[n_segments - 1] == total, "dropout_masks: the segments must cover [0, total)");
-  for (int k = 0; k + 1 < n_segments; ++k)
-    IGCN_REQUIRE(sg.end[k] % 4 == 0, "dropout_masks: interior segment ends must be multiples of 4");
-  int64_t blocks = igcn_cdiv(total, 1024);
-  blocks = blocks > 2048 ? 2048 : blocks;
-  hipLaunchKernelGGL(k_dropout_masks, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, total, sg,
-                     (unsigned long long*)state, out, cnt);
-  IGCN_CHECK_LAUNCH("dropout_masks");
-  return IGCN_OK;
+  DropJob job;
+  const int rc = igcn_dropout_job(job, "dropout_masks", total, n_segments, seg_end, seg_p, state, out, n_counters, counters,
+                                  counter_inc);
+  if (rc) return rc;
+  return igcn_dropout_launch(job, (hipStream_t)stream);
 }

@@ -95,7 +95,17 @@ class Gene_ontology_network(nn.Module):
         bns = (self.conc_for_attention[1], self.B[0], self.B_D[0], self.latent[1], self.latent[5])
         return [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
 
-    def _dropout_masks(self, b, dev, extra=(), groups=1):
+    def predraw_dropout(self, b, dev, extra=(), groups=1):
+        """Draw the masks of the NEXT training forward now, as a rider of the launch that follows on this stream (the
+        per-graph plan build of a train step: ops.dropout_masks ``ride``); the forward picks them up."""
+        if not (self.training and self._dropout_enabled):
+            return
+        self._predrawn = None
+        res = self._dropout_masks(b, dev, extra, groups, ride=True)
+        key = (int(b), str(dev), tuple((tuple(s), float(p)) for s, p in extra), int(groups))
+        self._predrawn = (key, res, self._counters_done)
+
+    def _dropout_masks(self, b, dev, extra=(), groups=1, ride=False):
         """Every dropout of this forward pass from ONE kernel launch (igcn_dropout_masks), as {0, 1/(1-p)} factors
         that the consumers multiply by inside their own kernels:
           * nn.Dropout2d(0.4) on [B,N,f] (:104,113) zeroes whole nodes per sample -> ``ln`` [B,n] per LayerNorm site;
@@ -106,6 +116,15 @@ class Gene_ontology_network(nn.Module):
         ln_sizes = [c.n_rows for c in self.enc_csr] + [c.n_rows for c in self.dec_csr]
         if not (self.training and self._dropout_enabled):
             return {"ln": [None] * len(ln_sizes), "inp": None, "out_d": None, "h": None}, [None] * len(extra)
+        pre = getattr(self, "_predrawn", None)
+        if pre is not None and not ride:
+            # drawn ahead of the forward (predraw_dropout: the job rode in the plan build's launch) for exactly this call
+            self._predrawn = None
+            key = (int(b), str(dev), tuple((tuple(s), float(p)) for s, p in extra), int(groups))
+            if pre[0] != key:
+                raise RuntimeError("dropout masks were drawn ahead for another forward call (predraw_dropout)")
+            self._counters_done = pre[2]
+            return pre[1]
         state = getattr(self, "_drop_state", None)
         if state is None or state.state.device != dev:
             state = self._drop_state = ops.DropoutState(dev)
@@ -114,7 +133,7 @@ class Gene_ontology_network(nn.Module):
         sites += list(extra)
         # the launch that draws the masks also advances the BatchNorm batch counters (one torch launch less per step)
         cnt = self._batch_counters()
-        m = ops.dropout_masks(sites, state, cnt, groups)
+        m = ops.dropout_masks(sites, state, cnt, groups, ride=ride)
         self._counters_done = bool(cnt)
         k = len(ln_sizes)
         return {"ln": m[:k], "inp": m[k], "out_d": m[k + 1], "h": m[k + 2]}, m[k + 3:]

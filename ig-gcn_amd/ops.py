@@ -1337,9 +1337,12 @@ class DropoutState:
         self.state[0] = seed
 
 
-def dropout_masks(sites, state, counters=(), inc=0):
+def dropout_masks(sites, state, counters=(), inc=0, ride=False):
     """``sites``: [(shape, p), ...] -> list of float tensors of {0, 1/(1-p)} factors, drawn by ONE kernel launch.
-    ``counters`` (<= 8 int64 device scalars): bumped by ``inc`` by the same launch (BatchNorm's num_batches_tracked)."""
+    ``counters`` (<= 8 int64 device scalars): bumped by ``inc`` by the same launch (BatchNorm's num_batches_tracked).
+    ``ride``: do not launch — queue the job for the current stream (igcn_rider_dropout): the next per-graph plan build on
+    it carries the mask generation in its own grid; ``igcn_rider_flush`` launches it if no build came.  The returned
+    tensors are valid behind that launch.  (Only for site lists one launch takes.)"""
     import math
     sizes = [int(math.prod(shape)) for shape, _ in sites]
     # every site starts on a 16-byte boundary (its consumers read it with 16-byte loads)
@@ -1350,6 +1353,14 @@ def dropout_masks(sites, state, counters=(), inc=0):
     ends = [(starts[k + 1] if k + 1 < len(sites) else total) for k in range(len(sites))]
     out = torch.empty(total, dtype=torch.float32, device=state.state.device)
     per = int(_lib.load().igcn_dropout_max_segments())
+    if ride and len(sites) <= per:
+        seg_end = (ctypes.c_int64 * len(sites))(*ends)
+        seg_p = (ctypes.c_float * len(sites))(*[float(p) for _, p in sites])
+        cnt = list(counters)
+        carr = (ctypes.c_void_p * max(len(cnt), 1))(*[c.data_ptr() for c in cnt])
+        call("igcn_rider_dropout", stream_ptr(), total, len(sites), seg_end, seg_p, ptr(state.state), ptr(out), len(cnt),
+             carr, int(inc))
+        return [out[s0:s0 + n].view(*shape) for (shape, _), s0, n in zip(sites, starts, sizes)]
     for k0 in range(0, len(sites), per):                     # a deep GO hierarchy has more sites than one launch takes
         k1 = min(k0 + per, len(sites))
         base = starts[k0]

@@ -289,6 +289,16 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         produce every parameter gradient once instead of adding two per-pass contributions."""
         return self._forward_grouped(data, temperature, device, (False, True))
 
+    def predraw_dropout(self, data, groups=2):
+        """The dropout masks of the next training sweep over ``data`` (``groups`` passes batched: the train step's plain |
+        masked pair), drawn as a RIDER of the launch that follows on this stream — a captured step queues them in front
+        of its per-graph plan build (train.GraphedTrainStep), whose grid then carries the mask generation."""
+        if not (self.training and self._dropout_enabled) or not data.x.is_cuda:
+            return
+        gb = groups * (data.x.shape[0] // self.rois)
+        hl = self.lin1.weight.shape[0]
+        self.go_network.predraw_dropout(gb, data.x.device, [((gb, hl), 0.5), ((gb, hl), 0.3)], groups)
+
     def _forward_grouped(self, data, temperature, device, explain_flags, split=True, raw_scores=False):
         x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
         snps_feat = data.snps_feat

@@ -290,6 +290,12 @@ def losses_sgcn(model, data, hp=HP):
     return hp.lamda_ce * t["ce"] + t["prob"] + hp.lamda_mi * t["mi"], t, (out, out_p)
 
 
+def _batched(model):
+    """The model takes both passes of a train step in one batched sweep (``_losses_batched``)."""
+    return (hasattr(model, "go_network") and getattr(model, "batched_passes", True)
+            and hasattr(model, "_forward_grouped") and model.isSoftSimilarity)
+
+
 def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None):
     """train() :521-543.  Returns (loss, terms dict, outputs).  A model without a GO branch (``SGCN_GCN``)
     takes the three-term loss of kernel/train_eval_sgcn.py:303-308 (``lambda_loss`` is not used there)."""
@@ -590,10 +596,16 @@ class GraphedTrainStep:
     def _fwd_bwd(self, rebuild=True):
         self.opt.zero_grad()
         self.data._igcn_plan = self.plan
+        rider = (rebuild and _batched(self.model) and hasattr(self.model, "predraw_dropout")
+                 and os.environ.get("IGCN_NO_DROPOUT_RIDER", "0") != "1")
+        if rider:
+            self.model.predraw_dropout(self.data)       # queued: the plan build below carries the mask generation
         if rebuild:
             self.plan.rebuild(self.data.edge_index)     # the plan is per batch: rebuilt (in place) every step
         else:
             self.plan._copies = {}                      # the replica of the batched sweep is derived in-graph
+        if rider:
+            call("igcn_rider_flush", stream_ptr())      # (a plan build that does not carry riders: a launch of its own)
         self.data.x.grad = None
         loss, _, _ = losses(self.model, self.data, self.lam, self.hp)
         backward_to_grads(loss, self.opt, self.data, defer=_single_use_parameters(self.model), tick=True)

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 411
+#define IGCN_ABI_VERSION 412
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -540,6 +540,13 @@ int igcn_dropout_max_segments(void);   /* sites one igcn_dropout_masks launch ta
 int igcn_dropout_state_words(void);
 int igcn_dropout_masks(int64_t total, int n_segments, const int64_t* seg_end, const float* seg_p, void* state,
                        float* out, int n_counters, int64_t* const* counters, int64_t counter_inc, void* stream);
+/* The same job as a RIDER: not launched, but queued for `stream` (at most one per stream) and carried by the next
+ * igcn_graph_plan_build_segmented[_rep] on that stream — extra workgroups of the plan build's grid draw the masks (both
+ * launches depend on nothing a train step computes; as two roles of one grid they overlap).  igcn_rider_flush launches a
+ * job nobody carried as a launch of its own (nothing waiting: nothing happens). */
+int igcn_rider_dropout(void* stream, int64_t total, int n_segments, const int64_t* seg_end, const float* seg_p, void* state,
+                       float* out, int n_counters, int64_t* const* counters, int64_t counter_inc);
+int igcn_rider_flush(void* stream);
 /* counters (HOST array of <= 8 device int64 pointers, or n_counters = 0): each is bumped by counter_inc by the launch —
  * BatchNorm's num_batches_tracked (kernel/go_model.py:119-146), which advance exactly when the masks are drawn.
  *

@@ -368,3 +368,32 @@ def test_copy_multi_moves_the_same_bytes_as_copy():
         else:
             assert torch.equal(dst.cpu(), src.cpu().to(dst.dtype)), (dst.shape, dst.dtype)
     assert int(b[0]) == 0 and int(b[4098]) == 0            # nothing written outside the ranges
+
+
+def test_captured_step_draws_its_dropout_masks_in_the_plan_builds_launch(monkeypatch):
+    """Dropout ON in the captured step: the masks of a replay are drawn by extra workgroups of its per-graph plan build
+    (ops.dropout_masks ``ride``; model.predraw_dropout) — the same masks, hence the same losses, as with the mask launch
+    of its own (IGCN_NO_DROPOUT_RIDER=1); fresh masks on every replay; num_batches_tracked advances by the two passes."""
+    from igcn_amd import synth
+    from igcn_amd.data import Batch
+    from igcn_amd.train import FlatAdam, GraphedTrainStep
+
+    def run():
+        torch.manual_seed(77)                                       # (seeds the device-side mask counter too)
+        m = _small_model()
+        for mod in (m, m.go_network):
+            mod._dropout_enabled = True
+        opt = FlatAdam(m.parameters(), lr=1e-3)
+        data = Batch.from_data_list(synth.brain_graph_list(16, seed=61, rois=90, tsne_dim=16)).to("cuda")
+        data.x.requires_grad_(True)
+        step = GraphedTrainStep(m, opt, data, LAM, warmup=1)
+        losses = [float(step()) for _ in range(4)]
+        return losses, int(m.go_network.latent[1].num_batches_tracked), m
+
+    want, nb_want, _ = run()
+    assert len(set(round(v, 6) for v in want)) > 1                  # the masks differ from replay to replay
+    monkeypatch.setenv("IGCN_NO_DROPOUT_RIDER", "1")
+    got, nb_got, m = run()
+    assert nb_got == nb_want and nb_want >= 8                       # two passes per step, warm-up rolled back or not
+    assert all(abs(a - b) <= 1e-6 * max(1.0, abs(b)) for a, b in zip(got, want)), (got, want)
+    assert getattr(m.go_network, "_predrawn", None) is None

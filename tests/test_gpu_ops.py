@@ -1901,6 +1901,49 @@ def test_dropout_launch_advances_the_batch_counters(ops):
     assert [int(c) for c in cnt] == [8, 15, 108]
 
 
+def test_dropout_masks_ride_in_the_plan_builds_launch(ops):
+    """``dropout_masks(ride=True)``: the job is queued for the stream and drawn by extra workgroups of the next per-graph
+    plan build's grid (k_plan_segmented_ride) — the SAME masks a launch of its own draws from the same counter, the
+    counters bumped once, the plan the same bits; a job nobody carried is launched by igcn_rider_flush; a second job on
+    a stream that still holds one is refused."""
+    from igcn_amd import _lib, synth
+    from igcn_amd._lib import call, stream_ptr
+    batch = synth.brain_batch(24, seed=3, rois=90).to("cuda")
+    sites = [((48, 3000), 0.4), ((48, 401), 0.5), ((7,), 0.3), ((96, 64), 0.3)]
+    torch.manual_seed(9)
+    st_a, st_b = ops.DropoutState(torch.device("cuda")), ops.DropoutState(torch.device("cuda"))
+    st_b.state.copy_(st_a.state)                                       # the same counter: the same masks
+    cnt_a = [torch.tensor(5, dtype=torch.int64, device="cuda")]
+    cnt_b = [torch.tensor(5, dtype=torch.int64, device="cuda")]
+    want = ops.dropout_masks(sites, st_a, cnt_a, 2)                    # a launch of its own
+    plan0 = ops.plan_for(batch)
+    ref = {n: getattr(plan0, n).clone() for n in ("src32", "dst32", "tgt_ptr", "tgt_perm", "src_ptr", "src_perm", "loop_edge")}
+    got = ops.dropout_masks(sites, st_b, cnt_b, 2, ride=True)          # queued ...
+    torch.cuda.synchronize()
+    assert int(cnt_b[0]) == 5                                          # ... nothing has run yet
+    plan0.rebuild(batch.edge_index)                                    # ... carried by this build
+    torch.cuda.synchronize()
+    assert int(cnt_b[0]) == 7 == int(cnt_a[0])
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert torch.equal(st_a.state, st_b.state)                         # counter advanced once, arrival words back at 0
+    for n, t in ref.items():
+        assert torch.equal(getattr(plan0, n), t), n
+    plan0.check()
+    # nobody carries it: the flush launches it
+    w2 = ops.dropout_masks(sites, st_a)
+    g2 = ops.dropout_masks(sites, st_b, ride=True)
+    call("igcn_rider_flush", stream_ptr())
+    call("igcn_rider_flush", stream_ptr())                             # nothing waiting: nothing happens
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(w2, g2))
+    ops.dropout_masks(sites, st_b, ride=True)
+    with pytest.raises(_lib.IgcnError):
+        ops.dropout_masks(sites, st_b, ride=True)                      # one job per stream
+    call("igcn_rider_flush", stream_ptr())
+    torch.cuda.synchronize()
+
+
 def test_grad_fan_sums_the_consumers_gradients_in_one_launch(ops):
     """ops.GradFan: k aliases of a tensor, the k incoming gradients summed by igcn_sum_n (16-byte path and scalar tail),
     a missing consumer gradient skipped, unaligned gradients summed by the fallback — all equal to autograd's own adds."""
