@@ -739,9 +739,66 @@ extern "C" int igcn_gemm_f32_batched(int64_t M, int64_t N, int64_t K, int batch,
 // as in igcn_gemm_bf16.  Slab sums follow per problem as there.  Falls back to one launch per
 // problem when the operands do not all allow at least 8-byte loads.
 static size_t gemm_lds_bytes(int bn, int64_t k_per_split, bool a_rfast, bool b_rfast);
+// ---- riders: products queued for a stream, carried by the NEXT grouped launch on it --------------------------------
+// Two chains of a train step's forward end in products that are ready at the same time and depend on nothing of each
+// other — the heads' first layers (lin1 | lin1_regr) and the per-pass Gram matrices of the batch losses — but are issued
+// by different parts of the host code (the model's forward; the loss function).  The later one is QUEUED before the
+// earlier one launches (igcn_gemm_rider, same table format) and joins its grid: one launch of four products instead of
+// two launches of two.  igcn_gemm_rider_flush launches products nobody carried.
+#include <map>
+#include <mutex>
+#include <vector>
+static std::mutex g_gr_mutex;
+static std::map<hipStream_t, std::vector<int64_t>> g_gemm_riders;      // 16 words per product
+
+extern "C" int igcn_gemm_rider(void* stream, int n, const int64_t* table) {
+  IGCN_REQUIRE(n >= 1 && n <= GG_MAX && table != nullptr, "gemm_rider: 1..%d products", GG_MAX);
+  std::lock_guard<std::mutex> lk(g_gr_mutex);
+  std::vector<int64_t>& q = g_gemm_riders[(hipStream_t)stream];
+  IGCN_REQUIRE(q.size() / 16 + (size_t)n <= GG_MAX, "gemm_rider: more than %d products waiting on this stream", GG_MAX);
+  q.insert(q.end(), table, table + 16 * n);
+  return IGCN_OK;
+}
+
+static std::vector<int64_t> gemm_riders_take(hipStream_t st, int room, bool bf16) {
+  std::lock_guard<std::mutex> lk(g_gr_mutex);
+  auto it = g_gemm_riders.find(st);
+  std::vector<int64_t> r;
+  if (it == g_gemm_riders.end()) return r;
+  // carried only whole, and only by a launch of the same operand type (the table's word 15)
+  if ((int)(it->second.size() / 16) <= room && (it->second[15] != 0) == bf16) {
+    r.swap(it->second);
+    g_gemm_riders.erase(it);
+  }
+  return r;
+}
+
+extern "C" int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream);
+extern "C" int igcn_gemm_rider_flush(void* stream) {
+  std::vector<int64_t> r;
+  {
+    std::lock_guard<std::mutex> lk(g_gr_mutex);
+    auto it = g_gemm_riders.find((hipStream_t)stream);
+    if (it == g_gemm_riders.end()) return IGCN_OK;
+    r.swap(it->second);
+    g_gemm_riders.erase(it);
+  }
+  return igcn_gemm_f32_grouped((int)(r.size() / 16), r.data(), stream);
+}
+
 extern "C" int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream) {
   IGCN_REQUIRE(n >= 1 && n <= GG_MAX && table != nullptr, "gemm_f32_grouped: 1..%d problems", GG_MAX);
   hipStream_t st = (hipStream_t)stream;
+  int64_t merged[16 * GG_MAX];
+  {
+    const std::vector<int64_t> r = gemm_riders_take(st, GG_MAX - n, table[15] != 0);
+    if (!r.empty()) {                                  // the queued products join this launch
+      for (int i = 0; i < 16 * n; ++i) merged[i] = table[i];
+      for (size_t i = 0; i < r.size(); ++i) merged[16 * n + i] = r[i];
+      n += (int)(r.size() / 16);
+      table = merged;
+    }
+  }
   GemmGroup G;
   G.n = n;
   int bn = 64, vw = 4, pf = 1, wgs = 0, split_of[GG_MAX];

@@ -792,13 +792,19 @@ def gemm_tn(a, b, bf16=False, final_grad=False, out=None):
     return out
 
 
-def gemm_group(specs, bf16=False):
-    """Several independent products in ONE launch (igcn_gemm_f32_grouped; at most four).  ``specs``: tuples
+def gemm_group(specs, bf16=False, ride=False):
+    """``ride``: do not launch — queue the products for the current stream (igcn_gemm_rider): the next grouped launch on it
+    carries them as further members (``igcn_gemm_rider_flush`` launches them if none came).  Returns (outs, hold): the
+    outputs are valid behind the carrying launch, ``hold`` keeps operands and slabs alive until then.
+
+    Several independent products in ONE launch (igcn_gemm_f32_grouped; at most four).  ``specs``: tuples
     (form, a, b, out, bias, final_grad[, act]) with form "nt" (a [M,K], b [N,K]), "nn" (a [M,K], b [K,N]) or "tn"
     (a [K,M], b [K,N]); ``out`` None allocates; act 1 = ReLU ("nt" only).  Returns the outputs.  ``bf16``: operands
     rounded to bf16 on the way into LDS (igcn_gemm_bf16 semantics) for every member."""
     outs = []
     specs = [tuple(sp) + (0,) * (7 - len(sp)) for sp in specs]
+    if ride and (len(specs) > 4 or os.environ.get("IGCN_NO_GEMM_GROUPS", "0") == "1"):
+        raise _lib.IgcnError("gemm_group(ride=True): at most four products, grouped launches enabled")
     if len(specs) > 4 or os.environ.get("IGCN_NO_GEMM_GROUPS", "0") == "1":
         for form, a, b, out, bias, final, act in specs:
             if form == "nt":
@@ -833,6 +839,9 @@ def gemm_group(specs, bf16=False):
                                      ptr(out) or 0, n, act | (0x100 if final else 0), sk, ptr(scratch) or 0]
         table[16 * i + 15] = 1 if bf16 else 0
         outs.append(out)
+    if ride:
+        call("igcn_gemm_rider", stream_ptr(), len(specs), ctypes.addressof(table))
+        return outs, hold
     call("igcn_gemm_f32_grouped", len(specs), ctypes.addressof(table), stream_ptr())
     return outs
 
@@ -2011,11 +2020,13 @@ class GramLosses(torch.autograd.Function):
     (sgcn_img_snp.py:183-205).  Returns two tensors of shape [G]."""
 
     @staticmethod
-    def forward(ctx, s, lap, groups=1, packed=False, rbf=None, expect=None):
+    def forward(ctx, s, lap, groups=1, packed=False, rbf=None, expect=None, pre=None):
         """``expect`` (with ``rbf``): the upstream gradient [G*2] the caller expects in the backward, as host floats (a
         train step's d loss / d (consist, orth) are its loss weights): the forward kernel then writes the backward's S
         as it goes, and a backward whose upstream IS that (announced by LossHead through UNIT_DGRAM, recognised by
         address like the unit scalar itself) launches no igcn_gram_loss_bwd.
+        ``pre``: the Gram matrices [G, B, B] of ``s``, already computed (``gram_rider``: the products rode in another
+        grouped launch) — no GEMM here.
         ``packed``: return ONE tensor [G,2] = (consist, orth) per group (what igcn_loss_head_* consumes);
         ``packed == "partials"``: the un-reduced row partials [B, G*2] whose column sums are that tensor (LossHead adds
         them up inside its own kernel: one launch less); every row then receives the gradient of the sum.
@@ -2031,14 +2042,19 @@ class GramLosses(torch.autograd.Function):
         else:
             lap, rbf = _f32(lap), None
         partials = packed == "partials"
-        gram = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
         out = None if partials else torch.empty(groups, 2, dtype=torch.float32, device=s.device)
         scratch = torch.empty(2 * b * groups, dtype=torch.float32, device=s.device)
-        # the per-group Gram matrices s_g s_g^T in ONE launch (+ one slab sum)
-        sk = _split_k(b * groups, b, rd)
-        gscr = torch.empty(groups * sk * b * b, dtype=torch.float32, device=s.device) if sk > 1 else None
-        call("igcn_gemm_f32_batched", b, b, rd, groups, ptr(s), rd, 1, b * rd, ptr(s), rd, 1, b * rd, ptr(gram), b * b, b,
-             sk, ptr(gscr), stream_ptr())
+        if pre is not None:
+            gram = pre
+            if tuple(gram.shape) != (groups, b, b) or gram.dtype != torch.float32 or not gram.is_contiguous():
+                raise _lib.IgcnError("GramLosses: the precomputed Gram matrices do not match the input")
+        else:
+            gram = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
+            # the per-group Gram matrices s_g s_g^T in ONE launch (+ one slab sum)
+            sk = _split_k(b * groups, b, rd)
+            gscr = torch.empty(groups * sk * b * b, dtype=torch.float32, device=s.device) if sk > 1 else None
+            call("igcn_gemm_f32_batched", b, b, rd, groups, ptr(s), rd, 1, b * rd, ptr(s), rd, 1, b * rd, ptr(gram), b * b,
+                 b, sk, ptr(gscr), stream_ptr())
         ctx.sym = ctx.expect = None
         if (rbf is not None and expect is not None and groups <= 4 and len(expect) == 2 * groups
                 and ctx.needs_input_grad[0]):
@@ -2082,7 +2098,20 @@ class GramLosses(torch.autograd.Function):
         rd = s.shape[1]
         call("igcn_gemm_f32_batched", b, rd, b, groups, ptr(sym), b, 1, b * b, ptr(s), 1, rd, b * rd, ptr(ds), b * rd, rd,
              1, None, stream_ptr())                                # ds_g = S_g s_g, every group in one launch
-        return ds, None, None, None, None, None
+        return ds, None, None, None, None, None, None
+
+
+def gram_rider(s, groups):
+    """Queue the per-group Gram products s_g s_g^T of ``s`` [G*B, RD] as RIDERS of the next grouped GEMM launch on this
+    stream (the heads' first layers, which read the same HeadInputs outputs): returns (gram [G, B, B], hold) — pass
+    ``gram`` to GramLosses(pre=...) after the carrying launch (or igcn_gemm_rider_flush)."""
+    s = _f32(s)
+    gb, rd = s.shape
+    b = gb // groups
+    gram = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
+    specs = [("nt", s[g * b:(g + 1) * b], s[g * b:(g + 1) * b], gram[g], None, False) for g in range(groups)]
+    _, hold = gemm_group(specs, ride=True)
+    return gram, hold
 
 
 class ProjectedAttention(torch.autograd.Function):

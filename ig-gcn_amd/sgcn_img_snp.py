@@ -299,7 +299,9 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         hl = self.lin1.weight.shape[0]
         self.go_network.predraw_dropout(gb, data.x.device, [((gb, hl), 0.5), ((gb, hl), 0.3)], groups)
 
-    def _forward_grouped(self, data, temperature, device, explain_flags, split=True, raw_scores=False):
+    def _forward_grouped(self, data, temperature, device, explain_flags, split=True, raw_scores=False, on_out_z=None):
+        """``on_out_z(out_z)``: called once the fused features exist and BEFORE the heads' first layers are launched — a
+        train step queues the Gram products of its batch losses there, as riders of that launch (ops.gram_rider)."""
         x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
         snps_feat = data.snps_feat
         x.requires_grad = True                                        # :210 — populates data.x.grad
@@ -438,6 +440,8 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             feat = torch.cat((out_lin, img_feat if g == 1 else img_feat.repeat(g, 1)), -1)
         else:
             feat = out_lin
+        if on_out_z is not None:
+            on_out_z(out_z)
         # the first layers of the two heads (:299 lin1, :302 lin1_regr) are independent: one grouped launch each way
         linear_outf, reg = ops.linear_pair(out_lin, self.lin1.weight, self.lin1.bias, feat, self.lin1_regr.weight,
                                            self.lin1_regr.bias, relu=True, bf16=bf)

@@ -351,9 +351,21 @@ def _losses_batched(model, data, lam, hp, temperature):
     per direction (igcn_loss_head_*) for the terms and their weighted sum — the per-pass means of equal-sized
     halves are taken on the stacked tensors, so nothing is sliced."""
     dev = data.x.device
-    scores, x_hat, out_z, out_lin, lin_f, reg = model._forward_grouped(data, temperature, dev, (False, True),
-                                                                       split=False, raw_scores=True)
     from . import ops
+    # the Gram products of the batch losses (out_z out_z^T per pass) read what the heads' first layers read — the outputs
+    # of the fusion — and depend on nothing else: queued from inside the forward, they ride in that grouped GEMM launch
+    # (ops.gram_rider) instead of a launch of their own behind the forward
+    pre = {}
+
+    def queue_gram(z):
+        if z.is_cuda and z.dtype == torch.float32 and z.is_contiguous() and z.shape[0] % 2 == 0 \
+                and os.environ.get("IGCN_NO_GRAM_RIDER", "0") != "1" and os.environ.get("IGCN_NO_GEMM_GROUPS", "0") != "1":
+            pre["gram"], pre["hold"] = ops.gram_rider(z.detach(), 2)
+
+    scores, x_hat, out_z, out_lin, lin_f, reg = model._forward_grouped(data, temperature, dev, (False, True),
+                                                                       split=False, raw_scores=True, on_out_z=queue_gram)
+    if pre:
+        call("igcn_gemm_rider_flush", stream_ptr())      # (a forward whose heads took another route: launch them now)
     # the Gram terms and the mask regulariser arrive as un-reduced partial sums and the class scores raw: the loss
     # kernel adds the partials up and takes log_softmax itself (two reductions and two torch launches less); the RBF
     # Laplacian of consist_loss is built inside the Gram loss kernel (model.laplacian() is a launch of its own)
@@ -361,7 +373,8 @@ def _losses_batched(model, data, lam, hp, temperature):
     # (the loss head's gradient of these partials for a unit upstream is known here: the Gram loss forward prepares its
     # own backward for it — ops.GramLosses ``expect``)
     unit = ops.unit_dgram(lam) if (ops.UNIT_GRAD_PTRS and os.environ.get("IGCN_NO_LOSS_HEAD_FUSED", "0") != "1") else None
-    gram = ops.GramLosses.apply(out_z, None, 2, "partials", (data.tsne_fdim if soft else None, model.rbf_gamma), unit)
+    gram = ops.GramLosses.apply(out_z, None, 2, "partials", (data.tsne_fdim if soft else None, model.rbf_gamma), unit,
+                                pre.get("gram"))
     # (rows sum to [2,2] = (consist, orth) per pass)
     prob = model.loss_probability(data.x, data.edge_index, data.edge_attr, hp, edge_prob=model.last_edge_prob,
                                   partials=True)

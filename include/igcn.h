@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 412
+#define IGCN_ABI_VERSION 413
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -470,6 +470,13 @@ int igcn_gemm_f32_batched(int64_t M, int64_t N, int64_t K, int batch, const floa
  * field as the igcn_gemm_f32 argument of that name (pointers as integers); bf16 != 0 in the first problem: operands
  * rounded to bf16 as in igcn_gemm_bf16.  Same results as n igcn_gemm_f32 / igcn_gemm_bf16 calls. */
 int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream);
+/* Products QUEUED for `stream` (same table format; at most 4 waiting) and carried by the next igcn_gemm_f32_grouped on it
+ * — if they fit beside its own products (4 in all) and share its operand type — as further members of that launch,
+ * slab sums included.  For products that are ready together but issued by different parts of the host code (the heads'
+ * first layers in the model's forward, the Gram matrices in the loss function).  igcn_gemm_rider_flush launches what
+ * nobody carried.  Operands and outputs must stay alive until the carrying launch. */
+int igcn_gemm_rider(void* stream, int n, const int64_t* table);
+int igcn_gemm_rider_flush(void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GO read-outs: per-node linear + BatchNorm1d(#nodes) + ReLU, fused — go_model.py:117-121,254
