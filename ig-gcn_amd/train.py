@@ -358,7 +358,9 @@ def _losses_batched(model, data, lam, hp, temperature):
     pre = {}
 
     def queue_gram(z):
+        # (a bf16 heads launch does not carry fp32 products: the batched launch behind the forward stays the better one)
         if z.is_cuda and z.dtype == torch.float32 and z.is_contiguous() and z.shape[0] % 2 == 0 \
+                and not getattr(model, "bf16_transforms", False) \
                 and os.environ.get("IGCN_NO_GRAM_RIDER", "0") != "1" and os.environ.get("IGCN_NO_GEMM_GROUPS", "0") != "1":
             pre["gram"], pre["hold"] = ops.gram_rider(z.detach(), 2)
 
