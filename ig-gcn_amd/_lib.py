@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 413        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 414        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -90,6 +90,7 @@ SIGNATURES = {
     "igcn_gemm_f32_grouped": (I, [I, P, P]),
     "igcn_gemm_rider": (I, [P, I, P]),
     "igcn_gemm_rider_flush": (I, [P]),
+    "igcn_rider_cancel": (I, [P]),
     "igcn_node_linear_bn_scratch_floats": (Z, [I, I, I]),
     "igcn_node_linear_bn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, I, F, F, P, P, P, P, P, P]),
     "igcn_node_linear_bn_bwd_scratch_floats": (Z, [I, I, I, I, I]),

@@ -773,6 +773,17 @@ static std::vector<int64_t> gemm_riders_take(hipStream_t st, int room, bool bf16
   return r;
 }
 
+void igcn_rider_dropout_cancel(hipStream_t st);         // plan.hip
+// Forget every rider still waiting on the stream (mask job and products) WITHOUT launching it: for the start of a step
+// that may follow one which failed between queueing a rider and the launch that would have carried it — the buffers it
+// points at may be gone.
+extern "C" int igcn_rider_cancel(void* stream) {
+  igcn_rider_dropout_cancel((hipStream_t)stream);
+  std::lock_guard<std::mutex> lk(g_gr_mutex);
+  g_gemm_riders.erase((hipStream_t)stream);
+  return IGCN_OK;
+}
+
 extern "C" int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream);
 extern "C" int igcn_gemm_rider_flush(void* stream) {
   std::vector<int64_t> r;

@@ -1099,6 +1099,13 @@ extern "C" int igcn_rider_flush(void* stream) {
   return igcn_dropout_launch(job, (hipStream_t)stream);
 }
 
+// forget a job that is still waiting (a step that failed between queueing it and the launch that would have carried it:
+// its output buffer may be gone — it must not be launched by a later flush)
+void igcn_rider_dropout_cancel(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_rider_mutex);
+  g_riders.erase(st);
+}
+
 static bool rider_take(hipStream_t st, DropJob& job) {
   std::lock_guard<std::mutex> lk(g_rider_mutex);
   auto it = g_riders.find(st);

@@ -101,7 +101,11 @@ class Gene_ontology_network(nn.Module):
         if not (self.training and self._dropout_enabled):
             return
         self._predrawn = None
-        res = self._dropout_masks(b, dev, extra, groups, ride=True)
+        try:
+            res = self._dropout_masks(b, dev, extra, groups, ride=True)
+        except Exception:
+            self._predrawn = None
+            raise
         key = (int(b), str(dev), tuple((tuple(s), float(p)) for s, p in extra), int(groups))
         self._predrawn = (key, res, self._counters_done)
 

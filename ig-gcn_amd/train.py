@@ -364,8 +364,14 @@ def _losses_batched(model, data, lam, hp, temperature):
                 and os.environ.get("IGCN_NO_GRAM_RIDER", "0") != "1" and os.environ.get("IGCN_NO_GEMM_GROUPS", "0") != "1":
             pre["gram"], pre["hold"] = ops.gram_rider(z.detach(), 2)
 
-    scores, x_hat, out_z, out_lin, lin_f, reg = model._forward_grouped(data, temperature, dev, (False, True),
-                                                                       split=False, raw_scores=True, on_out_z=queue_gram)
+    try:
+        scores, x_hat, out_z, out_lin, lin_f, reg = model._forward_grouped(data, temperature, dev, (False, True),
+                                                                           split=False, raw_scores=True,
+                                                                           on_out_z=queue_gram)
+    except BaseException:
+        if pre:
+            call("igcn_rider_cancel", stream_ptr())      # the queued products must not outlive their buffers
+        raise
     if pre:
         call("igcn_gemm_rider_flush", stream_ptr())      # (a forward whose heads took another route: launch them now)
     # the Gram terms and the mask regulariser arrive as un-reduced partial sums and the class scores raw: the loss
@@ -611,6 +617,7 @@ class GraphedTrainStep:
     def _fwd_bwd(self, rebuild=True):
         self.opt.zero_grad()
         self.data._igcn_plan = self.plan
+        call("igcn_rider_cancel", stream_ptr())         # (leftovers of a step that failed half way must never launch)
         rider = (rebuild and _batched(self.model) and hasattr(self.model, "predraw_dropout")
                  and os.environ.get("IGCN_NO_DROPOUT_RIDER", "0") != "1")
         if rider:

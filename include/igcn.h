@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 413
+#define IGCN_ABI_VERSION 414
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -477,6 +477,9 @@ int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream);
  * nobody carried.  Operands and outputs must stay alive until the carrying launch. */
 int igcn_gemm_rider(void* stream, int n, const int64_t* table);
 int igcn_gemm_rider_flush(void* stream);
+/* Forget every rider still waiting on the stream (mask job, products) WITHOUT launching it — at the start of a step that
+ * may follow one which failed between queueing a rider and its carrier (the buffers it points at may be gone). */
+int igcn_rider_cancel(void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GO read-outs: per-node linear + BatchNorm1d(#nodes) + ReLU, fused — go_model.py:117-121,254

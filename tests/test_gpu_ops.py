@@ -1942,6 +1942,17 @@ def test_dropout_masks_ride_in_the_plan_builds_launch(ops):
         ops.dropout_masks(sites, st_b, ride=True)                      # one job per stream
     call("igcn_rider_flush", stream_ptr())
     torch.cuda.synchronize()
+    # a job of a step that failed half way is FORGOTTEN, not launched (its buffers may be gone)
+    before = st_b.state.clone()
+    ops.dropout_masks(sites, st_b, cnt_b, 2, ride=True)
+    call("igcn_rider_cancel", stream_ptr())
+    plan0.rebuild(batch.edge_index)
+    call("igcn_rider_flush", stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(st_b.state, before) and int(cnt_b[0]) == 7
+    ops.dropout_masks(sites, st_b, ride=True)                          # (the stream takes a new job)
+    call("igcn_rider_flush", stream_ptr())
+    torch.cuda.synchronize()
 
 
 def test_grad_fan_sums_the_consumers_gradients_in_one_launch(ops):
