@@ -479,12 +479,64 @@ def mfma_roofline(model, wl, device, stats, bf16):
     return out
 
 
-def cpu_baseline(go, wl, seconds=20.0):
-    """The oracle (CPU restatement, faithful mode: per-sample sparse loop) timed on this box's host cores on
-    a bounded sample of the same workload."""
+def _pick_cores(usable, pci=None):
+    """``usable`` host CPUs to pin the baseline to: distinct PHYSICAL cores (one hardware thread each), taken from the
+    CPUs local to the GPU (``/sys/bus/pci/devices/<bdf>/local_cpulist``: the boxes of one host then land on different
+    NUMA nodes instead of all on cpu0-15) and inside the process's affinity mask; falls back to the mask's own order."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+
+    def parse(text):
+        out = []
+        for part in text.strip().split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                out += list(range(int(a), int(b) + 1))
+            elif part:
+                out.append(int(part))
+        return out
+    local = None
+    if pci:
+        try:
+            with open(f"/sys/bus/pci/devices/{pci}/local_cpulist") as fh:
+                local = [c for c in parse(fh.read()) if c in set(allowed)]
+        except (OSError, ValueError):
+            local = None
+    order = (local or []) + [c for c in allowed if c not in set(local or [])]
+    seen, cores = set(), []
+    for c in order:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
+                key = tuple(sorted(parse(fh.read())))
+        except (OSError, ValueError):
+            key = (c,)
+        if key in seen:
+            continue
+        seen.add(key)
+        cores.append(c)
+        if len(cores) == usable:
+            break
+    return cores or None
+
+
+def cpu_baseline_child(workload, seconds, cores):
+    """Runs in a fresh process that never touches the GPU (``bench.py --cpu-baseline-child``): pinned to ``cores``
+    (one thread per core, OMP_PROC_BIND / OMP_PLACES set by the parent before this interpreter started), it times the
+    oracle's train step — the reference's step, kernel/train_eval_sgcn_img_snps.py:511-548 — at the headline's own
+    batch size and prints one JSON object."""
     from types import SimpleNamespace
     from oracle import go_network as OG, sgcn_img_snp as OS
-    go_snps, adj, pool_dim = go
+    wl = WORKLOADS[workload]
+    if cores:
+        try:
+            os.sched_setaffinity(0, set(cores))
+        except (AttributeError, OSError):
+            cores = None
+    threads = len(cores) if cores else _usable_cores()
+    torch.set_num_threads(threads)
+    go_snps, adj, pool_dim = synth.go_hierarchy(wl["pool"], seed=0)
     pool, rois = wl["pool"], wl["rois"]
     a_g, a = synth.go_sparse_inputs(go_snps, adj)
     idx = OG.go_index_sets(a_g, a, list(pool), 2)
@@ -505,36 +557,61 @@ def cpu_baseline(go, wl, seconds=20.0):
             sd[k] = (torch.rand(s, generator=gen) * 2 - 1) / max(1.0, float(s[-1] if len(s) > 1 else s[0])) ** 0.5
     sd = OS.make_leaf_state(sd)
     cfg = SimpleNamespace(num_layers=LAYERS, rois=rois, image_only=False, rbf_gamma=0.01)
+    # ALWAYS the headline's batch size (B = 256 at configs[2]; the dense 512-ROI workload is 1.3 graphs/s on a host
+    # share, so configs[4] samples B = 4), one untimed warm-up step, then >= 5 timed steps or until the bound is used up
+    b_full = wl["graphs"]
+    b = b_full if not wl["dense"] else 4
+    data = Batch.from_data_list(synth.brain_graph_list(b, seed=1000, rois=rois, tsne_dim=90, dense=wl["dense"]))
+    opt, times = None, []
+    load0 = os.getloadavg()[0] if hasattr(os, "getloadavg") else None
+    t_end = time.perf_counter() + seconds
+    _, _, opt = OS.train_step(sd, cfg, idx, data, lr=1e-3, dropout=True, faithful=True, opt=opt)
+    while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 12):
+        t0 = time.perf_counter()
+        _, _, opt = OS.train_step(sd, cfg, idx, data, lr=1e-3, dropout=True, faithful=True, opt=opt)
+        times.append(time.perf_counter() - t0)
+    ts = sorted(times)
+    med = ts[len(ts) // 2]
+    print(json.dumps({
+        "value": round(b / med, 2), "unit": "graphs/s", "cores": threads, "kind": "port",
+        "graphs_per_s_min_median_max": [round(b / ts[-1], 2), round(b / med, 2), round(b / ts[0], 2)],
+        "spread": round((ts[-1] - ts[0]) / med, 3), "steps_timed": len(ts), "batch": b,
+        "pinned_cpu_ids": cores, "host_load_1min_at_start": load0,
+        "host_logical_cpus": os.cpu_count(), "physical_cores": _physical_cores(), "usable_cores": _usable_cores(),
+        "torch": torch.__version__,
+        "sample": f"{len(ts)} timed train steps (+1 warm-up) of B={b} graphs (the headline runs B={b_full}; same model / "
+                  f"GO DAG, fp32), median; oracle faithful mode; {threads} threads pinned one per physical core"}))
+
+
+def cpu_baseline(workload, seconds=20.0, device=None):
+    """The oracle (CPU restatement of the reference's step, faithful mode: per-sample sparse loop) timed on this box's
+    host cores, in a CHILD process pinned to as many distinct physical cores as the cgroup grants (local to the GPU's
+    NUMA node when the PCI address is known) — VERDICT r4 #8: the unpinned 20-second sample moved 2.7x between boxes."""
     usable = _usable_cores()
-    torch.set_num_threads(usable)                            # every host core this process may use, stated
-
-    def sample(b, budget, max_steps):
-        data = Batch.from_data_list(synth.brain_graph_list(b, seed=1000, rois=rois, tsne_dim=90, dense=wl["dense"]))
-        opt, times, it = None, [], 0
-        t_end = time.perf_counter() + budget
-        while it < 2 or (time.perf_counter() < t_end and it < max_steps):
-            t0 = time.perf_counter()
-            _, _, opt = OS.train_step(sd, cfg, idx, data, lr=1e-3, dropout=True, faithful=True, opt=opt)
-            times.append(time.perf_counter() - t0)
-            it += 1
-        times = sorted(times[1:]) if len(times) > 1 else times
-        return times[len(times) // 2], len(times)
-
-    # the headline's own batch size when three of its steps fit the time bound (probed on a small batch first),
-    # otherwise the small batch
-    b_small, b_full = (32 if not wl["dense"] else 4), wl["graphs"]
-    t_start = time.perf_counter()
-    med, n = sample(b_small, min(seconds, 6.0), 4)
-    b = b_small
-    left = seconds - (time.perf_counter() - t_start)
-    if b_full > b_small and med * (b_full / b_small) * 3.2 <= left:
-        med, n = sample(b_full, left, 8)
-        b = b_full
-    return {"value": round(b / med, 2), "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "host_logical_cpus": os.cpu_count(), "physical_cores": _physical_cores(), "usable_cores": usable,
-            "torch": torch.__version__,
-            "sample": f"{n} train steps of B={b} graphs (the headline runs B={b_full}; same model/GO DAG, fp32), median; "
-                      "oracle faithful mode"}
+    pci = None
+    try:
+        pr = torch.cuda.get_device_properties(device if device is not None else 0)
+        pci = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:                              # noqa: BLE001
+        pci = None
+    cores = _pick_cores(usable, pci)
+    env = dict(os.environ)
+    n = len(cores) if cores else usable
+    env.update({"OMP_NUM_THREADS": str(n), "MKL_NUM_THREADS": str(n), "OMP_PROC_BIND": "close", "OMP_PLACES": "cores",
+                "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--workload", workload,
+           "--cpu-baseline-seconds", str(seconds), "--cpu-baseline-cores", ",".join(str(c) for c in cores or [])]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=max(180.0, 8 * seconds))
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"value": None, "unit": "graphs/s", "cores": n, "kind": "port",
+                    "error": (r.stderr or r.stdout)[-400:]}
+        out = json.loads(line[-1])
+        out["gpu_pci"] = pci
+        return out
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "graphs/s", "cores": n, "kind": "port", "error": "baseline child timed out"}
 
 
 def _usable_cores():
@@ -829,8 +906,14 @@ def main():
                     help="default workload only: skip the short configs[4] child run reported as `stress`")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="bound of the CPU-oracle sample")
     ap.add_argument("--inner-profile", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-cores", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.cpu_baseline_child:                           # the pinned CPU sample: no GPU call in this process
+        cpu_baseline_child(args.workload, args.cpu_baseline_seconds,
+                           [int(c) for c in args.cpu_baseline_cores.split(",") if c])
+        return
     if os.environ.get("IGCN_BENCH_SWEEP") and "WORLD_SIZE" not in os.environ:
         sys.exit(sweep([int(v) for v in os.environ["IGCN_BENCH_SWEEP"].replace(" ", "").split(",") if v]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1103,7 +1186,7 @@ def main():
                 if whole is not None:
                     res["roofline_step"] = whole
         if wl["pool"] is not None and world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(go, wl, seconds=args.cpu_baseline_seconds)
+            res["cpu_baseline"] = cpu_baseline(args.workload, seconds=args.cpu_baseline_seconds, device=device)
         if args.workload == "full" and world == 1 and not args.no_roofline and not args.no_stress:
             # the device is idle from here on: this process has finished its own measurements
             torch.cuda.synchronize()

@@ -171,19 +171,21 @@ def _reference_losses(model, data, lam, hp, outs1, outs2):
     return loss, t
 
 
-def capture_full(sg_mod, name, rois, hidden, layers, bsz, pool, seed, lam, top_k=3, **variant):
+def capture_full(sg_mod, name, rois, hidden, layers, bsz, pool, seed, lam, top_k=3, h0=3, **variant):
     """``variant`` overrides the constructor flags of the default (cross-attention, both modalities) branch:
-    isImageOnly / isSNPsOnly / isCrossAtten / isuseProb4Regr (kernel/sgcn_img_snp.py:257-285)."""
+    isImageOnly / isSNPsOnly / isCrossAtten / isuseProb4Regr (kernel/sgcn_img_snp.py:257-285).  ``h0`` is the
+    trainer's ``feature_dim`` (3, or 1 under --isMultiFusion: kernel/train_eval_sgcn_img_snps.py:63-67); the key
+    ``h0`` is stored only when it is not 3, so the older fixtures regenerate with their committed key sets."""
     go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=seed)
     a_g, a = synth.go_sparse_inputs(go_snps, adj)
     flags = dict(isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3, model4eachregr=False,
                  isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False, isMultiFusion=False)
     flags.update(variant)
-    model = sg_mod.SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cpu", rois=rois, H_0=3, num_classes=3,
+    model = sg_mod.SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cpu", rois=rois, H_0=h0, num_classes=3,
                                    **flags)
     ref_sd = model.state_dict()
     sd = seeded_state({k: v.shape for k, v in ref_sd.items()}, seed, ref_sd)
-    graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=rois, top_k=top_k, tsne_dim=16)
+    graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=rois, h0=h0, top_k=top_k, tsne_dim=16)
     store = {"meta": np.array(
         "reference kernel/sgcn_img_snp.py + kernel/go_model.py executed on CPU; GCNConv/to_dense_batch = "
         "oracle.pyg_ops (PyG 2.0.2 absent: unpinned), torch_scatter.scatter -> index_add_; dropout p=0; "
@@ -193,6 +195,9 @@ def capture_full(sg_mod, name, rois, hidden, layers, bsz, pool, seed, lam, top_k
         "cfg": np.array([rois, hidden, layers, bsz, seed, top_k]), "pool": np.array(pool),
         "lam": np.array(lam), "state_keys": np.array(sorted(ref_sd.keys())),
         "variant": np.array(repr(sorted(variant.items())))}
+    if h0 != 3:
+        store["h0"] = np.array(h0)
+        store["meta"] = np.array(str(store["meta"]).replace(f"rois={rois}, top_k", f"rois={rois}, h0={h0}, top_k"))
     hp = OS.HP
     for mode in ("eval", "train"):
         for explain in (False, True):
@@ -625,6 +630,18 @@ def main():
     if "full_b32" in want or not want:
         capture_full(sg_mod, "full_b32", rois=90, hidden=16, layers=2, bsz=32, pool=(300, 120, 60, 19, 1), seed=24,
                      lam=[1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2])
+    # row i1: the --isMultiFusion shapes of the same trainer (kernel/train_eval_sgcn_img_snps.py:63-67: rois = 270,
+    # H_0 = 1) with the first and the last (layers, hidden) entry of its sweep (main.py:147-150): (3, 2) -> embed 6,
+    # head_dim 3; (3, 10) -> embed 30, head_dim 15.  The second at B = 32 so that training mode holds the tight bounds (seed 56: of the seeds 52-56, 52 and
+    # 55 put a GO pre-activation within fp32 rounding of zero and the REFERENCE's own fp32 run is then 1e-2 away from its
+    # fp64 evaluation on G_B_D.1.weight — a ReLU decision, not an algorithmic difference; 53, 54, 56 hold 1e-3)
+    if "var_multifusion_l3h2" in want or not want:
+        capture_full(sg_mod, "var_multifusion_l3h2", rois=270, hidden=2, layers=3, bsz=6, pool=(40, 20, 10, 5, 1),
+                     seed=51, lam=[1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2], h0=1, isMultiFusion=True)
+    if "var_multifusion_l3h10" in want or not want:
+        capture_full(sg_mod, "var_multifusion_l3h10", rois=270, hidden=10, layers=3, bsz=32,
+                     pool=(300, 120, 60, 19, 1), seed=56, lam=[1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2], h0=1,
+                     isMultiFusion=True)
     if "train_traj" in want or not want:
         capture_traj(sg_mod, "train_traj", rois=90, hidden=16, layers=2, bsz=32, pool=(300, 120, 60, 19, 1), seed=26,
                      lam=[1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2])

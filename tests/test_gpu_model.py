@@ -20,10 +20,16 @@ TOL = {"eval": 1e-4, "train": 1e-3}
 GTOL = {"eval": 1e-3, "train": 3e-2}
 NAMES = ["logp", "x_hat", "out_z", "out_lin", "lin_f", "reg"]
 FULL = ["full_tiny", "full_r90", "full_l3", "full_b32", "var_image_only", "var_image_only_noprob", "var_snps_only",
-        "var_fusion_noprob", "var_graph_pool"]
+        "var_fusion_noprob", "var_graph_pool", "var_multifusion_l3h2", "var_multifusion_l3h10"]
 # the *_b32 fixtures were captured from the reference at B=32, where training-mode BatchNorm no longer amplifies fp32
 # rounding: there the north-star bounds hold in TRAINING mode too — 1e-4 on outputs, 1e-3 on gradients
-B32 = ("go_b32", "full_b32")
+B32 = ("go_b32", "full_b32", "var_multifusion_l3h10")
+# var_multifusion_l3h10 (B = 32, rois = 270, hidden 10): outputs at 1e-4 like the other B = 32 fixtures; gradients at
+# 3e-3 — one GO read-out pre-activation of that fixture lies within fp32 rounding of zero and the HIP path decides it
+# unlike the reference's CPU run (d w_att_in.1.weight 1.2e-3 away; seeds 53 / 54 of the same shape: 2.5e-3 / 1.2e-3,
+# seeds 52 / 55: the reference's own fp32 run is 1e-2 from its fp64 evaluation).  The same shape holds 1e-3 against the
+# fp64 oracle once those decisions are imposed: test_train_mode_multifusion_vs_oracle
+GT_FIXTURE = {"var_multifusion_l3h10": 3e-3}
 
 
 def tol(name, mode):
@@ -31,7 +37,7 @@ def tol(name, mode):
 
 
 def gtol(name, mode):
-    return 1e-3 if name in B32 else GTOL[mode]
+    return GT_FIXTURE.get(name, 1e-3) if name in B32 else GTOL[mode]
 
 
 def grad_floor(wg, k, floor):
@@ -109,7 +115,8 @@ def _full_model(store):
                  isImageOnly=False, isSNPsOnly=False)
     if "variant" in store:              # var_* fixtures: the other heads of forward() (sgcn_img_snp.py:257-285)
         flags.update(dict(ast.literal_eval(str(store["variant"]))))
-    model = SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=3, num_classes=3,
+    h0 = int(store["h0"]) if "h0" in store else 3       # 1 under --isMultiFusion (var_multifusion_*: row i1)
+    model = SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=h0, num_classes=3,
                             **flags).cuda()
     ref_keys = sorted(store["state_keys"].tolist())
     assert sorted(model.state_dict().keys()) == ref_keys          # checkpoints interchange with the reference
@@ -117,7 +124,7 @@ def _full_model(store):
     model.load_state_dict(sd)
     model._dropout_enabled = False
     model.go_network._dropout_enabled = False
-    graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=rois, top_k=top_k, tsne_dim=16)
+    graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=rois, h0=h0, top_k=top_k, tsne_dim=16)
     return model, graphs, seed
 
 
@@ -169,8 +176,10 @@ def test_train_step_vs_reference_golden(golden, name, batched):
     # OrthogonalConstraint: the reference sums the squares of an (R*D) x (R*D) fp32 matrix (:198-205), which at
     # R*D = 2880 is itself ~1e-3 away from the exact value; the Gram form here is exact to 1e-7 (checked against an
     # fp64 evaluation of the reference's own formula below), so this one term gets the reference's rounding as slack
+    # (--isMultiFusion: R*D = 8100, the reference's fp32 sum is 9e-3 from its exact value there)
     ref_orth = float(store["step/term/orth"])
-    slack = 2e-3 * abs(ref_orth)
+    rd = int(store["cfg"][0]) * int(store["cfg"][1]) * int(store["cfg"][2])
+    slack = (2e-3 if rd <= 3000 else 2e-2) * abs(ref_orth)
     assert abs(float(loss) - ref_loss) <= 2e-4 * max(1.0, abs(ref_loss)) + slack
     for k, v in terms.items():
         ref = float(store[f"step/term/{k}"])
@@ -184,7 +193,7 @@ def test_train_step_vs_reference_golden(golden, name, batched):
     loss.backward()
     params = dict(model.named_parameters())
     wg = golden_group(store, "step/grad")
-    gt = 1e-3 if name in B32 else 1e-2
+    gt = GT_FIXTURE.get(name, 1e-3) if name in B32 else 1e-2
     assert_matches(data.x.grad, wg.pop("data.x"), gt, "grad data.x")
     grads = {}
     for k, w in wg.items():
@@ -258,7 +267,8 @@ def test_full_model_vs_oracle_larger(bsz, pool, explain):
 
 
 def train_mode_vs_oracle(monkeypatch, rois, pool, bsz, dense=False, bf16=False, maps=("sparse", "default"),
-                         graph_seed=78, go_seed=1, tol=1e-4, gtol=1e-3, max_flips=40, band=2e-5, formulations=(True, False)):
+                         graph_seed=78, go_seed=1, tol=1e-4, gtol=1e-3, max_flips=40, band=2e-5, formulations=(True, False),
+                         layers=2, hidden=16, h0=3):
     """TRAINING mode (batch statistics in every BatchNorm, dropout off) of the HIP model against the fp64 oracle: the
     seven loss terms of train() at ``tol`` and every gradient at ``gtol``, for the step formulations ``formulations``
     (True: both passes as one 2B-sample sweep; False: two forward() calls).  Returns the number of imposed ReLU
@@ -279,18 +289,18 @@ def train_mode_vs_oracle(monkeypatch, rois, pool, bsz, dense=False, bf16=False, 
     lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
     go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=go_seed)
     a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
-    model = SGCN_GCN_IMGSNP(2, 16, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=3, num_classes=3,
+    model = SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=h0, num_classes=3,
                             isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3,
                             isuseProb4Regr=True, isImageOnly=False, isSNPsOnly=False, bf16_transforms=bf16).cuda().train()
     sd = seeded_state({k: v.shape for k, v in model.state_dict().items()}, 5)
     model.load_state_dict(sd)
     for m in (model, model.go_network):
         m._dropout_enabled = False
-    graphs = synth.brain_graph_list(bsz, seed=graph_seed, rois=rois, tsne_dim=16, dense=dense)
+    graphs = synth.brain_graph_list(bsz, seed=graph_seed, rois=rois, h0=h0, tsne_dim=16, dense=dense)
     # oracle, fp64, training mode
     a_g_c, a_c = synth.go_sparse_inputs(go_snps, adj)
     idx = OG.go_index_sets(a_g_c, a_c, list(pool), 2)
-    cfg = SimpleNamespace(num_layers=2, rois=rois, image_only=False, rbf_gamma=0.01)
+    cfg = SimpleNamespace(num_layers=layers, rois=rois, image_only=False, rbf_gamma=0.01)
     n0, n1 = sum(pool), sum(pool[1:])
 
     def hip_run(batched):
@@ -340,9 +350,13 @@ def train_mode_vs_oracle(monkeypatch, rois, pool, bsz, dense=False, bf16=False, 
         hb = [per_pass("BatchNorm1dGrouped", k) for k in range(2)]
         lp = [per_pass("LinearPair", 0, lambda o, i=i: o[i]) for i in range(2)]
         for p_ in range(2):
-            base = 14 * p_
-            forced[base + 0] = xc[p_][:, :16] > 0
-            forced[base + 1] = xc[p_][:, 16:] > 0
+            # oracle ReLU sites per pass: ``layers`` GCNConv layers, then twelve more (2 encoder LayerNorms, two read-outs,
+            # 2 decoder LayerNorms, gene decoding, 2 latent BatchNorms, out_proj, 2 head layers)
+            base = (12 + layers) * p_
+            fp_ = xc[p_].shape[1] // layers               # hidden widths off the kernel grid come back zero-padded
+            for l_ in range(layers):
+                forced[base + l_] = xc[p_][:, l_ * fp_:l_ * fp_ + hidden] > 0
+            base += layers - 2
             # encoder LayerNorm sites: the HIP kernel returns the POOLED activations (nodes >= pool[j]); the nodes it
             # drops feed nothing (go_model.py:251), so their decisions are ignored
             for j, (n_in, drop) in enumerate(((n0, pool[0]), (n1, pool[1]))):
@@ -400,6 +414,17 @@ def test_train_mode_losses_and_gradients_at_default_dims_vs_oracle(monkeypatch):
     against the fp64 oracle, both step formulations."""
     flips = train_mode_vs_oracle(monkeypatch, 90, (1800, 800, 300, 99, 1), 32)
     assert flips > 0                          # the mechanism is exercised: B.0 has a node that close to zero (of ~3.3 M)
+
+
+@pytest.mark.parametrize("layers,hidden", [(3, 2), (3, 10)])
+def test_train_mode_multifusion_vs_oracle(monkeypatch, layers, hidden):
+    """Row i1 in TRAINING mode: rois = 270, H_0 = 1 (kernel/train_eval_sgcn_img_snps.py:63-67) with the first and the
+    last entry of the --isMultiFusion sweep (main.py:147-150), B = 32, a 500-node GO DAG: the seven loss terms at 1e-4,
+    every gradient at 1e-3 against the fp64 oracle with the HIP path's ReLU decisions imposed inside the 2e-5 band (the
+    reference-captured fixture of the same shape, var_multifusion_l3h10, sits 1.2e-3 away on one GO gradient because
+    fp32 decides such a pre-activation differently — see test_full_model_vs_reference_golden's bound for it)."""
+    train_mode_vs_oracle(monkeypatch, 270, (300, 120, 60, 19, 1), 32, maps=("default",), layers=layers, hidden=hidden,
+                         h0=1)
 
 
 # ---- the image-only sibling SGCN_GCN (kernel/sgcn.py:272-388; BASELINE configs[0]/[1]) -------------------------
@@ -899,6 +924,76 @@ def test_sweep_widths_off_the_kernel_grid_vs_oracle(layers, hidden, fused):
         if sdo[k].grad is None:
             continue
         assert_matches(params[k].grad, sdo[k].grad.numpy(), 5e-3, "grad " + k, floor=1e-6)
+
+
+MULTIFUSION = [(3, 2), (2, 3), (4, 3), (2, 5), (3, 10)]        # main.py:147-150 (layers, hiddens)
+
+
+@pytest.mark.parametrize("layers,hidden", MULTIFUSION)
+def test_multifusion_sweep_vs_oracle(layers, hidden):
+    """Row i1: every (layers, hidden) entry of the --isMultiFusion sweep (main.py:147-150) at the shapes that flag gives
+    the trainer (kernel/train_eval_sgcn_img_snps.py:63-67: rois = 270, H_0 = 1) — hidden 2 / 3 padded to 4, 5 to 8, 10
+    to 16; head_dim 3 / 6 / 5 / 15; 270 queries — eval forward (isExplain=True) and every gradient against the fp64
+    oracle, then one captured train step (both passes batched) against the eager step."""
+    from igcn_amd import synth
+    from igcn_amd.data import Batch
+    from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
+    from igcn_amd.train import FlatAdam, GraphedTrainStep, train_step
+    from oracle import go_network as OG, sgcn_img_snp as OS
+    pool = (60, 30, 20, 9, 1)
+    rois = 270
+    go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=1)
+    a_g, a = synth.go_sparse_inputs(go_snps, adj, "cuda")
+
+    def build():
+        m = SGCN_GCN_IMGSNP(layers, hidden, a_g, a, pool_dim, 32, "cuda", rois=rois, H_0=1, num_classes=3,
+                            isSoftSimilarity=True, rbf_gamma=0.01, isCrossAtten=True, num_regr=3, isuseProb4Regr=True,
+                            isImageOnly=False, isSNPsOnly=False, isMultiFusion=True).cuda()
+        m.load_state_dict(seeded_state({k: v.shape for k, v in m.state_dict().items()}, 6))
+        return m
+    model = build().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    graphs = synth.brain_graph_list(8, seed=78, rois=rois, h0=1, tsne_dim=16)
+    data = Batch.from_data_list(graphs).to("cuda")
+    outs = model(data, None, "cuda", isExplain=True)
+    assert outs[2].shape == (8, rois * layers * hidden)
+    cot = _probe(outs, 9)
+    sum((o * c.cuda()).sum() for o, c in zip(outs, cot)).backward()
+    a_g_c, a_c = synth.go_sparse_inputs(go_snps, adj)
+    idx = OG.go_index_sets(a_g_c, a_c, list(pool), 2)
+    sdo = OS.make_leaf_state(sd, dtype=torch.float64)
+    dcpu = Batch.from_data_list(graphs)
+    dcpu.x = dcpu.x.double().requires_grad_(True)
+    dcpu.edge_attr, dcpu.snps_feat = dcpu.edge_attr.double(), dcpu.snps_feat.double()
+    cfg = SimpleNamespace(num_layers=layers, rois=rois, image_only=False, rbf_gamma=0.01)
+    ref = OS.model_forward(sdo, cfg, idx, dcpu, True, training=False)
+    sum((o * c.double()).sum() for o, c in zip(ref, cot)).backward()
+    for n, o, r in zip(NAMES, outs, ref):
+        assert_matches(o, r.detach().numpy(), 1e-4, n)
+    assert_matches(data.x.grad, dcpu.x.grad.numpy(), 3e-3, "grad data.x")
+    params = dict(model.named_parameters())
+    for k in OS.trainable_keys(sdo):
+        if sdo[k].grad is None:
+            continue
+        assert_matches(params[k].grad, sdo[k].grad.numpy(), 5e-3, "grad " + k, floor=1e-6)
+    # the captured step on these shapes = the eager step (dropout off: the two draw different masks otherwise)
+    lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
+    res = []
+    for graphed in (False, True):
+        m = build().train()
+        m._dropout_enabled = m.go_network._dropout_enabled = False
+        opt = FlatAdam(m.parameters(), lr=1e-3)
+        d = Batch.from_data_list(graphs).to("cuda")
+        if graphed:
+            loss = GraphedTrainStep(m, opt, d, lam)()
+        else:
+            loss = train_step(m, opt, d, lam)
+        torch.cuda.synchronize()
+        res.append((float(loss), {k: v.detach().clone() for k, v in m.state_dict().items()}))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * max(1.0, abs(res[0][0]))
+    for k, v in res[0][1].items():
+        if v.dtype.is_floating_point:
+            assert_matches(res[1][1][k], v.cpu().numpy(), 2.5e-3, "after step " + k, floor=1.0)
 
 
 def test_graphed_step_load_takes_the_new_batch_s_graph_offsets():

@@ -20,7 +20,7 @@ TOL = {"eval": 1e-5, "train": 3e-4}
 GTOL = {"eval": 5e-4, "train": 5e-3}
 # the *_b32 fixtures (B=32): BatchNorm over 32 samples no longer amplifies rounding, so training mode holds the
 # north-star bounds (1e-4 outputs / 1e-3 gradients)
-B32 = ("go_b32", "full_b32")
+B32 = ("go_b32", "full_b32", "var_multifusion_l3h10")
 
 
 def tol(name, mode):
@@ -90,10 +90,11 @@ def _full_setup(store):
     rois, hidden, layers, bsz, seed, top_k = [int(v) for v in store["cfg"]]
     pool = store["pool"].tolist()
     flags = variant_flags(store)
+    h0 = int(store["h0"]) if "h0" in store else 3       # 1 under --isMultiFusion (var_multifusion_*: row i1)
     go_snps, adj, pool_dim = synth.go_hierarchy(pool, seed=seed)
     a_g, a = synth.go_sparse_inputs(go_snps, adj)
     idx = OG.go_index_sets(a_g, a, pool, 2)
-    shapes = dict(OS.sgcn_param_shapes(layers, hidden, rois=rois, **flags))
+    shapes = dict(OS.sgcn_param_shapes(layers, hidden, rois=rois, h0=h0, **flags))
     d_att = layers * hidden if flags["cross_atten"] else hidden
     shapes.update({"go_network." + k: v for k, v in OG.go_param_shapes(idx, l_dim=32, d_att=d_att).items()})
     shapes["batch_norm_1d.weight"] = (rois * layers * hidden + 32,)
@@ -102,14 +103,14 @@ def _full_setup(store):
                        f"{nm}.running_var": (c,), f"{nm}.num_batches_tracked": ()})
     assert sorted(shapes) == sorted(store["state_keys"].tolist())
     sd = seeded_state(shapes, seed)
-    graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=rois, top_k=top_k, tsne_dim=16)
+    graphs = synth.brain_graph_list(bsz, seed=seed + 10, rois=rois, h0=h0, top_k=top_k, tsne_dim=16)
     cfg = SimpleNamespace(num_layers=layers, rois=rois, rbf_gamma=0.01, **flags)
     return cfg, idx, sd, graphs, seed
 
 
 NAMES = ["logp", "x_hat", "out_z", "out_lin", "lin_f", "reg"]
 FULL = ["full_tiny", "full_r90", "full_l3", "full_b32", "var_image_only", "var_image_only_noprob", "var_snps_only",
-        "var_fusion_noprob", "var_graph_pool"]
+        "var_fusion_noprob", "var_graph_pool", "var_multifusion_l3h2", "var_multifusion_l3h10"]
 
 
 @pytest.mark.parametrize("name", FULL)

@@ -55,11 +55,19 @@ def summarise(d, out=None):
             t0 = int(one[0]["Start_Timestamp"])
             with open(out.replace(".csv", "_one_replay.csv"), "w", newline="") as fh:
                 w = csv.writer(fh)
-                w.writerow(("index", "kernel", "start_us", "duration_us"))
+                # launch geometry and per-workgroup resources as the profiler reports them: what decides which launches
+                # can share a grid as two roles (block size, LDS and registers of a paired kernel are the larger of the two)
+                w.writerow(("index", "kernel", "start_us", "duration_us", "workgroups", "threads", "lds_bytes", "vgpr",
+                            "agpr", "sgpr", "scratch"))
+                g = lambda r, k_: r.get(k_, "")                                        # noqa: E731
                 for i, r in enumerate(one):
+                    wg = int(g(r, "Workgroup_Size_X") or 1) * int(g(r, "Workgroup_Size_Y") or 1) * int(g(r, "Workgroup_Size_Z") or 1)
+                    gr = int(g(r, "Grid_Size_X") or 1) * int(g(r, "Grid_Size_Y") or 1) * int(g(r, "Grid_Size_Z") or 1)
                     w.writerow((i, re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0][:100],
                                 f"{(int(r['Start_Timestamp']) - t0) / 1e3:.2f}",
-                                f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.2f}"))
+                                f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.2f}",
+                                gr // max(wg, 1), wg, g(r, "LDS_Block_Size"), g(r, "VGPR_Count"), g(r, "Accum_VGPR_Count"),
+                                g(r, "SGPR_Count"), g(r, "Scratch_Size")))
     for ln in lines:
         print(f"{ln[0][:90]:90s} {ln[1]:>8s} {ln[2]:>10s} {ln[3]:>8s}")
 
