@@ -846,12 +846,19 @@ def self_launch(n):
 
 
 def sweep(ns):
-    """IGCN_BENCH_SWEEP="1,2,4,8": one invocation, one result line per N.  Every N is a fresh CHILD process of this
-    script started before this process has made any GPU call (the child self-launches its ranks); the N = 1 value is
-    handed to the larger runs, whose lines then carry ``weak_scaling_efficiency_vs_n1`` = value_N / (N * value_1)."""
+    """IGCN_BENCH_SWEEP="1,2,4,8": one invocation, result lines per N.  Every run is a fresh CHILD process of this script
+    started before this process has made any GPU call (the child self-launches its ranks); the N = 1 value is handed to
+    the larger runs, whose lines then carry ``weak_scaling_efficiency_vs_n1`` = value_N / (N * value_1).
+
+    At N > 1 EVERY gradient-exchange form is run, one child each, so that a single hardware run says which to keep
+    (VERDICT r4 #5): ``two_graphs`` = [zero_grad .. backward + pack] graph -> igcn_comm_allreduce -> [Adam] graph (the
+    default), ``in_graph`` = one graph with the collective captured (IGCN_COMM_IN_GRAPH=1; the ranks agree on it through
+    a MIN-reduced flag and fall back together).  The line of each child carries ``exchange_form``; a child that hangs is
+    killed after IGCN_BENCH_SWEEP_TIMEOUT seconds (default 600) and only loses its own line."""
     env = dict(os.environ)
     env.pop("IGCN_BENCH_SWEEP")
     n1, rc = None, 0
+    tmo = float(os.environ.get("IGCN_BENCH_SWEEP_TIMEOUT", "600"))
     for n in ns:
         argv = [a for a in sys.argv[1:]]
         if "--gpus" in argv:
@@ -863,18 +870,29 @@ def sweep(ns):
             cmd += [f for f in ("--no-roofline", "--no-cpu-baseline", "--no-pipeline") if f not in argv]
         if n1 is not None:
             env["IGCN_BENCH_N1_VALUE"] = str(n1)
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
-        if r.returncode != 0 or not lines:
-            print(f"[bench] sweep: N={n} failed (rc={r.returncode})", file=sys.stderr)
-            rc = rc or r.returncode or 4
-            continue
-        line = json.loads(lines[-1])
-        if n == 1:
-            n1 = line["value"]
-        elif n1 is not None and "weak_scaling_efficiency_vs_n1" not in line:
-            line["weak_scaling_efficiency_vs_n1"] = round(line["value"] / (n * n1), 4)
-        print(json.dumps(line), flush=True)
+        forms = [("single", None)] if n == 1 else [("two_graphs", "0"), ("in_graph", "1")]
+        for form, in_graph in forms:
+            cenv = dict(env)
+            if in_graph is not None:
+                cenv["IGCN_COMM_IN_GRAPH"] = in_graph
+            try:
+                r = subprocess.run(cmd, env=cenv, stdout=subprocess.PIPE, text=True, timeout=tmo)
+            except subprocess.TimeoutExpired:
+                print(f"[bench] sweep: N={n} form={form} timed out after {tmo:.0f} s", file=sys.stderr)
+                rc = rc or 5
+                continue
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+            if r.returncode != 0 or not lines:
+                print(f"[bench] sweep: N={n} form={form} failed (rc={r.returncode})", file=sys.stderr)
+                rc = rc or r.returncode or 4
+                continue
+            line = json.loads(lines[-1])
+            line["exchange_form"] = form
+            if n == 1:
+                n1 = line["value"]
+            elif n1 is not None and "weak_scaling_efficiency_vs_n1" not in line:
+                line["weak_scaling_efficiency_vs_n1"] = round(line["value"] / (n * n1), 4)
+            print(json.dumps(line), flush=True)
     return rc
 
 

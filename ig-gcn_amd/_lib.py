@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 414        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 416        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -91,6 +91,7 @@ SIGNATURES = {
     "igcn_gemm_rider": (I, [P, I, P]),
     "igcn_gemm_rider_flush": (I, [P]),
     "igcn_rider_cancel": (I, [P]),
+    "igcn_stream_pending": (I, [P]),
     "igcn_node_linear_bn_scratch_floats": (Z, [I, I, I]),
     "igcn_node_linear_bn_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, I, F, F, P, P, P, P, P, P]),
     "igcn_node_linear_bn_bwd_scratch_floats": (Z, [I, I, I, I, I]),
@@ -104,6 +105,9 @@ SIGNATURES = {
                                          I, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_bn1d_fwd": (I, [I, I, I, P, P, P, P, P, I, F, F, I, P, P, P, P, P]),
     "igcn_bn1d_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_bn1d_fwd_supported": (I, [I, I]),
+    "igcn_bn1d_fwd_slabs": (I, [I, I, I, P, I, P, P, P, P, P, I, F, F, I, P, P, P, P, P]),
+    "igcn_gemm_effective_split": (I, [L, I]),
     "igcn_dropout_state_words": (I, []),
     "igcn_dropout_max_segments": (I, []),
     "igcn_dropout_masks": (I, [L, I, P, P, P, P, I, P, L, P]),

@@ -603,10 +603,13 @@ static int gemm_launch(bool bf16, int64_t M, int64_t N, int64_t K, const float* 
                        int split_k, float* scratch, void* stream) {
   const char* nm = bf16 ? "gemm_bf16" : "gemm_f32";
   const bool final_grad = (act & 0x100) != 0;     // the output is a parameter gradient: its split-K sum may be deferred
+  const bool leave_slabs = (act & 0x200) != 0;    // a consumer sums the slabs itself (igcn_bn1d_fwd_slabs): no sum launch
   act &= 0xff;
   IGCN_REQUIRE(M > 0 && N > 0 && K >= 0 && split_k >= 1, "%s: bad sizes M=%lld N=%lld K=%lld split=%d", nm,
                (long long)M, (long long)N, (long long)K, split_k);
   IGCN_REQUIRE(split_k == 1 || scratch != nullptr, "%s: split_k>1 needs scratch", nm);
+  IGCN_REQUIRE(!leave_slabs || (bias == nullptr && act == 0 && !final_grad && ldc == N),
+               "%s: act | 0x200 (leave the slabs) takes no bias / activation / deferral and a dense C", nm);
   hipStream_t st = (hipStream_t)stream;
   if (split_k > K / G_BK) split_k = (int)(K / G_BK > 0 ? K / G_BK : 1);
   int64_t kps = igcn_cdiv(igcn_cdiv(K, split_k), G_BK) * G_BK;
@@ -637,7 +640,18 @@ static int gemm_launch(bool bf16, int64_t M, int64_t N, int64_t K, const float* 
     launch_f32(bn, vw, grid, st, g);
   }
   IGCN_CHECK_LAUNCH(nm);
+  if (leave_slabs) return IGCN_OK;                // igcn_gemm_effective_split(K, split_k) slabs in scratch (1: C is final)
   return gemm_sum_slabs(split_k, final_grad, M, N, scratch, bias, C, ldc, act, st);
+}
+
+// the number of K-slices a product asked to split `split_k` ways really runs in (whole 32-deep steps per slice): what a
+// caller that sums the slabs itself (act | 0x200) has to read
+extern "C" int igcn_gemm_effective_split(int64_t K, int split_k) {
+  if (split_k < 1) split_k = 1;
+  if (split_k > K / G_BK) split_k = (int)(K / G_BK > 0 ? K / G_BK : 1);
+  int64_t kps = igcn_cdiv(igcn_cdiv(K, split_k), G_BK) * G_BK;
+  if (kps == 0) kps = G_BK;
+  return (int)igcn_cdiv(K > 0 ? K : 1, kps);
 }
 
 extern "C" int igcn_gemm_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t sam, int64_t sak,
@@ -782,6 +796,19 @@ extern "C" int igcn_rider_cancel(void* stream) {
   std::lock_guard<std::mutex> lk(g_gr_mutex);
   g_gemm_riders.erase((hipStream_t)stream);
   return IGCN_OK;
+}
+
+// Everything the library still holds for `stream` on the host side and has NOT launched: deferred reductions (entries),
+// the dropout rider (0 / 1), product riders (products).  0 at the end of every step; see the header for each queue's
+// ordering contract.
+int igcn_reduce_pending_on(hipStream_t st);            // plan.hip
+int igcn_rider_dropout_waiting(hipStream_t st);        // plan.hip
+extern "C" int igcn_stream_pending(void* stream) {
+  int n = igcn_reduce_pending_on((hipStream_t)stream) + igcn_rider_dropout_waiting((hipStream_t)stream);
+  std::lock_guard<std::mutex> lk(g_gr_mutex);
+  auto it = g_gemm_riders.find((hipStream_t)stream);
+  if (it != g_gemm_riders.end()) n += (int)(it->second.size() / 16);
+  return n;
 }
 
 extern "C" int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream);

@@ -344,6 +344,13 @@ extern "C" int igcn_reduce_pending(void) {
   return (int)n;
 }
 
+// deferred reductions waiting on ONE stream (igcn_stream_pending, gemm.hip)
+int igcn_reduce_pending_on(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_rq_mutex);
+  auto it = g_rq.find(st);
+  return it == g_rq.end() ? 0 : (int)it->second.q.size();
+}
+
 __global__ void k_tick(int32_t* tick) { *tick += 1; }
 
 // the queue of `st` when that stream is in defer mode, else NULL (caller holds the mutex)
@@ -1104,6 +1111,11 @@ extern "C" int igcn_rider_flush(void* stream) {
 void igcn_rider_dropout_cancel(hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_rider_mutex);
   g_riders.erase(st);
+}
+
+int igcn_rider_dropout_waiting(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_rider_mutex);
+  return (int)g_riders.count(st);
 }
 
 static bool rider_take(hipStream_t st, DropJob& job) {

@@ -1049,11 +1049,20 @@ k_bn1d_bwd(int B, int C, int groups, int training, int relu, const float* __rest
 // pairs.  [The general form walks the column three times per group, one group after the other: eight dependent
 // barrier-separated trips over 64 KB, 6-7 us on 32 workgroups.]  Same per-thread order and reduction tree: same bits.
 #define BN1_VP 4
+// PRODUCER (template): where the column comes from.  0 = x as given.  1 = the sum of `n_slabs` split-K slabs
+// [n_slabs][B*C] of the product in front (igcn_gemm_f32 with act | 0x200 leaves them un-summed): the slab-sum launch
+// between the product and this kernel disappears, the sum is taken in slab order (k_gemm_splitk_reduce's) and written to
+// `x_out` for the backward — 8.6 us against 5.0 + 5.1 for the two launches (round 5).  [A third form that computed a
+// narrow product itself — the latent MLP's 32 -> 32 layer, every channel's workgroup reading all of h — was measured at
+// 12.0 us against 4.7 + 4.9 for product + BatchNorm and removed: 32 workgroups cannot read 64 KB each, a row per lane,
+// in less than the 8-workgroup product and its launch take.]
+template <int PRODUCER>
 __global__ void __launch_bounds__(256)
 k_bn1d_fwd_reg(int B, int C, int groups, int training, float momentum, float eps, int relu,
                const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                const float* __restrict__ keep, float* __restrict__ running_mean, float* __restrict__ running_var,
-               float* __restrict__ y, float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+               float* __restrict__ y, float* __restrict__ save_mean, float* __restrict__ save_rstd, int n_slabs,
+               float* __restrict__ x_out) {
   __shared__ float red[32];
   const int c = blockIdx.x, bg = B / groups;
   float rm = running_mean[c], rv = running_var[c];
@@ -1066,7 +1075,25 @@ k_bn1d_fwd_reg(int B, int C, int groups, int training, float momentum, float eps
       const int b = threadIdx.x + 256 * j;
       const bool ok = g < groups && b < bg;
       const int64_t o = ((int64_t)g * bg + b) * C + c;
-      xv[g][j] = ok ? x[o] : 0.f;
+      if constexpr (PRODUCER == 1) {
+        float t = 0.f;
+        if (ok) {
+          for (int z0 = 0; z0 < n_slabs; z0 += 8) {          // slab order, eight loads in flight (= slab_sum, gemm.hip)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const float xs = x[(int64_t)(z0 + u < n_slabs ? z0 + u : 0) * B * C + o];
+              v[u] = z0 + u < n_slabs ? xs : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+          }
+          x_out[o] = t;
+        }
+        xv[g][j] = t;
+      } else {
+        xv[g][j] = ok ? x[o] : 0.f;
+      }
       kv[g][j] = (ok && keep) ? keep[o] : 1.f;
     }
   float mean[2] = {rm, rm}, var[2] = {rv, rv};
@@ -1187,12 +1214,33 @@ extern "C" int igcn_bn1d_fwd(int B, int C, int groups, const float* x, const flo
   IGCN_REQUIRE(B > 0 && C > 0 && groups >= 1 && B % groups == 0 && (!training || B / groups > 1),
                "bn1d_fwd: bad sizes");
   if (groups <= 2 && B / groups <= 256 * BN1_VP)
-    hipLaunchKernelGGL(k_bn1d_fwd_reg, dim3(C), dim3(256), 0, (hipStream_t)stream, B, C, groups, training, momentum, eps,
-                       relu, x, gamma, beta, keep, running_mean, running_var, y, save_mean, save_rstd);
+    hipLaunchKernelGGL(k_bn1d_fwd_reg<0>, dim3(C), dim3(256), 0, (hipStream_t)stream, B, C, groups, training, momentum,
+                       eps, relu, x, gamma, beta, keep, running_mean, running_var, y, save_mean, save_rstd, 0,
+                       (float*)nullptr);
   else
     hipLaunchKernelGGL(k_bn1d_fwd, dim3(C), dim3(256), 0, (hipStream_t)stream, B, C, groups, training, momentum, eps,
                        relu, x, gamma, beta, keep, running_mean, running_var, y, save_mean, save_rstd);
   IGCN_CHECK_LAUNCH("bn1d_fwd");
+  return IGCN_OK;
+}
+
+// BatchNorm1d(C) (+ ReLU, + dropout factors) of a column whose split-K slabs the product in front left un-summed
+// (igcn_gemm_f32 with act | 0x200): `slabs` [n_slabs][B, C]; x_out [B, C] receives the sum (the backward's operand).
+// Shapes: groups <= 2, B / groups <= 1024 (igcn_bn1d_fwd_supported).
+extern "C" int igcn_bn1d_fwd_supported(int B, int groups) {
+  return groups >= 1 && groups <= 2 && B > 0 && B % groups == 0 && B / groups <= 256 * BN1_VP;
+}
+extern "C" int igcn_bn1d_fwd_slabs(int B, int C, int groups, const float* slabs, int n_slabs, float* x_out,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   int training, float momentum, float eps, int relu, const float* keep, float* y,
+                                   float* save_mean, float* save_rstd, void* stream) {
+  IGCN_REQUIRE(C > 0 && igcn_bn1d_fwd_supported(B, groups) && (!training || B / groups > 1) && slabs && x_out &&
+                   n_slabs >= 1,
+               "bn1d_fwd_slabs: unsupported shape (B=%d groups=%d n_slabs=%d)", B, groups, n_slabs);
+  hipLaunchKernelGGL(k_bn1d_fwd_reg<1>, dim3(C), dim3(256), 0, (hipStream_t)stream, B, C, groups, training, momentum,
+                     eps, relu, slabs, gamma, beta, keep, running_mean, running_var, y, save_mean, save_rstd, n_slabs,
+                     x_out);
+  IGCN_CHECK_LAUNCH("bn1d_fwd_slabs");
   return IGCN_OK;
 }
 

@@ -159,6 +159,16 @@ class Gene_ontology_network(nn.Module):
         return ops.BatchNorm1dGrouped.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
                                             bn.momentum, bn.eps, True, groups, keep)
 
+    def _lin_bn_relu(self, x, lin, bn, groups=1, keep=None):
+        """dropout(relu(bn(lin(x)))) of the latent MLP (:138-146); a split-K product's slabs are summed by the BatchNorm
+        launch itself (ops.LinearBN1d: no slab-sum launch behind the wide layer)."""
+        if lin.bias is None and ops.linear_bn1d_supported(x, lin.weight, groups):
+            if self.training and bn.track_running_stats:
+                self._tracked.append(bn.num_batches_tracked)
+            return ops.LinearBN1d.apply(x, lin.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
+                                        bn.momentum, bn.eps, groups, keep)
+        return self._bn_relu(ops.linear(x, lin.weight, lin.bias), bn, groups, keep)
+
     def forward(self, data, T=None, device=None, groups=1, extra_dropout=()):
         """``groups`` > 1: ``data`` holds that many equally sized batches stacked along dim 0 that are treated as
         successive forward calls (own BatchNorm statistics, running statistics updated in order).
@@ -220,8 +230,8 @@ class Gene_ontology_network(nn.Module):
         out_d = self._node_linear_bn(x, self.conc_D.weight, self.B_D[0], groups, masks["out_d"]).squeeze(2)   # [B,N]
         x_d = ops.SparseMap.apply(out_d, self.gene_t_csr, self.t_D[0]).squeeze(1)               # [B, 54]
         # latent projection (:138-146,285)
-        h = self._bn_relu(ops.linear(inp_out.view(bsz, -1), self.latent[0].weight), self.latent[1], groups, masks["h"])
-        latent = self._bn_relu(ops.linear(h, self.latent[4].weight), self.latent[5], groups)
+        h = self._lin_bn_relu(inp_out.view(bsz, -1), self.latent[0], self.latent[1], groups, masks["h"])
+        latent = self._lin_bn_relu(h, self.latent[4], self.latent[5], groups)
         if self._tracked and not self._counters_done:  # num_batches_tracked of the five BatchNorms: one launch (with
             torch._foreach_add_(self._tracked, groups)  # dropout on, the mask launch has advanced them already)
         self._tracked = []

@@ -101,6 +101,10 @@ class deferred_reductions:
                 _DEFER["ln_affine"].clear()
                 _DEFER["spmm_dval"].clear()
                 _DEFER["keep"].clear()
+        if _lib._DEBUG_SYNC and ok:                  # checked mode: the flush has emptied the stream's queue
+            n = int(_lib.load().igcn_stream_pending(stream_ptr()))
+            if n:
+                raise _lib.IgcnError(f"deferred_reductions: {n} queued launch(es) left on the stream after the flush")
         return False
 
 
@@ -1972,6 +1976,64 @@ class BatchNorm1dGrouped(torch.autograd.Function):
         call("igcn_bn1d_bwd", b, c, groups, training, relu, ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
              ptr(dy), ptr(keep), ptr(dx), ptr(dg), ptr(db), stream_ptr())
         return dx, dg, db, None, None, None, None, None, None, None, None
+
+
+class LinearBN1d(torch.autograd.Function):
+    """dropout(relu(BatchNorm1d(x W^T))) — a bias-less Linear and the BatchNorm1d block behind it (the wide layer of the
+    latent MLP, kernel/go_model.py:138-146) with the product's split-K slabs summed by the BatchNorm launch while it
+    loads its column: no slab-sum launch in between.  Backward: igcn_bn1d_bwd, then dX | dW as ops.Linear."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, groups, keep=None):
+        x, weight, gamma, beta = _f32(x), _f32(weight), _f32(gamma), _f32(beta)
+        keep = _f32(keep) if keep is not None else None
+        b, k = x.shape
+        c = weight.shape[0]
+        dev = x.device
+        xl = torch.empty(b, c, dtype=torch.float32, device=dev)
+        y = torch.empty_like(xl)
+        mean = torch.empty(groups, c, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        lib = _lib.load()
+        tail = (ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), int(training), float(momentum), float(eps), 1,
+                ptr(keep), ptr(y), ptr(mean), ptr(rstd), stream_ptr())
+        sk = _split_k(b, c, k)
+        scratch = torch.empty(sk * b * c, dtype=torch.float32, device=dev) if sk > 1 else None
+        call("igcn_gemm_f32", b, c, k, ptr(x), k, 1, ptr(weight), k, 1, None, ptr(xl), c, 0x200, sk, ptr(scratch),
+             stream_ptr())
+        eff = int(lib.igcn_gemm_effective_split(k, sk))
+        if eff > 1:
+            call("igcn_bn1d_fwd_slabs", b, c, groups, ptr(scratch), eff, ptr(xl), *tail)
+        else:
+            call("igcn_bn1d_fwd", b, c, groups, ptr(xl), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                 int(training), float(momentum), float(eps), 1, ptr(keep), ptr(y), ptr(mean), ptr(rstd), stream_ptr())
+        ctx.save_for_backward(x, weight, xl, gamma, beta, mean, rstd, keep)
+        ctx.cfg = (int(training), groups)
+        ctx.w_final = _leaves(weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, xl, gamma, beta, mean, rstd, keep = ctx.saved_tensors
+        training, groups = ctx.cfg
+        dy = _f32(dy)
+        b, c = xl.shape
+        dxl, dg, db = torch.empty_like(xl), torch.empty_like(gamma), torch.empty_like(beta)
+        call("igcn_bn1d_bwd", b, c, groups, training, 1, ptr(xl), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dy),
+             ptr(keep), ptr(dxl), ptr(dg), ptr(db), stream_ptr())
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            dx, dw = gemm_group([("nn", dxl, weight, None, None, False), ("tn", dxl, x, None, None, ctx.w_final)])
+        else:
+            dx = gemm_nn(dxl, weight) if ctx.needs_input_grad[0] else None
+            dw = gemm_tn(dxl, x, final_grad=ctx.w_final) if ctx.needs_input_grad[1] else None
+        return dx, dw, dg, db, None, None, None, None, None, None, None
+
+
+def linear_bn1d_supported(x, weight, groups):
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() and weight.is_contiguous()
+            and os.environ.get("IGCN_NO_LINEAR_BN_FUSED", "0") != "1"
+            and _split_k(x.shape[0], weight.shape[0], x.shape[1]) > 1      # (an unsplit product has no slab sum to save)
+            and bool(_lib.load().igcn_bn1d_fwd_supported(x.shape[0], groups)))
 
 
 # =================================================================================================

@@ -458,6 +458,32 @@ def _single_use_parameters(model):
     return hasattr(model, "forward_pair")
 
 
+def forget_riders(model=None):
+    """Drop every rider still waiting on the current stream WITHOUT launching it (igcn_rider_cancel) together with the
+    dropout masks a model drew ahead for a forward that never came (go_network._predrawn): the start of every step, and
+    the error path of one that raised half way."""
+    call("igcn_rider_cancel", stream_ptr())
+    go = getattr(model, "go_network", None)
+    if go is not None:
+        go._predrawn = None
+
+
+def stream_pending():
+    """What is still queued for the current stream and has not been launched: the library's host-side queues
+    (igcn_stream_pending: deferred reductions, dropout rider, product riders) plus the two parameter-gradient queues of
+    ops (LayerNorm affine passes, SNP <-> GO value-gradient passes).  0 at the end of every step."""
+    from . import ops
+    return int(_lib.load().igcn_stream_pending(stream_ptr())) + len(ops._DEFER["ln_affine"]) + len(ops._DEFER["spmm_dval"])
+
+
+def assert_nothing_pending(where):
+    """Checked mode (IGCN_DEBUG_SYNC=1): a step must leave none of the library's queues behind."""
+    if _lib._DEBUG_SYNC:
+        n = stream_pending()
+        if n:
+            raise _lib.IgcnError(f"{where}: {n} queued launch(es) left on the stream at the end of the step")
+
+
 def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None, world_size=1,
                comm=None):
     """One iteration of the loop body of train() :515-547.  Returns the (device) loss tensor.
@@ -472,8 +498,14 @@ def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temper
     optimizer.zero_grad()
     if data.x.grad is not None:
         data.x.grad = None
-    loss, _, _ = losses(model, data, lambda_loss, hp, temperature)
-    backward_to_grads(loss, optimizer, data, defer=_single_use_parameters(model), tick=True)
+    forget_riders(model)          # (a failed step before this one may have left riders / masks drawn ahead: ADVICE r4)
+    try:
+        loss, _, _ = losses(model, data, lambda_loss, hp, temperature)
+        backward_to_grads(loss, optimizer, data, defer=_single_use_parameters(model), tick=True)
+    except BaseException:
+        forget_riders(model)
+        raise
+    assert_nothing_pending("train_step")
     if world_size > 1 or comm is not None:
         flat = optimizer.pack_grads()
         if comm is not None:
@@ -533,6 +565,10 @@ class GraphedTrainStep:
         saved = [t.clone() for t in (opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_count)]
         saved_buf = [(b, b.clone()) for b in model.buffers()]
         saved_has = list(opt._has_state)
+        # the dropout generator's stream counter is not a registered buffer: saved / restored like them, so that a shape
+        # captured in the middle of an epoch does not shift the masks of every later step against an eager run
+        drop = getattr(getattr(model, "go_network", None), "_drop_state", None)
+        saved_drop = drop.state.clone() if drop is not None else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -550,6 +586,10 @@ class GraphedTrainStep:
                 dst.copy_(src)
             for b, v in saved_buf:
                 b.copy_(v)
+            drop_now = getattr(getattr(model, "go_network", None), "_drop_state", None)
+            if saved_drop is not None and drop_now is drop:
+                drop.state.copy_(saved_drop)
+        forget_riders(model)
         opt._has_state = saved_has
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
@@ -617,20 +657,27 @@ class GraphedTrainStep:
     def _fwd_bwd(self, rebuild=True):
         self.opt.zero_grad()
         self.data._igcn_plan = self.plan
-        call("igcn_rider_cancel", stream_ptr())         # (leftovers of a step that failed half way must never launch)
+        forget_riders(self.model)                       # (leftovers of a step that failed half way must never launch)
         rider = (rebuild and _batched(self.model) and hasattr(self.model, "predraw_dropout")
                  and os.environ.get("IGCN_NO_DROPOUT_RIDER", "0") != "1")
-        if rider:
-            self.model.predraw_dropout(self.data)       # queued: the plan build below carries the mask generation
-        if rebuild:
-            self.plan.rebuild(self.data.edge_index)     # the plan is per batch: rebuilt (in place) every step
-        else:
-            self.plan._copies = {}                      # the replica of the batched sweep is derived in-graph
-        if rider:
-            call("igcn_rider_flush", stream_ptr())      # (a plan build that does not carry riders: a launch of its own)
-        self.data.x.grad = None
-        loss, _, _ = losses(self.model, self.data, self.lam, self.hp)
-        backward_to_grads(loss, self.opt, self.data, defer=_single_use_parameters(self.model), tick=True)
+        try:
+            if rider:
+                self.model.predraw_dropout(self.data)   # queued: the plan build below carries the mask generation
+            if rebuild:
+                self.plan.rebuild(self.data.edge_index)  # the plan is per batch: rebuilt (in place) every step
+            else:
+                self.plan._copies = {}                  # the replica of the batched sweep is derived in-graph
+            if rider:
+                call("igcn_rider_flush", stream_ptr())  # (a plan build that does not carry riders: a launch of its own)
+            self.data.x.grad = None
+            loss, _, _ = losses(self.model, self.data, self.lam, self.hp)
+            backward_to_grads(loss, self.opt, self.data, defer=_single_use_parameters(self.model), tick=True)
+        except BaseException:
+            # a step that raised between queueing a rider and its carrier: the rider's buffers die with this frame, and
+            # the masks drawn ahead for THIS forward must not be handed to a later one
+            forget_riders(self.model)
+            raise
+        assert_nothing_pending("GraphedTrainStep._fwd_bwd")
         return loss.detach()
 
     def _reduce(self):
@@ -742,7 +789,10 @@ class EpochTrainer:
     captured step once it has been seen ``capture_after`` times (default: the second time — one-off shapes never pay for
     a capture); until then, and beyond ``max_graphs`` captured shapes, the batch runs through the eager ``train_step``.
     Both routes are the same kernels on the same optimiser state, so an epoch is the same sequence of Adam steps either
-    way.  All captured steps share the optimiser: each restores its own gradient-pointer table before it replays.
+    way; with dropout ON the two routes also draw from the same mask stream — a capture's warm-up steps are rolled back
+    including the generator's counter — but a captured step draws its masks in the launch of its plan build and the eager
+    step in a launch of its own, so runs that differ in ``capture_after`` agree in distribution, not bit for bit.  All
+    captured steps share the optimiser: each restores its own gradient-pointer table before it replays.
 
     The learning-rate schedule of the epoch loop (:169-171) is ``optimizer.param_groups[0]['lr'] *= factor`` exactly as
     with torch.optim.Adam: the rate lives in device memory and captured steps read it there.
@@ -798,11 +848,21 @@ def fit_epoch(model, optimizer, loader, temperature=None, lambda_loss=DEFAULT_LA
     """``train(model, optimizer, loader, temperature, lambda_loss, ..., device)`` of the reference (:511-548) as a
     function: the EpochTrainer is kept on the optimiser, so calling this once per epoch — as the reference's epoch
     loop calls ``train`` — re-uses the captured steps."""
-    key = (id(model), tuple(float(v) for v in lambda_loss), world_size, id(comm))
+    # (``temperature`` is accepted for the reference's signature and, like the reference's GO network, never read.)
+    # The captured steps bake the regulariser weights of ``hp`` in as launch arguments: they are part of the key; the
+    # model and the communicator are held by weak reference, so an id() recycled after garbage collection cannot alias
+    import weakref
+    hp_key = tuple(float(getattr(hp, k)) for k in ("lamda_x_l1", "lamda_e_l1", "lamda_x_ent", "lamda_e_ent", "lamda_mi",
+                                                    "lamda_ce"))
+    key = (id(model), tuple(float(v) for v in lambda_loss), hp_key, world_size, id(comm))
     cache = optimizer.__dict__.setdefault("_igcn_epoch_trainers", {})
     tr = cache.get(key)
+    if tr is not None and (tr._model_ref() is not model or (comm is not None and tr._comm_ref() is not comm)):
+        tr = None                                             # the id belonged to an object that is gone
     if tr is None:
         tr = cache[key] = EpochTrainer(model, optimizer, lambda_loss, hp, world_size=world_size, comm=comm)
+        tr._model_ref = weakref.ref(model)
+        tr._comm_ref = weakref.ref(comm) if comm is not None else (lambda: None)
     return tr.fit_epoch(loader, device)
 
 

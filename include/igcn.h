@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 414
+#define IGCN_ABI_VERSION 416
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -450,6 +450,10 @@ int igcn_gemm_bf16(int64_t M, int64_t N, int64_t K,
                    const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
                    const float* bias, float* C, int64_t ldc, int act, int split_k, float* scratch,
                    void* stream);
+/* act | 0x200 (igcn_gemm_f32 / igcn_gemm_bf16; no bias, no activation, ldc == N): LEAVE the split-K slabs un-summed in
+ * `scratch` ([igcn_gemm_effective_split(K, split_k)][M, N], slab order = K order) for a consumer that sums them while it
+ * loads them (igcn_bn1d_fwd_slabs); with an effective split of 1 the product is written to C as usual. */
+int igcn_gemm_effective_split(int64_t K, int split_k);
 
 /* Batched-sum variant: C = sum_z A_z . B_z^T with A_z = A + z*a_batch, B_z = B + z*b_batch (element offsets),
  * every z covering the whole K; slabs are summed in z order.  Used for weight gradients whose reduction index is
@@ -480,6 +484,22 @@ int igcn_gemm_rider_flush(void* stream);
 /* Forget every rider still waiting on the stream (mask job, products) WITHOUT launching it — at the start of a step that
  * may follow one which failed between queueing a rider and its carrier (the buffers it points at may be gone). */
 int igcn_rider_cancel(void* stream);
+/* HOST-SIDE QUEUES OF THE LIBRARY — the complete list, with the ordering contract of each.  All are keyed by the stream
+ * handle, hold raw device pointers that the CALLER keeps alive, never launch anything by themselves, and are empty at the
+ * end of every step (igcn_stream_pending == 0; ig-gcn_amd/train.py asserts it under IGCN_DEBUG_SYNC=1):
+ *   1. deferred reductions   igcn_reduce_defer(stream, 1) .. igcn_reduce_flush[_tick](stream): every "sum the block
+ *      partials" launch issued on the stream in between is queued; the flush runs them in issue order in one launch.  The
+ *      partial buffers must outlive the flush; igcn_reduce_defer(stream, 0) + flush also runs on the error path.
+ *   2. the dropout rider     igcn_rider_dropout(stream, ...): at most ONE job; carried by the NEXT
+ *      igcn_graph_plan_build_segmented[_rep] on the stream and by nothing else; igcn_rider_flush launches it alone.
+ *   3. product riders        igcn_gemm_rider(stream, ...): at most 4 products; carried, all or none, by the NEXT
+ *      igcn_gemm_f32_grouped on the stream with room for them and the same operand type; igcn_gemm_rider_flush launches
+ *      them alone.
+ * A rider is only ever picked up by the entry point named above: any other launch on the stream passes it by, so the
+ * caller issues rider -> (independent launches) -> carrier or flush and must not read the rider's outputs before that.
+ * igcn_rider_cancel forgets 2 and 3 without launching (start of a step that may follow a failed one).
+ * igcn_stream_pending(stream) = entries of 1 + jobs of 2 + products of 3 still waiting on that stream. */
+int igcn_stream_pending(void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GO read-outs: per-node linear + BatchNorm1d(#nodes) + ReLU, fused — go_model.py:117-121,254
@@ -538,6 +558,15 @@ int igcn_bn1d_fwd(int B, int C, int groups, const float* x, const float* gamma, 
 int igcn_bn1d_bwd(int B, int C, int groups, int training, int relu, const float* x, const float* gamma,
                   const float* beta, const float* save_mean, const float* save_rstd, const float* dy,
                   const float* keep, float* dx, float* dgamma, float* dbeta, void* stream);
+/* The same forward on a column whose split-K slabs the product in front left un-summed (igcn_gemm_f32 with act | 0x200):
+ * the latent MLP's wide layer, kernel/go_model.py:138-146 (Linear -> BatchNorm1d -> ReLU -> Dropout).  `slabs`
+ * [n_slabs][B, C] are summed in slab order while the column is loaded; x_out [B, C] receives the sum (igcn_bn1d_bwd's
+ * operand).  groups <= 2 and B / groups <= 1024 (igcn_bn1d_fwd_supported). */
+int igcn_bn1d_fwd_supported(int B, int groups);
+int igcn_bn1d_fwd_slabs(int B, int C, int groups, const float* slabs, int n_slabs, float* x_out, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var, int training, float momentum,
+                        float eps, int relu, const float* keep, float* y, float* save_mean, float* save_rstd,
+                        void* stream);
 
 /* Dropout factors of every site of a forward pass in ONE launch (the reference draws them site by site: nn.Dropout /
  * nn.Dropout2d / F.dropout, kernel/go_model.py:104,113,128,136,143, kernel/sgcn_img_snp.py:289,299).  out [total]:

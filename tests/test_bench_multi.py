@@ -58,8 +58,11 @@ def test_gpus_2_self_launch_rehearsal_on_one_device():
 
 
 @pytest.mark.gpu
-def test_sweep_prints_one_line_per_n_with_efficiency():
-    """IGCN_BENCH_SWEEP="1,2": one invocation, a fresh child per N, the N = 2 line scaled by the sweep's own N = 1 run."""
+def test_sweep_prints_one_line_per_n_and_exchange_form_with_efficiency():
+    """IGCN_BENCH_SWEEP="1,2": one invocation, a fresh child per N and — at N > 1 — per gradient-exchange form
+    (``two_graphs`` around the all-reduce; ``in_graph``: the collective captured, which on this one-device rehearsal
+    (gloo, no RCCL communicator) is refused and falls back on every rank alike — the control flow a multi-rank run
+    takes when the capture is refused), every N = 2 line scaled by the sweep's own N = 1 run."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "IGCN_BENCH_N1_VALUE")}
@@ -69,6 +72,9 @@ def test_sweep_prints_one_line_per_n_with_efficiency():
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip()]
-    assert [ln["n_gpus"] for ln in lines] == [1, 2]
+    assert [ln["n_gpus"] for ln in lines] == [1, 2, 2]
+    assert [ln["exchange_form"] for ln in lines] == ["single", "two_graphs", "in_graph"]
     assert "weak_scaling_efficiency_vs_n1" not in lines[0]
-    assert lines[1]["weak_scaling_efficiency_vs_n1"] == pytest.approx(lines[1]["value"] / (2 * lines[0]["value"]), abs=1e-3)
+    for ln in lines[1:]:
+        assert ln["weak_scaling_efficiency_vs_n1"] == pytest.approx(ln["value"] / (2 * lines[0]["value"]), abs=1e-3)
+        assert "launch" in ln["config"]

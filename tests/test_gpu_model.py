@@ -306,8 +306,8 @@ def train_mode_vs_oracle(monkeypatch, rois, pool, bsz, dense=False, bf16=False, 
     def hip_run(batched):
         """(loss, terms, grads, forced decisions per oracle ReLU site, ignore masks) of one HIP evaluation."""
         seen = {}
-        classes = (ops.SgcnStack, ops.DenseSgcn, ops.GoAttentionLN, ops.GoDecodeLN, ops.NodeLinearBNPair, ops.NodeLinearBN,
-                   ops.BatchNorm1dGrouped, ops.Linear, ops.LinearPair)
+        classes = (ops.SgcnStack, ops.DenseSgcn, ops.GcnPropagate, ops.GoAttentionLN, ops.GoDecodeLN, ops.NodeLinearBNPair,
+                   ops.NodeLinearBN, ops.BatchNorm1dGrouped, ops.LinearBN1d, ops.Linear, ops.LinearPair)
         model.load_state_dict(sd)                                     # running statistics back to the start
         model.zero_grad()
         model.batched_passes = batched
@@ -338,7 +338,11 @@ def train_mode_vs_oracle(monkeypatch, rois, pool, bsz, dense=False, bf16=False, 
             n = len(calls) // 2
             return [pick(calls[k_th]).detach().cpu(), pick(calls[n + k_th]).detach().cpu()]
         stack = "DenseSgcn" if "DenseSgcn" in seen else "SgcnStack"    # complete graphs run on the dense blocks
-        xc = per_pass(stack, 0, lambda o: o[0] if isinstance(o, tuple) else o)
+        if stack in seen:
+            xc = per_pass(stack, 0, lambda o: o[0] if isinstance(o, tuple) else o)
+        else:       # a graph too large for the LDS-resident stack (rois = 270 at three 16-wide layers): one launch per layer
+            cols = [per_pass("GcnPropagate", l_) for l_ in range(layers)]
+            xc = [torch.cat([c[p_] for c in cols], dim=1) for p_ in range(2)]
         first = lambda o: o[0] if isinstance(o, tuple) else o        # noqa: E731 — the last encoder layer returns three aliases
         ln = [per_pass("GoAttentionLN", k, first) for k in range(2)] + [per_pass("GoDecodeLN", k) for k in range(2)]
         if "NodeLinearBNPair" in seen:
@@ -347,7 +351,8 @@ def train_mode_vs_oracle(monkeypatch, rois, pool, bsz, dense=False, bf16=False, 
             outd = per_pass("NodeLinearBN", 0)
         else:                                # read-outs as three single launches: attention, input, gene decoding
             att, inp, outd = (per_pass("NodeLinearBN", k) for k in range(3))
-        hb = [per_pass("BatchNorm1dGrouped", k) for k in range(2)]
+        bn_name = "LinearBN1d" if "LinearBN1d" in seen else "BatchNorm1dGrouped"   # (the latent MLP's two layers)
+        hb = [per_pass(bn_name, k) for k in range(2)]
         lp = [per_pass("LinearPair", 0, lambda o, i=i: o[i]) for i in range(2)]
         for p_ in range(2):
             # oracle ReLU sites per pass: ``layers`` GCNConv layers, then twelve more (2 encoder LayerNorms, two read-outs,
@@ -812,7 +817,7 @@ def test_deferred_reductions_give_the_same_gradients(golden):
 @pytest.mark.parametrize("switch", ["IGCN_NO_FUSED_SGCN", "IGCN_NO_DEFER", "IGCN_NO_GEMM_GROUPS", "IGCN_NO_READOUT_PAIR",
                                     "IGCN_LN_AFFINE_NOW", "IGCN_SPMM_DVAL_NOW", "IGCN_NO_PROJ_FUSED", "IGCN_NO_HEAD_FUSED",
                                     "IGCN_NO_MASK_REG_FUSED", "IGCN_NO_GRAD_FAN", "IGCN_NO_LN_FUSED",
-                                    "IGCN_NO_LOSS_HEAD_FUSED", "IGCN_SPARSE_MAPS"])
+                                    "IGCN_NO_LOSS_HEAD_FUSED", "IGCN_SPARSE_MAPS", "IGCN_NO_LINEAR_BN_FUSED"])
 def test_every_host_side_switch_gives_the_default_train_step(golden, monkeypatch, switch):
     """every A/B switch that the Python layer reads selects a second code path — each of them must give
     the default path's train step (loss, every gradient) on the ``full_b32`` model, so a losing variant cannot rot
@@ -879,6 +884,54 @@ def test_a_failed_deferred_block_leaves_no_queue_behind(golden, monkeypatch):
         assert set(got) == set(want)
         for k in want:
             assert torch.equal(got[k], want[k]), (defer, k)
+
+
+def test_nothing_stays_queued_after_a_step_even_one_that_raises_half_way(golden, monkeypatch):
+    """igcn_stream_pending(stream) — deferred reductions + dropout rider + product riders still waiting — is
+    0 after a train step, eager or graphed, and also after a step that raised between queueing its riders and the
+    launches that would have carried them (the Gram products are queued inside the forward; here the heads' launch that
+    carries them never comes); the masks drawn ahead for that forward are dropped with them and the next step
+    runs as if nothing had happened."""
+    from igcn_amd import _lib, ops, train
+    from igcn_amd.data import Batch
+    from igcn_amd.train import FlatAdam, GraphedTrainStep, stream_pending, train_step
+    store = golden("full_b32")
+    model, graphs, _ = _full_model(store)
+    model.train(True)
+    model._dropout_enabled = model.go_network._dropout_enabled = True
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    lam = store["lam"].tolist()
+    data = Batch.from_data_list(graphs).to("cuda")
+    assert stream_pending() == 0
+    train_step(model, opt, data, lam)
+    assert stream_pending() == 0
+    # riders queued, then the step dies before their carriers: the Gram riders inside the forward ...
+    seen = {}
+
+    def boom(*a, **k):
+        seen["pending"] = int(_lib.load().igcn_stream_pending(_lib.stream_ptr()))
+        raise RuntimeError("injected")
+    with monkeypatch.context() as mp:
+        mp.setattr(ops, "linear_pair", boom)
+        with pytest.raises(RuntimeError, match="injected"):
+            train_step(model, opt, data, lam)
+    assert seen["pending"] >= 1                      # (the products really were waiting when the step died)
+    assert stream_pending() == 0
+    # ... and the dropout rider of a captured step's plan build
+    step = GraphedTrainStep(model, opt, data, lam, warmup=1)
+    assert stream_pending() == 0
+    with monkeypatch.context() as mp:
+        mp.setattr(step.plan, "rebuild", boom)
+        with pytest.raises(RuntimeError, match="injected"):
+            step._fwd_bwd()
+    assert seen["pending"] >= 1 and stream_pending() == 0
+    assert model.go_network._predrawn is None        # masks drawn ahead for the forward that never came: dropped
+    loss = train_step(model, opt, data, lam)         # an eager step of the same shape does not inherit them
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss)) and stream_pending() == 0
+    step()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(step.loss)) and stream_pending() == 0
 
 
 @pytest.mark.parametrize("layers,hidden", [(2, 10), (3, 10), (4, 5)])
