@@ -72,9 +72,10 @@ WORKLOADS = {
 }
 
 
-def build_model(device, wl=None, bf16=None):
+def build_model(device, wl=None, bf16=None, layers=None, hidden=None):
     wl = wl or WORKLOADS["full"]
     bf16 = wl["bf16"] if bf16 is None else bf16
+    LAYERS, HIDDEN = (layers or globals()["LAYERS"]), (hidden or globals()["HIDDEN"])
     torch.manual_seed(1000)                                   # main.py:102 seed
     if wl["pool"] is None:
         from igcn_amd.sgcn import SGCN_GCN
@@ -90,6 +91,48 @@ def build_model(device, wl=None, bf16=None):
                             bf16_transforms=bf16).to(device)
     model.train()
     return model, (go_snps, adj, pool_dim)
+
+
+MODEL_SWEEP = [(2, 16), (3, 16), (2, 10), (3, 10), (4, 5)]       # main.py:152-154 (layers, hiddens): the default sweep
+
+
+def model_sweep(wl, device, data, steps=20, warmup=3):
+    """The five (layers, hidden) entries of the reference's own hyper-parameter sweep (main.py:152-154) at the headline
+    workload, each as its own captured step: ms per step, graphs/s, and the cost per graph relative to the (2, 16) entry
+    the metric is quoted on — how deep the cliff is off the shape the kernels were tuned at (VERDICT r4 #4, #6)."""
+    from igcn_amd.train import FlatAdam, GraphedTrainStep
+    rows, base = [], None
+    for layers, hidden in MODEL_SWEEP:
+        model, _ = build_model(device, wl, layers=layers, hidden=hidden)
+        opt = FlatAdam(model.parameters(), lr=1e-3)
+        d = Batch.from_data_list(synth.brain_graph_list(wl["graphs"], seed=1000, rois=wl["rois"], tsne_dim=90,
+                                                        dense=wl["dense"])).to(device)
+        d.x.requires_grad_(True)
+        try:
+            step = GraphedTrainStep(model, opt, d)
+        except Exception as exc:                  # noqa: BLE001
+            rows.append({"layers": layers, "hidden": hidden, "error": f"{type(exc).__name__}: {exc}"[:200]})
+            continue
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / steps)
+        ms = sorted(ts)[1] * 1e3
+        if base is None:
+            base = ms
+        rows.append({"layers": layers, "hidden": hidden, "ms_per_step": round(ms, 4),
+                     "graphs_per_s": round(wl["graphs"] / ms * 1e3, 1), "cost_per_graph_vs_2x16": round(ms / base, 3),
+                     "loss": round(float(step.loss), 5)})
+        del step, opt, model
+        torch.cuda.empty_cache()
+    return {"entries": rows, "reference": "main.py:152-154 (layers, hiddens); same batch, GO DAG and step as the headline",
+            "timing": f"median of 3 blocks of {steps} hipGraph replays per entry"}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -923,6 +966,9 @@ def main():
     ap.add_argument("--no-stress", action="store_true",
                     help="default workload only: skip the short configs[4] child run reported as `stress`")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="bound of the CPU-oracle sample")
+    ap.add_argument("--model-sweep", action="store_true",
+                    help="also time the five (layers, hidden) entries of the reference's sweep (main.py:152-154)")
+    ap.add_argument("--no-model-sweep", action="store_true", help="skip them in the default line")
     ap.add_argument("--inner-profile", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-cores", default="", help=argparse.SUPPRESS)
@@ -1203,6 +1249,9 @@ def main():
                 whole = step_traffic(args.workload, res["profile"]["kernel_us_per_step"])
                 if whole is not None:
                     res["roofline_step"] = whole
+        if wl["pool"] is not None and world == 1 and not wl["dense"] and gstep is not None \
+                and (args.model_sweep or (args.workload == "full" and not args.no_roofline and not args.no_model_sweep)):
+            res["model_sweep"] = model_sweep(wl, device, data)
         if wl["pool"] is not None and world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.workload, seconds=args.cpu_baseline_seconds, device=device)
         if args.workload == "full" and world == 1 and not args.no_roofline and not args.no_stress:

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 416        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 417        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -43,6 +43,9 @@ SIGNATURES = {
     "igcn_sgcn_stack_param_floats": (I, [I, I, I]),
     "igcn_sgcn_stack_fwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_sgcn_stack_bwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_sgcn_front_lds_bytes": (Z, [I, I, I, I, I]),
+    "igcn_sgcn_front_fwd": (I, [L, L, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, F, F, F, F, F, P, P, P,
+                                P, P, P, P]),
     "igcn_proj_bwd_supported": (I, [L, I, I]),
     "igcn_proj_bwd_blocks": (I, [L]),
     "igcn_proj_bwd_scratch_floats": (Z, [L, I]),

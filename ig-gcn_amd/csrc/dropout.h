@@ -32,14 +32,18 @@ __device__ __forceinline__ uint32_t dm_hash(uint32_t x) {       // lowbias32
 // at most 512 grid-striding workgroups — left two waves per SIMD to do the hashing (19 us for 18 MB of factors).
 #define DM_GROUPS 16
 #define DM_WORDS (2 + 32 * DM_GROUPS)
-// workgroup `blk` of `nblk` (a launch of its own, or the tail of another launch's grid), 256 threads
+// 256-thread block `blk` of `nblk` (a launch of its own, or the tail of another launch's grid).  `tid` = the thread's
+// index inside that block: threadIdx.x, or — in a carrier whose workgroups are 512 threads wide — threadIdx.x & 255 with
+// blk = 2 * workgroup + (threadIdx.x >> 8), so that no half of a carrier workgroup idles (a block index >= nblk takes
+// part in the barrier and does nothing else).
 __device__ __forceinline__ void dropout_masks_body(unsigned blk, unsigned nblk, int64_t total, const DropSegs& segs,
                                                    unsigned long long* __restrict__ state, float* __restrict__ out,
-                                                   const DropCounters& cnt) {
-  if (blk == 0 && (int)threadIdx.x < cnt.n) *cnt.c[threadIdx.x] += cnt.inc;
+                                                   const DropCounters& cnt, unsigned tid = threadIdx.x) {
+  const bool live = blk < nblk;
+  if (blk == 0 && (int)tid < cnt.n) *cnt.c[tid] += cnt.inc;
   const unsigned long long c = state[0];
   const uint32_t k0 = dm_hash((uint32_t)c ^ 0x9E3779B9u), k1 = dm_hash((uint32_t)(c >> 32) + 0x85EBCA6Bu + k0);
-  for (int64_t i0 = ((int64_t)blk * 256 + threadIdx.x) * 4; i0 < total; i0 += (int64_t)nblk * 1024) {
+  for (int64_t i0 = live ? ((int64_t)blk * 256 + tid) * 4 : total; i0 < total; i0 += (int64_t)nblk * 1024) {
     float v[4];
     float p = 0.f;                                     // a quad never straddles sites (sites start on multiples of 4)
     for (int sgm = 0; sgm < segs.n; ++sgm)
@@ -59,7 +63,7 @@ __device__ __forceinline__ void dropout_masks_body(unsigned blk, unsigned nblk, 
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (tid == 0 && live) {
     // every workgroup has read the counter before it arrives here; group g = blockIdx % DM_GROUPS has
     // ceil((nblk - g) / DM_GROUPS) members
     const unsigned g = blk % DM_GROUPS, ng = nblk < DM_GROUPS ? nblk : DM_GROUPS;

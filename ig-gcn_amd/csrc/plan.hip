@@ -1118,7 +1118,10 @@ int igcn_rider_dropout_waiting(hipStream_t st) {
   return (int)g_riders.count(st);
 }
 
-static bool rider_take(hipStream_t st, DropJob& job) {
+// (also taken by the front kernel of the image branch, csrc/sgcn_fused.hip, which builds the plan itself)
+bool igcn_rider_dropout_take(hipStream_t st, DropJob& job);
+static bool rider_take(hipStream_t st, DropJob& job) { return igcn_rider_dropout_take(st, job); }
+bool igcn_rider_dropout_take(hipStream_t st, DropJob& job) {
   std::lock_guard<std::mutex> lk(g_rider_mutex);
   auto it = g_riders.find(st);
   if (it == g_riders.end()) return false;

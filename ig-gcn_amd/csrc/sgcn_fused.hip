@@ -33,10 +33,13 @@ struct SfLayout {
   int x, dis, wl, wloop, ew, what, src, dst, tptr, tperm, wallT, act, wall, loop, tsrc, twhat;   // forward part
   int ycat;                                                                             // [R][L*F] layer outputs
   int sptr, sperm, g, dh, dx, dwhat, dwloop, ddeg, red, dycat, prow, bdst, bwhat, v1, v2;   // backward part
+  int fprob, fct, fcs, fsperm, fe;                                                       // front part (k_sgcn_front_fwd)
   int total;
 };
 
-__host__ __device__ inline SfLayout sf_layout(int R, int Emax, int H0, int F, int L, int backward) {
+// front = 1: the forward kernel that also BUILDS the graph's plan and its masks (k_sgcn_front_fwd) — histograms, the
+// by-source permutation, the mask's node factors and edge probabilities live in LDS until the one store burst at the end
+__host__ __device__ inline SfLayout sf_layout(int R, int Emax, int H0, int F, int L, int backward, int front = 0) {
   SfLayout o;
   int p = 0;
   auto take = [&](int n) { int q = p; p += (n + 3) & ~3; return q; };
@@ -65,6 +68,14 @@ __host__ __device__ inline SfLayout sf_layout(int R, int Emax, int H0, int F, in
   o.ycat = take(R * L * F);
   o.sptr = o.sperm = o.g = o.dh = o.dx = o.dwhat = o.dwloop = o.ddeg = o.red = o.dycat = o.prow = o.bdst = o.bwhat = 0;
   o.v1 = o.v2 = 0;
+  o.fprob = o.fct = o.fcs = o.fsperm = o.fe = 0;
+  if (front) {
+    o.fprob = take(R * H0);
+    o.fct = take(R + 1);
+    o.fcs = take(R + 1);
+    o.fsperm = take(Emax);
+    o.fe = take(Emax);
+  }
   if (backward) {
     o.sptr = take(R + 1);
     o.sperm = take(Emax);
@@ -101,6 +112,9 @@ extern "C" int igcn_debug_sf_probe(long long* out) {
 #else
 #define SF_PROBE(i)
 #endif
+
+template <bool BWD>
+__device__ __forceinline__ void sf_lists(float* lds, const SfLayout& o, int R, int ne, int32_t eb);
 
 // Returns the graph's edge count, or -1 (nothing staged beyond the fixed-size arrays) when it exceeds Emax.  The loads
 // whose size is fixed by R go out FIRST, together with the two pointer words that give the graph's edge range: the
@@ -222,6 +236,20 @@ __device__ __forceinline__ int sf_stage(float* lds, const SfLayout& o, int R, in
   }
   __syncthreads();
   SF_PROBE(1);
+  sf_lists<BWD>(lds, o, R, ne, eb);
+  return ne;
+}
+
+// From the staged graph (local endpoints, weights, by-target pointers / permutation, loop edges — by-source ones too for
+// the backward) to the lists every layer walks.  Ends WITHOUT a barrier: the caller's next __syncthreads() orders the
+// coefficient arrays before their first use.
+template <bool BWD>
+__device__ __forceinline__ void sf_lists(float* lds, const SfLayout& o, int R, int ne, int32_t eb) {
+  const int tid = threadIdx.x;
+  int32_t* ssrc = reinterpret_cast<int32_t*>(lds + o.src);
+  int32_t* sdst = reinterpret_cast<int32_t*>(lds + o.dst);
+  int32_t* stptr = reinterpret_cast<int32_t*>(lds + o.tptr);
+  int32_t* stperm = reinterpret_cast<int32_t*>(lds + o.tperm);
   // gcn_norm (PyG: drop stored loops, add one loop per node whose weight is the LAST stored loop's or 1), with the
   // list entries laid out in BY-TARGET order (tsrc, twhat): every later walk of a target's list reads two consecutive
   // arrays instead of chasing permutation -> edge -> endpoint.  Three short phases with a thread per list POSITION
@@ -268,8 +296,6 @@ __device__ __forceinline__ int sf_stage(float* lds, const SfLayout& o, int R, in
       lds[o.bwhat + p] = t != i ? lds[o.dis + i] * lds[o.ew + k] * lds[o.dis + t] : 0.f;
     }
   }
-  // (the caller's next __syncthreads() orders `what` before its first use)
-  return ne;
 }
 
 // H = X W^T (X [R, fin], row stride ldx, at `xin`), then Y = relu(A_hat H + b) (row stride ldy): one layer, out of LDS
@@ -377,6 +403,269 @@ k_sgcn_stack_fwd(int R, int Emax, int H0, int L, const float* __restrict__ x_in,
   for (int e = threadIdx.x; e < R * D / 4; e += SF_T)
     reinterpret_cast<float4*>(xcat + nb * D)[e] = reinterpret_cast<const float4*>(Y)[e];
   SF_PROBE(8);
+}
+
+// ---- the FRONT of a train step's image branch as one launch ---------------------------------------------------------
+// plan build (csrc/plan.hip: k_plan_segmented) -> masks of both passes + loss_probability + the SNP mask (csrc/sgcn.hip:
+// k_edge_mask_fwd<true>) -> the stack above were three dependent launches of one workgroup per graph each (11.7 + 6.3 +
+// 9.0 us at the bench shape, every one of them a latency chain over the same 270 edges).  Here workgroup (copy, graph) of
+// the stacked (plain | masked) batch reads the graph's int64 edge list ONCE, groups it by target and by source in LDS
+// (histograms, one-wave scan, stable placement — the arithmetic of plan_segmented_body), forms its pass's inputs (the
+// masked copy: x * prob, e = sigmoid(<xm_src | xm_dst, prob_bias>), ew * e, its share of the regulariser, its row of the
+// SNP mask; the plain copy: x, ew as they are), runs gcn_norm and the layers out of LDS, and only then writes everything
+// the rest of the step reads — the plan arrays of the batch and of its 2-copy replica (the backward kernels and the mask
+// backward walk them), x_in / ew_in / e, the regulariser partials, xcat — in one burst behind the last barrier.
+// Extra workgroups behind the 2 G graph workgroups carry the step's dropout rider (csrc/dropout.h), as the plan build's did.
+#include "dropout.h"
+#include "mask_reg.h"
+struct SfFront {
+  int64_t n_nodes, n_edges;
+  int n_graphs;
+  const int64_t *ei, *node_ptr, *edge_ptr;
+  int32_t *src32, *dst32, *tgt_ptr, *tgt_perm, *src_ptr, *src_perm, *loop_edge;             // plan of the batch
+  int32_t *r_src32, *r_dst32, *r_tgt_ptr, *r_tgt_perm, *r_src_ptr, *r_src_perm, *r_loop_edge;   // of its 2-copy replica
+  int32_t* status;
+  const float *x, *prob, *pb, *ew;
+  float *x_in, *ew_in, *e;
+  const float* snps_logits;       // [n_snps]
+  int n_snps;
+  float l1_x, ent_x, l1_e, ent_e, eps;
+  float* reg_partial;             // [n_graphs]: their SUM is loss_probability
+  const float* snps_feat;         // [n_graphs, n_snps]
+  float* snps_full;               // [2 n_graphs, n_snps] = (feat | feat * sigmoid(logits))
+};
+
+template <int F>
+__global__ void __launch_bounds__(SF_T)
+k_sgcn_front_fwd(int R, int Emax, int H0, int L, const SfFront fr, SfParams prm, float* __restrict__ xcat,
+                 int64_t d_total, const DropSegs d_segs, unsigned long long* __restrict__ d_state,
+                 float* __restrict__ d_out, const DropCounters d_cnt, unsigned d_blocks) {
+  extern __shared__ float sf_lds[];
+  const int G = fr.n_graphs;
+  if ((int)blockIdx.x >= 2 * G) {                // the dropout rider: two of its 256-thread blocks per carrier workgroup
+    dropout_masks_body(2u * (blockIdx.x - 2u * (unsigned)G) + (threadIdx.x >> 8), d_blocks, d_total, d_segs, d_state, d_out,
+                       d_cnt, threadIdx.x & 255u);
+    return;
+  }
+  float* lds = sf_lds;
+  const SfLayout o = sf_layout(R, Emax, H0, F, L, 0, 1);
+  const int tid = threadIdx.x, bd = (int)blockDim.x;
+  const int copy = (int)blockIdx.x / G, g = (int)blockIdx.x - copy * G;
+  // (uniform graphs: the node offset is g R — the loads of x do not wait for a pointer; node_ptr must agree, below)
+  const int64_t nb = (int64_t)g * R, nb_given = fr.node_ptr[g], eb64 = fr.edge_ptr[g];
+  const int nn = (int)(fr.node_ptr[g + 1] - nb_given), ne = (int)(fr.edge_ptr[g + 1] - eb64);
+  const int32_t N32 = (int32_t)fr.n_nodes, E32 = (int32_t)fr.n_edges;
+  // node features and mask factors: requested BEFORE the pointer words are waited for (the host has checked that the
+  // batch holds n_graphs * R nodes, so the addresses are inside x whatever the pointers say)
+  const int nx = R * H0;
+  float xv[4], pv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + j * bd;
+    xv[j] = i < nx ? fr.x[nb * H0 + i] : 0.f;
+    pv[j] = (copy && i < nx) ? fr.prob[i] : 1.f;
+  }
+  // the offsets come from device memory (a loader may have handed over garbage): refuse anything that is not a graph of
+  // R nodes inside the batch with at most Emax edges — status bit 0 (not a block-diagonal batch) / bit 1 (too many edges)
+  if (nn != R || nb_given != nb || ne < 0 || eb64 < 0 || nb + nn > fr.n_nodes || eb64 + ne > fr.n_edges) {
+    if (tid == 0) atomicOr(fr.status, 1);
+    return;
+  }
+  if (ne > Emax) {
+    if (tid == 0) atomicOr(fr.status, 2);
+    return;
+  }
+  const int32_t eb = (int32_t)eb64;
+  int32_t* ssrc = reinterpret_cast<int32_t*>(lds + o.src);
+  int32_t* sdst = reinterpret_cast<int32_t*>(lds + o.dst);
+  int32_t* stptr = reinterpret_cast<int32_t*>(lds + o.tptr);
+  int32_t* stperm = reinterpret_cast<int32_t*>(lds + o.tperm);
+  int32_t* sloop = reinterpret_cast<int32_t*>(lds + o.loop);
+  int32_t* ct = reinterpret_cast<int32_t*>(lds + o.fct);
+  int32_t* cs = reinterpret_cast<int32_t*>(lds + o.fcs);
+  int32_t* ssperm = reinterpret_cast<int32_t*>(lds + o.fsperm);
+  // ---- stage: one batch of loads per thread (edge endpoints, weight; node features and mask factors are on their way)
+  int64_t es[2] = {0, 0}, ed[2] = {0, 0};
+  float ev[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = tid + j * bd;
+    if (k < ne) {
+      es[j] = fr.ei[eb64 + k];
+      ed[j] = fr.ei[fr.n_edges + eb64 + k];
+      ev[j] = fr.ew[eb64 + k];
+    }
+  }
+  const int wstride = F * (F > H0 ? F : H0) + F;
+  const int wtotal = F * H0 + F + (L - 1) * (F * F + F);
+  for (int j = tid; j < wtotal; j += bd) {                        // W_l transposed | b_l, as sf_stage lays them out
+    int off = 0;
+    for (int l = 0; l < L; ++l) {
+      const int fin = l == 0 ? H0 : F, nw = F * fin, n = nw + F;
+      if (j < off + n) {
+        const int r = j - off;
+        lds[o.wallT + l * wstride + (r < nw ? (r % fin) * F + r / fin : r)] = r < nw ? prm.W[l][r] : prm.b[l][r - nw];
+        break;
+      }
+      off += n;
+    }
+  }
+  for (int i = tid; i <= R; i += bd) { ct[i] = 0; cs[i] = 0; }
+  for (int i = tid; i < R; i += bd) sloop[i] = -1;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = tid + j * bd;
+    if (k < ne) {
+      int64_t s = es[j] - nb, d = ed[j] - nb;
+      if (s < 0 || s >= R || d < 0 || d >= R) { bad = true; s = 0; d = 0; }
+      ssrc[k] = (int32_t)s;
+      sdst[k] = (int32_t)d;
+      lds[o.ew + k] = ev[j];
+    }
+  }
+  for (int k = tid + 2 * bd; k < ne; k += bd) {                   // graphs with more than 2 * 512 edges
+    int64_t s = fr.ei[eb64 + k] - nb, d = fr.ei[fr.n_edges + eb64 + k] - nb;
+    if (s < 0 || s >= R || d < 0 || d >= R) { bad = true; s = 0; d = 0; }
+    ssrc[k] = (int32_t)s;
+    sdst[k] = (int32_t)d;
+    lds[o.ew + k] = fr.ew[eb64 + k];
+  }
+  if (bad) atomicOr(fr.status, 1);                                 // an edge leaves its graph: not a PyG batch
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + j * bd;
+    if (i < nx) lds[o.x + i] = xv[j] * pv[j];                      // the masked copy's x * prob (plain: x * 1 = x)
+  }
+  for (int i = tid + 4 * bd; i < nx; i += bd) lds[o.x + i] = fr.x[nb * H0 + i] * (copy ? fr.prob[i] : 1.f);
+  __syncthreads();
+  // ---- plan: histograms by target / by source, last stored loop per node
+  for (int k = tid; k < ne; k += bd) {
+    const int s = ssrc[k], d = sdst[k];
+    atomicAdd(&ct[d + 1], 1);
+    atomicAdd(&cs[s + 1], 1);
+    if (s == d) atomicMax(&sloop[s], k);
+  }
+  __syncthreads();
+  if (tid < 64) {                                                  // both scans by one wave (plan_segmented_body)
+    const int per = (R + 64) / 64, lo = tid * per, hi = min(R + 1, lo + per);
+    int st = 0, ss = 0;
+    for (int i = lo; i < hi; ++i) { st += ct[i]; ss += cs[i]; }
+    int pt = st, ps = ss;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int a = __shfl_up(pt, off, 64), b = __shfl_up(ps, off, 64);
+      if (tid >= off) { pt += a; ps += b; }
+    }
+    int rt = pt - st, rs = ps - ss;
+    for (int i = lo; i < hi; ++i) {
+      rt += ct[i]; rs += cs[i];
+      ct[i] = rt; cs[i] = rs;
+    }
+  }
+  __syncthreads();
+  // stable placement (one thread per edge: its slot = the number of EARLIER edges with the same key), the masked copy's
+  // edge probabilities beside it
+  const float* pbv = fr.pb;
+  float racc = 0.f;
+  for (int k = tid; k < ne; k += bd) {
+    const int kd = sdst[k], ks = ssrc[k];
+    int rd = 0, rs = 0;
+#pragma unroll 8
+    for (int j = 0; j < k; ++j) {
+      rd += (sdst[j] == kd);
+      rs += (ssrc[j] == ks);
+    }
+    stperm[ct[kd] + rd] = k;
+    ssperm[cs[ks] + rs] = k;
+    if (copy) {
+      float z = 0.f;
+      for (int h = 0; h < H0; ++h) z += lds[o.x + ks * H0 + h] * pbv[h];
+      for (int h = 0; h < H0; ++h) z += lds[o.x + kd * H0 + h] * pbv[H0 + h];
+      const float p = 1.f / (1.f + expf(-z));
+      lds[o.fe + k] = p;
+      racc += em_reg_term(p, fr.l1_e, fr.ent_e, fr.eps) / (float)fr.n_edges;
+    }
+  }
+  for (int i = tid; i <= R; i += bd) stptr[i] = ct[i];
+  for (int i = tid; i < R; i += bd) {                              // (sf_lists reads batch-global loop edge ids)
+    const int32_t l = sloop[i];
+    sloop[i] = l >= 0 ? eb + l : -1;
+  }
+  __syncthreads();
+  if (copy)
+    for (int k = tid; k < ne; k += bd) lds[o.ew + k] = lds[o.ew + k] * lds[o.fe + k];     // ew * e
+  __syncthreads();
+  sf_lists<false>(lds, o, R, ne, eb);          // (the first barrier inside sf_layer orders its lists before their use)
+  float* H = lds + o.act;
+  float* Y = lds + o.ycat;
+  const int D = L * F;
+  for (int l = 0; l < L; ++l) {
+    const float* wl = lds + o.wallT + l * wstride;
+    sf_layer<F>(lds, o, R, l == 0 ? H0 : F, l == 0 ? lds + o.x : Y + (l - 1) * F, l == 0 ? H0 : D, H, Y + l * F, D, wl,
+                wl + F * (l == 0 ? H0 : F));
+  }
+  // loss_probability: the edge term of this graph; workgroup (1, 0) adds the two node-level means (the same sums as
+  // k_edge_mask_fwd<true>, grouped per graph instead of per 256 edges)
+  if (copy) {
+    if (g == 0) {
+      const int64_t np = (int64_t)R * H0;
+      for (int i = tid; i < np; i += bd)
+        racc += em_reg_term(1.f / (1.f + expf(-fr.prob[i])), fr.l1_x, fr.ent_x, fr.eps) / (float)np;
+      if (fr.snps_logits)
+        for (int i = tid; i < fr.n_snps; i += bd)
+          racc += em_reg_term(1.f / (1.f + expf(-fr.snps_logits[i])), fr.l1_x, fr.ent_x, fr.eps) / (float)fr.n_snps;
+    }
+    racc = block_sum_all(racc, lds + o.dis);                       // (dis is dead behind the last layer)
+    if (tid == 0) fr.reg_partial[g] = racc;
+  }
+  // ---- the one store burst -----------------------------------------------------------------------------------------
+  const int64_t nbo = (int64_t)copy * fr.n_nodes + nb, ebo = (int64_t)copy * fr.n_edges + eb64;
+  for (int q = tid; q < R * D / 4; q += bd)
+    reinterpret_cast<float4*>(xcat + nbo * D)[q] = reinterpret_cast<const float4*>(Y)[q];
+  for (int i = tid; i < nx; i += bd) fr.x_in[nbo * H0 + i] = lds[o.x + i];
+  for (int k = tid; k < ne; k += bd) {
+    fr.ew_in[ebo + k] = lds[o.ew + k];
+    if (copy) fr.e[eb64 + k] = lds[o.fe + k];
+    const int32_t s = (int32_t)nb + ssrc[k], d = (int32_t)nb + sdst[k];
+    const int32_t tp = eb + stperm[k], sp = eb + ssperm[k];
+    fr.r_src32[ebo + k] = s + copy * N32;
+    fr.r_dst32[ebo + k] = d + copy * N32;
+    fr.r_tgt_perm[ebo + k] = tp + copy * E32;
+    fr.r_src_perm[ebo + k] = sp + copy * E32;
+    if (!copy) {
+      fr.src32[eb64 + k] = s;
+      fr.dst32[eb64 + k] = d;
+      fr.tgt_perm[eb64 + k] = tp;
+      fr.src_perm[eb64 + k] = sp;
+    }
+  }
+  for (int i = tid; i < R; i += bd) {
+    const int32_t tp = eb + ct[i], sp = eb + cs[i], le = sloop[i];
+    fr.r_tgt_ptr[nbo + i] = tp + copy * E32;
+    fr.r_src_ptr[nbo + i] = sp + copy * E32;
+    fr.r_loop_edge[nbo + i] = le >= 0 ? le + copy * E32 : -1;
+    if (!copy) {
+      fr.tgt_ptr[nb + i] = tp;
+      fr.src_ptr[nb + i] = sp;
+      fr.loop_edge[nb + i] = le;
+    }
+  }
+  if (g == G - 1 && tid == 0) {
+    if (copy) {
+      fr.r_tgt_ptr[2 * fr.n_nodes] = 2 * E32;
+      fr.r_src_ptr[2 * fr.n_nodes] = 2 * E32;
+    } else {
+      fr.tgt_ptr[fr.n_nodes] = E32;
+      fr.src_ptr[fr.n_nodes] = E32;
+    }
+  }
+  if (fr.snps_feat)
+    for (int j = tid; j < fr.n_snps; j += bd) {
+      const float v = fr.snps_feat[(int64_t)g * fr.n_snps + j];
+      fr.snps_full[((int64_t)copy * G + g) * fr.n_snps + j] =
+          copy ? v * (1.f / (1.f + __expf(-fr.snps_logits[j]))) : v;                         // = k_snps_mask_fwd, bit for bit
+    }
 }
 
 // parameter-gradient partial row of one graph: [ dW_0 (F x H0) | db_0 (F) | dW_1 (F x F) | db_1 | ... ]
@@ -719,6 +1008,70 @@ extern "C" int igcn_sgcn_stack_fwd(int64_t n_graphs, int R, int max_edges, int H
   }
 #undef SF_FWD
   IGCN_CHECK_LAUNCH("sgcn_stack_fwd");
+  return IGCN_OK;
+}
+
+extern "C" size_t igcn_sgcn_front_lds_bytes(int R, int max_edges, int H0, int F, int L) {
+  return (size_t)sf_layout(R, max_edges, H0, F, L, 0, 1).total * 4;
+}
+
+bool igcn_rider_dropout_take(hipStream_t st, DropJob& job);        // plan.hip
+
+// The front of the image branch of a train step (see k_sgcn_front_fwd): plan of the batch + of its 2-copy replica, the
+// stacked (plain | masked) inputs x_in [2N, H0] / ew_in [2E], the edge mask e [E], loss_probability as reg_partial
+// [n_graphs] (their sum), the SNP mask snps_full [2 n_graphs, n_snps], and xcat [2N, L F] — one launch, which also
+// carries a dropout rider waiting on the stream.  Uniform graphs of R nodes, at most max_edges edges each.
+extern "C" int igcn_sgcn_front_fwd(int64_t n_nodes, int64_t n_edges, int n_graphs, int R, int max_edges, int H0, int F,
+                                   int L, const int64_t* edge_index, const int64_t* node_ptr, const int64_t* edge_ptr,
+                                   int32_t* const* plan /*HOST [7]: src32 dst32 tgt_ptr tgt_perm src_ptr src_perm loop_edge*/,
+                                   int32_t* const* plan2 /*HOST [7]: the same arrays of the 2-copy replica*/,
+                                   int32_t* status, const float* x, const float* prob, const float* prob_bias,
+                                   const float* ew, float* x_in, float* ew_in, float* e, const float* snps_logits,
+                                   int n_snps, float l1_x, float ent_x, float l1_e, float ent_e, float eps,
+                                   float* reg_partial, const float* snps_feat, float* snps_full,
+                                   const float* const* W /*HOST [L]*/, const float* const* b /*HOST [L]*/, float* xcat,
+                                   void* stream) {
+  int rc = sf_check("sgcn_front_fwd", 2 * (int64_t)n_graphs, R, max_edges, H0, F, L, 0);
+  if (rc) return rc;
+  IGCN_REQUIRE(n_graphs > 0 && n_nodes == (int64_t)n_graphs * R && n_edges > 0 && 2 * n_nodes < ((int64_t)1 << 31) &&
+                   2 * n_edges < ((int64_t)1 << 31),
+               "sgcn_front_fwd: uniform graphs of R nodes, sizes of the 2-copy batch inside int32");
+  IGCN_REQUIRE(edge_index && node_ptr && edge_ptr && plan && plan2 && status && x && prob && prob_bias && ew && x_in &&
+                   ew_in && e && reg_partial && xcat && ((uintptr_t)xcat & 15) == 0,
+               "sgcn_front_fwd: null argument / xcat not 16-byte aligned");
+  IGCN_REQUIRE(n_snps >= 0 && (snps_feat == nullptr || (snps_logits && snps_full && n_snps > 0)),
+               "sgcn_front_fwd: the SNP mask needs logits and an output");
+  for (int i = 0; i < 7; ++i) IGCN_REQUIRE(plan[i] && plan2[i], "sgcn_front_fwd: null plan array %d", i);
+  const size_t lds = igcn_sgcn_front_lds_bytes(R, max_edges, H0, F, L);
+  if (lds > 150 * 1024) {
+    igcn_set_error("sgcn_front_fwd: a graph of %d nodes / %d edges does not fit LDS", R, max_edges);
+    return IGCN_ERR_UNSUPPORTED;
+  }
+  SfParams prm = {};
+  for (int l = 0; l < L; ++l) { prm.W[l] = W[l]; prm.b[l] = b[l]; }
+  SfFront fr = {n_nodes, n_edges, n_graphs, edge_index, node_ptr, edge_ptr,
+                plan[0], plan[1], plan[2], plan[3], plan[4], plan[5], plan[6],
+                plan2[0], plan2[1], plan2[2], plan2[3], plan2[4], plan2[5], plan2[6],
+                status, x, prob, prob_bias, ew, x_in, ew_in, e, snps_logits, snps_logits ? n_snps : 0, l1_x, ent_x, l1_e,
+                ent_e, eps, reg_partial, snps_feat, snps_full};
+  hipStream_t st = (hipStream_t)stream;
+  DropJob job = {};
+  const bool ride = igcn_rider_dropout_take(st, job);
+  const unsigned grid = 2u * (unsigned)n_graphs + (ride ? (job.blocks + 1u) / 2u : 0u);
+#define SF_FRONT(FV)                                                                                              \
+  {                                                                                                               \
+    if (lds > 64 * 1024) IGCN_ALLOW_BIG_LDS((k_sgcn_front_fwd<FV>));                                              \
+    hipLaunchKernelGGL((k_sgcn_front_fwd<FV>), dim3(grid), dim3(SF_T), lds, st, R, max_edges, H0, L, fr, prm, xcat, \
+                       job.total, job.sg, job.state, job.out, job.cnt, job.blocks);                                \
+  }
+  switch (F) {
+    case 4: SF_FRONT(4) break;
+    case 8: SF_FRONT(8) break;
+    case 16: SF_FRONT(16) break;
+    default: SF_FRONT(32) break;
+  }
+#undef SF_FRONT
+  IGCN_CHECK_LAUNCH("sgcn_front_fwd");
   return IGCN_OK;
 }
 

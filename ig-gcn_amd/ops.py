@@ -259,11 +259,18 @@ class GraphPlan:
              ptr(self.tgt_perm), ptr(self.src_ptr), ptr(self.src_perm), ptr(self.loop_edge), ptr(self._ws),
              self._ws.numel(), stream_ptr())
 
-    def rebuild(self, edge_index):
+    def rebuild(self, edge_index, lazy=False):
         """Build again IN PLACE for a new ``edge_index`` of the same size (same graph segments): every plan tensor
-        keeps its address, so kernels captured in a hipGraph keep reading the right memory."""
+        keeps its address, so kernels captured in a hipGraph keep reading the right memory.
+        ``lazy``: a per-graph LDS build is only NOTED — the first consumer either builds the plan itself while it reads the
+        edges anyway (ops.SgcnFront: ``take_pending_build``) or launches the build (``flush_pending_build``)."""
         if edge_index.shape != (2, self.n_edges) or edge_index.dtype != torch.int64:
             raise _lib.IgcnError("rebuild needs an int64 edge_index of the shape the plan was built for")
+        self._pending_build = None
+        if (lazy and self._seg is not None and not self._tiled and self._stack_dims is not None
+                and not getattr(self, "dense_blocks", False)):
+            self._pending_build = edge_index.contiguous()
+            return
         if getattr(self, "dense_blocks", False):
             # complete row-major graphs: the new batch has the SAME structure or none the dense kernels can use — one
             # pass over edge_index verifies it (status bit 2); the sorted arrays of the first build stay valid.  The
@@ -281,6 +288,18 @@ class GraphPlan:
             self._copies = {}
         self._build(edge_index.contiguous())
 
+    def take_pending_build(self):
+        """The edge_index of a ``rebuild(lazy=True)`` nobody has performed yet (None: the plan is up to date)."""
+        ei = getattr(self, "_pending_build", None)
+        self._pending_build = None
+        return ei
+
+    def flush_pending_build(self):
+        """Perform a deferred ``rebuild`` now (a consumer that reads the plan arrays instead of building them)."""
+        ei = self.take_pending_build()
+        if ei is not None:
+            self.rebuild(ei)
+
     def take_pending_check(self):
         """The edge_index whose structure check is still to run (``rebuild`` of a dense-block plan), handed to the
         consumer that lets it ride in its own launch (igcn_dense_sgcn_fwd); None when nothing is pending."""
@@ -297,6 +316,7 @@ class GraphPlan:
 
     def check(self):
         """Host-synchronising validation of the segmented build (tests / debugging only)."""
+        self.flush_pending_build()
         self.flush_pending_check()
         code = int(self.status[0].item()) if self.status is not None else 0
         if code & 4:
@@ -313,6 +333,7 @@ class GraphPlan:
         """Plan of ``copies`` disjoint copies of this batch (igcn_graph_plan_replicate), cached."""
         if copies == 1:
             return self
+        self.flush_pending_build()
         if copies not in self._copies:
             rep = object.__new__(GraphPlan)
             n, e = self.n_nodes, self.n_edges
@@ -333,8 +354,9 @@ class GraphPlan:
         return self._copies[copies]
 
 
-def plan_for(data):
-    """The GraphPlan of a batch object, built on first use and cached on it."""
+def plan_for(data, keep_pending=False):
+    """The GraphPlan of a batch object, built on first use and cached on it.  A build that ``rebuild(lazy=True)`` deferred
+    is performed here unless the caller takes care of it itself (``keep_pending``: SGCN_GCN_IMGSNP._forward_grouped)."""
     plan = getattr(data, "_igcn_plan", None)
     if plan is None or plan.n_edges != data.edge_index.shape[1] or plan.src32.device != data.edge_index.device:
         plan = GraphPlan(data.edge_index, data.x.shape[0], getattr(data, "ptr", None),
@@ -344,6 +366,8 @@ def plan_for(data):
             data._igcn_plan = plan
         except AttributeError:
             pass
+    if not keep_pending:
+        plan.flush_pending_build()
     return plan
 
 
@@ -442,21 +466,28 @@ class EdgeMaskStacked(torch.autograd.Function):
         if ctx.reg is None:
             return _edge_mask_backward(ctx, d_xm, d_ewm, d_e, d_xp) + (None, None, None)
         x, prob, pb, ew, e, snps, feat = ctx.saved_tensors
-        hp, ns, snps_shape, rows = ctx.reg
-        plan, rois = ctx.plan, ctx.rois
-        h0 = x.shape[1]
-        d_xm, d_ewm, d_e, d_xp, d_full = (_f32(t) if t is not None else None for t in (d_xm, d_ewm, d_e, d_xp, d_full))
-        # the partials' gradient is one scalar, repeated (ops.LossHead); none: the regulariser was not used
-        greg = _f32(d_regp[:1]).reshape(1) if d_regp is not None else torch.zeros(1, dtype=torch.float32, device=x.device)
-        dx, dprob, dpb = torch.empty_like(x), torch.empty_like(prob), torch.empty_like(pb)
-        dsnps = torch.empty(snps_shape, dtype=torch.float32, device=x.device) if snps is not None else None
-        scratch = torch.empty(n * h0 + 16 * ((n + 3) // 4) + 16, dtype=torch.float32, device=x.device)
-        use_feat = feat is not None and d_full is not None
-        call("igcn_edge_mask_bwd_reg", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew), ptr(e), ptr(d_xm),
-             ptr(d_ewm), ptr(d_e), ptr(d_xp), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm),
-             ptr(greg), ptr(snps), ns, *hp, ptr(dx), ptr(dprob), ptr(dpb), ptr(dsnps), ptr(scratch),
-             ptr(feat) if use_feat else None, rows if use_feat else 0, ptr(d_full) if use_feat else None, stream_ptr())
+        dx, dprob, dpb, dsnps = _edge_mask_reg_backward(x, prob, pb, ew, e, snps, feat, ctx.reg, ctx.plan, ctx.rois, d_xm,
+                                                        d_ewm, d_e, d_xp, d_regp, d_full)
         return dx, dprob, dpb, None, None, None, dsnps, None, None
+
+
+def _edge_mask_reg_backward(x, prob, pb, ew, e, snps, feat, reg, plan, rois, d_xm, d_ewm, d_e, d_xp, d_regp, d_full):
+    """Backward of the stacked mask launch with the regulariser and the SNP mask riding in it (igcn_edge_mask_bwd_reg):
+    (dx, dprob, dpb, dsnps)."""
+    hp, ns, snps_shape, rows = reg
+    n, h0 = x.shape
+    d_xm, d_ewm, d_e, d_xp, d_full = (_f32(t) if t is not None else None for t in (d_xm, d_ewm, d_e, d_xp, d_full))
+    # the partials' gradient is one scalar, repeated (ops.LossHead); none: the regulariser was not used
+    greg = _f32(d_regp[:1]).reshape(1) if d_regp is not None else torch.zeros(1, dtype=torch.float32, device=x.device)
+    dx, dprob, dpb = torch.empty_like(x), torch.empty_like(prob), torch.empty_like(pb)
+    dsnps = torch.empty(snps_shape, dtype=torch.float32, device=x.device) if snps is not None else None
+    scratch = torch.empty(n * h0 + 16 * ((n + 3) // 4) + 16, dtype=torch.float32, device=x.device)
+    use_feat = feat is not None and d_full is not None
+    call("igcn_edge_mask_bwd_reg", n, plan.n_edges, rois, h0, ptr(x), ptr(prob), ptr(pb), ptr(ew), ptr(e), ptr(d_xm),
+         ptr(d_ewm), ptr(d_e), ptr(d_xp), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm),
+         ptr(greg), ptr(snps), ns, *hp, ptr(dx), ptr(dprob), ptr(dpb), ptr(dsnps), ptr(scratch),
+         ptr(feat) if use_feat else None, rows if use_feat else 0, ptr(d_full) if use_feat else None, stream_ptr())
+    return dx, dprob, dpb, dsnps
 
 
 class GcnNorm(torch.autograd.Function):
@@ -615,37 +646,110 @@ class SgcnStack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dxcat, dxcat2=None):
         x_in, ew_in, *wb = ctx.saved_tensors
+        dx, dew, grads = _sgcn_stack_backward(x_in, ew_in, wb, ctx.plan, ctx.rois, ctx.final, dxcat, dxcat2)
+        return (dx, dew, None, None, *grads)
+
+
+def _sgcn_stack_backward(x_in, ew_in, wb, plan, rois, final, dxcat, dxcat2):
+    """igcn_sgcn_stack_bwd on the batched plan ``plan``: (dx_in, dew_in, [dW_0, db_0, dW_1, ...])."""
+    ws, bs = wb[0::2], wb[1::2]
+    if dxcat is None:
+        dxcat, dxcat2 = dxcat2, None
+    if dxcat is None:
+        dxcat = torch.zeros(x_in.shape[0], len(ws) * ws[0].shape[0], dtype=torch.float32, device=x_in.device)
+    dxcat = _f32(dxcat)
+    dxcat2 = _f32(dxcat2) if dxcat2 is not None else None
+    n, h0 = x_in.shape
+    f, layers = ws[0].shape[0], len(ws)
+    emax = plan._stack_dims[1]
+    g = n // rois
+    lib = _lib.load()
+    npar = int(lib.igcn_sgcn_stack_param_floats(h0, f, layers))
+    dx, dew = torch.empty_like(x_in), torch.empty_like(ew_in)
+    dpar = torch.empty(npar, dtype=torch.float32, device=x_in.device)
+    scratch = _keep(torch.empty(g * npar, dtype=torch.float32, device=x_in.device))
+    wp = (ctypes.c_void_p * layers)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * layers)(*[b.data_ptr() for b in bs])
+    with _immediate(final):
+        call("igcn_sgcn_stack_bwd", g, rois, emax, h0, f, layers, ptr(x_in), ptr(ew_in), ptr(plan.src32),
+             ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm),
+             ptr(plan.loop_edge), wp, bp, ptr(dxcat), ptr(dxcat2), ptr(dx), ptr(dew), ptr(dpar), ptr(scratch),
+             ptr(plan.status), stream_ptr())
+    grads, off = [], 0
+    for l in range(layers):
+        fin = h0 if l == 0 else f
+        grads.append(dpar[off:off + f * fin].view(f, fin))
+        grads.append(dpar[off + f * fin:off + f * fin + f])
+        off += f * fin + f
+    return dx, dew, grads
+
+
+def sgcn_front_supported(plan, rois, h0, f, layers, snps_feat, snps_logits):
+    """The one-launch front of a train step's image branch (igcn_sgcn_front_fwd) covers this batch: what the LDS-resident
+    stack covers, on a plan that is built per graph in LDS (not tiled, not dense blocks), with the SNP mask riding along."""
+    if (not sgcn_stack_supported(plan, rois, h0, f, layers) or plan._seg is None or plan._tiled
+            or getattr(plan, "dense_blocks", False) or os.environ.get("IGCN_NO_FRONT_FUSED", "0") == "1"
+            or os.environ.get("IGCN_NO_FUSED_SGCN", "0") == "1" or os.environ.get("IGCN_PLAN_REPLICATE_LAUNCH", "0") == "1"):
+        return False
+    if snps_feat is None or snps_feat.dim() != 2 or snps_logits is None or snps_feat.shape[1] != snps_logits.numel():
+        return False
+    return int(_lib.load().igcn_sgcn_front_lds_bytes(rois, plan._stack_dims[1], h0, f, layers)) <= 150 * 1024
+
+
+class SgcnFront(torch.autograd.Function):
+    """The front of the image branch of a train step — graph plan, cal_probability for the stacked (plain | masked) batch,
+    loss_probability, the SNP mask and the GCNConv stack of both passes (kernel/sgcn_img_snp.py:133-181,218-224; train()
+    :521-523) — as ONE launch (igcn_sgcn_front_fwd) instead of plan build -> EdgeMaskStacked -> SgcnStack.  Outputs
+    (xcat, xcat alias, e, reg partials, stacked SNP mask); backward = the two existing backward launches (igcn_sgcn_stack_bwd
+    on the 2-copy plan, igcn_edge_mask_bwd_reg), which walk the plan arrays this launch wrote."""
+
+    @staticmethod
+    def forward(ctx, x, prob, prob_bias, ew, plan, rois, snps_logits, reg_hp, snps_feat, edge_index, *wb):
+        x, prob, pb, ew = _f32(x), _f32(prob), _f32(prob_bias), _f32(ew)
+        wb = [_f32(t) for t in wb]
         ws, bs = wb[0::2], wb[1::2]
-        plan, rois = ctx.plan, ctx.rois
-        if dxcat is None:
-            dxcat, dxcat2 = dxcat2, None
-        if dxcat is None:
-            dxcat = torch.zeros(x_in.shape[0], len(ws) * ws[0].shape[0], dtype=torch.float32, device=x_in.device)
-        dxcat = _f32(dxcat)
-        dxcat2 = _f32(dxcat2) if dxcat2 is not None else None
-        n, h0 = x_in.shape
+        n, h0 = x.shape
+        ne = ew.shape[0]
         f, layers = ws[0].shape[0], len(ws)
-        emax = plan._stack_dims[1]
-        g = n // rois
-        lib = _lib.load()
-        npar = int(lib.igcn_sgcn_stack_param_floats(h0, f, layers))
-        dx, dew = torch.empty_like(x_in), torch.empty_like(ew_in)
-        dpar = torch.empty(npar, dtype=torch.float32, device=x_in.device)
-        scratch = _keep(torch.empty(g * npar, dtype=torch.float32, device=x_in.device))
+        dev = x.device
+        node_ptr, edge_ptr, _, _ = plan._seg
+        g = int(node_ptr.numel()) - 1
+        plan.take_pending_build()                       # a deferred build is not needed: this launch fills the plan ...
+        plan_g = plan.replicate(2)                      # ... and its 2-copy replica (here: the arrays)
+        snps = _f32(snps_logits).reshape(-1)
+        feat = _f32(snps_feat)
+        ns = snps.numel()
+        f32 = dict(dtype=torch.float32, device=dev)
+        x_in = torch.empty(2 * n, h0, **f32)
+        ew_in = torch.empty(2 * ne, **f32)
+        e = torch.empty(ne, **f32)
+        regp = torch.empty(g, **f32)
+        full = torch.empty(2 * feat.shape[0], ns, **f32)
+        xcat = torch.empty(2 * n, layers * f, **f32)
+        hp = tuple(float(v) for v in reg_hp)
+        names = ("src32", "dst32", "tgt_ptr", "tgt_perm", "src_ptr", "src_perm", "loop_edge")
+        p1 = (ctypes.c_void_p * 7)(*[getattr(plan, k).data_ptr() for k in names])
+        p2 = (ctypes.c_void_p * 7)(*[getattr(plan_g, k).data_ptr() for k in names])
         wp = (ctypes.c_void_p * layers)(*[w.data_ptr() for w in ws])
         bp = (ctypes.c_void_p * layers)(*[b.data_ptr() for b in bs])
-        with _immediate(ctx.final):
-            call("igcn_sgcn_stack_bwd", g, rois, emax, h0, f, layers, ptr(x_in), ptr(ew_in), ptr(plan.src32),
-                 ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.src_ptr), ptr(plan.src_perm),
-                 ptr(plan.loop_edge), wp, bp, ptr(dxcat), ptr(dxcat2), ptr(dx), ptr(dew), ptr(dpar), ptr(scratch),
-                 ptr(plan.status), stream_ptr())
-        grads, off = [], 0
-        for l in range(layers):
-            fin = h0 if l == 0 else f
-            grads.append(dpar[off:off + f * fin].view(f, fin))
-            grads.append(dpar[off + f * fin:off + f * fin + f])
-            off += f * fin + f
-        return (dx, dew, None, None, *grads)
+        call("igcn_sgcn_front_fwd", n, ne, g, rois, plan._stack_dims[1], h0, f, layers, ptr(edge_index), ptr(node_ptr),
+             ptr(edge_ptr), p1, p2, ptr(plan.status), ptr(x), ptr(prob), ptr(pb), ptr(ew), ptr(x_in), ptr(ew_in), ptr(e),
+             ptr(snps), ns, *hp, ptr(regp), ptr(feat), ptr(full), wp, bp, ptr(xcat), stream_ptr())
+        ctx.save_for_backward(x, prob, pb, ew, e, snps, feat, x_in, ew_in, *wb)
+        ctx.plan, ctx.plan_g, ctx.rois = plan, plan_g, rois
+        ctx.reg = (hp, ns, snps_logits.shape, feat.shape[0])
+        ctx.final = _leaves(*wb)
+        ctx.set_materialize_grads(False)
+        return xcat, xcat.view(2 * n, layers * f), e, regp, full
+
+    @staticmethod
+    def backward(ctx, dxcat, dxcat2, d_e, d_regp, d_full):
+        x, prob, pb, ew, e, snps, feat, x_in, ew_in, *wb = ctx.saved_tensors
+        n, ne = x.shape[0], ew.shape[0]
+        dx_in, dew_in, grads = _sgcn_stack_backward(x_in, ew_in, wb, ctx.plan_g, ctx.rois, ctx.final, dxcat, dxcat2)
+        dx, dprob, dpb, dsnps = _edge_mask_reg_backward(x, prob, pb, ew, e, snps, feat, ctx.reg, ctx.plan, ctx.rois,
+                                                        dx_in[n:], dew_in[ne:], d_e, dx_in[:n], d_regp, d_full)
+        return (dx, dprob, dpb, None, None, None, dsnps, None, None, None, *grads)
 
 
 def dense_sgcn_supported(plan, rois, h0, f, layers):

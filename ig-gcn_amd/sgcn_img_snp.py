@@ -310,7 +310,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         if n % self.rois:
             raise ValueError(f"every graph must have exactly rois={self.rois} nodes (got {n} nodes)")
         bsz, g = n // self.rois, len(explain_flags)
-        plan = ops.plan_for(data)
+        plan = ops.plan_for(data, keep_pending=True)
         self.last_edge_prob = None
         self._dense_reg = None
         self._last_mask_key = self._reg_key(x, edge_weight)
@@ -328,6 +328,18 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                      and ops.dense_sgcn_supported(plan, self.rois, x.shape[1], convs[0].out_channels, len(convs)))
         if not use_dense:
             plan.flush_pending_check()     # (a dense-block plan's structure check rides in ops.DenseSgcn otherwise)
+        # the train step's (plain | masked) pair on small uniform graphs: plan build, masks, regulariser, SNP mask and the
+        # GCNConv stack of both passes as ONE launch (ops.SgcnFront) — decided here, because every other route reads the
+        # plan arrays and has to perform a deferred build first
+        f_conv = convs[0].out_channels
+        fp_conv = f_conv if f_conv in _WIDE else next((w for w in _WIDE if w >= f_conv), f_conv)
+        use_front = (not use_dense and tuple(explain_flags) == (False, True) and x.is_cuda and snps_ok and fan
+                     and self._reg_hp is not None and os.environ.get("IGCN_NO_MASK_REG_FUSED", "0") != "1"
+                     and self.fused_sgcn_stack and not self.bf16_transforms
+                     and ops.sgcn_front_supported(plan, self.rois, x.shape[1], fp_conv, len(convs), snps_feat,
+                                                  self.snps_prob))
+        if not use_front:
+            plan.flush_pending_build()
         if use_dense:
             # complete graphs (a dense adjacency as COO): masks, gcn_norm, every GCNConv and the mask regulariser of the
             # pass(es) on the dense blocks — no plan arrays, no per-edge intermediates (ops.DenseSgcn)
@@ -353,6 +365,24 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                 snps_in = snps_feat
             else:
                 snps_in, _ = ops.SnpsMask.apply(snps_feat, sp_m, mode == "both")
+        elif use_front:
+            prob_m, prob_h = ops.GradFan.apply(self.prob, 2)        # (prob: this op and the head inputs; x likewise)
+            x_m, x_h = ops.GradFan.apply(x, 2)
+            ws = [c.lin.weight for c in convs]
+            bs = [c.bias for c in convs]
+            if fp_conv != f_conv:                                   # widths off the kernel grid: zero-padded (sgcn_stack)
+                ws = [F.pad(w, (0, 0 if l == 0 else fp_conv - f_conv, 0, fp_conv - f_conv)) for l, w in enumerate(ws)]
+                bs = [F.pad(b, (0, fp_conv - f_conv)) for b in bs]
+            xcat, xcat_alias, e, regp, snps_in = ops.SgcnFront.apply(
+                x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois, self.snps_prob, self._reg_hp, snps_feat,
+                edge_index, *[t for pair in zip(ws, bs) for t in pair])
+            if fp_conv != f_conv:
+                xcat = xcat.view(2 * n, len(convs), fp_conv)[:, :, :f_conv].reshape(2 * n, len(convs) * f_conv)
+                xcat_alias = xcat
+            dual_ok = self.isCrossAtten and not self.graph_pool and not self.isImageOnly and not self.isSNPsOnly
+            xcat_dense_img = xcat_alias if (dual_ok and fp_conv == f_conv) else None
+            self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp), self._reg_key(x, edge_weight))
+            self.last_edge_prob = e
         elif (tuple(explain_flags) == (False, True) and x.is_cuda and snps_feat is not None and snps_feat.dim() == 2
                 and snps_feat.shape[1] == self.snps_prob.numel()):
             # the train step's (plain | masked) pair: cal_probability writes both halves of the stacked batch itself.

@@ -664,13 +664,18 @@ class GraphedTrainStep:
             if rider:
                 self.model.predraw_dropout(self.data)   # queued: the plan build below carries the mask generation
             if rebuild:
-                self.plan.rebuild(self.data.edge_index)  # the plan is per batch: rebuilt (in place) every step
+                # the plan is per batch: rebuilt (in place) every step — by the first consumer: the front kernel of the
+                # image branch builds it while it reads the edges anyway (ops.SgcnFront), any other route launches the
+                # build; either launch carries the dropout rider
+                self.plan.rebuild(self.data.edge_index, lazy=True)
             else:
                 self.plan._copies = {}                  # the replica of the batched sweep is derived in-graph
-            if rider:
+            if rider and getattr(self.plan, "_pending_build", None) is None:
                 call("igcn_rider_flush", stream_ptr())  # (a plan build that does not carry riders: a launch of its own)
             self.data.x.grad = None
             loss, _, _ = losses(self.model, self.data, self.lam, self.hp)
+            if rider:
+                call("igcn_rider_flush", stream_ptr())  # (nothing waiting unless no launch of the forward took the rider)
             backward_to_grads(loss, self.opt, self.data, defer=_single_use_parameters(self.model), tick=True)
         except BaseException:
             # a step that raised between queueing a rider and its carrier: the rider's buffers die with this frame, and

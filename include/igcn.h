@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 416
+#define IGCN_ABI_VERSION 417
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -230,6 +230,26 @@ int igcn_sgcn_stack_bwd(int64_t n_graphs, int R, int max_edges, int H0, int F, i
                         const int32_t* loop_edge, const float* const* W, const float* const* b, const float* dxcat,
                         const float* dxcat2, float* dx_in, float* dew_in, float* dparams, float* scratch,
                         int32_t* status, void* stream);
+/* THE FRONT OF THE IMAGE BRANCH OF A TRAIN STEP AS ONE LAUNCH (kernel/sgcn_img_snp.py:133-151 cal_probability, :153-181
+ * loss_probability, :218-224 the GCNConv stack; train() :521-523 runs them for the plain and the masked pass): for a batch
+ * of n_graphs uniform graphs of R nodes (at most max_edges edges each, edge_index int64 [2, n_edges] with per-graph
+ * offsets node_ptr / edge_ptr [n_graphs + 1]) workgroup (copy, graph) of the stacked (plain | masked) batch builds the
+ * graph's plan in LDS — what igcn_graph_plan_build_segmented_rep(copies = 2) writes: `plan` = the seven arrays of the
+ * batch, `plan2` = those of its 2-copy replica — forms the pass's inputs (x_in [2N, H0], ew_in [2E], the edge mask e [E]
+ * = igcn_edge_mask_fwd_reg's outputs, reg_partial [n_graphs] whose SUM is loss_probability, snps_full [2 n_graphs, n_snps]
+ * = (snps_feat | snps_feat * sigmoid(snps_logits)); snps_feat NULL: no SNP mask) and runs igcn_sgcn_stack_fwd's layers:
+ * xcat [2N, L F].  Same arithmetic, in the same order, as the three launches it replaces (the regulariser's partial sums
+ * are grouped per graph instead of per 256 edges).  A dropout rider waiting on the stream (igcn_rider_dropout) is carried
+ * by this launch.  status: bit 0 = the batch is not block diagonal in the declared segments / not uniform, bit 1 = a graph
+ * has more than max_edges edges (its outputs are not written). */
+size_t igcn_sgcn_front_lds_bytes(int R, int max_edges, int H0, int F, int L);
+int igcn_sgcn_front_fwd(int64_t n_nodes, int64_t n_edges, int n_graphs, int R, int max_edges, int H0, int F, int L,
+                        const int64_t* edge_index, const int64_t* node_ptr, const int64_t* edge_ptr,
+                        int32_t* const* plan /*HOST [7]*/, int32_t* const* plan2 /*HOST [7]*/, int32_t* status,
+                        const float* x, const float* prob, const float* prob_bias, const float* ew, float* x_in,
+                        float* ew_in, float* e, const float* snps_logits, int n_snps, float l1_x, float ent_x, float l1_e,
+                        float ent_e, float eps, float* reg_partial, const float* snps_feat, float* snps_full,
+                        const float* const* W /*HOST [L]*/, const float* const* b /*HOST [L]*/, float* xcat, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of a bias-free projection y = x W^T (x [M, K], W [N, K]) in ONE pass over the gradient G = dL/dy [M, N]:
@@ -491,7 +511,8 @@ int igcn_rider_cancel(void* stream);
  *      partials" launch issued on the stream in between is queued; the flush runs them in issue order in one launch.  The
  *      partial buffers must outlive the flush; igcn_reduce_defer(stream, 0) + flush also runs on the error path.
  *   2. the dropout rider     igcn_rider_dropout(stream, ...): at most ONE job; carried by the NEXT
- *      igcn_graph_plan_build_segmented[_rep] on the stream and by nothing else; igcn_rider_flush launches it alone.
+ *      igcn_graph_plan_build_segmented[_rep] or igcn_sgcn_front_fwd (which builds the plan itself) on the stream and by
+ *      nothing else; igcn_rider_flush launches it alone.
  *   3. product riders        igcn_gemm_rider(stream, ...): at most 4 products; carried, all or none, by the NEXT
  *      igcn_gemm_f32_grouped on the stream with room for them and the same operand type; igcn_gemm_rider_flush launches
  *      them alone.

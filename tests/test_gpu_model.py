@@ -306,7 +306,7 @@ def train_mode_vs_oracle(monkeypatch, rois, pool, bsz, dense=False, bf16=False, 
     def hip_run(batched):
         """(loss, terms, grads, forced decisions per oracle ReLU site, ignore masks) of one HIP evaluation."""
         seen = {}
-        classes = (ops.SgcnStack, ops.DenseSgcn, ops.GcnPropagate, ops.GoAttentionLN, ops.GoDecodeLN, ops.NodeLinearBNPair,
+        classes = (ops.SgcnStack, ops.SgcnFront, ops.DenseSgcn, ops.GcnPropagate, ops.GoAttentionLN, ops.GoDecodeLN, ops.NodeLinearBNPair,
                    ops.NodeLinearBN, ops.BatchNorm1dGrouped, ops.LinearBN1d, ops.Linear, ops.LinearPair)
         model.load_state_dict(sd)                                     # running statistics back to the start
         model.zero_grad()
@@ -337,7 +337,8 @@ def train_mode_vs_oracle(monkeypatch, rois, pool, bsz, dense=False, bf16=False, 
                 return halves(pick(calls[k_th]))
             n = len(calls) // 2
             return [pick(calls[k_th]).detach().cpu(), pick(calls[n + k_th]).detach().cpu()]
-        stack = "DenseSgcn" if "DenseSgcn" in seen else "SgcnStack"    # complete graphs run on the dense blocks
+        # complete graphs run on the dense blocks; the batched sweep on small graphs through the one-launch front
+        stack = "DenseSgcn" if "DenseSgcn" in seen else "SgcnFront" if "SgcnFront" in seen else "SgcnStack"
         if stack in seen:
             xc = per_pass(stack, 0, lambda o: o[0] if isinstance(o, tuple) else o)
         else:       # a graph too large for the LDS-resident stack (rois = 270 at three 16-wide layers): one launch per layer
@@ -351,8 +352,9 @@ def train_mode_vs_oracle(monkeypatch, rois, pool, bsz, dense=False, bf16=False, 
             outd = per_pass("NodeLinearBN", 0)
         else:                                # read-outs as three single launches: attention, input, gene decoding
             att, inp, outd = (per_pass("NodeLinearBN", k) for k in range(3))
-        bn_name = "LinearBN1d" if "LinearBN1d" in seen else "BatchNorm1dGrouped"   # (the latent MLP's two layers)
-        hb = [per_pass(bn_name, k) for k in range(2)]
+        # the latent MLP's two BatchNorm layers: the wide one through ops.LinearBN1d when its product is split
+        hb = ([per_pass("LinearBN1d", 0), per_pass("BatchNorm1dGrouped", 0)] if "LinearBN1d" in seen
+              else [per_pass("BatchNorm1dGrouped", k) for k in range(2)])
         lp = [per_pass("LinearPair", 0, lambda o, i=i: o[i]) for i in range(2)]
         for p_ in range(2):
             # oracle ReLU sites per pass: ``layers`` GCNConv layers, then twelve more (2 encoder LayerNorms, two read-outs,
@@ -817,7 +819,8 @@ def test_deferred_reductions_give_the_same_gradients(golden):
 @pytest.mark.parametrize("switch", ["IGCN_NO_FUSED_SGCN", "IGCN_NO_DEFER", "IGCN_NO_GEMM_GROUPS", "IGCN_NO_READOUT_PAIR",
                                     "IGCN_LN_AFFINE_NOW", "IGCN_SPMM_DVAL_NOW", "IGCN_NO_PROJ_FUSED", "IGCN_NO_HEAD_FUSED",
                                     "IGCN_NO_MASK_REG_FUSED", "IGCN_NO_GRAD_FAN", "IGCN_NO_LN_FUSED",
-                                    "IGCN_NO_LOSS_HEAD_FUSED", "IGCN_SPARSE_MAPS", "IGCN_NO_LINEAR_BN_FUSED"])
+                                    "IGCN_NO_LOSS_HEAD_FUSED", "IGCN_SPARSE_MAPS", "IGCN_NO_LINEAR_BN_FUSED",
+                                    "IGCN_NO_FRONT_FUSED"])
 def test_every_host_side_switch_gives_the_default_train_step(golden, monkeypatch, switch):
     """every A/B switch that the Python layer reads selects a second code path — each of them must give
     the default path's train step (loss, every gradient) on the ``full_b32`` model, so a losing variant cannot rot

@@ -1844,6 +1844,84 @@ def test_fused_sgcn_stack_fwd_bwd(ops, g, r, h0, f, layers, deg, loops):
         assert_matches(bg[l].grad, bd[l].grad.numpy(), TOL, f"db{l}", floor=1e-6)
 
 
+@pytest.mark.parametrize("g,r,h0,f,layers,deg,loops", [(5, 90, 3, 16, 2, 3, "some"), (3, 24, 1, 8, 3, 4, "multi"),
+                                                      (4, 270, 1, 4, 3, 3, "none"), (6, 40, 3, 32, 1, 2, "all")])
+def test_front_kernel_equals_plan_build_mask_and_stack(ops, g, r, h0, f, layers, deg, loops):
+    """igcn_sgcn_front_fwd — the plan of the batch and of its 2-copy replica, the stacked (plain | masked) inputs, the edge
+    mask, loss_probability, the SNP mask and the GCNConv stack of both passes in ONE launch — against the three launches it
+    replaces (igcn_graph_plan_build_segmented_rep, igcn_edge_mask_fwd_reg, igcn_sgcn_stack_fwd): every plan array
+    bit-exact (edge_index indexing), x_in / ew_in / e / the SNP mask / xcat bit-exact (same arithmetic in the same order),
+    the regulariser to fp32 rounding (its partial sums are grouped per graph instead of per 256 edges); then the gradients
+    of the combined op against those of the chain (same two backward launches on the plan the front kernel wrote)."""
+    from igcn_amd.data import Batch, Data
+    rng = np.random.default_rng(g * 1000 + r + f)
+    graphs = []
+    for _ in range(g):
+        src = rng.integers(0, r, deg * r)
+        dst = rng.integers(0, r, deg * r)
+        keep = src != dst
+        src, dst = src[keep], dst[keep]
+        if loops in ("all", "some", "multi"):
+            nodes = np.arange(r) if loops == "all" else rng.choice(r, r // 2, replace=False)
+            src, dst = np.concatenate([src, nodes]), np.concatenate([dst, nodes])
+        if loops == "multi":
+            src, dst = np.concatenate([src, [2, 2]]), np.concatenate([dst, [2, 2]])
+        order = rng.permutation(src.size)
+        ei = torch.from_numpy(np.vstack([src[order], dst[order]])).long()
+        graphs.append(Data(x=torch.from_numpy(rng.random((r, h0))).float(), edge_index=ei,
+                           edge_attr=torch.from_numpy(rng.random(ei.shape[1]) + 0.05).float()))
+    batch = Batch.from_data_list(graphs).to("cuda")
+    n, ne = batch.x.shape[0], batch.edge_index.shape[1]
+    hp = (0.1, 0.2, 0.15, 0.05, 1e-6)
+    t = lambda a: torch.from_numpy(np.asarray(a)).float().cuda()                     # noqa: E731
+    prob, pb, snps = t(rng.standard_normal((r, h0))), t(rng.standard_normal((2 * h0, 1))), t(rng.standard_normal((1, 54)))
+    feat = t(rng.random((g, 54)))
+    ws = [t(rng.standard_normal((f, h0 if l == 0 else f)) / np.sqrt(h0 if l == 0 else f)) for l in range(layers)]
+    bs = [t(0.3 * rng.standard_normal(f)) for _ in range(layers)]
+    cot = t(rng.standard_normal((2 * n, layers * f)))
+    cot_e, cot_s = t(rng.standard_normal(ne)), t(rng.standard_normal((2 * g, 54)))
+    names = ("src32", "dst32", "tgt_ptr", "tgt_perm", "src_ptr", "src_perm", "loop_edge")
+
+    def run(front):
+        b = Batch.from_data_list(graphs).to("cuda")
+        plan = ops.plan_for(b)
+        plan_g = plan.replicate(2)
+        if front:                                        # the plan arrays are the front kernel's to fill: poison them
+            for p_ in (plan, plan_g):
+                for k in names:
+                    getattr(p_, k).fill_(-7)
+            plan.rebuild(b.edge_index, lazy=True)
+            assert plan._pending_build is not None
+        leaves = [v.clone().requires_grad_(True) for v in (b.x, prob, pb, b.edge_attr, snps, *ws, *bs)]
+        x, pr, pbv, ew, sn = leaves[:5]
+        wl, bl = leaves[5:5 + layers], leaves[5 + layers:]
+        wb = [v for pair in zip(wl, bl) for v in pair]
+        if front:
+            assert ops.sgcn_front_supported(plan, r, h0, f, layers, feat, sn)
+            xcat, _, e, regp, full = ops.SgcnFront.apply(x, pr, pbv, ew, plan, r, sn, hp, feat, b.edge_index, *wb)
+            assert plan._pending_build is None
+        else:
+            x_in, ew_in, e, regp, full = ops.EdgeMaskStacked.apply(x, pr, pbv, ew, plan, r, sn, hp, feat)
+            xcat = ops.SgcnStack.apply(x_in, ew_in, plan_g, r, *wb)
+        loss = (xcat * cot).sum() + (e * cot_e).sum() + 3.0 * regp.sum() + (full * cot_s).sum()
+        loss.backward()
+        plan.check()
+        arrays = {("p", k): getattr(plan, k).clone() for k in names}
+        arrays.update({("r", k): getattr(plan_g, k).clone() for k in names})
+        return (xcat.detach(), e.detach(), regp.detach().sum(), full.detach()), [v.grad for v in leaves], arrays
+
+    (xc0, e0, reg0, full0), g0, a0 = run(False)
+    (xc1, e1, reg1, full1), g1, a1 = run(True)
+    for k in a0:
+        assert torch.equal(a0[k], a1[k]), k
+    assert torch.equal(xc0, xc1) and torch.equal(e0, e1) and torch.equal(full0, full1)
+    assert abs(float(reg0) - float(reg1)) <= 1e-6 * max(1.0, abs(float(reg0)))
+    for i, (a, b_) in enumerate(zip(g0, g1)):
+        assert (a is None) == (b_ is None), i
+        if a is not None:
+            assert_matches(b_, a.cpu().numpy(), 2e-6, f"grad of leaf {i}", floor=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ fused dropout
 def test_dropout_masks_one_launch(ops):
     """igcn_dropout_masks: factors in {0, 1/(1-p)} per site, keep rate ~ 1-p, fresh masks on every launch AND on every
