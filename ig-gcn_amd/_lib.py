@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 417        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 419        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -133,6 +133,10 @@ SIGNATURES = {
     "igcn_attn_core_bf16_supported": (I, [I, I, I, I]),
     "igcn_attn_core_bf16_fwd": (I, [I, I, I, I, I, P, P, P, P, P]),
     "igcn_attn_core_bf16_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
+    "igcn_attn_core_split_supported": (I, [I, I, I, I]),
+    "igcn_attn_core_split_fwd": (I, [I, I, I, I, I, P, P, P, P, P]),
+    "igcn_attn_core_split_bwd_supported": (I, [I, I, I, I]),
+    "igcn_attn_core_split_bwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "igcn_spmm_fwd": (I, [I, I, I, I, L, P, P, P, P, P, P]),
     "igcn_spmm_bwd_scratch_floats": (Z, [I, I, I, I, L]),
     "igcn_spmm_bwd": (I, [I, I, I, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P]),
@@ -209,7 +213,8 @@ def load():
     # the library's A/B switches: read from the environment HERE, once, and handed over (no getenv in a launch path)
     bits = 0
     for bit, name in enumerate(("IGCN_NO_TILED_LISTS", "IGCN_PROPAGATE_NO_LDS", "IGCN_SPMM_NO_LDS", "IGCN_GO_ATTN_CM",
-                                "IGCN_DEBUG_REDUCE", "IGCN_ATTN_FP32_CORE", "IGCN_ATTN_BWD_TWICE")):
+                                "IGCN_DEBUG_REDUCE", "IGCN_ATTN_FP32_CORE", "IGCN_ATTN_BWD_TWICE",
+                                "IGCN_ATTN_EXACT_FP32")):
         v = os.environ.get(name)
         if v is not None and (v == "1" or name in ("IGCN_NO_TILED_LISTS", "IGCN_PROPAGATE_NO_LDS", "IGCN_DEBUG_REDUCE", "IGCN_ATTN_FP32_CORE", "IGCN_ATTN_BWD_TWICE")):
             bits |= 1 << bit

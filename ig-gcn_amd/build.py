@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libigcn.so")
-SOURCES = ["plan.hip", "sgcn.hip", "sgcn_fused.hip", "sgcn_dense.hip", "go.hip", "readout.hip", "loss.hip", "attn_core.hip", "attn_mfma.hip", "attn_bf16.hip", "gemm.hip", "proj.hip", "head.hip", "misc.hip", "gdc.hip", "comm.hip"]
+SOURCES = ["plan.hip", "sgcn.hip", "sgcn_fused.hip", "sgcn_dense.hip", "go.hip", "readout.hip", "loss.hip", "attn_core.hip", "attn_mfma.hip", "attn_bf16.hip", "attn_split.hip", "gemm.hip", "proj.hip", "head.hip", "misc.hip", "gdc.hip", "comm.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Werror=return-type"]
 FLAGS += os.environ.get("IGCN_HIPCC_EXTRA", "").split()       # e.g. -DGO_ABL_PROBE for tools/go_probe.py
 

@@ -6,6 +6,7 @@
 // the backward, Q and dO) of the head in LDS, or — when those do not fit — chunked variants that stream the other side
 // of the attention through LDS.  [Round 1's VALU kernels, reachable only through an A/B switch since the matrix-core
 // path covered every shape they did, are removed.]
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -22,6 +23,22 @@ int igcn_attn_mfma_fwd_chunked(int B, int D, int H, int Lq, int Lk, const float*
 int igcn_attn_mfma_bwd_chunked(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
                                const float* lse, const float* dout, float* dq, float* dkv, float* delta,
                                hipStream_t st);
+
+// attn_split.hip: head_dim 16 on split bf16 operands (fp32-grade results, bf16 matrix rate) — the default for that width;
+// IGCN_ATTN_EXACT_FP32=1 keeps the exact-fp32 kernels
+extern "C" int igcn_attn_core_split_supported(int D, int H, int Lq, int Lk);
+extern "C" int igcn_attn_core_split_bwd_supported(int D, int H, int Lq, int Lk);
+extern "C" int igcn_attn_core_split_fwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o,
+                                        float* lse, void* stream);
+extern "C" int igcn_attn_core_split_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv,
+                                        const float* o, const float* lse, const float* dout, float* dq, float* dkv,
+                                        float* scratch, void* stream);
+static bool aligned16(const void* a, const void* b, const void* c, const void* d) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0;
+}
+static bool use_split(int D, int H, int Lq, int Lk) {
+  return !igcn_opt(IGCN_OPT_ATTN_EXACT_FP32) && g_igcn_attn_chunk_rows == 0 && igcn_attn_core_split_supported(D, H, Lq, Lk);
+}
 
 // K, V (and Q, dO) of one head fit LDS
 static bool use_resident(int D, int H, int Lq, int Lk) {
@@ -48,6 +65,7 @@ extern "C" size_t igcn_attn_core_lds_bytes(int D, int H, int Lq, int Lk, int bac
 
 extern "C" int igcn_attn_core_fwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o,
                                   float* lse, void* stream) {
+  if (use_split(D, H, Lq, Lk) && aligned16(q, kv, o, o)) return igcn_attn_core_split_fwd(B, D, H, Lq, Lk, q, kv, o, lse, stream);
   if (use_resident(D, H, Lq, Lk)) return igcn_attn_mfma_fwd(B, D, H, Lq, Lk, q, kv, o, lse, (hipStream_t)stream);
   if (use_chunked(D, H, Lq, Lk))
     return igcn_attn_mfma_fwd_chunked(B, D, H, Lq, Lk, q, kv, o, lse, (hipStream_t)stream);
@@ -58,6 +76,9 @@ extern "C" int igcn_attn_core_fwd(int B, int D, int H, int Lq, int Lk, const flo
 extern "C" int igcn_attn_core_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
                                   const float* lse, const float* dout, float* dq, float* dkv, float* scratch,
                                   void* stream) {
+  if (use_split(D, H, Lq, Lk) && igcn_attn_core_split_bwd_supported(D, H, Lq, Lk) && aligned16(q, kv, o, dout) &&
+      aligned16(dq, dkv, dq, dkv))
+    return igcn_attn_core_split_bwd(B, D, H, Lq, Lk, q, kv, o, lse, dout, dq, dkv, scratch, stream);
   if (use_resident(D, H, Lq, Lk))
     return igcn_attn_mfma_bwd(B, D, H, Lq, Lk, q, kv, o, lse, dout, dq, dkv, (hipStream_t)stream);
   if (use_chunked(D, H, Lq, Lk)) {

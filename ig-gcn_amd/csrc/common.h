@@ -21,6 +21,7 @@ void igcn_set_error(const char* fmt, ...);
 #define IGCN_OPT_DEBUG_REDUCE 16u         /* print every deferred reduction at the flush */
 #define IGCN_OPT_ATTN_FP32_CORE 32u       /* bf16 feature transforms: keep the fp32 attention core (igcn_attn_core_bf16_supported() = 0) */
 #define IGCN_OPT_ATTN_BWD_TWICE 64u       /* fp32 attention backward: the two-orientation kernel (every score tile computed twice) even where the shared-tile kernel applies */
+#define IGCN_OPT_ATTN_EXACT_FP32 128u     /* fp32 attention core, head_dim 16: the exact-fp32 MFMA kernels (csrc/attn_mfma.hip) instead of the split-bf16 ones (csrc/attn_split.hip) */
 extern unsigned g_igcn_options;
 extern int g_igcn_gemm_bn_cap;            /* > 0: cap of the GEMM tile width (sweeps only) */
 extern int g_igcn_attn_chunk_rows;        /* > 0: rows per LDS chunk of the streamed attention kernels (sweeps only) */

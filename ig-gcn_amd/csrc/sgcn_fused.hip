@@ -451,6 +451,7 @@ k_sgcn_front_fwd(int R, int Emax, int H0, int L, const SfFront fr, SfParams prm,
   const SfLayout o = sf_layout(R, Emax, H0, F, L, 0, 1);
   const int tid = threadIdx.x, bd = (int)blockDim.x;
   const int copy = (int)blockIdx.x / G, g = (int)blockIdx.x - copy * G;
+  SF_PROBE(0);
   // (uniform graphs: the node offset is g R — the loads of x do not wait for a pointer; node_ptr must agree, below)
   const int64_t nb = (int64_t)g * R, nb_given = fr.node_ptr[g], eb64 = fr.edge_ptr[g];
   const int nn = (int)(fr.node_ptr[g + 1] - nb_given), ne = (int)(fr.edge_ptr[g + 1] - eb64);
@@ -539,6 +540,7 @@ k_sgcn_front_fwd(int R, int Emax, int H0, int L, const SfFront fr, SfParams prm,
   }
   for (int i = tid + 4 * bd; i < nx; i += bd) lds[o.x + i] = fr.x[nb * H0 + i] * (copy ? fr.prob[i] : 1.f);
   __syncthreads();
+  SF_PROBE(1);
   // ---- plan: histograms by target / by source, last stored loop per node
   for (int k = tid; k < ne; k += bd) {
     const int s = ssrc[k], d = sdst[k];
@@ -564,6 +566,7 @@ k_sgcn_front_fwd(int R, int Emax, int H0, int L, const SfFront fr, SfParams prm,
     }
   }
   __syncthreads();
+  SF_PROBE(2);
   // stable placement (one thread per edge: its slot = the number of EARLIER edges with the same key), the masked copy's
   // edge probabilities beside it
   const float* pbv = fr.pb;
@@ -593,10 +596,12 @@ k_sgcn_front_fwd(int R, int Emax, int H0, int L, const SfFront fr, SfParams prm,
     sloop[i] = l >= 0 ? eb + l : -1;
   }
   __syncthreads();
+  SF_PROBE(3);
   if (copy)
     for (int k = tid; k < ne; k += bd) lds[o.ew + k] = lds[o.ew + k] * lds[o.fe + k];     // ew * e
   __syncthreads();
-  sf_lists<false>(lds, o, R, ne, eb);          // (the first barrier inside sf_layer orders its lists before their use)
+  sf_lists<false>(lds, o, R, ne, eb);
+  SF_PROBE(4);          // (the first barrier inside sf_layer orders its lists before their use)
   float* H = lds + o.act;
   float* Y = lds + o.ycat;
   const int D = L * F;
@@ -605,6 +610,7 @@ k_sgcn_front_fwd(int R, int Emax, int H0, int L, const SfFront fr, SfParams prm,
     sf_layer<F>(lds, o, R, l == 0 ? H0 : F, l == 0 ? lds + o.x : Y + (l - 1) * F, l == 0 ? H0 : D, H, Y + l * F, D, wl,
                 wl + F * (l == 0 ? H0 : F));
   }
+  SF_PROBE(5);
   // loss_probability: the edge term of this graph; workgroup (1, 0) adds the two node-level means (the same sums as
   // k_edge_mask_fwd<true>, grouped per graph instead of per 256 edges)
   if (copy) {
@@ -619,6 +625,7 @@ k_sgcn_front_fwd(int R, int Emax, int H0, int L, const SfFront fr, SfParams prm,
     racc = block_sum_all(racc, lds + o.dis);                       // (dis is dead behind the last layer)
     if (tid == 0) fr.reg_partial[g] = racc;
   }
+  SF_PROBE(6);
   // ---- the one store burst -----------------------------------------------------------------------------------------
   const int64_t nbo = (int64_t)copy * fr.n_nodes + nb, ebo = (int64_t)copy * fr.n_edges + eb64;
   for (int q = tid; q < R * D / 4; q += bd)
@@ -666,6 +673,7 @@ k_sgcn_front_fwd(int R, int Emax, int H0, int L, const SfFront fr, SfParams prm,
       fr.snps_full[((int64_t)copy * G + g) * fr.n_snps + j] =
           copy ? v * (1.f / (1.f + __expf(-fr.snps_logits[j]))) : v;                         // = k_snps_mask_fwd, bit for bit
     }
+  SF_PROBE(7);
 }
 
 // parameter-gradient partial row of one graph: [ dW_0 (F x H0) | db_0 (F) | dW_1 (F x F) | db_1 | ... ]

@@ -518,6 +518,32 @@ def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temper
     return loss.detach()
 
 
+class _capture:
+    """``torch.cuda.graph`` with the cyclic garbage collector held off while the capture is open.  torch collects once on
+    entry; a collection that starts DURING the capture — any allocation of the step, on this thread or on the autograd
+    engine's — may finalise an object whose destructor the runtime refuses inside a capture (another captured step's
+    hipGraph: every GraphedTrainStep sits in a reference cycle with its optimiser's pointer table, so it dies whenever the
+    collector gets to it) and the process aborts."""
+
+    def __init__(self, graph, **kw):
+        self.ctx = torch.cuda.graph(graph, **kw)
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        self.ctx.__enter__()            # (synchronises, collects once, empties the allocator cache, begins the capture)
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was:
+                gc.enable()
+
+
 class GraphedTrainStep:
     """The whole optimisation step captured ONCE into a hipGraph and replayed per step.
 
@@ -605,7 +631,7 @@ class GraphedTrainStep:
         if dist and comm is not None and comm_in_graph is not False:
             # one graph for the whole distributed step: RCCL's all-reduce is captured between pack and Adam
             try:
-                with torch.cuda.graph(self.g_main, capture_error_mode=mode):
+                with _capture(self.g_main, capture_error_mode=mode):
                     self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
                     self.opt.pack_grads(refresh=False, table=self._table)
                     comm.all_reduce_(self.opt.grad)
@@ -628,7 +654,7 @@ class GraphedTrainStep:
                     self.comm_in_graph = False
                     self.g_main = torch.cuda.CUDAGraph()
         if not self.comm_in_graph:
-            with torch.cuda.graph(self.g_main, capture_error_mode=mode):
+            with _capture(self.g_main, capture_error_mode=mode):
                 self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
                 if not dist:
                     self.opt.step(refresh=False, table=self._table)   # reads the pointer table at replay time
@@ -650,7 +676,7 @@ class GraphedTrainStep:
         self.g_opt = None
         if dist and not self.comm_in_graph:
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt, pool=self.g_main.pool(), capture_error_mode=mode):
+            with _capture(self.g_opt, pool=self.g_main.pool(), capture_error_mode=mode):
                 self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
         torch.cuda.synchronize()
 

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 417
+#define IGCN_ABI_VERSION 419
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -691,6 +691,18 @@ int igcn_attn_core_bf16_fwd(int B, int D, int H, int Lq, int Lk, const float* q,
                             void* stream);
 int igcn_attn_core_bf16_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
                             const float* lse, const float* dout, float* dq, float* dkv, float* scratch, void* stream);
+
+/* The attention core on SPLIT bf16 operands (csrc/attn_split.hip; head_dim 16): every fp32 operand is carried as a bf16
+ * head and a bf16 remainder (x = hi + lo to 2^-17 |x|) and every product runs on v_mfma_f32_16x16x32_bf16 — fp32-grade
+ * results (the 1e-4 / 1e-3 bounds of igcn_attn_core_fwd / _bwd hold, tests/test_gpu_ops.py) at the bf16 rate of the
+ * matrix cores.  Arguments as igcn_attn_core_fwd / igcn_attn_core_bwd. */
+int igcn_attn_core_split_supported(int D, int H, int Lq, int Lk);
+int igcn_attn_core_split_fwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, float* o, float* lse,
+                             void* stream);
+/* (backward: one workgroup per (sample, head), <= 128 queries and >= 128 keys — igcn_attn_core_split_bwd_supported) */
+int igcn_attn_core_split_bwd_supported(int D, int H, int Lq, int Lk);
+int igcn_attn_core_split_bwd(int B, int D, int H, int Lq, int Lk, const float* q, const float* kv, const float* o,
+                             const float* lse, const float* dout, float* dq, float* dkv, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sparse SNP<->GO maps with learnable non-zeros — gene encoding go_model.py:208-215 (C=2 channels,

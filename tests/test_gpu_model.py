@@ -240,10 +240,24 @@ def test_full_model_vs_oracle_larger(bsz, pool, explain):
     model.load_state_dict(sd)
     graphs = synth.brain_graph_list(bsz, seed=77, rois=90, tsne_dim=16)
     data = Batch.from_data_list(graphs).to("cuda")
+    # relu(out_proj(attention)) (:242) has pre-activations that are zero to rounding (at B = 32 / the 500-node DAG one of
+    # 92 160 sits at 4e-8 of a 0.35 scale): which side of zero it falls on decides one summand of every gradient
+    # upstream (1 % of d out_proj.weight's largest entry), and the split-bf16 attention core — 6e-6 from the exact one
+    # on the attention output — decides it the other way.  The HIP path's decisions at that site are observed and
+    # imposed on the oracle INSIDE a 2e-5 band, agreement is required outside it (tools/attn_flip_check.py)
+    seen = []
+    real_ca = model._cross_attention
+
+    def spy(query, memory):
+        out = real_ca(query, memory)
+        seen.append(out.detach().cpu() > 0)
+        return out
+    model._cross_attention = spy
     outs = model(data, None, "cuda", isExplain=explain)
     cot = _probe(outs, 9)
     sum((o * c.cuda()).sum() for o, c in zip(outs, cot)).backward()
     # oracle, fp64
+    from conftest import relu_forced
     a_g_c, a_c = synth.go_sparse_inputs(go_snps, adj)
     idx = OG.go_index_sets(a_g_c, a_c, list(pool), 2)
     sdo = OS.make_leaf_state(sd, dtype=torch.float64)
@@ -251,7 +265,9 @@ def test_full_model_vs_oracle_larger(bsz, pool, explain):
     dcpu.x = dcpu.x.double().requires_grad_(True)
     dcpu.edge_attr, dcpu.snps_feat = dcpu.edge_attr.double(), dcpu.snps_feat.double()
     cfg = SimpleNamespace(num_layers=2, rois=90, image_only=False, rbf_gamma=0.01)
-    ref = OS.model_forward(sdo, cfg, idx, dcpu, explain, training=False)
+    with relu_forced({11: seen[0]}, band=2e-5) as rf:           # (site 11 of a pass with two GCNConv layers: out_proj)
+        ref = OS.model_forward(sdo, cfg, idx, dcpu, explain, training=False)
+    assert rf.mismatch_outside == 0 and rf.flips <= 4, (rf.mismatch_outside, rf.flips)
     sum((o * c.double()).sum() for o, c in zip(ref, cot)).backward()
     for n, o, r in zip(NAMES, outs, ref):
         assert_matches(o, r.detach().numpy(), 1e-4, n)

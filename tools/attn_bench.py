@@ -16,7 +16,9 @@ lq = int(sys.argv[2]) if len(sys.argv) > 2 else 90
 lk = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 core = sys.argv[5] if len(sys.argv) > 5 else "fp32"
-FWD, BWD = ("igcn_attn_core_bf16_fwd", "igcn_attn_core_bf16_bwd") if core == "bf16" else ("igcn_attn_core_fwd", "igcn_attn_core_bwd")
+FWD, BWD = {"bf16": ("igcn_attn_core_bf16_fwd", "igcn_attn_core_bf16_bwd"),
+            "split": ("igcn_attn_core_split_fwd", "igcn_attn_core_split_bwd")}.get(core, ("igcn_attn_core_fwd", "igcn_attn_core_bwd"))
+ONLY = sys.argv[6] if len(sys.argv) > 6 else "fwd,bwd"
 h, d = 2, 32
 dev = "cuda"
 q = torch.randn(b, lq, d, device=dev)
@@ -38,6 +40,8 @@ def bwd():
 
 
 for name, fn in (("fwd", fwd), ("bwd", bwd)):
+    if name not in ONLY.split(","):
+        continue
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
