@@ -203,14 +203,14 @@ def instep_profile(workload, bf16, steps=12, timeout=420):
             shutil.rmtree(out, ignore_errors=True)
 
 
-PMC_JSON = next((p for p in (os.path.join(ROOT, "profiles", r + "_pmc", "traffic.json") for r in ("r04", "r03"))
+PMC_JSON = next((p for p in (os.path.join(ROOT, "profiles", r + "_pmc", "traffic.json") for r in ("r05", "r04", "r03"))
                  if os.path.exists(p)), os.path.join(ROOT, "profiles", "r04_pmc", "traffic.json"))
 
 
 def _attach_traffic(res):
     """``traffic``: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction, calibrated
     on a 256 MiB float4 copy; WRITE_SIZE x1).  PMC collection needs its own profiler passes, so the figure comes from
-    the COMMITTED passes of tools/roofline_kernel.py (profiles/r04_pmc/, or $IGCN_BENCH_PMC_JSON) — a separate run of
+    the COMMITTED passes of tools/roofline_kernel.py (profiles/r05_pmc/, or $IGCN_BENCH_PMC_JSON) — a separate run of
     the same kernel on the same launch shape, not this invocation — and says so."""
     path = os.environ.get("IGCN_BENCH_PMC_JSON", PMC_JSON)
     try:
@@ -346,6 +346,20 @@ def fused_stack_roofline(model, data, device, wl, stats):
            for _ in range(sets)]
     cold = _time_graph(lambda: [fn() for fn in fns]) / sets
     picked = _pick(stats[0], "k_sgcn_stack_fwd") if stats else None
+    front = _pick(stats[0], "k_sgcn_front_fwd") if stats else None
+    if front is not None:
+        # round 5: the default step runs the stack inside the FRONT kernel of the image branch (igcn_sgcn_front_fwd: the
+        # per-graph plan build, the masks of both passes, loss_probability, the SNP mask and the stack in one launch,
+        # carrying the step's dropout rider).  `achieved` keeps the contract's definition — SURVEY 8d's fused lower bound
+        # per graph-pass x the 512 graph-passes of the launch / the launch's duration — and so charges the whole launch
+        # to the stack's 9.2 MB; `kernel_bytes_per_launch` is what the launch itself reads and writes (int64 edge list,
+        # x, weights in; both plans' seven arrays, x_in, ew_in, e, xcat out), the dropout factors its rider writes not
+        # counted.  The stack alone (the kernel the other routes launch) keeps its cold / hot replay beside it.
+        gr, eg = g // 2, e // g
+        front_bytes = gr * (16 * eg + 4 * eg + 4 * rois * h0) * 2 + 4 * n * d + 4 * n * h0 + 4 * e + 2 * e \
+            + 3 * (16 * (e // 2) + 12 * (n // 2))
+        picked = front
+        kern_bytes_front = front_bytes
     us = picked[2] if picked else cold
     src = ("rocprofv3 --kernel-trace of this command (child process): average over the launches of its timed replays"
            if picked else ("HIP events, cold replay (the rocprofv3 child of this run failed)" if stats is None else
@@ -365,6 +379,14 @@ def fused_stack_roofline(model, data, device, wl, stats):
             "note": "latency-bound by construction: 512 workgroups (2 per CU) each run ~12 barrier-separated LDS phases; "
                     "the kernel replaces 7 launches (norm x2, GEMM + scatter-aggregate per layer, concat), whose "
                     "own scatter-aggregate launch is roofline_scatter_standalone"}
+    if front is not None:
+        res["kernel_bytes_per_launch"] = kern_bytes_front
+        res["frac_kernel_bytes"] = round(kern_bytes_front / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        res["launch"] = (f"{g} graph-passes x {e // g} edges: per-graph plan build + masks + loss_probability + SNP mask + "
+                         f"gcn_norm + {layers} x GCNConv + ReLU + concatenation, and the step's dropout rider, in ONE launch")
+        res["note"] = ("latency-bound by construction (one workgroup per graph-pass, ~20 barrier-separated LDS phases: "
+                       "tools/front_probe.py); replaces plan build + mask + stack launches (11.7 + 6.3 + 9.0 us); the "
+                       "stack kernel alone: replay_hot_us / replay_cold_us")
     _attach_traffic(res)
     return res
 
@@ -513,6 +535,35 @@ def mfma_roofline(model, wl, device, stats, bf16):
         dict(M=mq + mk, N=2 * d, K=d), "k_gemm_bf16_grouped" if bf16 else "k_proj_fwd")
     best = max(out["products"], key=lambda p: p["frac"])
     out["achieved"], out["frac"], out["kernel"] = best["achieved"], best["frac"], f"{best['kernel']} ({best['name']})"
+    # the cross-attention core as the step runs it (in-step durations of this run's profiled child) with the MATRIX-PIPE
+    # busy fraction of the same kernels from the committed counter pass (profiles/r05_pmc/mfma*.json: SQ_VALU_MFMA_BUSY_CYCLES
+    # / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), tools/mfma_run.sh — a separate run, labelled as such)
+    counters = {}
+    for fn in ("mfma.json", "mfma_exact_fp32.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "r05_pmc", fn)) as fh:
+                for key, row in json.load(fh)["kernels"].items():
+                    counters.setdefault(key.split(" #")[0].split("<")[0], row)
+        except (OSError, KeyError, ValueError):
+            pass
+    if stats and not bf16:
+        lq, lk, heads = wl["rois"], n_top, 2
+        for pref, mult, what in (("k_attn_split_fwd", 2, "attention forward (split bf16 operands)"),
+                                 ("k_attn_split_bwd", 5, "attention backward (split bf16 operands)"),
+                                 ("k_attn_mfma_fwd", 2, "attention forward (exact fp32)"),
+                                 ("k_attn_mfma_bwd", 5, "attention backward (exact fp32)")):
+            hit = _pick(stats[0], pref)
+            if hit is None:
+                continue
+            flops = 2.0 * mult * g * heads * lq * lk * (d // heads)
+            row = dict(name=what, kernel=hit[0].split("(")[0], us=round(hit[2], 2), useful_tflops=round(flops / hit[2] / 1e6, 1),
+                       note="useful flops 2 x %d x B H Lq Lk hd; the split core issues 2-3 bf16 instructions per product" % mult
+                       if "split" in pref else "useful flops 2 x %d x B H Lq Lk hd" % mult)
+            c = counters.get(pref)
+            if c:
+                row["mfma_busy_frac"] = c["mfma_busy_frac"]
+                row["mfma_busy_source"] = "profiles/r05_pmc: separate counter pass, %s us there" % c["us_median_unprofiled_pass"]
+            out.setdefault("attention_core", []).append(row)
     if stats:
         tot = sum(t for nme, (c, a_, t) in stats[0].items()
                   if ("k_gemm_" in nme or "k_proj_" in nme or "k_head_bwd" in nme) and "reduce" not in nme)
@@ -540,6 +591,27 @@ def _pick_cores(usable, pci=None):
             elif part:
                 out.append(int(part))
         return out
+    # how busy every logical CPU is right now (two /proc/stat samples 0.3 s apart): a GPU box is a share of a host whose
+    # other tenants may sit on the very cores a fixed choice would take (first run of this round: load average 22 on the 16
+    # GPU-local cores, 2.6x between the fastest and the slowest of five steps)
+    def busy_now():
+        def snap():
+            out = {}
+            try:
+                with open("/proc/stat") as fh:
+                    for ln in fh:
+                        if ln.startswith("cpu") and ln[3].isdigit():
+                            f = ln.split()
+                            v = [int(x) for x in f[1:9]]
+                            out[int(f[0][3:])] = (sum(v), v[3] + v[4])
+            except (OSError, ValueError, IndexError):
+                return {}
+            return out
+        a = snap()
+        time.sleep(0.3)
+        b = snap()
+        return {c: 1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in a if c in b}
+    busy = busy_now()
     local = None
     if pci:
         try:
@@ -548,8 +620,8 @@ def _pick_cores(usable, pci=None):
         except (OSError, ValueError):
             local = None
     order = (local or []) + [c for c in allowed if c not in set(local or [])]
-    seen, cores = set(), []
-    for c in order:
+    seen, cand = set(), []
+    for rank, c in enumerate(order):
         try:
             with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
                 key = tuple(sorted(parse(fh.read())))
@@ -558,9 +630,10 @@ def _pick_cores(usable, pci=None):
         if key in seen:
             continue
         seen.add(key)
-        cores.append(c)
-        if len(cores) == usable:
-            break
+        load = max(busy.get(t, 0.0) for t in key)              # a physical core is as busy as its busiest thread
+        cand.append((load > 0.25, round(load, 1), rank, c))      # idle cores first (GPU-local ones before the others)
+    cand.sort()
+    cores = sorted(c for _, _, _, c in cand[:usable])
     return cores or None
 
 
@@ -609,7 +682,7 @@ def cpu_baseline_child(workload, seconds, cores):
     load0 = os.getloadavg()[0] if hasattr(os, "getloadavg") else None
     t_end = time.perf_counter() + seconds
     _, _, opt = OS.train_step(sd, cfg, idx, data, lr=1e-3, dropout=True, faithful=True, opt=opt)
-    while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 12):
+    while len(times) < 6 or (time.perf_counter() < t_end and len(times) < 12):
         t0 = time.perf_counter()
         _, _, opt = OS.train_step(sd, cfg, idx, data, lr=1e-3, dropout=True, faithful=True, opt=opt)
         times.append(time.perf_counter() - t0)
@@ -805,9 +878,10 @@ def pipeline_bench(gstep, wl, device, steps, warmup, resident_ms):
 
 def step_traffic(workload, kernel_us_per_step):
     """The WHOLE step against the HBM roof: bytes per replay summed over every kernel of the step — the COMMITTED PMC
-    passes of tools/step_traffic.sh (profiles/r04_step_traffic_<workload>.csv: --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+    passes of tools/step_traffic.sh (profiles/r05_step_traffic_<workload>.csv: --pmc FETCH_SIZE and --pmc WRITE_SIZE in
     runs of their own over marker-bracketed replays) — divided by THIS run's kernel time per replay."""
-    path = os.path.join(ROOT, "profiles", f"r04_step_traffic_{workload}.csv")
+    path = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_step_traffic_{workload}.csv") for r in ("r05", "r04"))
+                 if os.path.exists(p)), os.path.join(ROOT, "profiles", f"r04_step_traffic_{workload}.csv"))
     try:
         import csv
         with open(path, newline="") as fh:
@@ -1225,7 +1299,7 @@ def main():
             dense_rf = dense_roofline(data, wl, stats) if wl["dense"] else None
             standalone = scatter_roofline(data, device, wl, stats) if dense_rf is None else None
             fused = None
-            if dense_rf is None and (stats is None or _pick(stats[0], "k_gcn_propagate_fwd") is None):
+            if dense_rf is None and (stats is None or _pick(stats[0], "k_gcn_propagate_fwd") is None):  # (front / stack kernel)
                 fused = fused_stack_roofline(model, data, device, wl, stats)
             if dense_rf is not None:
                 res["roofline"] = dense_rf

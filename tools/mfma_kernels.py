@@ -4,7 +4,9 @@ of tools/mfma_run.sh (kernel trace; then ONE --pmc pass of SQ_VALU_MFMA_BUSY_CYC
 GRBM_GUI_ACTIVE; the program goes directly after `--`):
 
   k_ds_agg / k_ds_aggT / k_ds_mask_bwd   configs[4]: 32 complete 512-ROI graphs, both passes per launch
-  k_attn_mfma_fwd / k_attn_mfma_bwd_shared   configs[2]: 512 samples x 2 heads, 90 queries x 400 keys, head_dim 16 (fp32)
+  k_attn_split_fwd / k_attn_split_bwd        configs[2]: 512 samples x 2 heads, 90 queries x 400 keys, head_dim 16 (the
+                                             default: split bf16 operands); with IGCN_ATTN_EXACT_FP32=1 in the environment
+                                             the same calls run k_attn_mfma_fwd / k_attn_mfma_bwd_shared (exact fp32)
   k_attn_bf16_*                              configs[4]: 64 samples x 2 heads, 512 x 1300, head_dim 16 (bf16 operands)
   k_gemm_f32                                 4096^3 (the calibration point: 65-69 % of the fp32 matrix peak by time) and
                                              lin1 of the default step (512 x 64 x 2912, split-K)

@@ -21,7 +21,7 @@ PEAK_F32 = 157.3e12
 
 
 def counters():
-    f = glob.glob(f"{d}/pmc/**/*counter_collection.csv", recursive=True)[0]
+    f = glob.glob(f"{d}/mpmc/**/*counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(lambda: collections.defaultdict(dict))
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"]][r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
@@ -29,7 +29,7 @@ def counters():
 
 
 def durations():
-    f = glob.glob(f"{d}/trace/**/*kernel_trace.csv", recursive=True)[0]
+    f = glob.glob(f"{d}/mtrace/**/*kernel_trace.csv", recursive=True)[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -39,6 +39,7 @@ def durations():
 med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
 pmc, dur = counters(), durations()
 want = ("k_ds_agg<", "k_ds_aggT<", "k_ds_mask_bwd<", "k_attn_mfma_fwd<", "k_attn_mfma_bwd_shared<", "k_attn_mfma_bwd<",
+        "k_attn_split_fwd", "k_attn_split_bwd<",
         "k_attn_bf16_fwd", "k_attn_bf16_bwd_dq", "k_attn_bf16_bwd_dkv", "k_gemm_f32<", "k_proj_fwd", "k_proj_bwd",
         "k_head_bwd", "k_go_attn_bwd_lds<")
 out = {"unit": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); medians over launches",

@@ -32,7 +32,7 @@ cw = known / (med(write[cal_name]) * 1024)
 out = {"calibration": {"kernel": cal_name[:60], "fetch_factor": round(cf, 3), "write_factor": round(cw, 3)}}
 # SURVEY 8d algorithmic bytes per launch: stand-alone scatter-aggregate (20 E' + 8 R F per graph), fused stack lower
 # bound (4 R H0 + 20 E + 4 R D per graph), 512 graphs; dense stress shape, 64 graphs
-alg = {"k_gcn_propagate_fwd_q": 512 * 16920, "k_sgcn_stack_fwd": 512 * 18000,
+alg = {"k_gcn_propagate_fwd_q": 512 * 16920, "k_sgcn_stack_fwd": 512 * 18000, "k_sgcn_front_fwd": 512 * 18000,
        "k_gcn_propagate_fwd_lds": 64 * (20 * 262144 + 8 * 512 * 16), "k_ds_agg": 64 * (20 * 262144 + 8 * 512 * 16),
        "k_ds_aggT": 64 * (20 * 262144 + 8 * 512 * 16), "k_ds_mask_bwd": 32 * (24 * 262144), "k_ds_deg": 64 * 24 * 262144}
 for k in fetch:

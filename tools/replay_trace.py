@@ -86,7 +86,9 @@ def main():
     from igcn_amd.train import FlatAdam, GraphedTrainStep
     dev = torch.device("cuda", 0)
     wl = bench.WORKLOADS[workload]
-    model, _ = bench.build_model(dev, wl)
+    # IGCN_TRACE_MODEL="layers,hidden": another entry of the reference's sweep (main.py:152-154) instead of (2, 16)
+    lh = [int(v) for v in os.environ.get("IGCN_TRACE_MODEL", "0,0").split(",")]
+    model, _ = bench.build_model(dev, wl, layers=lh[0] or None, hidden=lh[1] or None)
     opt = FlatAdam(model.parameters(), lr=1e-3)
     data = Batch.from_data_list(synth.brain_graph_list(wl["graphs"], seed=1000, rois=wl["rois"], tsne_dim=90,
                                                        dense=wl["dense"])).to(dev)

@@ -69,6 +69,17 @@ for _ in range(LAUNCHES):
          ptr(plan.dst32), ptr(plan.tgt_ptr), ptr(plan.tgt_perm), ptr(plan.loop_edge), wp, bp, ptr(xcat), None, stream_ptr())
 torch.cuda.synchronize()
 
+# ... and the FRONT kernel of the default step's image branch (round 5: plan build + masks + stack of both passes in one
+# launch; no dropout rider here, so the traffic is the kernel's own)
+prob_f, pb_f, snps_f = torch.randn(rois, h0, device=dev), torch.randn(2 * h0, 1, device=dev), torch.randn(1, 54, device=dev)
+wb_f = [t for pair in zip(ws, bs) for t in pair]
+fplan = ops.plan_for(batch)
+with torch.no_grad():
+    for _ in range(LAUNCHES):
+        ops.SgcnFront.apply(batch.x, prob_f, pb_f, batch.edge_attr, fplan, rois, snps_f, (0.1, 0.1, 0.1, 0.1, 1e-6),
+                            batch.snps_feat, batch.edge_index, *wb_f)
+torch.cuda.synchronize()
+
 # stress shape: 64 dense 512-ROI graphs (both passes of a configs[4] step)
 sb = Batch.from_data_list(synth.brain_graph_list(32, seed=1, rois=512, tsne_dim=8, dense=True)).to(dev)
 splan = ops.plan_for(sb).replicate(2)
