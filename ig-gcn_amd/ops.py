@@ -1586,6 +1586,10 @@ class SparseMap(torch.autograd.Function):
             else:
                 val = torch.stack([_f32(v).reshape(-1) for v in vals])
         b, c = x.shape[0], (len(vals) if ctx.vstride is not None else val.shape[0])
+        # ``x._igcn_grad_rows = (lo, hi)`` (set by the producer of x): only rows [lo, hi) of d x will ever be read — the
+        # stacked (plain | masked) SNP batch of a train step, whose plain half is data — and the backward computes only
+        # those (the rest of dx stays unwritten)
+        ctx.grad_rows = getattr(x, "_igcn_grad_rows", None)
         ctx.csr, ctx.stacked, ctx.nvals = csr, stacked, len(vals)
         ctx.final = _leaves(*vals)
         ctx.dense, ctx.channels = dense, c
@@ -1644,14 +1648,19 @@ class SparseMap(torch.autograd.Function):
                                                                                       csr.nnz)),
                                         dtype=torch.float32, device=x.device)) if dval is not None else None
             def bwd(dx_, dval_):
+                bb, xx, dyy = b, x, dy
+                if dval_ is None and dx_ is not None and ctx.grad_rows is not None and ctx.dense is False:
+                    lo_, hi_ = ctx.grad_rows                      # input gradient of the rows somebody reads, only
+                    if 0 <= lo_ < hi_ <= b:
+                        bb, xx, dyy, dx_ = hi_ - lo_, x[lo_:hi_], dy[lo_:hi_], dx_[lo_:hi_]
                 with _immediate(ctx.final):
                     if ctx.vstride is not None:
-                        call("igcn_spmm_bwd_strided", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
-                             ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ctx.vstride, ptr(x),
-                             ptr(dy), ptr(dx_), ptr(dval_), ptr(scratch), stream_ptr())
+                        call("igcn_spmm_bwd_strided", bb, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
+                             ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ctx.vstride, ptr(xx),
+                             ptr(dyy), ptr(dx_), ptr(dval_), ptr(scratch), stream_ptr())
                     else:
-                        call("igcn_spmm_bwd", b, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
-                             ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(x), ptr(dy),
+                        call("igcn_spmm_bwd", bb, c, csr.n_rows, csr.n_cols, csr.nnz, ptr(csr.row_ptr), ptr(csr.col),
+                             ptr(csr.row_of), ptr(csr.t_ptr), ptr(csr.t_row), ptr(csr.t_k), ptr(val), ptr(xx), ptr(dyy),
                              ptr(dx_), ptr(dval_), ptr(scratch), stream_ptr())
             if (dval is not None and _DEFER["on"] and ctx.final and csr.nnz > 0
                     and os.environ.get("IGCN_SPMM_DVAL_NOW", "0") != "1"):

@@ -383,6 +383,8 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             xcat_dense_img = xcat_alias if (dual_ok and fp_conv == f_conv) else None
             self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp), self._reg_key(x, edge_weight))
             self.last_edge_prob = e
+            # (the plain half of the stacked SNP batch is data: its gradient is never read — ops.SparseMap skips it)
+            snps_in._igcn_grad_rows = (bsz, 2 * bsz)
         elif (tuple(explain_flags) == (False, True) and x.is_cuda and snps_feat is not None and snps_feat.dim() == 2
                 and snps_feat.shape[1] == self.snps_prob.numel()):
             # the train step's (plain | masked) pair: cal_probability writes both halves of the stacked batch itself.
@@ -404,6 +406,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                 x_in, ew_in, e, regp, snps_in = ops.EdgeMaskStacked.apply(
                     x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois, self.snps_prob, self._reg_hp, snps_feat)
                 self._dense_reg = (regp, tuple(float(v) for v in self._reg_hp), self._reg_key(x, edge_weight))
+                snps_in._igcn_grad_rows = (bsz, 2 * bsz)
             else:
                 x_in, ew_in, e = ops.EdgeMaskStacked.apply(x_m, prob_m, self.prob_bias, edge_weight, plan, self.rois)
                 snps_in, _ = ops.SnpsMask.apply(snps_feat, sp_m, True)
