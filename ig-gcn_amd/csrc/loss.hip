@@ -499,6 +499,232 @@ k_loss_head_bwd(int B, int C, int NR, int S, const int64_t* __restrict__ y, cons
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The OUTPUT HEADS and the loss head of a train step as one multi-workgroup launch.  lin2 / lin2_regr (64 -> 3 each,
+// kernel/sgcn_img_snp.py:289-290,300-301), log_softmax (:305), the cross-entropy / regression / reconstruction terms of
+// train() (:525-530) AND the backward of all of it for an upstream gradient of one were four launches on the step's
+// critical path — k_small_linear_fwd (4.9 us), k_loss_head_fwd (ONE workgroup, 10.7 us), k_small_linear_bwd (5.1 us) — for
+// a few hundred KB: a workgroup here owns 256 / (K / 4) rows of the stacked sweep, computes their scores, the softmax,
+// the three row-wise loss sums, d loss / d (scores, regression outputs), and from those — they are in registers — the
+// gradients of the two layers' inputs and its rows' share of their weight / bias gradients (partial rows for the deferred
+// reduction).  The loss VALUE is only read by the host: its last step (loss_final.h) rides in the backward's flush.
+// -------------------------------------------------------------------------------------------------
+#include "loss_final.h"
+#define HL_MAXC 4
+struct HeadLossArgs {
+  int B, K, C, NR, S;
+  const float *x1, *keep1, *W1, *b1;      // classifier head: features [2B, K] (dropout factors or NULL), lin2 [C, K], [C]
+  const float *x2, *keep2, *W2, *b2;      // regression head: features [2B, K], lin2_regr [NR, K], [NR]
+  const int64_t* y;                        // [B]
+  const float *clin, *x_hat, *snps;        // [B, NR], [2B, S], [B, S]
+  LossHeadW w;
+  float *logp_out, *reg_out;               // [2B, C] log_softmax, [2B, NR]
+  float *dx1, *dx2, *dxhat;                // d loss / d (features, x_hat) for an upstream gradient of one
+  float *parts;                            // [blocks][4]: sums of -logp[y] (plain | masked pass), (reg - clin)^2, (x_hat - snps)^2
+  float *wpart;                            // [blocks][C K + C + NR K + NR]: the layers' weight | bias gradient partials
+  float *dgram, *dprob;                    // [4], [1]: d loss / d (Gram terms, regulariser)
+};
+
+__global__ void __launch_bounds__(256) k_head_loss_fwd(const HeadLossArgs a) {
+  __shared__ float red[256 * 4 * HL_MAXC + 256 * HL_MAXC];
+  const int K = a.K, kq = K / 4, q = threadIdx.x % kq, rl = threadIdx.x / kq, rpb = 256 / kq;
+  const int rows = 2 * a.B;
+  const int r = (int)blockIdx.x * rpb + rl;
+  const bool live = rl < rpb && r < rows;
+  const int b = r < a.B ? r : r - a.B;
+  float ce = 0.f, mi = 0.f, mse = 0.f, rec = 0.f;
+  float4 gw1[HL_MAXC], gw2[HL_MAXC];
+  float gb1[HL_MAXC], gb2[HL_MAXC];
+#pragma unroll
+  for (int c = 0; c < HL_MAXC; ++c) {
+    gw1[c] = gw2[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gb1[c] = gb2[c] = 0.f;
+  }
+  if (live) {
+    // every load of the row up front: features, dropout factors, both layers' weight quads, label, targets
+    float4 x1 = *reinterpret_cast<const float4*>(a.x1 + (int64_t)r * K + 4 * q);
+    float4 x2 = *reinterpret_cast<const float4*>(a.x2 + (int64_t)r * K + 4 * q);
+    float4 k1 = make_float4(1.f, 1.f, 1.f, 1.f), k2 = k1;
+    if (a.keep1) k1 = *reinterpret_cast<const float4*>(a.keep1 + (int64_t)r * K + 4 * q);
+    if (a.keep2) k2 = *reinterpret_cast<const float4*>(a.keep2 + (int64_t)r * K + 4 * q);
+    float4 w1[HL_MAXC], w2[HL_MAXC];
+    float tgt[HL_MAXC];
+#pragma unroll
+    for (int c = 0; c < HL_MAXC; ++c) {
+      w1[c] = c < a.C ? *reinterpret_cast<const float4*>(a.W1 + c * K + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      w2[c] = c < a.NR ? *reinterpret_cast<const float4*>(a.W2 + c * K + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      tgt[c] = c < a.NR ? a.clin[(int64_t)b * a.NR + c] : 0.f;
+    }
+    const int64_t yc = a.y[b];
+    x1.x *= k1.x; x1.y *= k1.y; x1.z *= k1.z; x1.w *= k1.w;           // dropout of the input, fused: x * keep
+    x2.x *= k2.x; x2.y *= k2.y; x2.z *= k2.z; x2.w *= k2.w;
+    float s1[HL_MAXC], s2[HL_MAXC];
+#pragma unroll
+    for (int c = 0; c < HL_MAXC; ++c) {
+      s1[c] = (x1.x * w1[c].x + x1.y * w1[c].y) + (x1.z * w1[c].z + x1.w * w1[c].w);      // (k_small_linear_fwd's order)
+      s2[c] = (x2.x * w2[c].x + x2.y * w2[c].y) + (x2.z * w2[c].z + x2.w * w2[c].w);
+      for (int o = 1; o < kq; o <<= 1) {
+        s1[c] += __shfl_xor(s1[c], o, 64);
+        s2[c] += __shfl_xor(s2[c], o, 64);
+      }
+      s1[c] += (c < a.C && a.b1) ? a.b1[c] : 0.f;
+      s2[c] += (c < a.NR && a.b2) ? a.b2[c] : 0.f;
+    }
+    // log_softmax of the scores, the cross-entropy term and its gradient (k_loss_head_fwd, from_logits)
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < HL_MAXC; ++c)
+      if (c < a.C) m = fmaxf(m, s1[c]);
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < HL_MAXC; ++c)
+      if (c < a.C) se += expf(s1[c] - m);
+    const float lse = logf(se);
+    const float wt = (r < a.B ? a.w.hp_ce : a.w.hp_mi) * a.w.lam[0];
+    float d1[HL_MAXC], d2[HL_MAXC];
+#pragma unroll
+    for (int c = 0; c < HL_MAXC; ++c) {
+      const float lp = (s1[c] - m) - lse;
+      d1[c] = (c < a.C && wt != 0.f) ? wt / (float)a.B * (expf(lp) - (yc == c ? 1.f : 0.f)) : 0.f;
+      const float dr = s2[c] - tgt[c];
+      d2[c] = c < a.NR ? a.w.lam[1] * 2.f * dr / (float)(2 * a.B * a.NR) : 0.f;
+      if (q == 0) {
+        if (c < a.C) a.logp_out[(int64_t)r * a.C + c] = lp;
+        if (c < a.NR) {
+          a.reg_out[(int64_t)r * a.NR + c] = s2[c];
+          mse += dr * dr;
+        }
+        if (c < a.C && a.w.lam[0] != 0.f && yc == c) {
+          if (r < a.B) ce -= lp; else mi -= lp;
+        }
+      }
+    }
+    if (q == 0 && a.w.lam[0] != 0.f && (yc < 0 || yc >= a.C)) ce = __builtin_nanf("");      // (a label outside the classes)
+    // backward of the two layers for exactly those upstream gradients: dx = (d W) * keep, dW += d x^T, db += d
+    float4 e1 = make_float4(0.f, 0.f, 0.f, 0.f), e2 = e1;
+#pragma unroll
+    for (int c = 0; c < HL_MAXC; ++c) {
+      e1.x += d1[c] * w1[c].x; e1.y += d1[c] * w1[c].y; e1.z += d1[c] * w1[c].z; e1.w += d1[c] * w1[c].w;
+      e2.x += d2[c] * w2[c].x; e2.y += d2[c] * w2[c].y; e2.z += d2[c] * w2[c].z; e2.w += d2[c] * w2[c].w;
+      gw1[c] = make_float4(d1[c] * x1.x, d1[c] * x1.y, d1[c] * x1.z, d1[c] * x1.w);
+      gw2[c] = make_float4(d2[c] * x2.x, d2[c] * x2.y, d2[c] * x2.z, d2[c] * x2.w);
+      gb1[c] = d1[c];
+      gb2[c] = d2[c];
+    }
+    *reinterpret_cast<float4*>(a.dx1 + (int64_t)r * K + 4 * q) = make_float4(e1.x * k1.x, e1.y * k1.y, e1.z * k1.z, e1.w * k1.w);
+    *reinterpret_cast<float4*>(a.dx2 + (int64_t)r * K + 4 * q) = make_float4(e2.x * k2.x, e2.y * k2.y, e2.z * k2.z, e2.w * k2.w);
+  }
+  // reconstruction term of the block's rows (:530) and its gradient
+  {
+    const int64_t e0 = (int64_t)blockIdx.x * rpb * a.S, e1 = min((int64_t)rows, (int64_t)(blockIdx.x + 1) * rpb) * a.S;
+    const int64_t half = (int64_t)a.B * a.S;
+    for (int64_t i = e0 + threadIdx.x; i < e1; i += 256) {
+      const float d = a.x_hat[i] - a.snps[i < half ? i : i - half];
+      rec += d * d;
+      a.dxhat[i] = a.w.lam[3] * d;
+    }
+  }
+  // the block's four loss sums
+  {
+    ce = wave_sum(ce); mi = wave_sum(mi); mse = wave_sum(mse); rec = wave_sum(rec);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[wv] = ce; red[4 + wv] = mi; red[8 + wv] = mse; red[12 + wv] = rec; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const float* p = red + 4 * threadIdx.x;
+      a.parts[(int64_t)blockIdx.x * 4 + threadIdx.x] = (p[0] + p[1]) + (p[2] + p[3]);
+    }
+    __syncthreads();
+  }
+  // weight / bias gradient partials: the block's row lanes summed in order through LDS, layer after layer
+  float* prow = a.wpart + (int64_t)blockIdx.x * (a.C * K + a.C + a.NR * K + a.NR);
+  float* redb = red + 256 * 4 * HL_MAXC;
+#pragma unroll
+  for (int layer = 0; layer < 2; ++layer) {
+    const int CC = layer ? a.NR : a.C;
+#pragma unroll
+    for (int c = 0; c < HL_MAXC; ++c) {
+      const float4 g4 = layer ? gw2[c] : gw1[c];
+      float* rc = red + c * 1024;
+      rc[threadIdx.x * 4 + 0] = g4.x; rc[threadIdx.x * 4 + 1] = g4.y; rc[threadIdx.x * 4 + 2] = g4.z; rc[threadIdx.x * 4 + 3] = g4.w;
+      redb[c * 256 + threadIdx.x] = (q == 0 && rl < rpb) ? (layer ? gb2[c] : gb1[c]) : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < CC * K; idx += 256) {
+      const int c = idx / K, k = idx - c * K, qq = k / 4, j = k % 4;
+      float t = 0.f;
+      for (int l = 0; l < rpb; ++l) t += red[c * 1024 + (l * kq + qq) * 4 + j];
+      prow[c * K + k] = t;
+    }
+    if (threadIdx.x < CC) {
+      float t = 0.f;
+      for (int l = 0; l < rpb; ++l) t += redb[threadIdx.x * 256 + l * kq];
+      prow[CC * K + threadIdx.x] = t;
+    }
+    prow += CC * K + CC;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.dgram[0] = a.w.lam[4] * 0.5f; a.dgram[1] = a.w.lam[5]; a.dgram[2] = a.w.lam[4] * 0.5f; a.dgram[3] = 0.f;
+    a.dprob[0] = a.w.lam[2];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_loss_final(const float* __restrict__ parts, int nparts, const float* __restrict__ gram, int gram_rows,
+             const float* __restrict__ prob, int prob_rows, const float* __restrict__ wts, float* __restrict__ out) {
+  __shared__ float lds[40];
+  loss_final_body(parts, nparts, gram, gram_rows, prob, prob_rows, wts, out, lds);
+}
+
+static LossHeadW loss_head_w(const float* lam6, float hp_ce, float hp_mi);
+static bool head_loss_ok(int K, int C, int NR) {
+  const int kq = K / 4;
+  return K % 4 == 0 && kq >= 1 && kq <= 64 && (kq & (kq - 1)) == 0 && C >= 1 && C <= HL_MAXC && NR >= 1 && NR <= HL_MAXC;
+}
+extern "C" int igcn_head_loss_supported(int K, int C, int NR) { return head_loss_ok(K, C, NR); }
+extern "C" int igcn_head_loss_blocks(int B, int K) { return (int)igcn_cdiv((int64_t)2 * B, 256 / (K / 4)); }
+
+// x1 / x2 [2B, K] (keep* [2B, K] or NULL), W1 [C, K] + b1, W2 [NR, K] + b2, y [B] int64, clin [B, NR], x_hat [2B, S],
+// snps [B, S]; lam6, hp_*: HOST.  Outputs: logp_out [2B, C], reg_out [2B, NR], dx1 / dx2 [2B, K], dxhat [2B, S],
+// parts [blocks, 4], wpart [blocks, C K + C + NR K + NR], dgram [4], dprob [1]  (blocks = igcn_head_loss_blocks(B, K)).
+extern "C" int igcn_head_loss_fwd(int B, int K, int C, int NR, int S, const float* x1, const float* keep1, const float* W1,
+                                  const float* b1, const float* x2, const float* keep2, const float* W2, const float* b2,
+                                  const int64_t* y, const float* clin, const float* x_hat, const float* snps,
+                                  const float* lam6 /*HOST [6]*/, float hp_ce, float hp_mi, float* logp_out, float* reg_out,
+                                  float* dx1, float* dx2, float* dxhat, float* parts, float* wpart, float* dgram,
+                                  float* dprob, void* stream) {
+  IGCN_REQUIRE(B > 0 && S > 0 && head_loss_ok(K, C, NR), "head_loss_fwd: K/4 a power of two <= 64, 1 <= C, NR <= 4 (K=%d C=%d NR=%d)",
+               K, C, NR);
+  IGCN_REQUIRE(x1 && W1 && x2 && W2 && y && clin && x_hat && snps && logp_out && reg_out && dx1 && dx2 && dxhat && parts &&
+                   wpart && dgram && dprob,
+               "head_loss_fwd: null argument");
+  IGCN_REQUIRE((((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)keep1 | (uintptr_t)keep2 | (uintptr_t)W1 | (uintptr_t)W2 |
+                 (uintptr_t)dx1 | (uintptr_t)dx2 | (uintptr_t)parts) & 15) == 0,
+               "head_loss_fwd: features, factors, weights and their gradients must be 16-byte aligned");
+  const HeadLossArgs a = {B, K, C, NR, S, x1, keep1, W1, b1, x2, keep2, W2, b2, y, clin, x_hat, snps,
+                          loss_head_w(lam6, hp_ce, hp_mi), logp_out, reg_out, dx1, dx2, dxhat, parts, wpart, dgram, dprob};
+  hipLaunchKernelGGL(k_head_loss_fwd, dim3((unsigned)igcn_head_loss_blocks(B, K)), dim3(256), 0, (hipStream_t)stream, a);
+  IGCN_CHECK_LAUNCH("head_loss_fwd");
+  return IGCN_OK;
+}
+
+// The loss value from its partial sums (loss_final.h): wts [10] DEVICE = {lam[0..5], hp_ce, hp_mi, B, NR}; out [8] = loss,
+// terms[7].  While the stream defers its reductions (igcn_reduce_defer) the job joins the flush; else a launch of its own.
+int igcn_queue_loss_final(const float* parts, int nparts, const float* gram, int gram_rows, const float* prob,
+                          int prob_rows, const float* wts, float* out, hipStream_t st);      // plan.hip
+extern "C" int igcn_loss_final(const float* parts, int nparts, const float* gram, int gram_rows, const float* prob,
+                               int prob_rows, const float* wts, float* out, void* stream) {
+  IGCN_REQUIRE(parts && nparts >= 1 && gram && gram_rows >= 1 && prob && prob_rows >= 1 && wts && out &&
+                   ((uintptr_t)parts & 15) == 0,
+               "loss_final: bad arguments");
+  if (igcn_queue_loss_final(parts, nparts, gram, gram_rows, prob, prob_rows, wts, out, (hipStream_t)stream)) return IGCN_OK;
+  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, (hipStream_t)stream, parts, nparts, gram, gram_rows, prob,
+                     prob_rows, wts, out);
+  IGCN_CHECK_LAUNCH("loss_final");
+  return IGCN_OK;
+}
+
 static LossHeadW loss_head_w(const float* lam6, float hp_ce, float hp_mi) {
   LossHeadW w;
   for (int k = 0; k < 6; ++k) w.lam[k] = lam6[k];

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include "loss_final.h"
 
 static thread_local char g_err[512] = "";
 
@@ -247,6 +248,13 @@ __global__ void __launch_bounds__(256) k_multi_reduce(ReduceTable t, int32_t* ti
   for (int i = 1; i < MRQ_MAX; ++i) ei += (int)blockIdx.x >= t.start[i] ? 1 : 0;
   const ReduceEntry e = t.e[ei];
   const int64_t blk = (int64_t)blockIdx.x - t.start[ei];
+  if (e.nptr == -2) {                                // the train step's loss value from its partial sums (loss_final.h):
+    // partial = [rows][4] head-loss sums, more[0] = Gram partials [ld & 0xffffffff][4], more[1] = regulariser partials
+    // [ld >> 32], more[2] = weights [10], out = loss | terms[7]; one workgroup
+    loss_final_body(e.partial, (int)e.rows, e.more[0], (int)(e.ld & 0xffffffff), e.more[1], (int)(e.ld >> 32), e.more[2], e.out,
+                    &lds[0][0]);
+    return;
+  }
   if (e.nptr < 0) {                                  // GO attention: parameter gradients from the block partials
     // (go_attn_finish_output, common.h — shared with go.hip's k_go_attn_bwd_finish; output j = blk, ld = FIN | FOUT << 8)
     go_attn_finish_output(e.partial, e.rows, (int)(e.ld & 255), (int)(e.ld >> 8), e.more[0], e.more[1], e.out, (int)blk,
@@ -366,7 +374,7 @@ static int reduce_flush_locked(hipStream_t st, int32_t* tick = nullptr) {
   if (igcn_opt(IGCN_OPT_DEBUG_REDUCE))
     for (const ReduceEntry& e : q)
       fprintf(stderr, "[igcn] deferred reduction: rows %lld x n %d (ld %lld)%s\n", (long long)e.rows, e.n,
-              (long long)e.ld, e.nptr < 0 ? "  GO attention finish" : e.nptr > 0 ? "  separate buffers" : rr_form(e.rows, e.n) ? "  tree" : "  in-order");
+              (long long)e.ld, e.nptr == -2 ? "  loss value" : e.nptr < 0 ? "  GO attention finish" : e.nptr > 0 ? "  separate buffers" : rr_form(e.rows, e.n) ? "  tree" : "  in-order");
   size_t done = 0;
   while (done < q.size()) {
     ReduceTable t = {};
@@ -375,7 +383,7 @@ static int reduce_flush_locked(hipStream_t st, int32_t* tick = nullptr) {
     for (int i = 0; i < cnt; ++i) {
       const ReduceEntry& e = q[done + i];
       t.e[i] = e;
-      const int64_t need = e.nptr < 0 ? e.n : e.nptr > 0 ? igcn_cdiv(e.n, 1024)
+      const int64_t need = e.nptr == -2 ? 1 : e.nptr < 0 ? e.n : e.nptr > 0 ? igcn_cdiv(e.n, 1024)
                            : rr_form(e.rows, e.n) == 1 ? igcn_cdiv(e.n, 4)
                            : rr_form(e.rows, e.n) == 2 ? igcn_cdiv(e.n, 16)
                            : rr_form(e.rows, e.n) == 3 ? igcn_cdiv(e.n, 64)
@@ -422,8 +430,26 @@ int igcn_launch_reduce_rows_final(const float* partial, int64_t rows, int64_t ld
 }
 
 // tools/reduce_bench.py: a final reduction by itself (queued while igcn_reduce_defer is on)
+// out[j] = sum_r partial[r * ld + j], j < n, as a FINAL reduction: queued while the stream defers (igcn_reduce_defer),
+// performed by a launch of its own otherwise — for partial rows a kernel left behind for a parameter gradient
+extern "C" int igcn_reduce_rows_final(const float* partial, int64_t rows, int64_t ld, int n, float* out, void* stream) {
+  IGCN_REQUIRE(partial && out && rows >= 1 && n >= 1 && ld >= n, "reduce_rows_final: bad arguments");
+  return igcn_launch_reduce_rows_final(partial, rows, ld, n, out, (hipStream_t)stream);
+}
 extern "C" int igcn_debug_reduce_rows_final(const float* partial, int64_t rows, int64_t ld, int n, float* out, void* stream) {
   return igcn_launch_reduce_rows_final(partial, rows, ld, n, out, (hipStream_t)stream);
+}
+
+// the loss value of a train step from its partial sums (loss.hip: igcn_loss_final) as an entry of the flush: queued while
+// the stream defers (returns 1), else not handled here (returns 0)
+int igcn_queue_loss_final(const float* parts, int nparts, const float* gram, int gram_rows, const float* prob,
+                          int prob_rows, const float* wts, float* out, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_rq_mutex);
+  std::vector<ReduceEntry>* q = rq_of(st);
+  if (!q) return 0;
+  q->push_back(ReduceEntry{parts, out, (int64_t)nparts, (int64_t)gram_rows | ((int64_t)prob_rows << 32), 8, -2,
+                           {gram, prob, wts}});
+  return 1;
 }
 
 // GO attention backward: dparams [2 FOUT FIN + 3 FOUT] from gpart [(2 FOUT + 3) FIN][parts] as a FINAL reduction:

@@ -1589,7 +1589,7 @@ class SparseMap(torch.autograd.Function):
         # ``x._igcn_grad_rows = (lo, hi)`` (set by the producer of x): only rows [lo, hi) of d x will ever be read — the
         # stacked (plain | masked) SNP batch of a train step, whose plain half is data — and the backward computes only
         # those (the rest of dx stays unwritten)
-        ctx.grad_rows = getattr(x, "_igcn_grad_rows", None)
+        ctx.grad_rows = getattr(x, "_igcn_grad_rows", None) if os.environ.get("IGCN_SNP_GRAD_ALL", "0") != "1" else None
         ctx.csr, ctx.stacked, ctx.nvals = csr, stacked, len(vals)
         ctx.final = _leaves(*vals)
         ctx.dense, ctx.channels = dense, c
@@ -2416,6 +2416,117 @@ class LossHead(torch.autograd.Function):
         dgram = dgram.view(2, 2) if gs == (2, 2) else dgram.view(1, 4).expand(gs[0], 4)
         dprob = dprob.view(()) if ps == () else dprob.expand(ps)
         return dlogp, None, dreg, None, dxhat, None, dgram, dprob, None, None, None, None
+
+
+_LOSS_WTS = {}
+
+
+def _loss_weights(lam, hp_ce, hp_mi, b, nr, dev):
+    """{lam[0..5], hp_ce, hp_mi, B, NR} as a cached DEVICE vector (igcn_loss_final reads its weights from memory: the
+    job may run as an entry of the deferred flush, whose table has no room for ten floats)."""
+    key = (tuple(float(v) for v in lam), float(hp_ce), float(hp_mi), int(b), int(nr), str(dev))
+    t = _LOSS_WTS.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                              # never upload from inside a capture: the caller takes the other route
+        t = _LOSS_WTS[key] = torch.tensor(list(key[0]) + [key[1], key[2], float(b), float(nr)], dtype=torch.float32,
+                                          device=dev)
+    return t
+
+
+def head_loss_supported(lin_f, w2, reg_f, w2r, keep1, keep2):
+    """The fused output-heads + loss launch (igcn_head_loss_fwd) covers these layers, and a unit upstream gradient is what
+    the backward will bring (train._unit_grad has registered its scalar)."""
+    return (lin_f.is_cuda and lin_f.dim() == 2 and lin_f.shape == reg_f.shape and w2.shape[1] == w2r.shape[1] == lin_f.shape[1]
+            and lin_f.dtype == torch.float32 and lin_f.is_contiguous() and reg_f.is_contiguous()
+            and (keep1 is None) == (keep2 is None) and torch.is_grad_enabled() and bool(UNIT_GRAD_PTRS)
+            and os.environ.get("IGCN_NO_LOSS_HEAD_FUSED", "0") != "1" and os.environ.get("IGCN_NO_HEAD_LOSS_FUSED", "0") != "1"
+            and bool(_lib.load().igcn_head_loss_supported(lin_f.shape[1], w2.shape[0], w2r.shape[0])))
+
+
+class HeadLoss(torch.autograd.Function):
+    """lin2 | lin2_regr -> log_softmax -> the cross-entropy / regression / reconstruction terms of train() AND their
+    backward for an upstream gradient of one, in ONE multi-workgroup launch (igcn_head_loss_fwd) — instead of
+    SmallLinearPair.forward, LossHead.forward (one workgroup) and SmallLinearPair.backward on the step's critical path.
+    Returns (loss, terms [7], log_softmax [2B, C], regression outputs [2B, NR]); the last three are not differentiable.
+
+    The loss VALUE is the weighted sum of partial sums that three launches leave behind (this one, the Gram loss, the mask
+    regulariser); nothing of the backward reads it.  ``lazy``: its last step (igcn_loss_final) is issued by the BACKWARD —
+    inside ``deferred_reductions`` it joins the flush as one more workgroup — so ``loss`` / ``terms`` hold their values
+    only after the step (train_step / GraphedTrainStep); otherwise a small launch right behind the forward."""
+
+    @staticmethod
+    def forward(ctx, lin_f, keep1, w2, b2, reg_f, keep2, w2r, b2r, y, clin, x_hat, snps, gram, prob, lam, hp_ce, hp_mi,
+                lazy=False):
+        f = lambda t: _f32(t) if t is not None else None               # noqa: E731
+        lin_f, keep1, w2, b2, reg_f, keep2, w2r, b2r, clin, x_hat, snps, gram, prob = (
+            f(t) for t in (lin_f, keep1, w2, b2, reg_f, keep2, w2r, b2r, clin, x_hat, snps, gram, prob))
+        y = y.contiguous()
+        rows, k = lin_f.shape
+        b, c, nr, s = rows // 2, w2.shape[0], w2r.shape[0], snps.shape[1]
+        if y.dtype != torch.int64 or y.numel() != b or clin.numel() != b * nr or x_hat.shape != (2 * b, s) \
+                or gram.numel() % 4 != 0 or gram.numel() == 0 or prob.numel() == 0 or snps.shape[0] != b:
+            raise _lib.IgcnError("head loss: inconsistent shapes")
+        dev = lin_f.device
+        lib = _lib.load()
+        f32 = dict(dtype=torch.float32, device=dev)
+        nblk = int(lib.igcn_head_loss_blocks(b, k))
+        out8 = torch.empty(8, **f32)
+        logp, our_reg = torch.empty(2 * b, c, **f32), torch.empty(2 * b, nr, **f32)
+        dx1, dx2, dxhat = torch.empty_like(lin_f), torch.empty_like(reg_f), torch.empty_like(x_hat)
+        parts = torch.empty(nblk, 4, **f32)
+        wcols = c * k + c + nr * k + nr
+        wpart = torch.empty(nblk, wcols, **f32)
+        dgram, dprob = torch.empty(4, **f32), torch.empty(1, **f32)
+        lam6 = (ctypes.c_float * 6)(*[float(v) for v in lam])
+        call("igcn_head_loss_fwd", b, k, c, nr, s, ptr(lin_f), ptr(keep1), ptr(w2), ptr(b2), ptr(reg_f), ptr(keep2), ptr(w2r),
+             ptr(b2r), ptr(y), ptr(clin), ptr(x_hat), ptr(snps), lam6, float(hp_ce), float(hp_mi), ptr(logp), ptr(our_reg),
+             ptr(dx1), ptr(dx2), ptr(dxhat), ptr(parts), ptr(wpart), ptr(dgram), ptr(dprob), stream_ptr())
+        wts = _loss_weights(lam, hp_ce, hp_mi, b, nr, dev)
+        ctx.final = (parts, gram, prob, wts, out8) if lazy else None
+        if not lazy:
+            call("igcn_loss_final", ptr(parts), nblk, ptr(gram), gram.numel() // 4, ptr(prob), prob.numel(), ptr(wts),
+                 ptr(out8), stream_ptr())
+        ctx.unit = (dx1, dx2, dxhat, dgram, dprob, wpart)
+        ctx.cfg = (b, k, c, nr, nblk, [float(v) for v in lam], b2 is not None, b2r is not None)
+        ctx.gram_shape, ctx.prob_shape = tuple(gram.shape), tuple(prob.shape)
+        ctx.w_final = (_leaves(w2, b2), _leaves(w2r, b2r))
+        loss, terms = out8[0], out8[1:]
+        ctx.mark_non_differentiable(terms, logp, our_reg)
+        ctx.set_materialize_grads(False)
+        return loss, terms, logp, our_reg
+
+    @staticmethod
+    def backward(ctx, gout, _gt=None, _gl=None, _gr=None):
+        b, k, c, nr, nblk, lam, has_b2, has_b2r = ctx.cfg
+        dx1, dx2, dxhat, dgram, dprob, wpart = ctx.unit
+        if ctx.final is not None:                    # the loss value: now, i.e. into the flush when the stream defers
+            parts, gram, prob, wts, out8 = ctx.final
+            call("igcn_loss_final", ptr(parts), nblk, ptr(gram), gram.numel() // 4, ptr(prob), prob.numel(), ptr(wts),
+                 ptr(out8), stream_ptr())
+            _keep(parts)
+        dev = dx1.device
+        wcols = c * k + c + nr * k + nr
+        dwb = torch.empty(wcols, dtype=torch.float32, device=dev)
+        _keep(wpart)
+        o1, o2 = c * k + c, nr * k + nr
+        with _immediate(ctx.w_final[0]):
+            call("igcn_reduce_rows_final", ptr(wpart), nblk, wcols, o1, ptr(dwb), stream_ptr())
+        with _immediate(ctx.w_final[1]):
+            call("igcn_reduce_rows_final", wpart.data_ptr() + 4 * o1, nblk, wcols, o2, ptr(dwb[o1:]), stream_ptr())
+        gout = _f32(gout).reshape(1)
+        UNIT_DGRAM.clear()
+        if gout.data_ptr() in UNIT_GRAD_PTRS:
+            UNIT_DGRAM[dgram.data_ptr()] = unit_dgram(lam)
+        else:                                        # every gradient is linear in the upstream one
+            dx1, dx2, dxhat, dgram, dprob, dwb = (t * gout for t in (dx1, dx2, dxhat, dgram, dprob, dwb))
+        gs, ps = ctx.gram_shape, ctx.prob_shape
+        dgram = dgram.view(2, 2) if gs == (2, 2) else dgram.view(1, 4).expand(gs[0], 4)
+        dprob = dprob.view(()) if ps == () else dprob.expand(ps)
+        dw2, db2 = dwb[:c * k].view(c, k), dwb[c * k:o1]
+        dw2r, db2r = dwb[o1:o1 + nr * k].view(nr, k), dwb[o1 + nr * k:]
+        return (dx1, None, dw2, db2 if has_b2 else None, dx2, None, dw2r, db2r if has_b2r else None, None, None, dxhat, None,
+                dgram, dprob, None, None, None, None)
 
 
 # =================================================================================================

@@ -299,9 +299,13 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         hl = self.lin1.weight.shape[0]
         self.go_network.predraw_dropout(gb, data.x.device, [((gb, hl), 0.5), ((gb, hl), 0.3)], groups)
 
-    def _forward_grouped(self, data, temperature, device, explain_flags, split=True, raw_scores=False, on_out_z=None):
+    def _forward_grouped(self, data, temperature, device, explain_flags, split=True, raw_scores=False, on_out_z=None,
+                         heads_to_loss=False):
         """``on_out_z(out_z)``: called once the fused features exist and BEFORE the heads' first layers are launched — a
-        train step queues the Gram products of its batch losses there, as riders of that launch (ops.gram_rider)."""
+        train step queues the Gram products of its batch losses there, as riders of that launch (ops.gram_rider).
+        ``heads_to_loss`` (with ``split=False``): where ops.HeadLoss covers the output layers, lin2 / lin2_regr are NOT
+        applied here — the first output is the tuple ("heads", features, factors, features_regr, factors_regr) and the
+        last None: the caller's loss launch runs them (train._losses_batched)."""
         x, edge_index, edge_weight = data.x, data.edge_index, data.edge_attr
         snps_feat = data.snps_feat
         x.requires_grad = True                                        # :210 — populates data.x.grad
@@ -478,6 +482,9 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         # the first layers of the two heads (:299 lin1, :302 lin1_regr) are independent: one grouped launch each way
         linear_outf, reg = ops.linear_pair(out_lin, self.lin1.weight, self.lin1.bias, feat, self.lin1_regr.weight,
                                            self.lin1_regr.bias, relu=True, bf16=bf)
+        if (heads_to_loss and not split and not (head_drop and keep1 is None)
+                and ops.head_loss_supported(linear_outf, self.lin2.weight, reg, self.lin2_regr.weight, keep1, keep2)):
+            return (("heads", linear_outf, keep1, reg, keep2), x_hat, out_z, out_lin, linear_outf, None)
         if head_drop and keep1 is None:               # the GO network's own dropout is switched off: library masks
             logits = ops.linear(self._drop(linear_outf, 0.5), self.lin2.weight, self.lin2.bias)
             our_reg = ops.linear(self._drop(reg, 0.3), self.lin2_regr.weight, self.lin2_regr.bias)

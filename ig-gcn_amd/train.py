@@ -296,15 +296,18 @@ def _batched(model):
             and hasattr(model, "_forward_grouped") and model.isSoftSimilarity)
 
 
-def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None):
+def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None, lazy_value=False):
     """train() :521-543.  Returns (loss, terms dict, outputs).  A model without a GO branch (``SGCN_GCN``)
-    takes the three-term loss of kernel/train_eval_sgcn.py:303-308 (``lambda_loss`` is not used there)."""
+    takes the three-term loss of kernel/train_eval_sgcn.py:303-308 (``lambda_loss`` is not used there).
+    ``lazy_value`` (train_step / GraphedTrainStep): ``loss`` and the terms may hold their VALUES only once the backward
+    that follows has finished — every gradient is complete without them, and the last step of the sum then rides in the
+    backward's final launch (ops.HeadLoss) instead of sitting on the step's critical path."""
     if not hasattr(model, "go_network"):
         return losses_sgcn(model, data, hp)
     if hasattr(model, "_reg_hp"):                    # the dense-block SGCN path reduces loss_probability in its forward
         model._reg_hp = (float(hp.lamda_x_l1), float(hp.lamda_x_ent), float(hp.lamda_e_l1), float(hp.lamda_e_ent), 1e-6)
     if getattr(model, "batched_passes", True) and hasattr(model, "_forward_grouped") and model.isSoftSimilarity:
-        return _losses_batched(model, data, lambda_loss, hp, temperature)
+        return _losses_batched(model, data, lambda_loss, hp, temperature, lazy_value)
     lam = lambda_loss
     dev = data.x.device
     o1 = model(data, temperature, dev)
@@ -345,7 +348,7 @@ def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None):
     return loss, t, (o1, o2)
 
 
-def _losses_batched(model, data, lam, hp, temperature):
+def _losses_batched(model, data, lam, hp, temperature, lazy_value=False):
     """Same seven terms on the outputs of ONE batched sweep over both passes (rows [0,B) = plain pass of :521,
     rows [B,2B) = isExplain pass of :523): the mask regulariser, one Gram matrix per pass, and ONE loss-head kernel
     per direction (igcn_loss_head_*) for the terms and their weighted sum — the per-pass means of equal-sized
@@ -364,10 +367,13 @@ def _losses_batched(model, data, lam, hp, temperature):
                 and os.environ.get("IGCN_NO_GRAM_RIDER", "0") != "1" and os.environ.get("IGCN_NO_GEMM_GROUPS", "0") != "1":
             pre["gram"], pre["hold"] = ops.gram_rider(z.detach(), 2)
 
+    # (the fused output-heads + loss launch reads its weights from a cached device vector: uploaded outside captures only)
+    heads = data.x.is_cuda and ops._loss_weights(lam, hp.lamda_ce, hp.lamda_mi, data.num_graphs,
+                                                 model.lin2_regr.weight.shape[0], dev) is not None
     try:
         scores, x_hat, out_z, out_lin, lin_f, reg = model._forward_grouped(data, temperature, dev, (False, True),
                                                                            split=False, raw_scores=True,
-                                                                           on_out_z=queue_gram)
+                                                                           on_out_z=queue_gram, heads_to_loss=heads)
     except BaseException:
         if pre:
             call("igcn_rider_cancel", stream_ptr())      # the queued products must not outlive their buffers
@@ -387,8 +393,17 @@ def _losses_batched(model, data, lam, hp, temperature):
     prob = model.loss_probability(data.x, data.edge_index, data.edge_attr, hp, edge_prob=model.last_edge_prob,
                                   partials=True)
     lam6 = [float(v) for v in lam]
-    loss, terms, logp = ops.LossHead.apply(scores, data.y.view(-1), reg, data.clini_score.view(-1), x_hat,
-                                           data.snps_feat, gram, prob, lam6, hp.lamda_ce, hp.lamda_mi, True)
+    if isinstance(scores, tuple):
+        # the output layers were left to the loss launch (ops.HeadLoss: lin2 | lin2_regr, log_softmax, three loss terms and
+        # the backward of all of it in one multi-workgroup launch; ``lazy_value``: the loss value joins the backward's flush)
+        _, hf, keep1, hr, keep2 = scores
+        loss, terms, logp, reg = ops.HeadLoss.apply(hf, keep1, model.lin2.weight, model.lin2.bias, hr, keep2,
+                                                    model.lin2_regr.weight, model.lin2_regr.bias, data.y.view(-1),
+                                                    data.clini_score.view(-1), x_hat, data.snps_feat, gram, prob, lam6,
+                                                    hp.lamda_ce, hp.lamda_mi, bool(lazy_value))
+    else:
+        loss, terms, logp = ops.LossHead.apply(scores, data.y.view(-1), reg, data.clini_score.view(-1), x_hat,
+                                               data.snps_feat, gram, prob, lam6, hp.lamda_ce, hp.lamda_mi, True)
     t = dict(zip(("ce", "mi", "reg", "prob", "recon", "cluster", "orth"), terms.unbind(0)))
     return loss, t, (logp, x_hat, out_z, out_lin, lin_f, reg)
 
@@ -407,6 +422,15 @@ def _unit_grad(loss):
             from . import ops
             ops.UNIT_GRAD_PTRS.add(_UNIT[key].data_ptr())   # (the tensor lives as long as the process: its address is its identity)
     return _UNIT[key]
+
+
+def ensure_unit_grad(device):
+    """Register the cached d loss / d loss = 1 of ``device`` BEFORE a step's forward: the forward's fused loss launches
+    (ops.LossHead / ops.HeadLoss) prepare their backward for exactly that upstream gradient when they know it exists — the
+    very first step of a process would otherwise take the unfused route and differ from every later one in rounding."""
+    device = torch.device(device)
+    if device.type == "cuda" and (device, torch.float32, ()) not in _UNIT and not torch.cuda.is_current_stream_capturing():
+        _unit_grad(torch.empty((), dtype=torch.float32, device=device))
 
 
 def backward_to_grads(loss, optimizer, data=None, defer=False, tick=False):
@@ -499,8 +523,9 @@ def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temper
     if data.x.grad is not None:
         data.x.grad = None
     forget_riders(model)          # (a failed step before this one may have left riders / masks drawn ahead: ADVICE r4)
+    ensure_unit_grad(data.x.device)
     try:
-        loss, _, _ = losses(model, data, lambda_loss, hp, temperature)
+        loss, _, _ = losses(model, data, lambda_loss, hp, temperature, lazy_value=True)
         backward_to_grads(loss, optimizer, data, defer=_single_use_parameters(model), tick=True)
     except BaseException:
         forget_riders(model)
@@ -684,6 +709,7 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         self.data._igcn_plan = self.plan
         forget_riders(self.model)                       # (leftovers of a step that failed half way must never launch)
+        ensure_unit_grad(self.data.x.device)
         rider = (rebuild and _batched(self.model) and hasattr(self.model, "predraw_dropout")
                  and os.environ.get("IGCN_NO_DROPOUT_RIDER", "0") != "1")
         try:
@@ -699,7 +725,7 @@ class GraphedTrainStep:
             if rider and getattr(self.plan, "_pending_build", None) is None:
                 call("igcn_rider_flush", stream_ptr())  # (a plan build that does not carry riders: a launch of its own)
             self.data.x.grad = None
-            loss, _, _ = losses(self.model, self.data, self.lam, self.hp)
+            loss, _, _ = losses(self.model, self.data, self.lam, self.hp, lazy_value=True)
             if rider:
                 call("igcn_rider_flush", stream_ptr())  # (nothing waiting unless no launch of the forward took the rider)
             backward_to_grads(loss, self.opt, self.data, defer=_single_use_parameters(self.model), tick=True)

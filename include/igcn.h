@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 419
+#define IGCN_ABI_VERSION 420
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -508,7 +508,8 @@ int igcn_rider_cancel(void* stream);
  * handle, hold raw device pointers that the CALLER keeps alive, never launch anything by themselves, and are empty at the
  * end of every step (igcn_stream_pending == 0; ig-gcn_amd/train.py asserts it under IGCN_DEBUG_SYNC=1):
  *   1. deferred reductions   igcn_reduce_defer(stream, 1) .. igcn_reduce_flush[_tick](stream): every "sum the block
- *      partials" launch issued on the stream in between is queued; the flush runs them in issue order in one launch.  The
+ *      partials" launch issued on the stream in between (and igcn_reduce_rows_final, igcn_loss_final) is queued; the flush
+ *      runs them in issue order in one launch.  The
  *      partial buffers must outlive the flush; igcn_reduce_defer(stream, 0) + flush also runs on the error path.
  *   2. the dropout rider     igcn_rider_dropout(stream, ...): at most ONE job; carried by the NEXT
  *      igcn_graph_plan_build_segmented[_rep] or igcn_sgcn_front_fwd (which builds the plan itself) on the stream and by
@@ -882,6 +883,9 @@ int igcn_reduce_flush(void* stream);
 /* the flush + `*step_counter += 1` (device int32: the optimiser's step) by the same launch (a one-thread launch of its
  * own when nothing is queued) */
 int igcn_reduce_flush_tick(void* stream, int32_t* step_counter);
+/* out[j] = sum_r partial[r * ld + j] (j < n) as such a final reduction: queued while the stream defers, a launch of its own
+ * otherwise — for the partial rows a kernel left behind for a parameter gradient (igcn_head_loss_fwd's wpart). */
+int igcn_reduce_rows_final(const float* partial, int64_t rows, int64_t ld, int n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Gradient exchange of the data-parallel step (the reference has no multi-GPU code): one RCCL
@@ -921,6 +925,30 @@ int igcn_loss_head_bwd(int B, int C, int NR, int S, const int64_t* y, const floa
                        const float* x_hat, const float* snps, const float* logp, const float* lam6, float hp_ce,
                        float hp_mi, const float* gout, float* dlogp, float* dreg, float* dxhat, float* dgram,
                        float* dprob, void* stream);
+
+/* THE OUTPUT HEADS AND THE LOSS HEAD OF A TRAIN STEP AS ONE LAUNCH (kernel/sgcn_img_snp.py:289-290,300-301,305 lin2 /
+ * lin2_regr / log_softmax on the stacked sweep; train() :525-530 the cross-entropy, regression and reconstruction terms)
+ * together with their BACKWARD for an upstream gradient of one: x1 / x2 [2B, K] = the heads' hidden features (keep1 / keep2
+ * [2B, K]: dropout factors of those inputs, or NULL), W1 [C, K] + b1 = lin2, W2 [NR, K] + b2 = lin2_regr, y [B] int64, clin
+ * [B, NR], x_hat [2B, S], snps [B, S]; K / 4 a power of two <= 64, C, NR <= 4 (igcn_head_loss_supported).  Outputs: logp_out
+ * [2B, C] = log_softmax of the scores, reg_out [2B, NR]; dx1 / dx2 [2B, K] = d loss / d (x1, x2), dxhat [2B, S]; wpart
+ * [blocks, C K + C + NR K + NR] = per-workgroup partial rows of (dW1 | db1 | dW2 | db2) for igcn_reduce_rows_final; dgram [4],
+ * dprob [1] = d loss / d (Gram terms, regulariser); parts [blocks, 4] = partial sums of the four row-wise loss terms
+ * (blocks = igcn_head_loss_blocks(B, K)).  Same arithmetic as igcn_small_linear_pair_fwd -> igcn_loss_head_fwd_grads ->
+ * igcn_small_linear_pair_bwd.
+ * igcn_loss_final: the loss VALUE from the partial sums of this launch, of igcn_gram_loss_fwd (gram [gram_rows, 4]) and of the
+ * mask regulariser (prob [prob_rows]); wts [10] DEVICE floats = {lam[0..5], hp_ce, hp_mi, B, NR}; out [8] = loss, terms[7].
+ * Nothing of the backward depends on it: while the stream defers its reductions (igcn_reduce_defer) it joins the flush as
+ * one more workgroup, otherwise it is a launch of its own. */
+int igcn_head_loss_supported(int K, int C, int NR);
+int igcn_head_loss_blocks(int B, int K);
+int igcn_head_loss_fwd(int B, int K, int C, int NR, int S, const float* x1, const float* keep1, const float* W1,
+                       const float* b1, const float* x2, const float* keep2, const float* W2, const float* b2,
+                       const int64_t* y, const float* clin, const float* x_hat, const float* snps,
+                       const float* lam6 /*HOST [6]*/, float hp_ce, float hp_mi, float* logp_out, float* reg_out, float* dx1,
+                       float* dx2, float* dxhat, float* parts, float* wpart, float* dgram, float* dprob, void* stream);
+int igcn_loss_final(const float* parts, int nparts, const float* gram, int gram_rows, const float* prob, int prob_rows,
+                    const float* wts, float* out, void* stream);
 /* igcn_loss_head_fwd that also writes the gradients igcn_loss_head_bwd would return for gout = 1 (each element's gradient
  * is known where its forward term is computed): a train step, whose d loss / d loss is one, then has no backward launch
  * for the loss head.  dlogp [2B,C] (of the raw scores when from_logits), dreg [2B,NR], dxhat [2B,S], dgram [4], dprob [1]. */

@@ -1441,6 +1441,65 @@ def test_loss_head_matches_composite():
         assert_matches(g, w.grad.float().cpu().numpy(), 1e-5, "grad " + name)
 
 
+@pytest.mark.parametrize("b,k,c,nr,drop,upstream,lazy", [(37, 64, 3, 3, True, 1.0, False), (256, 64, 3, 3, True, 1.0, True),
+                                                          (5, 32, 2, 4, False, 1.0, False), (40, 64, 3, 3, True, 1.7, False),
+                                                          (16, 16, 4, 1, False, 1.0, True)])
+def test_head_loss_one_launch_equals_heads_plus_loss_head(b, k, c, nr, drop, upstream, lazy):
+    """ops.HeadLoss (igcn_head_loss_fwd + igcn_loss_final): lin2 | lin2_regr, log_softmax, the loss head and the backward
+    of all of it in one multi-workgroup launch, against the chain it replaces — ops.small_linear_pair -> ops.LossHead
+    (unit-gradient route) -> their backward launches — on the same inputs: loss, the seven terms, log_softmax, regression
+    outputs and every gradient (features, both layers' weights and biases, x_hat, Gram terms, regulariser), with and without
+    dropout factors, for the unit upstream gradient of a train step and a general one, with the loss value issued at once
+    and lazily (inside ``deferred_reductions``: as an entry of the flush)."""
+    from igcn_amd import ops
+    from igcn_amd.train import _unit_grad
+    torch.manual_seed(b + k)
+    dev, s = "cuda", 54
+    mk = lambda *sh: torch.randn(*sh, device=dev)                        # noqa: E731
+    hf, hr = mk(2 * b, k).relu(), mk(2 * b, k).relu()
+    keep1 = (torch.rand(2 * b, k, device=dev) > 0.5).float() * 2.0 if drop else None
+    keep2 = (torch.rand(2 * b, k, device=dev) > 0.3).float() / 0.7 if drop else None
+    w2, b2, w2r, b2r = mk(c, k) * 0.3, mk(c) * 0.1, mk(nr, k) * 0.3, mk(nr) * 0.1
+    y = torch.randint(0, c, (b,), device=dev)
+    clin, x_hat, snps = torch.rand(b * nr, device=dev), mk(2 * b, s), torch.rand(b, s, device=dev)
+    gram, prob = torch.rand(7, 4, device=dev), torch.rand(11, device=dev)
+    lam, hp_ce, hp_mi = [0.7, 1.0, 0.5, 1.5e-3, 0.1, 0.2], 1.3, 0.8
+    unit = _unit_grad(torch.zeros((), device=dev))                   # registers the cached d loss / d loss = 1
+    assert unit is not None and ops.UNIT_GRAD_PTRS
+
+    def leaves():
+        return [t.clone().requires_grad_(True) for t in (hf, w2, b2, hr, w2r, b2r, x_hat, gram, prob)]
+
+    def finish(loss, ls):
+        go = unit if upstream == 1.0 else torch.full((), upstream, device=dev)
+        if lazy:
+            with ops.deferred_reductions():
+                g = torch.autograd.grad(loss, ls, grad_outputs=go)
+        else:
+            g = torch.autograd.grad(loss, ls, grad_outputs=go)
+        torch.cuda.synchronize()
+        return g
+    # the chain
+    ls0 = leaves()
+    logits, reg_o = ops.small_linear_pair(ls0[0], ls0[1], ls0[2], keep1, ls0[3], ls0[4], ls0[5], keep2)
+    loss0, terms0, logp0 = ops.LossHead.apply(logits, y, reg_o, clin, ls0[6], snps, ls0[7], ls0[8], lam, hp_ce, hp_mi, True)
+    g0 = finish(loss0, ls0)
+    # the one launch
+    ls1 = leaves()
+    assert ops.head_loss_supported(ls1[0], ls1[1], ls1[3], ls1[4], keep1, keep2)
+    loss1, terms1, logp1, reg1 = ops.HeadLoss.apply(ls1[0], keep1, ls1[1], ls1[2], ls1[3], keep2, ls1[4], ls1[5], y, clin,
+                                                    ls1[6], snps, ls1[7], ls1[8], lam, hp_ce, hp_mi, lazy)
+    g1 = finish(loss1, ls1)
+    assert abs(float(loss1) - float(loss0)) <= 2e-6 * max(1.0, abs(float(loss0)))
+    for j in range(7):
+        assert abs(float(terms1[j]) - float(terms0[j])) <= 2e-6 * max(1e-3, abs(float(terms0[j]))), j
+    assert_matches(logp1, logp0.detach().cpu().numpy(), 2e-6, "log_softmax")
+    assert_matches(reg1, reg_o.detach().cpu().numpy(), 2e-6, "regression outputs")
+    for a_, w_, nm in zip(g1, g0, ("features", "lin2.weight", "lin2.bias", "features_regr", "lin2_regr.weight",
+                                    "lin2_regr.bias", "x_hat", "gram", "prob")):
+        assert_matches(a_, w_.detach().cpu().numpy(), 5e-6, "grad " + nm, floor=1e-7)
+
+
 @pytest.mark.parametrize("m,n,k,batch,sk,form", [(256, 256, 2880, 2, 4, "nt"), (256, 2880, 256, 2, 1, "nn"),
                                                  (70, 33, 131, 3, 2, "nt"), (5, 7, 32, 4, 1, "nn")])
 def test_gemm_f32_batched(m, n, k, batch, sk, form):
