@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 420        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 421        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -175,6 +175,8 @@ SIGNATURES = {
     "igcn_head_loss_supported": (I, [I, I, I]),
     "igcn_head_loss_blocks": (I, [I, I]),
     "igcn_head_loss_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, F, F, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_head_loss_gram_fwd": (I, [I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, F, F, P, P, P, P, P, P, P, P, P,
+                                    I, I, I, P, P, I, F, P, P, P, P, P]),
     "igcn_loss_final": (I, [P, I, P, I, P, I, P, P, P]),
     "igcn_reduce_flush": (I, [P]),
     "igcn_reduce_flush_tick": (I, [P, P]),

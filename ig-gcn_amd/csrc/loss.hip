@@ -115,13 +115,13 @@ extern "C" int igcn_mask_reg_bwd(int64_t n_prob, int64_t n_edge, int64_t n_snps,
 // known on the host: a train step's d loss / d (consist, orth) are the loss weights) — S = dG + dG^T per group, from the
 // same expressions in the same order, so a step whose upstream IS that has no Gram-loss backward launch.
 struct GramUnit { float gc[4], go[4]; };
+// (row i of group grp; the body of k_gram_loss_fwd, also one role of k_head_loss_gram_fwd)
 template <bool RBF>
-__global__ void __launch_bounds__(256)
-k_gram_loss_fwd(int B, int RD, const float* __restrict__ Gall, const float* __restrict__ Lap,
-                float* __restrict__ partial /*[B, 2 groups]*/, const float* __restrict__ t, int T, float gamma,
-                float* __restrict__ lap_out, GramUnit unit, float* __restrict__ Sall) {
-  __shared__ float red[16];
-  const int i = blockIdx.x, grp = blockIdx.y, groups = gridDim.y;
+__device__ __forceinline__ void gram_loss_fwd_body(const int i, const int grp, const int groups, int B, int RD,
+                                                   const float* __restrict__ Gall, const float* __restrict__ Lap,
+                                                   float* __restrict__ partial, const float* __restrict__ t, int T,
+                                                   float gamma, float* __restrict__ lap_out, const GramUnit& unit,
+                                                   float* __restrict__ Sall, float* red) {
   const float* G = Gall + (int64_t)grp * B * B;
   const float gii = G[(int64_t)i * B + i];
   const bool UNIT = RBF && Sall != nullptr;
@@ -171,6 +171,16 @@ k_gram_loss_fwd(int B, int RD, const float* __restrict__ Gall, const float* __re
     partial[(int64_t)i * 2 * groups + 2 * grp] = c / b2;
     partial[(int64_t)i * 2 * groups + 2 * grp + 1] = (o - 2.f + (float)RD / (float)B) / b2;   // -2B + RD, spread over rows
   }
+}
+
+template <bool RBF>
+__global__ void __launch_bounds__(256)
+k_gram_loss_fwd(int B, int RD, const float* __restrict__ Gall, const float* __restrict__ Lap,
+                float* __restrict__ partial /*[B, 2 groups]*/, const float* __restrict__ t, int T, float gamma,
+                float* __restrict__ lap_out, GramUnit unit, float* __restrict__ Sall) {
+  __shared__ float red[16];
+  gram_loss_fwd_body<RBF>((int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, B, RD, Gall, Lap, partial, t, T, gamma, lap_out,
+                          unit, Sall, red);
 }
 
 __global__ void __launch_bounds__(256)
@@ -525,11 +535,11 @@ struct HeadLossArgs {
   float *dgram, *dprob;                    // [4], [1]: d loss / d (Gram terms, regulariser)
 };
 
-__global__ void __launch_bounds__(256) k_head_loss_fwd(const HeadLossArgs a) {
-  __shared__ float red[256 * 4 * HL_MAXC + 256 * HL_MAXC];
+#define HL_RED_FLOATS (256 * 4 * HL_MAXC + 256 * HL_MAXC)
+__device__ __forceinline__ void head_loss_body(const unsigned blk, const HeadLossArgs& a, float* red) {
   const int K = a.K, kq = K / 4, q = threadIdx.x % kq, rl = threadIdx.x / kq, rpb = 256 / kq;
   const int rows = 2 * a.B;
-  const int r = (int)blockIdx.x * rpb + rl;
+  const int r = (int)blk * rpb + rl;
   const bool live = rl < rpb && r < rows;
   const int b = r < a.B ? r : r - a.B;
   float ce = 0.f, mi = 0.f, mse = 0.f, rec = 0.f;
@@ -616,7 +626,7 @@ __global__ void __launch_bounds__(256) k_head_loss_fwd(const HeadLossArgs a) {
   }
   // reconstruction term of the block's rows (:530) and its gradient
   {
-    const int64_t e0 = (int64_t)blockIdx.x * rpb * a.S, e1 = min((int64_t)rows, (int64_t)(blockIdx.x + 1) * rpb) * a.S;
+    const int64_t e0 = (int64_t)blk * rpb * a.S, e1 = min((int64_t)rows, (int64_t)(blk + 1) * rpb) * a.S;
     const int64_t half = (int64_t)a.B * a.S;
     for (int64_t i = e0 + threadIdx.x; i < e1; i += 256) {
       const float d = a.x_hat[i] - a.snps[i < half ? i : i - half];
@@ -632,12 +642,12 @@ __global__ void __launch_bounds__(256) k_head_loss_fwd(const HeadLossArgs a) {
     __syncthreads();
     if (threadIdx.x < 4) {
       const float* p = red + 4 * threadIdx.x;
-      a.parts[(int64_t)blockIdx.x * 4 + threadIdx.x] = (p[0] + p[1]) + (p[2] + p[3]);
+      a.parts[(int64_t)blk * 4 + threadIdx.x] = (p[0] + p[1]) + (p[2] + p[3]);
     }
     __syncthreads();
   }
   // weight / bias gradient partials: the block's row lanes summed in order through LDS, layer after layer
-  float* prow = a.wpart + (int64_t)blockIdx.x * (a.C * K + a.C + a.NR * K + a.NR);
+  float* prow = a.wpart + (int64_t)blk * (a.C * K + a.C + a.NR * K + a.NR);
   float* redb = red + 256 * 4 * HL_MAXC;
 #pragma unroll
   for (int layer = 0; layer < 2; ++layer) {
@@ -664,9 +674,31 @@ __global__ void __launch_bounds__(256) k_head_loss_fwd(const HeadLossArgs a) {
     prow += CC * K + CC;
     __syncthreads();
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blk == 0 && threadIdx.x == 0) {
     a.dgram[0] = a.w.lam[4] * 0.5f; a.dgram[1] = a.w.lam[5]; a.dgram[2] = a.w.lam[4] * 0.5f; a.dgram[3] = 0.f;
     a.dprob[0] = a.w.lam[2];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_head_loss_fwd(const HeadLossArgs a) {
+  __shared__ float red[HL_RED_FLOATS];
+  head_loss_body(blockIdx.x, a, red);
+}
+
+// The two launches that close a train step's forward — the output heads + loss head above and the Gram-form batch
+// losses (k_gram_loss_fwd<true>, unit form) — read disjoint outputs of the launches in front of them and write disjoint
+// buffers: as two ROLES of one grid (workgroups [0, n_head) the heads, the rest one Gram row each) they overlap instead of
+// running back to back (9.9 + 11.1 us).
+__global__ void __launch_bounds__(256)
+k_head_loss_gram_fwd(const HeadLossArgs a, unsigned n_head, int B, int RD, int groups, const float* __restrict__ Gall,
+                     float* __restrict__ partial, const float* __restrict__ t, int T, float gamma,
+                     float* __restrict__ lap_out, GramUnit unit, float* __restrict__ Sall) {
+  __shared__ float red[HL_RED_FLOATS];
+  if (blockIdx.x < n_head) {
+    head_loss_body(blockIdx.x, a, red);
+  } else {
+    const int idx = (int)(blockIdx.x - n_head);
+    gram_loss_fwd_body<true>(idx % B, idx / B, groups, B, RD, Gall, nullptr, partial, t, T, gamma, lap_out, unit, Sall, red);
   }
 }
 
@@ -706,6 +738,39 @@ extern "C" int igcn_head_loss_fwd(int B, int K, int C, int NR, int S, const floa
                           loss_head_w(lam6, hp_ce, hp_mi), logp_out, reg_out, dx1, dx2, dxhat, parts, wpart, dgram, dprob};
   hipLaunchKernelGGL(k_head_loss_fwd, dim3((unsigned)igcn_head_loss_blocks(B, K)), dim3(256), 0, (hipStream_t)stream, a);
   IGCN_CHECK_LAUNCH("head_loss_fwd");
+  return IGCN_OK;
+}
+
+// igcn_head_loss_fwd and igcn_gram_loss_fwd_rbf_unit (out = NULL: the row partials stay in gscratch) as ONE launch.
+extern "C" int igcn_head_loss_gram_fwd(int B, int K, int C, int NR, int S, const float* x1, const float* keep1,
+                                       const float* W1, const float* b1, const float* x2, const float* keep2,
+                                       const float* W2, const float* b2, const int64_t* y, const float* clin,
+                                       const float* x_hat, const float* snps, const float* lam6 /*HOST [6]*/, float hp_ce,
+                                       float hp_mi, float* logp_out, float* reg_out, float* dx1, float* dx2, float* dxhat,
+                                       float* parts, float* wpart, float* dgram, float* dprob,
+                                       int Bg, int RD, int groups, const float* G, const float* tsne, int T, float gamma,
+                                       float* lap_out, float* gscratch, const float* gout /*HOST [2 groups]*/, float* Ssym,
+                                       void* stream) {
+  IGCN_REQUIRE(B > 0 && S > 0 && head_loss_ok(K, C, NR), "head_loss_gram_fwd: K/4 a power of two <= 64, 1 <= C, NR <= 4");
+  IGCN_REQUIRE(x1 && W1 && x2 && W2 && y && clin && x_hat && snps && logp_out && reg_out && dx1 && dx2 && dxhat && parts &&
+                   wpart && dgram && dprob,
+               "head_loss_gram_fwd: null argument");
+  IGCN_REQUIRE((((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)keep1 | (uintptr_t)keep2 | (uintptr_t)W1 | (uintptr_t)W2 |
+                 (uintptr_t)dx1 | (uintptr_t)dx2 | (uintptr_t)parts) & 15) == 0,
+               "head_loss_gram_fwd: features, factors, weights and their gradients must be 16-byte aligned");
+  IGCN_REQUIRE(Bg > 0 && groups >= 1 && groups <= 4 && G && lap_out && gscratch && gout && Ssym && (tsne == nullptr || T > 0),
+               "head_loss_gram_fwd: bad Gram-loss arguments (groups <= 4)");
+  const HeadLossArgs a = {B, K, C, NR, S, x1, keep1, W1, b1, x2, keep2, W2, b2, y, clin, x_hat, snps,
+                          loss_head_w(lam6, hp_ce, hp_mi), logp_out, reg_out, dx1, dx2, dxhat, parts, wpart, dgram, dprob};
+  GramUnit u{};
+  for (int g = 0; g < groups; ++g) {
+    u.gc[g] = gout[2 * g];
+    u.go[g] = gout[2 * g + 1];
+  }
+  const unsigned nh = (unsigned)igcn_head_loss_blocks(B, K);
+  hipLaunchKernelGGL(k_head_loss_gram_fwd, dim3(nh + (unsigned)(Bg * groups)), dim3(256), 0, (hipStream_t)stream, a, nh, Bg,
+                     RD, groups, G, gscratch, tsne, T, gamma, lap_out, u, Ssym);
+  IGCN_CHECK_LAUNCH("head_loss_gram_fwd");
   return IGCN_OK;
 }
 

@@ -2195,7 +2195,7 @@ class GramLosses(torch.autograd.Function):
     (sgcn_img_snp.py:183-205).  Returns two tensors of shape [G]."""
 
     @staticmethod
-    def forward(ctx, s, lap, groups=1, packed=False, rbf=None, expect=None, pre=None):
+    def forward(ctx, s, lap, groups=1, packed=False, rbf=None, expect=None, pre=None, hold=None):
         """``expect`` (with ``rbf``): the upstream gradient [G*2] the caller expects in the backward, as host floats (a
         train step's d loss / d (consist, orth) are its loss weights): the forward kernel then writes the backward's S
         as it goes, and a backward whose upstream IS that (announced by LossHead through UNIT_DGRAM, recognised by
@@ -2235,9 +2235,16 @@ class GramLosses(torch.autograd.Function):
                 and ctx.needs_input_grad[0]):
             ctx.expect = tuple(float(v) for v in expect)
             ctx.sym = torch.empty(groups, b, b, dtype=torch.float32, device=s.device)
-            call("igcn_gram_loss_fwd_rbf_unit", b, rd, groups, ptr(gram), ptr(tsne),
-                 tsne.shape[1] if tsne is not None else 0, float(rbf[1]), ptr(lap), ptr(out), ptr(scratch),
-                 (ctypes.c_float * (2 * groups))(*ctx.expect), ptr(ctx.sym), stream_ptr())
+            if hold is not None and partials:
+                # ``hold`` (a dict of the caller): the launch is NOT issued here — its arguments are handed to the caller,
+                # whose next launch runs it as a second role of its own grid (ops.HeadLoss: igcn_head_loss_gram_fwd).  The
+                # returned partials hold their values behind THAT launch.
+                hold["gram"] = (b, rd, groups, gram, tsne, tsne.shape[1] if tsne is not None else 0, float(rbf[1]), lap,
+                                scratch, ctx.expect, ctx.sym)
+            else:
+                call("igcn_gram_loss_fwd_rbf_unit", b, rd, groups, ptr(gram), ptr(tsne),
+                     tsne.shape[1] if tsne is not None else 0, float(rbf[1]), ptr(lap), ptr(out), ptr(scratch),
+                     (ctypes.c_float * (2 * groups))(*ctx.expect), ptr(ctx.sym), stream_ptr())
         elif rbf is not None:
             call("igcn_gram_loss_fwd_rbf", b, rd, groups, ptr(gram), ptr(tsne), tsne.shape[1] if tsne is not None else 0,
                  float(rbf[1]), ptr(lap), ptr(out), ptr(scratch), stream_ptr())
@@ -2273,7 +2280,7 @@ class GramLosses(torch.autograd.Function):
         rd = s.shape[1]
         call("igcn_gemm_f32_batched", b, rd, b, groups, ptr(sym), b, 1, b * b, ptr(s), 1, rd, b * rd, ptr(ds), b * rd, rd,
              1, None, stream_ptr())                                # ds_g = S_g s_g, every group in one launch
-        return ds, None, None, None, None, None, None
+        return ds, None, None, None, None, None, None, None
 
 
 def gram_rider(s, groups):
@@ -2457,7 +2464,9 @@ class HeadLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, lin_f, keep1, w2, b2, reg_f, keep2, w2r, b2r, y, clin, x_hat, snps, gram, prob, lam, hp_ce, hp_mi,
-                lazy=False):
+                lazy=False, gram_job=None):
+        """``gram_job``: the arguments of a Gram-loss launch that GramLosses handed back instead of issuing
+        (``hold``): it runs as a second role of this launch's grid (igcn_head_loss_gram_fwd)."""
         f = lambda t: _f32(t) if t is not None else None               # noqa: E731
         lin_f, keep1, w2, b2, reg_f, keep2, w2r, b2r, clin, x_hat, snps, gram, prob = (
             f(t) for t in (lin_f, keep1, w2, b2, reg_f, keep2, w2r, b2r, clin, x_hat, snps, gram, prob))
@@ -2479,9 +2488,15 @@ class HeadLoss(torch.autograd.Function):
         wpart = torch.empty(nblk, wcols, **f32)
         dgram, dprob = torch.empty(4, **f32), torch.empty(1, **f32)
         lam6 = (ctypes.c_float * 6)(*[float(v) for v in lam])
-        call("igcn_head_loss_fwd", b, k, c, nr, s, ptr(lin_f), ptr(keep1), ptr(w2), ptr(b2), ptr(reg_f), ptr(keep2), ptr(w2r),
-             ptr(b2r), ptr(y), ptr(clin), ptr(x_hat), ptr(snps), lam6, float(hp_ce), float(hp_mi), ptr(logp), ptr(our_reg),
-             ptr(dx1), ptr(dx2), ptr(dxhat), ptr(parts), ptr(wpart), ptr(dgram), ptr(dprob), stream_ptr())
+        head = (b, k, c, nr, s, ptr(lin_f), ptr(keep1), ptr(w2), ptr(b2), ptr(reg_f), ptr(keep2), ptr(w2r), ptr(b2r), ptr(y),
+                ptr(clin), ptr(x_hat), ptr(snps), lam6, float(hp_ce), float(hp_mi), ptr(logp), ptr(our_reg), ptr(dx1), ptr(dx2),
+                ptr(dxhat), ptr(parts), ptr(wpart), ptr(dgram), ptr(dprob))
+        if gram_job is not None:
+            gb_, grd, ggr, gmat, gts, gt, ggam, glap, gscr, gexp, gsym = gram_job
+            call("igcn_head_loss_gram_fwd", *head, gb_, grd, ggr, ptr(gmat), ptr(gts), gt, ggam, ptr(glap), ptr(gscr),
+                 (ctypes.c_float * (2 * ggr))(*gexp), ptr(gsym), stream_ptr())
+        else:
+            call("igcn_head_loss_fwd", *head, stream_ptr())
         wts = _loss_weights(lam, hp_ce, hp_mi, b, nr, dev)
         ctx.final = (parts, gram, prob, wts, out8) if lazy else None
         if not lazy:
@@ -2526,7 +2541,7 @@ class HeadLoss(torch.autograd.Function):
         dw2, db2 = dwb[:c * k].view(c, k), dwb[c * k:o1]
         dw2r, db2r = dwb[o1:o1 + nr * k].view(nr, k), dwb[o1 + nr * k:]
         return (dx1, None, dw2, db2 if has_b2 else None, dx2, None, dw2r, db2r if has_b2r else None, None, None, dxhat, None,
-                dgram, dprob, None, None, None, None)
+                dgram, dprob, None, None, None, None, None)
 
 
 # =================================================================================================

@@ -387,8 +387,10 @@ def _losses_batched(model, data, lam, hp, temperature, lazy_value=False):
     # (the loss head's gradient of these partials for a unit upstream is known here: the Gram loss forward prepares its
     # own backward for it — ops.GramLosses ``expect``)
     unit = ops.unit_dgram(lam) if (ops.UNIT_GRAD_PTRS and os.environ.get("IGCN_NO_LOSS_HEAD_FUSED", "0") != "1") else None
+    # (with the output layers left to the loss launch, the Gram loss launch is left to it too: two roles of one grid)
+    job = {} if (isinstance(scores, tuple) and os.environ.get("IGCN_NO_GRAM_LOSS_PAIRED", "0") != "1") else None
     gram = ops.GramLosses.apply(out_z, None, 2, "partials", (data.tsne_fdim if soft else None, model.rbf_gamma), unit,
-                                pre.get("gram"))
+                                pre.get("gram"), job)
     # (rows sum to [2,2] = (consist, orth) per pass)
     prob = model.loss_probability(data.x, data.edge_index, data.edge_attr, hp, edge_prob=model.last_edge_prob,
                                   partials=True)
@@ -400,7 +402,8 @@ def _losses_batched(model, data, lam, hp, temperature, lazy_value=False):
         loss, terms, logp, reg = ops.HeadLoss.apply(hf, keep1, model.lin2.weight, model.lin2.bias, hr, keep2,
                                                     model.lin2_regr.weight, model.lin2_regr.bias, data.y.view(-1),
                                                     data.clini_score.view(-1), x_hat, data.snps_feat, gram, prob, lam6,
-                                                    hp.lamda_ce, hp.lamda_mi, bool(lazy_value))
+                                                    hp.lamda_ce, hp.lamda_mi, bool(lazy_value),
+                                                    job.get("gram") if job is not None else None)
     else:
         loss, terms, logp = ops.LossHead.apply(scores, data.y.view(-1), reg, data.clini_score.view(-1), x_hat,
                                                data.snps_feat, gram, prob, lam6, hp.lamda_ce, hp.lamda_mi, True)

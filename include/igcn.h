@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 420
+#define IGCN_ABI_VERSION 421
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -947,6 +947,16 @@ int igcn_head_loss_fwd(int B, int K, int C, int NR, int S, const float* x1, cons
                        const int64_t* y, const float* clin, const float* x_hat, const float* snps,
                        const float* lam6 /*HOST [6]*/, float hp_ce, float hp_mi, float* logp_out, float* reg_out, float* dx1,
                        float* dx2, float* dxhat, float* parts, float* wpart, float* dgram, float* dprob, void* stream);
+/* igcn_head_loss_fwd and igcn_gram_loss_fwd_rbf_unit(out = NULL: the row partials stay in gscratch [Bg, 2 groups]) as two
+ * roles of ONE launch: the two read disjoint outputs of the launches in front of them and write disjoint buffers. */
+int igcn_head_loss_gram_fwd(int B, int K, int C, int NR, int S, const float* x1, const float* keep1, const float* W1,
+                            const float* b1, const float* x2, const float* keep2, const float* W2, const float* b2,
+                            const int64_t* y, const float* clin, const float* x_hat, const float* snps,
+                            const float* lam6 /*HOST [6]*/, float hp_ce, float hp_mi, float* logp_out, float* reg_out,
+                            float* dx1, float* dx2, float* dxhat, float* parts, float* wpart, float* dgram, float* dprob,
+                            int Bg, int RD, int groups, const float* G, const float* tsne, int T, float gamma,
+                            float* lap_out, float* gscratch, const float* gout /*HOST [2 groups]*/, float* Ssym,
+                            void* stream);
 int igcn_loss_final(const float* parts, int nparts, const float* gram, int gram_rows, const float* prob, int prob_rows,
                     const float* wts, float* out, void* stream);
 /* igcn_loss_head_fwd that also writes the gradients igcn_loss_head_bwd would return for gout = 1 (each element's gradient

@@ -836,7 +836,8 @@ def test_deferred_reductions_give_the_same_gradients(golden):
                                     "IGCN_LN_AFFINE_NOW", "IGCN_SPMM_DVAL_NOW", "IGCN_NO_PROJ_FUSED", "IGCN_NO_HEAD_FUSED",
                                     "IGCN_NO_MASK_REG_FUSED", "IGCN_NO_GRAD_FAN", "IGCN_NO_LN_FUSED",
                                     "IGCN_NO_LOSS_HEAD_FUSED", "IGCN_SPARSE_MAPS", "IGCN_NO_LINEAR_BN_FUSED",
-                                    "IGCN_NO_FRONT_FUSED", "IGCN_NO_HEAD_LOSS_FUSED"])
+                                    "IGCN_NO_FRONT_FUSED", "IGCN_NO_HEAD_LOSS_FUSED",
+                                    "IGCN_NO_GRAM_LOSS_PAIRED"])
 def test_every_host_side_switch_gives_the_default_train_step(golden, monkeypatch, switch):
     """every A/B switch that the Python layer reads selects a second code path — each of them must give
     the default path's train step (loss, every gradient) on the ``full_b32`` model, so a losing variant cannot rot
