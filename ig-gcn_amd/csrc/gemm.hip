@@ -545,8 +545,12 @@ __global__ void k_gemm_splitk_reduce(int64_t M, int64_t N, int split_k, const fl
 }
 
 // the slab sums of up to four split products of the SAME output shape in one launch (blockIdx.y = product)
-struct SlabSums { const float* slabs[4]; const float* bias[4]; float* C[4]; int split[4]; };
-__global__ void k_gemm_splitk_reduce_multi(int64_t M, int64_t N, SlabSums q, int64_t ldc, int act) {
+// (round 5: the products may differ in shape — the heads' two [512, 64] sums and the Gram riders' two [256, 256] sums of
+// one grouped launch were two launches of this kernel; gridDim.x covers the largest, the others' spare workgroups leave)
+struct SlabSums { const float* slabs[4]; const float* bias[4]; float* C[4]; int split[4]; int64_t M[4], N[4], ldc[4]; int act[4]; };
+__global__ void k_gemm_splitk_reduce_multi(SlabSums q) {
+  const int64_t M = q.M[blockIdx.y], N = q.N[blockIdx.y], ldc = q.ldc[blockIdx.y];
+  const int act = q.act[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * N) return;
   const float* __restrict__ slabs = q.slabs[blockIdx.y];
@@ -913,31 +917,28 @@ extern "C" int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream) 
 #undef LAUNCH_GB
 #undef LAUNCH_GG
   IGCN_CHECK_LAUNCH("gemm_f32_grouped");
-  // slab sums: the plain column-walk ones of equal output shape share a launch (lin1 / lin1_regr: two [512, 64] sums)
+  // slab sums: the plain column-walk ones share ONE launch, whatever their output shapes
   bool done[GG_MAX] = {false, false, false, false};
-  for (int i = 0; i < n; ++i) {
-    const int64_t* t = table + 16 * i;
-    const int act = (int)t[12] & 0xff;
-    auto plain = [&](int k) {
-      const int64_t* u = table + 16 * k;
-      const bool tree = u[11] == u[1] && u[0] * u[1] <= 4096 && split_of[k] > 32 && u[9] == 0 && ((int)u[12] & 0xff) == 0;
-      return split_of[k] > 1 && !fgrad[k] && !tree;
-    };
-    if (done[i] || !plain(i)) continue;
+  {
     SlabSums q = {};
     int cnt = 0;
-    for (int k = i; k < n; ++k) {
+    int64_t blocks = 0;
+    for (int k = 0; k < n; ++k) {
       const int64_t* u = table + 16 * k;
-      if (!done[k] && plain(k) && u[0] == t[0] && u[1] == t[1] && u[11] == t[11] && ((int)u[12] & 0xff) == act) {
-        q.slabs[cnt] = (const float*)u[14]; q.bias[cnt] = (const float*)u[9]; q.C[cnt] = (float*)u[10];
-        q.split[cnt] = split_of[k];
-        done[k] = true;
-        ++cnt;
-      }
+      const bool tree = u[11] == u[1] && u[0] * u[1] <= 4096 && split_of[k] > 32 && u[9] == 0 && ((int)u[12] & 0xff) == 0;
+      if (!(split_of[k] > 1 && !fgrad[k] && !tree)) continue;
+      q.slabs[cnt] = (const float*)u[14]; q.bias[cnt] = (const float*)u[9]; q.C[cnt] = (float*)u[10];
+      q.split[cnt] = split_of[k];
+      q.M[cnt] = u[0]; q.N[cnt] = u[1]; q.ldc[cnt] = u[11]; q.act[cnt] = (int)u[12] & 0xff;
+      const int64_t b = igcn_cdiv(u[0] * u[1], 256);
+      blocks = b > blocks ? b : blocks;
+      done[k] = true;
+      ++cnt;
     }
-    hipLaunchKernelGGL(k_gemm_splitk_reduce_multi, dim3((unsigned)igcn_cdiv(t[0] * t[1], 256), (unsigned)cnt), dim3(256), 0,
-                       st, t[0], t[1], q, t[11], act);
-    IGCN_CHECK_LAUNCH("gemm_splitk_reduce_multi");
+    if (cnt > 0) {
+      hipLaunchKernelGGL(k_gemm_splitk_reduce_multi, dim3((unsigned)blocks, (unsigned)cnt), dim3(256), 0, st, q);
+      IGCN_CHECK_LAUNCH("gemm_splitk_reduce_multi");
+    }
   }
   for (int i = 0; i < n; ++i) {
     if (done[i]) continue;
