@@ -615,13 +615,23 @@ k_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, const float* __restri
 
 // d_mid [R, W] = (d_out_z + d_out_lin[:, :W] + d_feat[:, :W]) / 2  (the gradient of img AND of cross);
 // d_latent [R, L] = d_out_lin[:, W:] + d_feat[:, W:W+L].  Any of the three incoming gradients may be NULL.
+// MASK (round 5): `cross` [R, W] is the POST-ReLU output of the layer in front (relu(out_proj(attention)),
+// kernel/sgcn_img_snp.py:241-242) — the launch also writes d_cross [R, W] = d_mid where cross > 0, else 0 (that layer's
+// ReLU backward: k_bias_grad's mask pass was a launch of its own, 7.6 us) and the workgroup's share of the layer's bias
+// gradient, db_part [blocks][D] (column c of a row belongs to output feature c % D; D a power of two <= 64, even), for
+// the deferred reduction.
+template <bool MASK>
 __global__ void __launch_bounds__(256)
 k_head_inputs_bwd_main(int64_t R, int W, int L, int P, const float* __restrict__ d_out_z,
                        const float* __restrict__ d_out_lin, const float* __restrict__ d_feat,
-                       float* __restrict__ d_mid, float* __restrict__ d_latent) {
+                       float* __restrict__ d_mid, float* __restrict__ d_latent, const float* __restrict__ cross,
+                       float* __restrict__ d_cross, float* __restrict__ db_part, int D) {
+  __shared__ float red[MASK ? 512 : 1];
   const int wf = (W + L) / 2;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= R * wf) return;
+  float2 m = make_float2(0.f, 0.f);                     // this thread's masked pair (bias partial)
+  int mc = 0;
+  if (i < R * wf) {
   const int64_t r = i / wf;
   const int c = (int)(i - r * wf) * 2;
   float2 t = make_float2(0.f, 0.f);
@@ -639,8 +649,39 @@ k_head_inputs_bwd_main(int64_t R, int W, int L, int P, const float* __restrict__
       t.x += a.x; t.y += a.y;
     }
     *reinterpret_cast<float2*>(d_mid + r * W + c) = make_float2(t.x * 0.5f, t.y * 0.5f);
+    if (MASK) {
+      const float2 y = *reinterpret_cast<const float2*>(cross + r * W + c);
+      m = make_float2(y.x > 0.f ? t.x * 0.5f : 0.f, y.y > 0.f ? t.y * 0.5f : 0.f);
+      *reinterpret_cast<float2*>(d_cross + r * W + c) = m;
+      mc = c & (D - 1);
+    }
   } else {
     *reinterpret_cast<float2*>(d_latent + r * L + (c - W)) = t;
+  }
+  }
+  if (MASK) {
+    // column sums of the masked gradient over the workgroup's 256 pairs, by feature, in a fixed order: thread (seg, f)
+    // sums the D pairs of segment seg that carry feature f, then thread f sums the 256 / D segments
+    __shared__ int cols[256];
+    __shared__ float seg_sum[256];
+    red[2 * threadIdx.x] = m.x;
+    red[2 * threadIdx.x + 1] = m.y;
+    cols[threadIdx.x] = mc;
+    __syncthreads();
+    {
+      const int f = threadIdx.x & (D - 1), seg = threadIdx.x / D;
+      float s = 0.f;
+      for (int t2 = seg * D; t2 < (seg + 1) * D; ++t2)
+        if (cols[t2] == (f & ~1)) s += red[2 * t2 + (f & 1)];
+      seg_sum[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < D) {
+      const int f = threadIdx.x;
+      float s = 0.f;
+      for (int g = 0; g < 256 / D; ++g) s += seg_sum[g * D + f];
+      db_part[(int64_t)blockIdx.x * D + f] = s;
+    }
   }
 }
 
@@ -684,12 +725,34 @@ extern "C" int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, con
   IGCN_REQUIRE(R > 0 && bsz > 0 && R % bsz == 0 && W % 2 == 0 && L % 2 == 0 && P % 2 == 0, "head_inputs_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = R * ((W + L) / 2);
-  hipLaunchKernelGGL(k_head_inputs_bwd_main, dim3((unsigned)igcn_cdiv(total, 256)), dim3(256), 0, st, R, W, L, P,
-                     d_out_z, d_out_lin, d_feat, d_mid, d_latent);
+  hipLaunchKernelGGL(k_head_inputs_bwd_main<false>, dim3((unsigned)igcn_cdiv(total, 256)), dim3(256), 0, st, R, W, L, P,
+                     d_out_z, d_out_lin, d_feat, d_mid, d_latent, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0);
   if (P > 0 && dx && dprob)
     hipLaunchKernelGGL(k_head_inputs_bwd_prob, dim3(P), dim3(256), 0, st, R, bsz, W, L, P, d_feat, x, prob, dx, dprob);
   IGCN_CHECK_LAUNCH("head_inputs_bwd");
   return IGCN_OK;
+}
+
+// The same backward that also takes the ReLU backward and the bias gradient of the layer that produced `cross` (its
+// post-ReLU output [R, W], W = rows x D features): d_cross [R, W] = the gradient of that layer's PRE-activation, db [D] = its
+// column sums by feature — through db_part [igcn_head_inputs_bwd_blocks(R, W, L)][D] and igcn_reduce_rows_final (a deferred
+// reduction while the stream defers).  D a power of two, 2 <= D <= 64, W % D == 0.
+extern "C" int igcn_head_inputs_bwd_blocks(int64_t R, int W, int L) { return (int)igcn_cdiv(R * ((W + L) / 2), 256); }
+extern "C" int igcn_head_inputs_bwd_relu(int64_t R, int bsz, int W, int L, int P, const float* d_out_z,
+                                         const float* d_out_lin, const float* d_feat, const float* x, const float* prob,
+                                         float* d_mid, float* d_latent, float* dx, float* dprob, const float* cross,
+                                         float* d_cross, int D, float* db_part, float* db, void* stream) {
+  IGCN_REQUIRE(R > 0 && bsz > 0 && R % bsz == 0 && W % 2 == 0 && L % 2 == 0 && P % 2 == 0, "head_inputs_bwd_relu: bad sizes");
+  IGCN_REQUIRE(cross && d_cross && db_part && db && D >= 2 && D <= 64 && (D & (D - 1)) == 0 && W % D == 0,
+               "head_inputs_bwd_relu: D a power of two in [2, 64] dividing W, non-null outputs");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t blocks = igcn_head_inputs_bwd_blocks(R, W, L);
+  hipLaunchKernelGGL(k_head_inputs_bwd_main<true>, dim3((unsigned)blocks), dim3(256), 0, st, R, W, L, P, d_out_z,
+                     d_out_lin, d_feat, d_mid, d_latent, cross, d_cross, db_part, D);
+  if (P > 0 && dx && dprob)
+    hipLaunchKernelGGL(k_head_inputs_bwd_prob, dim3(P), dim3(256), 0, st, R, bsz, W, L, P, d_feat, x, prob, dx, dprob);
+  IGCN_CHECK_LAUNCH("head_inputs_bwd_relu");
+  return igcn_launch_reduce_rows_final(db_part, blocks, D, D, db, st);
 }
 
 // =================================================================================================

@@ -1001,6 +1001,32 @@ class Linear(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class LinearReluOwed(torch.autograd.Function):
+    """y = relu(x W^T + b) whose ReLU backward and bias gradient are taken by the CONSUMER of y: the incoming gradient
+    is already that of the pre-activation, and b's gradient is returned by the consumer (HeadInputs with ``cross_bias``,
+    which reads y anyway — kernel/sgcn_img_snp.py:241-242 then :284).  Only valid when y has that one consumer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bf16=False):
+        y = gemm_nt(x, weight, _f32(bias), 1, bf16=bf16)
+        ctx.save_for_backward(x, weight)
+        ctx.bf16 = bf16
+        ctx.w_final = _leaves(weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight = ctx.saved_tensors
+        dz = _f32(dz)
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            dx, dw = gemm_group([("nn", dz, weight, None, None, False), ("tn", dz, x, None, None, ctx.w_final)],
+                                bf16=ctx.bf16)
+        else:
+            dx = gemm_nn(dz, weight, bf16=ctx.bf16) if ctx.needs_input_grad[0] else None
+            dw = gemm_tn(dz, x, bf16=ctx.bf16, final_grad=ctx.w_final) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
 def _bias_grad_into(dy, db, final):
     """db[cols] = column sums of dy (igcn_bias_grad without a ReLU mask), written into ``db`` (may be a slice)."""
     lib = _lib.load()
@@ -1283,7 +1309,7 @@ class HeadInputs(torch.autograd.Function):
     row's sample.  ``prob`` None: no regression features, ``feat`` is ``out_lin``."""
 
     @staticmethod
-    def forward(ctx, img, cross, latent, x, prob, bsz):
+    def forward(ctx, img, cross, latent, x, prob, bsz, cross_bias=None):
         img, cross, latent = _f32(img), _f32(cross), _f32(latent)
         r, w = img.shape
         l = latent.shape[1]
@@ -1297,7 +1323,12 @@ class HeadInputs(torch.autograd.Function):
         feat = torch.empty(r, w + l + p, dtype=torch.float32, device=dev) if p else None
         call("igcn_head_inputs_fwd", r, bsz, w, l, p, ptr(img), ptr(cross), ptr(latent), ptr(x) if p else None,
              ptr(prob) if p else None, ptr(out_z), ptr(out_lin), ptr(feat), stream_ptr())
-        ctx.save_for_backward(x if p else None, prob if p else None)
+        # cross_bias [D]: ``cross`` is the output of a LinearReluOwed layer with that bias — the backward also takes that
+        # layer's ReLU mask and bias gradient (igcn_head_inputs_bwd_relu)
+        ctx.owed = cross_bias is not None
+        ctx.save_for_backward(x if p else None, prob if p else None, cross if ctx.owed else None)
+        ctx.b_final = _leaves(cross_bias)
+        ctx.feat_dim = cross_bias.numel() if ctx.owed else 0
         ctx.dims = (r, bsz, w, l, p)
         ctx.x_shape = x.shape if p else None
         ctx.set_materialize_grads(False)
@@ -1309,7 +1340,7 @@ class HeadInputs(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out_z, d_out_lin, d_feat):
-        x, prob = ctx.saved_tensors
+        x, prob, cross = ctx.saved_tensors
         r, bsz, w, l, p = ctx.dims
         dev = d_out_z.device if d_out_z is not None else (d_out_lin.device if d_out_lin is not None else d_feat.device)
         gz = _f32(d_out_z) if d_out_z is not None else None
@@ -1319,9 +1350,20 @@ class HeadInputs(torch.autograd.Function):
         d_latent = torch.empty(r, l, dtype=torch.float32, device=dev)
         dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if p else None
         dprob = torch.empty(prob.shape, dtype=torch.float32, device=dev) if p else None
+        if ctx.owed:
+            d = ctx.feat_dim
+            d_cross = torch.empty(r, w, dtype=torch.float32, device=dev)
+            db = torch.empty(d, dtype=torch.float32, device=dev)
+            part = _keep(torch.empty(int(_lib.load().igcn_head_inputs_bwd_blocks(r, w, l)), d, dtype=torch.float32,
+                                     device=dev))
+            with _immediate(ctx.b_final):
+                call("igcn_head_inputs_bwd_relu", r, bsz, w, l, p, ptr(gz), ptr(gl), ptr(gf), ptr(x), ptr(prob),
+                     ptr(d_mid), ptr(d_latent), ptr(dx), ptr(dprob), ptr(cross), ptr(d_cross), d, ptr(part), ptr(db),
+                     stream_ptr())
+            return d_mid, d_cross, d_latent, dx, dprob, None, db
         call("igcn_head_inputs_bwd", r, bsz, w, l, p, ptr(gz), ptr(gl), ptr(gf), ptr(x), ptr(prob), ptr(d_mid),
              ptr(d_latent), ptr(dx), ptr(dprob), stream_ptr())
-        return d_mid, d_mid, d_latent, dx, dprob, None
+        return d_mid, d_mid, d_latent, dx, dprob, None, None
 
 
 def head_inputs_supported(img, cross, latent, x, prob):
@@ -1331,6 +1373,12 @@ def head_inputs_supported(img, cross, latent, x, prob):
     w, l = img.shape[1], latent.shape[1]
     p = prob.numel() if prob is not None else 0
     return img.shape == cross.shape and w % 2 == 0 and l % 2 == 0 and p % 2 == 0
+
+
+def relu_owed_supported(d, width):
+    """HeadInputs can take the ReLU backward and bias gradient of a D-feature layer whose output is its ``cross``
+    operand (igcn_head_inputs_bwd_relu): D a power of two in [2, 64] dividing the row width."""
+    return os.environ.get("IGCN_NO_RELU_OWED", "0") != "1" and 2 <= d <= 64 and (d & (d - 1)) == 0 and width % d == 0
 
 
 class SmallLinear(torch.autograd.Function):

@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 421
+#define IGCN_ABI_VERSION 422
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -386,6 +386,16 @@ int igcn_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, const float* i
 int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, const float* d_out_z, const float* d_out_lin,
                          const float* d_feat, const float* x, const float* prob, float* d_mid, float* d_latent,
                          float* dx, float* dprob, void* stream);
+/* The same backward that also takes the ReLU backward and the bias gradient of the layer whose POST-ReLU output `cross`
+ * [R, W] is (relu(out_proj(.)), kernel/sgcn_img_snp.py:241-242; W = positions x D features): d_cross [R, W] = the gradient
+ * of that layer's pre-activation (d_mid where cross > 0), db [D] = its column sums by feature, through the partial rows
+ * db_part [igcn_head_inputs_bwd_blocks(R, W, L)][D] and a final reduction that is deferred while the stream defers.
+ * D a power of two, 2 <= D <= 64, W % D == 0. */
+int igcn_head_inputs_bwd_blocks(int64_t R, int W, int L);
+int igcn_head_inputs_bwd_relu(int64_t R, int bsz, int W, int L, int P, const float* d_out_z, const float* d_out_lin,
+                              const float* d_feat, const float* x, const float* prob, float* d_mid, float* d_latent,
+                              float* dx, float* dprob, const float* cross, float* d_cross, int D, float* db_part,
+                              float* db, void* stream);
 
 /* out[r, p*F + c] = parts[p][r, c], p < nparts <= 4: concatenation of the GCN layer outputs along the feature axis
  * (kernel/sgcn_img_snp.py:223-224, kernel/sgcn.py:376-377 `torch.cat(xs, dim=1)`).  F % 4 == 0, 16-byte aligned

@@ -248,8 +248,8 @@ def test_full_model_vs_oracle_larger(bsz, pool, explain):
     seen = []
     real_ca = model._cross_attention
 
-    def spy(query, memory):
-        out = real_ca(query, memory)
+    def spy(query, memory, **kw):
+        out = real_ca(query, memory, **kw)
         seen.append(out.detach().cpu() > 0)
         return out
     model._cross_attention = spy

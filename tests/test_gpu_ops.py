@@ -242,6 +242,59 @@ def test_head_inputs(ops, bsz, g, w, l, rois, use_prob, used):
             assert_matches(got, want.numpy(), TOL, nm)
 
 
+@pytest.mark.parametrize("bsz,g,rois,d,l,use_prob", [(8, 2, 90, 32, 64, True), (5, 1, 12, 16, 10, False),
+                                                      (3, 2, 7, 2, 4, True), (16, 2, 90, 64, 2, False)])
+def test_relu_owed_layer_and_head_inputs(ops, bsz, g, rois, d, l, use_prob):
+    """relu(out_proj(.)) whose ReLU backward and bias gradient ride in the head-input backward (ops.LinearReluOwed +
+    HeadInputs(cross_bias=...), igcn_head_inputs_bwd_relu) against the composite of kernel/sgcn_img_snp.py:241-242,
+    :284-297 in fp64: outputs and the gradients of every input, weight and bias."""
+    rng = np.random.default_rng(bsz * 7 + d)
+    mk = lambda *shape: torch.from_numpy(rng.standard_normal(shape)).float()      # noqa: E731
+    w = rois * d
+    o, wt, bias = mk(g * bsz * rois, d), mk(d, d) * 0.3, mk(d) * 0.2
+    img, latent, x, prob = mk(g * bsz, w), mk(g * bsz, l), mk(bsz * rois, 2), mk(rois, 2)
+    cots = [mk(g * bsz, w), mk(g * bsz, w + l), mk(g * bsz, w + l + (2 * rois if use_prob else 0))]
+
+    def composite(o, wt, bias, img, latent, x, prob):
+        cross = torch.relu(o @ wt.t() + bias).reshape(g * bsz, -1)
+        out_z = (img + cross) / 2
+        out_lin = torch.cat((out_z, latent), -1)
+        feat = out_lin
+        if use_prob:
+            feat = torch.cat((out_lin, (x.view(bsz, rois, -1) * prob).reshape(bsz, -1).repeat(g, 1)), -1)
+        return out_z, out_lin, feat
+
+    ref_in = [t.double().requires_grad_(True) for t in (o, wt, bias, img, latent, x, prob)]
+    ref_out = composite(*ref_in)
+    g_ref = torch.autograd.grad(sum((a * c.double()).sum() for a, c in zip(ref_out, cots)), ref_in, allow_unused=True)
+    dev = [t.cuda().requires_grad_(True) for t in (o, wt, bias, img, latent, x, prob)]
+    assert ops.relu_owed_supported(d, w)
+    cross = ops.LinearReluOwed.apply(dev[0], dev[1], dev[2], False).reshape(g * bsz, -1)
+    if use_prob:
+        outs = ops.HeadInputs.apply(dev[3], cross, dev[4], dev[5].view(bsz, -1), dev[6].view(-1), bsz, dev[2])
+    else:
+        oz, ol, _ = ops.HeadInputs.apply(dev[3], cross, dev[4], None, None, bsz, dev[2])
+        outs = (oz, ol, ol)
+    for got, want, nm in zip(outs, ref_out, ("out_z", "out_lin", "feat")):
+        assert_matches(got, want.detach().numpy(), TOL, nm)
+    gd = torch.autograd.grad(sum((a * c.cuda()).sum() for a, c in zip(outs, cots)), dev, allow_unused=True)
+    for got, want, nm in zip(gd, g_ref, ("d_o", "d_weight", "d_bias", "d_img", "d_latent", "dx", "dprob")):
+        if want is None:
+            assert got is None or float(got.abs().max()) == 0.0, nm
+        else:
+            assert_matches(got, want.numpy(), TOL, nm)
+    # the same through the deferred reductions of a captured step (the bias sums join the flush), bit for bit
+    with ops.deferred_reductions():
+        cross = ops.LinearReluOwed.apply(dev[0], dev[1], dev[2], False).reshape(g * bsz, -1)
+        o2 = ops.HeadInputs.apply(dev[3], cross, dev[4], dev[5].view(bsz, -1) if use_prob else None,
+                                  dev[6].view(-1) if use_prob else None, bsz, dev[2])
+        o2 = o2 if use_prob else (o2[0], o2[1], o2[1])
+        g2 = torch.autograd.grad(sum((a * c.cuda()).sum() for a, c in zip(o2, cots)), dev, allow_unused=True)
+    torch.cuda.synchronize()
+    for a, b_, nm in zip(gd, g2, ("d_o", "d_weight", "d_bias")):
+        assert torch.equal(a, b_), nm
+
+
 @pytest.mark.parametrize("b,lq,lk,d", [(6, 90, 40, 32), (3, 7, 5, 16)])
 def test_in_proj_packed_projection(ops, b, lq, lk, d):
     """ops.InProj = the packed q / key|value projection of nn.MultiheadAttention (cross-attention) with the parameters
