@@ -615,23 +615,13 @@ k_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, const float* __restri
 
 // d_mid [R, W] = (d_out_z + d_out_lin[:, :W] + d_feat[:, :W]) / 2  (the gradient of img AND of cross);
 // d_latent [R, L] = d_out_lin[:, W:] + d_feat[:, W:W+L].  Any of the three incoming gradients may be NULL.
-// MASK (round 5): `cross` [R, W] is the POST-ReLU output of the layer in front (relu(out_proj(attention)),
-// kernel/sgcn_img_snp.py:241-242) — the launch also writes d_cross [R, W] = d_mid where cross > 0, else 0 (that layer's
-// ReLU backward: k_bias_grad's mask pass was a launch of its own, 7.6 us) and the workgroup's share of the layer's bias
-// gradient, db_part [blocks][D] (column c of a row belongs to output feature c % D; D a power of two <= 64, even), for
-// the deferred reduction.
-template <bool MASK>
 __global__ void __launch_bounds__(256)
 k_head_inputs_bwd_main(int64_t R, int W, int L, int P, const float* __restrict__ d_out_z,
                        const float* __restrict__ d_out_lin, const float* __restrict__ d_feat,
-                       float* __restrict__ d_mid, float* __restrict__ d_latent, const float* __restrict__ cross,
-                       float* __restrict__ d_cross, float* __restrict__ db_part, int D) {
-  __shared__ float red[MASK ? 512 : 1];
+                       float* __restrict__ d_mid, float* __restrict__ d_latent) {
   const int wf = (W + L) / 2;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  float2 m = make_float2(0.f, 0.f);                     // this thread's masked pair (bias partial)
-  int mc = 0;
-  if (i < R * wf) {
+  if (i >= R * wf) return;
   const int64_t r = i / wf;
   const int c = (int)(i - r * wf) * 2;
   float2 t = make_float2(0.f, 0.f);
@@ -649,50 +639,19 @@ k_head_inputs_bwd_main(int64_t R, int W, int L, int P, const float* __restrict__
       t.x += a.x; t.y += a.y;
     }
     *reinterpret_cast<float2*>(d_mid + r * W + c) = make_float2(t.x * 0.5f, t.y * 0.5f);
-    if (MASK) {
-      const float2 y = *reinterpret_cast<const float2*>(cross + r * W + c);
-      m = make_float2(y.x > 0.f ? t.x * 0.5f : 0.f, y.y > 0.f ? t.y * 0.5f : 0.f);
-      *reinterpret_cast<float2*>(d_cross + r * W + c) = m;
-      mc = c & (D - 1);
-    }
   } else {
     *reinterpret_cast<float2*>(d_latent + r * L + (c - W)) = t;
-  }
-  }
-  if (MASK) {
-    // column sums of the masked gradient over the workgroup's 256 pairs, by feature, in a fixed order: thread (seg, f)
-    // sums the D pairs of segment seg that carry feature f, then thread f sums the 256 / D segments
-    __shared__ int cols[256];
-    __shared__ float seg_sum[256];
-    red[2 * threadIdx.x] = m.x;
-    red[2 * threadIdx.x + 1] = m.y;
-    cols[threadIdx.x] = mc;
-    __syncthreads();
-    {
-      const int f = threadIdx.x & (D - 1), seg = threadIdx.x / D;
-      float s = 0.f;
-      for (int t2 = seg * D; t2 < (seg + 1) * D; ++t2)
-        if (cols[t2] == (f & ~1)) s += red[2 * t2 + (f & 1)];
-      seg_sum[threadIdx.x] = s;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < D) {
-      const int f = threadIdx.x;
-      float s = 0.f;
-      for (int g = 0; g < 256 / D; ++g) s += seg_sum[g * D + f];
-      db_part[(int64_t)blockIdx.x * D + f] = s;
-    }
   }
 }
 
 // regression features: g[b, j] = sum_passes d_feat[pass*bsz + b, W+L+j];  dx[b, j] = g * prob[j];
 // dprob[j] = sum_b g[b, j] * x[b, j].  One workgroup per column j, threads stride the samples.
-__global__ void __launch_bounds__(256)
-k_head_inputs_bwd_prob(int64_t R, int bsz, int W, int L, int P, const float* __restrict__ d_feat,
-                       const float* __restrict__ x, const float* __restrict__ prob, float* __restrict__ dx,
-                       float* __restrict__ dprob) {
-  __shared__ float red[16];
-  const int j = blockIdx.x, passes = (int)(R / bsz);
+__device__ __forceinline__ void head_inputs_bwd_prob_body(int j, int64_t R, int bsz, int W, int L, int P,
+                                                          const float* __restrict__ d_feat,
+                                                          const float* __restrict__ x, const float* __restrict__ prob,
+                                                          float* __restrict__ dx, float* __restrict__ dprob,
+                                                          float* red) {
+  const int passes = (int)(R / bsz);
   const float pj = prob[j];
   float acc = 0.f;
   for (int b = threadIdx.x; b < bsz; b += 256) {
@@ -704,6 +663,80 @@ k_head_inputs_bwd_prob(int64_t R, int bsz, int W, int L, int P, const float* __r
   }
   acc = block_sum_all(acc, red);
   if (threadIdx.x == 0) dprob[j] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_head_inputs_bwd_prob(int64_t R, int bsz, int W, int L, int P, const float* __restrict__ d_feat,
+                       const float* __restrict__ x, const float* __restrict__ prob, float* __restrict__ dx,
+                       float* __restrict__ dprob) {
+  __shared__ float red[16];
+  head_inputs_bwd_prob_body(blockIdx.x, R, bsz, W, L, P, d_feat, x, prob, dx, dprob, red);
+}
+
+// The same sums when `cross` [R, W] is the POST-ReLU output of the layer in front (relu(out_proj(attention)),
+// kernel/sgcn_img_snp.py:241-242): the launch also writes d_cross [R, W] = d_mid where cross > 0, else 0 (that layer's
+// ReLU backward — k_bias_grad's mask pass was a launch of its own, 7.6 us) and the workgroup's share of the layer's bias
+// gradient, db_part [blocks][D] (column c of a row belongs to output feature c % D; D a power of two, 2 <= D <= 64), for
+// the deferred reduction.  Workgroup (chunk, row pair): thread t owns columns chunk * 512 + 2t, 2t + 1 of HIB_ROWS rows,
+// so its feature pair is (2t) % D whatever the chunk and the bias sums are lane shuffles (strides D/2 .. 32) and one
+// 4-wave LDS step — a fixed order.  Workgroups past the n_main of that grid are the regression-feature columns
+// (head_inputs_bwd_prob_body: one column each — a launch of its own, 5.9 us, otherwise).
+#define HIB_ROWS 2
+__global__ void __launch_bounds__(256)
+k_head_inputs_bwd_relu(int64_t R, int W, int L, int P, const float* __restrict__ d_out_z,
+                       const float* __restrict__ d_out_lin, const float* __restrict__ d_feat,
+                       float* __restrict__ d_mid, float* __restrict__ d_latent, const float* __restrict__ cross,
+                       float* __restrict__ d_cross, float* __restrict__ db_part, int D, int chunks, int n_main, int bsz,
+                       const float* __restrict__ x, const float* __restrict__ prob, float* __restrict__ dx,
+                       float* __restrict__ dprob) {
+  __shared__ float wsum[4][64];
+  if ((int)blockIdx.x >= n_main) {
+    head_inputs_bwd_prob_body(blockIdx.x - n_main, R, bsz, W, L, P, d_feat, x, prob, dx, dprob, &wsum[0][0]);
+    return;
+  }
+  const int chunk = blockIdx.x % chunks, rp = blockIdx.x / chunks;
+  const int c = chunk * 512 + 2 * threadIdx.x;
+  float2 m = make_float2(0.f, 0.f);                     // this thread's masked pair summed over its rows
+  if (c < W + L) {
+#pragma unroll
+    for (int k = 0; k < HIB_ROWS; ++k) {
+      const int64_t r = (int64_t)rp * HIB_ROWS + k;
+      if (r >= R) break;
+      float2 t = make_float2(0.f, 0.f);
+      if (d_out_lin) {
+        const float2 a = *reinterpret_cast<const float2*>(d_out_lin + r * (W + L) + c);
+        t.x += a.x; t.y += a.y;
+      }
+      if (d_feat) {
+        const float2 a = *reinterpret_cast<const float2*>(d_feat + r * (W + L + P) + c);
+        t.x += a.x; t.y += a.y;
+      }
+      if (c < W) {
+        if (d_out_z) {
+          const float2 a = *reinterpret_cast<const float2*>(d_out_z + r * W + c);
+          t.x += a.x; t.y += a.y;
+        }
+        const float2 y = *reinterpret_cast<const float2*>(cross + r * W + c);
+        const float2 h = make_float2(t.x * 0.5f, t.y * 0.5f);
+        const float2 g = make_float2(y.x > 0.f ? h.x : 0.f, y.y > 0.f ? h.y : 0.f);
+        *reinterpret_cast<float2*>(d_mid + r * W + c) = h;
+        *reinterpret_cast<float2*>(d_cross + r * W + c) = g;
+        m.x += g.x; m.y += g.y;
+      } else {
+        *reinterpret_cast<float2*>(d_latent + r * L + (c - W)) = t;
+      }
+    }
+  }
+  for (int s = D / 2; s < 64; s *= 2) {                 // lanes that share (2t) % D
+    m.x += __shfl_xor(m.x, s);
+    m.y += __shfl_xor(m.y, s);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < D / 2) { wsum[wave][2 * lane] = m.x; wsum[wave][2 * lane + 1] = m.y; }
+  __syncthreads();
+  if ((int)threadIdx.x < D)
+    db_part[(int64_t)blockIdx.x * D + threadIdx.x] =
+        (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
 }
 
 extern "C" int igcn_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, const float* img, const float* cross,
@@ -725,8 +758,8 @@ extern "C" int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, con
   IGCN_REQUIRE(R > 0 && bsz > 0 && R % bsz == 0 && W % 2 == 0 && L % 2 == 0 && P % 2 == 0, "head_inputs_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = R * ((W + L) / 2);
-  hipLaunchKernelGGL(k_head_inputs_bwd_main<false>, dim3((unsigned)igcn_cdiv(total, 256)), dim3(256), 0, st, R, W, L, P,
-                     d_out_z, d_out_lin, d_feat, d_mid, d_latent, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0);
+  hipLaunchKernelGGL(k_head_inputs_bwd_main, dim3((unsigned)igcn_cdiv(total, 256)), dim3(256), 0, st, R, W, L, P,
+                     d_out_z, d_out_lin, d_feat, d_mid, d_latent);
   if (P > 0 && dx && dprob)
     hipLaunchKernelGGL(k_head_inputs_bwd_prob, dim3(P), dim3(256), 0, st, R, bsz, W, L, P, d_feat, x, prob, dx, dprob);
   IGCN_CHECK_LAUNCH("head_inputs_bwd");
@@ -737,7 +770,9 @@ extern "C" int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, con
 // post-ReLU output [R, W], W = rows x D features): d_cross [R, W] = the gradient of that layer's PRE-activation, db [D] = its
 // column sums by feature — through db_part [igcn_head_inputs_bwd_blocks(R, W, L)][D] and igcn_reduce_rows_final (a deferred
 // reduction while the stream defers).  D a power of two, 2 <= D <= 64, W % D == 0.
-extern "C" int igcn_head_inputs_bwd_blocks(int64_t R, int W, int L) { return (int)igcn_cdiv(R * ((W + L) / 2), 256); }
+extern "C" int igcn_head_inputs_bwd_blocks(int64_t R, int W, int L) {
+  return (int)(igcn_cdiv(W + L, 512) * igcn_cdiv(R, HIB_ROWS));
+}
 extern "C" int igcn_head_inputs_bwd_relu(int64_t R, int bsz, int W, int L, int P, const float* d_out_z,
                                          const float* d_out_lin, const float* d_feat, const float* x, const float* prob,
                                          float* d_mid, float* d_latent, float* dx, float* dprob, const float* cross,
@@ -747,10 +782,11 @@ extern "C" int igcn_head_inputs_bwd_relu(int64_t R, int bsz, int W, int L, int P
                "head_inputs_bwd_relu: D a power of two in [2, 64] dividing W, non-null outputs");
   hipStream_t st = (hipStream_t)stream;
   const int64_t blocks = igcn_head_inputs_bwd_blocks(R, W, L);
-  hipLaunchKernelGGL(k_head_inputs_bwd_main<true>, dim3((unsigned)blocks), dim3(256), 0, st, R, W, L, P, d_out_z,
-                     d_out_lin, d_feat, d_mid, d_latent, cross, d_cross, db_part, D);
-  if (P > 0 && dx && dprob)
-    hipLaunchKernelGGL(k_head_inputs_bwd_prob, dim3(P), dim3(256), 0, st, R, bsz, W, L, P, d_feat, x, prob, dx, dprob);
+  const int chunks = (int)igcn_cdiv(W + L, 512);
+  const bool with_prob = P > 0 && dx && dprob;
+  hipLaunchKernelGGL(k_head_inputs_bwd_relu, dim3((unsigned)(blocks + (with_prob ? P : 0))), dim3(256), 0, st, R, W, L, P,
+                     d_out_z, d_out_lin, d_feat, d_mid, d_latent, cross, d_cross, db_part, D, chunks, (int)blocks, bsz, x,
+                     prob, dx, dprob);
   IGCN_CHECK_LAUNCH("head_inputs_bwd_relu");
   return igcn_launch_reduce_rows_final(db_part, blocks, D, D, db, st);
 }

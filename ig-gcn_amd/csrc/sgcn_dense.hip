@@ -112,14 +112,16 @@ __device__ __forceinline__ void ds_block(int nblk, int& g, int& xb) {
 
 #ifdef DS_PROBE_ON
 // phase stamps of the first workgroups of k_ds_agg (tools/dense_probe.py, IGCN_HIPCC_EXTRA=-DDS_PROBE_ON)
-__device__ long long ds_probe_buf[8 * 8 * 8];                     // [workgroup][wave][stamp]
+__device__ long long ds_probe_buf[8 * 8 * 16];                    // [workgroup][wave][stamp: wall clock (100 MHz) | 8 + stamp: shader clock]
 #define DS_PROBE(i)                                                                                     \
   do {                                                                                                  \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64 && (blockIdx.x & 7) == 0)                            \
-      ds_probe_buf[((blockIdx.x >> 3) * 8 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64();            \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64 && (blockIdx.x & 7) == 0) {                          \
+      ds_probe_buf[((blockIdx.x >> 3) * 8 + (threadIdx.x >> 6)) * 16 + (i)] = wall_clock64();           \
+      ds_probe_buf[((blockIdx.x >> 3) * 8 + (threadIdx.x >> 6)) * 16 + 8 + (i)] = clock64();            \
+    }                                                                                                   \
   } while (0)
 extern "C" int igcn_debug_ds_probe(long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ds_probe_buf), sizeof(long long) * 8 * 8 * 8);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ds_probe_buf), sizeof(long long) * 8 * 8 * 16);
 }
 #else
 #define DS_PROBE(i)
@@ -471,20 +473,36 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
       bf.us[jj] = ANYM ? u[nb + s] : 0.f;
     }
   };
-  auto compute = [&](const auto& bf, int) {
+  auto compute = [&](const auto& bf, int row) {
     constexpr int N = sizeof(bf.us) / sizeof(float);
 #pragma unroll
     for (int jj = 0; jj < N; ++jj) {
       float ev[VW];
+      // DS_ABL (tools/dense_ablate.sh; never in a shipped build — the results are wrong, only durations mean anything):
+      // 1 = stream only (one VALU fma per product slot), 2 = masks kept, products on the VALU slot, 3 = matrix products
+      // kept, masks dropped
+#if defined(DS_ABL) && (DS_ABL == 1 || DS_ABL == 3)
+#pragma unroll
+      for (int t = 0; t < VW; ++t) ev[t] = 1.f + bf.us[jj] * 0.f;
+#else
 #pragma unroll
       for (int t = 0; t < VW; ++t) ev[t] = ANYM ? ds_mask(bf.us[jj], vd[t]) : 1.f;
+#endif
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int t = 0; t < VW; ++t) {
           const float a = ds_masked<NC, M0>(c) ? bf.w[jj][t] * ev[t] : bf.w[jj][t];      // A[target VW q + t][k = sub]
+#if defined(DS_ABL) && (DS_ABL == 1 || DS_ABL == 2)
+          acc[c][t][0] = fmaf(a, bf.bop[jj][c], acc[c][t][0]);
+#else
           acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf.bop[jj][c], acc[c][t], 0, 0, 0);
+#endif
         }
+#ifdef DS_PROBE_ON
+      if (row + 4 * jj == sb) DS_PROBE(1);            // the wave's first step has its data and its products are issued
+      if (row + 4 * jj == sb + 28) DS_PROBE(2);       // ... its first 8 steps
+#endif
     }
   };
   // epilogue operands of this thread (its (copy, target, feature) slots o = tid + 512 k and its row of W_next): requested
@@ -508,6 +526,23 @@ k_ds_agg(int R, int64_t GR, const float* __restrict__ ew, const float* __restric
   //   node operands staged in LDS per workgroup (64 KB + barrier) + all loads up front            17.3 / 21.4
   //   node operands staged in LDS per WAVE (8 KB, no barrier) + all loads up front                17.0
   // The single-pass instance (NC = 1: 4 instead of 8 matrix instructions per step) runs in 9.1 us.
+  // Round 5, where the 13.0 us of the launch inside the captured configs[4] step go (tools/dense_ablate.sh: kernel durations
+  // with parts compiled out; tools/dense_probe.py step: stamps of the first workgroups, shader clock 2.37 GHz in the step):
+  //   products compiled out (DS_ABL=1)   8.97 us   workgroup: first data +2.6 us, all 16 steps' data by +3.4, done +4.4
+  //   masks kept, no products (2)        8.95 us   (the masks cost nothing)
+  //   products kept, no masks (3)       13.67 us
+  //   as shipped                        12.99 us   workgroup: first data +2.6, walk done +7.7, done +8.6
+  // i.e. ~4.5 us of every one of these launches lie outside its workgroups (dispatch of 256 x 512 threads with 72 KB of
+  // LDS, end-of-kernel write-back: the in-step floor of any launch), the data of a workgroup arrives as ONE burst 2.6 us
+  // after its waves start (1.5 us stand-alone, warm or evicted alike), and the 256 matrix instructions of a SIMD
+  // (8192 cycles = 3.46 us at 2.37 GHz) then run in 4.2-5.1 us with nothing left to overlap them with: latency + products +
+  // epilogue in series.  Tried on that picture, all within +-0.1 us of 13.0 and not kept: every load pinned in front of the
+  // first product (__builtin_amdgcn_sched_barrier; the scheduler otherwise sinks half of them in between the products),
+  // u as ONE load per wave + lane permutes (48 instead of 64 loads in flight), the 64 masks of a wave computed during the
+  // data wait (219 registers).  Worse: loads issued in 2 / 4 groups with a fence-less workgroup barrier between the groups
+  // so that the two waves of a SIMD get their data alternately (13.6 / 14.0).  With exact-fp32 products the launch is
+  // bounded near 4.5 + 2.6 + 3.5 + 0.9 = 11.5 us (0.46 of HBM by its bytes); the 10.6 us that 0.5 asks for needs fewer
+  // matrix cycles, i.e. split-bf16 products on a transposed operand (LDS transpose + 2.5 conversion instructions per edge).
   if (R == 512)
     ds_walk<PIPE, 4, DsAggBuf<8, NC, VW>, DsAggBuf<1, NC, VW>, decltype(load), decltype(compute), decltype(load),
             decltype(compute), 8>(sb, sb + rows, load, compute, load, compute);
@@ -682,6 +717,10 @@ k_ds_aggT(int R, int64_t GR, const float* __restrict__ ew, const float* __restri
     if (ANYM)
       for (int i = tid; i < R; i += 512) lv[i] = v[nb + i];
     __syncthreads();
+    // [Round 5: every adjacency load of the walk issued BEFORE the staging and pinned there (sched_barrier) — 16 float4 per
+    // lane in flight instead of the two the scheduler leaves ahead of each s_waitcnt — ran 21.2 us against 12.4 in the
+    // stress step (17.9 without the pin): a wave-load here is 16 rows x 64 bytes, HALF of each 128-byte line, and steps jj,
+    // jj + 1 share the lines; issued far apart, the second half has left the 32 KB L1 before it is asked for.]
     auto run = [&](auto nsc) {
       constexpr int NS = decltype(nsc)::value;
       float4 w4[NS];
