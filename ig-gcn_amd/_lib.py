@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libigcn.so")
 
-ABI_VERSION = 422        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
+ABI_VERSION = 423        # include/igcn.h IGCN_ABI_VERSION this table was written against (tests/test_abi.py compares)
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
@@ -73,6 +73,7 @@ SIGNATURES = {
     "igcn_snps_mask_bwd": (I, [I, I, P, P, P, P, P, P]),
     "igcn_head_inputs_fwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "igcn_head_inputs_bwd": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
+    "igcn_outproj_head_inputs_fwd": (I, [L, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
     "igcn_head_inputs_bwd_blocks": (I, [L, I, I]),
     "igcn_head_inputs_bwd_relu": (I, [L, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P]),
     "igcn_concat_cols": (I, [L, I, I, P, P, P]),

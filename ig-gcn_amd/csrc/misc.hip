@@ -613,6 +613,109 @@ k_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, const float* __restri
   if (feat) *reinterpret_cast<float2*>(feat + r * (W + L + P) + c) = v;
 }
 
+// The same outputs with the layer in front computed on the way: cross[r, node * D + f] = relu(o[r, node, :] . Wp[f, :] + bp[f])
+// (relu(out_proj(attention output)), kernel/sgcn_img_snp.py:241-242; a 32 x 32 product per graph node — as a GEMM launch of
+// its own 6.4 us and 5.9 MB written and read back).  Workgroup (chunk of 512 columns, HOF_ROWS rows): the chunk's
+// 512 / D nodes of o and Wp^T are staged in LDS; thread t owns columns chunk * 512 + 2t, + 1 as in k_head_inputs_fwd.
+// `cross` is still written: the backward's ReLU mask reads it (igcn_head_inputs_bwd_relu).  D a power of two, 2 <= D <= 64.
+// Both operands come from LDS, four k at a time: the thread's two columns of Wp^T for those k (4 x 8 bytes) serve all
+// HOF_ROWS rows, and a row's o values are one 16-byte read — 8 LDS instructions per 32 FMAs.  [First form, one k and one row
+// at a time (a 4-byte and an 8-byte read per two FMAs): 13.4 us, LDS-issue-bound, against 6.4 + 8.5 for the two launches it
+// replaces.  Wp in registers (2 x 32 floats per thread): the compiler reloads them per row, 15.5-17 us.]
+#define HOF_ROWS 4
+__global__ void __launch_bounds__(256)
+k_outproj_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, int D, const float* __restrict__ o,
+                          const float* __restrict__ Wp, const float* __restrict__ bp, const float* __restrict__ img,
+                          const float* __restrict__ latent, const float* __restrict__ x, const float* __restrict__ prob,
+                          float* __restrict__ cross, float* __restrict__ out_z, float* __restrict__ out_lin,
+                          float* __restrict__ feat, int chunks) {
+  __shared__ __attribute__((aligned(16))) float wt[64 * 64];                 // Wp^T [k][f]
+  __shared__ __attribute__((aligned(16))) float os[HOF_ROWS][512 + 256];     // o of the chunk's nodes per row: [node][k], node stride D + 4
+  const int chunk = blockIdx.x % chunks, rp = blockIdx.x / chunks;
+  const int tid = threadIdx.x;
+  const int c0 = chunk * 512, c = c0 + 2 * tid;
+  const int f = c & (D - 1), nl = (2 * tid) / D;         // feature pair (f, f + 1) of local node nl
+  const int ost = D >= 8 ? D + 4 : D + 1;                 // <= 768 floats per row for every D; 16-byte aligned rows for D >= 8
+  // every global operand of the thread's HOF_ROWS rows is requested before the first one is used
+  float2 ov2[HOF_ROWS], in2[HOF_ROWS];
+  float2 bias = make_float2(0.f, 0.f), pv = make_float2(0.f, 0.f);
+  if (c < W) bias = *reinterpret_cast<const float2*>(bp + f);
+  else if (c >= W + L && c < W + L + P) pv = *reinterpret_cast<const float2*>(prob + (c - W - L));
+#pragma unroll
+  for (int k = 0; k < HOF_ROWS; ++k) {
+    const int64_t r0 = (int64_t)rp * HOF_ROWS + k, r = r0 < R ? r0 : R - 1;
+    ov2[k] = in2[k] = make_float2(0.f, 0.f);
+    if (c < W) {
+      ov2[k] = *reinterpret_cast<const float2*>(o + r * W + c);
+      in2[k] = *reinterpret_cast<const float2*>(img + r * W + c);
+    } else if (c < W + L) {
+      in2[k] = *reinterpret_cast<const float2*>(latent + r * L + (c - W));
+    } else if (c < W + L + P) {
+      in2[k] = *reinterpret_cast<const float2*>(x + (r % bsz) * P + (c - W - L));
+    }
+  }
+  if (c0 < W) {
+    for (int i = tid; i < D * D; i += 256) wt[(i % D) * D + i / D] = Wp[i];            // Wp [f][k] -> wt[k][f]
+#pragma unroll
+    for (int k = 0; k < HOF_ROWS; ++k)
+      if (c < W) {
+        const int at = nl * ost + f;
+        os[k][at] = ov2[k].x;
+        os[k][at + 1] = ov2[k].y;
+      }
+    __syncthreads();
+  }
+  if (c >= W + L + P) return;
+  float2 a[HOF_ROWS];
+#pragma unroll
+  for (int k = 0; k < HOF_ROWS; ++k) a[k] = bias;
+  if (c < W) {
+    if (D >= 8) {
+      for (int kk = 0; kk < D; kk += 4) {
+        float2 w2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w2[i] = *reinterpret_cast<const float2*>(&wt[(kk + i) * D + f]);
+#pragma unroll
+        for (int k = 0; k < HOF_ROWS; ++k) {
+          const float4 ov = *reinterpret_cast<const float4*>(&os[k][nl * ost + kk]);
+          a[k].x = fmaf(ov.x, w2[0].x, a[k].x);     a[k].y = fmaf(ov.x, w2[0].y, a[k].y);
+          a[k].x = fmaf(ov.y, w2[1].x, a[k].x);     a[k].y = fmaf(ov.y, w2[1].y, a[k].y);
+          a[k].x = fmaf(ov.z, w2[2].x, a[k].x);     a[k].y = fmaf(ov.z, w2[2].y, a[k].y);
+          a[k].x = fmaf(ov.w, w2[3].x, a[k].x);     a[k].y = fmaf(ov.w, w2[3].y, a[k].y);
+        }
+      }
+    } else {
+      for (int kk = 0; kk < D; ++kk) {
+        const float2 w2 = *reinterpret_cast<const float2*>(&wt[kk * D + f]);
+#pragma unroll
+        for (int k = 0; k < HOF_ROWS; ++k) {
+          const float ov = os[k][nl * ost + kk];
+          a[k].x = fmaf(ov, w2.x, a[k].x);
+          a[k].y = fmaf(ov, w2.y, a[k].y);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < HOF_ROWS; ++k) {
+    const int64_t r = (int64_t)rp * HOF_ROWS + k;
+    if (r >= R) break;
+    float2 v;
+    if (c < W) {
+      const float2 y = make_float2(fmaxf(a[k].x, 0.f), fmaxf(a[k].y, 0.f));
+      *reinterpret_cast<float2*>(cross + r * W + c) = y;
+      v = make_float2((in2[k].x + y.x) * 0.5f, (in2[k].y + y.y) * 0.5f);
+      *reinterpret_cast<float2*>(out_z + r * W + c) = v;
+    } else if (c < W + L) {
+      v = in2[k];
+    } else {
+      v = make_float2(in2[k].x * pv.x, in2[k].y * pv.y);
+    }
+    if (c < W + L) *reinterpret_cast<float2*>(out_lin + r * (W + L) + c) = v;
+    if (feat) *reinterpret_cast<float2*>(feat + r * (W + L + P) + c) = v;
+  }
+}
+
 // d_mid [R, W] = (d_out_z + d_out_lin[:, :W] + d_feat[:, :W]) / 2  (the gradient of img AND of cross);
 // d_latent [R, L] = d_out_lin[:, W:] + d_feat[:, W:W+L].  Any of the three incoming gradients may be NULL.
 __global__ void __launch_bounds__(256)
@@ -665,6 +768,62 @@ __device__ __forceinline__ void head_inputs_bwd_prob_body(int j, int64_t R, int 
   if (threadIdx.x == 0) dprob[j] = acc;
 }
 
+// The same sums by workgroups of HIP_COLS = 16 COLUMNS x all samples (thread = (sample group tid / 8, column pair tid % 8)):
+// a row's 16 columns are half a 128-byte line shared by 8 lanes, and 256 samples are ONE trip of eight per thread.  [One workgroup per column touches a different line per lane — 270
+// columns were ~35 MB of line traffic for 0.8 MB of data and cost the launch they rode in 3.7 us.]  red: 512 floats.
+#define HIP_COLS 16
+__device__ __forceinline__ void head_inputs_bwd_probc_body(int blk, int64_t R, int bsz, int W, int L, int P,
+                                                            const float* __restrict__ d_feat,
+                                                            const float* __restrict__ x, const float* __restrict__ prob,
+                                                            float* __restrict__ dx, float* __restrict__ dprob,
+                                                            float* red) {
+  const int passes = (int)(R / bsz), sg = threadIdx.x >> 3, jl = threadIdx.x & 7;
+  const int j = HIP_COLS * blk + 2 * jl;
+  const bool live = j < P;
+  float2 acc = make_float2(0.f, 0.f);
+  if (live) {
+    const float2 pj = *reinterpret_cast<const float2*>(prob + j);
+    // eight samples per trip, every load of the trip requested before the first sum (few workgroups carry this part: a
+    // dependent round trip per sample made them the tail of the launch)
+    for (int b0 = sg; b0 < bsz; b0 += 256) {
+      float2 t0[8], t1[8], xv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int b = b0 + 32 * i < bsz ? b0 + 32 * i : bsz - 1;
+        t0[i] = t1[i] = make_float2(0.f, 0.f);
+        if (d_feat) {
+          t0[i] = *reinterpret_cast<const float2*>(d_feat + (int64_t)b * (W + L + P) + W + L + j);
+          if (passes > 1) t1[i] = *reinterpret_cast<const float2*>(d_feat + ((int64_t)bsz + b) * (W + L + P) + W + L + j);
+        }
+        xv[i] = *reinterpret_cast<const float2*>(x + (int64_t)b * P + j);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int b = b0 + 32 * i;
+        if (b >= bsz) break;
+        float2 g = make_float2(t0[i].x + t1[i].x, t0[i].y + t1[i].y);
+        if (d_feat)
+          for (int k = 2; k < passes; ++k) {
+            const float2 t = *reinterpret_cast<const float2*>(d_feat + ((int64_t)k * bsz + b) * (W + L + P) + W + L + j);
+            g.x += t.x; g.y += t.y;
+          }
+        *reinterpret_cast<float2*>(dx + (int64_t)b * P + j) = make_float2(g.x * pj.x, g.y * pj.y);
+        acc.x = fmaf(g.x, xv[i].x, acc.x);
+        acc.y = fmaf(g.y, xv[i].y, acc.y);
+      }
+    }
+  }
+  red[2 * threadIdx.x] = acc.x;
+  red[2 * threadIdx.x + 1] = acc.y;
+  __syncthreads();
+  if (threadIdx.x < HIP_COLS && HIP_COLS * blk + (int)threadIdx.x < P) {
+    float a = 0.f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) a += red[2 * (8 * g + (threadIdx.x >> 1)) + (threadIdx.x & 1)];
+    dprob[HIP_COLS * blk + threadIdx.x] = a;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_head_inputs_bwd_prob(int64_t R, int bsz, int W, int L, int P, const float* __restrict__ d_feat,
                        const float* __restrict__ x, const float* __restrict__ prob, float* __restrict__ dx,
@@ -679,46 +838,52 @@ k_head_inputs_bwd_prob(int64_t R, int bsz, int W, int L, int P, const float* __r
 // gradient, db_part [blocks][D] (column c of a row belongs to output feature c % D; D a power of two, 2 <= D <= 64), for
 // the deferred reduction.  Workgroup (chunk, row pair): thread t owns columns chunk * 512 + 2t, 2t + 1 of HIB_ROWS rows,
 // so its feature pair is (2t) % D whatever the chunk and the bias sums are lane shuffles (strides D/2 .. 32) and one
-// 4-wave LDS step — a fixed order.  Workgroups past the n_main of that grid are the regression-feature columns
-// (head_inputs_bwd_prob_body: one column each — a launch of its own, 5.9 us, otherwise).
+// 4-wave LDS step — a fixed order.  The first n_prob workgroups of the grid are the regression-feature columns
+// (head_inputs_bwd_probc_body, HIP_COLS columns each — a launch of its own, 5.9 us, otherwise).
 #define HIB_ROWS 2
 __global__ void __launch_bounds__(256)
 k_head_inputs_bwd_relu(int64_t R, int W, int L, int P, const float* __restrict__ d_out_z,
                        const float* __restrict__ d_out_lin, const float* __restrict__ d_feat,
                        float* __restrict__ d_mid, float* __restrict__ d_latent, const float* __restrict__ cross,
-                       float* __restrict__ d_cross, float* __restrict__ db_part, int D, int chunks, int n_main, int bsz,
+                       float* __restrict__ d_cross, float* __restrict__ db_part, int D, int chunks, int n_prob, int bsz,
                        const float* __restrict__ x, const float* __restrict__ prob, float* __restrict__ dx,
                        float* __restrict__ dprob) {
-  __shared__ float wsum[4][64];
-  if ((int)blockIdx.x >= n_main) {
-    head_inputs_bwd_prob_body(blockIdx.x - n_main, R, bsz, W, L, P, d_feat, x, prob, dx, dprob, &wsum[0][0]);
+  __shared__ float wsum[8][64];
+  // the n_prob workgroups of the regression-feature columns (HIP_COLS columns each) come first in the grid
+  if ((int)blockIdx.x < n_prob) {
+    head_inputs_bwd_probc_body(blockIdx.x, R, bsz, W, L, P, d_feat, x, prob, dx, dprob, &wsum[0][0]);
     return;
   }
-  const int chunk = blockIdx.x % chunks, rp = blockIdx.x / chunks;
+  const int blk = blockIdx.x - n_prob;
+  const int chunk = blk % chunks, rp = blk / chunks;
   const int c = chunk * 512 + 2 * threadIdx.x;
   float2 m = make_float2(0.f, 0.f);                     // this thread's masked pair summed over its rows
   if (c < W + L) {
+    // the loads of every row first, then the sums and stores (a row at a time, a row's loads waited behind the stores of the
+    // row before)
+    float2 l1[HIB_ROWS], l2[HIB_ROWS], l3[HIB_ROWS], y[HIB_ROWS];
+#pragma unroll
+    for (int k = 0; k < HIB_ROWS; ++k) {
+      const int64_t r0 = (int64_t)rp * HIB_ROWS + k, r = r0 < R ? r0 : R - 1;
+      l1[k] = l2[k] = l3[k] = y[k] = make_float2(0.f, 0.f);
+      if (d_out_lin) l1[k] = *reinterpret_cast<const float2*>(d_out_lin + r * (W + L) + c);
+      if (d_feat) l2[k] = *reinterpret_cast<const float2*>(d_feat + r * (W + L + P) + c);
+      if (c < W) {
+        if (d_out_z) l3[k] = *reinterpret_cast<const float2*>(d_out_z + r * W + c);
+        y[k] = *reinterpret_cast<const float2*>(cross + r * W + c);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < HIB_ROWS; ++k) {
       const int64_t r = (int64_t)rp * HIB_ROWS + k;
       if (r >= R) break;
-      float2 t = make_float2(0.f, 0.f);
-      if (d_out_lin) {
-        const float2 a = *reinterpret_cast<const float2*>(d_out_lin + r * (W + L) + c);
-        t.x += a.x; t.y += a.y;
-      }
-      if (d_feat) {
-        const float2 a = *reinterpret_cast<const float2*>(d_feat + r * (W + L + P) + c);
-        t.x += a.x; t.y += a.y;
-      }
+      float2 t = make_float2(0.f, 0.f);                  // (the order of the additions is the plain kernel's)
+      t.x += l1[k].x; t.y += l1[k].y;
+      t.x += l2[k].x; t.y += l2[k].y;
       if (c < W) {
-        if (d_out_z) {
-          const float2 a = *reinterpret_cast<const float2*>(d_out_z + r * W + c);
-          t.x += a.x; t.y += a.y;
-        }
-        const float2 y = *reinterpret_cast<const float2*>(cross + r * W + c);
+        t.x += l3[k].x; t.y += l3[k].y;
         const float2 h = make_float2(t.x * 0.5f, t.y * 0.5f);
-        const float2 g = make_float2(y.x > 0.f ? h.x : 0.f, y.y > 0.f ? h.y : 0.f);
+        const float2 g = make_float2(y[k].x > 0.f ? h.x : 0.f, y[k].y > 0.f ? h.y : 0.f);
         *reinterpret_cast<float2*>(d_mid + r * W + c) = h;
         *reinterpret_cast<float2*>(d_cross + r * W + c) = g;
         m.x += g.x; m.y += g.y;
@@ -735,7 +900,7 @@ k_head_inputs_bwd_relu(int64_t R, int W, int L, int P, const float* __restrict__
   if (lane < D / 2) { wsum[wave][2 * lane] = m.x; wsum[wave][2 * lane + 1] = m.y; }
   __syncthreads();
   if ((int)threadIdx.x < D)
-    db_part[(int64_t)blockIdx.x * D + threadIdx.x] =
+    db_part[(int64_t)blk * D + threadIdx.x] =
         (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
 }
 
@@ -749,6 +914,25 @@ extern "C" int igcn_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, con
   hipLaunchKernelGGL(k_head_inputs_fwd, dim3((unsigned)igcn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, R,
                      bsz, W, L, P, img, cross, latent, x, prob, out_z, out_lin, feat);
   IGCN_CHECK_LAUNCH("head_inputs_fwd");
+  return IGCN_OK;
+}
+
+// relu(out_proj(o)) and the heads' inputs in one launch (k_outproj_head_inputs_fwd): o [R, W] = [R, W / D nodes, D], Wp [D, D],
+// bp [D]; cross [R, W] is written too (the backward's ReLU mask).  D a power of two in [2, 64] dividing 512 and W.
+extern "C" int igcn_outproj_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, int D, const float* o, const float* Wp,
+                                            const float* bp, const float* img, const float* latent, const float* x,
+                                            const float* prob, float* cross, float* out_z, float* out_lin, float* feat,
+                                            void* stream) {
+  IGCN_REQUIRE(R > 0 && bsz > 0 && R % bsz == 0 && W > 0 && L > 0 && P >= 0 && W % 2 == 0 && L % 2 == 0 && P % 2 == 0,
+               "outproj_head_inputs_fwd: even widths, R divisible by bsz");
+  IGCN_REQUIRE((P == 0) == (feat == nullptr), "outproj_head_inputs_fwd: feat goes with P > 0");
+  IGCN_REQUIRE(D >= 2 && D <= 64 && (D & (D - 1)) == 0 && W % D == 0 && o && Wp && bp && cross,
+               "outproj_head_inputs_fwd: D a power of two in [2, 64] dividing W");
+  const int chunks = (int)igcn_cdiv(W + L + P, 512);
+  const int64_t blocks = (int64_t)chunks * igcn_cdiv(R, HOF_ROWS);
+hipLaunchKernelGGL(k_outproj_head_inputs_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, R, bsz, W, L, P,
+                     D, o, Wp, bp, img, latent, x, prob, cross, out_z, out_lin, feat, chunks);
+  IGCN_CHECK_LAUNCH("outproj_head_inputs_fwd");
   return IGCN_OK;
 }
 
@@ -784,8 +968,9 @@ extern "C" int igcn_head_inputs_bwd_relu(int64_t R, int bsz, int W, int L, int P
   const int64_t blocks = igcn_head_inputs_bwd_blocks(R, W, L);
   const int chunks = (int)igcn_cdiv(W + L, 512);
   const bool with_prob = P > 0 && dx && dprob;
-  hipLaunchKernelGGL(k_head_inputs_bwd_relu, dim3((unsigned)(blocks + (with_prob ? P : 0))), dim3(256), 0, st, R, W, L, P,
-                     d_out_z, d_out_lin, d_feat, d_mid, d_latent, cross, d_cross, db_part, D, chunks, (int)blocks, bsz, x,
+  const int n_prob = with_prob ? (int)igcn_cdiv(P, HIP_COLS) : 0;
+  hipLaunchKernelGGL(k_head_inputs_bwd_relu, dim3((unsigned)(blocks + n_prob)), dim3(256), 0, st, R, W, L, P,
+                     d_out_z, d_out_lin, d_feat, d_mid, d_latent, cross, d_cross, db_part, D, chunks, n_prob, bsz, x,
                      prob, dx, dprob);
   IGCN_CHECK_LAUNCH("head_inputs_bwd_relu");
   return igcn_launch_reduce_rows_final(db_part, blocks, D, D, db, st);

@@ -1366,6 +1366,71 @@ class HeadInputs(torch.autograd.Function):
         return d_mid, d_mid, d_latent, dx, dprob, None, None
 
 
+class OutProjHeadInputs(torch.autograd.Function):
+    """HeadInputs with the layer in front computed on the way (igcn_outproj_head_inputs_fwd): cross = relu(out_proj(o)) per
+    graph node (kernel/sgcn_img_snp.py:241-242), then (out_z, out_lin, feat) of :284-297 — one launch instead of a GEMM and
+    an elementwise pass.  Backward: igcn_head_inputs_bwd_relu (ReLU mask, bias gradient, the sums), then the layer's two
+    products as one grouped launch."""
+
+    @staticmethod
+    def forward(ctx, o, weight, bias, img, latent, x, prob, bsz, bf16=False):
+        o, weight, bias = _f32(o), _f32(weight), _f32(bias)
+        img, latent = _f32(img), _f32(latent)
+        r, w = img.shape
+        l, d = latent.shape[1], weight.shape[0]
+        p = 0
+        if prob is not None:
+            x, prob = _f32(x), _f32(prob)
+            p = prob.numel()
+        dev = img.device
+        cross = torch.empty(r, w, dtype=torch.float32, device=dev)
+        out_z = torch.empty(r, w, dtype=torch.float32, device=dev)
+        out_lin = torch.empty(r, w + l, dtype=torch.float32, device=dev)
+        feat = torch.empty(r, w + l + p, dtype=torch.float32, device=dev) if p else None
+        call("igcn_outproj_head_inputs_fwd", r, bsz, w, l, p, d, ptr(o), ptr(weight), ptr(bias), ptr(img), ptr(latent),
+             ptr(x) if p else None, ptr(prob) if p else None, ptr(cross), ptr(out_z), ptr(out_lin), ptr(feat), stream_ptr())
+        ctx.save_for_backward(x if p else None, prob if p else None, cross, o, weight)
+        ctx.dims = (r, bsz, w, l, p, d)
+        ctx.x_shape = x.shape if p else None
+        ctx.o_shape = o.shape
+        ctx.bf16 = bf16
+        ctx.w_final, ctx.b_final = _leaves(weight), _leaves(bias)
+        ctx.set_materialize_grads(False)
+        # cross is handed out as well, for inspection only (tests read the layer's ReLU decisions off it)
+        if p:
+            ctx.mark_non_differentiable(cross)
+            return out_z, out_lin, feat, cross
+        none = out_lin.new_empty(0)
+        ctx.mark_non_differentiable(none, cross)
+        return out_z, out_lin, none, cross
+
+    @staticmethod
+    def backward(ctx, d_out_z, d_out_lin, d_feat, _d_cross):
+        x, prob, cross, o, weight = ctx.saved_tensors
+        r, bsz, w, l, p, d = ctx.dims
+        dev = cross.device
+        gz = _f32(d_out_z) if d_out_z is not None else None
+        gl = _f32(d_out_lin) if d_out_lin is not None else None
+        gf = _f32(d_feat) if (d_feat is not None and p) else None
+        d_mid = torch.empty(r, w, dtype=torch.float32, device=dev)
+        d_latent = torch.empty(r, l, dtype=torch.float32, device=dev)
+        dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if p else None
+        dprob = torch.empty(prob.shape, dtype=torch.float32, device=dev) if p else None
+        d_cross = torch.empty(r, w, dtype=torch.float32, device=dev)
+        db = torch.empty(d, dtype=torch.float32, device=dev)
+        part = _keep(torch.empty(int(_lib.load().igcn_head_inputs_bwd_blocks(r, w, l)), d, dtype=torch.float32, device=dev))
+        with _immediate(ctx.b_final):
+            call("igcn_head_inputs_bwd_relu", r, bsz, w, l, p, ptr(gz), ptr(gl), ptr(gf), ptr(x), ptr(prob), ptr(d_mid),
+                 ptr(d_latent), ptr(dx), ptr(dprob), ptr(cross), ptr(d_cross), d, ptr(part), ptr(db), stream_ptr())
+        dz, o2 = d_cross.view(-1, d), o.reshape(-1, d)
+        do, dw = gemm_group([("nn", dz, weight, None, None, False), ("tn", dz, o2, None, None, ctx.w_final)], bf16=ctx.bf16)
+        return do.view(ctx.o_shape), dw, db, d_mid, d_latent, dx, dprob, None, None
+
+
+def outproj_head_inputs_supported(d, width):
+    return relu_owed_supported(d, width) and 512 % d == 0 and os.environ.get("IGCN_NO_OUTPROJ_FUSED", "0") != "1"
+
+
 def head_inputs_supported(img, cross, latent, x, prob):
     ts = [img, cross, latent] + ([x, prob] if prob is not None else [])
     if not all(t.is_cuda and t.dtype == torch.float32 for t in ts):

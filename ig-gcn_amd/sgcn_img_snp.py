@@ -251,7 +251,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
     def _drop(self, x, p):
         return F.dropout(x, p, True) if (self.training and self._dropout_enabled) else x
 
-    def _cross_attention(self, query, memory, relu_owed=False):
+    def _cross_attention(self, query, memory, relu_owed=False, defer_out_proj=False):
         """relu(nn.MultiheadAttention(D, 2, batch_first=True)(query, memory, memory)[0]) (:240-241) with the
         parameters of ``self.multihead_attn``: MFMA-GEMM projections (key and value as one GEMM) around the attention
         core igcn_attn_core_*, which works on the projection outputs in place (head_dim 16: matrix cores); shapes the
@@ -274,6 +274,8 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
             kvh = kv.view(b, lk, 2, h, hd)
             att = torch.softmax((qh @ kvh[:, :, 0].permute(0, 2, 3, 1)) * (1.0 / math.sqrt(hd)), dim=-1)
             o = (att @ kvh[:, :, 1].transpose(1, 2)).transpose(1, 2).reshape(b, lq, d)
+        if defer_out_proj:
+            return o                     # relu(out_proj(.)) is computed by the head-input launch (ops.OutProjHeadInputs)
         if relu_owed:
             # the head-input kernel (the one consumer of this output) takes the ReLU backward and the bias gradient
             return ops.LinearReluOwed.apply(o.reshape(-1, d), mha.out_proj.weight, mha.out_proj.bias, bf).view(b, lq, d)
@@ -446,7 +448,7 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         latent, x_hat, _, atten_out = self.go_network(snps_in, temperature, device, groups=g, extra_dropout=head_drop)
         keep1, keep2 = self.go_network.extra_masks if head_drop and self.go_network.extra_masks[0] is not None \
             else (None, None)
-        owed = False
+        owed = fuse_proj = False
         use_prob = self.isuseProb4Regr and not self.isImageOnly and not self.isSNPsOnly
         x_flat, prob_flat = (x_h.view(bsz, -1), prob_h.view(-1)) if use_prob else (None, None)
         if self.isCrossAtten:
@@ -457,7 +459,8 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                     and ops.relu_owed_supported(self.multihead_attn.embed_dim, img_out.shape[1])
                     and img_out.shape[1] == batch_x.shape[1] * self.multihead_attn.embed_dim
                     and ops.head_inputs_supported(img_out, img_out, latent, x_flat, prob_flat))
-            out_cross = self._cross_attention(batch_x, atten_out, relu_owed=owed)
+            fuse_proj = owed and ops.outproj_head_inputs_supported(self.multihead_attn.embed_dim, img_out.shape[1])
+            out_cross = self._cross_attention(batch_x, atten_out, relu_owed=owed, defer_out_proj=fuse_proj)
             if self.graph_pool:                                       # :246-252
                 out_cross = ops.GraphPool.apply(out_cross.reshape(gb * self.rois, -1), self.rois)
             else:
@@ -475,8 +478,13 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         else:
             if ops.head_inputs_supported(img_out, out_cross, latent, x_flat, prob_flat):
                 fused_head = True                                         # :284-297 in one launch
-                out_z, out_lin, feat = ops.HeadInputs.apply(img_out, out_cross, latent, x_flat, prob_flat, bsz,
-                                                            self.multihead_attn.out_proj.bias if owed else None)
+                if self.isCrossAtten and fuse_proj:                  # out_cross is still the attention output here
+                    op = self.multihead_attn.out_proj
+                    out_z, out_lin, feat, _ = ops.OutProjHeadInputs.apply(out_cross, op.weight, op.bias, img_out, latent,
+                                                                          x_flat, prob_flat, bsz, bf)
+                else:
+                    out_z, out_lin, feat = ops.HeadInputs.apply(img_out, out_cross, latent, x_flat, prob_flat, bsz,
+                                                                self.multihead_attn.out_proj.bias if owed else None)
                 if not use_prob:
                     feat = out_lin
             else:

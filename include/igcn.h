@@ -31,7 +31,7 @@ extern "C" {
 /* ABI revision: bumped whenever a prototype below changes (argument added, removed or re-ordered).  igcn_version()
  * returns the revision the library was built from; a binding written against a different one must refuse to call
  * (igcn_amd/_lib.py does). */
-#define IGCN_ABI_VERSION 422
+#define IGCN_ABI_VERSION 423
 int igcn_version(void);
 const char* igcn_last_error(void);
 /* A/B switches, set ONCE by the binding when it loads the library (from the IGCN_* environment variables): bit 0 no tiled
@@ -391,6 +391,13 @@ int igcn_head_inputs_bwd(int64_t R, int bsz, int W, int L, int P, const float* d
  * of that layer's pre-activation (d_mid where cross > 0), db [D] = its column sums by feature, through the partial rows
  * db_part [igcn_head_inputs_bwd_blocks(R, W, L)][D] and a final reduction that is deferred while the stream defers.
  * D a power of two, 2 <= D <= 64, W % D == 0. */
+/* igcn_head_inputs_fwd with the layer in front computed on the way: cross [R, W] = relu(o Wp^T + bp) per graph node
+ * (o [R, W] = [R, W / D nodes, D features], Wp [D, D], bp [D]: relu(out_proj(.)), kernel/sgcn_img_snp.py:241-242), written
+ * as well (the backward's ReLU mask, igcn_head_inputs_bwd_relu).  fp32 FMAs in k order.  D a power of two in [2, 64]
+ * dividing W. */
+int igcn_outproj_head_inputs_fwd(int64_t R, int bsz, int W, int L, int P, int D, const float* o, const float* Wp,
+                                 const float* bp, const float* img, const float* latent, const float* x, const float* prob,
+                                 float* cross, float* out_z, float* out_lin, float* feat, void* stream);
 int igcn_head_inputs_bwd_blocks(int64_t R, int W, int L);
 int igcn_head_inputs_bwd_relu(int64_t R, int bsz, int W, int L, int P, const float* d_out_z, const float* d_out_lin,
                               const float* d_feat, const float* x, const float* prob, float* d_mid, float* d_latent,

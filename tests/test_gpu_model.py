@@ -227,7 +227,7 @@ def test_train_step_vs_reference_golden(golden, name, batched):
                                               (16, (1800, 800, 300, 99, 1), True)])
 def test_full_model_vs_oracle_larger(bsz, pool, explain):
     """R=90, L=2, h=16 (the benchmark model) against the CPU oracle, eval mode, 1e-4."""
-    from igcn_amd import synth
+    from igcn_amd import ops, synth
     from igcn_amd.data import Batch
     from igcn_amd.sgcn_img_snp import SGCN_GCN_IMGSNP
     from oracle import go_network as OG, sgcn_img_snp as OS
@@ -250,10 +250,21 @@ def test_full_model_vs_oracle_larger(bsz, pool, explain):
 
     def spy(query, memory, **kw):
         out = real_ca(query, memory, **kw)
-        seen.append(out.detach().cpu() > 0)
+        if not kw.get("defer_out_proj"):
+            seen.append(out.detach().cpu() > 0)
         return out
     model._cross_attention = spy
-    outs = model(data, None, "cuda", isExplain=explain)
+    real_fused = ops.OutProjHeadInputs.apply        # relu(out_proj) inside the head-input launch: its 4th output is the layer's
+
+    def spy_fused(*a):
+        out = real_fused(*a)
+        seen.append(out[3].detach().cpu().view(a[0].shape[0], -1, a[1].shape[0]) > 0)
+        return out
+    ops.OutProjHeadInputs.apply = spy_fused
+    try:
+        outs = model(data, None, "cuda", isExplain=explain)
+    finally:
+        ops.OutProjHeadInputs.apply = real_fused
     cot = _probe(outs, 9)
     sum((o * c.cuda()).sum() for o, c in zip(outs, cot)).backward()
     # oracle, fp64
@@ -837,7 +848,7 @@ def test_deferred_reductions_give_the_same_gradients(golden):
                                     "IGCN_NO_MASK_REG_FUSED", "IGCN_NO_GRAD_FAN", "IGCN_NO_LN_FUSED",
                                     "IGCN_NO_LOSS_HEAD_FUSED", "IGCN_SPARSE_MAPS", "IGCN_NO_LINEAR_BN_FUSED",
                                     "IGCN_NO_FRONT_FUSED", "IGCN_NO_HEAD_LOSS_FUSED",
-                                    "IGCN_NO_GRAM_LOSS_PAIRED"])
+                                    "IGCN_NO_GRAM_LOSS_PAIRED", "IGCN_NO_RELU_OWED", "IGCN_NO_OUTPROJ_FUSED"])
 def test_every_host_side_switch_gives_the_default_train_step(golden, monkeypatch, switch):
     """every A/B switch that the Python layer reads selects a second code path — each of them must give
     the default path's train step (loss, every gradient) on the ``full_b32`` model, so a losing variant cannot rot

@@ -283,6 +283,24 @@ def test_relu_owed_layer_and_head_inputs(ops, bsz, g, rois, d, l, use_prob):
             assert got is None or float(got.abs().max()) == 0.0, nm
         else:
             assert_matches(got, want.numpy(), TOL, nm)
+    # ... and with the layer itself inside the head-input launch (ops.OutProjHeadInputs: igcn_outproj_head_inputs_fwd)
+    if ops.outproj_head_inputs_supported(d, w):
+        dev3 = [t.cuda().requires_grad_(True) for t in (o, wt, bias, img, latent, x, prob)]
+        o3 = ops.OutProjHeadInputs.apply(dev3[0].view(g * bsz, -1), dev3[1], dev3[2], dev3[3], dev3[4],
+                                         dev3[5].view(bsz, -1) if use_prob else None,
+                                         dev3[6].view(-1) if use_prob else None, bsz, False)
+        cross3 = o3[3]
+        o3 = o3[:3] if use_prob else (o3[0], o3[1], o3[1])
+        for got, want, nm in zip(o3, ref_out, ("out_z", "out_lin", "feat")):
+            assert_matches(got, want.detach().numpy(), TOL, "fused " + nm)
+        assert_matches(cross3, torch.relu(ref_in[0] @ ref_in[1].t() + ref_in[2]).reshape(g * bsz, -1).detach().numpy(), TOL,
+                       "fused cross")
+        g3 = torch.autograd.grad(sum((a * c.cuda()).sum() for a, c in zip(o3, cots)), dev3, allow_unused=True)
+        for got, want, nm in zip(g3, g_ref, ("d_o", "d_weight", "d_bias", "d_img", "d_latent", "dx", "dprob")):
+            if want is None:
+                assert got is None or float(got.abs().max()) == 0.0, nm
+            else:
+                assert_matches(got, want.numpy(), TOL, "fused " + nm)
     # the same through the deferred reductions of a captured step (the bias sums join the flush), bit for bit
     with ops.deferred_reductions():
         cross = ops.LinearReluOwed.apply(dev[0], dev[1], dev[2], False).reshape(g * bsz, -1)
