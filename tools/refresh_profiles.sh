@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): the bench lines kept under profiles/ plus the in-step kernel summaries and the replay-only
 # traces of the two profiled workloads, written to gpurun_out/refresh/ (copy to profiles/<tag>_* afterwards).
-#   tools/refresh_profiles.sh [tag]      (tag = r04 by default: the round the files are named after)
+#   tools/refresh_profiles.sh [tag]      (tag = r05 by default: the round the files are named after)
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=$GRAFT_REPO_ROOT/gpurun_out/refresh
 rm -rf $O
 mkdir -p $O
@@ -30,3 +30,6 @@ for f in full stress sgcn pipeline; do python -c "
 import json,sys
 d=json.load(open('$O/${TAG}_bench_$f.json')); print('$f', d['value'], d['unit'], d['ms_per_step'], 'ms', (d.get('stress') or {}).get('ms_per_step',''), json.dumps(d.get('pipeline',''))[:300])"; done
 tail -4 $O/${TAG}_replay_full_summary.csv; tail -4 $O/${TAG}_replay_stress_summary.csv
+# configs[4]: k_ds_agg with parts compiled out (kernel durations inside the captured step) and the in-step phase stamps
+tools/dense_ablate.sh > $O/dense_ablate.log 2>&1 && cp $GRAFT_REPO_ROOT/gpurun_out/dense_ablate.txt $O/${TAG}_dense_ablate.txt
+python tools/dense_ablate_report.py $O/${TAG}_dense_ablate.txt | grep -E "==|k_ds_agg<" || true
