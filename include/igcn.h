@@ -509,7 +509,10 @@ int igcn_gemm_f32_batched(int64_t M, int64_t N, int64_t K, int batch, const floa
 /* n (1..4) products of DIFFERENT shapes in one launch (the dX and dW products of a linear layer's backward): table
  * [n][16] int64 = {M, N, K, A, sam, sak, B, sbn, sbk, bias, C, ldc, act, split_k, scratch, bf16} per problem, each
  * field as the igcn_gemm_f32 argument of that name (pointers as integers); bf16 != 0 in the first problem: operands
- * rounded to bf16 as in igcn_gemm_bf16.  Same results as n igcn_gemm_f32 / igcn_gemm_bf16 calls. */
+ * rounded to bf16 as in igcn_gemm_bf16.  Same products as n igcn_gemm_f32 / igcn_gemm_bf16 calls; where K is split, the
+ * slabs of a member are added in slab order (one launch for all members that need a plain sum) — the single-product entry
+ * points choose their slab sum by shape (a tree for few outputs x many slabs, igcn_gemm_f32_batched likewise), so a split
+ * product agrees with them to fp32 rounding, not bit for bit.  Within one entry point results are reproducible run to run. */
 int igcn_gemm_f32_grouped(int n, const int64_t* table, void* stream);
 /* Products QUEUED for `stream` (same table format; at most 4 waiting) and carried by the next igcn_gemm_f32_grouped on it
  * — if they fit beside its own products (4 in all) and share its operand type — as further members of that launch,
