@@ -969,7 +969,8 @@ def sweep(ns):
 
     At N > 1 EVERY gradient-exchange form is run, one child each, so that a single hardware run says which to keep
     (VERDICT r4 #5): ``two_graphs`` = [zero_grad .. backward + pack] graph -> igcn_comm_allreduce -> [Adam] graph (the
-    default), ``in_graph`` = one graph with the collective captured (IGCN_COMM_IN_GRAPH=1; the ranks agree on it through
+    default), ``two_buckets`` = three graphs with the heads' all-reduce on a side stream beside the rest of the backward
+    (IGCN_DP_TWO_BUCKETS=1), ``in_graph`` = one graph with the collective captured (IGCN_COMM_IN_GRAPH=1; the ranks agree on it through
     a MIN-reduced flag and fall back together).  The line of each child carries ``exchange_form``; a child that hangs is
     killed after IGCN_BENCH_SWEEP_TIMEOUT seconds (default 600) and only loses its own line."""
     env = dict(os.environ)
@@ -987,11 +988,12 @@ def sweep(ns):
             cmd += [f for f in ("--no-roofline", "--no-cpu-baseline", "--no-pipeline") if f not in argv]
         if n1 is not None:
             env["IGCN_BENCH_N1_VALUE"] = str(n1)
-        forms = [("single", None)] if n == 1 else [("two_graphs", "0"), ("in_graph", "1")]
+        forms = [("single", None)] if n == 1 else [("two_graphs", "0"), ("in_graph", "1"), ("two_buckets", "0")]
         for form, in_graph in forms:
             cenv = dict(env)
             if in_graph is not None:
                 cenv["IGCN_COMM_IN_GRAPH"] = in_graph
+                cenv["IGCN_DP_TWO_BUCKETS"] = "1" if form == "two_buckets" else "0"
             try:
                 r = subprocess.run(cmd, env=cenv, stdout=subprocess.PIPE, text=True, timeout=tmo)
             except subprocess.TimeoutExpired:
@@ -1128,9 +1130,13 @@ def main():
     if dist_on and comm is None:
         exchange = "torch.distributed all_reduce (%s)" % torch.distributed.get_backend()
 
+    # IGCN_DP_TWO_BUCKETS=1: the heads' gradients (4/5 of the bucket) all-reduced on a side stream while the rest of the
+    # backward runs, the remainder behind it (train._TwoBucketExchange; three graphs, collectives outside them)
+    two_buckets = dist_on and os.environ.get("IGCN_DP_TWO_BUCKETS", "0") == "1"
+
     def eager_step():
         data._igcn_plan = None                    # the plan is per batch: rebuild it inside every step
-        return train_step(model, opt, data, world_size=world, comm=comm)
+        return train_step(model, opt, data, world_size=world, comm=comm, two_buckets=two_buckets)
 
     launch = "eager"
     step = eager_step
@@ -1141,9 +1147,12 @@ def main():
             # call into the one step graph is verified on a single-rank communicator only (IGCN_COMM_IN_GRAPH=1)
             in_graph = None if os.environ.get("IGCN_COMM_IN_GRAPH", "0") == "1" else False
             gstep = step = GraphedTrainStep(model, opt, data, world_size=world, distributed=dist_on, comm=comm,
-                                            comm_in_graph=in_graph)
+                                            comm_in_graph=in_graph, two_buckets=two_buckets)
             launch = "hipGraph replay"
-            if dist_on:
+            if dist_on and gstep.two is not None:
+                launch += (" (three graphs: the heads' all-reduce on a side stream beside the rest of the backward, the "
+                           "remainder's behind it)")
+            elif dist_on:
                 launch += " (all-reduce inside the graph)" if gstep.comm_in_graph else " (two graphs around the all-reduce)"
         except Exception as exc:                  # noqa: BLE001 — a capture refused by the runtime must not sink the run
             print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running the eager step",
@@ -1206,14 +1215,22 @@ def main():
         def ev():
             return torch.cuda.Event(enable_timing=True)
         recs, host_us = [], []
+        two = gstep.two
         for _ in range(20):
             gstep._own_the_table()
-            e = [ev() for _ in range(4)]
+            e = [ev() for _ in range(5)]
             h0 = time.perf_counter()
             e[0].record()
             gstep.g_main.replay()
             e[1].record()
-            gstep._reduce()
+            if two is not None:                  # the heads' all-reduce runs on the side stream beside g_rest
+                two.start_early()
+                gstep.g_rest.replay()
+                e[4].record()
+                two.finish()
+            else:
+                e[4].record()
+                gstep._reduce()
             e[2].record()
             gstep.g_opt.replay()
             e[3].record()
@@ -1224,27 +1241,35 @@ def main():
         for _ in range(20):
             a, b = ev(), ev()
             a.record()
-            gstep._reduce()
+            if two is not None:                  # both buckets, one after the other on the launch stream
+                two._all_reduce(two.early)
+                for t_ in two.rest:
+                    two._all_reduce(t_)
+            else:
+                gstep._reduce()
             b.record()
             alone.append((a, b))
         torch.cuda.synchronize()
         med = lambda v: sorted(v)[len(v) // 2]                    # noqa: E731
-        mine = [med([e[0].elapsed_time(e[1]) * 1e3 for e in recs]), med([e[1].elapsed_time(e[2]) * 1e3 for e in recs]),
+        mine = [med([e[0].elapsed_time(e[1]) * 1e3 for e in recs]), med([e[4].elapsed_time(e[2]) * 1e3 for e in recs]),
                 med([e[2].elapsed_time(e[3]) * 1e3 for e in recs]), med([a.elapsed_time(b) * 1e3 for a, b in alone]),
-                med(host_us)]
+                med(host_us), med([e[1].elapsed_time(e[4]) * 1e3 for e in recs])]
         t = torch.tensor(mine, device=device, dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)] if world > 1 else [t]
         if world > 1:
             torch.distributed.all_gather(every, t)
         rows = [[round(float(v), 1) for v in r.tolist()] for r in every]
-        totals = [r[0] + r[1] + r[2] for r in rows]
+        totals = [r[0] + r[1] + r[2] + r[5] for r in rows]
         allreduce_us = max(r[1] for r in rows)
         dist_parts = {
+            "exchange": "two_buckets" if two is not None else "two_graphs",
             "per_rank_median_us": {"g_main_replay": [r[0] for r in rows],
                                    "allreduce_in_step (incl. any wait for the host to enqueue it)": [r[1] for r in rows],
                                    "allreduce_alone_back_to_back": [r[3] for r in rows],
                                    "gap_before_allreduce = in_step - alone": [round(r[1] - r[3], 1) for r in rows],
                                    "g_opt_replay": [r[2] for r in rows],
+                                   "g_rest_replay (two-bucket form: the rest of the backward, beside the heads' all-reduce)":
+                                       [r[5] for r in rows],
                                    "host_enqueue_per_step": [r[4] for r in rows]},
             "slowest_rank": int(max(range(len(rows)), key=lambda i: totals[i])),
             "device_us_per_step_by_rank": [round(v, 1) for v in totals], "steps_sampled": 20}

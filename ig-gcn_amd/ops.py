@@ -2635,7 +2635,10 @@ class HeadLoss(torch.autograd.Function):
             _keep(parts)
         dev = dx1.device
         wcols = c * k + c + nr * k + nr
-        dwb = torch.empty(wcols, dtype=torch.float32, device=dev)
+        # kept until the flush: the sums below are QUEUED, and a backward sweep that does not ask for the heads' gradients
+        # (the second sweep of train.backward_two_buckets visits this node again) drops dwb on return — its memory would be
+        # handed to a later tensor of the sweep and the flush would write the sums into it
+        dwb = _keep(torch.empty(wcols, dtype=torch.float32, device=dev))
         _keep(wpart)
         o1, o2 = c * k + c, nr * k + nr
         with _immediate(ctx.w_final[0]):

@@ -500,7 +500,16 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         if on_out_z is not None:
             on_out_z(out_z)
         # the first layers of the two heads (:299 lin1, :302 lin1_regr) are independent: one grouped launch each way
-        linear_outf, reg = ops.linear_pair(out_lin, self.lin1.weight, self.lin1.bias, feat, self.lin1_regr.weight,
+        hin1, hin2 = out_lin, feat
+        self._cut = None
+        if getattr(self, "_cut_heads", False) and torch.is_grad_enabled() and out_lin.requires_grad:
+            # two-bucket gradient exchange (train.backward_two_buckets): the heads take DETACHED copies of their inputs, so
+            # that a first backward sweep ends at them (the heads' parameter gradients — 4/5 of the bucket — are complete
+            # and on the wire while the second sweep runs through the rest of the model)
+            hin1 = out_lin.detach().requires_grad_(True)
+            hin2 = hin1 if feat is out_lin else feat.detach().requires_grad_(True)
+            self._cut = [(out_lin, hin1)] + ([] if feat is out_lin else [(feat, hin2)])
+        linear_outf, reg = ops.linear_pair(hin1, self.lin1.weight, self.lin1.bias, hin2, self.lin1_regr.weight,
                                            self.lin1_regr.bias, relu=True, bf16=bf)
         if (heads_to_loss and not split and not (head_drop and keep1 is None)
                 and ops.head_loss_supported(linear_outf, self.lin2.weight, reg, self.lin2_regr.weight, keep1, keep2)):
@@ -518,6 +527,11 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
         if g == 1:
             return [outs]
         return [tuple(t[k * bsz:(k + 1) * bsz] for t in outs) for k in range(g)]
+
+    def head_parameters(self):
+        """The parameters of the two MLP heads (:284-305) — consecutive in ``parameters()``, 4/5 of the model's weights,
+        and the first whose gradients a backward pass completes: the early bucket of the two-bucket gradient exchange."""
+        return [p for m in (self.lin1, self.lin1_regr, self.lin2, self.lin2_regr) for p in m.parameters()]
 
     def __repr__(self):
         return self.__class__.__name__

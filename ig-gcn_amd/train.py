@@ -4,6 +4,7 @@ graph-batch data parallelism the reference does not have (one process per GPU, o
 flat fp32 gradient buffer per step).
 """
 import os
+import sys
 from types import SimpleNamespace
 
 import torch
@@ -121,6 +122,7 @@ class FlatAdam:
         self._table_live = [False] * nt              # which parameters the current table holds a gradient for
         self.numel = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
         self.offset = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self._off_host = [int(o) for o in offs]
         # block list of the multi-tensor step: one workgroup per chunk of a tensor (igcn_adam_step_blocks)
         self._blocks = None
         if dev.type == "cuda":
@@ -183,15 +185,39 @@ class FlatAdam:
             self._uploaded[k] = torch.cuda.Event()
             self._uploaded[k].record()
 
-    def pack_grads(self, refresh=True, table=None):
-        """Gather the per-tensor gradients into the flat bucket ``self.grad`` (data-parallel exchange)."""
+    def pack_grads(self, refresh=True, table=None, lo=0, hi=None):
+        """Gather the per-tensor gradients into the flat bucket ``self.grad`` (data-parallel exchange).  ``lo`` / ``hi``: only
+        the parameters [lo, hi) of ``self.params`` (a bucket of the two-bucket exchange)."""
         if self.flat_grads:
             return self.grad
         if refresh:
             self.refresh_table(table=table)
-        call("igcn_pack_grads", len(self.params), ptr(self.table if table is None else table), ptr(self.numel),
-             ptr(self.offset), ptr(self.grad), stream_ptr())
+        hi = len(self.params) if hi is None else hi
+        if hi <= lo:
+            return self.grad
+        tab = self.table if table is None else table
+        call("igcn_pack_grads", hi - lo, tab.data_ptr() + 32 * lo, self.numel.data_ptr() + 8 * lo,
+             self.offset.data_ptr() + 8 * lo, ptr(self.grad), stream_ptr())
         return self.grad
+
+    def bucket_of(self, params):
+        """(lo, hi, flat slice) of a run of CONSECUTIVE parameters of ``self.params``: the slice of the flat bucket that
+        holds exactly their gradients (every parameter starts on a 64-byte boundary; the padding in between belongs to the
+        parameter in front and is zero)."""
+        ids = [id(p) for p in self.params]
+        idx = sorted(ids.index(id(p)) for p in params)
+        lo, hi = idx[0], idx[-1] + 1
+        if idx != list(range(lo, hi)):
+            raise ValueError("bucket_of: the parameters are not consecutive in the optimiser")
+        off = self._offsets_host()
+        start = off[lo]
+        end = off[hi] if hi < len(self.params) else int(self.grad.numel())
+        return lo, hi, self.grad[start:end]
+
+    def _offsets_host(self):
+        if getattr(self, "_off_host", None) is None:
+            self._off_host = [int(v) for v in self.offset.cpu().tolist()]
+        return self._off_host
 
     def step(self, grad_scale=1.0, refresh=True, from_flat=None, table=None):
         """``from_flat``: read gradients from the flat bucket (after an all-reduce); default = flat mode only.
@@ -474,6 +500,44 @@ def backward_to_grads(loss, optimizer, data=None, defer=False, tick=False):
         t.grad = g
 
 
+def backward_two_buckets(loss, optimizer, data, model, on_early, tick=False):
+    """``backward_to_grads(defer=True)`` in TWO sweeps for the two-bucket gradient exchange: the forward ran with
+    ``model._cut_heads`` (the heads took detached copies of their inputs, ``model._cut``).  Sweep 1 stops at those copies:
+    the heads' parameter gradients are final after its flush, ``on_early()`` is called (pack + start their all-reduce),
+    sweep 2 takes the rest of the model from the loss and from the cut tensors' gradients — autograd prunes the heads'
+    first layers from it.  Same kernels, same arithmetic, same gradients bit for bit as the one-sweep backward; the price is
+    a second flush launch and the loss head's (launch-free) backward node visited twice."""
+    from . import ops
+    cut = getattr(model, "_cut", None)
+    if not cut:
+        raise RuntimeError("backward_two_buckets: the forward did not cut the heads off (model._cut_heads)")
+    early = list(model.head_parameters())
+    early_ids = {id(p) for p in early}
+    rest = [p for p in optimizer.params if id(p) not in early_ids]
+    if data is not None and getattr(data, "x", None) is not None and data.x.requires_grad:
+        rest.append(data.x)
+    if getattr(optimizer, "_ticked", False):
+        raise RuntimeError("backward_two_buckets(tick=True): the previous backward advanced the step counter and no "
+                           "optimizer.step() followed it")
+    unit = _unit_grad(loss)
+    copies = [c for _, c in cut]
+    with ops.deferred_reductions():
+        g1 = torch.autograd.grad(loss, early + copies, grad_outputs=unit, retain_graph=True, allow_unused=True)
+    for p, g in zip(early, g1[:len(early)]):
+        p.grad = g
+    on_early()
+    counter = getattr(optimizer, "step_count", None) if tick else None
+    outs = [loss] + [x for x, _ in cut]
+    gouts = [unit] + list(g1[len(early):])
+    with ops.deferred_reductions(tick=counter):
+        g2 = torch.autograd.grad(outs, rest, grad_outputs=gouts, allow_unused=True)
+    if counter is not None:
+        optimizer._ticked = True
+    for t, g in zip(rest, g2):
+        t.grad = g
+    model._cut = None
+
+
 def _single_use_parameters(model):
     """True when the step runs both passes as ONE batched sweep (``losses`` picks ``_losses_batched`` /
     ``forward_pair``): every parameter then enters the autograd graph once, which is what deferring the final
@@ -511,8 +575,63 @@ def assert_nothing_pending(where):
             raise _lib.IgcnError(f"{where}: {n} queued launch(es) left on the stream at the end of the step")
 
 
+def _two_buckets_possible(model, optimizer):
+    """The two-bucket exchange needs the table-mode optimiser, the batched sweep with deferred reductions and a model whose
+    heads can be cut off (SGCN_GCN_IMGSNP)."""
+    return (hasattr(model, "head_parameters") and not getattr(optimizer, "flat_grads", True)
+            and _single_use_parameters(model))
+
+
+class _TwoBucketExchange:
+    """The gradient exchange of a data-parallel step in TWO all-reduces (``two_buckets=True``; IGCN_DP_TWO_BUCKETS=1 in
+    bench.py): the heads' gradients (``model.head_parameters()``: 4/5 of the bucket, complete after the first fifth of
+    the backward) are reduced on a SIDE stream while the launch stream runs the rest of the backward; the remainder
+    follows on the launch stream; Adam waits for both.  Collectives of one communicator are issued in the same order on
+    every rank (early, then rest).  The reference has no multi-GPU code."""
+
+    def __init__(self, model, optimizer, comm):
+        self.opt, self.comm = optimizer, comm
+        self.lo, self.hi, self.early = optimizer.bucket_of(model.head_parameters())
+        flat = optimizer.grad
+        start = self.early.data_ptr() - flat.data_ptr()
+        n0 = start // 4
+        n1 = n0 + self.early.numel()
+        self.rest = [t for t in (flat[:n0], flat[n1:]) if t.numel()]
+        self.side = torch.cuda.Stream(device=flat.device)
+        self.ev_packed = torch.cuda.Event()
+        self.ev_reduced = torch.cuda.Event()
+
+    def _all_reduce(self, t):
+        if self.comm is not None:
+            self.comm.all_reduce_(t)
+        else:
+            torch.distributed.all_reduce(t)
+
+    def pack_early(self, table=None, refresh=True):
+        self.opt.pack_grads(refresh=refresh, table=table, lo=self.lo, hi=self.hi)
+
+    def start_early(self):
+        """Behind pack_early on the launch stream: the early bucket's all-reduce on the side stream."""
+        main = torch.cuda.current_stream()
+        self.ev_packed.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_packed)
+            self._all_reduce(self.early)
+            self.ev_reduced.record(self.side)
+
+    def pack_rest(self, table=None, refresh=True):
+        self.opt.pack_grads(refresh=refresh, table=table, lo=0, hi=self.lo)
+        self.opt.pack_grads(refresh=False, table=table, lo=self.hi, hi=len(self.opt.params))
+
+    def finish(self):
+        """The remainder's all-reduce on the launch stream, then the join with the side stream."""
+        for t in self.rest:
+            self._all_reduce(t)
+        torch.cuda.current_stream().wait_event(self.ev_reduced)
+
+
 def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None, world_size=1,
-               comm=None):
+               comm=None, two_buckets=False):
     """One iteration of the loop body of train() :515-547.  Returns the (device) loss tensor.
 
     With ``world_size > 1`` every rank has run the step on its own shard of the graph batch; gradients are summed
@@ -527,6 +646,28 @@ def train_step(model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temper
         data.x.grad = None
     forget_riders(model)          # (a failed step before this one may have left riders / masks drawn ahead: ADVICE r4)
     ensure_unit_grad(data.x.device)
+    if two_buckets and (world_size > 1 or comm is not None) and _two_buckets_possible(model, optimizer):
+        ex = getattr(optimizer, "_two_bucket_exchange", None)
+        if ex is None or ex.comm is not comm:
+            ex = optimizer._two_bucket_exchange = _TwoBucketExchange(model, optimizer, comm)
+        model._cut_heads = True
+        try:
+            loss, _, _ = losses(model, data, lambda_loss, hp, temperature, lazy_value=True)
+
+            def on_early():
+                ex.pack_early()
+                ex.start_early()
+            backward_two_buckets(loss, optimizer, data, model, on_early, tick=True)
+        except BaseException:
+            forget_riders(model)
+            raise
+        finally:
+            model._cut_heads = False
+        assert_nothing_pending("train_step")
+        ex.pack_rest()
+        ex.finish()
+        optimizer.step(grad_scale=1.0 / world_size, from_flat=True)
+        return loss.detach()
     try:
         loss, _, _ = losses(model, data, lambda_loss, hp, temperature, lazy_value=True)
         backward_to_grads(loss, optimizer, data, defer=_single_use_parameters(model), tick=True)
@@ -590,7 +731,7 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, world_size=1, warmup=3,
-                 distributed=None, comm=None, comm_in_graph=False, max_edges=None):
+                 distributed=None, comm=None, comm_in_graph=False, max_edges=None, two_buckets=False):
         """``comm`` (``igcn_amd.comm.Comm``): the gradient all-reduce is igcn_comm_allreduce on the launch stream.
         ``comm_in_graph`` (opt-in): capture it INTO the step graph (one graph: ... pack -> all-reduce -> Adam).  True =
         required (a refused capture raises); None = try — the choice is agreed across ranks (an all-reduce of a flag)
@@ -598,13 +739,21 @@ class GraphedTrainStep:
         (default) = the two-graph form: in-graph capture of a multi-rank collective is verified on single-rank
         communicators only.
         ``max_edges``: size the captured per-graph kernels for graphs of up to this many edges (default: the largest
-        graph of the construction batch); ``load`` refuses batches beyond it."""
+        graph of the construction batch); ``load`` refuses batches beyond it.
+        ``two_buckets`` (opt-in, distributed steps): THREE graphs — [forward .. the heads' backward + pack of their
+        gradients], [the rest of the backward + pack], [Adam] — with the heads' all-reduce (4/5 of the bucket) on a side
+        stream beside the second graph and the remainder's behind it (``_TwoBucketExchange``); collectives stay outside
+        the graphs.  Same gradients, bit for bit, as the default form."""
         self.model, self.opt, self.data, self.world = model, optimizer, data, world_size
         # distributed=True with world_size 1 takes the multi-rank control flow (two graphs around a collective) on
         # a single-rank process group: the rehearsal of the N>1 path that a one-GPU box allows
         self.dist = dist = (world_size > 1 or comm is not None) if distributed is None else bool(distributed)
         self.comm = comm
         self.comm_in_graph = False
+        self.two = None
+        if two_buckets and dist and _two_buckets_possible(model, optimizer):
+            self.two = _TwoBucketExchange(model, optimizer, comm)
+            comm_in_graph = False
         self.lam, self.hp = lambda_loss, hp
         from . import ops
         self.plan = ops.plan_for(data)                  # static plan tensors: rebuilt in place every step
@@ -627,6 +776,15 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                     # eager steps: allocator + library warm-up
+                if self.two is not None:
+                    def between_eager():
+                        self.two.pack_early()
+                        self.two.start_early()
+                    self._fwd_bwd(between=between_eager)
+                    self.two.pack_rest()
+                    self.two.finish()
+                    self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
+                    continue
                 self._fwd_bwd()
                 if dist:
                     self.opt.pack_grads()
@@ -681,7 +839,43 @@ class GraphedTrainStep:
                 if self.comm_in_graph and int(flag.item()) == 0:
                     self.comm_in_graph = False
                     self.g_main = torch.cuda.CUDAGraph()
-        if not self.comm_in_graph:
+        self.g_rest = None
+        if self.two is not None:
+            # two captures around ONE backward: the first ends (and the second begins) between its two sweeps, on the same
+            # capture stream and without leaving it (torch.cuda.graph's own entry — synchronise, collect, empty the
+            # allocator's cache — must not run in the middle of a backward whose tensors live in the first graph's pool)
+            import gc
+            self.g_rest = torch.cuda.CUDAGraph()
+            cap_stream = torch.cuda.Stream()
+            torch.cuda.synchronize()
+            gc.collect()
+            torch.cuda.empty_cache()
+            was = gc.isenabled()
+            gc.disable()
+            cap_stream.wait_stream(torch.cuda.current_stream())
+            open_graph = [None]
+            try:
+                with torch.cuda.stream(cap_stream):
+                    self.g_main.capture_begin(capture_error_mode=mode)
+                    open_graph[0] = self.g_main
+
+                    def between():
+                        self.two.pack_early(table=self._table, refresh=False)
+                        self.g_main.capture_end()
+                        open_graph[0] = None
+                        self.g_rest.capture_begin(pool=self.g_main.pool(), capture_error_mode=mode)
+                        open_graph[0] = self.g_rest
+                    try:
+                        self.loss = self._fwd_bwd(rebuild=self.plan_in_graph, between=between)
+                        self.two.pack_rest(table=self._table, refresh=False)
+                    finally:
+                        if open_graph[0] is not None:
+                            open_graph[0].capture_end()
+                torch.cuda.current_stream().wait_stream(cap_stream)
+            finally:
+                if was:
+                    gc.enable()
+        elif not self.comm_in_graph:
             with _capture(self.g_main, capture_error_mode=mode):
                 self.loss = self._fwd_bwd(rebuild=self.plan_in_graph)
                 if not dist:
@@ -708,7 +902,9 @@ class GraphedTrainStep:
                 self.opt.step(grad_scale=1.0 / world_size, from_flat=True)
         torch.cuda.synchronize()
 
-    def _fwd_bwd(self, rebuild=True):
+    def _fwd_bwd(self, rebuild=True, between=None):
+        """``between`` (two-bucket form): called between the two sweeps of the backward, when the heads' gradients are
+        final (``backward_two_buckets``)."""
         self.opt.zero_grad()
         self.data._igcn_plan = self.plan
         forget_riders(self.model)                       # (leftovers of a step that failed half way must never launch)
@@ -728,10 +924,17 @@ class GraphedTrainStep:
             if rider and getattr(self.plan, "_pending_build", None) is None:
                 call("igcn_rider_flush", stream_ptr())  # (a plan build that does not carry riders: a launch of its own)
             self.data.x.grad = None
-            loss, _, _ = losses(self.model, self.data, self.lam, self.hp, lazy_value=True)
+            self.model._cut_heads = between is not None
+            try:
+                loss, _, _ = losses(self.model, self.data, self.lam, self.hp, lazy_value=True)
+            finally:
+                self.model._cut_heads = False
             if rider:
                 call("igcn_rider_flush", stream_ptr())  # (nothing waiting unless no launch of the forward took the rider)
-            backward_to_grads(loss, self.opt, self.data, defer=_single_use_parameters(self.model), tick=True)
+            if between is not None:
+                backward_two_buckets(loss, self.opt, self.data, self.model, between, tick=True)
+            else:
+                backward_to_grads(loss, self.opt, self.data, defer=_single_use_parameters(self.model), tick=True)
         except BaseException:
             # a step that raised between queueing a rider and its carrier: the rider's buffers die with this frame, and
             # the masks drawn ahead for THIS forward must not be handed to a later one
@@ -807,7 +1010,13 @@ class GraphedTrainStep:
         if not self.plan_in_graph:
             self.plan.rebuild(self.data.edge_index)
         self.g_main.replay()
-        if self.g_opt is not None:
+        if self.two is not None:
+            self.two.start_early()                      # the heads' all-reduce: side stream, beside the second graph
+            self.g_rest.replay()
+            self.two.finish()                           # the remainder's, then the join
+            self.g_opt.replay()
+            self.opt._has_state = [True] * len(self.opt.params)
+        elif self.g_opt is not None:
             self._reduce()
             self.g_opt.replay()
             self.opt._has_state = [True] * len(self.opt.params)

@@ -106,6 +106,33 @@ def main():
         res["epoch_param_after"] = {k: p.detach().cpu().clone() for k, p in zip(names, opt3.params)}
         res["epoch_ref_param_after"] = {k: p.detach().cpu().clone() for k, p in zip(names, opt4.params)}
         res["epoch_step_count"] = (int(opt3.step_count.item()), int(opt4.step_count.item()))
+        # (D) the two-bucket exchange (heads' gradients all-reduced on a side stream beside the rest of the backward), eager
+        # and as three graphs: the same gradients and parameters as (A) / (B), bit for bit
+        model5, _ = build_model(dev)
+        opt5 = FlatAdam(model5.parameters(), lr=1e-3)
+        data5 = Batch.from_data_list(graphs).to(dev)
+        loss5 = train_step(model5, opt5, data5, LAM, world_size=world, two_buckets=True)
+        torch.cuda.synchronize()
+        res["two_loss"] = float(loss5)
+        res["two_used"] = getattr(opt5, "_two_bucket_exchange", None) is not None
+        res["two_grad_sum"] = {k: opt5.grad[o:o + p.numel()].view_as(p).cpu().clone()
+                               for k, o, p in zip(names, opt5._offs, opt5.params)}
+        res["two_param_after"] = {k: p.detach().cpu().clone() for k, p in zip(names, opt5.params)}
+        model6, _ = build_model(dev)
+        opt6 = FlatAdam(model6.parameters(), lr=1e-3)
+        data6 = Batch.from_data_list(graphs).to(dev)
+        data6.x.requires_grad_(True)
+        step6 = GraphedTrainStep(model6, opt6, data6, LAM, world_size=world, distributed=True, two_buckets=True)
+        res["two_graphed_loss"] = float(step6())          # (read before the next replay overwrites the tensor)
+        res["two_graphed_param_after"] = {k: p.detach().cpu().clone() for k, p in zip(names, opt6.params)}
+        step6()
+        torch.cuda.synchronize()
+        res["two_graphed_used"] = step6.two is not None and step6.g_rest is not None
+        res["two_graphed_param_after_2_steps"] = {k: p.detach().cpu().clone() for k, p in zip(names, opt6.params)}
+        step()                                            # (B)'s second step, for the comparison after two steps
+        torch.cuda.synchronize()
+        res["graphed_param_after_2_steps"] = {k: p.detach().cpu().clone() for k, p in zip(names, opt2.params)}
+        res["two_early_share"] = float(step6.two.early.numel()) / float(opt6.grad.numel())
         torch.save(res, f"{out}.rank{rank}.pt")
         torch.distributed.barrier()
     finally:

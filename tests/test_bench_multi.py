@@ -60,7 +60,8 @@ def test_gpus_2_self_launch_rehearsal_on_one_device():
 @pytest.mark.gpu
 def test_sweep_prints_one_line_per_n_and_exchange_form_with_efficiency():
     """IGCN_BENCH_SWEEP="1,2": one invocation, a fresh child per N and — at N > 1 — per gradient-exchange form
-    (``two_graphs`` around the all-reduce; ``in_graph``: the collective captured, which on this one-device rehearsal
+    (``two_graphs`` around the all-reduce; ``two_buckets``: three graphs, the heads' all-reduce on a side stream beside the
+    rest of the backward; ``in_graph``: the collective captured, which on this one-device rehearsal
     (gloo, no RCCL communicator) is refused and falls back on every rank alike — the control flow a multi-rank run
     takes when the capture is refused), every N = 2 line scaled by the sweep's own N = 1 run."""
     if not torch.cuda.is_available():
@@ -72,8 +73,11 @@ def test_sweep_prints_one_line_per_n_and_exchange_form_with_efficiency():
                        timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip()]
-    assert [ln["n_gpus"] for ln in lines] == [1, 2, 2]
-    assert [ln["exchange_form"] for ln in lines] == ["single", "two_graphs", "in_graph"]
+    assert [ln["n_gpus"] for ln in lines] == [1, 2, 2, 2]
+    assert [ln["exchange_form"] for ln in lines] == ["single", "two_graphs", "in_graph", "two_buckets"]
+    assert "three graphs" in lines[3]["config"]["launch"]
+    for ln in lines[1:]:                            # the N > 1 step taken apart, with the exchange it ran named
+        assert ln["distributed_step"]["exchange"] == ("two_buckets" if ln["exchange_form"] == "two_buckets" else "two_graphs")
     assert "weak_scaling_efficiency_vs_n1" not in lines[0]
     for ln in lines[1:]:
         assert ln["weak_scaling_efficiency_vs_n1"] == pytest.approx(ln["value"] / (2 * lines[0]["value"]), abs=1e-3)

@@ -134,6 +134,30 @@ def test_graphed_distributed_step_equals_the_eager_one(ranks):
         assert torch.equal(ranks[0]["graphed_param_after"][k], ranks[1]["graphed_param_after"][k]), k
 
 
+def test_two_bucket_exchange_gives_the_default_step_bit_for_bit(ranks):
+    """``two_buckets=True``: the backward in two sweeps, the heads' gradients — most of the bucket —
+    all-reduced on a side stream while the second sweep runs, the remainder behind it; eager and as three captured graphs.
+    Same kernels, same arithmetic: the reduced gradients and the parameters after one (eager) / two (graphed) steps equal
+    the default form's bit for bit, on every rank."""
+    for res in ranks:
+        assert res["two_used"] and res["two_graphed_used"]
+        assert res["two_early_share"] > 0.7                       # lin1 + lin1_regr + lin2 + lin2_regr
+        assert res["two_loss"] == res["loss"]
+        for k, g in res["grad_sum"].items():
+            assert torch.equal(res["two_grad_sum"][k], g), k
+        for k, p in res["param_after"].items():
+            assert torch.equal(res["two_param_after"][k], p), k
+        assert abs(res["two_graphed_loss"] - res["graphed_loss"]) == 0.0
+        bad1 = {k: float((res["two_graphed_param_after"][k] - p).abs().max()) for k, p in res["graphed_param_after"].items()
+                if not torch.equal(res["two_graphed_param_after"][k], p)}
+        bad2 = {k: float((res["two_graphed_param_after_2_steps"][k] - p).abs().max())
+                for k, p in res["graphed_param_after_2_steps"].items()
+                if not torch.equal(res["two_graphed_param_after_2_steps"][k], p)}
+        assert not bad1 and not bad2, (bad1, bad2)
+    for k in ranks[0]["two_param_after"]:
+        assert torch.equal(ranks[0]["two_param_after"][k], ranks[1]["two_param_after"][k]), k
+
+
 def test_epoch_loop_in_data_parallel_keeps_the_ranks_identical(ranks):
     """``fit_epoch(world_size=2)`` on every rank's shard (batches of 6 + 6 + 4 graphs, three epochs, the rate halved after
     the first): the ranks take the same route per batch (eager -> capture -> replay), end bit-identical, and land where
