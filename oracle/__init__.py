@@ -16,6 +16,8 @@ Parity pinning status:
 * ``sgcn_img_snp`` glue (masks, fusion, MHA wiring, heads, losses, train step) — pinned against
   the reference's ``kernel/sgcn_img_snp.py`` executed with PyG's ``GCNConv``/``to_dense_batch``
   replaced by ``oracle.pyg_ops`` (PyG 2.0.2 is not installable here).
+* ``dropout`` — the product's own dropout-mask generator restated in numpy (the reference draws from torch's global
+  generator: nothing of its numbers to pin); pinned against the kernel bit for bit on the GPU, known answers on the CPU.
 * ``sgcn`` (the image-only sibling ``SGCN_GCN`` and its train loss) — pinned against the reference's
   ``kernel/sgcn.py`` executed the same way (tests/golden/sgcn_only.npz).
 * ``gdc`` (PPR diffusion, top-k, column normalisation, COO emission) — pinned against the reference's own

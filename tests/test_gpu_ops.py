@@ -2140,6 +2140,33 @@ def test_dropout_masks_one_launch(ops):
         assert abs(float((a > 0).float().mean()) - (1 - p)) < 0.12
 
 
+def test_dropout_masks_are_a_pure_function_of_counter_and_index(ops):
+    """The mask generator's contract (first half): a factor depends on (stream counter, flat element index,
+    the site's p) only — ``oracle/dropout.py`` rebuilds the arrays of any launch on the host, bit for bit: a launch of its
+    own, the next launch (counter + 1), and a launch that RIDES in another kernel's grid."""
+    from oracle import dropout as OD
+    state = ops.DropoutState(torch.device("cuda"))
+    sites = [((64, 3001), 0.4), ((9, 401), 0.5), ((7,), 0.3), ((128, 64), 0.3), ((2, 5, 33), 0.1)]
+    for _ in range(2):
+        c = int(state.state[0].item())
+        got = ops.dropout_masks(sites, state)
+        torch.cuda.synchronize()
+        assert int(state.state[0].item()) == c + 1
+        for g, w in zip(got, OD.masks(sites, c)):
+            assert np.array_equal(g.cpu().numpy(), w)
+    state.state[0] = (1 << 40) + 12345                           # the high word of the counter takes part
+    c = int(state.state[0].item())
+    got = ops.dropout_masks(sites[:2], state)
+    for g, w in zip(got, OD.masks(sites[:2], c)):
+        assert np.array_equal(g.cpu().numpy(), w)
+    c = int(state.state[0].item())
+    got = ops.dropout_masks(sites, state, ride=True)             # queued: nothing launched yet
+    ops.call("igcn_rider_flush", ops.stream_ptr())
+    torch.cuda.synchronize()
+    for g, w in zip(got, OD.masks(sites, c)):
+        assert np.array_equal(g.cpu().numpy(), w)
+
+
 def test_dropout_launch_advances_the_batch_counters(ops):
     """igcn_dropout_masks with counters: BatchNorm's num_batches_tracked words advance by `inc` per launch — eagerly and
     on every replay of a captured launch — and nothing else of the contract changes."""
