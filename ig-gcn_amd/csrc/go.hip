@@ -1710,13 +1710,24 @@ k_nodes_ln_fwd_v(int f, int N, int pool, float eps, const float* __restrict__ y,
   const int row = ln_row(), b = row / f, nv = N / 4;
   const float* yr = y + (int64_t)row * N;
   float4 v[LN_VPT];
-  float s = 0.f;
+  // the affine parameters and the dropout factors of the thread's slots are requested with the row, in front of the two
+  // block sums (asked for behind them, their round trip was the tail of every workgroup of a 2560-workgroup latency chain)
+  float4 g4[LN_VPT], be4[LN_VPT], k4[LN_VPT];
 #pragma unroll
   for (int i = 0; i < LN_VPT; ++i) {
-    const int q = threadIdx.x + i * (int)blockDim.x;
+    const int q = threadIdx.x + i * (int)blockDim.x, n = 4 * q;
     v[i] = q < nv ? ld4(yr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    g4[i] = be4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    k4[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (q < nv && n >= pool) {
+      g4[i] = ld4(gamma + n);
+      be4[i] = ld4(beta + n);
+      if (keep) k4[i] = ld4(keep + (int64_t)b * N + n);
+    }
   }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_VPT; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   const float mean = block_sum_all(s, red) / (float)N;
   float var = 0.f;
 #pragma unroll
@@ -1737,14 +1748,14 @@ k_nodes_ln_fwd_v(int f, int N, int pool, float eps, const float* __restrict__ y,
   for (int i = 0; i < LN_VPT; ++i) {
     const int q = threadIdx.x + i * (int)blockDim.x, n = 4 * q;
     if (q < nv && n >= pool) {
-      const float4 g = ld4(gamma + n), be = ld4(beta + n);
+      const float4 g = g4[i], be = be4[i];
       float4 o;
       o.x = fmaxf((v[i].x - mean) * rstd * g.x + be.x, 0.f);
       o.y = fmaxf((v[i].y - mean) * rstd * g.y + be.y, 0.f);
       o.z = fmaxf((v[i].z - mean) * rstd * g.z + be.z, 0.f);
       o.w = fmaxf((v[i].w - mean) * rstd * g.w + be.w, 0.f);
       if (keep) {
-        const float4 k = ld4(keep + (int64_t)b * N + n);
+        const float4 k = k4[i];
         o.x *= k.x; o.y *= k.y; o.z *= k.z; o.w *= k.w;
       }
       *reinterpret_cast<float4*>(zr + (n - pool)) = o;
