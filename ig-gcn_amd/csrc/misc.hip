@@ -98,7 +98,7 @@ k_adam_multi(const int64_t* __restrict__ table, const int64_t* __restrict__ nume
 // The same update over a precomputed block list: block b covers elements [blk_off[b], blk_off[b] + ADAM_CHUNK) of tensor
 // blk_tensor[b].  The (96, n_tensors) grid above launches 7 680 workgroups for the ~80 tensors of the model, of which
 // ~7 400 find nothing to do (most tensors are a few hundred floats): their dispatch was most of the kernel's 10 us.
-#define ADAM_CHUNK 2048
+#define ADAM_CHUNK 1024
 __global__ void __launch_bounds__(256)
 k_adam_blocks(const int64_t* __restrict__ table, const int64_t* __restrict__ numel, const int32_t* __restrict__ blk_tensor,
               const int32_t* __restrict__ blk_off, const int32_t* __restrict__ step, const float* __restrict__ lr_dev,
