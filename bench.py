@@ -688,15 +688,18 @@ def cpu_baseline_child(workload, seconds, cores):
         times.append(time.perf_counter() - t0)
     ts = sorted(times)
     med = ts[len(ts) // 2]
+    # `value` = the FASTEST timed step: the host is shared (load average 20-60 on a 256-thread box, 16 usable cores), a step
+    # is disturbed or it is not, and the minimum time is the estimator other tenants move least — two runs of this round
+    # gave medians of 120.3 and 80.2 graphs/s but fastest steps of 129.6 and 125.4 (3 %).  min / median / max stay in the line.
     print(json.dumps({
-        "value": round(b / med, 2), "unit": "graphs/s", "cores": threads, "kind": "port",
+        "value": round(b / ts[0], 2), "unit": "graphs/s", "cores": threads, "kind": "port", "estimator": "fastest timed step",
         "graphs_per_s_min_median_max": [round(b / ts[-1], 2), round(b / med, 2), round(b / ts[0], 2)],
         "spread": round((ts[-1] - ts[0]) / med, 3), "steps_timed": len(ts), "batch": b,
         "pinned_cpu_ids": cores, "host_load_1min_at_start": load0,
         "host_logical_cpus": os.cpu_count(), "physical_cores": _physical_cores(), "usable_cores": _usable_cores(),
         "torch": torch.__version__,
         "sample": f"{len(ts)} timed train steps (+1 warm-up) of B={b} graphs (the headline runs B={b_full}; same model / "
-                  f"GO DAG, fp32), median; oracle faithful mode; {threads} threads pinned one per physical core"}))
+                  f"GO DAG, fp32), fastest step; oracle faithful mode; {threads} threads pinned one per physical core"}))
 
 
 def cpu_baseline(workload, seconds=20.0, device=None):
