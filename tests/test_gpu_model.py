@@ -721,11 +721,11 @@ m1 = SGCN_GCN_IMGSNP(2, 8, a_g, a, pool_dim, 32, "cuda", rois=90, H_0=3, num_cla
                      isSNPsOnly=False).cuda().train()
 for m in (m1, m1.go_network):
     m._dropout_enabled = False
-m2, m3 = copy.deepcopy(m1), copy.deepcopy(m1)
+m2, m3, m4 = copy.deepcopy(m1), copy.deepcopy(m1), copy.deepcopy(m1)
 batches = [Batch.from_data_list(synth.brain_graph_list(6, seed=50 + i, rois=90, tsne_dim=16)).to("cuda")
            for i in range(3)]
 lam = [1.0, 1.0, 0.5, 1.5e-6, 0.1, 0.2]
-o1, o2, o3 = (FlatAdam(m.parameters(), lr=1e-3) for m in (m1, m2, m3))
+o1, o2, o3, o4 = (FlatAdam(m.parameters(), lr=1e-3) for m in (m1, m2, m3, m4))
 def static_batch():
     b = Batch.from_data_list(synth.brain_graph_list(6, seed=50, rois=90, tsne_dim=16)).to("cuda")
     b.x.requires_grad_(True)
@@ -739,14 +739,22 @@ comm = Comm()
 step3 = GraphedTrainStep(m3, o3, static_batch(), lam, warmup=2, comm=comm, comm_in_graph=True)   # opt-in
 print("comm_in_graph", step3.comm_in_graph)
 assert step3.comm_in_graph and step3.g_opt is None
+# (3) the two-bucket exchange on that communicator: three graphs, the heads' all-reduce (RCCL, side stream) beside the second
+step4 = GraphedTrainStep(m4, o4, static_batch(), lam, warmup=2, comm=comm, two_buckets=True)
+assert step4.two is not None and step4.g_rest is not None and step4.g_opt is not None and not step4.comm_in_graph
 for b in batches:
     step.load(b)
     step3.load(b)
+    step4.load(b)
     l1 = float(step())
     l3 = float(step3())
+    l4 = float(step4())
     l2 = float(train_step(m2, o2, b, lam))
     assert abs(l1 - l2) <= 1e-4 * max(1.0, abs(l2)), (l1, l2)
     assert abs(l3 - l2) <= 1e-4 * max(1.0, abs(l2)), (l3, l2)
+    assert l4 == l3, (l4, l3)                              # same kernels, same arithmetic as the one-graph form
+for (k, p3), (_, p4) in zip(m3.named_parameters(), m4.named_parameters()):
+    assert torch.equal(p3.detach(), p4.detach()), k        # ... and the same parameters, bit for bit, after three steps
 for ma in (m1, m3):
     for (k, p1), (_, p2) in zip(ma.named_parameters(), m2.named_parameters()):
         # Adam normalises: an ELEMENT whose gradient is rounding noise (< 1e-6) moves by up to lr per step in a
@@ -764,8 +772,9 @@ def test_graphed_step_with_live_rccl_group():
     """The N>1 control flow of GraphedTrainStep on a single-rank RCCL group — the part of the multi-GPU path a one-GPU
     box can run — against the eager step of a twin model: (1) [forward..backward, pack] graph -> torch.distributed
     all-reduce on the flat gradient -> [Adam] graph, captured in thread-local mode while the process group's threads
-    are alive; (2) libigcn's own communicator (igcn_comm_*), its all-reduce captured inside ONE step graph.  In a child
-    process, so that the process group does not outlive the test."""
+    are alive; (2) libigcn's own communicator (igcn_comm_*), its all-reduce captured inside ONE step graph; (3) the
+    two-bucket form on that communicator (three graphs, the heads' all-reduce on a side stream), bit-identical to (2).  In
+    a child process, so that the process group does not outlive the test."""
     import os
     import subprocess
     import sys
