@@ -313,7 +313,7 @@ def test_relu_owed_layer_and_head_inputs(ops, bsz, g, rois, d, l, use_prob):
         assert torch.equal(a, b_), nm
 
 
-@pytest.mark.parametrize("b,lq,lk,d", [(6, 90, 40, 32), (3, 7, 5, 16)])
+@pytest.mark.parametrize("b,lq,lk,d", [(6, 90, 40, 32), (3, 7, 5, 16), (5, 90, 130, 48)])
 def test_in_proj_packed_projection(ops, b, lq, lk, d):
     """ops.InProj = the packed q / key|value projection of nn.MultiheadAttention (cross-attention) with the parameters
     taken whole: outputs and all four gradients against F.linear on the slices in fp64; under deferred reductions the
@@ -345,7 +345,7 @@ def test_in_proj_packed_projection(ops, b, lq, lk, d):
         assert torch.equal(a, c)
 
 
-@pytest.mark.parametrize("b,lq,lk,d,h", [(5, 90, 40, 32, 2), (3, 17, 70, 32, 4)])
+@pytest.mark.parametrize("b,lq,lk,d,h", [(5, 90, 40, 32, 2), (3, 17, 70, 32, 4), (4, 90, 130, 48, 2)])
 def test_projected_attention_matches_multihead_attention(ops, b, lq, lk, d, h):
     """ops.ProjectedAttention (packed in-projection + attention core as one autograd node) against
     nn.MultiheadAttention's in-projection + scaled-dot-product attention in fp64: output and all four gradients —
@@ -370,27 +370,30 @@ def test_projected_attention_matches_multihead_attention(ops, b, lq, lk, d, h):
     assert float(g[3][d:2 * d].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("m,n", [(64, 32), (1000, 64), (70001, 64), (4613, 32)])
-def test_proj_bwd_one_pass(ops, m, n):
-    """igcn_proj_bwd: dX = G W and dW = G^T X of a bias-free projection from ONE pass over G (K = 32; ragged last row
-    block, more row blocks than workgroups) against fp64."""
+@pytest.mark.parametrize("m,n,k", [(64, 32, 32), (1000, 64, 32), (70001, 64, 32), (4613, 32, 32), (64, 48, 48),
+                                   (70001, 96, 48), (4613, 48, 48), (1000, 96, 48)])
+def test_proj_bwd_one_pass(ops, m, n, k):
+    """igcn_proj_bwd: dX = G W and dW = G^T X of a bias-free projection from ONE pass over G (K = 32 or 48, N = K or 2 K;
+    ragged last row block, more row blocks than workgroups) against fp64."""
     from igcn_amd._lib import call, load, ptr, stream_ptr
     rng = np.random.default_rng(m + n)
     mk = lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32))     # noqa: E731
-    g, x, w = mk(m, n), mk(m, 32), mk(n, 32)
+    g, x, w = mk(m, n), mk(m, k), mk(n, k)
     lib = load()
-    assert lib.igcn_proj_bwd_supported(m, n, 32) and not lib.igcn_proj_bwd_supported(m, n, 16)
+    assert lib.igcn_proj_bwd_supported(m, n, k) and not lib.igcn_proj_bwd_supported(m, n, 16)
+    assert not lib.igcn_proj_bwd_supported(m, 3 * k, k) and not lib.igcn_proj_bwd_supported(m, 64, 48)
     gd, xd, wd = g.cuda(), x.cuda(), w.cuda()
-    dx = torch.empty(m, 32, device="cuda")
-    dw = torch.empty(n, 32, device="cuda")
+    dx = torch.empty(m, k, device="cuda")
+    dw = torch.empty(n, k, device="cuda")
     scr = torch.empty(int(lib.igcn_proj_bwd_scratch_floats(m, n)), device="cuda")
-    call("igcn_proj_bwd", m, n, 32, ptr(gd), ptr(xd), ptr(wd), ptr(dx), ptr(dw), ptr(scr), stream_ptr())
+    call("igcn_proj_bwd", m, n, k, ptr(gd), ptr(xd), ptr(wd), ptr(dx), ptr(dw), ptr(scr), stream_ptr())
     assert_matches(dx, (g.double() @ w.double()).numpy(), TOL, "dX")
     assert_matches(dw, (g.double().t() @ x.double()).numpy(), TOL, "dW")
 
 
+@pytest.mark.parametrize("kd", [32, 48])
 @pytest.mark.parametrize("m1,m2", [(23040, 102400), (90, 400), (1, 1), (64 * 2100 + 7, 130)])
-def test_proj_fwd_streaming_pair(ops, m1, m2):
+def test_proj_fwd_streaming_pair(ops, m1, m2, kd):
     """igcn_proj_fwd_pair: y1 = x1 W1^T + b1 (32 columns) and y2 = x2 W2^T + b2 (64 columns) in one streaming launch
     (K = 32): the bench shape, single tiles, ragged last tiles, more tiles than workgroups; small-integer operands are
     reproduced EXACTLY (fp32 products, k-ordered accumulation), random ones match fp64; and the second projection may be
@@ -402,12 +405,12 @@ def test_proj_fwd_streaming_pair(ops, m1, m2):
     for exact in (True, False):
         mk = (lambda *sh: torch.from_numpy(rng.integers(-8, 9, sh).astype(np.float32))) if exact else \
             (lambda *sh: torch.from_numpy(rng.standard_normal(sh).astype(np.float32)))
-        x1, w1, b1, x2, w2, b2 = mk(m1, 32), mk(32, 32), mk(32), mk(m2, 32), mk(64, 32), mk(64)
+        x1, w1, b1, x2, w2, b2 = mk(m1, kd), mk(kd, kd), mk(kd), mk(m2, kd), mk(2 * kd, kd), mk(2 * kd)
         dev = [t.cuda() for t in (x1, w1, b1, x2, w2, b2)]
-        y1 = torch.full((m1, 32), float("nan"), device="cuda")
-        y2 = torch.full((m2, 64), float("nan"), device="cuda")
-        call("igcn_proj_fwd_pair", m1, 32, ptr(dev[0]), ptr(dev[1]), ptr(dev[2]), ptr(y1), m2, 64, ptr(dev[3]), ptr(dev[4]),
-             ptr(dev[5]), ptr(y2), 32, stream_ptr())
+        y1 = torch.full((m1, kd), float("nan"), device="cuda")
+        y2 = torch.full((m2, 2 * kd), float("nan"), device="cuda")
+        call("igcn_proj_fwd_pair", m1, kd, ptr(dev[0]), ptr(dev[1]), ptr(dev[2]), ptr(y1), m2, 2 * kd, ptr(dev[3]), ptr(dev[4]),
+             ptr(dev[5]), ptr(y2), kd, stream_ptr())
         r1 = x1.double() @ w1.double().t() + b1.double()
         r2 = x2.double() @ w2.double().t() + b2.double()
         if exact:
@@ -416,7 +419,7 @@ def test_proj_fwd_streaming_pair(ops, m1, m2):
             assert_matches(y1, r1.numpy(), TOL, "y1")
             assert_matches(y2, r2.numpy(), TOL, "y2")
     y1.fill_(float("nan"))
-    call("igcn_proj_fwd_pair", m1, 32, ptr(dev[0]), ptr(dev[1]), None, ptr(y1), 0, 0, None, None, None, None, 32, stream_ptr())
+    call("igcn_proj_fwd_pair", m1, kd, ptr(dev[0]), ptr(dev[1]), None, ptr(y1), 0, 0, None, None, None, None, kd, stream_ptr())
     assert_matches(y1, (x1.double() @ w1.double().t()).numpy(), TOL, "y1 alone, no bias")
 
 
