@@ -28,6 +28,9 @@
 // in matrix-core / tree order, not the reference's sequential scatter order (fp32 rounding ~1e-7, like the LDS-staged
 // aggregation it replaces at this shape).
 #include "common.h"
+#include "dropout.h"
+
+bool igcn_rider_dropout_take(hipStream_t st, DropJob& job);        // plan.hip
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -298,13 +301,21 @@ template <int NC, bool M0, bool PIPE>
 __global__ void __launch_bounds__(512)
 k_ds_deg(int R, int64_t GR, const float* __restrict__ ew, const float* __restrict__ u, const float* __restrict__ v,
          float* __restrict__ dis, DsReg rg, float inv_ne, float* __restrict__ reg_partial, int n_deg_blocks,
-         const int64_t* __restrict__ chk_ei, int64_t chk_rows, int64_t chk_edges, int32_t* __restrict__ status) {
+         const int64_t* __restrict__ chk_ei, int64_t chk_rows, int64_t chk_edges, int32_t* __restrict__ status,
+         int n_chk_blocks, int64_t d_total, const DropSegs d_segs, unsigned long long* __restrict__ d_state,
+         float* __restrict__ d_out, const DropCounters d_cnt, unsigned d_blocks) {
   constexpr bool ANYM = NC == 2 || M0;
+  if ((int)blockIdx.x >= n_deg_blocks + n_chk_blocks) {
+    // the step's dropout rider (csrc/dropout.h; queued by the captured step, a launch of its own — the FIRST of the replay,
+    // 7.7 us — where no per-graph plan build carries it): two of its 256-thread blocks per workgroup
+    dropout_masks_body(2u * (blockIdx.x - (unsigned)(n_deg_blocks + n_chk_blocks)) + (threadIdx.x >> 8), d_blocks, d_total,
+                       d_segs, d_state, d_out, d_cnt, threadIdx.x & 255u);
+    return;
+  }
   if ((int)blockIdx.x >= n_deg_blocks) {
     // the batch's structure check rides in this launch: these workgroups stream the index pairs (16 bytes per edge)
     // while the others stream the weights (4 bytes per edge); the verdict is read by the NEXT launch (k_ds_h0)
-    ds_check_rows((int64_t)blockIdx.x - n_deg_blocks, (int64_t)gridDim.x - n_deg_blocks, chk_rows, R, chk_ei, chk_edges,
-                  status);
+    ds_check_rows((int64_t)blockIdx.x - n_deg_blocks, (int64_t)n_chk_blocks, chk_rows, R, chk_ei, chk_edges, status);
     return;
   }
   __shared__ float red[8][NC][64];
@@ -1088,9 +1099,13 @@ extern "C" int igcn_dense_sgcn_fwd(int64_t n_graphs, int R, int H0, int F, int L
 #define DS_PIPE(...) if (pipe) { constexpr bool PIPE = true; __VA_ARGS__; } else { constexpr bool PIPE = false; __VA_ARGS__; }
   int64_t chk = ride ? igcn_cdiv(GR, 2 * DS_CHK_ROWS) : 0;         // one trip of 8 rows per 512-thread workgroup
   chk = chk > 4096 ? 4096 : chk;
-  const dim3 dg((unsigned)(eg.x + chk));
+  // a dropout rider waiting on the stream (igcn_rider_dropout) is carried by this launch
+  DropJob job = {};
+  if (!igcn_rider_dropout_take(st, job)) job.blocks = 0;
+  const dim3 dg((unsigned)(eg.x + chk + (job.blocks + 1u) / 2u));
   DS_DISPATCH(DS_PIPE(hipLaunchKernelGGL((k_ds_deg<NC, M0, PIPE>), dg, dim3(512), 0, st, R, GR, ew, ws + o.u, ws + o.v,
-                                         ws + o.dis, rg, inv_ne, regp, (int)eg.x, check_edge_index, GR, GR * R, status)));
+                                         ws + o.dis, rg, inv_ne, regp, (int)eg.x, check_edge_index, GR, GR * R, status,
+                                         (int)chk, job.total, job.sg, job.state, job.out, job.cnt, job.blocks)));
   DS_DISPATCH(hipLaunchKernelGGL((k_ds_h0<NC, M0>), dim3((unsigned)igcn_cdiv((int64_t)copies * GR * DS_F, 256)),
                                  dim3(256), 0, st, GR, R, H0, x, prob, W[0], ws + o.dis, ws + o.hp,
                                  (const int32_t*)status));

@@ -337,6 +337,8 @@ class SGCN_GCN_IMGSNP(torch.nn.Module):
                      and ops.dense_sgcn_supported(plan, self.rois, x.shape[1], convs[0].out_channels, len(convs)))
         if not use_dense:
             plan.flush_pending_check()     # (a dense-block plan's structure check rides in ops.DenseSgcn otherwise)
+            if getattr(plan, "dense_blocks", False) and x.is_cuda:
+                ops.call("igcn_rider_flush", ops.stream_ptr())        # ... and so does a dropout rider the step queued
         # the train step's (plain | masked) pair on small uniform graphs: plan build, masks, regulariser, SNP mask and the
         # GCNConv stack of both passes as ONE launch (ops.SgcnFront) — decided here, because every other route reads the
         # plan arrays and has to perform a deferred build first

@@ -921,8 +921,11 @@ class GraphedTrainStep:
                 self.plan.rebuild(self.data.edge_index, lazy=True)
             else:
                 self.plan._copies = {}                  # the replica of the batched sweep is derived in-graph
-            if rider and getattr(self.plan, "_pending_build", None) is None:
-                call("igcn_rider_flush", stream_ptr())  # (a plan build that does not carry riders: a launch of its own)
+            if (rider and getattr(self.plan, "_pending_build", None) is None
+                    and not getattr(self.plan, "dense_blocks", False)):
+                # (a plan build that does not carry riders: a launch of its own.  A dense-block plan has no build at all: the
+                # first edge pass of ops.DenseSgcn carries the rider, and the model flushes it where that path is not taken)
+                call("igcn_rider_flush", stream_ptr())
             self.data.x.grad = None
             self.model._cut_heads = between is not None
             try:

@@ -532,8 +532,9 @@ int igcn_rider_cancel(void* stream);
  *      runs them in issue order in one launch.  The
  *      partial buffers must outlive the flush; igcn_reduce_defer(stream, 0) + flush also runs on the error path.
  *   2. the dropout rider     igcn_rider_dropout(stream, ...): at most ONE job; carried by the NEXT
- *      igcn_graph_plan_build_segmented[_rep] or igcn_sgcn_front_fwd (which builds the plan itself) on the stream and by
- *      nothing else; igcn_rider_flush launches it alone.
+ *      igcn_graph_plan_build_segmented[_rep], igcn_sgcn_front_fwd (which builds the plan itself) or igcn_dense_sgcn_fwd
+ *      (complete graphs: no plan build; its first edge pass carries the job) on the stream and by nothing else;
+ *      igcn_rider_flush launches it alone.
  *   3. product riders        igcn_gemm_rider(stream, ...): at most 4 products; carried, all or none, by the NEXT
  *      igcn_gemm_f32_grouped on the stream with room for them and the same operand type; igcn_gemm_rider_flush launches
  *      them alone.
