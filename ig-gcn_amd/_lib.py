@@ -256,7 +256,7 @@ def call(name, *args):
     """Invoke an int-returning entry point; raise with igcn_last_error() on failure.
 
     IGCN_DEBUG_SYNC=1 (debugging a kernel fault): announce every entry point on stderr and synchronise the device
-    after it, so that the last line printed names the faulting call."""
+    after it, so that the last line printed names the faulting call (inside a stream capture: announced only)."""
     lib = load()
     if _DEBUG_SYNC:
         print(f"[igcn] {name} {args}", file=sys.stderr, flush=True)
@@ -265,7 +265,8 @@ def call(name, *args):
         raise IgcnError(f"{name} failed (rc={rc}): {lib.igcn_last_error().decode()}")
     if _DEBUG_SYNC:
         import torch
-        torch.cuda.synchronize()
+        if not torch.cuda.is_current_stream_capturing():    # (a capture refuses the synchronisation and is invalidated by it)
+            torch.cuda.synchronize()
 
 
 def copy_multi(pairs):
