@@ -140,10 +140,12 @@ def _keep(t):
 
 
 def _leaves(*ts):
-    """True when every given tensor is an autograd LEAF (a parameter): only then is its gradient final — a view of a
-    parameter (``in_proj_weight.split``), or any tensor with a grad_fn, hands its gradient to another backward node,
-    which would read it before the flush."""
-    return all(t is None or t.is_leaf for t in ts)
+    """True when every given tensor is an autograd LEAF that takes a gradient (a trainable parameter): only then is its
+    gradient final AND kept — a view of a parameter (``in_proj_weight.split``), or any tensor with a grad_fn, hands its
+    gradient to another backward node, which would read it before the flush; and the gradient of a FROZEN parameter is
+    dropped by autograd the moment the backward returns it, so a sum still queued for the flush would land in memory that a
+    later tensor of the backward has inherited (the hazard train.backward_two_buckets ran into with the loss head)."""
+    return all(t is None or (t.is_leaf and t.requires_grad) for t in ts)
 
 
 class _immediate:

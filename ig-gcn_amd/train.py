@@ -330,6 +330,10 @@ def losses(model, data, lambda_loss=DEFAULT_LAMBDA, hp=HP, temperature=None, laz
     backward's final launch (ops.HeadLoss) instead of sitting on the step's critical path."""
     if not hasattr(model, "go_network"):
         return losses_sgcn(model, data, hp)
+    # (the fused loss launches prepare their backward for the cached unit upstream gradient when it exists: registered here,
+    # so that a process's FIRST evaluation takes the same route — the same rounding — as every later one, whoever calls)
+    if data.x.is_cuda and torch.is_grad_enabled():
+        ensure_unit_grad(data.x.device)
     if hasattr(model, "_reg_hp"):                    # the dense-block SGCN path reduces loss_probability in its forward
         model._reg_hp = (float(hp.lamda_x_l1), float(hp.lamda_x_ent), float(hp.lamda_e_l1), float(hp.lamda_e_ent), 1e-6)
     if getattr(model, "batched_passes", True) and hasattr(model, "_forward_grouped") and model.isSoftSimilarity:

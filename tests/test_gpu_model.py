@@ -888,6 +888,40 @@ def test_every_host_side_switch_gives_the_default_train_step(golden, monkeypatch
         assert_matches(got[k], w.cpu().numpy(), 2e-4, f"{switch}: grad {k}", floor=1e-6)
 
 
+def test_deferred_reductions_with_frozen_parameters(golden):
+    """Parameters with ``requires_grad=False``: autograd drops their gradients as soon as a backward node returns them, so
+    an op must not leave a QUEUED sum pointing at such a buffer (it reduces on the spot instead: ``ops._leaves``).  The
+    deferred backward with a handful of frozen tensors gives every remaining gradient bit for bit as the immediate one."""
+    from igcn_amd.data import Batch
+    from igcn_amd.train import FlatAdam, backward_to_grads, losses
+    store = golden("full_b32")
+    model, graphs, _ = _full_model(store)
+    model.train(True)
+    frozen = ("lin2.weight", "lin2_regr.bias", "lin1.weight", "multihead_attn.out_proj.weight", "go_network.t.0",
+              "go_network.w_inc.0.weight", "conv1.bias", "go_network.latent.0.weight")
+    params = dict(model.named_parameters())
+    for k in frozen:
+        params[k].requires_grad_(False)
+    opt = FlatAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    got = []
+    for defer in (False, True):
+        data = Batch.from_data_list(graphs).to("cuda")
+        opt.zero_grad()
+        loss, _, _ = losses(model, data, store["lam"].tolist())
+        backward_to_grads(loss, opt, data, defer=defer)
+        torch.cuda.synchronize()
+        got.append({k: (p.grad.clone() if p.grad is not None else None) for k, p in params.items()})
+    assert all(got[1][k] is None for k in frozen)
+    n = 0
+    for k, g in got[0].items():
+        if g is None:
+            assert got[1][k] is None, k
+            continue
+        n += 1
+        assert torch.equal(g, got[1][k]), k
+    assert n > 35
+
+
 def test_a_failed_deferred_block_leaves_no_queue_behind(golden, monkeypatch):
     """an exception while the block exits (here: the queued LayerNorm-affine pass fails) must not leave the
     library in defer mode with entries that point at freed partial buffers — the queue is emptied while the buffers are
