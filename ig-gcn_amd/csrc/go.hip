@@ -103,13 +103,55 @@ k_spmm_rows_tiled(int B, int C, int I, int J, int64_t nnz, int sum_c, const int3
 #pragma unroll
     for (int s = 0; s < SPMM_SB; ++s) acc[s] = 0.f;
     if (!heavy)
-      for (int32_t p = p0; p < p1; ++p) {
-        const int32_t k = vk ? vk[p] : p, r = idx[p];
-        for (int ci = 0; ci < nc_in; ++ci) {
-          const float v = val[(int64_t)(co + ci) * nnz + k];
-          const float* xr = sp_lds + ci * J + r;
+      // four list entries per trip, their index / value loads requested together (clamped slots carry a zero value): one
+      // entry per trip was a dependent round trip each — a node's three SNPs were three round trips in front of its store
+      for (int32_t pb = p0; pb < p1; pb += 4) {
+        int32_t rr[4];
+        float vv[4];
+        if (nc_in == 1) {
 #pragma unroll
-          for (int s = 0; s < SPMM_SB; ++s) acc[s] += v * xr[s * RL];
+          for (int u = 0; u < 4; ++u) {
+            const int32_t p = pb + u < p1 ? pb + u : p1 - 1;
+            const int32_t k = vk ? vk[p] : p;
+            rr[u] = idx[p];
+            vv[u] = val[(int64_t)co * nnz + k];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (pb + u >= p1) break;
+            const float* xr = sp_lds + rr[u];
+#pragma unroll
+            for (int s = 0; s < SPMM_SB; ++s) acc[s] += vv[u] * xr[s * RL];
+          }
+        } else if (nc_in == 2) {                       // (the model's two-channel maps, summed over the channels)
+          float v2[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int32_t p = pb + u < p1 ? pb + u : p1 - 1;
+            const int32_t k = vk ? vk[p] : p;
+            rr[u] = idx[p];
+            vv[u] = val[(int64_t)co * nnz + k];
+            v2[u] = val[(int64_t)(co + 1) * nnz + k];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (pb + u >= p1) break;
+            const float* xr = sp_lds + rr[u];
+#pragma unroll
+            for (int s = 0; s < SPMM_SB; ++s) acc[s] += vv[u] * xr[s * RL];
+#pragma unroll
+            for (int s = 0; s < SPMM_SB; ++s) acc[s] += v2[u] * xr[J + s * RL];
+          }
+        } else {
+          for (int32_t p = pb; p < p1 && p < pb + 4; ++p) {
+            const int32_t k = vk ? vk[p] : p, r = idx[p];
+            for (int ci = 0; ci < nc_in; ++ci) {
+              const float v = val[(int64_t)(co + ci) * nnz + k];
+              const float* xr = sp_lds + ci * J + r;
+#pragma unroll
+              for (int s = 0; s < SPMM_SB; ++s) acc[s] += v * xr[s * RL];
+            }
+          }
         }
       }
     unsigned long long hm = __ballot(heavy);
